@@ -1,0 +1,189 @@
+/*
+ * loik_amd.h -- C-ABI of the MI355X-native batched LoIK solver (libloik_amd.so).
+ *
+ * Drop-in boundary: the reference has no FFI layer; its public surface for this path is the C++ class
+ * `loik::FirstOrderLoikOptimizedTpl<double>` together with the caller-owned data object
+ * `loik::IkIdDataTypeOptimizedTpl<double>` (include/loik/loik-loid-optimized.hpp:22-808,
+ * include/loik/loik-loid-data-optimized.hpp:62-379).  Every entry point below names the reference member
+ * it replaces.  The only new concept is the batch: one handle solves `batch` independent problem instances
+ * of the same kinematic tree; `batch = 1` reproduces the reference's single-instance semantics.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns an int status
+ * (0 = ok, negative = one of the reference's `throw std::runtime_error` sites or a runtime failure), never
+ * throws.  6-vectors are [linear; angular], 6x6 matrices are row-major, joint 0 is the universe -- exactly
+ * Pinocchio's conventions.  Per-instance arrays are instance-major ("array of problems"):
+ * q[batch][nq], bis[batch][nc][6], z[batch][nv] ...; the library transposes them to its batch-innermost
+ * struct-of-arrays device layout on the GPU.
+ */
+#ifndef LOIK_AMD_H
+#define LOIK_AMD_H
+
+#include "loik_amd_models.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOIKB_VERSION 100
+
+/* ---- status codes -------------------------------------------------------------------------------- */
+enum {
+  LOIKB_OK = 0,
+  /* reference throw sites */
+  LOIKB_ERR_EQ_C_DIM = -1,        /* eq_c_dim != 6                 ik-id-description-optimized.hpp:41-44   */
+  LOIKB_ERR_EQ_C_SIZE = -2,       /* #constraints != num_eq_c      ik-id-description-optimized.hpp:132-145 */
+  LOIKB_ERR_INEQ_DIM = -3,        /* lb/ub size != nv              ik-id-description-optimized.hpp:328-335 */
+  LOIKB_ERR_NO_SUCH_CONSTRAINT = -4, /* UpdateEqConstraint on an unknown link       ...hpp:184-186          */
+  LOIKB_ERR_DUP_CONSTRAINT = -5,  /* same link listed twice                         ...hpp:197-199          */
+  LOIKB_ERR_MU_STRATEGY = -6,     /* OSQP / MAXEIGENVALUE not implemented  loik-loid-optimized.hxx:632-640  */
+  LOIKB_ERR_MODEL = -7,           /* nb != nj-1 (hpp:37-39), multi-DoF joint, or tree not depth-first       */
+  /* runtime */
+  LOIKB_ERR_ARG = -20,
+  LOIKB_ERR_HIP = -21,            /* a HIP call failed: loikb_last_error() has the text */
+  LOIKB_ERR_NO_DEVICE = -22,
+  LOIKB_ERR_HREF_NOT_SYMMETRIC = -23, /* device path stores H_i as 21 symmetric entries (SE3actOn symmetrises
+                                         implicitly upstream) */
+  LOIKB_ERR_STATE = -24           /* Solve() before SolveInit() */
+};
+
+/* ---- ADMMPenaltyUpdateStrat, task-solver-base.hpp:13-18 -------------------------------------------- */
+enum { LOIKB_MU_DEFAULT = 0, LOIKB_MU_OSQP = 1, LOIKB_MU_MAXEIGENVALUE = 3 };
+
+enum { LOIKB_F64 = 0, LOIKB_F32 = 1 };
+
+/* option flags */
+enum {
+  LOIKB_OPT_FIXED_ITERS = 1, /* run exactly max_iter-1 ADMM iterations, mu frozen, no stopping logic       */
+  LOIKB_OPT_NO_H_CACHE = 2   /* recompute H_i/UDinv/Dinv every iteration like upstream (default: reuse them
+                                 while mu is unchanged -- bit-identical results, fewer HBM bytes)            */
+};
+
+/* input flags of solve_init / solve_full / solve_tailored */
+enum {
+  LOIKB_IN_DEVICE = 1,      /* per-instance input pointers are device pointers (resident in HBM)           */
+  LOIKB_A_SHARED = 2,       /* Ais is [nc][36]: one constraint matrix per constraint for the whole batch  */
+  LOIKB_BOUNDS_SHARED = 4,  /* lb/ub are [nv]: one box for the whole batch                                 */
+  LOIKB_B_SHARED = 8,       /* bis is [nc][6] (tailored/single-instance convenience)                        */
+  LOIKB_Q_SHARED = 16       /* q is [nq]                                                                     */
+};
+
+/* output flags of loikb_get */
+enum { LOIKB_OUT_DEVICE = 1 };
+
+typedef struct loikb_options {
+  /* the reference constructor's arguments, same order and meaning (loik-loid-optimized.hpp:129-134) */
+  int max_iter;
+  double tol_abs, tol_rel, tol_primal_inf, tol_dual_inf;
+  double rho, mu, mu_equality_scale_factor;
+  int mu_update_strat;
+  int num_eq_c, eq_c_dim;
+  int warm_start;
+  double tol_tail_solve;
+  int verbose, logging;
+  /* batch / device */
+  int batch;      /* number of problem instances                       */
+  int device;     /* HIP device ordinal                                */
+  int precision;  /* LOIKB_F64 (reference arithmetic) | LOIKB_F32      */
+  int flags;      /* LOIKB_OPT_*                                       */
+  int max_launch_iters; /* ADMM iterations per kernel launch, 0 = all  */
+} loikb_options;
+
+typedef struct loikb_solver loikb_solver;
+
+/* ctor: IkIdDataTypeOptimizedTpl(model,num_eq_c) + FirstOrderLoikOptimizedTpl(...)
+ * (loik-loid-data-optimized.hxx:40-104, loik-loid-optimized.hpp:129-162).  The model is copied (hpp:762). */
+int loikb_create(const loikb_model_desc *model, const loikb_options *opts, loikb_solver **out);
+int loikb_destroy(loikb_solver *s);
+/* launch on the caller's HIP stream (a hipStream_t); default is the null stream */
+int loikb_set_stream(loikb_solver *s, void *hip_stream);
+
+/* SolveInit(q,H_ref,v_ref,active_task_constraint_ids,Ais,bis,lb,ub), loik-loid-optimized.hpp:335-361 */
+int loikb_solve_init(loikb_solver *s, const double *q, const double *H_ref /*[36]*/, const double *v_ref /*[6]*/,
+                     const int *c_ids /*[nc]*/, int nc, const double *Ais, const double *bis, const double *lb,
+                     const double *ub, int nbound, int in_flags);
+/* Solve(), loik-loid-optimized.hpp:368-455: cold main loop on the problem set by SolveInit */
+int loikb_solve(loikb_solver *s);
+/* Solve(q,H_ref,v_ref,ids,Ais,bis,lb,ub), loik-loid-optimized.hpp:475-580 */
+int loikb_solve_full(loikb_solver *s, const double *q, const double *H_ref, const double *v_ref, const int *c_ids,
+                     int nc, const double *Ais, const double *bis, const double *lb, const double *ub, int nbound,
+                     int in_flags);
+/* Solve(q,c_id,Ai,bi), loik-loid-optimized.hpp:596-695: honours warm_start, keeps reference and bounds */
+int loikb_solve_tailored(loikb_solver *s, const double *q, int c_id, const double *Ai, const double *bi,
+                         int in_flags);
+
+/* setters of IkIdSolverBaseTpl / the solver (task-solver-base.hpp:104-141, loik-loid-optimized.hpp:702-703) */
+int loikb_set_max_iter(loikb_solver *s, int max_iter);
+int loikb_set_rho(loikb_solver *s, double rho);
+int loikb_set_mu(loikb_solver *s, double mu);
+int loikb_set_tol(loikb_solver *s, double tol_abs, double tol_rel);
+int loikb_set_tol_primal_inf(loikb_solver *s, double tol);
+int loikb_set_tol_tail_solve(loikb_solver *s, double tol);
+int loikb_set_warm_start(loikb_solver *s, int warm_start);
+
+/* results: the public members of the caller-owned IkIdData the reference's tests read
+ * (tests/loik-loid.cpp:597-615) and the getters of the solver (task-solver-base.hpp:87-102,
+ * loik-loid-optimized.hpp:698-755), one value per instance */
+enum {
+  /* double [batch][nv] */
+  LOIKB_F_Z = 0,      /* ik_id_data.z  -- the answer: box-projected joint velocity */
+  LOIKB_F_NU,         /* ik_id_data.nu */
+  LOIKB_F_W,          /* ik_id_data.w  */
+  LOIKB_F_STF_PLUS_W, /* ik_id_data.Stf_plus_w */
+  LOIKB_F_R,          /* ik_id_data.r (after the backward pass) */
+  LOIKB_F_DINV,       /* JointData::Dinv */
+  /* double [batch][nb][6], joints 1..nb */
+  LOIKB_F_VIS,        /* ik_id_data.vis[i] */
+  LOIKB_F_FIS,        /* ik_id_data.fis[i] */
+  LOIKB_F_G,          /* ik_id_data.fis_diff_plus_Aty[i] */
+  LOIKB_F_PIS,        /* ik_id_data.pis[i] */
+  LOIKB_F_UDINV,      /* JointData::UDinv */
+  /* double [batch][nb][21]: upper triangle, row-major */
+  LOIKB_F_HIS,        /* ik_id_data.His[i] */
+  /* double [batch][nb][12]: R row-major, t */
+  LOIKB_F_LIMI,       /* ik_id_data.liMi[i] */
+  /* double [batch][nc][6] */
+  LOIKB_F_YIS,        /* ik_id_data.yis[c] */
+  LOIKB_F_ATY,        /* ik_id_data.Aty[c] */
+  /* int [batch] */
+  LOIKB_F_ITER,               /* get_iter()                        */
+  LOIKB_F_CONVERGED,          /* get_convergence_status()          */
+  LOIKB_F_PRIMAL_INFEASIBLE,  /* get_primal_infeasibility_status() */
+  LOIKB_F_STATUS,             /* raw bits: 1 converged, 2 primal infeasible, 4 tail solve ran, 8 finished */
+  /* double [batch] */
+  LOIKB_F_PRIMAL_RESIDUAL = 32, LOIKB_F_DUAL_RESIDUAL, LOIKB_F_PRIMAL_RESIDUAL_TASK, LOIKB_F_PRIMAL_RESIDUAL_SLACK,
+  LOIKB_F_DUAL_RESIDUAL_V, LOIKB_F_DUAL_RESIDUAL_NU, LOIKB_F_TOL_PRIMAL, LOIKB_F_TOL_DUAL, LOIKB_F_MU, LOIKB_F_MU_EQ,
+  LOIKB_F_MU_INEQ, LOIKB_F_DELTA_X_QP_INF_NORM, LOIKB_F_DELTA_Z_QP_INF_NORM, LOIKB_F_DELTA_Y_QP_INF_NORM,
+  LOIKB_F_A_QP_T_DELTA_Y_QP_INF_NORM, LOIKB_F_UB_QP_T_DELTA_Y_QP_PLUS, LOIKB_F_LB_QP_T_DELTA_Y_QP_MINUS,
+  LOIKB_F_DELTA_FIS_INF_NORM, LOIKB_F_DELTA_YIS_INF_NORM, LOIKB_F_DELTA_W_INF_NORM, LOIKB_F_DELTA_VIS_INF_NORM,
+  LOIKB_F_DELTA_NU_INF_NORM, LOIKB_F_AV_INF_NORM, LOIKB_F_NU_INF_NORM, LOIKB_F_HREF_V_INF_NORM, LOIKB_F_G_INF_NORM,
+  LOIKB_F_STF_PLUS_W_INF_NORM, LOIKB_F_PRIMAL_INFEASIBILITY_COND_1, LOIKB_F_PRIMAL_INFEASIBILITY_COND_2,
+  LOIKB_F_TAIL_SOLVE_ITER
+};
+/* copies one field for the whole batch into `out` (host pointer, or device pointer with LOIKB_OUT_DEVICE) */
+int loikb_get(loikb_solver *s, int field, void *out, int out_flags);
+
+/* measurement: what the last loikb_solve* call did */
+typedef struct loikb_stats {
+  unsigned long long instance_iterations; /* ADMM iterations summed over instances                */
+  int launches;                           /* k_solve launches                                     */
+  int n_unfinished;                       /* instances that hit max_iter without stopping         */
+  double kernel_ms;                       /* HIP-event time of the k_solve launches on the stream */
+  double total_ms;                        /* HIP-event time of the whole call on the stream       */
+  double bytes_per_instance_iteration;    /* algorithmic bytes, SURVEY.md 8(d): s*(203 nb+108 nc) */
+} loikb_stats;
+int loikb_get_stats(loikb_solver *s, loikb_stats *out);
+
+/* introspection */
+int loikb_batch(const loikb_solver *s);
+int loikb_nv(const loikb_solver *s);
+int loikb_njoints(const loikb_solver *s);
+const char *loikb_last_error(void);
+const char *loikb_status_string(int code);
+int loikb_version(void);
+/* number of visible HIP devices (0 when none / no driver) */
+int loikb_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

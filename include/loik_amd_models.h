@@ -1,0 +1,61 @@
+/*
+ * loik_amd_models.h -- kinematic-tree description handed across the C-ABI, plus built-in robot tables.
+ *
+ * The reference takes a `pinocchio::ModelTpl<double>` by const-ref in the solver constructor
+ * (include/loik/loik-loid-optimized.hpp:129-134) and reads exactly these members on the hot path:
+ * `njoints`, `nv`, `parents[]`, `joints[i]` (type, `idx_q()`, `idx_v()`, `nv()==1`), `jointPlacements[i]`
+ * (loik-loid-optimized.hxx:46-47, :118-119, :257-265).  `loikb_model_desc` carries the same data with the
+ * same names and memory order (joint 0 = universe, parents[i] < i, 6-vectors [linear; angular]) so a
+ * Pinocchio -> loikb adapter is a field-by-field copy.
+ *
+ * Only 1-DoF joints are supported in this round (SURVEY.md 8(f) rank 2 lists multi-DoF joints as "next").
+ */
+#ifndef LOIK_AMD_MODELS_H
+#define LOIK_AMD_MODELS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* joint types; names follow Pinocchio's JointModel{RX,RY,RZ,PX,PY,PZ,RevoluteUnaligned,PrismaticUnaligned} */
+enum {
+  LOIKB_J_NONE = 0, /* universe */
+  LOIKB_J_RX = 1,
+  LOIKB_J_RY = 2,
+  LOIKB_J_RZ = 3,
+  LOIKB_J_PX = 4,
+  LOIKB_J_PY = 5,
+  LOIKB_J_PZ = 6,
+  LOIKB_J_RU = 7,
+  LOIKB_J_PU = 8
+};
+
+typedef struct loikb_model_desc {
+  int njoints;             /* model.njoints, includes the universe joint 0                    */
+  int nq, nv;              /* model.nq, model.nv (== njoints-1 for all-1-DoF trees)           */
+  const int *parents;      /* [njoints] model.parents                                         */
+  const int *jtype;        /* [njoints] LOIKB_J_*                                             */
+  const double *axis;      /* [njoints][3] unit axis in the joint frame (e_k for aligned)     */
+  const int *idx_q;        /* [njoints] joints[i].idx_q()                                     */
+  const int *idx_v;        /* [njoints] joints[i].idx_v()                                     */
+  const double *placement; /* [njoints][12] jointPlacements[i]: R row-major (9), then t (3)   */
+} loikb_model_desc;
+
+/*
+ * Built-in tables (restated from public URDF knowledge; not verifiable offline -- SURVEY.md Appendix C):
+ *   "panda7"  : Franka Panda arm, 7 revolute-z joints, chain
+ *   "panda9"  : panda7 + two prismatic fingers (PY and prismatic-unaligned -y), as example-robot-data's panda.urdf
+ *   "talos32" : Talos humanoid topology, fixed base, legs(6+6) torso(2) arms(7+1, 7+1) head(2)
+ * Returns 0 and fills *out with pointers to static storage valid for the process lifetime, or -1.
+ * q_lo / q_hi (may be NULL) receive pointers to [nq] sampling ranges for synthetic configurations.
+ */
+int loikb_builtin_model(const char *name, loikb_model_desc *out, const double **q_lo, const double **q_hi);
+/* joint name of a built-in model (index 0 = "universe"), or NULL */
+const char *loikb_builtin_joint_name(const char *name, int joint);
+/* index of a named joint in a built-in model, or -1 */
+int loikb_builtin_joint_id(const char *name, const char *joint_name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,353 @@
+"""ctypes binding of include/loik_amd.h (the drop-in C-ABI) + a host-side mirror of the reference's solver API.
+
+`BatchedLoik` keeps the reference's method names and argument meaning
+(`SolveInit`, `Solve`, getters: /root/reference/include/loik/loik-loid-optimized.hpp:335-361, :368-455, :475-580,
+:596-695; /root/reference/include/loik/task-solver-base.hpp:87-141) so the parity tests read like the
+reference's own tests.  All compute happens in libloik_amd.so on the GPU; nothing here falls back to a CPU path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libloik_amd.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class LoikError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("loik_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("njoints", C.c_int), ("nq", C.c_int), ("nv", C.c_int), ("parents", _ip), ("jtype", _ip),
+                ("axis", _dp), ("idx_q", _ip), ("idx_v", _ip), ("placement", _dp)]
+
+
+class Options(C.Structure):
+    _fields_ = [("max_iter", C.c_int),
+                ("tol_abs", C.c_double), ("tol_rel", C.c_double), ("tol_primal_inf", C.c_double),
+                ("tol_dual_inf", C.c_double), ("rho", C.c_double), ("mu", C.c_double),
+                ("mu_equality_scale_factor", C.c_double), ("mu_update_strat", C.c_int),
+                ("num_eq_c", C.c_int), ("eq_c_dim", C.c_int), ("warm_start", C.c_int),
+                ("tol_tail_solve", C.c_double), ("verbose", C.c_int), ("logging", C.c_int),
+                ("batch", C.c_int), ("device", C.c_int), ("precision", C.c_int), ("flags", C.c_int),
+                ("max_launch_iters", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("instance_iterations", C.c_ulonglong), ("launches", C.c_int), ("n_unfinished", C.c_int),
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("bytes_per_instance_iteration", C.c_double)]
+
+
+# enums of loik_amd.h
+F64, F32 = 0, 1
+OPT_FIXED_ITERS, OPT_NO_H_CACHE = 1, 2
+IN_DEVICE, A_SHARED, BOUNDS_SHARED, B_SHARED, Q_SHARED = 1, 2, 4, 8, 16
+OUT_DEVICE = 1
+
+_VEC_FIELDS = ["z", "nu", "w", "Stf_plus_w", "r", "Dinv", "vis", "fis", "g", "pis", "UDinv", "His", "liMi", "yis",
+               "Aty", "iter", "converged", "primal_infeasible", "status"]
+_SCALAR_FIELDS = ["primal_residual", "dual_residual", "primal_residual_task", "primal_residual_slack",
+                  "dual_residual_v", "dual_residual_nu", "tol_primal", "tol_dual", "mu", "mu_eq", "mu_ineq",
+                  "delta_x_qp_inf_norm", "delta_z_qp_inf_norm", "delta_y_qp_inf_norm", "A_qp_T_delta_y_qp_inf_norm",
+                  "ub_qp_T_delta_y_qp_plus", "lb_qp_T_delta_y_qp_minus", "delta_fis_inf_norm", "delta_yis_inf_norm",
+                  "delta_w_inf_norm", "delta_vis_inf_norm", "delta_nu_inf_norm", "Av_inf_norm", "nu_inf_norm",
+                  "Href_v_inf_norm", "g_inf_norm", "Stf_plus_w_inf_norm", "primal_infeasibility_cond_1",
+                  "primal_infeasibility_cond_2", "tail_solve_iter"]
+FIELD_ID = {n: i for i, n in enumerate(_VEC_FIELDS)}
+FIELD_ID.update({n: 32 + i for i, n in enumerate(_SCALAR_FIELDS)})
+
+# every symbol include/loik_amd.h and include/loik_amd_models.h declare
+EXPORTED_SYMBOLS = [
+    "loikb_create", "loikb_destroy", "loikb_set_stream", "loikb_solve_init", "loikb_solve", "loikb_solve_full",
+    "loikb_solve_tailored", "loikb_set_max_iter", "loikb_set_rho", "loikb_set_mu", "loikb_set_tol",
+    "loikb_set_tol_primal_inf", "loikb_set_tol_tail_solve", "loikb_set_warm_start", "loikb_get", "loikb_get_stats",
+    "loikb_batch", "loikb_nv", "loikb_njoints", "loikb_last_error", "loikb_status_string", "loikb_version",
+    "loikb_device_count", "loikb_builtin_model", "loikb_builtin_joint_name", "loikb_builtin_joint_id"]
+
+_lib = None
+
+
+def lib():
+    """Load libloik_amd.so; fail loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError("loik_amd: %s is missing -- build the HIP extension first "
+                          "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
+                          % _LIB_PATH)
+    L = C.CDLL(_LIB_PATH)
+    L.loikb_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(Options), C.POINTER(C.c_void_p)]
+    L.loikb_destroy.argtypes = [C.c_void_p]
+    L.loikb_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    sig = [C.c_void_p, C.c_void_p, _dp, _dp, _ip, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+           C.c_int]
+    L.loikb_solve_init.argtypes = sig
+    L.loikb_solve_full.argtypes = sig
+    L.loikb_solve.argtypes = [C.c_void_p]
+    L.loikb_solve_tailored.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.loikb_set_max_iter.argtypes = [C.c_void_p, C.c_int]
+    for n in ["loikb_set_rho", "loikb_set_mu", "loikb_set_tol_primal_inf", "loikb_set_tol_tail_solve"]:
+        getattr(L, n).argtypes = [C.c_void_p, C.c_double]
+    L.loikb_set_tol.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    L.loikb_set_warm_start.argtypes = [C.c_void_p, C.c_int]
+    L.loikb_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.loikb_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    for n in ["loikb_batch", "loikb_nv", "loikb_njoints"]:
+        getattr(L, n).argtypes = [C.c_void_p]
+    L.loikb_last_error.restype = C.c_char_p
+    L.loikb_status_string.argtypes = [C.c_int]
+    L.loikb_status_string.restype = C.c_char_p
+    L.loikb_builtin_model.argtypes = [C.c_char_p, C.POINTER(ModelDesc), C.POINTER(_dp), C.POINTER(_dp)]
+    L.loikb_builtin_joint_name.argtypes = [C.c_char_p, C.c_int]
+    L.loikb_builtin_joint_name.restype = C.c_char_p
+    L.loikb_builtin_joint_id.argtypes = [C.c_char_p, C.c_char_p]
+    _lib = L
+    return L
+
+
+def device_count():
+    return int(lib().loikb_device_count())
+
+
+def _check(rc):
+    if rc != 0:
+        L = lib()
+        msg = L.loikb_last_error().decode() if rc <= -20 or rc == -7 else L.loikb_status_string(rc).decode()
+        if not msg:
+            msg = L.loikb_status_string(rc).decode()
+        raise LoikError(rc, msg)
+
+
+class Model:
+    """Kinematic tree with Pinocchio's member names: njoints, nq, nv, parents, jointPlacements (here `placement`,
+    [nj][12] = R row-major + t), joint type / axis / idx_q / idx_v per joint."""
+
+    def __init__(self, parents, jtype, axis, placement, names=None, q_lo=None, q_hi=None, name="custom"):
+        self.parents = np.ascontiguousarray(parents, dtype=np.int32)
+        self.jtype = np.ascontiguousarray(jtype, dtype=np.int32)
+        self.axis = np.ascontiguousarray(axis, dtype=np.float64).reshape(-1, 3)
+        self.placement = np.ascontiguousarray(placement, dtype=np.float64).reshape(-1, 12)
+        self.njoints = int(self.parents.size)
+        self.nq = self.nv = self.njoints - 1
+        self.idx_q = np.ascontiguousarray(np.maximum(np.arange(self.njoints) - 1, 0), dtype=np.int32)
+        self.idx_v = self.idx_q.copy()
+        self.names = list(names) if names is not None else ["universe"] + ["joint%d" % i for i in range(1, self.njoints)]
+        self.q_lo = None if q_lo is None else np.asarray(q_lo, dtype=np.float64)
+        self.q_hi = None if q_hi is None else np.asarray(q_hi, dtype=np.float64)
+        self.name = name
+
+    def desc(self):
+        return ModelDesc(self.njoints, self.nq, self.nv, self.parents.ctypes.data_as(_ip),
+                         self.jtype.ctypes.data_as(_ip), self.axis.ctypes.data_as(_dp),
+                         self.idx_q.ctypes.data_as(_ip), self.idx_v.ctypes.data_as(_ip),
+                         self.placement.ctypes.data_as(_dp))
+
+    def getJointId(self, name):
+        return self.names.index(name)
+
+
+def builtin_model(name):
+    """'panda7' | 'panda9' | 'talos32' (tables in loik_amd/csrc/models.c)"""
+    L = lib()
+    d = ModelDesc()
+    lo, hi = _dp(), _dp()
+    if L.loikb_builtin_model(name.encode(), C.byref(d), C.byref(lo), C.byref(hi)) != 0:
+        raise KeyError(name)
+    nj = d.njoints
+    arr = lambda p, n, t: np.ctypeslib.as_array(p, shape=(n,)).astype(t).copy()
+    names = [L.loikb_builtin_joint_name(name.encode(), i).decode() for i in range(nj)]
+    return Model(arr(d.parents, nj, np.int32), arr(d.jtype, nj, np.int32), arr(d.axis, 3 * nj, np.float64),
+                 arr(d.placement, 12 * nj, np.float64), names, arr(lo, nj - 1, np.float64),
+                 arr(hi, nj - 1, np.float64), name=name)
+
+
+def _ptr(a):
+    """host numpy array, raw device pointer (int) or object with data_ptr() (torch tensor) -> (void*, is_device)"""
+    if a is None:
+        return None, False
+    if isinstance(a, int):
+        return C.c_void_p(a), True
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr()), bool(getattr(a, "is_cuda", False))
+    return a.ctypes.data_as(C.c_void_p), False
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class BatchedLoik:
+    """`FirstOrderLoikOptimized` over a batch of independent instances, on one MI355X.
+
+    Constructor keywords are the reference constructor's arguments (loik-loid-optimized.hpp:129-134) plus
+    `batch`, `device`, `precision`, `flags`, `max_launch_iters`."""
+
+    def __init__(self, model, batch, max_iter=200, tol_abs=1e-3, tol_rel=1e-3, tol_primal_inf=1e-2, tol_dual_inf=1e-2,
+                 rho=1e-5, mu=1e-2, mu_equality_scale_factor=1e4, mu_update_strat=0, num_eq_c=1, eq_c_dim=6,
+                 warm_start=False, tol_tail_solve=1e-1, verbose=False, logging=False, device=0, precision=F64, flags=0,
+                 max_launch_iters=0):
+        self.L = lib()
+        self.model = model
+        self.batch = int(batch)
+        self.nc = int(num_eq_c)
+        self.opts = Options(max_iter, tol_abs, tol_rel, tol_primal_inf, tol_dual_inf, rho, mu, mu_equality_scale_factor,
+                            mu_update_strat, num_eq_c, eq_c_dim, int(bool(warm_start)), tol_tail_solve,
+                            int(bool(verbose)), int(bool(logging)), self.batch, device, precision, flags, max_launch_iters)
+        self._desc = model.desc()
+        h = C.c_void_p()
+        _check(self.L.loikb_create(C.byref(self._desc), C.byref(self.opts), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.loikb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        _check(self.L.loikb_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    # ------------------------------------------------------------------------------------------------------
+    def SolveInit(self, q, H_ref, v_ref, active_task_constraint_ids, Ais, bis, lb, ub):
+        keep, args = self._raw_args(q, H_ref, v_ref, active_task_constraint_ids, Ais, bis, lb, ub)
+        _check(self.L.loikb_solve_init(*args))
+
+    def _raw_args(self, q, H_ref, v_ref, c_ids, Ais, bis, lb, ub):
+        """size validation is the library's job (it returns the reference's error codes)"""
+        B, nc, nv, nq = self.batch, self.nc, self.model.nv, self.model.nq
+        flags = 0
+        keep = []
+        H_ref = _f64(H_ref).reshape(36); v_ref = _f64(v_ref).reshape(6)
+        c_ids = np.ascontiguousarray(c_ids, dtype=np.int32)
+        ncin = int(c_ids.size)
+        keep += [H_ref, v_ref, c_ids]
+        devs = []
+
+        def prep(a, per, shared_flag, allow_shared=True):
+            nonlocal flags
+            if hasattr(a, "data_ptr") or isinstance(a, int):
+                p, dev = _ptr(a)
+                devs.append(dev)
+                return p
+            a = _f64(a)
+            keep.append(a)
+            if allow_shared and a.size == per and not (B == 1 and shared_flag in (Q_SHARED, B_SHARED)):
+                flags |= shared_flag
+            else:
+                devs.append(False)
+            return a.ctypes.data_as(C.c_void_p)
+
+        qp = prep(q, nq, Q_SHARED)
+        Ap = prep(Ais, 36 * ncin, A_SHARED)
+        bp = prep(bis, 6 * ncin, B_SHARED)
+        lb_n = None if (hasattr(lb, "data_ptr") or isinstance(lb, int)) else int(np.asarray(lb).size)
+        nbound = nv if lb_n is None or lb_n == nv * B else lb_n
+        lp = prep(lb, nbound, BOUNDS_SHARED)
+        up = prep(ub, nbound, BOUNDS_SHARED)
+        if any(devs):
+            if not all(devs):
+                raise ValueError("per-instance inputs must be all host or all device arrays")
+            flags |= IN_DEVICE
+        args = (self.h, qp, H_ref.ctypes.data_as(_dp), v_ref.ctypes.data_as(_dp), c_ids.ctypes.data_as(_ip), ncin, Ap,
+                bp, lp, up, nbound, flags)
+        return keep, args
+
+    def Solve(self, *a):
+        """Solve() | Solve(q,H_ref,v_ref,ids,Ais,bis,lb,ub) | Solve(q,c_id,Ai,bi)"""
+        if len(a) == 0:
+            _check(self.L.loikb_solve(self.h))
+        elif len(a) == 8:
+            keep, args = self._raw_args(*a)
+            _check(self.L.loikb_solve_full(*args))
+        elif len(a) == 4:
+            q, c_id, Ai, bi = a
+            B = self.batch
+            flags = 0
+            keep = []
+            devs = []
+
+            def prep(x, per, shared_flag):
+                nonlocal flags
+                if hasattr(x, "data_ptr") or isinstance(x, int):
+                    p, dev = _ptr(x)
+                    devs.append(dev)
+                    return p
+                x = _f64(x)
+                keep.append(x)
+                if x.size == per and not (B == 1 and shared_flag in (Q_SHARED, B_SHARED)):
+                    flags |= shared_flag
+                else:
+                    devs.append(False)
+                return x.ctypes.data_as(C.c_void_p)
+
+            qp = prep(q, self.model.nq, Q_SHARED)
+            Ap = prep(Ai, 36, A_SHARED)
+            bp = prep(bi, 6, B_SHARED)
+            if any(devs):
+                flags |= IN_DEVICE
+            _check(self.L.loikb_solve_tailored(self.h, qp, int(c_id), Ap, bp, flags))
+        else:
+            raise TypeError("Solve() takes 0, 4 or 8 arguments")
+
+    # ------------------------------------------------------------------------------------------------------
+    def set_max_iter(self, n): _check(self.L.loikb_set_max_iter(self.h, int(n)))
+    def set_rho(self, x): _check(self.L.loikb_set_rho(self.h, float(x)))
+    def set_mu(self, x): _check(self.L.loikb_set_mu(self.h, float(x)))
+    def set_tol(self, tol_abs, tol_rel): _check(self.L.loikb_set_tol(self.h, float(tol_abs), float(tol_rel)))
+    def set_tol_primal_inf(self, x): _check(self.L.loikb_set_tol_primal_inf(self.h, float(x)))
+    def set_tol_tail_solve(self, x): _check(self.L.loikb_set_tol_tail_solve(self.h, float(x)))
+    def set_warm_start(self, w): _check(self.L.loikb_set_warm_start(self.h, int(bool(w))))
+
+    def get(self, name, out=None):
+        """one field for the whole batch as a numpy array (or into a device pointer / torch tensor `out`)"""
+        fid = FIELD_ID[name]
+        B, nb, nc = self.batch, self.model.njoints - 1, self.nc
+        shapes = {"z": (B, nb), "nu": (B, nb), "w": (B, nb), "Stf_plus_w": (B, nb), "r": (B, nb), "Dinv": (B, nb),
+                  "vis": (B, nb, 6), "fis": (B, nb, 6), "g": (B, nb, 6), "pis": (B, nb, 6), "UDinv": (B, nb, 6),
+                  "His": (B, nb, 21), "liMi": (B, nb, 12), "yis": (B, nc, 6), "Aty": (B, nc, 6)}
+        is_int = name in ("iter", "converged", "primal_infeasible", "status")
+        if out is not None:
+            p, dev = _ptr(out)
+            _check(self.L.loikb_get(self.h, fid, p, OUT_DEVICE if dev else 0))
+            return out
+        arr = np.empty(shapes.get(name, (B,)), dtype=np.int32 if is_int else np.float64)
+        _check(self.L.loikb_get(self.h, fid, arr.ctypes.data_as(C.c_void_p), 0))
+        return arr
+
+    def His_full(self):
+        """ik_id_data.His[i] as full symmetric 6x6 blocks: [B][nb][6][6]"""
+        packed = self.get("His")
+        B, nb = packed.shape[:2]
+        full = np.zeros((B, nb, 6, 6))
+        k = 0
+        for i in range(6):
+            for j in range(i, 6):
+                full[:, :, i, j] = packed[:, :, k]
+                full[:, :, j, i] = packed[:, :, k]
+                k += 1
+        return full
+
+    def stats(self):
+        st = Stats()
+        _check(self.L.loikb_get_stats(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in Stats._fields_}
+
+    # reference getter names (task-solver-base.hpp:87-102), one value per instance
+    def get_iter(self): return self.get("iter")
+    def get_convergence_status(self): return self.get("converged").astype(bool)
+    def get_primal_infeasibility_status(self): return self.get("primal_infeasible").astype(bool)
+    def get_primal_residual(self): return self.get("primal_residual")
+    def get_dual_residual(self): return self.get("dual_residual")
+    def get_mu(self): return self.get("mu")

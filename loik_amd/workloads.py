@@ -1,0 +1,116 @@
+"""Synthetic IK workloads of BASELINE.json / SURVEY.md 8(d) (host-side input generation only, numpy).
+
+The targets are built to be *feasible*: b = A * J_c(q) * nu_star with nu_star inside the box, so that "solves to
+1e-6 residual" is well defined (the reference fixture's head target is primal-infeasible).
+J_c(q) nu_star is evaluated by propagating link velocities down the kinematic chain,
+v_i = liMi^-1 . v_parent + S_i nu_i (the same recursion as the reference's forward pass,
+/root/reference/include/loik/loik-loid-optimized.hxx:125-134) -- vectorised over the batch.
+"""
+import numpy as np
+
+J_RX, J_RY, J_RZ, J_PX, J_PY, J_PZ, J_RU, J_PU = 1, 2, 3, 4, 5, 6, 7, 8
+
+# the reference fixture's solver parameters, /root/reference/tests/loik-loid.cpp:91-105
+FIXTURE_PARAMS = dict(tol_primal_inf=1e-2, tol_dual_inf=1e-2, tol_tail_solve=1e-1, rho=1e-5, mu=1e-2,
+                      mu_equality_scale_factor=1e4, mu_update_strat=0, num_eq_c=1, eq_c_dim=6, warm_start=False)
+
+
+def _rot(jtype, axis, q):
+    """batched joint rotation M(q).rotation(): [B,3,3]"""
+    B = q.shape[0]
+    c, s = np.cos(q), np.sin(q)
+    R = np.zeros((B, 3, 3))
+    if jtype in (J_RX, J_RY, J_RZ):
+        a = np.zeros(3)
+        a[jtype - J_RX] = 1.0
+    else:
+        a = np.asarray(axis, dtype=float)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    R[:] = np.eye(3)[None] * c[:, None, None] + (1 - c)[:, None, None] * np.outer(a, a)[None] + s[:, None, None] * K[None]
+    return R
+
+
+def link_velocity(model, q, nu, link):
+    """spatial velocity [B,6] (Pinocchio order [linear; angular], link frame) of `link` for joint velocities nu"""
+    B = q.shape[0]
+    chain = []
+    i = int(link)
+    while i > 0:
+        chain.append(i)
+        i = int(model.parents[i])
+    v = np.zeros((B, 6))
+    for i in reversed(chain):
+        jt = int(model.jtype[i])
+        P = model.placement[i]
+        Rp, tp = P[:9].reshape(3, 3), P[9:]
+        qi, nui = q[:, int(model.idx_q[i])], nu[:, int(model.idx_v[i])]
+        if jt in (J_RX, J_RY, J_RZ, J_RU):
+            R = Rp[None] @ _rot(jt, model.axis[i], qi)
+            t = np.broadcast_to(tp, (B, 3))
+        else:
+            a = np.zeros(3)
+            if jt == J_PU:
+                a = np.asarray(model.axis[i], dtype=float)
+            else:
+                a[jt - J_PX] = 1.0
+            R = np.broadcast_to(Rp, (B, 3, 3))
+            t = tp[None] + (Rp @ a)[None] * qi[:, None]
+        lin, ang = v[:, :3], v[:, 3:]
+        d = lin - np.cross(t, ang)
+        vl = np.einsum("bji,bj->bi", R, d)
+        va = np.einsum("bji,bj->bi", R, ang)
+        v = np.concatenate([vl, va], axis=1)
+        S = np.zeros(6)
+        if jt in (J_RX, J_RY, J_RZ):
+            S[3 + jt - J_RX] = 1
+        elif jt in (J_PX, J_PY, J_PZ):
+            S[jt - J_PX] = 1
+        elif jt == J_RU:
+            S[3:] = model.axis[i]
+        else:
+            S[:3] = model.axis[i]
+        v = v + S[None] * nui[:, None]
+    return v
+
+
+def make_workload(model, batch, link, seed, bound=0.5, snap_prob=0.25, nu_scale=None):
+    """Feasible single-task workload: q ~ U(q_lo,q_hi); nu_star ~ U(-bound,bound), each component snapped to
+    +-bound w.p. snap_prob (so that joint-velocity limits are active); A = I6; b = J_link(q) nu_star; box = +-bound."""
+    rng = np.random.default_rng(seed)
+    nq, nv = model.nq, model.nv
+    q = rng.uniform(model.q_lo, model.q_hi, size=(batch, nq))
+    s = bound if nu_scale is None else nu_scale
+    nu_star = rng.uniform(-s, s, size=(batch, nv))
+    snap = rng.random((batch, nv)) < snap_prob
+    nu_star = np.where(snap, np.sign(nu_star) * s, nu_star)
+    b = link_velocity(model, q, nu_star, link)
+    return dict(q=q, H_ref=np.eye(6), v_ref=np.zeros(6), c_ids=np.array([link], dtype=np.int32),
+                Ais=np.eye(6).reshape(1, 6, 6), bis=b.reshape(batch, 1, 6), lb=-bound * np.ones(nv),
+                ub=bound * np.ones(nv), nu_star=nu_star)
+
+
+def talos_c3(batch, seed=0x101C + 3, model=None):
+    """BASELINE config "Talos humanoid with joint-limit inequality constraints, batch=65536, adaptive rho, fp64":
+    task on the left wrist (arm_left_7_joint; support chain torso_1-2 + arm_left_1-7 = 9 joints), SURVEY.md 8(d) C3."""
+    if model is None:
+        from . import builtin_model
+        model = builtin_model("talos32")
+    link = model.getJointId("arm_left_7_joint")
+    wl = make_workload(model, batch, link, seed, bound=0.5, snap_prob=0.0)
+    wl["params"] = dict(FIXTURE_PARAMS, max_iter=1000, tol_abs=1e-6, tol_rel=0.0)
+    wl["model"] = model
+    wl["name"] = "talos32_leftwrist_B%d_tol1e-6_adaptive_mu_fp64" % batch
+    return wl
+
+
+def panda_c2(batch=4096, seed=0x101C + 2, model=None):
+    """BASELINE config "Panda 7-DoF, batch=4096, fixed 50 ADMM iters, fp64": mu frozen, no stopping logic."""
+    if model is None:
+        from . import builtin_model
+        model = builtin_model("panda7")
+    link = model.njoints - 1
+    wl = make_workload(model, batch, link, seed, bound=4.0, snap_prob=0.0, nu_scale=1.0)
+    wl["params"] = dict(FIXTURE_PARAMS, max_iter=51, tol_abs=0.0, tol_rel=0.0)
+    wl["model"] = model
+    wl["name"] = "panda7_B%d_fixed50_fp64" % batch
+    return wl

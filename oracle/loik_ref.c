@@ -1,0 +1,1083 @@
+/*
+ * oracle/loik_ref.c -- CPU ORACLE (test infrastructure, NOT product code).  See loik_ref.h.
+ *
+ * Restates, function by function, the reference's optimized solver.  Every function cites the
+ * reference file:line it follows (paths relative to /root/reference/).  Pinocchio 3.0.0
+ * primitives (not in the reference tree; pinned in pixi.lock:167) are restated from their
+ * published algorithms in the "Pinocchio primitives" section.
+ *
+ * PARITY UNPINNED (no golden vectors exist upstream and the reference cannot be built here);
+ * pinned relationally against oracle/loik_dense.py exactly as the reference's own tests pin the
+ * optimized solver against the plain one.
+ */
+#include "loik_ref.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* small fixed-size helpers.  6-vectors are [linear(3); angular(3)] (Pinocchio order).       */
+/* 6x6 matrices are row-major double[36].  SE3 = R row-major [9] followed by t [3].          */
+/* ------------------------------------------------------------------------------------------ */
+
+static double inf_norm(const double *x, int n)
+{
+  double m = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double a = fabs(x[i]);
+    if (a > m) m = a;
+  }
+  return m;
+}
+
+static void cross3(const double *a, const double *b, double *o)
+{
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+static void mat3_mul(const double *A, const double *B, double *C) /* C = A B */
+{
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 3; ++k) s += A[3 * i + k] * B[3 * k + j];
+      C[3 * i + j] = s;
+    }
+}
+
+static void mat3_mul_Bt(const double *A, const double *B, double *C) /* C = A B^T */
+{
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 3; ++k) s += A[3 * i + k] * B[3 * j + k];
+      C[3 * i + j] = s;
+    }
+}
+
+static void mat3_vec(const double *A, const double *x, double *y)
+{
+  for (int i = 0; i < 3; ++i) y[i] = A[3 * i] * x[0] + A[3 * i + 1] * x[1] + A[3 * i + 2] * x[2];
+}
+
+static void mat3t_vec(const double *A, const double *x, double *y)
+{
+  for (int i = 0; i < 3; ++i) y[i] = A[i] * x[0] + A[3 + i] * x[1] + A[6 + i] * x[2];
+}
+
+static void mat6_vec(const double *A, const double *x, double *y)
+{
+  for (int i = 0; i < 6; ++i) {
+    double s = 0.0;
+    for (int k = 0; k < 6; ++k) s += A[6 * i + k] * x[k];
+    y[i] = s;
+  }
+}
+
+static void mat6t_vec(const double *A, const double *x, double *y)
+{
+  for (int i = 0; i < 6; ++i) {
+    double s = 0.0;
+    for (int k = 0; k < 6; ++k) s += A[6 * k + i] * x[k];
+    y[i] = s;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Pinocchio primitives (restated)                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+/* SE3 composition: (R1,t1)*(R2,t2) = (R1 R2, t1 + R1 t2)   [used at loik-loid-optimized.hxx:264-265] */
+static void se3_mul(const double *a, const double *b, double *o)
+{
+  double R[9], t[3];
+  mat3_mul(a, b, R);
+  mat3_vec(a, b + 9, t);
+  for (int i = 0; i < 9; ++i) o[i] = R[i];
+  for (int i = 0; i < 3; ++i) o[9 + i] = a[9 + i] + t[i];
+}
+
+static void se3_identity(double *o)
+{
+  memset(o, 0, 12 * sizeof(double));
+  o[0] = o[4] = o[8] = 1.0;
+}
+
+/* SE3::act(Force): (R f_l, R f_a + t x (R f_l))        [call sites hxx:74, :212] */
+static void se3_act_force(const double *M, const double *f, double *o)
+{
+  double l[3], a[3], c[3];
+  mat3_vec(M, f, l);
+  mat3_vec(M, f + 3, a);
+  cross3(M + 9, l, c);
+  for (int i = 0; i < 3; ++i) {
+    o[i] = l[i];
+    o[3 + i] = a[i] + c[i];
+  }
+}
+
+/* SE3::actInv(Motion): (R^T (v_l - t x v_a), R^T v_a)   [call site hxx:125] */
+static void se3_actinv_motion(const double *M, const double *v, double *o)
+{
+  double c[3], d[3];
+  cross3(M + 9, v + 3, c);
+  for (int i = 0; i < 3; ++i) d[i] = v[i] - c[i];
+  mat3t_vec(M, d, o);
+  mat3t_vec(M, v + 3, o + 3);
+}
+
+/*
+ * pinocchio::impl::internal::SE3actOn<Scalar>::run(M, I)   [call site hxx:66]
+ * = X*(M) I X(M)^-1 evaluated from the A (lin,lin), B (lin,ang) and D (ang,ang) blocks only
+ * (assumes I symmetric):
+ *   Ao = R A R^T ; Bo = R B R^T ; Do = R D R^T
+ *   Do.row(k) += t x Bo.col(k)
+ *   Co.col(k)  = t x Ao.col(k) ; Co += Bo^T ; Bo = Co^T
+ *   Do.col(k) += t x Bo.col(k)
+ */
+static void se3_act_on(const double *M, const double *I, double *res)
+{
+  const double *R = M, *t = M + 9;
+  double Ai[9], Bi[9], Di[9], tmp[9], Ao[9], Bo[9], Co[9], Do[9], col[3], cr[3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      Ai[3 * i + j] = I[6 * i + j];
+      Bi[3 * i + j] = I[6 * i + 3 + j];
+      Di[3 * i + j] = I[6 * (3 + i) + 3 + j];
+    }
+  mat3_mul(R, Ai, tmp);
+  mat3_mul_Bt(tmp, R, Ao);
+  mat3_mul(R, Bi, tmp);
+  mat3_mul_Bt(tmp, R, Bo);
+  mat3_mul(R, Di, tmp);
+  mat3_mul_Bt(tmp, R, Do);
+
+  for (int k = 0; k < 3; ++k) { /* Do.row(k) += t x Bo.col(k) */
+    col[0] = Bo[k]; col[1] = Bo[3 + k]; col[2] = Bo[6 + k];
+    cross3(t, col, cr);
+    for (int j = 0; j < 3; ++j) Do[3 * k + j] += cr[j];
+  }
+  for (int k = 0; k < 3; ++k) { /* Co.col(k) = t x Ao.col(k) */
+    col[0] = Ao[k]; col[1] = Ao[3 + k]; col[2] = Ao[6 + k];
+    cross3(t, col, cr);
+    for (int j = 0; j < 3; ++j) Co[3 * j + k] = cr[j];
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Co[3 * i + j] += Bo[3 * j + i];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) Bo[3 * i + j] = Co[3 * j + i];
+  for (int k = 0; k < 3; ++k) { /* Do.col(k) += t x Bo.col(k) */
+    col[0] = Bo[k]; col[1] = Bo[3 + k]; col[2] = Bo[6 + k];
+    cross3(t, col, cr);
+    for (int j = 0; j < 3; ++j) Do[3 * j + k] += cr[j];
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      res[6 * i + j] = Ao[3 * i + j];
+      res[6 * i + 3 + j] = Bo[3 * i + j];
+      res[6 * (3 + i) + j] = Co[3 * i + j];
+      res[6 * (3 + i) + 3 + j] = Do[3 * i + j];
+    }
+}
+
+/* JointModel{RX,RY,RZ,PX,PY,PZ,RevoluteUnaligned,PrismaticUnaligned}::calc(jdata, q)
+ * -> joint transform M(q) (call site hxx:263) */
+static void joint_calc(int jtype, const double *axis, double q, double *M)
+{
+  se3_identity(M);
+  double c = cos(q), s = sin(q);
+  switch (jtype) {
+  case REF_J_RX:
+    M[4] = c; M[5] = -s; M[7] = s; M[8] = c;
+    break;
+  case REF_J_RY:
+    M[0] = c; M[2] = s; M[6] = -s; M[8] = c;
+    break;
+  case REF_J_RZ:
+    M[0] = c; M[1] = -s; M[3] = s; M[4] = c;
+    break;
+  case REF_J_RU: { /* Rodrigues: c I + (1-c) a a^T + s [a]x */
+    double ax = axis[0], ay = axis[1], az = axis[2], c1 = 1.0 - c, tmp;
+    tmp = c1 * ax * ay; M[1] = tmp - s * az; M[3] = tmp + s * az;
+    tmp = c1 * ax * az; M[2] = tmp + s * ay; M[6] = tmp - s * ay;
+    tmp = c1 * ay * az; M[5] = tmp - s * ax; M[7] = tmp + s * ax;
+    M[0] = c1 * ax * ax + c; M[4] = c1 * ay * ay + c; M[8] = c1 * az * az + c;
+    break;
+  }
+  case REF_J_PX: M[9] = q; break;
+  case REF_J_PY: M[10] = q; break;
+  case REF_J_PZ: M[11] = q; break;
+  case REF_J_PU:
+    M[9] = axis[0] * q; M[10] = axis[1] * q; M[11] = axis[2] * q;
+    break;
+  default: break;
+  }
+}
+
+/* joint motion subspace S (6-vector, one column since every supported joint has nv = 1) */
+static void joint_S(int jtype, const double *axis, double *S)
+{
+  memset(S, 0, 6 * sizeof(double));
+  switch (jtype) {
+  case REF_J_PX: S[0] = 1.0; break;
+  case REF_J_PY: S[1] = 1.0; break;
+  case REF_J_PZ: S[2] = 1.0; break;
+  case REF_J_RX: S[3] = 1.0; break;
+  case REF_J_RY: S[4] = 1.0; break;
+  case REF_J_RZ: S[5] = 1.0; break;
+  case REF_J_PU: S[0] = axis[0]; S[1] = axis[1]; S[2] = axis[2]; break;
+  case REF_J_RU: S[3] = axis[0]; S[4] = axis[1]; S[5] = axis[2]; break;
+  default: break;
+  }
+}
+
+/* JointModel::calc_aba(jdata, armature, I, update_I)    [call site hxx:60-63]
+ *   U = I S ; Dinv = 1/(S^T U + armature) ; UDinv = U Dinv ; if (update_I) I -= UDinv U^T */
+static void joint_calc_aba(const double *S, double armature, double *I, int update_I, double *U,
+                           double *Dinv, double *UDinv)
+{
+  mat6_vec(I, S, U);
+  double d = 0.0;
+  for (int k = 0; k < 6; ++k) d += S[k] * U[k];
+  *Dinv = 1.0 / (d + armature);
+  for (int k = 0; k < 6; ++k) UDinv[k] = U[k] * (*Dinv);
+  if (update_I)
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) I[6 * i + j] -= UDinv[i] * U[j];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* solver object = IkIdDataTypeOptimizedTpl + IkProblemFormulationOptimized + solver scalars   */
+/* ------------------------------------------------------------------------------------------ */
+struct ref_solver {
+  /* model (copied, reference keeps `Model model_` by value, loik-loid-optimized.hpp:762) */
+  int nj, nb, nq, nv, nc;
+  int *parents, *jtype, *idx_q, *idx_v;
+  double *axis, *placement;
+
+  /* --- IkIdDataTypeOptimizedTpl members (loik-loid-data-optimized.hxx:40-86) --- */
+  double *oMi, *liMi;                /* [nj][12] */
+  double *jS, *jU, *jUDinv, *jDinv;  /* JointData: S,U,UDinv [nj][6], Dinv [nj] */
+  double *nu, *nu_prev;              /* [nv] */
+  double *vis, *vis_prev;            /* [nj][6] */
+  double *His, *His_aba;             /* [nj][36] */
+  double *pis, *pis_aba;             /* [nj][6] */
+  double *R, *r;                     /* [nv] */
+  double *fis, *delta_fis;           /* [nj][6] */
+  double *yis, *delta_yis;           /* [nc][6] */
+  double *w, *delta_w, *z, *z_prev;  /* [nv] */
+  double *Aty;                       /* [nc][6] */
+  double *g, *delta_g;               /* fis_diff_plus_Aty, delta_fis_diff_plus_Aty [nj][6] */
+  double *Href_v;                    /* [nj][6] */
+  double *Av_minus_b;                /* [nc][6] */
+  double *Stf_plus_w, *delta_Stf_plus_w; /* [nv] */
+  double bT_delta_y_plus, bT_delta_y_minus;
+  double Av_inf_norm, nu_inf_norm, Href_v_inf_norm, g_inf_norm, Stf_plus_w_inf_norm;
+  double delta_g_inf_norm, delta_Stf_plus_w_inf_norm, delta_vis_inf_norm, delta_nu_inf_norm;
+  double delta_z_inf_norm, delta_fis_inf_norm, delta_yis_inf_norm, delta_w_inf_norm;
+
+  /* --- IkProblemFormulationOptimized members (ik-id-description-optimized.hpp:342-362) --- */
+  int eq_c_dim;
+  double *H_refs, *v_refs, *Hv;      /* [nj][36], [nj][6], [nj][6] */
+  int *active_ids;                   /* [nc] */
+  double *Ais, *bis, *AtA, *Atb;     /* [nc][36], [nc][6], [nc][36], [nc][6] */
+  double *lb, *ub;                   /* [nv] */
+  double bis_inf_norm, Hv_inf_norm;
+
+  /* --- IkIdSolverBaseTpl members (task-solver-base.hpp:145-170) --- */
+  double rho, mu0, mu, mu_equality_scale_factor;
+  int mu_update_strat, max_iter, iter, converged;
+  double tol_abs, tol_rel, tol_primal, tol_dual, tol_primal_inf, tol_dual_inf;
+  int primal_infeasible, dual_infeasible;
+  double primal_residual, dual_residual;
+
+  /* --- FirstOrderLoikOptimizedTpl members (loik-loid-optimized.hpp:762-806) --- */
+  int tail_solve_iter;
+  double primal_residual_task, primal_residual_slack;
+  double *primal_residual_vec, *dual_residual_vec; /* [6nb+nv] */
+  double dual_residual_v, dual_residual_nu;
+  double delta_x_qp_inf_norm, delta_y_qp_inf_norm, A_qp_T_delta_y_qp_inf_norm;
+  double ub_qp_T_delta_y_qp_plus, lb_qp_T_delta_y_qp_minus;
+  int primal_infeasibility_cond_1, primal_infeasibility_cond_2;
+  double mu_eq, mu_ineq;
+  int warm_start;
+  double tol_tail_solve;
+};
+
+static double *dalloc(size_t n)
+{
+  return (double *)calloc(n ? n : 1, sizeof(double));
+}
+
+/* IkIdSolverBaseTpl::Reset, task-solver-base.hpp:73-84 */
+static void base_reset(ref_solver *s)
+{
+  s->iter = 0;
+  s->converged = 0;
+  s->primal_infeasible = 0;
+  s->dual_infeasible = 0;
+  s->mu = s->mu0;
+}
+
+/* FirstOrderLoikOptimizedTpl::ResetSolver, loik-loid-optimized.hpp:168-186 */
+static void reset_solver(ref_solver *s)
+{
+  base_reset(s);
+  s->tail_solve_iter = 0;
+  s->delta_x_qp_inf_norm = 0.0;
+  s->delta_y_qp_inf_norm = 0.0;
+  s->A_qp_T_delta_y_qp_inf_norm = 0.0;
+  s->ub_qp_T_delta_y_qp_plus = 0.0;
+  s->lb_qp_T_delta_y_qp_minus = 0.0;
+  s->primal_infeasibility_cond_1 = 0;
+  s->primal_infeasibility_cond_2 = 0;
+  s->mu_eq = s->mu_equality_scale_factor * s->mu;
+  s->mu_ineq = s->mu;
+}
+
+/* IkProblemFormulationOptimized::Reset, ik-id-description-optimized.hpp:61-72, :369-420 */
+static void problem_reset(ref_solver *s)
+{
+  memset(s->H_refs, 0, sizeof(double) * 36 * (size_t)s->nj);
+  memset(s->v_refs, 0, sizeof(double) * 6 * (size_t)s->nj);
+  memset(s->Hv, 0, sizeof(double) * 6 * (size_t)s->nj);
+  s->Hv_inf_norm = 0.0;
+  for (int c = 0; c < s->nc; ++c) s->active_ids[c] = 0;
+  memset(s->Ais, 0, sizeof(double) * 36 * (size_t)s->nc);
+  memset(s->bis, 0, sizeof(double) * 6 * (size_t)s->nc);
+  memset(s->AtA, 0, sizeof(double) * 36 * (size_t)s->nc);
+  memset(s->Atb, 0, sizeof(double) * 6 * (size_t)s->nc);
+  s->bis_inf_norm = 0.0;
+  memset(s->lb, 0, sizeof(double) * (size_t)s->nv);
+  memset(s->ub, 0, sizeof(double) * (size_t)s->nv);
+}
+
+int ref_create(const ref_model *m, const ref_params *p, ref_solver **out)
+{
+  if (!m || !p || !out) return REF_ERR_ARG;
+  /* ik-id-description-optimized.hpp:41-44 */
+  if (p->eq_c_dim != 6) return REF_ERR_EQ_DIM;
+  ref_solver *s = (ref_solver *)calloc(1, sizeof(ref_solver));
+  const int nj = m->njoints, nv = m->nv, nc = p->num_eq_c;
+  s->nj = nj; s->nb = nj - 1; s->nq = m->nq; s->nv = nv; s->nc = nc;
+  s->parents = (int *)malloc(sizeof(int) * nj);
+  s->jtype = (int *)malloc(sizeof(int) * nj);
+  s->idx_q = (int *)malloc(sizeof(int) * nj);
+  s->idx_v = (int *)malloc(sizeof(int) * nj);
+  s->axis = dalloc(3 * nj);
+  s->placement = dalloc(12 * nj);
+  memcpy(s->parents, m->parents, sizeof(int) * nj);
+  memcpy(s->jtype, m->jtype, sizeof(int) * nj);
+  memcpy(s->idx_q, m->idx_q, sizeof(int) * nj);
+  memcpy(s->idx_v, m->idx_v, sizeof(int) * nj);
+  memcpy(s->axis, m->axis, sizeof(double) * 3 * nj);
+  memcpy(s->placement, m->placement, sizeof(double) * 12 * nj);
+
+  /* data ctor, loik-loid-data-optimized.hxx:40-86 */
+  s->oMi = dalloc(12 * nj); s->liMi = dalloc(12 * nj);
+  for (int i = 0; i < nj; ++i) { se3_identity(s->oMi + 12 * i); se3_identity(s->liMi + 12 * i); }
+  s->jS = dalloc(6 * nj); s->jU = dalloc(6 * nj); s->jUDinv = dalloc(6 * nj); s->jDinv = dalloc(nj);
+  for (int i = 0; i < nj; ++i) joint_S(s->jtype[i], s->axis + 3 * i, s->jS + 6 * i);
+  s->nu = dalloc(nv); s->nu_prev = dalloc(nv);
+  s->vis = dalloc(6 * nj); s->vis_prev = dalloc(6 * nj);
+  s->His = dalloc(36 * nj); s->His_aba = dalloc(36 * nj);
+  for (int i = 0; i < nj; ++i)
+    for (int k = 0; k < 6; ++k) { s->His[36 * i + 7 * k] = 1.0; s->His_aba[36 * i + 7 * k] = 1.0; }
+  s->pis = dalloc(6 * nj); s->pis_aba = dalloc(6 * nj);
+  s->R = dalloc(nv); s->r = dalloc(nv);
+  s->fis = dalloc(6 * nj); s->delta_fis = dalloc(6 * nj);
+  s->yis = dalloc(6 * nc); s->delta_yis = dalloc(6 * nc);
+  s->w = dalloc(nv); s->delta_w = dalloc(nv); s->z = dalloc(nv); s->z_prev = dalloc(nv);
+  s->Aty = dalloc(6 * nc);
+  s->g = dalloc(6 * nj); s->delta_g = dalloc(6 * nj);
+  s->Href_v = dalloc(6 * nj);
+  s->Av_minus_b = dalloc(6 * nc);
+  s->Stf_plus_w = dalloc(nv); s->delta_Stf_plus_w = dalloc(nv);
+
+  /* problem ctor, ik-id-description-optimized.hpp:30-59 */
+  s->eq_c_dim = p->eq_c_dim;
+  s->H_refs = dalloc(36 * nj); s->v_refs = dalloc(6 * nj); s->Hv = dalloc(6 * nj);
+  s->active_ids = (int *)calloc(nc ? nc : 1, sizeof(int));
+  s->Ais = dalloc(36 * nc); s->bis = dalloc(6 * nc); s->AtA = dalloc(36 * nc); s->Atb = dalloc(6 * nc);
+  s->lb = dalloc(nv); s->ub = dalloc(nv);
+  problem_reset(s);
+
+  /* base ctor, task-solver-base.hpp:54-70 */
+  s->rho = p->rho; s->mu0 = p->mu; s->mu = p->mu;
+  s->mu_equality_scale_factor = p->mu_equality_scale_factor;
+  s->mu_update_strat = p->mu_update_strat;
+  s->max_iter = p->max_iter;
+  s->tol_abs = p->tol_abs; s->tol_rel = p->tol_rel;
+  s->tol_primal_inf = p->tol_primal_inf; s->tol_dual_inf = p->tol_dual_inf;
+  s->tol_primal = 0.0; s->tol_dual = 0.0;
+  s->primal_residual = 0.0; s->dual_residual = 0.0;
+
+  /* solver ctor, loik-loid-optimized.hpp:144-161 */
+  s->warm_start = p->warm_start;
+  s->tol_tail_solve = p->tol_tail_solve;
+  s->primal_residual_vec = dalloc(6 * (nj - 1) + nv);
+  s->dual_residual_vec = dalloc(6 * (nj - 1) + nv);
+  reset_solver(s);
+  *out = s;
+  return REF_OK;
+}
+
+void ref_destroy(ref_solver *s)
+{
+  if (!s) return;
+  free(s->parents); free(s->jtype); free(s->idx_q); free(s->idx_v); free(s->axis); free(s->placement);
+  free(s->oMi); free(s->liMi); free(s->jS); free(s->jU); free(s->jUDinv); free(s->jDinv);
+  free(s->nu); free(s->nu_prev); free(s->vis); free(s->vis_prev); free(s->His); free(s->His_aba);
+  free(s->pis); free(s->pis_aba); free(s->R); free(s->r); free(s->fis); free(s->delta_fis);
+  free(s->yis); free(s->delta_yis); free(s->w); free(s->delta_w); free(s->z); free(s->z_prev);
+  free(s->Aty); free(s->g); free(s->delta_g); free(s->Href_v); free(s->Av_minus_b);
+  free(s->Stf_plus_w); free(s->delta_Stf_plus_w);
+  free(s->H_refs); free(s->v_refs); free(s->Hv); free(s->active_ids);
+  free(s->Ais); free(s->bis); free(s->AtA); free(s->Atb); free(s->lb); free(s->ub);
+  free(s->primal_residual_vec); free(s->dual_residual_vec);
+  free(s);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* IkIdDataTypeOptimizedTpl methods                                                            */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Reset(warm_start), loik-loid-data-optimized.hxx:114-127 */
+static void data_reset(ref_solver *s, int warm_start)
+{
+  if (!warm_start) {
+    memset(s->w, 0, sizeof(double) * s->nv);
+    memset(s->z, 0, sizeof(double) * s->nv);
+    memset(s->nu, 0, sizeof(double) * s->nv);
+    memset(s->vis, 0, sizeof(double) * 6 * s->nj);
+    memset(s->fis, 0, sizeof(double) * 6 * s->nj);
+    memset(s->g, 0, sizeof(double) * 6 * s->nj);
+  }
+}
+
+/* ResetRecursion(), loik-loid-data-optimized.hxx:138-154 (nu, nu_prev, Stf_plus_w NOT reset) */
+static void data_reset_recursion(ref_solver *s)
+{
+  memset(s->w, 0, sizeof(double) * s->nv);
+  memset(s->z, 0, sizeof(double) * s->nv);
+  memset(s->vis, 0, sizeof(double) * 6 * s->nj);
+  memset(s->fis, 0, sizeof(double) * 6 * s->nj);
+  memset(s->g, 0, sizeof(double) * 6 * s->nj);
+  memset(s->yis, 0, sizeof(double) * 6 * s->nc);
+  memset(s->Aty, 0, sizeof(double) * 6 * s->nc);
+}
+
+/* ResetInfNorms(), loik-loid-data-optimized.hxx:165-182 */
+void ref_reset_inf_norms(ref_solver *s)
+{
+  s->bT_delta_y_plus = 0.0; s->bT_delta_y_minus = 0.0;
+  s->Av_inf_norm = 0.0; s->nu_inf_norm = 0.0; s->Href_v_inf_norm = 0.0;
+  s->g_inf_norm = 0.0; s->Stf_plus_w_inf_norm = 0.0;
+  s->delta_g_inf_norm = 0.0; s->delta_Stf_plus_w_inf_norm = 0.0;
+  s->delta_vis_inf_norm = 0.0; s->delta_nu_inf_norm = 0.0; s->delta_z_inf_norm = 0.0;
+  s->delta_fis_inf_norm = 0.0; s->delta_yis_inf_norm = 0.0; s->delta_w_inf_norm = 0.0;
+}
+
+/* UpdatePrev(), loik-loid-data-optimized.hxx:192-197 */
+void ref_update_prev(ref_solver *s)
+{
+  memcpy(s->vis_prev, s->vis, sizeof(double) * 6 * s->nj);
+  memcpy(s->nu_prev, s->nu, sizeof(double) * s->nv);
+  memcpy(s->z_prev, s->z, sizeof(double) * s->nv);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* IkProblemFormulationOptimized methods                                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* UpdateReference, ik-id-description-optimized.hpp:78-97 (one H_ref,v_ref broadcast to all nj
+ * links; Hv_inf_norm_ taken from link 0 only) */
+static void problem_update_reference(ref_solver *s, const double *H_ref, const double *v_ref)
+{
+  for (int i = 0; i < s->nj; ++i) {
+    memcpy(s->H_refs + 36 * i, H_ref, 36 * sizeof(double));
+    memcpy(s->v_refs + 6 * i, v_ref, 6 * sizeof(double));
+    mat6_vec(s->H_refs + 36 * i, s->v_refs + 6 * i, s->Hv + 6 * i);
+  }
+  s->Hv_inf_norm = inf_norm(s->Hv, 6);
+}
+
+/* UpdateIneqConstraints, ik-id-description-optimized.hpp:325-339 */
+static int problem_update_ineq(ref_solver *s, const double *lb, const double *ub, int n)
+{
+  if (n != s->nv) return REF_ERR_INEQ_DIM;
+  memcpy(s->lb, lb, sizeof(double) * n);
+  memcpy(s->ub, ub, sizeof(double) * n);
+  return REF_OK;
+}
+
+/* AtA = A^T A, Atb = A^T b  (ik-id-description-optimized.hpp:162-163, :210-211) */
+static void compute_AtA_Atb(const double *A, const double *b, double *AtA, double *Atb)
+{
+  for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j < 6; ++j) {
+      double sum = 0.0;
+      for (int k = 0; k < 6; ++k) sum += A[6 * k + i] * A[6 * k + j];
+      AtA[6 * i + j] = sum;
+    }
+  }
+  mat6t_vec(A, b, Atb);
+}
+
+/* UpdateEqConstraints, ik-id-description-optimized.hpp:127-171 */
+static int problem_update_eq(ref_solver *s, const int *ids, int nc, const double *Ais, const double *bis)
+{
+  if (nc != s->nc) return REF_ERR_EQ_SIZE;
+  for (int c = 0; c < nc; ++c) s->active_ids[c] = ids[c];
+  memcpy(s->Ais, Ais, sizeof(double) * 36 * nc);
+  memcpy(s->bis, bis, sizeof(double) * 6 * nc);
+  s->bis_inf_norm = 0.0;
+  for (int c = 0; c < nc; ++c) {
+    compute_AtA_Atb(s->Ais + 36 * c, s->bis + 6 * c, s->AtA + 36 * c, s->Atb + 6 * c);
+    double n = inf_norm(s->bis + 6 * c, 6);
+    if (n > s->bis_inf_norm) s->bis_inf_norm = n;
+  }
+  return REF_OK;
+}
+
+/* UpdateEqConstraint(c_id, Ai, bi), ik-id-description-optimized.hpp:178-218
+ * (bis_inf_norm_ only ever grows here) */
+static int problem_update_eq_single(ref_solver *s, int c_id, const double *Ai, const double *bi)
+{
+  int found = -1, count = 0;
+  for (int c = 0; c < s->nc; ++c)
+    if (s->active_ids[c] == c_id) {
+      if (found < 0) found = c;
+      ++count;
+    }
+  if (found < 0) return REF_ERR_NO_SUCH_CONSTRAINT;
+  if (count > 1) return REF_ERR_DUP_CONSTRAINT;
+  memcpy(s->Ais + 36 * found, Ai, 36 * sizeof(double));
+  memcpy(s->bis + 6 * found, bi, 6 * sizeof(double));
+  compute_AtA_Atb(Ai, bi, s->AtA + 36 * found, s->Atb + 6 * found);
+  double n = inf_norm(bi, 6);
+  if (n > s->bis_inf_norm) s->bis_inf_norm = n;
+  return REF_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* solver passes                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+/* FwdPassInit(q), loik-loid-optimized.hxx:253-283 */
+void ref_fwd_pass_init(ref_solver *s, const double *q)
+{
+  double M[12];
+  for (int idx = 1; idx < s->nj; ++idx) {
+    int parent = s->parents[idx];
+    joint_calc(s->jtype[idx], s->axis + 3 * idx, q[s->idx_q[idx]], M);
+    se3_mul(s->placement + 12 * idx, M, s->liMi + 12 * idx);
+    se3_mul(s->oMi + 12 * parent, s->liMi + 12 * idx, s->oMi + 12 * idx);
+  }
+  if (!s->warm_start) {
+    memset(s->yis, 0, sizeof(double) * 6 * s->nc);
+    memset(s->Aty, 0, sizeof(double) * 6 * s->nc);
+  }
+}
+
+/* FwdPass1(), loik-loid-optimized.hxx:290-338 */
+void ref_fwd_pass1(ref_solver *s)
+{
+  for (int k = 0; k < s->nv; ++k) {
+    s->R[k] = 1.0;
+    s->R[k] *= s->mu_ineq;
+    s->r[k] = s->w[k] - s->mu_ineq * s->z[k];
+  }
+  for (int idx = 1; idx < s->nj; ++idx) {
+    double *Hi = s->His + 36 * idx;
+    const double *H_ref = s->H_refs + 36 * idx;
+    const double *Hv_i = s->Hv + 6 * idx;
+    memset(Hi, 0, 36 * sizeof(double));
+    for (int k = 0; k < 6; ++k) Hi[7 * k] = 1.0;
+    for (int k = 0; k < 36; ++k) Hi[k] *= s->rho;
+    for (int k = 0; k < 36; ++k) Hi[k] += H_ref[k];
+    memcpy(s->His_aba + 36 * idx, Hi, 36 * sizeof(double));
+    for (int k = 0; k < 6; ++k) {
+      s->pis[6 * idx + k] = -s->rho * s->vis_prev[6 * idx + k];
+      s->pis[6 * idx + k] -= Hv_i[k];
+    }
+    memcpy(s->pis_aba + 6 * idx, s->pis + 6 * idx, 6 * sizeof(double));
+  }
+  for (int c = 0; c < s->nc; ++c) {
+    int c_id = s->active_ids[c];
+    const double *AtA_i = s->AtA + 36 * c, *Atb_i = s->Atb + 6 * c, *Aty_i = s->Aty + 6 * c;
+    for (int k = 0; k < 36; ++k) {
+      s->His[36 * c_id + k] += s->mu_eq * AtA_i[k];
+      s->His_aba[36 * c_id + k] += s->mu_eq * AtA_i[k];
+    }
+    for (int k = 0; k < 6; ++k) s->pis[6 * c_id + k] += (Aty_i[k] - s->mu_eq * Atb_i[k]);
+    memcpy(s->pis_aba + 6 * c_id, s->pis + 6 * c_id, 6 * sizeof(double));
+  }
+}
+
+/* BwdPassOptimizedVisitor + LoikBackwardStepVisitor::algo, loik-loid-optimized.hxx:345-354, :31-81 */
+void ref_bwd_pass(ref_solver *s)
+{
+  double acted[36], tmp[6], f[6];
+  for (int idx = s->nj - 1; idx > 0; --idx) {
+    int parent = s->parents[idx];
+    const double *liMi = s->liMi + 12 * idx;
+    double *Hi_aba = s->His_aba + 36 * idx;
+    const double *pi = s->pis + 6 * idx;
+    double *pi_aba = s->pis_aba + 6 * idx;
+    const double *S = s->jS + 6 * idx;
+    int iv = s->idx_v[idx];
+
+    joint_calc_aba(S, s->R[iv], Hi_aba, parent > 0, s->jU + 6 * idx, s->jDinv + idx, s->jUDinv + 6 * idx);
+
+    se3_act_on(liMi, Hi_aba, acted);
+    for (int k = 0; k < 36; ++k) s->His_aba[36 * parent + k] += acted[k];
+    memcpy(s->His + 36 * parent, s->His_aba + 36 * parent, 36 * sizeof(double));
+
+    double Stp = 0.0;
+    for (int k = 0; k < 6; ++k) Stp += S[k] * pi[k];
+    s->r[iv] += Stp;
+    for (int k = 0; k < 6; ++k) tmp[k] = s->jUDinv[6 * idx + k] * s->r[iv];
+    for (int k = 0; k < 6; ++k) pi_aba[k] -= tmp[k];
+    se3_act_force(liMi, pi_aba, f);
+    for (int k = 0; k < 6; ++k) s->pis[6 * parent + k] += f[k];
+    memcpy(s->pis_aba + 6 * parent, s->pis + 6 * parent, 6 * sizeof(double));
+  }
+}
+
+/* FwdPass2OptimizedVisitor + LoikForwardStep2Visitor::algo, loik-loid-optimized.hxx:361-377, :102-163 */
+void ref_fwd_pass2(ref_solver *s)
+{
+  double vp[6], Hv6[6], d6[6];
+  memcpy(s->delta_g, s->g, sizeof(double) * 6 * s->nj);
+  for (int idx = 1; idx < s->nj; ++idx) {
+    int parent = s->parents[idx];
+    int iv = s->idx_v[idx];
+    const double *Hi = s->His + 36 * idx, *pi = s->pis + 6 * idx, *liMi = s->liMi + 12 * idx;
+    const double *S = s->jS + 6 * idx, *UDinv = s->jUDinv + 6 * idx;
+
+    se3_actinv_motion(liMi, s->vis + 6 * parent, vp);
+    double udv = 0.0;
+    for (int k = 0; k < 6; ++k) udv += UDinv[k] * vp[k];
+    s->nu[iv] = -udv - s->jDinv[idx] * s->r[iv];
+    if (fabs(s->nu[iv]) > s->nu_inf_norm) s->nu_inf_norm = fabs(s->nu[iv]);
+
+    for (int k = 0; k < 6; ++k) s->vis[6 * idx + k] = vp[k];
+    for (int k = 0; k < 6; ++k) s->vis[6 * idx + k] += S[k] * s->nu[iv];
+
+    memcpy(s->delta_fis + 6 * idx, s->fis + 6 * idx, 6 * sizeof(double));
+    mat6_vec(Hi, s->vis + 6 * idx, Hv6);
+    for (int k = 0; k < 6; ++k) s->fis[6 * idx + k] = Hv6[k] + pi[k];
+    for (int k = 0; k < 6; ++k) s->delta_fis[6 * idx + k] = s->fis[6 * idx + k] - s->delta_fis[6 * idx + k];
+    double n = inf_norm(s->delta_fis + 6 * idx, 6);
+    if (n > s->delta_fis_inf_norm) s->delta_fis_inf_norm = n;
+
+    mat6_vec(s->H_refs + 36 * idx, s->vis + 6 * idx, s->Href_v + 6 * idx);
+    n = inf_norm(s->Href_v + 6 * idx, 6);
+    if (n > s->Href_v_inf_norm) s->Href_v_inf_norm = n;
+
+    for (int k = 0; k < 6; ++k) d6[k] = s->vis[6 * idx + k] - s->vis_prev[6 * idx + k];
+    n = inf_norm(d6, 6);
+    if (n > s->delta_vis_inf_norm) s->delta_vis_inf_norm = n;
+
+    memset(s->g + 6 * idx, 0, 6 * sizeof(double)); /* hxx:370 */
+  }
+  double m = 0.0;
+  for (int k = 0; k < s->nv; ++k) {
+    double a = fabs(s->nu[k] - s->nu_prev[k]);
+    if (a > m) m = a;
+  }
+  s->delta_nu_inf_norm = m;
+}
+
+/* BoxProj(), loik-loid-optimized.hxx:384-397 */
+void ref_box_proj(ref_solver *s)
+{
+  double m = 0.0;
+  for (int k = 0; k < s->nv; ++k) {
+    double x = s->nu[k] + (1.0 / s->mu_ineq) * s->w[k];
+    double lo = s->lb[k] > x ? s->lb[k] : x;   /* lb.cwiseMax(x) */
+    s->z[k] = s->ub[k] < lo ? s->ub[k] : lo;   /* ub.cwiseMin(.) */
+    double a = fabs(s->z[k] - s->z_prev[k]);
+    if (a > m) m = a;
+    s->primal_residual_vec[6 * s->nb + k] = s->nu[k] - s->z[k];
+  }
+  s->delta_z_inf_norm = m;
+}
+
+/* DualUpdate(), loik-loid-optimized.hxx:404-461 */
+void ref_dual_update(ref_solver *s)
+{
+  double Av[6];
+  for (int c = 0; c < s->nc; ++c) {
+    int c_id = s->active_ids[c];
+    const double *Ai = s->Ais + 36 * c, *bi = s->bis + 6 * c, *vi = s->vis + 6 * c_id;
+    mat6_vec(Ai, vi, Av);
+    for (int k = 0; k < 6; ++k) s->Av_minus_b[6 * c + k] = Av[k] - bi[k];
+    for (int k = 0; k < 6; ++k) s->delta_yis[6 * c + k] = s->mu_eq * s->Av_minus_b[6 * c + k];
+    for (int k = 0; k < 6; ++k) s->yis[6 * c + k] += s->delta_yis[6 * c + k];
+    mat6t_vec(Ai, s->yis + 6 * c, s->Aty + 6 * c);
+    double n = inf_norm(s->delta_yis + 6 * c, 6);
+    if (n > s->delta_yis_inf_norm) s->delta_yis_inf_norm = n;
+    for (int k = 0; k < 6; ++k) s->primal_residual_vec[6 * (c_id - 1) + k] = s->Av_minus_b[6 * c + k];
+    for (int k = 0; k < 6; ++k) s->g[6 * c_id + k] = s->Aty[6 * c + k];
+    double plus = 0.0, minus = 0.0;
+    for (int k = 0; k < 6; ++k) {
+      double dy = s->delta_yis[6 * c + k];
+      plus += bi[k] * (dy > 0.0 ? dy : 0.0);
+      minus += bi[k] * (dy < 0.0 ? dy : 0.0);
+    }
+    s->bT_delta_y_plus += plus;
+    s->bT_delta_y_minus += minus;
+    n = inf_norm(Av, 6);
+    if (n > s->Av_inf_norm) s->Av_inf_norm = n;
+  }
+  for (int k = 0; k < s->nv; ++k) {
+    s->delta_w[k] = s->mu_ineq * (s->nu[k] - s->z[k]);
+    s->w[k] += s->delta_w[k];
+  }
+  s->delta_w_inf_norm = inf_norm(s->delta_w, s->nv);
+}
+
+/* BwdPass2OptimizedVisitor + LoikBackwardStep2Visitor::algo, loik-loid-optimized.hxx:468-487, :185-241 */
+static void bwd_pass2(ref_solver *s)
+{
+  double f[6];
+  memcpy(s->delta_Stf_plus_w, s->Stf_plus_w, sizeof(double) * s->nv);
+  for (int idx = s->nj - 1; idx > 0; --idx) {
+    int parent = s->parents[idx];
+    int iv = s->idx_v[idx];
+    const double *liMi = s->liMi + 12 * idx, *fi = s->fis + 6 * idx, *S = s->jS + 6 * idx;
+    for (int k = 0; k < 6; ++k) s->g[6 * idx + k] += -fi[k];
+    se3_act_force(liMi, fi, f);
+    for (int k = 0; k < 6; ++k) s->g[6 * parent + k] += f[k];
+    for (int k = 0; k < 6; ++k) s->delta_g[6 * idx + k] = s->g[6 * idx + k] - s->delta_g[6 * idx + k];
+    double n = inf_norm(s->delta_g + 6 * idx, 6);
+    if (n > s->delta_g_inf_norm) s->delta_g_inf_norm = n;
+    n = inf_norm(s->g + 6 * idx, 6);
+    if (n > s->g_inf_norm) s->g_inf_norm = n;
+    for (int k = 0; k < 6; ++k)
+      s->dual_residual_vec[6 * (idx - 1) + k] = s->Href_v[6 * idx + k] - s->Hv[6 * idx + k] + s->g[6 * idx + k];
+    double Stf = 0.0;
+    for (int k = 0; k < 6; ++k) Stf += S[k] * fi[k];
+    s->Stf_plus_w[iv] = Stf + s->w[iv];
+    if (fabs(s->Stf_plus_w[iv]) > s->Stf_plus_w_inf_norm) s->Stf_plus_w_inf_norm = fabs(s->Stf_plus_w[iv]);
+  }
+  for (int k = 0; k < s->nv; ++k) s->delta_Stf_plus_w[k] = s->Stf_plus_w[k] - s->delta_Stf_plus_w[k];
+  s->delta_Stf_plus_w_inf_norm = inf_norm(s->delta_Stf_plus_w, s->nv);
+  for (int k = 0; k < s->nv; ++k) s->dual_residual_vec[6 * s->nb + k] = s->Stf_plus_w[k];
+}
+
+/* ComputeResiduals = ComputePrimalResiduals (hxx:494-503) + ComputeDualResiduals (hxx:510-522) */
+void ref_compute_residuals(ref_solver *s)
+{
+  s->primal_residual = inf_norm(s->primal_residual_vec, 6 * s->nb + s->nv);
+  s->primal_residual_task = inf_norm(s->primal_residual_vec, 6 * s->nb);
+  s->primal_residual_slack = inf_norm(s->primal_residual_vec + 6 * s->nb, s->nv);
+  bwd_pass2(s);
+  s->dual_residual = inf_norm(s->dual_residual_vec, 6 * s->nb + s->nv);
+  s->dual_residual_v = inf_norm(s->dual_residual_vec, 6 * s->nb);
+  s->dual_residual_nu = inf_norm(s->dual_residual_vec + 6 * s->nb, s->nv);
+}
+
+static double dmax(double a, double b) { return a > b ? a : b; }
+
+/* CheckConvergence(), loik-loid-optimized.hxx:540-565 (nu_inf_norm appears twice, as upstream) */
+void ref_check_convergence(ref_solver *s)
+{
+  s->tol_primal = s->tol_abs +
+                  s->tol_rel * dmax(dmax(s->Av_inf_norm, s->nu_inf_norm), dmax(s->bis_inf_norm, s->nu_inf_norm));
+  s->tol_dual = s->tol_abs + s->tol_rel * dmax(dmax(s->Href_v_inf_norm, dmax(s->g_inf_norm, s->Stf_plus_w_inf_norm)),
+                                               s->Hv_inf_norm);
+  if ((s->primal_residual < s->tol_primal) && (s->dual_residual < s->tol_dual)) s->converged = 1;
+}
+
+/* CheckFeasibility(), loik-loid-optimized.hxx:572-606 */
+void ref_check_feasibility(ref_solver *s)
+{
+  s->delta_y_qp_inf_norm = dmax(s->delta_fis_inf_norm, dmax(s->delta_yis_inf_norm, s->delta_w_inf_norm));
+  s->A_qp_T_delta_y_qp_inf_norm = dmax(s->delta_g_inf_norm, s->delta_Stf_plus_w_inf_norm);
+  s->primal_infeasibility_cond_1 = s->A_qp_T_delta_y_qp_inf_norm <= s->tol_primal_inf * s->delta_y_qp_inf_norm;
+
+  s->ub_qp_T_delta_y_qp_plus = s->bT_delta_y_plus;
+  double acc = 0.0;
+  for (int k = 0; k < s->nv; ++k) acc += s->ub[k] * (s->delta_w[k] > 0.0 ? s->delta_w[k] : 0.0);
+  s->ub_qp_T_delta_y_qp_plus += acc;
+  s->lb_qp_T_delta_y_qp_minus = s->bT_delta_y_minus;
+  acc = 0.0;
+  for (int k = 0; k < s->nv; ++k) acc += s->lb[k] * (s->delta_w[k] < 0.0 ? s->delta_w[k] : 0.0);
+  s->lb_qp_T_delta_y_qp_minus += acc;
+
+  s->primal_infeasibility_cond_2 =
+      (s->ub_qp_T_delta_y_qp_plus + s->lb_qp_T_delta_y_qp_minus) <= s->tol_primal_inf * s->delta_y_qp_inf_norm;
+  if (s->primal_infeasibility_cond_1 && s->primal_infeasibility_cond_2) s->primal_infeasible = 1;
+  s->delta_x_qp_inf_norm = dmax(s->delta_vis_inf_norm, s->delta_nu_inf_norm);
+}
+
+/* UpdateMu(), loik-loid-optimized.hxx:613-641 */
+int ref_update_mu(ref_solver *s)
+{
+  if (s->mu_update_strat == REF_MU_DEFAULT) {
+    if (s->primal_residual > 10 * s->dual_residual) {
+      s->mu *= 10;
+      s->mu_eq = s->mu_equality_scale_factor * s->mu;
+      s->mu_ineq = s->mu;
+    } else if (s->dual_residual > 10 * s->primal_residual) {
+      s->mu *= 0.1;
+      s->mu_eq = s->mu_equality_scale_factor * s->mu;
+      s->mu_ineq = s->mu;
+    }
+    return REF_OK;
+  }
+  return REF_ERR_MU_STRAT;
+}
+
+/* body shared by the three Solve loops and the tail solve (hpp:384-404, :292-306) */
+void ref_iteration_body(ref_solver *s)
+{
+  ref_update_prev(s);
+  ref_reset_inf_norms(s);
+  ref_fwd_pass1(s);
+  ref_bwd_pass(s);
+  ref_fwd_pass2(s);
+  ref_box_proj(s);
+  ref_dual_update(s);
+  ref_compute_residuals(s);
+}
+
+/* InfeasibilityTailSolve(), loik-loid-optimized.hpp:271-319 */
+static void infeasibility_tail_solve(ref_solver *s)
+{
+  s->tail_solve_iter = 0;
+  while (s->delta_x_qp_inf_norm >= s->tol_tail_solve || s->delta_z_inf_norm >= s->tol_tail_solve) {
+    if (s->iter >= s->max_iter) return;
+    s->iter++;
+    s->tail_solve_iter++;
+    ref_iteration_body(s);
+    s->delta_x_qp_inf_norm = dmax(s->delta_vis_inf_norm, s->delta_nu_inf_norm);
+  }
+}
+
+/* main loop, identical in the three Solve overloads (hpp:377-454, :502-579, :616-693) */
+static int main_loop(ref_solver *s)
+{
+  for (int i = 1; i < s->max_iter; i++) {
+    s->iter = i;
+    ref_iteration_body(s);
+    ref_check_convergence(s);
+    if (s->iter > 1) ref_check_feasibility(s);
+    if (s->converged) {
+      break;
+    } else if (s->primal_infeasible) {
+      infeasibility_tail_solve(s);
+      break;
+    } else if (s->dual_infeasible) { /* never set by the optimized solver */
+      infeasibility_tail_solve(s);
+      break;
+    }
+    int rc = ref_update_mu(s);
+    if (rc != REF_OK) return rc;
+  }
+  return REF_OK;
+}
+
+int ref_solve_init(ref_solver *s, const double *q, const double *H_ref, const double *v_ref, const int *c_ids,
+                   int nc, const double *Ais, const double *bis, const double *lb, const double *ub, int nbound)
+{
+  problem_reset(s);
+  data_reset(s, s->warm_start);
+  reset_solver(s);
+  problem_update_reference(s, H_ref, v_ref);
+  int rc = problem_update_ineq(s, lb, ub, nbound);
+  if (rc != REF_OK) return rc;
+  rc = problem_update_eq(s, c_ids, nc, Ais, bis);
+  if (rc != REF_OK) return rc;
+  ref_fwd_pass_init(s, q);
+  return REF_OK;
+}
+
+int ref_solve(ref_solver *s)
+{
+  data_reset_recursion(s);
+  reset_solver(s);
+  return main_loop(s);
+}
+
+int ref_solve_full(ref_solver *s, const double *q, const double *H_ref, const double *v_ref, const int *c_ids,
+                   int nc, const double *Ais, const double *bis, const double *lb, const double *ub, int nbound)
+{
+  int rc = ref_solve_init(s, q, H_ref, v_ref, c_ids, nc, Ais, bis, lb, ub, nbound);
+  if (rc != REF_OK) return rc;
+  return main_loop(s);
+}
+
+int ref_solve_tailored(ref_solver *s, const double *q, int c_id, const double *Ai, const double *bi)
+{
+  data_reset(s, s->warm_start);
+  reset_solver(s);
+  int rc = problem_update_eq_single(s, c_id, Ai, bi);
+  if (rc != REF_OK) return rc;
+  ref_fwd_pass_init(s, q);
+  return main_loop(s);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* accessors                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+const double *ref_field(const ref_solver *s, int field, int *len)
+{
+  const double *p = NULL;
+  int n = 0;
+  switch (field) {
+  case REF_F_LIMI: p = s->liMi; n = 12 * s->nj; break;
+  case REF_F_OMI: p = s->oMi; n = 12 * s->nj; break;
+  case REF_F_VIS: p = s->vis; n = 6 * s->nj; break;
+  case REF_F_VIS_PREV: p = s->vis_prev; n = 6 * s->nj; break;
+  case REF_F_FIS: p = s->fis; n = 6 * s->nj; break;
+  case REF_F_HIS: p = s->His; n = 36 * s->nj; break;
+  case REF_F_PIS: p = s->pis; n = 6 * s->nj; break;
+  case REF_F_NU: p = s->nu; n = s->nv; break;
+  case REF_F_Z: p = s->z; n = s->nv; break;
+  case REF_F_W: p = s->w; n = s->nv; break;
+  case REF_F_YIS: p = s->yis; n = 6 * s->nc; break;
+  case REF_F_ATY: p = s->Aty; n = 6 * s->nc; break;
+  case REF_F_G: p = s->g; n = 6 * s->nj; break;
+  case REF_F_STF_PLUS_W: p = s->Stf_plus_w; n = s->nv; break;
+  case REF_F_R_VEC: p = s->r; n = s->nv; break;
+  case REF_F_UDINV: p = s->jUDinv; n = 6 * s->nj; break;
+  case REF_F_DINV: p = s->jDinv; n = s->nj; break;
+  case REF_F_PRIMAL_RES_VEC: p = s->primal_residual_vec; n = 6 * s->nb + s->nv; break;
+  case REF_F_DUAL_RES_VEC: p = s->dual_residual_vec; n = 6 * s->nb + s->nv; break;
+  case REF_F_DELTA_W: p = s->delta_w; n = s->nv; break;
+  case REF_F_HIS_ABA: p = s->His_aba; n = 36 * s->nj; break;
+  case REF_F_PIS_ABA: p = s->pis_aba; n = 6 * s->nj; break;
+  default: break;
+  }
+  if (len) *len = n;
+  return p;
+}
+
+double ref_scalar(ref_solver *s, int which)
+{
+  switch (which) {
+  case REF_S_ITER: return s->iter;
+  case REF_S_CONVERGED: return s->converged;
+  case REF_S_PRIMAL_INFEASIBLE: return s->primal_infeasible;
+  case REF_S_DUAL_INFEASIBLE: return s->dual_infeasible;
+  case REF_S_PRIMAL_RESIDUAL: return s->primal_residual;
+  case REF_S_DUAL_RESIDUAL: return s->dual_residual;
+  case REF_S_PRIMAL_RESIDUAL_TASK: return s->primal_residual_task;
+  case REF_S_PRIMAL_RESIDUAL_SLACK: return s->primal_residual_slack;
+  case REF_S_DUAL_RESIDUAL_V: return s->dual_residual_v;
+  case REF_S_DUAL_RESIDUAL_NU: return s->dual_residual_nu;
+  case REF_S_TOL_PRIMAL: return s->tol_primal;
+  case REF_S_TOL_DUAL: return s->tol_dual;
+  case REF_S_MU: return s->mu;
+  case REF_S_MU_EQ: return s->mu_eq;
+  case REF_S_MU_INEQ: return s->mu_ineq;
+  /* debug getters recompute like upstream, loik-loid-optimized.hpp:706-755 */
+  case REF_S_DELTA_X_QP_INF_NORM:
+    s->delta_x_qp_inf_norm = dmax(s->delta_vis_inf_norm, s->delta_nu_inf_norm);
+    return s->delta_x_qp_inf_norm;
+  case REF_S_DELTA_Z_QP_INF_NORM: return s->delta_z_inf_norm;
+  case REF_S_DELTA_Y_QP_INF_NORM:
+    s->delta_y_qp_inf_norm = dmax(s->delta_fis_inf_norm, dmax(s->delta_yis_inf_norm, s->delta_w_inf_norm));
+    return s->delta_y_qp_inf_norm;
+  case REF_S_A_QP_T_DELTA_Y_QP_INF_NORM:
+    s->A_qp_T_delta_y_qp_inf_norm = dmax(s->delta_g_inf_norm, s->delta_Stf_plus_w_inf_norm);
+    return s->A_qp_T_delta_y_qp_inf_norm;
+  case REF_S_UB_QP_T_DELTA_Y_QP_PLUS: {
+    double acc = 0.0;
+    for (int k = 0; k < s->nv; ++k) acc += s->ub[k] * (s->delta_w[k] > 0.0 ? s->delta_w[k] : 0.0);
+    s->ub_qp_T_delta_y_qp_plus = s->bT_delta_y_plus + acc;
+    return s->ub_qp_T_delta_y_qp_plus;
+  }
+  case REF_S_LB_QP_T_DELTA_Y_QP_MINUS: {
+    double acc = 0.0;
+    for (int k = 0; k < s->nv; ++k) acc += s->lb[k] * (s->delta_w[k] < 0.0 ? s->delta_w[k] : 0.0);
+    s->lb_qp_T_delta_y_qp_minus = s->bT_delta_y_minus + acc;
+    return s->lb_qp_T_delta_y_qp_minus;
+  }
+  case REF_S_PRIMAL_INFEASIBILITY_COND_1:
+    return s->A_qp_T_delta_y_qp_inf_norm <= s->tol_primal_inf * s->delta_y_qp_inf_norm;
+  case REF_S_PRIMAL_INFEASIBILITY_COND_2:
+    return (s->ub_qp_T_delta_y_qp_plus + s->lb_qp_T_delta_y_qp_minus) <= s->tol_primal_inf * s->delta_y_qp_inf_norm;
+  case REF_S_TAIL_SOLVE_ITER: return s->tail_solve_iter;
+  case REF_S_DELTA_FIS_INF_NORM: return s->delta_fis_inf_norm;
+  case REF_S_DELTA_YIS_INF_NORM: return s->delta_yis_inf_norm;
+  case REF_S_DELTA_W_INF_NORM: return s->delta_w_inf_norm;
+  case REF_S_DELTA_VIS_INF_NORM: return s->delta_vis_inf_norm;
+  case REF_S_DELTA_NU_INF_NORM: return s->delta_nu_inf_norm;
+  case REF_S_AV_INF_NORM: return s->Av_inf_norm;
+  case REF_S_NU_INF_NORM: return s->nu_inf_norm;
+  case REF_S_HREF_V_INF_NORM: return s->Href_v_inf_norm;
+  case REF_S_G_INF_NORM: return s->g_inf_norm;
+  case REF_S_STF_PLUS_W_INF_NORM: return s->Stf_plus_w_inf_norm;
+  case REF_S_BIS_INF_NORM: return s->bis_inf_norm;
+  case REF_S_HV_INF_NORM: return s->Hv_inf_norm;
+  default: return NAN;
+  }
+}
+
+void ref_set_max_iter(ref_solver *s, int max_iter) { s->max_iter = max_iter; }
+void ref_set_tols(ref_solver *s, double tol_abs, double tol_rel) { s->tol_abs = tol_abs; s->tol_rel = tol_rel; }
+void ref_set_warm_start(ref_solver *s, int warm) { s->warm_start = warm; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* batch driver (cpu_baseline + batch parity tests)                                            */
+/* ------------------------------------------------------------------------------------------ */
+int ref_solve_batch(const ref_model *model, const ref_params *prm, int B, const double *q, const double *H_ref,
+                    const double *v_ref, const int *c_ids, int nc, const double *Ais, const double *bis,
+                    const double *lb, const double *ub, int shared_mask, int nthreads, double *z_out,
+                    double *nu_out, int *iters_out, int *flags_out, double *res_out)
+{
+  const int nq = model->nq, nv = model->nv;
+  int err = REF_OK;
+  if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+  {
+    ref_solver *s = NULL;
+    int rc = ref_create(model, prm, &s);
+#ifdef _OPENMP
+    int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+    int tid = 0, nt = 1;
+#endif
+    if (rc == REF_OK) {
+      long lo = (long)B * tid / nt, hi = (long)B * (tid + 1) / nt;
+      for (long b = lo; b < hi; ++b) {
+        const double *Ab = (shared_mask & 1) ? Ais : Ais + (size_t)b * 36 * nc;
+        const double *lbb = (shared_mask & 2) ? lb : lb + (size_t)b * nv;
+        const double *ubb = (shared_mask & 2) ? ub : ub + (size_t)b * nv;
+        rc = ref_solve_full(s, q + (size_t)b * nq, H_ref, v_ref, c_ids, nc, Ab, bis + (size_t)b * 6 * nc, lbb,
+                            ubb, nv);
+        if (rc != REF_OK) break;
+        memcpy(z_out + (size_t)b * nv, s->z, sizeof(double) * nv);
+        if (nu_out) memcpy(nu_out + (size_t)b * nv, s->nu, sizeof(double) * nv);
+        if (iters_out) iters_out[b] = s->iter;
+        if (flags_out) flags_out[b] = (s->converged ? 1 : 0) | (s->primal_infeasible ? 2 : 0);
+        if (res_out) {
+          res_out[2 * b] = s->primal_residual;
+          res_out[2 * b + 1] = s->dual_residual;
+        }
+      }
+    }
+    if (rc != REF_OK) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+      err = rc;
+    }
+    ref_destroy(s);
+  }
+  return err;
+}

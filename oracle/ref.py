@@ -1,0 +1,260 @@
+"""ctypes front-end of the C oracle (oracle/loik_ref.c).  TEST INFRASTRUCTURE ONLY.
+
+Mirrors the reference's `FirstOrderLoikOptimizedTpl<double>` API (include/loik/loik-loid-optimized.hpp)
+so that tests read like the reference's own tests (tests/loik-loid.cpp).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_c_double_p = C.POINTER(C.c_double)
+_c_int_p = C.POINTER(C.c_int)
+
+
+class RefModel(C.Structure):
+    _fields_ = [("njoints", C.c_int), ("nq", C.c_int), ("nv", C.c_int),
+                ("parents", _c_int_p), ("jtype", _c_int_p), ("axis", _c_double_p),
+                ("idx_q", _c_int_p), ("idx_v", _c_int_p), ("placement", _c_double_p)]
+
+
+class RefParams(C.Structure):
+    _fields_ = [("max_iter", C.c_int),
+                ("tol_abs", C.c_double), ("tol_rel", C.c_double),
+                ("tol_primal_inf", C.c_double), ("tol_dual_inf", C.c_double),
+                ("rho", C.c_double), ("mu", C.c_double), ("mu_equality_scale_factor", C.c_double),
+                ("mu_update_strat", C.c_int), ("num_eq_c", C.c_int), ("eq_c_dim", C.c_int),
+                ("warm_start", C.c_int), ("tol_tail_solve", C.c_double)]
+
+
+# field / scalar ids, keep in sync with loik_ref.h
+FIELDS = ["liMi", "oMi", "vis", "vis_prev", "fis", "His", "pis", "nu", "z", "w", "yis", "Aty", "g",
+          "Stf_plus_w", "r", "UDinv", "Dinv", "primal_residual_vec", "dual_residual_vec", "delta_w",
+          "His_aba", "pis_aba"]
+SCALARS = ["iter", "converged", "primal_infeasible", "dual_infeasible", "primal_residual", "dual_residual",
+           "primal_residual_task", "primal_residual_slack", "dual_residual_v", "dual_residual_nu",
+           "tol_primal", "tol_dual", "mu", "mu_eq", "mu_ineq", "delta_x_qp_inf_norm", "delta_z_qp_inf_norm",
+           "delta_y_qp_inf_norm", "A_qp_T_delta_y_qp_inf_norm", "ub_qp_T_delta_y_qp_plus",
+           "lb_qp_T_delta_y_qp_minus", "primal_infeasibility_cond_1", "primal_infeasibility_cond_2",
+           "tail_solve_iter", "delta_fis_inf_norm", "delta_yis_inf_norm", "delta_w_inf_norm",
+           "delta_vis_inf_norm", "delta_nu_inf_norm", "Av_inf_norm", "nu_inf_norm", "Href_v_inf_norm",
+           "g_inf_norm", "Stf_plus_w_inf_norm", "bis_inf_norm", "Hv_inf_norm"]
+
+_lib_cache = {}
+
+
+def load(native=False):
+    key = bool(native)
+    if key in _lib_cache:
+        return _lib_cache[key]
+    path = _build.build(native=native)
+    lib = C.CDLL(path)
+    lib.ref_create.argtypes = [C.POINTER(RefModel), C.POINTER(RefParams), C.POINTER(C.c_void_p)]
+    lib.ref_create.restype = C.c_int
+    lib.ref_destroy.argtypes = [C.c_void_p]
+    lib.ref_destroy.restype = None
+    sig_init = [C.c_void_p, _c_double_p, _c_double_p, _c_double_p, _c_int_p, C.c_int, _c_double_p, _c_double_p,
+                _c_double_p, _c_double_p, C.c_int]
+    lib.ref_solve_init.argtypes = sig_init
+    lib.ref_solve_init.restype = C.c_int
+    lib.ref_solve_full.argtypes = sig_init
+    lib.ref_solve_full.restype = C.c_int
+    lib.ref_solve.argtypes = [C.c_void_p]
+    lib.ref_solve.restype = C.c_int
+    lib.ref_solve_tailored.argtypes = [C.c_void_p, _c_double_p, C.c_int, _c_double_p, _c_double_p]
+    lib.ref_solve_tailored.restype = C.c_int
+    for name in ["ref_update_prev", "ref_reset_inf_norms", "ref_fwd_pass1", "ref_bwd_pass", "ref_fwd_pass2",
+                 "ref_box_proj", "ref_dual_update", "ref_compute_residuals", "ref_check_convergence",
+                 "ref_check_feasibility", "ref_iteration_body"]:
+        getattr(lib, name).argtypes = [C.c_void_p]
+        getattr(lib, name).restype = None
+    lib.ref_update_mu.argtypes = [C.c_void_p]
+    lib.ref_update_mu.restype = C.c_int
+    lib.ref_fwd_pass_init.argtypes = [C.c_void_p, _c_double_p]
+    lib.ref_fwd_pass_init.restype = None
+    lib.ref_field.argtypes = [C.c_void_p, C.c_int, _c_int_p]
+    lib.ref_field.restype = _c_double_p
+    lib.ref_scalar.argtypes = [C.c_void_p, C.c_int]
+    lib.ref_scalar.restype = C.c_double
+    lib.ref_set_max_iter.argtypes = [C.c_void_p, C.c_int]
+    lib.ref_set_tols.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    lib.ref_set_warm_start.argtypes = [C.c_void_p, C.c_int]
+    lib.ref_solve_batch.argtypes = [C.POINTER(RefModel), C.POINTER(RefParams), C.c_int, _c_double_p, _c_double_p,
+                                    _c_double_p, _c_int_p, C.c_int, _c_double_p, _c_double_p, _c_double_p,
+                                    _c_double_p, C.c_int, C.c_int, _c_double_p, _c_double_p, _c_int_p, _c_int_p,
+                                    _c_double_p]
+    lib.ref_solve_batch.restype = C.c_int
+    _lib_cache[key] = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(_c_double_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_c_int_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class _ModelHolder:
+    """keeps the numpy arrays backing a RefModel alive"""
+
+    def __init__(self, model):
+        self.parents = _i32(model.parents)
+        self.jtype = _i32(model.jtype)
+        self.axis = _f64(model.axis)
+        self.idx_q = _i32(model.idx_q)
+        self.idx_v = _i32(model.idx_v)
+        self.placement = _f64(model.placement)
+        self.struct = RefModel(int(model.njoints), int(model.nq), int(model.nv), _ip(self.parents),
+                               _ip(self.jtype), _dp(self.axis), _ip(self.idx_q), _ip(self.idx_v),
+                               _dp(self.placement))
+
+
+def make_params(max_iter=200, tol_abs=1e-3, tol_rel=1e-3, tol_primal_inf=1e-2, tol_dual_inf=1e-2, rho=1e-5,
+                mu=1e-2, mu_equality_scale_factor=1e4, mu_update_strat=0, num_eq_c=1, eq_c_dim=6,
+                warm_start=False, tol_tail_solve=1e-1):
+    """defaults = the reference fixture, tests/loik-loid.cpp:91-105"""
+    return RefParams(max_iter, tol_abs, tol_rel, tol_primal_inf, tol_dual_inf, rho, mu, mu_equality_scale_factor,
+                     mu_update_strat, num_eq_c, eq_c_dim, int(bool(warm_start)), tol_tail_solve)
+
+
+class RefSolver:
+    """CPU oracle object = IkIdDataTypeOptimized + FirstOrderLoikOptimized of the reference."""
+
+    def __init__(self, model, native=False, **params):
+        self.lib = load(native)
+        self._mh = _ModelHolder(model)
+        self.model = model
+        self.params = make_params(**params)
+        self.nc = self.params.num_eq_c
+        h = C.c_void_p()
+        rc = self.lib.ref_create(C.byref(self._mh.struct), C.byref(self.params), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("ref_create failed with code %d" % rc)
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_destroy(self.h)
+            self.h = None
+
+    # -- problem entry points ---------------------------------------------------------------------
+    def _init_args(self, q, H_ref, v_ref, c_ids, Ais, bis, lb, ub):
+        q = _f64(q); H_ref = _f64(H_ref).reshape(36); v_ref = _f64(v_ref).reshape(6)
+        c_ids = _i32(c_ids); Ais = _f64(Ais).reshape(-1); bis = _f64(bis).reshape(-1)
+        lb = _f64(lb); ub = _f64(ub)
+        keep = (q, H_ref, v_ref, c_ids, Ais, bis, lb, ub)
+        args = (self.h, _dp(q), _dp(H_ref), _dp(v_ref), _ip(c_ids), int(c_ids.size), _dp(Ais), _dp(bis), _dp(lb),
+                _dp(ub), int(lb.size))
+        return keep, args
+
+    def SolveInit(self, q, H_ref, v_ref, c_ids, Ais, bis, lb, ub):
+        keep, args = self._init_args(q, H_ref, v_ref, c_ids, Ais, bis, lb, ub)
+        rc = self.lib.ref_solve_init(*args)
+        if rc != 0:
+            raise RuntimeError("ref_solve_init failed with code %d" % rc)
+
+    def Solve(self, *a):
+        if len(a) == 0:
+            rc = self.lib.ref_solve(self.h)
+        elif len(a) == 8:
+            keep, args = self._init_args(*a)
+            rc = self.lib.ref_solve_full(*args)
+        elif len(a) == 4:
+            q, c_id, Ai, bi = a
+            q = _f64(q); Ai = _f64(Ai).reshape(36); bi = _f64(bi).reshape(6)
+            rc = self.lib.ref_solve_tailored(self.h, _dp(q), int(c_id), _dp(Ai), _dp(bi))
+        else:
+            raise TypeError("Solve() takes 0, 4 or 8 arguments")
+        if rc != 0:
+            raise RuntimeError("ref solve failed with code %d" % rc)
+
+    # -- pass-level ---------------------------------------------------------------------------------
+    def FwdPassInit(self, q):
+        q = _f64(q)
+        self.lib.ref_fwd_pass_init(self.h, _dp(q))
+
+    def UpdatePrev(self): self.lib.ref_update_prev(self.h)
+    def ResetInfNorms(self): self.lib.ref_reset_inf_norms(self.h)
+    def FwdPass1(self): self.lib.ref_fwd_pass1(self.h)
+    def BwdPass(self): self.lib.ref_bwd_pass(self.h)
+    def FwdPass2(self): self.lib.ref_fwd_pass2(self.h)
+    def BoxProj(self): self.lib.ref_box_proj(self.h)
+    def DualUpdate(self): self.lib.ref_dual_update(self.h)
+    def ComputeResiduals(self): self.lib.ref_compute_residuals(self.h)
+    def CheckConvergence(self): self.lib.ref_check_convergence(self.h)
+    def CheckFeasibility(self): self.lib.ref_check_feasibility(self.h)
+    def IterationBody(self): self.lib.ref_iteration_body(self.h)
+
+    def UpdateMu(self):
+        rc = self.lib.ref_update_mu(self.h)
+        if rc != 0:
+            raise RuntimeError("mu update strategy not supported (code %d)" % rc)
+
+    def set_max_iter(self, n): self.lib.ref_set_max_iter(self.h, int(n))
+    def set_tols(self, tol_abs, tol_rel): self.lib.ref_set_tols(self.h, float(tol_abs), float(tol_rel))
+    def set_warm_start(self, w): self.lib.ref_set_warm_start(self.h, int(bool(w)))
+
+    # -- accessors ----------------------------------------------------------------------------------
+    def field(self, name):
+        n = C.c_int(0)
+        p = self.lib.ref_field(self.h, FIELDS.index(name), C.byref(n))
+        a = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+        nj = self.model.njoints
+        shapes = {"liMi": (nj, 12), "oMi": (nj, 12), "vis": (nj, 6), "vis_prev": (nj, 6), "fis": (nj, 6),
+                  "His": (nj, 6, 6), "pis": (nj, 6), "yis": (-1, 6), "Aty": (-1, 6), "g": (nj, 6),
+                  "UDinv": (nj, 6), "His_aba": (nj, 6, 6), "pis_aba": (nj, 6)}
+        return a.reshape(shapes[name]) if name in shapes else a
+
+    def scalar(self, name):
+        return self.lib.ref_scalar(self.h, SCALARS.index(name))
+
+    def __getattr__(self, name):
+        if name in FIELDS:
+            return self.field(name)
+        if name.startswith("get_") and name[4:] in SCALARS:
+            key = name[4:]
+            return lambda: self.scalar(key)
+        raise AttributeError(name)
+
+    def get_iter(self): return int(self.scalar("iter"))
+    def get_convergence_status(self): return bool(self.scalar("converged"))
+    def get_primal_infeasibility_status(self): return bool(self.scalar("primal_infeasible"))
+    def get_dual_infeasibility_status(self): return bool(self.scalar("dual_infeasible"))
+
+
+def solve_batch(model, q, H_ref, v_ref, c_ids, Ais, bis, lb, ub, nthreads=1, native=False, want_nu=False,
+                **params):
+    """Cold `Solve(q,H_ref,v_ref,ids,Ais,bis,lb,ub)` of every instance (instance-major arrays).
+    Ais: [nc,6,6] (shared) or [B,nc,6,6]; lb/ub: [nv] (shared) or [B,nv]; bis: [B,nc,6]."""
+    lib = load(native)
+    mh = _ModelHolder(model)
+    prm = make_params(**params)
+    q = _f64(q); B = q.shape[0]; nv = model.nv
+    H_ref = _f64(H_ref).reshape(36); v_ref = _f64(v_ref).reshape(6); c_ids = _i32(c_ids)
+    nc = int(c_ids.size)
+    Ais = _f64(Ais); bis = _f64(bis); lb = _f64(lb); ub = _f64(ub)
+    shared = (1 if Ais.size == 36 * nc else 0) | (2 if lb.size == nv else 0)
+    z = np.empty((B, nv)); nu = np.empty((B, nv)) if want_nu else None
+    iters = np.empty(B, dtype=np.int32); flags = np.empty(B, dtype=np.int32); res = np.empty((B, 2))
+    rc = lib.ref_solve_batch(C.byref(mh.struct), C.byref(prm), B, _dp(q), _dp(H_ref), _dp(v_ref), _ip(c_ids), nc,
+                             _dp(Ais), _dp(bis), _dp(lb), _dp(ub), shared, int(nthreads), _dp(z),
+                             _dp(nu) if want_nu else None, _ip(iters), _ip(flags), _dp(res))
+    if rc != 0:
+        raise RuntimeError("ref_solve_batch failed with code %d" % rc)
+    out = dict(z=z, iters=iters, converged=(flags & 1).astype(bool), primal_infeasible=(flags & 2).astype(bool),
+               primal_residual=res[:, 0], dual_residual=res[:, 1])
+    if want_nu:
+        out["nu"] = nu
+    return out
