@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X-native batched LoIK solver.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Metric (BASELINE.json): IK solves/s to 1e-6 residual, Talos humanoid, batch = 65536 per GPU, fp64, adaptive mu.
+A "step" is one cold `Solve()` (the reference's hot loop, /root/reference/include/loik/loik-loid-optimized.hpp:368-455)
+over one batch of 65536 synthetic problem instances whose inputs were placed in HBM by `SolveInit()` before the
+timed region -- the same split the reference's own timing test uses (`SolveInit` once, then time `Solve()`,
+/root/reference/tests/loik-loid.cpp:987-1032).  A "solve" is an instance that stops with primal AND dual residual
+below 1e-6 (`get_convergence_status()`); instances that trip the reference's infeasibility certificate or hit
+max_iter are executed and timed but not counted.  The batch shards over GPUs with no exchange step (instances are
+independent): every rank solves its own 65536 instances, no collective on the data path ("scaling": "weak").
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (`k_solve`) against HBM bandwidth with the
+ALGORITHMIC byte model of SURVEY.md 8(d): bytes per ADMM instance-iteration = sizeof(scalar)*(203 nb + 108 nc);
+kernel time comes from HIP events recorded by the library on the stream the kernel is launched on.
+`cpu_baseline` times the CPU oracle (a line-faithful port of the reference solver, NOT upstream libloik) on a
+bounded sample of the same workload on all host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(wl, budget_s=15.0):
+    """oracle (kind "port") on the box's host cores, bounded sample of the same workload"""
+    from oracle import ref
+    cores = os.cpu_count() or 1
+    m, prm = wl["model"], wl["params"]
+
+    def run(n):
+        t = time.perf_counter()
+        out = ref.solve_batch(m, wl["q"][:n], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"][:n], wl["lb"],
+                              wl["ub"], nthreads=cores, native=True, **prm)
+        return time.perf_counter() - t, out
+
+    n0 = min(wl["q"].shape[0], 8 * cores)
+    t0, _ = run(n0)  # pilot (also warms the thread pool)
+    t0, _ = run(n0)
+    n = int(min(wl["q"].shape[0], max(n0, n0 * budget_s / max(t0, 1e-4))))
+    n = max(cores, (n // cores) * cores)
+    dt, out = run(n)
+    return dict(value=float(out["converged"].sum() / dt), unit="solves/s", cores=cores, kind="port",
+                sample="first %d instances of the same workload, %d threads, %.1f s, %.0f ADMM instance-iterations/s; "
+                       "oracle/loik_ref.c = line-faithful C port of the reference solver (not upstream libloik)"
+                       % (n, cores, dt, out["iters"].sum() / dt),
+                instance_iterations_per_s=float(out["iters"].sum() / dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--max-launch-iters", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the data path has no collective; the process group only carries the timing barrier / max-reduce
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    import loik_amd
+    from loik_amd import workloads
+
+    def device_sync():
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+
+    def barrier():
+        device_sync()
+        if dist is not None:
+            dist.barrier()
+        device_sync()
+
+    if loik_amd.device_count() <= local_rank:
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+
+    B = args.batch
+    wl = workloads.talos_c3(B, seed=0x101C + 3 + rank)
+    model, prm = wl["model"], wl["params"]
+    solver = loik_amd.BatchedLoik(model, B, device=local_rank, flags=args.flags, max_launch_iters=args.max_launch_iters,
+                                  **prm)
+    t_init = time.perf_counter()
+    solver.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    t_init = time.perf_counter() - t_init  # includes the PCIe upload of the host-side synthetic inputs
+
+    for _ in range(args.warmup):
+        solver.Solve()
+    kernel_ms = 0.0
+    inst_iters = 0
+    launches = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.Solve()
+        st = solver.stats()
+        kernel_ms += st["kernel_ms"]
+        inst_iters += st["instance_iterations"]
+        launches += st["launches"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    conv = solver.get("converged").astype(bool)
+    it = solver.get("iter")
+    n_solved = int(conv.sum())
+    stats = dict(solved=n_solved, infeasible=int(solver.get("primal_infeasible").sum()),
+                 unfinished=int(st["n_unfinished"]), iters_sum=int(it.sum()), elapsed=elapsed)
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+        agg = torch.tensor([n_solved, int(it.sum()), B], dtype=torch.float64)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        total_solved, total_iters, total_B = (float(x) for x in agg)
+    else:
+        total_solved, total_iters, total_B = float(n_solved), float(it.sum()), float(B)
+
+    if rank == 0:
+        bytes_iter = st["bytes_per_instance_iteration"]
+        achieved = inst_iters * bytes_iter / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        line = {
+            "metric": "IK solves/sec to 1e-6 residual, Talos humanoid, batch=65536 per GPU",
+            "value": total_solved * args.steps / elapsed,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": wl["name"],
+                "robot": "talos32 (fixed base, 32 x 1-DoF, Talos topology)",
+                "batch_per_gpu": B,
+                "task": "6-D velocity task on arm_left_7_joint, A=I, b=J(q) nu*, nu*~U(-0.5,0.5)^32, box +-0.5",
+                "stop": "tol_abs=1e-6, tol_rel=0, max_iter=1000, reference fixture rho/mu/scale, adaptive mu (DEFAULT)",
+                "parallelism": "%d independent shard(s), no collective" % world,
+                "solved_fraction": total_solved / total_B,
+                "flagged_infeasible_fraction_rank0": stats["infeasible"] / B,
+                "hit_max_iter_fraction_rank0": stats["unfinished"] / B,
+                "mean_admm_iterations": total_iters / total_B,
+                "instance_iterations_per_s": total_iters * args.steps / elapsed,
+                "solve_init_s_rank0_incl_pcie": t_init,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_solve<double>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_unit": bytes_iter,
+                "unit_def": "one ADMM iteration of one instance: 8 B x (203 nb + 108 nc), nb=32, nc=1",
+                "units_per_launch": inst_iters / max(launches, 1),
+                "avg_launch_ms": kernel_ms / max(launches, 1),
+                "launches_per_step": launches / args.steps,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(wl)
+            except Exception as e:  # the GPU number must survive a broken host toolchain
+                line["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": os.cpu_count(), "kind": "port",
+                                        "sample": "failed: %r" % (e,)}
+        print(json.dumps(line), flush=True)
+    solver.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -32,7 +32,7 @@ def build(force=False, verbose=False, extra_flags=()):
     c_obj = os.path.join(LIBDIR, "models.o")
     subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=c11", "-I", inc, "-c", os.path.join(CSRC, "models.c"), "-o", c_obj])
     objs.append(c_obj)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", inc,
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=on", "-std=c++17", "-fPIC", "-shared", "-I", inc,
            "-Wall", "-Wno-unused-function", "-x", "hip", os.path.join(CSRC, "loik_host.hip"),
            "-x", "none", c_obj, "-o", LIB] + list(extra_flags)
     if verbose:

@@ -1,0 +1,109 @@
+"""shared test helpers: the reference's comparison predicates, its fixture problem, random kinematic trees"""
+import numpy as np
+
+import loik_amd
+from loik_amd import workloads
+
+
+def scalar_abs_or_rel_equal(a, b, tol=1e-10):
+    """check_scalar_abs_or_rel_equal, /root/reference/tests/loik-loid.cpp:39-57"""
+    a, b = float(a), float(b)
+    d = abs(a - b)
+    c_abs = d < tol
+    c_rel = (abs(a) > 0 and abs(b) > 0 and d / abs(a) < tol and d / abs(b) < tol)
+    return c_abs or c_rel
+
+
+def dense_abs_or_rel_equal(a, b, tol=1e-10):
+    """check_eigen_dense_abs_or_rel_equal, /root/reference/tests/loik-loid.cpp:60-83
+    (Eigen isApprox: ||a-b||_F <= 1e-12 * min(||a||_F, ||b||_F), OR inf-norm of the difference < tol)"""
+    a = np.asarray(a, dtype=float); b = np.asarray(b, dtype=float)
+    c1 = np.linalg.norm(a - b) <= 1e-12 * min(np.linalg.norm(a), np.linalg.norm(b))
+    c2 = np.max(np.abs(a - b)) < tol if a.size else True
+    return bool(c1 or c2)
+
+
+def assert_close(a, b, tol=1e-10, what=""):
+    a = np.asarray(a, dtype=float); b = np.asarray(b, dtype=float)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    d = np.abs(a - b)
+    den = np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-300)
+    bad = np.minimum(d, d / den) >= tol
+    assert not bad.any(), "%s: abs-or-rel mismatch %.3e (tol %.1e)" % (what, float(np.minimum(d, d / den).max()), tol)
+
+
+def fixture_problem(model, bound=4.0, link=None):
+    """ProblemSetupFixture, /root/reference/tests/loik-loid.cpp:87-165: q = neutral, H_ref = I, v_ref = 0, one
+    constraint on the LAST joint with A = I, b = (0,0,.5,0,0,0), box = +-bound"""
+    link = model.njoints - 1 if link is None else link
+    return dict(q=np.zeros(model.nq), H_ref=np.eye(6), v_ref=np.zeros(6), c_ids=np.array([link], dtype=np.int32),
+                Ais=np.eye(6).reshape(1, 6, 6), bis=np.array([[0, 0, 0.5, 0, 0, 0.0]]),
+                lb=-bound * np.ones(model.nv), ub=bound * np.ones(model.nv))
+
+
+def problem_args(p, b=None):
+    """(q,H_ref,v_ref,ids,Ais,bis,lb,ub) of one instance `b` of a batched workload, or of a single problem"""
+    if b is None:
+        return (p["q"], p["H_ref"], p["v_ref"], p["c_ids"], p["Ais"], p["bis"], p["lb"], p["ub"])
+    Ais = p["Ais"] if np.asarray(p["Ais"]).ndim == 3 else p["Ais"][b]
+    lb = p["lb"] if np.asarray(p["lb"]).ndim == 1 else p["lb"][b]
+    ub = p["ub"] if np.asarray(p["ub"]).ndim == 1 else p["ub"][b]
+    return (p["q"][b], p["H_ref"], p["v_ref"], p["c_ids"], Ais, p["bis"][b], lb, ub)
+
+
+FIXTURE = dict(tol_abs=1e-3, tol_rel=1e-3, tol_primal_inf=1e-2, tol_dual_inf=1e-2, tol_tail_solve=1e-1, rho=1e-5,
+               mu=1e-2, mu_equality_scale_factor=1e4, mu_update_strat=0, num_eq_c=1, eq_c_dim=6, warm_start=False)
+
+
+def random_rotation(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def random_tree(seed, nb, branch_prob=0.35, all_types=True):
+    """random depth-first-numbered kinematic tree (like pinocchio::buildModels::humanoidRandom in spirit,
+    /root/reference/tests/loik-loid-data.cpp:24-31): mixed revolute / prismatic / unaligned joints, random
+    placements, several branch points and several root children -> exercises the LDS branch stack."""
+    rng = np.random.default_rng(seed)
+    parents = [0]
+    # build by DFS: keep a stack of "open" ancestors; next joint attaches to the top or pops
+    path = [0]
+    for i in range(1, nb + 1):
+        while len(path) > 1 and rng.random() < branch_prob:
+            path.pop()
+        parents.append(path[-1])
+        path.append(i)
+    types = [0]
+    axis = [np.zeros(3)]
+    placement = [np.concatenate([np.eye(3).ravel(), np.zeros(3)])]
+    for i in range(1, nb + 1):
+        t = int(rng.integers(1, 9)) if all_types else int(rng.integers(1, 4))
+        a = np.zeros(3)
+        if t in (7, 8):
+            a = rng.normal(size=3)
+            a /= np.linalg.norm(a)
+        else:
+            a[(t - 1) % 3] = 1.0
+        types.append(t)
+        axis.append(a)
+        placement.append(np.concatenate([random_rotation(rng).ravel(), rng.uniform(-0.4, 0.4, size=3)]))
+    return loik_amd.Model(parents, types, np.array(axis), np.array(placement), q_lo=-np.ones(nb), q_hi=np.ones(nb),
+                          name="random_tree_%d_%d" % (seed, nb))
+
+
+def feasible_batch(model, batch, link, seed, bound=0.5, nu_scale=0.4, per_instance_A=False, per_instance_bounds=False):
+    wl = workloads.make_workload(model, batch, link, seed, bound=bound, snap_prob=0.0, nu_scale=nu_scale)
+    rng = np.random.default_rng(seed + 1)
+    if per_instance_A:
+        A = np.eye(6)[None, None] + 0.3 * rng.normal(size=(batch, 1, 6, 6))
+        v = workloads.link_velocity(model, wl["q"], wl["nu_star"], link)
+        wl["Ais"] = A
+        wl["bis"] = np.einsum("bcij,bj->bci", A, v)
+    if per_instance_bounds:
+        wl["lb"] = -bound * (1 + 0.2 * rng.random((batch, model.nv)))
+        wl["ub"] = bound * (1 + 0.2 * rng.random((batch, model.nv)))
+    return wl

@@ -1,0 +1,285 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI (loik_amd.capi -> libloik_amd.so), against the
+live CPU oracle on identical seeded inputs.  Tolerances: 1e-9 abs-or-rel on the state after a fixed number of ADMM
+iterations (the reference's own cross-implementation bar is 1e-10, tests/loik-loid.cpp:39-83; the extra decade
+covers FMA contraction and a different summation order on the GPU), identical iteration counts and flags, and
+1e-9 on the converged joint velocities."""
+import numpy as np
+import pytest
+
+import loik_amd
+from loik_amd import capi, workloads
+from oracle import ref
+from helpers import FIXTURE, assert_close, feasible_batch, fixture_problem, problem_args, random_tree
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ["nu", "z", "w", "vis", "fis", "g", "yis", "Aty", "pis", "UDinv", "Dinv", "Stf_plus_w"]
+SCALARS = ["primal_residual", "dual_residual", "primal_residual_task", "primal_residual_slack", "dual_residual_v",
+           "dual_residual_nu", "mu", "delta_fis_inf_norm", "delta_yis_inf_norm", "delta_w_inf_norm",
+           "delta_vis_inf_norm", "delta_nu_inf_norm", "Av_inf_norm", "nu_inf_norm", "Href_v_inf_norm", "g_inf_norm",
+           "Stf_plus_w_inf_norm"]
+
+
+def gpu_solve(model, wl, prm, **kw):
+    B = wl["q"].shape[0]
+    s = loik_amd.BatchedLoik(model, B, **prm, **kw)
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    return s
+
+
+def compare_instance(s, cache, r, b, tol, scalars=True):
+    for name in FIELDS:
+        want = r.field(name)
+        if name in ("vis", "fis", "g", "pis", "UDinv", "Dinv"):
+            want = want[1:]
+        assert_close(cache[name][b], want, tol, "%s b%d" % (name, b))
+    assert_close(cache["His"][b], r.His[1:], tol, "His b%d" % b)
+    if scalars:
+        for name in SCALARS:
+            assert_close(cache[name][b], r.scalar(name), tol, "%s b%d" % (name, b))
+
+
+def fetch(s):
+    cache = {n: s.get(n) for n in FIELDS + SCALARS + ["iter", "converged", "primal_infeasible", "tol_primal", "tol_dual"]}
+    cache["His"] = s.His_full()
+    return cache
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 7])
+def test_k_iterations_talos(talos, k):
+    link = talos.getJointId("arm_left_7_joint")
+    wl = feasible_batch(talos, 96, link, 31, nu_scale=0.5)
+    prm = dict(FIXTURE, max_iter=k + 1, tol_abs=0.0, tol_rel=0.0, tol_primal_inf=0.0)
+    s = gpu_solve(talos, wl, prm)
+    cache = fetch(s)
+    assert np.all(cache["iter"] == k)
+    for b in range(0, 96, 5):
+        r = ref.RefSolver(talos, **prm)
+        r.Solve(*problem_args(wl, b))
+        compare_instance(s, cache, r, b, 1e-9)
+    s.close()
+
+
+@pytest.mark.parametrize("seed,nb", [(1, 6), (2, 17), (3, 40), (4, 63)])
+def test_random_trees_all_joint_types(seed, nb):
+    """unaligned revolute / prismatic axes, random placements, deep branch stacks, per-instance A and bounds"""
+    model = random_tree(seed, nb)
+    link = model.njoints - 1
+    wl = feasible_batch(model, 70, link, seed + 40, nu_scale=0.5, per_instance_A=True, per_instance_bounds=True)
+    for k, tol in [(1, 1e-9), (4, 1e-9)]:
+        prm = dict(FIXTURE, max_iter=k + 1, tol_abs=0.0, tol_rel=0.0, tol_primal_inf=0.0)
+        s = gpu_solve(model, wl, prm)
+        cache = fetch(s)
+        for b in range(0, 70, 9):
+            r = ref.RefSolver(model, **prm)
+            r.Solve(*problem_args(wl, b))
+            assert_close(s.get("liMi")[b], r.liMi[1:], 1e-14, "liMi")
+            compare_instance(s, cache, r, b, tol)
+        s.close()
+    # end to end with stopping logic
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
+    s = gpu_solve(model, wl, prm)
+    out = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"].reshape(70, 1, 6, 6), wl["bis"],
+                          wl["lb"], wl["ub"], nthreads=4, want_nu=True, **prm)
+    it = s.get("iter")
+    same = it == out["iters"]
+    assert same.mean() >= 0.97, (it, out["iters"])
+    assert np.array_equal(s.get("converged").astype(bool)[same], out["converged"][same])
+    assert np.array_equal(s.get("primal_infeasible").astype(bool)[same], out["primal_infeasible"][same])
+    assert np.max(np.abs(s.get("z") - out["z"])[same]) < 1e-9
+    assert np.max(np.abs(s.get("nu") - out["nu"])[same]) < 1e-9
+    s.close()
+
+
+def test_reference_fixture_infeasible_target(talos):
+    """ProblemSetupFixture (tests/loik-loid.cpp:87-165): certificate, tail solve, iteration count, every flag"""
+    for bound, max_iter in [(5.0, 200), (1.0, 200), (2.0, 8), (1.5, 100), (1.0, 2)]:
+        p = fixture_problem(talos, bound=bound)
+        prm = dict(FIXTURE, max_iter=max_iter)
+        wl = dict(p, q=np.tile(p["q"], (3, 1)), bis=np.tile(p["bis"], (3, 1, 1)))
+        s = gpu_solve(talos, wl, prm)
+        r = ref.RefSolver(talos, **prm)
+        r.Solve(*problem_args(p))
+        cache = fetch(s)
+        for b in range(3):
+            assert cache["iter"][b] == r.get_iter()
+            assert bool(cache["converged"][b]) == r.get_convergence_status()
+            assert bool(cache["primal_infeasible"][b]) == r.get_primal_infeasibility_status()
+            compare_instance(s, cache, r, b, 1e-9)
+            assert_close(cache["tol_primal"][b], r.scalar("tol_primal"), 1e-12, "tol_primal")
+            assert_close(cache["tol_dual"][b], r.scalar("tol_dual"), 1e-12, "tol_dual")
+            if r.get_iter() > 1:
+                for g_name, r_name in [("delta_y_qp_inf_norm",) * 2, ("A_qp_T_delta_y_qp_inf_norm",) * 2,
+                                       ("ub_qp_T_delta_y_qp_plus",) * 2, ("lb_qp_T_delta_y_qp_minus",) * 2]:
+                    assert_close(s.get(g_name)[b], r.scalar(r_name), 1e-9, g_name)
+        s.close()
+
+
+def test_split_one_shot_and_repeat_solve_are_identical(talos):
+    """SolveInit + Solve() == Solve(args) (tests/loik-loid.cpp:261-302); repeated Solve() is idempotent (:592-669)"""
+    link = talos.getJointId("arm_left_7_joint")
+    wl = feasible_batch(talos, 130, link, 32, nu_scale=0.5)
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
+    a = gpu_solve(talos, wl, prm)
+    b = loik_amd.BatchedLoik(talos, 130, **prm)
+    b.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    for _ in range(3):
+        b.Solve()
+        for name in ["z", "nu", "w", "vis", "fis", "yis", "iter", "converged", "primal_infeasible", "mu"]:
+            assert np.array_equal(a.get(name), b.get(name)), name
+    a.close(); b.close()
+
+
+def test_h_cache_and_relaunch_are_bit_identical(talos):
+    """(a) re-using H_i/UDinv/Dinv while mu is unchanged and (b) cutting the solve into several kernel launches
+    change nothing: results are bit-identical to recomputing everything every iteration in one launch"""
+    link = talos.getJointId("arm_left_7_joint")
+    wl = feasible_batch(talos, 200, link, 33, nu_scale=0.5)
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
+    base = gpu_solve(talos, wl, prm, flags=capi.OPT_NO_H_CACHE)
+    for kw in [dict(flags=0), dict(flags=0, max_launch_iters=7), dict(flags=capi.OPT_NO_H_CACHE, max_launch_iters=1)]:
+        s = gpu_solve(talos, wl, prm, **kw)
+        for name in ["z", "nu", "w", "vis", "fis", "g", "yis", "iter", "status", "mu", "primal_residual", "dual_residual"]:
+            assert np.array_equal(base.get(name), s.get(name)), (kw, name)
+        s.close()
+    base.close()
+
+
+def test_tailored_warm_started_sequence(talos):
+    """Solve(q,c_id,Ai,bi) with warm_start over a sequence of targets (sampling-planner entry,
+    loik-loid-optimized.hpp:596-695; Reset(warm_start) loik-loid-data-optimized.hxx:117-126)"""
+    link = talos.getJointId("arm_left_7_joint")
+    B, T = 40, 4
+    wls = [feasible_batch(talos, B, link, 50 + t, nu_scale=0.4) for t in range(T)]
+    prm = dict(FIXTURE, max_iter=400, tol_abs=1e-6, tol_rel=0.0, warm_start=True)
+    s = loik_amd.BatchedLoik(talos, B, **prm)
+    s.SolveInit(wls[0]["q"], wls[0]["H_ref"], wls[0]["v_ref"], wls[0]["c_ids"], wls[0]["Ais"], wls[0]["bis"],
+                wls[0]["lb"], wls[0]["ub"])
+    refs = []
+    for b in range(0, B, 7):
+        r = ref.RefSolver(talos, **prm)
+        r.SolveInit(*problem_args(wls[0], b))
+        refs.append((b, r))
+    for t in range(T):
+        s.Solve(wls[t]["q"], link, wls[t]["Ais"], wls[t]["bis"])
+        it, z = s.get("iter"), s.get("z")
+        for b, r in refs:
+            r.Solve(wls[t]["q"][b], link, wls[t]["Ais"][0], wls[t]["bis"][b, 0])
+            assert it[b] == r.get_iter(), (t, b)
+            assert_close(z[b], r.z, 1e-9, "z t%d b%d" % (t, b))
+            assert_close(s.get("w")[b], r.w, 1e-9, "w")
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.Solve(wls[0]["q"], link - 1, wls[0]["Ais"], wls[0]["bis"])
+    assert e.value.code == -4
+    s.close()
+
+
+def test_fixed_iterations_mode_panda(panda7):
+    """BASELINE config 2: Panda-7, B=4096, exactly 50 ADMM iterations, mu frozen, fp64"""
+    wl = workloads.panda_c2(4096)
+    s = loik_amd.BatchedLoik(panda7, 4096, flags=capi.OPT_FIXED_ITERS, **wl["params"])
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    assert np.all(s.get("iter") == 50)
+    assert s.stats()["instance_iterations"] == 50 * 4096
+    z, nu, vis, pres = s.get("z"), s.get("nu"), s.get("vis"), s.get("primal_residual")
+    assert np.all(s.get("mu") == wl["params"]["mu"])  # frozen
+    for b in range(0, 4096, 409):
+        r = ref.RefSolver(panda7, **wl["params"])
+        r.SolveInit(*problem_args(wl, b))
+        for _ in range(50):
+            r.IterationBody()
+        assert_close(z[b], r.z, 1e-9, "z")
+        assert_close(nu[b], r.nu, 1e-9, "nu")
+        assert_close(vis[b], r.vis[1:], 1e-9, "vis")
+        assert_close(pres[b], r.scalar("primal_residual"), 1e-9, "primal_residual")
+    # the task error |A v_c - b| is what the device reports as primal residual (task part)
+    task = np.max(np.abs(vis[:, -1, :] - wl["bis"][:, 0, :]), axis=1)
+    assert np.max(np.abs(task - s.get("primal_residual_task"))) < 1e-12
+    s.close()
+
+
+def test_error_codes_through_the_abi(talos):
+    p = fixture_problem(talos)
+    s = loik_amd.BatchedLoik(talos, 2, **dict(FIXTURE, max_iter=10))
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.Solve()
+    assert e.value.code == -24
+    q2 = np.tile(p["q"], (2, 1)); b2 = np.tile(p["bis"], (2, 1, 1))
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.Solve(q2, p["H_ref"], p["v_ref"], p["c_ids"], p["Ais"], b2, p["lb"][:-1], p["ub"][:-1])
+    assert e.value.code == -3
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.Solve(q2, p["H_ref"], p["v_ref"], [3, 4], np.tile(np.eye(6), (2, 1, 1)), np.zeros((2, 2, 6)), p["lb"], p["ub"])
+    assert e.value.code == -2
+    Hbad = np.eye(6); Hbad[0, 1] = 0.3
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.Solve(q2, Hbad, p["v_ref"], p["c_ids"], p["Ais"], b2, p["lb"], p["ub"])
+    assert e.value.code == -23
+    s.close()
+    s = loik_amd.BatchedLoik(talos, 2, **dict(FIXTURE, max_iter=10, mu_update_strat=1))
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.Solve(q2, p["H_ref"], p["v_ref"], p["c_ids"], p["Ais"], b2, p["lb"], p["ub"])
+    assert e.value.code == -6
+    s.close()
+
+
+def test_ragged_and_tiny_batches(panda9):
+    """batch sizes that do not fill a wavefront, incl. 1 (the reference's single-instance semantics)"""
+    link = panda9.getJointId("panda_joint7")
+    prm = dict(FIXTURE, max_iter=200, tol_abs=1e-6, tol_rel=0.0)
+    for B in (1, 3, 63, 65, 129):
+        wl = feasible_batch(panda9, B, link, 60 + B, nu_scale=0.5)
+        s = gpu_solve(panda9, wl, prm)
+        out = ref.solve_batch(panda9, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"],
+                              wl["ub"], nthreads=2, **prm)
+        assert np.array_equal(s.get("iter"), out["iters"])
+        assert np.max(np.abs(s.get("z") - out["z"])) < 1e-9
+        s.close()
+
+
+def test_full_size_properties_talos_65536():
+    """BASELINE's headline configuration at full size: properties that need no oracle, plus an oracle spot check"""
+    B = 65536
+    wl = workloads.talos_c3(B)
+    m = wl["model"]
+    s = loik_amd.BatchedLoik(m, B, **wl["params"])
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    conv = s.get("converged").astype(bool)
+    z, nu, vis = s.get("z"), s.get("nu"), s.get("vis")
+    link = int(wl["c_ids"][0])
+    assert conv.mean() > 0.8
+    assert np.all(z <= wl["ub"] + 1e-15) and np.all(z >= wl["lb"] - 1e-15)
+    # converged => both residuals below tol, task met, slack closed
+    assert np.all(s.get("primal_residual")[conv] < 1e-6) and np.all(s.get("dual_residual")[conv] < 1e-6)
+    assert np.max(np.abs(vis[conv, link - 1, :] - wl["bis"][conv, 0, :])) < 1e-6
+    assert np.max(np.abs(nu - z)[conv]) < 1e-6
+    # kinematic consistency of the device sweep: v_c = J_c(q) nu (independent numpy propagation)
+    vc = workloads.link_velocity(m, wl["q"], nu, link)
+    assert np.max(np.abs(vc - vis[:, link - 1, :])) < 1e-12
+    # legs carry no task: exactly zero velocity there
+    assert np.max(np.abs(nu[:, :12])) < 1e-12
+    st = s.stats()
+    assert st["instance_iterations"] == int(s.get("iter").sum())
+    # oracle spot check on a strided sample
+    idx = np.arange(0, B, 257)
+    sub = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in wl.items()}
+    out = ref.solve_batch(m, sub["q"], sub["H_ref"], sub["v_ref"], sub["c_ids"], sub["Ais"], sub["bis"], sub["lb"],
+                          sub["ub"], nthreads=8, **wl["params"])
+    same = s.get("iter")[idx] == out["iters"]
+    assert same.mean() > 0.97
+    assert np.max(np.abs(z[idx] - out["z"])[same]) < 1e-9
+    s.close()
+
+
+def test_fp32_path_tracks_fp64(panda7):
+    """BASELINE config 5: no fp32 reference exists upstream (only `double` is instantiated,
+    src/loik-loid-optimized.cpp:10-13) -> measured against the fp64 oracle at a tolerance fp32 can reach"""
+    wl = feasible_batch(panda7, 512, panda7.njoints - 1, 70, nu_scale=0.5)
+    prm = dict(FIXTURE, max_iter=200, tol_abs=1e-3, tol_rel=0.0)
+    s32 = gpu_solve(panda7, wl, prm, precision=capi.F32)
+    s64 = gpu_solve(panda7, wl, prm)
+    c32, c64 = s32.get("converged").astype(bool), s64.get("converged").astype(bool)
+    assert c64.mean() > 0.9 and c32.mean() > 0.85
+    both = c32 & c64
+    assert np.max(np.abs(s32.get("z") - s64.get("z"))[both]) < 5e-3
+    s32.close(); s64.close()

@@ -1,0 +1,194 @@
+"""CPU-only: pins the oracle the way the reference pins its optimized solver -- by cross-implementation agreement
+with the dense-QP "plain" solver at 1e-10 abs-or-rel (/root/reference/tests/loik-loid.cpp:305-556, :559-671,
+:674-865, :868-984) -- plus the split/one-shot and repeat-Solve() relations (:261-302, :592-669).
+
+oracle/loik_ref.c  = restatement of FirstOrderLoikOptimizedTpl (recursive, SE3actOn, running inf-norms)
+oracle/dense.py    = restatement of FirstOrderLoikTpl + IkProblemStandardQPFormulation (action matrices, dense QP)
+The two share no code.
+"""
+import numpy as np
+import pytest
+
+from oracle import dense, ref
+from helpers import (FIXTURE, assert_close, dense_abs_or_rel_equal, fixture_problem, problem_args, random_tree,
+                     scalar_abs_or_rel_equal, feasible_batch)
+
+
+def make_pair(model, max_iter, **over):
+    prm = dict(FIXTURE, max_iter=max_iter)
+    prm.update(over)
+    return ref.RefSolver(model, **prm), dense.DenseSolver(model, **prm)
+
+
+def compare_state(opt, pl, c_ids, tol=1e-10):
+    nj = opt.model.njoints
+    for idx in range(1, nj):
+        assert dense_abs_or_rel_equal(opt.His[idx], pl.His[idx], tol), idx
+        assert dense_abs_or_rel_equal(opt.pis[idx], pl.pis[idx], tol), idx
+        assert dense_abs_or_rel_equal(opt.vis[idx], pl.vis[idx], tol), idx
+        assert dense_abs_or_rel_equal(opt.fis[idx], pl.fis[idx], tol), idx
+    assert dense_abs_or_rel_equal(opt.nu, pl.nu, tol)
+    assert dense_abs_or_rel_equal(opt.z, pl.z, tol)
+    assert dense_abs_or_rel_equal(opt.w, pl.w, tol)
+    for c, c_id in enumerate(c_ids):
+        assert dense_abs_or_rel_equal(opt.yis[c], pl.yis[c_id], tol)
+
+
+def compare_residuals_and_flags(opt, pl, tol=1e-10):
+    assert dense_abs_or_rel_equal(pl.primal_residual_vec, opt.primal_residual_vec, tol)
+    assert scalar_abs_or_rel_equal(pl.primal_residual, opt.scalar("primal_residual"), tol)
+    assert scalar_abs_or_rel_equal(pl.dual_residual, opt.scalar("dual_residual"), tol)
+    assert dense_abs_or_rel_equal(pl.dual_residual_vec, opt.dual_residual_vec, tol)
+    assert scalar_abs_or_rel_equal(pl.get_delta_y_qp_inf_norm(), opt.scalar("delta_y_qp_inf_norm"), tol)
+    assert scalar_abs_or_rel_equal(pl.get_delta_x_qp_inf_norm(), opt.scalar("delta_x_qp_inf_norm"), tol)
+    assert scalar_abs_or_rel_equal(pl.get_delta_z_qp_inf_norm(), opt.scalar("delta_z_qp_inf_norm"), tol)
+    nb, nv = opt.model.njoints - 1, opt.model.nv
+    dy = pl.delta_y_qp
+    assert scalar_abs_or_rel_equal(np.max(np.abs(dy[:6 * nb])), opt.scalar("delta_fis_inf_norm"), tol)
+    assert scalar_abs_or_rel_equal(np.max(np.abs(dy[6 * nb:12 * nb])), opt.scalar("delta_yis_inf_norm"), tol)
+    assert scalar_abs_or_rel_equal(np.max(np.abs(dy[12 * nb:12 * nb + nv])), opt.scalar("delta_w_inf_norm"), tol)
+    assert scalar_abs_or_rel_equal(pl.get_A_qp_T_delta_y_qp_inf_norm(), opt.scalar("A_qp_T_delta_y_qp_inf_norm"), tol)
+    assert scalar_abs_or_rel_equal(pl.get_ub_qp_T_delta_y_qp_plus(), opt.scalar("ub_qp_T_delta_y_qp_plus"), tol)
+    assert scalar_abs_or_rel_equal(pl.get_lb_qp_T_delta_y_qp_minus(), opt.scalar("lb_qp_T_delta_y_qp_minus"), tol)
+
+
+@pytest.mark.parametrize("modelname", ["talos", "panda9"])
+def test_component_wise(modelname, request):
+    """test_1st_order_loik_optimized_correctness_component_wise (max_iter 200, bound 1)"""
+    model = request.getfixturevalue(modelname)
+    p = fixture_problem(model, bound=1.0)
+    opt, pl = make_pair(model, 200)
+    pl.SolveInit(*problem_args(p))
+    opt.SolveInit(*problem_args(p))
+    # FK agreement of the two independent implementations
+    for idx in range(1, model.njoints):
+        R, t = pl.liMi[idx]
+        assert_close(opt.liMi[idx], np.concatenate([R.ravel(), t]), 1e-14, "liMi")
+        R, t = pl.oMi[idx]
+        assert_close(opt.oMi[idx], np.concatenate([R.ravel(), t]), 1e-13, "oMi")
+    # fwd pass 1
+    opt.UpdatePrev(); opt.ResetInfNorms()
+    pl.FwdPass1(); opt.FwdPass1()
+    for idx in range(model.njoints):
+        assert dense_abs_or_rel_equal(opt.His_aba[idx], opt.His[idx])
+        if idx == 0:
+            assert np.allclose(pl.His[0], 0) and np.allclose(opt.His[0], np.eye(6))  # quirk 8
+        else:
+            assert dense_abs_or_rel_equal(opt.His[idx], pl.His[idx])
+        assert dense_abs_or_rel_equal(opt.pis[idx], pl.pis[idx])
+        assert dense_abs_or_rel_equal(opt.pis_aba[idx], opt.pis[idx])
+    for idx in range(1, model.njoints):
+        assert scalar_abs_or_rel_equal(opt.r[model.idx_v[idx]], pl.ris[idx])
+    # bwd pass
+    pl.BwdPass(); opt.BwdPass()
+    for idx in range(1, model.njoints):
+        assert dense_abs_or_rel_equal(opt.His[idx], pl.His[idx])
+        assert dense_abs_or_rel_equal(opt.pis[idx], pl.pis[idx])
+    # fwd pass 2
+    pl.FwdPass2(); opt.FwdPass2()
+    assert dense_abs_or_rel_equal(opt.nu, pl.nu)
+    for idx in range(1, model.njoints):
+        assert dense_abs_or_rel_equal(opt.vis[idx], pl.vis[idx])
+        assert dense_abs_or_rel_equal(opt.fis[idx], pl.fis[idx])
+    pl.BoxProj(); opt.BoxProj()
+    assert dense_abs_or_rel_equal(opt.z, pl.z)
+    pl.DualUpdate(); opt.DualUpdate()
+    assert dense_abs_or_rel_equal(opt.w, pl.w)
+    for c, c_id in enumerate(p["c_ids"]):
+        assert dense_abs_or_rel_equal(opt.yis[c], pl.yis[c_id])
+    pl.UpdateQPADMMSolveLoopUtility(); pl.ComputeResiduals(); opt.ComputeResiduals()
+    pl.CheckConvergence(); opt.CheckConvergence()
+    assert scalar_abs_or_rel_equal(pl.tol_primal, opt.scalar("tol_primal"))
+    assert scalar_abs_or_rel_equal(pl.tol_dual, opt.scalar("tol_dual"))
+    assert pl.tol_primal != 0.0 and pl.tol_dual != 0.0
+    assert pl.converged == opt.get_convergence_status()
+    compare_residuals_and_flags(opt, pl)
+    pl.CheckFeasibility(); opt.CheckFeasibility()
+    assert pl.get_primal_infeasibility_cond_1() == bool(opt.scalar("primal_infeasibility_cond_1"))
+    assert pl.get_primal_infeasibility_cond_2() == bool(opt.scalar("primal_infeasibility_cond_2"))
+    assert pl.primal_infeasible == opt.get_primal_infeasibility_status()
+    assert scalar_abs_or_rel_equal(pl.mu, opt.scalar("mu"), 1e-14)
+    pl.UpdateMu(); opt.UpdateMu()
+    assert scalar_abs_or_rel_equal(pl.mu, opt.scalar("mu"), 1e-14)
+    compare_state(opt, pl, p["c_ids"])
+
+
+@pytest.mark.parametrize("max_iter,bound", [(8, 2.0), (100, 2.0), (200, 5.0)])
+def test_end_to_end_and_repeat_solve(talos, max_iter, bound):
+    """test_1st_order_loik_optimized_correctness / _reset: plain one-shot Solve(args) vs opt SolveInit + repeated
+    Solve(); answers, residuals, flags, mu and iteration count must agree every time"""
+    p = fixture_problem(talos, bound=bound)
+    opt, pl = make_pair(talos, max_iter)
+    pl.Solve(*problem_args(p))
+    opt.SolveInit(*problem_args(p))
+    for _ in range(3):
+        opt.Solve()
+        compare_state(opt, pl, p["c_ids"])
+        compare_residuals_and_flags(opt, pl)
+        assert pl.converged == opt.get_convergence_status()
+        assert pl.primal_infeasible == opt.get_primal_infeasibility_status()
+        assert scalar_abs_or_rel_equal(pl.mu, opt.scalar("mu"))
+        assert pl.get_iter() == opt.get_iter()
+
+
+def test_split_equals_one_shot(talos):
+    """test_loik_solve_split (tests/loik-loid.cpp:261-302)"""
+    p = fixture_problem(talos, bound=5.0)
+    a = ref.RefSolver(talos, **dict(FIXTURE, max_iter=200))
+    b = ref.RefSolver(talos, **dict(FIXTURE, max_iter=200))
+    a.Solve(*problem_args(p))
+    b.SolveInit(*problem_args(p))
+    b.Solve()
+    assert np.array_equal(a.nu, b.nu) and np.array_equal(a.z, b.z) and np.array_equal(a.w, b.w)
+    assert np.array_equal(a.His[1], b.His[1])
+    assert a.get_iter() == b.get_iter()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_trees_feasible_targets(seed):
+    """mixed joint types (incl. unaligned axes / prismatic), random placements, branching: opt == plain on
+    feasible problems that actually iterate (adaptive mu, active limits), at every stopping point"""
+    model = random_tree(seed, nb=12 + 3 * seed)
+    link = model.njoints - 1
+    wl = feasible_batch(model, 4, link, seed, bound=0.5, nu_scale=0.5)
+    for b in range(4):
+        for max_iter in (3, 6, 40):
+            opt, pl = make_pair(model, max_iter, tol_abs=1e-8, tol_rel=0.0)
+            pl.Solve(*problem_args(wl, b))
+            opt.Solve(*problem_args(wl, b))
+            assert pl.get_iter() == opt.get_iter()
+            compare_state(opt, pl, wl["c_ids"], tol=1e-9)
+            assert pl.converged == opt.get_convergence_status()
+            assert pl.primal_infeasible == opt.get_primal_infeasibility_status()
+            assert scalar_abs_or_rel_equal(pl.mu, opt.scalar("mu"))
+
+
+def test_tailored_solve_warm_start(talos):
+    """Solve(q,c_id,Ai,bi) (loik-loid-optimized.hpp:596-695) with warm_start keeps the iterates of the previous
+    call: solving the same target twice must need no more iterations the second time and give the same answer"""
+    link = talos.getJointId("arm_left_7_joint")
+    wl = feasible_batch(talos, 2, link, 5, bound=0.5, nu_scale=0.3)
+    s = ref.RefSolver(talos, **dict(FIXTURE, max_iter=300, tol_abs=1e-7, tol_rel=0.0, warm_start=True, tol_primal_inf=1e-9))
+    s.SolveInit(*problem_args(wl, 0))
+    s.Solve(wl["q"][0], link, wl["Ais"][0], wl["bis"][0, 0])
+    it1, z1 = s.get_iter(), s.z.copy()
+    assert s.get_convergence_status()
+    s.Solve(wl["q"][0], link, wl["Ais"][0], wl["bis"][0, 0])
+    assert s.get_convergence_status() and s.get_iter() <= it1
+    assert np.max(np.abs(s.z - z1)) < 1e-5
+    with pytest.raises(RuntimeError):
+        s.Solve(wl["q"][0], link - 1, wl["Ais"][0], wl["bis"][0, 0])  # no constraint on that link (hpp:184-186)
+
+
+def test_error_sites(talos):
+    p = fixture_problem(talos)
+    with pytest.raises(RuntimeError):
+        ref.RefSolver(talos, **dict(FIXTURE, max_iter=10, eq_c_dim=3))
+    s = ref.RefSolver(talos, **dict(FIXTURE, max_iter=10))
+    with pytest.raises(RuntimeError):  # lb/ub dimension (ik-id-description-optimized.hpp:328-335)
+        s.Solve(p["q"], p["H_ref"], p["v_ref"], p["c_ids"], p["Ais"], p["bis"], p["lb"][:-1], p["ub"][:-1])
+    with pytest.raises(RuntimeError):  # number of constraints (ik-id-description-optimized.hpp:142-145)
+        s.Solve(p["q"], p["H_ref"], p["v_ref"], [1, 2], np.tile(np.eye(6), (2, 1, 1)), np.zeros((2, 6)), p["lb"], p["ub"])
+    s2 = ref.RefSolver(talos, **dict(FIXTURE, max_iter=10, mu_update_strat=1))
+    with pytest.raises(RuntimeError):  # OSQP strategy not implemented (loik-loid-optimized.hxx:632-634)
+        s2.Solve(*problem_args(p))
