@@ -54,8 +54,12 @@ enum { LOIKB_F64 = 0, LOIKB_F32 = 1 };
 /* option flags */
 enum {
   LOIKB_OPT_FIXED_ITERS = 1, /* run exactly max_iter-1 ADMM iterations, mu frozen, no stopping logic       */
-  LOIKB_OPT_NO_H_CACHE = 2   /* recompute H_i/UDinv/Dinv every iteration like upstream (default: reuse them
+  LOIKB_OPT_NO_H_CACHE = 2,  /* recompute H_i/UDinv/Dinv every iteration like upstream (default: reuse them
                                  while mu is unchanged -- bit-identical results, fewer HBM bytes)            */
+  LOIKB_OPT_NO_COMPACTION = 4 /* never repack live instances into dense wavefronts between launches (default:
+                                 repack when at most half of the slots are still iterating; results are
+                                 bit-identical, but the inter-sweep temporaries His/pis/UDinv/Dinv/r of
+                                 instances that moved are not retrievable afterwards)                         */
 };
 
 /* input flags of solve_init / solve_full / solve_tailored */
@@ -85,7 +89,8 @@ typedef struct loikb_options {
   int device;     /* HIP device ordinal                                */
   int precision;  /* LOIKB_F64 (reference arithmetic) | LOIKB_F32      */
   int flags;      /* LOIKB_OPT_*                                       */
-  int max_launch_iters; /* ADMM iterations per kernel launch, 0 = all  */
+  int max_launch_iters; /* ADMM iterations per kernel launch, 0 = automatic                    */
+  int compact_min_instances; /* stop compacting below this many slots, 0 = default (4096)     */
 } loikb_options;
 
 typedef struct loikb_solver loikb_solver;
@@ -167,6 +172,7 @@ typedef struct loikb_stats {
   unsigned long long instance_iterations; /* ADMM iterations summed over instances                */
   int launches;                           /* k_solve launches                                     */
   int n_unfinished;                       /* instances that hit max_iter without stopping         */
+  int compactions;                        /* lane compactions performed                           */
   double kernel_ms;                       /* HIP-event time of the k_solve launches on the stream */
   double total_ms;                        /* HIP-event time of the whole call on the stream       */
   double bytes_per_instance_iteration;    /* algorithmic bytes, SURVEY.md 8(d): s*(203 nb+108 nc) */

@@ -123,6 +123,7 @@ struct Bufs {
   int* status;   // [ld]
   T* scal;       // [NSCAL][ld]
   unsigned int* counters;  // [0] live instances at exit, [1] instance-iterations executed
+  int* wave_live;          // [ld/64] live lanes of each wavefront at exit (feeds the host-side compaction scan)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -852,6 +853,7 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
   for (int off = 32; off > 0; off >>= 1) it_sum += __shfl_down(it_sum, off);
   if (lane == 0) {
     const unsigned int nlive = __popcll(live_mask);
+    Bf.wave_live[blockIdx.x] = (int)nlive;
     if (nlive) atomicAdd(&Bf.counters[0], nlive);
     if (it_sum) atomicAdd(&Bf.counters[1], it_sum);
   }
@@ -948,6 +950,63 @@ __global__ void k_fill_int(int* __restrict__ p, size_t n, int val)
 {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = val;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lane compaction: physical repack of the live instances of one buffer set into the first slots of another
+// (dense wavefronts again), and return of the finished ones to their home slot.  One source wavefront per
+// workgroup; `wave_off[w]` = exclusive prefix sum of the live-lane counts (host-side scan of `wave_live`).
+// A field is a run of `rows` SoA rows of `esz`-byte elements.
+// ------------------------------------------------------------------------------------------------
+struct MoveField {
+  const void* src;
+  void* dst_live;   // destination set (compacted slots)
+  void* dst_home;   // home set (slot = instance id), or nullptr when the source IS the home set
+  int rows;
+  int esz;          // 4 or 8
+};
+constexpr int MAX_MOVE_FIELDS = 32;
+struct MovePlan {
+  MoveField f[MAX_MOVE_FIELDS];
+  int nfields;
+  int n_src;        // slots in use in the source set
+  int ld_src, ld_dst, ld_home;
+  const int* status;     // source status
+  const int* map_src;    // slot -> instance id in the source set (nullptr: identity, source is home)
+  int* map_dst;          // slot -> instance id in the destination set
+  const int* wave_off;   // [n_src/64]
+  int force_home;        // 1: every slot of the source set goes home (end of the solve)
+};
+
+__global__ void __launch_bounds__(WAVE) k_move(const MovePlan P)
+{
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * WAVE + lane;
+  const bool inb = b < P.n_src;
+  const bool live = inb && !P.force_home && !(P.status[inb ? b : 0] & ST_DONE);
+  const unsigned long long mask = __ballot(live);
+  const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+  const int inst = inb ? (P.map_src ? P.map_src[b] : b) : 0;
+  const int dst = P.wave_off[blockIdx.x] + rank;
+  const bool to_home = inb && !live && P.map_src != nullptr;
+  if (live) P.map_dst[dst] = inst;
+  if (!live && !to_home) return;
+  for (int k = 0; k < P.nfields; ++k) {
+    const MoveField F = P.f[k];
+    if (F.esz == 8) {
+      const unsigned long long* s = (const unsigned long long*)F.src;
+      unsigned long long* d = live ? (unsigned long long*)F.dst_live : (unsigned long long*)F.dst_home;
+      const size_t ldd = live ? P.ld_dst : P.ld_home;
+      const size_t slot = live ? dst : inst;
+      for (int r = 0; r < F.rows; ++r) d[(size_t)r * ldd + slot] = s[(size_t)r * P.ld_src + b];
+    } else {
+      const unsigned int* s = (const unsigned int*)F.src;
+      unsigned int* d = live ? (unsigned int*)F.dst_live : (unsigned int*)F.dst_home;
+      const size_t ldd = live ? P.ld_dst : P.ld_home;
+      const size_t slot = live ? dst : inst;
+      for (int r = 0; r < F.rows; ++r) d[(size_t)r * ldd + slot] = s[(size_t)r * P.ld_src + b];
+    }
+  }
 }
 
 }  // namespace loikb

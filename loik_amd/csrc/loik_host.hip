@@ -70,12 +70,18 @@ struct loikb_solver_impl {
   unsigned int* h_counters = nullptr;  // pinned
   void* d_stage = nullptr;             // staging for host<->device transposes (doubles)
   size_t stage_bytes = 0;
-  // SoA fields (void*, cast by precision)
-  void *cs = nullptr, *v = nullptr, *f = nullptr, *g = nullptr, *nu = nullptr, *z = nullptr, *w = nullptr,
-       *s = nullptr, *y = nullptr, *aty = nullptr, *H = nullptr, *p = nullptr, *ud = nullptr, *dinv = nullptr,
-       *rr = nullptr, *A = nullptr, *AtA = nullptr, *b = nullptr, *Atb = nullptr, *lb = nullptr, *ub = nullptr,
-       *bnorm = nullptr, *mu = nullptr, *mu_h = nullptr, *scal = nullptr;
-  int *iter = nullptr, *status = nullptr;
+  // per-instance SoA arrays live in buffer sets: set 0 = home (slot == instance id, capacity ld);
+  // sets 1,2 = compaction work sets (capacity ld/2), allocated on first use
+  struct Set {
+    int ld = 0;
+    bool allocated = false;
+    void *cs = nullptr, *v = nullptr, *f = nullptr, *g = nullptr, *nu = nullptr, *z = nullptr, *w = nullptr,
+         *s = nullptr, *y = nullptr, *aty = nullptr, *H = nullptr, *p = nullptr, *ud = nullptr, *dinv = nullptr,
+         *rr = nullptr, *A = nullptr, *AtA = nullptr, *b = nullptr, *Atb = nullptr, *lb = nullptr, *ub = nullptr,
+         *bnorm = nullptr, *mu = nullptr, *mu_h = nullptr, *scal = nullptr;
+    int *iter = nullptr, *status = nullptr, *map = nullptr, *wave_live = nullptr, *wave_off = nullptr;
+  } set[3];
+  std::vector<int> h_wave;  // host scratch for the compaction scan
   // stats of the last solve
   loikb_stats stats{};
 };
@@ -98,6 +104,30 @@ int ensure_stage(loikb_solver_impl* S, size_t bytes)
   S->stage_bytes = 0;
   HIPCHK(hipMalloc(&S->d_stage, bytes));
   S->stage_bytes = bytes;
+  return LOIKB_OK;
+}
+
+// allocate every per-instance array of buffer set k with capacity `ld` slots
+int alloc_set(loikb_solver_impl* S, int k, int ld_)
+{
+  loikb_solver_impl::Set& W = S->set[k];
+  if (W.allocated) return LOIKB_OK;
+  const size_t ld = ld_, e = S->esz, nb = S->nb, nc = S->nc > 0 ? S->nc : 1;
+  W.ld = ld_;
+  int rc;
+#define A_(field, n) if ((rc = alloc_dev(S, &W.field, (size_t)(n) * ld * e))) return rc
+  A_(cs, 2 * nb); A_(v, 6 * nb); A_(f, 6 * nb); A_(g, 6 * nb); A_(nu, nb); A_(z, nb); A_(w, nb); A_(s, nb);
+  A_(y, 6 * nc); A_(aty, 6 * nc); A_(H, 21 * nb); A_(p, 6 * nb); A_(ud, 6 * nb); A_(dinv, nb); A_(rr, nb);
+  A_(A, 36 * nc); A_(AtA, 21 * nc); A_(b, 6 * nc); A_(Atb, 6 * nc); A_(lb, nb); A_(ub, nb); A_(bnorm, 1);
+  A_(mu, 1); A_(mu_h, 1); A_(scal, NSCAL);
+#undef A_
+  void* tmp = nullptr;
+  if ((rc = alloc_dev(S, &tmp, sizeof(int) * ld))) return rc; W.iter = (int*)tmp;
+  if ((rc = alloc_dev(S, &tmp, sizeof(int) * ld))) return rc; W.status = (int*)tmp;
+  if ((rc = alloc_dev(S, &tmp, sizeof(int) * ld))) return rc; W.map = (int*)tmp;
+  if ((rc = alloc_dev(S, &tmp, sizeof(int) * (ld / WAVE + 1)))) return rc; W.wave_live = (int*)tmp;
+  if ((rc = alloc_dev(S, &tmp, sizeof(int) * (ld / WAVE + 1)))) return rc; W.wave_off = (int*)tmp;
+  W.allocated = true;
   return LOIKB_OK;
 }
 
@@ -183,15 +213,20 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
 }
 
 template <typename T>
-Bufs<T> make_bufs(loikb_solver_impl* S)
+Bufs<T> make_bufs(loikb_solver_impl* S, int k = 0)
 {
+  const loikb_solver_impl::Set& W = S->set[k];
+  const loikb_solver_impl::Set& H0 = S->set[0];
   Bufs<T> Bf{};
-  Bf.cs = (const T*)S->cs; Bf.v = (T*)S->v; Bf.f = (T*)S->f; Bf.g = (T*)S->g; Bf.nu = (T*)S->nu; Bf.z = (T*)S->z;
-  Bf.w = (T*)S->w; Bf.s = (T*)S->s; Bf.y = (T*)S->y; Bf.aty = (T*)S->aty; Bf.H = (T*)S->H; Bf.p = (T*)S->p;
-  Bf.ud = (T*)S->ud; Bf.dinv = (T*)S->dinv; Bf.rr = (T*)S->rr; Bf.A = (const T*)S->A; Bf.AtA = (const T*)S->AtA;
-  Bf.b = (const T*)S->b; Bf.Atb = (const T*)S->Atb; Bf.lb = (const T*)S->lb; Bf.ub = (const T*)S->ub;
-  Bf.bnorm = (const T*)S->bnorm; Bf.mu = (T*)S->mu; Bf.mu_h = (T*)S->mu_h; Bf.iter = S->iter; Bf.status = S->status;
-  Bf.scal = (T*)S->scal; Bf.counters = S->d_counters;
+  Bf.cs = (const T*)W.cs; Bf.v = (T*)W.v; Bf.f = (T*)W.f; Bf.g = (T*)W.g; Bf.nu = (T*)W.nu; Bf.z = (T*)W.z;
+  Bf.w = (T*)W.w; Bf.s = (T*)W.s; Bf.y = (T*)W.y; Bf.aty = (T*)W.aty; Bf.H = (T*)W.H; Bf.p = (T*)W.p;
+  Bf.ud = (T*)W.ud; Bf.dinv = (T*)W.dinv; Bf.rr = (T*)W.rr;
+  // shared inputs exist once (in the home set); per-instance inputs travel with the instance
+  Bf.A = (const T*)(S->a_shared ? H0.A : W.A); Bf.AtA = (const T*)(S->a_shared ? H0.AtA : W.AtA);
+  Bf.b = (const T*)W.b; Bf.Atb = (const T*)W.Atb;
+  Bf.lb = (const T*)(S->bnd_shared ? H0.lb : W.lb); Bf.ub = (const T*)(S->bnd_shared ? H0.ub : W.ub);
+  Bf.bnorm = (const T*)W.bnorm; Bf.mu = (T*)W.mu; Bf.mu_h = (T*)W.mu_h; Bf.iter = W.iter; Bf.status = W.status;
+  Bf.scal = (T*)W.scal; Bf.counters = S->d_counters; Bf.wave_live = W.wave_live;
   return Bf;
 }
 
@@ -238,12 +273,12 @@ int data_reset(loikb_solver_impl* S, bool warm_start)
 {
   if (warm_start) return LOIKB_OK;
   int rc;
-  if ((rc = zero_field(S, S->w, S->nb))) return rc;
-  if ((rc = zero_field(S, S->z, S->nb))) return rc;
-  if ((rc = zero_field(S, S->nu, S->nb))) return rc;
-  if ((rc = zero_field(S, S->v, 6 * (size_t)S->nb))) return rc;
-  if ((rc = zero_field(S, S->f, 6 * (size_t)S->nb))) return rc;
-  if ((rc = zero_field(S, S->g, 6 * (size_t)S->nb))) return rc;
+  if ((rc = zero_field(S, S->set[0].w, S->nb))) return rc;
+  if ((rc = zero_field(S, S->set[0].z, S->nb))) return rc;
+  if ((rc = zero_field(S, S->set[0].nu, S->nb))) return rc;
+  if ((rc = zero_field(S, S->set[0].v, 6 * (size_t)S->nb))) return rc;
+  if ((rc = zero_field(S, S->set[0].f, 6 * (size_t)S->nb))) return rc;
+  if ((rc = zero_field(S, S->set[0].g, 6 * (size_t)S->nb))) return rc;
   return LOIKB_OK;
 }
 
@@ -251,13 +286,13 @@ int data_reset(loikb_solver_impl* S, bool warm_start)
 int data_reset_recursion(loikb_solver_impl* S)
 {
   int rc;
-  if ((rc = zero_field(S, S->w, S->nb))) return rc;
-  if ((rc = zero_field(S, S->z, S->nb))) return rc;
-  if ((rc = zero_field(S, S->v, 6 * (size_t)S->nb))) return rc;
-  if ((rc = zero_field(S, S->f, 6 * (size_t)S->nb))) return rc;
-  if ((rc = zero_field(S, S->g, 6 * (size_t)S->nb))) return rc;
-  if ((rc = zero_field(S, S->y, 6 * (size_t)S->nc))) return rc;
-  if ((rc = zero_field(S, S->aty, 6 * (size_t)S->nc))) return rc;
+  if ((rc = zero_field(S, S->set[0].w, S->nb))) return rc;
+  if ((rc = zero_field(S, S->set[0].z, S->nb))) return rc;
+  if ((rc = zero_field(S, S->set[0].v, 6 * (size_t)S->nb))) return rc;
+  if ((rc = zero_field(S, S->set[0].f, 6 * (size_t)S->nb))) return rc;
+  if ((rc = zero_field(S, S->set[0].g, 6 * (size_t)S->nb))) return rc;
+  if ((rc = zero_field(S, S->set[0].y, 6 * (size_t)S->nc))) return rc;
+  if ((rc = zero_field(S, S->set[0].aty, 6 * (size_t)S->nc))) return rc;
   return LOIKB_OK;
 }
 
@@ -265,18 +300,18 @@ int data_reset_recursion(loikb_solver_impl* S)
 int reset_solver(loikb_solver_impl* S)
 {
   int rc;
-  HIPCHK(hipMemsetAsync(S->iter, 0, sizeof(int) * (size_t)S->ld, S->stream));
-  HIPCHK(hipMemsetAsync(S->status, 0, sizeof(int) * (size_t)S->ld, S->stream));
-  if ((rc = zero_field(S, S->scal, NSCAL))) return rc;
-  if (S->f32) rc = fill_field<float>(S, S->mu, S->ld, S->opt.mu);
-  else rc = fill_field<double>(S, S->mu, S->ld, S->opt.mu);
+  HIPCHK(hipMemsetAsync(S->set[0].iter, 0, sizeof(int) * (size_t)S->ld, S->stream));
+  HIPCHK(hipMemsetAsync(S->set[0].status, 0, sizeof(int) * (size_t)S->ld, S->stream));
+  if ((rc = zero_field(S, S->set[0].scal, NSCAL))) return rc;
+  if (S->f32) rc = fill_field<float>(S, S->set[0].mu, S->ld, S->opt.mu);
+  else rc = fill_field<double>(S, S->set[0].mu, S->ld, S->opt.mu);
   return rc;
 }
 
 int invalidate_h_cache(loikb_solver_impl* S)
 {
-  if (S->f32) return fill_field<float>(S, S->mu_h, S->ld, -1.0);
-  return fill_field<double>(S, S->mu_h, S->ld, -1.0);
+  if (S->f32) return fill_field<float>(S, S->set[0].mu_h, S->ld, -1.0);
+  return fill_field<double>(S, S->set[0].mu_h, S->ld, -1.0);
 }
 
 // bring a per-instance instance-major double array [B][n] (host or device) into SoA [n][ld] of T
@@ -345,10 +380,10 @@ int fwd_pass_init(loikb_solver_impl* S, const double* q, int in_flags)
   }
   if (S->f32)
     hipLaunchKernelGGL(k_fk_init<float>, grid1(S->B), dim3(256), 0, S->stream, dq, S->nq, S->d_jd, S->d_idx_q, S->nb,
-                       S->B, S->ld, (float*)S->cs);
+                       S->B, S->ld, (float*)S->set[0].cs);
   else
     hipLaunchKernelGGL(k_fk_init<double>, grid1(S->B), dim3(256), 0, S->stream, dq, S->nq, S->d_jd, S->d_idx_q, S->nb,
-                       S->B, S->ld, (double*)S->cs);
+                       S->B, S->ld, (double*)S->set[0].cs);
   HIPCHK(hipGetLastError());
   if (dq == S->d_stage) HIPCHK(hipStreamSynchronize(S->stream));
   // H/UDinv/Dinv cache depends on liMi
@@ -356,8 +391,8 @@ int fwd_pass_init(loikb_solver_impl* S, const double* q, int in_flags)
   if (rc) return rc;
   // cold start: yis = 0, Aty = 0 (hxx:270-278)
   if (!S->opt.warm_start) {
-    if ((rc = zero_field(S, S->y, 6 * (size_t)S->nc))) return rc;
-    if ((rc = zero_field(S, S->aty, 6 * (size_t)S->nc))) return rc;
+    if ((rc = zero_field(S, S->set[0].y, 6 * (size_t)S->nc))) return rc;
+    if ((rc = zero_field(S, S->set[0].aty, 6 * (size_t)S->nc))) return rc;
   }
   return LOIKB_OK;
 }
@@ -372,13 +407,13 @@ int upload_jd(loikb_solver_impl* S)
 int constraint_products(loikb_solver_impl* S, int c_lo, int c_hi, bool grow_only)
 {
   if (S->f32)
-    hipLaunchKernelGGL(k_constraint_products<float>, grid1(S->B), dim3(256), 0, S->stream, (const float*)S->A,
-                       (const float*)S->b, S->nc, c_lo, c_hi, (int)S->a_shared, S->B, S->ld, (float*)S->AtA,
-                       (float*)S->Atb, (float*)S->bnorm, (int)grow_only);
+    hipLaunchKernelGGL(k_constraint_products<float>, grid1(S->B), dim3(256), 0, S->stream, (const float*)S->set[0].A,
+                       (const float*)S->set[0].b, S->nc, c_lo, c_hi, (int)S->a_shared, S->B, S->ld, (float*)S->set[0].AtA,
+                       (float*)S->set[0].Atb, (float*)S->set[0].bnorm, (int)grow_only);
   else
-    hipLaunchKernelGGL(k_constraint_products<double>, grid1(S->B), dim3(256), 0, S->stream, (const double*)S->A,
-                       (const double*)S->b, S->nc, c_lo, c_hi, (int)S->a_shared, S->B, S->ld, (double*)S->AtA,
-                       (double*)S->Atb, (double*)S->bnorm, (int)grow_only);
+    hipLaunchKernelGGL(k_constraint_products<double>, grid1(S->B), dim3(256), 0, S->stream, (const double*)S->set[0].A,
+                       (const double*)S->set[0].b, S->nc, c_lo, c_hi, (int)S->a_shared, S->B, S->ld, (double*)S->set[0].AtA,
+                       (double*)S->set[0].Atb, (double*)S->set[0].bnorm, (int)grow_only);
   HIPCHK(hipGetLastError());
   return LOIKB_OK;
 }
@@ -396,10 +431,10 @@ int upload_shared_AtA(loikb_solver_impl* S, const double* A, int c)
   if (S->f32) {
     float tmp[21];
     for (int k = 0; k < 21; ++k) tmp[k] = (float)AtA[k];
-    HIPCHK(hipMemcpyAsync((float*)S->AtA + 21 * c, tmp, sizeof(tmp), hipMemcpyHostToDevice, S->stream));
+    HIPCHK(hipMemcpyAsync((float*)S->set[0].AtA + 21 * c, tmp, sizeof(tmp), hipMemcpyHostToDevice, S->stream));
     HIPCHK(hipStreamSynchronize(S->stream));
   } else {
-    HIPCHK(hipMemcpyAsync((double*)S->AtA + 21 * c, AtA, sizeof(AtA), hipMemcpyHostToDevice, S->stream));
+    HIPCHK(hipMemcpyAsync((double*)S->set[0].AtA + 21 * c, AtA, sizeof(AtA), hipMemcpyHostToDevice, S->stream));
     HIPCHK(hipStreamSynchronize(S->stream));
   }
   return LOIKB_OK;
@@ -437,23 +472,84 @@ int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, 
   // UpdateIneqConstraints
   S->bnd_shared = in_flags & LOIKB_BOUNDS_SHARED;
   int rc;
-  if ((rc = upload_aos(S, lb, S->nv, S->lb, dev && !S->bnd_shared, S->bnd_shared))) return rc;
-  if ((rc = upload_aos(S, ub, S->nv, S->ub, dev && !S->bnd_shared, S->bnd_shared))) return rc;
+  if ((rc = upload_aos(S, lb, S->nv, S->set[0].lb, dev && !S->bnd_shared, S->bnd_shared))) return rc;
+  if ((rc = upload_aos(S, ub, S->nv, S->set[0].ub, dev && !S->bnd_shared, S->bnd_shared))) return rc;
   // UpdateEqConstraints
   S->active_ids.assign(c_ids, c_ids + nc);
   for (int i = 1; i < S->nj; ++i) S->jd[i].cslot = -1;
   for (int c = 0; c < nc; ++c) S->jd[c_ids[c]].cslot = c;
   if ((rc = upload_jd(S))) return rc;
   S->a_shared = in_flags & LOIKB_A_SHARED;
-  if ((rc = upload_aos(S, Ais, 36 * nc, S->A, dev && !S->a_shared, S->a_shared))) return rc;
+  if ((rc = upload_aos(S, Ais, 36 * nc, S->set[0].A, dev && !S->a_shared, S->a_shared))) return rc;
   if (S->a_shared)
     for (int c = 0; c < nc; ++c)
       if ((rc = upload_shared_AtA(S, Ais + 36 * c, c))) return rc;
-  if (in_flags & LOIKB_B_SHARED) rc = upload_broadcast(S, bis, 6 * nc, S->b);
-  else rc = upload_aos(S, bis, 6 * nc, S->b, dev, false);
+  if (in_flags & LOIKB_B_SHARED) rc = upload_broadcast(S, bis, 6 * nc, S->set[0].b);
+  else rc = upload_aos(S, bis, 6 * nc, S->set[0].b, dev, false);
   if (rc) return rc;
   if ((rc = constraint_products(S, 0, nc, false))) return rc;
   S->have_problem = true;
+  return LOIKB_OK;
+}
+
+// list of the per-instance arrays that travel with an instance when it changes buffer set.  Inter-sweep
+// temporaries (H, p, UDinv, Dinv, r) stay behind: they are rebuilt by the first sweep after the move (mu_h = -1).
+template <typename T>
+void fill_move_plan(loikb_solver_impl* S, int src, int dst, MovePlan& M)
+{
+  const loikb_solver_impl::Set &A = S->set[src], &D = S->set[dst], &H0 = S->set[0];
+  const int nb = S->nb, nc = S->nc, e = (int)sizeof(T);
+  int k = 0;
+  auto add = [&](const void* s, void* dl, void* dh, int rows, int esz) {
+    M.f[k].src = s; M.f[k].dst_live = dl; M.f[k].dst_home = src == 0 ? nullptr : dh; M.f[k].rows = rows; M.f[k].esz = esz;
+    ++k;
+  };
+  add(A.cs, D.cs, H0.cs, 2 * nb, e); add(A.v, D.v, H0.v, 6 * nb, e); add(A.f, D.f, H0.f, 6 * nb, e);
+  add(A.g, D.g, H0.g, 6 * nb, e); add(A.nu, D.nu, H0.nu, nb, e); add(A.z, D.z, H0.z, nb, e);
+  add(A.w, D.w, H0.w, nb, e); add(A.s, D.s, H0.s, nb, e); add(A.y, D.y, H0.y, 6 * nc, e);
+  add(A.aty, D.aty, H0.aty, 6 * nc, e); add(A.b, D.b, H0.b, 6 * nc, e); add(A.Atb, D.Atb, H0.Atb, 6 * nc, e);
+  add(A.bnorm, D.bnorm, H0.bnorm, 1, e); add(A.mu, D.mu, H0.mu, 1, e); add(A.scal, D.scal, H0.scal, NSCAL, e);
+  add(A.iter, D.iter, H0.iter, 1, 4); add(A.status, D.status, H0.status, 1, 4);
+  if (!S->a_shared) { add(A.A, D.A, H0.A, 36 * nc, e); add(A.AtA, D.AtA, H0.AtA, 21 * nc, e); }
+  if (!S->bnd_shared) { add(A.lb, D.lb, H0.lb, nb, e); add(A.ub, D.ub, H0.ub, nb, e); }
+  M.nfields = k;
+  M.ld_src = A.ld; M.ld_dst = D.ld; M.ld_home = H0.ld;
+  M.status = A.status;
+  M.map_src = src == 0 ? nullptr : A.map;
+  M.map_dst = D.map;
+  M.wave_off = A.wave_off;
+  M.force_home = 0;
+}
+
+// move the live instances of set `src` (n_src slots) to the first slots of set `dst`; finished ones go home
+template <typename T>
+int compact(loikb_solver_impl* S, int src, int dst, int n_src, int* n_dst_out)
+{
+  loikb_solver_impl::Set& A = S->set[src];
+  const int nw = (n_src + WAVE - 1) / WAVE;
+  int rc;
+  if (dst >= 0 && (rc = alloc_set(S, dst, ((S->ld / 2 + WAVE - 1) / WAVE) * WAVE))) return rc;
+  // exclusive scan of the per-wavefront live counts on the host (nw <= B/64 ints)
+  S->h_wave.resize(2 * (size_t)nw + 2);
+  int* cnt = S->h_wave.data();
+  int* off = cnt + nw + 1;
+  HIPCHK(hipMemcpyAsync(cnt, A.wave_live, sizeof(int) * nw, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  int total = 0;
+  for (int w = 0; w < nw; ++w) { off[w] = total; total += dst >= 0 ? cnt[w] : 0; }
+  HIPCHK(hipMemcpyAsync(A.wave_off, off, sizeof(int) * nw, hipMemcpyHostToDevice, S->stream));
+  MovePlan M{};
+  fill_move_plan<T>(S, src, dst >= 0 ? dst : 0, M);
+  M.n_src = n_src;
+  M.force_home = dst < 0;
+  hipLaunchKernelGGL(k_move, dim3(nw), dim3(WAVE), 0, S->stream, M);
+  HIPCHK(hipGetLastError());
+  if (dst >= 0) {
+    // the H/UDinv/Dinv cache did not travel
+    if ((rc = fill_field<T>(S, S->set[dst].mu_h, total, -1.0))) return rc;
+  }
+  HIPCHK(hipStreamSynchronize(S->stream));  // h_wave is reused
+  if (n_dst_out) *n_dst_out = total;
   return LOIKB_OK;
 }
 
@@ -461,18 +557,30 @@ template <typename T>
 int run_main_loop_t(loikb_solver_impl* S)
 {
   Params<T> P = make_params<T>(S);
-  Bufs<T> Bf = make_bufs<T>(S);
   const size_t lds = (size_t)(S->stack_levels > 0 ? S->stack_levels : 1) * 27 * WAVE * sizeof(T);
-  const dim3 grid((unsigned)((S->B + WAVE - 1) / WAVE)), block(WAVE);
   S->stats = loikb_stats{};
   S->stats.bytes_per_instance_iteration = (double)sizeof(T) * (203.0 * S->nb + 108.0 * S->nc);
   double kernel_ms = 0.0;
   HIPCHK(hipEventRecord(S->ev_t0, S->stream));
   // main-loop bound: at most max_iter-1 iterations, tail solve may reach max_iter (hpp:377, :276)
   const int max_total = S->opt.max_iter + 1;
+  const bool can_compact = !(S->opt.flags & LOIKB_OPT_NO_COMPACTION) && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS);
+  // compaction pays only while the launch is bandwidth-bound (many wavefronts); below ~COMPACT_MIN_WAVES
+  // wavefronts an ADMM iteration costs the same single-wavefront latency however few lanes are live
+  const int compact_min = S->opt.compact_min_instances > 0 ? S->opt.compact_min_instances : 64 * WAVE;
+  int cur = 0, n_cur = S->B;
   int done_iters = 0;
   unsigned long long inst_iters = 0;
+  unsigned int n_live = 0;
   while (true) {
+    const bool may_compact_later = can_compact && n_cur > compact_min;
+    int launch_iters = S->opt.max_launch_iters > 0 ? S->opt.max_launch_iters : (may_compact_later ? 8 : max_total);
+    if (launch_iters > max_total - done_iters) launch_iters = max_total - done_iters;
+    P.B = n_cur;
+    P.ld = S->set[cur].ld;
+    P.max_launch_iters = launch_iters;
+    Bufs<T> Bf = make_bufs<T>(S, cur);
+    const dim3 grid((unsigned)((n_cur + WAVE - 1) / WAVE)), block(WAVE);
     HIPCHK(hipMemsetAsync(S->d_counters, 0, 2 * sizeof(unsigned int), S->stream));
     HIPCHK(hipEventRecord(S->ev_k0, S->stream));
     hipLaunchKernelGGL(k_solve<T>, grid, block, lds, S->stream, P, Bf, (const JointDesc*)S->d_jd);
@@ -485,15 +593,29 @@ int run_main_loop_t(loikb_solver_impl* S)
     kernel_ms += ms;
     S->stats.launches++;
     inst_iters += S->h_counters[1];
-    done_iters += P.max_launch_iters;
-    if (S->h_counters[0] == 0 || done_iters >= max_total) break;
+    n_live = S->h_counters[0];
+    done_iters += launch_iters;
+    if (n_live == 0 || done_iters >= max_total) break;
+    if (may_compact_later && 2 * (long long)n_live <= n_cur) {
+      const int dst = cur == 1 ? 2 : 1;
+      int n_new = 0;
+      int rc = compact<T>(S, cur, dst, n_cur, &n_new);
+      if (rc) return rc;
+      cur = dst;
+      n_cur = n_new;
+      S->stats.compactions++;
+    }
+  }
+  if (cur != 0) {
+    int rc = compact<T>(S, cur, -1, n_cur, nullptr);  // everything that is still in a work set goes home
+    if (rc) return rc;
   }
   HIPCHK(hipEventRecord(S->ev_t1, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
   float tms = 0.f;
   HIPCHK(hipEventElapsedTime(&tms, S->ev_t0, S->ev_t1));
   S->stats.instance_iterations = inst_iters;
-  S->stats.n_unfinished = (int)S->h_counters[0];
+  S->stats.n_unfinished = (int)n_live;
   S->stats.kernel_ms = kernel_ms;
   S->stats.total_ms = tms;
   return LOIKB_OK;
@@ -605,38 +727,11 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
   HIPTRY(hipEventCreate(&S->ev_t0));
   HIPTRY(hipEventCreate(&S->ev_t1));
   HIPTRY(hipHostMalloc((void**)&S->h_counters, 2 * sizeof(unsigned int)));
-  const size_t ld = S->ld, e = S->esz, nb = S->nb, nc = S->nc > 0 ? S->nc : 1;
   void* tmp = nullptr;
   TRY(alloc_dev(S, &tmp, sizeof(JointDesc) * S->nj)); S->d_jd = (JointDesc*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * S->nj)); S->d_idx_q = (int*)tmp;
   TRY(alloc_dev(S, &tmp, 2 * sizeof(unsigned int))); S->d_counters = (unsigned int*)tmp;
-  TRY(alloc_dev(S, &S->cs, 2 * nb * ld * e));
-  TRY(alloc_dev(S, &S->v, 6 * nb * ld * e));
-  TRY(alloc_dev(S, &S->f, 6 * nb * ld * e));
-  TRY(alloc_dev(S, &S->g, 6 * nb * ld * e));
-  TRY(alloc_dev(S, &S->nu, nb * ld * e));
-  TRY(alloc_dev(S, &S->z, nb * ld * e));
-  TRY(alloc_dev(S, &S->w, nb * ld * e));
-  TRY(alloc_dev(S, &S->s, nb * ld * e));
-  TRY(alloc_dev(S, &S->y, 6 * nc * ld * e));
-  TRY(alloc_dev(S, &S->aty, 6 * nc * ld * e));
-  TRY(alloc_dev(S, &S->H, 21 * nb * ld * e));
-  TRY(alloc_dev(S, &S->p, 6 * nb * ld * e));
-  TRY(alloc_dev(S, &S->ud, 6 * nb * ld * e));
-  TRY(alloc_dev(S, &S->dinv, nb * ld * e));
-  TRY(alloc_dev(S, &S->rr, nb * ld * e));
-  TRY(alloc_dev(S, &S->A, 36 * nc * ld * e));
-  TRY(alloc_dev(S, &S->AtA, 21 * nc * ld * e));
-  TRY(alloc_dev(S, &S->b, 6 * nc * ld * e));
-  TRY(alloc_dev(S, &S->Atb, 6 * nc * ld * e));
-  TRY(alloc_dev(S, &S->lb, nb * ld * e));
-  TRY(alloc_dev(S, &S->ub, nb * ld * e));
-  TRY(alloc_dev(S, &S->bnorm, ld * e));
-  TRY(alloc_dev(S, &S->mu, ld * e));
-  TRY(alloc_dev(S, &S->mu_h, ld * e));
-  TRY(alloc_dev(S, &S->scal, (size_t)NSCAL * ld * e));
-  TRY(alloc_dev(S, &tmp, sizeof(int) * ld)); S->iter = (int*)tmp;
-  TRY(alloc_dev(S, &tmp, sizeof(int) * ld)); S->status = (int*)tmp;
+  TRY(alloc_set(S, 0, S->ld));
   HIPTRY(hipMemcpyAsync(S->d_idx_q, S->idx_q.data(), sizeof(int) * S->nj, hipMemcpyHostToDevice, S->stream));
   TRY(upload_jd(S));
   TRY(reset_solver(S));
@@ -727,10 +822,10 @@ int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const doubl
     return LOIKB_ERR_ARG;
   }
   const size_t ld = S->ld, e = S->esz;
-  void* Adst = (char*)S->A + (a_shared_in ? (size_t)36 * found * e : (size_t)36 * found * ld * e);
+  void* Adst = (char*)S->set[0].A + (a_shared_in ? (size_t)36 * found * e : (size_t)36 * found * ld * e);
   if ((rc = upload_aos(S, Ai, 36, Adst, dev && !a_shared_in, a_shared_in))) return rc;
   if (a_shared_in && (rc = upload_shared_AtA(S, Ai, found))) return rc;
-  void* bdst = (char*)S->b + (size_t)6 * found * ld * e;
+  void* bdst = (char*)S->set[0].b + (size_t)6 * found * ld * e;
   if (in_flags & LOIKB_B_SHARED) rc = upload_broadcast(S, bi, 6, bdst);
   else rc = upload_aos(S, bi, 6, bdst, dev, false);
   if (rc) return rc;
@@ -778,31 +873,31 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   bool is_int = false;
   int mask = 0;
   switch (field) {
-  case LOIKB_F_Z: src = S->z; n = S->nb; break;
-  case LOIKB_F_NU: src = S->nu; n = S->nb; break;
-  case LOIKB_F_W: src = S->w; n = S->nb; break;
-  case LOIKB_F_STF_PLUS_W: src = S->s; n = S->nb; break;
-  case LOIKB_F_R: src = S->rr; n = S->nb; break;
-  case LOIKB_F_DINV: src = S->dinv; n = S->nb; break;
-  case LOIKB_F_VIS: src = S->v; n = 6 * S->nb; break;
-  case LOIKB_F_FIS: src = S->f; n = 6 * S->nb; break;
-  case LOIKB_F_G: src = S->g; n = 6 * S->nb; break;
-  case LOIKB_F_PIS: src = S->p; n = 6 * S->nb; break;
-  case LOIKB_F_UDINV: src = S->ud; n = 6 * S->nb; break;
-  case LOIKB_F_HIS: src = S->H; n = 21 * S->nb; break;
-  case LOIKB_F_YIS: src = S->y; n = 6 * S->nc; break;
-  case LOIKB_F_ATY: src = S->aty; n = 6 * S->nc; break;
+  case LOIKB_F_Z: src = S->set[0].z; n = S->nb; break;
+  case LOIKB_F_NU: src = S->set[0].nu; n = S->nb; break;
+  case LOIKB_F_W: src = S->set[0].w; n = S->nb; break;
+  case LOIKB_F_STF_PLUS_W: src = S->set[0].s; n = S->nb; break;
+  case LOIKB_F_R: src = S->set[0].rr; n = S->nb; break;
+  case LOIKB_F_DINV: src = S->set[0].dinv; n = S->nb; break;
+  case LOIKB_F_VIS: src = S->set[0].v; n = 6 * S->nb; break;
+  case LOIKB_F_FIS: src = S->set[0].f; n = 6 * S->nb; break;
+  case LOIKB_F_G: src = S->set[0].g; n = 6 * S->nb; break;
+  case LOIKB_F_PIS: src = S->set[0].p; n = 6 * S->nb; break;
+  case LOIKB_F_UDINV: src = S->set[0].ud; n = 6 * S->nb; break;
+  case LOIKB_F_HIS: src = S->set[0].H; n = 21 * S->nb; break;
+  case LOIKB_F_YIS: src = S->set[0].y; n = 6 * S->nc; break;
+  case LOIKB_F_ATY: src = S->set[0].aty; n = 6 * S->nc; break;
   case LOIKB_F_LIMI: n = 12 * S->nb; break;
   case LOIKB_F_ITER: is_int = true; break;
   case LOIKB_F_STATUS: is_int = true; break;
   case LOIKB_F_CONVERGED: is_int = true; mask = ST_CONVERGED; break;
   case LOIKB_F_PRIMAL_INFEASIBLE: is_int = true; mask = ST_PRIMAL_INF; break;
-  case LOIKB_F_MU: src = S->mu; n = 1; break;  // per-instance mu_ (== mu0 right after ResetSolver)
+  case LOIKB_F_MU: src = S->set[0].mu; n = 1; break;  // per-instance mu_ (== mu0 right after ResetSolver)
   default:
     static_assert(LOIKB_F_TAIL_SOLVE_ITER - LOIKB_F_PRIMAL_RESIDUAL + 1 == NSCAL, "scalar field ids out of sync");
     if (field >= LOIKB_F_PRIMAL_RESIDUAL && field <= LOIKB_F_TAIL_SOLVE_ITER) {
       const int row = field - LOIKB_F_PRIMAL_RESIDUAL;  // same order as the SC_* enum
-      src = (const char*)S->scal + (size_t)row * S->ld * S->esz;
+      src = (const char*)S->set[0].scal + (size_t)row * S->ld * S->esz;
       n = 1;
     } else {
       return LOIKB_ERR_ARG;
@@ -816,9 +911,9 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
       dst = (int*)S->d_stage;
     }
     if (field == LOIKB_F_ITER)
-      HIPCHK(hipMemcpyAsync(dst, S->iter, sizeof(int) * (size_t)S->B, hipMemcpyDeviceToDevice, S->stream));
+      HIPCHK(hipMemcpyAsync(dst, S->set[0].iter, sizeof(int) * (size_t)S->B, hipMemcpyDeviceToDevice, S->stream));
     else {
-      hipLaunchKernelGGL(k_status_extract, grid1(S->B), dim3(256), 0, S->stream, S->status, S->B, mask, dst);
+      hipLaunchKernelGGL(k_status_extract, grid1(S->B), dim3(256), 0, S->stream, S->set[0].status, S->B, mask, dst);
       HIPCHK(hipGetLastError());
     }
     if (!to_dev) HIPCHK(hipMemcpyAsync(out, dst, sizeof(int) * (size_t)S->B, hipMemcpyDeviceToHost, S->stream));
@@ -834,10 +929,10 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   }
   if (field == LOIKB_F_LIMI) {
     if (S->f32)
-      hipLaunchKernelGGL(k_limi<float>, grid1(S->B), dim3(256), 0, S->stream, (const float*)S->cs, S->d_jd, S->nb, S->B,
+      hipLaunchKernelGGL(k_limi<float>, grid1(S->B), dim3(256), 0, S->stream, (const float*)S->set[0].cs, S->d_jd, S->nb, S->B,
                          S->ld, dst);
     else
-      hipLaunchKernelGGL(k_limi<double>, grid1(S->B), dim3(256), 0, S->stream, (const double*)S->cs, S->d_jd, S->nb, S->B,
+      hipLaunchKernelGGL(k_limi<double>, grid1(S->B), dim3(256), 0, S->stream, (const double*)S->set[0].cs, S->d_jd, S->nb, S->B,
                          S->ld, dst);
   } else if (S->f32) {
     hipLaunchKernelGGL(k_soa_to_aos<float>, grid1(S->B), dim3(256), 0, S->stream, (const float*)src, n, S->B, S->ld, dst);
