@@ -1,10 +1,16 @@
 // loik_device.hpp -- CDNA4 (gfx950) device code of the batched LoIK ADMM solve.
 //
-// One problem instance per lane, 64-lane wavefronts, one wavefront per workgroup.  All per-instance
-// arrays are struct-of-arrays with the batch index innermost ([field][joint][component][B]) so every
-// vector memory instruction of a wavefront is one contiguous 512-byte (fp64) / 256-byte (fp32) run.
-// The kinematic tree (parents[], joint type/axis, jointPlacements) is baked on the host into a
-// per-joint `JointDesc` schedule that is uniform across lanes (scalar loads, SGPR operands).
+// Execution model: one problem instance per lane, 64-lane wavefronts, one wavefront per workgroup, and the
+// wavefront iterates ITS 64 instances to completion (persistent loop, no inter-wavefront communication --
+// instances are independent).
+//
+// Memory layout: wavefront-tiled AoSoA.  All state of the 64 instances a wavefront owns is ONE contiguous
+// "tile" in HBM.  A tile is an array of "pairs"; a pair is 64 lanes x 2 scalars, lane-interleaved
+// ([lane][2]), so one 16-byte load per lane (dwordx4 in fp64) moves a contiguous 1-KiB run per wavefront
+// and every access of a sweep is `tile base + compile-time pair offset` (no per-access address arithmetic).
+// Inside a tile the data is grouped per joint ("joint record", JREC pairs), then per constraint, then the
+// per-instance solver scalars.  The kinematic tree (parents[], joint type/axis, jointPlacements) is baked on
+// the host into a per-joint `JointDesc` schedule, uniform across lanes (scalar loads, SGPR operands).
 //
 // What each sweep computes, and the reference function it replaces (paths under /root/reference/):
 //   sweep_bwd   : FwdPass1 + BwdPassOptimizedVisitor/LoikBackwardStepVisitor
@@ -25,6 +31,47 @@
 namespace loikb {
 
 constexpr int WAVE = 64;
+
+// ---- tile layout (units: pairs) -------------------------------------------------------------------
+enum : int {
+  // joint record
+  JP_CS = 0,     // (cos q, sin q) | (q, 0) for prismatic joints           -- constant per configuration
+  JP_V = 1,      // vis[i]                      3 pairs                     -- persistent ADMM state
+  JP_F = 4,      // fis[i]                      3 pairs
+  JP_G = 7,      // fis_diff_plus_Aty[i]        3 pairs
+  JP_WZ = 10,    // (w_i, z_i)
+  JP_NUS = 11,   // (nu_i, Stf_plus_w_i)
+  JP_P = 12,     // pis[i]                      3 pairs                     -- inter-sweep temporaries
+  JP_R = 15,     // (r_i after += S^T p, unused)   -- always written as a full 16-byte pair
+  JP_UD = 16,    // UDinv                       3 pairs
+  JP_H = 19,     // His[i] packed 21, then Dinv 11 pairs
+  JP_LBUB = 30,  // (lb_i, ub_i) when the box is per instance
+  JREC = 32,
+  JP_NPERSIST = 12,  // pairs [0, JP_NPERSIST) (+ JP_LBUB) travel with an instance on compaction
+  // constraint record
+  CP_Y = 0,      // yis[c]     3 pairs
+  CP_ATY = 3,    // Aty[c]     3 pairs
+  CP_B = 6,      // bis_[c]    3 pairs
+  CP_ATB = 9,    // Atb[c]     3 pairs
+  CREC_SHARED_A = 12,
+  CP_A = 12,     // Ais_[c] row-major 36 -> 18 pairs      (only when A is per instance)
+  CP_ATA = 30,   // AtA[c] packed 21 + pad -> 11 pairs
+  CREC_FULL = 42,
+  // per-instance solver scalars
+  SP_MU = 0,     // (mu_, mu the cached H/UDinv/Dinv were computed with)
+  SP_BI = 1,     // (bis_inf_norm_, iter_)
+  SP_ST = 2,     // (status bits, unused)
+  SP_SCAL = 3,   // scal[NSCAL] -> 15 pairs
+  SREC = 18,
+};
+
+struct Layout {
+  int nb, nc;
+  int crec;        // CREC_SHARED_A or CREC_FULL
+  int off_c;       // first constraint record  = nb * JREC
+  int off_s;       // scalar record            = off_c + nc * crec
+  int tile_pairs;  // off_s + SREC
+};
 
 // joint-schedule flags (uniform per joint)
 enum : int {
@@ -59,7 +106,7 @@ enum : int {
   MODE_BND_SHARED = 8,   // one lb/ub for the whole batch
 };
 
-// per-iteration scalars dumped for the getters / parity tests: rows of `scal[NSCAL][ld]`
+// per-iteration scalars dumped for the getters / parity tests (scalar record, SP_SCAL)
 enum : int {
   SC_PRIMAL_RES = 0, SC_DUAL_RES, SC_PRIMAL_RES_TASK, SC_PRIMAL_RES_SLACK, SC_DUAL_RES_V, SC_DUAL_RES_NU,
   SC_TOL_PRIMAL, SC_TOL_DUAL, SC_MU, SC_MU_EQ, SC_MU_INEQ,
@@ -69,6 +116,7 @@ enum : int {
   SC_COND1, SC_COND2, SC_TAIL_ITER,
   NSCAL
 };
+static_assert(SP_SCAL + (NSCAL + 1) / 2 <= SREC, "scalar record too small");
 
 template <typename T>
 struct Params {
@@ -80,51 +128,59 @@ struct Params {
   T tol_abs, tol_rel, tol_primal_inf, tol_tail_solve;
   int max_iter;
   int mode;
-  int nb;   // joints 1..nb
-  int nc;   // active constraints
-  int B;    // instances in this launch (slots 0..B-1)
-  int ld;   // leading dimension (padded batch) of every SoA array
+  int B;    // instances (slots) of this launch
   int max_launch_iters;
-  int stack_levels;
+  Layout L;
 };
 
 template <typename T>
 struct Bufs {
-  // configuration: cos/sin (revolute) or q,0 (prismatic) per joint: [nb][2][ld]
-  const T* cs;
-  // persistent ADMM state
-  T* v;    // [nb][6][ld]  vis
-  T* f;    // [nb][6][ld]  fis
-  T* g;    // [nb][6][ld]  fis_diff_plus_Aty
-  T* nu;   // [nb][ld]
-  T* z;    // [nb][ld]
-  T* w;    // [nb][ld]
-  T* s;    // [nb][ld]     Stf_plus_w
-  T* y;    // [nc][6][ld]  yis
-  T* aty;  // [nc][6][ld]  Aty
-  // inter-sweep temporaries (within one iteration)
-  T* H;    // [nb][21][ld] His (pre-projection, accumulated), symmetric packed
-  T* p;    // [nb][6][ld]  pis
-  T* ud;   // [nb][6][ld]  UDinv
-  T* dinv; // [nb][ld]
-  T* rr;   // [nb][ld]     r after += S^T p
-  // inputs
-  const T* A;    // [nc][36] (shared) or [nc][36][ld]
-  const T* AtA;  // [nc][21] or [nc][21][ld]
-  const T* b;    // [nc][6][ld]
-  const T* Atb;  // [nc][6][ld]
-  const T* lb;   // [nb] or [nb][ld]
-  const T* ub;
-  const T* bnorm;  // [ld] bis_inf_norm_ per instance
-  // per-instance solver scalars
-  T* mu;         // [ld]
-  T* mu_h;       // [ld] mu the cached H/UDinv/Dinv were computed with (MODE_CACHE_H)
-  int* iter;     // [ld]
-  int* status;   // [ld]
-  T* scal;       // [NSCAL][ld]
+  char* tiles;             // tile t at tiles + t * L.tile_pairs * PAIR_BYTES
+  const T* uni;            // uniform inputs: A[nc][36], AtA[nc][21], lb[nb], ub[nb]
   unsigned int* counters;  // [0] live instances at exit, [1] instance-iterations executed
-  int* wave_live;          // [ld/64] live lanes of each wavefront at exit (feeds the host-side compaction scan)
+  int* wave_live;          // [tiles] live lanes of each wavefront at exit (feeds the host-side compaction scan)
 };
+
+template <typename T> struct Vec2;
+template <> struct Vec2<double> { using type = double2; };
+template <> struct Vec2<float> { using type = float2; };
+
+template <typename T>
+__host__ __device__ constexpr size_t pair_bytes() { return (size_t)WAVE * 2 * sizeof(T); }
+
+// pair `p` of the record `rec` (per-lane pointer: record base + lane * 2 * sizeof(T))
+template <typename T>
+__device__ __forceinline__ typename Vec2<T>::type ldp(const char* rec, int p)
+{
+  return *reinterpret_cast<const typename Vec2<T>::type*>(rec + (size_t)p * pair_bytes<T>());
+}
+template <typename T>
+__device__ __forceinline__ void stp(char* rec, int p, T x, T y)
+{
+  typename Vec2<T>::type v;
+  v.x = x; v.y = y;
+  *reinterpret_cast<typename Vec2<T>::type*>(rec + (size_t)p * pair_bytes<T>()) = v;
+}
+template <typename T>
+__device__ __forceinline__ void st_lo(char* rec, int p, T x) { *reinterpret_cast<T*>(rec + (size_t)p * pair_bytes<T>()) = x; }
+template <typename T>
+__device__ __forceinline__ void st_hi(char* rec, int p, T x) { *reinterpret_cast<T*>(rec + (size_t)p * pair_bytes<T>() + sizeof(T)) = x; }
+
+template <typename T>
+__device__ __forceinline__ void ld6(const char* rec, int p, T* x)
+{
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const typename Vec2<T>::type v = ldp<T>(rec, p + k);
+    x[2 * k] = v.x; x[2 * k + 1] = v.y;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void st6(char* rec, int p, const T* x)
+{
+#pragma unroll
+  for (int k = 0; k < 3; ++k) stp<T>(rec, p + k, x[2 * k], x[2 * k + 1]);
+}
 
 // ------------------------------------------------------------------------------------------------
 // small fixed-size algebra, everything fully unrolled so all register arrays are statically indexed
@@ -135,12 +191,14 @@ __host__ __device__ constexpr int sym(int i, int j)
   return (i <= j) ? (i * 6 - (i * (i - 1)) / 2 + (j - i)) : (j * 6 - (j * (j - 1)) / 2 + (i - j));
 }
 
-template <typename T>
-__device__ __forceinline__ T tabs(T x) { return x < T(0) ? -x : x; }
-template <typename T>
-__device__ __forceinline__ T tmax(T a, T b) { return a > b ? a : b; }
-template <typename T>
-__device__ __forceinline__ T tmin(T a, T b) { return a < b ? a : b; }
+// |x|, max, min map to v_max_f64 / v_min_f64 with |.| source modifiers (no compare + select chains).
+// NaN handling equals the reference's `if (x > norm) norm = x` idiom: a NaN candidate never wins.
+__host__ __device__ __forceinline__ double tabs(double x) { return __builtin_fabs(x); }
+__host__ __device__ __forceinline__ float tabs(float x) { return __builtin_fabsf(x); }
+__host__ __device__ __forceinline__ double tmax(double a, double b) { return __builtin_fmax(a, b); }
+__host__ __device__ __forceinline__ float tmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__host__ __device__ __forceinline__ double tmin(double a, double b) { return __builtin_fmin(a, b); }
+__host__ __device__ __forceinline__ float tmin(float a, float b) { return __builtin_fminf(a, b); }
 
 template <typename T>
 __device__ __forceinline__ T inf6(const T* x)
@@ -174,7 +232,7 @@ __device__ __forceinline__ void mat3t_vec(const T* A, const T* x, T* y)
 }
 
 // liMi = jointPlacement * M(q)  (hxx:263-264).  `c`,`s` = cos q, sin q for revolute joints; for prismatic
-// joints `c` carries q.
+// joints `c` carries q.  liMi is never stored: every sweep rebuilds it from (c,s) + uniform constants.
 template <typename T>
 __device__ __forceinline__ void make_liMi(const JointDesc& d, T c, T s, T* R, T* t)
 {
@@ -184,26 +242,43 @@ __device__ __forceinline__ void make_liMi(const JointDesc& d, T c, T s, T* R, T*
 #pragma unroll
   for (int k = 0; k < 3; ++k) { tp[k] = (T)d.tp[k]; ax[k] = (T)d.axis[k]; }
   if (d.flags & JF_REVOLUTE) {
-    T M[9];
+    // R = Rp * Rot(axis, q).  For the axis-aligned joints only two columns of Rp are mixed (the dense product's
+    // other terms are exact zeros / ones).
     if (d.rot == ROT_X) {
-      M[0] = T(1); M[1] = T(0); M[2] = T(0); M[3] = T(0); M[4] = c; M[5] = -s; M[6] = T(0); M[7] = s; M[8] = c;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        R[3 * i] = Rp[3 * i];
+        R[3 * i + 1] = Rp[3 * i + 1] * c + Rp[3 * i + 2] * s;
+        R[3 * i + 2] = Rp[3 * i + 2] * c - Rp[3 * i + 1] * s;
+      }
     } else if (d.rot == ROT_Y) {
-      M[0] = c; M[1] = T(0); M[2] = s; M[3] = T(0); M[4] = T(1); M[5] = T(0); M[6] = -s; M[7] = T(0); M[8] = c;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        R[3 * i] = Rp[3 * i] * c - Rp[3 * i + 2] * s;
+        R[3 * i + 1] = Rp[3 * i + 1];
+        R[3 * i + 2] = Rp[3 * i] * s + Rp[3 * i + 2] * c;
+      }
     } else if (d.rot == ROT_Z) {
-      M[0] = c; M[1] = -s; M[2] = T(0); M[3] = s; M[4] = c; M[5] = T(0); M[6] = T(0); M[7] = T(0); M[8] = T(1);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        R[3 * i] = Rp[3 * i] * c + Rp[3 * i + 1] * s;
+        R[3 * i + 1] = Rp[3 * i + 1] * c - Rp[3 * i] * s;
+        R[3 * i + 2] = Rp[3 * i + 2];
+      }
     } else {  // Rodrigues: c I + (1-c) a a^T + s [a]x
+      T M[9];
       const T c1 = T(1) - c;
       T tmp;
       tmp = c1 * ax[0] * ax[1]; M[1] = tmp - s * ax[2]; M[3] = tmp + s * ax[2];
       tmp = c1 * ax[0] * ax[2]; M[2] = tmp + s * ax[1]; M[6] = tmp - s * ax[1];
       tmp = c1 * ax[1] * ax[2]; M[5] = tmp - s * ax[0]; M[7] = tmp + s * ax[0];
       M[0] = c1 * ax[0] * ax[0] + c; M[4] = c1 * ax[1] * ax[1] + c; M[8] = c1 * ax[2] * ax[2] + c;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          R[3 * i + j] = Rp[3 * i] * M[j] + Rp[3 * i + 1] * M[3 + j] + Rp[3 * i + 2] * M[6 + j];
     }
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        R[3 * i + j] = Rp[3 * i] * M[j] + Rp[3 * i + 1] * M[3 + j] + Rp[3 * i + 2] * M[6 + j];
 #pragma unroll
     for (int k = 0; k < 3; ++k) t[k] = tp[k];
   } else {
@@ -320,11 +395,24 @@ __device__ __forceinline__ void symv(const T* h, const T* x, T* y)
   }
 }
 
-// coalesced SoA access: element (row, lane-slot)
-template <typename T>
-__device__ __forceinline__ T ld(const T* base, int row, int ldim, int b) { return base[(size_t)row * ldim + b]; }
-template <typename T>
-__device__ __forceinline__ void st(T* base, int row, int ldim, int b, T x) { base[(size_t)row * ldim + b] = x; }
+// Href * v (hxx:149, :228).  HDIAG: H_ref is diagonal (e.g. the identity of every reference test), 6 uniform
+// scalars instead of 36 -- keeps the kernel's SGPR budget for the joint descriptor.
+template <typename T, bool HDIAG>
+__device__ __forceinline__ void href_mul(const T* Href, const T* v, T* o)
+{
+  if (HDIAG) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) o[r] = Href[7 * r] * v[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      T a = Href[6 * r] * v[0];
+#pragma unroll
+      for (int k = 1; k < 6; ++k) a += Href[6 * r + k] * v[k];
+      o[r] = a;
+    }
+  }
+}
 
 // per-lane LDS stack of pending branch accumulators: [level][entry][lane]
 template <typename T>
@@ -362,54 +450,61 @@ struct Norms {
 // ------------------------------------------------------------------------------------------------
 // leaf -> root sweep: FwdPass1 + BwdPass.  WITH_H=false re-uses the cached H/UDinv/Dinv (valid while
 // mu is unchanged: they depend only on rho, mu, liMi, H_ref, AtA -- never on the iterates).
+// `lp` = this lane's pointer into its wavefront's tile.
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool WITH_H>
+template <typename T, bool WITH_H, bool HDIAG>
 __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf, const JointDesc* __restrict__ jd,
-                                          T* stk, int b, int lane, bool live, T mu_eq, T mu_in)
+                                          T* stk, char* lp, int lane, bool live, T mu_eq, T mu_in)
 {
   constexpr int NENT = 27;
-  const int ldm = P.ld;
+  const Layout& L = P.L;
   T accH[21], accp[6];
 #pragma unroll
   for (int k = 0; k < 21; ++k) accH[k] = T(0);
 #pragma unroll
   for (int k = 0; k < 6; ++k) accp[k] = T(0);
   int level = 0;
-  const int a_bs = (P.mode & MODE_A_SHARED) ? 0 : 1;
-  const int a_es = (P.mode & MODE_A_SHARED) ? 1 : ldm;
 
-  for (int i = P.nb; i >= 1; --i) {
+  for (int i = L.nb; i >= 1; --i) {
     const JointDesc d = jd[i];
-    const int j = i - 1;  // storage row of joint i
+    char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
     if (live) {
       T vprev[6], hh[21], pp[6], U[6], UD[6];
-      const T c = ld(Bf.cs, 2 * j, ldm, b), s = ld(Bf.cs, 2 * j + 1, ldm, b);
-      const T wi = ld(Bf.w, j, ldm, b), zi = ld(Bf.z, j, ldm, b);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) vprev[k] = ld(Bf.v, 6 * j + k, ldm, b);
-      if (!WITH_H) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) UD[k] = ld(Bf.ud, 6 * j + k, ldm, b);
-      }
+      const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ);
+      ld6<T>(rec, JP_V, vprev);
+      if (!WITH_H) ld6<T>(rec, JP_UD, UD);
       // FwdPass1 (hxx:304-315): H_i = rho I + H_ref ; p_i = -rho v_prev - Hv
       if (WITH_H) {
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
-          for (int cc = r; cc < 6; ++cc) hh[sym(r, cc)] = (r == cc ? P.rho : T(0)) + P.Href[6 * r + cc];
+          for (int cc = r; cc < 6; ++cc)
+            hh[sym(r, cc)] = (r == cc ? P.rho : T(0)) + ((HDIAG && r != cc) ? T(0) : P.Href[6 * r + cc]);
       }
 #pragma unroll
       for (int k = 0; k < 6; ++k) pp[k] = -P.rho * vprev[k] - P.Hv[k];
       // constraint terms (hxx:321-334)
       if (d.cslot >= 0) {
-        const int cs_ = d.cslot;
+        const char* crec = lp + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>();
         if (WITH_H) {
+          if (P.mode & MODE_A_SHARED) {
+            const T* AtA = Bf.uni + L.nc * 36 + d.cslot * 21;
 #pragma unroll
-          for (int k = 0; k < 21; ++k) hh[k] += mu_eq * Bf.AtA[(size_t)(cs_ * 21 + k) * a_es + (size_t)b * a_bs];
+            for (int k = 0; k < 21; ++k) hh[k] += mu_eq * AtA[k];
+          } else {
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+              const typename Vec2<T>::type a = ldp<T>(crec, CP_ATA + k);
+              hh[2 * k] += mu_eq * a.x;
+              if (2 * k + 1 < 21) hh[2 * k + 1] += mu_eq * a.y;
+            }
+          }
         }
+        T aty[6], atb[6];
+        ld6<T>(crec, CP_ATY, aty);
+        ld6<T>(crec, CP_ATB, atb);
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
-          pp[k] += ld(Bf.aty, 6 * cs_ + k, ldm, b) - mu_eq * ld(Bf.Atb, 6 * cs_ + k, ldm, b);
+        for (int k = 0; k < 6; ++k) pp[k] += aty[k] - mu_eq * atb[k];
       }
       // children contributions accumulated so far (hxx:66-67, :74-75)
       if (!(d.flags & JF_LEAF)) {
@@ -420,48 +515,41 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
 #pragma unroll
         for (int k = 0; k < 6; ++k) pp[k] += accp[k];
       }
-      if (WITH_H) {
-#pragma unroll
-        for (int k = 0; k < 21; ++k) st(Bf.H, 21 * j + k, ldm, b, hh[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) st(Bf.p, 6 * j + k, ldm, b, pp[k]);
+      st6<T>(rec, JP_P, pp);
 
       // calc_aba (hxx:60-63): U = H S ; Dinv = 1/(S^T U + R) ; UDinv = U Dinv
       const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
-      T Stp;
+      T Stp, dd = T(0);
       if (d.flags & JF_REVOLUTE) {
         if (WITH_H) {
 #pragma unroll
           for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 3)] * ax0 + hh[sym(k, 4)] * ax1 + hh[sym(k, 5)] * ax2;
-          const T dd = T(1) / ((ax0 * U[3] + ax1 * U[4] + ax2 * U[5]) + mu_in);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) UD[k] = U[k] * dd;
-          st(Bf.dinv, j, ldm, b, dd);
+          dd = T(1) / ((ax0 * U[3] + ax1 * U[4] + ax2 * U[5]) + mu_in);
         }
         Stp = ax0 * pp[3] + ax1 * pp[4] + ax2 * pp[5];
       } else {
         if (WITH_H) {
 #pragma unroll
           for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 0)] * ax0 + hh[sym(k, 1)] * ax1 + hh[sym(k, 2)] * ax2;
-          const T dd = T(1) / ((ax0 * U[0] + ax1 * U[1] + ax2 * U[2]) + mu_in);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) UD[k] = U[k] * dd;
-          st(Bf.dinv, j, ldm, b, dd);
+          dd = T(1) / ((ax0 * U[0] + ax1 * U[1] + ax2 * U[2]) + mu_in);
         }
         Stp = ax0 * pp[0] + ax1 * pp[1] + ax2 * pp[2];
       }
+      // r_i = (w_i - mu_in z_i) + S^T p_i   (hxx:296, :70)
+      const T ri = (wz.x - mu_in * wz.y) + Stp;
       if (WITH_H) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) st(Bf.ud, 6 * j + k, ldm, b, UD[k]);
+        for (int k = 0; k < 6; ++k) UD[k] = U[k] * dd;
+        // store the pre-projection H (what the forward sweep needs, hxx:121) with Dinv in its 22nd slot, UDinv
+#pragma unroll
+        for (int k = 0; k < 11; ++k) stp<T>(rec, JP_H + k, hh[2 * k], 2 * k + 1 < 21 ? hh[2 * k + 1] : dd);
+        st6<T>(rec, JP_UD, UD);
       }
-      // r_i = (w_i - mu_in z_i) + S^T p_i   (hxx:296, :70)
-      const T ri = (wi - mu_in * zi) + Stp;
-      st(Bf.rr, j, ldm, b, ri);
+      stp<T>(rec, JP_R, ri, T(0));
 
       if (!(d.flags & JF_PARENT_ROOT)) {
         T R[9], t[3], part[27], pa[6];
-        make_liMi(d, c, s, R, t);
+        make_liMi(d, cs.x, cs.y, R, t);
         if (WITH_H) {
           // H_aba = H - UDinv U^T (hxx:60-63), then SE3actOn (hxx:66)
 #pragma unroll
@@ -499,37 +587,40 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
 // ------------------------------------------------------------------------------------------------
 // root -> leaf sweep: FwdPass2 + BoxProj + DualUpdate
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool HDIAG>
 __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf, const JointDesc* __restrict__ jd,
-                                          int b, bool live, T mu_eq, T mu_in, Norms<T>& N)
+                                          char* lp, bool live, T mu_eq, T mu_in, Norms<T>& N)
 {
-  const int ldm = P.ld;
-  const int a_bs = (P.mode & MODE_A_SHARED) ? 0 : 1;
-  const int a_es = (P.mode & MODE_A_SHARED) ? 1 : ldm;
-  const int bd_bs = (P.mode & MODE_BND_SHARED) ? 0 : 1;
-  const int bd_es = (P.mode & MODE_BND_SHARED) ? 1 : ldm;
+  const Layout& L = P.L;
   T vcur[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) vcur[k] = T(0);
 
-  for (int i = 1; i <= P.nb; ++i) {
+  for (int i = 1; i <= L.nb; ++i) {
     const JointDesc d = jd[i];
-    const int j = i - 1;
+    char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
     if (live) {
-      T hh[21], pp[6], UD[6], vprev[6], fold[6], vpar[6], vp[6], vi[6], fi[6], R[9], t[3];
-      const T c = ld(Bf.cs, 2 * j, ldm, b), s = ld(Bf.cs, 2 * j + 1, ldm, b);
+      T hh[22], pp[6], UD[6], vprev[6], fold[6], vpar[6], vp[6], vi[6], fi[6], R[9], t[3];
+      const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS),
+                                   rd = ldp<T>(rec, JP_R);
 #pragma unroll
-      for (int k = 0; k < 21; ++k) hh[k] = ld(Bf.H, 21 * j + k, ldm, b);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        pp[k] = ld(Bf.p, 6 * j + k, ldm, b);
-        UD[k] = ld(Bf.ud, 6 * j + k, ldm, b);
-        vprev[k] = ld(Bf.v, 6 * j + k, ldm, b);
-        fold[k] = ld(Bf.f, 6 * j + k, ldm, b);
+      for (int k = 0; k < 11; ++k) {
+        const typename Vec2<T>::type a = ldp<T>(rec, JP_H + k);
+        hh[2 * k] = a.x; hh[2 * k + 1] = a.y;
       }
-      const T dd = ld(Bf.dinv, j, ldm, b), ri = ld(Bf.rr, j, ldm, b);
-      const T wi = ld(Bf.w, j, ldm, b), nuprev = ld(Bf.nu, j, ldm, b), zprev = ld(Bf.z, j, ldm, b);
-      const T lbi = Bf.lb[(size_t)j * bd_es + (size_t)b * bd_bs], ubi = Bf.ub[(size_t)j * bd_es + (size_t)b * bd_bs];
+      ld6<T>(rec, JP_P, pp);
+      ld6<T>(rec, JP_UD, UD);
+      ld6<T>(rec, JP_V, vprev);
+      ld6<T>(rec, JP_F, fold);
+      T lbi, ubi;
+      if (P.mode & MODE_BND_SHARED) {
+        lbi = Bf.uni[L.nc * 57 + (i - 1)];
+        ubi = Bf.uni[L.nc * 57 + L.nb + (i - 1)];
+      } else {
+        const typename Vec2<T>::type lu = ldp<T>(rec, JP_LBUB);
+        lbi = lu.x; ubi = lu.y;
+      }
+      const T ri = rd.x, dd = hh[21], wi = wz.x, zprev = wz.y, nuprev = nus.x;
       // parent velocity: universe = 0, chain = registers, branch point = re-read (written earlier by this lane)
       if (d.parent == 0) {
 #pragma unroll
@@ -538,10 +629,9 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
 #pragma unroll
         for (int k = 0; k < 6; ++k) vpar[k] = vcur[k];
       } else {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) vpar[k] = ld(Bf.v, 6 * (d.parent - 1) + k, ldm, b);
+        ld6<T>(lp + (size_t)(d.parent - 1) * JREC * pair_bytes<T>(), JP_V, vpar);
       }
-      make_liMi(d, c, s, R, t);
+      make_liMi(d, cs.x, cs.y, R, t);
       actinv_motion(R, t, vpar, vp);  // hxx:125
       // nu_i = -UDinv^T v' - Dinv r_i  (hxx:127)
       T udv = UD[0] * vp[0];
@@ -569,13 +659,7 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
       }
       N.dfis = tmax(N.dfis, inf6(df));
       // Href_v (hxx:149-153)
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        T a = P.Href[6 * r] * vi[0];
-#pragma unroll
-        for (int k = 1; k < 6; ++k) a += P.Href[6 * r + k] * vi[k];
-        hrv[r] = a;
-      }
+      href_mul<T, HDIAG>(P.Href, vi, hrv);
       N.href_v = tmax(N.href_v, inf6(hrv));
       N.dvis = tmax(N.dvis, inf6(dv6));  // hxx:156-158
       N.dnu = tmax(N.dnu, tabs(nui - nuprev));  // hxx:375
@@ -589,37 +673,45 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
       N.dw = tmax(N.dw, tabs(dwi));
       N.ub_dw_plus += ubi * tmax(dwi, T(0));
       N.lb_dw_minus += lbi * tmin(dwi, T(0));
-      st(Bf.w, j, ldm, b, wi + dwi);
-      st(Bf.nu, j, ldm, b, nui);
-      st(Bf.z, j, ldm, b, zi);
+      stp<T>(rec, JP_WZ, wi + dwi, zi);
+      stp<T>(rec, JP_NUS, nui, nus.y);  // full 16-byte store: Stf_plus_w rewritten unchanged
+      st6<T>(rec, JP_V, vi);
+      st6<T>(rec, JP_F, fi);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        st(Bf.v, 6 * j + k, ldm, b, vi[k]);
-        st(Bf.f, 6 * j + k, ldm, b, fi[k]);
-        vcur[k] = vi[k];
-      }
+      for (int k = 0; k < 6; ++k) vcur[k] = vi[k];
       // DualUpdate, task part (hxx:410-451)
       if (d.cslot >= 0) {
-        const int cs_ = d.cslot;
-        T Av[6], e[6], yy[6], aty[6];
+        char* crec = lp + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>();
+        T A[36], Av[6], e[6], yy[6], aty[6], bb[6];
+        if (P.mode & MODE_A_SHARED) {
+          const T* Au = Bf.uni + d.cslot * 36;
+#pragma unroll
+          for (int k = 0; k < 36; ++k) A[k] = Au[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 18; ++k) {
+            const typename Vec2<T>::type a = ldp<T>(crec, CP_A + k);
+            A[2 * k] = a.x; A[2 * k + 1] = a.y;
+          }
+        }
+        ld6<T>(crec, CP_B, bb);
+        ld6<T>(crec, CP_Y, yy);
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
           T a = T(0);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) a += Bf.A[(size_t)(cs_ * 36 + 6 * r + k) * a_es + (size_t)b * a_bs] * vi[k];
+          for (int k = 0; k < 6; ++k) a += A[6 * r + k] * vi[k];
           Av[r] = a;
         }
         T plus = T(0), minus = T(0);
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-          const T bk = ld(Bf.b, 6 * cs_ + k, ldm, b);
-          e[k] = Av[k] - bk;
+          e[k] = Av[k] - bb[k];
           const T dy = mu_eq * e[k];
-          yy[k] = ld(Bf.y, 6 * cs_ + k, ldm, b) + dy;
-          st(Bf.y, 6 * cs_ + k, ldm, b, yy[k]);
+          yy[k] += dy;
           N.dyis = tmax(N.dyis, tabs(dy));
-          plus += bk * tmax(dy, T(0));
-          minus += bk * tmin(dy, T(0));
+          plus += bb[k] * tmax(dy, T(0));
+          minus += bb[k] * tmin(dy, T(0));
         }
         N.bTdy_plus += plus;
         N.bTdy_minus += minus;
@@ -629,10 +721,11 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
         for (int r = 0; r < 6; ++r) {
           T a = T(0);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) a += Bf.A[(size_t)(cs_ * 36 + 6 * k + r) * a_es + (size_t)b * a_bs] * yy[k];
+          for (int k = 0; k < 6; ++k) a += A[6 * k + r] * yy[k];
           aty[r] = a;
-          st(Bf.aty, 6 * cs_ + r, ldm, b, a);
         }
+        st6<T>(crec, CP_Y, yy);
+        st6<T>(crec, CP_ATY, aty);
       }
     }
   }
@@ -641,33 +734,29 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
 // ------------------------------------------------------------------------------------------------
 // leaf -> root residual sweep: BwdPass2 + dual residual
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool HDIAG>
 __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf, const JointDesc* __restrict__ jd,
-                                           T* stk, int b, int lane, bool live, Norms<T>& N)
+                                           T* stk, char* lp, int lane, bool live, Norms<T>& N)
 {
   constexpr int NENT = 27;
-  const int ldm = P.ld;
+  const Layout& L = P.L;
   T acc[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) acc[k] = T(0);
   int level = 0;
-  for (int i = P.nb; i >= 1; --i) {
+  for (int i = L.nb; i >= 1; --i) {
     const JointDesc d = jd[i];
-    const int j = i - 1;
+    char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
     if (live) {
       T fi[6], vi[6], gold[6], gi[6];
-      const T c = ld(Bf.cs, 2 * j, ldm, b), s = ld(Bf.cs, 2 * j + 1, ldm, b);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        fi[k] = ld(Bf.f, 6 * j + k, ldm, b);
-        vi[k] = ld(Bf.v, 6 * j + k, ldm, b);
-        gold[k] = ld(Bf.g, 6 * j + k, ldm, b);
-      }
-      const T wi = ld(Bf.w, j, ldm, b), sold = ld(Bf.s, j, ldm, b);
+      const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
+      ld6<T>(rec, JP_F, fi);
+      ld6<T>(rec, JP_V, vi);
+      ld6<T>(rec, JP_G, gold);
+      const T wi = wz.x, sold = nus.y;
       // g_i = (Aty_c | 0) + sum_children act(f_j) - f_i   (hxx:438-439, :210-212)
       if (d.cslot >= 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) gi[k] = ld(Bf.aty, 6 * d.cslot + k, ldm, b);
+        ld6<T>(lp + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>(), CP_ATY, gi);
       } else {
 #pragma unroll
         for (int k = 0; k < 6; ++k) gi[k] = T(0);
@@ -681,18 +770,14 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
       for (int k = 0; k < 6; ++k) {
         gi[k] += -fi[k];
         dg[k] = gi[k] - gold[k];
-        st(Bf.g, 6 * j + k, ldm, b, gi[k]);
       }
+      st6<T>(rec, JP_G, gi);
       N.dg = tmax(N.dg, inf6(dg));      // hxx:215-220
       N.g_inf = tmax(N.g_inf, inf6(gi));  // hxx:223-225
       // dual residual, v block (hxx:228): Href v_i - Hv + g_i
+      href_mul<T, HDIAG>(P.Href, vi, dvr);
 #pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        T a = P.Href[6 * r] * vi[0];
-#pragma unroll
-        for (int k = 1; k < 6; ++k) a += P.Href[6 * r + k] * vi[k];
-        dvr[r] = a - P.Hv[r] + gi[r];
-      }
+      for (int r = 0; r < 6; ++r) dvr[r] = dvr[r] - P.Hv[r] + gi[r];
       N.dual_v = tmax(N.dual_v, inf6(dvr));
       // Stf_plus_w (hxx:231-236, :482-484)
       const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
@@ -700,12 +785,12 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
       if (d.flags & JF_REVOLUTE) stf = ax0 * fi[3] + ax1 * fi[4] + ax2 * fi[5];
       else stf = ax0 * fi[0] + ax1 * fi[1] + ax2 * fi[2];
       const T si = stf + wi;
-      st(Bf.s, j, ldm, b, si);
+      stp<T>(rec, JP_NUS, nus.x, si);  // full 16-byte store: nu rewritten unchanged
       N.stf_w_inf = tmax(N.stf_w_inf, tabs(si));
       N.dstf_w = tmax(N.dstf_w, tabs(si - sold));
       if (!(d.flags & JF_PARENT_ROOT)) {
         T R[9], t[3], part[6];
-        make_liMi(d, c, s, R, t);
+        make_liMi(d, cs.x, cs.y, R, t);
         act_force(R, t, fi, part);  // hxx:212
         if (!(d.flags & JF_LAST_CHILD)) {
           --level;
@@ -723,26 +808,42 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
   }
 }
 
+// scalar record accessors
+template <typename T>
+__device__ __forceinline__ T ld_scal(const char* srec, int idx)
+{
+  const typename Vec2<T>::type v = ldp<T>(srec, SP_SCAL + idx / 2);
+  return (idx & 1) ? v.y : v.x;
+}
+template <typename T>
+__device__ __forceinline__ void st_scal(char* srec, int idx, T x)
+{
+  if (idx & 1) st_hi<T>(srec, SP_SCAL + idx / 2, x);
+  else st_lo<T>(srec, SP_SCAL + idx / 2, x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // persistent solve kernel: each wavefront iterates its 64 instances until all are done (or the launch
 // iteration budget is spent).  No inter-wavefront communication: instances are independent.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool HDIAG>
 __global__ void __launch_bounds__(WAVE)
 k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* stk = reinterpret_cast<T*>(smem_raw);
+  const Layout& L = P.L;
   const int lane = threadIdx.x;
   const int b = blockIdx.x * WAVE + lane;
   const bool inb = b < P.B;
-  const int bb = inb ? b : 0;
+  char* lp = Bf.tiles + (size_t)blockIdx.x * L.tile_pairs * pair_bytes<T>() + (size_t)lane * 2 * sizeof(T);
+  char* srec = lp + (size_t)L.off_s * pair_bytes<T>();
 
-  int status = inb ? Bf.status[bb] : ST_DONE;
-  int iter = inb ? Bf.iter[bb] : 0;
-  T mu = inb ? Bf.mu[bb] : P.mu0;
-  T mu_h = inb ? Bf.mu_h[bb] : T(-1);
-  const T bnorm = inb ? Bf.bnorm[bb] : T(0);
+  const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
+  int status = inb ? (int)st2.x : ST_DONE;
+  int iter = (int)bi2.y;
+  T mu = mu2.x, mu_h = mu2.y;
+  const T bnorm = bi2.x;
   bool live = inb && !(status & ST_DONE);
   // main-loop bound `for (i = 1; i < max_iter; ++i)` (hpp:377): nothing to do when max_iter <= 1
   if (live && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { live = false; status |= ST_DONE; }
@@ -758,19 +859,19 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
 
     const bool need_h = !(P.mode & MODE_CACHE_H) || __any(live && (mu_h != mu));
     if (need_h) {
-      sweep_bwd<T, true>(P, Bf, jd, stk, bb, lane, live, mu_eq, mu_in);
+      sweep_bwd<T, true, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in);
       if (live) mu_h = mu;
     } else {
-      sweep_bwd<T, false>(P, Bf, jd, stk, bb, lane, live, mu_eq, mu_in);
+      sweep_bwd<T, false, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in);
     }
-    sweep_fwd<T>(P, Bf, jd, bb, live, mu_eq, mu_in, N);
-    sweep_bwd2<T>(P, Bf, jd, stk, bb, lane, live, N);
+    sweep_fwd<T, HDIAG>(P, Bf, jd, lp, live, mu_eq, mu_in, N);
+    sweep_bwd2<T, HDIAG>(P, Bf, jd, stk, lp, lane, live, N);
 
     if (live) {
       // ComputePrimalResiduals / ComputeDualResiduals (hxx:494-522)
       const T primal = tmax(N.pr_task, N.pr_slack);
       const T dual = tmax(N.dual_v, N.stf_w_inf);
-      T tol_p = ld(Bf.scal, SC_TOL_PRIMAL, P.ld, bb), tol_d = ld(Bf.scal, SC_TOL_DUAL, P.ld, bb);
+      T tol_p = ld_scal<T>(srec, SC_TOL_PRIMAL), tol_d = ld_scal<T>(srec, SC_TOL_DUAL);
       T dx = tmax(N.dvis, N.dnu);
       T dyqp = T(0), atdy = T(0), ubp = T(0), lbm = T(0);
       int c1 = 0, c2 = 0;
@@ -814,38 +915,43 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
         }
       } else {
         // tail-solve iteration (hpp:286-308)
-        tail_iter = (int)ld(Bf.scal, SC_TAIL_ITER, P.ld, bb) + 1;
+        tail_iter = (int)ldp<T>(srec, SP_SCAL + 14).y + 1;
         if (!(dx >= P.tol_tail_solve || N.dz >= P.tol_tail_solve) || iter >= P.max_iter) {
           status |= ST_DONE;
           live = false;
         }
       }
-      T* sc = Bf.scal;
-      const int l = P.ld;
-      st(sc, SC_PRIMAL_RES, l, bb, primal); st(sc, SC_DUAL_RES, l, bb, dual);
-      st(sc, SC_PRIMAL_RES_TASK, l, bb, N.pr_task); st(sc, SC_PRIMAL_RES_SLACK, l, bb, N.pr_slack);
-      st(sc, SC_DUAL_RES_V, l, bb, N.dual_v); st(sc, SC_DUAL_RES_NU, l, bb, N.stf_w_inf);
-      st(sc, SC_TOL_PRIMAL, l, bb, tol_p); st(sc, SC_TOL_DUAL, l, bb, tol_d);
-      st(sc, SC_MU, l, bb, mu); st(sc, SC_MU_EQ, l, bb, P.mu_scale * mu); st(sc, SC_MU_INEQ, l, bb, mu);
-      st(sc, SC_DELTA_X_QP, l, bb, dx); st(sc, SC_DELTA_Z_QP, l, bb, N.dz);
-      if (ran_feas) {
-        st(sc, SC_DELTA_Y_QP, l, bb, dyqp); st(sc, SC_AT_DELTA_Y_QP, l, bb, atdy);
-        st(sc, SC_UB_DY_PLUS, l, bb, ubp); st(sc, SC_LB_DY_MINUS, l, bb, lbm);
-        st(sc, SC_COND1, l, bb, (T)c1); st(sc, SC_COND2, l, bb, (T)c2);
+      // per-iteration scalar dump: full 16-byte pairs of the scalar record.  The feasibility scalars keep their
+      // last evaluated value when CheckFeasibility did not run this iteration (iter 1, tail solve), as upstream.
+      if (!ran_feas) {
+        const typename Vec2<T>::type o6 = ldp<T>(srec, SP_SCAL + 6), o7 = ldp<T>(srec, SP_SCAL + 7),
+                                     o8 = ldp<T>(srec, SP_SCAL + 8), o13 = ldp<T>(srec, SP_SCAL + 13),
+                                     o14 = ldp<T>(srec, SP_SCAL + 14);
+        dyqp = o6.y; atdy = o7.x; ubp = o7.y; lbm = o8.x; c1 = (int)o13.y; c2 = (int)o14.x;
       }
-      st(sc, SC_DELTA_FIS, l, bb, N.dfis); st(sc, SC_DELTA_YIS, l, bb, N.dyis); st(sc, SC_DELTA_W, l, bb, N.dw);
-      st(sc, SC_DELTA_VIS, l, bb, N.dvis); st(sc, SC_DELTA_NU, l, bb, N.dnu);
-      st(sc, SC_AV_INF, l, bb, N.av_inf); st(sc, SC_NU_INF, l, bb, N.nu_inf); st(sc, SC_HREF_V_INF, l, bb, N.href_v);
-      st(sc, SC_G_INF, l, bb, N.g_inf); st(sc, SC_STF_PLUS_W_INF, l, bb, N.stf_w_inf);
-      if (status & ST_TAIL) st(sc, SC_TAIL_ITER, l, bb, (T)tail_iter);
+      if (!(status & ST_TAIL)) tail_iter = (int)ldp<T>(srec, SP_SCAL + 14).y;
+      stp<T>(srec, SP_SCAL + 0, primal, dual);                     // PRIMAL_RES, DUAL_RES
+      stp<T>(srec, SP_SCAL + 1, N.pr_task, N.pr_slack);            // PRIMAL_RES_TASK, _SLACK
+      stp<T>(srec, SP_SCAL + 2, N.dual_v, N.stf_w_inf);            // DUAL_RES_V, DUAL_RES_NU
+      stp<T>(srec, SP_SCAL + 3, tol_p, tol_d);                     // TOL_PRIMAL, TOL_DUAL
+      stp<T>(srec, SP_SCAL + 4, mu, P.mu_scale * mu);              // MU, MU_EQ
+      stp<T>(srec, SP_SCAL + 5, mu, dx);                           // MU_INEQ, DELTA_X_QP
+      stp<T>(srec, SP_SCAL + 6, N.dz, dyqp);                       // DELTA_Z_QP, DELTA_Y_QP
+      stp<T>(srec, SP_SCAL + 7, atdy, ubp);                        // AT_DELTA_Y_QP, UB_DY_PLUS
+      stp<T>(srec, SP_SCAL + 8, lbm, N.dfis);                      // LB_DY_MINUS, DELTA_FIS
+      stp<T>(srec, SP_SCAL + 9, N.dyis, N.dw);                     // DELTA_YIS, DELTA_W
+      stp<T>(srec, SP_SCAL + 10, N.dvis, N.dnu);                   // DELTA_VIS, DELTA_NU
+      stp<T>(srec, SP_SCAL + 11, N.av_inf, N.nu_inf);              // AV_INF, NU_INF
+      stp<T>(srec, SP_SCAL + 12, N.href_v, N.g_inf);               // HREF_V_INF, G_INF
+      stp<T>(srec, SP_SCAL + 13, N.stf_w_inf, (T)c1);              // STF_PLUS_W_INF, COND1
+      stp<T>(srec, SP_SCAL + 14, (T)c2, (T)tail_iter);             // COND2, TAIL_ITER
     }
   }
 
   if (inb) {
-    Bf.status[bb] = status;
-    Bf.iter[bb] = iter;
-    Bf.mu[bb] = mu;
-    Bf.mu_h[bb] = mu_h;
+    stp<T>(srec, SP_MU, mu, mu_h);
+    stp<T>(srec, SP_BI, bnorm, (T)iter);
+    stp<T>(srec, SP_ST, (T)status, T(0));
   }
   const unsigned long long live_mask = __ballot(live);
   unsigned int it_sum = my_iters;
@@ -858,20 +964,37 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
     if (it_sum) atomicAdd(&Bf.counters[1], it_sum);
   }
 }
+static_assert(SC_PRIMAL_RES == 0 && SC_DUAL_RES == 1 && SC_TOL_PRIMAL == 6 && SC_MU == 8 && SC_MU_INEQ == 10 &&
+              SC_DELTA_X_QP == 11 && SC_DELTA_Z_QP == 12 && SC_DELTA_Y_QP == 13 && SC_AT_DELTA_Y_QP == 14 &&
+              SC_UB_DY_PLUS == 15 && SC_LB_DY_MINUS == 16 && SC_DELTA_FIS == 17 && SC_DELTA_YIS == 18 &&
+              SC_DELTA_VIS == 20 && SC_AV_INF == 22 && SC_HREF_V_INF == 24 && SC_STF_PLUS_W_INF == 26 &&
+              SC_COND1 == 27 && SC_COND2 == 28 && SC_TAIL_ITER == 29, "scalar dump pairs out of sync with the SC_* enum");
 
 // ------------------------------------------------------------------------------------------------
-// FwdPassInit (hxx:253-283): joint configuration -> per-joint (cos q, sin q) | (q, 0).  liMi itself is
-// never stored: every sweep rebuilds R = Rp*Rot(q), t from these two scalars + uniform constants.
-// q is instance-major [B][nq] (the caller's layout).
+// host-side plumbing kernels (one lane per instance, tile addressing)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void k_fk_init(const double* __restrict__ q, int nq, const JointDesc* __restrict__ jd,
-                          const int* __restrict__ idx_q, int nb, int B, int ldm, T* __restrict__ cs)
+__device__ __forceinline__ char* lane_ptr(char* tiles, const Layout& L, int b)
+{
+  return tiles + (size_t)(b / WAVE) * L.tile_pairs * pair_bytes<T>() + (size_t)(b % WAVE) * 2 * sizeof(T);
+}
+template <typename T>
+__device__ __forceinline__ T* elem_ptr(char* lp, int pair, int half)
+{
+  return reinterpret_cast<T*>(lp + (size_t)pair * pair_bytes<T>() + (size_t)half * sizeof(T));
+}
+
+// FwdPassInit (hxx:253-283): joint configuration -> per-joint (cos q, sin q) | (q, 0).
+// q is instance-major [B][nq] (the caller's layout) or one shared [nq].
+template <typename T>
+__global__ void k_fk_init(const double* __restrict__ q, int nq, int q_shared, const JointDesc* __restrict__ jd,
+                          const int* __restrict__ idx_q, Layout L, int B, char* tiles)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  for (int i = 1; i <= nb; ++i) {
-    const double qi = q[(size_t)b * nq + idx_q[i]];
+  char* lp = lane_ptr<T>(tiles, L, b);
+  for (int i = 1; i <= L.nb; ++i) {
+    const double qi = q[(q_shared ? 0 : (size_t)b * nq) + idx_q[i]];
     T c, s;
     if (jd[i].flags & JF_REVOLUTE) {
       double sd, cd;
@@ -880,46 +1003,61 @@ __global__ void k_fk_init(const double* __restrict__ q, int nq, const JointDesc*
     } else {
       c = (T)qi; s = T(0);
     }
-    cs[(size_t)(2 * (i - 1)) * ldm + b] = c;
-    cs[(size_t)(2 * (i - 1) + 1) * ldm + b] = s;
+    stp<T>(lp + (size_t)(i - 1) * JREC * pair_bytes<T>(), JP_CS, c, s);
   }
 }
 
-// instance-major [B][n] (double, caller layout) -> SoA [n][ld] (T)
+// instance-major [B][n] doubles (or one shared [n]) -> tile elements given by rowmap[r] = pair*2 + half
 template <typename T>
-__global__ void k_aos_to_soa(const double* __restrict__ src, int n, int B, int ldm, T* __restrict__ dst)
+__global__ void k_upload_rows(const double* __restrict__ src, int n, int shared, const int* __restrict__ rowmap,
+                              Layout L, int B, char* tiles)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  for (int k = 0; k < n; ++k) dst[(size_t)k * ldm + b] = (T)src[(size_t)b * n + k];
+  char* lp = lane_ptr<T>(tiles, L, b);
+  for (int r = 0; r < n; ++r) {
+    const int m = rowmap[r];
+    *elem_ptr<T>(lp, m >> 1, m & 1) = (T)src[(shared ? 0 : (size_t)b * n) + r];
+  }
 }
 
-// SoA [n][ld] (T) -> instance-major [B][n] (double)
+// tile elements -> instance-major [B][n] doubles; as_int: write int32 instead
 template <typename T>
-__global__ void k_soa_to_aos(const T* __restrict__ src, int n, int B, int ldm, double* __restrict__ dst)
+__global__ void k_download_rows(char* tiles, Layout L, const int* __restrict__ rowmap, int n, int B,
+                                double* __restrict__ dst, int as_int, int mask)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  for (int k = 0; k < n; ++k) dst[(size_t)b * n + k] = (double)src[(size_t)k * ldm + b];
+  char* lp = lane_ptr<T>(tiles, L, b);
+  for (int r = 0; r < n; ++r) {
+    const int m = rowmap[r];
+    const T x = *elem_ptr<T>(lp, m >> 1, m & 1);
+    if (as_int) {
+      const int v = (int)x;
+      reinterpret_cast<int*>(dst)[(size_t)b * n + r] = mask ? ((v & mask) ? 1 : 0) : v;
+    } else {
+      dst[(size_t)b * n + r] = (double)x;
+    }
+  }
 }
 
 // per-instance constraint products: AtA (packed), Atb, bis_inf_norm (ik-id-description-optimized.hpp:160-170,
-// :210-215).  A is [nc][36] shared or [nc][36][ld]; b is [nc][6][ld].  grow_only: single-constraint update
-// only ever grows bis_inf_norm_ (hpp:213-215).
+// :210-215).  grow_only: the single-constraint update only ever grows bis_inf_norm_ (hpp:213-215).
 template <typename T>
-__global__ void k_constraint_products(const T* __restrict__ A, const T* __restrict__ bvec, int nc, int c_lo,
-                                      int c_hi, int a_shared, int B, int ldm, T* __restrict__ AtA,
-                                      T* __restrict__ Atb, T* __restrict__ bnorm, int grow_only)
+__global__ void k_constraint_products(char* tiles, Layout L, const T* __restrict__ uni, int a_shared, int c_lo,
+                                      int c_hi, int B, int grow_only)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const size_t a_es = a_shared ? 1 : ldm, a_bs = a_shared ? 0 : 1;
-  T bn = grow_only ? bnorm[b] : T(0);
+  char* lp = lane_ptr<T>(tiles, L, b);
+  char* srec = lp + (size_t)L.off_s * pair_bytes<T>();
+  T bn = grow_only ? *elem_ptr<T>(srec, SP_BI, 0) : T(0);
   for (int c = c_lo; c < c_hi; ++c) {
+    char* crec = lp + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
     T Al[36], bl[6];
-    for (int k = 0; k < 36; ++k) Al[k] = A[(size_t)(c * 36 + k) * a_es + (size_t)b * a_bs];
+    for (int k = 0; k < 36; ++k) Al[k] = a_shared ? uni[c * 36 + k] : *elem_ptr<T>(crec, CP_A + k / 2, k & 1);
     for (int k = 0; k < 6; ++k) {
-      bl[k] = bvec[(size_t)(6 * c + k) * ldm + b];
+      bl[k] = *elem_ptr<T>(crec, CP_B + k / 2, k & 1);
       bn = tmax(bn, tabs(bl[k]));
     }
     if (!a_shared) {
@@ -927,86 +1065,112 @@ __global__ void k_constraint_products(const T* __restrict__ A, const T* __restri
         for (int j = i; j < 6; ++j) {
           T a = T(0);
           for (int k = 0; k < 6; ++k) a += Al[6 * k + i] * Al[6 * k + j];
-          AtA[(size_t)(c * 21 + sym(i, j)) * ldm + b] = a;
+          const int e = sym(i, j);
+          *elem_ptr<T>(crec, CP_ATA + e / 2, e & 1) = a;
         }
     }
     for (int i = 0; i < 6; ++i) {
       T a = T(0);
       for (int k = 0; k < 6; ++k) a += Al[6 * k + i] * bl[k];
-      Atb[(size_t)(6 * c + i) * ldm + b] = a;
+      *elem_ptr<T>(crec, CP_ATB + i / 2, i & 1) = a;
     }
   }
-  bnorm[b] = bn;
+  *elem_ptr<T>(srec, SP_BI, 0) = bn;
 }
 
+// resets (one wavefront per tile), bits of `what`:
+enum : int {
+  RS_DATA_COLD = 1,   // IkIdData::Reset(false): w, z, nu, vis, fis, fis_diff_plus_Aty = 0  (data-optimized.hxx:117-126)
+  RS_RECURSION = 2,   // IkIdData::ResetRecursion: w, z, vis, fis, g, yis, Aty = 0; nu and Stf_plus_w kept (hxx:138-154)
+  RS_SOLVER = 4,      // ResetSolver: iter = 0, flags = 0, mu = mu0, logged scalars = 0 (optimized.hpp:168-186)
+  RS_Y = 8,           // FwdPassInit cold start: yis = 0, Aty = 0 (optimized.hxx:270-278)
+  RS_HCACHE = 16,     // invalidate the H/UDinv/Dinv cache
+};
 template <typename T>
-__global__ void k_fill(T* __restrict__ p, size_t n, T val)
+__global__ void __launch_bounds__(WAVE) k_reset(char* tiles, Layout L, int what, T mu0)
 {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = val;
-}
-
-__global__ void k_fill_int(int* __restrict__ p, size_t n, int val)
-{
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = val;
+  char* lp = tiles + (size_t)blockIdx.x * L.tile_pairs * pair_bytes<T>() + (size_t)threadIdx.x * 2 * sizeof(T);
+  if (what & (RS_DATA_COLD | RS_RECURSION)) {
+    for (int j = 0; j < L.nb; ++j) {
+      char* rec = lp + (size_t)j * JREC * pair_bytes<T>();
+      for (int p = JP_V; p < JP_WZ; ++p) stp<T>(rec, p, T(0), T(0));
+      stp<T>(rec, JP_WZ, T(0), T(0));
+      if (what & RS_DATA_COLD) st_lo<T>(rec, JP_NUS, T(0));
+    }
+  }
+  if (what & (RS_RECURSION | RS_Y)) {
+    for (int c = 0; c < L.nc; ++c) {
+      char* crec = lp + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+      for (int p = CP_Y; p < CP_B; ++p) stp<T>(crec, p, T(0), T(0));
+    }
+  }
+  char* srec = lp + (size_t)L.off_s * pair_bytes<T>();
+  if (what & RS_SOLVER) {
+    st_lo<T>(srec, SP_MU, mu0);
+    st_hi<T>(srec, SP_BI, T(0));
+    stp<T>(srec, SP_ST, T(0), T(0));
+    for (int p = SP_SCAL; p < SREC; ++p) stp<T>(srec, p, T(0), T(0));
+  }
+  if (what & RS_HCACHE) st_hi<T>(srec, SP_MU, T(-1));
 }
 
 // ------------------------------------------------------------------------------------------------
 // lane compaction: physical repack of the live instances of one buffer set into the first slots of another
-// (dense wavefronts again), and return of the finished ones to their home slot.  One source wavefront per
-// workgroup; `wave_off[w]` = exclusive prefix sum of the live-lane counts (host-side scan of `wave_live`).
-// A field is a run of `rows` SoA rows of `esz`-byte elements.
+// (dense wavefronts again), and return of the finished ones to their home slot.  One source wavefront (tile)
+// per workgroup; `wave_off[w]` = exclusive prefix sum of the live-lane counts (host-side scan of `wave_live`).
+// Only the persistent pairs travel; the inter-sweep temporaries are rebuilt (mu_h = -1 forces the H sweep).
 // ------------------------------------------------------------------------------------------------
-struct MoveField {
-  const void* src;
-  void* dst_live;   // destination set (compacted slots)
-  void* dst_home;   // home set (slot = instance id), or nullptr when the source IS the home set
-  int rows;
-  int esz;          // 4 or 8
-};
-constexpr int MAX_MOVE_FIELDS = 32;
 struct MovePlan {
-  MoveField f[MAX_MOVE_FIELDS];
-  int nfields;
-  int n_src;        // slots in use in the source set
-  int ld_src, ld_dst, ld_home;
-  const int* status;     // source status
+  char* src;
+  char* dst_live;
+  char* dst_home;        // nullptr when the source IS the home set
+  Layout L;
+  int n_src;             // slots in use in the source set
+  int move_bounds;       // JP_LBUB travels too (per-instance box)
   const int* map_src;    // slot -> instance id in the source set (nullptr: identity, source is home)
   int* map_dst;          // slot -> instance id in the destination set
-  const int* wave_off;   // [n_src/64]
+  const int* wave_off;   // [source tiles]
   int force_home;        // 1: every slot of the source set goes home (end of the solve)
 };
 
-__global__ void __launch_bounds__(WAVE) k_move(const MovePlan P)
+template <typename T>
+__global__ void __launch_bounds__(WAVE) k_move(const MovePlan M)
 {
+  const Layout& L = M.L;
   const int lane = threadIdx.x;
   const int b = blockIdx.x * WAVE + lane;
-  const bool inb = b < P.n_src;
-  const bool live = inb && !P.force_home && !(P.status[inb ? b : 0] & ST_DONE);
+  const bool inb = b < M.n_src;
+  char* sp = lane_ptr<T>(M.src, L, b);
+  char* ssrec = sp + (size_t)L.off_s * pair_bytes<T>();
+  const int status = inb ? (int)ldp<T>(ssrec, SP_ST).x : ST_DONE;
+  const bool live = inb && !M.force_home && !(status & ST_DONE);
   const unsigned long long mask = __ballot(live);
   const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-  const int inst = inb ? (P.map_src ? P.map_src[b] : b) : 0;
-  const int dst = P.wave_off[blockIdx.x] + rank;
-  const bool to_home = inb && !live && P.map_src != nullptr;
-  if (live) P.map_dst[dst] = inst;
+  const int inst = inb ? (M.map_src ? M.map_src[b] : b) : 0;
+  const int dst = M.wave_off[blockIdx.x] + rank;
+  const bool to_home = inb && !live && M.dst_home != nullptr;
+  if (live) M.map_dst[dst] = inst;
   if (!live && !to_home) return;
-  for (int k = 0; k < P.nfields; ++k) {
-    const MoveField F = P.f[k];
-    if (F.esz == 8) {
-      const unsigned long long* s = (const unsigned long long*)F.src;
-      unsigned long long* d = live ? (unsigned long long*)F.dst_live : (unsigned long long*)F.dst_home;
-      const size_t ldd = live ? P.ld_dst : P.ld_home;
-      const size_t slot = live ? dst : inst;
-      for (int r = 0; r < F.rows; ++r) d[(size_t)r * ldd + slot] = s[(size_t)r * P.ld_src + b];
-    } else {
-      const unsigned int* s = (const unsigned int*)F.src;
-      unsigned int* d = live ? (unsigned int*)F.dst_live : (unsigned int*)F.dst_home;
-      const size_t ldd = live ? P.ld_dst : P.ld_home;
-      const size_t slot = live ? dst : inst;
-      for (int r = 0; r < F.rows; ++r) d[(size_t)r * ldd + slot] = s[(size_t)r * P.ld_src + b];
+  char* dp = live ? lane_ptr<T>(M.dst_live, L, dst) : lane_ptr<T>(M.dst_home, L, inst);
+  for (int j = 0; j < L.nb; ++j) {
+    const char* sr = sp + (size_t)j * JREC * pair_bytes<T>();
+    char* dr = dp + (size_t)j * JREC * pair_bytes<T>();
+#pragma unroll
+    for (int p = 0; p < JP_NPERSIST; ++p) {
+      const typename Vec2<T>::type v = ldp<T>(sr, p);
+      stp<T>(dr, p, v.x, v.y);
+    }
+    if (M.move_bounds) {
+      const typename Vec2<T>::type v = ldp<T>(sr, JP_LBUB);
+      stp<T>(dr, JP_LBUB, v.x, v.y);
     }
   }
+  for (int p = L.off_c; p < L.tile_pairs; ++p) {
+    const typename Vec2<T>::type v = ldp<T>(sp, p);
+    stp<T>(dp, p, v.x, v.y);
+  }
+  // the H/UDinv/Dinv cache did not travel
+  st_hi<T>(dp + (size_t)L.off_s * pair_bytes<T>(), SP_MU, T(-1));
 }
 
 }  // namespace loikb

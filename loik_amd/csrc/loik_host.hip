@@ -9,12 +9,16 @@
 //   loikb_solve_tailored  <- Solve(q,c_id,A,b)  (loik-loid-optimized.hpp:596-695)
 // Reset semantics follow IkIdDataTypeOptimizedTpl::Reset / ResetRecursion
 // (loik-loid-data-optimized.hxx:114-154) and IkProblemFormulationOptimized (ik-id-description-optimized.hpp).
+//
+// Device memory: wavefront tiles (see loik_device.hpp).  Set 0 is the "home" set (tile t, lane l holds instance
+// 64 t + l); sets 1 and 2 are half-size work sets used by lane compaction.
 #include "loik_device.hpp"
 
 #include "../../include/loik_amd.h"
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -36,12 +40,8 @@ static thread_local std::string g_last_error;
 
 namespace {
 
-struct DevMem {
-  void* p = nullptr;
-  size_t bytes = 0;
-};
+constexpr int ROWMAP_CAP = 8192;
 
-// type-erased device workspace; element size chosen at create time
 struct loikb_solver_impl {
   // model (copied)
   int nj = 0, nb = 0, nq = 0, nv = 0;
@@ -50,7 +50,7 @@ struct loikb_solver_impl {
   int stack_levels = 0;
   // options
   loikb_options opt{};
-  int B = 0, ld = 0, nc = 0;
+  int B = 0, nc = 0;
   size_t esz = 8;
   bool f32 = false;
   // problem (uniform part)
@@ -59,30 +59,28 @@ struct loikb_solver_impl {
   std::vector<int> active_ids;
   bool have_problem = false;
   bool a_shared = true, bnd_shared = true;
+  bool href_diag = true;  // H_ref diagonal -> k_solve<T, true>
   // device
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
-  std::vector<DevMem> allocs;
+  std::vector<void*> allocs;
   JointDesc* d_jd = nullptr;
   int* d_idx_q = nullptr;
+  int* d_rowmap = nullptr;
+  void* d_uni = nullptr;               // A[nc][36], AtA[nc][21], lb[nb], ub[nb] (T)
   unsigned int* d_counters = nullptr;
   unsigned int* h_counters = nullptr;  // pinned
-  void* d_stage = nullptr;             // staging for host<->device transposes (doubles)
+  void* d_stage = nullptr;             // staging for host<->device copies
   size_t stage_bytes = 0;
-  // per-instance SoA arrays live in buffer sets: set 0 = home (slot == instance id, capacity ld);
-  // sets 1,2 = compaction work sets (capacity ld/2), allocated on first use
+  // tile layouts: A per instance needs the long constraint record
+  Layout L{};
   struct Set {
-    int ld = 0;
-    bool allocated = false;
-    void *cs = nullptr, *v = nullptr, *f = nullptr, *g = nullptr, *nu = nullptr, *z = nullptr, *w = nullptr,
-         *s = nullptr, *y = nullptr, *aty = nullptr, *H = nullptr, *p = nullptr, *ud = nullptr, *dinv = nullptr,
-         *rr = nullptr, *A = nullptr, *AtA = nullptr, *b = nullptr, *Atb = nullptr, *lb = nullptr, *ub = nullptr,
-         *bnorm = nullptr, *mu = nullptr, *mu_h = nullptr, *scal = nullptr;
-    int *iter = nullptr, *status = nullptr, *map = nullptr, *wave_live = nullptr, *wave_off = nullptr;
+    char* tiles = nullptr;
+    int ntiles = 0;
+    int *map = nullptr, *wave_live = nullptr, *wave_off = nullptr;
   } set[3];
   std::vector<int> h_wave;  // host scratch for the compaction scan
-  // stats of the last solve
   loikb_stats stats{};
 };
 
@@ -91,7 +89,7 @@ int alloc_dev(loikb_solver_impl* S, void** out, size_t bytes)
   void* p = nullptr;
   HIPCHK(hipMalloc(&p, bytes ? bytes : 16));
   HIPCHK(hipMemsetAsync(p, 0, bytes ? bytes : 16, S->stream));
-  S->allocs.push_back({p, bytes});
+  S->allocs.push_back(p);
   *out = p;
   return LOIKB_OK;
 }
@@ -107,31 +105,27 @@ int ensure_stage(loikb_solver_impl* S, size_t bytes)
   return LOIKB_OK;
 }
 
-// allocate every per-instance array of buffer set k with capacity `ld` slots
-int alloc_set(loikb_solver_impl* S, int k, int ld_)
+inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
+inline size_t pair_b(const loikb_solver_impl* S) { return (size_t)WAVE * 2 * S->esz; }
+inline size_t tile_bytes(const loikb_solver_impl* S) { return (size_t)S->L.tile_pairs * pair_b(S); }
+
+int alloc_set(loikb_solver_impl* S, int k, int ntiles)
 {
   loikb_solver_impl::Set& W = S->set[k];
-  if (W.allocated) return LOIKB_OK;
-  const size_t ld = ld_, e = S->esz, nb = S->nb, nc = S->nc > 0 ? S->nc : 1;
-  W.ld = ld_;
+  if (W.tiles) return LOIKB_OK;
   int rc;
-#define A_(field, n) if ((rc = alloc_dev(S, &W.field, (size_t)(n) * ld * e))) return rc
-  A_(cs, 2 * nb); A_(v, 6 * nb); A_(f, 6 * nb); A_(g, 6 * nb); A_(nu, nb); A_(z, nb); A_(w, nb); A_(s, nb);
-  A_(y, 6 * nc); A_(aty, 6 * nc); A_(H, 21 * nb); A_(p, 6 * nb); A_(ud, 6 * nb); A_(dinv, nb); A_(rr, nb);
-  A_(A, 36 * nc); A_(AtA, 21 * nc); A_(b, 6 * nc); A_(Atb, 6 * nc); A_(lb, nb); A_(ub, nb); A_(bnorm, 1);
-  A_(mu, 1); A_(mu_h, 1); A_(scal, NSCAL);
-#undef A_
   void* tmp = nullptr;
-  if ((rc = alloc_dev(S, &tmp, sizeof(int) * ld))) return rc; W.iter = (int*)tmp;
-  if ((rc = alloc_dev(S, &tmp, sizeof(int) * ld))) return rc; W.status = (int*)tmp;
-  if ((rc = alloc_dev(S, &tmp, sizeof(int) * ld))) return rc; W.map = (int*)tmp;
-  if ((rc = alloc_dev(S, &tmp, sizeof(int) * (ld / WAVE + 1)))) return rc; W.wave_live = (int*)tmp;
-  if ((rc = alloc_dev(S, &tmp, sizeof(int) * (ld / WAVE + 1)))) return rc; W.wave_off = (int*)tmp;
-  W.allocated = true;
+  if ((rc = alloc_dev(S, &tmp, tile_bytes(S) * ntiles))) return rc;
+  W.tiles = (char*)tmp;
+  W.ntiles = ntiles;
+  if ((rc = alloc_dev(S, &tmp, sizeof(int) * (size_t)ntiles * WAVE))) return rc;
+  W.map = (int*)tmp;
+  if ((rc = alloc_dev(S, &tmp, sizeof(int) * ((size_t)ntiles + 1)))) return rc;
+  W.wave_live = (int*)tmp;
+  if ((rc = alloc_dev(S, &tmp, sizeof(int) * ((size_t)ntiles + 1)))) return rc;
+  W.wave_off = (int*)tmp;
   return LOIKB_OK;
 }
-
-inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 // build the uniform per-joint schedule from the Pinocchio-style model
 int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
@@ -167,11 +161,9 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
     const int p = S->parents[i];
     if (subtree_end[i] > subtree_end[p]) subtree_end[p] = subtree_end[i];
   }
-  for (int i = 1; i < nj; ++i) {
-    // every joint in (i, subtree_end[i]] must have its parent inside [i, subtree_end[i]]
+  for (int i = 1; i < nj; ++i)
     for (int k = i + 1; k <= subtree_end[i]; ++k)
       if (S->parents[k] < i) { g_last_error = "model: joints are not numbered depth-first"; return LOIKB_ERR_MODEL; }
-  }
   S->jd.assign(nj, JointDesc{});
   for (int i = 1; i < nj; ++i) {
     JointDesc& d = S->jd[i];
@@ -213,20 +205,13 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
 }
 
 template <typename T>
-Bufs<T> make_bufs(loikb_solver_impl* S, int k = 0)
+Bufs<T> make_bufs(loikb_solver_impl* S, int k)
 {
-  const loikb_solver_impl::Set& W = S->set[k];
-  const loikb_solver_impl::Set& H0 = S->set[0];
   Bufs<T> Bf{};
-  Bf.cs = (const T*)W.cs; Bf.v = (T*)W.v; Bf.f = (T*)W.f; Bf.g = (T*)W.g; Bf.nu = (T*)W.nu; Bf.z = (T*)W.z;
-  Bf.w = (T*)W.w; Bf.s = (T*)W.s; Bf.y = (T*)W.y; Bf.aty = (T*)W.aty; Bf.H = (T*)W.H; Bf.p = (T*)W.p;
-  Bf.ud = (T*)W.ud; Bf.dinv = (T*)W.dinv; Bf.rr = (T*)W.rr;
-  // shared inputs exist once (in the home set); per-instance inputs travel with the instance
-  Bf.A = (const T*)(S->a_shared ? H0.A : W.A); Bf.AtA = (const T*)(S->a_shared ? H0.AtA : W.AtA);
-  Bf.b = (const T*)W.b; Bf.Atb = (const T*)W.Atb;
-  Bf.lb = (const T*)(S->bnd_shared ? H0.lb : W.lb); Bf.ub = (const T*)(S->bnd_shared ? H0.ub : W.ub);
-  Bf.bnorm = (const T*)W.bnorm; Bf.mu = (T*)W.mu; Bf.mu_h = (T*)W.mu_h; Bf.iter = W.iter; Bf.status = W.status;
-  Bf.scal = (T*)W.scal; Bf.counters = S->d_counters; Bf.wave_live = W.wave_live;
+  Bf.tiles = S->set[k].tiles;
+  Bf.uni = (const T*)S->d_uni;
+  Bf.counters = S->d_counters;
+  Bf.wave_live = S->set[k].wave_live;
   return Bf;
 }
 
@@ -247,152 +232,72 @@ Params<T> make_params(loikb_solver_impl* S)
   if (S->a_shared) mode |= MODE_A_SHARED;
   if (S->bnd_shared) mode |= MODE_BND_SHARED;
   P.mode = mode;
-  P.nb = S->nb; P.nc = S->nc; P.B = S->B; P.ld = S->ld;
-  P.max_launch_iters = S->opt.max_launch_iters > 0 ? S->opt.max_launch_iters : (S->opt.max_iter + 1);
-  P.stack_levels = S->stack_levels;
+  P.B = S->B;
+  P.max_launch_iters = S->opt.max_iter + 1;
+  P.L = S->L;
   return P;
 }
 
-// memset a whole SoA field
-int zero_field(loikb_solver_impl* S, void* p, size_t rows)
+// one k_reset launch over the home set
+int reset_home(loikb_solver_impl* S, int what)
 {
-  HIPCHK(hipMemsetAsync(p, 0, rows * (size_t)S->ld * S->esz, S->stream));
-  return LOIKB_OK;
-}
-
-template <typename T>
-int fill_field(loikb_solver_impl* S, void* p, size_t n, double val)
-{
-  hipLaunchKernelGGL(k_fill<T>, grid1(n), dim3(256), 0, S->stream, (T*)p, n, (T)val);
+  const dim3 grid(S->set[0].ntiles), block(WAVE);
+  if (S->f32) hipLaunchKernelGGL(k_reset<float>, grid, block, 0, S->stream, S->set[0].tiles, S->L, what, (float)S->opt.mu);
+  else hipLaunchKernelGGL(k_reset<double>, grid, block, 0, S->stream, S->set[0].tiles, S->L, what, (double)S->opt.mu);
   HIPCHK(hipGetLastError());
   return LOIKB_OK;
 }
 
-// IkIdDataTypeOptimizedTpl::Reset(warm_start), loik-loid-data-optimized.hxx:114-127
-int data_reset(loikb_solver_impl* S, bool warm_start)
+// make `src` (host or device, `bytes`) readable by a kernel: returns a device pointer
+int to_device(loikb_solver_impl* S, const void* src, size_t bytes, bool src_device, const void** out)
 {
-  if (warm_start) return LOIKB_OK;
-  int rc;
-  if ((rc = zero_field(S, S->set[0].w, S->nb))) return rc;
-  if ((rc = zero_field(S, S->set[0].z, S->nb))) return rc;
-  if ((rc = zero_field(S, S->set[0].nu, S->nb))) return rc;
-  if ((rc = zero_field(S, S->set[0].v, 6 * (size_t)S->nb))) return rc;
-  if ((rc = zero_field(S, S->set[0].f, 6 * (size_t)S->nb))) return rc;
-  if ((rc = zero_field(S, S->set[0].g, 6 * (size_t)S->nb))) return rc;
-  return LOIKB_OK;
-}
-
-// ResetRecursion(), loik-loid-data-optimized.hxx:138-154 (nu and Stf_plus_w are NOT reset upstream)
-int data_reset_recursion(loikb_solver_impl* S)
-{
-  int rc;
-  if ((rc = zero_field(S, S->set[0].w, S->nb))) return rc;
-  if ((rc = zero_field(S, S->set[0].z, S->nb))) return rc;
-  if ((rc = zero_field(S, S->set[0].v, 6 * (size_t)S->nb))) return rc;
-  if ((rc = zero_field(S, S->set[0].f, 6 * (size_t)S->nb))) return rc;
-  if ((rc = zero_field(S, S->set[0].g, 6 * (size_t)S->nb))) return rc;
-  if ((rc = zero_field(S, S->set[0].y, 6 * (size_t)S->nc))) return rc;
-  if ((rc = zero_field(S, S->set[0].aty, 6 * (size_t)S->nc))) return rc;
-  return LOIKB_OK;
-}
-
-// ResetSolver(), loik-loid-optimized.hpp:168-186 + Base::Reset task-solver-base.hpp:73-84
-int reset_solver(loikb_solver_impl* S)
-{
-  int rc;
-  HIPCHK(hipMemsetAsync(S->set[0].iter, 0, sizeof(int) * (size_t)S->ld, S->stream));
-  HIPCHK(hipMemsetAsync(S->set[0].status, 0, sizeof(int) * (size_t)S->ld, S->stream));
-  if ((rc = zero_field(S, S->set[0].scal, NSCAL))) return rc;
-  if (S->f32) rc = fill_field<float>(S, S->set[0].mu, S->ld, S->opt.mu);
-  else rc = fill_field<double>(S, S->set[0].mu, S->ld, S->opt.mu);
-  return rc;
-}
-
-int invalidate_h_cache(loikb_solver_impl* S)
-{
-  if (S->f32) return fill_field<float>(S, S->set[0].mu_h, S->ld, -1.0);
-  return fill_field<double>(S, S->set[0].mu_h, S->ld, -1.0);
-}
-
-// bring a per-instance instance-major double array [B][n] (host or device) into SoA [n][ld] of T
-int upload_aos(loikb_solver_impl* S, const double* src, int n, void* dst, bool src_device, bool shared)
-{
-  const size_t count = shared ? (size_t)n : (size_t)S->B * n;
-  const double* dsrc = src;
-  if (!src_device) {
-    int rc = ensure_stage(S, count * sizeof(double));
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(S->d_stage, src, count * sizeof(double), hipMemcpyHostToDevice, S->stream));
-    dsrc = (const double*)S->d_stage;
-  }
-  if (shared) {
-    // [n] -> [n] (T); a 1-"instance" transpose with ld = 1
-    if (S->f32) hipLaunchKernelGGL(k_aos_to_soa<float>, dim3(1), dim3(64), 0, S->stream, dsrc, n, 1, 1, (float*)dst);
-    else hipLaunchKernelGGL(k_aos_to_soa<double>, dim3(1), dim3(64), 0, S->stream, dsrc, n, 1, 1, (double*)dst);
-  } else {
-    if (S->f32)
-      hipLaunchKernelGGL(k_aos_to_soa<float>, grid1(S->B), dim3(256), 0, S->stream, dsrc, n, S->B, S->ld, (float*)dst);
-    else
-      hipLaunchKernelGGL(k_aos_to_soa<double>, grid1(S->B), dim3(256), 0, S->stream, dsrc, n, S->B, S->ld, (double*)dst);
-  }
-  HIPCHK(hipGetLastError());
-  if (!src_device) HIPCHK(hipStreamSynchronize(S->stream));  // staging buffer is reused
-  return LOIKB_OK;
-}
-
-// a per-instance array given once ([n], host) and replicated to every instance: SoA rows filled with a constant
-int upload_broadcast(loikb_solver_impl* S, const double* src, int n, void* dst)
-{
-  for (int k = 0; k < n; ++k) {
-    int rc;
-    if (S->f32) rc = fill_field<float>(S, (float*)dst + (size_t)k * S->ld, S->ld, src[k]);
-    else rc = fill_field<double>(S, (double*)dst + (size_t)k * S->ld, S->ld, src[k]);
-    if (rc) return rc;
-  }
-  return LOIKB_OK;
-}
-
-// FwdPassInit(q), loik-loid-optimized.hxx:253-283
-int fwd_pass_init(loikb_solver_impl* S, const double* q, int in_flags)
-{
-  const bool dev = in_flags & LOIKB_IN_DEVICE;
-  const double* dq = q;
-  std::vector<double> rep;
-  if (in_flags & LOIKB_Q_SHARED) {
-    // replicate on the host (single-instance convenience path)
-    rep.resize((size_t)S->B * S->nq);
-    std::vector<double> hq(S->nq);
-    if (dev) {
-      HIPCHK(hipMemcpyAsync(hq.data(), q, sizeof(double) * S->nq, hipMemcpyDeviceToHost, S->stream));
-      HIPCHK(hipStreamSynchronize(S->stream));
-    } else {
-      memcpy(hq.data(), q, sizeof(double) * S->nq);
-    }
-    for (int b = 0; b < S->B; ++b) memcpy(&rep[(size_t)b * S->nq], hq.data(), sizeof(double) * S->nq);
-    q = rep.data();
-  }
-  if (!dev || (in_flags & LOIKB_Q_SHARED)) {
-    const size_t bytes = (size_t)S->B * S->nq * sizeof(double);
-    int rc = ensure_stage(S, bytes);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(S->d_stage, q, bytes, hipMemcpyHostToDevice, S->stream));
-    dq = (const double*)S->d_stage;
-  }
-  if (S->f32)
-    hipLaunchKernelGGL(k_fk_init<float>, grid1(S->B), dim3(256), 0, S->stream, dq, S->nq, S->d_jd, S->d_idx_q, S->nb,
-                       S->B, S->ld, (float*)S->set[0].cs);
-  else
-    hipLaunchKernelGGL(k_fk_init<double>, grid1(S->B), dim3(256), 0, S->stream, dq, S->nq, S->d_jd, S->d_idx_q, S->nb,
-                       S->B, S->ld, (double*)S->set[0].cs);
-  HIPCHK(hipGetLastError());
-  if (dq == S->d_stage) HIPCHK(hipStreamSynchronize(S->stream));
-  // H/UDinv/Dinv cache depends on liMi
-  int rc = invalidate_h_cache(S);
+  if (src_device) { *out = src; return LOIKB_OK; }
+  int rc = ensure_stage(S, bytes);
   if (rc) return rc;
-  // cold start: yis = 0, Aty = 0 (hxx:270-278)
-  if (!S->opt.warm_start) {
-    if ((rc = zero_field(S, S->set[0].y, 6 * (size_t)S->nc))) return rc;
-    if ((rc = zero_field(S, S->set[0].aty, 6 * (size_t)S->nc))) return rc;
+  HIPCHK(hipMemcpyAsync(S->d_stage, src, bytes, hipMemcpyHostToDevice, S->stream));
+  *out = S->d_stage;
+  return LOIKB_OK;
+}
+
+int set_rowmap(loikb_solver_impl* S, const std::vector<int>& rm)
+{
+  if ((int)rm.size() > ROWMAP_CAP) { g_last_error = "row map too large"; return LOIKB_ERR_ARG; }
+  // rm is a local of the caller: the copy must complete before it goes out of scope
+  HIPCHK(hipMemcpyAsync(S->d_rowmap, rm.data(), sizeof(int) * rm.size(), hipMemcpyHostToDevice, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  return LOIKB_OK;
+}
+
+// instance-major [B][n] doubles (or one shared [n] replicated to every instance) -> tile elements
+int upload_rows(loikb_solver_impl* S, const double* src, const std::vector<int>& rm, bool src_device, bool shared)
+{
+  const int n = (int)rm.size();
+  const void* dsrc = nullptr;
+  int rc;
+  if ((rc = set_rowmap(S, rm))) return rc;
+  if ((rc = to_device(S, src, sizeof(double) * (shared ? (size_t)n : (size_t)S->B * n), src_device && !shared, &dsrc))) return rc;
+  if (S->f32)
+    hipLaunchKernelGGL(k_upload_rows<float>, grid1(S->B), dim3(256), 0, S->stream, (const double*)dsrc, n, (int)shared,
+                       S->d_rowmap, S->L, S->B, S->set[0].tiles);
+  else
+    hipLaunchKernelGGL(k_upload_rows<double>, grid1(S->B), dim3(256), 0, S->stream, (const double*)dsrc, n, (int)shared,
+                       S->d_rowmap, S->L, S->B, S->set[0].tiles);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(S->stream));  // staging buffer / rowmap are reused
+  return LOIKB_OK;
+}
+
+// uniform inputs (shared A/AtA, shared bounds) as T
+int upload_uni(loikb_solver_impl* S, int offset, const double* src, int n)
+{
+  if (S->f32) {
+    std::vector<float> tmp(n);
+    for (int k = 0; k < n; ++k) tmp[k] = (float)src[k];
+    HIPCHK(hipMemcpyAsync((float*)S->d_uni + offset, tmp.data(), sizeof(float) * n, hipMemcpyHostToDevice, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
+  } else {
+    HIPCHK(hipMemcpyAsync((double*)S->d_uni + offset, src, sizeof(double) * n, hipMemcpyHostToDevice, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
   }
   return LOIKB_OK;
 }
@@ -404,22 +309,40 @@ int upload_jd(loikb_solver_impl* S)
   return LOIKB_OK;
 }
 
+// FwdPassInit(q), loik-loid-optimized.hxx:253-283
+int fwd_pass_init(loikb_solver_impl* S, const double* q, int in_flags)
+{
+  const bool shared = in_flags & LOIKB_Q_SHARED;
+  const bool dev = (in_flags & LOIKB_IN_DEVICE) && !shared;
+  const void* dq = nullptr;
+  int rc = to_device(S, q, sizeof(double) * (shared ? (size_t)S->nq : (size_t)S->B * S->nq), dev, &dq);
+  if (rc) return rc;
+  if (S->f32)
+    hipLaunchKernelGGL(k_fk_init<float>, grid1(S->B), dim3(256), 0, S->stream, (const double*)dq, S->nq, (int)shared,
+                       S->d_jd, S->d_idx_q, S->L, S->B, S->set[0].tiles);
+  else
+    hipLaunchKernelGGL(k_fk_init<double>, grid1(S->B), dim3(256), 0, S->stream, (const double*)dq, S->nq, (int)shared,
+                       S->d_jd, S->d_idx_q, S->L, S->B, S->set[0].tiles);
+  HIPCHK(hipGetLastError());
+  if (!dev) HIPCHK(hipStreamSynchronize(S->stream));
+  // the H/UDinv/Dinv cache depends on liMi; cold start: yis = 0, Aty = 0 (hxx:270-278)
+  return reset_home(S, RS_HCACHE | (S->opt.warm_start ? 0 : RS_Y));
+}
+
 int constraint_products(loikb_solver_impl* S, int c_lo, int c_hi, bool grow_only)
 {
   if (S->f32)
-    hipLaunchKernelGGL(k_constraint_products<float>, grid1(S->B), dim3(256), 0, S->stream, (const float*)S->set[0].A,
-                       (const float*)S->set[0].b, S->nc, c_lo, c_hi, (int)S->a_shared, S->B, S->ld, (float*)S->set[0].AtA,
-                       (float*)S->set[0].Atb, (float*)S->set[0].bnorm, (int)grow_only);
+    hipLaunchKernelGGL(k_constraint_products<float>, grid1(S->B), dim3(256), 0, S->stream, S->set[0].tiles, S->L,
+                       (const float*)S->d_uni, (int)S->a_shared, c_lo, c_hi, S->B, (int)grow_only);
   else
-    hipLaunchKernelGGL(k_constraint_products<double>, grid1(S->B), dim3(256), 0, S->stream, (const double*)S->set[0].A,
-                       (const double*)S->set[0].b, S->nc, c_lo, c_hi, (int)S->a_shared, S->B, S->ld, (double*)S->set[0].AtA,
-                       (double*)S->set[0].Atb, (double*)S->set[0].bnorm, (int)grow_only);
+    hipLaunchKernelGGL(k_constraint_products<double>, grid1(S->B), dim3(256), 0, S->stream, S->set[0].tiles, S->L,
+                       (const double*)S->d_uni, (int)S->a_shared, c_lo, c_hi, S->B, (int)grow_only);
   HIPCHK(hipGetLastError());
   return LOIKB_OK;
 }
 
-// shared A: AtA computed once on the host (ik-id-description-optimized.hpp:162)
-int upload_shared_AtA(loikb_solver_impl* S, const double* A, int c)
+// shared A: A and AtA computed once on the host (ik-id-description-optimized.hpp:162)
+int upload_shared_A(loikb_solver_impl* S, const double* A, int c)
 {
   double AtA[21];
   for (int i = 0; i < 6; ++i)
@@ -428,16 +351,52 @@ int upload_shared_AtA(loikb_solver_impl* S, const double* A, int c)
       for (int k = 0; k < 6; ++k) a += A[6 * k + i] * A[6 * k + j];
       AtA[sym(i, j)] = a;
     }
-  if (S->f32) {
-    float tmp[21];
-    for (int k = 0; k < 21; ++k) tmp[k] = (float)AtA[k];
-    HIPCHK(hipMemcpyAsync((float*)S->set[0].AtA + 21 * c, tmp, sizeof(tmp), hipMemcpyHostToDevice, S->stream));
+  int rc;
+  if ((rc = upload_uni(S, c * 36, A, 36))) return rc;
+  return upload_uni(S, S->nc * 36 + c * 21, AtA, 21);
+}
+
+std::vector<int> rowmap_constraint(const loikb_solver_impl* S, int c, int first_pair, int n)
+{
+  std::vector<int> rm(n);
+  for (int k = 0; k < n; ++k) rm[k] = (S->L.off_c + c * S->L.crec + first_pair + k / 2) * 2 + (k & 1);
+  return rm;
+}
+
+// the tile layout depends on whether A is shared (short constraint record) -> (re)allocate the sets on change
+int ensure_layout(loikb_solver_impl* S, bool a_shared)
+{
+  Layout L{};
+  L.nb = S->nb; L.nc = S->nc;
+  L.crec = a_shared ? CREC_SHARED_A : CREC_FULL;
+  L.off_c = S->nb * JREC;
+  L.off_s = L.off_c + S->nc * L.crec;
+  L.tile_pairs = L.off_s + SREC;
+  // odd number of 1-KiB pairs per tile: consecutive tiles (= wavefronts that run in lockstep through the same joint
+  // offsets) then start on different HBM channel groups instead of camping on a few of them
+  if (const char* e = getenv("LOIKB_TILE_PAD")) L.tile_pairs += atoi(e);
+  else if (!(L.tile_pairs & 1)) L.tile_pairs += 1;
+  if (S->set[0].tiles && L.crec == S->L.crec) return LOIKB_OK;
+  if (S->set[0].tiles) {
+    // sharing mode of A changed: every tile has a different size now
     HIPCHK(hipStreamSynchronize(S->stream));
-  } else {
-    HIPCHK(hipMemcpyAsync((double*)S->set[0].AtA + 21 * c, AtA, sizeof(AtA), hipMemcpyHostToDevice, S->stream));
-    HIPCHK(hipStreamSynchronize(S->stream));
+    for (int k = 0; k < 3; ++k) {
+      loikb_solver_impl::Set& W = S->set[k];
+      void* ptrs[4] = {W.tiles, W.map, W.wave_live, W.wave_off};
+      for (void* p : ptrs)
+        if (p) {
+          (void)hipFree(p);
+          for (auto& a : S->allocs) if (a == p) a = nullptr;
+        }
+      W = loikb_solver_impl::Set{};
+    }
+    S->have_problem = false;
   }
-  return LOIKB_OK;
+  S->L = L;
+  int rc = alloc_set(S, 0, (S->B + WAVE - 1) / WAVE);
+  if (rc) return rc;
+  // fresh tiles: the reference ctor state is all-zero data (loik-loid-data-optimized.hxx:40-86) + ResetSolver
+  return reset_home(S, RS_SOLVER | RS_HCACHE);
 }
 
 // problem_.UpdateReference / UpdateIneqConstraints / UpdateEqConstraints (ik-id-description-optimized.hpp:78-171,
@@ -459,9 +418,14 @@ int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, 
       if (c_ids[c2] == c_ids[c]) { g_last_error = "multiple constraints on the same link"; return LOIKB_ERR_DUP_CONSTRAINT; }
   }
   const bool dev = in_flags & LOIKB_IN_DEVICE;
+  int rc;
   // UpdateReference: Hv = H_ref v_ref, Hv_inf_norm_ (hpp:85-96)
   memcpy(S->Href, H_ref, sizeof(S->Href));
   memcpy(S->vref, v_ref, sizeof(S->vref));
+  S->href_diag = true;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j)
+      if (i != j && H_ref[6 * i + j] != 0.0) S->href_diag = false;
   S->Hv_inf_norm = 0.0;
   for (int i = 0; i < 6; ++i) {
     double a = 0.0;
@@ -471,83 +435,74 @@ int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, 
   }
   // UpdateIneqConstraints
   S->bnd_shared = in_flags & LOIKB_BOUNDS_SHARED;
-  int rc;
-  if ((rc = upload_aos(S, lb, S->nv, S->set[0].lb, dev && !S->bnd_shared, S->bnd_shared))) return rc;
-  if ((rc = upload_aos(S, ub, S->nv, S->set[0].ub, dev && !S->bnd_shared, S->bnd_shared))) return rc;
+  if (S->bnd_shared) {
+    if ((rc = upload_uni(S, S->nc * 57, lb, S->nv))) return rc;
+    if ((rc = upload_uni(S, S->nc * 57 + S->nb, ub, S->nv))) return rc;
+  } else {
+    std::vector<int> rl(S->nb), ru(S->nb);
+    for (int j = 0; j < S->nb; ++j) { rl[j] = (j * JREC + JP_LBUB) * 2; ru[j] = rl[j] + 1; }
+    if ((rc = upload_rows(S, lb, rl, dev, false))) return rc;
+    if ((rc = upload_rows(S, ub, ru, dev, false))) return rc;
+  }
   // UpdateEqConstraints
   S->active_ids.assign(c_ids, c_ids + nc);
   for (int i = 1; i < S->nj; ++i) S->jd[i].cslot = -1;
   for (int c = 0; c < nc; ++c) S->jd[c_ids[c]].cslot = c;
   if ((rc = upload_jd(S))) return rc;
   S->a_shared = in_flags & LOIKB_A_SHARED;
-  if ((rc = upload_aos(S, Ais, 36 * nc, S->set[0].A, dev && !S->a_shared, S->a_shared))) return rc;
-  if (S->a_shared)
-    for (int c = 0; c < nc; ++c)
-      if ((rc = upload_shared_AtA(S, Ais + 36 * c, c))) return rc;
-  if (in_flags & LOIKB_B_SHARED) rc = upload_broadcast(S, bis, 6 * nc, S->set[0].b);
-  else rc = upload_aos(S, bis, 6 * nc, S->set[0].b, dev, false);
-  if (rc) return rc;
+  for (int c = 0; c < nc; ++c) {
+    if (S->a_shared) {
+      if ((rc = upload_shared_A(S, Ais + 36 * c, c))) return rc;
+    }
+  }
+  if (!S->a_shared && nc > 0) {
+    std::vector<int> rm;
+    for (int c = 0; c < nc; ++c) { auto r = rowmap_constraint(S, c, CP_A, 36); rm.insert(rm.end(), r.begin(), r.end()); }
+    if ((rc = upload_rows(S, Ais, rm, dev, false))) return rc;
+  }
+  if (nc > 0) {
+    std::vector<int> rm;
+    for (int c = 0; c < nc; ++c) { auto r = rowmap_constraint(S, c, CP_B, 6); rm.insert(rm.end(), r.begin(), r.end()); }
+    if ((rc = upload_rows(S, bis, rm, dev, in_flags & LOIKB_B_SHARED))) return rc;
+  }
   if ((rc = constraint_products(S, 0, nc, false))) return rc;
   S->have_problem = true;
   return LOIKB_OK;
 }
 
-// list of the per-instance arrays that travel with an instance when it changes buffer set.  Inter-sweep
-// temporaries (H, p, UDinv, Dinv, r) stay behind: they are rebuilt by the first sweep after the move (mu_h = -1).
-template <typename T>
-void fill_move_plan(loikb_solver_impl* S, int src, int dst, MovePlan& M)
-{
-  const loikb_solver_impl::Set &A = S->set[src], &D = S->set[dst], &H0 = S->set[0];
-  const int nb = S->nb, nc = S->nc, e = (int)sizeof(T);
-  int k = 0;
-  auto add = [&](const void* s, void* dl, void* dh, int rows, int esz) {
-    M.f[k].src = s; M.f[k].dst_live = dl; M.f[k].dst_home = src == 0 ? nullptr : dh; M.f[k].rows = rows; M.f[k].esz = esz;
-    ++k;
-  };
-  add(A.cs, D.cs, H0.cs, 2 * nb, e); add(A.v, D.v, H0.v, 6 * nb, e); add(A.f, D.f, H0.f, 6 * nb, e);
-  add(A.g, D.g, H0.g, 6 * nb, e); add(A.nu, D.nu, H0.nu, nb, e); add(A.z, D.z, H0.z, nb, e);
-  add(A.w, D.w, H0.w, nb, e); add(A.s, D.s, H0.s, nb, e); add(A.y, D.y, H0.y, 6 * nc, e);
-  add(A.aty, D.aty, H0.aty, 6 * nc, e); add(A.b, D.b, H0.b, 6 * nc, e); add(A.Atb, D.Atb, H0.Atb, 6 * nc, e);
-  add(A.bnorm, D.bnorm, H0.bnorm, 1, e); add(A.mu, D.mu, H0.mu, 1, e); add(A.scal, D.scal, H0.scal, NSCAL, e);
-  add(A.iter, D.iter, H0.iter, 1, 4); add(A.status, D.status, H0.status, 1, 4);
-  if (!S->a_shared) { add(A.A, D.A, H0.A, 36 * nc, e); add(A.AtA, D.AtA, H0.AtA, 21 * nc, e); }
-  if (!S->bnd_shared) { add(A.lb, D.lb, H0.lb, nb, e); add(A.ub, D.ub, H0.ub, nb, e); }
-  M.nfields = k;
-  M.ld_src = A.ld; M.ld_dst = D.ld; M.ld_home = H0.ld;
-  M.status = A.status;
-  M.map_src = src == 0 ? nullptr : A.map;
-  M.map_dst = D.map;
-  M.wave_off = A.wave_off;
-  M.force_home = 0;
-}
-
-// move the live instances of set `src` (n_src slots) to the first slots of set `dst`; finished ones go home
+// move the live instances of set `src` (n_src slots) to the first slots of set `dst`; finished ones go home.
+// dst < 0: end of the solve, everything still in a work set goes home.
 template <typename T>
 int compact(loikb_solver_impl* S, int src, int dst, int n_src, int* n_dst_out)
 {
   loikb_solver_impl::Set& A = S->set[src];
   const int nw = (n_src + WAVE - 1) / WAVE;
   int rc;
-  if (dst >= 0 && (rc = alloc_set(S, dst, ((S->ld / 2 + WAVE - 1) / WAVE) * WAVE))) return rc;
+  if (dst >= 0 && (rc = alloc_set(S, dst, (S->set[0].ntiles + 1) / 2))) return rc;
   // exclusive scan of the per-wavefront live counts on the host (nw <= B/64 ints)
   S->h_wave.resize(2 * (size_t)nw + 2);
   int* cnt = S->h_wave.data();
   int* off = cnt + nw + 1;
-  HIPCHK(hipMemcpyAsync(cnt, A.wave_live, sizeof(int) * nw, hipMemcpyDeviceToHost, S->stream));
-  HIPCHK(hipStreamSynchronize(S->stream));
   int total = 0;
-  for (int w = 0; w < nw; ++w) { off[w] = total; total += dst >= 0 ? cnt[w] : 0; }
-  HIPCHK(hipMemcpyAsync(A.wave_off, off, sizeof(int) * nw, hipMemcpyHostToDevice, S->stream));
-  MovePlan M{};
-  fill_move_plan<T>(S, src, dst >= 0 ? dst : 0, M);
-  M.n_src = n_src;
-  M.force_home = dst < 0;
-  hipLaunchKernelGGL(k_move, dim3(nw), dim3(WAVE), 0, S->stream, M);
-  HIPCHK(hipGetLastError());
   if (dst >= 0) {
-    // the H/UDinv/Dinv cache did not travel
-    if ((rc = fill_field<T>(S, S->set[dst].mu_h, total, -1.0))) return rc;
+    HIPCHK(hipMemcpyAsync(cnt, A.wave_live, sizeof(int) * nw, hipMemcpyDeviceToHost, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
+    for (int w = 0; w < nw; ++w) { off[w] = total; total += cnt[w]; }
+    HIPCHK(hipMemcpyAsync(A.wave_off, off, sizeof(int) * nw, hipMemcpyHostToDevice, S->stream));
   }
+  MovePlan M{};
+  M.src = A.tiles;
+  M.dst_live = dst >= 0 ? S->set[dst].tiles : nullptr;
+  M.dst_home = src == 0 ? nullptr : S->set[0].tiles;
+  M.L = S->L;
+  M.n_src = n_src;
+  M.move_bounds = !S->bnd_shared;
+  M.map_src = src == 0 ? nullptr : A.map;
+  M.map_dst = dst >= 0 ? S->set[dst].map : nullptr;
+  M.wave_off = A.wave_off;
+  M.force_home = dst < 0;
+  hipLaunchKernelGGL(k_move<T>, dim3(nw), dim3(WAVE), 0, S->stream, M);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(S->stream));  // h_wave is reused
   if (n_dst_out) *n_dst_out = total;
   return LOIKB_OK;
@@ -565,8 +520,8 @@ int run_main_loop_t(loikb_solver_impl* S)
   // main-loop bound: at most max_iter-1 iterations, tail solve may reach max_iter (hpp:377, :276)
   const int max_total = S->opt.max_iter + 1;
   const bool can_compact = !(S->opt.flags & LOIKB_OPT_NO_COMPACTION) && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS);
-  // compaction pays only while the launch is bandwidth-bound (many wavefronts); below ~COMPACT_MIN_WAVES
-  // wavefronts an ADMM iteration costs the same single-wavefront latency however few lanes are live
+  // compaction pays only while the launch is bandwidth-bound (many wavefronts); below that an ADMM iteration
+  // costs the same single-wavefront latency however few lanes are live
   const int compact_min = S->opt.compact_min_instances > 0 ? S->opt.compact_min_instances : 64 * WAVE;
   int cur = 0, n_cur = S->B;
   int done_iters = 0;
@@ -577,13 +532,13 @@ int run_main_loop_t(loikb_solver_impl* S)
     int launch_iters = S->opt.max_launch_iters > 0 ? S->opt.max_launch_iters : (may_compact_later ? 8 : max_total);
     if (launch_iters > max_total - done_iters) launch_iters = max_total - done_iters;
     P.B = n_cur;
-    P.ld = S->set[cur].ld;
     P.max_launch_iters = launch_iters;
     Bufs<T> Bf = make_bufs<T>(S, cur);
     const dim3 grid((unsigned)((n_cur + WAVE - 1) / WAVE)), block(WAVE);
     HIPCHK(hipMemsetAsync(S->d_counters, 0, 2 * sizeof(unsigned int), S->stream));
     HIPCHK(hipEventRecord(S->ev_k0, S->stream));
-    hipLaunchKernelGGL(k_solve<T>, grid, block, lds, S->stream, P, Bf, (const JointDesc*)S->d_jd);
+    if (S->href_diag) hipLaunchKernelGGL((k_solve<T, true>), grid, block, lds, S->stream, P, Bf, (const JointDesc*)S->d_jd);
+    else hipLaunchKernelGGL((k_solve<T, false>), grid, block, lds, S->stream, P, Bf, (const JointDesc*)S->d_jd);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(S->ev_k1, S->stream));
     HIPCHK(hipMemcpyAsync(S->h_counters, S->d_counters, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
@@ -632,24 +587,19 @@ int run_main_loop(loikb_solver_impl* S)
 }
 
 template <typename T>
-__global__ void k_limi(const T* __restrict__ cs, const JointDesc* __restrict__ jd, int nb, int B, int ldm,
-                       double* __restrict__ out)
+__global__ void k_limi(char* tiles, Layout L, const JointDesc* __restrict__ jd, int B, double* __restrict__ out)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  for (int i = 1; i <= nb; ++i) {
+  char* lp = lane_ptr<T>(tiles, L, b);
+  for (int i = 1; i <= L.nb; ++i) {
     T R[9], t[3];
-    make_liMi<T>(jd[i], cs[(size_t)(2 * (i - 1)) * ldm + b], cs[(size_t)(2 * (i - 1) + 1) * ldm + b], R, t);
-    double* o = out + ((size_t)b * nb + (i - 1)) * 12;
+    const typename Vec2<T>::type cs = ldp<T>(lp + (size_t)(i - 1) * JREC * pair_bytes<T>(), JP_CS);
+    make_liMi<T>(jd[i], cs.x, cs.y, R, t);
+    double* o = out + ((size_t)b * L.nb + (i - 1)) * 12;
     for (int k = 0; k < 9; ++k) o[k] = (double)R[k];
     for (int k = 0; k < 3; ++k) o[9 + k] = (double)t[k];
   }
-}
-
-__global__ void k_status_extract(const int* __restrict__ status, int B, int mask, int* __restrict__ out)
-{
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < B) out[b] = mask ? ((status[b] & mask) ? 1 : 0) : status[b];
 }
 
 }  // namespace
@@ -708,7 +658,6 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
   if (rc) { delete S; return rc; }
   S->opt = *opts;
   S->B = opts->batch;
-  S->ld = ((S->B + WAVE - 1) / WAVE) * WAVE;
   S->nc = opts->num_eq_c;
   S->f32 = opts->precision == LOIKB_F32;
   S->esz = S->f32 ? 4 : 8;
@@ -730,12 +679,12 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
   void* tmp = nullptr;
   TRY(alloc_dev(S, &tmp, sizeof(JointDesc) * S->nj)); S->d_jd = (JointDesc*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * S->nj)); S->d_idx_q = (int*)tmp;
+  TRY(alloc_dev(S, &tmp, sizeof(int) * ROWMAP_CAP)); S->d_rowmap = (int*)tmp;
   TRY(alloc_dev(S, &tmp, 2 * sizeof(unsigned int))); S->d_counters = (unsigned int*)tmp;
-  TRY(alloc_set(S, 0, S->ld));
+  TRY(alloc_dev(S, &S->d_uni, S->esz * ((size_t)(S->nc > 0 ? S->nc : 1) * 57 + 2 * (size_t)S->nb)));
   HIPTRY(hipMemcpyAsync(S->d_idx_q, S->idx_q.data(), sizeof(int) * S->nj, hipMemcpyHostToDevice, S->stream));
   TRY(upload_jd(S));
-  TRY(reset_solver(S));
-  TRY(invalidate_h_cache(S));
+  TRY(ensure_layout(S, true));
   HIPTRY(hipStreamSynchronize(S->stream));
 #undef TRY
 #undef HIPTRY
@@ -747,7 +696,7 @@ int loikb_destroy(loikb_solver* S)
 {
   if (!S) return LOIKB_OK;
   (void)hipSetDevice(S->device);
-  for (auto& a : S->allocs) (void)hipFree(a.p);
+  for (void* a : S->allocs) if (a) (void)hipFree(a);
   if (S->d_stage) (void)hipFree(S->d_stage);
   if (S->h_counters) (void)hipHostFree(S->h_counters);
   if (S->ev_k0) (void)hipEventDestroy(S->ev_k0);
@@ -772,9 +721,9 @@ int loikb_solve_init(loikb_solver* S, const double* q, const double* H_ref, cons
   if (!S || !q || !H_ref || !v_ref || (nc > 0 && (!c_ids || !Ais || !bis)) || !lb || !ub) return LOIKB_ERR_ARG;
   HIPCHK(hipSetDevice(S->device));
   int rc;
+  if ((rc = ensure_layout(S, in_flags & LOIKB_A_SHARED))) return rc;
   // problem_.Reset(); ik_id_data_.Reset(warm_start); ResetSolver()  (hpp:345-352)
-  if ((rc = data_reset(S, S->opt.warm_start))) return rc;
-  if ((rc = reset_solver(S))) return rc;
+  if ((rc = reset_home(S, RS_SOLVER | (S->opt.warm_start ? 0 : RS_DATA_COLD)))) return rc;
   if ((rc = set_problem(S, H_ref, v_ref, c_ids, nc, Ais, bis, lb, ub, nbound, in_flags))) return rc;
   if ((rc = fwd_pass_init(S, q, in_flags))) return rc;
   HIPCHK(hipStreamSynchronize(S->stream));
@@ -787,8 +736,8 @@ int loikb_solve(loikb_solver* S)
   if (!S->have_problem) { g_last_error = "Solve() before SolveInit()"; return LOIKB_ERR_STATE; }
   HIPCHK(hipSetDevice(S->device));
   int rc;
-  if ((rc = data_reset_recursion(S))) return rc;
-  if ((rc = reset_solver(S))) return rc;
+  // ik_id_data_.ResetRecursion(); ResetSolver()  (hpp:370-374)
+  if ((rc = reset_home(S, RS_RECURSION | RS_SOLVER))) return rc;
   return run_main_loop(S);
 }
 
@@ -807,8 +756,8 @@ int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const doubl
   if (!S->have_problem) { g_last_error = "tailored Solve() before SolveInit()"; return LOIKB_ERR_STATE; }
   HIPCHK(hipSetDevice(S->device));
   int rc;
-  if ((rc = data_reset(S, S->opt.warm_start))) return rc;
-  if ((rc = reset_solver(S))) return rc;
+  // ik_id_data_.Reset(warm_start); ResetSolver()  (hpp:604-608)
+  if ((rc = reset_home(S, RS_SOLVER | (S->opt.warm_start ? 0 : RS_DATA_COLD)))) return rc;
   // problem_.UpdateEqConstraint(c_id, Ai, bi), ik-id-description-optimized.hpp:178-218
   int found = -1, count = 0;
   for (int c = 0; c < S->nc; ++c)
@@ -821,14 +770,10 @@ int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const doubl
     g_last_error = "tailored solve: A sharing mode must match SolveInit";
     return LOIKB_ERR_ARG;
   }
-  const size_t ld = S->ld, e = S->esz;
-  void* Adst = (char*)S->set[0].A + (a_shared_in ? (size_t)36 * found * e : (size_t)36 * found * ld * e);
-  if ((rc = upload_aos(S, Ai, 36, Adst, dev && !a_shared_in, a_shared_in))) return rc;
-  if (a_shared_in && (rc = upload_shared_AtA(S, Ai, found))) return rc;
-  void* bdst = (char*)S->set[0].b + (size_t)6 * found * ld * e;
-  if (in_flags & LOIKB_B_SHARED) rc = upload_broadcast(S, bi, 6, bdst);
-  else rc = upload_aos(S, bi, 6, bdst, dev, false);
+  if (a_shared_in) rc = upload_shared_A(S, Ai, found);
+  else rc = upload_rows(S, Ai, rowmap_constraint(S, found, CP_A, 36), dev, false);
   if (rc) return rc;
+  if ((rc = upload_rows(S, bi, rowmap_constraint(S, found, CP_B, 6), dev, in_flags & LOIKB_B_SHARED))) return rc;
   if ((rc = constraint_products(S, found, found + 1, true))) return rc;
   if ((rc = fwd_pass_init(S, q, in_flags))) return rc;
   return run_main_loop(S);
@@ -839,7 +784,7 @@ int loikb_set_rho(loikb_solver* S, double v)
 {
   if (!S) return LOIKB_ERR_ARG;
   S->opt.rho = v;
-  return invalidate_h_cache(S);
+  return reset_home(S, RS_HCACHE);
 }
 int loikb_set_mu(loikb_solver* S, double v) { if (!S) return LOIKB_ERR_ARG; S->opt.mu = v; return LOIKB_OK; }
 int loikb_set_tol(loikb_solver* S, double a, double r)
@@ -868,76 +813,69 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   if (!S || !out) return LOIKB_ERR_ARG;
   HIPCHK(hipSetDevice(S->device));
   const bool to_dev = out_flags & LOIKB_OUT_DEVICE;
-  const void* src = nullptr;
-  int n = 0;
+  const Layout& L = S->L;
+  const int nb = S->nb;
+  std::vector<int> rm;
   bool is_int = false;
   int mask = 0;
+  auto per_joint = [&](int pair, int half) { for (int j = 0; j < nb; ++j) rm.push_back((j * JREC + pair) * 2 + half); };
+  auto per_joint_vec = [&](int pair, int n) {
+    for (int j = 0; j < nb; ++j)
+      for (int k = 0; k < n; ++k) rm.push_back((j * JREC + pair + k / 2) * 2 + (k & 1));
+  };
+  auto per_constraint_vec = [&](int pair) {
+    for (int c = 0; c < S->nc; ++c)
+      for (int k = 0; k < 6; ++k) rm.push_back((L.off_c + c * L.crec + pair + k / 2) * 2 + (k & 1));
+  };
   switch (field) {
-  case LOIKB_F_Z: src = S->set[0].z; n = S->nb; break;
-  case LOIKB_F_NU: src = S->set[0].nu; n = S->nb; break;
-  case LOIKB_F_W: src = S->set[0].w; n = S->nb; break;
-  case LOIKB_F_STF_PLUS_W: src = S->set[0].s; n = S->nb; break;
-  case LOIKB_F_R: src = S->set[0].rr; n = S->nb; break;
-  case LOIKB_F_DINV: src = S->set[0].dinv; n = S->nb; break;
-  case LOIKB_F_VIS: src = S->set[0].v; n = 6 * S->nb; break;
-  case LOIKB_F_FIS: src = S->set[0].f; n = 6 * S->nb; break;
-  case LOIKB_F_G: src = S->set[0].g; n = 6 * S->nb; break;
-  case LOIKB_F_PIS: src = S->set[0].p; n = 6 * S->nb; break;
-  case LOIKB_F_UDINV: src = S->set[0].ud; n = 6 * S->nb; break;
-  case LOIKB_F_HIS: src = S->set[0].H; n = 21 * S->nb; break;
-  case LOIKB_F_YIS: src = S->set[0].y; n = 6 * S->nc; break;
-  case LOIKB_F_ATY: src = S->set[0].aty; n = 6 * S->nc; break;
-  case LOIKB_F_LIMI: n = 12 * S->nb; break;
-  case LOIKB_F_ITER: is_int = true; break;
-  case LOIKB_F_STATUS: is_int = true; break;
-  case LOIKB_F_CONVERGED: is_int = true; mask = ST_CONVERGED; break;
-  case LOIKB_F_PRIMAL_INFEASIBLE: is_int = true; mask = ST_PRIMAL_INF; break;
-  case LOIKB_F_MU: src = S->set[0].mu; n = 1; break;  // per-instance mu_ (== mu0 right after ResetSolver)
+  case LOIKB_F_Z: per_joint(JP_WZ, 1); break;
+  case LOIKB_F_NU: per_joint(JP_NUS, 0); break;
+  case LOIKB_F_W: per_joint(JP_WZ, 0); break;
+  case LOIKB_F_STF_PLUS_W: per_joint(JP_NUS, 1); break;
+  case LOIKB_F_R: per_joint(JP_R, 0); break;
+  case LOIKB_F_DINV: per_joint(JP_H + 10, 1); break;
+  case LOIKB_F_VIS: per_joint_vec(JP_V, 6); break;
+  case LOIKB_F_FIS: per_joint_vec(JP_F, 6); break;
+  case LOIKB_F_G: per_joint_vec(JP_G, 6); break;
+  case LOIKB_F_PIS: per_joint_vec(JP_P, 6); break;
+  case LOIKB_F_UDINV: per_joint_vec(JP_UD, 6); break;
+  case LOIKB_F_HIS: per_joint_vec(JP_H, 21); break;
+  case LOIKB_F_YIS: per_constraint_vec(CP_Y); break;
+  case LOIKB_F_ATY: per_constraint_vec(CP_ATY); break;
+  case LOIKB_F_LIMI: break;
+  case LOIKB_F_ITER: is_int = true; rm.push_back((L.off_s + SP_BI) * 2 + 1); break;
+  case LOIKB_F_STATUS: is_int = true; rm.push_back((L.off_s + SP_ST) * 2); break;
+  case LOIKB_F_CONVERGED: is_int = true; mask = ST_CONVERGED; rm.push_back((L.off_s + SP_ST) * 2); break;
+  case LOIKB_F_PRIMAL_INFEASIBLE: is_int = true; mask = ST_PRIMAL_INF; rm.push_back((L.off_s + SP_ST) * 2); break;
+  case LOIKB_F_MU: rm.push_back((L.off_s + SP_MU) * 2); break;  // per-instance mu_ (== mu0 right after ResetSolver)
   default:
     static_assert(LOIKB_F_TAIL_SOLVE_ITER - LOIKB_F_PRIMAL_RESIDUAL + 1 == NSCAL, "scalar field ids out of sync");
     if (field >= LOIKB_F_PRIMAL_RESIDUAL && field <= LOIKB_F_TAIL_SOLVE_ITER) {
-      const int row = field - LOIKB_F_PRIMAL_RESIDUAL;  // same order as the SC_* enum
-      src = (const char*)S->set[0].scal + (size_t)row * S->ld * S->esz;
-      n = 1;
+      const int idx = field - LOIKB_F_PRIMAL_RESIDUAL;  // same order as the SC_* enum
+      rm.push_back((L.off_s + SP_SCAL + idx / 2) * 2 + (idx & 1));
     } else {
       return LOIKB_ERR_ARG;
     }
   }
-  if (is_int) {
-    int* dst = (int*)out;
-    if (!to_dev) {
-      int rc = ensure_stage(S, sizeof(int) * (size_t)S->B);
-      if (rc) return rc;
-      dst = (int*)S->d_stage;
-    }
-    if (field == LOIKB_F_ITER)
-      HIPCHK(hipMemcpyAsync(dst, S->set[0].iter, sizeof(int) * (size_t)S->B, hipMemcpyDeviceToDevice, S->stream));
-    else {
-      hipLaunchKernelGGL(k_status_extract, grid1(S->B), dim3(256), 0, S->stream, S->set[0].status, S->B, mask, dst);
-      HIPCHK(hipGetLastError());
-    }
-    if (!to_dev) HIPCHK(hipMemcpyAsync(out, dst, sizeof(int) * (size_t)S->B, hipMemcpyDeviceToHost, S->stream));
-    HIPCHK(hipStreamSynchronize(S->stream));
-    return LOIKB_OK;
-  }
-  const size_t bytes = sizeof(double) * (size_t)S->B * n;
+  const int n = field == LOIKB_F_LIMI ? 12 * nb : (int)rm.size();
+  const size_t bytes = (is_int ? sizeof(int) : sizeof(double)) * (size_t)S->B * n;
   double* dst = (double*)out;
+  int rc;
   if (!to_dev) {
-    int rc = ensure_stage(S, bytes);
-    if (rc) return rc;
+    if ((rc = ensure_stage(S, bytes))) return rc;
     dst = (double*)S->d_stage;
   }
   if (field == LOIKB_F_LIMI) {
-    if (S->f32)
-      hipLaunchKernelGGL(k_limi<float>, grid1(S->B), dim3(256), 0, S->stream, (const float*)S->set[0].cs, S->d_jd, S->nb, S->B,
-                         S->ld, dst);
-    else
-      hipLaunchKernelGGL(k_limi<double>, grid1(S->B), dim3(256), 0, S->stream, (const double*)S->set[0].cs, S->d_jd, S->nb, S->B,
-                         S->ld, dst);
-  } else if (S->f32) {
-    hipLaunchKernelGGL(k_soa_to_aos<float>, grid1(S->B), dim3(256), 0, S->stream, (const float*)src, n, S->B, S->ld, dst);
+    if (S->f32) hipLaunchKernelGGL(k_limi<float>, grid1(S->B), dim3(256), 0, S->stream, S->set[0].tiles, L, S->d_jd, S->B, dst);
+    else hipLaunchKernelGGL(k_limi<double>, grid1(S->B), dim3(256), 0, S->stream, S->set[0].tiles, L, S->d_jd, S->B, dst);
   } else {
-    hipLaunchKernelGGL(k_soa_to_aos<double>, grid1(S->B), dim3(256), 0, S->stream, (const double*)src, n, S->B, S->ld, dst);
+    if ((rc = set_rowmap(S, rm))) return rc;
+    if (S->f32)
+      hipLaunchKernelGGL(k_download_rows<float>, grid1(S->B), dim3(256), 0, S->stream, S->set[0].tiles, L, S->d_rowmap, n,
+                         S->B, dst, (int)is_int, mask);
+    else
+      hipLaunchKernelGGL(k_download_rows<double>, grid1(S->B), dim3(256), 0, S->stream, S->set[0].tiles, L, S->d_rowmap, n,
+                         S->B, dst, (int)is_int, mask);
   }
   HIPCHK(hipGetLastError());
   if (!to_dev) HIPCHK(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, S->stream));

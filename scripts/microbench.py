@@ -1,7 +1,7 @@
 """micro-benchmarks of k_solve in fixed-iteration mode (no stopping logic): bulk rate vs single-wave latency"""
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import loik_amd
 from loik_amd import capi, workloads
 
@@ -22,6 +22,7 @@ def run(B, iters, flags, reps=3, model=None):
     s.close()
 
 if __name__ == "__main__":
-    for B in (64, 256, 4096, 16384, 65536, 262144):
+    sizes = [int(x) for x in sys.argv[1:]] or [64, 256, 4096, 16384, 65536, 262144]
+    for B in sizes:
         for flags in (0, capi.OPT_NO_H_CACHE):
             run(B, 100 if B <= 65536 else 30, flags)
