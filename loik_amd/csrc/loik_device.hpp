@@ -808,6 +808,109 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fused leaf -> root sweep: the residual sweep of iteration k (BwdPass2, as sweep_bwd2) AND, in the same
+// pass over the tree, the p-recursion of iteration k+1 (FwdPass1 + BwdPass with the cached H/UDinv/Dinv, as
+// sweep_bwd<.., false, ..>).  Both walk the joints leaf -> root and read the same v_i, w_i, z_i, liMi, so fusing
+// them removes one of the three tree walks of an iteration.  The p-recursion is speculative in mu: it uses the
+// mu of iteration k; if the epilogue of iteration k changes mu for any lane of the wavefront, the next iteration
+// starts with a full sweep_bwd<.., true, ..> that rebuilds H, UDinv, Dinv, p and r with the new mu.
+// The arithmetic of each half is unchanged, so results are bit-identical to the unfused sweeps.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool HDIAG>
+__device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& Bf, const JointDesc* __restrict__ jd,
+                                            T* stk, char* lp, int lane, bool live, T mu_eq, T mu_in, Norms<T>& N)
+{
+  constexpr int NENT = 27;
+  const Layout& L = P.L;
+  T acc[6], accp[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { acc[k] = T(0); accp[k] = T(0); }
+  int level = 0;
+  for (int i = L.nb; i >= 1; --i) {
+    const JointDesc d = jd[i];
+    char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
+    if (live) {
+      T fi[6], vi[6], gold[6], gi[6], UD[6], pp[6];
+      const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
+      ld6<T>(rec, JP_F, fi);
+      ld6<T>(rec, JP_V, vi);
+      ld6<T>(rec, JP_G, gold);
+      ld6<T>(rec, JP_UD, UD);
+      const T wi = wz.x, sold = nus.y;
+      // ---- iteration k: g_i = (Aty_c | 0) + sum_children act(f_j) - f_i   (hxx:438-439, :210-212)
+      //      iteration k+1: p_i = -rho v_i - Hv (+ Aty_c - mu_eq Atb_c)       (hxx:304-315, :321-334)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pp[k] = -P.rho * vi[k] - P.Hv[k];
+      if (d.cslot >= 0) {
+        const char* crec = lp + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>();
+        T atb[6];
+        ld6<T>(crec, CP_ATY, gi);
+        ld6<T>(crec, CP_ATB, atb);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pp[k] += gi[k] - mu_eq * atb[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gi[k] = T(0);
+      }
+      if (!(d.flags & JF_LEAF)) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { gi[k] += acc[k]; pp[k] += accp[k]; }
+      }
+      T dg[6], dvr[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        gi[k] += -fi[k];
+        dg[k] = gi[k] - gold[k];
+      }
+      st6<T>(rec, JP_G, gi);
+      st6<T>(rec, JP_P, pp);
+      N.dg = tmax(N.dg, inf6(dg));        // hxx:215-220
+      N.g_inf = tmax(N.g_inf, inf6(gi));  // hxx:223-225
+      // dual residual, v block (hxx:228): Href v_i - Hv + g_i
+      href_mul<T, HDIAG>(P.Href, vi, dvr);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) dvr[r] = dvr[r] - P.Hv[r] + gi[r];
+      N.dual_v = tmax(N.dual_v, inf6(dvr));
+      // Stf_plus_w (hxx:231-236, :482-484) and r_i = (w_i - mu_in z_i) + S^T p_i (hxx:296, :70)
+      const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
+      T stf, Stp;
+      if (d.flags & JF_REVOLUTE) {
+        stf = ax0 * fi[3] + ax1 * fi[4] + ax2 * fi[5];
+        Stp = ax0 * pp[3] + ax1 * pp[4] + ax2 * pp[5];
+      } else {
+        stf = ax0 * fi[0] + ax1 * fi[1] + ax2 * fi[2];
+        Stp = ax0 * pp[0] + ax1 * pp[1] + ax2 * pp[2];
+      }
+      const T si = stf + wi;
+      const T ri = (wz.x - mu_in * wz.y) + Stp;
+      stp<T>(rec, JP_NUS, nus.x, si);
+      stp<T>(rec, JP_R, ri, T(0));
+      N.stf_w_inf = tmax(N.stf_w_inf, tabs(si));
+      N.dstf_w = tmax(N.dstf_w, tabs(si - sold));
+      if (!(d.flags & JF_PARENT_ROOT)) {
+        T R[9], t[3], part[12], pa[6];
+        make_liMi(d, cs.x, cs.y, R, t);
+        act_force(R, t, fi, part);  // hxx:212
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pa[k] = pp[k] - UD[k] * ri;  // hxx:71-73
+        act_force(R, t, pa, part + 6);                            // hxx:74
+        if (!(d.flags & JF_LAST_CHILD)) {
+          --level;
+          stack_pop_add(stk, level, NENT, part, 12, lane);
+        }
+        if (d.flags & JF_NEXT_IS_PARENT) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { acc[k] = part[k]; accp[k] = part[6 + k]; }
+        } else {
+          stack_push(stk, level, NENT, part, 12, lane);
+          ++level;
+        }
+      }
+    }
+  }
+}
+
 // scalar record accessors
 template <typename T>
 __device__ __forceinline__ T ld_scal(const char* srec, int idx)
@@ -848,6 +951,7 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
   // main-loop bound `for (i = 1; i < max_iter; ++i)` (hpp:377): nothing to do when max_iter <= 1
   if (live && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { live = false; status |= ST_DONE; }
   unsigned int my_iters = 0;
+  bool have_p = false;  // p_i, r_i of the coming iteration already built by the fused sweep (with the current mu)
 
   for (int k = 0; k < P.max_launch_iters; ++k) {
     if (!__any(live)) break;
@@ -857,15 +961,23 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
     N.reset();
     if (live) { ++iter; ++my_iters; }
 
-    const bool need_h = !(P.mode & MODE_CACHE_H) || __any(live && (mu_h != mu));
-    if (need_h) {
-      sweep_bwd<T, true, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in);
-      if (live) mu_h = mu;
-    } else {
-      sweep_bwd<T, false, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in);
+    // leaf -> root sweep of this iteration, unless the previous iteration's fused sweep already did it
+    if (!have_p) {
+      const bool need_h = !(P.mode & MODE_CACHE_H) || __any(live && (mu_h != mu));
+      if (need_h) {
+        sweep_bwd<T, true, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in);
+        if (live) mu_h = mu;
+      } else {
+        sweep_bwd<T, false, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in);
+      }
     }
     sweep_fwd<T, HDIAG>(P, Bf, jd, lp, live, mu_eq, mu_in, N);
-    sweep_bwd2<T, HDIAG>(P, Bf, jd, stk, lp, lane, live, N);
+    if (P.mode & MODE_CACHE_H) {
+      sweep_fused<T, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in, N);
+      have_p = true;
+    } else {
+      sweep_bwd2<T, HDIAG>(P, Bf, jd, stk, lp, lane, live, N);
+    }
 
     if (live) {
       // ComputePrimalResiduals / ComputeDualResiduals (hxx:494-522)
@@ -946,6 +1058,8 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
       stp<T>(srec, SP_SCAL + 13, N.stf_w_inf, (T)c1);              // STF_PLUS_W_INF, COND1
       stp<T>(srec, SP_SCAL + 14, (T)c2, (T)tail_iter);             // COND2, TAIL_ITER
     }
+    // the speculative p-recursion used this iteration's mu: redo the leaf -> root sweep if any lane moved on
+    if (have_p && __any(live && (mu_h != mu))) have_p = false;
   }
 
   if (inb) {

@@ -13,7 +13,9 @@ from helpers import FIXTURE, assert_close, feasible_batch, fixture_problem, prob
 
 pytestmark = pytest.mark.gpu
 
-FIELDS = ["nu", "z", "w", "vis", "fis", "g", "yis", "Aty", "pis", "UDinv", "Dinv", "Stf_plus_w"]
+# `pis` (and `r`) are inter-sweep temporaries: in the default mode the fused leaf->root sweep has already replaced
+# them with the NEXT iteration's values when a solve returns; they are compared under LOIKB_OPT_NO_H_CACHE below
+FIELDS = ["nu", "z", "w", "vis", "fis", "g", "yis", "Aty", "UDinv", "Dinv", "Stf_plus_w"]
 SCALARS = ["primal_residual", "dual_residual", "primal_residual_task", "primal_residual_slack", "dual_residual_v",
            "dual_residual_nu", "mu", "delta_fis_inf_norm", "delta_yis_inf_norm", "delta_w_inf_norm",
            "delta_vis_inf_norm", "delta_nu_inf_norm", "Av_inf_norm", "nu_inf_norm", "Href_v_inf_norm", "g_inf_norm",
@@ -46,17 +48,22 @@ def fetch(s):
 
 
 @pytest.mark.parametrize("k", [1, 2, 3, 7])
-def test_k_iterations_talos(talos, k):
+@pytest.mark.parametrize("flags", [0, capi.OPT_NO_H_CACHE], ids=["default", "no_h_cache"])
+def test_k_iterations_talos(talos, k, flags):
     link = talos.getJointId("arm_left_7_joint")
     wl = feasible_batch(talos, 96, link, 31, nu_scale=0.5)
     prm = dict(FIXTURE, max_iter=k + 1, tol_abs=0.0, tol_rel=0.0, tol_primal_inf=0.0)
-    s = gpu_solve(talos, wl, prm)
+    s = gpu_solve(talos, wl, prm, flags=flags)
     cache = fetch(s)
     assert np.all(cache["iter"] == k)
+    pis, rr = s.get("pis"), s.get("r")
     for b in range(0, 96, 5):
         r = ref.RefSolver(talos, **prm)
         r.Solve(*problem_args(wl, b))
         compare_instance(s, cache, r, b, 1e-9)
+        if flags & capi.OPT_NO_H_CACHE:  # upstream's three-sweep iteration: temporaries of the LAST iteration
+            assert_close(pis[b], r.pis[1:], 1e-9, "pis")
+            assert_close(rr[b], r.r, 1e-9, "r")
     s.close()
 
 
