@@ -91,6 +91,8 @@ typedef struct loikb_options {
   int flags;      /* LOIKB_OPT_*                                       */
   int max_launch_iters; /* ADMM iterations per kernel launch, 0 = automatic                    */
   int compact_min_instances; /* stop compacting below this many slots, 0 = default (4096)     */
+  int tail_max_instances;    /* hand the last N live instances to the cooperative tail kernel (one wavefront per
+                                instance): 0 = default (8192), < 0 = never                    */
 } loikb_options;
 
 typedef struct loikb_solver loikb_solver;
@@ -173,6 +175,8 @@ typedef struct loikb_stats {
   int launches;                           /* k_solve launches                                     */
   int n_unfinished;                       /* instances that hit max_iter without stopping         */
   int compactions;                        /* lane compactions performed                           */
+  int tail_instances;                     /* instances finished by the cooperative tail kernel    */
+  double tail_ms;                         /* HIP-event time of the tail kernel (part of kernel_ms)*/
   double kernel_ms;                       /* HIP-event time of the k_solve launches on the stream */
   double total_ms;                        /* HIP-event time of the whole call on the stream       */
   double bytes_per_instance_iteration;    /* algorithmic bytes, SURVEY.md 8(d): s*(203 nb+108 nc) */

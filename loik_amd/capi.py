@@ -36,12 +36,13 @@ class Options(C.Structure):
                 ("num_eq_c", C.c_int), ("eq_c_dim", C.c_int), ("warm_start", C.c_int),
                 ("tol_tail_solve", C.c_double), ("verbose", C.c_int), ("logging", C.c_int),
                 ("batch", C.c_int), ("device", C.c_int), ("precision", C.c_int), ("flags", C.c_int),
-                ("max_launch_iters", C.c_int), ("compact_min_instances", C.c_int)]
+                ("max_launch_iters", C.c_int), ("compact_min_instances", C.c_int),
+                ("tail_max_instances", C.c_int)]
 
 
 class Stats(C.Structure):
     _fields_ = [("instance_iterations", C.c_ulonglong), ("launches", C.c_int), ("n_unfinished", C.c_int),
-                ("compactions", C.c_int),
+                ("compactions", C.c_int), ("tail_instances", C.c_int), ("tail_ms", C.c_double),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("bytes_per_instance_iteration", C.c_double)]
 
 
@@ -193,7 +194,7 @@ class BatchedLoik:
     def __init__(self, model, batch, max_iter=200, tol_abs=1e-3, tol_rel=1e-3, tol_primal_inf=1e-2, tol_dual_inf=1e-2,
                  rho=1e-5, mu=1e-2, mu_equality_scale_factor=1e4, mu_update_strat=0, num_eq_c=1, eq_c_dim=6,
                  warm_start=False, tol_tail_solve=1e-1, verbose=False, logging=False, device=0, precision=F64, flags=0,
-                 max_launch_iters=0, compact_min_instances=0):
+                 max_launch_iters=0, compact_min_instances=0, tail_max_instances=0):
         self.L = lib()
         self.model = model
         self.batch = int(batch)
@@ -201,7 +202,7 @@ class BatchedLoik:
         self.opts = Options(max_iter, tol_abs, tol_rel, tol_primal_inf, tol_dual_inf, rho, mu, mu_equality_scale_factor,
                             mu_update_strat, num_eq_c, eq_c_dim, int(bool(warm_start)), tol_tail_solve,
                             int(bool(verbose)), int(bool(logging)), self.batch, device, precision, flags, max_launch_iters,
-                            compact_min_instances)
+                            compact_min_instances, tail_max_instances)
         self._desc = model.desc()
         h = C.c_void_p()
         _check(self.L.loikb_create(C.byref(self._desc), C.byref(self.opts), C.byref(h)))

@@ -13,6 +13,7 @@
 // Device memory: wavefront tiles (see loik_device.hpp).  Set 0 is the "home" set (tile t, lane l holds instance
 // 64 t + l); sets 1 and 2 are half-size work sets used by lane compaction.
 #include "loik_device.hpp"
+#include "loik_tail.hpp"
 
 #include "../../include/loik_amd.h"
 
@@ -48,6 +49,13 @@ struct loikb_solver_impl {
   std::vector<int> parents, jtype, idx_q, idx_v;
   std::vector<JointDesc> jd;
   int stack_levels = 0;
+  // level schedule of the cooperative tail kernel (one joint per lane)
+  std::vector<TailTopo> topo;
+  std::vector<int> child_list;
+  int maxdepth = 0, maxchild = 0;
+  TailTopo* d_topo = nullptr;
+  int* d_child_list = nullptr;
+  int* d_slots = nullptr;
   // options
   loikb_options opt{};
   int B = 0, nc = 0;
@@ -201,6 +209,21 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
     if (!(d.flags & JF_NEXT_IS_PARENT)) { ++level; if (level > maxlevel) maxlevel = level; }
   }
   S->stack_levels = maxlevel;
+  // depth / children of every joint for the level-synchronous tail kernel
+  S->topo.assign(nj, TailTopo{});
+  S->child_list.clear();
+  S->maxdepth = 0; S->maxchild = 0;
+  for (int i = 1; i < nj; ++i) {
+    S->topo[i].depth = S->parents[i] == 0 ? 1 : S->topo[S->parents[i]].depth + 1;
+    if (S->topo[i].depth > S->maxdepth) S->maxdepth = S->topo[i].depth;
+  }
+  for (int i = 1; i < nj; ++i) {
+    S->topo[i].child_start = (int)S->child_list.size();
+    for (int c = nj - 1; c > i; --c)  // decreasing joint index = the order of the reference's leaf->root sweep
+      if (S->parents[c] == i) S->child_list.push_back(c - 1);  // lane of the child
+    S->topo[i].nchild = (int)S->child_list.size() - S->topo[i].child_start;
+    if (S->topo[i].nchild > S->maxchild) S->maxchild = S->topo[i].nchild;
+  }
   return LOIKB_OK;
 }
 
@@ -508,6 +531,45 @@ int compact(loikb_solver_impl* S, int src, int dst, int n_src, int* n_dst_out)
   return LOIKB_OK;
 }
 
+// finish the remaining live instances of set `cur` (n_cur slots, n_live of them live) with the cooperative tail
+// kernel: one wavefront per instance, runs every instance to its stopping point in ONE launch
+template <typename T>
+int run_tail(loikb_solver_impl* S, Params<T>& P, int cur, int n_cur, int n_live, double* ms_out)
+{
+  loikb_solver_impl::Set& A = S->set[cur];
+  const int nw = (n_cur + WAVE - 1) / WAVE;
+  S->h_wave.resize(2 * (size_t)nw + 2);
+  int* cnt = S->h_wave.data();
+  int* off = cnt + nw + 1;
+  HIPCHK(hipMemcpyAsync(cnt, A.wave_live, sizeof(int) * nw, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  int total = 0;
+  for (int w = 0; w < nw; ++w) { off[w] = total; total += cnt[w]; }
+  if (total != n_live) { g_last_error = "tail: live count mismatch"; return LOIKB_ERR_STATE; }
+  HIPCHK(hipMemcpyAsync(A.wave_off, off, sizeof(int) * nw, hipMemcpyHostToDevice, S->stream));
+  hipLaunchKernelGGL(k_list_live<T>, dim3(nw), dim3(WAVE), 0, S->stream, A.tiles, S->L, n_cur, A.wave_off, S->d_slots);
+  HIPCHK(hipGetLastError());
+  Bufs<T> Bf = make_bufs<T>(S, cur);
+  P.B = n_cur;
+  const size_t lds = ((size_t)WAVE * XS + (size_t)WAVE * 22 + (size_t)S->nc * CD) * sizeof(T);
+  HIPCHK(hipMemsetAsync(S->d_counters, 0, 2 * sizeof(unsigned int), S->stream));
+  HIPCHK(hipEventRecord(S->ev_k0, S->stream));
+  if (S->href_diag)
+    hipLaunchKernelGGL((k_tail<T, true>), dim3(n_live), dim3(WAVE), lds, S->stream, P, Bf, (const JointDesc*)S->d_jd,
+                       (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, (const int*)S->d_slots);
+  else
+    hipLaunchKernelGGL((k_tail<T, false>), dim3(n_live), dim3(WAVE), lds, S->stream, P, Bf, (const JointDesc*)S->d_jd,
+                       (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, (const int*)S->d_slots);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(S->ev_k1, S->stream));
+  HIPCHK(hipMemcpyAsync(S->h_counters, S->d_counters, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, S->ev_k0, S->ev_k1));
+  *ms_out = ms;
+  return LOIKB_OK;
+}
+
 template <typename T>
 int run_main_loop_t(loikb_solver_impl* S)
 {
@@ -523,13 +585,17 @@ int run_main_loop_t(loikb_solver_impl* S)
   // compaction pays only while the launch is bandwidth-bound (many wavefronts); below that an ADMM iteration
   // costs the same single-wavefront latency however few lanes are live
   const int compact_min = S->opt.compact_min_instances > 0 ? S->opt.compact_min_instances : 64 * WAVE;
+  // cooperative tail kernel (one wavefront per instance) once few instances are left
+  const bool use_tail = can_compact && S->nb <= WAVE && S->opt.tail_max_instances >= 0;
+  const int tail_max = S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : 8192;
   int cur = 0, n_cur = S->B;
   int done_iters = 0;
   unsigned long long inst_iters = 0;
   unsigned int n_live = 0;
   while (true) {
     const bool may_compact_later = can_compact && n_cur > compact_min;
-    int launch_iters = S->opt.max_launch_iters > 0 ? S->opt.max_launch_iters : (may_compact_later ? 8 : max_total);
+    int launch_iters = S->opt.max_launch_iters > 0 ? S->opt.max_launch_iters
+                                                   : ((may_compact_later || use_tail) ? 8 : max_total);
     if (launch_iters > max_total - done_iters) launch_iters = max_total - done_iters;
     P.B = n_cur;
     P.max_launch_iters = launch_iters;
@@ -551,6 +617,18 @@ int run_main_loop_t(loikb_solver_impl* S)
     n_live = S->h_counters[0];
     done_iters += launch_iters;
     if (n_live == 0 || done_iters >= max_total) break;
+    if (use_tail && (int)n_live <= tail_max) {
+      double tms = 0.0;
+      int rc = run_tail<T>(S, P, cur, n_cur, (int)n_live, &tms);
+      if (rc) return rc;
+      kernel_ms += tms;
+      S->stats.tail_ms = tms;
+      S->stats.tail_instances = (int)n_live;
+      S->stats.launches++;
+      inst_iters += S->h_counters[1];
+      n_live = S->h_counters[0];
+      break;
+    }
     if (may_compact_later && 2 * (long long)n_live <= n_cur) {
       const int dst = cur == 1 ? 2 : 1;
       int n_new = 0;
@@ -681,6 +759,13 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
   TRY(alloc_dev(S, &tmp, sizeof(int) * S->nj)); S->d_idx_q = (int*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * ROWMAP_CAP)); S->d_rowmap = (int*)tmp;
   TRY(alloc_dev(S, &tmp, 2 * sizeof(unsigned int))); S->d_counters = (unsigned int*)tmp;
+  TRY(alloc_dev(S, &tmp, sizeof(TailTopo) * S->nj)); S->d_topo = (TailTopo*)tmp;
+  TRY(alloc_dev(S, &tmp, sizeof(int) * (S->child_list.size() + 1))); S->d_child_list = (int*)tmp;
+  TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)(S->B + WAVE))); S->d_slots = (int*)tmp;
+  HIPTRY(hipMemcpyAsync(S->d_topo, S->topo.data(), sizeof(TailTopo) * S->nj, hipMemcpyHostToDevice, S->stream));
+  if (!S->child_list.empty())
+    HIPTRY(hipMemcpyAsync(S->d_child_list, S->child_list.data(), sizeof(int) * S->child_list.size(),
+                          hipMemcpyHostToDevice, S->stream));
   TRY(alloc_dev(S, &S->d_uni, S->esz * ((size_t)(S->nc > 0 ? S->nc : 1) * 57 + 2 * (size_t)S->nb)));
   HIPTRY(hipMemcpyAsync(S->d_idx_q, S->idx_q.data(), sizeof(int) * S->nj, hipMemcpyHostToDevice, S->stream));
   TRY(upload_jd(S));

@@ -1,0 +1,468 @@
+// loik_tail.hpp -- cooperative "tail" kernel: ONE wavefront per problem instance, ONE joint per lane.
+//
+// Why it exists: the ADMM iteration counts of a batch are heavy-tailed (on the Talos workload the median is ~26
+// iterations, 1 % of the instances need > 900 because the reference's DEFAULT penalty update keeps flipping mu
+// between two decades).  With one instance per lane (k_solve) every remaining iteration costs one full
+// single-wavefront tree walk (~50-90 us) however few instances are left, so the stragglers set the batch time.
+// Here the 64 lanes of a wavefront split ONE instance by joint: the whole ADMM state of a joint lives in the
+// registers / LDS of its lane for the entire solve (zero HBM traffic per iteration), the tree sweeps become
+// level-synchronous (tree depth, not joint count, sequential steps; Talos: 10 instead of 32) and the inf-norms
+// become wavefront reductions.  One ADMM iteration costs a few microseconds.
+//
+// The arithmetic per joint is the same as in loik_device.hpp (same helpers, same reference citations); only
+// the order in which children contributions / norm maxima are combined differs, so results agree with k_solve
+// and the CPU oracle to rounding (not bit for bit).  Used when nb <= 64.
+#pragma once
+
+#include "loik_device.hpp"
+
+namespace loikb {
+
+struct TailTopo {
+  int depth;        // 1 for children of the universe
+  int child_start;  // into child_list (children in DECREASING joint index, the order of the reference's sweep)
+  int nchild;
+  int pad;
+};
+
+constexpr int XS = 28;  // doubles per lane in the exchange buffer: 21 (H) + 6 (p / v / f) + 1 pad
+constexpr int CD = 82;  // per-constraint LDS block: A[36] AtA[21] pad b[6] Atb[6] y[6] aty[6]
+enum : int { CD_A = 0, CD_ATA = 36, CD_B = 58, CD_ATB = 64, CD_Y = 70, CD_ATY = 76 };
+
+template <typename T>
+__device__ __forceinline__ T wave_max(T x)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x = tmax(x, __shfl_xor(x, off));
+  return x;
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum(T x)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+  return x;
+}
+
+template <typename T, bool HDIAG>
+__global__ void __launch_bounds__(WAVE)
+k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
+       const int* __restrict__ child_list, int maxdepth, int maxchild, const int* __restrict__ slots)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Layout& L = P.L;
+  T* xch = reinterpret_cast<T*>(smem_raw);  // [WAVE][XS]   exchange between a joint and its parent / children
+  T* hst = xch + WAVE * XS;                 // [WAVE][22]   this joint's H (pre-projection) + Dinv
+  T* cd = hst + WAVE * 22;                  // [nc][CD]     constraint data
+  const int lane = threadIdx.x;
+  const int slot = slots[blockIdx.x];
+  const bool isj = lane < L.nb;
+  const int jl = isj ? lane : 0;
+  char* ip = lane_ptr<T>(Bf.tiles, L, slot);  // the instance's lane pointer: identical for the 64 lanes
+  char* rec = ip + (size_t)jl * JREC * pair_bytes<T>();
+  char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+
+  // ---- per-lane joint description (VGPRs: every lane owns a different joint) ------------------------------
+  const JointDesc d = jd[jl + 1];
+  const TailTopo tp = topo[jl + 1];
+  const int depth = isj ? tp.depth : 0;
+  const bool rev = d.flags & JF_REVOLUTE;
+  const bool has_parent = !(d.flags & JF_PARENT_ROOT);
+  const int plane = d.parent - 1;  // parent's lane
+  const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
+
+  // ---- load the instance: joint j -> lane j -----------------------------------------------------------------
+  T R[9], t[3], v[6], f[6], g[6], UD[6], p[6];
+  T w, z, nu, s, r = T(0), dinv = T(0), lbi, ubi;
+  {
+    const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
+    make_liMi(d, cs.x, cs.y, R, t);  // liMi is kept in registers for the whole solve
+    ld6<T>(rec, JP_V, v);
+    ld6<T>(rec, JP_F, f);
+    ld6<T>(rec, JP_G, g);
+    w = wz.x; z = wz.y; nu = nus.x; s = nus.y;
+    if (P.mode & MODE_BND_SHARED) {
+      lbi = Bf.uni[L.nc * 57 + jl];
+      ubi = Bf.uni[L.nc * 57 + L.nb + jl];
+    } else {
+      const typename Vec2<T>::type lu = ldp<T>(rec, JP_LBUB);
+      lbi = lu.x; ubi = lu.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { UD[k] = T(0); p[k] = T(0); }
+  }
+  // constraint blocks -> LDS (lanes cooperate: element e of block c by lane e, e+64)
+  for (int c = 0; c < L.nc; ++c) {
+    const char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+    for (int e = lane; e < CD; e += WAVE) {
+      T val = T(0);
+      if (e < 36) {
+        val = (P.mode & MODE_A_SHARED) ? Bf.uni[c * 36 + e]
+                                       : *reinterpret_cast<const T*>(crec + (size_t)(CP_A + e / 2) * pair_bytes<T>() + (e & 1) * sizeof(T));
+      } else if (e < 57) {
+        const int q = e - 36;
+        val = (P.mode & MODE_A_SHARED) ? Bf.uni[L.nc * 36 + c * 21 + q]
+                                       : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + q / 2) * pair_bytes<T>() + (q & 1) * sizeof(T));
+      } else if (e >= CD_B) {
+        const int q = e - CD_B;  // b, Atb, y, aty are consecutive 6-vectors in the tile record too, in another order
+        const int which = q / 6, k = q % 6;
+        const int pair = which == 0 ? CP_B : which == 1 ? CP_ATB : which == 2 ? CP_Y : CP_ATY;
+        val = *reinterpret_cast<const T*>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+      }
+      cd[c * CD + e] = val;
+    }
+  }
+  // per-instance solver scalars: every lane reads the same words
+  const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
+  T mu = mu2.x;
+  T mu_h = T(-1);  // the cached H did not come along
+  const T bnorm = bi2.x;
+  int iter = (int)bi2.y;
+  int status = (int)st2.x;
+  T tol_p = ld_scal<T>(srec, SC_TOL_PRIMAL), tol_d = ld_scal<T>(srec, SC_TOL_DUAL);
+  int tail_iter = (int)ld_scal<T>(srec, SC_TAIL_ITER);
+  T dyqp = ld_scal<T>(srec, SC_DELTA_Y_QP), atdy = ld_scal<T>(srec, SC_AT_DELTA_Y_QP);
+  T ubp = ld_scal<T>(srec, SC_UB_DY_PLUS), lbm = ld_scal<T>(srec, SC_LB_DY_MINUS);
+  int c1 = (int)ld_scal<T>(srec, SC_COND1), c2 = (int)ld_scal<T>(srec, SC_COND2);
+  __syncthreads();
+
+  bool done = (status & ST_DONE) != 0;
+  if (!done && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { done = true; status |= ST_DONE; }
+  unsigned int my_iters = 0;
+  // last-iteration scalars (for the final dump)
+  T primal = T(0), dual = T(0), pr_task = T(0), pr_slack = T(0), dual_v = T(0), stf_w_inf = T(0), dx = T(0), dz = T(0);
+  T n_dfis = T(0), n_dyis = T(0), n_dw = T(0), n_dvis = T(0), n_dnu = T(0), n_av = T(0), n_nu = T(0), n_hrefv = T(0),
+    n_g = T(0);
+  bool any_iter = false;
+
+  while (!done) {
+    const T mu_eq = P.mu_scale * mu, mu_in = mu;
+    ++iter; ++my_iters; any_iter = true;
+
+    // ================= leaf -> root: FwdPass1 + BwdPass (hxx:290-338, :31-81) =================================
+    const bool need_h = !(P.mode & MODE_CACHE_H) || (mu_h != mu);
+    T hh[22];
+    if (need_h) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b2 = a; b2 < 6; ++b2)
+          hh[sym(a, b2)] = (a == b2 ? P.rho : T(0)) + ((HDIAG && a != b2) ? T(0) : P.Href[6 * a + b2]);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p[k] = -P.rho * v[k] - P.Hv[k];
+    if (isj && d.cslot >= 0) {
+      const T* c_ = cd + d.cslot * CD;
+      if (need_h) {
+#pragma unroll
+        for (int k = 0; k < 21; ++k) hh[k] += mu_eq * c_[CD_ATA + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) p[k] += c_[CD_ATY + k] - mu_eq * c_[CD_ATB + k];
+    }
+    for (int lev = maxdepth; lev >= 1; --lev) {
+      if (depth == lev) {
+        // children contributions (deposited one level deeper), largest child index first as upstream
+        for (int c = 0; c < maxchild; ++c) {
+          if (c < tp.nchild) {
+            const T* x = xch + child_list[tp.child_start + c] * XS;
+            if (need_h) {
+#pragma unroll
+              for (int k = 0; k < 21; ++k) hh[k] += x[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) p[k] += x[21 + k];
+          }
+        }
+        T U[6], Stp;
+        if (need_h) {
+          if (rev) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 3)] * ax0 + hh[sym(k, 4)] * ax1 + hh[sym(k, 5)] * ax2;
+            dinv = T(1) / ((ax0 * U[3] + ax1 * U[4] + ax2 * U[5]) + mu_in);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 0)] * ax0 + hh[sym(k, 1)] * ax1 + hh[sym(k, 2)] * ax2;
+            dinv = T(1) / ((ax0 * U[0] + ax1 * U[1] + ax2 * U[2]) + mu_in);
+          }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) UD[k] = U[k] * dinv;
+#pragma unroll
+          for (int k = 0; k < 21; ++k) hst[lane * 22 + k] = hh[k];  // pre-projection H for the forward sweep
+        }
+        Stp = rev ? (ax0 * p[3] + ax1 * p[4] + ax2 * p[5]) : (ax0 * p[0] + ax1 * p[1] + ax2 * p[2]);
+        r = (w - mu_in * z) + Stp;
+        if (has_parent) {
+          T* x = xch + lane * XS;
+          if (need_h) {
+            T part[21];
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+              for (int b2 = a; b2 < 6; ++b2) hh[sym(a, b2)] -= UD[a] * U[b2];
+            congr_sym(R, t, hh, part);
+#pragma unroll
+            for (int k = 0; k < 21; ++k) x[k] = part[k];
+          }
+          T pa[6], pc[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) pa[k] = p[k] - UD[k] * r;
+          act_force(R, t, pa, pc);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) x[21 + k] = pc[k];
+        }
+      }
+      __syncthreads();
+    }
+    if (need_h) mu_h = mu;
+
+    // ================= root -> leaf: FwdPass2 + BoxProj + DualUpdate (hxx:102-163, :384-461) ==================
+    T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_dyis = T(0),
+      l_av = T(0), l_prt = T(0), l_prs = T(0), l_bp = T(0), l_bm = T(0), l_ubp = T(0), l_lbm = T(0);
+    for (int lev = 1; lev <= maxdepth; ++lev) {
+      if (depth == lev) {
+        T vpar[6], vp[6], vi[6], fi[6], hl[21];
+        if (has_parent) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) vpar[k] = xch[plane * XS + 21 + k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) vpar[k] = T(0);
+        }
+#pragma unroll
+        for (int k = 0; k < 21; ++k) hl[k] = hst[lane * 22 + k];
+        actinv_motion(R, t, vpar, vp);
+        T udv = UD[0] * vp[0];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) udv += UD[k] * vp[k];
+        const T nui = -udv - dinv * r;
+        l_nu = tabs(nui);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vi[k] = vp[k];
+        if (rev) { vi[3] += ax0 * nui; vi[4] += ax1 * nui; vi[5] += ax2 * nui; }
+        else { vi[0] += ax0 * nui; vi[1] += ax1 * nui; vi[2] += ax2 * nui; }
+        symv(hl, vi, fi);
+        T df[6], dv6[6], hrv[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          fi[k] += p[k];
+          df[k] = fi[k] - f[k];
+          dv6[k] = vi[k] - v[k];
+        }
+        l_dfis = inf6(df);
+        href_mul<T, HDIAG>(P.Href, vi, hrv);
+        l_hrefv = inf6(hrv);
+        l_dvis = inf6(dv6);
+        l_dnu = tabs(nui - nu);
+        const T x = nui + (T(1) / mu_in) * w;
+        const T zi = tmin(ubi, tmax(lbi, x));
+        l_dz = tabs(zi - z);
+        l_prs = tabs(nui - zi);
+        const T dwi = mu_in * (nui - zi);
+        l_dw = tabs(dwi);
+        l_ubp = ubi * tmax(dwi, T(0));
+        l_lbm = lbi * tmin(dwi, T(0));
+        w = w + dwi; z = zi; nu = nui;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { v[k] = vi[k]; f[k] = fi[k]; xch[lane * XS + 21 + k] = vi[k]; }
+        if (d.cslot >= 0) {
+          T* c_ = cd + d.cslot * CD;
+          T Av[6], e[6], yy[6];
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc += c_[CD_A + 6 * a + k] * vi[k];
+            Av[a] = acc;
+          }
+          T plus = T(0), minus = T(0);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            const T bk = c_[CD_B + k];
+            e[k] = Av[k] - bk;
+            const T dy = mu_eq * e[k];
+            yy[k] = c_[CD_Y + k] + dy;
+            l_dyis = tmax(l_dyis, tabs(dy));
+            plus += bk * tmax(dy, T(0));
+            minus += bk * tmin(dy, T(0));
+          }
+          l_bp = plus; l_bm = minus;
+          l_prt = inf6(e);
+          l_av = inf6(Av);
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            T acc = T(0);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc += c_[CD_A + 6 * k + a] * yy[k];
+            c_[CD_ATY + a] = acc;
+          }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) c_[CD_Y + k] = yy[k];
+        }
+      }
+      __syncthreads();
+    }
+
+    // ================= leaf -> root: BwdPass2 + dual residual (hxx:185-241, :468-487) ==========================
+    T gi[6], l_dg = T(0), l_g = T(0), l_dualv = T(0), l_stf = T(0), l_dstf = T(0);
+    if (isj && d.cslot >= 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gi[k] = cd[d.cslot * CD + CD_ATY + k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) gi[k] = T(0);
+    }
+    for (int lev = maxdepth; lev >= 1; --lev) {
+      if (depth == lev) {
+        for (int c = 0; c < maxchild; ++c) {
+          if (c < tp.nchild) {
+            const T* x = xch + child_list[tp.child_start + c] * XS;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) gi[k] += x[k];
+          }
+        }
+        T dg[6], dvr[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          gi[k] += -f[k];
+          dg[k] = gi[k] - g[k];
+          g[k] = gi[k];
+        }
+        l_dg = inf6(dg);
+        l_g = inf6(gi);
+        href_mul<T, HDIAG>(P.Href, v, dvr);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) dvr[a] = dvr[a] - P.Hv[a] + gi[a];
+        l_dualv = inf6(dvr);
+        const T stf = rev ? (ax0 * f[3] + ax1 * f[4] + ax2 * f[5]) : (ax0 * f[0] + ax1 * f[1] + ax2 * f[2]);
+        const T si = stf + w;
+        l_stf = tabs(si);
+        l_dstf = tabs(si - s);
+        s = si;
+        if (has_parent) {
+          T pc[6];
+          act_force(R, t, f, pc);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) xch[lane * XS + k] = pc[k];
+        }
+      }
+      __syncthreads();
+    }
+
+    // ================= wavefront reductions of the running norms, then the scalar epilogue ======================
+    pr_task = wave_max(l_prt); pr_slack = wave_max(l_prs);
+    dual_v = wave_max(l_dualv); stf_w_inf = wave_max(l_stf);
+    primal = tmax(pr_task, pr_slack);
+    dual = tmax(dual_v, stf_w_inf);
+    n_dvis = wave_max(l_dvis); n_dnu = wave_max(l_dnu);
+    dx = tmax(n_dvis, n_dnu);
+    dz = wave_max(l_dz);
+    n_dfis = wave_max(l_dfis); n_dyis = wave_max(l_dyis); n_dw = wave_max(l_dw);
+    n_av = wave_max(l_av); n_nu = wave_max(l_nu); n_hrefv = wave_max(l_hrefv); n_g = wave_max(l_g);
+    bool ran_feas = false;
+    if (P.mode & MODE_FIXED_ITERS) {
+      if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
+    } else if (!(status & ST_TAIL)) {
+      tol_p = P.tol_abs + P.tol_rel * tmax(tmax(n_av, n_nu), tmax(bnorm, n_nu));
+      tol_d = P.tol_abs + P.tol_rel * tmax(tmax(n_hrefv, tmax(n_g, stf_w_inf)), P.Hv_inf_norm);
+      const bool conv = (primal < tol_p) && (dual < tol_d);
+      bool infeas = false;
+      if (iter > 1) {
+        dyqp = tmax(n_dfis, tmax(n_dyis, n_dw));
+        atdy = tmax(wave_max(l_dg), wave_max(l_dstf));
+        c1 = atdy <= P.tol_primal_inf * dyqp;
+        ubp = wave_sum(l_bp) + wave_sum(l_ubp);
+        lbm = wave_sum(l_bm) + wave_sum(l_lbm);
+        c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp;
+        infeas = c1 && c2;
+        ran_feas = true;
+      }
+      if (conv) {
+        status |= ST_CONVERGED | ST_DONE;
+        if (infeas) status |= ST_PRIMAL_INF;
+        done = true;
+      } else if (infeas) {
+        status |= ST_PRIMAL_INF | ST_TAIL;
+        tail_iter = 0;
+        if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
+      } else {
+        if (primal > T(10) * dual) mu *= T(10);
+        else if (dual > T(10) * primal) mu *= T(0.1);
+        if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
+      }
+    } else {
+      tail_iter += 1;
+      if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
+    }
+    (void)ran_feas;
+  }
+
+  // ---- write the instance back (same slot; the H cache is declared invalid) --------------------------------------
+  if (isj) {
+    st6<T>(rec, JP_V, v);
+    st6<T>(rec, JP_F, f);
+    st6<T>(rec, JP_G, g);
+    stp<T>(rec, JP_WZ, w, z);
+    stp<T>(rec, JP_NUS, nu, s);
+    if (any_iter) {
+      // inter-sweep temporaries of the LAST iteration (His, pis, UDinv, Dinv, r), as upstream leaves them
+      st6<T>(rec, JP_P, p);
+      st6<T>(rec, JP_UD, UD);
+      stp<T>(rec, JP_R, r, T(0));
+#pragma unroll
+      for (int k = 0; k < 11; ++k)
+        stp<T>(rec, JP_H + k, hst[lane * 22 + 2 * k], 2 * k + 1 < 21 ? hst[lane * 22 + 2 * k + 1] : dinv);
+    }
+  }
+  __syncthreads();
+  for (int c = 0; c < L.nc; ++c) {
+    char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+    if (lane < 6) {
+      const int k = lane;
+      const int pair_y = CP_Y + k / 2, pair_a = CP_ATY + k / 2;
+      *reinterpret_cast<T*>(crec + (size_t)pair_y * pair_bytes<T>() + (k & 1) * sizeof(T)) = cd[c * CD + CD_Y + k];
+      *reinterpret_cast<T*>(crec + (size_t)pair_a * pair_bytes<T>() + (k & 1) * sizeof(T)) = cd[c * CD + CD_ATY + k];
+    }
+  }
+  if (lane == 0) {
+    stp<T>(srec, SP_MU, mu, any_iter ? mu_h : T(-1));
+    stp<T>(srec, SP_BI, bnorm, (T)iter);
+    stp<T>(srec, SP_ST, (T)status, T(0));
+    if (any_iter) {
+      stp<T>(srec, SP_SCAL + 0, primal, dual);
+      stp<T>(srec, SP_SCAL + 1, pr_task, pr_slack);
+      stp<T>(srec, SP_SCAL + 2, dual_v, stf_w_inf);
+      stp<T>(srec, SP_SCAL + 3, tol_p, tol_d);
+      stp<T>(srec, SP_SCAL + 4, mu, P.mu_scale * mu);
+      stp<T>(srec, SP_SCAL + 5, mu, dx);
+      stp<T>(srec, SP_SCAL + 6, dz, dyqp);
+      stp<T>(srec, SP_SCAL + 7, atdy, ubp);
+      stp<T>(srec, SP_SCAL + 8, lbm, n_dfis);
+      stp<T>(srec, SP_SCAL + 9, n_dyis, n_dw);
+      stp<T>(srec, SP_SCAL + 10, n_dvis, n_dnu);
+      stp<T>(srec, SP_SCAL + 11, n_av, n_nu);
+      stp<T>(srec, SP_SCAL + 12, n_hrefv, n_g);
+      stp<T>(srec, SP_SCAL + 13, stf_w_inf, (T)c1);
+      stp<T>(srec, SP_SCAL + 14, (T)c2, (T)tail_iter);
+    }
+    if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
+    if (!(status & ST_DONE)) atomicAdd(&Bf.counters[0], 1u);
+  }
+}
+
+// slot indices of the live instances of a set, dense, in slot order (same scan as k_move)
+template <typename T>
+__global__ void __launch_bounds__(WAVE) k_list_live(char* tiles, Layout L, int n, const int* __restrict__ wave_off,
+                                                    int* __restrict__ list)
+{
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * WAVE + lane;
+  const bool inb = b < n;
+  char* sp = lane_ptr<T>(tiles, L, inb ? b : 0);
+  const int status = inb ? (int)ldp<T>(sp + (size_t)L.off_s * pair_bytes<T>(), SP_ST).x : ST_DONE;
+  const bool live = inb && !(status & ST_DONE);
+  const unsigned long long mask = __ballot(live);
+  if (live) list[wave_off[blockIdx.x] + __popcll(mask & ((1ull << lane) - 1ull))] = b;
+}
+
+}  // namespace loikb

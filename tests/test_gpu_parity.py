@@ -143,8 +143,9 @@ def test_h_cache_and_relaunch_are_bit_identical(talos):
     link = talos.getJointId("arm_left_7_joint")
     wl = feasible_batch(talos, 200, link, 33, nu_scale=0.5)
     prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
-    base = gpu_solve(talos, wl, prm, flags=capi.OPT_NO_H_CACHE)
-    for kw in [dict(flags=0), dict(flags=0, max_launch_iters=7), dict(flags=capi.OPT_NO_H_CACHE, max_launch_iters=1)]:
+    base = gpu_solve(talos, wl, prm, flags=capi.OPT_NO_H_CACHE, tail_max_instances=-1)
+    for kw in [dict(flags=0, tail_max_instances=-1), dict(flags=0, max_launch_iters=7, tail_max_instances=-1),
+               dict(flags=capi.OPT_NO_H_CACHE, max_launch_iters=1, tail_max_instances=-1)]:
         s = gpu_solve(talos, wl, prm, **kw)
         for name in ["z", "nu", "w", "vis", "fis", "g", "yis", "iter", "status", "mu", "primal_residual", "dual_residual"]:
             assert np.array_equal(base.get(name), s.get(name)), (kw, name)
@@ -302,7 +303,7 @@ def test_lane_compaction_changes_nothing(talos, per_instance):
     wl = feasible_batch(talos, B, link, 90, nu_scale=0.5, per_instance_A=per_instance, per_instance_bounds=per_instance)
     prm = dict(FIXTURE, max_iter=400, tol_abs=1e-6, tol_rel=0.0)
     base = gpu_solve(talos, wl, prm, flags=capi.OPT_NO_COMPACTION)
-    s = gpu_solve(talos, wl, prm, compact_min_instances=128, max_launch_iters=5)
+    s = gpu_solve(talos, wl, prm, compact_min_instances=128, max_launch_iters=5, tail_max_instances=-1)
     st = s.stats()
     assert st["compactions"] >= 3, st
     assert st["instance_iterations"] == base.stats()["instance_iterations"] == int(base.get("iter").sum())
@@ -317,3 +318,85 @@ def test_lane_compaction_changes_nothing(talos, per_instance):
     for name in ["z", "nu", "w", "iter", "status"]:
         assert np.array_equal(base.get(name), s.get(name)), name
     s.close(); base.close()
+
+
+@pytest.mark.parametrize("which", ["talos", "panda9", "tree17", "tree40", "tree63"])
+def test_cooperative_tail_kernel(which, request):
+    """the one-wavefront-per-instance tail kernel (one joint per lane, state in registers, level-synchronous sweeps,
+    wavefront reductions) must reproduce the oracle from ANY hand-over point: after 1, 3 or 8 iterations of k_solve"""
+    if which.startswith("tree"):
+        model = random_tree(int(which[4:]), int(which[4:]))
+        link = model.njoints - 1
+    else:
+        model = request.getfixturevalue(which)
+        link = model.getJointId("arm_left_7_joint") if which == "talos" else model.getJointId("panda_joint7")
+    B = 150
+    wl = feasible_batch(model, B, link, 77, nu_scale=0.5, per_instance_A=(which == "tree40"),
+                        per_instance_bounds=(which in ("tree40", "panda9")))
+    prm = dict(FIXTURE, max_iter=400, tol_abs=1e-6, tol_rel=0.0)
+    Ais = wl["Ais"] if wl["Ais"].ndim == 4 else wl["Ais"]
+    out = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], Ais, wl["bis"], wl["lb"], wl["ub"],
+                          nthreads=4, want_nu=True, **prm)
+    for handover in (1, 3, 8):
+        s = gpu_solve(model, wl, prm, max_launch_iters=handover, tail_max_instances=1 << 20)
+        st = s.stats()
+        assert st["tail_instances"] > 0 and st["launches"] == 2, st
+        assert st["instance_iterations"] == int(s.get("iter").sum())
+        it = s.get("iter")
+        same = it == out["iters"]
+        assert same.mean() >= 0.97, (which, handover, it[~same], out["iters"][~same])
+        assert np.array_equal(s.get("converged").astype(bool)[same], out["converged"][same])
+        assert np.array_equal(s.get("primal_infeasible").astype(bool)[same], out["primal_infeasible"][same])
+        assert np.max(np.abs(s.get("z") - out["z"])[same]) < 1e-9
+        assert np.max(np.abs(s.get("nu") - out["nu"])[same]) < 1e-9
+        assert np.max(np.abs(s.get("primal_residual") - out["primal_residual"])[same]) < 1e-9
+        assert np.max(np.abs(s.get("dual_residual") - out["dual_residual"])[same]) < 1e-9
+        # full state of a few instances
+        for b in np.flatnonzero(same)[:6]:
+            r = ref.RefSolver(model, **prm)
+            r.Solve(*problem_args(wl, b))
+            for name in ["w", "vis", "fis", "g", "yis", "Aty", "Stf_plus_w"]:
+                want = r.field(name)
+                if name in ("vis", "fis", "g"):
+                    want = want[1:]
+                assert_close(s.get(name)[b], want, 1e-9, "%s b%d" % (name, b))
+            for name in ["mu", "delta_fis_inf_norm", "delta_w_inf_norm", "delta_vis_inf_norm", "nu_inf_norm",
+                         "g_inf_norm", "Stf_plus_w_inf_norm", "tol_primal", "tol_dual"]:
+                assert_close(s.get(name)[b], r.scalar(name), 1e-9, name)
+        s.close()
+
+
+def test_tail_kernel_reference_fixture_and_warm_start(talos):
+    """infeasible head target (certificate + tail-solve mode inside the tail kernel) and a warm-started sequence"""
+    p = fixture_problem(talos, bound=1.5)
+    prm = dict(FIXTURE, max_iter=100)
+    wl = dict(p, q=np.tile(p["q"], (5, 1)), bis=np.tile(p["bis"], (5, 1, 1)))
+    s = gpu_solve(talos, wl, prm, max_launch_iters=1, tail_max_instances=1 << 20)
+    r = ref.RefSolver(talos, **prm)
+    r.Solve(*problem_args(p))
+    assert s.stats()["tail_instances"] == 5
+    assert np.all(s.get("iter") == r.get_iter())
+    assert np.all(s.get("primal_infeasible").astype(bool) == r.get_primal_infeasibility_status())
+    assert_close(s.get("z")[2], r.z, 1e-9, "z")
+    assert_close(s.get("w")[2], r.w, 1e-9, "w")
+    assert_close(s.get("tail_solve_iter")[2], r.scalar("tail_solve_iter"), 1e-12, "tail_solve_iter")
+    s.close()
+    link = talos.getJointId("arm_left_7_joint")
+    B, T = 20, 3
+    wls = [feasible_batch(talos, B, link, 150 + t, nu_scale=0.4) for t in range(T)]
+    prm = dict(FIXTURE, max_iter=400, tol_abs=1e-6, tol_rel=0.0, warm_start=True)
+    s = loik_amd.BatchedLoik(talos, B, max_launch_iters=2, tail_max_instances=1 << 20, **prm)
+    s.SolveInit(wls[0]["q"], wls[0]["H_ref"], wls[0]["v_ref"], wls[0]["c_ids"], wls[0]["Ais"], wls[0]["bis"],
+                wls[0]["lb"], wls[0]["ub"])
+    refs = []
+    for b in range(0, B, 6):
+        rr = ref.RefSolver(talos, **prm)
+        rr.SolveInit(*problem_args(wls[0], b))
+        refs.append((b, rr))
+    for t in range(T):
+        s.Solve(wls[t]["q"], link, wls[t]["Ais"], wls[t]["bis"])
+        for b, rr in refs:
+            rr.Solve(wls[t]["q"][b], link, wls[t]["Ais"][0], wls[t]["bis"][b, 0])
+            assert s.get("iter")[b] == rr.get_iter(), (t, b)
+            assert_close(s.get("z")[b], rr.z, 1e-9, "z")
+    s.close()
