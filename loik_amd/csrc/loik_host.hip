@@ -551,15 +551,21 @@ int run_tail(loikb_solver_impl* S, Params<T>& P, int cur, int n_cur, int n_live,
   HIPCHK(hipGetLastError());
   Bufs<T> Bf = make_bufs<T>(S, cur);
   P.B = n_cur;
-  const size_t lds = ((size_t)WAVE * XS + (size_t)WAVE * 22 + (size_t)S->nc * CD) * sizeof(T);
+  int G = 8;  // lanes per instance: smallest power of two >= nb
+  while (G < S->nb) G <<= 1;
+  const int ipw = WAVE / G;
+  const size_t lds = ((size_t)WAVE * XS + 2 * (size_t)WAVE * HS + (size_t)ipw * S->nc * CD) * sizeof(T);
+  const dim3 grid((unsigned)((n_live + ipw - 1) / ipw));
   HIPCHK(hipMemsetAsync(S->d_counters, 0, 2 * sizeof(unsigned int), S->stream));
   HIPCHK(hipEventRecord(S->ev_k0, S->stream));
   if (S->href_diag)
-    hipLaunchKernelGGL((k_tail<T, true>), dim3(n_live), dim3(WAVE), lds, S->stream, P, Bf, (const JointDesc*)S->d_jd,
-                       (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, (const int*)S->d_slots);
+    hipLaunchKernelGGL((k_tail<T, true>), grid, dim3(WAVE), lds, S->stream, P, Bf, (const JointDesc*)S->d_jd,
+                       (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
+                       (const int*)S->d_slots, n_live, G);
   else
-    hipLaunchKernelGGL((k_tail<T, false>), dim3(n_live), dim3(WAVE), lds, S->stream, P, Bf, (const JointDesc*)S->d_jd,
-                       (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, (const int*)S->d_slots);
+    hipLaunchKernelGGL((k_tail<T, false>), grid, dim3(WAVE), lds, S->stream, P, Bf, (const JointDesc*)S->d_jd,
+                       (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
+                       (const int*)S->d_slots, n_live, G);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(S->ev_k1, S->stream));
   HIPCHK(hipMemcpyAsync(S->h_counters, S->d_counters, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
@@ -587,7 +593,7 @@ int run_main_loop_t(loikb_solver_impl* S)
   const int compact_min = S->opt.compact_min_instances > 0 ? S->opt.compact_min_instances : 64 * WAVE;
   // cooperative tail kernel (one wavefront per instance) once few instances are left
   const bool use_tail = can_compact && S->nb <= WAVE && S->opt.tail_max_instances >= 0;
-  const int tail_max = S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : 8192;
+  const int tail_max = S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : 2048;
   int cur = 0, n_cur = S->B;
   int done_iters = 0;
   unsigned long long inst_iters = 0;

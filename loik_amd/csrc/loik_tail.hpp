@@ -1,13 +1,15 @@
-// loik_tail.hpp -- cooperative "tail" kernel: ONE wavefront per problem instance, ONE joint per lane.
+// loik_tail.hpp -- cooperative "tail" kernel: one problem instance per lane GROUP, ONE joint per lane.
 //
 // Why it exists: the ADMM iteration counts of a batch are heavy-tailed (on the Talos workload the median is ~26
 // iterations, 1 % of the instances need > 900 because the reference's DEFAULT penalty update keeps flipping mu
 // between two decades).  With one instance per lane (k_solve) every remaining iteration costs one full
 // single-wavefront tree walk (~50-90 us) however few instances are left, so the stragglers set the batch time.
-// Here the 64 lanes of a wavefront split ONE instance by joint: the whole ADMM state of a joint lives in the
-// registers / LDS of its lane for the entire solve (zero HBM traffic per iteration), the tree sweeps become
-// level-synchronous (tree depth, not joint count, sequential steps; Talos: 10 instead of 32) and the inf-norms
-// become wavefront reductions.  One ADMM iteration costs a few microseconds.
+// Here a group of G = 8/16/32/64 lanes (G >= nb, 64/G instances per wavefront) splits ONE instance by joint: the
+// whole ADMM state of a joint lives in the registers / LDS of its lane for the entire solve (zero HBM traffic per
+// iteration), the tree sweeps become level-synchronous (tree depth, not joint count, sequential steps; Talos: 10
+// instead of 32) and the inf-norms become lane-group reductions.  One ADMM iteration costs a few microseconds.
+// H_i / UDinv / Dinv are cached for the TWO most recent values of mu, so an instance whose penalty flips between
+// two decades (the typical straggler) never repeats the H-recursion.
 //
 // The arithmetic per joint is the same as in loik_device.hpp (same helpers, same reference citations); only
 // the order in which children contributions / norm maxima are combined differs, so results agree with k_solve
@@ -25,42 +27,53 @@ struct TailTopo {
   int pad;
 };
 
-constexpr int XS = 28;  // doubles per lane in the exchange buffer: 21 (H) + 6 (p / v / f) + 1 pad
+constexpr int XS = 28;  // scalars per lane in the exchange buffer: 21 (H) + 6 (p / v / f) + 1 pad
+constexpr int HS = 22;  // scalars per lane and mu-slot in the H store: H[21], Dinv  (4 wavefronts/CU fit in 160 KiB)
 constexpr int CD = 82;  // per-constraint LDS block: A[36] AtA[21] pad b[6] Atb[6] y[6] aty[6]
 enum : int { CD_A = 0, CD_ATA = 36, CD_B = 58, CD_ATB = 64, CD_Y = 70, CD_ATY = 76 };
 
+// reductions over an aligned group of G lanes (G a power of two <= 64)
 template <typename T>
-__device__ __forceinline__ T wave_max(T x)
+__device__ __forceinline__ T group_max(T x, int G)
 {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x = tmax(x, __shfl_xor(x, off));
+  for (int off = G >> 1; off > 0; off >>= 1) x = tmax(x, __shfl_xor(x, off));
   return x;
 }
 template <typename T>
-__device__ __forceinline__ T wave_sum(T x)
+__device__ __forceinline__ T group_sum(T x, int G)
 {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+  for (int off = G >> 1; off > 0; off >>= 1) x += __shfl_xor(x, off);
   return x;
+}
+
+template <typename T>
+__device__ __forceinline__ size_t tail_lds_bytes(int nc, int G)
+{
+  return ((size_t)WAVE * XS + 2 * (size_t)WAVE * HS + (size_t)(WAVE / G) * nc * CD) * sizeof(T);
 }
 
 template <typename T, bool HDIAG>
 __global__ void __launch_bounds__(WAVE)
 k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
-       const int* __restrict__ child_list, int maxdepth, int maxchild, const int* __restrict__ slots)
+       const int* __restrict__ child_list, int maxdepth, int maxchild, const int* __restrict__ slots, int nslots, int G)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
-  T* xch = reinterpret_cast<T*>(smem_raw);  // [WAVE][XS]   exchange between a joint and its parent / children
-  T* hst = xch + WAVE * XS;                 // [WAVE][22]   this joint's H (pre-projection) + Dinv
-  T* cd = hst + WAVE * 22;                  // [nc][CD]     constraint data
+  T* xch = reinterpret_cast<T*>(smem_raw);  // [WAVE][XS]      exchange between a joint and its parent / children
+  T* hst = xch + WAVE * XS;                 // [2][WAVE][HS]   this joint's H (pre-projection) for two values of mu
+  T* cd = hst + 2 * WAVE * HS;              // [64/G][nc][CD]  constraint data of every instance of the wavefront
   const int lane = threadIdx.x;
-  const int slot = slots[blockIdx.x];
-  const bool isj = lane < L.nb;
-  const int jl = isj ? lane : 0;
-  char* ip = lane_ptr<T>(Bf.tiles, L, slot);  // the instance's lane pointer: identical for the 64 lanes
+  const int sub = lane / G, jlane = lane % G, gbase = sub * G;
+  const int ipw = WAVE / G;
+  const int idx = blockIdx.x * ipw + sub;
+  const bool has_inst = idx < nslots;
+  const int slot = slots[has_inst ? idx : 0];
+  const bool isj = has_inst && jlane < L.nb;
+  const int jl = isj ? jlane : 0;
+  char* ip = lane_ptr<T>(Bf.tiles, L, slot);  // the instance's lane pointer: identical within the group
   char* rec = ip + (size_t)jl * JREC * pair_bytes<T>();
   char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+  T* cdi = cd + (size_t)sub * L.nc * CD;
 
   // ---- per-lane joint description (VGPRs: every lane owns a different joint) ------------------------------
   const JointDesc d = jd[jl + 1];
@@ -68,11 +81,11 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   const int depth = isj ? tp.depth : 0;
   const bool rev = d.flags & JF_REVOLUTE;
   const bool has_parent = !(d.flags & JF_PARENT_ROOT);
-  const int plane = d.parent - 1;  // parent's lane
+  const int plane = gbase + d.parent - 1;  // parent's lane
   const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
 
-  // ---- load the instance: joint j -> lane j -----------------------------------------------------------------
-  T R[9], t[3], v[6], f[6], g[6], UD[6], p[6];
+  // ---- load the instance: joint j -> lane j of the group -----------------------------------------------------
+  T R[9], t[3], v[6], f[6], g[6], UD[6], UDo[6], p[6];
   T w, z, nu, s, r = T(0), dinv = T(0), lbi, ubi;
   {
     const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
@@ -89,12 +102,12 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       lbi = lu.x; ubi = lu.y;
     }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { UD[k] = T(0); p[k] = T(0); }
+    for (int k = 0; k < 6; ++k) { UD[k] = T(0); UDo[k] = T(0); p[k] = T(0); }
   }
-  // constraint blocks -> LDS (lanes cooperate: element e of block c by lane e, e+64)
+  // constraint blocks -> LDS (the lanes of a group cooperate)
   for (int c = 0; c < L.nc; ++c) {
     const char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
-    for (int e = lane; e < CD; e += WAVE) {
+    for (int e = jlane; e < CD; e += G) {
       T val = T(0);
       if (e < 36) {
         val = (P.mode & MODE_A_SHARED) ? Bf.uni[c * 36 + e]
@@ -104,21 +117,22 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         val = (P.mode & MODE_A_SHARED) ? Bf.uni[L.nc * 36 + c * 21 + q]
                                        : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + q / 2) * pair_bytes<T>() + (q & 1) * sizeof(T));
       } else if (e >= CD_B) {
-        const int q = e - CD_B;  // b, Atb, y, aty are consecutive 6-vectors in the tile record too, in another order
+        const int q = e - CD_B;
         const int which = q / 6, k = q % 6;
         const int pair = which == 0 ? CP_B : which == 1 ? CP_ATB : which == 2 ? CP_Y : CP_ATY;
         val = *reinterpret_cast<const T*>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
       }
-      cd[c * CD + e] = val;
+      cdi[c * CD + e] = val;
     }
   }
-  // per-instance solver scalars: every lane reads the same words
+  // per-instance solver scalars: every lane of the group reads the same words
   const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
   T mu = mu2.x;
-  T mu_h = T(-1);  // the cached H did not come along
+  T mu_h = T(-1), mu_o = T(-1);  // mu of the current / the other H slot: nothing cached yet
+  int hsl = 0;                   // current H slot
   const T bnorm = bi2.x;
   int iter = (int)bi2.y;
-  int status = (int)st2.x;
+  int status = has_inst ? (int)st2.x : ST_DONE;
   T tol_p = ld_scal<T>(srec, SC_TOL_PRIMAL), tol_d = ld_scal<T>(srec, SC_TOL_DUAL);
   int tail_iter = (int)ld_scal<T>(srec, SC_TAIL_ITER);
   T dyqp = ld_scal<T>(srec, SC_DELTA_Y_QP), atdy = ld_scal<T>(srec, SC_AT_DELTA_Y_QP);
@@ -135,12 +149,25 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     n_g = T(0);
   bool any_iter = false;
 
-  while (!done) {
+  // the loops below stay in wavefront-uniform control flow (LDS exchanges + barriers inside); a finished group only
+  // masks its updates with `act`
+  while (__any(!done)) {
+    const bool act = !done;
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
-    ++iter; ++my_iters; any_iter = true;
+    if (act) { ++iter; ++my_iters; any_iter = true; }
+
+    // ---- H cache: two slots (two most recent mu); a flip back to the previous mu costs a register swap ----------
+    if (act && (P.mode & MODE_CACHE_H) && mu_h != mu) {
+      { const T tmp = mu_h; mu_h = mu_o; mu_o = tmp; }
+      hsl ^= 1;
+      dinv = hst[((size_t)hsl * WAVE + lane) * HS + 21];  // Dinv of the slot that becomes current
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { const T tmp = UD[k]; UD[k] = UDo[k]; UDo[k] = tmp; }
+    }
+    const bool need_h = act && (!(P.mode & MODE_CACHE_H) || (mu_h != mu));
+    T* hcur = hst + ((size_t)hsl * WAVE + lane) * HS;
 
     // ================= leaf -> root: FwdPass1 + BwdPass (hxx:290-338, :31-81) =================================
-    const bool need_h = !(P.mode & MODE_CACHE_H) || (mu_h != mu);
     T hh[22];
     if (need_h) {
 #pragma unroll
@@ -149,23 +176,25 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         for (int b2 = a; b2 < 6; ++b2)
           hh[sym(a, b2)] = (a == b2 ? P.rho : T(0)) + ((HDIAG && a != b2) ? T(0) : P.Href[6 * a + b2]);
     }
+    if (act) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) p[k] = -P.rho * v[k] - P.Hv[k];
-    if (isj && d.cslot >= 0) {
-      const T* c_ = cd + d.cslot * CD;
-      if (need_h) {
+      for (int k = 0; k < 6; ++k) p[k] = -P.rho * v[k] - P.Hv[k];
+      if (isj && d.cslot >= 0) {
+        const T* c_ = cdi + d.cslot * CD;
+        if (need_h) {
 #pragma unroll
-        for (int k = 0; k < 21; ++k) hh[k] += mu_eq * c_[CD_ATA + k];
+          for (int k = 0; k < 21; ++k) hh[k] += mu_eq * c_[CD_ATA + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p[k] += c_[CD_ATY + k] - mu_eq * c_[CD_ATB + k];
       }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) p[k] += c_[CD_ATY + k] - mu_eq * c_[CD_ATB + k];
     }
     for (int lev = maxdepth; lev >= 1; --lev) {
-      if (depth == lev) {
+      if (act && depth == lev) {
         // children contributions (deposited one level deeper), largest child index first as upstream
         for (int c = 0; c < maxchild; ++c) {
           if (c < tp.nchild) {
-            const T* x = xch + child_list[tp.child_start + c] * XS;
+            const T* x = xch + (gbase + child_list[tp.child_start + c]) * XS;
             if (need_h) {
 #pragma unroll
               for (int k = 0; k < 21; ++k) hh[k] += x[k];
@@ -174,7 +203,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
             for (int k = 0; k < 6; ++k) p[k] += x[21 + k];
           }
         }
-        T U[6], Stp;
+        T U[6];
         if (need_h) {
           if (rev) {
 #pragma unroll
@@ -188,9 +217,10 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
           for (int k = 0; k < 6; ++k) UD[k] = U[k] * dinv;
 #pragma unroll
-          for (int k = 0; k < 21; ++k) hst[lane * 22 + k] = hh[k];  // pre-projection H for the forward sweep
+          for (int k = 0; k < 21; ++k) hcur[k] = hh[k];  // pre-projection H for the forward sweep
+          hcur[21] = dinv;
         }
-        Stp = rev ? (ax0 * p[3] + ax1 * p[4] + ax2 * p[5]) : (ax0 * p[0] + ax1 * p[1] + ax2 * p[2]);
+        const T Stp = rev ? (ax0 * p[3] + ax1 * p[4] + ax2 * p[5]) : (ax0 * p[0] + ax1 * p[1] + ax2 * p[2]);
         r = (w - mu_in * z) + Stp;
         if (has_parent) {
           T* x = xch + lane * XS;
@@ -220,7 +250,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_dyis = T(0),
       l_av = T(0), l_prt = T(0), l_prs = T(0), l_bp = T(0), l_bm = T(0), l_ubp = T(0), l_lbm = T(0);
     for (int lev = 1; lev <= maxdepth; ++lev) {
-      if (depth == lev) {
+      if (act && depth == lev) {
         T vpar[6], vp[6], vi[6], fi[6], hl[21];
         if (has_parent) {
 #pragma unroll
@@ -230,7 +260,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
           for (int k = 0; k < 6; ++k) vpar[k] = T(0);
         }
 #pragma unroll
-        for (int k = 0; k < 21; ++k) hl[k] = hst[lane * 22 + k];
+        for (int k = 0; k < 21; ++k) hl[k] = hcur[k];
         actinv_motion(R, t, vpar, vp);
         T udv = UD[0] * vp[0];
 #pragma unroll
@@ -266,7 +296,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
         for (int k = 0; k < 6; ++k) { v[k] = vi[k]; f[k] = fi[k]; xch[lane * XS + 21 + k] = vi[k]; }
         if (d.cslot >= 0) {
-          T* c_ = cd + d.cslot * CD;
+          T* c_ = cdi + d.cslot * CD;
           T Av[6], e[6], yy[6];
 #pragma unroll
           for (int a = 0; a < 6; ++a) {
@@ -307,16 +337,16 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     T gi[6], l_dg = T(0), l_g = T(0), l_dualv = T(0), l_stf = T(0), l_dstf = T(0);
     if (isj && d.cslot >= 0) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) gi[k] = cd[d.cslot * CD + CD_ATY + k];
+      for (int k = 0; k < 6; ++k) gi[k] = cdi[d.cslot * CD + CD_ATY + k];
     } else {
 #pragma unroll
       for (int k = 0; k < 6; ++k) gi[k] = T(0);
     }
     for (int lev = maxdepth; lev >= 1; --lev) {
-      if (depth == lev) {
+      if (act && depth == lev) {
         for (int c = 0; c < maxchild; ++c) {
           if (c < tp.nchild) {
-            const T* x = xch + child_list[tp.child_start + c] * XS;
+            const T* x = xch + (gbase + child_list[tp.child_start + c]) * XS;
 #pragma unroll
             for (int k = 0; k < 6; ++k) gi[k] += x[k];
           }
@@ -349,55 +379,60 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       __syncthreads();
     }
 
-    // ================= wavefront reductions of the running norms, then the scalar epilogue ======================
-    pr_task = wave_max(l_prt); pr_slack = wave_max(l_prs);
-    dual_v = wave_max(l_dualv); stf_w_inf = wave_max(l_stf);
-    primal = tmax(pr_task, pr_slack);
-    dual = tmax(dual_v, stf_w_inf);
-    n_dvis = wave_max(l_dvis); n_dnu = wave_max(l_dnu);
-    dx = tmax(n_dvis, n_dnu);
-    dz = wave_max(l_dz);
-    n_dfis = wave_max(l_dfis); n_dyis = wave_max(l_dyis); n_dw = wave_max(l_dw);
-    n_av = wave_max(l_av); n_nu = wave_max(l_nu); n_hrefv = wave_max(l_hrefv); n_g = wave_max(l_g);
-    bool ran_feas = false;
-    if (P.mode & MODE_FIXED_ITERS) {
-      if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
-    } else if (!(status & ST_TAIL)) {
-      tol_p = P.tol_abs + P.tol_rel * tmax(tmax(n_av, n_nu), tmax(bnorm, n_nu));
-      tol_d = P.tol_abs + P.tol_rel * tmax(tmax(n_hrefv, tmax(n_g, stf_w_inf)), P.Hv_inf_norm);
-      const bool conv = (primal < tol_p) && (dual < tol_d);
-      bool infeas = false;
-      if (iter > 1) {
-        dyqp = tmax(n_dfis, tmax(n_dyis, n_dw));
-        atdy = tmax(wave_max(l_dg), wave_max(l_dstf));
-        c1 = atdy <= P.tol_primal_inf * dyqp;
-        ubp = wave_sum(l_bp) + wave_sum(l_ubp);
-        lbm = wave_sum(l_bm) + wave_sum(l_lbm);
-        c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp;
-        infeas = c1 && c2;
-        ran_feas = true;
-      }
-      if (conv) {
-        status |= ST_CONVERGED | ST_DONE;
-        if (infeas) status |= ST_PRIMAL_INF;
-        done = true;
-      } else if (infeas) {
-        status |= ST_PRIMAL_INF | ST_TAIL;
-        tail_iter = 0;
-        if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
-      } else {
-        if (primal > T(10) * dual) mu *= T(10);
-        else if (dual > T(10) * primal) mu *= T(0.1);
+    // ================= lane-group reductions of the running norms, then the scalar epilogue ======================
+    // (executed by every lane: the shuffles need the whole wavefront; finished groups discard the results)
+    const T r_prt = group_max(l_prt, G), r_prs = group_max(l_prs, G), r_dualv = group_max(l_dualv, G),
+            r_stf = group_max(l_stf, G), r_dvis = group_max(l_dvis, G), r_dnu = group_max(l_dnu, G),
+            r_dz = group_max(l_dz, G), r_dfis = group_max(l_dfis, G), r_dyis = group_max(l_dyis, G),
+            r_dw = group_max(l_dw, G), r_av = group_max(l_av, G), r_nu = group_max(l_nu, G),
+            r_hrefv = group_max(l_hrefv, G), r_g = group_max(l_g, G), r_dg = group_max(l_dg, G),
+            r_dstf = group_max(l_dstf, G);
+    const T r_up = group_sum(l_bp, G) + group_sum(l_ubp, G), r_lm = group_sum(l_bm, G) + group_sum(l_lbm, G);
+    if (act) {
+      pr_task = r_prt; pr_slack = r_prs; dual_v = r_dualv; stf_w_inf = r_stf;
+      primal = tmax(pr_task, pr_slack);
+      dual = tmax(dual_v, stf_w_inf);
+      n_dvis = r_dvis; n_dnu = r_dnu;
+      dx = tmax(n_dvis, n_dnu);
+      dz = r_dz;
+      n_dfis = r_dfis; n_dyis = r_dyis; n_dw = r_dw; n_av = r_av; n_nu = r_nu; n_hrefv = r_hrefv; n_g = r_g;
+      if (P.mode & MODE_FIXED_ITERS) {
         if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
+      } else if (!(status & ST_TAIL)) {
+        tol_p = P.tol_abs + P.tol_rel * tmax(tmax(n_av, n_nu), tmax(bnorm, n_nu));
+        tol_d = P.tol_abs + P.tol_rel * tmax(tmax(n_hrefv, tmax(n_g, stf_w_inf)), P.Hv_inf_norm);
+        const bool conv = (primal < tol_p) && (dual < tol_d);
+        bool infeas = false;
+        if (iter > 1) {
+          dyqp = tmax(n_dfis, tmax(n_dyis, n_dw));
+          atdy = tmax(r_dg, r_dstf);
+          c1 = atdy <= P.tol_primal_inf * dyqp;
+          ubp = r_up;
+          lbm = r_lm;
+          c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp;
+          infeas = c1 && c2;
+        }
+        if (conv) {
+          status |= ST_CONVERGED | ST_DONE;
+          if (infeas) status |= ST_PRIMAL_INF;
+          done = true;
+        } else if (infeas) {
+          status |= ST_PRIMAL_INF | ST_TAIL;
+          tail_iter = 0;
+          if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
+        } else {
+          if (primal > T(10) * dual) mu *= T(10);
+          else if (dual > T(10) * primal) mu *= T(0.1);
+          if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
+        }
+      } else {
+        tail_iter += 1;
+        if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
       }
-    } else {
-      tail_iter += 1;
-      if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
     }
-    (void)ran_feas;
   }
 
-  // ---- write the instance back (same slot; the H cache is declared invalid) --------------------------------------
+  // ---- write the instance back (same slot) -------------------------------------------------------------------------
   if (isj) {
     st6<T>(rec, JP_V, v);
     st6<T>(rec, JP_F, f);
@@ -406,47 +441,48 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     stp<T>(rec, JP_NUS, nu, s);
     if (any_iter) {
       // inter-sweep temporaries of the LAST iteration (His, pis, UDinv, Dinv, r), as upstream leaves them
+      const T* hcur = hst + ((size_t)hsl * WAVE + lane) * HS;
       st6<T>(rec, JP_P, p);
       st6<T>(rec, JP_UD, UD);
       stp<T>(rec, JP_R, r, T(0));
 #pragma unroll
-      for (int k = 0; k < 11; ++k)
-        stp<T>(rec, JP_H + k, hst[lane * 22 + 2 * k], 2 * k + 1 < 21 ? hst[lane * 22 + 2 * k + 1] : dinv);
+      for (int k = 0; k < 11; ++k) stp<T>(rec, JP_H + k, hcur[2 * k], 2 * k + 1 < 21 ? hcur[2 * k + 1] : dinv);
     }
   }
   __syncthreads();
-  for (int c = 0; c < L.nc; ++c) {
-    char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
-    if (lane < 6) {
-      const int k = lane;
-      const int pair_y = CP_Y + k / 2, pair_a = CP_ATY + k / 2;
-      *reinterpret_cast<T*>(crec + (size_t)pair_y * pair_bytes<T>() + (k & 1) * sizeof(T)) = cd[c * CD + CD_Y + k];
-      *reinterpret_cast<T*>(crec + (size_t)pair_a * pair_bytes<T>() + (k & 1) * sizeof(T)) = cd[c * CD + CD_ATY + k];
+  if (has_inst) {
+    for (int c = 0; c < L.nc; ++c) {
+      char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+      if (jlane < 6) {
+        const int k = jlane;
+        *reinterpret_cast<T*>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * CD + CD_Y + k];
+        *reinterpret_cast<T*>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * CD + CD_ATY + k];
+      }
     }
-  }
-  if (lane == 0) {
-    stp<T>(srec, SP_MU, mu, any_iter ? mu_h : T(-1));
-    stp<T>(srec, SP_BI, bnorm, (T)iter);
-    stp<T>(srec, SP_ST, (T)status, T(0));
-    if (any_iter) {
-      stp<T>(srec, SP_SCAL + 0, primal, dual);
-      stp<T>(srec, SP_SCAL + 1, pr_task, pr_slack);
-      stp<T>(srec, SP_SCAL + 2, dual_v, stf_w_inf);
-      stp<T>(srec, SP_SCAL + 3, tol_p, tol_d);
-      stp<T>(srec, SP_SCAL + 4, mu, P.mu_scale * mu);
-      stp<T>(srec, SP_SCAL + 5, mu, dx);
-      stp<T>(srec, SP_SCAL + 6, dz, dyqp);
-      stp<T>(srec, SP_SCAL + 7, atdy, ubp);
-      stp<T>(srec, SP_SCAL + 8, lbm, n_dfis);
-      stp<T>(srec, SP_SCAL + 9, n_dyis, n_dw);
-      stp<T>(srec, SP_SCAL + 10, n_dvis, n_dnu);
-      stp<T>(srec, SP_SCAL + 11, n_av, n_nu);
-      stp<T>(srec, SP_SCAL + 12, n_hrefv, n_g);
-      stp<T>(srec, SP_SCAL + 13, stf_w_inf, (T)c1);
-      stp<T>(srec, SP_SCAL + 14, (T)c2, (T)tail_iter);
+    if (jlane == 0) {
+      stp<T>(srec, SP_MU, mu, any_iter ? mu_h : T(-1));
+      stp<T>(srec, SP_BI, bnorm, (T)iter);
+      stp<T>(srec, SP_ST, (T)status, T(0));
+      if (any_iter) {
+        stp<T>(srec, SP_SCAL + 0, primal, dual);
+        stp<T>(srec, SP_SCAL + 1, pr_task, pr_slack);
+        stp<T>(srec, SP_SCAL + 2, dual_v, stf_w_inf);
+        stp<T>(srec, SP_SCAL + 3, tol_p, tol_d);
+        stp<T>(srec, SP_SCAL + 4, mu, P.mu_scale * mu);
+        stp<T>(srec, SP_SCAL + 5, mu, dx);
+        stp<T>(srec, SP_SCAL + 6, dz, dyqp);
+        stp<T>(srec, SP_SCAL + 7, atdy, ubp);
+        stp<T>(srec, SP_SCAL + 8, lbm, n_dfis);
+        stp<T>(srec, SP_SCAL + 9, n_dyis, n_dw);
+        stp<T>(srec, SP_SCAL + 10, n_dvis, n_dnu);
+        stp<T>(srec, SP_SCAL + 11, n_av, n_nu);
+        stp<T>(srec, SP_SCAL + 12, n_hrefv, n_g);
+        stp<T>(srec, SP_SCAL + 13, stf_w_inf, (T)c1);
+        stp<T>(srec, SP_SCAL + 14, (T)c2, (T)tail_iter);
+      }
+      if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
+      if (!(status & ST_DONE)) atomicAdd(&Bf.counters[0], 1u);
     }
-    if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
-    if (!(status & ST_DONE)) atomicAdd(&Bf.counters[0], 1u);
   }
 }
 
