@@ -112,14 +112,18 @@ def main():
     for _ in range(args.warmup):
         solver.Solve()
     kernel_ms = 0.0
+    tail_ms = 0.0
     inst_iters = 0
     launches = 0
+    tail_inst = 0
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         solver.Solve()
         st = solver.stats()
         kernel_ms += st["kernel_ms"]
+        tail_ms += st["tail_ms"]
+        tail_inst += st["tail_instances"]
         inst_iters += st["instance_iterations"]
         launches += st["launches"]
     barrier()
@@ -127,22 +131,28 @@ def main():
 
     conv = solver.get("converged").astype(bool)
     it = solver.get("iter")
+    infeas = solver.get("primal_infeasible").astype(bool)
     n_solved = int(conv.sum())
-    stats = dict(solved=n_solved, infeasible=int(solver.get("primal_infeasible").sum()),
-                 unfinished=int(st["n_unfinished"]), iters_sum=int(it.sum()), elapsed=elapsed)
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0])
-        agg = torch.tensor([n_solved, int(it.sum()), B], dtype=torch.float64)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        total_solved, total_iters, total_B = (float(x) for x in agg)
-    else:
-        total_solved, total_iters, total_B = float(n_solved), float(it.sum()), float(B)
+    hit_max = int(((it >= prm["max_iter"] - 1) & ~conv).sum())
+    from loik_amd import sharding
+    elapsed, tot = sharding.aggregate(dist, elapsed, dict(solved=n_solved, iters=int(it.sum()), batch=B))
+    total_solved, total_iters, total_B = tot["solved"], tot["iters"], tot["batch"]
+    stats = dict(infeasible=int(infeas.sum()), unfinished=hit_max)
 
     if rank == 0:
         bytes_iter = st["bytes_per_instance_iteration"]
+        # HBM bytes from the PMC counters: collected by scripts/pmc_traffic.sh (rocprofv3 cannot run inside this
+        # process); the committed summary is used when it describes this workload
+        traffic_per_launch, traffic_note = None, "no PMC summary found (run scripts/pmc_traffic.sh on the GPU box)"
+        tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tj) and B == 65536:
+            try:
+                tjd = json.load(open(tj))
+                traffic_per_launch = tjd["hbm_bytes_per_step"] / max(launches / args.steps, 1)
+                traffic_note = "profiles/traffic_latest.json: %.3g HBM bytes per Solve() step / %.0f launches" % (
+                    tjd["hbm_bytes_per_step"], launches / args.steps)
+            except Exception as e:
+                traffic_note = "unreadable PMC summary: %r" % (e,)
         achieved = inst_iters * bytes_iter / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         line = {
             "metric": "IK solves/sec to 1e-6 residual, Talos humanoid, batch=65536 per GPU",
@@ -178,12 +188,16 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic_per_launch,
+                "traffic_note": traffic_note,
                 "bytes_per_unit": bytes_iter,
                 "unit_def": "one ADMM iteration of one instance: 8 B x (203 nb + 108 nc), nb=32, nc=1",
                 "units_per_launch": inst_iters / max(launches, 1),
                 "avg_launch_ms": kernel_ms / max(launches, 1),
                 "launches_per_step": launches / args.steps,
+                "kernels": "k_solve<double,true> (one instance per lane; %d launches/step with lane compaction) + "
+                           "k_tail<double,true> (one wavefront per 2 instances; last %d instances/step, %.1f ms/step)"
+                           % (launches / args.steps - 1, tail_inst / args.steps, tail_ms / args.steps),
             },
         }
         if world == 1 and not args.no_cpu_baseline:

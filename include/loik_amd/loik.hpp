@@ -1,0 +1,269 @@
+// loik_amd/loik.hpp -- C++17 host-side mirror of the reference's solver interface over the C-ABI (loik_amd.h).
+//
+// Same class / method names, argument order and error behaviour as
+//   loik::FirstOrderLoikOptimizedTpl<double>   (/root/reference/include/loik/loik-loid-optimized.hpp:22-808)
+//   loik::IkIdDataTypeOptimizedTpl<double>     (/root/reference/include/loik/loik-loid-data-optimized.hpp:62-379)
+//   loik::IkIdSolverBaseTpl<double>            (/root/reference/include/loik/task-solver-base.hpp:21-174)
+// so a caller of the reference switches by changing the namespace and the vector types (no Eigen / Pinocchio in
+// this image: 6-vectors are std::array<double,6> in Pinocchio's [linear; angular] order, 6x6 matrices are row-major
+// std::array<double,36>; INTEGRATION.md shows the two-line Eigen/Pinocchio adapters).
+//
+// The one addition is the batch: `batch` independent problem instances are solved by one object on one MI355X.
+// With batch == 1 every call has exactly the reference's single-instance meaning.  For batch > 1 the per-instance
+// inputs are instance-major arrays (q[batch*nq], bis[batch*nc], ...); results land in the caller-owned data
+// object, as upstream (the solver keeps `IkIdData&`, loik-loid-optimized.hpp:763).
+// All compute happens in libloik_amd.so on the GPU; there is no CPU path behind this header.
+#pragma once
+
+#include "../loik_amd.h"
+
+#include <array>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace loik_amd {
+
+// task-solver-base.hpp:13-18
+enum ADMMPenaltyUpdateStrat { DEFAULT = 0, OSQP = 1, MAXEIGENVALUE = 3 };
+
+using Index = std::size_t;
+using DVec = std::vector<double>;
+using Vec6 = std::array<double, 6>;
+using Mat6x6 = std::array<double, 36>;  // row-major
+using Motion = Vec6;                    // [linear; angular]
+
+inline Mat6x6 Identity6()
+{
+  Mat6x6 m{};
+  for (int k = 0; k < 6; ++k) m[7 * k] = 1.0;
+  return m;
+}
+
+// the members of pinocchio::Model the hot path reads (loik-loid-optimized.hxx:46-47, :118-119, :257-265)
+struct Model {
+  int njoints = 0, nq = 0, nv = 0;
+  std::vector<int> parents, jtype, idx_q, idx_v;
+  std::vector<double> axis;             // [njoints][3]
+  std::vector<double> jointPlacements;  // [njoints][12]: R row-major, t
+  std::vector<std::string> names;
+
+  static Model Builtin(const std::string& name)
+  {
+    loikb_model_desc d{};
+    if (loikb_builtin_model(name.c_str(), &d, nullptr, nullptr) != 0) throw std::runtime_error("unknown built-in model " + name);
+    Model m;
+    m.njoints = d.njoints; m.nq = d.nq; m.nv = d.nv;
+    m.parents.assign(d.parents, d.parents + d.njoints);
+    m.jtype.assign(d.jtype, d.jtype + d.njoints);
+    m.idx_q.assign(d.idx_q, d.idx_q + d.njoints);
+    m.idx_v.assign(d.idx_v, d.idx_v + d.njoints);
+    m.axis.assign(d.axis, d.axis + 3 * d.njoints);
+    m.jointPlacements.assign(d.placement, d.placement + 12 * d.njoints);
+    for (int i = 0; i < d.njoints; ++i) m.names.emplace_back(loikb_builtin_joint_name(name.c_str(), i));
+    return m;
+  }
+  Index getJointId(const std::string& n) const
+  {
+    for (std::size_t i = 0; i < names.size(); ++i)
+      if (names[i] == n) return i;
+    return names.size();
+  }
+  loikb_model_desc desc() const
+  {
+    loikb_model_desc d{};
+    d.njoints = njoints; d.nq = nq; d.nv = nv;
+    d.parents = parents.data(); d.jtype = jtype.data(); d.axis = axis.data();
+    d.idx_q = idx_q.data(); d.idx_v = idx_v.data(); d.placement = jointPlacements.data();
+    return d;
+  }
+};
+
+// caller-owned result / state object (public members, as upstream).  Instance b, joint i (1..nb), component k:
+//   z[b*nv + j], nu[...], w[...];  vis[(b*nb + (i-1))*6 + k], fis likewise;  yis[(b*nc + c)*6 + k]
+struct IkIdDataOptimized {
+  IkIdDataOptimized(const Model& model, int num_eq_c_, int batch_ = 1)
+  : batch(batch_), nb(model.njoints - 1), nv(model.nv), num_eq_c(num_eq_c_),
+    nu(static_cast<std::size_t>(batch_) * model.nv, 0.0), z(nu.size(), 0.0), w(nu.size(), 0.0),
+    vis(static_cast<std::size_t>(batch_) * (model.njoints - 1) * 6, 0.0), fis(vis.size(), 0.0),
+    yis(static_cast<std::size_t>(batch_) * num_eq_c_ * 6, 0.0)
+  {
+  }
+  int batch, nb, nv, num_eq_c;
+  DVec nu, z, w;  // z is the answer: box-projected joint velocity (loik-loid-optimized.hpp:333)
+  DVec vis, fis, yis;
+};
+
+class FirstOrderLoikOptimized {
+public:
+  using IkIdData = IkIdDataOptimized;
+
+  // the reference's 17 constructor arguments, same order (loik-loid-optimized.hpp:129-134), then batch / device
+  FirstOrderLoikOptimized(const int max_iter, const double& tol_abs, const double& tol_rel, const double& tol_primal_inf,
+                          const double& tol_dual_inf, const double& rho, const double& mu,
+                          const double& mu_equality_scale_factor, const ADMMPenaltyUpdateStrat& mu_update_strat,
+                          const int num_eq_c, const int eq_c_dim, const Model& model, IkIdData& ik_id_data,
+                          const bool warm_start, const double tol_tail_solve, const bool verbose, const bool logging,
+                          const int device = 0, const int flags = 0)
+  : model_(model), ik_id_data_(ik_id_data), batch_(ik_id_data.batch), nc_(num_eq_c)
+  {
+    loikb_options o{};
+    o.max_iter = max_iter; o.tol_abs = tol_abs; o.tol_rel = tol_rel; o.tol_primal_inf = tol_primal_inf;
+    o.tol_dual_inf = tol_dual_inf; o.rho = rho; o.mu = mu; o.mu_equality_scale_factor = mu_equality_scale_factor;
+    o.mu_update_strat = mu_update_strat; o.num_eq_c = num_eq_c; o.eq_c_dim = eq_c_dim; o.warm_start = warm_start;
+    o.tol_tail_solve = tol_tail_solve; o.verbose = verbose; o.logging = logging;
+    o.batch = batch_; o.device = device; o.precision = LOIKB_F64; o.flags = flags;
+    const loikb_model_desc d = model_.desc();
+    check(loikb_create(&d, &o, &h_));
+    rho_ = rho; tol_tail_solve_ = tol_tail_solve;
+  }
+  ~FirstOrderLoikOptimized() { loikb_destroy(h_); }
+  FirstOrderLoikOptimized(const FirstOrderLoikOptimized&) = delete;
+  FirstOrderLoikOptimized& operator=(const FirstOrderLoikOptimized&) = delete;
+
+  // loik-loid-optimized.hpp:335-361
+  void SolveInit(const DVec& q, const Mat6x6& H_ref, const Motion& v_ref, const std::vector<Index>& active_task_constraint_ids,
+                 const std::vector<Mat6x6>& Ais, const std::vector<Vec6>& bis, const DVec& lb, const DVec& ub)
+  {
+    Args a(*this, q, active_task_constraint_ids, Ais, bis, lb, ub);
+    check(loikb_solve_init(h_, q.data(), H_ref.data(), v_ref.data(), a.ids.data(), (int)a.ids.size(), a.A.data(),
+                           a.b.data(), lb.data(), ub.data(), a.nbound, a.flags));
+  }
+  // loik-loid-optimized.hpp:368-455
+  void Solve()
+  {
+    check(loikb_solve(h_));
+    fetch();
+  }
+  // loik-loid-optimized.hpp:475-580
+  void Solve(const DVec& q, const Mat6x6& H_ref, const Motion& v_ref, const std::vector<Index>& active_task_constraint_ids,
+             const std::vector<Mat6x6>& Ais, const std::vector<Vec6>& bis, const DVec& lb, const DVec& ub)
+  {
+    Args a(*this, q, active_task_constraint_ids, Ais, bis, lb, ub);
+    check(loikb_solve_full(h_, q.data(), H_ref.data(), v_ref.data(), a.ids.data(), (int)a.ids.size(), a.A.data(),
+                           a.b.data(), lb.data(), ub.data(), a.nbound, a.flags));
+    fetch();
+  }
+  // loik-loid-optimized.hpp:596-695 (one Ai for the batch; bi per instance when bi.size() == batch)
+  void Solve(const DVec& q, const Index c_id, const Mat6x6& Ai, const Vec6& bi)
+  {
+    int flags = LOIKB_A_SHARED | LOIKB_B_SHARED;
+    if (batch_ > 1 && q.size() == static_cast<std::size_t>(model_.nq)) flags |= LOIKB_Q_SHARED;
+    check(loikb_solve_tailored(h_, q.data(), (int)c_id, Ai.data(), bi.data(), flags));
+    fetch();
+  }
+  void Solve(const DVec& q, const Index c_id, const Mat6x6& Ai, const std::vector<Vec6>& bis)
+  {
+    DVec b(bis.size() * 6);
+    for (std::size_t i = 0; i < bis.size(); ++i)
+      for (int k = 0; k < 6; ++k) b[6 * i + k] = bis[i][k];
+    int flags = LOIKB_A_SHARED;
+    if (bis.size() == 1 && batch_ > 1) flags |= LOIKB_B_SHARED;
+    if (batch_ > 1 && q.size() == static_cast<std::size_t>(model_.nq)) flags |= LOIKB_Q_SHARED;
+    check(loikb_solve_tailored(h_, q.data(), (int)c_id, Ai.data(), b.data(), flags));
+    fetch();
+  }
+
+  // task-solver-base.hpp:87-141 (instance index defaults to 0: the single-instance reading)
+  int get_iter(int b = 0) const { return geti(LOIKB_F_ITER, b); }
+  double get_primal_residual(int b = 0) const { return getd(LOIKB_F_PRIMAL_RESIDUAL, b); }
+  double get_dual_residual(int b = 0) const { return getd(LOIKB_F_DUAL_RESIDUAL, b); }
+  bool get_convergence_status(int b = 0) const { return geti(LOIKB_F_CONVERGED, b) != 0; }
+  bool get_primal_infeasibility_status(int b = 0) const { return geti(LOIKB_F_PRIMAL_INFEASIBLE, b) != 0; }
+  bool get_dual_infeasibility_status(int = 0) const { return false; }  // never set by the optimized solver upstream
+  double get_mu(int b = 0) const { return getd(LOIKB_F_MU, b); }
+  double get_rho() const { return rho_; }
+  double get_tol_primal(int b = 0) const { return getd(LOIKB_F_TOL_PRIMAL, b); }
+  double get_tol_dual(int b = 0) const { return getd(LOIKB_F_TOL_DUAL, b); }
+  void set_max_iter(const int max_iter) { check(loikb_set_max_iter(h_, max_iter)); }
+  void set_rho(const double rho) { rho_ = rho; check(loikb_set_rho(h_, rho)); }
+  void set_mu(const double mu) { check(loikb_set_mu(h_, mu)); }
+  void set_tol_primal_inf(const double t) { check(loikb_set_tol_primal_inf(h_, t)); }
+  // loik-loid-optimized.hpp:700-755
+  double get_dual_residual_v(int b = 0) const { return getd(LOIKB_F_DUAL_RESIDUAL_V, b); }
+  double get_dual_residual_nu(int b = 0) const { return getd(LOIKB_F_DUAL_RESIDUAL_NU, b); }
+  double get_tol_tail_solve() const { return tol_tail_solve_; }
+  void set_tol_tail_solve(const double tol) { tol_tail_solve_ = tol; check(loikb_set_tol_tail_solve(h_, tol)); }
+  double get_delta_x_qp_inf_norm(int b = 0) const { return getd(LOIKB_F_DELTA_X_QP_INF_NORM, b); }
+  double get_delta_z_qp_inf_norm(int b = 0) const { return getd(LOIKB_F_DELTA_Z_QP_INF_NORM, b); }
+  double get_delta_y_qp_inf_norm(int b = 0) const { return getd(LOIKB_F_DELTA_Y_QP_INF_NORM, b); }
+  double get_A_qp_T_delta_y_qp_inf_norm(int b = 0) const { return getd(LOIKB_F_A_QP_T_DELTA_Y_QP_INF_NORM, b); }
+  double get_ub_qp_T_delta_y_qp_plus(int b = 0) const { return getd(LOIKB_F_UB_QP_T_DELTA_Y_QP_PLUS, b); }
+  double get_lb_qp_T_delta_y_qp_minus(int b = 0) const { return getd(LOIKB_F_LB_QP_T_DELTA_Y_QP_MINUS, b); }
+  bool get_primal_infeasibility_cond_1(int b = 0) const { return getd(LOIKB_F_PRIMAL_INFEASIBILITY_COND_1, b) != 0.0; }
+  bool get_primal_infeasibility_cond_2(int b = 0) const { return getd(LOIKB_F_PRIMAL_INFEASIBILITY_COND_2, b) != 0.0; }
+
+  loikb_stats stats() const
+  {
+    loikb_stats s{};
+    loikb_get_stats(h_, &s);
+    return s;
+  }
+  loikb_solver* handle() const { return h_; }
+
+private:
+  struct Args {
+    std::vector<int> ids;
+    DVec A, b;
+    int flags = 0, nbound = 0;
+    Args(const FirstOrderLoikOptimized& s, const DVec& q, const std::vector<Index>& cids, const std::vector<Mat6x6>& Ais,
+         const std::vector<Vec6>& bis, const DVec& lb, const DVec& ub)
+    {
+      // same consistency checks, same messages as ik-id-description-optimized.hpp:132-151, :328-335
+      if (lb.size() != ub.size())
+        throw std::runtime_error("[IkProblemFormulation::UpdateIneqConstraints]: lower bound and upper bound have different dimensions!!!");
+      const std::size_t nc = cids.size(), B = static_cast<std::size_t>(s.batch_);
+      if (!(Ais.size() == nc || Ais.size() == nc * B) || !(bis.size() == nc || bis.size() == nc * B))
+        throw std::runtime_error("[IkProblemFormulation::UpdateEqConstraints]: task_constraint_ids, Ais, and bis have different size !!!");
+      for (Index c : cids) ids.push_back(static_cast<int>(c));
+      A.resize(Ais.size() * 36);
+      for (std::size_t i = 0; i < Ais.size(); ++i)
+        for (int k = 0; k < 36; ++k) A[36 * i + k] = Ais[i][k];
+      b.resize(bis.size() * 6);
+      for (std::size_t i = 0; i < bis.size(); ++i)
+        for (int k = 0; k < 6; ++k) b[6 * i + k] = bis[i][k];
+      if (Ais.size() == nc) flags |= LOIKB_A_SHARED;
+      if (bis.size() == nc && B > 1) flags |= LOIKB_B_SHARED;
+      const std::size_t nv = static_cast<std::size_t>(s.model_.nv);
+      if (lb.size() == nv * B && B > 1) nbound = (int)nv;
+      else { nbound = (int)lb.size(); flags |= LOIKB_BOUNDS_SHARED; }
+      if (B > 1 && q.size() == static_cast<std::size_t>(s.model_.nq)) flags |= LOIKB_Q_SHARED;
+    }
+  };
+
+  void check(int rc) const
+  {
+    if (rc == LOIKB_OK) return;
+    const char* msg = (rc <= LOIKB_ERR_ARG || rc == LOIKB_ERR_MODEL) ? loikb_last_error() : loikb_status_string(rc);
+    throw std::runtime_error(msg && *msg ? msg : loikb_status_string(rc));
+  }
+  void fetch()
+  {
+    check(loikb_get(h_, LOIKB_F_Z, ik_id_data_.z.data(), 0));
+    check(loikb_get(h_, LOIKB_F_NU, ik_id_data_.nu.data(), 0));
+    check(loikb_get(h_, LOIKB_F_W, ik_id_data_.w.data(), 0));
+    check(loikb_get(h_, LOIKB_F_VIS, ik_id_data_.vis.data(), 0));
+    check(loikb_get(h_, LOIKB_F_FIS, ik_id_data_.fis.data(), 0));
+    if (nc_ > 0) check(loikb_get(h_, LOIKB_F_YIS, ik_id_data_.yis.data(), 0));
+  }
+  int geti(int field, int b) const
+  {
+    std::vector<int> tmp(static_cast<std::size_t>(batch_));
+    check(loikb_get(h_, field, tmp.data(), 0));
+    return tmp[static_cast<std::size_t>(b)];
+  }
+  double getd(int field, int b) const
+  {
+    DVec tmp(static_cast<std::size_t>(batch_));
+    check(loikb_get(h_, field, tmp.data(), 0));
+    return tmp[static_cast<std::size_t>(b)];
+  }
+
+  Model model_;             // by value, as upstream (loik-loid-optimized.hpp:762)
+  IkIdData& ik_id_data_;    // caller-owned, must outlive the solver (loik-loid-optimized.hpp:763)
+  loikb_solver* h_ = nullptr;
+  int batch_, nc_;
+  double rho_ = 0.0, tol_tail_solve_ = 0.0;
+};
+
+}  // namespace loik_amd

@@ -1,0 +1,32 @@
+"""Builds and runs the C++ parity test of the drop-in wrapper (include/loik_amd/loik.hpp) on the GPU box."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "test_wrapper")
+
+
+def build():
+    src = os.path.join(ROOT, "tests", "cpp", "test_wrapper.cpp")
+    libdir = os.path.join(ROOT, "loik_amd", "lib")
+    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), src, "-o", EXE,
+           "-L", libdir, "-lloik_amd", "-L", os.path.join(ROOT, "oracle"), "-lloik_ref",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+
+
+def test_cpp_wrapper_compiles():
+    """CPU: the header-only wrapper compiles against the C-ABI and links"""
+    build()
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+def test_cpp_wrapper_matches_oracle():
+    build()
+    out = subprocess.run([EXE], capture_output=True, text=True, timeout=600)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all wrapper checks passed" in out.stdout
