@@ -97,13 +97,20 @@ def main():
             dist.barrier()
         device_sync()
 
-    if loik_amd.device_count() <= local_rank:
+    ndev = loik_amd.device_count()
+    if ndev < 1:
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    device = local_rank
+    if device >= ndev:
+        # fewer visible GPUs than ranks (only for smoke-testing the multi-process path on a 1-GPU box)
+        if os.environ.get("LOIKB_ALLOW_SHARED_GPU") != "1":
+            raise SystemExit("rank %d has no GPU of its own (%d visible); set LOIKB_ALLOW_SHARED_GPU=1 to share" % (rank, ndev))
+        device = local_rank % ndev
 
     B = args.batch
     wl = workloads.talos_c3(B, seed=0x101C + 3 + rank)
     model, prm = wl["model"], wl["params"]
-    solver = loik_amd.BatchedLoik(model, B, device=local_rank, flags=args.flags, max_launch_iters=args.max_launch_iters,
+    solver = loik_amd.BatchedLoik(model, B, device=device, flags=args.flags, max_launch_iters=args.max_launch_iters,
                                   **prm)
     t_init = time.perf_counter()
     solver.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])

@@ -57,7 +57,7 @@ enum {
   LOIKB_OPT_NO_H_CACHE = 2,  /* recompute H_i/UDinv/Dinv every iteration like upstream (default: reuse them
                                  while mu is unchanged -- bit-identical results, fewer HBM bytes)            */
   LOIKB_OPT_NO_COMPACTION = 4 /* never repack live instances into dense wavefronts between launches (default:
-                                 repack when at most half of the slots are still iterating; results are
+                                 repack when at most 85 % of the slots are still iterating; results are
                                  bit-identical, but the inter-sweep temporaries His/pis/UDinv/Dinv/r of
                                  instances that moved are not retrievable afterwards)                         */
 };

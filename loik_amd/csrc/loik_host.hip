@@ -501,7 +501,7 @@ int compact(loikb_solver_impl* S, int src, int dst, int n_src, int* n_dst_out)
   loikb_solver_impl::Set& A = S->set[src];
   const int nw = (n_src + WAVE - 1) / WAVE;
   int rc;
-  if (dst >= 0 && (rc = alloc_set(S, dst, (S->set[0].ntiles + 1) / 2))) return rc;
+  if (dst >= 0 && (rc = alloc_set(S, dst, S->set[0].ntiles))) return rc;
   // exclusive scan of the per-wavefront live counts on the host (nw <= B/64 ints)
   S->h_wave.resize(2 * (size_t)nw + 2);
   int* cnt = S->h_wave.data();
@@ -591,9 +591,13 @@ int run_main_loop_t(loikb_solver_impl* S)
   // compaction pays only while the launch is bandwidth-bound (many wavefronts); below that an ADMM iteration
   // costs the same single-wavefront latency however few lanes are live
   const int compact_min = S->opt.compact_min_instances > 0 ? S->opt.compact_min_instances : 64 * WAVE;
+  // k_move costs ~6 KB of traffic per live instance (a fraction of ONE iteration's ~32 KB), so repack eagerly
+  double compact_ratio = 0.85;
+  if (const char* e = getenv("LOIKB_COMPACT_RATIO")) compact_ratio = atof(e);
   // cooperative tail kernel (one wavefront per instance) once few instances are left
   const bool use_tail = can_compact && S->nb <= WAVE && S->opt.tail_max_instances >= 0;
   const int tail_max = S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : 2048;
+  const bool trace = getenv("LOIKB_TRACE") != nullptr;
   int cur = 0, n_cur = S->B;
   int done_iters = 0;
   unsigned long long inst_iters = 0;
@@ -622,12 +626,17 @@ int run_main_loop_t(loikb_solver_impl* S)
     inst_iters += S->h_counters[1];
     n_live = S->h_counters[0];
     done_iters += launch_iters;
+    if (trace)
+      fprintf(stderr, "[loikb] launch %3d: set %d slots %7d iters %4d..%4d  %8.3f ms  inst-iters %9u (%.1f M/s)  live after %7u\n",
+              S->stats.launches, cur, n_cur, done_iters - launch_iters + 1, done_iters, ms, S->h_counters[1],
+              S->h_counters[1] / ms / 1e3, n_live);
     if (n_live == 0 || done_iters >= max_total) break;
     if (use_tail && (int)n_live <= tail_max) {
       double tms = 0.0;
       int rc = run_tail<T>(S, P, cur, n_cur, (int)n_live, &tms);
       if (rc) return rc;
       kernel_ms += tms;
+      if (trace) fprintf(stderr, "[loikb] tail kernel: %u instances  %8.3f ms  inst-iters %9u\n", n_live, tms, S->h_counters[1]);
       S->stats.tail_ms = tms;
       S->stats.tail_instances = (int)n_live;
       S->stats.launches++;
@@ -635,7 +644,7 @@ int run_main_loop_t(loikb_solver_impl* S)
       n_live = S->h_counters[0];
       break;
     }
-    if (may_compact_later && 2 * (long long)n_live <= n_cur) {
+    if (may_compact_later && (double)n_live <= compact_ratio * n_cur) {
       const int dst = cur == 1 ? 2 : 1;
       int n_new = 0;
       int rc = compact<T>(S, cur, dst, n_cur, &n_new);
