@@ -43,10 +43,18 @@ enum : int {
   JP_NUS = 11,   // (nu_i, Stf_plus_w_i)
   JP_P = 12,     // pis[i]                      3 pairs                     -- inter-sweep temporaries
   JP_R = 15,     // (r_i after += S^T p, unused)   -- always written as a full 16-byte pair
-  JP_UD = 16,    // UDinv                       3 pairs
-  JP_H = 19,     // His[i] packed 21, then Dinv 11 pairs
-  JP_LBUB = 30,  // (lb_i, ub_i) when the box is per instance
-  JREC = 32,
+  JP_LBUB = 16,  // (lb_i, ub_i) when the box is per instance
+  // H cache: NSLOT copies of {UDinv (3 pairs), His packed 21 + Dinv (11 pairs)}, one per cached value of mu.  mu only
+  // ever moves by decades (mu0 * 10^k), so slot = k mod NSLOT.  Measured on MI355X: NSLOT = 3 removes nearly every
+  // repeated H-recursion of the stragglers (which flip between 2-3 decades) but the lanes of a wavefront then sit in
+  // DIFFERENT slots, every H/UDinv access touches up to 3 partially used 1-KiB rows, and the bandwidth-bound phases
+  // lose more than the cached sweeps win (88 -> 95 ms/step).  So one slot in HBM; the tail kernel keeps two in LDS.
+  JP_SLOT0 = 17,
+  SL_UD = 0,
+  SL_H = 3,
+  SLOT_PAIRS = 14,
+  NSLOT = 1,
+  JREC = JP_SLOT0 + NSLOT * SLOT_PAIRS,  // 59
   JP_NPERSIST = 12,  // pairs [0, JP_NPERSIST) (+ JP_LBUB) travel with an instance on compaction
   // constraint record
   CP_Y = 0,      // yis[c]     3 pairs
@@ -58,11 +66,12 @@ enum : int {
   CP_ATA = 30,   // AtA[c] packed 21 + pad -> 11 pairs
   CREC_FULL = 42,
   // per-instance solver scalars
-  SP_MU = 0,     // (mu_, mu the cached H/UDinv/Dinv were computed with)
+  SP_MU = 0,     // (mu_, k) with mu_ = mu0 * 10^k
   SP_BI = 1,     // (bis_inf_norm_, iter_)
-  SP_ST = 2,     // (status bits, unused)
-  SP_SCAL = 3,   // scal[NSCAL] -> 15 pairs
-  SREC = 18,
+  SP_ST = 2,     // (status bits, decade k of the mu the LAST executed iteration used = slot of its His/UDinv/Dinv)
+  SP_TAG = 3,    // mu each H-cache slot was computed with: (tag0, tag1), (tag2, unused); -1 = empty
+  SP_SCAL = 5,   // scal[NSCAL] -> 15 pairs
+  SREC = 20,
 };
 
 struct Layout {
@@ -454,7 +463,7 @@ struct Norms {
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool WITH_H, bool HDIAG>
 __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf, const JointDesc* __restrict__ jd,
-                                          T* stk, char* lp, int lane, bool live, T mu_eq, T mu_in)
+                                          T* stk, char* lp, int lane, bool live, T mu_eq, T mu_in, size_t hoff)
 {
   constexpr int NENT = 27;
   const Layout& L = P.L;
@@ -471,8 +480,9 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
     if (live) {
       T vprev[6], hh[21], pp[6], U[6], UD[6];
       const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ);
+      char* hrec = rec + (size_t)JP_SLOT0 * pair_bytes<T>() + hoff;  // this lane's H-cache slot
       ld6<T>(rec, JP_V, vprev);
-      if (!WITH_H) ld6<T>(rec, JP_UD, UD);
+      if (!WITH_H) ld6<T>(hrec, SL_UD, UD);
       // FwdPass1 (hxx:304-315): H_i = rho I + H_ref ; p_i = -rho v_prev - Hv
       if (WITH_H) {
 #pragma unroll
@@ -542,8 +552,8 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
         for (int k = 0; k < 6; ++k) UD[k] = U[k] * dd;
         // store the pre-projection H (what the forward sweep needs, hxx:121) with Dinv in its 22nd slot, UDinv
 #pragma unroll
-        for (int k = 0; k < 11; ++k) stp<T>(rec, JP_H + k, hh[2 * k], 2 * k + 1 < 21 ? hh[2 * k + 1] : dd);
-        st6<T>(rec, JP_UD, UD);
+        for (int k = 0; k < 11; ++k) stp<T>(hrec, SL_H + k, hh[2 * k], 2 * k + 1 < 21 ? hh[2 * k + 1] : dd);
+        st6<T>(hrec, SL_UD, UD);
       }
       stp<T>(rec, JP_R, ri, T(0));
 
@@ -589,7 +599,7 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool HDIAG>
 __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf, const JointDesc* __restrict__ jd,
-                                          char* lp, bool live, T mu_eq, T mu_in, Norms<T>& N)
+                                          char* lp, bool live, T mu_eq, T mu_in, size_t hoff, Norms<T>& N)
 {
   const Layout& L = P.L;
   T vcur[6];
@@ -601,15 +611,16 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
     char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
     if (live) {
       T hh[22], pp[6], UD[6], vprev[6], fold[6], vpar[6], vp[6], vi[6], fi[6], R[9], t[3];
+      const char* hrec = rec + (size_t)JP_SLOT0 * pair_bytes<T>() + hoff;
       const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS),
                                    rd = ldp<T>(rec, JP_R);
 #pragma unroll
       for (int k = 0; k < 11; ++k) {
-        const typename Vec2<T>::type a = ldp<T>(rec, JP_H + k);
+        const typename Vec2<T>::type a = ldp<T>(hrec, SL_H + k);
         hh[2 * k] = a.x; hh[2 * k + 1] = a.y;
       }
       ld6<T>(rec, JP_P, pp);
-      ld6<T>(rec, JP_UD, UD);
+      ld6<T>(hrec, SL_UD, UD);
       ld6<T>(rec, JP_V, vprev);
       ld6<T>(rec, JP_F, fold);
       T lbi, ubi;
@@ -819,7 +830,8 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool HDIAG>
 __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& Bf, const JointDesc* __restrict__ jd,
-                                            T* stk, char* lp, int lane, bool live, T mu_eq, T mu_in, Norms<T>& N)
+                                            T* stk, char* lp, int lane, bool live, T mu_eq, T mu_in, size_t hoff,
+                                            Norms<T>& N)
 {
   constexpr int NENT = 27;
   const Layout& L = P.L;
@@ -836,7 +848,7 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
       ld6<T>(rec, JP_F, fi);
       ld6<T>(rec, JP_V, vi);
       ld6<T>(rec, JP_G, gold);
-      ld6<T>(rec, JP_UD, UD);
+      ld6<T>(rec + (size_t)JP_SLOT0 * pair_bytes<T>() + hoff, SL_UD, UD);
       const T wi = wz.x, sold = nus.y;
       // ---- iteration k: g_i = (Aty_c | 0) + sum_children act(f_j) - f_i   (hxx:438-439, :210-212)
       //      iteration k+1: p_i = -rho v_i - Hv (+ Aty_c - mu_eq Atb_c)       (hxx:304-315, :321-334)
@@ -942,16 +954,21 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
   char* lp = Bf.tiles + (size_t)blockIdx.x * L.tile_pairs * pair_bytes<T>() + (size_t)lane * 2 * sizeof(T);
   char* srec = lp + (size_t)L.off_s * pair_bytes<T>();
 
-  const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
+  const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST),
+                               tg01 = ldp<T>(srec, SP_TAG), tg2 = ldp<T>(srec, SP_TAG + 1);
   int status = inb ? (int)st2.x : ST_DONE;
   int iter = (int)bi2.y;
-  T mu = mu2.x, mu_h = mu2.y;
+  T mu = mu2.x;
+  int kexp = (int)mu2.y;                      // mu = mu0 * 10^kexp
+  int klast = (int)st2.y;                     // decade of the last executed iteration (for the His/UDinv getters)
+  T tag0 = tg01.x, tag1 = tg01.y, tag2 = tg2.x;  // mu each H-cache slot holds (-1: empty)
   const T bnorm = bi2.x;
   bool live = inb && !(status & ST_DONE);
   // main-loop bound `for (i = 1; i < max_iter; ++i)` (hpp:377): nothing to do when max_iter <= 1
   if (live && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { live = false; status |= ST_DONE; }
   unsigned int my_iters = 0;
   bool have_p = false;  // p_i, r_i of the coming iteration already built by the fused sweep (with the current mu)
+  bool spec = true;     // fuse the next p-recursion into the residual sweep (pays only if no lane then changes mu)
 
   for (int k = 0; k < P.max_launch_iters; ++k) {
     if (!__any(live)) break;
@@ -959,25 +976,35 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
     const T mu_in = mu;
     Norms<T> N;
     N.reset();
-    if (live) { ++iter; ++my_iters; }
+    if (live) { ++iter; ++my_iters; klast = kexp; }
 
+    // H-cache slot of this lane's current mu (slot = kexp mod 3) and whether it holds that mu
+    const int slot = ((kexp % NSLOT) + NSLOT) % NSLOT;
+    const size_t hoff = (size_t)slot * SLOT_PAIRS * pair_bytes<T>();
+    const T tag = slot == 0 ? tag0 : (slot == 1 ? tag1 : tag2);
     // leaf -> root sweep of this iteration, unless the previous iteration's fused sweep already did it
     if (!have_p) {
-      const bool need_h = !(P.mode & MODE_CACHE_H) || __any(live && (mu_h != mu));
+      const bool need_h = !(P.mode & MODE_CACHE_H) || __any(live && (tag != mu));
       if (need_h) {
-        sweep_bwd<T, true, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in);
-        if (live) mu_h = mu;
+        sweep_bwd<T, true, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in, hoff);
+        if (live) {
+          if (slot == 0) tag0 = mu;
+          else if (slot == 1) tag1 = mu;
+          else tag2 = mu;
+        }
       } else {
-        sweep_bwd<T, false, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in);
+        sweep_bwd<T, false, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in, hoff);
       }
     }
-    sweep_fwd<T, HDIAG>(P, Bf, jd, lp, live, mu_eq, mu_in, N);
-    if (P.mode & MODE_CACHE_H) {
-      sweep_fused<T, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in, N);
+    sweep_fwd<T, HDIAG>(P, Bf, jd, lp, live, mu_eq, mu_in, hoff, N);
+    if ((P.mode & MODE_CACHE_H) && spec) {
+      sweep_fused<T, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in, hoff, N);
       have_p = true;
     } else {
       sweep_bwd2<T, HDIAG>(P, Bf, jd, stk, lp, lane, live, N);
+      have_p = false;
     }
+    const T mu_before = mu;
 
     if (live) {
       // ComputePrimalResiduals / ComputeDualResiduals (hxx:494-522)
@@ -1021,8 +1048,8 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
           }
         } else {
           // UpdateMu (hxx:617-631)
-          if (primal > T(10) * dual) mu *= T(10);
-          else if (dual > T(10) * primal) mu *= T(0.1);
+          if (primal > T(10) * dual) { mu *= T(10); ++kexp; }
+          else if (dual > T(10) * primal) { mu *= T(0.1); --kexp; }
           if (iter + 1 >= P.max_iter) { status |= ST_DONE; live = false; }
         }
       } else {
@@ -1058,14 +1085,20 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
       stp<T>(srec, SP_SCAL + 13, N.stf_w_inf, (T)c1);              // STF_PLUS_W_INF, COND1
       stp<T>(srec, SP_SCAL + 14, (T)c2, (T)tail_iter);             // COND2, TAIL_ITER
     }
-    // the speculative p-recursion used this iteration's mu: redo the leaf -> root sweep if any lane moved on
-    if (have_p && __any(live && (mu_h != mu))) have_p = false;
+    // the speculative p-recursion used this iteration's mu: redo the leaf -> root sweep if any lane moved on; and
+    // speculate again only after an iteration in which no lane of the wavefront changed mu (wavefronts full of
+    // stragglers flip mu almost every iteration: there the plain three-sweep iteration is cheaper)
+    const bool changed = __any(live && (mu != mu_before));
+    if (changed) have_p = false;
+    spec = !changed;
   }
 
   if (inb) {
-    stp<T>(srec, SP_MU, mu, mu_h);
+    stp<T>(srec, SP_MU, mu, (T)kexp);
+    stp<T>(srec, SP_TAG, tag0, tag1);
+    stp<T>(srec, SP_TAG + 1, tag2, T(0));
     stp<T>(srec, SP_BI, bnorm, (T)iter);
-    stp<T>(srec, SP_ST, (T)status, T(0));
+    stp<T>(srec, SP_ST, (T)status, (T)klast);
   }
   const unsigned long long live_mask = __ballot(live);
   unsigned int it_sum = my_iters;
@@ -1136,15 +1169,21 @@ __global__ void k_upload_rows(const double* __restrict__ src, int n, int shared,
 }
 
 // tile elements -> instance-major [B][n] doubles; as_int: write int32 instead
+// h_slot: the rows address H-cache slot 0; shift them to the slot of the instance's current mu
 template <typename T>
 __global__ void k_download_rows(char* tiles, Layout L, const int* __restrict__ rowmap, int n, int B,
-                                double* __restrict__ dst, int as_int, int mask)
+                                double* __restrict__ dst, int as_int, int mask, int h_slot)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   char* lp = lane_ptr<T>(tiles, L, b);
+  int shift = 0;
+  if (h_slot) {
+    const int kexp = (int)*elem_ptr<T>(lp + (size_t)L.off_s * pair_bytes<T>(), SP_ST, 1);
+    shift = (((kexp % NSLOT) + NSLOT) % NSLOT) * SLOT_PAIRS * 2;
+  }
   for (int r = 0; r < n; ++r) {
-    const int m = rowmap[r];
+    const int m = rowmap[r] + shift;
     const T x = *elem_ptr<T>(lp, m >> 1, m & 1);
     if (as_int) {
       const int v = (int)x;
@@ -1220,19 +1259,22 @@ __global__ void __launch_bounds__(WAVE) k_reset(char* tiles, Layout L, int what,
   }
   char* srec = lp + (size_t)L.off_s * pair_bytes<T>();
   if (what & RS_SOLVER) {
-    st_lo<T>(srec, SP_MU, mu0);
+    stp<T>(srec, SP_MU, mu0, T(0));
     st_hi<T>(srec, SP_BI, T(0));
     stp<T>(srec, SP_ST, T(0), T(0));
     for (int p = SP_SCAL; p < SREC; ++p) stp<T>(srec, p, T(0), T(0));
   }
-  if (what & RS_HCACHE) st_hi<T>(srec, SP_MU, T(-1));
+  if (what & RS_HCACHE) {
+    stp<T>(srec, SP_TAG, T(-1), T(-1));
+    stp<T>(srec, SP_TAG + 1, T(-1), T(0));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // lane compaction: physical repack of the live instances of one buffer set into the first slots of another
 // (dense wavefronts again), and return of the finished ones to their home slot.  One source wavefront (tile)
 // per workgroup; `wave_off[w]` = exclusive prefix sum of the live-lane counts (host-side scan of `wave_live`).
-// Only the persistent pairs travel; the inter-sweep temporaries are rebuilt (mu_h = -1 forces the H sweep).
+// Only the persistent pairs travel; the inter-sweep temporaries are rebuilt (empty H-cache tags force the H sweep).
 // ------------------------------------------------------------------------------------------------
 struct MovePlan {
   char* src;
@@ -1284,7 +1326,8 @@ __global__ void __launch_bounds__(WAVE) k_move(const MovePlan M)
     stp<T>(dp, p, v.x, v.y);
   }
   // the H/UDinv/Dinv cache did not travel
-  st_hi<T>(dp + (size_t)L.off_s * pair_bytes<T>(), SP_MU, T(-1));
+  stp<T>(dp + (size_t)L.off_s * pair_bytes<T>(), SP_TAG, T(-1), T(-1));
+  stp<T>(dp + (size_t)L.off_s * pair_bytes<T>(), SP_TAG + 1, T(-1), T(0));
 }
 
 }  // namespace loikb

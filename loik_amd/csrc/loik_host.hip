@@ -917,7 +917,7 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   const int nb = S->nb;
   std::vector<int> rm;
   bool is_int = false;
-  int mask = 0;
+  int mask = 0, h_slot = 0;
   auto per_joint = [&](int pair, int half) { for (int j = 0; j < nb; ++j) rm.push_back((j * JREC + pair) * 2 + half); };
   auto per_joint_vec = [&](int pair, int n) {
     for (int j = 0; j < nb; ++j)
@@ -933,13 +933,13 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   case LOIKB_F_W: per_joint(JP_WZ, 0); break;
   case LOIKB_F_STF_PLUS_W: per_joint(JP_NUS, 1); break;
   case LOIKB_F_R: per_joint(JP_R, 0); break;
-  case LOIKB_F_DINV: per_joint(JP_H + 10, 1); break;
+  case LOIKB_F_DINV: per_joint(JP_SLOT0 + SL_H + 10, 1); h_slot = 1; break;
   case LOIKB_F_VIS: per_joint_vec(JP_V, 6); break;
   case LOIKB_F_FIS: per_joint_vec(JP_F, 6); break;
   case LOIKB_F_G: per_joint_vec(JP_G, 6); break;
   case LOIKB_F_PIS: per_joint_vec(JP_P, 6); break;
-  case LOIKB_F_UDINV: per_joint_vec(JP_UD, 6); break;
-  case LOIKB_F_HIS: per_joint_vec(JP_H, 21); break;
+  case LOIKB_F_UDINV: per_joint_vec(JP_SLOT0 + SL_UD, 6); h_slot = 1; break;
+  case LOIKB_F_HIS: per_joint_vec(JP_SLOT0 + SL_H, 21); h_slot = 1; break;
   case LOIKB_F_YIS: per_constraint_vec(CP_Y); break;
   case LOIKB_F_ATY: per_constraint_vec(CP_ATY); break;
   case LOIKB_F_LIMI: break;
@@ -972,10 +972,10 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
     if ((rc = set_rowmap(S, rm))) return rc;
     if (S->f32)
       hipLaunchKernelGGL(k_download_rows<float>, grid1(S->B), dim3(256), 0, S->stream, S->set[0].tiles, L, S->d_rowmap, n,
-                         S->B, dst, (int)is_int, mask);
+                         S->B, dst, (int)is_int, mask, h_slot);
     else
       hipLaunchKernelGGL(k_download_rows<double>, grid1(S->B), dim3(256), 0, S->stream, S->set[0].tiles, L, S->d_rowmap, n,
-                         S->B, dst, (int)is_int, mask);
+                         S->B, dst, (int)is_int, mask, h_slot);
   }
   HIPCHK(hipGetLastError());
   if (!to_dev) HIPCHK(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, S->stream));

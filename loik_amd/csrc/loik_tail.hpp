@@ -128,6 +128,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   // per-instance solver scalars: every lane of the group reads the same words
   const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
   T mu = mu2.x;
+  int kexp = (int)mu2.y;         // mu = mu0 * 10^kexp
   T mu_h = T(-1), mu_o = T(-1);  // mu of the current / the other H slot: nothing cached yet
   int hsl = 0;                   // current H slot
   const T bnorm = bi2.x;
@@ -421,8 +422,8 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
           tail_iter = 0;
           if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
         } else {
-          if (primal > T(10) * dual) mu *= T(10);
-          else if (dual > T(10) * primal) mu *= T(0.1);
+          if (primal > T(10) * dual) { mu *= T(10); ++kexp; }
+          else if (dual > T(10) * primal) { mu *= T(0.1); --kexp; }
           if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
         }
       } else {
@@ -441,12 +442,16 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     stp<T>(rec, JP_NUS, nu, s);
     if (any_iter) {
       // inter-sweep temporaries of the LAST iteration (His, pis, UDinv, Dinv, r), as upstream leaves them
+      // (they belong to the mu of the last iteration: slot of mu_h's decade; getters read the slot of the final mu,
+      //  which is the same unless the very last epilogue changed mu at the iteration bound)
       const T* hcur = hst + ((size_t)hsl * WAVE + lane) * HS;
+      const int kh = kexp + (mu_h == mu ? 0 : (mu_h > mu ? 1 : -1));
+      char* hrec = rec + (size_t)(JP_SLOT0 + (((kh % NSLOT) + NSLOT) % NSLOT) * SLOT_PAIRS) * pair_bytes<T>();
       st6<T>(rec, JP_P, p);
-      st6<T>(rec, JP_UD, UD);
+      st6<T>(hrec, SL_UD, UD);
       stp<T>(rec, JP_R, r, T(0));
 #pragma unroll
-      for (int k = 0; k < 11; ++k) stp<T>(rec, JP_H + k, hcur[2 * k], 2 * k + 1 < 21 ? hcur[2 * k + 1] : dinv);
+      for (int k = 0; k < 11; ++k) stp<T>(hrec, SL_H + k, hcur[2 * k], 2 * k + 1 < 21 ? hcur[2 * k + 1] : dinv);
     }
   }
   __syncthreads();
@@ -460,9 +465,19 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       }
     }
     if (jlane == 0) {
-      stp<T>(srec, SP_MU, mu, any_iter ? mu_h : T(-1));
+      stp<T>(srec, SP_MU, mu, (T)kexp);
+      {  // H-cache tags: only the slot written above is valid
+        const int kh = kexp + (mu_h == mu ? 0 : (mu_h > mu ? 1 : -1));
+        const int sl = ((kh % NSLOT) + NSLOT) % NSLOT;
+        const T tv = any_iter ? mu_h : T(-1);
+        stp<T>(srec, SP_TAG, sl == 0 ? tv : T(-1), sl == 1 ? tv : T(-1));
+        stp<T>(srec, SP_TAG + 1, sl == 2 ? tv : T(-1), T(0));
+      }
       stp<T>(srec, SP_BI, bnorm, (T)iter);
-      stp<T>(srec, SP_ST, (T)status, T(0));
+      {
+        const int kh = kexp + (mu_h == mu ? 0 : (mu_h > mu ? 1 : -1));
+        stp<T>(srec, SP_ST, (T)status, any_iter ? (T)kh : st2.y);
+      }
       if (any_iter) {
         stp<T>(srec, SP_SCAL + 0, primal, dual);
         stp<T>(srec, SP_SCAL + 1, pr_task, pr_slack);
