@@ -423,20 +423,77 @@ __device__ __forceinline__ void href_mul(const T* Href, const T* v, T* o)
   }
 }
 
-// per-lane LDS stack of pending branch accumulators: [level][entry][lane]
-template <typename T>
-__device__ __forceinline__ void stack_push(T* stk, int level, int nent, const T* x, int n, int lane)
+// ---- team schedule ---------------------------------------------------------------------------------
+// A tile (64 instances, one per lane) is advanced by a TEAM of `nw` wavefronts (one workgroup).  Every wavefront
+// keeps the lane = instance mapping, so all tile accesses stay full 1-KiB rows; the joints of a sweep are dealt
+// out to the wavefronts by a host-built step schedule (list scheduling over the kinematic tree, see
+// build_team_schedule() in loik_host.hip): at step t wavefront w handles joint sched[w][t] (0 = idle), all
+// wavefronts meet at a workgroup barrier after every step.  Independent chains of the tree (legs, arms, head of a
+// humanoid) therefore run concurrently and a sweep costs the tree's critical path instead of nb joint visits.
+// nw = 1 is the plain one-wavefront-per-tile case (no barriers).
+// Leaf->root hand-over of a joint's contribution to its parent: in registers when the same wavefront handles the
+// parent next (SF_OUT_REG / SF_IN_REG), otherwise through an LDS "edge slot" [slot][entry][lane] (SF_OUT_LDS; the
+// parent adds the slots listed in rlist[rstart .. rstart+nread)).
+struct StepDesc {
+  JointDesc d; // copy of the joint's descriptor (one scalar-load burst per step)
+  int joint;   // 1..nb, 0 = idle step
+  int flags;   // SF_*
+  int wslot;   // edge slot written (SF_OUT_LDS)
+  int rstart;  // leaf->root: first entry of this joint's edge-slot list in rlist; root->leaf: slot of the parent's v
+  int nread;   // number of edge slots the joint adds
+  int pad_;
+};
+enum : int {
+  SF_IN_REG = 1,    // leaf->root: add the register accumulator (the chain child was the wavefront's previous joint)
+  SF_OUT_REG = 2,   // leaf->root: keep the contribution in registers (the parent is the wavefront's next joint)
+  SF_OUT_LDS = 4,   // leaf->root: write the contribution to edge slot `wslot`; root->leaf: write v to v-slot `wslot`
+  SF_VPAR_REG = 8,  // root->leaf: the parent's velocity is still in registers
+};
+constexpr int EDGE_ENT = 27;  // entries of an edge slot: 21 (H, symmetric) + 6 (p)
+constexpr int MAX_TEAM = 4;   // wavefronts per tile (workgroup of up to 256 lanes: one wavefront per SIMD of a CU)
+
+// The three tables are separate `const __restrict__` kernel arguments on purpose: only then the compiler proves them
+// unclobbered by the tile stores and reads them with scalar loads (SMEM) instead of vector loads + readfirstlane.
+struct Team {
+  const StepDesc* __restrict__ up;    // [nw][T_up]   leaf -> root
+  const StepDesc* __restrict__ down;  // [nw][T_down] root -> leaf
+  const int* __restrict__ rlist;
+  int T_up, T_down;
+  int edge_ent;          // entries (x 64 lanes) of the edge-slot area; the v-slots of the root->leaf sweep follow it
+};
+
+template <typename T, int N0, int N>
+__device__ __forceinline__ void edge_store(T* edge, int slot, const T* x, int lane)
 {
 #pragma unroll
-  for (int k = 0; k < 27; ++k)
-    if (k < n) stk[(level * nent + k) * WAVE + lane] = x[k];
+  for (int k = 0; k < N; ++k) edge[(slot * EDGE_ENT + N0 + k) * WAVE + lane] = x[k];
 }
-template <typename T>
-__device__ __forceinline__ void stack_pop_add(const T* stk, int level, int nent, T* x, int n, int lane)
+template <typename T, int N0, int N>
+__device__ __forceinline__ void edge_add(const T* edge, int slot, T* x, int lane)
 {
 #pragma unroll
-  for (int k = 0; k < 27; ++k)
-    if (k < n) x[k] += stk[(level * nent + k) * WAVE + lane];
+  for (int k = 0; k < N; ++k) x[k] += edge[(slot * EDGE_ENT + N0 + k) * WAVE + lane];
+}
+// x += contributions of the children of the step's joint (register accumulator first, then the edge slots)
+template <typename T, int N0, int N>
+__device__ __forceinline__ void edge_gather(const StepDesc& sd, const int* __restrict__ rlist, const T* edge,
+                                            const T* acc, T* x, int lane)
+{
+  if (sd.flags & SF_IN_REG) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) x[k] += acc[k];
+  }
+  for (int r = 0; r < sd.nread; ++r) edge_add<T, N0, N>(edge, rlist[sd.rstart + r], x, lane);
+}
+template <typename T, int N0, int N>
+__device__ __forceinline__ void edge_emit(const StepDesc& sd, T* edge, T* acc, const T* part, int lane)
+{
+  if (sd.flags & SF_OUT_REG) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k] = part[k];
+  } else if (sd.flags & SF_OUT_LDS) {
+    edge_store<T, N0, N>(edge, sd.wslot, part, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -454,30 +511,82 @@ struct Norms {
     bTdy_plus = bTdy_minus = ub_dw_plus = lb_dw_minus = T(0);
     g_inf = dg = stf_w_inf = dstf_w = dual_v = T(0);
   }
+  static constexpr int NMAX = 16, NSUM = 4, NALL = NMAX + NSUM;
+  __device__ __forceinline__ void pack(T* a) const
+  {
+    a[0] = nu_inf; a[1] = dfis; a[2] = href_v; a[3] = dvis; a[4] = dnu; a[5] = dz; a[6] = dw; a[7] = dyis;
+    a[8] = av_inf; a[9] = pr_task; a[10] = pr_slack; a[11] = g_inf; a[12] = dg; a[13] = stf_w_inf; a[14] = dstf_w;
+    a[15] = dual_v;
+    a[16] = bTdy_plus; a[17] = bTdy_minus; a[18] = ub_dw_plus; a[19] = lb_dw_minus;
+  }
+  __device__ __forceinline__ void unpack(const T* a)
+  {
+    nu_inf = a[0]; dfis = a[1]; href_v = a[2]; dvis = a[3]; dnu = a[4]; dz = a[5]; dw = a[6]; dyis = a[7];
+    av_inf = a[8]; pr_task = a[9]; pr_slack = a[10]; g_inf = a[11]; dg = a[12]; stf_w_inf = a[13]; dstf_w = a[14];
+    dual_v = a[15];
+    bTdy_plus = a[16]; bTdy_minus = a[17]; ub_dw_plus = a[18]; lb_dw_minus = a[19];
+  }
+  // combine the partial scalars of the `nw` wavefronts of a team (each covers its own joints): every wavefront
+  // ends up with bit-identical totals (same order), so all of them take the same control-flow decisions
+  __device__ __forceinline__ void team_combine(T* xch, int w, int nw, int lane)
+  {
+    T a[NALL];
+    pack(a);
+#pragma unroll
+    for (int k = 0; k < NALL; ++k) xch[(w * NALL + k) * WAVE + lane] = a[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NALL; ++k) a[k] = xch[k * WAVE + lane];
+    for (int ww = 1; ww < nw; ++ww) {
+#pragma unroll
+      for (int k = 0; k < NMAX; ++k) a[k] = tmax(a[k], xch[(ww * NALL + k) * WAVE + lane]);
+#pragma unroll
+      for (int k = NMAX; k < NALL; ++k) a[k] += xch[(ww * NALL + k) * WAVE + lane];
+    }
+    unpack(a);
+    __syncthreads();  // the exchange area aliases the edge slots of the next sweep
+  }
 };
+
+// barrier between two steps of a sweep: only the LDS hand-overs have to be visible to the other wavefronts of the
+// team (every joint record is touched by one wavefront per sweep), so outstanding global loads/stores are NOT
+// drained here -- the prefetch of the next step stays in flight across it.
+__device__ __forceinline__ void step_barrier(int nw)
+{
+  if (nw > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// end of a sweep: the next sweep reads records written by other wavefronts of the team -> full workgroup fence
+__device__ __forceinline__ void sweep_barrier(int nw)
+{
+  if (nw > 1) __syncthreads();
+}
 
 // ------------------------------------------------------------------------------------------------
 // leaf -> root sweep: FwdPass1 + BwdPass.  WITH_H=false re-uses the cached H/UDinv/Dinv (valid while
 // mu is unchanged: they depend only on rho, mu, liMi, H_ref, AtA -- never on the iterates).
-// `lp` = this lane's pointer into its wavefront's tile.
+// `lp` = this lane's pointer into its team's tile.
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool WITH_H, bool HDIAG>
-__device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf, const JointDesc* __restrict__ jd,
-                                          T* stk, char* lp, int lane, bool live, T mu_eq, T mu_in, size_t hoff)
+__device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf, const Team& tm, int w, int nw,
+                                          T* edge, char* lp, int lane, bool live, T mu_eq, T mu_in, size_t hoff)
 {
-  constexpr int NENT = 27;
   const Layout& L = P.L;
   T accH[21], accp[6];
 #pragma unroll
   for (int k = 0; k < 21; ++k) accH[k] = T(0);
 #pragma unroll
   for (int k = 0; k < 6; ++k) accp[k] = T(0);
-  int level = 0;
+  const StepDesc* __restrict__ steps = tm.up + (size_t)w * tm.T_up;
 
-  for (int i = L.nb; i >= 1; --i) {
-    const JointDesc d = jd[i];
-    char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
-    if (live) {
+  int jn = steps[0].joint;
+  for (int t_ = 0; t_ < tm.T_up; ++t_) {
+    const StepDesc sd = steps[t_];  // by value: one scalar-load burst, never re-read behind a store
+    // the joint index is fetched one step ahead: the record loads below must not wait for a descriptor load
+    const int i = jn;
+    jn = steps[t_ + 1 < tm.T_up ? t_ + 1 : t_].joint;
+    if (i > 0 && live) {
+      const JointDesc& d = sd.d;
+      char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
       T vprev[6], hh[21], pp[6], U[6], UD[6];
       const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ);
       char* hrec = rec + (size_t)JP_SLOT0 * pair_bytes<T>() + hoff;  // this lane's H-cache slot
@@ -516,15 +625,9 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
 #pragma unroll
         for (int k = 0; k < 6; ++k) pp[k] += aty[k] - mu_eq * atb[k];
       }
-      // children contributions accumulated so far (hxx:66-67, :74-75)
-      if (!(d.flags & JF_LEAF)) {
-        if (WITH_H) {
-#pragma unroll
-          for (int k = 0; k < 21; ++k) hh[k] += accH[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) pp[k] += accp[k];
-      }
+      // children contributions (hxx:66-67, :74-75)
+      if (WITH_H) edge_gather<T, 0, 21>(sd, tm.rlist, edge, accH, hh, lane);
+      edge_gather<T, 21, 6>(sd, tm.rlist, edge, accp, pp, lane);
       st6<T>(rec, JP_P, pp);
 
       // calc_aba (hxx:60-63): U = H S ; Dinv = 1/(S^T U + R) ; UDinv = U Dinv
@@ -572,82 +675,93 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
 #pragma unroll
         for (int k = 0; k < 6; ++k) pa[k] = pp[k] - UD[k] * ri;
         act_force(R, t, pa, part + 21);
-        if (!(d.flags & JF_LAST_CHILD)) {
-          --level;
-          if (WITH_H) stack_pop_add(stk, level, NENT, part, 21, lane);
-          stack_pop_add(stk + 21 * WAVE, level, NENT, part + 21, 6, lane);
-        }
-        if (d.flags & JF_NEXT_IS_PARENT) {
-          if (WITH_H) {
-#pragma unroll
-            for (int k = 0; k < 21; ++k) accH[k] = part[k];
-          }
-#pragma unroll
-          for (int k = 0; k < 6; ++k) accp[k] = part[21 + k];
-        } else {
-          if (WITH_H) stack_push(stk, level, NENT, part, 21, lane);
-          stack_push(stk + 21 * WAVE, level, NENT, part + 21, 6, lane);
-          ++level;
-        }
+        if (WITH_H) edge_emit<T, 0, 21>(sd, edge, accH, part, lane);
+        edge_emit<T, 21, 6>(sd, edge, accp, part + 21, lane);
       }
     }
+    step_barrier(nw);
   }
+  sweep_barrier(nw);
 }
 
 // ------------------------------------------------------------------------------------------------
-// root -> leaf sweep: FwdPass2 + BoxProj + DualUpdate
+// root -> leaf sweep: FwdPass2 + BoxProj + DualUpdate.  The record of the NEXT step's joint is fetched
+// while the current joint is computed (one step of software prefetch: a wavefront runs alone on its SIMD,
+// nothing else hides the HBM latency of a step).
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool HDIAG>
-__device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf, const JointDesc* __restrict__ jd,
-                                          char* lp, bool live, T mu_eq, T mu_in, size_t hoff, Norms<T>& N)
+template <typename T>
+struct FwdIn {
+  typename Vec2<T>::type cs, wz, nus, rd, lu, h[11];
+  T pp[6], UD[6], vprev[6], fold[6];
+  __device__ __forceinline__ void load(const char* rec, size_t hoff, bool bnd_shared)
+  {
+    const char* hrec = rec + (size_t)JP_SLOT0 * pair_bytes<T>() + hoff;
+    cs = ldp<T>(rec, JP_CS); wz = ldp<T>(rec, JP_WZ); nus = ldp<T>(rec, JP_NUS); rd = ldp<T>(rec, JP_R);
+#pragma unroll
+    for (int k = 0; k < 11; ++k) h[k] = ldp<T>(hrec, SL_H + k);
+    ld6<T>(rec, JP_P, pp);
+    ld6<T>(hrec, SL_UD, UD);
+    ld6<T>(rec, JP_V, vprev);
+    ld6<T>(rec, JP_F, fold);
+    if (!bnd_shared) lu = ldp<T>(rec, JP_LBUB);
+  }
+};
+
+template <typename T, bool HDIAG, bool PF>
+__device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf, const Team& tm, int w, int nw,
+                                          T* vedge, char* lp, int lane, bool live, T mu_eq, T mu_in, size_t hoff,
+                                          Norms<T>& N)
 {
   const Layout& L = P.L;
+  const bool bnd_shared = P.mode & MODE_BND_SHARED;
   T vcur[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) vcur[k] = T(0);
+  const StepDesc* __restrict__ steps = tm.down + (size_t)w * tm.T_down;
+  FwdIn<T> in;
+  if (PF) {
+    const int i0 = steps[0].joint;
+    if (i0 > 0 && live) in.load(lp + (size_t)(i0 - 1) * JREC * pair_bytes<T>(), hoff, bnd_shared);
+  }
 
-  for (int i = 1; i <= L.nb; ++i) {
-    const JointDesc d = jd[i];
-    char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
-    if (live) {
-      T hh[22], pp[6], UD[6], vprev[6], fold[6], vpar[6], vp[6], vi[6], fi[6], R[9], t[3];
-      const char* hrec = rec + (size_t)JP_SLOT0 * pair_bytes<T>() + hoff;
-      const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS),
-                                   rd = ldp<T>(rec, JP_R);
+  int jn = steps[0].joint;
+  for (int t_ = 0; t_ < tm.T_down; ++t_) {
+    const StepDesc sd = steps[t_];  // by value: one scalar-load burst, never re-read behind a store
+    // the joint index is fetched one step ahead: the record loads below must not wait for a descriptor load
+    const int i = jn;
+    jn = steps[t_ + 1 < tm.T_down ? t_ + 1 : t_].joint;
+    if (i > 0 && live) {
+      const JointDesc& d = sd.d;
+      char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
+      if (!PF) in.load(rec, hoff, bnd_shared);
+      T hh[22], vpar[6], vp[6], vi[6], fi[6], R[9], t[3];
 #pragma unroll
-      for (int k = 0; k < 11; ++k) {
-        const typename Vec2<T>::type a = ldp<T>(hrec, SL_H + k);
-        hh[2 * k] = a.x; hh[2 * k + 1] = a.y;
-      }
-      ld6<T>(rec, JP_P, pp);
-      ld6<T>(hrec, SL_UD, UD);
-      ld6<T>(rec, JP_V, vprev);
-      ld6<T>(rec, JP_F, fold);
+      for (int k = 0; k < 11; ++k) { hh[2 * k] = in.h[k].x; hh[2 * k + 1] = in.h[k].y; }
       T lbi, ubi;
-      if (P.mode & MODE_BND_SHARED) {
+      if (bnd_shared) {
         lbi = Bf.uni[L.nc * 57 + (i - 1)];
         ubi = Bf.uni[L.nc * 57 + L.nb + (i - 1)];
       } else {
-        const typename Vec2<T>::type lu = ldp<T>(rec, JP_LBUB);
-        lbi = lu.x; ubi = lu.y;
+        lbi = in.lu.x; ubi = in.lu.y;
       }
-      const T ri = rd.x, dd = hh[21], wi = wz.x, zprev = wz.y, nuprev = nus.x;
-      // parent velocity: universe = 0, chain = registers, branch point = re-read (written earlier by this lane)
+      const T ri = in.rd.x, dd = hh[21], wi = in.wz.x, zprev = in.wz.y, nuprev = in.nus.x;
+      // parent velocity: universe = 0, chain = registers, otherwise the parent's LDS hand-over slot
       if (d.parent == 0) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) vpar[k] = T(0);
-      } else if (d.flags & JF_NEXT_IS_PARENT) {
+      } else if (sd.flags & SF_VPAR_REG) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) vpar[k] = vcur[k];
       } else {
-        ld6<T>(lp + (size_t)(d.parent - 1) * JREC * pair_bytes<T>(), JP_V, vpar);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vpar[k] = vedge[(sd.rstart * 6 + k) * WAVE + lane];
       }
-      make_liMi(d, cs.x, cs.y, R, t);
+      make_liMi(d, in.cs.x, in.cs.y, R, t);
       actinv_motion(R, t, vpar, vp);  // hxx:125
       // nu_i = -UDinv^T v' - Dinv r_i  (hxx:127)
-      T udv = UD[0] * vp[0];
+      T udv = in.UD[0] * vp[0];
 #pragma unroll
-      for (int k = 1; k < 6; ++k) udv += UD[k] * vp[k];
+      for (int k = 1; k < 6; ++k) udv += in.UD[k] * vp[k];
       const T nui = -udv - dd * ri;
       N.nu_inf = tmax(N.nu_inf, tabs(nui));
       // v_i = v' + S nu_i (hxx:133-134)
@@ -664,9 +778,9 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
       T df[6], dv6[6], hrv[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        fi[k] += pp[k];
-        df[k] = fi[k] - fold[k];
-        dv6[k] = vi[k] - vprev[k];
+        fi[k] += in.pp[k];
+        df[k] = fi[k] - in.fold[k];
+        dv6[k] = vi[k] - in.vprev[k];
       }
       N.dfis = tmax(N.dfis, inf6(df));
       // Href_v (hxx:149-153)
@@ -685,11 +799,15 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
       N.ub_dw_plus += ubi * tmax(dwi, T(0));
       N.lb_dw_minus += lbi * tmin(dwi, T(0));
       stp<T>(rec, JP_WZ, wi + dwi, zi);
-      stp<T>(rec, JP_NUS, nui, nus.y);  // full 16-byte store: Stf_plus_w rewritten unchanged
+      stp<T>(rec, JP_NUS, nui, in.nus.y);  // full 16-byte store: Stf_plus_w rewritten unchanged
       st6<T>(rec, JP_V, vi);
       st6<T>(rec, JP_F, fi);
 #pragma unroll
       for (int k = 0; k < 6; ++k) vcur[k] = vi[k];
+      if (sd.flags & SF_OUT_LDS) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vedge[(sd.wslot * 6 + k) * WAVE + lane] = vi[k];
+      }
       // DualUpdate, task part (hxx:410-451)
       if (d.cslot >= 0) {
         char* crec = lp + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>();
@@ -739,26 +857,36 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
         st6<T>(crec, CP_ATY, aty);
       }
     }
+    // request the next step's record behind this step's stores: it is in flight across the barrier.  (Requesting
+    // it before the arithmetic measured slower: the compiler's vmcnt(0) waits inside the step then stall on it.)
+    if (PF && t_ + 1 < tm.T_down && jn > 0 && live)
+      in.load(lp + (size_t)(jn - 1) * JREC * pair_bytes<T>(), hoff, bnd_shared);
+    step_barrier(nw);
   }
+  sweep_barrier(nw);
 }
 
 // ------------------------------------------------------------------------------------------------
 // leaf -> root residual sweep: BwdPass2 + dual residual
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool HDIAG>
-__device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf, const JointDesc* __restrict__ jd,
-                                           T* stk, char* lp, int lane, bool live, Norms<T>& N)
+__device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf, const Team& tm, int w, int nw,
+                                           T* edge, char* lp, int lane, bool live, Norms<T>& N)
 {
-  constexpr int NENT = 27;
   const Layout& L = P.L;
   T acc[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) acc[k] = T(0);
-  int level = 0;
-  for (int i = L.nb; i >= 1; --i) {
-    const JointDesc d = jd[i];
-    char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
-    if (live) {
+  const StepDesc* __restrict__ steps = tm.up + (size_t)w * tm.T_up;
+  int jn = steps[0].joint;
+  for (int t_ = 0; t_ < tm.T_up; ++t_) {
+    const StepDesc sd = steps[t_];  // by value: one scalar-load burst, never re-read behind a store
+    // the joint index is fetched one step ahead: the record loads below must not wait for a descriptor load
+    const int i = jn;
+    jn = steps[t_ + 1 < tm.T_up ? t_ + 1 : t_].joint;
+    if (i > 0 && live) {
+      const JointDesc& d = sd.d;
+      char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
       T fi[6], vi[6], gold[6], gi[6];
       const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
       ld6<T>(rec, JP_F, fi);
@@ -772,10 +900,7 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
 #pragma unroll
         for (int k = 0; k < 6; ++k) gi[k] = T(0);
       }
-      if (!(d.flags & JF_LEAF)) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) gi[k] += acc[k];
-      }
+      edge_gather<T, 0, 6>(sd, tm.rlist, edge, acc, gi, lane);
       T dg[6], dvr[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
@@ -803,20 +928,12 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
         T R[9], t[3], part[6];
         make_liMi(d, cs.x, cs.y, R, t);
         act_force(R, t, fi, part);  // hxx:212
-        if (!(d.flags & JF_LAST_CHILD)) {
-          --level;
-          stack_pop_add(stk, level, NENT, part, 6, lane);
-        }
-        if (d.flags & JF_NEXT_IS_PARENT) {
-#pragma unroll
-          for (int k = 0; k < 6; ++k) acc[k] = part[k];
-        } else {
-          stack_push(stk, level, NENT, part, 6, lane);
-          ++level;
-        }
+        edge_emit<T, 0, 6>(sd, edge, acc, part, lane);
       }
     }
+    step_barrier(nw);
   }
+  sweep_barrier(nw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -824,36 +941,56 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
 // pass over the tree, the p-recursion of iteration k+1 (FwdPass1 + BwdPass with the cached H/UDinv/Dinv, as
 // sweep_bwd<.., false, ..>).  Both walk the joints leaf -> root and read the same v_i, w_i, z_i, liMi, so fusing
 // them removes one of the three tree walks of an iteration.  The p-recursion is speculative in mu: it uses the
-// mu of iteration k; if the epilogue of iteration k changes mu for any lane of the wavefront, the next iteration
+// mu of iteration k; if the epilogue of iteration k changes mu for any lane of the team, the next iteration
 // starts with a full sweep_bwd<.., true, ..> that rebuilds H, UDinv, Dinv, p and r with the new mu.
 // The arithmetic of each half is unchanged, so results are bit-identical to the unfused sweeps.
+// Same one-step prefetch as sweep_fwd.
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool HDIAG>
-__device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& Bf, const JointDesc* __restrict__ jd,
-                                            T* stk, char* lp, int lane, bool live, T mu_eq, T mu_in, size_t hoff,
+template <typename T>
+struct FusedIn {
+  typename Vec2<T>::type cs, wz, nus;
+  T fi[6], vi[6], gold[6], UD[6];
+  __device__ __forceinline__ void load(const char* rec, size_t hoff)
+  {
+    cs = ldp<T>(rec, JP_CS); wz = ldp<T>(rec, JP_WZ); nus = ldp<T>(rec, JP_NUS);
+    ld6<T>(rec, JP_F, fi);
+    ld6<T>(rec, JP_V, vi);
+    ld6<T>(rec, JP_G, gold);
+    ld6<T>(rec + (size_t)JP_SLOT0 * pair_bytes<T>() + hoff, SL_UD, UD);
+  }
+};
+
+template <typename T, bool HDIAG, bool PF>
+__device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& Bf, const Team& tm, int w, int nw,
+                                            T* edge, char* lp, int lane, bool live, T mu_eq, T mu_in, size_t hoff,
                                             Norms<T>& N)
 {
-  constexpr int NENT = 27;
   const Layout& L = P.L;
-  T acc[6], accp[6];
+  T acc[12];  // [0,6): sum of act(f_child), [6,12): sum of act(p_aba child)
 #pragma unroll
-  for (int k = 0; k < 6; ++k) { acc[k] = T(0); accp[k] = T(0); }
-  int level = 0;
-  for (int i = L.nb; i >= 1; --i) {
-    const JointDesc d = jd[i];
-    char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
-    if (live) {
-      T fi[6], vi[6], gold[6], gi[6], UD[6], pp[6];
-      const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
-      ld6<T>(rec, JP_F, fi);
-      ld6<T>(rec, JP_V, vi);
-      ld6<T>(rec, JP_G, gold);
-      ld6<T>(rec + (size_t)JP_SLOT0 * pair_bytes<T>() + hoff, SL_UD, UD);
-      const T wi = wz.x, sold = nus.y;
+  for (int k = 0; k < 12; ++k) acc[k] = T(0);
+  const StepDesc* __restrict__ steps = tm.up + (size_t)w * tm.T_up;
+  FusedIn<T> in;
+  if (PF) {
+    const int i0 = steps[0].joint;
+    if (i0 > 0 && live) in.load(lp + (size_t)(i0 - 1) * JREC * pair_bytes<T>(), hoff);
+  }
+  int jn = steps[0].joint;
+  for (int t_ = 0; t_ < tm.T_up; ++t_) {
+    const StepDesc sd = steps[t_];  // by value: one scalar-load burst, never re-read behind a store
+    // the joint index is fetched one step ahead: the record loads below must not wait for a descriptor load
+    const int i = jn;
+    jn = steps[t_ + 1 < tm.T_up ? t_ + 1 : t_].joint;
+    if (i > 0 && live) {
+      const JointDesc& d = sd.d;
+      char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
+      if (!PF) in.load(rec, hoff);
+      T gi[6], pp[6];
+      const T wi = in.wz.x, sold = in.nus.y;
       // ---- iteration k: g_i = (Aty_c | 0) + sum_children act(f_j) - f_i   (hxx:438-439, :210-212)
       //      iteration k+1: p_i = -rho v_i - Hv (+ Aty_c - mu_eq Atb_c)       (hxx:304-315, :321-334)
 #pragma unroll
-      for (int k = 0; k < 6; ++k) pp[k] = -P.rho * vi[k] - P.Hv[k];
+      for (int k = 0; k < 6; ++k) pp[k] = -P.rho * in.vi[k] - P.Hv[k];
       if (d.cslot >= 0) {
         const char* crec = lp + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>();
         T atb[6];
@@ -865,22 +1002,20 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
 #pragma unroll
         for (int k = 0; k < 6; ++k) gi[k] = T(0);
       }
-      if (!(d.flags & JF_LEAF)) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { gi[k] += acc[k]; pp[k] += accp[k]; }
-      }
+      edge_gather<T, 0, 6>(sd, tm.rlist, edge, acc, gi, lane);
+      edge_gather<T, 6, 6>(sd, tm.rlist, edge, acc + 6, pp, lane);
       T dg[6], dvr[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        gi[k] += -fi[k];
-        dg[k] = gi[k] - gold[k];
+        gi[k] += -in.fi[k];
+        dg[k] = gi[k] - in.gold[k];
       }
       st6<T>(rec, JP_G, gi);
       st6<T>(rec, JP_P, pp);
       N.dg = tmax(N.dg, inf6(dg));        // hxx:215-220
       N.g_inf = tmax(N.g_inf, inf6(gi));  // hxx:223-225
       // dual residual, v block (hxx:228): Href v_i - Hv + g_i
-      href_mul<T, HDIAG>(P.Href, vi, dvr);
+      href_mul<T, HDIAG>(P.Href, in.vi, dvr);
 #pragma unroll
       for (int r = 0; r < 6; ++r) dvr[r] = dvr[r] - P.Hv[r] + gi[r];
       N.dual_v = tmax(N.dual_v, inf6(dvr));
@@ -888,39 +1023,32 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
       const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
       T stf, Stp;
       if (d.flags & JF_REVOLUTE) {
-        stf = ax0 * fi[3] + ax1 * fi[4] + ax2 * fi[5];
+        stf = ax0 * in.fi[3] + ax1 * in.fi[4] + ax2 * in.fi[5];
         Stp = ax0 * pp[3] + ax1 * pp[4] + ax2 * pp[5];
       } else {
-        stf = ax0 * fi[0] + ax1 * fi[1] + ax2 * fi[2];
+        stf = ax0 * in.fi[0] + ax1 * in.fi[1] + ax2 * in.fi[2];
         Stp = ax0 * pp[0] + ax1 * pp[1] + ax2 * pp[2];
       }
       const T si = stf + wi;
-      const T ri = (wz.x - mu_in * wz.y) + Stp;
-      stp<T>(rec, JP_NUS, nus.x, si);
+      const T ri = (in.wz.x - mu_in * in.wz.y) + Stp;
+      stp<T>(rec, JP_NUS, in.nus.x, si);
       stp<T>(rec, JP_R, ri, T(0));
       N.stf_w_inf = tmax(N.stf_w_inf, tabs(si));
       N.dstf_w = tmax(N.dstf_w, tabs(si - sold));
       if (!(d.flags & JF_PARENT_ROOT)) {
         T R[9], t[3], part[12], pa[6];
-        make_liMi(d, cs.x, cs.y, R, t);
-        act_force(R, t, fi, part);  // hxx:212
+        make_liMi(d, in.cs.x, in.cs.y, R, t);
+        act_force(R, t, in.fi, part);  // hxx:212
 #pragma unroll
-        for (int k = 0; k < 6; ++k) pa[k] = pp[k] - UD[k] * ri;  // hxx:71-73
-        act_force(R, t, pa, part + 6);                            // hxx:74
-        if (!(d.flags & JF_LAST_CHILD)) {
-          --level;
-          stack_pop_add(stk, level, NENT, part, 12, lane);
-        }
-        if (d.flags & JF_NEXT_IS_PARENT) {
-#pragma unroll
-          for (int k = 0; k < 6; ++k) { acc[k] = part[k]; accp[k] = part[6 + k]; }
-        } else {
-          stack_push(stk, level, NENT, part, 12, lane);
-          ++level;
-        }
+        for (int k = 0; k < 6; ++k) pa[k] = pp[k] - in.UD[k] * ri;  // hxx:71-73
+        act_force(R, t, pa, part + 6);                               // hxx:74
+        edge_emit<T, 0, 12>(sd, edge, acc, part, lane);
       }
     }
+    if (PF && t_ + 1 < tm.T_up && jn > 0 && live) in.load(lp + (size_t)(jn - 1) * JREC * pair_bytes<T>(), hoff);
+    step_barrier(nw);
   }
+  sweep_barrier(nw);
 }
 
 // scalar record accessors
@@ -941,14 +1069,18 @@ __device__ __forceinline__ void st_scal(char* srec, int idx, T x)
 // persistent solve kernel: each wavefront iterates its 64 instances until all are done (or the launch
 // iteration budget is spent).  No inter-wavefront communication: instances are independent.
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool HDIAG>
-__global__ void __launch_bounds__(WAVE)
-k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
+template <typename T, bool HDIAG, bool TEAM>
+__global__ void __launch_bounds__(TEAM ? WAVE * MAX_TEAM : WAVE)
+k_solve(const Params<T> P, const Bufs<T> Bf, const StepDesc* __restrict__ sched_up,
+        const StepDesc* __restrict__ sched_down, const int* __restrict__ sched_rlist, int T_up, int T_down, int edge_ent)
 {
+  const Team tm{sched_up, sched_down, sched_rlist, T_up, T_down, edge_ent};
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* stk = reinterpret_cast<T*>(smem_raw);
+  T* edge = reinterpret_cast<T*>(smem_raw);  // edge slots of the leaf->root sweeps / scalar exchange of the team
   const Layout& L = P.L;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int w = TEAM ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;  // wavefront of the team
+  const int nw = TEAM ? (int)(blockDim.x >> 6) : 1;
   const int b = blockIdx.x * WAVE + lane;
   const bool inb = b < P.B;
   char* lp = Bf.tiles + (size_t)blockIdx.x * L.tile_pairs * pair_bytes<T>() + (size_t)lane * 2 * sizeof(T);
@@ -967,6 +1099,17 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
   // main-loop bound `for (i = 1; i < max_iter; ++i)` (hpp:377): nothing to do when max_iter <= 1
   if (live && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { live = false; status |= ST_DONE; }
   unsigned int my_iters = 0;
+  // scalars of the per-iteration dump that keep their last value when an iteration does not re-evaluate them
+  // (CheckFeasibility is skipped at iteration 1 and in the tail solve): carried in registers, no reload per iteration
+  T p_tolp, p_told, p_dyqp, p_atdy, p_ubp, p_lbm;
+  int p_c1, p_c2, p_tail_iter;
+  {
+    const typename Vec2<T>::type o3 = ldp<T>(srec, SP_SCAL + 3), o6 = ldp<T>(srec, SP_SCAL + 6),
+                                 o7 = ldp<T>(srec, SP_SCAL + 7), o8 = ldp<T>(srec, SP_SCAL + 8),
+                                 o13 = ldp<T>(srec, SP_SCAL + 13), o14 = ldp<T>(srec, SP_SCAL + 14);
+    p_tolp = o3.x; p_told = o3.y; p_dyqp = o6.y; p_atdy = o7.x; p_ubp = o7.y; p_lbm = o8.x;
+    p_c1 = (int)o13.y; p_c2 = (int)o14.x; p_tail_iter = (int)o14.y;
+  }
   bool have_p = false;  // p_i, r_i of the coming iteration already built by the fused sweep (with the current mu)
   bool spec = true;     // fuse the next p-recursion into the residual sweep (pays only if no lane then changes mu)
 
@@ -986,31 +1129,32 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
     if (!have_p) {
       const bool need_h = !(P.mode & MODE_CACHE_H) || __any(live && (tag != mu));
       if (need_h) {
-        sweep_bwd<T, true, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in, hoff);
+        sweep_bwd<T, true, HDIAG>(P, Bf, tm, w, nw, edge, lp, lane, live, mu_eq, mu_in, hoff);
         if (live) {
           if (slot == 0) tag0 = mu;
           else if (slot == 1) tag1 = mu;
           else tag2 = mu;
         }
       } else {
-        sweep_bwd<T, false, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in, hoff);
+        sweep_bwd<T, false, HDIAG>(P, Bf, tm, w, nw, edge, lp, lane, live, mu_eq, mu_in, hoff);
       }
     }
-    sweep_fwd<T, HDIAG>(P, Bf, jd, lp, live, mu_eq, mu_in, hoff, N);
+    sweep_fwd<T, HDIAG, TEAM>(P, Bf, tm, w, nw, edge + (size_t)tm.edge_ent * WAVE, lp, lane, live, mu_eq, mu_in, hoff, N);
     if ((P.mode & MODE_CACHE_H) && spec) {
-      sweep_fused<T, HDIAG>(P, Bf, jd, stk, lp, lane, live, mu_eq, mu_in, hoff, N);
+      sweep_fused<T, HDIAG, TEAM>(P, Bf, tm, w, nw, edge, lp, lane, live, mu_eq, mu_in, hoff, N);
       have_p = true;
     } else {
-      sweep_bwd2<T, HDIAG>(P, Bf, jd, stk, lp, lane, live, N);
+      sweep_bwd2<T, HDIAG>(P, Bf, tm, w, nw, edge, lp, lane, live, N);
       have_p = false;
     }
+    if (nw > 1) N.team_combine(edge, w, nw, lane);
     const T mu_before = mu;
 
     if (live) {
       // ComputePrimalResiduals / ComputeDualResiduals (hxx:494-522)
       const T primal = tmax(N.pr_task, N.pr_slack);
       const T dual = tmax(N.dual_v, N.stf_w_inf);
-      T tol_p = ld_scal<T>(srec, SC_TOL_PRIMAL), tol_d = ld_scal<T>(srec, SC_TOL_DUAL);
+      T tol_p = p_tolp, tol_d = p_told;
       T dx = tmax(N.dvis, N.dnu);
       T dyqp = T(0), atdy = T(0), ubp = T(0), lbm = T(0);
       int c1 = 0, c2 = 0;
@@ -1054,7 +1198,7 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
         }
       } else {
         // tail-solve iteration (hpp:286-308)
-        tail_iter = (int)ldp<T>(srec, SP_SCAL + 14).y + 1;
+        tail_iter = p_tail_iter + 1;
         if (!(dx >= P.tol_tail_solve || N.dz >= P.tol_tail_solve) || iter >= P.max_iter) {
           status |= ST_DONE;
           live = false;
@@ -1062,13 +1206,11 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
       }
       // per-iteration scalar dump: full 16-byte pairs of the scalar record.  The feasibility scalars keep their
       // last evaluated value when CheckFeasibility did not run this iteration (iter 1, tail solve), as upstream.
-      if (!ran_feas) {
-        const typename Vec2<T>::type o6 = ldp<T>(srec, SP_SCAL + 6), o7 = ldp<T>(srec, SP_SCAL + 7),
-                                     o8 = ldp<T>(srec, SP_SCAL + 8), o13 = ldp<T>(srec, SP_SCAL + 13),
-                                     o14 = ldp<T>(srec, SP_SCAL + 14);
-        dyqp = o6.y; atdy = o7.x; ubp = o7.y; lbm = o8.x; c1 = (int)o13.y; c2 = (int)o14.x;
-      }
-      if (!(status & ST_TAIL)) tail_iter = (int)ldp<T>(srec, SP_SCAL + 14).y;
+      if (!ran_feas) { dyqp = p_dyqp; atdy = p_atdy; ubp = p_ubp; lbm = p_lbm; c1 = p_c1; c2 = p_c2; }
+      if (!(status & ST_TAIL)) tail_iter = p_tail_iter;
+      p_tolp = tol_p; p_told = tol_d; p_dyqp = dyqp; p_atdy = atdy; p_ubp = ubp; p_lbm = lbm;
+      p_c1 = c1; p_c2 = c2; p_tail_iter = tail_iter;
+      if (w == 0) {
       stp<T>(srec, SP_SCAL + 0, primal, dual);                     // PRIMAL_RES, DUAL_RES
       stp<T>(srec, SP_SCAL + 1, N.pr_task, N.pr_slack);            // PRIMAL_RES_TASK, _SLACK
       stp<T>(srec, SP_SCAL + 2, N.dual_v, N.stf_w_inf);            // DUAL_RES_V, DUAL_RES_NU
@@ -1084,6 +1226,7 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
       stp<T>(srec, SP_SCAL + 12, N.href_v, N.g_inf);               // HREF_V_INF, G_INF
       stp<T>(srec, SP_SCAL + 13, N.stf_w_inf, (T)c1);              // STF_PLUS_W_INF, COND1
       stp<T>(srec, SP_SCAL + 14, (T)c2, (T)tail_iter);             // COND2, TAIL_ITER
+      }
     }
     // the speculative p-recursion used this iteration's mu: redo the leaf -> root sweep if any lane moved on; and
     // speculate again only after an iteration in which no lane of the wavefront changed mu (wavefronts full of
@@ -1093,7 +1236,7 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
     spec = !changed;
   }
 
-  if (inb) {
+  if (inb && w == 0) {
     stp<T>(srec, SP_MU, mu, (T)kexp);
     stp<T>(srec, SP_TAG, tag0, tag1);
     stp<T>(srec, SP_TAG + 1, tag2, T(0));
@@ -1104,7 +1247,7 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd)
   unsigned int it_sum = my_iters;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) it_sum += __shfl_down(it_sum, off);
-  if (lane == 0) {
+  if (lane == 0 && w == 0) {
     const unsigned int nlive = __popcll(live_mask);
     Bf.wave_live[blockIdx.x] = (int)nlive;
     if (nlive) atomicAdd(&Bf.counters[0], nlive);
