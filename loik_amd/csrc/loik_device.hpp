@@ -31,6 +31,9 @@
 namespace loikb {
 
 constexpr int WAVE = 64;
+#ifndef LOIKB_NSLOT
+#define LOIKB_NSLOT 1
+#endif
 
 // ---- tile layout (units: pairs) -------------------------------------------------------------------
 enum : int {
@@ -53,7 +56,7 @@ enum : int {
   SL_UD = 0,
   SL_H = 3,
   SLOT_PAIRS = 14,
-  NSLOT = 1,
+  NSLOT = LOIKB_NSLOT,
   JREC = JP_SLOT0 + NSLOT * SLOT_PAIRS,  // 59
   JP_NPERSIST = 12,  // pairs [0, JP_NPERSIST) (+ JP_LBUB) travel with an instance on compaction
   // constraint record

@@ -63,7 +63,7 @@ struct loikb_solver_impl {
   int maxdepth = 0, maxchild = 0;
   TailTopo* d_topo = nullptr;
   int* d_child_list = nullptr;
-  int* d_slots = nullptr;
+  int* d_slots[2] = {nullptr, nullptr};  // live-instance lists of the tail kernel (ping-pong between launches)
   // options
   loikb_options opt{};
   int B = 0, nc = 0;
@@ -710,9 +710,10 @@ int compact(loikb_solver_impl* S, int src, int dst, int n_src, int* n_dst_out)
 }
 
 // finish the remaining live instances of set `cur` (n_cur slots, n_live of them live) with the cooperative tail
-// kernel: one wavefront per instance, runs every instance to its stopping point in ONE launch
+// kernel (a lane group per instance, one joint per lane)
 template <typename T>
-int run_tail(loikb_solver_impl* S, Params<T>& P, int cur, int n_cur, int n_live, double* ms_out)
+int run_tail(loikb_solver_impl* S, Params<T>& P, int cur, int n_cur, int n_live, double* ms_out,
+             unsigned long long* iters_out)
 {
   loikb_solver_impl::Set& A = S->set[cur];
   const int nw = (n_cur + WAVE - 1) / WAVE;
@@ -725,7 +726,7 @@ int run_tail(loikb_solver_impl* S, Params<T>& P, int cur, int n_cur, int n_live,
   for (int w = 0; w < nw; ++w) { off[w] = total; total += cnt[w]; }
   if (total != n_live) { g_last_error = "tail: live count mismatch"; return LOIKB_ERR_STATE; }
   HIPCHK(hipMemcpyAsync(A.wave_off, off, sizeof(int) * nw, hipMemcpyHostToDevice, S->stream));
-  hipLaunchKernelGGL(k_list_live<T>, dim3(nw), dim3(WAVE), 0, S->stream, A.tiles, S->L, n_cur, A.wave_off, S->d_slots);
+  hipLaunchKernelGGL(k_list_live<T>, dim3(nw), dim3(WAVE), 0, S->stream, A.tiles, S->L, n_cur, A.wave_off, S->d_slots[0]);
   HIPCHK(hipGetLastError());
   Bufs<T> Bf = make_bufs<T>(S, cur);
   P.B = n_cur;
@@ -733,24 +734,55 @@ int run_tail(loikb_solver_impl* S, Params<T>& P, int cur, int n_cur, int n_live,
   while (G < S->nb) G <<= 1;
   const int ipw = WAVE / G;
   const size_t lds = ((size_t)WAVE * XS + 2 * (size_t)WAVE * HS + (size_t)ipw * S->nc * CD) * sizeof(T);
-  const dim3 grid((unsigned)((n_live + ipw - 1) / ipw));
-  HIPCHK(hipMemsetAsync(S->d_counters, 0, 2 * sizeof(unsigned int), S->stream));
-  HIPCHK(hipEventRecord(S->ev_k0, S->stream));
-  if (S->href_diag)
-    hipLaunchKernelGGL((k_tail<T, true>), grid, dim3(WAVE), lds, S->stream, P, Bf, (const JointDesc*)S->d_jd,
-                       (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
-                       (const int*)S->d_slots, n_live, G);
-  else
-    hipLaunchKernelGGL((k_tail<T, false>), grid, dim3(WAVE), lds, S->stream, P, Bf, (const JointDesc*)S->d_jd,
-                       (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
-                       (const int*)S->d_slots, n_live, G);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(S->ev_k1, S->stream));
-  HIPCHK(hipMemcpyAsync(S->h_counters, S->d_counters, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
-  HIPCHK(hipStreamSynchronize(S->stream));
-  float ms = 0.f;
-  HIPCHK(hipEventElapsedTime(&ms, S->ev_k0, S->ev_k1));
-  *ms_out = ms;
+  // The kernel keeps one wavefront per SIMD resident (register budget): `resident` instances run concurrently.
+  // With more live instances than that, bounded launches keep every wavefront busy (instances finish at very
+  // different iterations; the survivors are re-listed and re-paired) -- once they all fit, one launch runs them out.
+  int ncu = 256;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, S->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+  }
+  const int resident = ncu * 4 * ipw;
+  int round_iters = 64;
+  if (const char* e = getenv("LOIKB_TAIL_ROUND")) round_iters = atoi(e);
+  int n = n_live, li = 0;
+  double total_ms = 0.0;
+  unsigned long long iters = 0;
+  const bool trace = getenv("LOIKB_TRACE") != nullptr;
+  while (n > 0) {
+    P.max_launch_iters = n > resident ? round_iters : S->opt.max_iter + 1;
+    const dim3 grid((unsigned)((n + ipw - 1) / ipw));
+    HIPCHK(hipMemsetAsync(S->d_counters, 0, 2 * sizeof(unsigned int), S->stream));
+    HIPCHK(hipEventRecord(S->ev_k0, S->stream));
+    if (S->href_diag)
+      hipLaunchKernelGGL((k_tail<T, true>), grid, dim3(WAVE), lds, S->stream, P, Bf, (const JointDesc*)S->d_jd,
+                         (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
+                         (const int*)S->d_slots[li], n, G, S->d_slots[li ^ 1]);
+    else
+      hipLaunchKernelGGL((k_tail<T, false>), grid, dim3(WAVE), lds, S->stream, P, Bf, (const JointDesc*)S->d_jd,
+                         (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
+                         (const int*)S->d_slots[li], n, G, S->d_slots[li ^ 1]);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(S->ev_k1, S->stream));
+    HIPCHK(hipMemcpyAsync(S->h_counters, S->d_counters, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, S->ev_k0, S->ev_k1));
+    total_ms += ms;
+    iters += S->h_counters[1];
+    if (trace)
+      fprintf(stderr, "[loikb] tail launch: %6d instances, budget %4d  %8.3f ms  inst-iters %9u (%.1f M/s)  live after %6u\n",
+              n, P.max_launch_iters, ms, S->h_counters[1], S->h_counters[1] / ms / 1e3, S->h_counters[0]);
+    S->stats.launches++;
+    if ((int)S->h_counters[0] >= n && P.max_launch_iters > S->opt.max_iter) {
+      g_last_error = "tail: no progress";
+      return LOIKB_ERR_STATE;
+    }
+    n = (int)S->h_counters[0];
+    li ^= 1;
+  }
+  *ms_out = total_ms;
+  *iters_out = iters;
   return LOIKB_OK;
 }
 
@@ -773,7 +805,7 @@ int run_main_loop_t(loikb_solver_impl* S)
   if (const char* e = getenv("LOIKB_COMPACT_RATIO")) compact_ratio = atof(e);
   // cooperative tail kernel (one wavefront per instance) once few instances are left
   const bool use_tail = can_compact && S->nb <= WAVE && S->opt.tail_max_instances >= 0;
-  const int tail_max = S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : 2048;
+  const int tail_max = S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : 6144;
   const bool trace = getenv("LOIKB_TRACE") != nullptr;
   // a team of wavefronts per tile walks independent chains of the tree concurrently: a sweep costs the tree's
   // critical path instead of nb joint visits, and four wavefronts keep four times the loads of a tile in flight.
@@ -845,15 +877,15 @@ int run_main_loop_t(loikb_solver_impl* S)
     if (n_live == 0 || done_iters >= max_total) break;
     if (use_tail && (int)n_live <= tail_max) {
       double tms = 0.0;
-      int rc = run_tail<T>(S, P, cur, n_cur, (int)n_live, &tms);
+      unsigned long long tit = 0;
+      int rc = run_tail<T>(S, P, cur, n_cur, (int)n_live, &tms, &tit);
       if (rc) return rc;
       kernel_ms += tms;
-      if (trace) fprintf(stderr, "[loikb] tail kernel: %u instances  %8.3f ms  inst-iters %9u\n", n_live, tms, S->h_counters[1]);
+      if (trace) fprintf(stderr, "[loikb] tail kernel: %u instances  %8.3f ms  inst-iters %9llu\n", n_live, tms, tit);
       S->stats.tail_ms = tms;
       S->stats.tail_instances = (int)n_live;
-      S->stats.launches++;
-      inst_iters += S->h_counters[1];
-      n_live = S->h_counters[0];
+      inst_iters += tit;
+      n_live = 0;
       break;
     }
     if (may_compact_later && (double)n_live <= compact_ratio * n_cur) {
@@ -988,7 +1020,7 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
   TRY(alloc_dev(S, &tmp, 2 * sizeof(unsigned int))); S->d_counters = (unsigned int*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(TailTopo) * S->nj)); S->d_topo = (TailTopo*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * (S->child_list.size() + 1))); S->d_child_list = (int*)tmp;
-  TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)(S->B + WAVE))); S->d_slots = (int*)tmp;
+  for (int k = 0; k < 2; ++k) { TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)(S->B + WAVE))); S->d_slots[k] = (int*)tmp; }
   HIPTRY(hipMemcpyAsync(S->d_topo, S->topo.data(), sizeof(TailTopo) * S->nj, hipMemcpyHostToDevice, S->stream));
   if (!S->child_list.empty())
     HIPTRY(hipMemcpyAsync(S->d_child_list, S->child_list.data(), sizeof(int) * S->child_list.size(),

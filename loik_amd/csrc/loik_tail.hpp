@@ -55,7 +55,8 @@ __device__ __forceinline__ size_t tail_lds_bytes(int nc, int G)
 template <typename T, bool HDIAG>
 __global__ void __launch_bounds__(WAVE)
 k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
-       const int* __restrict__ child_list, int maxdepth, int maxchild, const int* __restrict__ slots, int nslots, int G)
+       const int* __restrict__ child_list, int maxdepth, int maxchild, const int* __restrict__ slots, int nslots, int G,
+       int* __restrict__ slots_out)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
@@ -131,6 +132,20 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   int kexp = (int)mu2.y;         // mu = mu0 * 10^kexp
   T mu_h = T(-1), mu_o = T(-1);  // mu of the current / the other H slot: nothing cached yet
   int hsl = 0;                   // current H slot
+  if ((P.mode & MODE_CACHE_H) && NSLOT == 1 && isj && ldp<T>(srec, SP_TAG).x == mu) {
+    // the instance arrives with a valid H cache for its current mu (left by k_solve or by an earlier launch of this
+    // kernel): take it over instead of rebuilding it in the first iteration
+    const char* hrec = rec + (size_t)JP_SLOT0 * pair_bytes<T>();
+    ld6<T>(hrec, SL_UD, UD);
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const typename Vec2<T>::type a = ldp<T>(hrec, SL_H + k);
+      hst[(size_t)lane * HS + 2 * k] = a.x;
+      hst[(size_t)lane * HS + 2 * k + 1] = a.y;
+      if (k == 10) dinv = a.y;
+    }
+    mu_h = mu;
+  }
   const T bnorm = bi2.x;
   int iter = (int)bi2.y;
   int status = has_inst ? (int)st2.x : ST_DONE;
@@ -152,7 +167,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 
   // the loops below stay in wavefront-uniform control flow (LDS exchanges + barriers inside); a finished group only
   // masks its updates with `act`
-  while (__any(!done)) {
+  for (int kk = 0; kk < P.max_launch_iters && __any(!done); ++kk) {
     const bool act = !done;
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
     if (act) { ++iter; ++my_iters; any_iter = true; }
@@ -248,11 +263,14 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     if (need_h) mu_h = mu;
 
     // ================= root -> leaf: FwdPass2 + BoxProj + DualUpdate (hxx:102-163, :384-461) ==================
-    T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_dyis = T(0),
-      l_av = T(0), l_prt = T(0), l_prs = T(0), l_bp = T(0), l_bm = T(0), l_ubp = T(0), l_lbm = T(0);
+    // Only nu_i / v_i form a recursion over the tree: the level loop carries just that.  Everything else of the pass
+    // (f_i = H_i v_i + p_i, the projections, the dual updates, the norms) is per-joint work, done ONCE by all lanes.
+    T vi[6], nui = T(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vi[k] = T(0);
     for (int lev = 1; lev <= maxdepth; ++lev) {
       if (act && depth == lev) {
-        T vpar[6], vp[6], vi[6], fi[6], hl[21];
+        T vpar[6], vp[6];
         if (has_parent) {
 #pragma unroll
           for (int k = 0; k < 6; ++k) vpar[k] = xch[plane * XS + 21 + k];
@@ -260,135 +278,163 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
           for (int k = 0; k < 6; ++k) vpar[k] = T(0);
         }
-#pragma unroll
-        for (int k = 0; k < 21; ++k) hl[k] = hcur[k];
-        actinv_motion(R, t, vpar, vp);
+        actinv_motion(R, t, vpar, vp);  // hxx:125
         T udv = UD[0] * vp[0];
 #pragma unroll
         for (int k = 1; k < 6; ++k) udv += UD[k] * vp[k];
-        const T nui = -udv - dinv * r;
-        l_nu = tabs(nui);
+        nui = -udv - dinv * r;          // hxx:127
 #pragma unroll
         for (int k = 0; k < 6; ++k) vi[k] = vp[k];
         if (rev) { vi[3] += ax0 * nui; vi[4] += ax1 * nui; vi[5] += ax2 * nui; }
         else { vi[0] += ax0 * nui; vi[1] += ax1 * nui; vi[2] += ax2 * nui; }
-        symv(hl, vi, fi);
-        T df[6], dv6[6], hrv[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          fi[k] += p[k];
-          df[k] = fi[k] - f[k];
-          dv6[k] = vi[k] - v[k];
-        }
-        l_dfis = inf6(df);
-        href_mul<T, HDIAG>(P.Href, vi, hrv);
-        l_hrefv = inf6(hrv);
-        l_dvis = inf6(dv6);
-        l_dnu = tabs(nui - nu);
-        const T x = nui + (T(1) / mu_in) * w;
-        const T zi = tmin(ubi, tmax(lbi, x));
-        l_dz = tabs(zi - z);
-        l_prs = tabs(nui - zi);
-        const T dwi = mu_in * (nui - zi);
-        l_dw = tabs(dwi);
-        l_ubp = ubi * tmax(dwi, T(0));
-        l_lbm = lbi * tmin(dwi, T(0));
-        w = w + dwi; z = zi; nu = nui;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { v[k] = vi[k]; f[k] = fi[k]; xch[lane * XS + 21 + k] = vi[k]; }
-        if (d.cslot >= 0) {
-          T* c_ = cdi + d.cslot * CD;
-          T Av[6], e[6], yy[6];
-#pragma unroll
-          for (int a = 0; a < 6; ++a) {
-            T acc = T(0);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) acc += c_[CD_A + 6 * a + k] * vi[k];
-            Av[a] = acc;
-          }
-          T plus = T(0), minus = T(0);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            const T bk = c_[CD_B + k];
-            e[k] = Av[k] - bk;
-            const T dy = mu_eq * e[k];
-            yy[k] = c_[CD_Y + k] + dy;
-            l_dyis = tmax(l_dyis, tabs(dy));
-            plus += bk * tmax(dy, T(0));
-            minus += bk * tmin(dy, T(0));
-          }
-          l_bp = plus; l_bm = minus;
-          l_prt = inf6(e);
-          l_av = inf6(Av);
-#pragma unroll
-          for (int a = 0; a < 6; ++a) {
-            T acc = T(0);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) acc += c_[CD_A + 6 * k + a] * yy[k];
-            c_[CD_ATY + a] = acc;
-          }
-#pragma unroll
-          for (int k = 0; k < 6; ++k) c_[CD_Y + k] = yy[k];
-        }
+        for (int k = 0; k < 6; ++k) xch[lane * XS + 21 + k] = vi[k];
       }
       __syncthreads();
+    }
+    T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_dyis = T(0),
+      l_av = T(0), l_prt = T(0), l_prs = T(0), l_up = T(0), l_lm = T(0);
+    if (act && isj) {
+      T fi[6], hl[21];
+#pragma unroll
+      for (int k = 0; k < 21; ++k) hl[k] = hcur[k];
+      l_nu = tabs(nui);
+      symv(hl, vi, fi);  // hxx:139-140
+      T df[6], dv6[6], hrv[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        fi[k] += p[k];
+        df[k] = fi[k] - f[k];
+        dv6[k] = vi[k] - v[k];
+      }
+      l_dfis = inf6(df);
+      href_mul<T, HDIAG>(P.Href, vi, hrv);
+      l_hrefv = inf6(hrv);
+      l_dvis = inf6(dv6);
+      l_dnu = tabs(nui - nu);
+      const T x = nui + (T(1) / mu_in) * w;
+      const T zi = tmin(ubi, tmax(lbi, x));
+      l_dz = tabs(zi - z);
+      l_prs = tabs(nui - zi);
+      const T dwi = mu_in * (nui - zi);
+      l_dw = tabs(dwi);
+      l_up = ubi * tmax(dwi, T(0));
+      l_lm = lbi * tmin(dwi, T(0));
+      w = w + dwi; z = zi; nu = nui;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { v[k] = vi[k]; f[k] = fi[k]; }
+      if (d.cslot >= 0) {
+        T* c_ = cdi + d.cslot * CD;
+        T Av[6], e[6], yy[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          T acc = T(0);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc += c_[CD_A + 6 * a + k] * vi[k];
+          Av[a] = acc;
+        }
+        T plus = T(0), minus = T(0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const T bk = c_[CD_B + k];
+          e[k] = Av[k] - bk;
+          const T dy = mu_eq * e[k];
+          yy[k] = c_[CD_Y + k] + dy;
+          l_dyis = tmax(l_dyis, tabs(dy));
+          plus += bk * tmax(dy, T(0));
+          minus += bk * tmin(dy, T(0));
+        }
+        l_up += plus; l_lm += minus;
+        l_prt = inf6(e);
+        l_av = inf6(Av);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          T acc = T(0);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc += c_[CD_A + 6 * k + a] * yy[k];
+          c_[CD_ATY + a] = acc;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c_[CD_Y + k] = yy[k];
+      }
     }
 
-    // ================= leaf -> root: BwdPass2 + dual residual (hxx:185-241, :468-487) ==========================
-    T gi[6], l_dg = T(0), l_g = T(0), l_dualv = T(0), l_stf = T(0), l_dstf = T(0);
-    if (isj && d.cslot >= 0) {
+    // ================= BwdPass2 + dual residual (hxx:185-241, :468-487) =========================================
+    // g_i = Aty_c + sum_children act(f_j) - f_i needs the children's f only (no recursion): one exchange, no levels.
+    T l_dg = T(0), l_g = T(0), l_dualv = T(0), l_stf = T(0), l_dstf = T(0);
+    if (act && isj && has_parent) {
+      T pc[6];
+      act_force(R, t, f, pc);  // hxx:212
 #pragma unroll
-      for (int k = 0; k < 6; ++k) gi[k] = cdi[d.cslot * CD + CD_ATY + k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) gi[k] = T(0);
+      for (int k = 0; k < 6; ++k) xch[lane * XS + k] = pc[k];
     }
-    for (int lev = maxdepth; lev >= 1; --lev) {
-      if (act && depth == lev) {
-        for (int c = 0; c < maxchild; ++c) {
-          if (c < tp.nchild) {
-            const T* x = xch + (gbase + child_list[tp.child_start + c]) * XS;
+    __syncthreads();
+    if (act && isj) {
+      T gi[6];
+      if (d.cslot >= 0) {
 #pragma unroll
-            for (int k = 0; k < 6; ++k) gi[k] += x[k];
-          }
-        }
-        T dg[6], dvr[6];
+        for (int k = 0; k < 6; ++k) gi[k] = cdi[d.cslot * CD + CD_ATY + k];
+      } else {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          gi[k] += -f[k];
-          dg[k] = gi[k] - g[k];
-          g[k] = gi[k];
-        }
-        l_dg = inf6(dg);
-        l_g = inf6(gi);
-        href_mul<T, HDIAG>(P.Href, v, dvr);
+        for (int k = 0; k < 6; ++k) gi[k] = T(0);
+      }
+      for (int c = 0; c < maxchild; ++c) {
+        if (c < tp.nchild) {
+          const T* x = xch + (gbase + child_list[tp.child_start + c]) * XS;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) dvr[a] = dvr[a] - P.Hv[a] + gi[a];
-        l_dualv = inf6(dvr);
-        const T stf = rev ? (ax0 * f[3] + ax1 * f[4] + ax2 * f[5]) : (ax0 * f[0] + ax1 * f[1] + ax2 * f[2]);
-        const T si = stf + w;
-        l_stf = tabs(si);
-        l_dstf = tabs(si - s);
-        s = si;
-        if (has_parent) {
-          T pc[6];
-          act_force(R, t, f, pc);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) xch[lane * XS + k] = pc[k];
+          for (int k = 0; k < 6; ++k) gi[k] += x[k];
         }
       }
-      __syncthreads();
+      T dg[6], dvr[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        gi[k] += -f[k];
+        dg[k] = gi[k] - g[k];
+        g[k] = gi[k];
+      }
+      l_dg = inf6(dg);
+      l_g = inf6(gi);
+      href_mul<T, HDIAG>(P.Href, v, dvr);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) dvr[a] = dvr[a] - P.Hv[a] + gi[a];
+      l_dualv = inf6(dvr);
+      const T stf = rev ? (ax0 * f[3] + ax1 * f[4] + ax2 * f[5]) : (ax0 * f[0] + ax1 * f[1] + ax2 * f[2]);
+      const T si = stf + w;
+      l_stf = tabs(si);
+      l_dstf = tabs(si - s);
+      s = si;
     }
+    __syncthreads();
 
     // ================= lane-group reductions of the running norms, then the scalar epilogue ======================
-    // (executed by every lane: the shuffles need the whole wavefront; finished groups discard the results)
-    const T r_prt = group_max(l_prt, G), r_prs = group_max(l_prs, G), r_dualv = group_max(l_dualv, G),
-            r_stf = group_max(l_stf, G), r_dvis = group_max(l_dvis, G), r_dnu = group_max(l_dnu, G),
-            r_dz = group_max(l_dz, G), r_dfis = group_max(l_dfis, G), r_dyis = group_max(l_dyis, G),
-            r_dw = group_max(l_dw, G), r_av = group_max(l_av, G), r_nu = group_max(l_nu, G),
-            r_hrefv = group_max(l_hrefv, G), r_g = group_max(l_g, G), r_dg = group_max(l_dg, G),
-            r_dstf = group_max(l_dstf, G);
-    const T r_up = group_sum(l_bp, G) + group_sum(l_ubp, G), r_lm = group_sum(l_bm, G) + group_sum(l_lbm, G);
+    // Through LDS: every lane deposits its NRED scalars in its exchange row, lane q of a group folds scalar q over the
+    // group's rows (max for the inf-norms, sum for the two dot products) and publishes it in column XS-1 of row q.
+    constexpr int NRED = 18, NRMAX = 16;
+    {
+      T* row = xch + lane * XS;
+      row[0] = l_prt; row[1] = l_prs; row[2] = l_dualv; row[3] = l_stf; row[4] = l_dvis; row[5] = l_dnu;
+      row[6] = l_dz; row[7] = l_dfis; row[8] = l_dyis; row[9] = l_dw; row[10] = l_av; row[11] = l_nu;
+      row[12] = l_hrefv; row[13] = l_g; row[14] = l_dg; row[15] = l_dstf; row[16] = l_up; row[17] = l_lm;
+    }
+    __syncthreads();
+    for (int q = jlane; q < NRED; q += G) {
+      const T* col = xch + gbase * XS + q;
+      T red = T(0);
+      if (q < NRMAX) {
+        for (int l = 0; l < G; ++l) red = tmax(red, col[l * XS]);
+      } else {
+        for (int l = 0; l < G; ++l) red += col[l * XS];
+      }
+      xch[(gbase + q % G) * XS + (XS - 1) - q / G] = red;
+    }
+    __syncthreads();
+    T rr[NRED];
+#pragma unroll
+    for (int q = 0; q < NRED; ++q) rr[q] = xch[(gbase + q % G) * XS + (XS - 1) - q / G];
+    __syncthreads();
+    const T r_prt = rr[0], r_prs = rr[1], r_dualv = rr[2], r_stf = rr[3], r_dvis = rr[4], r_dnu = rr[5], r_dz = rr[6],
+            r_dfis = rr[7], r_dyis = rr[8], r_dw = rr[9], r_av = rr[10], r_nu = rr[11], r_hrefv = rr[12], r_g = rr[13],
+            r_dg = rr[14], r_dstf = rr[15], r_up = rr[16], r_lm = rr[17];
     if (act) {
       pr_task = r_prt; pr_slack = r_prs; dual_v = r_dualv; stf_w_inf = r_stf;
       primal = tmax(pr_task, pr_slack);
@@ -496,7 +542,11 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         stp<T>(srec, SP_SCAL + 14, (T)c2, (T)tail_iter);
       }
       if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
-      if (!(status & ST_DONE)) atomicAdd(&Bf.counters[0], 1u);
+      if (!(status & ST_DONE)) {
+        // still live when the launch budget ran out: queue it for the next launch
+        const unsigned int pos = atomicAdd(&Bf.counters[0], 1u);
+        if (slots_out) slots_out[pos] = slot;
+      }
     }
   }
 }
