@@ -92,7 +92,7 @@ typedef struct loikb_options {
   int max_launch_iters; /* ADMM iterations per kernel launch, 0 = automatic                    */
   int compact_min_instances; /* stop compacting below this many slots, 0 = default (4096)     */
   int tail_max_instances;    /* hand the last N live instances to the cooperative tail kernel (one wavefront per
-                                instance): 0 = default (2048), < 0 = never                    */
+                                instance): 0 = default (6144), < 0 = never                    */
 } loikb_options;
 
 typedef struct loikb_solver loikb_solver;
@@ -192,6 +192,16 @@ const char *loikb_status_string(int code);
 int loikb_version(void);
 /* number of visible HIP devices (0 when none / no driver) */
 int loikb_device_count(void);
+
+/* Host-side introspection of the sweep schedule (no device needed).  The solve kernel advances a tile of 64 instances
+ * with a team of `team` wavefronts; the joints of a tree sweep are list-scheduled onto the wavefronts, one joint per
+ * wavefront and step.  direction 0 = leaf->root (FwdPass1+BwdPass / BwdPass2 order), 1 = root->leaf (FwdPass2 order).
+ * joint_out / flags_out: [team][steps_cap] row-major, joint 0 = idle step; flags: 1 = child contribution arrives in
+ * registers, 2 = result stays in registers for the parent, 4 = result goes through an LDS slot (slot_out),
+ * 8 = parent velocity still in registers.  Returns the number of steps (the sweep's critical path in joint visits),
+ * or a negative status (LOIKB_ERR_ARG when steps_cap is too small or the tree is malformed).                          */
+int loikb_sweep_schedule(const int *parents, int njoints, int team, int direction, int steps_cap, int *joint_out,
+                         int *flags_out, int *slot_out, int *lds_slots_out);
 
 #ifdef __cplusplus
 }

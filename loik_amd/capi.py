@@ -70,7 +70,8 @@ EXPORTED_SYMBOLS = [
     "loikb_solve_tailored", "loikb_set_max_iter", "loikb_set_rho", "loikb_set_mu", "loikb_set_tol",
     "loikb_set_tol_primal_inf", "loikb_set_tol_tail_solve", "loikb_set_warm_start", "loikb_get", "loikb_get_stats",
     "loikb_batch", "loikb_nv", "loikb_njoints", "loikb_last_error", "loikb_status_string", "loikb_version",
-    "loikb_device_count", "loikb_builtin_model", "loikb_builtin_joint_name", "loikb_builtin_joint_id"]
+    "loikb_device_count", "loikb_sweep_schedule", "loikb_builtin_model", "loikb_builtin_joint_name",
+    "loikb_builtin_joint_id"]
 
 _lib = None
 
@@ -93,6 +94,7 @@ def lib():
     L.loikb_solve_init.argtypes = sig
     L.loikb_solve_full.argtypes = sig
     L.loikb_solve.argtypes = [C.c_void_p]
+    L.loikb_sweep_schedule.argtypes = [_ip, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip]
     L.loikb_solve_tailored.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     L.loikb_set_max_iter.argtypes = [C.c_void_p, C.c_int]
     for n in ["loikb_set_rho", "loikb_set_mu", "loikb_set_tol_primal_inf", "loikb_set_tol_tail_solve"]:
@@ -116,6 +118,24 @@ def lib():
 
 def device_count():
     return int(lib().loikb_device_count())
+
+
+def sweep_schedule(parents, team, direction):
+    """Step schedule of a tree sweep for a team of `team` wavefronts (host-only introspection, no device).
+    Returns (joint[team][T], flags[team][T], slot[team][T], n_lds_slots); direction 0 = leaf->root, 1 = root->leaf."""
+    parents = np.ascontiguousarray(parents, dtype=np.int32)
+    nj = int(parents.shape[0])
+    cap = nj
+    joint = np.zeros((team, cap), dtype=np.int32)
+    flags = np.zeros((team, cap), dtype=np.int32)
+    slot = np.zeros((team, cap), dtype=np.int32)
+    nslots = C.c_int(0)
+    T = lib().loikb_sweep_schedule(parents.ctypes.data_as(_ip), nj, int(team), int(direction), cap,
+                                   joint.ctypes.data_as(_ip), flags.ctypes.data_as(_ip), slot.ctypes.data_as(_ip),
+                                   C.byref(nslots))
+    if T < 0:
+        _check(T)
+    return joint[:, :T].copy(), flags[:, :T].copy(), slot[:, :T].copy(), int(nslots.value)
 
 
 def _check(rc):

@@ -947,6 +947,29 @@ extern "C" {
 
 int loikb_version(void) { return LOIKB_VERSION; }
 
+int loikb_sweep_schedule(const int* parents, int njoints, int team, int direction, int steps_cap, int* joint_out,
+                         int* flags_out, int* slot_out, int* lds_slots_out)
+{
+  if (!parents || njoints < 2 || team < 1 || team > MAX_TEAM || (direction != 0 && direction != 1) || !joint_out)
+    return LOIKB_ERR_ARG;
+  for (int i = 1; i < njoints; ++i)
+    if (parents[i] < 0 || parents[i] >= i) return LOIKB_ERR_ARG;
+  loikb_solver_impl::TeamSched sc;
+  build_team_schedule(std::vector<int>(parents, parents + njoints), team, sc);
+  const int T = direction == 0 ? sc.T_up : sc.T_down;
+  const std::vector<StepDesc>& st = direction == 0 ? sc.up : sc.down;
+  if (T > steps_cap) return LOIKB_ERR_ARG;
+  for (int w = 0; w < team; ++w)
+    for (int t = 0; t < steps_cap; ++t) {
+      const bool in = t < T;
+      joint_out[w * steps_cap + t] = in ? st[(size_t)w * T + t].joint : 0;
+      if (flags_out) flags_out[w * steps_cap + t] = in ? st[(size_t)w * T + t].flags : 0;
+      if (slot_out) slot_out[w * steps_cap + t] = in && (st[(size_t)w * T + t].flags & SF_OUT_LDS) ? st[(size_t)w * T + t].wslot : -1;
+    }
+  if (lds_slots_out) *lds_slots_out = direction == 0 ? sc.nslots : sc.nvslots;
+  return T;
+}
+
 const char* loikb_last_error(void) { return g_last_error.c_str(); }
 
 const char* loikb_status_string(int code)

@@ -84,6 +84,12 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   const bool has_parent = !(d.flags & JF_PARENT_ROOT);
   const int plane = gbase + d.parent - 1;  // parent's lane
   const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
+  // rows (lanes) of this joint's children in the exchange buffer: kept in registers, the sweeps must not go to
+  // global memory for them (children beyond NCH_REG are looked up in child_list)
+  constexpr int NCH_REG = 4;
+  int chl[NCH_REG];
+#pragma unroll
+  for (int c = 0; c < NCH_REG; ++c) chl[c] = gbase + (c < tp.nchild ? child_list[tp.child_start + c] : 0);
 
   // ---- load the instance: joint j -> lane j of the group -----------------------------------------------------
   T R[9], t[3], v[6], f[6], g[6], UD[6], UDo[6], p[6];
@@ -210,7 +216,9 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         // children contributions (deposited one level deeper), largest child index first as upstream
         for (int c = 0; c < maxchild; ++c) {
           if (c < tp.nchild) {
-            const T* x = xch + (gbase + child_list[tp.child_start + c]) * XS;
+            const int crow = c == 0 ? chl[0] : c == 1 ? chl[1] : c == 2 ? chl[2] : c == 3 ? chl[3]
+                                                                     : gbase + child_list[tp.child_start + c];
+            const T* x = xch + crow * XS;
             if (need_h) {
 #pragma unroll
               for (int k = 0; k < 21; ++k) hh[k] += x[k];
@@ -380,7 +388,9 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       }
       for (int c = 0; c < maxchild; ++c) {
         if (c < tp.nchild) {
-          const T* x = xch + (gbase + child_list[tp.child_start + c]) * XS;
+          const int crow = c == 0 ? chl[0] : c == 1 ? chl[1] : c == 2 ? chl[2] : c == 3 ? chl[3]
+                                                                   : gbase + child_list[tp.child_start + c];
+          const T* x = xch + crow * XS;
 #pragma unroll
           for (int k = 0; k < 6; ++k) gi[k] += x[k];
         }

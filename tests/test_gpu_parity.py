@@ -400,3 +400,67 @@ def test_tail_kernel_reference_fixture_and_warm_start(talos):
             assert s.get("iter")[b] == rr.get_iter(), (t, b)
             assert_close(s.get("z")[b], rr.z, 1e-9, "z")
     s.close()
+
+
+@pytest.mark.parametrize("which", ["talos", "tree40"])
+def test_team_and_single_wavefront_sweeps_agree(which, request, monkeypatch):
+    """a tile advanced by a team of wavefronts (chains of the tree walked concurrently, contributions handed over
+    through LDS slots) against the same tile walked by ONE wavefront: same iteration counts and flags, state equal
+    to rounding (children contributions / inf-norm partials are combined in a different order)"""
+    if which == "talos":
+        model = request.getfixturevalue("talos")
+        link = model.getJointId("arm_left_7_joint")
+    else:
+        model = random_tree(40, 40)
+        link = model.njoints - 1
+    B = 700
+    wl = feasible_batch(model, B, link, 321, nu_scale=0.5)
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
+    team = gpu_solve(model, wl, prm, tail_max_instances=-1)
+    monkeypatch.setenv("LOIKB_TEAM", "1")
+    single = gpu_solve(model, wl, prm, tail_max_instances=-1)
+    it_t, it_s = team.get("iter"), single.get("iter")
+    same = it_t == it_s
+    assert same.mean() >= 0.99, (it_t[~same], it_s[~same])
+    assert np.array_equal(team.get("status")[same], single.get("status")[same])
+    for name in ["z", "nu", "w", "vis", "fis", "g", "yis", "Stf_plus_w", "primal_residual", "dual_residual", "mu"]:
+        a, b = team.get(name)[same], single.get(name)[same]
+        assert np.max(np.abs(a - b) / (1.0 + np.abs(b))) < 1e-9, name
+    # and the team path against the oracle on a few instances
+    for b in np.flatnonzero(same)[:4]:
+        r = ref.RefSolver(model, **prm)
+        r.Solve(*problem_args(wl, b))
+        assert team.get("iter")[b] == r.get_iter()
+        assert_close(team.get("z")[b], r.z, 1e-9, "z b%d" % b)
+        assert_close(team.get("w")[b], r.w, 1e-9, "w b%d" % b)
+    team.close(); single.close()
+
+
+def test_tail_kernel_bounded_relaunches(talos, monkeypatch):
+    """more live instances than the tail kernel keeps resident: it runs in bounded launches and re-lists the
+    survivors; instances must come out as when the tail kernel runs each of them to the end in one launch"""
+    link = talos.getJointId("arm_left_7_joint")
+    B = 5000
+    wl = feasible_batch(talos, B, link, 555, nu_scale=0.5)
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
+    monkeypatch.setenv("LOIKB_TAIL_ROUND", "100000")
+    one = gpu_solve(talos, wl, prm, max_launch_iters=2, tail_max_instances=1 << 20)
+    monkeypatch.setenv("LOIKB_TAIL_ROUND", "7")
+    many = gpu_solve(talos, wl, prm, max_launch_iters=2, tail_max_instances=1 << 20)
+    st1, stn = one.stats(), many.stats()
+    assert st1["tail_instances"] == stn["tail_instances"] > 2048
+    assert stn["launches"] > st1["launches"] + 3, (st1, stn)
+    assert st1["instance_iterations"] == stn["instance_iterations"] == int(many.get("iter").sum())
+    # each launch restarts from the state written home by the previous one (and takes over the H cache left there).
+    # Not bit for bit: which of an instance's cached H_i were built by k_solve and which were rebuilt by the tail
+    # kernel (children summed in another order) depends on where the launches cut -- rounding-level differences only
+    for name in ["iter", "status", "mu"]:
+        assert np.array_equal(one.get(name), many.get(name)), name
+    for name in ["z", "nu", "w", "vis", "fis", "g", "yis", "Aty", "Stf_plus_w", "primal_residual", "dual_residual"]:
+        assert np.max(np.abs(one.get(name) - many.get(name))) < 1e-11, name
+    ref_out = ref.solve_batch(talos, wl["q"][:64], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"][:64],
+                              wl["lb"], wl["ub"], nthreads=4, **prm)
+    same = many.get("iter")[:64] == ref_out["iters"]
+    assert same.mean() >= 0.95
+    assert np.max(np.abs(many.get("z")[:64] - ref_out["z"])[same]) < 1e-9
+    one.close(); many.close()
