@@ -172,14 +172,17 @@ int loikb_get(loikb_solver *s, int field, void *out, int out_flags);
 /* measurement: what the last loikb_solve* call did */
 typedef struct loikb_stats {
   unsigned long long instance_iterations; /* ADMM iterations summed over instances                */
-  int launches;                           /* k_solve launches                                     */
+  int launches;                           /* kernel launches (solve kernel + tail kernel)         */
   int n_unfinished;                       /* instances that hit max_iter without stopping         */
   int compactions;                        /* lane compactions performed                           */
   int tail_instances;                     /* instances finished by the cooperative tail kernel    */
   double tail_ms;                         /* HIP-event time of the tail kernel (part of kernel_ms)*/
-  double kernel_ms;                       /* HIP-event time of the k_solve launches on the stream */
+  double kernel_ms;                       /* HIP-event time of all solve + tail launches          */
   double total_ms;                        /* HIP-event time of the whole call on the stream       */
   double bytes_per_instance_iteration;    /* algorithmic bytes, SURVEY.md 8(d): s*(203 nb+108 nc) */
+  unsigned long long tail_instance_iterations; /* the part of instance_iterations run by the tail kernel */
+  int tail_launches;                      /* launches of the tail kernel (part of `launches`)     */
+  int team;                               /* wavefronts per tile used by the solve kernel         */
 } loikb_stats;
 int loikb_get_stats(loikb_solver *s, loikb_stats *out);
 

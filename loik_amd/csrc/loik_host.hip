@@ -774,6 +774,7 @@ int run_tail(loikb_solver_impl* S, Params<T>& P, int cur, int n_cur, int n_live,
       fprintf(stderr, "[loikb] tail launch: %6d instances, budget %4d  %8.3f ms  inst-iters %9u (%.1f M/s)  live after %6u\n",
               n, P.max_launch_iters, ms, S->h_counters[1], S->h_counters[1] / ms / 1e3, S->h_counters[0]);
     S->stats.launches++;
+    S->stats.tail_launches++;
     if ((int)S->h_counters[0] >= n && P.max_launch_iters > S->opt.max_iter) {
       g_last_error = "tail: no progress";
       return LOIKB_ERR_STATE;
@@ -846,6 +847,7 @@ int run_main_loop_t(loikb_solver_impl* S)
     P.max_launch_iters = launch_iters;
     Bufs<T> Bf = make_bufs<T>(S, cur);
     const loikb_solver_impl::TeamSched& sc = S->sched[(team_ok && n_cur <= team_max) ? 1 : 0];
+    S->stats.team = sc.nw;
     const int edge_ent = edge_entries(sc);
     const Team tm{sc.d_up, sc.d_down, sc.d_rlist, sc.T_up, sc.T_down, edge_ent};
     const size_t lds = lds_bytes(sc);
@@ -884,6 +886,7 @@ int run_main_loop_t(loikb_solver_impl* S)
       if (trace) fprintf(stderr, "[loikb] tail kernel: %u instances  %8.3f ms  inst-iters %9llu\n", n_live, tms, tit);
       S->stats.tail_ms = tms;
       S->stats.tail_instances = (int)n_live;
+      S->stats.tail_instance_iterations = tit;
       inst_iters += tit;
       n_live = 0;
       break;

@@ -21,4 +21,7 @@ for k in sorted(set(f) | set(w)):
                          "write_bytes_per_step": w[k] * 1024 / nsolves}
 tot = sum(v["fetch_bytes_per_step"] + v["write_bytes_per_step"] for v in out["kernels"].values())
 out["hbm_bytes_per_step"] = tot
+ks = out["kernels"].get("k_solve")
+if ks:
+    out["k_solve_hbm_bytes_per_step"] = ks["fetch_bytes_per_step"] + ks["write_bytes_per_step"]
 print(json.dumps(out, indent=1))
