@@ -118,6 +118,7 @@ enum : int {
   MODE_BND_SHARED = 8,   // one lb/ub for the whole batch
 };
 
+
 // per-iteration scalars dumped for the getters / parity tests (scalar record, SP_SCAL)
 enum : int {
   SC_PRIMAL_RES = 0, SC_DUAL_RES, SC_PRIMAL_RES_TASK, SC_PRIMAL_RES_SLACK, SC_DUAL_RES_V, SC_DUAL_RES_NU,
@@ -149,7 +150,8 @@ template <typename T>
 struct Bufs {
   char* tiles;             // tile t at tiles + t * L.tile_pairs * PAIR_BYTES
   const T* uni;            // uniform inputs: A[nc][36], AtA[nc][21], lb[nb], ub[nb]
-  unsigned int* counters;  // [0] live instances at exit, [1] instance-iterations executed
+  unsigned int* counters;  // [0] live instances at exit, [1] instance-iterations executed,
+                           // [2] tile-iterations, [3] of them with an H rebuild, [4] of them with the fused sweep
   int* wave_live;          // [tiles] live lanes of each wavefront at exit (feeds the host-side compaction scan)
 };
 
@@ -1102,6 +1104,7 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const StepDesc* __restrict__ sched_
   // main-loop bound `for (i = 1; i < max_iter; ++i)` (hpp:377): nothing to do when max_iter <= 1
   if (live && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { live = false; status |= ST_DONE; }
   unsigned int my_iters = 0;
+  unsigned int n_tile_iters = 0, n_h_iters = 0, n_fused_iters = 0;  // sweep mix of this tile (diagnostics)
   // scalars of the per-iteration dump that keep their last value when an iteration does not re-evaluate them
   // (CheckFeasibility is skipped at iteration 1 and in the tail solve): carried in registers, no reload per iteration
   T p_tolp, p_told, p_dyqp, p_atdy, p_ubp, p_lbm;
@@ -1131,6 +1134,7 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const StepDesc* __restrict__ sched_
     // leaf -> root sweep of this iteration, unless the previous iteration's fused sweep already did it
     if (!have_p) {
       const bool need_h = !(P.mode & MODE_CACHE_H) || __any(live && (tag != mu));
+      n_h_iters += need_h;
       if (need_h) {
         sweep_bwd<T, true, HDIAG>(P, Bf, tm, w, nw, edge, lp, lane, live, mu_eq, mu_in, hoff);
         if (live) {
@@ -1143,6 +1147,8 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const StepDesc* __restrict__ sched_
       }
     }
     sweep_fwd<T, HDIAG, TEAM>(P, Bf, tm, w, nw, edge + (size_t)tm.edge_ent * WAVE, lp, lane, live, mu_eq, mu_in, hoff, N);
+    ++n_tile_iters;
+    n_fused_iters += ((P.mode & MODE_CACHE_H) && spec);
     if ((P.mode & MODE_CACHE_H) && spec) {
       sweep_fused<T, HDIAG, TEAM>(P, Bf, tm, w, nw, edge, lp, lane, live, mu_eq, mu_in, hoff, N);
       have_p = true;
@@ -1255,6 +1261,9 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const StepDesc* __restrict__ sched_
     Bf.wave_live[blockIdx.x] = (int)nlive;
     if (nlive) atomicAdd(&Bf.counters[0], nlive);
     if (it_sum) atomicAdd(&Bf.counters[1], it_sum);
+    atomicAdd(&Bf.counters[2], n_tile_iters);
+    atomicAdd(&Bf.counters[3], n_h_iters);
+    atomicAdd(&Bf.counters[4], n_fused_iters);
   }
 }
 static_assert(SC_PRIMAL_RES == 0 && SC_DUAL_RES == 1 && SC_TOL_PRIMAL == 6 && SC_MU == 8 && SC_MU_INEQ == 10 &&

@@ -752,7 +752,7 @@ int run_tail(loikb_solver_impl* S, Params<T>& P, int cur, int n_cur, int n_live,
   while (n > 0) {
     P.max_launch_iters = n > resident ? round_iters : S->opt.max_iter + 1;
     const dim3 grid((unsigned)((n + ipw - 1) / ipw));
-    HIPCHK(hipMemsetAsync(S->d_counters, 0, 2 * sizeof(unsigned int), S->stream));
+    HIPCHK(hipMemsetAsync(S->d_counters, 0, 8 * sizeof(unsigned int), S->stream));
     HIPCHK(hipEventRecord(S->ev_k0, S->stream));
     if (S->href_diag)
       hipLaunchKernelGGL((k_tail<T, true>), grid, dim3(WAVE), lds, S->stream, P, Bf, (const JointDesc*)S->d_jd,
@@ -764,15 +764,17 @@ int run_tail(loikb_solver_impl* S, Params<T>& P, int cur, int n_cur, int n_live,
                          (const int*)S->d_slots[li], n, G, S->d_slots[li ^ 1]);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(S->ev_k1, S->stream));
-    HIPCHK(hipMemcpyAsync(S->h_counters, S->d_counters, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
+    HIPCHK(hipMemcpyAsync(S->h_counters, S->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
     HIPCHK(hipStreamSynchronize(S->stream));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, S->ev_k0, S->ev_k1));
     total_ms += ms;
     iters += S->h_counters[1];
     if (trace)
-      fprintf(stderr, "[loikb] tail launch: %6d instances, budget %4d  %8.3f ms  inst-iters %9u (%.1f M/s)  live after %6u\n",
-              n, P.max_launch_iters, ms, S->h_counters[1], S->h_counters[1] / ms / 1e3, S->h_counters[0]);
+      fprintf(stderr, "[loikb] tail launch: %6d instances, budget %4d  %8.3f ms  inst-iters %9u (%.1f M/s)  live after %6u"
+                      "  wave-iters %7u H-rebuild %3.0f%%\n",
+              n, P.max_launch_iters, ms, S->h_counters[1], S->h_counters[1] / ms / 1e3, S->h_counters[0],
+              S->h_counters[5], 100.0 * S->h_counters[6] / (S->h_counters[5] ? S->h_counters[5] : 1));
     S->stats.launches++;
     S->stats.tail_launches++;
     if ((int)S->h_counters[0] >= n && P.max_launch_iters > S->opt.max_iter) {
@@ -852,7 +854,7 @@ int run_main_loop_t(loikb_solver_impl* S)
     const Team tm{sc.d_up, sc.d_down, sc.d_rlist, sc.T_up, sc.T_down, edge_ent};
     const size_t lds = lds_bytes(sc);
     const dim3 grid((unsigned)((n_cur + WAVE - 1) / WAVE)), block(WAVE * sc.nw);
-    HIPCHK(hipMemsetAsync(S->d_counters, 0, 2 * sizeof(unsigned int), S->stream));
+    HIPCHK(hipMemsetAsync(S->d_counters, 0, 8 * sizeof(unsigned int), S->stream));
     HIPCHK(hipEventRecord(S->ev_k0, S->stream));
     if (sc.nw > 1) {
       if (S->href_diag) hipLaunchKernelGGL((k_solve<T, true, true>), grid, block, lds, S->stream, P, Bf, tm.up, tm.down, tm.rlist, tm.T_up, tm.T_down, tm.edge_ent);
@@ -863,7 +865,7 @@ int run_main_loop_t(loikb_solver_impl* S)
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(S->ev_k1, S->stream));
-    HIPCHK(hipMemcpyAsync(S->h_counters, S->d_counters, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
+    HIPCHK(hipMemcpyAsync(S->h_counters, S->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
     HIPCHK(hipStreamSynchronize(S->stream));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, S->ev_k0, S->ev_k1));
@@ -873,9 +875,12 @@ int run_main_loop_t(loikb_solver_impl* S)
     n_live = S->h_counters[0];
     done_iters += launch_iters;
     if (trace)
-      fprintf(stderr, "[loikb] launch %3d: set %d slots %7d iters %4d..%4d  %8.3f ms  inst-iters %9u (%.1f M/s)  live after %7u\n",
+      fprintf(stderr, "[loikb] launch %3d: set %d slots %7d iters %4d..%4d  %8.3f ms  inst-iters %9u (%.1f M/s)  live after %7u"
+                      "  tile-iters %6u H-rebuild %3.0f%% fused %3.0f%%\n",
               S->stats.launches, cur, n_cur, done_iters - launch_iters + 1, done_iters, ms, S->h_counters[1],
-              S->h_counters[1] / ms / 1e3, n_live);
+              S->h_counters[1] / ms / 1e3, n_live, S->h_counters[2],
+              100.0 * S->h_counters[3] / (S->h_counters[2] ? S->h_counters[2] : 1),
+              100.0 * S->h_counters[4] / (S->h_counters[2] ? S->h_counters[2] : 1));
     if (n_live == 0 || done_iters >= max_total) break;
     if (use_tail && (int)n_live <= tail_max) {
       double tms = 0.0;
@@ -1038,12 +1043,12 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
   HIPTRY(hipEventCreate(&S->ev_k1));
   HIPTRY(hipEventCreate(&S->ev_t0));
   HIPTRY(hipEventCreate(&S->ev_t1));
-  HIPTRY(hipHostMalloc((void**)&S->h_counters, 2 * sizeof(unsigned int)));
+  HIPTRY(hipHostMalloc((void**)&S->h_counters, 8 * sizeof(unsigned int)));
   void* tmp = nullptr;
   TRY(alloc_dev(S, &tmp, sizeof(JointDesc) * S->nj)); S->d_jd = (JointDesc*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * S->nj)); S->d_idx_q = (int*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * ROWMAP_CAP)); S->d_rowmap = (int*)tmp;
-  TRY(alloc_dev(S, &tmp, 2 * sizeof(unsigned int))); S->d_counters = (unsigned int*)tmp;
+  TRY(alloc_dev(S, &tmp, 8 * sizeof(unsigned int))); S->d_counters = (unsigned int*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(TailTopo) * S->nj)); S->d_topo = (TailTopo*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * (S->child_list.size() + 1))); S->d_child_list = (int*)tmp;
   for (int k = 0; k < 2; ++k) { TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)(S->B + WAVE))); S->d_slots[k] = (int*)tmp; }

@@ -165,6 +165,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   bool done = (status & ST_DONE) != 0;
   if (!done && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { done = true; status |= ST_DONE; }
   unsigned int my_iters = 0;
+  unsigned int n_wave_iters = 0, n_h_iters = 0;  // diagnostics: wavefront-iterations, those with an H rebuild
   // last-iteration scalars (for the final dump)
   T primal = T(0), dual = T(0), pr_task = T(0), pr_slack = T(0), dual_v = T(0), stf_w_inf = T(0), dx = T(0), dz = T(0);
   T n_dfis = T(0), n_dyis = T(0), n_dw = T(0), n_dvis = T(0), n_dnu = T(0), n_av = T(0), n_nu = T(0), n_hrefv = T(0),
@@ -179,7 +180,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     if (act) { ++iter; ++my_iters; any_iter = true; }
 
     // ---- H cache: two slots (two most recent mu); a flip back to the previous mu costs a register swap ----------
-    if (act && (P.mode & MODE_CACHE_H) && mu_h != mu) {
+    if (act && (P.mode & MODE_CACHE_H) && (mu_h != mu)) {
       { const T tmp = mu_h; mu_h = mu_o; mu_o = tmp; }
       hsl ^= 1;
       dinv = hst[((size_t)hsl * WAVE + lane) * HS + 21];  // Dinv of the slot that becomes current
@@ -187,6 +188,8 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       for (int k = 0; k < 6; ++k) { const T tmp = UD[k]; UD[k] = UDo[k]; UDo[k] = tmp; }
     }
     const bool need_h = act && (!(P.mode & MODE_CACHE_H) || (mu_h != mu));
+    ++n_wave_iters;
+    n_h_iters += __any(need_h) ? 1u : 0u;
     T* hcur = hst + ((size_t)hsl * WAVE + lane) * HS;
 
     // ================= leaf -> root: FwdPass1 + BwdPass (hxx:290-338, :31-81) =================================
@@ -552,6 +555,10 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         stp<T>(srec, SP_SCAL + 14, (T)c2, (T)tail_iter);
       }
       if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
+      if (lane == 0) {
+        atomicAdd(&Bf.counters[5], n_wave_iters);
+        atomicAdd(&Bf.counters[6], n_h_iters);
+      }
       if (!(status & ST_DONE)) {
         // still live when the launch budget ran out: queue it for the next launch
         const unsigned int pos = atomicAdd(&Bf.counters[0], 1u);

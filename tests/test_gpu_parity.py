@@ -457,7 +457,8 @@ def test_tail_kernel_bounded_relaunches(talos, monkeypatch):
     for name in ["iter", "status", "mu"]:
         assert np.array_equal(one.get(name), many.get(name)), name
     for name in ["z", "nu", "w", "vis", "fis", "g", "yis", "Aty", "Stf_plus_w", "primal_residual", "dual_residual"]:
-        assert np.max(np.abs(one.get(name) - many.get(name))) < 1e-11, name
+        a, b = one.get(name), many.get(name)
+        assert np.max(np.abs(a - b) / (1.0 + np.abs(b))) < 1e-10, name
     ref_out = ref.solve_batch(talos, wl["q"][:64], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"][:64],
                               wl["lb"], wl["ub"], nthreads=4, **prm)
     same = many.get("iter")[:64] == ref_out["iters"]
