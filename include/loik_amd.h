@@ -183,6 +183,9 @@ typedef struct loikb_stats {
   unsigned long long tail_instance_iterations; /* the part of instance_iterations run by the tail kernel */
   int tail_launches;                      /* launches of the tail kernel (part of `launches`)     */
   int team;                               /* wavefronts per tile used by the solve kernel         */
+  int chunks;                             /* independent ranges of the batch solved concurrently (own stream each);
+                                             kernel_ms / tail_ms sum the launches of all chunks, so with chunks > 1
+                                             they can exceed total_ms                                            */
 } loikb_stats;
 int loikb_get_stats(loikb_solver *s, loikb_stats *out);
 

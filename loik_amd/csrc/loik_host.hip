@@ -22,7 +22,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace loikb;
@@ -63,7 +65,6 @@ struct loikb_solver_impl {
   int maxdepth = 0, maxchild = 0;
   TailTopo* d_topo = nullptr;
   int* d_child_list = nullptr;
-  int* d_slots[2] = {nullptr, nullptr};  // live-instance lists of the tail kernel (ping-pong between launches)
   // options
   loikb_options opt{};
   int B = 0, nc = 0;
@@ -79,14 +80,13 @@ struct loikb_solver_impl {
   // device
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   std::vector<void*> allocs;
+  std::mutex alloc_mu;
   JointDesc* d_jd = nullptr;
   int* d_idx_q = nullptr;
   int* d_rowmap = nullptr;
   void* d_uni = nullptr;               // A[nc][36], AtA[nc][21], lb[nb], ub[nb] (T)
-  unsigned int* d_counters = nullptr;
-  unsigned int* h_counters = nullptr;  // pinned
   void* d_stage = nullptr;             // staging for host<->device copies
   size_t stage_bytes = 0;
   // tile layouts: A per instance needs the long constraint record
@@ -95,17 +95,43 @@ struct loikb_solver_impl {
     char* tiles = nullptr;
     int ntiles = 0;
     int *map = nullptr, *wave_live = nullptr, *wave_off = nullptr;
-  } set[3];
-  std::vector<int> h_wave;  // host scratch for the compaction scan
+  };
+  Set home;  // tile t, lane l <-> instance 64 t + l
+  // The batch is solved as `chunks.size()` independent contiguous ranges of tiles, each driven by its own host
+  // thread on its own stream (instances never interact).  While one chunk is in its latency-bound straggler phase
+  // (few wavefronts resident) the others keep the machine busy with their bandwidth-bound bulk phase, and the
+  // host-side gaps between launches (counter read-back, compaction scan) of one chunk are covered by the others.
+  struct Chunk {
+    int first_tile = 0, B = 0;           // instances [64 first_tile, 64 first_tile + B)
+    Set set[3];                          // [0] view of the home tiles of the range, [1],[2] work sets of the compaction
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+    unsigned int* d_counters = nullptr;
+    unsigned int* h_counters = nullptr;  // pinned
+    int* d_slots[2] = {nullptr, nullptr};  // live-instance lists of the tail kernel (ping-pong between launches)
+    std::vector<int> h_wave;             // host scratch for the compaction scan
+    loikb_stats stats{};
+    int rc = 0;
+    std::string err;
+  };
+  std::vector<Chunk> chunks;
+  hipEvent_t ev_fork = nullptr;
   loikb_stats stats{};
 };
+using Chunk = loikb_solver_impl::Chunk;
 
-int alloc_dev(loikb_solver_impl* S, void** out, size_t bytes)
+// `st`: the stream that will use the buffer first (the zero fill is ordered on it); chunk threads allocate their
+// work sets concurrently, hence the lock around the bookkeeping
+int alloc_dev(loikb_solver_impl* S, void** out, size_t bytes, hipStream_t st = nullptr, bool use_st = false)
 {
   void* p = nullptr;
   HIPCHK(hipMalloc(&p, bytes ? bytes : 16));
-  HIPCHK(hipMemsetAsync(p, 0, bytes ? bytes : 16, S->stream));
-  S->allocs.push_back(p);
+  HIPCHK(hipMemsetAsync(p, 0, bytes ? bytes : 16, use_st ? st : S->stream));
+  {
+    std::lock_guard<std::mutex> lock(S->alloc_mu);
+    S->allocs.push_back(p);
+  }
   *out = p;
   return LOIKB_OK;
 }
@@ -125,20 +151,19 @@ inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block
 inline size_t pair_b(const loikb_solver_impl* S) { return (size_t)WAVE * 2 * S->esz; }
 inline size_t tile_bytes(const loikb_solver_impl* S) { return (size_t)S->L.tile_pairs * pair_b(S); }
 
-int alloc_set(loikb_solver_impl* S, int k, int ntiles)
+int alloc_set(loikb_solver_impl* S, loikb_solver_impl::Set& W, int ntiles, hipStream_t st = nullptr, bool use_st = false)
 {
-  loikb_solver_impl::Set& W = S->set[k];
   if (W.tiles) return LOIKB_OK;
   int rc;
   void* tmp = nullptr;
-  if ((rc = alloc_dev(S, &tmp, tile_bytes(S) * ntiles))) return rc;
+  if ((rc = alloc_dev(S, &tmp, tile_bytes(S) * ntiles, st, use_st))) return rc;
   W.tiles = (char*)tmp;
   W.ntiles = ntiles;
-  if ((rc = alloc_dev(S, &tmp, sizeof(int) * (size_t)ntiles * WAVE))) return rc;
+  if ((rc = alloc_dev(S, &tmp, sizeof(int) * (size_t)ntiles * WAVE, st, use_st))) return rc;
   W.map = (int*)tmp;
-  if ((rc = alloc_dev(S, &tmp, sizeof(int) * ((size_t)ntiles + 1)))) return rc;
+  if ((rc = alloc_dev(S, &tmp, sizeof(int) * ((size_t)ntiles + 1), st, use_st))) return rc;
   W.wave_live = (int*)tmp;
-  if ((rc = alloc_dev(S, &tmp, sizeof(int) * ((size_t)ntiles + 1)))) return rc;
+  if ((rc = alloc_dev(S, &tmp, sizeof(int) * ((size_t)ntiles + 1), st, use_st))) return rc;
   W.wave_off = (int*)tmp;
   return LOIKB_OK;
 }
@@ -399,13 +424,13 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
 }
 
 template <typename T>
-Bufs<T> make_bufs(loikb_solver_impl* S, int k)
+Bufs<T> make_bufs(loikb_solver_impl* S, Chunk* C, int k)
 {
   Bufs<T> Bf{};
-  Bf.tiles = S->set[k].tiles;
+  Bf.tiles = C->set[k].tiles;
   Bf.uni = (const T*)S->d_uni;
-  Bf.counters = S->d_counters;
-  Bf.wave_live = S->set[k].wave_live;
+  Bf.counters = C->d_counters;
+  Bf.wave_live = C->set[k].wave_live;
   return Bf;
 }
 
@@ -435,9 +460,9 @@ Params<T> make_params(loikb_solver_impl* S)
 // one k_reset launch over the home set
 int reset_home(loikb_solver_impl* S, int what)
 {
-  const dim3 grid(S->set[0].ntiles), block(WAVE);
-  if (S->f32) hipLaunchKernelGGL(k_reset<float>, grid, block, 0, S->stream, S->set[0].tiles, S->L, what, (float)S->opt.mu);
-  else hipLaunchKernelGGL(k_reset<double>, grid, block, 0, S->stream, S->set[0].tiles, S->L, what, (double)S->opt.mu);
+  const dim3 grid(S->home.ntiles), block(WAVE);
+  if (S->f32) hipLaunchKernelGGL(k_reset<float>, grid, block, 0, S->stream, S->home.tiles, S->L, what, (float)S->opt.mu);
+  else hipLaunchKernelGGL(k_reset<double>, grid, block, 0, S->stream, S->home.tiles, S->L, what, (double)S->opt.mu);
   HIPCHK(hipGetLastError());
   return LOIKB_OK;
 }
@@ -472,10 +497,10 @@ int upload_rows(loikb_solver_impl* S, const double* src, const std::vector<int>&
   if ((rc = to_device(S, src, sizeof(double) * (shared ? (size_t)n : (size_t)S->B * n), src_device && !shared, &dsrc))) return rc;
   if (S->f32)
     hipLaunchKernelGGL(k_upload_rows<float>, grid1(S->B), dim3(256), 0, S->stream, (const double*)dsrc, n, (int)shared,
-                       S->d_rowmap, S->L, S->B, S->set[0].tiles);
+                       S->d_rowmap, S->L, S->B, S->home.tiles);
   else
     hipLaunchKernelGGL(k_upload_rows<double>, grid1(S->B), dim3(256), 0, S->stream, (const double*)dsrc, n, (int)shared,
-                       S->d_rowmap, S->L, S->B, S->set[0].tiles);
+                       S->d_rowmap, S->L, S->B, S->home.tiles);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(S->stream));  // staging buffer / rowmap are reused
   return LOIKB_OK;
@@ -520,10 +545,10 @@ int fwd_pass_init(loikb_solver_impl* S, const double* q, int in_flags)
   if (rc) return rc;
   if (S->f32)
     hipLaunchKernelGGL(k_fk_init<float>, grid1(S->B), dim3(256), 0, S->stream, (const double*)dq, S->nq, (int)shared,
-                       S->d_jd, S->d_idx_q, S->L, S->B, S->set[0].tiles);
+                       S->d_jd, S->d_idx_q, S->L, S->B, S->home.tiles);
   else
     hipLaunchKernelGGL(k_fk_init<double>, grid1(S->B), dim3(256), 0, S->stream, (const double*)dq, S->nq, (int)shared,
-                       S->d_jd, S->d_idx_q, S->L, S->B, S->set[0].tiles);
+                       S->d_jd, S->d_idx_q, S->L, S->B, S->home.tiles);
   HIPCHK(hipGetLastError());
   if (!dev) HIPCHK(hipStreamSynchronize(S->stream));
   // the H/UDinv/Dinv cache depends on liMi; cold start: yis = 0, Aty = 0 (hxx:270-278)
@@ -533,10 +558,10 @@ int fwd_pass_init(loikb_solver_impl* S, const double* q, int in_flags)
 int constraint_products(loikb_solver_impl* S, int c_lo, int c_hi, bool grow_only)
 {
   if (S->f32)
-    hipLaunchKernelGGL(k_constraint_products<float>, grid1(S->B), dim3(256), 0, S->stream, S->set[0].tiles, S->L,
+    hipLaunchKernelGGL(k_constraint_products<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L,
                        (const float*)S->d_uni, (int)S->a_shared, c_lo, c_hi, S->B, (int)grow_only);
   else
-    hipLaunchKernelGGL(k_constraint_products<double>, grid1(S->B), dim3(256), 0, S->stream, S->set[0].tiles, S->L,
+    hipLaunchKernelGGL(k_constraint_products<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L,
                        (const double*)S->d_uni, (int)S->a_shared, c_lo, c_hi, S->B, (int)grow_only);
   HIPCHK(hipGetLastError());
   return LOIKB_OK;
@@ -577,25 +602,38 @@ int ensure_layout(loikb_solver_impl* S, bool a_shared)
   // offsets) then start on different HBM channel groups instead of camping on a few of them
   if (const char* e = getenv("LOIKB_TILE_PAD")) L.tile_pairs += atoi(e);
   else if (!(L.tile_pairs & 1)) L.tile_pairs += 1;
-  if (S->set[0].tiles && L.crec == S->L.crec) return LOIKB_OK;
-  if (S->set[0].tiles) {
+  if (S->home.tiles && L.crec == S->L.crec) return LOIKB_OK;
+  auto free_set = [&](loikb_solver_impl::Set& W, bool owns_tiles) {
+    void* ptrs[4] = {owns_tiles ? W.tiles : nullptr, W.map, W.wave_live, W.wave_off};
+    for (void* p : ptrs)
+      if (p) {
+        (void)hipFree(p);
+        for (auto& a : S->allocs) if (a == p) a = nullptr;
+      }
+    W = loikb_solver_impl::Set{};
+  };
+  if (S->home.tiles) {
     // sharing mode of A changed: every tile has a different size now
     HIPCHK(hipStreamSynchronize(S->stream));
-    for (int k = 0; k < 3; ++k) {
-      loikb_solver_impl::Set& W = S->set[k];
-      void* ptrs[4] = {W.tiles, W.map, W.wave_live, W.wave_off};
-      for (void* p : ptrs)
-        if (p) {
-          (void)hipFree(p);
-          for (auto& a : S->allocs) if (a == p) a = nullptr;
-        }
-      W = loikb_solver_impl::Set{};
-    }
+    for (Chunk& C : S->chunks)
+      for (int k = 0; k < 3; ++k) free_set(C.set[k], k != 0);
+    free_set(S->home, true);
     S->have_problem = false;
   }
   S->L = L;
-  int rc = alloc_set(S, 0, (S->B + WAVE - 1) / WAVE);
+  int rc = alloc_set(S, S->home, (S->B + WAVE - 1) / WAVE);
   if (rc) return rc;
+  // chunk views of the home set (their work sets are allocated on first use)
+  for (Chunk& C : S->chunks) {
+    loikb_solver_impl::Set& V = C.set[0];
+    V.tiles = S->home.tiles + (size_t)C.first_tile * tile_bytes(S);
+    V.ntiles = (C.B + WAVE - 1) / WAVE;
+    void* tmp = nullptr;
+    if ((rc = alloc_dev(S, &tmp, sizeof(int) * ((size_t)V.ntiles + 1)))) return rc;
+    V.wave_live = (int*)tmp;
+    if ((rc = alloc_dev(S, &tmp, sizeof(int) * ((size_t)V.ntiles + 1)))) return rc;
+    V.wave_off = (int*)tmp;
+  }
   // fresh tiles: the reference ctor state is all-zero data (loik-loid-data-optimized.hxx:40-86) + ResetSolver
   return reset_home(S, RS_SOLVER | RS_HCACHE);
 }
@@ -674,37 +712,37 @@ int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, 
 // move the live instances of set `src` (n_src slots) to the first slots of set `dst`; finished ones go home.
 // dst < 0: end of the solve, everything still in a work set goes home.
 template <typename T>
-int compact(loikb_solver_impl* S, int src, int dst, int n_src, int* n_dst_out)
+int compact(loikb_solver_impl* S, Chunk* C, int src, int dst, int n_src, int* n_dst_out)
 {
-  loikb_solver_impl::Set& A = S->set[src];
+  loikb_solver_impl::Set& A = C->set[src];
   const int nw = (n_src + WAVE - 1) / WAVE;
   int rc;
-  if (dst >= 0 && (rc = alloc_set(S, dst, S->set[0].ntiles))) return rc;
+  if (dst >= 0 && (rc = alloc_set(S, C->set[dst], C->set[0].ntiles, C->stream, true))) return rc;
   // exclusive scan of the per-wavefront live counts on the host (nw <= B/64 ints)
-  S->h_wave.resize(2 * (size_t)nw + 2);
-  int* cnt = S->h_wave.data();
+  C->h_wave.resize(2 * (size_t)nw + 2);
+  int* cnt = C->h_wave.data();
   int* off = cnt + nw + 1;
   int total = 0;
   if (dst >= 0) {
-    HIPCHK(hipMemcpyAsync(cnt, A.wave_live, sizeof(int) * nw, hipMemcpyDeviceToHost, S->stream));
-    HIPCHK(hipStreamSynchronize(S->stream));
+    HIPCHK(hipMemcpyAsync(cnt, A.wave_live, sizeof(int) * nw, hipMemcpyDeviceToHost, C->stream));
+    HIPCHK(hipStreamSynchronize(C->stream));
     for (int w = 0; w < nw; ++w) { off[w] = total; total += cnt[w]; }
-    HIPCHK(hipMemcpyAsync(A.wave_off, off, sizeof(int) * nw, hipMemcpyHostToDevice, S->stream));
+    HIPCHK(hipMemcpyAsync(A.wave_off, off, sizeof(int) * nw, hipMemcpyHostToDevice, C->stream));
   }
   MovePlan M{};
   M.src = A.tiles;
-  M.dst_live = dst >= 0 ? S->set[dst].tiles : nullptr;
-  M.dst_home = src == 0 ? nullptr : S->set[0].tiles;
+  M.dst_live = dst >= 0 ? C->set[dst].tiles : nullptr;
+  M.dst_home = src == 0 ? nullptr : C->set[0].tiles;
   M.L = S->L;
   M.n_src = n_src;
   M.move_bounds = !S->bnd_shared;
   M.map_src = src == 0 ? nullptr : A.map;
-  M.map_dst = dst >= 0 ? S->set[dst].map : nullptr;
+  M.map_dst = dst >= 0 ? C->set[dst].map : nullptr;
   M.wave_off = A.wave_off;
   M.force_home = dst < 0;
-  hipLaunchKernelGGL(k_move<T>, dim3(nw), dim3(WAVE), 0, S->stream, M);
+  hipLaunchKernelGGL(k_move<T>, dim3(nw), dim3(WAVE), 0, C->stream, M);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(S->stream));  // h_wave is reused
+  HIPCHK(hipStreamSynchronize(C->stream));  // h_wave is reused
   if (n_dst_out) *n_dst_out = total;
   return LOIKB_OK;
 }
@@ -712,23 +750,23 @@ int compact(loikb_solver_impl* S, int src, int dst, int n_src, int* n_dst_out)
 // finish the remaining live instances of set `cur` (n_cur slots, n_live of them live) with the cooperative tail
 // kernel (a lane group per instance, one joint per lane)
 template <typename T>
-int run_tail(loikb_solver_impl* S, Params<T>& P, int cur, int n_cur, int n_live, double* ms_out,
+int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, int n_live, double* ms_out,
              unsigned long long* iters_out)
 {
-  loikb_solver_impl::Set& A = S->set[cur];
+  loikb_solver_impl::Set& A = C->set[cur];
   const int nw = (n_cur + WAVE - 1) / WAVE;
-  S->h_wave.resize(2 * (size_t)nw + 2);
-  int* cnt = S->h_wave.data();
+  C->h_wave.resize(2 * (size_t)nw + 2);
+  int* cnt = C->h_wave.data();
   int* off = cnt + nw + 1;
-  HIPCHK(hipMemcpyAsync(cnt, A.wave_live, sizeof(int) * nw, hipMemcpyDeviceToHost, S->stream));
-  HIPCHK(hipStreamSynchronize(S->stream));
+  HIPCHK(hipMemcpyAsync(cnt, A.wave_live, sizeof(int) * nw, hipMemcpyDeviceToHost, C->stream));
+  HIPCHK(hipStreamSynchronize(C->stream));
   int total = 0;
   for (int w = 0; w < nw; ++w) { off[w] = total; total += cnt[w]; }
   if (total != n_live) { g_last_error = "tail: live count mismatch"; return LOIKB_ERR_STATE; }
-  HIPCHK(hipMemcpyAsync(A.wave_off, off, sizeof(int) * nw, hipMemcpyHostToDevice, S->stream));
-  hipLaunchKernelGGL(k_list_live<T>, dim3(nw), dim3(WAVE), 0, S->stream, A.tiles, S->L, n_cur, A.wave_off, S->d_slots[0]);
+  HIPCHK(hipMemcpyAsync(A.wave_off, off, sizeof(int) * nw, hipMemcpyHostToDevice, C->stream));
+  hipLaunchKernelGGL(k_list_live<T>, dim3(nw), dim3(WAVE), 0, C->stream, A.tiles, S->L, n_cur, A.wave_off, C->d_slots[0]);
   HIPCHK(hipGetLastError());
-  Bufs<T> Bf = make_bufs<T>(S, cur);
+  Bufs<T> Bf = make_bufs<T>(S, C, cur);
   P.B = n_cur;
   int G = 8;  // lanes per instance: smallest power of two >= nb
   while (G < S->nb) G <<= 1;
@@ -742,7 +780,7 @@ int run_tail(loikb_solver_impl* S, Params<T>& P, int cur, int n_cur, int n_live,
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, S->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
   }
-  const int resident = ncu * 4 * ipw;
+  const int resident = std::max(ipw, (int)(ncu * 4 * ipw * ((double)C->B / (double)S->B)));
   int round_iters = 64;
   if (const char* e = getenv("LOIKB_TAIL_ROUND")) round_iters = atoi(e);
   int n = n_live, li = 0;
@@ -752,36 +790,36 @@ int run_tail(loikb_solver_impl* S, Params<T>& P, int cur, int n_cur, int n_live,
   while (n > 0) {
     P.max_launch_iters = n > resident ? round_iters : S->opt.max_iter + 1;
     const dim3 grid((unsigned)((n + ipw - 1) / ipw));
-    HIPCHK(hipMemsetAsync(S->d_counters, 0, 8 * sizeof(unsigned int), S->stream));
-    HIPCHK(hipEventRecord(S->ev_k0, S->stream));
+    HIPCHK(hipMemsetAsync(C->d_counters, 0, 8 * sizeof(unsigned int), C->stream));
+    HIPCHK(hipEventRecord(C->ev_k0, C->stream));
     if (S->href_diag)
-      hipLaunchKernelGGL((k_tail<T, true>), grid, dim3(WAVE), lds, S->stream, P, Bf, (const JointDesc*)S->d_jd,
+      hipLaunchKernelGGL((k_tail<T, true>), grid, dim3(WAVE), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                          (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
-                         (const int*)S->d_slots[li], n, G, S->d_slots[li ^ 1]);
+                         (const int*)C->d_slots[li], n, G, C->d_slots[li ^ 1]);
     else
-      hipLaunchKernelGGL((k_tail<T, false>), grid, dim3(WAVE), lds, S->stream, P, Bf, (const JointDesc*)S->d_jd,
+      hipLaunchKernelGGL((k_tail<T, false>), grid, dim3(WAVE), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                          (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
-                         (const int*)S->d_slots[li], n, G, S->d_slots[li ^ 1]);
+                         (const int*)C->d_slots[li], n, G, C->d_slots[li ^ 1]);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(S->ev_k1, S->stream));
-    HIPCHK(hipMemcpyAsync(S->h_counters, S->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
-    HIPCHK(hipStreamSynchronize(S->stream));
+    HIPCHK(hipEventRecord(C->ev_k1, C->stream));
+    HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+    HIPCHK(hipStreamSynchronize(C->stream));
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, S->ev_k0, S->ev_k1));
+    HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));
     total_ms += ms;
-    iters += S->h_counters[1];
+    iters += C->h_counters[1];
     if (trace)
       fprintf(stderr, "[loikb] tail launch: %6d instances, budget %4d  %8.3f ms  inst-iters %9u (%.1f M/s)  live after %6u"
                       "  wave-iters %7u H-rebuild %3.0f%%\n",
-              n, P.max_launch_iters, ms, S->h_counters[1], S->h_counters[1] / ms / 1e3, S->h_counters[0],
-              S->h_counters[5], 100.0 * S->h_counters[6] / (S->h_counters[5] ? S->h_counters[5] : 1));
-    S->stats.launches++;
-    S->stats.tail_launches++;
-    if ((int)S->h_counters[0] >= n && P.max_launch_iters > S->opt.max_iter) {
+              n, P.max_launch_iters, ms, C->h_counters[1], C->h_counters[1] / ms / 1e3, C->h_counters[0],
+              C->h_counters[5], 100.0 * C->h_counters[6] / (C->h_counters[5] ? C->h_counters[5] : 1));
+    C->stats.launches++;
+    C->stats.tail_launches++;
+    if ((int)C->h_counters[0] >= n && P.max_launch_iters > S->opt.max_iter) {
       g_last_error = "tail: no progress";
       return LOIKB_ERR_STATE;
     }
-    n = (int)S->h_counters[0];
+    n = (int)C->h_counters[0];
     li ^= 1;
   }
   *ms_out = total_ms;
@@ -789,14 +827,13 @@ int run_tail(loikb_solver_impl* S, Params<T>& P, int cur, int n_cur, int n_live,
   return LOIKB_OK;
 }
 
+// one chunk of the batch, start to finish, on the chunk's stream (called from the chunk's host thread)
 template <typename T>
-int run_main_loop_t(loikb_solver_impl* S)
+int run_chunk(loikb_solver_impl* S, Chunk* C)
 {
   Params<T> P = make_params<T>(S);
-  S->stats = loikb_stats{};
-  S->stats.bytes_per_instance_iteration = (double)sizeof(T) * (203.0 * S->nb + 108.0 * S->nc);
+  C->stats = loikb_stats{};
   double kernel_ms = 0.0;
-  HIPCHK(hipEventRecord(S->ev_t0, S->stream));
   // main-loop bound: at most max_iter-1 iterations, tail solve may reach max_iter (hpp:377, :276)
   const int max_total = S->opt.max_iter + 1;
   const bool can_compact = !(S->opt.flags & LOIKB_OPT_NO_COMPACTION) && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS);
@@ -808,7 +845,9 @@ int run_main_loop_t(loikb_solver_impl* S)
   if (const char* e = getenv("LOIKB_COMPACT_RATIO")) compact_ratio = atof(e);
   // cooperative tail kernel (one wavefront per instance) once few instances are left
   const bool use_tail = can_compact && S->nb <= WAVE && S->opt.tail_max_instances >= 0;
-  const int tail_max = S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : 6144;
+  // (thresholds are stated for the whole batch: a chunk applies its share)
+  const double share = (double)C->B / (double)S->B;
+  const int tail_max = std::max(1, (int)((S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : 6144) * share));
   const bool trace = getenv("LOIKB_TRACE") != nullptr;
   // a team of wavefronts per tile walks independent chains of the tree concurrently: a sweep costs the tree's
   // critical path instead of nb joint visits, and four wavefronts keep four times the loads of a tile in flight.
@@ -836,7 +875,7 @@ int run_main_loop_t(loikb_solver_impl* S)
       HIPCHK(hipFuncSetAttribute((const void*)k_solve<T, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     }
   }
-  int cur = 0, n_cur = S->B;
+  int cur = 0, n_cur = C->B;
   int done_iters = 0;
   unsigned long long inst_iters = 0;
   unsigned int n_live = 0;
@@ -847,51 +886,51 @@ int run_main_loop_t(loikb_solver_impl* S)
     if (launch_iters > max_total - done_iters) launch_iters = max_total - done_iters;
     P.B = n_cur;
     P.max_launch_iters = launch_iters;
-    Bufs<T> Bf = make_bufs<T>(S, cur);
+    Bufs<T> Bf = make_bufs<T>(S, C, cur);
     const loikb_solver_impl::TeamSched& sc = S->sched[(team_ok && n_cur <= team_max) ? 1 : 0];
-    S->stats.team = sc.nw;
+    C->stats.team = sc.nw;
     const int edge_ent = edge_entries(sc);
     const Team tm{sc.d_up, sc.d_down, sc.d_rlist, sc.T_up, sc.T_down, edge_ent};
     const size_t lds = lds_bytes(sc);
     const dim3 grid((unsigned)((n_cur + WAVE - 1) / WAVE)), block(WAVE * sc.nw);
-    HIPCHK(hipMemsetAsync(S->d_counters, 0, 8 * sizeof(unsigned int), S->stream));
-    HIPCHK(hipEventRecord(S->ev_k0, S->stream));
+    HIPCHK(hipMemsetAsync(C->d_counters, 0, 8 * sizeof(unsigned int), C->stream));
+    HIPCHK(hipEventRecord(C->ev_k0, C->stream));
     if (sc.nw > 1) {
-      if (S->href_diag) hipLaunchKernelGGL((k_solve<T, true, true>), grid, block, lds, S->stream, P, Bf, tm.up, tm.down, tm.rlist, tm.T_up, tm.T_down, tm.edge_ent);
-      else hipLaunchKernelGGL((k_solve<T, false, true>), grid, block, lds, S->stream, P, Bf, tm.up, tm.down, tm.rlist, tm.T_up, tm.T_down, tm.edge_ent);
+      if (S->href_diag) hipLaunchKernelGGL((k_solve<T, true, true>), grid, block, lds, C->stream, P, Bf, tm.up, tm.down, tm.rlist, tm.T_up, tm.T_down, tm.edge_ent);
+      else hipLaunchKernelGGL((k_solve<T, false, true>), grid, block, lds, C->stream, P, Bf, tm.up, tm.down, tm.rlist, tm.T_up, tm.T_down, tm.edge_ent);
     } else {
-      if (S->href_diag) hipLaunchKernelGGL((k_solve<T, true, false>), grid, block, lds, S->stream, P, Bf, tm.up, tm.down, tm.rlist, tm.T_up, tm.T_down, tm.edge_ent);
-      else hipLaunchKernelGGL((k_solve<T, false, false>), grid, block, lds, S->stream, P, Bf, tm.up, tm.down, tm.rlist, tm.T_up, tm.T_down, tm.edge_ent);
+      if (S->href_diag) hipLaunchKernelGGL((k_solve<T, true, false>), grid, block, lds, C->stream, P, Bf, tm.up, tm.down, tm.rlist, tm.T_up, tm.T_down, tm.edge_ent);
+      else hipLaunchKernelGGL((k_solve<T, false, false>), grid, block, lds, C->stream, P, Bf, tm.up, tm.down, tm.rlist, tm.T_up, tm.T_down, tm.edge_ent);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(S->ev_k1, S->stream));
-    HIPCHK(hipMemcpyAsync(S->h_counters, S->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
-    HIPCHK(hipStreamSynchronize(S->stream));
+    HIPCHK(hipEventRecord(C->ev_k1, C->stream));
+    HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+    HIPCHK(hipStreamSynchronize(C->stream));
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, S->ev_k0, S->ev_k1));
+    HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));
     kernel_ms += ms;
-    S->stats.launches++;
-    inst_iters += S->h_counters[1];
-    n_live = S->h_counters[0];
+    C->stats.launches++;
+    inst_iters += C->h_counters[1];
+    n_live = C->h_counters[0];
     done_iters += launch_iters;
     if (trace)
       fprintf(stderr, "[loikb] launch %3d: set %d slots %7d iters %4d..%4d  %8.3f ms  inst-iters %9u (%.1f M/s)  live after %7u"
                       "  tile-iters %6u H-rebuild %3.0f%% fused %3.0f%%\n",
-              S->stats.launches, cur, n_cur, done_iters - launch_iters + 1, done_iters, ms, S->h_counters[1],
-              S->h_counters[1] / ms / 1e3, n_live, S->h_counters[2],
-              100.0 * S->h_counters[3] / (S->h_counters[2] ? S->h_counters[2] : 1),
-              100.0 * S->h_counters[4] / (S->h_counters[2] ? S->h_counters[2] : 1));
+              C->stats.launches, cur, n_cur, done_iters - launch_iters + 1, done_iters, ms, C->h_counters[1],
+              C->h_counters[1] / ms / 1e3, n_live, C->h_counters[2],
+              100.0 * C->h_counters[3] / (C->h_counters[2] ? C->h_counters[2] : 1),
+              100.0 * C->h_counters[4] / (C->h_counters[2] ? C->h_counters[2] : 1));
     if (n_live == 0 || done_iters >= max_total) break;
     if (use_tail && (int)n_live <= tail_max) {
       double tms = 0.0;
       unsigned long long tit = 0;
-      int rc = run_tail<T>(S, P, cur, n_cur, (int)n_live, &tms, &tit);
+      int rc = run_tail<T>(S, C, P, cur, n_cur, (int)n_live, &tms, &tit);
       if (rc) return rc;
       kernel_ms += tms;
       if (trace) fprintf(stderr, "[loikb] tail kernel: %u instances  %8.3f ms  inst-iters %9llu\n", n_live, tms, tit);
-      S->stats.tail_ms = tms;
-      S->stats.tail_instances = (int)n_live;
-      S->stats.tail_instance_iterations = tit;
+      C->stats.tail_ms = tms;
+      C->stats.tail_instances = (int)n_live;
+      C->stats.tail_instance_iterations = tit;
       inst_iters += tit;
       n_live = 0;
       break;
@@ -899,27 +938,73 @@ int run_main_loop_t(loikb_solver_impl* S)
     if (may_compact_later && (double)n_live <= compact_ratio * n_cur) {
       const int dst = cur == 1 ? 2 : 1;
       int n_new = 0;
-      int rc = compact<T>(S, cur, dst, n_cur, &n_new);
+      int rc = compact<T>(S, C, cur, dst, n_cur, &n_new);
       if (rc) return rc;
       cur = dst;
       n_cur = n_new;
-      S->stats.compactions++;
+      C->stats.compactions++;
     }
   }
   if (cur != 0) {
-    int rc = compact<T>(S, cur, -1, n_cur, nullptr);  // everything that is still in a work set goes home
+    int rc = compact<T>(S, C, cur, -1, n_cur, nullptr);  // everything that is still in a work set goes home
     if (rc) return rc;
+  }
+  HIPCHK(hipStreamSynchronize(C->stream));
+  C->stats.instance_iterations = inst_iters;
+  C->stats.n_unfinished = (int)n_live;
+  C->stats.kernel_ms = kernel_ms;
+  return LOIKB_OK;
+}
+
+// fork: one host thread + stream per chunk; join: sum the per-chunk statistics
+template <typename T>
+int run_main_loop_t(loikb_solver_impl* S)
+{
+  S->stats = loikb_stats{};
+  S->stats.bytes_per_instance_iteration = (double)sizeof(T) * (203.0 * S->nb + 108.0 * S->nc);
+  HIPCHK(hipEventRecord(S->ev_t0, S->stream));
+  const int nchunks = (int)S->chunks.size();
+  if (nchunks == 1) {
+    Chunk* C = &S->chunks[0];
+    C->stream = S->stream;
+    int rc = run_chunk<T>(S, C);
+    if (rc) return rc;
+  } else {
+    // the chunk streams start after everything queued on the caller's stream (SolveInit uploads, resets)
+    HIPCHK(hipEventRecord(S->ev_fork, S->stream));
+    for (Chunk& C : S->chunks) HIPCHK(hipStreamWaitEvent(C.stream, S->ev_fork, 0));
+    std::vector<std::thread> th;
+    for (Chunk& C : S->chunks)
+      th.emplace_back([S, &C]() {
+        if (hipSetDevice(S->device) != hipSuccess) { C.rc = LOIKB_ERR_HIP; C.err = "hipSetDevice failed in a chunk thread"; return; }
+        C.rc = run_chunk<T>(S, &C);
+        if (C.rc) C.err = g_last_error;
+      });
+    for (auto& t : th) t.join();
+    for (Chunk& C : S->chunks)
+      if (C.rc) { g_last_error = C.err; return C.rc; }
   }
   HIPCHK(hipEventRecord(S->ev_t1, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
   float tms = 0.f;
   HIPCHK(hipEventElapsedTime(&tms, S->ev_t0, S->ev_t1));
-  S->stats.instance_iterations = inst_iters;
-  S->stats.n_unfinished = (int)n_live;
-  S->stats.kernel_ms = kernel_ms;
+  for (const Chunk& C : S->chunks) {
+    S->stats.instance_iterations += C.stats.instance_iterations;
+    S->stats.launches += C.stats.launches;
+    S->stats.n_unfinished += C.stats.n_unfinished;
+    S->stats.compactions += C.stats.compactions;
+    S->stats.tail_instances += C.stats.tail_instances;
+    S->stats.tail_ms += C.stats.tail_ms;
+    S->stats.kernel_ms += C.stats.kernel_ms;
+    S->stats.tail_instance_iterations += C.stats.tail_instance_iterations;
+    S->stats.tail_launches += C.stats.tail_launches;
+    S->stats.team = C.stats.team;
+  }
+  S->stats.chunks = nchunks;
   S->stats.total_ms = tms;
   return LOIKB_OK;
 }
+
 
 int run_main_loop(loikb_solver_impl* S)
 {
@@ -1039,19 +1124,46 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
 #define TRY(x) do { int _rc = (x); if (_rc) return fail(_rc); } while (0)
 #define HIPTRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { g_last_error = std::string(#x) + ": " + hipGetErrorString(_e); return fail(LOIKB_ERR_HIP); } } while (0)
   HIPTRY(hipSetDevice(S->device));
-  HIPTRY(hipEventCreate(&S->ev_k0));
-  HIPTRY(hipEventCreate(&S->ev_k1));
   HIPTRY(hipEventCreate(&S->ev_t0));
   HIPTRY(hipEventCreate(&S->ev_t1));
-  HIPTRY(hipHostMalloc((void**)&S->h_counters, 8 * sizeof(unsigned int)));
+  HIPTRY(hipEventCreate(&S->ev_fork));
   void* tmp = nullptr;
+  {
+    // chunks: contiguous ranges of tiles, each large enough to fill the machine in its bulk phase
+    const int ntiles = (S->B + WAVE - 1) / WAVE;
+    // Measured on MI355X (Talos-32, B = 65536): 1 chunk 53.1 ms/step, 2 chunks 51.5, 4 chunks 82, 8 chunks 105.  Both
+    // kernels need a whole SIMD per wavefront (register budget) and the solve kernel a whole CU per workgroup, so
+    // concurrent chunks mostly queue behind each other, and tail-kernel wavefronts scattered over the CUs keep solve
+    // workgroups from being placed.  One chunk by default (clean per-kernel timings); LOIKB_CHUNKS overrides.
+    int nchunks = 1;
+    if (const char* e = getenv("LOIKB_CHUNKS")) nchunks = atoi(e);
+    if (nchunks < 1) nchunks = 1;
+    if (nchunks > ntiles) nchunks = ntiles;
+    const int per = (ntiles + nchunks - 1) / nchunks;
+    S->chunks.clear();
+    for (int t0 = 0; t0 < ntiles; t0 += per) {
+      Chunk C;
+      C.first_tile = t0;
+      C.B = std::min(S->B - t0 * WAVE, per * WAVE);
+      S->chunks.push_back(C);
+    }
+    for (Chunk& C : S->chunks) {
+      HIPTRY(hipEventCreate(&C.ev_k0));
+      HIPTRY(hipEventCreate(&C.ev_k1));
+      HIPTRY(hipHostMalloc((void**)&C.h_counters, 8 * sizeof(unsigned int)));
+      TRY(alloc_dev(S, &tmp, 8 * sizeof(unsigned int))); C.d_counters = (unsigned int*)tmp;
+      for (int k = 0; k < 2; ++k) { TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)(C.B + WAVE))); C.d_slots[k] = (int*)tmp; }
+      if (S->chunks.size() > 1) {
+        HIPTRY(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
+        C.own_stream = true;
+      }
+    }
+  }
   TRY(alloc_dev(S, &tmp, sizeof(JointDesc) * S->nj)); S->d_jd = (JointDesc*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * S->nj)); S->d_idx_q = (int*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * ROWMAP_CAP)); S->d_rowmap = (int*)tmp;
-  TRY(alloc_dev(S, &tmp, 8 * sizeof(unsigned int))); S->d_counters = (unsigned int*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(TailTopo) * S->nj)); S->d_topo = (TailTopo*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * (S->child_list.size() + 1))); S->d_child_list = (int*)tmp;
-  for (int k = 0; k < 2; ++k) { TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)(S->B + WAVE))); S->d_slots[k] = (int*)tmp; }
   HIPTRY(hipMemcpyAsync(S->d_topo, S->topo.data(), sizeof(TailTopo) * S->nj, hipMemcpyHostToDevice, S->stream));
   if (!S->child_list.empty())
     HIPTRY(hipMemcpyAsync(S->d_child_list, S->child_list.data(), sizeof(int) * S->child_list.size(),
@@ -1079,9 +1191,13 @@ int loikb_destroy(loikb_solver* S)
   (void)hipSetDevice(S->device);
   for (void* a : S->allocs) if (a) (void)hipFree(a);
   if (S->d_stage) (void)hipFree(S->d_stage);
-  if (S->h_counters) (void)hipHostFree(S->h_counters);
-  if (S->ev_k0) (void)hipEventDestroy(S->ev_k0);
-  if (S->ev_k1) (void)hipEventDestroy(S->ev_k1);
+  for (Chunk& C : S->chunks) {
+    if (C.h_counters) (void)hipHostFree(C.h_counters);
+    if (C.ev_k0) (void)hipEventDestroy(C.ev_k0);
+    if (C.ev_k1) (void)hipEventDestroy(C.ev_k1);
+    if (C.own_stream && C.stream) (void)hipStreamDestroy(C.stream);
+  }
+  if (S->ev_fork) (void)hipEventDestroy(S->ev_fork);
   if (S->ev_t0) (void)hipEventDestroy(S->ev_t0);
   if (S->ev_t1) (void)hipEventDestroy(S->ev_t1);
   delete S;
@@ -1247,15 +1363,15 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
     dst = (double*)S->d_stage;
   }
   if (field == LOIKB_F_LIMI) {
-    if (S->f32) hipLaunchKernelGGL(k_limi<float>, grid1(S->B), dim3(256), 0, S->stream, S->set[0].tiles, L, S->d_jd, S->B, dst);
-    else hipLaunchKernelGGL(k_limi<double>, grid1(S->B), dim3(256), 0, S->stream, S->set[0].tiles, L, S->d_jd, S->B, dst);
+    if (S->f32) hipLaunchKernelGGL(k_limi<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->B, dst);
+    else hipLaunchKernelGGL(k_limi<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->B, dst);
   } else {
     if ((rc = set_rowmap(S, rm))) return rc;
     if (S->f32)
-      hipLaunchKernelGGL(k_download_rows<float>, grid1(S->B), dim3(256), 0, S->stream, S->set[0].tiles, L, S->d_rowmap, n,
+      hipLaunchKernelGGL(k_download_rows<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_rowmap, n,
                          S->B, dst, (int)is_int, mask, h_slot);
     else
-      hipLaunchKernelGGL(k_download_rows<double>, grid1(S->B), dim3(256), 0, S->stream, S->set[0].tiles, L, S->d_rowmap, n,
+      hipLaunchKernelGGL(k_download_rows<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_rowmap, n,
                          S->B, dst, (int)is_int, mask, h_slot);
   }
   HIPCHK(hipGetLastError());

@@ -32,6 +32,15 @@ constexpr int HS = 22;  // scalars per lane and mu-slot in the H store: H[21], D
 constexpr int CD = 82;  // per-constraint LDS block: A[36] AtA[21] pad b[6] Atb[6] y[6] aty[6]
 enum : int { CD_A = 0, CD_ATA = 36, CD_B = 58, CD_ATB = 64, CD_Y = 70, CD_ATY = 76 };
 
+// The kernel runs one wavefront per workgroup: LDS operations of a wavefront execute in program order, so an exchange
+// between lanes needs no hardware barrier -- only a fence that keeps the compiler from reordering the LDS accesses.
+__device__ __forceinline__ void tail_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // reductions over an aligned group of G lanes (G a power of two <= 64)
 template <typename T>
 __device__ __forceinline__ T group_max(T x, int G)
@@ -160,7 +169,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   T dyqp = ld_scal<T>(srec, SC_DELTA_Y_QP), atdy = ld_scal<T>(srec, SC_AT_DELTA_Y_QP);
   T ubp = ld_scal<T>(srec, SC_UB_DY_PLUS), lbm = ld_scal<T>(srec, SC_LB_DY_MINUS);
   int c1 = (int)ld_scal<T>(srec, SC_COND1), c2 = (int)ld_scal<T>(srec, SC_COND2);
-  __syncthreads();
+  tail_sync();
 
   bool done = (status & ST_DONE) != 0;
   if (!done && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { done = true; status |= ST_DONE; }
@@ -269,7 +278,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
           for (int k = 0; k < 6; ++k) x[21 + k] = pc[k];
         }
       }
-      __syncthreads();
+      tail_sync();
     }
     if (need_h) mu_h = mu;
 
@@ -301,7 +310,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
         for (int k = 0; k < 6; ++k) xch[lane * XS + 21 + k] = vi[k];
       }
-      __syncthreads();
+      tail_sync();
     }
     T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_dyis = T(0),
       l_av = T(0), l_prt = T(0), l_prs = T(0), l_up = T(0), l_lm = T(0);
@@ -379,7 +388,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
       for (int k = 0; k < 6; ++k) xch[lane * XS + k] = pc[k];
     }
-    __syncthreads();
+    tail_sync();
     if (act && isj) {
       T gi[6];
       if (d.cslot >= 0) {
@@ -417,7 +426,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       l_dstf = tabs(si - s);
       s = si;
     }
-    __syncthreads();
+    tail_sync();
 
     // ================= lane-group reductions of the running norms, then the scalar epilogue ======================
     // Through LDS: every lane deposits its NRED scalars in its exchange row, lane q of a group folds scalar q over the
@@ -429,7 +438,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       row[6] = l_dz; row[7] = l_dfis; row[8] = l_dyis; row[9] = l_dw; row[10] = l_av; row[11] = l_nu;
       row[12] = l_hrefv; row[13] = l_g; row[14] = l_dg; row[15] = l_dstf; row[16] = l_up; row[17] = l_lm;
     }
-    __syncthreads();
+    tail_sync();
     for (int q = jlane; q < NRED; q += G) {
       const T* col = xch + gbase * XS + q;
       T red = T(0);
@@ -440,11 +449,11 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       }
       xch[(gbase + q % G) * XS + (XS - 1) - q / G] = red;
     }
-    __syncthreads();
+    tail_sync();
     T rr[NRED];
 #pragma unroll
     for (int q = 0; q < NRED; ++q) rr[q] = xch[(gbase + q % G) * XS + (XS - 1) - q / G];
-    __syncthreads();
+    tail_sync();
     const T r_prt = rr[0], r_prs = rr[1], r_dualv = rr[2], r_stf = rr[3], r_dvis = rr[4], r_dnu = rr[5], r_dz = rr[6],
             r_dfis = rr[7], r_dyis = rr[8], r_dw = rr[9], r_av = rr[10], r_nu = rr[11], r_hrefv = rr[12], r_g = rr[13],
             r_dg = rr[14], r_dstf = rr[15], r_up = rr[16], r_lm = rr[17];
@@ -513,7 +522,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       for (int k = 0; k < 11; ++k) stp<T>(hrec, SL_H + k, hcur[2 * k], 2 * k + 1 < 21 ? hcur[2 * k + 1] : dinv);
     }
   }
-  __syncthreads();
+  tail_sync();
   if (has_inst) {
     for (int c = 0; c < L.nc; ++c) {
       char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();

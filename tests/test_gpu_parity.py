@@ -465,3 +465,31 @@ def test_tail_kernel_bounded_relaunches(talos, monkeypatch):
     assert same.mean() >= 0.95
     assert np.max(np.abs(many.get("z")[:64] - ref_out["z"])[same]) < 1e-9
     one.close(); many.close()
+
+
+def test_concurrent_chunks_change_nothing(talos, monkeypatch):
+    """the batch split into independent ranges of tiles, each driven by its own host thread and stream
+    (LOIKB_CHUNKS): same per-instance results as the single-stream run, statistics add up"""
+    link = talos.getJointId("arm_left_7_joint")
+    B = 3000
+    wl = feasible_batch(talos, B, link, 808, nu_scale=0.5)
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
+    kw = dict(compact_min_instances=128, max_launch_iters=5, tail_max_instances=900)
+    one = gpu_solve(talos, wl, prm, **kw)
+    monkeypatch.setenv("LOIKB_CHUNKS", "3")
+    three = gpu_solve(talos, wl, prm, **kw)
+    s1, s3 = one.stats(), three.stats()
+    assert s1["chunks"] == 1 and s3["chunks"] == 3
+    assert s1["instance_iterations"] == s3["instance_iterations"] == int(three.get("iter").sum())
+    assert s3["tail_instances"] > 0 and s3["compactions"] >= 3
+    for name in ["iter", "status", "mu"]:
+        assert np.array_equal(one.get(name), three.get(name)), name
+    for name in ["z", "nu", "w", "vis", "fis", "g", "yis", "Aty", "Stf_plus_w", "primal_residual", "dual_residual"]:
+        a, b = one.get(name), three.get(name)
+        assert np.max(np.abs(a - b) / (1.0 + np.abs(b))) < 1e-10, name
+    # and a second solve on the same handles (work sets and streams are re-used)
+    for sol in (one, three):
+        sol.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    assert np.array_equal(one.get("iter"), three.get("iter"))
+    assert np.max(np.abs(one.get("z") - three.get("z"))) < 1e-10
+    one.close(); three.close()
