@@ -186,6 +186,9 @@ typedef struct loikb_stats {
   int chunks;                             /* independent ranges of the batch solved concurrently (own stream each);
                                              kernel_ms / tail_ms sum the launches of all chunks, so with chunks > 1
                                              they can exceed total_ms                                            */
+  double solve_busy_ms;                   /* time during which >= 1 solve-kernel launch was executing (HIP events;
+                                             equals kernel_ms - tail_ms when chunks == 1)                        */
+  double tail_busy_ms;                    /* same for the tail kernel                                            */
 } loikb_stats;
 int loikb_get_stats(loikb_solver *s, loikb_stats *out);
 

@@ -44,7 +44,8 @@ class Stats(C.Structure):
     _fields_ = [("instance_iterations", C.c_ulonglong), ("launches", C.c_int), ("n_unfinished", C.c_int),
                 ("compactions", C.c_int), ("tail_instances", C.c_int), ("tail_ms", C.c_double),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("bytes_per_instance_iteration", C.c_double),
-                ("tail_instance_iterations", C.c_ulonglong), ("tail_launches", C.c_int), ("team", C.c_int), ("chunks", C.c_int)]
+                ("tail_instance_iterations", C.c_ulonglong), ("tail_launches", C.c_int), ("team", C.c_int), ("chunks", C.c_int),
+                ("solve_busy_ms", C.c_double), ("tail_busy_ms", C.c_double)]
 
 
 # enums of loik_amd.h

@@ -114,6 +114,8 @@ struct loikb_solver_impl {
     loikb_stats stats{};
     int rc = 0;
     std::string err;
+    // [start, end) of every solve / tail launch of the last call, ms since the fork event (HIP events)
+    std::vector<std::pair<float, float>> solve_iv, tail_iv;
   };
   std::vector<Chunk> chunks;
   hipEvent_t ev_fork = nullptr;
@@ -771,7 +773,14 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
   int G = 8;  // lanes per instance: smallest power of two >= nb
   while (G < S->nb) G <<= 1;
   const int ipw = WAVE / G;
-  const size_t lds = ((size_t)WAVE * XS + 2 * (size_t)WAVE * HS + (size_t)ipw * S->nc * CD) * sizeof(T);
+  int tw = TAIL_WAVES;  // wavefronts per workgroup
+  while (tw > 1 && tw * tail_lds_bytes<T>(S->nc, G) > 160 * 1024) --tw;
+  const size_t lds = tw * tail_lds_bytes<T>(S->nc, G);
+  if (lds > 160 * 1024) { g_last_error = "tail kernel: constraint data exceeds the LDS of a CU"; return LOIKB_ERR_ARG; }
+  if (lds > 64 * 1024) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_tail<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_tail<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   // The kernel keeps one wavefront per SIMD resident (register budget): `resident` instances run concurrently.
   // With more live instances than that, bounded launches keep every wavefront busy (instances finish at very
   // different iterations; the survivors are re-listed and re-paired) -- once they all fit, one launch runs them out.
@@ -789,23 +798,25 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
   const bool trace = getenv("LOIKB_TRACE") != nullptr;
   while (n > 0) {
     P.max_launch_iters = n > resident ? round_iters : S->opt.max_iter + 1;
-    const dim3 grid((unsigned)((n + ipw - 1) / ipw));
+    const dim3 grid((unsigned)((n + ipw * tw - 1) / (ipw * tw)));
     HIPCHK(hipMemsetAsync(C->d_counters, 0, 8 * sizeof(unsigned int), C->stream));
     HIPCHK(hipEventRecord(C->ev_k0, C->stream));
     if (S->href_diag)
-      hipLaunchKernelGGL((k_tail<T, true>), grid, dim3(WAVE), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+      hipLaunchKernelGGL((k_tail<T, true>), grid, dim3(WAVE * tw), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                          (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
                          (const int*)C->d_slots[li], n, G, C->d_slots[li ^ 1]);
     else
-      hipLaunchKernelGGL((k_tail<T, false>), grid, dim3(WAVE), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+      hipLaunchKernelGGL((k_tail<T, false>), grid, dim3(WAVE * tw), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                          (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
                          (const int*)C->d_slots[li], n, G, C->d_slots[li ^ 1]);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(C->ev_k1, C->stream));
     HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
     HIPCHK(hipStreamSynchronize(C->stream));
-    float ms = 0.f;
+    float ms = 0.f, t0 = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));
+    HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0));
+    C->tail_iv.emplace_back(t0, t0 + ms);
     total_ms += ms;
     iters += C->h_counters[1];
     if (trace)
@@ -833,6 +844,8 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
 {
   Params<T> P = make_params<T>(S);
   C->stats = loikb_stats{};
+  C->solve_iv.clear();
+  C->tail_iv.clear();
   double kernel_ms = 0.0;
   // main-loop bound: at most max_iter-1 iterations, tail solve may reach max_iter (hpp:377, :276)
   const int max_total = S->opt.max_iter + 1;
@@ -906,8 +919,10 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
     HIPCHK(hipEventRecord(C->ev_k1, C->stream));
     HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
     HIPCHK(hipStreamSynchronize(C->stream));
-    float ms = 0.f;
+    float ms = 0.f, t0 = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));
+    HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0));
+    C->solve_iv.emplace_back(t0, t0 + ms);
     kernel_ms += ms;
     C->stats.launches++;
     inst_iters += C->h_counters[1];
@@ -973,6 +988,8 @@ int run_main_loop_t(loikb_solver_impl* S)
     // the chunk streams start after everything queued on the caller's stream (SolveInit uploads, resets)
     HIPCHK(hipEventRecord(S->ev_fork, S->stream));
     for (Chunk& C : S->chunks) HIPCHK(hipStreamWaitEvent(C.stream, S->ev_fork, 0));
+    // (Starting chunk k+1 only when chunk k reaches its straggler phase was measured too: 61 vs 48 ms/step -- two
+    // bulk phases side by side cost less than a bulk phase squeezed between tail-kernel workgroups.)
     std::vector<std::thread> th;
     for (Chunk& C : S->chunks)
       th.emplace_back([S, &C]() {
@@ -1002,6 +1019,25 @@ int run_main_loop_t(loikb_solver_impl* S)
   }
   S->stats.chunks = nchunks;
   S->stats.total_ms = tms;
+  // time during which at least one launch of a kernel was executing (= the sum of its launch times when chunks == 1)
+  auto busy = [&](bool tail) {
+    std::vector<std::pair<float, float>> iv;
+    for (const Chunk& C : S->chunks) {
+      const auto& v = tail ? C.tail_iv : C.solve_iv;
+      iv.insert(iv.end(), v.begin(), v.end());
+    }
+    std::sort(iv.begin(), iv.end());
+    double tot = 0.0;
+    float lo = 0.f, hi = -1.f;
+    for (const auto& x : iv) {
+      if (hi < lo || x.first > hi) { if (hi >= lo) tot += hi - lo; lo = x.first; hi = x.second; }
+      else if (x.second > hi) hi = x.second;
+    }
+    if (hi >= lo) tot += hi - lo;
+    return tot;
+  };
+  S->stats.solve_busy_ms = busy(false);
+  S->stats.tail_busy_ms = busy(true);
   return LOIKB_OK;
 }
 
@@ -1131,11 +1167,11 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
   {
     // chunks: contiguous ranges of tiles, each large enough to fill the machine in its bulk phase
     const int ntiles = (S->B + WAVE - 1) / WAVE;
-    // Measured on MI355X (Talos-32, B = 65536): 1 chunk 53.1 ms/step, 2 chunks 51.5, 4 chunks 82, 8 chunks 105.  Both
-    // kernels need a whole SIMD per wavefront (register budget) and the solve kernel a whole CU per workgroup, so
-    // concurrent chunks mostly queue behind each other, and tail-kernel wavefronts scattered over the CUs keep solve
-    // workgroups from being placed.  One chunk by default (clean per-kernel timings); LOIKB_CHUNKS overrides.
-    int nchunks = 1;
+    // Measured on MI355X (Talos-32, B = 65536): 1 chunk 52.9 ms/step, 2 chunks 47.9, 3 chunks 48.2, 4 chunks 74.
+    // Both kernels need a whole SIMD per wavefront (register budget) and both claim whole CUs per workgroup, so
+    // chunks mostly time-share the machine; the gain is the straggler phase of one chunk (down to a few hundred
+    // resident wavefronts for ~10 ms) running beside the bulk phase of the other.  More chunks only queue.
+    int nchunks = ntiles >= 512 ? 2 : 1;
     if (const char* e = getenv("LOIKB_CHUNKS")) nchunks = atoi(e);
     if (nchunks < 1) nchunks = 1;
     if (nchunks > ntiles) nchunks = ntiles;

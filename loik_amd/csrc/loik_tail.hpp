@@ -29,6 +29,7 @@ struct TailTopo {
 
 constexpr int XS = 28;  // scalars per lane in the exchange buffer: 21 (H) + 6 (p / v / f) + 1 pad
 constexpr int HS = 22;  // scalars per lane and mu-slot in the H store: H[21], Dinv  (4 wavefronts/CU fit in 160 KiB)
+constexpr int TAIL_WAVES = 4;  // wavefronts per workgroup of the tail kernel (one per SIMD of a CU; fewer if their LDS does not fit)
 constexpr int CD = 82;  // per-constraint LDS block: A[36] AtA[21] pad b[6] Atb[6] y[6] aty[6]
 enum : int { CD_A = 0, CD_ATA = 36, CD_B = 58, CD_ATB = 64, CD_Y = 70, CD_ATY = 76 };
 
@@ -55,27 +56,33 @@ __device__ __forceinline__ T group_sum(T x, int G)
   return x;
 }
 
+// LDS of ONE wavefront of the tail kernel (rounded to 16 B: the next wavefront's slice starts behind it)
 template <typename T>
-__device__ __forceinline__ size_t tail_lds_bytes(int nc, int G)
+__host__ __device__ __forceinline__ size_t tail_lds_bytes(int nc, int G)
 {
-  return ((size_t)WAVE * XS + 2 * (size_t)WAVE * HS + (size_t)(WAVE / G) * nc * CD) * sizeof(T);
+  return ((((size_t)WAVE * XS + 2 * (size_t)WAVE * HS + (size_t)(WAVE / G) * nc * CD) * sizeof(T)) + 15) & ~(size_t)15;
 }
 
 template <typename T, bool HDIAG>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(WAVE * TAIL_WAVES)
 k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
        const int* __restrict__ child_list, int maxdepth, int maxchild, const int* __restrict__ slots, int nslots, int G,
        int* __restrict__ slots_out)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
-  T* xch = reinterpret_cast<T*>(smem_raw);  // [WAVE][XS]      exchange between a joint and its parent / children
+  // TAIL_WAVES independent wavefronts per workgroup (they never talk to each other: the workgroup only makes the
+  // kernel claim whole CUs, so that solve-kernel workgroups of another stream are not locked out of a CU by a
+  // stray tail wavefront); every wavefront has its own slice of the LDS
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const size_t wave_lds = tail_lds_bytes<T>(L.nc, G);
+  T* xch = reinterpret_cast<T*>(smem_raw + wv * wave_lds);  // [WAVE][XS]  exchange between a joint and its parent / children
   T* hst = xch + WAVE * XS;                 // [2][WAVE][HS]   this joint's H (pre-projection) for two values of mu
   T* cd = hst + 2 * WAVE * HS;              // [64/G][nc][CD]  constraint data of every instance of the wavefront
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1);
   const int sub = lane / G, jlane = lane % G, gbase = sub * G;
   const int ipw = WAVE / G;
-  const int idx = blockIdx.x * ipw + sub;
+  const int idx = (blockIdx.x * (int)(blockDim.x >> 6) + wv) * ipw + sub;
   const bool has_inst = idx < nslots;
   const int slot = slots[has_inst ? idx : 0];
   const bool isj = has_inst && jlane < L.nb;
