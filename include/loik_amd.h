@@ -118,6 +118,14 @@ int loikb_solve_full(loikb_solver *s, const double *q, const double *H_ref, cons
 int loikb_solve_tailored(loikb_solver *s, const double *q, int c_id, const double *Ai, const double *bi,
                          int in_flags);
 
+/* Outer loop on the device (the caller side of the path: a sampling planner / global IK iterates
+ * solve -> integrate -> re-target, README.md:5 of the reference).  The configurations q stay
+ * resident in HBM between steps: no per-step upload of q, FwdPassInit (loik-loid-optimized.hxx:253-283) runs from the
+ * resident copy.
+ *   loikb_integrate(s, dt):  q <- q (+) dt * z, z = the answer of the last solve (all joints 1-DoF: q += dt z)
+ *   loikb_solve_tailored(s, NULL, c_id, Ai, bi, flags):  q == NULL means "the resident q"                           */
+int loikb_integrate(loikb_solver *s, double dt);
+
 /* setters of IkIdSolverBaseTpl / the solver (task-solver-base.hpp:104-141, loik-loid-optimized.hpp:702-703) */
 int loikb_set_max_iter(loikb_solver *s, int max_iter);
 int loikb_set_rho(loikb_solver *s, double rho);
@@ -164,7 +172,10 @@ enum {
   LOIKB_F_DELTA_FIS_INF_NORM, LOIKB_F_DELTA_YIS_INF_NORM, LOIKB_F_DELTA_W_INF_NORM, LOIKB_F_DELTA_VIS_INF_NORM,
   LOIKB_F_DELTA_NU_INF_NORM, LOIKB_F_AV_INF_NORM, LOIKB_F_NU_INF_NORM, LOIKB_F_HREF_V_INF_NORM, LOIKB_F_G_INF_NORM,
   LOIKB_F_STF_PLUS_W_INF_NORM, LOIKB_F_PRIMAL_INFEASIBILITY_COND_1, LOIKB_F_PRIMAL_INFEASIBILITY_COND_2,
-  LOIKB_F_TAIL_SOLVE_ITER
+  LOIKB_F_TAIL_SOLVE_ITER,
+  /* double [batch][nq]: the configurations resident on the device (SolveInit/Solve input, advanced by
+     loikb_integrate) */
+  LOIKB_F_Q = 96
 };
 /* copies one field for the whole batch into `out` (host pointer, or device pointer with LOIKB_OUT_DEVICE) */
 int loikb_get(loikb_solver *s, int field, void *out, int out_flags);

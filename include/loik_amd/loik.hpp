@@ -164,6 +164,29 @@ public:
     fetch();
   }
 
+  // ---- outer loop on the device (not in the reference class: its callers -- a sampling planner, README.md:5 --
+  //      integrate on the host and pass a new q to the tailored Solve every step; here q stays resident in HBM)
+  // q <- q (+) dt * z, z = the answer of the last solve
+  void Integrate(double dt) { check(loikb_integrate(h_, dt)); }
+  // tailored Solve (loik-loid-optimized.hpp:596-695) on the resident q
+  void Solve(const Index c_id, const Mat6x6& Ai, const std::vector<Vec6>& bis)
+  {
+    DVec b(bis.size() * 6);
+    for (std::size_t i = 0; i < bis.size(); ++i)
+      for (int k = 0; k < 6; ++k) b[6 * i + k] = bis[i][k];
+    int flags = LOIKB_A_SHARED;
+    if (bis.size() == 1 && batch_ > 1) flags |= LOIKB_B_SHARED;
+    check(loikb_solve_tailored(h_, nullptr, (int)c_id, Ai.data(), b.data(), flags));
+    fetch();
+  }
+  // the resident configurations, [batch][nq]
+  DVec q_resident() const
+  {
+    DVec q((std::size_t)batch_ * model_.nq);
+    check(loikb_get(h_, LOIKB_F_Q, q.data(), 0));
+    return q;
+  }
+
   // task-solver-base.hpp:87-141 (instance index defaults to 0: the single-instance reading)
   int get_iter(int b = 0) const { return geti(LOIKB_F_ITER, b); }
   double get_primal_residual(int b = 0) const { return getd(LOIKB_F_PRIMAL_RESIDUAL, b); }

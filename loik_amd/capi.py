@@ -64,6 +64,7 @@ _SCALAR_FIELDS = ["primal_residual", "dual_residual", "primal_residual_task", "p
                   "Href_v_inf_norm", "g_inf_norm", "Stf_plus_w_inf_norm", "primal_infeasibility_cond_1",
                   "primal_infeasibility_cond_2", "tail_solve_iter"]
 FIELD_ID = {n: i for i, n in enumerate(_VEC_FIELDS)}
+FIELD_ID["q"] = 96
 FIELD_ID.update({n: 32 + i for i, n in enumerate(_SCALAR_FIELDS)})
 
 # every symbol include/loik_amd.h and include/loik_amd_models.h declare
@@ -72,7 +73,7 @@ EXPORTED_SYMBOLS = [
     "loikb_solve_tailored", "loikb_set_max_iter", "loikb_set_rho", "loikb_set_mu", "loikb_set_tol",
     "loikb_set_tol_primal_inf", "loikb_set_tol_tail_solve", "loikb_set_warm_start", "loikb_get", "loikb_get_stats",
     "loikb_batch", "loikb_nv", "loikb_njoints", "loikb_last_error", "loikb_status_string", "loikb_version",
-    "loikb_device_count", "loikb_sweep_schedule", "loikb_builtin_model", "loikb_builtin_joint_name",
+    "loikb_device_count", "loikb_sweep_schedule", "loikb_integrate", "loikb_builtin_model", "loikb_builtin_joint_name",
     "loikb_builtin_joint_id"]
 
 _lib = None
@@ -96,6 +97,7 @@ def lib():
     L.loikb_solve_init.argtypes = sig
     L.loikb_solve_full.argtypes = sig
     L.loikb_solve.argtypes = [C.c_void_p]
+    L.loikb_integrate.argtypes = [C.c_void_p, C.c_double]
     L.loikb_sweep_schedule.argtypes = [_ip, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip]
     L.loikb_solve_tailored.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     L.loikb_set_max_iter.argtypes = [C.c_void_p, C.c_int]
@@ -290,7 +292,8 @@ class BatchedLoik:
         return keep, args
 
     def Solve(self, *a):
-        """Solve() | Solve(q,H_ref,v_ref,ids,Ais,bis,lb,ub) | Solve(q,c_id,Ai,bi)"""
+        """Solve() | Solve(q,H_ref,v_ref,ids,Ais,bis,lb,ub) | Solve(q,c_id,Ai,bi); q=None in the tailored form uses
+        the configurations resident on the device (outer loop: integrate(dt) then Solve(None, c_id, Ai, bi))"""
         if len(a) == 0:
             _check(self.L.loikb_solve(self.h))
         elif len(a) == 8:
@@ -317,7 +320,7 @@ class BatchedLoik:
                     devs.append(False)
                 return x.ctypes.data_as(C.c_void_p)
 
-            qp = prep(q, self.model.nq, Q_SHARED)
+            qp = None if q is None else prep(q, self.model.nq, Q_SHARED)  # None: the q resident on the device
             Ap = prep(Ai, 36, A_SHARED)
             bp = prep(bi, 6, B_SHARED)
             if any(devs):
@@ -325,6 +328,10 @@ class BatchedLoik:
             _check(self.L.loikb_solve_tailored(self.h, qp, int(c_id), Ap, bp, flags))
         else:
             raise TypeError("Solve() takes 0, 4 or 8 arguments")
+
+    def integrate(self, dt):
+        """outer loop on the device: q <- q (+) dt * z of the last solve, q stays resident in HBM"""
+        _check(self.L.loikb_integrate(self.h, float(dt)))
 
     # ------------------------------------------------------------------------------------------------------
     def set_max_iter(self, n): _check(self.L.loikb_set_max_iter(self.h, int(n)))
@@ -341,7 +348,8 @@ class BatchedLoik:
         B, nb, nc = self.batch, self.model.njoints - 1, self.nc
         shapes = {"z": (B, nb), "nu": (B, nb), "w": (B, nb), "Stf_plus_w": (B, nb), "r": (B, nb), "Dinv": (B, nb),
                   "vis": (B, nb, 6), "fis": (B, nb, 6), "g": (B, nb, 6), "pis": (B, nb, 6), "UDinv": (B, nb, 6),
-                  "His": (B, nb, 21), "liMi": (B, nb, 12), "yis": (B, nc, 6), "Aty": (B, nc, 6)}
+                  "His": (B, nb, 21), "liMi": (B, nb, 12), "yis": (B, nc, 6), "Aty": (B, nc, 6),
+                  "q": (B, self.model.nq)}
         is_int = name in ("iter", "converged", "primal_infeasible", "status")
         if out is not None:
             p, dev = _ptr(out)

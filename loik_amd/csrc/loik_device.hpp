@@ -1309,6 +1309,25 @@ __global__ void k_fk_init(const double* __restrict__ q, int nq, int q_shared, co
   }
 }
 
+// outer loop: q <- q + dt * z on the resident configurations (1-DoF joints: the manifold update is a plain sum),
+// `src` != nullptr first (re)fills the resident copy from a caller's q (one shared row or one row per instance)
+template <typename T>
+__global__ void k_advance_q(double* __restrict__ q_res, const double* __restrict__ src, int src_shared, int nq,
+                            const int* __restrict__ idx_q, Layout L, int B, const char* tiles, double dt)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (src) {
+    for (int k = 0; k < nq; ++k) q_res[(size_t)b * nq + k] = src[(src_shared ? 0 : (size_t)b * nq) + k];
+    return;
+  }
+  const char* lp = lane_ptr<T>(const_cast<char*>(tiles), L, b);
+  for (int i = 1; i <= L.nb; ++i) {
+    const T z = ldp<T>(lp + (size_t)(i - 1) * JREC * pair_bytes<T>(), JP_WZ).y;
+    q_res[(size_t)b * nq + idx_q[i]] += dt * (double)z;
+  }
+}
+
 // instance-major [B][n] doubles (or one shared [n]) -> tile elements given by rowmap[r] = pair*2 + half
 template <typename T>
 __global__ void k_upload_rows(const double* __restrict__ src, int n, int shared, const int* __restrict__ rowmap,

@@ -75,6 +75,7 @@ struct loikb_solver_impl {
   double Hv_inf_norm = 0.0;
   std::vector<int> active_ids;
   bool have_problem = false;
+  bool have_q = false;
   bool a_shared = true, bnd_shared = true;
   bool href_diag = true;  // H_ref diagonal -> k_solve<T, true>
   // device
@@ -86,6 +87,7 @@ struct loikb_solver_impl {
   JointDesc* d_jd = nullptr;
   int* d_idx_q = nullptr;
   int* d_rowmap = nullptr;
+  double* d_q = nullptr;               // [B][nq] configurations resident on the device (outer loop)
   void* d_uni = nullptr;               // A[nc][36], AtA[nc][21], lb[nb], ub[nb] (T)
   void* d_stage = nullptr;             // staging for host<->device copies
   size_t stage_bytes = 0;
@@ -537,22 +539,36 @@ int upload_jd(loikb_solver_impl* S)
   return LOIKB_OK;
 }
 
-// FwdPassInit(q), loik-loid-optimized.hxx:253-283
+// FwdPassInit(q), loik-loid-optimized.hxx:253-283.  q == nullptr: the configurations already resident on the device
 int fwd_pass_init(loikb_solver_impl* S, const double* q, int in_flags)
 {
-  const bool shared = in_flags & LOIKB_Q_SHARED;
-  const bool dev = (in_flags & LOIKB_IN_DEVICE) && !shared;
-  const void* dq = nullptr;
-  int rc = to_device(S, q, sizeof(double) * (shared ? (size_t)S->nq : (size_t)S->B * S->nq), dev, &dq);
-  if (rc) return rc;
+  if (q) {
+    const bool shared = in_flags & LOIKB_Q_SHARED;
+    const bool dev = (in_flags & LOIKB_IN_DEVICE) && !shared;
+    const void* dq = nullptr;
+    int rc = to_device(S, q, sizeof(double) * (shared ? (size_t)S->nq : (size_t)S->B * S->nq), dev, &dq);
+    if (rc) return rc;
+    // the resident copy is what the outer loop advances (loikb_integrate)
+    if (S->f32)
+      hipLaunchKernelGGL(k_advance_q<float>, grid1(S->B), dim3(256), 0, S->stream, S->d_q, (const double*)dq, (int)shared,
+                         S->nq, S->d_idx_q, S->L, S->B, S->home.tiles, 0.0);
+    else
+      hipLaunchKernelGGL(k_advance_q<double>, grid1(S->B), dim3(256), 0, S->stream, S->d_q, (const double*)dq, (int)shared,
+                         S->nq, S->d_idx_q, S->L, S->B, S->home.tiles, 0.0);
+    HIPCHK(hipGetLastError());
+    if (!dev) HIPCHK(hipStreamSynchronize(S->stream));  // the staging buffer is re-used by the next upload
+    S->have_q = true;
+  } else if (!S->have_q) {
+    g_last_error = "no configurations resident on the device yet (call SolveInit / Solve with a q first)";
+    return LOIKB_ERR_STATE;
+  }
   if (S->f32)
-    hipLaunchKernelGGL(k_fk_init<float>, grid1(S->B), dim3(256), 0, S->stream, (const double*)dq, S->nq, (int)shared,
+    hipLaunchKernelGGL(k_fk_init<float>, grid1(S->B), dim3(256), 0, S->stream, (const double*)S->d_q, S->nq, 0,
                        S->d_jd, S->d_idx_q, S->L, S->B, S->home.tiles);
   else
-    hipLaunchKernelGGL(k_fk_init<double>, grid1(S->B), dim3(256), 0, S->stream, (const double*)dq, S->nq, (int)shared,
+    hipLaunchKernelGGL(k_fk_init<double>, grid1(S->B), dim3(256), 0, S->stream, (const double*)S->d_q, S->nq, 0,
                        S->d_jd, S->d_idx_q, S->L, S->B, S->home.tiles);
   HIPCHK(hipGetLastError());
-  if (!dev) HIPCHK(hipStreamSynchronize(S->stream));
   // the H/UDinv/Dinv cache depends on liMi; cold start: yis = 0, Aty = 0 (hxx:270-278)
   return reset_home(S, RS_HCACHE | (S->opt.warm_start ? 0 : RS_Y));
 }
@@ -1198,6 +1214,7 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
   TRY(alloc_dev(S, &tmp, sizeof(JointDesc) * S->nj)); S->d_jd = (JointDesc*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * S->nj)); S->d_idx_q = (int*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * ROWMAP_CAP)); S->d_rowmap = (int*)tmp;
+  TRY(alloc_dev(S, &tmp, sizeof(double) * (size_t)S->B * S->nq)); S->d_q = (double*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(TailTopo) * S->nj)); S->d_topo = (TailTopo*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * (S->child_list.size() + 1))); S->d_child_list = (int*)tmp;
   HIPTRY(hipMemcpyAsync(S->d_topo, S->topo.data(), sizeof(TailTopo) * S->nj, hipMemcpyHostToDevice, S->stream));
@@ -1285,7 +1302,7 @@ int loikb_solve_full(loikb_solver* S, const double* q, const double* H_ref, cons
 
 int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const double* Ai, const double* bi, int in_flags)
 {
-  if (!S || !q || !Ai || !bi) return LOIKB_ERR_ARG;
+  if (!S || !Ai || !bi) return LOIKB_ERR_ARG;  // q == NULL: the configurations resident on the device
   if (!S->have_problem) { g_last_error = "tailored Solve() before SolveInit()"; return LOIKB_ERR_STATE; }
   HIPCHK(hipSetDevice(S->device));
   int rc;
@@ -1310,6 +1327,21 @@ int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const doubl
   if ((rc = constraint_products(S, found, found + 1, true))) return rc;
   if ((rc = fwd_pass_init(S, q, in_flags))) return rc;
   return run_main_loop(S);
+}
+
+int loikb_integrate(loikb_solver* S, double dt)
+{
+  if (!S) return LOIKB_ERR_ARG;
+  if (!S->have_q) { g_last_error = "integrate: no configurations resident on the device yet"; return LOIKB_ERR_STATE; }
+  HIPCHK(hipSetDevice(S->device));
+  if (S->f32)
+    hipLaunchKernelGGL(k_advance_q<float>, grid1(S->B), dim3(256), 0, S->stream, S->d_q, (const double*)nullptr, 0, S->nq,
+                       S->d_idx_q, S->L, S->B, S->home.tiles, dt);
+  else
+    hipLaunchKernelGGL(k_advance_q<double>, grid1(S->B), dim3(256), 0, S->stream, S->d_q, (const double*)nullptr, 0, S->nq,
+                       S->d_idx_q, S->L, S->B, S->home.tiles, dt);
+  HIPCHK(hipGetLastError());
+  return LOIKB_OK;
 }
 
 int loikb_set_max_iter(loikb_solver* S, int v) { if (!S) return LOIKB_ERR_ARG; S->opt.max_iter = v; return LOIKB_OK; }
@@ -1346,6 +1378,13 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   if (!S || !out) return LOIKB_ERR_ARG;
   HIPCHK(hipSetDevice(S->device));
   const bool to_dev = out_flags & LOIKB_OUT_DEVICE;
+  if (field == LOIKB_F_Q) {
+    if (!S->have_q) { g_last_error = "no configurations resident on the device yet"; return LOIKB_ERR_STATE; }
+    HIPCHK(hipMemcpyAsync(out, S->d_q, sizeof(double) * (size_t)S->B * S->nq,
+                          to_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
+    return LOIKB_OK;
+  }
   const Layout& L = S->L;
   const int nb = S->nb;
   std::vector<int> rm;

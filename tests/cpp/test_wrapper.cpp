@@ -153,6 +153,34 @@ int main()
     // (whether this hand-made target converges is the oracle's call: compare() checks the flags against it)
     compare(f, d, solver, o);
   }
+  {  // outer loop on the device: Integrate(dt) + tailored Solve on the resident q  ==  integrating on the host and
+     // passing the new q (what a caller of the reference does every planner step)
+    Fixture f; f.max_iter = 300; f.tol_abs = 1e-6; f.tol_rel = 0.0; f.set_bound(0.5); f.warm_start = true;
+    f.active_task_constraint_ids[0] = f.robot_model.getJointId("arm_left_7_joint");
+    for (int k = 0; k < f.robot_model.nq; ++k) f.q[k] = 0.1 * std::sin(1.0 + k);
+    f.bis[0] = Vec6{0.05, -0.03, 0.02, 0.01, 0.02, -0.04};
+    IkIdDataOptimized dh(f.robot_model, f.num_eq_c), dd(f.robot_model, f.num_eq_c);
+    MAKE_SOLVER(host_loop, dh, f);
+    MAKE_SOLVER(dev_loop, dd, f);
+    host_loop.SolveInit(f.q, f.H_ref, f.v_ref, f.active_task_constraint_ids, f.Ais, f.bis, f.lb, f.ub);
+    dev_loop.SolveInit(f.q, f.H_ref, f.v_ref, f.active_task_constraint_ids, f.Ais, f.bis, f.lb, f.ub);
+    DVec q = f.q;
+    const double dt = 0.05;
+    for (int step = 0; step < 4; ++step) {
+      Vec6 b = f.bis[0];
+      for (int k = 0; k < 6; ++k) b[k] *= (1.0 - 0.2 * step);  // the target velocity decays as the planner closes in
+      host_loop.Solve(q, f.active_task_constraint_ids[0], f.Ais[0], b);
+      if (step > 0) dev_loop.Integrate(dt);
+      dev_loop.Solve(f.active_task_constraint_ids[0], f.Ais[0], std::vector<Vec6>{b});
+      // (q + dt z may be contracted to an fma on one side and not the other: equal to rounding, not bit for bit)
+      CHECK(close(dh.z.data(), dd.z.data(), f.robot_model.nv));
+      CHECK(close(dh.w.data(), dd.w.data(), f.robot_model.nv));
+      CHECK(host_loop.get_iter() == dev_loop.get_iter());
+      const DVec qr = dev_loop.q_resident();
+      CHECK(close(qr.data(), q.data(), f.robot_model.nq));
+      for (int k = 0; k < f.robot_model.nq; ++k) q[k] += dt * dh.z[k];
+    }
+  }
   {  // throw sites carry the reference's messages
     Fixture f; f.max_iter = 10;
     IkIdDataOptimized d(f.robot_model, f.num_eq_c);

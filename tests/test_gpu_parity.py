@@ -493,3 +493,72 @@ def test_concurrent_chunks_change_nothing(talos, monkeypatch):
     assert np.array_equal(one.get("iter"), three.get("iter"))
     assert np.max(np.abs(one.get("z") - three.get("z"))) < 1e-10
     one.close(); three.close()
+
+
+def test_outer_loop_on_device_matches_host_loop(talos):
+    """solve -> integrate q <- q + dt z -> re-target, with q resident on the device
+    (loikb_integrate + tailored Solve on the resident q), against the oracle driven the way a caller drives the
+    reference: integrate on the host, pass the new q to Solve(q, c_id, Ai, bi) (loik-loid-optimized.hpp:596-695)
+    every step, warm-started (loik-loid-data-optimized.hxx:117-126)"""
+    link = talos.getJointId("arm_left_7_joint")
+    B, T, dt = 96, 5, 0.1
+    rng = np.random.default_rng(4242)
+    wl0 = feasible_batch(talos, B, link, 900, nu_scale=0.4)
+    prm = dict(FIXTURE, max_iter=400, tol_abs=1e-6, tol_rel=0.0, warm_start=True)
+    nu_star = rng.uniform(-0.4, 0.4, size=(T, B, talos.nv))
+    # oracle: one RefSolver per checked instance, host-side integration
+    checked = list(range(0, B, 7))
+    refs = {}
+    for b in checked:
+        r = ref.RefSolver(talos, **prm)
+        r.SolveInit(*problem_args(wl0, b))
+        refs[b] = (r, wl0["q"][b].copy())
+    s = loik_amd.BatchedLoik(talos, B, max_launch_iters=6, **prm)
+    s.SolveInit(wl0["q"], wl0["H_ref"], wl0["v_ref"], wl0["c_ids"], wl0["Ais"], wl0["bis"], wl0["lb"], wl0["ub"])
+    q_host = wl0["q"].copy()  # mirror of the device-resident q, advanced with the GPU's own z (to build the targets)
+    for t in range(T):
+        if t > 0:
+            s.integrate(dt)
+        assert np.max(np.abs(s.get("q") - q_host)) < 1e-12
+        # re-target: a feasible task velocity at the CURRENT configuration of every instance
+        b_t = workloads.link_velocity(talos, q_host, nu_star[t], link)[:, None, :]
+        s.Solve(None, link, wl0["Ais"], b_t)
+        z = s.get("z")
+        for b in checked:
+            r, qb = refs[b]
+            assert np.max(np.abs(qb - q_host[b])) < 1e-9, (t, b)
+            r.Solve(qb, link, wl0["Ais"][0], workloads.link_velocity(talos, qb[None], nu_star[t, b][None], link)[0])
+            assert s.get("iter")[b] == r.get_iter(), (t, b)
+            assert_close(z[b], r.z, 1e-9, "z step %d b%d" % (t, b))
+            assert_close(s.get("w")[b], r.w, 1e-9, "w step %d b%d" % (t, b))
+            refs[b] = (r, qb + dt * r.z)
+        q_host = q_host + dt * z
+    s.close()
+    # passing the integrated q from the host every step instead (what a caller of the reference does) gives the
+    # same answers (to rounding: q + dt z is one fma on the device, a product and a sum in numpy)
+    s1 = loik_amd.BatchedLoik(talos, B, max_launch_iters=6, **prm)
+    s2 = loik_amd.BatchedLoik(talos, B, max_launch_iters=6, **prm)
+    for sol in (s1, s2):
+        sol.SolveInit(wl0["q"], wl0["H_ref"], wl0["v_ref"], wl0["c_ids"], wl0["Ais"], wl0["bis"], wl0["lb"], wl0["ub"])
+    qh = wl0["q"].copy()
+    for t in range(3):
+        b_t = workloads.link_velocity(talos, qh, nu_star[t], link)[:, None, :]
+        if t > 0:
+            s1.integrate(dt)
+        s1.Solve(None, link, wl0["Ais"], b_t)
+        s2.Solve(qh, link, wl0["Ais"], b_t)
+        assert np.array_equal(s1.get("iter"), s2.get("iter"))
+        assert np.max(np.abs(s1.get("z") - s2.get("z"))) < 1e-10
+        qh = qh + dt * s2.get("z")
+    s1.close(); s2.close()
+
+
+def test_outer_loop_state_errors(talos):
+    """integrate / resident tailored solve before any q was given: the library's state error, not a crash"""
+    s = loik_amd.BatchedLoik(talos, 4, **dict(FIXTURE, max_iter=10))
+    with pytest.raises(capi.LoikError) as e:
+        s.integrate(0.1)
+    assert e.value.code == -24  # LOIKB_ERR_STATE
+    with pytest.raises(capi.LoikError):
+        s.get("q")
+    s.close()
