@@ -31,9 +31,6 @@
 namespace loikb {
 
 constexpr int WAVE = 64;
-#ifndef LOIKB_NSLOT
-#define LOIKB_NSLOT 1
-#endif
 
 // ---- tile layout (units: pairs) -------------------------------------------------------------------
 enum : int {
@@ -44,20 +41,18 @@ enum : int {
   JP_G = 7,      // fis_diff_plus_Aty[i]        3 pairs
   JP_WZ = 10,    // (w_i, z_i)
   JP_NUS = 11,   // (nu_i, Stf_plus_w_i)
-  JP_P = 12,     // pis[i]                      3 pairs                     -- inter-sweep temporaries
-  JP_R = 15,     // (r_i after += S^T p, unused)   -- always written as a full 16-byte pair
+  JP_P = 12,     // p_i^base = -rho v_i^prev - Hv (+ A^T y - mu_eq A^T b): pis[i] before the children's contributions
+                 //                             3 pairs                     -- inter-sweep temporaries
+  JP_R = 15,     // (r_i after += S^T p, Dinv_i)   -- always written as a full 16-byte pair
   JP_LBUB = 16,  // (lb_i, ub_i) when the box is per instance
-  // H cache: NSLOT copies of {UDinv (3 pairs), His packed 21 + Dinv (11 pairs)}, one per cached value of mu.  mu only
-  // ever moves by decades (mu0 * 10^k), so slot = k mod NSLOT.  Measured on MI355X: NSLOT = 3 removes nearly every
-  // repeated H-recursion of the stragglers (which flip between 2-3 decades) but the lanes of a wavefront then sit in
-  // DIFFERENT slots, every H/UDinv access touches up to 3 partially used 1-KiB rows, and the bandwidth-bound phases
-  // lose more than the cached sweeps win (88 -> 95 ms/step).  So one slot in HBM; the tail kernel keeps two in LDS.
-  JP_SLOT0 = 17,
-  SL_UD = 0,
-  SL_H = 3,
-  SLOT_PAIRS = 14,
-  NSLOT = LOIKB_NSLOT,
-  JREC = JP_SLOT0 + NSLOT * SLOT_PAIRS,  // 59
+  JP_UD = 17,    // UDinv_i                     3 pairs  -- with Dinv_i the H cache: valid while mu is unchanged
+  // H_i itself is NOT stored.  Upstream keeps His[i] for the forward pass' f_i = H_i v_i + p_i (hxx:139-140); here
+  // f_i comes from the force-balance recursion f_i = H_i^base v_i + p_i^base + sum_children X*_c f_c (identical in
+  // exact arithmetic, see sweep_bwd2), which needs neither H_i nor p_i -- H_i lives only in registers / LDS edge
+  // slots during the H recursion.  The getters for His / pis rebuild them on demand (k_rebuild_his / k_rebuild_pis).
+  // (Per-lane multi-slot caches keyed by the decade of mu were measured and rejected: lanes of a tile then sit in
+  // different slots, every access touches partially used 1-KiB rows: 61 -> 71 ms/step.)
+  JREC = 20,
   JP_NPERSIST = 12,  // pairs [0, JP_NPERSIST) (+ JP_LBUB) travel with an instance on compaction
   // constraint record
   CP_Y = 0,      // yis[c]     3 pairs
@@ -71,8 +66,8 @@ enum : int {
   // per-instance solver scalars
   SP_MU = 0,     // (mu_, k) with mu_ = mu0 * 10^k
   SP_BI = 1,     // (bis_inf_norm_, iter_)
-  SP_ST = 2,     // (status bits, decade k of the mu the LAST executed iteration used = slot of its His/UDinv/Dinv)
-  SP_TAG = 3,    // mu each H-cache slot was computed with: (tag0, tag1), (tag2, unused); -1 = empty
+  SP_ST = 2,     // (status bits, mu the LAST executed iteration used = the mu of the stored UDinv/Dinv/r/p^base)
+  SP_TAG = 3,    // (mu the cached UDinv/Dinv were computed with; -1 = empty, unused), (unused, unused)
   SP_SCAL = 5,   // scal[NSCAL] -> 15 pairs
   SREC = 20,
 };
@@ -108,7 +103,8 @@ struct JointDesc {
 };
 
 // status bits per instance
-enum : int { ST_CONVERGED = 1, ST_PRIMAL_INF = 2, ST_TAIL = 4, ST_DONE = 8 };
+enum : int { ST_CONVERGED = 1, ST_PRIMAL_INF = 2, ST_TAIL = 4, ST_DONE = 8,
+             ST_PFULL = 16 };  // the p slot holds the accumulated p_i (left by k_tail), not p_i^base
 
 // solver mode flags (uniform)
 enum : int {
@@ -573,7 +569,7 @@ __device__ __forceinline__ void sweep_barrier(int nw)
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool WITH_H, bool HDIAG>
 __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf, const Team& tm, int w, int nw,
-                                          T* edge, char* lp, int lane, bool live, T mu_eq, T mu_in, size_t hoff)
+                                          T* edge, char* lp, int lane, bool live, T mu_eq, T mu_in)
 {
   const Layout& L = P.L;
   T accH[21], accp[6];
@@ -594,9 +590,12 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
       char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
       T vprev[6], hh[21], pp[6], U[6], UD[6];
       const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ);
-      char* hrec = rec + (size_t)JP_SLOT0 * pair_bytes<T>() + hoff;  // this lane's H-cache slot
       ld6<T>(rec, JP_V, vprev);
-      if (!WITH_H) ld6<T>(hrec, SL_UD, UD);
+      T dd_cached = T(0);
+      if (!WITH_H) {
+        ld6<T>(rec, JP_UD, UD);
+        dd_cached = ldp<T>(rec, JP_R).y;  // Dinv shares the pair of r: read it to rewrite the full pair below
+      }
       // FwdPass1 (hxx:304-315): H_i = rho I + H_ref ; p_i = -rho v_prev - Hv
       if (WITH_H) {
 #pragma unroll
@@ -630,10 +629,11 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
 #pragma unroll
         for (int k = 0; k < 6; ++k) pp[k] += aty[k] - mu_eq * atb[k];
       }
+      // p_i^base is what the residual sweep needs (force-balance recursion for f_i), not the accumulated p_i
+      st6<T>(rec, JP_P, pp);
       // children contributions (hxx:66-67, :74-75)
       if (WITH_H) edge_gather<T, 0, 21>(sd, tm.rlist, edge, accH, hh, lane);
       edge_gather<T, 21, 6>(sd, tm.rlist, edge, accp, pp, lane);
-      st6<T>(rec, JP_P, pp);
 
       // calc_aba (hxx:60-63): U = H S ; Dinv = 1/(S^T U + R) ; UDinv = U Dinv
       const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
@@ -658,12 +658,9 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
       if (WITH_H) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) UD[k] = U[k] * dd;
-        // store the pre-projection H (what the forward sweep needs, hxx:121) with Dinv in its 22nd slot, UDinv
-#pragma unroll
-        for (int k = 0; k < 11; ++k) stp<T>(hrec, SL_H + k, hh[2 * k], 2 * k + 1 < 21 ? hh[2 * k + 1] : dd);
-        st6<T>(hrec, SL_UD, UD);
+        st6<T>(rec, JP_UD, UD);  // UDinv and Dinv are all the forward sweep needs of the H recursion
       }
-      stp<T>(rec, JP_R, ri, T(0));
+      stp<T>(rec, JP_R, ri, WITH_H ? dd : dd_cached);
 
       if (!(d.flags & JF_PARENT_ROOT)) {
         T R[9], t[3], part[27], pa[6];
@@ -696,26 +693,20 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 struct FwdIn {
-  typename Vec2<T>::type cs, wz, nus, rd, lu, h[11];
-  T pp[6], UD[6], vprev[6], fold[6];
-  __device__ __forceinline__ void load(const char* rec, size_t hoff, bool bnd_shared)
+  typename Vec2<T>::type cs, wz, nus, rd, lu;
+  T UD[6], vprev[6];
+  __device__ __forceinline__ void load(const char* rec, bool bnd_shared)
   {
-    const char* hrec = rec + (size_t)JP_SLOT0 * pair_bytes<T>() + hoff;
     cs = ldp<T>(rec, JP_CS); wz = ldp<T>(rec, JP_WZ); nus = ldp<T>(rec, JP_NUS); rd = ldp<T>(rec, JP_R);
-#pragma unroll
-    for (int k = 0; k < 11; ++k) h[k] = ldp<T>(hrec, SL_H + k);
-    ld6<T>(rec, JP_P, pp);
-    ld6<T>(hrec, SL_UD, UD);
+    ld6<T>(rec, JP_UD, UD);
     ld6<T>(rec, JP_V, vprev);
-    ld6<T>(rec, JP_F, fold);
     if (!bnd_shared) lu = ldp<T>(rec, JP_LBUB);
   }
 };
 
 template <typename T, bool HDIAG, bool PF>
 __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf, const Team& tm, int w, int nw,
-                                          T* vedge, char* lp, int lane, bool live, T mu_eq, T mu_in, size_t hoff,
-                                          Norms<T>& N)
+                                          T* vedge, char* lp, int lane, bool live, T mu_eq, T mu_in, Norms<T>& N)
 {
   const Layout& L = P.L;
   const bool bnd_shared = P.mode & MODE_BND_SHARED;
@@ -726,7 +717,7 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
   FwdIn<T> in;
   if (PF) {
     const int i0 = steps[0].joint;
-    if (i0 > 0 && live) in.load(lp + (size_t)(i0 - 1) * JREC * pair_bytes<T>(), hoff, bnd_shared);
+    if (i0 > 0 && live) in.load(lp + (size_t)(i0 - 1) * JREC * pair_bytes<T>(), bnd_shared);
   }
 
   int jn = steps[0].joint;
@@ -738,10 +729,8 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
     if (i > 0 && live) {
       const JointDesc& d = sd.d;
       char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
-      if (!PF) in.load(rec, hoff, bnd_shared);
-      T hh[22], vpar[6], vp[6], vi[6], fi[6], R[9], t[3];
-#pragma unroll
-      for (int k = 0; k < 11; ++k) { hh[2 * k] = in.h[k].x; hh[2 * k + 1] = in.h[k].y; }
+      if (!PF) in.load(rec, bnd_shared);
+      T vpar[6], vp[6], vi[6], R[9], t[3];
       T lbi, ubi;
       if (bnd_shared) {
         lbi = Bf.uni[L.nc * 57 + (i - 1)];
@@ -749,7 +738,7 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
       } else {
         lbi = in.lu.x; ubi = in.lu.y;
       }
-      const T ri = in.rd.x, dd = hh[21], wi = in.wz.x, zprev = in.wz.y, nuprev = in.nus.x;
+      const T ri = in.rd.x, dd = in.rd.y, wi = in.wz.x, zprev = in.wz.y, nuprev = in.nus.x;
       // parent velocity: universe = 0, chain = registers, otherwise the parent's LDS hand-over slot
       if (d.parent == 0) {
 #pragma unroll
@@ -778,16 +767,10 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
       } else {
         vi[0] += ax0 * nui; vi[1] += ax1 * nui; vi[2] += ax2 * nui;
       }
-      // f_i = H_i v_i + p_i (hxx:139-140), delta_fis (hxx:137-146)
-      symv(hh, vi, fi);
-      T df[6], dv6[6], hrv[6];
+      // f_i (hxx:139-140) and delta_fis (hxx:137-146) are produced by the residual sweep: see sweep_bwd2
+      T dv6[6], hrv[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        fi[k] += in.pp[k];
-        df[k] = fi[k] - in.fold[k];
-        dv6[k] = vi[k] - in.vprev[k];
-      }
-      N.dfis = tmax(N.dfis, inf6(df));
+      for (int k = 0; k < 6; ++k) dv6[k] = vi[k] - in.vprev[k];
       // Href_v (hxx:149-153)
       href_mul<T, HDIAG>(P.Href, vi, hrv);
       N.href_v = tmax(N.href_v, inf6(hrv));
@@ -806,7 +789,6 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
       stp<T>(rec, JP_WZ, wi + dwi, zi);
       stp<T>(rec, JP_NUS, nui, in.nus.y);  // full 16-byte store: Stf_plus_w rewritten unchanged
       st6<T>(rec, JP_V, vi);
-      st6<T>(rec, JP_F, fi);
 #pragma unroll
       for (int k = 0; k < 6; ++k) vcur[k] = vi[k];
       if (sd.flags & SF_OUT_LDS) {
@@ -865,18 +847,58 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
     // request the next step's record behind this step's stores: it is in flight across the barrier.  (Requesting
     // it before the arithmetic measured slower: the compiler's vmcnt(0) waits inside the step then stall on it.)
     if (PF && t_ + 1 < tm.T_down && jn > 0 && live)
-      in.load(lp + (size_t)(jn - 1) * JREC * pair_bytes<T>(), hoff, bnd_shared);
+      in.load(lp + (size_t)(jn - 1) * JREC * pair_bytes<T>(), bnd_shared);
     step_barrier(nw);
   }
   sweep_barrier(nw);
 }
 
 // ------------------------------------------------------------------------------------------------
-// leaf -> root residual sweep: BwdPass2 + dual residual
+// f_i by force balance.  Upstream's forward pass sets f_i = H_i v_i + p_i with the accumulated H_i, p_i of the
+// backward pass (hxx:139-140).  With H_i = H_i^base + sum_c X*_c H_c^aba X_c^-1, p_i = p_i^base + sum_c X*_c p_c^aba,
+// v_c = X_c^-1 v_i + S_c nu_c and nu_c = -Dinv_c (U_c^T X_c^-1 v_i + r_c) one gets H_c^aba X_c^-1 v_i + p_c^aba = f_c,
+// hence
+//      f_i = H_i^base v_i + p_i^base + sum_children X*_c f_c ,      H_i^base = rho I + H_ref (+ mu_eq A^T A),
+// the same number in exact arithmetic, computed leaf -> root from the children's f -- which the residual sweep
+// accumulates anyway for g_i (hxx:210-212).  Neither H_i nor p_i is read: the backward sweep does not store H_i
+// at all (11 of the 27 pairs the forward sweep used to load per joint, and 11 of the 18 the H sweep used to store).
+// hv = H_ref v_i (also needed by the dual residual), sumf = sum_children act(liMi_c, f_c).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void force_balance(const Params<T>& P, const Bufs<T>& Bf, const JointDesc& d, const char* lp,
+                                              T mu_eq, const T* vi, const T* hv, const T* pb, const T* sumf, T* fi)
+{
+  const Layout& L = P.L;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) fi[k] = (hv[k] + P.rho * vi[k]) + pb[k];
+  if (d.cslot >= 0) {
+    T ata[22], av[6];
+    if (P.mode & MODE_A_SHARED) {
+      const T* AtA = Bf.uni + L.nc * 36 + d.cslot * 21;
+#pragma unroll
+      for (int k = 0; k < 21; ++k) ata[k] = AtA[k];
+    } else {
+      const char* crec = lp + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>();
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const typename Vec2<T>::type a = ldp<T>(crec, CP_ATA + k);
+        ata[2 * k] = a.x; ata[2 * k + 1] = a.y;
+      }
+    }
+    symv(ata, vi, av);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) fi[k] += mu_eq * av[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) fi[k] += sumf[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// leaf -> root residual sweep: f_i (force balance, above), BwdPass2 + dual residual
 // ------------------------------------------------------------------------------------------------
 template <typename T, bool HDIAG>
 __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf, const Team& tm, int w, int nw,
-                                           T* edge, char* lp, int lane, bool live, Norms<T>& N)
+                                           T* edge, char* lp, int lane, bool live, T mu_eq, Norms<T>& N)
 {
   const Layout& L = P.L;
   T acc[6];
@@ -892,12 +914,20 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
     if (i > 0 && live) {
       const JointDesc& d = sd.d;
       char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
-      T fi[6], vi[6], gold[6], gi[6];
+      T fold[6], fi[6], vi[6], gold[6], gi[6], pb[6], sf[6], hv[6];
       const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
-      ld6<T>(rec, JP_F, fi);
+      ld6<T>(rec, JP_F, fold);
       ld6<T>(rec, JP_V, vi);
       ld6<T>(rec, JP_G, gold);
+      ld6<T>(rec, JP_P, pb);
       const T wi = wz.x, sold = nus.y;
+      // sum_children act(f_j), then f_i (hxx:139-140 via force balance) and delta_fis (hxx:137-146)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sf[k] = T(0);
+      edge_gather<T, 0, 6>(sd, tm.rlist, edge, acc, sf, lane);
+      href_mul<T, HDIAG>(P.Href, vi, hv);
+      force_balance<T>(P, Bf, d, lp, mu_eq, vi, hv, pb, sf, fi);
+      st6<T>(rec, JP_F, fi);
       // g_i = (Aty_c | 0) + sum_children act(f_j) - f_i   (hxx:438-439, :210-212)
       if (d.cslot >= 0) {
         ld6<T>(lp + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>(), CP_ATY, gi);
@@ -905,20 +935,20 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
 #pragma unroll
         for (int k = 0; k < 6; ++k) gi[k] = T(0);
       }
-      edge_gather<T, 0, 6>(sd, tm.rlist, edge, acc, gi, lane);
-      T dg[6], dvr[6];
+      T dg[6], dvr[6], df[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        gi[k] += -fi[k];
+        df[k] = fi[k] - fold[k];
+        gi[k] = (gi[k] + sf[k]) - fi[k];
         dg[k] = gi[k] - gold[k];
       }
       st6<T>(rec, JP_G, gi);
+      N.dfis = tmax(N.dfis, inf6(df));
       N.dg = tmax(N.dg, inf6(dg));      // hxx:215-220
       N.g_inf = tmax(N.g_inf, inf6(gi));  // hxx:223-225
       // dual residual, v block (hxx:228): Href v_i - Hv + g_i
-      href_mul<T, HDIAG>(P.Href, vi, dvr);
 #pragma unroll
-      for (int r = 0; r < 6; ++r) dvr[r] = dvr[r] - P.Hv[r] + gi[r];
+      for (int r = 0; r < 6; ++r) dvr[r] = hv[r] - P.Hv[r] + gi[r];
       N.dual_v = tmax(N.dual_v, inf6(dvr));
       // Stf_plus_w (hxx:231-236, :482-484)
       const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
@@ -953,22 +983,22 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 struct FusedIn {
-  typename Vec2<T>::type cs, wz, nus;
-  T fi[6], vi[6], gold[6], UD[6];
-  __device__ __forceinline__ void load(const char* rec, size_t hoff)
+  typename Vec2<T>::type cs, wz, nus, rd;
+  T fold[6], vi[6], gold[6], UD[6], pb[6];
+  __device__ __forceinline__ void load(const char* rec)
   {
-    cs = ldp<T>(rec, JP_CS); wz = ldp<T>(rec, JP_WZ); nus = ldp<T>(rec, JP_NUS);
-    ld6<T>(rec, JP_F, fi);
+    cs = ldp<T>(rec, JP_CS); wz = ldp<T>(rec, JP_WZ); nus = ldp<T>(rec, JP_NUS); rd = ldp<T>(rec, JP_R);
+    ld6<T>(rec, JP_F, fold);
     ld6<T>(rec, JP_V, vi);
     ld6<T>(rec, JP_G, gold);
-    ld6<T>(rec + (size_t)JP_SLOT0 * pair_bytes<T>() + hoff, SL_UD, UD);
+    ld6<T>(rec, JP_UD, UD);
+    ld6<T>(rec, JP_P, pb);
   }
 };
 
 template <typename T, bool HDIAG, bool PF>
 __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& Bf, const Team& tm, int w, int nw,
-                                            T* edge, char* lp, int lane, bool live, T mu_eq, T mu_in, size_t hoff,
-                                            Norms<T>& N)
+                                            T* edge, char* lp, int lane, bool live, T mu_eq, T mu_in, Norms<T>& N)
 {
   const Layout& L = P.L;
   T acc[12];  // [0,6): sum of act(f_child), [6,12): sum of act(p_aba child)
@@ -978,7 +1008,7 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
   FusedIn<T> in;
   if (PF) {
     const int i0 = steps[0].joint;
-    if (i0 > 0 && live) in.load(lp + (size_t)(i0 - 1) * JREC * pair_bytes<T>(), hoff);
+    if (i0 > 0 && live) in.load(lp + (size_t)(i0 - 1) * JREC * pair_bytes<T>());
   }
   int jn = steps[0].joint;
   for (int t_ = 0; t_ < tm.T_up; ++t_) {
@@ -989,13 +1019,13 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
     if (i > 0 && live) {
       const JointDesc& d = sd.d;
       char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
-      if (!PF) in.load(rec, hoff);
-      T gi[6], pp[6];
+      if (!PF) in.load(rec);
+      T gi[6], pp[6], sf[6], fi[6], hv[6];
       const T wi = in.wz.x, sold = in.nus.y;
-      // ---- iteration k: g_i = (Aty_c | 0) + sum_children act(f_j) - f_i   (hxx:438-439, :210-212)
+      // ---- iteration k: f_i by force balance, g_i = (Aty_c | 0) + sum_children act(f_j) - f_i   (hxx:438-439, :210-212)
       //      iteration k+1: p_i = -rho v_i - Hv (+ Aty_c - mu_eq Atb_c)       (hxx:304-315, :321-334)
 #pragma unroll
-      for (int k = 0; k < 6; ++k) pp[k] = -P.rho * in.vi[k] - P.Hv[k];
+      for (int k = 0; k < 6; ++k) { pp[k] = -P.rho * in.vi[k] - P.Hv[k]; sf[k] = T(0); }
       if (d.cslot >= 0) {
         const char* crec = lp + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>();
         T atb[6];
@@ -1007,50 +1037,54 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
 #pragma unroll
         for (int k = 0; k < 6; ++k) gi[k] = T(0);
       }
-      edge_gather<T, 0, 6>(sd, tm.rlist, edge, acc, gi, lane);
+      st6<T>(rec, JP_P, pp);  // p^base of iteration k+1 (the slot's p^base of iteration k is already in `in.pb`)
+      edge_gather<T, 0, 6>(sd, tm.rlist, edge, acc, sf, lane);
       edge_gather<T, 6, 6>(sd, tm.rlist, edge, acc + 6, pp, lane);
-      T dg[6], dvr[6];
+      href_mul<T, HDIAG>(P.Href, in.vi, hv);
+      force_balance<T>(P, Bf, d, lp, mu_eq, in.vi, hv, in.pb, sf, fi);
+      st6<T>(rec, JP_F, fi);
+      T dg[6], dvr[6], df[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        gi[k] += -in.fi[k];
+        df[k] = fi[k] - in.fold[k];
+        gi[k] = (gi[k] + sf[k]) - fi[k];
         dg[k] = gi[k] - in.gold[k];
       }
       st6<T>(rec, JP_G, gi);
-      st6<T>(rec, JP_P, pp);
+      N.dfis = tmax(N.dfis, inf6(df));
       N.dg = tmax(N.dg, inf6(dg));        // hxx:215-220
       N.g_inf = tmax(N.g_inf, inf6(gi));  // hxx:223-225
       // dual residual, v block (hxx:228): Href v_i - Hv + g_i
-      href_mul<T, HDIAG>(P.Href, in.vi, dvr);
 #pragma unroll
-      for (int r = 0; r < 6; ++r) dvr[r] = dvr[r] - P.Hv[r] + gi[r];
+      for (int r = 0; r < 6; ++r) dvr[r] = hv[r] - P.Hv[r] + gi[r];
       N.dual_v = tmax(N.dual_v, inf6(dvr));
       // Stf_plus_w (hxx:231-236, :482-484) and r_i = (w_i - mu_in z_i) + S^T p_i (hxx:296, :70)
       const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
       T stf, Stp;
       if (d.flags & JF_REVOLUTE) {
-        stf = ax0 * in.fi[3] + ax1 * in.fi[4] + ax2 * in.fi[5];
+        stf = ax0 * fi[3] + ax1 * fi[4] + ax2 * fi[5];
         Stp = ax0 * pp[3] + ax1 * pp[4] + ax2 * pp[5];
       } else {
-        stf = ax0 * in.fi[0] + ax1 * in.fi[1] + ax2 * in.fi[2];
+        stf = ax0 * fi[0] + ax1 * fi[1] + ax2 * fi[2];
         Stp = ax0 * pp[0] + ax1 * pp[1] + ax2 * pp[2];
       }
       const T si = stf + wi;
       const T ri = (in.wz.x - mu_in * in.wz.y) + Stp;
       stp<T>(rec, JP_NUS, in.nus.x, si);
-      stp<T>(rec, JP_R, ri, T(0));
+      stp<T>(rec, JP_R, ri, in.rd.y);  // Dinv of the cache rewritten unchanged
       N.stf_w_inf = tmax(N.stf_w_inf, tabs(si));
       N.dstf_w = tmax(N.dstf_w, tabs(si - sold));
       if (!(d.flags & JF_PARENT_ROOT)) {
         T R[9], t[3], part[12], pa[6];
         make_liMi(d, in.cs.x, in.cs.y, R, t);
-        act_force(R, t, in.fi, part);  // hxx:212
+        act_force(R, t, fi, part);  // hxx:212
 #pragma unroll
         for (int k = 0; k < 6; ++k) pa[k] = pp[k] - in.UD[k] * ri;  // hxx:71-73
         act_force(R, t, pa, part + 6);                               // hxx:74
         edge_emit<T, 0, 12>(sd, edge, acc, part, lane);
       }
     }
-    if (PF && t_ + 1 < tm.T_up && jn > 0 && live) in.load(lp + (size_t)(jn - 1) * JREC * pair_bytes<T>(), hoff);
+    if (PF && t_ + 1 < tm.T_up && jn > 0 && live) in.load(lp + (size_t)(jn - 1) * JREC * pair_bytes<T>());
     step_barrier(nw);
   }
   sweep_barrier(nw);
@@ -1092,13 +1126,13 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const StepDesc* __restrict__ sched_
   char* srec = lp + (size_t)L.off_s * pair_bytes<T>();
 
   const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST),
-                               tg01 = ldp<T>(srec, SP_TAG), tg2 = ldp<T>(srec, SP_TAG + 1);
+                               tg01 = ldp<T>(srec, SP_TAG);
   int status = inb ? (int)st2.x : ST_DONE;
   int iter = (int)bi2.y;
   T mu = mu2.x;
   int kexp = (int)mu2.y;                      // mu = mu0 * 10^kexp
-  int klast = (int)st2.y;                     // decade of the last executed iteration (for the His/UDinv getters)
-  T tag0 = tg01.x, tag1 = tg01.y, tag2 = tg2.x;  // mu each H-cache slot holds (-1: empty)
+  T mu_last = st2.y;                          // mu of the last executed iteration (for the His / pis / UDinv getters)
+  T tag = tg01.x;                             // mu the cached UDinv / Dinv were computed with (-1: none)
   const T bnorm = bi2.x;
   bool live = inb && !(status & ST_DONE);
   // main-loop bound `for (i = 1; i < max_iter; ++i)` (hpp:377): nothing to do when max_iter <= 1
@@ -1125,35 +1159,27 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const StepDesc* __restrict__ sched_
     const T mu_in = mu;
     Norms<T> N;
     N.reset();
-    if (live) { ++iter; ++my_iters; klast = kexp; }
+    if (live) { ++iter; ++my_iters; mu_last = mu; status &= ~ST_PFULL; }
 
-    // H-cache slot of this lane's current mu (slot = kexp mod 3) and whether it holds that mu
-    const int slot = ((kexp % NSLOT) + NSLOT) % NSLOT;
-    const size_t hoff = (size_t)slot * SLOT_PAIRS * pair_bytes<T>();
-    const T tag = slot == 0 ? tag0 : (slot == 1 ? tag1 : tag2);
     // leaf -> root sweep of this iteration, unless the previous iteration's fused sweep already did it
     if (!have_p) {
       const bool need_h = !(P.mode & MODE_CACHE_H) || __any(live && (tag != mu));
       n_h_iters += need_h;
       if (need_h) {
-        sweep_bwd<T, true, HDIAG>(P, Bf, tm, w, nw, edge, lp, lane, live, mu_eq, mu_in, hoff);
-        if (live) {
-          if (slot == 0) tag0 = mu;
-          else if (slot == 1) tag1 = mu;
-          else tag2 = mu;
-        }
+        sweep_bwd<T, true, HDIAG>(P, Bf, tm, w, nw, edge, lp, lane, live, mu_eq, mu_in);
+        if (live) tag = mu;
       } else {
-        sweep_bwd<T, false, HDIAG>(P, Bf, tm, w, nw, edge, lp, lane, live, mu_eq, mu_in, hoff);
+        sweep_bwd<T, false, HDIAG>(P, Bf, tm, w, nw, edge, lp, lane, live, mu_eq, mu_in);
       }
     }
-    sweep_fwd<T, HDIAG, TEAM>(P, Bf, tm, w, nw, edge + (size_t)tm.edge_ent * WAVE, lp, lane, live, mu_eq, mu_in, hoff, N);
+    sweep_fwd<T, HDIAG, TEAM>(P, Bf, tm, w, nw, edge + (size_t)tm.edge_ent * WAVE, lp, lane, live, mu_eq, mu_in, N);
     ++n_tile_iters;
     n_fused_iters += ((P.mode & MODE_CACHE_H) && spec);
     if ((P.mode & MODE_CACHE_H) && spec) {
-      sweep_fused<T, HDIAG, TEAM>(P, Bf, tm, w, nw, edge, lp, lane, live, mu_eq, mu_in, hoff, N);
+      sweep_fused<T, HDIAG, TEAM>(P, Bf, tm, w, nw, edge, lp, lane, live, mu_eq, mu_in, N);
       have_p = true;
     } else {
-      sweep_bwd2<T, HDIAG>(P, Bf, tm, w, nw, edge, lp, lane, live, N);
+      sweep_bwd2<T, HDIAG>(P, Bf, tm, w, nw, edge, lp, lane, live, mu_eq, N);
       have_p = false;
     }
     if (nw > 1) N.team_combine(edge, w, nw, lane);
@@ -1247,10 +1273,9 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const StepDesc* __restrict__ sched_
 
   if (inb && w == 0) {
     stp<T>(srec, SP_MU, mu, (T)kexp);
-    stp<T>(srec, SP_TAG, tag0, tag1);
-    stp<T>(srec, SP_TAG + 1, tag2, T(0));
+    stp<T>(srec, SP_TAG, tag, T(0));
     stp<T>(srec, SP_BI, bnorm, (T)iter);
-    stp<T>(srec, SP_ST, (T)status, (T)klast);
+    stp<T>(srec, SP_ST, (T)status, mu_last);
   }
   const unsigned long long live_mask = __ballot(live);
   unsigned int it_sum = my_iters;
@@ -1343,28 +1368,99 @@ __global__ void k_upload_rows(const double* __restrict__ src, int n, int shared,
 }
 
 // tile elements -> instance-major [B][n] doubles; as_int: write int32 instead
-// h_slot: the rows address H-cache slot 0; shift them to the slot of the instance's current mu
 template <typename T>
 __global__ void k_download_rows(char* tiles, Layout L, const int* __restrict__ rowmap, int n, int B,
-                                double* __restrict__ dst, int as_int, int mask, int h_slot)
+                                double* __restrict__ dst, int as_int, int mask)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   char* lp = lane_ptr<T>(tiles, L, b);
-  int shift = 0;
-  if (h_slot) {
-    const int kexp = (int)*elem_ptr<T>(lp + (size_t)L.off_s * pair_bytes<T>(), SP_ST, 1);
-    shift = (((kexp % NSLOT) + NSLOT) % NSLOT) * SLOT_PAIRS * 2;
-  }
   for (int r = 0; r < n; ++r) {
-    const int m = rowmap[r] + shift;
+    const int m = rowmap[r];
     const T x = *elem_ptr<T>(lp, m >> 1, m & 1);
     if (as_int) {
       const int v = (int)x;
-      reinterpret_cast<int*>(dst)[(size_t)b * n + r] = mask ? ((v & mask) ? 1 : 0) : v;
+      // mask > 0: flag test; mask < 0: keep the bits of -mask; 0: the value itself
+      reinterpret_cast<int*>(dst)[(size_t)b * n + r] = mask > 0 ? ((v & mask) ? 1 : 0) : (mask < 0 ? (v & -mask) : v);
     } else {
       dst[(size_t)b * n + r] = (double)x;
     }
+  }
+}
+
+// ---- getters for quantities the hot path no longer materialises -----------------------------------------------
+// ik_id_data.His[i] (accumulated, pre-projection: what upstream leaves in His after BwdPass, hxx:60-67) for the mu of
+// the last executed iteration.  One instance per thread, out = [B][nb][21]; the output rows double as the running
+// accumulators of the leaf -> root recursion.  Same arithmetic as sweep_bwd<.., true, ..>.
+template <typename T>
+__global__ void k_rebuild_his(const char* tiles, Layout L, const JointDesc* __restrict__ jd, const T* __restrict__ uni,
+                              T rho, T mu_scale, const T* __restrict__ Href, int a_shared, int B, double* __restrict__ out)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const char* lp = lane_ptr<T>(const_cast<char*>(tiles), L, b);
+  const T mu = *elem_ptr<T>(const_cast<char*>(lp) + (size_t)L.off_s * pair_bytes<T>(), SP_ST, 1);
+  const T mu_eq = mu_scale * mu, mu_in = mu;
+  double* o = out + (size_t)b * L.nb * 21;
+  for (int i = 1; i <= L.nb; ++i) {
+    for (int r = 0; r < 6; ++r)
+      for (int c = r; c < 6; ++c) o[(i - 1) * 21 + sym(r, c)] = (double)((r == c ? rho : T(0)) + Href[6 * r + c]);
+    if (jd[i].cslot >= 0) {
+      const int cs = jd[i].cslot;
+      for (int k = 0; k < 21; ++k) {
+        const T a = a_shared ? uni[L.nc * 36 + cs * 21 + k]
+                             : *elem_ptr<T>(const_cast<char*>(lp) + (size_t)(L.off_c + cs * L.crec) * pair_bytes<T>(), CP_ATA + k / 2, k & 1);
+        o[(i - 1) * 21 + k] += (double)(mu_eq * a);
+      }
+    }
+  }
+  for (int i = L.nb; i >= 1; --i) {
+    const JointDesc d = jd[i];
+    if (d.parent == 0) continue;
+    T hh[21], U[6], UD[6], R[9], t[3], part[21];
+    for (int k = 0; k < 21; ++k) hh[k] = (T)o[(i - 1) * 21 + k];
+    const int a0 = (d.flags & JF_REVOLUTE) ? 3 : 0;
+    const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
+    for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, a0)] * ax0 + hh[sym(k, a0 + 1)] * ax1 + hh[sym(k, a0 + 2)] * ax2;
+    const T dd = T(1) / ((ax0 * U[a0] + ax1 * U[a0 + 1] + ax2 * U[a0 + 2]) + mu_in);
+    for (int k = 0; k < 6; ++k) UD[k] = U[k] * dd;
+    for (int r = 0; r < 6; ++r)
+      for (int c = r; c < 6; ++c) hh[sym(r, c)] -= UD[r] * U[c];
+    const typename Vec2<T>::type cs = ldp<T>(lp + (size_t)(i - 1) * JREC * pair_bytes<T>(), JP_CS);
+    make_liMi(d, cs.x, cs.y, R, t);
+    congr_sym(R, t, hh, part);
+    for (int k = 0; k < 21; ++k) o[(d.parent - 1) * 21 + k] += (double)part[k];
+  }
+}
+
+// ik_id_data.pis[i] (accumulated p_i of the last backward pass, hxx:70-75) from the stored p_i^base, UDinv_i, r_i.
+// k_tail leaves the accumulated p_i itself in the slot and flags the instance ST_PFULL.
+template <typename T>
+__global__ void k_rebuild_pis(const char* tiles, Layout L, const JointDesc* __restrict__ jd, int B, double* __restrict__ out)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const char* lp = lane_ptr<T>(const_cast<char*>(tiles), L, b);
+  const int status = (int)*elem_ptr<T>(const_cast<char*>(lp) + (size_t)L.off_s * pair_bytes<T>(), SP_ST, 0);
+  double* o = out + (size_t)b * L.nb * 6;
+  for (int i = 1; i <= L.nb; ++i) {
+    T p[6];
+    ld6<T>(lp + (size_t)(i - 1) * JREC * pair_bytes<T>(), JP_P, p);
+    for (int k = 0; k < 6; ++k) o[(i - 1) * 6 + k] = (double)p[k];
+  }
+  if (status & ST_PFULL) return;
+  for (int i = L.nb; i >= 1; --i) {
+    const JointDesc d = jd[i];
+    if (d.parent == 0) continue;
+    const char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
+    T UD[6], pa[6], pc[6], R[9], t[3];
+    ld6<T>(rec, JP_UD, UD);
+    const T ri = ldp<T>(rec, JP_R).x;
+    for (int k = 0; k < 6; ++k) pa[k] = (T)o[(i - 1) * 6 + k] - UD[k] * ri;
+    const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS);
+    make_liMi(d, cs.x, cs.y, R, t);
+    act_force(R, t, pa, pc);
+    for (int k = 0; k < 6; ++k) o[(d.parent - 1) * 6 + k] += (double)pc[k];
   }
 }
 

@@ -1389,7 +1389,7 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   const int nb = S->nb;
   std::vector<int> rm;
   bool is_int = false;
-  int mask = 0, h_slot = 0;
+  int mask = 0;
   auto per_joint = [&](int pair, int half) { for (int j = 0; j < nb; ++j) rm.push_back((j * JREC + pair) * 2 + half); };
   auto per_joint_vec = [&](int pair, int n) {
     for (int j = 0; j < nb; ++j)
@@ -1405,18 +1405,19 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   case LOIKB_F_W: per_joint(JP_WZ, 0); break;
   case LOIKB_F_STF_PLUS_W: per_joint(JP_NUS, 1); break;
   case LOIKB_F_R: per_joint(JP_R, 0); break;
-  case LOIKB_F_DINV: per_joint(JP_SLOT0 + SL_H + 10, 1); h_slot = 1; break;
+  case LOIKB_F_DINV: per_joint(JP_R, 1); break;
   case LOIKB_F_VIS: per_joint_vec(JP_V, 6); break;
   case LOIKB_F_FIS: per_joint_vec(JP_F, 6); break;
   case LOIKB_F_G: per_joint_vec(JP_G, 6); break;
-  case LOIKB_F_PIS: per_joint_vec(JP_P, 6); break;
-  case LOIKB_F_UDINV: per_joint_vec(JP_SLOT0 + SL_UD, 6); h_slot = 1; break;
-  case LOIKB_F_HIS: per_joint_vec(JP_SLOT0 + SL_H, 21); h_slot = 1; break;
+  case LOIKB_F_PIS: break;  // the hot path keeps p_i^base: the accumulated p_i is rebuilt below
+  case LOIKB_F_UDINV: per_joint_vec(JP_UD, 6); break;
+  case LOIKB_F_HIS: break;  // not materialised by the hot path: rebuilt below
+
   case LOIKB_F_YIS: per_constraint_vec(CP_Y); break;
   case LOIKB_F_ATY: per_constraint_vec(CP_ATY); break;
   case LOIKB_F_LIMI: break;
   case LOIKB_F_ITER: is_int = true; rm.push_back((L.off_s + SP_BI) * 2 + 1); break;
-  case LOIKB_F_STATUS: is_int = true; rm.push_back((L.off_s + SP_ST) * 2); break;
+  case LOIKB_F_STATUS: is_int = true; mask = -(ST_CONVERGED | ST_PRIMAL_INF | ST_TAIL | ST_DONE); rm.push_back((L.off_s + SP_ST) * 2); break;
   case LOIKB_F_CONVERGED: is_int = true; mask = ST_CONVERGED; rm.push_back((L.off_s + SP_ST) * 2); break;
   case LOIKB_F_PRIMAL_INFEASIBLE: is_int = true; mask = ST_PRIMAL_INF; rm.push_back((L.off_s + SP_ST) * 2); break;
   case LOIKB_F_MU: rm.push_back((L.off_s + SP_MU) * 2); break;  // per-instance mu_ (== mu0 right after ResetSolver)
@@ -1429,7 +1430,8 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
       return LOIKB_ERR_ARG;
     }
   }
-  const int n = field == LOIKB_F_LIMI ? 12 * nb : (int)rm.size();
+  const int n = field == LOIKB_F_LIMI ? 12 * nb : field == LOIKB_F_HIS ? 21 * nb : field == LOIKB_F_PIS ? 6 * nb
+                                                                                                          : (int)rm.size();
   const size_t bytes = (is_int ? sizeof(int) : sizeof(double)) * (size_t)S->B * n;
   double* dst = (double*)out;
   int rc;
@@ -1437,17 +1439,42 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
     if ((rc = ensure_stage(S, bytes))) return rc;
     dst = (double*)S->d_stage;
   }
-  if (field == LOIKB_F_LIMI) {
+  if (field == LOIKB_F_HIS) {
+    // device copy of H_ref in the solve precision (d_stage may be the output buffer: use the uniform buffer's tail?)
+    // -> small separate upload each call: getters are not on the hot path
+    void* d_href = nullptr;
+    HIPCHK(hipMalloc(&d_href, 36 * S->esz));
+    if (S->f32) {
+      float h[36];
+      for (int k = 0; k < 36; ++k) h[k] = (float)S->Href[k];
+      HIPCHK(hipMemcpyAsync(d_href, h, sizeof(h), hipMemcpyHostToDevice, S->stream));
+      HIPCHK(hipStreamSynchronize(S->stream));
+      hipLaunchKernelGGL(k_rebuild_his<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd,
+                         (const float*)S->d_uni, (float)S->opt.rho, (float)S->opt.mu_equality_scale_factor,
+                         (const float*)d_href, (int)S->a_shared, S->B, dst);
+    } else {
+      HIPCHK(hipMemcpyAsync(d_href, S->Href, sizeof(double) * 36, hipMemcpyHostToDevice, S->stream));
+      hipLaunchKernelGGL(k_rebuild_his<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd,
+                         (const double*)S->d_uni, (double)S->opt.rho, (double)S->opt.mu_equality_scale_factor,
+                         (const double*)d_href, (int)S->a_shared, S->B, dst);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(S->stream));
+    HIPCHK(hipFree(d_href));
+  } else if (field == LOIKB_F_PIS) {
+    if (S->f32) hipLaunchKernelGGL(k_rebuild_pis<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->B, dst);
+    else hipLaunchKernelGGL(k_rebuild_pis<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->B, dst);
+  } else if (field == LOIKB_F_LIMI) {
     if (S->f32) hipLaunchKernelGGL(k_limi<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->B, dst);
     else hipLaunchKernelGGL(k_limi<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->B, dst);
   } else {
     if ((rc = set_rowmap(S, rm))) return rc;
     if (S->f32)
       hipLaunchKernelGGL(k_download_rows<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_rowmap, n,
-                         S->B, dst, (int)is_int, mask, h_slot);
+                         S->B, dst, (int)is_int, mask);
     else
       hipLaunchKernelGGL(k_download_rows<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_rowmap, n,
-                         S->B, dst, (int)is_int, mask, h_slot);
+                         S->B, dst, (int)is_int, mask);
   }
   HIPCHK(hipGetLastError());
   if (!to_dev) HIPCHK(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, S->stream));

@@ -152,22 +152,12 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
   T mu = mu2.x;
   int kexp = (int)mu2.y;         // mu = mu0 * 10^kexp
+  const T tg_in = ldp<T>(srec, SP_TAG).x;
   T mu_h = T(-1), mu_o = T(-1);  // mu of the current / the other H slot: nothing cached yet
   int hsl = 0;                   // current H slot
-  if ((P.mode & MODE_CACHE_H) && NSLOT == 1 && isj && ldp<T>(srec, SP_TAG).x == mu) {
-    // the instance arrives with a valid H cache for its current mu (left by k_solve or by an earlier launch of this
-    // kernel): take it over instead of rebuilding it in the first iteration
-    const char* hrec = rec + (size_t)JP_SLOT0 * pair_bytes<T>();
-    ld6<T>(hrec, SL_UD, UD);
-#pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const typename Vec2<T>::type a = ldp<T>(hrec, SL_H + k);
-      hst[(size_t)lane * HS + 2 * k] = a.x;
-      hst[(size_t)lane * HS + 2 * k + 1] = a.y;
-      if (k == 10) dinv = a.y;
-    }
-    mu_h = mu;
-  }
+  // (H_i is not kept in HBM -- k_solve gets f_i from the force-balance recursion -- so the first iteration of a
+  //  launch rebuilds this instance's H cache; this kernel keeps f_i = H_i v_i + p_i: H_i sits in LDS anyway and the
+  //  extra recursion over the tree levels would cost more than the 36 multiply-adds per joint.)
   const T bnorm = bi2.x;
   int iter = (int)bi2.y;
   int status = has_inst ? (int)st2.x : ST_DONE;
@@ -516,17 +506,11 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     stp<T>(rec, JP_WZ, w, z);
     stp<T>(rec, JP_NUS, nu, s);
     if (any_iter) {
-      // inter-sweep temporaries of the LAST iteration (His, pis, UDinv, Dinv, r), as upstream leaves them
-      // (they belong to the mu of the last iteration: slot of mu_h's decade; getters read the slot of the final mu,
-      //  which is the same unless the very last epilogue changed mu at the iteration bound)
-      const T* hcur = hst + ((size_t)hsl * WAVE + lane) * HS;
-      const int kh = kexp + (mu_h == mu ? 0 : (mu_h > mu ? 1 : -1));
-      char* hrec = rec + (size_t)(JP_SLOT0 + (((kh % NSLOT) + NSLOT) % NSLOT) * SLOT_PAIRS) * pair_bytes<T>();
+      // inter-sweep temporaries of the LAST iteration (pis, UDinv, Dinv, r), as upstream leaves them: here the
+      // accumulated p_i itself (flagged ST_PFULL below; k_solve stores p_i^base in that slot)
       st6<T>(rec, JP_P, p);
-      st6<T>(hrec, SL_UD, UD);
-      stp<T>(rec, JP_R, r, T(0));
-#pragma unroll
-      for (int k = 0; k < 11; ++k) stp<T>(hrec, SL_H + k, hcur[2 * k], 2 * k + 1 < 21 ? hcur[2 * k + 1] : dinv);
+      st6<T>(rec, JP_UD, UD);
+      stp<T>(rec, JP_R, r, dinv);
     }
   }
   tail_sync();
@@ -541,18 +525,10 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     }
     if (jlane == 0) {
       stp<T>(srec, SP_MU, mu, (T)kexp);
-      {  // H-cache tags: only the slot written above is valid
-        const int kh = kexp + (mu_h == mu ? 0 : (mu_h > mu ? 1 : -1));
-        const int sl = ((kh % NSLOT) + NSLOT) % NSLOT;
-        const T tv = any_iter ? mu_h : T(-1);
-        stp<T>(srec, SP_TAG, sl == 0 ? tv : T(-1), sl == 1 ? tv : T(-1));
-        stp<T>(srec, SP_TAG + 1, sl == 2 ? tv : T(-1), T(0));
-      }
+      // the UDinv / Dinv written above belong to mu_h, the mu of the last executed iteration
+      stp<T>(srec, SP_TAG, any_iter ? mu_h : tg_in, T(0));
       stp<T>(srec, SP_BI, bnorm, (T)iter);
-      {
-        const int kh = kexp + (mu_h == mu ? 0 : (mu_h > mu ? 1 : -1));
-        stp<T>(srec, SP_ST, (T)status, any_iter ? (T)kh : st2.y);
-      }
+      stp<T>(srec, SP_ST, (T)(any_iter ? (status | ST_PFULL) : status), any_iter ? mu_h : st2.y);
       if (any_iter) {
         stp<T>(srec, SP_SCAL + 0, primal, dual);
         stp<T>(srec, SP_SCAL + 1, pr_task, pr_slack);
