@@ -1108,6 +1108,10 @@ __device__ __forceinline__ void st_scal(char* srec, int idx, T x)
 // persistent solve kernel: each wavefront iterates its 64 instances until all are done (or the launch
 // iteration budget is spent).  No inter-wavefront communication: instances are independent.
 // ------------------------------------------------------------------------------------------------
+// (A build capped at 256 registers -- amdgpu_waves_per_eu(2,2), two workgroups per CU, the H sweep spilling ~330 B/lane
+//  to scratch -- was measured: 289 vs 186 M instance-iterations/s in a 100-iteration steady-state run at B = 65536, but
+//  on the real workload (8-iteration launches, H rebuilt at every iteration) every launch is slower, 2.54 vs 2.08 ms
+//  for the first one, 47.1 vs 45.4 ms/step.  One wavefront per SIMD with the whole register file it is.)
 template <typename T, bool HDIAG, bool TEAM>
 __global__ void __launch_bounds__(TEAM ? WAVE * MAX_TEAM : WAVE)
 k_solve(const Params<T> P, const Bufs<T> Bf, const StepDesc* __restrict__ sched_up,
