@@ -27,7 +27,9 @@ struct TailTopo {
   int pad;
 };
 
-constexpr int XS = 28;  // scalars per lane in the exchange buffer: 21 (H) + 6 (p / v / f) + 1 pad
+constexpr int XS = 28;  // scalars per lane in the exchange buffer: 21 (H) + 1 pad + 6 (p / v / f)
+constexpr int XC = 22;  // first of the 6 exchange columns for p / v (16-byte aligned: read as three b128)
+constexpr int XROWS = WAVE + 1;  // one exchange row per lane + a row of zeros ("no parent" / "no such child")
 constexpr int HS = 22;  // scalars per lane and mu-slot in the H store: H[21], Dinv  (4 wavefronts/CU fit in 160 KiB)
 constexpr int TAIL_WAVES = 4;  // wavefronts per workgroup of the tail kernel (one per SIMD of a CU; fewer if their LDS does not fit)
 constexpr int CD = 82;  // per-constraint LDS block: A[36] AtA[21] pad b[6] Atb[6] y[6] aty[6]
@@ -60,7 +62,7 @@ __device__ __forceinline__ T group_sum(T x, int G)
 template <typename T>
 __host__ __device__ __forceinline__ size_t tail_lds_bytes(int nc, int G)
 {
-  return ((((size_t)WAVE * XS + 2 * (size_t)WAVE * HS + (size_t)(WAVE / G) * nc * CD) * sizeof(T)) + 15) & ~(size_t)15;
+  return ((((size_t)XROWS * XS + 2 * (size_t)WAVE * HS + (size_t)(WAVE / G) * nc * CD) * sizeof(T)) + 15) & ~(size_t)15;
 }
 
 template <typename T, bool HDIAG>
@@ -77,7 +79,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const size_t wave_lds = tail_lds_bytes<T>(L.nc, G);
   T* xch = reinterpret_cast<T*>(smem_raw + wv * wave_lds);  // [WAVE][XS]  exchange between a joint and its parent / children
-  T* hst = xch + WAVE * XS;                 // [2][WAVE][HS]   this joint's H (pre-projection) for two values of mu
+  T* hst = xch + XROWS * XS;                // [2][WAVE][HS]   this joint's H (pre-projection) for two values of mu
   T* cd = hst + 2 * WAVE * HS;              // [64/G][nc][CD]  constraint data of every instance of the wavefront
   const int lane = threadIdx.x & (WAVE - 1);
   const int sub = lane / G, jlane = lane % G, gbase = sub * G;
@@ -105,7 +107,13 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   constexpr int NCH_REG = 4;
   int chl[NCH_REG];
 #pragma unroll
-  for (int c = 0; c < NCH_REG; ++c) chl[c] = gbase + (c < tp.nchild ? child_list[tp.child_start + c] : 0);
+  for (int c = 0; c < NCH_REG; ++c) chl[c] = c < tp.nchild ? gbase + child_list[tp.child_start + c] : WAVE;  // WAVE: the zero row
+  const int prow = has_parent ? plane : WAVE;  // exchange row of the parent's velocity (zero row under the universe)
+  // S_i as a 6-vector: v' + S nu and S^T p become plain multiply-adds, no branch on the joint type in the loops
+  T Sv[6];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { Sv[k] = rev ? T(0) : (T)d.axis[k]; Sv[3 + k] = rev ? (T)d.axis[k] : T(0); }
+  if (lane < XS) xch[WAVE * XS + lane] = T(0);
 
   // ---- load the instance: joint j -> lane j of the group -----------------------------------------------------
   T R[9], t[3], v[6], f[6], g[6], UD[6], UDo[6], p[6];
@@ -220,6 +228,46 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         for (int k = 0; k < 6; ++k) p[k] += c_[CD_ATY + k] - mu_eq * c_[CD_ATB + k];
       }
     }
+    // Two forms of the leaf -> root recursion.  While some instance of the wavefront rebuilds its H cache: the masked
+    // level loop (only the lanes of a level work, the 21 entries of H travel with p).  Otherwise (95-98 % of the
+    // iterations) the LEAN loop: every lane recomputes p_i = p_i^base + sum of its children's exchange rows at every
+    // level -- a joint of height h is final after h levels and simply recomputes the same value afterwards -- so the
+    // body is branch-free and select-free, all lanes active, no per-level bookkeeping of who is "at" the level.
+    const bool lean = !__any(need_h) && maxchild <= NCH_REG;
+    if (lean) {
+      T pl[6], rl = T(0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pl[k] = p[k];
+      for (int lev = maxdepth; lev >= 1; --lev) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pl[k] = p[k];  // p still holds p^base
+#pragma unroll
+        for (int c = 0; c < NCH_REG; ++c) {
+          if (c < maxchild) {  // uniform
+            const T* x = xch + chl[c] * XS + XC;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pl[k] += x[k];
+          }
+        }
+        T Stp = Sv[0] * pl[0];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) Stp += Sv[k] * pl[k];
+        rl = (w - mu_in * z) + Stp;
+        T pa[6], pc[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pa[k] = pl[k] - UD[k] * rl;
+        act_force(R, t, pa, pc);
+        tail_sync();  // every lane has read its children's rows of the previous level
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xch[lane * XS + XC + k] = pc[k];
+        tail_sync();
+      }
+      if (act) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p[k] = pl[k];
+        r = rl;
+      }
+    } else
     for (int lev = maxdepth; lev >= 1; --lev) {
       if (act && depth == lev) {
         // children contributions (deposited one level deeper), largest child index first as upstream
@@ -233,7 +281,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
               for (int k = 0; k < 21; ++k) hh[k] += x[k];
             }
 #pragma unroll
-            for (int k = 0; k < 6; ++k) p[k] += x[21 + k];
+            for (int k = 0; k < 6; ++k) p[k] += x[XC + k];
           }
         }
         T U[6];
@@ -272,7 +320,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
           for (int k = 0; k < 6; ++k) pa[k] = p[k] - UD[k] * r;
           act_force(R, t, pa, pc);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) x[21 + k] = pc[k];
+          for (int k = 0; k < 6; ++k) x[XC + k] = pc[k];
         }
       }
       tail_sync();
@@ -282,31 +330,25 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     // ================= root -> leaf: FwdPass2 + BoxProj + DualUpdate (hxx:102-163, :384-461) ==================
     // Only nu_i / v_i form a recursion over the tree: the level loop carries just that.  Everything else of the pass
     // (f_i = H_i v_i + p_i, the projections, the dual updates, the norms) is per-joint work, done ONCE by all lanes.
+    // Lean form as above: every lane recomputes (nu_i, v_i) from its parent's exchange row at every level; a joint at
+    // depth d is final after d levels.
     T vi[6], nui = T(0);
 #pragma unroll
     for (int k = 0; k < 6; ++k) vi[k] = T(0);
     for (int lev = 1; lev <= maxdepth; ++lev) {
-      if (act && depth == lev) {
-        T vpar[6], vp[6];
-        if (has_parent) {
+      T vpar[6], vp[6];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) vpar[k] = xch[plane * XS + 21 + k];
-        } else {
+      for (int k = 0; k < 6; ++k) vpar[k] = xch[prow * XS + XC + k];
+      actinv_motion(R, t, vpar, vp);  // hxx:125
+      T udv = UD[0] * vp[0];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) vpar[k] = T(0);
-        }
-        actinv_motion(R, t, vpar, vp);  // hxx:125
-        T udv = UD[0] * vp[0];
+      for (int k = 1; k < 6; ++k) udv += UD[k] * vp[k];
+      nui = -udv - dinv * r;          // hxx:127
 #pragma unroll
-        for (int k = 1; k < 6; ++k) udv += UD[k] * vp[k];
-        nui = -udv - dinv * r;          // hxx:127
+      for (int k = 0; k < 6; ++k) vi[k] = vp[k] + Sv[k] * nui;  // hxx:133-134
+      tail_sync();  // every lane has read its parent's row of the previous level
 #pragma unroll
-        for (int k = 0; k < 6; ++k) vi[k] = vp[k];
-        if (rev) { vi[3] += ax0 * nui; vi[4] += ax1 * nui; vi[5] += ax2 * nui; }
-        else { vi[0] += ax0 * nui; vi[1] += ax1 * nui; vi[2] += ax2 * nui; }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) xch[lane * XS + 21 + k] = vi[k];
-      }
+      for (int k = 0; k < 6; ++k) xch[lane * XS + XC + k] = vi[k];
       tail_sync();
     }
     T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_dyis = T(0),
