@@ -27,7 +27,9 @@ struct TailTopo {
   int pad;
 };
 
-constexpr int XS = 28;  // scalars per lane in the exchange buffer: 21 (H) + 1 pad + 6 (p / v / f)
+constexpr int XS = 30;  // scalars per lane in the exchange buffer: 21 (H) + 1 pad + 6 (p / v / f) + 2 pad.  The row stride is
+                        // an ODD number of 16-byte slots (15): b128 accesses of consecutive lanes do not collide
+                        // (with 28 = 14 slots the PMC counters showed 36 % of the LDS cycles in bank conflicts)
 constexpr int XC = 22;  // first of the 6 exchange columns for p / v (16-byte aligned: read as three b128)
 constexpr int XROWS = WAVE + 1;  // one exchange row per lane + a row of zeros ("no parent" / "no such child")
 constexpr int HS = 22;  // scalars per lane and mu-slot in the H store: H[21], Dinv  (4 wavefronts/CU fit in 160 KiB)
