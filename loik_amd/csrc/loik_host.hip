@@ -80,6 +80,7 @@ struct loikb_solver_impl {
   bool href_diag = true;  // H_ref diagonal -> k_solve<T, true>
   // device
   int device = 0;
+  int ncu = 256;  // compute units of the device
   hipStream_t stream = nullptr;
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   std::vector<void*> allocs;
@@ -800,11 +801,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
   // The kernel keeps one wavefront per SIMD resident (register budget): `resident` instances run concurrently.
   // With more live instances than that, bounded launches keep every wavefront busy (instances finish at very
   // different iterations; the survivors are re-listed and re-paired) -- once they all fit, one launch runs them out.
-  int ncu = 256;
-  {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, S->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-  }
+  const int ncu = S->ncu;
   const int resident = std::max(ipw, (int)(ncu * 4 * ipw * ((double)C->B / (double)S->B)));
   int round_iters = 64;
   if (const char* e = getenv("LOIKB_TAIL_ROUND")) round_iters = atoi(e);
@@ -909,9 +906,16 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
   unsigned long long inst_iters = 0;
   unsigned int n_live = 0;
   while (true) {
-    const bool may_compact_later = can_compact && n_cur > compact_min;
+    // Latency-bound regime: once the chunk's tiles fit its share of the CUs (one workgroup per CU), an iteration
+    // costs the same however few tiles are left -- repacking buys nothing any more and every launch boundary costs a
+    // host round trip plus the kernel's prologue/epilogue, so the launches get longer.
+    const int tiles_cur = (n_cur + WAVE - 1) / WAVE;
+    const bool latency_bound = tiles_cur * (int)S->chunks.size() <= S->ncu;
+    const bool may_compact_later = can_compact && n_cur > compact_min && !latency_bound;
+    int lat_iters = 16;
+    if (const char* e = getenv("LOIKB_LAT_ITERS")) lat_iters = atoi(e);
     int launch_iters = S->opt.max_launch_iters > 0 ? S->opt.max_launch_iters
-                                                   : ((may_compact_later || use_tail) ? 8 : max_total);
+                       : (may_compact_later ? 8 : (use_tail || (can_compact && n_cur > compact_min)) ? lat_iters : max_total);
     if (launch_iters > max_total - done_iters) launch_iters = max_total - done_iters;
     P.B = n_cur;
     P.max_launch_iters = launch_iters;
@@ -1176,6 +1180,10 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
 #define TRY(x) do { int _rc = (x); if (_rc) return fail(_rc); } while (0)
 #define HIPTRY(x) do { hipError_t _e = (x); if (_e != hipSuccess) { g_last_error = std::string(#x) + ": " + hipGetErrorString(_e); return fail(LOIKB_ERR_HIP); } } while (0)
   HIPTRY(hipSetDevice(S->device));
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, S->device) == hipSuccess && prop.multiProcessorCount > 0) S->ncu = prop.multiProcessorCount;
+  }
   HIPTRY(hipEventCreate(&S->ev_t0));
   HIPTRY(hipEventCreate(&S->ev_t1));
   HIPTRY(hipEventCreate(&S->ev_fork));
