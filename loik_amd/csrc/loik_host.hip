@@ -910,7 +910,8 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
     // costs the same however few tiles are left -- repacking buys nothing any more and every launch boundary costs a
     // host round trip plus the kernel's prologue/epilogue, so the launches get longer.
     const int tiles_cur = (n_cur + WAVE - 1) / WAVE;
-    const bool latency_bound = tiles_cur * (int)S->chunks.size() <= S->ncu;
+    // (an explicit compact_min_instances is the caller's policy: it is honoured as given)
+    const bool latency_bound = S->opt.compact_min_instances <= 0 && tiles_cur * (int)S->chunks.size() <= S->ncu;
     const bool may_compact_later = can_compact && n_cur > compact_min && !latency_bound;
     int lat_iters = 16;
     if (const char* e = getenv("LOIKB_LAT_ITERS")) lat_iters = atoi(e);
