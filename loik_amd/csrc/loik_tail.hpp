@@ -35,7 +35,8 @@ constexpr int XROWS = WAVE + 1;  // one exchange row per lane + a row of zeros (
 constexpr int HS = 22;  // scalars per lane and mu-slot in the H store: H[21], Dinv  (4 wavefronts/CU fit in 160 KiB)
 constexpr int TAIL_WAVES = 4;  // wavefronts per workgroup of the tail kernel (one per SIMD of a CU; fewer if their LDS does not fit)
 constexpr int CD = 82;  // per-constraint LDS block: A[36] AtA[21] pad b[6] Atb[6] y[6] aty[6]
-enum : int { CD_A = 0, CD_ATA = 36, CD_B = 58, CD_ATB = 64, CD_Y = 70, CD_ATY = 76 };
+enum : int { CD_A = 0, CD_ATA = 36, CD_PAD = 57 /* group lane of the constrained joint */, CD_B = 58, CD_ATB = 64, CD_Y = 70,
+             CD_ATY = 76 };
 
 // The kernel runs one wavefront per workgroup: LDS operations of a wavefront execute in program order, so an exchange
 // between lanes needs no hardware barrier -- only a fence that keeps the compiler from reordering the LDS accesses.
@@ -155,9 +156,10 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         const int pair = which == 0 ? CP_B : which == 1 ? CP_ATB : which == 2 ? CP_Y : CP_ATY;
         val = *reinterpret_cast<const T*>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
       }
-      cdi[c * CD + e] = val;
+      if (e != CD_PAD) cdi[c * CD + e] = val;
     }
   }
+  if (isj && d.cslot >= 0) cdi[d.cslot * CD + CD_PAD] = (T)jlane;  // which lane of the group owns the constrained joint
   // per-instance solver scalars: every lane of the group reads the same words
   const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
   T mu = mu2.x;
@@ -384,40 +386,38 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       w = w + dwi; z = zi; nu = nui;
 #pragma unroll
       for (int k = 0; k < 6; ++k) { v[k] = vi[k]; f[k] = fi[k]; }
-      if (d.cslot >= 0) {
-        T* c_ = cdi + d.cslot * CD;
-        T Av[6], e[6], yy[6];
+    }
+    // DualUpdate of the task constraints (hxx:410-451), spread over six lanes of the group: lane k < 6 owns row k of
+    // A v_c - b and of A^T y (the constrained joint's own lane used to do all 72 multiply-adds, i.e. the whole
+    // wavefront paid for them).  v_c is still in the joint's exchange row from the forward recursion.
+    for (int c = 0; c < L.nc; ++c) {
+      T* c_ = cdi + c * CD;
+      if (act && jlane < 6) {
+        const int k = jlane;
+        const T* vc = xch + (gbase + (int)c_[CD_PAD]) * XS + XC;
+        T avk = c_[CD_A + 6 * k] * vc[0];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          T acc = T(0);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) acc += c_[CD_A + 6 * a + k] * vi[k];
-          Av[a] = acc;
-        }
-        T plus = T(0), minus = T(0);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          const T bk = c_[CD_B + k];
-          e[k] = Av[k] - bk;
-          const T dy = mu_eq * e[k];
-          yy[k] = c_[CD_Y + k] + dy;
-          l_dyis = tmax(l_dyis, tabs(dy));
-          plus += bk * tmax(dy, T(0));
-          minus += bk * tmin(dy, T(0));
-        }
-        l_up += plus; l_lm += minus;
-        l_prt = inf6(e);
-        l_av = inf6(Av);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          T acc = T(0);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) acc += c_[CD_A + 6 * k + a] * yy[k];
-          c_[CD_ATY + a] = acc;
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c_[CD_Y + k] = yy[k];
+        for (int j = 1; j < 6; ++j) avk += c_[CD_A + 6 * k + j] * vc[j];
+        const T bk = c_[CD_B + k];
+        const T ek = avk - bk;
+        const T dy = mu_eq * ek;
+        const T yk = c_[CD_Y + k] + dy;
+        l_dyis = tmax(l_dyis, tabs(dy));
+        l_up += bk * tmax(dy, T(0));
+        l_lm += bk * tmin(dy, T(0));
+        l_prt = tmax(l_prt, tabs(ek));
+        l_av = tmax(l_av, tabs(avk));
+        c_[CD_Y + k] = yk;
       }
+      tail_sync();
+      if (act && jlane < 6) {
+        const int k = jlane;
+        T at = c_[CD_A + k] * c_[CD_Y];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) at += c_[CD_A + 6 * j + k] * c_[CD_Y + j];
+        c_[CD_ATY + k] = at;
+      }
+      tail_sync();
     }
 
     // ================= BwdPass2 + dual residual (hxx:185-241, :468-487) =========================================
