@@ -80,12 +80,9 @@ struct Layout {
   int tile_pairs;  // off_s + SREC
 };
 
-// joint-schedule flags (uniform per joint)
+// joint flags (uniform per joint)
 enum : int {
-  JF_LEAF = 1,            // no children: children-accumulator starts at 0
   JF_PARENT_ROOT = 2,     // parent is the universe: contribution discarded (update_I = parent > 0, hxx:63)
-  JF_LAST_CHILD = 4,      // largest-index child of its parent: first one visited in a leaf->root sweep
-  JF_NEXT_IS_PARENT = 8,  // i-1 == parent: partial sum stays in registers, else it is pushed to the LDS stack
   JF_REVOLUTE = 16,       // S = [0; axis], else prismatic S = [axis; 0]
 };
 

@@ -352,7 +352,7 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
   S->jtype.assign(m->jtype, m->jtype + nj);
   S->idx_q.assign(m->idx_q, m->idx_q + nj);
   S->idx_v.assign(m->idx_v, m->idx_v + nj);
-  std::vector<int> nchild(nj, 0), last_child(nj, -1), subtree_end(nj, 0);
+  std::vector<int> subtree_end(nj, 0);
   for (int i = 1; i < nj; ++i) {
     const int p = S->parents[i];
     if (p < 0 || p >= i) { g_last_error = "model: parents[i] must be < i"; return LOIKB_ERR_MODEL; }
@@ -364,8 +364,6 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
       g_last_error = "model: unsupported joint type";
       return LOIKB_ERR_MODEL;
     }
-    nchild[p]++;
-    last_child[p] = i;  // increasing i: ends as the largest-index child
   }
   // depth-first numbering check: descendants of every joint are the contiguous range (i, subtree_end[i]]
   for (int i = nj - 1; i >= 0; --i) subtree_end[i] = i;
@@ -396,10 +394,7 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
     }
     for (int k = 0; k < 3; ++k) d.axis[k] = ax[k];
     d.parent = S->parents[i];
-    if (nchild[i] == 0) flags |= JF_LEAF;
     if (d.parent == 0) flags |= JF_PARENT_ROOT;
-    if (last_child[d.parent] == i) flags |= JF_LAST_CHILD;
-    if (d.parent == i - 1) flags |= JF_NEXT_IS_PARENT;
     d.flags = flags;
     d.cslot = -1;
     d.rot = rot;
