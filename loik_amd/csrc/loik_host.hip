@@ -765,20 +765,25 @@ int compact(loikb_solver_impl* S, Chunk* C, int src, int dst, int n_src, int* n_
 // kernel (a lane group per instance, one joint per lane)
 template <typename T>
 int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, int n_live, double* ms_out,
-             unsigned long long* iters_out)
+             unsigned long long* iters_out, bool whole_set = false)
 {
   loikb_solver_impl::Set& A = C->set[cur];
   const int nw = (n_cur + WAVE - 1) / WAVE;
-  C->h_wave.resize(2 * (size_t)nw + 2);
-  int* cnt = C->h_wave.data();
-  int* off = cnt + nw + 1;
-  HIPCHK(hipMemcpyAsync(cnt, A.wave_live, sizeof(int) * nw, hipMemcpyDeviceToHost, C->stream));
-  HIPCHK(hipStreamSynchronize(C->stream));
-  int total = 0;
-  for (int w = 0; w < nw; ++w) { off[w] = total; total += cnt[w]; }
-  if (total != n_live) { g_last_error = "tail: live count mismatch"; return LOIKB_ERR_STATE; }
-  HIPCHK(hipMemcpyAsync(A.wave_off, off, sizeof(int) * nw, hipMemcpyHostToDevice, C->stream));
-  hipLaunchKernelGGL(k_list_live<T>, dim3(nw), dim3(WAVE), 0, C->stream, A.tiles, S->L, n_cur, A.wave_off, C->d_slots[0]);
+  if (whole_set) {
+    // every slot of the set (finished instances, if any, stop at once inside the kernel)
+    hipLaunchKernelGGL(k_list_iota, grid1(n_cur), dim3(256), 0, C->stream, C->d_slots[0], n_cur);
+  } else {
+    C->h_wave.resize(2 * (size_t)nw + 2);
+    int* cnt = C->h_wave.data();
+    int* off = cnt + nw + 1;
+    HIPCHK(hipMemcpyAsync(cnt, A.wave_live, sizeof(int) * nw, hipMemcpyDeviceToHost, C->stream));
+    HIPCHK(hipStreamSynchronize(C->stream));
+    int total = 0;
+    for (int w = 0; w < nw; ++w) { off[w] = total; total += cnt[w]; }
+    if (total != n_live) { g_last_error = "tail: live count mismatch"; return LOIKB_ERR_STATE; }
+    HIPCHK(hipMemcpyAsync(A.wave_off, off, sizeof(int) * nw, hipMemcpyHostToDevice, C->stream));
+    hipLaunchKernelGGL(k_list_live<T>, dim3(nw), dim3(WAVE), 0, C->stream, A.tiles, S->L, n_cur, A.wave_off, C->d_slots[0]);
+  }
   HIPCHK(hipGetLastError());
   Bufs<T> Bf = make_bufs<T>(S, C, cur);
   P.B = n_cur;
@@ -900,7 +905,25 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
   int done_iters = 0;
   unsigned long long inst_iters = 0;
   unsigned int n_live = 0;
-  while (true) {
+  // A batch that is below the hand-over threshold from the start never fills the machine with one instance per lane:
+  // it goes to the tail kernel (a lane group per instance, 12 us instead of 30-55 us per iteration) for the whole
+  // solve.  (Not when the caller fixed the launch length or asked for the solve kernel's bit-exact behaviour.)
+  const bool direct_tail = S->nb <= WAVE && S->opt.tail_max_instances >= 0 && S->opt.max_launch_iters <= 0 &&
+                           !(S->opt.flags & (LOIKB_OPT_NO_COMPACTION | LOIKB_OPT_NO_H_CACHE)) && C->B <= tail_max &&
+                           getenv("LOIKB_NO_DIRECT_TAIL") == nullptr;
+  if (direct_tail) {
+    double tms = 0.0;
+    unsigned long long tit = 0;
+    int rc = run_tail<T>(S, C, P, 0, C->B, C->B, &tms, &tit, true);
+    if (rc) return rc;
+    kernel_ms += tms;
+    if (trace) fprintf(stderr, "[loikb] tail kernel from the first iteration: %d instances  %8.3f ms  inst-iters %9llu\n", C->B, tms, tit);
+    C->stats.tail_ms = tms;
+    C->stats.tail_instances = C->B;
+    C->stats.tail_instance_iterations = tit;
+    inst_iters = tit;
+  }
+  while (!direct_tail) {
     // Latency-bound regime: once the chunk's tiles fit its share of the CUs (one workgroup per CU), an iteration
     // costs the same however few tiles are left -- repacking buys nothing any more and every launch boundary costs a
     // host round trip plus the kernel's prologue/epilogue, so the launches get longer.

@@ -619,4 +619,11 @@ __global__ void __launch_bounds__(WAVE) k_list_live(char* tiles, Layout L, int n
   if (live) list[wave_off[blockIdx.x] + __popcll(mask & ((1ull << lane) - 1ull))] = b;
 }
 
+// the identity list: every slot of a set (a batch small enough to go to the tail kernel from its first iteration)
+__global__ void k_list_iota(int* __restrict__ list, int n)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < n) list[b] = b;
+}
+
 }  // namespace loikb
