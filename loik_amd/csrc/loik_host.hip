@@ -798,30 +798,27 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     HIPCHK(hipFuncSetAttribute((const void*)k_tail<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(hipFuncSetAttribute((const void*)k_tail<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  // The kernel keeps one wavefront per SIMD resident (register budget): `resident` instances run concurrently.
-  // With more live instances than that, bounded launches keep every wavefront busy (instances finish at very
-  // different iterations; the survivors are re-listed and re-paired) -- once they all fit, one launch runs them out.
-  const int ncu = S->ncu;
-  const int resident = std::max(ipw, (int)(ncu * 4 * ipw * ((double)C->B / (double)S->B)));
-  int round_iters = 64;
-  if (const char* e = getenv("LOIKB_TAIL_ROUND")) round_iters = atoi(e);
-  int n = n_live, li = 0;
+  // ONE launch: as many workgroups as the chunk's share of the CUs holds (one wavefront per SIMD: register budget);
+  // the lane groups pull the listed instances from an atomic queue head until the list is empty.
+  const int cu_share = std::max(1, (int)(S->ncu * ((double)C->B / (double)S->B) + 0.5));
+  const int n = n_live;
   double total_ms = 0.0;
   unsigned long long iters = 0;
   const bool trace = getenv("LOIKB_TRACE") != nullptr;
-  while (n > 0) {
-    P.max_launch_iters = n > resident ? round_iters : S->opt.max_iter + 1;
-    const dim3 grid((unsigned)((n + ipw * tw - 1) / (ipw * tw)));
+  {
+    P.max_launch_iters = S->opt.max_iter + 1;
+    const int wg_needed = (n + ipw * tw - 1) / (ipw * tw);
+    const dim3 grid((unsigned)std::min(wg_needed, cu_share));
     HIPCHK(hipMemsetAsync(C->d_counters, 0, 8 * sizeof(unsigned int), C->stream));
     HIPCHK(hipEventRecord(C->ev_k0, C->stream));
     if (S->href_diag)
       hipLaunchKernelGGL((k_tail<T, true>), grid, dim3(WAVE * tw), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                          (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
-                         (const int*)C->d_slots[li], n, G, C->d_slots[li ^ 1]);
+                         (const int*)C->d_slots[0], n, G, C->d_slots[1]);
     else
       hipLaunchKernelGGL((k_tail<T, false>), grid, dim3(WAVE * tw), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                          (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
-                         (const int*)C->d_slots[li], n, G, C->d_slots[li ^ 1]);
+                         (const int*)C->d_slots[0], n, G, C->d_slots[1]);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(C->ev_k1, C->stream));
     HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
@@ -833,18 +830,12 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     total_ms += ms;
     iters += C->h_counters[1];
     if (trace)
-      fprintf(stderr, "[loikb] tail launch: %6d instances, budget %4d  %8.3f ms  inst-iters %9u (%.1f M/s)  live after %6u"
+      fprintf(stderr, "[loikb] tail launch: %6d instances on %u workgroups  %8.3f ms  inst-iters %9u (%.1f M/s)"
                       "  wave-iters %7u H-rebuild %3.0f%%\n",
-              n, P.max_launch_iters, ms, C->h_counters[1], C->h_counters[1] / ms / 1e3, C->h_counters[0],
+              n, grid.x, ms, C->h_counters[1], C->h_counters[1] / ms / 1e3,
               C->h_counters[5], 100.0 * C->h_counters[6] / (C->h_counters[5] ? C->h_counters[5] : 1));
     C->stats.launches++;
     C->stats.tail_launches++;
-    if ((int)C->h_counters[0] >= n && P.max_launch_iters > S->opt.max_iter) {
-      g_last_error = "tail: no progress";
-      return LOIKB_ERR_STATE;
-    }
-    n = (int)C->h_counters[0];
-    li ^= 1;
   }
   *ms_out = total_ms;
   *iters_out = iters;

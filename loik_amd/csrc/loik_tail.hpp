@@ -86,21 +86,14 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   T* cd = hst + 2 * WAVE * HS;              // [64/G][nc][CD]  constraint data of every instance of the wavefront
   const int lane = threadIdx.x & (WAVE - 1);
   const int sub = lane / G, jlane = lane % G, gbase = sub * G;
-  const int ipw = WAVE / G;
-  const int idx = (blockIdx.x * (int)(blockDim.x >> 6) + wv) * ipw + sub;
-  const bool has_inst = idx < nslots;
-  const int slot = slots[has_inst ? idx : 0];
-  const bool isj = has_inst && jlane < L.nb;
-  const int jl = isj ? jlane : 0;
-  char* ip = lane_ptr<T>(Bf.tiles, L, slot);  // the instance's lane pointer: identical within the group
-  char* rec = ip + (size_t)jl * JREC * pair_bytes<T>();
-  char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+  const bool isj_lane = jlane < L.nb;
+  const int jl = isj_lane ? jlane : 0;
   T* cdi = cd + (size_t)sub * L.nc * CD;
 
   // ---- per-lane joint description (VGPRs: every lane owns a different joint) ------------------------------
   const JointDesc d = jd[jl + 1];
   const TailTopo tp = topo[jl + 1];
-  const int depth = isj ? tp.depth : 0;
+  const int depth = isj_lane ? tp.depth : 0;
   const bool rev = d.flags & JF_REVOLUTE;
   const bool has_parent = !(d.flags & JF_PARENT_ROOT);
   const int plane = gbase + d.parent - 1;  // parent's lane
@@ -118,81 +111,168 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   for (int k = 0; k < 3; ++k) { Sv[k] = rev ? T(0) : (T)d.axis[k]; Sv[3 + k] = rev ? (T)d.axis[k] : T(0); }
   if (lane < XS) xch[WAVE * XS + lane] = T(0);
 
-  // ---- load the instance: joint j -> lane j of the group -----------------------------------------------------
+  // ---- the instance a group works on (all of this is reloaded when the group takes the next one) -----------------
+  bool has_inst = false, isj = false, done = true, any_iter = false;
+  int slot = 0;
+  char *ip = Bf.tiles, *rec = Bf.tiles, *srec = Bf.tiles;
   T R[9], t[3], v[6], f[6], g[6], UD[6], UDo[6], p[6];
-  T w, z, nu, s, r = T(0), dinv = T(0), lbi, ubi;
-  {
-    const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
-    make_liMi(d, cs.x, cs.y, R, t);  // liMi is kept in registers for the whole solve
-    ld6<T>(rec, JP_V, v);
-    ld6<T>(rec, JP_F, f);
-    ld6<T>(rec, JP_G, g);
-    w = wz.x; z = wz.y; nu = nus.x; s = nus.y;
-    if (P.mode & MODE_BND_SHARED) {
-      lbi = Bf.uni[L.nc * 57 + jl];
-      ubi = Bf.uni[L.nc * 57 + L.nb + jl];
-    } else {
-      const typename Vec2<T>::type lu = ldp<T>(rec, JP_LBUB);
-      lbi = lu.x; ubi = lu.y;
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { UD[k] = T(0); UDo[k] = T(0); p[k] = T(0); }
-  }
-  // constraint blocks -> LDS (the lanes of a group cooperate)
-  for (int c = 0; c < L.nc; ++c) {
-    const char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
-    for (int e = jlane; e < CD; e += G) {
-      T val = T(0);
-      if (e < 36) {
-        val = (P.mode & MODE_A_SHARED) ? Bf.uni[c * 36 + e]
-                                       : *reinterpret_cast<const T*>(crec + (size_t)(CP_A + e / 2) * pair_bytes<T>() + (e & 1) * sizeof(T));
-      } else if (e < 57) {
-        const int q = e - 36;
-        val = (P.mode & MODE_A_SHARED) ? Bf.uni[L.nc * 36 + c * 21 + q]
-                                       : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + q / 2) * pair_bytes<T>() + (q & 1) * sizeof(T));
-      } else if (e >= CD_B) {
-        const int q = e - CD_B;
-        const int which = q / 6, k = q % 6;
-        const int pair = which == 0 ? CP_B : which == 1 ? CP_ATB : which == 2 ? CP_Y : CP_ATY;
-        val = *reinterpret_cast<const T*>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
-      }
-      if (e != CD_PAD) cdi[c * CD + e] = val;
-    }
-  }
-  if (isj && d.cslot >= 0) cdi[d.cslot * CD + CD_PAD] = (T)jlane;  // which lane of the group owns the constrained joint
-  // per-instance solver scalars: every lane of the group reads the same words
-  const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
-  T mu = mu2.x;
-  int kexp = (int)mu2.y;         // mu = mu0 * 10^kexp
-  const T tg_in = ldp<T>(srec, SP_TAG).x;
-  T mu_h = T(-1), mu_o = T(-1);  // mu of the current / the other H slot: nothing cached yet
-  int hsl = 0;                   // current H slot
-  // (H_i is not kept in HBM -- k_solve gets f_i from the force-balance recursion -- so the first iteration of a
-  //  launch rebuilds this instance's H cache; this kernel keeps f_i = H_i v_i + p_i: H_i sits in LDS anyway and the
-  //  extra recursion over the tree levels would cost more than the 36 multiply-adds per joint.)
-  const T bnorm = bi2.x;
-  int iter = (int)bi2.y;
-  int status = has_inst ? (int)st2.x : ST_DONE;
-  T tol_p = ld_scal<T>(srec, SC_TOL_PRIMAL), tol_d = ld_scal<T>(srec, SC_TOL_DUAL);
-  int tail_iter = (int)ld_scal<T>(srec, SC_TAIL_ITER);
-  T dyqp = ld_scal<T>(srec, SC_DELTA_Y_QP), atdy = ld_scal<T>(srec, SC_AT_DELTA_Y_QP);
-  T ubp = ld_scal<T>(srec, SC_UB_DY_PLUS), lbm = ld_scal<T>(srec, SC_LB_DY_MINUS);
-  int c1 = (int)ld_scal<T>(srec, SC_COND1), c2 = (int)ld_scal<T>(srec, SC_COND2);
-  tail_sync();
-
-  bool done = (status & ST_DONE) != 0;
-  if (!done && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { done = true; status |= ST_DONE; }
+  T w = T(0), z = T(0), nu = T(0), s = T(0), r = T(0), dinv = T(0), lbi = T(0), ubi = T(0);
+  T mu = T(1), tg_in = T(-1), mu_h = T(-1), mu_o = T(-1), bnorm = T(0), st_y = T(0);
+  int kexp = 0, hsl = 0, iter = 0, status = ST_DONE, tail_iter = 0, c1 = 0, c2 = 0;
+  T tol_p = T(0), tol_d = T(0), dyqp = T(0), atdy = T(0), ubp = T(0), lbm = T(0);
   unsigned int my_iters = 0;
-  unsigned int n_wave_iters = 0, n_h_iters = 0;  // diagnostics: wavefront-iterations, those with an H rebuild
   // last-iteration scalars (for the final dump)
   T primal = T(0), dual = T(0), pr_task = T(0), pr_slack = T(0), dual_v = T(0), stf_w_inf = T(0), dx = T(0), dz = T(0);
   T n_dfis = T(0), n_dyis = T(0), n_dw = T(0), n_dvis = T(0), n_dnu = T(0), n_av = T(0), n_nu = T(0), n_hrefv = T(0),
     n_g = T(0);
-  bool any_iter = false;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k] = T(0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) t[k] = T(0);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { v[k] = f[k] = g[k] = UD[k] = UDo[k] = p[k] = T(0); }
+  unsigned int n_wave_iters = 0, n_h_iters = 0;  // diagnostics: wavefront-iterations, those with an H rebuild
 
-  // the loops below stay in wavefront-uniform control flow (LDS exchanges + barriers inside); a finished group only
-  // masks its updates with `act`
-  for (int kk = 0; kk < P.max_launch_iters && __any(!done); ++kk) {
+  // The live instances are handed out through an atomic queue head: a group that finishes its instance stores it and
+  // takes the next one from the list, so every lane group stays busy until the list is empty although instances
+  // finish at very different iterations (1.2 % run 1000 iterations, the median is 26), and every instance is loaded
+  // and stored exactly once.
+  auto fetch = [&]() -> int {
+    int nx = 0;
+    if (jlane == 0) nx = (int)atomicAdd(&Bf.counters[7], 1u);
+    return __shfl(nx, gbase);
+  };
+  // joint j of instance list[idx] -> lane j of the group
+  auto load_instance = [&](int idx) {
+    has_inst = idx < nslots;
+    isj = has_inst && isj_lane;
+    slot = slots[has_inst ? idx : 0];
+    ip = lane_ptr<T>(Bf.tiles, L, slot);  // the instance's lane pointer: identical within the group
+    rec = ip + (size_t)jl * JREC * pair_bytes<T>();
+    srec = ip + (size_t)L.off_s * pair_bytes<T>();
+    {
+      const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
+      make_liMi(d, cs.x, cs.y, R, t);  // liMi is kept in registers for the whole solve of the instance
+      ld6<T>(rec, JP_V, v);
+      ld6<T>(rec, JP_F, f);
+      ld6<T>(rec, JP_G, g);
+      w = wz.x; z = wz.y; nu = nus.x; s = nus.y;
+      if (P.mode & MODE_BND_SHARED) {
+        lbi = Bf.uni[L.nc * 57 + jl];
+        ubi = Bf.uni[L.nc * 57 + L.nb + jl];
+      } else {
+        const typename Vec2<T>::type lu = ldp<T>(rec, JP_LBUB);
+        lbi = lu.x; ubi = lu.y;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { UD[k] = T(0); UDo[k] = T(0); p[k] = T(0); }
+      r = T(0); dinv = T(0);
+    }
+    // constraint blocks -> LDS (the lanes of a group cooperate)
+    for (int c = 0; c < L.nc; ++c) {
+      const char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+      for (int e = jlane; e < CD; e += G) {
+        T val = T(0);
+        if (e < 36) {
+          val = (P.mode & MODE_A_SHARED) ? Bf.uni[c * 36 + e]
+                                         : *reinterpret_cast<const T*>(crec + (size_t)(CP_A + e / 2) * pair_bytes<T>() + (e & 1) * sizeof(T));
+        } else if (e < 57) {
+          const int q = e - 36;
+          val = (P.mode & MODE_A_SHARED) ? Bf.uni[L.nc * 36 + c * 21 + q]
+                                         : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + q / 2) * pair_bytes<T>() + (q & 1) * sizeof(T));
+        } else if (e >= CD_B) {
+          const int q = e - CD_B;
+          const int which = q / 6, k = q % 6;
+          const int pair = which == 0 ? CP_B : which == 1 ? CP_ATB : which == 2 ? CP_Y : CP_ATY;
+          val = *reinterpret_cast<const T*>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+        }
+        if (e != CD_PAD) cdi[c * CD + e] = val;
+      }
+    }
+    if (isj_lane && d.cslot >= 0) cdi[d.cslot * CD + CD_PAD] = (T)jlane;  // which lane of the group owns the constrained joint
+    // per-instance solver scalars: every lane of the group reads the same words
+    const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
+    mu = mu2.x;
+    kexp = (int)mu2.y;         // mu = mu0 * 10^kexp
+    tg_in = ldp<T>(srec, SP_TAG).x;
+    mu_h = T(-1); mu_o = T(-1);  // mu of the current / the other H slot: nothing cached yet
+    hsl = 0;                     // current H slot
+    // (H_i is not kept in HBM -- k_solve gets f_i from the force-balance recursion -- so the first iteration on an
+    //  instance rebuilds its H cache; this kernel keeps f_i = H_i v_i + p_i: H_i sits in LDS anyway and the extra
+    //  recursion over the tree levels would cost more than the 36 multiply-adds per joint.)
+    bnorm = bi2.x;
+    iter = (int)bi2.y;
+    status = has_inst ? (int)st2.x : ST_DONE;
+    st_y = st2.y;
+    tol_p = ld_scal<T>(srec, SC_TOL_PRIMAL); tol_d = ld_scal<T>(srec, SC_TOL_DUAL);
+    tail_iter = (int)ld_scal<T>(srec, SC_TAIL_ITER);
+    dyqp = ld_scal<T>(srec, SC_DELTA_Y_QP); atdy = ld_scal<T>(srec, SC_AT_DELTA_Y_QP);
+    ubp = ld_scal<T>(srec, SC_UB_DY_PLUS); lbm = ld_scal<T>(srec, SC_LB_DY_MINUS);
+    c1 = (int)ld_scal<T>(srec, SC_COND1); c2 = (int)ld_scal<T>(srec, SC_COND2);
+    tail_sync();
+    done = (status & ST_DONE) != 0;
+    if (!done && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { done = true; status |= ST_DONE; }
+    my_iters = 0;
+    any_iter = false;
+  };
+  // write the group's instance back (same slot)
+  auto store_instance = [&]() {
+    if (isj) {
+      st6<T>(rec, JP_V, v);
+      st6<T>(rec, JP_F, f);
+      st6<T>(rec, JP_G, g);
+      stp<T>(rec, JP_WZ, w, z);
+      stp<T>(rec, JP_NUS, nu, s);
+      if (any_iter) {
+        // inter-sweep temporaries of the LAST iteration (pis, UDinv, Dinv, r), as upstream leaves them: here the
+        // accumulated p_i itself (flagged ST_PFULL below; k_solve stores p_i^base in that slot)
+        st6<T>(rec, JP_P, p);
+        st6<T>(rec, JP_UD, UD);
+        stp<T>(rec, JP_R, r, dinv);
+      }
+    }
+    tail_sync();
+    if (has_inst) {
+      for (int c = 0; c < L.nc; ++c) {
+        char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+        if (jlane < 6) {
+          const int k = jlane;
+          *reinterpret_cast<T*>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * CD + CD_Y + k];
+          *reinterpret_cast<T*>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * CD + CD_ATY + k];
+        }
+      }
+      if (jlane == 0) {
+        stp<T>(srec, SP_MU, mu, (T)kexp);
+        // the UDinv / Dinv written above belong to mu_h, the mu of the last executed iteration
+        stp<T>(srec, SP_TAG, any_iter ? mu_h : tg_in, T(0));
+        stp<T>(srec, SP_BI, bnorm, (T)iter);
+        stp<T>(srec, SP_ST, (T)(any_iter ? (status | ST_PFULL) : status), any_iter ? mu_h : st_y);
+        if (any_iter) {
+          stp<T>(srec, SP_SCAL + 0, primal, dual);
+          stp<T>(srec, SP_SCAL + 1, pr_task, pr_slack);
+          stp<T>(srec, SP_SCAL + 2, dual_v, stf_w_inf);
+          stp<T>(srec, SP_SCAL + 3, tol_p, tol_d);
+          stp<T>(srec, SP_SCAL + 4, mu, P.mu_scale * mu);
+          stp<T>(srec, SP_SCAL + 5, mu, dx);
+          stp<T>(srec, SP_SCAL + 6, dz, dyqp);
+          stp<T>(srec, SP_SCAL + 7, atdy, ubp);
+          stp<T>(srec, SP_SCAL + 8, lbm, n_dfis);
+          stp<T>(srec, SP_SCAL + 9, n_dyis, n_dw);
+          stp<T>(srec, SP_SCAL + 10, n_dvis, n_dnu);
+          stp<T>(srec, SP_SCAL + 11, n_av, n_nu);
+          stp<T>(srec, SP_SCAL + 12, n_hrefv, n_g);
+          stp<T>(srec, SP_SCAL + 13, stf_w_inf, (T)c1);
+          stp<T>(srec, SP_SCAL + 14, (T)c2, (T)tail_iter);
+        }
+        if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
+      }
+    }
+  };
+
+  // the loops below stay in wavefront-uniform control flow (LDS exchanges inside); a group without work only masks its
+  // updates with `act`
+  load_instance(fetch());
+  while (__any(!done)) {
     const bool act = !done;
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
     if (act) { ++iter; ++my_iters; any_iter = true; }
@@ -540,68 +620,20 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
       }
     }
-  }
+  
 
-  // ---- write the instance back (same slot) -------------------------------------------------------------------------
-  if (isj) {
-    st6<T>(rec, JP_V, v);
-    st6<T>(rec, JP_F, f);
-    st6<T>(rec, JP_G, g);
-    stp<T>(rec, JP_WZ, w, z);
-    stp<T>(rec, JP_NUS, nu, s);
-    if (any_iter) {
-      // inter-sweep temporaries of the LAST iteration (pis, UDinv, Dinv, r), as upstream leaves them: here the
-      // accumulated p_i itself (flagged ST_PFULL below; k_solve stores p_i^base in that slot)
-      st6<T>(rec, JP_P, p);
-      st6<T>(rec, JP_UD, UD);
-      stp<T>(rec, JP_R, r, dinv);
+    // a group whose instance just stopped stores it and takes the next one from the list
+    if (done && has_inst) {
+      store_instance();
+      load_instance(fetch());
     }
   }
-  tail_sync();
-  if (has_inst) {
-    for (int c = 0; c < L.nc; ++c) {
-      char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
-      if (jlane < 6) {
-        const int k = jlane;
-        *reinterpret_cast<T*>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * CD + CD_Y + k];
-        *reinterpret_cast<T*>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * CD + CD_ATY + k];
-      }
-    }
-    if (jlane == 0) {
-      stp<T>(srec, SP_MU, mu, (T)kexp);
-      // the UDinv / Dinv written above belong to mu_h, the mu of the last executed iteration
-      stp<T>(srec, SP_TAG, any_iter ? mu_h : tg_in, T(0));
-      stp<T>(srec, SP_BI, bnorm, (T)iter);
-      stp<T>(srec, SP_ST, (T)(any_iter ? (status | ST_PFULL) : status), any_iter ? mu_h : st2.y);
-      if (any_iter) {
-        stp<T>(srec, SP_SCAL + 0, primal, dual);
-        stp<T>(srec, SP_SCAL + 1, pr_task, pr_slack);
-        stp<T>(srec, SP_SCAL + 2, dual_v, stf_w_inf);
-        stp<T>(srec, SP_SCAL + 3, tol_p, tol_d);
-        stp<T>(srec, SP_SCAL + 4, mu, P.mu_scale * mu);
-        stp<T>(srec, SP_SCAL + 5, mu, dx);
-        stp<T>(srec, SP_SCAL + 6, dz, dyqp);
-        stp<T>(srec, SP_SCAL + 7, atdy, ubp);
-        stp<T>(srec, SP_SCAL + 8, lbm, n_dfis);
-        stp<T>(srec, SP_SCAL + 9, n_dyis, n_dw);
-        stp<T>(srec, SP_SCAL + 10, n_dvis, n_dnu);
-        stp<T>(srec, SP_SCAL + 11, n_av, n_nu);
-        stp<T>(srec, SP_SCAL + 12, n_hrefv, n_g);
-        stp<T>(srec, SP_SCAL + 13, stf_w_inf, (T)c1);
-        stp<T>(srec, SP_SCAL + 14, (T)c2, (T)tail_iter);
-      }
-      if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
-      if (lane == 0) {
-        atomicAdd(&Bf.counters[5], n_wave_iters);
-        atomicAdd(&Bf.counters[6], n_h_iters);
-      }
-      if (!(status & ST_DONE)) {
-        // still live when the launch budget ran out: queue it for the next launch
-        const unsigned int pos = atomicAdd(&Bf.counters[0], 1u);
-        if (slots_out) slots_out[pos] = slot;
-      }
-    }
+  // instances that were already finished when they were fetched (nothing to store), diagnostics
+  if (lane == 0) {
+    atomicAdd(&Bf.counters[5], n_wave_iters);
+    atomicAdd(&Bf.counters[6], n_h_iters);
   }
+  (void)slots_out;
 }
 
 // slot indices of the live instances of a set, dense, in slot order (same scan as k_move)
