@@ -112,7 +112,7 @@ struct loikb_solver_impl {
     hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
     unsigned int* d_counters = nullptr;
     unsigned int* h_counters = nullptr;  // pinned
-    int* d_slots[2] = {nullptr, nullptr};  // live-instance lists of the tail kernel (ping-pong between launches)
+    int* d_slots = nullptr;              // list of the live instances handed to the tail kernel
     std::vector<int> h_wave;             // host scratch for the compaction scan
     loikb_stats stats{};
     int rc = 0;
@@ -771,7 +771,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
   const int nw = (n_cur + WAVE - 1) / WAVE;
   if (whole_set) {
     // every slot of the set (finished instances, if any, stop at once inside the kernel)
-    hipLaunchKernelGGL(k_list_iota, grid1(n_cur), dim3(256), 0, C->stream, C->d_slots[0], n_cur);
+    hipLaunchKernelGGL(k_list_iota, grid1(n_cur), dim3(256), 0, C->stream, C->d_slots, n_cur);
   } else {
     C->h_wave.resize(2 * (size_t)nw + 2);
     int* cnt = C->h_wave.data();
@@ -782,7 +782,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     for (int w = 0; w < nw; ++w) { off[w] = total; total += cnt[w]; }
     if (total != n_live) { g_last_error = "tail: live count mismatch"; return LOIKB_ERR_STATE; }
     HIPCHK(hipMemcpyAsync(A.wave_off, off, sizeof(int) * nw, hipMemcpyHostToDevice, C->stream));
-    hipLaunchKernelGGL(k_list_live<T>, dim3(nw), dim3(WAVE), 0, C->stream, A.tiles, S->L, n_cur, A.wave_off, C->d_slots[0]);
+    hipLaunchKernelGGL(k_list_live<T>, dim3(nw), dim3(WAVE), 0, C->stream, A.tiles, S->L, n_cur, A.wave_off, C->d_slots);
   }
   HIPCHK(hipGetLastError());
   Bufs<T> Bf = make_bufs<T>(S, C, cur);
@@ -814,11 +814,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     if (S->href_diag)
       hipLaunchKernelGGL((k_tail<T, true>), grid, dim3(WAVE * tw), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                          (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
-                         (const int*)C->d_slots[0], n, G, C->d_slots[1]);
+                         (const int*)C->d_slots, n, G);
     else
       hipLaunchKernelGGL((k_tail<T, false>), grid, dim3(WAVE * tw), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                          (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
-                         (const int*)C->d_slots[0], n, G, C->d_slots[1]);
+                         (const int*)C->d_slots, n, G);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(C->ev_k1, C->stream));
     HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
@@ -860,7 +860,7 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
   // k_move costs ~6 KB of traffic per live instance (a fraction of ONE iteration's ~32 KB), so repack eagerly
   double compact_ratio = 0.85;
   if (const char* e = getenv("LOIKB_COMPACT_RATIO")) compact_ratio = atof(e);
-  // cooperative tail kernel (one wavefront per instance) once few instances are left
+  // cooperative tail kernel (a lane group per instance) once few instances are left
   const bool use_tail = can_compact && S->nb <= WAVE && S->opt.tail_max_instances >= 0;
   // (thresholds are stated for the whole batch: a chunk applies its share)
   const double share = (double)C->B / (double)S->B;
@@ -1222,7 +1222,7 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
       HIPTRY(hipEventCreate(&C.ev_k1));
       HIPTRY(hipHostMalloc((void**)&C.h_counters, 8 * sizeof(unsigned int)));
       TRY(alloc_dev(S, &tmp, 8 * sizeof(unsigned int))); C.d_counters = (unsigned int*)tmp;
-      for (int k = 0; k < 2; ++k) { TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)(C.B + WAVE))); C.d_slots[k] = (int*)tmp; }
+      TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)(C.B + WAVE))); C.d_slots = (int*)tmp;
       if (S->chunks.size() > 1) {
         HIPTRY(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
         C.own_stream = true;

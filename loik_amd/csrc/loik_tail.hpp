@@ -1,15 +1,18 @@
 // loik_tail.hpp -- cooperative "tail" kernel: one problem instance per lane GROUP, ONE joint per lane.
 //
 // Why it exists: the ADMM iteration counts of a batch are heavy-tailed (on the Talos workload the median is ~26
-// iterations, 1 % of the instances need > 900 because the reference's DEFAULT penalty update keeps flipping mu
-// between two decades).  With one instance per lane (k_solve) every remaining iteration costs one full
-// single-wavefront tree walk (~50-90 us) however few instances are left, so the stragglers set the batch time.
+// iterations, 1.2 % of the instances run to max_iter = 1000 because the reference's DEFAULT penalty update keeps
+// flipping mu between two decades).  With one instance per lane (k_solve) an iteration costs 30-55 us of HBM round
+// trips however few instances are left, so the stragglers set the batch time.
 // Here a group of G = 8/16/32/64 lanes (G >= nb, 64/G instances per wavefront) splits ONE instance by joint: the
-// whole ADMM state of a joint lives in the registers / LDS of its lane for the entire solve (zero HBM traffic per
-// iteration), the tree sweeps become level-synchronous (tree depth, not joint count, sequential steps; Talos: 10
-// instead of 32) and the inf-norms become lane-group reductions.  One ADMM iteration costs a few microseconds.
+// whole ADMM state of a joint lives in the registers / LDS of its lane for as long as the group works on the instance
+// (zero HBM traffic per iteration).  Only the two true recursions over the tree (p leaf -> root, (nu, v) root -> leaf)
+// are loops over the tree depth (Talos: 10 steps instead of 32 joint visits), and they are branch-free: every lane
+// recomputes its value from its children's / parent's exchange rows at every step.  Everything else is per-joint work
+// done once by all lanes; inf-norms and dot products are folded through LDS.  ~12.5 us per iteration.
 // H_i / UDinv / Dinv are cached for the TWO most recent values of mu, so an instance whose penalty flips between
-// two decades (the typical straggler) never repeats the H-recursion.
+// two decades (the typical straggler) does not repeat the H-recursion.
+// The live instances are handed out through an atomic queue: a group that finishes one takes the next.
 //
 // The arithmetic per joint is the same as in loik_device.hpp (same helpers, same reference citations); only
 // the order in which children contributions / norm maxima are combined differs, so results agree with k_solve
@@ -71,8 +74,7 @@ __host__ __device__ __forceinline__ size_t tail_lds_bytes(int nc, int G)
 template <typename T, bool HDIAG>
 __global__ void __launch_bounds__(WAVE * TAIL_WAVES)
 k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
-       const int* __restrict__ child_list, int maxdepth, int maxchild, const int* __restrict__ slots, int nslots, int G,
-       int* __restrict__ slots_out)
+       const int* __restrict__ child_list, int maxdepth, int maxchild, const int* __restrict__ slots, int nslots, int G)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
@@ -633,7 +635,6 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     atomicAdd(&Bf.counters[5], n_wave_iters);
     atomicAdd(&Bf.counters[6], n_h_iters);
   }
-  (void)slots_out;
 }
 
 // slot indices of the live instances of a set, dense, in slot order (same scan as k_move)
