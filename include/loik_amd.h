@@ -175,7 +175,10 @@ enum {
   LOIKB_F_TAIL_SOLVE_ITER,
   /* double [batch][nq]: the configurations resident on the device (SolveInit/Solve input, advanced by
      loikb_integrate) */
-  LOIKB_F_Q = 96
+  LOIKB_F_Q = 96,
+  /* int [batch]: how many times UpdateMu (optimized.hxx:613-641) changed mu in the last solve -- a diagnostic: the
+     instances that run to max_iter are the ones that keep flipping mu between two decades */
+  LOIKB_F_MU_UPDATES = 97
 };
 /* copies one field for the whole batch into `out` (host pointer, or device pointer with LOIKB_OUT_DEVICE) */
 int loikb_get(loikb_solver *s, int field, void *out, int out_flags);

@@ -65,6 +65,7 @@ _SCALAR_FIELDS = ["primal_residual", "dual_residual", "primal_residual_task", "p
                   "primal_infeasibility_cond_2", "tail_solve_iter"]
 FIELD_ID = {n: i for i, n in enumerate(_VEC_FIELDS)}
 FIELD_ID["q"] = 96
+FIELD_ID["mu_updates"] = 97
 FIELD_ID.update({n: 32 + i for i, n in enumerate(_SCALAR_FIELDS)})
 
 # every symbol include/loik_amd.h and include/loik_amd_models.h declare
@@ -350,7 +351,7 @@ class BatchedLoik:
                   "vis": (B, nb, 6), "fis": (B, nb, 6), "g": (B, nb, 6), "pis": (B, nb, 6), "UDinv": (B, nb, 6),
                   "His": (B, nb, 21), "liMi": (B, nb, 12), "yis": (B, nc, 6), "Aty": (B, nc, 6),
                   "q": (B, self.model.nq)}
-        is_int = name in ("iter", "converged", "primal_infeasible", "status")
+        is_int = name in ("iter", "converged", "primal_infeasible", "status", "mu_updates")
         if out is not None:
             p, dev = _ptr(out)
             _check(self.L.loikb_get(self.h, fid, p, OUT_DEVICE if dev else 0))

@@ -67,7 +67,9 @@ enum : int {
   SP_MU = 0,     // (mu_, k) with mu_ = mu0 * 10^k
   SP_BI = 1,     // (bis_inf_norm_, iter_)
   SP_ST = 2,     // (status bits, mu the LAST executed iteration used = the mu of the stored UDinv/Dinv/r/p^base)
-  SP_TAG = 3,    // (mu the cached UDinv/Dinv were computed with; -1 = empty, unused), (unused, unused)
+  SP_TAG = 3,    // (mu the cached UDinv/Dinv were computed with; -1 = empty, unused)
+  SP_FLIP = 4,   // (number of mu updates of this solve so far, unused): the stragglers are the instances that keep
+                 // flipping mu -- the tail kernel's queue serves them first
   SP_SCAL = 5,   // scal[NSCAL] -> 15 pairs
   SREC = 20,
 };
@@ -1134,6 +1136,7 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const StepDesc* __restrict__ sched_
   int kexp = (int)mu2.y;                      // mu = mu0 * 10^kexp
   T mu_last = st2.y;                          // mu of the last executed iteration (for the His / pis / UDinv getters)
   T tag = tg01.x;                             // mu the cached UDinv / Dinv were computed with (-1: none)
+  int nflip = (int)ldp<T>(srec, SP_FLIP).x;   // mu updates so far
   const T bnorm = bi2.x;
   bool live = inb && !(status & ST_DONE);
   // main-loop bound `for (i = 1; i < max_iter; ++i)` (hpp:377): nothing to do when max_iter <= 1
@@ -1228,8 +1231,8 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const StepDesc* __restrict__ sched_
           }
         } else {
           // UpdateMu (hxx:617-631)
-          if (primal > T(10) * dual) { mu *= T(10); ++kexp; }
-          else if (dual > T(10) * primal) { mu *= T(0.1); --kexp; }
+          if (primal > T(10) * dual) { mu *= T(10); ++kexp; ++nflip; }
+          else if (dual > T(10) * primal) { mu *= T(0.1); --kexp; ++nflip; }
           if (iter + 1 >= P.max_iter) { status |= ST_DONE; live = false; }
         }
       } else {
@@ -1275,6 +1278,7 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const StepDesc* __restrict__ sched_
   if (inb && w == 0) {
     stp<T>(srec, SP_MU, mu, (T)kexp);
     stp<T>(srec, SP_TAG, tag, T(0));
+    stp<T>(srec, SP_FLIP, (T)nflip, T(0));
     stp<T>(srec, SP_BI, bnorm, (T)iter);
     stp<T>(srec, SP_ST, (T)status, mu_last);
   }
@@ -1535,10 +1539,8 @@ __global__ void __launch_bounds__(WAVE) k_reset(char* tiles, Layout L, int what,
     stp<T>(srec, SP_ST, T(0), T(0));
     for (int p = SP_SCAL; p < SREC; ++p) stp<T>(srec, p, T(0), T(0));
   }
-  if (what & RS_HCACHE) {
-    stp<T>(srec, SP_TAG, T(-1), T(-1));
-    stp<T>(srec, SP_TAG + 1, T(-1), T(0));
-  }
+  if (what & RS_SOLVER) stp<T>(srec, SP_FLIP, T(0), T(0));
+  if (what & RS_HCACHE) stp<T>(srec, SP_TAG, T(-1), T(0));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1596,9 +1598,8 @@ __global__ void __launch_bounds__(WAVE) k_move(const MovePlan M)
     const typename Vec2<T>::type v = ldp<T>(sp, p);
     stp<T>(dp, p, v.x, v.y);
   }
-  // the H/UDinv/Dinv cache did not travel
-  stp<T>(dp + (size_t)L.off_s * pair_bytes<T>(), SP_TAG, T(-1), T(-1));
-  stp<T>(dp + (size_t)L.off_s * pair_bytes<T>(), SP_TAG + 1, T(-1), T(0));
+  // the UDinv/Dinv cache did not travel
+  stp<T>(dp + (size_t)L.off_s * pair_bytes<T>(), SP_TAG, T(-1), T(0));
 }
 
 }  // namespace loikb

@@ -1439,6 +1439,7 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   case LOIKB_F_CONVERGED: is_int = true; mask = ST_CONVERGED; rm.push_back((L.off_s + SP_ST) * 2); break;
   case LOIKB_F_PRIMAL_INFEASIBLE: is_int = true; mask = ST_PRIMAL_INF; rm.push_back((L.off_s + SP_ST) * 2); break;
   case LOIKB_F_MU: rm.push_back((L.off_s + SP_MU) * 2); break;  // per-instance mu_ (== mu0 right after ResetSolver)
+  case LOIKB_F_MU_UPDATES: is_int = true; rm.push_back((L.off_s + SP_FLIP) * 2); break;
   default:
     static_assert(LOIKB_F_TAIL_SOLVE_ITER - LOIKB_F_PRIMAL_RESIDUAL + 1 == NSCAL, "scalar field ids out of sync");
     if (field >= LOIKB_F_PRIMAL_RESIDUAL && field <= LOIKB_F_TAIL_SOLVE_ITER) {
