@@ -452,6 +452,11 @@ def test_tail_kernel_work_queue(talos):
     same = queued.get("iter") == solve_only.get("iter")
     assert same.mean() >= 0.98
     assert np.array_equal(queued.get("status")[same], solve_only.get("status")[same])
+    # UpdateMu decisions (optimized.hxx:613-641) counted the same in both kernels, consistent with the final decade
+    nup = queued.get("mu_updates")
+    assert np.array_equal(nup[same], solve_only.get("mu_updates")[same])
+    decade = np.rint(np.log10(queued.get("mu") / FIXTURE["mu"])).astype(int)
+    assert np.all(nup >= np.abs(decade)) and np.all((nup - np.abs(decade)) % 2 == 0)
     for name in ["z", "nu", "w", "vis", "fis", "g", "yis", "Aty", "Stf_plus_w", "primal_residual", "dual_residual", "mu"]:
         a, b = queued.get(name)[same], solve_only.get(name)[same]
         assert np.max(np.abs(a - b) / (1.0 + np.abs(b))) < 1e-9, name
