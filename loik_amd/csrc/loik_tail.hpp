@@ -276,7 +276,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   // the loops below stay in wavefront-uniform control flow (LDS exchanges inside); a group without work only masks its
   // updates with `act`
   load_instance(fetch());
-  while (__any(!done)) {
+  while (__any(!done || has_inst)) {  // (done && has_inst: an instance that was already finished when it was fetched)
     const bool act = !done;
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
     if (act) { ++iter; ++my_iters; any_iter = true; }
@@ -642,7 +642,10 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 // slot indices of the live instances of a set, dense, in slot order (same scan as k_move).
 // (Serving the instances with the largest residual/tolerance ratio first -- it predicts the iterations still to come
 //  with correlation 0.88 -- was measured: fewer wavefront-iterations (464 k vs 513 k per chunk) but a LONGER launch,
-//  16.9 vs 15.8 ms: every wavefront then starts with two long runners and the short instances queue up behind them.)
+//  16.9 vs 15.8 ms: every wavefront then starts with two long runners and the short instances queue up behind them.
+//  Other predictors of the remaining iterations (mu updates so far / recently, residual decay rate, stagnation) rank
+//  even worse in a queue simulation on the real remaining-iteration counts; a first launch with a quantum of 100-400
+//  iterations per instance followed by a run-out launch of the survivors: 35.1-35.8 vs 34.8 ms/step.)
 template <typename T>
 __global__ void __launch_bounds__(WAVE) k_list_live(char* tiles, Layout L, int n, const int* __restrict__ wave_off,
                                                     int* __restrict__ list)
