@@ -54,7 +54,18 @@ def cpu_baseline(wl, budget_s=15.0):
     n = int(min(wl["q"].shape[0], max(n0, n0 * budget_s / max(t0, 1e-4))))
     n = max(cores, (n // cores) * cores)
     dt, out = run(n)
+    # one thread, one instance: microseconds per ADMM iteration, as the reference's own timing test measures it
+    # (SolveInit once, then Solve() with max_iter = 2, i.e. exactly one iteration; /root/reference/tests/loik-loid.cpp:987-1032)
+    one_us = None
+    try:
+        t1 = time.perf_counter()
+        o1 = ref.solve_batch(m, wl["q"][:64], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"][:64], wl["lb"],
+                             wl["ub"], nthreads=1, native=True, **dict(prm, max_iter=201, tol_abs=0.0, tol_primal_inf=0.0))
+        one_us = (time.perf_counter() - t1) / max(int(o1["iters"].sum()), 1) * 1e6
+    except Exception:
+        pass
     return dict(value=float(out["converged"].sum() / dt), unit="solves/s", cores=cores, kind="port",
+                single_thread_us_per_iteration=one_us,
                 sample="first %d instances of the same workload, %d threads, %.1f s, %.0f ADMM instance-iterations/s; "
                        "oracle/loik_ref.c = line-faithful C port of the reference solver (not upstream libloik)"
                        % (n, cores, dt, out["iters"].sum() / dt),
