@@ -152,6 +152,12 @@ def _check(rc):
         raise LoikError(rc, msg)
 
 
+# JointModelFreeFlyer / Spherical / Translation (LOIKB_J_FREEFLYER, _SPHERICAL, _TRANSLATION)
+J_FREEFLYER, J_SPHERICAL, J_TRANSLATION = 9, 10, 11
+JOINT_NQ = {J_FREEFLYER: 7, J_SPHERICAL: 4, J_TRANSLATION: 3}
+JOINT_NV = {J_FREEFLYER: 6, J_SPHERICAL: 3, J_TRANSLATION: 3}
+
+
 class Model:
     """Kinematic tree with Pinocchio's member names: njoints, nq, nv, parents, jointPlacements (here `placement`,
     [nj][12] = R row-major + t), joint type / axis / idx_q / idx_v per joint."""
@@ -162,9 +168,16 @@ class Model:
         self.axis = np.ascontiguousarray(axis, dtype=np.float64).reshape(-1, 3)
         self.placement = np.ascontiguousarray(placement, dtype=np.float64).reshape(-1, 12)
         self.njoints = int(self.parents.size)
-        self.nq = self.nv = self.njoints - 1
-        self.idx_q = np.ascontiguousarray(np.maximum(np.arange(self.njoints) - 1, 0), dtype=np.int32)
-        self.idx_v = self.idx_q.copy()
+        # joints[i].nq() / nv() / idx_q() / idx_v() of Pinocchio: cumulative in joint order
+        nqs = np.array([JOINT_NQ.get(int(t), 1) if i else 0 for i, t in enumerate(self.jtype)], dtype=np.int32)
+        nvs = np.array([JOINT_NV.get(int(t), 1) if i else 0 for i, t in enumerate(self.jtype)], dtype=np.int32)
+        self.nqs, self.nvs = nqs, nvs
+        self.nq, self.nv = int(nqs.sum()), int(nvs.sum())
+        self.idx_q = np.ascontiguousarray(np.concatenate([[0], np.cumsum(nqs)[:-1]]), dtype=np.int32)
+        self.idx_v = np.ascontiguousarray(np.concatenate([[0], np.cumsum(nvs)[:-1]]), dtype=np.int32)
+        if self.njoints > 1:  # joint 0 (universe) has no coordinates; keep its index at 0 like before
+            self.idx_q[0] = 0
+            self.idx_v[0] = 0
         self.names = list(names) if names is not None else ["universe"] + ["joint%d" % i for i in range(1, self.njoints)]
         self.q_lo = None if q_lo is None else np.asarray(q_lo, dtype=np.float64)
         self.q_hi = None if q_hi is None else np.asarray(q_hi, dtype=np.float64)
@@ -178,6 +191,20 @@ class Model:
 
     def getJointId(self, name):
         return self.names.index(name)
+
+    def random_configurations(self, rng, batch):
+        """[batch][nq] configurations: uniform in [q_lo, q_hi] (unit box when none was given), the quaternion
+        segments of free-flyer / spherical joints replaced by uniformly random unit quaternions (x, y, z, w)"""
+        lo = -np.ones(self.nq) if self.q_lo is None else self.q_lo
+        hi = np.ones(self.nq) if self.q_hi is None else self.q_hi
+        q = rng.uniform(lo, hi, size=(batch, self.nq))
+        for i in range(1, self.njoints):
+            t = int(self.jtype[i])
+            if t in (J_FREEFLYER, J_SPHERICAL):
+                o = int(self.idx_q[i]) + (3 if t == J_FREEFLYER else 0)
+                qt = rng.normal(size=(batch, 4))
+                q[:, o:o + 4] = qt / np.linalg.norm(qt, axis=1, keepdims=True)
+        return q
 
 
 def builtin_model(name):

@@ -9,6 +9,7 @@ v_i = liMi^-1 . v_parent + S_i nu_i (the same recursion as the reference's forwa
 import numpy as np
 
 J_RX, J_RY, J_RZ, J_PX, J_PY, J_PZ, J_RU, J_PU = 1, 2, 3, 4, 5, 6, 7, 8
+J_FREEFLYER, J_SPHERICAL, J_TRANSLATION = 9, 10, 11
 
 # the reference fixture's solver parameters, /root/reference/tests/loik-loid.cpp:91-105
 FIXTURE_PARAMS = dict(tol_primal_inf=1e-2, tol_dual_inf=1e-2, tol_tail_solve=1e-1, rho=1e-5, mu=1e-2,
@@ -30,6 +31,16 @@ def _rot(jtype, axis, q):
     return R
 
 
+def quat_rot(qt):
+    """batched Eigen::Quaternion::toRotationMatrix for (x, y, z, w) rows: [B,3,3]"""
+    x, y, z, w = qt[:, 0], qt[:, 1], qt[:, 2], qt[:, 3]
+    R = np.empty((qt.shape[0], 3, 3))
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - z * w); R[:, 0, 2] = 2 * (x * z + y * w)
+    R[:, 1, 0] = 2 * (x * y + z * w); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - x * w)
+    R[:, 2, 0] = 2 * (x * z - y * w); R[:, 2, 1] = 2 * (y * z + x * w); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
 def link_velocity(model, q, nu, link):
     """spatial velocity [B,6] (Pinocchio order [linear; angular], link frame) of `link` for joint velocities nu"""
     B = q.shape[0]
@@ -43,7 +54,25 @@ def link_velocity(model, q, nu, link):
         jt = int(model.jtype[i])
         P = model.placement[i]
         Rp, tp = P[:9].reshape(3, 3), P[9:]
-        qi, nui = q[:, int(model.idx_q[i])], nu[:, int(model.idx_v[i])]
+        iq, iv = int(model.idx_q[i]), int(model.idx_v[i])
+        qi, nui = q[:, iq], nu[:, iv]
+        if jt in (J_FREEFLYER, J_SPHERICAL, J_TRANSLATION):
+            # M(q) = (R(quat), t) ; S = I6 | [0; I3] | [I3; 0]: the joint velocity is added in the child frame
+            Rj = quat_rot(q[:, iq + 3:iq + 7]) if jt == J_FREEFLYER else (
+                quat_rot(q[:, iq:iq + 4]) if jt == J_SPHERICAL else np.broadcast_to(np.eye(3), (B, 3, 3)))
+            tj = q[:, iq:iq + 3] if jt != J_SPHERICAL else np.zeros((B, 3))
+            R = Rp[None] @ Rj
+            t = tp[None] + tj @ Rp.T
+            lin, ang = v[:, :3], v[:, 3:]
+            d = lin - np.cross(t, ang)
+            v = np.concatenate([np.einsum("bji,bj->bi", R, d), np.einsum("bji,bj->bi", R, ang)], axis=1)
+            if jt == J_FREEFLYER:
+                v = v + nu[:, iv:iv + 6]
+            elif jt == J_SPHERICAL:
+                v[:, 3:] += nu[:, iv:iv + 3]
+            else:
+                v[:, :3] += nu[:, iv:iv + 3]
+            continue
         if jt in (J_RX, J_RY, J_RZ, J_RU):
             R = Rp[None] @ _rot(jt, model.axis[i], qi)
             t = np.broadcast_to(tp, (B, 3))
@@ -78,7 +107,7 @@ def make_workload(model, batch, link, seed, bound=0.5, snap_prob=0.25, nu_scale=
     +-bound w.p. snap_prob (so that joint-velocity limits are active); A = I6; b = J_link(q) nu_star; box = +-bound."""
     rng = np.random.default_rng(seed)
     nq, nv = model.nq, model.nv
-    q = rng.uniform(model.q_lo, model.q_hi, size=(batch, nq))
+    q = model.random_configurations(rng, batch)
     s = bound if nu_scale is None else nu_scale
     nu_star = rng.uniform(-s, s, size=(batch, nv))
     snap = rng.random((batch, nv)) < snap_prob

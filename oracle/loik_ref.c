@@ -187,11 +187,54 @@ static void se3_act_on(const double *M, const double *I, double *res)
     }
 }
 
-/* JointModel{RX,RY,RZ,PX,PY,PZ,RevoluteUnaligned,PrismaticUnaligned}::calc(jdata, q)
- * -> joint transform M(q) (call site hxx:263) */
-static void joint_calc(int jtype, const double *axis, double q, double *M)
+/* number of configuration / velocity coordinates of a joint type (JointModel::nq(), ::nv()) */
+static int joint_nq(int jtype)
+{
+  switch (jtype) {
+  case REF_J_NONE: return 0;
+  case REF_J_FREEFLYER: return 7;
+  case REF_J_SPHERICAL: return 4;
+  case REF_J_TRANSLATION: return 3;
+  default: return 1;
+  }
+}
+static int joint_nv(int jtype)
+{
+  switch (jtype) {
+  case REF_J_NONE: return 0;
+  case REF_J_FREEFLYER: return 6;
+  case REF_J_SPHERICAL: return 3;
+  case REF_J_TRANSLATION: return 3;
+  default: return 1;
+  }
+}
+
+/* Eigen::Quaternion::toRotationMatrix for the coefficient order (x, y, z, w) Pinocchio stores in q */
+static void quat_to_rot(const double *qt, double *R)
+{
+  const double x = qt[0], y = qt[1], z = qt[2], w = qt[3];
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1.0 - (txx + tyy);
+}
+
+/* JointModel{RX,RY,RZ,PX,PY,PZ,RevoluteUnaligned,PrismaticUnaligned,FreeFlyer,Spherical,Translation}::calc(jdata, q)
+ * -> joint transform M(q) (call site hxx:263); `q` points at the joint's own segment of the configuration */
+static void joint_calc(int jtype, const double *axis, const double *qs, double *M)
 {
   se3_identity(M);
+  if (jtype == REF_J_FREEFLYER) {
+    quat_to_rot(qs + 3, M);
+    M[9] = qs[0]; M[10] = qs[1]; M[11] = qs[2];
+    return;
+  }
+  if (jtype == REF_J_SPHERICAL) { quat_to_rot(qs, M); return; }
+  if (jtype == REF_J_TRANSLATION) { M[9] = qs[0]; M[10] = qs[1]; M[11] = qs[2]; return; }
+  const double q = qs[0];
   double c = cos(q), s = sin(q);
   switch (jtype) {
   case REF_J_RX:
@@ -221,10 +264,10 @@ static void joint_calc(int jtype, const double *axis, double q, double *M)
   }
 }
 
-/* joint motion subspace S (6-vector, one column since every supported joint has nv = 1) */
+/* joint motion subspace S: 6 x nv_i, column c stored at S[6c .. 6c+6) */
 static void joint_S(int jtype, const double *axis, double *S)
 {
-  memset(S, 0, 6 * sizeof(double));
+  memset(S, 0, 36 * sizeof(double));
   switch (jtype) {
   case REF_J_PX: S[0] = 1.0; break;
   case REF_J_PY: S[1] = 1.0; break;
@@ -234,23 +277,75 @@ static void joint_S(int jtype, const double *axis, double *S)
   case REF_J_RZ: S[5] = 1.0; break;
   case REF_J_PU: S[0] = axis[0]; S[1] = axis[1]; S[2] = axis[2]; break;
   case REF_J_RU: S[3] = axis[0]; S[4] = axis[1]; S[5] = axis[2]; break;
+  case REF_J_FREEFLYER: for (int c = 0; c < 6; ++c) S[6 * c + c] = 1.0; break;        /* ConstraintIdentity */
+  case REF_J_SPHERICAL: for (int c = 0; c < 3; ++c) S[6 * c + 3 + c] = 1.0; break;    /* angular block      */
+  case REF_J_TRANSLATION: for (int c = 0; c < 3; ++c) S[6 * c + c] = 1.0; break;      /* linear block       */
   default: break;
   }
 }
 
+/* inverse of a symmetric positive definite n x n matrix (n <= 6) by Cholesky, the way Pinocchio's
+ * internal::PerformStYSInversion does it (Dinv.setIdentity(); StYS.llt().solveInPlace(Dinv)) */
+static void spd_inverse(const double *A, int n, double *Ainv)
+{
+  double L[36];
+  memset(L, 0, sizeof(L));
+  for (int j = 0; j < n; ++j) {
+    double d = A[n * j + j];
+    for (int k = 0; k < j; ++k) d -= L[n * j + k] * L[n * j + k];
+    d = sqrt(d);
+    L[n * j + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double x = A[n * i + j];
+      for (int k = 0; k < j; ++k) x -= L[n * i + k] * L[n * j + k];
+      L[n * i + j] = x / d;
+    }
+  }
+  for (int c = 0; c < n; ++c) {
+    double y[6];
+    for (int i = 0; i < n; ++i) { /* L y = e_c */
+      double x = (i == c) ? 1.0 : 0.0;
+      for (int k = 0; k < i; ++k) x -= L[n * i + k] * y[k];
+      y[i] = x / L[n * i + i];
+    }
+    for (int i = n - 1; i >= 0; --i) { /* L^T x = y */
+      double x = y[i];
+      for (int k = i + 1; k < n; ++k) x -= L[n * k + i] * Ainv[n * k + c];
+      Ainv[n * i + c] = x / L[n * i + i];
+    }
+  }
+}
+
 /* JointModel::calc_aba(jdata, armature, I, update_I)    [call site hxx:60-63]
- *   U = I S ; Dinv = 1/(S^T U + armature) ; UDinv = U Dinv ; if (update_I) I -= UDinv U^T */
-static void joint_calc_aba(const double *S, double armature, double *I, int update_I, double *U,
+ *   U = I S ; Dinv = (S^T U + diag(armature))^-1 ; UDinv = U Dinv ; if (update_I) I -= UDinv U^T
+ * U, UDinv: 6 x n (column c at [6c, 6c+6)); Dinv: n x n row-major.  n = 1 is the scalar formula. */
+static void joint_calc_aba(const double *S, int n, const double *armature, double *I, int update_I, double *U,
                            double *Dinv, double *UDinv)
 {
-  mat6_vec(I, S, U);
-  double d = 0.0;
-  for (int k = 0; k < 6; ++k) d += S[k] * U[k];
-  *Dinv = 1.0 / (d + armature);
-  for (int k = 0; k < 6; ++k) UDinv[k] = U[k] * (*Dinv);
+  double StU[36];
+  for (int c = 0; c < n; ++c) mat6_vec(I, S + 6 * c, U + 6 * c);
+  for (int a = 0; a < n; ++a)
+    for (int b = 0; b < n; ++b) {
+      double d = 0.0;
+      for (int k = 0; k < 6; ++k) d += S[6 * a + k] * U[6 * b + k];
+      StU[n * a + b] = d;
+    }
+  for (int a = 0; a < n; ++a) StU[n * a + a] += armature[a];
+  if (n == 1) Dinv[0] = 1.0 / StU[0];
+  else spd_inverse(StU, n, Dinv);
+  for (int c = 0; c < n; ++c)
+    for (int k = 0; k < 6; ++k) {
+      double x = 0.0;
+      for (int j = 0; j < n; ++j) x += U[6 * j + k] * Dinv[n * j + c];
+      UDinv[6 * c + k] = x;
+    }
   if (update_I)
     for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) I[6 * i + j] -= UDinv[i] * U[j];
+      for (int j = 0; j < 6; ++j) {
+        double x = 0.0;
+        for (int c = 0; c < n; ++c) x += UDinv[6 * c + i] * U[6 * c + j];
+        I[6 * i + j] -= x;
+      }
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -259,12 +354,13 @@ static void joint_calc_aba(const double *S, double armature, double *I, int upda
 struct ref_solver {
   /* model (copied, reference keeps `Model model_` by value, loik-loid-optimized.hpp:762) */
   int nj, nb, nq, nv, nc;
-  int *parents, *jtype, *idx_q, *idx_v;
+  int *parents, *jtype, *idx_q, *idx_v, *jnv, *massless;
   double *axis, *placement;
 
   /* --- IkIdDataTypeOptimizedTpl members (loik-loid-data-optimized.hxx:40-86) --- */
   double *oMi, *liMi;                /* [nj][12] */
-  double *jS, *jU, *jUDinv, *jDinv;  /* JointData: S,U,UDinv [nj][6], Dinv [nj] */
+  double *jS, *jU, *jUDinvM, *jDinvM; /* JointData: S,U,UDinv [nj][36] (6 x nv_i, column-wise), Dinv [nj][36] */
+  double *jUDinv, *jDinv;            /* first column / [0][0] entry of the above: the 1-DoF view ([nj][6], [nj]) */
   double *nu, *nu_prev;              /* [nv] */
   double *vis, *vis_prev;            /* [nj][6] */
   double *His, *His_aba;             /* [nj][36] */
@@ -379,12 +475,18 @@ int ref_create(const ref_model *m, const ref_params *p, ref_solver **out)
   memcpy(s->idx_v, m->idx_v, sizeof(int) * nj);
   memcpy(s->axis, m->axis, sizeof(double) * 3 * nj);
   memcpy(s->placement, m->placement, sizeof(double) * 12 * nj);
+  s->jnv = (int *)calloc(nj, sizeof(int));
+  s->massless = (int *)calloc(nj, sizeof(int));
+  for (int i = 1; i < nj; ++i) s->jnv[i] = joint_nv(s->jtype[i]);
+  if (m->massless) memcpy(s->massless, m->massless, sizeof(int) * nj);
+  (void)joint_nq;
 
   /* data ctor, loik-loid-data-optimized.hxx:40-86 */
   s->oMi = dalloc(12 * nj); s->liMi = dalloc(12 * nj);
   for (int i = 0; i < nj; ++i) { se3_identity(s->oMi + 12 * i); se3_identity(s->liMi + 12 * i); }
-  s->jS = dalloc(6 * nj); s->jU = dalloc(6 * nj); s->jUDinv = dalloc(6 * nj); s->jDinv = dalloc(nj);
-  for (int i = 0; i < nj; ++i) joint_S(s->jtype[i], s->axis + 3 * i, s->jS + 6 * i);
+  s->jS = dalloc(36 * nj); s->jU = dalloc(36 * nj); s->jUDinvM = dalloc(36 * nj); s->jDinvM = dalloc(36 * nj);
+  s->jUDinv = dalloc(6 * nj); s->jDinv = dalloc(nj);
+  for (int i = 0; i < nj; ++i) joint_S(s->jtype[i], s->axis + 3 * i, s->jS + 36 * i);
   s->nu = dalloc(nv); s->nu_prev = dalloc(nv);
   s->vis = dalloc(6 * nj); s->vis_prev = dalloc(6 * nj);
   s->His = dalloc(36 * nj); s->His_aba = dalloc(36 * nj);
@@ -433,7 +535,9 @@ void ref_destroy(ref_solver *s)
 {
   if (!s) return;
   free(s->parents); free(s->jtype); free(s->idx_q); free(s->idx_v); free(s->axis); free(s->placement);
-  free(s->oMi); free(s->liMi); free(s->jS); free(s->jU); free(s->jUDinv); free(s->jDinv);
+  free(s->jnv); free(s->massless);
+  free(s->oMi); free(s->liMi); free(s->jS); free(s->jU); free(s->jUDinvM); free(s->jDinvM);
+  free(s->jUDinv); free(s->jDinv);
   free(s->nu); free(s->nu_prev); free(s->vis); free(s->vis_prev); free(s->His); free(s->His_aba);
   free(s->pis); free(s->pis_aba); free(s->R); free(s->r); free(s->fis); free(s->delta_fis);
   free(s->yis); free(s->delta_yis); free(s->w); free(s->delta_w); free(s->z); free(s->z_prev);
@@ -505,6 +609,10 @@ static void problem_update_reference(ref_solver *s, const double *H_ref, const d
     memcpy(s->H_refs + 36 * i, H_ref, 36 * sizeof(double));
     memcpy(s->v_refs + 6 * i, v_ref, 6 * sizeof(double));
     mat6_vec(s->H_refs + 36 * i, s->v_refs + 6 * i, s->Hv + 6 * i);
+    if (s->massless[i]) { /* test-only concept, see loik_ref.h: the link has no reference cost */
+      memset(s->H_refs + 36 * i, 0, 36 * sizeof(double));
+      memset(s->Hv + 6 * i, 0, 6 * sizeof(double));
+    }
   }
   s->Hv_inf_norm = inf_norm(s->Hv, 6);
 }
@@ -577,7 +685,7 @@ void ref_fwd_pass_init(ref_solver *s, const double *q)
   double M[12];
   for (int idx = 1; idx < s->nj; ++idx) {
     int parent = s->parents[idx];
-    joint_calc(s->jtype[idx], s->axis + 3 * idx, q[s->idx_q[idx]], M);
+    joint_calc(s->jtype[idx], s->axis + 3 * idx, q + s->idx_q[idx], M);
     se3_mul(s->placement + 12 * idx, M, s->liMi + 12 * idx);
     se3_mul(s->oMi + 12 * parent, s->liMi + 12 * idx, s->oMi + 12 * idx);
   }
@@ -599,13 +707,16 @@ void ref_fwd_pass1(ref_solver *s)
     double *Hi = s->His + 36 * idx;
     const double *H_ref = s->H_refs + 36 * idx;
     const double *Hv_i = s->Hv + 6 * idx;
+    /* a massless link (test-only concept, see loik_ref.h) has no rho I + H_ref and no reference term: its
+       H_refs / Hv rows are zero (problem_update_reference) and rho is dropped here */
+    const double rho_i = s->massless[idx] ? 0.0 : s->rho;
     memset(Hi, 0, 36 * sizeof(double));
     for (int k = 0; k < 6; ++k) Hi[7 * k] = 1.0;
-    for (int k = 0; k < 36; ++k) Hi[k] *= s->rho;
+    for (int k = 0; k < 36; ++k) Hi[k] *= rho_i;
     for (int k = 0; k < 36; ++k) Hi[k] += H_ref[k];
     memcpy(s->His_aba + 36 * idx, Hi, 36 * sizeof(double));
     for (int k = 0; k < 6; ++k) {
-      s->pis[6 * idx + k] = -s->rho * s->vis_prev[6 * idx + k];
+      s->pis[6 * idx + k] = -rho_i * s->vis_prev[6 * idx + k];
       s->pis[6 * idx + k] -= Hv_i[k];
     }
     memcpy(s->pis_aba + 6 * idx, s->pis + 6 * idx, 6 * sizeof(double));
@@ -632,19 +743,28 @@ void ref_bwd_pass(ref_solver *s)
     double *Hi_aba = s->His_aba + 36 * idx;
     const double *pi = s->pis + 6 * idx;
     double *pi_aba = s->pis_aba + 6 * idx;
-    const double *S = s->jS + 6 * idx;
-    int iv = s->idx_v[idx];
+    const double *S = s->jS + 36 * idx;
+    const int iv = s->idx_v[idx], n = s->jnv[idx];
+    double *UDinv = s->jUDinvM + 36 * idx;
 
-    joint_calc_aba(S, s->R[iv], Hi_aba, parent > 0, s->jU + 6 * idx, s->jDinv + idx, s->jUDinv + 6 * idx);
+    joint_calc_aba(S, n, s->R + iv, Hi_aba, parent > 0, s->jU + 36 * idx, s->jDinvM + 36 * idx, UDinv);
+    memcpy(s->jUDinv + 6 * idx, UDinv, 6 * sizeof(double));
+    s->jDinv[idx] = s->jDinvM[36 * idx];
 
     se3_act_on(liMi, Hi_aba, acted);
     for (int k = 0; k < 36; ++k) s->His_aba[36 * parent + k] += acted[k];
     memcpy(s->His + 36 * parent, s->His_aba + 36 * parent, 36 * sizeof(double));
 
-    double Stp = 0.0;
-    for (int k = 0; k < 6; ++k) Stp += S[k] * pi[k];
-    s->r[iv] += Stp;
-    for (int k = 0; k < 6; ++k) tmp[k] = s->jUDinv[6 * idx + k] * s->r[iv];
+    for (int c = 0; c < n; ++c) { /* jointVelocitySelector(r) += S^T p (hxx:70) */
+      double Stp = 0.0;
+      for (int k = 0; k < 6; ++k) Stp += S[6 * c + k] * pi[k];
+      s->r[iv + c] += Stp;
+    }
+    for (int k = 0; k < 6; ++k) {
+      double x = 0.0;
+      for (int c = 0; c < n; ++c) x += UDinv[6 * c + k] * s->r[iv + c];
+      tmp[k] = x;
+    }
     for (int k = 0; k < 6; ++k) pi_aba[k] -= tmp[k];
     se3_act_force(liMi, pi_aba, f);
     for (int k = 0; k < 6; ++k) s->pis[6 * parent + k] += f[k];
@@ -661,16 +781,21 @@ void ref_fwd_pass2(ref_solver *s)
     int parent = s->parents[idx];
     int iv = s->idx_v[idx];
     const double *Hi = s->His + 36 * idx, *pi = s->pis + 6 * idx, *liMi = s->liMi + 12 * idx;
-    const double *S = s->jS + 6 * idx, *UDinv = s->jUDinv + 6 * idx;
+    const double *S = s->jS + 36 * idx, *UDinv = s->jUDinvM + 36 * idx, *Dinv = s->jDinvM + 36 * idx;
+    const int nvj = s->jnv[idx];
 
     se3_actinv_motion(liMi, s->vis + 6 * parent, vp);
-    double udv = 0.0;
-    for (int k = 0; k < 6; ++k) udv += UDinv[k] * vp[k];
-    s->nu[iv] = -udv - s->jDinv[idx] * s->r[iv];
-    if (fabs(s->nu[iv]) > s->nu_inf_norm) s->nu_inf_norm = fabs(s->nu[iv]);
+    for (int c = 0; c < nvj; ++c) { /* nu_i = -UDinv^T v' - Dinv r_i (hxx:127) */
+      double udv = 0.0, dr = 0.0;
+      for (int k = 0; k < 6; ++k) udv += UDinv[6 * c + k] * vp[k];
+      for (int j = 0; j < nvj; ++j) dr += Dinv[nvj * c + j] * s->r[iv + j];
+      s->nu[iv + c] = -udv - dr;
+      if (fabs(s->nu[iv + c]) > s->nu_inf_norm) s->nu_inf_norm = fabs(s->nu[iv + c]);
+    }
 
     for (int k = 0; k < 6; ++k) s->vis[6 * idx + k] = vp[k];
-    for (int k = 0; k < 6; ++k) s->vis[6 * idx + k] += S[k] * s->nu[iv];
+    for (int c = 0; c < nvj; ++c)
+      for (int k = 0; k < 6; ++k) s->vis[6 * idx + k] += S[6 * c + k] * s->nu[iv + c];
 
     memcpy(s->delta_fis + 6 * idx, s->fis + 6 * idx, 6 * sizeof(double));
     mat6_vec(Hi, s->vis + 6 * idx, Hv6);
@@ -685,7 +810,9 @@ void ref_fwd_pass2(ref_solver *s)
 
     for (int k = 0; k < 6; ++k) d6[k] = s->vis[6 * idx + k] - s->vis_prev[6 * idx + k];
     n = inf_norm(d6, 6);
-    if (n > s->delta_vis_inf_norm) s->delta_vis_inf_norm = n;
+    /* a massless chain link (test-only concept, loik_ref.h) is not a body of the reference's model: its partial
+       velocity must not enter the norm over the links */
+    if (n > s->delta_vis_inf_norm && !s->massless[idx]) s->delta_vis_inf_norm = n;
 
     memset(s->g + 6 * idx, 0, 6 * sizeof(double)); /* hxx:370 */
   }
@@ -754,7 +881,7 @@ static void bwd_pass2(ref_solver *s)
   for (int idx = s->nj - 1; idx > 0; --idx) {
     int parent = s->parents[idx];
     int iv = s->idx_v[idx];
-    const double *liMi = s->liMi + 12 * idx, *fi = s->fis + 6 * idx, *S = s->jS + 6 * idx;
+    const double *liMi = s->liMi + 12 * idx, *fi = s->fis + 6 * idx, *S = s->jS + 36 * idx;
     for (int k = 0; k < 6; ++k) s->g[6 * idx + k] += -fi[k];
     se3_act_force(liMi, fi, f);
     for (int k = 0; k < 6; ++k) s->g[6 * parent + k] += f[k];
@@ -765,10 +892,12 @@ static void bwd_pass2(ref_solver *s)
     if (n > s->g_inf_norm) s->g_inf_norm = n;
     for (int k = 0; k < 6; ++k)
       s->dual_residual_vec[6 * (idx - 1) + k] = s->Href_v[6 * idx + k] - s->Hv[6 * idx + k] + s->g[6 * idx + k];
-    double Stf = 0.0;
-    for (int k = 0; k < 6; ++k) Stf += S[k] * fi[k];
-    s->Stf_plus_w[iv] = Stf + s->w[iv];
-    if (fabs(s->Stf_plus_w[iv]) > s->Stf_plus_w_inf_norm) s->Stf_plus_w_inf_norm = fabs(s->Stf_plus_w[iv]);
+    for (int c = 0; c < s->jnv[idx]; ++c) {
+      double Stf = 0.0;
+      for (int k = 0; k < 6; ++k) Stf += S[6 * c + k] * fi[k];
+      s->Stf_plus_w[iv + c] = Stf + s->w[iv + c];
+      if (fabs(s->Stf_plus_w[iv + c]) > s->Stf_plus_w_inf_norm) s->Stf_plus_w_inf_norm = fabs(s->Stf_plus_w[iv + c]);
+    }
   }
   for (int k = 0; k < s->nv; ++k) s->delta_Stf_plus_w[k] = s->Stf_plus_w[k] - s->delta_Stf_plus_w[k];
   s->delta_Stf_plus_w_inf_norm = inf_norm(s->delta_Stf_plus_w, s->nv);
@@ -953,6 +1082,8 @@ const double *ref_field(const ref_solver *s, int field, int *len)
   case REF_F_R_VEC: p = s->r; n = s->nv; break;
   case REF_F_UDINV: p = s->jUDinv; n = 6 * s->nj; break;
   case REF_F_DINV: p = s->jDinv; n = s->nj; break;
+  case REF_F_UDINV_FULL: p = s->jUDinvM; n = 36 * s->nj; break;
+  case REF_F_DINV_FULL: p = s->jDinvM; n = 36 * s->nj; break;
   case REF_F_PRIMAL_RES_VEC: p = s->primal_residual_vec; n = 6 * s->nb + s->nv; break;
   case REF_F_DUAL_RES_VEC: p = s->dual_residual_vec; n = 6 * s->nb + s->nv; break;
   case REF_F_DELTA_W: p = s->delta_w; n = s->nv; break;

@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-/* joint types (1-DoF joints only; Pinocchio names in comments) */
+/* joint types (Pinocchio names in comments).  The multi-DoF ones are the joints whose motion subspace is a constant
+ * selection of the columns of I6 */
 enum {
   REF_J_NONE = 0, /* universe */
   REF_J_RX = 1,   /* JointModelRX */
@@ -36,7 +37,10 @@ enum {
   REF_J_PY = 5,
   REF_J_PZ = 6,
   REF_J_RU = 7,   /* JointModelRevoluteUnaligned  */
-  REF_J_PU = 8    /* JointModelPrismaticUnaligned */
+  REF_J_PU = 8,   /* JointModelPrismaticUnaligned */
+  REF_J_FREEFLYER = 9,   /* JointModelFreeFlyer:   nq 7 (t, quat xyzw), nv 6, S = I6               */
+  REF_J_SPHERICAL = 10,  /* JointModelSpherical:   nq 4 (quat xyzw),    nv 3, S = [0; I3]          */
+  REF_J_TRANSLATION = 11 /* JointModelTranslation: nq 3,                nv 3, S = [I3; 0]          */
 };
 
 /* mirrors enum ADMMPenaltyUpdateStrat, task-solver-base.hpp:13-18 */
@@ -63,6 +67,10 @@ typedef struct ref_model {
   const int *idx_q;        /* [nj]                                                   */
   const int *idx_v;        /* [nj]                                                   */
   const double *placement; /* [nj][12] jointPlacements: R row-major (9) then t (3)   */
+  const int *massless;     /* [nj] or NULL.  1 = the link carries no cost of its own (no rho I + H_ref, no
+                              H_ref v_ref term): the intermediate bodies of a multi-DoF joint written as a chain
+                              of 1-DoF joints.  Not a reference concept -- it exists so that the tests can prove
+                              that such a chain reproduces the multi-DoF joint (the device's representation).   */
 } ref_model;
 
 typedef struct ref_params {
@@ -129,13 +137,15 @@ enum {
   REF_F_G,          /* fis_diff_plus_Aty [nj][6] */
   REF_F_STF_PLUS_W, /* [nv]      */
   REF_F_R_VEC,      /* r [nv]    */
-  REF_F_UDINV,      /* [nj][6]   */
-  REF_F_DINV,       /* [nj]      */
+  REF_F_UDINV,      /* [nj][6]: first column (all of it for a 1-DoF joint) */
+  REF_F_DINV,       /* [nj]:    [0][0] entry                               */
   REF_F_PRIMAL_RES_VEC, /* [6nb+nv] */
   REF_F_DUAL_RES_VEC,   /* [6nb+nv] */
   REF_F_DELTA_W,    /* [nv] */
   REF_F_HIS_ABA,    /* [nj][36] */
   REF_F_PIS_ABA,    /* [nj][6]  */
+  REF_F_UDINV_FULL, /* [nj][36]: 6 x nv_i, column c at [6c, 6c+6)                 */
+  REF_F_DINV_FULL,  /* [nj][36]: nv_i x nv_i row-major in the leading entries      */
   REF_F_COUNT
 };
 const double *ref_field(const ref_solver *s, int field, int *len);

@@ -17,7 +17,7 @@ _c_int_p = C.POINTER(C.c_int)
 class RefModel(C.Structure):
     _fields_ = [("njoints", C.c_int), ("nq", C.c_int), ("nv", C.c_int),
                 ("parents", _c_int_p), ("jtype", _c_int_p), ("axis", _c_double_p),
-                ("idx_q", _c_int_p), ("idx_v", _c_int_p), ("placement", _c_double_p)]
+                ("idx_q", _c_int_p), ("idx_v", _c_int_p), ("placement", _c_double_p), ("massless", _c_int_p)]
 
 
 class RefParams(C.Structure):
@@ -32,7 +32,7 @@ class RefParams(C.Structure):
 # field / scalar ids, keep in sync with loik_ref.h
 FIELDS = ["liMi", "oMi", "vis", "vis_prev", "fis", "His", "pis", "nu", "z", "w", "yis", "Aty", "g",
           "Stf_plus_w", "r", "UDinv", "Dinv", "primal_residual_vec", "dual_residual_vec", "delta_w",
-          "His_aba", "pis_aba"]
+          "His_aba", "pis_aba", "UDinv_full", "Dinv_full"]
 SCALARS = ["iter", "converged", "primal_infeasible", "dual_infeasible", "primal_residual", "dual_residual",
            "primal_residual_task", "primal_residual_slack", "dual_residual_v", "dual_residual_nu",
            "tol_primal", "tol_dual", "mu", "mu_eq", "mu_ineq", "delta_x_qp_inf_norm", "delta_z_qp_inf_norm",
@@ -116,9 +116,11 @@ class _ModelHolder:
         self.idx_q = _i32(model.idx_q)
         self.idx_v = _i32(model.idx_v)
         self.placement = _f64(model.placement)
+        massless = getattr(model, "massless", None)
+        self.massless = None if massless is None else _i32(massless)
         self.struct = RefModel(int(model.njoints), int(model.nq), int(model.nv), _ip(self.parents),
                                _ip(self.jtype), _dp(self.axis), _ip(self.idx_q), _ip(self.idx_v),
-                               _dp(self.placement))
+                               _dp(self.placement), None if self.massless is None else _ip(self.massless))
 
 
 def make_params(max_iter=200, tol_abs=1e-3, tol_rel=1e-3, tol_primal_inf=1e-2, tol_dual_inf=1e-2, rho=1e-5,
@@ -214,7 +216,8 @@ class RefSolver:
         nj = self.model.njoints
         shapes = {"liMi": (nj, 12), "oMi": (nj, 12), "vis": (nj, 6), "vis_prev": (nj, 6), "fis": (nj, 6),
                   "His": (nj, 6, 6), "pis": (nj, 6), "yis": (-1, 6), "Aty": (-1, 6), "g": (nj, 6),
-                  "UDinv": (nj, 6), "His_aba": (nj, 6, 6), "pis_aba": (nj, 6)}
+                  "UDinv": (nj, 6), "His_aba": (nj, 6, 6), "pis_aba": (nj, 6), "UDinv_full": (nj, 6, 6),
+                  "Dinv_full": (nj, 36)}
         return a.reshape(shapes[name]) if name in shapes else a
 
     def scalar(self, name):
@@ -242,6 +245,7 @@ def solve_batch(model, q, H_ref, v_ref, c_ids, Ais, bis, lb, ub, nthreads=1, nat
     mh = _ModelHolder(model)
     prm = make_params(**params)
     q = _f64(q); B = q.shape[0]; nv = model.nv
+    assert q.shape[1] == model.nq
     H_ref = _f64(H_ref).reshape(36); v_ref = _f64(v_ref).reshape(6); c_ids = _i32(c_ids)
     nc = int(c_ids.size)
     Ais = _f64(Ais); bis = _f64(bis); lb = _f64(lb); ub = _f64(ub)

@@ -107,3 +107,71 @@ def feasible_batch(model, batch, link, seed, bound=0.5, nu_scale=0.4, per_instan
         wl["lb"] = -bound * (1 + 0.2 * rng.random((batch, model.nv)))
         wl["ub"] = bound * (1 + 0.2 * rng.random((batch, model.nv)))
     return wl
+
+
+# ---- multi-DoF joints (free-flyer / spherical / translation) ------------------------------------------------------
+J_FREEFLYER, J_SPHERICAL, J_TRANSLATION = 9, 10, 11
+# virtual 1-DoF joint types of the chain that stands for a multi-DoF joint (S = the columns of I6 it selects)
+CHAIN_TYPES = {J_FREEFLYER: [4, 5, 6, 1, 2, 3], J_SPHERICAL: [1, 2, 3], J_TRANSLATION: [4, 5, 6]}
+
+
+def random_tree_multidof(seed, nb, root_freeflyer=True, n_spherical=1, n_translation=1, branch_prob=0.3):
+    """random_tree() with some joints replaced by multi-DoF ones (optionally a free-flyer root joint: the
+    floating-base case of SURVEY.md 8(f) rank 2)"""
+    m = random_tree(seed, nb, branch_prob=branch_prob)
+    rng = np.random.default_rng(seed + 77)
+    jt = m.jtype.copy()
+    if root_freeflyer:
+        jt[1] = J_FREEFLYER
+    cand = [i for i in range(2 if root_freeflyer else 1, nb + 1)]
+    rng.shuffle(cand)
+    for i in cand[:n_spherical]:
+        jt[i] = J_SPHERICAL
+    for i in cand[n_spherical:n_spherical + n_translation]:
+        jt[i] = J_TRANSLATION
+    return loik_amd.Model(m.parents, jt, m.axis, m.placement, name="random_multidof_%d_%d" % (seed, nb))
+
+
+def expand_to_chains(model, q):
+    """The all-1-DoF model the device solves instead of `model` (single configuration q): every multi-DoF joint becomes
+    a chain of 1-DoF joints about the axes of ONE frame (identity placements in between) whose intermediate links are
+    massless; M(q) of the joint is folded into the placement of the first chain joint.  Returns (model1, q1, link_of)
+    with link_of[i] = the chain link that carries body i."""
+    from loik_amd import workloads as W
+    parents, types, axis, placement, massless, link_of = [0], [0], [np.zeros(3)], [model.placement[0]], [0], [0]
+    for i in range(1, model.njoints):
+        t = int(model.jtype[i])
+        par = link_of[int(model.parents[i])]
+        if t not in CHAIN_TYPES:
+            parents.append(par); types.append(t); axis.append(model.axis[i]); placement.append(model.placement[i])
+            massless.append(0)
+            link_of.append(len(parents) - 1)
+            continue
+        iq = int(model.idx_q[i])
+        P = model.placement[i]
+        Rp, tp = P[:9].reshape(3, 3), P[9:]
+        if t == J_FREEFLYER:
+            Rj, tj = W.quat_rot(q[None, iq + 3:iq + 7])[0], q[iq:iq + 3]
+        elif t == J_SPHERICAL:
+            Rj, tj = W.quat_rot(q[None, iq:iq + 4])[0], np.zeros(3)
+        else:
+            Rj, tj = np.eye(3), q[iq:iq + 3]
+        first = np.concatenate([(Rp @ Rj).ravel(), tp + Rp @ tj])
+        ident = np.concatenate([np.eye(3).ravel(), np.zeros(3)])
+        chain = CHAIN_TYPES[t]
+        for k, ct in enumerate(chain):
+            parents.append(par if k == 0 else len(parents) - 1)
+            types.append(ct)
+            a = np.zeros(3); a[(ct - 1) % 3] = 1.0
+            axis.append(a)
+            placement.append(first if k == 0 else ident)
+            massless.append(0 if k == len(chain) - 1 else 1)
+        link_of.append(len(parents) - 1)
+    m1 = loik_amd.Model(parents, types, np.array(axis), np.array(placement), name=model.name + "_chains")
+    m1.massless = np.array(massless, dtype=np.int32)
+    # configuration of the chain model: the 1-DoF joints keep their q, the chain joints sit at 0
+    q1 = np.zeros(m1.nq)
+    for i in range(1, model.njoints):
+        if int(model.jtype[i]) not in CHAIN_TYPES:
+            q1[int(m1.idx_q[link_of[i]])] = q[int(model.idx_q[i])]
+    return m1, q1, np.array(link_of)
