@@ -8,7 +8,10 @@
  * same names and memory order (joint 0 = universe, parents[i] < i, 6-vectors [linear; angular]) so a
  * Pinocchio -> loikb adapter is a field-by-field copy.
  *
- * Only 1-DoF joints are supported in this round (SURVEY.md 8(f) rank 2 lists multi-DoF joints as "next").
+ * Joints: all of Pinocchio's 1-DoF types, and the multi-DoF types whose motion subspace is a constant selection of the
+ * columns of I6 -- free-flyer (floating base), spherical, translation.  On the device such a
+ * joint is a chain of 1-DoF joints with massless links in between; the caller never sees that: q, z / nu / w / lb / ub
+ * (length model.nv, Pinocchio's idx_v order) and the per-link results are the caller's model's.
  */
 #ifndef LOIK_AMD_MODELS_H
 #define LOIK_AMD_MODELS_H
@@ -17,7 +20,8 @@
 extern "C" {
 #endif
 
-/* joint types; names follow Pinocchio's JointModel{RX,RY,RZ,PX,PY,PZ,RevoluteUnaligned,PrismaticUnaligned} */
+/* joint types; names follow Pinocchio's JointModel{RX,RY,RZ,PX,PY,PZ,RevoluteUnaligned,PrismaticUnaligned,
+ * FreeFlyer,Spherical,Translation} */
 enum {
   LOIKB_J_NONE = 0, /* universe */
   LOIKB_J_RX = 1,
@@ -27,7 +31,10 @@ enum {
   LOIKB_J_PY = 5,
   LOIKB_J_PZ = 6,
   LOIKB_J_RU = 7,
-  LOIKB_J_PU = 8
+  LOIKB_J_PU = 8,
+  LOIKB_J_FREEFLYER = 9,   /* nq 7: translation, quaternion (x,y,z,w); nv 6: [linear; angular] in the joint frame */
+  LOIKB_J_SPHERICAL = 10,  /* nq 4: quaternion (x,y,z,w);              nv 3: angular velocity in the joint frame  */
+  LOIKB_J_TRANSLATION = 11 /* nq 3, nv 3                                                                          */
 };
 
 typedef struct loikb_model_desc {
@@ -36,8 +43,8 @@ typedef struct loikb_model_desc {
   const int *parents;      /* [njoints] model.parents                                         */
   const int *jtype;        /* [njoints] LOIKB_J_*                                             */
   const double *axis;      /* [njoints][3] unit axis in the joint frame (e_k for aligned)     */
-  const int *idx_q;        /* [njoints] joints[i].idx_q()                                     */
-  const int *idx_v;        /* [njoints] joints[i].idx_v()                                     */
+  const int *idx_q;        /* [njoints] joints[i].idx_q(): cumulative in joint order          */
+  const int *idx_v;        /* [njoints] joints[i].idx_v(): cumulative in joint order          */
   const double *placement; /* [njoints][12] jointPlacements[i]: R row-major (9), then t (3)   */
 } loikb_model_desc;
 
@@ -46,8 +53,10 @@ typedef struct loikb_model_desc {
  *   "panda7"  : Franka Panda arm, 7 revolute-z joints, chain
  *   "panda9"  : panda7 + two prismatic fingers (PY and prismatic-unaligned -y), as example-robot-data's panda.urdf
  *   "talos32" : Talos humanoid topology, fixed base, legs(6+6) torso(2) arms(7+1, 7+1) head(2)
+ *   "talos32_freeflyer" : the same robot under a free-flyer "root_joint" (floating base): 33 joints, nq 39, nv 38
  * Returns 0 and fills *out with pointers to static storage valid for the process lifetime, or -1.
- * q_lo / q_hi (may be NULL) receive pointers to [nq] sampling ranges for synthetic configurations.
+ * q_lo / q_hi (may be NULL) receive pointers to [nq] sampling ranges for synthetic configurations (the quaternion
+ * entries of a free-flyer are placeholders: draw unit quaternions).
  */
 int loikb_builtin_model(const char *name, loikb_model_desc *out, const double **q_lo, const double **q_hi);
 /* joint name of a built-in model (index 0 = "universe"), or NULL */

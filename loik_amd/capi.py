@@ -208,7 +208,7 @@ class Model:
 
 
 def builtin_model(name):
-    """'panda7' | 'panda9' | 'talos32' (tables in loik_amd/csrc/models.c)"""
+    """'panda7' | 'panda9' | 'talos32' | 'talos32_freeflyer' (tables in loik_amd/csrc/models.c)"""
     L = lib()
     d = ModelDesc()
     lo, hi = _dp(), _dp()
@@ -218,8 +218,8 @@ def builtin_model(name):
     arr = lambda p, n, t: np.ctypeslib.as_array(p, shape=(n,)).astype(t).copy()
     names = [L.loikb_builtin_joint_name(name.encode(), i).decode() for i in range(nj)]
     return Model(arr(d.parents, nj, np.int32), arr(d.jtype, nj, np.int32), arr(d.axis, 3 * nj, np.float64),
-                 arr(d.placement, 12 * nj, np.float64), names, arr(lo, nj - 1, np.float64),
-                 arr(hi, nj - 1, np.float64), name=name)
+                 arr(d.placement, 12 * nj, np.float64), names, arr(lo, d.nq, np.float64),
+                 arr(hi, d.nq, np.float64), name=name)
 
 
 def _ptr(a):
@@ -373,9 +373,11 @@ class BatchedLoik:
     def get(self, name, out=None):
         """one field for the whole batch as a numpy array (or into a device pointer / torch tensor `out`)"""
         fid = FIELD_ID[name]
-        B, nb, nc = self.batch, self.model.njoints - 1, self.nc
-        shapes = {"z": (B, nb), "nu": (B, nb), "w": (B, nb), "Stf_plus_w": (B, nb), "r": (B, nb), "Dinv": (B, nb),
-                  "vis": (B, nb, 6), "fis": (B, nb, 6), "g": (B, nb, 6), "pis": (B, nb, 6), "UDinv": (B, nb, 6),
+        B, nb, nv, nc = self.batch, self.model.njoints - 1, self.model.nv, self.nc
+        # per DoF: [B][nv]; per link: [B][nb].  r / Dinv / UDinv are inter-sweep temporaries of the device's
+        # elimination: per DoF, equal to upstream's per-joint values for 1-DoF joints only
+        shapes = {"z": (B, nv), "nu": (B, nv), "w": (B, nv), "Stf_plus_w": (B, nv), "r": (B, nv), "Dinv": (B, nv),
+                  "vis": (B, nb, 6), "fis": (B, nb, 6), "g": (B, nb, 6), "pis": (B, nb, 6), "UDinv": (B, nv, 6),
                   "His": (B, nb, 21), "liMi": (B, nb, 12), "yis": (B, nc, 6), "Aty": (B, nc, 6),
                   "q": (B, self.model.nq)}
         is_int = name in ("iter", "converged", "primal_infeasible", "status", "mu_updates")

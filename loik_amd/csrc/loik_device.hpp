@@ -85,11 +85,16 @@ struct Layout {
 // joint flags (uniform per joint)
 enum : int {
   JF_PARENT_ROOT = 2,     // parent is the universe: contribution discarded (update_I = parent > 0, hxx:63)
+  JF_MASSLESS = 4,        // intermediate link of the chain that stands for a multi-DoF joint: no rho I + H_ref, no
+                          // reference term, not counted in the norms over the links (see build_schedule)
+  JF_NOQ = 8,             // chain joint after the first: its transform is the identity whatever its JP_CS pair holds
   JF_REVOLUTE = 16,       // S = [0; axis], else prismatic S = [axis; 0]
 };
 
-// rotation generator selector for M(q)
-enum : int { ROT_X = 0, ROT_Y = 1, ROT_Z = 2, ROT_U = 3, ROT_NONE = 4 };
+// rotation generator selector for M(q).  ROT_FREE / ROT_SPH / ROT_TRANS: first joint of the chain of a free-flyer /
+// spherical / translation joint -- M(q) = (R(quat), t) comes from the JP_CS pairs of this and the next chain records:
+//   free-flyer (tx,ty) (tz,qx) (qy,qz) (qw,-) ; spherical (qx,qy) (qz,qw) ; translation (tx,ty) (tz,-)
+enum : int { ROT_X = 0, ROT_Y = 1, ROT_Z = 2, ROT_U = 3, ROT_NONE = 4, ROT_FREE = 5, ROT_SPH = 6, ROT_TRANS = 7 };
 
 struct JointDesc {
   double Rp[9];   // jointPlacements[i].rotation(), row-major
@@ -298,6 +303,54 @@ __device__ __forceinline__ void make_liMi(const JointDesc& d, T c, T s, T* R, T*
 #pragma unroll
     for (int k = 0; k < 3; ++k) t[k] = tp[k] + rt[k];
   }
+}
+
+// Eigen::Quaternion::toRotationMatrix, coefficients (x, y, z, w) as Pinocchio stores them in q
+template <typename T>
+__device__ __forceinline__ void quat_to_rot(T x, T y, T z, T w, T* R)
+{
+  const T tx = T(2) * x, ty = T(2) * y, tz = T(2) * z;
+  const T twx = tx * w, twy = ty * w, twz = tz * w;
+  const T txx = tx * x, txy = ty * x, txz = tz * x;
+  const T tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = T(1) - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = T(1) - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = T(1) - (txx + tyy);
+}
+
+// liMi of any joint of the (all-1-DoF) device tree.  1-DoF joints: make_liMi from their own (c,s).  The first joint of
+// the chain of a multi-DoF joint carries the whole M(q) = (R(quat), t) of that joint
+// (JointModelFreeFlyer/Spherical/Translation::calc), read from the JP_CS pairs of the chain's records; the other
+// chain joints are the identity.
+template <typename T>
+__device__ __forceinline__ void joint_xform(const JointDesc& d, const char* rec, T c, T s, T* R, T* t)
+{
+  if (d.rot >= ROT_FREE) {
+    constexpr size_t RB = (size_t)JREC * pair_bytes<T>();
+    T Rq[9], tq[3] = {T(0), T(0), T(0)}, Rp[9], rt[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { Rp[k] = (T)d.Rp[k]; Rq[k] = (k % 4 == 0) ? T(1) : T(0); }
+    const typename Vec2<T>::type c1 = ldp<T>(rec + RB, JP_CS);
+    if (d.rot == ROT_FREE) {
+      const typename Vec2<T>::type c2 = ldp<T>(rec + 2 * RB, JP_CS), c3 = ldp<T>(rec + 3 * RB, JP_CS);
+      tq[0] = c; tq[1] = s; tq[2] = c1.x;
+      quat_to_rot(c1.y, c2.x, c2.y, c3.x, Rq);
+    } else if (d.rot == ROT_SPH) {
+      quat_to_rot(c, s, c1.x, c1.y, Rq);
+    } else {
+      tq[0] = c; tq[1] = s; tq[2] = c1.x;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) R[3 * i + j] = Rp[3 * i] * Rq[j] + Rp[3 * i + 1] * Rq[3 + j] + Rp[3 * i + 2] * Rq[6 + j];
+    mat3_vec(Rp, tq, rt);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = (T)d.tp[k] + rt[k];
+    return;
+  }
+  if (d.flags & JF_NOQ) { c = (d.flags & JF_REVOLUTE) ? T(1) : T(0); s = T(0); }
+  make_liMi(d, c, s, R, t);
 }
 
 // SE3::act(Force): (R f_l, R f_a + t x R f_l)           [Pinocchio; call sites hxx:74, :212]
@@ -595,16 +648,17 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
         ld6<T>(rec, JP_UD, UD);
         dd_cached = ldp<T>(rec, JP_R).y;  // Dinv shares the pair of r: read it to rewrite the full pair below
       }
-      // FwdPass1 (hxx:304-315): H_i = rho I + H_ref ; p_i = -rho v_prev - Hv
+      // FwdPass1 (hxx:304-315): H_i = rho I + H_ref ; p_i = -rho v_prev - Hv   (a massless chain link: both zero)
+      const T m = (d.flags & JF_MASSLESS) ? T(0) : T(1);
       if (WITH_H) {
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
           for (int cc = r; cc < 6; ++cc)
-            hh[sym(r, cc)] = (r == cc ? P.rho : T(0)) + ((HDIAG && r != cc) ? T(0) : P.Href[6 * r + cc]);
+            hh[sym(r, cc)] = m * ((r == cc ? P.rho : T(0)) + ((HDIAG && r != cc) ? T(0) : P.Href[6 * r + cc]));
       }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) pp[k] = -P.rho * vprev[k] - P.Hv[k];
+      for (int k = 0; k < 6; ++k) pp[k] = m * (-P.rho * vprev[k] - P.Hv[k]);
       // constraint terms (hxx:321-334)
       if (d.cslot >= 0) {
         const char* crec = lp + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>();
@@ -663,7 +717,7 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
 
       if (!(d.flags & JF_PARENT_ROOT)) {
         T R[9], t[3], part[27], pa[6];
-        make_liMi(d, cs.x, cs.y, R, t);
+        joint_xform<T>(d, rec, cs.x, cs.y, R, t);
         if (WITH_H) {
           // H_aba = H - UDinv U^T (hxx:60-63), then SE3actOn (hxx:66)
 #pragma unroll
@@ -749,7 +803,7 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
 #pragma unroll
         for (int k = 0; k < 6; ++k) vpar[k] = vedge[(sd.rstart * 6 + k) * WAVE + lane];
       }
-      make_liMi(d, in.cs.x, in.cs.y, R, t);
+      joint_xform<T>(d, rec, in.cs.x, in.cs.y, R, t);
       actinv_motion(R, t, vpar, vp);  // hxx:125
       // nu_i = -UDinv^T v' - Dinv r_i  (hxx:127)
       T udv = in.UD[0] * vp[0];
@@ -772,8 +826,9 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
       for (int k = 0; k < 6; ++k) dv6[k] = vi[k] - in.vprev[k];
       // Href_v (hxx:149-153)
       href_mul<T, HDIAG>(P.Href, vi, hrv);
-      N.href_v = tmax(N.href_v, inf6(hrv));
-      N.dvis = tmax(N.dvis, inf6(dv6));  // hxx:156-158
+      const T m = (d.flags & JF_MASSLESS) ? T(0) : T(1);  // a massless chain link is not a body of the model
+      N.href_v = tmax(N.href_v, m * inf6(hrv));
+      N.dvis = tmax(N.dvis, m * inf6(dv6));  // hxx:156-158
       N.dnu = tmax(N.dnu, tabs(nui - nuprev));  // hxx:375
       // BoxProj (hxx:388-394)
       const T x = nui + (T(1) / mu_in) * wi;
@@ -865,11 +920,13 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void force_balance(const Params<T>& P, const Bufs<T>& Bf, const JointDesc& d, const char* lp,
-                                              T mu_eq, const T* vi, const T* hv, const T* pb, const T* sumf, T* fi)
+                                              T mu_eq, T m, const T* vi, const T* hv, const T* pb, const T* sumf, T* fi)
 {
+  // m = 0 for a massless chain link (H_i^base = 0), else 1; hv comes in already scaled by m
   const Layout& L = P.L;
+  const T rho_i = m * P.rho;
 #pragma unroll
-  for (int k = 0; k < 6; ++k) fi[k] = (hv[k] + P.rho * vi[k]) + pb[k];
+  for (int k = 0; k < 6; ++k) fi[k] = (hv[k] + rho_i * vi[k]) + pb[k];
   if (d.cslot >= 0) {
     T ata[22], av[6];
     if (P.mode & MODE_A_SHARED) {
@@ -925,7 +982,10 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
       for (int k = 0; k < 6; ++k) sf[k] = T(0);
       edge_gather<T, 0, 6>(sd, tm.rlist, edge, acc, sf, lane);
       href_mul<T, HDIAG>(P.Href, vi, hv);
-      force_balance<T>(P, Bf, d, lp, mu_eq, vi, hv, pb, sf, fi);
+      const T m = (d.flags & JF_MASSLESS) ? T(0) : T(1);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) hv[k] *= m;
+      force_balance<T>(P, Bf, d, lp, mu_eq, m, vi, hv, pb, sf, fi);
       st6<T>(rec, JP_F, fi);
       // g_i = (Aty_c | 0) + sum_children act(f_j) - f_i   (hxx:438-439, :210-212)
       if (d.cslot >= 0) {
@@ -947,7 +1007,7 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
       N.g_inf = tmax(N.g_inf, inf6(gi));  // hxx:223-225
       // dual residual, v block (hxx:228): Href v_i - Hv + g_i
 #pragma unroll
-      for (int r = 0; r < 6; ++r) dvr[r] = hv[r] - P.Hv[r] + gi[r];
+      for (int r = 0; r < 6; ++r) dvr[r] = hv[r] - m * P.Hv[r] + gi[r];
       N.dual_v = tmax(N.dual_v, inf6(dvr));
       // Stf_plus_w (hxx:231-236, :482-484)
       const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
@@ -960,7 +1020,7 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
       N.dstf_w = tmax(N.dstf_w, tabs(si - sold));
       if (!(d.flags & JF_PARENT_ROOT)) {
         T R[9], t[3], part[6];
-        make_liMi(d, cs.x, cs.y, R, t);
+        joint_xform<T>(d, rec, cs.x, cs.y, R, t);
         act_force(R, t, fi, part);  // hxx:212
         edge_emit<T, 0, 6>(sd, edge, acc, part, lane);
       }
@@ -1023,8 +1083,9 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
       const T wi = in.wz.x, sold = in.nus.y;
       // ---- iteration k: f_i by force balance, g_i = (Aty_c | 0) + sum_children act(f_j) - f_i   (hxx:438-439, :210-212)
       //      iteration k+1: p_i = -rho v_i - Hv (+ Aty_c - mu_eq Atb_c)       (hxx:304-315, :321-334)
+      const T m = (d.flags & JF_MASSLESS) ? T(0) : T(1);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { pp[k] = -P.rho * in.vi[k] - P.Hv[k]; sf[k] = T(0); }
+      for (int k = 0; k < 6; ++k) { pp[k] = m * (-P.rho * in.vi[k] - P.Hv[k]); sf[k] = T(0); }
       if (d.cslot >= 0) {
         const char* crec = lp + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>();
         T atb[6];
@@ -1040,7 +1101,9 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
       edge_gather<T, 0, 6>(sd, tm.rlist, edge, acc, sf, lane);
       edge_gather<T, 6, 6>(sd, tm.rlist, edge, acc + 6, pp, lane);
       href_mul<T, HDIAG>(P.Href, in.vi, hv);
-      force_balance<T>(P, Bf, d, lp, mu_eq, in.vi, hv, in.pb, sf, fi);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) hv[k] *= m;
+      force_balance<T>(P, Bf, d, lp, mu_eq, m, in.vi, hv, in.pb, sf, fi);
       st6<T>(rec, JP_F, fi);
       T dg[6], dvr[6], df[6];
 #pragma unroll
@@ -1055,7 +1118,7 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
       N.g_inf = tmax(N.g_inf, inf6(gi));  // hxx:223-225
       // dual residual, v block (hxx:228): Href v_i - Hv + g_i
 #pragma unroll
-      for (int r = 0; r < 6; ++r) dvr[r] = hv[r] - P.Hv[r] + gi[r];
+      for (int r = 0; r < 6; ++r) dvr[r] = hv[r] - m * P.Hv[r] + gi[r];
       N.dual_v = tmax(N.dual_v, inf6(dvr));
       // Stf_plus_w (hxx:231-236, :482-484) and r_i = (w_i - mu_in z_i) + S^T p_i (hxx:296, :70)
       const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
@@ -1075,7 +1138,7 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
       N.dstf_w = tmax(N.dstf_w, tabs(si - sold));
       if (!(d.flags & JF_PARENT_ROOT)) {
         T R[9], t[3], part[12], pa[6];
-        make_liMi(d, in.cs.x, in.cs.y, R, t);
+        joint_xform<T>(d, rec, in.cs.x, in.cs.y, R, t);
         act_force(R, t, fi, part);  // hxx:212
 #pragma unroll
         for (int k = 0; k < 6; ++k) pa[k] = pp[k] - in.UD[k] * ri;  // hxx:71-73
@@ -1316,8 +1379,9 @@ __device__ __forceinline__ T* elem_ptr(char* lp, int pair, int half)
   return reinterpret_cast<T*>(lp + (size_t)pair * pair_bytes<T>() + (size_t)half * sizeof(T));
 }
 
-// FwdPassInit (hxx:253-283): joint configuration -> per-joint (cos q, sin q) | (q, 0).
-// q is instance-major [B][nq] (the caller's layout) or one shared [nq].
+// FwdPassInit (hxx:253-283): joint configuration -> per-joint (cos q, sin q) | (q, 0); the first joint of the chain of
+// a multi-DoF joint spreads that joint's (t, quat) over the JP_CS pairs of the chain (layout: see ROT_FREE).
+// q is instance-major [B][nq] (the caller's layout) or one shared [nq]; idx_q[i] = where joint i's coordinates start.
 template <typename T>
 __global__ void k_fk_init(const double* __restrict__ q, int nq, int q_shared, const JointDesc* __restrict__ jd,
                           const int* __restrict__ idx_q, Layout L, int B, char* tiles)
@@ -1325,8 +1389,30 @@ __global__ void k_fk_init(const double* __restrict__ q, int nq, int q_shared, co
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   char* lp = lane_ptr<T>(tiles, L, b);
+  constexpr size_t RB = (size_t)JREC * pair_bytes<T>();
   for (int i = 1; i <= L.nb; ++i) {
-    const double qi = q[(q_shared ? 0 : (size_t)b * nq) + idx_q[i]];
+    if (jd[i].flags & JF_NOQ) continue;  // its pair belongs to the first joint of the chain
+    const double* qs = q + (q_shared ? 0 : (size_t)b * nq) + idx_q[i];
+    char* rec = lp + (size_t)(i - 1) * RB;
+    const int rot = jd[i].rot;
+    if (rot == ROT_FREE) {
+      stp<T>(rec, JP_CS, (T)qs[0], (T)qs[1]);
+      stp<T>(rec + RB, JP_CS, (T)qs[2], (T)qs[3]);
+      stp<T>(rec + 2 * RB, JP_CS, (T)qs[4], (T)qs[5]);
+      stp<T>(rec + 3 * RB, JP_CS, (T)qs[6], T(0));
+      continue;
+    }
+    if (rot == ROT_SPH) {
+      stp<T>(rec, JP_CS, (T)qs[0], (T)qs[1]);
+      stp<T>(rec + RB, JP_CS, (T)qs[2], (T)qs[3]);
+      continue;
+    }
+    if (rot == ROT_TRANS) {
+      stp<T>(rec, JP_CS, (T)qs[0], (T)qs[1]);
+      stp<T>(rec + RB, JP_CS, (T)qs[2], T(0));
+      continue;
+    }
+    const double qi = qs[0];
     T c, s;
     if (jd[i].flags & JF_REVOLUTE) {
       double sd, cd;
@@ -1335,15 +1421,79 @@ __global__ void k_fk_init(const double* __restrict__ q, int nq, int q_shared, co
     } else {
       c = (T)qi; s = T(0);
     }
-    stp<T>(lp + (size_t)(i - 1) * JREC * pair_bytes<T>(), JP_CS, c, s);
+    stp<T>(rec, JP_CS, c, s);
   }
 }
 
-// outer loop: q <- q + dt * z on the resident configurations (1-DoF joints: the manifold update is a plain sum),
-// `src` != nullptr first (re)fills the resident copy from a caller's q (one shared row or one row per instance)
+// ---- configuration-space integration of the quaternion joints (what pinocchio::integrate does for
+// JointModelFreeFlyer / JointModelSpherical: SpecialEuclideanOperation<3> / SpecialOrthogonalOperation<3>), fp64 --------
+__device__ __forceinline__ void quat_mul_xyzw(const double* a, const double* b, double* o)
+{
+  o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+  o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+  o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+// quaternion of exp([w]x)
+__device__ __forceinline__ void so3_exp_quat(const double* w, double* qe)
+{
+  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double k, cw;
+  if (t2 > 1.220703125e-4) {  // sqrt(sqrt(eps))
+    const double t = sqrt(t2);
+    double sh, ch;
+    sincos(0.5 * t, &sh, &ch);
+    k = sh / t; cw = ch;
+  } else {
+    k = 0.5 - t2 / 48.0; cw = 1.0 - t2 / 8.0;
+  }
+  qe[0] = k * w[0]; qe[1] = k * w[1]; qe[2] = k * w[2]; qe[3] = cw;
+}
+// q.coeffs() *= (3 - |q|^2) / 2   (quaternion::firstOrderNormalize)
+__device__ __forceinline__ void quat_first_order_normalize(double* qt)
+{
+  const double n2 = qt[0] * qt[0] + qt[1] * qt[1] + qt[2] * qt[2] + qt[3] * qt[3];
+  const double a = (3.0 - n2) / 2.0;
+  for (int k = 0; k < 4; ++k) qt[k] *= a;
+}
+// (t, quat) <- (t, quat) * exp6(v), v = [linear; angular] in the body frame
+__device__ __forceinline__ void se3_integrate(double* q7, const double* v)
+{
+  const double* w = v + 3;
+  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double a, b2;  // p = v_l + a (w x v_l) + b (w x (w x v_l))
+  if (t2 > 1.220703125e-4) {
+    const double t = sqrt(t2);
+    double st, ct;
+    sincos(t, &st, &ct);
+    a = (1.0 - ct) / t2;
+    b2 = (t - st) / (t2 * t);
+  } else {
+    a = 0.5 - t2 / 24.0;
+    b2 = 1.0 / 6.0 - t2 / 120.0;
+  }
+  const double wxv[3] = {w[1] * v[2] - w[2] * v[1], w[2] * v[0] - w[0] * v[2], w[0] * v[1] - w[1] * v[0]};
+  const double wwv[3] = {w[1] * wxv[2] - w[2] * wxv[1], w[2] * wxv[0] - w[0] * wxv[2], w[0] * wxv[1] - w[1] * wxv[0]};
+  double p[3], R[9], qe[4], qo[4];
+  for (int k = 0; k < 3; ++k) p[k] = v[k] + a * wxv[k] + b2 * wwv[k];
+  quat_to_rot<double>(q7[3], q7[4], q7[5], q7[6], R);
+  for (int k = 0; k < 3; ++k) q7[k] += R[3 * k] * p[0] + R[3 * k + 1] * p[1] + R[3 * k + 2] * p[2];
+  so3_exp_quat(w, qe);
+  quat_mul_xyzw(q7 + 3, qe, qo);
+  const double dot = qo[0] * q7[3] + qo[1] * q7[4] + qo[2] * q7[5] + qo[3] * q7[6];
+  if (dot < 0.0)
+    for (int k = 0; k < 4; ++k) qo[k] = -qo[k];
+  quat_first_order_normalize(qo);
+  for (int k = 0; k < 4; ++k) q7[3 + k] = qo[k];
+}
+
+// outer loop: q <- q (+) dt * z on the resident configurations (1-DoF and translation joints: a plain sum; free-flyer
+// and spherical joints: the Lie-group update above), `src` != nullptr first (re)fills the resident copy from a
+// caller's q (one shared row or one row per instance)
 template <typename T>
 __global__ void k_advance_q(double* __restrict__ q_res, const double* __restrict__ src, int src_shared, int nq,
-                            const int* __restrict__ idx_q, Layout L, int B, const char* tiles, double dt)
+                            const JointDesc* __restrict__ jd, const int* __restrict__ idx_q, Layout L, int B,
+                            const char* tiles, double dt)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -1352,9 +1502,26 @@ __global__ void k_advance_q(double* __restrict__ q_res, const double* __restrict
     return;
   }
   const char* lp = lane_ptr<T>(const_cast<char*>(tiles), L, b);
+  constexpr size_t RB = (size_t)JREC * pair_bytes<T>();
   for (int i = 1; i <= L.nb; ++i) {
-    const T z = ldp<T>(lp + (size_t)(i - 1) * JREC * pair_bytes<T>(), JP_WZ).y;
-    q_res[(size_t)b * nq + idx_q[i]] += dt * (double)z;
+    if (jd[i].flags & JF_NOQ) continue;
+    const char* rec = lp + (size_t)(i - 1) * RB;
+    double* qs = q_res + (size_t)b * nq + idx_q[i];
+    const int rot = jd[i].rot;
+    const int n = rot == ROT_FREE ? 6 : (rot == ROT_SPH || rot == ROT_TRANS) ? 3 : 1;
+    double v[6];
+    for (int k = 0; k < n; ++k) v[k] = dt * (double)ldp<T>(rec + k * RB, JP_WZ).y;  // z of the chain's joints
+    if (rot == ROT_FREE) {
+      se3_integrate(qs, v);
+    } else if (rot == ROT_SPH) {
+      double qe[4], qo[4];
+      so3_exp_quat(v, qe);
+      quat_mul_xyzw(qs, qe, qo);
+      quat_first_order_normalize(qo);
+      for (int k = 0; k < 4; ++k) qs[k] = qo[k];
+    } else {
+      for (int k = 0; k < n; ++k) qs[k] += v[k];
+    }
   }
 }
 
@@ -1409,7 +1576,8 @@ __global__ void k_rebuild_his(const char* tiles, Layout L, const JointDesc* __re
   double* o = out + (size_t)b * L.nb * 21;
   for (int i = 1; i <= L.nb; ++i) {
     for (int r = 0; r < 6; ++r)
-      for (int c = r; c < 6; ++c) o[(i - 1) * 21 + sym(r, c)] = (double)((r == c ? rho : T(0)) + Href[6 * r + c]);
+      for (int c = r; c < 6; ++c)
+        o[(i - 1) * 21 + sym(r, c)] = (jd[i].flags & JF_MASSLESS) ? 0.0 : (double)((r == c ? rho : T(0)) + Href[6 * r + c]);
     if (jd[i].cslot >= 0) {
       const int cs = jd[i].cslot;
       for (int k = 0; k < 21; ++k) {
@@ -1431,8 +1599,9 @@ __global__ void k_rebuild_his(const char* tiles, Layout L, const JointDesc* __re
     for (int k = 0; k < 6; ++k) UD[k] = U[k] * dd;
     for (int r = 0; r < 6; ++r)
       for (int c = r; c < 6; ++c) hh[sym(r, c)] -= UD[r] * U[c];
-    const typename Vec2<T>::type cs = ldp<T>(lp + (size_t)(i - 1) * JREC * pair_bytes<T>(), JP_CS);
-    make_liMi(d, cs.x, cs.y, R, t);
+    const char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
+    const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS);
+    joint_xform<T>(d, rec, cs.x, cs.y, R, t);
     congr_sym(R, t, hh, part);
     for (int k = 0; k < 21; ++k) o[(d.parent - 1) * 21 + k] += (double)part[k];
   }
@@ -1463,7 +1632,7 @@ __global__ void k_rebuild_pis(const char* tiles, Layout L, const JointDesc* __re
     const T ri = ldp<T>(rec, JP_R).x;
     for (int k = 0; k < 6; ++k) pa[k] = (T)o[(i - 1) * 6 + k] - UD[k] * ri;
     const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS);
-    make_liMi(d, cs.x, cs.y, R, t);
+    joint_xform<T>(d, rec, cs.x, cs.y, R, t);
     act_force(R, t, pa, pc);
     for (int k = 0; k < 6; ++k) o[(d.parent - 1) * 6 + k] += (double)pc[k];
   }

@@ -47,10 +47,18 @@ namespace {
 constexpr int ROWMAP_CAP = 8192;
 
 struct loikb_solver_impl {
-  // model (copied)
+  // model (copied).  nj/nb/parents/jtype/idx_q/jd describe the DEVICE tree, in which every joint has one DoF: a
+  // free-flyer / spherical / translation joint of the caller's model is a chain of 6 / 3 / 3 one-DoF joints about the
+  // axes of one frame with massless links in between (build_schedule).  nq, nv are the caller's; nv == nb.
   int nj = 0, nb = 0, nq = 0, nv = 0;
   std::vector<int> parents, jtype, idx_q, idx_v;
   std::vector<JointDesc> jd;
+  // the caller's model: ext_nj joints; link_of[i] / first_of[i] = device joint that carries body i / that carries
+  // M(q) of joint i (the last / first joint of its chain; both i's own image for a 1-DoF joint)
+  int ext_nj = 0;
+  std::vector<int> link_of, first_of;
+  int* d_link_sel = nullptr;  // [ext_nj - 1] link_of[1..] - 1 on the device (getters)
+  int* d_first_sel = nullptr;
   // step schedules of the sweeps: [0] one wavefront per tile, [1] a team of wavefronts per tile
   struct TeamSched {
     int nw = 1, T_up = 0, T_down = 0, nslots = 0, nvslots = 0;
@@ -342,63 +350,102 @@ void build_team_schedule(const std::vector<int>& parents, int nw, loikb_solver_i
 // build the uniform per-joint schedule from the Pinocchio-style model
 int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
 {
-  const int nj = m->njoints;
-  if (nj < 2 || m->nv != nj - 1 || m->nq != nj - 1) {
-    g_last_error = "model not supported: only 1-DoF joints (nq == nv == njoints-1)";
-    return LOIKB_ERR_MODEL;
-  }
-  S->nj = nj; S->nb = nj - 1; S->nq = m->nq; S->nv = m->nv;
-  S->parents.assign(m->parents, m->parents + nj);
-  S->jtype.assign(m->jtype, m->jtype + nj);
-  S->idx_q.assign(m->idx_q, m->idx_q + nj);
-  S->idx_v.assign(m->idx_v, m->idx_v + nj);
-  std::vector<int> subtree_end(nj, 0);
-  for (int i = 1; i < nj; ++i) {
-    const int p = S->parents[i];
-    if (p < 0 || p >= i) { g_last_error = "model: parents[i] must be < i"; return LOIKB_ERR_MODEL; }
-    if (S->idx_v[i] != i - 1 || S->idx_q[i] != i - 1) {
-      g_last_error = "model: idx_q/idx_v must equal joint index - 1 (all joints 1-DoF)";
-      return LOIKB_ERR_MODEL;
+  const int enj = m->njoints;
+  if (enj < 2) { g_last_error = "model: no joints"; return LOIKB_ERR_MODEL; }
+  auto jt_nq = [](int jt) { return jt == LOIKB_J_FREEFLYER ? 7 : jt == LOIKB_J_SPHERICAL ? 4 : jt == LOIKB_J_TRANSLATION ? 3 : 1; };
+  auto jt_nv = [](int jt) { return jt == LOIKB_J_FREEFLYER ? 6 : (jt == LOIKB_J_SPHERICAL || jt == LOIKB_J_TRANSLATION) ? 3 : 1; };
+  // ---- the caller's model: Pinocchio numbering (parents[i] < i, idx_q / idx_v cumulative in joint order)
+  {
+    int iq = 0, iv = 0;
+    for (int i = 1; i < enj; ++i) {
+      const int p = m->parents[i], jt = m->jtype[i];
+      if (p < 0 || p >= i) { g_last_error = "model: parents[i] must be < i"; return LOIKB_ERR_MODEL; }
+      if (jt < LOIKB_J_RX || jt > LOIKB_J_TRANSLATION) {
+        g_last_error = "model: unsupported joint type (1-DoF joints, free-flyer, spherical and translation joints are)";
+        return LOIKB_ERR_MODEL;
+      }
+      if (m->idx_q[i] != iq || m->idx_v[i] != iv) {
+        g_last_error = "model: idx_q/idx_v must be cumulative in joint order (Pinocchio's layout)";
+        return LOIKB_ERR_MODEL;
+      }
+      iq += jt_nq(jt); iv += jt_nv(jt);
     }
-    if (S->jtype[i] < LOIKB_J_RX || S->jtype[i] > LOIKB_J_PU) {
-      g_last_error = "model: unsupported joint type";
-      return LOIKB_ERR_MODEL;
+    if (m->nq != iq || m->nv != iv) { g_last_error = "model: nq/nv do not match the joint types"; return LOIKB_ERR_MODEL; }
+    // depth-first numbering check: descendants of every joint are the contiguous range (i, subtree_end[i]]
+    std::vector<int> subtree_end(enj, 0);
+    for (int i = enj - 1; i >= 0; --i) subtree_end[i] = i;
+    for (int i = enj - 1; i >= 1; --i) {
+      const int p = m->parents[i];
+      if (subtree_end[i] > subtree_end[p]) subtree_end[p] = subtree_end[i];
     }
+    for (int i = 1; i < enj; ++i)
+      for (int k = i + 1; k <= subtree_end[i]; ++k)
+        if (m->parents[k] < i) { g_last_error = "model: joints are not numbered depth-first"; return LOIKB_ERR_MODEL; }
   }
-  // depth-first numbering check: descendants of every joint are the contiguous range (i, subtree_end[i]]
-  for (int i = nj - 1; i >= 0; --i) subtree_end[i] = i;
-  for (int i = nj - 1; i >= 1; --i) {
-    const int p = S->parents[i];
-    if (subtree_end[i] > subtree_end[p]) subtree_end[p] = subtree_end[i];
-  }
-  for (int i = 1; i < nj; ++i)
-    for (int k = i + 1; k <= subtree_end[i]; ++k)
-      if (S->parents[k] < i) { g_last_error = "model: joints are not numbered depth-first"; return LOIKB_ERR_MODEL; }
-  S->jd.assign(nj, JointDesc{});
-  for (int i = 1; i < nj; ++i) {
-    JointDesc& d = S->jd[i];
-    for (int k = 0; k < 9; ++k) d.Rp[k] = m->placement[12 * i + k];
-    for (int k = 0; k < 3; ++k) d.tp[k] = m->placement[12 * i + 9 + k];
-    const int jt = S->jtype[i];
-    double ax[3] = {0, 0, 0};
-    int rot = ROT_NONE, flags = 0;
-    switch (jt) {
-    case LOIKB_J_RX: ax[0] = 1; rot = ROT_X; flags |= JF_REVOLUTE; break;
-    case LOIKB_J_RY: ax[1] = 1; rot = ROT_Y; flags |= JF_REVOLUTE; break;
-    case LOIKB_J_RZ: ax[2] = 1; rot = ROT_Z; flags |= JF_REVOLUTE; break;
-    case LOIKB_J_PX: ax[0] = 1; break;
-    case LOIKB_J_PY: ax[1] = 1; break;
-    case LOIKB_J_PZ: ax[2] = 1; break;
-    case LOIKB_J_RU: for (int k = 0; k < 3; ++k) ax[k] = m->axis[3 * i + k]; rot = ROT_U; flags |= JF_REVOLUTE; break;
-    case LOIKB_J_PU: for (int k = 0; k < 3; ++k) ax[k] = m->axis[3 * i + k]; break;
+  // ---- the device tree.  A multi-DoF joint whose S selects columns of I6 (free-flyer: all six, spherical: the angular
+  // three, translation: the linear three) becomes a chain of 1-DoF joints about those axes of ONE frame: the first
+  // chain joint carries placement * M(q), the others are the identity, and the links between them are massless (no
+  // rho I + H_ref, no reference term, not counted in the norms over links).  Eliminating nu_k one coordinate at a time
+  // along the chain is the block elimination upstream's calc_aba does with its nv x nv Dinv (hxx:60-63) -- the same
+  // Schur complement, so all iterates agree up to rounding (tests/test_multidof.py proves it on the CPU oracle).
+  // DoF k of the model is device joint k + 1, so nu / z / w / lb / ub keep the caller's order.
+  S->ext_nj = enj;
+  S->nq = m->nq; S->nv = m->nv;
+  S->link_of.assign(enj, 0);
+  S->first_of.assign(enj, 0);
+  S->parents.assign(1, 0);
+  S->jtype.assign(1, LOIKB_J_NONE);
+  S->idx_q.assign(1, 0);
+  S->jd.assign(1, JointDesc{});
+  for (int i = 1; i < enj; ++i) {
+    const int jt = m->jtype[i];
+    const int n = jt_nv(jt);
+    const int par = S->link_of[m->parents[i]];
+    S->first_of[i] = (int)S->parents.size();
+    for (int k = 0; k < n; ++k) {
+      JointDesc d{};
+      double ax[3] = {0, 0, 0};
+      int rot = ROT_NONE, flags = 0, sub = jt;
+      if (n > 1) {
+        // chain joint k: prismatic along / revolute about axis (k mod 3) of the joint frame
+        const bool angular = jt == LOIKB_J_SPHERICAL || (jt == LOIKB_J_FREEFLYER && k >= 3);
+        sub = (angular ? LOIKB_J_RX : LOIKB_J_PX) + k % 3;
+      }
+      switch (sub) {
+      case LOIKB_J_RX: ax[0] = 1; rot = ROT_X; flags |= JF_REVOLUTE; break;
+      case LOIKB_J_RY: ax[1] = 1; rot = ROT_Y; flags |= JF_REVOLUTE; break;
+      case LOIKB_J_RZ: ax[2] = 1; rot = ROT_Z; flags |= JF_REVOLUTE; break;
+      case LOIKB_J_PX: ax[0] = 1; break;
+      case LOIKB_J_PY: ax[1] = 1; break;
+      case LOIKB_J_PZ: ax[2] = 1; break;
+      case LOIKB_J_RU: for (int c = 0; c < 3; ++c) ax[c] = m->axis[3 * i + c]; rot = ROT_U; flags |= JF_REVOLUTE; break;
+      case LOIKB_J_PU: for (int c = 0; c < 3; ++c) ax[c] = m->axis[3 * i + c]; break;
+      }
+      for (int c = 0; c < 9; ++c) d.Rp[c] = (n > 1 && k > 0) ? (c % 4 == 0 ? 1.0 : 0.0) : m->placement[12 * i + c];
+      for (int c = 0; c < 3; ++c) d.tp[c] = (n > 1 && k > 0) ? 0.0 : m->placement[12 * i + 9 + c];
+      if (n > 1) {
+        if (k == 0) rot = jt == LOIKB_J_FREEFLYER ? ROT_FREE : jt == LOIKB_J_SPHERICAL ? ROT_SPH : ROT_TRANS;
+        else flags |= JF_NOQ;
+        if (k < n - 1) flags |= JF_MASSLESS;
+      }
+      for (int c = 0; c < 3; ++c) d.axis[c] = ax[c];
+      d.parent = k == 0 ? par : (int)S->parents.size() - 1;
+      if (d.parent == 0) flags |= JF_PARENT_ROOT;
+      d.flags = flags;
+      d.cslot = -1;
+      d.rot = rot;
+      S->parents.push_back(d.parent);
+      S->jtype.push_back(sub);
+      S->idx_q.push_back(k == 0 ? m->idx_q[i] : 0);
+      S->jd.push_back(d);
     }
-    for (int k = 0; k < 3; ++k) d.axis[k] = ax[k];
-    d.parent = S->parents[i];
-    if (d.parent == 0) flags |= JF_PARENT_ROOT;
-    d.flags = flags;
-    d.cslot = -1;
-    d.rot = rot;
+    S->link_of[i] = (int)S->parents.size() - 1;
   }
+  const int nj = (int)S->parents.size();
+  S->nj = nj; S->nb = nj - 1;
+  if (S->nb != S->nv) { g_last_error = "internal: device tree size != nv"; return LOIKB_ERR_MODEL; }
+  S->idx_v.resize(nj);
+  for (int i = 0; i < nj; ++i) S->idx_v[i] = i > 0 ? i - 1 : 0;
   build_team_schedule(S->parents, 1, S->sched[0]);
   int team = MAX_TEAM;
   if (const char* e = getenv("LOIKB_TEAM")) team = atoi(e);
@@ -547,10 +594,10 @@ int fwd_pass_init(loikb_solver_impl* S, const double* q, int in_flags)
     // the resident copy is what the outer loop advances (loikb_integrate)
     if (S->f32)
       hipLaunchKernelGGL(k_advance_q<float>, grid1(S->B), dim3(256), 0, S->stream, S->d_q, (const double*)dq, (int)shared,
-                         S->nq, S->d_idx_q, S->L, S->B, S->home.tiles, 0.0);
+                         S->nq, S->d_jd, S->d_idx_q, S->L, S->B, S->home.tiles, 0.0);
     else
       hipLaunchKernelGGL(k_advance_q<double>, grid1(S->B), dim3(256), 0, S->stream, S->d_q, (const double*)dq, (int)shared,
-                         S->nq, S->d_idx_q, S->L, S->B, S->home.tiles, 0.0);
+                         S->nq, S->d_jd, S->d_idx_q, S->L, S->B, S->home.tiles, 0.0);
     HIPCHK(hipGetLastError());
     if (!dev) HIPCHK(hipStreamSynchronize(S->stream));  // the staging buffer is re-used by the next upload
     S->have_q = true;
@@ -666,7 +713,7 @@ int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, 
         return LOIKB_ERR_HREF_NOT_SYMMETRIC;
       }
   for (int c = 0; c < nc; ++c) {
-    if (c_ids[c] < 1 || c_ids[c] >= S->nj) { g_last_error = "constraint link id out of range"; return LOIKB_ERR_ARG; }
+    if (c_ids[c] < 1 || c_ids[c] >= S->ext_nj) { g_last_error = "constraint link id out of range"; return LOIKB_ERR_ARG; }
     for (int c2 = 0; c2 < c; ++c2)
       if (c_ids[c2] == c_ids[c]) { g_last_error = "multiple constraints on the same link"; return LOIKB_ERR_DUP_CONSTRAINT; }
   }
@@ -700,7 +747,7 @@ int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, 
   // UpdateEqConstraints
   S->active_ids.assign(c_ids, c_ids + nc);
   for (int i = 1; i < S->nj; ++i) S->jd[i].cslot = -1;
-  for (int c = 0; c < nc; ++c) S->jd[c_ids[c]].cslot = c;
+  for (int c = 0; c < nc; ++c) S->jd[S->link_of[c_ids[c]]].cslot = c;  // the device joint that carries the body
   if ((rc = upload_jd(S))) return rc;
   S->a_shared = in_flags & LOIKB_A_SHARED;
   for (int c = 0; c < nc; ++c) {
@@ -1082,20 +1129,34 @@ int run_main_loop(loikb_solver_impl* S)
   return S->f32 ? run_main_loop_t<float>(S) : run_main_loop_t<double>(S);
 }
 
+// liMi of the caller's joints: sel[e] + 1 = the device joint that carries M(q) of joint e + 1
 template <typename T>
-__global__ void k_limi(char* tiles, Layout L, const JointDesc* __restrict__ jd, int B, double* __restrict__ out)
+__global__ void k_limi(char* tiles, Layout L, const JointDesc* __restrict__ jd, const int* __restrict__ sel, int nsel,
+                       int B, double* __restrict__ out)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   char* lp = lane_ptr<T>(tiles, L, b);
-  for (int i = 1; i <= L.nb; ++i) {
+  for (int e = 0; e < nsel; ++e) {
+    const int i = sel[e] + 1;
     T R[9], t[3];
-    const typename Vec2<T>::type cs = ldp<T>(lp + (size_t)(i - 1) * JREC * pair_bytes<T>(), JP_CS);
-    make_liMi<T>(jd[i], cs.x, cs.y, R, t);
-    double* o = out + ((size_t)b * L.nb + (i - 1)) * 12;
+    const char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
+    const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS);
+    joint_xform<T>(jd[i], rec, cs.x, cs.y, R, t);
+    double* o = out + ((size_t)b * nsel + e) * 12;
     for (int k = 0; k < 9; ++k) o[k] = (double)R[k];
     for (int k = 0; k < 3; ++k) o[9 + k] = (double)t[k];
   }
+}
+
+// dst[b][e][:] = src[b][sel[e]][:]  (rows of w doubles): the bodies of the caller's model out of the device tree's
+__global__ void k_select_rows(const double* __restrict__ src, int nrow_src, int w, const int* __restrict__ sel, int nsel,
+                              int B, double* __restrict__ dst)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int e = 0; e < nsel; ++e)
+    for (int k = 0; k < w; ++k) dst[((size_t)b * nsel + e) * w + k] = src[((size_t)b * nrow_src + sel[e]) * w + k];
 }
 
 }  // namespace
@@ -1241,6 +1302,15 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
                           hipMemcpyHostToDevice, S->stream));
   TRY(alloc_dev(S, &S->d_uni, S->esz * ((size_t)(S->nc > 0 ? S->nc : 1) * 57 + 2 * (size_t)S->nb)));
   HIPTRY(hipMemcpyAsync(S->d_idx_q, S->idx_q.data(), sizeof(int) * S->nj, hipMemcpyHostToDevice, S->stream));
+  {
+    std::vector<int> sel(S->ext_nj), fsel(S->ext_nj);
+    for (int i = 1; i < S->ext_nj; ++i) { sel[i - 1] = S->link_of[i] - 1; fsel[i - 1] = S->first_of[i] - 1; }
+    TRY(alloc_dev(S, &tmp, sizeof(int) * S->ext_nj)); S->d_link_sel = (int*)tmp;
+    TRY(alloc_dev(S, &tmp, sizeof(int) * S->ext_nj)); S->d_first_sel = (int*)tmp;
+    HIPTRY(hipMemcpyAsync(S->d_link_sel, sel.data(), sizeof(int) * (S->ext_nj - 1), hipMemcpyHostToDevice, S->stream));
+    HIPTRY(hipMemcpyAsync(S->d_first_sel, fsel.data(), sizeof(int) * (S->ext_nj - 1), hipMemcpyHostToDevice, S->stream));
+    HIPTRY(hipStreamSynchronize(S->stream));  // the host vectors go out of scope
+  }
   for (auto& sc : S->sched) {
     TRY(alloc_dev(S, &tmp, sizeof(StepDesc) * sc.up.size())); sc.d_up = (StepDesc*)tmp;
     TRY(alloc_dev(S, &tmp, sizeof(StepDesc) * sc.down.size())); sc.d_down = (StepDesc*)tmp;
@@ -1354,10 +1424,10 @@ int loikb_integrate(loikb_solver* S, double dt)
   HIPCHK(hipSetDevice(S->device));
   if (S->f32)
     hipLaunchKernelGGL(k_advance_q<float>, grid1(S->B), dim3(256), 0, S->stream, S->d_q, (const double*)nullptr, 0, S->nq,
-                       S->d_idx_q, S->L, S->B, S->home.tiles, dt);
+                       S->d_jd, S->d_idx_q, S->L, S->B, S->home.tiles, dt);
   else
     hipLaunchKernelGGL(k_advance_q<double>, grid1(S->B), dim3(256), 0, S->stream, S->d_q, (const double*)nullptr, 0, S->nq,
-                       S->d_idx_q, S->L, S->B, S->home.tiles, dt);
+                       S->d_jd, S->d_idx_q, S->L, S->B, S->home.tiles, dt);
   HIPCHK(hipGetLastError());
   return LOIKB_OK;
 }
@@ -1382,7 +1452,7 @@ int loikb_set_warm_start(loikb_solver* S, int v) { if (!S) return LOIKB_ERR_ARG;
 
 int loikb_batch(const loikb_solver* S) { return S ? S->B : 0; }
 int loikb_nv(const loikb_solver* S) { return S ? S->nv : 0; }
-int loikb_njoints(const loikb_solver* S) { return S ? S->nj : 0; }
+int loikb_njoints(const loikb_solver* S) { return S ? S->ext_nj : 0; }
 
 int loikb_get_stats(loikb_solver* S, loikb_stats* out)
 {
@@ -1404,14 +1474,15 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
     return LOIKB_OK;
   }
   const Layout& L = S->L;
-  const int nb = S->nb;
+  const int nb = S->nb;         // device joints == model.nv: the per-DoF fields
+  const int nl = S->ext_nj - 1; // bodies of the caller's model: the per-link fields
   std::vector<int> rm;
   bool is_int = false;
   int mask = 0;
   auto per_joint = [&](int pair, int half) { for (int j = 0; j < nb; ++j) rm.push_back((j * JREC + pair) * 2 + half); };
-  auto per_joint_vec = [&](int pair, int n) {
-    for (int j = 0; j < nb; ++j)
-      for (int k = 0; k < n; ++k) rm.push_back((j * JREC + pair + k / 2) * 2 + (k & 1));
+  auto per_joint_vec = [&](int pair, int n) {  // body i of the caller's model lives in device joint link_of[i]
+    for (int i = 1; i <= nl; ++i)
+      for (int k = 0; k < n; ++k) rm.push_back(((S->link_of[i] - 1) * JREC + pair + k / 2) * 2 + (k & 1));
   };
   auto per_constraint_vec = [&](int pair) {
     for (int c = 0; c < S->nc; ++c)
@@ -1428,7 +1499,10 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   case LOIKB_F_FIS: per_joint_vec(JP_F, 6); break;
   case LOIKB_F_G: per_joint_vec(JP_G, 6); break;
   case LOIKB_F_PIS: break;  // the hot path keeps p_i^base: the accumulated p_i is rebuilt below
-  case LOIKB_F_UDINV: per_joint_vec(JP_UD, 6); break;
+  case LOIKB_F_UDINV:  // per DoF (== per joint for 1-DoF joints; one column of the chain's elimination otherwise)
+    for (int j = 0; j < nb; ++j)
+      for (int k = 0; k < 6; ++k) rm.push_back((j * JREC + JP_UD + k / 2) * 2 + (k & 1));
+    break;
   case LOIKB_F_HIS: break;  // not materialised by the hot path: rebuilt below
 
   case LOIKB_F_YIS: per_constraint_vec(CP_Y); break;
@@ -1449,14 +1523,23 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
       return LOIKB_ERR_ARG;
     }
   }
-  const int n = field == LOIKB_F_LIMI ? 12 * nb : field == LOIKB_F_HIS ? 21 * nb : field == LOIKB_F_PIS ? 6 * nb
+  const int n = field == LOIKB_F_LIMI ? 12 * nl : field == LOIKB_F_HIS ? 21 * nl : field == LOIKB_F_PIS ? 6 * nl
                                                                                                           : (int)rm.size();
+  // the rebuild kernels work on the device tree; with multi-DoF joints the caller's bodies are selected afterwards
+  const bool select = nl != nb && (field == LOIKB_F_HIS || field == LOIKB_F_PIS);
+  double* final_dst = nullptr;
+  void* d_tmp = nullptr;
   const size_t bytes = (is_int ? sizeof(int) : sizeof(double)) * (size_t)S->B * n;
   double* dst = (double*)out;
   int rc;
   if (!to_dev) {
     if ((rc = ensure_stage(S, bytes))) return rc;
     dst = (double*)S->d_stage;
+  }
+  if (select) {
+    final_dst = dst;
+    HIPCHK(hipMalloc(&d_tmp, sizeof(double) * (size_t)S->B * nb * (field == LOIKB_F_HIS ? 21 : 6)));
+    dst = (double*)d_tmp;
   }
   if (field == LOIKB_F_HIS) {
     // device copy of H_ref in the solve precision (d_stage may be the output buffer: use the uniform buffer's tail?)
@@ -1484,8 +1567,8 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
     if (S->f32) hipLaunchKernelGGL(k_rebuild_pis<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->B, dst);
     else hipLaunchKernelGGL(k_rebuild_pis<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->B, dst);
   } else if (field == LOIKB_F_LIMI) {
-    if (S->f32) hipLaunchKernelGGL(k_limi<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->B, dst);
-    else hipLaunchKernelGGL(k_limi<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->B, dst);
+    if (S->f32) hipLaunchKernelGGL(k_limi<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->d_first_sel, nl, S->B, dst);
+    else hipLaunchKernelGGL(k_limi<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->d_first_sel, nl, S->B, dst);
   } else {
     if ((rc = set_rowmap(S, rm))) return rc;
     if (S->f32)
@@ -1496,8 +1579,15 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
                          S->B, dst, (int)is_int, mask);
   }
   HIPCHK(hipGetLastError());
+  if (select) {
+    hipLaunchKernelGGL(k_select_rows, grid1(S->B), dim3(256), 0, S->stream, (const double*)d_tmp, nb,
+                       field == LOIKB_F_HIS ? 21 : 6, S->d_link_sel, nl, S->B, final_dst);
+    HIPCHK(hipGetLastError());
+    dst = final_dst;
+  }
   if (!to_dev) HIPCHK(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
+  if (d_tmp) HIPCHK(hipFree(d_tmp));
   return LOIKB_OK;
 }
 

@@ -97,6 +97,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   const TailTopo tp = topo[jl + 1];
   const int depth = isj_lane ? tp.depth : 0;
   const bool rev = d.flags & JF_REVOLUTE;
+  const T mass = (d.flags & JF_MASSLESS) ? T(0) : T(1);  // chain link of a multi-DoF joint: no cost of its own
   const bool has_parent = !(d.flags & JF_PARENT_ROOT);
   const int plane = gbase + d.parent - 1;  // parent's lane
   const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
@@ -154,7 +155,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     srec = ip + (size_t)L.off_s * pair_bytes<T>();
     {
       const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
-      make_liMi(d, cs.x, cs.y, R, t);  // liMi is kept in registers for the whole solve of the instance
+      joint_xform<T>(d, rec, cs.x, cs.y, R, t);  // liMi is kept in registers for the whole solve of the instance
       ld6<T>(rec, JP_V, v);
       ld6<T>(rec, JP_F, f);
       ld6<T>(rec, JP_G, g);
@@ -301,11 +302,11 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       for (int a = 0; a < 6; ++a)
 #pragma unroll
         for (int b2 = a; b2 < 6; ++b2)
-          hh[sym(a, b2)] = (a == b2 ? P.rho : T(0)) + ((HDIAG && a != b2) ? T(0) : P.Href[6 * a + b2]);
+          hh[sym(a, b2)] = mass * ((a == b2 ? P.rho : T(0)) + ((HDIAG && a != b2) ? T(0) : P.Href[6 * a + b2]));
     }
     if (act) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) p[k] = -P.rho * v[k] - P.Hv[k];
+      for (int k = 0; k < 6; ++k) p[k] = mass * (-P.rho * v[k] - P.Hv[k]);
       if (isj && d.cslot >= 0) {
         const T* c_ = cdi + d.cslot * CD;
         if (need_h) {
@@ -456,8 +457,8 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       }
       l_dfis = inf6(df);
       href_mul<T, HDIAG>(P.Href, vi, hrv);
-      l_hrefv = inf6(hrv);
-      l_dvis = inf6(dv6);
+      l_hrefv = mass * inf6(hrv);  // a massless chain link is not a body of the model
+      l_dvis = mass * inf6(dv6);
       l_dnu = tabs(nui - nu);
       const T x = nui + (T(1) / mu_in) * w;
       const T zi = tmin(ubi, tmax(lbi, x));
@@ -543,7 +544,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       l_g = inf6(gi);
       href_mul<T, HDIAG>(P.Href, v, dvr);
 #pragma unroll
-      for (int a = 0; a < 6; ++a) dvr[a] = dvr[a] - P.Hv[a] + gi[a];
+      for (int a = 0; a < 6; ++a) dvr[a] = mass * (dvr[a] - P.Hv[a]) + gi[a];
       l_dualv = inf6(dvr);
       const T stf = rev ? (ax0 * f[3] + ax1 * f[4] + ax2 * f[5]) : (ax0 * f[0] + ax1 * f[1] + ax2 * f[2]);
       const T si = stf + w;

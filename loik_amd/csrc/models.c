@@ -17,13 +17,13 @@
 typedef struct {
   const char *name;
   int built;
-  int nj;
+  int nj, nq, nv;
   int parents[MAXJ], jtype[MAXJ], idx_q[MAXJ], idx_v[MAXJ];
   double axis[MAXJ * 3], placement[MAXJ * 12], q_lo[MAXJ], q_hi[MAXJ];
   const char *jname[MAXJ];
 } table_t;
 
-static table_t g_panda7 = {"panda7"}, g_panda9 = {"panda9"}, g_talos32 = {"talos32"};
+static table_t g_panda7 = {"panda7"}, g_panda9 = {"panda9"}, g_talos32 = {"talos32"}, g_talos32_ff = {"talos32_freeflyer"};
 
 static void rpy_to_R(double r, double p, double y, double *R)
 {
@@ -41,7 +41,7 @@ static void rpy_to_R(double r, double p, double y, double *R)
 
 static void tbl_init(table_t *t)
 {
-  t->nj = 1;
+  t->nj = 1; t->nq = 0; t->nv = 0;
   t->parents[0] = 0; t->jtype[0] = LOIKB_J_NONE; t->idx_q[0] = 0; t->idx_v[0] = 0;
   t->jname[0] = "universe";
   memset(t->axis, 0, sizeof(t->axis));
@@ -56,8 +56,8 @@ static int tbl_add(table_t *t, const char *name, int parent, int jtype, double a
   t->jname[i] = name;
   t->parents[i] = parent;
   t->jtype[i] = jtype;
-  t->idx_q[i] = i - 1;
-  t->idx_v[i] = i - 1;
+  t->idx_q[i] = t->nq;
+  t->idx_v[i] = t->nv;
   double *a = t->axis + 3 * i;
   switch (jtype) {
   case LOIKB_J_RX: case LOIKB_J_PX: a[0] = 1; break;
@@ -67,7 +67,15 @@ static int tbl_add(table_t *t, const char *name, int parent, int jtype, double a
   }
   rpy_to_R(roll, pitch, yaw, t->placement + 12 * i);
   t->placement[12 * i + 9] = x; t->placement[12 * i + 10] = y; t->placement[12 * i + 11] = z;
-  t->q_lo[i - 1] = lo; t->q_hi[i - 1] = hi;
+  if (jtype == LOIKB_J_FREEFLYER) {
+    /* translation in [lo, hi]^3; the quaternion entries are placeholders (callers draw unit quaternions) */
+    for (int k = 0; k < 3; ++k) { t->q_lo[t->nq + k] = lo; t->q_hi[t->nq + k] = hi; }
+    for (int k = 3; k < 7; ++k) { t->q_lo[t->nq + k] = -1.0; t->q_hi[t->nq + k] = 1.0; }
+    t->nq += 7; t->nv += 6;
+  } else {
+    t->q_lo[t->nq] = lo; t->q_hi[t->nq] = hi;
+    t->nq += 1; t->nv += 1;
+  }
   return i;
 }
 
@@ -91,27 +99,30 @@ static void build_panda(table_t *t, int fingers)
   t->built = 1;
 }
 
-static void build_talos32(table_t *t)
+/* floating = 1: Pinocchio's buildModel(urdf, JointModelFreeFlyer(), model): joint 1 = "root_joint" (free-flyer,
+ * identity placement), the robot's root children hang off it */
+static void build_talos32(table_t *t, int floating)
 {
   tbl_init(t);
   const double d = 0.3; /* sampling half-range around the nominal pose */
   int j;
+  const int base = floating ? tbl_add(t, "root_joint", 0, LOIKB_J_FREEFLYER, 0, 0, 0, 0, 0, 0, 0, 0, 0, -0.5, 0.5) : 0;
   /* left leg (root child) */
-  j = tbl_add(t, "leg_left_1_joint", 0, LOIKB_J_RZ, 0, 0, 0, -0.02, 0.085, -0.27105, 0, 0, 0, -d, d);
+  j = tbl_add(t, "leg_left_1_joint", base, LOIKB_J_RZ, 0, 0, 0, -0.02, 0.085, -0.27105, 0, 0, 0, -d, d);
   j = tbl_add(t, "leg_left_2_joint", j, LOIKB_J_RX, 0, 0, 0, 0, 0, 0, 0, 0, 0, -d, d);
   j = tbl_add(t, "leg_left_3_joint", j, LOIKB_J_RY, 0, 0, 0, 0, 0, 0, 0, 0, 0, -0.4 - d, -0.4 + d);
   j = tbl_add(t, "leg_left_4_joint", j, LOIKB_J_RY, 0, 0, 0, 0, 0, -0.38, 0, 0, 0, 0.8 - d, 0.8 + d);
   j = tbl_add(t, "leg_left_5_joint", j, LOIKB_J_RY, 0, 0, 0, 0, 0, -0.325, 0, 0, 0, -0.4 - d, -0.4 + d);
   j = tbl_add(t, "leg_left_6_joint", j, LOIKB_J_RX, 0, 0, 0, 0, 0, 0, 0, 0, 0, -d, d);
   /* right leg (root child) */
-  j = tbl_add(t, "leg_right_1_joint", 0, LOIKB_J_RZ, 0, 0, 0, -0.02, -0.085, -0.27105, 0, 0, 0, -d, d);
+  j = tbl_add(t, "leg_right_1_joint", base, LOIKB_J_RZ, 0, 0, 0, -0.02, -0.085, -0.27105, 0, 0, 0, -d, d);
   j = tbl_add(t, "leg_right_2_joint", j, LOIKB_J_RX, 0, 0, 0, 0, 0, 0, 0, 0, 0, -d, d);
   j = tbl_add(t, "leg_right_3_joint", j, LOIKB_J_RY, 0, 0, 0, 0, 0, 0, 0, 0, 0, -0.4 - d, -0.4 + d);
   j = tbl_add(t, "leg_right_4_joint", j, LOIKB_J_RY, 0, 0, 0, 0, 0, -0.38, 0, 0, 0, 0.8 - d, 0.8 + d);
   j = tbl_add(t, "leg_right_5_joint", j, LOIKB_J_RY, 0, 0, 0, 0, 0, -0.325, 0, 0, 0, -0.4 - d, -0.4 + d);
   j = tbl_add(t, "leg_right_6_joint", j, LOIKB_J_RX, 0, 0, 0, 0, 0, 0, 0, 0, 0, -d, d);
   /* torso (root child) */
-  j = tbl_add(t, "torso_1_joint", 0, LOIKB_J_RZ, 0, 0, 0, 0, 0, 0.0722, 0, 0, 0, -d, d);
+  j = tbl_add(t, "torso_1_joint", base, LOIKB_J_RZ, 0, 0, 0, 0, 0, 0.0722, 0, 0, 0, -d, d);
   int torso2 = tbl_add(t, "torso_2_joint", j, LOIKB_J_RY, 0, 0, 0, 0, 0, 0, 0, 0, 0, -d, d);
   /* left arm */
   j = tbl_add(t, "arm_left_1_joint", torso2, LOIKB_J_RZ, 0, 0, 0, 0, 0.1575, 0.232, 0, 0, 0, 0.25 - d, 0.25 + d);
@@ -142,7 +153,8 @@ static table_t *find(const char *name)
   if (!name) return 0;
   if (!strcmp(name, "panda7")) { if (!g_panda7.built) build_panda(&g_panda7, 0); return &g_panda7; }
   if (!strcmp(name, "panda9")) { if (!g_panda9.built) build_panda(&g_panda9, 1); return &g_panda9; }
-  if (!strcmp(name, "talos32")) { if (!g_talos32.built) build_talos32(&g_talos32); return &g_talos32; }
+  if (!strcmp(name, "talos32")) { if (!g_talos32.built) build_talos32(&g_talos32, 0); return &g_talos32; }
+  if (!strcmp(name, "talos32_freeflyer")) { if (!g_talos32_ff.built) build_talos32(&g_talos32_ff, 1); return &g_talos32_ff; }
   return 0;
 }
 
@@ -151,8 +163,8 @@ int loikb_builtin_model(const char *name, loikb_model_desc *out, const double **
   table_t *t = find(name);
   if (!t || !out) return -1;
   out->njoints = t->nj;
-  out->nq = t->nj - 1;
-  out->nv = t->nj - 1;
+  out->nq = t->nq;
+  out->nv = t->nv;
   out->parents = t->parents;
   out->jtype = t->jtype;
   out->axis = t->axis;

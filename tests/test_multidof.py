@@ -81,3 +81,162 @@ def test_multidof_solve_satisfies_the_task(case):
     v = workloads.link_velocity(model, p["q"][None], z[None], int(p["c_ids"][0]))[0]
     assert np.max(np.abs(v - p["bis"][0])) < 1e-6
     assert np.all(z <= p["ub"] + 1e-9) and np.all(z >= p["lb"] - 1e-9)
+
+
+# =====================================================================================================================
+# GPU: the product (chains on the device, invisible to the caller) against the TRUE multi-DoF oracle
+# =====================================================================================================================
+LINK_FIELDS = ["vis", "fis", "g"]
+DOF_FIELDS = ["nu", "z", "w", "Stf_plus_w"]
+GPU_SCALARS = ["primal_residual", "dual_residual", "primal_residual_task", "primal_residual_slack", "dual_residual_v",
+               "dual_residual_nu", "mu", "delta_fis_inf_norm", "delta_yis_inf_norm", "delta_w_inf_norm",
+               "delta_vis_inf_norm", "delta_nu_inf_norm", "Av_inf_norm", "nu_inf_norm", "Href_v_inf_norm", "g_inf_norm",
+               "Stf_plus_w_inf_norm"]
+
+
+def _batch(model, B, seed, link=None):
+    link = model.njoints - 1 if link is None else link
+    return workloads.make_workload(model, B, link, seed, bound=0.5, snap_prob=0.2, nu_scale=0.4)
+
+
+def _gpu(model, wl, prm, **kw):
+    s = loik_amd.BatchedLoik(model, wl["q"].shape[0], **prm, **kw)
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    return s
+
+
+def _args(wl, b):
+    return (wl["q"][b], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"][b], wl["lb"], wl["ub"])
+
+
+def _compare_k_iterations(model, wl, k, tol, step=7, **kw):
+    prm = dict(FIXTURE, max_iter=k + 1, tol_abs=0.0, tol_rel=0.0, tol_primal_inf=0.0)
+    s = _gpu(model, wl, prm, **kw)
+    B = wl["q"].shape[0]
+    got = {n: s.get(n) for n in LINK_FIELDS + DOF_FIELDS + GPU_SCALARS + ["yis", "Aty", "liMi", "pis"]}
+    got["His"] = s.His_full()
+    assert np.all(s.get("iter") == k)
+    assert got["vis"].shape == (B, model.njoints - 1, 6) and got["z"].shape == (B, model.nv)
+    for b in range(0, B, step):
+        r = ref.RefSolver(model, **prm)
+        r.Solve(*_args(wl, b))
+        assert_close(got["liMi"][b], r.liMi[1:], 1e-13, "liMi")
+        for n in LINK_FIELDS:
+            assert_close(got[n][b], r.field(n)[1:], tol, "%s b%d k%d" % (n, b, k))
+        for n in DOF_FIELDS + ["yis", "Aty"]:
+            assert_close(got[n][b], r.field(n), tol, "%s b%d k%d" % (n, b, k))
+        assert_close(got["His"][b], r.His[1:], tol, "His b%d" % b)
+        if kw.get("flags", 0) & loik_amd.capi.OPT_NO_H_CACHE:
+            assert_close(got["pis"][b], r.pis[1:], tol, "pis b%d" % b)
+        for n in GPU_SCALARS:
+            assert_close(got[n][b], r.scalar(n), tol, "%s b%d k%d" % (n, b, k))
+    s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "seed%d" % c["seed"])
+def test_gpu_random_trees_with_multidof_joints(case):
+    model = random_tree_multidof(**case)
+    wl = _batch(model, 80, case["seed"] + 200)
+    for k in (1, 3, 6):
+        _compare_k_iterations(model, wl, k, TOL)
+    _compare_k_iterations(model, wl, 4, TOL, flags=loik_amd.capi.OPT_NO_H_CACHE)
+    # end to end with the stopping logic, through the tail kernel as well
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
+    out = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"],
+                          wl["ub"], nthreads=4, want_nu=True, **prm)
+    for kw in (dict(), dict(tail_max_instances=-1)):
+        s = _gpu(model, wl, prm, **kw)
+        it = s.get("iter")
+        same = it == out["iters"]
+        assert same.mean() >= 0.95, (it, out["iters"])
+        assert np.array_equal(s.get("converged").astype(bool)[same], out["converged"][same])
+        assert np.array_equal(s.get("primal_infeasible").astype(bool)[same], out["primal_infeasible"][same])
+        assert np.max(np.abs(s.get("z") - out["z"])[same]) < 1e-7
+        s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_floating_base_talos():
+    """the floating-base humanoid of SURVEY.md 8(f) rank 2: free-flyer root_joint + 32 revolute joints"""
+    model = loik_amd.builtin_model("talos32_freeflyer")
+    assert (model.njoints, model.nq, model.nv) == (34, 39, 38)
+    link = model.getJointId("arm_left_7_joint")
+    wl = _batch(model, 200, 77, link)
+    _compare_k_iterations(model, wl, 2, TOL, step=23)
+    _compare_k_iterations(model, wl, 5, TOL, step=23)
+    prm = dict(FIXTURE, max_iter=400, tol_abs=1e-6, tol_rel=0.0)
+    out = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"],
+                          wl["ub"], nthreads=4, **prm)
+    s = _gpu(model, wl, prm)
+    it = s.get("iter")
+    same = it == out["iters"]
+    assert same.mean() >= 0.95
+    assert np.array_equal(s.get("converged").astype(bool)[same], out["converged"][same])
+    assert np.max(np.abs(s.get("z") - out["z"])[same]) < 1e-7
+    # the answer moves the wrist as asked: first principles, independent of both solvers
+    ok = s.get("converged").astype(bool)
+    assert ok.mean() > 0.5
+    v = workloads.link_velocity(model, wl["q"], s.get("z"), link)
+    assert np.max(np.abs(v - wl["bis"][:, 0])[ok]) < 1e-5
+    s.close()
+
+
+def _np_quat_mul(a, b):
+    return np.array([a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1],
+                     a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0],
+                     a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3],
+                     a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2]])
+
+
+def _np_integrate(model, q, v):
+    """pinocchio::integrate for the supported joints, written with scipy's rotation exponential"""
+    from scipy.spatial.transform import Rotation
+    out = q.copy()
+    for i in range(1, model.njoints):
+        t, iq, iv = int(model.jtype[i]), int(model.idx_q[i]), int(model.idx_v[i])
+        if t == J_FREEFLYER:
+            R0 = Rotation.from_quat(q[iq + 3:iq + 7])
+            w, vl = v[iv + 3:iv + 6], v[iv:iv + 3]
+            th = np.linalg.norm(w)
+            K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+            V = np.eye(3) + ((1 - np.cos(th)) / th ** 2) * K + ((th - np.sin(th)) / th ** 3) * K @ K
+            out[iq:iq + 3] = q[iq:iq + 3] + R0.apply(V @ vl)
+            qn = (R0 * Rotation.from_rotvec(w)).as_quat()
+            out[iq + 3:iq + 7] = qn if qn @ q[iq + 3:iq + 7] >= 0 else -qn
+        elif t == J_SPHERICAL:
+            qn = (Rotation.from_quat(q[iq:iq + 4]) * Rotation.from_rotvec(v[iv:iv + 3])).as_quat()
+            out[iq:iq + 4] = qn if qn @ q[iq:iq + 4] >= 0 else -qn
+        elif t == J_TRANSLATION:
+            out[iq:iq + 3] = q[iq:iq + 3] + v[iv:iv + 3]
+        else:
+            out[iq] = q[iq] + v[iv]
+    return out
+
+
+@pytest.mark.gpu
+def test_gpu_integrate_on_the_configuration_manifold():
+    """outer loop with quaternion joints: q <- q (+) dt z is the Lie-group update"""
+    model = random_tree_multidof(seed=5, nb=9, root_freeflyer=True, n_spherical=1, n_translation=1)
+    wl = _batch(model, 70, 123)
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
+    s = _gpu(model, wl, prm)
+    z = s.get("z")
+    dt = 0.37
+    s.integrate(dt)
+    q1 = s.get("q")
+    for b in range(0, 70, 3):
+        want = _np_integrate(model, wl["q"][b], dt * z[b])
+        assert np.max(np.abs(q1[b] - want)) < 1e-12, b
+    # the quaternions stay unit, and a second solve from the resident configurations equals a solve from q1
+    for i in range(1, model.njoints):
+        t, iq = int(model.jtype[i]), int(model.idx_q[i])
+        if t in (J_FREEFLYER, J_SPHERICAL):
+            o = iq + (3 if t == J_FREEFLYER else 0)
+            assert np.max(np.abs(np.linalg.norm(q1[:, o:o + 4], axis=1) - 1)) < 1e-12
+    link = int(wl["c_ids"][0])
+    s.Solve(None, link, wl["Ais"], wl["bis"])
+    t2 = loik_amd.BatchedLoik(model, 70, **prm)
+    t2.Solve(q1, wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    assert np.max(np.abs(s.get("liMi") - t2.get("liMi"))) < 1e-14
+    s.close(); t2.close()
