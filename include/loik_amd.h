@@ -36,7 +36,7 @@ enum {
   LOIKB_ERR_NO_SUCH_CONSTRAINT = -4, /* UpdateEqConstraint on an unknown link       ...hpp:184-186          */
   LOIKB_ERR_DUP_CONSTRAINT = -5,  /* same link listed twice                         ...hpp:197-199          */
   LOIKB_ERR_MU_STRATEGY = -6,     /* OSQP / MAXEIGENVALUE not implemented  loik-loid-optimized.hxx:632-640  */
-  LOIKB_ERR_MODEL = -7,           /* nb != nj-1 (hpp:37-39), multi-DoF joint, or tree not depth-first       */
+  LOIKB_ERR_MODEL = -7,           /* unsupported joint type, inconsistent nq/nv/idx_q/idx_v, or tree not depth-first */
   /* runtime */
   LOIKB_ERR_ARG = -20,
   LOIKB_ERR_HIP = -21,            /* a HIP call failed: loikb_last_error() has the text */
@@ -122,7 +122,9 @@ int loikb_solve_tailored(loikb_solver *s, const double *q, int c_id, const doubl
  * solve -> integrate -> re-target, README.md:5 of the reference).  The configurations q stay
  * resident in HBM between steps: no per-step upload of q, FwdPassInit (loik-loid-optimized.hxx:253-283) runs from the
  * resident copy.
- *   loikb_integrate(s, dt):  q <- q (+) dt * z, z = the answer of the last solve (all joints 1-DoF: q += dt z)
+ *   loikb_integrate(s, dt):  q <- q (+) dt * z, z = the answer of the last solve (pinocchio::integrate: a plain sum
+ *                            for 1-DoF and translation joints, the SE(3) / SO(3) exponential update with the
+ *                            first-order re-normalised quaternion for free-flyer and spherical joints)
  *   loikb_solve_tailored(s, NULL, c_id, Ai, bi, flags):  q == NULL means "the resident q"                           */
 int loikb_integrate(loikb_solver *s, double dt);
 
@@ -139,19 +141,21 @@ int loikb_set_warm_start(loikb_solver *s, int warm_start);
  * (tests/loik-loid.cpp:597-615) and the getters of the solver (task-solver-base.hpp:87-102,
  * loik-loid-optimized.hpp:698-755), one value per instance */
 enum {
-  /* double [batch][nv] */
+  /* double [batch][nv], Pinocchio's idx_v order (a free-flyer contributes 6 entries [linear; angular], ...) */
   LOIKB_F_Z = 0,      /* ik_id_data.z  -- the answer: box-projected joint velocity */
   LOIKB_F_NU,         /* ik_id_data.nu */
   LOIKB_F_W,          /* ik_id_data.w  */
   LOIKB_F_STF_PLUS_W, /* ik_id_data.Stf_plus_w */
-  LOIKB_F_R,          /* ik_id_data.r (after the backward pass) */
-  LOIKB_F_DINV,       /* JointData::Dinv */
+  LOIKB_F_R,          /* ik_id_data.r (after the backward pass)             } inter-sweep temporaries, one entry per   */
+  LOIKB_F_DINV,       /* JointData::Dinv                                    } DoF: upstream's values for 1-DoF joints; */
+                      /*   for a multi-DoF joint the device eliminates its coordinates one at a time (same Schur   */
+                      /*   complement), so r / Dinv / UDinv are those of that sequence, not upstream's blocks       */
   /* double [batch][nb][6], joints 1..nb */
   LOIKB_F_VIS,        /* ik_id_data.vis[i] */
   LOIKB_F_FIS,        /* ik_id_data.fis[i] */
   LOIKB_F_G,          /* ik_id_data.fis_diff_plus_Aty[i] */
   LOIKB_F_PIS,        /* ik_id_data.pis[i] */
-  LOIKB_F_UDINV,      /* JointData::UDinv */
+  LOIKB_F_UDINV,      /* JointData::UDinv: [batch][nv][6], per DoF (see LOIKB_F_R) */
   /* double [batch][nb][21]: upper triangle, row-major */
   LOIKB_F_HIS,        /* ik_id_data.His[i] */
   /* double [batch][nb][12]: R row-major, t */

@@ -325,7 +325,7 @@ __device__ __forceinline__ void quat_to_rot(T x, T y, T z, T w, T* R)
 template <typename T>
 __device__ __forceinline__ void joint_xform(const JointDesc& d, const char* rec, T c, T s, T* R, T* t)
 {
-  if (d.rot >= ROT_FREE) {
+  if (__builtin_expect(d.rot >= ROT_FREE, 0)) {
     constexpr size_t RB = (size_t)JREC * pair_bytes<T>();
     T Rq[9], tq[3] = {T(0), T(0), T(0)}, Rp[9], rt[3];
 #pragma unroll
@@ -349,7 +349,7 @@ __device__ __forceinline__ void joint_xform(const JointDesc& d, const char* rec,
     for (int k = 0; k < 3; ++k) t[k] = (T)d.tp[k] + rt[k];
     return;
   }
-  if (d.flags & JF_NOQ) { c = (d.flags & JF_REVOLUTE) ? T(1) : T(0); s = T(0); }
+  if (__builtin_expect(d.flags & JF_NOQ, 0)) { c = (d.flags & JF_REVOLUTE) ? T(1) : T(0); s = T(0); }
   make_liMi(d, c, s, R, t);
 }
 
@@ -475,6 +475,23 @@ __device__ __forceinline__ void href_mul(const T* Href, const T* v, T* o)
     }
   }
 }
+
+// The cost a link carries by itself: rho I + H_ref and the reference term H_ref v_ref -- all zero for a massless chain
+// link (JF_MASSLESS).  The flag is uniform per joint and the parameters are kernel arguments, so these are scalar
+// selects on SGPRs: the vector work per joint is the same as without the flag.
+template <typename T, bool HDIAG>
+struct LinkCost {
+  T rho, Hv[6], Href[36];
+  __device__ __forceinline__ LinkCost(const Params<T>& P, int jflags)
+  {
+    const bool ml = jflags & JF_MASSLESS;
+    rho = ml ? T(0) : P.rho;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Hv[k] = ml ? T(0) : P.Hv[k];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) Href[k] = (HDIAG && (k % 7 != 0)) ? T(0) : (ml ? T(0) : P.Href[k]);
+  }
+};
 
 // ---- team schedule ---------------------------------------------------------------------------------
 // A tile (64 instances, one per lane) is advanced by a TEAM of `nw` wavefronts (one workgroup).  Every wavefront
@@ -649,16 +666,16 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
         dd_cached = ldp<T>(rec, JP_R).y;  // Dinv shares the pair of r: read it to rewrite the full pair below
       }
       // FwdPass1 (hxx:304-315): H_i = rho I + H_ref ; p_i = -rho v_prev - Hv   (a massless chain link: both zero)
-      const T m = (d.flags & JF_MASSLESS) ? T(0) : T(1);
+      const LinkCost<T, HDIAG> lc(P, d.flags);
       if (WITH_H) {
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
           for (int cc = r; cc < 6; ++cc)
-            hh[sym(r, cc)] = m * ((r == cc ? P.rho : T(0)) + ((HDIAG && r != cc) ? T(0) : P.Href[6 * r + cc]));
+            hh[sym(r, cc)] = (r == cc ? lc.rho : T(0)) + ((HDIAG && r != cc) ? T(0) : lc.Href[6 * r + cc]);
       }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) pp[k] = m * (-P.rho * vprev[k] - P.Hv[k]);
+      for (int k = 0; k < 6; ++k) pp[k] = -lc.rho * vprev[k] - lc.Hv[k];
       // constraint terms (hxx:321-334)
       if (d.cslot >= 0) {
         const char* crec = lp + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>();
@@ -825,10 +842,11 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
 #pragma unroll
       for (int k = 0; k < 6; ++k) dv6[k] = vi[k] - in.vprev[k];
       // Href_v (hxx:149-153)
-      href_mul<T, HDIAG>(P.Href, vi, hrv);
-      const T m = (d.flags & JF_MASSLESS) ? T(0) : T(1);  // a massless chain link is not a body of the model
-      N.href_v = tmax(N.href_v, m * inf6(hrv));
-      N.dvis = tmax(N.dvis, m * inf6(dv6));  // hxx:156-158
+      // a massless chain link is not a body of the model: H_ref = 0 for it, and its velocity stays out of the norm
+      const LinkCost<T, HDIAG> lc(P, d.flags);
+      href_mul<T, HDIAG>(lc.Href, vi, hrv);
+      N.href_v = tmax(N.href_v, inf6(hrv));
+      if (!(d.flags & JF_MASSLESS)) N.dvis = tmax(N.dvis, inf6(dv6));  // hxx:156-158
       N.dnu = tmax(N.dnu, tabs(nui - nuprev));  // hxx:375
       // BoxProj (hxx:388-394)
       const T x = nui + (T(1) / mu_in) * wi;
@@ -920,11 +938,10 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void force_balance(const Params<T>& P, const Bufs<T>& Bf, const JointDesc& d, const char* lp,
-                                              T mu_eq, T m, const T* vi, const T* hv, const T* pb, const T* sumf, T* fi)
+                                              T mu_eq, T rho_i, const T* vi, const T* hv, const T* pb, const T* sumf, T* fi)
 {
-  // m = 0 for a massless chain link (H_i^base = 0), else 1; hv comes in already scaled by m
+  // rho_i, hv: the link's own rho and H_ref v_i (LinkCost: zero for a massless chain link)
   const Layout& L = P.L;
-  const T rho_i = m * P.rho;
 #pragma unroll
   for (int k = 0; k < 6; ++k) fi[k] = (hv[k] + rho_i * vi[k]) + pb[k];
   if (d.cslot >= 0) {
@@ -981,11 +998,9 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
 #pragma unroll
       for (int k = 0; k < 6; ++k) sf[k] = T(0);
       edge_gather<T, 0, 6>(sd, tm.rlist, edge, acc, sf, lane);
-      href_mul<T, HDIAG>(P.Href, vi, hv);
-      const T m = (d.flags & JF_MASSLESS) ? T(0) : T(1);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) hv[k] *= m;
-      force_balance<T>(P, Bf, d, lp, mu_eq, m, vi, hv, pb, sf, fi);
+      const LinkCost<T, HDIAG> lc(P, d.flags);
+      href_mul<T, HDIAG>(lc.Href, vi, hv);
+      force_balance<T>(P, Bf, d, lp, mu_eq, lc.rho, vi, hv, pb, sf, fi);
       st6<T>(rec, JP_F, fi);
       // g_i = (Aty_c | 0) + sum_children act(f_j) - f_i   (hxx:438-439, :210-212)
       if (d.cslot >= 0) {
@@ -1007,7 +1022,7 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
       N.g_inf = tmax(N.g_inf, inf6(gi));  // hxx:223-225
       // dual residual, v block (hxx:228): Href v_i - Hv + g_i
 #pragma unroll
-      for (int r = 0; r < 6; ++r) dvr[r] = hv[r] - m * P.Hv[r] + gi[r];
+      for (int r = 0; r < 6; ++r) dvr[r] = hv[r] - lc.Hv[r] + gi[r];
       N.dual_v = tmax(N.dual_v, inf6(dvr));
       // Stf_plus_w (hxx:231-236, :482-484)
       const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
@@ -1083,9 +1098,9 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
       const T wi = in.wz.x, sold = in.nus.y;
       // ---- iteration k: f_i by force balance, g_i = (Aty_c | 0) + sum_children act(f_j) - f_i   (hxx:438-439, :210-212)
       //      iteration k+1: p_i = -rho v_i - Hv (+ Aty_c - mu_eq Atb_c)       (hxx:304-315, :321-334)
-      const T m = (d.flags & JF_MASSLESS) ? T(0) : T(1);
+      const LinkCost<T, HDIAG> lc(P, d.flags);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { pp[k] = m * (-P.rho * in.vi[k] - P.Hv[k]); sf[k] = T(0); }
+      for (int k = 0; k < 6; ++k) { pp[k] = -lc.rho * in.vi[k] - lc.Hv[k]; sf[k] = T(0); }
       if (d.cslot >= 0) {
         const char* crec = lp + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>();
         T atb[6];
@@ -1100,10 +1115,8 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
       st6<T>(rec, JP_P, pp);  // p^base of iteration k+1 (the slot's p^base of iteration k is already in `in.pb`)
       edge_gather<T, 0, 6>(sd, tm.rlist, edge, acc, sf, lane);
       edge_gather<T, 6, 6>(sd, tm.rlist, edge, acc + 6, pp, lane);
-      href_mul<T, HDIAG>(P.Href, in.vi, hv);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) hv[k] *= m;
-      force_balance<T>(P, Bf, d, lp, mu_eq, m, in.vi, hv, in.pb, sf, fi);
+      href_mul<T, HDIAG>(lc.Href, in.vi, hv);
+      force_balance<T>(P, Bf, d, lp, mu_eq, lc.rho, in.vi, hv, in.pb, sf, fi);
       st6<T>(rec, JP_F, fi);
       T dg[6], dvr[6], df[6];
 #pragma unroll
@@ -1118,7 +1131,7 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
       N.g_inf = tmax(N.g_inf, inf6(gi));  // hxx:223-225
       // dual residual, v block (hxx:228): Href v_i - Hv + g_i
 #pragma unroll
-      for (int r = 0; r < 6; ++r) dvr[r] = hv[r] - m * P.Hv[r] + gi[r];
+      for (int r = 0; r < 6; ++r) dvr[r] = hv[r] - lc.Hv[r] + gi[r];
       N.dual_v = tmax(N.dual_v, inf6(dvr));
       // Stf_plus_w (hxx:231-236, :482-484) and r_i = (w_i - mu_in z_i) + S^T p_i (hxx:296, :70)
       const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];

@@ -38,7 +38,7 @@ struct Fixture {  // ProblemSetupFixture, tests/loik-loid.cpp:87-165
   ADMMPenaltyUpdateStrat mu_update_strat = DEFAULT;
   int num_eq_c = 1, eq_c_dim = 6;
   bool warm_start = false, verbose = false, logging = false;
-  Model robot_model = Model::Builtin("talos32");
+  Model robot_model;
   DVec q;
   Mat6x6 H_ref = Identity6();
   Motion v_ref{};
@@ -47,9 +47,11 @@ struct Fixture {  // ProblemSetupFixture, tests/loik-loid.cpp:87-165
   std::vector<Vec6> bis;
   double bound_magnitude = 4.0;
   DVec lb, ub;
-  Fixture()
+  explicit Fixture(const char* robot = "talos32") : robot_model(Model::Builtin(robot))
   {
-    q.assign(robot_model.nq, 0.0);  // pinocchio::neutral
+    q.assign(robot_model.nq, 0.0);  // pinocchio::neutral (unit quaternion for a free-flyer)
+    for (int i = 1; i < robot_model.njoints; ++i)
+      if (robot_model.jtype[i] == LOIKB_J_FREEFLYER) q[robot_model.idx_q[i] + 6] = 1.0;
     active_task_constraint_ids.push_back(static_cast<Index>(robot_model.njoints - 1));
     Ais.push_back(Identity6());
     Vec6 bi{};
@@ -225,6 +227,22 @@ int main()
       CHECK(solver.get_iter(b) == (int)ref_scalar(o.s, REF_S_ITER));
       CHECK(close(d.z.data() + b * f.robot_model.nv, o.field(REF_F_Z), f.robot_model.nv));
     }
+  }
+  {  // floating base: free-flyer root_joint + 32 revolute joints, nq = 39, nv = 38
+    Fixture f("talos32_freeflyer"); f.max_iter = 300; f.tol_abs = 1e-6; f.tol_rel = 0.0; f.set_bound(0.5);
+    CHECK(f.robot_model.nq == 39 && f.robot_model.nv == 38 && f.robot_model.njoints == 34);
+    f.active_task_constraint_ids[0] = f.robot_model.getJointId("arm_left_7_joint");
+    for (int k = 7; k < f.robot_model.nq; ++k) f.q[k] = 0.1 * std::sin(1.0 + k);
+    f.bis[0] = Vec6{0.05, -0.03, 0.02, 0.01, 0.02, -0.04};
+    IkIdDataOptimized d(f.robot_model, f.num_eq_c);
+    MAKE_SOLVER(solver, d, f);
+    solver.Solve(f.q, f.H_ref, f.v_ref, f.active_task_constraint_ids, f.Ais, f.bis, f.lb, f.ub);
+    Oracle o(f);  // the oracle solves the true 6-DoF joint (6 x 6 Dinv); the device a chain of six 1-DoF joints
+    o.Solve(f, f.q, f.bis[0]);
+    CHECK(solver.get_convergence_status());
+    CHECK(solver.get_iter() == (int)ref_scalar(o.s, REF_S_ITER));
+    CHECK(close(d.z.data(), o.field(REF_F_Z), f.robot_model.nv, 1e-7));
+    CHECK(close(d.vis.data(), o.field(REF_F_VIS) + 6, 6 * (f.robot_model.njoints - 1), 1e-7));
   }
   std::printf(failures ? "%d CHECKS FAILED\n" : "all wrapper checks passed\n", failures);
   return failures ? 1 : 0;
