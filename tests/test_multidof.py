@@ -83,6 +83,45 @@ def test_multidof_solve_satisfies_the_task(case):
     assert np.all(z <= p["ub"] + 1e-9) and np.all(z >= p["lb"] - 1e-9)
 
 
+@pytest.mark.parametrize("case", CASES[:3], ids=lambda c: "seed%d" % c["seed"])
+def test_multidof_oracle_answer_is_the_qp_optimum(case):
+    """pins the oracle's nv x nv joints themselves: the converged answer is the optimum of the reduced dense QP
+    min_nu sum_i 1/2 |J_i nu|^2  s.t.  J_c nu = b, lb <= nu <= ub  found by scipy's SLSQP, with Jacobians built by an
+    independent numpy kinematics (workloads.link_velocity)"""
+    from scipy.optimize import minimize
+    model = random_tree_multidof(**case)
+    p = one_problem(model, case["seed"] + 300)
+    s = ref.RefSolver(model, **dict(FIXTURE, max_iter=4000, tol_abs=1e-9, tol_rel=0.0, tol_primal_inf=1e-12))
+    s.Solve(p["q"], p["H_ref"], p["v_ref"], p["c_ids"], p["Ais"], p["bis"], p["lb"], p["ub"])
+    assert s.get_convergence_status(), s.get_iter()
+    nu, z, link = s.nu, s.z, int(p["c_ids"][0])
+
+    def jac(i):
+        J = np.zeros((6, model.nv))
+        for k in range(model.nv):
+            e = np.zeros((1, model.nv)); e[0, k] = 1.0
+            J[:, k] = workloads.link_velocity(model, p["q"][None], e, i)[0]
+        return J
+    Js = [jac(i) for i in range(1, model.njoints)]
+    for i in range(1, model.njoints):
+        assert np.max(np.abs(Js[i - 1] @ nu - s.vis[i])) < 1e-11
+    bb = p["bis"][0]
+    assert np.max(np.abs(s.vis[link] - bb)) < 1e-8 and np.max(np.abs(nu - z)) < 1e-8
+    Hq = sum(J.T @ J for J in Js)
+    Jc = Js[link - 1]
+    # the task link may hang off a short chain (rank-deficient J_c, target still reachable): keep independent rows
+    U, sv, _ = np.linalg.svd(Jc)
+    Ur = U[:, sv > 1e-9 * sv[0]]
+    Jc, bb = Ur.T @ Jc, Ur.T @ bb
+    res = minimize(lambda x: 0.5 * x @ Hq @ x, np.zeros(model.nv), jac=lambda x: Hq @ x, method="SLSQP",
+                   bounds=list(zip(p["lb"], p["ub"])),
+                   constraints=[dict(type="eq", fun=lambda x: Jc @ x - bb, jac=lambda x: Jc)],
+                   options=dict(ftol=1e-15, maxiter=800))
+    assert res.success
+    assert abs(0.5 * z @ Hq @ z - res.fun) < 1e-7 * max(1.0, abs(res.fun))
+    assert np.max(np.abs(z - res.x)) < 5e-4
+
+
 # =====================================================================================================================
 # GPU: the product (chains on the device, invisible to the caller) against the TRUE multi-DoF oracle
 # =====================================================================================================================
