@@ -182,7 +182,13 @@ enum {
   LOIKB_F_Q = 96,
   /* int [batch]: how many times UpdateMu (optimized.hxx:613-641) changed mu in the last solve -- a diagnostic: the
      instances that run to max_iter are the ones that keep flipping mu between two decades */
-  LOIKB_F_MU_UPDATES = 97
+  LOIKB_F_MU_UPDATES = 97,
+  /* double [batch][6 nb + nv]: get_primal_residual_vec() / get_dual_residual_vec() (loik-loid-optimized.hpp:698-699)
+     of the last iteration.  The hot path only forms their running maxima (the scalar residuals); these getters
+     rebuild the vectors from the state: primal = (A_c v_c - b_c on the constrained links' rows, 0 elsewhere | nu - z),
+     dual = (H_ref v_i - H_ref v_ref + fis_diff_plus_Aty[i] | Stf_plus_w) */
+  LOIKB_F_PRIMAL_RESIDUAL_VEC = 98,
+  LOIKB_F_DUAL_RESIDUAL_VEC = 99
 };
 /* copies one field for the whole batch into `out` (host pointer, or device pointer with LOIKB_OUT_DEVICE) */
 int loikb_get(loikb_solver *s, int field, void *out, int out_flags);

@@ -203,6 +203,9 @@ public:
   void set_mu(const double mu) { check(loikb_set_mu(h_, mu)); }
   void set_tol_primal_inf(const double t) { check(loikb_set_tol_primal_inf(h_, t)); }
   // loik-loid-optimized.hpp:700-755
+  // get_primal_residual_vec() / get_dual_residual_vec(), loik-loid-optimized.hpp:698-699: [6 nb + nv] of instance b
+  DVec get_primal_residual_vec(int b = 0) const { return getvec(LOIKB_F_PRIMAL_RESIDUAL_VEC, b); }
+  DVec get_dual_residual_vec(int b = 0) const { return getvec(LOIKB_F_DUAL_RESIDUAL_VEC, b); }
   double get_dual_residual_v(int b = 0) const { return getd(LOIKB_F_DUAL_RESIDUAL_V, b); }
   double get_dual_residual_nu(int b = 0) const { return getd(LOIKB_F_DUAL_RESIDUAL_NU, b); }
   double get_tol_tail_solve() const { return tol_tail_solve_; }
@@ -280,6 +283,13 @@ private:
     DVec tmp(static_cast<std::size_t>(batch_));
     check(loikb_get(h_, field, tmp.data(), 0));
     return tmp[static_cast<std::size_t>(b)];
+  }
+  DVec getvec(int field, int b) const
+  {
+    const std::size_t n = 6 * static_cast<std::size_t>(model_.njoints - 1) + static_cast<std::size_t>(model_.nv);
+    DVec tmp(static_cast<std::size_t>(batch_) * n);
+    check(loikb_get(h_, field, tmp.data(), 0));
+    return DVec(tmp.begin() + b * n, tmp.begin() + (b + 1) * n);
   }
 
   Model model_;             // by value, as upstream (loik-loid-optimized.hpp:762)

@@ -66,6 +66,8 @@ _SCALAR_FIELDS = ["primal_residual", "dual_residual", "primal_residual_task", "p
 FIELD_ID = {n: i for i, n in enumerate(_VEC_FIELDS)}
 FIELD_ID["q"] = 96
 FIELD_ID["mu_updates"] = 97
+FIELD_ID["primal_residual_vec"] = 98
+FIELD_ID["dual_residual_vec"] = 99
 FIELD_ID.update({n: 32 + i for i, n in enumerate(_SCALAR_FIELDS)})
 
 # every symbol include/loik_amd.h and include/loik_amd_models.h declare
@@ -379,7 +381,8 @@ class BatchedLoik:
         shapes = {"z": (B, nv), "nu": (B, nv), "w": (B, nv), "Stf_plus_w": (B, nv), "r": (B, nv), "Dinv": (B, nv),
                   "vis": (B, nb, 6), "fis": (B, nb, 6), "g": (B, nb, 6), "pis": (B, nb, 6), "UDinv": (B, nv, 6),
                   "His": (B, nb, 21), "liMi": (B, nb, 12), "yis": (B, nc, 6), "Aty": (B, nc, 6),
-                  "q": (B, self.model.nq)}
+                  "q": (B, self.model.nq), "primal_residual_vec": (B, 6 * nb + nv),
+                  "dual_residual_vec": (B, 6 * nb + nv)}
         is_int = name in ("iter", "converged", "primal_infeasible", "status", "mu_updates")
         if out is not None:
             p, dev = _ptr(out)

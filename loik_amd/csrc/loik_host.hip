@@ -1149,6 +1149,60 @@ __global__ void k_limi(char* tiles, Layout L, const JointDesc* __restrict__ jd, 
   }
 }
 
+// get_primal_residual_vec() / get_dual_residual_vec() (loik-loid-optimized.hpp:698-699), [6 nl + nv] per instance, rebuilt
+// from the state of the last iteration -- the hot path only ever forms their running maxima:
+//   primal: rows 6(c_id-1).. = A_c v_c - b_c for the constrained links, 0 elsewhere (hxx:433);
+//           tail = nu - z (hxx:394)
+//   dual:   rows 6(i-1).. = H_ref v_i - H_ref v_ref + g_i (hxx:228);  tail = S^T f + w (hxx:484)
+struct RefCost { double Href[36], Hv[6]; };
+template <typename T>
+__global__ void k_residual_vecs(char* tiles, Layout L, const JointDesc* __restrict__ jd, const T* __restrict__ uni,
+                                RefCost rc, int a_shared, const int* __restrict__ sel, int nl, int B, int dual,
+                                double* __restrict__ out)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  char* lp = lane_ptr<T>(tiles, L, b);
+  double* o = out + (size_t)b * (6 * nl + L.nb);
+  for (int e = 0; e < nl; ++e) {
+    const int i = sel[e] + 1;
+    const char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
+    T v[6];
+    ld6<T>(rec, JP_V, v);
+    if (dual) {
+      T g[6];
+      ld6<T>(rec, JP_G, g);
+      for (int r = 0; r < 6; ++r) {
+        double a = 0.0;
+        for (int k = 0; k < 6; ++k) a += rc.Href[6 * r + k] * (double)v[k];
+        o[6 * e + r] = a - rc.Hv[r] + (double)g[r];
+      }
+    } else {
+      const int cs = jd[i].cslot;
+      for (int r = 0; r < 6; ++r) o[6 * e + r] = 0.0;
+      if (cs >= 0) {
+        const char* crec = lp + (size_t)(L.off_c + cs * L.crec) * pair_bytes<T>();
+        T bb[6];
+        ld6<T>(crec, CP_B, bb);
+        for (int r = 0; r < 6; ++r) {
+          double a = 0.0;
+          for (int k = 0; k < 6; ++k) {
+            const int q = 6 * r + k;
+            const T A = a_shared ? uni[cs * 36 + q] : *elem_ptr<T>(const_cast<char*>(crec), CP_A + q / 2, q & 1);
+            a += (double)A * (double)v[k];
+          }
+          o[6 * e + r] = a - (double)bb[r];
+        }
+      }
+    }
+  }
+  for (int j = 0; j < L.nb; ++j) {
+    const char* rec = lp + (size_t)j * JREC * pair_bytes<T>();
+    const typename Vec2<T>::type nus = ldp<T>(rec, JP_NUS);
+    o[6 * nl + j] = dual ? (double)nus.y : (double)nus.x - (double)ldp<T>(rec, JP_WZ).y;
+  }
+}
+
 // dst[b][e][:] = src[b][sel[e]][:]  (rows of w doubles): the bodies of the caller's model out of the device tree's
 __global__ void k_select_rows(const double* __restrict__ src, int nrow_src, int w, const int* __restrict__ sel, int nsel,
                               int B, double* __restrict__ dst)
@@ -1508,6 +1562,7 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   case LOIKB_F_YIS: per_constraint_vec(CP_Y); break;
   case LOIKB_F_ATY: per_constraint_vec(CP_ATY); break;
   case LOIKB_F_LIMI: break;
+  case LOIKB_F_PRIMAL_RESIDUAL_VEC: case LOIKB_F_DUAL_RESIDUAL_VEC: break;  // rebuilt below
   case LOIKB_F_ITER: is_int = true; rm.push_back((L.off_s + SP_BI) * 2 + 1); break;
   case LOIKB_F_STATUS: is_int = true; mask = -(ST_CONVERGED | ST_PRIMAL_INF | ST_TAIL | ST_DONE); rm.push_back((L.off_s + SP_ST) * 2); break;
   case LOIKB_F_CONVERGED: is_int = true; mask = ST_CONVERGED; rm.push_back((L.off_s + SP_ST) * 2); break;
@@ -1523,8 +1578,9 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
       return LOIKB_ERR_ARG;
     }
   }
+  const bool resvec = field == LOIKB_F_PRIMAL_RESIDUAL_VEC || field == LOIKB_F_DUAL_RESIDUAL_VEC;
   const int n = field == LOIKB_F_LIMI ? 12 * nl : field == LOIKB_F_HIS ? 21 * nl : field == LOIKB_F_PIS ? 6 * nl
-                                                                                                          : (int)rm.size();
+                : resvec ? 6 * nl + nb : (int)rm.size();
   // the rebuild kernels work on the device tree; with multi-DoF joints the caller's bodies are selected afterwards
   const bool select = nl != nb && (field == LOIKB_F_HIS || field == LOIKB_F_PIS);
   double* final_dst = nullptr;
@@ -1566,6 +1622,13 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   } else if (field == LOIKB_F_PIS) {
     if (S->f32) hipLaunchKernelGGL(k_rebuild_pis<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->B, dst);
     else hipLaunchKernelGGL(k_rebuild_pis<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->B, dst);
+  } else if (resvec) {
+    RefCost rcst;
+    for (int k = 0; k < 36; ++k) rcst.Href[k] = S->Href[k];
+    for (int k = 0; k < 6; ++k) rcst.Hv[k] = S->Hv[k];
+    const int dual = field == LOIKB_F_DUAL_RESIDUAL_VEC;
+    if (S->f32) hipLaunchKernelGGL(k_residual_vecs<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, (const float*)S->d_uni, rcst, (int)S->a_shared, S->d_link_sel, nl, S->B, dual, dst);
+    else hipLaunchKernelGGL(k_residual_vecs<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, (const double*)S->d_uni, rcst, (int)S->a_shared, S->d_link_sel, nl, S->B, dual, dst);
   } else if (field == LOIKB_F_LIMI) {
     if (S->f32) hipLaunchKernelGGL(k_limi<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->d_first_sel, nl, S->B, dst);
     else hipLaunchKernelGGL(k_limi<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->d_first_sel, nl, S->B, dst);

@@ -92,6 +92,12 @@ static void compare(const Fixture& f, const IkIdDataOptimized& d, FirstOrderLoik
   const int nv = f.robot_model.nv, nb = f.robot_model.njoints - 1;
   CHECK(close(d.z.data(), o.field(REF_F_Z), nv));
   CHECK(close(d.nu.data(), o.field(REF_F_NU), nv));
+  {
+    const DVec pr = solver.get_primal_residual_vec(), du = solver.get_dual_residual_vec();
+    CHECK((int)pr.size() == 6 * (f.robot_model.njoints - 1) + nv && pr.size() == du.size());
+    CHECK(close(pr.data(), o.field(REF_F_PRIMAL_RES_VEC), (int)pr.size()));
+    CHECK(close(du.data(), o.field(REF_F_DUAL_RES_VEC), (int)du.size()));
+  }
   CHECK(close(d.w.data(), o.field(REF_F_W), nv));
   CHECK(close(d.vis.data(), o.field(REF_F_VIS) + 6, 6 * nb));
   CHECK(close(d.fis.data(), o.field(REF_F_FIS) + 6, 6 * nb));

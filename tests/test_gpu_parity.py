@@ -36,6 +36,8 @@ def compare_instance(s, cache, r, b, tol, scalars=True):
             want = want[1:]
         assert_close(cache[name][b], want, tol, "%s b%d" % (name, b))
     assert_close(cache["His"][b], r.His[1:], tol, "His b%d" % b)
+    for name in ("primal_residual_vec", "dual_residual_vec"):  # public getters, loik-loid-optimized.hpp:698-699
+        assert_close(cache[name][b], r.field(name), tol, "%s b%d" % (name, b))
     if scalars:
         for name in SCALARS:
             assert_close(cache[name][b], r.scalar(name), tol, "%s b%d" % (name, b))
@@ -44,6 +46,8 @@ def compare_instance(s, cache, r, b, tol, scalars=True):
 def fetch(s):
     cache = {n: s.get(n) for n in FIELDS + SCALARS + ["iter", "converged", "primal_infeasible", "tol_primal", "tol_dual"]}
     cache["His"] = s.His_full()
+    for name in ("primal_residual_vec", "dual_residual_vec"):
+        cache[name] = s.get(name)
     return cache
 
 

@@ -154,6 +154,7 @@ def _compare_k_iterations(model, wl, k, tol, step=7, **kw):
     B = wl["q"].shape[0]
     got = {n: s.get(n) for n in LINK_FIELDS + DOF_FIELDS + GPU_SCALARS + ["yis", "Aty", "liMi", "pis"]}
     got["His"] = s.His_full()
+    resvec = {n: s.get(n) for n in ("primal_residual_vec", "dual_residual_vec")}
     assert np.all(s.get("iter") == k)
     assert got["vis"].shape == (B, model.njoints - 1, 6) and got["z"].shape == (B, model.nv)
     for b in range(0, B, step):
@@ -169,6 +170,8 @@ def _compare_k_iterations(model, wl, k, tol, step=7, **kw):
             assert_close(got["pis"][b], r.pis[1:], tol, "pis b%d" % b)
         for n in GPU_SCALARS:
             assert_close(got[n][b], r.scalar(n), tol, "%s b%d k%d" % (n, b, k))
+        for n in ("primal_residual_vec", "dual_residual_vec"):  # public getters, loik-loid-optimized.hpp:698-699
+            assert_close(resvec[n][b], r.field(n), tol, "%s b%d k%d" % (n, b, k))
     s.close()
 
 
