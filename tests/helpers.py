@@ -175,3 +175,22 @@ def expand_to_chains(model, q):
         if int(model.jtype[i]) not in CHAIN_TYPES:
             q1[int(m1.idx_q[link_of[i]])] = q[int(model.idx_q[i])]
     return m1, q1, np.array(link_of)
+
+
+def multi_task_batch(model, batch, links, seed, bound=0.5, nu_scale=0.4, per_instance_A=False):
+    """several simultaneous task constraints (num_eq_c = len(links) > 1, the ctor argument of the reference,
+    loik-loid-optimized.hpp:129-134): b_c = A_c J_c(q) nu_star for one common nu_star -> jointly feasible"""
+    wl = workloads.make_workload(model, batch, links[0], seed, bound=bound, snap_prob=0.0, nu_scale=nu_scale)
+    rng = np.random.default_rng(seed + 5)
+    nc = len(links)
+    if per_instance_A:
+        A = np.eye(6)[None, None] + 0.3 * rng.normal(size=(batch, nc, 6, 6))
+    else:
+        A = np.eye(6)[None] + 0.3 * rng.normal(size=(nc, 6, 6))
+    b = np.empty((batch, nc, 6))
+    for c, link in enumerate(links):
+        v = workloads.link_velocity(model, wl["q"], wl["nu_star"], link)
+        b[:, c] = np.einsum("bij,bj->bi", A[:, c], v) if per_instance_A else v @ A[c].T
+    wl["c_ids"] = np.array(links, dtype=np.int32)
+    wl["Ais"], wl["bis"] = A, b
+    return wl

@@ -1,0 +1,121 @@
+"""Several simultaneous task constraints: `num_eq_c > 1` is a constructor argument of the reference
+(/root/reference/include/loik/loik-loid-optimized.hpp:129-134; FwdPass1 / DualUpdate loop over
+`active_task_constraint_ids_`, loik-loid-optimized.hxx:321-334, :410-451) although its own fixture uses one."""
+import numpy as np
+import pytest
+
+import loik_amd
+from helpers import FIXTURE, assert_close, multi_task_batch, problem_args, random_tree
+from oracle import dense, ref
+
+
+def _links(model, nc):
+    """nc distinct links, leaves first (so that the constraints sit on different branches where there are any)"""
+    children = {i: 0 for i in range(model.njoints)}
+    for i in range(1, model.njoints):
+        children[int(model.parents[i])] += 1
+    leaves = [i for i in range(model.njoints - 1, 0, -1) if children[i] == 0]
+    rest = [i for i in range(model.njoints - 1, 0, -1) if children[i] != 0]
+    return (leaves + rest)[:nc]
+
+
+@pytest.mark.parametrize("nc", [2, 3])
+def test_recursive_and_dense_oracles_agree_with_several_constraints(nc):
+    """the reference's relational pin (opt == plain, tests/loik-loid.cpp:305-556) with nc > 1"""
+    model = random_tree(21 + nc, 11)
+    links = _links(model, nc)
+    wl = multi_task_batch(model, 2, links, 5 + nc)
+    prm = dict(FIXTURE, num_eq_c=nc, max_iter=12, tol_abs=0.0, tol_rel=0.0, tol_primal_inf=0.0)
+    for b in range(2):
+        opt = ref.RefSolver(model, **prm)
+        pl = dense.DenseSolver(model, **prm)
+        args = problem_args(wl, b)
+        opt.Solve(*args)
+        pl.Solve(*args)
+        assert opt.get_iter() == pl.get_iter() == 11
+        assert_close(opt.nu, pl.nu, 1e-9, "nu"); assert_close(opt.z, pl.z, 1e-9, "z"); assert_close(opt.w, pl.w, 1e-9, "w")
+        assert_close(opt.vis[1:], pl.vis[1:], 1e-9, "vis"); assert_close(opt.fis[1:], pl.fis[1:], 1e-8, "fis")
+        for c, cid in enumerate(links):
+            assert_close(opt.yis[c], pl.yis[cid], 1e-8, "yis")
+        assert_close(opt.scalar("primal_residual"), pl.primal_residual, 1e-9, "primal")
+        assert_close(opt.scalar("dual_residual"), pl.dual_residual, 1e-8, "dual")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+FIELDS = ["nu", "z", "w", "vis", "fis", "g", "yis", "Aty", "Stf_plus_w", "primal_residual_vec", "dual_residual_vec"]
+SCALARS = ["primal_residual", "dual_residual", "primal_residual_task", "primal_residual_slack", "mu",
+           "delta_yis_inf_norm", "Av_inf_norm", "g_inf_norm", "delta_fis_inf_norm"]
+
+
+def _gpu(model, wl, prm, **kw):
+    s = loik_amd.BatchedLoik(model, wl["q"].shape[0], **prm, **kw)
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    return s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,nc,per_instance_A", [("talos", 2, False), ("talos", 3, True), ("tree", 2, True),
+                                                     ("tree", 4, False), ("panda9", 2, False)])
+def test_gpu_several_constraints(which, nc, per_instance_A, request):
+    model = random_tree(9, 19) if which == "tree" else request.getfixturevalue(which)
+    if which == "talos":
+        links = [model.getJointId(n) for n in ("arm_left_7_joint", "arm_right_7_joint", "head_2_joint")][:nc]
+    else:
+        links = _links(model, nc)
+    B = 90
+    wl = multi_task_batch(model, B, links, 3 + nc, per_instance_A=per_instance_A)
+    for k in (1, 2, 5):
+        prm = dict(FIXTURE, num_eq_c=nc, max_iter=k + 1, tol_abs=0.0, tol_rel=0.0, tol_primal_inf=0.0)
+        s = _gpu(model, wl, prm)
+        got = {n: s.get(n) for n in FIELDS + SCALARS}
+        got["His"] = s.His_full()
+        for b in range(0, B, 11):
+            r = ref.RefSolver(model, **prm)
+            r.Solve(*problem_args(wl, b))
+            for n in FIELDS:
+                want = r.field(n)
+                if n in ("vis", "fis", "g"):
+                    want = want[1:]
+                assert_close(got[n][b], want, 1e-9, "%s b%d k%d" % (n, b, k))
+            assert_close(got["His"][b], r.His[1:], 1e-9, "His")
+            for n in SCALARS:
+                assert_close(got[n][b], r.scalar(n), 1e-9, "%s b%d k%d" % (n, b, k))
+        s.close()
+    # end to end: stopping logic, the solve kernel alone and the tail kernel alone
+    prm = dict(FIXTURE, num_eq_c=nc, max_iter=400, tol_abs=1e-6, tol_rel=0.0)
+    Ais = wl["Ais"] if per_instance_A else wl["Ais"]
+    out = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], Ais, wl["bis"], wl["lb"], wl["ub"],
+                          nthreads=4, want_nu=True, **prm)
+    for kw in (dict(tail_max_instances=-1), dict()):
+        s = _gpu(model, wl, prm, **kw)
+        it = s.get("iter")
+        same = it == out["iters"]
+        assert same.mean() >= 0.95, (it, out["iters"])
+        assert np.array_equal(s.get("converged").astype(bool)[same], out["converged"][same])
+        assert np.array_equal(s.get("primal_infeasible").astype(bool)[same], out["primal_infeasible"][same])
+        assert np.max(np.abs(s.get("z") - out["z"])[same]) < 1e-8
+        assert s.stats()["tail_instances"] == (0 if kw else B)
+        s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_tailored_update_of_one_of_several_constraints(talos):
+    """Solve(q, c_id, Ai, bi) replaces ONE constraint of the active set (ik-id-description-optimized.hpp:178-218)"""
+    links = [talos.getJointId(n) for n in ("arm_left_7_joint", "arm_right_7_joint")]
+    B = 40
+    wl = multi_task_batch(talos, B, links, 12)
+    prm = dict(FIXTURE, num_eq_c=2, max_iter=300, tol_abs=1e-6, tol_rel=0.0, warm_start=True)
+    s = _gpu(talos, wl, prm)
+    refs = []
+    for b in range(0, B, 7):
+        r = ref.RefSolver(talos, **prm)
+        r.Solve(*problem_args(wl, b))
+        refs.append((b, r))
+    b2 = 0.7 * wl["bis"][:, 1]
+    s.Solve(wl["q"], links[1], wl["Ais"][1], b2)
+    z, it = s.get("z"), s.get("iter")
+    for b, r in refs:
+        r.Solve(wl["q"][b], links[1], wl["Ais"][1], b2[b])
+        assert it[b] == r.get_iter()
+        assert_close(z[b], r.z, 1e-8, "z b%d" % b)
+    s.close()
