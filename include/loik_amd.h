@@ -128,7 +128,14 @@ int loikb_solve_tailored(loikb_solver *s, const double *q, int c_id, const doubl
  *   loikb_solve_tailored(s, NULL, c_id, Ai, bi, flags):  q == NULL means "the resident q"                           */
 int loikb_integrate(loikb_solver *s, double dt);
 
-/* setters of IkIdSolverBaseTpl / the solver (task-solver-base.hpp:104-141, loik-loid-optimized.hpp:702-703) */
+/* setters of IkIdSolverBaseTpl / the solver (task-solver-base.hpp:104-141, loik-loid-optimized.hpp:702-703).
+ * Two deliberate differences from upstream, both flagged here because a drop-in must not surprise:
+ *  - loikb_set_mu sets the INITIAL penalty mu0 of the following solves.  Upstream's set_mu writes mu_ only
+ *    (task-solver-base.hpp:114), which ResetSolver() -- called by SolveInit and every Solve overload -- immediately
+ *    overwrites with mu0_ (task-solver-base.hpp:73-84): upstream's setter cannot influence a solve at all.
+ *  - loikb_set_tol(tol_abs, tol_rel) has no upstream counterpart (tol_abs_/tol_rel_ are constructor-only there;
+ *    set_tol_primal / set_tol_dual write values that CheckConvergence recomputes every iteration, hxx:544-552).
+ * set_tol_dual_inf is not exposed: dual infeasibility can never be flagged on this path.            */
 int loikb_set_max_iter(loikb_solver *s, int max_iter);
 int loikb_set_rho(loikb_solver *s, double rho);
 int loikb_set_mu(loikb_solver *s, double mu);
