@@ -571,3 +571,27 @@ def test_outer_loop_state_errors(talos):
     with pytest.raises(capi.LoikError):
         s.get("q")
     s.close()
+
+
+def test_setters_equal_constructor_arguments(talos):
+    """set_max_iter / set_rho / set_mu(0) / set_tol / set_tol_primal_inf / set_tol_tail_solve / set_warm_start
+    (task-solver-base.hpp:104-141, loik-loid-optimized.hpp:702-703): a solver re-parameterised through the setters
+    behaves like one constructed with those values (see include/loik_amd.h for the two documented differences)"""
+    link = talos.getJointId("arm_left_7_joint")
+    wl = feasible_batch(talos, 150, link, 77, nu_scale=0.5)
+    args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    new = dict(FIXTURE, max_iter=250, tol_abs=1e-5, tol_rel=1e-7, rho=3e-5, mu=5e-2, tol_primal_inf=5e-3, tol_tail_solve=5e-2)
+    a = loik_amd.BatchedLoik(talos, 150, **dict(FIXTURE, max_iter=20))
+    a.Solve(*args)  # state of an earlier solve with the old parameters must not leak (H cache, mu)
+    a.set_max_iter(new["max_iter"]); a.set_rho(new["rho"]); a.set_mu(new["mu"]); a.set_tol(new["tol_abs"], new["tol_rel"])
+    a.set_tol_primal_inf(new["tol_primal_inf"]); a.set_tol_tail_solve(new["tol_tail_solve"])
+    a.Solve(*args)
+    b = loik_amd.BatchedLoik(talos, 150, **new)
+    b.Solve(*args)
+    for name in ["iter", "converged", "primal_infeasible", "z", "nu", "w", "mu", "primal_residual", "dual_residual"]:
+        assert np.array_equal(a.get(name), b.get(name)), name
+    out = ref.solve_batch(talos, *args[:4], wl["Ais"], wl["bis"], wl["lb"], wl["ub"], nthreads=4, **new)
+    same = a.get("iter") == out["iters"]
+    assert same.mean() >= 0.97
+    assert np.max(np.abs(a.get("z") - out["z"])[same]) < 1e-8
+    a.close(); b.close()
