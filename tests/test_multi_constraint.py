@@ -119,3 +119,42 @@ def test_gpu_tailored_update_of_one_of_several_constraints(talos):
         assert it[b] == r.get_iter()
         assert_close(z[b], r.z, 1e-8, "z b%d" % b)
     s.close()
+
+
+def _no_constraint_problem(model, B, seed):
+    rng = np.random.default_rng(seed)
+    nv = model.nv
+    lb = rng.uniform(-0.5, 0.2, size=(B, nv))      # some boxes exclude 0: the answer is then on the boundary
+    ub = lb + rng.uniform(0.1, 0.6, size=(B, nv))
+    return dict(q=model.random_configurations(rng, B), H_ref=np.eye(6), v_ref=0.1 * rng.normal(size=6),
+                c_ids=np.zeros(0, dtype=np.int32), Ais=np.zeros((0, 6, 6)), bis=np.zeros((B, 0, 6)), lb=lb, ub=ub)
+
+
+def test_oracle_without_constraints(panda7):
+    """num_eq_c = 0 (empty active set): only the reference cost and the box remain"""
+    p = _no_constraint_problem(panda7, 3, 1)
+    prm = dict(FIXTURE, num_eq_c=0, max_iter=500, tol_abs=1e-8, tol_rel=0.0)
+    for b in range(3):
+        r = ref.RefSolver(panda7, **prm)
+        r.Solve(p["q"][b], p["H_ref"], p["v_ref"], p["c_ids"], p["Ais"], p["bis"][b], p["lb"][b], p["ub"][b])
+        assert r.get_convergence_status()
+        assert np.all(r.z >= p["lb"][b] - 1e-12) and np.all(r.z <= p["ub"][b] + 1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["panda7", "talos"])
+def test_gpu_without_constraints(which, request):
+    model = request.getfixturevalue(which)
+    B = 70
+    p = _no_constraint_problem(model, B, 2)
+    for max_iter, kw in [(4, {}), (400, {}), (400, dict(tail_max_instances=-1))]:
+        prm = dict(FIXTURE, num_eq_c=0, max_iter=max_iter, tol_abs=1e-7, tol_rel=0.0)
+        s = loik_amd.BatchedLoik(model, B, **prm, **kw)
+        s.Solve(p["q"], p["H_ref"], p["v_ref"], p["c_ids"], p["Ais"], p["bis"], p["lb"], p["ub"])
+        it, z, nu, conv = s.get("iter"), s.get("z"), s.get("nu"), s.get("converged")
+        for b in range(0, B, 6):
+            r = ref.RefSolver(model, **prm)
+            r.Solve(p["q"][b], p["H_ref"], p["v_ref"], p["c_ids"], p["Ais"], p["bis"][b], p["lb"][b], p["ub"][b])
+            assert it[b] == r.get_iter() and bool(conv[b]) == r.get_convergence_status()
+            assert_close(z[b], r.z, 1e-9, "z"); assert_close(nu[b], r.nu, 1e-9, "nu")
+        s.close()
