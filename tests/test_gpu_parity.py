@@ -71,13 +71,14 @@ def test_k_iterations_talos(talos, k, flags):
     s.close()
 
 
-@pytest.mark.parametrize("seed,nb", [(1, 6), (2, 17), (3, 40), (4, 63)])
+@pytest.mark.parametrize("seed,nb", [(1, 6), (2, 17), (3, 40), (4, 63), (5, 100)])
 def test_random_trees_all_joint_types(seed, nb):
     """unaligned revolute / prismatic axes, random placements, deep branch stacks, per-instance A and bounds"""
     model = random_tree(seed, nb)
     link = model.njoints - 1
     wl = feasible_batch(model, 70, link, seed + 40, nu_scale=0.5, per_instance_A=True, per_instance_bounds=True)
-    for k, tol in [(1, 1e-9), (4, 1e-9)]:
+    # 100 joints (more than a wavefront has lanes: no tail kernel): f_i sums up to 100 terms of size ~25
+    for k, tol in [(1, 1e-9), (4, 1e-9 if nb < 100 else 1e-8)]:
         prm = dict(FIXTURE, max_iter=k + 1, tol_abs=0.0, tol_rel=0.0, tol_primal_inf=0.0)
         s = gpu_solve(model, wl, prm)
         cache = fetch(s)
