@@ -19,14 +19,30 @@ abs-or-rel reproduces the reference's relational pin.  PARITY UNPINNED w.r.t. up
 import numpy as np
 
 J_RX, J_RY, J_RZ, J_PX, J_PY, J_PZ, J_RU, J_PU = 1, 2, 3, 4, 5, 6, 7, 8
+J_FREEFLYER, J_SPHERICAL, J_TRANSLATION = 9, 10, 11   # JointModelFreeFlyer / Spherical / Translation
 
 
 def skew(t):
     return np.array([[0.0, -t[2], t[1]], [t[2], 0.0, -t[0]], [-t[1], t[0], 0.0]])
 
 
+def quat_matrix(x, y, z, w):
+    """Eigen::Quaternion::toRotationMatrix"""
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
 def joint_transform(jtype, axis, q):
-    """JointModel::calc -> (R, t) of M(q)"""
+    """JointModel::calc -> (R, t) of M(q); q = the joint's own segment of the configuration"""
+    q = np.atleast_1d(np.asarray(q, dtype=float))
+    if jtype == J_FREEFLYER:
+        return quat_matrix(*q[3:7]), q[:3].copy()
+    if jtype == J_SPHERICAL:
+        return quat_matrix(*q[:4]), np.zeros(3)
+    if jtype == J_TRANSLATION:
+        return np.eye(3), q[:3].copy()
+    q = q[0]
     R = np.eye(3)
     t = np.zeros(3)
     c, s = np.cos(q), np.sin(q)
@@ -47,6 +63,17 @@ def joint_transform(jtype, axis, q):
 
 
 def joint_S(jtype, axis):
+    """motion subspace, 6 x nv_i"""
+    if jtype == J_FREEFLYER:
+        return np.eye(6)
+    if jtype == J_SPHERICAL:
+        return np.eye(6)[:, 3:]
+    if jtype == J_TRANSLATION:
+        return np.eye(6)[:, :3]
+    return joint_S1(jtype, axis).reshape(6, 1)
+
+
+def joint_S1(jtype, axis):
     S = np.zeros(6)
     if jtype in (J_PX, J_PY, J_PZ):
         S[jtype - J_PX] = 1.0
@@ -103,12 +130,15 @@ class DenseSolver:
         self.nc, self.m = num_eq_c, eq_c_dim
         self.warm_start, self.tol_tail_solve = warm_start, tol_tail_solve
         nj, nv = self.nj, self.nv
-        self.S = [joint_S(int(m.jtype[i]), m.axis[i]) for i in range(nj)]
+        self.S = [joint_S(int(m.jtype[i]), m.axis[i]) for i in range(nj)]      # 6 x nv_i
+        self.nvs = [0] + [self.S[i].shape[1] for i in range(1, nj)]
+        self.nqs = [0] + [{J_FREEFLYER: 7, J_SPHERICAL: 4, J_TRANSLATION: 3}.get(int(m.jtype[i]), 1) for i in range(1, nj)]
         self.nu = np.zeros(nv); self.w = np.zeros(nv); self.z = np.zeros(nv)
         self.vis = np.zeros((nj, 6)); self.vis_prev = np.zeros((nj, 6)); self.fis = np.zeros((nj, 6))
         self.yis = np.zeros((nj, 6))
         self.His = np.zeros((nj, 6, 6)); self.pis = np.zeros((nj, 6))
-        self.Ris = np.zeros(nj); self.ris = np.zeros(nj); self.Di_invs = np.zeros(nj)
+        self.Ris = [np.zeros(n) for n in self.nvs]; self.ris = [np.zeros(n) for n in self.nvs]
+        self.Di_invs = [np.zeros((n, n)) for n in self.nvs]
         self.Pis = np.zeros((nj, 6, 6))
         self.liMi = [(np.eye(3), np.zeros(3)) for _ in range(nj)]
         self.oMi = [(np.eye(3), np.zeros(3)) for _ in range(nj)]
@@ -150,7 +180,8 @@ class DenseSolver:
     def FwdPassInit(self, q):
         m = self.model
         for idx in range(1, self.nj):
-            Rj, tj = joint_transform(int(m.jtype[idx]), m.axis[idx], q[int(m.idx_q[idx])])
+            iq = int(m.idx_q[idx])
+            Rj, tj = joint_transform(int(m.jtype[idx]), m.axis[idx], q[iq:iq + self.nqs[idx]])
             P = np.asarray(m.placement[idx], dtype=float)
             Rp, tp = P[:9].reshape(3, 3), P[9:]
             R, t = Rp @ Rj, tp + Rp @ tj
@@ -180,7 +211,8 @@ class DenseSolver:
             r0 = (idx - 1) * 6
             self.P_qp[r0:r0 + 6, r0:r0 + 6] = H_ref
             self.q_qp[r0:r0 + 6] = -H_ref.T @ v_ref
-            self.A_qp[r0:r0 + 6, 6 * nb + int(mdl.idx_v[idx])] = self.S[idx]
+            iv = int(mdl.idx_v[idx])
+            self.A_qp[r0:r0 + 6, 6 * nb + iv:6 * nb + iv + self.nvs[idx]] = self.S[idx]
             parent = int(mdl.parents[idx])
             if parent > 0:
                 cp = (parent - 1) * 6
@@ -206,9 +238,9 @@ class DenseSolver:
     # ---- loik-loid.hxx:39-76 ---------------------------------------------------------------------
     def FwdPass1(self):
         for idx in range(1, self.nj):
-            iv = int(self.model.idx_v[idx])
-            self.Ris[idx] = self.mu_ineq
-            self.ris[idx] = self.w[iv] - self.mu_ineq * self.z[iv]
+            iv, n = int(self.model.idx_v[idx]), self.nvs[idx]
+            self.Ris[idx] = self.mu_ineq * np.ones(n)
+            self.ris[idx] = self.w[iv:iv + n] - self.mu_ineq * self.z[iv:iv + n]
             self.His[idx] = self.rho * np.eye(6) + self.H_ref
             self.pis[idx] = -self.rho * self.vis_prev[idx] - self.H_ref.T @ self.v_ref
         for c, c_id in enumerate(self.c_ids):
@@ -222,25 +254,25 @@ class DenseSolver:
             parent = int(self.model.parents[idx])
             R, t = self.liMi[idx]
             Hi, pi, Si = self.His[idx], self.pis[idx], self.S[idx]
-            Di = self.Ris[idx] + Si @ Hi @ Si
-            Dinv = 1.0 / Di
+            Di = np.diag(self.Ris[idx]) + Si.T @ Hi @ Si
+            Dinv = np.linalg.inv(Di)
             self.Di_invs[idx] = Dinv
-            Pi = np.eye(6) - np.outer(Hi @ Si, Si) * Dinv
+            Pi = np.eye(6) - Hi @ Si @ Dinv @ Si.T
             self.Pis[idx] = Pi
             Xd = dual_action_matrix(R, t)
             self.His[parent] = self.His[parent] + Xd @ (Pi @ Hi) @ action_matrix_inverse(R, t)
-            self.pis[parent] = self.pis[parent] + Xd @ (Pi @ pi - Hi @ Si * Dinv * self.ris[idx])
+            self.pis[parent] = self.pis[parent] + Xd @ (Pi @ pi - Hi @ Si @ Dinv @ self.ris[idx])
 
     # ---- loik-loid.hxx:120-151 -------------------------------------------------------------------
     def FwdPass2(self):
         for idx in range(1, self.nj):
             parent = int(self.model.parents[idx])
-            iv = int(self.model.idx_v[idx])
+            iv, n = int(self.model.idx_v[idx]), self.nvs[idx]
             R, t = self.liMi[idx]
             Hi, pi, Si = self.His[idx], self.pis[idx], self.S[idx]
             vi_parent = action_matrix_inverse(R, t) @ self.vis[parent]
-            self.nu[iv] = -self.Di_invs[idx] * (Si @ (Hi @ vi_parent + pi) + self.ris[idx])
-            self.vis[idx] = vi_parent + Si * self.nu[iv]
+            self.nu[iv:iv + n] = -self.Di_invs[idx] @ (Si.T @ (Hi @ vi_parent + pi) + self.ris[idx])
+            self.vis[idx] = vi_parent + Si @ self.nu[iv:iv + n]
             self.fis[idx] = Hi @ self.vis[idx] + pi
 
     # ---- loik-loid.hxx:158-164 -------------------------------------------------------------------

@@ -83,6 +83,28 @@ def test_multidof_solve_satisfies_the_task(case):
     assert np.all(z <= p["ub"] + 1e-9) and np.all(z >= p["lb"] - 1e-9)
 
 
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "seed%d" % c["seed"])
+def test_recursive_and_dense_oracles_agree_on_multidof_joints(case):
+    """the reference's relational pin (optimized == plain at 1e-10, tests/loik-loid.cpp:305-556) with nv_i x nv_i
+    joints: oracle/loik_ref.c (recursive, Cholesky Dinv) against oracle/dense.py (dense QP residuals, numpy inverse)"""
+    from oracle import dense
+    model = random_tree_multidof(**case)
+    p = one_problem(model, case["seed"] + 50)
+    prm = dict(FIXTURE, max_iter=8, tol_abs=0.0, tol_rel=0.0, tol_primal_inf=0.0)
+    opt, pl = ref.RefSolver(model, **prm), dense.DenseSolver(model, **prm)
+    args = (p["q"], p["H_ref"], p["v_ref"], p["c_ids"], p["Ais"], p["bis"], p["lb"], p["ub"])
+    opt.Solve(*args); pl.Solve(*args)
+    assert opt.get_iter() == pl.get_iter() == 7
+    for n in ("nu", "z", "w"):
+        assert_close(getattr(opt, n), getattr(pl, n), 1e-9, n)
+    assert_close(opt.vis[1:], pl.vis[1:], 1e-9, "vis")
+    assert_close(opt.fis[1:], pl.fis[1:], 1e-8, "fis")
+    assert_close(opt.His[1:], pl.His[1:], 1e-8, "His")
+    assert_close(opt.scalar("primal_residual"), pl.primal_residual, 1e-9, "primal")
+    assert_close(opt.scalar("dual_residual"), pl.dual_residual, 1e-8, "dual")
+    assert_close(opt.dual_residual_vec, pl.dual_residual_vec, 1e-8, "dual vec")
+
+
 @pytest.mark.parametrize("case", CASES[:3], ids=lambda c: "seed%d" % c["seed"])
 def test_multidof_oracle_answer_is_the_qp_optimum(case):
     """pins the oracle's nv x nv joints themselves: the converged answer is the optimum of the reduced dense QP

@@ -78,7 +78,7 @@ def test_component_wise(modelname, request):
         assert dense_abs_or_rel_equal(opt.pis[idx], pl.pis[idx])
         assert dense_abs_or_rel_equal(opt.pis_aba[idx], opt.pis[idx])
     for idx in range(1, model.njoints):
-        assert scalar_abs_or_rel_equal(opt.r[model.idx_v[idx]], pl.ris[idx])
+        assert scalar_abs_or_rel_equal(opt.r[model.idx_v[idx]], pl.ris[idx][0])
     # bwd pass
     pl.BwdPass(); opt.BwdPass()
     for idx in range(1, model.njoints):
