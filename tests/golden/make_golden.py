@@ -16,7 +16,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 
 import loik_amd  # noqa: E402
-from helpers import FIXTURE, feasible_batch, fixture_problem, problem_args, random_tree  # noqa: E402
+from helpers import (FIXTURE, feasible_batch, fixture_problem, multi_task_batch, problem_args, random_tree,  # noqa: E402
+                     random_tree_multidof)
+from loik_amd import workloads  # noqa: E402
 from oracle import ref  # noqa: E402
 
 STATE = ["nu", "z", "w", "vis", "fis", "g", "yis", "Aty", "His", "pis", "UDinv", "Dinv", "Stf_plus_w", "liMi"]
@@ -64,6 +66,23 @@ def main():
     wl = dict(fx, q=fx["q"][None], bis=fx["bis"][None])
     np.savez_compressed(os.path.join(HERE, "talos32_reference_fixture.npz"),
                         **case(talos, wl, 1, dict(FIXTURE, max_iter=200)))
+    # multi-DoF joints: floating-base Talos (free-flyer root_joint) and a random tree with a free-flyer root, a
+    # spherical and a translation joint (the oracle's nv x nv joints; the device solves chains of 1-DoF joints)
+    tff = loik_amd.builtin_model("talos32_freeflyer")
+    link = tff.getJointId("arm_left_7_joint")
+    np.savez_compressed(os.path.join(HERE, "talos32_freeflyer_leftwrist.npz"),
+                        **case(tff, workloads.make_workload(tff, 2, link, 24, bound=0.5, snap_prob=0.0, nu_scale=0.4), 2, prm))
+    md = random_tree_multidof(seed=5, nb=9, root_freeflyer=True, n_spherical=1, n_translation=1)
+    np.savez_compressed(os.path.join(HERE, "random_multidof9.npz"),
+                        **case(md, workloads.make_workload(md, 2, md.njoints - 1, 25, bound=0.5, snap_prob=0.2, nu_scale=0.4), 2, prm))
+    # two simultaneous tasks (both wrists), full symmetric H_ref, non-zero v_ref
+    links = [talos.getJointId("arm_left_7_joint"), talos.getJointId("arm_right_7_joint")]
+    wl2 = multi_task_batch(talos, 2, links, 26)
+    rng = np.random.default_rng(27)
+    M = rng.normal(size=(6, 6))
+    wl2["H_ref"], wl2["v_ref"] = M @ M.T / 6 + 0.5 * np.eye(6), 0.2 * rng.normal(size=6)
+    np.savez_compressed(os.path.join(HERE, "talos32_two_wrists_full_href.npz"),
+                        **case(talos, wl2, 2, dict(prm, num_eq_c=2)))
 
 
 if __name__ == "__main__":
