@@ -1654,4 +1654,13 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   return LOIKB_OK;
 }
 
+#ifdef LOIKB_TAIL_PROF
+// diagnostic build only: cycles per phase of wavefront 0 of the last tail launch + its iteration count
+int loikb_debug_tail_prof(unsigned long long* out)
+{
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(loikb::g_tail_prof), sizeof(unsigned long long) * 10));
+  return LOIKB_OK;
+}
+#endif
+
 }  // extern "C"

@@ -71,6 +71,14 @@ __host__ __device__ __forceinline__ size_t tail_lds_bytes(int nc, int G)
   return ((((size_t)XROWS * XS + 2 * (size_t)WAVE * HS + (size_t)(WAVE / G) * nc * CD) * sizeof(T)) + 15) & ~(size_t)15;
 }
 
+// Phase timeline of one wavefront (diagnostic build only: -DLOIKB_TAIL_PROF, scripts/tail_phase_profile.py)
+#ifdef LOIKB_TAIL_PROF
+__device__ unsigned long long g_tail_prof[10];
+#define TAIL_TP(k) { const unsigned long long tn_ = clock64(); prof_[k] += tn_ - tprev_; tprev_ = tn_; }
+#else
+#define TAIL_TP(k)
+#endif
+
 template <typename T, bool HDIAG>
 __global__ void __launch_bounds__(WAVE * TAIL_WAVES)
 k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
@@ -277,6 +285,9 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   // the loops below stay in wavefront-uniform control flow (LDS exchanges inside); a group without work only masks its
   // updates with `act`
   load_instance(fetch());
+#ifdef LOIKB_TAIL_PROF
+  unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
+#endif
   while (__any(!done || has_inst)) {  // (done && has_inst: an instance that was already finished when it was fetched)
     const bool act = !done;
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
@@ -323,6 +334,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     // level -- a joint of height h is final after h levels and simply recomputes the same value afterwards -- so the
     // body is branch-free and select-free, all lanes active, no per-level bookkeeping of who is "at" the level.
     const bool lean = !__any(need_h) && maxchild <= NCH_REG;
+    TAIL_TP(0)
     if (lean) {
       T pl[6], rl = T(0);
 #pragma unroll
@@ -415,6 +427,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       tail_sync();
     }
     if (need_h) mu_h = mu;
+    TAIL_TP(1)
 
     // ================= root -> leaf: FwdPass2 + BoxProj + DualUpdate (hxx:102-163, :384-461) ==================
     // Only nu_i / v_i form a recursion over the tree: the level loop carries just that.  Everything else of the pass
@@ -440,6 +453,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       for (int k = 0; k < 6; ++k) xch[lane * XS + XC + k] = vi[k];
       tail_sync();
     }
+    TAIL_TP(2)
     T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_dyis = T(0),
       l_av = T(0), l_prt = T(0), l_prs = T(0), l_up = T(0), l_lm = T(0);
     if (act && isj) {
@@ -472,6 +486,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
       for (int k = 0; k < 6; ++k) { v[k] = vi[k]; f[k] = fi[k]; }
     }
+    TAIL_TP(3)
     // DualUpdate of the task constraints (hxx:410-451), spread over six lanes of the group: lane k < 6 owns row k of
     // A v_c - b and of A^T y (the constrained joint's own lane used to do all 72 multiply-adds, i.e. the whole
     // wavefront paid for them).  v_c is still in the joint's exchange row from the forward recursion.
@@ -505,6 +520,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       tail_sync();
     }
 
+    TAIL_TP(4)
     // ================= BwdPass2 + dual residual (hxx:185-241, :468-487) =========================================
     // g_i = Aty_c + sum_children act(f_j) - f_i needs the children's f only (no recursion): one exchange, no levels.
     T l_dg = T(0), l_g = T(0), l_dualv = T(0), l_stf = T(0), l_dstf = T(0);
@@ -524,13 +540,24 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
         for (int k = 0; k < 6; ++k) gi[k] = T(0);
       }
-      for (int c = 0; c < maxchild; ++c) {
-        if (c < tp.nchild) {
-          const int crow = c == 0 ? chl[0] : c == 1 ? chl[1] : c == 2 ? chl[2] : c == 3 ? chl[3]
-                                                                   : gbase + child_list[tp.child_start + c];
-          const T* x = xch + crow * XS;
+      if (maxchild <= NCH_REG) {  // uniform; missing children read the zero row: no branch, no select
 #pragma unroll
-          for (int k = 0; k < 6; ++k) gi[k] += x[k];
+        for (int c = 0; c < NCH_REG; ++c) {
+          if (c < maxchild) {
+            const T* x = xch + chl[c] * XS;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) gi[k] += x[k];
+          }
+        }
+      } else {
+        for (int c = 0; c < maxchild; ++c) {
+          if (c < tp.nchild) {
+            const int crow = c == 0 ? chl[0] : c == 1 ? chl[1] : c == 2 ? chl[2] : c == 3 ? chl[3]
+                                                                     : gbase + child_list[tp.child_start + c];
+            const T* x = xch + crow * XS;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) gi[k] += x[k];
+          }
         }
       }
       T dg[6], dvr[6];
@@ -554,6 +581,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     }
     tail_sync();
 
+    TAIL_TP(5)
     // ================= lane-group reductions of the running norms, then the scalar epilogue ======================
     // Through LDS: every lane deposits its NRED scalars in its exchange row, lane q of a group folds scalar q over the
     // group's rows (max for the inf-norms, sum for the two dot products) and publishes it in column XS-1 of row q.
@@ -566,12 +594,20 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     }
     tail_sync();
     for (int q = jlane; q < NRED; q += G) {
+      // eight rows per trip (G is 8, 16, 32 or 64): the LDS reads of a trip are in flight together instead of one
+      // read-wait-fold round trip per row; the sums keep the joint order of upstream's dot products (hxx:587-590)
       const T* col = xch + gbase * XS + q;
       T red = T(0);
-      if (q < NRMAX) {
-        for (int l = 0; l < G; ++l) red = tmax(red, col[l * XS]);
-      } else {
-        for (int l = 0; l < G; ++l) red += col[l * XS];
+      for (int l = 0; l < G; l += 8) {
+        T a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = col[(l + u) * XS];
+        if (q < NRMAX) {
+          red = tmax(red, tmax(tmax(tmax(a[0], a[1]), tmax(a[2], a[3])), tmax(tmax(a[4], a[5]), tmax(a[6], a[7]))));
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) red += a[u];
+        }
       }
       xch[(gbase + q % G) * XS + (XS - 1) - q / G] = red;
     }
@@ -580,6 +616,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
     for (int q = 0; q < NRED; ++q) rr[q] = xch[(gbase + q % G) * XS + (XS - 1) - q / G];
     tail_sync();
+    TAIL_TP(6)
     const T r_prt = rr[0], r_prs = rr[1], r_dualv = rr[2], r_stf = rr[3], r_dvis = rr[4], r_dnu = rr[5], r_dz = rr[6],
             r_dfis = rr[7], r_dyis = rr[8], r_dw = rr[9], r_av = rr[10], r_nu = rr[11], r_hrefv = rr[12], r_g = rr[13],
             r_dg = rr[14], r_dstf = rr[15], r_up = rr[16], r_lm = rr[17];
@@ -632,7 +669,14 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       store_instance();
       load_instance(fetch());
     }
+    TAIL_TP(7)
   }
+#ifdef LOIKB_TAIL_PROF
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int k = 0; k < 8; ++k) g_tail_prof[k] = prof_[k];
+    g_tail_prof[8] = n_wave_iters;
+  }
+#endif
   // instances that were already finished when they were fetched (nothing to store), diagnostics
   if (lane == 0) {
     atomicAdd(&Bf.counters[5], n_wave_iters);
