@@ -79,6 +79,34 @@ __device__ unsigned long long g_tail_prof[10];
 #define TAIL_TP(k)
 #endif
 
+// acc[0..6) += the 6-vectors at column `off` of the exchange rows chl[0..NCH): all LDS reads are issued before the
+// first add (a per-child "if" makes the compiler wait for each child's rows in turn -- three LDS round trips per tree
+// level on a humanoid); the adds keep the child order.  A missing child is the zero row.
+template <typename T, int NCH>
+__device__ __forceinline__ void gather_rows(const T* xch, const int* chl, int off, T* acc)
+{
+  T x[NCH][6];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x[c][k] = xch[chl[c] * XS + off + k];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] += x[c][k];
+}
+template <typename T>
+__device__ __forceinline__ void gather_rows_n(int n, const T* xch, const int* chl, int off, T* acc)
+{
+  switch (n) {  // uniform
+  case 0: break;
+  case 1: gather_rows<T, 1>(xch, chl, off, acc); break;
+  case 2: gather_rows<T, 2>(xch, chl, off, acc); break;
+  case 3: gather_rows<T, 3>(xch, chl, off, acc); break;
+  default: gather_rows<T, 4>(xch, chl, off, acc); break;
+  }
+}
+
 template <typename T, bool HDIAG>
 __global__ void __launch_bounds__(WAVE * TAIL_WAVES)
 k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
@@ -342,14 +370,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       for (int lev = maxdepth; lev >= 1; --lev) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) pl[k] = p[k];  // p still holds p^base
-#pragma unroll
-        for (int c = 0; c < NCH_REG; ++c) {
-          if (c < maxchild) {  // uniform
-            const T* x = xch + chl[c] * XS + XC;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) pl[k] += x[k];
-          }
-        }
+        gather_rows_n<T>(maxchild, xch, chl, XC, pl);
         T Stp = Sv[0] * pl[0];
 #pragma unroll
         for (int k = 1; k < 6; ++k) Stp += Sv[k] * pl[k];
@@ -541,14 +562,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         for (int k = 0; k < 6; ++k) gi[k] = T(0);
       }
       if (maxchild <= NCH_REG) {  // uniform; missing children read the zero row: no branch, no select
-#pragma unroll
-        for (int c = 0; c < NCH_REG; ++c) {
-          if (c < maxchild) {
-            const T* x = xch + chl[c] * XS;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) gi[k] += x[k];
-          }
-        }
+        gather_rows_n<T>(maxchild, xch, chl, 0, gi);
       } else {
         for (int c = 0; c < maxchild; ++c) {
           if (c < tp.nchild) {
