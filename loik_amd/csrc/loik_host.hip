@@ -911,7 +911,7 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
   const bool use_tail = can_compact && S->nb <= WAVE && S->opt.tail_max_instances >= 0;
   // (thresholds are stated for the whole batch: a chunk applies its share)
   const double share = (double)C->B / (double)S->B;
-  const int tail_max = std::max(1, (int)((S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : 8192) * share));
+  const int tail_max = std::max(1, (int)((S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : 32768) * share));
   const bool trace = getenv("LOIKB_TRACE") != nullptr;
   // a team of wavefronts per tile walks independent chains of the tree concurrently: a sweep costs the tree's
   // critical path instead of nb joint visits, and four wavefronts keep four times the loads of a tile in flight.
