@@ -13,12 +13,15 @@ below 1e-6 (`get_convergence_status()`); instances that trip the reference's inf
 max_iter are executed and timed but not counted.  The batch shards over GPUs with no exchange step (instances are
 independent): every rank solves its own 65536 instances, no collective on the data path ("scaling": "weak").
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (`k_solve`, the team kernel that advances one
-instance per lane through HBM-resident tiles) against HBM bandwidth with the ALGORITHMIC byte model of SURVEY.md 8(d):
-bytes per ADMM instance-iteration = sizeof(scalar)*(203 nb + 108 nc), times the instance-iterations k_solve executed,
-over k_solve's launch time -- HIP events recorded by the library on the stream the kernels are launched on.  The
-stragglers' iterations run in `k_tail` (whole instance state in registers/LDS, no HBM traffic per iteration); they are
-reported beside it (`tail`) and are NOT credited to the HBM roofline.
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel -- the one that ran most of the ADMM
+instance-iterations of the timed steps -- against HBM bandwidth with the ALGORITHMIC byte model of SURVEY.md 8(d):
+bytes per ADMM instance-iteration = sizeof(scalar)*(203 nb + 108 nc), times the instance-iterations the kernel executed,
+over the time during which at least one of its launches was executing (HIP events recorded by the library on the
+streams the kernels are launched on).  Two kernels share a solve: `k_solve` advances one instance per lane through
+HBM-resident tiles for the first iterations of the whole batch (HBM-bound), `k_tail` takes over once at most 32768
+instances are still iterating and keeps each instance's whole state in registers/LDS until it stops (its HBM traffic
+is one load and one store per instance, reported as `traffic`; the streaming model's roofline does not bind it, a
+`frac` above 1 says exactly that).  The other kernel is reported beside the dominant one (`other_kernel`).
 `cpu_baseline` times the CPU oracle (a line-faithful port of the reference solver, NOT upstream libloik) on a
 bounded sample of the same workload on all host cores.
 """
@@ -172,26 +175,54 @@ def main():
 
     if rank == 0:
         bytes_iter = st["bytes_per_instance_iteration"]
-        # HBM bytes from the PMC counters: collected by scripts/pmc_traffic.sh (rocprofv3 cannot run inside this
-        # process); the committed summary is used when it describes this workload
-        traffic_per_launch, traffic_note = None, "no PMC summary found (run scripts/pmc_traffic.sh on the GPU box)"
+        # per kernel: algorithmic bytes (SURVEY.md 8(d) per-unit figure x instance-iterations it ran) over the time during
+        # which at least one of its launches was executing (HIP events on the launch streams; the batch may be solved
+        # as concurrent chunks, so launches of one kernel overlap) -- and the HBM bytes the PMC counters saw
+        # (scripts/pmc_traffic.sh; rocprofv3 cannot run inside this process, the committed summary is used when it
+        # describes this workload)
+        pmc = None
         tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tj) and B == 65536:
             try:
-                tjd = json.load(open(tj))
-                kb = tjd.get("k_solve_hbm_bytes_per_step", tjd["hbm_bytes_per_step"])
-                traffic_per_launch = kb / max((launches - tail_launches) / args.steps, 1)
-                traffic_note = "profiles/traffic_latest.json: %.3g HBM bytes of k_solve per Solve() step / %.0f launches" % (
-                    kb, (launches - tail_launches) / args.steps)
-            except Exception as e:
-                traffic_note = "unreadable PMC summary: %r" % (e,)
+                pmc = json.load(open(tj))["kernels"]
+            except Exception:
+                pmc = None
+
+        def kernel_entry(key, name, iters, launches_k, sum_ms, busy_ms, extra):
+            ach = iters * bytes_iter / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0
+            traffic, note = None, "no PMC summary for this workload (run scripts/pmc_traffic.sh on the GPU box)"
+            if pmc and key in pmc and launches_k > 0:
+                kb = pmc[key]["fetch_bytes_per_step"] + pmc[key]["write_bytes_per_step"]
+                traffic = kb / max(launches_k / args.steps, 1)
+                note = "profiles/traffic_latest.json: %.3g HBM bytes of %s per Solve() step (%.0f launches there, %.0f here)" % (
+                    kb, key, pmc[key]["dispatches_per_step"], launches_k / args.steps)
+            e = {"kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                 "traffic": traffic, "traffic_note": note,
+                 "units_per_launch": iters / max(launches_k, 1), "avg_launch_ms": sum_ms / max(launches_k, 1),
+                 "launches_per_step": launches_k / args.steps, "sum_of_launch_ms_per_step": sum_ms / args.steps,
+                 "busy_ms_per_step": busy_ms / args.steps,
+                 "launch_concurrency": sum_ms / busy_ms if busy_ms > 0 else None,
+                 "share_of_instance_iterations": iters / max(inst_iters, 1),
+                 "instance_iterations_per_s": iters / (busy_ms * 1e-3) if busy_ms > 0 else None}
+            e.update(extra)
+            return e
+
         solve_ms = kernel_ms - tail_ms
         solve_iters = inst_iters - tail_iters
         solve_launches = launches - tail_launches
-        # the batch may be solved as concurrent chunks (own stream each): launches of the kernel then overlap, and the
-        # kernel's bandwidth is its bytes over the time during which at least one of its launches was executing
-        # (`solve_busy_ms`, from the same HIP events; identical to the sum of the launch times for a single chunk)
-        achieved = solve_iters * bytes_iter / (solve_busy_ms * 1e-3) / 1e9 if solve_busy_ms > 0 else 0.0
+        k_solve = kernel_entry(
+            "k_solve", "k_solve<double, team of %d wavefronts per 64-instance tile>" % st["team"], solve_iters,
+            solve_launches, solve_ms, solve_busy_ms,
+            {"regime": "one instance per lane, state streamed through HBM every iteration: HBM-bound in bulk"})
+        k_tail = kernel_entry(
+            "k_tail", "k_tail<double> (a 32-lane group per instance, one joint per lane, state in registers/LDS)",
+            tail_iters, tail_launches, tail_ms, tail_busy_ms,
+            {"regime": "the state of an instance stays on chip for its whole solve: the kernel's HBM traffic is one load "
+                       "and one store per instance (`traffic`), so the streaming byte model's roofline does not bind it; "
+                       "what does is fp64 VALU issue and LDS round trips along the tree levels "
+                       "(scripts/tail_phase_profile.py: ~21.5 k cycles per ADMM iteration of a wavefront = 2 instances)",
+             "instances_per_step": tail_inst / args.steps})
+        dominant, other = (k_tail, k_solve) if tail_iters >= solve_iters else (k_solve, k_tail)
         line = {
             "metric": "IK solves/sec to 1e-6 residual, Talos humanoid, batch=65536 per GPU",
             "value": total_solved * args.steps / elapsed,
@@ -219,44 +250,23 @@ def main():
                 "instance_iterations_per_s": total_iters * args.steps / elapsed,
                 "solve_init_s_rank0_incl_pcie": t_init,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_solve<double, team of %d wavefronts per 64-instance tile>" % st["team"],
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic_per_launch,
-                "traffic_note": traffic_note,
-                "bytes_per_unit": bytes_iter,
-                "unit_def": "one ADMM iteration of one instance: 8 B x (203 nb + 108 nc), nb=32, nc=1",
-                "units_per_launch": solve_iters / max(solve_launches, 1),
-                "avg_launch_ms": solve_ms / max(solve_launches, 1),
-                "launches_per_step": solve_launches / args.steps,
-                "sum_of_launch_ms_per_step": solve_ms / args.steps,
-                "busy_ms_per_step": solve_busy_ms / args.steps,
-                "launch_concurrency": solve_ms / solve_busy_ms if solve_busy_ms > 0 else None,
-                "achieved_def": "algorithmic bytes of all k_solve launches / time with >= 1 k_solve launch executing "
-                                "(= bytes per launch / average launch duration x launch_concurrency)",
-                "share_of_instance_iterations": solve_iters / max(inst_iters, 1),
-                "tail": {
-                    "kernel": "k_tail<double> (a 32-lane group per instance, one joint per lane, state in registers/LDS)",
-                    "bound": "latency/issue (no HBM traffic per iteration)",
-                    "instances_per_step": tail_inst / args.steps,
-                    "instance_iterations_per_step": tail_iters / args.steps,
-                    "launches_per_step": tail_launches / args.steps,
-                    "sum_of_launch_ms_per_step": tail_ms / args.steps,
-                    "busy_ms_per_step": tail_busy_ms / args.steps,
-                    "instance_iterations_per_s": tail_iters / (tail_busy_ms * 1e-3) if tail_busy_ms > 0 else None,
-                },
-                "concurrent_chunks": st["chunks"],
-                "concurrency_note": "the batch is solved as %d independent chunk(s), each on its own stream; "
-                                    "avg_launch_ms is per launch as timed by HIP events (launches of the two chunks "
-                                    "overlap and slow each other down), `aggregate` is all kernels' algorithmic bytes "
-                                    "against the stream wall time of the whole Solve()" % st["chunks"],
-                "aggregate_algorithmic_GBps": inst_iters * bytes_iter / (solve_wall_ms * 1e-3) / 1e9 if solve_wall_ms > 0 else None,
-                "aggregate_frac_of_peak": inst_iters * bytes_iter / (solve_wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if solve_wall_ms > 0 else None,
-            },
+            "roofline": dict(
+                {"bound": "hbm",
+                 "bytes_per_unit": bytes_iter,
+                 "unit_def": "one ADMM iteration of one instance: 8 B x (203 nb + 108 nc), nb=32, nc=1 (the three-sweep "
+                             "streaming model of SURVEY.md 8(d))",
+                 "achieved_def": "algorithmic bytes of all launches of the kernel / time with >= 1 of its launches "
+                                 "executing (= bytes per launch / average launch duration x launch_concurrency); "
+                                 "frac > 1 means the kernel does not move the model's bytes: it keeps state on chip"},
+                **dominant,
+                **{"other_kernel": other,
+                   "concurrent_chunks": st["chunks"],
+                   "concurrency_note": "the batch is solved as %d independent chunk(s), each on its own stream; "
+                                       "avg_launch_ms is per launch as timed by HIP events (launches of the chunks "
+                                       "overlap and slow each other down), `aggregate` is all kernels' algorithmic bytes "
+                                       "against the stream wall time of the whole Solve()" % st["chunks"],
+                   "aggregate_algorithmic_GBps": inst_iters * bytes_iter / (solve_wall_ms * 1e-3) / 1e9 if solve_wall_ms > 0 else None,
+                   "aggregate_frac_of_peak": inst_iters * bytes_iter / (solve_wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if solve_wall_ms > 0 else None}),
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

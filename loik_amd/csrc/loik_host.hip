@@ -838,6 +838,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
   while (G < S->nb) G <<= 1;
   const int ipw = WAVE / G;
   int tw = TAIL_WAVES;  // wavefronts per workgroup
+  if (const char* e = getenv("LOIKB_TAIL_WAVES")) tw = std::max(1, std::min(TAIL_WAVES, atoi(e)));
   while (tw > 1 && tw * tail_lds_bytes<T>(S->nc, G) > 160 * 1024) --tw;
   const size_t lds = tw * tail_lds_bytes<T>(S->nc, G);
   if (lds > 160 * 1024) { g_last_error = "tail kernel: constraint data exceeds the LDS of a CU"; return LOIKB_ERR_ARG; }
@@ -847,7 +848,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
   }
   // ONE launch: as many workgroups as the chunk's share of the CUs holds (one wavefront per SIMD: register budget);
   // the lane groups pull the listed instances from an atomic queue head until the list is empty.
-  const int cu_share = std::max(1, (int)(S->ncu * ((double)C->B / (double)S->B) + 0.5));
+  const int cu_share = std::max(1, (int)(S->ncu * (TAIL_WAVES / tw) * ((double)C->B / (double)S->B) + 0.5));
   const int n = n_live;
   double total_ms = 0.0;
   unsigned long long iters = 0;

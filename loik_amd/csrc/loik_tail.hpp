@@ -82,6 +82,16 @@ __device__ unsigned long long g_tail_prof[10];
 // acc[0..6) += the 6-vectors at column `off` of the exchange rows chl[0..NCH): all LDS reads are issued before the
 // first add (a per-child "if" makes the compiler wait for each child's rows in turn -- three LDS round trips per tree
 // level on a humanoid); the adds keep the child order.  A missing child is the zero row.
+// a . b over a 6-vector as the sum of its linear and angular halves: two independent chains of three multiply-adds
+// instead of one of six (a wavefront runs alone on its SIMD in this kernel: the dependent fp64 latency is exposed)
+template <typename T>
+__device__ __forceinline__ T dot6_halves(const T* a, const T* b)
+{
+  const T lin = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  const T ang = a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+  return lin + ang;
+}
+
 template <typename T, int NCH>
 __device__ __forceinline__ void gather_rows(const T* xch, const int* chl, int off, T* acc)
 {
@@ -156,7 +166,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   char *ip = Bf.tiles, *rec = Bf.tiles, *srec = Bf.tiles;
   T R[9], t[3], v[6], f[6], g[6], UD[6], UDo[6], p[6];
   T w = T(0), z = T(0), nu = T(0), s = T(0), r = T(0), dinv = T(0), lbi = T(0), ubi = T(0);
-  T mu = T(1), tg_in = T(-1), mu_h = T(-1), mu_o = T(-1), bnorm = T(0), st_y = T(0);
+  T mu = T(1), tg_in = T(-1), mu_h = T(-1), mu_o = T(-1), mu_v = T(-1), bnorm = T(0), st_y = T(0);
   int kexp = 0, hsl = 0, iter = 0, status = ST_DONE, tail_iter = 0, c1 = 0, c2 = 0, nflip = 0;
   T tol_p = T(0), tol_d = T(0), dyqp = T(0), atdy = T(0), ubp = T(0), lbm = T(0);
   unsigned int my_iters = 0;
@@ -236,6 +246,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     tg_in = ldp<T>(srec, SP_TAG).x;
     nflip = (int)ldp<T>(srec, SP_FLIP).x;
     mu_h = T(-1); mu_o = T(-1);  // mu of the current / the other H slot: nothing cached yet
+    mu_v = T(-1);                // mu of the victim slot (third level of the cache, see the main loop)
     hsl = 0;                     // current H slot
     // (H_i is not kept in HBM -- k_solve gets f_i from the force-balance recursion -- so the first iteration on an
     //  instance rebuilds its H cache; this kernel keeps f_i = H_i v_i + p_i: H_i sits in LDS anyway and the extra
@@ -329,10 +340,53 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
       for (int k = 0; k < 6; ++k) { const T tmp = UD[k]; UD[k] = UDo[k]; UDo[k] = tmp; }
     }
+    T* hcur = hst + ((size_t)hsl * WAVE + lane) * HS;
+    // ---- third level of the H cache: a victim slot in HBM.  Most long runners alternate between two decades of mu
+    // (both LDS slots hit), but some cycle through three (k, k+1, k+2, k+1, k ...): with two slots every other move
+    // is a rebuild -- a masked level loop with the H recursion, several times the cost of a plain iteration, paid by
+    // both instances of the wavefront -- and exactly these instances run to max_iter and decide when the launch ends.
+    // The joint's record in the tile is scratch while the instance lives in this kernel (store_instance rewrites
+    // pairs JP_V .. JP_P): the slot that a rebuild would overwrite is parked there, and fetched back on a hit.
+    if (act && (P.mode & MODE_CACHE_H) && mu_h != mu) {
+      constexpr int VP = JP_V;  // 14 pairs: H (21) + Dinv, UDinv (6)
+      static_assert(JP_P + 3 - JP_V == 14 && JP_F == JP_V + 3 && JP_G == JP_F + 3 && JP_WZ == JP_G + 3 && JP_NUS == JP_WZ + 1 &&
+                    JP_P == JP_NUS + 1, "victim slot: pairs JP_V .. JP_P + 2 must be contiguous");
+      if (mu_v == mu) {
+        // hit: exchange the current slot with the victim, seven pairs at a time (loads before the stores they alias)
+        if (isj) {
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            typename Vec2<T>::type in[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) in[k] = ldp<T>(rec, VP + 7 * half + k);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+              const int e = 14 * half + 2 * k;  // entries e, e+1 of (H[0..21], UD[0..5])
+              const T o0 = e < 22 ? hcur[e] : UD[e - 22], o1 = e + 1 < 22 ? hcur[e + 1] : UD[e + 1 - 22];
+              stp<T>(rec, VP + 7 * half + k, o0, o1);
+              if (e < 22) hcur[e] = in[k].x; else UD[e - 22] = in[k].x;
+              if (e + 1 < 22) hcur[e + 1] = in[k].y; else UD[e + 1 - 22] = in[k].y;
+            }
+          }
+          dinv = hcur[21];
+        }
+        { const T tmp = mu_h; mu_h = mu_v; mu_v = tmp; }
+      } else if (mu_h >= T(0)) {
+        // miss with a valid slot about to be overwritten: park it
+        if (isj) {
+#pragma unroll
+          for (int k = 0; k < 14; ++k) {
+            const int e = 2 * k;
+            const T o0 = e < 22 ? hcur[e] : UD[e - 22], o1 = e + 1 < 22 ? hcur[e + 1] : UD[e + 1 - 22];
+            stp<T>(rec, VP + k, o0, o1);
+          }
+        }
+        mu_v = mu_h;
+      }
+    }
     const bool need_h = act && (!(P.mode & MODE_CACHE_H) || (mu_h != mu));
     ++n_wave_iters;
     n_h_iters += __any(need_h) ? 1u : 0u;
-    T* hcur = hst + ((size_t)hsl * WAVE + lane) * HS;
 
     // ================= leaf -> root: FwdPass1 + BwdPass (hxx:290-338, :31-81) =================================
     T hh[22];
@@ -371,9 +425,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
         for (int k = 0; k < 6; ++k) pl[k] = p[k];  // p still holds p^base
         gather_rows_n<T>(maxchild, xch, chl, XC, pl);
-        T Stp = Sv[0] * pl[0];
-#pragma unroll
-        for (int k = 1; k < 6; ++k) Stp += Sv[k] * pl[k];
+        const T Stp = dot6_halves(Sv, pl);
         rl = (w - mu_in * z) + Stp;
         T pa[6], pc[6];
 #pragma unroll
@@ -463,9 +515,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
       for (int k = 0; k < 6; ++k) vpar[k] = xch[prow * XS + XC + k];
       actinv_motion(R, t, vpar, vp);  // hxx:125
-      T udv = UD[0] * vp[0];
-#pragma unroll
-      for (int k = 1; k < 6; ++k) udv += UD[k] * vp[k];
+      const T udv = dot6_halves(UD, vp);
       nui = -udv - dinv * r;          // hxx:127
 #pragma unroll
       for (int k = 0; k < 6; ++k) vi[k] = vp[k] + Sv[k] * nui;  // hxx:133-134

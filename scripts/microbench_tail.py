@@ -6,7 +6,7 @@ import loik_amd
 from loik_amd import capi, workloads
 iters = 200
 for B in [int(x) for x in sys.argv[1:]] or [64, 1024, 2048, 4096, 8192, 16384]:
-    wl = workloads.talos_c3(B, seed=5)
+    wl = workloads.talos_c3(B, seed=int(os.environ.get("MB_SEED", "5")))
     prm = dict(wl["params"], max_iter=iters + 1, tol_abs=0.0, tol_rel=0.0, tol_primal_inf=0.0)
     s = loik_amd.BatchedLoik(wl["model"], B, max_launch_iters=1, tail_max_instances=1 << 24, **prm)
     s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
