@@ -14,6 +14,7 @@
 // 64 t + l); sets 1 and 2 are half-size work sets used by lane compaction.
 #include "loik_device.hpp"
 #include "loik_tail.hpp"
+#include "loik_lean.hpp"
 
 #include "../../include/loik_amd.h"
 
@@ -121,6 +122,9 @@ struct loikb_solver_impl {
     unsigned int* d_counters = nullptr;
     unsigned int* h_counters = nullptr;  // pinned
     int* d_slots = nullptr;              // list of the live instances handed to the tail kernel
+    int* d_slots2 = nullptr;             // instances that left the lean kernel unfinished (same capacity)
+    void* d_hslots = nullptr;            // decade slots of the lean tail kernel (H, Dinv, UDinv per joint and decade)
+    size_t hslots_bytes = 0;
     std::vector<int> h_wave;             // host scratch for the compaction scan
     loikb_stats stats{};
     int rc = 0;
@@ -810,6 +814,19 @@ int compact(loikb_solver_impl* S, Chunk* C, int src, int dst, int n_src, int* n_
 
 // finish the remaining live instances of set `cur` (n_cur slots, n_live of them live) with the cooperative tail
 // kernel (a lane group per instance, one joint per lane)
+// Can the stragglers / small batches of this solver run in the lean tail kernel (two wavefronts per SIMD, loik_lean.hpp)?
+// fp64, adaptive stopping logic, H cache on, one joint per lane, at most 4 children per joint, and an LDS footprint that
+// lets two 4-wavefront workgroups share a CU.  LOIKB_LEAN=0 switches it off.
+bool lean_applicable(const loikb_solver_impl* S)
+{
+  if (const char* e = getenv("LOIKB_LEAN")) if (atoi(e) == 0) return false;
+  if (S->f32 || S->nb > WAVE || S->maxchild > 4) return false;
+  if (S->opt.flags & (LOIKB_OPT_FIXED_ITERS | LOIKB_OPT_NO_H_CACHE)) return false;
+  int G = 8;
+  while (G < S->nb) G <<= 1;
+  return 2 * TAIL_WAVES * lean_lds_bytes<double>(S->nc, G) <= 160 * 1024;
+}
+
 template <typename T>
 int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, int n_live, double* ms_out,
              unsigned long long* iters_out, bool whole_set = false)
@@ -849,10 +866,98 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
   // ONE launch: as many workgroups as the chunk's share of the CUs holds (one wavefront per SIMD: register budget);
   // the lane groups pull the listed instances from an atomic queue head until the list is empty.
   const int cu_share = std::max(1, (int)(S->ncu * (TAIL_WAVES / tw) * ((double)C->B / (double)S->B) + 0.5));
-  const int n = n_live;
+  int n = n_live;
   double total_ms = 0.0;
   unsigned long long iters = 0;
   const bool trace = getenv("LOIKB_TRACE") != nullptr;
+  const int* list = C->d_slots;
+  // ---- lean tail kernel: two wavefronts per SIMD (loik_lean.hpp).  H_i / Dinv_i / UDinv_i of the listed instances are
+  // precomputed for the decades mu0 * 10^(0 .. ndec-1) (k_hslots); instances whose mu leaves them come back unfinished
+  // and go through k_tail below.
+  {
+    // decades of mu with precomputed slots: mu0 * 10^(kexp_lo .. kexp_lo + ndec - 1).  The DEFAULT rule moves mu up from
+    // mu0 in the first iterations and then mostly oscillates between two or three decades (Talos workload: 0..7 seen,
+    // < 0 never); an instance that leaves the range is finished by k_tail.
+    int ndec = 10, kexp_lo = -2;
+    if (const char* e = getenv("LOIKB_LEAN_DECADES")) ndec = std::max(1, std::min(16, atoi(e)));
+    if (const char* e = getenv("LOIKB_LEAN_KLO")) kexp_lo = atoi(e);
+    const size_t wave_lds = lean_lds_bytes<T>(S->nc, G);
+    bool lean_ok = lean_applicable(S) && (P.mode & MODE_CACHE_H) && !(P.mode & MODE_FIXED_ITERS) && n >= 64;
+    if (lean_ok) {
+      const size_t need = (size_t)n * ndec * HSLOT_PAIRS * G * 2 * sizeof(T);
+      if (need > C->hslots_bytes) {
+        if (C->d_hslots) HIPCHK(hipFree(C->d_hslots));
+        C->d_hslots = nullptr; C->hslots_bytes = 0;
+        if (hipMalloc(&C->d_hslots, need + need / 8) == hipSuccess) {
+          C->hslots_bytes = need + need / 8;
+        } else {
+          (void)hipGetLastError();  // not enough memory for the decade slots: the 1-wavefront-per-SIMD kernel needs none
+          C->d_hslots = nullptr;
+          lean_ok = false;
+        }
+      }
+    }
+    if (lean_ok) {
+      const size_t lds = TAIL_WAVES * wave_lds;
+      if (lds > 64 * 1024) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      }
+      P.max_launch_iters = S->opt.max_iter + 1;
+      const int wg_needed = (n + ipw * TAIL_WAVES - 1) / (ipw * TAIL_WAVES);
+      const dim3 grid((unsigned)std::min(wg_needed, 2 * std::max(1, (int)(S->ncu * ((double)C->B / (double)S->B) + 0.5))));
+      const dim3 hgrid((unsigned)((n + ipw - 1) / ipw));
+      const size_t hlds = (size_t)(WAVE + 1) * 22 * sizeof(T);
+      HIPCHK(hipMemsetAsync(C->d_counters, 0, 8 * sizeof(unsigned int), C->stream));
+      HIPCHK(hipEventRecord(C->ev_k0, C->stream));
+      if (S->href_diag) {
+        hipLaunchKernelGGL((k_hslots<T, true>), hgrid, dim3(WAVE), hlds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                           (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
+                           (T*)C->d_hslots, kexp_lo, ndec);
+        hipLaunchKernelGGL((k_lean<T, true>), grid, dim3(WAVE * TAIL_WAVES), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                           (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
+                           (const T*)C->d_hslots, kexp_lo, ndec);
+      } else {
+        hipLaunchKernelGGL((k_hslots<T, false>), hgrid, dim3(WAVE), hlds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                           (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
+                           (T*)C->d_hslots, kexp_lo, ndec);
+        hipLaunchKernelGGL((k_lean<T, false>), grid, dim3(WAVE * TAIL_WAVES), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                           (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
+                           (const T*)C->d_hslots, kexp_lo, ndec);
+      }
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(C->ev_k1, C->stream));
+      HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+      HIPCHK(hipStreamSynchronize(C->stream));
+      float ms = 0.f, t0 = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));
+      HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0));
+      C->tail_iv.emplace_back(t0, t0 + ms);
+      total_ms += ms;
+      iters += C->h_counters[1];
+      const unsigned int escaped = C->h_counters[2];
+      if (trace)
+        fprintf(stderr, "[loikb] lean tail launch: %6d instances on %u workgroups  %8.3f ms  inst-iters %9u (%.1f M/s)"
+                        "  wave-iters %7u slot loads %7u  escaped %u\n",
+                n, grid.x, ms, C->h_counters[1], C->h_counters[1] / ms / 1e3, C->h_counters[5], C->h_counters[6], escaped);
+      C->stats.launches++;
+      C->stats.tail_launches++;
+      if (escaped == 0) {
+        *ms_out = total_ms;
+        *iters_out = iters;
+        return LOIKB_OK;
+      }
+      // the survivors, for k_tail
+      HIPCHK(hipMemsetAsync(C->d_counters, 0, 8 * sizeof(unsigned int), C->stream));
+      hipLaunchKernelGGL(k_list_unfinished<T>, grid1(n), dim3(256), 0, C->stream, A.tiles, S->L, list, n, C->d_slots2, C->d_counters + 3);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+      HIPCHK(hipStreamSynchronize(C->stream));
+      n = (int)C->h_counters[3];
+      list = C->d_slots2;
+      if (n == 0) { *ms_out = total_ms; *iters_out = iters; return LOIKB_OK; }
+    }
+  }
   {
     P.max_launch_iters = S->opt.max_iter + 1;
     const int wg_needed = (n + ipw * tw - 1) / (ipw * tw);
@@ -862,11 +967,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     if (S->href_diag)
       hipLaunchKernelGGL((k_tail<T, true>), grid, dim3(WAVE * tw), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                          (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
-                         (const int*)C->d_slots, n, G);
+                         list, n, G);
     else
       hipLaunchKernelGGL((k_tail<T, false>), grid, dim3(WAVE * tw), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                          (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
-                         (const int*)C->d_slots, n, G);
+                         list, n, G);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(C->ev_k1, C->stream));
     HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
@@ -912,7 +1017,10 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
   const bool use_tail = can_compact && S->nb <= WAVE && S->opt.tail_max_instances >= 0;
   // (thresholds are stated for the whole batch: a chunk applies its share)
   const double share = (double)C->B / (double)S->B;
-  const int tail_max = std::max(1, (int)((S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : 32768) * share));
+  // (with the lean tail kernel, whole batches up to 2^20 instances go to it directly: it is as fast as the solve kernel's
+  //  bulk phase and has neither ragged tiles nor compaction; without it the hand-over is at 32768 live instances)
+  const int tail_max = std::max(1, (int)((S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances
+                                                                         : (lean_applicable(S) ? (1 << 20) : 32768)) * share));
   const bool trace = getenv("LOIKB_TRACE") != nullptr;
   // a team of wavefronts per tile walks independent chains of the tree concurrently: a sweep costs the tree's
   // critical path instead of nb joint visits, and four wavefronts keep four times the loads of a tile in flight.
@@ -1321,7 +1429,8 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
     // Both kernels need a whole SIMD per wavefront (register budget) and both claim whole CUs per workgroup, so
     // chunks mostly time-share the machine; the gain is the straggler phase of one chunk (down to a few hundred
     // resident wavefronts for ~10 ms) running beside the bulk phase of the other.  More chunks only queue.
-    int nchunks = ntiles >= 512 ? 2 : 1;
+    // (the lean tail kernel takes whole batches in one launch: one chunk)
+    int nchunks = (ntiles >= 512 && !lean_applicable(S)) ? 2 : 1;
     if (const char* e = getenv("LOIKB_CHUNKS")) nchunks = atoi(e);
     if (nchunks < 1) nchunks = 1;
     if (nchunks > ntiles) nchunks = ntiles;
@@ -1339,6 +1448,7 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
       HIPTRY(hipHostMalloc((void**)&C.h_counters, 8 * sizeof(unsigned int)));
       TRY(alloc_dev(S, &tmp, 8 * sizeof(unsigned int))); C.d_counters = (unsigned int*)tmp;
       TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)(C.B + WAVE))); C.d_slots = (int*)tmp;
+      TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)(C.B + WAVE))); C.d_slots2 = (int*)tmp;
       if (S->chunks.size() > 1) {
         HIPTRY(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
         C.own_stream = true;
@@ -1389,6 +1499,7 @@ int loikb_destroy(loikb_solver* S)
   if (S->d_stage) (void)hipFree(S->d_stage);
   for (Chunk& C : S->chunks) {
     if (C.h_counters) (void)hipHostFree(C.h_counters);
+    if (C.d_hslots) (void)hipFree(C.d_hslots);
     if (C.ev_k0) (void)hipEventDestroy(C.ev_k0);
     if (C.ev_k1) (void)hipEventDestroy(C.ev_k1);
     if (C.own_stream && C.stream) (void)hipStreamDestroy(C.stream);

@@ -1,0 +1,694 @@
+// loik_lean.hpp -- the tail kernel at TWO wavefronts per SIMD.
+//
+// k_tail (loik_tail.hpp) keeps an instance's whole ADMM state in registers/LDS, one joint per lane, and is bound by
+// fp64 issue latency: one wavefront per SIMD (512 registers, 39 KB of LDS) executes its dependent chains along the tree
+// levels at ~13 cycles per instruction while the SIMD could issue one every 4 (scripts/ubench/fp64_issue.hip: a second
+// wavefront on the SIMD halves the time per instruction at this amount of instruction-level parallelism).
+// k_lean is the same iteration at <= 256 registers and <= 20 KB of LDS per wavefront, so that two wavefronts share a
+// SIMD.  What had to go:
+//   * the H rebuild (the masked level loop that carries the 21 entries of H_i up the tree: ~150 registers on its own).
+//     H_i / Dinv_i / UDinv_i depend on q and mu only, and mu only ever moves by decades (UpdateMu, hxx:613-641):
+//     k_hslots below precomputes them for the decades mu0 * 10^(kexp_lo .. kexp_lo+ndec-1) into HBM "decade slots"
+//     before the lean launch; on a change of mu a lane fetches its 14 pairs.  An instance whose mu leaves the
+//     precomputed decades is written back unfinished ("escapes") and is finished by k_tail.
+//   * the second H slot in LDS and the 22 exchange columns the rebuild needs (22.5 -> 10.5 KB, 15.6 -> 7.1 KB)
+//   * the ~60 registers of per-instance scalars every lane carried redundantly (tolerances, the 14 norms kept for the
+//     getters, flags): they live once per instance in LDS; every lane reads what the epilogue needs.
+// Arithmetic per joint is k_tail's lean path; the only numerical difference is that a decade slot was built for
+// mu0 * 10^k (repeated multiplication by 10) while the solver's mu may have reached the decade through x0.1 steps --
+// a relative 1e-16 in H, far inside the parity tolerance.
+#pragma once
+
+#include "loik_tail.hpp"
+
+namespace loikb {
+
+constexpr int LXS = 14;  // scalars per exchange row: A = cols 0..5 (p messages up, act(f) for g), B = cols 6..11 (v down),
+                         // 2 pad; the stride is 7 (odd) 16-byte slots -> conflict-free b128 rows; norms are deposited in
+                         // cols 0..11 once both exchanges of the iteration are over
+constexpr int LXA = 0, LXB = 6;
+constexpr int LHS = 21;  // H_i per lane (Dinv_i stays in a register)
+constexpr int HSLOT_PAIRS = 14;  // decade slot of a joint: H[21], Dinv, UDinv[6]
+// per-instance scalars in LDS (T each, integers included: they are small and exact)
+enum : int { IS_MU = 0, IS_KEXP, IS_ITER, IS_STATUS, IS_TAILIT, IS_C1, IS_C2, IS_NFLIP, IS_TOLP, IS_TOLD, IS_DYQP, IS_ATDY,
+             IS_UBP, IS_LBM, IS_BNORM, IS_PRIMAL, IS_DUAL, IS_PRT, IS_PRS, IS_DUALV, IS_STF, IS_DX, IS_DZ, IS_DFIS,
+             IS_DYIS, IS_DW, IS_DVIS, IS_DNU, IS_AV, IS_NU, IS_HREFV, IS_G, IS_TGIN, IS_STY, IS_MULAST,
+             IS_RED /* results of the folds: 12 */, ISC = IS_RED + 12 };
+
+template <typename T>
+__host__ __device__ __forceinline__ size_t lean_lds_bytes(int nc, int G)
+{
+  return ((((size_t)XROWS * LXS + (size_t)WAVE * LHS + (size_t)(WAVE / G) * ((size_t)nc * CD + ISC)) * sizeof(T)) + 15) & ~(size_t)15;
+}
+
+// pair k of lane j of the decade slot (list position idx, decade d): lanes of a group read consecutive 16-byte pairs
+__device__ __forceinline__ size_t hslot_pair(int idx, int ndec, int dsl, int G, int k, int jlane)
+{
+  return (((size_t)idx * ndec + dsl) * HSLOT_PAIRS + k) * G + jlane;
+}
+
+// fold 12 columns of the group's exchange rows (columns < nmax: max, the others: sum in lane order) into isc[IS_RED..]
+template <typename T>
+__device__ __forceinline__ void lean_fold(const T* xch, T* isc, int gbase, int jlane, int G, int ncol, int nmax)
+{
+  for (int q = jlane; q < ncol; q += G) {
+    const T* col = xch + gbase * LXS + q;
+    T red = T(0);
+    for (int l = 0; l < G; l += 8) {
+      T a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = col[(l + u) * LXS];
+      if (q < nmax) {
+        red = tmax(red, tmax(tmax(tmax(a[0], a[1]), tmax(a[2], a[3])), tmax(tmax(a[4], a[5]), tmax(a[6], a[7]))));
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) red += a[u];
+      }
+    }
+    isc[IS_RED + q] = red;
+  }
+}
+
+// acc += the 6-vectors at column `off` of the exchange rows chl[0..n): see gather_rows in loik_tail.hpp (row stride LXS)
+// (one child at a time: here registers are scarce and the LDS latency is covered by the SIMD's other wavefront)
+template <typename T, int NCH>
+__device__ __forceinline__ void lean_gather(const T* xch, const int* chl, int off, T* acc)
+{
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const T* x = xch + chl[c] * LXS + off;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] += x[k];
+  }
+}
+template <typename T>
+__device__ __forceinline__ void lean_gather_n(int n, const T* xch, const int* chl, int off, T* acc)
+{
+  switch (n) {  // uniform
+  case 0: break;
+  case 1: lean_gather<T, 1>(xch, chl, off, acc); break;
+  case 2: lean_gather<T, 2>(xch, chl, off, acc); break;
+  case 3: lean_gather<T, 3>(xch, chl, off, acc); break;
+  default: lean_gather<T, 4>(xch, chl, off, acc); break;
+  }
+}
+
+template <typename T, bool HDIAG>
+__global__ void __launch_bounds__(WAVE * TAIL_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
+       const int* __restrict__ child_list, int maxdepth, int maxchild, const int* __restrict__ slots, int nslots, int G,
+       const T* __restrict__ hslots, int kexp_lo, int ndec)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Layout& L = P.L;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const size_t wave_lds = lean_lds_bytes<T>(L.nc, G);
+  T* xch = reinterpret_cast<T*>(smem_raw + wv * wave_lds);  // [WAVE + 1][LXS]
+  T* hst = xch + XROWS * LXS;                               // [WAVE][LHS]
+  T* cd = hst + WAVE * LHS;                                 // [64/G][nc][CD]
+  T* iscb = cd + (size_t)(WAVE / G) * L.nc * CD;            // [64/G][ISC]
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int sub = lane / G, jlane = lane % G, gbase = sub * G;
+  const bool isj_lane = jlane < L.nb;
+  const int jl = isj_lane ? jlane : 0;
+  T* cdi = cd + (size_t)sub * L.nc * CD;
+  T* isc = iscb + (size_t)sub * ISC;
+  T* hcur = hst + (size_t)lane * LHS;
+
+  const JointDesc d = jd[jl + 1];
+  const TailTopo tp = topo[jl + 1];
+  const bool rev = d.flags & JF_REVOLUTE;
+  const T mass = (d.flags & JF_MASSLESS) ? T(0) : T(1);
+  const bool has_parent = !(d.flags & JF_PARENT_ROOT);
+  constexpr int NCH_REG = 4;
+  int chl[NCH_REG];
+#pragma unroll
+  for (int c = 0; c < NCH_REG; ++c) chl[c] = c < tp.nchild ? gbase + child_list[tp.child_start + c] : WAVE;
+  const int prow = has_parent ? gbase + d.parent - 1 : WAVE;
+  T Sv[6];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { Sv[k] = rev ? T(0) : (T)d.axis[k]; Sv[3 + k] = rev ? (T)d.axis[k] : T(0); }
+  if (lane < LXS) xch[WAVE * LXS + lane] = T(0);
+
+  bool has_inst = false, isj = false, done = true, any_iter = false;
+  int lidx = 0;
+  char *ip = Bf.tiles, *rec = Bf.tiles;
+  T R[9], t[3], v[6], f[6], g[6], UD[6], p[6];
+  T w = T(0), z = T(0), nu = T(0), s = T(0), r = T(0), dinv = T(0), lbi = T(0), ubi = T(0), mu = T(1);
+  int kexp = 0, kslot = -(1 << 30);
+  unsigned int my_iters = 0;
+  unsigned int n_wave_iters = 0, n_slot_loads = 0;
+
+  auto fetch = [&]() -> int {
+    int nx = 0;
+    if (jlane == 0) nx = (int)atomicAdd(&Bf.counters[7], 1u);
+    return __shfl(nx, gbase);
+  };
+  auto load_instance = [&](int idx) {
+    has_inst = idx < nslots;
+    isj = has_inst && isj_lane;
+    lidx = has_inst ? idx : 0;
+    const int slot = slots[lidx];
+    ip = lane_ptr<T>(Bf.tiles, L, slot);
+    rec = ip + (size_t)jl * JREC * pair_bytes<T>();
+    const char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+    {
+      const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
+      joint_xform<T>(d, rec, cs.x, cs.y, R, t);
+      ld6<T>(rec, JP_V, v);
+      ld6<T>(rec, JP_F, f);
+      ld6<T>(rec, JP_G, g);
+      w = wz.x; z = wz.y; nu = nus.x; s = nus.y;
+      if (P.mode & MODE_BND_SHARED) {
+        lbi = Bf.uni[L.nc * 57 + jl];
+        ubi = Bf.uni[L.nc * 57 + L.nb + jl];
+      } else {
+        const typename Vec2<T>::type lu = ldp<T>(rec, JP_LBUB);
+        lbi = lu.x; ubi = lu.y;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { UD[k] = T(0); p[k] = T(0); }
+      r = T(0); dinv = T(0);
+    }
+    for (int c = 0; c < L.nc; ++c) {
+      const char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+      for (int e = jlane; e < CD; e += G) {
+        T val = T(0);
+        if (e < 36) {
+          val = (P.mode & MODE_A_SHARED) ? Bf.uni[c * 36 + e]
+                                         : *reinterpret_cast<const T*>(crec + (size_t)(CP_A + e / 2) * pair_bytes<T>() + (e & 1) * sizeof(T));
+        } else if (e < 57) {
+          const int q = e - 36;
+          val = (P.mode & MODE_A_SHARED) ? Bf.uni[L.nc * 36 + c * 21 + q]
+                                         : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + q / 2) * pair_bytes<T>() + (q & 1) * sizeof(T));
+        } else if (e >= CD_B) {
+          const int q = e - CD_B;
+          const int which = q / 6, k = q % 6;
+          const int pair = which == 0 ? CP_B : which == 1 ? CP_ATB : which == 2 ? CP_Y : CP_ATY;
+          val = *reinterpret_cast<const T*>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+        }
+        if (e != CD_PAD) cdi[c * CD + e] = val;
+      }
+    }
+    if (isj_lane && d.cslot >= 0) cdi[d.cslot * CD + CD_PAD] = (T)jlane;
+    const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
+    mu = mu2.x;
+    kexp = (int)mu2.y;
+    kslot = -(1 << 30);
+    int status = has_inst ? (int)st2.x : ST_DONE;
+    const int iter = (int)bi2.y;
+    done = (status & ST_DONE) != 0;
+    if (!done && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { done = true; status |= ST_DONE; }
+    if (jlane == 0) {
+      isc[IS_MU] = mu; isc[IS_KEXP] = (T)kexp; isc[IS_ITER] = (T)iter; isc[IS_STATUS] = (T)status;
+      isc[IS_TAILIT] = ld_scal<T>(srec, SC_TAIL_ITER);
+      isc[IS_C1] = ld_scal<T>(srec, SC_COND1); isc[IS_C2] = ld_scal<T>(srec, SC_COND2);
+      isc[IS_NFLIP] = ldp<T>(srec, SP_FLIP).x;
+      isc[IS_TOLP] = ld_scal<T>(srec, SC_TOL_PRIMAL); isc[IS_TOLD] = ld_scal<T>(srec, SC_TOL_DUAL);
+      isc[IS_DYQP] = ld_scal<T>(srec, SC_DELTA_Y_QP); isc[IS_ATDY] = ld_scal<T>(srec, SC_AT_DELTA_Y_QP);
+      isc[IS_UBP] = ld_scal<T>(srec, SC_UB_DY_PLUS); isc[IS_LBM] = ld_scal<T>(srec, SC_LB_DY_MINUS);
+      isc[IS_BNORM] = bi2.x;
+      isc[IS_TGIN] = ldp<T>(srec, SP_TAG).x; isc[IS_STY] = st2.y; isc[IS_MULAST] = T(-1);
+    }
+    tail_sync();
+    my_iters = 0;
+    any_iter = false;
+  };
+  auto store_instance = [&]() {
+    char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+    if (isj) {
+      st6<T>(rec, JP_V, v);
+      st6<T>(rec, JP_F, f);
+      st6<T>(rec, JP_G, g);
+      stp<T>(rec, JP_WZ, w, z);
+      stp<T>(rec, JP_NUS, nu, s);
+      if (any_iter) {
+        st6<T>(rec, JP_P, p);
+        st6<T>(rec, JP_UD, UD);
+        stp<T>(rec, JP_R, r, dinv);
+      }
+    }
+    tail_sync();
+    if (has_inst) {
+      for (int c = 0; c < L.nc; ++c) {
+        char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+        if (jlane < 6) {
+          const int k = jlane;
+          *reinterpret_cast<T*>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * CD + CD_Y + k];
+          *reinterpret_cast<T*>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * CD + CD_ATY + k];
+        }
+      }
+      if (jlane == 0) {
+        const T mu_s = isc[IS_MU], mu_last = isc[IS_MULAST];
+        const int status = (int)isc[IS_STATUS];
+        stp<T>(srec, SP_MU, mu_s, isc[IS_KEXP]);
+        stp<T>(srec, SP_TAG, any_iter ? mu_last : isc[IS_TGIN], T(0));
+        stp<T>(srec, SP_BI, isc[IS_BNORM], isc[IS_ITER]);
+        stp<T>(srec, SP_FLIP, isc[IS_NFLIP], T(0));
+        stp<T>(srec, SP_ST, (T)(any_iter ? (status | ST_PFULL) : status), any_iter ? mu_last : isc[IS_STY]);
+        if (any_iter) {
+          stp<T>(srec, SP_SCAL + 0, isc[IS_PRIMAL], isc[IS_DUAL]);
+          stp<T>(srec, SP_SCAL + 1, isc[IS_PRT], isc[IS_PRS]);
+          stp<T>(srec, SP_SCAL + 2, isc[IS_DUALV], isc[IS_STF]);
+          stp<T>(srec, SP_SCAL + 3, isc[IS_TOLP], isc[IS_TOLD]);
+          stp<T>(srec, SP_SCAL + 4, mu_s, P.mu_scale * mu_s);
+          stp<T>(srec, SP_SCAL + 5, mu_s, isc[IS_DX]);
+          stp<T>(srec, SP_SCAL + 6, isc[IS_DZ], isc[IS_DYQP]);
+          stp<T>(srec, SP_SCAL + 7, isc[IS_ATDY], isc[IS_UBP]);
+          stp<T>(srec, SP_SCAL + 8, isc[IS_LBM], isc[IS_DFIS]);
+          stp<T>(srec, SP_SCAL + 9, isc[IS_DYIS], isc[IS_DW]);
+          stp<T>(srec, SP_SCAL + 10, isc[IS_DVIS], isc[IS_DNU]);
+          stp<T>(srec, SP_SCAL + 11, isc[IS_AV], isc[IS_NU]);
+          stp<T>(srec, SP_SCAL + 12, isc[IS_HREFV], isc[IS_G]);
+          stp<T>(srec, SP_SCAL + 13, isc[IS_STF], isc[IS_C1]);
+          stp<T>(srec, SP_SCAL + 14, isc[IS_C2], isc[IS_TAILIT]);
+        }
+        if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
+      }
+    }
+    tail_sync();
+  };
+
+  load_instance(fetch());
+  while (__any(!done || has_inst)) {
+    // ---- decade slot of the current mu (H_i, Dinv_i, UDinv_i) -------------------------------------------------------
+    if (!done && kexp != kslot) {
+      const int dsl = kexp - kexp_lo;
+      if (dsl < 0 || dsl >= ndec) {
+        done = true;  // mu left the precomputed decades: written back unfinished, k_tail takes over
+        if (jlane == 0) atomicAdd(&Bf.counters[2], 1u);
+      } else {
+        if (isj) {
+          const typename Vec2<T>::type* hp = reinterpret_cast<const typename Vec2<T>::type*>(hslots);
+          // (in two halves: 28 doubles in flight at once would cost registers the level loops need)
+          {
+            typename Vec2<T>::type in[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) in[k] = hp[hslot_pair(lidx, ndec, dsl, G, k, jlane)];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) { hcur[2 * k] = in[k].x; hcur[2 * k + 1] = in[k].y; }
+          }
+          {
+            typename Vec2<T>::type in[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) in[k] = hp[hslot_pair(lidx, ndec, dsl, G, 7 + k, jlane)];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { hcur[14 + 2 * k] = in[k].x; hcur[15 + 2 * k] = in[k].y; }
+            hcur[20] = in[3].x;
+            dinv = in[3].y;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { UD[2 * k] = in[4 + k].x; UD[2 * k + 1] = in[4 + k].y; }
+          }
+        }
+        kslot = kexp;
+        ++n_slot_loads;
+      }
+    }
+    const bool act = !done;
+    const T mu_eq = P.mu_scale * mu, mu_in = mu;
+    if (act) { ++my_iters; any_iter = true; }
+    ++n_wave_iters;
+
+    // ================= leaf -> root: FwdPass1 + BwdPass, p only (hxx:290-338, :31-81) =================================
+    if (act) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) p[k] = mass * (-P.rho * v[k] - P.Hv[k]);
+      if (isj && d.cslot >= 0) {
+        const T* c_ = cdi + d.cslot * CD;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p[k] += c_[CD_ATY + k] - mu_eq * c_[CD_ATB + k];
+      }
+    }
+    {
+      T pl[6], rl = T(0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pl[k] = p[k];
+      for (int lev = maxdepth; lev >= 1; --lev) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pl[k] = p[k];
+        lean_gather_n<T>(maxchild, xch, chl, LXA, pl);
+        const T Stp = dot6_halves(Sv, pl);
+        rl = (w - mu_in * z) + Stp;
+        T pa[6], pc[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pa[k] = pl[k] - UD[k] * rl;
+        act_force(R, t, pa, pc);
+        tail_sync();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xch[lane * LXS + LXA + k] = pc[k];
+        tail_sync();
+      }
+      if (act) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) p[k] = pl[k];
+        r = rl;
+      }
+    }
+
+    // ================= root -> leaf: FwdPass2 (hxx:102-163) ==============================================================
+    T vi[6], nui = T(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vi[k] = T(0);
+    for (int lev = 1; lev <= maxdepth; ++lev) {
+      T vpar[6], vp[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vpar[k] = xch[prow * LXS + LXB + k];
+      actinv_motion(R, t, vpar, vp);
+      const T udv = dot6_halves(UD, vp);
+      nui = -udv - dinv * r;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vi[k] = vp[k] + Sv[k] * nui;
+      tail_sync();
+#pragma unroll
+      for (int k = 0; k < 6; ++k) xch[lane * LXS + LXB + k] = vi[k];
+      tail_sync();
+    }
+    // per-lane norms of this iteration (folded over the group below)
+    T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_dyis = T(0),
+      l_av = T(0), l_prt = T(0), l_prs = T(0), l_up = T(0), l_lm = T(0);
+    if (act && isj) {
+      T fi[6];
+      l_nu = tabs(nui);
+      // f = H v straight from the LDS slot, entry by entry (no 21-entry copy in registers)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) fi[k] = T(0);
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b2 = a; b2 < 6; ++b2) {
+          const T h = hcur[sym(a, b2)];
+          fi[a] += h * vi[b2];
+          if (a != b2) fi[b2] += h * vi[a];
+        }
+      T df[6], dv6[6], hrv[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        fi[k] += p[k];
+        df[k] = fi[k] - f[k];
+        dv6[k] = vi[k] - v[k];
+      }
+      l_dfis = inf6(df);
+      href_mul<T, HDIAG>(P.Href, vi, hrv);
+      l_hrefv = mass * inf6(hrv);
+      l_dvis = mass * inf6(dv6);
+      l_dnu = tabs(nui - nu);
+      const T x = nui + (T(1) / mu_in) * w;
+      const T zi = tmin(ubi, tmax(lbi, x));
+      l_dz = tabs(zi - z);
+      l_prs = tabs(nui - zi);
+      const T dwi = mu_in * (nui - zi);
+      l_dw = tabs(dwi);
+      l_up = ubi * tmax(dwi, T(0));
+      l_lm = lbi * tmin(dwi, T(0));
+      w = w + dwi; z = zi; nu = nui;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { v[k] = vi[k]; f[k] = fi[k]; }
+    }
+    // DualUpdate of the task constraints (hxx:410-451), six lanes of the group
+    for (int c = 0; c < L.nc; ++c) {
+      T* c_ = cdi + c * CD;
+      if (act && jlane < 6) {
+        const int k = jlane;
+        const T* vc = xch + (gbase + (int)c_[CD_PAD]) * LXS + LXB;
+        T avk = c_[CD_A + 6 * k] * vc[0];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) avk += c_[CD_A + 6 * k + j] * vc[j];
+        const T bk = c_[CD_B + k];
+        const T ek = avk - bk;
+        const T dy = mu_eq * ek;
+        const T yk = c_[CD_Y + k] + dy;
+        l_dyis = tmax(l_dyis, tabs(dy));
+        l_up += bk * tmax(dy, T(0));
+        l_lm += bk * tmin(dy, T(0));
+        l_prt = tmax(l_prt, tabs(ek));
+        l_av = tmax(l_av, tabs(avk));
+        c_[CD_Y + k] = yk;
+      }
+      tail_sync();
+      if (act && jlane < 6) {
+        const int k = jlane;
+        T at = c_[CD_A + k] * c_[CD_Y];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) at += c_[CD_A + 6 * j + k] * c_[CD_Y + j];
+        c_[CD_ATY + k] = at;
+      }
+      tail_sync();
+    }
+
+    // ================= BwdPass2 + dual residual (hxx:185-241, :468-487) =================================================
+    T l_dg = T(0), l_g = T(0), l_dualv = T(0), l_stf = T(0), l_dstf = T(0);
+    {
+      T pc[6];
+      act_force(R, t, f, pc);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) xch[lane * LXS + LXA + k] = (act && isj && has_parent) ? pc[k] : T(0);
+    }
+    tail_sync();
+    if (act && isj) {
+      T gi[6];
+      if (d.cslot >= 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gi[k] = cdi[d.cslot * CD + CD_ATY + k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gi[k] = T(0);
+      }
+      lean_gather_n<T>(maxchild, xch, chl, LXA, gi);
+      T dg[6], dvr[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        gi[k] += -f[k];
+        dg[k] = gi[k] - g[k];
+        g[k] = gi[k];
+      }
+      l_dg = inf6(dg);
+      l_g = inf6(gi);
+      href_mul<T, HDIAG>(P.Href, v, dvr);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) dvr[a] = mass * (dvr[a] - P.Hv[a]) + gi[a];
+      l_dualv = inf6(dvr);
+      const T si = dot6_halves(Sv, f) + w;
+      l_stf = tabs(si);
+      l_dstf = tabs(si - s);
+      s = si;
+    }
+    tail_sync();
+
+    // ================= the ten scalars the stopping logic needs, folded over the group ================================
+    {
+      T* row = xch + lane * LXS;
+      row[0] = tmax(l_prt, l_prs); row[1] = tmax(l_dualv, l_stf); row[2] = tmax(l_dvis, l_dnu); row[3] = l_dz;
+      row[4] = tmax(l_av, l_nu); row[5] = tmax(tmax(l_hrefv, l_g), l_stf); row[6] = tmax(l_dfis, tmax(l_dyis, l_dw));
+      row[7] = tmax(l_dg, l_dstf); row[8] = l_up; row[9] = l_lm;
+    }
+    tail_sync();
+    lean_fold<T>(xch, isc, gbase, jlane, G, 10, 8);
+    tail_sync();
+    bool finishing = false;
+    if (act) {
+      const T primal = isc[IS_RED + 0], dual = isc[IS_RED + 1], dx = isc[IS_RED + 2], dz = isc[IS_RED + 3];
+      int status = (int)isc[IS_STATUS];
+      const int iter = (int)isc[IS_ITER] + 1;
+      int tail_iter = (int)isc[IS_TAILIT], c1 = (int)isc[IS_C1], c2 = (int)isc[IS_C2], nflip = (int)isc[IS_NFLIP];
+      T tol_p = isc[IS_TOLP], tol_d = isc[IS_TOLD], dyqp = isc[IS_DYQP], atdy = isc[IS_ATDY], ubp = isc[IS_UBP], lbm = isc[IS_LBM];
+      const T mu_used = mu;
+      if (P.mode & MODE_FIXED_ITERS) {
+        if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
+      } else if (!(status & ST_TAIL)) {
+        tol_p = P.tol_abs + P.tol_rel * tmax(isc[IS_RED + 4], isc[IS_BNORM]);
+        tol_d = P.tol_abs + P.tol_rel * tmax(isc[IS_RED + 5], P.Hv_inf_norm);
+        const bool conv = (primal < tol_p) && (dual < tol_d);
+        bool infeas = false;
+        if (iter > 1) {
+          dyqp = isc[IS_RED + 6];
+          atdy = isc[IS_RED + 7];
+          c1 = atdy <= P.tol_primal_inf * dyqp;
+          ubp = isc[IS_RED + 8];
+          lbm = isc[IS_RED + 9];
+          c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp;
+          infeas = c1 && c2;
+        }
+        if (conv) {
+          status |= ST_CONVERGED | ST_DONE;
+          if (infeas) status |= ST_PRIMAL_INF;
+          done = true;
+        } else if (infeas) {
+          status |= ST_PRIMAL_INF | ST_TAIL;
+          tail_iter = 0;
+          if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
+        } else {
+          if (primal > T(10) * dual) { mu *= T(10); ++kexp; ++nflip; }
+          else if (dual > T(10) * primal) { mu *= T(0.1); --kexp; ++nflip; }
+          if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
+        }
+      } else {
+        tail_iter += 1;
+        if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
+      }
+      finishing = done;
+      tail_sync();  // every lane has read the instance's scalars before lane 0 rewrites them
+      if (jlane == 0) {
+        isc[IS_MU] = mu; isc[IS_KEXP] = (T)kexp; isc[IS_ITER] = (T)iter; isc[IS_STATUS] = (T)status;
+        isc[IS_TAILIT] = (T)tail_iter; isc[IS_C1] = (T)c1; isc[IS_C2] = (T)c2; isc[IS_NFLIP] = (T)nflip;
+        isc[IS_TOLP] = tol_p; isc[IS_TOLD] = tol_d; isc[IS_DYQP] = dyqp; isc[IS_ATDY] = atdy; isc[IS_UBP] = ubp; isc[IS_LBM] = lbm;
+        isc[IS_PRIMAL] = primal; isc[IS_DUAL] = dual; isc[IS_DX] = dx; isc[IS_DZ] = dz; isc[IS_MULAST] = mu_used;
+      }
+    } else {
+      tail_sync();
+    }
+    // an escaped instance (mu left the precomputed decades) is written back as it is
+    const bool leaving = done && has_inst;
+    // ---- the norms the getters report (13 more maxima): only when some instance of the wavefront stops ------------------
+    if (__any(finishing)) {
+      tail_sync();
+      {
+        T* row = xch + lane * LXS;
+        row[0] = l_prt; row[1] = l_prs; row[2] = l_dualv; row[3] = l_stf; row[4] = l_dvis; row[5] = l_dnu; row[6] = l_dfis;
+        row[7] = l_dyis; row[8] = l_dw; row[9] = l_av; row[10] = l_nu; row[11] = l_hrefv;
+      }
+      tail_sync();
+      lean_fold<T>(xch, isc, gbase, jlane, G, 12, 12);
+      tail_sync();
+      if (finishing && jlane == 0) {
+        isc[IS_PRT] = isc[IS_RED + 0]; isc[IS_PRS] = isc[IS_RED + 1]; isc[IS_DUALV] = isc[IS_RED + 2]; isc[IS_STF] = isc[IS_RED + 3];
+        isc[IS_DVIS] = isc[IS_RED + 4]; isc[IS_DNU] = isc[IS_RED + 5]; isc[IS_DFIS] = isc[IS_RED + 6]; isc[IS_DYIS] = isc[IS_RED + 7];
+        isc[IS_DW] = isc[IS_RED + 8]; isc[IS_AV] = isc[IS_RED + 9]; isc[IS_NU] = isc[IS_RED + 10]; isc[IS_HREFV] = isc[IS_RED + 11];
+      }
+      tail_sync();
+      xch[lane * LXS + 0] = l_g;
+      tail_sync();
+      lean_fold<T>(xch, isc, gbase, jlane, G, 1, 1);
+      tail_sync();
+      if (finishing && jlane == 0) isc[IS_G] = isc[IS_RED + 0];
+      tail_sync();
+    }
+    if (leaving) {
+      store_instance();
+      load_instance(fetch());
+    }
+  }
+  if (lane == 0) {
+    atomicAdd(&Bf.counters[5], n_wave_iters);
+    atomicAdd(&Bf.counters[6], n_slot_loads);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Decade slots: H_i (accumulated, pre-projection), Dinv_i, UDinv_i of every listed instance for mu = mu0 * 10^(kexp_lo + d),
+// d = 0 .. ndec-1.  One joint per lane like k_tail, the masked leaf -> root level loop of its H rebuild (hxx:290-338,
+// :31-81, H part only), once per decade.
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename T, bool HDIAG>
+__global__ void __launch_bounds__(WAVE)
+k_hslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
+         const int* __restrict__ child_list, int maxdepth, int maxchild, const int* __restrict__ slots, int nslots, int G,
+         T* __restrict__ hslots, int kexp_lo, int ndec)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Layout& L = P.L;
+  T* xch = reinterpret_cast<T*>(smem_raw);  // [WAVE + 1][22]: the projected, transported H of a child
+  constexpr int HX = 22;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int ipw = WAVE / G;
+  const int sub = lane / G, jlane = lane % G, gbase = sub * G;
+  const int idx = blockIdx.x * ipw + sub;
+  const bool has_inst = idx < nslots;
+  const bool isj = has_inst && jlane < L.nb;
+  const int jl = jlane < L.nb ? jlane : 0;
+  const JointDesc d = jd[jl + 1];
+  const TailTopo tp = topo[jl + 1];
+  const int depth = jlane < L.nb ? tp.depth : 0;
+  const bool rev = d.flags & JF_REVOLUTE;
+  const T mass = (d.flags & JF_MASSLESS) ? T(0) : T(1);
+  const bool has_parent = !(d.flags & JF_PARENT_ROOT);
+  const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
+  const int slot = slots[has_inst ? idx : 0];
+  char* ip = lane_ptr<T>(Bf.tiles, L, slot);
+  const char* rec = ip + (size_t)jl * JREC * pair_bytes<T>();
+  T R[9], t[3];
+  {
+    const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS);
+    joint_xform<T>(d, rec, cs.x, cs.y, R, t);
+  }
+  T ata[21];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) ata[k] = T(0);
+  if (isj && d.cslot >= 0) {
+    const char* crec = ip + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>();
+    for (int k = 0; k < 21; ++k)
+      ata[k] = (P.mode & MODE_A_SHARED) ? Bf.uni[L.nc * 36 + d.cslot * 21 + k]
+                                        : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+  }
+  typename Vec2<T>::type* hp = reinterpret_cast<typename Vec2<T>::type*>(hslots);
+  T mu = P.mu0;
+  for (int k = 0; k < kexp_lo; ++k) mu *= T(10);
+  for (int k = 0; k > kexp_lo; --k) mu *= T(0.1);
+  for (int dsl = 0; dsl < ndec; ++dsl) {
+    const T mu_eq = P.mu_scale * mu, mu_in = mu;
+    T hh[21];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b2 = a; b2 < 6; ++b2)
+        hh[sym(a, b2)] = mass * ((a == b2 ? P.rho : T(0)) + ((HDIAG && a != b2) ? T(0) : P.Href[6 * a + b2]));
+#pragma unroll
+    for (int k = 0; k < 21; ++k) hh[k] += mu_eq * ata[k];
+    for (int lev = maxdepth; lev >= 1; --lev) {
+      if (isj && depth == lev) {
+        for (int c = 0; c < tp.nchild; ++c) {
+          const T* x = xch + (gbase + child_list[tp.child_start + c]) * HX;
+#pragma unroll
+          for (int k = 0; k < 21; ++k) hh[k] += x[k];
+        }
+        T U[6], UD[6];
+        T dinv;
+        if (rev) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 3)] * ax0 + hh[sym(k, 4)] * ax1 + hh[sym(k, 5)] * ax2;
+          dinv = T(1) / ((ax0 * U[3] + ax1 * U[4] + ax2 * U[5]) + mu_in);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 0)] * ax0 + hh[sym(k, 1)] * ax1 + hh[sym(k, 2)] * ax2;
+          dinv = T(1) / ((ax0 * U[0] + ax1 * U[1] + ax2 * U[2]) + mu_in);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) UD[k] = U[k] * dinv;
+        // the slot: H (pre-projection), Dinv, UDinv
+#pragma unroll
+        for (int k = 0; k < 10; ++k) hp[hslot_pair(idx, ndec, dsl, G, k, jlane)] = typename Vec2<T>::type{hh[2 * k], hh[2 * k + 1]};
+        hp[hslot_pair(idx, ndec, dsl, G, 10, jlane)] = typename Vec2<T>::type{hh[20], dinv};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) hp[hslot_pair(idx, ndec, dsl, G, 11 + k, jlane)] = typename Vec2<T>::type{UD[2 * k], UD[2 * k + 1]};
+        if (has_parent) {
+          T part[21];
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b2 = a; b2 < 6; ++b2) hh[sym(a, b2)] -= UD[a] * U[b2];
+          congr_sym(R, t, hh, part);
+          T* x = xch + lane * HX;
+#pragma unroll
+          for (int k = 0; k < 21; ++k) x[k] = part[k];
+        }
+      }
+      tail_sync();
+    }
+    tail_sync();
+    mu *= T(10);
+  }
+}
+
+// the listed instances that are still iterating after a lean launch (the ones that escaped), in arbitrary order
+template <typename T>
+__global__ void k_list_unfinished(char* tiles, Layout L, const int* __restrict__ list_in, int n_in, int* __restrict__ list_out,
+                                  unsigned int* __restrict__ counter)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_in) return;
+  const int b = list_in[i];
+  char* sp = lane_ptr<T>(tiles, L, b);
+  const int status = (int)ldp<T>(sp + (size_t)L.off_s * pair_bytes<T>(), SP_ST).x;
+  if (!(status & ST_DONE)) list_out[atomicAdd(counter, 1u)] = b;
+}
+
+}  // namespace loikb
