@@ -188,9 +188,11 @@ def main():
             except Exception:
                 pmc = None
 
-        def kernel_entry(key, name, iters, launches_k, sum_ms, busy_ms, extra):
+        def kernel_entry(key, name, iters, launches_k, sum_ms, busy_ms, extra, pmc=pmc):
             ach = iters * bytes_iter / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0
             traffic, note = None, "no PMC summary for this workload (run scripts/pmc_traffic.sh on the GPU box)"
+            if key == "k_tail" and pmc and "k_lean" in pmc and lean:  # the lean kernel and its slot precomputation
+                pmc = dict(pmc, k_tail={k_: pmc["k_lean"][k_] + pmc.get("k_hslots", {}).get(k_, 0.0) for k_ in pmc["k_lean"]})
             if pmc and key in pmc and launches_k > 0:
                 kb = pmc[key]["fetch_bytes_per_step"] + pmc[key]["write_bytes_per_step"]
                 traffic = kb / max(launches_k / args.steps, 1)
@@ -214,14 +216,19 @@ def main():
             "k_solve", "k_solve<double, team of %d wavefronts per 64-instance tile>" % st["team"], solve_iters,
             solve_launches, solve_ms, solve_busy_ms,
             {"regime": "one instance per lane, state streamed through HBM every iteration: HBM-bound in bulk"})
+        lean = st["lean_launches"] > 0
+        tail_name = ("k_lean<double> (tail kernel at two wavefronts per SIMD: a 32-lane group per instance, one joint per lane, "
+                     "state in registers/LDS, H/Dinv/UDinv of the decades of mu precomputed by k_hslots)" if lean else
+                     "k_tail<double> (a 32-lane group per instance, one joint per lane, state in registers/LDS)")
         k_tail = kernel_entry(
-            "k_tail", "k_tail<double> (a 32-lane group per instance, one joint per lane, state in registers/LDS)",
-            tail_iters, tail_launches, tail_ms, tail_busy_ms,
+            "k_tail", tail_name, tail_iters, tail_launches, tail_ms, tail_busy_ms,
             {"regime": "the state of an instance stays on chip for its whole solve: the kernel's HBM traffic is one load "
-                       "and one store per instance (`traffic`), so the streaming byte model's roofline does not bind it; "
-                       "what does is fp64 VALU issue and LDS round trips along the tree levels "
-                       "(scripts/tail_phase_profile.py: ~21.5 k cycles per ADMM iteration of a wavefront = 2 instances)",
-             "instances_per_step": tail_inst / args.steps})
+                       "and one store per instance plus the decade slots (`traffic`), so the streaming byte model's "
+                       "roofline does not bind it; what does is fp64 VALU issue latency along the tree levels "
+                       "(DESIGN.md section 4: phase timeline, scripts/ubench/fp64_issue.hip)",
+             "instances_per_step": tail_inst / args.steps,
+             "lean_launches_per_step": st["lean_launches"], "lean_escaped_last_step": st["lean_escaped"],
+             "decade_slots_ms_last_step": st["hslots_ms"]})
         dominant, other = (k_tail, k_solve) if tail_iters >= solve_iters else (k_solve, k_tail)
         line = {
             "metric": "IK solves/sec to 1e-6 residual, Talos humanoid, batch=65536 per GPU",

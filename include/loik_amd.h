@@ -220,6 +220,11 @@ typedef struct loikb_stats {
   double solve_busy_ms;                   /* time during which >= 1 solve-kernel launch was executing (HIP events;
                                              equals kernel_ms - tail_ms when chunks == 1)                        */
   double tail_busy_ms;                    /* same for the tail kernel                                            */
+  int lean_launches;                      /* tail launches that ran the lean kernel (two wavefronts per SIMD, decade
+                                             slots of H precomputed); the rest ran the one-wavefront-per-SIMD kernel   */
+  int lean_escaped;                       /* instances whose mu left the precomputed decades in a lean launch and were
+                                             finished by the other tail kernel                                         */
+  double hslots_ms;                       /* HIP-event time of the decade-slot precomputation (part of tail_ms)        */
 } loikb_stats;
 int loikb_get_stats(loikb_solver *s, loikb_stats *out);
 

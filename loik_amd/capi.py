@@ -45,7 +45,8 @@ class Stats(C.Structure):
                 ("compactions", C.c_int), ("tail_instances", C.c_int), ("tail_ms", C.c_double),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("bytes_per_instance_iteration", C.c_double),
                 ("tail_instance_iterations", C.c_ulonglong), ("tail_launches", C.c_int), ("team", C.c_int), ("chunks", C.c_int),
-                ("solve_busy_ms", C.c_double), ("tail_busy_ms", C.c_double)]
+                ("solve_busy_ms", C.c_double), ("tail_busy_ms", C.c_double), ("lean_launches", C.c_int),
+                ("lean_escaped", C.c_int), ("hslots_ms", C.c_double)]
 
 
 # enums of loik_amd.h

@@ -118,7 +118,7 @@ struct loikb_solver_impl {
     Set set[3];                          // [0] view of the home tiles of the range, [1],[2] work sets of the compaction
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_k2 = nullptr;
     unsigned int* d_counters = nullptr;
     unsigned int* h_counters = nullptr;  // pinned
     int* d_slots = nullptr;              // list of the live instances handed to the tail kernel
@@ -914,6 +914,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         hipLaunchKernelGGL((k_hslots<T, true>), hgrid, dim3(WAVE), hlds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                            (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
                            (T*)C->d_hslots, kexp_lo, ndec);
+        HIPCHK(hipEventRecord(C->ev_k2, C->stream));
         hipLaunchKernelGGL((k_lean<T, true>), grid, dim3(WAVE * TAIL_WAVES), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                            (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
                            (const T*)C->d_hslots, kexp_lo, ndec);
@@ -921,6 +922,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         hipLaunchKernelGGL((k_hslots<T, false>), hgrid, dim3(WAVE), hlds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                            (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
                            (T*)C->d_hslots, kexp_lo, ndec);
+        HIPCHK(hipEventRecord(C->ev_k2, C->stream));
         hipLaunchKernelGGL((k_lean<T, false>), grid, dim3(WAVE * TAIL_WAVES), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                            (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
                            (const T*)C->d_hslots, kexp_lo, ndec);
@@ -936,12 +938,17 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       total_ms += ms;
       iters += C->h_counters[1];
       const unsigned int escaped = C->h_counters[2];
+      float hms = 0.f;
+      HIPCHK(hipEventElapsedTime(&hms, C->ev_k0, C->ev_k2));
       if (trace)
-        fprintf(stderr, "[loikb] lean tail launch: %6d instances on %u workgroups  %8.3f ms  inst-iters %9u (%.1f M/s)"
-                        "  wave-iters %7u slot loads %7u  escaped %u\n",
-                n, grid.x, ms, C->h_counters[1], C->h_counters[1] / ms / 1e3, C->h_counters[5], C->h_counters[6], escaped);
+        fprintf(stderr, "[loikb] lean tail launch: %6d instances on %u workgroups  %8.3f ms (decade slots %.3f ms)  inst-iters %9u"
+                        " (%.1f M/s)  wave-iters %7u slot loads %7u  escaped %u\n",
+                n, grid.x, ms, hms, C->h_counters[1], C->h_counters[1] / ms / 1e3, C->h_counters[5], C->h_counters[6], escaped);
       C->stats.launches++;
       C->stats.tail_launches++;
+      C->stats.lean_launches++;
+      C->stats.lean_escaped += (int)escaped;
+      C->stats.hslots_ms += hms;
       if (escaped == 0) {
         *ms_out = total_ms;
         *iters_out = iters;
@@ -1201,6 +1208,9 @@ int run_main_loop_t(loikb_solver_impl* S)
     S->stats.kernel_ms += C.stats.kernel_ms;
     S->stats.tail_instance_iterations += C.stats.tail_instance_iterations;
     S->stats.tail_launches += C.stats.tail_launches;
+    S->stats.lean_launches += C.stats.lean_launches;
+    S->stats.lean_escaped += C.stats.lean_escaped;
+    S->stats.hslots_ms += C.stats.hslots_ms;
     S->stats.team = C.stats.team;
   }
   S->stats.chunks = nchunks;
@@ -1443,6 +1453,7 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
       S->chunks.push_back(C);
     }
     for (Chunk& C : S->chunks) {
+      HIPTRY(hipEventCreate(&C.ev_k2));
       HIPTRY(hipEventCreate(&C.ev_k0));
       HIPTRY(hipEventCreate(&C.ev_k1));
       HIPTRY(hipHostMalloc((void**)&C.h_counters, 8 * sizeof(unsigned int)));
@@ -1501,6 +1512,7 @@ int loikb_destroy(loikb_solver* S)
     if (C.h_counters) (void)hipHostFree(C.h_counters);
     if (C.d_hslots) (void)hipFree(C.d_hslots);
     if (C.ev_k0) (void)hipEventDestroy(C.ev_k0);
+    if (C.ev_k2) (void)hipEventDestroy(C.ev_k2);
     if (C.ev_k1) (void)hipEventDestroy(C.ev_k1);
     if (C.own_stream && C.stream) (void)hipStreamDestroy(C.stream);
   }

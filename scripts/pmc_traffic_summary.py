@@ -7,7 +7,8 @@ def load(path, counter):
         if row["Counter_Name"] != counter:
             continue
         name = row["Kernel_Name"]
-        key = "k_solve" if "k_solve" in name else "k_tail" if "k_tail" in name else "k_move" if "k_move" in name else None
+        key = ("k_solve" if "k_solve" in name else "k_tail" if "k_tail" in name else "k_move" if "k_move" in name else
+               "k_lean" if "k_lean" in name else "k_hslots" if "k_hslots" in name else None)
         if key:
             tot[key] += float(row["Counter_Value"]); n[key] += 1
     return tot, n

@@ -1,0 +1,91 @@
+"""The same solves through every execution path of the library: the lean tail kernel (default for fp64 batches: two
+wavefronts per SIMD, decade slots of H precomputed), the one-wavefront-per-SIMD tail kernel (LOIKB_LEAN=0), the solve
+kernel alone (tail_max_instances < 0), the hybrid of solve kernel and tail kernel, and the lean kernel with too few
+precomputed decades (instances "escape" and are finished by the other tail kernel).  All must agree with the oracle."""
+import numpy as np
+import pytest
+
+import loik_amd
+from helpers import FIXTURE, assert_close, feasible_batch, problem_args, random_tree
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+
+ENGINES = {
+    "lean": (dict(), dict()),
+    "tail": (dict(LOIKB_LEAN="0"), dict(tail_max_instances=1 << 20)),
+    "solve": (dict(), dict(tail_max_instances=-1)),
+    "hybrid": (dict(LOIKB_LEAN="0"), dict(tail_max_instances=120, max_launch_iters=2)),
+    "hybrid_lean": (dict(), dict(tail_max_instances=120, max_launch_iters=2)),
+    "lean_escapes": (dict(LOIKB_LEAN_KLO="0", LOIKB_LEAN_DECADES="2"), dict()),
+}
+FIELDS = ["nu", "z", "w", "vis", "fis", "g", "yis", "Aty", "Stf_plus_w", "primal_residual_vec", "dual_residual_vec"]
+SCALARS = ["primal_residual", "dual_residual", "primal_residual_task", "primal_residual_slack", "dual_residual_v",
+           "dual_residual_nu", "mu", "delta_fis_inf_norm", "delta_yis_inf_norm", "delta_w_inf_norm", "delta_vis_inf_norm",
+           "delta_nu_inf_norm", "Av_inf_norm", "nu_inf_norm", "Href_v_inf_norm", "g_inf_norm", "Stf_plus_w_inf_norm",
+           "tol_primal", "tol_dual"]
+
+
+def _solver(model, B, prm, engine, monkeypatch):
+    env, kw = ENGINES[engine]
+    for k in ("LOIKB_LEAN", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    return loik_amd.BatchedLoik(model, B, **prm, **kw)
+
+
+@pytest.mark.parametrize("engine", list(ENGINES))
+@pytest.mark.parametrize("which", ["talos", "tree"])
+def test_every_engine_matches_the_oracle(which, engine, request, monkeypatch):
+    model = random_tree(6, 21) if which == "tree" else request.getfixturevalue("talos")
+    link = model.njoints - 1 if which == "tree" else model.getJointId("arm_left_7_joint")
+    B = 200
+    wl = feasible_batch(model, B, link, 91, nu_scale=0.5)
+    args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    for k in (1, 2, 5, 12):
+        prm = dict(FIXTURE, max_iter=k + 1, tol_abs=0.0, tol_rel=1e-30, tol_primal_inf=0.0)
+        s = _solver(model, B, prm, engine, monkeypatch)
+        s.Solve(*args)
+        got = {n: s.get(n) for n in FIELDS + SCALARS}
+        got["His"] = s.His_full()
+        assert np.all(s.get("iter") == k)
+        for b in range(0, B, 23):
+            r = ref.RefSolver(model, **prm)
+            r.Solve(*problem_args(wl, b))
+            for n in FIELDS:
+                want = r.field(n)
+                if n in ("vis", "fis", "g"):
+                    want = want[1:]
+                assert_close(got[n][b], want, 1e-9, "%s b%d k%d %s" % (n, b, k, engine))
+            assert_close(got["His"][b], r.His[1:], 1e-9, "His")
+            for n in SCALARS:
+                assert_close(got[n][b], r.scalar(n), 1e-9, "%s b%d k%d %s" % (n, b, k, engine))
+        s.close()
+    prm = dict(FIXTURE, max_iter=500, tol_abs=1e-6, tol_rel=0.0)
+    out = ref.solve_batch(model, *args[:4], wl["Ais"], wl["bis"], wl["lb"], wl["ub"], nthreads=4, want_nu=True, **prm)
+    s = _solver(model, B, prm, engine, monkeypatch)
+    s.Solve(*args)
+    st = s.stats()
+    if engine == "lean":
+        assert st["lean_launches"] == 1 and st["lean_escaped"] == 0 and st["tail_instances"] == B
+    if engine in ("tail", "hybrid"):
+        assert st["lean_launches"] == 0 and st["tail_instances"] > 0
+    if engine == "solve":
+        assert st["tail_instances"] == 0
+    if engine == "hybrid_lean":
+        assert st["lean_launches"] == 1 and 0 < st["tail_instances"] < B
+    if engine == "lean_escapes":
+        assert st["lean_launches"] == 1 and st["lean_escaped"] > 0, st
+    it = s.get("iter")
+    same = it == out["iters"]
+    assert same.mean() >= 0.97, (engine, it[~same], out["iters"][~same])
+    assert np.array_equal(s.get("converged").astype(bool)[same], out["converged"][same])
+    assert np.array_equal(s.get("primal_infeasible").astype(bool)[same], out["primal_infeasible"][same])
+    assert np.max(np.abs(s.get("z") - out["z"])[same]) < 1e-8
+    assert np.max(np.abs(s.get("nu") - out["nu"])[same]) < 1e-8
+    # the residuals the getters report are those of the last iteration of every instance
+    pr, du = s.get("primal_residual"), s.get("dual_residual")
+    assert np.all(np.abs(pr - out["primal_residual"])[same] <= 1e-9 + 1e-6 * np.abs(out["primal_residual"][same]))
+    assert np.all(np.abs(du - out["dual_residual"])[same] <= 1e-9 + 1e-6 * np.abs(out["dual_residual"][same]))
+    s.close()
