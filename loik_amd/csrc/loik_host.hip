@@ -878,7 +878,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     // decades of mu with precomputed slots: mu0 * 10^(kexp_lo .. kexp_lo + ndec - 1).  The DEFAULT rule moves mu up from
     // mu0 in the first iterations and then mostly oscillates between two or three decades (Talos workload: 0..7 seen,
     // < 0 never); an instance that leaves the range is finished by k_tail.
-    int ndec = 10, kexp_lo = -2;
+    int ndec = 10, kexp_lo = -2;  // (the table is built as a pipeline over the tree levels: a decade more costs one step)
     if (const char* e = getenv("LOIKB_LEAN_DECADES")) ndec = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("LOIKB_LEAN_KLO")) kexp_lo = atoi(e);
     const size_t wave_lds = lean_lds_bytes<T>(S->nc, G);

@@ -41,10 +41,13 @@ __host__ __device__ __forceinline__ size_t lean_lds_bytes(int nc, int G)
   return ((((size_t)XROWS * LXS + (size_t)WAVE * LHS + (size_t)(WAVE / G) * ((size_t)nc * CD + ISC)) * sizeof(T)) + 15) & ~(size_t)15;
 }
 
-// pair k of lane j of the decade slot (list position idx, decade d): lanes of a group read consecutive 16-byte pairs
+// pair k of lane j of the decade slot (list position idx, decade d).  The 14 pairs of a joint are contiguous (224 B):
+// the builder writes a joint's slot from the few lanes that sit at one tree level at a time -- with the pairs of
+// different joints interleaved every store touched a quarter of a 64-byte line (4.2 ms for the headline's table,
+// write-bound); whole lines per lane bring it to the cost of the arithmetic.
 __device__ __forceinline__ size_t hslot_pair(int idx, int ndec, int dsl, int G, int k, int jlane)
 {
-  return (((size_t)idx * ndec + dsl) * HSLOT_PAIRS + k) * G + jlane;
+  return (((size_t)idx * ndec + dsl) * G + jlane) * HSLOT_PAIRS + k;
 }
 
 // fold 12 columns of the group's exchange rows (columns < nmax: max, the others: sum in lane order) into isc[IS_RED..]
@@ -620,61 +623,69 @@ k_hslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
                                         : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
   }
   typename Vec2<T>::type* hp = reinterpret_cast<typename Vec2<T>::type*>(hslots);
-  T mu = P.mu0;
+  T mu = P.mu0;  // mu of this lane's NEXT decade: mu0 * 10^kexp_lo, then x10 per decade
   for (int k = 0; k < kexp_lo; ++k) mu *= T(10);
   for (int k = 0; k > kexp_lo; --k) mu *= T(0.1);
-  for (int dsl = 0; dsl < ndec; ++dsl) {
-    const T mu_eq = P.mu_scale * mu, mu_in = mu;
-    T hh[21];
+  // The decades travel up the tree as a pipeline: at step s the joints of depth l work on decade s - (maxdepth - l), so
+  // every level is busy at once (on different decades) and the whole table costs maxdepth + ndec - 1 steps instead of
+  // maxdepth * ndec.  A parent reads at step s what its children wrote at step s - 1: the same decade.
+  const int lag = maxdepth - depth;
+  for (int st = 0; st < maxdepth + ndec - 1; ++st) {
+    const int dsl = st - lag;
+    const bool on = isj && depth > 0 && dsl >= 0 && dsl < ndec;
+    T part[21];
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
+    for (int k = 0; k < 21; ++k) part[k] = T(0);
+    if (on) {
+      const T mu_eq = P.mu_scale * mu, mu_in = mu;
+      T hh[21];
 #pragma unroll
-      for (int b2 = a; b2 < 6; ++b2)
-        hh[sym(a, b2)] = mass * ((a == b2 ? P.rho : T(0)) + ((HDIAG && a != b2) ? T(0) : P.Href[6 * a + b2]));
+      for (int a = 0; a < 6; ++a)
 #pragma unroll
-    for (int k = 0; k < 21; ++k) hh[k] += mu_eq * ata[k];
-    for (int lev = maxdepth; lev >= 1; --lev) {
-      if (isj && depth == lev) {
-        for (int c = 0; c < tp.nchild; ++c) {
-          const T* x = xch + (gbase + child_list[tp.child_start + c]) * HX;
+        for (int b2 = a; b2 < 6; ++b2)
+          hh[sym(a, b2)] = mass * ((a == b2 ? P.rho : T(0)) + ((HDIAG && a != b2) ? T(0) : P.Href[6 * a + b2]));
 #pragma unroll
-          for (int k = 0; k < 21; ++k) hh[k] += x[k];
-        }
-        T U[6], UD[6];
-        T dinv;
-        if (rev) {
+      for (int k = 0; k < 21; ++k) hh[k] += mu_eq * ata[k];
+      for (int c = 0; c < tp.nchild; ++c) {
+        const T* x = xch + (gbase + child_list[tp.child_start + c]) * HX;
 #pragma unroll
-          for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 3)] * ax0 + hh[sym(k, 4)] * ax1 + hh[sym(k, 5)] * ax2;
-          dinv = T(1) / ((ax0 * U[3] + ax1 * U[4] + ax2 * U[5]) + mu_in);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 0)] * ax0 + hh[sym(k, 1)] * ax1 + hh[sym(k, 2)] * ax2;
-          dinv = T(1) / ((ax0 * U[0] + ax1 * U[1] + ax2 * U[2]) + mu_in);
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) UD[k] = U[k] * dinv;
-        // the slot: H (pre-projection), Dinv, UDinv
-#pragma unroll
-        for (int k = 0; k < 10; ++k) hp[hslot_pair(idx, ndec, dsl, G, k, jlane)] = typename Vec2<T>::type{hh[2 * k], hh[2 * k + 1]};
-        hp[hslot_pair(idx, ndec, dsl, G, 10, jlane)] = typename Vec2<T>::type{hh[20], dinv};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) hp[hslot_pair(idx, ndec, dsl, G, 11 + k, jlane)] = typename Vec2<T>::type{UD[2 * k], UD[2 * k + 1]};
-        if (has_parent) {
-          T part[21];
-#pragma unroll
-          for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b2 = a; b2 < 6; ++b2) hh[sym(a, b2)] -= UD[a] * U[b2];
-          congr_sym(R, t, hh, part);
-          T* x = xch + lane * HX;
-#pragma unroll
-          for (int k = 0; k < 21; ++k) x[k] = part[k];
-        }
+        for (int k = 0; k < 21; ++k) hh[k] += x[k];
       }
-      tail_sync();
+      T U[6], UD[6];
+      T dinv;
+      if (rev) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 3)] * ax0 + hh[sym(k, 4)] * ax1 + hh[sym(k, 5)] * ax2;
+        dinv = T(1) / ((ax0 * U[3] + ax1 * U[4] + ax2 * U[5]) + mu_in);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 0)] * ax0 + hh[sym(k, 1)] * ax1 + hh[sym(k, 2)] * ax2;
+        dinv = T(1) / ((ax0 * U[0] + ax1 * U[1] + ax2 * U[2]) + mu_in);
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) UD[k] = U[k] * dinv;
+      // the slot: H (pre-projection), Dinv, UDinv
+#pragma unroll
+      for (int k = 0; k < 10; ++k) hp[hslot_pair(idx, ndec, dsl, G, k, jlane)] = typename Vec2<T>::type{hh[2 * k], hh[2 * k + 1]};
+      hp[hslot_pair(idx, ndec, dsl, G, 10, jlane)] = typename Vec2<T>::type{hh[20], dinv};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) hp[hslot_pair(idx, ndec, dsl, G, 11 + k, jlane)] = typename Vec2<T>::type{UD[2 * k], UD[2 * k + 1]};
+      if (has_parent) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b2 = a; b2 < 6; ++b2) hh[sym(a, b2)] -= UD[a] * U[b2];
+        congr_sym(R, t, hh, part);
+      }
+      mu *= T(10);
+    }
+    tail_sync();  // every lane has read its children's rows of the previous step
+    if (on && has_parent) {
+      T* x = xch + lane * HX;
+#pragma unroll
+      for (int k = 0; k < 21; ++k) x[k] = part[k];
     }
     tail_sync();
-    mu *= T(10);
   }
 }
 
