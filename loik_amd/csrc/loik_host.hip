@@ -884,7 +884,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     const size_t wave_lds = lean_lds_bytes<T>(S->nc, G);
     bool lean_ok = lean_applicable(S) && (P.mode & MODE_CACHE_H) && !(P.mode & MODE_FIXED_ITERS) && n >= 64;
     if (lean_ok) {
-      const size_t need = (size_t)n * ndec * HSLOT_PAIRS * G * 2 * sizeof(T);
+      // (indexed by the instance's slot in the set, so that relaunches with shorter lists find their slots again)
+      const size_t need = (size_t)n_cur * ndec * HSLOT_PAIRS * G * 2 * sizeof(T);
       if (need > C->hslots_bytes) {
         if (C->d_hslots) HIPCHK(hipFree(C->d_hslots));
         C->d_hslots = nullptr; C->hslots_bytes = 0;
@@ -903,66 +904,89 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       }
-      P.max_launch_iters = S->opt.max_iter + 1;
-      const int wg_needed = (n + ipw * TAIL_WAVES - 1) / (ipw * TAIL_WAVES);
-      const dim3 grid((unsigned)std::min(wg_needed, 2 * std::max(1, (int)(S->ncu * ((double)C->B / (double)S->B) + 0.5))));
-      const dim3 hgrid((unsigned)((n + ipw - 1) / ipw));
-      const size_t hlds = (size_t)(WAVE + 1) * 22 * sizeof(T);
-      HIPCHK(hipMemsetAsync(C->d_counters, 0, 8 * sizeof(unsigned int), C->stream));
+      int wg_per_cu = 2;
+      if (const char* e = getenv("LOIKB_LEAN_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
+      const int wg_cap = wg_per_cu * std::max(1, (int)(S->ncu * ((double)C->B / (double)S->B) + 0.5));
+      // Optional rounds with a bounded share of iterations per instance (LOIKB_LEAN_QUANTA="24,64,160,400"; default: one
+      // launch).  Iteration counts are heavy-tailed and unpredictable: in one launch the work queue drains after ~60 % of
+      // the launch time and the rest is waiting for long runners that were fetched late.  Bounded rounds make every long
+      // runner advance from the start -- but it then only advances `quantum` iterations per round, i.e. it shares the
+      // machine instead of running flat out from an early start.  Measured: Talos headline (1.2 % of the instances run
+      // all 1000 iterations) 22.85 -> 21.99 ms, B = 131072 36.9 -> 36.2 ms; floating-base Talos (a handful of long runners)
+      // 36.5 -> 44.1 ms.  Not a default.
+      std::vector<int> quanta;
+      if (const char* e = getenv("LOIKB_LEAN_QUANTA")) {
+        quanta.clear();
+        for (const char* p = e; *p;) { quanta.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+      }
+      quanta.push_back(S->opt.max_iter + 1);
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
-      if (S->href_diag) {
-        hipLaunchKernelGGL((k_hslots<T, true>), hgrid, dim3(WAVE), hlds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
-                           (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
-                           (T*)C->d_hslots, kexp_lo, ndec);
-        HIPCHK(hipEventRecord(C->ev_k2, C->stream));
-        hipLaunchKernelGGL((k_lean<T, true>), grid, dim3(WAVE * TAIL_WAVES), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
-                           (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
-                           (const T*)C->d_hslots, kexp_lo, ndec);
-      } else {
-        hipLaunchKernelGGL((k_hslots<T, false>), hgrid, dim3(WAVE), hlds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
-                           (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
-                           (T*)C->d_hslots, kexp_lo, ndec);
-        HIPCHK(hipEventRecord(C->ev_k2, C->stream));
-        hipLaunchKernelGGL((k_lean<T, false>), grid, dim3(WAVE * TAIL_WAVES), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
-                           (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
-                           (const T*)C->d_hslots, kexp_lo, ndec);
+      float t_first = -1.f;
+      unsigned int escaped = 0;
+      bool slots_built = false, first_timed = false;
+      for (size_t round = 0; round < quanta.size() && n > 0; ++round) {
+        if (quanta[round] <= 0) continue;
+        P.max_launch_iters = quanta[round];
+        const int wg_needed = (n + ipw * TAIL_WAVES - 1) / (ipw * TAIL_WAVES);
+        const dim3 grid((unsigned)std::min(wg_needed, wg_cap));
+        HIPCHK(hipMemsetAsync(C->d_counters, 0, 8 * sizeof(unsigned int), C->stream));
+        if (!slots_built) {
+          slots_built = true;
+          const dim3 hgrid((unsigned)((n + ipw - 1) / ipw));
+          const size_t hlds = (size_t)(WAVE + 1) * 22 * sizeof(T);
+          if (S->href_diag)
+            hipLaunchKernelGGL((k_hslots<T, true>), hgrid, dim3(WAVE), hlds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                               (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
+                               (T*)C->d_hslots, kexp_lo, ndec);
+          else
+            hipLaunchKernelGGL((k_hslots<T, false>), hgrid, dim3(WAVE), hlds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                               (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
+                               (T*)C->d_hslots, kexp_lo, ndec);
+          HIPCHK(hipEventRecord(C->ev_k2, C->stream));
+        }
+        if (S->href_diag)
+          hipLaunchKernelGGL((k_lean<T, true>), grid, dim3(WAVE * TAIL_WAVES), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                             (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
+                             (const T*)C->d_hslots, kexp_lo, ndec);
+        else
+          hipLaunchKernelGGL((k_lean<T, false>), grid, dim3(WAVE * TAIL_WAVES), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                             (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
+                             (const T*)C->d_hslots, kexp_lo, ndec);
+        HIPCHK(hipGetLastError());
+        // the instances that are still iterating: the next round's list (ping-pong between the two list buffers)
+        int* next = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
+        hipLaunchKernelGGL(k_list_unfinished<T>, grid1(n), dim3(256), 0, C->stream, A.tiles, S->L, list, n, next, C->d_counters + 3);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(C->ev_k1, C->stream));
+        HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+        HIPCHK(hipStreamSynchronize(C->stream));
+        float ms = 0.f, t0 = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));  // since the start of the first round
+        if (t_first < 0.f) { HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0)); t_first = t0; }
+        iters += C->h_counters[1];
+        escaped = C->h_counters[2];
+        if (!first_timed) {
+          first_timed = true;
+          float hms = 0.f;
+          HIPCHK(hipEventElapsedTime(&hms, C->ev_k0, C->ev_k2));
+          C->stats.hslots_ms += hms;
+        }
+        if (trace)
+          fprintf(stderr, "[loikb] lean tail round %zu (<= %d iterations each): %6d instances on %u workgroups, done at %8.3f ms"
+                          "  inst-iters %9u  wave-iters %7u slot loads %7u  escaped %u  still iterating %u\n",
+                  round, quanta[round], n, grid.x, ms, C->h_counters[1], C->h_counters[5], C->h_counters[6], escaped,
+                  C->h_counters[3]);
+        C->stats.launches++;
+        C->stats.tail_launches++;
+        C->stats.lean_launches++;
+        total_ms = ms;
+        n = (int)C->h_counters[3];
+        list = next;
       }
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipEventRecord(C->ev_k1, C->stream));
-      HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
-      HIPCHK(hipStreamSynchronize(C->stream));
-      float ms = 0.f, t0 = 0.f;
-      HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));
-      HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0));
-      C->tail_iv.emplace_back(t0, t0 + ms);
-      total_ms += ms;
-      iters += C->h_counters[1];
-      const unsigned int escaped = C->h_counters[2];
-      float hms = 0.f;
-      HIPCHK(hipEventElapsedTime(&hms, C->ev_k0, C->ev_k2));
-      if (trace)
-        fprintf(stderr, "[loikb] lean tail launch: %6d instances on %u workgroups  %8.3f ms (decade slots %.3f ms)  inst-iters %9u"
-                        " (%.1f M/s)  wave-iters %7u slot loads %7u  escaped %u\n",
-                n, grid.x, ms, hms, C->h_counters[1], C->h_counters[1] / ms / 1e3, C->h_counters[5], C->h_counters[6], escaped);
-      C->stats.launches++;
-      C->stats.tail_launches++;
-      C->stats.lean_launches++;
+      C->tail_iv.emplace_back(t_first, t_first + (float)total_ms);
       C->stats.lean_escaped += (int)escaped;
-      C->stats.hslots_ms += hms;
-      if (escaped == 0) {
-        *ms_out = total_ms;
-        *iters_out = iters;
-        return LOIKB_OK;
-      }
-      // the survivors, for k_tail
-      HIPCHK(hipMemsetAsync(C->d_counters, 0, 8 * sizeof(unsigned int), C->stream));
-      hipLaunchKernelGGL(k_list_unfinished<T>, grid1(n), dim3(256), 0, C->stream, A.tiles, S->L, list, n, C->d_slots2, C->d_counters + 3);
-      HIPCHK(hipGetLastError());
-      HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
-      HIPCHK(hipStreamSynchronize(C->stream));
-      n = (int)C->h_counters[3];
-      list = C->d_slots2;
       if (n == 0) { *ms_out = total_ms; *iters_out = iters; return LOIKB_OK; }
+      // what is left escaped the precomputed decades: k_tail below finishes it
     }
   }
   {

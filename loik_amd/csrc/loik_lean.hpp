@@ -123,6 +123,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   const bool rev = d.flags & JF_REVOLUTE;
   const T mass = (d.flags & JF_MASSLESS) ? T(0) : T(1);
   const bool has_parent = !(d.flags & JF_PARENT_ROOT);
+  const int depth = isj_lane ? tp.depth : 0;
   constexpr int NCH_REG = 4;
   int chl[NCH_REG];
 #pragma unroll
@@ -134,7 +135,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   if (lane < LXS) xch[WAVE * LXS + lane] = T(0);
 
   bool has_inst = false, isj = false, done = true, any_iter = false;
-  int lidx = 0;
+  int lidx = 0;  // the instance's slot in the set: also the index of its decade slots
   char *ip = Bf.tiles, *rec = Bf.tiles;
   T R[9], t[3], v[6], f[6], g[6], UD[6], p[6];
   T w = T(0), z = T(0), nu = T(0), s = T(0), r = T(0), dinv = T(0), lbi = T(0), ubi = T(0), mu = T(1);
@@ -150,8 +151,8 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   auto load_instance = [&](int idx) {
     has_inst = idx < nslots;
     isj = has_inst && isj_lane;
-    lidx = has_inst ? idx : 0;
-    const int slot = slots[lidx];
+    const int slot = slots[has_inst ? idx : 0];
+    lidx = slot;
     ip = lane_ptr<T>(Bf.tiles, L, slot);
     rec = ip + (size_t)jl * JREC * pair_bytes<T>();
     const char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
@@ -273,8 +274,15 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   };
 
   load_instance(fetch());
+#ifdef LOIKB_TAIL_PROF
+  unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
+  const unsigned long long wall0_ = wall_clock64(), clk0_ = tprev_;
+#endif
   while (__any(!done || has_inst)) {
     // ---- decade slot of the current mu (H_i, Dinv_i, UDinv_i) -------------------------------------------------------
+    if (!done && (int)my_iters >= P.max_launch_iters) {
+      done = true;  // this launch's share of iterations is used up: back to the list, the host relaunches (run_tail)
+    }
     if (!done && kexp != kslot) {
       const int dsl = kexp - kexp_lo;
       if (dsl < 0 || dsl >= ndec) {
@@ -322,6 +330,23 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         for (int k = 0; k < 6; ++k) p[k] += c_[CD_ATY + k] - mu_eq * c_[CD_ATB + k];
       }
     }
+    TAIL_TP(0)
+#ifdef LEAN_MASKED_LEVELS
+    for (int lev = maxdepth; lev >= 1; --lev) {
+      if (act && depth == lev) {
+        lean_gather_n<T>(maxchild, xch, chl, LXA, p);
+        const T Stp = dot6_halves(Sv, p);
+        r = (w - mu_in * z) + Stp;
+        T pa[6], pc[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) pa[k] = p[k] - UD[k] * r;
+        act_force(R, t, pa, pc);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xch[lane * LXS + LXA + k] = pc[k];
+      }
+      tail_sync();
+    }
+#else
     {
       T pl[6], rl = T(0);
 #pragma unroll
@@ -348,10 +373,29 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       }
     }
 
+#endif
+    TAIL_TP(1)
     // ================= root -> leaf: FwdPass2 (hxx:102-163) ==============================================================
     T vi[6], nui = T(0);
 #pragma unroll
     for (int k = 0; k < 6; ++k) vi[k] = T(0);
+#ifdef LEAN_MASKED_LEVELS
+    for (int lev = 1; lev <= maxdepth; ++lev) {
+      if (depth == lev) {
+        T vpar[6], vp[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vpar[k] = xch[prow * LXS + LXB + k];
+        actinv_motion(R, t, vpar, vp);
+        const T udv = dot6_halves(UD, vp);
+        nui = -udv - dinv * r;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vi[k] = vp[k] + Sv[k] * nui;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xch[lane * LXS + LXB + k] = vi[k];
+      }
+      tail_sync();
+    }
+#else
     for (int lev = 1; lev <= maxdepth; ++lev) {
       T vpar[6], vp[6];
 #pragma unroll
@@ -366,6 +410,8 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       for (int k = 0; k < 6; ++k) xch[lane * LXS + LXB + k] = vi[k];
       tail_sync();
     }
+#endif
+    TAIL_TP(2)
     // per-lane norms of this iteration (folded over the group below)
     T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_dyis = T(0),
       l_av = T(0), l_prt = T(0), l_prs = T(0), l_up = T(0), l_lm = T(0);
@@ -407,6 +453,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
       for (int k = 0; k < 6; ++k) { v[k] = vi[k]; f[k] = fi[k]; }
     }
+    TAIL_TP(3)
     // DualUpdate of the task constraints (hxx:410-451), six lanes of the group
     for (int c = 0; c < L.nc; ++c) {
       T* c_ = cdi + c * CD;
@@ -438,6 +485,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       tail_sync();
     }
 
+    TAIL_TP(4)
     // ================= BwdPass2 + dual residual (hxx:185-241, :468-487) =================================================
     T l_dg = T(0), l_g = T(0), l_dualv = T(0), l_stf = T(0), l_dstf = T(0);
     {
@@ -477,6 +525,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     }
     tail_sync();
 
+    TAIL_TP(5)
     // ================= the ten scalars the stopping logic needs, folded over the group ================================
     {
       T* row = xch + lane * LXS;
@@ -487,6 +536,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     tail_sync();
     lean_fold<T>(xch, isc, gbase, jlane, G, 10, 8);
     tail_sync();
+    TAIL_TP(6)
     bool finishing = false;
     if (act) {
       const T primal = isc[IS_RED + 0], dual = isc[IS_RED + 1], dx = isc[IS_RED + 2], dz = isc[IS_RED + 3];
@@ -569,7 +619,16 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       store_instance();
       load_instance(fetch());
     }
+    TAIL_TP(7)
   }
+#ifdef LOIKB_TAIL_PROF
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int k = 0; k < 8; ++k) g_tail_prof[k] = prof_[k];
+    g_tail_prof[8] = n_wave_iters;
+    // shader clock in kHz: clock64 ticks per wall_clock64 tick (100 MHz)
+    g_tail_prof[9] = (clock64() - clk0_) * 100000ull / (wall_clock64() - wall0_ + 1);
+  }
+#endif
   if (lane == 0) {
     atomicAdd(&Bf.counters[5], n_wave_iters);
     atomicAdd(&Bf.counters[6], n_slot_loads);
@@ -606,6 +665,7 @@ k_hslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
   const bool has_parent = !(d.flags & JF_PARENT_ROOT);
   const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
   const int slot = slots[has_inst ? idx : 0];
+  const int sidx = slot;  // decade slots are indexed by the instance's slot in the set
   char* ip = lane_ptr<T>(Bf.tiles, L, slot);
   const char* rec = ip + (size_t)jl * JREC * pair_bytes<T>();
   T R[9], t[3];
@@ -666,10 +726,10 @@ k_hslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
       for (int k = 0; k < 6; ++k) UD[k] = U[k] * dinv;
       // the slot: H (pre-projection), Dinv, UDinv
 #pragma unroll
-      for (int k = 0; k < 10; ++k) hp[hslot_pair(idx, ndec, dsl, G, k, jlane)] = typename Vec2<T>::type{hh[2 * k], hh[2 * k + 1]};
-      hp[hslot_pair(idx, ndec, dsl, G, 10, jlane)] = typename Vec2<T>::type{hh[20], dinv};
+      for (int k = 0; k < 10; ++k) hp[hslot_pair(sidx, ndec, dsl, G, k, jlane)] = typename Vec2<T>::type{hh[2 * k], hh[2 * k + 1]};
+      hp[hslot_pair(sidx, ndec, dsl, G, 10, jlane)] = typename Vec2<T>::type{hh[20], dinv};
 #pragma unroll
-      for (int k = 0; k < 3; ++k) hp[hslot_pair(idx, ndec, dsl, G, 11 + k, jlane)] = typename Vec2<T>::type{UD[2 * k], UD[2 * k + 1]};
+      for (int k = 0; k < 3; ++k) hp[hslot_pair(sidx, ndec, dsl, G, 11 + k, jlane)] = typename Vec2<T>::type{UD[2 * k], UD[2 * k + 1]};
       if (has_parent) {
 #pragma unroll
         for (int a = 0; a < 6; ++a)
