@@ -92,7 +92,9 @@ typedef struct loikb_options {
   int max_launch_iters; /* ADMM iterations per kernel launch, 0 = automatic                    */
   int compact_min_instances; /* stop compacting below this many slots, 0 = default (4096)     */
   int tail_max_instances;    /* hand the last N live instances to the cooperative tail kernel (one wavefront per
-                                instance): 0 = default (32768), < 0 = never                   */
+                                instance): 0 = default (2^20 when the lean tail kernel applies
+                                -- fp64, stopping logic on, <= 1 task constraint: whole batches run in it --, else
+                                32768), < 0 = never                                           */
 } loikb_options;
 
 typedef struct loikb_solver loikb_solver;
