@@ -815,13 +815,13 @@ int compact(loikb_solver_impl* S, Chunk* C, int src, int dst, int n_src, int* n_
 // finish the remaining live instances of set `cur` (n_cur slots, n_live of them live) with the cooperative tail
 // kernel (a lane group per instance, one joint per lane)
 // Can the stragglers / small batches of this solver run in the lean tail kernel (two wavefronts per SIMD, loik_lean.hpp)?
-// fp64, adaptive stopping logic, H cache on, one joint per lane, at most 4 children per joint, and an LDS footprint that
+// fp64, H cache on, one joint per lane, at most 4 children per joint, and an LDS footprint that
 // lets two 4-wavefront workgroups share a CU.  LOIKB_LEAN=0 switches it off.
 bool lean_applicable(const loikb_solver_impl* S)
 {
   if (const char* e = getenv("LOIKB_LEAN")) if (atoi(e) == 0) return false;
   if (S->f32 || S->nb > WAVE || S->maxchild > 4) return false;
-  if (S->opt.flags & (LOIKB_OPT_FIXED_ITERS | LOIKB_OPT_NO_H_CACHE)) return false;
+  if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) return false;
   int G = 8;
   while (G < S->nb) G <<= 1;
   return 2 * TAIL_WAVES * lean_lds_bytes<double>(S->nc, G) <= 160 * 1024;
@@ -882,7 +882,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     if (const char* e = getenv("LOIKB_LEAN_DECADES")) ndec = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("LOIKB_LEAN_KLO")) kexp_lo = atoi(e);
     const size_t wave_lds = lean_lds_bytes<T>(S->nc, G);
-    bool lean_ok = lean_applicable(S) && (P.mode & MODE_CACHE_H) && !(P.mode & MODE_FIXED_ITERS) && n >= 64;
+    bool lean_ok = lean_applicable(S) && (P.mode & MODE_CACHE_H) && n >= 64;
+    if (P.mode & MODE_FIXED_ITERS) { ndec = 1; kexp_lo = 0; }  // mu frozen at mu0: one decade
     if (lean_ok) {
       // (indexed by the instance's slot in the set, so that relaunches with shorter lists find their slots again)
       const size_t need = (size_t)n_cur * ndec * HSLOT_PAIRS * G * 2 * sizeof(T);
