@@ -815,12 +815,12 @@ int compact(loikb_solver_impl* S, Chunk* C, int src, int dst, int n_src, int* n_
 // finish the remaining live instances of set `cur` (n_cur slots, n_live of them live) with the cooperative tail
 // kernel (a lane group per instance, one joint per lane)
 // Can the stragglers / small batches of this solver run in the lean tail kernel (two wavefronts per SIMD, loik_lean.hpp)?
-// fp64, H cache on, one joint per lane, at most 4 children per joint, and an LDS footprint that
+// H cache on, one joint per lane, at most 4 children per joint, and an LDS footprint that
 // lets two 4-wavefront workgroups share a CU.  LOIKB_LEAN=0 switches it off.
 bool lean_applicable(const loikb_solver_impl* S)
 {
   if (const char* e = getenv("LOIKB_LEAN")) if (atoi(e) == 0) return false;
-  if (S->f32 || S->nb > WAVE || S->maxchild > 4) return false;
+  if (S->nb > WAVE || S->maxchild > 4) return false;
   if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) return false;
   int G = 8;
   while (G < S->nb) G <<= 1;
