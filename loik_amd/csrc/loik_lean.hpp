@@ -9,8 +9,10 @@
 //   * the H rebuild (the masked level loop that carries the 21 entries of H_i up the tree: ~150 registers on its own).
 //     H_i / Dinv_i / UDinv_i depend on q and mu only, and mu only ever moves by decades (UpdateMu, hxx:613-641):
 //     k_hslots below precomputes them for the decades mu0 * 10^(kexp_lo .. kexp_lo+ndec-1) into HBM "decade slots"
-//     before the lean launch; on a change of mu a lane fetches its 14 pairs.  An instance whose mu leaves the
-//     precomputed decades is written back unfinished ("escapes") and is finished by k_tail.
+//     (indexed by the instance's slot in the tile set, 224 contiguous bytes per joint and decade) before the lean
+//     launch; on a change of mu a lane fetches its 14 pairs.  An instance whose mu leaves the precomputed decades is
+//     written back unfinished ("escapes") and is finished by k_tail.  An instance can also be sent back after a
+//     bounded number of iterations (P.max_launch_iters: optional rounds, run_tail in loik_host.hip).
 //   * the second H slot in LDS and the 22 exchange columns the rebuild needs (22.5 -> 10.5 KB, 15.6 -> 7.1 KB)
 //   * the ~60 registers of per-instance scalars every lane carried redundantly (tolerances, the 14 norms kept for the
 //     getters, flags): they live once per instance in LDS; every lane reads what the epilogue needs.

@@ -9,7 +9,7 @@
 // (zero HBM traffic per iteration).  Only the two true recursions over the tree (p leaf -> root, (nu, v) root -> leaf)
 // are loops over the tree depth (Talos: 10 steps instead of 32 joint visits), and they are branch-free: every lane
 // recomputes its value from its children's / parent's exchange rows at every step.  Everything else is per-joint work
-// done once by all lanes; inf-norms and dot products are folded through LDS.  ~12.5 us per iteration.
+// done once by all lanes; inf-norms and dot products are folded through LDS.  ~10 us per iteration.
 // H_i / UDinv / Dinv are cached for the TWO most recent values of mu, so an instance whose penalty flips between
 // two decades (the typical straggler) does not repeat the H-recursion.
 // The live instances are handed out through an atomic queue: a group that finishes one takes the next.
@@ -17,6 +17,10 @@
 // The arithmetic per joint is the same as in loik_device.hpp (same helpers, same reference citations); only
 // the order in which children contributions / norm maxima are combined differs, so results agree with k_solve
 // and the CPU oracle to rounding (not bit for bit).  Used when nb <= 64.
+// loik_lean.hpp holds the variant of this kernel that runs two wavefronts per SIMD (the default engine for whole
+// batches); this one rebuilds H itself and serves what the lean kernel cannot: several task constraints, more than four
+// children per joint, LOIKB_OPT_NO_H_CACHE, fewer than 64 instances, and instances whose mu leaves the lean kernel's
+// precomputed decades.
 #pragma once
 
 #include "loik_device.hpp"
