@@ -30,7 +30,7 @@ constexpr int LXS = 14;  // scalars per exchange row: A = cols 0..5 (p messages 
                          // cols 0..11 once both exchanges of the iteration are over
 constexpr int LXA = 0, LXB = 6;
 constexpr int LHS = 21;  // H_i per lane (Dinv_i stays in a register)
-constexpr int HSLOT_PAIRS = 14;  // decade slot of a joint: H[21], Dinv, UDinv[6]
+constexpr int HSLOT_PAIRS = 11;  // decade slot of a joint: H[21], Dinv (UDinv = H S Dinv is recomputed by the reader: 21 % fewer bytes)
 // per-instance scalars in LDS (T each, integers included: they are small and exact)
 enum : int { IS_MU = 0, IS_KEXP, IS_ITER, IS_STATUS, IS_TAILIT, IS_C1, IS_C2, IS_NFLIP, IS_TOLP, IS_TOLD, IS_DYQP, IS_ATDY,
              IS_UBP, IS_LBM, IS_BNORM, IS_PRIMAL, IS_DUAL, IS_PRT, IS_PRS, IS_DUALV, IS_STF, IS_DX, IS_DZ, IS_DFIS,
@@ -43,7 +43,7 @@ __host__ __device__ __forceinline__ size_t lean_lds_bytes(int nc, int G)
   return ((((size_t)XROWS * LXS + (size_t)WAVE * LHS + (size_t)(WAVE / G) * ((size_t)nc * CD + ISC)) * sizeof(T)) + 15) & ~(size_t)15;
 }
 
-// pair k of lane j of the decade slot (list position idx, decade d).  The 14 pairs of a joint are contiguous (224 B):
+// pair k of lane j of the decade slot (instance slot idx, decade d).  The 11 pairs of a joint are contiguous (176 B):
 // the builder writes a joint's slot from the few lanes that sit at one tree level at a time -- with the pairs of
 // different joints interleaved every store touched a quarter of a 64-byte line (4.2 ms for the headline's table,
 // write-bound); whole lines per lane bring it to the cost of the arithmetic.
@@ -293,24 +293,30 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       } else {
         if (isj) {
           const typename Vec2<T>::type* hp = reinterpret_cast<const typename Vec2<T>::type*>(hslots);
-          // (in two halves: 28 doubles in flight at once would cost registers the level loops need)
+          // (in two parts: 22 doubles in flight at once would cost registers the level loops need)
           {
-            typename Vec2<T>::type in[7];
+            typename Vec2<T>::type in[6];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) in[k] = hp[hslot_pair(lidx, ndec, dsl, G, k, jlane)];
+            for (int k = 0; k < 6; ++k) in[k] = hp[hslot_pair(lidx, ndec, dsl, G, k, jlane)];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) { hcur[2 * k] = in[k].x; hcur[2 * k + 1] = in[k].y; }
+            for (int k = 0; k < 6; ++k) { hcur[2 * k] = in[k].x; hcur[2 * k + 1] = in[k].y; }
           }
           {
-            typename Vec2<T>::type in[7];
+            typename Vec2<T>::type in[5];
 #pragma unroll
-            for (int k = 0; k < 7; ++k) in[k] = hp[hslot_pair(lidx, ndec, dsl, G, 7 + k, jlane)];
+            for (int k = 0; k < 5; ++k) in[k] = hp[hslot_pair(lidx, ndec, dsl, G, 6 + k, jlane)];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { hcur[14 + 2 * k] = in[k].x; hcur[15 + 2 * k] = in[k].y; }
-            hcur[20] = in[3].x;
-            dinv = in[3].y;
+            for (int k = 0; k < 4; ++k) { hcur[12 + 2 * k] = in[k].x; hcur[13 + 2 * k] = in[k].y; }
+            hcur[20] = in[4].x;
+            dinv = in[4].y;
+          }
+          // UDinv = (H S) Dinv  (calc_aba, hxx:60-63) from the slot just written to LDS
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { UD[2 * k] = in[4 + k].x; UD[2 * k + 1] = in[4 + k].y; }
+          for (int k = 0; k < 6; ++k) {
+            T u = T(0);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) u += hcur[sym(k, j)] * Sv[j];
+            UD[k] = u * dinv;
           }
         }
         kslot = kexp;
@@ -730,8 +736,6 @@ k_hslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
 #pragma unroll
       for (int k = 0; k < 10; ++k) hp[hslot_pair(sidx, ndec, dsl, G, k, jlane)] = typename Vec2<T>::type{hh[2 * k], hh[2 * k + 1]};
       hp[hslot_pair(sidx, ndec, dsl, G, 10, jlane)] = typename Vec2<T>::type{hh[20], dinv};
-#pragma unroll
-      for (int k = 0; k < 3; ++k) hp[hslot_pair(sidx, ndec, dsl, G, 11 + k, jlane)] = typename Vec2<T>::type{UD[2 * k], UD[2 * k + 1]};
       if (has_parent) {
 #pragma unroll
         for (int a = 0; a < 6; ++a)
