@@ -824,7 +824,10 @@ bool lean_applicable(const loikb_solver_impl* S)
   if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) return false;
   int G = 8;
   while (G < S->nb) G <<= 1;
-  return 2 * TAIL_WAVES * lean_lds_bytes<double>(S->nc, G) <= 160 * 1024;
+  const size_t esz = S->f32 ? sizeof(float) : sizeof(double);  // (lean_lds_bytes<double> / 8 * esz, rounded the same way)
+  const size_t per_wave = S->f32 ? lean_lds_bytes<float>(S->nc, G, S->a_shared) : lean_lds_bytes<double>(S->nc, G, S->a_shared);
+  (void)esz;
+  return 2 * TAIL_WAVES * per_wave <= 160 * 1024;
 }
 
 template <typename T>
@@ -881,7 +884,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     int ndec = 10, kexp_lo = -2;  // (the table is built as a pipeline over the tree levels: a decade more costs one step)
     if (const char* e = getenv("LOIKB_LEAN_DECADES")) ndec = std::max(1, std::min(16, atoi(e)));
     if (const char* e = getenv("LOIKB_LEAN_KLO")) kexp_lo = atoi(e);
-    const size_t wave_lds = lean_lds_bytes<T>(S->nc, G);
+    const size_t wave_lds = lean_lds_bytes<T>(S->nc, G, S->a_shared);
     bool lean_ok = lean_applicable(S) && (P.mode & MODE_CACHE_H) && n >= 64;
     if (P.mode & MODE_FIXED_ITERS) { ndec = 1; kexp_lo = 0; }  // mu frozen at mu0: one decade
     if (lean_ok) {

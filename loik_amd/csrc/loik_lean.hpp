@@ -37,10 +37,17 @@ enum : int { IS_MU = 0, IS_KEXP, IS_ITER, IS_STATUS, IS_TAILIT, IS_C1, IS_C2, IS
              IS_DYIS, IS_DW, IS_DVIS, IS_DNU, IS_AV, IS_NU, IS_HREFV, IS_G, IS_TGIN, IS_STY, IS_MULAST,
              IS_RED /* results of the folds: 12 */, ISC = IS_RED + 12 };
 
+// constraint block of an instance in LDS: lane of the constrained joint, b, A^T b, y, A^T y (+ A when it is per instance;
+// a shared A is kept once per wavefront).  AtA is not needed: H is never rebuilt here.
+constexpr int LCD = 26, LCA = 36;
+enum : int { LC_PAD = 0, LC_B = 1, LC_ATB = 7, LC_Y = 13, LC_ATY = 19 };
+
 template <typename T>
-__host__ __device__ __forceinline__ size_t lean_lds_bytes(int nc, int G)
+__host__ __device__ __forceinline__ size_t lean_lds_bytes(int nc, int G, bool a_shared)
 {
-  return ((((size_t)XROWS * LXS + (size_t)WAVE * LHS + (size_t)(WAVE / G) * ((size_t)nc * CD + ISC)) * sizeof(T)) + 15) & ~(size_t)15;
+  const size_t per_inst = (size_t)nc * (LCD + (a_shared ? 0 : LCA)) + ISC;
+  return ((((size_t)XROWS * LXS + (size_t)WAVE * LHS + (a_shared ? (size_t)nc * LCA : 0) + (size_t)(WAVE / G) * per_inst) *
+           sizeof(T)) + 15) & ~(size_t)15;
 }
 
 // pair k of lane j of the decade slot (instance slot idx, decade d).  The 11 pairs of a joint are contiguous (176 B):
@@ -107,16 +114,19 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const size_t wave_lds = lean_lds_bytes<T>(L.nc, G);
+  const bool a_shared = P.mode & MODE_A_SHARED;
+  const int cs = LCD + (a_shared ? 0 : LCA);                // scalars per constraint block of an instance
+  const size_t wave_lds = lean_lds_bytes<T>(L.nc, G, a_shared);
   T* xch = reinterpret_cast<T*>(smem_raw + wv * wave_lds);  // [WAVE + 1][LXS]
   T* hst = xch + XROWS * LXS;                               // [WAVE][LHS]
-  T* cd = hst + WAVE * LHS;                                 // [64/G][nc][CD]
-  T* iscb = cd + (size_t)(WAVE / G) * L.nc * CD;            // [64/G][ISC]
+  T* ash = hst + WAVE * LHS;                                // [nc][36]        the shared A (if it is shared)
+  T* cd = ash + (a_shared ? L.nc * LCA : 0);                // [64/G][nc][cs]
+  T* iscb = cd + (size_t)(WAVE / G) * L.nc * cs;            // [64/G][ISC]
   const int lane = threadIdx.x & (WAVE - 1);
   const int sub = lane / G, jlane = lane % G, gbase = sub * G;
   const bool isj_lane = jlane < L.nb;
   const int jl = isj_lane ? jlane : 0;
-  T* cdi = cd + (size_t)sub * L.nc * CD;
+  T* cdi = cd + (size_t)sub * L.nc * cs;
   T* isc = iscb + (size_t)sub * ISC;
   T* hcur = hst + (size_t)lane * LHS;
 
@@ -135,6 +145,8 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
   for (int k = 0; k < 3; ++k) { Sv[k] = rev ? T(0) : (T)d.axis[k]; Sv[3 + k] = rev ? (T)d.axis[k] : T(0); }
   if (lane < LXS) xch[WAVE * LXS + lane] = T(0);
+  if (a_shared)
+    for (int e = lane; e < L.nc * LCA; e += WAVE) ash[e] = Bf.uni[e];
 
   bool has_inst = false, isj = false, done = true, any_iter = false;
   int lidx = 0;  // the instance's slot in the set: also the index of its decade slots
@@ -178,25 +190,22 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     }
     for (int c = 0; c < L.nc; ++c) {
       const char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
-      for (int e = jlane; e < CD; e += G) {
-        T val = T(0);
-        if (e < 36) {
-          val = (P.mode & MODE_A_SHARED) ? Bf.uni[c * 36 + e]
-                                         : *reinterpret_cast<const T*>(crec + (size_t)(CP_A + e / 2) * pair_bytes<T>() + (e & 1) * sizeof(T));
-        } else if (e < 57) {
-          const int q = e - 36;
-          val = (P.mode & MODE_A_SHARED) ? Bf.uni[L.nc * 36 + c * 21 + q]
-                                         : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + q / 2) * pair_bytes<T>() + (q & 1) * sizeof(T));
-        } else if (e >= CD_B) {
-          const int q = e - CD_B;
+      for (int e = jlane + 1; e < cs; e += G) {  // (entry 0: the lane of the constrained joint, set below)
+        T val;
+        if (e < LCD) {
+          const int q = e - 1;
+          if (q >= 24) continue;  // pad
           const int which = q / 6, k = q % 6;
           const int pair = which == 0 ? CP_B : which == 1 ? CP_ATB : which == 2 ? CP_Y : CP_ATY;
           val = *reinterpret_cast<const T*>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+        } else {
+          const int q = e - LCD;
+          val = *reinterpret_cast<const T*>(crec + (size_t)(CP_A + q / 2) * pair_bytes<T>() + (q & 1) * sizeof(T));
         }
-        if (e != CD_PAD) cdi[c * CD + e] = val;
+        cdi[c * cs + e] = val;
       }
     }
-    if (isj_lane && d.cslot >= 0) cdi[d.cslot * CD + CD_PAD] = (T)jlane;
+    if (isj_lane && d.cslot >= 0) cdi[d.cslot * cs + LC_PAD] = (T)jlane;
     const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
     mu = mu2.x;
     kexp = (int)mu2.y;
@@ -240,8 +249,8 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
         if (jlane < 6) {
           const int k = jlane;
-          *reinterpret_cast<T*>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * CD + CD_Y + k];
-          *reinterpret_cast<T*>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * CD + CD_ATY + k];
+          *reinterpret_cast<T*>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * cs + LC_Y + k];
+          *reinterpret_cast<T*>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * cs + LC_ATY + k];
         }
       }
       if (jlane == 0) {
@@ -333,9 +342,9 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
       for (int k = 0; k < 6; ++k) p[k] = mass * (-P.rho * v[k] - P.Hv[k]);
       if (isj && d.cslot >= 0) {
-        const T* c_ = cdi + d.cslot * CD;
+        const T* c_ = cdi + d.cslot * cs;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) p[k] += c_[CD_ATY + k] - mu_eq * c_[CD_ATB + k];
+        for (int k = 0; k < 6; ++k) p[k] += c_[LC_ATY + k] - mu_eq * c_[LC_ATB + k];
       }
     }
     TAIL_TP(0)
@@ -464,31 +473,32 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     TAIL_TP(3)
     // DualUpdate of the task constraints (hxx:410-451), six lanes of the group
     for (int c = 0; c < L.nc; ++c) {
-      T* c_ = cdi + c * CD;
+      T* c_ = cdi + c * cs;
+      const T* A_ = a_shared ? ash + c * LCA : c_ + LCD;
       if (act && jlane < 6) {
         const int k = jlane;
-        const T* vc = xch + (gbase + (int)c_[CD_PAD]) * LXS + LXB;
-        T avk = c_[CD_A + 6 * k] * vc[0];
+        const T* vc = xch + (gbase + (int)c_[LC_PAD]) * LXS + LXB;
+        T avk = A_[6 * k] * vc[0];
 #pragma unroll
-        for (int j = 1; j < 6; ++j) avk += c_[CD_A + 6 * k + j] * vc[j];
-        const T bk = c_[CD_B + k];
+        for (int j = 1; j < 6; ++j) avk += A_[6 * k + j] * vc[j];
+        const T bk = c_[LC_B + k];
         const T ek = avk - bk;
         const T dy = mu_eq * ek;
-        const T yk = c_[CD_Y + k] + dy;
+        const T yk = c_[LC_Y + k] + dy;
         l_dyis = tmax(l_dyis, tabs(dy));
         l_up += bk * tmax(dy, T(0));
         l_lm += bk * tmin(dy, T(0));
         l_prt = tmax(l_prt, tabs(ek));
         l_av = tmax(l_av, tabs(avk));
-        c_[CD_Y + k] = yk;
+        c_[LC_Y + k] = yk;
       }
       tail_sync();
       if (act && jlane < 6) {
         const int k = jlane;
-        T at = c_[CD_A + k] * c_[CD_Y];
+        T at = A_[k] * c_[LC_Y];
 #pragma unroll
-        for (int j = 1; j < 6; ++j) at += c_[CD_A + 6 * j + k] * c_[CD_Y + j];
-        c_[CD_ATY + k] = at;
+        for (int j = 1; j < 6; ++j) at += A_[6 * j + k] * c_[LC_Y + j];
+        c_[LC_ATY + k] = at;
       }
       tail_sync();
     }
@@ -507,7 +517,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       T gi[6];
       if (d.cslot >= 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) gi[k] = cdi[d.cslot * CD + CD_ATY + k];
+        for (int k = 0; k < 6; ++k) gi[k] = cdi[d.cslot * cs + LC_ATY + k];
       } else {
 #pragma unroll
         for (int k = 0; k < 6; ++k) gi[k] = T(0);
