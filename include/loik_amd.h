@@ -93,7 +93,8 @@ typedef struct loikb_options {
   int compact_min_instances; /* stop compacting below this many slots, 0 = default (4096)     */
   int tail_max_instances;    /* hand the last N live instances to the cooperative tail kernel (one wavefront per
                                 instance): 0 = default (2^20 when the lean tail kernel applies
-                                -- H cache on, <= 1 task constraint, <= 4 children per joint: whole batches run in it --, else
+                                -- H cache on, <= 2 task constraints with a shared A (1 otherwise), <= 4 children per joint:
+                                whole batches run in it --, else
                                 32768), < 0 = never                                           */
 } loikb_options;
 

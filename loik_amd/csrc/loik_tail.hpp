@@ -18,7 +18,7 @@
 // the order in which children contributions / norm maxima are combined differs, so results agree with k_solve
 // and the CPU oracle to rounding (not bit for bit).  Used when nb <= 64.
 // loik_lean.hpp holds the variant of this kernel that runs two wavefronts per SIMD (the default engine for whole
-// batches); this one rebuilds H itself and serves what the lean kernel cannot: several task constraints, more than four
+// batches); this one rebuilds H itself and serves what the lean kernel cannot: more than two task constraints, more than four
 // children per joint, LOIKB_OPT_NO_H_CACHE, fewer than 64 instances, and instances whose mu leaves the lean kernel's
 // precomputed decades.
 #pragma once
