@@ -17,11 +17,14 @@ Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel -- the one
 instance-iterations of the timed steps -- against HBM bandwidth with the ALGORITHMIC byte model of SURVEY.md 8(d):
 bytes per ADMM instance-iteration = sizeof(scalar)*(203 nb + 108 nc), times the instance-iterations the kernel executed,
 over the time during which at least one of its launches was executing (HIP events recorded by the library on the
-streams the kernels are launched on).  Two kernels share a solve: `k_solve` advances one instance per lane through
-HBM-resident tiles for the first iterations of the whole batch (HBM-bound), `k_tail` takes over once at most 32768
-instances are still iterating and keeps each instance's whole state in registers/LDS until it stops (its HBM traffic
-is one load and one store per instance, reported as `traffic`; the streaming model's roofline does not bind it, a
-`frac` above 1 says exactly that).  The other kernel is reported beside the dominant one (`other_kernel`).
+streams the kernels are launched on).  By default the whole batch runs in `k_lean` (loik_amd/csrc/loik_lean.hpp: one
+joint per lane, an instance's whole ADMM state in registers/LDS until it stops, two wavefronts per SIMD; `k_hslots`
+precomputes H_i/Dinv_i per decade of mu before it): its HBM traffic is one load and one store per instance plus the
+decade slots (reported as `traffic`), so the streaming model's roofline does not bind it -- a `frac` above 1 says exactly
+that -- and what does (fp64 issue, the serial chains of the 1000-iteration instances) is stated in `regime`.  With
+LOIKB_LEAN=0 two kernels share a solve (`k_solve`: one instance per lane through HBM-resident tiles, HBM-bound; `k_tail`:
+the one-wavefront-per-SIMD predecessor of `k_lean`); the kernel that ran fewer instance-iterations is then reported
+beside the dominant one (`other_kernel`).
 `cpu_baseline` times the CPU oracle (a line-faithful port of the reference solver, NOT upstream libloik) on a
 bounded sample of the same workload on all host cores.
 """
