@@ -230,6 +230,9 @@ def main():
                        "roofline does not bind it; what does is fp64 VALU issue latency along the tree levels "
                        "(DESIGN.md section 4: phase timeline, scripts/ubench/fp64_issue.hip)",
              "instances_per_step": tail_inst / args.steps,
+             "valu_note": "PMC (profiles/r01_j_k_lean_pmc_summary.txt): 1707 VALU instructions per wavefront-iteration, "
+                          "two wavefronts per SIMD keep its fp64 VALU ~63 % busy (k_tail, one per SIMD: ~31 %); "
+                          "10 % of the wavefront cycles wait on LDS; HBM ~0.6 TB/s",
              "lean_launches_per_step": st["lean_launches"], "lean_escaped_last_step": st["lean_escaped"],
              "decade_slots_ms_last_step": st["hslots_ms"]})
         dominant, other = (k_tail, k_solve) if tail_iters >= solve_iters else (k_solve, k_tail)
