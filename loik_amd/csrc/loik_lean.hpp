@@ -557,20 +557,24 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     TAIL_TP(6)
     bool finishing = false;
     if (act) {
+      // (only what the logic needs is read from the instance's scalars, only what changed is written back)
       const T primal = isc[IS_RED + 0], dual = isc[IS_RED + 1], dx = isc[IS_RED + 2], dz = isc[IS_RED + 3];
       int status = (int)isc[IS_STATUS];
       const int iter = (int)isc[IS_ITER] + 1;
-      int tail_iter = (int)isc[IS_TAILIT], c1 = (int)isc[IS_C1], c2 = (int)isc[IS_C2], nflip = (int)isc[IS_NFLIP];
-      T tol_p = isc[IS_TOLP], tol_d = isc[IS_TOLD], dyqp = isc[IS_DYQP], atdy = isc[IS_ATDY], ubp = isc[IS_UBP], lbm = isc[IS_LBM];
       const T mu_used = mu;
+      bool flipped = false, feas_checked = false, tail_mode = false, tol_computed = false;
+      int tail_iter = 0, c1 = 0, c2 = 0;
+      T tol_p = T(0), tol_d = T(0), dyqp = T(0), atdy = T(0), ubp = T(0), lbm = T(0);
       if (P.mode & MODE_FIXED_ITERS) {
         if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
       } else if (!(status & ST_TAIL)) {
+        tol_computed = true;
         tol_p = P.tol_abs + P.tol_rel * tmax(isc[IS_RED + 4], isc[IS_BNORM]);
         tol_d = P.tol_abs + P.tol_rel * tmax(isc[IS_RED + 5], P.Hv_inf_norm);
         const bool conv = (primal < tol_p) && (dual < tol_d);
         bool infeas = false;
         if (iter > 1) {
+          feas_checked = true;
           dyqp = isc[IS_RED + 6];
           atdy = isc[IS_RED + 7];
           c1 = atdy <= P.tol_primal_inf * dyqp;
@@ -585,24 +589,30 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
           done = true;
         } else if (infeas) {
           status |= ST_PRIMAL_INF | ST_TAIL;
+          tail_mode = true;
           tail_iter = 0;
           if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
         } else {
-          if (primal > T(10) * dual) { mu *= T(10); ++kexp; ++nflip; }
-          else if (dual > T(10) * primal) { mu *= T(0.1); --kexp; ++nflip; }
+          if (primal > T(10) * dual) { mu *= T(10); ++kexp; flipped = true; }
+          else if (dual > T(10) * primal) { mu *= T(0.1); --kexp; flipped = true; }
           if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
         }
       } else {
-        tail_iter += 1;
+        tail_mode = true;
+        tail_iter = (int)isc[IS_TAILIT] + 1;
         if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
       }
       finishing = done;
       tail_sync();  // every lane has read the instance's scalars before lane 0 rewrites them
       if (jlane == 0) {
-        isc[IS_MU] = mu; isc[IS_KEXP] = (T)kexp; isc[IS_ITER] = (T)iter; isc[IS_STATUS] = (T)status;
-        isc[IS_TAILIT] = (T)tail_iter; isc[IS_C1] = (T)c1; isc[IS_C2] = (T)c2; isc[IS_NFLIP] = (T)nflip;
-        isc[IS_TOLP] = tol_p; isc[IS_TOLD] = tol_d; isc[IS_DYQP] = dyqp; isc[IS_ATDY] = atdy; isc[IS_UBP] = ubp; isc[IS_LBM] = lbm;
+        isc[IS_ITER] = (T)iter; isc[IS_STATUS] = (T)status;
         isc[IS_PRIMAL] = primal; isc[IS_DUAL] = dual; isc[IS_DX] = dx; isc[IS_DZ] = dz; isc[IS_MULAST] = mu_used;
+        if (flipped) { isc[IS_MU] = mu; isc[IS_KEXP] = (T)kexp; isc[IS_NFLIP] = isc[IS_NFLIP] + T(1); }
+        if (tail_mode) isc[IS_TAILIT] = (T)tail_iter;
+        if (tol_computed) { isc[IS_TOLP] = tol_p; isc[IS_TOLD] = tol_d; }
+        if (feas_checked) {
+          isc[IS_C1] = (T)c1; isc[IS_C2] = (T)c2; isc[IS_DYQP] = dyqp; isc[IS_ATDY] = atdy; isc[IS_UBP] = ubp; isc[IS_LBM] = lbm;
+        }
       }
     } else {
       tail_sync();
