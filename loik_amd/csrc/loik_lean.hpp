@@ -348,22 +348,6 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       }
     }
     TAIL_TP(0)
-#ifdef LEAN_MASKED_LEVELS
-    for (int lev = maxdepth; lev >= 1; --lev) {
-      if (act && depth == lev) {
-        lean_gather_n<T>(maxchild, xch, chl, LXA, p);
-        const T Stp = dot6_halves(Sv, p);
-        r = (w - mu_in * z) + Stp;
-        T pa[6], pc[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) pa[k] = p[k] - UD[k] * r;
-        act_force(R, t, pa, pc);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) xch[lane * LXS + LXA + k] = pc[k];
-      }
-      tail_sync();
-    }
-#else
     {
       T pl[6], rl = T(0);
 #pragma unroll
@@ -390,29 +374,11 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       }
     }
 
-#endif
     TAIL_TP(1)
     // ================= root -> leaf: FwdPass2 (hxx:102-163) ==============================================================
     T vi[6], nui = T(0);
 #pragma unroll
     for (int k = 0; k < 6; ++k) vi[k] = T(0);
-#ifdef LEAN_MASKED_LEVELS
-    for (int lev = 1; lev <= maxdepth; ++lev) {
-      if (depth == lev) {
-        T vpar[6], vp[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) vpar[k] = xch[prow * LXS + LXB + k];
-        actinv_motion(R, t, vpar, vp);
-        const T udv = dot6_halves(UD, vp);
-        nui = -udv - dinv * r;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) vi[k] = vp[k] + Sv[k] * nui;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) xch[lane * LXS + LXB + k] = vi[k];
-      }
-      tail_sync();
-    }
-#else
     for (int lev = 1; lev <= maxdepth; ++lev) {
       T vpar[6], vp[6];
 #pragma unroll
@@ -427,7 +393,6 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       for (int k = 0; k < 6; ++k) xch[lane * LXS + LXB + k] = vi[k];
       tail_sync();
     }
-#endif
     TAIL_TP(2)
     // per-lane norms of this iteration (folded over the group below)
     T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_dyis = T(0),
