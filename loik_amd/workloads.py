@@ -143,3 +143,35 @@ def panda_c2(batch=4096, seed=0x101C + 2, model=None):
     wl["model"] = model
     wl["name"] = "panda7_B%d_fixed50_fp64" % batch
     return wl
+
+
+def talos_c4(batch, T=4, seed=0x101C + 4, model=None):
+    """BASELINE config "Talos batch=1,048,576 sharded across 8xMI355X (sampling-planner workload; per-instance early stop
+    + lane compaction)": `batch` is ONE GPU's share (131072).  T successive targets per instance through the tailored
+    warm-started entry Solve(q, c_id, Ai, bi) (loik-loid-optimized.hpp:596-695): step t has its own configuration and
+    its own feasible wrist twist.  Returns the C3-style workload of step 0 plus `steps` = [(q_t, bis_t)], SURVEY.md 8(d) C4."""
+    wl = talos_c3(batch, seed=seed, model=model)
+    model = wl["model"]
+    link = int(wl["c_ids"][0])
+    steps = [(wl["q"], wl["bis"])]
+    for t in range(1, T):
+        w = make_workload(model, batch, link, seed + 1000 * t, bound=0.5, snap_prob=0.0)
+        steps.append((w["q"], w["bis"]))
+    wl["steps"] = steps
+    wl["params"] = dict(wl["params"], warm_start=True)
+    wl["name"] = "talos32_leftwrist_B%d_T%d_tailored_warm_start_fp64" % (batch, T)
+    return wl
+
+
+def panda_c5(batch=65536, seed=0x101C + 5, tol=1e-3, model=None):
+    """BASELINE config "fp32 path: Panda batch=65536, fp32 vs fp64 tolerance/throughput trade-off": the C2 generator with
+    the stopping logic on, at a tolerance fp32 can reach."""
+    if model is None:
+        from . import builtin_model
+        model = builtin_model("panda7")
+    link = model.njoints - 1
+    wl = make_workload(model, batch, link, seed, bound=4.0, snap_prob=0.0, nu_scale=1.0)
+    wl["params"] = dict(FIXTURE_PARAMS, max_iter=200, tol_abs=tol, tol_rel=0.0)
+    wl["model"] = model
+    wl["name"] = "panda7_B%d_tol%g" % (batch, tol)
+    return wl

@@ -194,3 +194,56 @@ def multi_task_batch(model, batch, links, seed, bound=0.5, nu_scale=0.4, per_ins
     wl["c_ids"] = np.array(links, dtype=np.int32)
     wl["Ais"], wl["bis"] = A, b
     return wl
+
+
+def assert_end_to_end(got, out, prm, same_frac=0.97, ztol=1e-9, off_ztol=1e-6, off_iter=None, what=""):
+    """End-to-end comparison of a batch with the oracle's `solve_batch` output -- every instance is checked, none dropped.
+
+    got: dict with iter, converged, primal_infeasible, z (optionally nu, primal_residual, dual_residual) of the device;
+    out: oracle.ref.solve_batch(...).  Instances with the oracle's iteration count (at least `same_frac` of the batch)
+    must agree in every flag and to `ztol` in z / nu.  The rest -- a comparison of the stopping logic (residual < tol,
+    primal > 10 dual, the certificate's <=) fell on the other side of a rounding error, so the instance stopped at a
+    neighbouring iteration or took a different mu for a while -- is NOT skipped: both solvers must have stopped the
+    same way (same flags, unless the oracle's own residual sits within rounding of the tolerance), within
+    `off_iter` iterations of each other when given, and their answers must coincide to the solver tolerance (`off_ztol`).
+    Returns the mask of identical-iteration instances."""
+    it = np.asarray(got["iter"]); it_o = np.asarray(out["iters"])
+    conv = np.asarray(got["converged"]).astype(bool); inf = np.asarray(got["primal_infeasible"]).astype(bool)
+    same = it == it_o
+    assert same.mean() >= same_frac, (what, "iteration counts differ", it[~same][:20], it_o[~same][:20])
+    assert np.array_equal(conv[same], out["converged"][same]), what
+    assert np.array_equal(inf[same], out["primal_infeasible"][same]), what
+    dz = np.abs(np.asarray(got["z"]) - out["z"]).reshape(it.size, -1).max(axis=1)
+    assert dz[same].max() < ztol, (what, "z", dz[same].max())
+    if "nu" in got and "nu" in out:
+        dn = np.abs(np.asarray(got["nu"]) - out["nu"]).reshape(it.size, -1).max(axis=1)
+        assert dn[same].max() < ztol, (what, "nu", dn[same].max())
+    for name in ("primal_residual", "dual_residual"):
+        if name in got and name in out:
+            a, b = np.asarray(got[name])[same], out[name][same]
+            assert np.all(np.abs(a - b) <= 1e-9 + 1e-6 * np.abs(b)), (what, name)
+    off = np.flatnonzero(~same)
+    tol = prm["tol_abs"]
+    for b in off:
+        # how close the oracle's stopping comparison was: relative distance of its residuals from the tolerance
+        near_tol = min(abs(out["primal_residual"][b] - tol), abs(out["dual_residual"][b] - tol)) <= 1e-6 * tol
+        hit_max = it[b] >= prm["max_iter"] - 1 or it_o[b] >= prm["max_iter"] - 1
+        assert dz[b] <= off_ztol, (what, "instance %d: iterations %d vs %d, |dz| = %.3e" % (b, it[b], it_o[b], dz[b]))
+        if not (near_tol or hit_max):
+            assert conv[b] == out["converged"][b] and inf[b] == out["primal_infeasible"][b], (what, b, it[b], it_o[b])
+        if off_iter is not None and not hit_max:
+            assert abs(int(it[b]) - int(it_o[b])) <= off_iter, (what, b, it[b], it_o[b])
+    return same
+
+
+def fetch_end_to_end(s, idx=None, nu=True, residuals=False):
+    """the device side of assert_end_to_end (optionally a subset `idx` of the batch)"""
+    sel = (lambda a: a) if idx is None else (lambda a: a[idx])
+    got = dict(iter=sel(s.get("iter")), converged=sel(s.get("converged")), primal_infeasible=sel(s.get("primal_infeasible")),
+               z=sel(s.get("z")))
+    if nu:
+        got["nu"] = sel(s.get("nu"))
+    if residuals:
+        got["primal_residual"] = sel(s.get("primal_residual"))
+        got["dual_residual"] = sel(s.get("dual_residual"))
+    return got

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import loik_amd
-from helpers import FIXTURE, assert_close, feasible_batch, problem_args, random_tree
+from helpers import FIXTURE, assert_close, assert_end_to_end, feasible_batch, fetch_end_to_end, problem_args, random_tree
 from oracle import ref
 
 pytestmark = pytest.mark.gpu
@@ -77,17 +77,7 @@ def test_every_engine_matches_the_oracle(which, engine, request, monkeypatch):
         assert st["lean_launches"] >= 1 and 0 < st["tail_instances"] < B
     if engine == "lean_escapes":
         assert st["lean_launches"] >= 1 and st["lean_escaped"] > 0, st
-    it = s.get("iter")
-    same = it == out["iters"]
-    assert same.mean() >= 0.97, (engine, it[~same], out["iters"][~same])
-    assert np.array_equal(s.get("converged").astype(bool)[same], out["converged"][same])
-    assert np.array_equal(s.get("primal_infeasible").astype(bool)[same], out["primal_infeasible"][same])
-    assert np.max(np.abs(s.get("z") - out["z"])[same]) < 1e-8
-    assert np.max(np.abs(s.get("nu") - out["nu"])[same]) < 1e-8
-    # the residuals the getters report are those of the last iteration of every instance
-    pr, du = s.get("primal_residual"), s.get("dual_residual")
-    assert np.all(np.abs(pr - out["primal_residual"])[same] <= 1e-9 + 1e-6 * np.abs(out["primal_residual"][same]))
-    assert np.all(np.abs(du - out["dual_residual"])[same] <= 1e-9 + 1e-6 * np.abs(out["dual_residual"][same]))
+    assert_end_to_end(fetch_end_to_end(s, residuals=True), out, prm, ztol=1e-8, what=engine)
     s.close()
 
 

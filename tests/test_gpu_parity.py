@@ -9,7 +9,8 @@ import pytest
 import loik_amd
 from loik_amd import capi, workloads
 from oracle import ref
-from helpers import FIXTURE, assert_close, feasible_batch, fixture_problem, problem_args, random_tree
+from helpers import (FIXTURE, assert_close, assert_end_to_end, feasible_batch, fetch_end_to_end, fixture_problem,
+                     problem_args, random_tree)
 
 pytestmark = pytest.mark.gpu
 
@@ -93,13 +94,7 @@ def test_random_trees_all_joint_types(seed, nb):
     s = gpu_solve(model, wl, prm)
     out = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"].reshape(70, 1, 6, 6), wl["bis"],
                           wl["lb"], wl["ub"], nthreads=4, want_nu=True, **prm)
-    it = s.get("iter")
-    same = it == out["iters"]
-    assert same.mean() >= 0.97, (it, out["iters"])
-    assert np.array_equal(s.get("converged").astype(bool)[same], out["converged"][same])
-    assert np.array_equal(s.get("primal_infeasible").astype(bool)[same], out["primal_infeasible"][same])
-    assert np.max(np.abs(s.get("z") - out["z"])[same]) < 1e-9
-    assert np.max(np.abs(s.get("nu") - out["nu"])[same]) < 1e-9
+    assert_end_to_end(fetch_end_to_end(s), out, prm, what="random tree %d" % nb)
     s.close()
 
 
@@ -278,25 +273,95 @@ def test_full_size_properties_talos_65536():
     sub = {k: (v[idx] if isinstance(v, np.ndarray) and v.shape[:1] == (B,) else v) for k, v in wl.items()}
     out = ref.solve_batch(m, sub["q"], sub["H_ref"], sub["v_ref"], sub["c_ids"], sub["Ais"], sub["bis"], sub["lb"],
                           sub["ub"], nthreads=8, **wl["params"])
-    same = s.get("iter")[idx] == out["iters"]
-    assert same.mean() > 0.97
-    assert np.max(np.abs(z[idx] - out["z"])[same]) < 1e-9
+    assert_end_to_end(fetch_end_to_end(s, idx, nu=False), out, wl["params"], what="C3 strided sample")
     s.close()
 
 
-def test_fp32_path_tracks_fp64(panda7):
-    """BASELINE config 5: no fp32 reference exists upstream (only `double` is instantiated,
-    src/loik-loid-optimized.cpp:10-13) -> measured against the fp64 oracle at a tolerance fp32 can reach"""
-    wl = feasible_batch(panda7, 512, panda7.njoints - 1, 70, nu_scale=0.5)
-    prm = dict(FIXTURE, max_iter=200, tol_abs=1e-3, tol_rel=0.0)
-    s32 = gpu_solve(panda7, wl, prm, precision=capi.F32)
-    s64 = gpu_solve(panda7, wl, prm)
-    c32, c64 = s32.get("converged").astype(bool), s64.get("converged").astype(bool)
-    assert c64.mean() > 0.7 and c32.mean() > 0.6 and abs(c64.mean() - c32.mean()) < 0.1
+def test_c5_fp32_panda_65536_against_fp64_oracle(panda7):
+    """BASELINE config 5 at its size: Panda-7, B = 65536, the `float` instantiation against the fp64 ORACLE.  No fp32
+    reference exists upstream (only `double` is instantiated, src/loik-loid-optimized.cpp:10-13), so the bar is the
+    fp64 answer at a tolerance fp32 can reach (tol_abs = 1e-3): the distribution of |z32 - z64|_inf over the batch is
+    pinned (median, p99, max), plus size-independent properties (box, task met when converged, kinematic consistency)."""
+    B = 65536
+    wl = workloads.panda_c5(B)
+    m, prm = wl["model"], wl["params"]
+    args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    out = ref.solve_batch(m, *args, nthreads=8, want_nu=True, **prm)
+    s64 = loik_amd.BatchedLoik(m, B, **prm)
+    s64.Solve(*args)
+    assert_end_to_end(fetch_end_to_end(s64), out, prm, same_frac=0.995, what="C5 fp64 device vs oracle, all 65536")
+    s64.close()
+    s32 = loik_amd.BatchedLoik(m, B, precision=capi.F32, **prm)
+    s32.Solve(*args)
+    z, nu, it = s32.get("z"), s32.get("nu"), s32.get("iter")
+    c32, c64 = s32.get("converged").astype(bool), out["converged"]
+    i32_, i64_ = s32.get("primal_infeasible").astype(bool), out["primal_infeasible"]
+    # the same instances converge / trip the certificate, up to borderline cases
+    assert c64.mean() > 0.7 and abs(c32.mean() - c64.mean()) < 0.01, (c32.mean(), c64.mean())
+    assert (c32 != c64).mean() < 0.02 and (i32_ != i64_).mean() < 0.02, ((c32 != c64).mean(), (i32_ != i64_).mean())
     both = c32 & c64
-    dz = np.abs(s32.get("z") - s64.get("z"))[both]
-    assert np.median(dz.max(axis=1)) < 1e-3 and dz.max() < 5e-2  # both stop at tol 1e-3
-    s32.close(); s64.close()
+    dz = np.abs(z - out["z"]).max(axis=1)[both]
+    q50, q99, qmax = np.median(dz), np.quantile(dz, 0.99), dz.max()
+    print("C5 fp32 vs fp64 oracle over %d instances converged in both: |dz|_inf median %.3e p99 %.3e max %.3e; "
+          "iterations fp32 %.2f fp64 %.2f" % (both.sum(), q50, q99, qmax, it.mean(), out["iters"].mean()))
+    # both stop at residual < 1e-3: the answers differ by the tolerance at most, typically by fp32 rounding
+    assert q50 <= 2e-5 and q99 <= 3e-3 and qmax <= 5e-2, (q50, q99, qmax)
+    assert abs(it.mean() - out["iters"].mean()) < 0.05 * out["iters"].mean()
+    # properties that hold whatever the precision: the box, the slack closed and the task met to the tolerance
+    assert np.all(z <= wl["ub"] + 1e-6) and np.all(z >= wl["lb"] - 1e-6)
+    assert np.max(np.abs(nu - z)[c32]) < 1e-3
+    vc = workloads.link_velocity(m, wl["q"], nu.astype(np.float64), int(wl["c_ids"][0]))
+    assert np.max(np.abs(vc - wl["bis"][:, 0])[c32]) < 2e-3
+    assert s32.stats()["instance_iterations"] == int(it.sum())
+    s32.close()
+
+
+def test_c4_tailored_warm_start_131072(talos):
+    """BASELINE config 4, one GPU's share: Talos, B = 131072, T = 4 successive targets per instance through the tailored
+    warm-started entry (loik-loid-optimized.hpp:596-695, Reset(warm_start) loik-loid-data-optimized.hxx:114-127), default
+    engine, per-instance early stop.  Full size: properties; strided sample: the oracle driven the same way."""
+    B, T = 131072, 4
+    wl = workloads.talos_c4(B, T)
+    m, prm = wl["model"], wl["params"]
+    link = int(wl["c_ids"][0])
+    s = loik_amd.BatchedLoik(m, B, **prm)
+    s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    idx = np.arange(0, B, 1021)
+    refs = []
+    for b in idx:
+        r = ref.RefSolver(m, **prm)
+        r.SolveInit(*problem_args(wl, b))
+        refs.append(r)
+    for t, (q_t, b_t) in enumerate(wl["steps"]):
+        s.Solve(q_t, link, wl["Ais"], b_t)
+        st = s.stats()
+        it, z, nu = s.get("iter"), s.get("z"), s.get("nu")
+        conv, inf = s.get("converged").astype(bool), s.get("primal_infeasible").astype(bool)
+        assert st["lean_launches"] >= 1 and st["lean_escaped"] == 0 and st["tail_instances"] == B, st
+        assert st["instance_iterations"] == int(it.sum())
+        # early stop per instance: iteration counts spread over two orders of magnitude, nobody beyond the bound
+        assert it.min() >= 1 and it.max() <= prm["max_iter"] and np.median(it) < 0.1 * prm["max_iter"]
+        assert conv.mean() > 0.8
+        assert np.all(z <= wl["ub"] + 1e-15) and np.all(z >= wl["lb"] - 1e-15)
+        assert np.all(s.get("primal_residual")[conv] < 1e-6) and np.all(s.get("dual_residual")[conv] < 1e-6)
+        vc = workloads.link_velocity(m, q_t, nu, link)
+        assert np.max(np.abs(vc - s.get("vis")[:, link - 1, :])) < 1e-12
+        assert np.max(np.abs(vc - b_t[:, 0])[conv]) < 1e-5
+        # the oracle, driven like a caller of the reference: one solver object per sampled instance, warm-started
+        out = dict(iters=np.empty(idx.size, dtype=np.int64), converged=np.empty(idx.size, dtype=bool),
+                   primal_infeasible=np.empty(idx.size, dtype=bool), z=np.empty((idx.size, m.nv)),
+                   primal_residual=np.empty(idx.size), dual_residual=np.empty(idx.size))
+        for k, (b, r) in enumerate(zip(idx, refs)):
+            r.Solve(q_t[b], link, wl["Ais"][0], b_t[b, 0])
+            out["iters"][k], out["converged"][k] = r.get_iter(), r.get_convergence_status()
+            out["primal_infeasible"][k], out["z"][k] = r.get_primal_infeasibility_status(), r.z
+            out["primal_residual"][k], out["dual_residual"][k] = r.scalar("primal_residual"), r.scalar("dual_residual")
+        got = dict(iter=it[idx], converged=conv[idx], primal_infeasible=inf[idx], z=z[idx])
+        # (a warm-started sequence carries its state: an instance that left the oracle's trajectory at a borderline
+        #  comparison starts the next step from a slightly different point and may stay off it -- it is still held
+        #  to the same flags and the same answer within the solver tolerance, only the identical-count share relaxes)
+        assert_end_to_end(got, out, prm, same_frac=0.97 if t == 0 else 0.9, what="C4 step %d" % t)
+    s.close()
 
 
 @pytest.mark.parametrize("per_instance", [False, True])
@@ -347,15 +412,7 @@ def test_cooperative_tail_kernel(which, request):
         st = s.stats()
         assert st["tail_instances"] > 0 and st["launches"] == 2, st
         assert st["instance_iterations"] == int(s.get("iter").sum())
-        it = s.get("iter")
-        same = it == out["iters"]
-        assert same.mean() >= 0.97, (which, handover, it[~same], out["iters"][~same])
-        assert np.array_equal(s.get("converged").astype(bool)[same], out["converged"][same])
-        assert np.array_equal(s.get("primal_infeasible").astype(bool)[same], out["primal_infeasible"][same])
-        assert np.max(np.abs(s.get("z") - out["z"])[same]) < 1e-9
-        assert np.max(np.abs(s.get("nu") - out["nu"])[same]) < 1e-9
-        assert np.max(np.abs(s.get("primal_residual") - out["primal_residual"])[same]) < 1e-9
-        assert np.max(np.abs(s.get("dual_residual") - out["dual_residual"])[same]) < 1e-9
+        same = assert_end_to_end(fetch_end_to_end(s, residuals=True), out, prm, what="%s handover %d" % (which, handover))
         # full state of a few instances
         for b in np.flatnonzero(same)[:6]:
             r = ref.RefSolver(model, **prm)
@@ -592,7 +649,5 @@ def test_setters_equal_constructor_arguments(talos):
     for name in ["iter", "converged", "primal_infeasible", "z", "nu", "w", "mu", "primal_residual", "dual_residual"]:
         assert np.array_equal(a.get(name), b.get(name)), name
     out = ref.solve_batch(talos, *args[:4], wl["Ais"], wl["bis"], wl["lb"], wl["ub"], nthreads=4, **new)
-    same = a.get("iter") == out["iters"]
-    assert same.mean() >= 0.97
-    assert np.max(np.abs(a.get("z") - out["z"])[same]) < 1e-8
+    assert_end_to_end(fetch_end_to_end(a, nu=False), out, new, ztol=1e-8, what="setters")
     a.close(); b.close()

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 import loik_amd
-from helpers import FIXTURE, assert_close, multi_task_batch, problem_args, random_tree
+from helpers import (FIXTURE, assert_close, assert_end_to_end, fetch_end_to_end, multi_task_batch, problem_args,
+                     random_tree)
 from oracle import dense, ref
 
 
@@ -88,12 +89,7 @@ def test_gpu_several_constraints(which, nc, per_instance_A, request):
                           nthreads=4, want_nu=True, **prm)
     for kw in (dict(tail_max_instances=-1), dict()):
         s = _gpu(model, wl, prm, **kw)
-        it = s.get("iter")
-        same = it == out["iters"]
-        assert same.mean() >= 0.95, (it, out["iters"])
-        assert np.array_equal(s.get("converged").astype(bool)[same], out["converged"][same])
-        assert np.array_equal(s.get("primal_infeasible").astype(bool)[same], out["primal_infeasible"][same])
-        assert np.max(np.abs(s.get("z") - out["z"])[same]) < 1e-8
+        assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.95, ztol=1e-8, what="nc=%d" % nc)
         assert s.stats()["tail_instances"] == (0 if kw else B)
         s.close()
 
