@@ -1,37 +1,44 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X-native batched LoIK solver.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-Metric (BASELINE.json): IK solves/s to 1e-6 residual, Talos humanoid, batch = 65536 per GPU, fp64, adaptive mu.
+`--gpus N` runs N GPUs BY ITSELF: the batch shards into independent contiguous ranges with no exchange step
+(SURVEY.md 8(e)), so one process drives N devices with one host thread + one solver handle + one stream per device
+(`loikb_options.device`); wall clock around all of them, sum of the solves, max of the time.  Under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (WORLD_SIZE > 1 in the environment) every
+rank drives ONE device instead and a gloo process group carries only the timing barrier, the max-over-ranks time and
+the sums of the counters -- still no collective on the data path.
+
+Metric (BASELINE.json): IK solves/s to 1e-6 residual, Talos humanoid, batch = 65536, fp64, adaptive mu.
 A "step" is one cold `Solve()` (the reference's hot loop, /root/reference/include/loik/loik-loid-optimized.hpp:368-455)
-over one batch of 65536 synthetic problem instances whose inputs were placed in HBM by `SolveInit()` before the
-timed region -- the same split the reference's own timing test uses (`SolveInit` once, then time `Solve()`,
-/root/reference/tests/loik-loid.cpp:987-1032).  A "solve" is an instance that stops with primal AND dual residual
-below 1e-6 (`get_convergence_status()`); instances that trip the reference's infeasibility certificate or hit
-max_iter are executed and timed but not counted.  The batch shards over GPUs with no exchange step (instances are
-independent): every rank solves its own 65536 instances, no collective on the data path ("scaling": "weak").
+over synthetic problem instances whose inputs were placed in HBM by `SolveInit()` before the timed region -- the same
+split the reference's own timing test uses (`SolveInit` once, then time `Solve()`, tests/loik-loid.cpp:987-1032).
+A "solve" is an instance that stops with primal AND dual residual below 1e-6 (`get_convergence_status()`); instances
+that trip the reference's infeasibility certificate or hit max_iter are executed and timed but not counted.
+  --scaling weak   (default) every GPU solves its own 65536 instances: `value` grows with N at fixed ms_per_step
+  --scaling strong the 65536 instances of the 1-GPU run are split over the N GPUs (BASELINE.json's wording "batch=65536 at
+                   1/2/4/8 GPUs"); with N > 1 the weak line also carries a `strong_scaling` object measured in the same run
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel -- the one that ran most of the ADMM
-instance-iterations of the timed steps -- against HBM bandwidth with the ALGORITHMIC byte model of SURVEY.md 8(d):
-bytes per ADMM instance-iteration = sizeof(scalar)*(203 nb + 108 nc), times the instance-iterations the kernel executed,
-over the time during which at least one of its launches was executing (HIP events recorded by the library on the
-streams the kernels are launched on).  By default the whole batch runs in `k_lean` (loik_amd/csrc/loik_lean.hpp: one
-joint per lane, an instance's whole ADMM state in registers/LDS until it stops, two wavefronts per SIMD; `k_hslots`
-precomputes H_i/Dinv_i per decade of mu before it): its HBM traffic is one load and one store per instance plus the
-decade slots (reported as `traffic`), so the streaming model's roofline does not bind it -- a `frac` above 1 says exactly
-that -- and what does (fp64 issue, the serial chains of the 1000-iteration instances) is stated in `regime`.  With
-LOIKB_LEAN=0 two kernels share a solve (`k_solve`: one instance per lane through HBM-resident tiles, HBM-bound; `k_tail`:
-the one-wavefront-per-SIMD predecessor of `k_lean`); the kernel that ran fewer instance-iterations is then reported
-beside the dominant one (`other_kernel`).
-`cpu_baseline` times the CPU oracle (a line-faithful port of the reference solver, NOT upstream libloik) on a
-bounded sample of the same workload on all host cores.
+Prints ONE JSON line (rank 0).  `roofline` prices the DOMINANT kernel (the one that ran most ADMM instance-iterations of
+the timed steps) against the roof that bounds it:
+  * `k_lean` / `k_tail` keep an instance's whole ADMM state in registers/LDS (one load and one store of the instance per
+    solve): they are bound by fp64 vector issue, not by HBM -> bound "fp64_valu", achieved = algorithmic flops per launch
+    (935 nb per instance-iteration) / average launch duration (HIP events recorded by the library on the
+    launch stream), peak 78.6 TFLOP/s (fp64 vector, half the guide's 157.3 TFLOP/s fp32 vector rate).  Beside it: the HBM
+    bytes the PMC counters saw (`traffic`, `hbm_measured_frac`) and the VALU issue fraction, from the committed rocprofv3
+    summary `profiles/pmc_latest.json` when it describes this workload.
+  * `k_solve` streams every instance through HBM each iteration: bound "hbm", achieved = algorithmic bytes
+    (8 B x (203 nb + 108 nc) per instance-iteration) per launch / average launch duration, peak 8000 GB/s.
+`cpu_baseline` times the CPU oracle (a line-faithful C port of the reference solver, NOT upstream libloik) on a bounded
+sample of the same workload on the cores this process may actually use (affinity mask and cgroup quota), rebuilt with
+-march=native on the box.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -39,259 +46,425 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_VALU_PEAK_TF = 157.3   # same guide: peak FP32 (vector)
+FP64_VALU_PEAK_TF = 78.6    # fp64 vector FMA issues at half the fp32 vector rate (4 cycles per wave64 instruction)
+FLOPS_PER_JOINT_ITERATION = 935  # ~935 flop per joint and ADMM iteration
+HEADLINE_BATCH = 65536
+
+
+def effective_cpus():
+    """cores this process may really use: the affinity mask, capped by the cgroup CPU quota (cpu.max / cfs_quota)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(p)
+    except Exception:
+        try:  # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    note = "affinity mask: %d" % n
+    if quota is not None:
+        note += ", cgroup quota: %.1f cpus" % quota
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, note
 
 
 def cpu_baseline(wl, budget_s=15.0):
     """oracle (kind "port") on the box's host cores, bounded sample of the same workload"""
     from oracle import ref
-    cores = os.cpu_count() or 1
+    cores, cores_note = effective_cpus()
     m, prm = wl["model"], wl["params"]
+    B = wl["q"].shape[0]
 
-    def run(n):
+    def run(n, threads):
         t = time.perf_counter()
         out = ref.solve_batch(m, wl["q"][:n], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"][:n], wl["lb"],
-                              wl["ub"], nthreads=cores, native=True, **prm)
+                              wl["ub"], nthreads=threads, native=True, **prm)
         return time.perf_counter() - t, out
 
-    n0 = min(wl["q"].shape[0], 8 * cores)
-    t0, _ = run(n0)  # pilot (also warms the thread pool)
-    t0, _ = run(n0)
-    n = int(min(wl["q"].shape[0], max(n0, n0 * budget_s / max(t0, 1e-4))))
-    n = max(cores, (n // cores) * cores)
-    dt, out = run(n)
-    # one thread, one instance: microseconds per ADMM iteration, as the reference's own timing test measures it
-    # (SolveInit once, then Solve() with max_iter = 2, i.e. exactly one iteration; /root/reference/tests/loik-loid.cpp:987-1032)
+    # one thread on the real workload (heavy-tailed iteration counts included): instance-iterations/s per core
+    n1 = min(B, 256)
+    t1, o1 = run(n1, 1)
+    t1, o1 = run(n1, 1)
+    rate1 = float(o1["iters"].sum()) / t1
+    # all usable cores, sample sized for ~budget_s of wall time
+    n0 = min(B, 64 * cores)
+    t0, _ = run(n0, cores)  # pilot (also starts the thread pool)
+    t0, _ = run(n0, cores)
+    n = int(min(B, max(n0, n0 * budget_s / max(t0, 1e-4))))
+    n = max(16 * cores, (n // (16 * cores)) * 16 * cores)
+    n = min(n, B)
+    dt, out = run(n, cores)
+    rate = float(out["iters"].sum()) / dt
+    # one thread, one iteration at a time: microseconds per ADMM iteration, as the reference's own timing test measures
+    # it (SolveInit once, then Solve() with max_iter = 2; /root/reference/tests/loik-loid.cpp:987-1032)
     one_us = None
     try:
-        t1 = time.perf_counter()
-        o1 = ref.solve_batch(m, wl["q"][:64], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"][:64], wl["lb"],
+        t2 = time.perf_counter()
+        o2 = ref.solve_batch(m, wl["q"][:64], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"][:64], wl["lb"],
                              wl["ub"], nthreads=1, native=True, **dict(prm, max_iter=201, tol_abs=0.0, tol_primal_inf=0.0))
-        one_us = (time.perf_counter() - t1) / max(int(o1["iters"].sum()), 1) * 1e6
+        one_us = (time.perf_counter() - t2) / max(int(o2["iters"].sum()), 1) * 1e6
     except Exception:
         pass
+    eff = rate / (cores * rate1)
     return dict(value=float(out["converged"].sum() / dt), unit="solves/s", cores=cores, kind="port",
+                cores_note=cores_note + ", os.cpu_count(): %s" % os.cpu_count(),
                 single_thread_us_per_iteration=one_us,
-                sample="first %d instances of the same workload, %d threads, %.1f s, %.0f ADMM instance-iterations/s; "
-                       "oracle/loik_ref.c = line-faithful C port of the reference solver (not upstream libloik)"
-                       % (n, cores, dt, out["iters"].sum() / dt),
-                instance_iterations_per_s=float(out["iters"].sum() / dt))
+                single_thread_instance_iterations_per_s=rate1,
+                instance_iterations_per_s=rate,
+                parallel_efficiency=eff,
+                consistent=bool(0.5 <= eff <= 2.0),
+                consistency_def="threads x single-thread rate vs measured rate must agree within 2x "
+                                "(parallel_efficiency = measured / (cores x single-thread rate))",
+                sample="first %d instances of the same workload, %d OpenMP threads (dynamic schedule, 16 instances per "
+                       "block), %.1f s, %.0f ADMM instance-iterations/s; oracle/loik_ref.c = line-faithful C port of the "
+                       "reference solver (not upstream libloik), built with -O3 -march=native on this box"
+                       % (n, cores, dt, rate))
 
 
-def main():
+class Shard:
+    """one device: its slice of the workload, its solver handle, the per-step statistics of its timed steps"""
+
+    def __init__(self, idx, device, wl, flags, max_launch_iters, factory=None):
+        if factory is None:
+            import loik_amd
+            factory = loik_amd.BatchedLoik
+        self.idx, self.device, self.wl = idx, device, wl
+        self.B = wl["q"].shape[0]
+        self.solver = factory(wl["model"], self.B, device=device, flags=flags, max_launch_iters=max_launch_iters,
+                              **wl["params"])
+        t = time.perf_counter()
+        self.solver.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+        self.t_init = time.perf_counter() - t  # includes the PCIe upload of the host-side synthetic inputs
+        self.acc = {}
+        self.last = None
+        self.err = None
+
+    def step(self, timed):
+        self.solver.Solve()
+        if timed:
+            st = self.solver.stats()
+            self.last = st
+            for k in ("kernel_ms", "tail_ms", "tail_instances", "tail_instance_iterations", "tail_launches", "total_ms",
+                      "solve_busy_ms", "tail_busy_ms", "instance_iterations", "launches", "hslots_ms", "lean_launches"):
+                self.acc[k] = self.acc.get(k, 0) + st[k]
+
+    def results(self):
+        s, prm = self.solver, self.wl["params"]
+        conv = s.get("converged").astype(bool)
+        it = s.get("iter")
+        infeas = s.get("primal_infeasible").astype(bool)
+        return dict(solved=int(conv.sum()), iters=int(it.sum()), batch=self.B, infeasible=int(infeas.sum()),
+                    unfinished=int(((it >= prm["max_iter"] - 1) & ~conv).sum()))
+
+
+def run_shards(shards, steps, warmup, barrier=None):
+    """every shard on its own host thread: W untimed steps, barrier, K timed steps, barrier.  Returns the wall time from
+    the moment all shards are through the first barrier until the last one finished its K steps."""
+    n = len(shards)
+    sync = threading.Barrier(n + 1)
+    t_done = [0.0] * n
+
+    def work(i):
+        sh = shards[i]
+        try:
+            for _ in range(warmup):
+                sh.step(False)
+            sh.solver.synchronize()
+        except Exception as e:  # keep the barriers balanced
+            sh.err = e
+        sync.wait()   # all warmed up
+        sync.wait()   # t0 taken
+        try:
+            if sh.err is None:
+                for _ in range(steps):
+                    sh.step(True)
+                sh.solver.synchronize()  # hipDeviceSynchronize on the shard's device (Solve() already drained its stream)
+        except Exception as e:
+            sh.err = e
+        t_done[i] = time.perf_counter()
+        sync.wait()
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+    for t in th:
+        t.start()
+    sync.wait()
+    if barrier is not None:
+        barrier()
+    t0 = time.perf_counter()
+    sync.wait()
+    sync.wait()
+    for t in th:
+        t.join()
+    for sh in shards:
+        if sh.err is not None:
+            raise sh.err
+    elapsed = max(t_done) - t0
+    if barrier is not None:
+        barrier()
+    return elapsed
+
+
+def load_pmc(B):
+    """committed rocprofv3 PMC summary of this workload (scripts/profile_round.sh writes it); None when absent"""
+    for name in ("pmc_latest.json", "traffic_latest.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            try:
+                d = json.load(open(p))
+                if d.get("batch", HEADLINE_BATCH) == B:
+                    d["_file"] = "profiles/" + name
+                    return d
+            except Exception:
+                pass
+    return None
+
+
+def kernel_roofline(acc, last, steps, nb, nc, B):
+    """roofline object of the dominant kernel of the timed steps of ONE device (rank 0 / shard 0)"""
+    bytes_iter = last["bytes_per_instance_iteration"]
+    flops_iter = float(FLOPS_PER_JOINT_ITERATION * nb)
+    inst_iters = acc["instance_iterations"]
+    tail_iters = acc["tail_instance_iterations"]
+    solve_iters = inst_iters - tail_iters
+    solve_launches = acc["launches"] - acc["tail_launches"]
+    solve_ms = acc["kernel_ms"] - acc["tail_ms"]
+    lean = acc["lean_launches"] > 0
+    pmc = load_pmc(B)
+    pk = (pmc or {}).get("kernels", {})
+
+    def pmc_bytes(key):
+        if key in pk:
+            return pk[key]["fetch_bytes_per_step"] + pk[key]["write_bytes_per_step"]
+        return None
+
+    if tail_iters >= solve_iters:
+        # ---- on-chip engine: fp64 vector issue is the roof
+        name = "k_lean" if lean else "k_tail"
+        launches = max(acc["tail_launches"], 1)
+        # the library times k_hslots (decade-slot precomputation) + the lean launch together; k_lean alone = the rest
+        own_ms = acc["tail_ms"] - (acc["hslots_ms"] if lean else 0.0)
+        avg_ms = own_ms / launches
+        units = tail_iters / launches
+        ach = units * flops_iter / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = pmc_bytes(name)
+        r = {"bound": "fp64_valu", "kernel": name, "achieved": ach, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+             "frac": ach / FP64_VALU_PEAK_TF,
+             "traffic": traffic,
+             "flops_per_unit": flops_iter,
+             "unit_def": "one ADMM iteration of one instance: 935 flop x nb (nb = %d), SURVEY.md 8(d)" % nb,
+             "units_per_launch": units, "avg_launch_ms": avg_ms, "launches_per_step": launches / steps,
+             "instance_iterations_per_s": units / (avg_ms * 1e-3) if avg_ms > 0 else None,
+             "share_of_instance_iterations": tail_iters / max(inst_iters, 1),
+             "why_not_hbm": "the state of an instance stays in registers/LDS for its whole solve: HBM sees one load and "
+                            "one store per instance plus the decade slots of H (k_hslots writes, k_lean fetches on a "
+                            "change of mu) -- `traffic` is what the PMC counters measured, a few %% of the streaming "
+                            "model's %.0f B per unit" % bytes_iter}
+        if traffic is not None and avg_ms > 0:
+            gbs = traffic / (avg_ms * 1e-3) / 1e9
+            r["hbm_measured_GBps"] = gbs
+            r["hbm_measured_frac"] = gbs / HBM_PEAK_GBS
+            r["hbm_algorithmic_bytes_per_launch"] = units * bytes_iter
+        if pmc and name in pk and "valu_insts_per_step" in pk[name]:
+            # VALU issue: wave64 fp64 instructions take 4 cycles on a SIMD; 4 SIMDs x CUs, at the shader clock
+            insts = pk[name]["valu_insts_per_step"] / max(pk[name].get("dispatches_per_step", 1.0), 1.0)
+            ncu, clk = pmc.get("compute_units", 256), pmc.get("shader_clock_ghz", 2.4)
+            r["valu_issue_frac"] = insts * 4.0 / (4 * ncu * avg_ms * 1e-3 * clk * 1e9)
+            r["valu_insts_per_wavefront_iteration"] = pk[name].get("valu_insts_per_wavefront_iteration")
+            r["lds_bank_conflict_frac"] = pk[name].get("lds_bank_conflict_frac")
+        if pmc:
+            r["pmc_source"] = pmc["_file"]
+        if lean:
+            hs = {"kernel": "k_hslots", "avg_launch_ms": acc["hslots_ms"] / steps, "traffic": pmc_bytes("k_hslots"),
+                  "role": "H_i / Dinv_i of the decades of mu, precomputed once per Solve() before k_lean (HBM write-bound)"}
+            if hs["traffic"] is not None and hs["avg_launch_ms"] > 0:
+                hs["hbm_measured_GBps"] = hs["traffic"] / (hs["avg_launch_ms"] * 1e-3) / 1e9
+            r["other_kernel"] = hs
+        elif solve_iters > 0:
+            r["other_kernel"] = {"kernel": "k_solve", "share_of_instance_iterations": solve_iters / max(inst_iters, 1),
+                                 "sum_of_launch_ms_per_step": solve_ms / steps}
+        return r
+    # ---- streaming engine: HBM is the roof
+    launches = max(solve_launches, 1)
+    avg_ms = solve_ms / launches
+    units = solve_iters / launches
+    ach = units * bytes_iter / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = pmc_bytes("k_solve")
+    r = {"bound": "hbm", "kernel": "k_solve", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": ach / HBM_PEAK_GBS, "traffic": None if traffic is None else traffic / (launches / steps),
+         "bytes_per_unit": bytes_iter,
+         "unit_def": "one ADMM iteration of one instance: 8 B x (203 nb + 108 nc), nb = %d, nc = %d (three-sweep streaming "
+                     "model of SURVEY.md 8(d))" % (nb, nc),
+         "units_per_launch": units, "avg_launch_ms": avg_ms, "launches_per_step": launches / steps,
+         "share_of_instance_iterations": solve_iters / max(inst_iters, 1)}
+    if tail_iters > 0:
+        r["other_kernel"] = {"kernel": "k_lean" if lean else "k_tail",
+                             "share_of_instance_iterations": tail_iters / max(inst_iters, 1),
+                             "sum_of_launch_ms_per_step": acc["tail_ms"] / steps}
+    return r
+
+
+def main(argv=None, solver_factory=None, device_count=None):
+    """solver_factory / device_count: test hooks (tests/test_bench_multi_device.py drives the N-device host logic with a
+    stand-in solver on a machine without GPUs); the product path leaves them None"""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--batch", type=int, default=HEADLINE_BATCH, help="instances per GPU (weak) / in total (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong-leg", action="store_true", help="skip the extra strong-scaling measurement at N > 1")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--max-launch-iters", type=int, default=0)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
-        import torch
+        import torch  # noqa: F401
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # the data path has no collective; the process group only carries the timing barrier / max-reduce
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        if args.gpus != world:
+            raise SystemExit("--gpus %d disagrees with WORLD_SIZE %d" % (args.gpus, world))
 
     import loik_amd
-    from loik_amd import workloads
+    from loik_amd import sharding, workloads
 
-    def device_sync():
-        try:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-        except Exception:
-            pass
-
-    def barrier():
-        device_sync()
-        if dist is not None:
-            dist.barrier()
-        device_sync()
-
-    ndev = loik_amd.device_count()
+    ndev = loik_amd.device_count() if device_count is None else device_count
     if ndev < 1:
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    device = local_rank
-    if device >= ndev:
-        # fewer visible GPUs than ranks (only for smoke-testing the multi-process path on a 1-GPU box)
-        if os.environ.get("LOIKB_ALLOW_SHARED_GPU") != "1":
-            raise SystemExit("rank %d has no GPU of its own (%d visible); set LOIKB_ALLOW_SHARED_GPU=1 to share" % (rank, ndev))
-        device = local_rank % ndev
+    n_total = args.gpus                      # GPUs of the whole job
+    local = [rank] if world > 1 else list(range(n_total))   # global shard indices this process drives
+    share_ok = os.environ.get("LOIKB_ALLOW_SHARED_GPU") == "1"
 
-    B = args.batch
-    wl = workloads.talos_c3(B, seed=0x101C + 3 + rank)
-    model, prm = wl["model"], wl["params"]
-    solver = loik_amd.BatchedLoik(model, B, device=device, flags=args.flags, max_launch_iters=args.max_launch_iters,
-                                  **prm)
-    t_init = time.perf_counter()
-    solver.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
-    t_init = time.perf_counter() - t_init  # includes the PCIe upload of the host-side synthetic inputs
+    def device_of(g):
+        d = local_rank if world > 1 else g
+        if d >= ndev:
+            # fewer visible GPUs than shards (only for smoke-testing the multi-device path on a 1-GPU box)
+            if not share_ok:
+                raise SystemExit("shard %d has no GPU of its own (%d visible); set LOIKB_ALLOW_SHARED_GPU=1 to share" % (g, ndev))
+            d = d % ndev
+        return d
 
-    for _ in range(args.warmup):
-        solver.Solve()
-    kernel_ms = 0.0
-    tail_ms = 0.0
-    inst_iters = 0
-    launches = 0
-    tail_inst = 0
-    tail_iters = 0
-    tail_launches = 0
-    solve_wall_ms = 0.0
-    solve_busy_ms = 0.0
-    tail_busy_ms = 0.0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        solver.Solve()
-        st = solver.stats()
-        kernel_ms += st["kernel_ms"]
-        tail_ms += st["tail_ms"]
-        tail_inst += st["tail_instances"]
-        tail_iters += st["tail_instance_iterations"]
-        tail_launches += st["tail_launches"]
-        solve_wall_ms += st["total_ms"]
-        solve_busy_ms += st["solve_busy_ms"]
-        tail_busy_ms += st["tail_busy_ms"]
-        inst_iters += st["instance_iterations"]
-        launches += st["launches"]
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def barrier():
+        if dist is not None:
+            dist.barrier()
 
-    conv = solver.get("converged").astype(bool)
-    it = solver.get("iter")
-    infeas = solver.get("primal_infeasible").astype(bool)
-    n_solved = int(conv.sum())
-    hit_max = int(((it >= prm["max_iter"] - 1) & ~conv).sum())
-    from loik_amd import sharding
-    elapsed, tot = sharding.aggregate(dist, elapsed, dict(solved=n_solved, iters=int(it.sum()), batch=B))
-    total_solved, total_iters, total_B = tot["solved"], tot["iters"], tot["batch"]
-    stats = dict(infeasible=int(infeas.sum()), unfinished=hit_max)
+    def measure(scaling):
+        """build the shards of this process for `scaling`, run W + K steps, aggregate over the job"""
+        shards = []
+        if scaling == "weak":
+            for g in local:
+                wl = workloads.talos_c3(args.batch, seed=0x101C + 3 + g)
+                shards.append(Shard(g, device_of(g), wl, args.flags, args.max_launch_iters, solver_factory))
+        else:
+            full = workloads.talos_c3(args.batch, seed=0x101C + 3)  # the 1-GPU workload, split contiguously
+            for g in local:
+                wl = sharding.shard_workload(full, g, n_total)
+                shards.append(Shard(g, device_of(g), wl, args.flags, args.max_launch_iters, solver_factory))
+        elapsed = run_shards(shards, args.steps, args.warmup, barrier if dist is not None else None)
+        res = [sh.results() for sh in shards]
+        cnt = {k: sum(r[k] for r in res) for k in ("solved", "iters", "batch")}
+        elapsed, tot = sharding.aggregate(dist, elapsed, cnt)
+        return shards, res, elapsed, tot
+
+    shards, res, elapsed, tot = measure(args.scaling)
+    strong = None
+    if args.scaling == "weak" and n_total > 1 and not args.no_strong_leg:
+        sh0_keep = (shards[0].acc, shards[0].last, shards[0].wl, shards[0].t_init, res[0])
+        for sh in shards[1:]:
+            sh.solver.close()
+        shards[0].solver.close()
+        s_shards, s_res, s_elapsed, s_tot = measure("strong")
+        strong = {"scaling": "strong", "batch_total": int(s_tot["batch"]), "batch_per_gpu": int(s_tot["batch"]) // n_total,
+                  "value": s_tot["solved"] * args.steps / s_elapsed, "unit": "solves/s",
+                  "ms_per_step": s_elapsed / args.steps * 1e3,
+                  "instance_iterations_per_s": s_tot["iters"] * args.steps / s_elapsed,
+                  "note": "the 65536 instances of the 1-GPU run split contiguously over the GPUs (BASELINE.json: "
+                          "'batch=65536 at 1/2/4/8 GPUs'); the ~1000-iteration instances are a serial chain of fixed "
+                          "length per batch, so this curve flattens where the weak one does not"}
+        for sh in s_shards:
+            sh.solver.close()
+        acc0, last0, wl0, t_init0, res0 = sh0_keep
+    else:
+        acc0, last0, wl0, t_init0, res0 = shards[0].acc, shards[0].last, shards[0].wl, shards[0].t_init, res[0]
 
     if rank == 0:
-        bytes_iter = st["bytes_per_instance_iteration"]
-        # per kernel: algorithmic bytes (SURVEY.md 8(d) per-unit figure x instance-iterations it ran) over the time during
-        # which at least one of its launches was executing (HIP events on the launch streams; the batch may be solved
-        # as concurrent chunks, so launches of one kernel overlap) -- and the HBM bytes the PMC counters saw
-        # (scripts/pmc_traffic.sh; rocprofv3 cannot run inside this process, the committed summary is used when it
-        # describes this workload)
-        pmc = None
-        tj = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tj) and B == 65536:
-            try:
-                pmc = json.load(open(tj))["kernels"]
-            except Exception:
-                pmc = None
-
-        def kernel_entry(key, name, iters, launches_k, sum_ms, busy_ms, extra, pmc=pmc):
-            ach = iters * bytes_iter / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0
-            traffic, note = None, "no PMC summary for this workload (run scripts/pmc_traffic.sh on the GPU box)"
-            if key == "k_tail" and pmc and "k_lean" in pmc and lean:  # the lean kernel and its slot precomputation
-                pmc = dict(pmc, k_tail={k_: pmc["k_lean"][k_] + pmc.get("k_hslots", {}).get(k_, 0.0) for k_ in pmc["k_lean"]})
-            if pmc and key in pmc and launches_k > 0:
-                kb = pmc[key]["fetch_bytes_per_step"] + pmc[key]["write_bytes_per_step"]
-                traffic = kb / max(launches_k / args.steps, 1)
-                note = "profiles/traffic_latest.json: %.3g HBM bytes of %s per Solve() step (%.0f launches there, %.0f here)" % (
-                    kb, key, pmc[key]["dispatches_per_step"], launches_k / args.steps)
-            e = {"kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                 "traffic": traffic, "traffic_note": note,
-                 "units_per_launch": iters / max(launches_k, 1), "avg_launch_ms": sum_ms / max(launches_k, 1),
-                 "launches_per_step": launches_k / args.steps, "sum_of_launch_ms_per_step": sum_ms / args.steps,
-                 "busy_ms_per_step": busy_ms / args.steps,
-                 "launch_concurrency": sum_ms / busy_ms if busy_ms > 0 else None,
-                 "share_of_instance_iterations": iters / max(inst_iters, 1),
-                 "instance_iterations_per_s": iters / (busy_ms * 1e-3) if busy_ms > 0 else None}
-            e.update(extra)
-            return e
-
-        solve_ms = kernel_ms - tail_ms
-        solve_iters = inst_iters - tail_iters
-        solve_launches = launches - tail_launches
-        k_solve = kernel_entry(
-            "k_solve", "k_solve<double, team of %d wavefronts per 64-instance tile>" % st["team"], solve_iters,
-            solve_launches, solve_ms, solve_busy_ms,
-            {"regime": "one instance per lane, state streamed through HBM every iteration: HBM-bound in bulk"})
-        lean = st["lean_launches"] > 0
-        tail_name = ("k_lean<double> (tail kernel at two wavefronts per SIMD: a 32-lane group per instance, one joint per lane, "
-                     "state in registers/LDS, H/Dinv/UDinv of the decades of mu precomputed by k_hslots)" if lean else
-                     "k_tail<double> (a 32-lane group per instance, one joint per lane, state in registers/LDS)")
-        k_tail = kernel_entry(
-            "k_tail", tail_name, tail_iters, tail_launches, tail_ms, tail_busy_ms,
-            {"regime": "the state of an instance stays on chip for its whole solve: the kernel's HBM traffic is one load "
-                       "and one store per instance plus the decade slots (`traffic`), so the streaming byte model's "
-                       "roofline does not bind it; what does is fp64 VALU issue latency along the tree levels "
-                       "(DESIGN.md section 4: phase timeline, scripts/ubench/fp64_issue.hip)",
-             "instances_per_step": tail_inst / args.steps,
-             "valu_note": "PMC (profiles/r01_j_k_lean_pmc_summary.txt): 1707 VALU instructions per wavefront-iteration, "
-                          "two wavefronts per SIMD keep its fp64 VALU ~63 % busy (k_tail, one per SIMD: ~31 %); "
-                          "10 % of the wavefront cycles wait on LDS; HBM ~0.6 TB/s",
-             "lean_launches_per_step": st["lean_launches"], "lean_escaped_last_step": st["lean_escaped"],
-             "decade_slots_ms_last_step": st["hslots_ms"]})
-        dominant, other = (k_tail, k_solve) if tail_iters >= solve_iters else (k_solve, k_tail)
+        model, prm = wl0["model"], wl0["params"]
+        nb, nc = model.nv, int(len(wl0["c_ids"]))
+        B0 = res0["batch"]
+        total_solved, total_iters, total_B = tot["solved"], tot["iters"], tot["batch"]
+        per_gpu = args.batch if args.scaling == "weak" else args.batch // n_total
         line = {
-            "metric": "IK solves/sec to 1e-6 residual, Talos humanoid, batch=65536 per GPU",
+            "metric": "IK solves/sec to 1e-6 residual, Talos humanoid, batch=65536 %s" % (
+                "per GPU" if args.scaling == "weak" else "in total"),
             "value": total_solved * args.steps / elapsed,
             "unit": "solves/s",
-            "n_gpus": world,
+            "n_gpus": n_total,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": wl["name"],
+                "workload": wl0["name"] if args.scaling == "weak" else "talos32_leftwrist_B%d_total_split_%d" % (args.batch, n_total),
                 "robot": "talos32 (fixed base, 32 x 1-DoF, Talos topology)",
-                "batch_per_gpu": B,
+                "batch_per_gpu": per_gpu,
+                "batch_total": int(total_B),
                 "task": "6-D velocity task on arm_left_7_joint, A=I, b=J(q) nu*, nu*~U(-0.5,0.5)^32, box +-0.5",
                 "stop": "tol_abs=1e-6, tol_rel=0, max_iter=1000, reference fixture rho/mu/scale, adaptive mu (DEFAULT)",
-                "parallelism": "%d independent shard(s), no collective" % world,
+                "parallelism": "%d independent shard(s), no collective; %s" % (
+                    n_total, "one process per GPU (torchrun), gloo for the timing barrier only" if world > 1 else
+                    "one process, one host thread + handle + stream per GPU"),
+                "devices_visible": ndev,
+                "shared_gpu_smoke_test": bool(n_total > ndev),
                 "solved_fraction": total_solved / total_B,
-                "flagged_infeasible_fraction_rank0": stats["infeasible"] / B,
-                "hit_max_iter_fraction_rank0": stats["unfinished"] / B,
+                "flagged_infeasible_fraction_gpu0": res0["infeasible"] / B0,
+                "hit_max_iter_fraction_gpu0": res0["unfinished"] / B0,
                 "mean_admm_iterations": total_iters / total_B,
                 "instance_iterations_per_s": total_iters * args.steps / elapsed,
-                "solve_init_s_rank0_incl_pcie": t_init,
+                "solve_init_s_gpu0_incl_pcie": t_init0,
             },
-            "roofline": dict(
-                {"bound": "hbm",
-                 "bytes_per_unit": bytes_iter,
-                 "unit_def": "one ADMM iteration of one instance: 8 B x (203 nb + 108 nc), nb=32, nc=1 (the three-sweep "
-                             "streaming model of SURVEY.md 8(d))",
-                 "achieved_def": "algorithmic bytes of all launches of the kernel / time with >= 1 of its launches "
-                                 "executing (= bytes per launch / average launch duration x launch_concurrency); "
-                                 "frac > 1 means the kernel does not move the model's bytes: it keeps state on chip"},
-                **dominant,
-                **{"other_kernel": other,
-                   "concurrent_chunks": st["chunks"],
-                   "concurrency_note": "the batch is solved as %d independent chunk(s), each on its own stream; "
-                                       "avg_launch_ms is per launch as timed by HIP events (launches of the chunks "
-                                       "overlap and slow each other down), `aggregate` is all kernels' algorithmic bytes "
-                                       "against the stream wall time of the whole Solve()" % st["chunks"],
-                   "aggregate_algorithmic_GBps": inst_iters * bytes_iter / (solve_wall_ms * 1e-3) / 1e9 if solve_wall_ms > 0 else None,
-                   "aggregate_frac_of_peak": inst_iters * bytes_iter / (solve_wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if solve_wall_ms > 0 else None}),
+            "roofline": kernel_roofline(acc0, last0, args.steps, nb, nc, B0),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if strong is not None:
+            line["strong_scaling"] = strong
+        if n_total == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(wl)
+                line["cpu_baseline"] = cpu_baseline(wl0)
             except Exception as e:  # the GPU number must survive a broken host toolchain
-                line["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": os.cpu_count(), "kind": "port",
+                line["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": effective_cpus()[0], "kind": "port",
                                         "sample": "failed: %r" % (e,)}
         print(json.dumps(line), flush=True)
-    solver.close()
+        ret = line
+    else:
+        ret = None
+    if strong is None:
+        for sh in shards:
+            sh.solver.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return ret
 
 
 if __name__ == "__main__":

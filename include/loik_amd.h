@@ -130,6 +130,9 @@ int loikb_solve_tailored(loikb_solver *s, const double *q, int c_id, const doubl
  *                            first-order re-normalised quaternion for free-flyer and spherical joints)
  *   loikb_solve_tailored(s, NULL, c_id, Ai, bi, flags):  q == NULL means "the resident q"                           */
 int loikb_integrate(loikb_solver *s, double dt);
+/* hipDeviceSynchronize() on the solver's device: every solve entry point already returns after its own stream drained;
+ * this is the explicit bracket a timing harness (bench.py) or a caller with its own streams puts around them */
+int loikb_synchronize(loikb_solver *s);
 
 /* setters of IkIdSolverBaseTpl / the solver (task-solver-base.hpp:104-141, loik-loid-optimized.hpp:702-703).
  * Two deliberate differences from upstream, both flagged here because a drop-in must not surprise:

@@ -77,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "loikb_solve_tailored", "loikb_set_max_iter", "loikb_set_rho", "loikb_set_mu", "loikb_set_tol",
     "loikb_set_tol_primal_inf", "loikb_set_tol_tail_solve", "loikb_set_warm_start", "loikb_get", "loikb_get_stats",
     "loikb_batch", "loikb_nv", "loikb_njoints", "loikb_last_error", "loikb_status_string", "loikb_version",
-    "loikb_device_count", "loikb_sweep_schedule", "loikb_integrate", "loikb_builtin_model", "loikb_builtin_joint_name",
+    "loikb_device_count", "loikb_sweep_schedule", "loikb_integrate", "loikb_synchronize", "loikb_builtin_model", "loikb_builtin_joint_name",
     "loikb_builtin_joint_id"]
 
 _lib = None
@@ -102,6 +102,7 @@ def lib():
     L.loikb_solve_full.argtypes = sig
     L.loikb_solve.argtypes = [C.c_void_p]
     L.loikb_integrate.argtypes = [C.c_void_p, C.c_double]
+    L.loikb_synchronize.argtypes = [C.c_void_p]
     L.loikb_sweep_schedule.argtypes = [_ip, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip]
     L.loikb_solve_tailored.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     L.loikb_set_max_iter.argtypes = [C.c_void_p, C.c_int]
@@ -282,42 +283,62 @@ class BatchedLoik:
         keep, args = self._raw_args(q, H_ref, v_ref, active_task_constraint_ids, Ais, bis, lb, ub)
         _check(self.L.loikb_solve_init(*args))
 
+    def _prep(self, a, what, per, shared_flag):
+        """One per-instance input: (void*, is_device, flag).  The C-ABI takes bare pointers without lengths, so the sizes are
+        validated HERE: a host array must hold exactly `per` elements (one value shared by the whole batch -> `shared_flag`)
+        or `batch * per` (instance-major).  Device pointers / torch tensors are per-instance by contract; a torch tensor's
+        numel is checked, a raw integer pointer cannot be."""
+        B = self.batch
+        if isinstance(a, int):
+            return C.c_void_p(a), True, 0, None
+        if hasattr(a, "data_ptr"):
+            n = int(a.numel()) if hasattr(a, "numel") else None
+            if n is not None and n != B * per:
+                raise ValueError("%s: device tensor has %d elements, expected batch * %d = %d" % (what, n, per, B * per))
+            if getattr(a, "is_cuda", False):
+                return C.c_void_p(a.data_ptr()), True, 0, a
+            a = a.numpy() if hasattr(a, "numpy") else np.asarray(a)
+        a = _f64(a)
+        if a.size == B * per and not (B == 1 and shared_flag in (A_SHARED, BOUNDS_SHARED)):
+            return a.ctypes.data_as(C.c_void_p), False, 0, a         # (batch 1: q / b count as per-instance, A / box as shared)
+        if a.size == per:
+            return a.ctypes.data_as(C.c_void_p), False, shared_flag, a
+        raise ValueError("%s has %d elements: expected %d (shared by the batch) or batch * %d = %d (instance-major)"
+                         % (what, a.size, per, per, B * per))
+
     def _raw_args(self, q, H_ref, v_ref, c_ids, Ais, bis, lb, ub):
-        """size validation is the library's job (it returns the reference's error codes)"""
-        B, nc, nv, nq = self.batch, self.nc, self.model.nv, self.model.nq
-        flags = 0
-        keep = []
-        H_ref = _f64(H_ref).reshape(36); v_ref = _f64(v_ref).reshape(6)
-        c_ids = np.ascontiguousarray(c_ids, dtype=np.int32)
+        """marshal SolveInit / Solve(q,H_ref,...) arguments; array lengths are checked here (see _prep), the reference's
+        own validation (constraint count, bound dimension, duplicates) is the library's and comes back as its error codes"""
+        B, nv, nq = self.batch, self.model.nv, self.model.nq
+        H_ref = _f64(H_ref); v_ref = _f64(v_ref)
+        if H_ref.size != 36 or v_ref.size != 6:
+            raise ValueError("H_ref must be 6x6 and v_ref a 6-vector")
+        H_ref = H_ref.reshape(36); v_ref = v_ref.reshape(6)
+        c_ids = np.ascontiguousarray(c_ids, dtype=np.int32).reshape(-1)
         ncin = int(c_ids.size)
-        keep += [H_ref, v_ref, c_ids]
-        devs = []
-
-        def prep(a, per, shared_flag, allow_shared=True):
-            nonlocal flags
-            if hasattr(a, "data_ptr") or isinstance(a, int):
-                p, dev = _ptr(a)
-                devs.append(dev)
-                return p
-            a = _f64(a)
-            keep.append(a)
-            if allow_shared and a.size == per and not (B == 1 and shared_flag in (Q_SHARED, B_SHARED)):
-                flags |= shared_flag
-            else:
-                devs.append(False)
-            return a.ctypes.data_as(C.c_void_p)
-
-        qp = prep(q, nq, Q_SHARED)
-        Ap = prep(Ais, 36 * ncin, A_SHARED)
-        bp = prep(bis, 6 * ncin, B_SHARED)
-        lb_n = None if (hasattr(lb, "data_ptr") or isinstance(lb, int)) else int(np.asarray(lb).size)
-        nbound = nv if lb_n is None or lb_n == nv * B else lb_n
-        lp = prep(lb, nbound, BOUNDS_SHARED)
-        up = prep(ub, nbound, BOUNDS_SHARED)
+        # lb/ub dimension: the library compares it with model.nv and returns the reference's error (hpp:328-335)
+        nbound = nv
+        if not (isinstance(lb, int) or hasattr(lb, "data_ptr")):
+            n = int(np.asarray(lb).size)
+            if n != nv and n != nv * B:
+                if int(np.asarray(ub).size) != n:
+                    raise ValueError("lb and ub differ in size")
+                nbound = n
+        qp, qd, qf, k0 = self._prep(q, "q", nq, Q_SHARED)
+        Ap, Ad, Af, k1 = self._prep(Ais, "Ais", 36 * ncin, A_SHARED) if ncin else (None, None, 0, None)
+        bp, bd, bf, k2 = self._prep(bis, "bis", 6 * ncin, B_SHARED) if ncin else (None, None, 0, None)
+        lp, ld, lf, k3 = self._prep(lb, "lb", nbound, BOUNDS_SHARED)
+        up, ud, uf, k4 = self._prep(ub, "ub", nbound, BOUNDS_SHARED)
+        if lf != uf:
+            raise ValueError("lb and ub must both be shared ([nv]) or both be per instance ([batch][nv])")
+        flags = qf | Af | bf | lf
+        # device residency is one flag for all per-instance inputs: those that are not shared must agree
+        devs = [d for d, f in ((qd, qf), (Ad, Af), (bd, bf), (ld, lf), (ud, uf)) if d is not None and not f]
         if any(devs):
             if not all(devs):
                 raise ValueError("per-instance inputs must be all host or all device arrays")
             flags |= IN_DEVICE
+        keep = [H_ref, v_ref, c_ids, k0, k1, k2, k3, k4]
         args = (self.h, qp, H_ref.ctypes.data_as(_dp), v_ref.ctypes.data_as(_dp), c_ids.ctypes.data_as(_ip), ncin, Ap,
                 bp, lp, up, nbound, flags)
         return keep, args
@@ -332,33 +353,24 @@ class BatchedLoik:
             _check(self.L.loikb_solve_full(*args))
         elif len(a) == 4:
             q, c_id, Ai, bi = a
-            B = self.batch
-            flags = 0
-            keep = []
-            devs = []
-
-            def prep(x, per, shared_flag):
-                nonlocal flags
-                if hasattr(x, "data_ptr") or isinstance(x, int):
-                    p, dev = _ptr(x)
-                    devs.append(dev)
-                    return p
-                x = _f64(x)
-                keep.append(x)
-                if x.size == per and not (B == 1 and shared_flag in (Q_SHARED, B_SHARED)):
-                    flags |= shared_flag
-                else:
-                    devs.append(False)
-                return x.ctypes.data_as(C.c_void_p)
-
-            qp = None if q is None else prep(q, self.model.nq, Q_SHARED)  # None: the q resident on the device
-            Ap = prep(Ai, 36, A_SHARED)
-            bp = prep(bi, 6, B_SHARED)
+            qp, qd, qf = None, None, 0
+            if q is not None:  # None: the q resident on the device
+                qp, qd, qf, k0 = self._prep(q, "q", self.model.nq, Q_SHARED)
+            Ap, Ad, Af, k1 = self._prep(Ai, "Ai", 36, A_SHARED)
+            bp, bd, bf, k2 = self._prep(bi, "bi", 6, B_SHARED)
+            flags = qf | Af | bf
+            devs = [d for d, f in ((qd, qf), (Ad, Af), (bd, bf)) if d is not None and not f]
             if any(devs):
+                if not all(devs):
+                    raise ValueError("per-instance inputs must be all host or all device arrays")
                 flags |= IN_DEVICE
             _check(self.L.loikb_solve_tailored(self.h, qp, int(c_id), Ap, bp, flags))
         else:
             raise TypeError("Solve() takes 0, 4 or 8 arguments")
+
+    def synchronize(self):
+        """hipDeviceSynchronize on the solver's device (bench.py's timing bracket)"""
+        _check(self.L.loikb_synchronize(self.h))
 
     def integrate(self, dt):
         """outer loop on the device: q <- q (+) dt * z of the last solve, q stays resident in HBM"""

@@ -774,6 +774,21 @@ int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, 
   return LOIKB_OK;
 }
 
+// instances of the home set that ran out of iterations: finished, neither converged nor flagged infeasible
+template <typename T>
+__global__ void k_count_unfinished(char* tiles, Layout L, int B, unsigned int* __restrict__ counter)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  int hit = 0;
+  if (b < B) {
+    char* sp = lane_ptr<T>(tiles, L, b);
+    const int status = (int)ldp<T>(sp + (size_t)L.off_s * pair_bytes<T>(), SP_ST).x;
+    hit = !(status & (ST_CONVERGED | ST_PRIMAL_INF));
+  }
+  const unsigned long long m = __ballot(hit);
+  if ((threadIdx.x & (WAVE - 1)) == 0 && m) atomicAdd(counter, (unsigned int)__popcll(m));
+}
+
 // move the live instances of set `src` (n_src slots) to the first slots of set `dst`; finished ones go home.
 // dst < 0: end of the solve, everything still in a work set goes home.
 template <typename T>
@@ -1222,14 +1237,20 @@ int run_main_loop_t(loikb_solver_impl* S)
     for (Chunk& C : S->chunks)
       if (C.rc) { g_last_error = C.err; return C.rc; }
   }
+  // n_unfinished: instances that stopped at max_iter, neither converged nor flagged (whatever engine finished them)
+  Chunk* C0 = &S->chunks[0];
+  HIPCHK(hipMemsetAsync(C0->d_counters, 0, sizeof(unsigned int), S->stream));
+  hipLaunchKernelGGL(k_count_unfinished<T>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, S->B, C0->d_counters);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(C0->h_counters, C0->d_counters, sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
   HIPCHK(hipEventRecord(S->ev_t1, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
   float tms = 0.f;
   HIPCHK(hipEventElapsedTime(&tms, S->ev_t0, S->ev_t1));
+  S->stats.n_unfinished = (int)C0->h_counters[0];
   for (const Chunk& C : S->chunks) {
     S->stats.instance_iterations += C.stats.instance_iterations;
     S->stats.launches += C.stats.launches;
-    S->stats.n_unfinished += C.stats.n_unfinished;
     S->stats.compactions += C.stats.compactions;
     S->stats.tail_instances += C.stats.tail_instances;
     S->stats.tail_ms += C.stats.tail_ms;
@@ -1433,7 +1454,8 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
 {
   if (!model || !opts || !out) return LOIKB_ERR_ARG;
   if (opts->eq_c_dim != 6) return LOIKB_ERR_EQ_C_DIM;
-  if (opts->batch < 1 || opts->num_eq_c < 0) { g_last_error = "batch must be >= 1"; return LOIKB_ERR_ARG; }
+  if (opts->batch < 1) { g_last_error = "batch must be >= 1"; return LOIKB_ERR_ARG; }
+  if (opts->num_eq_c < 0) { g_last_error = "num_eq_c must be >= 0"; return LOIKB_ERR_ARG; }
   loikb_solver* S = new loikb_solver();
   int rc = build_schedule(S, model);
   if (rc) { delete S; return rc; }
@@ -1638,11 +1660,20 @@ int loikb_integrate(loikb_solver* S, double dt)
   return LOIKB_OK;
 }
 
+int loikb_synchronize(loikb_solver* S)
+{
+  if (!S) return LOIKB_ERR_ARG;
+  HIPCHK(hipSetDevice(S->device));
+  HIPCHK(hipDeviceSynchronize());
+  return LOIKB_OK;
+}
+
 int loikb_set_max_iter(loikb_solver* S, int v) { if (!S) return LOIKB_ERR_ARG; S->opt.max_iter = v; return LOIKB_OK; }
 int loikb_set_rho(loikb_solver* S, double v)
 {
   if (!S) return LOIKB_ERR_ARG;
   S->opt.rho = v;
+  HIPCHK(hipSetDevice(S->device));
   return reset_home(S, RS_HCACHE);
 }
 int loikb_set_mu(loikb_solver* S, double v) { if (!S) return LOIKB_ERR_ARG; S->opt.mu = v; return LOIKB_OK; }

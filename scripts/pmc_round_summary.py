@@ -1,0 +1,53 @@
+"""Summarise the PMC passes of scripts/profile_round.sh into one JSON (per kernel, per Solve() step of the profiled bench run).
+HBM bytes as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE from separate passes, KiB units,
+FETCH_SIZE doubled on gfx950 (it reports half the bytes of wide coalesced streaming reads); WRITE_SIZE uncorrected."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+out_dir, nsolves = sys.argv[1], int(sys.argv[2])  # nsolves = warmup + steps of every profiled run
+KEYS = ["k_solve", "k_tail", "k_lean", "k_hslots", "k_move", "k_sched"]
+tot = collections.defaultdict(lambda: collections.defaultdict(float))
+ndisp = collections.defaultdict(lambda: collections.defaultdict(int))
+for path in glob.glob(os.path.join(out_dir, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(path)):
+        name = row["Kernel_Name"]
+        key = next((k for k in KEYS if k in name), None)
+        if key is None:
+            continue
+        tot[key][row["Counter_Name"]] += float(row["Counter_Value"])
+        ndisp[key][row["Counter_Name"]] += 1
+out = {"source": "rocprofv3 --kernel-trace --pmc, separate passes (scripts/profile_round.sh); FETCH_SIZE/WRITE_SIZE in KiB, "
+                 "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950), WRITE_SIZE uncorrected",
+       "batch": 65536, "solves_profiled": nsolves, "compute_units": 256, "shader_clock_ghz": 2.4, "kernels": {}}
+for k, d in tot.items():
+    e = {}
+    anyc = next(iter(d))
+    e["dispatches_per_step"] = ndisp[k][anyc] / nsolves
+    if "FETCH_SIZE" in d:
+        e["fetch_bytes_per_step"] = 2.0 * d["FETCH_SIZE"] * 1024 / nsolves
+    if "WRITE_SIZE" in d:
+        e["write_bytes_per_step"] = d["WRITE_SIZE"] * 1024 / nsolves
+    for c, label in [("SQ_INSTS_VALU", "valu_insts_per_step"), ("SQ_INSTS_SALU", "salu_insts_per_step"),
+                     ("SQ_INSTS_LDS", "lds_insts_per_step"), ("SQ_WAVE_CYCLES", "wave_cycles_per_step"),
+                     ("SQ_BUSY_CYCLES", "busy_cycles_per_step"), ("SQ_WAIT_INST_LDS", "wait_inst_lds_per_step")]:
+        if c in d:
+            e[label] = d[c] / nsolves
+    if "SQ_ACTIVE_INST_LDS" in d and d["SQ_ACTIVE_INST_LDS"] > 0 and "SQ_LDS_BANK_CONFLICT" in d:
+        e["lds_bank_conflict_frac"] = d["SQ_LDS_BANK_CONFLICT"] / d["SQ_ACTIVE_INST_LDS"]
+    out["kernels"][k] = e
+# wavefront-iterations of the lean kernel of one step, when the bench line of the same tag is there
+try:
+    line = json.loads(open(os.path.join(out_dir, "bench_line.json")).read().strip().splitlines()[-1])
+    out["bench_ms_per_step"] = line["ms_per_step"]
+    out["instance_iterations_per_step"] = line["roofline"]["units_per_launch"] * line["roofline"]["launches_per_step"]
+    kl = out["kernels"].get(line["roofline"]["kernel"])
+    if kl and "valu_insts_per_step" in kl:
+        # two instances per wavefront on Talos (a 32-lane group each): wavefront-iterations ~ instance-iterations / 2 at full packing
+        kl["valu_insts_per_instance_iteration"] = kl["valu_insts_per_step"] / out["instance_iterations_per_step"]
+except Exception as e:  # noqa: BLE001
+    out["bench_line_note"] = "no bench line: %r" % (e,)
+print(json.dumps(out, indent=1))

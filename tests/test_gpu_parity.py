@@ -651,3 +651,32 @@ def test_setters_equal_constructor_arguments(talos):
     out = ref.solve_batch(talos, *args[:4], wl["Ais"], wl["bis"], wl["lb"], wl["ub"], nthreads=4, **new)
     assert_end_to_end(fetch_end_to_end(a, nu=False), out, new, ztol=1e-8, what="setters")
     a.close(); b.close()
+
+
+def test_stats_count_unfinished_instances(talos):
+    """loikb_stats.n_unfinished = instances that ran out of iterations (neither converged nor flagged), on every engine"""
+    link = talos.getJointId("arm_left_7_joint")
+    wl = feasible_batch(talos, 300, link, 5, nu_scale=0.5)
+    prm = dict(FIXTURE, max_iter=12, tol_abs=1e-6, tol_rel=0.0)
+    for kw in (dict(), dict(tail_max_instances=-1)):
+        s = gpu_solve(talos, wl, prm, **kw)
+        conv, inf = s.get("converged").astype(bool), s.get("primal_infeasible").astype(bool)
+        want = int((~conv & ~inf).sum())
+        assert want > 0 and s.stats()["n_unfinished"] == want, (kw, want, s.stats()["n_unfinished"])
+        s.close()
+
+
+def test_bench_two_shards_in_one_process(monkeypatch, capsys):
+    """`bench.py --gpus 2` drives two handles from two host threads in one process (here both on the one visible GPU:
+    LOIKB_ALLOW_SHARED_GPU=1) -- the multi-GPU path of the bench executes on hardware; weak line + strong leg"""
+    import json
+    import bench
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setenv("LOIKB_ALLOW_SHARED_GPU", "1")
+    ndev = loik_amd.device_count()
+    line = bench.main(["--gpus", str(2 * ndev), "--steps", "2", "--warmup", "1", "--batch", "4096", "--no-cpu-baseline"])
+    assert line["n_gpus"] == 2 * ndev and line["config"]["batch_total"] == 4096 * 2 * ndev
+    assert 0.5 < line["config"]["solved_fraction"] <= 1.0
+    assert line["roofline"]["bound"] == "fp64_valu" and 0.0 < line["roofline"]["frac"] < 1.0
+    assert line["strong_scaling"]["batch_total"] == 4096
+    assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])["value"] == line["value"]
