@@ -231,6 +231,8 @@ typedef struct loikb_stats {
   int lean_escaped;                       /* instances whose mu left the precomputed decades in a lean launch and were
                                              finished by the other tail kernel                                         */
   double hslots_ms;                       /* HIP-event time of the decade-slot precomputation (part of tail_ms)        */
+  int lean_requeues;                      /* time slices that ended with the instance going to the back of the lean kernel's
+                                             work queue (round-robin among the instances waiting for a slot)                */
 } loikb_stats;
 int loikb_get_stats(loikb_solver *s, loikb_stats *out);
 

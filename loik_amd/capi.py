@@ -46,7 +46,7 @@ class Stats(C.Structure):
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("bytes_per_instance_iteration", C.c_double),
                 ("tail_instance_iterations", C.c_ulonglong), ("tail_launches", C.c_int), ("team", C.c_int), ("chunks", C.c_int),
                 ("solve_busy_ms", C.c_double), ("tail_busy_ms", C.c_double), ("lean_launches", C.c_int),
-                ("lean_escaped", C.c_int), ("hslots_ms", C.c_double)]
+                ("lean_escaped", C.c_int), ("hslots_ms", C.c_double), ("lean_requeues", C.c_int)]
 
 
 # enums of loik_amd.h

@@ -123,6 +123,8 @@ struct loikb_solver_impl {
     unsigned int* h_counters = nullptr;  // pinned
     int* d_slots = nullptr;              // list of the live instances handed to the tail kernel
     int* d_slots2 = nullptr;             // instances that left the lean kernel unfinished (same capacity)
+    int* d_ring = nullptr;               // work queue of the lean kernel: ring of instance slots (ring_cap, a power of two)
+    int ring_cap = 0;
     void* d_hslots = nullptr;            // decade slots of the lean tail kernel (H, Dinv, UDinv per joint and decade)
     size_t hslots_bytes = 0;
     std::vector<int> h_wave;             // host scratch for the compaction scan
@@ -920,8 +922,10 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     if (lean_ok) {
       const size_t lds = TAIL_WAVES * wave_lds;
       if (lds > 64 * 1024) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       }
       int wg_per_cu = 2;
       if (const char* e = getenv("LOIKB_LEAN_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
@@ -939,6 +943,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         for (const char* p = e; *p;) { quanta.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
       }
       quanta.push_back(S->opt.max_iter + 1);
+      int lean_quantum = 0;  // default: run to completion in arrival order (scheduling study)
+      if (const char* e = getenv("LOIKB_LEAN_SLICE")) lean_quantum = std::max(0, atoi(e));
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
       float t_first = -1.f;
       unsigned int escaped = 0;
@@ -948,7 +954,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         P.max_launch_iters = quanta[round];
         const int wg_needed = (n + ipw * TAIL_WAVES - 1) / (ipw * TAIL_WAVES);
         const dim3 grid((unsigned)std::min(wg_needed, wg_cap));
-        HIPCHK(hipMemsetAsync(C->d_counters, 0, 8 * sizeof(unsigned int), C->stream));
+        HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
         if (!slots_built) {
           slots_built = true;
           const dim3 hgrid((unsigned)((n + ipw - 1) / ipw));
@@ -963,27 +969,31 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                                (T*)C->d_hslots, kexp_lo, ndec);
           HIPCHK(hipEventRecord(C->ev_k2, C->stream));
         }
-        if (S->href_diag)
-          hipLaunchKernelGGL((k_lean<T, true>), grid, dim3(WAVE * TAIL_WAVES), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
-                             (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
-                             (const T*)C->d_hslots, kexp_lo, ndec);
-        else
-          hipLaunchKernelGGL((k_lean<T, false>), grid, dim3(WAVE * TAIL_WAVES), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
-                             (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
-                             (const T*)C->d_hslots, kexp_lo, ndec);
+        hipLaunchKernelGGL(k_ring_fill, grid1(C->ring_cap), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, list, n, C->d_counters);
+        // time slice of the in-kernel round-robin queue (0 = run every instance to completion in arrival order); bounded
+        // host-side rounds (LOIKB_LEAN_QUANTA) bring their own bound and switch it off
+        const int quantum = quanta.size() > 1 ? 0 : lean_quantum;
+#define LOIKB_LAUNCH_LEAN(HD, SL)                                                                                             \
+  hipLaunchKernelGGL((k_lean<T, HD, SL>), grid, dim3(WAVE * TAIL_WAVES), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,      \
+                     (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, C->d_ring,              \
+                     C->ring_cap - 1, n, G, (const T*)C->d_hslots, kexp_lo, ndec, quantum)
+        if (quantum > 0) { if (S->href_diag) LOIKB_LAUNCH_LEAN(true, true); else LOIKB_LAUNCH_LEAN(false, true); }
+        else { if (S->href_diag) LOIKB_LAUNCH_LEAN(true, false); else LOIKB_LAUNCH_LEAN(false, false); }
+#undef LOIKB_LAUNCH_LEAN
         HIPCHK(hipGetLastError());
         // the instances that are still iterating: the next round's list (ping-pong between the two list buffers)
         int* next = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
         hipLaunchKernelGGL(k_list_unfinished<T>, grid1(n), dim3(256), 0, C->stream, A.tiles, S->L, list, n, next, C->d_counters + 3);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(C->ev_k1, C->stream));
-        HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+        HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
         HIPCHK(hipStreamSynchronize(C->stream));
         float ms = 0.f, t0 = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));  // since the start of the first round
         if (t_first < 0.f) { HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0)); t_first = t0; }
         iters += C->h_counters[1];
         escaped = C->h_counters[2];
+        C->stats.lean_requeues += (int)C->h_counters[LEAN_Q_REQUEUES];
         if (!first_timed) {
           first_timed = true;
           float hms = 0.f;
@@ -992,9 +1002,9 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         }
         if (trace)
           fprintf(stderr, "[loikb] lean tail round %zu (<= %d iterations each): %6d instances on %u workgroups, done at %8.3f ms"
-                          "  inst-iters %9u  wave-iters %7u slot loads %7u  escaped %u  still iterating %u\n",
+                          "  inst-iters %9u  wave-iters %7u slot loads %7u  escaped %u  still iterating %u  requeued %u\n",
                   round, quanta[round], n, grid.x, ms, C->h_counters[1], C->h_counters[5], C->h_counters[6], escaped,
-                  C->h_counters[3]);
+                  C->h_counters[3], C->h_counters[LEAN_Q_REQUEUES]);
         C->stats.launches++;
         C->stats.tail_launches++;
         C->stats.lean_launches++;
@@ -1012,7 +1022,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     P.max_launch_iters = S->opt.max_iter + 1;
     const int wg_needed = (n + ipw * tw - 1) / (ipw * tw);
     const dim3 grid((unsigned)std::min(wg_needed, cu_share));
-    HIPCHK(hipMemsetAsync(C->d_counters, 0, 8 * sizeof(unsigned int), C->stream));
+    HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
     HIPCHK(hipEventRecord(C->ev_k0, C->stream));
     if (S->href_diag)
       hipLaunchKernelGGL((k_tail<T, true>), grid, dim3(WAVE * tw), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
@@ -1024,7 +1034,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                          list, n, G);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(C->ev_k1, C->stream));
-    HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+    HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
     HIPCHK(hipStreamSynchronize(C->stream));
     float ms = 0.f, t0 = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));
@@ -1142,7 +1152,7 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
     const Team tm{sc.d_up, sc.d_down, sc.d_rlist, sc.T_up, sc.T_down, edge_ent};
     const size_t lds = lds_bytes(sc);
     const dim3 grid((unsigned)((n_cur + WAVE - 1) / WAVE)), block(WAVE * sc.nw);
-    HIPCHK(hipMemsetAsync(C->d_counters, 0, 8 * sizeof(unsigned int), C->stream));
+    HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
     HIPCHK(hipEventRecord(C->ev_k0, C->stream));
     if (sc.nw > 1) {
       if (S->href_diag) hipLaunchKernelGGL((k_solve<T, true, true>), grid, block, lds, C->stream, P, Bf, tm.up, tm.down, tm.rlist, tm.T_up, tm.T_down, tm.edge_ent);
@@ -1153,7 +1163,7 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(C->ev_k1, C->stream));
-    HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, 8 * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+    HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
     HIPCHK(hipStreamSynchronize(C->stream));
     float ms = 0.f, t0 = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));
@@ -1260,6 +1270,7 @@ int run_main_loop_t(loikb_solver_impl* S)
     S->stats.lean_launches += C.stats.lean_launches;
     S->stats.lean_escaped += C.stats.lean_escaped;
     S->stats.hslots_ms += C.stats.hslots_ms;
+    S->stats.lean_requeues += C.stats.lean_requeues;
     S->stats.team = C.stats.team;
   }
   S->stats.chunks = nchunks;
@@ -1506,10 +1517,13 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
       HIPTRY(hipEventCreate(&C.ev_k2));
       HIPTRY(hipEventCreate(&C.ev_k0));
       HIPTRY(hipEventCreate(&C.ev_k1));
-      HIPTRY(hipHostMalloc((void**)&C.h_counters, 8 * sizeof(unsigned int)));
-      TRY(alloc_dev(S, &tmp, 8 * sizeof(unsigned int))); C.d_counters = (unsigned int*)tmp;
+      HIPTRY(hipHostMalloc((void**)&C.h_counters, NCOUNTERS * sizeof(unsigned int)));
+      TRY(alloc_dev(S, &tmp, NCOUNTERS * sizeof(unsigned int))); C.d_counters = (unsigned int*)tmp;
       TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)(C.B + WAVE))); C.d_slots = (int*)tmp;
       TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)(C.B + WAVE))); C.d_slots2 = (int*)tmp;
+      C.ring_cap = 64;
+      while (C.ring_cap < 2 * (C.B + WAVE)) C.ring_cap <<= 1;
+      TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)C.ring_cap)); C.d_ring = (int*)tmp;
       if (S->chunks.size() > 1) {
         HIPTRY(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
         C.own_stream = true;
@@ -1839,6 +1853,11 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
 
 #ifdef LOIKB_TAIL_PROF
 // diagnostic build only: cycles per phase of wavefront 0 of the last tail launch + its iteration count
+int loikb_debug_wave_dbg(unsigned long long* out)
+{
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(loikb::g_wave_dbg), sizeof(unsigned long long) * 4096 * 6));
+  return LOIKB_OK;
+}
 int loikb_debug_tail_prof(unsigned long long* out)
 {
   HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(loikb::g_tail_prof), sizeof(unsigned long long) * 10));

@@ -40,7 +40,85 @@ enum : int { IS_MU = 0, IS_KEXP, IS_ITER, IS_STATUS, IS_TAILIT, IS_C1, IS_C2, IS
 // constraint block of an instance in LDS: lane of the constrained joint, b, A^T b, y, A^T y (+ A when it is per instance;
 // a shared A is kept once per wavefront).  AtA is not needed: H is never rebuilt here.
 constexpr int LCD = 26, LCA = 36;
+// counters of a lean launch (Bufs::counters): [1] instance-iterations, [2] escaped instances, [5] wavefront-iterations,
+// [6] decade-slot loads, and the work queue:
+constexpr int LEAN_Q_HEAD = 7, LEAN_Q_TAIL = 8, LEAN_Q_REQUEUES = 9, LEAN_Q_RETIRED = 10;
+constexpr int NCOUNTERS = 16;
+#ifndef LOIKB_POLL_MASK
+#define LOIKB_POLL_MASK 3u
+#endif
 enum : int { LC_PAD = 0, LC_B = 1, LC_ATB = 7, LC_Y = 13, LC_ATY = 19 };
+
+// ---- accesses to an instance's record that are coherent across the chip WITHOUT fences.  The lean kernel's work queue lets
+// an instance migrate between lane groups -- i.e. between CUs of different XCDs, each with its own L2 -- within ONE launch.
+// An agent-scope release/acquire pair would make that safe, but on gfx950 it costs a write-back + invalidate of a whole
+// 4 MB L2 (measured: 20 us per instance switch, 60x the kernel's run time).  Instead every load/store of the mutable part
+// of a record is an agent-scope relaxed atomic: the access itself carries the scope bits (sc1: stores write through, loads
+// do not hit possibly stale L2/L1 lines), nothing else is flushed.  Ordering between the record and the queue entry that
+// publishes it is by completion: the pusher waits for its stores (s_waitcnt vmcnt(0)) before it writes the ring entry,
+// the popper issues its loads after it has read the entry.
+template <typename T>
+#ifdef LOIKB_PLAIN_RECORDS
+__device__ __forceinline__ T cld(const char* p) { return *reinterpret_cast<const T*>(p); }
+#else
+__device__ __forceinline__ T cld(const char* p) { return __hip_atomic_load(reinterpret_cast<const T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+template <typename T>
+#ifdef LOIKB_PLAIN_RECORDS
+__device__ __forceinline__ void cst(char* p, T v) { *reinterpret_cast<T*>(p) = v; }
+#else
+__device__ __forceinline__ void cst(char* p, T v) { __hip_atomic_store(reinterpret_cast<T*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+template <typename T>
+__device__ __forceinline__ typename Vec2<T>::type cldp(const char* rec, int p)
+{
+  typename Vec2<T>::type v;
+  v.x = cld<T>(rec + (size_t)p * pair_bytes<T>());
+  v.y = cld<T>(rec + (size_t)p * pair_bytes<T>() + sizeof(T));
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ void cstp(char* rec, int p, T x, T y)
+{
+  cst<T>(rec + (size_t)p * pair_bytes<T>(), x);
+  cst<T>(rec + (size_t)p * pair_bytes<T>() + sizeof(T), y);
+}
+template <typename T>
+__device__ __forceinline__ void cld6(const char* rec, int p, T* x)
+{
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const typename Vec2<T>::type v = cldp<T>(rec, p + k);
+    x[2 * k] = v.x; x[2 * k + 1] = v.y;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void cst6(char* rec, int p, const T* x)
+{
+#pragma unroll
+  for (int k = 0; k < 3; ++k) cstp<T>(rec, p + k, x[2 * k], x[2 * k + 1]);
+}
+template <typename T>
+__device__ __forceinline__ T cld_scal(const char* srec, int idx)
+{
+  return cld<T>(srec + (size_t)(SP_SCAL + idx / 2) * pair_bytes<T>() + (idx & 1) * sizeof(T));
+}
+
+// record accessors of the lean kernel: coherent when instances migrate between lane groups (SLICED), plain otherwise
+template <typename T, bool COH>
+__device__ __forceinline__ typename Vec2<T>::type rldp(const char* rec, int p) { if constexpr (COH) return cldp<T>(rec, p); else return ldp<T>(rec, p); }
+template <typename T, bool COH>
+__device__ __forceinline__ void rstp(char* rec, int p, T x, T y) { if constexpr (COH) cstp<T>(rec, p, x, y); else stp<T>(rec, p, x, y); }
+template <typename T, bool COH>
+__device__ __forceinline__ void rld6(const char* rec, int p, T* x) { if constexpr (COH) cld6<T>(rec, p, x); else ld6<T>(rec, p, x); }
+template <typename T, bool COH>
+__device__ __forceinline__ void rst6(char* rec, int p, const T* x) { if constexpr (COH) cst6<T>(rec, p, x); else st6<T>(rec, p, x); }
+template <typename T, bool COH>
+__device__ __forceinline__ T rld_scal(const char* srec, int idx) { if constexpr (COH) return cld_scal<T>(srec, idx); else return ld_scal<T>(srec, idx); }
+template <typename T, bool COH>
+__device__ __forceinline__ T rld(const char* p) { if constexpr (COH) return cld<T>(p); else return *reinterpret_cast<const T*>(p); }
+template <typename T, bool COH>
+__device__ __forceinline__ void rst(char* p, T v) { if constexpr (COH) cst<T>(p, v); else *reinterpret_cast<T*>(p) = v; }
 
 template <typename T>
 __host__ __device__ __forceinline__ size_t lean_lds_bytes(int nc, int G, bool a_shared)
@@ -105,11 +183,11 @@ __device__ __forceinline__ void lean_gather_n(int n, const T* xch, const int* ch
   }
 }
 
-template <typename T, bool HDIAG>
+template <typename T, bool HDIAG, bool SLICED>
 __global__ void __launch_bounds__(WAVE * TAIL_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
-       const int* __restrict__ child_list, int maxdepth, int maxchild, const int* __restrict__ slots, int nslots, int G,
-       const T* __restrict__ hslots, int kexp_lo, int ndec)
+       const int* __restrict__ child_list, int maxdepth, int maxchild, int* __restrict__ ring, int ring_mask, int nslots, int G,
+       const T* __restrict__ hslots, int kexp_lo, int ndec, int quantum)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
@@ -154,28 +232,78 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   T R[9], t[3], v[6], f[6], g[6], UD[6], p[6];
   T w = T(0), z = T(0), nu = T(0), s = T(0), r = T(0), dinv = T(0), lbi = T(0), ubi = T(0), mu = T(1);
   int kexp = 0, kslot = -(1 << 30);
-  unsigned int my_iters = 0;
+  unsigned int my_iters = 0, slice_iters = 0;  // (slice_iters, requeue, ticket, fin: SLICED only)
   unsigned int n_wave_iters = 0, n_slot_loads = 0;
+  bool requeue = false;
 
-  auto fetch = [&]() -> int {
-    int nx = 0;
-    if (jlane == 0) nx = (int)atomicAdd(&Bf.counters[7], 1u);
-    return __shfl(nx, gbase);
+  // ---- work queue: a ring of instance slots in HBM, tickets on both sides (LEAN_Q_HEAD = tickets handed to groups that want
+  // an instance, LEAN_Q_TAIL = entries pushed; ticket t is served by entry t -- one atomicAdd per pop or push, no CAS loop:
+  // thousands of groups pop at the same moment at the start and at the first time-slice boundaries).  The ring starts out
+  // holding every listed instance; a lane group takes one, iterates it for at most `quantum` iterations and, if other
+  // instances are still waiting for a slot (tail > head), writes it back and pushes it to the BACK of the ring: round-robin
+  // time slicing.  Iteration counts are heavy-tailed (median 26, 1.2 % run all 1000) and unpredictable, and a
+  // 1000-iteration instance is a serial chain of ~10 ms -- run to completion in arrival order such instances are fetched
+  // late and the launch ends ~9 ms after the queue ran dry; time-sliced, every long runner advances from the start and
+  // the machine stays full until shortly before the end (scripts/r02/sim_sched.py: 22.1 -> 14.1 ms on the headline).
+  // An instance whose quantum expires while nothing waits simply continues.  A group holding a ticket beyond the tail
+  // polls until its entry appears or every listed instance has retired (LEAN_Q_RETIRED == nslots): finished, or written
+  // back because its mu left the decade slots.
+  unsigned int* q_head = Bf.counters + LEAN_Q_HEAD;
+  unsigned int* q_tail = Bf.counters + LEAN_Q_TAIL;
+  unsigned int* q_retired = Bf.counters + LEAN_Q_RETIRED;
+  unsigned int ticket = 0;
+  bool fin = false;  // this group will get no more work
+  auto q_waiting = [&]() -> bool {
+    int wtg = 0;
+    if (jlane == 0)
+      wtg = (int)(__hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                  __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > 0;
+    return __shfl(wtg, gbase) != 0;
   };
-  auto load_instance = [&](int idx) {
-    has_inst = idx < nslots;
+  auto q_ticket = [&]() {
+    unsigned int tk = 0;
+    if (jlane == 0) tk = atomicAdd(q_head, 1u);
+    ticket = (unsigned int)__shfl((int)tk, gbase);
+  };
+  auto q_poll = [&]() -> int {  // the instance slot of this group's ticket; -1: not there yet; -2: nothing will come any more
+    int got = -1;
+    if (jlane == 0) {
+      int* e = ring + (ticket & (unsigned int)ring_mask);
+      const int v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v >= 0) {
+        __hip_atomic_store(e, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        got = v;
+      } else if (__hip_atomic_load(q_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)nslots) {
+        got = -2;
+      }
+    }
+    return __shfl(got, gbase);
+  };
+  auto q_push = [&](int slot) {  // (after store_instance: every store of the record has completed before the entry appears)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): stores count in vmcnt on gfx9
+    __builtin_amdgcn_wave_barrier();
+    if (jlane == 0) {
+      const unsigned int pos = atomicAdd(q_tail, 1u);
+      int* e = ring + (pos & (unsigned int)ring_mask);
+      // (the ring has more entries than instances + groups: the entry of the previous lap was consumed long ago)
+      while (__hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) __builtin_amdgcn_s_sleep(1);
+      __hip_atomic_store(e, slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto load_instance = [&](int slot_in) {
+    has_inst = slot_in >= 0;
     isj = has_inst && isj_lane;
-    const int slot = slots[has_inst ? idx : 0];
+    const int slot = has_inst ? slot_in : 0;
     lidx = slot;
     ip = lane_ptr<T>(Bf.tiles, L, slot);
     rec = ip + (size_t)jl * JREC * pair_bytes<T>();
     const char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
     {
-      const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
+      const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS), wz = rldp<T, SLICED>(rec, JP_WZ), nus = rldp<T, SLICED>(rec, JP_NUS);
       joint_xform<T>(d, rec, cs.x, cs.y, R, t);
-      ld6<T>(rec, JP_V, v);
-      ld6<T>(rec, JP_F, f);
-      ld6<T>(rec, JP_G, g);
+      rld6<T, SLICED>(rec, JP_V, v);
+      rld6<T, SLICED>(rec, JP_F, f);
+      rld6<T, SLICED>(rec, JP_G, g);
       w = wz.x; z = wz.y; nu = nus.x; s = nus.y;
       if (P.mode & MODE_BND_SHARED) {
         lbi = Bf.uni[L.nc * 57 + jl];
@@ -197,7 +325,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
           if (q >= 24) continue;  // pad
           const int which = q / 6, k = q % 6;
           const int pair = which == 0 ? CP_B : which == 1 ? CP_ATB : which == 2 ? CP_Y : CP_ATY;
-          val = *reinterpret_cast<const T*>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+          val = rld<T, SLICED>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));  // (y, A^T y change in the kernel)
         } else {
           const int q = e - LCD;
           val = *reinterpret_cast<const T*>(crec + (size_t)(CP_A + q / 2) * pair_bytes<T>() + (q & 1) * sizeof(T));
@@ -206,7 +334,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       }
     }
     if (isj_lane && d.cslot >= 0) cdi[d.cslot * cs + LC_PAD] = (T)jlane;
-    const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
+    const typename Vec2<T>::type mu2 = rldp<T, SLICED>(srec, SP_MU), bi2 = rldp<T, SLICED>(srec, SP_BI), st2 = rldp<T, SLICED>(srec, SP_ST);
     mu = mu2.x;
     kexp = (int)mu2.y;
     kslot = -(1 << 30);
@@ -216,31 +344,32 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     if (!done && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { done = true; status |= ST_DONE; }
     if (jlane == 0) {
       isc[IS_MU] = mu; isc[IS_KEXP] = (T)kexp; isc[IS_ITER] = (T)iter; isc[IS_STATUS] = (T)status;
-      isc[IS_TAILIT] = ld_scal<T>(srec, SC_TAIL_ITER);
-      isc[IS_C1] = ld_scal<T>(srec, SC_COND1); isc[IS_C2] = ld_scal<T>(srec, SC_COND2);
-      isc[IS_NFLIP] = ldp<T>(srec, SP_FLIP).x;
-      isc[IS_TOLP] = ld_scal<T>(srec, SC_TOL_PRIMAL); isc[IS_TOLD] = ld_scal<T>(srec, SC_TOL_DUAL);
-      isc[IS_DYQP] = ld_scal<T>(srec, SC_DELTA_Y_QP); isc[IS_ATDY] = ld_scal<T>(srec, SC_AT_DELTA_Y_QP);
-      isc[IS_UBP] = ld_scal<T>(srec, SC_UB_DY_PLUS); isc[IS_LBM] = ld_scal<T>(srec, SC_LB_DY_MINUS);
+      isc[IS_TAILIT] = rld_scal<T, SLICED>(srec, SC_TAIL_ITER);
+      isc[IS_C1] = rld_scal<T, SLICED>(srec, SC_COND1); isc[IS_C2] = rld_scal<T, SLICED>(srec, SC_COND2);
+      isc[IS_NFLIP] = rldp<T, SLICED>(srec, SP_FLIP).x;
+      isc[IS_TOLP] = rld_scal<T, SLICED>(srec, SC_TOL_PRIMAL); isc[IS_TOLD] = rld_scal<T, SLICED>(srec, SC_TOL_DUAL);
+      isc[IS_DYQP] = rld_scal<T, SLICED>(srec, SC_DELTA_Y_QP); isc[IS_ATDY] = rld_scal<T, SLICED>(srec, SC_AT_DELTA_Y_QP);
+      isc[IS_UBP] = rld_scal<T, SLICED>(srec, SC_UB_DY_PLUS); isc[IS_LBM] = rld_scal<T, SLICED>(srec, SC_LB_DY_MINUS);
       isc[IS_BNORM] = bi2.x;
-      isc[IS_TGIN] = ldp<T>(srec, SP_TAG).x; isc[IS_STY] = st2.y; isc[IS_MULAST] = T(-1);
+      isc[IS_TGIN] = rldp<T, SLICED>(srec, SP_TAG).x; isc[IS_STY] = st2.y; isc[IS_MULAST] = T(-1);
     }
     tail_sync();
     my_iters = 0;
+    slice_iters = 0;
     any_iter = false;
   };
   auto store_instance = [&]() {
     char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
     if (isj) {
-      st6<T>(rec, JP_V, v);
-      st6<T>(rec, JP_F, f);
-      st6<T>(rec, JP_G, g);
-      stp<T>(rec, JP_WZ, w, z);
-      stp<T>(rec, JP_NUS, nu, s);
+      rst6<T, SLICED>(rec, JP_V, v);
+      rst6<T, SLICED>(rec, JP_F, f);
+      rst6<T, SLICED>(rec, JP_G, g);
+      rstp<T, SLICED>(rec, JP_WZ, w, z);
+      rstp<T, SLICED>(rec, JP_NUS, nu, s);
       if (any_iter) {
-        st6<T>(rec, JP_P, p);
-        st6<T>(rec, JP_UD, UD);
-        stp<T>(rec, JP_R, r, dinv);
+        rst6<T, SLICED>(rec, JP_P, p);
+        rst6<T, SLICED>(rec, JP_UD, UD);
+        rstp<T, SLICED>(rec, JP_R, r, dinv);
       }
     }
     tail_sync();
@@ -249,34 +378,34 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
         if (jlane < 6) {
           const int k = jlane;
-          *reinterpret_cast<T*>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * cs + LC_Y + k];
-          *reinterpret_cast<T*>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * cs + LC_ATY + k];
+          rst<T, SLICED>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), cdi[c * cs + LC_Y + k]);
+          rst<T, SLICED>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), cdi[c * cs + LC_ATY + k]);
         }
       }
       if (jlane == 0) {
         const T mu_s = isc[IS_MU], mu_last = isc[IS_MULAST];
         const int status = (int)isc[IS_STATUS];
-        stp<T>(srec, SP_MU, mu_s, isc[IS_KEXP]);
-        stp<T>(srec, SP_TAG, any_iter ? mu_last : isc[IS_TGIN], T(0));
-        stp<T>(srec, SP_BI, isc[IS_BNORM], isc[IS_ITER]);
-        stp<T>(srec, SP_FLIP, isc[IS_NFLIP], T(0));
-        stp<T>(srec, SP_ST, (T)(any_iter ? (status | ST_PFULL) : status), any_iter ? mu_last : isc[IS_STY]);
+        rstp<T, SLICED>(srec, SP_MU, mu_s, isc[IS_KEXP]);
+        rstp<T, SLICED>(srec, SP_TAG, any_iter ? mu_last : isc[IS_TGIN], T(0));
+        rstp<T, SLICED>(srec, SP_BI, isc[IS_BNORM], isc[IS_ITER]);
+        rstp<T, SLICED>(srec, SP_FLIP, isc[IS_NFLIP], T(0));
+        rstp<T, SLICED>(srec, SP_ST, (T)(any_iter ? (status | ST_PFULL) : status), any_iter ? mu_last : isc[IS_STY]);
         if (any_iter) {
-          stp<T>(srec, SP_SCAL + 0, isc[IS_PRIMAL], isc[IS_DUAL]);
-          stp<T>(srec, SP_SCAL + 1, isc[IS_PRT], isc[IS_PRS]);
-          stp<T>(srec, SP_SCAL + 2, isc[IS_DUALV], isc[IS_STF]);
-          stp<T>(srec, SP_SCAL + 3, isc[IS_TOLP], isc[IS_TOLD]);
-          stp<T>(srec, SP_SCAL + 4, mu_s, P.mu_scale * mu_s);
-          stp<T>(srec, SP_SCAL + 5, mu_s, isc[IS_DX]);
-          stp<T>(srec, SP_SCAL + 6, isc[IS_DZ], isc[IS_DYQP]);
-          stp<T>(srec, SP_SCAL + 7, isc[IS_ATDY], isc[IS_UBP]);
-          stp<T>(srec, SP_SCAL + 8, isc[IS_LBM], isc[IS_DFIS]);
-          stp<T>(srec, SP_SCAL + 9, isc[IS_DYIS], isc[IS_DW]);
-          stp<T>(srec, SP_SCAL + 10, isc[IS_DVIS], isc[IS_DNU]);
-          stp<T>(srec, SP_SCAL + 11, isc[IS_AV], isc[IS_NU]);
-          stp<T>(srec, SP_SCAL + 12, isc[IS_HREFV], isc[IS_G]);
-          stp<T>(srec, SP_SCAL + 13, isc[IS_STF], isc[IS_C1]);
-          stp<T>(srec, SP_SCAL + 14, isc[IS_C2], isc[IS_TAILIT]);
+          rstp<T, SLICED>(srec, SP_SCAL + 0, isc[IS_PRIMAL], isc[IS_DUAL]);
+          rstp<T, SLICED>(srec, SP_SCAL + 1, isc[IS_PRT], isc[IS_PRS]);
+          rstp<T, SLICED>(srec, SP_SCAL + 2, isc[IS_DUALV], isc[IS_STF]);
+          rstp<T, SLICED>(srec, SP_SCAL + 3, isc[IS_TOLP], isc[IS_TOLD]);
+          rstp<T, SLICED>(srec, SP_SCAL + 4, mu_s, P.mu_scale * mu_s);
+          rstp<T, SLICED>(srec, SP_SCAL + 5, mu_s, isc[IS_DX]);
+          rstp<T, SLICED>(srec, SP_SCAL + 6, isc[IS_DZ], isc[IS_DYQP]);
+          rstp<T, SLICED>(srec, SP_SCAL + 7, isc[IS_ATDY], isc[IS_UBP]);
+          rstp<T, SLICED>(srec, SP_SCAL + 8, isc[IS_LBM], isc[IS_DFIS]);
+          rstp<T, SLICED>(srec, SP_SCAL + 9, isc[IS_DYIS], isc[IS_DW]);
+          rstp<T, SLICED>(srec, SP_SCAL + 10, isc[IS_DVIS], isc[IS_DNU]);
+          rstp<T, SLICED>(srec, SP_SCAL + 11, isc[IS_AV], isc[IS_NU]);
+          rstp<T, SLICED>(srec, SP_SCAL + 12, isc[IS_HREFV], isc[IS_G]);
+          rstp<T, SLICED>(srec, SP_SCAL + 13, isc[IS_STF], isc[IS_C1]);
+          rstp<T, SLICED>(srec, SP_SCAL + 14, isc[IS_C2], isc[IS_TAILIT]);
         }
         if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
       }
@@ -284,15 +413,56 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     tail_sync();
   };
 
-  load_instance(fetch());
+  // SLICED = false: the plain work list -- ring[0 .. nslots) handed out once by one atomic counter, every instance runs to
+  // completion in the group that fetched it (no migration: plain loads/stores of the records)
+  auto fetch_plain = [&]() -> int {
+    int nx = 0;
+    if (jlane == 0) nx = (int)atomicAdd(q_head, 1u);
+    nx = __shfl(nx, gbase);
+    return nx < nslots ? ring[nx] : -1;
+  };
+  if constexpr (SLICED) {
+    q_ticket();  // (has_inst = false, done = true: the group starts out idle, waiting for the entry of its first ticket)
+  } else {
+    load_instance(fetch_plain());
+  }
 #ifdef LOIKB_TAIL_PROF
   unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
   const unsigned long long wall0_ = wall_clock64(), clk0_ = tprev_;
 #endif
-  while (__any(!done || has_inst)) {
+  unsigned int poll_skip = 0;
+#ifdef LOIKB_TAIL_PROF
+  unsigned long long dbg_last_ = wall0_, dbg_both_ = 0, dbg_sw_ = 0;
+#endif
+  bool want_poll = true;
+  while (SLICED ? true : __any(!done || has_inst)) {
+    if constexpr (SLICED) {
+      // a group without an instance looks for the entry of its ticket: right after it took the ticket (the ring starts out
+      // full: the first ticket of every group is served at once), then every 4th wavefront-iteration while the wavefront's
+      // other group keeps iterating (a poll is a global round trip), or after a nap when the whole wavefront is idle
+      if (!has_inst && !fin && want_poll) {
+        const int got = q_poll();
+        if (got >= 0) load_instance(got);  // (the record's loads are issued after the entry was read, and are coherent)
+        else fin = got == -2;
+      }
+      if (!__any(has_inst)) {
+        if (__all(fin)) break;
+        __builtin_amdgcn_s_sleep(32);
+        want_poll = true;
+        continue;
+      }
+    }
     // ---- decade slot of the current mu (H_i, Dinv_i, UDinv_i) -------------------------------------------------------
     if (!done && (int)my_iters >= P.max_launch_iters) {
       done = true;  // this launch's share of iterations is used up: back to the list, the host relaunches (run_tail)
+    }
+    if (SLICED && quantum > 0 && __any(!done && (int)slice_iters >= quantum)) {
+      const bool expired = !done && (int)slice_iters >= quantum;
+      const bool waiting = q_waiting();
+      if (expired) {
+        if (waiting) { done = true; requeue = true; }  // time slice used up and others are waiting: to the back of the ring
+        else slice_iters = 0;                           // nobody is waiting for this slot: carry on
+      }
     }
     if (!done && kexp != kslot) {
       const int dsl = kexp - kexp_lo;
@@ -333,8 +503,12 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       }
     }
     const bool act = !done;
+#ifdef LOIKB_TAIL_PROF
+    dbg_last_ = wall_clock64();
+    if (__popcll(__ballot(act && jlane == 0)) * G == WAVE) ++dbg_both_;
+#endif
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
-    if (act) { ++my_iters; any_iter = true; }
+    if (act) { ++my_iters; ++slice_iters; any_iter = true; }
     ++n_wave_iters;
 
     // ================= leaf -> root: FwdPass1 + BwdPass, p only (hxx:290-338, :31-81) =================================
@@ -608,9 +782,28 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       if (finishing && jlane == 0) isc[IS_G] = isc[IS_RED + 0];
       tail_sync();
     }
-    if (leaving) {
-      store_instance();
-      load_instance(fetch());
+#ifdef LOIKB_TAIL_PROF
+    if (__any(leaving)) ++dbg_sw_;
+#endif
+    if constexpr (SLICED) {
+      if (leaving) {
+        store_instance();
+        if (requeue) {
+          q_push(lidx);
+          if (jlane == 0) atomicAdd(&Bf.counters[LEAN_Q_REQUEUES], 1u);
+          requeue = false;
+        } else if (jlane == 0) {
+          atomicAdd(q_retired, 1u);
+        }
+        has_inst = false; isj = false; done = true; my_iters = 0; slice_iters = 0; any_iter = false;
+        q_ticket();
+      }
+      want_poll = leaving || (poll_skip++ & LOIKB_POLL_MASK) == 0u;
+    } else {
+      if (leaving) {
+        store_instance();
+        load_instance(fetch_plain());
+      }
     }
     TAIL_TP(7)
   }
@@ -620,6 +813,13 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     g_tail_prof[8] = n_wave_iters;
     // shader clock in kHz: clock64 ticks per wall_clock64 tick (100 MHz)
     g_tail_prof[9] = (clock64() - clk0_) * 100000ull / (wall_clock64() - wall0_ + 1);
+  }
+  if (lane == 0) {
+    const int wid = blockIdx.x * TAIL_WAVES + wv;
+    if (wid < 4096) {
+      g_wave_dbg[wid][0] = wall0_; g_wave_dbg[wid][1] = dbg_last_; g_wave_dbg[wid][2] = wall_clock64();
+      g_wave_dbg[wid][3] = n_wave_iters; g_wave_dbg[wid][4] = dbg_both_; g_wave_dbg[wid][5] = dbg_sw_;
+    }
   }
 #endif
   if (lane == 0) {
@@ -737,6 +937,17 @@ k_hslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
       for (int k = 0; k < 21; ++k) x[k] = part[k];
     }
     tail_sync();
+  }
+}
+
+// the lean kernel's work queue at launch: ring[0 .. n) = the listed instances, the rest empty; pops start at 0, pushes at n
+__global__ void k_ring_fill(int* __restrict__ ring, int cap, const int* __restrict__ list, int n, unsigned int* __restrict__ counters)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) ring[i] = i < n ? list[i] : -1;
+  if (i == 0) {
+    counters[LEAN_Q_HEAD] = 0u; counters[LEAN_Q_TAIL] = (unsigned int)n; counters[LEAN_Q_REQUEUES] = 0u;
+    counters[LEAN_Q_RETIRED] = 0u;
   }
 }
 

@@ -78,6 +78,9 @@ __host__ __device__ __forceinline__ size_t tail_lds_bytes(int nc, int G)
 // Phase timeline of one wavefront (diagnostic build only: -DLOIKB_TAIL_PROF, scripts/tail_phase_profile.py)
 #ifdef LOIKB_TAIL_PROF
 __device__ unsigned long long g_tail_prof[10];
+// per wavefront of the last lean launch: [0] wall clock (100 MHz) at start, [1] when the wavefront last had an instance,
+// [2] at exit, [3] wavefront-iterations, [4] wavefront-iterations with both groups active, [5] instance switches
+__device__ unsigned long long g_wave_dbg[4096][6];
 #define TAIL_TP(k) { const unsigned long long tn_ = clock64(); prof_[k] += tn_ - tprev_; tprev_ = tn_; }
 #else
 #define TAIL_TP(k)
