@@ -35,7 +35,7 @@ enum {
   LOIKB_ERR_INEQ_DIM = -3,        /* lb/ub size != nv              ik-id-description-optimized.hpp:328-335 */
   LOIKB_ERR_NO_SUCH_CONSTRAINT = -4, /* UpdateEqConstraint on an unknown link       ...hpp:184-186          */
   LOIKB_ERR_DUP_CONSTRAINT = -5,  /* same link listed twice                         ...hpp:197-199          */
-  LOIKB_ERR_MU_STRATEGY = -6,     /* OSQP / MAXEIGENVALUE not implemented  loik-loid-optimized.hxx:632-640  */
+  LOIKB_ERR_MU_STRATEGY = -6,     /* MAXEIGENVALUE (and upstream: OSQP) not implemented  loik-loid-optimized.hxx:632-640 */
   LOIKB_ERR_MODEL = -7,           /* unsupported joint type, inconsistent nq/nv/idx_q/idx_v, or tree not depth-first */
   /* runtime */
   LOIKB_ERR_ARG = -20,
@@ -47,6 +47,11 @@ enum {
 };
 
 /* ---- ADMMPenaltyUpdateStrat, task-solver-base.hpp:13-18 -------------------------------------------- */
+/* DEFAULT is the reference's rule.  OSQP is declared upstream but throws "not yet implemented" there (hxx:632-637); HERE it
+ * is implemented -- OSQP's published penalty rule on LoIK's residuals and normalisers, see update_mu() in
+ * loik_amd/csrc/loik_device.hpp and the identical expression in the oracle -- as an extension, not a parity target: on the
+ * headline workload it ends most of DEFAULT's mu limit cycles (instances hitting max_iter: 0.85 % -> 0.17 %).  mu is then
+ * off the decade grid, so such solves run in the k_solve / k_tail engines.  MAXEIGENVALUE returns LOIKB_ERR_MU_STRATEGY. */
 enum { LOIKB_MU_DEFAULT = 0, LOIKB_MU_OSQP = 1, LOIKB_MU_MAXEIGENVALUE = 3 };
 
 enum { LOIKB_F64 = 0, LOIKB_F32 = 1 };

@@ -18,6 +18,7 @@
 #include "../loik_amd.h"
 
 #include <array>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -79,19 +80,66 @@ struct Model {
   }
 };
 
+class FirstOrderLoikOptimized;
+
+// A member of the data object that is fetched from the device the first time it is read after a solve (His, pis, Aty,
+// liMi: large, rarely read -- upstream's tests read His / pis, tests/loik-loid.cpp:597-615).  Reads like the std::vector it
+// wraps: operator[], data(), size(), begin()/end(), implicit conversion to const DVec&.
+class LazyField {
+public:
+  LazyField() = default;
+  LazyField(int field, std::size_t n) : field_(field), buf_(n, 0.0) {}
+  const DVec& get() const;
+  operator const DVec&() const { return get(); }
+  double operator[](std::size_t i) const { return get()[i]; }
+  const double* data() const { return get().data(); }
+  std::size_t size() const { return buf_.size(); }
+  DVec::const_iterator begin() const { return get().begin(); }
+  DVec::const_iterator end() const { return get().end(); }
+
+private:
+  friend class FirstOrderLoikOptimized;
+  friend struct IkIdDataOptimized;
+  int field_ = -1;
+  mutable DVec buf_;
+  mutable unsigned long long seen_ = 0;                  // generation of the solver state the buffer holds
+  const FirstOrderLoikOptimized* owner_ = nullptr;       // set by the solver that references the data object
+  const unsigned long long* generation_ = nullptr;
+};
+
 // caller-owned result / state object (public members, as upstream).  Instance b, joint i (1..nb), component k:
-//   z[b*nv + j], nu[...], w[...];  vis[(b*nb + (i-1))*6 + k], fis likewise;  yis[(b*nc + c)*6 + k]
+//   z[b*nv + j], nu[...], w[...];  vis[(b*nb + (i-1))*6 + k], fis likewise;  yis[(b*nc + c)*6 + k], Aty likewise;
+//   His[(b*nb + (i-1))*21 + sym(r,c)] (upper triangle, row-major: H_i is symmetric);  pis like vis;
+//   liMi[(b*nb + (i-1))*12 + ..] = R row-major, t.
+// z, nu, w, vis, fis, yis are copied after every solve (selectable: FirstOrderLoikOptimized::set_fetch); His, pis, Aty, liMi
+// are fetched on first access.
 struct IkIdDataOptimized {
   IkIdDataOptimized(const Model& model, int num_eq_c_, int batch_ = 1)
   : batch(batch_), nb(model.njoints - 1), nv(model.nv), num_eq_c(num_eq_c_),
     nu(static_cast<std::size_t>(batch_) * model.nv, 0.0), z(nu.size(), 0.0), w(nu.size(), 0.0),
     vis(static_cast<std::size_t>(batch_) * (model.njoints - 1) * 6, 0.0), fis(vis.size(), 0.0),
-    yis(static_cast<std::size_t>(batch_) * num_eq_c_ * 6, 0.0)
+    yis(static_cast<std::size_t>(batch_) * num_eq_c_ * 6, 0.0),
+    His(LOIKB_F_HIS, static_cast<std::size_t>(batch_) * (model.njoints - 1) * 21),
+    pis(LOIKB_F_PIS, static_cast<std::size_t>(batch_) * (model.njoints - 1) * 6),
+    Aty(LOIKB_F_ATY, static_cast<std::size_t>(batch_) * num_eq_c_ * 6),
+    liMi(LOIKB_F_LIMI, static_cast<std::size_t>(batch_) * (model.njoints - 1) * 12)
   {
   }
   int batch, nb, nv, num_eq_c;
   DVec nu, z, w;  // z is the answer: box-projected joint velocity (loik-loid-optimized.hpp:333)
   DVec vis, fis, yis;
+  LazyField His, pis, Aty, liMi;
+  // full symmetric 6x6 of link i (1..nb) of instance b out of the packed His
+  Mat6x6 His_full(int i, int b = 0) const
+  {
+    const DVec& h = His.get();
+    const double* p = h.data() + (static_cast<std::size_t>(b) * nb + (i - 1)) * 21;
+    Mat6x6 m{};
+    int k = 0;
+    for (int r = 0; r < 6; ++r)
+      for (int c = r; c < 6; ++c, ++k) { m[6 * r + c] = p[k]; m[6 * c + r] = p[k]; }
+    return m;
+  }
 };
 
 class FirstOrderLoikOptimized {
@@ -115,7 +163,11 @@ public:
     o.batch = batch_; o.device = device; o.precision = LOIKB_F64; o.flags = flags;
     const loikb_model_desc d = model_.desc();
     check(loikb_create(&d, &o, &h_));
-    rho_ = rho; tol_tail_solve_ = tol_tail_solve;
+    rho_ = rho; tol_tail_solve_ = tol_tail_solve; tol_primal_inf_ = tol_primal_inf; tol_dual_inf_ = tol_dual_inf;
+    for (LazyField* f : {&ik_id_data_.His, &ik_id_data_.pis, &ik_id_data_.Aty, &ik_id_data_.liMi}) {
+      f->owner_ = this;
+      f->generation_ = &generation_;
+    }
   }
   ~FirstOrderLoikOptimized() { loikb_destroy(h_); }
   FirstOrderLoikOptimized(const FirstOrderLoikOptimized&) = delete;
@@ -133,7 +185,7 @@ public:
   void Solve()
   {
     check(loikb_solve(h_));
-    fetch();
+    solved();
   }
   // loik-loid-optimized.hpp:475-580
   void Solve(const DVec& q, const Mat6x6& H_ref, const Motion& v_ref, const std::vector<Index>& active_task_constraint_ids,
@@ -142,7 +194,7 @@ public:
     Args a(*this, q, active_task_constraint_ids, Ais, bis, lb, ub);
     check(loikb_solve_full(h_, q.data(), H_ref.data(), v_ref.data(), a.ids.data(), (int)a.ids.size(), a.A.data(),
                            a.b.data(), lb.data(), ub.data(), a.nbound, a.flags));
-    fetch();
+    solved();
   }
   // loik-loid-optimized.hpp:596-695 (one Ai for the batch; bi per instance when bi.size() == batch)
   void Solve(const DVec& q, const Index c_id, const Mat6x6& Ai, const Vec6& bi)
@@ -150,7 +202,7 @@ public:
     int flags = LOIKB_A_SHARED | LOIKB_B_SHARED;
     if (batch_ > 1 && q.size() == static_cast<std::size_t>(model_.nq)) flags |= LOIKB_Q_SHARED;
     check(loikb_solve_tailored(h_, q.data(), (int)c_id, Ai.data(), bi.data(), flags));
-    fetch();
+    solved();
   }
   void Solve(const DVec& q, const Index c_id, const Mat6x6& Ai, const std::vector<Vec6>& bis)
   {
@@ -161,7 +213,7 @@ public:
     if (bis.size() == 1 && batch_ > 1) flags |= LOIKB_B_SHARED;
     if (batch_ > 1 && q.size() == static_cast<std::size_t>(model_.nq)) flags |= LOIKB_Q_SHARED;
     check(loikb_solve_tailored(h_, q.data(), (int)c_id, Ai.data(), b.data(), flags));
-    fetch();
+    solved();
   }
 
   // ---- outer loop on the device (not in the reference class: its callers -- a sampling planner, README.md:5 --
@@ -177,7 +229,7 @@ public:
     int flags = LOIKB_A_SHARED;
     if (bis.size() == 1 && batch_ > 1) flags |= LOIKB_B_SHARED;
     check(loikb_solve_tailored(h_, nullptr, (int)c_id, Ai.data(), b.data(), flags));
-    fetch();
+    solved();
   }
   // the resident configurations, [batch][nq]
   DVec q_resident() const
@@ -187,7 +239,17 @@ public:
     return q;
   }
 
-  // task-solver-base.hpp:87-141 (instance index defaults to 0: the single-instance reading)
+  // ---- which members of the data object every solve copies back (default: all six, as upstream's callers expect).
+  // FETCH_NONE leaves the results on the device: read them with loikb_get(handle(), field, ptr, LOIKB_OUT_DEVICE) or call
+  // fetch_now(mask) when needed -- a planner that only integrates on the device (Integrate) never needs the copy.
+  enum : unsigned { FETCH_NONE = 0, FETCH_Z = 1, FETCH_NU = 2, FETCH_W = 4, FETCH_VIS = 8, FETCH_FIS = 16, FETCH_YIS = 32,
+                    FETCH_ALL = 63 };
+  void set_fetch(unsigned mask) { fetch_mask_ = mask; }
+  unsigned get_fetch() const { return fetch_mask_; }
+  void fetch_now(unsigned mask) { fetch(mask); }
+
+  // task-solver-base.hpp:87-141 (instance index defaults to 0: the single-instance reading).  The per-instance scalars of
+  // a solve are downloaded once, on the first getter call after it, and served from that copy: O(1) per call.
   int get_iter(int b = 0) const { return geti(LOIKB_F_ITER, b); }
   double get_primal_residual(int b = 0) const { return getd(LOIKB_F_PRIMAL_RESIDUAL, b); }
   double get_dual_residual(int b = 0) const { return getd(LOIKB_F_DUAL_RESIDUAL, b); }
@@ -196,12 +258,20 @@ public:
   bool get_dual_infeasibility_status(int = 0) const { return false; }  // never set by the optimized solver upstream
   double get_mu(int b = 0) const { return getd(LOIKB_F_MU, b); }
   double get_rho() const { return rho_; }
-  double get_tol_primal(int b = 0) const { return getd(LOIKB_F_TOL_PRIMAL, b); }
-  double get_tol_dual(int b = 0) const { return getd(LOIKB_F_TOL_DUAL, b); }
+  // set_tol_primal / set_tol_dual (task-solver-base.hpp:118-127) write tol_primal_ / tol_dual_, which CheckConvergence
+  // recomputes at every iteration (hxx:544-552): as upstream, the value set is what the getter returns until the next solve
+  double get_tol_primal(int b = 0) const { return tol_primal_set_ ? tol_primal_ : getd(LOIKB_F_TOL_PRIMAL, b); }
+  double get_tol_dual(int b = 0) const { return tol_dual_set_ ? tol_dual_ : getd(LOIKB_F_TOL_DUAL, b); }
+  void set_tol_primal(const double t) { tol_primal_ = t; tol_primal_set_ = true; }
+  void set_tol_dual(const double t) { tol_dual_ = t; tol_dual_set_ = true; }
+  double get_tol_primal_inf() const { return tol_primal_inf_; }
+  double get_tol_dual_inf() const { return tol_dual_inf_; }
   void set_max_iter(const int max_iter) { check(loikb_set_max_iter(h_, max_iter)); }
   void set_rho(const double rho) { rho_ = rho; check(loikb_set_rho(h_, rho)); }
   void set_mu(const double mu) { check(loikb_set_mu(h_, mu)); }
-  void set_tol_primal_inf(const double t) { check(loikb_set_tol_primal_inf(h_, t)); }
+  void set_tol_primal_inf(const double t) { tol_primal_inf_ = t; check(loikb_set_tol_primal_inf(h_, t)); }
+  // dual infeasibility is never evaluated on this path: the tolerance is stored, as upstream stores it
+  void set_tol_dual_inf(const double t) { tol_dual_inf_ = t; }
   // loik-loid-optimized.hpp:700-755
   // get_primal_residual_vec() / get_dual_residual_vec(), loik-loid-optimized.hpp:698-699: [6 nb + nv] of instance b
   DVec get_primal_residual_vec(int b = 0) const { return getvec(LOIKB_F_PRIMAL_RESIDUAL_VEC, b); }
@@ -263,40 +333,78 @@ private:
     const char* msg = (rc <= LOIKB_ERR_ARG || rc == LOIKB_ERR_MODEL) ? loikb_last_error() : loikb_status_string(rc);
     throw std::runtime_error(msg && *msg ? msg : loikb_status_string(rc));
   }
-  void fetch()
+  void solved()
   {
-    check(loikb_get(h_, LOIKB_F_Z, ik_id_data_.z.data(), 0));
-    check(loikb_get(h_, LOIKB_F_NU, ik_id_data_.nu.data(), 0));
-    check(loikb_get(h_, LOIKB_F_W, ik_id_data_.w.data(), 0));
-    check(loikb_get(h_, LOIKB_F_VIS, ik_id_data_.vis.data(), 0));
-    check(loikb_get(h_, LOIKB_F_FIS, ik_id_data_.fis.data(), 0));
-    if (nc_ > 0) check(loikb_get(h_, LOIKB_F_YIS, ik_id_data_.yis.data(), 0));
+    ++generation_;  // lazy members and cached scalars of the previous solve are stale now
+    tol_primal_set_ = tol_dual_set_ = false;
+    fetch(fetch_mask_);
   }
+  void fetch(unsigned mask)
+  {
+    if (mask & FETCH_Z) check(loikb_get(h_, LOIKB_F_Z, ik_id_data_.z.data(), 0));
+    if (mask & FETCH_NU) check(loikb_get(h_, LOIKB_F_NU, ik_id_data_.nu.data(), 0));
+    if (mask & FETCH_W) check(loikb_get(h_, LOIKB_F_W, ik_id_data_.w.data(), 0));
+    if (mask & FETCH_VIS) check(loikb_get(h_, LOIKB_F_VIS, ik_id_data_.vis.data(), 0));
+    if (mask & FETCH_FIS) check(loikb_get(h_, LOIKB_F_FIS, ik_id_data_.fis.data(), 0));
+    if ((mask & FETCH_YIS) && nc_ > 0) check(loikb_get(h_, LOIKB_F_YIS, ik_id_data_.yis.data(), 0));
+  }
+  // one download per field and solve, then O(1) per getter call
+  template <typename V>
+  struct Cached { V data; unsigned long long gen = ~0ull; };
   int geti(int field, int b) const
   {
-    std::vector<int> tmp(static_cast<std::size_t>(batch_));
-    check(loikb_get(h_, field, tmp.data(), 0));
-    return tmp[static_cast<std::size_t>(b)];
+    Cached<std::vector<int>>& c = icache_[field];
+    if (c.gen != generation_) {
+      c.data.resize(static_cast<std::size_t>(batch_));
+      check(loikb_get(h_, field, c.data.data(), 0));
+      c.gen = generation_;
+    }
+    return c.data[static_cast<std::size_t>(b)];
   }
   double getd(int field, int b) const
   {
-    DVec tmp(static_cast<std::size_t>(batch_));
-    check(loikb_get(h_, field, tmp.data(), 0));
-    return tmp[static_cast<std::size_t>(b)];
+    Cached<DVec>& c = dcache_[field];
+    if (c.gen != generation_) {
+      c.data.resize(static_cast<std::size_t>(batch_));
+      check(loikb_get(h_, field, c.data.data(), 0));
+      c.gen = generation_;
+    }
+    return c.data[static_cast<std::size_t>(b)];
   }
   DVec getvec(int field, int b) const
   {
     const std::size_t n = 6 * static_cast<std::size_t>(model_.njoints - 1) + static_cast<std::size_t>(model_.nv);
-    DVec tmp(static_cast<std::size_t>(batch_) * n);
-    check(loikb_get(h_, field, tmp.data(), 0));
-    return DVec(tmp.begin() + b * n, tmp.begin() + (b + 1) * n);
+    Cached<DVec>& c = dcache_[field];
+    if (c.gen != generation_) {
+      c.data.resize(static_cast<std::size_t>(batch_) * n);
+      check(loikb_get(h_, field, c.data.data(), 0));
+      c.gen = generation_;
+    }
+    return DVec(c.data.begin() + b * n, c.data.begin() + (b + 1) * n);
   }
+  friend class LazyField;
+  void lazy_fetch(int field, double* dst) const { check(loikb_get(h_, field, dst, 0)); }
 
   Model model_;             // by value, as upstream (loik-loid-optimized.hpp:762)
   IkIdData& ik_id_data_;    // caller-owned, must outlive the solver (loik-loid-optimized.hpp:763)
   loikb_solver* h_ = nullptr;
   int batch_, nc_;
-  double rho_ = 0.0, tol_tail_solve_ = 0.0;
+  double rho_ = 0.0, tol_tail_solve_ = 0.0, tol_primal_inf_ = 0.0, tol_dual_inf_ = 0.0;
+  double tol_primal_ = 0.0, tol_dual_ = 0.0;
+  bool tol_primal_set_ = false, tol_dual_set_ = false;
+  unsigned fetch_mask_ = FETCH_ALL;
+  unsigned long long generation_ = 1;
+  mutable std::map<int, Cached<std::vector<int>>> icache_;
+  mutable std::map<int, Cached<DVec>> dcache_;
 };
+
+inline const DVec& LazyField::get() const
+{
+  if (owner_ && generation_ && seen_ != *generation_) {
+    owner_->lazy_fetch(field_, buf_.data());
+    seen_ = *generation_;
+  }
+  return buf_;
+}
 
 }  // namespace loik_amd

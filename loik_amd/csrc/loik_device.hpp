@@ -116,6 +116,7 @@ enum : int {
   MODE_CACHE_H = 2,      // skip the H-recursion of the leaf->root sweep while no live lane changed mu
   MODE_A_SHARED = 4,     // one A per constraint for the whole batch
   MODE_BND_SHARED = 8,   // one lb/ub for the whole batch
+  MODE_MU_OSQP = 16,     // UpdateMu: OSQP's rule instead of the DEFAULT decade steps (update_mu below)
 };
 
 
@@ -213,6 +214,26 @@ __host__ __device__ __forceinline__ double tmax(double a, double b) { return __b
 __host__ __device__ __forceinline__ float tmax(float a, float b) { return __builtin_fmaxf(a, b); }
 __host__ __device__ __forceinline__ double tmin(double a, double b) { return __builtin_fmin(a, b); }
 __host__ __device__ __forceinline__ float tmin(float a, float b) { return __builtin_fminf(a, b); }
+
+// UpdateMu (loik-loid-optimized.hxx:613-641).  DEFAULT: the reference's decade steps.  OSQP: declared upstream
+// (ADMMPenaltyUpdateStrat::OSQP, task-solver-base.hpp:13-18) but never implemented there (it throws, hxx:632-637); this is
+// OSQP's published rule on LoIK's quantities, the same expression as oracle/loik_ref.c::ref_update_mu:
+//   mu <- mu * sqrt( (r_p / max(|Av|, |nu|, |b|)) / (r_d / max(|H_ref v|, |g|, |S^T f + w|, |H_ref v_ref|)) ), clipped to
+//   [1e-6, 1e6], applied only when it moves mu by more than a factor of 5.  Returns true when mu changed.
+template <typename T>
+__device__ __forceinline__ bool update_mu(int mode, T primal, T dual, T norm_p, T norm_d, T& mu, int& kexp)
+{
+  if (mode & MODE_MU_OSQP) {
+    const T rp = primal / (norm_p + T(1e-10)), rd = dual / (norm_d + T(1e-10));
+    T mu_new = mu * (T)__builtin_sqrt((double)(rp / (rd + T(1e-10))));
+    mu_new = tmin(tmax(mu_new, T(1e-6)), T(1e6));
+    if (mu_new > T(5.0) * mu || mu_new < T(0.2) * mu) { mu = mu_new; return true; }
+    return false;
+  }
+  if (primal > T(10) * dual) { mu *= T(10); ++kexp; return true; }
+  if (dual > T(10) * primal) { mu *= T(0.1); --kexp; return true; }
+  return false;
+}
 
 template <typename T>
 __device__ __forceinline__ T inf6(const T* x)
@@ -1307,8 +1328,9 @@ k_solve(const Params<T> P, const Bufs<T> Bf, const StepDesc* __restrict__ sched_
           }
         } else {
           // UpdateMu (hxx:617-631)
-          if (primal > T(10) * dual) { mu *= T(10); ++kexp; ++nflip; }
-          else if (dual > T(10) * primal) { mu *= T(0.1); --kexp; ++nflip; }
+          if (update_mu<T>(P.mode, primal, dual, tmax(tmax(N.av_inf, N.nu_inf), bnorm),
+                           tmax(tmax(N.href_v, tmax(N.g_inf, N.stf_w_inf)), P.Hv_inf_norm), mu, kexp))
+            ++nflip;
           if (iter + 1 >= P.max_iter) { status |= ST_DONE; live = false; }
         }
       } else {

@@ -503,6 +503,7 @@ Params<T> make_params(loikb_solver_impl* S)
   if (!(S->opt.flags & LOIKB_OPT_NO_H_CACHE)) mode |= MODE_CACHE_H;
   if (S->a_shared) mode |= MODE_A_SHARED;
   if (S->bnd_shared) mode |= MODE_BND_SHARED;
+  if (S->opt.mu_update_strat == LOIKB_MU_OSQP) mode |= MODE_MU_OSQP;
   P.mode = mode;
   P.B = S->B;
   P.max_launch_iters = S->opt.max_iter + 1;
@@ -839,6 +840,7 @@ bool lean_applicable(const loikb_solver_impl* S)
   if (const char* e = getenv("LOIKB_LEAN")) if (atoi(e) == 0) return false;
   if (S->nb > WAVE || S->maxchild > 4) return false;
   if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) return false;
+  if (S->opt.mu_update_strat == LOIKB_MU_OSQP) return false;  // mu is not on the decade grid: no precomputed slots
   int G = 8;
   while (G < S->nb) G <<= 1;
   const size_t esz = S->f32 ? sizeof(float) : sizeof(double);  // (lean_lds_bytes<double> / 8 * esz, rounded the same way)
@@ -1301,7 +1303,8 @@ int run_main_loop_t(loikb_solver_impl* S)
 int run_main_loop(loikb_solver_impl* S)
 {
   // UpdateMu's throw sites (hxx:632-640)
-  if (S->opt.mu_update_strat != LOIKB_MU_DEFAULT && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS)) {
+  if (S->opt.mu_update_strat != LOIKB_MU_DEFAULT && S->opt.mu_update_strat != LOIKB_MU_OSQP &&
+      !(S->opt.flags & LOIKB_OPT_FIXED_ITERS)) {
     g_last_error = "[FirstOrderLoikOptimizedTpl::UpdateMu]: mu update strategy not yet implemented";
     return LOIKB_ERR_MU_STRATEGY;
   }

@@ -724,8 +724,9 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
           tail_iter = 0;
           if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
         } else {
-          if (primal > T(10) * dual) { mu *= T(10); ++kexp; ++nflip; }
-          else if (dual > T(10) * primal) { mu *= T(0.1); --kexp; ++nflip; }
+          if (update_mu<T>(P.mode, primal, dual, tmax(tmax(n_av, n_nu), bnorm),
+                           tmax(tmax(n_hrefv, tmax(n_g, stf_w_inf)), P.Hv_inf_norm), mu, kexp))
+            ++nflip;
           if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
         }
       } else {

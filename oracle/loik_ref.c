@@ -965,6 +965,25 @@ int ref_update_mu(ref_solver *s)
     }
     return REF_OK;
   }
+  if (s->mu_update_strat == REF_MU_OSQP) {
+    /* ORACLE EXTENSION -- upstream declares ADMMPenaltyUpdateStrat::OSQP (task-solver-base.hpp:13-18) and throws
+       "not yet implemented" for it (hxx:632-637).  This is OSQP's published rule (Stellato et al. 2020, sec. 5.2) on LoIK's
+       quantities: mu <- mu * sqrt( (r_p / max(|Av|, |nu|, |b|)) / (r_d / max(|H_ref v|, |g|, |S^T f + w|, |H_ref v_ref|)) ),
+       clipped to [1e-6, 1e6], applied only when it changes mu by more than a factor of 5 (adaptive_rho_tolerance);
+       the normalisers are those of CheckConvergence (hxx:544-552).  The device implements the same expression. */
+    const double np = dmax(dmax(s->Av_inf_norm, s->nu_inf_norm), s->bis_inf_norm);
+    const double nd = dmax(dmax(s->Href_v_inf_norm, dmax(s->g_inf_norm, s->Stf_plus_w_inf_norm)), s->Hv_inf_norm);
+    const double rp = s->primal_residual / (np + 1e-10), rd = s->dual_residual / (nd + 1e-10);
+    double mu_new = s->mu * sqrt(rp / (rd + 1e-10));
+    if (mu_new < 1e-6) mu_new = 1e-6;
+    if (mu_new > 1e6) mu_new = 1e6;
+    if (mu_new > 5.0 * s->mu || mu_new < 0.2 * s->mu) {
+      s->mu = mu_new;
+      s->mu_eq = s->mu_equality_scale_factor * s->mu;
+      s->mu_ineq = s->mu;
+    }
+    return REF_OK;
+  }
   return REF_ERR_MU_STRAT;
 }
 

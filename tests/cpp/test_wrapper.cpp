@@ -102,6 +102,13 @@ static void compare(const Fixture& f, const IkIdDataOptimized& d, FirstOrderLoik
   CHECK(close(d.vis.data(), o.field(REF_F_VIS) + 6, 6 * nb));
   CHECK(close(d.fis.data(), o.field(REF_F_FIS) + 6, 6 * nb));
   CHECK(close(d.yis.data(), o.field(REF_F_YIS), 6));
+  // members fetched on first access (upstream's tests read His / pis: tests/loik-loid.cpp:597-615)
+  CHECK(close(d.Aty.data(), o.field(REF_F_ATY), 6));
+  CHECK(close(d.liMi.data(), o.field(REF_F_LIMI) + 12, 12 * nb, 1e-14));
+  for (int i = 1; i <= nb; ++i) {
+    const Mat6x6 H = d.His_full(i);
+    CHECK(close(H.data(), o.field(REF_F_HIS) + 36 * i, 36));
+  }
   CHECK(solver.get_iter() == (int)ref_scalar(o.s, REF_S_ITER));
   CHECK(solver.get_convergence_status() == (ref_scalar(o.s, REF_S_CONVERGED) != 0));
   CHECK(solver.get_primal_infeasibility_status() == (ref_scalar(o.s, REF_S_PRIMAL_INFEASIBLE) != 0));
@@ -188,6 +195,28 @@ int main()
       CHECK(close(qr.data(), q.data(), f.robot_model.nq));
       for (int k = 0; k < f.robot_model.nq; ++k) q[k] += dt * dh.z[k];
     }
+  }
+  {  // results left on the device (set_fetch), fetched on demand; O(1) getters; tolerance setters of the base class
+    Fixture f; f.max_iter = 100; f.set_bound(2.0);
+    IkIdDataOptimized d(f.robot_model, f.num_eq_c), dref(f.robot_model, f.num_eq_c);
+    MAKE_SOLVER(solver, d, f); MAKE_SOLVER(sref, dref, f);
+    sref.Solve(f.q, f.H_ref, f.v_ref, f.active_task_constraint_ids, f.Ais, f.bis, f.lb, f.ub);
+    solver.set_fetch(FirstOrderLoikOptimized::FETCH_Z);
+    solver.Solve(f.q, f.H_ref, f.v_ref, f.active_task_constraint_ids, f.Ais, f.bis, f.lb, f.ub);
+    CHECK(d.z == dref.z);
+    bool untouched = true;
+    for (double x : d.nu) untouched = untouched && x == 0.0;
+    CHECK(untouched);  // nu was not copied
+    solver.fetch_now(FirstOrderLoikOptimized::FETCH_NU | FirstOrderLoikOptimized::FETCH_VIS);
+    CHECK(d.nu == dref.nu); CHECK(d.vis == dref.vis);
+    CHECK(DVec(d.pis) == DVec(dref.pis));
+    for (int rep = 0; rep < 1000; ++rep) CHECK(solver.get_iter() == sref.get_iter());  // served from one download
+    CHECK(solver.get_tol_primal_inf() == f.tol_primal_inf && solver.get_tol_dual_inf() == f.tol_dual_inf);
+    solver.set_tol_dual_inf(0.5); CHECK(solver.get_tol_dual_inf() == 0.5);
+    const double tp = solver.get_tol_primal();
+    solver.set_tol_primal(123.0); CHECK(solver.get_tol_primal() == 123.0);
+    solver.Solve(f.q, f.H_ref, f.v_ref, f.active_task_constraint_ids, f.Ais, f.bis, f.lb, f.ub);
+    CHECK(solver.get_tol_primal() == tp);  // CheckConvergence recomputed it, as upstream (hxx:544-546)
   }
   {  // throw sites carry the reference's messages
     Fixture f; f.max_iter = 10;

@@ -101,3 +101,31 @@ def test_lean_rounds_with_iteration_quanta(talos, monkeypatch):
     for name in ["z", "nu", "w", "vis", "fis", "primal_residual", "dual_residual", "delta_vis_inf_norm", "g_inf_norm"]:
         assert np.max(np.abs(a.get(name) - b.get(name))) < 1e-10, name
     a.close(); b.close()
+
+
+def test_lean_time_slicing_changes_nothing(talos, monkeypatch):
+    """LOIKB_LEAN_SLICE=q: round-robin time slicing inside the lean launch (k_lean<.., SLICED = true>): an instance that used
+    q iterations while others wait for a slot is written back and re-queued -- it migrates between lane groups, i.e. between
+    CUs of different XCDs, within one launch (coherent record accesses).  Per-instance results are bit-identical."""
+    link = talos.getJointId("arm_left_7_joint")
+    B = 12000  # more instances than resident lane groups (4096): the queue is never empty at the first slice boundaries
+    wl = feasible_batch(talos, B, link, 23, nu_scale=0.5)
+    args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    prm = dict(FIXTURE, max_iter=400, tol_abs=1e-6, tol_rel=0.0)
+    monkeypatch.delenv("LOIKB_LEAN_SLICE", raising=False)
+    a = loik_amd.BatchedLoik(talos, B, **prm)
+    a.Solve(*args)
+    assert a.stats()["lean_requeues"] == 0
+    for q in ("7", "40"):
+        monkeypatch.setenv("LOIKB_LEAN_SLICE", q)
+        b = loik_amd.BatchedLoik(talos, B, **prm)
+        for _ in range(2):
+            b.Solve(*args)
+            st = b.stats()
+            assert st["lean_requeues"] > 0 and st["lean_escaped"] == 0
+            assert st["instance_iterations"] == a.stats()["instance_iterations"]
+            for name in ["iter", "converged", "primal_infeasible", "mu", "z", "nu", "w", "vis", "fis", "g", "yis", "primal_residual",
+                         "dual_residual", "delta_vis_inf_norm", "g_inf_norm", "mu_updates"]:
+                assert np.array_equal(a.get(name), b.get(name)), (q, name)
+        b.close()
+    a.close()

@@ -224,10 +224,42 @@ def test_error_codes_through_the_abi(talos):
         s.Solve(q2, Hbad, p["v_ref"], p["c_ids"], p["Ais"], b2, p["lb"], p["ub"])
     assert e.value.code == -23
     s.close()
-    s = loik_amd.BatchedLoik(talos, 2, **dict(FIXTURE, max_iter=10, mu_update_strat=1))
+    s = loik_amd.BatchedLoik(talos, 2, **dict(FIXTURE, max_iter=10, mu_update_strat=3))  # MAXEIGENVALUE, hxx:635-637
     with pytest.raises(loik_amd.LoikError) as e:
         s.Solve(q2, p["H_ref"], p["v_ref"], p["c_ids"], p["Ais"], b2, p["lb"], p["ub"])
     assert e.value.code == -6
+    s.close()
+
+
+@pytest.mark.parametrize("engine", ["tail", "solve", "hybrid"])
+def test_osqp_mu_rule_matches_oracle(talos, engine):
+    """ADMMPenaltyUpdateStrat::OSQP (declared upstream, throws there: hxx:632-634) -- implemented here as an extension
+    (update_mu in loik_device.hpp == ref_update_mu in the oracle).  mu leaves the decade grid, so the solve runs in
+    k_tail (whole batch below the hand-over threshold), in k_solve alone, or in both (hand-over after 5 iterations)."""
+    link = talos.getJointId("arm_left_7_joint")
+    B = 700
+    wl = feasible_batch(talos, B, link, 91, nu_scale=0.5)
+    prm = dict(FIXTURE, max_iter=500, tol_abs=1e-6, tol_rel=0.0, mu_update_strat=1)
+    kw = {"tail": {}, "solve": dict(tail_max_instances=-1), "hybrid": dict(max_launch_iters=5, tail_max_instances=1 << 20)}[engine]
+    s = gpu_solve(talos, wl, prm, **kw)
+    st = s.stats()
+    assert st["lean_launches"] == 0
+    assert (st["tail_instances"] == B) if engine == "tail" else (st["tail_instances"] == 0) if engine == "solve" else (0 < st["tail_instances"] < B)
+    out = ref.solve_batch(talos, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"],
+                          nthreads=4, want_nu=True, **prm)
+    assert_end_to_end(fetch_end_to_end(s, residuals=True), out, prm, same_frac=0.95, what="OSQP mu rule, " + engine)
+    mu = s.get("mu")
+    assert np.unique(np.round(np.log10(mu), 9)).size > 12  # off the decade grid: a continuum of penalties
+    # k iterations exactly, full state incl. mu
+    for k in (3, 9):
+        prk = dict(prm, max_iter=k + 1, tol_abs=0.0, tol_primal_inf=0.0)
+        sk = gpu_solve(talos, wl, prk, **kw)
+        cache = fetch(sk)
+        for b in range(0, B, 97):
+            r = ref.RefSolver(talos, **prk)
+            r.Solve(*problem_args(wl, b))
+            compare_instance(sk, cache, r, b, 1e-8)
+        sk.close()
     s.close()
 
 

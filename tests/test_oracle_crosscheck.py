@@ -189,6 +189,34 @@ def test_error_sites(talos):
         s.Solve(p["q"], p["H_ref"], p["v_ref"], p["c_ids"], p["Ais"], p["bis"], p["lb"][:-1], p["ub"][:-1])
     with pytest.raises(RuntimeError):  # number of constraints (ik-id-description-optimized.hpp:142-145)
         s.Solve(p["q"], p["H_ref"], p["v_ref"], [1, 2], np.tile(np.eye(6), (2, 1, 1)), np.zeros((2, 6)), p["lb"], p["ub"])
-    s2 = ref.RefSolver(talos, **dict(FIXTURE, max_iter=10, mu_update_strat=1))
-    with pytest.raises(RuntimeError):  # OSQP strategy not implemented (loik-loid-optimized.hxx:632-634)
+    s2 = ref.RefSolver(talos, **dict(FIXTURE, max_iter=10, mu_update_strat=3))
+    with pytest.raises(RuntimeError):  # MAXEIGENVALUE strategy not implemented (loik-loid-optimized.hxx:635-637)
         s2.Solve(*problem_args(p))
+    # (OSQP, which upstream also throws for, hxx:632-634, is an EXTENSION here: test_osqp_mu_rule_extension below)
+
+
+def test_osqp_mu_rule_extension(talos):
+    """ADMMPenaltyUpdateStrat::OSQP is declared upstream (task-solver-base.hpp:13-18) and throws there (hxx:632-634).  The
+    oracle and the device implement OSQP's published rule as an extension; no upstream behaviour exists to compare with, so
+    this pins what the rule must do: same optimum as DEFAULT (both solve the same QP), mu moves only in steps > 5x, and the
+    mu limit cycles of DEFAULT (instances running into max_iter) mostly disappear."""
+    from loik_amd import workloads
+    wl = workloads.talos_c3(600, seed=11)
+    m, prm = wl["model"], dict(wl["params"], max_iter=600)
+    args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    d = ref.solve_batch(m, *args, nthreads=4, **prm)
+    o = ref.solve_batch(m, *args, nthreads=4, **dict(prm, mu_update_strat=1))
+    both = d["converged"] & o["converged"]
+    assert both.mean() > 0.75
+    assert np.abs(d["z"] - o["z"])[both].max() < 1e-4          # same optimum to the solver tolerance
+    hit_d = ((d["iters"] >= 599) & ~d["converged"]).sum(); hit_o = ((o["iters"] >= 599) & ~o["converged"]).sum()
+    assert hit_o <= hit_d and o["converged"].sum() >= d["converged"].sum()
+    # one instance step by step: mu constant between updates, every update by more than a factor 5, inside the clip range
+    r = ref.RefSolver(m, **dict(prm, mu_update_strat=1))
+    r.SolveInit(*problem_args(wl, 3))
+    mus = [r.scalar("mu")]
+    for it in range(40):
+        r.IterationBody(); r.CheckConvergence(); r.UpdateMu()
+        mus.append(r.scalar("mu"))
+    ratios = [b / a for a, b in zip(mus[:-1], mus[1:]) if b != a]
+    assert ratios and all(x > 5.0 or x < 0.2 for x in ratios) and all(1e-6 <= x <= 1e6 for x in mus)
