@@ -315,6 +315,40 @@ def kernel_roofline(acc, last, steps, nb, nc, B):
     return r
 
 
+def whole_body_variant(args, device):
+    """Reported beside the headline (not `value`): the 44-DoF Talos tree of the reference's fixture file with FOUR simultaneous
+    6-D tasks (both wrists, both feet) -- every limb of the robot works, unlike C3's 9-joint support chain -- same batch,
+    tolerances and engine selection (loik_amd.workloads.talos_wholebody)."""
+    import loik_amd
+    from loik_amd import workloads
+    wl = workloads.talos_wholebody(args.batch)
+    m, prm = wl["model"], wl["params"]
+    s = loik_amd.BatchedLoik(m, args.batch, device=device, flags=args.flags, **prm)
+    s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    s.Solve()
+    s.synchronize()
+    steps = max(2, min(args.steps, 3))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        s.Solve()
+    s.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    st = s.stats()
+    conv = s.get("converged").astype(bool)
+    it = s.get("iter")
+    out = {"workload": wl["name"], "robot": "talos44 (topology of talos_full_v2.urdf, 44 x 1-DoF, depth 11, four joints on each wrist link)",
+           "num_eq_c": len(wl["c_ids"]), "batch": args.batch, "ms_per_step": dt * 1e3, "value": float(conv.sum() / dt),
+           "unit": "solves/s", "solved_fraction": float(conv.mean()),
+           "flagged_infeasible_fraction": float(s.get("primal_infeasible").astype(bool).mean()),
+           "mean_admm_iterations": float(it.mean()), "instance_iterations_per_s": float(it.sum() / dt),
+           "engine": "k_lean" if st["lean_launches"] > 0 and st["tail_instances"] == args.batch else "k_solve+k_tail",
+           "lean_escaped": st["lean_escaped"],
+           "achieved_TFLOPs": float(it.sum() * FLOPS_PER_JOINT_ITERATION * m.nv / dt / 1e12),
+           "frac_of_fp64_valu_peak": float(it.sum() * FLOPS_PER_JOINT_ITERATION * m.nv / dt / 1e12 / FP64_VALU_PEAK_TF)}
+    s.close()
+    return out
+
+
 def main(argv=None, solver_factory=None, device_count=None):
     """solver_factory / device_count: test hooks (tests/test_bench_multi_device.py drives the N-device host logic with a
     stand-in solver on a machine without GPUs); the product path leaves them None"""
@@ -325,6 +359,7 @@ def main(argv=None, solver_factory=None, device_count=None):
     ap.add_argument("--batch", type=int, default=HEADLINE_BATCH, help="instances per GPU (weak) / in total (strong)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the whole-body variant reported beside the headline at N = 1")
     ap.add_argument("--no-strong-leg", action="store_true", help="skip the extra strong-scaling measurement at N > 1")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--max-launch-iters", type=int, default=0)
@@ -448,6 +483,13 @@ def main(argv=None, solver_factory=None, device_count=None):
         }
         if strong is not None:
             line["strong_scaling"] = strong
+        if n_total == 1 and not args.no_variants and solver_factory is None:
+            try:
+                for sh in shards:
+                    sh.solver.close()
+                line["whole_body_variant"] = whole_body_variant(args, device_of(0))
+            except Exception as e:  # the headline must survive a failing variant
+                line["whole_body_variant"] = {"failed": repr(e)}
         if n_total == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(wl0)
@@ -460,7 +502,7 @@ def main(argv=None, solver_factory=None, device_count=None):
         ret = None
     if strong is None:
         for sh in shards:
-            sh.solver.close()
+            sh.solver.close()  # (idempotent)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

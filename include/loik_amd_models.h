@@ -54,6 +54,9 @@ typedef struct loikb_model_desc {
  *   "panda9"  : panda7 + two prismatic fingers (PY and prismatic-unaligned -y), as example-robot-data's panda.urdf
  *   "talos32" : Talos humanoid topology, fixed base, legs(6+6) torso(2) arms(7+1, 7+1) head(2)
  *   "talos32_freeflyer" : the same robot under a free-flyer "root_joint" (floating base): 33 joints, nq 39, nv 38
+ *   "talos44" : the topology of talos_full_v2.urdf, the file the reference's fixture loads (tests/loik-loid.cpp:110-111):
+ *               talos32 + six passive finger joints under each wrist (nq = nv = 44, last joint head_2_joint); the wrist
+ *               link carries four joints.  Finger placements are representative, not the URDF's
  * Returns 0 and fills *out with pointers to static storage valid for the process lifetime, or -1.
  * q_lo / q_hi (may be NULL) receive pointers to [nq] sampling ranges for synthetic configurations (the quaternion
  * entries of a free-flyer are placeholders: draw unit quaternions).

@@ -212,7 +212,7 @@ class Model:
 
 
 def builtin_model(name):
-    """'panda7' | 'panda9' | 'talos32' | 'talos32_freeflyer' (tables in loik_amd/csrc/models.c)"""
+    """'panda7' | 'panda9' | 'talos32' | 'talos32_freeflyer' | 'talos44' (tables in loik_amd/csrc/models.c)"""
     L = lib()
     d = ModelDesc()
     lo, hi = _dp(), _dp()

@@ -835,18 +835,26 @@ int compact(loikb_solver_impl* S, Chunk* C, int src, int dst, int n_src, int* n_
 // Can the stragglers / small batches of this solver run in the lean tail kernel (two wavefronts per SIMD, loik_lean.hpp)?
 // H cache on, one joint per lane, at most 4 children per joint, and an LDS footprint that
 // lets two 4-wavefront workgroups share a CU.  LOIKB_LEAN=0 switches it off.
+// wavefronts of the lean kernel a CU can hold: two per SIMD by registers (256 each), fewer when the LDS of 160 KB is the
+// limit (each wavefront owns its exchange rows, one H slot per lane and its instances' constraint blocks: 19.5 KB with one
+// shared-A task constraint, 21.6 KB with four).  Wavefronts of this kernel never synchronise with each other, so the
+// workgroup size is free: four wavefronts per workgroup while eight fit, single-wavefront workgroups otherwise (seven fit
+// with four task constraints -- a whole-body task set stays in this engine at 7/8 of the residency).
+int lean_waves_per_cu(const loikb_solver_impl* S)
+{
+  int G = 8;
+  while (G < S->nb) G <<= 1;
+  const size_t per_wave = S->f32 ? lean_lds_bytes<float>(S->nc, G, S->a_shared) : lean_lds_bytes<double>(S->nc, G, S->a_shared);
+  return (int)std::min<size_t>(8, (160 * 1024) / per_wave);
+}
+
 bool lean_applicable(const loikb_solver_impl* S)
 {
   if (const char* e = getenv("LOIKB_LEAN")) if (atoi(e) == 0) return false;
   if (S->nb > WAVE || S->maxchild > 4) return false;
   if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) return false;
   if (S->opt.mu_update_strat == LOIKB_MU_OSQP) return false;  // mu is not on the decade grid: no precomputed slots
-  int G = 8;
-  while (G < S->nb) G <<= 1;
-  const size_t esz = S->f32 ? sizeof(float) : sizeof(double);  // (lean_lds_bytes<double> / 8 * esz, rounded the same way)
-  const size_t per_wave = S->f32 ? lean_lds_bytes<float>(S->nc, G, S->a_shared) : lean_lds_bytes<double>(S->nc, G, S->a_shared);
-  (void)esz;
-  return 2 * TAIL_WAVES * per_wave <= 160 * 1024;
+  return lean_waves_per_cu(S) >= 6;
 }
 
 template <typename T>
@@ -922,14 +930,16 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       }
     }
     if (lean_ok) {
-      const size_t lds = TAIL_WAVES * wave_lds;
+      const int waves_cu = lean_waves_per_cu(S);
+      const int ltw = waves_cu == 8 ? TAIL_WAVES : 1;  // wavefronts per workgroup
+      const size_t lds = ltw * wave_lds;
       if (lds > 64 * 1024) {
         HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       }
-      int wg_per_cu = 2;
+      int wg_per_cu = waves_cu / ltw;
       if (const char* e = getenv("LOIKB_LEAN_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
       const int wg_cap = wg_per_cu * std::max(1, (int)(S->ncu * ((double)C->B / (double)S->B) + 0.5));
       // Optional rounds with a bounded share of iterations per instance (LOIKB_LEAN_QUANTA="24,64,160,400"; default: one
@@ -954,7 +964,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       for (size_t round = 0; round < quanta.size() && n > 0; ++round) {
         if (quanta[round] <= 0) continue;
         P.max_launch_iters = quanta[round];
-        const int wg_needed = (n + ipw * TAIL_WAVES - 1) / (ipw * TAIL_WAVES);
+        const int wg_needed = (n + ipw * ltw - 1) / (ipw * ltw);
         const dim3 grid((unsigned)std::min(wg_needed, wg_cap));
         HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
         if (!slots_built) {
@@ -976,7 +986,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         // host-side rounds (LOIKB_LEAN_QUANTA) bring their own bound and switch it off
         const int quantum = quanta.size() > 1 ? 0 : lean_quantum;
 #define LOIKB_LAUNCH_LEAN(HD, SL)                                                                                             \
-  hipLaunchKernelGGL((k_lean<T, HD, SL>), grid, dim3(WAVE * TAIL_WAVES), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,      \
+  hipLaunchKernelGGL((k_lean<T, HD, SL>), grid, dim3(WAVE * ltw), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,             \
                      (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, C->d_ring,              \
                      C->ring_cap - 1, n, G, (const T*)C->d_hslots, kexp_lo, ndec, quantum)
         if (quantum > 0) { if (S->href_diag) LOIKB_LAUNCH_LEAN(true, true); else LOIKB_LAUNCH_LEAN(false, true); }

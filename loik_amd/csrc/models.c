@@ -23,7 +23,8 @@ typedef struct {
   const char *jname[MAXJ];
 } table_t;
 
-static table_t g_panda7 = {"panda7"}, g_panda9 = {"panda9"}, g_talos32 = {"talos32"}, g_talos32_ff = {"talos32_freeflyer"};
+static table_t g_panda7 = {"panda7"}, g_panda9 = {"panda9"}, g_talos32 = {"talos32"}, g_talos32_ff = {"talos32_freeflyer"},
+               g_talos44 = {"talos44"};
 
 static void rpy_to_R(double r, double p, double y, double *R)
 {
@@ -101,8 +102,29 @@ static void build_panda(table_t *t, int fingers)
 
 /* floating = 1: Pinocchio's buildModel(urdf, JointModelFreeFlyer(), model): joint 1 = "root_joint" (free-flyer,
  * identity placement), the robot's root children hang off it */
-static void build_talos32(table_t *t, int floating)
+/* The six passive finger joints under a wrist of talos_full_v2.urdf (the file the reference's fixture loads,
+ * tests/loik-loid.cpp:110-111; its <mimic> tags are ignored by pinocchio::urdf::buildModel, so each is a revolute DoF):
+ * the wrist link then carries FOUR joints (gripper, inner_double, inner_single, motor_single), inner_double two fingertips,
+ * inner_single one.  Names and topology as in the public talos_data gripper description; the centimetre-scale placements
+ * are representative values, not the URDF's (no URDF in this image) -- same arithmetic per joint, a synthetic geometry. */
+static void add_fingers(table_t *t, int wrist, const char *const *nm, double sy)
 {
+  int j = tbl_add(t, nm[0], wrist, LOIKB_J_RX, 0, 0, 0, 0, sy * 0.018, -0.135, 0, 0, 0, -0.3, 0.3);   /* inner_double */
+  tbl_add(t, nm[1], j, LOIKB_J_RX, 0, 0, 0, 0.032, sy * 0.004, -0.063, 0, 0, 0, -0.3, 0.3);           /* fingertip_1  */
+  tbl_add(t, nm[2], j, LOIKB_J_RX, 0, 0, 0, -0.032, sy * 0.004, -0.063, 0, 0, 0, -0.3, 0.3);          /* fingertip_2  */
+  j = tbl_add(t, nm[3], wrist, LOIKB_J_RX, 0, 0, 0, 0, sy * -0.018, -0.135, 0, 0, 0, -0.3, 0.3);      /* inner_single */
+  tbl_add(t, nm[4], j, LOIKB_J_RX, 0, 0, 0, 0, sy * -0.004, -0.063, 0, 0, 0, -0.3, 0.3);              /* fingertip_3  */
+  tbl_add(t, nm[5], wrist, LOIKB_J_RX, 0, 0, 0, 0, sy * -0.02025, -0.12193, 0, 0, 0, -0.3, 0.3);      /* motor_single */
+}
+
+static void build_talos32(table_t *t, int floating, int fingers)
+{
+  static const char *const fl[6] = {"gripper_left_inner_double_joint", "gripper_left_fingertip_1_joint",
+                                    "gripper_left_fingertip_2_joint", "gripper_left_inner_single_joint",
+                                    "gripper_left_fingertip_3_joint", "gripper_left_motor_single_joint"};
+  static const char *const fr[6] = {"gripper_right_inner_double_joint", "gripper_right_fingertip_1_joint",
+                                    "gripper_right_fingertip_2_joint", "gripper_right_inner_single_joint",
+                                    "gripper_right_fingertip_3_joint", "gripper_right_motor_single_joint"};
   tbl_init(t);
   const double d = 0.3; /* sampling half-range around the nominal pose */
   int j;
@@ -132,7 +154,8 @@ static void build_talos32(table_t *t, int floating)
   j = tbl_add(t, "arm_left_5_joint", j, LOIKB_J_RZ, 0, 0, 0, -0.02, 0, -0.2643, 0, 0, 0, -d, d);
   j = tbl_add(t, "arm_left_6_joint", j, LOIKB_J_RX, 0, 0, 0, 0, 0, 0, 0, 0, 0, -d, d);
   j = tbl_add(t, "arm_left_7_joint", j, LOIKB_J_RY, 0, 0, 0, 0, 0, 0, 0, 0, 0, -d, d);
-  j = tbl_add(t, "gripper_left_joint", j, LOIKB_J_RY, 0, 0, 0, 0, 0.02025, -0.12193, 0, 0, 0, -0.5, 0.0);
+  tbl_add(t, "gripper_left_joint", j, LOIKB_J_RY, 0, 0, 0, 0, 0.02025, -0.12193, 0, 0, 0, -0.5, 0.0);
+  if (fingers) add_fingers(t, j, fl, 1.0);
   /* right arm */
   j = tbl_add(t, "arm_right_1_joint", torso2, LOIKB_J_RZ, 0, 0, 0, 0, -0.1575, 0.232, 0, 0, 0, -0.25 - d, -0.25 + d);
   j = tbl_add(t, "arm_right_2_joint", j, LOIKB_J_RX, 0, 0, 0, 0.00493378, -0.1365, 0.04673, 0, 0, 0, -0.17 - d, -0.17 + d);
@@ -141,7 +164,8 @@ static void build_talos32(table_t *t, int floating)
   j = tbl_add(t, "arm_right_5_joint", j, LOIKB_J_RZ, 0, 0, 0, -0.02, 0, -0.2643, 0, 0, 0, -d, d);
   j = tbl_add(t, "arm_right_6_joint", j, LOIKB_J_RX, 0, 0, 0, 0, 0, 0, 0, 0, 0, -d, d);
   j = tbl_add(t, "arm_right_7_joint", j, LOIKB_J_RY, 0, 0, 0, 0, 0, 0, 0, 0, 0, -d, d);
-  j = tbl_add(t, "gripper_right_joint", j, LOIKB_J_RY, 0, 0, 0, 0, -0.02025, -0.12193, 0, 0, 0, -0.5, 0.0);
+  tbl_add(t, "gripper_right_joint", j, LOIKB_J_RY, 0, 0, 0, 0, -0.02025, -0.12193, 0, 0, 0, -0.5, 0.0);
+  if (fingers) add_fingers(t, j, fr, -1.0);
   /* head */
   j = tbl_add(t, "head_1_joint", torso2, LOIKB_J_RY, 0, 0, 0, 0, 0, 0.316, 0, 0, 0, -d, d);
   j = tbl_add(t, "head_2_joint", j, LOIKB_J_RZ, 0, 0, 0, 0.02, 0, 0, 0, 0, 0, -d, d);
@@ -153,8 +177,9 @@ static table_t *find(const char *name)
   if (!name) return 0;
   if (!strcmp(name, "panda7")) { if (!g_panda7.built) build_panda(&g_panda7, 0); return &g_panda7; }
   if (!strcmp(name, "panda9")) { if (!g_panda9.built) build_panda(&g_panda9, 1); return &g_panda9; }
-  if (!strcmp(name, "talos32")) { if (!g_talos32.built) build_talos32(&g_talos32, 0); return &g_talos32; }
-  if (!strcmp(name, "talos32_freeflyer")) { if (!g_talos32_ff.built) build_talos32(&g_talos32_ff, 1); return &g_talos32_ff; }
+  if (!strcmp(name, "talos32")) { if (!g_talos32.built) build_talos32(&g_talos32, 0, 0); return &g_talos32; }
+  if (!strcmp(name, "talos32_freeflyer")) { if (!g_talos32_ff.built) build_talos32(&g_talos32_ff, 1, 0); return &g_talos32_ff; }
+  if (!strcmp(name, "talos44")) { if (!g_talos44.built) build_talos32(&g_talos44, 0, 1); return &g_talos44; }
   return 0;
 }
 

@@ -175,3 +175,27 @@ def panda_c5(batch=65536, seed=0x101C + 5, tol=1e-3, model=None):
     wl["model"] = model
     wl["name"] = "panda7_B%d_tol%g" % (batch, tol)
     return wl
+
+
+def talos_wholebody(batch, seed=0x101C + 6, model=None, links=("arm_left_7_joint", "arm_right_7_joint", "leg_left_6_joint",
+                                                               "leg_right_6_joint")):
+    """Whole-body variant of the headline workload: FOUR simultaneous 6-D tasks (both wrists, both feet; num_eq_c = 4, the
+    constructor argument of the reference, loik-loid-optimized.hpp:129-134) on the Talos topology -- by default the 44-DoF
+    tree of talos_full_v2.urdf, the file the reference's fixture loads (tests/loik-loid.cpp:110-111).  b_c = J_c(q) nu* for ONE
+    common nu* ~ U(-0.5, 0.5)^nv -> jointly feasible; A_c = I, box +-0.5, the C3 stopping rule.  Every joint of the robot is
+    in some task's support chain except the head."""
+    if model is None:
+        from . import builtin_model
+        model = builtin_model("talos44")
+    ids = [model.getJointId(n) for n in links]
+    wl = make_workload(model, batch, ids[0], seed, bound=0.5, snap_prob=0.0)
+    b = np.empty((batch, len(ids), 6))
+    for c, link in enumerate(ids):
+        b[:, c] = link_velocity(model, wl["q"], wl["nu_star"], link)
+    wl["c_ids"] = np.array(ids, dtype=np.int32)
+    wl["Ais"] = np.tile(np.eye(6), (len(ids), 1, 1))
+    wl["bis"] = b
+    wl["params"] = dict(FIXTURE_PARAMS, max_iter=1000, tol_abs=1e-6, tol_rel=0.0, num_eq_c=len(ids))
+    wl["model"] = model
+    wl["name"] = "%s_wholebody_%dtasks_B%d_tol1e-6_adaptive_mu_fp64" % (model.name, len(ids), batch)
+    return wl

@@ -154,3 +154,50 @@ def test_gpu_without_constraints(which, request):
             assert it[b] == r.get_iter() and bool(conv[b]) == r.get_convergence_status()
             assert_close(z[b], r.z, 1e-9, "z"); assert_close(nu[b], r.nu, 1e-9, "nu")
         s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot", ["talos32", "talos44"])
+def test_whole_body_four_tasks_in_the_lean_engine(robot):
+    """both wrists + both feet (num_eq_c = 4) on the Talos topology incl. the 44-DoF tree of the reference's fixture file
+    (talos_full_v2.urdf, tests/loik-loid.cpp:110-111: four joints on each wrist link, depth 11): the default engine is
+    the lean kernel (single-wavefront workgroups: seven per CU fit the LDS) -- k iterations and end to end vs the oracle"""
+    from loik_amd import workloads
+    model = loik_amd.builtin_model(robot)
+    assert (model.nv == 44 and model.names[-1] == "head_2_joint") if robot == "talos44" else model.nv == 32
+    B = 320
+    wl = workloads.talos_wholebody(B, seed=5, model=model)
+    args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    for k in (1, 4):
+        prm = dict(wl["params"], max_iter=k + 1, tol_abs=0.0, tol_primal_inf=0.0)
+        s = loik_amd.BatchedLoik(model, B, **prm)
+        s.Solve(*args)
+        assert s.stats()["lean_launches"] >= 1
+        got = {n: s.get(n) for n in FIELDS + SCALARS}
+        got["His"] = s.His_full()
+        for b in range(0, B, 53):
+            r = ref.RefSolver(model, **prm)
+            r.Solve(*problem_args(wl, b))
+            for n in FIELDS:
+                want = r.field(n)
+                if n in ("vis", "fis", "g"):
+                    want = want[1:]
+                assert_close(got[n][b], want, 1e-9, "%s b%d k%d" % (n, b, k))
+            assert_close(got["His"][b], r.His[1:], 1e-9, "His")
+            for n in SCALARS:
+                assert_close(got[n][b], r.scalar(n), 1e-9, "%s b%d k%d" % (n, b, k))
+        s.close()
+    prm = dict(wl["params"], max_iter=500)
+    out = ref.solve_batch(model, *args, nthreads=4, want_nu=True, **prm)
+    s = loik_amd.BatchedLoik(model, B, **prm)
+    s.Solve(*args)
+    st = s.stats()
+    assert st["lean_launches"] >= 1 and st["lean_escaped"] == 0 and st["tail_instances"] == B, st
+    assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.95, ztol=1e-8, what="whole body " + robot)
+    # every task met where the solver converged (first principles)
+    conv = s.get("converged").astype(bool)
+    assert conv.mean() > 0.5
+    for c, link in enumerate(wl["c_ids"]):
+        v = workloads.link_velocity(model, wl["q"], s.get("z"), int(link))
+        assert np.max(np.abs(v - wl["bis"][:, c])[conv]) < 1e-5
+    s.close()
