@@ -49,7 +49,7 @@ enum {
 /* ---- ADMMPenaltyUpdateStrat, task-solver-base.hpp:13-18 -------------------------------------------- */
 /* DEFAULT is the reference's rule.  OSQP is declared upstream but throws "not yet implemented" there (hxx:632-637); HERE it
  * is implemented -- OSQP's published penalty rule on LoIK's residuals and normalisers, see update_mu() in
- * loik_amd/csrc/loik_device.hpp and the identical expression in the oracle -- as an extension, not a parity target: on the
+ * loik_amd/csrc/loik_device.hpp and the identical expression in the CPU oracle -- as an extension, not a parity target: on the
  * headline workload it ends most of DEFAULT's mu limit cycles (instances hitting max_iter: 0.85 % -> 0.17 %).  mu is then
  * off the decade grid, so such solves run in the k_solve / k_tail engines.  MAXEIGENVALUE returns LOIKB_ERR_MU_STRATEGY. */
 enum { LOIKB_MU_DEFAULT = 0, LOIKB_MU_OSQP = 1, LOIKB_MU_MAXEIGENVALUE = 3 };
@@ -240,6 +240,10 @@ typedef struct loikb_stats {
                                              work queue (round-robin among the instances waiting for a slot)                */
 } loikb_stats;
 int loikb_get_stats(loikb_solver *s, loikb_stats *out);
+/* which kernels the solves of this handle use and why (the engine plan is made in one place, from (nb, nc, sharing mode of
+ * A, children per joint, batch, options): at create and again at SolveInit) -- a human-readable line, valid until the next
+ * call on this thread */
+const char *loikb_plan_string(loikb_solver *s);
 
 /* introspection */
 int loikb_batch(const loikb_solver *s);

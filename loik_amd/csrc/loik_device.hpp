@@ -217,7 +217,7 @@ __host__ __device__ __forceinline__ float tmin(float a, float b) { return __buil
 
 // UpdateMu (loik-loid-optimized.hxx:613-641).  DEFAULT: the reference's decade steps.  OSQP: declared upstream
 // (ADMMPenaltyUpdateStrat::OSQP, task-solver-base.hpp:13-18) but never implemented there (it throws, hxx:632-637); this is
-// OSQP's published rule on LoIK's quantities, the same expression as oracle/loik_ref.c::ref_update_mu:
+// OSQP's published rule on LoIK's quantities (the CPU checker used by the tests evaluates the same expression):
 //   mu <- mu * sqrt( (r_p / max(|Av|, |nu|, |b|)) / (r_d / max(|H_ref v|, |g|, |S^T f + w|, |H_ref v_ref|)) ), clipped to
 //   [1e-6, 1e6], applied only when it moves mu by more than a factor of 5.  Returns true when mu changed.
 template <typename T>

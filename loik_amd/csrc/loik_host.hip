@@ -47,7 +47,63 @@ namespace {
 
 constexpr int ROWMAP_CAP = 8192;
 
+// Developer overrides from the environment, read ONCE in loikb_create (never inside a solve).  Defaults are the measured
+// choices; the variables exist for the experiments recorded in DESIGN.md / profiles/ and for tests/test_engines.py.
+struct Tuning {
+  int team = MAX_TEAM;          // LOIKB_TEAM          wavefronts per tile of k_solve
+  int team_max = 1 << 30;       // LOIKB_TEAM_MAX      use the team schedule only up to this many slots
+  int tile_pad = -1;            // LOIKB_TILE_PAD      extra pairs per tile (-1: pad to an odd number of 1-KiB pairs)
+  bool lean = true;             // LOIKB_LEAN=0        never use k_lean
+  int tail_waves = TAIL_WAVES;  // LOIKB_TAIL_WAVES    wavefronts per k_tail workgroup
+  int lean_decades = 10;        // LOIKB_LEAN_DECADES  decades of mu with precomputed H slots ...
+  int lean_klo = -2;            // LOIKB_LEAN_KLO      ... starting at mu0 * 10^klo
+  int lean_wg_per_cu = 0;       // LOIKB_LEAN_WG_PER_CU (0: what registers and LDS allow)
+  std::vector<int> lean_quanta; // LOIKB_LEAN_QUANTA   host-side rounds of the lean launch (default: none)
+  int lean_slice = 0;           // LOIKB_LEAN_SLICE    in-kernel round-robin time slice (0: run to completion)
+  double compact_ratio = 0.85;  // LOIKB_COMPACT_RATIO repack k_solve's tiles when at most this share of the slots is live
+  bool direct_tail = true;      // LOIKB_NO_DIRECT_TAIL small batches go to the on-chip engines from the first iteration
+  int lat_iters = 16;           // LOIKB_LAT_ITERS     iterations per k_solve launch in its latency-bound regime
+  int chunks = 0;               // LOIKB_CHUNKS        concurrent chunks (0: by engine plan)
+  bool trace = false;           // LOIKB_TRACE         per-launch lines on stderr
+  void read_env()
+  {
+    auto geti = [](const char* n, int& v) { if (const char* e = getenv(n)) v = atoi(e); };
+    geti("LOIKB_TEAM", team); team = std::max(1, std::min(MAX_TEAM, team));
+    geti("LOIKB_TEAM_MAX", team_max);
+    geti("LOIKB_TILE_PAD", tile_pad);
+    if (const char* e = getenv("LOIKB_LEAN")) lean = atoi(e) != 0;
+    geti("LOIKB_TAIL_WAVES", tail_waves); tail_waves = std::max(1, std::min(TAIL_WAVES, tail_waves));
+    geti("LOIKB_LEAN_DECADES", lean_decades); lean_decades = std::max(1, std::min(16, lean_decades));
+    geti("LOIKB_LEAN_KLO", lean_klo);
+    geti("LOIKB_LEAN_WG_PER_CU", lean_wg_per_cu);
+    if (const char* e = getenv("LOIKB_LEAN_QUANTA"))
+      for (const char* p = e; *p;) { lean_quanta.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+    geti("LOIKB_LEAN_SLICE", lean_slice); lean_slice = std::max(0, lean_slice);
+    if (const char* e = getenv("LOIKB_COMPACT_RATIO")) compact_ratio = atof(e);
+    direct_tail = getenv("LOIKB_NO_DIRECT_TAIL") == nullptr;
+    geti("LOIKB_LAT_ITERS", lat_iters);
+    geti("LOIKB_CHUNKS", chunks);
+    trace = getenv("LOIKB_TRACE") != nullptr;
+  }
+};
+
+// Which kernels a solve of this handle uses -- decided in ONE place (plan_engines) from (nb, nc, A shared?, children per
+// joint, batch, options), whenever one of them changes (create, SolveInit):
+//   lean        k_hslots + k_lean take whole batches / the hand-over from k_solve (else k_tail does)
+//   tail_max    hand the solve over to the on-chip engine once at most this many instances are live (whole batch: direct)
+//   nchunks     concurrent chunks of the k_solve phase (1 when the on-chip engine runs the whole batch in one launch)
+struct EnginePlan {
+  bool lean = false;
+  const char* why_not_lean = "";
+  int lean_waves_cu = 0, lean_wg_waves = TAIL_WAVES;
+  int ndec = 10, kexp_lo = -2;
+  int tail_max = 32768;
+  int nchunks = 1;
+};
+
 struct loikb_solver_impl {
+  Tuning tune;
+  EnginePlan plan;
   // model (copied).  nj/nb/parents/jtype/idx_q/jd describe the DEVICE tree, in which every joint has one DoF: a
   // free-flyer / spherical / translation joint of the caller's model is a chain of 6 / 3 / 3 one-DoF joints about the
   // axes of one frame with massless links in between (build_schedule).  nq, nv are the caller's; nv == nb.
@@ -453,11 +509,7 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
   S->idx_v.resize(nj);
   for (int i = 0; i < nj; ++i) S->idx_v[i] = i > 0 ? i - 1 : 0;
   build_team_schedule(S->parents, 1, S->sched[0]);
-  int team = MAX_TEAM;
-  if (const char* e = getenv("LOIKB_TEAM")) team = atoi(e);
-  if (team < 1) team = 1;
-  if (team > MAX_TEAM) team = MAX_TEAM;
-  build_team_schedule(S->parents, team, S->sched[1]);
+  build_team_schedule(S->parents, S->tune.team, S->sched[1]);
   // depth / children of every joint for the level-synchronous tail kernel
   S->topo.assign(nj, TailTopo{});
   S->child_list.clear();
@@ -657,9 +709,100 @@ std::vector<int> rowmap_constraint(const loikb_solver_impl* S, int c, int first_
   return rm;
 }
 
-// the tile layout depends on whether A is shared (short constraint record) -> (re)allocate the sets on change
+void plan_engines(loikb_solver_impl* S);
+
+void destroy_chunks(loikb_solver_impl* S)
+{
+  for (Chunk& C : S->chunks) {
+    if (C.h_counters) (void)hipHostFree(C.h_counters);
+    if (C.d_hslots) (void)hipFree(C.d_hslots);
+    if (C.ev_k0) (void)hipEventDestroy(C.ev_k0);
+    if (C.ev_k2) (void)hipEventDestroy(C.ev_k2);
+    if (C.ev_k1) (void)hipEventDestroy(C.ev_k1);
+    if (C.own_stream && C.stream) (void)hipStreamDestroy(C.stream);
+    void* ptrs[4] = {C.d_counters, C.d_slots, C.d_slots2, C.d_ring};
+    for (void* p : ptrs)
+      if (p) {
+        (void)hipFree(p);
+        for (auto& a : S->allocs) if (a == p) a = nullptr;
+      }
+  }
+  S->chunks.clear();
+}
+
+// chunks: contiguous ranges of tiles, each with its own stream, counters, instance lists and work queue
+int build_chunks(loikb_solver_impl* S, int nchunks)
+{
+  const int ntiles = (S->B + WAVE - 1) / WAVE;
+  const int per = (ntiles + nchunks - 1) / nchunks;
+  S->chunks.clear();
+  for (int t0 = 0; t0 < ntiles; t0 += per) {
+    Chunk C;
+    C.first_tile = t0;
+    C.B = std::min(S->B - t0 * WAVE, per * WAVE);
+    S->chunks.push_back(C);
+  }
+  void* tmp = nullptr;
+  int rc;
+  for (Chunk& C : S->chunks) {
+    HIPCHK(hipEventCreate(&C.ev_k2));
+    HIPCHK(hipEventCreate(&C.ev_k0));
+    HIPCHK(hipEventCreate(&C.ev_k1));
+    HIPCHK(hipHostMalloc((void**)&C.h_counters, NCOUNTERS * sizeof(unsigned int)));
+    if ((rc = alloc_dev(S, &tmp, NCOUNTERS * sizeof(unsigned int)))) return rc;
+    C.d_counters = (unsigned int*)tmp;
+    if ((rc = alloc_dev(S, &tmp, sizeof(int) * (size_t)(C.B + WAVE)))) return rc;
+    C.d_slots = (int*)tmp;
+    if ((rc = alloc_dev(S, &tmp, sizeof(int) * (size_t)(C.B + WAVE)))) return rc;
+    C.d_slots2 = (int*)tmp;
+    C.ring_cap = 64;
+    while (C.ring_cap < 2 * (C.B + WAVE)) C.ring_cap <<= 1;
+    if ((rc = alloc_dev(S, &tmp, sizeof(int) * (size_t)C.ring_cap))) return rc;
+    C.d_ring = (int*)tmp;
+    if (S->chunks.size() > 1) {
+      HIPCHK(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
+      C.own_stream = true;
+    }
+  }
+  return LOIKB_OK;
+}
+
+// Decade slots of the lean engine (H_i, Dinv_i per joint and decade of mu, loik_lean.hpp): sized for the whole chunk when
+// the plan is made -- never inside a solve -- with a stated budget: batch x decades x 176 B x lanes per instance
+// (Talos-32: 3.7 GB for 65536 instances, 59 GB for 2^20).  Not enough memory is an error the caller can act on
+// (LOIKB_LEAN=0 selects the engines that need none), not a silent change of engine.
+int ensure_hslots(loikb_solver_impl* S)
+{
+  if (!S->plan.lean) return LOIKB_OK;
+  int G = 8;
+  while (G < S->nb) G <<= 1;
+  for (Chunk& C : S->chunks) {
+    const size_t need = (size_t)C.B * S->plan.ndec * HSLOT_PAIRS * G * 2 * S->esz;
+    if (need <= C.hslots_bytes) continue;
+    if (C.d_hslots) HIPCHK(hipFree(C.d_hslots));
+    C.d_hslots = nullptr; C.hslots_bytes = 0;
+    if (hipMalloc(&C.d_hslots, need) != hipSuccess) {
+      (void)hipGetLastError();
+      char buf[400];
+      snprintf(buf, sizeof(buf), "the lean engine needs %.2f GB of decade slots for %d instances (%d decades x %d B x %d lanes each) "
+               "and the device has no room for them: create the solver with a smaller batch, or set LOIKB_LEAN=0 to use the "
+               "k_solve + k_tail engines, which need none", need / 1e9, C.B, S->plan.ndec, (int)(HSLOT_PAIRS * 2 * S->esz), G);
+      g_last_error = buf;
+      C.d_hslots = nullptr;
+      return LOIKB_ERR_HIP;
+    }
+    C.hslots_bytes = need;
+  }
+  return LOIKB_OK;
+}
+
+// The tile layout depends on whether A is shared (short constraint record), and so does the engine plan (LDS budget of
+// the lean kernel, hence the number of concurrent chunks): both are (re)established here -- at create with the default
+// sharing mode, at SolveInit with the real one.
 int ensure_layout(loikb_solver_impl* S, bool a_shared)
 {
+  S->a_shared = a_shared;
+  plan_engines(S);
   Layout L{};
   L.nb = S->nb; L.nc = S->nc;
   L.crec = a_shared ? CREC_SHARED_A : CREC_FULL;
@@ -668,9 +811,11 @@ int ensure_layout(loikb_solver_impl* S, bool a_shared)
   L.tile_pairs = L.off_s + SREC;
   // odd number of 1-KiB pairs per tile: consecutive tiles (= wavefronts that run in lockstep through the same joint
   // offsets) then start on different HBM channel groups instead of camping on a few of them
-  if (const char* e = getenv("LOIKB_TILE_PAD")) L.tile_pairs += atoi(e);
+  if (S->tune.tile_pad >= 0) L.tile_pairs += S->tune.tile_pad;
   else if (!(L.tile_pairs & 1)) L.tile_pairs += 1;
-  if (S->home.tiles && L.crec == S->L.crec) return LOIKB_OK;
+  const bool relayout = !S->home.tiles || L.crec != S->L.crec;
+  const bool rechunk = (int)S->chunks.size() != S->plan.nchunks;
+  if (!relayout && !rechunk) return ensure_hslots(S);
   auto free_set = [&](loikb_solver_impl::Set& W, bool owns_tiles) {
     void* ptrs[4] = {owns_tiles ? W.tiles : nullptr, W.map, W.wave_live, W.wave_off};
     for (void* p : ptrs)
@@ -680,17 +825,23 @@ int ensure_layout(loikb_solver_impl* S, bool a_shared)
       }
     W = loikb_solver_impl::Set{};
   };
-  if (S->home.tiles) {
-    // sharing mode of A changed: every tile has a different size now
-    HIPCHK(hipStreamSynchronize(S->stream));
-    for (Chunk& C : S->chunks)
-      for (int k = 0; k < 3; ++k) free_set(C.set[k], k != 0);
-    free_set(S->home, true);
-    S->have_problem = false;
+  int rc;
+  if (S->home.tiles) HIPCHK(hipStreamSynchronize(S->stream));
+  for (Chunk& C : S->chunks)
+    for (int k = 0; k < 3; ++k) free_set(C.set[k], k != 0);
+  if (rechunk) {
+    destroy_chunks(S);
+    if ((rc = build_chunks(S, S->plan.nchunks))) return rc;
   }
-  S->L = L;
-  int rc = alloc_set(S, S->home, (S->B + WAVE - 1) / WAVE);
-  if (rc) return rc;
+  if (relayout) {
+    if (S->home.tiles) {
+      // sharing mode of A changed: every tile has a different size now
+      free_set(S->home, true);
+      S->have_problem = false;
+    }
+    S->L = L;
+    if ((rc = alloc_set(S, S->home, (S->B + WAVE - 1) / WAVE))) return rc;
+  }
   // chunk views of the home set (their work sets are allocated on first use)
   for (Chunk& C : S->chunks) {
     loikb_solver_impl::Set& V = C.set[0];
@@ -702,8 +853,9 @@ int ensure_layout(loikb_solver_impl* S, bool a_shared)
     if ((rc = alloc_dev(S, &tmp, sizeof(int) * ((size_t)V.ntiles + 1)))) return rc;
     V.wave_off = (int*)tmp;
   }
+  if ((rc = ensure_hslots(S))) return rc;
   // fresh tiles: the reference ctor state is all-zero data (loik-loid-data-optimized.hxx:40-86) + ResetSolver
-  return reset_home(S, RS_SOLVER | RS_HCACHE);
+  return relayout ? reset_home(S, RS_SOLVER | RS_HCACHE) : LOIKB_OK;
 }
 
 // problem_.UpdateReference / UpdateIneqConstraints / UpdateEqConstraints (ik-id-description-optimized.hpp:78-171,
@@ -848,13 +1000,34 @@ int lean_waves_per_cu(const loikb_solver_impl* S)
   return (int)std::min<size_t>(8, (160 * 1024) / per_wave);
 }
 
-bool lean_applicable(const loikb_solver_impl* S)
+// THE engine dispatch: (nb, nc, A shared?, children per joint, precision, options, tuning) -> plan.  Called from
+// ensure_layout: at create with the default sharing mode of A, at SolveInit with the real one.
+void plan_engines(loikb_solver_impl* S)
 {
-  if (const char* e = getenv("LOIKB_LEAN")) if (atoi(e) == 0) return false;
-  if (S->nb > WAVE || S->maxchild > 4) return false;
-  if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) return false;
-  if (S->opt.mu_update_strat == LOIKB_MU_OSQP) return false;  // mu is not on the decade grid: no precomputed slots
-  return lean_waves_per_cu(S) >= 6;
+  EnginePlan pl;
+  pl.ndec = S->tune.lean_decades;
+  pl.kexp_lo = S->tune.lean_klo;
+  if (S->opt.flags & LOIKB_OPT_FIXED_ITERS) { pl.ndec = 1; pl.kexp_lo = 0; }  // mu frozen at mu0: one decade
+  pl.lean_waves_cu = S->nb <= WAVE ? lean_waves_per_cu(S) : 0;
+  pl.lean_wg_waves = pl.lean_waves_cu == 8 ? TAIL_WAVES : 1;
+  if (!S->tune.lean) pl.why_not_lean = "LOIKB_LEAN=0";
+  else if (S->nb > WAVE) pl.why_not_lean = "more joints than lanes of a wavefront";
+  else if (S->maxchild > 4) pl.why_not_lean = "a joint with more than four children";
+  else if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) pl.why_not_lean = "LOIKB_OPT_NO_H_CACHE (no precomputed H)";
+  else if (S->opt.mu_update_strat == LOIKB_MU_OSQP) pl.why_not_lean = "OSQP penalty rule: mu is off the decade grid";
+  else if (pl.lean_waves_cu < 6) pl.why_not_lean = "constraint blocks leave fewer than six wavefronts per CU in LDS";
+  else pl.lean = true;
+  // with the lean kernel whole batches up to 2^20 instances go to it directly (it is as fast as k_solve's bulk phase and
+  // has neither ragged tiles nor compaction); without it k_solve hands over to k_tail at 32768 live instances
+  pl.tail_max = S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : (pl.lean ? (1 << 20) : 32768);
+  // Concurrent chunks pay only in the k_solve + k_tail configuration (measured on MI355X, Talos-32, B = 65536: 1 chunk
+  // 52.9 ms/step, 2 chunks 47.9, 3 chunks 48.2, 4 chunks 74: one chunk's latency-bound straggler phase runs beside the
+  // other's bulk phase); the lean kernel takes the whole batch in one launch.
+  const int ntiles = (S->B + WAVE - 1) / WAVE;
+  pl.nchunks = (ntiles >= 512 && !pl.lean) ? 2 : 1;
+  if (S->tune.chunks > 0) pl.nchunks = S->tune.chunks;
+  pl.nchunks = std::max(1, std::min(pl.nchunks, ntiles));
+  S->plan = pl;
 }
 
 template <typename T>
@@ -884,8 +1057,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
   int G = 8;  // lanes per instance: smallest power of two >= nb
   while (G < S->nb) G <<= 1;
   const int ipw = WAVE / G;
-  int tw = TAIL_WAVES;  // wavefronts per workgroup
-  if (const char* e = getenv("LOIKB_TAIL_WAVES")) tw = std::max(1, std::min(TAIL_WAVES, atoi(e)));
+  int tw = S->tune.tail_waves;  // wavefronts per workgroup
   while (tw > 1 && tw * tail_lds_bytes<T>(S->nc, G) > 160 * 1024) --tw;
   const size_t lds = tw * tail_lds_bytes<T>(S->nc, G);
   if (lds > 160 * 1024) { g_last_error = "tail kernel: constraint data exceeds the LDS of a CU"; return LOIKB_ERR_ARG; }
@@ -899,7 +1071,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
   int n = n_live;
   double total_ms = 0.0;
   unsigned long long iters = 0;
-  const bool trace = getenv("LOIKB_TRACE") != nullptr;
+  const bool trace = S->tune.trace;
   const int* list = C->d_slots;
   // ---- lean tail kernel: two wavefronts per SIMD (loik_lean.hpp).  H_i / Dinv_i / UDinv_i of the listed instances are
   // precomputed for the decades mu0 * 10^(0 .. ndec-1) (k_hslots); instances whose mu leaves them come back unfinished
@@ -908,30 +1080,20 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     // decades of mu with precomputed slots: mu0 * 10^(kexp_lo .. kexp_lo + ndec - 1).  The DEFAULT rule moves mu up from
     // mu0 in the first iterations and then mostly oscillates between two or three decades (Talos workload: 0..7 seen,
     // < 0 never); an instance that leaves the range is finished by k_tail.
-    int ndec = 10, kexp_lo = -2;  // (the table is built as a pipeline over the tree levels: a decade more costs one step)
-    if (const char* e = getenv("LOIKB_LEAN_DECADES")) ndec = std::max(1, std::min(16, atoi(e)));
-    if (const char* e = getenv("LOIKB_LEAN_KLO")) kexp_lo = atoi(e);
+    // (the table is built as a pipeline over the tree levels: a decade more costs one step)
+    const int ndec = S->plan.ndec, kexp_lo = S->plan.kexp_lo;
     const size_t wave_lds = lean_lds_bytes<T>(S->nc, G, S->a_shared);
-    bool lean_ok = lean_applicable(S) && (P.mode & MODE_CACHE_H) && n >= 64;
-    if (P.mode & MODE_FIXED_ITERS) { ndec = 1; kexp_lo = 0; }  // mu frozen at mu0: one decade
+    // (k_lean's lane groups need whole wavefronts of work to pay: below 64 instances k_tail's direct path is as good)
+    const bool lean_ok = S->plan.lean && (P.mode & MODE_CACHE_H) && n >= 64;
     if (lean_ok) {
-      // (indexed by the instance's slot in the set, so that relaunches with shorter lists find their slots again)
+      // decade slots are indexed by the instance's slot in the set (relaunches with shorter lists find them again);
+      // the buffer was sized for the chunk at SolveInit (ensure_hslots)
       const size_t need = (size_t)n_cur * ndec * HSLOT_PAIRS * G * 2 * sizeof(T);
-      if (need > C->hslots_bytes) {
-        if (C->d_hslots) HIPCHK(hipFree(C->d_hslots));
-        C->d_hslots = nullptr; C->hslots_bytes = 0;
-        if (hipMalloc(&C->d_hslots, need + need / 8) == hipSuccess) {
-          C->hslots_bytes = need + need / 8;
-        } else {
-          (void)hipGetLastError();  // not enough memory for the decade slots: the 1-wavefront-per-SIMD kernel needs none
-          C->d_hslots = nullptr;
-          lean_ok = false;
-        }
-      }
+      if (need > C->hslots_bytes) { g_last_error = "internal: decade-slot buffer smaller than the chunk"; return LOIKB_ERR_STATE; }
     }
     if (lean_ok) {
-      const int waves_cu = lean_waves_per_cu(S);
-      const int ltw = waves_cu == 8 ? TAIL_WAVES : 1;  // wavefronts per workgroup
+      const int waves_cu = S->plan.lean_waves_cu;
+      const int ltw = S->plan.lean_wg_waves;  // wavefronts per workgroup
       const size_t lds = ltw * wave_lds;
       if (lds > 64 * 1024) {
         HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -939,8 +1101,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       }
-      int wg_per_cu = waves_cu / ltw;
-      if (const char* e = getenv("LOIKB_LEAN_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
+      const int wg_per_cu = S->tune.lean_wg_per_cu > 0 ? S->tune.lean_wg_per_cu : waves_cu / ltw;
       const int wg_cap = wg_per_cu * std::max(1, (int)(S->ncu * ((double)C->B / (double)S->B) + 0.5));
       // Optional rounds with a bounded share of iterations per instance (LOIKB_LEAN_QUANTA="24,64,160,400"; default: one
       // launch).  Iteration counts are heavy-tailed and unpredictable: in one launch the work queue drains after ~60 % of
@@ -949,14 +1110,10 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       // machine instead of running flat out from an early start.  Measured: Talos headline (1.2 % of the instances run
       // all 1000 iterations) 22.85 -> 21.99 ms, B = 131072 36.9 -> 36.2 ms; floating-base Talos (a handful of long runners)
       // 36.5 -> 44.1 ms.  Not a default.
-      std::vector<int> quanta;
-      if (const char* e = getenv("LOIKB_LEAN_QUANTA")) {
-        quanta.clear();
-        for (const char* p = e; *p;) { quanta.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
-      }
+      std::vector<int> quanta = S->tune.lean_quanta;
       quanta.push_back(S->opt.max_iter + 1);
-      int lean_quantum = 0;  // default: run to completion in arrival order (scheduling study)
-      if (const char* e = getenv("LOIKB_LEAN_SLICE")) lean_quantum = std::max(0, atoi(e));
+      // (default 0: run to completion in arrival order -- DESIGN.md, scheduling study)
+      const int lean_quantum = S->tune.lean_slice;
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
       float t_first = -1.f;
       unsigned int escaped = 0;
@@ -1083,8 +1240,7 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
   // costs the same single-wavefront latency however few lanes are live
   const int compact_min = S->opt.compact_min_instances > 0 ? S->opt.compact_min_instances : 64 * WAVE;
   // k_move costs ~6 KB of traffic per live instance (a fraction of ONE iteration's ~32 KB), so repack eagerly
-  double compact_ratio = 0.85;
-  if (const char* e = getenv("LOIKB_COMPACT_RATIO")) compact_ratio = atof(e);
+  const double compact_ratio = S->tune.compact_ratio;
   // cooperative tail kernel (a lane group per instance) once few instances are left
   const bool use_tail = can_compact && S->nb <= WAVE && S->opt.tail_max_instances >= 0;
   // (thresholds are stated for the whole batch: a chunk applies its share)
@@ -1092,14 +1248,13 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
   // (with the lean tail kernel, whole batches up to 2^20 instances go to it directly: it is as fast as the solve kernel's
   //  bulk phase and has neither ragged tiles nor compaction; without it the hand-over is at 32768 live instances)
   const int tail_max = std::max(1, (int)((S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances
-                                                                         : (lean_applicable(S) ? (1 << 20) : 32768)) * share));
-  const bool trace = getenv("LOIKB_TRACE") != nullptr;
+                                                                         : S->plan.tail_max) * share));
+  const bool trace = S->tune.trace;
   // a team of wavefronts per tile walks independent chains of the tree concurrently: a sweep costs the tree's
   // critical path instead of nb joint visits, and four wavefronts keep four times the loads of a tile in flight.
   // Measured faster than one wavefront per tile at every batch size on a branching robot (Talos: 250 vs 175 M
   // instance-iterations/s in bulk, 30 vs 67 us per iteration for a single tile); pointless on a pure chain.
-  int team_max = 1 << 30;
-  if (const char* e = getenv("LOIKB_TEAM_MAX")) team_max = atoi(e);
+  const int team_max = S->tune.team_max;
   // LDS of a workgroup: edge slots of the leaf->root sweeps (aliased by the team's scalar exchange) + v slots
   auto edge_entries = [](const loikb_solver_impl::TeamSched& sc) {
     return std::max(std::max(sc.nslots, 1) * EDGE_ENT, sc.nw > 1 ? sc.nw * Norms<T>::NALL : 0);
@@ -1129,7 +1284,7 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
   // solve.  (Not when the caller fixed the launch length or asked for the solve kernel's bit-exact behaviour.)
   const bool direct_tail = S->nb <= WAVE && S->opt.tail_max_instances >= 0 && S->opt.max_launch_iters <= 0 &&
                            !(S->opt.flags & (LOIKB_OPT_NO_COMPACTION | LOIKB_OPT_NO_H_CACHE)) && C->B <= tail_max &&
-                           getenv("LOIKB_NO_DIRECT_TAIL") == nullptr;
+                           S->tune.direct_tail;
   if (direct_tail) {
     double tms = 0.0;
     unsigned long long tit = 0;
@@ -1150,8 +1305,7 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
     // (an explicit compact_min_instances is the caller's policy: it is honoured as given)
     const bool latency_bound = S->opt.compact_min_instances <= 0 && tiles_cur * (int)S->chunks.size() <= S->ncu;
     const bool may_compact_later = can_compact && n_cur > compact_min && !latency_bound;
-    int lat_iters = 16;
-    if (const char* e = getenv("LOIKB_LAT_ITERS")) lat_iters = atoi(e);
+    const int lat_iters = S->tune.lat_iters;
     int launch_iters = S->opt.max_launch_iters > 0 ? S->opt.max_launch_iters
                        : (may_compact_later ? 8 : (use_tail || (can_compact && n_cur > compact_min)) ? lat_iters : max_total);
     if (launch_iters > max_total - done_iters) launch_iters = max_total - done_iters;
@@ -1481,6 +1635,7 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
   if (opts->batch < 1) { g_last_error = "batch must be >= 1"; return LOIKB_ERR_ARG; }
   if (opts->num_eq_c < 0) { g_last_error = "num_eq_c must be >= 0"; return LOIKB_ERR_ARG; }
   loikb_solver* S = new loikb_solver();
+  S->tune.read_env();
   int rc = build_schedule(S, model);
   if (rc) { delete S; return rc; }
   S->opt = *opts;
@@ -1506,43 +1661,6 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
   HIPTRY(hipEventCreate(&S->ev_t1));
   HIPTRY(hipEventCreate(&S->ev_fork));
   void* tmp = nullptr;
-  {
-    // chunks: contiguous ranges of tiles, each large enough to fill the machine in its bulk phase
-    const int ntiles = (S->B + WAVE - 1) / WAVE;
-    // Measured on MI355X (Talos-32, B = 65536): 1 chunk 52.9 ms/step, 2 chunks 47.9, 3 chunks 48.2, 4 chunks 74.
-    // Both kernels need a whole SIMD per wavefront (register budget) and both claim whole CUs per workgroup, so
-    // chunks mostly time-share the machine; the gain is the straggler phase of one chunk (down to a few hundred
-    // resident wavefronts for ~10 ms) running beside the bulk phase of the other.  More chunks only queue.
-    // (the lean tail kernel takes whole batches in one launch: one chunk)
-    int nchunks = (ntiles >= 512 && !lean_applicable(S)) ? 2 : 1;
-    if (const char* e = getenv("LOIKB_CHUNKS")) nchunks = atoi(e);
-    if (nchunks < 1) nchunks = 1;
-    if (nchunks > ntiles) nchunks = ntiles;
-    const int per = (ntiles + nchunks - 1) / nchunks;
-    S->chunks.clear();
-    for (int t0 = 0; t0 < ntiles; t0 += per) {
-      Chunk C;
-      C.first_tile = t0;
-      C.B = std::min(S->B - t0 * WAVE, per * WAVE);
-      S->chunks.push_back(C);
-    }
-    for (Chunk& C : S->chunks) {
-      HIPTRY(hipEventCreate(&C.ev_k2));
-      HIPTRY(hipEventCreate(&C.ev_k0));
-      HIPTRY(hipEventCreate(&C.ev_k1));
-      HIPTRY(hipHostMalloc((void**)&C.h_counters, NCOUNTERS * sizeof(unsigned int)));
-      TRY(alloc_dev(S, &tmp, NCOUNTERS * sizeof(unsigned int))); C.d_counters = (unsigned int*)tmp;
-      TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)(C.B + WAVE))); C.d_slots = (int*)tmp;
-      TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)(C.B + WAVE))); C.d_slots2 = (int*)tmp;
-      C.ring_cap = 64;
-      while (C.ring_cap < 2 * (C.B + WAVE)) C.ring_cap <<= 1;
-      TRY(alloc_dev(S, &tmp, sizeof(int) * (size_t)C.ring_cap)); C.d_ring = (int*)tmp;
-      if (S->chunks.size() > 1) {
-        HIPTRY(hipStreamCreateWithFlags(&C.stream, hipStreamNonBlocking));
-        C.own_stream = true;
-      }
-    }
-  }
   TRY(alloc_dev(S, &tmp, sizeof(JointDesc) * S->nj)); S->d_jd = (JointDesc*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * S->nj)); S->d_idx_q = (int*)tmp;
   TRY(alloc_dev(S, &tmp, sizeof(int) * ROWMAP_CAP)); S->d_rowmap = (int*)tmp;
@@ -1583,16 +1701,10 @@ int loikb_destroy(loikb_solver* S)
 {
   if (!S) return LOIKB_OK;
   (void)hipSetDevice(S->device);
+  destroy_chunks(S);  // (first: it takes its buffers out of `allocs`)
   for (void* a : S->allocs) if (a) (void)hipFree(a);
   if (S->d_stage) (void)hipFree(S->d_stage);
-  for (Chunk& C : S->chunks) {
-    if (C.h_counters) (void)hipHostFree(C.h_counters);
-    if (C.d_hslots) (void)hipFree(C.d_hslots);
-    if (C.ev_k0) (void)hipEventDestroy(C.ev_k0);
-    if (C.ev_k2) (void)hipEventDestroy(C.ev_k2);
-    if (C.ev_k1) (void)hipEventDestroy(C.ev_k1);
-    if (C.own_stream && C.stream) (void)hipStreamDestroy(C.stream);
-  }
+  (void)hipGetLastError();  // a failed free must not surface in the next solver's first launch check
   if (S->ev_fork) (void)hipEventDestroy(S->ev_fork);
   if (S->ev_t0) (void)hipEventDestroy(S->ev_t0);
   if (S->ev_t1) (void)hipEventDestroy(S->ev_t1);
@@ -1717,6 +1829,23 @@ int loikb_set_warm_start(loikb_solver* S, int v) { if (!S) return LOIKB_ERR_ARG;
 int loikb_batch(const loikb_solver* S) { return S ? S->B : 0; }
 int loikb_nv(const loikb_solver* S) { return S ? S->nv : 0; }
 int loikb_njoints(const loikb_solver* S) { return S ? S->ext_nj : 0; }
+
+const char* loikb_plan_string(loikb_solver* S)
+{
+  static thread_local std::string out;
+  if (!S) return "";
+  char buf[512];
+  const EnginePlan& pl = S->plan;
+  if (pl.lean)
+    snprintf(buf, sizeof(buf), "k_hslots + k_lean for whole batches up to %d instances (%d wavefronts per CU in workgroups of %d, "
+             "decades mu0*10^%d..%d, time slice %d); k_solve above that; %d chunk(s)", pl.tail_max, pl.lean_waves_cu,
+             pl.lean_wg_waves, pl.kexp_lo, pl.kexp_lo + pl.ndec - 1, S->tune.lean_slice, pl.nchunks);
+  else
+    snprintf(buf, sizeof(buf), "k_solve (team of %d), hand-over to k_tail at %d live instances; %d chunk(s); no k_lean: %s",
+             S->sched[1].nw, pl.tail_max, pl.nchunks, pl.why_not_lean);
+  out = buf;
+  return out.c_str();
+}
 
 int loikb_get_stats(loikb_solver* S, loikb_stats* out)
 {

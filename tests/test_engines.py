@@ -129,3 +129,30 @@ def test_lean_time_slicing_changes_nothing(talos, monkeypatch):
                 assert np.array_equal(a.get(name), b.get(name)), (q, name)
         b.close()
     a.close()
+
+
+def test_engine_plan_is_made_in_one_place(talos, panda7, monkeypatch):
+    """loikb_plan_string: the dispatch (nb, nc, A shared?, children, options) -> engines, re-made at SolveInit when the sharing
+    mode of A is known (round 1 fixed the chunk count at create with the default mode)"""
+    for v in ("LOIKB_LEAN", "LOIKB_CHUNKS", "LOIKB_LEAN_SLICE"):
+        monkeypatch.delenv(v, raising=False)
+    s = loik_amd.BatchedLoik(talos, 40000, **dict(FIXTURE, num_eq_c=2))
+    assert "k_lean" in s.plan() and "1 chunk" in s.plan() and "8 wavefronts per CU" in s.plan()
+    # per-instance A with two constraints: the constraint blocks no longer leave six wavefronts per CU -> other engines, and
+    # their two concurrent chunks
+    link = [talos.getJointId("arm_left_7_joint"), talos.getJointId("arm_right_7_joint")]
+    from helpers import multi_task_batch
+    wl = multi_task_batch(talos, 40000, link, 3, per_instance_A=True)
+    s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    assert "no k_lean" in s.plan() and "2 chunk" in s.plan(), s.plan()
+    s.Solve()
+    st = s.stats()
+    assert st["chunks"] == 2 and st["lean_launches"] == 0
+    s.close()
+    s = loik_amd.BatchedLoik(talos, 64, mu_update_strat=1, **{k: v for k, v in FIXTURE.items() if k != "mu_update_strat"})
+    assert "OSQP" in s.plan()
+    s.close()
+    monkeypatch.setenv("LOIKB_LEAN", "0")
+    s = loik_amd.BatchedLoik(panda7, 64, **FIXTURE)
+    assert "LOIKB_LEAN=0" in s.plan()
+    s.close()
