@@ -138,21 +138,24 @@ def test_engine_plan_is_made_in_one_place(talos, panda7, monkeypatch):
         monkeypatch.delenv(v, raising=False)
     s = loik_amd.BatchedLoik(talos, 40000, **dict(FIXTURE, num_eq_c=2))
     assert "k_lean" in s.plan() and "1 chunk" in s.plan() and "8 wavefronts per CU" in s.plan()
-    # per-instance A with two constraints: the constraint blocks no longer leave six wavefronts per CU -> other engines, and
-    # their two concurrent chunks
+    # per-instance A with two constraints: larger constraint blocks in LDS -> the plan is re-made at SolveInit: seven
+    # single-wavefront workgroups per CU instead of two 4-wavefront ones
     link = [talos.getJointId("arm_left_7_joint"), talos.getJointId("arm_right_7_joint")]
     from helpers import multi_task_batch
     wl = multi_task_batch(talos, 40000, link, 3, per_instance_A=True)
     s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
-    assert "no k_lean" in s.plan() and "2 chunk" in s.plan(), s.plan()
+    assert "7 wavefronts per CU in workgroups of 1" in s.plan(), s.plan()
     s.Solve()
     st = s.stats()
-    assert st["chunks"] == 2 and st["lean_launches"] == 0
+    assert st["chunks"] == 1 and st["lean_launches"] == 1 and st["tail_instances"] == 40000
     s.close()
     s = loik_amd.BatchedLoik(talos, 64, mu_update_strat=1, **{k: v for k, v in FIXTURE.items() if k != "mu_update_strat"})
     assert "OSQP" in s.plan()
     s.close()
     monkeypatch.setenv("LOIKB_LEAN", "0")
     s = loik_amd.BatchedLoik(panda7, 64, **FIXTURE)
-    assert "LOIKB_LEAN=0" in s.plan()
+    assert "LOIKB_LEAN=0" in s.plan() and "1 chunk" in s.plan()
+    s.close()
+    s = loik_amd.BatchedLoik(talos, 40000, **FIXTURE)  # without the lean kernel a large batch is solved as two chunks
+    assert "no k_lean" in s.plan() and "2 chunk" in s.plan(), s.plan()
     s.close()
