@@ -36,7 +36,7 @@ enum {
   LOIKB_ERR_NO_SUCH_CONSTRAINT = -4, /* UpdateEqConstraint on an unknown link       ...hpp:184-186          */
   LOIKB_ERR_DUP_CONSTRAINT = -5,  /* same link listed twice                         ...hpp:197-199          */
   LOIKB_ERR_MU_STRATEGY = -6,     /* MAXEIGENVALUE (and upstream: OSQP) not implemented  loik-loid-optimized.hxx:632-640 */
-  LOIKB_ERR_MODEL = -7,           /* unsupported joint type, inconsistent nq/nv/idx_q/idx_v, or tree not depth-first */
+  LOIKB_ERR_MODEL = -7,           /* unsupported joint type, inconsistent nq/nv/idx_q/idx_v, parents[i] >= i */
   /* runtime */
   LOIKB_ERR_ARG = -20,
   LOIKB_ERR_HIP = -21,            /* a HIP call failed: loikb_last_error() has the text */

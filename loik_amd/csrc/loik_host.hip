@@ -433,16 +433,9 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
       iq += jt_nq(jt); iv += jt_nv(jt);
     }
     if (m->nq != iq || m->nv != iv) { g_last_error = "model: nq/nv do not match the joint types"; return LOIKB_ERR_MODEL; }
-    // depth-first numbering check: descendants of every joint are the contiguous range (i, subtree_end[i]]
-    std::vector<int> subtree_end(enj, 0);
-    for (int i = enj - 1; i >= 0; --i) subtree_end[i] = i;
-    for (int i = enj - 1; i >= 1; --i) {
-      const int p = m->parents[i];
-      if (subtree_end[i] > subtree_end[p]) subtree_end[p] = subtree_end[i];
-    }
-    for (int i = 1; i < enj; ++i)
-      for (int k = i + 1; k <= subtree_end[i]; ++k)
-        if (m->parents[k] < i) { g_last_error = "model: joints are not numbered depth-first"; return LOIKB_ERR_MODEL; }
+    // (any numbering with parents[i] < i is accepted, as upstream: depth-first like pinocchio::urdf::buildModel, breadth-first
+    //  or mixed like a model assembled with addJoint -- the sweep schedules, the level loops and the child lists are built
+    //  from `parents` alone)
   }
   // ---- the device tree.  A multi-DoF joint whose S selects columns of I6 (free-flyer: all six, spherical: the angular
   // three, translation: the linear three) becomes a chain of 1-DoF joints about those axes of ONE frame: the first

@@ -247,3 +247,19 @@ def fetch_end_to_end(s, idx=None, nu=True, residuals=False):
         got["primal_residual"] = sel(s.get("primal_residual"))
         got["dual_residual"] = sel(s.get("dual_residual"))
     return got
+
+
+def renumber_breadth_first(model):
+    """the same tree with its joints numbered level by level (parents[i] < i still holds, subtrees are no longer contiguous):
+    what a model assembled with pinocchio's addJoint in arbitrary order may look like"""
+    nj = model.njoints
+    depth = [0] * nj
+    for i in range(1, nj):
+        depth[i] = depth[int(model.parents[i])] + 1
+    order = sorted(range(nj), key=lambda i: (depth[i], i))      # new index -> old index
+    new_of = {old: new for new, old in enumerate(order)}
+    parents = [new_of[int(model.parents[o])] if o else 0 for o in order]
+    m = loik_amd.Model(parents, model.jtype[order], model.axis[order], model.placement[order],
+                       names=[model.names[o] for o in order], q_lo=None if model.q_lo is None else model.q_lo[[o - 1 for o in order[1:]]],
+                       q_hi=None if model.q_hi is None else model.q_hi[[o - 1 for o in order[1:]]], name=model.name + "_bfs")
+    return m, np.array(order)

@@ -159,3 +159,43 @@ def test_engine_plan_is_made_in_one_place(talos, panda7, monkeypatch):
     s = loik_amd.BatchedLoik(talos, 40000, **FIXTURE)  # without the lean kernel a large batch is solved as two chunks
     assert "no k_lean" in s.plan() and "2 chunk" in s.plan(), s.plan()
     s.close()
+
+
+@pytest.mark.parametrize("engine", ["lean", "tail", "solve"])
+def test_joints_not_numbered_depth_first(talos, engine, monkeypatch):
+    """Pinocchio only guarantees parents[i] < i; a model assembled with addJoint need not be depth-first (round 1 refused
+    such trees).  Talos renumbered level by level and a random tree: every engine against the oracle on the SAME numbering,
+    and the answer is the depth-first model's answer, permuted."""
+    from helpers import renumber_breadth_first
+    for base in (talos, random_tree(9, 28, branch_prob=0.45, all_types=False)):
+        bfs, order = renumber_breadth_first(base)
+        assert not np.array_equal(bfs.parents, base.parents)
+        link_old = base.getJointId("arm_left_7_joint") if base is talos else base.njoints - 1
+        link = int(np.flatnonzero(order == link_old)[0])
+        B = 200
+        wl0 = feasible_batch(base, B, link_old, 61, nu_scale=0.5)
+        # the same problems in the new numbering (1-DoF joints: q / bounds / nu are permuted with the joints)
+        perm = order[1:] - 1
+        wl = dict(wl0, q=wl0["q"][:, perm], c_ids=np.array([link], dtype=np.int32), lb=wl0["lb"][perm], ub=wl0["ub"][perm])
+        args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+        prm = dict(FIXTURE, max_iter=400, tol_abs=1e-6, tol_rel=0.0)
+        out = ref.solve_batch(bfs, *args, nthreads=4, want_nu=True, **prm)
+        out0 = ref.solve_batch(base, wl0["q"], wl0["H_ref"], wl0["v_ref"], wl0["c_ids"], wl0["Ais"], wl0["bis"], wl0["lb"], wl0["ub"],
+                               nthreads=4, **prm)
+        same = out["iters"] == out0["iters"]
+        assert same.mean() > 0.97 and np.abs(out["z"] - out0["z"][:, perm])[same].max() < 1e-9  # (oracle: numbering-invariant)
+        s = _solver(bfs, B, prm, engine, monkeypatch)
+        s.Solve(*args)
+        assert_end_to_end(fetch_end_to_end(s, residuals=True), out, prm, ztol=1e-8, what="bfs numbering, " + engine)
+        for k in (2,):
+            prk = dict(prm, max_iter=k + 1, tol_abs=0.0, tol_primal_inf=0.0)
+            sk = _solver(bfs, B, prk, engine, monkeypatch)
+            sk.Solve(*args)
+            vis, fis, His = sk.get("vis"), sk.get("fis"), sk.His_full()
+            for b in range(0, B, 41):
+                r = ref.RefSolver(bfs, **prk)
+                r.Solve(*problem_args(wl, b))
+                assert_close(vis[b], r.vis[1:], 1e-9, "vis"); assert_close(fis[b], r.fis[1:], 1e-9, "fis")
+                assert_close(His[b], r.His[1:], 1e-9, "His")
+            sk.close()
+        s.close()
