@@ -139,6 +139,21 @@ int loikb_integrate(loikb_solver *s, double dt);
  * this is the explicit bracket a timing harness (bench.py) or a caller with its own streams puts around them */
 int loikb_synchronize(loikb_solver *s);
 
+/* The PASS-LEVEL public methods of the reference (loik-loid-optimized.hpp:192-264), which its own component-wise test calls
+ * one by one while reading the data object in between (tests/loik-loid.cpp:305-556).  The production kernels fuse the passes
+ * and never hold the state in between, so these run on a separate, plain implementation (loik_amd/csrc/loik_passes.hpp: one
+ * instance per thread, the reference's data object restated member by member) -- a debug path, and the second implementation
+ * on the device the fused engines are checked against.  The first loikb_pass after SolveInit / a solve copies the solver's
+ * state; from then until the next SolveInit / Solve call loikb_get serves the members from that copy, in the same layouts
+ * (His, pis, r, Dinv, UDinv are exactly what the last pass left, as upstream).  1-DoF joints, fp64.
+ *   LOIKB_PASS_BEGIN_ITERATION = iter_++, ik_id_data.UpdatePrev(), ik_id_data.ResetInfNorms()   (hpp:381-388)          */
+enum {
+  LOIKB_PASS_BEGIN_ITERATION = 0, LOIKB_PASS_FWD_PASS1, LOIKB_PASS_BWD_PASS, LOIKB_PASS_FWD_PASS2, LOIKB_PASS_BOX_PROJ,
+  LOIKB_PASS_DUAL_UPDATE, LOIKB_PASS_COMPUTE_RESIDUALS, LOIKB_PASS_CHECK_CONVERGENCE, LOIKB_PASS_CHECK_FEASIBILITY,
+  LOIKB_PASS_UPDATE_MU
+};
+int loikb_pass(loikb_solver *s, int pass);
+
 /* setters of IkIdSolverBaseTpl / the solver (task-solver-base.hpp:104-141, loik-loid-optimized.hpp:702-703).
  * Two deliberate differences from upstream, both flagged here because a drop-in must not surprise:
  *  - loikb_set_mu sets the INITIAL penalty mu0 of the following solves.  Upstream's set_mu writes mu_ only

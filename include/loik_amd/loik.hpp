@@ -216,6 +216,21 @@ public:
     solved();
   }
 
+  // ---- pass-level public methods (loik-loid-optimized.hpp:192-264; the reference's component-wise test calls them one by one,
+  // tests/loik-loid.cpp:305-556).  They run on the plain one-instance-per-thread implementation behind loikb_pass (a debug
+  // path; the Solve() overloads use the fused kernels); after each call the data object is refreshed like after a solve.
+  void FwdPass1() { pass(LOIKB_PASS_FWD_PASS1); }
+  void BwdPassOptimizedVisitor() { pass(LOIKB_PASS_BWD_PASS); }
+  void FwdPass2OptimizedVisitor() { pass(LOIKB_PASS_FWD_PASS2); }
+  void BoxProj() { pass(LOIKB_PASS_BOX_PROJ); }
+  void DualUpdate() { pass(LOIKB_PASS_DUAL_UPDATE); }
+  void ComputeResiduals() { pass(LOIKB_PASS_COMPUTE_RESIDUALS); }
+  void CheckConvergence() { pass(LOIKB_PASS_CHECK_CONVERGENCE); }
+  void CheckFeasibility() { pass(LOIKB_PASS_CHECK_FEASIBILITY); }
+  void UpdateMu() { pass(LOIKB_PASS_UPDATE_MU); }
+  // iter_ = i; ik_id_data_.UpdatePrev(); ik_id_data_.ResetInfNorms()  -- the head of a loop iteration (hpp:381-388)
+  void BeginIteration() { pass(LOIKB_PASS_BEGIN_ITERATION); }
+
   // ---- outer loop on the device (not in the reference class: its callers -- a sampling planner, README.md:5 --
   //      integrate on the host and pass a new q to the tailored Solve every step; here q stays resident in HBM)
   // q <- q (+) dt * z, z = the answer of the last solve
@@ -332,6 +347,11 @@ private:
     if (rc == LOIKB_OK) return;
     const char* msg = (rc <= LOIKB_ERR_ARG || rc == LOIKB_ERR_MODEL) ? loikb_last_error() : loikb_status_string(rc);
     throw std::runtime_error(msg && *msg ? msg : loikb_status_string(rc));
+  }
+  void pass(int id)
+  {
+    check(loikb_pass(h_, id));
+    solved();
   }
   void solved()
   {

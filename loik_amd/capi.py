@@ -77,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "loikb_solve_tailored", "loikb_set_max_iter", "loikb_set_rho", "loikb_set_mu", "loikb_set_tol",
     "loikb_set_tol_primal_inf", "loikb_set_tol_tail_solve", "loikb_set_warm_start", "loikb_get", "loikb_get_stats",
     "loikb_batch", "loikb_nv", "loikb_njoints", "loikb_last_error", "loikb_status_string", "loikb_version",
-    "loikb_device_count", "loikb_sweep_schedule", "loikb_integrate", "loikb_synchronize", "loikb_plan_string", "loikb_builtin_model", "loikb_builtin_joint_name",
+    "loikb_device_count", "loikb_sweep_schedule", "loikb_integrate", "loikb_synchronize", "loikb_plan_string", "loikb_pass", "loikb_builtin_model", "loikb_builtin_joint_name",
     "loikb_builtin_joint_id"]
 
 _lib = None
@@ -104,6 +104,7 @@ def lib():
     L.loikb_integrate.argtypes = [C.c_void_p, C.c_double]
     L.loikb_synchronize.argtypes = [C.c_void_p]
     L.loikb_plan_string.argtypes = [C.c_void_p]
+    L.loikb_pass.argtypes = [C.c_void_p, C.c_int]
     L.loikb_plan_string.restype = C.c_char_p
     L.loikb_sweep_schedule.argtypes = [_ip, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip]
     L.loikb_solve_tailored.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
@@ -369,6 +370,19 @@ class BatchedLoik:
             _check(self.L.loikb_solve_tailored(self.h, qp, int(c_id), Ap, bp, flags))
         else:
             raise TypeError("Solve() takes 0, 4 or 8 arguments")
+
+    # pass-level public methods of the reference (loik-loid-optimized.hpp:192-264): the debug path of loik_passes.hpp
+    def _pass(self, k): _check(self.L.loikb_pass(self.h, k))
+    def BeginIteration(self): self._pass(0)   # iter_++, UpdatePrev(), ResetInfNorms() (hpp:381-388)
+    def FwdPass1(self): self._pass(1)
+    def BwdPassOptimizedVisitor(self): self._pass(2)
+    def FwdPass2OptimizedVisitor(self): self._pass(3)
+    def BoxProj(self): self._pass(4)
+    def DualUpdate(self): self._pass(5)
+    def ComputeResiduals(self): self._pass(6)
+    def CheckConvergence(self): self._pass(7)
+    def CheckFeasibility(self): self._pass(8)
+    def UpdateMu(self): self._pass(9)
 
     def plan(self):
         """which kernels this handle's solves use, and why (loikb_plan_string)"""

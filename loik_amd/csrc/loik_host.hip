@@ -15,6 +15,7 @@
 #include "loik_device.hpp"
 #include "loik_tail.hpp"
 #include "loik_lean.hpp"
+#include "loik_passes.hpp"
 
 #include "../../include/loik_amd.h"
 
@@ -193,6 +194,11 @@ struct loikb_solver_impl {
   std::vector<Chunk> chunks;
   hipEvent_t ev_fork = nullptr;
   loikb_stats stats{};
+  // pass-level debug path (loik_passes.hpp): the data object of the reference, field by field, per instance
+  bool pass_active = false;
+  PassLayout PL{};
+  double* d_pass = nullptr;
+  int* d_pass_cslot = nullptr;
 };
 using Chunk = loikb_solver_impl::Chunk;
 
@@ -1459,6 +1465,7 @@ int run_main_loop_t(loikb_solver_impl* S)
 
 int run_main_loop(loikb_solver_impl* S)
 {
+  S->pass_active = false;  // (pass-level calls work on a copy of the state: a solve continues from the solver's own)
   // UpdateMu's throw sites (hxx:632-640)
   if (S->opt.mu_update_strat != LOIKB_MU_DEFAULT && S->opt.mu_update_strat != LOIKB_MU_OSQP &&
       !(S->opt.flags & LOIKB_OPT_FIXED_ITERS)) {
@@ -1697,6 +1704,8 @@ int loikb_destroy(loikb_solver* S)
   destroy_chunks(S);  // (first: it takes its buffers out of `allocs`)
   for (void* a : S->allocs) if (a) (void)hipFree(a);
   if (S->d_stage) (void)hipFree(S->d_stage);
+  if (S->d_pass) (void)hipFree(S->d_pass);
+  if (S->d_pass_cslot) (void)hipFree(S->d_pass_cslot);
   (void)hipGetLastError();  // a failed free must not surface in the next solver's first launch check
   if (S->ev_fork) (void)hipEventDestroy(S->ev_fork);
   if (S->ev_t0) (void)hipEventDestroy(S->ev_t0);
@@ -1720,6 +1729,7 @@ int loikb_solve_init(loikb_solver* S, const double* q, const double* H_ref, cons
   HIPCHK(hipSetDevice(S->device));
   int rc;
   if ((rc = ensure_layout(S, in_flags & LOIKB_A_SHARED))) return rc;
+  S->pass_active = false;
   // problem_.Reset(); ik_id_data_.Reset(warm_start); ResetSolver()  (hpp:345-352)
   if ((rc = reset_home(S, RS_SOLVER | (S->opt.warm_start ? 0 : RS_DATA_COLD)))) return rc;
   if ((rc = set_problem(S, H_ref, v_ref, c_ids, nc, Ais, bis, lb, ub, nbound, in_flags))) return rc;
@@ -1800,6 +1810,139 @@ int loikb_synchronize(loikb_solver* S)
   return LOIKB_OK;
 }
 
+// ---- pass-level public methods of the reference (loik-loid-optimized.hpp:192-264) as a debug path, loik_passes.hpp
+static PassParams pass_params(const loikb_solver_impl* S)
+{
+  PassParams P{};
+  for (int k = 0; k < 36; ++k) P.Href[k] = S->Href[k];
+  for (int k = 0; k < 6; ++k) P.Hv[k] = S->Hv[k];
+  P.Hv_inf_norm = S->Hv_inf_norm;
+  P.rho = S->opt.rho; P.mu0 = S->opt.mu; P.mu_scale = S->opt.mu_equality_scale_factor;
+  P.tol_abs = S->opt.tol_abs; P.tol_rel = S->opt.tol_rel; P.tol_primal_inf = S->opt.tol_primal_inf;
+  P.tol_tail_solve = S->opt.tol_tail_solve;
+  P.max_iter = S->opt.max_iter;
+  P.mu_osqp = S->opt.mu_update_strat == LOIKB_MU_OSQP;
+  P.a_shared = S->a_shared; P.bnd_shared = S->bnd_shared;
+  return P;
+}
+
+int loikb_pass(loikb_solver* S, int pass)
+{
+  if (!S || pass < PASS_BEGIN_ITERATION || pass > PASS_UPDATE_MU) return LOIKB_ERR_ARG;
+  if (!S->have_problem) { g_last_error = "pass-level call before SolveInit()"; return LOIKB_ERR_STATE; }
+  if (S->f32 || S->nb != S->ext_nj - 1) {
+    g_last_error = "the pass-level debug path covers fp64 solvers of models with 1-DoF joints";
+    return LOIKB_ERR_MODEL;
+  }
+  HIPCHK(hipSetDevice(S->device));
+  const PassParams P = pass_params(S);
+  if (!S->pass_active) {
+    const PassLayout PL = make_pass_layout(S->nj, S->nv, S->nc, S->B);
+    if (!S->d_pass || PL.stride != S->PL.stride) {
+      if (S->d_pass) HIPCHK(hipFree(S->d_pass));
+      S->d_pass = nullptr;
+      HIPCHK(hipMalloc((void**)&S->d_pass, sizeof(double) * (size_t)PL.stride * S->B));
+      if (!S->d_pass_cslot) HIPCHK(hipMalloc((void**)&S->d_pass_cslot, sizeof(int) * S->nj));
+    }
+    S->PL = PL;
+    std::vector<int> cs(S->nj, -1);
+    for (int i = 1; i < S->nj; ++i) cs[i] = S->jd[i].cslot;
+    HIPCHK(hipMemcpyAsync(S->d_pass_cslot, cs.data(), sizeof(int) * S->nj, hipMemcpyHostToDevice, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
+    hipLaunchKernelGGL(k_pass_load<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, (const JointDesc*)S->d_jd,
+                       (const double*)S->d_uni, S->PL, P, S->d_pass);
+    HIPCHK(hipGetLastError());
+    S->pass_active = true;
+  }
+  hipLaunchKernelGGL(k_pass, grid1(S->B, 64), dim3(64), 0, S->stream, pass, S->PL, P, (const JointDesc*)S->d_jd,
+                     (const int*)S->d_pass_cslot, S->d_pass);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(S->stream));
+  return LOIKB_OK;
+}
+
+// loikb_get while the pass-level state is active: the members of the data object the passes maintain
+static int pass_get(loikb_solver_impl* S, int field, void* out, bool to_dev)
+{
+  const PassLayout& L = S->PL;
+  const int nb = S->nb;
+  int off = -1, n = 0, skip = 0, scal = -1;
+  bool is_int = false;
+  switch (field) {
+  case LOIKB_F_Z: off = L.z; n = S->nv; break;
+  case LOIKB_F_NU: off = L.nu; n = S->nv; break;
+  case LOIKB_F_W: off = L.w; n = S->nv; break;
+  case LOIKB_F_STF_PLUS_W: off = L.Stf; n = S->nv; break;
+  case LOIKB_F_R: off = L.r; n = S->nv; break;
+  case LOIKB_F_DINV: off = L.Dinv; n = nb; skip = 1; break;
+  case LOIKB_F_VIS: off = L.vis; n = 6 * nb; skip = 6; break;
+  case LOIKB_F_FIS: off = L.fis; n = 6 * nb; skip = 6; break;
+  case LOIKB_F_G: off = L.g; n = 6 * nb; skip = 6; break;
+  case LOIKB_F_PIS: off = L.pis; n = 6 * nb; skip = 6; break;
+  case LOIKB_F_UDINV: off = L.UDinv; n = 6 * nb; skip = 6; break;
+  case LOIKB_F_LIMI: off = L.liMi; n = 12 * nb; skip = 12; break;
+  case LOIKB_F_YIS: off = L.yis; n = 6 * S->nc; break;
+  case LOIKB_F_ATY: off = L.Aty; n = 6 * S->nc; break;
+  case LOIKB_F_HIS: n = 21 * nb; break;
+  case LOIKB_F_ITER: scal = PS_ITER; is_int = true; break;
+  case LOIKB_F_CONVERGED: scal = PS_CONVERGED; is_int = true; break;
+  case LOIKB_F_PRIMAL_INFEASIBLE: scal = PS_PRIMAL_INF; is_int = true; break;
+  case LOIKB_F_PRIMAL_RESIDUAL: scal = PS_PRIMAL; break;
+  case LOIKB_F_DUAL_RESIDUAL: scal = PS_DUAL; break;
+  case LOIKB_F_PRIMAL_RESIDUAL_TASK: scal = PS_PR_TASK; break;
+  case LOIKB_F_PRIMAL_RESIDUAL_SLACK: scal = PS_PR_SLACK; break;
+  case LOIKB_F_DUAL_RESIDUAL_V: scal = PS_DUAL_V; break;
+  case LOIKB_F_DUAL_RESIDUAL_NU: scal = PS_DUAL_NU; break;
+  case LOIKB_F_TOL_PRIMAL: scal = PS_TOL_P; break;
+  case LOIKB_F_TOL_DUAL: scal = PS_TOL_D; break;
+  case LOIKB_F_MU: scal = PS_MU; break;
+  case LOIKB_F_MU_EQ: scal = PS_MU_EQ; break;
+  case LOIKB_F_MU_INEQ: scal = PS_MU_IN; break;
+  case LOIKB_F_DELTA_X_QP_INF_NORM: scal = PS_DX; break;
+  case LOIKB_F_DELTA_Z_QP_INF_NORM: scal = PS_DZ_INF; break;
+  case LOIKB_F_DELTA_Y_QP_INF_NORM: scal = PS_DYQP; break;
+  case LOIKB_F_A_QP_T_DELTA_Y_QP_INF_NORM: scal = PS_ATDY; break;
+  case LOIKB_F_UB_QP_T_DELTA_Y_QP_PLUS: scal = PS_UBP; break;
+  case LOIKB_F_LB_QP_T_DELTA_Y_QP_MINUS: scal = PS_LBM; break;
+  case LOIKB_F_DELTA_FIS_INF_NORM: scal = PS_DFIS_INF; break;
+  case LOIKB_F_DELTA_YIS_INF_NORM: scal = PS_DYIS_INF; break;
+  case LOIKB_F_DELTA_W_INF_NORM: scal = PS_DW_INF; break;
+  case LOIKB_F_DELTA_VIS_INF_NORM: scal = PS_DVIS_INF; break;
+  case LOIKB_F_DELTA_NU_INF_NORM: scal = PS_DNU_INF; break;
+  case LOIKB_F_AV_INF_NORM: scal = PS_AV_INF; break;
+  case LOIKB_F_NU_INF_NORM: scal = PS_NU_INF; break;
+  case LOIKB_F_HREF_V_INF_NORM: scal = PS_HREFV_INF; break;
+  case LOIKB_F_G_INF_NORM: scal = PS_G_INF; break;
+  case LOIKB_F_STF_PLUS_W_INF_NORM: scal = PS_STF_INF; break;
+  case LOIKB_F_PRIMAL_INFEASIBILITY_COND_1: scal = PS_C1; break;
+  case LOIKB_F_PRIMAL_INFEASIBILITY_COND_2: scal = PS_C2; break;
+  default:
+    g_last_error = "this field is not part of the pass-level state";
+    return LOIKB_ERR_ARG;
+  }
+  if (scal >= 0) { off = L.scal + scal; n = 1; }
+  const size_t bytes = sizeof(double) * (size_t)S->B * n;
+  int rc;
+  if ((rc = ensure_stage(S, bytes))) return rc;
+  double* dst = (to_dev && !is_int) ? (double*)out : (double*)S->d_stage;
+  if (field == LOIKB_F_HIS) hipLaunchKernelGGL(k_pass_get_his, grid1(S->B), dim3(256), 0, S->stream, S->PL, (const double*)S->d_pass, dst);
+  else hipLaunchKernelGGL(k_pass_get, grid1(S->B), dim3(256), 0, S->stream, S->PL, (const double*)S->d_pass, off, n, skip, dst);
+  HIPCHK(hipGetLastError());
+  if (is_int) {
+    std::vector<double> tmp((size_t)S->B);
+    HIPCHK(hipMemcpyAsync(tmp.data(), dst, bytes, hipMemcpyDeviceToHost, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
+    std::vector<int> iv((size_t)S->B);
+    for (int b = 0; b < S->B; ++b) iv[b] = (int)tmp[b];
+    if (to_dev) HIPCHK(hipMemcpy(out, iv.data(), sizeof(int) * S->B, hipMemcpyHostToDevice));
+    else memcpy(out, iv.data(), sizeof(int) * S->B);
+    return LOIKB_OK;
+  }
+  if (!to_dev) HIPCHK(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  return LOIKB_OK;
+}
+
 int loikb_set_max_iter(loikb_solver* S, int v) { if (!S) return LOIKB_ERR_ARG; S->opt.max_iter = v; return LOIKB_OK; }
 int loikb_set_rho(loikb_solver* S, double v)
 {
@@ -1852,6 +1995,7 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   if (!S || !out) return LOIKB_ERR_ARG;
   HIPCHK(hipSetDevice(S->device));
   const bool to_dev = out_flags & LOIKB_OUT_DEVICE;
+  if (S->pass_active && field != LOIKB_F_Q) return pass_get(S, field, out, to_dev);
   if (field == LOIKB_F_Q) {
     if (!S->have_q) { g_last_error = "no configurations resident on the device yet"; return LOIKB_ERR_STATE; }
     HIPCHK(hipMemcpyAsync(out, S->d_q, sizeof(double) * (size_t)S->B * S->nq,

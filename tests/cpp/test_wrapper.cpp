@@ -196,6 +196,45 @@ int main()
       for (int k = 0; k < f.robot_model.nq; ++k) q[k] += dt * dh.z[k];
     }
   }
+  {  // test_1st_order_loik_optimized_correctness_component_wise (tests/loik-loid.cpp:305-556): the passes one by one
+    Fixture f; f.max_iter = 200; f.set_bound(1.0);
+    IkIdDataOptimized d(f.robot_model, f.num_eq_c);
+    MAKE_SOLVER(solver, d, f);
+    Oracle o(f);
+    int id = (int)f.active_task_constraint_ids[0];
+    ref_solve_init(o.s, f.q.data(), f.H_ref.data(), f.v_ref.data(), &id, 1, f.Ais[0].data(), f.bis[0].data(), f.lb.data(),
+                   f.ub.data(), (int)f.lb.size());
+    solver.SolveInit(f.q, f.H_ref, f.v_ref, f.active_task_constraint_ids, f.Ais, f.bis, f.lb, f.ub);
+    const int nv = f.robot_model.nv, nb = f.robot_model.njoints - 1;
+    solver.FwdPass1(); ref_fwd_pass1(o.s);
+    for (int i = 1; i <= nb; ++i) CHECK(close(d.His_full(i).data(), o.field(REF_F_HIS) + 36 * i, 36, 1e-10));
+    CHECK(close(d.pis.data(), o.field(REF_F_PIS) + 6, 6 * nb, 1e-10));
+    solver.BwdPassOptimizedVisitor(); ref_bwd_pass(o.s);
+    for (int i = 1; i <= nb; ++i) CHECK(close(d.His_full(i).data(), o.field(REF_F_HIS) + 36 * i, 36, 1e-10));
+    CHECK(close(d.pis.data(), o.field(REF_F_PIS) + 6, 6 * nb, 1e-10));
+    solver.FwdPass2OptimizedVisitor(); ref_fwd_pass2(o.s);
+    CHECK(close(d.nu.data(), o.field(REF_F_NU), nv, 1e-10));
+    CHECK(close(d.vis.data(), o.field(REF_F_VIS) + 6, 6 * nb, 1e-10));
+    CHECK(close(d.fis.data(), o.field(REF_F_FIS) + 6, 6 * nb, 1e-10));
+    solver.BoxProj(); ref_box_proj(o.s);
+    CHECK(close(d.nu.data(), o.field(REF_F_NU), nv, 1e-10)); CHECK(close(d.w.data(), o.field(REF_F_W), nv, 1e-10));
+    CHECK(close(d.z.data(), o.field(REF_F_Z), nv, 1e-10));
+    solver.DualUpdate(); ref_dual_update(o.s);
+    CHECK(close(d.w.data(), o.field(REF_F_W), nv, 1e-10)); CHECK(close(d.yis.data(), o.field(REF_F_YIS), 6, 1e-10));
+    solver.ComputeResiduals(); ref_compute_residuals(o.s);
+    CHECK(close(solver.get_primal_residual(), ref_scalar(o.s, REF_S_PRIMAL_RESIDUAL), 1e-10));
+    CHECK(close(solver.get_dual_residual(), ref_scalar(o.s, REF_S_DUAL_RESIDUAL), 1e-10));
+    solver.CheckConvergence(); ref_check_convergence(o.s);
+    CHECK(close(solver.get_tol_primal(), ref_scalar(o.s, REF_S_TOL_PRIMAL), 1e-12));
+    CHECK(close(solver.get_tol_dual(), ref_scalar(o.s, REF_S_TOL_DUAL), 1e-12));
+    CHECK(solver.get_convergence_status() == (ref_scalar(o.s, REF_S_CONVERGED) != 0));
+    solver.CheckFeasibility(); ref_check_feasibility(o.s);
+    CHECK(close(solver.get_delta_y_qp_inf_norm(), ref_scalar(o.s, REF_S_DELTA_Y_QP_INF_NORM), 1e-10));
+    CHECK(close(solver.get_A_qp_T_delta_y_qp_inf_norm(), ref_scalar(o.s, REF_S_A_QP_T_DELTA_Y_QP_INF_NORM), 1e-10));
+    CHECK(solver.get_primal_infeasibility_status() == (ref_scalar(o.s, REF_S_PRIMAL_INFEASIBLE) != 0));
+    solver.UpdateMu(); ref_update_mu(o.s);
+    CHECK(close(solver.get_mu(), ref_scalar(o.s, REF_S_MU), 1e-14));
+  }
   {  // results left on the device (set_fetch), fetched on demand; O(1) getters; tolerance setters of the base class
     Fixture f; f.max_iter = 100; f.set_bound(2.0);
     IkIdDataOptimized d(f.robot_model, f.num_eq_c), dref(f.robot_model, f.num_eq_c);

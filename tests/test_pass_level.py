@@ -1,0 +1,125 @@
+"""The reference's pass-level public methods (loik-loid-optimized.hpp:192-264) through the C-ABI (loikb_pass, the plain
+one-instance-per-thread implementation of loik_amd/csrc/loik_passes.hpp):
+  * the reference's own component-wise test sequence (tests/loik-loid.cpp:305-556) replayed pass by pass against the oracle;
+  * N iterations COMPOSED of passes == Solve() of every fused engine (lean / tail / solve) -- two implementations on one GPU
+    checked against each other, the way the reference checks its optimized solver against its plain one."""
+import numpy as np
+import pytest
+
+import loik_amd
+from helpers import FIXTURE, assert_close, feasible_batch, fixture_problem, problem_args, random_tree
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+
+VEC = ["nu", "z", "w", "vis", "fis", "pis", "yis", "Aty", "r", "Dinv", "UDinv", "Stf_plus_w", "g"]
+
+
+def _cmp(s, r, b, names, tol=1e-10, what=""):
+    for n in names:
+        got = s.get(n)[b]
+        want = r.field("r" if n == "r" else n)
+        if n in ("vis", "fis", "pis", "UDinv", "Dinv", "g"):
+            want = want[1:]
+        assert_close(got, want, tol, "%s after %s" % (n, what))
+
+
+def test_component_wise_sequence_of_the_reference(talos):
+    """tests/loik-loid.cpp:305-556: SolveInit, then every pass once, the data object compared after each"""
+    for bound in (1.0, 4.0):
+        p = fixture_problem(talos, bound=bound)
+        prm = dict(FIXTURE, max_iter=200)
+        B = 3
+        wl = dict(p, q=np.tile(p["q"], (B, 1)), bis=np.tile(p["bis"], (B, 1, 1)))
+        s = loik_amd.BatchedLoik(talos, B, **prm)
+        s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+        r = ref.RefSolver(talos, **prm)
+        r.SolveInit(*problem_args(p))
+        s.FwdPass1(); r.FwdPass1()
+        assert_close(s.His_full()[1], r.His[1:], 1e-10, "His after FwdPass1")
+        _cmp(s, r, 1, ["pis", "r"], what="FwdPass1")
+        s.BwdPassOptimizedVisitor(); r.BwdPass()
+        assert_close(s.His_full()[2], r.His[1:], 1e-10, "His after BwdPass")
+        _cmp(s, r, 2, ["pis", "r", "Dinv", "UDinv"], what="BwdPass")
+        s.FwdPass2OptimizedVisitor(); r.FwdPass2()
+        _cmp(s, r, 0, ["nu", "vis", "fis"], what="FwdPass2")
+        s.BoxProj(); r.BoxProj()
+        _cmp(s, r, 0, ["nu", "w", "z"], what="BoxProj")     # (w is still the OLD multiplier here, as upstream)
+        s.DualUpdate(); r.DualUpdate()
+        _cmp(s, r, 1, ["w", "yis", "Aty"], what="DualUpdate")
+        s.ComputeResiduals(); r.ComputeResiduals()
+        for n in ("primal_residual", "dual_residual", "primal_residual_task", "primal_residual_slack", "dual_residual_v",
+                  "dual_residual_nu", "g_inf_norm", "Stf_plus_w_inf_norm"):
+            assert_close(s.get(n)[2], r.scalar(n), 1e-10, n)
+        _cmp(s, r, 2, ["g", "Stf_plus_w"], what="ComputeResiduals")
+        s.CheckConvergence(); r.CheckConvergence()
+        assert_close(s.get("tol_primal")[0], r.scalar("tol_primal"), 1e-12, "tol_primal")
+        assert_close(s.get("tol_dual")[0], r.scalar("tol_dual"), 1e-12, "tol_dual")
+        assert bool(s.get("converged")[0]) == r.get_convergence_status()
+        s.CheckFeasibility(); r.CheckFeasibility()
+        for n in ("delta_y_qp_inf_norm", "A_qp_T_delta_y_qp_inf_norm", "ub_qp_T_delta_y_qp_plus", "lb_qp_T_delta_y_qp_minus",
+                  "delta_x_qp_inf_norm"):
+            assert_close(s.get(n)[1], r.scalar(n), 1e-10, n)
+        assert bool(s.get("primal_infeasible")[1]) == r.get_primal_infeasibility_status()
+        s.UpdateMu(); r.UpdateMu()
+        assert_close(s.get("mu")[0], r.scalar("mu"), 1e-14, "mu")
+        s.close()
+
+
+@pytest.mark.parametrize("engine_kw", [dict(), dict(tail_max_instances=-1)], ids=["on_chip_engines", "k_solve"])
+@pytest.mark.parametrize("which", ["talos", "tree19"])
+def test_iterations_composed_of_passes_equal_the_fused_engines(which, engine_kw, request):
+    """N iterations built from the ten passes == Solve() with max_iter = N + 1 of the production engines: the plain
+    implementation and the fused kernels agree on every member of the data object (the reference's opt == plain, on the GPU)"""
+    model = request.getfixturevalue("talos") if which == "talos" else random_tree(19, 19)
+    link = model.getJointId("arm_left_7_joint") if which == "talos" else model.njoints - 1
+    B, N = 130, 6
+    wl = feasible_batch(model, B, link, 13, nu_scale=0.5, per_instance_A=(which != "talos"), per_instance_bounds=(which != "talos"))
+    args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    prm = dict(FIXTURE, max_iter=N + 1, tol_abs=0.0, tol_rel=0.0, tol_primal_inf=0.0)
+    fused = loik_amd.BatchedLoik(model, B, **prm, **engine_kw)
+    fused.Solve(*args)
+    plain = loik_amd.BatchedLoik(model, B, **prm)
+    plain.SolveInit(*args)
+    for it in range(1, N + 1):
+        plain.BeginIteration()
+        plain.FwdPass1(); plain.BwdPassOptimizedVisitor(); plain.FwdPass2OptimizedVisitor(); plain.BoxProj(); plain.DualUpdate()
+        plain.ComputeResiduals(); plain.CheckConvergence()
+        if it > 1:
+            plain.CheckFeasibility()
+        if it < N:
+            plain.UpdateMu()   # (the fused engines stop before the last UpdateMu would matter; mu of the last iteration)
+    assert np.all(plain.get("iter") == N) and np.all(fused.get("iter") == N)
+    for n in ["nu", "z", "w", "vis", "fis", "yis", "Aty", "g", "Stf_plus_w", "primal_residual", "dual_residual",
+              "primal_residual_task", "primal_residual_slack", "dual_residual_v", "dual_residual_nu", "delta_vis_inf_norm",
+              "delta_nu_inf_norm", "delta_fis_inf_norm", "Av_inf_norm", "nu_inf_norm", "g_inf_norm", "Stf_plus_w_inf_norm",
+              "delta_y_qp_inf_norm", "A_qp_T_delta_y_qp_inf_norm", "ub_qp_T_delta_y_qp_plus", "lb_qp_T_delta_y_qp_minus"]:
+        assert_close(plain.get(n), fused.get(n), 1e-9, "%s (plain passes vs fused engine)" % n)
+    assert_close(plain.His_full(), fused.His_full(), 1e-9, "His")
+    # and both against the oracle
+    for b in range(0, B, 43):
+        r = ref.RefSolver(model, **prm)
+        r.Solve(*problem_args(wl, b))
+        assert_close(plain.get("z")[b], r.z, 1e-10, "z vs oracle")
+        assert_close(plain.get("fis")[b], r.fis[1:], 1e-9, "fis vs oracle")
+    # a solve after pass-level calls continues from the SOLVER's state, not from the copy the passes worked on
+    plain.Solve()
+    assert_close(plain.get("z"), fused.get("z"), 1e-9, "Solve() after pass-level calls")
+    plain.close(); fused.close()
+
+
+def test_pass_level_errors(talos):
+    s = loik_amd.BatchedLoik(talos, 2, **FIXTURE)
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.FwdPass1()   # before SolveInit
+    assert e.value.code == -24
+    s.close()
+    ff = loik_amd.builtin_model("talos32_freeflyer")
+    s = loik_amd.BatchedLoik(ff, 2, **FIXTURE)
+    p = fixture_problem(ff)
+    q = np.zeros((2, ff.nq)); q[:, 6] = 1.0
+    s.SolveInit(q, p["H_ref"], p["v_ref"], p["c_ids"], p["Ais"], np.tile(p["bis"], (2, 1, 1)), p["lb"], p["ub"])
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.FwdPass1()   # multi-DoF joints: not covered by the debug path
+    assert e.value.code == -7
+    s.close()
