@@ -8,8 +8,10 @@
  * same names and memory order (joint 0 = universe, parents[i] < i, 6-vectors [linear; angular]) so a
  * Pinocchio -> loikb adapter is a field-by-field copy.
  *
- * Joints: all of Pinocchio's 1-DoF types, and the multi-DoF types whose motion subspace is a constant selection of the
- * columns of I6 -- free-flyer (floating base), spherical, translation.  On the device such a
+ * Joints: all of Pinocchio's 1-DoF types (incl. the unbounded revolute joints with q = (cos, sin)), the multi-DoF types
+ * whose motion subspace is a constant selection of the columns of I6 -- free-flyer (floating base), spherical, translation,
+ * planar -- and JointModelSphericalZYX, whose q-dependent subspace is that of a Z-Y-X revolute chain.
+ * Not covered: JointModelComposite and JointModelMimic (one jtype per joint here).  On the device such a
  * joint is a chain of 1-DoF joints with massless links in between; the caller never sees that: q, z / nu / w / lb / ub
  * (length model.nv, Pinocchio's idx_v order) and the per-link results are the caller's model's.
  */
@@ -34,7 +36,13 @@ enum {
   LOIKB_J_PU = 8,
   LOIKB_J_FREEFLYER = 9,   /* nq 7: translation, quaternion (x,y,z,w); nv 6: [linear; angular] in the joint frame */
   LOIKB_J_SPHERICAL = 10,  /* nq 4: quaternion (x,y,z,w);              nv 3: angular velocity in the joint frame  */
-  LOIKB_J_TRANSLATION = 11 /* nq 3, nv 3                                                                          */
+  LOIKB_J_TRANSLATION = 11,/* nq 3, nv 3                                                                          */
+  LOIKB_J_SPHERICAL_ZYX = 12, /* JointModelSphericalZYX: nq 3 (angles about z, y, x: R = Rz Ry Rx), nv 3 = their rates.
+                                 The motion subspace depends on q; on the device it is the chain RZ -> RY -> RX it describes */
+  LOIKB_J_PLANAR = 13,     /* JointModelPlanar: nq 4 (x, y, cos, sin), nv 3 (vx, vy, wz in the joint frame)               */
+  LOIKB_J_RUBX = 14,       /* JointModelRUBX / RUBY / RUBZ (revolute unbounded): nq 2 (cos, sin), nv 1                     */
+  LOIKB_J_RUBY = 15,
+  LOIKB_J_RUBZ = 16
 };
 
 typedef struct loikb_model_desc {

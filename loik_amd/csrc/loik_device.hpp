@@ -89,12 +89,14 @@ enum : int {
                           // reference term, not counted in the norms over the links (see build_schedule)
   JF_NOQ = 8,             // chain joint after the first: its transform is the identity whatever its JP_CS pair holds
   JF_REVOLUTE = 16,       // S = [0; axis], else prismatic S = [axis; 0]
+  JF_CS_DIRECT = 32,      // unbounded revolute joint (JointModelRUBX/Y/Z): its configuration IS (cos, sin)
 };
 
 // rotation generator selector for M(q).  ROT_FREE / ROT_SPH / ROT_TRANS: first joint of the chain of a free-flyer /
 // spherical / translation joint -- M(q) = (R(quat), t) comes from the JP_CS pairs of this and the next chain records:
 //   free-flyer (tx,ty) (tz,qx) (qy,qz) (qw,-) ; spherical (qx,qy) (qz,qw) ; translation (tx,ty) (tz,-)
-enum : int { ROT_X = 0, ROT_Y = 1, ROT_Z = 2, ROT_U = 3, ROT_NONE = 4, ROT_FREE = 5, ROT_SPH = 6, ROT_TRANS = 7 };
+//   planar (x, y) (cos, sin)
+enum : int { ROT_X = 0, ROT_Y = 1, ROT_Z = 2, ROT_U = 3, ROT_NONE = 4, ROT_FREE = 5, ROT_SPH = 6, ROT_TRANS = 7, ROT_PLANAR = 8 };
 
 struct JointDesc {
   double Rp[9];   // jointPlacements[i].rotation(), row-major
@@ -358,6 +360,9 @@ __device__ __forceinline__ void joint_xform(const JointDesc& d, const char* rec,
       quat_to_rot(c1.y, c2.x, c2.y, c3.x, Rq);
     } else if (d.rot == ROT_SPH) {
       quat_to_rot(c, s, c1.x, c1.y, Rq);
+    } else if (d.rot == ROT_PLANAR) {  // JointModelPlanar::calc: M = (Rz(theta), (x, y, 0)), theta given as (cos, sin)
+      tq[0] = c; tq[1] = s;
+      Rq[0] = c1.x; Rq[1] = -c1.y; Rq[3] = c1.y; Rq[4] = c1.x;
     } else {
       tq[0] = c; tq[1] = s; tq[2] = c1.x;
     }
@@ -1038,7 +1043,9 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
         dg[k] = gi[k] - gold[k];
       }
       st6<T>(rec, JP_G, gi);
-      N.dfis = tmax(N.dfis, inf6(df));
+      // (the f of a massless chain link is no member of upstream's fis: between the revolute joints of a SphericalZYX chain it
+      //  is a ROTATED copy of the body's f, with another inf-norm)
+      N.dfis = tmax(N.dfis, (d.flags & JF_MASSLESS) ? T(0) : inf6(df));
       N.dg = tmax(N.dg, inf6(dg));      // hxx:215-220
       N.g_inf = tmax(N.g_inf, inf6(gi));  // hxx:223-225
       // dual residual, v block (hxx:228): Href v_i - Hv + g_i
@@ -1147,7 +1154,7 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
         dg[k] = gi[k] - in.gold[k];
       }
       st6<T>(rec, JP_G, gi);
-      N.dfis = tmax(N.dfis, inf6(df));
+      N.dfis = tmax(N.dfis, (d.flags & JF_MASSLESS) ? T(0) : inf6(df));
       N.dg = tmax(N.dg, inf6(dg));        // hxx:215-220
       N.g_inf = tmax(N.g_inf, inf6(gi));  // hxx:223-225
       // dual residual, v block (hxx:228): Href v_i - Hv + g_i
@@ -1447,6 +1454,15 @@ __global__ void k_fk_init(const double* __restrict__ q, int nq, int q_shared, co
       stp<T>(rec + RB, JP_CS, (T)qs[2], T(0));
       continue;
     }
+    if (rot == ROT_PLANAR) {
+      stp<T>(rec, JP_CS, (T)qs[0], (T)qs[1]);
+      stp<T>(rec + RB, JP_CS, (T)qs[2], (T)qs[3]);
+      continue;
+    }
+    if (jd[i].flags & JF_CS_DIRECT) {  // JointModelRevoluteUnbounded: q = (cos, sin)
+      stp<T>(rec, JP_CS, (T)qs[0], (T)qs[1]);
+      continue;
+    }
     const double qi = qs[0];
     T c, s;
     if (jd[i].flags & JF_REVOLUTE) {
@@ -1543,7 +1559,7 @@ __global__ void k_advance_q(double* __restrict__ q_res, const double* __restrict
     const char* rec = lp + (size_t)(i - 1) * RB;
     double* qs = q_res + (size_t)b * nq + idx_q[i];
     const int rot = jd[i].rot;
-    const int n = rot == ROT_FREE ? 6 : (rot == ROT_SPH || rot == ROT_TRANS) ? 3 : 1;
+    const int n = rot == ROT_FREE ? 6 : (rot == ROT_SPH || rot == ROT_TRANS || rot == ROT_PLANAR) ? 3 : 1;
     double v[6];
     for (int k = 0; k < n; ++k) v[k] = dt * (double)ldp<T>(rec + k * RB, JP_WZ).y;  // z of the chain's joints
     if (rot == ROT_FREE) {
@@ -1554,6 +1570,26 @@ __global__ void k_advance_q(double* __restrict__ q_res, const double* __restrict
       quat_mul_xyzw(qs, qe, qo);
       quat_first_order_normalize(qo);
       for (int k = 0; k < 4; ++k) qs[k] = qo[k];
+    } else if (rot == ROT_PLANAR) {
+      // SpecialEuclideanOperationTpl<2>::integrate: (x, y, cos, sin) * exp(vx, vy, w), first-order re-normalised (cos, sin)
+      const double c0 = qs[2], s0 = qs[3], w = v[2];
+      double sw, cw, tx, ty;
+      sincos(w, &sw, &cw);
+      if (fabs(w) > 1e-14) { tx = (sw * v[0] - (1.0 - cw) * v[1]) / w; ty = ((1.0 - cw) * v[0] + sw * v[1]) / w; }
+      else { tx = v[0]; ty = v[1]; }
+      qs[0] += c0 * tx - s0 * ty;
+      qs[1] += s0 * tx + c0 * ty;
+      double c1 = c0 * cw - s0 * sw, s1 = s0 * cw + c0 * sw;
+      const double nrm = 0.5 * (3.0 - (c1 * c1 + s1 * s1));
+      qs[2] = c1 * nrm; qs[3] = s1 * nrm;
+    } else if (jd[i].flags & JF_CS_DIRECT) {
+      // SpecialOrthogonalOperationTpl<2>::integrate: (cos, sin) rotated by w, first-order re-normalised
+      const double c0 = qs[0], s0 = qs[1];
+      double sw, cw;
+      sincos(v[0], &sw, &cw);
+      double c1 = c0 * cw - s0 * sw, s1 = s0 * cw + c0 * sw;
+      const double nrm = 0.5 * (3.0 - (c1 * c1 + s1 * s1));
+      qs[0] = c1 * nrm; qs[1] = s1 * nrm;
     } else {
       for (int k = 0; k < n; ++k) qs[k] += v[k];
     }

@@ -420,16 +420,23 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
 {
   const int enj = m->njoints;
   if (enj < 2) { g_last_error = "model: no joints"; return LOIKB_ERR_MODEL; }
-  auto jt_nq = [](int jt) { return jt == LOIKB_J_FREEFLYER ? 7 : jt == LOIKB_J_SPHERICAL ? 4 : jt == LOIKB_J_TRANSLATION ? 3 : 1; };
-  auto jt_nv = [](int jt) { return jt == LOIKB_J_FREEFLYER ? 6 : (jt == LOIKB_J_SPHERICAL || jt == LOIKB_J_TRANSLATION) ? 3 : 1; };
+  auto jt_nq = [](int jt) {
+    return jt == LOIKB_J_FREEFLYER ? 7 : (jt == LOIKB_J_SPHERICAL || jt == LOIKB_J_PLANAR) ? 4
+           : (jt == LOIKB_J_TRANSLATION || jt == LOIKB_J_SPHERICAL_ZYX) ? 3 : (jt >= LOIKB_J_RUBX && jt <= LOIKB_J_RUBZ) ? 2 : 1;
+  };
+  auto jt_nv = [](int jt) {
+    return jt == LOIKB_J_FREEFLYER ? 6
+           : (jt == LOIKB_J_SPHERICAL || jt == LOIKB_J_TRANSLATION || jt == LOIKB_J_SPHERICAL_ZYX || jt == LOIKB_J_PLANAR) ? 3 : 1;
+  };
   // ---- the caller's model: Pinocchio numbering (parents[i] < i, idx_q / idx_v cumulative in joint order)
   {
     int iq = 0, iv = 0;
     for (int i = 1; i < enj; ++i) {
       const int p = m->parents[i], jt = m->jtype[i];
       if (p < 0 || p >= i) { g_last_error = "model: parents[i] must be < i"; return LOIKB_ERR_MODEL; }
-      if (jt < LOIKB_J_RX || jt > LOIKB_J_TRANSLATION) {
-        g_last_error = "model: unsupported joint type (1-DoF joints, free-flyer, spherical and translation joints are)";
+      if (jt < LOIKB_J_RX || jt > LOIKB_J_RUBZ) {
+        g_last_error = "model: unsupported joint type (supported: 1-DoF joints incl. unbounded revolute, free-flyer, spherical, "
+                       "spherical ZYX, translation, planar; not: composite, mimic)";
         return LOIKB_ERR_MODEL;
       }
       if (m->idx_q[i] != iq || m->idx_v[i] != iv) {
@@ -467,7 +474,16 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
       JointDesc d{};
       double ax[3] = {0, 0, 0};
       int rot = ROT_NONE, flags = 0, sub = jt;
-      if (n > 1) {
+      if (jt == LOIKB_J_SPHERICAL_ZYX) {
+        // R = Rz(q0) Ry(q1) Rx(q2), nu = the three angle rates: literally a chain of three revolute joints about z, y, x
+        // with their own coordinates (S(q) of JointModelSphericalZYX::calc is this chain's Jacobian) and massless links
+        sub = k == 0 ? LOIKB_J_RZ : k == 1 ? LOIKB_J_RY : LOIKB_J_RX;
+      } else if (jt == LOIKB_J_PLANAR) {
+        sub = k == 0 ? LOIKB_J_PX : k == 1 ? LOIKB_J_PY : LOIKB_J_RZ;  // ConstraintPlanar: vx, vy, wz of ONE frame
+      } else if (jt >= LOIKB_J_RUBX && jt <= LOIKB_J_RUBZ) {
+        sub = LOIKB_J_RX + (jt - LOIKB_J_RUBX);
+        flags |= JF_CS_DIRECT;
+      } else if (n > 1) {
         // chain joint k: prismatic along / revolute about axis (k mod 3) of the joint frame
         const bool angular = jt == LOIKB_J_SPHERICAL || (jt == LOIKB_J_FREEFLYER && k >= 3);
         sub = (angular ? LOIKB_J_RX : LOIKB_J_PX) + k % 3;
@@ -485,8 +501,11 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
       for (int c = 0; c < 9; ++c) d.Rp[c] = (n > 1 && k > 0) ? (c % 4 == 0 ? 1.0 : 0.0) : m->placement[12 * i + c];
       for (int c = 0; c < 3; ++c) d.tp[c] = (n > 1 && k > 0) ? 0.0 : m->placement[12 * i + 9 + c];
       if (n > 1) {
-        if (k == 0) rot = jt == LOIKB_J_FREEFLYER ? ROT_FREE : jt == LOIKB_J_SPHERICAL ? ROT_SPH : ROT_TRANS;
-        else flags |= JF_NOQ;
+        if (jt != LOIKB_J_SPHERICAL_ZYX) {  // (a ZYX chain consists of ordinary revolute joints: each reads its own angle)
+          if (k == 0) rot = jt == LOIKB_J_FREEFLYER ? ROT_FREE : jt == LOIKB_J_SPHERICAL ? ROT_SPH
+                            : jt == LOIKB_J_PLANAR ? ROT_PLANAR : ROT_TRANS;
+          else flags |= JF_NOQ;
+        }
         if (k < n - 1) flags |= JF_MASSLESS;
       }
       for (int c = 0; c < 3; ++c) d.axis[c] = ax[c];
@@ -497,7 +516,7 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
       d.rot = rot;
       S->parents.push_back(d.parent);
       S->jtype.push_back(sub);
-      S->idx_q.push_back(k == 0 ? m->idx_q[i] : 0);
+      S->idx_q.push_back(jt == LOIKB_J_SPHERICAL_ZYX ? m->idx_q[i] + k : (k == 0 ? m->idx_q[i] : 0));
       S->jd.push_back(d);
     }
     S->link_of[i] = (int)S->parents.size() - 1;
@@ -1475,23 +1494,34 @@ int run_main_loop(loikb_solver_impl* S)
   return S->f32 ? run_main_loop_t<float>(S) : run_main_loop_t<double>(S);
 }
 
-// liMi of the caller's joints: sel[e] + 1 = the device joint that carries M(q) of joint e + 1
+// liMi of the caller's joints: sel[e] + 1 = the first device joint of joint e + 1, last[e] + 1 = the last one.  One device
+// joint carries the whole M(q) for 1-DoF joints and for the chains about ONE frame (free-flyer, spherical, translation,
+// planar: the other chain joints are the identity); a SphericalZYX joint is the product of its three revolute joints.
 template <typename T>
-__global__ void k_limi(char* tiles, Layout L, const JointDesc* __restrict__ jd, const int* __restrict__ sel, int nsel,
-                       int B, double* __restrict__ out)
+__global__ void k_limi(char* tiles, Layout L, const JointDesc* __restrict__ jd, const int* __restrict__ sel,
+                       const int* __restrict__ last, int nsel, int B, double* __restrict__ out)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   char* lp = lane_ptr<T>(tiles, L, b);
   for (int e = 0; e < nsel; ++e) {
-    const int i = sel[e] + 1;
-    T R[9], t[3];
-    const char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
-    const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS);
-    joint_xform<T>(jd[i], rec, cs.x, cs.y, R, t);
+    double Ra[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, ta[3] = {0, 0, 0};
+    for (int i = sel[e] + 1; i <= last[e] + 1; ++i) {
+      T R[9], t[3];
+      const char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
+      const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS);
+      joint_xform<T>(jd[i], rec, cs.x, cs.y, R, t);
+      double Rn[9], tn[3];
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) Rn[3 * r + c] = Ra[3 * r] * (double)R[c] + Ra[3 * r + 1] * (double)R[3 + c] + Ra[3 * r + 2] * (double)R[6 + c];
+        tn[r] = ta[r] + Ra[3 * r] * (double)t[0] + Ra[3 * r + 1] * (double)t[1] + Ra[3 * r + 2] * (double)t[2];
+      }
+      for (int k = 0; k < 9; ++k) Ra[k] = Rn[k];
+      for (int k = 0; k < 3; ++k) ta[k] = tn[k];
+    }
     double* o = out + ((size_t)b * nsel + e) * 12;
-    for (int k = 0; k < 9; ++k) o[k] = (double)R[k];
-    for (int k = 0; k < 3; ++k) o[9 + k] = (double)t[k];
+    for (int k = 0; k < 9; ++k) o[k] = Ra[k];
+    for (int k = 0; k < 3; ++k) o[9 + k] = ta[k];
   }
 }
 
@@ -2106,8 +2136,8 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
     if (S->f32) hipLaunchKernelGGL(k_residual_vecs<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, (const float*)S->d_uni, rcst, (int)S->a_shared, S->d_link_sel, nl, S->B, dual, dst);
     else hipLaunchKernelGGL(k_residual_vecs<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, (const double*)S->d_uni, rcst, (int)S->a_shared, S->d_link_sel, nl, S->B, dual, dst);
   } else if (field == LOIKB_F_LIMI) {
-    if (S->f32) hipLaunchKernelGGL(k_limi<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->d_first_sel, nl, S->B, dst);
-    else hipLaunchKernelGGL(k_limi<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->d_first_sel, nl, S->B, dst);
+    if (S->f32) hipLaunchKernelGGL(k_limi<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->d_first_sel, S->d_link_sel, nl, S->B, dst);
+    else hipLaunchKernelGGL(k_limi<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->d_first_sel, S->d_link_sel, nl, S->B, dst);
   } else {
     if ((rc = set_rowmap(S, rm))) return rc;
     if (S->f32)

@@ -592,7 +592,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         df[k] = fi[k] - f[k];
         dv6[k] = vi[k] - v[k];
       }
-      l_dfis = inf6(df);
+      l_dfis = mass * inf6(df);  // (a massless chain link is not a body of the model: no f_i of its own upstream)
       href_mul<T, HDIAG>(P.Href, vi, hrv);
       l_hrefv = mass * inf6(hrv);
       l_dvis = mass * inf6(dv6);

@@ -10,6 +10,7 @@ import numpy as np
 
 J_RX, J_RY, J_RZ, J_PX, J_PY, J_PZ, J_RU, J_PU = 1, 2, 3, 4, 5, 6, 7, 8
 J_FREEFLYER, J_SPHERICAL, J_TRANSLATION = 9, 10, 11
+J_SPHERICAL_ZYX, J_PLANAR, J_RUBX, J_RUBY, J_RUBZ = 12, 13, 14, 15, 16
 
 # the reference fixture's solver parameters, /root/reference/tests/loik-loid.cpp:91-105
 FIXTURE_PARAMS = dict(tol_primal_inf=1e-2, tol_dual_inf=1e-2, tol_tail_solve=1e-1, rho=1e-5, mu=1e-2,
@@ -56,6 +57,35 @@ def link_velocity(model, q, nu, link):
         Rp, tp = P[:9].reshape(3, 3), P[9:]
         iq, iv = int(model.idx_q[i]), int(model.idx_v[i])
         qi, nui = q[:, iq], nu[:, iv]
+        if jt in (J_SPHERICAL_ZYX, J_PLANAR):
+            # JointModelSphericalZYX::calc / JointModelPlanar::calc: M(q) and the motion subspace S (q-dependent for ZYX)
+            if jt == J_SPHERICAL_ZYX:
+                c0, s0 = np.cos(q[:, iq]), np.sin(q[:, iq]); c1, s1 = np.cos(q[:, iq + 1]), np.sin(q[:, iq + 1])
+                c2, s2 = np.cos(q[:, iq + 2]), np.sin(q[:, iq + 2])
+                Rj = np.empty((B, 3, 3))
+                Rj[:, 0, 0] = c0 * c1; Rj[:, 0, 1] = c0 * s1 * s2 - s0 * c2; Rj[:, 0, 2] = c0 * s1 * c2 + s0 * s2
+                Rj[:, 1, 0] = s0 * c1; Rj[:, 1, 1] = s0 * s1 * s2 + c0 * c2; Rj[:, 1, 2] = s0 * s1 * c2 - c0 * s2
+                Rj[:, 2, 0] = -s1; Rj[:, 2, 1] = c1 * s2; Rj[:, 2, 2] = c1 * c2
+                tj = np.zeros((B, 3))
+                Sa = np.zeros((B, 3, 3))  # angular subspace, columns
+                Sa[:, 0, 0] = -s1; Sa[:, 1, 0] = c1 * s2; Sa[:, 2, 0] = c1 * c2
+                Sa[:, 1, 1] = c2; Sa[:, 2, 1] = -s2
+                Sa[:, 0, 2] = 1.0
+                dv = np.concatenate([np.zeros((B, 3)), np.einsum("bij,bj->bi", Sa, nu[:, iv:iv + 3])], axis=1)
+            else:
+                c, s_ = q[:, iq + 2], q[:, iq + 3]
+                Rj = np.zeros((B, 3, 3)); Rj[:, 0, 0] = c; Rj[:, 0, 1] = -s_; Rj[:, 1, 0] = s_; Rj[:, 1, 1] = c; Rj[:, 2, 2] = 1.0
+                tj = np.concatenate([q[:, iq:iq + 2], np.zeros((B, 1))], axis=1)
+                dv = np.zeros((B, 6)); dv[:, 0] = nu[:, iv]; dv[:, 1] = nu[:, iv + 1]; dv[:, 5] = nu[:, iv + 2]
+            R = Rp[None] @ Rj
+            t = tp[None] + tj @ Rp.T
+            lin, ang = v[:, :3], v[:, 3:]
+            d = lin - np.cross(t, ang)
+            v = np.concatenate([np.einsum("bji,bj->bi", R, d), np.einsum("bji,bj->bi", R, ang)], axis=1) + dv
+            continue
+        if jt in (J_RUBX, J_RUBY, J_RUBZ):  # JointModelRevoluteUnbounded: q = (cos, sin)
+            qi = np.arctan2(q[:, iq + 1], q[:, iq])
+            jt = J_RX + (jt - J_RUBX)
         if jt in (J_FREEFLYER, J_SPHERICAL, J_TRANSLATION):
             # M(q) = (R(quat), t) ; S = I6 | [0; I3] | [I3; 0]: the joint velocity is added in the child frame
             Rj = quat_rot(q[:, iq + 3:iq + 7]) if jt == J_FREEFLYER else (

@@ -195,6 +195,9 @@ static int joint_nq(int jtype)
   case REF_J_FREEFLYER: return 7;
   case REF_J_SPHERICAL: return 4;
   case REF_J_TRANSLATION: return 3;
+  case REF_J_SPHERICAL_ZYX: return 3;
+  case REF_J_PLANAR: return 4;
+  case REF_J_RUBX: case REF_J_RUBY: case REF_J_RUBZ: return 2;
   default: return 1;
   }
 }
@@ -205,6 +208,8 @@ static int joint_nv(int jtype)
   case REF_J_FREEFLYER: return 6;
   case REF_J_SPHERICAL: return 3;
   case REF_J_TRANSLATION: return 3;
+  case REF_J_SPHERICAL_ZYX: return 3;
+  case REF_J_PLANAR: return 3;
   default: return 1;
   }
 }
@@ -234,8 +239,25 @@ static void joint_calc(int jtype, const double *axis, const double *qs, double *
   }
   if (jtype == REF_J_SPHERICAL) { quat_to_rot(qs, M); return; }
   if (jtype == REF_J_TRANSLATION) { M[9] = qs[0]; M[10] = qs[1]; M[11] = qs[2]; return; }
-  const double q = qs[0];
+  if (jtype == REF_J_SPHERICAL_ZYX) { /* JointModelSphericalZYX::calc: R = Rz(q0) Ry(q1) Rx(q2) */
+    const double c0 = cos(qs[0]), s0 = sin(qs[0]), c1 = cos(qs[1]), s1 = sin(qs[1]), c2 = cos(qs[2]), s2 = sin(qs[2]);
+    M[0] = c0 * c1; M[1] = c0 * s1 * s2 - s0 * c2; M[2] = c0 * s1 * c2 + s0 * s2;
+    M[3] = s0 * c1; M[4] = s0 * s1 * s2 + c0 * c2; M[5] = s0 * s1 * c2 - c0 * s2;
+    M[6] = -s1;     M[7] = c1 * s2;                M[8] = c1 * c2;
+    return;
+  }
+  if (jtype == REF_J_PLANAR) { /* JointModelPlanar::calc: q = (x, y, cos, sin) */
+    const double c = qs[2], s = qs[3];
+    M[0] = c; M[1] = -s; M[3] = s; M[4] = c;
+    M[9] = qs[0]; M[10] = qs[1];
+    return;
+  }
+  double q = qs[0];
   double c = cos(q), s = sin(q);
+  if (jtype == REF_J_RUBX || jtype == REF_J_RUBY || jtype == REF_J_RUBZ) { /* JointModelRevoluteUnbounded: q = (cos, sin) */
+    c = qs[0]; s = qs[1];
+    jtype = REF_J_RX + (jtype - REF_J_RUBX);
+  }
   switch (jtype) {
   case REF_J_RX:
     M[4] = c; M[5] = -s; M[7] = s; M[8] = c;
@@ -264,11 +286,24 @@ static void joint_calc(int jtype, const double *axis, const double *qs, double *
   }
 }
 
-/* joint motion subspace S: 6 x nv_i, column c stored at S[6c .. 6c+6) */
-static void joint_S(int jtype, const double *axis, double *S)
+/* joint motion subspace S: 6 x nv_i, column c stored at S[6c .. 6c+6).  Constant for every joint type but
+ * JointModelSphericalZYX, whose calc() sets it from q (`qs`, may be NULL for the others) */
+static void joint_S(int jtype, const double *axis, const double *qs, double *S)
 {
   memset(S, 0, 36 * sizeof(double));
   switch (jtype) {
+  case REF_J_RUBX: S[3] = 1.0; break;
+  case REF_J_RUBY: S[4] = 1.0; break;
+  case REF_J_RUBZ: S[5] = 1.0; break;
+  case REF_J_PLANAR: S[0] = 1.0; S[6 + 1] = 1.0; S[12 + 5] = 1.0; break;               /* ConstraintPlanar: vx, vy, wz */
+  case REF_J_SPHERICAL_ZYX: {  /* S.angularSubspace() << -s1, 0, 1,  c1 s2, c2, 0,  c1 c2, -s2, 0 (rows) */
+    const double q1 = qs ? qs[1] : 0.0, q2 = qs ? qs[2] : 0.0;
+    const double c1 = cos(q1), s1 = sin(q1), c2 = cos(q2), s2 = sin(q2);
+    S[3] = -s1; S[4] = c1 * s2; S[5] = c1 * c2;
+    S[6 + 3] = 0.0; S[6 + 4] = c2; S[6 + 5] = -s2;
+    S[12 + 3] = 1.0;
+    break;
+  }
   case REF_J_PX: S[0] = 1.0; break;
   case REF_J_PY: S[1] = 1.0; break;
   case REF_J_PZ: S[2] = 1.0; break;
@@ -486,7 +521,7 @@ int ref_create(const ref_model *m, const ref_params *p, ref_solver **out)
   for (int i = 0; i < nj; ++i) { se3_identity(s->oMi + 12 * i); se3_identity(s->liMi + 12 * i); }
   s->jS = dalloc(36 * nj); s->jU = dalloc(36 * nj); s->jUDinvM = dalloc(36 * nj); s->jDinvM = dalloc(36 * nj);
   s->jUDinv = dalloc(6 * nj); s->jDinv = dalloc(nj);
-  for (int i = 0; i < nj; ++i) joint_S(s->jtype[i], s->axis + 3 * i, s->jS + 36 * i);
+  for (int i = 0; i < nj; ++i) joint_S(s->jtype[i], s->axis + 3 * i, NULL, s->jS + 36 * i);
   s->nu = dalloc(nv); s->nu_prev = dalloc(nv);
   s->vis = dalloc(6 * nj); s->vis_prev = dalloc(6 * nj);
   s->His = dalloc(36 * nj); s->His_aba = dalloc(36 * nj);
@@ -686,6 +721,7 @@ void ref_fwd_pass_init(ref_solver *s, const double *q)
   for (int idx = 1; idx < s->nj; ++idx) {
     int parent = s->parents[idx];
     joint_calc(s->jtype[idx], s->axis + 3 * idx, q + s->idx_q[idx], M);
+    if (s->jtype[idx] == REF_J_SPHERICAL_ZYX) joint_S(s->jtype[idx], s->axis + 3 * idx, q + s->idx_q[idx], s->jS + 36 * idx);
     se3_mul(s->placement + 12 * idx, M, s->liMi + 12 * idx);
     se3_mul(s->oMi + 12 * parent, s->liMi + 12 * idx, s->oMi + 12 * idx);
   }

@@ -40,7 +40,12 @@ enum {
   REF_J_PU = 8,   /* JointModelPrismaticUnaligned */
   REF_J_FREEFLYER = 9,   /* JointModelFreeFlyer:   nq 7 (t, quat xyzw), nv 6, S = I6               */
   REF_J_SPHERICAL = 10,  /* JointModelSpherical:   nq 4 (quat xyzw),    nv 3, S = [0; I3]          */
-  REF_J_TRANSLATION = 11 /* JointModelTranslation: nq 3,                nv 3, S = [I3; 0]          */
+  REF_J_TRANSLATION = 11,/* JointModelTranslation: nq 3,                nv 3, S = [I3; 0]          */
+  REF_J_SPHERICAL_ZYX = 12, /* JointModelSphericalZYX: nq 3 (z, y, x angles), nv 3, S(q) angular: R = Rz Ry Rx */
+  REF_J_PLANAR = 13,     /* JointModelPlanar: nq 4 (x, y, cos, sin), nv 3 (vx, vy, wz in the joint frame)    */
+  REF_J_RUBX = 14,       /* JointModelRUBX / RUBY / RUBZ: nq 2 (cos, sin), nv 1                               */
+  REF_J_RUBY = 15,
+  REF_J_RUBZ = 16
 };
 
 /* mirrors enum ADMMPenaltyUpdateStrat, task-solver-base.hpp:13-18 */

@@ -115,7 +115,11 @@ J_FREEFLYER, J_SPHERICAL, J_TRANSLATION = 9, 10, 11
 CHAIN_TYPES = {J_FREEFLYER: [4, 5, 6, 1, 2, 3], J_SPHERICAL: [1, 2, 3], J_TRANSLATION: [4, 5, 6]}
 
 
-def random_tree_multidof(seed, nb, root_freeflyer=True, n_spherical=1, n_translation=1, branch_prob=0.3):
+J_SPHERICAL_ZYX, J_PLANAR, J_RUBX, J_RUBY, J_RUBZ = 12, 13, 14, 15, 16
+
+
+def random_tree_multidof(seed, nb, root_freeflyer=True, n_spherical=1, n_translation=1, branch_prob=0.3, n_zyx=0, n_planar=0,
+                         n_rub=0, root_planar=False):
     """random_tree() with some joints replaced by multi-DoF ones (optionally a free-flyer root joint: the
     floating-base case of SURVEY.md 8(f) rank 2)"""
     m = random_tree(seed, nb, branch_prob=branch_prob)
@@ -123,12 +127,21 @@ def random_tree_multidof(seed, nb, root_freeflyer=True, n_spherical=1, n_transla
     jt = m.jtype.copy()
     if root_freeflyer:
         jt[1] = J_FREEFLYER
-    cand = [i for i in range(2 if root_freeflyer else 1, nb + 1)]
+    cand = [i for i in range(2 if (root_freeflyer or root_planar) else 1, nb + 1)]
     rng.shuffle(cand)
     for i in cand[:n_spherical]:
         jt[i] = J_SPHERICAL
     for i in cand[n_spherical:n_spherical + n_translation]:
         jt[i] = J_TRANSLATION
+    k = n_spherical + n_translation
+    for i in cand[k:k + n_zyx]:
+        jt[i] = J_SPHERICAL_ZYX
+    for i in cand[k + n_zyx:k + n_zyx + n_planar]:
+        jt[i] = J_PLANAR
+    for n_, i in enumerate(cand[k + n_zyx + n_planar:k + n_zyx + n_planar + n_rub]):
+        jt[i] = J_RUBX + n_ % 3
+    if root_planar:
+        jt[1] = J_PLANAR
     return loik_amd.Model(m.parents, jt, m.axis, m.placement, name="random_multidof_%d_%d" % (seed, nb))
 
 

@@ -296,3 +296,103 @@ def test_gpu_integrate_on_the_configuration_manifold():
     t2.Solve(q1, wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
     assert np.max(np.abs(s.get("liMi") - t2.get("liMi"))) < 1e-14
     s.close(); t2.close()
+
+
+# ---- JointModelSphericalZYX (q-dependent motion subspace), JointModelPlanar, JointModelRUBX/Y/Z --------------------------------
+NEW_CASES = [dict(seed=21, nb=8, root_freeflyer=False, n_spherical=0, n_translation=0, n_zyx=2, n_rub=2),
+             dict(seed=22, nb=10, root_freeflyer=False, n_spherical=1, n_translation=0, n_zyx=1, n_planar=1, n_rub=1, root_planar=True),
+             dict(seed=23, nb=13, root_freeflyer=True, n_spherical=0, n_translation=1, n_zyx=2, n_planar=1, n_rub=3)]
+
+
+@pytest.mark.parametrize("case", NEW_CASES, ids=lambda c: "seed%d" % c["seed"])
+def test_oracle_zyx_planar_unbounded_joints_solve_the_qp(case):
+    """pins the oracle's new joint types by first principles: the converged answer is SLSQP's optimum of the reduced dense QP
+    whose Jacobians come from an independent numpy kinematics (workloads.link_velocity: M(q) and S(q) of
+    JointModelSphericalZYX::calc / JointModelPlanar::calc written out again)"""
+    from scipy.optimize import minimize
+    model = random_tree_multidof(**case)
+    assert model.nq > model.nv >= model.njoints - 1
+    p = one_problem(model, case["seed"] + 300)
+    s = ref.RefSolver(model, **dict(FIXTURE, max_iter=4000, tol_abs=1e-9, tol_rel=0.0, tol_primal_inf=1e-12))
+    s.Solve(p["q"], p["H_ref"], p["v_ref"], p["c_ids"], p["Ais"], p["bis"], p["lb"], p["ub"])
+    assert s.get_convergence_status(), s.get_iter()
+    nu, link = s.z, int(p["c_ids"][0])
+    nv = model.nv
+    eye = np.eye(nv)
+    J = [np.stack([workloads.link_velocity(model, p["q"][None], eye[k][None], i)[0] for k in range(nv)], axis=1)
+         for i in range(1, model.njoints)]
+    # kinematic consistency of the oracle's sweep with the independent Jacobians (incl. S(q) of the ZYX joints)
+    for i in range(1, model.njoints):
+        assert_close(s.vis[i], J[i - 1] @ s.nu, 1e-9, "v_%d = J nu" % i)
+    cost = lambda x: 0.5 * sum(float((Ji @ x) @ (Ji @ x)) for Ji in J)
+    grad = lambda x: sum(Ji.T @ (Ji @ x) for Ji in J)
+    Jc = J[link - 1]
+    res = minimize(cost, np.zeros(nv), jac=grad, method="SLSQP", bounds=list(zip(p["lb"], p["ub"])),
+                   constraints=[dict(type="eq", fun=lambda x: Jc @ x - p["bis"][0], jac=lambda x: Jc)],
+                   options=dict(ftol=1e-14, maxiter=500))
+    assert res.success
+    assert abs(cost(nu) - res.fun) < 1e-6 * max(1.0, res.fun) and np.max(np.abs(Jc @ nu - p["bis"][0])) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", NEW_CASES, ids=lambda c: "seed%d" % c["seed"])
+def test_gpu_zyx_planar_unbounded_joints(case):
+    """the device's chains (RZ-RY-RX with their own angles; PX-PY-RZ of one frame) and (cos, sin) joints against the oracle's
+    true joints: k iterations and end to end, every engine that applies"""
+    model = random_tree_multidof(**case)
+    wl = _batch(model, 90, case["seed"] + 200)
+    for k in (1, 3, 6):
+        _compare_k_iterations(model, wl, k, TOL)
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
+    out = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"],
+                          wl["ub"], nthreads=4, want_nu=True, **prm)
+    for kw in (dict(), dict(tail_max_instances=-1)):
+        s = _gpu(model, wl, prm, **kw)
+        assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.95, ztol=1e-7, what="new joints seed %d" % case["seed"])
+        # liMi of the caller's joints (a ZYX joint's is the product over its chain)
+        r = ref.RefSolver(model, **prm)
+        r.Solve(*[wl[k][0] if k in ("q", "bis") else wl[k] for k in ("q", "H_ref", "v_ref", "c_ids", "Ais", "bis", "lb", "ub")])
+        assert_close(s.get("liMi")[0], r.liMi[1:], 1e-13, "liMi")
+        s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_integrate_planar_and_unbounded_joints():
+    """loikb_integrate on the (x, y, cos, sin) and (cos, sin) configuration spaces: SpecialEuclideanOperationTpl<2> /
+    SpecialOrthogonalOperationTpl<2>::integrate written out in numpy"""
+    model = random_tree_multidof(seed=31, nb=7, root_freeflyer=False, n_spherical=0, n_translation=0, n_zyx=1, n_planar=1, n_rub=2,
+                                 root_planar=True)
+    B = 50
+    wl = _batch(model, B, 31)
+    prm = dict(FIXTURE, max_iter=100, tol_abs=1e-6, tol_rel=0.0)
+    s = _gpu(model, wl, prm)
+    z, q0, dt = s.get("z"), wl["q"].copy(), 0.37
+    s.integrate(dt)
+    q1 = s.get("q")
+    want = q0.copy()
+    for i in range(1, model.njoints):
+        t, iq, iv = int(model.jtype[i]), int(model.idx_q[i]), int(model.idx_v[i])
+        if t == 13:
+            vx, vy, w = (dt * z[:, iv + k] for k in range(3))
+            c0, s0 = q0[:, iq + 2], q0[:, iq + 3]
+            sw, cw = np.sin(w), np.cos(w)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                tx = np.where(np.abs(w) > 1e-14, (sw * vx - (1 - cw) * vy) / w, vx)
+                ty = np.where(np.abs(w) > 1e-14, ((1 - cw) * vx + sw * vy) / w, vy)
+            want[:, iq] = q0[:, iq] + c0 * tx - s0 * ty
+            want[:, iq + 1] = q0[:, iq + 1] + s0 * tx + c0 * ty
+            c1, s1 = c0 * cw - s0 * sw, s0 * cw + c0 * sw
+            n = 0.5 * (3 - (c1 * c1 + s1 * s1))
+            want[:, iq + 2], want[:, iq + 3] = c1 * n, s1 * n
+        elif t in (14, 15, 16):
+            w = dt * z[:, iv]
+            c0, s0 = q0[:, iq], q0[:, iq + 1]
+            c1, s1 = c0 * np.cos(w) - s0 * np.sin(w), s0 * np.cos(w) + c0 * np.sin(w)
+            n = 0.5 * (3 - (c1 * c1 + s1 * s1))
+            want[:, iq], want[:, iq + 1] = c1 * n, s1 * n
+        else:
+            nvj = 3 if t == 12 else 1
+            want[:, iq:iq + nvj] = q0[:, iq:iq + nvj] + dt * z[:, iv:iv + nvj]
+    assert np.abs(z).max() > 1e-3
+    assert_close(q1, want, 1e-13, "q after integrate")
+    s.close()
