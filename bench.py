@@ -281,7 +281,7 @@ def kernel_roofline(acc, last, steps, nb, nc, B):
             insts = pk[name]["valu_insts_per_step"] / max(pk[name].get("dispatches_per_step", 1.0), 1.0)
             ncu, clk = pmc.get("compute_units", 256), pmc.get("shader_clock_ghz", 2.4)
             r["valu_issue_frac"] = insts * 4.0 / (4 * ncu * avg_ms * 1e-3 * clk * 1e9)
-            r["valu_insts_per_wavefront_iteration"] = pk[name].get("valu_insts_per_wavefront_iteration")
+            r["valu_insts_per_instance_iteration"] = pk[name].get("valu_insts_per_instance_iteration")
             r["lds_bank_conflict_frac"] = pk[name].get("lds_bank_conflict_frac")
         if pmc:
             r["pmc_source"] = pmc["_file"]
