@@ -129,6 +129,7 @@ struct loikb_solver_impl {
   std::vector<TailTopo> topo;
   std::vector<int> child_list;
   int maxdepth = 0, maxchild = 0;
+  int multi_from = 1;  // leaf->root level loop of k_lean: the step from which joints with several children can be final
   TailTopo* d_topo = nullptr;
   int* d_child_list = nullptr;
   // options
@@ -542,6 +543,15 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
       if (S->parents[c] == i) S->child_list.push_back(c - 1);  // lane of the child
     S->topo[i].nchild = (int)S->child_list.size() - S->topo[i].child_start;
     if (S->topo[i].nchild > S->maxchild) S->maxchild = S->topo[i].nchild;
+  }
+  {
+    // height of a joint = steps of the leaf->root level loop after which its message is final (a leaf: 1)
+    std::vector<int> height(nj, 1);
+    for (int i = nj - 1; i >= 1; --i)
+      if (S->parents[i] > 0 && height[i] + 1 > height[S->parents[i]]) height[S->parents[i]] = height[i] + 1;
+    S->multi_from = 1 << 30;
+    for (int i = 1; i < nj; ++i)
+      if (S->topo[i].nchild > 1 && height[i] < S->multi_from) S->multi_from = height[i];
   }
   return LOIKB_OK;
 }
@@ -1169,7 +1179,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
 #define LOIKB_LAUNCH_LEAN(HD, SL)                                                                                             \
   hipLaunchKernelGGL((k_lean<T, HD, SL>), grid, dim3(WAVE * ltw), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,             \
                      (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, C->d_ring,              \
-                     C->ring_cap - 1, n, G, (const T*)C->d_hslots, kexp_lo, ndec, quantum)
+                     C->ring_cap - 1, n, G, (const T*)C->d_hslots, kexp_lo, ndec, quantum, S->multi_from)
         if (quantum > 0) { if (S->href_diag) LOIKB_LAUNCH_LEAN(true, true); else LOIKB_LAUNCH_LEAN(false, true); }
         else { if (S->href_diag) LOIKB_LAUNCH_LEAN(true, false); else LOIKB_LAUNCH_LEAN(false, false); }
 #undef LOIKB_LAUNCH_LEAN

@@ -187,7 +187,7 @@ template <typename T, bool HDIAG, bool SLICED>
 __global__ void __launch_bounds__(WAVE * TAIL_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
        const int* __restrict__ child_list, int maxdepth, int maxchild, int* __restrict__ ring, int ring_mask, int nslots, int G,
-       const T* __restrict__ hslots, int kexp_lo, int ndec, int quantum)
+       const T* __restrict__ hslots, int kexp_lo, int ndec, int quantum, int multi_from)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
@@ -529,7 +529,10 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       for (int lev = maxdepth; lev >= 1; --lev) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) pl[k] = p[k];
-        lean_gather_n<T>(maxchild, xch, chl, LXA, pl);
+        // (a joint with several children is final only from step `multi_from` on -- the smallest height of such a joint,
+        //  loik_host.hip: before that every lane that matters has at most its first child, and the further child rows
+        //  are not read: 18 instructions and three 16-byte LDS reads per skipped child, level and wavefront)
+        lean_gather_n<T>((maxdepth - lev + 1 >= multi_from) ? maxchild : (maxchild > 0 ? 1 : 0), xch, chl, LXA, pl);
         const T Stp = dot6_halves(Sv, pl);
         rl = (w - mu_in * z) + Stp;
         T pa[6], pc[6];
