@@ -14,14 +14,14 @@ export TMPDIR=/tmp
 cd /tmp
 python "$REPO/bench.py" "$@" > "$OUT/bench_line.json" 2> "$OUT/bench.err"
 echo "bench exit $?"; cat "$OUT/bench_line.json"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python "$REPO/bench.py" --no-cpu-baseline "$@" > "$OUT/bench_under_rocprof.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python "$REPO/bench.py" --no-cpu-baseline --no-variants "$@" > "$OUT/bench_under_rocprof.log" 2>&1
 echo "trace exit $?"
 find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 STEPS=3
 for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_BUSY_CYCLES"; do
   D=$OUT/pmc_$(echo $C | tr ' ' '_' | cut -c1-40)
   mkdir -p "$D"
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$D" -o pmc -- python "$REPO/bench.py" --no-cpu-baseline --steps 2 --warmup 1 "$@" > "$D/log.txt" 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$D" -o pmc -- python "$REPO/bench.py" --no-cpu-baseline --no-variants --steps 2 --warmup 1 "$@" > "$D/log.txt" 2>&1
   echo "pmc [$C] exit $?"
 done
 python "$REPO/scripts/pmc_round_summary.py" "$OUT" $STEPS > "$OUT/pmc.json"
