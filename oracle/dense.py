@@ -198,7 +198,7 @@ class DenseSolver:
             raise RuntimeError("number of equality constraints doesn't match initialization")
         if len(lb) != nv or len(ub) != nv:
             raise RuntimeError("inequality constraint dimension has changed")
-        self.H_ref, self.v_ref = H_ref, v_ref
+        self.H_refs = [H_ref.copy() for _ in range(self.nj)]; self.v_refs = [v_ref.copy() for _ in range(self.nj)]
         self.c_ids = [int(c) for c in c_ids]; self.Ais = Ais; self.bis = bis
         self.lb = np.asarray(lb, dtype=float).copy(); self.ub = np.asarray(ub, dtype=float).copy()
         off = 6 * nb + m6 * nb
@@ -210,7 +210,7 @@ class DenseSolver:
         for idx in range(1, self.nj):
             r0 = (idx - 1) * 6
             self.P_qp[r0:r0 + 6, r0:r0 + 6] = H_ref
-            self.q_qp[r0:r0 + 6] = -H_ref.T @ v_ref
+            self.q_qp[r0:r0 + 6] = -H_ref.T @ v_ref   # (rewritten per link by UpdateReferences)
             iv = int(mdl.idx_v[idx])
             self.A_qp[r0:r0 + 6, 6 * nb + iv:6 * nb + iv + self.nvs[idx]] = self.S[idx]
             parent = int(mdl.parents[idx])
@@ -229,6 +229,18 @@ class DenseSolver:
             self.ub_qp[r0:r0 + m6] = bis[c]
         self.z_qp[6 * nb:6 * nb + m6 * nb] = self.ub_qp[6 * nb:6 * nb + m6 * nb]
 
+    # ---- per-link weights and targets: ik-id-description.hpp's UpdateReferences (same text as the optimized class',
+    #      ik-id-description-optimized.hpp:103-121) + the P_qp / q_qp blocks UpdateQPADMMSolveInit fills from them
+    def UpdateReferences(self, H_refs, v_refs):
+        H_refs = np.asarray(H_refs, dtype=float).reshape(-1, 6, 6); v_refs = np.asarray(v_refs, dtype=float).reshape(-1, 6)
+        if H_refs.shape[0] != self.nj or v_refs.shape[0] != self.nj:
+            raise RuntimeError("input arguments 'H_refs', 'v_refs' have wrong size")
+        self.H_refs = [H.copy() for H in H_refs]; self.v_refs = [v.copy() for v in v_refs]
+        for idx in range(1, self.nj):
+            r0 = (idx - 1) * 6
+            self.P_qp[r0:r0 + 6, r0:r0 + 6] = self.H_refs[idx]
+            self.q_qp[r0:r0 + 6] = -self.H_refs[idx].T @ self.v_refs[idx]
+
     # ---- loik-loid.hpp:362-377 -------------------------------------------------------------------
     def SolveInit(self, q, H_ref, v_ref, c_ids, Ais, bis, lb, ub):
         self.ResetSolver()
@@ -241,8 +253,8 @@ class DenseSolver:
             iv, n = int(self.model.idx_v[idx]), self.nvs[idx]
             self.Ris[idx] = self.mu_ineq * np.ones(n)
             self.ris[idx] = self.w[iv:iv + n] - self.mu_ineq * self.z[iv:iv + n]
-            self.His[idx] = self.rho * np.eye(6) + self.H_ref
-            self.pis[idx] = -self.rho * self.vis_prev[idx] - self.H_ref.T @ self.v_ref
+            self.His[idx] = self.rho * np.eye(6) + self.H_refs[idx]
+            self.pis[idx] = -self.rho * self.vis_prev[idx] - self.H_refs[idx].T @ self.v_refs[idx]
         for c, c_id in enumerate(self.c_ids):
             Ai, bi = self.Ais[c], self.bis[c]
             self.His[c_id] += self.mu_eq * Ai.T @ Ai

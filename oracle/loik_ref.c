@@ -418,9 +418,11 @@ struct ref_solver {
   int eq_c_dim;
   double *H_refs, *v_refs, *Hv;      /* [nj][36], [nj][6], [nj][6] */
   int *active_ids;                   /* [nc] */
+  int nc_cap;                        /* allocated constraint slots (>= nc = nc_eq_) */
   double *Ais, *bis, *AtA, *Atb;     /* [nc][36], [nc][6], [nc][36], [nc][6] */
   double *lb, *ub;                   /* [nv] */
   double bis_inf_norm, Hv_inf_norm;
+  int per_link_refs;                 /* UpdateReferences() in force (not a reference member: test bookkeeping) */
 
   /* --- IkIdSolverBaseTpl members (task-solver-base.hpp:145-170) --- */
   double rho, mu0, mu, mu_equality_scale_factor;
@@ -480,11 +482,11 @@ static void problem_reset(ref_solver *s)
   memset(s->v_refs, 0, sizeof(double) * 6 * (size_t)s->nj);
   memset(s->Hv, 0, sizeof(double) * 6 * (size_t)s->nj);
   s->Hv_inf_norm = 0.0;
-  for (int c = 0; c < s->nc; ++c) s->active_ids[c] = 0;
-  memset(s->Ais, 0, sizeof(double) * 36 * (size_t)s->nc);
-  memset(s->bis, 0, sizeof(double) * 6 * (size_t)s->nc);
-  memset(s->AtA, 0, sizeof(double) * 36 * (size_t)s->nc);
-  memset(s->Atb, 0, sizeof(double) * 6 * (size_t)s->nc);
+  for (int c = 0; c < s->nc_cap; ++c) s->active_ids[c] = 0;
+  memset(s->Ais, 0, sizeof(double) * 36 * (size_t)s->nc_cap);
+  memset(s->bis, 0, sizeof(double) * 6 * (size_t)s->nc_cap);
+  memset(s->AtA, 0, sizeof(double) * 36 * (size_t)s->nc_cap);
+  memset(s->Atb, 0, sizeof(double) * 6 * (size_t)s->nc_cap);
   s->bis_inf_norm = 0.0;
   memset(s->lb, 0, sizeof(double) * (size_t)s->nv);
   memset(s->ub, 0, sizeof(double) * (size_t)s->nv);
@@ -496,8 +498,12 @@ int ref_create(const ref_model *m, const ref_params *p, ref_solver **out)
   /* ik-id-description-optimized.hpp:41-44 */
   if (p->eq_c_dim != 6) return REF_ERR_EQ_DIM;
   ref_solver *s = (ref_solver *)calloc(1, sizeof(ref_solver));
-  const int nj = m->njoints, nv = m->nv, nc = p->num_eq_c;
-  s->nj = nj; s->nb = nj - 1; s->nq = m->nq; s->nv = nv; s->nc = nc;
+  const int nj = m->njoints, nv = m->nv;
+  /* the per-constraint arrays are sized for eq_c_capacity (>= num_eq_c) so that AddEqConstraint has room: upstream sizes
+     them for num_eq_c only and AddEqConstraint ("deactivated for now", ik-id-description-optimized.hpp:242) would
+     overrun yis/Aty -- the capacity is how the intended behaviour becomes well defined */
+  const int nc = p->eq_c_capacity > p->num_eq_c ? p->eq_c_capacity : p->num_eq_c;
+  s->nj = nj; s->nb = nj - 1; s->nq = m->nq; s->nv = nv; s->nc = p->num_eq_c; s->nc_cap = nc;
   s->parents = (int *)malloc(sizeof(int) * nj);
   s->jtype = (int *)malloc(sizeof(int) * nj);
   s->idx_q = (int *)malloc(sizeof(int) * nj);
@@ -640,6 +646,7 @@ void ref_update_prev(ref_solver *s)
  * links; Hv_inf_norm_ taken from link 0 only) */
 static void problem_update_reference(ref_solver *s, const double *H_ref, const double *v_ref)
 {
+  s->per_link_refs = 0;
   for (int i = 0; i < s->nj; ++i) {
     memcpy(s->H_refs + 36 * i, H_ref, 36 * sizeof(double));
     memcpy(s->v_refs + 6 * i, v_ref, 6 * sizeof(double));
@@ -709,6 +716,100 @@ static int problem_update_eq_single(ref_solver *s, int c_id, const double *Ai, c
   if (n > s->bis_inf_norm) s->bis_inf_norm = n;
   return REF_OK;
 }
+
+
+/* UpdateReferences(H_refs, v_refs), ik-id-description-optimized.hpp:103-121: one weight and one target per link
+ * (index 0 = the universe, carried but never read by the passes).  Hv_inf_norm_ is NOT reset there: it keeps growing from
+ * whatever UpdateReference / an earlier UpdateReferences left (quirk kept). */
+int ref_update_references(ref_solver *s, const double *H_refs, const double *v_refs, int n)
+{
+  if (n != s->nj) return REF_ERR_REFS_SIZE;
+  memcpy(s->H_refs, H_refs, sizeof(double) * 36 * (size_t)s->nj);
+  memcpy(s->v_refs, v_refs, sizeof(double) * 6 * (size_t)s->nj);
+  for (int i = 0; i < s->nj; ++i) {
+    mat6_vec(s->H_refs + 36 * i, s->v_refs + 6 * i, s->Hv + 6 * i);
+    if (s->massless[i]) { /* test-only concept, see loik_ref.h */
+      memset(s->H_refs + 36 * i, 0, 36 * sizeof(double));
+      memset(s->Hv + 6 * i, 0, 6 * sizeof(double));
+    }
+    const double n_i = inf_norm(s->Hv + 6 * i, 6);
+    if (n_i > s->Hv_inf_norm) s->Hv_inf_norm = n_i;
+  }
+  s->per_link_refs = 1;
+  return REF_OK;
+}
+
+/* UpdateEqConstraint(c_id, Ai, bi) / UpdateEqConstraint(c_id, bi) (Ai == NULL), :178-238 */
+int ref_update_eq_constraint(ref_solver *s, int c_id, const double *Ai, const double *bi)
+{
+  if (!Ai) {
+    for (int c = 0; c < s->nc; ++c)
+      if (s->active_ids[c] == c_id) {
+        double keep[36];
+        memcpy(keep, s->Ais + 36 * c, sizeof(keep));
+        return problem_update_eq_single(s, c_id, keep, bi);
+      }
+    return REF_ERR_NO_SUCH_CONSTRAINT;
+  }
+  return problem_update_eq_single(s, c_id, Ai, bi);
+}
+
+/* AddEqConstraint(c_id, Ai, bi), :244-286: present -> UpdateEqConstraint; else appended, nc_eq_++, bis_inf_norm_ grows.
+ * The dual of the new constraint starts at zero (upstream would read past the end of yis: see ref_create). */
+int ref_add_eq_constraint(ref_solver *s, int c_id, const double *Ai, const double *bi)
+{
+  for (int c = 0; c < s->nc; ++c)
+    if (s->active_ids[c] == c_id) return problem_update_eq_single(s, c_id, Ai, bi);
+  if (s->nc >= s->nc_cap) return REF_ERR_EQ_SIZE;
+  const int c = s->nc++;
+  s->active_ids[c] = c_id;
+  memcpy(s->Ais + 36 * c, Ai, 36 * sizeof(double));
+  memcpy(s->bis + 6 * c, bi, 6 * sizeof(double));
+  compute_AtA_Atb(Ai, bi, s->AtA + 36 * c, s->Atb + 6 * c);
+  memset(s->yis + 6 * c, 0, 6 * sizeof(double));
+  memset(s->Aty + 6 * c, 0, 6 * sizeof(double));
+  memset(s->delta_yis + 6 * c, 0, 6 * sizeof(double));
+  memset(s->Av_minus_b + 6 * c, 0, 6 * sizeof(double));
+  const double n = inf_norm(bi, 6);
+  if (n > s->bis_inf_norm) s->bis_inf_norm = n;
+  return REF_OK;
+}
+
+/* RemoveEqConstraint(c_id), :292-319: absent -> nothing (upstream warns on stderr; returns 1 here); else the entry is
+ * erased from every per-constraint vector (the later ones move down), bis_inf_norm_ is recomputed, nc_eq_--.  Upstream
+ * leaves Aty alone ("// Aty.erase(found_it)"): here yis/Aty move with their constraints, which is what a warm start
+ * after the edit needs. */
+int ref_remove_eq_constraint(ref_solver *s, int c_id)
+{
+  int found = -1;
+  for (int c = 0; c < s->nc; ++c)
+    if (s->active_ids[c] == c_id) { found = c; break; }
+  if (found < 0) return 1;
+  /* the link's rows of primal_residual_vec_ are only ever written while it carries a constraint (hxx:433) and
+     primal_residual_ is the norm of the whole vector (hxx:498): without this line the removed constraint's last residual
+     would stay in every later primal residual.  Not upstream (whose RemoveEqConstraint is deactivated and has no access to
+     the solver's vector): part of making the intended behaviour well defined, like eq_c_capacity. */
+  memset(s->primal_residual_vec + 6 * (c_id - 1), 0, 6 * sizeof(double));
+  for (int c = found; c + 1 < s->nc; ++c) {
+    s->active_ids[c] = s->active_ids[c + 1];
+    memcpy(s->Ais + 36 * c, s->Ais + 36 * (c + 1), 36 * sizeof(double));
+    memcpy(s->AtA + 36 * c, s->AtA + 36 * (c + 1), 36 * sizeof(double));
+    memcpy(s->bis + 6 * c, s->bis + 6 * (c + 1), 6 * sizeof(double));
+    memcpy(s->Atb + 6 * c, s->Atb + 6 * (c + 1), 6 * sizeof(double));
+    memcpy(s->yis + 6 * c, s->yis + 6 * (c + 1), 6 * sizeof(double));
+    memcpy(s->Aty + 6 * c, s->Aty + 6 * (c + 1), 6 * sizeof(double));
+  }
+  --s->nc;
+  s->bis_inf_norm = 0.0;
+  for (int c = 0; c < s->nc; ++c) {
+    const double n = inf_norm(s->bis + 6 * c, 6);
+    if (n > s->bis_inf_norm) s->bis_inf_norm = n;
+  }
+  return REF_OK;
+}
+
+int ref_num_eq_c(const ref_solver *s) { return s->nc; }
+int ref_active_id(const ref_solver *s, int c) { return (c >= 0 && c < s->nc) ? s->active_ids[c] : -1; }
 
 /* ------------------------------------------------------------------------------------------ */
 /* solver passes                                                                               */
@@ -1106,7 +1207,8 @@ int ref_solve_tailored(ref_solver *s, const double *q, int c_id, const double *A
 {
   data_reset(s, s->warm_start);
   reset_solver(s);
-  int rc = problem_update_eq_single(s, c_id, Ai, bi);
+  /* c_id < 0: no constraint update (not upstream: the way to solve once AddEq/RemoveEq changed the set, e.g. to none) */
+  int rc = c_id < 0 ? REF_OK : problem_update_eq_single(s, c_id, Ai, bi);
   if (rc != REF_OK) return rc;
   ref_fwd_pass_init(s, q);
   return main_loop(s);

@@ -60,7 +60,8 @@ enum {
   REF_ERR_NO_SUCH_CONSTRAINT = -4, /* :184-186                             */
   REF_ERR_DUP_CONSTRAINT = -5,  /* :197-199                                */
   REF_ERR_MU_STRAT = -6,        /* loik-loid-optimized.hxx:632-640         */
-  REF_ERR_ARG = -7
+  REF_ERR_ARG = -7,
+  REF_ERR_REFS_SIZE = -8        /* ik-id-description-optimized.hpp:105-107 */
 };
 
 typedef struct ref_model {
@@ -86,6 +87,7 @@ typedef struct ref_params {
   int num_eq_c, eq_c_dim;
   int warm_start;
   double tol_tail_solve;
+  int eq_c_capacity;       /* constraint slots to allocate (0 = num_eq_c): room for AddEqConstraint, see ref_create */
 } ref_params;
 
 typedef struct ref_solver ref_solver;
@@ -108,6 +110,19 @@ int ref_solve_full(ref_solver *s, const double *q, const double *H_ref, const do
                    const double *lb, const double *ub, int nbound);
 /* loik-loid-optimized.hpp:596-695 */
 int ref_solve_tailored(ref_solver *s, const double *q, int c_id, const double *Ai, const double *bi);
+
+/* IkProblemFormulationOptimized's editing methods (ik-id-description-optimized.hpp).  The solver class keeps problem_
+ * protected, so upstream they are reachable from a subclass only; they act between SolveInit / Solve calls:
+ *   ref_update_references     UpdateReferences(H_refs, v_refs), :103-121  ([nj][36], [nj][6]; n must be nj)
+ *   ref_update_eq_constraint  UpdateEqConstraint(c_id, Ai, bi) :178-218, (c_id, bi) :224-238 (Ai == NULL)
+ *   ref_add_eq_constraint     AddEqConstraint, :244-286 ("deactivated for now" upstream; needs eq_c_capacity)
+ *   ref_remove_eq_constraint  RemoveEqConstraint, :292-319 (returns 1 when there was nothing to remove)             */
+int ref_update_references(ref_solver *s, const double *H_refs, const double *v_refs, int n);
+int ref_update_eq_constraint(ref_solver *s, int c_id, const double *Ai, const double *bi);
+int ref_add_eq_constraint(ref_solver *s, int c_id, const double *Ai, const double *bi);
+int ref_remove_eq_constraint(ref_solver *s, int c_id);
+int ref_num_eq_c(const ref_solver *s);
+int ref_active_id(const ref_solver *s, int c);
 
 /* pass-level entry points (loik-loid-optimized.hpp:192-264) */
 void ref_fwd_pass_init(ref_solver *s, const double *q);

@@ -26,7 +26,7 @@ class RefParams(C.Structure):
                 ("tol_primal_inf", C.c_double), ("tol_dual_inf", C.c_double),
                 ("rho", C.c_double), ("mu", C.c_double), ("mu_equality_scale_factor", C.c_double),
                 ("mu_update_strat", C.c_int), ("num_eq_c", C.c_int), ("eq_c_dim", C.c_int),
-                ("warm_start", C.c_int), ("tol_tail_solve", C.c_double)]
+                ("warm_start", C.c_int), ("tol_tail_solve", C.c_double), ("eq_c_capacity", C.c_int)]
 
 
 # field / scalar ids, keep in sync with loik_ref.h
@@ -81,6 +81,17 @@ def load(native=False):
     lib.ref_set_max_iter.argtypes = [C.c_void_p, C.c_int]
     lib.ref_set_tols.argtypes = [C.c_void_p, C.c_double, C.c_double]
     lib.ref_set_warm_start.argtypes = [C.c_void_p, C.c_int]
+    lib.ref_update_references.argtypes = [C.c_void_p, _c_double_p, _c_double_p, C.c_int]
+    lib.ref_update_references.restype = C.c_int
+    for name in ["ref_update_eq_constraint", "ref_add_eq_constraint"]:
+        getattr(lib, name).argtypes = [C.c_void_p, C.c_int, _c_double_p, _c_double_p]
+        getattr(lib, name).restype = C.c_int
+    lib.ref_remove_eq_constraint.argtypes = [C.c_void_p, C.c_int]
+    lib.ref_remove_eq_constraint.restype = C.c_int
+    lib.ref_num_eq_c.argtypes = [C.c_void_p]
+    lib.ref_num_eq_c.restype = C.c_int
+    lib.ref_active_id.argtypes = [C.c_void_p, C.c_int]
+    lib.ref_active_id.restype = C.c_int
     lib.ref_solve_batch.argtypes = [C.POINTER(RefModel), C.POINTER(RefParams), C.c_int, _c_double_p, _c_double_p,
                                     _c_double_p, _c_int_p, C.c_int, _c_double_p, _c_double_p, _c_double_p,
                                     _c_double_p, C.c_int, C.c_int, _c_double_p, _c_double_p, _c_int_p, _c_int_p,
@@ -125,10 +136,10 @@ class _ModelHolder:
 
 def make_params(max_iter=200, tol_abs=1e-3, tol_rel=1e-3, tol_primal_inf=1e-2, tol_dual_inf=1e-2, rho=1e-5,
                 mu=1e-2, mu_equality_scale_factor=1e4, mu_update_strat=0, num_eq_c=1, eq_c_dim=6,
-                warm_start=False, tol_tail_solve=1e-1):
+                warm_start=False, tol_tail_solve=1e-1, eq_c_capacity=0):
     """defaults = the reference fixture, tests/loik-loid.cpp:91-105"""
     return RefParams(max_iter, tol_abs, tol_rel, tol_primal_inf, tol_dual_inf, rho, mu, mu_equality_scale_factor,
-                     mu_update_strat, num_eq_c, eq_c_dim, int(bool(warm_start)), tol_tail_solve)
+                     mu_update_strat, num_eq_c, eq_c_dim, int(bool(warm_start)), tol_tail_solve, int(eq_c_capacity))
 
 
 class RefSolver:
@@ -175,12 +186,45 @@ class RefSolver:
             rc = self.lib.ref_solve_full(*args)
         elif len(a) == 4:
             q, c_id, Ai, bi = a
-            q = _f64(q); Ai = _f64(Ai).reshape(36); bi = _f64(bi).reshape(6)
-            rc = self.lib.ref_solve_tailored(self.h, _dp(q), int(c_id), _dp(Ai), _dp(bi))
+            q = _f64(q)
+            if int(c_id) < 0:   # no constraint update (see ref_solve_tailored)
+                rc = self.lib.ref_solve_tailored(self.h, _dp(q), -1, None, None)
+            else:
+                Ai = _f64(Ai).reshape(36); bi = _f64(bi).reshape(6)
+                rc = self.lib.ref_solve_tailored(self.h, _dp(q), int(c_id), _dp(Ai), _dp(bi))
         else:
             raise TypeError("Solve() takes 0, 4 or 8 arguments")
         if rc != 0:
             raise RuntimeError("ref solve failed with code %d" % rc)
+
+    # -- IkProblemFormulationOptimized's editing methods (protected behind the solver upstream) -----------
+    def UpdateReferences(self, H_refs, v_refs):
+        H_refs = _f64(H_refs).reshape(-1, 36); v_refs = _f64(v_refs).reshape(-1, 6)
+        rc = self.lib.ref_update_references(self.h, _dp(H_refs), _dp(v_refs),
+                                            int(H_refs.shape[0]) if H_refs.shape[0] == v_refs.shape[0] else -1)
+        if rc != 0:
+            raise RuntimeError("ref_update_references failed with code %d" % rc)
+
+    def UpdateEqConstraint(self, c_id, *a):
+        if len(a) == 1:
+            Ai, bi = None, _f64(a[0]).reshape(6)
+        else:
+            Ai, bi = _f64(a[0]).reshape(36), _f64(a[1]).reshape(6)
+        rc = self.lib.ref_update_eq_constraint(self.h, int(c_id), None if Ai is None else _dp(Ai), _dp(bi))
+        if rc != 0:
+            raise RuntimeError("ref_update_eq_constraint failed with code %d" % rc)
+
+    def AddEqConstraint(self, c_id, Ai, bi):
+        Ai = _f64(Ai).reshape(36); bi = _f64(bi).reshape(6)
+        rc = self.lib.ref_add_eq_constraint(self.h, int(c_id), _dp(Ai), _dp(bi))
+        if rc != 0:
+            raise RuntimeError("ref_add_eq_constraint failed with code %d" % rc)
+
+    def RemoveEqConstraint(self, c_id):
+        return self.lib.ref_remove_eq_constraint(self.h, int(c_id)) == 0   # False: nothing to remove
+
+    def active_task_constraint_ids(self):
+        return [self.lib.ref_active_id(self.h, c) for c in range(self.lib.ref_num_eq_c(self.h))]
 
     # -- pass-level ---------------------------------------------------------------------------------
     def FwdPassInit(self, q):
