@@ -37,6 +37,7 @@ enum {
   LOIKB_ERR_DUP_CONSTRAINT = -5,  /* same link listed twice                         ...hpp:197-199          */
   LOIKB_ERR_MU_STRATEGY = -6,     /* MAXEIGENVALUE (and upstream: OSQP) not implemented  loik-loid-optimized.hxx:632-640 */
   LOIKB_ERR_MODEL = -7,           /* unsupported joint type, inconsistent nq/nv/idx_q/idx_v, parents[i] >= i */
+  LOIKB_ERR_REFS_SIZE = -8,       /* UpdateReferences: not one entry per joint      ...hpp:105-107          */
   /* runtime */
   LOIKB_ERR_ARG = -20,
   LOIKB_ERR_HIP = -21,            /* a HIP call failed: loikb_last_error() has the text */
@@ -101,6 +102,10 @@ typedef struct loikb_options {
                                 -- H cache on, <= 2 task constraints with a shared A (1 otherwise), <= 4 children per joint:
                                 whole batches run in it --, else
                                 32768), < 0 = never                                           */
+  int eq_c_capacity;         /* constraint slots to allocate, 0 = num_eq_c.  Room for loikb_add_eq_constraint: upstream sizes
+                                yis/Aty for num_eq_c only, so its AddEqConstraint ("deactivated for now",
+                                ik-id-description-optimized.hpp:242) has nowhere to put a new dual; a slot without a
+                                constraint holds the null constraint (A = 0, b = 0, y = 0), which changes no number  */
 } loikb_options;
 
 typedef struct loikb_solver loikb_solver;
@@ -125,6 +130,33 @@ int loikb_solve_full(loikb_solver *s, const double *q, const double *H_ref, cons
 /* Solve(q,c_id,Ai,bi), loik-loid-optimized.hpp:596-695: honours warm_start, keeps reference and bounds */
 int loikb_solve_tailored(loikb_solver *s, const double *q, int c_id, const double *Ai, const double *bi,
                          int in_flags);
+
+/* IkProblemFormulationOptimized's editing methods (ik-id-description-optimized.hpp).  Upstream the solver keeps `problem_`
+ * protected (loik-loid-optimized.hpp:765), so they are reachable from a subclass only; here they are entry points.  They act
+ * on the problem SolveInit set and stay in force for loikb_solve / loikb_solve_tailored until the next SolveInit
+ * (whose UpdateReference / UpdateEqConstraints overwrite them, hpp:355-357).
+ *   loikb_update_references     UpdateReferences(H_refs, v_refs), :103-121.  [n][36] row-major and [n][6], n = njoints incl. the
+ *                               universe (else LOIKB_ERR_REFS_SIZE); entry 0 is carried and counts in Hv_inf_norm_, which this
+ *                               call never resets (quirks kept).  Per-link references run in k_solve / k_tail, not in k_lean.
+ *   loikb_update_eq_constraint  UpdateEqConstraint(c_id, Ai, bi) :178-218; Ai == NULL: the (c_id, bi) overload :224-238.
+ *                               Ai: [36] with LOIKB_A_SHARED (must match SolveInit) else [B][36]; bi: [B][6] or [6] with
+ *                               LOIKB_B_SHARED; LOIKB_IN_DEVICE as in solve_init.  bis_inf_norm_ only grows (quirk kept).
+ *   loikb_add_eq_constraint     AddEqConstraint, :244-286: a link that has a constraint -> UpdateEqConstraint; else the
+ *                               constraint is appended (its dual starts at zero).  LOIKB_ERR_EQ_C_SIZE without a free slot.
+ *   loikb_remove_eq_constraint  RemoveEqConstraint, :292-319: the later constraints move down (with their duals),
+ *                               bis_inf_norm_ is recomputed.  LOIKB_NOTHING_TO_REMOVE (= 1, not an error; upstream warns on
+ *                               stderr) when the link has none.
+ *   loikb_solve_tailored(s, q, -1, NULL, NULL, flags) solves on the edited set without updating a constraint (not upstream,
+ *   whose tailored Solve always rewrites one).  SolveInit's count check is against the CURRENT number of constraints, like
+ *   upstream's nc_eq_ (hpp:143).  loikb_get(YIS / ATY) return the active constraints, in active_ids order.               */
+enum { LOIKB_NOTHING_TO_REMOVE = 1 };
+int loikb_update_references(loikb_solver *s, const double *H_refs, const double *v_refs, int n);
+int loikb_update_eq_constraint(loikb_solver *s, int c_id, const double *Ai, const double *bi, int in_flags);
+int loikb_add_eq_constraint(loikb_solver *s, int c_id, const double *Ai, const double *bi, int in_flags);
+int loikb_remove_eq_constraint(loikb_solver *s, int c_id);
+int loikb_num_eq_c(const loikb_solver *s);        /* nc_eq_: constraints in force                                  */
+int loikb_eq_c_capacity(const loikb_solver *s);   /* slots allocated                                               */
+int loikb_active_constraint_ids(const loikb_solver *s, int *out, int cap); /* returns nc_eq_, writes min(nc_eq_, cap) ids */
 
 /* Outer loop on the device (the caller side of the path: a sampling planner / global IK iterates
  * solve -> integrate -> re-target, README.md:5 of the reference).  The configurations q stay

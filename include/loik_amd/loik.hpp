@@ -152,7 +152,7 @@ public:
                           const double& mu_equality_scale_factor, const ADMMPenaltyUpdateStrat& mu_update_strat,
                           const int num_eq_c, const int eq_c_dim, const Model& model, IkIdData& ik_id_data,
                           const bool warm_start, const double tol_tail_solve, const bool verbose, const bool logging,
-                          const int device = 0, const int flags = 0)
+                          const int device = 0, const int flags = 0, const int eq_c_capacity = 0)
   : model_(model), ik_id_data_(ik_id_data), batch_(ik_id_data.batch), nc_(num_eq_c)
   {
     loikb_options o{};
@@ -161,6 +161,7 @@ public:
     o.mu_update_strat = mu_update_strat; o.num_eq_c = num_eq_c; o.eq_c_dim = eq_c_dim; o.warm_start = warm_start;
     o.tol_tail_solve = tol_tail_solve; o.verbose = verbose; o.logging = logging;
     o.batch = batch_; o.device = device; o.precision = LOIKB_F64; o.flags = flags;
+    o.eq_c_capacity = eq_c_capacity;  // room for AddEqConstraint (0: num_eq_c slots, as upstream sizes yis / Aty)
     const loikb_model_desc d = model_.desc();
     check(loikb_create(&d, &o, &h_));
     rho_ = rho; tol_tail_solve_ = tol_tail_solve; tol_primal_inf_ = tol_primal_inf; tol_dual_inf_ = tol_dual_inf;
@@ -213,6 +214,62 @@ public:
     if (bis.size() == 1 && batch_ > 1) flags |= LOIKB_B_SHARED;
     if (batch_ > 1 && q.size() == static_cast<std::size_t>(model_.nq)) flags |= LOIKB_Q_SHARED;
     check(loikb_solve_tailored(h_, q.data(), (int)c_id, Ai.data(), b.data(), flags));
+    solved();
+  }
+
+  // ---- IkProblemFormulationOptimized's editing methods (ik-id-description-optimized.hpp).  Upstream they sit behind the
+  // protected problem_ member (loik-loid-optimized.hpp:765): a subclass reaches them; here they are public.  They act on the
+  // problem the last SolveInit / Solve(q, H_ref, ...) set and stay in force until the next one.
+  // UpdateReferences(H_refs, v_refs), :103-121: one weight and target per joint, index 0 = the universe
+  void UpdateReferences(const std::vector<Mat6x6>& H_refs, const std::vector<Motion>& v_refs)
+  {
+    if (H_refs.size() != v_refs.size() || H_refs.size() != static_cast<std::size_t>(model_.njoints))
+      throw std::runtime_error("[IkProblemFormulation::UpdateReferences]: input arguments 'H_refs', 'v_refs' have wrong size!!");
+    DVec H(H_refs.size() * 36), v(v_refs.size() * 6);
+    for (std::size_t i = 0; i < H_refs.size(); ++i) {
+      for (int k = 0; k < 36; ++k) H[36 * i + k] = H_refs[i][k];
+      for (int k = 0; k < 6; ++k) v[6 * i + k] = v_refs[i][k];
+    }
+    check(loikb_update_references(h_, H.data(), v.data(), (int)H_refs.size()));
+  }
+  // UpdateEqConstraint(c_id, Ai, bi) :178-218 and (c_id, bi) :224-238; bis: one per instance or one for the batch
+  void UpdateEqConstraint(const Index c_id, const Mat6x6& Ai, const std::vector<Vec6>& bis)
+  {
+    const DVec b = flat(bis);
+    check(loikb_update_eq_constraint(h_, (int)c_id, Ai.data(), b.data(), LOIKB_A_SHARED | b_flag(bis)));
+  }
+  void UpdateEqConstraint(const Index c_id, const std::vector<Vec6>& bis)
+  {
+    const DVec b = flat(bis);
+    check(loikb_update_eq_constraint(h_, (int)c_id, nullptr, b.data(), b_flag(bis)));
+  }
+  // AddEqConstraint, :244-286 (needs a free slot: constructor argument eq_c_capacity)
+  void AddEqConstraint(const Index c_id, const Mat6x6& Ai, const std::vector<Vec6>& bis)
+  {
+    const DVec b = flat(bis);
+    check(loikb_add_eq_constraint(h_, (int)c_id, Ai.data(), b.data(), LOIKB_A_SHARED | b_flag(bis)));
+    resize_constraints();
+  }
+  // RemoveEqConstraint, :292-319; false: nothing to remove (upstream prints a warning)
+  bool RemoveEqConstraint(const Index c_id)
+  {
+    const int rc = loikb_remove_eq_constraint(h_, (int)c_id);
+    if (rc < 0) check(rc);
+    resize_constraints();
+    return rc == LOIKB_OK;
+  }
+  std::vector<Index> active_task_constraint_ids() const
+  {
+    std::vector<int> ids(static_cast<std::size_t>(loikb_eq_c_capacity(h_)) + 1);
+    const int n = loikb_active_constraint_ids(h_, ids.data(), (int)ids.size());
+    return std::vector<Index>(ids.begin(), ids.begin() + n);
+  }
+  // solve on the edited set without rewriting a constraint (not upstream, whose tailored Solve always updates one)
+  void Solve(const DVec& q)
+  {
+    int flags = 0;
+    if (batch_ > 1 && q.size() == static_cast<std::size_t>(model_.nq)) flags |= LOIKB_Q_SHARED;
+    check(loikb_solve_tailored(h_, q.data(), -1, nullptr, nullptr, flags));
     solved();
   }
 
@@ -341,6 +398,24 @@ private:
       if (B > 1 && q.size() == static_cast<std::size_t>(s.model_.nq)) flags |= LOIKB_Q_SHARED;
     }
   };
+
+  static DVec flat(const std::vector<Vec6>& bis)
+  {
+    DVec b(bis.size() * 6);
+    for (std::size_t i = 0; i < bis.size(); ++i)
+      for (int k = 0; k < 6; ++k) b[6 * i + k] = bis[i][k];
+    return b;
+  }
+  int b_flag(const std::vector<Vec6>& bis) const { return (bis.size() == 1 && batch_ > 1) ? LOIKB_B_SHARED : 0; }
+  // yis / Aty of the data object follow nc_eq_ (upstream never resizes them: its AddEqConstraint is deactivated)
+  void resize_constraints()
+  {
+    nc_ = loikb_num_eq_c(h_);
+    ik_id_data_.num_eq_c = nc_;
+    ik_id_data_.yis.assign(static_cast<std::size_t>(batch_) * nc_ * 6, 0.0);
+    ik_id_data_.Aty.buf_.assign(static_cast<std::size_t>(batch_) * nc_ * 6, 0.0);
+    ++generation_;
+  }
 
   void check(int rc) const
   {

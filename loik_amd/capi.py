@@ -37,7 +37,7 @@ class Options(C.Structure):
                 ("tol_tail_solve", C.c_double), ("verbose", C.c_int), ("logging", C.c_int),
                 ("batch", C.c_int), ("device", C.c_int), ("precision", C.c_int), ("flags", C.c_int),
                 ("max_launch_iters", C.c_int), ("compact_min_instances", C.c_int),
-                ("tail_max_instances", C.c_int)]
+                ("tail_max_instances", C.c_int), ("eq_c_capacity", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -77,7 +77,9 @@ EXPORTED_SYMBOLS = [
     "loikb_solve_tailored", "loikb_set_max_iter", "loikb_set_rho", "loikb_set_mu", "loikb_set_tol",
     "loikb_set_tol_primal_inf", "loikb_set_tol_tail_solve", "loikb_set_warm_start", "loikb_get", "loikb_get_stats",
     "loikb_batch", "loikb_nv", "loikb_njoints", "loikb_last_error", "loikb_status_string", "loikb_version",
-    "loikb_device_count", "loikb_sweep_schedule", "loikb_integrate", "loikb_synchronize", "loikb_plan_string", "loikb_pass", "loikb_builtin_model", "loikb_builtin_joint_name",
+    "loikb_device_count", "loikb_sweep_schedule", "loikb_integrate", "loikb_synchronize", "loikb_plan_string", "loikb_pass",
+    "loikb_update_references", "loikb_update_eq_constraint", "loikb_add_eq_constraint", "loikb_remove_eq_constraint",
+    "loikb_num_eq_c", "loikb_eq_c_capacity", "loikb_active_constraint_ids", "loikb_builtin_model", "loikb_builtin_joint_name",
     "loikb_builtin_joint_id"]
 
 _lib = None
@@ -108,6 +110,13 @@ def lib():
     L.loikb_plan_string.restype = C.c_char_p
     L.loikb_sweep_schedule.argtypes = [_ip, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip]
     L.loikb_solve_tailored.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.loikb_update_references.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+    L.loikb_update_eq_constraint.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.loikb_add_eq_constraint.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.loikb_remove_eq_constraint.argtypes = [C.c_void_p, C.c_int]
+    L.loikb_num_eq_c.argtypes = [C.c_void_p]
+    L.loikb_eq_c_capacity.argtypes = [C.c_void_p]
+    L.loikb_active_constraint_ids.argtypes = [C.c_void_p, _ip, C.c_int]
     L.loikb_set_max_iter.argtypes = [C.c_void_p, C.c_int]
     for n in ["loikb_set_rho", "loikb_set_mu", "loikb_set_tol_primal_inf", "loikb_set_tol_tail_solve"]:
         getattr(L, n).argtypes = [C.c_void_p, C.c_double]
@@ -259,7 +268,7 @@ class BatchedLoik:
     def __init__(self, model, batch, max_iter=200, tol_abs=1e-3, tol_rel=1e-3, tol_primal_inf=1e-2, tol_dual_inf=1e-2,
                  rho=1e-5, mu=1e-2, mu_equality_scale_factor=1e4, mu_update_strat=0, num_eq_c=1, eq_c_dim=6,
                  warm_start=False, tol_tail_solve=1e-1, verbose=False, logging=False, device=0, precision=F64, flags=0,
-                 max_launch_iters=0, compact_min_instances=0, tail_max_instances=0):
+                 max_launch_iters=0, compact_min_instances=0, tail_max_instances=0, eq_c_capacity=0):
         self.L = lib()
         self.model = model
         self.batch = int(batch)
@@ -267,7 +276,7 @@ class BatchedLoik:
         self.opts = Options(max_iter, tol_abs, tol_rel, tol_primal_inf, tol_dual_inf, rho, mu, mu_equality_scale_factor,
                             mu_update_strat, num_eq_c, eq_c_dim, int(bool(warm_start)), tol_tail_solve,
                             int(bool(verbose)), int(bool(logging)), self.batch, device, precision, flags, max_launch_iters,
-                            compact_min_instances, tail_max_instances)
+                            compact_min_instances, tail_max_instances, int(eq_c_capacity))
         self._desc = model.desc()
         h = C.c_void_p()
         _check(self.L.loikb_create(C.byref(self._desc), C.byref(self.opts), C.byref(h)))
@@ -365,6 +374,10 @@ class BatchedLoik:
             qp, qd, qf = None, None, 0
             if q is not None:  # None: the q resident on the device
                 qp, qd, qf, k0 = self._prep(q, "q", self.model.nq, Q_SHARED)
+            if int(c_id) < 0:  # no constraint update: solve on the set AddEqConstraint / RemoveEqConstraint left
+                flags = qf | (IN_DEVICE if qd and not qf else 0)
+                _check(self.L.loikb_solve_tailored(self.h, qp, -1, None, None, flags))
+                return
             Ap, Ad, Af, k1 = self._prep(Ai, "Ai", 36, A_SHARED)
             bp, bd, bf, k2 = self._prep(bi, "bi", 6, B_SHARED)
             flags = qf | Af | bf
@@ -376,6 +389,49 @@ class BatchedLoik:
             _check(self.L.loikb_solve_tailored(self.h, qp, int(c_id), Ap, bp, flags))
         else:
             raise TypeError("Solve() takes 0, 4 or 8 arguments")
+
+    # IkProblemFormulationOptimized's editing methods (ik-id-description-optimized.hpp; `problem_` is protected upstream)
+    def UpdateReferences(self, H_refs, v_refs):
+        """one weight [6][6] and one target [6] per joint of the model incl. the universe (hpp:103-121); in force for Solve() /
+        the tailored Solve until the next SolveInit broadcasts one pair again"""
+        H = _f64(np.asarray(H_refs, dtype=np.float64).reshape(-1, 36)); v = _f64(np.asarray(v_refs, dtype=np.float64).reshape(-1, 6))
+        n = H.shape[0] if H.shape[0] == v.shape[0] else -1
+        _check(self.L.loikb_update_references(self.h, H.ctypes.data_as(_dp), v.ctypes.data_as(_dp), n))
+
+    def _edit_args(self, Ai, bi):
+        Ap, Ad, Af, k1 = (None, None, 0, None) if Ai is None else self._prep(Ai, "Ai", 36, A_SHARED)
+        bp, bd, bf, k2 = self._prep(bi, "bi", 6, B_SHARED)
+        flags = Af | bf
+        devs = [d for d, f in ((Ad, Af), (bd, bf)) if d is not None and not f]
+        if any(devs):
+            if not all(devs):
+                raise ValueError("per-instance inputs must be all host or all device arrays")
+            flags |= IN_DEVICE
+        return Ap, bp, flags, (k1, k2)
+
+    def UpdateEqConstraint(self, c_id, *a):
+        """UpdateEqConstraint(c_id, Ai, bi) (hpp:178-218) | UpdateEqConstraint(c_id, bi) (hpp:224-238)"""
+        Ai, bi = (None, a[0]) if len(a) == 1 else a
+        Ap, bp, flags, keep = self._edit_args(Ai, bi)
+        _check(self.L.loikb_update_eq_constraint(self.h, int(c_id), Ap, bp, flags))
+
+    def AddEqConstraint(self, c_id, Ai, bi):
+        """hpp:244-286; needs a free slot (constructor keyword eq_c_capacity)"""
+        Ap, bp, flags, keep = self._edit_args(Ai, bi)
+        _check(self.L.loikb_add_eq_constraint(self.h, int(c_id), Ap, bp, flags))
+
+    def RemoveEqConstraint(self, c_id):
+        """hpp:292-319; False when there was nothing to remove (upstream: a warning on stderr)"""
+        rc = self.L.loikb_remove_eq_constraint(self.h, int(c_id))
+        if rc < 0:
+            _check(rc)
+        return rc == 0
+
+    def active_task_constraint_ids(self):
+        n = self.L.loikb_num_eq_c(self.h)
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        self.L.loikb_active_constraint_ids(self.h, out.ctypes.data_as(_ip), n)
+        return [int(x) for x in out[:n]]
 
     # pass-level public methods of the reference (loik-loid-optimized.hpp:192-264): the debug path of loik_passes.hpp
     def _pass(self, k): _check(self.L.loikb_pass(self.h, k))
@@ -414,7 +470,7 @@ class BatchedLoik:
     def get(self, name, out=None):
         """one field for the whole batch as a numpy array (or into a device pointer / torch tensor `out`)"""
         fid = FIELD_ID[name]
-        B, nb, nv, nc = self.batch, self.model.njoints - 1, self.model.nv, self.nc
+        B, nb, nv, nc = self.batch, self.model.njoints - 1, self.model.nv, self.L.loikb_num_eq_c(self.h)
         # per DoF: [B][nv]; per link: [B][nb].  r / Dinv / UDinv are inter-sweep temporaries of the device's
         # elimination: per DoF, equal to upstream's per-joint values for 1-DoF joints only
         shapes = {"z": (B, nv), "nu": (B, nv), "w": (B, nv), "Stf_plus_w": (B, nv), "r": (B, nv), "Dinv": (B, nv),

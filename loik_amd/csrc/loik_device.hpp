@@ -140,6 +140,10 @@ struct Params {
   T Href[36];  // full matrix (used as-is for Href*v, hxx:149)
   T Hv[6];     // H_ref * v_ref
   T Hv_inf_norm;
+  // UpdateReferences (ik-id-description-optimized.hpp:103-121): one weight and one target per link.  nullptr = the
+  // broadcast pair above; else [nj][HREF_ROW] rows (H_ref_i row-major 36, then H_ref_i v_ref_i), row 0 and the rows of
+  // massless chain links zero.  The lean kernel does not take it (the engine plan sends such solves to k_tail / k_solve).
+  const T* href_tab;
   T rho, mu0, mu_scale;
   T tol_abs, tol_rel, tol_primal_inf, tol_tail_solve;
   int max_iter;
@@ -483,6 +487,8 @@ __device__ __forceinline__ void symv(const T* h, const T* x, T* y)
   }
 }
 
+constexpr int HREF_ROW = 42;
+
 // Href * v (hxx:149, :228).  HDIAG: H_ref is diagonal (e.g. the identity of every reference test), 6 uniform
 // scalars instead of 36 -- keeps the kernel's SGPR budget for the joint descriptor.
 template <typename T, bool HDIAG>
@@ -508,16 +514,46 @@ __device__ __forceinline__ void href_mul(const T* Href, const T* v, T* o)
 template <typename T, bool HDIAG>
 struct LinkCost {
   T rho, Hv[6], Href[36];
-  __device__ __forceinline__ LinkCost(const Params<T>& P, int jflags)
+  __device__ __forceinline__ LinkCost(const Params<T>& P, int jflags, int joint)
   {
     const bool ml = jflags & JF_MASSLESS;
     rho = ml ? T(0) : P.rho;
+    if (P.href_tab) {  // per-link references: the joint's row of the table (uniform address; zero for a massless link)
+      const T* row = P.href_tab + (size_t)joint * HREF_ROW;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) Hv[k] = ml ? T(0) : P.Hv[k];
+      for (int k = 0; k < 6; ++k) Hv[k] = row[36 + k];
 #pragma unroll
-    for (int k = 0; k < 36; ++k) Href[k] = (HDIAG && (k % 7 != 0)) ? T(0) : (ml ? T(0) : P.Href[k]);
+      for (int k = 0; k < 36; ++k) Href[k] = (HDIAG && (k % 7 != 0)) ? T(0) : row[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Hv[k] = ml ? T(0) : P.Hv[k];
+#pragma unroll
+      for (int k = 0; k < 36; ++k) Href[k] = (HDIAG && (k % 7 != 0)) ? T(0) : (ml ? T(0) : P.Href[k]);
+    }
   }
 };
+
+// the same for the engines with one joint per lane (k_tail): `row` = the lane's row of the table or nullptr
+template <typename T, bool HDIAG>
+__device__ __forceinline__ void href_mul_link(const Params<T>& P, const T* row, const T* v, T* o)
+{
+  if (row) {
+    if (HDIAG) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) o[r] = row[7 * r] * v[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        T a = row[6 * r] * v[0];
+#pragma unroll
+        for (int k = 1; k < 6; ++k) a += row[6 * r + k] * v[k];
+        o[r] = a;
+      }
+    }
+  } else {
+    href_mul<T, HDIAG>(P.Href, v, o);
+  }
+}
 
 // ---- team schedule ---------------------------------------------------------------------------------
 // A tile (64 instances, one per lane) is advanced by a TEAM of `nw` wavefronts (one workgroup).  Every wavefront
@@ -692,7 +728,7 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
         dd_cached = ldp<T>(rec, JP_R).y;  // Dinv shares the pair of r: read it to rewrite the full pair below
       }
       // FwdPass1 (hxx:304-315): H_i = rho I + H_ref ; p_i = -rho v_prev - Hv   (a massless chain link: both zero)
-      const LinkCost<T, HDIAG> lc(P, d.flags);
+      const LinkCost<T, HDIAG> lc(P, d.flags, i);
       if (WITH_H) {
 #pragma unroll
         for (int r = 0; r < 6; ++r)
@@ -869,7 +905,7 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
       for (int k = 0; k < 6; ++k) dv6[k] = vi[k] - in.vprev[k];
       // Href_v (hxx:149-153)
       // a massless chain link is not a body of the model: H_ref = 0 for it, and its velocity stays out of the norm
-      const LinkCost<T, HDIAG> lc(P, d.flags);
+      const LinkCost<T, HDIAG> lc(P, d.flags, i);
       href_mul<T, HDIAG>(lc.Href, vi, hrv);
       N.href_v = tmax(N.href_v, inf6(hrv));
       if (!(d.flags & JF_MASSLESS)) N.dvis = tmax(N.dvis, inf6(dv6));  // hxx:156-158
@@ -1024,7 +1060,7 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
 #pragma unroll
       for (int k = 0; k < 6; ++k) sf[k] = T(0);
       edge_gather<T, 0, 6>(sd, tm.rlist, edge, acc, sf, lane);
-      const LinkCost<T, HDIAG> lc(P, d.flags);
+      const LinkCost<T, HDIAG> lc(P, d.flags, i);
       href_mul<T, HDIAG>(lc.Href, vi, hv);
       force_balance<T>(P, Bf, d, lp, mu_eq, lc.rho, vi, hv, pb, sf, fi);
       st6<T>(rec, JP_F, fi);
@@ -1126,7 +1162,7 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
       const T wi = in.wz.x, sold = in.nus.y;
       // ---- iteration k: f_i by force balance, g_i = (Aty_c | 0) + sum_children act(f_j) - f_i   (hxx:438-439, :210-212)
       //      iteration k+1: p_i = -rho v_i - Hv (+ Aty_c - mu_eq Atb_c)       (hxx:304-315, :321-334)
-      const LinkCost<T, HDIAG> lc(P, d.flags);
+      const LinkCost<T, HDIAG> lc(P, d.flags, i);
 #pragma unroll
       for (int k = 0; k < 6; ++k) { pp[k] = -lc.rho * in.vi[k] - lc.Hv[k]; sf[k] = T(0); }
       if (d.cslot >= 0) {
@@ -1637,7 +1673,7 @@ __global__ void k_download_rows(char* tiles, Layout L, const int* __restrict__ r
 // accumulators of the leaf -> root recursion.  Same arithmetic as sweep_bwd<.., true, ..>.
 template <typename T>
 __global__ void k_rebuild_his(const char* tiles, Layout L, const JointDesc* __restrict__ jd, const T* __restrict__ uni,
-                              T rho, T mu_scale, const T* __restrict__ Href, int a_shared, int B, double* __restrict__ out)
+                              T rho, T mu_scale, const T* __restrict__ href_tab, int a_shared, int B, double* __restrict__ out)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -1648,7 +1684,8 @@ __global__ void k_rebuild_his(const char* tiles, Layout L, const JointDesc* __re
   for (int i = 1; i <= L.nb; ++i) {
     for (int r = 0; r < 6; ++r)
       for (int c = r; c < 6; ++c)
-        o[(i - 1) * 21 + sym(r, c)] = (jd[i].flags & JF_MASSLESS) ? 0.0 : (double)((r == c ? rho : T(0)) + Href[6 * r + c]);
+        o[(i - 1) * 21 + sym(r, c)] =
+            (jd[i].flags & JF_MASSLESS) ? 0.0 : (double)((r == c ? rho : T(0)) + href_tab[(size_t)i * HREF_ROW + 6 * r + c]);
     if (jd[i].cslot >= 0) {
       const int cs = jd[i].cslot;
       for (int k = 0; k < 21; ++k) {
@@ -1744,6 +1781,26 @@ __global__ void k_constraint_products(char* tiles, Layout L, const T* __restrict
     }
   }
   *elem_ptr<T>(srec, SP_BI, 0) = bn;
+}
+
+// Editing the constraint set between solves (AddEqConstraint / RemoveEqConstraint, ik-id-description-optimized.hpp:244-319).
+// shift != 0: records [c_lo, c_hi) of every instance <- the records one slot up (an erased entry: the later ones move down,
+// hpp:305-309, and their duals yis/Aty travel with them); the last record of the range -- with shift == 0 every record of it --
+// becomes the NULL constraint: A = 0, b = 0, y = 0.  A null constraint adds mu_eq * 0 to H_i, 0 to p_i, 0 to every norm and
+// keeps y = 0: the slot is there for the kernels' fixed layout and changes no number.
+template <typename T>
+__global__ void k_edit_constraints(char* tiles, Layout L, int c_lo, int c_hi, int shift, int B)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  char* lp = lane_ptr<T>(tiles, L, b);
+  for (int c = c_lo; c < c_hi; ++c) {
+    char* dst = lp + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+    const char* src = dst + (size_t)L.crec * pair_bytes<T>();
+    const bool copy = shift && c + 1 < c_hi;
+    for (int k = 0; k < L.crec; ++k)
+      for (int h = 0; h < 2; ++h) *elem_ptr<T>(dst, k, h) = copy ? *elem_ptr<T>(const_cast<char*>(src), k, h) : T(0);
+  }
 }
 
 // resets (one wavefront per tile), bits of `what`:

@@ -140,7 +140,18 @@ struct loikb_solver_impl {
   // problem (uniform part)
   double Href[36]{}, vref[6]{}, Hv[6]{};
   double Hv_inf_norm = 0.0;
-  std::vector<int> active_ids;
+  // the same per device joint: [nj][HREF_ROW] = (H_ref_i, H_ref_i v_ref_i), rows of the universe and of massless chain
+  // links zero.  Broadcast by SolveInit (UpdateReference), per link after loikb_update_references (UpdateReferences).
+  std::vector<double> href_tab;
+  bool per_link = false;
+  void* d_href = nullptr;       // the table in the solve precision
+  double* d_href64 = nullptr;   // and in double (== d_href for an fp64 solver): residual-vector getter
+  std::vector<float> href_tab32;
+  std::vector<int> active_ids;     // [nc_active] = active_task_constraint_ids_
+  // `nc` constraint slots exist on the device (eq_c_capacity >= num_eq_c); nc_active = nc_eq_ of them carry a constraint,
+  // the others are null constraints (k_edit_constraints) parked on bodies that have none
+  int nc_active = 0;
+  std::vector<double> A_host;      // [nc][36] the shared A per slot (host mirror: RemoveEqConstraint moves entries down)
   bool have_problem = false;
   bool have_q = false;
   bool a_shared = true, bnd_shared = true;
@@ -574,6 +585,7 @@ Params<T> make_params(loikb_solver_impl* S)
   for (int k = 0; k < 36; ++k) P.Href[k] = (T)S->Href[k];
   for (int k = 0; k < 6; ++k) P.Hv[k] = (T)S->Hv[k];
   P.Hv_inf_norm = (T)S->Hv_inf_norm;
+  P.href_tab = S->per_link ? (const T*)S->d_href : nullptr;
   P.rho = (T)S->opt.rho; P.mu0 = (T)S->opt.mu; P.mu_scale = (T)S->opt.mu_equality_scale_factor;
   P.tol_abs = (T)S->opt.tol_abs; P.tol_rel = (T)S->opt.tol_rel; P.tol_primal_inf = (T)S->opt.tol_primal_inf;
   P.tol_tail_solve = (T)S->opt.tol_tail_solve;
@@ -886,19 +898,126 @@ int ensure_layout(loikb_solver_impl* S, bool a_shared)
   return relayout ? reset_home(S, RS_SOLVER | RS_HCACHE) : LOIKB_OK;
 }
 
+
+// upload S->href_tab (see the member) to the device in the solve precision and in double
+int upload_href_tab(loikb_solver_impl* S)
+{
+  const size_t n = (size_t)S->nj * HREF_ROW;
+  if (!S->d_href64) {
+    int rc;
+    if ((rc = alloc_dev(S, (void**)&S->d_href64, n * sizeof(double)))) return rc;
+    if (S->f32) { if ((rc = alloc_dev(S, &S->d_href, n * sizeof(float)))) return rc; }
+    else S->d_href = S->d_href64;
+  }
+  // (the host vectors are members: they outlive the asynchronous copies; a second update waits for the stream first)
+  HIPCHK(hipMemcpyAsync(S->d_href64, S->href_tab.data(), n * sizeof(double), hipMemcpyHostToDevice, S->stream));
+  if (S->f32) {
+    S->href_tab32.assign(S->href_tab.begin(), S->href_tab.end());
+    HIPCHK(hipMemcpyAsync(S->d_href, S->href_tab32.data(), n * sizeof(float), hipMemcpyHostToDevice, S->stream));
+  }
+  HIPCHK(hipStreamSynchronize(S->stream));
+  return LOIKB_OK;
+}
+
+// rows of the table from one (H, v) pair per body of the caller's model ([ext_nj][36], [ext_nj][6]; stride 0 = broadcast)
+void fill_href_tab(loikb_solver_impl* S, const double* H, const double* v, size_t strideH, size_t stridev)
+{
+  S->href_tab.assign((size_t)S->nj * HREF_ROW, 0.0);
+  for (int e = 1; e < S->ext_nj; ++e) {
+    double* row = S->href_tab.data() + (size_t)S->link_of[e] * HREF_ROW;  // the chain link that carries the body
+    const double *He = H + strideH * e, *ve = v + stridev * e;
+    memcpy(row, He, 36 * sizeof(double));
+    for (int i = 0; i < 6; ++i) {
+      double a = 0.0;
+      for (int k = 0; k < 6; ++k) a += He[6 * i + k] * ve[k];
+      row[36 + i] = a;
+    }
+  }
+}
+
+static bool symmetric6(const double* H)
+{
+  for (int i = 0; i < 6; ++i)
+    for (int j = i + 1; j < 6; ++j)
+      if (std::fabs(H[6 * i + j] - H[6 * j + i]) > 1e-14 * (1.0 + std::fabs(H[6 * i + j]))) return false;
+  return true;
+}
+
+
+// joints <-> constraint slots: slot c < nc_active sits on the body active_ids[c]; the null slots behind them are parked on
+// the first bodies without a constraint (the kernels find a slot through its joint; where a null slot sits changes nothing)
+int bind_constraint_slots(loikb_solver_impl* S)
+{
+  for (int i = 1; i < S->nj; ++i) S->jd[i].cslot = -1;
+  for (int c = 0; c < S->nc_active; ++c) S->jd[S->link_of[S->active_ids[c]]].cslot = c;  // the device joint that carries the body
+  int e = 1;
+  for (int c = S->nc_active; c < S->nc; ++c) {
+    while (e < S->ext_nj && S->jd[S->link_of[e]].cslot >= 0) ++e;
+    if (e >= S->ext_nj) { g_last_error = "more constraint slots than bodies"; return LOIKB_ERR_EQ_C_SIZE; }
+    S->jd[S->link_of[e]].cslot = c;
+  }
+  S->pass_active = false;  // (the pass-level path copies the slot table when it starts)
+  return upload_jd(S);
+}
+
+int edit_constraints(loikb_solver_impl* S, int c_lo, int c_hi, int shift)
+{
+  if (S->f32) hipLaunchKernelGGL(k_edit_constraints<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, c_lo, c_hi, shift, S->B);
+  else hipLaunchKernelGGL(k_edit_constraints<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, c_lo, c_hi, shift, S->B);
+  HIPCHK(hipGetLastError());
+  return LOIKB_OK;
+}
+
+// slots [c_lo, c_hi) become null constraints
+int null_constraint_slots(loikb_solver_impl* S, int c_lo, int c_hi)
+{
+  int rc;
+  if ((rc = edit_constraints(S, c_lo, c_hi, 0))) return rc;
+  const double zero[36] = {0};
+  for (int c = c_lo; c < c_hi; ++c) {
+    memset(S->A_host.data() + 36 * c, 0, 36 * sizeof(double));
+    if ((rc = upload_shared_A(S, zero, c))) return rc;   // (harmless when A is per instance: the uniform copy is unused)
+  }
+  return LOIKB_OK;
+}
+
+// problem_.UpdateEqConstraint(c_id, Ai, bi), ik-id-description-optimized.hpp:178-218; Ai == NULL: the (c_id, bi) overload,
+// :224-238, which keeps the old Ai
+int update_eq_single(loikb_solver_impl* S, int c_id, const double* Ai, const double* bi, int in_flags)
+{
+  int found = -1, count = 0;
+  for (int c = 0; c < S->nc_active; ++c)
+    if (S->active_ids[c] == c_id) { if (found < 0) found = c; ++count; }
+  if (found < 0) { g_last_error = loikb_status_string(LOIKB_ERR_NO_SUCH_CONSTRAINT); return LOIKB_ERR_NO_SUCH_CONSTRAINT; }
+  if (count > 1) { g_last_error = loikb_status_string(LOIKB_ERR_DUP_CONSTRAINT); return LOIKB_ERR_DUP_CONSTRAINT; }
+  const bool dev = in_flags & LOIKB_IN_DEVICE;
+  int rc = LOIKB_OK;
+  if (Ai) {
+    const bool a_shared_in = in_flags & LOIKB_A_SHARED;
+    if (a_shared_in != S->a_shared) {
+      g_last_error = "UpdateEqConstraint: A sharing mode must match SolveInit";
+      return LOIKB_ERR_ARG;
+    }
+    if (a_shared_in) {
+      memcpy(S->A_host.data() + 36 * found, Ai, 36 * sizeof(double));
+      rc = upload_shared_A(S, Ai, found);
+    } else {
+      rc = upload_rows(S, Ai, rowmap_constraint(S, found, CP_A, 36), dev, false);
+    }
+    if (rc) return rc;
+  }
+  if ((rc = upload_rows(S, bi, rowmap_constraint(S, found, CP_B, 6), dev, in_flags & LOIKB_B_SHARED))) return rc;
+  return constraint_products(S, found, found + 1, true);
+}
+
 // problem_.UpdateReference / UpdateIneqConstraints / UpdateEqConstraints (ik-id-description-optimized.hpp:78-171,
 // :325-339) with the batch layouts of loik_amd.h
 int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, const int* c_ids, int nc,
                 const double* Ais, const double* bis, const double* lb, const double* ub, int nbound, int in_flags)
 {
   if (nbound != S->nv) { g_last_error = "lb/ub dimension differs from model.nv"; return LOIKB_ERR_INEQ_DIM; }
-  if (nc != S->nc) { g_last_error = "number of equality constraints doesn't match initialization"; return LOIKB_ERR_EQ_C_SIZE; }
-  for (int i = 0; i < 6; ++i)
-    for (int j = i + 1; j < 6; ++j)
-      if (std::fabs(H_ref[6 * i + j] - H_ref[6 * j + i]) > 1e-14 * (1.0 + std::fabs(H_ref[6 * i + j]))) {
-        g_last_error = "H_ref must be symmetric";
-        return LOIKB_ERR_HREF_NOT_SYMMETRIC;
-      }
+  if (nc != S->nc_active) { g_last_error = "number of equality constraints doesn't match initialization"; return LOIKB_ERR_EQ_C_SIZE; }
+  if (!symmetric6(H_ref)) { g_last_error = "H_ref must be symmetric"; return LOIKB_ERR_HREF_NOT_SYMMETRIC; }
   for (int c = 0; c < nc; ++c) {
     if (c_ids[c] < 1 || c_ids[c] >= S->ext_nj) { g_last_error = "constraint link id out of range"; return LOIKB_ERR_ARG; }
     for (int c2 = 0; c2 < c; ++c2)
@@ -907,6 +1026,7 @@ int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, 
   const bool dev = in_flags & LOIKB_IN_DEVICE;
   int rc;
   // UpdateReference: Hv = H_ref v_ref, Hv_inf_norm_ (hpp:85-96)
+  const bool same_ref = S->d_href64 && !S->per_link && !memcmp(S->Href, H_ref, sizeof(S->Href)) && !memcmp(S->vref, v_ref, sizeof(S->vref));
   memcpy(S->Href, H_ref, sizeof(S->Href));
   memcpy(S->vref, v_ref, sizeof(S->vref));
   S->href_diag = true;
@@ -919,6 +1039,11 @@ int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, 
     for (int k = 0; k < 6; ++k) a += H_ref[6 * i + k] * v_ref[k];
     S->Hv[i] = a;
     if (std::fabs(a) > S->Hv_inf_norm) S->Hv_inf_norm = std::fabs(a);
+  }
+  S->per_link = false;
+  if (!same_ref) {  // (the table the getters and the pass-level path read; the engines take the broadcast pair as arguments)
+    fill_href_tab(S, H_ref, v_ref, 0, 0);
+    if ((rc = upload_href_tab(S))) return rc;
   }
   // UpdateIneqConstraints
   S->bnd_shared = in_flags & LOIKB_BOUNDS_SHARED;
@@ -933,16 +1058,19 @@ int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, 
   }
   // UpdateEqConstraints
   S->active_ids.assign(c_ids, c_ids + nc);
-  for (int i = 1; i < S->nj; ++i) S->jd[i].cslot = -1;
-  for (int c = 0; c < nc; ++c) S->jd[S->link_of[c_ids[c]]].cslot = c;  // the device joint that carries the body
-  if ((rc = upload_jd(S))) return rc;
+  if ((rc = bind_constraint_slots(S))) return rc;
   S->a_shared = in_flags & LOIKB_A_SHARED;
+  S->A_host.assign((size_t)S->nc * 36, 0.0);
+  if (nc < S->nc && (rc = null_constraint_slots(S, nc, S->nc))) return rc;
   for (int c = 0; c < nc; ++c) {
     if (S->a_shared) {
+      memcpy(S->A_host.data() + 36 * c, Ais + 36 * c, 36 * sizeof(double));
       if ((rc = upload_shared_A(S, Ais + 36 * c, c))) return rc;
     }
   }
   if (!S->a_shared && nc > 0) {
+    // (instance-major [B][nc][36]: the rows of the active slots; with spare slots the tile records are not contiguous per
+    //  instance in the caller's array, which the row map takes care of)
     std::vector<int> rm;
     for (int c = 0; c < nc; ++c) { auto r = rowmap_constraint(S, c, CP_A, 36); rm.insert(rm.end(), r.begin(), r.end()); }
     if ((rc = upload_rows(S, Ais, rm, dev, false))) return rc;
@@ -952,7 +1080,7 @@ int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, 
     for (int c = 0; c < nc; ++c) { auto r = rowmap_constraint(S, c, CP_B, 6); rm.insert(rm.end(), r.begin(), r.end()); }
     if ((rc = upload_rows(S, bis, rm, dev, in_flags & LOIKB_B_SHARED))) return rc;
   }
-  if ((rc = constraint_products(S, 0, nc, false))) return rc;
+  if ((rc = constraint_products(S, 0, S->nc, false))) return rc;
   S->have_problem = true;
   return LOIKB_OK;
 }
@@ -1118,7 +1246,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     const int ndec = S->plan.ndec, kexp_lo = S->plan.kexp_lo;
     const size_t wave_lds = lean_lds_bytes<T>(S->nc, G, S->a_shared);
     // (k_lean's lane groups need whole wavefronts of work to pay: below 64 instances k_tail's direct path is as good)
-    const bool lean_ok = S->plan.lean && (P.mode & MODE_CACHE_H) && n >= 64;
+    const bool lean_ok = S->plan.lean && !S->per_link && (P.mode & MODE_CACHE_H) && n >= 64;  // (k_lean has no per-link table)
     if (lean_ok) {
       // decade slots are indexed by the instance's slot in the set (relaunches with shorter lists find them again);
       // the buffer was sized for the chunk at SolveInit (ensure_hslots)
@@ -1546,10 +1674,9 @@ __global__ void k_limi(char* tiles, Layout L, const JointDesc* __restrict__ jd, 
 //   primal: rows 6(c_id-1).. = A_c v_c - b_c for the constrained links, 0 elsewhere (hxx:433);
 //           tail = nu - z (hxx:394)
 //   dual:   rows 6(i-1).. = H_ref v_i - H_ref v_ref + g_i (hxx:228);  tail = S^T f + w (hxx:484)
-struct RefCost { double Href[36], Hv[6]; };
 template <typename T>
 __global__ void k_residual_vecs(char* tiles, Layout L, const JointDesc* __restrict__ jd, const T* __restrict__ uni,
-                                RefCost rc, int a_shared, const int* __restrict__ sel, int nl, int B, int dual,
+                                const double* __restrict__ href_tab, int a_shared, const int* __restrict__ sel, int nl, int B, int dual,
                                 double* __restrict__ out)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1564,10 +1691,11 @@ __global__ void k_residual_vecs(char* tiles, Layout L, const JointDesc* __restri
     if (dual) {
       T g[6];
       ld6<T>(rec, JP_G, g);
+      const double* row = href_tab + (size_t)i * HREF_ROW;
       for (int r = 0; r < 6; ++r) {
         double a = 0.0;
-        for (int k = 0; k < 6; ++k) a += rc.Href[6 * r + k] * (double)v[k];
-        o[6 * e + r] = a - rc.Hv[r] + (double)g[r];
+        for (int k = 0; k < 6; ++k) a += row[6 * r + k] * (double)v[k];
+        o[6 * e + r] = a - row[36 + r] + (double)g[r];
       }
     } else {
       const int cs = jd[i].cslot;
@@ -1658,6 +1786,8 @@ const char* loikb_status_string(int code)
   case LOIKB_ERR_MU_STRATEGY: return "[FirstOrderLoikOptimizedTpl::UpdateMu]: mu update strategy not supported";
   case LOIKB_ERR_MODEL:
     return "[IkProblemFormulation::IkProblemFormulation]: nb does not equal to nj - 1, robot model not supported !!!";
+  case LOIKB_ERR_REFS_SIZE:
+    return "[IkProblemFormulation::UpdateReferences]: input arguments 'H_refs', 'v_refs' have wrong size!!";
   case LOIKB_ERR_ARG: return "invalid argument";
   case LOIKB_ERR_HIP: return "HIP runtime error";
   case LOIKB_ERR_NO_DEVICE: return "no HIP device";
@@ -1686,7 +1816,9 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
   if (rc) { delete S; return rc; }
   S->opt = *opts;
   S->B = opts->batch;
-  S->nc = opts->num_eq_c;
+  if (opts->eq_c_capacity < 0) { g_last_error = "eq_c_capacity must be >= 0"; return LOIKB_ERR_ARG; }
+  S->nc = std::max(opts->num_eq_c, opts->eq_c_capacity);
+  S->nc_active = opts->num_eq_c;
   S->f32 = opts->precision == LOIKB_F32;
   S->esz = S->f32 ? 4 : 8;
   S->device = opts->device;
@@ -1784,6 +1916,37 @@ int loikb_solve_init(loikb_solver* S, const double* q, const double* H_ref, cons
   return LOIKB_OK;
 }
 
+// problem_.UpdateReferences(H_refs, v_refs), ik-id-description-optimized.hpp:103-121
+int loikb_update_references(loikb_solver* S, const double* H_refs, const double* v_refs, int n)
+{
+  if (!S || !H_refs || !v_refs) return LOIKB_ERR_ARG;
+  if (!S->have_problem) { g_last_error = "UpdateReferences() before SolveInit()"; return LOIKB_ERR_STATE; }
+  if (n != S->ext_nj) { g_last_error = "'H_refs', 'v_refs' have wrong size (one entry per joint incl. the universe)"; return LOIKB_ERR_REFS_SIZE; }
+  for (int e = 1; e < n; ++e)
+    if (!symmetric6(H_refs + 36 * e)) { g_last_error = "H_refs[i] must be symmetric"; return LOIKB_ERR_HREF_NOT_SYMMETRIC; }
+  HIPCHK(hipSetDevice(S->device));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  fill_href_tab(S, H_refs, v_refs, 36, 6);
+  // Hv_inf_norm_ is not reset here and the universe's entry counts (hpp:110-118: the loop runs over all nj entries)
+  S->href_diag = true;
+  for (int e = 0; e < n; ++e) {
+    const double *He = H_refs + 36 * e, *ve = v_refs + 6 * e;
+    for (int i = 0; i < 6; ++i) {
+      double a = 0.0;
+      for (int k = 0; k < 6; ++k) {
+        a += He[6 * i + k] * ve[k];
+        if (e > 0 && i != k && He[6 * i + k] != 0.0) S->href_diag = false;
+      }
+      if (std::fabs(a) > S->Hv_inf_norm) S->Hv_inf_norm = std::fabs(a);
+    }
+  }
+  S->per_link = true;
+  S->pass_active = false;   // (the pass-level path re-reads the problem on its next call)
+  int rc;
+  if ((rc = upload_href_tab(S))) return rc;
+  return reset_home(S, RS_HCACHE);  // H_i = rho I + H_ref_i + ...: the cached factors are stale
+}
+
 int loikb_solve(loikb_solver* S)
 {
   if (!S) return LOIKB_ERR_ARG;
@@ -1806,31 +1969,94 @@ int loikb_solve_full(loikb_solver* S, const double* q, const double* H_ref, cons
 
 int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const double* Ai, const double* bi, int in_flags)
 {
-  if (!S || !Ai || !bi) return LOIKB_ERR_ARG;  // q == NULL: the configurations resident on the device
+  if (!S || (c_id >= 0 && (!Ai || !bi))) return LOIKB_ERR_ARG;  // q == NULL: the configurations resident on the device
   if (!S->have_problem) { g_last_error = "tailored Solve() before SolveInit()"; return LOIKB_ERR_STATE; }
   HIPCHK(hipSetDevice(S->device));
   int rc;
   // ik_id_data_.Reset(warm_start); ResetSolver()  (hpp:604-608)
   if ((rc = reset_home(S, RS_SOLVER | (S->opt.warm_start ? 0 : RS_DATA_COLD)))) return rc;
-  // problem_.UpdateEqConstraint(c_id, Ai, bi), ik-id-description-optimized.hpp:178-218
-  int found = -1, count = 0;
-  for (int c = 0; c < S->nc; ++c)
-    if (S->active_ids[c] == c_id) { if (found < 0) found = c; ++count; }
-  if (found < 0) { g_last_error = loikb_status_string(LOIKB_ERR_NO_SUCH_CONSTRAINT); return LOIKB_ERR_NO_SUCH_CONSTRAINT; }
-  if (count > 1) { g_last_error = loikb_status_string(LOIKB_ERR_DUP_CONSTRAINT); return LOIKB_ERR_DUP_CONSTRAINT; }
-  const bool dev = in_flags & LOIKB_IN_DEVICE;
-  const bool a_shared_in = in_flags & LOIKB_A_SHARED;
-  if (a_shared_in != S->a_shared) {
-    g_last_error = "tailored solve: A sharing mode must match SolveInit";
-    return LOIKB_ERR_ARG;
-  }
-  if (a_shared_in) rc = upload_shared_A(S, Ai, found);
-  else rc = upload_rows(S, Ai, rowmap_constraint(S, found, CP_A, 36), dev, false);
-  if (rc) return rc;
-  if ((rc = upload_rows(S, bi, rowmap_constraint(S, found, CP_B, 6), dev, in_flags & LOIKB_B_SHARED))) return rc;
-  if ((rc = constraint_products(S, found, found + 1, true))) return rc;
+  // problem_.UpdateEqConstraint(c_id, Ai, bi), ik-id-description-optimized.hpp:178-218.  c_id < 0: no constraint update (not
+  // upstream: the way to solve after AddEqConstraint / RemoveEqConstraint changed the set, possibly to the empty one)
+  if (c_id >= 0 && (rc = update_eq_single(S, c_id, Ai, bi, in_flags))) return rc;
   if ((rc = fwd_pass_init(S, q, in_flags))) return rc;
   return run_main_loop(S);
+}
+
+// problem_.UpdateEqConstraint (hpp:178-238), AddEqConstraint (:244-286), RemoveEqConstraint (:292-319) between solves
+int loikb_update_eq_constraint(loikb_solver* S, int c_id, const double* Ai, const double* bi, int in_flags)
+{
+  if (!S || !bi) return LOIKB_ERR_ARG;
+  if (!S->have_problem) { g_last_error = "UpdateEqConstraint() before SolveInit()"; return LOIKB_ERR_STATE; }
+  HIPCHK(hipSetDevice(S->device));
+  int rc;
+  if ((rc = update_eq_single(S, c_id, Ai, bi, in_flags))) return rc;
+  S->pass_active = false;
+  return reset_home(S, RS_HCACHE);  // H_i = rho I + H_ref + mu_eq AtA: the cached factors are stale
+}
+
+int loikb_add_eq_constraint(loikb_solver* S, int c_id, const double* Ai, const double* bi, int in_flags)
+{
+  if (!S || !Ai || !bi) return LOIKB_ERR_ARG;
+  if (!S->have_problem) { g_last_error = "AddEqConstraint() before SolveInit()"; return LOIKB_ERR_STATE; }
+  for (int c = 0; c < S->nc_active; ++c)
+    if (S->active_ids[c] == c_id) return loikb_update_eq_constraint(S, c_id, Ai, bi, in_flags);  // hpp:250-253
+  if (c_id < 1 || c_id >= S->ext_nj) { g_last_error = "constraint link id out of range"; return LOIKB_ERR_ARG; }
+  if (S->nc_active >= S->nc) {
+    g_last_error = "AddEqConstraint: no free constraint slot (loikb_options.eq_c_capacity)";
+    return LOIKB_ERR_EQ_C_SIZE;
+  }
+  HIPCHK(hipSetDevice(S->device));
+  int rc;
+  const int k = S->nc_active;
+  if ((rc = null_constraint_slots(S, k, k + 1))) return rc;  // the new constraint's dual starts at zero
+  S->active_ids.push_back(c_id);
+  ++S->nc_active;
+  if ((rc = bind_constraint_slots(S))) return rc;
+  if ((rc = update_eq_single(S, c_id, Ai, bi, in_flags))) {  // bis_inf_norm_ grows (hpp:281-283)
+    S->active_ids.pop_back();
+    --S->nc_active;
+    (void)bind_constraint_slots(S);
+    return rc;
+  }
+  return reset_home(S, RS_HCACHE);
+}
+
+int loikb_remove_eq_constraint(loikb_solver* S, int c_id)
+{
+  if (!S) return LOIKB_ERR_ARG;
+  if (!S->have_problem) { g_last_error = "RemoveEqConstraint() before SolveInit()"; return LOIKB_ERR_STATE; }
+  int found = -1;
+  for (int c = 0; c < S->nc_active; ++c)
+    if (S->active_ids[c] == c_id) { found = c; break; }
+  if (found < 0) {  // upstream prints this warning on stderr and returns (hpp:297-301)
+    g_last_error = "WARNING RemoveEqConstraint: no constraint defined at link id, nothing to remove";
+    return LOIKB_NOTHING_TO_REMOVE;
+  }
+  HIPCHK(hipSetDevice(S->device));
+  int rc;
+  // the entries behind it move down with their duals; the freed last slot becomes a null constraint
+  if ((rc = edit_constraints(S, found, S->nc_active, 1))) return rc;
+  for (int c = found; c + 1 < S->nc_active; ++c) {
+    memcpy(S->A_host.data() + 36 * c, S->A_host.data() + 36 * (c + 1), 36 * sizeof(double));
+    if (S->a_shared && (rc = upload_shared_A(S, S->A_host.data() + 36 * c, c))) return rc;
+  }
+  const double zero[36] = {0};
+  memset(S->A_host.data() + 36 * (S->nc_active - 1), 0, 36 * sizeof(double));
+  if ((rc = upload_shared_A(S, zero, S->nc_active - 1))) return rc;
+  S->active_ids.erase(S->active_ids.begin() + found);
+  --S->nc_active;
+  if ((rc = bind_constraint_slots(S))) return rc;
+  if ((rc = constraint_products(S, 0, S->nc, false))) return rc;  // bis_inf_norm_ recomputed over what is left (hpp:310-315)
+  return reset_home(S, RS_HCACHE);
+}
+
+int loikb_num_eq_c(const loikb_solver* S) { return S ? S->nc_active : 0; }
+int loikb_eq_c_capacity(const loikb_solver* S) { return S ? S->nc : 0; }
+int loikb_active_constraint_ids(const loikb_solver* S, int* out, int cap)
+{
+  if (!S || (cap > 0 && !out)) return LOIKB_ERR_ARG;
+  for (int c = 0; c < S->nc_active && c < cap; ++c) out[c] = S->active_ids[c];
+  return S->nc_active;
 }
 
 int loikb_integrate(loikb_solver* S, double dt)
@@ -1860,8 +2086,7 @@ int loikb_synchronize(loikb_solver* S)
 static PassParams pass_params(const loikb_solver_impl* S)
 {
   PassParams P{};
-  for (int k = 0; k < 36; ++k) P.Href[k] = S->Href[k];
-  for (int k = 0; k < 6; ++k) P.Hv[k] = S->Hv[k];
+  P.href_tab = S->d_href64;
   P.Hv_inf_norm = S->Hv_inf_norm;
   P.rho = S->opt.rho; P.mu0 = S->opt.mu; P.mu_scale = S->opt.mu_equality_scale_factor;
   P.tol_abs = S->opt.tol_abs; P.tol_rel = S->opt.tol_rel; P.tol_primal_inf = S->opt.tol_primal_inf;
@@ -1927,8 +2152,8 @@ static int pass_get(loikb_solver_impl* S, int field, void* out, bool to_dev)
   case LOIKB_F_PIS: off = L.pis; n = 6 * nb; skip = 6; break;
   case LOIKB_F_UDINV: off = L.UDinv; n = 6 * nb; skip = 6; break;
   case LOIKB_F_LIMI: off = L.liMi; n = 12 * nb; skip = 12; break;
-  case LOIKB_F_YIS: off = L.yis; n = 6 * S->nc; break;
-  case LOIKB_F_ATY: off = L.Aty; n = 6 * S->nc; break;
+  case LOIKB_F_YIS: off = L.yis; n = 6 * S->nc_active; break;  // (the active constraints are the first slots)
+  case LOIKB_F_ATY: off = L.Aty; n = 6 * S->nc_active; break;
   case LOIKB_F_HIS: n = 21 * nb; break;
   case LOIKB_F_ITER: scal = PS_ITER; is_int = true; break;
   case LOIKB_F_CONVERGED: scal = PS_CONVERGED; is_int = true; break;
@@ -2026,6 +2251,7 @@ const char* loikb_plan_string(loikb_solver* S)
     snprintf(buf, sizeof(buf), "k_solve (team of %d), hand-over to k_tail at %d live instances; %d chunk(s); no k_lean: %s",
              S->sched[1].nw, pl.tail_max, pl.nchunks, pl.why_not_lean);
   out = buf;
+  if (pl.lean && S->per_link) out += "; per-link references in force (UpdateReferences): k_tail takes k_lean's place until the next SolveInit";
   return out.c_str();
 }
 
@@ -2061,7 +2287,7 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
       for (int k = 0; k < n; ++k) rm.push_back(((S->link_of[i] - 1) * JREC + pair + k / 2) * 2 + (k & 1));
   };
   auto per_constraint_vec = [&](int pair) {
-    for (int c = 0; c < S->nc; ++c)
+    for (int c = 0; c < S->nc_active; ++c)  // (the active constraints are the first slots; the null ones behind them hold zeros)
       for (int k = 0; k < 6; ++k) rm.push_back((L.off_c + c * L.crec + pair + k / 2) * 2 + (k & 1));
   };
   switch (field) {
@@ -2120,37 +2346,21 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
     dst = (double*)d_tmp;
   }
   if (field == LOIKB_F_HIS) {
-    // device copy of H_ref in the solve precision (d_stage may be the output buffer: use the uniform buffer's tail?)
-    // -> small separate upload each call: getters are not on the hot path
-    void* d_href = nullptr;
-    HIPCHK(hipMalloc(&d_href, 36 * S->esz));
-    if (S->f32) {
-      float h[36];
-      for (int k = 0; k < 36; ++k) h[k] = (float)S->Href[k];
-      HIPCHK(hipMemcpyAsync(d_href, h, sizeof(h), hipMemcpyHostToDevice, S->stream));
-      HIPCHK(hipStreamSynchronize(S->stream));
+    if (S->f32)
       hipLaunchKernelGGL(k_rebuild_his<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd,
                          (const float*)S->d_uni, (float)S->opt.rho, (float)S->opt.mu_equality_scale_factor,
-                         (const float*)d_href, (int)S->a_shared, S->B, dst);
-    } else {
-      HIPCHK(hipMemcpyAsync(d_href, S->Href, sizeof(double) * 36, hipMemcpyHostToDevice, S->stream));
+                         (const float*)S->d_href, (int)S->a_shared, S->B, dst);
+    else
       hipLaunchKernelGGL(k_rebuild_his<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd,
                          (const double*)S->d_uni, (double)S->opt.rho, (double)S->opt.mu_equality_scale_factor,
-                         (const double*)d_href, (int)S->a_shared, S->B, dst);
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(S->stream));
-    HIPCHK(hipFree(d_href));
+                         (const double*)S->d_href, (int)S->a_shared, S->B, dst);
   } else if (field == LOIKB_F_PIS) {
     if (S->f32) hipLaunchKernelGGL(k_rebuild_pis<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->B, dst);
     else hipLaunchKernelGGL(k_rebuild_pis<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->B, dst);
   } else if (resvec) {
-    RefCost rcst;
-    for (int k = 0; k < 36; ++k) rcst.Href[k] = S->Href[k];
-    for (int k = 0; k < 6; ++k) rcst.Hv[k] = S->Hv[k];
     const int dual = field == LOIKB_F_DUAL_RESIDUAL_VEC;
-    if (S->f32) hipLaunchKernelGGL(k_residual_vecs<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, (const float*)S->d_uni, rcst, (int)S->a_shared, S->d_link_sel, nl, S->B, dual, dst);
-    else hipLaunchKernelGGL(k_residual_vecs<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, (const double*)S->d_uni, rcst, (int)S->a_shared, S->d_link_sel, nl, S->B, dual, dst);
+    if (S->f32) hipLaunchKernelGGL(k_residual_vecs<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, (const float*)S->d_uni, S->d_href64, (int)S->a_shared, S->d_link_sel, nl, S->B, dual, dst);
+    else hipLaunchKernelGGL(k_residual_vecs<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, (const double*)S->d_uni, S->d_href64, (int)S->a_shared, S->d_link_sel, nl, S->B, dual, dst);
   } else if (field == LOIKB_F_LIMI) {
     if (S->f32) hipLaunchKernelGGL(k_limi<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->d_first_sel, S->d_link_sel, nl, S->B, dst);
     else hipLaunchKernelGGL(k_limi<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->d_first_sel, S->d_link_sel, nl, S->B, dst);

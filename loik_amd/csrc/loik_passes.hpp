@@ -52,7 +52,8 @@ inline PassLayout make_pass_layout(int nj, int nv, int nc, int B)
 }
 
 struct PassParams {
-  double Href[36], Hv[6], Hv_inf_norm;
+  const double* href_tab;  // [nj][HREF_ROW]: (H_ref_i, H_ref_i v_ref_i) per joint (broadcast or UpdateReferences)
+  double Hv_inf_norm;
   double rho, mu0, mu_scale, tol_abs, tol_rel, tol_primal_inf, tol_tail_solve;
   int max_iter, mu_osqp, a_shared, bnd_shared;
 };
@@ -208,8 +209,8 @@ __global__ void k_pass(int pass, PassLayout L, PassParams P, const JointDesc* __
       double* H = s + L.His + 36 * i; double* p = s + L.pis + 6 * i;
       const double* vp = s + L.vis_prev + 6 * i;
       for (int r = 0; r < 6; ++r) {
-        for (int c = 0; c < 6; ++c) H[6 * r + c] = (r == c ? P.rho : 0.0) + P.Href[6 * r + c];
-        p[r] = -P.rho * vp[r] - P.Hv[r];
+        for (int c = 0; c < 6; ++c) H[6 * r + c] = (r == c ? P.rho : 0.0) + P.href_tab[i * HREF_ROW + 6 * r + c];
+        p[r] = -P.rho * vp[r] - P.href_tab[i * HREF_ROW + 36 + r];
       }
       const int cs = cslot_of[i];
       if (cs >= 0) {
@@ -271,7 +272,7 @@ __global__ void k_pass(int pass, PassLayout L, PassParams P, const JointDesc* __
       for (int r = 0; r < 6; ++r) v[r] = vp[r] + S[r] * nu;
       for (int r = 0; r < 6; ++r) {
         double a = s[L.pis + 6 * i + r], h = 0.0;
-        for (int c = 0; c < 6; ++c) { a += s[L.His + 36 * i + 6 * r + c] * v[c]; h += P.Href[6 * r + c] * v[c]; }
+        for (int c = 0; c < 6; ++c) { a += s[L.His + 36 * i + 6 * r + c] * v[c]; h += P.href_tab[i * HREF_ROW + 6 * r + c] * v[c]; }
         f[r] = a; hv[r] = h;
         df[r] = f[r] - s[L.fis + 6 * i + r];
         dv[r] = v[r] - s[L.vis_prev + 6 * i + r];
@@ -359,7 +360,7 @@ __global__ void k_pass(int pass, PassLayout L, PassParams P, const JointDesc* __
       for (int r = 0; r < 6; ++r) s[L.gnew + 6 * par + r] += tf[r];
       sc[PS_G_INF] = fmax(sc[PS_G_INF], p_inf6(gi));
       sc[PS_DG_INF] = fmax(sc[PS_DG_INF], p_inf6(dg));
-      for (int r = 0; r < 6; ++r) { dvr[r] = s[L.Href_v + 6 * i + r] - P.Hv[r] + gi[r]; s[L.g + 6 * i + r] = gi[r]; }
+      for (int r = 0; r < 6; ++r) { dvr[r] = s[L.Href_v + 6 * i + r] - P.href_tab[i * HREF_ROW + 36 + r] + gi[r]; s[L.g + 6 * i + r] = gi[r]; }
       dualv = fmax(dualv, p_inf6(dvr));
       double sf = 0.0;
       for (int r = 0; r < 6; ++r) sf += S[r] * s[L.fis + 6 * i + r];

@@ -151,6 +151,8 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   const int depth = isj_lane ? tp.depth : 0;
   const bool rev = d.flags & JF_REVOLUTE;
   const T mass = (d.flags & JF_MASSLESS) ? T(0) : T(1);  // chain link of a multi-DoF joint: no cost of its own
+  // per-link references (UpdateReferences): this lane's row of the table, else the broadcast pair in P (uniform branch)
+  const T* const hrow = P.href_tab ? P.href_tab + (size_t)(jl + 1) * HREF_ROW : nullptr;
   const bool has_parent = !(d.flags & JF_PARENT_ROOT);
   const int plane = gbase + d.parent - 1;  // parent's lane
   const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
@@ -402,11 +404,12 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       for (int a = 0; a < 6; ++a)
 #pragma unroll
         for (int b2 = a; b2 < 6; ++b2)
-          hh[sym(a, b2)] = mass * ((a == b2 ? P.rho : T(0)) + ((HDIAG && a != b2) ? T(0) : P.Href[6 * a + b2]));
+          hh[sym(a, b2)] = mass * ((a == b2 ? P.rho : T(0)) +
+                                   ((HDIAG && a != b2) ? T(0) : (hrow ? hrow[6 * a + b2] : P.Href[6 * a + b2])));
     }
     if (act) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) p[k] = mass * (-P.rho * v[k] - P.Hv[k]);
+      for (int k = 0; k < 6; ++k) p[k] = mass * (-P.rho * v[k] - (hrow ? hrow[36 + k] : P.Hv[k]));
       if (isj && d.cslot >= 0) {
         const T* c_ = cdi + d.cslot * CD;
         if (need_h) {
@@ -548,7 +551,7 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         dv6[k] = vi[k] - v[k];
       }
       l_dfis = mass * inf6(df);  // (a massless chain link is not a body of the model: no f_i of its own upstream)
-      href_mul<T, HDIAG>(P.Href, vi, hrv);
+      href_mul_link<T, HDIAG>(P, hrow, vi, hrv);
       l_hrefv = mass * inf6(hrv);  // a massless chain link is not a body of the model
       l_dvis = mass * inf6(dv6);
       l_dnu = tabs(nui - nu);
@@ -640,9 +643,9 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       }
       l_dg = inf6(dg);
       l_g = inf6(gi);
-      href_mul<T, HDIAG>(P.Href, v, dvr);
+      href_mul_link<T, HDIAG>(P, hrow, v, dvr);
 #pragma unroll
-      for (int a = 0; a < 6; ++a) dvr[a] = mass * (dvr[a] - P.Hv[a]) + gi[a];
+      for (int a = 0; a < 6; ++a) dvr[a] = mass * (dvr[a] - (hrow ? hrow[36 + a] : P.Hv[a])) + gi[a];
       l_dualv = inf6(dvr);
       const T stf = rev ? (ax0 * f[3] + ax1 * f[4] + ax2 * f[5]) : (ax0 * f[0] + ax1 * f[1] + ax2 * f[2]);
       const T si = stf + w;

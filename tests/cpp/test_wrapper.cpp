@@ -69,12 +69,12 @@ struct Fixture {  // ProblemSetupFixture, tests/loik-loid.cpp:87-165
 
 struct Oracle {
   ref_solver* s = nullptr;
-  Oracle(const Fixture& f)
+  explicit Oracle(const Fixture& f, int eq_c_capacity = 0)
   {
     const loikb_model_desc d = f.robot_model.desc();
     ref_model m{d.njoints, d.nq, d.nv, d.parents, d.jtype, d.axis, d.idx_q, d.idx_v, d.placement};
     ref_params p{f.max_iter, f.tol_abs, f.tol_rel, f.tol_primal_inf, f.tol_dual_inf, f.rho, f.mu, f.mu_equality_scale_factor,
-                 (int)f.mu_update_strat, f.num_eq_c, f.eq_c_dim, (int)f.warm_start, f.tol_tail_solve};
+                 (int)f.mu_update_strat, f.num_eq_c, f.eq_c_dim, (int)f.warm_start, f.tol_tail_solve, eq_c_capacity};
     ref_create(&m, &p, &s);
   }
   ~Oracle() { ref_destroy(s); }
@@ -301,6 +301,70 @@ int main()
       CHECK(solver.get_iter(b) == (int)ref_scalar(o.s, REF_S_ITER));
       CHECK(close(d.z.data() + b * f.robot_model.nv, o.field(REF_F_Z), f.robot_model.nv));
     }
+  }
+  {  // editing the formulation between solves (ik-id-description-optimized.hpp:103-121, :178-319): per-link references,
+     // AddEqConstraint / RemoveEqConstraint with one spare constraint slot
+    Fixture f; f.max_iter = 300; f.tol_abs = 1e-6; f.tol_rel = 0.0; f.set_bound(0.5);
+    const Index left = f.robot_model.getJointId("arm_left_7_joint"), right = f.robot_model.getJointId("arm_right_7_joint");
+    f.active_task_constraint_ids[0] = left;
+    f.bis[0] = Vec6{0.05, -0.03, 0.02, 0.01, 0.02, -0.04};
+    IkIdDataOptimized d(f.robot_model, f.num_eq_c);
+    FirstOrderLoikOptimized solver{f.max_iter, f.tol_abs, f.tol_rel, f.tol_primal_inf, f.tol_dual_inf, f.rho, f.mu,
+                                   f.mu_equality_scale_factor, f.mu_update_strat, f.num_eq_c, f.eq_c_dim, f.robot_model, d,
+                                   f.warm_start, f.tol_tail_solve, f.verbose, f.logging, 0, 0, /*eq_c_capacity=*/2};
+    Oracle o(f, 2);
+    const int nj = f.robot_model.njoints, nv = f.robot_model.nv;
+    int id = (int)left;
+    solver.SolveInit(f.q, f.H_ref, f.v_ref, f.active_task_constraint_ids, f.Ais, f.bis, f.lb, f.ub);
+    ref_solve_init(o.s, f.q.data(), f.H_ref.data(), f.v_ref.data(), &id, 1, f.Ais[0].data(), f.bis[0].data(), f.lb.data(),
+                   f.ub.data(), nv);
+    std::vector<Mat6x6> H_refs(nj, Identity6());
+    std::vector<Motion> v_refs(nj, Motion{});
+    for (int i = 0; i < nj; ++i)
+      for (int k = 0; k < 6; ++k) { H_refs[i][7 * k] = 0.5 + 0.1 * ((i + k) % 7); v_refs[i][k] = 0.02 * std::sin(1.0 + i + 3 * k); }
+    H_refs[4][1] = H_refs[4][6] = 0.05;  // one full (symmetric) weight
+    solver.UpdateReferences(H_refs, v_refs);
+    ref_update_references(o.s, H_refs[0].data(), v_refs[0].data(), nj);  // (vectors of std::array are contiguous)
+    solver.Solve();
+    ref_solve(o.s);
+    CHECK(solver.get_iter() == (int)ref_scalar(o.s, REF_S_ITER));
+    CHECK(close(d.z.data(), o.field(REF_F_Z), nv, 1e-8));
+    CHECK(close(d.vis.data(), o.field(REF_F_VIS) + 6, 6 * (nj - 1), 1e-8));
+    {
+      bool thrown = false;
+      try { solver.UpdateReferences(std::vector<Mat6x6>(nj - 1, Identity6()), std::vector<Motion>(nj - 1, Motion{})); }
+      catch (const std::runtime_error& e) { thrown = std::strstr(e.what(), "have wrong size") != nullptr; }
+      CHECK(thrown);
+    }
+    // a second task on the other wrist
+    const Vec6 b2{-0.02, 0.04, 0.01, 0.0, -0.03, 0.02};
+    solver.AddEqConstraint(right, Identity6(), {b2});
+    CHECK(ref_add_eq_constraint(o.s, (int)right, Identity6().data(), b2.data()) == REF_OK);
+    CHECK((solver.active_task_constraint_ids() == std::vector<Index>{left, right}));
+    solver.Solve(f.q);
+    ref_solve_tailored(o.s, f.q.data(), -1, nullptr, nullptr);
+    CHECK(solver.get_iter() == (int)ref_scalar(o.s, REF_S_ITER));
+    CHECK(close(d.z.data(), o.field(REF_F_Z), nv, 1e-8));
+    CHECK(d.yis.size() == 12 && close(d.yis.data(), o.field(REF_F_YIS), 12, 1e-6));
+    CHECK(d.Aty.size() == 12 && close(d.Aty.data(), o.field(REF_F_ATY), 12, 1e-6));
+    {
+      bool thrown = false;  // no third slot
+      try { solver.AddEqConstraint(3, Identity6(), {b2}); } catch (const std::runtime_error&) { thrown = true; }
+      CHECK(thrown);
+    }
+    // drop the first one: the second moves down with its dual
+    CHECK(solver.RemoveEqConstraint(left));
+    CHECK(!solver.RemoveEqConstraint(left));
+    CHECK(ref_remove_eq_constraint(o.s, (int)left) == REF_OK);
+    CHECK((solver.active_task_constraint_ids() == std::vector<Index>{right}));
+    solver.UpdateEqConstraint(right, std::vector<Vec6>{f.bis[0]});
+    CHECK(ref_update_eq_constraint(o.s, (int)right, nullptr, f.bis[0].data()) == REF_OK);
+    solver.Solve(f.q);
+    ref_solve_tailored(o.s, f.q.data(), -1, nullptr, nullptr);
+    CHECK(solver.get_iter() == (int)ref_scalar(o.s, REF_S_ITER));
+    CHECK(close(d.z.data(), o.field(REF_F_Z), nv, 1e-8));
+    CHECK(d.yis.size() == 6 && close(d.yis.data(), o.field(REF_F_YIS), 6, 1e-6));
+    CHECK(close(solver.get_primal_residual(), ref_scalar(o.s, REF_S_PRIMAL_RESIDUAL), 1e-7));
   }
   {  // floating base: free-flyer root_joint + 32 revolute joints, nq = 39, nv = 38
     Fixture f("talos32_freeflyer"); f.max_iter = 300; f.tol_abs = 1e-6; f.tol_rel = 0.0; f.set_bound(0.5);

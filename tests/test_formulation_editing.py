@@ -160,3 +160,252 @@ def test_add_and_remove_equal_a_fresh_solver():
     w0 = ref.RefSolver(model, **dict(prm, num_eq_c=0))
     w0.Solve(q, full["H_ref"], full["v_ref"], np.zeros(0, dtype=np.int32), np.zeros((0, 6, 6)), np.zeros((0, 6)), lb, ub)
     assert s.get_iter() == w0.get_iter() and np.array_equal(s.z, w0.z)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# GPU: the C-ABI's editing entry points against the oracle's
+# ---------------------------------------------------------------------------------------------------------------------------
+def oracle_batch(model, prm, B, run):
+    """run(solver, pick) on one oracle solver per instance (pick(x) = instance b's slice of a per-instance array) and collect
+    what assert_end_to_end compares"""
+    out = dict(iters=np.zeros(B, dtype=np.int64), converged=np.zeros(B, dtype=bool), primal_infeasible=np.zeros(B, dtype=bool),
+               z=np.zeros((B, model.nv)), nu=np.zeros((B, model.nv)), primal_residual=np.zeros(B), dual_residual=np.zeros(B))
+    solvers = []
+    for b in range(B):
+        s = ref.RefSolver(model, **prm)
+        run(s, lambda x, b=b: x[b])
+        out["iters"][b] = s.get_iter(); out["converged"][b] = s.get_convergence_status()
+        out["primal_infeasible"][b] = s.get_primal_infeasibility_status()
+        out["z"][b] = s.z; out["nu"][b] = s.nu
+        out["primal_residual"][b] = s.scalar("primal_residual"); out["dual_residual"][b] = s.scalar("dual_residual")
+        solvers.append(s)
+    return out, solvers
+
+
+ENGINE_KW = {"default": {}, "solve_only": dict(tail_max_instances=-1), "handover": dict(max_launch_iters=3, tail_max_instances=1 << 20)}
+REF_FIELDS = ["nu", "z", "w", "vis", "fis", "g", "yis", "Aty", "Stf_plus_w", "dual_residual_vec", "primal_residual_vec"]
+REF_SCALARS = ["primal_residual", "dual_residual", "dual_residual_v", "dual_residual_nu", "mu", "Href_v_inf_norm", "g_inf_norm",
+               "delta_fis_inf_norm", "tol_dual", "tol_primal"]
+
+
+def _model_for(which, request):
+    if which == "talos":
+        model = request.getfixturevalue("talos"); link = model.getJointId("arm_left_7_joint")
+    elif which == "tree":
+        model = random_tree(13, 23); link = model.njoints - 1
+    else:
+        model = random_tree_multidof(seed=5, nb=9, root_freeflyer=True, n_spherical=1, n_translation=1)
+        link = model.njoints - 1
+    return model, link
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["full", "diag"])
+@pytest.mark.parametrize("which", ["talos", "tree", "multidof"])
+def test_gpu_per_link_references_iteration_by_iteration(which, kind, request):
+    """the state after 1, 3, 6 iterations, field by field (tol_rel > 0: tol_dual depends on |H_i v_i| and on Hv_inf_norm_)"""
+    from loik_amd import workloads
+    model, link = _model_for(which, request)
+    tol = 1e-7 if which == "multidof" else 1e-9
+    B = 48
+    wl = workloads.make_workload(model, B, link, 44, bound=0.5, snap_prob=0.0, nu_scale=0.4)
+    wl["H_ref"], wl["v_ref"] = 2.0 * np.eye(6), np.full(6, 0.1)      # what SolveInit broadcasts first (Hv_inf_norm_ = 0.2)
+    H, v = per_link_references(model, 7, kind)
+    for k in (1, 3, 6):
+        prm = dict(FIXTURE, max_iter=k + 1, tol_abs=0.0, tol_rel=1e-30, tol_primal_inf=0.0)
+        s = loik_amd.BatchedLoik(model, B, **prm)
+        s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+        s.UpdateReferences(H, v)
+        s.Solve()
+        got = {n: s.get(n) for n in REF_FIELDS + REF_SCALARS}
+        got["His"] = s.His_full()
+        for b in range(0, B, 7):
+            r = ref.RefSolver(model, **prm)
+            r.SolveInit(*problem_args(wl, b)); r.UpdateReferences(H, v); r.Solve()
+            for n in REF_FIELDS:
+                want = r.field(n)
+                if n in ("vis", "fis", "g"):
+                    want = want[1:]
+                assert_close(got[n][b], want, tol, "%s b%d k%d" % (n, b, k))
+            assert_close(got["His"][b], r.His[1:], tol, "His")
+            for n in REF_SCALARS:
+                assert_close(got[n][b], r.scalar(n), tol, "%s b%d k%d" % (n, b, k))
+        s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", sorted(ENGINE_KW))
+@pytest.mark.parametrize("which", ["talos", "tree", "multidof"])
+def test_gpu_per_link_references_end_to_end(which, engine, request):
+    from helpers import assert_end_to_end, fetch_end_to_end
+    from loik_amd import workloads
+    model, link = _model_for(which, request)
+    B = 200
+    wl = workloads.make_workload(model, B, link, 45, bound=0.5, snap_prob=0.0, nu_scale=0.4)
+    H, v = per_link_references(model, 9, "full")
+    prm = dict(FIXTURE, max_iter=400, tol_abs=1e-6, tol_rel=0.0)
+
+    def run_oracle(s, pick):
+        s.SolveInit(wl["q"][pick(np.arange(B))], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], pick(wl["bis"]), wl["lb"], wl["ub"])
+        s.UpdateReferences(H, v)
+        s.Solve()
+    out, _ = oracle_batch(model, prm, B, run_oracle)
+    s = loik_amd.BatchedLoik(model, B, **prm, **ENGINE_KW[engine])
+    s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    s.UpdateReferences(H, v)
+    if which == "talos" and engine == "default":
+        assert "per-link references in force" in s.plan()
+    s.Solve()
+    loose = which == "multidof"
+    assert_end_to_end(fetch_end_to_end(s, residuals=not loose), out, prm, same_frac=0.95, ztol=1e-6 if loose else 1e-8,
+                      off_ztol=1e-5, what="%s %s" % (which, engine))
+    st = s.stats()
+    assert st["lean_launches"] == 0                     # k_lean has no per-link table
+    # the next SolveInit broadcasts one pair again (hpp:355) and the lean engine is back
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    out0 = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"],
+                           nthreads=4, want_nu=True, **prm)
+    assert_end_to_end(fetch_end_to_end(s, residuals=not loose), out0, prm, same_frac=0.95, ztol=1e-6 if loose else 1e-8,
+                      off_ztol=1e-5, what="%s %s broadcast again" % (which, engine))
+    assert "per-link" not in s.plan()
+    s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_update_references_errors_and_quirks(talos):
+    wl = feasible_batch(talos, 4, talos.njoints - 1, 3)
+    s = loik_amd.BatchedLoik(talos, 4, **dict(FIXTURE, max_iter=5))
+    H, v = per_link_references(talos, 1, "diag")
+    with pytest.raises(loik_amd.LoikError) as e:      # before SolveInit
+        s.UpdateReferences(H, v)
+    assert e.value.code == -24
+    wl["H_ref"], wl["v_ref"] = 2.0 * np.eye(6), np.full(6, 0.25)
+    s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    with pytest.raises(loik_amd.LoikError) as e:      # one entry per joint incl. the universe (hpp:105-107)
+        s.UpdateReferences(H[1:], v[1:])
+    assert e.value.code == -8
+    Hbad = H.copy(); Hbad[3, 0, 1] = 0.3
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.UpdateReferences(Hbad, v)
+    assert e.value.code == -23
+    # Hv_inf_norm_ only grows in UpdateReferences (hpp:114-116): visible through tol_dual with tol_rel > 0
+    r = ref.RefSolver(talos, **dict(FIXTURE, max_iter=5))
+    r.SolveInit(*problem_args(wl, 0))
+    for scale in (0.01, 100.0):
+        s.UpdateReferences(scale * H, v); r.UpdateReferences(scale * H, v)
+        s.Solve(); r.Solve()
+        assert_close(s.get("tol_dual")[0], r.scalar("tol_dual"), 1e-12, "tol_dual")
+    s.close()
+
+
+def _edit_sequence(model, full, links, B, shared_A, warm):
+    """the same editing session on any solver with the reference's method names; pick(x) = this solver's slice of a
+    per-instance array.  Starts with {a, b}, capacity 3."""
+    a, b_, c = links
+    A = {l: (full["Ais"][k] if shared_A else full["Ais"][:, k]) for k, l in enumerate(links)}
+    bv = {l: full["bis"][:, k] for k, l in enumerate(links)}
+    pa = (lambda x, pick: x) if shared_A else (lambda x, pick: pick(x))
+    checkpoints = []
+
+    def run(s, pick, snap):
+        def A2(ls):
+            return np.stack([pa(A[l], pick) for l in ls], axis=-3)
+        def b2(ls):
+            return np.stack([pick(bv[l]) for l in ls], axis=-2)
+        q = pick(full["q"])
+        s.Solve(q, full["H_ref"], full["v_ref"], np.array([a, b_], dtype=np.int32), A2([a, b_]), b2([a, b_]), full["lb"], full["ub"])
+        snap("init {a,b}")
+        s.AddEqConstraint(c, pa(A[c], pick), pick(bv[c]))
+        assert s.active_task_constraint_ids() == [a, b_, c]
+        s.Solve(q, -1, None, None); snap("add c")
+        assert s.RemoveEqConstraint(b_) and not s.RemoveEqConstraint(b_)
+        assert s.active_task_constraint_ids() == [a, c]
+        s.Solve(q, -1, None, None); snap("remove b")
+        s.AddEqConstraint(c, pa(A[b_], pick), pick(bv[b_]))           # present: UpdateEqConstraint (hpp:250-253)
+        s.UpdateEqConstraint(a, pick(bv[c]))                          # (c_id, bi) overload keeps A (hpp:224-238)
+        s.Solve(q, a, pa(A[a], pick), pick(bv[a])); snap("update, tailored")
+        s.AddEqConstraint(b_, pa(A[b_], pick), pick(bv[b_]))          # the freed slot is taken again: order [a, c, b]
+        assert s.active_task_constraint_ids() == [a, c, b_]
+        s.Solve(q, -1, None, None); snap("add b back")
+        s.RemoveEqConstraint(a); s.RemoveEqConstraint(c); s.RemoveEqConstraint(b_)
+        s.Solve(q, -1, None, None); snap("none left")
+    return run
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("warm", [False, True])
+@pytest.mark.parametrize("shared_A", [True, False])
+@pytest.mark.parametrize("which", ["talos", "tree"])
+def test_gpu_constraint_editing_session(which, shared_A, warm, request):
+    """Add / Remove / Update between tailored solves, compared with the oracle's editing functions after every solve (all
+    instances).  talos runs in k_lean (null slots in its constraint blocks), tree in k_solve + k_tail."""
+    from helpers import assert_end_to_end, fetch_end_to_end
+    if which == "talos":
+        model = request.getfixturevalue("talos")
+        links = [model.getJointId("arm_left_7_joint"), model.getJointId("arm_right_7_joint"), model.getJointId("leg_left_6_joint")]
+    else:
+        model = random_tree(8, 12, branch_prob=0.4); links = [5, 9, 12]
+    B = 96
+    full = multi_task_batch(model, B, links, 3, bound=0.5, nu_scale=0.4, per_instance_A=not shared_A)
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0, num_eq_c=2, eq_c_capacity=3, warm_start=warm)
+    run = _edit_sequence(model, full, links, B, shared_A, warm)
+    # oracle: one solver per instance, snapshots after every solve
+    snaps_o = {}
+    for b in range(B):
+        r = ref.RefSolver(model, **prm)
+
+        def snap(name, r=r, b=b):
+            d = snaps_o.setdefault(name, dict(iters=np.zeros(B, dtype=np.int64), converged=np.zeros(B, dtype=bool),
+                                              primal_infeasible=np.zeros(B, dtype=bool), z=np.zeros((B, model.nv)),
+                                              nu=np.zeros((B, model.nv)), primal_residual=np.zeros(B), dual_residual=np.zeros(B),
+                                              yis=[None] * B))
+            d["iters"][b] = r.get_iter(); d["converged"][b] = r.get_convergence_status()
+            d["primal_infeasible"][b] = r.get_primal_infeasibility_status(); d["z"][b] = r.z; d["nu"][b] = r.nu
+            d["primal_residual"][b] = r.scalar("primal_residual"); d["dual_residual"][b] = r.scalar("dual_residual")
+            d["yis"][b] = r.yis.copy()
+        run(r, lambda x, b=b: x[b], snap)
+    s = loik_amd.BatchedLoik(model, B, **prm)
+    order = []
+
+    def snap_g(name):
+        order.append(name)
+        out = snaps_o[name]
+        same = assert_end_to_end(fetch_end_to_end(s, residuals=True), out, prm, same_frac=0.9, ztol=1e-7, off_ztol=1e-5,
+                                 what="%s: %s" % (which, name), res_tol=(1e-7, 1e-5))
+        y = s.get("yis")
+        want = np.array([out["yis"][b] for b in range(B)]).reshape(B, -1, 6)
+        assert y.shape == want.shape, (name, y.shape, want.shape)
+        if want.size:
+            scale = 1.0 + np.abs(want).max()
+            assert np.abs(y - want)[same].max() < 1e-6 * scale, (name, np.abs(y - want)[same].max())
+    run(s, lambda x: x, snap_g)
+    assert len(order) == 6
+    if which == "talos" and shared_A:
+        assert s.stats()["lean_launches"] > 0, s.plan()
+    s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_constraint_editing_errors(talos):
+    links = [talos.getJointId("arm_left_7_joint"), talos.getJointId("arm_right_7_joint")]
+    wl = multi_task_batch(talos, 4, links, 3)
+    s = loik_amd.BatchedLoik(talos, 4, **dict(FIXTURE, max_iter=5, num_eq_c=2))          # capacity = num_eq_c
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.AddEqConstraint(3, wl["Ais"][0], wl["bis"][:, 0])
+    assert e.value.code == -24                                                           # before SolveInit
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.AddEqConstraint(3, wl["Ais"][0], wl["bis"][:, 0])
+    assert e.value.code == -2                                                            # no free slot
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.UpdateEqConstraint(3, wl["bis"][:, 0])
+    assert e.value.code == -4                                                            # hpp:184-186
+    assert s.RemoveEqConstraint(links[0])
+    with pytest.raises(loik_amd.LoikError) as e:                                         # SolveInit checks against nc_eq_ (hpp:143)
+        s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    assert e.value.code == -2
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"][1:], wl["Ais"][1:], wl["bis"][:, 1:], wl["lb"], wl["ub"])
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.AddEqConstraint(talos.njoints, wl["Ais"][0], wl["bis"][:, 0])                  # link id out of range
+    assert e.value.code == -20
+    s.close()
