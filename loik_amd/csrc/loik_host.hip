@@ -1810,13 +1810,18 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
   if (opts->eq_c_dim != 6) return LOIKB_ERR_EQ_C_DIM;
   if (opts->batch < 1) { g_last_error = "batch must be >= 1"; return LOIKB_ERR_ARG; }
   if (opts->num_eq_c < 0) { g_last_error = "num_eq_c must be >= 0"; return LOIKB_ERR_ARG; }
+  if (opts->eq_c_capacity < 0) { g_last_error = "eq_c_capacity must be >= 0"; return LOIKB_ERR_ARG; }
+  // one constraint per link at most (hpp:197-199) and every slot sits on a body: no more slots than bodies
+  if (std::max(opts->num_eq_c, opts->eq_c_capacity) > model->njoints - 1) {
+    g_last_error = "more constraint slots (num_eq_c / eq_c_capacity) than bodies";
+    return LOIKB_ERR_EQ_C_SIZE;
+  }
   loikb_solver* S = new loikb_solver();
   S->tune.read_env();
   int rc = build_schedule(S, model);
   if (rc) { delete S; return rc; }
   S->opt = *opts;
   S->B = opts->batch;
-  if (opts->eq_c_capacity < 0) { g_last_error = "eq_c_capacity must be >= 0"; return LOIKB_ERR_ARG; }
   S->nc = std::max(opts->num_eq_c, opts->eq_c_capacity);
   S->nc_active = opts->num_eq_c;
   S->f32 = opts->precision == LOIKB_F32;

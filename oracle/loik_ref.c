@@ -1321,10 +1321,11 @@ void ref_set_warm_start(ref_solver *s, int warm) { s->warm_start = warm; }
 /* ------------------------------------------------------------------------------------------ */
 /* batch driver (cpu_baseline + batch parity tests)                                            */
 /* ------------------------------------------------------------------------------------------ */
-int ref_solve_batch(const ref_model *model, const ref_params *prm, int B, const double *q, const double *H_ref,
-                    const double *v_ref, const int *c_ids, int nc, const double *Ais, const double *bis,
-                    const double *lb, const double *ub, int shared_mask, int nthreads, double *z_out,
-                    double *nu_out, int *iters_out, int *flags_out, double *res_out)
+static int solve_batch_impl(const ref_model *model, const ref_params *prm, int B, const double *q, const double *H_ref,
+                            const double *v_ref, const int *c_ids, int nc, const double *Ais, const double *bis,
+                            const double *lb, const double *ub, int shared_mask, int nthreads, double *z_out,
+                            double *nu_out, int *iters_out, int *flags_out, double *res_out, const double *H_refs,
+                            const double *v_refs)
 {
   const int nq = model->nq, nv = model->nv;
   int err = REF_OK;
@@ -1346,7 +1347,13 @@ int ref_solve_batch(const ref_model *model, const ref_params *prm, int B, const 
       const double *Ab = (shared_mask & 1) ? Ais : Ais + (size_t)b * 36 * nc;
       const double *lbb = (shared_mask & 2) ? lb : lb + (size_t)b * nv;
       const double *ubb = (shared_mask & 2) ? ub : ub + (size_t)b * nv;
-      rc = ref_solve_full(s, q + (size_t)b * nq, H_ref, v_ref, c_ids, nc, Ab, bis + (size_t)b * 6 * nc, lbb, ubb, nv);
+      if (H_refs) { /* SolveInit, UpdateReferences (one table for the batch), Solve() */
+        rc = ref_solve_init(s, q + (size_t)b * nq, H_ref, v_ref, c_ids, nc, Ab, bis + (size_t)b * 6 * nc, lbb, ubb, nv);
+        if (rc == REF_OK) rc = ref_update_references(s, H_refs, v_refs, model->njoints);
+        if (rc == REF_OK) rc = ref_solve(s);
+      } else {
+        rc = ref_solve_full(s, q + (size_t)b * nq, H_ref, v_ref, c_ids, nc, Ab, bis + (size_t)b * 6 * nc, lbb, ubb, nv);
+      }
       if (rc != REF_OK) { failed = 1; continue; }
       memcpy(z_out + (size_t)b * nv, s->z, sizeof(double) * nv);
       if (nu_out) memcpy(nu_out + (size_t)b * nv, s->nu, sizeof(double) * nv);
@@ -1366,4 +1373,24 @@ int ref_solve_batch(const ref_model *model, const ref_params *prm, int B, const 
     ref_destroy(s);
   }
   return err;
+}
+
+int ref_solve_batch(const ref_model *model, const ref_params *prm, int B, const double *q, const double *H_ref,
+                    const double *v_ref, const int *c_ids, int nc, const double *Ais, const double *bis,
+                    const double *lb, const double *ub, int shared_mask, int nthreads, double *z_out,
+                    double *nu_out, int *iters_out, int *flags_out, double *res_out)
+{
+  return solve_batch_impl(model, prm, B, q, H_ref, v_ref, c_ids, nc, Ais, bis, lb, ub, shared_mask, nthreads, z_out, nu_out,
+                          iters_out, flags_out, res_out, NULL, NULL);
+}
+
+/* the same with per-link references: SolveInit(q, H_ref, v_ref, ...) ; UpdateReferences(H_refs, v_refs) ; Solve() */
+int ref_solve_batch_refs(const ref_model *model, const ref_params *prm, int B, const double *q, const double *H_ref,
+                         const double *v_ref, const int *c_ids, int nc, const double *Ais, const double *bis,
+                         const double *lb, const double *ub, int shared_mask, int nthreads, double *z_out,
+                         double *nu_out, int *iters_out, int *flags_out, double *res_out, const double *H_refs,
+                         const double *v_refs)
+{
+  return solve_batch_impl(model, prm, B, q, H_ref, v_ref, c_ids, nc, Ais, bis, lb, ub, shared_mask, nthreads, z_out, nu_out,
+                          iters_out, flags_out, res_out, H_refs, v_refs);
 }

@@ -230,6 +230,15 @@ int ref_solve_batch(const ref_model *model, const ref_params *prm, int B, const 
                     double *z_out /*[B][nv]*/, double *nu_out /*[B][nv] or NULL*/,
                     int *iters_out /*[B]*/, int *flags_out /*[B] bit0 converged bit1 primal_inf*/,
                     double *res_out /*[B][2] or NULL*/);
+/* the same with per-link references: SolveInit(...) ; UpdateReferences(H_refs [nj][36], v_refs [nj][6]) ; Solve() */
+int ref_solve_batch_refs(const ref_model *model, const ref_params *prm, int B, const double *q,
+                    const double *H_ref, const double *v_ref, const int *c_ids, int nc,
+                    const double *Ais, const double *bis, const double *lb, const double *ub,
+                    int shared_mask, int nthreads,
+                    double *z_out /*[B][nv]*/, double *nu_out /*[B][nv] or NULL*/,
+                    int *iters_out /*[B]*/, int *flags_out /*[B] bit0 converged bit1 primal_inf*/,
+                    double *res_out /*[B][2] or NULL*/,
+                         const double *H_refs, const double *v_refs);
 
 #ifdef __cplusplus
 }

@@ -97,6 +97,8 @@ def load(native=False):
                                     _c_double_p, C.c_int, C.c_int, _c_double_p, _c_double_p, _c_int_p, _c_int_p,
                                     _c_double_p]
     lib.ref_solve_batch.restype = C.c_int
+    lib.ref_solve_batch_refs.argtypes = lib.ref_solve_batch.argtypes + [_c_double_p, _c_double_p]
+    lib.ref_solve_batch_refs.restype = C.c_int
     _lib_cache[key] = lib
     return lib
 
@@ -282,9 +284,10 @@ class RefSolver:
 
 
 def solve_batch(model, q, H_ref, v_ref, c_ids, Ais, bis, lb, ub, nthreads=1, native=False, want_nu=False,
-                **params):
+                refs=None, **params):
     """Cold `Solve(q,H_ref,v_ref,ids,Ais,bis,lb,ub)` of every instance (instance-major arrays).
-    Ais: [nc,6,6] (shared) or [B,nc,6,6]; lb/ub: [nv] (shared) or [B,nv]; bis: [B,nc,6]."""
+    Ais: [nc,6,6] (shared) or [B,nc,6,6]; lb/ub: [nv] (shared) or [B,nv]; bis: [B,nc,6].
+    refs = (H_refs [nj,6,6], v_refs [nj,6]): SolveInit, UpdateReferences(H_refs, v_refs), Solve() instead."""
     lib = load(native)
     mh = _ModelHolder(model)
     prm = make_params(**params)
@@ -296,9 +299,14 @@ def solve_batch(model, q, H_ref, v_ref, c_ids, Ais, bis, lb, ub, nthreads=1, nat
     shared = (1 if Ais.size == 36 * nc else 0) | (2 if lb.size == nv else 0)
     z = np.empty((B, nv)); nu = np.empty((B, nv)) if want_nu else None
     iters = np.empty(B, dtype=np.int32); flags = np.empty(B, dtype=np.int32); res = np.empty((B, 2))
-    rc = lib.ref_solve_batch(C.byref(mh.struct), C.byref(prm), B, _dp(q), _dp(H_ref), _dp(v_ref), _ip(c_ids), nc,
-                             _dp(Ais), _dp(bis), _dp(lb), _dp(ub), shared, int(nthreads), _dp(z),
-                             _dp(nu) if want_nu else None, _ip(iters), _ip(flags), _dp(res))
+    args = (C.byref(mh.struct), C.byref(prm), B, _dp(q), _dp(H_ref), _dp(v_ref), _ip(c_ids), nc,
+            _dp(Ais), _dp(bis), _dp(lb), _dp(ub), shared, int(nthreads), _dp(z),
+            _dp(nu) if want_nu else None, _ip(iters), _ip(flags), _dp(res))
+    if refs is None:
+        rc = lib.ref_solve_batch(*args)
+    else:
+        H_refs = _f64(refs[0]).reshape(model.njoints, 36); v_refs = _f64(refs[1]).reshape(model.njoints, 6)
+        rc = lib.ref_solve_batch_refs(*args, _dp(H_refs), _dp(v_refs))
     if rc != 0:
         raise RuntimeError("ref_solve_batch failed with code %d" % rc)
     out = dict(z=z, iters=iters, converged=(flags & 1).astype(bool), primal_infeasible=(flags & 2).astype(bool),

@@ -5,7 +5,8 @@
 Each case draws: a random kinematic tree (3..44 joints, depth-first or breadth-first numbered; 1-DoF joints of every type,
 optionally a free-flyer / planar root, spherical, translation, SphericalZYX, planar and unbounded-revolute joints), 0..4 task
 constraints with a shared or per-instance A, shared or per-instance bounds, an identity / diagonal / full reference cost
-with or without v_ref, tolerances and max_iter, the DEFAULT or the OSQP penalty rule -- and an ENGINE configuration (default
+with or without v_ref -- or per-link references (UpdateReferences) --, tolerances and max_iter, the DEFAULT or the OSQP penalty
+rule, optionally a spare constraint slot (a null constraint in every engine) -- and an ENGINE configuration (default
 plan, k_solve only, k_tail from the first iteration, hand-over after a few iterations, lean kernel with forced escapes, lean
 kernel time-sliced).  The comparison is tests/helpers.py::assert_end_to_end: no instance is dropped."""
 import json
@@ -61,6 +62,13 @@ for case in range(ncase):
         M = rng.normal(size=(6, 6)); wl["H_ref"] = M @ M.T / 6 + 0.5 * np.eye(6); wl["v_ref"] = 0.2 * rng.normal(size=6)
     if rng.random() < 0.3:
         wl["lb"] = -0.5 * (1 + 0.2 * rng.random((B, model.nv))); wl["ub"] = 0.5 * (1 + 0.2 * rng.random((B, model.nv)))
+    refs = None
+    if rng.random() < 0.2:   # per-link references: one weight / target per joint of the caller's model
+        Hs = np.zeros((model.njoints, 6, 6)); vs = 0.2 * rng.normal(size=(model.njoints, 6))
+        for i in range(model.njoints):
+            M = rng.normal(size=(6, 6)); Hs[i] = M @ M.T / 6 + rng.uniform(0.2, 1.0) * np.eye(6)
+        refs = (Hs, vs)
+    spare = int(rng.random() < 0.2 and nc + 1 <= model.njoints - 1)   # eq_c_capacity = num_eq_c + 1
     osqp = bool(rng.random() < 0.2)
     multidof = model.nv != model.njoints - 1
     # (a tolerance of 1e-8 is below the rounding noise of the multi-DoF chain representation and of mu ~ 1e6: the iteration at
@@ -74,9 +82,21 @@ for case in range(ncase):
         os.environ.pop(k, None)
     os.environ.update(env)
     out = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"],
-                          nthreads=8, want_nu=True, **prm)
-    s = loik_amd.BatchedLoik(model, B, **prm, **kw)
-    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+                          nthreads=8, want_nu=True, refs=refs, **prm)
+    s = loik_amd.BatchedLoik(model, B, **prm, **kw, eq_c_capacity=nc + spare)
+    try:
+        if refs is None:
+            s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+        else:
+            s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+            s.UpdateReferences(*refs)
+            s.Solve()
+    except loik_amd.LoikError as e:   # a stated limit of the library (e.g. a tree too bushy for k_solve's LDS slots): not a mismatch
+        summary["refused"] = summary.get("refused", 0) + 1
+        children = np.bincount(np.asarray(model.parents[1:]), minlength=model.njoints)
+        print("case %3d %-12s nb %2d REFUSED: %s (max children %d)" % (case, engine, model.njoints - 1, e, children.max()), flush=True)
+        s.close()
+        continue
     st = s.stats()
     # Rounding budget.  1-DoF trees under the DEFAULT rule: z to 1e-7 on identical-iteration instances and the residuals to
     # 1e-9 + 1e-6 relative.  Multi-DoF chains (a different elimination order than the oracle's nv x nv blocks) and the OSQP
@@ -97,9 +117,10 @@ for case in range(ncase):
     summary["instances"] += B; summary["off_count"] += int((~same).sum())
     e = summary["by_engine"].setdefault(engine, dict(cases=0, mismatches=0))
     e["cases"] += 1; e["mismatches"] += not ok
-    print("case %3d %-12s nb %2d nv %2d nc %d B %4d %s Href %d max_iter %4d tol %.0e %s: same-iteration %.3f max|dz| %.1e off %d "
+    print("case %3d %-12s nb %2d nv %2d nc %d%s B %4d %s Href %s max_iter %4d tol %.0e %s: same-iteration %.3f max|dz| %.1e off %d "
           "lean %d esc %d requeue %d  %s %s" % (
-              case, engine, model.njoints - 1, model.nv, nc, B, model.name[:18], hk, prm["max_iter"], prm["tol_abs"],
+              case, engine, model.njoints - 1, model.nv, nc, "+1" if spare else "  ", B, model.name[:18], "L" if refs else str(hk),
+              prm["max_iter"], prm["tol_abs"],
               "OSQP" if osqp else "DEF ", same.mean(), dz[same].max() if same.any() else 0.0, int((~same).sum()), st["lean_launches"],
               st["lean_escaped"], st["lean_requeues"], "ok" if ok else "MISMATCH", why), flush=True)
     s.close()
