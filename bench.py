@@ -349,6 +349,28 @@ def whole_body_variant(args, device):
     return out
 
 
+def two_in_flight_variant(args, device):
+    """Reported beside the headline (not `value`): TWO headline batches in flight on the one GPU -- two solver handles, two
+    host threads, two streams, different instances -- the way a caller that streams batches would drive it.  The lean launch of
+    one batch ends ragged (a few long-running instances keep their workgroups while most of the machine is idle); the other
+    batch's launch fills that space.  Per-batch latency is NOT better than the headline's; the sum of solves per second is."""
+    from loik_amd import workloads
+    import loik_amd
+    shards = [Shard(g, device, workloads.talos_c3(args.batch, seed=0x101C + 3 + g), args.flags | loik_amd.capi.OPT_OWN_STREAM,
+                    args.max_launch_iters) for g in range(2)]
+    steps = max(2, min(args.steps, 3))
+    try:
+        elapsed = run_shards(shards, steps, 1)
+        res = [sh.results() for sh in shards]
+    finally:
+        for sh in shards:
+            sh.solver.close()
+    solved = sum(r["solved"] for r in res)
+    return {"batches_in_flight": 2, "batch_each": args.batch, "steps_each": steps, "ms_per_pair_of_batches": elapsed / steps * 1e3,
+            "value": solved * steps / elapsed, "unit": "solves/s",
+            "note": "two independent handles on one device; latency per batch is that of a pair"}
+
+
 def main(argv=None, solver_factory=None, device_count=None):
     """solver_factory / device_count: test hooks (tests/test_bench_multi_device.py drives the N-device host logic with a
     stand-in solver on a machine without GPUs); the product path leaves them None"""
@@ -490,6 +512,10 @@ def main(argv=None, solver_factory=None, device_count=None):
                 line["whole_body_variant"] = whole_body_variant(args, device_of(0))
             except Exception as e:  # the headline must survive a failing variant
                 line["whole_body_variant"] = {"failed": repr(e)}
+            try:
+                line["two_batches_in_flight_variant"] = two_in_flight_variant(args, device_of(0))
+            except Exception as e:
+                line["two_batches_in_flight_variant"] = {"failed": repr(e)}
         if n_total == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(wl0)

@@ -62,6 +62,9 @@ enum {
   LOIKB_OPT_FIXED_ITERS = 1, /* run exactly max_iter-1 ADMM iterations, mu frozen, no stopping logic       */
   LOIKB_OPT_NO_H_CACHE = 2,  /* recompute H_i/UDinv/Dinv every iteration like upstream (default: reuse them
                                  while mu is unchanged -- bit-identical results, fewer HBM bytes)            */
+  LOIKB_OPT_OWN_STREAM = 8,  /* the handle creates its own non-blocking HIP stream instead of launching on the null stream:
+                                 two handles on one device then run concurrently (batches in flight from two host threads);
+                                 loikb_set_stream still overrides it                                                  */
   LOIKB_OPT_NO_COMPACTION = 4 /* never repack live instances into dense wavefronts between launches (default:
                                  repack when at most 85 % of the slots are still iterating; results are
                                  bit-identical, but the inter-sweep temporaries His/pis/UDinv/Dinv/r of

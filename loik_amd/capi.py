@@ -51,7 +51,7 @@ class Stats(C.Structure):
 
 # enums of loik_amd.h
 F64, F32 = 0, 1
-OPT_FIXED_ITERS, OPT_NO_H_CACHE, OPT_NO_COMPACTION = 1, 2, 4
+OPT_FIXED_ITERS, OPT_NO_H_CACHE, OPT_NO_COMPACTION, OPT_OWN_STREAM = 1, 2, 4, 8
 IN_DEVICE, A_SHARED, BOUNDS_SHARED, B_SHARED, Q_SHARED = 1, 2, 4, 8, 16
 OUT_DEVICE = 1
 

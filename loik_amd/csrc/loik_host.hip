@@ -160,6 +160,7 @@ struct loikb_solver_impl {
   int device = 0;
   int ncu = 256;  // compute units of the device
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;  // LOIKB_OPT_OWN_STREAM
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
   std::vector<void*> allocs;
   std::mutex alloc_mu;
@@ -1840,6 +1841,10 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, S->device) == hipSuccess && prop.multiProcessorCount > 0) S->ncu = prop.multiProcessorCount;
   }
+  if (opts->flags & LOIKB_OPT_OWN_STREAM) {
+    HIPTRY(hipStreamCreateWithFlags(&S->own_stream, hipStreamNonBlocking));
+    S->stream = S->own_stream;
+  }
   HIPTRY(hipEventCreate(&S->ev_t0));
   HIPTRY(hipEventCreate(&S->ev_t1));
   HIPTRY(hipEventCreate(&S->ev_fork));
@@ -1890,6 +1895,7 @@ int loikb_destroy(loikb_solver* S)
   if (S->d_pass) (void)hipFree(S->d_pass);
   if (S->d_pass_cslot) (void)hipFree(S->d_pass_cslot);
   (void)hipGetLastError();  // a failed free must not surface in the next solver's first launch check
+  if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
   if (S->ev_fork) (void)hipEventDestroy(S->ev_fork);
   if (S->ev_t0) (void)hipEventDestroy(S->ev_t0);
   if (S->ev_t1) (void)hipEventDestroy(S->ev_t1);
