@@ -1,0 +1,133 @@
+// loik_amd/pinocchio_adapter.hpp -- from a Pinocchio model / Eigen arguments to the types of loik_amd/loik.hpp.
+//
+// What a caller of the reference holds is a `pinocchio::Model` (built by urdf::buildModel, /root/reference/tests/loik-loid.cpp:
+// 108-113) and Eigen arguments (`Mat6x6 H_ref`, `Motion v_ref`, `PINOCCHIO_ALIGNED_STD_VECTOR(Mat6x6) Ais`, `DVec lb`, ...,
+// loik-loid-optimized.hpp:335-361).  This header converts them.  It is written against the INTERFACE of those types, as
+// templates, so that it compiles and is tested in this repository without Pinocchio or Eigen (tests/cpp/test_adapter.cpp drives
+// it with a model type of the same shape); with Pinocchio included before this header, `to_loik_amd(const pinocchio::Model&)`
+// is available directly.
+//
+//   members used of the model type M:   njoints, nq, nv (int-like), parents[i], names[i], joints[i], jointPlacements[i]
+//   of a joint model  M::joints[i]:     shortname() -> std::string ("JointModelRZ", "JointModelRevoluteUnaligned", ...),
+//                                        idx_q(), idx_v()
+//   of a placement    jointPlacements[i]: rotation()(r, c), translation()[k]              (pinocchio::SE3)
+//   AxisOf(joint, shortname) -> something indexable [0..2]: the axis of an unaligned joint (JointModelRevoluteUnaligned::axis)
+#pragma once
+
+#include <cstddef>
+#include <stdexcept>
+#include <string>
+
+#include "loik_amd/loik.hpp"
+
+namespace loik_amd {
+
+// joint type of include/loik_amd_models.h for a Pinocchio joint short name; LOIKB_J_NONE for an unknown one
+inline int joint_type_of(const std::string& n)
+{
+  static const struct { const char* name; int type; } table[] = {
+      {"JointModelRX", LOIKB_J_RX}, {"JointModelRY", LOIKB_J_RY}, {"JointModelRZ", LOIKB_J_RZ},
+      {"JointModelPX", LOIKB_J_PX}, {"JointModelPY", LOIKB_J_PY}, {"JointModelPZ", LOIKB_J_PZ},
+      {"JointModelRevoluteUnaligned", LOIKB_J_RU}, {"JointModelPrismaticUnaligned", LOIKB_J_PU},
+      {"JointModelFreeFlyer", LOIKB_J_FREEFLYER},        // nq 7 (t, quat xyzw), nv 6
+      {"JointModelSpherical", LOIKB_J_SPHERICAL},        // nq 4 (quat xyzw), nv 3
+      {"JointModelTranslation", LOIKB_J_TRANSLATION},    // nq 3, nv 3
+      {"JointModelSphericalZYX", LOIKB_J_SPHERICAL_ZYX}, // nq 3 (z, y, x angles), nv 3
+      {"JointModelPlanar", LOIKB_J_PLANAR},              // nq 4 (x, y, cos, sin), nv 3
+      {"JointModelRUBX", LOIKB_J_RUBX}, {"JointModelRUBY", LOIKB_J_RUBY}, {"JointModelRUBZ", LOIKB_J_RUBZ},  // nq 2 (cos, sin)
+  };
+  for (const auto& e : table)
+    if (n == e.name) return e.type;
+  return LOIKB_J_NONE;
+}
+
+template <class PinocchioModel, class AxisOf>
+Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of)
+{
+  Model o;
+  o.njoints = static_cast<int>(m.njoints); o.nq = static_cast<int>(m.nq); o.nv = static_cast<int>(m.nv);
+  for (std::size_t i = 0; i < static_cast<std::size_t>(m.njoints); ++i) {
+    o.parents.push_back(static_cast<int>(m.parents[i]));
+    o.idx_q.push_back(i ? static_cast<int>(m.joints[i].idx_q()) : 0);
+    o.idx_v.push_back(i ? static_cast<int>(m.joints[i].idx_v()) : 0);
+    const std::string n = i ? m.joints[i].shortname() : std::string();
+    const int t = i ? joint_type_of(n) : LOIKB_J_NONE;
+    if (i && t == LOIKB_J_NONE)
+      throw std::runtime_error("loik_amd: joint type '" + n + "' of joint '" + m.names[i] +
+                               "' is not supported (composite, mimic, helical, universal, unbounded-unaligned)");
+    double ax[3] = {0.0, 0.0, 0.0};
+    if (t == LOIKB_J_RU || t == LOIKB_J_PU) {
+      const auto a = axis_of(m.joints[i], n);
+      for (int k = 0; k < 3; ++k) ax[k] = a[k];
+    }
+    o.jtype.push_back(t);
+    o.axis.insert(o.axis.end(), {ax[0], ax[1], ax[2]});
+    const auto& P = m.jointPlacements[i];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) o.jointPlacements.push_back(P.rotation()(r, c));  // row-major here, whatever Eigen stores
+    for (int k = 0; k < 3; ++k) o.jointPlacements.push_back(P.translation()[k]);
+    o.names.push_back(m.names[i]);
+  }
+  return o;
+}
+
+// Eigen's 6x6 (column-major by default) -> row-major array
+template <class Matrix6>
+Mat6x6 to_rowmajor(const Matrix6& M)
+{
+  Mat6x6 o;
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) o[6 * r + c] = M(r, c);
+  return o;
+}
+// pinocchio::Motion (toVector() = [linear; angular]) or any 6-vector with operator[]
+template <class MotionLike>
+auto to_vec6(const MotionLike& v) -> decltype(v.toVector(), Vec6())
+{
+  Vec6 o;
+  const auto x = v.toVector();
+  for (int k = 0; k < 6; ++k) o[k] = x[k];
+  return o;
+}
+template <class VectorLike>
+auto to_vec6(const VectorLike& v) -> decltype(v[0], Vec6())
+{
+  Vec6 o;
+  for (int k = 0; k < 6; ++k) o[k] = v[k];
+  return o;
+}
+// Eigen::VectorXd -> DVec
+template <class VectorLike>
+DVec to_dvec(const VectorLike& v)
+{
+  DVec o(static_cast<std::size_t>(v.size()));
+  for (std::size_t k = 0; k < o.size(); ++k) o[k] = v[static_cast<decltype(v.size())>(k)];
+  return o;
+}
+// aligned_vector<Mat6x6> / <Vec6> -> std::vector of the array types
+template <class Matrices>
+std::vector<Mat6x6> to_rowmajor_list(const Matrices& Ms)
+{
+  std::vector<Mat6x6> o;
+  for (const auto& M : Ms) o.push_back(to_rowmajor(M));
+  return o;
+}
+template <class Vectors>
+std::vector<Vec6> to_vec6_list(const Vectors& vs)
+{
+  std::vector<Vec6> o;
+  for (const auto& v : vs) o.push_back(to_vec6(v));
+  return o;
+}
+
+#ifdef PINOCCHIO_MAJOR_VERSION  // <pinocchio/...> was included before this header
+inline Model to_loik_amd(const pinocchio::Model& m)
+{
+  return to_loik_amd(m, [](const pinocchio::JointModel& j, const std::string& n) {
+    return n == "JointModelRevoluteUnaligned" ? boost::get<pinocchio::JointModelRevoluteUnaligned>(j.toVariant()).axis
+                                              : boost::get<pinocchio::JointModelPrismaticUnaligned>(j.toVariant()).axis;
+  });
+}
+#endif
+
+}  // namespace loik_amd

@@ -1,0 +1,160 @@
+// CPU test of include/loik_amd/pinocchio_adapter.hpp: the conversion from a Pinocchio-shaped model and Eigen-shaped arguments
+// to the wrapper's types.  Pinocchio / Eigen are not in this image; `shape::` below has the INTERFACE the adapter reads of
+// pinocchio::Model / JointModel / SE3 (member names, index types, column-major rotation storage like Eigen) and nothing else.
+// Round trip: built-in table -> shape::Model -> to_loik_amd -> must equal the table.  No GPU, no library call that launches.
+#include "loik_amd/pinocchio_adapter.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+using namespace loik_amd;
+
+static int failures = 0;
+#define CHECK(cond)                                                              \
+  do {                                                                           \
+    if (!(cond)) { ++failures; std::printf("CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); } \
+  } while (0)
+
+namespace shape {
+struct Rotation {  // Eigen::Matrix3d: column-major storage, (r, c) access
+  double d[9];
+  double operator()(int r, int c) const { return d[3 * c + r]; }
+};
+struct Translation {
+  double d[3];
+  double operator[](int k) const { return d[k]; }
+};
+struct SE3 {
+  Rotation R;
+  Translation t;
+  const Rotation& rotation() const { return R; }
+  const Translation& translation() const { return t; }
+};
+struct JointModel {
+  std::string sn;
+  int iq = 0, iv = 0;
+  double ax[3] = {0, 0, 0};
+  std::string shortname() const { return sn; }
+  int idx_q() const { return iq; }
+  int idx_v() const { return iv; }
+};
+struct Model {
+  int njoints = 0, nq = 0, nv = 0;
+  std::vector<std::size_t> parents;  // JointIndex
+  std::vector<std::string> names;
+  std::vector<JointModel> joints;
+  std::vector<SE3> jointPlacements;
+};
+struct Matrix6 {  // column-major 6x6
+  double d[36];
+  double operator()(int r, int c) const { return d[6 * c + r]; }
+};
+struct Vector6 {
+  double d[6];
+  double operator[](int k) const { return d[k]; }
+};
+struct Motion {
+  Vector6 v;
+  Vector6 toVector() const { return v; }
+};
+struct VectorX {
+  std::vector<double> d;
+  long size() const { return (long)d.size(); }
+  double operator[](long k) const { return d[(std::size_t)k]; }
+};
+}  // namespace shape
+
+static const char* short_name(int t)
+{
+  static const char* names[] = {"", "JointModelRX", "JointModelRY", "JointModelRZ", "JointModelPX", "JointModelPY", "JointModelPZ",
+                                "JointModelRevoluteUnaligned", "JointModelPrismaticUnaligned", "JointModelFreeFlyer",
+                                "JointModelSpherical", "JointModelTranslation", "JointModelSphericalZYX", "JointModelPlanar",
+                                "JointModelRUBX", "JointModelRUBY", "JointModelRUBZ"};
+  return names[t];
+}
+
+static shape::Model pinocchio_shaped(const Model& m)
+{
+  shape::Model p;
+  p.njoints = m.njoints; p.nq = m.nq; p.nv = m.nv;
+  for (int i = 0; i < m.njoints; ++i) {
+    p.parents.push_back((std::size_t)m.parents[i]);
+    p.names.push_back(m.names[i]);
+    shape::JointModel j;
+    j.sn = short_name(m.jtype[i]); j.iq = m.idx_q[i]; j.iv = m.idx_v[i];
+    for (int k = 0; k < 3; ++k) j.ax[k] = m.axis[3 * i + k];
+    p.joints.push_back(j);
+    shape::SE3 P;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) P.R.d[3 * c + r] = m.jointPlacements[12 * i + 3 * r + c];
+    for (int k = 0; k < 3; ++k) P.t.d[k] = m.jointPlacements[12 * i + 9 + k];
+    p.jointPlacements.push_back(P);
+  }
+  return p;
+}
+
+static void round_trip(const Model& m)
+{
+  const shape::Model p = pinocchio_shaped(m);
+  const Model o = to_loik_amd(p, [](const shape::JointModel& j, const std::string&) { return j.ax; });
+  CHECK(o.njoints == m.njoints && o.nq == m.nq && o.nv == m.nv);
+  CHECK(o.parents == m.parents && o.jtype == m.jtype && o.idx_q == m.idx_q && o.idx_v == m.idx_v);
+  CHECK(o.names == m.names && o.jointPlacements == m.jointPlacements);
+  for (int i = 1; i < m.njoints; ++i)
+    for (int k = 0; k < 3; ++k) {
+      // aligned joints carry no axis in Pinocchio: the adapter leaves it zero, the library derives it from the type
+      const bool unaligned = m.jtype[i] == LOIKB_J_RU || m.jtype[i] == LOIKB_J_PU;
+      CHECK(o.axis[3 * i + k] == (unaligned ? m.axis[3 * i + k] : 0.0));
+    }
+}
+
+int main()
+{
+  for (const char* name : {"talos32", "talos32_freeflyer", "talos44", "panda7", "panda9"}) round_trip(Model::Builtin(name));
+  {  // a model with every joint type, unaligned axes, rotated placements
+    Model m;
+    const int types[] = {LOIKB_J_NONE, LOIKB_J_FREEFLYER, LOIKB_J_RU, LOIKB_J_PU, LOIKB_J_SPHERICAL, LOIKB_J_TRANSLATION,
+                         LOIKB_J_SPHERICAL_ZYX, LOIKB_J_PLANAR, LOIKB_J_RUBY, LOIKB_J_PZ, LOIKB_J_RX};
+    const int nqs[] = {0, 7, 1, 1, 4, 3, 3, 4, 2, 1, 1}, nvs[] = {0, 6, 1, 1, 3, 3, 3, 3, 1, 1, 1};
+    m.njoints = 11;
+    for (int i = 0; i < m.njoints; ++i) {
+      m.parents.push_back(i ? (i - 1) / 2 : 0);
+      m.jtype.push_back(types[i]);
+      m.idx_q.push_back(m.nq); m.idx_v.push_back(m.nv);
+      m.nq += nqs[i]; m.nv += nvs[i];
+      const double a[3] = {std::sin(1.0 + i), std::cos(2.0 * i), 0.3};
+      const double n = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+      const bool un = types[i] == LOIKB_J_RU || types[i] == LOIKB_J_PU;
+      for (int k = 0; k < 3; ++k) m.axis.push_back(un ? a[k] / n : 0.0);
+      const double c = std::cos(0.3 * i), s = std::sin(0.3 * i);
+      const double P[12] = {c, -s, 0, s, c, 0, 0, 0, 1, 0.1 * i, -0.2, 0.05 * i};  // Rz(0.3 i): not symmetric -> order matters
+      m.jointPlacements.insert(m.jointPlacements.end(), P, P + 12);
+      m.names.push_back(i ? "joint_" + std::to_string(i) : "universe");
+    }
+    round_trip(m);
+    shape::Model p = pinocchio_shaped(m);
+    p.joints[3].sn = "JointModelComposite";
+    bool thrown = false;
+    try { (void)to_loik_amd(p, [](const shape::JointModel& j, const std::string&) { return j.ax; }); }
+    catch (const std::runtime_error& e) { thrown = std::strstr(e.what(), "JointModelComposite") && std::strstr(e.what(), "joint_3"); }
+    CHECK(thrown);
+  }
+  {  // argument conversions: column-major in, row-major out; Motion through toVector(); lists; VectorXd
+    shape::Matrix6 M;
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) M.d[6 * c + r] = 10.0 * r + c;
+    const Mat6x6 R = to_rowmajor(M);
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) CHECK(R[6 * r + c] == 10.0 * r + c);
+    shape::Motion v{{{1, 2, 3, 4, 5, 6}}};
+    const Vec6 a = to_vec6(v), b = to_vec6(v.v);
+    for (int k = 0; k < 6; ++k) CHECK(a[k] == k + 1 && b[k] == k + 1);
+    CHECK(to_rowmajor_list(std::vector<shape::Matrix6>{M, M}).size() == 2);
+    CHECK(to_vec6_list(std::vector<shape::Vector6>{v.v})[0][5] == 6.0);
+    const DVec d = to_dvec(shape::VectorX{{0.5, -0.5, 2.0}});
+    CHECK(d.size() == 3 && d[2] == 2.0);
+  }
+  std::printf(failures ? "%d CHECKS FAILED\n" : "all adapter checks passed\n", failures);
+  return failures ? 1 : 0;
+}

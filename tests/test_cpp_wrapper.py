@@ -23,6 +23,18 @@ def test_cpp_wrapper_compiles():
     assert os.path.exists(EXE)
 
 
+def test_pinocchio_adapter_round_trip():
+    """CPU: include/loik_amd/pinocchio_adapter.hpp against a model type with pinocchio::Model's interface (the image has no
+    Pinocchio / Eigen): every built-in table and a model with every joint type go through and come back equal"""
+    src = os.path.join(ROOT, "tests", "cpp", "test_adapter.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "test_adapter")
+    libdir = os.path.join(ROOT, "loik_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                           "-L", libdir, "-lloik_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "all adapter checks passed" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.gpu
 def test_cpp_wrapper_matches_oracle():
     build()
