@@ -427,7 +427,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     load_instance(fetch_plain());
   }
 #ifdef LOIKB_TAIL_PROF
-  unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
+  unsigned long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
   const unsigned long long wall0_ = wall_clock64(), clk0_ = tprev_;
 #endif
   unsigned int poll_skip = 0;
@@ -472,22 +472,14 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       } else {
         if (isj) {
           const typename Vec2<T>::type* hp = reinterpret_cast<const typename Vec2<T>::type*>(hslots);
-          // (in two parts: 22 doubles in flight at once would cost registers the level loops need)
           {
-            typename Vec2<T>::type in[6];
+            typename Vec2<T>::type in[11];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) in[k] = hp[hslot_pair(lidx, ndec, dsl, G, k, jlane)];
+            for (int k = 0; k < 11; ++k) in[k] = hp[hslot_pair(lidx, ndec, dsl, G, k, jlane)];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) { hcur[2 * k] = in[k].x; hcur[2 * k + 1] = in[k].y; }
-          }
-          {
-            typename Vec2<T>::type in[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) in[k] = hp[hslot_pair(lidx, ndec, dsl, G, 6 + k, jlane)];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { hcur[12 + 2 * k] = in[k].x; hcur[13 + 2 * k] = in[k].y; }
-            hcur[20] = in[4].x;
-            dinv = in[4].y;
+            for (int k = 0; k < 10; ++k) { hcur[2 * k] = in[k].x; hcur[2 * k + 1] = in[k].y; }
+            hcur[20] = in[10].x;
+            dinv = in[10].y;
           }
           // UDinv = (H S) Dinv  (calc_aba, hxx:60-63) from the slot just written to LDS
 #pragma unroll
@@ -502,6 +494,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         ++n_slot_loads;
       }
     }
+    TAIL_TP(8)
     const bool act = !done;
 #ifdef LOIKB_TAIL_PROF
     dbg_last_ = wall_clock64();
@@ -745,6 +738,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
       }
       finishing = done;
+      TAIL_TP(9)
       tail_sync();  // every lane has read the instance's scalars before lane 0 rewrites them
       if (jlane == 0) {
         isc[IS_ITER] = (T)iter; isc[IS_STATUS] = (T)status;
@@ -759,6 +753,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     } else {
       tail_sync();
     }
+    TAIL_TP(10)
     // an escaped instance (mu left the precomputed decades) is written back as it is
     const bool leaving = done && has_inst;
     // ---- the norms the getters report (13 more maxima): only when some instance of the wavefront stops ------------------
@@ -785,6 +780,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       if (finishing && jlane == 0) isc[IS_G] = isc[IS_RED + 0];
       tail_sync();
     }
+    TAIL_TP(11)
 #ifdef LOIKB_TAIL_PROF
     if (__any(leaving)) ++dbg_sw_;
 #endif
@@ -813,6 +809,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #ifdef LOIKB_TAIL_PROF
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     for (int k = 0; k < 8; ++k) g_tail_prof[k] = prof_[k];
+    for (int k = 8; k < 12; ++k) g_tail_prof[2 + k] = prof_[k];
     g_tail_prof[8] = n_wave_iters;
     // shader clock in kHz: clock64 ticks per wall_clock64 tick (100 MHz)
     g_tail_prof[9] = (clock64() - clk0_) * 100000ull / (wall_clock64() - wall0_ + 1);

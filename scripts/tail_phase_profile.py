@@ -18,12 +18,15 @@ for B in [int(x) for x in sys.argv[1:]] or [64, 4096]:  # >= 64 instances: the l
     for _ in range(2):
         s.Solve()
     st = s.stats()
-    out = (C.c_ulonglong * 10)()
+    out = (C.c_ulonglong * 14)()
     assert L.loikb_debug_tail_prof(out) == 0
     n = out[8]
-    tot = sum(out[:8])
+    tot = sum(out[:8]) + sum(out[10:14])
     print("B=%d: tail %.2f ms; wavefront 0: %d iterations, %.0f cycles per iteration%s" % (
         B, st["tail_ms"], n, tot / n, ("; clock64 runs at %.0f MHz against the 100 MHz wall clock" % (out[9] / 1e3)) if out[9] else ""))
     for k in range(8):
         print("   %-34s %8.0f cycles  %5.1f %%" % (NAMES[k], out[k] / n, 100.0 * out[k] / tot))
+    for k, nm in enumerate(["8 loop top + decade slot load (was in 0)", "9 stop / mu logic (was in 7)", "10 instance scalars written (was in 7)",
+                            "11 finishing norms (was in 7)"]):
+        print("   %-34s %8.0f cycles  %5.1f %%" % (nm, out[10 + k] / n, 100.0 * out[10 + k] / tot))
     s.close()
