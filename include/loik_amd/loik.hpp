@@ -48,6 +48,10 @@ struct Model {
   std::vector<double> axis;             // [njoints][3]
   std::vector<double> jointPlacements;  // [njoints][12]: R row-major, t
   std::vector<std::string> names;
+  // JointModelComposite (empty when the model has none): joint i of type LOIKB_J_COMPOSITE = sub-joints comp_first[i] ..
+  // comp_first[i] + comp_count[i] - 1 of comp_jtype / comp_axis / comp_placement (include/loik_amd_models.h)
+  std::vector<int> comp_first, comp_count, comp_jtype;
+  std::vector<double> comp_axis, comp_placement;
 
   static Model Builtin(const std::string& name)
   {
@@ -76,6 +80,10 @@ struct Model {
     d.njoints = njoints; d.nq = nq; d.nv = nv;
     d.parents = parents.data(); d.jtype = jtype.data(); d.axis = axis.data();
     d.idx_q = idx_q.data(); d.idx_v = idx_v.data(); d.placement = jointPlacements.data();
+    if (!comp_jtype.empty()) {
+      d.comp_first = comp_first.data(); d.comp_count = comp_count.data(); d.comp_jtype = comp_jtype.data();
+      d.comp_axis = comp_axis.data(); d.comp_placement = comp_placement.data();
+    }
     return d;
   }
 };

@@ -12,11 +12,15 @@
 //                                        idx_q(), idx_v()
 //   of a placement    jointPlacements[i]: rotation()(r, c), translation()[k]              (pinocchio::SE3)
 //   AxisOf(joint, shortname) -> something indexable [0..2]: the axis of an unaligned joint (JointModelRevoluteUnaligned::axis)
+//   SubJointsOf(joint) -> a range of (sub-joint model, placement) pairs (.first / .second) of a JointModelComposite
+//                         (JointModelComposite::joints[k], ::jointPlacements[k]); sub-joints must be 1-DoF joints
 #pragma once
 
 #include <cstddef>
 #include <stdexcept>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "loik_amd/loik.hpp"
 
@@ -35,17 +39,41 @@ inline int joint_type_of(const std::string& n)
       {"JointModelSphericalZYX", LOIKB_J_SPHERICAL_ZYX}, // nq 3 (z, y, x angles), nv 3
       {"JointModelPlanar", LOIKB_J_PLANAR},              // nq 4 (x, y, cos, sin), nv 3
       {"JointModelRUBX", LOIKB_J_RUBX}, {"JointModelRUBY", LOIKB_J_RUBY}, {"JointModelRUBZ", LOIKB_J_RUBZ},  // nq 2 (cos, sin)
+      {"JointModelComposite", LOIKB_J_COMPOSITE},        // of 1-DoF joints: loikb_model_desc.comp_*
   };
   for (const auto& e : table)
     if (n == e.name) return e.type;
   return LOIKB_J_NONE;
 }
 
-template <class PinocchioModel, class AxisOf>
-Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of)
+namespace detail {
+template <class SE3Like>
+void push_placement(std::vector<double>& out, const SE3Like& P)
+{
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) out.push_back(P.rotation()(r, c));  // row-major here, whatever Eigen stores
+  for (int k = 0; k < 3; ++k) out.push_back(P.translation()[k]);
+}
+struct NoPlacement {  // (never read: NoComposite throws)
+  struct Rot { double operator()(int, int) const { return 0.0; } };
+  Rot rotation() const { return Rot(); }
+  const double* translation() const { static const double z[3] = {0.0, 0.0, 0.0}; return z; }
+};
+struct NoComposite {
+  template <class J>
+  std::vector<std::pair<J, NoPlacement>> operator()(const J&) const
+  {
+    throw std::runtime_error("loik_amd: the model has a JointModelComposite: pass a SubJointsOf functor to to_loik_amd");
+  }
+};
+}  // namespace detail
+
+template <class PinocchioModel, class AxisOf, class SubJointsOf>
+Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joints_of)
 {
   Model o;
   o.njoints = static_cast<int>(m.njoints); o.nq = static_cast<int>(m.nq); o.nv = static_cast<int>(m.nv);
+  bool any_composite = false;
   for (std::size_t i = 0; i < static_cast<std::size_t>(m.njoints); ++i) {
     o.parents.push_back(static_cast<int>(m.parents[i]));
     o.idx_q.push_back(i ? static_cast<int>(m.joints[i].idx_q()) : 0);
@@ -54,21 +82,47 @@ Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of)
     const int t = i ? joint_type_of(n) : LOIKB_J_NONE;
     if (i && t == LOIKB_J_NONE)
       throw std::runtime_error("loik_amd: joint type '" + n + "' of joint '" + m.names[i] +
-                               "' is not supported (composite, mimic, helical, universal, unbounded-unaligned)");
+                               "' is not supported (mimic, helical, universal, unbounded-unaligned)");
     double ax[3] = {0.0, 0.0, 0.0};
     if (t == LOIKB_J_RU || t == LOIKB_J_PU) {
       const auto a = axis_of(m.joints[i], n);
       for (int k = 0; k < 3; ++k) ax[k] = a[k];
     }
+    o.comp_first.push_back(static_cast<int>(o.comp_jtype.size()));
+    int count = 0;
+    if (t == LOIKB_J_COMPOSITE) {
+      any_composite = true;
+      for (const auto& sub : sub_joints_of(m.joints[i])) {
+        const std::string sn = sub.first.shortname();
+        const int st = joint_type_of(sn);
+        const bool one_dof = (st >= LOIKB_J_RX && st <= LOIKB_J_PU) || (st >= LOIKB_J_RUBX && st <= LOIKB_J_RUBZ);
+        if (!one_dof)
+          throw std::runtime_error("loik_amd: sub-joint '" + sn + "' of the composite joint '" + m.names[i] + "' is not a 1-DoF joint");
+        double sa[3] = {0.0, 0.0, 0.0};
+        if (st == LOIKB_J_RU || st == LOIKB_J_PU) {
+          const auto a = axis_of(sub.first, sn);
+          for (int k = 0; k < 3; ++k) sa[k] = a[k];
+        }
+        o.comp_jtype.push_back(st);
+        o.comp_axis.insert(o.comp_axis.end(), {sa[0], sa[1], sa[2]});
+        detail::push_placement(o.comp_placement, sub.second);
+        ++count;
+      }
+    }
+    o.comp_count.push_back(count);
     o.jtype.push_back(t);
     o.axis.insert(o.axis.end(), {ax[0], ax[1], ax[2]});
-    const auto& P = m.jointPlacements[i];
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) o.jointPlacements.push_back(P.rotation()(r, c));  // row-major here, whatever Eigen stores
-    for (int k = 0; k < 3; ++k) o.jointPlacements.push_back(P.translation()[k]);
+    detail::push_placement(o.jointPlacements, m.jointPlacements[i]);
     o.names.push_back(m.names[i]);
   }
+  if (!any_composite) { o.comp_first.clear(); o.comp_count.clear(); }
   return o;
+}
+
+template <class PinocchioModel, class AxisOf>
+Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of)
+{
+  return to_loik_amd(m, axis_of, detail::NoComposite());
 }
 
 // Eigen's 6x6 (column-major by default) -> row-major array
@@ -123,10 +177,17 @@ std::vector<Vec6> to_vec6_list(const Vectors& vs)
 #ifdef PINOCCHIO_MAJOR_VERSION  // <pinocchio/...> was included before this header
 inline Model to_loik_amd(const pinocchio::Model& m)
 {
-  return to_loik_amd(m, [](const pinocchio::JointModel& j, const std::string& n) {
+  auto axis_of = [](const pinocchio::JointModel& j, const std::string& n) {
     return n == "JointModelRevoluteUnaligned" ? boost::get<pinocchio::JointModelRevoluteUnaligned>(j.toVariant()).axis
                                               : boost::get<pinocchio::JointModelPrismaticUnaligned>(j.toVariant()).axis;
-  });
+  };
+  auto sub_joints_of = [](const pinocchio::JointModel& j) {
+    const auto& c = boost::get<pinocchio::JointModelComposite>(j.toVariant());
+    std::vector<std::pair<pinocchio::JointModel, pinocchio::SE3>> subs;
+    for (std::size_t k = 0; k < c.joints.size(); ++k) subs.emplace_back(pinocchio::JointModel(c.joints[k]), c.jointPlacements[k]);
+    return subs;
+  };
+  return to_loik_amd(m, axis_of, sub_joints_of);
 }
 #endif
 

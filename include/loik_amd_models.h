@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 /* joint types; names follow Pinocchio's JointModel{RX,RY,RZ,PX,PY,PZ,RevoluteUnaligned,PrismaticUnaligned,
- * FreeFlyer,Spherical,Translation} */
+ * FreeFlyer,Spherical,Translation,SphericalZYX,Planar,RUBX/Y/Z,Composite} */
 enum {
   LOIKB_J_NONE = 0, /* universe */
   LOIKB_J_RX = 1,
@@ -42,7 +42,11 @@ enum {
   LOIKB_J_PLANAR = 13,     /* JointModelPlanar: nq 4 (x, y, cos, sin), nv 3 (vx, vy, wz in the joint frame)               */
   LOIKB_J_RUBX = 14,       /* JointModelRUBX / RUBY / RUBZ (revolute unbounded): nq 2 (cos, sin), nv 1                     */
   LOIKB_J_RUBY = 15,
-  LOIKB_J_RUBZ = 16
+  LOIKB_J_RUBZ = 16,
+  LOIKB_J_COMPOSITE = 17   /* JointModelComposite of 1-DoF joints: see loikb_model_desc.comp_*; nq / nv = the sums over its
+                              sub-joints, coordinates in sub-joint order.  M = prod_k (placement_k * M_k(q_k)), the motion
+                              subspace column of sub-joint k is its S_k seen from the last sub-joint's frame (q-dependent);
+                              on the device it is the chain of its sub-joints with massless links in between                */
 };
 
 typedef struct loikb_model_desc {
@@ -54,6 +58,16 @@ typedef struct loikb_model_desc {
   const int *idx_q;        /* [njoints] joints[i].idx_q(): cumulative in joint order          */
   const int *idx_v;        /* [njoints] joints[i].idx_v(): cumulative in joint order          */
   const double *placement; /* [njoints][12] jointPlacements[i]: R row-major (9), then t (3)   */
+  /* JointModelComposite (all NULL / ignored when the model has none): joint i of type LOIKB_J_COMPOSITE consists of the
+     sub-joints comp_first[i] .. comp_first[i] + comp_count[i] - 1 of the three arrays below -- what
+     JointModelComposite::addJoint(jmodel, placement) stores: the sub-joint's type (a 1-DoF type: R*, P*, RU, PU, RUB*), its
+     axis (RU / PU) and its placement relative to the previous sub-joint's frame (the first: relative to the frame
+     jointPlacements[i] defines).  comp_count[i] <= 6. */
+  const int *comp_first;        /* [njoints] */
+  const int *comp_count;        /* [njoints] */
+  const int *comp_jtype;        /* [n_sub]   */
+  const double *comp_axis;      /* [n_sub][3]  */
+  const double *comp_placement; /* [n_sub][12] */
 } loikb_model_desc;
 
 /*

@@ -25,7 +25,8 @@ class LoikError(RuntimeError):
 
 class ModelDesc(C.Structure):
     _fields_ = [("njoints", C.c_int), ("nq", C.c_int), ("nv", C.c_int), ("parents", _ip), ("jtype", _ip),
-                ("axis", _dp), ("idx_q", _ip), ("idx_v", _ip), ("placement", _dp)]
+                ("axis", _dp), ("idx_q", _ip), ("idx_v", _ip), ("placement", _dp),
+                ("comp_first", _ip), ("comp_count", _ip), ("comp_jtype", _ip), ("comp_axis", _dp), ("comp_placement", _dp)]
 
 
 class Options(C.Structure):
@@ -172,6 +173,7 @@ def _check(rc):
 J_FREEFLYER, J_SPHERICAL, J_TRANSLATION = 9, 10, 11
 # JointModelSphericalZYX, JointModelPlanar, JointModelRUBX / RUBY / RUBZ
 J_SPHERICAL_ZYX, J_PLANAR, J_RUBX, J_RUBY, J_RUBZ = 12, 13, 14, 15, 16
+J_COMPOSITE = 17  # JointModelComposite of 1-DoF joints (Model(..., composite={joint: [(jtype, axis, placement12), ...]}))
 JOINT_NQ = {J_FREEFLYER: 7, J_SPHERICAL: 4, J_TRANSLATION: 3, J_SPHERICAL_ZYX: 3, J_PLANAR: 4, J_RUBX: 2, J_RUBY: 2, J_RUBZ: 2}
 JOINT_NV = {J_FREEFLYER: 6, J_SPHERICAL: 3, J_TRANSLATION: 3, J_SPHERICAL_ZYX: 3, J_PLANAR: 3}
 
@@ -180,15 +182,35 @@ class Model:
     """Kinematic tree with Pinocchio's member names: njoints, nq, nv, parents, jointPlacements (here `placement`,
     [nj][12] = R row-major + t), joint type / axis / idx_q / idx_v per joint."""
 
-    def __init__(self, parents, jtype, axis, placement, names=None, q_lo=None, q_hi=None, name="custom"):
+    def __init__(self, parents, jtype, axis, placement, names=None, q_lo=None, q_hi=None, name="custom", composite=None):
         self.parents = np.ascontiguousarray(parents, dtype=np.int32)
         self.jtype = np.ascontiguousarray(jtype, dtype=np.int32)
         self.axis = np.ascontiguousarray(axis, dtype=np.float64).reshape(-1, 3)
         self.placement = np.ascontiguousarray(placement, dtype=np.float64).reshape(-1, 12)
         self.njoints = int(self.parents.size)
+        # JointModelComposite: composite[i] = [(sub-joint type, axis [3], placement [12] relative to the previous sub-joint), ...]
+        self.composite = {int(i): [(int(t), np.asarray(a, dtype=np.float64).reshape(3), np.asarray(P, dtype=np.float64).reshape(12))
+                                   for t, a, P in subs] for i, subs in (composite or {}).items()}
+        self.comp_first = np.zeros(self.njoints, dtype=np.int32); self.comp_count = np.zeros(self.njoints, dtype=np.int32)
+        ct, ca, cp = [], [], []
+        for i in sorted(self.composite):
+            self.comp_first[i] = len(ct); self.comp_count[i] = len(self.composite[i])
+            for t, a, P in self.composite[i]:
+                ct.append(t); ca.append(a); cp.append(P)
+        self.comp_jtype = np.ascontiguousarray(ct if ct else [0], dtype=np.int32)
+        self.comp_axis = np.ascontiguousarray(ca if ca else [[0, 0, 0]], dtype=np.float64).reshape(-1, 3)
+        self.comp_placement = np.ascontiguousarray(cp if cp else [[0] * 12], dtype=np.float64).reshape(-1, 12)
+
+        def nq_of(i, t):
+            if t == J_COMPOSITE:
+                return sum(JOINT_NQ.get(st, 1) for st, _, _ in self.composite[i])
+            return JOINT_NQ.get(t, 1)
+
+        def nv_of(i, t):
+            return len(self.composite[i]) if t == J_COMPOSITE else JOINT_NV.get(t, 1)
         # joints[i].nq() / nv() / idx_q() / idx_v() of Pinocchio: cumulative in joint order
-        nqs = np.array([JOINT_NQ.get(int(t), 1) if i else 0 for i, t in enumerate(self.jtype)], dtype=np.int32)
-        nvs = np.array([JOINT_NV.get(int(t), 1) if i else 0 for i, t in enumerate(self.jtype)], dtype=np.int32)
+        nqs = np.array([nq_of(i, int(t)) if i else 0 for i, t in enumerate(self.jtype)], dtype=np.int32)
+        nvs = np.array([nv_of(i, int(t)) if i else 0 for i, t in enumerate(self.jtype)], dtype=np.int32)
         self.nqs, self.nvs = nqs, nvs
         self.nq, self.nv = int(nqs.sum()), int(nvs.sum())
         self.idx_q = np.ascontiguousarray(np.concatenate([[0], np.cumsum(nqs)[:-1]]), dtype=np.int32)
@@ -205,7 +227,9 @@ class Model:
         return ModelDesc(self.njoints, self.nq, self.nv, self.parents.ctypes.data_as(_ip),
                          self.jtype.ctypes.data_as(_ip), self.axis.ctypes.data_as(_dp),
                          self.idx_q.ctypes.data_as(_ip), self.idx_v.ctypes.data_as(_ip),
-                         self.placement.ctypes.data_as(_dp))
+                         self.placement.ctypes.data_as(_dp), self.comp_first.ctypes.data_as(_ip),
+                         self.comp_count.ctypes.data_as(_ip), self.comp_jtype.ctypes.data_as(_ip),
+                         self.comp_axis.ctypes.data_as(_dp), self.comp_placement.ctypes.data_as(_dp))
 
     def getJointId(self, name):
         return self.names.index(name)
@@ -226,6 +250,13 @@ class Model:
                 o = int(self.idx_q[i]) + (2 if t == J_PLANAR else 0)
                 th = rng.uniform(-np.pi, np.pi, size=batch)
                 q[:, o] = np.cos(th); q[:, o + 1] = np.sin(th)
+            elif t == J_COMPOSITE:
+                o = int(self.idx_q[i])
+                for st, _, _ in self.composite[i]:
+                    if st in (J_RUBX, J_RUBY, J_RUBZ):
+                        th = rng.uniform(-np.pi, np.pi, size=batch)
+                        q[:, o] = np.cos(th); q[:, o + 1] = np.sin(th)
+                    o += JOINT_NQ.get(st, 1)
         return q
 
 

@@ -42,8 +42,49 @@ def quat_rot(qt):
     return R
 
 
+J_COMPOSITE = 17
+
+
+class _Chain:
+    """the same kinematics with every JointModelComposite written out as its sub-joints (one joint each, in order, with the
+    composite's internal placements): link velocities do not care that the bodies in between do not exist; q / nu keep
+    their layout (a composite's coordinates are its sub-joints' in order)"""
+
+    def __init__(self, model):
+        parents, jtype, axis, placement, idx_q, idx_v = [0], [0], [np.zeros(3)], [np.asarray(model.placement[0])], [0], [0]
+        self.link_of = [0]
+        for i in range(1, model.njoints):
+            par = self.link_of[int(model.parents[i])]
+            if int(model.jtype[i]) != J_COMPOSITE:
+                parents.append(par); jtype.append(int(model.jtype[i])); axis.append(np.asarray(model.axis[i]))
+                placement.append(np.asarray(model.placement[i])); idx_q.append(int(model.idx_q[i])); idx_v.append(int(model.idx_v[i]))
+            else:
+                iq, iv = int(model.idx_q[i]), int(model.idx_v[i])
+                Pj = np.asarray(model.placement[i]); Rj, tj = Pj[:9].reshape(3, 3), Pj[9:]
+                for k, (st, a, P) in enumerate(model.composite[i]):
+                    P = np.asarray(P, dtype=float)
+                    if k == 0:   # jointPlacements[i] * placement of the first sub-joint
+                        P = np.concatenate([(Rj @ P[:9].reshape(3, 3)).ravel(), tj + Rj @ P[9:]])
+                    parents.append(par if k == 0 else len(parents) - 1)
+                    jtype.append(int(st)); axis.append(np.asarray(a, dtype=float)); placement.append(P)
+                    idx_q.append(iq); idx_v.append(iv)
+                    iq += 2 if st in (J_RUBX, J_RUBY, J_RUBZ) else 1
+                    iv += 1
+            self.link_of.append(len(parents) - 1)
+        self.njoints = len(parents)
+        self.parents, self.jtype = np.array(parents), np.array(jtype)
+        self.axis, self.placement = np.array(axis), np.array(placement)
+        self.idx_q, self.idx_v = np.array(idx_q), np.array(idx_v)
+        self.composite = None
+
+
 def link_velocity(model, q, nu, link):
     """spatial velocity [B,6] (Pinocchio order [linear; angular], link frame) of `link` for joint velocities nu"""
+    if getattr(model, "composite", None):
+        ch = getattr(model, "_chain_cache", None)
+        if ch is None:
+            ch = model._chain_cache = _Chain(model)
+        return link_velocity(ch, q, nu, ch.link_of[int(link)])
     B = q.shape[0]
     chain = []
     i = int(link)

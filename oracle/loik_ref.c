@@ -319,6 +319,14 @@ static void joint_S(int jtype, const double *axis, const double *qs, double *S)
   }
 }
 
+/* inverse of a placement */
+static void se3_inv(const double *a, double *o)
+{
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) o[3 * r + c] = a[3 * c + r];
+  for (int r = 0; r < 3; ++r) o[9 + r] = -(a[r] * a[9] + a[3 + r] * a[10] + a[6 + r] * a[11]);
+}
+
 /* inverse of a symmetric positive definite n x n matrix (n <= 6) by Cholesky, the way Pinocchio's
  * internal::PerformStYSInversion does it (Dinv.setIdentity(); StYS.llt().solveInPlace(Dinv)) */
 static void spd_inverse(const double *A, int n, double *Ainv)
@@ -417,6 +425,7 @@ struct ref_solver {
   /* --- IkProblemFormulationOptimized members (ik-id-description-optimized.hpp:342-362) --- */
   int eq_c_dim;
   double *H_refs, *v_refs, *Hv;      /* [nj][36], [nj][6], [nj][6] */
+  int *comp_first, *comp_count, *comp_jtype; double *comp_axis, *comp_placement; int n_sub; /* JointModelComposite */
   int *active_ids;                   /* [nc] */
   int nc_cap;                        /* allocated constraint slots (>= nc = nc_eq_) */
   double *Ais, *bis, *AtA, *Atb;     /* [nc][36], [nc][6], [nc][36], [nc][6] */
@@ -519,6 +528,22 @@ int ref_create(const ref_model *m, const ref_params *p, ref_solver **out)
   s->jnv = (int *)calloc(nj, sizeof(int));
   s->massless = (int *)calloc(nj, sizeof(int));
   for (int i = 1; i < nj; ++i) s->jnv[i] = joint_nv(s->jtype[i]);
+  s->comp_first = (int *)calloc(nj, sizeof(int)); s->comp_count = (int *)calloc(nj, sizeof(int));
+  s->n_sub = 0;
+  if (m->comp_first && m->comp_count)
+    for (int i = 1; i < nj; ++i)
+      if (s->jtype[i] == REF_J_COMPOSITE) {
+        s->comp_first[i] = m->comp_first[i]; s->comp_count[i] = m->comp_count[i];
+        s->jnv[i] = m->comp_count[i];
+        if (m->comp_first[i] + m->comp_count[i] > s->n_sub) s->n_sub = m->comp_first[i] + m->comp_count[i];
+      }
+  s->comp_jtype = (int *)calloc(s->n_sub ? s->n_sub : 1, sizeof(int));
+  s->comp_axis = dalloc(3 * (size_t)s->n_sub); s->comp_placement = dalloc(12 * (size_t)s->n_sub);
+  if (s->n_sub) {
+    memcpy(s->comp_jtype, m->comp_jtype, sizeof(int) * s->n_sub);
+    memcpy(s->comp_axis, m->comp_axis, sizeof(double) * 3 * s->n_sub);
+    memcpy(s->comp_placement, m->comp_placement, sizeof(double) * 12 * s->n_sub);
+  }
   if (m->massless) memcpy(s->massless, m->massless, sizeof(int) * nj);
   (void)joint_nq;
 
@@ -577,6 +602,7 @@ void ref_destroy(ref_solver *s)
   if (!s) return;
   free(s->parents); free(s->jtype); free(s->idx_q); free(s->idx_v); free(s->axis); free(s->placement);
   free(s->jnv); free(s->massless);
+  free(s->comp_first); free(s->comp_count); free(s->comp_jtype); free(s->comp_axis); free(s->comp_placement);
   free(s->oMi); free(s->liMi); free(s->jS); free(s->jU); free(s->jUDinvM); free(s->jDinvM);
   free(s->jUDinv); free(s->jDinv);
   free(s->nu); free(s->nu_prev); free(s->vis); free(s->vis_prev); free(s->His); free(s->His_aba);
@@ -815,13 +841,47 @@ int ref_active_id(const ref_solver *s, int c) { return (c >= 0 && c < s->nc) ? s
 /* solver passes                                                                               */
 /* ------------------------------------------------------------------------------------------ */
 
+/* JointModelCompositeTpl::calc(jdata, q) (pinocchio/multibody/joint/joint-composite.hxx, JointCompositeCalcZeroOrderStep):
+ * the sub-joints are visited last to first; with iMlast[k] = the placement of sub-joint k's frame (before its own motion:
+ * jointPlacements[k] * M_k) seen ... from the LAST sub-joint's frame,
+ *     M = prod_k jointPlacements[k] * M_k(q_k)            (the composite's transform)
+ *     S.col(k) = iMlast[k+1].actInv(S_k)                   (S_k seen from the last frame; the last column is S_{n-1} itself)
+ * `qs` = the composite's segment of q, S: 6 x nv columns */
+static void composite_calc(const ref_solver *s, int idx, const double *qs, double *M, double *S)
+{
+  const int first = s->comp_first[idx], n = s->comp_count[idx];
+  double T[7][12];   /* T[k] = prod_{j<k} P_j M_j : frame reached before sub-joint k's placement; T[n] = M */
+  double after[6][12];
+  se3_identity(T[0]);
+  int oq = 0;
+  for (int k = 0; k < n; ++k) {
+    const int st = s->comp_jtype[first + k];
+    double Mk[12], PM[12];
+    joint_calc(st, s->comp_axis + 3 * (first + k), qs + oq, Mk);
+    se3_mul(s->comp_placement + 12 * (first + k), Mk, PM);
+    se3_mul(T[k], PM, T[k + 1]);
+    memcpy(after[k], T[k + 1], sizeof(double) * 12);   /* the frame in which S_k is expressed (after sub-joint k moved) */
+    oq += joint_nq(st);
+  }
+  memcpy(M, T[n], sizeof(double) * 12);
+  memset(S, 0, 36 * sizeof(double));
+  for (int k = 0; k < n; ++k) {
+    double Sk[36], inv[12], kMlast[12];
+    joint_S(s->comp_jtype[first + k], s->comp_axis + 3 * (first + k), NULL, Sk);   /* 1-DoF: first column */
+    se3_inv(after[k], inv);
+    se3_mul(inv, T[n], kMlast);                       /* placement of the last frame seen from sub-joint k's */
+    se3_actinv_motion(kMlast, Sk, S + 6 * k);         /* S_k seen from the last frame */
+  }
+}
+
 /* FwdPassInit(q), loik-loid-optimized.hxx:253-283 */
 void ref_fwd_pass_init(ref_solver *s, const double *q)
 {
   double M[12];
   for (int idx = 1; idx < s->nj; ++idx) {
     int parent = s->parents[idx];
-    joint_calc(s->jtype[idx], s->axis + 3 * idx, q + s->idx_q[idx], M);
+    if (s->jtype[idx] == REF_J_COMPOSITE) composite_calc(s, idx, q + s->idx_q[idx], M, s->jS + 36 * idx);
+    else joint_calc(s->jtype[idx], s->axis + 3 * idx, q + s->idx_q[idx], M);
     if (s->jtype[idx] == REF_J_SPHERICAL_ZYX) joint_S(s->jtype[idx], s->axis + 3 * idx, q + s->idx_q[idx], s->jS + 36 * idx);
     se3_mul(s->placement + 12 * idx, M, s->liMi + 12 * idx);
     se3_mul(s->oMi + 12 * parent, s->liMi + 12 * idx, s->oMi + 12 * idx);

@@ -45,7 +45,8 @@ enum {
   REF_J_PLANAR = 13,     /* JointModelPlanar: nq 4 (x, y, cos, sin), nv 3 (vx, vy, wz in the joint frame)    */
   REF_J_RUBX = 14,       /* JointModelRUBX / RUBY / RUBZ: nq 2 (cos, sin), nv 1                               */
   REF_J_RUBY = 15,
-  REF_J_RUBZ = 16
+  REF_J_RUBZ = 16,
+  REF_J_COMPOSITE = 17   /* JointModelComposite of 1-DoF joints, described by ref_model.comp_* (nv <= 6)               */
 };
 
 /* mirrors enum ADMMPenaltyUpdateStrat, task-solver-base.hpp:13-18 */
@@ -77,6 +78,13 @@ typedef struct ref_model {
                               H_ref v_ref term): the intermediate bodies of a multi-DoF joint written as a chain
                               of 1-DoF joints.  Not a reference concept -- it exists so that the tests can prove
                               that such a chain reproduces the multi-DoF joint (the device's representation).   */
+  /* JointModelComposite (NULL when the model has none): joint i of type REF_J_COMPOSITE = the sub-joints
+     comp_first[i] .. + comp_count[i] - 1: type (1-DoF), axis, placement relative to the previous sub-joint
+     (JointModelComposite::addJoint(jmodel, placement)) */
+  const int *comp_first, *comp_count;   /* [nj]                 */
+  const int *comp_jtype;                /* [n_sub]              */
+  const double *comp_axis;              /* [n_sub][3]           */
+  const double *comp_placement;         /* [n_sub][12]          */
 } ref_model;
 
 typedef struct ref_params {

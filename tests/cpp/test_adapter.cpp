@@ -35,6 +35,7 @@ struct JointModel {
   std::string sn;
   int iq = 0, iv = 0;
   double ax[3] = {0, 0, 0};
+  std::vector<std::pair<JointModel, SE3>> subs;  // JointModelComposite::joints / ::jointPlacements
   std::string shortname() const { return sn; }
   int idx_q() const { return iq; }
   int idx_v() const { return iv; }
@@ -70,7 +71,7 @@ static const char* short_name(int t)
   static const char* names[] = {"", "JointModelRX", "JointModelRY", "JointModelRZ", "JointModelPX", "JointModelPY", "JointModelPZ",
                                 "JointModelRevoluteUnaligned", "JointModelPrismaticUnaligned", "JointModelFreeFlyer",
                                 "JointModelSpherical", "JointModelTranslation", "JointModelSphericalZYX", "JointModelPlanar",
-                                "JointModelRUBX", "JointModelRUBY", "JointModelRUBZ"};
+                                "JointModelRUBX", "JointModelRUBY", "JointModelRUBZ", "JointModelComposite"};
   return names[t];
 }
 
@@ -94,10 +95,31 @@ static shape::Model pinocchio_shaped(const Model& m)
   return p;
 }
 
+static shape::SE3 se3_of(const double* P12)
+{
+  shape::SE3 P;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) P.R.d[3 * c + r] = P12[3 * r + c];
+  for (int k = 0; k < 3; ++k) P.t.d[k] = P12[9 + k];
+  return P;
+}
+
 static void round_trip(const Model& m)
 {
-  const shape::Model p = pinocchio_shaped(m);
-  const Model o = to_loik_amd(p, [](const shape::JointModel& j, const std::string&) { return j.ax; });
+  shape::Model p = pinocchio_shaped(m);
+  for (int i = 1; i < m.njoints; ++i)
+    if (m.jtype[i] == LOIKB_J_COMPOSITE)
+      for (int k = 0; k < m.comp_count[i]; ++k) {
+        const int e = m.comp_first[i] + k;
+        shape::JointModel sj;
+        sj.sn = short_name(m.comp_jtype[e]);
+        for (int c = 0; c < 3; ++c) sj.ax[c] = m.comp_axis[3 * e + c];
+        p.joints[i].subs.emplace_back(sj, se3_of(&m.comp_placement[12 * e]));
+      }
+  const Model o = to_loik_amd(p, [](const shape::JointModel& j, const std::string&) { return j.ax; },
+                              [](const shape::JointModel& j) { return j.subs; });
+  CHECK(o.comp_first == m.comp_first && o.comp_count == m.comp_count && o.comp_jtype == m.comp_jtype);
+  CHECK(o.comp_axis == m.comp_axis && o.comp_placement == m.comp_placement);
   CHECK(o.njoints == m.njoints && o.nq == m.nq && o.nv == m.nv);
   CHECK(o.parents == m.parents && o.jtype == m.jtype && o.idx_q == m.idx_q && o.idx_v == m.idx_v);
   CHECK(o.names == m.names && o.jointPlacements == m.jointPlacements);
@@ -115,9 +137,9 @@ int main()
   {  // a model with every joint type, unaligned axes, rotated placements
     Model m;
     const int types[] = {LOIKB_J_NONE, LOIKB_J_FREEFLYER, LOIKB_J_RU, LOIKB_J_PU, LOIKB_J_SPHERICAL, LOIKB_J_TRANSLATION,
-                         LOIKB_J_SPHERICAL_ZYX, LOIKB_J_PLANAR, LOIKB_J_RUBY, LOIKB_J_PZ, LOIKB_J_RX};
-    const int nqs[] = {0, 7, 1, 1, 4, 3, 3, 4, 2, 1, 1}, nvs[] = {0, 6, 1, 1, 3, 3, 3, 3, 1, 1, 1};
-    m.njoints = 11;
+                         LOIKB_J_SPHERICAL_ZYX, LOIKB_J_PLANAR, LOIKB_J_RUBY, LOIKB_J_PZ, LOIKB_J_RX, LOIKB_J_COMPOSITE};
+    const int nqs[] = {0, 7, 1, 1, 4, 3, 3, 4, 2, 1, 1, 4}, nvs[] = {0, 6, 1, 1, 3, 3, 3, 3, 1, 1, 1, 3};
+    m.njoints = 12;
     for (int i = 0; i < m.njoints; ++i) {
       m.parents.push_back(i ? (i - 1) / 2 : 0);
       m.jtype.push_back(types[i]);
@@ -131,13 +153,28 @@ int main()
       const double P[12] = {c, -s, 0, s, c, 0, 0, 0, 1, 0.1 * i, -0.2, 0.05 * i};  // Rz(0.3 i): not symmetric -> order matters
       m.jointPlacements.insert(m.jointPlacements.end(), P, P + 12);
       m.names.push_back(i ? "joint_" + std::to_string(i) : "universe");
+      // joint 11: a composite of RU, RUBZ (nq 2), PY with rotated internal placements
+      m.comp_first.push_back(i == 11 ? 0 : (i < 11 ? 0 : 3));
+      m.comp_count.push_back(i == 11 ? 3 : 0);
+    }
+    m.comp_jtype = {LOIKB_J_RU, LOIKB_J_RUBZ, LOIKB_J_PY};
+    m.comp_axis = {0.6, 0.0, 0.8, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 3; ++k) {
+      const double c = std::cos(0.7 + k), s = std::sin(0.7 + k);
+      const double P[12] = {1, 0, 0, 0, c, -s, 0, s, c, 0.01 * k, 0.2, -0.1};  // Rx
+      m.comp_placement.insert(m.comp_placement.end(), P, P + 12);
     }
     round_trip(m);
     shape::Model p = pinocchio_shaped(m);
-    p.joints[3].sn = "JointModelComposite";
+    p.joints[3].sn = "JointModelMimic";
     bool thrown = false;
     try { (void)to_loik_amd(p, [](const shape::JointModel& j, const std::string&) { return j.ax; }); }
-    catch (const std::runtime_error& e) { thrown = std::strstr(e.what(), "JointModelComposite") && std::strstr(e.what(), "joint_3"); }
+    catch (const std::runtime_error& e) { thrown = std::strstr(e.what(), "JointModelMimic") && std::strstr(e.what(), "joint_3"); }
+    CHECK(thrown);
+    p.joints[3].sn = "JointModelComposite";   // a composite needs the SubJointsOf functor
+    thrown = false;
+    try { (void)to_loik_amd(p, [](const shape::JointModel& j, const std::string&) { return j.ax; }); }
+    catch (const std::runtime_error& e) { thrown = std::strstr(e.what(), "SubJointsOf") != nullptr; }
     CHECK(thrown);
   }
   {  // argument conversions: column-major in, row-major out; Motion through toVector(); lists; VectorXd

@@ -276,3 +276,31 @@ def renumber_breadth_first(model):
                        names=[model.names[o] for o in order], q_lo=None if model.q_lo is None else model.q_lo[[o - 1 for o in order[1:]]],
                        q_hi=None if model.q_hi is None else model.q_hi[[o - 1 for o in order[1:]]], name=model.name + "_bfs")
     return m, np.array(order)
+
+
+J_COMPOSITE_ = 17
+
+
+def _unit(rng):
+    a = rng.normal(size=3)
+    return a / np.linalg.norm(a)
+
+
+def composite_tree(seed, nb, which, kinds=None):
+    """random_tree(seed, nb) with the joints `which` replaced by composites of 2..4 random 1-DoF sub-joints (aligned,
+    unaligned, unbounded revolute) with random internal placements"""
+    m = random_tree(seed, nb, branch_prob=0.3)
+    rng = np.random.default_rng(seed + 1234)
+    jt = m.jtype.copy()
+    comp = {}
+    for n_, i in enumerate(which):
+        jt[i] = J_COMPOSITE_
+        subs = []
+        types = kinds[n_] if kinds else [int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, J_RUBY]))
+                                         for _ in range(int(rng.integers(2, 5)))]
+        for t in types:
+            a = _unit(rng) if t in (7, 8) else np.zeros(3)
+            P = np.concatenate([random_rotation(rng).ravel(), rng.uniform(-0.3, 0.3, size=3)])
+            subs.append((t, a, P))
+        comp[i] = subs
+    return loik_amd.Model(m.parents, jt, m.axis, m.placement, composite=comp, name="composite_tree_%d_%d" % (seed, nb))
