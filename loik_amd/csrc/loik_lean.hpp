@@ -738,7 +738,6 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
       }
       finishing = done;
-      TAIL_TP(9)
       tail_sync();  // every lane has read the instance's scalars before lane 0 rewrites them
       if (jlane == 0) {
         isc[IS_ITER] = (T)iter; isc[IS_STATUS] = (T)status;
@@ -753,7 +752,6 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     } else {
       tail_sync();
     }
-    TAIL_TP(10)
     // an escaped instance (mu left the precomputed decades) is written back as it is
     const bool leaving = done && has_inst;
     // ---- the norms the getters report (13 more maxima): only when some instance of the wavefront stops ------------------
@@ -780,7 +778,6 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       if (finishing && jlane == 0) isc[IS_G] = isc[IS_RED + 0];
       tail_sync();
     }
-    TAIL_TP(11)
 #ifdef LOIKB_TAIL_PROF
     if (__any(leaving)) ++dbg_sw_;
 #endif
@@ -800,8 +797,18 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       want_poll = leaving || (poll_skip++ & LOIKB_POLL_MASK) == 0u;
     } else {
       if (leaving) {
+#ifdef LOIKB_TAIL_PROF
+        __builtin_amdgcn_s_waitcnt(0); TAIL_TP(7)
+        store_instance();
+        __builtin_amdgcn_s_waitcnt(0); TAIL_TP(9)
+        const int nx_ = fetch_plain();
+        __builtin_amdgcn_s_waitcnt(0); TAIL_TP(10)
+        load_instance(nx_);
+        __builtin_amdgcn_s_waitcnt(0); TAIL_TP(11)
+#else
         store_instance();
         load_instance(fetch_plain());
+#endif
       }
     }
     TAIL_TP(7)

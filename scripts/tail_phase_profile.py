@@ -26,7 +26,7 @@ for B in [int(x) for x in sys.argv[1:]] or [64, 4096]:  # >= 64 instances: the l
         B, st["tail_ms"], n, tot / n, ("; clock64 runs at %.0f MHz against the 100 MHz wall clock" % (out[9] / 1e3)) if out[9] else ""))
     for k in range(8):
         print("   %-34s %8.0f cycles  %5.1f %%" % (NAMES[k], out[k] / n, 100.0 * out[k] / tot))
-    for k, nm in enumerate(["8 loop top + decade slot load (was in 0)", "9 stop / mu logic (was in 7)", "10 instance scalars written (was in 7)",
-                            "11 finishing norms (was in 7)"]):
+    for k, nm in enumerate(["8 loop top + decade slot load (was in 0)", "9 switch: store_instance", "10 switch: ticket + ring entry",
+                            "11 switch: load_instance"]):
         print("   %-34s %8.0f cycles  %5.1f %%" % (nm, out[10 + k] / n, 100.0 * out[10 + k] / tot))
     s.close()
