@@ -90,6 +90,15 @@ struct Model {
 
 class FirstOrderLoikOptimized;
 
+// LoikSolverInfo of the reference (loik-loid-optimized.hpp:47-127; base lists task-solver-base.hpp:25-52): the lists a solver
+// constructed with logging = true fills, for one instance.  Upstream keeps the struct protected; get_solver_info() hands it out.
+struct LoikSolverInfo {
+  std::vector<int> iter_list_, tail_solve_iter_list_;
+  std::vector<double> primal_residual_task_list_, primal_residual_slack_list_, primal_residual_list_, dual_residual_nu_list_,
+      dual_residual_v_list_, dual_residual_list_, mu_list_, mu_eq_list_, mu_ineq_list_;
+  int Size() const { return (int)iter_list_.size(); }
+};
+
 // A member of the data object that is fetched from the device the first time it is read after a solve (His, pis, Aty,
 // liMi: large, rarely read -- upstream's tests read His / pis, tests/loik-loid.cpp:597-615).  Reads like the std::vector it
 // wraps: operator[], data(), size(), begin()/end(), implicit conversion to const DVec&.
@@ -172,7 +181,7 @@ public:
     o.eq_c_capacity = eq_c_capacity;  // room for AddEqConstraint (0: num_eq_c slots, as upstream sizes yis / Aty)
     const loikb_model_desc d = model_.desc();
     check(loikb_create(&d, &o, &h_));
-    rho_ = rho; tol_tail_solve_ = tol_tail_solve; tol_primal_inf_ = tol_primal_inf; tol_dual_inf_ = tol_dual_inf;
+    max_iter_ = max_iter; rho_ = rho; tol_tail_solve_ = tol_tail_solve; tol_primal_inf_ = tol_primal_inf; tol_dual_inf_ = tol_dual_inf;
     for (LazyField* f : {&ik_id_data_.His, &ik_id_data_.pis, &ik_id_data_.Aty, &ik_id_data_.liMi}) {
       f->owner_ = this;
       f->generation_ = &generation_;
@@ -319,6 +328,27 @@ public:
     return q;
   }
 
+  // ---- the logged lists of instance b (constructor argument logging = true; such a solver runs on the plain pass-by-pass
+  //      implementation: "logging residuals, should be disabled for speed", loik-loid-optimized.hpp:408)
+  LoikSolverInfo get_solver_info(int b = 0) const
+  {
+    LoikSolverInfo info;
+    const std::size_t cap = static_cast<std::size_t>(max_iter_ > 1 ? max_iter_ - 1 : 1);
+    DVec buf(static_cast<std::size_t>(batch_) * cap);
+    std::vector<int> rows(static_cast<std::size_t>(batch_));
+    std::vector<double>* lists[] = {&info.primal_residual_task_list_, &info.primal_residual_slack_list_, &info.primal_residual_list_,
+                                    &info.dual_residual_nu_list_, &info.dual_residual_v_list_, &info.dual_residual_list_,
+                                    &info.mu_list_, &info.mu_eq_list_, &info.mu_ineq_list_};
+    for (int l = 0; l < LOIKB_LOG_NLIST; ++l) {
+      check(loikb_get_solver_info(h_, l, buf.data(), rows.data()));
+      lists[l]->assign(buf.begin() + b * cap, buf.begin() + b * cap + rows[b]);
+    }
+    const int n_iter = get_iter(b), n_tail = n_iter - rows[b];   // the tail solve extends iter_list_ only (hpp:286-290)
+    for (int i = 1; i <= n_iter; ++i) info.iter_list_.push_back(i);
+    for (int i = 1; i <= n_tail; ++i) info.tail_solve_iter_list_.push_back(i);
+    return info;
+  }
+
   // ---- which members of the data object every solve copies back (default: all six, as upstream's callers expect).
   // FETCH_NONE leaves the results on the device: read them with loikb_get(handle(), field, ptr, LOIKB_OUT_DEVICE) or call
   // fetch_now(mask) when needed -- a planner that only integrates on the device (Integrate) never needs the copy.
@@ -346,7 +376,7 @@ public:
   void set_tol_dual(const double t) { tol_dual_ = t; tol_dual_set_ = true; }
   double get_tol_primal_inf() const { return tol_primal_inf_; }
   double get_tol_dual_inf() const { return tol_dual_inf_; }
-  void set_max_iter(const int max_iter) { check(loikb_set_max_iter(h_, max_iter)); }
+  void set_max_iter(const int max_iter) { check(loikb_set_max_iter(h_, max_iter)); max_iter_ = max_iter; }
   void set_rho(const double rho) { rho_ = rho; check(loikb_set_rho(h_, rho)); }
   void set_mu(const double mu) { check(loikb_set_mu(h_, mu)); }
   void set_tol_primal_inf(const double t) { tol_primal_inf_ = t; check(loikb_set_tol_primal_inf(h_, t)); }
@@ -492,6 +522,7 @@ private:
   IkIdData& ik_id_data_;    // caller-owned, must outlive the solver (loik-loid-optimized.hpp:763)
   loikb_solver* h_ = nullptr;
   int batch_, nc_;
+  int max_iter_ = 0;
   double rho_ = 0.0, tol_tail_solve_ = 0.0, tol_primal_inf_ = 0.0, tol_dual_inf_ = 0.0;
   double tol_primal_ = 0.0, tol_dual_ = 0.0;
   bool tol_primal_set_ = false, tol_dual_set_ = false;

@@ -80,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "loikb_batch", "loikb_nv", "loikb_njoints", "loikb_last_error", "loikb_status_string", "loikb_version",
     "loikb_device_count", "loikb_sweep_schedule", "loikb_integrate", "loikb_synchronize", "loikb_plan_string", "loikb_pass",
     "loikb_update_references", "loikb_update_eq_constraint", "loikb_add_eq_constraint", "loikb_remove_eq_constraint",
-    "loikb_num_eq_c", "loikb_eq_c_capacity", "loikb_active_constraint_ids", "loikb_builtin_model", "loikb_builtin_joint_name",
+    "loikb_num_eq_c", "loikb_eq_c_capacity", "loikb_active_constraint_ids", "loikb_get_solver_info", "loikb_builtin_model", "loikb_builtin_joint_name",
     "loikb_builtin_joint_id"]
 
 _lib = None
@@ -118,6 +118,7 @@ def lib():
     L.loikb_num_eq_c.argtypes = [C.c_void_p]
     L.loikb_eq_c_capacity.argtypes = [C.c_void_p]
     L.loikb_active_constraint_ids.argtypes = [C.c_void_p, _ip, C.c_int]
+    L.loikb_get_solver_info.argtypes = [C.c_void_p, C.c_int, _dp, _ip]
     L.loikb_set_max_iter.argtypes = [C.c_void_p, C.c_int]
     for n in ["loikb_set_rho", "loikb_set_mu", "loikb_set_tol_primal_inf", "loikb_set_tol_tail_solve"]:
         getattr(L, n).argtypes = [C.c_void_p, C.c_double]
@@ -490,7 +491,9 @@ class BatchedLoik:
         _check(self.L.loikb_integrate(self.h, float(dt)))
 
     # ------------------------------------------------------------------------------------------------------
-    def set_max_iter(self, n): _check(self.L.loikb_set_max_iter(self.h, int(n)))
+    def set_max_iter(self, n):
+        _check(self.L.loikb_set_max_iter(self.h, int(n)))
+        self.opts.max_iter = int(n)
     def set_rho(self, x): _check(self.L.loikb_set_rho(self.h, float(x)))
     def set_mu(self, x): _check(self.L.loikb_set_mu(self.h, float(x)))
     def set_tol(self, tol_abs, tol_rel): _check(self.L.loikb_set_tol(self.h, float(tol_abs), float(tol_rel)))
@@ -530,6 +533,21 @@ class BatchedLoik:
                 full[:, :, j, i] = packed[:, :, k]
                 k += 1
         return full
+
+    SOLVER_INFO_LISTS = ["primal_residual_task_list", "primal_residual_slack_list", "primal_residual_list", "dual_residual_nu_list",
+                         "dual_residual_v_list", "dual_residual_list", "mu_list", "mu_eq_list", "mu_ineq_list"]
+
+    def solver_info(self):
+        """LoikSolverInfo of the last solve (constructor keyword logging=True): {list name: [B][max_iter - 1]}, 'rows': [B]"""
+        cap = max(self.opts.max_iter - 1, 1)
+        out = {}
+        rows = np.zeros(self.batch, dtype=np.int32)
+        for k, name in enumerate(self.SOLVER_INFO_LISTS):
+            a = np.zeros((self.batch, cap))
+            _check(self.L.loikb_get_solver_info(self.h, k, a.ctypes.data_as(_dp), rows.ctypes.data_as(_ip)))
+            out[name] = a
+        out["rows"] = rows
+        return out
 
     def stats(self):
         st = Stats()

@@ -212,6 +212,11 @@ struct loikb_solver_impl {
   PassLayout PL{};
   double* d_pass = nullptr;
   int* d_pass_cslot = nullptr;
+  // SolverInfo lists of a handle created with logging = 1 (k_pass_solve)
+  double* d_log = nullptr;
+  int* d_log_rows = nullptr;
+  int log_rows_cap = 0;
+  bool have_log = false;
 };
 using Chunk = loikb_solver_impl::Chunk;
 
@@ -1934,6 +1939,8 @@ int loikb_destroy(loikb_solver* S)
   if (S->d_stage) (void)hipFree(S->d_stage);
   if (S->d_pass) (void)hipFree(S->d_pass);
   if (S->d_pass_cslot) (void)hipFree(S->d_pass_cslot);
+  if (S->d_log) (void)hipFree(S->d_log);
+  if (S->d_log_rows) (void)hipFree(S->d_log_rows);
   (void)hipGetLastError();  // a failed free must not surface in the next solver's first launch check
   if (S->own_stream) (void)hipStreamDestroy(S->own_stream);
   if (S->ev_fork) (void)hipEventDestroy(S->ev_fork);
@@ -1998,6 +2005,8 @@ int loikb_update_references(loikb_solver* S, const double* H_refs, const double*
   return reset_home(S, RS_HCACHE);  // H_i = rho I + H_ref_i + ...: the cached factors are stale
 }
 
+static int run_logged(loikb_solver_impl* S);
+
 int loikb_solve(loikb_solver* S)
 {
   if (!S) return LOIKB_ERR_ARG;
@@ -2006,7 +2015,7 @@ int loikb_solve(loikb_solver* S)
   int rc;
   // ik_id_data_.ResetRecursion(); ResetSolver()  (hpp:370-374)
   if ((rc = reset_home(S, RS_RECURSION | RS_SOLVER))) return rc;
-  return run_main_loop(S);
+  return S->opt.logging ? run_logged(S) : run_main_loop(S);
 }
 
 int loikb_solve_full(loikb_solver* S, const double* q, const double* H_ref, const double* v_ref, const int* c_ids,
@@ -2015,7 +2024,7 @@ int loikb_solve_full(loikb_solver* S, const double* q, const double* H_ref, cons
 {
   int rc = loikb_solve_init(S, q, H_ref, v_ref, c_ids, nc, Ais, bis, lb, ub, nbound, in_flags);
   if (rc) return rc;
-  return run_main_loop(S);
+  return S->opt.logging ? run_logged(S) : run_main_loop(S);
 }
 
 int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const double* Ai, const double* bi, int in_flags)
@@ -2030,7 +2039,7 @@ int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const doubl
   // upstream: the way to solve after AddEqConstraint / RemoveEqConstraint changed the set, possibly to the empty one)
   if (c_id >= 0 && (rc = update_eq_single(S, c_id, Ai, bi, in_flags))) return rc;
   if ((rc = fwd_pass_init(S, q, in_flags))) return rc;
-  return run_main_loop(S);
+  return S->opt.logging ? run_logged(S) : run_main_loop(S);
 }
 
 // problem_.UpdateEqConstraint (hpp:178-238), AddEqConstraint (:244-286), RemoveEqConstraint (:292-319) between solves
@@ -2148,38 +2157,101 @@ static PassParams pass_params(const loikb_solver_impl* S)
   return P;
 }
 
+// the pass state: allocated on first use, (re)loaded from the tiles whenever the solver state changed underneath it
+static int ensure_pass_state(loikb_solver_impl* S, const PassParams& P)
+{
+  if (S->f32 || S->nb != S->ext_nj - 1) {
+    g_last_error = "the pass-level path (loikb_pass, logging = 1) covers fp64 solvers of models with 1-DoF joints";
+    return LOIKB_ERR_MODEL;
+  }
+  if (S->pass_active) return LOIKB_OK;
+  const PassLayout PL = make_pass_layout(S->nj, S->nv, S->nc, S->B);
+  if (!S->d_pass || PL.stride != S->PL.stride) {
+    if (S->d_pass) HIPCHK(hipFree(S->d_pass));
+    S->d_pass = nullptr;
+    HIPCHK(hipMalloc((void**)&S->d_pass, sizeof(double) * (size_t)PL.stride * S->B));
+    if (!S->d_pass_cslot) HIPCHK(hipMalloc((void**)&S->d_pass_cslot, sizeof(int) * S->nj));
+  }
+  S->PL = PL;
+  std::vector<int> cs(S->nj, -1);
+  for (int i = 1; i < S->nj; ++i) cs[i] = S->jd[i].cslot;
+  HIPCHK(hipMemcpyAsync(S->d_pass_cslot, cs.data(), sizeof(int) * S->nj, hipMemcpyHostToDevice, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  hipLaunchKernelGGL(k_pass_load<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, (const JointDesc*)S->d_jd,
+                     (const double*)S->d_uni, S->PL, P, S->d_pass);
+  HIPCHK(hipGetLastError());
+  S->pass_active = true;
+  return LOIKB_OK;
+}
+
 int loikb_pass(loikb_solver* S, int pass)
 {
   if (!S || pass < PASS_BEGIN_ITERATION || pass > PASS_UPDATE_MU) return LOIKB_ERR_ARG;
   if (!S->have_problem) { g_last_error = "pass-level call before SolveInit()"; return LOIKB_ERR_STATE; }
-  if (S->f32 || S->nb != S->ext_nj - 1) {
-    g_last_error = "the pass-level debug path covers fp64 solvers of models with 1-DoF joints";
-    return LOIKB_ERR_MODEL;
-  }
   HIPCHK(hipSetDevice(S->device));
   const PassParams P = pass_params(S);
-  if (!S->pass_active) {
-    const PassLayout PL = make_pass_layout(S->nj, S->nv, S->nc, S->B);
-    if (!S->d_pass || PL.stride != S->PL.stride) {
-      if (S->d_pass) HIPCHK(hipFree(S->d_pass));
-      S->d_pass = nullptr;
-      HIPCHK(hipMalloc((void**)&S->d_pass, sizeof(double) * (size_t)PL.stride * S->B));
-      if (!S->d_pass_cslot) HIPCHK(hipMalloc((void**)&S->d_pass_cslot, sizeof(int) * S->nj));
-    }
-    S->PL = PL;
-    std::vector<int> cs(S->nj, -1);
-    for (int i = 1; i < S->nj; ++i) cs[i] = S->jd[i].cslot;
-    HIPCHK(hipMemcpyAsync(S->d_pass_cslot, cs.data(), sizeof(int) * S->nj, hipMemcpyHostToDevice, S->stream));
-    HIPCHK(hipStreamSynchronize(S->stream));
-    hipLaunchKernelGGL(k_pass_load<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, (const JointDesc*)S->d_jd,
-                       (const double*)S->d_uni, S->PL, P, S->d_pass);
-    HIPCHK(hipGetLastError());
-    S->pass_active = true;
-  }
+  int rc;
+  if ((rc = ensure_pass_state(S, P))) return rc;
   hipLaunchKernelGGL(k_pass, grid1(S->B, 64), dim3(64), 0, S->stream, pass, S->PL, P, (const JointDesc*)S->d_jd,
                      (const int*)S->d_pass_cslot, S->d_pass);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(S->stream));
+  return LOIKB_OK;
+}
+
+// Solve with logging_ = true: the main loop on the plain pass implementation, SolverInfo lists filled (k_pass_solve).  The
+// results are then read from the pass state (loikb_get), like after loikb_pass.
+static int run_logged(loikb_solver_impl* S)
+{
+  const PassParams P = pass_params(S);
+  S->pass_active = false;  // the resets / updates of this solve went to the tiles: reload
+  int rc;
+  if ((rc = ensure_pass_state(S, P))) return rc;
+  const int cap = std::max(S->opt.max_iter - 1, 1);
+  if (!S->d_log || cap != S->log_rows_cap) {
+    if (S->d_log) HIPCHK(hipFree(S->d_log));
+    S->d_log = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)S->B * cap * LOG_NLIST;
+    if (hipMalloc((void**)&S->d_log, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      char buf[256];
+      snprintf(buf, sizeof(buf), "logging: the SolverInfo lists need %.2f GB (batch %d x (max_iter - 1) %d x %d lists x 8 B)",
+               bytes / 1e9, S->B, cap, (int)LOG_NLIST);
+      g_last_error = buf;
+      return LOIKB_ERR_HIP;
+    }
+    if (!S->d_log_rows) HIPCHK(hipMalloc((void**)&S->d_log_rows, sizeof(int) * S->B));
+    S->log_rows_cap = cap;
+  }
+  HIPCHK(hipEventRecord(S->ev_t0, S->stream));
+  hipLaunchKernelGGL(k_pass_solve, grid1(S->B, 64), dim3(64), 0, S->stream, S->PL, P, (const JointDesc*)S->d_jd,
+                     (const int*)S->d_pass_cslot, S->d_pass, S->d_log, cap, S->d_log_rows);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(S->ev_t1, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, S->ev_t0, S->ev_t1));
+  S->stats = loikb_stats{};
+  S->stats.launches = 1;
+  S->stats.kernel_ms = ms; S->stats.total_ms = ms;
+  S->have_log = true;
+  return LOIKB_OK;
+}
+
+int loikb_get_solver_info(loikb_solver* S, int list, double* out, int* rows_out)
+{
+  if (!S || list < 0 || list >= LOG_NLIST || !out) return LOIKB_ERR_ARG;
+  if (!S->have_log) { g_last_error = "no SolverInfo: create the solver with logging = 1 and solve"; return LOIKB_ERR_STATE; }
+  HIPCHK(hipSetDevice(S->device));
+  const int cap = S->log_rows_cap;
+  std::vector<double> all((size_t)S->B * cap * LOG_NLIST);
+  std::vector<int> rows(S->B);
+  HIPCHK(hipMemcpy(all.data(), S->d_log, all.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(rows.data(), S->d_log_rows, rows.size() * sizeof(int), hipMemcpyDeviceToHost));
+  for (int b = 0; b < S->B; ++b)
+    for (int k = 0; k < cap; ++k)
+      out[(size_t)b * cap + k] = k < rows[b] ? all[((size_t)b * cap + k) * LOG_NLIST + list] : 0.0;
+  if (rows_out) memcpy(rows_out, rows.data(), sizeof(int) * S->B);
   return LOIKB_OK;
 }
 
@@ -2238,6 +2310,7 @@ static int pass_get(loikb_solver_impl* S, int field, void* out, bool to_dev)
   case LOIKB_F_STF_PLUS_W_INF_NORM: scal = PS_STF_INF; break;
   case LOIKB_F_PRIMAL_INFEASIBILITY_COND_1: scal = PS_C1; break;
   case LOIKB_F_PRIMAL_INFEASIBILITY_COND_2: scal = PS_C2; break;
+  case LOIKB_F_TAIL_SOLVE_ITER: scal = PS_TAIL_IT; break;
   default:
     g_last_error = "this field is not part of the pass-level state";
     return LOIKB_ERR_ARG;

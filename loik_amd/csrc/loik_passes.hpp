@@ -22,7 +22,7 @@ enum : int {
   PS_MU = 0, PS_MU_EQ, PS_MU_IN, PS_ITER, PS_CONVERGED, PS_PRIMAL_INF, PS_BIS_INF, PS_PRIMAL, PS_DUAL, PS_PR_TASK, PS_PR_SLACK,
   PS_DUAL_V, PS_DUAL_NU, PS_TOL_P, PS_TOL_D, PS_NU_INF, PS_DFIS_INF, PS_HREFV_INF, PS_DVIS_INF, PS_DNU_INF, PS_DZ_INF,
   PS_DYIS_INF, PS_AV_INF, PS_BTDY_PLUS, PS_BTDY_MINUS, PS_DW_INF, PS_G_INF, PS_DG_INF, PS_STF_INF, PS_DSTF_INF, PS_DX, PS_DYQP,
-  PS_ATDY, PS_UBP, PS_LBM, PS_C1, PS_C2, PS_COUNT = 40
+  PS_ATDY, PS_UBP, PS_LBM, PS_C1, PS_C2, PS_TAIL_IT, PS_COUNT = 40
 };
 
 struct PassLayout {
@@ -182,13 +182,10 @@ enum : int {  // loikb_pass ids (include/loik_amd.h)
   PASS_CHECK_FEAS, PASS_UPDATE_MU
 };
 
-// one pass of one instance; `cslot_of[i]` = constraint slot of joint i or -1
-__global__ void k_pass(int pass, PassLayout L, PassParams P, const JointDesc* __restrict__ jd, const int* __restrict__ cslot_of,
-                       double* __restrict__ st)
+// one pass of one instance (its block `s` of the pass state); `cslot_of[i]` = constraint slot of joint i or -1
+__device__ inline void pass_one(int pass, const PassLayout& L, const PassParams& P, const JointDesc* __restrict__ jd,
+                                const int* __restrict__ cslot_of, double* __restrict__ s)
 {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= L.B) return;
-  double* s = st + (size_t)b * L.stride;
   double* sc = s + L.scal;
   const int nj = L.nj;
   switch (pass) {
@@ -402,6 +399,61 @@ __global__ void k_pass(int pass, PassLayout L, PassParams P, const JointDesc* __
   } break;
   default: break;
   }
+}
+
+__global__ void k_pass(int pass, PassLayout L, PassParams P, const JointDesc* __restrict__ jd, const int* __restrict__ cslot_of,
+                       double* __restrict__ st)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= L.B) return;
+  pass_one(pass, L, P, jd, cslot_of, st + (size_t)b * L.stride);
+}
+
+// ---- Solve() with logging_ = true (loik-loid-optimized.hpp:375-455, :271-319): the main loop and the infeasibility tail solve
+// of every instance written out pass by pass, one thread per instance, with the lists of LoikSolverInfo (hpp:47-127) filled the
+// way upstream fills them -- after ComputeResiduals, before the stopping tests; mu_list_ therefore holds the mu the iteration
+// RAN with.  "logging residuals, should be disabled for speed" (hpp:408): this is the plain implementation, not the engines.
+//   log[(b * rows_cap + k) * LOG_NLIST + list], k = iteration - 1;  rows[b] = entries of the residual / mu lists
+// (the tail solve appends to iter_list_ / tail_solve_iter_list_ only: its length is the instance's tail_solve_iter).
+enum : int { LOG_PR_TASK = 0, LOG_PR_SLACK, LOG_PRIMAL, LOG_DUAL_NU, LOG_DUAL_V, LOG_DUAL, LOG_MU, LOG_MU_EQ, LOG_MU_INEQ, LOG_NLIST };
+
+__global__ void k_pass_solve(PassLayout L, PassParams P, const JointDesc* __restrict__ jd, const int* __restrict__ cslot_of,
+                             double* __restrict__ st, double* __restrict__ log, int rows_cap, int* __restrict__ rows)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= L.B) return;
+  double* s = st + (size_t)b * L.stride;
+  double* sc = s + L.scal;
+  auto body = [&]() {  // UpdatePrev ... ComputeResiduals (hpp:381-404)
+    for (int pass = PASS_BEGIN_ITERATION; pass <= PASS_RESIDUALS; ++pass) pass_one(pass, L, P, jd, cslot_of, s);
+  };
+  int n = 0;
+  sc[PS_TAIL_IT] = 0.0;
+  for (int i = 1; i < P.max_iter; ++i) {
+    body();  // (PASS_BEGIN_ITERATION: iter_ = i)
+    if (n < rows_cap) {
+      double* row = log + ((size_t)b * rows_cap + n) * LOG_NLIST;
+      row[LOG_PR_TASK] = sc[PS_PR_TASK]; row[LOG_PR_SLACK] = sc[PS_PR_SLACK]; row[LOG_PRIMAL] = sc[PS_PRIMAL];
+      row[LOG_DUAL_NU] = sc[PS_DUAL_NU]; row[LOG_DUAL_V] = sc[PS_DUAL_V]; row[LOG_DUAL] = sc[PS_DUAL];
+      row[LOG_MU] = sc[PS_MU]; row[LOG_MU_EQ] = sc[PS_MU_EQ]; row[LOG_MU_INEQ] = sc[PS_MU_IN];
+      ++n;
+    }
+    pass_one(PASS_CHECK_CONV, L, P, jd, cslot_of, s);
+    if (i > 1) pass_one(PASS_CHECK_FEAS, L, P, jd, cslot_of, s);
+    if (sc[PS_CONVERGED] != 0.0) break;
+    if (sc[PS_PRIMAL_INF] != 0.0) {
+      // InfeasibilityTailSolve (hpp:271-319)
+      while (sc[PS_DX] >= P.tol_tail_solve || sc[PS_DZ_INF] >= P.tol_tail_solve) {
+        if ((int)sc[PS_ITER] >= P.max_iter) break;
+        sc[PS_TAIL_IT] += 1.0;
+        body();  // iter_++
+        sc[PS_DX] = fmax(sc[PS_DVIS_INF], sc[PS_DNU_INF]);
+      }
+      break;
+    }
+    pass_one(PASS_UPDATE_MU, L, P, jd, cslot_of, s);
+  }
+  rows[b] = n;
 }
 
 // out[b][...] of one field of the pass state (instance-major, the layouts of loikb_get)

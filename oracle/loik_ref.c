@@ -451,6 +451,11 @@ struct ref_solver {
   double mu_eq, mu_ineq;
   int warm_start;
   double tol_tail_solve;
+
+  /* LoikSolverInfo (loik-loid-optimized.hpp:47-127): what `logging_` pushes after ComputeResiduals (hpp:406-420), kept for
+     the LAST solve: log[list][k], k = iteration - 1 < n_log */
+  double *log[9];
+  int n_log, log_cap;
 };
 
 static double *dalloc(size_t n)
@@ -613,6 +618,7 @@ void ref_destroy(ref_solver *s)
   free(s->H_refs); free(s->v_refs); free(s->Hv); free(s->active_ids);
   free(s->Ais); free(s->bis); free(s->AtA); free(s->Atb); free(s->lb); free(s->ub);
   free(s->primal_residual_vec); free(s->dual_residual_vec);
+  for (int l = 0; l < 9; ++l) free(s->log[l]);
   free(s);
 }
 
@@ -832,6 +838,13 @@ int ref_remove_eq_constraint(ref_solver *s, int c_id)
     if (n > s->bis_inf_norm) s->bis_inf_norm = n;
   }
   return REF_OK;
+}
+
+const double *ref_solver_info(const ref_solver *s, int list, int *n)
+{
+  if (list < 0 || list >= 9) return NULL;
+  if (n) *n = s->n_log;
+  return s->log[list];
 }
 
 int ref_num_eq_c(const ref_solver *s) { return s->nc; }
@@ -1213,9 +1226,20 @@ static void infeasibility_tail_solve(ref_solver *s)
 /* main loop, identical in the three Solve overloads (hpp:377-454, :502-579, :616-693) */
 static int main_loop(ref_solver *s)
 {
+  s->n_log = 0;
+  if (s->max_iter - 1 > s->log_cap) {
+    s->log_cap = s->max_iter - 1;
+    for (int l = 0; l < 9; ++l) { free(s->log[l]); s->log[l] = dalloc((size_t)s->log_cap); }
+  }
   for (int i = 1; i < s->max_iter; i++) {
     s->iter = i;
     ref_iteration_body(s);
+    { /* if (logging_) ... push_back (hpp:406-420): mu_list_ holds the mu this iteration ran with */
+      const double v[9] = {s->primal_residual_task, s->primal_residual_slack, s->primal_residual, s->dual_residual_nu,
+                           s->dual_residual_v, s->dual_residual, s->mu, s->mu_eq, s->mu_ineq};
+      for (int l = 0; l < 9; ++l) s->log[l][s->n_log] = v[l];
+      ++s->n_log;
+    }
     ref_check_convergence(s);
     if (s->iter > 1) ref_check_feasibility(s);
     if (s->converged) {

@@ -130,6 +130,9 @@ int ref_update_eq_constraint(ref_solver *s, int c_id, const double *Ai, const do
 int ref_add_eq_constraint(ref_solver *s, int c_id, const double *Ai, const double *bi);
 int ref_remove_eq_constraint(ref_solver *s, int c_id);
 int ref_num_eq_c(const ref_solver *s);
+/* LoikSolverInfo lists of the last solve (hpp:406-420): 0 primal_residual_task, 1 _slack, 2 primal_residual, 3 dual_residual_nu,
+ * 4 dual_residual_v, 5 dual_residual, 6 mu, 7 mu_eq, 8 mu_ineq; *n = entries (iterations of the main loop) */
+const double *ref_solver_info(const ref_solver *s, int list, int *n);
 int ref_active_id(const ref_solver *s, int c);
 
 /* pass-level entry points (loik-loid-optimized.hpp:192-264) */

@@ -90,6 +90,8 @@ def load(native=False):
         getattr(lib, name).restype = C.c_int
     lib.ref_remove_eq_constraint.argtypes = [C.c_void_p, C.c_int]
     lib.ref_remove_eq_constraint.restype = C.c_int
+    lib.ref_solver_info.argtypes = [C.c_void_p, C.c_int, _c_int_p]
+    lib.ref_solver_info.restype = _c_double_p
     lib.ref_num_eq_c.argtypes = [C.c_void_p]
     lib.ref_num_eq_c.restype = C.c_int
     lib.ref_active_id.argtypes = [C.c_void_p, C.c_int]
@@ -233,6 +235,12 @@ class RefSolver:
 
     def RemoveEqConstraint(self, c_id):
         return self.lib.ref_remove_eq_constraint(self.h, int(c_id)) == 0   # False: nothing to remove
+
+    def solver_info(self, list_id):
+        """list `list_id` (0..8, loik_ref.h) of LoikSolverInfo for the last solve"""
+        n = C.c_int(0)
+        p = self.lib.ref_solver_info(self.h, int(list_id), C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(max(n.value, 1),))[:n.value].copy()
 
     def active_task_constraint_ids(self):
         return [self.lib.ref_active_id(self.h, c) for c in range(self.lib.ref_num_eq_c(self.h))]

@@ -366,6 +366,25 @@ int main()
     CHECK(d.yis.size() == 6 && close(d.yis.data(), o.field(REF_F_YIS), 6, 1e-6));
     CHECK(close(solver.get_primal_residual(), ref_scalar(o.s, REF_S_PRIMAL_RESIDUAL), 1e-7));
   }
+  {  // logging = true: LoikSolverInfo (loik-loid-optimized.hpp:406-420) of the last solve, against the oracle's lists
+    Fixture f; f.max_iter = 200; f.tol_abs = 1e-6; f.tol_rel = 0.0; f.set_bound(0.5); f.logging = true;
+    f.active_task_constraint_ids[0] = f.robot_model.getJointId("arm_left_7_joint");
+    f.bis[0] = Vec6{0.05, -0.03, 0.02, 0.01, 0.02, -0.04};
+    IkIdDataOptimized d(f.robot_model, f.num_eq_c);
+    MAKE_SOLVER(solver, d, f);
+    solver.Solve(f.q, f.H_ref, f.v_ref, f.active_task_constraint_ids, f.Ais, f.bis, f.lb, f.ub);
+    Oracle o(f);
+    o.Solve(f, f.q, f.bis[0]);
+    const LoikSolverInfo info = solver.get_solver_info();
+    int n = 0;
+    const double* pr = ref_solver_info(o.s, 2, &n);
+    CHECK(solver.get_iter() == (int)ref_scalar(o.s, REF_S_ITER));
+    CHECK(info.Size() == solver.get_iter() && (int)info.primal_residual_list_.size() == n && (int)info.mu_list_.size() == n);
+    CHECK(n > 0 && close(info.primal_residual_list_.data(), pr, n));
+    CHECK(close(info.dual_residual_list_.data(), ref_solver_info(o.s, 5, nullptr), n));
+    CHECK(close(info.mu_list_.data(), ref_solver_info(o.s, 6, nullptr), n, 1e-14));
+    CHECK(close(d.z.data(), o.field(REF_F_Z), f.robot_model.nv));
+  }
   {  // floating base: free-flyer root_joint + 32 revolute joints, nq = 39, nv = 38
     Fixture f("talos32_freeflyer"); f.max_iter = 300; f.tol_abs = 1e-6; f.tol_rel = 0.0; f.set_bound(0.5);
     CHECK(f.robot_model.nq == 39 && f.robot_model.nv == 38 && f.robot_model.njoints == 34);

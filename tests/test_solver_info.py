@@ -1,0 +1,103 @@
+"""LoikSolverInfo (SURVEY 8(a) a15 / section 5 "Metrics / logging"): the per-iteration lists the reference fills when it is
+constructed with logging = true (/root/reference/include/loik/loik-loid-optimized.hpp:406-420, lists declared :47-127 and
+task-solver-base.hpp:25-52).  Upstream keeps the struct protected without accessor; here the oracle and the C-ABI expose it."""
+import numpy as np
+import pytest
+
+import loik_amd
+from helpers import FIXTURE, assert_close, feasible_batch, fixture_problem, problem_args, random_tree, random_tree_multidof
+from oracle import ref
+
+LISTS = ["primal_residual_task_list", "primal_residual_slack_list", "primal_residual_list", "dual_residual_nu_list",
+         "dual_residual_v_list", "dual_residual_list", "mu_list", "mu_eq_list", "mu_ineq_list"]
+
+
+def test_oracle_lists_follow_the_main_loop(talos):
+    wl = feasible_batch(talos, 3, talos.getJointId("arm_left_7_joint"), 5)
+    prm = dict(FIXTURE, max_iter=400, tol_abs=1e-6, tol_rel=0.0)
+    for b in range(3):
+        s = ref.RefSolver(talos, **prm)
+        s.Solve(*problem_args(wl, b))
+        n = s.get_iter() - int(s.scalar("tail_solve_iter"))
+        lists = [s.solver_info(k) for k in range(9)]
+        assert all(len(x) == n for x in lists)
+        assert lists[6][0] == prm["mu"] and np.all(lists[7] == prm["mu_equality_scale_factor"] * lists[6]) and np.all(lists[8] == lists[6])
+        if s.scalar("tail_solve_iter") == 0:     # the last entries are the solver's final residuals
+            assert lists[2][-1] == s.scalar("primal_residual") and lists[5][-1] == s.scalar("dual_residual")
+        assert np.all(lists[2] == np.maximum(lists[0], lists[1])) and np.all(lists[5] == np.maximum(lists[3], lists[4]))
+        # a second solve starts new lists (upstream's Solve() never clears them: not replicated)
+        s.Solve()
+        assert len(s.solver_info(0)) == n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["talos", "tree"])
+def test_gpu_solver_info_matches_oracle(which, request):
+    if which == "talos":
+        model = request.getfixturevalue("talos"); link = model.getJointId("arm_left_7_joint")
+    else:
+        model = random_tree(13, 23); link = model.njoints - 1
+    B = 48
+    wl = feasible_batch(model, B, link, 5)
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
+    s = loik_amd.BatchedLoik(model, B, logging=True, **prm)
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    info = s.solver_info()
+    it, z, tail = s.get("iter"), s.get("z"), s.get("tail_solve_iter")
+    for b in range(B):
+        r = ref.RefSolver(model, **prm)
+        r.Solve(*problem_args(wl, b))
+        assert it[b] == r.get_iter() and tail[b] == int(r.scalar("tail_solve_iter")), (b, it[b], r.get_iter())
+        n = len(r.solver_info(0))
+        assert info["rows"][b] == n
+        for k, name in enumerate(LISTS):
+            assert_close(info[name][b, :n], r.solver_info(k), 1e-9, "%s b%d" % (name, b))
+            assert np.all(info[name][b, n:] == 0.0)
+        assert_close(z[b], r.z, 1e-9, "z")
+    # a repeated Solve() and a tailored solve refill the lists from the start
+    s.Solve()
+    assert np.array_equal(s.solver_info()["rows"], info["rows"])
+    s.Solve(wl["q"], link, wl["Ais"], 0.5 * wl["bis"][:, 0])
+    r = ref.RefSolver(model, **prm)
+    r.Solve(*problem_args(wl, 0)); r.Solve(); r.Solve(wl["q"][0], link, wl["Ais"][0], 0.5 * wl["bis"][0, 0])
+    i2 = s.solver_info()
+    assert i2["rows"][0] == len(r.solver_info(2))
+    assert_close(i2["primal_residual_list"][0, :i2["rows"][0]], r.solver_info(2), 1e-9, "tailored")
+    # the logged solve runs the same problem as the engines: same answers from a handle without logging
+    s2 = loik_amd.BatchedLoik(model, B, **prm)
+    s2.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    same = s.get("iter") == s2.get("iter")
+    assert same.mean() >= 0.97 and np.abs(s.get("z") - s2.get("z"))[same].max() < 1e-9
+    s.close(); s2.close()
+
+
+@pytest.mark.gpu
+def test_gpu_solver_info_infeasible_fixture_and_errors(talos):
+    """the reference fixture's unreachable head target: the lists stop at the iteration that raises the certificate, the tail
+    solve only counts (hpp:286-290)"""
+    p = fixture_problem(talos, bound=4.0)
+    prm = dict(FIXTURE, max_iter=200)
+    s = loik_amd.BatchedLoik(talos, 1, logging=True, **prm)
+    s.Solve(*problem_args(p))
+    r = ref.RefSolver(talos, **prm)
+    r.Solve(*problem_args(p))
+    assert s.get("primal_infeasible")[0] == 1 and r.get_primal_infeasibility_status()
+    info = s.solver_info()
+    assert info["rows"][0] == len(r.solver_info(0)) == r.get_iter() - int(r.scalar("tail_solve_iter"))
+    assert s.get("tail_solve_iter")[0] == int(r.scalar("tail_solve_iter")) and s.get("iter")[0] == r.get_iter()
+    assert_close(info["mu_list"][0, :info["rows"][0]], r.solver_info(6), 1e-12, "mu_list")
+    s.close()
+    s = loik_amd.BatchedLoik(talos, 1, **prm)            # no logging: no lists
+    s.Solve(*problem_args(p))
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.solver_info()
+    assert e.value.code == -24
+    s.close()
+    m = random_tree_multidof(seed=5, nb=9, root_freeflyer=True, n_spherical=1, n_translation=1)
+    wl = feasible_batch(m, 2, m.njoints - 1, 3)
+    s = loik_amd.BatchedLoik(m, 2, logging=True, **prm)   # the logged path is the plain pass implementation: 1-DoF joints
+    with pytest.raises(loik_amd.LoikError) as e:
+        s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    assert e.value.code == -7
+    s.close()
