@@ -469,8 +469,8 @@ def main(argv=None, solver_factory=None, device_count=None):
         total_solved, total_iters, total_B = tot["solved"], tot["iters"], tot["batch"]
         per_gpu = args.batch if args.scaling == "weak" else args.batch // n_total
         line = {
-            "metric": "IK solves/sec to 1e-6 residual, Talos humanoid, batch=65536 %s" % (
-                "per GPU" if args.scaling == "weak" else "in total"),
+            "metric": "IK solves/sec to 1e-6 residual, Talos humanoid, batch=%d %s" % (
+                args.batch, "per GPU" if args.scaling == "weak" else "in total"),
             "value": total_solved * args.steps / elapsed,
             "unit": "solves/s",
             "n_gpus": n_total,
