@@ -12,8 +12,8 @@
  * (0 = ok, negative = one of the reference's `throw std::runtime_error` sites or a runtime failure), never
  * throws.  6-vectors are [linear; angular], 6x6 matrices are row-major, joint 0 is the universe -- exactly
  * Pinocchio's conventions.  Per-instance arrays are instance-major ("array of problems"):
- * q[batch][nq], bis[batch][nc][6], z[batch][nv] ...; the library transposes them to its batch-innermost
- * struct-of-arrays device layout on the GPU.
+ * q[batch][nq], bis[batch][nc][6], z[batch][nv] ...; the library transposes them to its wavefront-tiled
+ * device layout (64 instances side by side per tile) on the GPU.
  */
 #ifndef LOIK_AMD_H
 #define LOIK_AMD_H
@@ -31,7 +31,7 @@ enum {
   LOIKB_OK = 0,
   /* reference throw sites */
   LOIKB_ERR_EQ_C_DIM = -1,        /* eq_c_dim != 6                 ik-id-description-optimized.hpp:41-44   */
-  LOIKB_ERR_EQ_C_SIZE = -2,       /* #constraints != num_eq_c      ik-id-description-optimized.hpp:132-145 */
+  LOIKB_ERR_EQ_C_SIZE = -2,       /* #constraints != nc_eq_ (:132-145); also: no free slot for AddEqConstraint, more slots than bodies */
   LOIKB_ERR_INEQ_DIM = -3,        /* lb/ub size != nv              ik-id-description-optimized.hpp:328-335 */
   LOIKB_ERR_NO_SUCH_CONSTRAINT = -4, /* UpdateEqConstraint on an unknown link       ...hpp:184-186          */
   LOIKB_ERR_DUP_CONSTRAINT = -5,  /* same link listed twice                         ...hpp:197-199          */
@@ -51,7 +51,7 @@ enum {
 /* DEFAULT is the reference's rule.  OSQP is declared upstream but throws "not yet implemented" there (hxx:632-637); HERE it
  * is implemented -- OSQP's published penalty rule on LoIK's residuals and normalisers, see update_mu() in
  * loik_amd/csrc/loik_device.hpp and the identical expression in the CPU oracle -- as an extension, not a parity target: on the
- * headline workload it ends most of DEFAULT's mu limit cycles (instances hitting max_iter: 0.85 % -> 0.17 %).  mu is then
+ * headline workload it ends most of DEFAULT's mu limit cycles (instances hitting max_iter: 1.16 % -> 0.14 %).  mu is then
  * off the decade grid, so such solves run in the k_solve / k_tail engines.  MAXEIGENVALUE returns LOIKB_ERR_MU_STRATEGY. */
 enum { LOIKB_MU_DEFAULT = 0, LOIKB_MU_OSQP = 1, LOIKB_MU_MAXEIGENVALUE = 3 };
 
@@ -101,10 +101,8 @@ typedef struct loikb_options {
   int max_launch_iters; /* ADMM iterations per kernel launch, 0 = automatic                    */
   int compact_min_instances; /* stop compacting below this many slots, 0 = default (4096)     */
   int tail_max_instances;    /* hand the last N live instances to the cooperative tail kernel (one wavefront per
-                                instance): 0 = default (2^20 when the lean tail kernel applies
-                                -- H cache on, <= 2 task constraints with a shared A (1 otherwise), <= 4 children per joint:
-                                whole batches run in it --, else
-                                32768), < 0 = never                                           */
+                                instance): 0 = default (2^20 when the lean kernel applies -- loikb_plan_string says
+                                whether and why: whole batches run in it --, else 32768), < 0 = never           */
   int eq_c_capacity;         /* constraint slots to allocate, 0 = num_eq_c.  Room for loikb_add_eq_constraint: upstream sizes
                                 yis/Aty for num_eq_c only, so its AddEqConstraint ("deactivated for now",
                                 ik-id-description-optimized.hpp:242) has nowhere to put a new dual; a slot without a
@@ -242,7 +240,7 @@ enum {
   LOIKB_F_HIS,        /* ik_id_data.His[i] */
   /* double [batch][nb][12]: R row-major, t */
   LOIKB_F_LIMI,       /* ik_id_data.liMi[i] */
-  /* double [batch][nc][6] */
+  /* double [batch][nc][6], nc = loikb_num_eq_c(): the constraints in force, in active_task_constraint_ids order */
   LOIKB_F_YIS,        /* ik_id_data.yis[c] */
   LOIKB_F_ATY,        /* ik_id_data.Aty[c] */
   /* int [batch] */
