@@ -80,6 +80,8 @@ for case in range(ncase):
                tol_rel=float(rng.choice([0.0, 1e-6])), mu_update_strat=1 if osqp else 0)
     engine = str(rng.choice(list(ENGINES)))
     env, kw = ENGINES[engine]
+    if os.environ.get("FUZZ_ONLY") and case != int(os.environ["FUZZ_ONLY"]):   # replay one case of a run (same draws)
+        continue
     for k in ENV_KEYS:
         os.environ.pop(k, None)
     os.environ.update(env)
@@ -111,11 +113,20 @@ for case in range(ncase):
     try:
         # (loose cases: the digits lost in f = H v + p scale with mu; the answer itself is only good to tol_abs -- the budget is
         #  the larger of 1e-5 and half the solver tolerance: OSQP at mu ~ 1e6 on a 50-DoF chain model reached 1.9e-5 at tol 1e-4)
-        assert_end_to_end(got, out, prm, same_frac=0.95 if B >= 70 else 0.0, ztol=max(1e-5, 0.5 * prm["tol_abs"]) if loose else 1e-7,
+        # (OSQP: mu follows the residual ratio continuously, so an instance that has NOT converged when max_iter stops it carries
+        #  the rounding history of every mu it went through: three of 3000 such instances ended 1e-5 .. 9e-5 apart at tol 1e-4 --
+        #  the budget under that rule is the solver tolerance itself)
+        assert_end_to_end(got, out, prm, same_frac=0.95 if B >= 70 else 0.0,
+                          ztol=(max(1e-5, (1.0 if osqp else 0.5) * prm["tol_abs"]) if loose else 1e-7),
                           off_ztol=max(1e-5 if loose else 1e-6, 10 * prm["tol_abs"]), what="case %d" % case,
                           res_tol=(1e-7, 1e-5))  # (several task constraints: forces ~ mu_eq ~ 1e4..1e7 cancel in the residuals)
     except AssertionError as e:
         ok, why = False, str(e)[:300]
+        if os.environ.get("FUZZ_ONLY"):
+            bad = np.argsort(-dz)[:8]
+            mu = s.get("mu")
+            print("  worst instances:", [(int(b), float(dz[b]), int(got["iter"][b]), bool(got["converged"][b]), float(mu[b]),
+                                          float(np.abs(out["z"][b]).max())) for b in bad])
     summary["cases"] += 1; summary["mismatches"] += not ok
     summary["worst_dz_same"] = max(summary["worst_dz_same"], float(dz[same].max()) if same.any() else 0.0)
     summary["instances"] += B; summary["off_count"] += int((~same).sum())
