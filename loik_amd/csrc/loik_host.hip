@@ -1217,13 +1217,13 @@ void plan_engines(loikb_solver_impl* S)
   else if (S->maxchild > 4) pl.why_not_lean = "a joint with more than four children";
   else if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) pl.why_not_lean = "LOIKB_OPT_NO_H_CACHE (no precomputed H)";
   else if (S->opt.mu_update_strat == LOIKB_MU_OSQP) pl.why_not_lean = "OSQP penalty rule: mu is off the decade grid";
-  // Eight wavefronts per CU is what the registers allow.  Seven (single-wavefront workgroups) are accepted for robots that
-  // fill at least half a wavefront per instance -- a whole-body task set (four constraint blocks) then stays in this engine.
-  // Small robots pack 4-8 instances, i.e. 4-8 constraint blocks, into a wavefront and would get here only at 6-7 per CU; for
-  // them the k_solve + k_tail engines are faster anyway (Panda-7, B = 65536, tol 1e-3, 4 iterations on average: 0.79 ms
-  // against 1.18 ms in k_lean, whose ten precomputed decades of H are mostly never used by such short solves).
-  else if (!(pl.lean_waves_cu == 8 || (S->nb > 16 && pl.lean_waves_cu >= 7)))
-    pl.why_not_lean = "constraint blocks leave too few wavefronts per CU in LDS";
+  // Eight wavefronts per CU is what the registers allow; seven (single-wavefront workgroups) when four constraint blocks -- a
+  // whole-body task set -- take more LDS.  Robots of up to 16 joints pack 4-8 instances into a wavefront and solve in a handful
+  // of iterations: for them k_solve + k_tail are faster in every case measured (Panda-7, B = 65536, fp64 / fp32: tol 1e-3
+  // 0.75 / 0.61 ms against 1.18 / 1.14 ms in k_lean, tol 1e-4 0.89 / 0.81 against - / 1.33; the ten precomputed decades of H
+  // are mostly never used by such short solves) -- scripts/r02/small_robot_plan_probe.py.
+  else if (S->nb <= 16) pl.why_not_lean = "a small robot (<= 16 joints): k_solve + k_tail are faster on its short solves";
+  else if (pl.lean_waves_cu < 7) pl.why_not_lean = "constraint blocks leave too few wavefronts per CU in LDS";
   else pl.lean = true;
   // with the lean kernel whole batches up to 2^20 instances go to it directly (it is as fast as k_solve's bulk phase and
   // has neither ragged tiles nor compaction); without it k_solve hands over to k_tail at 32768 live instances
