@@ -199,3 +199,24 @@ def test_joints_not_numbered_depth_first(talos, engine, monkeypatch):
                 assert_close(His[b], r.His[1:], 1e-9, "His")
             sk.close()
         s.close()
+
+
+@pytest.mark.gpu
+def test_more_joints_than_lanes_of_a_wavefront():
+    """a robot with more than 64 joints (a humanoid with hands): the one-joint-per-lane engines do not apply, k_solve runs the
+    whole solve; every instance against the oracle"""
+    from helpers import assert_end_to_end, fetch_end_to_end, multi_task_batch
+    nb = 80
+    model = random_tree(3, nb, branch_prob=0.3)
+    B = 200
+    wl = multi_task_batch(model, B, [nb // 3, nb], 7, bound=0.5, nu_scale=0.3)
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0, num_eq_c=2)
+    out = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"],
+                          nthreads=8, want_nu=True, **prm)
+    s = loik_amd.BatchedLoik(model, B, **prm)
+    assert "more joints than lanes" in s.plan()
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.97, ztol=1e-6, off_ztol=1e-5, what="80 joints")
+    st = s.stats()
+    assert st["tail_instances"] == 0 and st["lean_launches"] == 0
+    s.close()
