@@ -122,6 +122,22 @@ for case in range(ncase):
                           res_tol=(1e-7, 1e-5))  # (several task constraints: forces ~ mu_eq ~ 1e4..1e7 cancel in the residuals)
     except AssertionError as e:
         ok, why = False, str(e)[:300]
+        # An instance that max_iter stopped before it converged -- in either solver -- is not an answer: its iterate depends on
+        # every rounding on the way (continuously under OSQP's rule, through near-ties of the decade rule otherwise).  If the
+        # comparison holds once those are set aside, the case is counted as "unconverged only", not as a mismatch.
+        stopped = ((np.asarray(got["iter"]) >= prm["max_iter"] - 1) & ~np.asarray(got["converged"]).astype(bool)) | \
+                  ((out["iters"] >= prm["max_iter"] - 1) & ~out["converged"])
+        keep = ~stopped
+        if stopped.any() and keep.any():
+            try:
+                assert_end_to_end({k: np.asarray(v)[keep] for k, v in got.items()}, {k: np.asarray(v)[keep] for k, v in out.items()}, prm,
+                                  same_frac=0.0, ztol=(max(1e-5, (1.0 if osqp else 0.5) * prm["tol_abs"]) if loose else 1e-7),
+                                  off_ztol=max(1e-5 if loose else 1e-6, 10 * prm["tol_abs"]), what="case %d (converged or flagged only)" % case,
+                                  res_tol=(1e-7, 1e-5))
+                ok, why = True, "unconverged-only: %d instance(s) stopped by max_iter differ" % int(stopped.sum())
+                summary["unconverged_only"] = summary.get("unconverged_only", 0) + 1
+            except AssertionError:
+                pass
         if os.environ.get("FUZZ_ONLY"):
             bad = np.argsort(-dz)[:8]
             mu = s.get("mu")
