@@ -59,6 +59,7 @@ struct Tuning {
   int lean_decades = 10;        // LOIKB_LEAN_DECADES  decades of mu with precomputed H slots ...
   int lean_klo = -2;            // LOIKB_LEAN_KLO      ... starting at mu0 * 10^klo
   int lean_wg_per_cu = 0;       // LOIKB_LEAN_WG_PER_CU (0: what registers and LDS allow)
+  int lean_wg_waves = 0;        // LOIKB_LEAN_WG_WAVES wavefronts per k_lean workgroup (0: by plan)
   std::vector<int> lean_quanta; // LOIKB_LEAN_QUANTA   host-side rounds of the lean launch (default: none)
   int lean_slice = 0;           // LOIKB_LEAN_SLICE    in-kernel round-robin time slice (0: run to completion)
   double compact_ratio = 0.85;  // LOIKB_COMPACT_RATIO repack k_solve's tiles when at most this share of the slots is live
@@ -77,6 +78,7 @@ struct Tuning {
     geti("LOIKB_LEAN_DECADES", lean_decades); lean_decades = std::max(1, std::min(16, lean_decades));
     geti("LOIKB_LEAN_KLO", lean_klo);
     geti("LOIKB_LEAN_WG_PER_CU", lean_wg_per_cu);
+    geti("LOIKB_LEAN_WG_WAVES", lean_wg_waves);
     if (const char* e = getenv("LOIKB_LEAN_QUANTA"))
       for (const char* p = e; *p;) { lean_quanta.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
     geti("LOIKB_LEAN_SLICE", lean_slice); lean_slice = std::max(0, lean_slice);
@@ -1211,7 +1213,12 @@ void plan_engines(loikb_solver_impl* S)
   pl.kexp_lo = S->tune.lean_klo;
   if (S->opt.flags & LOIKB_OPT_FIXED_ITERS) { pl.ndec = 1; pl.kexp_lo = 0; }  // mu frozen at mu0: one decade
   pl.lean_waves_cu = S->nb <= WAVE ? lean_waves_per_cu(S) : 0;
-  pl.lean_wg_waves = pl.lean_waves_cu == 8 ? TAIL_WAVES : 1;
+  // Single-wavefront workgroups: wavefronts of k_lean never synchronise with each other, and a workgroup gives its registers and
+  // LDS back as soon as ITS two instances are done -- with four wavefronts per workgroup one long runner kept the slots of
+  // seven finished neighbours, which costs nothing while one launch owns the machine (headline 21.85 vs 21.99 ms, noise) but
+  // is what a second batch in flight has to wait for (two batches in flight: 32.3 vs 35.6 ms per pair).
+  pl.lean_wg_waves = 1;
+  if (S->tune.lean_wg_waves > 0 && pl.lean_waves_cu % S->tune.lean_wg_waves == 0) pl.lean_wg_waves = S->tune.lean_wg_waves;
   if (!S->tune.lean) pl.why_not_lean = "LOIKB_LEAN=0";
   else if (S->nb > WAVE) pl.why_not_lean = "more joints than lanes of a wavefront";
   else if (S->maxchild > 4) pl.why_not_lean = "a joint with more than four children";
