@@ -2230,6 +2230,7 @@ static int run_logged(loikb_solver_impl* S)
     if (!S->d_log_rows) HIPCHK(hipMalloc((void**)&S->d_log_rows, sizeof(int) * S->B));
     S->log_rows_cap = cap;
   }
+  HIPCHK(hipMemsetAsync(S->d_log, 0, sizeof(double) * (size_t)S->B * cap * LOG_NLIST, S->stream));
   HIPCHK(hipEventRecord(S->ev_t0, S->stream));
   hipLaunchKernelGGL(k_pass_solve, grid1(S->B, 64), dim3(64), 0, S->stream, S->PL, P, (const JointDesc*)S->d_jd,
                      (const int*)S->d_pass_cslot, S->d_pass, S->d_log, cap, S->d_log_rows);
@@ -2251,14 +2252,9 @@ int loikb_get_solver_info(loikb_solver* S, int list, double* out, int* rows_out)
   if (!S->have_log) { g_last_error = "no SolverInfo: create the solver with logging = 1 and solve"; return LOIKB_ERR_STATE; }
   HIPCHK(hipSetDevice(S->device));
   const int cap = S->log_rows_cap;
-  std::vector<double> all((size_t)S->B * cap * LOG_NLIST);
-  std::vector<int> rows(S->B);
-  HIPCHK(hipMemcpy(all.data(), S->d_log, all.size() * sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(rows.data(), S->d_log_rows, rows.size() * sizeof(int), hipMemcpyDeviceToHost));
-  for (int b = 0; b < S->B; ++b)
-    for (int k = 0; k < cap; ++k)
-      out[(size_t)b * cap + k] = k < rows[b] ? all[((size_t)b * cap + k) * LOG_NLIST + list] : 0.0;
-  if (rows_out) memcpy(rows_out, rows.data(), sizeof(int) * S->B);
+  // (the lists are stored list-major and zero beyond rows[b]: one contiguous copy per list)
+  HIPCHK(hipMemcpy(out, S->d_log + (size_t)list * S->B * cap, sizeof(double) * (size_t)S->B * cap, hipMemcpyDeviceToHost));
+  if (rows_out) HIPCHK(hipMemcpy(rows_out, S->d_log_rows, sizeof(int) * (size_t)S->B, hipMemcpyDeviceToHost));
   return LOIKB_OK;
 }
 

@@ -413,7 +413,7 @@ __global__ void k_pass(int pass, PassLayout L, PassParams P, const JointDesc* __
 // of every instance written out pass by pass, one thread per instance, with the lists of LoikSolverInfo (hpp:47-127) filled the
 // way upstream fills them -- after ComputeResiduals, before the stopping tests; mu_list_ therefore holds the mu the iteration
 // RAN with.  "logging residuals, should be disabled for speed" (hpp:408): this is the plain implementation, not the engines.
-//   log[(b * rows_cap + k) * LOG_NLIST + list], k = iteration - 1;  rows[b] = entries of the residual / mu lists
+//   log[(list * B + b) * rows_cap + k], k = iteration - 1 (zero beyond rows[b]);  rows[b] = entries of the residual / mu lists
 // (the tail solve appends to iter_list_ / tail_solve_iter_list_ only: its length is the instance's tail_solve_iter).
 enum : int { LOG_PR_TASK = 0, LOG_PR_SLACK, LOG_PRIMAL, LOG_DUAL_NU, LOG_DUAL_V, LOG_DUAL, LOG_MU, LOG_MU_EQ, LOG_MU_INEQ, LOG_NLIST };
 
@@ -432,10 +432,9 @@ __global__ void k_pass_solve(PassLayout L, PassParams P, const JointDesc* __rest
   for (int i = 1; i < P.max_iter; ++i) {
     body();  // (PASS_BEGIN_ITERATION: iter_ = i)
     if (n < rows_cap) {
-      double* row = log + ((size_t)b * rows_cap + n) * LOG_NLIST;
-      row[LOG_PR_TASK] = sc[PS_PR_TASK]; row[LOG_PR_SLACK] = sc[PS_PR_SLACK]; row[LOG_PRIMAL] = sc[PS_PRIMAL];
-      row[LOG_DUAL_NU] = sc[PS_DUAL_NU]; row[LOG_DUAL_V] = sc[PS_DUAL_V]; row[LOG_DUAL] = sc[PS_DUAL];
-      row[LOG_MU] = sc[PS_MU]; row[LOG_MU_EQ] = sc[PS_MU_EQ]; row[LOG_MU_INEQ] = sc[PS_MU_IN];
+      const double v[LOG_NLIST] = {sc[PS_PR_TASK], sc[PS_PR_SLACK], sc[PS_PRIMAL], sc[PS_DUAL_NU], sc[PS_DUAL_V], sc[PS_DUAL],
+                                   sc[PS_MU], sc[PS_MU_EQ], sc[PS_MU_IN]};
+      for (int l = 0; l < LOG_NLIST; ++l) log[((size_t)l * L.B + b) * rows_cap + n] = v[l];
       ++n;
     }
     pass_one(PASS_CHECK_CONV, L, P, jd, cslot_of, s);
