@@ -2378,6 +2378,7 @@ const char* loikb_plan_string(loikb_solver* S)
     snprintf(buf, sizeof(buf), "k_solve (team of %d), hand-over to k_tail at %d live instances; %d chunk(s); no k_lean: %s",
              S->sched[1].nw, pl.tail_max, pl.nchunks, pl.why_not_lean);
   out = buf;
+  if (S->opt.logging) out = "logging = 1: every solve runs on the plain pass-by-pass implementation (k_pass_solve) and fills SolverInfo; without it: " + out;
   if (pl.lean && S->per_link) out += "; per-link references in force (UpdateReferences): k_tail takes k_lean's place until the next SolveInit";
   return out.c_str();
 }
