@@ -433,7 +433,10 @@ private:
       const std::size_t nv = static_cast<std::size_t>(s.model_.nv);
       if (lb.size() == nv * B && B > 1) nbound = (int)nv;
       else { nbound = (int)lb.size(); flags |= LOIKB_BOUNDS_SHARED; }
-      if (B > 1 && q.size() == static_cast<std::size_t>(s.model_.nq)) flags |= LOIKB_Q_SHARED;
+      const std::size_t nq = static_cast<std::size_t>(s.model_.nq);
+      if (q.size() != nq && q.size() != nq * B)   // (the C-ABI takes bare pointers: sizes are checked here)
+        throw std::runtime_error("loik_amd: q must hold model.nq values (one configuration for the batch) or batch * model.nq");
+      if (B > 1 && q.size() == nq) flags |= LOIKB_Q_SHARED;
     }
   };
 
