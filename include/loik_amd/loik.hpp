@@ -218,6 +218,7 @@ public:
   void Solve(const DVec& q, const Index c_id, const Mat6x6& Ai, const Vec6& bi)
   {
     int flags = LOIKB_A_SHARED | LOIKB_B_SHARED;
+    check_q(q);
     if (batch_ > 1 && q.size() == static_cast<std::size_t>(model_.nq)) flags |= LOIKB_Q_SHARED;
     check(loikb_solve_tailored(h_, q.data(), (int)c_id, Ai.data(), bi.data(), flags));
     solved();
@@ -229,6 +230,7 @@ public:
       for (int k = 0; k < 6; ++k) b[6 * i + k] = bis[i][k];
     int flags = LOIKB_A_SHARED;
     if (bis.size() == 1 && batch_ > 1) flags |= LOIKB_B_SHARED;
+    check_q(q);
     if (batch_ > 1 && q.size() == static_cast<std::size_t>(model_.nq)) flags |= LOIKB_Q_SHARED;
     check(loikb_solve_tailored(h_, q.data(), (int)c_id, Ai.data(), b.data(), flags));
     solved();
@@ -285,6 +287,7 @@ public:
   void Solve(const DVec& q)
   {
     int flags = 0;
+    check_q(q);
     if (batch_ > 1 && q.size() == static_cast<std::size_t>(model_.nq)) flags |= LOIKB_Q_SHARED;
     check(loikb_solve_tailored(h_, q.data(), -1, nullptr, nullptr, flags));
     solved();
@@ -440,6 +443,12 @@ private:
     }
   };
 
+  void check_q(const DVec& q) const
+  {
+    const std::size_t nq = static_cast<std::size_t>(model_.nq);
+    if (q.size() != nq && q.size() != nq * static_cast<std::size_t>(batch_))
+      throw std::runtime_error("loik_amd: q must hold model.nq values (one configuration for the batch) or batch * model.nq");
+  }
   static DVec flat(const std::vector<Vec6>& bis)
   {
     DVec b(bis.size() * 6);
