@@ -229,6 +229,7 @@ public:
     for (std::size_t i = 0; i < bis.size(); ++i)
       for (int k = 0; k < 6; ++k) b[6 * i + k] = bis[i][k];
     int flags = LOIKB_A_SHARED;
+    check_bis(bis);
     if (bis.size() == 1 && batch_ > 1) flags |= LOIKB_B_SHARED;
     check_q(q);
     if (batch_ > 1 && q.size() == static_cast<std::size_t>(model_.nq)) flags |= LOIKB_Q_SHARED;
@@ -319,6 +320,7 @@ public:
     for (std::size_t i = 0; i < bis.size(); ++i)
       for (int k = 0; k < 6; ++k) b[6 * i + k] = bis[i][k];
     int flags = LOIKB_A_SHARED;
+    check_bis(bis);
     if (bis.size() == 1 && batch_ > 1) flags |= LOIKB_B_SHARED;
     check(loikb_solve_tailored(h_, nullptr, (int)c_id, Ai.data(), b.data(), flags));
     solved();
@@ -456,7 +458,12 @@ private:
       for (int k = 0; k < 6; ++k) b[6 * i + k] = bis[i][k];
     return b;
   }
-  int b_flag(const std::vector<Vec6>& bis) const { return (bis.size() == 1 && batch_ > 1) ? LOIKB_B_SHARED : 0; }
+  void check_bis(const std::vector<Vec6>& bis) const
+  {
+    if (bis.size() != 1 && bis.size() != static_cast<std::size_t>(batch_))
+      throw std::runtime_error("loik_amd: bis must hold one target (for the whole batch) or one per instance");
+  }
+  int b_flag(const std::vector<Vec6>& bis) const { check_bis(bis); return (bis.size() == 1 && batch_ > 1) ? LOIKB_B_SHARED : 0; }
   // yis / Aty of the data object follow nc_eq_ (upstream never resizes them: its AddEqConstraint is deactivated)
   void resize_constraints()
   {
