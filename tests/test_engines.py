@@ -220,3 +220,40 @@ def test_more_joints_than_lanes_of_a_wavefront():
     st = s.stats()
     assert st["tail_instances"] == 0 and st["lean_launches"] == 0
     s.close()
+
+
+@pytest.mark.gpu
+def test_two_handles_on_their_own_streams_run_concurrently_and_agree(talos):
+    """LOIKB_OPT_OWN_STREAM: two handles, two host threads, one device -- the launches interleave on the GPU; each handle's
+    results are those of the same solve run alone"""
+    import threading
+    from loik_amd import capi
+    link = talos.getJointId("arm_left_7_joint")
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
+    wls = [feasible_batch(talos, 4096, link, 11 + k) for k in range(2)]
+    alone = []
+    for wl in wls:
+        s = loik_amd.BatchedLoik(talos, 4096, **prm)
+        s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+        alone.append((s.get("z"), s.get("iter"), s.get("converged")))
+        s.close()
+    solvers = [loik_amd.BatchedLoik(talos, 4096, flags=capi.OPT_OWN_STREAM, **prm) for _ in wls]
+    got, errs = [None, None], []
+
+    def work(k):
+        try:
+            s, wl = solvers[k], wls[k]
+            for _ in range(3):
+                s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+            got[k] = (s.get("z"), s.get("iter"), s.get("converged"))
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errs, errs
+    for k in range(2):
+        assert np.array_equal(got[k][1], alone[k][1]) and np.array_equal(got[k][2], alone[k][2])
+        assert np.array_equal(got[k][0], alone[k][0])      # bit-identical: instances never interact
+    for s in solvers:
+        s.close()
