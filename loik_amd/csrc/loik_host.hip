@@ -60,6 +60,7 @@ struct Tuning {
   int lean_klo = -2;            // LOIKB_LEAN_KLO      ... starting at mu0 * 10^klo
   int lean_wg_per_cu = 0;       // LOIKB_LEAN_WG_PER_CU (0: what registers and LDS allow)
   int lean_wg_waves = 0;        // LOIKB_LEAN_WG_WAVES wavefronts per k_lean workgroup (0: by plan)
+  bool lean_adapt = true;       // LOIKB_LEAN_ADAPT=0  always build the whole configured range of decade slots
   std::vector<int> lean_quanta; // LOIKB_LEAN_QUANTA   host-side rounds of the lean launch (default: none)
   int lean_slice = 0;           // LOIKB_LEAN_SLICE    in-kernel round-robin time slice (0: run to completion)
   double compact_ratio = 0.85;  // LOIKB_COMPACT_RATIO repack k_solve's tiles when at most this share of the slots is live
@@ -79,6 +80,7 @@ struct Tuning {
     geti("LOIKB_LEAN_KLO", lean_klo);
     geti("LOIKB_LEAN_WG_PER_CU", lean_wg_per_cu);
     geti("LOIKB_LEAN_WG_WAVES", lean_wg_waves);
+    if (const char* e = getenv("LOIKB_LEAN_ADAPT")) lean_adapt = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_LEAN_QUANTA"))
       for (const char* p = e; *p;) { lean_quanta.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
     geti("LOIKB_LEAN_SLICE", lean_slice); lean_slice = std::max(0, lean_slice);
@@ -214,6 +216,9 @@ struct loikb_solver_impl {
   PassLayout PL{};
   double* d_pass = nullptr;
   int* d_pass_cslot = nullptr;
+  // decades of mu the lean engine's instances actually visited in the solves of this handle so far (absolute exponents): the
+  // next solve builds slots for [seen_lo - 1, seen_hi + 1] only (within the configured range); an escape widens it again
+  int seen_lo = 1 << 20, seen_hi = -(1 << 20);
   // SolverInfo lists of a handle created with logging = 1 (k_pass_solve)
   double* d_log = nullptr;
   int* d_log_rows = nullptr;
@@ -1296,7 +1301,16 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     // mu0 in the first iterations and then mostly oscillates between two or three decades (Talos workload: 0..7 seen,
     // < 0 never); an instance that leaves the range is finished by k_tail.
     // (the table is built as a pipeline over the tree levels: a decade more costs one step)
-    const int ndec = S->plan.ndec, kexp_lo = S->plan.kexp_lo;
+    // Every decade costs k_hslots a pipeline step and 176 B x joints per instance of HBM writes (0.14 ms per decade on the
+    // headline): after the first solve of a handle the table covers the decades its instances were seen in, plus one on
+    // each side (the headline workload lives in 0..6 of the configured -2..7: 21.8 -> 21.2 ms).  mu restarts at mu0 in every
+    // solve, batches of one application resemble each other; when they do not, the instance that leaves the table escapes
+    // to k_tail as always and the full range is back for the next solve.
+    int ndec = S->plan.ndec, kexp_lo = S->plan.kexp_lo;
+    if (S->tune.lean_adapt && S->seen_hi >= S->seen_lo && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS)) {
+      const int lo = std::max(kexp_lo, S->seen_lo - 1), hi = std::min(kexp_lo + ndec - 1, S->seen_hi + 1);
+      if (hi >= lo) { kexp_lo = lo; ndec = hi - lo + 1; }
+    }
     const size_t wave_lds = lean_lds_bytes<T>(S->nc, G, S->a_shared);
     // (k_lean's lane groups need whole wavefronts of work to pay: below 64 instances k_tail's direct path is as good)
     const bool lean_ok = S->plan.lean && !S->per_link && (P.mode & MODE_CACHE_H) && n >= 64;  // (k_lean has no per-link table)
@@ -1377,6 +1391,13 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         if (t_first < 0.f) { HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0)); t_first = t0; }
         iters += C->h_counters[1];
         escaped = C->h_counters[2];
+        {
+          std::lock_guard<std::mutex> lock(S->alloc_mu);
+          const unsigned int seen = C->h_counters[LEAN_DECADES_SEEN];
+          for (int d = 0; d < 16; ++d)
+            if (seen & (1u << d)) { S->seen_lo = std::min(S->seen_lo, kexp_lo + d); S->seen_hi = std::max(S->seen_hi, kexp_lo + d); }
+          if (escaped) { S->seen_lo = S->plan.kexp_lo; S->seen_hi = S->plan.kexp_lo + S->plan.ndec - 1; }  // the table was too narrow
+        }
         C->stats.lean_requeues += (int)C->h_counters[LEAN_Q_REQUEUES];
         if (!first_timed) {
           first_timed = true;
@@ -2349,7 +2370,13 @@ int loikb_set_rho(loikb_solver* S, double v)
   HIPCHK(hipSetDevice(S->device));
   return reset_home(S, RS_HCACHE);
 }
-int loikb_set_mu(loikb_solver* S, double v) { if (!S) return LOIKB_ERR_ARG; S->opt.mu = v; return LOIKB_OK; }
+int loikb_set_mu(loikb_solver* S, double v)
+{
+  if (!S) return LOIKB_ERR_ARG;
+  S->opt.mu = v;
+  S->seen_lo = 1 << 20; S->seen_hi = -(1 << 20);  // the decades are counted from mu0: the history no longer applies
+  return LOIKB_OK;
+}
 int loikb_set_tol(loikb_solver* S, double a, double r)
 {
   if (!S) return LOIKB_ERR_ARG;

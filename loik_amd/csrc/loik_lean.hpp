@@ -43,6 +43,7 @@ constexpr int LCD = 26, LCA = 36;
 // counters of a lean launch (Bufs::counters): [1] instance-iterations, [2] escaped instances, [5] wavefront-iterations,
 // [6] decade-slot loads, and the work queue:
 constexpr int LEAN_Q_HEAD = 7, LEAN_Q_TAIL = 8, LEAN_Q_REQUEUES = 9, LEAN_Q_RETIRED = 10;
+constexpr int LEAN_DECADES_SEEN = 11;  // bit d: some instance loaded the slot of decade kexp_lo + d in this launch
 constexpr int NCOUNTERS = 16;
 #ifndef LOIKB_POLL_MASK
 #define LOIKB_POLL_MASK 3u
@@ -491,7 +492,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
           }
         }
         kslot = kexp;
-        ++n_slot_loads;
+        n_slot_loads = (n_slot_loads + 0x10000u) | (1u << dsl);  // count in the upper half, the decades visited in the lower
       }
     }
     TAIL_TP(8)
@@ -831,7 +832,10 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #endif
   if (lane == 0) {
     atomicAdd(&Bf.counters[5], n_wave_iters);
-    atomicAdd(&Bf.counters[6], n_slot_loads);
+  }
+  if (jlane == 0) {  // (per lane group: each group loads the slots of its own instances)
+    atomicAdd(&Bf.counters[6], n_slot_loads >> 16);
+    atomicOr(&Bf.counters[LEAN_DECADES_SEEN], n_slot_loads & 0xFFFFu);
   }
 }
 

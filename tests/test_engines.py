@@ -257,3 +257,21 @@ def test_two_handles_on_their_own_streams_run_concurrently_and_agree(talos):
         assert np.array_equal(got[k][0], alone[k][0])      # bit-identical: instances never interact
     for s in solvers:
         s.close()
+
+
+@pytest.mark.gpu
+def test_decade_table_follows_the_handles_history(talos):
+    """after the first solve of a handle the lean engine builds decade slots only around the decades its instances were seen in;
+    a later solve that needs more escapes to k_tail for those instances (correct answers) and gets the full table back"""
+    link = talos.getJointId("arm_left_7_joint")
+    easy = feasible_batch(talos, 2048, link, 3, bound=2.0, nu_scale=0.1)     # converges in a few iterations at mu0
+    hard = feasible_batch(talos, 2048, link, 4, bound=0.5, nu_scale=0.4)     # mu moves over several decades
+    prm = dict(FIXTURE, max_iter=400, tol_abs=1e-6, tol_rel=0.0)
+    s = loik_amd.BatchedLoik(talos, 2048, **prm)
+    for wl in (easy, easy, hard, hard, easy):
+        args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+        s.Solve(*args)
+        out = ref.solve_batch(talos, *args, nthreads=8, want_nu=True, **prm)
+        assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.97, ztol=1e-8, off_ztol=1e-5, what="history")
+        assert s.stats()["lean_launches"] > 0
+    s.close()
