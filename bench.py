@@ -442,6 +442,7 @@ def main(argv=None, solver_factory=None, device_count=None):
         return shards, res, elapsed, tot
 
     shards, res, elapsed, tot = measure(args.scaling)
+    plan0 = shards[0].solver.plan() if hasattr(shards[0].solver, "plan") else None   # which kernels ran, and why
     strong = None
     if args.scaling == "weak" and n_total > 1 and not args.no_strong_leg:
         sh0_keep = (shards[0].acc, shards[0].last, shards[0].wl, shards[0].t_init, res[0])
@@ -500,6 +501,7 @@ def main(argv=None, solver_factory=None, device_count=None):
                 "mean_admm_iterations": total_iters / total_B,
                 "instance_iterations_per_s": total_iters * args.steps / elapsed,
                 "solve_init_s_gpu0_incl_pcie": t_init0,
+                "engines_gpu0": plan0,
             },
             "roofline": kernel_roofline(acc0, last0, args.steps, nb, nc, B0),
         }

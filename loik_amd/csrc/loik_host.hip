@@ -2405,6 +2405,11 @@ const char* loikb_plan_string(loikb_solver* S)
     snprintf(buf, sizeof(buf), "k_solve (team of %d), hand-over to k_tail at %d live instances; %d chunk(s); no k_lean: %s",
              S->sched[1].nw, pl.tail_max, pl.nchunks, pl.why_not_lean);
   out = buf;
+  if (pl.lean && S->tune.lean_adapt && S->seen_hi >= S->seen_lo) {
+    char b2[160];
+    snprintf(b2, sizeof(b2), "; decades visited by this handle's solves so far: %d..%d (the next solve builds those +-1)", S->seen_lo, S->seen_hi);
+    out += b2;
+  }
   if (S->opt.logging) out = "logging = 1: every solve runs on the plain pass-by-pass implementation (k_pass_solve) and fills SolverInfo; without it: " + out;
   if (pl.lean && S->per_link) out += "; per-link references in force (UpdateReferences): k_tail takes k_lean's place until the next SolveInit";
   return out.c_str();
