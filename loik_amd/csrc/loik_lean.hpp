@@ -473,6 +473,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       } else {
         if (isj) {
           const typename Vec2<T>::type* hp = reinterpret_cast<const typename Vec2<T>::type*>(hslots);
+#ifndef LOIKB_SLOT_TWO_PARTS
           {
             typename Vec2<T>::type in[11];
 #pragma unroll
@@ -482,6 +483,24 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
             hcur[20] = in[10].x;
             dinv = in[10].y;
           }
+#else  // (the round-1 form, kept for A/B builds: two dependent round trips)
+          {
+            typename Vec2<T>::type in[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) in[k] = hp[hslot_pair(lidx, ndec, dsl, G, k, jlane)];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { hcur[2 * k] = in[k].x; hcur[2 * k + 1] = in[k].y; }
+          }
+          {
+            typename Vec2<T>::type in[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) in[k] = hp[hslot_pair(lidx, ndec, dsl, G, 6 + k, jlane)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { hcur[12 + 2 * k] = in[k].x; hcur[13 + 2 * k] = in[k].y; }
+            hcur[20] = in[4].x;
+            dinv = in[4].y;
+          }
+#endif
           // UDinv = (H S) Dinv  (calc_aba, hxx:60-63) from the slot just written to LDS
 #pragma unroll
           for (int k = 0; k < 6; ++k) {
