@@ -214,7 +214,6 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   const bool rev = d.flags & JF_REVOLUTE;
   const T mass = (d.flags & JF_MASSLESS) ? T(0) : T(1);
   const bool has_parent = !(d.flags & JF_PARENT_ROOT);
-  const int depth = isj_lane ? tp.depth : 0;
   constexpr int NCH_REG = 4;
   int chl[NCH_REG];
 #pragma unroll
