@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LOIKB_VERSION 100
+#define LOIKB_VERSION 300  /* round.minor: bumped whenever a struct or an entry point of this header changes */
 
 /* ---- status codes -------------------------------------------------------------------------------- */
 enum {
@@ -300,12 +300,22 @@ typedef struct loikb_stats {
   double hslots_ms;                       /* HIP-event time of the decade-slot precomputation (part of tail_ms)        */
   int lean_requeues;                      /* time slices that ended with the instance going to the back of the lean kernel's
                                              work queue (round-robin among the instances waiting for a slot)                */
+  int flat_launches;                      /* of lean_launches: those that ran the flat engine (k_fslots + k_flat: no loops over the
+                                             tree levels, loik_amd/csrc/loik_flat.hpp) instead of k_hslots + k_lean             */
 } loikb_stats;
 int loikb_get_stats(loikb_solver *s, loikb_stats *out);
 /* which kernels the solves of this handle use and why (the engine plan is made in one place, from (nb, nc, sharing mode of
  * A, children per joint, batch, options): at create and again at SolveInit) -- a human-readable line, valid until the next
  * call on this thread */
 const char *loikb_plan_string(loikb_solver *s);
+/* The flat engine's schedule of a kinematic tree (inspection / tests; loik_amd/csrc/loik_flat.hpp: the engine replaces the
+ * level-by-level recursions of LoikBackwardStepVisitor / LoikForwardStep2Visitor, loik-loid-optimized.hxx:31-81, :102-163, by
+ * sums over subtrees and root paths).  meta[5] = {applicable, lanes per instance G, ancestors per joint, scan steps, jump
+ * rounds}; out = G records of 37 ints: depth, subtree size, jmp[5] (lane of the ancestor at distance 1, 2, 4, 8, 16), anc[16]
+ * (lane of the ancestor at depth k + 1), red[8] (entries k * G + lane of the W tau products the lane sums), helper, part[5]
+ * (lanes whose partial sums the lane collects); -1 = none.  Returns 0, or the number of ints `out` needs when cap is smaller;
+ * not applicable (meta[0] == 0): loikb_last_error() says why. */
+int loikb_flat_schedule(const int *parents, int njoints, int *out, int cap, int *meta);
 
 /* introspection */
 int loikb_batch(const loikb_solver *s);

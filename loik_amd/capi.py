@@ -47,8 +47,10 @@ class Stats(C.Structure):
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("bytes_per_instance_iteration", C.c_double),
                 ("tail_instance_iterations", C.c_ulonglong), ("tail_launches", C.c_int), ("team", C.c_int), ("chunks", C.c_int),
                 ("solve_busy_ms", C.c_double), ("tail_busy_ms", C.c_double), ("lean_launches", C.c_int),
-                ("lean_escaped", C.c_int), ("hslots_ms", C.c_double), ("lean_requeues", C.c_int)]
+                ("lean_escaped", C.c_int), ("hslots_ms", C.c_double), ("lean_requeues", C.c_int), ("flat_launches", C.c_int)]
 
+
+ABI_VERSION = 300   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
 
 # enums of loik_amd.h
 F64, F32 = 0, 1
@@ -81,7 +83,7 @@ EXPORTED_SYMBOLS = [
     "loikb_device_count", "loikb_sweep_schedule", "loikb_integrate", "loikb_synchronize", "loikb_plan_string", "loikb_pass",
     "loikb_update_references", "loikb_update_eq_constraint", "loikb_add_eq_constraint", "loikb_remove_eq_constraint",
     "loikb_num_eq_c", "loikb_eq_c_capacity", "loikb_active_constraint_ids", "loikb_get_solver_info", "loikb_builtin_model", "loikb_builtin_joint_name",
-    "loikb_builtin_joint_id"]
+    "loikb_builtin_joint_id", "loikb_flat_schedule"]
 
 _lib = None
 
@@ -135,6 +137,10 @@ def lib():
     L.loikb_builtin_joint_name.argtypes = [C.c_char_p, C.c_int]
     L.loikb_builtin_joint_name.restype = C.c_char_p
     L.loikb_builtin_joint_id.argtypes = [C.c_char_p, C.c_char_p]
+    L.loikb_flat_schedule.argtypes = [_ip, C.c_int, _ip, C.c_int, _ip]
+    if L.loikb_version() != ABI_VERSION:
+        raise ImportError("loik_amd: %s has ABI version %d, this binding was written for %d -- rebuild the library"
+                          % (_LIB_PATH, L.loikb_version(), ABI_VERSION))
     _lib = L
     return L
 
@@ -159,6 +165,26 @@ def sweep_schedule(parents, team, direction):
     if T < 0:
         _check(T)
     return joint[:, :T].copy(), flags[:, :T].copy(), slot[:, :T].copy(), int(nslots.value)
+
+
+def flat_schedule(parents):
+    """The flat engine's schedule of a tree (host-only introspection, loikb_flat_schedule): None when the engine does not apply
+    (loikb_last_error says why), else a dict: G, nanc, nscan, njmp and per lane depth / size / jmp / anc / red / helper / part."""
+    parents = np.ascontiguousarray(parents, dtype=np.int32)
+    meta = np.zeros(5, dtype=np.int32)
+    L = lib()
+    need = L.loikb_flat_schedule(parents.ctypes.data_as(_ip), int(parents.size), None, 0, meta.ctypes.data_as(_ip))
+    if need < 0:
+        _check(need)
+    if not meta[0]:
+        return None
+    out = np.zeros(need, dtype=np.int32)
+    _check(L.loikb_flat_schedule(parents.ctypes.data_as(_ip), int(parents.size), out.ctypes.data_as(_ip), need, meta.ctypes.data_as(_ip)))
+    G = int(meta[1])
+    rec = out.reshape(G, -1)
+    return dict(G=G, nanc=int(meta[2]), nscan=int(meta[3]), njmp=int(meta[4]), depth=rec[:, 0].copy(), size=rec[:, 1].copy(),
+                jmp=rec[:, 2:7].copy(), anc=rec[:, 7:23].copy(), red=rec[:, 23:31].copy(), helper=rec[:, 31].copy(),
+                part=rec[:, 32:37].copy())
 
 
 def _check(rc):

@@ -1,0 +1,1057 @@
+// loik_flat.hpp -- the ADMM iteration WITHOUT loops over the tree levels ("flat" engine, round 3).
+//
+// k_tail / k_lean (loik_tail.hpp, loik_lean.hpp) keep one joint per lane and walk the two recursions of an iteration --
+// p, r leaf -> root (FwdPass1 + BwdPass, loik-loid-optimized.hxx:290-338, :31-81) and nu, v root -> leaf (FwdPass2,
+// hxx:102-163) -- as level-synchronous loops: maxdepth steps each, one LDS round trip and ~60 dependent fp64 instructions
+// per step, every lane recomputing at every level.  Half of an iteration was those two loops, and a 1000-iteration instance
+// was a serial chain of 10 us per iteration that decided when a launch ends (profiles/r02_e_k_lean_phase_timeline.txt).
+//
+// The recursions are the sparse LDL^T solve of  (J^T H J + mu I) nu = -(J^T p^base + w - mu z)  in tree order.  With every
+// spatial quantity expressed at the WORLD origin the joint-to-joint transports disappear and what is left are sums over
+// subtrees / root paths of the kinematic tree, which do not need one step per level:
+//
+//   tau_a = (w_a - mu z_a) + S^w_a . sum_{d in subtree(a)} p^base,w_d           subtree sum of 6-vectors   (log2 G steps)
+//   r'    = W tau ,   W = (I + L)^-1 ,  L_{a,d} = S^w_a . UDinv^w_d  (d below a)  scalars per (ancestor, joint) pair
+//   nu    = -W^T (Dinv r')
+//   v^w_i = sum_{a in root path of i} S^w_a nu_a                                path sum of 6-vectors      (log2 depth steps)
+//   f^w_i = sum_{d in subtree(i)} phi^w_d ,  phi_d = H^base_d v_d + p^base_d    force balance
+//   g_i   = A^T y_i - phi_i                                                      BwdPass2 (hxx:185-241) in closed form
+//
+// (r' is upstream's `r` after `+= S^T p`, Dinv its JointData::Dinv; W is the explicit inverse of the unit-triangular factor the
+// recursion applies by substitution -- W_{a,d} != 0 only for d in the subtree of a: <= depth-1 scalars per joint.)
+// W and Dinv depend on (q, mu) only; mu moves by decades (UpdateMu, hxx:613-641): k_fslots precomputes them for the decades
+// mu0 * 10^(kexp_lo ..) like k_hslots did for H_i -- 10 scalars per joint and decade instead of 22 -- and an instance keeps the
+// two most recent decades in LDS (the typical 1000-iteration instance flips between two).
+//
+// Subtree sums: the joints are numbered depth-first, so a subtree is a contiguous range of lanes [i, i + size_i): window sums
+// B_k[i] = x_i + ... + x_{i+2^k-1} are built by doubling and each lane assembles its range from the windows that tile it
+// (only members of the subtree are ever added: no cancellation).  Path sums: pointer jumping over the ancestors at distance
+// 1, 2, 4, 8.  The sum r'_a = tau_a + sum_d W_{a,d} tau_d runs over the descendants of a (torso: 20, most joints: 0..7): the
+// host deals the long rows out to lanes that have none (build_flat_schedule), <= FLAT_RED terms per lane.
+//
+// This first version serves H_ref = h I (the reference fixture's H_ref = I, tests/loik-loid.cpp:118-120): then
+// H^base_d v_d = (rho + h) v_d and ONE subtree sum per iteration (of the links' velocities, as forces, in the world frame)
+// yields both p^base,w of the next iteration and f^w of this one.  Other reference costs run in k_lean / k_tail.
+//
+// scripts/r03/flat_proto.py is the same arithmetic in numpy: identical iteration counts to the CPU oracle on 8192 headline
+// instances (incl. the 70 that run all 999 iterations), max |dz| 4e-11.
+#pragma once
+
+#include "loik_lean.hpp"
+
+namespace loikb {
+
+constexpr int FLAT_RED = 8;    // terms of the W tau products one lane sums
+constexpr int FLAT_PART = 5;   // partial sums a joint with a long row collects from helper lanes
+constexpr int FLAT_JMP = 5;    // pointer-jumping rounds (tree depth <= 32)
+constexpr int FLAT_MAXA = 16;  // strict ancestors per joint (tree depth <= 17)
+constexpr int FOLDW = 10;      // scalars per lane row of the norm fold (80 B: an odd number of 16-byte slots)
+constexpr int FLAT_COUNTERS_SLOT_HITS = 12;  // Bufs::counters[12]: decade changes served from the second LDS slot
+
+// per lane of a group: the lane's joint (lane j <-> device joint j + 1, depth-first numbering) in the static tree
+struct FlatLane {
+  int depth;               // 1 = child of the universe; 0 = no joint on this lane
+  int size;                // joints in the subtree (incl. this one)
+  int jmp[FLAT_JMP];       // lane of the ancestor at distance 2^r, -1 = beyond the root
+  int anc[FLAT_MAXA];      // lane of the ancestor at depth k + 1 (k < depth - 1), else -1
+  int red[FLAT_RED];       // terms this lane sums: entry k * G + lane' of the product buffer (W_{anc_k(lane'), lane'} tau_lane'), -1 = none
+  int helper;              // 1: the sum is a partial of another joint's row (published in the partial buffer)
+  int part[FLAT_PART];     // lanes whose partials belong to this joint's row, -1 = none
+};
+
+// constraint block of an instance in LDS (T each)
+enum : int { FC_LANE = 0, FC_B = 1, FC_Y = 7, FC_ATY = 13, FC_ATYW = 19, FC_ATBW = 25, FC_AW = 31, FCD = 67 };
+// per-instance scalars kept in LDS for the getters (written when an instance stops)
+enum : int { FI_BNORM = 0, FI_TGIN, FI_STY, FI_TOLP, FI_TOLD, FI_DYQP, FI_ATDY, FI_UBP, FI_LBM, FI_C1, FI_C2, FI_PRIMAL, FI_DUAL, FI_DX,
+             FI_DZ, FI_MULAST, FI_RED /* 16 folded values */, FISC = FI_RED + 16 };
+
+template <typename T>
+__host__ __device__ __forceinline__ int flat_xregion(int nanc)
+{
+  int n = XROWS * 6;                                   // scan / path-sum rows (+ the zero row)
+  if (nanc * WAVE + 2 > n) n = nanc * WAVE + 2;        // W tau products (+ a zero slot)
+  if (WAVE * FOLDW > n) n = WAVE * FOLDW;              // norm fold rows
+  if ((WAVE + 1) * 12 > n) n = (WAVE + 1) * 12;        // placement rows of the oMi chain (when an instance is loaded)
+  return (n + 1) & ~1;
+}
+
+template <typename T>
+__host__ __device__ __forceinline__ size_t flat_lds_bytes(int nc, int G, bool a_shared, int nanc, bool has_hv)
+{
+  const size_t per_inst = (size_t)nc * (FCD + (a_shared ? 0 : LCA)) + FISC;
+  size_t n = (size_t)flat_xregion<T>(nanc) + 2 * (size_t)nanc * WAVE + 2 * (WAVE + 2) + (has_hv ? (size_t)WAVE * 6 : 0) + (a_shared ? (size_t)nc * LCA : 0) + (size_t)(WAVE / G) * per_inst;
+  n = n * sizeof(T) + (size_t)nanc * WAVE /* ancestor rows, bytes */;
+  return (n + 15) & ~(size_t)15;
+}
+
+// decade slot of an instance: rows [k][lane], k < nanc: W_{anc_k(lane), lane}; row nanc: Dinv
+__device__ __forceinline__ size_t fslot_at(int idx, int ndec, int dsl, int G, int frows, int k, int jlane)
+{
+  return ((((size_t)idx * ndec + dsl) * frows + k) * G) + jlane;
+}
+
+// (R, t) <- (Ra, ta) o (R, t): SE3 composition, the left factor being the transform of an ancestor frame
+template <typename T>
+__device__ __forceinline__ void se3_compose_left(const T* Ra, const T* ta, T* R, T* t)
+{
+  T Rn[9], tn[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) Rn[3 * i + j] = Ra[3 * i] * R[j] + Ra[3 * i + 1] * R[3 + j] + Ra[3 * i + 2] * R[6 + j];
+    tn[i] = ta[i] + Ra[3 * i] * t[0] + Ra[3 * i + 1] * t[1] + Ra[3 * i + 2] * t[2];
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[k] = Rn[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) t[k] = tn[k];
+}
+
+// oMi of every lane's joint by pointer jumping over liMi (4 rounds for depth <= 16): after round r, (R, t) is the placement of
+// the joint in the frame of its ancestor at distance 2^(r+1) (or in the world when the root path is shorter).  xb: scratch rows
+// of 12 scalars; row WAVE = the identity.
+template <typename T>
+__device__ __forceinline__ void flat_world_placement(T* xb, int lane, int jlane, const int* jrow, int njmp, T* R, T* t)
+{
+  // (jlane, not lane: one lane group of a wavefront may run this alone, inside a divergent branch)
+  tail_sync();
+  if (jlane < 12) xb[WAVE * 12 + jlane] = (jlane == 0 || jlane == 4 || jlane == 8) ? T(1) : T(0);
+#pragma unroll
+  for (int r = 0; r < FLAT_JMP; ++r) {
+    if (r < njmp) {
+      tail_sync();
+#pragma unroll
+      for (int k = 0; k < 9; ++k) xb[lane * 12 + k] = R[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) xb[lane * 12 + 9 + k] = t[k];
+      tail_sync();
+      T Ra[9], ta[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Ra[k] = xb[jrow[r] * 12 + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ta[k] = xb[jrow[r] * 12 + 9 + k];
+      se3_compose_left(Ra, ta, R, t);
+    }
+  }
+  tail_sync();
+}
+
+// S_i = sum over the subtree of lane i (lanes [i, i + size)) of the 6-vectors x: window sums by doubling, each lane adds the
+// windows that tile its range (low bits of `size` first).  rows: [WAVE + 1][6], row WAVE = 0.  `lim` = first lane behind the group.
+template <typename T>
+__device__ __forceinline__ void flat_subtree_sum(T* rows, int lane, int jlane, int lim, int size, int nscan, const T* x, T* S)
+{
+  // (the region is shared with other phases: the zero row is re-established; by jlane -- a lane group may run this alone)
+  tail_sync();
+  if (jlane < 6) rows[WAVE * 6 + jlane] = T(0);
+  T B[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { B[k] = x[k]; S[k] = T(0); }
+  int pos = lane;
+  for (int k = 0; k < nscan; ++k) {
+    tail_sync();
+#pragma unroll
+    for (int c = 0; c < 6; ++c) rows[lane * 6 + c] = B[c];
+    tail_sync();
+    const bool take = (size >> k) & 1;
+    const int ra = take ? pos : WAVE;
+    const int nx = lane + (1 << k);
+    const int rb = nx < lim ? nx : WAVE;
+    T a[6], b[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a[c] = rows[ra * 6 + c];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) b[c] = rows[rb * 6 + c];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) { S[c] += a[c]; B[c] += b[c]; }
+    pos += take ? (1 << k) : 0;
+  }
+}
+
+// y_i = sum over the root path of lane i (the joint and its ancestors) of the 6-vectors x: pointer jumping
+template <typename T>
+__device__ __forceinline__ void flat_path_sum(T* rows, int lane, int jlane, const int* jrow, int njmp, T* y)
+{
+  tail_sync();
+  if (jlane < 6) rows[WAVE * 6 + jlane] = T(0);
+#pragma unroll
+  for (int r = 0; r < FLAT_JMP; ++r) {
+    if (r < njmp) {
+      tail_sync();
+#pragma unroll
+      for (int c = 0; c < 6; ++c) rows[lane * 6 + c] = y[c];
+      tail_sync();
+      T a[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) a[c] = rows[jrow[r] * 6 + c];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) y[c] += a[c];
+    }
+  }
+}
+
+// force-like 6-vector of a link frame -> world origin: (R0 f_l, R0 f_a + t0 x R0 f_l)   [SE3::act(Force)]
+// motion world -> link: actinv_motion(R0, t0, ...); force world -> link: (R0^T F_l, R0^T (F_a - t0 x F_l))
+template <typename T>
+__device__ __forceinline__ void actinv_force(const T* R, const T* t, const T* F, T* o)
+{
+  T c[3], d[3];
+  cross3(t, F, c);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d[k] = F[3 + k] - c[k];
+  mat3t_vec(R, F, o);
+  mat3t_vec(R, d, o + 3);
+}
+
+// fold FOLDW-2 = 8 columns of the group's rows: columns < nmax by max, the others by sum (lane order); every lane returns
+// with all eight results.  rows: [WAVE][FOLDW]; column 8 / 9 of a row are scratch.
+template <typename T>
+__device__ __forceinline__ void flat_fold8(T* rows, int lane, int gbase, int jlane, int G, int nmax, const T* in, T* out)
+{
+  tail_sync();
+  T* row = rows + lane * FOLDW;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) row[q] = in[q];
+  tail_sync();
+  const int q = jlane & 7, part = jlane >> 3;
+  {
+    const T* col = rows + (gbase + part * 8) * FOLDW + q;
+    T a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = col[u * FOLDW];
+    T red;
+    if (q < nmax) red = tmax(tmax(tmax(a[0], a[1]), tmax(a[2], a[3])), tmax(tmax(a[4], a[5]), tmax(a[6], a[7])));
+    else { red = a[0];
+#pragma unroll
+      for (int u = 1; u < 8; ++u) red += a[u]; }
+    row[8] = red;
+  }
+  tail_sync();
+  {
+    T red = rows[(gbase + q) * FOLDW + 8];
+    for (int p = 1; p < (G >> 3); ++p) {
+      const T a = rows[(gbase + p * 8 + q) * FOLDW + 8];
+      red = q < nmax ? tmax(red, a) : red + a;
+    }
+    row[9] = red;
+  }
+  tail_sync();
+#pragma unroll
+  for (int u = 0; u < 8; ++u) out[u] = rows[(gbase + u) * FOLDW + 9];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc, int nscan,
+       int njmp, const int* __restrict__ ring, int nslots, int G, const T* __restrict__ fslots, int kexp_lo, int ndec, T href_s,
+       int has_hv)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Layout& L = P.L;
+  const bool a_shared = P.mode & MODE_A_SHARED;
+  const int cs = FCD + (a_shared ? 0 : LCA);
+  const int lane = threadIdx.x;
+  const int sub = lane / G, jlane = lane % G, gbase = sub * G, glim = gbase + G;
+  // ---- LDS of the wavefront (one wavefront per workgroup)
+  T* xb = reinterpret_cast<T*>(smem_raw);                 // scan rows | W tau products | fold rows (used one after the other)
+  T* wl = xb + flat_xregion<T>(nanc);                     // [2][nanc][WAVE]  W rows of two decades of mu
+  T* nbuf = wl + 2 * (size_t)nanc * WAVE;                 // [WAVE + 2]       Dinv r' of every joint (+ a zero)
+  T* pbuf = nbuf + WAVE + 2;                              // [WAVE + 2]       partial sums of long rows
+  T* shv = pbuf + WAVE + 2;                               // [WAVE][6]        subtree sums of the links' H_ref v_ref (if != 0)
+  T* ash = shv + (has_hv ? WAVE * 6 : 0);                 // [nc][36]         the shared A
+  T* cd = ash + (a_shared ? L.nc * LCA : 0);              // [64/G][nc][cs]
+  T* iscb = cd + (size_t)(WAVE / G) * L.nc * cs;          // [64/G][FISC]
+  unsigned char* ancb = reinterpret_cast<unsigned char*>(iscb + (size_t)(WAVE / G) * FISC);  // [nanc][WAVE] rows of the ancestors
+  T* cdi = cd + (size_t)sub * L.nc * cs;
+  T* isc = iscb + (size_t)sub * FISC;
+
+  const bool isj_lane = jlane < L.nb;
+  const int jl = isj_lane ? jlane : 0;
+  // (the joint's placement is only needed when an instance is loaded: load_instance reads the description again instead of
+  //  keeping 15 scalars of it alive through the iteration loop)
+  const int jflags = jd[jl + 1].flags, jcslot = isj_lane ? jd[jl + 1].cslot : -1;
+  const bool rev = jflags & JF_REVOLUTE;
+  const T mass = (!isj_lane || (jflags & JF_MASSLESS)) ? T(0) : T(1);
+  T ax[3];  // S_i = [axis; 0] (prismatic) or [0; axis] (revolute); 0 on a lane without a joint
+#pragma unroll
+  for (int k = 0; k < 3; ++k) ax[k] = isj_lane ? (T)jd[jl + 1].axis[k] : T(0);
+  int size, jrow[FLAT_JMP], ra[FLAT_RED], prow[FLAT_PART];
+  bool helper;
+  {
+    // static addresses (rows of this group's lanes); helper lanes may be lanes without a joint
+    const FlatLane F = fl[jlane];
+    size = isj_lane ? F.size : 0;
+#pragma unroll
+    for (int r = 0; r < FLAT_JMP; ++r) jrow[r] = F.jmp[r] >= 0 ? gbase + F.jmp[r] : WAVE;
+#pragma unroll
+    for (int t = 0; t < FLAT_RED; ++t) ra[t] = F.red[t] >= 0 ? (F.red[t] / G) * WAVE + gbase + F.red[t] % G : nanc * WAVE;
+#pragma unroll
+    for (int j = 0; j < FLAT_PART; ++j) prow[j] = F.part[j] >= 0 ? gbase + F.part[j] : WAVE;
+    helper = F.helper != 0;
+    for (int k = 0; k < nanc; ++k) ancb[k * WAVE + lane] = (unsigned char)((k < FLAT_MAXA && F.anc[k] >= 0) ? gbase + F.anc[k] : WAVE);
+  }
+  if (lane < 2) { nbuf[WAVE + lane] = T(0); pbuf[WAVE + lane] = T(0); }
+  if (a_shared)
+    for (int e = lane; e < L.nc * LCA; e += WAVE) ash[e] = Bf.uni[e];
+
+  // ---- the instance of this lane group
+  bool has_inst = false, isj = false, done = true, any_iter = false;
+  int lidx = 0;
+  char *ip = Bf.tiles, *rec = Bf.tiles;
+  T R0[9], t0[3], Sw[6], v[6], f[6], g[6], SE[6];
+  T w = T(0), z = T(0), nu = T(0), s = T(0), rp = T(0), dinv = T(0), dinv_o = T(0), lbi = T(0), ubi = T(0), mu = T(1);
+  int kexp = 0, kslot = -(1 << 30), kslot_o = -(1 << 30), wsel = 0;
+  int iter = 0, status = ST_DONE, tail_it = 0, nflip = 0;
+  unsigned int my_iters = 0, n_wave_iters = 0, n_slot_loads = 0, n_slot_hits = 0;
+  unsigned int* q_head = Bf.counters + LEAN_Q_HEAD;
+
+  auto fetch = [&]() -> int {
+    int nx = 0;
+    if (jlane == 0) nx = (int)atomicAdd(q_head, 1u);
+    nx = __shfl(nx, gbase);
+    return nx < nslots ? ring[nx] : -1;
+  };
+  // constraint c: is its joint in this lane's subtree?  (1 / 0)
+  auto cmask = [&](int c) -> T {
+    const int cl = (int)cdi[c * cs + FC_LANE];
+    return (isj_lane && cl >= jlane && cl < jlane + size) ? T(1) : T(0);
+  };
+  // links' velocities as forces at the world origin: E = mass * (R0 v_l, R0 v_a + t0 x R0 v_l), from the world-frame motion
+  // (vw_l = R0 v_l + t0 x R0 v_a, vw_a = R0 v_a):  R0 v_l = vw_l - t0 x vw_a
+  auto force_of_motion = [&](const T* vw, T* E) {
+    T c1[3], c2[3];
+    cross3(t0, vw + 3, c1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) E[k] = vw[k] - c1[k];
+    cross3(t0, E, c2);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) E[3 + k] = vw[3 + k] + c2[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) E[k] *= mass;
+  };
+  auto load_instance = [&](int slot_in) {
+    has_inst = slot_in >= 0;
+    isj = has_inst && isj_lane;
+    const int slot = has_inst ? slot_in : 0;
+    lidx = slot;
+    ip = lane_ptr<T>(Bf.tiles, L, slot);
+    rec = ip + (size_t)jl * JREC * pair_bytes<T>();
+    const char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+    {
+      const typename Vec2<T>::type csn = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
+      const JointDesc d = jd[jl + 1];
+      joint_xform<T>(d, rec, csn.x, csn.y, R0, t0);  // liMi ...
+      ld6<T>(rec, JP_V, v);
+      ld6<T>(rec, JP_F, f);
+      ld6<T>(rec, JP_G, g);
+      w = wz.x; z = wz.y; nu = nus.x; s = nus.y;
+      if (P.mode & MODE_BND_SHARED) {
+        lbi = Bf.uni[L.nc * 57 + jl];
+        ubi = Bf.uni[L.nc * 57 + L.nb + jl];
+      } else {
+        const typename Vec2<T>::type lu = ldp<T>(rec, JP_LBUB);
+        lbi = lu.x; ubi = lu.y;
+      }
+    }
+    if (!isj_lane) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R0[k] = (k % 4 == 0) ? T(1) : T(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t0[k] = T(0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { v[k] = T(0); f[k] = T(0); g[k] = T(0); }
+      w = z = nu = s = T(0);
+    }
+    flat_world_placement<T>(xb, lane, jlane, jrow, njmp, R0, t0);  // ... -> oMi (FwdPassInit's oMi chain, hxx:265)
+    {
+      // S^w: the joint's motion subspace at the world origin (R0 S_l + t0 x R0 S_a, R0 S_a)
+      T ra3[3], c[3];
+      mat3_vec(R0, ax, ra3);
+      cross3(t0, ra3, c);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { Sw[k] = rev ? c[k] : ra3[k]; Sw[3 + k] = rev ? ra3[k] : T(0); }
+    }
+    // constraint blocks: lane of the joint, b, y, A^T y (+ A); then AW = X*_{0<-joint} A^T, AW b
+    for (int c = 0; c < L.nc; ++c) {
+      const char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+      T* c_ = cdi + c * cs;
+      if (jlane < 18) {
+        const int which = jlane / 6, k = jlane % 6;
+        const int pair = which == 0 ? CP_B : which == 1 ? CP_Y : CP_ATY;
+        const int dst = which == 0 ? FC_B : which == 1 ? FC_Y : FC_ATY;
+        const T val = *reinterpret_cast<const T*>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+        c_[dst + k] = val;
+      }
+      if (!a_shared)
+        for (int e = jlane; e < LCA; e += G)
+          c_[FCD + e] = *reinterpret_cast<const T*>(crec + (size_t)(CP_A + e / 2) * pair_bytes<T>() + (e & 1) * sizeof(T));
+    }
+    if (jcslot >= 0) cdi[jcslot * cs + FC_LANE] = (T)jlane;
+    tail_sync();
+    for (int c = 0; c < L.nc; ++c) {
+      T* c_ = cdi + c * cs;
+      const T* A_ = a_shared ? ash + c * LCA : c_ + FCD;
+      if (jcslot == c) {  // the constrained joint's lane: column j of AW = row j of A carried to the world origin
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          T aj[6], o[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) aj[k] = A_[6 * j + k];
+          act_force(R0, t0, aj, o);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) c_[FC_AW + 6 * k + j] = o[k];
+        }
+      }
+    }
+    tail_sync();
+    for (int c = 0; c < L.nc; ++c) {
+      T* c_ = cdi + c * cs;
+      if (jlane < 6) {
+        const int k = jlane;
+        T ab = T(0), ay = T(0);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { ab += c_[FC_AW + 6 * k + j] * c_[FC_B + j]; ay += c_[FC_AW + 6 * k + j] * c_[FC_Y + j]; }
+        c_[FC_ATBW + k] = ab;
+        c_[FC_ATYW + k] = ay;
+      }
+    }
+    // subtree sums of the state the instance arrives with (cold start: v = 0) and of the reference term
+    {
+      T vw[6], E[6];
+      // world-frame motion of the link from its local velocity
+      T a[3], l[3], c[3];
+      mat3_vec(R0, v, l);
+      mat3_vec(R0, v + 3, a);
+      cross3(t0, a, c);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { vw[k] = l[k] + c[k]; vw[3 + k] = a[k]; }
+      force_of_motion(vw, E);
+      flat_subtree_sum<T>(xb, lane, jlane, glim, size, nscan, E, SE);
+      if (has_hv) {
+        T hv[6], hw[6], Sh[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) hv[k] = mass * P.Hv[k];
+        act_force(R0, t0, hv, hw);
+        flat_subtree_sum<T>(xb, lane, jlane, glim, size, nscan, hw, Sh);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) shv[lane * 6 + k] = Sh[k];
+      }
+    }
+    const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
+    mu = mu2.x;
+    kexp = (int)mu2.y;
+    kslot = -(1 << 30); kslot_o = -(1 << 30);
+    status = has_inst ? (int)st2.x : ST_DONE;
+    iter = (int)bi2.y;
+    tail_it = (int)ld_scal<T>(srec, SC_TAIL_ITER);
+    nflip = (int)ldp<T>(srec, SP_FLIP).x;
+    done = (status & ST_DONE) != 0;
+    if (!done && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { done = true; status |= ST_DONE; }
+    if (jlane == 0) {
+      isc[FI_BNORM] = bi2.x; isc[FI_TGIN] = ldp<T>(srec, SP_TAG).x; isc[FI_STY] = st2.y; isc[FI_MULAST] = T(-1);
+      isc[FI_TOLP] = ld_scal<T>(srec, SC_TOL_PRIMAL); isc[FI_TOLD] = ld_scal<T>(srec, SC_TOL_DUAL);
+      isc[FI_DYQP] = ld_scal<T>(srec, SC_DELTA_Y_QP); isc[FI_ATDY] = ld_scal<T>(srec, SC_AT_DELTA_Y_QP);
+      isc[FI_UBP] = ld_scal<T>(srec, SC_UB_DY_PLUS); isc[FI_LBM] = ld_scal<T>(srec, SC_LB_DY_MINUS);
+      isc[FI_C1] = ld_scal<T>(srec, SC_COND1); isc[FI_C2] = ld_scal<T>(srec, SC_COND2);
+    }
+    tail_sync();
+    my_iters = 0;
+    any_iter = false;
+  };
+  auto store_instance = [&]() {
+    char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+    if (isj) {
+      st6<T>(rec, JP_V, v);
+      st6<T>(rec, JP_F, f);
+      st6<T>(rec, JP_G, g);
+      stp<T>(rec, JP_WZ, w, z);
+      stp<T>(rec, JP_NUS, nu, s);
+      if (any_iter) {
+        // inter-sweep temporaries of the last iteration: r_i and Dinv_i.  This engine forms neither UDinv_i nor the
+        // accumulated p_i: the scalar record's tag says so (SP_TAG = -2) and the getters rebuild them (k_rebuild_ud).
+        stp<T>(rec, JP_R, rp, dinv);
+      }
+    }
+    tail_sync();
+    if (has_inst) {
+      for (int c = 0; c < L.nc; ++c) {
+        char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+        if (jlane < 6) {
+          const int k = jlane;
+          *reinterpret_cast<T*>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * cs + FC_Y + k];
+          *reinterpret_cast<T*>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * cs + FC_ATY + k];
+        }
+      }
+      if (jlane == 0) {
+        stp<T>(srec, SP_MU, mu, (T)kexp);
+        stp<T>(srec, SP_TAG, any_iter ? T(-2) : isc[FI_TGIN], T(0));
+        stp<T>(srec, SP_BI, isc[FI_BNORM], (T)iter);
+        stp<T>(srec, SP_FLIP, (T)nflip, T(0));
+        stp<T>(srec, SP_ST, (T)(any_iter ? (status & ~ST_PFULL) : status), any_iter ? isc[FI_MULAST] : isc[FI_STY]);
+        if (any_iter) {
+          const T* rr = isc + FI_RED;  // prt prs stf dvis dnu dfis dyis dw av nu hrefv g (12), filled when the instance stopped
+          const T mu_s = mu;
+          stp<T>(srec, SP_SCAL + 0, isc[FI_PRIMAL], isc[FI_DUAL]);
+          stp<T>(srec, SP_SCAL + 1, rr[0], rr[1]);
+          stp<T>(srec, SP_SCAL + 2, P.rho * rr[3], rr[2]);
+          stp<T>(srec, SP_SCAL + 3, isc[FI_TOLP], isc[FI_TOLD]);
+          stp<T>(srec, SP_SCAL + 4, mu_s, P.mu_scale * mu_s);
+          stp<T>(srec, SP_SCAL + 5, mu_s, isc[FI_DX]);
+          stp<T>(srec, SP_SCAL + 6, isc[FI_DZ], isc[FI_DYQP]);
+          stp<T>(srec, SP_SCAL + 7, isc[FI_ATDY], isc[FI_UBP]);
+          stp<T>(srec, SP_SCAL + 8, isc[FI_LBM], rr[5]);
+          stp<T>(srec, SP_SCAL + 9, rr[6], rr[7]);
+          stp<T>(srec, SP_SCAL + 10, rr[3], rr[4]);
+          stp<T>(srec, SP_SCAL + 11, rr[8], rr[9]);
+          stp<T>(srec, SP_SCAL + 12, rr[10], rr[11]);
+          stp<T>(srec, SP_SCAL + 13, rr[2], isc[FI_C1]);
+          stp<T>(srec, SP_SCAL + 14, isc[FI_C2], (T)tail_it);
+        }
+        if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
+      }
+    }
+    tail_sync();
+  };
+
+  load_instance(fetch());
+#ifdef LOIKB_TAIL_PROF
+  unsigned long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
+  const unsigned long long wall0_ = wall_clock64(), clk0_ = tprev_;
+#endif
+  while (__any(!done || has_inst)) {
+    // ---- decade of mu: W rows and Dinv.  Two decades stay in LDS: a flip back to the previous one costs nothing.
+    if (!done && (int)my_iters >= P.max_launch_iters) done = true;
+    if (!done && kexp != kslot) {
+      if (kexp == kslot_o) {
+        { const int tk = kslot; kslot = kslot_o; kslot_o = tk; }
+        { const T td = dinv; dinv = dinv_o; dinv_o = td; }
+        wsel ^= 1;
+        ++n_slot_hits;
+      } else {
+        const int dsl = kexp - kexp_lo;
+        if (dsl < 0 || dsl >= ndec) {
+          done = true;  // mu left the precomputed decades: written back unfinished, k_tail takes over
+          if (jlane == 0) atomicAdd(&Bf.counters[2], 1u);
+        } else {
+          // the slot that was not used last is overwritten
+          kslot_o = kslot; dinv_o = dinv;
+          wsel ^= 1;
+          T* wdst = wl + (size_t)wsel * nanc * WAVE;
+          if (isj) {
+            for (int k = 0; k < nanc; ++k) wdst[k * WAVE + lane] = fslots[fslot_at(lidx, ndec, dsl, G, nanc + 1, k, jlane)];
+            dinv = fslots[fslot_at(lidx, ndec, dsl, G, nanc + 1, nanc, jlane)];
+          } else {
+            for (int k = 0; k < nanc; ++k) wdst[k * WAVE + lane] = T(0);
+            dinv = T(0);
+          }
+          kslot = kexp;
+          n_slot_loads = (n_slot_loads + 0x10000u) | (1u << dsl);
+        }
+      }
+    }
+    // (a group's W slot selection is per group: wsel differs between the two groups of a wavefront)
+    const T* wcur = wl + (size_t)wsel * nanc * WAVE;
+    TAIL_TP(8)
+    const bool act = !done;
+    const T mu_eq = P.mu_scale * mu, mu_in = mu;
+    if (act) { ++my_iters; any_iter = true; }
+    ++n_wave_iters;
+
+    // ================= p^base at the world origin, summed over the subtrees; tau  (FwdPass1 + the p part of BwdPass) ===========
+    T tau;
+    {
+      T PB[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) PB[k] = -P.rho * SE[k];
+      if (has_hv) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) PB[k] -= shv[lane * 6 + k];
+      }
+      for (int c = 0; c < L.nc; ++c) {
+        const T* c_ = cdi + c * cs;
+        const T m = cmask(c);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) PB[k] += m * (c_[FC_ATYW + k] - mu_eq * c_[FC_ATBW + k]);
+      }
+      tau = (w - mu_in * z) + dot6_halves(Sw, PB);
+    }
+    TAIL_TP(0)
+    // ================= r' = W tau: products to LDS, every lane sums its share, long rows collect their partials ================
+    tail_sync();
+    for (int k = 0; k < nanc; ++k) xb[k * WAVE + lane] = wcur[k * WAVE + lane] * tau;
+    if (jlane == 0) { xb[nanc * WAVE] = T(0); xb[nanc * WAVE + 1] = T(0); }
+    tail_sync();
+    {
+      T a[FLAT_RED];
+#pragma unroll
+      for (int t = 0; t < FLAT_RED; ++t) a[t] = xb[ra[t]];
+      T acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      pbuf[lane] = helper ? acc : T(0);
+      tail_sync();
+      T pp[FLAT_PART];
+#pragma unroll
+      for (int j = 0; j < FLAT_PART; ++j) pp[j] = pbuf[prow[j]];
+      if (helper) acc = T(0);
+#pragma unroll
+      for (int j = 0; j < FLAT_PART; ++j) acc += pp[j];
+      const T rn = tau + acc;
+      if (act) rp = rn;
+      nbuf[lane] = dinv * rn;
+    }
+    tail_sync();
+    TAIL_TP(1)
+    // ================= nu = -W^T (Dinv r')  (FwdPass2's nu_i, hxx:127) ======================================================
+    T nui;
+    {
+      T acc = nbuf[lane];
+      for (int k = 0; k < nanc; ++k) acc += wcur[k * WAVE + lane] * nbuf[ancb[k * WAVE + lane]];
+      nui = -acc;
+    }
+    // ================= v = J nu: path sum of S^w nu at the world origin, then into the link frame (hxx:125-134) ===============
+    T vw[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) vw[k] = Sw[k] * nui;
+    flat_path_sum<T>(xb, lane, jlane, jrow, njmp, vw);
+    T vi[6], E[6];
+    actinv_motion(R0, t0, vw, vi);
+    force_of_motion(vw, E);
+    TAIL_TP(2)
+    // ================= DualUpdate of the task constraints (hxx:410-451), six lanes of the group ================================
+    T l_dyis = T(0), l_av = T(0), l_prt = T(0), l_up = T(0), l_lm = T(0);
+    tail_sync();
+    if (jcslot >= 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) xb[lane * 6 + k] = vi[k];
+    }
+    tail_sync();
+    for (int c = 0; c < L.nc; ++c) {
+      T* c_ = cdi + c * cs;
+      const T* A_ = a_shared ? ash + c * LCA : c_ + FCD;
+      if (act && jlane < 6) {
+        const int k = jlane;
+        const T* vc = xb + (gbase + (int)c_[FC_LANE]) * 6;
+        T avk = A_[6 * k] * vc[0];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) avk += A_[6 * k + j] * vc[j];
+        const T bk = c_[FC_B + k];
+        const T ek = avk - bk;
+        const T dy = mu_eq * ek;
+        const T yk = c_[FC_Y + k] + dy;
+        l_dyis = tmax(l_dyis, tabs(dy));
+        l_up += bk * tmax(dy, T(0));
+        l_lm += bk * tmin(dy, T(0));
+        l_prt = tmax(l_prt, tabs(ek));
+        l_av = tmax(l_av, tabs(avk));
+        c_[FC_Y + k] = yk;
+      }
+    }
+    tail_sync();
+    for (int c = 0; c < L.nc; ++c) {
+      T* c_ = cdi + c * cs;
+      const T* A_ = a_shared ? ash + c * LCA : c_ + FCD;
+      if (act && jlane < 6) {
+        const int k = jlane;
+        T at = A_[k] * c_[FC_Y], aw = c_[FC_AW + 6 * k] * c_[FC_Y];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) { at += A_[6 * j + k] * c_[FC_Y + j]; aw += c_[FC_AW + 6 * k + j] * c_[FC_Y + j]; }
+        c_[FC_ATY + k] = at;
+        c_[FC_ATYW + k] = aw;
+      }
+    }
+    TAIL_TP(4)
+    // ================= f by force balance at the world origin: one subtree sum (BwdPass2's transport, hxx:210-212) =============
+    T fi[6];
+    {
+      T SEn[6], Fw[6];
+      flat_subtree_sum<T>(xb, lane, jlane, glim, size, nscan, E, SEn);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Fw[k] = (P.rho + href_s) * SEn[k] - P.rho * SE[k];
+      if (has_hv) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Fw[k] -= shv[lane * 6 + k];
+      }
+      for (int c = 0; c < L.nc; ++c) {
+        const T* c_ = cdi + c * cs;
+        const T m = cmask(c);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Fw[k] += m * c_[FC_ATYW + k];
+      }
+      actinv_force(R0, t0, Fw, fi);
+      if (act) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) SE[k] = SEn[k];
+      }
+    }
+    TAIL_TP(5)
+    // ================= per-joint work: BoxProj, the w update, the norms (hxx:129-158, :384-397, :454-458) ======================
+    T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_prs = T(0);
+    T l_dg = T(0), l_g = T(0), l_stf = T(0), l_dstf = T(0);
+    if (act && isj) {
+      T df[6], dv6[6], gi[6], dg[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        df[k] = fi[k] - f[k];
+        dv6[k] = vi[k] - v[k];
+        // g_i = A^T y_i + sum_children act(f_c) - f_i = A^T y_i - (H^base_i v_i + p^base_i)  (force balance)
+        gi[k] = -mass * (P.rho * dv6[k] + href_s * vi[k] - P.Hv[k]);
+        dg[k] = gi[k] - g[k];
+      }
+      l_nu = tabs(nui);
+      l_dfis = mass * inf6(df);
+      l_hrefv = mass * tabs(href_s) * inf6(vi);
+      l_dvis = mass * inf6(dv6);
+      l_dnu = tabs(nui - nu);
+      const T x = nui + (T(1) / mu_in) * w;
+      const T zi = tmin(ubi, tmax(lbi, x));
+      l_dz = tabs(zi - z);
+      l_prs = tabs(nui - zi);
+      const T dwi = mu_in * (nui - zi);
+      l_dw = tabs(dwi);
+      l_up += ubi * tmax(dwi, T(0));
+      l_lm += lbi * tmin(dwi, T(0));
+      w = w + dwi; z = zi; nu = nui;
+      l_dg = inf6(dg);
+      l_g = inf6(gi);
+      const T si = (rev ? (ax[0] * fi[3] + ax[1] * fi[4] + ax[2] * fi[5]) : (ax[0] * fi[0] + ax[1] * fi[1] + ax[2] * fi[2])) + w;
+      l_stf = tabs(si);
+      l_dstf = tabs(si - s);
+      s = si;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { v[k] = vi[k]; f[k] = fi[k]; g[k] = gi[k]; }
+    }
+    TAIL_TP(3)
+    // ================= the scalars of the stopping logic, folded over the group ================================================
+    T red[8];
+    {
+      // (the dual residual's v block is H_ref v - Hv + g = -rho dv for a body: rho * |dv|)
+      T in[8] = {tmax(l_prt, l_prs), tmax(P.rho * l_dvis, l_stf), tmax(l_dvis, l_dnu), l_dz,
+                 tmax(l_dfis, tmax(l_dyis, l_dw)), tmax(l_dg, l_dstf), l_up, l_lm};
+      flat_fold8<T>(xb, lane, gbase, jlane, G, 6, in, red);
+    }
+    T ntol_p = T(0), ntol_d = T(0);
+    if (P.tol_rel != T(0)) {  // (uniform) relative tolerances need two more maxima
+      T in2[8] = {tmax(l_av, l_nu), tmax(tmax(l_hrefv, l_g), l_stf), T(0), T(0), T(0), T(0), T(0), T(0)}, r2[8];
+      flat_fold8<T>(xb, lane, gbase, jlane, G, 8, in2, r2);
+      ntol_p = r2[0]; ntol_d = r2[1];
+    }
+    TAIL_TP(6)
+    bool finishing = false;
+    const T mu_used = mu;
+    if (act) {
+      const T primal = red[0], dual = red[1], dx = red[2], dz = red[3];
+      ++iter;
+      bool tol_computed = false, feas_checked = false;
+      T tol_p = T(0), tol_d = T(0), dyqp = T(0), atdy = T(0), ubp = T(0), lbm = T(0);
+      int c1 = 0, c2 = 0;
+      if (P.mode & MODE_FIXED_ITERS) {
+        if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
+      } else if (!(status & ST_TAIL)) {
+        tol_computed = true;
+        tol_p = P.tol_abs + P.tol_rel * tmax(ntol_p, isc[FI_BNORM]);
+        tol_d = P.tol_abs + P.tol_rel * tmax(ntol_d, P.Hv_inf_norm);
+        const bool conv = (primal < tol_p) && (dual < tol_d);
+        bool infeas = false;
+        if (iter > 1) {
+          feas_checked = true;
+          dyqp = red[4]; atdy = red[5]; ubp = red[6]; lbm = red[7];
+          c1 = atdy <= P.tol_primal_inf * dyqp;
+          c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp;
+          infeas = c1 && c2;
+        }
+        if (conv) {
+          status |= ST_CONVERGED | ST_DONE;
+          if (infeas) status |= ST_PRIMAL_INF;
+          done = true;
+        } else if (infeas) {
+          status |= ST_PRIMAL_INF | ST_TAIL;
+          tail_it = 0;
+          if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
+        } else {
+          if (primal > T(10) * dual) { mu *= T(10); ++kexp; ++nflip; }
+          else if (dual > T(10) * primal) { mu *= T(0.1); --kexp; ++nflip; }
+          if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
+        }
+      } else {
+        tail_it += 1;
+        if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
+      }
+      finishing = done;
+      if (jlane == 0) {
+        isc[FI_PRIMAL] = primal; isc[FI_DUAL] = dual; isc[FI_DX] = dx; isc[FI_DZ] = dz; isc[FI_MULAST] = mu_used;
+        if (tol_computed) { isc[FI_TOLP] = tol_p; isc[FI_TOLD] = tol_d; }
+        if (feas_checked) {
+          isc[FI_C1] = (T)c1; isc[FI_C2] = (T)c2; isc[FI_DYQP] = dyqp; isc[FI_ATDY] = atdy; isc[FI_UBP] = ubp; isc[FI_LBM] = lbm;
+        }
+      }
+    }
+    const bool leaving = done && has_inst;
+    // ---- the norms the getters report: only when some instance of the wavefront stops --------------------------------------
+    if (__any(finishing)) {
+      T in1[8] = {l_prt, l_prs, l_stf, l_dvis, l_dnu, l_dfis, l_dyis, l_dw}, in2[8] = {l_av, l_nu, l_hrefv, l_g, T(0), T(0), T(0), T(0)};
+      T r1[8], r2[8];
+      flat_fold8<T>(xb, lane, gbase, jlane, G, 8, in1, r1);
+      flat_fold8<T>(xb, lane, gbase, jlane, G, 8, in2, r2);
+      if (finishing && jlane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) isc[FI_RED + k] = r1[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) isc[FI_RED + 8 + k] = r2[k];
+      }
+      tail_sync();
+    }
+    if (leaving) {
+      store_instance();
+      load_instance(fetch());
+    }
+    TAIL_TP(7)
+  }
+#ifdef LOIKB_TAIL_PROF
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int k = 0; k < 8; ++k) g_tail_prof[k] = prof_[k];
+    for (int k = 8; k < 12; ++k) g_tail_prof[2 + k] = prof_[k];
+    g_tail_prof[8] = n_wave_iters;
+    g_tail_prof[9] = (clock64() - clk0_) * 100000ull / (wall_clock64() - wall0_ + 1);
+  }
+#endif
+  if (lane == 0) atomicAdd(&Bf.counters[5], n_wave_iters);
+  if (jlane == 0) {
+    atomicAdd(&Bf.counters[6], n_slot_loads >> 16);
+    atomicAdd(&Bf.counters[FLAT_COUNTERS_SLOT_HITS], n_slot_hits);
+    atomicOr(&Bf.counters[LEAN_DECADES_SEEN], n_slot_loads & 0xFFFFu);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Decade slots of the flat engine: W_{a,d} (d below a) and Dinv_d of every listed instance for mu = mu0 * 10^(kexp_lo + s).
+// Pass A: the H recursion of k_hslots (hxx:290-338, :31-81, H part), as a pipeline of the decades over the tree levels; a
+// joint that has its UDinv for a decade carries it to the world origin and leaves L_{a,d} = S^w_a . UDinv^w_d for its ancestors
+// a (and Dinv_d) in the instance's slot.  Pass B: per decade, the joints' L columns go to LDS and every joint inverts its
+// column of the unit-triangular factor:  W_{a,d} = -(L_{a,d} + sum_{e strictly between a and d} L_{a,e} W_{e,d}), nearest
+// ancestor first; the slot rows are overwritten with W.
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename T, bool HDIAG>
+__global__ void __launch_bounds__(WAVE)
+k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
+         const int* __restrict__ child_list, const FlatLane* __restrict__ fl, int maxdepth, int nanc, int njmp,
+         const int* __restrict__ slots, int nslots, int G, T* __restrict__ fslots, int kexp_lo, int ndec)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Layout& L = P.L;
+  constexpr int HX = 22;
+  T* xch = reinterpret_cast<T*>(smem_raw);        // [WAVE + 1][22]: the projected, transported H of a child | placement rows [12]
+  T* swt = xch + (WAVE + 1) * HX;                 // [WAVE + 1][6]: S^w of every lane's joint (+ a zero row)
+  T* lb = swt + (WAVE + 1) * 6;                   // [nanc][WAVE] + 2: L columns of one decade (+ zero)
+  const int lane = threadIdx.x;
+  const int ipw = WAVE / G;
+  const int sub = lane / G, jlane = lane % G, gbase = sub * G;
+  const int idx = blockIdx.x * ipw + sub;
+  const bool has_inst = idx < nslots;
+  const bool isj_lane = jlane < L.nb;
+  const bool isj = has_inst && isj_lane;
+  const int jl = isj_lane ? jlane : 0;
+  const JointDesc d = jd[jl + 1];
+  const TailTopo tp = topo[jl + 1];
+  const FlatLane F = fl[jlane];
+  const int depth = isj_lane ? tp.depth : 0;
+  const bool rev = d.flags & JF_REVOLUTE;
+  const T mass = (d.flags & JF_MASSLESS) ? T(0) : T(1);
+  const bool has_parent = !(d.flags & JF_PARENT_ROOT);
+  const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
+  const int slot = slots[has_inst ? idx : 0];
+  const int sidx = slot;
+  char* ip = lane_ptr<T>(Bf.tiles, L, slot);
+  const char* rec = ip + (size_t)jl * JREC * pair_bytes<T>();
+  int jrow[FLAT_JMP], arow[FLAT_MAXA];
+#pragma unroll
+  for (int r = 0; r < FLAT_JMP; ++r) jrow[r] = (isj_lane && F.jmp[r] >= 0) ? gbase + F.jmp[r] : WAVE;
+#pragma unroll
+  for (int k = 0; k < FLAT_MAXA; ++k) arow[k] = (isj_lane && F.anc[k] >= 0) ? gbase + F.anc[k] : WAVE;
+  T R[9], t[3], R0[9], t0[3];
+  {
+    const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS);
+    joint_xform<T>(d, rec, cs.x, cs.y, R, t);
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R0[k] = isj_lane ? R[k] : ((k % 4 == 0) ? T(1) : T(0));
+#pragma unroll
+  for (int k = 0; k < 3; ++k) t0[k] = isj_lane ? t[k] : T(0);
+  flat_world_placement<T>(xch, lane, jlane, jrow, njmp, R0, t0);
+  {
+    T Sv[6], a[3], l[3], c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { Sv[k] = (rev || !isj_lane) ? T(0) : (T)d.axis[k]; Sv[3 + k] = (rev && isj_lane) ? (T)d.axis[k] : T(0); }
+    mat3_vec(R0, Sv, l);
+    mat3_vec(R0, Sv + 3, a);
+    cross3(t0, a, c);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { swt[lane * 6 + k] = l[k] + c[k]; swt[lane * 6 + 3 + k] = a[k]; }
+    if (lane < 6) swt[WAVE * 6 + lane] = T(0);
+    if (lane < HX) xch[WAVE * HX + lane] = T(0);
+  }
+  tail_sync();
+  T ata[21];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) ata[k] = T(0);
+  if (isj && d.cslot >= 0) {
+    const char* crec = ip + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>();
+    for (int k = 0; k < 21; ++k)
+      ata[k] = (P.mode & MODE_A_SHARED) ? Bf.uni[L.nc * 36 + d.cslot * 21 + k]
+                                        : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+  }
+  const int frows = nanc + 1;
+  T mu = P.mu0;
+  for (int k = 0; k < kexp_lo; ++k) mu *= T(10);
+  for (int k = 0; k > kexp_lo; --k) mu *= T(0.1);
+  // ---- pass A
+  const int lag = maxdepth - depth;
+  for (int st = 0; st < maxdepth + ndec - 1; ++st) {
+    const int dsl = st - lag;
+    const bool on = isj && depth > 0 && dsl >= 0 && dsl < ndec;
+    T part[21];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) part[k] = T(0);
+    if (on) {
+      const T mu_eq = P.mu_scale * mu, mu_in = mu;
+      T hh[21];
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b2 = a; b2 < 6; ++b2)
+          hh[sym(a, b2)] = mass * ((a == b2 ? P.rho : T(0)) + ((HDIAG && a != b2) ? T(0) : P.Href[6 * a + b2]));
+#pragma unroll
+      for (int k = 0; k < 21; ++k) hh[k] += mu_eq * ata[k];
+      for (int c = 0; c < tp.nchild; ++c) {
+        const T* x = xch + (gbase + child_list[tp.child_start + c]) * HX;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) hh[k] += x[k];
+      }
+      T U[6], UD[6], UDw[6];
+      T dinv;
+      if (rev) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 3)] * ax0 + hh[sym(k, 4)] * ax1 + hh[sym(k, 5)] * ax2;
+        dinv = T(1) / ((ax0 * U[3] + ax1 * U[4] + ax2 * U[5]) + mu_in);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 0)] * ax0 + hh[sym(k, 1)] * ax1 + hh[sym(k, 2)] * ax2;
+        dinv = T(1) / ((ax0 * U[0] + ax1 * U[1] + ax2 * U[2]) + mu_in);
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) UD[k] = U[k] * dinv;
+      act_force(R0, t0, UD, UDw);
+#pragma unroll
+      for (int k = 0; k < FLAT_MAXA; ++k)
+        if (k < nanc) fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] = dot6_halves(swt + arow[k] * 6, UDw);
+      fslots[fslot_at(sidx, ndec, dsl, G, frows, nanc, jlane)] = dinv;
+      if (has_parent) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b2 = a; b2 < 6; ++b2) hh[sym(a, b2)] -= UD[a] * U[b2];
+        congr_sym(R, t, hh, part);
+      }
+      mu *= T(10);
+    }
+    tail_sync();
+    if (on && has_parent) {
+      T* x = xch + lane * HX;
+#pragma unroll
+      for (int k = 0; k < 21; ++k) x[k] = part[k];
+    }
+    tail_sync();
+  }
+  // ---- pass B (every lane reads back the L column it wrote itself)
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane < 2) lb[nanc * WAVE + lane] = T(0);
+  for (int dsl = 0; dsl < ndec; ++dsl) {
+    T Lc[FLAT_MAXA], Wc[FLAT_MAXA];
+#pragma unroll
+    for (int k = 0; k < FLAT_MAXA; ++k) {
+      Lc[k] = (k < nanc && isj && k < depth - 1) ? fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] : T(0);
+      Wc[k] = T(0);
+    }
+    tail_sync();
+#pragma unroll
+    for (int k = 0; k < FLAT_MAXA; ++k)
+      if (k < nanc) lb[k * WAVE + lane] = Lc[k];
+    tail_sync();
+#pragma unroll
+    for (int k = FLAT_MAXA - 1; k >= 0; --k) {
+      if (k < nanc) {
+        T acc = Lc[k];
+#pragma unroll
+        for (int k2 = k + 1; k2 < FLAT_MAXA; ++k2)
+          if (k2 < nanc) acc += lb[k * WAVE + arow[k2]] * Wc[k2];
+        Wc[k] = (k < depth - 1) ? -acc : T(0);
+      }
+    }
+    if (isj) {
+#pragma unroll
+      for (int k = 0; k < FLAT_MAXA; ++k)
+        if (k < nanc) fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] = Wc[k];
+    }
+  }
+}
+
+// JointData::UDinv / Dinv and pis of the last executed iteration for instances solved by the flat engine (scalar record's
+// SP_TAG == -2: that engine forms neither): one instance per thread, the H recursion of sweep_bwd<.., true, ..> at that
+// iteration's mu; results into the record's JP_UD / JP_R / JP_P slots (p flagged ST_PFULL), the tag set to that mu.
+template <typename T>
+__global__ void k_rebuild_ud(char* tiles, Layout L, const JointDesc* __restrict__ jd, const T* __restrict__ uni, T rho, T mu_scale,
+                             const T* __restrict__ href_tab, int a_shared, int B, T* __restrict__ scratch)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  char* lp = lane_ptr<T>(tiles, L, b);
+  char* srec = lp + (size_t)L.off_s * pair_bytes<T>();
+  if (*elem_ptr<T>(srec, SP_TAG, 0) != T(-2)) return;
+  const T mu = *elem_ptr<T>(srec, SP_ST, 1);
+  const T mu_eq = mu_scale * mu, mu_in = mu;
+  T* o = scratch + (size_t)b * L.nb * 21;
+  for (int i = 1; i <= L.nb; ++i) {
+    for (int r = 0; r < 6; ++r)
+      for (int c = r; c < 6; ++c)
+        o[(i - 1) * 21 + sym(r, c)] = (jd[i].flags & JF_MASSLESS) ? T(0) : ((r == c ? rho : T(0)) + href_tab[(size_t)i * HREF_ROW + 6 * r + c]);
+    if (jd[i].cslot >= 0) {
+      const int cs = jd[i].cslot;
+      for (int k = 0; k < 21; ++k) {
+        const T a = a_shared ? uni[L.nc * 36 + cs * 21 + k]
+                             : *elem_ptr<T>(lp + (size_t)(L.off_c + cs * L.crec) * pair_bytes<T>(), CP_ATA + k / 2, k & 1);
+        o[(i - 1) * 21 + k] += mu_eq * a;
+      }
+    }
+  }
+  for (int i = L.nb; i >= 1; --i) {
+    const JointDesc d = jd[i];
+    T hh[21], U[6], UD[6], R[9], t[3], part[21];
+    for (int k = 0; k < 21; ++k) hh[k] = o[(i - 1) * 21 + k];
+    const int a0 = (d.flags & JF_REVOLUTE) ? 3 : 0;
+    const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
+    for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, a0)] * ax0 + hh[sym(k, a0 + 1)] * ax1 + hh[sym(k, a0 + 2)] * ax2;
+    const T dd = T(1) / ((ax0 * U[a0] + ax1 * U[a0 + 1] + ax2 * U[a0 + 2]) + mu_in);
+    for (int k = 0; k < 6; ++k) UD[k] = U[k] * dd;
+    char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
+    st6<T>(rec, JP_UD, UD);
+    st_hi<T>(rec, JP_R, dd);
+    {
+      // pis[i] of the last backward pass from f_i = H_i v_i + p_i (hxx:139-140) with the final iterates
+      T vv[6], ff[6], hv[6];
+      ld6<T>(rec, JP_V, vv);
+      ld6<T>(rec, JP_F, ff);
+      symv(hh, vv, hv);
+      for (int k = 0; k < 6; ++k) ff[k] -= hv[k];
+      st6<T>(rec, JP_P, ff);
+    }
+    if (d.parent == 0) continue;
+    for (int r = 0; r < 6; ++r)
+      for (int c = r; c < 6; ++c) hh[sym(r, c)] -= UD[r] * U[c];
+    const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS);
+    joint_xform<T>(d, rec, cs.x, cs.y, R, t);
+    congr_sym(R, t, hh, part);
+    for (int k = 0; k < 21; ++k) o[(d.parent - 1) * 21 + k] += part[k];
+  }
+  *elem_ptr<T>(srec, SP_TAG, 0) = mu;
+  *elem_ptr<T>(srec, SP_ST, 0) = (T)((int)*elem_ptr<T>(srec, SP_ST, 0) | ST_PFULL);
+}
+
+}  // namespace loikb

@@ -15,6 +15,7 @@
 #include "loik_device.hpp"
 #include "loik_tail.hpp"
 #include "loik_lean.hpp"
+#include "loik_flat.hpp"
 #include "loik_passes.hpp"
 
 #include "../../include/loik_amd.h"
@@ -55,6 +56,7 @@ struct Tuning {
   int team_max = 1 << 30;       // LOIKB_TEAM_MAX      use the team schedule only up to this many slots
   int tile_pad = -1;            // LOIKB_TILE_PAD      extra pairs per tile (-1: pad to an odd number of 1-KiB pairs)
   bool lean = true;             // LOIKB_LEAN=0        never use k_lean
+  bool flat = true;             // LOIKB_FLAT=0        never use k_flat (the engine without level loops, loik_flat.hpp)
   int tail_waves = TAIL_WAVES;  // LOIKB_TAIL_WAVES    wavefronts per k_tail workgroup
   int lean_decades = 10;        // LOIKB_LEAN_DECADES  decades of mu with precomputed H slots ...
   int lean_klo = -2;            // LOIKB_LEAN_KLO      ... starting at mu0 * 10^klo
@@ -75,6 +77,7 @@ struct Tuning {
     geti("LOIKB_TEAM_MAX", team_max);
     geti("LOIKB_TILE_PAD", tile_pad);
     if (const char* e = getenv("LOIKB_LEAN")) lean = atoi(e) != 0;
+    if (const char* e = getenv("LOIKB_FLAT")) flat = atoi(e) != 0;
     geti("LOIKB_TAIL_WAVES", tail_waves); tail_waves = std::max(1, std::min(TAIL_WAVES, tail_waves));
     geti("LOIKB_LEAN_DECADES", lean_decades); lean_decades = std::max(1, std::min(16, lean_decades));
     geti("LOIKB_LEAN_KLO", lean_klo);
@@ -98,6 +101,9 @@ struct Tuning {
 //   tail_max    hand the solve over to the on-chip engine once at most this many instances are live (whole batch: direct)
 //   nchunks     concurrent chunks of the k_solve phase (1 when the on-chip engine runs the whole batch in one launch)
 struct EnginePlan {
+  bool flat = false;               // k_fslots + k_flat take whole batches (when the reference cost of the solve allows: flat_applicable)
+  const char* why_not_flat = "";
+  int flat_waves_cu = 0;
   bool lean = false;
   const char* why_not_lean = "";
   int lean_waves_cu = 0, lean_wg_waves = TAIL_WAVES;
@@ -136,6 +142,15 @@ struct loikb_solver_impl {
   int multi_from = 1;  // leaf->root level loop of k_lean: the step from which joints with several children can be final
   TailTopo* d_topo = nullptr;
   int* d_child_list = nullptr;
+  // the flat engine's view of the static tree (build_flat_schedule; loik_flat.hpp): one FlatLane per lane of a group
+  struct FlatSched {
+    bool ok = false;
+    const char* why = "";
+    int G = 0, nanc = 0, nscan = 0, njmp = 0;
+    std::vector<FlatLane> lanes;
+    FlatLane* d_lanes = nullptr;
+  } flat;
+  bool ud_stale = false;  // a solve went through the flat engine: the getters of UDinv / pis rebuild them first (k_rebuild_ud)
   // options
   loikb_options opt{};
   int B = 0, nc = 0;
@@ -201,6 +216,8 @@ struct loikb_solver_impl {
     int ring_cap = 0;
     void* d_hslots = nullptr;            // decade slots of the lean tail kernel (H, Dinv, UDinv per joint and decade)
     size_t hslots_bytes = 0;
+    void* d_fslots = nullptr;            // decade slots of the flat engine (W rows, Dinv per joint and decade)
+    size_t fslots_bytes = 0;
     std::vector<int> h_wave;             // host scratch for the compaction scan
     loikb_stats stats{};
     int rc = 0;
@@ -620,6 +637,75 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
   return LOIKB_OK;
 }
 
+
+// The flat engine's view of the static tree (loik_flat.hpp): lane j of a group carries device joint j + 1, the joints must be
+// numbered depth-first (every subtree a contiguous range of lanes -- Pinocchio's numbering of a parsed model), at most
+// FLAT_MAXA strict ancestors per joint.  Per lane: depth, subtree size, the ancestors at distance 1, 2, 4, ... (path sums by
+// pointer jumping), the ancestors by depth (the W rows), and its share of the products W_{a,d} tau_d: row a of that sum runs
+// over the descendants of a, <= FLAT_RED terms go to lane a itself, the rest in chunks of FLAT_RED to lanes that have no
+// row of their own (leaves, unused lanes of the group), which publish partial sums.  `parents` is the device tree.
+void build_flat_schedule(const std::vector<int>& parents, loikb_solver_impl::FlatSched& out)
+{
+  out = loikb_solver_impl::FlatSched{};
+  const int nj = (int)parents.size(), nb = nj - 1;
+  if (nb > WAVE) { out.why = "more joints than lanes of a wavefront"; return; }
+  int G = 8;
+  while (G < nb) G <<= 1;
+  std::vector<int> depth(nj, 0), size(nj, 1);
+  int maxdepth = 0, maxsize = 0;
+  for (int i = 1; i < nj; ++i) { depth[i] = parents[i] == 0 ? 1 : depth[parents[i]] + 1; maxdepth = std::max(maxdepth, depth[i]); }
+  for (int i = nj - 1; i >= 1; --i) if (parents[i] > 0) size[parents[i]] += size[i];
+  for (int i = 1; i < nj; ++i) {
+    maxsize = std::max(maxsize, size[i]);
+    for (int a = parents[i]; a > 0; a = parents[a])
+      if (!(a < i && i < a + size[a])) { out.why = "joints not numbered depth-first (a subtree is not a contiguous range)"; return; }
+  }
+  // (contiguity of every subtree: the joints in [a, a + size_a) must all descend from a -- counted above from the other side:
+  //  every descendant lies inside; there are size_a - 1 of them and the range holds size_a - 1 joints)
+  if (maxdepth - 1 > FLAT_MAXA) { out.why = "tree deeper than the flat engine's ancestor table"; return; }
+  int njmp = 0;
+  while ((1 << njmp) < maxdepth) ++njmp;
+  if (njmp > FLAT_JMP) { out.why = "tree deeper than the flat engine's jump table"; return; }
+  int nscan = 0;
+  while ((1 << nscan) <= maxsize) ++nscan;
+  out.lanes.assign(G, FlatLane{});
+  for (int l = 0; l < G; ++l) {
+    FlatLane& F = out.lanes[l];
+    for (int& x : F.jmp) x = -1;
+    for (int& x : F.anc) x = -1;
+    for (int& x : F.red) x = -1;
+    for (int& x : F.part) x = -1;
+    if (l >= nb) continue;
+    const int i = l + 1;
+    F.depth = depth[i]; F.size = size[i];
+    int a = i;
+    for (int dist = 0, r = 0; a > 0; a = parents[a], ++dist) {
+      if (dist > 0) F.anc[depth[a] - 1] = a - 1;
+      if (dist == (1 << r) && r < FLAT_JMP) F.jmp[r++] = a - 1;
+    }
+  }
+  // the products' rows: lane a sums the entries (depth_a - 1, lane') of its descendants lane' = a+1 .. a+size_a-1
+  std::vector<int> free_lanes;
+  for (int l = G - 1; l >= 0; --l)
+    if (l >= nb || size[l + 1] == 1) free_lanes.push_back(l);  // (taken from the back of the vector: low lanes first)
+  for (int l = 0; l < nb; ++l) {
+    const int m = size[l + 1] - 1, k = depth[l + 1] - 1;
+    int nparts = 0;
+    for (int c0 = 0; c0 < m; c0 += FLAT_RED) {
+      int owner = l;
+      if (c0 > 0) {
+        if (free_lanes.empty() || nparts >= FLAT_PART) { out.why = "a joint with too many descendants for the flat engine's reduction schedule"; out.lanes.clear(); return; }
+        owner = free_lanes.back(); free_lanes.pop_back();
+        out.lanes[owner].helper = 1;
+        out.lanes[l].part[nparts++] = owner;
+      }
+      for (int t = 0; t < FLAT_RED && c0 + t < m; ++t) out.lanes[owner].red[t] = k * G + (l + 1 + c0 + t);
+    }
+  }
+  out.G = G; out.nanc = std::max(1, maxdepth - 1); out.nscan = nscan; out.njmp = njmp;
+  out.ok = true;
+}
+
 template <typename T>
 Bufs<T> make_bufs(loikb_solver_impl* S, Chunk* C, int k)
 {
@@ -809,6 +895,7 @@ void destroy_chunks(loikb_solver_impl* S)
   for (Chunk& C : S->chunks) {
     if (C.h_counters) (void)hipHostFree(C.h_counters);
     if (C.d_hslots) (void)hipFree(C.d_hslots);
+    if (C.d_fslots) (void)hipFree(C.d_fslots);
     if (C.ev_k0) (void)hipEventDestroy(C.ev_k0);
     if (C.ev_k2) (void)hipEventDestroy(C.ev_k2);
     if (C.ev_k1) (void)hipEventDestroy(C.ev_k1);
@@ -864,8 +951,40 @@ int build_chunks(loikb_solver_impl* S, int nchunks)
 // the plan is made -- never inside a solve -- with a stated budget: batch x decades x 176 B x lanes per instance
 // (Talos-32: 3.7 GB for 65536 instances, 59 GB for 2^20).  Not enough memory is an error the caller can act on
 // (LOIKB_LEAN=0 selects the engines that need none), not a silent change of engine.
+// Does the current problem allow the flat engine?  (plan.flat is the structural part: tree, precision, options; the reference
+// cost is known after SolveInit / UpdateReferences: this first version of the engine serves H_ref = h I broadcast to all links)
+bool href_is_scalar(const loikb_solver_impl* S)
+{
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j)
+      if (S->Href[6 * i + j] != (i == j ? S->Href[0] : 0.0)) return false;
+  return true;
+}
+bool flat_applicable(const loikb_solver_impl* S) { return S->plan.flat && !S->per_link && href_is_scalar(S); }
+
 int ensure_hslots(loikb_solver_impl* S)
 {
+  if (S->plan.flat && (flat_applicable(S) || !S->have_problem)) {
+    // decade slots of the flat engine: (ancestors + 1) scalars per lane, decade and instance
+    for (Chunk& C : S->chunks) {
+      const size_t need = (size_t)C.B * S->plan.ndec * (S->flat.nanc + 1) * S->flat.G * S->esz;
+      if (need <= C.fslots_bytes) continue;
+      if (C.d_fslots) HIPCHK(hipFree(C.d_fslots));
+      C.d_fslots = nullptr; C.fslots_bytes = 0;
+      if (hipMalloc(&C.d_fslots, need) != hipSuccess) {
+        (void)hipGetLastError();
+        char buf[400];
+        snprintf(buf, sizeof(buf), "the flat engine needs %.2f GB of decade slots for %d instances (%d decades x %d rows x %d lanes x %d B) "
+                 "and the device has no room for them: create the solver with a smaller batch, or set LOIKB_FLAT=0 LOIKB_LEAN=0 to use "
+                 "the k_solve + k_tail engines, which need none", need / 1e9, C.B, S->plan.ndec, S->flat.nanc + 1, S->flat.G, (int)S->esz);
+        g_last_error = buf;
+        return LOIKB_ERR_HIP;
+      }
+      C.fslots_bytes = need;
+    }
+    if (flat_applicable(S) || !S->plan.lean) return LOIKB_OK;
+    if (!S->have_problem) return LOIKB_OK;  // (the lean engine's slots are only needed once a solve cannot use the flat engine)
+  }
   if (!S->plan.lean) return LOIKB_OK;
   int G = 8;
   while (G < S->nb) G <<= 1;
@@ -1135,7 +1254,7 @@ int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, 
   }
   if ((rc = constraint_products(S, 0, S->nc, false))) return rc;
   S->have_problem = true;
-  return LOIKB_OK;
+  return ensure_hslots(S);  // (which engine's decade slots this problem needs is known now: H_ref)
 }
 
 // instances of the home set that ran out of iterations: finished, neither converged nor flagged infeasible
@@ -1237,14 +1356,27 @@ void plan_engines(loikb_solver_impl* S)
   else if (S->nb <= 16) pl.why_not_lean = "a small robot (<= 16 joints): k_solve + k_tail are faster on its short solves";
   else if (pl.lean_waves_cu < 7) pl.why_not_lean = "constraint blocks leave too few wavefronts per CU in LDS";
   else pl.lean = true;
+  // the flat engine (no loops over the tree levels, loik_flat.hpp): same regime as k_lean, any number of children per joint
+  if (S->flat.ok) {
+    const size_t per_wave = flat_lds_bytes<double>(S->nc, S->flat.G, S->a_shared, S->flat.nanc, true);
+    pl.flat_waves_cu = (int)std::min<size_t>(8, (160 * 1024) / per_wave);
+  }
+  if (!S->tune.flat) pl.why_not_flat = "LOIKB_FLAT=0";
+  else if (!S->flat.ok) pl.why_not_flat = S->flat.why;
+  else if (S->f32) pl.why_not_flat = "fp32 solver";
+  else if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) pl.why_not_flat = "LOIKB_OPT_NO_H_CACHE (no precomputed factors)";
+  else if (S->opt.mu_update_strat == LOIKB_MU_OSQP) pl.why_not_flat = "OSQP penalty rule: mu is off the decade grid";
+  else if (S->nb <= 16) pl.why_not_flat = "a small robot (<= 16 joints): k_solve + k_tail are faster on its short solves";
+  else if (pl.flat_waves_cu < 6) pl.why_not_flat = "constraint blocks leave too few wavefronts per CU in LDS";
+  else pl.flat = true;
   // with the lean kernel whole batches up to 2^20 instances go to it directly (it is as fast as k_solve's bulk phase and
   // has neither ragged tiles nor compaction); without it k_solve hands over to k_tail at 32768 live instances
-  pl.tail_max = S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : (pl.lean ? (1 << 20) : 32768);
+  pl.tail_max = S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : ((pl.lean || pl.flat) ? (1 << 20) : 32768);
   // Concurrent chunks pay only in the k_solve + k_tail configuration (measured on MI355X, Talos-32, B = 65536: 1 chunk
   // 52.9 ms/step, 2 chunks 47.9, 3 chunks 48.2, 4 chunks 74: one chunk's latency-bound straggler phase runs beside the
   // other's bulk phase); the lean kernel takes the whole batch in one launch.
   const int ntiles = (S->B + WAVE - 1) / WAVE;
-  pl.nchunks = (ntiles >= 512 && !pl.lean) ? 2 : 1;
+  pl.nchunks = (ntiles >= 512 && !pl.lean && !pl.flat) ? 2 : 1;
   if (S->tune.chunks > 0) pl.nchunks = S->tune.chunks;
   pl.nchunks = std::max(1, std::min(pl.nchunks, ntiles));
   S->plan = pl;
@@ -1312,8 +1444,77 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       if (hi >= lo) { kexp_lo = lo; ndec = hi - lo + 1; }
     }
     const size_t wave_lds = lean_lds_bytes<T>(S->nc, G, S->a_shared);
+    // ---- the flat engine (loik_flat.hpp: no loops over the tree levels) takes the place of k_hslots + k_lean when the solve's
+    // reference cost allows (H_ref = h I for all links)
+    const bool flat_ok = flat_applicable(S) && (P.mode & MODE_CACHE_H) && n >= 64;
+    if (flat_ok) {
+      const int nanc = S->flat.nanc, frows = nanc + 1;
+      const size_t need = (size_t)n_cur * ndec * frows * G * sizeof(T);
+      if (need > C->fslots_bytes) { g_last_error = "internal: decade-slot buffer of the flat engine smaller than the chunk"; return LOIKB_ERR_STATE; }
+      const int has_hv = S->Hv_inf_norm != 0.0;
+      const size_t flds = flat_lds_bytes<T>(S->nc, G, S->a_shared, nanc, has_hv);
+      if (flds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_flat<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+      const int waves_cu = (int)std::min<size_t>(8, (160 * 1024) / flds);
+      const int wg_per_cu = S->tune.lean_wg_per_cu > 0 ? S->tune.lean_wg_per_cu : waves_cu;
+      const int wg_cap = wg_per_cu * std::max(1, (int)(S->ncu * ((double)C->B / (double)S->B) + 0.5));
+      P.max_launch_iters = S->opt.max_iter + 1;
+      const dim3 grid((unsigned)std::min((n + ipw - 1) / ipw, wg_cap));
+      HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
+      HIPCHK(hipEventRecord(C->ev_k0, C->stream));
+      {
+        const dim3 hgrid((unsigned)((n + ipw - 1) / ipw));
+        const size_t hlds = ((size_t)(WAVE + 1) * 22 + (size_t)(WAVE + 1) * 6 + (size_t)nanc * WAVE + 2) * sizeof(T);
+        hipLaunchKernelGGL((k_fslots<T, true>), hgrid, dim3(WAVE), hlds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                           (const TailTopo*)S->d_topo, (const int*)S->d_child_list, (const FlatLane*)S->flat.d_lanes, S->maxdepth,
+                           nanc, S->flat.njmp, list, n, G, (T*)C->d_fslots, kexp_lo, ndec);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(C->ev_k2, C->stream));
+      }
+      hipLaunchKernelGGL(k_ring_fill, grid1(C->ring_cap), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, list, n, C->d_counters);
+      hipLaunchKernelGGL((k_flat<T>), grid, dim3(WAVE), flds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                         (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, (const int*)C->d_ring, n, G,
+                         (const T*)C->d_fslots, kexp_lo, ndec, (T)S->Href[0], has_hv);
+      HIPCHK(hipGetLastError());
+      int* next = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
+      hipLaunchKernelGGL(k_list_unfinished<T>, grid1(n), dim3(256), 0, C->stream, A.tiles, S->L, list, n, next, C->d_counters + 3);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(C->ev_k1, C->stream));
+      HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+      HIPCHK(hipStreamSynchronize(C->stream));
+      float ms = 0.f, t0 = 0.f, hms = 0.f;
+      HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));
+      HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0));
+      HIPCHK(hipEventElapsedTime(&hms, C->ev_k0, C->ev_k2));
+      iters += C->h_counters[1];
+      const unsigned int escaped = C->h_counters[2];
+      {
+        std::lock_guard<std::mutex> lock(S->alloc_mu);
+        const unsigned int seen = C->h_counters[LEAN_DECADES_SEEN];
+        for (int d = 0; d < 16; ++d)
+          if (seen & (1u << d)) { S->seen_lo = std::min(S->seen_lo, kexp_lo + d); S->seen_hi = std::max(S->seen_hi, kexp_lo + d); }
+        if (escaped) { S->seen_lo = S->plan.kexp_lo; S->seen_hi = S->plan.kexp_lo + S->plan.ndec - 1; }
+        S->ud_stale = true;
+      }
+      C->stats.hslots_ms += hms;
+      if (trace)
+        fprintf(stderr, "[loikb] flat engine: %6d instances on %u workgroups, done at %8.3f ms (slots %6.3f ms)  inst-iters %9u  "
+                        "wave-iters %7u  slot loads %7u (+ %u served from LDS)  escaped %u  still iterating %u\n",
+                n, grid.x, ms, hms, C->h_counters[1], C->h_counters[5], C->h_counters[6], C->h_counters[FLAT_COUNTERS_SLOT_HITS],
+                escaped, C->h_counters[3]);
+      C->stats.launches++;
+      C->stats.tail_launches++;
+      C->stats.lean_launches++;
+      C->stats.flat_launches++;
+      C->stats.lean_escaped += (int)escaped;
+      C->tail_iv.emplace_back(t0, t0 + ms);
+      total_ms = ms;
+      n = (int)C->h_counters[3];
+      list = next;
+      if (n == 0) { *ms_out = total_ms; *iters_out = iters; return LOIKB_OK; }
+      // what is left escaped the precomputed decades: k_tail below finishes it
+    }
     // (k_lean's lane groups need whole wavefronts of work to pay: below 64 instances k_tail's direct path is as good)
-    const bool lean_ok = S->plan.lean && !S->per_link && (P.mode & MODE_CACHE_H) && n >= 64;  // (k_lean has no per-link table)
+    const bool lean_ok = !flat_ok && S->plan.lean && !S->per_link && (P.mode & MODE_CACHE_H) && n >= 64;  // (k_lean has no per-link table)
     if (lean_ok) {
       // decade slots are indexed by the instance's slot in the set (relaunches with shorter lists find them again);
       // the buffer was sized for the chunk at SolveInit (ensure_hslots)
@@ -1670,6 +1871,7 @@ int run_main_loop_t(loikb_solver_impl* S)
     S->stats.tail_instance_iterations += C.stats.tail_instance_iterations;
     S->stats.tail_launches += C.stats.tail_launches;
     S->stats.lean_launches += C.stats.lean_launches;
+    S->stats.flat_launches += C.stats.flat_launches;
     S->stats.lean_escaped += C.stats.lean_escaped;
     S->stats.hslots_ms += C.stats.hslots_ms;
     S->stats.lean_requeues += C.stats.lean_requeues;
@@ -1838,6 +2040,23 @@ int loikb_sweep_schedule(const int* parents, int njoints, int team, int directio
   return T;
 }
 
+// the flat engine's static schedule of a tree (inspection / tests, like loikb_sweep_schedule)
+int loikb_flat_schedule(const int* parents, int njoints, int* out, int cap, int* meta)
+{
+  if (!parents || njoints < 2 || !meta) return LOIKB_ERR_ARG;
+  for (int i = 1; i < njoints; ++i)
+    if (parents[i] < 0 || parents[i] >= i) { g_last_error = "parents[i] must be < i"; return LOIKB_ERR_MODEL; }
+  loikb_solver_impl::FlatSched fs;
+  build_flat_schedule(std::vector<int>(parents, parents + njoints), fs);
+  meta[0] = fs.ok; meta[1] = fs.G; meta[2] = fs.nanc; meta[3] = fs.nscan; meta[4] = fs.njmp;
+  if (!fs.ok) { g_last_error = fs.why; return LOIKB_OK; }
+  constexpr int W = (int)(sizeof(FlatLane) / sizeof(int));
+  static_assert(sizeof(FlatLane) == sizeof(int) * (2 + FLAT_JMP + FLAT_MAXA + FLAT_RED + 1 + FLAT_PART), "FlatLane is a plain int record");
+  if (!out || cap < fs.G * W) return fs.G * W;
+  memcpy(out, fs.lanes.data(), sizeof(FlatLane) * fs.lanes.size());
+  return LOIKB_OK;
+}
+
 const char* loikb_last_error(void) { return g_last_error.c_str(); }
 
 const char* loikb_status_string(int code)
@@ -1894,6 +2113,7 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
   S->tune.read_env();
   int rc = build_schedule(S, model);
   if (rc) { delete S; return rc; }
+  build_flat_schedule(S->parents, S->flat);
   S->opt = *opts;
   S->B = opts->batch;
   S->nc = std::max(opts->num_eq_c, opts->eq_c_capacity);
@@ -1948,6 +2168,10 @@ int loikb_create(const loikb_model_desc* model, const loikb_options* opts, loikb
     TRY(alloc_dev(S, &tmp, sizeof(StepDesc) * sc.down.size())); sc.d_down = (StepDesc*)tmp;
     TRY(alloc_dev(S, &tmp, sizeof(int) * sc.rlist.size())); sc.d_rlist = (int*)tmp;
     HIPTRY(hipMemcpyAsync(sc.d_rlist, sc.rlist.data(), sizeof(int) * sc.rlist.size(), hipMemcpyHostToDevice, S->stream));
+  }
+  if (S->flat.ok) {
+    TRY(alloc_dev(S, &tmp, sizeof(FlatLane) * S->flat.lanes.size())); S->flat.d_lanes = (FlatLane*)tmp;
+    HIPTRY(hipMemcpyAsync(S->flat.d_lanes, S->flat.lanes.data(), sizeof(FlatLane) * S->flat.lanes.size(), hipMemcpyHostToDevice, S->stream));
   }
   TRY(upload_jd(S));
   TRY(ensure_layout(S, true));
@@ -2030,6 +2254,7 @@ int loikb_update_references(loikb_solver* S, const double* H_refs, const double*
   S->pass_active = false;   // (the pass-level path re-reads the problem on its next call)
   int rc;
   if ((rc = upload_href_tab(S))) return rc;
+  if ((rc = ensure_hslots(S))) return rc;
   return reset_home(S, RS_HCACHE);  // H_i = rho I + H_ref_i + ...: the cached factors are stale
 }
 
@@ -2397,7 +2622,12 @@ const char* loikb_plan_string(loikb_solver* S)
   if (!S) return "";
   char buf[512];
   const EnginePlan& pl = S->plan;
-  if (pl.lean)
+  if (pl.flat && (flat_applicable(S) || !S->have_problem))
+    snprintf(buf, sizeof(buf), "k_fslots + k_flat (no loops over the tree levels) for whole batches up to %d instances (%d wavefronts per "
+             "CU, decades mu0*10^%d..%d, %d ancestors per joint, %d scan steps, %d jump rounds)%s; k_solve above that; %d chunk(s)",
+             pl.tail_max, pl.flat_waves_cu, pl.kexp_lo, pl.kexp_lo + pl.ndec - 1, S->flat.nanc, S->flat.nscan, S->flat.njmp,
+             S->have_problem ? "" : " when H_ref = h I", pl.nchunks);
+  else if (pl.lean)
     snprintf(buf, sizeof(buf), "k_hslots + k_lean for whole batches up to %d instances (%d wavefronts per CU in workgroups of %d, "
              "decades mu0*10^%d..%d, time slice %d); k_solve above that; %d chunk(s)", pl.tail_max, pl.lean_waves_cu,
              pl.lean_wg_waves, pl.kexp_lo, pl.kexp_lo + pl.ndec - 1, S->tune.lean_slice, pl.nchunks);
@@ -2405,7 +2635,9 @@ const char* loikb_plan_string(loikb_solver* S)
     snprintf(buf, sizeof(buf), "k_solve (team of %d), hand-over to k_tail at %d live instances; %d chunk(s); no k_lean: %s",
              S->sched[1].nw, pl.tail_max, pl.nchunks, pl.why_not_lean);
   out = buf;
-  if (pl.lean && S->tune.lean_adapt && S->seen_hi >= S->seen_lo) {
+  if (!pl.flat && *pl.why_not_flat) out += std::string("; no k_flat: ") + pl.why_not_flat;
+  else if (pl.flat && S->have_problem && !flat_applicable(S)) out += "; no k_flat for this problem: its reference cost is not H_ref = h I on every link";
+  if ((pl.lean || pl.flat) && S->tune.lean_adapt && S->seen_hi >= S->seen_lo) {
     char b2[160];
     snprintf(b2, sizeof(b2), "; decades visited by this handle's solves so far: %d..%d (the next solve builds those +-1)", S->seen_lo, S->seen_hi);
     out += b2;
@@ -2504,6 +2736,23 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
     final_dst = dst;
     HIPCHK(hipMalloc(&d_tmp, sizeof(double) * (size_t)S->B * nb * (field == LOIKB_F_HIS ? 21 : 6)));
     dst = (double*)d_tmp;
+  }
+  if ((field == LOIKB_F_UDINV || field == LOIKB_F_PIS) && S->ud_stale) {
+    // instances left by the flat engine carry neither UDinv nor pis (tag -2 in their scalar record): rebuilt in place
+    void* d_scr = nullptr;
+    HIPCHK(hipMalloc(&d_scr, S->esz * (size_t)S->B * nb * 21));
+    if (S->f32)
+      hipLaunchKernelGGL(k_rebuild_ud<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, (const JointDesc*)S->d_jd,
+                         (const float*)S->d_uni, (float)S->opt.rho, (float)S->opt.mu_equality_scale_factor, (const float*)S->d_href,
+                         (int)S->a_shared, S->B, (float*)d_scr);
+    else
+      hipLaunchKernelGGL(k_rebuild_ud<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, (const JointDesc*)S->d_jd,
+                         (const double*)S->d_uni, (double)S->opt.rho, (double)S->opt.mu_equality_scale_factor,
+                         (const double*)S->d_href, (int)S->a_shared, S->B, (double*)d_scr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(S->stream));
+    HIPCHK(hipFree(d_scr));
+    S->ud_stale = false;
   }
   if (field == LOIKB_F_HIS) {
     if (S->f32)
