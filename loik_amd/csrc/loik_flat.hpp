@@ -60,7 +60,7 @@ struct FlatLane {
 };
 
 // constraint block of an instance in LDS (T each)
-enum : int { FC_LANE = 0, FC_B = 1, FC_Y = 7, FC_ATY = 13, FC_ATYW = 19, FC_ATBW = 25, FC_AW = 31, FCD = 67 };
+enum : int { FC_LANE = 0, FC_B = 1, FC_Y = 7, FC_ATY = 13, FC_ATYW = 19, FC_ATBW = 25, FC_DY = 31, FC_DLT = 37, FC_ATYF = 43, FC_AW = 49, FCD = 85 };
 // per-instance scalars kept in LDS for the getters (written when an instance stops)
 enum : int { FI_BNORM = 0, FI_TGIN, FI_STY, FI_TOLP, FI_TOLD, FI_DYQP, FI_ATDY, FI_UBP, FI_LBM, FI_C1, FI_C2, FI_PRIMAL, FI_DUAL, FI_DX,
              FI_DZ, FI_MULAST, FI_RED /* 16 folded values */, FISC = FI_RED + 16 };
@@ -401,6 +401,14 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
           for (int k = 0; k < 6; ++k) c_[FC_AW + 6 * k + j] = o[k];
         }
+        // A^T y as the instance brings it (a warm-started tailored solve arrives with the A^T y of the matrix it had BEFORE
+        // UpdateEqConstraint replaced it, and upstream's first FwdPass1 uses exactly that, hxx:329-331), at the world origin
+        T ay[6], o[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ay[k] = c_[FC_ATY + k];
+        act_force(R0, t0, ay, o);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c_[FC_ATYW + k] = o[k];
       }
     }
     tail_sync();
@@ -408,11 +416,10 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       T* c_ = cdi + c * cs;
       if (jlane < 6) {
         const int k = jlane;
-        T ab = T(0), ay = T(0);
+        T ab = T(0);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { ab += c_[FC_AW + 6 * k + j] * c_[FC_B + j]; ay += c_[FC_AW + 6 * k + j] * c_[FC_Y + j]; }
+        for (int j = 0; j < 6; ++j) ab += c_[FC_AW + 6 * k + j] * c_[FC_B + j];
         c_[FC_ATBW + k] = ab;
-        c_[FC_ATYW + k] = ay;
       }
     }
     // subtree sums of the state the instance arrives with (cold start: v = 0) and of the reference term
@@ -489,11 +496,11 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         stp<T>(srec, SP_FLIP, (T)nflip, T(0));
         stp<T>(srec, SP_ST, (T)(any_iter ? (status & ~ST_PFULL) : status), any_iter ? isc[FI_MULAST] : isc[FI_STY]);
         if (any_iter) {
-          const T* rr = isc + FI_RED;  // prt prs stf dvis dnu dfis dyis dw av nu hrefv g (12), filled when the instance stopped
+          const T* rr = isc + FI_RED;  // prt prs stf dvis dnu dfis dyis dw av nu hrefv g dualv (13), filled when the instance stopped
           const T mu_s = mu;
           stp<T>(srec, SP_SCAL + 0, isc[FI_PRIMAL], isc[FI_DUAL]);
           stp<T>(srec, SP_SCAL + 1, rr[0], rr[1]);
-          stp<T>(srec, SP_SCAL + 2, P.rho * rr[3], rr[2]);
+          stp<T>(srec, SP_SCAL + 2, rr[12], rr[2]);
           stp<T>(srec, SP_SCAL + 3, isc[FI_TOLP], isc[FI_TOLD]);
           stp<T>(srec, SP_SCAL + 4, mu_s, P.mu_scale * mu_s);
           stp<T>(srec, SP_SCAL + 5, mu_s, isc[FI_DX]);
@@ -643,6 +650,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         l_prt = tmax(l_prt, tabs(ek));
         l_av = tmax(l_av, tabs(avk));
         c_[FC_Y + k] = yk;
+        c_[FC_DY + k] = dy;
       }
     }
     tail_sync();
@@ -650,10 +658,19 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       T* c_ = cdi + c * cs;
       const T* A_ = a_shared ? ash + c * LCA : c_ + FCD;
       if (act && jlane < 6) {
+        // A^T y (hxx:422) and the same at the world origin; and the two pieces of THIS iteration's force balance that are not
+        // A^T y of the new dual: the constraint's share of H^base v + p^base is A^T dy + (the A^T y FwdPass1 used), which is
+        // A^T y_new only when the instance arrived with A^T y consistent with its A (not after UpdateEqConstraint replaced A
+        // under a warm start: upstream's first iteration then runs on the old product, hxx:329-331)
         const int k = jlane;
-        T at = A_[k] * c_[FC_Y], aw = c_[FC_AW + 6 * k] * c_[FC_Y];
+        T at = A_[k] * c_[FC_Y], aw = c_[FC_AW + 6 * k] * c_[FC_Y], atd = A_[k] * c_[FC_DY], awd = c_[FC_AW + 6 * k] * c_[FC_DY];
 #pragma unroll
-        for (int j = 1; j < 6; ++j) { at += A_[6 * j + k] * c_[FC_Y + j]; aw += c_[FC_AW + 6 * k + j] * c_[FC_Y + j]; }
+        for (int j = 1; j < 6; ++j) {
+          at += A_[6 * j + k] * c_[FC_Y + j]; aw += c_[FC_AW + 6 * k + j] * c_[FC_Y + j];
+          atd += A_[6 * j + k] * c_[FC_DY + j]; awd += c_[FC_AW + 6 * k + j] * c_[FC_DY + j];
+        }
+        c_[FC_DLT + k] = (at - atd) - c_[FC_ATY + k];   // A^T y_old - (A^T y used): added to g of the constrained joint
+        c_[FC_ATYF + k] = c_[FC_ATYW + k] + awd;       // the constraint's force in f, world origin
         c_[FC_ATY + k] = at;
         c_[FC_ATYW + k] = aw;
       }
@@ -674,7 +691,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         const T* c_ = cdi + c * cs;
         const T m = cmask(c);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) Fw[k] += m * c_[FC_ATYW + k];
+        for (int k = 0; k < 6; ++k) Fw[k] += m * c_[FC_ATYF + k];
       }
       actinv_force(R0, t0, Fw, fi);
       if (act) {
@@ -685,17 +702,26 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     TAIL_TP(5)
     // ================= per-joint work: BoxProj, the w update, the norms (hxx:129-158, :384-397, :454-458) ======================
     T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_prs = T(0);
-    T l_dg = T(0), l_g = T(0), l_stf = T(0), l_dstf = T(0);
+    T l_dg = T(0), l_g = T(0), l_stf = T(0), l_dstf = T(0), l_dualv = T(0);
     if (act && isj) {
-      T df[6], dv6[6], gi[6], dg[6];
+      T df[6], dv6[6], gi[6], dg[6], dvr[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         df[k] = fi[k] - f[k];
         dv6[k] = vi[k] - v[k];
         // g_i = A^T y_i + sum_children act(f_c) - f_i = A^T y_i - (H^base_i v_i + p^base_i)  (force balance)
         gi[k] = -mass * (P.rho * dv6[k] + href_s * vi[k] - P.Hv[k]);
-        dg[k] = gi[k] - g[k];
       }
+      if (jcslot >= 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gi[k] += cdi[jcslot * cs + FC_DLT + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        dg[k] = gi[k] - g[k];
+        dvr[k] = mass * (href_s * vi[k] - P.Hv[k]) + gi[k];  // dual residual, v block (hxx:228)
+      }
+      l_dualv = inf6(dvr);
       l_nu = tabs(nui);
       l_dfis = mass * inf6(df);
       l_hrefv = mass * tabs(href_s) * inf6(vi);
@@ -723,8 +749,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     // ================= the scalars of the stopping logic, folded over the group ================================================
     T red[8];
     {
-      // (the dual residual's v block is H_ref v - Hv + g = -rho dv for a body: rho * |dv|)
-      T in[8] = {tmax(l_prt, l_prs), tmax(P.rho * l_dvis, l_stf), tmax(l_dvis, l_dnu), l_dz,
+      T in[8] = {tmax(l_prt, l_prs), tmax(l_dualv, l_stf), tmax(l_dvis, l_dnu), l_dz,
                  tmax(l_dfis, tmax(l_dyis, l_dw)), tmax(l_dg, l_dstf), l_up, l_lm};
       flat_fold8<T>(xb, lane, gbase, jlane, G, 6, in, red);
     }
@@ -787,7 +812,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     const bool leaving = done && has_inst;
     // ---- the norms the getters report: only when some instance of the wavefront stops --------------------------------------
     if (__any(finishing)) {
-      T in1[8] = {l_prt, l_prs, l_stf, l_dvis, l_dnu, l_dfis, l_dyis, l_dw}, in2[8] = {l_av, l_nu, l_hrefv, l_g, T(0), T(0), T(0), T(0)};
+      T in1[8] = {l_prt, l_prs, l_stf, l_dvis, l_dnu, l_dfis, l_dyis, l_dw}, in2[8] = {l_av, l_nu, l_hrefv, l_g, l_dualv, T(0), T(0), T(0)};
       T r1[8], r2[8];
       flat_fold8<T>(xb, lane, gbase, jlane, G, 8, in1, r1);
       flat_fold8<T>(xb, lane, gbase, jlane, G, 8, in2, r2);
@@ -795,7 +820,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
         for (int k = 0; k < 8; ++k) isc[FI_RED + k] = r1[k];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) isc[FI_RED + 8 + k] = r2[k];
+        for (int k = 0; k < 5; ++k) isc[FI_RED + 8 + k] = r2[k];
       }
       tail_sync();
     }

@@ -55,7 +55,7 @@ struct Tuning {
   int team = MAX_TEAM;          // LOIKB_TEAM          wavefronts per tile of k_solve
   int team_max = 1 << 30;       // LOIKB_TEAM_MAX      use the team schedule only up to this many slots
   int tile_pad = -1;            // LOIKB_TILE_PAD      extra pairs per tile (-1: pad to an odd number of 1-KiB pairs)
-  bool lean = true;             // LOIKB_LEAN=0        never use k_lean
+  bool lean = true;             // LOIKB_LEAN=0        never use k_lean nor k_flat (the engines with precomputed decade slots)
   bool flat = true;             // LOIKB_FLAT=0        never use k_flat (the engine without level loops, loik_flat.hpp)
   int tail_waves = TAIL_WAVES;  // LOIKB_TAIL_WAVES    wavefronts per k_tail workgroup
   int lean_decades = 10;        // LOIKB_LEAN_DECADES  decades of mu with precomputed H slots ...
@@ -78,6 +78,7 @@ struct Tuning {
     geti("LOIKB_TILE_PAD", tile_pad);
     if (const char* e = getenv("LOIKB_LEAN")) lean = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT")) flat = atoi(e) != 0;
+    if (!lean) flat = false;  // (LOIKB_LEAN=0 asks for the engines without precomputed factors: k_solve / k_tail)
     geti("LOIKB_TAIL_WAVES", tail_waves); tail_waves = std::max(1, std::min(TAIL_WAVES, tail_waves));
     geti("LOIKB_LEAN_DECADES", lean_decades); lean_decades = std::max(1, std::min(16, lean_decades));
     geti("LOIKB_LEAN_KLO", lean_klo);
@@ -1361,7 +1362,7 @@ void plan_engines(loikb_solver_impl* S)
     const size_t per_wave = flat_lds_bytes<double>(S->nc, S->flat.G, S->a_shared, S->flat.nanc, true);
     pl.flat_waves_cu = (int)std::min<size_t>(8, (160 * 1024) / per_wave);
   }
-  if (!S->tune.flat) pl.why_not_flat = "LOIKB_FLAT=0";
+  if (!S->tune.flat) pl.why_not_flat = S->tune.lean ? "LOIKB_FLAT=0" : "LOIKB_LEAN=0";
   else if (!S->flat.ok) pl.why_not_flat = S->flat.why;
   else if (S->f32) pl.why_not_flat = "fp32 solver";
   else if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) pl.why_not_flat = "LOIKB_OPT_NO_H_CACHE (no precomputed factors)";

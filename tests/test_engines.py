@@ -12,12 +12,15 @@ from oracle import ref
 pytestmark = pytest.mark.gpu
 
 ENGINES = {
-    "lean": (dict(), dict()),
+    "flat": (dict(), dict()),
+    "lean": (dict(LOIKB_FLAT="0"), dict()),
     "tail": (dict(LOIKB_LEAN="0"), dict(tail_max_instances=1 << 20)),
     "solve": (dict(), dict(tail_max_instances=-1)),
     "hybrid": (dict(LOIKB_LEAN="0"), dict(tail_max_instances=120, max_launch_iters=2)),
-    "hybrid_lean": (dict(), dict(tail_max_instances=120, max_launch_iters=2)),
-    "lean_escapes": (dict(LOIKB_LEAN_KLO="0", LOIKB_LEAN_DECADES="2"), dict()),
+    "hybrid_flat": (dict(), dict(tail_max_instances=120, max_launch_iters=2)),
+    "hybrid_lean": (dict(LOIKB_FLAT="0"), dict(tail_max_instances=120, max_launch_iters=2)),
+    "flat_escapes": (dict(LOIKB_LEAN_KLO="0", LOIKB_LEAN_DECADES="2"), dict()),
+    "lean_escapes": (dict(LOIKB_FLAT="0", LOIKB_LEAN_KLO="0", LOIKB_LEAN_DECADES="2"), dict()),
 }
 FIELDS = ["nu", "z", "w", "vis", "fis", "g", "yis", "Aty", "Stf_plus_w", "primal_residual_vec", "dual_residual_vec"]
 SCALARS = ["primal_residual", "dual_residual", "primal_residual_task", "primal_residual_slack", "dual_residual_v",
@@ -28,7 +31,7 @@ SCALARS = ["primal_residual", "dual_residual", "primal_residual_task", "primal_r
 
 def _solver(model, B, prm, engine, monkeypatch):
     env, kw = ENGINES[engine]
-    for k in ("LOIKB_LEAN", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES"):
+    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -67,16 +70,20 @@ def test_every_engine_matches_the_oracle(which, engine, request, monkeypatch):
     s = _solver(model, B, prm, engine, monkeypatch)
     s.Solve(*args)
     st = s.stats()
-    if engine == "lean":
+    if engine in ("lean", "flat"):
         assert st["lean_launches"] >= 1 and st["lean_escaped"] == 0 and st["tail_instances"] == B
+        # (the random tree's joints are numbered depth-first too: both run the engine they ask for)
+        assert st["flat_launches"] == (1 if engine == "flat" else 0), (s.plan(), st)
     if engine in ("tail", "hybrid"):
         assert st["lean_launches"] == 0 and st["tail_instances"] > 0
     if engine == "solve":
         assert st["tail_instances"] == 0
-    if engine == "hybrid_lean":
+    if engine in ("hybrid_lean", "hybrid_flat"):
         assert st["lean_launches"] >= 1 and 0 < st["tail_instances"] < B
-    if engine == "lean_escapes":
+        assert (st["flat_launches"] >= 1) == (engine == "hybrid_flat")
+    if engine in ("lean_escapes", "flat_escapes"):
         assert st["lean_launches"] >= 1 and st["lean_escaped"] > 0, st
+        assert (st["flat_launches"] >= 1) == (engine == "flat_escapes")
     assert_end_to_end(fetch_end_to_end(s, residuals=True), out, prm, ztol=1e-8, what=engine)
     s.close()
 
@@ -89,6 +96,7 @@ def test_lean_rounds_with_iteration_quanta(talos, monkeypatch):
     wl = feasible_batch(talos, B, link, 17, nu_scale=0.5)
     args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
     prm = dict(FIXTURE, max_iter=600, tol_abs=1e-6, tol_rel=0.0)
+    monkeypatch.setenv("LOIKB_FLAT", "0")  # (a mechanism of k_lean)
     monkeypatch.delenv("LOIKB_LEAN_QUANTA", raising=False)
     a = loik_amd.BatchedLoik(talos, B, **prm)
     a.Solve(*args)
@@ -112,6 +120,7 @@ def test_lean_time_slicing_changes_nothing(talos, monkeypatch):
     wl = feasible_batch(talos, B, link, 23, nu_scale=0.5)
     args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
     prm = dict(FIXTURE, max_iter=400, tol_abs=1e-6, tol_rel=0.0)
+    monkeypatch.setenv("LOIKB_FLAT", "0")  # (a mechanism of k_lean)
     monkeypatch.delenv("LOIKB_LEAN_SLICE", raising=False)
     a = loik_amd.BatchedLoik(talos, B, **prm)
     a.Solve(*args)
@@ -134,10 +143,14 @@ def test_lean_time_slicing_changes_nothing(talos, monkeypatch):
 def test_engine_plan_is_made_in_one_place(talos, panda7, monkeypatch):
     """loikb_plan_string: the dispatch (nb, nc, A shared?, children, options) -> engines, re-made at SolveInit when the sharing
     mode of A is known (round 1 fixed the chunk count at create with the default mode)"""
-    for v in ("LOIKB_LEAN", "LOIKB_CHUNKS", "LOIKB_LEAN_SLICE"):
+    for v in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_CHUNKS", "LOIKB_LEAN_SLICE"):
         monkeypatch.delenv(v, raising=False)
+    s = loik_amd.BatchedLoik(talos, 256, **FIXTURE)
+    assert "k_flat" in s.plan() and "1 chunk" in s.plan() and "when H_ref = h I" in s.plan(), s.plan()
+    s.close()
+    monkeypatch.setenv("LOIKB_FLAT", "0")
     s = loik_amd.BatchedLoik(talos, 40000, **dict(FIXTURE, num_eq_c=2))
-    assert "k_lean" in s.plan() and "1 chunk" in s.plan() and "8 wavefronts per CU" in s.plan()
+    assert "k_lean" in s.plan() and "1 chunk" in s.plan() and "8 wavefronts per CU" in s.plan() and "LOIKB_FLAT=0" in s.plan()
     # per-instance A with two constraints: larger constraint blocks in LDS -> the plan is re-made at SolveInit: seven
     # single-wavefront workgroups per CU instead of two 4-wavefront ones
     link = [talos.getJointId("arm_left_7_joint"), talos.getJointId("arm_right_7_joint")]

@@ -588,7 +588,9 @@ def test_concurrent_chunks_change_nothing(talos, monkeypatch):
         assert np.array_equal(one.get(name), three.get(name)), name
     for name in ["z", "nu", "w", "vis", "fis", "g", "yis", "Aty", "Stf_plus_w", "primal_residual", "dual_residual"]:
         a, b = one.get(name), three.get(name)
-        assert np.max(np.abs(a - b) / (1.0 + np.abs(b))) < 1e-10, name
+        # (the chunks hand over to the on-chip engine at different iterations; k_solve walks the tree joint by joint in the
+        #  link frames, the flat engine sums at the world origin: the two round differently, and the duals integrate it)
+        assert np.max(np.abs(a - b) / (1.0 + np.abs(b))) < 1e-9, name
     # and a second solve on the same handles (work sets and streams are re-used)
     for sol in (one, three):
         sol.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
