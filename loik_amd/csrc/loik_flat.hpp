@@ -47,6 +47,7 @@ constexpr int FLAT_JMP = 5;    // pointer-jumping rounds (tree depth <= 32)
 constexpr int FLAT_MAXA = 16;  // strict ancestors per joint (tree depth <= 17)
 constexpr int FOLDW = 10;      // scalars per lane row of the norm fold (80 B: an odd number of 16-byte slots)
 constexpr int FLAT_COUNTERS_SLOT_HITS = 12;  // Bufs::counters[12]: decade changes served from the second LDS slot
+constexpr int FLAT_NA_SMALL = 10;  // k_flat / k_fslots_b are compiled for <= 10 and <= FLAT_MAXA ancestors per joint
 
 // per lane of a group: the lane's joint (lane j <-> device joint j + 1, depth-first numbering) in the static tree
 struct FlatLane {
@@ -60,31 +61,37 @@ struct FlatLane {
 };
 
 // constraint block of an instance in LDS (T each)
-enum : int { FC_LANE = 0, FC_B = 1, FC_Y = 7, FC_ATY = 13, FC_ATYW = 19, FC_ATBW = 25, FC_DY = 31, FC_DLT = 37, FC_ATYF = 43, FC_AW = 49, FCD = 85 };
+enum : int { FC_LANE = 0, FC_B = 1, FC_Y = 7, FC_ATY = 13, FC_ATYW = 19, FC_ATBW = 25, FC_DY = 31, FC_DLT = 37, FC_ATYF = 43, FC_AW = 49, FC_A = 85,
+              FCD = 121 };  // (the block carries its own copy of A, shared or not: one constant stride, no selects in the loop)
 // per-instance scalars kept in LDS for the getters (written when an instance stops)
 enum : int { FI_BNORM = 0, FI_TGIN, FI_STY, FI_TOLP, FI_TOLD, FI_DYQP, FI_ATDY, FI_UBP, FI_LBM, FI_C1, FI_C2, FI_PRIMAL, FI_DUAL, FI_DX,
              FI_DZ, FI_MULAST, FI_RED /* 16 folded values */, FISC = FI_RED + 16 };
 
-template <typename T>
-__host__ __device__ __forceinline__ int flat_xregion(int nanc)
+// LDS of one wavefront of k_flat<T, NA> (T units unless said otherwise); the regions up to `shv` have compile-time offsets
+template <int NA>
+__host__ __device__ constexpr int flat_xregion()
 {
-  int n = XROWS * 6;                                   // scan / path-sum rows (+ the zero row)
-  if (nanc * WAVE + 2 > n) n = nanc * WAVE + 2;        // W tau products (+ a zero slot)
+  int n = XROWS * 9;                                   // placement rows of the oMi chain (R, then t), scan / path-sum rows [6]
+  if (NA * WAVE + 2 > n) n = NA * WAVE + 2;            // W tau products (+ a zero slot)
   if (WAVE * FOLDW > n) n = WAVE * FOLDW;              // norm fold rows
-  if ((WAVE + 1) * 12 > n) n = (WAVE + 1) * 12;        // placement rows of the oMi chain (when an instance is loaded)
   return (n + 1) & ~1;
 }
+template <int NA> __host__ __device__ constexpr int flat_off_wl() { return flat_xregion<NA>(); }             // [2][NA + 1][WAVE]: W rows, Dinv row
+template <int NA> __host__ __device__ constexpr int flat_off_nbuf() { return flat_off_wl<NA>() + 2 * (NA + 1) * WAVE; }  // [WAVE + 2]
+template <int NA> __host__ __device__ constexpr int flat_off_pbuf() { return flat_off_nbuf<NA>() + WAVE + 2; }         // [WAVE + 2]
+template <int NA> __host__ __device__ constexpr int flat_off_rbuf() { return flat_off_pbuf<NA>() + WAVE + 2; }         // [WAVE]
+template <int NA> __host__ __device__ constexpr int flat_off_tail() { return flat_off_rbuf<NA>() + WAVE; }
 
-template <typename T>
-__host__ __device__ __forceinline__ size_t flat_lds_bytes(int nc, int G, bool a_shared, int nanc, bool has_hv)
+template <typename T, int NA>
+__host__ __device__ __forceinline__ size_t flat_lds_bytes(int nc, int G, bool a_shared, bool has_hv)
 {
-  const size_t per_inst = (size_t)nc * (FCD + (a_shared ? 0 : LCA)) + FISC;
-  size_t n = (size_t)flat_xregion<T>(nanc) + 2 * (size_t)nanc * WAVE + 2 * (WAVE + 2) + (has_hv ? (size_t)WAVE * 6 : 0) + (a_shared ? (size_t)nc * LCA : 0) + (size_t)(WAVE / G) * per_inst;
-  n = n * sizeof(T) + (size_t)nanc * WAVE /* ancestor rows, bytes */;
-  return (n + 15) & ~(size_t)15;
+  (void)a_shared;
+  const size_t per_inst = (size_t)nc * FCD + FISC;
+  const size_t n = (size_t)flat_off_tail<NA>() + (has_hv ? (size_t)WAVE * 6 : 0) + (size_t)(WAVE / G) * per_inst;
+  return (n * sizeof(T) + 15) & ~(size_t)15;
 }
 
-// decade slot of an instance: rows [k][lane], k < nanc: W_{anc_k(lane), lane}; row nanc: Dinv
+// decade slot of an instance: frows = NA + 1 rows [k][lane]; k < NA: W_{anc_k(lane), lane} (0 beyond the joint's depth); row NA: Dinv
 __device__ __forceinline__ size_t fslot_at(int idx, int ndec, int dsl, int G, int frows, int k, int jlane)
 {
   return ((((size_t)idx * ndec + dsl) * frows + k) * G) + jlane;
@@ -109,27 +116,30 @@ __device__ __forceinline__ void se3_compose_left(const T* Ra, const T* ta, T* R,
 
 // oMi of every lane's joint by pointer jumping over liMi (4 rounds for depth <= 16): after round r, (R, t) is the placement of
 // the joint in the frame of its ancestor at distance 2^(r+1) (or in the world when the root path is shorter).  xb: scratch rows
-// of 12 scalars; row WAVE = the identity.
+// of 9 scalars (the rotations, then the translations in the same rows); row WAVE = the identity.
 template <typename T>
-__device__ __forceinline__ void flat_world_placement(T* xb, int lane, int jlane, const int* jrow, int njmp, T* R, T* t)
+__device__ __forceinline__ void flat_world_placement(T* xb, int lane, int jlane, const unsigned int* jrow4, int njmp, T* R, T* t)
 {
   // (jlane, not lane: one lane group of a wavefront may run this alone, inside a divergent branch)
-  tail_sync();
-  if (jlane < 12) xb[WAVE * 12 + jlane] = (jlane == 0 || jlane == 4 || jlane == 8) ? T(1) : T(0);
-#pragma unroll
-  for (int r = 0; r < FLAT_JMP; ++r) {
-    if (r < njmp) {
-      tail_sync();
-#pragma unroll
-      for (int k = 0; k < 9; ++k) xb[lane * 12 + k] = R[k];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) xb[lane * 12 + 9 + k] = t[k];
-      tail_sync();
+#pragma unroll 1
+  for (int r = 0; r < njmp; ++r) {
+    {
+      const int jr = (int)(((r < 4 ? jrow4[0] : jrow4[1]) >> (8 * (r & 3))) & 0xFFu);
       T Ra[9], ta[3];
+      tail_sync();
+      if (jlane < 9) xb[WAVE * 9 + jlane] = (jlane == 0 || jlane == 4 || jlane == 8) ? T(1) : T(0);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Ra[k] = xb[jrow[r] * 12 + k];
+      for (int k = 0; k < 9; ++k) xb[lane * 9 + k] = R[k];
+      tail_sync();
 #pragma unroll
-      for (int k = 0; k < 3; ++k) ta[k] = xb[jrow[r] * 12 + 9 + k];
+      for (int k = 0; k < 9; ++k) Ra[k] = xb[jr * 9 + k];
+      tail_sync();
+      if (jlane < 3) xb[WAVE * 9 + jlane] = T(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) xb[lane * 9 + k] = t[k];
+      tail_sync();
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ta[k] = xb[jr * 9 + k];
       se3_compose_left(Ra, ta, R, t);
     }
   }
@@ -170,20 +180,21 @@ __device__ __forceinline__ void flat_subtree_sum(T* rows, int lane, int jlane, i
 
 // y_i = sum over the root path of lane i (the joint and its ancestors) of the 6-vectors x: pointer jumping
 template <typename T>
-__device__ __forceinline__ void flat_path_sum(T* rows, int lane, int jlane, const int* jrow, int njmp, T* y)
+__device__ __forceinline__ void flat_path_sum(T* rows, int lane, int jlane, const unsigned int* jrow4, int njmp, T* y)
 {
   tail_sync();
   if (jlane < 6) rows[WAVE * 6 + jlane] = T(0);
-#pragma unroll
-  for (int r = 0; r < FLAT_JMP; ++r) {
-    if (r < njmp) {
+#pragma unroll 1
+  for (int r = 0; r < njmp; ++r) {
+    {
+      const int jr = (int)(((r < 4 ? jrow4[0] : jrow4[1]) >> (8 * (r & 3))) & 0xFFu);
       tail_sync();
 #pragma unroll
       for (int c = 0; c < 6; ++c) rows[lane * 6 + c] = y[c];
       tail_sync();
       T a[6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) a[c] = rows[jrow[r] * 6 + c];
+      for (int c = 0; c < 6; ++c) a[c] = rows[jr * 6 + c];
 #pragma unroll
       for (int c = 0; c < 6; ++c) y[c] += a[c];
     }
@@ -203,114 +214,125 @@ __device__ __forceinline__ void actinv_force(const T* R, const T* t, const T* F,
   mat3t_vec(R, d, o + 3);
 }
 
-// fold FOLDW-2 = 8 columns of the group's rows: columns < nmax by max, the others by sum (lane order); every lane returns
-// with all eight results.  rows: [WAVE][FOLDW]; column 8 / 9 of a row are scratch.
-template <typename T>
-__device__ __forceinline__ void flat_fold8(T* rows, int lane, int gbase, int jlane, int G, int nmax, const T* in, T* out)
+// fold 8 columns of the group's rows: columns < NMAX by max, the others by sum (lane order); every lane returns with all
+// eight results.  rows: [WAVE][FOLDW]; columns 8 / 9 of a row are scratch.
+template <typename T, int NMAX>
+__device__ __forceinline__ void flat_fold8(T* rows, int lane, int gbase, int jlane, int lgG, const T* in, T* out)
 {
   tail_sync();
   T* row = rows + lane * FOLDW;
 #pragma unroll
   for (int q = 0; q < 8; ++q) row[q] = in[q];
   tail_sync();
-  const int q = jlane & 7, part = jlane >> 3;
+  const int q = jlane & 7;
+  const bool ismax = q < NMAX;
   {
-    const T* col = rows + (gbase + part * 8) * FOLDW + q;
+    const T* col = rows + (lane & ~7) * FOLDW + q;  // the eight rows of this lane's part of the group
     T a[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) a[u] = col[u * FOLDW];
-    T red;
-    if (q < nmax) red = tmax(tmax(tmax(a[0], a[1]), tmax(a[2], a[3])), tmax(tmax(a[4], a[5]), tmax(a[6], a[7])));
-    else { red = a[0];
+    const T m = tmax(tmax(tmax(a[0], a[1]), tmax(a[2], a[3])), tmax(tmax(a[4], a[5]), tmax(a[6], a[7])));
+    T sm = a[0];
 #pragma unroll
-      for (int u = 1; u < 8; ++u) red += a[u]; }
-    row[8] = red;
+    for (int u = 1; u < 8; ++u) sm += a[u];
+    row[8] = (NMAX >= 8 || ismax) ? m : sm;
   }
   tail_sync();
   {
-    T red = rows[(gbase + q) * FOLDW + 8];
-    for (int p = 1; p < (G >> 3); ++p) {
-      const T a = rows[(gbase + p * 8 + q) * FOLDW + 8];
-      red = q < nmax ? tmax(red, a) : red + a;
-    }
-    row[9] = red;
+    const T* col = rows + (gbase + q) * FOLDW + 8;
+    T a[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) a[p] = (p < 4 || lgG > 5) ? col[p * 8 * FOLDW] : T(0);  // (G = 32: four parts, G = 64: eight)
+    const T m = tmax(tmax(tmax(a[0], a[1]), tmax(a[2], a[3])), tmax(tmax(a[4], a[5]), tmax(a[6], a[7])));
+    T sm = a[0];
+#pragma unroll
+    for (int p = 1; p < 8; ++p) sm += a[p];
+    row[9] = (NMAX >= 8 || ismax) ? m : sm;
   }
   tail_sync();
 #pragma unroll
   for (int u = 0; u < 8; ++u) out[u] = rows[(gbase + u) * FOLDW + 9];
 }
 
-template <typename T>
+// packed per-lane address tables: four lane indices (bytes) / two product indices (16 bit) per register.  The tables are
+// loop-invariant; left alone, the compiler unpacks them once before the iteration loop and keeps (spills) ~30 addresses --
+// `opaque` makes a register's content unknown to it at the point of use, so the unpacking stays where the address is needed.
+__device__ __forceinline__ unsigned int opaque(unsigned int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ int unpack8(const unsigned int* w, int k) { return (int)((opaque(w[k >> 2]) >> (8 * (k & 3))) & 0xFFu); }
+__device__ __forceinline__ int unpack16(const unsigned int* w, int k) { return (int)((opaque(w[k >> 1]) >> (16 * (k & 1))) & 0xFFFFu); }
+
+template <typename T, int NA>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc, int nscan,
-       int njmp, const int* __restrict__ ring, int nslots, int G, const T* __restrict__ fslots, int kexp_lo, int ndec, T href_s,
-       int has_hv)
+       int njmp, const int* __restrict__ ring, int nslots, int lgG, const T* __restrict__ fslots, int frows, int kexp_lo, int ndec,
+       T href_s, int has_hv)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
   const bool a_shared = P.mode & MODE_A_SHARED;
-  const int cs = FCD + (a_shared ? 0 : LCA);
+  constexpr int cs = FCD;
   const int lane = threadIdx.x;
-  const int sub = lane / G, jlane = lane % G, gbase = sub * G, glim = gbase + G;
+  const int G = 1 << lgG;
+  const int sub = lane >> lgG, jlane = lane & (G - 1), gbase = sub << lgG, glim = gbase + G;
   // ---- LDS of the wavefront (one wavefront per workgroup)
-  T* xb = reinterpret_cast<T*>(smem_raw);                 // scan rows | W tau products | fold rows (used one after the other)
-  T* wl = xb + flat_xregion<T>(nanc);                     // [2][nanc][WAVE]  W rows of two decades of mu
-  T* nbuf = wl + 2 * (size_t)nanc * WAVE;                 // [WAVE + 2]       Dinv r' of every joint (+ a zero)
-  T* pbuf = nbuf + WAVE + 2;                              // [WAVE + 2]       partial sums of long rows
-  T* shv = pbuf + WAVE + 2;                               // [WAVE][6]        subtree sums of the links' H_ref v_ref (if != 0)
-  T* ash = shv + (has_hv ? WAVE * 6 : 0);                 // [nc][36]         the shared A
-  T* cd = ash + (a_shared ? L.nc * LCA : 0);              // [64/G][nc][cs]
-  T* iscb = cd + (size_t)(WAVE / G) * L.nc * cs;          // [64/G][FISC]
-  unsigned char* ancb = reinterpret_cast<unsigned char*>(iscb + (size_t)(WAVE / G) * FISC);  // [nanc][WAVE] rows of the ancestors
-  T* cdi = cd + (size_t)sub * L.nc * cs;
-  T* isc = iscb + (size_t)sub * FISC;
+  T* const xb = reinterpret_cast<T*>(smem_raw);          // placement rows | scan rows | W tau products | fold rows (one after the other)
+  T* const wl = xb + flat_off_wl<NA>();                  // [2][NA + 1][WAVE]  W rows and the Dinv row of two decades of mu
+  T* const nbuf = xb + flat_off_nbuf<NA>();              // [WAVE + 2]         Dinv r' of every joint (+ a zero)
+  T* const pbuf = xb + flat_off_pbuf<NA>();              // [WAVE + 2]         partial sums of long rows
+  T* const rbuf = xb + flat_off_rbuf<NA>();              // [WAVE]             r' of the last iteration (stored with the instance)
+  T* const shv = xb + flat_off_tail<NA>();               // [WAVE][6]          subtree sums of the links' H_ref v_ref (if != 0)
+  T* const cd = shv + (has_hv ? WAVE * 6 : 0);           // [64/G][nc][FCD]    constraint blocks of the instances
+  T* const iscb = cd + (size_t)(WAVE >> lgG) * L.nc * cs;  // [64/G][FISC]
+  T* const cdi = cd + (size_t)sub * L.nc * cs;
+  T* const isc = iscb + (size_t)sub * FISC;
 
   const bool isj_lane = jlane < L.nb;
   const int jl = isj_lane ? jlane : 0;
   // (the joint's placement is only needed when an instance is loaded: load_instance reads the description again instead of
   //  keeping 15 scalars of it alive through the iteration loop)
   const int jflags = jd[jl + 1].flags, jcslot = isj_lane ? jd[jl + 1].cslot : -1;
-  const bool rev = jflags & JF_REVOLUTE;
   const T mass = (!isj_lane || (jflags & JF_MASSLESS)) ? T(0) : T(1);
-  T ax[3];  // S_i = [axis; 0] (prismatic) or [0; axis] (revolute); 0 on a lane without a joint
-#pragma unroll
-  for (int k = 0; k < 3; ++k) ax[k] = isj_lane ? (T)jd[jl + 1].axis[k] : T(0);
-  int size, jrow[FLAT_JMP], ra[FLAT_RED], prow[FLAT_PART];
+  int size;
+  unsigned int jrow4[(FLAT_JMP + 3) / 4], ra2[FLAT_RED / 2], prow4[(FLAT_PART + 3) / 4], anc4[(NA + 3) / 4];
   bool helper;
   {
-    // static addresses (rows of this group's lanes); helper lanes may be lanes without a joint
+    // static rows / entries of this group's lanes; helper lanes may be lanes without a joint
     const FlatLane F = fl[jlane];
     size = isj_lane ? F.size : 0;
-#pragma unroll
-    for (int r = 0; r < FLAT_JMP; ++r) jrow[r] = F.jmp[r] >= 0 ? gbase + F.jmp[r] : WAVE;
-#pragma unroll
-    for (int t = 0; t < FLAT_RED; ++t) ra[t] = F.red[t] >= 0 ? (F.red[t] / G) * WAVE + gbase + F.red[t] % G : nanc * WAVE;
-#pragma unroll
-    for (int j = 0; j < FLAT_PART; ++j) prow[j] = F.part[j] >= 0 ? gbase + F.part[j] : WAVE;
     helper = F.helper != 0;
-    for (int k = 0; k < nanc; ++k) ancb[k * WAVE + lane] = (unsigned char)((k < FLAT_MAXA && F.anc[k] >= 0) ? gbase + F.anc[k] : WAVE);
+#pragma unroll
+    for (int k = 0; k < (FLAT_JMP + 3) / 4; ++k) jrow4[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < FLAT_RED / 2; ++k) ra2[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < (FLAT_PART + 3) / 4; ++k) prow4[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < (NA + 3) / 4; ++k) anc4[k] = 0u;
+#pragma unroll
+    for (int r = 0; r < FLAT_JMP; ++r) jrow4[r >> 2] |= (unsigned int)(F.jmp[r] >= 0 ? gbase + F.jmp[r] : WAVE) << (8 * (r & 3));
+#pragma unroll
+    for (int t = 0; t < FLAT_RED; ++t)
+      ra2[t >> 1] |= (unsigned int)(F.red[t] >= 0 ? (F.red[t] >> lgG) * WAVE + gbase + (F.red[t] & (G - 1)) : NA * WAVE) << (16 * (t & 1));
+#pragma unroll
+    for (int j = 0; j < FLAT_PART; ++j) prow4[j >> 2] |= (unsigned int)(F.part[j] >= 0 ? gbase + F.part[j] : WAVE) << (8 * (j & 3));
+#pragma unroll
+    for (int k = 0; k < NA; ++k) anc4[k >> 2] |= (unsigned int)((k < FLAT_MAXA && F.anc[k] >= 0) ? gbase + F.anc[k] : WAVE) << (8 * (k & 3));
   }
-  if (lane < 2) { nbuf[WAVE + lane] = T(0); pbuf[WAVE + lane] = T(0); }
-  if (a_shared)
-    for (int e = lane; e < L.nc * LCA; e += WAVE) ash[e] = Bf.uni[e];
+  if (jlane < 2) { nbuf[WAVE + jlane] = T(0); pbuf[WAVE + jlane] = T(0); }
+#pragma unroll
+  for (int k = 0; k <= NA; ++k) { wl[k * WAVE + lane] = T(0); wl[(NA + 1 + k) * WAVE + lane] = T(0); }
 
   // ---- the instance of this lane group
-  bool has_inst = false, isj = false, done = true, any_iter = false;
+  bool has_inst = false, isj = false, done = true, any_iter = false, need_load = true;
   int lidx = 0;
   char *ip = Bf.tiles, *rec = Bf.tiles;
   T R0[9], t0[3], Sw[6], v[6], f[6], g[6], SE[6];
-  T w = T(0), z = T(0), nu = T(0), s = T(0), rp = T(0), dinv = T(0), dinv_o = T(0), lbi = T(0), ubi = T(0), mu = T(1);
+  T w = T(0), z = T(0), nu = T(0), s = T(0), lbi = T(0), ubi = T(0), mu = T(1);
   int kexp = 0, kslot = -(1 << 30), kslot_o = -(1 << 30), wsel = 0;
   int iter = 0, status = ST_DONE, tail_it = 0, nflip = 0;
   unsigned int my_iters = 0, n_wave_iters = 0, n_slot_loads = 0, n_slot_hits = 0;
   unsigned int* q_head = Bf.counters + LEAN_Q_HEAD;
 
-  auto fetch = [&]() -> int {
-    int nx = 0;
-    if (jlane == 0) nx = (int)atomicAdd(q_head, 1u);
-    nx = __shfl(nx, gbase);
-    return nx < nslots ? ring[nx] : -1;
-  };
   // constraint c: is its joint in this lane's subtree?  (1 / 0)
   auto cmask = [&](int c) -> T {
     const int cl = (int)cdi[c * cs + FC_LANE];
@@ -329,7 +351,14 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
     for (int k = 0; k < 6; ++k) E[k] *= mass;
   };
-  auto load_instance = [&](int slot_in) {
+  auto load_instance = [&]() {
+    int slot_in;
+    {
+      int nx = 0;
+      if (jlane == 0) nx = (int)atomicAdd(q_head, 1u);
+      nx = __shfl(nx, gbase);
+      slot_in = nx < nslots ? ring[nx] : -1;
+    }
     has_inst = slot_in >= 0;
     isj = has_inst && isj_lane;
     const int slot = has_inst ? slot_in : 0;
@@ -337,9 +366,13 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     ip = lane_ptr<T>(Bf.tiles, L, slot);
     rec = ip + (size_t)jl * JREC * pair_bytes<T>();
     const char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+    T ax[3];
+    const bool rev = jflags & JF_REVOLUTE;
     {
       const typename Vec2<T>::type csn = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
       const JointDesc d = jd[jl + 1];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ax[k] = isj_lane ? (T)d.axis[k] : T(0);
       joint_xform<T>(d, rec, csn.x, csn.y, R0, t0);  // liMi ...
       ld6<T>(rec, JP_V, v);
       ld6<T>(rec, JP_F, f);
@@ -362,7 +395,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       for (int k = 0; k < 6; ++k) { v[k] = T(0); f[k] = T(0); g[k] = T(0); }
       w = z = nu = s = T(0);
     }
-    flat_world_placement<T>(xb, lane, jlane, jrow, njmp, R0, t0);  // ... -> oMi (FwdPassInit's oMi chain, hxx:265)
+    flat_world_placement<T>(xb, lane, jlane, jrow4, njmp, R0, t0);  // ... -> oMi (FwdPassInit's oMi chain, hxx:265)
     {
       // S^w: the joint's motion subspace at the world origin (R0 S_l + t0 x R0 S_a, R0 S_a)
       T ra3[3], c[3];
@@ -379,37 +412,34 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         const int which = jlane / 6, k = jlane % 6;
         const int pair = which == 0 ? CP_B : which == 1 ? CP_Y : CP_ATY;
         const int dst = which == 0 ? FC_B : which == 1 ? FC_Y : FC_ATY;
-        const T val = *reinterpret_cast<const T*>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
-        c_[dst + k] = val;
+        c_[dst + k] = *reinterpret_cast<const T*>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
       }
-      if (!a_shared)
-        for (int e = jlane; e < LCA; e += G)
-          c_[FCD + e] = *reinterpret_cast<const T*>(crec + (size_t)(CP_A + e / 2) * pair_bytes<T>() + (e & 1) * sizeof(T));
+      for (int e = jlane; e < LCA; e += G)
+        c_[FC_A + e] = a_shared ? Bf.uni[c * LCA + e]
+                                : *reinterpret_cast<const T*>(crec + (size_t)(CP_A + e / 2) * pair_bytes<T>() + (e & 1) * sizeof(T));
     }
     if (jcslot >= 0) cdi[jcslot * cs + FC_LANE] = (T)jlane;
     tail_sync();
-    for (int c = 0; c < L.nc; ++c) {
-      T* c_ = cdi + c * cs;
-      const T* A_ = a_shared ? ash + c * LCA : c_ + FCD;
-      if (jcslot == c) {  // the constrained joint's lane: column j of AW = row j of A carried to the world origin
+    if (jcslot >= 0) {  // the constrained joint's lane: column j of AW = row j of A carried to the world origin
+      T* c_ = cdi + jcslot * cs;
+      const T* A_ = c_ + FC_A;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          T aj[6], o[6];
+      for (int j = 0; j < 6; ++j) {
+        T aj[6], o[6];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) aj[k] = A_[6 * j + k];
-          act_force(R0, t0, aj, o);
+        for (int k = 0; k < 6; ++k) aj[k] = A_[6 * j + k];
+        act_force(R0, t0, aj, o);
 #pragma unroll
-          for (int k = 0; k < 6; ++k) c_[FC_AW + 6 * k + j] = o[k];
-        }
-        // A^T y as the instance brings it (a warm-started tailored solve arrives with the A^T y of the matrix it had BEFORE
-        // UpdateEqConstraint replaced it, and upstream's first FwdPass1 uses exactly that, hxx:329-331), at the world origin
-        T ay[6], o[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) ay[k] = c_[FC_ATY + k];
-        act_force(R0, t0, ay, o);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) c_[FC_ATYW + k] = o[k];
+        for (int k = 0; k < 6; ++k) c_[FC_AW + 6 * k + j] = o[k];
       }
+      // A^T y as the instance brings it (a warm-started tailored solve arrives with the A^T y of the matrix it had BEFORE
+      // UpdateEqConstraint replaced it, and upstream's first FwdPass1 uses exactly that, hxx:329-331), at the world origin
+      T ay[6], o[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ay[k] = c_[FC_ATY + k];
+      act_force(R0, t0, ay, o);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) c_[FC_ATYW + k] = o[k];
     }
     tail_sync();
     for (int c = 0; c < L.nc; ++c) {
@@ -425,7 +455,6 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     // subtree sums of the state the instance arrives with (cold start: v = 0) and of the reference term
     {
       T vw[6], E[6];
-      // world-frame motion of the link from its local velocity
       T a[3], l[3], c[3];
       mat3_vec(R0, v, l);
       mat3_vec(R0, v + 3, a);
@@ -476,10 +505,9 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       if (any_iter) {
         // inter-sweep temporaries of the last iteration: r_i and Dinv_i.  This engine forms neither UDinv_i nor the
         // accumulated p_i: the scalar record's tag says so (SP_TAG = -2) and the getters rebuild them (k_rebuild_ud).
-        stp<T>(rec, JP_R, rp, dinv);
+        stp<T>(rec, JP_R, rbuf[lane], wl[(wsel * (NA + 1) + NA) * WAVE + lane]);
       }
     }
-    tail_sync();
     if (has_inst) {
       for (int c = 0; c < L.nc; ++c) {
         char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
@@ -520,18 +548,18 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     tail_sync();
   };
 
-  load_instance(fetch());
 #ifdef LOIKB_TAIL_PROF
   unsigned long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
   const unsigned long long wall0_ = wall_clock64(), clk0_ = tprev_;
 #endif
-  while (__any(!done || has_inst)) {
+  while (true) {
+    if (need_load) { load_instance(); need_load = false; }
+    if (!__any(has_inst)) break;
     // ---- decade of mu: W rows and Dinv.  Two decades stay in LDS: a flip back to the previous one costs nothing.
     if (!done && (int)my_iters >= P.max_launch_iters) done = true;
     if (!done && kexp != kslot) {
       if (kexp == kslot_o) {
         { const int tk = kslot; kslot = kslot_o; kslot_o = tk; }
-        { const T td = dinv; dinv = dinv_o; dinv_o = td; }
         wsel ^= 1;
         ++n_slot_hits;
       } else {
@@ -540,24 +568,25 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
           done = true;  // mu left the precomputed decades: written back unfinished, k_tail takes over
           if (jlane == 0) atomicAdd(&Bf.counters[2], 1u);
         } else {
-          // the slot that was not used last is overwritten
-          kslot_o = kslot; dinv_o = dinv;
+          kslot_o = kslot;  // the slot that was not used last is overwritten
           wsel ^= 1;
-          T* wdst = wl + (size_t)wsel * nanc * WAVE;
+          T* wdst = wl + (size_t)wsel * (NA + 1) * WAVE;
           if (isj) {
-            for (int k = 0; k < nanc; ++k) wdst[k * WAVE + lane] = fslots[fslot_at(lidx, ndec, dsl, G, nanc + 1, k, jlane)];
-            dinv = fslots[fslot_at(lidx, ndec, dsl, G, nanc + 1, nanc, jlane)];
+            T in[NA + 1];
+#pragma unroll
+            for (int k = 0; k <= NA; ++k) in[k] = fslots[fslot_at(lidx, ndec, dsl, G, NA + 1, k, jlane)];
+#pragma unroll
+            for (int k = 0; k <= NA; ++k) wdst[k * WAVE + lane] = in[k];
           } else {
-            for (int k = 0; k < nanc; ++k) wdst[k * WAVE + lane] = T(0);
-            dinv = T(0);
+#pragma unroll
+            for (int k = 0; k <= NA; ++k) wdst[k * WAVE + lane] = T(0);
           }
           kslot = kexp;
           n_slot_loads = (n_slot_loads + 0x10000u) | (1u << dsl);
         }
       }
     }
-    // (a group's W slot selection is per group: wsel differs between the two groups of a wavefront)
-    const T* wcur = wl + (size_t)wsel * nanc * WAVE;
+    const T* wcur = wl + (size_t)wsel * (NA + 1) * WAVE;  // (per lane group: wsel differs between the groups of a wavefront)
     TAIL_TP(8)
     const bool act = !done;
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
@@ -565,6 +594,10 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     ++n_wave_iters;
 
     // ================= p^base at the world origin, summed over the subtrees; tau  (FwdPass1 + the p part of BwdPass) ===========
+    T wc[NA];  // this joint's W entries (its ancestors' rows): used twice, up and down
+#pragma unroll
+    for (int k = 0; k < NA; ++k) wc[k] = wcur[k * WAVE + lane];
+    const T dinv = wcur[NA * WAVE + lane];
     T tau;
     {
       T PB[6];
@@ -585,24 +618,26 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     TAIL_TP(0)
     // ================= r' = W tau: products to LDS, every lane sums its share, long rows collect their partials ================
     tail_sync();
-    for (int k = 0; k < nanc; ++k) xb[k * WAVE + lane] = wcur[k * WAVE + lane] * tau;
-    if (jlane == 0) { xb[nanc * WAVE] = T(0); xb[nanc * WAVE + 1] = T(0); }
+#pragma unroll
+    for (int k = 0; k < NA; ++k) xb[k * WAVE + lane] = wc[k] * tau;
+    if (jlane == 0) { xb[NA * WAVE] = T(0); xb[NA * WAVE + 1] = T(0); }
     tail_sync();
+    T rn;
     {
       T a[FLAT_RED];
 #pragma unroll
-      for (int t = 0; t < FLAT_RED; ++t) a[t] = xb[ra[t]];
+      for (int t = 0; t < FLAT_RED; ++t) a[t] = xb[unpack16(ra2, t)];
       T acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
       pbuf[lane] = helper ? acc : T(0);
       tail_sync();
       T pp[FLAT_PART];
 #pragma unroll
-      for (int j = 0; j < FLAT_PART; ++j) pp[j] = pbuf[prow[j]];
+      for (int j = 0; j < FLAT_PART; ++j) pp[j] = pbuf[unpack8(prow4, j)];
       if (helper) acc = T(0);
 #pragma unroll
       for (int j = 0; j < FLAT_PART; ++j) acc += pp[j];
-      const T rn = tau + acc;
-      if (act) rp = rn;
+      rn = tau + acc;
+      if (act) rbuf[lane] = rn;
       nbuf[lane] = dinv * rn;
     }
     tail_sync();
@@ -610,18 +645,24 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     // ================= nu = -W^T (Dinv r')  (FwdPass2's nu_i, hxx:127) ======================================================
     T nui;
     {
-      T acc = nbuf[lane];
-      for (int k = 0; k < nanc; ++k) acc += wcur[k * WAVE + lane] * nbuf[ancb[k * WAVE + lane]];
+      T nb_[NA];
+#pragma unroll
+      for (int k = 0; k < NA; ++k) nb_[k] = nbuf[unpack8(anc4, k)];
+      T acc = dinv * rn;
+#pragma unroll
+      for (int k = 0; k < NA; ++k) acc += wc[k] * nb_[k];
       nui = -acc;
     }
     // ================= v = J nu: path sum of S^w nu at the world origin, then into the link frame (hxx:125-134) ===============
-    T vw[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) vw[k] = Sw[k] * nui;
-    flat_path_sum<T>(xb, lane, jlane, jrow, njmp, vw);
     T vi[6], E[6];
-    actinv_motion(R0, t0, vw, vi);
-    force_of_motion(vw, E);
+    {
+      T vw[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vw[k] = Sw[k] * nui;
+      flat_path_sum<T>(xb, lane, jlane, jrow4, njmp, vw);
+      actinv_motion(R0, t0, vw, vi);
+      force_of_motion(vw, E);
+    }
     TAIL_TP(2)
     // ================= DualUpdate of the task constraints (hxx:410-451), six lanes of the group ================================
     T l_dyis = T(0), l_av = T(0), l_prt = T(0), l_up = T(0), l_lm = T(0);
@@ -633,7 +674,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     tail_sync();
     for (int c = 0; c < L.nc; ++c) {
       T* c_ = cdi + c * cs;
-      const T* A_ = a_shared ? ash + c * LCA : c_ + FCD;
+      const T* A_ = c_ + FC_A;
       if (act && jlane < 6) {
         const int k = jlane;
         const T* vc = xb + (gbase + (int)c_[FC_LANE]) * 6;
@@ -656,7 +697,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     tail_sync();
     for (int c = 0; c < L.nc; ++c) {
       T* c_ = cdi + c * cs;
-      const T* A_ = a_shared ? ash + c * LCA : c_ + FCD;
+      const T* A_ = c_ + FC_A;
       if (act && jlane < 6) {
         // A^T y (hxx:422) and the same at the world origin; and the two pieces of THIS iteration's force balance that are not
         // A^T y of the new dual: the constraint's share of H^base v + p^base is A^T dy + (the A^T y FwdPass1 used), which is
@@ -677,7 +718,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     }
     TAIL_TP(4)
     // ================= f by force balance at the world origin: one subtree sum (BwdPass2's transport, hxx:210-212) =============
-    T fi[6];
+    T fi[6], si;
     {
       T SEn[6], Fw[6];
       flat_subtree_sum<T>(xb, lane, jlane, glim, size, nscan, E, SEn);
@@ -694,6 +735,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         for (int k = 0; k < 6; ++k) Fw[k] += m * c_[FC_ATYF + k];
       }
       actinv_force(R0, t0, Fw, fi);
+      si = dot6_halves(Sw, Fw);  // S^T f (hxx:231-233): the pairing of a motion and a force does not depend on the frame
       if (act) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) SE[k] = SEn[k];
@@ -710,7 +752,11 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         df[k] = fi[k] - f[k];
         dv6[k] = vi[k] - v[k];
         // g_i = A^T y_i + sum_children act(f_c) - f_i = A^T y_i - (H^base_i v_i + p^base_i)  (force balance)
-        gi[k] = -mass * (P.rho * dv6[k] + href_s * vi[k] - P.Hv[k]);
+        gi[k] = -mass * (P.rho * dv6[k] + href_s * vi[k]);
+      }
+      if (has_hv) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gi[k] += mass * P.Hv[k];
       }
       if (jcslot >= 0) {
 #pragma unroll
@@ -719,7 +765,11 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         dg[k] = gi[k] - g[k];
-        dvr[k] = mass * (href_s * vi[k] - P.Hv[k]) + gi[k];  // dual residual, v block (hxx:228)
+        dvr[k] = mass * (href_s * vi[k]) + gi[k];  // dual residual, v block (hxx:228): H_ref v - Hv + g
+      }
+      if (has_hv) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dvr[k] -= mass * P.Hv[k];
       }
       l_dualv = inf6(dvr);
       l_nu = tabs(nui);
@@ -738,7 +788,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       w = w + dwi; z = zi; nu = nui;
       l_dg = inf6(dg);
       l_g = inf6(gi);
-      const T si = (rev ? (ax[0] * fi[3] + ax[1] * fi[4] + ax[2] * fi[5]) : (ax[0] * fi[0] + ax[1] * fi[1] + ax[2] * fi[2])) + w;
+      si += w;
       l_stf = tabs(si);
       l_dstf = tabs(si - s);
       s = si;
@@ -751,71 +801,59 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     {
       T in[8] = {tmax(l_prt, l_prs), tmax(l_dualv, l_stf), tmax(l_dvis, l_dnu), l_dz,
                  tmax(l_dfis, tmax(l_dyis, l_dw)), tmax(l_dg, l_dstf), l_up, l_lm};
-      flat_fold8<T>(xb, lane, gbase, jlane, G, 6, in, red);
+      flat_fold8<T, 6>(xb, lane, gbase, jlane, lgG, in, red);
     }
     T ntol_p = T(0), ntol_d = T(0);
     if (P.tol_rel != T(0)) {  // (uniform) relative tolerances need two more maxima
       T in2[8] = {tmax(l_av, l_nu), tmax(tmax(l_hrefv, l_g), l_stf), T(0), T(0), T(0), T(0), T(0), T(0)}, r2[8];
-      flat_fold8<T>(xb, lane, gbase, jlane, G, 8, in2, r2);
+      flat_fold8<T, 8>(xb, lane, gbase, jlane, lgG, in2, r2);
       ntol_p = r2[0]; ntol_d = r2[1];
     }
     TAIL_TP(6)
-    bool finishing = false;
+    // ================= CheckConvergence, CheckFeasibility, UpdateMu, the tail solve's stopping rule (hpp:377-454, :271-319) ====
+    // without branches: every lane of the group evaluates the same scalars
+    const T primal = red[0], dual = red[1], dx = red[2], dz = red[3], dyqp = red[4], atdy = red[5], ubp = red[6], lbm = red[7];
     const T mu_used = mu;
-    if (act) {
-      const T primal = red[0], dual = red[1], dx = red[2], dz = red[3];
-      ++iter;
-      bool tol_computed = false, feas_checked = false;
-      T tol_p = T(0), tol_d = T(0), dyqp = T(0), atdy = T(0), ubp = T(0), lbm = T(0);
-      int c1 = 0, c2 = 0;
-      if (P.mode & MODE_FIXED_ITERS) {
-        if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
-      } else if (!(status & ST_TAIL)) {
-        tol_computed = true;
-        tol_p = P.tol_abs + P.tol_rel * tmax(ntol_p, isc[FI_BNORM]);
-        tol_d = P.tol_abs + P.tol_rel * tmax(ntol_d, P.Hv_inf_norm);
-        const bool conv = (primal < tol_p) && (dual < tol_d);
-        bool infeas = false;
-        if (iter > 1) {
-          feas_checked = true;
-          dyqp = red[4]; atdy = red[5]; ubp = red[6]; lbm = red[7];
-          c1 = atdy <= P.tol_primal_inf * dyqp;
-          c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp;
-          infeas = c1 && c2;
-        }
-        if (conv) {
-          status |= ST_CONVERGED | ST_DONE;
-          if (infeas) status |= ST_PRIMAL_INF;
-          done = true;
-        } else if (infeas) {
-          status |= ST_PRIMAL_INF | ST_TAIL;
-          tail_it = 0;
-          if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
-        } else {
-          if (primal > T(10) * dual) { mu *= T(10); ++kexp; ++nflip; }
-          else if (dual > T(10) * primal) { mu *= T(0.1); --kexp; ++nflip; }
-          if (iter + 1 >= P.max_iter) { status |= ST_DONE; done = true; }
-        }
-      } else {
-        tail_it += 1;
-        if (!(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || iter >= P.max_iter) { status |= ST_DONE; done = true; }
-      }
-      finishing = done;
-      if (jlane == 0) {
+    const bool fixed = P.mode & MODE_FIXED_ITERS;
+    const bool in_tail = (status & ST_TAIL) != 0;
+    const bool logic = act && !fixed && !in_tail;  // the main loop's stopping logic runs
+    const T tol_p = P.tol_abs + P.tol_rel * tmax(ntol_p, isc[FI_BNORM]);
+    const T tol_d = P.tol_abs + P.tol_rel * tmax(ntol_d, P.Hv_inf_norm);
+    const int itn = iter + (act ? 1 : 0);
+    const bool conv = logic && (primal < tol_p) && (dual < tol_d);
+    const bool feas_chk = logic && itn > 1;
+    const bool c1 = atdy <= P.tol_primal_inf * dyqp, c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp;
+    const bool infeas = feas_chk && c1 && c2;
+    const bool enter_tail = infeas && !conv;
+    const bool upd = logic && !conv && !infeas;
+    const bool mu_up = upd && (primal > T(10) * dual), mu_dn = upd && !mu_up && (dual > T(10) * primal);
+    const bool tail_stop = !(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || itn >= P.max_iter;
+    const bool stop = act && (conv || ((enter_tail || in_tail) && tail_stop) || ((upd || fixed) && itn + 1 >= P.max_iter));
+    iter = itn;
+    status |= (conv ? ST_CONVERGED : 0) | (infeas ? ST_PRIMAL_INF : 0) | (enter_tail ? ST_TAIL : 0) | (stop ? ST_DONE : 0);
+    tail_it = enter_tail ? 0 : (act && in_tail ? tail_it + 1 : tail_it);
+    mu = mu_up ? mu * T(10) : (mu_dn ? mu * T(0.1) : mu);
+    kexp += (mu_up ? 1 : 0) - (mu_dn ? 1 : 0);
+    nflip += (mu_up || mu_dn) ? 1 : 0;
+    done = done || stop;
+    const bool finishing = stop;
+    const bool leaving = done && has_inst;
+    // ---- what the getters report: written when an instance stops (the certificate's scalars also when it enters the tail
+    // solve: they keep the values of the last iteration that evaluated them) -------------------------------------------------
+    if (__any(finishing || enter_tail)) {
+      if ((finishing || enter_tail) && jlane == 0) {
         isc[FI_PRIMAL] = primal; isc[FI_DUAL] = dual; isc[FI_DX] = dx; isc[FI_DZ] = dz; isc[FI_MULAST] = mu_used;
-        if (tol_computed) { isc[FI_TOLP] = tol_p; isc[FI_TOLD] = tol_d; }
-        if (feas_checked) {
-          isc[FI_C1] = (T)c1; isc[FI_C2] = (T)c2; isc[FI_DYQP] = dyqp; isc[FI_ATDY] = atdy; isc[FI_UBP] = ubp; isc[FI_LBM] = lbm;
+        if (logic) { isc[FI_TOLP] = tol_p; isc[FI_TOLD] = tol_d; }
+        if (feas_chk) {
+          isc[FI_C1] = (T)(c1 ? 1 : 0); isc[FI_C2] = (T)(c2 ? 1 : 0); isc[FI_DYQP] = dyqp; isc[FI_ATDY] = atdy; isc[FI_UBP] = ubp; isc[FI_LBM] = lbm;
         }
       }
     }
-    const bool leaving = done && has_inst;
-    // ---- the norms the getters report: only when some instance of the wavefront stops --------------------------------------
     if (__any(finishing)) {
       T in1[8] = {l_prt, l_prs, l_stf, l_dvis, l_dnu, l_dfis, l_dyis, l_dw}, in2[8] = {l_av, l_nu, l_hrefv, l_g, l_dualv, T(0), T(0), T(0)};
       T r1[8], r2[8];
-      flat_fold8<T>(xb, lane, gbase, jlane, G, 8, in1, r1);
-      flat_fold8<T>(xb, lane, gbase, jlane, G, 8, in2, r2);
+      flat_fold8<T, 8>(xb, lane, gbase, jlane, lgG, in1, r1);
+      flat_fold8<T, 8>(xb, lane, gbase, jlane, lgG, in2, r2);
       if (finishing && jlane == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) isc[FI_RED + k] = r1[k];
@@ -826,7 +864,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     }
     if (leaving) {
       store_instance();
-      load_instance(fetch());
+      need_load = true;
     }
     TAIL_TP(7)
   }
@@ -848,72 +886,46 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Decade slots of the flat engine: W_{a,d} (d below a) and Dinv_d of every listed instance for mu = mu0 * 10^(kexp_lo + s).
-// Pass A: the H recursion of k_hslots (hxx:290-338, :31-81, H part), as a pipeline of the decades over the tree levels; a
-// joint that has its UDinv for a decade carries it to the world origin and leaves L_{a,d} = S^w_a . UDinv^w_d for its ancestors
-// a (and Dinv_d) in the instance's slot.  Pass B: per decade, the joints' L columns go to LDS and every joint inverts its
-// column of the unit-triangular factor:  W_{a,d} = -(L_{a,d} + sum_{e strictly between a and d} L_{a,e} W_{e,d}), nearest
-// ancestor first; the slot rows are overwritten with W.
+// k_fslots_a: the H recursion of k_hslots (hxx:290-338, :31-81, H part), as a pipeline of the decades over the tree levels; a
+// joint that has its UDinv for a decade leaves it (six scalars, link frame) and Dinv in the instance's slot rows 0..6.
+// k_fslots_b: per decade, every joint carries its UDinv to the world origin, L_{a,d} = S^w_a . UDinv^w_d for its ancestors a go
+// to LDS, and the joint inverts its column of the unit-triangular factor:
+//   W_{a,d} = -(L_{a,d} + sum_{e strictly between a and d} L_{a,e} W_{e,d}),  nearest ancestor first;
+// the slot rows are overwritten with W (rows 0 .. NA-1) and Dinv (row NA).  A slot has NA + 1 >= 11 rows.
 // ------------------------------------------------------------------------------------------------------------------------
 template <typename T, bool HDIAG>
 __global__ void __launch_bounds__(WAVE)
-k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
-         const int* __restrict__ child_list, const FlatLane* __restrict__ fl, int maxdepth, int nanc, int njmp,
-         const int* __restrict__ slots, int nslots, int G, T* __restrict__ fslots, int kexp_lo, int ndec)
+k_fslots_a(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
+           const int* __restrict__ child_list, int maxdepth, int frows, const int* __restrict__ slots, int nslots, int G,
+           T* __restrict__ fslots, int kexp_lo, int ndec)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
   constexpr int HX = 22;
-  T* xch = reinterpret_cast<T*>(smem_raw);        // [WAVE + 1][22]: the projected, transported H of a child | placement rows [12]
-  T* swt = xch + (WAVE + 1) * HX;                 // [WAVE + 1][6]: S^w of every lane's joint (+ a zero row)
-  T* lb = swt + (WAVE + 1) * 6;                   // [nanc][WAVE] + 2: L columns of one decade (+ zero)
+  T* xch = reinterpret_cast<T*>(smem_raw);        // [WAVE + 1][22]: the projected, transported H of a child
   const int lane = threadIdx.x;
   const int ipw = WAVE / G;
   const int sub = lane / G, jlane = lane % G, gbase = sub * G;
   const int idx = blockIdx.x * ipw + sub;
   const bool has_inst = idx < nslots;
-  const bool isj_lane = jlane < L.nb;
-  const bool isj = has_inst && isj_lane;
-  const int jl = isj_lane ? jlane : 0;
+  const bool isj = has_inst && jlane < L.nb;
+  const int jl = jlane < L.nb ? jlane : 0;
   const JointDesc d = jd[jl + 1];
   const TailTopo tp = topo[jl + 1];
-  const FlatLane F = fl[jlane];
-  const int depth = isj_lane ? tp.depth : 0;
+  const int depth = jlane < L.nb ? tp.depth : 0;
   const bool rev = d.flags & JF_REVOLUTE;
   const T mass = (d.flags & JF_MASSLESS) ? T(0) : T(1);
   const bool has_parent = !(d.flags & JF_PARENT_ROOT);
   const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
-  const int slot = slots[has_inst ? idx : 0];
-  const int sidx = slot;
-  char* ip = lane_ptr<T>(Bf.tiles, L, slot);
+  const int sidx = slots[has_inst ? idx : 0];
+  char* ip = lane_ptr<T>(Bf.tiles, L, sidx);
   const char* rec = ip + (size_t)jl * JREC * pair_bytes<T>();
-  int jrow[FLAT_JMP], arow[FLAT_MAXA];
-#pragma unroll
-  for (int r = 0; r < FLAT_JMP; ++r) jrow[r] = (isj_lane && F.jmp[r] >= 0) ? gbase + F.jmp[r] : WAVE;
-#pragma unroll
-  for (int k = 0; k < FLAT_MAXA; ++k) arow[k] = (isj_lane && F.anc[k] >= 0) ? gbase + F.anc[k] : WAVE;
-  T R[9], t[3], R0[9], t0[3];
+  T R[9], t[3];
   {
     const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS);
     joint_xform<T>(d, rec, cs.x, cs.y, R, t);
   }
-#pragma unroll
-  for (int k = 0; k < 9; ++k) R0[k] = isj_lane ? R[k] : ((k % 4 == 0) ? T(1) : T(0));
-#pragma unroll
-  for (int k = 0; k < 3; ++k) t0[k] = isj_lane ? t[k] : T(0);
-  flat_world_placement<T>(xch, lane, jlane, jrow, njmp, R0, t0);
-  {
-    T Sv[6], a[3], l[3], c[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { Sv[k] = (rev || !isj_lane) ? T(0) : (T)d.axis[k]; Sv[3 + k] = (rev && isj_lane) ? (T)d.axis[k] : T(0); }
-    mat3_vec(R0, Sv, l);
-    mat3_vec(R0, Sv + 3, a);
-    cross3(t0, a, c);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { swt[lane * 6 + k] = l[k] + c[k]; swt[lane * 6 + 3 + k] = a[k]; }
-    if (lane < 6) swt[WAVE * 6 + lane] = T(0);
-    if (lane < HX) xch[WAVE * HX + lane] = T(0);
-  }
-  tail_sync();
+  if (lane < HX) xch[WAVE * HX + lane] = T(0);
   T ata[21];
 #pragma unroll
   for (int k = 0; k < 21; ++k) ata[k] = T(0);
@@ -923,11 +935,9 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
       ata[k] = (P.mode & MODE_A_SHARED) ? Bf.uni[L.nc * 36 + d.cslot * 21 + k]
                                         : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
   }
-  const int frows = nanc + 1;
   T mu = P.mu0;
   for (int k = 0; k < kexp_lo; ++k) mu *= T(10);
   for (int k = 0; k > kexp_lo; --k) mu *= T(0.1);
-  // ---- pass A
   const int lag = maxdepth - depth;
   for (int st = 0; st < maxdepth + ndec - 1; ++st) {
     const int dsl = st - lag;
@@ -950,7 +960,7 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
 #pragma unroll
         for (int k = 0; k < 21; ++k) hh[k] += x[k];
       }
-      T U[6], UD[6], UDw[6];
+      T U[6], UD[6];
       T dinv;
       if (rev) {
 #pragma unroll
@@ -963,11 +973,9 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
       }
 #pragma unroll
       for (int k = 0; k < 6; ++k) UD[k] = U[k] * dinv;
-      act_force(R0, t0, UD, UDw);
 #pragma unroll
-      for (int k = 0; k < FLAT_MAXA; ++k)
-        if (k < nanc) fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] = dot6_halves(swt + arow[k] * 6, UDw);
-      fslots[fslot_at(sidx, ndec, dsl, G, frows, nanc, jlane)] = dinv;
+      for (int k = 0; k < 6; ++k) fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] = UD[k];
+      fslots[fslot_at(sidx, ndec, dsl, G, frows, 6, jlane)] = dinv;
       if (has_parent) {
 #pragma unroll
         for (int a = 0; a < 6; ++a)
@@ -985,35 +993,89 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
     }
     tail_sync();
   }
-  // ---- pass B (every lane reads back the L column it wrote itself)
-  __builtin_amdgcn_s_waitcnt(0);
-  if (lane < 2) lb[nanc * WAVE + lane] = T(0);
-  for (int dsl = 0; dsl < ndec; ++dsl) {
-    T Lc[FLAT_MAXA], Wc[FLAT_MAXA];
+}
+
+template <typename T, int NA>
+__global__ void __launch_bounds__(WAVE)
+k_fslots_b(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc, int frows,
+           int njmp, const int* __restrict__ slots, int nslots, int G, T* __restrict__ fslots, int ndec)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Layout& L = P.L;
+  T* xb = reinterpret_cast<T*>(smem_raw);         // [WAVE + 1][9]: placement rows
+  T* swt = xb + (WAVE + 1) * 9;                   // [WAVE + 1][6]: S^w of every lane's joint (+ a zero row)
+  T* lb = swt + (WAVE + 1) * 6;                   // [NA][WAVE] + WAVE: L columns of one decade (+ zeros)
+  const int lane = threadIdx.x;
+  const int ipw = WAVE / G;
+  const int sub = lane / G, jlane = lane % G, gbase = sub * G;
+  const int idx = blockIdx.x * ipw + sub;
+  const bool has_inst = idx < nslots;
+  const bool isj_lane = jlane < L.nb;
+  const bool isj = has_inst && isj_lane;
+  const int jl = isj_lane ? jlane : 0;
+  const int sidx = slots[has_inst ? idx : 0];
+  int depth, arow[NA];
+  T R0[9], t0[3];
+  {
+    const JointDesc d = jd[jl + 1];
+    const FlatLane F = fl[jlane];
+    depth = isj_lane ? F.depth : 0;
+    unsigned int jrow4[(FLAT_JMP + 3) / 4] = {0u, 0u};
 #pragma unroll
-    for (int k = 0; k < FLAT_MAXA; ++k) {
-      Lc[k] = (k < nanc && isj && k < depth - 1) ? fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] : T(0);
+    for (int r = 0; r < FLAT_JMP; ++r) jrow4[r >> 2] |= (unsigned int)(F.jmp[r] >= 0 ? gbase + F.jmp[r] : WAVE) << (8 * (r & 3));
+#pragma unroll
+    for (int k = 0; k < NA; ++k) arow[k] = (k < FLAT_MAXA && F.anc[k] >= 0) ? gbase + F.anc[k] : WAVE;
+    char* ip = lane_ptr<T>(Bf.tiles, L, sidx);
+    const char* rec = ip + (size_t)jl * JREC * pair_bytes<T>();
+    const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS);
+    joint_xform<T>(d, rec, cs.x, cs.y, R0, t0);
+    if (!isj_lane) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R0[k] = (k % 4 == 0) ? T(1) : T(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t0[k] = T(0);
+    }
+    flat_world_placement<T>(xb, lane, jlane, jrow4, njmp, R0, t0);
+    const bool rev = d.flags & JF_REVOLUTE;
+    T ax[3], ra3[3], c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ax[k] = isj_lane ? (T)d.axis[k] : T(0);
+    mat3_vec(R0, ax, ra3);
+    cross3(t0, ra3, c);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { swt[lane * 6 + k] = rev ? c[k] : ra3[k]; swt[lane * 6 + 3 + k] = rev ? ra3[k] : T(0); }
+    if (lane < 6) swt[WAVE * 6 + lane] = T(0);
+  }
+  lb[NA * WAVE + lane] = T(0);
+  tail_sync();
+  for (int dsl = 0; dsl < ndec; ++dsl) {
+    T UD[6], UDw[6], dinv = T(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) UD[k] = isj ? fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] : T(0);
+    if (isj) dinv = fslots[fslot_at(sidx, ndec, dsl, G, frows, 6, jlane)];
+    act_force(R0, t0, UD, UDw);
+    T Lc[NA], Wc[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      Lc[k] = dot6_halves(swt + arow[k] * 6, UDw);
       Wc[k] = T(0);
     }
     tail_sync();
 #pragma unroll
-    for (int k = 0; k < FLAT_MAXA; ++k)
-      if (k < nanc) lb[k * WAVE + lane] = Lc[k];
+    for (int k = 0; k < NA; ++k) lb[k * WAVE + lane] = Lc[k];
     tail_sync();
 #pragma unroll
-    for (int k = FLAT_MAXA - 1; k >= 0; --k) {
-      if (k < nanc) {
-        T acc = Lc[k];
+    for (int k = NA - 1; k >= 0; --k) {
+      T acc = Lc[k];
 #pragma unroll
-        for (int k2 = k + 1; k2 < FLAT_MAXA; ++k2)
-          if (k2 < nanc) acc += lb[k * WAVE + arow[k2]] * Wc[k2];
-        Wc[k] = (k < depth - 1) ? -acc : T(0);
-      }
+      for (int k2 = k + 1; k2 < NA; ++k2) acc += lb[k * WAVE + arow[k2]] * Wc[k2];
+      Wc[k] = (k < depth - 1) ? -acc : T(0);
     }
     if (isj) {
 #pragma unroll
-      for (int k = 0; k < FLAT_MAXA; ++k)
-        if (k < nanc) fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] = Wc[k];
+      for (int k = 0; k < NA; ++k)
+        fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] = Wc[k];
+      fslots[fslot_at(sidx, ndec, dsl, G, frows, NA, jlane)] = dinv;
     }
   }
 }

@@ -968,7 +968,8 @@ int ensure_hslots(loikb_solver_impl* S)
   if (S->plan.flat && (flat_applicable(S) || !S->have_problem)) {
     // decade slots of the flat engine: (ancestors + 1) scalars per lane, decade and instance
     for (Chunk& C : S->chunks) {
-      const size_t need = (size_t)C.B * S->plan.ndec * (S->flat.nanc + 1) * S->flat.G * S->esz;
+      const int frows = (S->flat.nanc <= FLAT_NA_SMALL ? FLAT_NA_SMALL : FLAT_MAXA) + 1;
+      const size_t need = (size_t)C.B * S->plan.ndec * frows * S->flat.G * S->esz;
       if (need <= C.fslots_bytes) continue;
       if (C.d_fslots) HIPCHK(hipFree(C.d_fslots));
       C.d_fslots = nullptr; C.fslots_bytes = 0;
@@ -977,7 +978,7 @@ int ensure_hslots(loikb_solver_impl* S)
         char buf[400];
         snprintf(buf, sizeof(buf), "the flat engine needs %.2f GB of decade slots for %d instances (%d decades x %d rows x %d lanes x %d B) "
                  "and the device has no room for them: create the solver with a smaller batch, or set LOIKB_FLAT=0 LOIKB_LEAN=0 to use "
-                 "the k_solve + k_tail engines, which need none", need / 1e9, C.B, S->plan.ndec, S->flat.nanc + 1, S->flat.G, (int)S->esz);
+                 "the k_solve + k_tail engines, which need none", need / 1e9, C.B, S->plan.ndec, frows, S->flat.G, (int)S->esz);
         g_last_error = buf;
         return LOIKB_ERR_HIP;
       }
@@ -1359,7 +1360,8 @@ void plan_engines(loikb_solver_impl* S)
   else pl.lean = true;
   // the flat engine (no loops over the tree levels, loik_flat.hpp): same regime as k_lean, any number of children per joint
   if (S->flat.ok) {
-    const size_t per_wave = flat_lds_bytes<double>(S->nc, S->flat.G, S->a_shared, S->flat.nanc, true);
+    const size_t per_wave = S->flat.nanc <= FLAT_NA_SMALL ? flat_lds_bytes<double, FLAT_NA_SMALL>(S->nc, S->flat.G, S->a_shared, false)
+                                                           : flat_lds_bytes<double, FLAT_MAXA>(S->nc, S->flat.G, S->a_shared, false);
     pl.flat_waves_cu = (int)std::min<size_t>(8, (160 * 1024) / per_wave);
   }
   if (!S->tune.flat) pl.why_not_flat = S->tune.lean ? "LOIKB_FLAT=0" : "LOIKB_LEAN=0";
@@ -1449,12 +1451,19 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     // reference cost allows (H_ref = h I for all links)
     const bool flat_ok = flat_applicable(S) && (P.mode & MODE_CACHE_H) && n >= 64;
     if (flat_ok) {
-      const int nanc = S->flat.nanc, frows = nanc + 1;
+      const int nanc = S->flat.nanc;
+      const bool small_na = nanc <= FLAT_NA_SMALL;
+      const int frows = (small_na ? FLAT_NA_SMALL : FLAT_MAXA) + 1;
       const size_t need = (size_t)n_cur * ndec * frows * G * sizeof(T);
       if (need > C->fslots_bytes) { g_last_error = "internal: decade-slot buffer of the flat engine smaller than the chunk"; return LOIKB_ERR_STATE; }
       const int has_hv = S->Hv_inf_norm != 0.0;
-      const size_t flds = flat_lds_bytes<T>(S->nc, G, S->a_shared, nanc, has_hv);
-      if (flds > 64 * 1024) HIPCHK(hipFuncSetAttribute((const void*)k_flat<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+      const size_t flds = small_na ? flat_lds_bytes<T, FLAT_NA_SMALL>(S->nc, G, S->a_shared, has_hv) : flat_lds_bytes<T, FLAT_MAXA>(S->nc, G, S->a_shared, has_hv);
+      if (flds > 64 * 1024) {
+        HIPCHK(hipFuncSetAttribute((const void*)k_flat<T, FLAT_NA_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_flat<T, FLAT_MAXA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+      }
+      int lgG = 3;
+      while ((1 << lgG) < G) ++lgG;
       const int waves_cu = (int)std::min<size_t>(8, (160 * 1024) / flds);
       const int wg_per_cu = S->tune.lean_wg_per_cu > 0 ? S->tune.lean_wg_per_cu : waves_cu;
       const int wg_cap = wg_per_cu * std::max(1, (int)(S->ncu * ((double)C->B / (double)S->B) + 0.5));
@@ -1464,17 +1473,30 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
       {
         const dim3 hgrid((unsigned)((n + ipw - 1) / ipw));
-        const size_t hlds = ((size_t)(WAVE + 1) * 22 + (size_t)(WAVE + 1) * 6 + (size_t)nanc * WAVE + 2) * sizeof(T);
-        hipLaunchKernelGGL((k_fslots<T, true>), hgrid, dim3(WAVE), hlds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
-                           (const TailTopo*)S->d_topo, (const int*)S->d_child_list, (const FlatLane*)S->flat.d_lanes, S->maxdepth,
-                           nanc, S->flat.njmp, list, n, G, (T*)C->d_fslots, kexp_lo, ndec);
+        const size_t alds = (size_t)(WAVE + 1) * 22 * sizeof(T);
+        hipLaunchKernelGGL((k_fslots_a<T, true>), hgrid, dim3(WAVE), alds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                           (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, frows, list, n, G, (T*)C->d_fslots,
+                           kexp_lo, ndec);
+        HIPCHK(hipGetLastError());
+        const size_t blds = ((size_t)(WAVE + 1) * 15 + (size_t)((small_na ? FLAT_NA_SMALL : FLAT_MAXA) + 1) * WAVE) * sizeof(T);
+        if (small_na)
+          hipLaunchKernelGGL((k_fslots_b<T, FLAT_NA_SMALL>), hgrid, dim3(WAVE), blds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                             (const FlatLane*)S->flat.d_lanes, nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, ndec);
+        else
+          hipLaunchKernelGGL((k_fslots_b<T, FLAT_MAXA>), hgrid, dim3(WAVE), blds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                             (const FlatLane*)S->flat.d_lanes, nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, ndec);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(C->ev_k2, C->stream));
       }
       hipLaunchKernelGGL(k_ring_fill, grid1(C->ring_cap), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, list, n, C->d_counters);
-      hipLaunchKernelGGL((k_flat<T>), grid, dim3(WAVE), flds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
-                         (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, (const int*)C->d_ring, n, G,
-                         (const T*)C->d_fslots, kexp_lo, ndec, (T)S->Href[0], has_hv);
+      if (small_na)
+        hipLaunchKernelGGL((k_flat<T, FLAT_NA_SMALL>), grid, dim3(WAVE), flds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                           (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, (const int*)C->d_ring, n, lgG,
+                           (const T*)C->d_fslots, frows, kexp_lo, ndec, (T)S->Href[0], has_hv);
+      else
+        hipLaunchKernelGGL((k_flat<T, FLAT_MAXA>), grid, dim3(WAVE), flds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                           (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, (const int*)C->d_ring, n, lgG,
+                           (const T*)C->d_fslots, frows, kexp_lo, ndec, (T)S->Href[0], has_hv);
       HIPCHK(hipGetLastError());
       int* next = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
       hipLaunchKernelGGL(k_list_unfinished<T>, grid1(n), dim3(256), 0, C->stream, A.tiles, S->L, list, n, next, C->d_counters + 3);
