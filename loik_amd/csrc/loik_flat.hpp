@@ -47,7 +47,11 @@ constexpr int FLAT_JMP = 5;    // pointer-jumping rounds (tree depth <= 32)
 constexpr int FLAT_MAXA = 16;  // strict ancestors per joint (tree depth <= 17)
 constexpr int FOLDW = 10;      // scalars per lane row of the norm fold (80 B: an odd number of 16-byte slots)
 constexpr int FLAT_COUNTERS_SLOT_HITS = 12;  // Bufs::counters[12]: decade changes served from the second LDS slot
-constexpr int FLAT_NA_SMALL = 10;  // k_flat / k_fslots_b are compiled for <= 10 and <= FLAT_MAXA ancestors per joint
+constexpr int FLAT_NA_SMALL = 10;  // k_flat is compiled for <= 10 and <= FLAT_MAXA ancestors per joint
+#ifndef LOIKB_FLAT_WSLOTS
+#define LOIKB_FLAT_WSLOTS 1  // 1: k_fslots precomputes the joints' W columns for every decade (default); 0 (kept for measurements): the
+#endif                      // slots hold UDinv / Dinv only and k_flat builds a column when an instance enters a decade (+12 % launch time)
+constexpr int FSLOT_ROWS = 7;      // decade slot of a joint: UDinv (6, link frame) and Dinv
 
 // per lane of a group: the lane's joint (lane j <-> device joint j + 1, depth-first numbering) in the static tree
 struct FlatLane {
@@ -91,7 +95,8 @@ __host__ __device__ __forceinline__ size_t flat_lds_bytes(int nc, int G, bool a_
   return (n * sizeof(T) + 15) & ~(size_t)15;
 }
 
-// decade slot of an instance: frows = NA + 1 rows [k][lane]; k < NA: W_{anc_k(lane), lane} (0 beyond the joint's depth); row NA: Dinv
+// decade slot of an instance: frows = max(nanc + 1, 7) rows [k][lane]: W_{anc_k(lane), lane} for k < nanc, Dinv at k = nanc
+// (rows 0..6 hold UDinv / Dinv of the joint between the two passes of k_fslots)
 __device__ __forceinline__ size_t fslot_at(int idx, int ndec, int dsl, int G, int frows, int k, int jlane)
 {
   return ((((size_t)idx * ndec + dsl) * frows + k) * G) + jlane;
@@ -292,13 +297,14 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   //  keeping 15 scalars of it alive through the iteration loop)
   const int jflags = jd[jl + 1].flags, jcslot = isj_lane ? jd[jl + 1].cslot : -1;
   const T mass = (!isj_lane || (jflags & JF_MASSLESS)) ? T(0) : T(1);
-  int size;
+  int size, depth1;
   unsigned int jrow4[(FLAT_JMP + 3) / 4], ra2[FLAT_RED / 2], prow4[(FLAT_PART + 3) / 4], anc4[(NA + 3) / 4];
   bool helper;
   {
     // static rows / entries of this group's lanes; helper lanes may be lanes without a joint
     const FlatLane F = fl[jlane];
     size = isj_lane ? F.size : 0;
+    depth1 = F.depth - 1;
     helper = F.helper != 0;
 #pragma unroll
     for (int k = 0; k < (FLAT_JMP + 3) / 4; ++k) jrow4[k] = 0u;
@@ -571,16 +577,60 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
           kslot_o = kslot;  // the slot that was not used last is overwritten
           wsel ^= 1;
           T* wdst = wl + (size_t)wsel * (NA + 1) * WAVE;
+#if LOIKB_FLAT_WSLOTS
           if (isj) {
             T in[NA + 1];
 #pragma unroll
-            for (int k = 0; k <= NA; ++k) in[k] = fslots[fslot_at(lidx, ndec, dsl, G, NA + 1, k, jlane)];
+            for (int k = 0; k <= NA; ++k) in[k] = fslots[fslot_at(lidx, ndec, dsl, G, frows, k < nanc ? k : nanc, jlane)];  // (rows beyond the
+            // tree's depth repeat the Dinv row: such a W entry only ever multiplies the zero behind the root)
 #pragma unroll
             for (int k = 0; k <= NA; ++k) wdst[k * WAVE + lane] = in[k];
           } else {
 #pragma unroll
             for (int k = 0; k <= NA; ++k) wdst[k * WAVE + lane] = T(0);
           }
+#else
+          // The decade's UDinv (link frame) and Dinv come from the slots k_fslots_a built; the joint's column of W is made
+          // here: UDinv to the world origin, L_{a,d} = S^w_a . UDinv^w_d for the ancestors a, the L columns of the group's
+          // joints exchanged through LDS, then  W_{a,d} = -(L_{a,d} + sum_{e strictly between a and d} L_{a,e} W_{e,d}),
+          // nearest ancestor first.  (A lane group may run this alone: the exchanges stay inside the group.)
+          T UD[6], UDw[6], dnew = T(0);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) UD[k] = isj ? fslots[fslot_at(lidx, ndec, dsl, G, FSLOT_ROWS, k, jlane)] : T(0);
+          if (isj) dnew = fslots[fslot_at(lidx, ndec, dsl, G, FSLOT_ROWS, 6, jlane)];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) UDw[k] = UD[k];  // (the slots hold UDinv at the world origin)
+          tail_sync();
+          if (jlane < 6) xb[WAVE * 6 + jlane] = T(0);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) xb[lane * 6 + k] = Sw[k];
+          tail_sync();
+          T Lc[NA], Wc[NA];
+          int arow[NA];
+#pragma unroll
+          for (int k = 0; k < NA; ++k) {
+            arow[k] = unpack8(anc4, k);
+            Lc[k] = dot6_halves(xb + arow[k] * 6, UDw);
+            Wc[k] = T(0);
+          }
+          tail_sync();
+#pragma unroll
+          for (int k = 0; k < NA; ++k) xb[k * WAVE + lane] = Lc[k];
+          if (jlane == 0) xb[NA * WAVE] = T(0);
+          tail_sync();
+          const int nown = isj_lane ? depth1 : 0;  // strict ancestors of this lane's joint
+#pragma unroll
+          for (int k = NA - 1; k >= 0; --k) {
+            T acc = Lc[k];
+#pragma unroll
+            for (int k2 = k + 1; k2 < NA; ++k2) acc += xb[arow[k2] < WAVE ? k * WAVE + arow[k2] : NA * WAVE] * Wc[k2];  // (no such ancestor: the zero)
+            Wc[k] = (k < nown) ? -acc : T(0);
+          }
+          tail_sync();
+#pragma unroll
+          for (int k = 0; k < NA; ++k) wdst[k * WAVE + lane] = Wc[k];
+          wdst[NA * WAVE + lane] = dnew;
+#endif
           kslot = kexp;
           n_slot_loads = (n_slot_loads + 0x10000u) | (1u << dsl);
         }
@@ -885,126 +935,33 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Decade slots of the flat engine: W_{a,d} (d below a) and Dinv_d of every listed instance for mu = mu0 * 10^(kexp_lo + s).
-// k_fslots_a: the H recursion of k_hslots (hxx:290-338, :31-81, H part), as a pipeline of the decades over the tree levels; a
-// joint that has its UDinv for a decade leaves it (six scalars, link frame) and Dinv in the instance's slot rows 0..6.
-// k_fslots_b: per decade, every joint carries its UDinv to the world origin, L_{a,d} = S^w_a . UDinv^w_d for its ancestors a go
-// to LDS, and the joint inverts its column of the unit-triangular factor:
+// Decade slots of the flat engine: the joints' columns of W and Dinv of every listed instance for mu = mu0 * 10^(kexp_lo + s).
+// Pass A: the H recursion (FwdPass1 + BwdPass, hxx:290-338, :31-81, H part) with every H_i expressed at the WORLD origin:
+//   H^w_i = X*_{0<-i} H^base_i X*^T_{0<-i} + sum_children (H^w_c - UDinv^w_c U^w_cT),  U^w = H^w S^w,  Dinv = 1 / (S^w . U^w + mu)
+// -- the congruence SE3actOn(liMi, .) that carries a child's H to its parent (hxx:66, ~250 instructions per joint and
+// decade in k_hslots) is the identity between quantities at one origin; the two base terms (rho I + H_ref and A^T A of a
+// constrained joint, both independent of mu) are carried to the origin once per instance.  Dinv is a scalar of the
+// elimination, the same number in any frame.  The decades run as a pipeline over the tree levels (as in k_hslots); a joint
+// that has its UDinv^w for a decade leaves it and Dinv in rows 0..6 of the instance's slot.
+// Pass B (same wavefront, the rows come back from the L2): per decade L_{a,d} = S^w_a . UDinv^w_d for the ancestors a of every
+// joint d go to LDS, and the joint inverts its column of the unit-triangular factor:
 //   W_{a,d} = -(L_{a,d} + sum_{e strictly between a and d} L_{a,e} W_{e,d}),  nearest ancestor first;
-// the slot rows are overwritten with W (rows 0 .. NA-1) and Dinv (row NA).  A slot has NA + 1 >= 11 rows.
+// the slot's rows are overwritten with W (rows 0 .. nanc-1) and Dinv (row nanc).  frows = max(nanc + 1, 7) rows per slot:
+// 10 scalars per joint and decade on Talos-32 where k_hslots wrote 22.
 // ------------------------------------------------------------------------------------------------------------------------
-template <typename T, bool HDIAG>
+template <typename T, int NA>
 __global__ void __launch_bounds__(WAVE)
-k_fslots_a(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
-           const int* __restrict__ child_list, int maxdepth, int frows, const int* __restrict__ slots, int nslots, int G,
-           T* __restrict__ fslots, int kexp_lo, int ndec)
+k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
+         const int* __restrict__ child_list, const FlatLane* __restrict__ fl, int maxdepth, int nanc, int frows, int njmp,
+         const int* __restrict__ slots, int nslots, int G, T* __restrict__ fslots, int kexp_lo, int ndec)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
   constexpr int HX = 22;
-  T* xch = reinterpret_cast<T*>(smem_raw);        // [WAVE + 1][22]: the projected, transported H of a child
-  const int lane = threadIdx.x;
-  const int ipw = WAVE / G;
-  const int sub = lane / G, jlane = lane % G, gbase = sub * G;
-  const int idx = blockIdx.x * ipw + sub;
-  const bool has_inst = idx < nslots;
-  const bool isj = has_inst && jlane < L.nb;
-  const int jl = jlane < L.nb ? jlane : 0;
-  const JointDesc d = jd[jl + 1];
-  const TailTopo tp = topo[jl + 1];
-  const int depth = jlane < L.nb ? tp.depth : 0;
-  const bool rev = d.flags & JF_REVOLUTE;
-  const T mass = (d.flags & JF_MASSLESS) ? T(0) : T(1);
-  const bool has_parent = !(d.flags & JF_PARENT_ROOT);
-  const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
-  const int sidx = slots[has_inst ? idx : 0];
-  char* ip = lane_ptr<T>(Bf.tiles, L, sidx);
-  const char* rec = ip + (size_t)jl * JREC * pair_bytes<T>();
-  T R[9], t[3];
-  {
-    const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS);
-    joint_xform<T>(d, rec, cs.x, cs.y, R, t);
-  }
-  if (lane < HX) xch[WAVE * HX + lane] = T(0);
-  T ata[21];
-#pragma unroll
-  for (int k = 0; k < 21; ++k) ata[k] = T(0);
-  if (isj && d.cslot >= 0) {
-    const char* crec = ip + (size_t)(L.off_c + d.cslot * L.crec) * pair_bytes<T>();
-    for (int k = 0; k < 21; ++k)
-      ata[k] = (P.mode & MODE_A_SHARED) ? Bf.uni[L.nc * 36 + d.cslot * 21 + k]
-                                        : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
-  }
-  T mu = P.mu0;
-  for (int k = 0; k < kexp_lo; ++k) mu *= T(10);
-  for (int k = 0; k > kexp_lo; --k) mu *= T(0.1);
-  const int lag = maxdepth - depth;
-  for (int st = 0; st < maxdepth + ndec - 1; ++st) {
-    const int dsl = st - lag;
-    const bool on = isj && depth > 0 && dsl >= 0 && dsl < ndec;
-    T part[21];
-#pragma unroll
-    for (int k = 0; k < 21; ++k) part[k] = T(0);
-    if (on) {
-      const T mu_eq = P.mu_scale * mu, mu_in = mu;
-      T hh[21];
-#pragma unroll
-      for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int b2 = a; b2 < 6; ++b2)
-          hh[sym(a, b2)] = mass * ((a == b2 ? P.rho : T(0)) + ((HDIAG && a != b2) ? T(0) : P.Href[6 * a + b2]));
-#pragma unroll
-      for (int k = 0; k < 21; ++k) hh[k] += mu_eq * ata[k];
-      for (int c = 0; c < tp.nchild; ++c) {
-        const T* x = xch + (gbase + child_list[tp.child_start + c]) * HX;
-#pragma unroll
-        for (int k = 0; k < 21; ++k) hh[k] += x[k];
-      }
-      T U[6], UD[6];
-      T dinv;
-      if (rev) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 3)] * ax0 + hh[sym(k, 4)] * ax1 + hh[sym(k, 5)] * ax2;
-        dinv = T(1) / ((ax0 * U[3] + ax1 * U[4] + ax2 * U[5]) + mu_in);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 0)] * ax0 + hh[sym(k, 1)] * ax1 + hh[sym(k, 2)] * ax2;
-        dinv = T(1) / ((ax0 * U[0] + ax1 * U[1] + ax2 * U[2]) + mu_in);
-      }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) UD[k] = U[k] * dinv;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] = UD[k];
-      fslots[fslot_at(sidx, ndec, dsl, G, frows, 6, jlane)] = dinv;
-      if (has_parent) {
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-          for (int b2 = a; b2 < 6; ++b2) hh[sym(a, b2)] -= UD[a] * U[b2];
-        congr_sym(R, t, hh, part);
-      }
-      mu *= T(10);
-    }
-    tail_sync();
-    if (on && has_parent) {
-      T* x = xch + lane * HX;
-#pragma unroll
-      for (int k = 0; k < 21; ++k) x[k] = part[k];
-    }
-    tail_sync();
-  }
-}
-
-template <typename T, int NA>
-__global__ void __launch_bounds__(WAVE)
-k_fslots_b(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc, int frows,
-           int njmp, const int* __restrict__ slots, int nslots, int G, T* __restrict__ fslots, int ndec)
-{
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const Layout& L = P.L;
-  T* xb = reinterpret_cast<T*>(smem_raw);         // [WAVE + 1][9]: placement rows
-  T* swt = xb + (WAVE + 1) * 9;                   // [WAVE + 1][6]: S^w of every lane's joint (+ a zero row)
-  T* lb = swt + (WAVE + 1) * 6;                   // [NA][WAVE] + WAVE: L columns of one decade (+ zeros)
+  T* xch = reinterpret_cast<T*>(smem_raw);        // [WAVE + 1][22] placement rows [9], then the H^w a joint passes to its parent
+  T* swt = xch + (WAVE + 1) * HX;                 // [WAVE + 1][6]  S^w of every lane's joint (+ a zero row)
+  T* ata_l = swt + (WAVE + 1) * 6;                // [64/G][nc][21] A^T A of the instances' constraints at the world origin
+  T* lb = ata_l + (size_t)(WAVE / G) * L.nc * 21; // [NA][WAVE] + WAVE: L columns of one decade (+ zeros)
   const int lane = threadIdx.x;
   const int ipw = WAVE / G;
   const int sub = lane / G, jlane = lane % G, gbase = sub * G;
@@ -1014,20 +971,26 @@ k_fslots_b(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd
   const bool isj = has_inst && isj_lane;
   const int jl = isj_lane ? jlane : 0;
   const int sidx = slots[has_inst ? idx : 0];
+  char* ip = lane_ptr<T>(Bf.tiles, L, sidx);
   int depth, arow[NA];
-  T R0[9], t0[3];
+  T Sw[6];
+  bool has_parent;
+  int cslot;
+  T base0[21];  // mass * (rho I + H_ref) of this joint's link at the world origin
   {
     const JointDesc d = jd[jl + 1];
     const FlatLane F = fl[jlane];
     depth = isj_lane ? F.depth : 0;
+    has_parent = !(d.flags & JF_PARENT_ROOT);
+    cslot = isj_lane ? d.cslot : -1;
     unsigned int jrow4[(FLAT_JMP + 3) / 4] = {0u, 0u};
 #pragma unroll
     for (int r = 0; r < FLAT_JMP; ++r) jrow4[r >> 2] |= (unsigned int)(F.jmp[r] >= 0 ? gbase + F.jmp[r] : WAVE) << (8 * (r & 3));
 #pragma unroll
     for (int k = 0; k < NA; ++k) arow[k] = (k < FLAT_MAXA && F.anc[k] >= 0) ? gbase + F.anc[k] : WAVE;
-    char* ip = lane_ptr<T>(Bf.tiles, L, sidx);
     const char* rec = ip + (size_t)jl * JREC * pair_bytes<T>();
     const typename Vec2<T>::type cs = ldp<T>(rec, JP_CS);
+    T R0[9], t0[3];
     joint_xform<T>(d, rec, cs.x, cs.y, R0, t0);
     if (!isj_lane) {
 #pragma unroll
@@ -1035,7 +998,7 @@ k_fslots_b(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd
 #pragma unroll
       for (int k = 0; k < 3; ++k) t0[k] = T(0);
     }
-    flat_world_placement<T>(xb, lane, jlane, jrow4, njmp, R0, t0);
+    flat_world_placement<T>(xch, lane, jlane, jrow4, njmp, R0, t0);
     const bool rev = d.flags & JF_REVOLUTE;
     T ax[3], ra3[3], c[3];
 #pragma unroll
@@ -1043,17 +1006,102 @@ k_fslots_b(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd
     mat3_vec(R0, ax, ra3);
     cross3(t0, ra3, c);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { swt[lane * 6 + k] = rev ? c[k] : ra3[k]; swt[lane * 6 + 3 + k] = rev ? ra3[k] : T(0); }
+    for (int k = 0; k < 3; ++k) { Sw[k] = rev ? c[k] : ra3[k]; Sw[3 + k] = rev ? ra3[k] : T(0); }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) swt[lane * 6 + k] = Sw[k];
     if (lane < 6) swt[WAVE * 6 + lane] = T(0);
+    // the base terms at the world origin
+    {
+      const T mass = (!isj_lane || (d.flags & JF_MASSLESS)) ? T(0) : T(1);
+      T hb[21];
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b2 = a; b2 < 6; ++b2) hb[sym(a, b2)] = mass * ((a == b2 ? P.rho : T(0)) + P.Href[6 * a + b2]);
+      congr_sym(R0, t0, hb, base0);
+    }
+    if (cslot >= 0) {
+      const char* crec = ip + (size_t)(L.off_c + cslot * L.crec) * pair_bytes<T>();
+      T at[21], atw[21];
+      for (int k = 0; k < 21; ++k)
+        at[k] = (P.mode & MODE_A_SHARED) ? Bf.uni[L.nc * 36 + cslot * 21 + k]
+                                         : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+      congr_sym(R0, t0, at, atw);
+#pragma unroll
+      for (int k = 0; k < 21; ++k) ata_l[(sub * L.nc + cslot) * 21 + k] = atw[k];
+    }
   }
+  const TailTopo tp = topo[jl + 1];
+  // the rows of the first children stay in registers: the step loop must not wait for global memory (the child list)
+  constexpr int NCH_REG = 3;
+  int chl[NCH_REG];
+#pragma unroll
+  for (int c = 0; c < NCH_REG; ++c) chl[c] = (isj_lane && c < tp.nchild) ? gbase + child_list[tp.child_start + c] : WAVE;
+  tail_sync();
+  if (lane < HX) xch[WAVE * HX + lane] = T(0);
+  // ---- pass A
+  {
+    T mu = P.mu0;
+    for (int k = 0; k < kexp_lo; ++k) mu *= T(10);
+    for (int k = 0; k > kexp_lo; --k) mu *= T(0.1);
+    const int lag = maxdepth - depth;
+    tail_sync();
+    for (int st = 0; st < maxdepth + ndec - 1; ++st) {
+      const int dsl = st - lag;
+      const bool on = isj && depth > 0 && dsl >= 0 && dsl < ndec;
+      T hh[21];
+#pragma unroll
+      for (int k = 0; k < 21; ++k) hh[k] = base0[k];
+      if (on) {  // the children's contributions of the previous step (the same decade); a missing child is the zero row
+#pragma unroll
+        for (int c = 0; c < NCH_REG; ++c) {
+          const T* x = xch + chl[c] * HX;
+#pragma unroll
+          for (int k = 0; k < 21; ++k) hh[k] += x[k];
+        }
+        for (int c = NCH_REG; c < tp.nchild; ++c) {
+          const T* x = xch + (gbase + child_list[tp.child_start + c]) * HX;
+#pragma unroll
+          for (int k = 0; k < 21; ++k) hh[k] += x[k];
+        }
+      }
+      tail_sync();  // every lane has read its children's rows: they may be overwritten
+      if (on) {
+        const T mu_eq = P.mu_scale * mu, mu_in = mu;
+        if (cslot >= 0) {
+          const T* at = ata_l + (sub * L.nc + cslot) * 21;
+#pragma unroll
+          for (int k = 0; k < 21; ++k) hh[k] += mu_eq * at[k];
+        }
+        T U[6], UD[6];
+        symv(hh, Sw, U);
+        const T dinv = T(1) / (dot6_halves(Sw, U) + mu_in);  // (S^T H S + mu: calc_aba with the armature mu, hxx:60-63)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) UD[k] = U[k] * dinv;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] = UD[k];
+        fslots[fslot_at(sidx, ndec, dsl, G, frows, 6, jlane)] = dinv;
+        if (has_parent) {
+          T* x = xch + lane * HX;
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b2 = a; b2 < 6; ++b2) x[sym(a, b2)] = hh[sym(a, b2)] - UD[a] * U[b2];
+        }
+        mu *= T(10);
+      }
+      tail_sync();
+    }
+  }
+  // ---- pass B (every lane reads back the rows it wrote itself)
   lb[NA * WAVE + lane] = T(0);
+  __builtin_amdgcn_s_waitcnt(0);
   tail_sync();
   for (int dsl = 0; dsl < ndec; ++dsl) {
-    T UD[6], UDw[6], dinv = T(0);
+    T UDw[6], dinv = T(0);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) UD[k] = isj ? fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] : T(0);
+    for (int k = 0; k < 6; ++k) UDw[k] = isj ? fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] : T(0);
     if (isj) dinv = fslots[fslot_at(sidx, ndec, dsl, G, frows, 6, jlane)];
-    act_force(R0, t0, UD, UDw);
     T Lc[NA], Wc[NA];
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
@@ -1074,8 +1122,8 @@ k_fslots_b(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd
     if (isj) {
 #pragma unroll
       for (int k = 0; k < NA; ++k)
-        fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] = Wc[k];
-      fslots[fslot_at(sidx, ndec, dsl, G, frows, NA, jlane)] = dinv;
+        if (k < nanc) fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] = Wc[k];
+      fslots[fslot_at(sidx, ndec, dsl, G, frows, nanc, jlane)] = dinv;
     }
   }
 }

@@ -968,7 +968,7 @@ int ensure_hslots(loikb_solver_impl* S)
   if (S->plan.flat && (flat_applicable(S) || !S->have_problem)) {
     // decade slots of the flat engine: (ancestors + 1) scalars per lane, decade and instance
     for (Chunk& C : S->chunks) {
-      const int frows = (S->flat.nanc <= FLAT_NA_SMALL ? FLAT_NA_SMALL : FLAT_MAXA) + 1;
+      const int frows = std::max(S->flat.nanc + 1, FSLOT_ROWS);
       const size_t need = (size_t)C.B * S->plan.ndec * frows * S->flat.G * S->esz;
       if (need <= C.fslots_bytes) continue;
       if (C.d_fslots) HIPCHK(hipFree(C.d_fslots));
@@ -1453,7 +1453,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     if (flat_ok) {
       const int nanc = S->flat.nanc;
       const bool small_na = nanc <= FLAT_NA_SMALL;
-      const int frows = (small_na ? FLAT_NA_SMALL : FLAT_MAXA) + 1;
+      const int frows = std::max(nanc + 1, FSLOT_ROWS);
       const size_t need = (size_t)n_cur * ndec * frows * G * sizeof(T);
       if (need > C->fslots_bytes) { g_last_error = "internal: decade-slot buffer of the flat engine smaller than the chunk"; return LOIKB_ERR_STATE; }
       const int has_hv = S->Hv_inf_norm != 0.0;
@@ -1473,18 +1473,15 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
       {
         const dim3 hgrid((unsigned)((n + ipw - 1) / ipw));
-        const size_t alds = (size_t)(WAVE + 1) * 22 * sizeof(T);
-        hipLaunchKernelGGL((k_fslots_a<T, true>), hgrid, dim3(WAVE), alds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
-                           (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, frows, list, n, G, (T*)C->d_fslots,
-                           kexp_lo, ndec);
-        HIPCHK(hipGetLastError());
-        const size_t blds = ((size_t)(WAVE + 1) * 15 + (size_t)((small_na ? FLAT_NA_SMALL : FLAT_MAXA) + 1) * WAVE) * sizeof(T);
+        const size_t slds = ((size_t)(WAVE + 1) * 28 + (size_t)ipw * S->nc * 21 + (size_t)((small_na ? FLAT_NA_SMALL : FLAT_MAXA) + 1) * WAVE) * sizeof(T);
         if (small_na)
-          hipLaunchKernelGGL((k_fslots_b<T, FLAT_NA_SMALL>), hgrid, dim3(WAVE), blds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
-                             (const FlatLane*)S->flat.d_lanes, nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, ndec);
+          hipLaunchKernelGGL((k_fslots<T, FLAT_NA_SMALL>), hgrid, dim3(WAVE), slds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                             (const TailTopo*)S->d_topo, (const int*)S->d_child_list, (const FlatLane*)S->flat.d_lanes, S->maxdepth,
+                             nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, kexp_lo, ndec);
         else
-          hipLaunchKernelGGL((k_fslots_b<T, FLAT_MAXA>), hgrid, dim3(WAVE), blds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
-                             (const FlatLane*)S->flat.d_lanes, nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, ndec);
+          hipLaunchKernelGGL((k_fslots<T, FLAT_MAXA>), hgrid, dim3(WAVE), slds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                             (const TailTopo*)S->d_topo, (const int*)S->d_child_list, (const FlatLane*)S->flat.d_lanes, S->maxdepth,
+                             nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, kexp_lo, ndec);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(C->ev_k2, C->stream));
       }
