@@ -66,7 +66,8 @@ struct FlatLane {
 
 // constraint block of an instance in LDS (T each)
 enum : int { FC_LANE = 0, FC_B = 1, FC_Y = 7, FC_ATY = 13, FC_ATYW = 19, FC_ATBW = 25, FC_DY = 31, FC_DLT = 37, FC_ATYF = 43, FC_AW = 49, FC_A = 85,
-              FCD = 121 };  // (the block carries its own copy of A, shared or not: one constant stride, no selects in the loop)
+              FC_VC = FC_DLT /* v of the constrained joint: written before the update's first half, which is done with it before the
+                                second half writes FC_DLT */, FCD = 121 };  // (the block carries its own copy of A, shared or not: one constant stride, no selects in the loop)
 // per-instance scalars kept in LDS for the getters (written when an instance stops)
 enum : int { FI_BNORM = 0, FI_TGIN, FI_STY, FI_TOLP, FI_TOLD, FI_DYQP, FI_ATDY, FI_UBP, FI_LBM, FI_C1, FI_C2, FI_PRIMAL, FI_DUAL, FI_DX,
              FI_DZ, FI_MULAST, FI_RED /* 16 folded values */, FISC = FI_RED + 16 };
@@ -266,11 +267,18 @@ __device__ __forceinline__ unsigned int opaque(unsigned int x) { asm volatile(""
 __device__ __forceinline__ int unpack8(const unsigned int* w, int k) { return (int)((opaque(w[k >> 2]) >> (8 * (k & 3))) & 0xFFu); }
 __device__ __forceinline__ int unpack16(const unsigned int* w, int k) { return (int)((opaque(w[k >> 1]) >> (16 * (k & 1))) & 0xFFFFu); }
 
-template <typename T, int NA>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// Two builds of the same kernel.  LAT = false, two wavefronts per SIMD (256 registers each, ~75 values of the iteration live in
+// scratch): the throughput build -- while the work queue holds instances every SIMD interleaves two wavefronts.  LAT = true,
+// one wavefront per SIMD (512 registers, no scratch): the latency build -- an instance alone on its SIMD iterates ~20 %
+// faster in it (no scratch reloads in its dependent chains), and the 999-iteration instances that decide when a batch ends
+// are exactly that.  The throughput build drains (writes its instances back unfinished) once the queue has run dry and
+// `drain` says so; the host relaunches the survivors in the latency build (run_tail, loik_host.hip).
+constexpr int FLAT_COUNTERS_DRY = 13;  // Bufs::counters[13]: set by the first lane group that finds the work queue empty
+template <typename T, int NA, bool LAT>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(LAT ? 1 : 2, LAT ? 1 : 2)))
 k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc, int nscan,
        int njmp, const int* __restrict__ ring, int nslots, int lgG, const T* __restrict__ fslots, int frows, int kexp_lo, int ndec,
-       T href_s, int has_hv)
+       T href_s, int has_hv, int drain)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
@@ -339,11 +347,13 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   unsigned int my_iters = 0, n_wave_iters = 0, n_slot_loads = 0, n_slot_hits = 0;
   unsigned int* q_head = Bf.counters + LEAN_Q_HEAD;
 
-  // constraint c: is its joint in this lane's subtree?  (1 / 0)
-  auto cmask = [&](int c) -> T {
-    const int cl = (int)cdi[c * cs + FC_LANE];
-    return (isj_lane && cl >= jlane && cl < jlane + size) ? T(1) : T(0);
-  };
+  // constraint c: is its joint in this lane's subtree?  (1 / 0; the bits are set when an instance is loaded)
+  unsigned int cbits = 0u;
+  auto cmask = [&](int c) -> T { return ((cbits >> c) & 1u) ? T(1) : T(0); };
+  // the DualUpdate's lanes: lane 6 c + k of the group owns row k of constraint c (all constraints side by side)
+  const int ccl = jlane / 6, ckl = jlane - 6 * ccl;
+  const bool iscl = jlane < 6 * L.nc;
+  T* const ccb = cdi + (iscl ? ccl : 0) * cs;
   // links' velocities as forces at the world origin: E = mass * (R0 v_l, R0 v_a + t0 x R0 v_l), from the world-frame motion
   // (vw_l = R0 v_l + t0 x R0 v_a, vw_a = R0 v_a):  R0 v_l = vw_l - t0 x vw_a
   auto force_of_motion = [&](const T* vw, T* E) {
@@ -364,6 +374,8 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       if (jlane == 0) nx = (int)atomicAdd(q_head, 1u);
       nx = __shfl(nx, gbase);
       slot_in = nx < nslots ? ring[nx] : -1;
+      if (!LAT && drain && nx >= nslots && jlane == 0)
+        __hip_atomic_store(Bf.counters + FLAT_COUNTERS_DRY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     has_inst = slot_in >= 0;
     isj = has_inst && isj_lane;
@@ -426,6 +438,11 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     }
     if (jcslot >= 0) cdi[jcslot * cs + FC_LANE] = (T)jlane;
     tail_sync();
+    cbits = 0u;
+    for (int c = 0; c < L.nc; ++c) {
+      const int cl = (int)cdi[c * cs + FC_LANE];
+      if (isj_lane && cl >= jlane && cl < jlane + size) cbits |= 1u << c;
+    }
     if (jcslot >= 0) {  // the constrained joint's lane: column j of AW = row j of A carried to the world origin
       T* c_ = cdi + jcslot * cs;
       const T* A_ = c_ + FC_A;
@@ -563,6 +580,12 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     if (!__any(has_inst)) break;
     // ---- decade of mu: W rows and Dinv.  Two decades stay in LDS: a flip back to the previous one costs nothing.
     if (!done && (int)my_iters >= P.max_launch_iters) done = true;
+    if (!LAT && drain && !done && (my_iters & 15u) == 15u) {
+      // has the queue run dry?  Then what is still iterating goes back to the list and continues in the latency build.  (Asked
+      // every 16th iteration of an instance: the flag is one word in global memory that every wavefront of the launch reads --
+      // read in every iteration, its round trip doubled the launch time.)
+      if (__hip_atomic_load(Bf.counters + FLAT_COUNTERS_DRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) done = true;
+    }
     if (!done && kexp != kslot) {
       if (kexp == kslot_o) {
         { const int tk = kslot; kslot = kslot_o; kslot_o = tk; }
@@ -706,6 +729,8 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     // ================= v = J nu: path sum of S^w nu at the world origin, then into the link frame (hxx:125-134) ===============
     T vi[6], E[6];
     {
+      // (measured and rejected: the ancestors' S^w in 120 registers and only their nu fetched -- one exchange instead of four,
+      //  but 66 dependent-ish fp64 multiply-adds and the registers they displace: 1.88 k cycles against 1.54 k)
       T vw[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) vw[k] = Sw[k] * nui;
@@ -714,64 +739,109 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       force_of_motion(vw, E);
     }
     TAIL_TP(2)
-    // ================= DualUpdate of the task constraints (hxx:410-451), six lanes of the group ================================
+    // ================= DualUpdate of the task constraints (hxx:410-451) inside the subtree sum of the links' velocities ==========
+    // f by force balance at the world origin needs one subtree sum (BwdPass2's transport, hxx:210-212): window sums by doubling,
+    // one LDS exchange per step.  The constraints' update -- (A v - b, dy, y) and then (A^T y, the same at the world origin, the
+    // pieces of this iteration's force balance) -- needs two exchanges of its own: it rides on the first two steps.
     T l_dyis = T(0), l_av = T(0), l_prt = T(0), l_up = T(0), l_lm = T(0);
-    tail_sync();
-    if (jcslot >= 0) {
+    T fi[6], si;
+    {
+      T SEn[6], Fw[6], Bk[6];
+      int pos = lane;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) xb[lane * 6 + k] = vi[k];
-    }
-    tail_sync();
-    for (int c = 0; c < L.nc; ++c) {
-      T* c_ = cdi + c * cs;
-      const T* A_ = c_ + FC_A;
-      if (act && jlane < 6) {
-        const int k = jlane;
-        const T* vc = xb + (gbase + (int)c_[FC_LANE]) * 6;
-        T avk = A_[6 * k] * vc[0];
+      for (int k = 0; k < 6; ++k) { Bk[k] = E[k]; SEn[k] = T(0); }
+      auto put_rows = [&]() {
+        tail_sync();
 #pragma unroll
-        for (int j = 1; j < 6; ++j) avk += A_[6 * k + j] * vc[j];
-        const T bk = c_[FC_B + k];
+        for (int c = 0; c < 6; ++c) xb[lane * 6 + c] = Bk[c];
+      };
+      auto scan_step = [&](int k) {  // (the rows hold the window sums of width 2^k)
+        const bool take = (size >> k) & 1;
+        const int ra_ = take ? pos : WAVE;
+        const int nx = lane + (1 << k);
+        const int rb_ = nx < glim ? nx : WAVE;
+        T a[6], b[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) a[c] = xb[ra_ * 6 + c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) b[c] = xb[rb_ * 6 + c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { SEn[c] += a[c]; Bk[c] += b[c]; }
+        pos += take ? (1 << k) : 0;
+      };
+      put_rows();
+      if (jlane < 6) xb[WAVE * 6 + jlane] = T(0);
+      if (jcslot >= 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cdi[jcslot * cs + FC_VC + k] = vi[k];
+      }
+      tail_sync();
+      scan_step(0);
+      if (act && iscl) {
+        const T* A_ = ccb + FC_A;
+        const T* vc = ccb + FC_VC;
+        T avk = A_[6 * ckl] * vc[0];
+#pragma unroll
+        for (int j = 1; j < 6; ++j) avk += A_[6 * ckl + j] * vc[j];
+        const T bk = ccb[FC_B + ckl];
         const T ek = avk - bk;
         const T dy = mu_eq * ek;
-        const T yk = c_[FC_Y + k] + dy;
-        l_dyis = tmax(l_dyis, tabs(dy));
-        l_up += bk * tmax(dy, T(0));
-        l_lm += bk * tmin(dy, T(0));
-        l_prt = tmax(l_prt, tabs(ek));
-        l_av = tmax(l_av, tabs(avk));
-        c_[FC_Y + k] = yk;
-        c_[FC_DY + k] = dy;
+        const T yk = ccb[FC_Y + ckl] + dy;
+        l_dyis = tabs(dy);
+        l_up = bk * tmax(dy, T(0));
+        l_lm = bk * tmin(dy, T(0));
+        l_prt = tabs(ek);
+        l_av = tabs(avk);
+        ccb[FC_Y + ckl] = yk;
+        ccb[FC_DY + ckl] = dy;
       }
-    }
-    tail_sync();
-    for (int c = 0; c < L.nc; ++c) {
-      T* c_ = cdi + c * cs;
-      const T* A_ = c_ + FC_A;
-      if (act && jlane < 6) {
+      put_rows();
+      tail_sync();
+      scan_step(1);
+      if (act && iscl) {
         // A^T y (hxx:422) and the same at the world origin; and the two pieces of THIS iteration's force balance that are not
         // A^T y of the new dual: the constraint's share of H^base v + p^base is A^T dy + (the A^T y FwdPass1 used), which is
         // A^T y_new only when the instance arrived with A^T y consistent with its A (not after UpdateEqConstraint replaced A
         // under a warm start: upstream's first iteration then runs on the old product, hxx:329-331)
-        const int k = jlane;
-        T at = A_[k] * c_[FC_Y], aw = c_[FC_AW + 6 * k] * c_[FC_Y], atd = A_[k] * c_[FC_DY], awd = c_[FC_AW + 6 * k] * c_[FC_DY];
+        const T* A_ = ccb + FC_A;
+        const int k = ckl;
+        T at = A_[k] * ccb[FC_Y], aw = ccb[FC_AW + 6 * k] * ccb[FC_Y], atd = A_[k] * ccb[FC_DY], awd = ccb[FC_AW + 6 * k] * ccb[FC_DY];
 #pragma unroll
         for (int j = 1; j < 6; ++j) {
-          at += A_[6 * j + k] * c_[FC_Y + j]; aw += c_[FC_AW + 6 * k + j] * c_[FC_Y + j];
-          atd += A_[6 * j + k] * c_[FC_DY + j]; awd += c_[FC_AW + 6 * k + j] * c_[FC_DY + j];
+          at += A_[6 * j + k] * ccb[FC_Y + j]; aw += ccb[FC_AW + 6 * k + j] * ccb[FC_Y + j];
+          atd += A_[6 * j + k] * ccb[FC_DY + j]; awd += ccb[FC_AW + 6 * k + j] * ccb[FC_DY + j];
         }
-        c_[FC_DLT + k] = (at - atd) - c_[FC_ATY + k];   // A^T y_old - (A^T y used): added to g of the constrained joint
-        c_[FC_ATYF + k] = c_[FC_ATYW + k] + awd;       // the constraint's force in f, world origin
-        c_[FC_ATY + k] = at;
-        c_[FC_ATYW + k] = aw;
+        ccb[FC_DLT + k] = (at - atd) - ccb[FC_ATY + k];   // A^T y_old - (A^T y used): added to g of the constrained joint
+        ccb[FC_ATYF + k] = ccb[FC_ATYW + k] + awd;       // the constraint's force in f, world origin
+        ccb[FC_ATY + k] = at;
+        ccb[FC_ATYW + k] = aw;
       }
-    }
-    TAIL_TP(4)
-    // ================= f by force balance at the world origin: one subtree sum (BwdPass2's transport, hxx:210-212) =============
-    T fi[6], si;
-    {
-      T SEn[6], Fw[6];
-      flat_subtree_sum<T>(xb, lane, jlane, glim, size, nscan, E, SEn);
+      int kk = 2;
+      for (; kk + 2 < nscan; ++kk) {
+        put_rows();
+        tail_sync();
+        scan_step(kk);
+      }
+      if (kk < nscan) {
+        // the last two bits of `size` in one exchange: the window of width 2^(kk+1) is two windows of width 2^kk
+        put_rows();
+        tail_sync();
+        const int wv = 1 << kk;
+        const bool take0 = (size >> kk) & 1, take1 = (size >> (kk + 1)) & 1;
+        const int p1 = pos + (take0 ? wv : 0);
+        const int r0 = take0 ? pos : WAVE, r1 = take1 ? p1 : WAVE, r2 = take1 ? p1 + wv : WAVE;
+        T a[6], b[6], c2[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) a[c] = xb[r0 * 6 + c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) b[c] = xb[r1 * 6 + c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) c2[c] = xb[r2 * 6 + c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) SEn[c] += a[c] + (b[c] + c2[c]);
+      }
+      tail_sync();
+      TAIL_TP(4)
 #pragma unroll
       for (int k = 0; k < 6; ++k) Fw[k] = (P.rho + href_s) * SEn[k] - P.rho * SE[k];
       if (has_hv) {

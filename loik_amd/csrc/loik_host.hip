@@ -57,6 +57,9 @@ struct Tuning {
   int tile_pad = -1;            // LOIKB_TILE_PAD      extra pairs per tile (-1: pad to an odd number of 1-KiB pairs)
   bool lean = true;             // LOIKB_LEAN=0        never use k_lean nor k_flat (the engines with precomputed decade slots)
   bool flat = true;             // LOIKB_FLAT=0        never use k_flat (the engine without level loops, loik_flat.hpp)
+  bool flat_two_stage = false;  // LOIKB_FLAT_STAGES=2 the flat engine's throughput build (two wavefronts per SIMD, ~75 values in scratch) until the
+                                // work queue runs dry, then its latency build (default: the latency build -- one wavefront per SIMD, no scratch -- alone:
+                                // measured faster in bulk too, 12.5 against 13.8 ms until the queue is dry on the headline)
   int tail_waves = TAIL_WAVES;  // LOIKB_TAIL_WAVES    wavefronts per k_tail workgroup
   int lean_decades = 10;        // LOIKB_LEAN_DECADES  decades of mu with precomputed H slots ...
   int lean_klo = -2;            // LOIKB_LEAN_KLO      ... starting at mu0 * 10^klo
@@ -79,6 +82,7 @@ struct Tuning {
     if (const char* e = getenv("LOIKB_LEAN")) lean = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT")) flat = atoi(e) != 0;
     if (!lean) flat = false;  // (LOIKB_LEAN=0 asks for the engines without precomputed factors: k_solve / k_tail)
+    if (const char* e = getenv("LOIKB_FLAT_STAGES")) flat_two_stage = atoi(e) == 2;
     geti("LOIKB_TAIL_WAVES", tail_waves); tail_waves = std::max(1, std::min(TAIL_WAVES, tail_waves));
     geti("LOIKB_LEAN_DECADES", lean_decades); lean_decades = std::max(1, std::min(16, lean_decades));
     geti("LOIKB_LEAN_KLO", lean_klo);
@@ -1458,17 +1462,16 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       if (need > C->fslots_bytes) { g_last_error = "internal: decade-slot buffer of the flat engine smaller than the chunk"; return LOIKB_ERR_STATE; }
       const int has_hv = S->Hv_inf_norm != 0.0;
       const size_t flds = small_na ? flat_lds_bytes<T, FLAT_NA_SMALL>(S->nc, G, S->a_shared, has_hv) : flat_lds_bytes<T, FLAT_MAXA>(S->nc, G, S->a_shared, has_hv);
-      if (flds > 64 * 1024) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_flat<T, FLAT_NA_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-        HIPCHK(hipFuncSetAttribute((const void*)k_flat<T, FLAT_MAXA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-      }
       int lgG = 3;
       while ((1 << lgG) < G) ++lgG;
-      const int waves_cu = (int)std::min<size_t>(8, (160 * 1024) / flds);
-      const int wg_per_cu = S->tune.lean_wg_per_cu > 0 ? S->tune.lean_wg_per_cu : waves_cu;
-      const int wg_cap = wg_per_cu * std::max(1, (int)(S->ncu * ((double)C->B / (double)S->B) + 0.5));
+      // Two builds of k_flat: throughput (two wavefronts per SIMD) while the work queue feeds every lane group, latency (one per
+      // SIMD, no scratch) for what is still iterating when the queue has run dry -- the 999-iteration instances that decide
+      // when the batch ends.  A list that fits the latency build's resident lane groups twice over goes to it directly.
+      const double cu_sh = std::max(1.0, S->ncu * ((double)C->B / (double)S->B));
+      const int cap_thr = (S->tune.lean_wg_per_cu > 0 ? S->tune.lean_wg_per_cu : (int)std::min<size_t>(8, (160 * 1024) / flds)) * (int)(cu_sh + 0.5);
+      const int cap_lat = (int)std::min<size_t>(4, (160 * 1024) / flds) * (int)(cu_sh + 0.5);
+      const bool two_stage = S->tune.flat_two_stage && n > 2 * cap_lat * ipw;
       P.max_launch_iters = S->opt.max_iter + 1;
-      const dim3 grid((unsigned)std::min((n + ipw - 1) / ipw, wg_cap));
       HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
       {
@@ -1485,19 +1488,43 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(C->ev_k2, C->stream));
       }
-      hipLaunchKernelGGL(k_ring_fill, grid1(C->ring_cap), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, list, n, C->d_counters);
-      if (small_na)
-        hipLaunchKernelGGL((k_flat<T, FLAT_NA_SMALL>), grid, dim3(WAVE), flds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
-                           (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, (const int*)C->d_ring, n, lgG,
-                           (const T*)C->d_fslots, frows, kexp_lo, ndec, (T)S->Href[0], has_hv);
-      else
-        hipLaunchKernelGGL((k_flat<T, FLAT_MAXA>), grid, dim3(WAVE), flds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
-                           (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, (const int*)C->d_ring, n, lgG,
-                           (const T*)C->d_fslots, frows, kexp_lo, ndec, (T)S->Href[0], has_hv);
-      HIPCHK(hipGetLastError());
+      unsigned int first_iters = 0, first_wave_iters = 0, first_loads = 0, first_hits = 0, first_seen = 0;
+      int n_first = n;
+      dim3 grid(1);
+      for (int stage = two_stage ? 0 : 1; stage < 2 && n > 0; ++stage) {
+        const bool lat = stage == 1;
+        grid = dim3((unsigned)std::min((n + ipw - 1) / ipw, lat ? cap_lat : cap_thr));
+        if (stage == 1 && two_stage) {
+          // (the survivors of the throughput stage: the list k_list_unfinished wrote; counters of that stage are kept)
+          HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+          HIPCHK(hipStreamSynchronize(C->stream));
+          first_iters = C->h_counters[1]; first_wave_iters = C->h_counters[5]; first_loads = C->h_counters[6];
+          first_hits = C->h_counters[FLAT_COUNTERS_SLOT_HITS]; first_seen = C->h_counters[LEAN_DECADES_SEEN];
+          n = (int)C->h_counters[3];
+          if (n == 0) { first_iters = first_wave_iters = first_loads = first_hits = 0; break; }  // (h_counters still hold them)
+          list = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
+          grid = dim3((unsigned)std::min((n + ipw - 1) / ipw, cap_lat));
+          HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
+          if (trace) fprintf(stderr, "[loikb] flat engine, throughput stage: %d of %d instances still iterating when the queue ran dry\n", n, n_first);
+        }
+        hipLaunchKernelGGL(k_ring_fill, grid1(C->ring_cap), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, list, n, C->d_counters);
+#define LOIKB_LAUNCH_FLAT(NAV, LATV)                                                                                            \
+  hipLaunchKernelGGL((k_flat<T, NAV, LATV>), grid, dim3(WAVE), flds, C->stream, P, Bf, (const JointDesc*)S->d_jd,                \
+                     (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, (const int*)C->d_ring, n, lgG,          \
+                     (const T*)C->d_fslots, frows, kexp_lo, ndec, (T)S->Href[0], has_hv, (int)(!lat))
+        if (small_na) { if (lat) LOIKB_LAUNCH_FLAT(FLAT_NA_SMALL, true); else LOIKB_LAUNCH_FLAT(FLAT_NA_SMALL, false); }
+        else { if (lat) LOIKB_LAUNCH_FLAT(FLAT_MAXA, true); else LOIKB_LAUNCH_FLAT(FLAT_MAXA, false); }
+#undef LOIKB_LAUNCH_FLAT
+        HIPCHK(hipGetLastError());
+        int* nxt = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
+        hipLaunchKernelGGL(k_list_unfinished<T>, grid1(n), dim3(256), 0, C->stream, A.tiles, S->L, list, n, nxt, C->d_counters + 3);
+        HIPCHK(hipGetLastError());
+        C->stats.launches++;
+        C->stats.tail_launches++;
+        C->stats.lean_launches++;
+        C->stats.flat_launches++;
+      }
       int* next = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
-      hipLaunchKernelGGL(k_list_unfinished<T>, grid1(n), dim3(256), 0, C->stream, A.tiles, S->L, list, n, next, C->d_counters + 3);
-      HIPCHK(hipGetLastError());
       HIPCHK(hipEventRecord(C->ev_k1, C->stream));
       HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
       HIPCHK(hipStreamSynchronize(C->stream));
@@ -1505,11 +1532,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));
       HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0));
       HIPCHK(hipEventElapsedTime(&hms, C->ev_k0, C->ev_k2));
-      iters += C->h_counters[1];
+      iters += first_iters + C->h_counters[1];
       const unsigned int escaped = C->h_counters[2];
       {
         std::lock_guard<std::mutex> lock(S->alloc_mu);
-        const unsigned int seen = C->h_counters[LEAN_DECADES_SEEN];
+        const unsigned int seen = C->h_counters[LEAN_DECADES_SEEN] | first_seen;
         for (int d = 0; d < 16; ++d)
           if (seen & (1u << d)) { S->seen_lo = std::min(S->seen_lo, kexp_lo + d); S->seen_hi = std::max(S->seen_hi, kexp_lo + d); }
         if (escaped) { S->seen_lo = S->plan.kexp_lo; S->seen_hi = S->plan.kexp_lo + S->plan.ndec - 1; }
@@ -1517,14 +1544,10 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       }
       C->stats.hslots_ms += hms;
       if (trace)
-        fprintf(stderr, "[loikb] flat engine: %6d instances on %u workgroups, done at %8.3f ms (slots %6.3f ms)  inst-iters %9u  "
-                        "wave-iters %7u  slot loads %7u (+ %u served from LDS)  escaped %u  still iterating %u\n",
-                n, grid.x, ms, hms, C->h_counters[1], C->h_counters[5], C->h_counters[6], C->h_counters[FLAT_COUNTERS_SLOT_HITS],
-                escaped, C->h_counters[3]);
-      C->stats.launches++;
-      C->stats.tail_launches++;
-      C->stats.lean_launches++;
-      C->stats.flat_launches++;
+        fprintf(stderr, "[loikb] flat engine: %6d instances (%d in the latency build on %u workgroups), done at %8.3f ms (slots %6.3f ms)  "
+                        "inst-iters %9u  wave-iters %7u  slot loads %7u (+ %u served from LDS)  escaped %u  still iterating %u\n",
+                n_first, n, grid.x, ms, hms, first_iters + C->h_counters[1], first_wave_iters + C->h_counters[5],
+                first_loads + C->h_counters[6], first_hits + C->h_counters[FLAT_COUNTERS_SLOT_HITS], escaped, C->h_counters[3]);
       C->stats.lean_escaped += (int)escaped;
       C->tail_iv.emplace_back(t0, t0 + ms);
       total_ms = ms;

@@ -3,6 +3,6 @@
 cd ${GRAFT_REPO_ROOT:-.}
 for f in "$@"; do
   python -c "from loik_amd import _build; _build.build(force=True, extra_flags=tuple('$f'.split()))" > /dev/null 2>&1 || echo "build failed: $f"
-  for r in 1 2; do TAG="[$f]" python ${SCRIPT:-scripts/r03/quick_headline.py} ${ARGS:-65536 6}; done
+  for a in ${SIZES:-65536 4096}; do TAG="[$f]" python ${SCRIPT:-scripts/r03/quick_headline.py} $a 6; done
 done
 python -c "from loik_amd import _build; _build.build(force=True)" > /dev/null 2>&1
