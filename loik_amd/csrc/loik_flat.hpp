@@ -48,9 +48,6 @@ constexpr int FLAT_MAXA = 16;  // strict ancestors per joint (tree depth <= 17)
 constexpr int FOLDW = 10;      // scalars per lane row of the norm fold (80 B: an odd number of 16-byte slots)
 constexpr int FLAT_COUNTERS_SLOT_HITS = 12;  // Bufs::counters[12]: decade changes served from the second LDS slot
 constexpr int FLAT_NA_SMALL = 10;  // k_flat is compiled for <= 10 and <= FLAT_MAXA ancestors per joint
-#ifndef LOIKB_FLAT_WSLOTS
-#define LOIKB_FLAT_WSLOTS 1  // 1: k_fslots precomputes the joints' W columns for every decade (default); 0 (kept for measurements): the
-#endif                      // slots hold UDinv / Dinv only and k_flat builds a column when an instance enters a decade (+12 % launch time)
 constexpr int FSLOT_ROWS = 7;      // decade slot of a joint: UDinv (6, link frame) and Dinv
 
 // per lane of a group: the lane's joint (lane j <-> device joint j + 1, depth-first numbering) in the static tree
@@ -578,15 +575,18 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   while (true) {
     if (need_load) { load_instance(); need_load = false; }
     if (!__any(has_inst)) break;
-    // ---- decade of mu: W rows and Dinv.  Two decades stay in LDS: a flip back to the previous one costs nothing.
-    if (!done && (int)my_iters >= P.max_launch_iters) done = true;
-    if (!LAT && drain && !done && (my_iters & 15u) == 15u) {
-      // has the queue run dry?  Then what is still iterating goes back to the list and continues in the latency build.  (Asked
-      // every 16th iteration of an instance: the flag is one word in global memory that every wavefront of the launch reads --
-      // read in every iteration, its round trip doubled the launch time.)
-      if (__hip_atomic_load(Bf.counters + FLAT_COUNTERS_DRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) done = true;
+    // ---- does the instance leave before this iteration?  (fetched already finished; this launch's share of iterations used
+    // up; the queue has run dry and the latency build takes over; mu left the precomputed decades.)  Then it goes back as it
+    // is, and the group idles through this iteration: a group without an instance computes on garbage, inside its own lanes
+    // and LDS rows, and nothing of it is kept -- so the iteration below updates its registers without predicates.
+    bool exit_now = has_inst && (done || (int)my_iters >= P.max_launch_iters);
+    if (!LAT && drain && has_inst && (my_iters & 15u) == 15u) {
+      // (asked every 16th iteration of an instance: the flag is one word in global memory that every wavefront of the launch
+      //  reads -- read in every iteration, its round trip doubled the launch time)
+      if (__hip_atomic_load(Bf.counters + FLAT_COUNTERS_DRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) exit_now = true;
     }
-    if (!done && kexp != kslot) {
+    // ---- decade of mu: W rows and Dinv.  Two decades stay in LDS: a flip back to the previous one costs nothing.
+    if (has_inst && !exit_now && kexp != kslot) {
       if (kexp == kslot_o) {
         { const int tk = kslot; kslot = kslot_o; kslot_o = tk; }
         wsel ^= 1;
@@ -594,13 +594,15 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       } else {
         const int dsl = kexp - kexp_lo;
         if (dsl < 0 || dsl >= ndec) {
-          done = true;  // mu left the precomputed decades: written back unfinished, k_tail takes over
+          exit_now = true;  // mu left the precomputed decades: written back unfinished, k_tail takes over
           if (jlane == 0) atomicAdd(&Bf.counters[2], 1u);
         } else {
           kslot_o = kslot;  // the slot that was not used last is overwritten
           wsel ^= 1;
           T* wdst = wl + (size_t)wsel * (NA + 1) * WAVE;
-#if LOIKB_FLAT_WSLOTS
+          // (k_fslots precomputes the joints' W columns for every decade.  Measured and rejected: slots that hold UDinv / Dinv
+          //  only -- 7 scalars instead of 10 -- with the column built here when an instance enters a decade: the instances that
+          //  cycle through three decades rebuild at every other move, +12 % launch time on the headline.)
           if (isj) {
             T in[NA + 1];
 #pragma unroll
@@ -612,56 +614,19 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
             for (int k = 0; k <= NA; ++k) wdst[k * WAVE + lane] = T(0);
           }
-#else
-          // The decade's UDinv (link frame) and Dinv come from the slots k_fslots_a built; the joint's column of W is made
-          // here: UDinv to the world origin, L_{a,d} = S^w_a . UDinv^w_d for the ancestors a, the L columns of the group's
-          // joints exchanged through LDS, then  W_{a,d} = -(L_{a,d} + sum_{e strictly between a and d} L_{a,e} W_{e,d}),
-          // nearest ancestor first.  (A lane group may run this alone: the exchanges stay inside the group.)
-          T UD[6], UDw[6], dnew = T(0);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) UD[k] = isj ? fslots[fslot_at(lidx, ndec, dsl, G, FSLOT_ROWS, k, jlane)] : T(0);
-          if (isj) dnew = fslots[fslot_at(lidx, ndec, dsl, G, FSLOT_ROWS, 6, jlane)];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) UDw[k] = UD[k];  // (the slots hold UDinv at the world origin)
-          tail_sync();
-          if (jlane < 6) xb[WAVE * 6 + jlane] = T(0);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) xb[lane * 6 + k] = Sw[k];
-          tail_sync();
-          T Lc[NA], Wc[NA];
-          int arow[NA];
-#pragma unroll
-          for (int k = 0; k < NA; ++k) {
-            arow[k] = unpack8(anc4, k);
-            Lc[k] = dot6_halves(xb + arow[k] * 6, UDw);
-            Wc[k] = T(0);
-          }
-          tail_sync();
-#pragma unroll
-          for (int k = 0; k < NA; ++k) xb[k * WAVE + lane] = Lc[k];
-          if (jlane == 0) xb[NA * WAVE] = T(0);
-          tail_sync();
-          const int nown = isj_lane ? depth1 : 0;  // strict ancestors of this lane's joint
-#pragma unroll
-          for (int k = NA - 1; k >= 0; --k) {
-            T acc = Lc[k];
-#pragma unroll
-            for (int k2 = k + 1; k2 < NA; ++k2) acc += xb[arow[k2] < WAVE ? k * WAVE + arow[k2] : NA * WAVE] * Wc[k2];  // (no such ancestor: the zero)
-            Wc[k] = (k < nown) ? -acc : T(0);
-          }
-          tail_sync();
-#pragma unroll
-          for (int k = 0; k < NA; ++k) wdst[k * WAVE + lane] = Wc[k];
-          wdst[NA * WAVE + lane] = dnew;
-#endif
           kslot = kexp;
           n_slot_loads = (n_slot_loads + 0x10000u) | (1u << dsl);
         }
       }
     }
+    if (exit_now) {
+      store_instance();
+      has_inst = false; isj = false; done = true;
+      need_load = true;
+    }
     const T* wcur = wl + (size_t)wsel * (NA + 1) * WAVE;  // (per lane group: wsel differs between the groups of a wavefront)
     TAIL_TP(8)
-    const bool act = !done;
+    const bool act = has_inst;  // (an instance that is here iterates: `done` is only set by the stopping logic below)
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
     if (act) { ++my_iters; any_iter = true; }
     ++n_wave_iters;
@@ -710,7 +675,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
       for (int j = 0; j < FLAT_PART; ++j) acc += pp[j];
       rn = tau + acc;
-      if (act) rbuf[lane] = rn;
+      rbuf[lane] = rn;
       nbuf[lane] = dinv * rn;
     }
     tail_sync();
@@ -744,6 +709,8 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     // one LDS exchange per step.  The constraints' update -- (A v - b, dy, y) and then (A^T y, the same at the world origin, the
     // pieces of this iteration's force balance) -- needs two exchanges of its own: it rides on the first two steps.
     T l_dyis = T(0), l_av = T(0), l_prt = T(0), l_up = T(0), l_lm = T(0);
+    T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_prs = T(0);
+    T l_dg = T(0), l_g = T(0), l_stf = T(0), l_dstf = T(0), l_dualv = T(0);
     T fi[6], si;
     {
       T SEn[6], Fw[6], Bk[6];
@@ -777,7 +744,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       }
       tail_sync();
       scan_step(0);
-      if (act && iscl) {
+      if (iscl) {
         const T* A_ = ccb + FC_A;
         const T* vc = ccb + FC_VC;
         T avk = A_[6 * ckl] * vc[0];
@@ -798,7 +765,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       put_rows();
       tail_sync();
       scan_step(1);
-      if (act && iscl) {
+      if (iscl) {
         // A^T y (hxx:422) and the same at the world origin; and the two pieces of THIS iteration's force balance that are not
         // A^T y of the new dual: the constraint's share of H^base v + p^base is A^T dy + (the A^T y FwdPass1 used), which is
         // A^T y_new only when the instance arrived with A^T y consistent with its A (not after UpdateEqConstraint replaced A
@@ -816,13 +783,64 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         ccb[FC_ATY + k] = at;
         ccb[FC_ATYW + k] = aw;
       }
+      // ---- per-joint work that needs v and nu only -- BoxProj, the w update, their norms, g (hxx:129-158, :384-397, :454-458) --
+      // placed here so that it runs while the last exchange of the subtree sum is in flight
+      auto part_v = [&]() {
+        {
+          T dv6[6], gi[6], dg[6], dvr[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            dv6[k] = vi[k] - v[k];
+            // g_i = A^T y_i + sum_children act(f_c) - f_i = A^T y_i - (H^base_i v_i + p^base_i)  (force balance)
+            gi[k] = -mass * (P.rho * dv6[k] + href_s * vi[k]);
+          }
+          if (has_hv) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) gi[k] += mass * P.Hv[k];
+          }
+          if (jcslot >= 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) gi[k] += cdi[jcslot * cs + FC_DLT + k];
+          }
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            dg[k] = gi[k] - g[k];
+            dvr[k] = mass * (href_s * vi[k]) + gi[k];  // dual residual, v block (hxx:228): H_ref v - Hv + g
+          }
+          if (has_hv) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dvr[k] -= mass * P.Hv[k];
+          }
+          l_dualv = inf6(dvr);
+          l_nu = tabs(nui);
+          l_hrefv = mass * tabs(href_s) * inf6(vi);
+          l_dvis = mass * inf6(dv6);
+          l_dnu = tabs(nui - nu);
+          const T x = nui + (T(1) / mu_in) * w;
+          const T zi = tmin(ubi, tmax(lbi, x));
+          l_dz = tabs(zi - z);
+          l_prs = tabs(nui - zi);
+          const T dwi = mu_in * (nui - zi);
+          l_dw = tabs(dwi);
+          l_up += ubi * tmax(dwi, T(0));
+          l_lm += lbi * tmin(dwi, T(0));
+          w = w + dwi; z = zi; nu = nui;
+          l_dg = inf6(dg);
+          l_g = inf6(gi);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { v[k] = vi[k]; g[k] = gi[k]; }
+        }
+      };
       int kk = 2;
       for (; kk + 2 < nscan; ++kk) {
         put_rows();
         tail_sync();
         scan_step(kk);
       }
-      if (kk < nscan) {
+      if (kk >= nscan) {  // (a tree without a subtree of four joints: no exchange left to hide behind)
+        tail_sync();
+        part_v();
+      } else {
         // the last two bits of `size` in one exchange: the window of width 2^(kk+1) is two windows of width 2^kk
         put_rows();
         tail_sync();
@@ -837,6 +855,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         for (int c = 0; c < 6; ++c) b[c] = xb[r1 * 6 + c];
 #pragma unroll
         for (int c = 0; c < 6; ++c) c2[c] = xb[r2 * 6 + c];
+        part_v();
 #pragma unroll
         for (int c = 0; c < 6; ++c) SEn[c] += a[c] + (b[c] + c2[c]);
       }
@@ -856,64 +875,22 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       }
       actinv_force(R0, t0, Fw, fi);
       si = dot6_halves(Sw, Fw);  // S^T f (hxx:231-233): the pairing of a motion and a force does not depend on the frame
-      if (act) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) SE[k] = SEn[k];
-      }
+      for (int k = 0; k < 6; ++k) SE[k] = SEn[k];
     }
     TAIL_TP(5)
-    // ================= per-joint work: BoxProj, the w update, the norms (hxx:129-158, :384-397, :454-458) ======================
-    T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_prs = T(0);
-    T l_dg = T(0), l_g = T(0), l_stf = T(0), l_dstf = T(0), l_dualv = T(0);
-    if (act && isj) {
-      T df[6], dv6[6], gi[6], dg[6], dvr[6];
+    // ================= what is left of the per-joint work: the norms that need f (hxx:137-146, :231-236) =========================
+    {
+      T df[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        df[k] = fi[k] - f[k];
-        dv6[k] = vi[k] - v[k];
-        // g_i = A^T y_i + sum_children act(f_c) - f_i = A^T y_i - (H^base_i v_i + p^base_i)  (force balance)
-        gi[k] = -mass * (P.rho * dv6[k] + href_s * vi[k]);
-      }
-      if (has_hv) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) gi[k] += mass * P.Hv[k];
-      }
-      if (jcslot >= 0) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) gi[k] += cdi[jcslot * cs + FC_DLT + k];
-      }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        dg[k] = gi[k] - g[k];
-        dvr[k] = mass * (href_s * vi[k]) + gi[k];  // dual residual, v block (hxx:228): H_ref v - Hv + g
-      }
-      if (has_hv) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) dvr[k] -= mass * P.Hv[k];
-      }
-      l_dualv = inf6(dvr);
-      l_nu = tabs(nui);
+      for (int k = 0; k < 6; ++k) df[k] = fi[k] - f[k];
       l_dfis = mass * inf6(df);
-      l_hrefv = mass * tabs(href_s) * inf6(vi);
-      l_dvis = mass * inf6(dv6);
-      l_dnu = tabs(nui - nu);
-      const T x = nui + (T(1) / mu_in) * w;
-      const T zi = tmin(ubi, tmax(lbi, x));
-      l_dz = tabs(zi - z);
-      l_prs = tabs(nui - zi);
-      const T dwi = mu_in * (nui - zi);
-      l_dw = tabs(dwi);
-      l_up += ubi * tmax(dwi, T(0));
-      l_lm += lbi * tmin(dwi, T(0));
-      w = w + dwi; z = zi; nu = nui;
-      l_dg = inf6(dg);
-      l_g = inf6(gi);
       si += w;
       l_stf = tabs(si);
       l_dstf = tabs(si - s);
       s = si;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { v[k] = vi[k]; f[k] = fi[k]; g[k] = gi[k]; }
+      for (int k = 0; k < 6; ++k) f[k] = fi[k];
     }
     TAIL_TP(3)
     // ================= the scalars of the stopping logic, folded over the group ================================================
