@@ -311,8 +311,8 @@ const char *loikb_plan_string(loikb_solver *s);
 /* The flat engine's schedule of a kinematic tree (inspection / tests; loik_amd/csrc/loik_flat.hpp: the engine replaces the
  * level-by-level recursions of LoikBackwardStepVisitor / LoikForwardStep2Visitor, loik-loid-optimized.hxx:31-81, :102-163, by
  * sums over subtrees and root paths).  meta[5] = {applicable, lanes per instance G, ancestors per joint, scan steps, jump
- * rounds}; out = G records of 37 ints: depth, subtree size, jmp[5] (lane of the ancestor at distance 1, 2, 4, 8, 16), anc[16]
- * (lane of the ancestor at depth k + 1), red[8] (entries k * G + lane of the W tau products the lane sums), helper, part[5]
+ * rounds}; out = G records of 40 ints: depth, subtree size, jmp[5] (lane of the ancestor at distance 1, 2, 4, 8, 16), anc[16]
+ * (lane of the ancestor at depth k + 1), red[8] (entries k * G + lane of the W tau products the lane sums), helper, part[8]
  * (lanes whose partial sums the lane collects); -1 = none.  Returns 0, or the number of ints `out` needs when cap is smaller;
  * not applicable (meta[0] == 0): loikb_last_error() says why. */
 int loikb_flat_schedule(const int *parents, int njoints, int *out, int cap, int *meta);

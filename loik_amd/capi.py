@@ -184,7 +184,7 @@ def flat_schedule(parents):
     rec = out.reshape(G, -1)
     return dict(G=G, nanc=int(meta[2]), nscan=int(meta[3]), njmp=int(meta[4]), depth=rec[:, 0].copy(), size=rec[:, 1].copy(),
                 jmp=rec[:, 2:7].copy(), anc=rec[:, 7:23].copy(), red=rec[:, 23:31].copy(), helper=rec[:, 31].copy(),
-                part=rec[:, 32:37].copy())
+                part=rec[:, 32:40].copy())
 
 
 def _check(rc):

@@ -42,7 +42,7 @@
 namespace loikb {
 
 constexpr int FLAT_RED = 8;    // terms of the W tau products one lane sums
-constexpr int FLAT_PART = 5;   // partial sums a joint with a long row collects from helper lanes
+constexpr int FLAT_PART = 8;   // partial sums a joint with a long row collects from helper lanes
 constexpr int FLAT_JMP = 5;    // pointer-jumping rounds (tree depth <= 32)
 constexpr int FLAT_MAXA = 16;  // strict ancestors per joint (tree depth <= 17)
 constexpr int FOLDW = 10;      // scalars per lane row of the norm fold (80 B: an odd number of 16-byte slots)
