@@ -163,7 +163,9 @@ int loikb_active_constraint_ids(const loikb_solver *s, int *out, int cap); /* re
  * with options.logging = 1 ("logging residuals, should be disabled for speed", hpp:408): every Solve then runs on the plain
  * pass-by-pass implementation behind loikb_pass (fp64, 1-DoF joints) and records, per instance and main-loop iteration, what
  * upstream pushes after ComputeResiduals (hpp:406-420).  loikb_get returns the state that implementation left.
- *   out[b][k], k = iteration - 1 < rows[b]: the list of instance b ([B][max_iter - 1], zero beyond rows[b]); rows may be NULL.
+ *   out[b][k], k = iteration - 1 < rows[b]: the list of instance b ([B][out_rows_cap], zero beyond rows[b]); rows may be NULL.
+ *   out_rows_cap = entries per instance the caller's buffer holds: loikb_solver_info_rows_cap() (= max_iter - 1 at the time of
+ *   the solve) gives the full lists; a shorter buffer gets their first out_rows_cap entries.
  *   rows[b] = iterations of the main loop = size of every residual / mu list; iter_list_ is 1 .. get_iter(), the tail solve adds
  *   get_tail_solve_iter entries to iter_list_ / tail_solve_iter_list_ only (hpp:286-290).  The lists are those of the LAST solve
  *   (upstream never clears them in Solve(): unbounded growth, SURVEY 8(a) note 2, not replicated).                          */
@@ -171,7 +173,8 @@ enum {
   LOIKB_LOG_PRIMAL_RESIDUAL_TASK = 0, LOIKB_LOG_PRIMAL_RESIDUAL_SLACK, LOIKB_LOG_PRIMAL_RESIDUAL, LOIKB_LOG_DUAL_RESIDUAL_NU,
   LOIKB_LOG_DUAL_RESIDUAL_V, LOIKB_LOG_DUAL_RESIDUAL, LOIKB_LOG_MU, LOIKB_LOG_MU_EQ, LOIKB_LOG_MU_INEQ, LOIKB_LOG_NLIST
 };
-int loikb_get_solver_info(loikb_solver *s, int list, double *out, int *rows);
+int loikb_get_solver_info(loikb_solver *s, int list, double *out, int out_rows_cap, int *rows);
+int loikb_solver_info_rows_cap(const loikb_solver *s);
 
 /* Outer loop on the device (the caller side of the path: a sampling planner / global IK iterates
  * solve -> integrate -> re-target, README.md:5 of the reference).  The configurations q stay

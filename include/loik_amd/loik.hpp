@@ -21,6 +21,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 namespace loik_amd {
@@ -180,6 +181,9 @@ public:
     o.batch = batch_; o.device = device; o.precision = LOIKB_F64; o.flags = flags;
     o.eq_c_capacity = eq_c_capacity;  // room for AddEqConstraint (0: num_eq_c slots, as upstream sizes yis / Aty)
     const loikb_model_desc d = model_.desc();
+    if (loikb_version() != LOIKB_VERSION)  // (struct layouts of this header against the loaded library's)
+      throw std::runtime_error("loik_amd: libloik_amd.so has ABI version " + std::to_string(loikb_version()) + ", this header is version " +
+                               std::to_string(LOIKB_VERSION) + ": rebuild the library");
     check(loikb_create(&d, &o, &h_));
     max_iter_ = max_iter; rho_ = rho; tol_tail_solve_ = tol_tail_solve; tol_primal_inf_ = tol_primal_inf; tol_dual_inf_ = tol_dual_inf;
     for (LazyField* f : {&ik_id_data_.His, &ik_id_data_.pis, &ik_id_data_.Aty, &ik_id_data_.liMi}) {
@@ -338,14 +342,15 @@ public:
   LoikSolverInfo get_solver_info(int b = 0) const
   {
     LoikSolverInfo info;
-    const std::size_t cap = static_cast<std::size_t>(max_iter_ > 1 ? max_iter_ - 1 : 1);
+    // (rows per instance as the library stored them: max_iter - 1 at the time of that solve, whatever set_max_iter did since)
+    const std::size_t cap = static_cast<std::size_t>(std::max(loikb_solver_info_rows_cap(h_), 1));
     DVec buf(static_cast<std::size_t>(batch_) * cap);
     std::vector<int> rows(static_cast<std::size_t>(batch_));
     std::vector<double>* lists[] = {&info.primal_residual_task_list_, &info.primal_residual_slack_list_, &info.primal_residual_list_,
                                     &info.dual_residual_nu_list_, &info.dual_residual_v_list_, &info.dual_residual_list_,
                                     &info.mu_list_, &info.mu_eq_list_, &info.mu_ineq_list_};
     for (int l = 0; l < LOIKB_LOG_NLIST; ++l) {
-      check(loikb_get_solver_info(h_, l, buf.data(), rows.data()));
+      check(loikb_get_solver_info(h_, l, buf.data(), static_cast<int>(cap), rows.data()));
       lists[l]->assign(buf.begin() + b * cap, buf.begin() + b * cap + rows[b]);
     }
     const int n_iter = get_iter(b), n_tail = n_iter - rows[b];   // the tail solve extends iter_list_ only (hpp:286-290)

@@ -10,8 +10,9 @@
  *
  * Joints: all of Pinocchio's 1-DoF types (incl. the unbounded revolute joints with q = (cos, sin)), the multi-DoF types
  * whose motion subspace is a constant selection of the columns of I6 -- free-flyer (floating base), spherical, translation,
- * planar -- and JointModelSphericalZYX, whose q-dependent subspace is that of a Z-Y-X revolute chain.
- * Not covered: JointModelComposite and JointModelMimic (one jtype per joint here).  On the device such a
+ * planar --, JointModelSphericalZYX, whose q-dependent subspace is that of a Z-Y-X revolute chain, and
+ * JointModelComposite of 1-DoF sub-joints (LOIKB_J_COMPOSITE + the comp_* arrays below).  Not covered: JointModelMimic, composites
+ * with multi-DoF sub-joints.  On the device a multi-DoF
  * joint is a chain of 1-DoF joints with massless links in between; the caller never sees that: q, z / nu / w / lb / ub
  * (length model.nv, Pinocchio's idx_v order) and the per-link results are the caller's model's.
  */

@@ -82,7 +82,7 @@ EXPORTED_SYMBOLS = [
     "loikb_batch", "loikb_nv", "loikb_njoints", "loikb_last_error", "loikb_status_string", "loikb_version",
     "loikb_device_count", "loikb_sweep_schedule", "loikb_integrate", "loikb_synchronize", "loikb_plan_string", "loikb_pass",
     "loikb_update_references", "loikb_update_eq_constraint", "loikb_add_eq_constraint", "loikb_remove_eq_constraint",
-    "loikb_num_eq_c", "loikb_eq_c_capacity", "loikb_active_constraint_ids", "loikb_get_solver_info", "loikb_builtin_model", "loikb_builtin_joint_name",
+    "loikb_num_eq_c", "loikb_eq_c_capacity", "loikb_active_constraint_ids", "loikb_get_solver_info", "loikb_solver_info_rows_cap", "loikb_builtin_model", "loikb_builtin_joint_name",
     "loikb_builtin_joint_id", "loikb_flat_schedule"]
 
 _lib = None
@@ -120,7 +120,8 @@ def lib():
     L.loikb_num_eq_c.argtypes = [C.c_void_p]
     L.loikb_eq_c_capacity.argtypes = [C.c_void_p]
     L.loikb_active_constraint_ids.argtypes = [C.c_void_p, _ip, C.c_int]
-    L.loikb_get_solver_info.argtypes = [C.c_void_p, C.c_int, _dp, _ip]
+    L.loikb_get_solver_info.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _ip]
+    L.loikb_solver_info_rows_cap.argtypes = [C.c_void_p]
     L.loikb_set_max_iter.argtypes = [C.c_void_p, C.c_int]
     for n in ["loikb_set_rho", "loikb_set_mu", "loikb_set_tol_primal_inf", "loikb_set_tol_tail_solve"]:
         getattr(L, n).argtypes = [C.c_void_p, C.c_double]
@@ -564,13 +565,14 @@ class BatchedLoik:
                          "dual_residual_v_list", "dual_residual_list", "mu_list", "mu_eq_list", "mu_ineq_list"]
 
     def solver_info(self):
-        """LoikSolverInfo of the last solve (constructor keyword logging=True): {list name: [B][max_iter - 1]}, 'rows': [B]"""
-        cap = max(self.opts.max_iter - 1, 1)
+        """LoikSolverInfo of the last solve (constructor keyword logging=True): {list name: [B][max_iter - 1]}, 'rows': [B]
+        (max_iter as it was when that solve ran: the library says how many rows it holds)"""
+        cap = max(int(self.L.loikb_solver_info_rows_cap(self.h)), 1)
         out = {}
         rows = np.zeros(self.batch, dtype=np.int32)
         for k, name in enumerate(self.SOLVER_INFO_LISTS):
             a = np.zeros((self.batch, cap))
-            _check(self.L.loikb_get_solver_info(self.h, k, a.ctypes.data_as(_dp), rows.ctypes.data_as(_ip)))
+            _check(self.L.loikb_get_solver_info(self.h, k, a.ctypes.data_as(_dp), cap, rows.ctypes.data_as(_ip)))
             out[name] = a
         out["rows"] = rows
         return out

@@ -1349,7 +1349,12 @@ void plan_engines(loikb_solver_impl* S)
   // is what a second batch in flight has to wait for (two batches in flight: 32.3 vs 35.6 ms per pair).
   pl.lean_wg_waves = 1;
   if (S->tune.lean_wg_waves > 0 && pl.lean_waves_cu % S->tune.lean_wg_waves == 0) pl.lean_wg_waves = S->tune.lean_wg_waves;
-  if (!S->tune.lean) pl.why_not_lean = "LOIKB_LEAN=0";
+  // (configurations that never reach the on-chip engines must not plan -- and allocate decade slots for -- them)
+  const char* never = S->opt.logging ? "logging = 1: every solve runs on the pass-by-pass implementation"
+                      : S->opt.tail_max_instances < 0 ? "tail_max_instances < 0: the caller asked for the solve kernel alone"
+                      : (S->opt.flags & LOIKB_OPT_NO_COMPACTION) ? "LOIKB_OPT_NO_COMPACTION: the solve kernel keeps every instance in its tile" : nullptr;
+  if (never) pl.why_not_lean = never;
+  else if (!S->tune.lean) pl.why_not_lean = "LOIKB_LEAN=0";
   else if (S->nb > WAVE) pl.why_not_lean = "more joints than lanes of a wavefront";
   else if (S->maxchild > 4) pl.why_not_lean = "a joint with more than four children";
   else if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) pl.why_not_lean = "LOIKB_OPT_NO_H_CACHE (no precomputed H)";
@@ -1368,7 +1373,8 @@ void plan_engines(loikb_solver_impl* S)
                                                            : flat_lds_bytes<double, FLAT_MAXA>(S->nc, S->flat.G, S->a_shared, false);
     pl.flat_waves_cu = (int)std::min<size_t>(8, (160 * 1024) / per_wave);
   }
-  if (!S->tune.flat) pl.why_not_flat = S->tune.lean ? "LOIKB_FLAT=0" : "LOIKB_LEAN=0";
+  if (never) pl.why_not_flat = never;
+  else if (!S->tune.flat) pl.why_not_flat = S->tune.lean ? "LOIKB_FLAT=0" : "LOIKB_LEAN=0";
   else if (!S->flat.ok) pl.why_not_flat = S->flat.why;
   else if (S->f32) pl.why_not_flat = "fp32 solver";
   else if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) pl.why_not_flat = "LOIKB_OPT_NO_H_CACHE (no precomputed factors)";
@@ -2524,6 +2530,9 @@ static int run_logged(loikb_solver_impl* S)
   hipLaunchKernelGGL(k_pass_solve, grid1(S->B, 64), dim3(64), 0, S->stream, S->PL, P, (const JointDesc*)S->d_jd,
                      (const int*)S->d_pass_cslot, S->d_pass, S->d_log, cap, S->d_log_rows);
   HIPCHK(hipGetLastError());
+  // the result goes back to the tiles too: a warm-started solve, loikb_integrate and the engines' getters continue from it
+  hipLaunchKernelGGL(k_pass_store<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, S->PL, P, (const double*)S->d_pass);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(S->ev_t1, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
   float ms = 0.f;
@@ -2531,18 +2540,32 @@ static int run_logged(loikb_solver_impl* S)
   S->stats = loikb_stats{};
   S->stats.launches = 1;
   S->stats.kernel_ms = ms; S->stats.total_ms = ms;
+  {
+    Chunk* C0 = &S->chunks[0];
+    HIPCHK(hipMemsetAsync(C0->d_counters, 0, sizeof(unsigned int), S->stream));
+    hipLaunchKernelGGL(k_count_unfinished<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, S->B, C0->d_counters);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(C0->h_counters, C0->d_counters, sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
+    S->stats.n_unfinished = (int)C0->h_counters[0];
+  }
   S->have_log = true;
   return LOIKB_OK;
 }
 
-int loikb_get_solver_info(loikb_solver* S, int list, double* out, int* rows_out)
+int loikb_solver_info_rows_cap(const loikb_solver* S) { return (S && S->have_log) ? S->log_rows_cap : 0; }
+
+int loikb_get_solver_info(loikb_solver* S, int list, double* out, int out_rows_cap, int* rows_out)
 {
-  if (!S || list < 0 || list >= LOG_NLIST || !out) return LOIKB_ERR_ARG;
+  if (!S || list < 0 || list >= LOG_NLIST || !out || out_rows_cap < 1) return LOIKB_ERR_ARG;
   if (!S->have_log) { g_last_error = "no SolverInfo: create the solver with logging = 1 and solve"; return LOIKB_ERR_STATE; }
   HIPCHK(hipSetDevice(S->device));
-  const int cap = S->log_rows_cap;
-  // (the lists are stored list-major and zero beyond rows[b]: one contiguous copy per list)
-  HIPCHK(hipMemcpy(out, S->d_log + (size_t)list * S->B * cap, sizeof(double) * (size_t)S->B * cap, hipMemcpyDeviceToHost));
+  const int cap = S->log_rows_cap;  // rows per instance of the stored lists (max_iter - 1 AT THE TIME OF THE SOLVE)
+  // (the lists are stored list-major and zero beyond rows[b]; the caller's rows may be shorter or longer than the stored ones)
+  const int n = std::min(cap, out_rows_cap);
+  if (out_rows_cap > cap) memset(out, 0, sizeof(double) * (size_t)S->B * out_rows_cap);
+  HIPCHK(hipMemcpy2D(out, sizeof(double) * (size_t)out_rows_cap, S->d_log + (size_t)list * S->B * cap, sizeof(double) * (size_t)cap,
+                     sizeof(double) * (size_t)n, (size_t)S->B, hipMemcpyDeviceToHost));
   if (rows_out) HIPCHK(hipMemcpy(rows_out, S->d_log_rows, sizeof(int) * (size_t)S->B, hipMemcpyDeviceToHost));
   return LOIKB_OK;
 }
@@ -2702,7 +2725,17 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   if (!S || !out) return LOIKB_ERR_ARG;
   HIPCHK(hipSetDevice(S->device));
   const bool to_dev = out_flags & LOIKB_OUT_DEVICE;
-  if (S->pass_active && field != LOIKB_F_Q) return pass_get(S, field, out, to_dev);
+  if ((field == LOIKB_F_HIS || field == LOIKB_F_PRIMAL_RESIDUAL_VEC || field == LOIKB_F_DUAL_RESIDUAL_VEC || field == LOIKB_F_UDINV ||
+       field == LOIKB_F_PIS) && !S->have_problem) {
+    g_last_error = "this member is built from the problem's reference cost: call SolveInit() first";
+    return LOIKB_ERR_STATE;
+  }
+  if (S->pass_active && field != LOIKB_F_Q) {
+    const int rc_pass = pass_get(S, field, out, to_dev);
+    if (rc_pass != LOIKB_ERR_ARG) return rc_pass;
+    // (not a member the pass state keeps -- status bits, mu updates, residual vectors: served from the tiles below, which a
+    //  logged solve leaves in sync, k_pass_store)
+  }
   if (field == LOIKB_F_Q) {
     if (!S->have_q) { g_last_error = "no configurations resident on the device yet"; return LOIKB_ERR_STATE; }
     HIPCHK(hipMemcpyAsync(out, S->d_q, sizeof(double) * (size_t)S->B * S->nq,

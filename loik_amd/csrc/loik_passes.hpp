@@ -177,6 +177,48 @@ __global__ void k_pass_load(char* tiles, Layout TL, const JointDesc* __restrict_
   sc[PS_PRIMAL_INF] = (status & ST_PRIMAL_INF) ? 1.0 : 0.0;
 }
 
+// ---- ... and written back to them after a logged solve (k_pass_solve): the persistent part of the data object and the
+// solver's scalars, so that what follows in the tiles -- a warm-started tailored Solve (Reset(true) keeps w, z, nu, the duals:
+// loik-loid-data-optimized.hxx:114-127), loikb_integrate (reads z), the getters of the fused engines -- continues from the
+// logged solve's result, not from the state before it.
+template <typename T>
+__global__ void k_pass_store(char* tiles, Layout TL, PassLayout L, PassParams P, const double* __restrict__ st)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= L.B) return;
+  const double* s = st + (size_t)b * L.stride;
+  char* lp = lane_ptr<T>(tiles, TL, b);
+  for (int i = 1; i < L.nj; ++i) {
+    char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
+    T v[6], f[6], g[6];
+    for (int k = 0; k < 6; ++k) { v[k] = (T)s[L.vis + 6 * i + k]; f[k] = (T)s[L.fis + 6 * i + k]; g[k] = (T)s[L.g + 6 * i + k]; }
+    st6<T>(rec, JP_V, v); st6<T>(rec, JP_F, f); st6<T>(rec, JP_G, g);
+    const int j = i - 1;
+    stp<T>(rec, JP_WZ, (T)s[L.w + j], (T)s[L.z + j]);
+    stp<T>(rec, JP_NUS, (T)s[L.nu + j], (T)s[L.Stf + j]);
+  }
+  for (int c = 0; c < L.nc; ++c) {
+    char* crec = lp + (size_t)(TL.off_c + c * TL.crec) * pair_bytes<T>();
+    T y[6], aty[6];
+    for (int k = 0; k < 6; ++k) { y[k] = (T)s[L.yis + 6 * c + k]; aty[k] = (T)s[L.Aty + 6 * c + k]; }
+    st6<T>(crec, CP_Y, y); st6<T>(crec, CP_ATY, aty);
+  }
+  const double* sc = s + L.scal;
+  char* srec = lp + (size_t)TL.off_s * pair_bytes<T>();
+  const double mu = sc[PS_MU];
+  const int kexp = (int)floor(log10(mu / P.mu0) + 0.5);  // mu = mu0 * 10^k under the DEFAULT rule (OSQP: the engines that read k do not run)
+  const bool conv = sc[PS_CONVERGED] != 0.0, pinf = sc[PS_PRIMAL_INF] != 0.0;
+  const int status = (conv ? ST_CONVERGED : 0) | (pinf ? ST_PRIMAL_INF : 0) | ((pinf && !conv) ? ST_TAIL : 0) | ST_DONE;
+  stp<T>(srec, SP_MU, (T)mu, (T)kexp);
+  st_hi<T>(srec, SP_BI, (T)sc[PS_ITER]);
+  stp<T>(srec, SP_ST, (T)status, (T)sc[PS_MU_IN]);
+  stp<T>(srec, SP_TAG, T(-1), T(0));   // no UDinv / Dinv of this solve in the tiles: the next engine rebuilds its cache
+  const int map[NSCAL] = {PS_PRIMAL, PS_DUAL, PS_PR_TASK, PS_PR_SLACK, PS_DUAL_V, PS_DUAL_NU, PS_TOL_P, PS_TOL_D, PS_MU, PS_MU_EQ, PS_MU_IN,
+                          PS_DX, PS_DZ_INF, PS_DYQP, PS_ATDY, PS_UBP, PS_LBM, PS_DFIS_INF, PS_DYIS_INF, PS_DW_INF, PS_DVIS_INF, PS_DNU_INF,
+                          PS_AV_INF, PS_NU_INF, PS_HREFV_INF, PS_G_INF, PS_STF_INF, PS_C1, PS_C2, PS_TAIL_IT};
+  for (int k = 0; k < NSCAL; ++k) st_scal<T>(srec, k, (T)sc[map[k]]);
+}
+
 enum : int {  // loikb_pass ids (include/loik_amd.h)
   PASS_BEGIN_ITERATION = 0, PASS_FWD1, PASS_BWD, PASS_FWD2, PASS_BOXPROJ, PASS_DUAL, PASS_RESIDUALS, PASS_CHECK_CONV,
   PASS_CHECK_FEAS, PASS_UPDATE_MU

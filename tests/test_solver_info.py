@@ -101,3 +101,42 @@ def test_gpu_solver_info_infeasible_fixture_and_errors(talos):
         s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
     assert e.value.code == -7
     s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_logged_solve_leaves_the_solver_state_in_the_tiles(talos):
+    """a handle with logging = 1 solves on the pass-by-pass implementation; what follows -- a warm-started tailored Solve
+    (Reset(true), loik-loid-data-optimized.hxx:114-127), loikb_integrate, the getters of the engines' own fields -- continues
+    from that solve's result: the same sequence with logging off gives the same numbers.  Also: the lists' capacity is the
+    library's (set_max_iter between the solve and the read changes nothing)."""
+    link = talos.getJointId("arm_left_7_joint")
+    B = 40
+    wl = feasible_batch(talos, B, link, 31, nu_scale=0.5)
+    wl2 = feasible_batch(talos, B, link, 32, nu_scale=0.5)
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0, warm_start=True)
+    res = {}
+    for logging in (False, True):
+        s = loik_amd.BatchedLoik(talos, B, logging=logging, **prm)
+        s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+        first = {n: s.get(n) for n in ["z", "iter", "status", "mu", "primal_residual", "mu_updates"] if not (logging and n == "mu_updates")}
+        if logging:
+            info = s.solver_info()
+            s.set_max_iter(20)                      # (the stored lists keep the capacity of the solve that filled them)
+            info2 = s.solver_info()
+            assert info["primal_residual_list"].shape == info2["primal_residual_list"].shape == (B, 299)
+            assert np.array_equal(info["primal_residual_list"], info2["primal_residual_list"])
+            s.set_max_iter(300)
+        s.integrate(0.05)                            # q <- q (+) z dt on the device: reads z from the tiles
+        q1 = s.get("q")
+        # warm-started tailored solve on the integrated configuration with a new target for the constraint
+        s.Solve(None, int(wl["c_ids"][0]), wl["Ais"][0], wl2["bis"][:, 0])
+        second = {n: s.get(n) for n in ["z", "iter", "status", "w"]}
+        res[logging] = (first, q1, second)
+        s.close()
+    (f0, q0, s0), (f1, q1, s1) = res[False], res[True]
+    assert np.array_equal(f0["iter"], f1["iter"]) and np.array_equal(f0["status"], f1["status"])
+    assert np.abs(f0["z"] - f1["z"]).max() < 1e-9 and np.allclose(f0["mu"], f1["mu"], rtol=1e-12)
+    assert np.abs(q0 - q1).max() < 1e-10, "integrate after a logged solve used a stale z"
+    same = s0["iter"] == s1["iter"]
+    assert same.mean() >= 0.95, "the warm start after a logged solve did not continue from its duals"
+    assert np.abs(s0["z"] - s1["z"])[same].max() < 1e-8 and np.abs(s0["w"] - s1["w"])[same].max() < 1e-6
