@@ -288,3 +288,35 @@ def test_decade_table_follows_the_handles_history(talos):
         assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.97, ztol=1e-8, off_ztol=1e-5, what="history")
         assert s.stats()["lean_launches"] > 0
     s.close()
+
+
+def _fuzz():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_engines", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                              "scripts", "fuzz_engines.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_fuzz_slice_every_engine(monkeypatch):
+    """a bounded slice of scripts/fuzz_engines.py inside the suite: random trees (1-DoF / multi-DoF / composite joints, depth- and
+    breadth-first numbering), 0..4 constraints, shared / per-instance data, reference costs, tolerances, penalty rules, every engine
+    configuration -- against the oracle, no instance dropped.  (The long runs live in profiles/r03_*_fuzz_summary.txt.)"""
+    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_STAGES", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE"):
+        monkeypatch.delenv(k, raising=False)   # (the fuzzer sets and clears them itself; restored after the test)
+    out = _fuzz().fuzz(40, 31337, verbose=False, max_batch=700)
+    assert out["cases"] + out["refused"] == 40 and out["instances"] > 5000, out
+    assert out["mismatches"] == 0, out
+    assert out["unconverged_only"] <= 2, out
+
+
+def test_fuzz_slice_flat_engine(monkeypatch):
+    """the same, drawn inside the flat engine's domain (> 16 joints numbered depth-first, H_ref = h I with or without a target,
+    DEFAULT penalty rule; default plan, hand-over from k_solve, forced escapes, two stages)"""
+    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_STAGES", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE"):
+        monkeypatch.delenv(k, raising=False)
+    out = _fuzz().fuzz(30, 4242, verbose=False, max_batch=700, flat_bias=1.0)
+    assert out["mismatches"] == 0 and out["unconverged_only"] <= 1, out
+    assert out["flat_cases"] >= 15, out   # (batches below 64 instances and trees the schedule refuses run elsewhere)

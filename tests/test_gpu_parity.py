@@ -719,3 +719,35 @@ def test_bench_two_shards_in_one_process(monkeypatch, capsys):
     assert line["roofline"]["bound"] == "fp64_valu" and 0.0 < line["roofline"]["frac"] < 1.0
     assert line["strong_scaling"]["batch_total"] == 4096
     assert json.loads(capsys.readouterr().out.strip().splitlines()[-1])["value"] == line["value"]
+
+
+def test_c3_hard_population_against_the_oracle():
+    """The instances that decide when the headline batch ends and that cross decade boundaries of mu most often: EVERY instance
+    of C3 at 65536 that runs to max_iter - 1 (~760) or updates mu at least 20 times is solved by the oracle too and compared --
+    iteration count, flags, z, mu.  (The strided sample of test_full_size_properties_talos_65536 meets about three of them.)"""
+    B = 65536
+    wl = workloads.talos_c3(B)
+    m, prm = wl["model"], wl["params"]
+    s = loik_amd.BatchedLoik(m, B, **prm)
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    it, nup = s.get("iter"), s.get("mu_updates")
+    idx = np.flatnonzero((it >= prm["max_iter"] - 1) | (nup >= 20))
+    assert 500 < (it >= prm["max_iter"] - 1).sum() < 1200 and idx.size >= 700, (int((it >= prm["max_iter"] - 1).sum()), idx.size)
+    out = ref.solve_batch(m, wl["q"][idx], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"][idx], wl["lb"], wl["ub"],
+                          nthreads=16, **prm)
+    got = fetch_end_to_end(s, idx, nu=False, residuals=True)
+    same = assert_end_to_end(got, out, prm, same_frac=0.99, what="C3 hard population (%d instances)" % idx.size)
+    # the exemption of helpers.assert_end_to_end for instances at max_iter - 1 (flags not compared when the counts differ) must
+    # stay a corner case: here the population IS the instances at max_iter - 1
+    off = ~same
+    assert off.mean() < 0.001 or off.sum() <= 1, "%d of %d hard instances off the oracle's iteration count" % (off.sum(), idx.size)
+    # mu of the last iteration (a decade of mu0): the DEFAULT rule's decisions along the way
+    mu_o = np.array([_oracle_mu(m, wl, b, prm) for b in idx[:48]])
+    assert np.allclose(s.get("mu")[idx[:48]], mu_o, rtol=1e-12)
+    s.close()
+
+
+def _oracle_mu(model, wl, b, prm):
+    r = ref.RefSolver(model, **prm)
+    r.Solve(*problem_args(wl, int(b)))
+    return r.scalar("mu")
