@@ -22,12 +22,15 @@ that trip the reference's infeasibility certificate or hit max_iter are executed
 
 Prints ONE JSON line (rank 0).  `roofline` prices the DOMINANT kernel (the one that ran most ADMM instance-iterations of
 the timed steps) against the roof that bounds it:
-  * `k_lean` / `k_tail` keep an instance's whole ADMM state in registers/LDS (one load and one store of the instance per
-    solve): they are bound by fp64 vector issue, not by HBM -> bound "fp64_valu", achieved = algorithmic flops per launch
+  * `k_flat` / `k_lean` / `k_tail` keep an instance's whole ADMM state in registers/LDS (one load and one store of the instance
+    per solve): they are bound by fp64 vector issue, not by HBM -> bound "fp64_valu", achieved = algorithmic flops per launch
     (935 nb per instance-iteration) / average launch duration (HIP events recorded by the library on the
     launch stream), peak 78.6 TFLOP/s (fp64 vector, half the guide's 157.3 TFLOP/s fp32 vector rate).  Beside it: the HBM
     bytes the PMC counters saw (`traffic`, `hbm_measured_frac`) and the VALU issue fraction, from the committed rocprofv3
-    summary `profiles/pmc_latest.json` when it describes this workload.
+    summary `profiles/pmc_latest.json` when it describes this workload.  A launch has two regimes, reported separately: `bulk`
+    (until the work queue runs dry: every lane group busy -- the library times it, `loikb_stats.queue_dry_ms`) and `tail` (the
+    rest: the launch waits for the instances that run all 999 iterations, a serial chain per instance -- its length is the
+    iteration time of a lone instance, measured on a 64-instance batch).
   * `k_solve` streams every instance through HBM each iteration: bound "hbm", achieved = algorithmic bytes
     (8 B x (203 nb + 108 nc) per instance-iteration) per launch / average launch duration, peak 8000 GB/s.
 `cpu_baseline` times the CPU oracle (a line-faithful C port of the reference solver, NOT upstream libloik) on a bounded
@@ -157,8 +160,9 @@ class Shard:
             st = self.solver.stats()
             self.last = st
             for k in ("kernel_ms", "tail_ms", "tail_instances", "tail_instance_iterations", "tail_launches", "total_ms",
-                      "solve_busy_ms", "tail_busy_ms", "instance_iterations", "launches", "hslots_ms", "lean_launches"):
-                self.acc[k] = self.acc.get(k, 0) + st[k]
+                      "solve_busy_ms", "tail_busy_ms", "instance_iterations", "launches", "hslots_ms", "lean_launches",
+                      "flat_launches", "queue_dry_ms"):
+                self.acc[k] = self.acc.get(k, 0) + st.get(k, 0)
 
     def results(self):
         s, prm = self.solver, self.wl["params"]
@@ -241,6 +245,7 @@ def kernel_roofline(acc, last, steps, nb, nc, B):
     solve_launches = acc["launches"] - acc["tail_launches"]
     solve_ms = acc["kernel_ms"] - acc["tail_ms"]
     lean = acc["lean_launches"] > 0
+    flat = acc.get("flat_launches", 0) > 0
     pmc = load_pmc(B)
     pk = (pmc or {}).get("kernels", {})
 
@@ -251,7 +256,8 @@ def kernel_roofline(acc, last, steps, nb, nc, B):
 
     if tail_iters >= solve_iters:
         # ---- on-chip engine: fp64 vector issue is the roof
-        name = "k_lean" if lean else "k_tail"
+        name = "k_flat" if flat else "k_lean" if lean else "k_tail"
+        slots_name = "k_fslots" if flat else "k_hslots"
         launches = max(acc["tail_launches"], 1)
         # the library times k_hslots (decade-slot precomputation) + the lean launch together; k_lean alone = the rest
         own_ms = acc["tail_ms"] - (acc["hslots_ms"] if lean else 0.0)
@@ -268,9 +274,19 @@ def kernel_roofline(acc, last, steps, nb, nc, B):
              "instance_iterations_per_s": units / (avg_ms * 1e-3) if avg_ms > 0 else None,
              "share_of_instance_iterations": tail_iters / max(inst_iters, 1),
              "why_not_hbm": "the state of an instance stays in registers/LDS for its whole solve: HBM sees one load and "
-                            "one store per instance plus the decade slots of H (k_hslots writes, k_lean fetches on a "
+                            "one store per instance plus the decade slots (%s writes, %s fetches on a "
                             "change of mu) -- `traffic` is what the PMC counters measured, a few %% of the streaming "
-                            "model's %.0f B per unit" % bytes_iter}
+                            "model's %.0f B per unit" % (slots_name, name, bytes_iter)}
+        if flat and acc.get("queue_dry_ms", 0.0) > 0:
+            # the two regimes of the launch: bulk = until a lane group first finds the work queue empty, tail = the rest
+            bulk_ms = acc["queue_dry_ms"] / launches
+            r["bulk"] = {"ms": bulk_ms, "share_of_launch": bulk_ms / avg_ms,
+                         "note": "every lane group busy; the instance-iterations of the launch are not split between the regimes "
+                                 "(an instance's count is known when it stops), so no flop rate is stated for either alone: "
+                                 "see `bulk_rate` for the saturated rate on a 4x batch"}
+            r["tail"] = {"ms": avg_ms - bulk_ms, "share_of_launch": 1.0 - bulk_ms / avg_ms,
+                         "note": "the launch waits for the instances that run to max_iter: a serial chain of <= 999 iterations "
+                                 "from whenever they were fetched -- see `lone_instance_us_per_iteration`"}
         if traffic is not None and avg_ms > 0:
             gbs = traffic / (avg_ms * 1e-3) / 1e9
             r["hbm_measured_GBps"] = gbs
@@ -286,8 +302,10 @@ def kernel_roofline(acc, last, steps, nb, nc, B):
         if pmc:
             r["pmc_source"] = pmc["_file"]
         if lean:
-            hs = {"kernel": "k_hslots", "avg_launch_ms": acc["hslots_ms"] / steps, "traffic": pmc_bytes("k_hslots"),
-                  "role": "H_i / Dinv_i of the decades of mu, precomputed once per Solve() before k_lean (HBM write-bound)"}
+            hs = {"kernel": slots_name, "avg_launch_ms": acc["hslots_ms"] / steps, "traffic": pmc_bytes(slots_name),
+                  "role": ("the joints' columns of W (the explicit inverse of the unit-triangular factor of the tree elimination) and "
+                           "Dinv for the decades of mu, precomputed once per Solve() before k_flat") if flat else
+                          "H_i / Dinv_i of the decades of mu, precomputed once per Solve() before k_lean (HBM write-bound)"}
             if hs["traffic"] is not None and hs["avg_launch_ms"] > 0:
                 hs["hbm_measured_GBps"] = hs["traffic"] / (hs["avg_launch_ms"] * 1e-3) / 1e9
             r["other_kernel"] = hs
@@ -309,7 +327,7 @@ def kernel_roofline(acc, last, steps, nb, nc, B):
          "units_per_launch": units, "avg_launch_ms": avg_ms, "launches_per_step": launches / steps,
          "share_of_instance_iterations": solve_iters / max(inst_iters, 1)}
     if tail_iters > 0:
-        r["other_kernel"] = {"kernel": "k_lean" if lean else "k_tail",
+        r["other_kernel"] = {"kernel": "k_flat" if flat else "k_lean" if lean else "k_tail",
                              "share_of_instance_iterations": tail_iters / max(inst_iters, 1),
                              "sum_of_launch_ms_per_step": acc["tail_ms"] / steps}
     return r
@@ -341,11 +359,40 @@ def whole_body_variant(args, device):
            "unit": "solves/s", "solved_fraction": float(conv.mean()),
            "flagged_infeasible_fraction": float(s.get("primal_infeasible").astype(bool).mean()),
            "mean_admm_iterations": float(it.mean()), "instance_iterations_per_s": float(it.sum() / dt),
-           "engine": "k_lean" if st["lean_launches"] > 0 and st["tail_instances"] == args.batch else "k_solve+k_tail",
+           "engine": ("k_flat" if st["flat_launches"] > 0 else "k_lean") if st["lean_launches"] > 0 and st["tail_instances"] == args.batch
+                     else "k_solve+k_tail",
            "lean_escaped": st["lean_escaped"],
            "achieved_TFLOPs": float(it.sum() * FLOPS_PER_JOINT_ITERATION * m.nv / dt / 1e12),
            "frac_of_fp64_valu_peak": float(it.sum() * FLOPS_PER_JOINT_ITERATION * m.nv / dt / 1e12 / FP64_VALU_PEAK_TF)}
     s.close()
+    return out
+
+
+def regimes_variant(args, device, nb):
+    """The two regimes of the dominant kernel, each measured where it is alone (goes into `roofline`): the SATURATED rate on a
+    batch four times the headline's (the work queue never runs dry for ~3/4 of the launch: the bulk regime) and the iteration
+    time of a LONE instance (a 64-instance batch: one launch, its duration / its longest instance's iteration count -- the
+    serial chain that the headline launch's tail consists of)."""
+    import loik_amd
+    from loik_amd import workloads
+    out = {}
+    for B, key in ((4 * args.batch, "bulk_rate"), (64, "lone")):
+        wl = workloads.talos_c3(B)
+        s = loik_amd.BatchedLoik(wl["model"], B, device=device, flags=args.flags, **wl["params"])
+        s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+        s.Solve(); s.Solve()
+        st = s.stats()
+        own_ms = st["tail_ms"] - st["hslots_ms"]
+        it = s.get("iter")
+        if key == "bulk_rate":
+            rate = float(st["instance_iterations"] / (own_ms * 1e-3))
+            tf = rate * FLOPS_PER_JOINT_ITERATION * nb / 1e12
+            out["bulk_rate"] = {"batch": B, "launch_ms": own_ms, "instance_iterations_per_s": rate, "achieved": tf, "unit": "TFLOP/s",
+                                "frac": tf / FP64_VALU_PEAK_TF, "queue_dry_share_of_launch": st["queue_dry_ms"] / own_ms if own_ms > 0 else None}
+        else:
+            out["lone_instance_us_per_iteration"] = float(own_ms * 1e3 / max(int(it.max()), 1))
+            out["lone_instance_note"] = "64 instances, one launch of %.2f ms, longest instance %d iterations" % (own_ms, int(it.max()))
+        s.close()
     return out
 
 
@@ -514,6 +561,10 @@ def main(argv=None, solver_factory=None, device_count=None):
                 line["whole_body_variant"] = whole_body_variant(args, device_of(0))
             except Exception as e:  # the headline must survive a failing variant
                 line["whole_body_variant"] = {"failed": repr(e)}
+            try:
+                line["roofline"].update(regimes_variant(args, device_of(0), nb))
+            except Exception as e:
+                line["roofline"]["regimes_failed"] = repr(e)
             try:
                 line["two_batches_in_flight_variant"] = two_in_flight_variant(args, device_of(0))
             except Exception as e:

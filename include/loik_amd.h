@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LOIKB_VERSION 300  /* round.minor: bumped whenever a struct or an entry point of this header changes */
+#define LOIKB_VERSION 301  /* round.minor: bumped whenever a struct or an entry point of this header changes */
 
 /* ---- status codes -------------------------------------------------------------------------------- */
 enum {
@@ -305,6 +305,8 @@ typedef struct loikb_stats {
                                              work queue (round-robin among the instances waiting for a slot)                */
   int flat_launches;                      /* of lean_launches: those that ran the flat engine (k_fslots + k_flat: no loops over the
                                              tree levels, loik_amd/csrc/loik_flat.hpp) instead of k_hslots + k_lean             */
+  double queue_dry_ms;                    /* flat engine: time from the start of its (last) launch until a lane group first found the
+                                             work queue empty -- the bulk phase; the rest of the launch waits for its long runners */
 } loikb_stats;
 int loikb_get_stats(loikb_solver *s, loikb_stats *out);
 /* which kernels the solves of this handle use and why (the engine plan is made in one place, from (nb, nc, sharing mode of

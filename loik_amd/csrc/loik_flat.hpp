@@ -229,11 +229,15 @@ __device__ __forceinline__ void flat_fold8(T* rows, int lane, int gbase, int jla
   tail_sync();
   const int q = jlane & 7;
   const bool ismax = q < NMAX;
+  const int nparts = 1 << (lgG - 3);
   {
-    const T* col = rows + (lane & ~7) * FOLDW + q;  // the eight rows of this lane's part of the group
+    // lane (q, part) folds column q over the rows part, part + nparts, part + 2 nparts, ... of its group (eight rows; rows
+    // interleaved over the parts: with a contiguous block of eight rows per part -- 640 B apart -- all parts of the wavefront
+    // hit the same banks, an eight-way conflict on each of the eight reads)
+    const T* col = rows + (gbase + (jlane >> 3)) * FOLDW + q;
     T a[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = col[u * FOLDW];
+    for (int u = 0; u < 8; ++u) a[u] = col[u * nparts * FOLDW];
     const T m = tmax(tmax(tmax(a[0], a[1]), tmax(a[2], a[3])), tmax(tmax(a[4], a[5]), tmax(a[6], a[7])));
     T sm = a[0];
 #pragma unroll
@@ -242,7 +246,7 @@ __device__ __forceinline__ void flat_fold8(T* rows, int lane, int gbase, int jla
   }
   tail_sync();
   {
-    const T* col = rows + (gbase + q) * FOLDW + 8;
+    const T* col = rows + (gbase + q) * FOLDW + 8;  // (lane (q, part) left its partial in its own row: gbase + q + 8 part)
     T a[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) a[p] = (p < 4 || lgG > 5) ? col[p * 8 * FOLDW] : T(0);  // (G = 32: four parts, G = 64: eight)
@@ -271,6 +275,7 @@ __device__ __forceinline__ int unpack16(const unsigned int* w, int k) { return (
 // are exactly that.  The throughput build drains (writes its instances back unfinished) once the queue has run dry and
 // `drain` says so; the host relaunches the survivors in the latency build (run_tail, loik_host.hip).
 constexpr int FLAT_COUNTERS_DRY = 13;  // Bufs::counters[13]: set by the first lane group that finds the work queue empty
+constexpr int FLAT_COUNTERS_T0 = 14, FLAT_COUNTERS_TDRY = 15;  // the 100 MHz clock (low word) when the ring was filled / when the queue ran dry
 template <typename T, int NA, bool LAT>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(LAT ? 1 : 2, LAT ? 1 : 2)))
 k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc, int nscan,
@@ -371,8 +376,12 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       if (jlane == 0) nx = (int)atomicAdd(q_head, 1u);
       nx = __shfl(nx, gbase);
       slot_in = nx < nslots ? ring[nx] : -1;
-      if (!LAT && drain && nx >= nslots && jlane == 0)
-        __hip_atomic_store(Bf.counters + FLAT_COUNTERS_DRY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (nx >= nslots && jlane == 0) {
+        // the queue is empty: the first group to find it so notes the time (the launch's bulk phase ends here: from now on lane
+        // groups idle and the launch waits for its long runners) and, in the throughput build, tells the others to drain
+        if (atomicCAS(Bf.counters + FLAT_COUNTERS_DRY, 0u, 1u) == 0u)
+          __hip_atomic_store(Bf.counters + FLAT_COUNTERS_TDRY, (unsigned int)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     has_inst = slot_in >= 0;
     isj = has_inst && isj_lane;
@@ -580,7 +589,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     // is, and the group idles through this iteration: a group without an instance computes on garbage, inside its own lanes
     // and LDS rows, and nothing of it is kept -- so the iteration below updates its registers without predicates.
     bool exit_now = has_inst && (done || (int)my_iters >= P.max_launch_iters);
-    if (!LAT && drain && has_inst && (my_iters & 15u) == 15u) {
+    if (!LAT && drain && has_inst && (my_iters & 15u) == 15u) {  // (drain: this launch is the first of two stages)
       // (asked every 16th iteration of an instance: the flag is one word in global memory that every wavefront of the launch
       //  reads -- read in every iteration, its round trip doubled the launch time)
       if (__hip_atomic_load(Bf.counters + FLAT_COUNTERS_DRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) exit_now = true;

@@ -1549,6 +1549,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         S->ud_stale = true;
       }
       C->stats.hslots_ms += hms;
+      if (C->h_counters[FLAT_COUNTERS_DRY])  // (100 MHz clock, low words: from the ring fill of the last stage to the first empty fetch)
+        C->stats.queue_dry_ms += (double)(unsigned int)(C->h_counters[FLAT_COUNTERS_TDRY] - C->h_counters[FLAT_COUNTERS_T0]) * 1e-5;
       if (trace)
         fprintf(stderr, "[loikb] flat engine: %6d instances (%d in the latency build on %u workgroups), done at %8.3f ms (slots %6.3f ms)  "
                         "inst-iters %9u  wave-iters %7u  slot loads %7u (+ %u served from LDS)  escaped %u  still iterating %u\n",
@@ -1921,6 +1923,7 @@ int run_main_loop_t(loikb_solver_impl* S)
     S->stats.tail_launches += C.stats.tail_launches;
     S->stats.lean_launches += C.stats.lean_launches;
     S->stats.flat_launches += C.stats.flat_launches;
+    S->stats.queue_dry_ms += C.stats.queue_dry_ms;
     S->stats.lean_escaped += C.stats.lean_escaped;
     S->stats.hslots_ms += C.stats.hslots_ms;
     S->stats.lean_requeues += C.stats.lean_requeues;

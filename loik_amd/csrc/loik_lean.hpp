@@ -977,6 +977,7 @@ __global__ void k_ring_fill(int* __restrict__ ring, int cap, const int* __restri
   if (i == 0) {
     counters[LEAN_Q_HEAD] = 0u; counters[LEAN_Q_TAIL] = (unsigned int)n; counters[LEAN_Q_REQUEUES] = 0u;
     counters[LEAN_Q_RETIRED] = 0u;
+    counters[14] = (unsigned int)wall_clock64();  // (FLAT_COUNTERS_T0: the launch that follows starts now)
   }
 }
 
