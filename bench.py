@@ -143,6 +143,8 @@ class Shard:
         if factory is None:
             import loik_amd
             factory = loik_amd.BatchedLoik
+        if callable(wl):
+            wl = wl()  # (generated here: build_shards constructs every shard on the host thread of its own)
         self.idx, self.device, self.wl = idx, device, wl
         self.B = wl["q"].shape[0]
         self.solver = factory(wl["model"], self.B, device=device, flags=flags, max_launch_iters=max_launch_iters,
@@ -171,6 +173,31 @@ class Shard:
         infeas = s.get("primal_infeasible").astype(bool)
         return dict(solved=int(conv.sum()), iters=int(it.sum()), batch=self.B, infeasible=int(infeas.sum()),
                     unfinished=int(((it >= prm["max_iter"] - 1) & ~conv).sum()))
+
+
+def build_shards(specs):
+    """Shard(*spec) for every spec, each on a host thread of its own: the synthetic workload of a shard is generated, uploaded
+    and SolveInit'ed concurrently with the others' (eight shards one after the other cost eight times the set-up of one)"""
+    out, errs = [None] * len(specs), [None] * len(specs)
+
+    def work(i):
+        try:
+            out[i] = Shard(*specs[i])
+        except Exception as e:
+            errs[i] = e
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(specs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for e in errs:
+        if e is not None:
+            for sh in out:
+                if sh is not None:
+                    sh.solver.close()
+            raise e
+    return out
 
 
 def run_shards(shards, steps, warmup, barrier=None):
@@ -368,6 +395,43 @@ def whole_body_variant(args, device):
     return out
 
 
+def fp32_tradeoff_variant(args, device):
+    """BASELINE config 5's table: Panda-7, B = 65536, tol 1e-3 / 1e-4 x {fp64, fp32 fast, fp32 accurate
+    (LOIKB_OPT_F32_ACCURATE)}: solves/s and the distance of the fp32 answers from the fp64 DEVICE answers (the fp64 oracle is
+    the judge in tests/test_gpu_parity.py::test_c5_fp32_accuracy_contract; no oracle here)"""
+    import numpy as np
+    import loik_amd
+    from loik_amd import capi, workloads
+    rows = []
+    for tol in (1e-3, 1e-4):
+        wl = workloads.panda_c5(args.batch, tol=tol)
+        m, prm = wl["model"], wl["params"]
+        z64 = c64 = None
+        for name, prec, flags in (("fp64", capi.F64, 0), ("fp32_fast", capi.F32, 0), ("fp32_accurate", capi.F32, capi.OPT_F32_ACCURATE)):
+            s = loik_amd.BatchedLoik(m, args.batch, device=device, precision=prec, flags=args.flags | flags, **prm)
+            s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+            s.Solve()
+            s.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                s.Solve()
+            s.synchronize()
+            dt = (time.perf_counter() - t0) / 3
+            z, conv = s.get("z"), s.get("converged").astype(bool)
+            st = s.stats()
+            row = {"tol_abs": tol, "variant": name, "ms_per_step": dt * 1e3, "value": float(conv.sum() / dt), "unit": "solves/s",
+                   "engine": "k_lean" if st["lean_launches"] > 0 else "k_solve+k_tail", "solved_fraction": float(conv.mean()),
+                   "mean_admm_iterations": float(s.get("iter").mean())}
+            if z64 is None:
+                z64, c64 = z, conv
+            else:
+                dz = np.abs(z - z64).max(axis=1)[conv & c64]
+                row["dz_inf_vs_fp64"] = {"median": float(np.median(dz)), "p99": float(np.quantile(dz, 0.99)), "max": float(dz.max())}
+            rows.append(row)
+            s.close()
+    return {"workload": "panda7 C5, B=%d" % args.batch, "rows": rows}
+
+
 def regimes_variant(args, device, nb):
     """The two regimes of the dominant kernel, each measured where it is alone (goes into `roofline`): the SATURATED rate on a
     batch four times the headline's (the work queue never runs dry for ~3/4 of the launch: the bulk regime) and the iteration
@@ -472,16 +536,12 @@ def main(argv=None, solver_factory=None, device_count=None):
 
     def measure(scaling):
         """build the shards of this process for `scaling`, run W + K steps, aggregate over the job"""
-        shards = []
         if scaling == "weak":
-            for g in local:
-                wl = workloads.talos_c3(args.batch, seed=0x101C + 3 + g)
-                shards.append(Shard(g, device_of(g), wl, args.flags, args.max_launch_iters, solver_factory))
+            make = lambda g: (lambda: workloads.talos_c3(args.batch, seed=0x101C + 3 + g))
         else:
             full = workloads.talos_c3(args.batch, seed=0x101C + 3)  # the 1-GPU workload, split contiguously
-            for g in local:
-                wl = sharding.shard_workload(full, g, n_total)
-                shards.append(Shard(g, device_of(g), wl, args.flags, args.max_launch_iters, solver_factory))
+            make = lambda g: (lambda: sharding.shard_workload(full, g, n_total))
+        shards = build_shards([(g, device_of(g), make(g), args.flags, args.max_launch_iters, solver_factory) for g in local])
         elapsed = run_shards(shards, args.steps, args.warmup, barrier if dist is not None else None)
         res = [sh.results() for sh in shards]
         cnt = {k: sum(r[k] for r in res) for k in ("solved", "iters", "batch")}
@@ -497,7 +557,9 @@ def main(argv=None, solver_factory=None, device_count=None):
             sh.solver.close()
         shards[0].solver.close()
         s_shards, s_res, s_elapsed, s_tot = measure("strong")
-        strong = {"scaling": "strong", "batch_total": int(s_tot["batch"]), "batch_per_gpu": int(s_tot["batch"]) // n_total,
+        strong = {"metric": "IK solves/sec to 1e-6 residual, Talos humanoid, batch=%d in total" % args.batch,
+                  "scaling": "strong", "n_gpus": n_total, "batch_total": int(s_tot["batch"]),
+                  "batch_per_gpu": int(s_tot["batch"]) // n_total,
                   "value": s_tot["solved"] * args.steps / s_elapsed, "unit": "solves/s",
                   "ms_per_step": s_elapsed / args.steps * 1e3,
                   "instance_iterations_per_s": s_tot["iters"] * args.steps / s_elapsed,
@@ -553,6 +615,12 @@ def main(argv=None, solver_factory=None, device_count=None):
             "roofline": kernel_roofline(acc0, last0, args.steps, nb, nc, B0),
         }
         if strong is not None:
+            # both legs as objects of their own, so that whichever a reader of the line wants is labelled: the top-level
+            # value / ms_per_step are the weak leg's
+            line["weak_scaling"] = {"metric": line["metric"], "scaling": "weak", "n_gpus": n_total, "batch_total": int(total_B),
+                                    "batch_per_gpu": per_gpu, "value": line["value"], "unit": "solves/s",
+                                    "ms_per_step": line["ms_per_step"],
+                                    "instance_iterations_per_s": total_iters * args.steps / elapsed}
             line["strong_scaling"] = strong
         if n_total == 1 and not args.no_variants and solver_factory is None:
             try:
@@ -565,6 +633,10 @@ def main(argv=None, solver_factory=None, device_count=None):
                 line["roofline"].update(regimes_variant(args, device_of(0), nb))
             except Exception as e:
                 line["roofline"]["regimes_failed"] = repr(e)
+            try:
+                line["fp32_tradeoff_variant"] = fp32_tradeoff_variant(args, device_of(0))
+            except Exception as e:
+                line["fp32_tradeoff_variant"] = {"failed": repr(e)}
             try:
                 line["two_batches_in_flight_variant"] = two_in_flight_variant(args, device_of(0))
             except Exception as e:

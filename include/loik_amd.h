@@ -65,10 +65,18 @@ enum {
   LOIKB_OPT_OWN_STREAM = 8,  /* the handle creates its own non-blocking HIP stream instead of launching on the null stream:
                                  two handles on one device then run concurrently (batches in flight from two host threads);
                                  loikb_set_stream still overrides it                                                  */
-  LOIKB_OPT_NO_COMPACTION = 4 /* never repack live instances into dense wavefronts between launches (default:
+  LOIKB_OPT_NO_COMPACTION = 4, /* never repack live instances into dense wavefronts between launches (default:
                                  repack when at most 85 % of the slots are still iterating; results are
                                  bit-identical, but the inter-sweep temporaries His/pis/UDinv/Dinv/r of
                                  instances that moved are not retrievable afterwards)                         */
+  LOIKB_OPT_F32_ACCURATE = 16 /* LOIKB_F32 only (no fp32 exists upstream: src/loik-loid-optimized.cpp:10-13): the accuracy
+                                 contract |z_f32 - z_f64|_inf <= tol_abs for 99 % of the instances that converge in both,
+                                 for tol_abs >= 1e-3 (below that single precision does not resolve D_i = S^T H S + mu once mu
+                                 has dropped to 1e-2: both fp32 paths end at p99 ~1e-3 -- use LOIKB_F64, +16 % time).  The
+                                 link forces come from f = H v + p with the stored H of the decade (k_lean) instead of the
+                                 force-balance recursion over the children, whose cancellation costs the fast path a decade
+                                 (Panda-7, tol 1e-3: p99 1.8e-4 against 3.9e-3, at 1.9x the time).  Robots of more than 16
+                                 joints run fp32 in k_lean either way.                                                  */
 };
 
 /* input flags of solve_init / solve_full / solve_tailored */

@@ -54,7 +54,7 @@ ABI_VERSION = 301   # LOIKB_VERSION of include/loik_amd.h this binding matches (
 
 # enums of loik_amd.h
 F64, F32 = 0, 1
-OPT_FIXED_ITERS, OPT_NO_H_CACHE, OPT_NO_COMPACTION, OPT_OWN_STREAM = 1, 2, 4, 8
+OPT_FIXED_ITERS, OPT_NO_H_CACHE, OPT_NO_COMPACTION, OPT_OWN_STREAM, OPT_F32_ACCURATE = 1, 2, 4, 8, 16
 IN_DEVICE, A_SHARED, BOUNDS_SHARED, B_SHARED, Q_SHARED = 1, 2, 4, 8, 16
 OUT_DEVICE = 1
 

@@ -307,14 +307,13 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   //  keeping 15 scalars of it alive through the iteration loop)
   const int jflags = jd[jl + 1].flags, jcslot = isj_lane ? jd[jl + 1].cslot : -1;
   const T mass = (!isj_lane || (jflags & JF_MASSLESS)) ? T(0) : T(1);
-  int size, depth1;
+  int size;
   unsigned int jrow4[(FLAT_JMP + 3) / 4], ra2[FLAT_RED / 2], prow4[(FLAT_PART + 3) / 4], anc4[(NA + 3) / 4];
   bool helper;
   {
     // static rows / entries of this group's lanes; helper lanes may be lanes without a joint
     const FlatLane F = fl[jlane];
     size = isj_lane ? F.size : 0;
-    depth1 = F.depth - 1;
     helper = F.helper != 0;
 #pragma unroll
     for (int k = 0; k < (FLAT_JMP + 3) / 4; ++k) jrow4[k] = 0u;

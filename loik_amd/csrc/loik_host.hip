@@ -1364,7 +1364,8 @@ void plan_engines(loikb_solver_impl* S)
   // of iterations: for them k_solve + k_tail are faster in every case measured (Panda-7, B = 65536, fp64 / fp32: tol 1e-3
   // 0.75 / 0.61 ms against 1.18 / 1.14 ms in k_lean, tol 1e-4 0.89 / 0.81 against - / 1.33; the ten precomputed decades of H
   // are mostly never used by such short solves) -- scripts/r02/small_robot_plan_probe.py.
-  else if (S->nb <= 16) pl.why_not_lean = "a small robot (<= 16 joints): k_solve + k_tail are faster on its short solves";
+  else if (S->nb <= 16 && !(S->f32 && (S->opt.flags & LOIKB_OPT_F32_ACCURATE)))
+    pl.why_not_lean = "a small robot (<= 16 joints): k_solve + k_tail are faster on its short solves";
   else if (pl.lean_waves_cu < 7) pl.why_not_lean = "constraint blocks leave too few wavefronts per CU in LDS";
   else pl.lean = true;
   // the flat engine (no loops over the tree levels, loik_flat.hpp): same regime as k_lean, any number of children per joint

@@ -67,7 +67,7 @@ def _run(argv, capsys, ndev=2):
 def test_gpus_2_weak_runs_two_devices_in_one_process(capsys, monkeypatch):
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     line = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "24", "--no-cpu-baseline"], capsys)
-    weak = [s for s in CREATED[:2]]
+    weak = sorted(CREATED[:2], key=lambda s: s.device)   # (the shards are constructed concurrently, each on its own thread)
     assert [s.device for s in weak] == [0, 1] and all(s.B == 24 for s in weak)
     assert weak[0].thread != weak[1].thread          # one host thread per device
     assert all(s.nsolve == 3 for s in weak)          # warmup + steps
@@ -79,12 +79,16 @@ def test_gpus_2_weak_runs_two_devices_in_one_process(capsys, monkeypatch):
     assert line["value"] == pytest.approx(solved * 2 / (line["ms_per_step"] * 2e-3))
     # the strong leg of the same run: the 1-GPU workload split contiguously
     st = line["strong_scaling"]
-    strong = CREATED[2:]
+    strong = sorted(CREATED[2:], key=lambda s: s.device)
     assert len(strong) == 2 and [s.B for s in strong] == [12, 12] and st["batch_total"] == 24
     full = workloads.talos_c3(24, seed=0x101C + 3)
     assert np.array_equal(np.concatenate([s.args[0] for s in strong]), full["q"])
     assert line["roofline"]["bound"] == "fp64_valu" and line["roofline"]["frac"] < 1.0
     assert "cpu_baseline" not in line
+    # both legs are labelled objects of the line; the strong one carries BASELINE.json's wording
+    wk = line["weak_scaling"]
+    assert wk["value"] == line["value"] and wk["batch_total"] == 48 and "per GPU" in wk["metric"]
+    assert st["n_gpus"] == 2 and "batch=24 in total" in st["metric"]
 
 
 def test_gpus_1_and_strong_flag(capsys, monkeypatch):
