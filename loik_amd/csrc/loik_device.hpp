@@ -160,6 +160,11 @@ struct Bufs {
   unsigned int* counters;  // [0] live instances at exit, [1] instance-iterations executed,
                            // [2] tile-iterations, [3] of them with an H rebuild, [4] of them with the fused sweep
   int* wave_live;          // [tiles] live lanes of each wavefront at exit (feeds the host-side compaction scan)
+  // SolverInfo lists of a handle created with logging = 1 (k_flat<.., LOG = true>; layout of k_pass_solve, loik_passes.hpp):
+  // log[(list * log_B + b) * log_cap + k], k = iteration - 1;  log_rows[b] = rows written
+  double* log;
+  int* log_rows;
+  int log_cap, log_B;
 };
 
 template <typename T> struct Vec2;

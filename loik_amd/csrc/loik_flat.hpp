@@ -276,7 +276,10 @@ __device__ __forceinline__ int unpack16(const unsigned int* w, int k) { return (
 // `drain` says so; the host relaunches the survivors in the latency build (run_tail, loik_host.hip).
 constexpr int FLAT_COUNTERS_DRY = 13;  // Bufs::counters[13]: set by the first lane group that finds the work queue empty
 constexpr int FLAT_COUNTERS_T0 = 14, FLAT_COUNTERS_TDRY = 15;  // the 100 MHz clock (low word) when the ring was filled / when the queue ran dry
-template <typename T, int NA, bool LAT>
+// LOG: the lists of LoikSolverInfo (loik-loid-optimized.hpp:47-127, filled at hpp:406-420 -- after ComputeResiduals, before the
+// stopping tests, so mu_list_ holds the mu the iteration RAN with) are written from here: nine scalars per main-loop iteration
+// (one more fold for the four residuals the stopping logic only needs combined).  An instantiation of its own.
+template <typename T, int NA, bool LAT, bool LOG = false>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(LAT ? 1 : 2, LAT ? 1 : 2)))
 k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc, int nscan,
        int njmp, const int* __restrict__ ring, int nslots, int lgG, const T* __restrict__ fslots, int frows, int kexp_lo, int ndec,
@@ -545,6 +548,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
           *reinterpret_cast<T*>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * cs + FC_ATY + k];
         }
       }
+      if (LOG && jlane == 0 && any_iter) Bf.log_rows[lidx] = iter - ((status & ST_TAIL) ? tail_it : 0);  // (main-loop iterations)
       if (jlane == 0) {
         stp<T>(srec, SP_MU, mu, (T)kexp);
         stp<T>(srec, SP_TAG, any_iter ? T(-2) : isc[FI_TGIN], T(0));
@@ -943,6 +947,19 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     done = done || stop;
     const bool finishing = stop;
     const bool leaving = done && has_inst;
+    if (LOG) {
+      T inl[8] = {l_prt, l_prs, l_stf, l_dualv, T(0), T(0), T(0), T(0)}, rl[8];
+      flat_fold8<T, 8>(xb, lane, gbase, jlane, lgG, inl, rl);
+      const int row = itn - 1;
+      if (act && !in_tail && jlane == 0 && row < Bf.log_cap) {
+        // (the nine lists of k_pass_solve, loik_passes.hpp: LOG_PR_TASK, LOG_PR_SLACK, LOG_PRIMAL, LOG_DUAL_NU, LOG_DUAL_V, LOG_DUAL,
+        //  LOG_MU, LOG_MU_EQ, LOG_MU_INEQ)
+        const double vals[9] = {(double)rl[0], (double)rl[1], (double)primal, (double)rl[2], (double)rl[3], (double)dual,
+                                (double)mu_used, (double)(P.mu_scale * mu_used), (double)mu_used};
+#pragma unroll
+        for (int l = 0; l < 9; ++l) Bf.log[((size_t)l * Bf.log_B + lidx) * Bf.log_cap + row] = vals[l];
+      }
+    }
     // ---- what the getters report: written when an instance stops (the certificate's scalars also when it enters the tail
     // solve: they keep the values of the last iteration that evaluated them) -------------------------------------------------
     if (__any(finishing || enter_tail)) {

@@ -719,6 +719,7 @@ Bufs<T> make_bufs(loikb_solver_impl* S, Chunk* C, int k)
   Bf.uni = (const T*)S->d_uni;
   Bf.counters = C->d_counters;
   Bf.wave_live = C->set[k].wave_live;
+  Bf.log = S->d_log; Bf.log_rows = S->d_log_rows; Bf.log_cap = S->log_rows_cap; Bf.log_B = S->B;
   return Bf;
 }
 
@@ -1374,7 +1375,9 @@ void plan_engines(loikb_solver_impl* S)
                                                            : flat_lds_bytes<double, FLAT_MAXA>(S->nc, S->flat.G, S->a_shared, false);
     pl.flat_waves_cu = (int)std::min<size_t>(8, (160 * 1024) / per_wave);
   }
-  if (never) pl.why_not_flat = never;
+  // (logging = 1 does not keep a solve off the flat engine: k_flat<.., LOG> writes the SolverInfo lists itself)
+  const char* never_flat = S->opt.tail_max_instances < 0 ? never : (S->opt.flags & LOIKB_OPT_NO_COMPACTION) ? never : nullptr;
+  if (never_flat) pl.why_not_flat = never_flat;
   else if (!S->tune.flat) pl.why_not_flat = S->tune.lean ? "LOIKB_FLAT=0" : "LOIKB_LEAN=0";
   else if (!S->flat.ok) pl.why_not_flat = S->flat.why;
   else if (S->f32) pl.why_not_flat = "fp32 solver";
@@ -1453,7 +1456,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     // solve, batches of one application resemble each other; when they do not, the instance that leaves the table escapes
     // to k_tail as always and the full range is back for the next solve.
     int ndec = S->plan.ndec, kexp_lo = S->plan.kexp_lo;
-    if (S->tune.lean_adapt && S->seen_hi >= S->seen_lo && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS)) {
+    // (a logged solve keeps the whole configured range: an instance that escaped to k_tail would stop writing its lists)
+    if (S->tune.lean_adapt && S->seen_hi >= S->seen_lo && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS) && !S->opt.logging) {
       const int lo = std::max(kexp_lo, S->seen_lo - 1), hi = std::min(kexp_lo + ndec - 1, S->seen_hi + 1);
       if (hi >= lo) { kexp_lo = lo; ndec = hi - lo + 1; }
     }
@@ -1477,7 +1481,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       const double cu_sh = std::max(1.0, S->ncu * ((double)C->B / (double)S->B));
       const int cap_thr = (S->tune.lean_wg_per_cu > 0 ? S->tune.lean_wg_per_cu : (int)std::min<size_t>(8, (160 * 1024) / flds)) * (int)(cu_sh + 0.5);
       const int cap_lat = (int)std::min<size_t>(4, (160 * 1024) / flds) * (int)(cu_sh + 0.5);
-      const bool two_stage = S->tune.flat_two_stage && n > 2 * cap_lat * ipw;
+      const bool two_stage = S->tune.flat_two_stage && n > 2 * cap_lat * ipw && !S->opt.logging;
       P.max_launch_iters = S->opt.max_iter + 1;
       HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
@@ -1515,11 +1519,12 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           if (trace) fprintf(stderr, "[loikb] flat engine, throughput stage: %d of %d instances still iterating when the queue ran dry\n", n, n_first);
         }
         hipLaunchKernelGGL(k_ring_fill, grid1(C->ring_cap), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, list, n, C->d_counters);
-#define LOIKB_LAUNCH_FLAT(NAV, LATV)                                                                                            \
-  hipLaunchKernelGGL((k_flat<T, NAV, LATV>), grid, dim3(WAVE), flds, C->stream, P, Bf, (const JointDesc*)S->d_jd,                \
+#define LOIKB_LAUNCH_FLAT(NAV, LATV, ...)                                                                                       \
+  hipLaunchKernelGGL((k_flat<T, NAV, LATV, ##__VA_ARGS__>), grid, dim3(WAVE), flds, C->stream, P, Bf, (const JointDesc*)S->d_jd,                \
                      (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, (const int*)C->d_ring, n, lgG,          \
                      (const T*)C->d_fslots, frows, kexp_lo, ndec, (T)S->Href[0], has_hv, (int)(!lat))
-        if (small_na) { if (lat) LOIKB_LAUNCH_FLAT(FLAT_NA_SMALL, true); else LOIKB_LAUNCH_FLAT(FLAT_NA_SMALL, false); }
+        if (S->opt.logging) { if (small_na) LOIKB_LAUNCH_FLAT(FLAT_NA_SMALL, true, true); else LOIKB_LAUNCH_FLAT(FLAT_MAXA, true, true); }
+        else if (small_na) { if (lat) LOIKB_LAUNCH_FLAT(FLAT_NA_SMALL, true); else LOIKB_LAUNCH_FLAT(FLAT_NA_SMALL, false); }
         else { if (lat) LOIKB_LAUNCH_FLAT(FLAT_MAXA, true); else LOIKB_LAUNCH_FLAT(FLAT_MAXA, false); }
 #undef LOIKB_LAUNCH_FLAT
         HIPCHK(hipGetLastError());
@@ -1566,7 +1571,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       // what is left escaped the precomputed decades: k_tail below finishes it
     }
     // (k_lean's lane groups need whole wavefronts of work to pay: below 64 instances k_tail's direct path is as good)
-    const bool lean_ok = !flat_ok && S->plan.lean && !S->per_link && (P.mode & MODE_CACHE_H) && n >= 64;  // (k_lean has no per-link table)
+    const bool lean_ok = !flat_ok && S->plan.lean && (P.mode & MODE_CACHE_H) && n >= 64;
+    const bool per_link = S->per_link;  // (UpdateReferences' table: the PERLINK instantiations of k_hslots / k_lean)
     if (lean_ok) {
       // decade slots are indexed by the instance's slot in the set (relaunches with shorter lists find them again);
       // the buffer was sized for the chunk at SolveInit (ensure_hslots)
@@ -1582,6 +1588,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute((const void*)k_lean<T, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       }
       const int wg_per_cu = S->tune.lean_wg_per_cu > 0 ? S->tune.lean_wg_per_cu : waves_cu / ltw;
       const int wg_cap = wg_per_cu * std::max(1, (int)(S->ncu * ((double)C->B / (double)S->B) + 0.5));
@@ -1610,7 +1618,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           slots_built = true;
           const dim3 hgrid((unsigned)((n + ipw - 1) / ipw));
           const size_t hlds = (size_t)(WAVE + 1) * 22 * sizeof(T);
-          if (S->href_diag)
+          if (per_link)
+            hipLaunchKernelGGL((k_hslots<T, false, true>), hgrid, dim3(WAVE), hlds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
+                               (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
+                               (T*)C->d_hslots, kexp_lo, ndec);
+          else if (S->href_diag)
             hipLaunchKernelGGL((k_hslots<T, true>), hgrid, dim3(WAVE), hlds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                                (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, list, n, G,
                                (T*)C->d_hslots, kexp_lo, ndec);
@@ -1624,11 +1636,12 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         // time slice of the in-kernel round-robin queue (0 = run every instance to completion in arrival order); bounded
         // host-side rounds (LOIKB_LEAN_QUANTA) bring their own bound and switch it off
         const int quantum = quanta.size() > 1 ? 0 : lean_quantum;
-#define LOIKB_LAUNCH_LEAN(HD, SL)                                                                                             \
-  hipLaunchKernelGGL((k_lean<T, HD, SL>), grid, dim3(WAVE * ltw), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,             \
+#define LOIKB_LAUNCH_LEAN(HD, SL, ...)                                                                                        \
+  hipLaunchKernelGGL((k_lean<T, HD, SL, ##__VA_ARGS__>), grid, dim3(WAVE * ltw), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,             \
                      (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild, C->d_ring,              \
                      C->ring_cap - 1, n, G, (const T*)C->d_hslots, kexp_lo, ndec, quantum, S->multi_from)
-        if (quantum > 0) { if (S->href_diag) LOIKB_LAUNCH_LEAN(true, true); else LOIKB_LAUNCH_LEAN(false, true); }
+        if (per_link) { if (quantum > 0) LOIKB_LAUNCH_LEAN(false, true, true); else LOIKB_LAUNCH_LEAN(false, false, true); }
+        else if (quantum > 0) { if (S->href_diag) LOIKB_LAUNCH_LEAN(true, true); else LOIKB_LAUNCH_LEAN(false, true); }
         else { if (S->href_diag) LOIKB_LAUNCH_LEAN(true, false); else LOIKB_LAUNCH_LEAN(false, false); }
 #undef LOIKB_LAUNCH_LEAN
         HIPCHK(hipGetLastError());
@@ -2505,14 +2518,45 @@ int loikb_pass(loikb_solver* S, int pass)
   return LOIKB_OK;
 }
 
-// Solve with logging_ = true: the main loop on the plain pass implementation, SolverInfo lists filled (k_pass_solve).  The
-// results are then read from the pass state (loikb_get), like after loikb_pass.
+static int ensure_log(loikb_solver_impl* S);
+static int finish_logged(loikb_solver_impl* S, const PassParams& P);
+// a logged solve that the flat engine takes whole: fp64, H_ref = h I on every link, one chunk, the batch goes to k_flat directly
+static bool logged_on_flat(const loikb_solver_impl* S)
+{
+  return S->opt.logging && !S->f32 && flat_applicable(S) && S->plan.nchunks == 1 && S->B >= 64 && S->B <= S->plan.tail_max &&
+         !(S->opt.flags & (LOIKB_OPT_NO_H_CACHE | LOIKB_OPT_FIXED_ITERS));
+}
+
+// Solve with logging_ = true: SolverInfo lists filled.  On the flat engine when the solve qualifies (logged_on_flat), else the
+// main loop on the plain pass implementation (k_pass_solve), whose results are then read from the pass state (loikb_get), like
+// after loikb_pass.
 static int run_logged(loikb_solver_impl* S)
 {
+  int rc;
+  if ((rc = ensure_log(S))) return rc;
+  if (logged_on_flat(S)) {
+    // the fast engine writes the lists itself (k_flat<.., LOG>); an instance whose mu leaves the ten configured decades is
+    // finished by k_tail as in any solve and its lists end where it left (loikb_stats.lean_escaped says how many)
+    HIPCHK(hipMemsetAsync(S->d_log_rows, 0, sizeof(int) * (size_t)S->B, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
+    if ((rc = run_main_loop(S))) return rc;
+    S->have_log = true;
+    return LOIKB_OK;
+  }
   const PassParams P = pass_params(S);
   S->pass_active = false;  // the resets / updates of this solve went to the tiles: reload
-  int rc;
   if ((rc = ensure_pass_state(S, P))) return rc;
+  const int cap = S->log_rows_cap;
+  HIPCHK(hipEventRecord(S->ev_t0, S->stream));
+  hipLaunchKernelGGL(k_pass_solve, grid1(S->B, 64), dim3(64), 0, S->stream, S->PL, P, (const JointDesc*)S->d_jd,
+                     (const int*)S->d_pass_cslot, S->d_pass, S->d_log, cap, S->d_log_rows);
+  HIPCHK(hipGetLastError());
+  return finish_logged(S, P);
+}
+
+// the SolverInfo lists of a logged solve: B x (max_iter - 1) rows x nine lists, zero beyond an instance's rows
+static int ensure_log(loikb_solver_impl* S)
+{
   const int cap = std::max(S->opt.max_iter - 1, 1);
   if (!S->d_log || cap != S->log_rows_cap) {
     if (S->d_log) HIPCHK(hipFree(S->d_log));
@@ -2530,10 +2574,11 @@ static int run_logged(loikb_solver_impl* S)
     S->log_rows_cap = cap;
   }
   HIPCHK(hipMemsetAsync(S->d_log, 0, sizeof(double) * (size_t)S->B * cap * LOG_NLIST, S->stream));
-  HIPCHK(hipEventRecord(S->ev_t0, S->stream));
-  hipLaunchKernelGGL(k_pass_solve, grid1(S->B, 64), dim3(64), 0, S->stream, S->PL, P, (const JointDesc*)S->d_jd,
-                     (const int*)S->d_pass_cslot, S->d_pass, S->d_log, cap, S->d_log_rows);
-  HIPCHK(hipGetLastError());
+  return LOIKB_OK;
+}
+
+static int finish_logged(loikb_solver_impl* S, const PassParams& P)
+{
   // the result goes back to the tiles too: a warm-started solve, loikb_integrate and the engines' getters continue from it
   hipLaunchKernelGGL(k_pass_store<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, S->PL, P, (const double*)S->d_pass);
   HIPCHK(hipGetLastError());
@@ -2706,14 +2751,17 @@ const char* loikb_plan_string(loikb_solver* S)
              S->sched[1].nw, pl.tail_max, pl.nchunks, pl.why_not_lean);
   out = buf;
   if (!pl.flat && *pl.why_not_flat) out += std::string("; no k_flat: ") + pl.why_not_flat;
-  else if (pl.flat && S->have_problem && !flat_applicable(S)) out += "; no k_flat for this problem: its reference cost is not H_ref = h I on every link";
+  else if (pl.flat && S->have_problem && !flat_applicable(S))
+    out += pl.lean ? "; no k_flat for this problem (its reference cost is not H_ref = h I on every link): k_hslots + k_lean take its place"
+                   : "; no k_flat for this problem: its reference cost is not H_ref = h I on every link";
   if ((pl.lean || pl.flat) && S->tune.lean_adapt && S->seen_hi >= S->seen_lo) {
     char b2[160];
     snprintf(b2, sizeof(b2), "; decades visited by this handle's solves so far: %d..%d (the next solve builds those +-1)", S->seen_lo, S->seen_hi);
     out += b2;
   }
-  if (S->opt.logging) out = "logging = 1: every solve runs on the plain pass-by-pass implementation (k_pass_solve) and fills SolverInfo; without it: " + out;
-  if (pl.lean && S->per_link) out += "; per-link references in force (UpdateReferences): k_tail takes k_lean's place until the next SolveInit";
+  if (S->opt.logging && logged_on_flat(S)) out = "logging = 1: k_flat writes the SolverInfo lists; " + out;
+  else if (S->opt.logging) out = "logging = 1: every solve runs on the plain pass-by-pass implementation (k_pass_solve) and fills SolverInfo; without it: " + out;
+  if (pl.lean && S->per_link) out += "; per-link references in force (UpdateReferences): k_hslots + k_lean in their per-link instantiations until the next SolveInit";
   return out.c_str();
 }
 

@@ -184,7 +184,10 @@ __device__ __forceinline__ void lean_gather_n(int n, const T* xch, const int* ch
   }
 }
 
-template <typename T, bool HDIAG, bool SLICED>
+// PERLINK: the links' (H_ref_i, H_ref_i v_ref_i) come from the table UpdateReferences left in HBM (Params::href_tab, one row per
+// joint: 10.5 KiB for Talos, read through L1 / L2 -- 42 loads per joint and iteration) instead of the one pair every link
+// shares.  An instantiation of its own: as a uniform branch in the shared-reference kernel it cost the headline 2-3 %.
+template <typename T, bool HDIAG, bool SLICED, bool PERLINK = false>
 __global__ void __launch_bounds__(WAVE * TAIL_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
        const int* __restrict__ child_list, int maxdepth, int maxchild, int* __restrict__ ring, int ring_mask, int nslots, int G,
@@ -213,6 +216,13 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   const TailTopo tp = topo[jl + 1];
   const bool rev = d.flags & JF_REVOLUTE;
   const T mass = (d.flags & JF_MASSLESS) ? T(0) : T(1);
+  static_assert(!(PERLINK && HDIAG), "per-link references are general 6x6 blocks");
+  const T* const hrow = PERLINK ? P.href_tab + (size_t)(jl + 1) * HREF_ROW : nullptr;
+  auto hv_ref = [&](int k) -> T { return PERLINK ? hrow[36 + k] : P.Hv[k]; };      // (H_ref_i v_ref_i)_k
+  auto href_times = [&](const T* x, T* o) {                                        // o = H_ref_i x
+    if (PERLINK) href_mul<T, false>(hrow, x, o);
+    else href_mul<T, HDIAG>(P.Href, x, o);
+  };
   const bool has_parent = !(d.flags & JF_PARENT_ROOT);
   constexpr int NCH_REG = 4;
   int chl[NCH_REG];
@@ -526,7 +536,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     // ================= leaf -> root: FwdPass1 + BwdPass, p only (hxx:290-338, :31-81) =================================
     if (act) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) p[k] = mass * (-P.rho * v[k] - P.Hv[k]);
+      for (int k = 0; k < 6; ++k) p[k] = mass * (-P.rho * v[k] - hv_ref(k));
       if (isj && d.cslot >= 0) {
         const T* c_ = cdi + d.cslot * cs;
 #pragma unroll
@@ -608,7 +618,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
         dv6[k] = vi[k] - v[k];
       }
       l_dfis = mass * inf6(df);  // (a massless chain link is not a body of the model: no f_i of its own upstream)
-      href_mul<T, HDIAG>(P.Href, vi, hrv);
+      href_times(vi, hrv);
       l_hrefv = mass * inf6(hrv);
       l_dvis = mass * inf6(dv6);
       l_dnu = tabs(nui - nu);
@@ -686,9 +696,9 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       }
       l_dg = inf6(dg);
       l_g = inf6(gi);
-      href_mul<T, HDIAG>(P.Href, v, dvr);
+      href_times(v, dvr);
 #pragma unroll
-      for (int a = 0; a < 6; ++a) dvr[a] = mass * (dvr[a] - P.Hv[a]) + gi[a];
+      for (int a = 0; a < 6; ++a) dvr[a] = mass * (dvr[a] - hv_ref(a)) + gi[a];
       l_dualv = inf6(dvr);
       const T si = dot6_halves(Sv, f) + w;
       l_stf = tabs(si);
@@ -862,7 +872,7 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 // d = 0 .. ndec-1.  One joint per lane like k_tail, the masked leaf -> root level loop of its H rebuild (hxx:290-338,
 // :31-81, H part only), once per decade.
 // ------------------------------------------------------------------------------------------------------------------------
-template <typename T, bool HDIAG>
+template <typename T, bool HDIAG, bool PERLINK = false>
 __global__ void __launch_bounds__(WAVE)
 k_hslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
          const int* __restrict__ child_list, int maxdepth, int maxchild, const int* __restrict__ slots, int nslots, int G,
@@ -884,6 +894,7 @@ k_hslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
   const int depth = jlane < L.nb ? tp.depth : 0;
   const bool rev = d.flags & JF_REVOLUTE;
   const T mass = (d.flags & JF_MASSLESS) ? T(0) : T(1);
+  const T* const hrow = PERLINK ? P.href_tab + (size_t)(jl + 1) * HREF_ROW : nullptr;  // (this link's H_ref: UpdateReferences' table)
   const bool has_parent = !(d.flags & JF_PARENT_ROOT);
   const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
   const int slot = slots[has_inst ? idx : 0];
@@ -925,7 +936,7 @@ k_hslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
       for (int a = 0; a < 6; ++a)
 #pragma unroll
         for (int b2 = a; b2 < 6; ++b2)
-          hh[sym(a, b2)] = mass * ((a == b2 ? P.rho : T(0)) + ((HDIAG && a != b2) ? T(0) : P.Href[6 * a + b2]));
+          hh[sym(a, b2)] = mass * ((a == b2 ? P.rho : T(0)) + ((HDIAG && a != b2) ? T(0) : (PERLINK ? hrow[6 * a + b2] : P.Href[6 * a + b2])));
 #pragma unroll
       for (int k = 0; k < 21; ++k) hh[k] += mu_eq * ata[k];
       for (int c = 0; c < tp.nchild; ++c) {

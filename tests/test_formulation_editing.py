@@ -260,7 +260,10 @@ def test_gpu_per_link_references_end_to_end(which, engine, request):
     assert_end_to_end(fetch_end_to_end(s, residuals=not loose), out, prm, same_frac=0.95, ztol=1e-6 if loose else 1e-8,
                       off_ztol=1e-5, what="%s %s" % (which, engine))
     st = s.stats()
-    assert st["lean_launches"] == 0                     # k_lean has no per-link table
+    if which == "talos" and engine == "default":
+        # ordinary API use stays on an on-chip engine: the per-link instantiations of k_hslots + k_lean (k_flat needs H_ref = h I)
+        assert st["lean_launches"] >= 1 and st["flat_launches"] == 0 and st["tail_instances"] == B, (st, s.plan())
+        assert "k_lean" in s.plan()
     # the next SolveInit broadcasts one pair again (hpp:355) and the lean engine is back
     s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
     out0 = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"],

@@ -73,6 +73,43 @@ def test_gpu_solver_info_matches_oracle(which, request):
 
 
 @pytest.mark.gpu
+def test_gpu_solver_info_from_the_flat_engine(talos):
+    """logging = 1 keeps a solve on the fast engine: k_flat writes the nine lists itself (one more fold per iteration); the same
+    lists, rows and results as the oracle's, instance by instance -- incl. instances that end in the infeasibility tail solve,
+    whose iterations append nothing (hpp:271-319)"""
+    from loik_amd import workloads
+    B = 256
+    wl = workloads.talos_c3(B, seed=77)
+    prm = dict(wl["params"], max_iter=300)
+    s = loik_amd.BatchedLoik(talos, B, logging=True, **prm)
+    s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    assert "k_flat writes the SolverInfo lists" in s.plan(), s.plan()
+    s.Solve()
+    st = s.stats()
+    assert st["flat_launches"] >= 1 and st["tail_instances"] == B and st["lean_escaped"] == 0, st
+    info = s.solver_info()
+    it, z, tail = s.get("iter"), s.get("z"), s.get("tail_solve_iter")
+    assert (s.get("primal_infeasible") > 0).sum() >= 5 and (tail > 0).sum() >= 1, "the sample should contain tail solves"
+    for b in range(B):
+        r = ref.RefSolver(talos, **prm)
+        r.Solve(*problem_args(wl, b))
+        assert it[b] == r.get_iter() and tail[b] == int(r.scalar("tail_solve_iter")), (b, it[b], r.get_iter())
+        n = len(r.solver_info(0))
+        assert info["rows"][b] == n == it[b] - tail[b]
+        for k, name in enumerate(LISTS):
+            assert_close(info[name][b, :n], r.solver_info(k), 1e-9, "%s b%d" % (name, b))
+            assert np.all(info[name][b, n:] == 0.0)
+        assert_close(z[b], r.z, 1e-9, "z")
+    # the lists restart with every solve; a handle without logging gives the same answers bit for bit (same kernel arithmetic)
+    s.Solve()
+    assert np.array_equal(s.solver_info()["rows"], info["rows"])
+    s2 = loik_amd.BatchedLoik(talos, B, **prm)
+    s2.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    assert np.array_equal(s.get("iter"), s2.get("iter")) and np.array_equal(s.get("z"), s2.get("z"))
+    s.close(); s2.close()
+
+
+@pytest.mark.gpu
 def test_gpu_solver_info_infeasible_fixture_and_errors(talos):
     """the reference fixture's unreachable head target: the lists stop at the iteration that raises the certificate, the tail
     solve only counts (hpp:286-290)"""
