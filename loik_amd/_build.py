@@ -7,7 +7,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libloik_amd.so")
 SOURCES = ["loik_host.hip", "models.c"]
-HEADERS = ["loik_device.hpp", "loik_tail.hpp", "loik_lean.hpp", "loik_flat.hpp", "loik_passes.hpp", os.path.join("..", "..", "include", "loik_amd.h"),
+HEADERS = ["loik_device.hpp", "loik_tail.hpp", "loik_lean.hpp", "loik_flat.hpp", "loik_flat2.hpp", "loik_passes.hpp", os.path.join("..", "..", "include", "loik_amd.h"),
            os.path.join("..", "..", "include", "loik_amd_models.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

@@ -1,0 +1,860 @@
+// loik_flat2.hpp -- the flat engine (loik_flat.hpp) with every 6-vector of the iteration SPLIT over two lanes: lane 32 h + j
+// carries the linear (h = 0) or the angular (h = 1) half of the spatial vectors of joint j + 1, one instance per wavefront
+// (the linear halves of all joints in lanes 0..31, the angular halves in lanes 32..63).
+//
+// Why: k_flat keeps ~360 registers per lane alive (the joint's placement, S^w, v, f, g, the subtree sum, the scan's rows in
+// flight), which allows ONE wavefront per SIMD; its fp64 issue slots are two-thirds empty (dependent chains, LDS round trips)
+// and a second wavefront that could fill them does not fit (the 256-register build spills ~100 values and is slower).  With
+// the halves on two lanes a lane's state is 3-vectors: ~2/3 of the registers, two or three wavefronts per SIMD without
+// scratch; the sums over subtrees / root paths move 3 scalars per lane instead of 6; and an instance alone on its SIMD (the
+// 999-iteration instances that decide when a batch ends) runs a shorter iteration.  What does NOT halve is what couples the
+// halves -- the cross products of the frame changes (R0^T (v - t0 x w), F_a - t0 x F_l) and everything scalar per joint
+// (BoxProj, the dot products S . x, which cost one exchange between the halves of the wavefront: v_permlane32_swap) -- so a
+// wavefront-iteration costs ~0.7 of k_flat's instructions for half as many instances.
+// With the joints of an instance in depth-first order along the lanes of a half, two of k_flat's LDS phases become register
+// work: the subtree sums are differences of a prefix sum (DPP row shifts + row broadcast, one ds_bpermute to fetch the prefix at
+// the subtree's last joint) instead of four window-doubling exchanges, and the eight scalars of the stopping logic are reduced by
+// a transpose-reduce over lane pairs / quads / rows (DPP, v_permlane16/32_swap) and leave in SGPRs (v_readlane) instead of
+// three LDS round trips.  What k_flat2 waits for is LDS latency (about thirty dependent round trips per iteration in k_flat),
+// not bandwidth: every exchange removed shortens the iteration of a lone instance AND frees the LDS pipe, which at two
+// wavefronts per SIMD is what the wavefronts of a CU queue for.
+//
+// The arithmetic is k_flat's (same formulation at the world origin, same decade slots from k_fslots, same record format when an
+// instance is stored: SP_TAG = -2), summed in a slightly different order where a sum is split between the two lanes of a joint.
+// Loading an instance runs k_flat's full-width code on BOTH lanes of a joint (identical values, identical LDS rows); each lane
+// then keeps its half.  Applies to robots of 17..32 joints (G = 32: smaller ones run in k_solve + k_tail, larger ones need more
+// than one wavefront's lanes in this layout and stay in k_flat), at most FLAT_NA_SMALL ancestors per joint, fp64.
+// Reference: /root/reference/include/loik/loik-loid-optimized.hxx (passes as cited in loik_flat.hpp).
+#pragma once
+
+#include "loik_flat.hpp"
+
+namespace loikb {
+
+constexpr int F2G = 32;  // joints per instance (lane pairs)
+constexpr int F2W = 32;  // row stride of the [ancestor][joint] arrays (W rows, W tau products): lane (j, h) touches row 2 i + h
+
+// ---- cross-lane helpers (registers only) --------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
+__device__ __forceinline__ double dpp_f64(double old, double x)
+{
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(x), CTRL, ROW_MASK, BANK_MASK, BOUND);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(x), CTRL, ROW_MASK, BANK_MASK, BOUND);
+  return __hiloint2double(hi, lo);
+}
+// both halves of the wavefront's values of x: lo = what lane (lane & 31) holds, hi = what lane 32 + (lane & 31) holds
+// (v_permlane32_swap: the upper half of one register changes places with the lower half of the other)
+__device__ __forceinline__ void both_halves(double x, double& lo, double& hi)
+{
+  const int xl = __double2loint(x), xh = __double2hiint(x);
+  const auto rl = __builtin_amdgcn_permlane32_swap(xl, xl, false, false);
+  const auto rh = __builtin_amdgcn_permlane32_swap(xh, xh, false, false);
+  lo = __hiloint2double(rh[0], rl[0]);
+  hi = __hiloint2double(rh[1], rl[1]);
+}
+// x of the linear lane + x of the angular lane of the joint (the same value, bit for bit, on both)
+__device__ __forceinline__ double pair_sum(double x)
+{
+  double lo, hi;
+  both_halves(x, lo, hi);
+  return lo + hi;
+}
+// inclusive prefix sum along the lanes of each half of the wavefront (lanes 0..31 and 32..63 separately)
+__device__ __forceinline__ double prefix32(double x)
+{
+  x += dpp_f64<0x111, 0xF, 0xF, true>(0.0, x);   // row_shr:1  (lanes without a source add 0)
+  x += dpp_f64<0x112, 0xF, 0xF, true>(0.0, x);   // row_shr:2
+  x += dpp_f64<0x114, 0xF, 0xF, true>(0.0, x);   // row_shr:4
+  x += dpp_f64<0x118, 0xF, 0xF, true>(0.0, x);   // row_shr:8
+  x += dpp_f64<0x142, 0xA, 0xF, false>(0.0, x);  // row_bcast:15 into rows 1 and 3: the total of the row before
+  return x;
+}
+__device__ __forceinline__ double lane_read(double x, int src_lane)  // x of lane src_lane (ds_bpermute: the LDS crossbar, no memory)
+{
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(x));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double uniform_of(double x, int src_lane)  // x of lane src_lane in SGPRs
+{
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src_lane), __builtin_amdgcn_readlane(__double2loint(x), src_lane));
+}
+// Eight scalars reduced over the 64 lanes: columns 0..5 by max, 6 and 7 by sum when SUMS (else max), all eight results uniform.
+// Transpose-reduce: lane pairs exchange four columns and keep four, neighbouring pairs exchange two and keep two, neighbouring
+// quads one -- a lane then owns ONE column (4 b0 + 2 b1 + b2, b = bits of the lane number) folded over its eight lanes -- and
+// three more exchanges (8 lanes, rows, halves) fold that over the wavefront.
+template <bool SUMS>
+__device__ __forceinline__ void wave_fold8(int lane, const double* in, double* out)
+{
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  const bool sm = SUMS && b0 && b1;  // this lane's column is a sum
+  auto comb = [&](double a, double b, bool is_sum) { return is_sum ? a + b : tmax(a, b); };
+  double k4[4], k2[2], k1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const double send = b0 ? in[q] : in[q + 4], keep = b0 ? in[q + 4] : in[q];
+    const double recv = dpp_f64<0xB1, 0xF, 0xF, true>(0.0, send);  // quad_perm [1, 0, 3, 2]
+    k4[q] = comb(keep, recv, SUMS && q >= 2 && b0);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const double send = b1 ? k4[q] : k4[q + 2], keep = b1 ? k4[q + 2] : k4[q];
+    const double recv = dpp_f64<0x4E, 0xF, 0xF, true>(0.0, send);  // quad_perm [2, 3, 0, 1]
+    k2[q] = comb(keep, recv, sm);
+  }
+  {
+    const double send = b2 ? k2[0] : k2[1], keep = b2 ? k2[1] : k2[0];
+    double recv = dpp_f64<0x104, 0xF, 0x5, false>(0.0, send);  // row_shl:4 into lanes 0-3, 8-11 of a row
+    recv = dpp_f64<0x114, 0xF, 0xA, false>(recv, send);        // row_shr:4 into lanes 4-7, 12-15
+    k1 = comb(keep, recv, sm);
+  }
+  {
+    double recv = dpp_f64<0x108, 0xF, 0x3, false>(0.0, k1);    // row_shl:8 into lanes 0-7
+    recv = dpp_f64<0x118, 0xF, 0xC, false>(recv, k1);          // row_shr:8 into lanes 8-15
+    k1 = comb(k1, recv, sm);
+  }
+  {
+    const int xl = __double2loint(k1), xh = __double2hiint(k1);
+    const auto rl = __builtin_amdgcn_permlane16_swap(xl, xl, false, false);  // rows 0 <-> 1, 2 <-> 3
+    const auto rh = __builtin_amdgcn_permlane16_swap(xh, xh, false, false);
+    k1 = comb(__hiloint2double(rh[0], rl[0]), __hiloint2double(rh[1], rl[1]), sm);
+  }
+  {
+    double lo, hi;
+    both_halves(k1, lo, hi);
+    k1 = comb(lo, hi, sm);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) out[q] = uniform_of(k1, ((q >> 2) & 1) | (((q >> 1) & 1) << 1) | ((q & 1) << 2));
+}
+
+template <typename T>
+__device__ __forceinline__ T inf3(const T* x) { return tmax(tmax(tabs(x[0]), tabs(x[1])), tabs(x[2])); }
+
+// LDS of one wavefront of k_flat2<NA> (doubles): one instance
+template <int NA>
+__host__ __device__ constexpr int flat2_xregion()
+{
+  int n = XROWS * 9;                              // placement rows / full-width scan rows while an instance is loaded
+  if (NA * F2W + 2 > n) n = NA * F2W + 2;         // W tau products (+ a zero slot)
+  return (n + 1) & ~1;
+}
+template <int NA> __host__ __device__ constexpr int flat2_off_wl() { return flat2_xregion<NA>(); }                          // [2][NA + 1][32]
+template <int NA> __host__ __device__ constexpr int flat2_off_nbuf() { return flat2_off_wl<NA>() + 2 * (NA + 1) * F2W; }  // [34]
+template <int NA> __host__ __device__ constexpr int flat2_off_pbuf() { return flat2_off_nbuf<NA>() + F2G + 2; }           // [34]
+template <int NA> __host__ __device__ constexpr int flat2_off_rbuf() { return flat2_off_pbuf<NA>() + F2G + 2; }           // [32]
+template <int NA> __host__ __device__ constexpr int flat2_off_tail() { return flat2_off_rbuf<NA>() + F2G; }
+
+template <int NA>
+__host__ __device__ __forceinline__ size_t flat2_lds_bytes(int nc, bool has_hv)
+{
+  const size_t n = (size_t)flat2_off_tail<NA>() + (has_hv ? (size_t)F2G * 6 : 0) + (size_t)nc * FCD + FISC;
+  return (n * sizeof(double) + 15) & ~(size_t)15;
+}
+
+template <int NA, int WPE>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
+        int nscan, int njmp, const int* __restrict__ ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
+        int ndec, double href_s, int has_hv)
+{
+  using T = double;
+  static_assert(NA % 2 == 0, "the W entries of a joint are dealt out to its two lanes");
+  constexpr int G = F2G, GW = F2W, cs = FCD, NH = NA / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Layout& L = P.L;
+  const bool a_shared = P.mode & MODE_A_SHARED;
+  const int lane = threadIdx.x;
+  const int j = lane & 31;       // lanes j and 32 + j <-> device joint j + 1
+  const bool h = lane >= 32;     // 0: linear halves, 1: angular halves
+  const int h3 = h ? 3 : 0;
+  // ---- LDS of the wavefront
+  T* const xb = reinterpret_cast<T*>(smem_raw);   // load-time rows | path rows [65][3] | W tau products [NA][32]
+  T* const wl = xb + flat2_off_wl<NA>();          // [2][NA + 1][32]  W rows and the Dinv row of two decades of mu
+  T* const nbuf = xb + flat2_off_nbuf<NA>();      // [34]             Dinv r' of every joint (+ zeros)
+  T* const pbuf = xb + flat2_off_pbuf<NA>();      // [34]             partial sums of long rows
+  T* const rbuf = xb + flat2_off_rbuf<NA>();      // [32]             r' of the last iteration (stored with the instance)
+  T* const shv = xb + flat2_off_tail<NA>();       // [32][6]          subtree sums of the links' H_ref v_ref (if != 0)
+  T* const cdi = shv + (has_hv ? G * 6 : 0);      // [nc][FCD]        constraint blocks of the instance
+  T* const isc = cdi + (size_t)L.nc * cs;         // [FISC]
+
+  const bool isj_lane = j < L.nb;
+  const int jl = isj_lane ? j : 0;
+  const int jflags = jd[jl + 1].flags, jcslot = isj_lane ? jd[jl + 1].cslot : -1;
+  const T mass = (!isj_lane || (jflags & JF_MASSLESS)) ? T(0) : T(1);
+  const T hz = h ? T(0) : T(1);  // scalar-per-joint contributions to sums come from the linear lane only
+  int size;
+  bool helper;
+  unsigned int jrow4[(FLAT_JMP + 3) / 4];  // load time: rows of the ancestors at distance 2^r in joint-indexed rows (WAVE = identity)
+  unsigned int prow4[(FLAT_JMP + 3) / 4];  // iteration: the same ancestors' lanes of this half (row 64 = zero)
+  unsigned int ra2[2], part4, anc4[(NH + 3) / 4];
+  {
+    const FlatLane F = fl[j];
+    size = isj_lane ? F.size : 0;
+    helper = F.helper != 0;
+#pragma unroll
+    for (int k = 0; k < (FLAT_JMP + 3) / 4; ++k) { jrow4[k] = 0u; prow4[k] = 0u; }
+#pragma unroll
+    for (int k = 0; k < (NH + 3) / 4; ++k) anc4[k] = 0u;
+#pragma unroll
+    for (int r = 0; r < FLAT_JMP; ++r) {
+      jrow4[r >> 2] |= (unsigned int)(F.jmp[r] >= 0 ? F.jmp[r] : WAVE) << (8 * (r & 3));
+      prow4[r >> 2] |= (unsigned int)(F.jmp[r] >= 0 ? F.jmp[r] + (h ? 32 : 0) : WAVE) << (8 * (r & 3));
+    }
+    // this lane's half of the joint's share of the W tau products, of its partials and of its W entries (k = 2 i + h)
+    ra2[0] = ra2[1] = 0u;
+    part4 = 0u;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int e = h ? F.red[4 + t] : F.red[t];  // (entry k * 32 + lane' of the product buffer: the schedule was built for G = 32)
+      ra2[t >> 1] |= (unsigned int)(e >= 0 ? (e >> 5) * GW + (e & 31) : NA * GW) << (16 * (t & 1));
+      const int p = h ? F.part[4 + t] : F.part[t];
+      part4 |= (unsigned int)(p >= 0 ? p : G) << (8 * t);
+    }
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int a0 = F.anc[2 * i], a1 = (2 * i + 1 < FLAT_MAXA) ? F.anc[2 * i + 1] : -1;
+      const int a = h ? a1 : a0;
+      anc4[i >> 2] |= (unsigned int)(a >= 0 ? a : G) << (8 * (i & 3));
+    }
+  }
+  if (lane < 2) { nbuf[G + lane] = T(0); pbuf[G + lane] = T(0); }
+  for (int e = lane; e < 2 * (NA + 1) * GW; e += WAVE) wl[e] = T(0);
+
+  // ---- the instance of this wavefront
+  bool has_inst = false, isj = false, done = true, any_iter = false;
+  int lidx = 0;
+  char *ip = Bf.tiles, *rec = Bf.tiles;
+  T R0[9], t0[3], Sw3[3], v3[3], f3[3], g3[3], SE3[3];
+  T w = T(0), z = T(0), nu = T(0), s = T(0), lbi = T(0), ubi = T(0), mu = T(1);
+  int kexp = 0, kslot = -(1 << 30), kslot_o = -(1 << 30), wsel = 0;
+  int iter = 0, status = ST_DONE, tail_it = 0, nflip = 0;
+  unsigned int my_iters = 0, n_wave_iters = 0, n_slot_loads = 0, n_slot_hits = 0;
+  unsigned int* q_head = Bf.counters + LEAN_Q_HEAD;
+  unsigned int cbits = 0u;  // constraint c: is its joint in this joint's subtree?
+  auto cmask = [&](int c) -> T { return ((cbits >> c) & 1u) ? T(1) : T(0); };
+  // the DualUpdate's lanes: lane 6 c + k owns row k of constraint c
+  const int ccl = lane / 6, ckl = lane - 6 * ccl;
+  const bool iscl = lane < 6 * L.nc;
+  T* const ccb = cdi + (iscl ? ccl : 0) * cs;
+  auto half = [&](const T* x6, T* x3) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x3[k] = h ? x6[3 + k] : x6[k];
+  };
+  auto whole = [&](const T* x3, T* x6) {  // both halves of a split vector (one exchange between the halves of the wavefront)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) both_halves(x3[k], x6[k], x6[3 + k]);
+  };
+
+  auto load_instance = [&]() {
+    int slot_in;
+    {
+      int nx = 0;
+      if (lane == 0) nx = (int)atomicAdd(q_head, 1u);
+      nx = __builtin_amdgcn_readfirstlane(nx);
+      slot_in = nx < nslots ? ring[nx] : -1;
+      if (nx >= nslots && lane == 0) {
+        // the queue is empty: the first wavefront to find it so notes the time (the launch's bulk phase ends here)
+        if (atomicCAS(Bf.counters + FLAT_COUNTERS_DRY, 0u, 1u) == 0u)
+          __hip_atomic_store(Bf.counters + FLAT_COUNTERS_TDRY, (unsigned int)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    has_inst = slot_in >= 0;
+    if (!has_inst) return;
+    isj = isj_lane;
+    const int slot = slot_in;
+    lidx = slot;
+    ip = lane_ptr<T>(Bf.tiles, L, slot);
+    rec = ip + (size_t)jl * JREC * pair_bytes<T>();
+    const char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+    // ---- full width on both lanes of a joint (identical values): k_flat's load, rows indexed by the joint
+    T ax[3], v[6], f[6], g[6], Sw[6], SE[6];
+    const bool rev = jflags & JF_REVOLUTE;
+    {
+      const typename Vec2<T>::type csn = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
+      const JointDesc d = jd[jl + 1];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ax[k] = isj_lane ? (T)d.axis[k] : T(0);
+      joint_xform<T>(d, rec, csn.x, csn.y, R0, t0);  // liMi ...
+      ld6<T>(rec, JP_V, v);
+      ld6<T>(rec, JP_F, f);
+      ld6<T>(rec, JP_G, g);
+      w = wz.x; z = wz.y; nu = nus.x; s = nus.y;
+      if (P.mode & MODE_BND_SHARED) {
+        lbi = Bf.uni[L.nc * 57 + jl];
+        ubi = Bf.uni[L.nc * 57 + L.nb + jl];
+      } else {
+        const typename Vec2<T>::type lu = ldp<T>(rec, JP_LBUB);
+        lbi = lu.x; ubi = lu.y;
+      }
+    }
+    if (!isj_lane) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R0[k] = (k % 4 == 0) ? T(1) : T(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t0[k] = T(0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { v[k] = T(0); f[k] = T(0); g[k] = T(0); }
+      w = z = nu = s = T(0);
+      lbi = ubi = T(0);
+    }
+    flat_world_placement<T>(xb, j, j, jrow4, njmp, R0, t0);  // ... -> oMi (FwdPassInit's oMi chain, hxx:265)
+    {
+      T ra3[3], c[3];
+      mat3_vec(R0, ax, ra3);
+      cross3(t0, ra3, c);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { Sw[k] = rev ? c[k] : ra3[k]; Sw[3 + k] = rev ? ra3[k] : T(0); }
+    }
+    // constraint blocks: lane of the joint, b, y, A^T y, A; then AW = X*_{0<-joint} A^T, AW b
+    for (int c = 0; c < L.nc; ++c) {
+      const char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+      T* c_ = cdi + c * cs;
+      if (lane < 18) {
+        const int which = lane / 6, k = lane % 6;
+        const int pair = which == 0 ? CP_B : which == 1 ? CP_Y : CP_ATY;
+        const int dst = which == 0 ? FC_B : which == 1 ? FC_Y : FC_ATY;
+        c_[dst + k] = *reinterpret_cast<const T*>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+      }
+      for (int e = lane; e < LCA; e += WAVE)
+        c_[FC_A + e] = a_shared ? Bf.uni[c * LCA + e]
+                                : *reinterpret_cast<const T*>(crec + (size_t)(CP_A + e / 2) * pair_bytes<T>() + (e & 1) * sizeof(T));
+    }
+    if (jcslot >= 0) cdi[jcslot * cs + FC_LANE] = (T)j;
+    tail_sync();
+    cbits = 0u;
+    for (int c = 0; c < L.nc; ++c) {
+      const int cl = (int)cdi[c * cs + FC_LANE];
+      if (isj_lane && cl >= j && cl < j + size) cbits |= 1u << c;
+    }
+    if (jcslot >= 0) {  // the constrained joint's lanes: column q of AW = row q of A carried to the world origin
+      T* c_ = cdi + jcslot * cs;
+      const T* A_ = c_ + FC_A;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        T aj[6], o[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) aj[k] = A_[6 * q + k];
+        act_force(R0, t0, aj, o);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c_[FC_AW + 6 * k + q] = o[k];
+      }
+      // A^T y as the instance brings it (a warm-started tailored solve arrives with the A^T y of the matrix it had BEFORE
+      // UpdateEqConstraint replaced it, and upstream's first FwdPass1 uses exactly that, hxx:329-331), at the world origin
+      T ay[6], o[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ay[k] = c_[FC_ATY + k];
+      act_force(R0, t0, ay, o);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) c_[FC_ATYW + k] = o[k];
+    }
+    tail_sync();
+    for (int c = 0; c < L.nc; ++c) {
+      T* c_ = cdi + c * cs;
+      if (lane < 6) {
+        const int k = lane;
+        T ab = T(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ab += c_[FC_AW + 6 * k + q] * c_[FC_B + q];
+        c_[FC_ATBW + k] = ab;
+      }
+    }
+    // subtree sums of the state the instance arrives with (cold start: v = 0) and of the reference term
+    {
+      T vw[6], E[6];
+      T a[3], l[3], c[3], c1[3], c2[3];
+      mat3_vec(R0, v, l);
+      mat3_vec(R0, v + 3, a);
+      cross3(t0, a, c);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { vw[k] = l[k] + c[k]; vw[3 + k] = a[k]; }
+      // E = mass * (R0 v_l, R0 v_a + t0 x R0 v_l), from the world-frame motion: R0 v_l = vw_l - t0 x vw_a
+      cross3(t0, vw + 3, c1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) E[k] = vw[k] - c1[k];
+      cross3(t0, E, c2);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) E[3 + k] = vw[3 + k] + c2[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) E[k] *= mass;
+      flat_subtree_sum<T>(xb, j, j, G, size, nscan, E, SE);
+      if (has_hv) {
+        T hv[6], hw[6], Sh[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) hv[k] = mass * P.Hv[k];
+        act_force(R0, t0, hv, hw);
+        flat_subtree_sum<T>(xb, j, j, G, size, nscan, hw, Sh);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) shv[j * 6 + k] = Sh[k];
+      }
+    }
+    half(Sw, Sw3); half(v, v3); half(f, f3); half(g, g3); half(SE, SE3);
+    const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
+    mu = mu2.x;
+    kexp = (int)mu2.y;
+    kslot = -(1 << 30); kslot_o = -(1 << 30);
+    status = (int)st2.x;
+    iter = (int)bi2.y;
+    tail_it = (int)ld_scal<T>(srec, SC_TAIL_ITER);
+    nflip = (int)ldp<T>(srec, SP_FLIP).x;
+    done = (status & ST_DONE) != 0;
+    if (!done && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { done = true; status |= ST_DONE; }
+    if (lane == 0) {
+      isc[FI_BNORM] = bi2.x; isc[FI_TGIN] = ldp<T>(srec, SP_TAG).x; isc[FI_STY] = st2.y; isc[FI_MULAST] = T(-1);
+      isc[FI_TOLP] = ld_scal<T>(srec, SC_TOL_PRIMAL); isc[FI_TOLD] = ld_scal<T>(srec, SC_TOL_DUAL);
+      isc[FI_DYQP] = ld_scal<T>(srec, SC_DELTA_Y_QP); isc[FI_ATDY] = ld_scal<T>(srec, SC_AT_DELTA_Y_QP);
+      isc[FI_UBP] = ld_scal<T>(srec, SC_UB_DY_PLUS); isc[FI_LBM] = ld_scal<T>(srec, SC_LB_DY_MINUS);
+      isc[FI_C1] = ld_scal<T>(srec, SC_COND1); isc[FI_C2] = ld_scal<T>(srec, SC_COND2);
+    }
+    tail_sync();
+    my_iters = 0;
+    any_iter = false;
+  };
+  auto store_instance = [&]() {
+    char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+    {
+      T v[6], f[6], g[6];
+      whole(v3, v); whole(f3, f); whole(g3, g);
+      if (isj && !h) {
+        st6<T>(rec, JP_V, v);
+        st6<T>(rec, JP_F, f);
+        st6<T>(rec, JP_G, g);
+        stp<T>(rec, JP_WZ, w, z);
+        stp<T>(rec, JP_NUS, nu, s);
+        if (any_iter) {
+          // inter-sweep temporaries of the last iteration: r_i and Dinv_i.  This engine forms neither UDinv_i nor the
+          // accumulated p_i: the scalar record's tag says so (SP_TAG = -2) and the getters rebuild them (k_rebuild_ud).
+          stp<T>(rec, JP_R, rbuf[j], wl[(wsel * (NA + 1) + NA) * GW + j]);
+        }
+      }
+    }
+    for (int c = 0; c < L.nc; ++c) {
+      char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+      if (lane < 6) {
+        const int k = lane;
+        *reinterpret_cast<T*>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * cs + FC_Y + k];
+        *reinterpret_cast<T*>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * cs + FC_ATY + k];
+      }
+    }
+    if (lane == 0) {
+      stp<T>(srec, SP_MU, mu, (T)kexp);
+      stp<T>(srec, SP_TAG, any_iter ? T(-2) : isc[FI_TGIN], T(0));
+      stp<T>(srec, SP_BI, isc[FI_BNORM], (T)iter);
+      stp<T>(srec, SP_FLIP, (T)nflip, T(0));
+      stp<T>(srec, SP_ST, (T)(any_iter ? (status & ~ST_PFULL) : status), any_iter ? isc[FI_MULAST] : isc[FI_STY]);
+      if (any_iter) {
+        const T* rr = isc + FI_RED;  // prt prs stf dvis dnu dfis dyis dw av nu hrefv g dualv (13), filled when the instance stopped
+        const T mu_s = mu;
+        stp<T>(srec, SP_SCAL + 0, isc[FI_PRIMAL], isc[FI_DUAL]);
+        stp<T>(srec, SP_SCAL + 1, rr[0], rr[1]);
+        stp<T>(srec, SP_SCAL + 2, rr[12], rr[2]);
+        stp<T>(srec, SP_SCAL + 3, isc[FI_TOLP], isc[FI_TOLD]);
+        stp<T>(srec, SP_SCAL + 4, mu_s, P.mu_scale * mu_s);
+        stp<T>(srec, SP_SCAL + 5, mu_s, isc[FI_DX]);
+        stp<T>(srec, SP_SCAL + 6, isc[FI_DZ], isc[FI_DYQP]);
+        stp<T>(srec, SP_SCAL + 7, isc[FI_ATDY], isc[FI_UBP]);
+        stp<T>(srec, SP_SCAL + 8, isc[FI_LBM], rr[5]);
+        stp<T>(srec, SP_SCAL + 9, rr[6], rr[7]);
+        stp<T>(srec, SP_SCAL + 10, rr[3], rr[4]);
+        stp<T>(srec, SP_SCAL + 11, rr[8], rr[9]);
+        stp<T>(srec, SP_SCAL + 12, rr[10], rr[11]);
+        stp<T>(srec, SP_SCAL + 13, rr[2], isc[FI_C1]);
+        stp<T>(srec, SP_SCAL + 14, isc[FI_C2], (T)tail_it);
+      }
+      if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
+    }
+    tail_sync();
+  };
+
+#ifdef LOIKB_TAIL_PROF
+  unsigned long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
+  const unsigned long long wall0_ = wall_clock64(), clk0_ = tprev_;
+#endif
+  // (two loops: everything only the load / store of an instance needs lives across the inner loop without being touched in it,
+  //  so the register allocator can park it around the loop instead of in it)
+  while (true) {
+    load_instance();
+    if (!has_inst) break;  // the queue is empty: this wavefront is done
+    T inv_mu = T(1) / mu;  // (a division per change of mu, not per iteration: BoxProj's 1 / mu_ineq, hxx:384-397)
+   while (true) {
+    // ---- does the instance leave before this iteration?  (fetched already finished; this launch's share of iterations used up;
+    // mu left the precomputed decades.)  Then it goes back as it is.
+    bool exit_now = done || (int)my_iters >= P.max_launch_iters;
+    // ---- decade of mu: W rows and Dinv.  Two decades stay in LDS: a flip back to the previous one costs nothing.
+    if (!exit_now && kexp != kslot) {
+      if (kexp == kslot_o) {
+        { const int tk = kslot; kslot = kslot_o; kslot_o = tk; }
+        wsel ^= 1;
+        ++n_slot_hits;
+      } else {
+        const int dsl = kexp - kexp_lo;
+        if (dsl < 0 || dsl >= ndec) {
+          exit_now = true;  // mu left the precomputed decades: written back unfinished, k_tail takes over
+          if (lane == 0) atomicAdd(&Bf.counters[2], 1u);
+        } else {
+          kslot_o = kslot;  // the slot that was not used last is overwritten
+          wsel ^= 1;
+          T* wdst = wl + (size_t)wsel * (NA + 1) * GW;
+          // rows k = 2 i + h of the joint's column (k <= NA: the linear lane also fetches the Dinv row)
+          T in[NH + 1];
+#pragma unroll
+          for (int i = 0; i <= NH; ++i) {
+            const int k = 2 * i + (h ? 1 : 0);
+            in[i] = (isj && k <= NA) ? fslots[fslot_at(lidx, ndec, dsl, G, frows, k < nanc ? k : nanc, j)] : T(0);
+          }
+          tail_sync();
+#pragma unroll
+          for (int i = 0; i <= NH; ++i) {
+            const int k = 2 * i + (h ? 1 : 0);
+            if (k <= NA) wdst[k * GW + j] = in[i];
+          }
+          kslot = kexp;
+          n_slot_loads = (n_slot_loads + 0x10000u) | (1u << dsl);
+          tail_sync();
+        }
+      }
+    }
+    if (exit_now) break;
+    const T* wcur = wl + (size_t)wsel * (NA + 1) * GW;
+    TAIL_TP(8)
+    const T mu_eq = P.mu_scale * mu, mu_in = mu;
+    ++my_iters; any_iter = true;
+    ++n_wave_iters;
+
+    // ================= p^base at the world origin, summed over the subtrees; tau  (FwdPass1 + the p part of BwdPass) ===========
+    T wc[NH];  // this lane's share of the joint's W entries (ancestors k = 2 i + h): used twice, up and down
+#pragma unroll
+    for (int i = 0; i < NH; ++i) wc[i] = wcur[(2 * i + (h ? 1 : 0)) * GW + j];
+    const T dinv = wcur[NA * GW + j];
+    T tau;
+    {
+      T PB[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) PB[k] = -P.rho * SE3[k];
+      if (has_hv) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) PB[k] -= shv[j * 6 + h3 + k];
+      }
+      for (int c = 0; c < L.nc; ++c) {
+        const T* c_ = cdi + c * cs + h3;
+        const T m = cmask(c);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) PB[k] += m * (c_[FC_ATYW + k] - mu_eq * c_[FC_ATBW + k]);
+      }
+      const T d3 = Sw3[0] * PB[0] + Sw3[1] * PB[1] + Sw3[2] * PB[2];
+      tau = (w - mu_in * z) + pair_sum(d3);
+    }
+    TAIL_TP(0)
+    // ================= r' = W tau: products to LDS, every lane sums its share, long rows collect their partials ================
+    tail_sync();
+#pragma unroll
+    for (int i = 0; i < NH; ++i) xb[(2 * i + (h ? 1 : 0)) * GW + j] = wc[i] * tau;
+    if (lane == 0) { xb[NA * GW] = T(0); xb[NA * GW + 1] = T(0); }
+    tail_sync();
+    T rn;
+    {
+      T a[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = xb[unpack16(ra2, t)];
+      T acc = (a[0] + a[1]) + (a[2] + a[3]);
+      acc = pair_sum(acc);
+      if (!h) pbuf[j] = helper ? acc : T(0);
+      tail_sync();
+      T pp[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pp[q] = pbuf[(int)((opaque(part4) >> (8 * q)) & 0xFFu)];
+      T ps = (pp[0] + pp[1]) + (pp[2] + pp[3]);
+      ps = pair_sum(ps);
+      if (helper) acc = T(0);
+      rn = tau + (acc + ps);
+      if (!h) { rbuf[j] = rn; nbuf[j] = dinv * rn; }
+    }
+    tail_sync();
+    TAIL_TP(1)
+    // ================= nu = -W^T (Dinv r')  (FwdPass2's nu_i, hxx:127) ======================================================
+    T nui;
+    {
+      T nb_[NH];
+#pragma unroll
+      for (int i = 0; i < NH; ++i) nb_[i] = nbuf[unpack8(anc4, i)];
+      T acc = T(0);
+#pragma unroll
+      for (int i = 0; i < NH; ++i) acc += wc[i] * nb_[i];
+      nui = -(dinv * rn + pair_sum(acc));
+    }
+    // ================= v = J nu: path sum of S^w nu at the world origin, then into the link frame (hxx:125-134) ===============
+    T vi3[3], E3[3];
+    {
+      T y[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) y[k] = Sw3[k] * nui;
+      tail_sync();
+      if (lane < 3) xb[WAVE * 3 + lane] = T(0);
+#pragma unroll 1
+      for (int r = 0; r < njmp; ++r) {
+        const int jr = (int)(((r < 4 ? prow4[0] : prow4[1]) >> (8 * (r & 3))) & 0xFFu);
+        tail_sync();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) xb[lane * 3 + c] = y[c];
+        tail_sync();
+        T a[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a[c] = xb[jr * 3 + c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) y[c] += a[c];
+      }
+      // the two halves meet: R0 v_l = vw_l - t0 x vw_a is needed by both lanes (the linear lane rotates it into the link frame,
+      // the angular lane builds the angular part of the link's momentum-like vector E from it)
+      T lin[3], ang[3], c1[3], El[3], c2[3], X[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) both_halves(y[k], lin[k], ang[k]);
+      cross3(t0, ang, c1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) El[k] = lin[k] - c1[k];
+      cross3(t0, El, c2);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        X[k] = h ? ang[k] : El[k];
+        E3[k] = mass * (h ? ang[k] + c2[k] : El[k]);
+      }
+      mat3t_vec(R0, X, vi3);  // SE3::actInv(Motion): (R^T (v_l - t x v_a), R^T v_a)
+    }
+    TAIL_TP(2)
+    // ================= DualUpdate of the task constraints (hxx:410-451) inside the subtree sum of the links' velocities ==========
+    T l_dyis = T(0), l_av = T(0), l_prt = T(0), l_up = T(0), l_lm = T(0);
+    T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_prs = T(0);
+    T l_dg = T(0), l_g = T(0), l_stf = T(0), l_dstf = T(0), l_dualv = T(0);
+    T fi3[3], si;
+    {
+      T SEn[3], Fw[3];
+      // ---- the task constraints' update: (A v - b, dy, y), then (A^T y, the same at the world origin, the pieces of this
+      // iteration's force balance): two dependent exchanges through the constraint block in LDS (lane 6 c + k owns row k)
+      tail_sync();
+      if (jcslot >= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cdi[jcslot * cs + FC_VC + h3 + k] = vi3[k];
+      }
+      tail_sync();
+      if (iscl) {
+        const T* A_ = ccb + FC_A;
+        const T* vc = ccb + FC_VC;
+        T avk = A_[6 * ckl] * vc[0];
+#pragma unroll
+        for (int q = 1; q < 6; ++q) avk += A_[6 * ckl + q] * vc[q];
+        const T bk = ccb[FC_B + ckl];
+        const T ek = avk - bk;
+        const T dy = mu_eq * ek;
+        const T yk = ccb[FC_Y + ckl] + dy;
+        l_dyis = tabs(dy);
+        l_up = bk * tmax(dy, T(0));
+        l_lm = bk * tmin(dy, T(0));
+        l_prt = tabs(ek);
+        l_av = tabs(avk);
+        ccb[FC_Y + ckl] = yk;
+        ccb[FC_DY + ckl] = dy;
+      }
+      // ---- subtree sums of E (BwdPass2's transport, hxx:210-212, as a force balance at the world origin): the joints of a subtree
+      // are the lanes [j, j + size) of this half, so S_j = P[j + size - 1] - P[j] + E_j with P the inclusive prefix sum -- in
+      // registers (DPP), placed here to run while the constraint block is on its way through LDS
+      {
+        T Pk[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Pk[c] = prefix32(E3[c]);
+        const int src = lane + (size > 0 ? size - 1 : 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) SEn[c] = (lane_read(Pk[c], src) - Pk[c]) + E3[c];
+      }
+      tail_sync();
+      if (iscl) {
+        // A^T y (hxx:422) and the same at the world origin; the constraint's share of this iteration's force balance is
+        // A^T dy + (the A^T y FwdPass1 used) -- see k_flat
+        const T* A_ = ccb + FC_A;
+        const int k = ckl;
+        T at = A_[k] * ccb[FC_Y], aw = ccb[FC_AW + 6 * k] * ccb[FC_Y], atd = A_[k] * ccb[FC_DY], awd = ccb[FC_AW + 6 * k] * ccb[FC_DY];
+#pragma unroll
+        for (int q = 1; q < 6; ++q) {
+          at += A_[6 * q + k] * ccb[FC_Y + q]; aw += ccb[FC_AW + 6 * k + q] * ccb[FC_Y + q];
+          atd += A_[6 * q + k] * ccb[FC_DY + q]; awd += ccb[FC_AW + 6 * k + q] * ccb[FC_DY + q];
+        }
+        ccb[FC_DLT + k] = (at - atd) - ccb[FC_ATY + k];   // A^T y_old - (A^T y used): added to g of the constrained joint
+        ccb[FC_ATYF + k] = ccb[FC_ATYW + k] + awd;       // the constraint's force in f, world origin
+        ccb[FC_ATY + k] = at;
+        ccb[FC_ATYW + k] = aw;
+      }
+      tail_sync();
+      // ---- per-joint work that needs v and nu only -- BoxProj, the w update, their norms, g (hxx:129-158, :384-397, :454-458) --
+      {
+        T dv[3], gi[3], dg[3], dvr[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          dv[k] = vi3[k] - v3[k];
+          // g_i = A^T y_i + sum_children act(f_c) - f_i = A^T y_i - (H^base_i v_i + p^base_i)  (force balance)
+          gi[k] = -mass * (P.rho * dv[k] + href_s * vi3[k]);
+        }
+        if (has_hv) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) gi[k] += mass * (h ? P.Hv[3 + k] : P.Hv[k]);
+        }
+        if (jcslot >= 0) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) gi[k] += cdi[jcslot * cs + FC_DLT + h3 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          dg[k] = gi[k] - g3[k];
+          dvr[k] = mass * (href_s * vi3[k]) + gi[k];  // dual residual, v block (hxx:228): H_ref v - Hv + g
+        }
+        if (has_hv) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) dvr[k] -= mass * (h ? P.Hv[3 + k] : P.Hv[k]);
+        }
+        l_dualv = inf3(dvr);
+        l_nu = tabs(nui);
+        l_hrefv = mass * tabs(href_s) * inf3(vi3);
+        l_dvis = mass * inf3(dv);
+        l_dnu = tabs(nui - nu);
+        const T x = nui + inv_mu * w;
+        const T zi = tmin(ubi, tmax(lbi, x));
+        l_dz = tabs(zi - z);
+        l_prs = tabs(nui - zi);
+        const T dwi = mu_in * (nui - zi);
+        l_dw = tabs(dwi);
+        l_up += hz * (ubi * tmax(dwi, T(0)));
+        l_lm += hz * (lbi * tmin(dwi, T(0)));
+        w = w + dwi; z = zi; nu = nui;
+        l_dg = inf3(dg);
+        l_g = inf3(gi);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { v3[k] = vi3[k]; g3[k] = gi[k]; }
+      }
+      TAIL_TP(4)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Fw[k] = (P.rho + href_s) * SEn[k] - P.rho * SE3[k];
+      if (has_hv) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Fw[k] -= shv[j * 6 + h3 + k];
+      }
+      for (int c = 0; c < L.nc; ++c) {
+        const T* c_ = cdi + c * cs + h3;
+        const T m = cmask(c);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Fw[k] += m * c_[FC_ATYF + k];
+      }
+      {
+        // SE3::actInv(Force): (R0^T F_l, R0^T (F_a - t0 x F_l)): the angular lane needs the linear half
+        T Fl[3], Fa[3], cc[3], X[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) both_halves(Fw[k], Fl[k], Fa[k]);
+        cross3(t0, Fl, cc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) X[k] = h ? Fw[k] - cc[k] : Fw[k];
+        mat3t_vec(R0, X, fi3);
+      }
+      {
+        const T d3 = Sw3[0] * Fw[0] + Sw3[1] * Fw[1] + Sw3[2] * Fw[2];
+        si = pair_sum(d3);  // S^T f (hxx:231-233): the pairing of a motion and a force does not depend on the frame
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) SE3[k] = SEn[k];
+    }
+    TAIL_TP(5)
+    // ================= what is left of the per-joint work: the norms that need f (hxx:137-146, :231-236) =========================
+    {
+      T df[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) df[k] = fi3[k] - f3[k];
+      l_dfis = mass * inf3(df);
+      si += w;
+      l_stf = tabs(si);
+      l_dstf = tabs(si - s);
+      s = si;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) f3[k] = fi3[k];
+    }
+    TAIL_TP(3)
+    // ================= the scalars of the stopping logic, folded over the wavefront ===============================================
+    T red[8];
+    {
+      T in[8] = {tmax(l_prt, l_prs), tmax(l_dualv, l_stf), tmax(l_dvis, l_dnu), l_dz,
+                 tmax(l_dfis, tmax(l_dyis, l_dw)), tmax(l_dg, l_dstf), l_up, l_lm};
+      wave_fold8<true>(lane, in, red);
+    }
+    T ntol_p = T(0), ntol_d = T(0);
+    if (P.tol_rel != T(0)) {  // (uniform) relative tolerances need two more maxima
+      T in2[8] = {tmax(l_av, l_nu), tmax(tmax(l_hrefv, l_g), l_stf), T(0), T(0), T(0), T(0), T(0), T(0)}, r2[8];
+      wave_fold8<false>(lane, in2, r2);
+      ntol_p = r2[0]; ntol_d = r2[1];
+    }
+    TAIL_TP(6)
+    // ================= CheckConvergence, CheckFeasibility, UpdateMu, the tail solve's stopping rule (hpp:377-454, :271-319) ====
+    const T primal = red[0], dual = red[1], dx = red[2], dz = red[3], dyqp = red[4], atdy = red[5], ubp = red[6], lbm = red[7];
+    const T mu_used = mu;
+    const bool fixed = P.mode & MODE_FIXED_ITERS;
+    const bool in_tail = (status & ST_TAIL) != 0;
+    const bool logic = !fixed && !in_tail;  // the main loop's stopping logic runs
+    const T tol_p = P.tol_abs + P.tol_rel * tmax(ntol_p, isc[FI_BNORM]);
+    const T tol_d = P.tol_abs + P.tol_rel * tmax(ntol_d, P.Hv_inf_norm);
+    const int itn = iter + 1;
+    const bool conv = logic && (primal < tol_p) && (dual < tol_d);
+    const bool feas_chk = logic && itn > 1;
+    const bool c1 = atdy <= P.tol_primal_inf * dyqp, c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp;
+    const bool infeas = feas_chk && c1 && c2;
+    const bool enter_tail = infeas && !conv;
+    const bool upd = logic && !conv && !infeas;
+    const bool mu_up = upd && (primal > T(10) * dual), mu_dn = upd && !mu_up && (dual > T(10) * primal);
+    const bool tail_stop = !(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || itn >= P.max_iter;
+    const bool stop = conv || ((enter_tail || in_tail) && tail_stop) || ((upd || fixed) && itn + 1 >= P.max_iter);
+    iter = itn;
+    status |= (conv ? ST_CONVERGED : 0) | (infeas ? ST_PRIMAL_INF : 0) | (enter_tail ? ST_TAIL : 0) | (stop ? ST_DONE : 0);
+    tail_it = enter_tail ? 0 : (in_tail ? tail_it + 1 : tail_it);
+    mu = mu_up ? mu * T(10) : (mu_dn ? mu * T(0.1) : mu);
+    if (mu_up || mu_dn) inv_mu = T(1) / mu;
+    kexp += (mu_up ? 1 : 0) - (mu_dn ? 1 : 0);
+    nflip += (mu_up || mu_dn) ? 1 : 0;
+    done = stop;
+    // ---- what the getters report: written when an instance stops (the certificate's scalars also when it enters the tail
+    // solve: they keep the values of the last iteration that evaluated them) -------------------------------------------------
+    if (stop || enter_tail) {
+      if (lane == 0) {
+        isc[FI_PRIMAL] = primal; isc[FI_DUAL] = dual; isc[FI_DX] = dx; isc[FI_DZ] = dz; isc[FI_MULAST] = mu_used;
+        if (logic) { isc[FI_TOLP] = tol_p; isc[FI_TOLD] = tol_d; }
+        if (feas_chk) {
+          isc[FI_C1] = (T)(c1 ? 1 : 0); isc[FI_C2] = (T)(c2 ? 1 : 0); isc[FI_DYQP] = dyqp; isc[FI_ATDY] = atdy; isc[FI_UBP] = ubp; isc[FI_LBM] = lbm;
+        }
+      }
+    }
+    if (stop) {
+      T in1[8] = {l_prt, l_prs, l_stf, l_dvis, l_dnu, l_dfis, l_dyis, l_dw}, in2[8] = {l_av, l_nu, l_hrefv, l_g, l_dualv, T(0), T(0), T(0)};
+      T r1[8], r2[8];
+      wave_fold8<false>(lane, in1, r1);
+      wave_fold8<false>(lane, in2, r2);
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) isc[FI_RED + k] = r1[k];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) isc[FI_RED + 8 + k] = r2[k];
+      }
+      tail_sync();
+      break;
+    }
+    TAIL_TP(7)
+   }
+    store_instance();
+  }
+#ifdef LOIKB_TAIL_PROF
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int k = 0; k < 8; ++k) g_tail_prof[k] = prof_[k];
+    for (int k = 8; k < 12; ++k) g_tail_prof[2 + k] = prof_[k];
+    g_tail_prof[8] = n_wave_iters;
+    g_tail_prof[9] = (clock64() - clk0_) * 100000ull / (wall_clock64() - wall0_ + 1);
+  }
+#endif
+  if (lane == 0) {
+    atomicAdd(&Bf.counters[5], n_wave_iters);
+    atomicAdd(&Bf.counters[6], n_slot_loads >> 16);
+    atomicAdd(&Bf.counters[FLAT_COUNTERS_SLOT_HITS], n_slot_hits);
+    atomicOr(&Bf.counters[LEAN_DECADES_SEEN], n_slot_loads & 0xFFFFu);
+  }
+}
+
+}  // namespace loikb

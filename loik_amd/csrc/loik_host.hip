@@ -16,6 +16,7 @@
 #include "loik_tail.hpp"
 #include "loik_lean.hpp"
 #include "loik_flat.hpp"
+#include "loik_flat2.hpp"
 #include "loik_passes.hpp"
 
 #include "../../include/loik_amd.h"
@@ -57,6 +58,8 @@ struct Tuning {
   int tile_pad = -1;            // LOIKB_TILE_PAD      extra pairs per tile (-1: pad to an odd number of 1-KiB pairs)
   bool lean = true;             // LOIKB_LEAN=0        never use k_lean nor k_flat (the engines with precomputed decade slots)
   bool flat = true;             // LOIKB_FLAT=0        never use k_flat (the engine without level loops, loik_flat.hpp)
+  bool flat_split = true;       // LOIKB_FLAT_SPLIT=0: k_flat (one joint per lane) also where k_flat2 (two lanes per joint) applies
+  int flat_split_wpe = 2;       // LOIKB_FLAT_WPE=3: k_flat2 built for three wavefronts per SIMD
   bool flat_two_stage = false;  // LOIKB_FLAT_STAGES=2 the flat engine's throughput build (two wavefronts per SIMD, ~75 values in scratch) until the
                                 // work queue runs dry, then its latency build (default: the latency build -- one wavefront per SIMD, no scratch -- alone:
                                 // measured faster in bulk too, 12.5 against 13.8 ms until the queue is dry on the headline)
@@ -83,6 +86,8 @@ struct Tuning {
     if (const char* e = getenv("LOIKB_FLAT")) flat = atoi(e) != 0;
     if (!lean) flat = false;  // (LOIKB_LEAN=0 asks for the engines without precomputed factors: k_solve / k_tail)
     if (const char* e = getenv("LOIKB_FLAT_STAGES")) flat_two_stage = atoi(e) == 2;
+    if (const char* e = getenv("LOIKB_FLAT_SPLIT")) flat_split = atoi(e) != 0;
+    if (const char* e = getenv("LOIKB_FLAT_WPE")) flat_split_wpe = atoi(e) == 3 ? 3 : 2;
     geti("LOIKB_TAIL_WAVES", tail_waves); tail_waves = std::max(1, std::min(TAIL_WAVES, tail_waves));
     geti("LOIKB_LEAN_DECADES", lean_decades); lean_decades = std::max(1, std::min(16, lean_decades));
     geti("LOIKB_LEAN_KLO", lean_klo);
@@ -1481,7 +1486,9 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       const double cu_sh = std::max(1.0, S->ncu * ((double)C->B / (double)S->B));
       const int cap_thr = (S->tune.lean_wg_per_cu > 0 ? S->tune.lean_wg_per_cu : (int)std::min<size_t>(8, (160 * 1024) / flds)) * (int)(cu_sh + 0.5);
       const int cap_lat = (int)std::min<size_t>(4, (160 * 1024) / flds) * (int)(cu_sh + 0.5);
-      const bool two_stage = S->tune.flat_two_stage && n > 2 * cap_lat * ipw && !S->opt.logging;
+      // two lanes per joint where the layout applies: 17..32 joints, few ancestors, fp64, no lists to write
+      const bool split = S->tune.flat_split && G == F2G && small_na && sizeof(T) == 8 && !S->opt.logging;
+      const bool two_stage = S->tune.flat_two_stage && n > 2 * cap_lat * ipw && !S->opt.logging && !split;
       P.max_launch_iters = S->opt.max_iter + 1;
       HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
@@ -1519,6 +1526,21 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           if (trace) fprintf(stderr, "[loikb] flat engine, throughput stage: %d of %d instances still iterating when the queue ran dry\n", n, n_first);
         }
         hipLaunchKernelGGL(k_ring_fill, grid1(C->ring_cap), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, list, n, C->d_counters);
+        if (split) {
+          // k_flat2: two lanes per joint, one instance per wavefront, two or three wavefronts per SIMD (loik_flat2.hpp)
+          const size_t lds2 = flat2_lds_bytes<FLAT_NA_SMALL>(S->nc, has_hv != 0);
+          const int wpe = S->tune.flat_split_wpe;
+          int per_cu = (int)std::min<size_t>((size_t)4 * wpe, (160 * 1024) / lds2);
+          if (S->tune.lean_wg_per_cu > 0) per_cu = std::min(per_cu, S->tune.lean_wg_per_cu);
+          grid = dim3((unsigned)std::min(n, per_cu * (int)(cu_sh + 0.5)));
+#define LOIKB_LAUNCH_FLAT2(WPE)                                                                                                 \
+  hipLaunchKernelGGL((k_flat2<FLAT_NA_SMALL, WPE>), grid, dim3(WAVE), lds2, C->stream, *reinterpret_cast<const Params<double>*>(&P), \
+                     *reinterpret_cast<const Bufs<double>*>(&Bf), (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes,    \
+                     nanc, S->flat.nscan, S->flat.njmp, (const int*)C->d_ring, n, (const double*)C->d_fslots, frows, kexp_lo,    \
+                     ndec, (double)S->Href[0], has_hv)
+          if (wpe == 3) LOIKB_LAUNCH_FLAT2(3); else LOIKB_LAUNCH_FLAT2(2);
+#undef LOIKB_LAUNCH_FLAT2
+        } else {
 #define LOIKB_LAUNCH_FLAT(NAV, LATV, ...)                                                                                       \
   hipLaunchKernelGGL((k_flat<T, NAV, LATV, ##__VA_ARGS__>), grid, dim3(WAVE), flds, C->stream, P, Bf, (const JointDesc*)S->d_jd,                \
                      (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, (const int*)C->d_ring, n, lgG,          \
@@ -1527,6 +1549,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         else if (small_na) { if (lat) LOIKB_LAUNCH_FLAT(FLAT_NA_SMALL, true); else LOIKB_LAUNCH_FLAT(FLAT_NA_SMALL, false); }
         else { if (lat) LOIKB_LAUNCH_FLAT(FLAT_MAXA, true); else LOIKB_LAUNCH_FLAT(FLAT_MAXA, false); }
 #undef LOIKB_LAUNCH_FLAT
+        }
         HIPCHK(hipGetLastError());
         int* nxt = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
         hipLaunchKernelGGL(k_list_unfinished<T>, grid1(n), dim3(256), 0, C->stream, A.tiles, S->L, list, n, nxt, C->d_counters + 3);

@@ -100,12 +100,13 @@ def test_gpu_solver_info_from_the_flat_engine(talos):
             assert_close(info[name][b, :n], r.solver_info(k), 1e-9, "%s b%d" % (name, b))
             assert np.all(info[name][b, n:] == 0.0)
         assert_close(z[b], r.z, 1e-9, "z")
-    # the lists restart with every solve; a handle without logging gives the same answers bit for bit (same kernel arithmetic)
+    # the lists restart with every solve; a handle without logging gives the same answers (it runs k_flat2, the build with two
+    # lanes per joint, which sums in another order: same iteration counts here, z to rounding)
     s.Solve()
     assert np.array_equal(s.solver_info()["rows"], info["rows"])
     s2 = loik_amd.BatchedLoik(talos, B, **prm)
     s2.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
-    assert np.array_equal(s.get("iter"), s2.get("iter")) and np.array_equal(s.get("z"), s2.get("z"))
+    assert np.array_equal(s.get("iter"), s2.get("iter")) and np.abs(s.get("z") - s2.get("z")).max() < 1e-9
     s.close(); s2.close()
 
 
