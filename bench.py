@@ -163,7 +163,7 @@ class Shard:
             self.last = st
             for k in ("kernel_ms", "tail_ms", "tail_instances", "tail_instance_iterations", "tail_launches", "total_ms",
                       "solve_busy_ms", "tail_busy_ms", "instance_iterations", "launches", "hslots_ms", "lean_launches",
-                      "flat_launches", "queue_dry_ms"):
+                      "flat_launches", "queue_dry_ms", "flat_split_launches"):
                 self.acc[k] = self.acc.get(k, 0) + st.get(k, 0)
 
     def results(self):
@@ -283,7 +283,7 @@ def kernel_roofline(acc, last, steps, nb, nc, B):
 
     if tail_iters >= solve_iters:
         # ---- on-chip engine: fp64 vector issue is the roof
-        name = "k_flat" if flat else "k_lean" if lean else "k_tail"
+        name = ("k_flat2" if acc.get("flat_split_launches", 0) > 0 else "k_flat") if flat else "k_lean" if lean else "k_tail"
         slots_name = "k_fslots" if flat else "k_hslots"
         launches = max(acc["tail_launches"], 1)
         # the library times k_hslots (decade-slot precomputation) + the lean launch together; k_lean alone = the rest
@@ -386,7 +386,8 @@ def whole_body_variant(args, device):
            "unit": "solves/s", "solved_fraction": float(conv.mean()),
            "flagged_infeasible_fraction": float(s.get("primal_infeasible").astype(bool).mean()),
            "mean_admm_iterations": float(it.mean()), "instance_iterations_per_s": float(it.sum() / dt),
-           "engine": ("k_flat" if st["flat_launches"] > 0 else "k_lean") if st["lean_launches"] > 0 and st["tail_instances"] == args.batch
+           "engine": (("k_flat2" if st["flat_split_launches"] > 0 else "k_flat") if st["flat_launches"] > 0 else "k_lean")
+                     if st["lean_launches"] > 0 and st["tail_instances"] == args.batch
                      else "k_solve+k_tail",
            "lean_escaped": st["lean_escaped"],
            "achieved_TFLOPs": float(it.sum() * FLOPS_PER_JOINT_ITERATION * m.nv / dt / 1e12),

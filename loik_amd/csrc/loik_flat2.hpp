@@ -131,6 +131,49 @@ __device__ __forceinline__ void wave_fold8(int lane, const double* in, double* o
 template <typename T>
 __device__ __forceinline__ T inf3(const T* x) { return tmax(tmax(tabs(x[0]), tabs(x[1])), tabs(x[2])); }
 
+// y_i <- sum over the root path of lane i (the joint and its ancestors) of the NC-vectors y, by pointer jumping in base 4: a
+// round adds the rows of the ancestors at distance 1, 2, 3 (x 4^round), so two rounds cover a tree of depth 16 where jumping in
+// base 2 (flat_path_sum) takes four -- the same number of LDS rows moved, half the dependent round trips.  rows: [WAVE + 1][NC],
+// row WAVE = 0; pa / pb: the lanes of the ancestors at distance 1, 2, 3 / 4, 8, 12 (bytes; WAVE = none), pc: at distance 16.
+template <typename T, int NC>
+__device__ __forceinline__ void flat_path_sum4(T* rows, int lane, unsigned int pa, unsigned int pb, int pc, int njmp, T* y)
+{
+  tail_sync();
+  if (lane < NC) rows[WAVE * NC + lane] = T(0);
+  auto round = [&](unsigned int p3) {
+    tail_sync();
+#pragma unroll
+    for (int c = 0; c < NC; ++c) rows[lane * NC + c] = y[c];
+    tail_sync();
+    const int r0 = (int)(p3 & 0xFFu), r1 = (int)((p3 >> 8) & 0xFFu), r2 = (int)((p3 >> 16) & 0xFFu);
+    T a[NC], b[NC], d[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) a[c] = rows[r0 * NC + c];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) b[c] = rows[r1 * NC + c];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) d[c] = rows[r2 * NC + c];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) y[c] += (a[c] + b[c]) + d[c];
+  };
+  round(pa);
+  if (njmp > 2) round(pb);
+  if (njmp > 4) round((unsigned int)pc | ((unsigned int)WAVE << 8) | ((unsigned int)WAVE << 16));
+}
+// the packed ancestor rows of flat_path_sum4 for the joint of FlatLane F: `off` is added to an ancestor's lane
+__device__ __forceinline__ void flat_path_rows4(const FlatLane* fl, int j, int off, unsigned int& pa, unsigned int& pb, int& pc)
+{
+  const int depth = fl[j].depth;
+  auto row = [&](int d) -> unsigned int {
+    const int k = depth - d - 1;
+    const int a = (k >= 0 && k < FLAT_MAXA) ? fl[j].anc[k] : -1;
+    return (unsigned int)(a >= 0 ? a + off : WAVE);
+  };
+  pa = row(1) | (row(2) << 8) | (row(3) << 16);
+  pb = row(4) | (row(8) << 8) | (row(12) << 16);
+  pc = (int)row(16);
+}
+
 // LDS of one wavefront of k_flat2<NA> (doubles): one instance
 template <int NA>
 __host__ __device__ constexpr int flat2_xregion()
@@ -186,20 +229,21 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   int size;
   bool helper;
   unsigned int jrow4[(FLAT_JMP + 3) / 4];  // load time: rows of the ancestors at distance 2^r in joint-indexed rows (WAVE = identity)
-  unsigned int prow4[(FLAT_JMP + 3) / 4];  // iteration: the same ancestors' lanes of this half (row 64 = zero)
+  unsigned int pathA, pathB;               // iteration: the ancestors at distance 1, 2, 3 / 4, 8, 12: their lanes of this half
+  int pathC;
   unsigned int ra2[2], part4, anc4[(NH + 3) / 4];
   {
     const FlatLane F = fl[j];
     size = isj_lane ? F.size : 0;
     helper = F.helper != 0;
 #pragma unroll
-    for (int k = 0; k < (FLAT_JMP + 3) / 4; ++k) { jrow4[k] = 0u; prow4[k] = 0u; }
+    for (int k = 0; k < (FLAT_JMP + 3) / 4; ++k) jrow4[k] = 0u;
+    flat_path_rows4(fl, j, h ? 32 : 0, pathA, pathB, pathC);
 #pragma unroll
     for (int k = 0; k < (NH + 3) / 4; ++k) anc4[k] = 0u;
 #pragma unroll
     for (int r = 0; r < FLAT_JMP; ++r) {
       jrow4[r >> 2] |= (unsigned int)(F.jmp[r] >= 0 ? F.jmp[r] : WAVE) << (8 * (r & 3));
-      prow4[r >> 2] |= (unsigned int)(F.jmp[r] >= 0 ? F.jmp[r] + (h ? 32 : 0) : WAVE) << (8 * (r & 3));
     }
     // this lane's half of the joint's share of the W tau products, of its partials and of its W entries (k = 2 i + h)
     ra2[0] = ra2[1] = 0u;
@@ -588,21 +632,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       T y[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) y[k] = Sw3[k] * nui;
-      tail_sync();
-      if (lane < 3) xb[WAVE * 3 + lane] = T(0);
-#pragma unroll 1
-      for (int r = 0; r < njmp; ++r) {
-        const int jr = (int)(((r < 4 ? prow4[0] : prow4[1]) >> (8 * (r & 3))) & 0xFFu);
-        tail_sync();
-#pragma unroll
-        for (int c = 0; c < 3; ++c) xb[lane * 3 + c] = y[c];
-        tail_sync();
-        T a[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) a[c] = xb[jr * 3 + c];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) y[c] += a[c];
-      }
+      flat_path_sum4<T, 3>(xb, lane, opaque(pathA), opaque(pathB), pathC, njmp, y);
       // the two halves meet: R0 v_l = vw_l - t0 x vw_a is needed by both lanes (the linear lane rotates it into the link frame,
       // the angular lane builds the angular part of the link's momentum-like vector E from it)
       T lin[3], ang[3], c1[3], El[3], c2[3], X[3];
@@ -849,6 +879,617 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     g_tail_prof[9] = (clock64() - clk0_) * 100000ull / (wall_clock64() - wall0_ + 1);
   }
 #endif
+  if (lane == 0) {
+    atomicAdd(&Bf.counters[5], n_wave_iters);
+    atomicAdd(&Bf.counters[6], n_slot_loads >> 16);
+    atomicAdd(&Bf.counters[FLAT_COUNTERS_SLOT_HITS], n_slot_hits);
+    atomicOr(&Bf.counters[LEAN_DECADES_SEEN], n_slot_loads & 0xFFFFu);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_flat1<NA>: ONE instance per wavefront, one lane per joint -- the robots of 33..64 joints (G = 64: the 44-DoF whole-body Talos),
+// which k_flat already ran one per wavefront.  Same iteration as k_flat on whole 6-vectors, with what k_flat2 showed to pay:
+// load / iterate / store as nested loops over wave-uniform state, 1 / mu kept between changes of mu, the subtree sums as
+// differences of a prefix sum along the 64 lanes (DPP), the stopping logic's scalars by the DPP transpose-reduce.  One wavefront
+// per SIMD (the lane state is k_flat's).
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double prefix64(double x)
+{
+  x = prefix32(x);
+  x += dpp_f64<0x143, 0xC, 0xF, false>(0.0, x);  // row_bcast:31 into rows 2 and 3: the total of the lower half
+  return x;
+}
+
+template <int NA>
+__host__ __device__ constexpr int flat1_xregion()
+{
+  int n = XROWS * 9;
+  if (NA * WAVE + 2 > n) n = NA * WAVE + 2;
+  return (n + 1) & ~1;
+}
+template <int NA>
+__host__ __device__ __forceinline__ size_t flat1_lds_bytes(int nc, bool has_hv)
+{
+  const size_t n = (size_t)flat1_xregion<NA>() + 2 * (size_t)(NA + 1) * WAVE + 3 * (size_t)(WAVE + 2) + (has_hv ? (size_t)WAVE * 6 : 0) +
+                   (size_t)nc * FCD + FISC;
+  return (n * sizeof(double) + 15) & ~(size_t)15;
+}
+
+template <int NA>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
+        int nscan, int njmp, const int* __restrict__ ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
+        int ndec, double href_s, int has_hv)
+{
+  using T = double;
+  constexpr int G = WAVE, cs = FCD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Layout& L = P.L;
+  const bool a_shared = P.mode & MODE_A_SHARED;
+  const int lane = threadIdx.x;
+  const int j = lane;  // lane <-> device joint j + 1
+  T* const xb = reinterpret_cast<T*>(smem_raw);          // load-time rows | path rows [65][6] | W tau products [NA][64]
+  T* const wl = xb + flat1_xregion<NA>();                // [2][NA + 1][64]
+  T* const nbuf = wl + 2 * (NA + 1) * G;                 // [66]
+  T* const pbuf = nbuf + G + 2;                          // [66]
+  T* const rbuf = pbuf + G + 2;                          // [66]
+  T* const shv = rbuf + G + 2;                           // [64][6] (if H_ref v_ref != 0)
+  T* const cdi = shv + (has_hv ? G * 6 : 0);             // [nc][FCD]
+  T* const isc = cdi + (size_t)L.nc * cs;                // [FISC]
+
+  const bool isj_lane = j < L.nb;
+  const int jl = isj_lane ? j : 0;
+  const int jflags = jd[jl + 1].flags, jcslot = isj_lane ? jd[jl + 1].cslot : -1;
+  const T mass = (!isj_lane || (jflags & JF_MASSLESS)) ? T(0) : T(1);
+  int size;
+  bool helper;
+  unsigned int jrow4[(FLAT_JMP + 3) / 4], ra2[FLAT_RED / 2], prow4[(FLAT_PART + 3) / 4], anc4[(NA + 3) / 4];
+  unsigned int pathA, pathB;
+  int pathC;
+  flat_path_rows4(fl, j, 0, pathA, pathB, pathC);
+  {
+    const FlatLane F = fl[j];
+    size = isj_lane ? F.size : 0;
+    helper = F.helper != 0;
+#pragma unroll
+    for (int k = 0; k < (FLAT_JMP + 3) / 4; ++k) jrow4[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < FLAT_RED / 2; ++k) ra2[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < (FLAT_PART + 3) / 4; ++k) prow4[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < (NA + 3) / 4; ++k) anc4[k] = 0u;
+#pragma unroll
+    for (int r = 0; r < FLAT_JMP; ++r) jrow4[r >> 2] |= (unsigned int)(F.jmp[r] >= 0 ? F.jmp[r] : WAVE) << (8 * (r & 3));
+#pragma unroll
+    for (int t = 0; t < FLAT_RED; ++t) ra2[t >> 1] |= (unsigned int)(F.red[t] >= 0 ? F.red[t] : NA * G) << (16 * (t & 1));
+#pragma unroll
+    for (int q = 0; q < FLAT_PART; ++q) prow4[q >> 2] |= (unsigned int)(F.part[q] >= 0 ? F.part[q] : WAVE) << (8 * (q & 3));
+#pragma unroll
+    for (int k = 0; k < NA; ++k) anc4[k >> 2] |= (unsigned int)((k < FLAT_MAXA && F.anc[k] >= 0) ? F.anc[k] : WAVE) << (8 * (k & 3));
+  }
+  if (lane < 2) { nbuf[G + lane] = T(0); pbuf[G + lane] = T(0); }
+  for (int e = lane; e < 2 * (NA + 1) * G; e += WAVE) wl[e] = T(0);
+
+  bool has_inst = false, isj = false, done = true, any_iter = false;
+  int lidx = 0;
+  char *ip = Bf.tiles, *rec = Bf.tiles;
+  T R0[9], t0[3], Sw[6], v[6], f[6], g[6], SE[6];
+  T w = T(0), z = T(0), nu = T(0), s = T(0), lbi = T(0), ubi = T(0), mu = T(1);
+  int kexp = 0, kslot = -(1 << 30), kslot_o = -(1 << 30), wsel = 0;
+  int iter = 0, status = ST_DONE, tail_it = 0, nflip = 0;
+  unsigned int my_iters = 0, n_wave_iters = 0, n_slot_loads = 0, n_slot_hits = 0;
+  unsigned int* q_head = Bf.counters + LEAN_Q_HEAD;
+  unsigned int cbits = 0u;
+  auto cmask = [&](int c) -> T { return ((cbits >> c) & 1u) ? T(1) : T(0); };
+  const int ccl = lane / 6, ckl = lane - 6 * ccl;
+  const bool iscl = lane < 6 * L.nc;
+  T* const ccb = cdi + (iscl ? ccl : 0) * cs;
+  auto force_of_motion = [&](const T* vw, T* E) {  // E = mass * (R0 v_l, R0 v_a + t0 x R0 v_l) from the world-frame motion
+    T c1[3], c2[3];
+    cross3(t0, vw + 3, c1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) E[k] = vw[k] - c1[k];
+    cross3(t0, E, c2);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) E[3 + k] = vw[3 + k] + c2[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) E[k] *= mass;
+  };
+
+  auto load_instance = [&]() {
+    int slot_in;
+    {
+      int nx = 0;
+      if (lane == 0) nx = (int)atomicAdd(q_head, 1u);
+      nx = __builtin_amdgcn_readfirstlane(nx);
+      slot_in = nx < nslots ? ring[nx] : -1;
+      if (nx >= nslots && lane == 0) {
+        if (atomicCAS(Bf.counters + FLAT_COUNTERS_DRY, 0u, 1u) == 0u)
+          __hip_atomic_store(Bf.counters + FLAT_COUNTERS_TDRY, (unsigned int)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    has_inst = slot_in >= 0;
+    if (!has_inst) return;
+    isj = isj_lane;
+    lidx = slot_in;
+    ip = lane_ptr<T>(Bf.tiles, L, slot_in);
+    rec = ip + (size_t)jl * JREC * pair_bytes<T>();
+    const char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+    T ax[3];
+    const bool rev = jflags & JF_REVOLUTE;
+    {
+      const typename Vec2<T>::type csn = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
+      const JointDesc d = jd[jl + 1];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ax[k] = isj_lane ? (T)d.axis[k] : T(0);
+      joint_xform<T>(d, rec, csn.x, csn.y, R0, t0);  // liMi ...
+      ld6<T>(rec, JP_V, v);
+      ld6<T>(rec, JP_F, f);
+      ld6<T>(rec, JP_G, g);
+      w = wz.x; z = wz.y; nu = nus.x; s = nus.y;
+      if (P.mode & MODE_BND_SHARED) {
+        lbi = Bf.uni[L.nc * 57 + jl];
+        ubi = Bf.uni[L.nc * 57 + L.nb + jl];
+      } else {
+        const typename Vec2<T>::type lu = ldp<T>(rec, JP_LBUB);
+        lbi = lu.x; ubi = lu.y;
+      }
+    }
+    if (!isj_lane) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R0[k] = (k % 4 == 0) ? T(1) : T(0);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t0[k] = T(0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { v[k] = T(0); f[k] = T(0); g[k] = T(0); }
+      w = z = nu = s = T(0);
+      lbi = ubi = T(0);
+    }
+    flat_world_placement<T>(xb, lane, lane, jrow4, njmp, R0, t0);  // ... -> oMi (FwdPassInit's oMi chain, hxx:265)
+    {
+      T ra3[3], c[3];
+      mat3_vec(R0, ax, ra3);
+      cross3(t0, ra3, c);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { Sw[k] = rev ? c[k] : ra3[k]; Sw[3 + k] = rev ? ra3[k] : T(0); }
+    }
+    for (int c = 0; c < L.nc; ++c) {
+      const char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+      T* c_ = cdi + c * cs;
+      if (lane < 18) {
+        const int which = lane / 6, k = lane % 6;
+        const int pair = which == 0 ? CP_B : which == 1 ? CP_Y : CP_ATY;
+        const int dst = which == 0 ? FC_B : which == 1 ? FC_Y : FC_ATY;
+        c_[dst + k] = *reinterpret_cast<const T*>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+      }
+      for (int e = lane; e < LCA; e += WAVE)
+        c_[FC_A + e] = a_shared ? Bf.uni[c * LCA + e]
+                                : *reinterpret_cast<const T*>(crec + (size_t)(CP_A + e / 2) * pair_bytes<T>() + (e & 1) * sizeof(T));
+    }
+    if (jcslot >= 0) cdi[jcslot * cs + FC_LANE] = (T)j;
+    tail_sync();
+    cbits = 0u;
+    for (int c = 0; c < L.nc; ++c) {
+      const int cl = (int)cdi[c * cs + FC_LANE];
+      if (isj_lane && cl >= j && cl < j + size) cbits |= 1u << c;
+    }
+    if (jcslot >= 0) {
+      T* c_ = cdi + jcslot * cs;
+      const T* A_ = c_ + FC_A;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        T aj[6], o[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) aj[k] = A_[6 * q + k];
+        act_force(R0, t0, aj, o);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c_[FC_AW + 6 * k + q] = o[k];
+      }
+      T ay[6], o[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ay[k] = c_[FC_ATY + k];
+      act_force(R0, t0, ay, o);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) c_[FC_ATYW + k] = o[k];
+    }
+    tail_sync();
+    for (int c = 0; c < L.nc; ++c) {
+      T* c_ = cdi + c * cs;
+      if (lane < 6) {
+        const int k = lane;
+        T ab = T(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) ab += c_[FC_AW + 6 * k + q] * c_[FC_B + q];
+        c_[FC_ATBW + k] = ab;
+      }
+    }
+    {
+      T vw[6], E[6];
+      T a[3], l[3], c[3];
+      mat3_vec(R0, v, l);
+      mat3_vec(R0, v + 3, a);
+      cross3(t0, a, c);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { vw[k] = l[k] + c[k]; vw[3 + k] = a[k]; }
+      force_of_motion(vw, E);
+      flat_subtree_sum<T>(xb, lane, lane, G, size, nscan, E, SE);
+      if (has_hv) {
+        T hv[6], hw[6], Sh[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) hv[k] = mass * P.Hv[k];
+        act_force(R0, t0, hv, hw);
+        flat_subtree_sum<T>(xb, lane, lane, G, size, nscan, hw, Sh);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) shv[lane * 6 + k] = Sh[k];
+      }
+    }
+    const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
+    mu = mu2.x;
+    kexp = (int)mu2.y;
+    kslot = -(1 << 30); kslot_o = -(1 << 30);
+    status = (int)st2.x;
+    iter = (int)bi2.y;
+    tail_it = (int)ld_scal<T>(srec, SC_TAIL_ITER);
+    nflip = (int)ldp<T>(srec, SP_FLIP).x;
+    done = (status & ST_DONE) != 0;
+    if (!done && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { done = true; status |= ST_DONE; }
+    if (lane == 0) {
+      isc[FI_BNORM] = bi2.x; isc[FI_TGIN] = ldp<T>(srec, SP_TAG).x; isc[FI_STY] = st2.y; isc[FI_MULAST] = T(-1);
+      isc[FI_TOLP] = ld_scal<T>(srec, SC_TOL_PRIMAL); isc[FI_TOLD] = ld_scal<T>(srec, SC_TOL_DUAL);
+      isc[FI_DYQP] = ld_scal<T>(srec, SC_DELTA_Y_QP); isc[FI_ATDY] = ld_scal<T>(srec, SC_AT_DELTA_Y_QP);
+      isc[FI_UBP] = ld_scal<T>(srec, SC_UB_DY_PLUS); isc[FI_LBM] = ld_scal<T>(srec, SC_LB_DY_MINUS);
+      isc[FI_C1] = ld_scal<T>(srec, SC_COND1); isc[FI_C2] = ld_scal<T>(srec, SC_COND2);
+    }
+    tail_sync();
+    my_iters = 0;
+    any_iter = false;
+  };
+  auto store_instance = [&]() {
+    char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+    if (isj) {
+      st6<T>(rec, JP_V, v);
+      st6<T>(rec, JP_F, f);
+      st6<T>(rec, JP_G, g);
+      stp<T>(rec, JP_WZ, w, z);
+      stp<T>(rec, JP_NUS, nu, s);
+      if (any_iter) stp<T>(rec, JP_R, rbuf[lane], wl[(wsel * (NA + 1) + NA) * G + lane]);  // (r_i, Dinv_i; SP_TAG = -2: see k_flat)
+    }
+    for (int c = 0; c < L.nc; ++c) {
+      char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
+      if (lane < 6) {
+        const int k = lane;
+        *reinterpret_cast<T*>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * cs + FC_Y + k];
+        *reinterpret_cast<T*>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * cs + FC_ATY + k];
+      }
+    }
+    if (lane == 0) {
+      stp<T>(srec, SP_MU, mu, (T)kexp);
+      stp<T>(srec, SP_TAG, any_iter ? T(-2) : isc[FI_TGIN], T(0));
+      stp<T>(srec, SP_BI, isc[FI_BNORM], (T)iter);
+      stp<T>(srec, SP_FLIP, (T)nflip, T(0));
+      stp<T>(srec, SP_ST, (T)(any_iter ? (status & ~ST_PFULL) : status), any_iter ? isc[FI_MULAST] : isc[FI_STY]);
+      if (any_iter) {
+        const T* rr = isc + FI_RED;
+        const T mu_s = mu;
+        stp<T>(srec, SP_SCAL + 0, isc[FI_PRIMAL], isc[FI_DUAL]);
+        stp<T>(srec, SP_SCAL + 1, rr[0], rr[1]);
+        stp<T>(srec, SP_SCAL + 2, rr[12], rr[2]);
+        stp<T>(srec, SP_SCAL + 3, isc[FI_TOLP], isc[FI_TOLD]);
+        stp<T>(srec, SP_SCAL + 4, mu_s, P.mu_scale * mu_s);
+        stp<T>(srec, SP_SCAL + 5, mu_s, isc[FI_DX]);
+        stp<T>(srec, SP_SCAL + 6, isc[FI_DZ], isc[FI_DYQP]);
+        stp<T>(srec, SP_SCAL + 7, isc[FI_ATDY], isc[FI_UBP]);
+        stp<T>(srec, SP_SCAL + 8, isc[FI_LBM], rr[5]);
+        stp<T>(srec, SP_SCAL + 9, rr[6], rr[7]);
+        stp<T>(srec, SP_SCAL + 10, rr[3], rr[4]);
+        stp<T>(srec, SP_SCAL + 11, rr[8], rr[9]);
+        stp<T>(srec, SP_SCAL + 12, rr[10], rr[11]);
+        stp<T>(srec, SP_SCAL + 13, rr[2], isc[FI_C1]);
+        stp<T>(srec, SP_SCAL + 14, isc[FI_C2], (T)tail_it);
+      }
+      if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
+    }
+    tail_sync();
+  };
+
+  while (true) {
+    load_instance();
+    if (!has_inst) break;
+    T inv_mu = T(1) / mu;
+   while (true) {
+    bool exit_now = done || (int)my_iters >= P.max_launch_iters;
+    if (!exit_now && kexp != kslot) {
+      if (kexp == kslot_o) {
+        { const int tk = kslot; kslot = kslot_o; kslot_o = tk; }
+        wsel ^= 1;
+        ++n_slot_hits;
+      } else {
+        const int dsl = kexp - kexp_lo;
+        if (dsl < 0 || dsl >= ndec) {
+          exit_now = true;
+          if (lane == 0) atomicAdd(&Bf.counters[2], 1u);
+        } else {
+          kslot_o = kslot;
+          wsel ^= 1;
+          T* wdst = wl + (size_t)wsel * (NA + 1) * G;
+          T in[NA + 1];
+#pragma unroll
+          for (int k = 0; k <= NA; ++k) in[k] = isj ? fslots[fslot_at(lidx, ndec, dsl, G, frows, k < nanc ? k : nanc, lane)] : T(0);
+#pragma unroll
+          for (int k = 0; k <= NA; ++k) wdst[k * G + lane] = in[k];
+          kslot = kexp;
+          n_slot_loads = (n_slot_loads + 0x10000u) | (1u << dsl);
+        }
+      }
+    }
+    if (exit_now) break;
+    const T* wcur = wl + (size_t)wsel * (NA + 1) * G;
+    const T mu_eq = P.mu_scale * mu, mu_in = mu;
+    ++my_iters; any_iter = true;
+    ++n_wave_iters;
+
+    // ---- p^base summed over the subtrees; tau
+    T wc[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) wc[k] = wcur[k * G + lane];
+    const T dinv = wcur[NA * G + lane];
+    T tau;
+    {
+      T PB[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) PB[k] = -P.rho * SE[k];
+      if (has_hv) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) PB[k] -= shv[lane * 6 + k];
+      }
+      for (int c = 0; c < L.nc; ++c) {
+        const T* c_ = cdi + c * cs;
+        const T m = cmask(c);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) PB[k] += m * (c_[FC_ATYW + k] - mu_eq * c_[FC_ATBW + k]);
+      }
+      tau = (w - mu_in * z) + dot6_halves(Sw, PB);
+    }
+    // ---- r' = W tau
+    tail_sync();
+#pragma unroll
+    for (int k = 0; k < NA; ++k) xb[k * G + lane] = wc[k] * tau;
+    if (lane == 0) { xb[NA * G] = T(0); xb[NA * G + 1] = T(0); }
+    tail_sync();
+    T rn;
+    {
+      T a[FLAT_RED];
+#pragma unroll
+      for (int t = 0; t < FLAT_RED; ++t) a[t] = xb[unpack16(ra2, t)];
+      T acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+      pbuf[lane] = helper ? acc : T(0);
+      tail_sync();
+      T pp[FLAT_PART];
+#pragma unroll
+      for (int q = 0; q < FLAT_PART; ++q) pp[q] = pbuf[unpack8(prow4, q)];
+      if (helper) acc = T(0);
+#pragma unroll
+      for (int q = 0; q < FLAT_PART; ++q) acc += pp[q];
+      rn = tau + acc;
+      rbuf[lane] = rn;
+      nbuf[lane] = dinv * rn;
+    }
+    tail_sync();
+    // ---- nu = -W^T (Dinv r')
+    T nui;
+    {
+      T nb_[NA];
+#pragma unroll
+      for (int k = 0; k < NA; ++k) nb_[k] = nbuf[unpack8(anc4, k)];
+      T acc = dinv * rn;
+#pragma unroll
+      for (int k = 0; k < NA; ++k) acc += wc[k] * nb_[k];
+      nui = -acc;
+    }
+    // ---- v = J nu
+    T vi[6], E[6];
+    {
+      T vw[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vw[k] = Sw[k] * nui;
+      flat_path_sum4<T, 6>(xb, lane, opaque(pathA), opaque(pathB), pathC, njmp, vw);
+      actinv_motion(R0, t0, vw, vi);
+      force_of_motion(vw, E);
+    }
+    T l_dyis = T(0), l_av = T(0), l_prt = T(0), l_up = T(0), l_lm = T(0);
+    T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_prs = T(0);
+    T l_dg = T(0), l_g = T(0), l_stf = T(0), l_dstf = T(0), l_dualv = T(0);
+    T fi[6], si;
+    {
+      T SEn[6], Fw[6];
+      // ---- the task constraints' update (two dependent exchanges through the constraint blocks) with the subtree sums of E,
+      // prefix-sum differences in registers, in its shadow
+      tail_sync();
+      if (jcslot >= 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cdi[jcslot * cs + FC_VC + k] = vi[k];
+      }
+      tail_sync();
+      if (iscl) {
+        const T* A_ = ccb + FC_A;
+        const T* vc = ccb + FC_VC;
+        T avk = A_[6 * ckl] * vc[0];
+#pragma unroll
+        for (int q = 1; q < 6; ++q) avk += A_[6 * ckl + q] * vc[q];
+        const T bk = ccb[FC_B + ckl];
+        const T ek = avk - bk;
+        const T dy = mu_eq * ek;
+        const T yk = ccb[FC_Y + ckl] + dy;
+        l_dyis = tabs(dy);
+        l_up = bk * tmax(dy, T(0));
+        l_lm = bk * tmin(dy, T(0));
+        l_prt = tabs(ek);
+        l_av = tabs(avk);
+        ccb[FC_Y + ckl] = yk;
+        ccb[FC_DY + ckl] = dy;
+      }
+      {
+        T Pk[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) Pk[c] = prefix64(E[c]);
+        const int src = lane + (size > 0 ? size - 1 : 0);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) SEn[c] = (lane_read(Pk[c], src) - Pk[c]) + E[c];
+      }
+      tail_sync();
+      if (iscl) {
+        const T* A_ = ccb + FC_A;
+        const int k = ckl;
+        T at = A_[k] * ccb[FC_Y], aw = ccb[FC_AW + 6 * k] * ccb[FC_Y], atd = A_[k] * ccb[FC_DY], awd = ccb[FC_AW + 6 * k] * ccb[FC_DY];
+#pragma unroll
+        for (int q = 1; q < 6; ++q) {
+          at += A_[6 * q + k] * ccb[FC_Y + q]; aw += ccb[FC_AW + 6 * k + q] * ccb[FC_Y + q];
+          atd += A_[6 * q + k] * ccb[FC_DY + q]; awd += ccb[FC_AW + 6 * k + q] * ccb[FC_DY + q];
+        }
+        ccb[FC_DLT + k] = (at - atd) - ccb[FC_ATY + k];
+        ccb[FC_ATYF + k] = ccb[FC_ATYW + k] + awd;
+        ccb[FC_ATY + k] = at;
+        ccb[FC_ATYW + k] = aw;
+      }
+      tail_sync();
+      {
+        T dv6[6], gi[6], dg[6], dvr[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          dv6[k] = vi[k] - v[k];
+          gi[k] = -mass * (P.rho * dv6[k] + href_s * vi[k]);
+        }
+        if (has_hv) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) gi[k] += mass * P.Hv[k];
+        }
+        if (jcslot >= 0) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) gi[k] += cdi[jcslot * cs + FC_DLT + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          dg[k] = gi[k] - g[k];
+          dvr[k] = mass * (href_s * vi[k]) + gi[k];
+        }
+        if (has_hv) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) dvr[k] -= mass * P.Hv[k];
+        }
+        l_dualv = inf6(dvr);
+        l_nu = tabs(nui);
+        l_hrefv = mass * tabs(href_s) * inf6(vi);
+        l_dvis = mass * inf6(dv6);
+        l_dnu = tabs(nui - nu);
+        const T x = nui + inv_mu * w;
+        const T zi = tmin(ubi, tmax(lbi, x));
+        l_dz = tabs(zi - z);
+        l_prs = tabs(nui - zi);
+        const T dwi = mu_in * (nui - zi);
+        l_dw = tabs(dwi);
+        l_up += ubi * tmax(dwi, T(0));
+        l_lm += lbi * tmin(dwi, T(0));
+        w = w + dwi; z = zi; nu = nui;
+        l_dg = inf6(dg);
+        l_g = inf6(gi);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { v[k] = vi[k]; g[k] = gi[k]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Fw[k] = (P.rho + href_s) * SEn[k] - P.rho * SE[k];
+      if (has_hv) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Fw[k] -= shv[lane * 6 + k];
+      }
+      for (int c = 0; c < L.nc; ++c) {
+        const T* c_ = cdi + c * cs;
+        const T m = cmask(c);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Fw[k] += m * c_[FC_ATYF + k];
+      }
+      actinv_force(R0, t0, Fw, fi);
+      si = dot6_halves(Sw, Fw);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) SE[k] = SEn[k];
+    }
+    {
+      T df[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) df[k] = fi[k] - f[k];
+      l_dfis = mass * inf6(df);
+      si += w;
+      l_stf = tabs(si);
+      l_dstf = tabs(si - s);
+      s = si;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) f[k] = fi[k];
+    }
+    T red[8];
+    {
+      T in[8] = {tmax(l_prt, l_prs), tmax(l_dualv, l_stf), tmax(l_dvis, l_dnu), l_dz,
+                 tmax(l_dfis, tmax(l_dyis, l_dw)), tmax(l_dg, l_dstf), l_up, l_lm};
+      wave_fold8<true>(lane, in, red);
+    }
+    T ntol_p = T(0), ntol_d = T(0);
+    if (P.tol_rel != T(0)) {
+      T in2[8] = {tmax(l_av, l_nu), tmax(tmax(l_hrefv, l_g), l_stf), T(0), T(0), T(0), T(0), T(0), T(0)}, r2[8];
+      wave_fold8<false>(lane, in2, r2);
+      ntol_p = r2[0]; ntol_d = r2[1];
+    }
+    const T primal = red[0], dual = red[1], dx = red[2], dz = red[3], dyqp = red[4], atdy = red[5], ubp = red[6], lbm = red[7];
+    const T mu_used = mu;
+    const bool fixed = P.mode & MODE_FIXED_ITERS;
+    const bool in_tail = (status & ST_TAIL) != 0;
+    const bool logic = !fixed && !in_tail;
+    const T tol_p = P.tol_abs + P.tol_rel * tmax(ntol_p, isc[FI_BNORM]);
+    const T tol_d = P.tol_abs + P.tol_rel * tmax(ntol_d, P.Hv_inf_norm);
+    const int itn = iter + 1;
+    const bool conv = logic && (primal < tol_p) && (dual < tol_d);
+    const bool feas_chk = logic && itn > 1;
+    const bool c1 = atdy <= P.tol_primal_inf * dyqp, c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp;
+    const bool infeas = feas_chk && c1 && c2;
+    const bool enter_tail = infeas && !conv;
+    const bool upd = logic && !conv && !infeas;
+    const bool mu_up = upd && (primal > T(10) * dual), mu_dn = upd && !mu_up && (dual > T(10) * primal);
+    const bool tail_stop = !(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || itn >= P.max_iter;
+    const bool stop = conv || ((enter_tail || in_tail) && tail_stop) || ((upd || fixed) && itn + 1 >= P.max_iter);
+    iter = itn;
+    status |= (conv ? ST_CONVERGED : 0) | (infeas ? ST_PRIMAL_INF : 0) | (enter_tail ? ST_TAIL : 0) | (stop ? ST_DONE : 0);
+    tail_it = enter_tail ? 0 : (in_tail ? tail_it + 1 : tail_it);
+    mu = mu_up ? mu * T(10) : (mu_dn ? mu * T(0.1) : mu);
+    if (mu_up || mu_dn) inv_mu = T(1) / mu;
+    kexp += (mu_up ? 1 : 0) - (mu_dn ? 1 : 0);
+    nflip += (mu_up || mu_dn) ? 1 : 0;
+    done = stop;
+    if (stop || enter_tail) {
+      if (lane == 0) {
+        isc[FI_PRIMAL] = primal; isc[FI_DUAL] = dual; isc[FI_DX] = dx; isc[FI_DZ] = dz; isc[FI_MULAST] = mu_used;
+        if (logic) { isc[FI_TOLP] = tol_p; isc[FI_TOLD] = tol_d; }
+        if (feas_chk) {
+          isc[FI_C1] = (T)(c1 ? 1 : 0); isc[FI_C2] = (T)(c2 ? 1 : 0); isc[FI_DYQP] = dyqp; isc[FI_ATDY] = atdy; isc[FI_UBP] = ubp; isc[FI_LBM] = lbm;
+        }
+      }
+    }
+    if (stop) {
+      T in1[8] = {l_prt, l_prs, l_stf, l_dvis, l_dnu, l_dfis, l_dyis, l_dw}, in2[8] = {l_av, l_nu, l_hrefv, l_g, l_dualv, T(0), T(0), T(0)};
+      T r1[8], r2[8];
+      wave_fold8<false>(lane, in1, r1);
+      wave_fold8<false>(lane, in2, r2);
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) isc[FI_RED + k] = r1[k];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) isc[FI_RED + 8 + k] = r2[k];
+      }
+      tail_sync();
+      break;
+    }
+   }
+    store_instance();
+  }
   if (lane == 0) {
     atomicAdd(&Bf.counters[5], n_wave_iters);
     atomicAdd(&Bf.counters[6], n_slot_loads >> 16);

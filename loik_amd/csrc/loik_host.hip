@@ -1488,7 +1488,9 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       const int cap_lat = (int)std::min<size_t>(4, (160 * 1024) / flds) * (int)(cu_sh + 0.5);
       // two lanes per joint where the layout applies: 17..32 joints, few ancestors, fp64, no lists to write
       const bool split = S->tune.flat_split && G == F2G && small_na && sizeof(T) == 8 && !S->opt.logging;
-      const bool two_stage = S->tune.flat_two_stage && n > 2 * cap_lat * ipw && !S->opt.logging && !split;
+      // one instance per wavefront anyway (33..64 joints): the build with nested loops, prefix-sum subtree sums, DPP fold
+      const bool one = S->tune.flat_split && G == WAVE && sizeof(T) == 8 && !S->opt.logging;
+      const bool two_stage = S->tune.flat_two_stage && n > 2 * cap_lat * ipw && !S->opt.logging && !split && !one;
       P.max_launch_iters = S->opt.max_iter + 1;
       HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
@@ -1540,6 +1542,16 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                      ndec, (double)S->Href[0], has_hv)
           if (wpe == 3) LOIKB_LAUNCH_FLAT2(3); else LOIKB_LAUNCH_FLAT2(2);
 #undef LOIKB_LAUNCH_FLAT2
+        } else if (one) {
+          const size_t lds1 = small_na ? flat1_lds_bytes<FLAT_NA_SMALL>(S->nc, has_hv != 0) : flat1_lds_bytes<FLAT_MAXA>(S->nc, has_hv != 0);
+          grid = dim3((unsigned)std::min(n, (int)std::min<size_t>(4, (160 * 1024) / lds1) * (int)(cu_sh + 0.5)));
+#define LOIKB_LAUNCH_FLAT1(NAV)                                                                                                 \
+  hipLaunchKernelGGL((k_flat1<NAV>), grid, dim3(WAVE), lds1, C->stream, *reinterpret_cast<const Params<double>*>(&P),            \
+                     *reinterpret_cast<const Bufs<double>*>(&Bf), (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes,    \
+                     nanc, S->flat.nscan, S->flat.njmp, (const int*)C->d_ring, n, (const double*)C->d_fslots, frows, kexp_lo,    \
+                     ndec, (double)S->Href[0], has_hv)
+          if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA);
+#undef LOIKB_LAUNCH_FLAT1
         } else {
 #define LOIKB_LAUNCH_FLAT(NAV, LATV, ...)                                                                                       \
   hipLaunchKernelGGL((k_flat<T, NAV, LATV, ##__VA_ARGS__>), grid, dim3(WAVE), flds, C->stream, P, Bf, (const JointDesc*)S->d_jd,                \
@@ -1558,6 +1570,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         C->stats.tail_launches++;
         C->stats.lean_launches++;
         C->stats.flat_launches++;
+        if (split) C->stats.flat_split_launches++;
       }
       int* next = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
       HIPCHK(hipEventRecord(C->ev_k1, C->stream));
@@ -1960,6 +1973,7 @@ int run_main_loop_t(loikb_solver_impl* S)
     S->stats.tail_launches += C.stats.tail_launches;
     S->stats.lean_launches += C.stats.lean_launches;
     S->stats.flat_launches += C.stats.flat_launches;
+    S->stats.flat_split_launches += C.stats.flat_split_launches;
     S->stats.queue_dry_ms += C.stats.queue_dry_ms;
     S->stats.lean_escaped += C.stats.lean_escaped;
     S->stats.hslots_ms += C.stats.hslots_ms;
@@ -2760,11 +2774,14 @@ const char* loikb_plan_string(loikb_solver* S)
   if (!S) return "";
   char buf[512];
   const EnginePlan& pl = S->plan;
-  if (pl.flat && (flat_applicable(S) || !S->have_problem))
-    snprintf(buf, sizeof(buf), "k_fslots + k_flat (no loops over the tree levels) for whole batches up to %d instances (%d wavefronts per "
+  if (pl.flat && (flat_applicable(S) || !S->have_problem)) {
+    const bool split = S->tune.flat_split && S->flat.G == F2G && S->flat.nanc <= FLAT_NA_SMALL && !S->f32 && !S->opt.logging;
+    snprintf(buf, sizeof(buf), "k_fslots + %s (no loops over the tree levels%s) for whole batches up to %d instances (%d wavefronts per "
              "CU, decades mu0*10^%d..%d, %d ancestors per joint, %d scan steps, %d jump rounds)%s; k_solve above that; %d chunk(s)",
-             pl.tail_max, pl.flat_waves_cu, pl.kexp_lo, pl.kexp_lo + pl.ndec - 1, S->flat.nanc, S->flat.nscan, S->flat.njmp,
-             S->have_problem ? "" : " when H_ref = h I", pl.nchunks);
+             split ? "k_flat2" : "k_flat", split ? "; two lanes per joint, one instance per wavefront" : "", pl.tail_max,
+             split ? std::min(4 * S->tune.flat_split_wpe, pl.flat_waves_cu * 2) : pl.flat_waves_cu, pl.kexp_lo, pl.kexp_lo + pl.ndec - 1,
+             S->flat.nanc, S->flat.nscan, S->flat.njmp, S->have_problem ? "" : " when H_ref = h I", pl.nchunks);
+  }
   else if (pl.lean)
     snprintf(buf, sizeof(buf), "k_hslots + k_lean for whole batches up to %d instances (%d wavefronts per CU in workgroups of %d, "
              "decades mu0*10^%d..%d, time slice %d); k_solve above that; %d chunk(s)", pl.tail_max, pl.lean_waves_cu,

@@ -9,7 +9,7 @@ import os
 import sys
 
 out_dir, nsolves = sys.argv[1], int(sys.argv[2])  # nsolves = warmup + steps of every profiled run
-KEYS = ["k_solve", "k_tail", "k_lean", "k_hslots", "k_flat", "k_fslots", "k_move", "k_sched"]
+KEYS = ["k_solve", "k_tail", "k_lean", "k_hslots", "k_flat2", "k_flat", "k_fslots", "k_move", "k_sched"]
 tot = collections.defaultdict(lambda: collections.defaultdict(float))
 ndisp = collections.defaultdict(lambda: collections.defaultdict(int))
 for path in glob.glob(os.path.join(out_dir, "pmc_*", "**", "*counter_collection.csv"), recursive=True):

@@ -854,10 +854,14 @@ def test_whole_body_talos44_full_size_against_the_oracle():
     idx = np.unique(np.concatenate([np.arange(0, B, 211), hard[:400]]))
     out = ref.solve_batch(m, wl["q"][idx], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"][idx], wl["lb"], wl["ub"],
                           nthreads=16, **prm)
-    # (z to 1e-8: the instances that run 999 iterations with four tasks' duals integrating mu_eq * rounding reach 1.6e-9)
-    same = assert_end_to_end(fetch_end_to_end(s, idx, nu=False, residuals=True), out, prm, same_frac=0.97, ztol=1e-8,
-                             what="whole body 44 DoF, %d instances (%d of them at max_iter)" % (idx.size, min(hard.size, 400)))
+    # (z to 1e-7: the instances that run all 999 iterations WITHOUT converging -- four tasks' duals integrating mu_eq * rounding
+    #  for 999 iterations -- reach 1.8e-8 with the subtree sums taken as differences of a prefix sum along the 44 joints
+    #  (k_flat1; 1.6e-9 with k_flat's window sums); the instances that converge agree to 1e-10)
+    same = assert_end_to_end(fetch_end_to_end(s, idx, nu=False, residuals=True), out, prm, same_frac=0.97, ztol=1e-7,
+                             res_tol=(1e-7, 1e-6), what="whole body 44 DoF, %d instances (%d of them at max_iter)" % (idx.size, min(hard.size, 400)))
     print("whole body: identical iteration counts %d / %d; at max_iter %d of %d" % (same.sum(), idx.size, hard.size, B))
+    cs = same & out["converged"]
+    assert np.abs(z[idx] - out["z"])[cs].max() < 1e-9, np.abs(z[idx] - out["z"])[cs].max()
     s.close()
 
 
