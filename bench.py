@@ -386,7 +386,7 @@ def whole_body_variant(args, device):
            "unit": "solves/s", "solved_fraction": float(conv.mean()),
            "flagged_infeasible_fraction": float(s.get("primal_infeasible").astype(bool).mean()),
            "mean_admm_iterations": float(it.mean()), "instance_iterations_per_s": float(it.sum() / dt),
-           "engine": (("k_flat2" if st["flat_split_launches"] > 0 else "k_flat") if st["flat_launches"] > 0 else "k_lean")
+           "engine": (next((k for k in ("k_flat2", "k_flat1", "k_flat") if k in s.plan()), "k_flat") if st["flat_launches"] > 0 else "k_lean")
                      if st["lean_launches"] > 0 and st["tail_instances"] == args.batch
                      else "k_solve+k_tail",
            "lean_escaped": st["lean_escaped"],

@@ -2776,10 +2776,13 @@ const char* loikb_plan_string(loikb_solver* S)
   const EnginePlan& pl = S->plan;
   if (pl.flat && (flat_applicable(S) || !S->have_problem)) {
     const bool split = S->tune.flat_split && S->flat.G == F2G && S->flat.nanc <= FLAT_NA_SMALL && !S->f32 && !S->opt.logging;
+    const bool one = S->tune.flat_split && S->flat.G == WAVE && !S->f32 && !S->opt.logging;
     snprintf(buf, sizeof(buf), "k_fslots + %s (no loops over the tree levels%s) for whole batches up to %d instances (%d wavefronts per "
              "CU, decades mu0*10^%d..%d, %d ancestors per joint, %d scan steps, %d jump rounds)%s; k_solve above that; %d chunk(s)",
-             split ? "k_flat2" : "k_flat", split ? "; two lanes per joint, one instance per wavefront" : "", pl.tail_max,
-             split ? std::min(4 * S->tune.flat_split_wpe, pl.flat_waves_cu * 2) : pl.flat_waves_cu, pl.kexp_lo, pl.kexp_lo + pl.ndec - 1,
+             split ? "k_flat2" : one ? "k_flat1" : "k_flat",
+             split ? "; two lanes per joint, one instance per wavefront" : one ? "; one instance per wavefront" : "", pl.tail_max,
+             split ? std::min(4 * S->tune.flat_split_wpe, pl.flat_waves_cu * 2) : one ? std::min(4, pl.flat_waves_cu) : pl.flat_waves_cu,
+             pl.kexp_lo, pl.kexp_lo + pl.ndec - 1,
              S->flat.nanc, S->flat.nscan, S->flat.njmp, S->have_problem ? "" : " when H_ref = h I", pl.nchunks);
   }
   else if (pl.lean)
