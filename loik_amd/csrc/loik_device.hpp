@@ -1815,6 +1815,7 @@ enum : int {
   RS_SOLVER = 4,      // ResetSolver: iter = 0, flags = 0, mu = mu0, logged scalars = 0 (optimized.hpp:168-186)
   RS_Y = 8,           // FwdPassInit cold start: yis = 0, Aty = 0 (optimized.hxx:270-278)
   RS_HCACHE = 16,     // invalidate the H/UDinv/Dinv cache
+  RS_MU = 32,         // mu = mu0 only (the MAXEIGENVALUE rule's starting value, known once the solve's references are)
 };
 template <typename T>
 __global__ void __launch_bounds__(WAVE) k_reset(char* tiles, Layout L, int what, T mu0)
@@ -1842,6 +1843,7 @@ __global__ void __launch_bounds__(WAVE) k_reset(char* tiles, Layout L, int what,
     for (int p = SP_SCAL; p < SREC; ++p) stp<T>(srec, p, T(0), T(0));
   }
   if (what & RS_SOLVER) stp<T>(srec, SP_FLIP, T(0), T(0));
+  if (what & RS_MU) stp<T>(srec, SP_MU, mu0, T(0));
   if (what & RS_HCACHE) stp<T>(srec, SP_TAG, T(-1), T(0));
 }
 

@@ -172,6 +172,7 @@ struct loikb_solver_impl {
   // the same per device joint: [nj][HREF_ROW] = (H_ref_i, H_ref_i v_ref_i), rows of the universe and of massless chain
   // links zero.  Broadcast by SolveInit (UpdateReference), per link after loikb_update_references (UpdateReferences).
   std::vector<double> href_tab;
+  double mu_start = 0.0;        // LOIKB_MU_MAXEIGENVALUE: the solve's starting mu (spectral_mu0), else unused
   bool per_link = false;
   void* d_href = nullptr;       // the table in the solve precision
   double* d_href64 = nullptr;   // and in double (== d_href for an fp64 solver): residual-vector getter
@@ -728,6 +729,72 @@ Bufs<T> make_bufs(loikb_solver_impl* S, Chunk* C, int k)
   return Bf;
 }
 
+// ---- LOIKB_MU_MAXEIGENVALUE (extension: declared upstream, task-solver-base.hpp:13-18, and never implemented there --
+// loik-loid-optimized.hxx:635-637 throws).  Defined as a spectral initialisation of the penalty followed by DEFAULT's decade
+// steps: mu starts at the geometric mean of the extreme eigenvalues of the links' cost blocks rho I + sym(H_ref,i) over all links
+// that carry a cost, snapped to a quarter decade (10^(k/4)), clipped to [1e-6, 1e6]; the constructor's mu is not used.  The
+// reference's fixture (H_ref = I, rho = 1e-5) starts at mu = 1 instead of 1e-2.  Every engine runs it: for the kernels it is the
+// DEFAULT rule with another mu0.  (The CPU checker of the tests implements the same definition on its own.)
+static void jacobi6(double* a, double* ev)  // eigenvalues of a symmetric 6x6 (overwritten), cyclic Jacobi
+{
+  for (int sweep = 0; sweep < 50; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 6; ++p)
+      for (int q = p + 1; q < 6; ++q) off += a[6 * p + q] * a[6 * p + q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 6; ++p)
+      for (int q = p + 1; q < 6; ++q) {
+        const double apq = a[6 * p + q];
+        if (apq == 0.0) continue;
+        const double theta = (a[6 * q + q] - a[6 * p + p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 6; ++k) {
+          const double akp = a[6 * k + p], akq = a[6 * k + q];
+          a[6 * k + p] = c * akp - sn * akq;
+          a[6 * k + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < 6; ++k) {
+          const double apk = a[6 * p + k], aqk = a[6 * q + k];
+          a[6 * p + k] = c * apk - sn * aqk;
+          a[6 * q + k] = sn * apk + c * aqk;
+        }
+      }
+  }
+  for (int k = 0; k < 6; ++k) ev[k] = a[7 * k];
+}
+
+static double spectral_mu0(const loikb_solver_impl* S)
+{
+  double lo = 0.0, hi = 0.0;
+  bool any = false;
+  for (int i = 1; i < S->nj; ++i) {
+    if (S->jd[i].flags & JF_MASSLESS) continue;  // (the intermediate links of a multi-DoF joint's chain carry no cost)
+    const double* H = S->href_tab.data() + (size_t)i * HREF_ROW;
+    double m[36], ev[6];
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c) m[6 * r + c] = 0.5 * (H[6 * r + c] + H[6 * c + r]) + (r == c ? S->opt.rho : 0.0);
+    jacobi6(m, ev);
+    for (int k = 0; k < 6; ++k) {
+      if (!any || ev[k] < lo) lo = ev[k];
+      if (!any || ev[k] > hi) hi = ev[k];
+      any = true;
+    }
+  }
+  if (!any) return S->opt.mu;
+  lo = std::max(lo, S->opt.rho);
+  hi = std::max(hi, lo);
+  if (!(lo > 0.0)) return S->opt.mu;
+  const long q = std::lround(4.0 * std::log10(std::sqrt(lo * hi)));
+  return std::min(1e6, std::max(1e-6, std::pow(10.0, (double)q / 4.0)));
+}
+
+// mu a solve starts from (and the decades of the on-chip engines are counted from)
+static double solve_mu0(const loikb_solver_impl* S)
+{
+  return S->opt.mu_update_strat == LOIKB_MU_MAXEIGENVALUE && S->mu_start > 0.0 ? S->mu_start : S->opt.mu;
+}
+
 template <typename T>
 Params<T> make_params(loikb_solver_impl* S)
 {
@@ -736,7 +803,7 @@ Params<T> make_params(loikb_solver_impl* S)
   for (int k = 0; k < 6; ++k) P.Hv[k] = (T)S->Hv[k];
   P.Hv_inf_norm = (T)S->Hv_inf_norm;
   P.href_tab = S->per_link ? (const T*)S->d_href : nullptr;
-  P.rho = (T)S->opt.rho; P.mu0 = (T)S->opt.mu; P.mu_scale = (T)S->opt.mu_equality_scale_factor;
+  P.rho = (T)S->opt.rho; P.mu0 = (T)solve_mu0(S); P.mu_scale = (T)S->opt.mu_equality_scale_factor;
   P.tol_abs = (T)S->opt.tol_abs; P.tol_rel = (T)S->opt.tol_rel; P.tol_primal_inf = (T)S->opt.tol_primal_inf;
   P.tol_tail_solve = (T)S->opt.tol_tail_solve;
   P.max_iter = S->opt.max_iter;
@@ -757,8 +824,8 @@ Params<T> make_params(loikb_solver_impl* S)
 int reset_home(loikb_solver_impl* S, int what)
 {
   const dim3 grid(S->home.ntiles), block(WAVE);
-  if (S->f32) hipLaunchKernelGGL(k_reset<float>, grid, block, 0, S->stream, S->home.tiles, S->L, what, (float)S->opt.mu);
-  else hipLaunchKernelGGL(k_reset<double>, grid, block, 0, S->stream, S->home.tiles, S->L, what, (double)S->opt.mu);
+  if (S->f32) hipLaunchKernelGGL(k_reset<float>, grid, block, 0, S->stream, S->home.tiles, S->L, what, (float)solve_mu0(S));
+  else hipLaunchKernelGGL(k_reset<double>, grid, block, 0, S->stream, S->home.tiles, S->L, what, (double)solve_mu0(S));
   HIPCHK(hipGetLastError());
   return LOIKB_OK;
 }
@@ -2005,15 +2072,27 @@ int run_main_loop_t(loikb_solver_impl* S)
 }
 
 
+// LOIKB_MU_MAXEIGENVALUE: the solve's starting mu, from the references in force now (SolveInit's reset ran before they were stored)
+static int start_mu(loikb_solver_impl* S)
+{
+  if (S->opt.mu_update_strat != LOIKB_MU_MAXEIGENVALUE) return LOIKB_OK;
+  const double mu = spectral_mu0(S);
+  if (mu != S->mu_start) { S->seen_lo = 1 << 20; S->seen_hi = -(1 << 20); }  // the decades are counted from this mu
+  S->mu_start = mu;
+  return reset_home(S, RS_MU);
+}
+
 int run_main_loop(loikb_solver_impl* S)
 {
   S->pass_active = false;  // (pass-level calls work on a copy of the state: a solve continues from the solver's own)
-  // UpdateMu's throw sites (hxx:632-640)
+  // UpdateMu's throw site for an unknown strategy (hxx:638-640); OSQP and MAXEIGENVALUE are extensions of this library
   if (S->opt.mu_update_strat != LOIKB_MU_DEFAULT && S->opt.mu_update_strat != LOIKB_MU_OSQP &&
-      !(S->opt.flags & LOIKB_OPT_FIXED_ITERS)) {
-    g_last_error = "[FirstOrderLoikOptimizedTpl::UpdateMu]: mu update strategy not yet implemented";
+      S->opt.mu_update_strat != LOIKB_MU_MAXEIGENVALUE && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS)) {
+    g_last_error = "[FirstOrderLoikOptimizedTpl::UpdateMu]: mu update strategy not supported";
     return LOIKB_ERR_MU_STRATEGY;
   }
+  int rc;
+  if ((rc = start_mu(S))) return rc;
   return S->f32 ? run_main_loop_t<float>(S) : run_main_loop_t<double>(S);
 }
 
@@ -2504,7 +2583,7 @@ static PassParams pass_params(const loikb_solver_impl* S)
   PassParams P{};
   P.href_tab = S->d_href64;
   P.Hv_inf_norm = S->Hv_inf_norm;
-  P.rho = S->opt.rho; P.mu0 = S->opt.mu; P.mu_scale = S->opt.mu_equality_scale_factor;
+  P.rho = S->opt.rho; P.mu0 = solve_mu0(S); P.mu_scale = S->opt.mu_equality_scale_factor;
   P.tol_abs = S->opt.tol_abs; P.tol_rel = S->opt.tol_rel; P.tol_primal_inf = S->opt.tol_primal_inf;
   P.tol_tail_solve = S->opt.tol_tail_solve;
   P.max_iter = S->opt.max_iter;
@@ -2571,6 +2650,7 @@ static int run_logged(loikb_solver_impl* S)
 {
   int rc;
   if ((rc = ensure_log(S))) return rc;
+  if (!logged_on_flat(S) && (rc = start_mu(S))) return rc;  // (run_main_loop does it on the other path)
   if (logged_on_flat(S)) {
     // the fast engine writes the lists itself (k_flat<.., LOG>); an instance whose mu leaves the ten configured decades is
     // finished by k_tail as in any solve and its lists end where it left (loikb_stats.lean_escaped says how many)

@@ -463,6 +463,71 @@ static double *dalloc(size_t n)
   return (double *)calloc(n ? n : 1, sizeof(double));
 }
 
+/* eigenvalues of a symmetric 6x6 matrix by cyclic Jacobi rotations (the matrix is overwritten; ev[0..5] unsorted) */
+static void sym6_eigenvalues(double *a, double *ev)
+{
+  for (int sweep = 0; sweep < 50; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 6; ++p)
+      for (int q = p + 1; q < 6; ++q) off += a[6 * p + q] * a[6 * p + q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 6; ++p)
+      for (int q = p + 1; q < 6; ++q) {
+        const double apq = a[6 * p + q];
+        if (apq == 0.0) continue;
+        const double theta = (a[6 * q + q] - a[6 * p + p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 6; ++k) { /* columns p, q */
+          const double akp = a[6 * k + p], akq = a[6 * k + q];
+          a[6 * k + p] = c * akp - sn * akq;
+          a[6 * k + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < 6; ++k) { /* rows p, q */
+          const double apk = a[6 * p + k], aqk = a[6 * q + k];
+          a[6 * p + k] = c * apk - sn * aqk;
+          a[6 * q + k] = sn * apk + c * aqk;
+        }
+      }
+  }
+  for (int k = 0; k < 6; ++k) ev[k] = a[7 * k];
+}
+
+/* ORACLE EXTENSION -- ADMMPenaltyUpdateStrat::MAXEIGENVALUE is declared upstream (task-solver-base.hpp:13-18) and throws "not
+   yet implemented" (loik-loid-optimized.hxx:635-637).  Defined here (and in the device library, loik_host.hip::spectral_mu0)
+   as a SPECTRAL INITIALISATION of the penalty followed by DEFAULT's decade steps: mu starts at the geometric mean of the
+   extreme eigenvalues of the links' cost blocks rho I + H_ref,i (all links that carry a cost; the symmetric part of H_ref,i),
+   snapped to a quarter decade (10^(k/4): the two implementations then agree whatever the last bits of their eigenvalues),
+   clipped to [1e-6, 1e6]; the constructor's mu is not used (set at the start of the main loop of every Solve overload).  For the reference's fixture (H_ref = I, rho = 1e-5) that is
+   mu = 1 instead of 1e-2. */
+static double spectral_mu0(const ref_solver *s)
+{
+  double lo = 0.0, hi = 0.0;
+  int any = 0;
+  for (int i = 1; i < s->nj; ++i) {
+    if (s->massless[i]) continue;
+    double m[36], ev[6];
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 6; ++c)
+        m[6 * r + c] = 0.5 * (s->H_refs[36 * i + 6 * r + c] + s->H_refs[36 * i + 6 * c + r]) + (r == c ? s->rho : 0.0);
+    sym6_eigenvalues(m, ev);
+    for (int k = 0; k < 6; ++k) {
+      if (!any || ev[k] < lo) lo = ev[k];
+      if (!any || ev[k] > hi) hi = ev[k];
+      any = 1;
+    }
+  }
+  if (!any) return s->mu0;
+  if (lo < s->rho) lo = s->rho; /* (an indefinite reference weight: the proximal term is what is left) */
+  if (hi < lo) hi = lo;
+  if (!(lo > 0.0)) return s->mu0;
+  const long q = lround(4.0 * log10(sqrt(lo * hi)));
+  double mu = pow(10.0, (double)q / 4.0);
+  if (mu < 1e-6) mu = 1e-6;
+  if (mu > 1e6) mu = 1e6;
+  return mu;
+}
+
 /* IkIdSolverBaseTpl::Reset, task-solver-base.hpp:73-84 */
 static void base_reset(ref_solver *s)
 {
@@ -1163,7 +1228,7 @@ void ref_check_feasibility(ref_solver *s)
 /* UpdateMu(), loik-loid-optimized.hxx:613-641 */
 int ref_update_mu(ref_solver *s)
 {
-  if (s->mu_update_strat == REF_MU_DEFAULT) {
+  if (s->mu_update_strat == REF_MU_DEFAULT || s->mu_update_strat == REF_MU_MAXEIGENVALUE) { /* (the latter: see spectral_mu0) */
     if (s->primal_residual > 10 * s->dual_residual) {
       s->mu *= 10;
       s->mu_eq = s->mu_equality_scale_factor * s->mu;
@@ -1226,6 +1291,13 @@ static void infeasibility_tail_solve(ref_solver *s)
 /* main loop, identical in the three Solve overloads (hpp:377-454, :502-579, :616-693) */
 static int main_loop(ref_solver *s)
 {
+  if (s->mu_update_strat == REF_MU_MAXEIGENVALUE) {
+    /* (at the start of the main loop, where every Solve overload has the solve's references in place -- SolveInit resets the
+        solver BEFORE it stores H_ref, hpp:343-360) */
+    s->mu = spectral_mu0(s);
+    s->mu_eq = s->mu_equality_scale_factor * s->mu;
+    s->mu_ineq = s->mu;
+  }
   s->n_log = 0;
   if (s->max_iter - 1 > s->log_cap) {
     s->log_cap = s->max_iter - 1;

@@ -224,7 +224,7 @@ def test_error_codes_through_the_abi(talos):
         s.Solve(q2, Hbad, p["v_ref"], p["c_ids"], p["Ais"], b2, p["lb"], p["ub"])
     assert e.value.code == -23
     s.close()
-    s = loik_amd.BatchedLoik(talos, 2, **dict(FIXTURE, max_iter=10, mu_update_strat=3))  # MAXEIGENVALUE, hxx:635-637
+    s = loik_amd.BatchedLoik(talos, 2, **dict(FIXTURE, max_iter=10, mu_update_strat=2))  # no such strategy, hxx:638-640
     with pytest.raises(loik_amd.LoikError) as e:
         s.Solve(q2, p["H_ref"], p["v_ref"], p["c_ids"], p["Ais"], b2, p["lb"], p["ub"])
     assert e.value.code == -6
@@ -260,6 +260,46 @@ def test_osqp_mu_rule_matches_oracle(talos, engine):
             r.Solve(*problem_args(wl, b))
             compare_instance(sk, cache, r, b, 1e-8)
         sk.close()
+    s.close()
+
+
+@pytest.mark.parametrize("engine", ["flat", "lean", "tail", "solve", "logged"])
+def test_maxeigenvalue_mu_rule_matches_oracle(talos, engine, monkeypatch):
+    """ADMMPenaltyUpdateStrat::MAXEIGENVALUE (declared upstream, throws there: hxx:635-637) -- an extension, defined in
+    include/loik_amd.h: mu starts at the geometric mean of the extreme eigenvalues of the links' cost blocks (quarter-decade
+    grid), then DEFAULT's decade steps.  For the kernels it is the DEFAULT rule with another mu0, so every engine runs it: the
+    flat engine, k_hslots + k_lean, k_tail, k_solve alone, and the pass-by-pass implementation of a logging handle -- each
+    against the oracle's own implementation of the definition, with an anisotropic reference weight."""
+    link = talos.getJointId("arm_left_7_joint")
+    B = 700
+    wl = feasible_batch(talos, B, link, 93, nu_scale=0.5)
+    prm = dict(FIXTURE, max_iter=500, tol_abs=1e-6, tol_rel=0.0, mu_update_strat=3)
+    if engine == "flat":
+        Href = 2.5 * np.eye(6)                       # H_ref = h I: mu0 = 10^(round(4 log10 sqrt((h + rho)^2)) / 4) = 10^0.5
+    else:
+        Href = np.diag([0.3, 0.3, 0.3, 4.0, 4.0, 4.0])  # general weight: k_lean's domain among the on-chip engines
+    wl = dict(wl, H_ref=Href)
+    kw = {"flat": {}, "lean": {}, "tail": dict(tail_max_instances=1 << 20), "solve": dict(tail_max_instances=-1), "logged": dict(logging=True)}[engine]
+    if engine == "tail":
+        monkeypatch.setenv("LOIKB_LEAN", "0")
+    s = gpu_solve(talos, wl, prm, **kw)
+    st = s.stats()
+    if engine == "flat":
+        assert st["flat_launches"] >= 1, s.plan()
+    elif engine == "lean":
+        assert st["lean_launches"] >= 1 and st["flat_launches"] == 0, s.plan()
+    elif engine == "tail":
+        assert st["lean_launches"] == 0 and st["tail_instances"] == B, s.plan()
+    elif engine == "solve":
+        assert st["tail_instances"] == 0
+    out = ref.solve_batch(talos, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"],
+                          nthreads=8, want_nu=True, **prm)
+    assert_end_to_end(fetch_end_to_end(s, residuals=True), out, prm, same_frac=0.97, what="MAXEIGENVALUE mu rule, " + engine)
+    # mu stays on the decade grid of the spectral start
+    ev = np.linalg.eigvalsh(Href + prm["rho"] * np.eye(6))
+    mu0 = 10.0 ** (np.round(4.0 * np.log10(np.sqrt(max(ev.min(), prm["rho"]) * ev.max()))) / 4.0)
+    k = np.log10(s.get("mu") / mu0)
+    assert np.abs(k - np.round(k)).max() < 1e-9 and mu0 != prm["mu"]
     s.close()
 
 
