@@ -12,7 +12,7 @@
 // (BoxProj, the dot products S . x, which cost one exchange between the halves of the wavefront: v_permlane32_swap) -- so a
 // wavefront-iteration costs ~0.7 of k_flat's instructions for half as many instances.
 // With the joints of an instance in depth-first order along the lanes of a half, two of k_flat's LDS phases become register
-// work: the subtree sums are differences of a prefix sum (DPP row shifts + row broadcast, one ds_bpermute to fetch the prefix at
+// work: the subtree sums are differences of a prefix sum (DPP row shifts + row broadcast; one LDS exchange fetches the prefix at
 // the subtree's last joint) instead of four window-doubling exchanges, and the eight scalars of the stopping logic are reduced by
 // a transpose-reduce over lane pairs / quads / rows (DPP, v_permlane16/32_swap) and leave in SGPRs (v_readlane) instead of
 // three LDS round trips.  What k_flat2 waits for is LDS latency (about thirty dependent round trips per iteration in k_flat),
@@ -80,52 +80,46 @@ __device__ __forceinline__ double uniform_of(double x, int src_lane)  // x of la
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src_lane), __builtin_amdgcn_readlane(__double2loint(x), src_lane));
 }
 // Eight scalars reduced over the 64 lanes: columns 0..5 by max, 6 and 7 by sum when SUMS (else max), all eight results uniform.
-// Transpose-reduce: lane pairs exchange four columns and keep four, neighbouring pairs exchange two and keep two, neighbouring
-// quads one -- a lane then owns ONE column (4 b0 + 2 b1 + b2, b = bits of the lane number) folded over its eight lanes -- and
-// three more exchanges (8 lanes, rows, halves) fold that over the wavefront.
+// Transpose-reduce.  The first two exchanges trade REGISTERS between lane groups, which is exactly what v_permlane32_swap /
+// v_permlane16_swap do (the upper half / the odd rows of one register change places with the lower half / the even rows of
+// another): after swap(in[q], in[q + 4]) and one max, the lower half of the wavefront holds column q folded over the lane pairs
+// (l, l + 32) and the upper half column q + 4 -- no selects; the same between the rows of a half with columns q, q + 2.  The
+// third exchange (lanes 8 apart in a row) needs selects; a lane then owns ONE column (4 [half] + 2 [odd row] + [lane & 8]),
+// folded over 8 lanes, and three butterflies inside its 8-lane group finish it.
 template <bool SUMS>
 __device__ __forceinline__ void wave_fold8(int lane, const double* in, double* out)
 {
-  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
-  const bool sm = SUMS && b0 && b1;  // this lane's column is a sum
+  const bool up = lane >= 32, b3 = lane & 8;
+  const bool sm = SUMS && lane >= 48;  // columns 6, 7: the lanes of row 3
   auto comb = [&](double a, double b, bool is_sum) { return is_sum ? a + b : tmax(a, b); };
   double k4[4], k2[2], k1;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const double send = b0 ? in[q] : in[q + 4], keep = b0 ? in[q + 4] : in[q];
-    const double recv = dpp_f64<0xB1, 0xF, 0xF, true>(0.0, send);  // quad_perm [1, 0, 3, 2]
-    k4[q] = comb(keep, recv, SUMS && q >= 2 && b0);
+    const auto rl = __builtin_amdgcn_permlane32_swap(__double2loint(in[q]), __double2loint(in[q + 4]), false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(in[q]), __double2hiint(in[q + 4]), false, false);
+    k4[q] = comb(__hiloint2double(rh[0], rl[0]), __hiloint2double(rh[1], rl[1]), SUMS && q >= 2 && up);
   }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const double send = b1 ? k4[q] : k4[q + 2], keep = b1 ? k4[q + 2] : k4[q];
-    const double recv = dpp_f64<0x4E, 0xF, 0xF, true>(0.0, send);  // quad_perm [2, 3, 0, 1]
-    k2[q] = comb(keep, recv, sm);
+    const auto rl = __builtin_amdgcn_permlane16_swap(__double2loint(k4[q]), __double2loint(k4[q + 2]), false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(__double2hiint(k4[q]), __double2hiint(k4[q + 2]), false, false);
+    k2[q] = comb(__hiloint2double(rh[0], rl[0]), __hiloint2double(rh[1], rl[1]), sm);
   }
   {
-    const double send = b2 ? k2[0] : k2[1], keep = b2 ? k2[1] : k2[0];
-    double recv = dpp_f64<0x104, 0xF, 0x5, false>(0.0, send);  // row_shl:4 into lanes 0-3, 8-11 of a row
-    recv = dpp_f64<0x114, 0xF, 0xA, false>(recv, send);        // row_shr:4 into lanes 4-7, 12-15
+    const double send = b3 ? k2[0] : k2[1], keep = b3 ? k2[1] : k2[0];
+    double recv = dpp_f64<0x108, 0xF, 0x3, false>(0.0, send);  // row_shl:8 into lanes 0-7 of a row
+    recv = dpp_f64<0x118, 0xF, 0xC, false>(recv, send);        // row_shr:8 into lanes 8-15
     k1 = comb(keep, recv, sm);
   }
   {
-    double recv = dpp_f64<0x108, 0xF, 0x3, false>(0.0, k1);    // row_shl:8 into lanes 0-7
-    recv = dpp_f64<0x118, 0xF, 0xC, false>(recv, k1);          // row_shr:8 into lanes 8-15
+    double recv = dpp_f64<0x104, 0xF, 0x5, false>(0.0, k1);    // row_shl:4 into lanes 0-3, 8-11
+    recv = dpp_f64<0x114, 0xF, 0xA, false>(recv, k1);          // row_shr:4 into lanes 4-7, 12-15
     k1 = comb(k1, recv, sm);
   }
-  {
-    const int xl = __double2loint(k1), xh = __double2hiint(k1);
-    const auto rl = __builtin_amdgcn_permlane16_swap(xl, xl, false, false);  // rows 0 <-> 1, 2 <-> 3
-    const auto rh = __builtin_amdgcn_permlane16_swap(xh, xh, false, false);
-    k1 = comb(__hiloint2double(rh[0], rl[0]), __hiloint2double(rh[1], rl[1]), sm);
-  }
-  {
-    double lo, hi;
-    both_halves(k1, lo, hi);
-    k1 = comb(lo, hi, sm);
-  }
+  k1 = comb(k1, dpp_f64<0x4E, 0xF, 0xF, true>(0.0, k1), sm);   // quad_perm [2, 3, 0, 1]
+  k1 = comb(k1, dpp_f64<0xB1, 0xF, 0xF, true>(0.0, k1), sm);   // quad_perm [1, 0, 3, 2]
 #pragma unroll
-  for (int q = 0; q < 8; ++q) out[q] = uniform_of(k1, ((q >> 2) & 1) | (((q >> 1) & 1) << 1) | ((q & 1) << 2));
+  for (int q = 0; q < 8; ++q) out[q] = uniform_of(k1, 32 * ((q >> 2) & 1) + 16 * ((q >> 1) & 1) + 8 * (q & 1));
 }
 
 template <typename T>
@@ -618,6 +612,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     // ================= nu = -W^T (Dinv r')  (FwdPass2's nu_i, hxx:127) ======================================================
     T nui;
     {
+      // (measured and rejected: these gathers -- and the partial sums above -- from lane to lane through the LDS crossbar,
+      //  ds_bpermute, instead of a write, a fence and the reads: one dependent trip less each, and 13.0 -> 13.9 ms)
       T nb_[NH];
 #pragma unroll
       for (int i = 0; i < NH; ++i) nb_[i] = nbuf[unpack8(anc4, i)];
@@ -691,8 +687,13 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
         for (int c = 0; c < 3; ++c) Pk[c] = prefix32(E3[c]);
         const int src = lane + (size > 0 ? size - 1 : 0);
+        // (the prefix at the subtree's last joint comes through LDS rows, free at this point: ds_bpermute -- no write, no fence --
+        //  measured 1.5 % slower on the headline and 2 % on a lone instance)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) SEn[c] = (lane_read(Pk[c], src) - Pk[c]) + E3[c];
+        for (int c = 0; c < 3; ++c) xb[lane * 3 + c] = Pk[c];
+        tail_sync();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) SEn[c] = (xb[src * 3 + c] - Pk[c]) + E3[c];
       }
       tail_sync();
       if (iscl) {
@@ -1337,7 +1338,10 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         for (int c = 0; c < 6; ++c) Pk[c] = prefix64(E[c]);
         const int src = lane + (size > 0 ? size - 1 : 0);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) SEn[c] = (lane_read(Pk[c], src) - Pk[c]) + E[c];
+        for (int c = 0; c < 6; ++c) xb[lane * 6 + c] = Pk[c];
+        tail_sync();
+#pragma unroll
+        for (int c = 0; c < 6; ++c) SEn[c] = (xb[src * 6 + c] - Pk[c]) + E[c];
       }
       tail_sync();
       if (iscl) {
