@@ -268,22 +268,19 @@ __device__ __forceinline__ unsigned int opaque(unsigned int x) { asm volatile(""
 __device__ __forceinline__ int unpack8(const unsigned int* w, int k) { return (int)((opaque(w[k >> 2]) >> (8 * (k & 3))) & 0xFFu); }
 __device__ __forceinline__ int unpack16(const unsigned int* w, int k) { return (int)((opaque(w[k >> 1]) >> (16 * (k & 1))) & 0xFFFFu); }
 
-// Two builds of the same kernel.  LAT = false, two wavefronts per SIMD (256 registers each, ~75 values of the iteration live in
-// scratch): the throughput build -- while the work queue holds instances every SIMD interleaves two wavefronts.  LAT = true,
-// one wavefront per SIMD (512 registers, no scratch): the latency build -- an instance alone on its SIMD iterates ~20 %
-// faster in it (no scratch reloads in its dependent chains), and the 999-iteration instances that decide when a batch ends
-// are exactly that.  The throughput build drains (writes its instances back unfinished) once the queue has run dry and
-// `drain` says so; the host relaunches the survivors in the latency build (run_tail, loik_host.hip).
+// (A second build of this kernel -- two wavefronts per SIMD at 256 registers, ~100 values of the iteration in scratch, drained
+// and relaunched in this build once the queue had run dry -- was measured through round 3 and removed: slower in bulk (21 against
+// 17 ms on the headline) and no faster in the tail.  k_flat2 is what two wavefronts per SIMD take: loik_flat2.hpp.)
 constexpr int FLAT_COUNTERS_DRY = 13;  // Bufs::counters[13]: set by the first lane group that finds the work queue empty
 constexpr int FLAT_COUNTERS_T0 = 14, FLAT_COUNTERS_TDRY = 15;  // the 100 MHz clock (low word) when the ring was filled / when the queue ran dry
 // LOG: the lists of LoikSolverInfo (loik-loid-optimized.hpp:47-127, filled at hpp:406-420 -- after ComputeResiduals, before the
 // stopping tests, so mu_list_ holds the mu the iteration RAN with) are written from here: nine scalars per main-loop iteration
 // (one more fold for the four residuals the stopping logic only needs combined).  An instantiation of its own.
-template <typename T, int NA, bool LAT, bool LOG = false>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(LAT ? 1 : 2, LAT ? 1 : 2)))
+template <typename T, int NA, bool LOG = false>
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc, int nscan,
        int njmp, const int* __restrict__ ring, int nslots, int lgG, const T* __restrict__ fslots, int frows, int kexp_lo, int ndec,
-       T href_s, int has_hv, int drain)
+       T href_s, int has_hv)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
@@ -380,7 +377,7 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       slot_in = nx < nslots ? ring[nx] : -1;
       if (nx >= nslots && jlane == 0) {
         // the queue is empty: the first group to find it so notes the time (the launch's bulk phase ends here: from now on lane
-        // groups idle and the launch waits for its long runners) and, in the throughput build, tells the others to drain
+        // groups idle and the launch waits for its long runners)
         if (atomicCAS(Bf.counters + FLAT_COUNTERS_DRY, 0u, 1u) == 0u)
           __hip_atomic_store(Bf.counters + FLAT_COUNTERS_TDRY, (unsigned int)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -592,11 +589,6 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     // is, and the group idles through this iteration: a group without an instance computes on garbage, inside its own lanes
     // and LDS rows, and nothing of it is kept -- so the iteration below updates its registers without predicates.
     bool exit_now = has_inst && (done || (int)my_iters >= P.max_launch_iters);
-    if (!LAT && drain && has_inst && (my_iters & 15u) == 15u) {  // (drain: this launch is the first of two stages)
-      // (asked every 16th iteration of an instance: the flag is one word in global memory that every wavefront of the launch
-      //  reads -- read in every iteration, its round trip doubled the launch time)
-      if (__hip_atomic_load(Bf.counters + FLAT_COUNTERS_DRY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) exit_now = true;
-    }
     // ---- decade of mu: W rows and Dinv.  Two decades stay in LDS: a flip back to the previous one costs nothing.
     if (has_inst && !exit_now && kexp != kslot) {
       if (kexp == kslot_o) {

@@ -60,9 +60,6 @@ struct Tuning {
   bool flat = true;             // LOIKB_FLAT=0        never use k_flat (the engine without level loops, loik_flat.hpp)
   bool flat_split = true;       // LOIKB_FLAT_SPLIT=0: k_flat (one joint per lane) also where k_flat2 (two lanes per joint) applies
   int flat_split_wpe = 2;       // LOIKB_FLAT_WPE=3: k_flat2 built for three wavefronts per SIMD
-  bool flat_two_stage = false;  // LOIKB_FLAT_STAGES=2 the flat engine's throughput build (two wavefronts per SIMD, ~75 values in scratch) until the
-                                // work queue runs dry, then its latency build (default: the latency build -- one wavefront per SIMD, no scratch -- alone:
-                                // measured faster in bulk too, 12.5 against 13.8 ms until the queue is dry on the headline)
   int tail_waves = TAIL_WAVES;  // LOIKB_TAIL_WAVES    wavefronts per k_tail workgroup
   int lean_decades = 10;        // LOIKB_LEAN_DECADES  decades of mu with precomputed H slots ...
   int lean_klo = -2;            // LOIKB_LEAN_KLO      ... starting at mu0 * 10^klo
@@ -85,7 +82,6 @@ struct Tuning {
     if (const char* e = getenv("LOIKB_LEAN")) lean = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT")) flat = atoi(e) != 0;
     if (!lean) flat = false;  // (LOIKB_LEAN=0 asks for the engines without precomputed factors: k_solve / k_tail)
-    if (const char* e = getenv("LOIKB_FLAT_STAGES")) flat_two_stage = atoi(e) == 2;
     if (const char* e = getenv("LOIKB_FLAT_SPLIT")) flat_split = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_WPE")) flat_split_wpe = atoi(e) == 3 ? 3 : 2;
     geti("LOIKB_TAIL_WAVES", tail_waves); tail_waves = std::max(1, std::min(TAIL_WAVES, tail_waves));
@@ -1547,17 +1543,12 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       const size_t flds = small_na ? flat_lds_bytes<T, FLAT_NA_SMALL>(S->nc, G, S->a_shared, has_hv) : flat_lds_bytes<T, FLAT_MAXA>(S->nc, G, S->a_shared, has_hv);
       int lgG = 3;
       while ((1 << lgG) < G) ++lgG;
-      // Two builds of k_flat: throughput (two wavefronts per SIMD) while the work queue feeds every lane group, latency (one per
-      // SIMD, no scratch) for what is still iterating when the queue has run dry -- the 999-iteration instances that decide
-      // when the batch ends.  A list that fits the latency build's resident lane groups twice over goes to it directly.
       const double cu_sh = std::max(1.0, S->ncu * ((double)C->B / (double)S->B));
-      const int cap_thr = (S->tune.lean_wg_per_cu > 0 ? S->tune.lean_wg_per_cu : (int)std::min<size_t>(8, (160 * 1024) / flds)) * (int)(cu_sh + 0.5);
-      const int cap_lat = (int)std::min<size_t>(4, (160 * 1024) / flds) * (int)(cu_sh + 0.5);
+      const int cap_lat = (int)std::min<size_t>(4, (160 * 1024) / flds) * (int)(cu_sh + 0.5);  // k_flat: one wavefront per SIMD
       // two lanes per joint where the layout applies: 17..32 joints, few ancestors, fp64, no lists to write
       const bool split = S->tune.flat_split && G == F2G && small_na && sizeof(T) == 8 && !S->opt.logging;
       // one instance per wavefront anyway (33..64 joints): the build with nested loops, prefix-sum subtree sums, DPP fold
       const bool one = S->tune.flat_split && G == WAVE && sizeof(T) == 8 && !S->opt.logging;
-      const bool two_stage = S->tune.flat_two_stage && n > 2 * cap_lat * ipw && !S->opt.logging && !split && !one;
       P.max_launch_iters = S->opt.max_iter + 1;
       HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
@@ -1575,25 +1566,9 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(C->ev_k2, C->stream));
       }
-      unsigned int first_iters = 0, first_wave_iters = 0, first_loads = 0, first_hits = 0, first_seen = 0;
-      int n_first = n;
-      dim3 grid(1);
-      for (int stage = two_stage ? 0 : 1; stage < 2 && n > 0; ++stage) {
-        const bool lat = stage == 1;
-        grid = dim3((unsigned)std::min((n + ipw - 1) / ipw, lat ? cap_lat : cap_thr));
-        if (stage == 1 && two_stage) {
-          // (the survivors of the throughput stage: the list k_list_unfinished wrote; counters of that stage are kept)
-          HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
-          HIPCHK(hipStreamSynchronize(C->stream));
-          first_iters = C->h_counters[1]; first_wave_iters = C->h_counters[5]; first_loads = C->h_counters[6];
-          first_hits = C->h_counters[FLAT_COUNTERS_SLOT_HITS]; first_seen = C->h_counters[LEAN_DECADES_SEEN];
-          n = (int)C->h_counters[3];
-          if (n == 0) { first_iters = first_wave_iters = first_loads = first_hits = 0; break; }  // (h_counters still hold them)
-          list = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
-          grid = dim3((unsigned)std::min((n + ipw - 1) / ipw, cap_lat));
-          HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
-          if (trace) fprintf(stderr, "[loikb] flat engine, throughput stage: %d of %d instances still iterating when the queue ran dry\n", n, n_first);
-        }
+      const int n_first = n;
+      dim3 grid((unsigned)std::min((n + ipw - 1) / ipw, cap_lat));
+      {
         hipLaunchKernelGGL(k_ring_fill, grid1(C->ring_cap), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, list, n, C->d_counters);
         if (split) {
           // k_flat2: two lanes per joint, one instance per wavefront, two or three wavefronts per SIMD (loik_flat2.hpp)
@@ -1620,13 +1595,13 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA);
 #undef LOIKB_LAUNCH_FLAT1
         } else {
-#define LOIKB_LAUNCH_FLAT(NAV, LATV, ...)                                                                                       \
-  hipLaunchKernelGGL((k_flat<T, NAV, LATV, ##__VA_ARGS__>), grid, dim3(WAVE), flds, C->stream, P, Bf, (const JointDesc*)S->d_jd,                \
+#define LOIKB_LAUNCH_FLAT(NAV, ...)                                                                                             \
+  hipLaunchKernelGGL((k_flat<T, NAV, ##__VA_ARGS__>), grid, dim3(WAVE), flds, C->stream, P, Bf, (const JointDesc*)S->d_jd,                \
                      (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, (const int*)C->d_ring, n, lgG,          \
-                     (const T*)C->d_fslots, frows, kexp_lo, ndec, (T)S->Href[0], has_hv, (int)(!lat))
-        if (S->opt.logging) { if (small_na) LOIKB_LAUNCH_FLAT(FLAT_NA_SMALL, true, true); else LOIKB_LAUNCH_FLAT(FLAT_MAXA, true, true); }
-        else if (small_na) { if (lat) LOIKB_LAUNCH_FLAT(FLAT_NA_SMALL, true); else LOIKB_LAUNCH_FLAT(FLAT_NA_SMALL, false); }
-        else { if (lat) LOIKB_LAUNCH_FLAT(FLAT_MAXA, true); else LOIKB_LAUNCH_FLAT(FLAT_MAXA, false); }
+                     (const T*)C->d_fslots, frows, kexp_lo, ndec, (T)S->Href[0], has_hv)
+        if (S->opt.logging) { if (small_na) LOIKB_LAUNCH_FLAT(FLAT_NA_SMALL, true); else LOIKB_LAUNCH_FLAT(FLAT_MAXA, true); }
+        else if (small_na) LOIKB_LAUNCH_FLAT(FLAT_NA_SMALL);
+        else LOIKB_LAUNCH_FLAT(FLAT_MAXA);
 #undef LOIKB_LAUNCH_FLAT
         }
         HIPCHK(hipGetLastError());
@@ -1647,11 +1622,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));
       HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0));
       HIPCHK(hipEventElapsedTime(&hms, C->ev_k0, C->ev_k2));
-      iters += first_iters + C->h_counters[1];
+      iters += C->h_counters[1];
       const unsigned int escaped = C->h_counters[2];
       {
         std::lock_guard<std::mutex> lock(S->alloc_mu);
-        const unsigned int seen = C->h_counters[LEAN_DECADES_SEEN] | first_seen;
+        const unsigned int seen = C->h_counters[LEAN_DECADES_SEEN];
         for (int d = 0; d < 16; ++d)
           if (seen & (1u << d)) { S->seen_lo = std::min(S->seen_lo, kexp_lo + d); S->seen_hi = std::max(S->seen_hi, kexp_lo + d); }
         if (escaped) { S->seen_lo = S->plan.kexp_lo; S->seen_hi = S->plan.kexp_lo + S->plan.ndec - 1; }
@@ -1661,10 +1636,10 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       if (C->h_counters[FLAT_COUNTERS_DRY])  // (100 MHz clock, low words: from the ring fill of the last stage to the first empty fetch)
         C->stats.queue_dry_ms += (double)(unsigned int)(C->h_counters[FLAT_COUNTERS_TDRY] - C->h_counters[FLAT_COUNTERS_T0]) * 1e-5;
       if (trace)
-        fprintf(stderr, "[loikb] flat engine: %6d instances (%d in the latency build on %u workgroups), done at %8.3f ms (slots %6.3f ms)  "
+        fprintf(stderr, "[loikb] flat engine: %6d instances on %u workgroups, done at %8.3f ms (slots %6.3f ms)  "
                         "inst-iters %9u  wave-iters %7u  slot loads %7u (+ %u served from LDS)  escaped %u  still iterating %u\n",
-                n_first, n, grid.x, ms, hms, first_iters + C->h_counters[1], first_wave_iters + C->h_counters[5],
-                first_loads + C->h_counters[6], first_hits + C->h_counters[FLAT_COUNTERS_SLOT_HITS], escaped, C->h_counters[3]);
+                n_first, grid.x, ms, hms, C->h_counters[1], C->h_counters[5], C->h_counters[6],
+                C->h_counters[FLAT_COUNTERS_SLOT_HITS], escaped, C->h_counters[3]);
       C->stats.lean_escaped += (int)escaped;
       C->tail_iv.emplace_back(t0, t0 + ms);
       total_ms = ms;

@@ -30,9 +30,9 @@ ENGINES = {
     "lean_escapes": ({"LOIKB_FLAT": "0", "LOIKB_LEAN_KLO": "1", "LOIKB_LEAN_DECADES": "3"}, {}),
     "lean_sliced": ({"LOIKB_FLAT": "0", "LOIKB_LEAN_SLICE": "9"}, {}),
     "flat_escapes": ({"LOIKB_LEAN_KLO": "1", "LOIKB_LEAN_DECADES": "3"}, {}),
-    "flat_two_stage": ({"LOIKB_FLAT_STAGES": "2"}, {}),
+    "flat_one_lane": ({"LOIKB_FLAT_SPLIT": "0"}, {}),   # k_flat (one joint per lane) where k_flat2 / k_flat1 would run
 }
-ENV_KEYS = ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_STAGES", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE")
+ENV_KEYS = ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE")
 
 
 def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
@@ -97,7 +97,7 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
         prm = dict(FIXTURE, num_eq_c=nc, max_iter=int(rng.choice([60, 300, 1000])),
                    tol_abs=float(rng.choice([1e-4, 1e-6] if (osqp or multidof) else [1e-4, 1e-6, 1e-8])),
                    tol_rel=float(rng.choice([0.0, 1e-6])), mu_update_strat=1 if osqp else 0)
-        engine = str(rng.choice(["default", "handover", "flat_escapes", "flat_two_stage"] if for_flat else list(ENGINES)))
+        engine = str(rng.choice(["default", "handover", "flat_escapes", "flat_one_lane"] if for_flat else list(ENGINES)))
         env, kw = ENGINES[engine]
         if only is not None and case != only:   # replay one case of a run (same draws)
             continue

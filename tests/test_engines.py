@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 
 ENGINES = {
     "flat": (dict(), dict()),
+    "flat_one_lane": (dict(LOIKB_FLAT_SPLIT="0"), dict()),   # k_flat (one joint per lane) where k_flat2 / k_flat1 would run
     "lean": (dict(LOIKB_FLAT="0"), dict()),
     "tail": (dict(LOIKB_LEAN="0"), dict(tail_max_instances=1 << 20)),
     "solve": (dict(), dict(tail_max_instances=-1)),
@@ -31,7 +32,7 @@ SCALARS = ["primal_residual", "dual_residual", "primal_residual_task", "primal_r
 
 def _solver(model, B, prm, engine, monkeypatch):
     env, kw = ENGINES[engine]
-    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES"):
+    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -74,6 +75,8 @@ def test_every_engine_matches_the_oracle(which, engine, request, monkeypatch):
         assert st["lean_launches"] >= 1 and st["lean_escaped"] == 0 and st["tail_instances"] == B
         # (the random tree's joints are numbered depth-first too: both run the engine they ask for)
         assert st["flat_launches"] == (1 if engine == "flat" else 0), (s.plan(), st)
+    if engine == "flat_one_lane":
+        assert st["flat_launches"] >= 1 and st["flat_split_launches"] == 0 and st["tail_instances"] == B, (s.plan(), st)
     if engine in ("tail", "hybrid"):
         assert st["lean_launches"] == 0 and st["tail_instances"] > 0
     if engine == "solve":
@@ -304,7 +307,7 @@ def test_fuzz_slice_every_engine(monkeypatch):
     """a bounded slice of scripts/fuzz_engines.py inside the suite: random trees (1-DoF / multi-DoF / composite joints, depth- and
     breadth-first numbering), 0..4 constraints, shared / per-instance data, reference costs, tolerances, penalty rules, every engine
     configuration -- against the oracle, no instance dropped.  (The long runs live in profiles/r03_*_fuzz_summary.txt.)"""
-    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_STAGES", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE"):
+    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE"):
         monkeypatch.delenv(k, raising=False)   # (the fuzzer sets and clears them itself; restored after the test)
     out = _fuzz().fuzz(40, 31337, verbose=False, max_batch=700)
     assert out["cases"] + out["refused"] == 40 and out["instances"] > 5000, out
@@ -315,7 +318,7 @@ def test_fuzz_slice_every_engine(monkeypatch):
 def test_fuzz_slice_flat_engine(monkeypatch):
     """the same, drawn inside the flat engine's domain (> 16 joints numbered depth-first, H_ref = h I with or without a target,
     DEFAULT penalty rule; default plan, hand-over from k_solve, forced escapes, two stages)"""
-    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_STAGES", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE"):
+    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE"):
         monkeypatch.delenv(k, raising=False)
     out = _fuzz().fuzz(30, 4242, verbose=False, max_batch=700, flat_bias=1.0)
     assert out["mismatches"] == 0 and out["unconverged_only"] <= 1, out
