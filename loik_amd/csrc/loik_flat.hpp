@@ -272,6 +272,7 @@ __device__ __forceinline__ int unpack16(const unsigned int* w, int k) { return (
 // and relaunched in this build once the queue had run dry -- was measured through round 3 and removed: slower in bulk (21 against
 // 17 ms on the headline) and no faster in the tail.  k_flat2 is what two wavefronts per SIMD take: loik_flat2.hpp.)
 constexpr int FLAT_COUNTERS_DRY = 13;  // Bufs::counters[13]: set by the first lane group that finds the work queue empty
+constexpr int FLAT_COUNTERS_ERR = 16;  // Bufs::counters[16]: a wavefront gave up waiting on the work queue (never: reported as an error)
 constexpr int FLAT_COUNTERS_T0 = 14, FLAT_COUNTERS_TDRY = 15;  // the 100 MHz clock (low word) when the ring was filled / when the queue ran dry
 // LOG: the lists of LoikSolverInfo (loik-loid-optimized.hpp:47-127, filled at hpp:406-420 -- after ComputeResiduals, before the
 // stopping tests, so mu_list_ holds the mu the iteration RAN with) are written from here: nine scalars per main-loop iteration

@@ -60,6 +60,8 @@ struct Tuning {
   bool flat = true;             // LOIKB_FLAT=0        never use k_flat (the engine without level loops, loik_flat.hpp)
   bool flat_split = true;       // LOIKB_FLAT_SPLIT=0: k_flat (one joint per lane) also where k_flat2 (two lanes per joint) applies
   int flat_split_wpe = 2;       // LOIKB_FLAT_WPE=3: k_flat2 built for three wavefronts per SIMD
+  int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's round-robin time slice in iterations (0 = run to completion; default -1:
+                                // 160 for launches of 12..96 instances per resident wavefront, where the stragglers' tail is worth it)
   int tail_waves = TAIL_WAVES;  // LOIKB_TAIL_WAVES    wavefronts per k_tail workgroup
   int lean_decades = 10;        // LOIKB_LEAN_DECADES  decades of mu with precomputed H slots ...
   int lean_klo = -2;            // LOIKB_LEAN_KLO      ... starting at mu0 * 10^klo
@@ -84,6 +86,7 @@ struct Tuning {
     if (!lean) flat = false;  // (LOIKB_LEAN=0 asks for the engines without precomputed factors: k_solve / k_tail)
     if (const char* e = getenv("LOIKB_FLAT_SPLIT")) flat_split = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_WPE")) flat_split_wpe = atoi(e) == 3 ? 3 : 2;
+    if (const char* e = getenv("LOIKB_FLAT_SLICE")) flat_slice = std::max(-1, atoi(e));
     geti("LOIKB_TAIL_WAVES", tail_waves); tail_waves = std::max(1, std::min(TAIL_WAVES, tail_waves));
     geti("LOIKB_LEAN_DECADES", lean_decades); lean_decades = std::max(1, std::min(16, lean_decades));
     geti("LOIKB_LEAN_KLO", lean_klo);
@@ -1577,12 +1580,25 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           int per_cu = (int)std::min<size_t>((size_t)4 * wpe, (160 * 1024) / lds2);
           if (S->tune.lean_wg_per_cu > 0) per_cu = std::min(per_cu, S->tune.lean_wg_per_cu);
           grid = dim3((unsigned)std::min(n, per_cu * (int)(cu_sh + 0.5)));
-#define LOIKB_LAUNCH_FLAT2(WPE)                                                                                                 \
-  hipLaunchKernelGGL((k_flat2<FLAT_NA_SMALL, WPE>), grid, dim3(WAVE), lds2, C->stream, *reinterpret_cast<const Params<double>*>(&P), \
-                     *reinterpret_cast<const Bufs<double>*>(&Bf), (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes,    \
-                     nanc, S->flat.nscan, S->flat.njmp, (const int*)C->d_ring, n, (const double*)C->d_fslots, frows, kexp_lo,    \
-                     ndec, (double)S->Href[0], has_hv)
-          if (wpe == 3) LOIKB_LAUNCH_FLAT2(3); else LOIKB_LAUNCH_FLAT2(2);
+          // Round-robin time slicing inside the launch (k_flat2<.., SLICED>).  Iteration counts are heavy-tailed and unknown: run to
+          // completion in arrival order, the 999-iteration instances that are fetched late keep the launch alive ~3 ms after
+          // the queue ran dry.  With a slice of 160 iterations every long runner has done ~500 by then.  Measured (Talos-32,
+          // one GPU, ms per batch without / with): 8192: 4.23 / 4.39, 16 384: 5.46 / 5.61, 32 768: 8.13 / 7.80, 65 536: 13.28 /
+          // 12.29, 131 072: 23.13 / 22.24, 262 144: 44.19 / 44.48 -- a switch costs a store, an agent-scope reload and the set-up of
+          // an instance (~25 us), small batches are one straggler chain whatever the order, large ones hide it in their bulk:
+          // on by default between 12 and 96 instances per resident wavefront.  Slices of 32 / 64 / 96 / 128 / 192 / 256 / 384
+          // iterations on the headline: 19.6 / 13.7 / 12.40 / 12.36 / 12.33 / 12.45 / 12.76 ms.
+          const int resident = (int)grid.x;
+          const int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice
+                              : (n_first >= 12 * resident && n_first <= 96 * resident && (int)grid.x == per_cu * (int)(cu_sh + 0.5)) ? 160 : 0;
+#define LOIKB_LAUNCH_FLAT2(WPE, ...)                                                                                            \
+  hipLaunchKernelGGL((k_flat2<FLAT_NA_SMALL, WPE, ##__VA_ARGS__>), grid, dim3(WAVE), lds2, C->stream,                            \
+                     *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
+                     (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
+                     (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv, C->ring_cap - 1, quantum)
+          if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true);
+          else if (wpe == 3) LOIKB_LAUNCH_FLAT2(3);
+          else LOIKB_LAUNCH_FLAT2(2);
 #undef LOIKB_LAUNCH_FLAT2
         } else if (one) {
           const size_t lds1 = small_na ? flat1_lds_bytes<FLAT_NA_SMALL>(S->nc, has_hv != 0) : flat1_lds_bytes<FLAT_MAXA>(S->nc, has_hv != 0);
@@ -1623,6 +1639,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0));
       HIPCHK(hipEventElapsedTime(&hms, C->ev_k0, C->ev_k2));
       iters += C->h_counters[1];
+      if (C->h_counters[FLAT_COUNTERS_ERR]) { g_last_error = "internal: a wavefront of the flat engine gave up waiting on its work queue"; return LOIKB_ERR_STATE; }
+      C->stats.lean_requeues += (int)C->h_counters[LEAN_Q_REQUEUES];
       const unsigned int escaped = C->h_counters[2];
       {
         std::lock_guard<std::mutex> lock(S->alloc_mu);

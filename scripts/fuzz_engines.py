@@ -30,9 +30,12 @@ ENGINES = {
     "lean_escapes": ({"LOIKB_FLAT": "0", "LOIKB_LEAN_KLO": "1", "LOIKB_LEAN_DECADES": "3"}, {}),
     "lean_sliced": ({"LOIKB_FLAT": "0", "LOIKB_LEAN_SLICE": "9"}, {}),
     "flat_escapes": ({"LOIKB_LEAN_KLO": "1", "LOIKB_LEAN_DECADES": "3"}, {}),
+    # k_flat2's round-robin time slicing forced (one wavefront per CU so that instances wait: requeues from the 7th iteration)
+    "flat_sliced": ({"LOIKB_FLAT_SLICE": "7", "LOIKB_LEAN_WG_PER_CU": "1"}, {}),
     "flat_one_lane": ({"LOIKB_FLAT_SPLIT": "0"}, {}),   # k_flat (one joint per lane) where k_flat2 / k_flat1 would run
 }
-ENV_KEYS = ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE")
+ENV_KEYS = ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE",
+            "LOIKB_LEAN_WG_PER_CU")
 
 
 def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
@@ -44,6 +47,7 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
     say = print if verbose else (lambda *a, **k: None)
     if only is None and os.environ.get("FUZZ_ONLY"):
         only = int(os.environ["FUZZ_ONLY"])
+    saved_env = {k: os.environ[k] for k in ENV_KEYS if k in os.environ}
     summary = dict(cases=0, mismatches=0, unconverged_only=0, refused=0, flat_cases=0, worst_dz_same=0.0, instances=0, off_count=0, by_engine={})
     for case in range(ncase):
         for_flat = bool(rng.random() < flat_bias)
@@ -97,7 +101,7 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
         prm = dict(FIXTURE, num_eq_c=nc, max_iter=int(rng.choice([60, 300, 1000])),
                    tol_abs=float(rng.choice([1e-4, 1e-6] if (osqp or multidof) else [1e-4, 1e-6, 1e-8])),
                    tol_rel=float(rng.choice([0.0, 1e-6])), mu_update_strat=1 if osqp else 0)
-        engine = str(rng.choice(["default", "handover", "flat_escapes", "flat_one_lane"] if for_flat else list(ENGINES)))
+        engine = str(rng.choice(["default", "handover", "flat_escapes", "flat_one_lane", "flat_sliced"] if for_flat else list(ENGINES)))
         env, kw = ENGINES[engine]
         if only is not None and case != only:   # replay one case of a run (same draws)
             continue
@@ -174,6 +178,9 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
                   "OSQP" if osqp else "DEF ", same.mean(), dz[same].max() if same.any() else 0.0, int((~same).sum()), st["lean_launches"], st["flat_launches"],
                   st["lean_escaped"], st["lean_requeues"], "ok" if ok else "MISMATCH", why), flush=True)
         s.close()
+    for k in ENV_KEYS:   # (the engines' switches are read at loikb_create: nothing of the last case may outlive the run)
+        os.environ.pop(k, None)
+    os.environ.update(saved_env)
     return summary
 
 if __name__ == "__main__":

@@ -15,5 +15,6 @@ for i in range(n):
     st = s.stats()
     rows.append((st["total_ms"], st["tail_ms"], st["hslots_ms"]))
 r = np.array(rows[2:])
-print("%s B=%d: total %.2f ms  on-chip launch %.2f ms  of which slots %.2f ms   (min total %.2f)  iters %d flat %d" % (
-    os.environ.get("TAG", ""), B, r[:, 0].mean(), r[:, 1].mean(), r[:, 2].mean(), r[:, 0].min(), st["instance_iterations"], st["flat_launches"]))
+print("%s B=%d: total %.2f ms  on-chip launch %.2f ms  of which slots %.2f ms   (min total %.2f)  iters %d flat %d  requeues %d  queue dry at %.2f ms" % (
+    os.environ.get("TAG", ""), B, r[:, 0].mean(), r[:, 1].mean(), r[:, 2].mean(), r[:, 0].min(), st["instance_iterations"], st["flat_launches"],
+    st["lean_requeues"], st["queue_dry_ms"]))

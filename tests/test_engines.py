@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 
 ENGINES = {
     "flat": (dict(), dict()),
-    "flat_one_lane": (dict(LOIKB_FLAT_SPLIT="0"), dict()),   # k_flat (one joint per lane) where k_flat2 / k_flat1 would run
+    "flat_one_lane": (dict(LOIKB_FLAT_SPLIT="0"), dict()),
+    # k_flat2's time slicing forced, one wavefront per CU so that instances wait: requeues at every 5th iteration
+    "flat_sliced": (dict(LOIKB_FLAT_SLICE="5", LOIKB_LEAN_WG_PER_CU="1"), dict()),
     "lean": (dict(LOIKB_FLAT="0"), dict()),
     "tail": (dict(LOIKB_LEAN="0"), dict(tail_max_instances=1 << 20)),
     "solve": (dict(), dict(tail_max_instances=-1)),
@@ -32,7 +34,7 @@ SCALARS = ["primal_residual", "dual_residual", "primal_residual_task", "primal_r
 
 def _solver(model, B, prm, engine, monkeypatch):
     env, kw = ENGINES[engine]
-    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES"):
+    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_WG_PER_CU", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -77,6 +79,8 @@ def test_every_engine_matches_the_oracle(which, engine, request, monkeypatch):
         assert st["flat_launches"] == (1 if engine == "flat" else 0), (s.plan(), st)
     if engine == "flat_one_lane":
         assert st["flat_launches"] >= 1 and st["flat_split_launches"] == 0 and st["tail_instances"] == B, (s.plan(), st)
+    if engine == "flat_sliced" and which == "talos":
+        assert st["flat_split_launches"] >= 1, (s.plan(), st)
     if engine in ("tail", "hybrid"):
         assert st["lean_launches"] == 0 and st["tail_instances"] > 0
     if engine == "solve":
@@ -307,7 +311,7 @@ def test_fuzz_slice_every_engine(monkeypatch):
     """a bounded slice of scripts/fuzz_engines.py inside the suite: random trees (1-DoF / multi-DoF / composite joints, depth- and
     breadth-first numbering), 0..4 constraints, shared / per-instance data, reference costs, tolerances, penalty rules, every engine
     configuration -- against the oracle, no instance dropped.  (The long runs live in profiles/r03_*_fuzz_summary.txt.)"""
-    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE"):
+    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE"):
         monkeypatch.delenv(k, raising=False)   # (the fuzzer sets and clears them itself; restored after the test)
     out = _fuzz().fuzz(40, 31337, verbose=False, max_batch=700)
     assert out["cases"] + out["refused"] == 40 and out["instances"] > 5000, out
@@ -318,8 +322,36 @@ def test_fuzz_slice_every_engine(monkeypatch):
 def test_fuzz_slice_flat_engine(monkeypatch):
     """the same, drawn inside the flat engine's domain (> 16 joints numbered depth-first, H_ref = h I with or without a target,
     DEFAULT penalty rule; default plan, hand-over from k_solve, forced escapes, two stages)"""
-    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE"):
+    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE"):
         monkeypatch.delenv(k, raising=False)
     out = _fuzz().fuzz(30, 4242, verbose=False, max_batch=700, flat_bias=1.0)
     assert out["mismatches"] == 0 and out["unconverged_only"] <= 1, out
     assert out["flat_cases"] >= 15, out   # (batches below 64 instances and trees the schedule refuses run elsewhere)
+
+
+def test_flat_time_slicing_changes_nothing(talos, monkeypatch):
+    """k_flat2's round-robin time slicing (LOIKB_FLAT_SLICE; on by default for launches of 12..96 instances per resident
+    wavefront): an instance whose slice is used up while others wait is written back and reloaded later, possibly by a wavefront
+    of another XCD (agent-scope accesses of the mutable record).  Same arithmetic, so bit-identical results; forced here with a
+    slice of 5 iterations and one wavefront per CU, 1500 instances: thousands of requeues."""
+    from loik_amd import workloads
+    B = 1500
+    wl = workloads.talos_c3(B, seed=123)
+    prm = dict(wl["params"], max_iter=400)
+    args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    res = {}
+    for name, env in (("plain", dict(LOIKB_FLAT_SLICE="0")), ("sliced", dict(LOIKB_FLAT_SLICE="5", LOIKB_LEAN_WG_PER_CU="1"))):
+        for k in ("LOIKB_FLAT_SLICE", "LOIKB_LEAN_WG_PER_CU"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = loik_amd.BatchedLoik(talos, B, **prm)
+        s.Solve(*args)
+        st = s.stats()
+        assert st["flat_split_launches"] >= 1 and st["tail_instances"] == B
+        assert (st["lean_requeues"] > 1000) == (name == "sliced"), st
+        res[name] = {k: s.get(k) for k in ("iter", "converged", "primal_infeasible", "z", "nu", "mu", "yis", "fis", "vis")}
+        assert st["instance_iterations"] == int(res[name]["iter"].sum())
+        s.close()
+    for k in res["plain"]:
+        assert np.array_equal(res["plain"][k], res["sliced"][k]), k
