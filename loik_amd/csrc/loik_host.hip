@@ -1590,7 +1590,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           // iterations on the headline: 19.6 / 13.7 / 12.40 / 12.36 / 12.33 / 12.45 / 12.76 ms.
           const int resident = (int)grid.x;
           const int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice
-                              : (n_first >= 12 * resident && n_first <= 96 * resident && (int)grid.x == per_cu * (int)(cu_sh + 0.5)) ? 160 : 0;
+                              : (n_first >= 12 * resident && n_first <= 96 * resident && (int)grid.x == per_cu * (int)(cu_sh + 0.5) &&
+                                 !(S->opt.flags & LOIKB_OPT_OWN_STREAM)) ? 160 : 0;
+          // (not for a handle on a stream of its own: that is how batches are kept in flight side by side, and then the other
+          //  batch's bulk fills this one's ragged end -- slicing only adds its switches, and its wavefronts that wait for queue
+          //  entries hold slots the other launch could use: two headline batches in flight 21.5 ms per pair without, 24.9 with)
 #define LOIKB_LAUNCH_FLAT2(WPE, ...)                                                                                            \
   hipLaunchKernelGGL((k_flat2<FLAT_NA_SMALL, WPE, ##__VA_ARGS__>), grid, dim3(WAVE), lds2, C->stream,                            \
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
