@@ -1007,11 +1007,11 @@ __host__ __device__ __forceinline__ size_t flat1_lds_bytes(int nc, bool has_hv)
   return (n * sizeof(double) + 15) & ~(size_t)15;
 }
 
-template <int NA>
+template <int NA, bool SLICED = false>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
-        int nscan, int njmp, const int* __restrict__ ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
-        int ndec, double href_s, int has_hv)
+        int nscan, int njmp, int* ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
+        int ndec, double href_s, int has_hv, int ring_mask, int quantum)
 {
   using T = double;
   constexpr int G = WAVE, cs = FCD;
@@ -1089,18 +1089,66 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     for (int k = 0; k < 6; ++k) E[k] *= mass;
   };
 
-  auto load_instance = [&]() {
-    int slot_in;
-    {
+  auto note_dry = [&]() {  // the first wavefront to find the queue empty notes the time (the launch's bulk phase ends here)
+    if (lane == 0 && atomicCAS(Bf.counters + FLAT_COUNTERS_DRY, 0u, 1u) == 0u)
+      __hip_atomic_store(Bf.counters + FLAT_COUNTERS_TDRY, (unsigned int)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // ---- work queue.  Plain: the listed instances in order, one atomic per fetch.  SLICED: the ring of k_lean (ticket t is served by
+  // entry t; entries are consumed by resetting them to -1; LEAN_Q_RETIRED counts the instances that will not come back)
+  unsigned int* q_tail = Bf.counters + LEAN_Q_TAIL;
+  unsigned int* q_retired = Bf.counters + LEAN_Q_RETIRED;
+  auto fetch = [&]() -> int {
+    if constexpr (!SLICED) {
       int nx = 0;
       if (lane == 0) nx = (int)atomicAdd(q_head, 1u);
       nx = __builtin_amdgcn_readfirstlane(nx);
-      slot_in = nx < nslots ? ring[nx] : -1;
-      if (nx >= nslots && lane == 0) {
-        if (atomicCAS(Bf.counters + FLAT_COUNTERS_DRY, 0u, 1u) == 0u)
-          __hip_atomic_store(Bf.counters + FLAT_COUNTERS_TDRY, (unsigned int)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (nx >= nslots) note_dry();
+      return nx < nslots ? ring[nx] : -1;
+    } else {
+      int got = -1;
+      if (lane == 0) {
+        const unsigned int ticket = atomicAdd(q_head, 1u);
+        int* e = ring + (ticket & (unsigned int)ring_mask);
+        bool noted = false;
+        for (unsigned int spins = 0;; ++spins) {
+          const int v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (v >= 0) { __hip_atomic_store(e, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); got = v; break; }
+          if (__hip_atomic_load(q_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)nslots) break;
+          if (!noted) {  // (this ticket is beyond the tail: from now on wavefronts wait for entries)
+            noted = true;
+            if (atomicCAS(Bf.counters + FLAT_COUNTERS_DRY, 0u, 1u) == 0u)
+              __hip_atomic_store(Bf.counters + FLAT_COUNTERS_TDRY, (unsigned int)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (spins > (1u << 23)) { atomicOr(Bf.counters + FLAT_COUNTERS_ERR, 1u); break; }  // (never: a lost entry must not hang the GPU)
+          __builtin_amdgcn_s_sleep(32);
+        }
       }
+      return __builtin_amdgcn_readfirstlane(got);
     }
+  };
+  auto q_waiting = [&]() -> bool {  // do entries wait for a wavefront?
+    int wtg = 0;
+    if (lane == 0)
+      wtg = (int)(__hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                  __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > 0;
+    return __builtin_amdgcn_readfirstlane(wtg) != 0;
+  };
+  auto q_push = [&](int slot) {  // (after store_instance: every store of the record has completed before the entry appears)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      const unsigned int pos = atomicAdd(q_tail, 1u);
+      int* e = ring + (pos & (unsigned int)ring_mask);
+      for (unsigned int spins = 0; __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0; ++spins) {
+        if (spins > (1u << 23)) { atomicOr(Bf.counters + FLAT_COUNTERS_ERR, 2u); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      __hip_atomic_store(e, slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicAdd(&Bf.counters[LEAN_Q_REQUEUES], 1u);
+    }
+  };
+  auto load_instance = [&]() {
+    const int slot_in = fetch();
     has_inst = slot_in >= 0;
     if (!has_inst) return;
     isj = isj_lane;
@@ -1111,14 +1159,14 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T ax[3];
     const bool rev = jflags & JF_REVOLUTE;
     {
-      const typename Vec2<T>::type csn = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
+      const typename Vec2<T>::type csn = ldp<T>(rec, JP_CS), wz = rldp<T, SLICED>(rec, JP_WZ), nus = rldp<T, SLICED>(rec, JP_NUS);
       const JointDesc d = jd[jl + 1];
 #pragma unroll
       for (int k = 0; k < 3; ++k) ax[k] = isj_lane ? (T)d.axis[k] : T(0);
       joint_xform<T>(d, rec, csn.x, csn.y, R0, t0);  // liMi ...
-      ld6<T>(rec, JP_V, v);
-      ld6<T>(rec, JP_F, f);
-      ld6<T>(rec, JP_G, g);
+      rld6<T, SLICED>(rec, JP_V, v);
+      rld6<T, SLICED>(rec, JP_F, f);
+      rld6<T, SLICED>(rec, JP_G, g);
       w = wz.x; z = wz.y; nu = nus.x; s = nus.y;
       if (P.mode & MODE_BND_SHARED) {
         lbi = Bf.uni[L.nc * 57 + jl];
@@ -1153,7 +1201,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         const int which = lane / 6, k = lane % 6;
         const int pair = which == 0 ? CP_B : which == 1 ? CP_Y : CP_ATY;
         const int dst = which == 0 ? FC_B : which == 1 ? FC_Y : FC_ATY;
-        c_[dst + k] = *reinterpret_cast<const T*>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+        c_[dst + k] = rld<T, SLICED>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
       }
       for (int e = lane; e < LCA; e += WAVE)
         c_[FC_A + e] = a_shared ? Bf.uni[c * LCA + e]
@@ -1216,69 +1264,85 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         for (int k = 0; k < 6; ++k) shv[lane * 6 + k] = Sh[k];
       }
     }
-    const typename Vec2<T>::type mu2 = ldp<T>(srec, SP_MU), bi2 = ldp<T>(srec, SP_BI), st2 = ldp<T>(srec, SP_ST);
+    if constexpr (SLICED) {  // an instance that comes back from the queue continues exactly where it left (see k_flat2)
+      if (rldp<T, SLICED>(srec, SP_TAG).x == T(-3)) {
+        rld6<T, SLICED>(rec, JP_P, SE);
+        if (jcslot >= 0) {
+          T aw[6];
+          rld6<T, SLICED>(rec, JP_UD, aw);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) cdi[jcslot * cs + FC_ATYW + k] = aw[k];
+        }
+      }
+    }
+    const typename Vec2<T>::type mu2 = rldp<T, SLICED>(srec, SP_MU), bi2 = rldp<T, SLICED>(srec, SP_BI), st2 = rldp<T, SLICED>(srec, SP_ST);
     mu = mu2.x;
     kexp = (int)mu2.y;
     kslot = -(1 << 30); kslot_o = -(1 << 30);
     status = (int)st2.x;
     iter = (int)bi2.y;
-    tail_it = (int)ld_scal<T>(srec, SC_TAIL_ITER);
-    nflip = (int)ldp<T>(srec, SP_FLIP).x;
+    tail_it = (int)rld_scal<T, SLICED>(srec, SC_TAIL_ITER);
+    nflip = (int)rldp<T, SLICED>(srec, SP_FLIP).x;
     done = (status & ST_DONE) != 0;
     if (!done && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { done = true; status |= ST_DONE; }
     if (lane == 0) {
-      isc[FI_BNORM] = bi2.x; isc[FI_TGIN] = ldp<T>(srec, SP_TAG).x; isc[FI_STY] = st2.y; isc[FI_MULAST] = T(-1);
-      isc[FI_TOLP] = ld_scal<T>(srec, SC_TOL_PRIMAL); isc[FI_TOLD] = ld_scal<T>(srec, SC_TOL_DUAL);
-      isc[FI_DYQP] = ld_scal<T>(srec, SC_DELTA_Y_QP); isc[FI_ATDY] = ld_scal<T>(srec, SC_AT_DELTA_Y_QP);
-      isc[FI_UBP] = ld_scal<T>(srec, SC_UB_DY_PLUS); isc[FI_LBM] = ld_scal<T>(srec, SC_LB_DY_MINUS);
-      isc[FI_C1] = ld_scal<T>(srec, SC_COND1); isc[FI_C2] = ld_scal<T>(srec, SC_COND2);
+      isc[FI_BNORM] = bi2.x; isc[FI_TGIN] = rldp<T, SLICED>(srec, SP_TAG).x; isc[FI_STY] = st2.y; isc[FI_MULAST] = T(-1);
+      isc[FI_TOLP] = rld_scal<T, SLICED>(srec, SC_TOL_PRIMAL); isc[FI_TOLD] = rld_scal<T, SLICED>(srec, SC_TOL_DUAL);
+      isc[FI_DYQP] = rld_scal<T, SLICED>(srec, SC_DELTA_Y_QP); isc[FI_ATDY] = rld_scal<T, SLICED>(srec, SC_AT_DELTA_Y_QP);
+      isc[FI_UBP] = rld_scal<T, SLICED>(srec, SC_UB_DY_PLUS); isc[FI_LBM] = rld_scal<T, SLICED>(srec, SC_LB_DY_MINUS);
+      isc[FI_C1] = rld_scal<T, SLICED>(srec, SC_COND1); isc[FI_C2] = rld_scal<T, SLICED>(srec, SC_COND2);
     }
     tail_sync();
     my_iters = 0;
     any_iter = false;
   };
+  bool requeue = false;
   auto store_instance = [&]() {
     char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+    if (SLICED && requeue && isj) {
+      rst6<T, SLICED>(rec, JP_P, SE);
+      if (jcslot >= 0) rst6<T, SLICED>(rec, JP_UD, cdi + jcslot * cs + FC_ATYW);
+    }
     if (isj) {
-      st6<T>(rec, JP_V, v);
-      st6<T>(rec, JP_F, f);
-      st6<T>(rec, JP_G, g);
-      stp<T>(rec, JP_WZ, w, z);
-      stp<T>(rec, JP_NUS, nu, s);
-      if (any_iter) stp<T>(rec, JP_R, rbuf[lane], wl[(wsel * (NA + 1) + NA) * G + lane]);  // (r_i, Dinv_i; SP_TAG = -2: see k_flat)
+      rst6<T, SLICED>(rec, JP_V, v);
+      rst6<T, SLICED>(rec, JP_F, f);
+      rst6<T, SLICED>(rec, JP_G, g);
+      rstp<T, SLICED>(rec, JP_WZ, w, z);
+      rstp<T, SLICED>(rec, JP_NUS, nu, s);
+      if (any_iter) rstp<T, SLICED>(rec, JP_R, rbuf[lane], wl[(wsel * (NA + 1) + NA) * G + lane]);  // (r_i, Dinv_i; SP_TAG = -2: see k_flat)
     }
     for (int c = 0; c < L.nc; ++c) {
       char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
       if (lane < 6) {
         const int k = lane;
-        *reinterpret_cast<T*>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * cs + FC_Y + k];
-        *reinterpret_cast<T*>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T)) = cdi[c * cs + FC_ATY + k];
+        rst<T, SLICED>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), cdi[c * cs + FC_Y + k]);
+        rst<T, SLICED>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), cdi[c * cs + FC_ATY + k]);
       }
     }
     if (lane == 0) {
-      stp<T>(srec, SP_MU, mu, (T)kexp);
-      stp<T>(srec, SP_TAG, any_iter ? T(-2) : isc[FI_TGIN], T(0));
-      stp<T>(srec, SP_BI, isc[FI_BNORM], (T)iter);
-      stp<T>(srec, SP_FLIP, (T)nflip, T(0));
-      stp<T>(srec, SP_ST, (T)(any_iter ? (status & ~ST_PFULL) : status), any_iter ? isc[FI_MULAST] : isc[FI_STY]);
+      rstp<T, SLICED>(srec, SP_MU, mu, (T)kexp);
+      rstp<T, SLICED>(srec, SP_TAG, (SLICED && requeue) ? T(-3) : any_iter ? T(-2) : isc[FI_TGIN], T(0));
+      rstp<T, SLICED>(srec, SP_BI, isc[FI_BNORM], (T)iter);
+      rstp<T, SLICED>(srec, SP_FLIP, (T)nflip, T(0));
+      rstp<T, SLICED>(srec, SP_ST, (T)(any_iter ? (status & ~ST_PFULL) : status), any_iter ? isc[FI_MULAST] : isc[FI_STY]);
       if (any_iter) {
         const T* rr = isc + FI_RED;
         const T mu_s = mu;
-        stp<T>(srec, SP_SCAL + 0, isc[FI_PRIMAL], isc[FI_DUAL]);
-        stp<T>(srec, SP_SCAL + 1, rr[0], rr[1]);
-        stp<T>(srec, SP_SCAL + 2, rr[12], rr[2]);
-        stp<T>(srec, SP_SCAL + 3, isc[FI_TOLP], isc[FI_TOLD]);
-        stp<T>(srec, SP_SCAL + 4, mu_s, P.mu_scale * mu_s);
-        stp<T>(srec, SP_SCAL + 5, mu_s, isc[FI_DX]);
-        stp<T>(srec, SP_SCAL + 6, isc[FI_DZ], isc[FI_DYQP]);
-        stp<T>(srec, SP_SCAL + 7, isc[FI_ATDY], isc[FI_UBP]);
-        stp<T>(srec, SP_SCAL + 8, isc[FI_LBM], rr[5]);
-        stp<T>(srec, SP_SCAL + 9, rr[6], rr[7]);
-        stp<T>(srec, SP_SCAL + 10, rr[3], rr[4]);
-        stp<T>(srec, SP_SCAL + 11, rr[8], rr[9]);
-        stp<T>(srec, SP_SCAL + 12, rr[10], rr[11]);
-        stp<T>(srec, SP_SCAL + 13, rr[2], isc[FI_C1]);
-        stp<T>(srec, SP_SCAL + 14, isc[FI_C2], (T)tail_it);
+        rstp<T, SLICED>(srec, SP_SCAL + 0, isc[FI_PRIMAL], isc[FI_DUAL]);
+        rstp<T, SLICED>(srec, SP_SCAL + 1, rr[0], rr[1]);
+        rstp<T, SLICED>(srec, SP_SCAL + 2, rr[12], rr[2]);
+        rstp<T, SLICED>(srec, SP_SCAL + 3, isc[FI_TOLP], isc[FI_TOLD]);
+        rstp<T, SLICED>(srec, SP_SCAL + 4, mu_s, P.mu_scale * mu_s);
+        rstp<T, SLICED>(srec, SP_SCAL + 5, mu_s, isc[FI_DX]);
+        rstp<T, SLICED>(srec, SP_SCAL + 6, isc[FI_DZ], isc[FI_DYQP]);
+        rstp<T, SLICED>(srec, SP_SCAL + 7, isc[FI_ATDY], isc[FI_UBP]);
+        rstp<T, SLICED>(srec, SP_SCAL + 8, isc[FI_LBM], rr[5]);
+        rstp<T, SLICED>(srec, SP_SCAL + 9, rr[6], rr[7]);
+        rstp<T, SLICED>(srec, SP_SCAL + 10, rr[3], rr[4]);
+        rstp<T, SLICED>(srec, SP_SCAL + 11, rr[8], rr[9]);
+        rstp<T, SLICED>(srec, SP_SCAL + 12, rr[10], rr[11]);
+        rstp<T, SLICED>(srec, SP_SCAL + 13, rr[2], isc[FI_C1]);
+        rstp<T, SLICED>(srec, SP_SCAL + 14, isc[FI_C2], (T)tail_it);
       }
       if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
     }
@@ -1289,7 +1353,13 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     load_instance();
     if (!has_inst) break;
     T inv_mu = T(1) / mu;
+    int slice_iters = 0;
+    requeue = false;
    while (true) {
+    if (SLICED && quantum > 0 && !done && slice_iters >= quantum) {
+      if (q_waiting()) { requeue = true; break; }
+      slice_iters = 0;
+    }
     bool exit_now = done || (int)my_iters >= P.max_launch_iters;
     if (!exit_now && kexp != kslot) {
       if (kexp == kslot_o) {
@@ -1320,6 +1390,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
     ++my_iters; any_iter = true;
     ++n_wave_iters;
+    if (SLICED) ++slice_iters;
 
     // ---- p^base summed over the subtrees; tau
     T wc[NA];
@@ -1582,6 +1653,10 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     }
    }
     store_instance();
+    if constexpr (SLICED) {
+      if (requeue) q_push(lidx);
+      else if (lane == 0) atomicAdd(q_retired, 1u);
+    }
   }
   if (lane == 0) {
     atomicAdd(&Bf.counters[5], n_wave_iters);

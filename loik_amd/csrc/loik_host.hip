@@ -1607,12 +1607,19 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         } else if (one) {
           const size_t lds1 = small_na ? flat1_lds_bytes<FLAT_NA_SMALL>(S->nc, has_hv != 0) : flat1_lds_bytes<FLAT_MAXA>(S->nc, has_hv != 0);
           grid = dim3((unsigned)std::min(n, (int)std::min<size_t>(4, (160 * 1024) / lds1) * (int)(cu_sh + 0.5)));
-#define LOIKB_LAUNCH_FLAT1(NAV)                                                                                                 \
-  hipLaunchKernelGGL((k_flat1<NAV>), grid, dim3(WAVE), lds1, C->stream, *reinterpret_cast<const Params<double>*>(&P),            \
-                     *reinterpret_cast<const Bufs<double>*>(&Bf), (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes,    \
-                     nanc, S->flat.nscan, S->flat.njmp, (const int*)C->d_ring, n, (const double*)C->d_fslots, frows, kexp_lo,    \
-                     ndec, (double)S->Href[0], has_hv)
-          if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA);
+          // (time slicing as in k_flat2, same window: whole body, four tasks, B = 65 536: 34.7 ms without)
+          const int resident = (int)grid.x, full = (int)std::min<size_t>(4, (160 * 1024) / lds1) * (int)(cu_sh + 0.5);
+          const int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice
+                              : (n_first >= 12 * resident && n_first <= 96 * resident && resident == full &&
+                                 !(S->opt.flags & LOIKB_OPT_OWN_STREAM)) ? 160 : 0;
+#define LOIKB_LAUNCH_FLAT1(NAV, ...)                                                                                            \
+  hipLaunchKernelGGL((k_flat1<NAV, ##__VA_ARGS__>), grid, dim3(WAVE), lds1, C->stream,                                          \
+                     *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
+                     (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
+                     (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv, C->ring_cap - 1, quantum)
+          if (quantum > 0) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, true); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, true); }
+          else if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL);
+          else LOIKB_LAUNCH_FLAT1(FLAT_MAXA);
 #undef LOIKB_LAUNCH_FLAT1
         } else {
 #define LOIKB_LAUNCH_FLAT(NAV, ...)                                                                                             \
