@@ -57,7 +57,8 @@ struct FlatLane {
   int jmp[FLAT_JMP];       // lane of the ancestor at distance 2^r, -1 = beyond the root
   int anc[FLAT_MAXA];      // lane of the ancestor at depth k + 1 (k < depth - 1), else -1
   int red[FLAT_RED];       // terms this lane sums: entry k * G + lane' of the product buffer (W_{anc_k(lane'), lane'} tau_lane'), -1 = none
-  int helper;              // 1: the sum is a partial of another joint's row (published in the partial buffer)
+  int helper;              // bit 0: the sum is a partial of another joint's row (published in the partial buffer); bits 8..: the
+                           // joint's column offset in a packed decade slot (fslotW_at)
   int part[FLAT_PART];     // lanes whose partials belong to this joint's row, -1 = none
 };
 
@@ -93,11 +94,18 @@ __host__ __device__ __forceinline__ size_t flat_lds_bytes(int nc, int G, bool a_
   return (n * sizeof(T) + 15) & ~(size_t)15;
 }
 
-// decade slot of an instance: frows = max(nanc + 1, 7) rows [k][lane]: W_{anc_k(lane), lane} for k < nanc, Dinv at k = nanc
-// (rows 0..6 hold UDinv / Dinv of the joint between the two passes of k_fslots)
-__device__ __forceinline__ size_t fslot_at(int idx, int ndec, int dsl, int G, int frows, int k, int jlane)
+// Decade slot of an instance: one block of `fblk` scalars per decade.  Between the two passes of k_fslots it holds UDinv / Dinv of
+// the joints as rows [k][lane], k < 7 (fslotA_at); pass B overwrites it with the joints' columns PACKED one after the other
+// (fslotW_at): joint j's column starts at col_j = sum_{i < j} depth_i and holds its depth_j - 1 entries W_{anc_k(j), j}, nearest
+// the root first, then Dinv_j -- 168 scalars for Talos-32 where a [10 rows][32 lanes] rectangle took 320 (the rows of a rectangle
+// beyond a joint's depth are zeros).  fblk = max(7 G, sum_j depth_j).  col_j travels in the upper bits of FlatLane::helper.
+__device__ __forceinline__ size_t fslotA_at(int idx, int ndec, int dsl, int fblk, int G, int k, int jlane)
 {
-  return ((((size_t)idx * ndec + dsl) * frows + k) * G) + jlane;
+  return ((size_t)idx * ndec + dsl) * fblk + (size_t)k * G + jlane;
+}
+__device__ __forceinline__ size_t fslotW_at(int idx, int ndec, int dsl, int fblk, int col)
+{
+  return ((size_t)idx * ndec + dsl) * fblk + col;
 }
 
 // (R, t) <- (Ra, ta) o (R, t): SE3 composition, the left factor being the transform of an ancestor frame
@@ -311,11 +319,13 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   int size;
   unsigned int jrow4[(FLAT_JMP + 3) / 4], ra2[FLAT_RED / 2], prow4[(FLAT_PART + 3) / 4], anc4[(NA + 3) / 4];
   bool helper;
+  int fcol, fdm1;  // this joint's column in a packed decade slot, its number of ancestors
   {
     // static rows / entries of this group's lanes; helper lanes may be lanes without a joint
     const FlatLane F = fl[jlane];
     size = isj_lane ? F.size : 0;
-    helper = F.helper != 0;
+    helper = (F.helper & 1) != 0;
+    fcol = F.helper >> 8; fdm1 = F.depth > 0 ? F.depth - 1 : 0;
 #pragma unroll
     for (int k = 0; k < (FLAT_JMP + 3) / 4; ++k) jrow4[k] = 0u;
 #pragma unroll
@@ -611,7 +621,8 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
           if (isj) {
             T in[NA + 1];
 #pragma unroll
-            for (int k = 0; k <= NA; ++k) in[k] = fslots[fslot_at(lidx, ndec, dsl, G, frows, k < nanc ? k : nanc, jlane)];  // (rows beyond the
+            for (int k = 0; k <= NA; ++k)
+              in[k] = (k == NA || k < fdm1) ? fslots[fslotW_at(lidx, ndec, dsl, frows, fcol + (k == NA ? fdm1 : k))] : T(0);  // (entries beyond the
             // tree's depth repeat the Dinv row: such a W entry only ever multiplies the zero behind the root)
 #pragma unroll
             for (int k = 0; k <= NA; ++k) wdst[k * WAVE + lane] = in[k];
@@ -1037,7 +1048,7 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
   const int jl = isj_lane ? jlane : 0;
   const int sidx = slots[has_inst ? idx : 0];
   char* ip = lane_ptr<T>(Bf.tiles, L, sidx);
-  int depth, arow[NA];
+  int depth, fcol, arow[NA];
   T Sw[6];
   bool has_parent;
   int cslot;
@@ -1046,6 +1057,7 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
     const JointDesc d = jd[jl + 1];
     const FlatLane F = fl[jlane];
     depth = isj_lane ? F.depth : 0;
+    fcol = F.helper >> 8;
     has_parent = !(d.flags & JF_PARENT_ROOT);
     cslot = isj_lane ? d.cslot : -1;
     unsigned int jrow4[(FLAT_JMP + 3) / 4] = {0u, 0u};
@@ -1144,8 +1156,8 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
 #pragma unroll
         for (int k = 0; k < 6; ++k) UD[k] = U[k] * dinv;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] = UD[k];
-        fslots[fslot_at(sidx, ndec, dsl, G, frows, 6, jlane)] = dinv;
+        for (int k = 0; k < 6; ++k) fslots[fslotA_at(sidx, ndec, dsl, frows, G, k, jlane)] = UD[k];
+        fslots[fslotA_at(sidx, ndec, dsl, frows, G, 6, jlane)] = dinv;
         if (has_parent) {
           T* x = xch + lane * HX;
 #pragma unroll
@@ -1165,8 +1177,8 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
   for (int dsl = 0; dsl < ndec; ++dsl) {
     T UDw[6], dinv = T(0);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) UDw[k] = isj ? fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] : T(0);
-    if (isj) dinv = fslots[fslot_at(sidx, ndec, dsl, G, frows, 6, jlane)];
+    for (int k = 0; k < 6; ++k) UDw[k] = isj ? fslots[fslotA_at(sidx, ndec, dsl, frows, G, k, jlane)] : T(0);
+    if (isj) dinv = fslots[fslotA_at(sidx, ndec, dsl, frows, G, 6, jlane)];
     T Lc[NA], Wc[NA];
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
@@ -1184,11 +1196,13 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
       for (int k2 = k + 1; k2 < NA; ++k2) acc += lb[k * WAVE + arow[k2]] * Wc[k2];
       Wc[k] = (k < depth - 1) ? -acc : T(0);
     }
+    tail_sync();  // (every lane of the instance has read its rows of this decade: the packed columns overwrite them)
     if (isj) {
+      const size_t base = fslotW_at(sidx, ndec, dsl, frows, fcol);
 #pragma unroll
       for (int k = 0; k < NA; ++k)
-        if (k < nanc) fslots[fslot_at(sidx, ndec, dsl, G, frows, k, jlane)] = Wc[k];
-      fslots[fslot_at(sidx, ndec, dsl, G, frows, nanc, jlane)] = dinv;
+        if (k < depth - 1) fslots[base + k] = Wc[k];
+      fslots[base + depth - 1] = dinv;
     }
   }
 }

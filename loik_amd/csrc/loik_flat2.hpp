@@ -226,7 +226,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const int jflags = jd[jl + 1].flags, jcslot = isj_lane ? jd[jl + 1].cslot : -1;
   const T mass = (!isj_lane || (jflags & JF_MASSLESS)) ? T(0) : T(1);
   const T hz = h ? T(0) : T(1);  // scalar-per-joint contributions to sums come from the linear lane only
-  int size;
+  int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
   bool helper;
   unsigned int jrow4[(FLAT_JMP + 3) / 4];  // load time: rows of the ancestors at distance 2^r in joint-indexed rows (WAVE = identity)
   unsigned int pathA, pathB;               // iteration: the ancestors at distance 1, 2, 3 / 4, 8, 12: their lanes of this half
@@ -235,7 +235,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   {
     const FlatLane F = fl[j];
     size = isj_lane ? F.size : 0;
-    helper = F.helper != 0;
+    helper = (F.helper & 1) != 0;
+    fcol = F.helper >> 8; fdm1 = F.depth > 0 ? F.depth - 1 : 0;
 #pragma unroll
     for (int k = 0; k < (FLAT_JMP + 3) / 4; ++k) jrow4[k] = 0u;
     flat_path_rows4(fl, j, h ? 32 : 0, pathA, pathB, pathC);
@@ -622,7 +623,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
           for (int i = 0; i <= NH; ++i) {
             const int k = 2 * i + (h ? 1 : 0);
-            in[i] = (isj && k <= NA) ? fslots[fslot_at(lidx, ndec, dsl, G, frows, k < nanc ? k : nanc, j)] : T(0);
+            in[i] = (isj && (k == NA || k < fdm1)) ? fslots[fslotW_at(lidx, ndec, dsl, frows, fcol + (k == NA ? fdm1 : k))] : T(0);
           }
           tail_sync();
 #pragma unroll
@@ -1033,7 +1034,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const int jl = isj_lane ? j : 0;
   const int jflags = jd[jl + 1].flags, jcslot = isj_lane ? jd[jl + 1].cslot : -1;
   const T mass = (!isj_lane || (jflags & JF_MASSLESS)) ? T(0) : T(1);
-  int size;
+  int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
   bool helper;
   unsigned int jrow4[(FLAT_JMP + 3) / 4], ra2[FLAT_RED / 2], prow4[(FLAT_PART + 3) / 4], anc4[(NA + 3) / 4];
   unsigned int pathA, pathB;
@@ -1042,7 +1043,8 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   {
     const FlatLane F = fl[j];
     size = isj_lane ? F.size : 0;
-    helper = F.helper != 0;
+    helper = (F.helper & 1) != 0;
+    fcol = F.helper >> 8; fdm1 = F.depth > 0 ? F.depth - 1 : 0;
 #pragma unroll
     for (int k = 0; k < (FLAT_JMP + 3) / 4; ++k) jrow4[k] = 0u;
 #pragma unroll
@@ -1377,7 +1379,8 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
           T* wdst = wl + (size_t)wsel * (NA + 1) * G;
           T in[NA + 1];
 #pragma unroll
-          for (int k = 0; k <= NA; ++k) in[k] = isj ? fslots[fslot_at(lidx, ndec, dsl, G, frows, k < nanc ? k : nanc, lane)] : T(0);
+          for (int k = 0; k <= NA; ++k)
+            in[k] = (isj && (k == NA || k < fdm1)) ? fslots[fslotW_at(lidx, ndec, dsl, frows, fcol + (k == NA ? fdm1 : k))] : T(0);
 #pragma unroll
           for (int k = 0; k <= NA; ++k) wdst[k * G + lane] = in[k];
           kslot = kexp;

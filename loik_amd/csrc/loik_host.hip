@@ -156,6 +156,7 @@ struct loikb_solver_impl {
     bool ok = false;
     const char* why = "";
     int G = 0, nanc = 0, nscan = 0, njmp = 0;
+    int fblk = 0;  // scalars per decade slot of an instance: max(7 G, sum of the joints' depths)
     std::vector<FlatLane> lanes;
     FlatLane* d_lanes = nullptr;
   } flat;
@@ -713,6 +714,13 @@ void build_flat_schedule(const std::vector<int>& parents, loikb_solver_impl::Fla
     }
   }
   out.G = G; out.nanc = std::max(1, maxdepth - 1); out.nscan = nscan; out.njmp = njmp;
+  // packed decade slots (fslotW_at, loik_flat.hpp): joint j's column starts at the sum of the depths before it
+  int col = 0;
+  for (int l = 0; l < G; ++l) {
+    out.lanes[l].helper |= col << 8;
+    col += out.lanes[l].depth;
+  }
+  out.fblk = (std::max(FSLOT_ROWS * G, col) + 1) & ~1;
   out.ok = true;
 }
 
@@ -1044,8 +1052,8 @@ int ensure_hslots(loikb_solver_impl* S)
   if (S->plan.flat && (flat_applicable(S) || !S->have_problem)) {
     // decade slots of the flat engine: (ancestors + 1) scalars per lane, decade and instance
     for (Chunk& C : S->chunks) {
-      const int frows = std::max(S->flat.nanc + 1, FSLOT_ROWS);
-      const size_t need = (size_t)C.B * S->plan.ndec * frows * S->flat.G * S->esz;
+      const int frows = S->flat.fblk;  // (scalars per decade slot)
+      const size_t need = (size_t)C.B * S->plan.ndec * frows * S->esz;
       if (need <= C.fslots_bytes) continue;
       if (C.d_fslots) HIPCHK(hipFree(C.d_fslots));
       C.d_fslots = nullptr; C.fslots_bytes = 0;
@@ -1054,7 +1062,7 @@ int ensure_hslots(loikb_solver_impl* S)
         char buf[400];
         snprintf(buf, sizeof(buf), "the flat engine needs %.2f GB of decade slots for %d instances (%d decades x %d rows x %d lanes x %d B) "
                  "and the device has no room for them: create the solver with a smaller batch, or set LOIKB_FLAT=0 LOIKB_LEAN=0 to use "
-                 "the k_solve + k_tail engines, which need none", need / 1e9, C.B, S->plan.ndec, frows, S->flat.G, (int)S->esz);
+                 "the k_solve + k_tail engines, which need none", need / 1e9, C.B, S->plan.ndec, frows / S->flat.G, S->flat.G, (int)S->esz);
         g_last_error = buf;
         return LOIKB_ERR_HIP;
       }
@@ -1539,8 +1547,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     if (flat_ok) {
       const int nanc = S->flat.nanc;
       const bool small_na = nanc <= FLAT_NA_SMALL;
-      const int frows = std::max(nanc + 1, FSLOT_ROWS);
-      const size_t need = (size_t)n_cur * ndec * frows * G * sizeof(T);
+      const int frows = S->flat.fblk;  // (scalars per decade slot of an instance, packed columns: loik_flat.hpp)
+      const size_t need = (size_t)n_cur * ndec * frows * sizeof(T);
       if (need > C->fslots_bytes) { g_last_error = "internal: decade-slot buffer of the flat engine smaller than the chunk"; return LOIKB_ERR_STATE; }
       const int has_hv = S->Hv_inf_norm != 0.0;
       const size_t flds = small_na ? flat_lds_bytes<T, FLAT_NA_SMALL>(S->nc, G, S->a_shared, has_hv) : flat_lds_bytes<T, FLAT_MAXA>(S->nc, G, S->a_shared, has_hv);
@@ -2240,6 +2248,7 @@ int loikb_flat_schedule(const int* parents, int njoints, int* out, int cap, int*
   static_assert(sizeof(FlatLane) == sizeof(int) * (2 + FLAT_JMP + FLAT_MAXA + FLAT_RED + 1 + FLAT_PART), "FlatLane is a plain int record");
   if (!out || cap < fs.G * W) return fs.G * W;
   memcpy(out, fs.lanes.data(), sizeof(FlatLane) * fs.lanes.size());
+  for (int l = 0; l < fs.G; ++l) out[l * W + (int)(offsetof(FlatLane, helper) / sizeof(int))] &= 1;  // (the upper bits are internal)
   return LOIKB_OK;
 }
 
