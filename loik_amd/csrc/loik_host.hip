@@ -1565,7 +1565,9 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
       {
         const dim3 hgrid((unsigned)((n + ipw - 1) / ipw));
-        const size_t slds = ((size_t)(WAVE + 1) * 28 + (size_t)ipw * S->nc * 21 + (size_t)((small_na ? FLAT_NA_SMALL : FLAT_MAXA) + 1) * WAVE) * sizeof(T);
+        // [65][22] exchange rows (pass B's L columns, [NA + 1][64], live in them afterwards) + [65][6] S^w + the constraints' A^T A
+        const size_t slds = (std::max((size_t)(WAVE + 1) * 22, (size_t)((small_na ? FLAT_NA_SMALL : FLAT_MAXA) + 1) * WAVE) + (size_t)(WAVE + 1) * 6 +
+                             (size_t)ipw * S->nc * 21) * sizeof(T);
         if (small_na)
           hipLaunchKernelGGL((k_fslots<T, FLAT_NA_SMALL>), hgrid, dim3(WAVE), slds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                              (const TailTopo*)S->d_topo, (const int*)S->d_child_list, (const FlatLane*)S->flat.d_lanes, S->maxdepth,
