@@ -39,6 +39,7 @@ inline int joint_type_of(const std::string& n)
       {"JointModelSphericalZYX", LOIKB_J_SPHERICAL_ZYX}, // nq 3 (z, y, x angles), nv 3
       {"JointModelPlanar", LOIKB_J_PLANAR},              // nq 4 (x, y, cos, sin), nv 3
       {"JointModelRUBX", LOIKB_J_RUBX}, {"JointModelRUBY", LOIKB_J_RUBY}, {"JointModelRUBZ", LOIKB_J_RUBZ},  // nq 2 (cos, sin)
+      {"JointModelRevoluteUnboundedUnaligned", LOIKB_J_RUBU},  // nq 2 (cos, sin), axis from axis_of
       {"JointModelComposite", LOIKB_J_COMPOSITE},        // of 1-DoF joints: loikb_model_desc.comp_*
   };
   for (const auto& e : table)
@@ -82,9 +83,9 @@ Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joint
     const int t = i ? joint_type_of(n) : LOIKB_J_NONE;
     if (i && t == LOIKB_J_NONE)
       throw std::runtime_error("loik_amd: joint type '" + n + "' of joint '" + m.names[i] +
-                               "' is not supported (mimic, helical, universal, unbounded-unaligned)");
+                               "' is not supported (mimic, helical, universal)");
     double ax[3] = {0.0, 0.0, 0.0};
-    if (t == LOIKB_J_RU || t == LOIKB_J_PU) {
+    if (t == LOIKB_J_RU || t == LOIKB_J_PU || t == LOIKB_J_RUBU) {
       const auto a = axis_of(m.joints[i], n);
       for (int k = 0; k < 3; ++k) ax[k] = a[k];
     }
@@ -95,11 +96,11 @@ Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joint
       for (const auto& sub : sub_joints_of(m.joints[i])) {
         const std::string sn = sub.first.shortname();
         const int st = joint_type_of(sn);
-        const bool one_dof = (st >= LOIKB_J_RX && st <= LOIKB_J_PU) || (st >= LOIKB_J_RUBX && st <= LOIKB_J_RUBZ);
+        const bool one_dof = (st >= LOIKB_J_RX && st <= LOIKB_J_PU) || (st >= LOIKB_J_RUBX && st <= LOIKB_J_RUBZ) || st == LOIKB_J_RUBU;
         if (!one_dof)
           throw std::runtime_error("loik_amd: sub-joint '" + sn + "' of the composite joint '" + m.names[i] + "' is not a 1-DoF joint");
         double sa[3] = {0.0, 0.0, 0.0};
-        if (st == LOIKB_J_RU || st == LOIKB_J_PU) {
+        if (st == LOIKB_J_RU || st == LOIKB_J_PU || st == LOIKB_J_RUBU) {
           const auto a = axis_of(sub.first, sn);
           for (int k = 0; k < 3; ++k) sa[k] = a[k];
         }

@@ -11,7 +11,7 @@
  * Joints: all of Pinocchio's 1-DoF types (incl. the unbounded revolute joints with q = (cos, sin)), the multi-DoF types
  * whose motion subspace is a constant selection of the columns of I6 -- free-flyer (floating base), spherical, translation,
  * planar --, JointModelSphericalZYX, whose q-dependent subspace is that of a Z-Y-X revolute chain, and
- * JointModelComposite of 1-DoF sub-joints (LOIKB_J_COMPOSITE + the comp_* arrays below).  Not covered: JointModelMimic, composites
+ * JointModelComposite of 1-DoF sub-joints (LOIKB_J_COMPOSITE + the comp_* arrays below).  Not covered: JointModelMimic, helical and universal joints, composites
  * with multi-DoF sub-joints.  On the device a multi-DoF
  * joint is a chain of 1-DoF joints with massless links in between; the caller never sees that: q, z / nu / w / lb / ub
  * (length model.nv, Pinocchio's idx_v order) and the per-link results are the caller's model's.
@@ -48,6 +48,9 @@ enum {
                               sub-joints, coordinates in sub-joint order.  M = prod_k (placement_k * M_k(q_k)), the motion
                               subspace column of sub-joint k is its S_k seen from the last sub-joint's frame (q-dependent);
                               on the device it is the chain of its sub-joints with massless links in between                */
+  ,
+  LOIKB_J_RUBU = 18        /* JointModelRevoluteUnboundedUnaligned: nq 2 (cos, sin), nv 1, about `axis` (also as a sub-joint of a
+                              composite)                                                                                    */
 };
 
 typedef struct loikb_model_desc {

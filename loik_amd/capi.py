@@ -203,7 +203,8 @@ J_FREEFLYER, J_SPHERICAL, J_TRANSLATION = 9, 10, 11
 # JointModelSphericalZYX, JointModelPlanar, JointModelRUBX / RUBY / RUBZ
 J_SPHERICAL_ZYX, J_PLANAR, J_RUBX, J_RUBY, J_RUBZ = 12, 13, 14, 15, 16
 J_COMPOSITE = 17  # JointModelComposite of 1-DoF joints (Model(..., composite={joint: [(jtype, axis, placement12), ...]}))
-JOINT_NQ = {J_FREEFLYER: 7, J_SPHERICAL: 4, J_TRANSLATION: 3, J_SPHERICAL_ZYX: 3, J_PLANAR: 4, J_RUBX: 2, J_RUBY: 2, J_RUBZ: 2}
+J_RUBU = 18       # JointModelRevoluteUnboundedUnaligned: nq 2 (cos, sin), nv 1, about `axis`
+JOINT_NQ = {J_FREEFLYER: 7, J_SPHERICAL: 4, J_TRANSLATION: 3, J_SPHERICAL_ZYX: 3, J_PLANAR: 4, J_RUBX: 2, J_RUBY: 2, J_RUBZ: 2, J_RUBU: 2}
 JOINT_NV = {J_FREEFLYER: 6, J_SPHERICAL: 3, J_TRANSLATION: 3, J_SPHERICAL_ZYX: 3, J_PLANAR: 3}
 
 
@@ -275,14 +276,14 @@ class Model:
                 o = int(self.idx_q[i]) + (3 if t == J_FREEFLYER else 0)
                 qt = rng.normal(size=(batch, 4))
                 q[:, o:o + 4] = qt / np.linalg.norm(qt, axis=1, keepdims=True)
-            elif t in (J_PLANAR, J_RUBX, J_RUBY, J_RUBZ):  # the (cos, sin) pair of a random angle
+            elif t in (J_PLANAR, J_RUBX, J_RUBY, J_RUBZ, J_RUBU):  # the (cos, sin) pair of a random angle
                 o = int(self.idx_q[i]) + (2 if t == J_PLANAR else 0)
                 th = rng.uniform(-np.pi, np.pi, size=batch)
                 q[:, o] = np.cos(th); q[:, o + 1] = np.sin(th)
             elif t == J_COMPOSITE:
                 o = int(self.idx_q[i])
                 for st, _, _ in self.composite[i]:
-                    if st in (J_RUBX, J_RUBY, J_RUBZ):
+                    if st in (J_RUBX, J_RUBY, J_RUBZ, J_RUBU):
                         th = rng.uniform(-np.pi, np.pi, size=batch)
                         q[:, o] = np.cos(th); q[:, o + 1] = np.sin(th)
                     o += JOINT_NQ.get(st, 1)

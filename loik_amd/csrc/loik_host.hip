@@ -475,10 +475,10 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
   if (enj < 2) { g_last_error = "model: no joints"; return LOIKB_ERR_MODEL; }
   // JointModelComposite: the sub-joints of joint i (validated below)
   auto comp_n = [&](int i) { return (m->jtype[i] == LOIKB_J_COMPOSITE && m->comp_count) ? m->comp_count[i] : 0; };
-  auto sub_nq = [](int st) { return (st >= LOIKB_J_RUBX && st <= LOIKB_J_RUBZ) ? 2 : 1; };
+  auto sub_nq = [](int st) { return ((st >= LOIKB_J_RUBX && st <= LOIKB_J_RUBZ) || st == LOIKB_J_RUBU) ? 2 : 1; };
   auto jt_nq = [](int jt) {
     return jt == LOIKB_J_FREEFLYER ? 7 : (jt == LOIKB_J_SPHERICAL || jt == LOIKB_J_PLANAR) ? 4
-           : (jt == LOIKB_J_TRANSLATION || jt == LOIKB_J_SPHERICAL_ZYX) ? 3 : (jt >= LOIKB_J_RUBX && jt <= LOIKB_J_RUBZ) ? 2 : 1;
+           : (jt == LOIKB_J_TRANSLATION || jt == LOIKB_J_SPHERICAL_ZYX) ? 3 : ((jt >= LOIKB_J_RUBX && jt <= LOIKB_J_RUBZ) || jt == LOIKB_J_RUBU) ? 2 : 1;
   };
   auto jt_nv = [](int jt) {
     return jt == LOIKB_J_FREEFLYER ? 6
@@ -490,9 +490,9 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
     for (int i = 1; i < enj; ++i) {
       const int p = m->parents[i], jt = m->jtype[i];
       if (p < 0 || p >= i) { g_last_error = "model: parents[i] must be < i"; return LOIKB_ERR_MODEL; }
-      if (jt < LOIKB_J_RX || jt > LOIKB_J_COMPOSITE) {
+      if (jt < LOIKB_J_RX || jt > LOIKB_J_RUBU) {
         g_last_error = "model: unsupported joint type (supported: 1-DoF joints incl. unbounded revolute, free-flyer, spherical, "
-                       "spherical ZYX, translation, planar, composites of 1-DoF joints; not: mimic)";
+                       "spherical ZYX, translation, planar, composites of 1-DoF joints; not: mimic, helical, universal)";
         return LOIKB_ERR_MODEL;
       }
       if (m->idx_q[i] != iq || m->idx_v[i] != iv) {
@@ -507,7 +507,7 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
         }
         for (int k = 0; k < m->comp_count[i]; ++k) {
           const int st = m->comp_jtype[m->comp_first[i] + k];
-          const bool one_dof = (st >= LOIKB_J_RX && st <= LOIKB_J_PU) || (st >= LOIKB_J_RUBX && st <= LOIKB_J_RUBZ);
+          const bool one_dof = (st >= LOIKB_J_RX && st <= LOIKB_J_PU) || (st >= LOIKB_J_RUBX && st <= LOIKB_J_RUBZ) || st == LOIKB_J_RUBU;
           if (!one_dof) { g_last_error = "model: the sub-joints of a composite joint must be 1-DoF joints"; return LOIKB_ERR_MODEL; }
           iq += sub_nq(st); iv += 1;
         }
@@ -551,7 +551,8 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
         // JointModelComposite: literally the chain of its sub-joints, each with its own placement and coordinate; the bodies
         // between them do not exist (massless), the last one carries the composite's body
         sub = m->comp_jtype[ce];
-        if (sub >= LOIKB_J_RUBX) { sub = LOIKB_J_RX + (sub - LOIKB_J_RUBX); flags |= JF_CS_DIRECT; }
+        if (sub == LOIKB_J_RUBU) { sub = LOIKB_J_RU; flags |= JF_CS_DIRECT; }
+        else if (sub >= LOIKB_J_RUBX) { sub = LOIKB_J_RX + (sub - LOIKB_J_RUBX); flags |= JF_CS_DIRECT; }
       } else if (jt == LOIKB_J_SPHERICAL_ZYX) {
         // R = Rz(q0) Ry(q1) Rx(q2), nu = the three angle rates: literally a chain of three revolute joints about z, y, x
         // with their own coordinates (S(q) of JointModelSphericalZYX::calc is this chain's Jacobian) and massless links
@@ -560,6 +561,9 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
         sub = k == 0 ? LOIKB_J_PX : k == 1 ? LOIKB_J_PY : LOIKB_J_RZ;  // ConstraintPlanar: vx, vy, wz of ONE frame
       } else if (jt >= LOIKB_J_RUBX && jt <= LOIKB_J_RUBZ) {
         sub = LOIKB_J_RX + (jt - LOIKB_J_RUBX);
+        flags |= JF_CS_DIRECT;
+      } else if (jt == LOIKB_J_RUBU) {  // JointModelRevoluteUnboundedUnaligned: a revolute joint about `axis` whose q IS (cos, sin)
+        sub = LOIKB_J_RU;
         flags |= JF_CS_DIRECT;
       } else if (n > 1) {
         // chain joint k: prismatic along / revolute about axis (k mod 3) of the joint frame

@@ -11,6 +11,7 @@ import numpy as np
 J_RX, J_RY, J_RZ, J_PX, J_PY, J_PZ, J_RU, J_PU = 1, 2, 3, 4, 5, 6, 7, 8
 J_FREEFLYER, J_SPHERICAL, J_TRANSLATION = 9, 10, 11
 J_SPHERICAL_ZYX, J_PLANAR, J_RUBX, J_RUBY, J_RUBZ = 12, 13, 14, 15, 16
+J_RUBU = 18
 
 # the reference fixture's solver parameters, /root/reference/tests/loik-loid.cpp:91-105
 FIXTURE_PARAMS = dict(tol_primal_inf=1e-2, tol_dual_inf=1e-2, tol_tail_solve=1e-1, rho=1e-5, mu=1e-2,
@@ -68,7 +69,7 @@ class _Chain:
                     parents.append(par if k == 0 else len(parents) - 1)
                     jtype.append(int(st)); axis.append(np.asarray(a, dtype=float)); placement.append(P)
                     idx_q.append(iq); idx_v.append(iv)
-                    iq += 2 if st in (J_RUBX, J_RUBY, J_RUBZ) else 1
+                    iq += 2 if st in (J_RUBX, J_RUBY, J_RUBZ, J_RUBU) else 1
                     iv += 1
             self.link_of.append(len(parents) - 1)
         self.njoints = len(parents)
@@ -124,9 +125,9 @@ def link_velocity(model, q, nu, link):
             d = lin - np.cross(t, ang)
             v = np.concatenate([np.einsum("bji,bj->bi", R, d), np.einsum("bji,bj->bi", R, ang)], axis=1) + dv
             continue
-        if jt in (J_RUBX, J_RUBY, J_RUBZ):  # JointModelRevoluteUnbounded: q = (cos, sin)
+        if jt in (J_RUBX, J_RUBY, J_RUBZ, J_RUBU):  # JointModelRevoluteUnbounded(Unaligned): q = (cos, sin)
             qi = np.arctan2(q[:, iq + 1], q[:, iq])
-            jt = J_RX + (jt - J_RUBX)
+            jt = J_RU if jt == J_RUBU else J_RX + (jt - J_RUBX)
         if jt in (J_FREEFLYER, J_SPHERICAL, J_TRANSLATION):
             # M(q) = (R(quat), t) ; S = I6 | [0; I3] | [I3; 0]: the joint velocity is added in the child frame
             Rj = quat_rot(q[:, iq + 3:iq + 7]) if jt == J_FREEFLYER else (

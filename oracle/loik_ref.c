@@ -197,7 +197,7 @@ static int joint_nq(int jtype)
   case REF_J_TRANSLATION: return 3;
   case REF_J_SPHERICAL_ZYX: return 3;
   case REF_J_PLANAR: return 4;
-  case REF_J_RUBX: case REF_J_RUBY: case REF_J_RUBZ: return 2;
+  case REF_J_RUBX: case REF_J_RUBY: case REF_J_RUBZ: case REF_J_RUBU: return 2;
   default: return 1;
   }
 }
@@ -257,6 +257,9 @@ static void joint_calc(int jtype, const double *axis, const double *qs, double *
   if (jtype == REF_J_RUBX || jtype == REF_J_RUBY || jtype == REF_J_RUBZ) { /* JointModelRevoluteUnbounded: q = (cos, sin) */
     c = qs[0]; s = qs[1];
     jtype = REF_J_RX + (jtype - REF_J_RUBX);
+  } else if (jtype == REF_J_RUBU) { /* JointModelRevoluteUnboundedUnaligned: the same about an arbitrary axis */
+    c = qs[0]; s = qs[1];
+    jtype = REF_J_RU;
   }
   switch (jtype) {
   case REF_J_RX:
@@ -295,6 +298,7 @@ static void joint_S(int jtype, const double *axis, const double *qs, double *S)
   case REF_J_RUBX: S[3] = 1.0; break;
   case REF_J_RUBY: S[4] = 1.0; break;
   case REF_J_RUBZ: S[5] = 1.0; break;
+  case REF_J_RUBU: S[3] = axis[0]; S[4] = axis[1]; S[5] = axis[2]; break;
   case REF_J_PLANAR: S[0] = 1.0; S[6 + 1] = 1.0; S[12 + 5] = 1.0; break;               /* ConstraintPlanar: vx, vy, wz */
   case REF_J_SPHERICAL_ZYX: {  /* S.angularSubspace() << -s1, 0, 1,  c1 s2, c2, 0,  c1 c2, -s2, 0 (rows) */
     const double q1 = qs ? qs[1] : 0.0, q2 = qs ? qs[2] : 0.0;

@@ -71,7 +71,8 @@ static const char* short_name(int t)
   static const char* names[] = {"", "JointModelRX", "JointModelRY", "JointModelRZ", "JointModelPX", "JointModelPY", "JointModelPZ",
                                 "JointModelRevoluteUnaligned", "JointModelPrismaticUnaligned", "JointModelFreeFlyer",
                                 "JointModelSpherical", "JointModelTranslation", "JointModelSphericalZYX", "JointModelPlanar",
-                                "JointModelRUBX", "JointModelRUBY", "JointModelRUBZ", "JointModelComposite"};
+                                "JointModelRUBX", "JointModelRUBY", "JointModelRUBZ", "JointModelComposite",
+                                "JointModelRevoluteUnboundedUnaligned"};
   return names[t];
 }
 
@@ -126,7 +127,7 @@ static void round_trip(const Model& m)
   for (int i = 1; i < m.njoints; ++i)
     for (int k = 0; k < 3; ++k) {
       // aligned joints carry no axis in Pinocchio: the adapter leaves it zero, the library derives it from the type
-      const bool unaligned = m.jtype[i] == LOIKB_J_RU || m.jtype[i] == LOIKB_J_PU;
+      const bool unaligned = m.jtype[i] == LOIKB_J_RU || m.jtype[i] == LOIKB_J_PU || m.jtype[i] == LOIKB_J_RUBU;
       CHECK(o.axis[3 * i + k] == (unaligned ? m.axis[3 * i + k] : 0.0));
     }
 }
@@ -137,8 +138,8 @@ int main()
   {  // a model with every joint type, unaligned axes, rotated placements
     Model m;
     const int types[] = {LOIKB_J_NONE, LOIKB_J_FREEFLYER, LOIKB_J_RU, LOIKB_J_PU, LOIKB_J_SPHERICAL, LOIKB_J_TRANSLATION,
-                         LOIKB_J_SPHERICAL_ZYX, LOIKB_J_PLANAR, LOIKB_J_RUBY, LOIKB_J_PZ, LOIKB_J_RX, LOIKB_J_COMPOSITE};
-    const int nqs[] = {0, 7, 1, 1, 4, 3, 3, 4, 2, 1, 1, 4}, nvs[] = {0, 6, 1, 1, 3, 3, 3, 3, 1, 1, 1, 3};
+                         LOIKB_J_SPHERICAL_ZYX, LOIKB_J_PLANAR, LOIKB_J_RUBY, LOIKB_J_PZ, LOIKB_J_RUBU, LOIKB_J_COMPOSITE};
+    const int nqs[] = {0, 7, 1, 1, 4, 3, 3, 4, 2, 1, 2, 4}, nvs[] = {0, 6, 1, 1, 3, 3, 3, 3, 1, 1, 1, 3};
     m.njoints = 12;
     for (int i = 0; i < m.njoints; ++i) {
       m.parents.push_back(i ? (i - 1) / 2 : 0);
@@ -147,7 +148,7 @@ int main()
       m.nq += nqs[i]; m.nv += nvs[i];
       const double a[3] = {std::sin(1.0 + i), std::cos(2.0 * i), 0.3};
       const double n = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-      const bool un = types[i] == LOIKB_J_RU || types[i] == LOIKB_J_PU;
+      const bool un = types[i] == LOIKB_J_RU || types[i] == LOIKB_J_PU || types[i] == LOIKB_J_RUBU;
       for (int k = 0; k < 3; ++k) m.axis.push_back(un ? a[k] / n : 0.0);
       const double c = std::cos(0.3 * i), s = std::sin(0.3 * i);
       const double P[12] = {c, -s, 0, s, c, 0, 0, 0, 1, 0.1 * i, -0.2, 0.05 * i};  // Rz(0.3 i): not symmetric -> order matters

@@ -116,10 +116,11 @@ CHAIN_TYPES = {J_FREEFLYER: [4, 5, 6, 1, 2, 3], J_SPHERICAL: [1, 2, 3], J_TRANSL
 
 
 J_SPHERICAL_ZYX, J_PLANAR, J_RUBX, J_RUBY, J_RUBZ = 12, 13, 14, 15, 16
+J_RUBU = 18   # JointModelRevoluteUnboundedUnaligned
 
 
 def random_tree_multidof(seed, nb, root_freeflyer=True, n_spherical=1, n_translation=1, branch_prob=0.3, n_zyx=0, n_planar=0,
-                         n_rub=0, root_planar=False):
+                         n_rub=0, root_planar=False, n_rubu=0):
     """random_tree() with some joints replaced by multi-DoF ones (optionally a free-flyer root joint: the
     floating-base case of SURVEY.md 8(f) rank 2)"""
     m = random_tree(seed, nb, branch_prob=branch_prob)
@@ -140,9 +141,14 @@ def random_tree_multidof(seed, nb, root_freeflyer=True, n_spherical=1, n_transla
         jt[i] = J_PLANAR
     for n_, i in enumerate(cand[k + n_zyx + n_planar:k + n_zyx + n_planar + n_rub]):
         jt[i] = J_RUBX + n_ % 3
+    axis = np.array(m.axis, dtype=float).copy()
+    for i in cand[k + n_zyx + n_planar + n_rub:k + n_zyx + n_planar + n_rub + n_rubu]:
+        jt[i] = J_RUBU
+        a = rng.normal(size=3)
+        axis[i] = a / np.linalg.norm(a)   # an axis aligned with nothing
     if root_planar:
         jt[1] = J_PLANAR
-    return loik_amd.Model(m.parents, jt, m.axis, m.placement, name="random_multidof_%d_%d" % (seed, nb))
+    return loik_amd.Model(m.parents, jt, axis, m.placement, name="random_multidof_%d_%d" % (seed, nb))
 
 
 def expand_to_chains(model, q):
@@ -306,10 +312,10 @@ def composite_tree(seed, nb, which, kinds=None):
     for n_, i in enumerate(which):
         jt[i] = J_COMPOSITE_
         subs = []
-        types = kinds[n_] if kinds else [int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, J_RUBY]))
+        types = kinds[n_] if kinds else [int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, J_RUBY, J_RUBU]))
                                          for _ in range(int(rng.integers(2, 5)))]
         for t in types:
-            a = _unit(rng) if t in (7, 8) else np.zeros(3)
+            a = _unit(rng) if t in (7, 8, J_RUBU) else np.zeros(3)
             P = np.concatenate([random_rotation(rng).ravel(), rng.uniform(-0.3, 0.3, size=3)])
             subs.append((t, a, P))
         comp[i] = subs

@@ -301,7 +301,9 @@ def test_gpu_integrate_on_the_configuration_manifold():
 # ---- JointModelSphericalZYX (q-dependent motion subspace), JointModelPlanar, JointModelRUBX/Y/Z --------------------------------
 NEW_CASES = [dict(seed=21, nb=8, root_freeflyer=False, n_spherical=0, n_translation=0, n_zyx=2, n_rub=2),
              dict(seed=22, nb=10, root_freeflyer=False, n_spherical=1, n_translation=0, n_zyx=1, n_planar=1, n_rub=1, root_planar=True),
-             dict(seed=23, nb=13, root_freeflyer=True, n_spherical=0, n_translation=1, n_zyx=2, n_planar=1, n_rub=3)]
+             dict(seed=23, nb=13, root_freeflyer=True, n_spherical=0, n_translation=1, n_zyx=2, n_planar=1, n_rub=3),
+             # JointModelRevoluteUnboundedUnaligned (LOIKB_J_RUBU): (cos, sin) about an arbitrary axis
+             dict(seed=24, nb=11, root_freeflyer=False, n_spherical=1, n_translation=0, n_zyx=0, n_planar=0, n_rub=1, n_rubu=3)]
 
 
 @pytest.mark.parametrize("case", NEW_CASES, ids=lambda c: "seed%d" % c["seed"])
