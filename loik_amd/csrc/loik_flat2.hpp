@@ -195,7 +195,11 @@ __host__ __device__ __forceinline__ size_t flat2_lds_bytes(int nc, bool has_hv)
 // different XCDs, whose L2s are not coherent with each other) and is accessed with agent-scope loads / stores.  Iteration counts
 // are heavy-tailed and unknown in advance: run to completion in arrival order, the 999-iteration instances fetched late keep
 // the launch alive for 3 ms after the queue ran dry (27 % of it); time-sliced, every long runner advances from the start.
-template <int NA, int WPE, bool SLICED = false>
+// HD: a DIAGONAL reference weight H_ref = diag(d_1 .. d_6), the same for every link (e.g. other weights on the angular than on the
+// linear velocity), instead of h I.  H_ref v then is no multiple of the link's velocity as a force at the world origin: the link
+// velocities are weighted in the link frame (d * v, three multiplications per lane), carried to the world origin and summed
+// over the subtrees beside E -- three more prefix sums and one more frame change per iteration.
+template <int NA, int WPE, bool SLICED = false, bool HD = false>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
         int nscan, int njmp, int* ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
@@ -226,6 +230,9 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const int jflags = jd[jl + 1].flags, jcslot = isj_lane ? jd[jl + 1].cslot : -1;
   const T mass = (!isj_lane || (jflags & JF_MASSLESS)) ? T(0) : T(1);
   const T hz = h ? T(0) : T(1);  // scalar-per-joint contributions to sums come from the linear lane only
+  T hd[3];  // this half's diagonal entries of H_ref (HD; = href_s otherwise)
+#pragma unroll
+  for (int k = 0; k < 3; ++k) hd[k] = HD ? (h ? P.Href[7 * (3 + k)] : P.Href[7 * k]) : href_s;
   int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
   bool helper;
   unsigned int jrow4[(FLAT_JMP + 3) / 4];  // load time: rows of the ancestors at distance 2^r in joint-indexed rows (WAVE = identity)
@@ -738,7 +745,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T l_dg = T(0), l_g = T(0), l_stf = T(0), l_dstf = T(0), l_dualv = T(0);
     T fi3[3], si;
     {
-      T SEn[3], Fw[3];
+      T SEn[3], SHn[3], Fw[3];  // (SHn: HD only -- the subtree sums of the links' H_ref v at the world origin)
       // ---- the task constraints' update: (A v - b, dy, y), then (A^T y, the same at the world origin, the pieces of this
       // iteration's force balance): two dependent exchanges through the constraint block in LDS (lane 6 c + k owns row k)
       tail_sync();
@@ -775,11 +782,32 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         const int src = lane + (size > 0 ? size - 1 : 0);
         // (the prefix at the subtree's last joint comes through LDS rows, free at this point: ds_bpermute -- no write, no fence --
         //  measured 1.5 % slower on the headline and 2 % on a lone instance)
+        T E2[3], P2[3];
+        if constexpr (HD) {
+          // the link's weighted velocity H_ref v (link frame) as a force at the world origin: (R0 f_l, R0 f_a + t0 x R0 f_l)
+          T fl[3], y3[3], L3[3], A3[3], cc[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) fl[k] = mass * (hd[k] * vi3[k]);
+          mat3_vec(R0, fl, y3);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) both_halves(y3[k], L3[k], A3[k]);
+          cross3(t0, L3, cc);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { E2[k] = h ? y3[k] + cc[k] : y3[k]; P2[k] = prefix32(E2[k]); }
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) xb[lane * 3 + c] = Pk[c];
+        if constexpr (HD) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) xb[(WAVE + 1) * 3 + lane * 3 + c] = P2[c];
+        }
         tail_sync();
 #pragma unroll
         for (int c = 0; c < 3; ++c) SEn[c] = (xb[src * 3 + c] - Pk[c]) + E3[c];
+        if constexpr (HD) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) SHn[c] = (xb[(WAVE + 1) * 3 + src * 3 + c] - P2[c]) + E2[c];
+        }
       }
       tail_sync();
       if (iscl) {
@@ -806,7 +834,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         for (int k = 0; k < 3; ++k) {
           dv[k] = vi3[k] - v3[k];
           // g_i = A^T y_i + sum_children act(f_c) - f_i = A^T y_i - (H^base_i v_i + p^base_i)  (force balance)
-          gi[k] = -mass * (P.rho * dv[k] + href_s * vi3[k]);
+          gi[k] = -mass * (P.rho * dv[k] + hd[k] * vi3[k]);
         }
         if (has_hv) {
 #pragma unroll
@@ -819,7 +847,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           dg[k] = gi[k] - g3[k];
-          dvr[k] = mass * (href_s * vi3[k]) + gi[k];  // dual residual, v block (hxx:228): H_ref v - Hv + g
+          dvr[k] = mass * (hd[k] * vi3[k]) + gi[k];  // dual residual, v block (hxx:228): H_ref v - Hv + g
         }
         if (has_hv) {
 #pragma unroll
@@ -827,7 +855,14 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         }
         l_dualv = inf3(dvr);
         l_nu = tabs(nui);
-        l_hrefv = mass * tabs(href_s) * inf3(vi3);
+        if constexpr (HD) {
+          T hv[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) hv[k] = hd[k] * vi3[k];
+          l_hrefv = mass * inf3(hv);
+        } else {
+          l_hrefv = mass * tabs(href_s) * inf3(vi3);
+        }
         l_dvis = mass * inf3(dv);
         l_dnu = tabs(nui - nu);
         const T x = nui + inv_mu * w;
@@ -846,7 +881,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       }
       TAIL_TP(4)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) Fw[k] = (P.rho + href_s) * SEn[k] - P.rho * SE3[k];
+      for (int k = 0; k < 3; ++k) Fw[k] = HD ? P.rho * (SEn[k] - SE3[k]) + SHn[k] : (P.rho + href_s) * SEn[k] - P.rho * SE3[k];
       if (has_hv) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) Fw[k] -= shv[j * 6 + h3 + k];
@@ -998,6 +1033,7 @@ __host__ __device__ constexpr int flat1_xregion()
 {
   int n = XROWS * 9;
   if (NA * WAVE + 2 > n) n = NA * WAVE + 2;
+  if (2 * XROWS * 6 > n) n = 2 * XROWS * 6;       // two sets of prefix rows (HD)
   return (n + 1) & ~1;
 }
 template <int NA>
@@ -1008,7 +1044,7 @@ __host__ __device__ __forceinline__ size_t flat1_lds_bytes(int nc, bool has_hv)
   return (n * sizeof(double) + 15) & ~(size_t)15;
 }
 
-template <int NA, bool SLICED = false>
+template <int NA, bool SLICED = false, bool HD = false>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
         int nscan, int njmp, int* ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
@@ -1034,6 +1070,9 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const int jl = isj_lane ? j : 0;
   const int jflags = jd[jl + 1].flags, jcslot = isj_lane ? jd[jl + 1].cslot : -1;
   const T mass = (!isj_lane || (jflags & JF_MASSLESS)) ? T(0) : T(1);
+  T hd[6];  // the diagonal of H_ref (HD: see k_flat2; = href_s otherwise)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) hd[k] = HD ? P.Href[7 * k] : href_s;
   int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
   bool helper;
   unsigned int jrow4[(FLAT_JMP + 3) / 4], ra2[FLAT_RED / 2], prow4[(FLAT_PART + 3) / 4], anc4[(NA + 3) / 4];
@@ -1468,7 +1507,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T l_dg = T(0), l_g = T(0), l_stf = T(0), l_dstf = T(0), l_dualv = T(0);
     T fi[6], si;
     {
-      T SEn[6], Fw[6];
+      T SEn[6], SHn[6], Fw[6];
       // ---- the task constraints' update (two dependent exchanges through the constraint blocks) with the subtree sums of E,
       // prefix-sum differences in registers, in its shadow
       tail_sync();
@@ -1500,11 +1539,28 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
         for (int c = 0; c < 6; ++c) Pk[c] = prefix64(E[c]);
         const int src = lane + (size > 0 ? size - 1 : 0);
+        T E2[6], P2[6];
+        if constexpr (HD) {
+          T fl[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) fl[k] = mass * (hd[k] * vi[k]);
+          act_force(R0, t0, fl, E2);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) P2[k] = prefix64(E2[k]);
+        }
 #pragma unroll
         for (int c = 0; c < 6; ++c) xb[lane * 6 + c] = Pk[c];
+        if constexpr (HD) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) xb[(WAVE + 1) * 6 + lane * 6 + c] = P2[c];
+        }
         tail_sync();
 #pragma unroll
         for (int c = 0; c < 6; ++c) SEn[c] = (xb[src * 6 + c] - Pk[c]) + E[c];
+        if constexpr (HD) {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) SHn[c] = (xb[(WAVE + 1) * 6 + src * 6 + c] - P2[c]) + E2[c];
+        }
       }
       tail_sync();
       if (iscl) {
@@ -1527,7 +1583,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
           dv6[k] = vi[k] - v[k];
-          gi[k] = -mass * (P.rho * dv6[k] + href_s * vi[k]);
+          gi[k] = -mass * (P.rho * dv6[k] + hd[k] * vi[k]);
         }
         if (has_hv) {
 #pragma unroll
@@ -1540,7 +1596,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
           dg[k] = gi[k] - g[k];
-          dvr[k] = mass * (href_s * vi[k]) + gi[k];
+          dvr[k] = mass * (hd[k] * vi[k]) + gi[k];
         }
         if (has_hv) {
 #pragma unroll
@@ -1548,7 +1604,14 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         }
         l_dualv = inf6(dvr);
         l_nu = tabs(nui);
-        l_hrefv = mass * tabs(href_s) * inf6(vi);
+        if constexpr (HD) {
+          T hv[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) hv[k] = hd[k] * vi[k];
+          l_hrefv = mass * inf6(hv);
+        } else {
+          l_hrefv = mass * tabs(href_s) * inf6(vi);
+        }
         l_dvis = mass * inf6(dv6);
         l_dnu = tabs(nui - nu);
         const T x = nui + inv_mu * w;
@@ -1566,7 +1629,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         for (int k = 0; k < 6; ++k) { v[k] = vi[k]; g[k] = gi[k]; }
       }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) Fw[k] = (P.rho + href_s) * SEn[k] - P.rho * SE[k];
+      for (int k = 0; k < 6; ++k) Fw[k] = HD ? P.rho * (SEn[k] - SE[k]) + SHn[k] : (P.rho + href_s) * SEn[k] - P.rho * SE[k];
       if (has_hv) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) Fw[k] -= shv[lane * 6 + k];

@@ -1049,7 +1049,24 @@ bool href_is_scalar(const loikb_solver_impl* S)
       if (S->Href[6 * i + j] != (i == j ? S->Href[0] : 0.0)) return false;
   return true;
 }
-bool flat_applicable(const loikb_solver_impl* S) { return S->plan.flat && !S->per_link && href_is_scalar(S); }
+bool href_is_diagonal(const loikb_solver_impl* S)
+{
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j)
+      if (i != j && S->Href[6 * i + j] != 0.0) return false;
+  return true;
+}
+// the builds with one instance per wavefront (k_flat2: 17..32 joints, <= FLAT_NA_SMALL ancestors; k_flat1: 33..64) also take a
+// diagonal reference weight (their HD instantiations); k_flat (logging handles, LOIKB_FLAT_SPLIT=0) takes h I only
+bool flat_takes_diagonal(const loikb_solver_impl* S)
+{
+  if (!S->tune.flat_split || S->f32 || S->opt.logging || !S->flat.ok) return false;
+  return (S->flat.G == F2G && S->flat.nanc <= FLAT_NA_SMALL) || S->flat.G == WAVE;
+}
+bool flat_applicable(const loikb_solver_impl* S)
+{
+  return S->plan.flat && !S->per_link && (href_is_scalar(S) || (href_is_diagonal(S) && flat_takes_diagonal(S)));
+}
 
 int ensure_hslots(loikb_solver_impl* S)
 {
@@ -1614,15 +1631,19 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
                      (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
                      (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv, C->ring_cap - 1, quantum)
-          if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true);
+          const bool hd = !href_is_scalar(S);  // (diagonal then: flat_applicable)
+          if (hd) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, true); else LOIKB_LAUNCH_FLAT2(2, false, true); }
+          else if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true);
           else if (wpe == 3) LOIKB_LAUNCH_FLAT2(3);
           else LOIKB_LAUNCH_FLAT2(2);
 #undef LOIKB_LAUNCH_FLAT2
         } else if (one) {
           const size_t lds1 = small_na ? flat1_lds_bytes<FLAT_NA_SMALL>(S->nc, has_hv != 0) : flat1_lds_bytes<FLAT_MAXA>(S->nc, has_hv != 0);
-          grid = dim3((unsigned)std::min(n, (int)std::min<size_t>(4, (160 * 1024) / lds1) * (int)(cu_sh + 0.5)));
+          int per_cu1 = (int)std::min<size_t>(4, (160 * 1024) / lds1);
+          if (S->tune.lean_wg_per_cu > 0) per_cu1 = std::min(per_cu1, S->tune.lean_wg_per_cu);
+          grid = dim3((unsigned)std::min(n, per_cu1 * (int)(cu_sh + 0.5)));
           // (time slicing as in k_flat2, same window: whole body, four tasks, B = 65 536: 34.7 ms without)
-          const int resident = (int)grid.x, full = (int)std::min<size_t>(4, (160 * 1024) / lds1) * (int)(cu_sh + 0.5);
+          const int resident = (int)grid.x, full = per_cu1 * (int)(cu_sh + 0.5);
           const int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice
                               : (n_first >= 12 * resident && n_first <= 96 * resident && resident == full &&
                                  !(S->opt.flags & LOIKB_OPT_OWN_STREAM)) ? 160 : 0;
@@ -1631,7 +1652,12 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
                      (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
                      (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv, C->ring_cap - 1, quantum)
-          if (quantum > 0) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, true); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, true); }
+          const bool hd = !href_is_scalar(S);
+          if (hd) {
+            if (quantum > 0) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, true, true); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, true, true); }
+            else if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, true);
+            else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, true);
+          } else if (quantum > 0) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, true); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, true); }
           else if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL);
           else LOIKB_LAUNCH_FLAT1(FLAT_MAXA);
 #undef LOIKB_LAUNCH_FLAT1
@@ -2882,7 +2908,7 @@ const char* loikb_plan_string(loikb_solver* S)
              split ? "; two lanes per joint, one instance per wavefront" : one ? "; one instance per wavefront" : "", pl.tail_max,
              split ? std::min(4 * S->tune.flat_split_wpe, pl.flat_waves_cu * 2) : one ? std::min(4, pl.flat_waves_cu) : pl.flat_waves_cu,
              pl.kexp_lo, pl.kexp_lo + pl.ndec - 1,
-             S->flat.nanc, S->flat.nscan, S->flat.njmp, S->have_problem ? "" : " when H_ref = h I", pl.nchunks);
+             S->flat.nanc, S->flat.nscan, S->flat.njmp, S->have_problem ? "" : " when H_ref = h I or a diagonal weight shared by the links", pl.nchunks);
   }
   else if (pl.lean)
     snprintf(buf, sizeof(buf), "k_hslots + k_lean for whole batches up to %d instances (%d wavefronts per CU in workgroups of %d, "
@@ -2894,8 +2920,8 @@ const char* loikb_plan_string(loikb_solver* S)
   out = buf;
   if (!pl.flat && *pl.why_not_flat) out += std::string("; no k_flat: ") + pl.why_not_flat;
   else if (pl.flat && S->have_problem && !flat_applicable(S))
-    out += pl.lean ? "; no k_flat for this problem (its reference cost is not H_ref = h I on every link): k_hslots + k_lean take its place"
-                   : "; no k_flat for this problem: its reference cost is not H_ref = h I on every link";
+    out += pl.lean ? "; no flat engine for this problem (its reference cost is neither h I nor a diagonal weight shared by the links): k_hslots + k_lean take its place"
+                   : "; no flat engine for this problem: its reference cost is neither h I nor a diagonal weight shared by the links";
   if ((pl.lean || pl.flat) && S->tune.lean_adapt && S->seen_hi >= S->seen_lo) {
     char b2[160];
     snprintf(b2, sizeof(b2), "; decades visited by this handle's solves so far: %d..%d (the next solve builds those +-1)", S->seen_lo, S->seen_hi);

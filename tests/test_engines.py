@@ -355,3 +355,50 @@ def test_flat_time_slicing_changes_nothing(talos, monkeypatch):
         s.close()
     for k in res["plain"]:
         assert np.array_equal(res["plain"][k], res["sliced"][k]), k
+
+
+@pytest.mark.parametrize("robot", ["talos32", "talos44"])
+@pytest.mark.parametrize("sliced", [False, True])
+def test_flat_engine_with_a_diagonal_reference_weight(robot, sliced, monkeypatch):
+    """H_ref = diag(d_1 .. d_6) shared by the links (other weights on the angular than on the linear velocity) stays on the flat
+    engine: the HD instantiations of k_flat2 (talos32) and k_flat1 (talos44) sum the weighted link velocities over the subtrees
+    beside the velocities themselves.  k iterations field by field and end to end against the oracle; with the time slicing forced."""
+    from loik_amd import workloads
+    from helpers import problem_args
+    model = loik_amd.builtin_model(robot)
+    B = 700
+    wl = workloads.talos_wholebody(B, seed=9, model=model) if robot == "talos44" else workloads.talos_c3(B, seed=9)
+    Href = np.diag([0.4, 1.5, 0.7, 3.0, 0.2, 2.2])
+    vref = np.array([0.02, -0.01, 0.03, 0.05, -0.04, 0.01])   # H_ref v_ref != 0: the reference term's subtree sums too
+    args = (wl["q"], Href, vref, wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    for k in ("LOIKB_FLAT_SLICE", "LOIKB_LEAN_WG_PER_CU"):
+        monkeypatch.delenv(k, raising=False)
+    if sliced:
+        monkeypatch.setenv("LOIKB_FLAT_SLICE", "4"); monkeypatch.setenv("LOIKB_LEAN_WG_PER_CU", "1")
+    for k in (1, 3, 9):
+        prm = dict(wl["params"], max_iter=k + 1, tol_abs=0.0, tol_primal_inf=0.0)
+        s = loik_amd.BatchedLoik(model, B, **prm)
+        s.Solve(*args)
+        st = s.stats()
+        assert st["flat_launches"] >= 1 and st["tail_instances"] == B, (s.plan(), st)
+        got = {n: s.get(n) for n in FIELDS + SCALARS}
+        for b in range(0, B, 97):
+            r = ref.RefSolver(model, **prm)
+            r.Solve(wl["q"][b], Href, vref, wl["c_ids"], wl["Ais"], wl["bis"][b], wl["lb"], wl["ub"])
+            for n in FIELDS:
+                want = r.field(n)
+                if n in ("vis", "fis", "g"):
+                    want = want[1:]
+                assert_close(got[n][b], want, 1e-9, "%s b%d k%d" % (n, b, k))
+            for n in SCALARS:
+                assert_close(got[n][b], r.scalar(n), 1e-9, "%s b%d k%d" % (n, b, k))
+        s.close()
+    prm = dict(wl["params"], max_iter=400)
+    out = ref.solve_batch(model, *args, nthreads=8, want_nu=True, **prm)
+    s = loik_amd.BatchedLoik(model, B, **prm)
+    s.Solve(*args)
+    st = s.stats()
+    assert st["flat_launches"] >= 1 and st["lean_escaped"] == 0 and st["tail_instances"] == B, (s.plan(), st)
+    assert (st["lean_requeues"] > 0) == sliced, st
+    assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.97, ztol=1e-8, what="diagonal H_ref, " + robot)
+    s.close()

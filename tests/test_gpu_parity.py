@@ -277,7 +277,9 @@ def test_maxeigenvalue_mu_rule_matches_oracle(talos, engine, monkeypatch):
     if engine == "flat":
         Href = 2.5 * np.eye(6)                       # H_ref = h I: mu0 = 10^(round(4 log10 sqrt((h + rho)^2)) / 4) = 10^0.5
     else:
-        Href = np.diag([0.3, 0.3, 0.3, 4.0, 4.0, 4.0])  # general weight: k_lean's domain among the on-chip engines
+        Q = np.linalg.qr(np.random.default_rng(3).normal(size=(6, 6)))[0]
+        Href = Q @ np.diag([0.3, 0.5, 0.8, 2.0, 3.0, 4.0]) @ Q.T  # a general symmetric weight: k_lean's domain among the on-chip engines
+        Href = 0.5 * (Href + Href.T)
     wl = dict(wl, H_ref=Href)
     kw = {"flat": {}, "lean": {}, "tail": dict(tail_max_instances=1 << 20), "solve": dict(tail_max_instances=-1), "logged": dict(logging=True)}[engine]
     if engine == "tail":
@@ -296,7 +298,7 @@ def test_maxeigenvalue_mu_rule_matches_oracle(talos, engine, monkeypatch):
                           nthreads=8, want_nu=True, **prm)
     assert_end_to_end(fetch_end_to_end(s, residuals=True), out, prm, same_frac=0.97, what="MAXEIGENVALUE mu rule, " + engine)
     # mu stays on the decade grid of the spectral start
-    ev = np.linalg.eigvalsh(Href + prm["rho"] * np.eye(6))
+    ev = np.linalg.eigvalsh(0.5 * (Href + Href.T) + prm["rho"] * np.eye(6))
     mu0 = 10.0 ** (np.round(4.0 * np.log10(np.sqrt(max(ev.min(), prm["rho"]) * ev.max()))) / 4.0)
     k = np.log10(s.get("mu") / mu0)
     assert np.abs(k - np.round(k)).max() < 1e-9 and mu0 != prm["mu"]
