@@ -185,7 +185,7 @@ template <int NA> __host__ __device__ constexpr int flat2_off_tail() { return fl
 template <int NA>
 __host__ __device__ __forceinline__ size_t flat2_lds_bytes(int nc, bool has_hv)
 {
-  const size_t n = (size_t)flat2_off_tail<NA>() + (has_hv ? (size_t)F2G * 6 : 0) + (size_t)nc * FCD + FISC;
+  const size_t n = (size_t)flat2_off_tail<NA>() + (has_hv ? (size_t)F2G * 6 : 0) + (size_t)nc * FCD + FISC + 36;
   return (n * sizeof(double) + 15) & ~(size_t)15;
 }
 
@@ -195,11 +195,12 @@ __host__ __device__ __forceinline__ size_t flat2_lds_bytes(int nc, bool has_hv)
 // different XCDs, whose L2s are not coherent with each other) and is accessed with agent-scope loads / stores.  Iteration counts
 // are heavy-tailed and unknown in advance: run to completion in arrival order, the 999-iteration instances fetched late keep
 // the launch alive for 3 ms after the queue ran dry (27 % of it); time-sliced, every long runner advances from the start.
-// HD: a DIAGONAL reference weight H_ref = diag(d_1 .. d_6), the same for every link (e.g. other weights on the angular than on the
-// linear velocity), instead of h I.  H_ref v then is no multiple of the link's velocity as a force at the world origin: the link
-// velocities are weighted in the link frame (d * v, three multiplications per lane), carried to the world origin and summed
-// over the subtrees beside E -- three more prefix sums and one more frame change per iteration.
-template <int NA, int WPE, bool SLICED = false, bool HD = false>
+// HM: the reference weight shared by the links.  0: H_ref = h I.  1: a DIAGONAL weight diag(d_1 .. d_6) (e.g. other weights on the
+// angular than on the linear velocity).  2: a general symmetric 6x6 (read from LDS: 18 multiply-adds per lane).  For 1 and 2
+// H_ref v is no multiple of the link's velocity as a force at the world origin: the link velocities are weighted in the link
+// frame, carried to the world origin and summed over the subtrees beside E -- three more prefix sums and one more frame change
+// per iteration.
+template <int NA, int WPE, bool SLICED = false, int HM = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
         int nscan, int njmp, int* ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
@@ -230,9 +231,12 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const int jflags = jd[jl + 1].flags, jcslot = isj_lane ? jd[jl + 1].cslot : -1;
   const T mass = (!isj_lane || (jflags & JF_MASSLESS)) ? T(0) : T(1);
   const T hz = h ? T(0) : T(1);  // scalar-per-joint contributions to sums come from the linear lane only
-  T hd[3];  // this half's diagonal entries of H_ref (HD; = href_s otherwise)
+  constexpr bool HD = HM > 0;  // (H_ref v needs its own subtree sums)
+  T hd[3];  // this half's diagonal entries of H_ref (HM = 1; = href_s for HM = 0)
 #pragma unroll
-  for (int k = 0; k < 3; ++k) hd[k] = HD ? (h ? P.Href[7 * (3 + k)] : P.Href[7 * k]) : href_s;
+  for (int k = 0; k < 3; ++k) hd[k] = HM == 1 ? (h ? P.Href[7 * (3 + k)] : P.Href[7 * k]) : href_s;
+  T* const hmat = isc + FISC;  // [36] H_ref (HM = 2)
+  if (HM == 2 && lane < 36) hmat[lane] = P.Href[lane];
   int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
   bool helper;
   unsigned int jrow4[(FLAT_JMP + 3) / 4];  // load time: rows of the ancestors at distance 2^r in joint-indexed rows (WAVE = identity)
@@ -738,6 +742,20 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       }
       mat3t_vec(R0, X, vi3);  // SE3::actInv(Motion): (R^T (v_l - t x v_a), R^T v_a)
     }
+    T hv3[3];  // this half of H_ref v_i (link frame)
+    if constexpr (HM == 2) {
+      T vl[3], va[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) both_halves(vi3[k], vl[k], va[k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const T* hr = hmat + (h3 + k) * 6;
+        hv3[k] = ((hr[0] * vl[0] + hr[1] * vl[1]) + hr[2] * vl[2]) + ((hr[3] * va[0] + hr[4] * va[1]) + hr[5] * va[2]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) hv3[k] = hd[k] * vi3[k];
+    }
     TAIL_TP(2)
     // ================= DualUpdate of the task constraints (hxx:410-451) inside the subtree sum of the links' velocities ==========
     T l_dyis = T(0), l_av = T(0), l_prt = T(0), l_up = T(0), l_lm = T(0);
@@ -787,7 +805,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
           // the link's weighted velocity H_ref v (link frame) as a force at the world origin: (R0 f_l, R0 f_a + t0 x R0 f_l)
           T fl[3], y3[3], L3[3], A3[3], cc[3];
 #pragma unroll
-          for (int k = 0; k < 3; ++k) fl[k] = mass * (hd[k] * vi3[k]);
+          for (int k = 0; k < 3; ++k) fl[k] = mass * hv3[k];
           mat3_vec(R0, fl, y3);
 #pragma unroll
           for (int k = 0; k < 3; ++k) both_halves(y3[k], L3[k], A3[k]);
@@ -834,7 +852,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         for (int k = 0; k < 3; ++k) {
           dv[k] = vi3[k] - v3[k];
           // g_i = A^T y_i + sum_children act(f_c) - f_i = A^T y_i - (H^base_i v_i + p^base_i)  (force balance)
-          gi[k] = -mass * (P.rho * dv[k] + hd[k] * vi3[k]);
+          gi[k] = -mass * (P.rho * dv[k] + hv3[k]);
         }
         if (has_hv) {
 #pragma unroll
@@ -847,7 +865,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           dg[k] = gi[k] - g3[k];
-          dvr[k] = mass * (hd[k] * vi3[k]) + gi[k];  // dual residual, v block (hxx:228): H_ref v - Hv + g
+          dvr[k] = mass * hv3[k] + gi[k];  // dual residual, v block (hxx:228): H_ref v - Hv + g
         }
         if (has_hv) {
 #pragma unroll
@@ -856,10 +874,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         l_dualv = inf3(dvr);
         l_nu = tabs(nui);
         if constexpr (HD) {
-          T hv[3];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) hv[k] = hd[k] * vi3[k];
-          l_hrefv = mass * inf3(hv);
+          l_hrefv = mass * inf3(hv3);
         } else {
           l_hrefv = mass * tabs(href_s) * inf3(vi3);
         }
@@ -1040,11 +1055,11 @@ template <int NA>
 __host__ __device__ __forceinline__ size_t flat1_lds_bytes(int nc, bool has_hv)
 {
   const size_t n = (size_t)flat1_xregion<NA>() + 2 * (size_t)(NA + 1) * WAVE + 3 * (size_t)(WAVE + 2) + (has_hv ? (size_t)WAVE * 6 : 0) +
-                   (size_t)nc * FCD + FISC;
+                   (size_t)nc * FCD + FISC + 36;
   return (n * sizeof(double) + 15) & ~(size_t)15;
 }
 
-template <int NA, bool SLICED = false, bool HD = false>
+template <int NA, bool SLICED = false, int HM = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
         int nscan, int njmp, int* ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
@@ -1070,9 +1085,12 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const int jl = isj_lane ? j : 0;
   const int jflags = jd[jl + 1].flags, jcslot = isj_lane ? jd[jl + 1].cslot : -1;
   const T mass = (!isj_lane || (jflags & JF_MASSLESS)) ? T(0) : T(1);
-  T hd[6];  // the diagonal of H_ref (HD: see k_flat2; = href_s otherwise)
+  constexpr bool HD = HM > 0;
+  T hd[6];  // the diagonal of H_ref (HM = 1: see k_flat2; = href_s for HM = 0)
 #pragma unroll
-  for (int k = 0; k < 6; ++k) hd[k] = HD ? P.Href[7 * k] : href_s;
+  for (int k = 0; k < 6; ++k) hd[k] = HM == 1 ? P.Href[7 * k] : href_s;
+  T* const hmat = isc + FISC;  // [36] H_ref (HM = 2)
+  if (HM == 2 && lane < 36) hmat[lane] = P.Href[lane];
   int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
   bool helper;
   unsigned int jrow4[(FLAT_JMP + 3) / 4], ra2[FLAT_RED / 2], prow4[(FLAT_PART + 3) / 4], anc4[(NA + 3) / 4];
@@ -1502,6 +1520,17 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       actinv_motion(R0, t0, vw, vi);
       force_of_motion(vw, E);
     }
+    T hv6[6];  // H_ref v_i (link frame)
+    if constexpr (HM == 2) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const T* hr = hmat + k * 6;
+        hv6[k] = ((hr[0] * vi[0] + hr[1] * vi[1]) + hr[2] * vi[2]) + ((hr[3] * vi[3] + hr[4] * vi[4]) + hr[5] * vi[5]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) hv6[k] = hd[k] * vi[k];
+    }
     T l_dyis = T(0), l_av = T(0), l_prt = T(0), l_up = T(0), l_lm = T(0);
     T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_prs = T(0);
     T l_dg = T(0), l_g = T(0), l_stf = T(0), l_dstf = T(0), l_dualv = T(0);
@@ -1543,7 +1572,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         if constexpr (HD) {
           T fl[6];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) fl[k] = mass * (hd[k] * vi[k]);
+          for (int k = 0; k < 6; ++k) fl[k] = mass * hv6[k];
           act_force(R0, t0, fl, E2);
 #pragma unroll
           for (int k = 0; k < 6; ++k) P2[k] = prefix64(E2[k]);
@@ -1583,7 +1612,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
           dv6[k] = vi[k] - v[k];
-          gi[k] = -mass * (P.rho * dv6[k] + hd[k] * vi[k]);
+          gi[k] = -mass * (P.rho * dv6[k] + hv6[k]);
         }
         if (has_hv) {
 #pragma unroll
@@ -1596,7 +1625,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
           dg[k] = gi[k] - g[k];
-          dvr[k] = mass * (hd[k] * vi[k]) + gi[k];
+          dvr[k] = mass * hv6[k] + gi[k];
         }
         if (has_hv) {
 #pragma unroll
@@ -1605,10 +1634,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         l_dualv = inf6(dvr);
         l_nu = tabs(nui);
         if constexpr (HD) {
-          T hv[6];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) hv[k] = hd[k] * vi[k];
-          l_hrefv = mass * inf6(hv);
+          l_hrefv = mass * inf6(hv6);
         } else {
           l_hrefv = mass * tabs(href_s) * inf6(vi);
         }

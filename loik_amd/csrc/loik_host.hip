@@ -1057,7 +1057,8 @@ bool href_is_diagonal(const loikb_solver_impl* S)
   return true;
 }
 // the builds with one instance per wavefront (k_flat2: 17..32 joints, <= FLAT_NA_SMALL ancestors; k_flat1: 33..64) also take a
-// diagonal reference weight (their HD instantiations); k_flat (logging handles, LOIKB_FLAT_SPLIT=0) takes h I only
+// diagonal or a general reference weight shared by the links (their HM = 1 / 2 instantiations); k_flat (logging handles,
+// LOIKB_FLAT_SPLIT=0) takes h I only
 bool flat_takes_diagonal(const loikb_solver_impl* S)
 {
   if (!S->tune.flat_split || S->f32 || S->opt.logging || !S->flat.ok) return false;
@@ -1065,7 +1066,7 @@ bool flat_takes_diagonal(const loikb_solver_impl* S)
 }
 bool flat_applicable(const loikb_solver_impl* S)
 {
-  return S->plan.flat && !S->per_link && (href_is_scalar(S) || (href_is_diagonal(S) && flat_takes_diagonal(S)));
+  return S->plan.flat && !S->per_link && (href_is_scalar(S) || flat_takes_diagonal(S));  // (k_flat2 / k_flat1: any shared weight)
 }
 
 int ensure_hslots(loikb_solver_impl* S)
@@ -1631,8 +1632,9 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
                      (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
                      (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv, C->ring_cap - 1, quantum)
-          const bool hd = !href_is_scalar(S);  // (diagonal then: flat_applicable)
-          if (hd) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, true); else LOIKB_LAUNCH_FLAT2(2, false, true); }
+          const int hm = href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
+          if (hm == 2) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 2); else LOIKB_LAUNCH_FLAT2(2, false, 2); }
+          else if (hm == 1) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 1); else LOIKB_LAUNCH_FLAT2(2, false, 1); }
           else if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true);
           else if (wpe == 3) LOIKB_LAUNCH_FLAT2(3);
           else LOIKB_LAUNCH_FLAT2(2);
@@ -1652,11 +1654,15 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
                      (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
                      (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv, C->ring_cap - 1, quantum)
-          const bool hd = !href_is_scalar(S);
-          if (hd) {
-            if (quantum > 0) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, true, true); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, true, true); }
-            else if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, true);
-            else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, true);
+          const int hm = href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
+          if (hm == 2) {
+            if (quantum > 0) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, true, 2); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, true, 2); }
+            else if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, 2);
+            else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, 2);
+          } else if (hm == 1) {
+            if (quantum > 0) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, true, 1); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, true, 1); }
+            else if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, 1);
+            else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, 1);
           } else if (quantum > 0) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, true); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, true); }
           else if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL);
           else LOIKB_LAUNCH_FLAT1(FLAT_MAXA);
@@ -2908,7 +2914,7 @@ const char* loikb_plan_string(loikb_solver* S)
              split ? "; two lanes per joint, one instance per wavefront" : one ? "; one instance per wavefront" : "", pl.tail_max,
              split ? std::min(4 * S->tune.flat_split_wpe, pl.flat_waves_cu * 2) : one ? std::min(4, pl.flat_waves_cu) : pl.flat_waves_cu,
              pl.kexp_lo, pl.kexp_lo + pl.ndec - 1,
-             S->flat.nanc, S->flat.nscan, S->flat.njmp, S->have_problem ? "" : " when H_ref = h I or a diagonal weight shared by the links", pl.nchunks);
+             S->flat.nanc, S->flat.nscan, S->flat.njmp, S->have_problem ? "" : " when the links share one reference weight", pl.nchunks);
   }
   else if (pl.lean)
     snprintf(buf, sizeof(buf), "k_hslots + k_lean for whole batches up to %d instances (%d wavefronts per CU in workgroups of %d, "
@@ -2920,8 +2926,8 @@ const char* loikb_plan_string(loikb_solver* S)
   out = buf;
   if (!pl.flat && *pl.why_not_flat) out += std::string("; no k_flat: ") + pl.why_not_flat;
   else if (pl.flat && S->have_problem && !flat_applicable(S))
-    out += pl.lean ? "; no flat engine for this problem (its reference cost is neither h I nor a diagonal weight shared by the links): k_hslots + k_lean take its place"
-                   : "; no flat engine for this problem: its reference cost is neither h I nor a diagonal weight shared by the links";
+    out += pl.lean ? "; no flat engine for this problem (per-link reference weights): k_hslots + k_lean take its place"
+                   : "; no flat engine for this problem: per-link reference weights";
   if ((pl.lean || pl.flat) && S->tune.lean_adapt && S->seen_hi >= S->seen_lo) {
     char b2[160];
     snprintf(b2, sizeof(b2), "; decades visited by this handle's solves so far: %d..%d (the next solve builds those +-1)", S->seen_lo, S->seen_hi);

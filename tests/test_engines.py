@@ -359,16 +359,22 @@ def test_flat_time_slicing_changes_nothing(talos, monkeypatch):
 
 @pytest.mark.parametrize("robot", ["talos32", "talos44"])
 @pytest.mark.parametrize("sliced", [False, True])
-def test_flat_engine_with_a_diagonal_reference_weight(robot, sliced, monkeypatch):
-    """H_ref = diag(d_1 .. d_6) shared by the links (other weights on the angular than on the linear velocity) stays on the flat
-    engine: the HD instantiations of k_flat2 (talos32) and k_flat1 (talos44) sum the weighted link velocities over the subtrees
-    beside the velocities themselves.  k iterations field by field and end to end against the oracle; with the time slicing forced."""
+@pytest.mark.parametrize("weight", ["diagonal", "general"])
+def test_flat_engine_with_a_diagonal_reference_weight(robot, sliced, weight, monkeypatch):
+    """A reference weight shared by the links that is not h I -- diag(d_1 .. d_6) (other weights on the angular than on the linear
+    velocity) or a general symmetric 6x6 -- stays on the flat engine: the HM = 1 / 2 instantiations of k_flat2 (talos32) and
+    k_flat1 (talos44) sum the weighted link velocities over the subtrees beside the velocities themselves.  k iterations field by
+    field and end to end against the oracle; with the time slicing forced."""
     from loik_amd import workloads
     from helpers import problem_args
     model = loik_amd.builtin_model(robot)
     B = 700
     wl = workloads.talos_wholebody(B, seed=9, model=model) if robot == "talos44" else workloads.talos_c3(B, seed=9)
     Href = np.diag([0.4, 1.5, 0.7, 3.0, 0.2, 2.2])
+    if weight == "general":
+        Q = np.linalg.qr(np.random.default_rng(4).normal(size=(6, 6)))[0]
+        Href = Q @ Href @ Q.T
+        Href = 0.5 * (Href + Href.T)
     vref = np.array([0.02, -0.01, 0.03, 0.05, -0.04, 0.01])   # H_ref v_ref != 0: the reference term's subtree sums too
     args = (wl["q"], Href, vref, wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
     for k in ("LOIKB_FLAT_SLICE", "LOIKB_LEAN_WG_PER_CU"):
@@ -400,5 +406,5 @@ def test_flat_engine_with_a_diagonal_reference_weight(robot, sliced, monkeypatch
     st = s.stats()
     assert st["flat_launches"] >= 1 and st["lean_escaped"] == 0 and st["tail_instances"] == B, (s.plan(), st)
     assert (st["lean_requeues"] > 0) == sliced, st
-    assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.97, ztol=1e-8, what="diagonal H_ref, " + robot)
+    assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.97, ztol=1e-8, what="%s H_ref, %s" % (weight, robot))
     s.close()

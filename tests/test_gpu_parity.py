@@ -284,6 +284,8 @@ def test_maxeigenvalue_mu_rule_matches_oracle(talos, engine, monkeypatch):
     kw = {"flat": {}, "lean": {}, "tail": dict(tail_max_instances=1 << 20), "solve": dict(tail_max_instances=-1), "logged": dict(logging=True)}[engine]
     if engine == "tail":
         monkeypatch.setenv("LOIKB_LEAN", "0")
+    if engine == "lean":
+        monkeypatch.setenv("LOIKB_FLAT", "0")   # (the flat engine would take this weight too: its HM = 2 instantiation)
     s = gpu_solve(talos, wl, prm, **kw)
     st = s.stats()
     if engine == "flat":
