@@ -1095,7 +1095,8 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
 #pragma unroll
       for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int b2 = a; b2 < 6; ++b2) hb[sym(a, b2)] = mass * ((a == b2 ? P.rho : T(0)) + P.Href[6 * a + b2]);
+        for (int b2 = a; b2 < 6; ++b2)  // (per-link references, UpdateReferences: the joint's row of the table)
+          hb[sym(a, b2)] = mass * ((a == b2 ? P.rho : T(0)) + (P.href_tab ? P.href_tab[(size_t)(jl + 1) * HREF_ROW + 6 * a + b2] : P.Href[6 * a + b2]));
       congr_sym(R0, t0, hb, base0);
     }
     if (cslot >= 0) {

@@ -196,7 +196,8 @@ __host__ __device__ __forceinline__ size_t flat2_lds_bytes(int nc, bool has_hv)
 // are heavy-tailed and unknown in advance: run to completion in arrival order, the 999-iteration instances fetched late keep
 // the launch alive for 3 ms after the queue ran dry (27 % of it); time-sliced, every long runner advances from the start.
 // HM: the reference weight shared by the links.  0: H_ref = h I.  1: a DIAGONAL weight diag(d_1 .. d_6) (e.g. other weights on the
-// angular than on the linear velocity).  2: a general symmetric 6x6 (read from LDS: 18 multiply-adds per lane).  For 1 and 2
+// angular than on the linear velocity).  2: a general symmetric 6x6 (read from LDS: 18 multiply-adds per lane).  3: one weight and
+// one target PER LINK (UpdateReferences' table in HBM, Params::href_tab: the joint's 18 entries come through L1 / L2).  For 1..3
 // H_ref v is no multiple of the link's velocity as a force at the world origin: the link velocities are weighted in the link
 // frame, carried to the world origin and summed over the subtrees beside E -- three more prefix sums and one more frame change
 // per iteration.
@@ -237,6 +238,10 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   for (int k = 0; k < 3; ++k) hd[k] = HM == 1 ? (h ? P.Href[7 * (3 + k)] : P.Href[7 * k]) : href_s;
   T* const hmat = isc + FISC;  // [36] H_ref (HM = 2)
   if (HM == 2 && lane < 36) hmat[lane] = P.Href[lane];
+  const T* const hrow = HM == 3 ? P.href_tab + (size_t)(jl + 1) * HREF_ROW : nullptr;  // (H_ref_i, H_ref_i v_ref_i) of this link
+  T hvl3[3];  // this half of H_ref v_ref of the link
+#pragma unroll
+  for (int k = 0; k < 3; ++k) hvl3[k] = HM == 3 ? hrow[36 + h3 + k] : (h ? P.Hv[3 + k] : P.Hv[k]);
   int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
   bool helper;
   unsigned int jrow4[(FLAT_JMP + 3) / 4];  // load time: rows of the ancestors at distance 2^r in joint-indexed rows (WAVE = identity)
@@ -484,7 +489,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       if (has_hv) {
         T hv[6], hw[6], Sh[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) hv[k] = mass * P.Hv[k];
+        for (int k = 0; k < 6; ++k) hv[k] = mass * (HM == 3 ? hrow[36 + k] : P.Hv[k]);
         act_force(R0, t0, hv, hw);
         flat_subtree_sum<T>(xb, j, j, G, size, nscan, hw, Sh);
 #pragma unroll
@@ -743,13 +748,13 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       mat3t_vec(R0, X, vi3);  // SE3::actInv(Motion): (R^T (v_l - t x v_a), R^T v_a)
     }
     T hv3[3];  // this half of H_ref v_i (link frame)
-    if constexpr (HM == 2) {
+    if constexpr (HM >= 2) {
       T vl[3], va[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) both_halves(vi3[k], vl[k], va[k]);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const T* hr = hmat + (h3 + k) * 6;
+        const T* hr = (HM == 3 ? hrow : hmat) + (h3 + k) * 6;
         hv3[k] = ((hr[0] * vl[0] + hr[1] * vl[1]) + hr[2] * vl[2]) + ((hr[3] * va[0] + hr[4] * va[1]) + hr[5] * va[2]);
       }
     } else {
@@ -856,7 +861,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         }
         if (has_hv) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) gi[k] += mass * (h ? P.Hv[3 + k] : P.Hv[k]);
+          for (int k = 0; k < 3; ++k) gi[k] += mass * hvl3[k];
         }
         if (jcslot >= 0) {
 #pragma unroll
@@ -869,7 +874,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         }
         if (has_hv) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) dvr[k] -= mass * (h ? P.Hv[3 + k] : P.Hv[k]);
+          for (int k = 0; k < 3; ++k) dvr[k] -= mass * hvl3[k];
         }
         l_dualv = inf3(dvr);
         l_nu = tabs(nui);
@@ -1091,6 +1096,10 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   for (int k = 0; k < 6; ++k) hd[k] = HM == 1 ? P.Href[7 * k] : href_s;
   T* const hmat = isc + FISC;  // [36] H_ref (HM = 2)
   if (HM == 2 && lane < 36) hmat[lane] = P.Href[lane];
+  const T* const hrow = HM == 3 ? P.href_tab + (size_t)(jl + 1) * HREF_ROW : nullptr;  // (H_ref_i, H_ref_i v_ref_i) of this link (HM = 3)
+  T hvl[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) hvl[k] = HM == 3 ? hrow[36 + k] : P.Hv[k];
   int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
   bool helper;
   unsigned int jrow4[(FLAT_JMP + 3) / 4], ra2[FLAT_RED / 2], prow4[(FLAT_PART + 3) / 4], anc4[(NA + 3) / 4];
@@ -1316,7 +1325,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       if (has_hv) {
         T hv[6], hw[6], Sh[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) hv[k] = mass * P.Hv[k];
+        for (int k = 0; k < 6; ++k) hv[k] = mass * hvl[k];
         act_force(R0, t0, hv, hw);
         flat_subtree_sum<T>(xb, lane, lane, G, size, nscan, hw, Sh);
 #pragma unroll
@@ -1521,10 +1530,10 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       force_of_motion(vw, E);
     }
     T hv6[6];  // H_ref v_i (link frame)
-    if constexpr (HM == 2) {
+    if constexpr (HM >= 2) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        const T* hr = hmat + k * 6;
+        const T* hr = (HM == 3 ? hrow : hmat) + k * 6;
         hv6[k] = ((hr[0] * vi[0] + hr[1] * vi[1]) + hr[2] * vi[2]) + ((hr[3] * vi[3] + hr[4] * vi[4]) + hr[5] * vi[5]);
       }
     } else {
@@ -1616,7 +1625,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         }
         if (has_hv) {
 #pragma unroll
-          for (int k = 0; k < 6; ++k) gi[k] += mass * P.Hv[k];
+          for (int k = 0; k < 6; ++k) gi[k] += mass * hvl[k];
         }
         if (jcslot >= 0) {
 #pragma unroll
@@ -1629,7 +1638,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         }
         if (has_hv) {
 #pragma unroll
-          for (int k = 0; k < 6; ++k) dvr[k] -= mass * P.Hv[k];
+          for (int k = 0; k < 6; ++k) dvr[k] -= mass * hvl[k];
         }
         l_dualv = inf6(dvr);
         l_nu = tabs(nui);

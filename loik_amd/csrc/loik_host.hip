@@ -1066,7 +1066,8 @@ bool flat_takes_diagonal(const loikb_solver_impl* S)
 }
 bool flat_applicable(const loikb_solver_impl* S)
 {
-  return S->plan.flat && !S->per_link && (href_is_scalar(S) || flat_takes_diagonal(S));  // (k_flat2 / k_flat1: any shared weight)
+  // (k_flat2 / k_flat1 take any reference cost: shared or per link; k_flat h I only)
+  return S->plan.flat && (flat_takes_diagonal(S) || (!S->per_link && href_is_scalar(S)));
 }
 
 int ensure_hslots(loikb_solver_impl* S)
@@ -1632,8 +1633,9 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
                      (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
                      (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv, C->ring_cap - 1, quantum)
-          const int hm = href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
-          if (hm == 2) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 2); else LOIKB_LAUNCH_FLAT2(2, false, 2); }
+          const int hm = S->per_link ? 3 : href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
+          if (hm == 3) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 3); else LOIKB_LAUNCH_FLAT2(2, false, 3); }
+          else if (hm == 2) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 2); else LOIKB_LAUNCH_FLAT2(2, false, 2); }
           else if (hm == 1) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 1); else LOIKB_LAUNCH_FLAT2(2, false, 1); }
           else if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true);
           else if (wpe == 3) LOIKB_LAUNCH_FLAT2(3);
@@ -1654,8 +1656,12 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
                      (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
                      (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv, C->ring_cap - 1, quantum)
-          const int hm = href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
-          if (hm == 2) {
+          const int hm = S->per_link ? 3 : href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
+          if (hm == 3) {
+            if (quantum > 0) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, true, 3); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, true, 3); }
+            else if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, 3);
+            else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, 3);
+          } else if (hm == 2) {
             if (quantum > 0) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, true, 2); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, true, 2); }
             else if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, 2);
             else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, 2);
@@ -2914,7 +2920,8 @@ const char* loikb_plan_string(loikb_solver* S)
              split ? "; two lanes per joint, one instance per wavefront" : one ? "; one instance per wavefront" : "", pl.tail_max,
              split ? std::min(4 * S->tune.flat_split_wpe, pl.flat_waves_cu * 2) : one ? std::min(4, pl.flat_waves_cu) : pl.flat_waves_cu,
              pl.kexp_lo, pl.kexp_lo + pl.ndec - 1,
-             S->flat.nanc, S->flat.nscan, S->flat.njmp, S->have_problem ? "" : " when the links share one reference weight", pl.nchunks);
+             S->flat.nanc, S->flat.nscan, S->flat.njmp,
+             (split || one) ? ", any reference cost" : S->have_problem ? "" : " when H_ref = h I", pl.nchunks);
   }
   else if (pl.lean)
     snprintf(buf, sizeof(buf), "k_hslots + k_lean for whole batches up to %d instances (%d wavefronts per CU in workgroups of %d, "
@@ -2935,7 +2942,8 @@ const char* loikb_plan_string(loikb_solver* S)
   }
   if (S->opt.logging && logged_on_flat(S)) out = "logging = 1: k_flat writes the SolverInfo lists; " + out;
   else if (S->opt.logging) out = "logging = 1: every solve runs on the plain pass-by-pass implementation (k_pass_solve) and fills SolverInfo; without it: " + out;
-  if (pl.lean && S->per_link) out += "; per-link references in force (UpdateReferences): k_hslots + k_lean in their per-link instantiations until the next SolveInit";
+  if (S->per_link && flat_applicable(S)) out += "; per-link references in force (UpdateReferences): the flat engine reads the links' table";
+  else if (pl.lean && S->per_link) out += "; per-link references in force (UpdateReferences): k_hslots + k_lean in their per-link instantiations until the next SolveInit";
   return out.c_str();
 }
 

@@ -182,7 +182,8 @@ def oracle_batch(model, prm, B, run):
     return out, solvers
 
 
-ENGINE_KW = {"default": {}, "solve_only": dict(tail_max_instances=-1), "handover": dict(max_launch_iters=3, tail_max_instances=1 << 20)}
+ENGINE_KW = {"default": {}, "solve_only": dict(tail_max_instances=-1), "handover": dict(max_launch_iters=3, tail_max_instances=1 << 20),
+             "lean": {}}   # ("lean": LOIKB_FLAT=0 -- the per-link instantiations of k_hslots + k_lean, the engine of robots outside the flat engine's domain)
 REF_FIELDS = ["nu", "z", "w", "vis", "fis", "g", "yis", "Aty", "Stf_plus_w", "dual_residual_vec", "primal_residual_vec"]
 REF_SCALARS = ["primal_residual", "dual_residual", "dual_residual_v", "dual_residual_nu", "mu", "Href_v_inf_norm", "g_inf_norm",
                "delta_fis_inf_norm", "tol_dual", "tol_primal"]
@@ -236,9 +237,11 @@ def test_gpu_per_link_references_iteration_by_iteration(which, kind, request):
 @pytest.mark.gpu
 @pytest.mark.parametrize("engine", sorted(ENGINE_KW))
 @pytest.mark.parametrize("which", ["talos", "tree", "multidof"])
-def test_gpu_per_link_references_end_to_end(which, engine, request):
+def test_gpu_per_link_references_end_to_end(which, engine, request, monkeypatch):
     from helpers import assert_end_to_end, fetch_end_to_end
     from loik_amd import workloads
+    if engine == "lean":
+        monkeypatch.setenv("LOIKB_FLAT", "0")
     model, link = _model_for(which, request)
     B = 200
     wl = workloads.make_workload(model, B, link, 45, bound=0.5, snap_prob=0.0, nu_scale=0.4)
@@ -260,10 +263,12 @@ def test_gpu_per_link_references_end_to_end(which, engine, request):
     assert_end_to_end(fetch_end_to_end(s, residuals=not loose), out, prm, same_frac=0.95, ztol=1e-6 if loose else 1e-8,
                       off_ztol=1e-5, what="%s %s" % (which, engine))
     st = s.stats()
+    if which == "talos" and engine == "lean":
+        assert st["lean_launches"] >= 1 and st["flat_launches"] == 0 and st["tail_instances"] == B and "k_lean" in s.plan(), (st, s.plan())
     if which == "talos" and engine == "default":
-        # ordinary API use stays on an on-chip engine: the per-link instantiations of k_hslots + k_lean (k_flat needs H_ref = h I)
-        assert st["lean_launches"] >= 1 and st["flat_launches"] == 0 and st["tail_instances"] == B, (st, s.plan())
-        assert "k_lean" in s.plan()
+        # ordinary API use stays on the fast engine: k_flat2's per-link instantiation reads the links' table (HM = 3)
+        assert st["flat_launches"] >= 1 and st["tail_instances"] == B, (st, s.plan())
+        assert "the flat engine reads the links' table" in s.plan()
     # the next SolveInit broadcasts one pair again (hpp:355) and the lean engine is back
     s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
     out0 = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"],
