@@ -176,7 +176,7 @@ int loikb_active_constraint_ids(const loikb_solver *s, int *out, int cap); /* re
 
 /* SolverInfo / LoikSolverInfo (task-solver-base.hpp:25-52, loik-loid-optimized.hpp:47-127), filled when the handle was created
  * with options.logging = 1 ("logging residuals, should be disabled for speed", hpp:408): every Solve then runs on the plain
- * pass-by-pass implementation behind loikb_pass (fp64, 1-DoF joints) and records, per instance and main-loop iteration, what
+ * pass-by-pass implementation behind loikb_pass (or, for fp64 handles with H_ref = h I, on k_flat's logging build) and records, per instance and main-loop iteration, what
  * upstream pushes after ComputeResiduals (hpp:406-420).  loikb_get returns the state that implementation left.
  *   out[b][k], k = iteration - 1 < rows[b]: the list of instance b ([B][out_rows_cap], zero beyond rows[b]); rows may be NULL.
  *   out_rows_cap = entries per instance the caller's buffer holds: loikb_solver_info_rows_cap() (= max_iter - 1 at the time of
@@ -210,7 +210,9 @@ int loikb_synchronize(loikb_solver *s);
  * instance per thread, the reference's data object restated member by member) -- a debug path, and the second implementation
  * on the device the fused engines are checked against.  The first loikb_pass after SolveInit / a solve copies the solver's
  * state; from then until the next SolveInit / Solve call loikb_get serves the members from that copy, in the same layouts
- * (His, pis, r, Dinv, UDinv are exactly what the last pass left, as upstream).  1-DoF joints, fp64.
+ * (His, pis, r, Dinv, UDinv are exactly what the last pass left, as upstream).  Any model the solver accepts: a multi-DoF
+ * joint is the chain of 1-DoF joints the engines use (per-link members: the body-carrying link; r, Dinv, UDinv: one column
+ * of the chain's elimination per DoF).  The arithmetic is fp64 whatever the handle's precision.
  *   LOIKB_PASS_BEGIN_ITERATION = iter_++, ik_id_data.UpdatePrev(), ik_id_data.ResetInfNorms()   (hpp:381-388)          */
 enum {
   LOIKB_PASS_BEGIN_ITERATION = 0, LOIKB_PASS_FWD_PASS1, LOIKB_PASS_BWD_PASS, LOIKB_PASS_FWD_PASS2, LOIKB_PASS_BOX_PROJ,

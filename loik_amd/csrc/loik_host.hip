@@ -2652,10 +2652,6 @@ static PassParams pass_params(const loikb_solver_impl* S)
 // the pass state: allocated on first use, (re)loaded from the tiles whenever the solver state changed underneath it
 static int ensure_pass_state(loikb_solver_impl* S, const PassParams& P)
 {
-  if (S->f32 || S->nb != S->ext_nj - 1) {
-    g_last_error = "the pass-level path (loikb_pass, logging = 1) covers fp64 solvers of models with 1-DoF joints";
-    return LOIKB_ERR_MODEL;
-  }
   if (S->pass_active) return LOIKB_OK;
   const PassLayout PL = make_pass_layout(S->nj, S->nv, S->nc, S->B);
   if (!S->d_pass || PL.stride != S->PL.stride) {
@@ -2669,8 +2665,12 @@ static int ensure_pass_state(loikb_solver_impl* S, const PassParams& P)
   for (int i = 1; i < S->nj; ++i) cs[i] = S->jd[i].cslot;
   HIPCHK(hipMemcpyAsync(S->d_pass_cslot, cs.data(), sizeof(int) * S->nj, hipMemcpyHostToDevice, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
-  hipLaunchKernelGGL(k_pass_load<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, (const JointDesc*)S->d_jd,
-                     (const double*)S->d_uni, S->PL, P, S->d_pass);
+  if (S->f32)   // (the pass state is fp64 whatever the handle's precision)
+    hipLaunchKernelGGL(k_pass_load<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, (const JointDesc*)S->d_jd,
+                       (const float*)S->d_uni, S->PL, P, S->d_pass);
+  else
+    hipLaunchKernelGGL(k_pass_load<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, (const JointDesc*)S->d_jd,
+                       (const double*)S->d_uni, S->PL, P, S->d_pass);
   HIPCHK(hipGetLastError());
   S->pass_active = true;
   return LOIKB_OK;
@@ -2754,7 +2754,8 @@ static int ensure_log(loikb_solver_impl* S)
 static int finish_logged(loikb_solver_impl* S, const PassParams& P)
 {
   // the result goes back to the tiles too: a warm-started solve, loikb_integrate and the engines' getters continue from it
-  hipLaunchKernelGGL(k_pass_store<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, S->PL, P, (const double*)S->d_pass);
+  if (S->f32) hipLaunchKernelGGL(k_pass_store<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, S->PL, P, (const double*)S->d_pass);
+  else hipLaunchKernelGGL(k_pass_store<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, S->PL, P, (const double*)S->d_pass);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(S->ev_t1, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
@@ -2766,7 +2767,8 @@ static int finish_logged(loikb_solver_impl* S, const PassParams& P)
   {
     Chunk* C0 = &S->chunks[0];
     HIPCHK(hipMemsetAsync(C0->d_counters, 0, sizeof(unsigned int), S->stream));
-    hipLaunchKernelGGL(k_count_unfinished<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, S->B, C0->d_counters);
+    if (S->f32) hipLaunchKernelGGL(k_count_unfinished<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, S->B, C0->d_counters);
+    else hipLaunchKernelGGL(k_count_unfinished<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, S->B, C0->d_counters);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(C0->h_counters, C0->d_counters, sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
     HIPCHK(hipStreamSynchronize(S->stream));
@@ -2798,7 +2800,8 @@ static int pass_get(loikb_solver_impl* S, int field, void* out, bool to_dev)
 {
   const PassLayout& L = S->PL;
   const int nb = S->nb;
-  int off = -1, n = 0, skip = 0, scal = -1;
+  const int nl = S->ext_nj - 1;  // links of the caller's model (== nb unless it has multi-DoF joints)
+  int off = -1, n = 0, skip = 0, scal = -1, width = 0;
   bool is_int = false;
   switch (field) {
   case LOIKB_F_Z: off = L.z; n = S->nv; break;
@@ -2807,15 +2810,17 @@ static int pass_get(loikb_solver_impl* S, int field, void* out, bool to_dev)
   case LOIKB_F_STF_PLUS_W: off = L.Stf; n = S->nv; break;
   case LOIKB_F_R: off = L.r; n = S->nv; break;
   case LOIKB_F_DINV: off = L.Dinv; n = nb; skip = 1; break;
-  case LOIKB_F_VIS: off = L.vis; n = 6 * nb; skip = 6; break;
-  case LOIKB_F_FIS: off = L.fis; n = 6 * nb; skip = 6; break;
-  case LOIKB_F_G: off = L.g; n = 6 * nb; skip = 6; break;
-  case LOIKB_F_PIS: off = L.pis; n = 6 * nb; skip = 6; break;
-  case LOIKB_F_UDINV: off = L.UDinv; n = 6 * nb; skip = 6; break;
-  case LOIKB_F_LIMI: off = L.liMi; n = 12 * nb; skip = 12; break;
+  case LOIKB_F_VIS: off = L.vis; n = 6 * nl; width = 6; break;
+  case LOIKB_F_FIS: off = L.fis; n = 6 * nl; width = 6; break;
+  case LOIKB_F_G: off = L.g; n = 6 * nl; width = 6; break;
+  case LOIKB_F_PIS: off = L.pis; n = 6 * nl; width = 6; break;
+  case LOIKB_F_UDINV: off = L.UDinv; n = 6 * nb; skip = 6; break;   // per DoF (a column of the chain's elimination)
+  case LOIKB_F_LIMI:
+    if (nl != nb) return LOIKB_ERR_ARG;  // (M(q) of a multi-DoF joint is a product along its chain: k_limi on the tiles, same q)
+    off = L.liMi; n = 12 * nb; skip = 12; break;
   case LOIKB_F_YIS: off = L.yis; n = 6 * S->nc_active; break;  // (the active constraints are the first slots)
   case LOIKB_F_ATY: off = L.Aty; n = 6 * S->nc_active; break;
-  case LOIKB_F_HIS: n = 21 * nb; break;
+  case LOIKB_F_HIS: n = 21 * nl; break;
   case LOIKB_F_ITER: scal = PS_ITER; is_int = true; break;
   case LOIKB_F_CONVERGED: scal = PS_CONVERGED; is_int = true; break;
   case LOIKB_F_PRIMAL_INFEASIBLE: scal = PS_PRIMAL_INF; is_int = true; break;
@@ -2858,7 +2863,11 @@ static int pass_get(loikb_solver_impl* S, int field, void* out, bool to_dev)
   int rc;
   if ((rc = ensure_stage(S, bytes))) return rc;
   double* dst = (to_dev && !is_int) ? (double*)out : (double*)S->d_stage;
-  if (field == LOIKB_F_HIS) hipLaunchKernelGGL(k_pass_get_his, grid1(S->B), dim3(256), 0, S->stream, S->PL, (const double*)S->d_pass, dst);
+  if (field == LOIKB_F_HIS)
+    hipLaunchKernelGGL(k_pass_get_his, grid1(S->B), dim3(256), 0, S->stream, S->PL, (const double*)S->d_pass, (const int*)S->d_link_sel, nl, dst);
+  else if (width)
+    hipLaunchKernelGGL(k_pass_get_links, grid1(S->B), dim3(256), 0, S->stream, S->PL, (const double*)S->d_pass, off, width,
+                       (const int*)S->d_link_sel, nl, dst);
   else hipLaunchKernelGGL(k_pass_get, grid1(S->B), dim3(256), 0, S->stream, S->PL, (const double*)S->d_pass, off, n, skip, dst);
   HIPCHK(hipGetLastError());
   if (is_int) {

@@ -10,7 +10,10 @@
 // joints in the reference's order.  Nothing here is tuned; it is a debug path -- and, like the reference's plain solver
 // next to its optimized one, a second implementation on the same GPU against which the fused engines are checked
 // (tests/test_pass_level.py: N iterations composed of passes == Solve() of every engine).
-// 1-DoF joints, fp64 handles.
+// The state is kept per DEVICE joint: a multi-DoF joint of the caller's model is the chain of 1-DoF joints the engines use
+// (JF_MASSLESS links carry no rho I + H_ref, no reference term and are left out of the norms over the links -- which reproduces
+// the reference's nv x nv elimination); the getters select the body-carrying link.  The arithmetic is fp64 whatever the
+// handle's precision (an fp32 handle's state is widened at load and rounded back by k_pass_store).
 #pragma once
 
 #include "loik_device.hpp"
@@ -247,9 +250,10 @@ __device__ inline void pass_one(int pass, const PassLayout& L, const PassParams&
     for (int i = 1; i < nj; ++i) {
       double* H = s + L.His + 36 * i; double* p = s + L.pis + 6 * i;
       const double* vp = s + L.vis_prev + 6 * i;
+      const double rho = (jd[i].flags & JF_MASSLESS) ? 0.0 : P.rho;  // (the table's row of a massless link is zero)
       for (int r = 0; r < 6; ++r) {
-        for (int c = 0; c < 6; ++c) H[6 * r + c] = (r == c ? P.rho : 0.0) + P.href_tab[i * HREF_ROW + 6 * r + c];
-        p[r] = -P.rho * vp[r] - P.href_tab[i * HREF_ROW + 36 + r];
+        for (int c = 0; c < 6; ++c) H[6 * r + c] = (r == c ? rho : 0.0) + P.href_tab[i * HREF_ROW + 6 * r + c];
+        p[r] = -rho * vp[r] - P.href_tab[i * HREF_ROW + 36 + r];
       }
       const int cs = cslot_of[i];
       if (cs >= 0) {
@@ -316,9 +320,11 @@ __device__ inline void pass_one(int pass, const PassLayout& L, const PassParams&
         df[r] = f[r] - s[L.fis + 6 * i + r];
         dv[r] = v[r] - s[L.vis_prev + 6 * i + r];
       }
-      sc[PS_DFIS_INF] = fmax(sc[PS_DFIS_INF], p_inf6(df));
-      sc[PS_HREFV_INF] = fmax(sc[PS_HREFV_INF], p_inf6(hv));
-      sc[PS_DVIS_INF] = fmax(sc[PS_DVIS_INF], p_inf6(dv));
+      if (!(d.flags & JF_MASSLESS)) {  // norms over the LINKS of the caller's model
+        sc[PS_DFIS_INF] = fmax(sc[PS_DFIS_INF], p_inf6(df));
+        sc[PS_HREFV_INF] = fmax(sc[PS_HREFV_INF], p_inf6(hv));
+        sc[PS_DVIS_INF] = fmax(sc[PS_DVIS_INF], p_inf6(dv));
+      }
       for (int r = 0; r < 6; ++r) { s[L.vis + 6 * i + r] = v[r]; s[L.fis + 6 * i + r] = f[r]; s[L.Href_v + 6 * i + r] = hv[r]; }
     }
     double dn = 0.0;
@@ -397,10 +403,12 @@ __device__ inline void pass_one(int pass, const PassLayout& L, const PassParams&
       for (int r = 0; r < 6; ++r) { gi[r] = s[L.gnew + 6 * i + r] - s[L.fis + 6 * i + r]; dg[r] = gi[r] - s[L.g + 6 * i + r]; }
       p_act_force(s + L.liMi + 12 * i, s + L.fis + 6 * i, tf);
       for (int r = 0; r < 6; ++r) s[L.gnew + 6 * par + r] += tf[r];
-      sc[PS_G_INF] = fmax(sc[PS_G_INF], p_inf6(gi));
-      sc[PS_DG_INF] = fmax(sc[PS_DG_INF], p_inf6(dg));
       for (int r = 0; r < 6; ++r) { dvr[r] = s[L.Href_v + 6 * i + r] - P.href_tab[i * HREF_ROW + 36 + r] + gi[r]; s[L.g + 6 * i + r] = gi[r]; }
-      dualv = fmax(dualv, p_inf6(dvr));
+      if (!(d.flags & JF_MASSLESS)) {
+        sc[PS_G_INF] = fmax(sc[PS_G_INF], p_inf6(gi));
+        sc[PS_DG_INF] = fmax(sc[PS_DG_INF], p_inf6(dg));
+        dualv = fmax(dualv, p_inf6(dvr));
+      }
       double sf = 0.0;
       for (int r = 0; r < 6; ++r) sf += S[r] * s[L.fis + 6 * i + r];
       const double si = sf + s[L.w + j];
@@ -505,15 +513,27 @@ __global__ void k_pass_get(PassLayout L, const double* __restrict__ st, int off,
   const double* s = st + (size_t)b * L.stride + off + skip;
   for (int k = 0; k < n; ++k) out[(size_t)b * n + k] = s[k];
 }
-__global__ void k_pass_get_his(PassLayout L, const double* __restrict__ st, double* __restrict__ out)  // [B][nb][21]
+// a per-link field: link l of the caller's model (l = 0 .. nl-1) is device joint sel[l] + 1 (the body-carrying link of its chain)
+__global__ void k_pass_get_links(PassLayout L, const double* __restrict__ st, int off, int width, const int* __restrict__ sel, int nl,
+                                 double* __restrict__ out)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= L.B) return;
+  const double* s = st + (size_t)b * L.stride + off;
+  for (int l = 0; l < nl; ++l)
+    for (int k = 0; k < width; ++k) out[((size_t)b * nl + l) * width + k] = s[width * (sel[l] + 1) + k];
+}
+__global__ void k_pass_get_his(PassLayout L, const double* __restrict__ st, const int* __restrict__ sel, int nl,
+                               double* __restrict__ out)  // [B][nl][21]
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= L.B) return;
   const double* s = st + (size_t)b * L.stride + L.His;
-  for (int i = 1; i < L.nj; ++i) {
+  for (int l = 0; l < nl; ++l) {
+    const int i = sel[l] + 1;
     int k = 0;
     for (int r = 0; r < 6; ++r)
-      for (int c = r; c < 6; ++c, ++k) out[((size_t)b * (L.nj - 1) + (i - 1)) * 21 + k] = s[36 * i + 6 * r + c];
+      for (int c = r; c < 6; ++c, ++k) out[((size_t)b * nl + l) * 21 + k] = s[36 * i + 6 * r + c];
   }
 }
 

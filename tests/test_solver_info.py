@@ -31,14 +31,20 @@ def test_oracle_lists_follow_the_main_loop(talos):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["talos", "tree"])
+@pytest.mark.parametrize("which", ["talos", "tree", "floating_base"])
 def test_gpu_solver_info_matches_oracle(which, request):
     if which == "talos":
         model = request.getfixturevalue("talos"); link = model.getJointId("arm_left_7_joint")
+    elif which == "floating_base":   # a multi-DoF joint: logged solves of any model the solver accepts (loik-loid-optimized.hpp:406-420)
+        model = loik_amd.builtin_model("talos32_freeflyer"); link = model.getJointId("arm_left_7_joint")
     else:
         model = random_tree(13, 23); link = model.njoints - 1
     B = 48
-    wl = feasible_batch(model, B, link, 5)
+    if which == "floating_base":
+        from loik_amd import workloads
+        wl = workloads.make_workload(model, B, link, 5, bound=0.5, snap_prob=0.2, nu_scale=0.4)
+    else:
+        wl = feasible_batch(model, B, link, 5)
     prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
     s = loik_amd.BatchedLoik(model, B, logging=True, **prm)
     s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
@@ -134,10 +140,14 @@ def test_gpu_solver_info_infeasible_fixture_and_errors(talos):
     s.close()
     m = random_tree_multidof(seed=5, nb=9, root_freeflyer=True, n_spherical=1, n_translation=1)
     wl = feasible_batch(m, 2, m.njoints - 1, 3)
-    s = loik_amd.BatchedLoik(m, 2, logging=True, **prm)   # the logged path is the plain pass implementation: 1-DoF joints
-    with pytest.raises(loik_amd.LoikError) as e:
-        s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
-    assert e.value.code == -7
+    s = loik_amd.BatchedLoik(m, 2, logging=True, **prm)   # multi-DoF joints (free-flyer, spherical, translation): logged like any model
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    for b in range(2):
+        r = ref.RefSolver(m, **prm)
+        r.Solve(*problem_args(wl, b))
+        n = len(r.solver_info(0))
+        assert s.solver_info()["rows"][b] == n and s.get("iter")[b] == r.get_iter()
+        assert_close(s.solver_info()["dual_residual_list"][b, :n], r.solver_info(5), 1e-8, "dual_residual_list, multi-DoF tree")
     s.close()
 
 
