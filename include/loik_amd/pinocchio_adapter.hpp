@@ -11,11 +11,16 @@
 //   of a joint model  M::joints[i]:     shortname() -> std::string ("JointModelRZ", "JointModelRevoluteUnaligned", ...),
 //                                        idx_q(), idx_v()
 //   of a placement    jointPlacements[i]: rotation()(r, c), translation()[k]              (pinocchio::SE3)
-//   AxisOf(joint, shortname) -> something indexable [0..2]: the axis of an unaligned joint (JointModelRevoluteUnaligned::axis)
+//   AxisOf(joint, shortname) -> something indexable [0..2]: the axis of an unaligned joint (JointModelRevoluteUnaligned::axis);
+//                         for a JointModelUniversal indexable [0..5]: (axis1, axis2)
 //   SubJointsOf(joint) -> a range of (sub-joint model, placement) pairs (.first / .second) of a JointModelComposite
-//                         (JointModelComposite::joints[k], ::jointPlacements[k]); sub-joints must be 1-DoF joints
+//                         (JointModelComposite::joints[k], ::jointPlacements[k]); any supported joint type but a composite
+// JointModelUniversal(axis1, axis2) -- M = R(axis1, q0) R(axis2, q1), S(q) = [R(axis2, q1)^T axis1 | axis2] -- is handed over
+// as what it is: the composite of RevoluteUnaligned(axis1) and RevoluteUnaligned(axis2) with identity placements (same q, same
+// nu; tests/test_composite.py::test_universal_joint_is_the_composite_of_its_two_revolute_joints).
 #pragma once
 
+#include <array>
 #include <cstddef>
 #include <stdexcept>
 #include <string>
@@ -25,6 +30,9 @@
 #include "loik_amd/loik.hpp"
 
 namespace loik_amd {
+
+// (adapter-internal marker, never crosses the C-ABI: a universal joint leaves this header as a LOIKB_J_COMPOSITE)
+enum { LOIKB_J_UNIVERSAL_AS_COMPOSITE = 1000 };
 
 // joint type of include/loik_amd_models.h for a Pinocchio joint short name; LOIKB_J_NONE for an unknown one
 inline int joint_type_of(const std::string& n)
@@ -40,7 +48,8 @@ inline int joint_type_of(const std::string& n)
       {"JointModelPlanar", LOIKB_J_PLANAR},              // nq 4 (x, y, cos, sin), nv 3
       {"JointModelRUBX", LOIKB_J_RUBX}, {"JointModelRUBY", LOIKB_J_RUBY}, {"JointModelRUBZ", LOIKB_J_RUBZ},  // nq 2 (cos, sin)
       {"JointModelRevoluteUnboundedUnaligned", LOIKB_J_RUBU},  // nq 2 (cos, sin), axis from axis_of
-      {"JointModelComposite", LOIKB_J_COMPOSITE},        // of 1-DoF joints: loikb_model_desc.comp_*
+      {"JointModelComposite", LOIKB_J_COMPOSITE},        // loikb_model_desc.comp_*
+      {"JointModelUniversal", LOIKB_J_UNIVERSAL_AS_COMPOSITE},  // -> composite of two unaligned revolute joints (below)
   };
   for (const auto& e : table)
     if (n == e.name) return e.type;
@@ -80,10 +89,10 @@ Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joint
     o.idx_q.push_back(i ? static_cast<int>(m.joints[i].idx_q()) : 0);
     o.idx_v.push_back(i ? static_cast<int>(m.joints[i].idx_v()) : 0);
     const std::string n = i ? m.joints[i].shortname() : std::string();
-    const int t = i ? joint_type_of(n) : LOIKB_J_NONE;
+    int t = i ? joint_type_of(n) : LOIKB_J_NONE;
     if (i && t == LOIKB_J_NONE)
       throw std::runtime_error("loik_amd: joint type '" + n + "' of joint '" + m.names[i] +
-                               "' is not supported (mimic, helical, universal)");
+                               "' is not supported (mimic, helical)");
     double ax[3] = {0.0, 0.0, 0.0};
     if (t == LOIKB_J_RU || t == LOIKB_J_PU || t == LOIKB_J_RUBU) {
       const auto a = axis_of(m.joints[i], n);
@@ -91,14 +100,35 @@ Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joint
     }
     o.comp_first.push_back(static_cast<int>(o.comp_jtype.size()));
     int count = 0;
-    if (t == LOIKB_J_COMPOSITE) {
+    static const double ident[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    // the two revolute joints of a universal joint; `first_placement`: 12 doubles (row-major R, t) of the first one
+    auto push_universal = [&](const auto& joint, const std::string& jn, const double* first_placement) {
+      const auto a = axis_of(joint, jn);  // (axis1, axis2)
+      for (int h = 0; h < 2; ++h) {
+        o.comp_jtype.push_back(LOIKB_J_RU);
+        o.comp_axis.insert(o.comp_axis.end(), {a[3 * h], a[3 * h + 1], a[3 * h + 2]});
+        const double* P = h ? ident : first_placement;
+        o.comp_placement.insert(o.comp_placement.end(), P, P + 12);
+        ++count;
+      }
+    };
+    if (t == LOIKB_J_UNIVERSAL_AS_COMPOSITE) {
+      any_composite = true;
+      push_universal(m.joints[i], n, ident);
+      t = LOIKB_J_COMPOSITE;
+    } else if (t == LOIKB_J_COMPOSITE) {
       any_composite = true;
       for (const auto& sub : sub_joints_of(m.joints[i])) {
         const std::string sn = sub.first.shortname();
         const int st = joint_type_of(sn);
-        const bool one_dof = (st >= LOIKB_J_RX && st <= LOIKB_J_PU) || (st >= LOIKB_J_RUBX && st <= LOIKB_J_RUBZ) || st == LOIKB_J_RUBU;
-        if (!one_dof)
-          throw std::runtime_error("loik_amd: sub-joint '" + sn + "' of the composite joint '" + m.names[i] + "' is not a 1-DoF joint");
+        if (st == LOIKB_J_NONE || st == LOIKB_J_COMPOSITE)
+          throw std::runtime_error("loik_amd: sub-joint '" + sn + "' of the composite joint '" + m.names[i] + "' is not supported");
+        if (st == LOIKB_J_UNIVERSAL_AS_COMPOSITE) {
+          std::vector<double> P;
+          detail::push_placement(P, sub.second);
+          push_universal(sub.first, sn, P.data());
+          continue;
+        }
         double sa[3] = {0.0, 0.0, 0.0};
         if (st == LOIKB_J_RU || st == LOIKB_J_PU || st == LOIKB_J_RUBU) {
           const auto a = axis_of(sub.first, sn);
@@ -179,8 +209,15 @@ std::vector<Vec6> to_vec6_list(const Vectors& vs)
 inline Model to_loik_amd(const pinocchio::Model& m)
 {
   auto axis_of = [](const pinocchio::JointModel& j, const std::string& n) {
-    return n == "JointModelRevoluteUnaligned" ? boost::get<pinocchio::JointModelRevoluteUnaligned>(j.toVariant()).axis
-                                              : boost::get<pinocchio::JointModelPrismaticUnaligned>(j.toVariant()).axis;
+    std::array<double, 6> a{};
+    auto put = [&a](const auto& v, int at) { for (int k = 0; k < 3; ++k) a[at + k] = v[k]; };
+    if (n == "JointModelRevoluteUnaligned") put(boost::get<pinocchio::JointModelRevoluteUnaligned>(j.toVariant()).axis, 0);
+    else if (n == "JointModelRevoluteUnboundedUnaligned") put(boost::get<pinocchio::JointModelRevoluteUnboundedUnaligned>(j.toVariant()).axis, 0);
+    else if (n == "JointModelUniversal") {
+      const auto& u = boost::get<pinocchio::JointModelUniversal>(j.toVariant());
+      put(u.axis1, 0); put(u.axis2, 3);
+    } else put(boost::get<pinocchio::JointModelPrismaticUnaligned>(j.toVariant()).axis, 0);
+    return a;
   };
   auto sub_joints_of = [](const pinocchio::JointModel& j) {
     const auto& c = boost::get<pinocchio::JointModelComposite>(j.toVariant());

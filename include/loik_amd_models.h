@@ -11,8 +11,11 @@
  * Joints: all of Pinocchio's 1-DoF types (incl. the unbounded revolute joints with q = (cos, sin)), the multi-DoF types
  * whose motion subspace is a constant selection of the columns of I6 -- free-flyer (floating base), spherical, translation,
  * planar --, JointModelSphericalZYX, whose q-dependent subspace is that of a Z-Y-X revolute chain, and
- * JointModelComposite of 1-DoF sub-joints (LOIKB_J_COMPOSITE + the comp_* arrays below).  Not covered: JointModelMimic, helical and universal joints, composites
- * with multi-DoF sub-joints.  On the device a multi-DoF
+ * JointModelComposite of any of those (LOIKB_J_COMPOSITE + the comp_* arrays below; up to 6 DoF -- e.g. the hand-made floating
+ * base "translation + spherical").  JointModelUniversal(axis1, axis2) is the composite of RevoluteUnaligned(axis1) and
+ * RevoluteUnaligned(axis2) with identity placements -- pass it as that (the Pinocchio adapter does).  Not covered: JointModelMimic
+ * (two joints share one coordinate: the elimination couples them across the tree) and the helical joints (S = [h a; a]: every
+ * engine exploits that a 1-DoF subspace is purely linear or purely angular).  On the device a multi-DoF
  * joint is a chain of 1-DoF joints with massless links in between; the caller never sees that: q, z / nu / w / lb / ub
  * (length model.nv, Pinocchio's idx_v order) and the per-link results are the caller's model's.
  */
@@ -44,10 +47,11 @@ enum {
   LOIKB_J_RUBX = 14,       /* JointModelRUBX / RUBY / RUBZ (revolute unbounded): nq 2 (cos, sin), nv 1                     */
   LOIKB_J_RUBY = 15,
   LOIKB_J_RUBZ = 16,
-  LOIKB_J_COMPOSITE = 17   /* JointModelComposite of 1-DoF joints: see loikb_model_desc.comp_*; nq / nv = the sums over its
-                              sub-joints, coordinates in sub-joint order.  M = prod_k (placement_k * M_k(q_k)), the motion
-                              subspace column of sub-joint k is its S_k seen from the last sub-joint's frame (q-dependent);
-                              on the device it is the chain of its sub-joints with massless links in between                */
+  LOIKB_J_COMPOSITE = 17   /* JointModelComposite: see loikb_model_desc.comp_*; nq / nv = the sums over its sub-joints (any type
+                              above or RUBU, not a composite; nv <= 6), coordinates in sub-joint order.  M = prod_k (placement_k *
+                              M_k(q_k)), the motion subspace columns of sub-joint k are its S_k seen from the last sub-joint's
+                              frame (q-dependent); on the device it is the chain of its sub-joints (each multi-DoF one its own
+                              chain) with massless links in between                                                          */
   ,
   LOIKB_J_RUBU = 18        /* JointModelRevoluteUnboundedUnaligned: nq 2 (cos, sin), nv 1, about `axis` (also as a sub-joint of a
                               composite)                                                                                    */
@@ -64,9 +68,9 @@ typedef struct loikb_model_desc {
   const double *placement; /* [njoints][12] jointPlacements[i]: R row-major (9), then t (3)   */
   /* JointModelComposite (all NULL / ignored when the model has none): joint i of type LOIKB_J_COMPOSITE consists of the
      sub-joints comp_first[i] .. comp_first[i] + comp_count[i] - 1 of the three arrays below -- what
-     JointModelComposite::addJoint(jmodel, placement) stores: the sub-joint's type (a 1-DoF type: R*, P*, RU, PU, RUB*), its
-     axis (RU / PU) and its placement relative to the previous sub-joint's frame (the first: relative to the frame
-     jointPlacements[i] defines).  comp_count[i] <= 6. */
+     JointModelComposite::addJoint(jmodel, placement) stores: the sub-joint's type (any LOIKB_J_* but COMPOSITE), its
+     axis (RU / PU / RUBU) and its placement relative to the previous sub-joint's frame (the first: relative to the frame
+     jointPlacements[i] defines).  comp_count[i] <= 6 and at most 6 degrees of freedom per composite. */
   const int *comp_first;        /* [njoints] */
   const int *comp_count;        /* [njoints] */
   const int *comp_jtype;        /* [n_sub]   */

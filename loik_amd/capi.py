@@ -202,7 +202,7 @@ def _check(rc):
 J_FREEFLYER, J_SPHERICAL, J_TRANSLATION = 9, 10, 11
 # JointModelSphericalZYX, JointModelPlanar, JointModelRUBX / RUBY / RUBZ
 J_SPHERICAL_ZYX, J_PLANAR, J_RUBX, J_RUBY, J_RUBZ = 12, 13, 14, 15, 16
-J_COMPOSITE = 17  # JointModelComposite of 1-DoF joints (Model(..., composite={joint: [(jtype, axis, placement12), ...]}))
+J_COMPOSITE = 17  # JointModelComposite (Model(..., composite={joint: [(jtype, axis, placement12), ...]}); sub-joints: any type but a composite)
 J_RUBU = 18       # JointModelRevoluteUnboundedUnaligned: nq 2 (cos, sin), nv 1, about `axis`
 JOINT_NQ = {J_FREEFLYER: 7, J_SPHERICAL: 4, J_TRANSLATION: 3, J_SPHERICAL_ZYX: 3, J_PLANAR: 4, J_RUBX: 2, J_RUBY: 2, J_RUBZ: 2, J_RUBU: 2}
 JOINT_NV = {J_FREEFLYER: 6, J_SPHERICAL: 3, J_TRANSLATION: 3, J_SPHERICAL_ZYX: 3, J_PLANAR: 3}
@@ -237,7 +237,7 @@ class Model:
             return JOINT_NQ.get(t, 1)
 
         def nv_of(i, t):
-            return len(self.composite[i]) if t == J_COMPOSITE else JOINT_NV.get(t, 1)
+            return sum(JOINT_NV.get(st, 1) for st, _, _ in self.composite[i]) if t == J_COMPOSITE else JOINT_NV.get(t, 1)
         # joints[i].nq() / nv() / idx_q() / idx_v() of Pinocchio: cumulative in joint order
         nqs = np.array([nq_of(i, int(t)) if i else 0 for i, t in enumerate(self.jtype)], dtype=np.int32)
         nvs = np.array([nv_of(i, int(t)) if i else 0 for i, t in enumerate(self.jtype)], dtype=np.int32)
@@ -270,23 +270,24 @@ class Model:
         lo = -np.ones(self.nq) if self.q_lo is None else self.q_lo
         hi = np.ones(self.nq) if self.q_hi is None else self.q_hi
         q = rng.uniform(lo, hi, size=(batch, self.nq))
-        for i in range(1, self.njoints):
-            t = int(self.jtype[i])
+        def manifold_segments(t, o0):
             if t in (J_FREEFLYER, J_SPHERICAL):
-                o = int(self.idx_q[i]) + (3 if t == J_FREEFLYER else 0)
+                o = o0 + (3 if t == J_FREEFLYER else 0)
                 qt = rng.normal(size=(batch, 4))
                 q[:, o:o + 4] = qt / np.linalg.norm(qt, axis=1, keepdims=True)
             elif t in (J_PLANAR, J_RUBX, J_RUBY, J_RUBZ, J_RUBU):  # the (cos, sin) pair of a random angle
-                o = int(self.idx_q[i]) + (2 if t == J_PLANAR else 0)
+                o = o0 + (2 if t == J_PLANAR else 0)
                 th = rng.uniform(-np.pi, np.pi, size=batch)
                 q[:, o] = np.cos(th); q[:, o + 1] = np.sin(th)
-            elif t == J_COMPOSITE:
+        for i in range(1, self.njoints):
+            t = int(self.jtype[i])
+            if t == J_COMPOSITE:
                 o = int(self.idx_q[i])
                 for st, _, _ in self.composite[i]:
-                    if st in (J_RUBX, J_RUBY, J_RUBZ, J_RUBU):
-                        th = rng.uniform(-np.pi, np.pi, size=batch)
-                        q[:, o] = np.cos(th); q[:, o + 1] = np.sin(th)
+                    manifold_segments(st, o)
                     o += JOINT_NQ.get(st, 1)
+            else:
+                manifold_segments(t, int(self.idx_q[i]))
         return q
 
 

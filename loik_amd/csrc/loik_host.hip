@@ -475,7 +475,6 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
   if (enj < 2) { g_last_error = "model: no joints"; return LOIKB_ERR_MODEL; }
   // JointModelComposite: the sub-joints of joint i (validated below)
   auto comp_n = [&](int i) { return (m->jtype[i] == LOIKB_J_COMPOSITE && m->comp_count) ? m->comp_count[i] : 0; };
-  auto sub_nq = [](int st) { return ((st >= LOIKB_J_RUBX && st <= LOIKB_J_RUBZ) || st == LOIKB_J_RUBU) ? 2 : 1; };
   auto jt_nq = [](int jt) {
     return jt == LOIKB_J_FREEFLYER ? 7 : (jt == LOIKB_J_SPHERICAL || jt == LOIKB_J_PLANAR) ? 4
            : (jt == LOIKB_J_TRANSLATION || jt == LOIKB_J_SPHERICAL_ZYX) ? 3 : ((jt >= LOIKB_J_RUBX && jt <= LOIKB_J_RUBZ) || jt == LOIKB_J_RUBU) ? 2 : 1;
@@ -492,7 +491,8 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
       if (p < 0 || p >= i) { g_last_error = "model: parents[i] must be < i"; return LOIKB_ERR_MODEL; }
       if (jt < LOIKB_J_RX || jt > LOIKB_J_RUBU) {
         g_last_error = "model: unsupported joint type (supported: 1-DoF joints incl. unbounded revolute, free-flyer, spherical, "
-                       "spherical ZYX, translation, planar, composites of 1-DoF joints; not: mimic, helical, universal)";
+                       "spherical ZYX, translation, planar, composites of those -- a universal joint is the composite of its two "
+                       "revolute joints; not: mimic, helical)";
         return LOIKB_ERR_MODEL;
       }
       if (m->idx_q[i] != iq || m->idx_v[i] != iv) {
@@ -505,12 +505,16 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
           g_last_error = "model: a composite joint needs comp_first / comp_count (1..6) / comp_jtype / comp_axis / comp_placement";
           return LOIKB_ERR_MODEL;
         }
+        int cnv = 0;
         for (int k = 0; k < m->comp_count[i]; ++k) {
           const int st = m->comp_jtype[m->comp_first[i] + k];
-          const bool one_dof = (st >= LOIKB_J_RX && st <= LOIKB_J_PU) || (st >= LOIKB_J_RUBX && st <= LOIKB_J_RUBZ) || st == LOIKB_J_RUBU;
-          if (!one_dof) { g_last_error = "model: the sub-joints of a composite joint must be 1-DoF joints"; return LOIKB_ERR_MODEL; }
-          iq += sub_nq(st); iv += 1;
+          if (st < LOIKB_J_RX || st > LOIKB_J_RUBU || st == LOIKB_J_COMPOSITE) {
+            g_last_error = "model: a sub-joint of a composite joint must be one of the supported joint types other than a composite";
+            return LOIKB_ERR_MODEL;
+          }
+          iq += jt_nq(st); iv += jt_nv(st); cnv += jt_nv(st);
         }
+        if (cnv > 6) { g_last_error = "model: a composite joint has at most 6 degrees of freedom here"; return LOIKB_ERR_MODEL; }
         continue;
       }
       iq += jt_nq(jt); iv += jt_nv(jt);
@@ -536,85 +540,84 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
   S->idx_q.assign(1, 0);
   S->jd.assign(1, JointDesc{});
   for (int i = 1; i < enj; ++i) {
-    const int jt = m->jtype[i];
+    // the ELEMENTARY joints of joint i: itself, or the sub-joints of a JointModelComposite -- literally the chain of its
+    // sub-joints, each with its own placement and coordinates (a multi-DoF sub-joint expands into its own chain below); the
+    // bodies between them do not exist (massless), the very last link carries the joint's body
     const int ncomp = comp_n(i);
-    const int n = ncomp ? ncomp : jt_nv(jt);
+    const int nelem = ncomp ? ncomp : 1;
     const int par = S->link_of[m->parents[i]];
     S->first_of[i] = (int)S->parents.size();
-    int comp_q = m->idx_q[i];  // configuration offset of the next sub-joint of a composite
-    for (int k = 0; k < n; ++k) {
-      JointDesc d{};
-      double ax[3] = {0, 0, 0};
-      int rot = ROT_NONE, flags = 0, sub = jt;
-      const int ce = ncomp ? m->comp_first[i] + k : -1;  // entry of the comp_* arrays
-      if (ncomp) {
-        // JointModelComposite: literally the chain of its sub-joints, each with its own placement and coordinate; the bodies
-        // between them do not exist (massless), the last one carries the composite's body
-        sub = m->comp_jtype[ce];
-        if (sub == LOIKB_J_RUBU) { sub = LOIKB_J_RU; flags |= JF_CS_DIRECT; }
-        else if (sub >= LOIKB_J_RUBX) { sub = LOIKB_J_RX + (sub - LOIKB_J_RUBX); flags |= JF_CS_DIRECT; }
-      } else if (jt == LOIKB_J_SPHERICAL_ZYX) {
-        // R = Rz(q0) Ry(q1) Rx(q2), nu = the three angle rates: literally a chain of three revolute joints about z, y, x
-        // with their own coordinates (S(q) of JointModelSphericalZYX::calc is this chain's Jacobian) and massless links
-        sub = k == 0 ? LOIKB_J_RZ : k == 1 ? LOIKB_J_RY : LOIKB_J_RX;
-      } else if (jt == LOIKB_J_PLANAR) {
-        sub = k == 0 ? LOIKB_J_PX : k == 1 ? LOIKB_J_PY : LOIKB_J_RZ;  // ConstraintPlanar: vx, vy, wz of ONE frame
-      } else if (jt >= LOIKB_J_RUBX && jt <= LOIKB_J_RUBZ) {
-        sub = LOIKB_J_RX + (jt - LOIKB_J_RUBX);
-        flags |= JF_CS_DIRECT;
-      } else if (jt == LOIKB_J_RUBU) {  // JointModelRevoluteUnboundedUnaligned: a revolute joint about `axis` whose q IS (cos, sin)
-        sub = LOIKB_J_RU;
-        flags |= JF_CS_DIRECT;
-      } else if (n > 1) {
-        // chain joint k: prismatic along / revolute about axis (k mod 3) of the joint frame
-        const bool angular = jt == LOIKB_J_SPHERICAL || (jt == LOIKB_J_FREEFLYER && k >= 3);
-        sub = (angular ? LOIKB_J_RX : LOIKB_J_PX) + k % 3;
-      }
-      switch (sub) {
-      case LOIKB_J_RX: ax[0] = 1; rot = ROT_X; flags |= JF_REVOLUTE; break;
-      case LOIKB_J_RY: ax[1] = 1; rot = ROT_Y; flags |= JF_REVOLUTE; break;
-      case LOIKB_J_RZ: ax[2] = 1; rot = ROT_Z; flags |= JF_REVOLUTE; break;
-      case LOIKB_J_PX: ax[0] = 1; break;
-      case LOIKB_J_PY: ax[1] = 1; break;
-      case LOIKB_J_PZ: ax[2] = 1; break;
-      case LOIKB_J_RU: for (int c = 0; c < 3; ++c) ax[c] = ncomp ? m->comp_axis[3 * ce + c] : m->axis[3 * i + c]; rot = ROT_U; flags |= JF_REVOLUTE; break;
-      case LOIKB_J_PU: for (int c = 0; c < 3; ++c) ax[c] = ncomp ? m->comp_axis[3 * ce + c] : m->axis[3 * i + c]; break;
-      }
-      for (int c = 0; c < 9; ++c) d.Rp[c] = (n > 1 && k > 0) ? (c % 4 == 0 ? 1.0 : 0.0) : m->placement[12 * i + c];
-      for (int c = 0; c < 3; ++c) d.tp[c] = (n > 1 && k > 0) ? 0.0 : m->placement[12 * i + 9 + c];
-      if (ncomp) {
-        // placement of sub-joint k: comp_placement[k], the first one seen from the parent link: jointPlacements[i] * it
+    int elem_q = m->idx_q[i];  // configuration offset of the next elementary joint
+    for (int e = 0; e < nelem; ++e) {
+      const int ce = ncomp ? m->comp_first[i] + e : -1;  // entry of the comp_* arrays
+      const int jt = ncomp ? m->comp_jtype[ce] : m->jtype[i];
+      const double* jaxis = ncomp ? m->comp_axis + 3 * ce : m->axis + 3 * i;
+      const int n = jt_nv(jt);
+      // placement of the elementary joint's frame seen from the link before it: jointPlacements[i] (* comp_placement[first])
+      // for the first one, comp_placement[e] for the later sub-joints of a composite
+      double P0[12];
+      if (!ncomp) for (int c = 0; c < 12; ++c) P0[c] = m->placement[12 * i + c];
+      else {
         const double* Pc = m->comp_placement + 12 * ce;
-        if (k == 0) {
+        if (e == 0) {
           const double* Pj = m->placement + 12 * i;
           for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) d.Rp[3 * r + c] = Pj[3 * r] * Pc[c] + Pj[3 * r + 1] * Pc[3 + c] + Pj[3 * r + 2] * Pc[6 + c];
-            d.tp[r] = Pj[9 + r] + Pj[3 * r] * Pc[9] + Pj[3 * r + 1] * Pc[10] + Pj[3 * r + 2] * Pc[11];
+            for (int c = 0; c < 3; ++c) P0[3 * r + c] = Pj[3 * r] * Pc[c] + Pj[3 * r + 1] * Pc[3 + c] + Pj[3 * r + 2] * Pc[6 + c];
+            P0[9 + r] = Pj[9 + r] + Pj[3 * r] * Pc[9] + Pj[3 * r + 1] * Pc[10] + Pj[3 * r + 2] * Pc[11];
           }
-        } else {
-          for (int c = 0; c < 9; ++c) d.Rp[c] = Pc[c];
-          for (int c = 0; c < 3; ++c) d.tp[c] = Pc[9 + c];
+        } else for (int c = 0; c < 12; ++c) P0[c] = Pc[c];
+      }
+      for (int k = 0; k < n; ++k) {
+        JointDesc d{};
+        double ax[3] = {0, 0, 0};
+        int rot = ROT_NONE, flags = 0, sub = jt;
+        if (jt == LOIKB_J_SPHERICAL_ZYX) {
+          // R = Rz(q0) Ry(q1) Rx(q2), nu = the three angle rates: literally a chain of three revolute joints about z, y, x
+          // with their own coordinates (S(q) of JointModelSphericalZYX::calc is this chain's Jacobian) and massless links
+          sub = k == 0 ? LOIKB_J_RZ : k == 1 ? LOIKB_J_RY : LOIKB_J_RX;
+        } else if (jt == LOIKB_J_PLANAR) {
+          sub = k == 0 ? LOIKB_J_PX : k == 1 ? LOIKB_J_PY : LOIKB_J_RZ;  // ConstraintPlanar: vx, vy, wz of ONE frame
+        } else if (jt >= LOIKB_J_RUBX && jt <= LOIKB_J_RUBZ) {
+          sub = LOIKB_J_RX + (jt - LOIKB_J_RUBX);
+          flags |= JF_CS_DIRECT;
+        } else if (jt == LOIKB_J_RUBU) {  // JointModelRevoluteUnboundedUnaligned: a revolute joint about `axis` whose q IS (cos, sin)
+          sub = LOIKB_J_RU;
+          flags |= JF_CS_DIRECT;
+        } else if (n > 1) {
+          // chain joint k: prismatic along / revolute about axis (k mod 3) of the joint frame
+          const bool angular = jt == LOIKB_J_SPHERICAL || (jt == LOIKB_J_FREEFLYER && k >= 3);
+          sub = (angular ? LOIKB_J_RX : LOIKB_J_PX) + k % 3;
         }
-        if (k < n - 1) flags |= JF_MASSLESS;
-      } else if (n > 1) {
-        if (jt != LOIKB_J_SPHERICAL_ZYX) {  // (a ZYX chain consists of ordinary revolute joints: each reads its own angle)
+        switch (sub) {
+        case LOIKB_J_RX: ax[0] = 1; rot = ROT_X; flags |= JF_REVOLUTE; break;
+        case LOIKB_J_RY: ax[1] = 1; rot = ROT_Y; flags |= JF_REVOLUTE; break;
+        case LOIKB_J_RZ: ax[2] = 1; rot = ROT_Z; flags |= JF_REVOLUTE; break;
+        case LOIKB_J_PX: ax[0] = 1; break;
+        case LOIKB_J_PY: ax[1] = 1; break;
+        case LOIKB_J_PZ: ax[2] = 1; break;
+        case LOIKB_J_RU: for (int c = 0; c < 3; ++c) ax[c] = jaxis[c]; rot = ROT_U; flags |= JF_REVOLUTE; break;
+        case LOIKB_J_PU: for (int c = 0; c < 3; ++c) ax[c] = jaxis[c]; break;
+        }
+        for (int c = 0; c < 9; ++c) d.Rp[c] = k > 0 ? (c % 4 == 0 ? 1.0 : 0.0) : P0[c];
+        for (int c = 0; c < 3; ++c) d.tp[c] = k > 0 ? 0.0 : P0[9 + c];
+        if (n > 1 && jt != LOIKB_J_SPHERICAL_ZYX) {  // (a ZYX chain consists of ordinary revolute joints: each reads its own angle)
           if (k == 0) rot = jt == LOIKB_J_FREEFLYER ? ROT_FREE : jt == LOIKB_J_SPHERICAL ? ROT_SPH
                             : jt == LOIKB_J_PLANAR ? ROT_PLANAR : ROT_TRANS;
           else flags |= JF_NOQ;
         }
-        if (k < n - 1) flags |= JF_MASSLESS;
+        if (!(e == nelem - 1 && k == n - 1)) flags |= JF_MASSLESS;
+        for (int c = 0; c < 3; ++c) d.axis[c] = ax[c];
+        d.parent = (e == 0 && k == 0) ? par : (int)S->parents.size() - 1;
+        if (d.parent == 0) flags |= JF_PARENT_ROOT;
+        d.flags = flags;
+        d.cslot = -1;
+        d.rot = rot;
+        S->parents.push_back(d.parent);
+        S->jtype.push_back(sub);
+        S->idx_q.push_back(jt == LOIKB_J_SPHERICAL_ZYX ? elem_q + k : (k == 0 ? elem_q : 0));
+        S->jd.push_back(d);
       }
-      for (int c = 0; c < 3; ++c) d.axis[c] = ax[c];
-      d.parent = k == 0 ? par : (int)S->parents.size() - 1;
-      if (d.parent == 0) flags |= JF_PARENT_ROOT;
-      d.flags = flags;
-      d.cslot = -1;
-      d.rot = rot;
-      S->parents.push_back(d.parent);
-      S->jtype.push_back(sub);
-      S->idx_q.push_back(ncomp ? comp_q : jt == LOIKB_J_SPHERICAL_ZYX ? m->idx_q[i] + k : (k == 0 ? m->idx_q[i] : 0));
-      if (ncomp) comp_q += sub_nq(m->comp_jtype[ce]);
-      S->jd.push_back(d);
+      elem_q += jt_nq(jt);
     }
     S->link_of[i] = (int)S->parents.size() - 1;
   }

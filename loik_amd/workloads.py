@@ -44,6 +44,8 @@ def quat_rot(qt):
 
 
 J_COMPOSITE = 17
+_NQ = {9: 7, 10: 4, 11: 3, 12: 3, 13: 4, 14: 2, 15: 2, 16: 2, 18: 2}   # (free-flyer, spherical, translation, ZYX, planar, RUB*)
+_NV = {9: 6, 10: 3, 11: 3, 12: 3, 13: 3}
 
 
 class _Chain:
@@ -69,8 +71,8 @@ class _Chain:
                     parents.append(par if k == 0 else len(parents) - 1)
                     jtype.append(int(st)); axis.append(np.asarray(a, dtype=float)); placement.append(P)
                     idx_q.append(iq); idx_v.append(iv)
-                    iq += 2 if st in (J_RUBX, J_RUBY, J_RUBZ, J_RUBU) else 1
-                    iv += 1
+                    iq += _NQ.get(int(st), 1)
+                    iv += _NV.get(int(st), 1)
             self.link_of.append(len(parents) - 1)
         self.njoints = len(parents)
         self.parents, self.jtype = np.array(parents), np.array(jtype)

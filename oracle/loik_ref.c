@@ -608,7 +608,8 @@ int ref_create(const ref_model *m, const ref_params *p, ref_solver **out)
     for (int i = 1; i < nj; ++i)
       if (s->jtype[i] == REF_J_COMPOSITE) {
         s->comp_first[i] = m->comp_first[i]; s->comp_count[i] = m->comp_count[i];
-        s->jnv[i] = m->comp_count[i];
+        s->jnv[i] = 0;   /* sum over the sub-joints (1-DoF or multi-DoF: translation + spherical, planar ...), <= 6 */
+        for (int k = 0; k < m->comp_count[i]; ++k) s->jnv[i] += joint_nv(m->comp_jtype[m->comp_first[i] + k]);
         if (m->comp_first[i] + m->comp_count[i] > s->n_sub) s->n_sub = m->comp_first[i] + m->comp_count[i];
       }
   s->comp_jtype = (int *)calloc(s->n_sub ? s->n_sub : 1, sizeof(int));
@@ -927,7 +928,8 @@ int ref_active_id(const ref_solver *s, int c) { return (c >= 0 && c < s->nc) ? s
  * the sub-joints are visited last to first; with iMlast[k] = the placement of sub-joint k's frame (before its own motion:
  * jointPlacements[k] * M_k) seen ... from the LAST sub-joint's frame,
  *     M = prod_k jointPlacements[k] * M_k(q_k)            (the composite's transform)
- *     S.col(k) = iMlast[k+1].actInv(S_k)                   (S_k seen from the last frame; the last column is S_{n-1} itself)
+ *     S.cols(k) = iMlast[k+1].actInv(S_k)                  (S_k seen from the last frame; the last columns are S_{n-1} itself;
+ *                                                           a multi-DoF sub-joint contributes its nv_k columns)
  * `qs` = the composite's segment of q, S: 6 x nv columns */
 static void composite_calc(const ref_solver *s, int idx, const double *qs, double *M, double *S)
 {
@@ -947,12 +949,17 @@ static void composite_calc(const ref_solver *s, int idx, const double *qs, doubl
   }
   memcpy(M, T[n], sizeof(double) * 12);
   memset(S, 0, 36 * sizeof(double));
+  int col = 0;
+  oq = 0;
   for (int k = 0; k < n; ++k) {
+    const int st = s->comp_jtype[first + k];
     double Sk[36], inv[12], kMlast[12];
-    joint_S(s->comp_jtype[first + k], s->comp_axis + 3 * (first + k), NULL, Sk);   /* 1-DoF: first column */
+    joint_S(st, s->comp_axis + 3 * (first + k), qs + oq, Sk);   /* nv_k columns (q-dependent for a ZYX sub-joint) */
     se3_inv(after[k], inv);
     se3_mul(inv, T[n], kMlast);                       /* placement of the last frame seen from sub-joint k's */
-    se3_actinv_motion(kMlast, Sk, S + 6 * k);         /* S_k seen from the last frame */
+    for (int c = 0; c < joint_nv(st) && col < 6; ++c, ++col)
+      se3_actinv_motion(kMlast, Sk + 6 * c, S + 6 * col);   /* S_k seen from the last frame */
+    oq += joint_nq(st);
   }
 }
 

@@ -46,7 +46,7 @@ enum {
   REF_J_RUBX = 14,       /* JointModelRUBX / RUBY / RUBZ: nq 2 (cos, sin), nv 1                               */
   REF_J_RUBY = 15,
   REF_J_RUBZ = 16,
-  REF_J_COMPOSITE = 17,  /* JointModelComposite of 1-DoF joints, described by ref_model.comp_* (nv <= 6)               */
+  REF_J_COMPOSITE = 17,  /* JointModelComposite of any sub-joints but composites, ref_model.comp_* (nv <= 6)                */
   REF_J_RUBU = 18        /* JointModelRevoluteUnboundedUnaligned: nq 2 (cos, sin), nv 1, about ref_model.axis          */
 };
 

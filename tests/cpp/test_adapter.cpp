@@ -34,7 +34,7 @@ struct SE3 {
 struct JointModel {
   std::string sn;
   int iq = 0, iv = 0;
-  double ax[3] = {0, 0, 0};
+  double ax[6] = {0, 0, 0, 0, 0, 0};   // (axis; JointModelUniversal: axis1, axis2)
   std::vector<std::pair<JointModel, SE3>> subs;  // JointModelComposite::joints / ::jointPlacements
   std::string shortname() const { return sn; }
   int idx_q() const { return iq; }
@@ -139,7 +139,7 @@ int main()
     Model m;
     const int types[] = {LOIKB_J_NONE, LOIKB_J_FREEFLYER, LOIKB_J_RU, LOIKB_J_PU, LOIKB_J_SPHERICAL, LOIKB_J_TRANSLATION,
                          LOIKB_J_SPHERICAL_ZYX, LOIKB_J_PLANAR, LOIKB_J_RUBY, LOIKB_J_PZ, LOIKB_J_RUBU, LOIKB_J_COMPOSITE};
-    const int nqs[] = {0, 7, 1, 1, 4, 3, 3, 4, 2, 1, 2, 4}, nvs[] = {0, 6, 1, 1, 3, 3, 3, 3, 1, 1, 1, 3};
+    const int nqs[] = {0, 7, 1, 1, 4, 3, 3, 4, 2, 1, 2, 7}, nvs[] = {0, 6, 1, 1, 3, 3, 3, 3, 1, 1, 1, 5};
     m.njoints = 12;
     for (int i = 0; i < m.njoints; ++i) {
       m.parents.push_back(i ? (i - 1) / 2 : 0);
@@ -154,11 +154,11 @@ int main()
       const double P[12] = {c, -s, 0, s, c, 0, 0, 0, 1, 0.1 * i, -0.2, 0.05 * i};  // Rz(0.3 i): not symmetric -> order matters
       m.jointPlacements.insert(m.jointPlacements.end(), P, P + 12);
       m.names.push_back(i ? "joint_" + std::to_string(i) : "universe");
-      // joint 11: a composite of RU, RUBZ (nq 2), PY with rotated internal placements
+      // joint 11: a composite of RU, RUBZ (nq 2), Spherical (nq 4, nv 3) with rotated internal placements
       m.comp_first.push_back(i == 11 ? 0 : (i < 11 ? 0 : 3));
       m.comp_count.push_back(i == 11 ? 3 : 0);
     }
-    m.comp_jtype = {LOIKB_J_RU, LOIKB_J_RUBZ, LOIKB_J_PY};
+    m.comp_jtype = {LOIKB_J_RU, LOIKB_J_RUBZ, LOIKB_J_SPHERICAL};
     m.comp_axis = {0.6, 0.0, 0.8, 0, 0, 0, 0, 0, 0};
     for (int k = 0; k < 3; ++k) {
       const double c = std::cos(0.7 + k), s = std::sin(0.7 + k);
@@ -172,6 +172,36 @@ int main()
     try { (void)to_loik_amd(p, [](const shape::JointModel& j, const std::string&) { return j.ax; }); }
     catch (const std::runtime_error& e) { thrown = std::strstr(e.what(), "JointModelMimic") && std::strstr(e.what(), "joint_3"); }
     CHECK(thrown);
+    {  // JointModelUniversal(axis1, axis2): leaves the adapter as the composite of RevoluteUnaligned(axis1), (axis2), identity
+       // placements; as a sub-joint of a composite: the same two in place, the first with the sub-joint's placement
+      shape::Model u = pinocchio_shaped(m);
+      u.joints[2].sn = "JointModelUniversal";     // (joint 2 was 1-DoF: the coordinates behind it move by one)
+      const double axes[6] = {0.0, 0.6, 0.8, 1.0, 0.0, 0.0};
+      for (int k = 0; k < 6; ++k) u.joints[2].ax[k] = axes[k];
+      for (int i = 3; i < u.njoints; ++i) { u.joints[i].iq += 1; u.joints[i].iv += 1; }
+      u.nq += 1; u.nv += 1;
+      shape::JointModel su; su.sn = "JointModelUniversal";
+      for (int k = 0; k < 6; ++k) su.ax[k] = axes[5 - k];
+      shape::JointModel sp; sp.sn = "JointModelPZ";
+      const double Psub[12] = {0, -1, 0, 1, 0, 0, 0, 0, 1, 0.3, 0.2, 0.1};
+      u.joints[11].subs = {{sp, se3_of(Psub)}, {su, se3_of(Psub)}};   // nq 3, nv 3
+      u.nq += 3 - 7; u.nv += 3 - 5;
+      const Model o = to_loik_amd(u, [](const shape::JointModel& j, const std::string&) { return j.ax; },
+                                  [](const shape::JointModel& j) { return j.subs; });
+      CHECK(o.jtype[2] == LOIKB_J_COMPOSITE && o.comp_count[2] == 2 && o.comp_first[2] == 0);
+      CHECK(o.comp_jtype[0] == LOIKB_J_RU && o.comp_jtype[1] == LOIKB_J_RU);
+      for (int k = 0; k < 6; ++k) CHECK(o.comp_axis[k] == axes[k]);
+      for (int h = 0; h < 2; ++h)
+        for (int k = 0; k < 12; ++k) CHECK(o.comp_placement[12 * h + k] == ((k < 9 && k % 4 == 0) ? 1.0 : 0.0));
+      CHECK(o.comp_first[11] == 2 && o.comp_count[11] == 3);
+      CHECK(o.comp_jtype[2] == LOIKB_J_PZ && o.comp_jtype[3] == LOIKB_J_RU && o.comp_jtype[4] == LOIKB_J_RU);
+      for (int k = 0; k < 6; ++k) CHECK(o.comp_axis[9 + k] == axes[5 - k]);
+      for (int k = 0; k < 12; ++k) {
+        CHECK(o.comp_placement[12 * 3 + k] == Psub[k]);
+        CHECK(o.comp_placement[12 * 4 + k] == ((k < 9 && k % 4 == 0) ? 1.0 : 0.0));
+      }
+      CHECK(o.nq == u.nq && o.nv == u.nv && o.idx_q[3] == u.joints[3].iq);
+    }
     p.joints[3].sn = "JointModelComposite";   // a composite needs the SubJointsOf functor
     thrown = false;
     try { (void)to_loik_amd(p, [](const shape::JointModel& j, const std::string&) { return j.ax; }); }
