@@ -163,7 +163,7 @@ class Shard:
             self.last = st
             for k in ("kernel_ms", "tail_ms", "tail_instances", "tail_instance_iterations", "tail_launches", "total_ms",
                       "solve_busy_ms", "tail_busy_ms", "instance_iterations", "launches", "hslots_ms", "lean_launches",
-                      "flat_launches", "queue_dry_ms", "flat_split_launches"):
+                      "flat_launches", "queue_dry_ms", "flat_split_launches", "flat_ordered"):
                 self.acc[k] = self.acc.get(k, 0) + st.get(k, 0)
 
     def results(self):
@@ -396,6 +396,57 @@ def whole_body_variant(args, device):
     return out
 
 
+def schedule_variant(args, device):
+    """What the order of the work queue is worth.  `value` is measured the way the reference's timing test measures (SolveInit once,
+    then Solve() again and again, tests/loik-loid.cpp:987-1032): from its second solve on the flat engine takes the instances
+    longest first, by the iteration counts the handle's previous solve had -- here the same batch, i.e. a perfect prediction.  This
+    variant reports the other ends: the same batch in arrival order (LOIKB_FLAT_ORDER=0: what a handle's first solve costs),
+    and a batch drawn afresh before every solve (the previous solve's order predicts nothing; the engine notices and goes back to
+    arrival order + time slices)."""
+    import loik_amd
+    from loik_amd import workloads
+    out = {}
+    wl = workloads.talos_c3(args.batch)
+    old = os.environ.get("LOIKB_FLAT_ORDER")
+    try:
+        os.environ["LOIKB_FLAT_ORDER"] = "0"
+        s = loik_amd.BatchedLoik(wl["model"], args.batch, device=device, flags=args.flags, **wl["params"])
+    finally:
+        if old is None:
+            os.environ.pop("LOIKB_FLAT_ORDER", None)
+        else:
+            os.environ["LOIKB_FLAT_ORDER"] = old
+    s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    s.Solve(); s.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        s.Solve()
+    s.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    conv = s.get("converged").astype(bool)
+    st = s.stats()
+    out["arrival_order"] = {"ms_per_step": dt * 1e3, "value": float(conv.sum() / dt), "unit": "solves/s", "flat_ordered": st["flat_ordered"],
+                            "time_slices_requeued": st["lean_requeues"], "queue_dry_ms": st["queue_dry_ms"]}
+    s.close()
+    s = loik_amd.BatchedLoik(wl["model"], args.batch, device=device, flags=args.flags, **wl["params"])
+    ms, solved, ordered = [], [], 0
+    for i in range(6):
+        w2 = workloads.talos_c3(args.batch, seed=0x5EED + i)
+        s.SolveInit(w2["q"], w2["H_ref"], w2["v_ref"], w2["c_ids"], w2["Ais"], w2["bis"], w2["lb"], w2["ub"])
+        s.synchronize()
+        t0 = time.perf_counter()
+        s.Solve()
+        s.synchronize()
+        if i:
+            ms.append((time.perf_counter() - t0) * 1e3)
+            solved.append(int(s.get("converged").astype(bool).sum()))
+            ordered += s.stats()["flat_ordered"]
+    out["another_batch_every_solve"] = {"ms_per_step": sum(ms) / len(ms), "value": float(sum(solved) / (sum(ms) * 1e-3)), "unit": "solves/s",
+                                        "solves": len(ms), "of_which_ordered": ordered}
+    s.close()
+    return out
+
+
 def fp32_tradeoff_variant(args, device):
     """BASELINE config 5's table: Panda-7, B = 65536, tol 1e-3 / 1e-4 x {fp64, fp32 fast, fp32 accurate
     (LOIKB_OPT_F32_ACCURATE)}: solves/s and the distance of the fp32 answers from the fp64 DEVICE answers (the fp64 oracle is
@@ -612,6 +663,9 @@ def main(argv=None, solver_factory=None, device_count=None):
                 "instance_iterations_per_s": total_iters * args.steps / elapsed,
                 "solve_init_s_gpu0_incl_pcie": t_init0,
                 "engines_gpu0": plan0,
+                "schedule": ("timed solves repeat one batch (as the reference's timing test does); the flat engine took %d of %d of them "
+                             "longest first, by the iteration counts of the handle's previous solve -- see schedule_variant for arrival "
+                             "order and for a fresh batch every solve" % (acc0.get("flat_ordered", 0), args.steps)),
             },
             "roofline": kernel_roofline(acc0, last0, args.steps, nb, nc, B0),
         }
@@ -630,6 +684,10 @@ def main(argv=None, solver_factory=None, device_count=None):
                 line["whole_body_variant"] = whole_body_variant(args, device_of(0))
             except Exception as e:  # the headline must survive a failing variant
                 line["whole_body_variant"] = {"failed": repr(e)}
+            try:
+                line["schedule_variant"] = schedule_variant(args, device_of(0))
+            except Exception as e:
+                line["schedule_variant"] = {"failed": repr(e)}
             try:
                 line["roofline"].update(regimes_variant(args, device_of(0), nb))
             except Exception as e:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LOIKB_VERSION 302  /* round.minor: bumped whenever a struct or an entry point of this header changes */
+#define LOIKB_VERSION 303  /* round.minor: bumped whenever a struct or an entry point of this header changes */
 
 /* ---- status codes -------------------------------------------------------------------------------- */
 enum {
@@ -326,6 +326,8 @@ typedef struct loikb_stats {
                                              work queue empty -- the bulk phase; the rest of the launch waits for its long runners */
   int flat_split_launches;                /* of flat_launches: those in the build with two lanes per joint (k_flat2,
                                              loik_amd/csrc/loik_flat2.hpp: robots of 17..32 joints, fp64, no logging)            */
+  int flat_ordered;                       /* of flat_launches: those that took their instances longest first, in the order the
+                                             handle's previous solve left (LOIKB_FLAT_ORDER=0 turns that off)                   */
 } loikb_stats;
 int loikb_get_stats(loikb_solver *s, loikb_stats *out);
 /* which kernels the solves of this handle use and why (the engine plan is made in one place, from (nb, nc, sharing mode of

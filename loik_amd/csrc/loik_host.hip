@@ -62,6 +62,8 @@ struct Tuning {
   int flat_split_wpe = 2;       // LOIKB_FLAT_WPE=3: k_flat2 built for three wavefronts per SIMD
   int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's round-robin time slice in iterations (0 = run to completion; default -1:
                                 // 160 for launches of 12..96 instances per resident wavefront, where the stragglers' tail is worth it)
+  bool flat_order = true;       // LOIKB_FLAT_ORDER=0: the flat engine takes its instances in arrival order even when the handle's previous
+                                // solve left an order (longest first, k_order_*: loik_lean.hpp)
   int tail_waves = TAIL_WAVES;  // LOIKB_TAIL_WAVES    wavefronts per k_tail workgroup
   int lean_decades = 10;        // LOIKB_LEAN_DECADES  decades of mu with precomputed H slots ...
   int lean_klo = -2;            // LOIKB_LEAN_KLO      ... starting at mu0 * 10^klo
@@ -87,6 +89,7 @@ struct Tuning {
     if (const char* e = getenv("LOIKB_FLAT_SPLIT")) flat_split = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_WPE")) flat_split_wpe = atoi(e) == 3 ? 3 : 2;
     if (const char* e = getenv("LOIKB_FLAT_SLICE")) flat_slice = std::max(-1, atoi(e));
+    if (const char* e = getenv("LOIKB_FLAT_ORDER")) flat_order = atoi(e) != 0;
     geti("LOIKB_TAIL_WAVES", tail_waves); tail_waves = std::max(1, std::min(TAIL_WAVES, tail_waves));
     geti("LOIKB_LEAN_DECADES", lean_decades); lean_decades = std::max(1, std::min(16, lean_decades));
     geti("LOIKB_LEAN_KLO", lean_klo);
@@ -223,6 +226,10 @@ struct loikb_solver_impl {
     unsigned int* h_counters = nullptr;  // pinned
     int* d_slots = nullptr;              // list of the live instances handed to the tail kernel
     int* d_slots2 = nullptr;             // instances that left the lean kernel unfinished (same capacity)
+    int* d_order = nullptr;              // the chunk's instances, longest first by the iteration counts of the previous solve
+    unsigned int* d_order_bins = nullptr;  // [2 ORDER_BINS] counts / offsets of the counting sort
+    int order_n = 0;                     // instances d_order lists (0: none yet)
+    int order_holdoff = 0;               // solves to go in arrival order after an order that predicted badly
     int* d_ring = nullptr;               // work queue of the lean kernel: ring of instance slots (ring_cap, a power of two)
     int ring_cap = 0;
     void* d_hslots = nullptr;            // decade slots of the lean tail kernel (H, Dinv, UDinv per joint and decade)
@@ -992,7 +999,7 @@ void destroy_chunks(loikb_solver_impl* S)
     if (C.ev_k2) (void)hipEventDestroy(C.ev_k2);
     if (C.ev_k1) (void)hipEventDestroy(C.ev_k1);
     if (C.own_stream && C.stream) (void)hipStreamDestroy(C.stream);
-    void* ptrs[4] = {C.d_counters, C.d_slots, C.d_slots2, C.d_ring};
+    void* ptrs[6] = {C.d_counters, C.d_slots, C.d_slots2, C.d_ring, C.d_order, C.d_order_bins};
     for (void* p : ptrs)
       if (p) {
         (void)hipFree(p);
@@ -1027,6 +1034,10 @@ int build_chunks(loikb_solver_impl* S, int nchunks)
     C.d_slots = (int*)tmp;
     if ((rc = alloc_dev(S, &tmp, sizeof(int) * (size_t)(C.B + WAVE)))) return rc;
     C.d_slots2 = (int*)tmp;
+    if ((rc = alloc_dev(S, &tmp, sizeof(int) * (size_t)(C.B + WAVE)))) return rc;
+    C.d_order = (int*)tmp;
+    if ((rc = alloc_dev(S, &tmp, sizeof(unsigned int) * 2 * ORDER_BINS))) return rc;
+    C.d_order_bins = (unsigned int*)tmp;
     C.ring_cap = 64;
     while (C.ring_cap < 2 * (C.B + WAVE)) C.ring_cap <<= 1;
     if ((rc = alloc_dev(S, &tmp, sizeof(int) * (size_t)C.ring_cap))) return rc;
@@ -1589,6 +1600,13 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       P.max_launch_iters = S->opt.max_iter + 1;
       HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
+      // longest first: the order the previous solve of this handle left (k_order_*, loik_lean.hpp) when this launch takes the same
+      // whole set; the decade slots are indexed by the position in the list, so k_fslots and the engine see the same one
+      const bool ordered = S->tune.flat_order && whole_set && list == C->d_slots && n == n_cur && C->order_n == n_cur &&
+                           C->order_holdoff == 0 && (split || one) && !(S->opt.flags & LOIKB_OPT_OWN_STREAM);
+      if (C->order_holdoff > 0) --C->order_holdoff;
+      if (ordered) HIPCHK(hipMemcpyAsync(C->d_slots, C->d_order, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, C->stream));
+      C->stats.flat_ordered += ordered ? 1 : 0;
       {
         const dim3 hgrid((unsigned)((n + ipw - 1) / ipw));
         // [65][22] exchange rows (pass B's L columns, [NA + 1][64], live in them afterwards) + [65][6] S^w + the constraints' A^T A
@@ -1625,7 +1643,10 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           // on by default between 12 and 96 instances per resident wavefront.  Slices of 32 / 64 / 96 / 128 / 192 / 256 / 384
           // iterations on the headline: 19.6 / 13.7 / 12.40 / 12.36 / 12.33 / 12.45 / 12.76 ms.
           const int resident = (int)grid.x;
-          const int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice
+          // (an ordered launch runs to completion: its long runners start first and must not go to the back of the queue.  Time
+          //  slices for everything behind the predicted-long prefix were tried: the SLICED build's agent-scope loads / stores of
+          //  the records cost the short instances more than the slices bring -- 12.2 ms against 10.6)
+          const int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice : ordered ? 0
                               : (n_first >= 12 * resident && n_first <= 96 * resident && (int)grid.x == per_cu * (int)(cu_sh + 0.5) &&
                                  !(S->opt.flags & LOIKB_OPT_OWN_STREAM)) ? 160 : 0;
           // (not for a handle on a stream of its own: that is how batches are kept in flight side by side, and then the other
@@ -1651,7 +1672,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           grid = dim3((unsigned)std::min(n, per_cu1 * (int)(cu_sh + 0.5)));
           // (time slicing as in k_flat2, same window: whole body, four tasks, B = 65 536: 34.7 ms without)
           const int resident = (int)grid.x, full = per_cu1 * (int)(cu_sh + 0.5);
-          const int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice
+          const int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice : ordered ? 0
                               : (n_first >= 12 * resident && n_first <= 96 * resident && resident == full &&
                                  !(S->opt.flags & LOIKB_OPT_OWN_STREAM)) ? 160 : 0;
 #define LOIKB_LAUNCH_FLAT1(NAV, ...)                                                                                            \
@@ -1699,6 +1720,16 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       int* next = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
       HIPCHK(hipEventRecord(C->ev_k1, C->stream));
       HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+      if (S->tune.flat_order && whole_set && n_first == n_cur && (split || one) && !(S->opt.flags & (LOIKB_OPT_OWN_STREAM | LOIKB_OPT_FIXED_ITERS))) {
+        // the order for the handle's next solve: longest first by the iteration counts of this one (an instance that escaped to
+        // k_tail counts with what it had when it left)
+        HIPCHK(hipMemsetAsync(C->d_order_bins, 0, sizeof(unsigned int) * 2 * ORDER_BINS, C->stream));
+        hipLaunchKernelGGL(k_order_count<T>, grid1(n_cur), dim3(256), 0, C->stream, A.tiles, S->L, n_cur, S->opt.max_iter, C->d_order_bins);
+        hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORDER_BINS), 0, C->stream, C->d_order_bins);
+        hipLaunchKernelGGL(k_order_scatter<T>, grid1(n_cur), dim3(256), 0, C->stream, A.tiles, S->L, n_cur, S->opt.max_iter, C->d_order_bins, C->d_order);
+        HIPCHK(hipGetLastError());
+        C->order_n = n_cur;
+      }
       HIPCHK(hipStreamSynchronize(C->stream));
       float ms = 0.f, t0 = 0.f, hms = 0.f;
       HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));
@@ -1719,6 +1750,14 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       C->stats.hslots_ms += hms;
       if (C->h_counters[FLAT_COUNTERS_DRY])  // (100 MHz clock, low words: from the ring fill of the last stage to the first empty fetch)
         C->stats.queue_dry_ms += (double)(unsigned int)(C->h_counters[FLAT_COUNTERS_TDRY] - C->h_counters[FLAT_COUNTERS_T0]) * 1e-5;
+      if (ordered && C->h_counters[FLAT_COUNTERS_DRY]) {
+        // did the order predict this solve?  A good one leaves the engine ~3 % of its time after the queue ran dry (only short
+        // instances are fetched last); a batch that does not resemble the previous one leaves the 20..25 % of arrival order
+        // without the time slices that would have softened it: then the next solves go back to arrival order + slices
+        const double flat_ms = (double)ms - (double)hms;
+        const double dry_ms = (double)(unsigned int)(C->h_counters[FLAT_COUNTERS_TDRY] - C->h_counters[FLAT_COUNTERS_T0]) * 1e-5;
+        if (flat_ms - dry_ms > 0.10 * flat_ms) C->order_holdoff = 4;
+      }
       if (trace)
         fprintf(stderr, "[loikb] flat engine: %6d instances on %u workgroups, done at %8.3f ms (slots %6.3f ms)  "
                         "inst-iters %9u  wave-iters %7u  slot loads %7u (+ %u served from LDS)  escaped %u  still iterating %u\n",
@@ -2100,6 +2139,7 @@ int run_main_loop_t(loikb_solver_impl* S)
     S->stats.lean_launches += C.stats.lean_launches;
     S->stats.flat_launches += C.stats.flat_launches;
     S->stats.flat_split_launches += C.stats.flat_split_launches;
+    S->stats.flat_ordered += C.stats.flat_ordered;
     S->stats.queue_dry_ms += C.stats.queue_dry_ms;
     S->stats.lean_escaped += C.stats.lean_escaped;
     S->stats.hslots_ms += C.stats.hslots_ms;

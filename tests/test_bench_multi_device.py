@@ -45,7 +45,7 @@ class FakeSolver:
         it = int(self.out["iters"].sum())
         return dict(kernel_ms=1.0, tail_ms=1.0, tail_instances=self.B, tail_instance_iterations=it, tail_launches=1,
                     total_ms=1.0, solve_busy_ms=0.0, tail_busy_ms=1.0, instance_iterations=it, launches=1, hslots_ms=0.1,
-                    lean_launches=1, flat_launches=1, flat_split_launches=1, queue_dry_ms=0.6, bytes_per_instance_iteration=8.0 * (203 * 32 + 108), team=4, chunks=1,
+                    lean_launches=1, flat_launches=1, flat_split_launches=1, flat_ordered=1, queue_dry_ms=0.6, bytes_per_instance_iteration=8.0 * (203 * 32 + 108), team=4, chunks=1,
                     lean_escaped=0)
 
     def get(self, name):

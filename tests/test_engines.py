@@ -147,6 +147,45 @@ def test_lean_time_slicing_changes_nothing(talos, monkeypatch):
     a.close()
 
 
+@pytest.mark.parametrize("robot", ["talos32", "talos44"])
+def test_longest_first_order_changes_nothing_but_the_schedule(robot, monkeypatch):
+    """the flat engine takes a handle's second and later solves longest first (counting sort of the previous solve's iteration
+    counts, k_order_*): the schedule changes, no number does -- every member bit-identical to the first solve's (arrival order,
+    time-sliced) and to a handle with LOIKB_FLAT_ORDER=0; a different problem on the same handle (stale order) as well"""
+    from loik_amd import workloads
+    for v in ("LOIKB_FLAT_ORDER", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_WG_PER_CU"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("LOIKB_LEAN_WG_PER_CU", "1")     # (few resident wavefronts: the queue matters at a test-sized batch)
+    B = 6000
+    wl = workloads.talos_c3(B, seed=5) if robot == "talos32" else workloads.talos_wholebody(B, seed=5)
+    wl2 = workloads.talos_c3(B, seed=6) if robot == "talos32" else workloads.talos_wholebody(B, seed=6)
+    names = ["iter", "converged", "primal_infeasible", "mu", "z", "nu", "w", "vis", "fis", "g", "yis", "primal_residual", "dual_residual",
+             "mu_updates"]
+
+    def run(s, w):
+        s.SolveInit(w["q"], w["H_ref"], w["v_ref"], w["c_ids"], w["Ais"], w["bis"], w["lb"], w["ub"])
+        s.Solve()
+        return {n: s.get(n) for n in names}, s.stats()
+    s = loik_amd.BatchedLoik(wl["model"], B, **wl["params"])
+    first, st1 = run(s, wl)
+    assert st1["flat_launches"] == 1 and st1["flat_ordered"] == 0, st1
+    s.Solve()
+    st2 = s.stats()
+    assert st2["flat_ordered"] == 1 and st2["lean_requeues"] == 0 and st2["tail_instances"] == B, st2
+    for n in names:
+        assert np.array_equal(s.get(n), first[n]), n
+    other, st3 = run(s, wl2)                           # another batch on the handle: the stale order is only a schedule
+    assert st3["flat_ordered"] == 1
+    monkeypatch.setenv("LOIKB_FLAT_ORDER", "0")
+    p = loik_amd.BatchedLoik(wl["model"], B, **wl["params"])
+    plain, _ = run(p, wl2)
+    p.Solve()
+    assert p.stats()["flat_ordered"] == 0
+    for n in names:
+        assert np.array_equal(other[n], plain[n]), n
+    s.close(); p.close()
+
+
 def test_engine_plan_is_made_in_one_place(talos, panda7, monkeypatch):
     """loikb_plan_string: the dispatch (nb, nc, A shared?, children, options) -> engines, re-made at SolveInit when the sharing
     mode of A is known (round 1 fixed the chunk count at create with the default mode)"""
