@@ -119,6 +119,8 @@ enum : int {
   MODE_A_SHARED = 4,     // one A per constraint for the whole batch
   MODE_BND_SHARED = 8,   // one lb/ub for the whole batch
   MODE_MU_OSQP = 16,     // UpdateMu: OSQP's rule instead of the DEFAULT decade steps (update_mu below)
+  MODE_ZERO_STATE = 32,  // the launch takes every instance straight from a cold reset (vis = fis = g = w = z = 0 in every record:
+                         // IkIdData::Reset(false) / ResetRecursion): the flat engine does not fetch those pairs
 };
 
 

@@ -365,8 +365,10 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       atomicAdd(&Bf.counters[LEAN_Q_REQUEUES], 1u);
     }
   };
+  int next_slot = -2;  // (plain queue) the entry store_instance fetched while its stores were in flight; -2: none
   auto load_instance = [&]() {
-    const int slot_in = fetch();
+    const int slot_in = (!SLICED && next_slot != -2) ? next_slot : fetch();
+    next_slot = -2;
     has_inst = slot_in >= 0;
     if (!has_inst) return;
     isj = isj_lane;
@@ -375,18 +377,41 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     ip = lane_ptr<T>(Bf.tiles, L, slot);
     rec = ip + (size_t)jl * JREC * pair_bytes<T>();
     const char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+    // the scalar record travels with the joints' records (one round trip to HBM, not two: the loads are independent)
+    const typename Vec2<T>::type mu2 = rldp<T, SLICED>(srec, SP_MU), bi2 = rldp<T, SLICED>(srec, SP_BI), st2 = rldp<T, SLICED>(srec, SP_ST);
+    const typename Vec2<T>::type tag2 = rldp<T, SLICED>(srec, SP_TAG), flip2 = rldp<T, SLICED>(srec, SP_FLIP);
+    const T tail_iter0 = rld_scal<T, SLICED>(srec, SC_TAIL_ITER);
+    T sc0[8] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
+    if (lane == 0) {
+      sc0[0] = rld_scal<T, SLICED>(srec, SC_TOL_PRIMAL); sc0[1] = rld_scal<T, SLICED>(srec, SC_TOL_DUAL);
+      sc0[2] = rld_scal<T, SLICED>(srec, SC_DELTA_Y_QP); sc0[3] = rld_scal<T, SLICED>(srec, SC_AT_DELTA_Y_QP);
+      sc0[4] = rld_scal<T, SLICED>(srec, SC_UB_DY_PLUS); sc0[5] = rld_scal<T, SLICED>(srec, SC_LB_DY_MINUS);
+      sc0[6] = rld_scal<T, SLICED>(srec, SC_COND1); sc0[7] = rld_scal<T, SLICED>(srec, SC_COND2);
+    }
     // ---- full width on both lanes of a joint (identical values): k_flat's load, rows indexed by the joint
     T ax[3], v[6], f[6], g[6], Sw[6], SE[6];
     const bool rev = jflags & JF_REVOLUTE;
     {
-      const typename Vec2<T>::type csn = ldp<T>(rec, JP_CS), wz = rldp<T, SLICED>(rec, JP_WZ), nus = rldp<T, SLICED>(rec, JP_NUS);
+      // (straight from a cold reset -- the plain queue hands every instance out once -- vis, fis, g, w, z are zeros in every
+      //  record: ten of the twelve pairs of a joint are not fetched.  A record's 16-byte pairs lie 1 KiB apart in the tiles of
+      //  the streaming engine: every pair costs a 64-byte line of its own)
+      const bool zero_state = !SLICED && (P.mode & MODE_ZERO_STATE);
+      typename Vec2<T>::type wz;
+      wz.x = T(0); wz.y = T(0);
+      const typename Vec2<T>::type csn = ldp<T>(rec, JP_CS), nus = rldp<T, SLICED>(rec, JP_NUS);
+      if (!zero_state) wz = rldp<T, SLICED>(rec, JP_WZ);
       const JointDesc d = jd[jl + 1];
 #pragma unroll
       for (int k = 0; k < 3; ++k) ax[k] = isj_lane ? (T)d.axis[k] : T(0);
       joint_xform<T>(d, rec, csn.x, csn.y, R0, t0);  // liMi ...
-      rld6<T, SLICED>(rec, JP_V, v);
-      rld6<T, SLICED>(rec, JP_F, f);
-      rld6<T, SLICED>(rec, JP_G, g);
+      if (!zero_state) {
+        rld6<T, SLICED>(rec, JP_V, v);
+        rld6<T, SLICED>(rec, JP_F, f);
+        rld6<T, SLICED>(rec, JP_G, g);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { v[k] = T(0); f[k] = T(0); g[k] = T(0); }
+      }
       w = wz.x; z = wz.y; nu = nus.x; s = nus.y;
       if (P.mode & MODE_BND_SHARED) {
         lbi = Bf.uni[L.nc * 57 + jl];
@@ -502,7 +527,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       // sums above) and A^T y at the world origin (AW y in the loop, X* (A^T y) above) -- travel in record pairs this engine does
       // not otherwise use (JP_P, JP_UD of the constrained joint).  Time slicing then changes no bit of any result, whatever the
       // order the hardware happens to serve the queue in.
-      if (rldp<T, SLICED>(srec, SP_TAG).x == T(-3)) {
+      if (tag2.x == T(-3)) {
         rld6<T, SLICED>(rec, JP_P, SE);
         if (jcslot >= 0) {
           T aw[6];
@@ -513,22 +538,21 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       }
     }
     half(Sw, Sw3); half(v, v3); half(f, f3); half(g, g3); half(SE, SE3);
-    const typename Vec2<T>::type mu2 = rldp<T, SLICED>(srec, SP_MU), bi2 = rldp<T, SLICED>(srec, SP_BI), st2 = rldp<T, SLICED>(srec, SP_ST);
     mu = mu2.x;
     kexp = (int)mu2.y;
     kslot = -(1 << 30); kslot_o = -(1 << 30);
     status = (int)st2.x;
     iter = (int)bi2.y;
-    tail_it = (int)rld_scal<T, SLICED>(srec, SC_TAIL_ITER);
-    nflip = (int)rldp<T, SLICED>(srec, SP_FLIP).x;
+    tail_it = (int)tail_iter0;
+    nflip = (int)flip2.x;
     done = (status & ST_DONE) != 0;
     if (!done && !(status & ST_TAIL) && iter + 1 >= P.max_iter) { done = true; status |= ST_DONE; }
     if (lane == 0) {
-      isc[FI_BNORM] = bi2.x; isc[FI_TGIN] = rldp<T, SLICED>(srec, SP_TAG).x; isc[FI_STY] = st2.y; isc[FI_MULAST] = T(-1);
-      isc[FI_TOLP] = rld_scal<T, SLICED>(srec, SC_TOL_PRIMAL); isc[FI_TOLD] = rld_scal<T, SLICED>(srec, SC_TOL_DUAL);
-      isc[FI_DYQP] = rld_scal<T, SLICED>(srec, SC_DELTA_Y_QP); isc[FI_ATDY] = rld_scal<T, SLICED>(srec, SC_AT_DELTA_Y_QP);
-      isc[FI_UBP] = rld_scal<T, SLICED>(srec, SC_UB_DY_PLUS); isc[FI_LBM] = rld_scal<T, SLICED>(srec, SC_LB_DY_MINUS);
-      isc[FI_C1] = rld_scal<T, SLICED>(srec, SC_COND1); isc[FI_C2] = rld_scal<T, SLICED>(srec, SC_COND2);
+      isc[FI_BNORM] = bi2.x; isc[FI_TGIN] = tag2.x; isc[FI_STY] = st2.y; isc[FI_MULAST] = T(-1);
+      isc[FI_TOLP] = sc0[0]; isc[FI_TOLD] = sc0[1];
+      isc[FI_DYQP] = sc0[2]; isc[FI_ATDY] = sc0[3];
+      isc[FI_UBP] = sc0[4]; isc[FI_LBM] = sc0[5];
+      isc[FI_C1] = sc0[6]; isc[FI_C2] = sc0[7];
     }
     tail_sync();
     my_iters = 0;
@@ -537,6 +561,9 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   bool requeue = false;  // (SLICED) the instance goes back to the queue, to be continued by whichever wavefront takes it
   auto store_instance = [&]() {
     char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
+    // (plain queue) the next ticket is drawn now: the atomic's round trip runs under the stores below
+    unsigned int nx_raw = 0u;
+    if constexpr (!SLICED) { if (lane == 0) nx_raw = atomicAdd(q_head, 1u); }
     {
       T v[6], f[6], g[6];
       whole(v3, v); whole(f3, f); whole(g3, g);
@@ -595,6 +622,11 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         rstp<T, SLICED>(srec, SP_SCAL + 14, isc[FI_C2], (T)tail_it);
       }
       if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
+    }
+    if constexpr (!SLICED) {
+      const int nx = __builtin_amdgcn_readfirstlane((int)nx_raw);
+      if (nx >= nslots) note_dry();
+      next_slot = nx < nslots ? ring[nx] : -1;
     }
     tail_sync();
   };
@@ -1227,14 +1259,26 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T ax[3];
     const bool rev = jflags & JF_REVOLUTE;
     {
-      const typename Vec2<T>::type csn = ldp<T>(rec, JP_CS), wz = rldp<T, SLICED>(rec, JP_WZ), nus = rldp<T, SLICED>(rec, JP_NUS);
+      // (straight from a cold reset -- the plain queue hands every instance out once -- vis, fis, g, w, z are zeros in every
+      //  record: ten of the twelve pairs of a joint are not fetched.  A record's 16-byte pairs lie 1 KiB apart in the tiles of
+      //  the streaming engine: every pair costs a 64-byte line of its own)
+      const bool zero_state = !SLICED && (P.mode & MODE_ZERO_STATE);
+      typename Vec2<T>::type wz;
+      wz.x = T(0); wz.y = T(0);
+      const typename Vec2<T>::type csn = ldp<T>(rec, JP_CS), nus = rldp<T, SLICED>(rec, JP_NUS);
+      if (!zero_state) wz = rldp<T, SLICED>(rec, JP_WZ);
       const JointDesc d = jd[jl + 1];
 #pragma unroll
       for (int k = 0; k < 3; ++k) ax[k] = isj_lane ? (T)d.axis[k] : T(0);
       joint_xform<T>(d, rec, csn.x, csn.y, R0, t0);  // liMi ...
-      rld6<T, SLICED>(rec, JP_V, v);
-      rld6<T, SLICED>(rec, JP_F, f);
-      rld6<T, SLICED>(rec, JP_G, g);
+      if (!zero_state) {
+        rld6<T, SLICED>(rec, JP_V, v);
+        rld6<T, SLICED>(rec, JP_F, f);
+        rld6<T, SLICED>(rec, JP_G, g);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { v[k] = T(0); f[k] = T(0); g[k] = T(0); }
+      }
       w = wz.x; z = wz.y; nu = nus.x; s = nus.y;
       if (P.mode & MODE_BND_SHARED) {
         lbi = Bf.uni[L.nc * 57 + jl];

@@ -62,6 +62,7 @@ struct Tuning {
   int flat_split_wpe = 2;       // LOIKB_FLAT_WPE=3: k_flat2 built for three wavefronts per SIMD
   int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's round-robin time slice in iterations (0 = run to completion; default -1:
                                 // 160 for launches of 12..96 instances per resident wavefront, where the stragglers' tail is worth it)
+  bool flat_zero_state = true;  // LOIKB_FLAT_ZERO_STATE=0: k_flat2 / k_flat1 fetch vis, fis, g, w, z of every instance even straight after a cold reset
   bool flat_order = true;       // LOIKB_FLAT_ORDER=0: the flat engine takes its instances in arrival order even when the handle's previous
                                 // solve left an order (longest first, k_order_*: loik_lean.hpp)
   int tail_waves = TAIL_WAVES;  // LOIKB_TAIL_WAVES    wavefronts per k_tail workgroup
@@ -90,6 +91,7 @@ struct Tuning {
     if (const char* e = getenv("LOIKB_FLAT_WPE")) flat_split_wpe = atoi(e) == 3 ? 3 : 2;
     if (const char* e = getenv("LOIKB_FLAT_SLICE")) flat_slice = std::max(-1, atoi(e));
     if (const char* e = getenv("LOIKB_FLAT_ORDER")) flat_order = atoi(e) != 0;
+    if (const char* e = getenv("LOIKB_FLAT_ZERO_STATE")) flat_zero_state = atoi(e) != 0;
     geti("LOIKB_TAIL_WAVES", tail_waves); tail_waves = std::max(1, std::min(TAIL_WAVES, tail_waves));
     geti("LOIKB_LEAN_DECADES", lean_decades); lean_decades = std::max(1, std::min(16, lean_decades));
     geti("LOIKB_LEAN_KLO", lean_klo);
@@ -248,6 +250,7 @@ struct loikb_solver_impl {
   loikb_stats stats{};
   // pass-level debug path (loik_passes.hpp): the data object of the reference, field by field, per instance
   bool pass_active = false;
+  bool zero_state = false;   // the solve in progress began with a reset that zeroed vis, fis, g, w, z of every instance
   PassLayout PL{};
   double* d_pass = nullptr;
   int* d_pass_cslot = nullptr;
@@ -845,6 +848,8 @@ Params<T> make_params(loikb_solver_impl* S)
 int reset_home(loikb_solver_impl* S, int what)
 {
   const dim3 grid(S->home.ntiles), block(WAVE);
+  // (a solve starts with RS_SOLVER: does it start from vis = fis = g = w = z = 0?  MODE_ZERO_STATE of the flat engine's launch)
+  if (what & RS_SOLVER) S->zero_state = (what & (RS_DATA_COLD | RS_RECURSION)) != 0;
   if (S->f32) hipLaunchKernelGGL(k_reset<float>, grid, block, 0, S->stream, S->home.tiles, S->L, what, (float)solve_mu0(S));
   else hipLaunchKernelGGL(k_reset<double>, grid, block, 0, S->stream, S->home.tiles, S->L, what, (double)solve_mu0(S));
   HIPCHK(hipGetLastError());
@@ -1598,6 +1603,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       // one instance per wavefront anyway (33..64 joints): the build with nested loops, prefix-sum subtree sums, DPP fold
       const bool one = S->tune.flat_split && G == WAVE && sizeof(T) == 8 && !S->opt.logging;
       P.max_launch_iters = S->opt.max_iter + 1;
+      const int mode_keep = P.mode;
+      if (whole_set && S->zero_state && S->tune.flat_zero_state) P.mode |= MODE_ZERO_STATE;
       HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
       // longest first: the order the previous solve of this handle left (k_order_*, loik_lean.hpp) when this launch takes the same
@@ -1708,6 +1715,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
 #undef LOIKB_LAUNCH_FLAT
         }
         HIPCHK(hipGetLastError());
+        P.mode = mode_keep;
         int* nxt = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
         hipLaunchKernelGGL(k_list_unfinished<T>, grid1(n), dim3(256), 0, C->stream, A.tiles, S->L, list, n, nxt, C->d_counters + 3);
         HIPCHK(hipGetLastError());
