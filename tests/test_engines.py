@@ -186,6 +186,35 @@ def test_longest_first_order_changes_nothing_but_the_schedule(robot, monkeypatch
     s.close(); p.close()
 
 
+def test_zero_state_launch_fetches_less_and_computes_the_same(monkeypatch):
+    """straight after a cold reset the flat engine does not fetch vis, fis, g, w, z (zeros in every record, MODE_ZERO_STATE): same
+    bits as with the fetch (LOIKB_FLAT_ZERO_STATE=0); Solve() again keeps nu / Stf_plus_w (ResetRecursion) and a warm-started
+    tailored solve fetches everything -- both against the handle that always fetches"""
+    from loik_amd import workloads
+    for v in ("LOIKB_FLAT_ORDER", "LOIKB_FLAT_SLICE", "LOIKB_FLAT_ZERO_STATE"):
+        monkeypatch.delenv(v, raising=False)
+    B = 1500
+    wl = workloads.talos_c3(B, seed=9)
+    link = int(wl["c_ids"][0])
+    names = ["iter", "converged", "mu", "z", "nu", "w", "vis", "fis", "g", "yis", "Stf_plus_w", "primal_residual", "dual_residual"]
+    a = loik_amd.BatchedLoik(wl["model"], B, **wl["params"])
+    monkeypatch.setenv("LOIKB_FLAT_ZERO_STATE", "0")
+    b = loik_amd.BatchedLoik(wl["model"], B, **wl["params"])
+    for s in (a, b):
+        s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    for step in ("Solve()", "Solve() again", "warm-started tailored Solve"):
+        for s in (a, b):
+            if step.startswith("warm"):
+                s.set_warm_start(True)
+                s.Solve(None, link, wl["Ais"], 0.9 * wl["bis"][:, 0])
+            else:
+                s.Solve()
+            assert s.stats()["flat_split_launches"] == 1
+        for n in names:
+            assert np.array_equal(a.get(n), b.get(n)), (step, n)
+    a.close(); b.close()
+
+
 def test_engine_plan_is_made_in_one_place(talos, panda7, monkeypatch):
     """loikb_plan_string: the dispatch (nb, nc, A shared?, children, options) -> engines, re-made at SolveInit when the sharing
     mode of A is known (round 1 fixed the chunk count at create with the default mode)"""
