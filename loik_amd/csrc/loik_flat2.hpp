@@ -827,6 +827,11 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         ccb[FC_Y + ckl] = yk;
         ccb[FC_DY + ckl] = dy;
       }
+      TAIL_TP(9)
+      // (the update's chain -- v -> LDS | fence | A v, y -> LDS | fence | A^T y -> LDS | fence -- is 1650 of the 8800 cycles of an
+      //  iteration at full load, on six busy lanes.  Moving v, y, dy between lanes by ds_bpermute (36 wavefront-wide LDS
+      //  instructions) or by v_readlane (one constraint) gives the same bits and is SLOWER, 11.16 / 10.93 against 10.62 ms:
+      //  the other wavefront of the SIMD hides this latency; what the loop lacks is issue slots, not shorter chains)
       // ---- subtree sums of E (BwdPass2's transport, hxx:210-212, as a force balance at the world origin): the joints of a subtree
       // are the lanes [j, j + size) of this half, so S_j = P[j + size - 1] - P[j] + E_j with P the inclusive prefix sum -- in
       // registers (DPP), placed here to run while the constraint block is on its way through LDS
@@ -864,6 +869,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
           for (int c = 0; c < 3; ++c) SHn[c] = (xb[(WAVE + 1) * 3 + src * 3 + c] - P2[c]) + E2[c];
         }
       }
+      TAIL_TP(10)
       tail_sync();
       if (iscl) {
         // A^T y (hxx:422) and the same at the world origin; the constraint's share of this iteration's force balance is
@@ -882,6 +888,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         ccb[FC_ATYW + k] = aw;
       }
       tail_sync();
+      TAIL_TP(11)
       // ---- per-joint work that needs v and nu only -- BoxProj, the w update, their norms, g (hxx:129-158, :384-397, :454-458) --
       {
         T dv[3], gi[3], dg[3], dvr[3];

@@ -7,8 +7,10 @@ from loik_amd import capi, workloads
 L = capi.lib()
 NAMES = {8: "loop top + decade slot change", 0: "p^base sums, tau", 1: "r' = W tau (products, shares, partials)",
          2: "nu = -W^T Dinv r', path sum, v", 4: "task dual update", 5: "subtree sum, f", 3: "per-joint work (box, w, norms)",
-         6: "norm fold", 7: "epilogue + instance switch"}
-ORDER = [8, 0, 1, 2, 4, 5, 3, 6, 7]
+         6: "norm fold", 7: "epilogue + instance switch", 9: "  task: v -> LDS, A v - b, y (two fences)", 10: "  subtree prefix sums of E (DPP) + exchange",
+         11: "  task: A^T y, A^T dy at the origin (two fences)"}
+NAMES[4] = "  per-joint work on v, nu (box, w, g, norms)"
+ORDER = [8, 0, 1, 2, 9, 10, 11, 4, 5, 3, 6, 7]
 for B in [int(x) for x in sys.argv[1:]] or [64, 65536]:
     wl = workloads.talos_c3(B, seed=5)
     prm = dict(wl["params"])
