@@ -1,6 +1,6 @@
 """Randomised cross-check of every engine against the CPU oracle (not part of the test suite: minutes on the GPU box).
 
-  python scripts/fuzz_engines.py [ncases] [seed]
+  python scripts/fuzz_engines.py [ncases] [seed] [flat_bias]
 
 Each case draws: a random kinematic tree (3..44 joints, depth-first or breadth-first numbered; 1-DoF joints of every type,
 optionally a free-flyer / planar root, spherical, translation, SphericalZYX, planar, unbounded-revolute and composite joints), 0..4 task
@@ -33,6 +33,8 @@ ENGINES = {
     # k_flat2's round-robin time slicing forced (one wavefront per CU so that instances wait: requeues from the 7th iteration)
     "flat_sliced": ({"LOIKB_FLAT_SLICE": "7", "LOIKB_LEAN_WG_PER_CU": "1"}, {}),
     "flat_one_lane": ({"LOIKB_FLAT_SPLIT": "0"}, {}),   # k_flat (one joint per lane) where k_flat2 / k_flat1 would run
+    # the same solve a second time on the handle: longest-first order from the first one, no fetch of the zero state (compared: the second)
+    "flat_ordered": ({}, {}),
 }
 ENV_KEYS = ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE",
             "LOIKB_LEAN_WG_PER_CU")
@@ -77,10 +79,8 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
         if nc == 0:
             wl["c_ids"] = np.zeros(0, dtype=np.int32); wl["Ais"] = np.zeros((0, 6, 6)); wl["bis"] = np.zeros((B, 0, 6))
         hk = int(rng.integers(0, 3))
-        if for_flat:
-            hk = 0
-            if rng.random() < 0.5:   # (H_ref = h I with a target: the engine's has_hv path)
-                wl["H_ref"] = float(rng.uniform(0.3, 2.0)) * np.eye(6); wl["v_ref"] = 0.2 * rng.normal(size=6)
+        if for_flat and hk == 0 and rng.random() < 0.5:   # (H_ref = h I with a target: the engine's has_hv path)
+            wl["H_ref"] = float(rng.uniform(0.3, 2.0)) * np.eye(6); wl["v_ref"] = 0.2 * rng.normal(size=6)
         if hk == 1:
             wl["H_ref"] = np.diag(rng.uniform(0.3, 2.0, size=6)); wl["v_ref"] = 0.2 * rng.normal(size=6)
         elif hk == 2:
@@ -88,7 +88,7 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
         if rng.random() < 0.3:
             wl["lb"] = -0.5 * (1 + 0.2 * rng.random((B, model.nv))); wl["ub"] = 0.5 * (1 + 0.2 * rng.random((B, model.nv)))
         refs = None
-        if rng.random() < 0.2 and not for_flat:   # per-link references: one weight / target per joint of the caller's model
+        if rng.random() < 0.2:   # per-link references: one weight / target per joint of the caller's model (flat engine: HM = 3)
             Hs = np.zeros((model.njoints, 6, 6)); vs = 0.2 * rng.normal(size=(model.njoints, 6))
             for i in range(model.njoints):
                 M = rng.normal(size=(6, 6)); Hs[i] = M @ M.T / 6 + rng.uniform(0.2, 1.0) * np.eye(6)
@@ -101,7 +101,9 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
         prm = dict(FIXTURE, num_eq_c=nc, max_iter=int(rng.choice([60, 300, 1000])),
                    tol_abs=float(rng.choice([1e-4, 1e-6] if (osqp or multidof) else [1e-4, 1e-6, 1e-8])),
                    tol_rel=float(rng.choice([0.0, 1e-6])), mu_update_strat=1 if osqp else 0)
-        engine = str(rng.choice(["default", "handover", "flat_escapes", "flat_one_lane", "flat_sliced"] if for_flat else list(ENGINES)))
+        engine = str(rng.choice(["default", "handover", "flat_escapes", "flat_one_lane", "flat_sliced", "flat_ordered", "flat_ordered"] if for_flat else list(ENGINES)))
+        if engine == "flat_one_lane" and (hk != 0 or refs is not None):
+            engine = "default"   # (k_flat takes H_ref = h I only: such a handle would run k_lean -- covered by "lean")
         env, kw = ENGINES[engine]
         if only is not None and case != only:   # replay one case of a run (same draws)
             continue
@@ -118,6 +120,16 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
                 s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
                 s.UpdateReferences(*refs)
                 s.Solve()
+            if engine == "flat_ordered":
+                first_ordered = s.stats()["flat_ordered"]
+                if refs is None:
+                    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+                else:
+                    s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+                    s.UpdateReferences(*refs)
+                    s.Solve()
+                summary["ordered_launches"] = summary.get("ordered_launches", 0) + s.stats()["flat_ordered"]
+                assert first_ordered == 0
         except loik_amd.LoikError as e:   # a stated limit of the library (e.g. a tree too bushy for k_solve's LDS slots): not a mismatch
             summary["refused"] += 1
             children = np.bincount(np.asarray(model.parents[1:]), minlength=model.njoints)
@@ -184,7 +196,8 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
     return summary
 
 if __name__ == "__main__":
-    out = fuzz(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+    out = fuzz(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 2024,
+               flat_bias=float(sys.argv[3]) if len(sys.argv) > 3 else 0.0)
     # (a case whose only differences are instances that max_iter stopped unconverged counts as "unconverged_only", a stated limit
     #  of the library as "refused": both are reported beside the mismatches, not hidden in them)
     print(json.dumps(out))
