@@ -53,6 +53,7 @@ struct Model {
   // comp_first[i] + comp_count[i] - 1 of comp_jtype / comp_axis / comp_placement (include/loik_amd_models.h)
   std::vector<int> comp_first, comp_count, comp_jtype;
   std::vector<double> comp_axis, comp_placement;
+  std::vector<double> pitch;  // [njoints] JointModelHelical*::m_pitch (LOIKB_J_HX .. HU); empty when the model has no helical joint
 
   static Model Builtin(const std::string& name)
   {
@@ -85,6 +86,7 @@ struct Model {
       d.comp_first = comp_first.data(); d.comp_count = comp_count.data(); d.comp_jtype = comp_jtype.data();
       d.comp_axis = comp_axis.data(); d.comp_placement = comp_placement.data();
     }
+    if (!pitch.empty()) d.pitch = pitch.data();
     return d;
   }
 };

@@ -13,6 +13,8 @@
 //   of a placement    jointPlacements[i]: rotation()(r, c), translation()[k]              (pinocchio::SE3)
 //   AxisOf(joint, shortname) -> something indexable [0..2]: the axis of an unaligned joint (JointModelRevoluteUnaligned::axis);
 //                         for a JointModelUniversal indexable [0..5]: (axis1, axis2)
+//   PitchOf(joint, shortname) -> double: JointModelHelical*::m_pitch (only called for helical joints; the 3-argument overloads
+//                         of to_loik_amd refuse a model with a helical joint)
 //   SubJointsOf(joint) -> a range of (sub-joint model, placement) pairs (.first / .second) of a JointModelComposite
 //                         (JointModelComposite::joints[k], ::jointPlacements[k]); any supported joint type but a composite
 // JointModelUniversal(axis1, axis2) -- M = R(axis1, q0) R(axis2, q1), S(q) = [R(axis2, q1)^T axis1 | axis2] -- is handed over
@@ -50,6 +52,8 @@ inline int joint_type_of(const std::string& n)
       {"JointModelRevoluteUnboundedUnaligned", LOIKB_J_RUBU},  // nq 2 (cos, sin), axis from axis_of
       {"JointModelComposite", LOIKB_J_COMPOSITE},        // loikb_model_desc.comp_*
       {"JointModelUniversal", LOIKB_J_UNIVERSAL_AS_COMPOSITE},  // -> composite of two unaligned revolute joints (below)
+      {"JointModelHX", LOIKB_J_HX}, {"JointModelHY", LOIKB_J_HY}, {"JointModelHZ", LOIKB_J_HZ},  // helical: pitch from pitch_of
+      {"JointModelHelicalUnaligned", LOIKB_J_HU},
   };
   for (const auto& e : table)
     if (n == e.name) return e.type;
@@ -78,10 +82,19 @@ struct NoComposite {
 };
 }  // namespace detail
 
-template <class PinocchioModel, class AxisOf, class SubJointsOf>
-Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joints_of)
+struct NoPitch {
+  template <class J>
+  double operator()(const J&, const std::string& n) const
+  {
+    throw std::runtime_error("loik_amd: the model has a helical joint (" + n + "): pass a PitchOf functor to to_loik_amd");
+  }
+};
+
+template <class PinocchioModel, class AxisOf, class SubJointsOf, class PitchOf>
+Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joints_of, PitchOf pitch_of)
 {
   Model o;
+  bool any_helical = false;
   o.njoints = static_cast<int>(m.njoints); o.nq = static_cast<int>(m.nq); o.nv = static_cast<int>(m.nv);
   bool any_composite = false;
   for (std::size_t i = 0; i < static_cast<std::size_t>(m.njoints); ++i) {
@@ -92,12 +105,14 @@ Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joint
     int t = i ? joint_type_of(n) : LOIKB_J_NONE;
     if (i && t == LOIKB_J_NONE)
       throw std::runtime_error("loik_amd: joint type '" + n + "' of joint '" + m.names[i] +
-                               "' is not supported (mimic, helical)");
+                               "' is not supported (mimic)");
     double ax[3] = {0.0, 0.0, 0.0};
-    if (t == LOIKB_J_RU || t == LOIKB_J_PU || t == LOIKB_J_RUBU) {
+    if (t == LOIKB_J_RU || t == LOIKB_J_PU || t == LOIKB_J_RUBU || t == LOIKB_J_HU) {
       const auto a = axis_of(m.joints[i], n);
       for (int k = 0; k < 3; ++k) ax[k] = a[k];
     }
+    o.pitch.push_back((t >= LOIKB_J_HX && t <= LOIKB_J_HU) ? static_cast<double>(pitch_of(m.joints[i], n)) : 0.0);
+    any_helical = any_helical || (t >= LOIKB_J_HX && t <= LOIKB_J_HU);
     o.comp_first.push_back(static_cast<int>(o.comp_jtype.size()));
     int count = 0;
     static const double ident[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
@@ -121,7 +136,7 @@ Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joint
       for (const auto& sub : sub_joints_of(m.joints[i])) {
         const std::string sn = sub.first.shortname();
         const int st = joint_type_of(sn);
-        if (st == LOIKB_J_NONE || st == LOIKB_J_COMPOSITE)
+        if (st == LOIKB_J_NONE || st == LOIKB_J_COMPOSITE || (st >= LOIKB_J_HX && st <= LOIKB_J_HU))
           throw std::runtime_error("loik_amd: sub-joint '" + sn + "' of the composite joint '" + m.names[i] + "' is not supported");
         if (st == LOIKB_J_UNIVERSAL_AS_COMPOSITE) {
           std::vector<double> P;
@@ -147,7 +162,14 @@ Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joint
     o.names.push_back(m.names[i]);
   }
   if (!any_composite) { o.comp_first.clear(); o.comp_count.clear(); }
+  if (!any_helical) o.pitch.clear();
   return o;
+}
+
+template <class PinocchioModel, class AxisOf, class SubJointsOf>
+Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joints_of)
+{
+  return to_loik_amd(m, axis_of, sub_joints_of, NoPitch());
 }
 
 template <class PinocchioModel, class AxisOf>
@@ -216,7 +238,8 @@ inline Model to_loik_amd(const pinocchio::Model& m)
     else if (n == "JointModelUniversal") {
       const auto& u = boost::get<pinocchio::JointModelUniversal>(j.toVariant());
       put(u.axis1, 0); put(u.axis2, 3);
-    } else put(boost::get<pinocchio::JointModelPrismaticUnaligned>(j.toVariant()).axis, 0);
+    } else if (n == "JointModelHelicalUnaligned") put(boost::get<pinocchio::JointModelHelicalUnaligned>(j.toVariant()).axis, 0);
+    else put(boost::get<pinocchio::JointModelPrismaticUnaligned>(j.toVariant()).axis, 0);
     return a;
   };
   auto sub_joints_of = [](const pinocchio::JointModel& j) {
@@ -225,7 +248,13 @@ inline Model to_loik_amd(const pinocchio::Model& m)
     for (std::size_t k = 0; k < c.joints.size(); ++k) subs.emplace_back(pinocchio::JointModel(c.joints[k]), c.jointPlacements[k]);
     return subs;
   };
-  return to_loik_amd(m, axis_of, sub_joints_of);
+  auto pitch_of = [](const pinocchio::JointModel& j, const std::string& n) -> double {
+    if (n == "JointModelHX") return boost::get<pinocchio::JointModelHX>(j.toVariant()).m_pitch;
+    if (n == "JointModelHY") return boost::get<pinocchio::JointModelHY>(j.toVariant()).m_pitch;
+    if (n == "JointModelHZ") return boost::get<pinocchio::JointModelHZ>(j.toVariant()).m_pitch;
+    return boost::get<pinocchio::JointModelHelicalUnaligned>(j.toVariant()).m_pitch;
+  };
+  return to_loik_amd(m, axis_of, sub_joints_of, pitch_of);
 }
 #endif
 

@@ -13,9 +13,9 @@
  * planar --, JointModelSphericalZYX, whose q-dependent subspace is that of a Z-Y-X revolute chain, and
  * JointModelComposite of any of those (LOIKB_J_COMPOSITE + the comp_* arrays below; up to 6 DoF -- e.g. the hand-made floating
  * base "translation + spherical").  JointModelUniversal(axis1, axis2) is the composite of RevoluteUnaligned(axis1) and
- * RevoluteUnaligned(axis2) with identity placements -- pass it as that (the Pinocchio adapter does).  Not covered: JointModelMimic
- * (two joints share one coordinate: the elimination couples them across the tree) and the helical joints (S = [h a; a]: every
- * engine exploits that a 1-DoF subspace is purely linear or purely angular).  On the device a multi-DoF
+ * RevoluteUnaligned(axis2) with identity placements -- pass it as that (the Pinocchio adapter does).  The helical joints (S = [pitch a; a]) are 1-DoF joints with a pitch
+ * (LOIKB_J_HX .. HU + the pitch array).  Not covered: JointModelMimic (two joints share one coordinate: the elimination couples them
+ * across the tree).  On the device a multi-DoF
  * joint is a chain of 1-DoF joints with massless links in between; the caller never sees that: q, z / nu / w / lb / ub
  * (length model.nv, Pinocchio's idx_v order) and the per-link results are the caller's model's.
  */
@@ -53,8 +53,12 @@ enum {
                               frame (q-dependent); on the device it is the chain of its sub-joints (each multi-DoF one its own
                               chain) with massless links in between                                                          */
   ,
-  LOIKB_J_RUBU = 18        /* JointModelRevoluteUnboundedUnaligned: nq 2 (cos, sin), nv 1, about `axis` (also as a sub-joint of a
+  LOIKB_J_RUBU = 18,       /* JointModelRevoluteUnboundedUnaligned: nq 2 (cos, sin), nv 1, about `axis` (also as a sub-joint of a
                               composite)                                                                                    */
+  LOIKB_J_HX = 19,         /* JointModelHelicalX / Y / Z (JointModelHX ...) and JointModelHelicalUnaligned: nq 1, nv 1; a rotation by q  */
+  LOIKB_J_HY = 20,         /* about the axis together with a translation of pitch * q along it: M(q) = (Rot(axis, q), pitch q axis),   */
+  LOIKB_J_HZ = 21,         /* S = [pitch axis; axis].  The pitch of joint i is loikb_model_desc.pitch[i]; HU takes its axis from `axis`. */
+  LOIKB_J_HU = 22          /* (Not as a sub-joint of a composite.)                                                                   */
 };
 
 typedef struct loikb_model_desc {
@@ -76,6 +80,7 @@ typedef struct loikb_model_desc {
   const int *comp_jtype;        /* [n_sub]   */
   const double *comp_axis;      /* [n_sub][3]  */
   const double *comp_placement; /* [n_sub][12] */
+  const double *pitch;          /* [njoints] JointModelHelical*::m_pitch (read for LOIKB_J_HX .. HU only); NULL when the model has none */
 } loikb_model_desc;
 
 /*

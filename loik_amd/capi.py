@@ -26,7 +26,8 @@ class LoikError(RuntimeError):
 class ModelDesc(C.Structure):
     _fields_ = [("njoints", C.c_int), ("nq", C.c_int), ("nv", C.c_int), ("parents", _ip), ("jtype", _ip),
                 ("axis", _dp), ("idx_q", _ip), ("idx_v", _ip), ("placement", _dp),
-                ("comp_first", _ip), ("comp_count", _ip), ("comp_jtype", _ip), ("comp_axis", _dp), ("comp_placement", _dp)]
+                ("comp_first", _ip), ("comp_count", _ip), ("comp_jtype", _ip), ("comp_axis", _dp), ("comp_placement", _dp),
+                ("pitch", _dp)]
 
 
 class Options(C.Structure):
@@ -51,7 +52,7 @@ class Stats(C.Structure):
                 ("flat_split_launches", C.c_int), ("flat_ordered", C.c_int)]
 
 
-ABI_VERSION = 303   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
+ABI_VERSION = 304   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
 
 # enums of loik_amd.h
 F64, F32 = 0, 1
@@ -204,6 +205,7 @@ J_FREEFLYER, J_SPHERICAL, J_TRANSLATION = 9, 10, 11
 J_SPHERICAL_ZYX, J_PLANAR, J_RUBX, J_RUBY, J_RUBZ = 12, 13, 14, 15, 16
 J_COMPOSITE = 17  # JointModelComposite (Model(..., composite={joint: [(jtype, axis, placement12), ...]}); sub-joints: any type but a composite)
 J_RUBU = 18       # JointModelRevoluteUnboundedUnaligned: nq 2 (cos, sin), nv 1, about `axis`
+J_HX, J_HY, J_HZ, J_HU = 19, 20, 21, 22   # JointModelHelicalX / Y / Z / Unaligned: nq = nv = 1, S = [pitch a; a] (Model(..., pitch=[nj]))
 JOINT_NQ = {J_FREEFLYER: 7, J_SPHERICAL: 4, J_TRANSLATION: 3, J_SPHERICAL_ZYX: 3, J_PLANAR: 4, J_RUBX: 2, J_RUBY: 2, J_RUBZ: 2, J_RUBU: 2}
 JOINT_NV = {J_FREEFLYER: 6, J_SPHERICAL: 3, J_TRANSLATION: 3, J_SPHERICAL_ZYX: 3, J_PLANAR: 3}
 
@@ -212,12 +214,14 @@ class Model:
     """Kinematic tree with Pinocchio's member names: njoints, nq, nv, parents, jointPlacements (here `placement`,
     [nj][12] = R row-major + t), joint type / axis / idx_q / idx_v per joint."""
 
-    def __init__(self, parents, jtype, axis, placement, names=None, q_lo=None, q_hi=None, name="custom", composite=None):
+    def __init__(self, parents, jtype, axis, placement, names=None, q_lo=None, q_hi=None, name="custom", composite=None, pitch=None):
         self.parents = np.ascontiguousarray(parents, dtype=np.int32)
         self.jtype = np.ascontiguousarray(jtype, dtype=np.int32)
         self.axis = np.ascontiguousarray(axis, dtype=np.float64).reshape(-1, 3)
         self.placement = np.ascontiguousarray(placement, dtype=np.float64).reshape(-1, 12)
         self.njoints = int(self.parents.size)
+        # JointModelHelical*: pitch [njoints] (translation along the axis per radian)
+        self.pitch = None if pitch is None else np.ascontiguousarray(pitch, dtype=np.float64).reshape(self.njoints)
         # JointModelComposite: composite[i] = [(sub-joint type, axis [3], placement [12] relative to the previous sub-joint), ...]
         self.composite = {int(i): [(int(t), np.asarray(a, dtype=np.float64).reshape(3), np.asarray(P, dtype=np.float64).reshape(12))
                                    for t, a, P in subs] for i, subs in (composite or {}).items()}
@@ -259,7 +263,8 @@ class Model:
                          self.idx_q.ctypes.data_as(_ip), self.idx_v.ctypes.data_as(_ip),
                          self.placement.ctypes.data_as(_dp), self.comp_first.ctypes.data_as(_ip),
                          self.comp_count.ctypes.data_as(_ip), self.comp_jtype.ctypes.data_as(_ip),
-                         self.comp_axis.ctypes.data_as(_dp), self.comp_placement.ctypes.data_as(_dp))
+                         self.comp_axis.ctypes.data_as(_dp), self.comp_placement.ctypes.data_as(_dp),
+                         None if self.pitch is None else self.pitch.ctypes.data_as(_dp))
 
     def getJointId(self, name):
         return self.names.index(name)

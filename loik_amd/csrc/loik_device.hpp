@@ -90,6 +90,10 @@ enum : int {
   JF_NOQ = 8,             // chain joint after the first: its transform is the identity whatever its JP_CS pair holds
   JF_REVOLUTE = 16,       // S = [0; axis], else prismatic S = [axis; 0]
   JF_CS_DIRECT = 32,      // unbounded revolute joint (JointModelRUBX/Y/Z): its configuration IS (cos, sin)
+  JF_HELICAL = 64,        // JointModelHelicalX/Y/Z/Unaligned (with JF_REVOLUTE): M(q) = (Rot(axis, q), pitch q axis), S = [pitch axis;
+                          // axis].  Its JP_CS pair holds (q, 0) -- the translation needs the angle itself -- and every formula
+                          // with S gets the linear term next to the revolute joint's angular one (scalar branches in k_solve,
+                          // the 6-vector S of the lane-per-joint engines)
 };
 
 // rotation generator selector for M(q).  ROT_FREE / ROT_SPH / ROT_TRANS: first joint of the chain of a free-flyer /
@@ -106,6 +110,7 @@ struct JointDesc {
   int flags;
   int cslot;      // index into the active constraint list, or -1
   int rot;        // ROT_*
+  double pitch;   // JF_HELICAL: translation along the axis per radian (JointModelHelical*: S = [pitch a; a]); 0 otherwise
 };
 
 // status bits per instance
@@ -387,6 +392,21 @@ __device__ __forceinline__ void joint_xform(const JointDesc& d, const char* rec,
     return;
   }
   if (__builtin_expect(d.flags & JF_NOQ, 0)) { c = (d.flags & JF_REVOLUTE) ? T(1) : T(0); s = T(0); }
+  if (__builtin_expect(d.flags & JF_HELICAL, 0)) {  // (q, 0) in the pair: the rotation by q about the axis, the translation pitch q axis
+    const T q = c;
+    T ra[3], ax[3], Rp[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rp[k] = (T)d.Rp[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ax[k] = (T)d.axis[k];
+    if constexpr (sizeof(T) == 8) { double sd, cd; sincos((double)q, &sd, &cd); c = (T)cd; s = (T)sd; }
+    else { float sf, cf; sincosf((float)q, &sf, &cf); c = (T)cf; s = (T)sf; }
+    make_liMi(d, c, s, R, t);
+    mat3_vec(Rp, ax, ra);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] += ((T)d.pitch * q) * ra[k];
+    return;
+  }
   make_liMi(d, c, s, R, t);
 }
 
@@ -777,7 +797,16 @@ __device__ __forceinline__ void sweep_bwd(const Params<T>& P, const Bufs<T>& Bf,
       // calc_aba (hxx:60-63): U = H S ; Dinv = 1/(S^T U + R) ; UDinv = U Dinv
       const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
       T Stp, dd = T(0);
-      if (d.flags & JF_REVOLUTE) {
+      if (d.flags & JF_HELICAL) {  // S = [pitch a; a]
+        const T ph = (T)d.pitch;
+        if (WITH_H) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k)
+            U[k] = (hh[sym(k, 3)] * ax0 + hh[sym(k, 4)] * ax1 + hh[sym(k, 5)] * ax2) + ph * (hh[sym(k, 0)] * ax0 + hh[sym(k, 1)] * ax1 + hh[sym(k, 2)] * ax2);
+          dd = T(1) / (((ax0 * U[3] + ax1 * U[4] + ax2 * U[5]) + ph * (ax0 * U[0] + ax1 * U[1] + ax2 * U[2])) + mu_in);
+        }
+        Stp = (ax0 * pp[3] + ax1 * pp[4] + ax2 * pp[5]) + ph * (ax0 * pp[0] + ax1 * pp[1] + ax2 * pp[2]);
+      } else if (d.flags & JF_REVOLUTE) {
         if (WITH_H) {
 #pragma unroll
           for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 3)] * ax0 + hh[sym(k, 4)] * ax1 + hh[sym(k, 5)] * ax2;
@@ -903,6 +932,7 @@ __device__ __forceinline__ void sweep_fwd(const Params<T>& P, const Bufs<T>& Bf,
       for (int k = 0; k < 6; ++k) vi[k] = vp[k];
       if (d.flags & JF_REVOLUTE) {
         vi[3] += ax0 * nui; vi[4] += ax1 * nui; vi[5] += ax2 * nui;
+        if (d.flags & JF_HELICAL) { const T pn = (T)d.pitch * nui; vi[0] += ax0 * pn; vi[1] += ax1 * pn; vi[2] += ax2 * pn; }
       } else {
         vi[0] += ax0 * nui; vi[1] += ax1 * nui; vi[2] += ax2 * nui;
       }
@@ -1100,6 +1130,7 @@ __device__ __forceinline__ void sweep_bwd2(const Params<T>& P, const Bufs<T>& Bf
       T stf;
       if (d.flags & JF_REVOLUTE) stf = ax0 * fi[3] + ax1 * fi[4] + ax2 * fi[5];
       else stf = ax0 * fi[0] + ax1 * fi[1] + ax2 * fi[2];
+      if (d.flags & JF_HELICAL) stf += (T)d.pitch * (ax0 * fi[0] + ax1 * fi[1] + ax2 * fi[2]);
       const T si = stf + wi;
       stp<T>(rec, JP_NUS, nus.x, si);  // full 16-byte store: nu rewritten unchanged
       N.stf_w_inf = tmax(N.stf_w_inf, tabs(si));
@@ -1210,6 +1241,10 @@ __device__ __forceinline__ void sweep_fused(const Params<T>& P, const Bufs<T>& B
       if (d.flags & JF_REVOLUTE) {
         stf = ax0 * fi[3] + ax1 * fi[4] + ax2 * fi[5];
         Stp = ax0 * pp[3] + ax1 * pp[4] + ax2 * pp[5];
+        if (d.flags & JF_HELICAL) {
+          stf += (T)d.pitch * (ax0 * fi[0] + ax1 * fi[1] + ax2 * fi[2]);
+          Stp += (T)d.pitch * (ax0 * pp[0] + ax1 * pp[1] + ax2 * pp[2]);
+        }
       } else {
         stf = ax0 * fi[0] + ax1 * fi[1] + ax2 * fi[2];
         Stp = ax0 * pp[0] + ax1 * pp[1] + ax2 * pp[2];
@@ -1508,7 +1543,7 @@ __global__ void k_fk_init(const double* __restrict__ q, int nq, int q_shared, co
     }
     const double qi = qs[0];
     T c, s;
-    if (jd[i].flags & JF_REVOLUTE) {
+    if ((jd[i].flags & JF_REVOLUTE) && !(jd[i].flags & JF_HELICAL)) {
       double sd, cd;
       sincos(qi, &sd, &cd);
       c = (T)cd; s = (T)sd;
@@ -1709,8 +1744,14 @@ __global__ void k_rebuild_his(const char* tiles, Layout L, const JointDesc* __re
     for (int k = 0; k < 21; ++k) hh[k] = (T)o[(i - 1) * 21 + k];
     const int a0 = (d.flags & JF_REVOLUTE) ? 3 : 0;
     const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
-    for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, a0)] * ax0 + hh[sym(k, a0 + 1)] * ax1 + hh[sym(k, a0 + 2)] * ax2;
-    const T dd = T(1) / ((ax0 * U[a0] + ax1 * U[a0 + 1] + ax2 * U[a0 + 2]) + mu_in);
+    const T ph = (d.flags & JF_HELICAL) ? (T)d.pitch : T(0);  // S = [pitch a; a]
+    for (int k = 0; k < 6; ++k) {
+      U[k] = hh[sym(k, a0)] * ax0 + hh[sym(k, a0 + 1)] * ax1 + hh[sym(k, a0 + 2)] * ax2;
+      if (d.flags & JF_HELICAL) U[k] += ph * (hh[sym(k, 0)] * ax0 + hh[sym(k, 1)] * ax1 + hh[sym(k, 2)] * ax2);
+    }
+    T sus = ax0 * U[a0] + ax1 * U[a0 + 1] + ax2 * U[a0 + 2];
+    if (d.flags & JF_HELICAL) sus = (ax0 * U[3] + ax1 * U[4] + ax2 * U[5]) + ph * (ax0 * U[0] + ax1 * U[1] + ax2 * U[2]);
+    const T dd = T(1) / (sus + mu_in);
     for (int k = 0; k < 6; ++k) UD[k] = U[k] * dd;
     for (int r = 0; r < 6; ++r)
       for (int c = r; c < 6; ++c) hh[sym(r, c)] -= UD[r] * U[c];

@@ -402,6 +402,8 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
     const char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
     T ax[3];
     const bool rev = jflags & JF_REVOLUTE;
+    const int jflags_h = jflags;
+    const T pitch_h = (jflags & JF_HELICAL) ? (T)jd[jl + 1].pitch : T(0);
     {
       const typename Vec2<T>::type csn = ldp<T>(rec, JP_CS), wz = ldp<T>(rec, JP_WZ), nus = ldp<T>(rec, JP_NUS);
       const JointDesc d = jd[jl + 1];
@@ -437,6 +439,10 @@ k_flat(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
       cross3(t0, ra3, c);
 #pragma unroll
       for (int k = 0; k < 3; ++k) { Sw[k] = rev ? c[k] : ra3[k]; Sw[3 + k] = rev ? ra3[k] : T(0); }
+      if (jflags_h & JF_HELICAL) {  // S = [pitch a; a] at the world origin: (t x R a + pitch R a, R a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Sw[k] += pitch_h * ra3[k];
+      }
     }
     // constraint blocks: lane of the joint, b, y, A^T y (+ A); then AW = X*_{0<-joint} A^T, AW b
     for (int c = 0; c < L.nc; ++c) {
@@ -1078,6 +1084,8 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
     }
     flat_world_placement<T>(xch, lane, jlane, jrow4, njmp, R0, t0);
     const bool rev = d.flags & JF_REVOLUTE;
+    const int jflags_h = d.flags;
+    const T pitch_h = (d.flags & JF_HELICAL) ? (T)d.pitch : T(0);
     T ax[3], ra3[3], c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) ax[k] = isj_lane ? (T)d.axis[k] : T(0);
@@ -1085,6 +1093,10 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
     cross3(t0, ra3, c);
 #pragma unroll
     for (int k = 0; k < 3; ++k) { Sw[k] = rev ? c[k] : ra3[k]; Sw[3 + k] = rev ? ra3[k] : T(0); }
+    if (jflags_h & JF_HELICAL) {  // S = [pitch a; a] at the world origin: (t x R a + pitch R a, R a)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Sw[k] += pitch_h * ra3[k];
+    }
 #pragma unroll
     for (int k = 0; k < 6; ++k) swt[lane * 6 + k] = Sw[k];
     if (lane < 6) swt[WAVE * 6 + lane] = T(0);
@@ -1244,7 +1256,13 @@ __global__ void k_rebuild_ud(char* tiles, Layout L, const JointDesc* __restrict_
     const int a0 = (d.flags & JF_REVOLUTE) ? 3 : 0;
     const T ax0 = (T)d.axis[0], ax1 = (T)d.axis[1], ax2 = (T)d.axis[2];
     for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, a0)] * ax0 + hh[sym(k, a0 + 1)] * ax1 + hh[sym(k, a0 + 2)] * ax2;
-    const T dd = T(1) / ((ax0 * U[a0] + ax1 * U[a0 + 1] + ax2 * U[a0 + 2]) + mu_in);
+    T sus = ax0 * U[a0] + ax1 * U[a0 + 1] + ax2 * U[a0 + 2];
+    if (d.flags & JF_HELICAL) {  // S = [pitch a; a]
+      const T ph = (T)d.pitch;
+      for (int k = 0; k < 6; ++k) U[k] += ph * (hh[sym(k, 0)] * ax0 + hh[sym(k, 1)] * ax1 + hh[sym(k, 2)] * ax2);
+      sus = (ax0 * U[3] + ax1 * U[4] + ax2 * U[5]) + ph * (ax0 * U[0] + ax1 * U[1] + ax2 * U[2]);
+    }
+    const T dd = T(1) / (sus + mu_in);
     for (int k = 0; k < 6; ++k) UD[k] = U[k] * dd;
     char* rec = lp + (size_t)(i - 1) * JREC * pair_bytes<T>();
     st6<T>(rec, JP_UD, UD);

@@ -391,6 +391,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     // ---- full width on both lanes of a joint (identical values): k_flat's load, rows indexed by the joint
     T ax[3], v[6], f[6], g[6], Sw[6], SE[6];
     const bool rev = jflags & JF_REVOLUTE;
+    const int jflags_h = jflags;
+    const T pitch_h = (jflags & JF_HELICAL) ? (T)jd[jl + 1].pitch : T(0);
     {
       // (straight from a cold reset -- the plain queue hands every instance out once -- vis, fis, g, w, z are zeros in every
       //  record: ten of the twelve pairs of a joint are not fetched.  A record's 16-byte pairs lie 1 KiB apart in the tiles of
@@ -438,6 +440,10 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       cross3(t0, ra3, c);
 #pragma unroll
       for (int k = 0; k < 3; ++k) { Sw[k] = rev ? c[k] : ra3[k]; Sw[3 + k] = rev ? ra3[k] : T(0); }
+      if (jflags_h & JF_HELICAL) {  // S = [pitch a; a] at the world origin: (t x R a + pitch R a, R a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Sw[k] += pitch_h * ra3[k];
+      }
     }
     // constraint blocks: lane of the joint, b, y, A^T y, A; then AW = X*_{0<-joint} A^T, AW b
     for (int c = 0; c < L.nc; ++c) {
@@ -1265,6 +1271,8 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
     T ax[3];
     const bool rev = jflags & JF_REVOLUTE;
+    const int jflags_h = jflags;
+    const T pitch_h = (jflags & JF_HELICAL) ? (T)jd[jl + 1].pitch : T(0);
     {
       // (straight from a cold reset -- the plain queue hands every instance out once -- vis, fis, g, w, z are zeros in every
       //  record: ten of the twelve pairs of a joint are not fetched.  A record's 16-byte pairs lie 1 KiB apart in the tiles of
@@ -1312,6 +1320,10 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       cross3(t0, ra3, c);
 #pragma unroll
       for (int k = 0; k < 3; ++k) { Sw[k] = rev ? c[k] : ra3[k]; Sw[3 + k] = rev ? ra3[k] : T(0); }
+      if (jflags_h & JF_HELICAL) {  // S = [pitch a; a] at the world origin: (t x R a + pitch R a, R a)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Sw[k] += pitch_h * ra3[k];
+      }
     }
     for (int c = 0; c < L.nc; ++c) {
       const char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();

@@ -499,12 +499,13 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
     for (int i = 1; i < enj; ++i) {
       const int p = m->parents[i], jt = m->jtype[i];
       if (p < 0 || p >= i) { g_last_error = "model: parents[i] must be < i"; return LOIKB_ERR_MODEL; }
-      if (jt < LOIKB_J_RX || jt > LOIKB_J_RUBU) {
+      if (jt < LOIKB_J_RX || jt > LOIKB_J_HU) {
         g_last_error = "model: unsupported joint type (supported: 1-DoF joints incl. unbounded revolute, free-flyer, spherical, "
-                       "spherical ZYX, translation, planar, composites of those -- a universal joint is the composite of its two "
-                       "revolute joints; not: mimic, helical)";
+                       "spherical ZYX, translation, planar, helical, composites of those -- a universal joint is the composite "
+                       "of its two revolute joints; not: mimic)";
         return LOIKB_ERR_MODEL;
       }
+      if (jt >= LOIKB_J_HX && !m->pitch) { g_last_error = "model: a helical joint needs loikb_model_desc.pitch"; return LOIKB_ERR_MODEL; }
       if (m->idx_q[i] != iq || m->idx_v[i] != iv) {
         g_last_error = "model: idx_q/idx_v must be cumulative in joint order (Pinocchio's layout)";
         return LOIKB_ERR_MODEL;
@@ -519,7 +520,7 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
         for (int k = 0; k < m->comp_count[i]; ++k) {
           const int st = m->comp_jtype[m->comp_first[i] + k];
           if (st < LOIKB_J_RX || st > LOIKB_J_RUBU || st == LOIKB_J_COMPOSITE) {
-            g_last_error = "model: a sub-joint of a composite joint must be one of the supported joint types other than a composite";
+            g_last_error = "model: a sub-joint of a composite joint must be one of the supported joint types other than a composite or a helical joint";
             return LOIKB_ERR_MODEL;
           }
           iq += jt_nq(st); iv += jt_nv(st); cnv += jt_nv(st);
@@ -593,6 +594,10 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
         } else if (jt == LOIKB_J_RUBU) {  // JointModelRevoluteUnboundedUnaligned: a revolute joint about `axis` whose q IS (cos, sin)
           sub = LOIKB_J_RU;
           flags |= JF_CS_DIRECT;
+        } else if (jt >= LOIKB_J_HX && jt <= LOIKB_J_HU) {  // JointModelHelical*: the revolute joint about the axis + JF_HELICAL, pitch
+          sub = jt == LOIKB_J_HU ? LOIKB_J_RU : LOIKB_J_RX + (jt - LOIKB_J_HX);
+          flags |= JF_HELICAL;
+          d.pitch = m->pitch[i];
         } else if (n > 1) {
           // chain joint k: prismatic along / revolute about axis (k mod 3) of the joint frame
           const bool angular = jt == LOIKB_J_SPHERICAL || (jt == LOIKB_J_FREEFLYER && k >= 3);

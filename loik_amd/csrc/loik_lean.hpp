@@ -232,6 +232,10 @@ k_lean(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   T Sv[6];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { Sv[k] = rev ? T(0) : (T)d.axis[k]; Sv[3 + k] = rev ? (T)d.axis[k] : T(0); }
+  if (d.flags & JF_HELICAL) {  // S = [pitch a; a]: every use of S in this kernel is the 6-vector
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Sv[k] = (T)d.pitch * (T)d.axis[k];
+  }
   if (lane < LXS) xch[WAVE * LXS + lane] = T(0);
   if (a_shared)
     for (int e = lane; e < L.nc * LCA; e += WAVE) ash[e] = Bf.uni[e];
@@ -954,6 +958,12 @@ k_hslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
 #pragma unroll
         for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 0)] * ax0 + hh[sym(k, 1)] * ax1 + hh[sym(k, 2)] * ax2;
         dinv = T(1) / ((ax0 * U[0] + ax1 * U[1] + ax2 * U[2]) + mu_in);
+      }
+      if (d.flags & JF_HELICAL) {  // S = [pitch a; a]
+        const T ph = (T)d.pitch;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) U[k] += ph * (hh[sym(k, 0)] * ax0 + hh[sym(k, 1)] * ax1 + hh[sym(k, 2)] * ax2);
+        dinv = T(1) / (((ax0 * U[3] + ax1 * U[4] + ax2 * U[5]) + ph * (ax0 * U[0] + ax1 * U[1] + ax2 * U[2])) + mu_in);
       }
 #pragma unroll
       for (int k = 0; k < 6; ++k) UD[k] = U[k] * dinv;

@@ -117,6 +117,8 @@ __device__ inline void p_S(const JointDesc& d, double* S)
 {
   const bool rev = d.flags & JF_REVOLUTE;
   for (int k = 0; k < 3; ++k) { S[k] = rev ? 0.0 : d.axis[k]; S[3 + k] = rev ? d.axis[k] : 0.0; }
+  if (d.flags & JF_HELICAL)   // JointModelHelical*: S = [pitch a; a]
+    for (int k = 0; k < 3; ++k) S[k] = d.pitch * d.axis[k];
 }
 __device__ inline double p_inf6(const double* x)
 {

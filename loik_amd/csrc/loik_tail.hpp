@@ -167,6 +167,14 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
   T Sv[6];
 #pragma unroll
   for (int k = 0; k < 3; ++k) { Sv[k] = rev ? T(0) : (T)d.axis[k]; Sv[3 + k] = rev ? (T)d.axis[k] : T(0); }
+  // helical joints (S = [pitch a; a]): a wavefront-uniform switch, so that models without one pay nothing
+  const bool hel = (d.flags & JF_HELICAL) != 0;
+  const bool hel_any = __any(hel ? 1 : 0) != 0;
+  const T ph = hel ? (T)d.pitch : T(0);
+  if (hel) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Sv[k] = ph * (T)d.axis[k];
+  }
   if (lane < XS) xch[WAVE * XS + lane] = T(0);
 
   // ---- the instance a group works on (all of this is reloaded when the group takes the next one) -----------------
@@ -479,13 +487,19 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
             for (int k = 0; k < 6; ++k) U[k] = hh[sym(k, 0)] * ax0 + hh[sym(k, 1)] * ax1 + hh[sym(k, 2)] * ax2;
             dinv = T(1) / ((ax0 * U[0] + ax1 * U[1] + ax2 * U[2]) + mu_in);
           }
+          if (hel_any && hel) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) U[k] += ph * (hh[sym(k, 0)] * ax0 + hh[sym(k, 1)] * ax1 + hh[sym(k, 2)] * ax2);
+            dinv = T(1) / (((ax0 * U[3] + ax1 * U[4] + ax2 * U[5]) + ph * (ax0 * U[0] + ax1 * U[1] + ax2 * U[2])) + mu_in);
+          }
 #pragma unroll
           for (int k = 0; k < 6; ++k) UD[k] = U[k] * dinv;
 #pragma unroll
           for (int k = 0; k < 21; ++k) hcur[k] = hh[k];  // pre-projection H for the forward sweep
           hcur[21] = dinv;
         }
-        const T Stp = rev ? (ax0 * p[3] + ax1 * p[4] + ax2 * p[5]) : (ax0 * p[0] + ax1 * p[1] + ax2 * p[2]);
+        T Stp = rev ? (ax0 * p[3] + ax1 * p[4] + ax2 * p[5]) : (ax0 * p[0] + ax1 * p[1] + ax2 * p[2]);
+        if (hel_any && hel) Stp += ph * (ax0 * p[0] + ax1 * p[1] + ax2 * p[2]);
         r = (w - mu_in * z) + Stp;
         if (has_parent) {
           T* x = xch + lane * XS;
@@ -647,7 +661,8 @@ k_tail(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, co
 #pragma unroll
       for (int a = 0; a < 6; ++a) dvr[a] = mass * (dvr[a] - (hrow ? hrow[36 + a] : P.Hv[a])) + gi[a];
       l_dualv = inf6(dvr);
-      const T stf = rev ? (ax0 * f[3] + ax1 * f[4] + ax2 * f[5]) : (ax0 * f[0] + ax1 * f[1] + ax2 * f[2]);
+      T stf = rev ? (ax0 * f[3] + ax1 * f[4] + ax2 * f[5]) : (ax0 * f[0] + ax1 * f[1] + ax2 * f[2]);
+      if (hel_any && hel) stf += ph * (ax0 * f[0] + ax1 * f[1] + ax2 * f[2]);
       const T si = stf + w;
       l_stf = tabs(si);
       l_dstf = tabs(si - s);

@@ -12,6 +12,7 @@ J_RX, J_RY, J_RZ, J_PX, J_PY, J_PZ, J_RU, J_PU = 1, 2, 3, 4, 5, 6, 7, 8
 J_FREEFLYER, J_SPHERICAL, J_TRANSLATION = 9, 10, 11
 J_SPHERICAL_ZYX, J_PLANAR, J_RUBX, J_RUBY, J_RUBZ = 12, 13, 14, 15, 16
 J_RUBU = 18
+J_HX, J_HY, J_HZ, J_HU = 19, 20, 21, 22   # JointModelHelical*: M = (Rot(a, q), pitch q a), S = [pitch a; a]
 
 # the reference fixture's solver parameters, /root/reference/tests/loik-loid.cpp:91-105
 FIXTURE_PARAMS = dict(tol_primal_inf=1e-2, tol_dual_inf=1e-2, tol_tail_solve=1e-1, rho=1e-5, mu=1e-2,
@@ -147,9 +148,16 @@ def link_velocity(model, q, nu, link):
             else:
                 v[:, :3] += nu[:, iv:iv + 3]
             continue
+        pitch = 0.0
+        if jt in (J_HX, J_HY, J_HZ, J_HU):   # the revolute joint about the same axis + the translation / velocity along it
+            pitch = float(model.pitch[i])
+            jt = J_RU if jt == J_HU else J_RX + (jt - J_HX)
         if jt in (J_RX, J_RY, J_RZ, J_RU):
             R = Rp[None] @ _rot(jt, model.axis[i], qi)
             t = np.broadcast_to(tp, (B, 3))
+            if pitch:
+                a = np.asarray(model.axis[i], dtype=float) if jt == J_RU else np.eye(3)[jt - J_RX]
+                t = tp[None] + (pitch * qi)[:, None] * (Rp @ a)[None]
         else:
             a = np.zeros(3)
             if jt == J_PU:
@@ -172,6 +180,8 @@ def link_velocity(model, q, nu, link):
             S[3:] = model.axis[i]
         else:
             S[:3] = model.axis[i]
+        if pitch:
+            S[:3] = pitch * S[3:]
         v = v + S[None] * nui[:, None]
     return v
 

@@ -254,6 +254,10 @@ static void joint_calc(int jtype, const double *axis, const double *qs, double *
   }
   double q = qs[0];
   double c = cos(q), s = sin(q);
+  /* JointModelHelical*: the rotation of the revolute joint about the same axis; the caller adds the translation pitch q axis
+   * (helical_axis / ref_fwd_pass_init) */
+  if (jtype >= REF_J_HX && jtype <= REF_J_HZ) jtype = REF_J_RX + (jtype - REF_J_HX);
+  else if (jtype == REF_J_HU) jtype = REF_J_RU;
   if (jtype == REF_J_RUBX || jtype == REF_J_RUBY || jtype == REF_J_RUBZ) { /* JointModelRevoluteUnbounded: q = (cos, sin) */
     c = qs[0]; s = qs[1];
     jtype = REF_J_RX + (jtype - REF_J_RUBX);
@@ -311,9 +315,10 @@ static void joint_S(int jtype, const double *axis, const double *qs, double *S)
   case REF_J_PX: S[0] = 1.0; break;
   case REF_J_PY: S[1] = 1.0; break;
   case REF_J_PZ: S[2] = 1.0; break;
-  case REF_J_RX: S[3] = 1.0; break;
-  case REF_J_RY: S[4] = 1.0; break;
-  case REF_J_RZ: S[5] = 1.0; break;
+  case REF_J_RX: case REF_J_HX: S[3] = 1.0; break;   /* (helical: the linear part pitch * axis is added by the caller) */
+  case REF_J_RY: case REF_J_HY: S[4] = 1.0; break;
+  case REF_J_RZ: case REF_J_HZ: S[5] = 1.0; break;
+  case REF_J_HU: S[3] = axis[0]; S[4] = axis[1]; S[5] = axis[2]; break;
   case REF_J_PU: S[0] = axis[0]; S[1] = axis[1]; S[2] = axis[2]; break;
   case REF_J_RU: S[3] = axis[0]; S[4] = axis[1]; S[5] = axis[2]; break;
   case REF_J_FREEFLYER: for (int c = 0; c < 6; ++c) S[6 * c + c] = 1.0; break;        /* ConstraintIdentity */
@@ -402,7 +407,7 @@ struct ref_solver {
   /* model (copied, reference keeps `Model model_` by value, loik-loid-optimized.hpp:762) */
   int nj, nb, nq, nv, nc;
   int *parents, *jtype, *idx_q, *idx_v, *jnv, *massless;
-  double *axis, *placement;
+  double *axis, *placement, *pitch;   /* pitch: [nj], zeros unless the model has helical joints */
 
   /* --- IkIdDataTypeOptimizedTpl members (loik-loid-data-optimized.hxx:40-86) --- */
   double *oMi, *liMi;                /* [nj][12] */
@@ -591,7 +596,8 @@ int ref_create(const ref_model *m, const ref_params *p, ref_solver **out)
   s->jtype = (int *)malloc(sizeof(int) * nj);
   s->idx_q = (int *)malloc(sizeof(int) * nj);
   s->idx_v = (int *)malloc(sizeof(int) * nj);
-  s->axis = dalloc(3 * nj);
+  s->axis = dalloc(3 * nj); s->pitch = dalloc(nj);
+  if (m->pitch) memcpy(s->pitch, m->pitch, sizeof(double) * nj);
   s->placement = dalloc(12 * nj);
   memcpy(s->parents, m->parents, sizeof(int) * nj);
   memcpy(s->jtype, m->jtype, sizeof(int) * nj);
@@ -627,7 +633,11 @@ int ref_create(const ref_model *m, const ref_params *p, ref_solver **out)
   for (int i = 0; i < nj; ++i) { se3_identity(s->oMi + 12 * i); se3_identity(s->liMi + 12 * i); }
   s->jS = dalloc(36 * nj); s->jU = dalloc(36 * nj); s->jUDinvM = dalloc(36 * nj); s->jDinvM = dalloc(36 * nj);
   s->jUDinv = dalloc(6 * nj); s->jDinv = dalloc(nj);
-  for (int i = 0; i < nj; ++i) joint_S(s->jtype[i], s->axis + 3 * i, NULL, s->jS + 36 * i);
+  for (int i = 0; i < nj; ++i) {
+    joint_S(s->jtype[i], s->axis + 3 * i, NULL, s->jS + 36 * i);
+    if (s->jtype[i] >= REF_J_HX && s->jtype[i] <= REF_J_HU)   /* JointMotionSubspaceHelical: S = [pitch a; a] */
+      for (int k = 0; k < 3; ++k) s->jS[36 * i + k] = s->pitch[i] * s->jS[36 * i + 3 + k];
+  }
   s->nu = dalloc(nv); s->nu_prev = dalloc(nv);
   s->vis = dalloc(6 * nj); s->vis_prev = dalloc(6 * nj);
   s->His = dalloc(36 * nj); s->His_aba = dalloc(36 * nj);
@@ -675,7 +685,7 @@ int ref_create(const ref_model *m, const ref_params *p, ref_solver **out)
 void ref_destroy(ref_solver *s)
 {
   if (!s) return;
-  free(s->parents); free(s->jtype); free(s->idx_q); free(s->idx_v); free(s->axis); free(s->placement);
+  free(s->parents); free(s->jtype); free(s->idx_q); free(s->idx_v); free(s->axis); free(s->pitch); free(s->placement);
   free(s->jnv); free(s->massless);
   free(s->comp_first); free(s->comp_count); free(s->comp_jtype); free(s->comp_axis); free(s->comp_placement);
   free(s->oMi); free(s->liMi); free(s->jS); free(s->jU); free(s->jUDinvM); free(s->jDinvM);
@@ -971,6 +981,10 @@ void ref_fwd_pass_init(ref_solver *s, const double *q)
     int parent = s->parents[idx];
     if (s->jtype[idx] == REF_J_COMPOSITE) composite_calc(s, idx, q + s->idx_q[idx], M, s->jS + 36 * idx);
     else joint_calc(s->jtype[idx], s->axis + 3 * idx, q + s->idx_q[idx], M);
+    if (s->jtype[idx] >= REF_J_HX && s->jtype[idx] <= REF_J_HU) {   /* JointModelHelical*::calc: translation pitch q axis */
+      const double *S = s->jS + 36 * idx, hq = s->pitch[idx] * q[s->idx_q[idx]];
+      for (int k = 0; k < 3; ++k) M[9 + k] = hq * S[3 + k];
+    }
     if (s->jtype[idx] == REF_J_SPHERICAL_ZYX) joint_S(s->jtype[idx], s->axis + 3 * idx, q + s->idx_q[idx], s->jS + 36 * idx);
     se3_mul(s->placement + 12 * idx, M, s->liMi + 12 * idx);
     se3_mul(s->oMi + 12 * parent, s->liMi + 12 * idx, s->oMi + 12 * idx);

@@ -47,7 +47,11 @@ enum {
   REF_J_RUBY = 15,
   REF_J_RUBZ = 16,
   REF_J_COMPOSITE = 17,  /* JointModelComposite of any sub-joints but composites, ref_model.comp_* (nv <= 6)                */
-  REF_J_RUBU = 18        /* JointModelRevoluteUnboundedUnaligned: nq 2 (cos, sin), nv 1, about ref_model.axis          */
+  REF_J_RUBU = 18,       /* JointModelRevoluteUnboundedUnaligned: nq 2 (cos, sin), nv 1, about ref_model.axis          */
+  REF_J_HX = 19,         /* JointModelHelicalX / Y / Z / Unaligned: nq 1, nv 1; M(q) = (Rot(axis, q), pitch q axis),      */
+  REF_J_HY = 20,         /* S = [pitch axis; axis]; pitch = ref_model.pitch[i]                                             */
+  REF_J_HZ = 21,
+  REF_J_HU = 22
 };
 
 /* mirrors enum ADMMPenaltyUpdateStrat, task-solver-base.hpp:13-18 */
@@ -86,6 +90,7 @@ typedef struct ref_model {
   const int *comp_jtype;                /* [n_sub]              */
   const double *comp_axis;              /* [n_sub][3]           */
   const double *comp_placement;         /* [n_sub][12]          */
+  const double *pitch;                  /* [nj] or NULL: JointModelHelical*::m_pitch */
 } ref_model;
 
 typedef struct ref_params {

@@ -3,7 +3,7 @@
   python scripts/fuzz_engines.py [ncases] [seed] [flat_bias]
 
 Each case draws: a random kinematic tree (3..44 joints, depth-first or breadth-first numbered; 1-DoF joints of every type,
-optionally a free-flyer / planar root, spherical, translation, SphericalZYX, planar, unbounded-revolute and composite joints), 0..4 task
+optionally helical joints, a free-flyer / planar root, spherical, translation, SphericalZYX, planar, unbounded-revolute and composite joints), 0..4 task
 constraints with a shared or per-instance A, shared or per-instance bounds, an identity / diagonal / full reference cost
 with or without v_ref -- or per-link references (UpdateReferences) --, tolerances and max_iter, the DEFAULT or the OSQP penalty
 rule, optionally a spare constraint slot (a null constraint in every engine) -- and an ENGINE configuration (default
@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import loik_amd  # noqa: E402
-from helpers import (FIXTURE, assert_end_to_end, composite_tree, fetch_end_to_end, multi_task_batch, random_tree,  # noqa: E402
+from helpers import (FIXTURE, assert_end_to_end, composite_tree, fetch_end_to_end, helical_tree, multi_task_batch, random_tree,  # noqa: E402
                      random_tree_multidof, renumber_breadth_first)
 from oracle import ref  # noqa: E402
 
@@ -66,9 +66,13 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
         elif kind < 0.45 and nb >= 6 and nb <= 30:   # JointModelComposite: 1..3 joints become composites of 2..4 sub-joints
             model = composite_tree(seed, nb, [int(x) for x in rng.choice(np.arange(1, nb + 1), size=int(rng.integers(1, 4)), replace=False)])
         else:
-            model = random_tree(seed, nb, branch_prob=float(rng.uniform(0.45, 0.7) if for_flat else rng.uniform(0.1, 0.6)))
-            if rng.random() < 0.3 and not for_flat:
-                model, _ = renumber_breadth_first(model)
+            bp = float(rng.uniform(0.45, 0.7) if for_flat else rng.uniform(0.1, 0.6))
+            if rng.random() < 0.2:   # helical joints (S = [pitch a; a]) among the revolute ones
+                model = helical_tree(seed, nb, int(rng.integers(1, 5)), branch_prob=bp)
+            else:
+                model = random_tree(seed, nb, branch_prob=bp)
+                if rng.random() < 0.3 and not for_flat:
+                    model, _ = renumber_breadth_first(model)
         if model.nv > 64:
             continue
         nc = int(rng.choice([0, 1, 1, 2, 3, 4]))

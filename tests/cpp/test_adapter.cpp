@@ -35,6 +35,7 @@ struct JointModel {
   std::string sn;
   int iq = 0, iv = 0;
   double ax[6] = {0, 0, 0, 0, 0, 0};   // (axis; JointModelUniversal: axis1, axis2)
+  double m_pitch = 0.0;                // JointModelHelical*
   std::vector<std::pair<JointModel, SE3>> subs;  // JointModelComposite::joints / ::jointPlacements
   std::string shortname() const { return sn; }
   int idx_q() const { return iq; }
@@ -72,7 +73,8 @@ static const char* short_name(int t)
                                 "JointModelRevoluteUnaligned", "JointModelPrismaticUnaligned", "JointModelFreeFlyer",
                                 "JointModelSpherical", "JointModelTranslation", "JointModelSphericalZYX", "JointModelPlanar",
                                 "JointModelRUBX", "JointModelRUBY", "JointModelRUBZ", "JointModelComposite",
-                                "JointModelRevoluteUnboundedUnaligned"};
+                                "JointModelRevoluteUnboundedUnaligned", "JointModelHX", "JointModelHY", "JointModelHZ",
+                                "JointModelHelicalUnaligned"};
   return names[t];
 }
 
@@ -86,6 +88,7 @@ static shape::Model pinocchio_shaped(const Model& m)
     shape::JointModel j;
     j.sn = short_name(m.jtype[i]); j.iq = m.idx_q[i]; j.iv = m.idx_v[i];
     for (int k = 0; k < 3; ++k) j.ax[k] = m.axis[3 * i + k];
+    if (!m.pitch.empty()) j.m_pitch = m.pitch[i];
     p.joints.push_back(j);
     shape::SE3 P;
     for (int r = 0; r < 3; ++r)
@@ -118,7 +121,9 @@ static void round_trip(const Model& m)
         p.joints[i].subs.emplace_back(sj, se3_of(&m.comp_placement[12 * e]));
       }
   const Model o = to_loik_amd(p, [](const shape::JointModel& j, const std::string&) { return j.ax; },
-                              [](const shape::JointModel& j) { return j.subs; });
+                              [](const shape::JointModel& j) { return j.subs; },
+                              [](const shape::JointModel& j, const std::string&) { return j.m_pitch; });
+  CHECK(o.pitch == m.pitch);
   CHECK(o.comp_first == m.comp_first && o.comp_count == m.comp_count && o.comp_jtype == m.comp_jtype);
   CHECK(o.comp_axis == m.comp_axis && o.comp_placement == m.comp_placement);
   CHECK(o.njoints == m.njoints && o.nq == m.nq && o.nv == m.nv);
@@ -127,7 +132,7 @@ static void round_trip(const Model& m)
   for (int i = 1; i < m.njoints; ++i)
     for (int k = 0; k < 3; ++k) {
       // aligned joints carry no axis in Pinocchio: the adapter leaves it zero, the library derives it from the type
-      const bool unaligned = m.jtype[i] == LOIKB_J_RU || m.jtype[i] == LOIKB_J_PU || m.jtype[i] == LOIKB_J_RUBU;
+      const bool unaligned = m.jtype[i] == LOIKB_J_RU || m.jtype[i] == LOIKB_J_PU || m.jtype[i] == LOIKB_J_RUBU || m.jtype[i] == LOIKB_J_HU;
       CHECK(o.axis[3 * i + k] == (unaligned ? m.axis[3 * i + k] : 0.0));
     }
 }
@@ -138,9 +143,10 @@ int main()
   {  // a model with every joint type, unaligned axes, rotated placements
     Model m;
     const int types[] = {LOIKB_J_NONE, LOIKB_J_FREEFLYER, LOIKB_J_RU, LOIKB_J_PU, LOIKB_J_SPHERICAL, LOIKB_J_TRANSLATION,
-                         LOIKB_J_SPHERICAL_ZYX, LOIKB_J_PLANAR, LOIKB_J_RUBY, LOIKB_J_PZ, LOIKB_J_RUBU, LOIKB_J_COMPOSITE};
-    const int nqs[] = {0, 7, 1, 1, 4, 3, 3, 4, 2, 1, 2, 7}, nvs[] = {0, 6, 1, 1, 3, 3, 3, 3, 1, 1, 1, 5};
-    m.njoints = 12;
+                         LOIKB_J_SPHERICAL_ZYX, LOIKB_J_PLANAR, LOIKB_J_RUBY, LOIKB_J_PZ, LOIKB_J_RUBU, LOIKB_J_COMPOSITE,
+                         LOIKB_J_HY, LOIKB_J_HU};   // (two helical joints: aligned and unaligned, with their pitch)
+    const int nqs[] = {0, 7, 1, 1, 4, 3, 3, 4, 2, 1, 2, 7, 1, 1}, nvs[] = {0, 6, 1, 1, 3, 3, 3, 3, 1, 1, 1, 5, 1, 1};
+    m.njoints = 14;
     for (int i = 0; i < m.njoints; ++i) {
       m.parents.push_back(i ? (i - 1) / 2 : 0);
       m.jtype.push_back(types[i]);
@@ -148,7 +154,8 @@ int main()
       m.nq += nqs[i]; m.nv += nvs[i];
       const double a[3] = {std::sin(1.0 + i), std::cos(2.0 * i), 0.3};
       const double n = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-      const bool un = types[i] == LOIKB_J_RU || types[i] == LOIKB_J_PU || types[i] == LOIKB_J_RUBU;
+      const bool un = types[i] == LOIKB_J_RU || types[i] == LOIKB_J_PU || types[i] == LOIKB_J_RUBU || types[i] == LOIKB_J_HU;
+      m.pitch.push_back(types[i] >= LOIKB_J_HX ? 0.1 * i - 1.0 : 0.0);
       for (int k = 0; k < 3; ++k) m.axis.push_back(un ? a[k] / n : 0.0);
       const double c = std::cos(0.3 * i), s = std::sin(0.3 * i);
       const double P[12] = {c, -s, 0, s, c, 0, 0, 0, 1, 0.1 * i, -0.2, 0.05 * i};  // Rz(0.3 i): not symmetric -> order matters
@@ -187,7 +194,8 @@ int main()
       u.joints[11].subs = {{sp, se3_of(Psub)}, {su, se3_of(Psub)}};   // nq 3, nv 3
       u.nq += 3 - 7; u.nv += 3 - 5;
       const Model o = to_loik_amd(u, [](const shape::JointModel& j, const std::string&) { return j.ax; },
-                                  [](const shape::JointModel& j) { return j.subs; });
+                                  [](const shape::JointModel& j) { return j.subs; },
+                                  [](const shape::JointModel& j, const std::string&) { return j.m_pitch; });
       CHECK(o.jtype[2] == LOIKB_J_COMPOSITE && o.comp_count[2] == 2 && o.comp_first[2] == 0);
       CHECK(o.comp_jtype[0] == LOIKB_J_RU && o.comp_jtype[1] == LOIKB_J_RU);
       for (int k = 0; k < 6; ++k) CHECK(o.comp_axis[k] == axes[k]);
@@ -202,6 +210,14 @@ int main()
       }
       CHECK(o.nq == u.nq && o.nv == u.nv && o.idx_q[3] == u.joints[3].iq);
     }
+    thrown = false;   // a helical joint needs the PitchOf functor
+    try {
+      shape::Model hp = pinocchio_shaped(m);
+      for (int i = 1; i < m.njoints; ++i)
+        if (m.jtype[i] == LOIKB_J_COMPOSITE) hp.joints[i].sn = "JointModelRZ";
+      (void)to_loik_amd(hp, [](const shape::JointModel& j, const std::string&) { return j.ax; });
+    } catch (const std::runtime_error& e) { thrown = std::strstr(e.what(), "PitchOf") != nullptr; }
+    CHECK(thrown);
     p.joints[3].sn = "JointModelComposite";   // a composite needs the SubJointsOf functor
     thrown = false;
     try { (void)to_loik_amd(p, [](const shape::JointModel& j, const std::string&) { return j.ax; }); }

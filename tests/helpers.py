@@ -95,6 +95,20 @@ def random_tree(seed, nb, branch_prob=0.35, all_types=True):
                           name="random_tree_%d_%d" % (seed, nb))
 
 
+def helical_tree(seed, nb, n_helical, branch_prob=0.35):
+    """random_tree(seed, nb) with `n_helical` of its revolute joints turned into helical ones (JointModelHelicalX / Y / Z /
+    Unaligned: the same axis + a pitch in +-[0.05, 0.3] m per radian)"""
+    m = random_tree(seed, nb, branch_prob=branch_prob)
+    rng = np.random.default_rng(seed + 4321)
+    jt = m.jtype.copy()
+    pitch = np.zeros(m.njoints)
+    rev = [i for i in range(1, m.njoints) if int(jt[i]) in (1, 2, 3, 7)]
+    for i in rng.choice(rev, size=min(n_helical, len(rev)), replace=False):
+        jt[i] = 22 if int(jt[i]) == 7 else 19 + (int(jt[i]) - 1)
+        pitch[i] = float(rng.choice([-1.0, 1.0]) * rng.uniform(0.05, 0.3))
+    return loik_amd.Model(m.parents, jt, m.axis, m.placement, q_lo=m.q_lo, q_hi=m.q_hi, pitch=pitch, name="helical_tree_%d_%d" % (seed, nb))
+
+
 def feasible_batch(model, batch, link, seed, bound=0.5, nu_scale=0.4, per_instance_A=False, per_instance_bounds=False):
     wl = workloads.make_workload(model, batch, link, seed, bound=bound, snap_prob=0.0, nu_scale=nu_scale)
     rng = np.random.default_rng(seed + 1)
