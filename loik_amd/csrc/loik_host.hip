@@ -232,6 +232,8 @@ struct loikb_solver_impl {
     unsigned int* d_order_bins = nullptr;  // [2 ORDER_BINS] counts / offsets of the counting sort
     int order_n = 0;                     // instances d_order lists (0: none yet)
     int order_holdoff = 0;               // solves to go in arrival order after an order that predicted badly
+    int arrival_n = 0;                   // the flat engine's last launch in arrival order: instances, ...
+    double arrival_ms = 0.0;             // ... its duration (0: none yet)
     int* d_ring = nullptr;               // work queue of the lean kernel: ring of instance slots (ring_cap, a power of two)
     int ring_cap = 0;
     void* d_hslots = nullptr;            // decade slots of the lean tail kernel (H, Dinv, UDinv per joint and decade)
@@ -1763,13 +1765,16 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       C->stats.hslots_ms += hms;
       if (C->h_counters[FLAT_COUNTERS_DRY])  // (100 MHz clock, low words: from the ring fill of the last stage to the first empty fetch)
         C->stats.queue_dry_ms += (double)(unsigned int)(C->h_counters[FLAT_COUNTERS_TDRY] - C->h_counters[FLAT_COUNTERS_T0]) * 1e-5;
-      if (ordered && C->h_counters[FLAT_COUNTERS_DRY]) {
-        // did the order predict this solve?  A good one leaves the engine ~3 % of its time after the queue ran dry (only short
-        // instances are fetched last); a batch that does not resemble the previous one leaves the 20..25 % of arrival order
-        // without the time slices that would have softened it: then the next solves go back to arrival order + slices
+      if ((split || one) && whole_set && n_first == n_cur) {
+        // did the order predict this solve?  The launch is compared with the handle's last launch in arrival order (+ time slices)
+        // of the same set: a batch that resembles the previous one runs 5..35 % shorter ordered (no ragged end); one that does
+        // not is arrival order without the slices that would have softened it, a few per cent LONGER -- then the next four solves
+        // go back to arrival order, which also refreshes the figure to compare with.  (What the launch leaves after its queue ran
+        // dry does not tell: a small batch's queue is empty long before its long runners are done, whatever the order.)
         const double flat_ms = (double)ms - (double)hms;
-        const double dry_ms = (double)(unsigned int)(C->h_counters[FLAT_COUNTERS_TDRY] - C->h_counters[FLAT_COUNTERS_T0]) * 1e-5;
-        if (flat_ms - dry_ms > 0.10 * flat_ms) C->order_holdoff = 4;
+        if (C->arrival_n != n_cur) { C->arrival_n = n_cur; C->arrival_ms = 0.0; }
+        if (!ordered) C->arrival_ms = flat_ms;
+        else if (C->arrival_ms > 0.0 && flat_ms > 0.985 * C->arrival_ms) C->order_holdoff = 4;
       }
       if (trace)
         fprintf(stderr, "[loikb] flat engine: %6d instances on %u workgroups, done at %8.3f ms (slots %6.3f ms)  "

@@ -13,8 +13,9 @@ rows = []
 for i in range(n):
     s.Solve()
     st = s.stats()
-    rows.append((st["total_ms"], st["tail_ms"], st["hslots_ms"]))
+    rows.append((st["total_ms"], st["tail_ms"], st["hslots_ms"], st["flat_ordered"]))
 r = np.array(rows[2:])
+print("   per solve: " + " ".join("%.2f%s" % (x[0], "o" if x[3] else "") for x in rows))
 print("%s B=%d: total %.2f ms  on-chip launch %.2f ms  of which slots %.2f ms   (min total %.2f)  iters %d flat %d  requeues %d  queue dry at %.2f ms" % (
     os.environ.get("TAG", ""), B, r[:, 0].mean(), r[:, 1].mean(), r[:, 2].mean(), r[:, 0].min(), st["instance_iterations"], st["flat_launches"],
     st["lean_requeues"], st["queue_dry_ms"]))
