@@ -1110,7 +1110,7 @@ __host__ __device__ __forceinline__ size_t flat1_lds_bytes(int nc, bool has_hv)
 }
 
 template <int NA, bool SLICED = false, int HM = 0>
-__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
         int nscan, int njmp, int* ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
         int ndec, double href_s, int has_hv, int ring_mask, int quantum)

@@ -1502,6 +1502,12 @@ void plan_engines(loikb_solver_impl* S)
     const size_t per_wave = S->flat.nanc <= FLAT_NA_SMALL ? flat_lds_bytes<double, FLAT_NA_SMALL>(S->nc, S->flat.G, S->a_shared, false)
                                                            : flat_lds_bytes<double, FLAT_MAXA>(S->nc, S->flat.G, S->a_shared, false);
     pl.flat_waves_cu = (int)std::min<size_t>(8, (160 * 1024) / per_wave);
+    // (the builds with one instance per wavefront have their own LDS layouts: what counts is the kernel that would run)
+    if (flat_takes_diagonal(S)) {
+      const size_t pw = S->flat.G == F2G ? flat2_lds_bytes<FLAT_NA_SMALL>(S->nc, true)
+                        : S->flat.nanc <= FLAT_NA_SMALL ? flat1_lds_bytes<FLAT_NA_SMALL>(S->nc, true) : flat1_lds_bytes<FLAT_MAXA>(S->nc, true);
+      pl.flat_waves_cu = std::max(pl.flat_waves_cu, (int)std::min<size_t>(8, (160 * 1024) / pw));
+    }
   }
   // (logging = 1 does not keep a solve off the flat engine: k_flat<.., LOG> writes the SolverInfo lists itself)
   const char* never_flat = S->opt.tail_max_instances < 0 ? never : (S->opt.flags & LOIKB_OPT_NO_COMPACTION) ? never : nullptr;
@@ -1512,7 +1518,7 @@ void plan_engines(loikb_solver_impl* S)
   else if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) pl.why_not_flat = "LOIKB_OPT_NO_H_CACHE (no precomputed factors)";
   else if (S->opt.mu_update_strat == LOIKB_MU_OSQP) pl.why_not_flat = "OSQP penalty rule: mu is off the decade grid";
   else if (S->nb <= 16) pl.why_not_flat = "a small robot (<= 16 joints): k_solve + k_tail are faster on its short solves";
-  else if (pl.flat_waves_cu < 6) pl.why_not_flat = "constraint blocks leave too few wavefronts per CU in LDS";
+  else if (pl.flat_waves_cu < (flat_takes_diagonal(S) ? 4 : 6)) pl.why_not_flat = "constraint blocks leave too few wavefronts per CU in LDS";
   else pl.flat = true;
   // with the lean kernel whole batches up to 2^20 instances go to it directly (it is as fast as k_solve's bulk phase and
   // has neither ragged tiles nor compaction); without it k_solve hands over to k_tail at 32768 live instances
@@ -1681,7 +1687,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
 #undef LOIKB_LAUNCH_FLAT2
         } else if (one) {
           const size_t lds1 = small_na ? flat1_lds_bytes<FLAT_NA_SMALL>(S->nc, has_hv != 0) : flat1_lds_bytes<FLAT_MAXA>(S->nc, has_hv != 0);
-          int per_cu1 = (int)std::min<size_t>(4, (160 * 1024) / lds1);
+          int per_cu1 = (int)std::min<size_t>(8, (160 * 1024) / lds1);
           if (S->tune.lean_wg_per_cu > 0) per_cu1 = std::min(per_cu1, S->tune.lean_wg_per_cu);
           grid = dim3((unsigned)std::min(n, per_cu1 * (int)(cu_sh + 0.5)));
           // (time slicing as in k_flat2, same window: whole body, four tasks, B = 65 536: 34.7 ms without)
@@ -2988,7 +2994,7 @@ const char* loikb_plan_string(loikb_solver* S)
              "CU, decades mu0*10^%d..%d, %d ancestors per joint, %d scan steps, %d jump rounds)%s; k_solve above that; %d chunk(s)",
              split ? "k_flat2" : one ? "k_flat1" : "k_flat",
              split ? "; two lanes per joint, one instance per wavefront" : one ? "; one instance per wavefront" : "", pl.tail_max,
-             split ? std::min(4 * S->tune.flat_split_wpe, pl.flat_waves_cu * 2) : one ? std::min(4, pl.flat_waves_cu) : pl.flat_waves_cu,
+             split ? std::min(4 * S->tune.flat_split_wpe, pl.flat_waves_cu * 2) : one ? std::min(8, pl.flat_waves_cu) : pl.flat_waves_cu,
              pl.kexp_lo, pl.kexp_lo + pl.ndec - 1,
              S->flat.nanc, S->flat.nscan, S->flat.njmp,
              (split || one) ? ", any reference cost" : S->have_problem ? "" : " when H_ref = h I", pl.nchunks);
