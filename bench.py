@@ -546,9 +546,14 @@ def main(argv=None, solver_factory=None, device_count=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the whole-body variant reported beside the headline at N = 1")
     ap.add_argument("--no-strong-leg", action="store_true", help="skip the extra strong-scaling measurement at N > 1")
+    ap.add_argument("--arrival-order", action="store_true",
+                    help="every timed solve in arrival order (LOIKB_FLAT_ORDER=0): what a handle's FIRST solve of a batch costs; the default "
+                         "line lets the flat engine order a handle's later solves by the previous solve's iteration counts")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--max-launch-iters", type=int, default=0)
     args = ap.parse_args(argv)
+    if args.arrival_order:
+        os.environ["LOIKB_FLAT_ORDER"] = "0"   # (read once per handle, at loikb_create)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
