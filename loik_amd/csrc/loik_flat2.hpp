@@ -1102,9 +1102,9 @@ __host__ __device__ constexpr int flat1_xregion()
   return (n + 1) & ~1;
 }
 template <int NA>
-__host__ __device__ __forceinline__ size_t flat1_lds_bytes(int nc, bool has_hv)
+__host__ __device__ __forceinline__ size_t flat1_lds_bytes(int nc, bool has_hv, int slot_bufs = 2)
 {
-  const size_t n = (size_t)flat1_xregion<NA>() + 2 * (size_t)(NA + 1) * WAVE + 3 * (size_t)(WAVE + 2) + (has_hv ? (size_t)WAVE * 6 : 0) +
+  const size_t n = (size_t)flat1_xregion<NA>() + (size_t)slot_bufs * (NA + 1) * WAVE + 3 * (size_t)(WAVE + 2) + (has_hv ? (size_t)WAVE * 6 : 0) +
                    (size_t)nc * FCD + FISC + 36;
   return (n * sizeof(double) + 15) & ~(size_t)15;
 }
@@ -1113,8 +1113,13 @@ template <int NA, bool SLICED = false, int HM = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
         int nscan, int njmp, int* ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
-        int ndec, double href_s, int has_hv, int ring_mask, int quantum)
+        int ndec, double href_s, int has_hv_bits, int ring_mask, int quantum)
 {
+  // has_hv_bits: bit 0 = the reference target is not zero (H_ref v_ref rows in LDS), bit 1 = ONE decade slot in LDS instead of two
+  // (a flip of mu back to the previous decade then reloads it, ~1.4 KB from the L2; the 5.6 KB it frees are worth two more
+  // wavefronts per CU with four task constraints: whole body 23.6 -> see DESIGN)
+  const int has_hv = has_hv_bits & 1;
+  const bool one_buf = (has_hv_bits & 2) != 0;
   using T = double;
   constexpr int G = WAVE, cs = FCD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1124,7 +1129,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const int j = lane;  // lane <-> device joint j + 1
   T* const xb = reinterpret_cast<T*>(smem_raw);          // load-time rows | path rows [65][6] | W tau products [NA][64]
   T* const wl = xb + flat1_xregion<NA>();                // [2][NA + 1][64]
-  T* const nbuf = wl + 2 * (NA + 1) * G;                 // [66]
+  T* const nbuf = wl + (one_buf ? 1 : 2) * (NA + 1) * G; // [66]
   T* const pbuf = nbuf + G + 2;                          // [66]
   T* const rbuf = pbuf + G + 2;                          // [66]
   T* const shv = rbuf + G + 2;                           // [64][6] (if H_ref v_ref != 0)
@@ -1174,7 +1179,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     for (int k = 0; k < NA; ++k) anc4[k >> 2] |= (unsigned int)((k < FLAT_MAXA && F.anc[k] >= 0) ? F.anc[k] : WAVE) << (8 * (k & 3));
   }
   if (lane < 2) { nbuf[G + lane] = T(0); pbuf[G + lane] = T(0); }
-  for (int e = lane; e < 2 * (NA + 1) * G; e += WAVE) wl[e] = T(0);
+  for (int e = lane; e < (one_buf ? 1 : 2) * (NA + 1) * G; e += WAVE) wl[e] = T(0);
 
   bool has_inst = false, isj = false, done = true, any_iter = false;
   int lidx = 0;
@@ -1493,7 +1498,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     }
     bool exit_now = done || (int)my_iters >= P.max_launch_iters;
     if (!exit_now && kexp != kslot) {
-      if (kexp == kslot_o) {
+      if (kexp == kslot_o && !one_buf) {
         { const int tk = kslot; kslot = kslot_o; kslot_o = tk; }
         wsel ^= 1;
         ++n_slot_hits;
@@ -1503,8 +1508,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
           exit_now = true;
           if (lane == 0) atomicAdd(&Bf.counters[2], 1u);
         } else {
-          kslot_o = kslot;
-          wsel ^= 1;
+          if (!one_buf) { kslot_o = kslot; wsel ^= 1; }
           T* wdst = wl + (size_t)wsel * (NA + 1) * G;
           T in[NA + 1];
 #pragma unroll

@@ -63,6 +63,7 @@ struct Tuning {
   int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's round-robin time slice in iterations (0 = run to completion; default -1:
                                 // 160 for launches of 12..96 instances per resident wavefront, where the stragglers' tail is worth it)
   bool flat_zero_state = true;  // LOIKB_FLAT_ZERO_STATE=0: k_flat2 / k_flat1 fetch vis, fis, g, w, z of every instance even straight after a cold reset
+  int flat_one_slot = 1;        // LOIKB_FLAT_ONE_SLOT=0: k_flat1 always keeps two decade slots in LDS
   bool flat_order = true;       // LOIKB_FLAT_ORDER=0: the flat engine takes its instances in arrival order even when the handle's previous
                                 // solve left an order (longest first, k_order_*: loik_lean.hpp)
   int tail_waves = TAIL_WAVES;  // LOIKB_TAIL_WAVES    wavefronts per k_tail workgroup
@@ -92,6 +93,7 @@ struct Tuning {
     if (const char* e = getenv("LOIKB_FLAT_SLICE")) flat_slice = std::max(-1, atoi(e));
     if (const char* e = getenv("LOIKB_FLAT_ORDER")) flat_order = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_ZERO_STATE")) flat_zero_state = atoi(e) != 0;
+    if (const char* e = getenv("LOIKB_FLAT_ONE_SLOT")) flat_one_slot = atoi(e);
     geti("LOIKB_TAIL_WAVES", tail_waves); tail_waves = std::max(1, std::min(TAIL_WAVES, tail_waves));
     geti("LOIKB_LEAN_DECADES", lean_decades); lean_decades = std::max(1, std::min(16, lean_decades));
     geti("LOIKB_LEAN_KLO", lean_klo);
@@ -1686,7 +1688,10 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           else LOIKB_LAUNCH_FLAT2(2);
 #undef LOIKB_LAUNCH_FLAT2
         } else if (one) {
-          const size_t lds1 = small_na ? flat1_lds_bytes<FLAT_NA_SMALL>(S->nc, has_hv != 0) : flat1_lds_bytes<FLAT_MAXA>(S->nc, has_hv != 0);
+          // one decade slot in LDS instead of two when that buys wavefronts per CU (whole body, four task constraints: 6 -> 8)
+          auto lds_of = [&](int bufs) { return small_na ? flat1_lds_bytes<FLAT_NA_SMALL>(S->nc, has_hv != 0, bufs) : flat1_lds_bytes<FLAT_MAXA>(S->nc, has_hv != 0, bufs); };
+          const int one_buf = (S->tune.flat_one_slot != 0) && std::min<size_t>(8, (160 * 1024) / lds_of(1)) > std::min<size_t>(8, (160 * 1024) / lds_of(2));
+          const size_t lds1 = lds_of(one_buf ? 1 : 2);
           int per_cu1 = (int)std::min<size_t>(8, (160 * 1024) / lds1);
           if (S->tune.lean_wg_per_cu > 0) per_cu1 = std::min(per_cu1, S->tune.lean_wg_per_cu);
           grid = dim3((unsigned)std::min(n, per_cu1 * (int)(cu_sh + 0.5)));
@@ -1699,7 +1704,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
   hipLaunchKernelGGL((k_flat1<NAV, ##__VA_ARGS__>), grid, dim3(WAVE), lds1, C->stream,                                          \
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
                      (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
-                     (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv, C->ring_cap - 1, quantum)
+                     (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv | (one_buf ? 2 : 0), C->ring_cap - 1, quantum)
           const int hm = S->per_link ? 3 : href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
           if (hm == 3) {
             if (quantum > 0) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, true, 3); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, true, 3); }
