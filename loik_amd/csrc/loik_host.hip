@@ -1507,7 +1507,8 @@ void plan_engines(loikb_solver_impl* S)
     // (the builds with one instance per wavefront have their own LDS layouts: what counts is the kernel that would run)
     if (flat_takes_diagonal(S)) {
       const size_t pw = S->flat.G == F2G ? flat2_lds_bytes<FLAT_NA_SMALL>(S->nc, true)
-                        : S->flat.nanc <= FLAT_NA_SMALL ? flat1_lds_bytes<FLAT_NA_SMALL>(S->nc, true) : flat1_lds_bytes<FLAT_MAXA>(S->nc, true);
+                        : S->flat.nanc <= FLAT_NA_SMALL ? flat1_lds_bytes<FLAT_NA_SMALL>(S->nc, true, S->tune.flat_one_slot ? 1 : 2)
+                                                        : flat1_lds_bytes<FLAT_MAXA>(S->nc, true, S->tune.flat_one_slot ? 1 : 2);
       pl.flat_waves_cu = std::max(pl.flat_waves_cu, (int)std::min<size_t>(8, (160 * 1024) / pw));
     }
   }
