@@ -63,6 +63,7 @@ struct Tuning {
   int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's round-robin time slice in iterations (0 = run to completion; default -1:
                                 // 160 for launches of 12..96 instances per resident wavefront, where the stragglers' tail is worth it)
   bool flat_zero_state = true;  // LOIKB_FLAT_ZERO_STATE=0: k_flat2 / k_flat1 fetch vis, fis, g, w, z of every instance even straight after a cold reset
+  int flat_order_holdoff = 4;   // LOIKB_FLAT_ORDER_HOLDOFF=n: solves in arrival order after an ordered launch that was not shorter (0: never hold off)
   int flat_one_slot = 1;        // LOIKB_FLAT_ONE_SLOT=0: k_flat1 always keeps two decade slots in LDS
   bool flat_order = true;       // LOIKB_FLAT_ORDER=0: the flat engine takes its instances in arrival order even when the handle's previous
                                 // solve left an order (longest first, k_order_*: loik_lean.hpp)
@@ -94,6 +95,7 @@ struct Tuning {
     if (const char* e = getenv("LOIKB_FLAT_ORDER")) flat_order = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_ZERO_STATE")) flat_zero_state = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_ONE_SLOT")) flat_one_slot = atoi(e);
+    if (const char* e = getenv("LOIKB_FLAT_ORDER_HOLDOFF")) flat_order_holdoff = std::max(0, atoi(e));
     geti("LOIKB_TAIL_WAVES", tail_waves); tail_waves = std::max(1, std::min(TAIL_WAVES, tail_waves));
     geti("LOIKB_LEAN_DECADES", lean_decades); lean_decades = std::max(1, std::min(16, lean_decades));
     geti("LOIKB_LEAN_KLO", lean_klo);
@@ -1786,7 +1788,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         const double flat_ms = (double)ms - (double)hms;
         if (C->arrival_n != n_cur) { C->arrival_n = n_cur; C->arrival_ms = 0.0; }
         if (!ordered) C->arrival_ms = flat_ms;
-        else if (C->arrival_ms > 0.0 && flat_ms > 0.985 * C->arrival_ms) C->order_holdoff = 4;
+        else if (C->arrival_ms > 0.0 && flat_ms > 0.985 * C->arrival_ms) C->order_holdoff = S->tune.flat_order_holdoff;
       }
       if (trace)
         fprintf(stderr, "[loikb] flat engine: %6d instances on %u workgroups, done at %8.3f ms (slots %6.3f ms)  "

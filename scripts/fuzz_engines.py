@@ -34,10 +34,10 @@ ENGINES = {
     "flat_sliced": ({"LOIKB_FLAT_SLICE": "7", "LOIKB_LEAN_WG_PER_CU": "1"}, {}),
     "flat_one_lane": ({"LOIKB_FLAT_SPLIT": "0"}, {}),   # k_flat (one joint per lane) where k_flat2 / k_flat1 would run
     # the same solve a second time on the handle: longest-first order from the first one, no fetch of the zero state (compared: the second)
-    "flat_ordered": ({}, {}),
+    "flat_ordered": ({"LOIKB_FLAT_ORDER_HOLDOFF": "0"}, {}),
 }
 ENV_KEYS = ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE",
-            "LOIKB_LEAN_WG_PER_CU")
+            "LOIKB_LEAN_WG_PER_CU", "LOIKB_FLAT_ORDER_HOLDOFF")
 
 
 def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):

@@ -156,6 +156,7 @@ def test_longest_first_order_changes_nothing_but_the_schedule(robot, monkeypatch
     for v in ("LOIKB_FLAT_ORDER", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_WG_PER_CU"):
         monkeypatch.delenv(v, raising=False)
     monkeypatch.setenv("LOIKB_LEAN_WG_PER_CU", "1")     # (few resident wavefronts: the queue matters at a test-sized batch)
+    monkeypatch.setenv("LOIKB_FLAT_ORDER_HOLDOFF", "0")  # (no fall-back to arrival order on a timing comparison: the test wants the ordered launches)
     B = 6000
     wl = workloads.talos_c3(B, seed=5) if robot == "talos32" else workloads.talos_wholebody(B, seed=5)
     wl2 = workloads.talos_c3(B, seed=6) if robot == "talos32" else workloads.talos_wholebody(B, seed=6)
