@@ -53,6 +53,7 @@ struct Model {
   // comp_first[i] + comp_count[i] - 1 of comp_jtype / comp_axis / comp_placement (include/loik_amd_models.h)
   std::vector<int> comp_first, comp_count, comp_jtype;
   std::vector<double> comp_axis, comp_placement;
+  std::vector<double> comp_pitch;  // [n_sub] the same for helical sub-joints of composites (empty: none)
   std::vector<double> pitch;  // [njoints] JointModelHelical*::m_pitch (LOIKB_J_HX .. HU); empty when the model has no helical joint
 
   static Model Builtin(const std::string& name)
@@ -87,6 +88,7 @@ struct Model {
       d.comp_axis = comp_axis.data(); d.comp_placement = comp_placement.data();
     }
     if (!pitch.empty()) d.pitch = pitch.data();
+    if (!comp_pitch.empty()) d.comp_pitch = comp_pitch.data();
     return d;
   }
 };

@@ -94,7 +94,7 @@ template <class PinocchioModel, class AxisOf, class SubJointsOf, class PitchOf>
 Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joints_of, PitchOf pitch_of)
 {
   Model o;
-  bool any_helical = false;
+  bool any_helical = false, any_helical_sub = false;
   o.njoints = static_cast<int>(m.njoints); o.nq = static_cast<int>(m.nq); o.nv = static_cast<int>(m.nv);
   bool any_composite = false;
   for (std::size_t i = 0; i < static_cast<std::size_t>(m.njoints); ++i) {
@@ -136,7 +136,7 @@ Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joint
       for (const auto& sub : sub_joints_of(m.joints[i])) {
         const std::string sn = sub.first.shortname();
         const int st = joint_type_of(sn);
-        if (st == LOIKB_J_NONE || st == LOIKB_J_COMPOSITE || (st >= LOIKB_J_HX && st <= LOIKB_J_HU))
+        if (st == LOIKB_J_NONE || st == LOIKB_J_COMPOSITE)
           throw std::runtime_error("loik_amd: sub-joint '" + sn + "' of the composite joint '" + m.names[i] + "' is not supported");
         if (st == LOIKB_J_UNIVERSAL_AS_COMPOSITE) {
           std::vector<double> P;
@@ -145,13 +145,15 @@ Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joint
           continue;
         }
         double sa[3] = {0.0, 0.0, 0.0};
-        if (st == LOIKB_J_RU || st == LOIKB_J_PU || st == LOIKB_J_RUBU) {
+        if (st == LOIKB_J_RU || st == LOIKB_J_PU || st == LOIKB_J_RUBU || st == LOIKB_J_HU) {
           const auto a = axis_of(sub.first, sn);
           for (int k = 0; k < 3; ++k) sa[k] = a[k];
         }
         o.comp_jtype.push_back(st);
         o.comp_axis.insert(o.comp_axis.end(), {sa[0], sa[1], sa[2]});
         detail::push_placement(o.comp_placement, sub.second);
+        o.comp_pitch.resize(o.comp_jtype.size(), 0.0);
+        if (st >= LOIKB_J_HX && st <= LOIKB_J_HU) { o.comp_pitch.back() = static_cast<double>(pitch_of(sub.first, sn)); any_helical_sub = true; }
         ++count;
       }
     }
@@ -163,6 +165,7 @@ Model to_loik_amd(const PinocchioModel& m, AxisOf axis_of, SubJointsOf sub_joint
   }
   if (!any_composite) { o.comp_first.clear(); o.comp_count.clear(); }
   if (!any_helical) o.pitch.clear();
+  if (any_helical_sub) o.comp_pitch.resize(o.comp_jtype.size(), 0.0); else o.comp_pitch.clear();
   return o;
 }
 

@@ -58,7 +58,7 @@ enum {
   LOIKB_J_HX = 19,         /* JointModelHelicalX / Y / Z (JointModelHX ...) and JointModelHelicalUnaligned: nq 1, nv 1; a rotation by q  */
   LOIKB_J_HY = 20,         /* about the axis together with a translation of pitch * q along it: M(q) = (Rot(axis, q), pitch q axis),   */
   LOIKB_J_HZ = 21,         /* S = [pitch axis; axis].  The pitch of joint i is loikb_model_desc.pitch[i]; HU takes its axis from `axis`. */
-  LOIKB_J_HU = 22          /* (Not as a sub-joint of a composite.)                                                                   */
+  LOIKB_J_HU = 22          /* (As a sub-joint of a composite: comp_jtype / comp_axis / comp_pitch.)                                  */
 };
 
 typedef struct loikb_model_desc {
@@ -81,6 +81,7 @@ typedef struct loikb_model_desc {
   const double *comp_axis;      /* [n_sub][3]  */
   const double *comp_placement; /* [n_sub][12] */
   const double *pitch;          /* [njoints] JointModelHelical*::m_pitch (read for LOIKB_J_HX .. HU only); NULL when the model has none */
+  const double *comp_pitch;     /* [n_sub]   the same for helical SUB-joints of composites; NULL when there is none                    */
 } loikb_model_desc;
 
 /*

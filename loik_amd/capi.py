@@ -27,7 +27,7 @@ class ModelDesc(C.Structure):
     _fields_ = [("njoints", C.c_int), ("nq", C.c_int), ("nv", C.c_int), ("parents", _ip), ("jtype", _ip),
                 ("axis", _dp), ("idx_q", _ip), ("idx_v", _ip), ("placement", _dp),
                 ("comp_first", _ip), ("comp_count", _ip), ("comp_jtype", _ip), ("comp_axis", _dp), ("comp_placement", _dp),
-                ("pitch", _dp)]
+                ("pitch", _dp), ("comp_pitch", _dp)]
 
 
 class Options(C.Structure):
@@ -52,7 +52,7 @@ class Stats(C.Structure):
                 ("flat_split_launches", C.c_int), ("flat_ordered", C.c_int)]
 
 
-ABI_VERSION = 304   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
+ABI_VERSION = 305   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
 
 # enums of loik_amd.h
 F64, F32 = 0, 1
@@ -223,14 +223,17 @@ class Model:
         # JointModelHelical*: pitch [njoints] (translation along the axis per radian)
         self.pitch = None if pitch is None else np.ascontiguousarray(pitch, dtype=np.float64).reshape(self.njoints)
         # JointModelComposite: composite[i] = [(sub-joint type, axis [3], placement [12] relative to the previous sub-joint), ...]
-        self.composite = {int(i): [(int(t), np.asarray(a, dtype=np.float64).reshape(3), np.asarray(P, dtype=np.float64).reshape(12))
-                                   for t, a, P in subs] for i, subs in (composite or {}).items()}
+        # (a helical sub-joint: a 4-tuple, the pitch last)
+        self.composite = {int(i): [(int(e[0]), np.asarray(e[1], dtype=np.float64).reshape(3), np.asarray(e[2], dtype=np.float64).reshape(12))
+                                   for e in subs] for i, subs in (composite or {}).items()}
+        sub_pitch = {int(i): [float(e[3]) if len(e) > 3 else 0.0 for e in subs] for i, subs in (composite or {}).items()}
         self.comp_first = np.zeros(self.njoints, dtype=np.int32); self.comp_count = np.zeros(self.njoints, dtype=np.int32)
-        ct, ca, cp = [], [], []
+        ct, ca, cp, cpi = [], [], [], []
         for i in sorted(self.composite):
             self.comp_first[i] = len(ct); self.comp_count[i] = len(self.composite[i])
-            for t, a, P in self.composite[i]:
-                ct.append(t); ca.append(a); cp.append(P)
+            for (t, a, P), ph in zip(self.composite[i], sub_pitch[i]):
+                ct.append(t); ca.append(a); cp.append(P); cpi.append(ph)
+        self.comp_pitch = np.ascontiguousarray(cpi if cpi else [0.0], dtype=np.float64)
         self.comp_jtype = np.ascontiguousarray(ct if ct else [0], dtype=np.int32)
         self.comp_axis = np.ascontiguousarray(ca if ca else [[0, 0, 0]], dtype=np.float64).reshape(-1, 3)
         self.comp_placement = np.ascontiguousarray(cp if cp else [[0] * 12], dtype=np.float64).reshape(-1, 12)
@@ -264,7 +267,7 @@ class Model:
                          self.placement.ctypes.data_as(_dp), self.comp_first.ctypes.data_as(_ip),
                          self.comp_count.ctypes.data_as(_ip), self.comp_jtype.ctypes.data_as(_ip),
                          self.comp_axis.ctypes.data_as(_dp), self.comp_placement.ctypes.data_as(_dp),
-                         None if self.pitch is None else self.pitch.ctypes.data_as(_dp))
+                         None if self.pitch is None else self.pitch.ctypes.data_as(_dp), self.comp_pitch.ctypes.data_as(_dp))
 
     def getJointId(self, name):
         return self.names.index(name)

@@ -511,7 +511,7 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
                        "of its two revolute joints; not: mimic)";
         return LOIKB_ERR_MODEL;
       }
-      if (jt >= LOIKB_J_HX && !m->pitch) { g_last_error = "model: a helical joint needs loikb_model_desc.pitch"; return LOIKB_ERR_MODEL; }
+      if (jt >= LOIKB_J_HX && jt <= LOIKB_J_HU && !m->pitch) { g_last_error = "model: a helical joint needs loikb_model_desc.pitch"; return LOIKB_ERR_MODEL; }
       if (m->idx_q[i] != iq || m->idx_v[i] != iv) {
         g_last_error = "model: idx_q/idx_v must be cumulative in joint order (Pinocchio's layout)";
         return LOIKB_ERR_MODEL;
@@ -525,10 +525,11 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
         int cnv = 0;
         for (int k = 0; k < m->comp_count[i]; ++k) {
           const int st = m->comp_jtype[m->comp_first[i] + k];
-          if (st < LOIKB_J_RX || st > LOIKB_J_RUBU || st == LOIKB_J_COMPOSITE) {
-            g_last_error = "model: a sub-joint of a composite joint must be one of the supported joint types other than a composite or a helical joint";
+          if (st < LOIKB_J_RX || st > LOIKB_J_HU || st == LOIKB_J_COMPOSITE) {
+            g_last_error = "model: a sub-joint of a composite joint must be one of the supported joint types other than a composite";
             return LOIKB_ERR_MODEL;
           }
+          if (st >= LOIKB_J_HX && !m->comp_pitch) { g_last_error = "model: a helical sub-joint needs loikb_model_desc.comp_pitch"; return LOIKB_ERR_MODEL; }
           iq += jt_nq(st); iv += jt_nv(st); cnv += jt_nv(st);
         }
         if (cnv > 6) { g_last_error = "model: a composite joint has at most 6 degrees of freedom here"; return LOIKB_ERR_MODEL; }
@@ -603,7 +604,7 @@ int build_schedule(loikb_solver_impl* S, const loikb_model_desc* m)
         } else if (jt >= LOIKB_J_HX && jt <= LOIKB_J_HU) {  // JointModelHelical*: the revolute joint about the axis + JF_HELICAL, pitch
           sub = jt == LOIKB_J_HU ? LOIKB_J_RU : LOIKB_J_RX + (jt - LOIKB_J_HX);
           flags |= JF_HELICAL;
-          d.pitch = m->pitch[i];
+          d.pitch = ncomp ? m->comp_pitch[ce] : m->pitch[i];
         } else if (n > 1) {
           // chain joint k: prismatic along / revolute about axis (k mod 3) of the joint frame
           const bool angular = jt == LOIKB_J_SPHERICAL || (jt == LOIKB_J_FREEFLYER && k >= 3);

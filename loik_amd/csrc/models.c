@@ -196,7 +196,7 @@ int loikb_builtin_model(const char *name, loikb_model_desc *out, const double **
   out->idx_q = t->idx_q;
   out->idx_v = t->idx_v;
   out->placement = t->placement;
-  out->comp_first = 0; out->comp_count = 0; out->comp_jtype = 0; out->comp_axis = 0; out->comp_placement = 0; out->pitch = 0;
+  out->comp_first = 0; out->comp_count = 0; out->comp_jtype = 0; out->comp_axis = 0; out->comp_placement = 0; out->pitch = 0; out->comp_pitch = 0;
   if (q_lo) *q_lo = t->q_lo;
   if (q_hi) *q_hi = t->q_hi;
   return 0;

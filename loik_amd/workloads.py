@@ -56,12 +56,15 @@ class _Chain:
 
     def __init__(self, model):
         parents, jtype, axis, placement, idx_q, idx_v = [0], [0], [np.zeros(3)], [np.asarray(model.placement[0])], [0], [0]
+        pitch = [0.0]   # (helical joints and helical sub-joints)
+        mp = getattr(model, "pitch", None)
         self.link_of = [0]
         for i in range(1, model.njoints):
             par = self.link_of[int(model.parents[i])]
             if int(model.jtype[i]) != J_COMPOSITE:
                 parents.append(par); jtype.append(int(model.jtype[i])); axis.append(np.asarray(model.axis[i]))
                 placement.append(np.asarray(model.placement[i])); idx_q.append(int(model.idx_q[i])); idx_v.append(int(model.idx_v[i]))
+                pitch.append(0.0 if mp is None else float(mp[i]))
             else:
                 iq, iv = int(model.idx_q[i]), int(model.idx_v[i])
                 Pj = np.asarray(model.placement[i]); Rj, tj = Pj[:9].reshape(3, 3), Pj[9:]
@@ -72,12 +75,14 @@ class _Chain:
                     parents.append(par if k == 0 else len(parents) - 1)
                     jtype.append(int(st)); axis.append(np.asarray(a, dtype=float)); placement.append(P)
                     idx_q.append(iq); idx_v.append(iv)
+                    pitch.append(float(model.comp_pitch[int(model.comp_first[i]) + k]))
                     iq += _NQ.get(int(st), 1)
                     iv += _NV.get(int(st), 1)
             self.link_of.append(len(parents) - 1)
         self.njoints = len(parents)
         self.parents, self.jtype = np.array(parents), np.array(jtype)
         self.axis, self.placement = np.array(axis), np.array(placement)
+        self.pitch = np.array(pitch)
         self.idx_q, self.idx_v = np.array(idx_q), np.array(idx_v)
         self.composite = None
 

@@ -434,7 +434,7 @@ struct ref_solver {
   /* --- IkProblemFormulationOptimized members (ik-id-description-optimized.hpp:342-362) --- */
   int eq_c_dim;
   double *H_refs, *v_refs, *Hv;      /* [nj][36], [nj][6], [nj][6] */
-  int *comp_first, *comp_count, *comp_jtype; double *comp_axis, *comp_placement; int n_sub; /* JointModelComposite */
+  int *comp_first, *comp_count, *comp_jtype; double *comp_axis, *comp_placement, *comp_pitch; int n_sub; /* JointModelComposite */
   int *active_ids;                   /* [nc] */
   int nc_cap;                        /* allocated constraint slots (>= nc = nc_eq_) */
   double *Ais, *bis, *AtA, *Atb;     /* [nc][36], [nc][6], [nc][36], [nc][6] */
@@ -619,10 +619,11 @@ int ref_create(const ref_model *m, const ref_params *p, ref_solver **out)
         if (m->comp_first[i] + m->comp_count[i] > s->n_sub) s->n_sub = m->comp_first[i] + m->comp_count[i];
       }
   s->comp_jtype = (int *)calloc(s->n_sub ? s->n_sub : 1, sizeof(int));
-  s->comp_axis = dalloc(3 * (size_t)s->n_sub); s->comp_placement = dalloc(12 * (size_t)s->n_sub);
+  s->comp_axis = dalloc(3 * (size_t)s->n_sub); s->comp_placement = dalloc(12 * (size_t)s->n_sub); s->comp_pitch = dalloc((size_t)s->n_sub);
   if (s->n_sub) {
     memcpy(s->comp_jtype, m->comp_jtype, sizeof(int) * s->n_sub);
     memcpy(s->comp_axis, m->comp_axis, sizeof(double) * 3 * s->n_sub);
+    if (m->comp_pitch) memcpy(s->comp_pitch, m->comp_pitch, sizeof(double) * s->n_sub);
     memcpy(s->comp_placement, m->comp_placement, sizeof(double) * 12 * s->n_sub);
   }
   if (m->massless) memcpy(s->massless, m->massless, sizeof(int) * nj);
@@ -687,7 +688,7 @@ void ref_destroy(ref_solver *s)
   if (!s) return;
   free(s->parents); free(s->jtype); free(s->idx_q); free(s->idx_v); free(s->axis); free(s->pitch); free(s->placement);
   free(s->jnv); free(s->massless);
-  free(s->comp_first); free(s->comp_count); free(s->comp_jtype); free(s->comp_axis); free(s->comp_placement);
+  free(s->comp_first); free(s->comp_count); free(s->comp_jtype); free(s->comp_axis); free(s->comp_placement); free(s->comp_pitch);
   free(s->oMi); free(s->liMi); free(s->jS); free(s->jU); free(s->jUDinvM); free(s->jDinvM);
   free(s->jUDinv); free(s->jDinv);
   free(s->nu); free(s->nu_prev); free(s->vis); free(s->vis_prev); free(s->His); free(s->His_aba);
@@ -952,6 +953,11 @@ static void composite_calc(const ref_solver *s, int idx, const double *qs, doubl
     const int st = s->comp_jtype[first + k];
     double Mk[12], PM[12];
     joint_calc(st, s->comp_axis + 3 * (first + k), qs + oq, Mk);
+    if (st >= REF_J_HX && st <= REF_J_HU) {   /* helical sub-joint: translation pitch q axis */
+      double Sh[36];
+      joint_S(st, s->comp_axis + 3 * (first + k), NULL, Sh);
+      for (int c = 0; c < 3; ++c) Mk[9 + c] = s->comp_pitch[first + k] * qs[oq] * Sh[3 + c];
+    }
     se3_mul(s->comp_placement + 12 * (first + k), Mk, PM);
     se3_mul(T[k], PM, T[k + 1]);
     memcpy(after[k], T[k + 1], sizeof(double) * 12);   /* the frame in which S_k is expressed (after sub-joint k moved) */
@@ -965,6 +971,8 @@ static void composite_calc(const ref_solver *s, int idx, const double *qs, doubl
     const int st = s->comp_jtype[first + k];
     double Sk[36], inv[12], kMlast[12];
     joint_S(st, s->comp_axis + 3 * (first + k), qs + oq, Sk);   /* nv_k columns (q-dependent for a ZYX sub-joint) */
+    if (st >= REF_J_HX && st <= REF_J_HU)
+      for (int c = 0; c < 3; ++c) Sk[c] = s->comp_pitch[first + k] * Sk[3 + c];   /* S = [pitch a; a] */
     se3_inv(after[k], inv);
     se3_mul(inv, T[n], kMlast);                       /* placement of the last frame seen from sub-joint k's */
     for (int c = 0; c < joint_nv(st) && col < 6; ++c, ++col)

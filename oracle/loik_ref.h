@@ -91,6 +91,7 @@ typedef struct ref_model {
   const double *comp_axis;              /* [n_sub][3]           */
   const double *comp_placement;         /* [n_sub][12]          */
   const double *pitch;                  /* [nj] or NULL: JointModelHelical*::m_pitch */
+  const double *comp_pitch;             /* [n_sub] or NULL: the same for helical sub-joints of composites */
 } ref_model;
 
 typedef struct ref_params {

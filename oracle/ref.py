@@ -19,7 +19,7 @@ class RefModel(C.Structure):
                 ("parents", _c_int_p), ("jtype", _c_int_p), ("axis", _c_double_p),
                 ("idx_q", _c_int_p), ("idx_v", _c_int_p), ("placement", _c_double_p), ("massless", _c_int_p),
                 ("comp_first", _c_int_p), ("comp_count", _c_int_p), ("comp_jtype", _c_int_p), ("comp_axis", _c_double_p),
-                ("comp_placement", _c_double_p), ("pitch", _c_double_p)]
+                ("comp_placement", _c_double_p), ("pitch", _c_double_p), ("comp_pitch", _c_double_p)]
 
 
 class RefParams(C.Structure):
@@ -142,12 +142,15 @@ class _ModelHolder:
             cargs = (_ip(self.comp[0]), _ip(self.comp[1]), _ip(self.comp[2]), _dp(self.comp[3]), _dp(self.comp[4]))
         else:
             cargs = (None, None, None, None, None)
+        cpitch = getattr(model, "comp_pitch", None) if comp else None
+        self.comp_pitch = None if cpitch is None else _f64(cpitch)
         pitch = getattr(model, "pitch", None)
         self.pitch = None if pitch is None else _f64(pitch)
         self.struct = RefModel(int(model.njoints), int(model.nq), int(model.nv), _ip(self.parents),
                                _ip(self.jtype), _dp(self.axis), _ip(self.idx_q), _ip(self.idx_v),
                                _dp(self.placement), None if self.massless is None else _ip(self.massless), *cargs,
-                               None if self.pitch is None else _dp(self.pitch))
+                               None if self.pitch is None else _dp(self.pitch),
+                               None if self.comp_pitch is None else _dp(self.comp_pitch))
 
 
 def make_params(max_iter=200, tol_abs=1e-3, tol_rel=1e-3, tol_primal_inf=1e-2, tol_dual_inf=1e-2, rho=1e-5,

@@ -118,12 +118,14 @@ static void round_trip(const Model& m)
         shape::JointModel sj;
         sj.sn = short_name(m.comp_jtype[e]);
         for (int c = 0; c < 3; ++c) sj.ax[c] = m.comp_axis[3 * e + c];
+        if (!m.comp_pitch.empty()) sj.m_pitch = m.comp_pitch[e];
         p.joints[i].subs.emplace_back(sj, se3_of(&m.comp_placement[12 * e]));
       }
   const Model o = to_loik_amd(p, [](const shape::JointModel& j, const std::string&) { return j.ax; },
                               [](const shape::JointModel& j) { return j.subs; },
                               [](const shape::JointModel& j, const std::string&) { return j.m_pitch; });
   CHECK(o.pitch == m.pitch);
+  CHECK(o.comp_pitch == m.comp_pitch);
   CHECK(o.comp_first == m.comp_first && o.comp_count == m.comp_count && o.comp_jtype == m.comp_jtype);
   CHECK(o.comp_axis == m.comp_axis && o.comp_placement == m.comp_placement);
   CHECK(o.njoints == m.njoints && o.nq == m.nq && o.nv == m.nv);
@@ -145,7 +147,7 @@ int main()
     const int types[] = {LOIKB_J_NONE, LOIKB_J_FREEFLYER, LOIKB_J_RU, LOIKB_J_PU, LOIKB_J_SPHERICAL, LOIKB_J_TRANSLATION,
                          LOIKB_J_SPHERICAL_ZYX, LOIKB_J_PLANAR, LOIKB_J_RUBY, LOIKB_J_PZ, LOIKB_J_RUBU, LOIKB_J_COMPOSITE,
                          LOIKB_J_HY, LOIKB_J_HU};   // (two helical joints: aligned and unaligned, with their pitch)
-    const int nqs[] = {0, 7, 1, 1, 4, 3, 3, 4, 2, 1, 2, 7, 1, 1}, nvs[] = {0, 6, 1, 1, 3, 3, 3, 3, 1, 1, 1, 5, 1, 1};
+    const int nqs[] = {0, 7, 1, 1, 4, 3, 3, 4, 2, 1, 2, 6, 1, 1}, nvs[] = {0, 6, 1, 1, 3, 3, 3, 3, 1, 1, 1, 5, 1, 1};
     m.njoints = 14;
     for (int i = 0; i < m.njoints; ++i) {
       m.parents.push_back(i ? (i - 1) / 2 : 0);
@@ -161,12 +163,13 @@ int main()
       const double P[12] = {c, -s, 0, s, c, 0, 0, 0, 1, 0.1 * i, -0.2, 0.05 * i};  // Rz(0.3 i): not symmetric -> order matters
       m.jointPlacements.insert(m.jointPlacements.end(), P, P + 12);
       m.names.push_back(i ? "joint_" + std::to_string(i) : "universe");
-      // joint 11: a composite of RU, RUBZ (nq 2), Spherical (nq 4, nv 3) with rotated internal placements
+      // joint 11: a composite of RU, HelicalUnaligned (with its pitch), Spherical (nq 4, nv 3) with rotated internal placements
       m.comp_first.push_back(i == 11 ? 0 : (i < 11 ? 0 : 3));
       m.comp_count.push_back(i == 11 ? 3 : 0);
     }
-    m.comp_jtype = {LOIKB_J_RU, LOIKB_J_RUBZ, LOIKB_J_SPHERICAL};
-    m.comp_axis = {0.6, 0.0, 0.8, 0, 0, 0, 0, 0, 0};
+    m.comp_jtype = {LOIKB_J_RU, LOIKB_J_HU, LOIKB_J_SPHERICAL};
+    m.comp_axis = {0.6, 0.0, 0.8, 0.0, 0.8, -0.6, 0, 0, 0};
+    m.comp_pitch = {0.0, 0.07, 0.0};
     for (int k = 0; k < 3; ++k) {
       const double c = std::cos(0.7 + k), s = std::sin(0.7 + k);
       const double P[12] = {1, 0, 0, 0, c, -s, 0, s, c, 0.01 * k, 0.2, -0.1};  // Rx
@@ -192,7 +195,7 @@ int main()
       shape::JointModel sp; sp.sn = "JointModelPZ";
       const double Psub[12] = {0, -1, 0, 1, 0, 0, 0, 0, 1, 0.3, 0.2, 0.1};
       u.joints[11].subs = {{sp, se3_of(Psub)}, {su, se3_of(Psub)}};   // nq 3, nv 3
-      u.nq += 3 - 7; u.nv += 3 - 5;
+      u.nq += 3 - 6; u.nv += 3 - 5;
       const Model o = to_loik_amd(u, [](const shape::JointModel& j, const std::string&) { return j.ax; },
                                   [](const shape::JointModel& j) { return j.subs; },
                                   [](const shape::JointModel& j, const std::string&) { return j.m_pitch; });

@@ -329,8 +329,11 @@ def composite_tree(seed, nb, which, kinds=None):
         types = kinds[n_] if kinds else [int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, J_RUBY, J_RUBU]))
                                          for _ in range(int(rng.integers(2, 5)))]
         for t in types:
-            a = _unit(rng) if t in (7, 8, J_RUBU) else np.zeros(3)
+            a = _unit(rng) if t in (7, 8, J_RUBU, 22) else np.zeros(3)
             P = np.concatenate([random_rotation(rng).ravel(), rng.uniform(-0.3, 0.3, size=3)])
-            subs.append((t, a, P))
+            if t in (19, 20, 21, 22):   # helical sub-joint: (type, axis, placement, pitch)
+                subs.append((t, a, P, float(rng.choice([-1.0, 1.0]) * rng.uniform(0.05, 0.3))))
+            else:
+                subs.append((t, a, P))
         comp[i] = subs
     return loik_amd.Model(m.parents, jt, m.axis, m.placement, composite=comp, name="composite_tree_%d_%d" % (seed, nb))

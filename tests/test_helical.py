@@ -142,6 +142,52 @@ def test_gpu_helical_joints(engine, nb, monkeypatch):
     s.close()
 
 
+HELICAL_SUBS = [[20, 4], [22, 10], [2, 19, 6]]   # (HY, PX) | (HU, spherical) | (RY, HX, PZ)
+
+
+def test_oracle_composite_with_helical_subjoints_equals_its_chain():
+    """a helical joint as a sub-joint of a JointModelComposite (comp_pitch): the oracle's composite (its S columns seen from the last
+    frame) against the same model written as the chain of its sub-joints with massless links"""
+    from helpers import composite_tree
+    from test_composite import chain_of
+    model = composite_tree(61, 9, [1, 4, 7], kinds=HELICAL_SUBS)
+    assert np.count_nonzero(model.comp_pitch) == 3
+    m1, link_of = chain_of(model)
+    m1.pitch = workloads._Chain(model).pitch
+    link = model.njoints - 1
+    wl = workloads.make_workload(model, 3, link, 8, bound=0.5, snap_prob=0.0, nu_scale=0.4)
+    prm = dict(FIXTURE, max_iter=60, tol_abs=0.0, tol_rel=0.0, tol_primal_inf=0.0)
+    for b in range(3):
+        t, c = ref.RefSolver(model, **prm), ref.RefSolver(m1, **prm)
+        t.Solve(*problem_args(wl, b))
+        c.Solve(wl["q"][b], wl["H_ref"], wl["v_ref"], np.array([link_of[link]], dtype=np.int32), wl["Ais"], wl["bis"][b], wl["lb"], wl["ub"])
+        for n in ("nu", "z", "w"):
+            assert_close(getattr(c, n), getattr(t, n), 1e-8, n)
+        assert_close(c.vis[link_of[1:]], t.vis[1:], 1e-8, "vis of the bodies")
+        assert_close(c.fis[link_of[1:]], t.fis[1:], 1e-7, "fis of the bodies")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["default", "solve_only"])
+def test_gpu_composite_with_helical_subjoints(engine):
+    from helpers import composite_tree
+    model = composite_tree(61, 12, [1, 4, 7], kinds=HELICAL_SUBS)
+    link = model.njoints - 1
+    B = 96
+    wl = workloads.make_workload(model, B, link, 6, bound=0.5, snap_prob=0.0, nu_scale=0.4)
+    prm = dict(FIXTURE, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
+    out = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"],
+                          nthreads=4, want_nu=True, **prm)
+    s = loik_amd.BatchedLoik(model, B, **prm, **ENGINE_KW[engine][1])
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.95, ztol=1e-6, off_ztol=1e-5, what="composite with helical sub-joints " + engine)
+    for b in range(0, B, 31):
+        r = ref.RefSolver(model, **prm)
+        r.Solve(*problem_args(wl, b))
+        assert_close(s.get("liMi")[b], r.liMi[1:], 1e-12, "liMi of the composite")
+    s.close()
+
+
 @pytest.mark.gpu
 def test_gpu_helical_pass_level_and_errors():
     model = helical_tree(5, 10, 3)
