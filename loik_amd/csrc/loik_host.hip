@@ -1839,6 +1839,14 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       // (default 0: run to completion in arrival order -- DESIGN.md, scheduling study)
       const int lean_quantum = S->tune.lean_slice;
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
+      // longest first, as in the flat engine: the order the handle's previous solve left, for a single whole-set launch that is not
+      // time-sliced (the decade slots are indexed by the instance: k_hslots and k_lean see the same list)
+      const bool lean_ordered = S->tune.flat_order && whole_set && list == C->d_slots && n == n_cur && C->order_n == n_cur &&
+                                C->order_holdoff == 0 && quanta.size() == 1 && lean_quantum == 0 && !(S->opt.flags & LOIKB_OPT_OWN_STREAM);
+      if (whole_set && C->order_holdoff > 0) --C->order_holdoff;
+      if (lean_ordered) HIPCHK(hipMemcpyAsync(C->d_slots, C->d_order, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, C->stream));
+      C->stats.flat_ordered += lean_ordered ? 1 : 0;
+      const int n_first_lean = n;
       float t_first = -1.f;
       unsigned int escaped = 0;
       bool slots_built = false, first_timed = false;
@@ -1885,9 +1893,24 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(C->ev_k1, C->stream));
         HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+        const bool lean_orders = S->tune.flat_order && whole_set && n_first_lean == n_cur && quanta.size() == 1 && lean_quantum == 0 &&
+                                 !(S->opt.flags & (LOIKB_OPT_OWN_STREAM | LOIKB_OPT_FIXED_ITERS));
+        if (lean_orders) {  // the order for the handle's next solve (k_order_*)
+          HIPCHK(hipMemsetAsync(C->d_order_bins, 0, sizeof(unsigned int) * 2 * ORDER_BINS, C->stream));
+          hipLaunchKernelGGL(k_order_count<T>, grid1(n_cur), dim3(256), 0, C->stream, A.tiles, S->L, n_cur, S->opt.max_iter, C->d_order_bins);
+          hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORDER_BINS), 0, C->stream, C->d_order_bins);
+          hipLaunchKernelGGL(k_order_scatter<T>, grid1(n_cur), dim3(256), 0, C->stream, A.tiles, S->L, n_cur, S->opt.max_iter, C->d_order_bins, C->d_order);
+          HIPCHK(hipGetLastError());
+          C->order_n = n_cur;
+        }
         HIPCHK(hipStreamSynchronize(C->stream));
         float ms = 0.f, t0 = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));  // since the start of the first round
+        if (lean_orders) {  // (held off like the flat engine's: compared with the handle's last launch in arrival order)
+          if (C->arrival_n != n_cur) { C->arrival_n = n_cur; C->arrival_ms = 0.0; }
+          if (!lean_ordered) C->arrival_ms = (double)ms;
+          else if (C->arrival_ms > 0.0 && (double)ms > 0.985 * C->arrival_ms) C->order_holdoff = S->tune.flat_order_holdoff;
+        }
         if (t_first < 0.f) { HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0)); t_first = t0; }
         iters += C->h_counters[1];
         escaped = C->h_counters[2];

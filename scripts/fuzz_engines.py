@@ -35,6 +35,7 @@ ENGINES = {
     "flat_one_lane": ({"LOIKB_FLAT_SPLIT": "0"}, {}),   # k_flat (one joint per lane) where k_flat2 / k_flat1 would run
     # the same solve a second time on the handle: longest-first order from the first one, no fetch of the zero state (compared: the second)
     "flat_ordered": ({"LOIKB_FLAT_ORDER_HOLDOFF": "0"}, {}),
+    "lean_ordered": ({"LOIKB_FLAT": "0", "LOIKB_FLAT_ORDER_HOLDOFF": "0"}, {}),   # the same with k_lean
 }
 ENV_KEYS = ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE",
             "LOIKB_LEAN_WG_PER_CU", "LOIKB_FLAT_ORDER_HOLDOFF")
@@ -124,7 +125,7 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
                 s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
                 s.UpdateReferences(*refs)
                 s.Solve()
-            if engine == "flat_ordered":
+            if engine in ("flat_ordered", "lean_ordered"):
                 first_ordered = s.stats()["flat_ordered"]
                 if refs is None:
                     s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])

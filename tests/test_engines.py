@@ -147,7 +147,7 @@ def test_lean_time_slicing_changes_nothing(talos, monkeypatch):
     a.close()
 
 
-@pytest.mark.parametrize("robot", ["talos32", "talos44"])
+@pytest.mark.parametrize("robot", ["talos32", "talos44", "talos32_lean"])
 def test_longest_first_order_changes_nothing_but_the_schedule(robot, monkeypatch):
     """the flat engine takes a handle's second and later solves longest first (counting sort of the previous solve's iteration
     counts, k_order_*): the schedule changes, no number does -- every member bit-identical to the first solve's (arrival order,
@@ -157,9 +157,12 @@ def test_longest_first_order_changes_nothing_but_the_schedule(robot, monkeypatch
         monkeypatch.delenv(v, raising=False)
     monkeypatch.setenv("LOIKB_LEAN_WG_PER_CU", "1")     # (few resident wavefronts: the queue matters at a test-sized batch)
     monkeypatch.setenv("LOIKB_FLAT_ORDER_HOLDOFF", "0")  # (no fall-back to arrival order on a timing comparison: the test wants the ordered launches)
+    lean = robot == "talos32_lean"     # (k_lean takes its list in the same order: LOIKB_FLAT=0)
+    if lean:
+        monkeypatch.setenv("LOIKB_FLAT", "0")
     B = 6000
-    wl = workloads.talos_c3(B, seed=5) if robot == "talos32" else workloads.talos_wholebody(B, seed=5)
-    wl2 = workloads.talos_c3(B, seed=6) if robot == "talos32" else workloads.talos_wholebody(B, seed=6)
+    wl = workloads.talos_wholebody(B, seed=5) if robot == "talos44" else workloads.talos_c3(B, seed=5)
+    wl2 = workloads.talos_wholebody(B, seed=6) if robot == "talos44" else workloads.talos_c3(B, seed=6)
     names = ["iter", "converged", "primal_infeasible", "mu", "z", "nu", "w", "vis", "fis", "g", "yis", "primal_residual", "dual_residual",
              "mu_updates"]
 
@@ -169,7 +172,7 @@ def test_longest_first_order_changes_nothing_but_the_schedule(robot, monkeypatch
         return {n: s.get(n) for n in names}, s.stats()
     s = loik_amd.BatchedLoik(wl["model"], B, **wl["params"])
     first, st1 = run(s, wl)
-    assert st1["flat_launches"] == 1 and st1["flat_ordered"] == 0, st1
+    assert st1["flat_launches"] == (0 if lean else 1) and st1["lean_launches"] == 1 and st1["flat_ordered"] == 0, st1
     s.Solve()
     st2 = s.stats()
     assert st2["flat_ordered"] == 1 and st2["lean_requeues"] == 0 and st2["tail_instances"] == B, st2
