@@ -1952,6 +1952,14 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     const dim3 grid((unsigned)std::min(wg_needed, cu_share));
     HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
     HIPCHK(hipEventRecord(C->ev_k0, C->stream));
+    // k_tail as the engine of a whole batch (OSQP rule, robots outside the on-chip engines' domain): longest first from the handle's
+    // previous solve, as in the flat and lean engines (its lane groups pull the list in order)
+    const bool tail_whole = whole_set && list == C->d_slots && n == n_cur && !(S->opt.flags & (LOIKB_OPT_OWN_STREAM | LOIKB_OPT_FIXED_ITERS)) &&
+                            S->tune.flat_order;
+    const bool tail_ordered = tail_whole && C->order_n == n_cur && C->order_holdoff == 0;
+    if (tail_whole && C->order_holdoff > 0) --C->order_holdoff;
+    if (tail_ordered) HIPCHK(hipMemcpyAsync(C->d_slots, C->d_order, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, C->stream));
+    C->stats.flat_ordered += tail_ordered ? 1 : 0;
     if (S->href_diag)
       hipLaunchKernelGGL((k_tail<T, true>), grid, dim3(WAVE * tw), lds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                          (const TailTopo*)S->d_topo, (const int*)S->d_child_list, S->maxdepth, S->maxchild,
@@ -1963,10 +1971,23 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(C->ev_k1, C->stream));
     HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+    if (tail_whole) {
+      HIPCHK(hipMemsetAsync(C->d_order_bins, 0, sizeof(unsigned int) * 2 * ORDER_BINS, C->stream));
+      hipLaunchKernelGGL(k_order_count<T>, grid1(n_cur), dim3(256), 0, C->stream, A.tiles, S->L, n_cur, S->opt.max_iter, C->d_order_bins);
+      hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORDER_BINS), 0, C->stream, C->d_order_bins);
+      hipLaunchKernelGGL(k_order_scatter<T>, grid1(n_cur), dim3(256), 0, C->stream, A.tiles, S->L, n_cur, S->opt.max_iter, C->d_order_bins, C->d_order);
+      HIPCHK(hipGetLastError());
+      C->order_n = n_cur;
+    }
     HIPCHK(hipStreamSynchronize(C->stream));
     float ms = 0.f, t0 = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));
     HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0));
+    if (tail_whole) {
+      if (C->arrival_n != n_cur) { C->arrival_n = n_cur; C->arrival_ms = 0.0; }
+      if (!tail_ordered) C->arrival_ms = (double)ms;
+      else if (C->arrival_ms > 0.0 && (double)ms > 0.985 * C->arrival_ms) C->order_holdoff = S->tune.flat_order_holdoff;
+    }
     C->tail_iv.emplace_back(t0, t0 + ms);
     total_ms += ms;
     iters += C->h_counters[1];
