@@ -459,8 +459,19 @@ def fp32_tradeoff_variant(args, device):
         wl = workloads.panda_c5(args.batch, tol=tol)
         m, prm = wl["model"], wl["params"]
         z64 = c64 = None
+        # fp32_fast: the streaming engines in fp32 (k_solve + k_tail: what a small robot's batches up to 32 768 instances run on; forced
+        # here with LOIKB_LEAN=0 -- since round 3 a plain fp32 handle of this size runs k_lean, i.e. the row fp32_accurate)
         for name, prec, flags in (("fp64", capi.F64, 0), ("fp32_fast", capi.F32, 0), ("fp32_accurate", capi.F32, capi.OPT_F32_ACCURATE)):
-            s = loik_amd.BatchedLoik(m, args.batch, device=device, precision=prec, flags=args.flags | flags, **prm)
+            old_env = os.environ.get("LOIKB_LEAN")
+            if name == "fp32_fast":
+                os.environ["LOIKB_LEAN"] = "0"
+            try:
+                s = loik_amd.BatchedLoik(m, args.batch, device=device, precision=prec, flags=args.flags | flags, **prm)
+            finally:
+                if old_env is None:
+                    os.environ.pop("LOIKB_LEAN", None)
+                else:
+                    os.environ["LOIKB_LEAN"] = old_env
             s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
             s.Solve()
             s.synchronize()

@@ -1498,7 +1498,10 @@ void plan_engines(loikb_solver_impl* S)
   // of iterations: for them k_solve + k_tail are faster in every case measured (Panda-7, B = 65536, fp64 / fp32: tol 1e-3
   // 0.75 / 0.61 ms against 1.18 / 1.14 ms in k_lean, tol 1e-4 0.89 / 0.81 against - / 1.33; the ten precomputed decades of H
   // are mostly never used by such short solves) -- scripts/r02/small_robot_plan_probe.py.
-  else if (S->nb <= 16 && !(S->f32 && (S->opt.flags & LOIKB_OPT_F32_ACCURATE)))
+  // (... up to the batch k_tail takes whole, 32 768 instances.  Above it the choice is k_solve + a hand-over to k_tail against k_lean
+  //  for the whole batch, and since k_lean takes a handle's later solves longest first it wins: Panda-7, B = 65 536, tol 1e-3 / 1e-4,
+  //  fp64 0.73 / 0.92 -> 0.60 / 0.66 ms, fp32 0.68 / 0.80 -> 0.52 / 0.55 ms; a handle's first solve 1.3 -> 1.5 ms)
+  else if (S->nb <= 16 && !(S->f32 && (S->opt.flags & LOIKB_OPT_F32_ACCURATE)) && S->B <= 32768)
     pl.why_not_lean = "a small robot (<= 16 joints): k_solve + k_tail are faster on its short solves";
   else if (pl.lean_waves_cu < 7) pl.why_not_lean = "constraint blocks leave too few wavefronts per CU in LDS";
   else pl.lean = true;
