@@ -34,6 +34,25 @@ namespace loikb {
 constexpr int F2G = 32;  // joints per instance (lane pairs)
 constexpr int F2W = 32;  // row stride of the [ancestor][joint] arrays (W rows, W tau products): lane (j, h) touches row 2 i + h
 
+// Constraint block of an instance in the LDS of k_flat2 / k_flat1 (doubles; every 6-vector starts at an even offset).  What the loop
+// needs of a task constraint (A, b) on joint c is its image at the world origin: AW = X*_{0<-c} A^T ([world component k][row q],
+// and transposed), because  A v_c = AW^T v^w_c  (the constrained link's velocity as the path sum leaves it, no frame change) and
+// X* (A^T y) = AW y.  A itself stays for the stored record's A^T y.
+enum : int { C2_LANE = 0, C2_B = 2, C2_Y = 8, C2_ATYW = 14 /* A^T y at the world origin: the next FwdPass1's */, C2_ATBW = 20,
+             C2_ATYF = 26 /* the constraint's force in this iteration's f */, C2_CW = 32, C2_DLT = 38 /* first-iteration corrections */,
+             C2_VC = 44 /* v^w of the constrained joint */, C2_ATY = 50 /* A^T y as the record brought it */, C2_AW = 56, C2_AWT = 92,
+             C2_A = 128, C2D = 164 };
+
+// v_max_f64 / v_min_f64 as the hardware does them.  __builtin_fmax on a value the compiler cannot prove quiet (anything that came
+// through a DPP / permlane move, an LDS read, a fabs) is preceded by a canonicalising v_max_f64 x, x, x in IEEE mode: 93 of the
+// 159 v_max_f64 of the round-3 loop.  The instruction itself already returns the other operand for a quiet NaN, which is fmax.
+__device__ __forceinline__ double hmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double hmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double hmaxa(double a, double b) { double r; asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }   // max(|a|, |b|)
+__device__ __forceinline__ double hmax_a(double a, double b) { double r; asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }    // max(a, |b|)
+__device__ __forceinline__ double hinf3(const double* x) { return hmax_a(hmaxa(x[0], x[1]), x[2]); }
+__device__ __forceinline__ double hinf6(const double* x) { return hmax(hinf3(x), hinf3(x + 3)); }
+
 // ---- cross-lane helpers (registers only) --------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK, int BANK_MASK, bool BOUND>
 __device__ __forceinline__ double dpp_f64(double old, double x)
@@ -91,7 +110,7 @@ __device__ __forceinline__ void wave_fold8(int lane, const double* in, double* o
 {
   const bool up = lane >= 32, b3 = lane & 8;
   const bool sm = SUMS && lane >= 48;  // columns 6, 7: the lanes of row 3
-  auto comb = [&](double a, double b, bool is_sum) { return is_sum ? a + b : tmax(a, b); };
+  auto comb = [&](double a, double b, bool is_sum) { return is_sum ? a + b : hmax(a, b); };
   double k4[4], k2[2], k1;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -120,6 +139,41 @@ __device__ __forceinline__ void wave_fold8(int lane, const double* in, double* o
   k1 = comb(k1, dpp_f64<0xB1, 0xF, 0xF, true>(0.0, k1), sm);   // quad_perm [1, 0, 3, 2]
 #pragma unroll
   for (int q = 0; q < 8; ++q) out[q] = uniform_of(k1, 32 * ((q >> 2) & 1) + 16 * ((q >> 1) & 1) + 8 * (q & 1));
+}
+
+// Four scalars reduced over the 64 lanes (column c by sum when bit c of SUMMASK is set, else by max), all four results uniform.
+// The same transpose-reduce with half the registers in flight: swap(in[q], in[q + 2]) between the halves of the wavefront, then
+// between the rows of a half -- row r of the wavefront now owns column r, folded over the four rows -- and four rotations inside
+// the row of 16 lanes.  The iteration's stopping logic needs four maxima in the main loop (primal, dual and the two sides of the
+// infeasibility certificate's first test) and the other four scalars only on the rare iterations that pass that test or run the
+// tail solve: 7 exchanges per iteration instead of 17.
+template <unsigned SUMMASK>
+__device__ __forceinline__ void wave_fold4(int lane, const double* in, double* out)
+{
+  const bool up = lane >= 32, odd = (lane & 16) != 0;
+  auto comb = [&](double a, double b, bool is_sum) { return is_sum ? a + b : hmax(a, b); };
+  double k2[2], k1;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const auto rl = __builtin_amdgcn_permlane32_swap(__double2loint(in[q]), __double2loint(in[q + 2]), false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(in[q]), __double2hiint(in[q + 2]), false, false);
+    const bool sm = ((SUMMASK >> q) & 1u) && ((SUMMASK >> (q + 2)) & 1u) ? true
+                    : ((SUMMASK >> q) & 1u) ? !up : ((SUMMASK >> (q + 2)) & 1u) ? up : false;
+    k2[q] = comb(__hiloint2double(rh[0], rl[0]), __hiloint2double(rh[1], rl[1]), sm);
+  }
+  const bool smr = (SUMMASK >> ((up ? 2 : 0) + (odd ? 1 : 0))) & 1u;  // is this row's column a sum?
+  {
+    const auto rl = __builtin_amdgcn_permlane16_swap(__double2loint(k2[0]), __double2loint(k2[1]), false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(__double2hiint(k2[0]), __double2hiint(k2[1]), false, false);
+    k1 = comb(__hiloint2double(rh[0], rl[0]), __hiloint2double(rh[1], rl[1]), SUMMASK == 0u ? false : SUMMASK == 0xFu ? true : smr);
+  }
+  const bool s4 = SUMMASK == 0u ? false : SUMMASK == 0xFu ? true : smr;
+  k1 = comb(k1, dpp_f64<0x128, 0xF, 0xF, true>(0.0, k1), s4);   // row_ror:8
+  k1 = comb(k1, dpp_f64<0x124, 0xF, 0xF, true>(0.0, k1), s4);   // row_ror:4
+  k1 = comb(k1, dpp_f64<0x4E, 0xF, 0xF, true>(0.0, k1), s4);    // quad_perm [2, 3, 0, 1]
+  k1 = comb(k1, dpp_f64<0xB1, 0xF, 0xF, true>(0.0, k1), s4);    // quad_perm [1, 0, 3, 2]
+#pragma unroll
+  for (int q = 0; q < 4; ++q) out[q] = uniform_of(k1, 16 * q);
 }
 
 template <typename T>
@@ -185,7 +239,7 @@ template <int NA> __host__ __device__ constexpr int flat2_off_tail() { return fl
 template <int NA>
 __host__ __device__ __forceinline__ size_t flat2_lds_bytes(int nc, bool has_hv)
 {
-  const size_t n = (size_t)flat2_off_tail<NA>() + (has_hv ? (size_t)F2G * 6 : 0) + (size_t)nc * FCD + FISC + 36;
+  const size_t n = (size_t)flat2_off_tail<NA>() + (has_hv ? (size_t)F2G * 6 : 0) + (size_t)nc * C2D + FISC + 36;
   return (n * sizeof(double) + 15) & ~(size_t)15;
 }
 
@@ -209,7 +263,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 {
   using T = double;
   static_assert(NA % 2 == 0, "the W entries of a joint are dealt out to its two lanes");
-  constexpr int G = F2G, GW = F2W, cs = FCD, NH = NA / 2;
+  constexpr int G = F2G, GW = F2W, cs = C2D, NH = NA / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
   const bool a_shared = P.mode & MODE_A_SHARED;
@@ -224,7 +278,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   T* const pbuf = xb + flat2_off_pbuf<NA>();      // [34]             partial sums of long rows
   T* const rbuf = xb + flat2_off_rbuf<NA>();      // [32]             r' of the last iteration (stored with the instance)
   T* const shv = xb + flat2_off_tail<NA>();       // [32][6]          subtree sums of the links' H_ref v_ref (if != 0)
-  T* const cdi = shv + (has_hv ? G * 6 : 0);      // [nc][FCD]        constraint blocks of the instance
+  T* const cdi = shv + (has_hv ? G * 6 : 0);      // [nc][C2D]        constraint blocks of the instance
   T* const isc = cdi + (size_t)L.nc * cs;         // [FISC]
 
   const bool isj_lane = j < L.nb;
@@ -298,6 +352,25 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const int ccl = lane / 6, ckl = lane - 6 * ccl;
   const bool iscl = lane < 6 * L.nc;
   T* const ccb = cdi + (iscl ? ccl : 0) * cs;
+  // (AW y)_k and (A^T y)_k of the constraint of lane 6 c + k: ONE order of operations wherever they are formed (load, loop, store),
+  // so that an instance resumed from the queue continues with the bits it would have had
+  auto awy_k = [&]() -> T {
+    const T* r = ccb + C2_AW + 6 * ckl;
+    const T* y = ccb + C2_Y;
+    T a = r[0] * y[0];
+#pragma unroll
+    for (int q = 1; q < 6; ++q) a += r[q] * y[q];
+    return a;
+  };
+  auto aty_k = [&]() -> T {
+    const T* A_ = ccb + C2_A + ckl;
+    const T* y = ccb + C2_Y;
+    T a = A_[0] * y[0];
+#pragma unroll
+    for (int q = 1; q < 6; ++q) a += A_[6 * q] * y[q];
+    return a;
+  };
+  bool resumed = false;  // (SLICED) the instance came back from the queue: no first-iteration corrections
   auto half = [&](const T* x6, T* x3) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) x3[k] = h ? x6[3 + k] : x6[k];
@@ -445,30 +518,30 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         for (int k = 0; k < 3; ++k) Sw[k] += pitch_h * ra3[k];
       }
     }
-    // constraint blocks: lane of the joint, b, y, A^T y, A; then AW = X*_{0<-joint} A^T, AW b
+    // constraint blocks: lane of the joint, b, y, A^T y, A; then AW = X*_{0<-joint} A^T (and transposed), AW b
     for (int c = 0; c < L.nc; ++c) {
       const char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
       T* c_ = cdi + c * cs;
       if (lane < 18) {
         const int which = lane / 6, k = lane % 6;
         const int pair = which == 0 ? CP_B : which == 1 ? CP_Y : CP_ATY;
-        const int dst = which == 0 ? FC_B : which == 1 ? FC_Y : FC_ATY;
-        c_[dst + k] = rld<T, SLICED>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));  // (y, A^T y change in the kernel)
+        const int dst = which == 0 ? C2_B : which == 1 ? C2_Y : C2_ATY;
+        c_[dst + k] = rld<T, SLICED>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));  // (y changes in the kernel)
       }
       for (int e = lane; e < LCA; e += WAVE)
-        c_[FC_A + e] = a_shared ? Bf.uni[c * LCA + e]
+        c_[C2_A + e] = a_shared ? Bf.uni[c * LCA + e]
                                 : *reinterpret_cast<const T*>(crec + (size_t)(CP_A + e / 2) * pair_bytes<T>() + (e & 1) * sizeof(T));
     }
-    if (jcslot >= 0) cdi[jcslot * cs + FC_LANE] = (T)j;
+    if (jcslot >= 0) cdi[jcslot * cs + C2_LANE] = (T)j;
     tail_sync();
     cbits = 0u;
     for (int c = 0; c < L.nc; ++c) {
-      const int cl = (int)cdi[c * cs + FC_LANE];
+      const int cl = (int)cdi[c * cs + C2_LANE];
       if (isj_lane && cl >= j && cl < j + size) cbits |= 1u << c;
     }
     if (jcslot >= 0) {  // the constrained joint's lanes: column q of AW = row q of A carried to the world origin
       T* c_ = cdi + jcslot * cs;
-      const T* A_ = c_ + FC_A;
+      const T* A_ = c_ + C2_A;
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         T aj[6], o[6];
@@ -476,27 +549,33 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         for (int k = 0; k < 6; ++k) aj[k] = A_[6 * q + k];
         act_force(R0, t0, aj, o);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) c_[FC_AW + 6 * k + q] = o[k];
+        for (int k = 0; k < 6; ++k) { c_[C2_AW + 6 * k + q] = o[k]; c_[C2_AWT + 6 * q + k] = o[k]; }
       }
       // A^T y as the instance brings it (a warm-started tailored solve arrives with the A^T y of the matrix it had BEFORE
       // UpdateEqConstraint replaced it, and upstream's first FwdPass1 uses exactly that, hxx:329-331), at the world origin
       T ay[6], o[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) ay[k] = c_[FC_ATY + k];
+      for (int k = 0; k < 6; ++k) ay[k] = c_[C2_ATY + k];
       act_force(R0, t0, ay, o);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) c_[FC_ATYW + k] = o[k];
+      for (int k = 0; k < 6; ++k) c_[C2_ATYW + k] = o[k];
     }
     tail_sync();
-    for (int c = 0; c < L.nc; ++c) {
-      T* c_ = cdi + c * cs;
-      if (lane < 6) {
-        const int k = lane;
-        T ab = T(0);
+    resumed = SLICED && tag2.x == T(-3);
+    if (iscl) {
+      // A^T b at the world origin; and what the first iteration owes to an A^T y that is not A^T (the y the record holds) -- the
+      // loop forms the constraint's force as AW y and g without an A^T y term, which is exact from the second iteration on
+      // (DualUpdate leaves A^T y = A^T y_new, hxx:422): C2_CW = X*(A^T y used) - AW y_old goes into the first f, C2_DLT =
+      // A^T y_old - (A^T y used) into the first g.  Zero for a cold start; rounding noise for a warm start with an unchanged A.
+      const int k = ckl;
+      T ab = T(0);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) ab += c_[FC_AW + 6 * k + q] * c_[FC_B + q];
-        c_[FC_ATBW + k] = ab;
-      }
+      for (int q = 0; q < 6; ++q) ab += ccb[C2_AW + 6 * k + q] * ccb[C2_B + q];
+      ccb[C2_ATBW + k] = ab;
+      const T aw = awy_k(), at = aty_k();
+      ccb[C2_CW + k] = resumed ? T(0) : ccb[C2_ATYW + k] - aw;
+      ccb[C2_DLT + k] = resumed ? T(0) : at - ccb[C2_ATY + k];
+      if (resumed) ccb[C2_ATYW + k] = aw;  // (what the loop had left there)
     }
     // subtree sums of the state the instance arrives with (cold start: v = 0) and of the reference term
     {
@@ -529,19 +608,11 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     }
     if constexpr (SLICED) {
       // An instance that comes back from the queue (SP_TAG = -3) continues EXACTLY where it left: the two quantities of the loop
-      // that are not functions of the stored record alone -- the subtree sums of E (prefix-sum differences in the loop, window
-      // sums above) and A^T y at the world origin (AW y in the loop, X* (A^T y) above) -- travel in record pairs this engine does
-      // not otherwise use (JP_P, JP_UD of the constrained joint).  Time slicing then changes no bit of any result, whatever the
-      // order the hardware happens to serve the queue in.
-      if (tag2.x == T(-3)) {
-        rld6<T, SLICED>(rec, JP_P, SE);
-        if (jcslot >= 0) {
-          T aw[6];
-          rld6<T, SLICED>(rec, JP_UD, aw);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) cdi[jcslot * cs + FC_ATYW + k] = aw[k];
-        }
-      }
+      // that are not functions of the stored record alone are the subtree sums of E (prefix-sum differences in the loop, window
+      // sums above): they travel in a record pair this engine does not otherwise use (JP_P); A^T y at the world origin is AW y,
+      // formed above in the loop's order of operations.  Time slicing then changes no bit of any result, whatever the order the
+      // hardware happens to serve the queue in.
+      if (tag2.x == T(-3)) rld6<T, SLICED>(rec, JP_P, SE);
     }
     half(Sw, Sw3); half(v, v3); half(f, f3); half(g, g3); half(SE, SE3);
     mu = mu2.x;
@@ -576,10 +647,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       if (SLICED && requeue) {  // (see load_instance)
         T se[6];
         whole(SE3, se);
-        if (isj && !h) {
-          rst6<T, SLICED>(rec, JP_P, se);
-          if (jcslot >= 0) rst6<T, SLICED>(rec, JP_UD, cdi + jcslot * cs + FC_ATYW);
-        }
+        if (isj && !h) rst6<T, SLICED>(rec, JP_P, se);
       }
       if (isj && !h) {
         rst6<T, SLICED>(rec, JP_V, v);
@@ -594,13 +662,11 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         }
       }
     }
-    for (int c = 0; c < L.nc; ++c) {
-      char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
-      if (lane < 6) {
-        const int k = lane;
-        rst<T, SLICED>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), cdi[c * cs + FC_Y + k]);
-        rst<T, SLICED>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), cdi[c * cs + FC_ATY + k]);
-      }
+    if (iscl) {  // y and A^T y (hxx:422; an instance that did not iterate goes back with the A^T y it came with)
+      char* crec = ip + (size_t)(L.off_c + ccl * L.crec) * pair_bytes<T>();
+      const int k = ckl;
+      rst<T, SLICED>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), ccb[C2_Y + k]);
+      rst<T, SLICED>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), any_iter ? aty_k() : ccb[C2_ATY + k]);
     }
     if (lane == 0) {
       rstp<T, SLICED>(srec, SP_MU, mu, (T)kexp);
@@ -717,7 +783,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         const T* c_ = cdi + c * cs + h3;
         const T m = cmask(c);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) PB[k] += m * (c_[FC_ATYW + k] - mu_eq * c_[FC_ATBW + k]);
+        for (int k = 0; k < 3; ++k) PB[k] += m * (c_[C2_ATYW + k] - mu_eq * c_[C2_ATBW + k]);
       }
       const T d3 = Sw3[0] * PB[0] + Sw3[1] * PB[1] + Sw3[2] * PB[2];
       tau = (w - mu_in * z) + pair_sum(d3);
@@ -769,6 +835,10 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
       for (int k = 0; k < 3; ++k) y[k] = Sw3[k] * nui;
       flat_path_sum4<T, 3>(xb, lane, opaque(pathA), opaque(pathB), pathC, njmp, y);
+      if (jcslot >= 0) {  // the constrained links' velocities at the world origin: the task constraints' update starts from them
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cdi[jcslot * cs + C2_VC + h3 + k] = y[k];
+      }
       // the two halves meet: R0 v_l = vw_l - t0 x vw_a is needed by both lanes (the linear lane rotates it into the link frame,
       // the angular lane builds the angular part of the link's momentum-like vector E from it)
       T lin[3], ang[3], c1[3], El[3], c2[3], X[3];
@@ -807,37 +877,30 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T fi3[3], si;
     {
       T SEn[3], SHn[3], Fw[3];  // (SHn: HD only -- the subtree sums of the links' H_ref v at the world origin)
-      // ---- the task constraints' update: (A v - b, dy, y), then (A^T y, the same at the world origin, the pieces of this
-      // iteration's force balance): two dependent exchanges through the constraint block in LDS (lane 6 c + k owns row k)
-      tail_sync();
-      if (jcslot >= 0) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) cdi[jcslot * cs + FC_VC + h3 + k] = vi3[k];
-      }
+      // ---- the task constraints' update: (A v - b, dy, y), then the constraint's force AW y at the world origin: two dependent
+      // exchanges through the constraint block in LDS (lane 6 c + k owns row k).  A v_c = AW^T v^w_c: no frame change first.
+      const bool first = my_iters == 1u && !resumed;  // (the first iteration of a fresh record: see load_instance)
       tail_sync();
       if (iscl) {
-        const T* A_ = ccb + FC_A;
-        const T* vc = ccb + FC_VC;
-        T avk = A_[6 * ckl] * vc[0];
+        const T* col = ccb + C2_AWT + 6 * ckl;
+        const T* vc = ccb + C2_VC;
+        T avk = col[0] * vc[0];
 #pragma unroll
-        for (int q = 1; q < 6; ++q) avk += A_[6 * ckl + q] * vc[q];
-        const T bk = ccb[FC_B + ckl];
+        for (int q = 1; q < 6; ++q) avk += col[q] * vc[q];
+        const T bk = ccb[C2_B + ckl];
         const T ek = avk - bk;
         const T dy = mu_eq * ek;
-        const T yk = ccb[FC_Y + ckl] + dy;
         l_dyis = tabs(dy);
         l_up = bk * tmax(dy, T(0));
         l_lm = bk * tmin(dy, T(0));
         l_prt = tabs(ek);
         l_av = tabs(avk);
-        ccb[FC_Y + ckl] = yk;
-        ccb[FC_DY + ckl] = dy;
+        ccb[C2_Y + ckl] += dy;
       }
       TAIL_TP(9)
-      // (the update's chain -- v -> LDS | fence | A v, y -> LDS | fence | A^T y -> LDS | fence -- is 1650 of the 8800 cycles of an
-      //  iteration at full load, on six busy lanes.  Moving v, y, dy between lanes by ds_bpermute (36 wavefront-wide LDS
-      //  instructions) or by v_readlane (one constraint) gives the same bits and is SLOWER, 11.16 / 10.93 against 10.62 ms:
-      //  the other wavefront of the SIMD hides this latency; what the loop lacks is issue slots, not shorter chains)
+      // (round 3 formed A v, A^T y, AW y, A^T dy and AW dy here, 30 multiply-adds on six lanes and 170 instructions of the
+      //  wavefront: A^T y only matters for the stored record -- store_instance -- and the dy products are the y products'
+      //  differences)
       // ---- subtree sums of E (BwdPass2's transport, hxx:210-212, as a force balance at the world origin): the joints of a subtree
       // are the lanes [j, j + size) of this half, so S_j = P[j + size - 1] - P[j] + E_j with P the inclusive prefix sum -- in
       // registers (DPP), placed here to run while the constraint block is on its way through LDS
@@ -876,22 +939,13 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         }
       }
       TAIL_TP(10)
-      tail_sync();
       if (iscl) {
-        // A^T y (hxx:422) and the same at the world origin; the constraint's share of this iteration's force balance is
-        // A^T dy + (the A^T y FwdPass1 used) -- see k_flat
-        const T* A_ = ccb + FC_A;
-        const int k = ckl;
-        T at = A_[k] * ccb[FC_Y], aw = ccb[FC_AW + 6 * k] * ccb[FC_Y], atd = A_[k] * ccb[FC_DY], awd = ccb[FC_AW + 6 * k] * ccb[FC_DY];
-#pragma unroll
-        for (int q = 1; q < 6; ++q) {
-          at += A_[6 * q + k] * ccb[FC_Y + q]; aw += ccb[FC_AW + 6 * k + q] * ccb[FC_Y + q];
-          atd += A_[6 * q + k] * ccb[FC_DY + q]; awd += ccb[FC_AW + 6 * k + q] * ccb[FC_DY + q];
-        }
-        ccb[FC_DLT + k] = (at - atd) - ccb[FC_ATY + k];   // A^T y_old - (A^T y used): added to g of the constrained joint
-        ccb[FC_ATYF + k] = ccb[FC_ATYW + k] + awd;       // the constraint's force in f, world origin
-        ccb[FC_ATY + k] = at;
-        ccb[FC_ATYW + k] = aw;
+        // X* (A^T y_new) = AW y: what the next FwdPass1 adds to p of the constrained joint (hxx:329-331) and, this iteration,
+        // the constraint's force in f: (A^T y used) + A^T dy
+        const T aw = awy_k();
+        const T cw = first ? ccb[C2_CW + ckl] : T(0);
+        ccb[C2_ATYW + ckl] = aw;
+        ccb[C2_ATYF + ckl] = aw + cw;
       }
       tail_sync();
       TAIL_TP(11)
@@ -908,9 +962,9 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
           for (int k = 0; k < 3; ++k) gi[k] += mass * hvl3[k];
         }
-        if (jcslot >= 0) {
+        if (first && jcslot >= 0) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) gi[k] += cdi[jcslot * cs + FC_DLT + h3 + k];
+          for (int k = 0; k < 3; ++k) gi[k] += cdi[jcslot * cs + C2_DLT + h3 + k];
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -921,17 +975,17 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
           for (int k = 0; k < 3; ++k) dvr[k] -= mass * hvl3[k];
         }
-        l_dualv = inf3(dvr);
+        l_dualv = hinf3(dvr);
         l_nu = tabs(nui);
         if constexpr (HD) {
-          l_hrefv = mass * inf3(hv3);
+          l_hrefv = mass * hinf3(hv3);
         } else {
-          l_hrefv = mass * tabs(href_s) * inf3(vi3);
+          l_hrefv = mass * tabs(href_s) * hinf3(vi3);
         }
-        l_dvis = mass * inf3(dv);
+        l_dvis = mass * hinf3(dv);
         l_dnu = tabs(nui - nu);
         const T x = nui + inv_mu * w;
-        const T zi = tmin(ubi, tmax(lbi, x));
+        const T zi = hmin(ubi, hmax(lbi, x));
         l_dz = tabs(zi - z);
         l_prs = tabs(nui - zi);
         const T dwi = mu_in * (nui - zi);
@@ -939,8 +993,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         l_up += hz * (ubi * tmax(dwi, T(0)));
         l_lm += hz * (lbi * tmin(dwi, T(0)));
         w = w + dwi; z = zi; nu = nui;
-        l_dg = inf3(dg);
-        l_g = inf3(gi);
+        l_dg = hinf3(dg);
+        l_g = hinf3(gi);
 #pragma unroll
         for (int k = 0; k < 3; ++k) { v3[k] = vi3[k]; g3[k] = gi[k]; }
       }
@@ -955,7 +1009,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         const T* c_ = cdi + c * cs + h3;
         const T m = cmask(c);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) Fw[k] += m * c_[FC_ATYF + k];
+        for (int k = 0; k < 3; ++k) Fw[k] += m * c_[C2_ATYF + k];
       }
       {
         // SE3::actInv(Force): (R0^T F_l, R0^T (F_a - t0 x F_l)): the angular lane needs the linear half
@@ -980,7 +1034,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       T df[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) df[k] = fi3[k] - f3[k];
-      l_dfis = mass * inf3(df);
+      l_dfis = mass * hinf3(df);
       si += w;
       l_stf = tabs(si);
       l_dstf = tabs(si - s);
@@ -990,36 +1044,46 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     }
     TAIL_TP(3)
     // ================= the scalars of the stopping logic, folded over the wavefront ===============================================
-    T red[8];
-    {
-      T in[8] = {tmax(l_prt, l_prs), tmax(l_dualv, l_stf), tmax(l_dvis, l_dnu), l_dz,
-                 tmax(l_dfis, tmax(l_dyis, l_dw)), tmax(l_dg, l_dstf), l_up, l_lm};
-      wave_fold8<true>(lane, in, red);
+    // Main loop: four maxima (primal, dual, the two sides of the certificate's first test); the certificate's second test and the
+    // tail solve's stopping rule need four more scalars, folded only when they are looked at.
+    const bool fixed = P.mode & MODE_FIXED_ITERS;
+    const bool in_tail = (status & ST_TAIL) != 0;
+    const bool logic = !fixed && !in_tail;  // the main loop's stopping logic runs
+    T primal = T(0), dual = T(0), dyqp = T(0), atdy = T(0), dx = T(0), dz = T(0), ubp = T(0), lbm = T(0);
+    if (logic) {
+      T in[4] = {hmax(l_prt, l_prs), hmax(l_dualv, l_stf), hmax(l_dfis, hmax(l_dyis, l_dw)), hmax(l_dg, l_dstf)}, r[4];
+      wave_fold4<0u>(lane, in, r);
+      primal = r[0]; dual = r[1]; dyqp = r[2]; atdy = r[3];
     }
     T ntol_p = T(0), ntol_d = T(0);
     if (P.tol_rel != T(0)) {  // (uniform) relative tolerances need two more maxima
-      T in2[8] = {tmax(l_av, l_nu), tmax(tmax(l_hrefv, l_g), l_stf), T(0), T(0), T(0), T(0), T(0), T(0)}, r2[8];
-      wave_fold8<false>(lane, in2, r2);
+      T in2[4] = {hmax(l_av, l_nu), hmax(hmax(l_hrefv, l_g), l_stf), T(0), T(0)}, r2[4];
+      wave_fold4<0u>(lane, in2, r2);
       ntol_p = r2[0]; ntol_d = r2[1];
     }
     TAIL_TP(6)
     // ================= CheckConvergence, CheckFeasibility, UpdateMu, the tail solve's stopping rule (hpp:377-454, :271-319) ====
-    const T primal = red[0], dual = red[1], dx = red[2], dz = red[3], dyqp = red[4], atdy = red[5], ubp = red[6], lbm = red[7];
     const T mu_used = mu;
-    const bool fixed = P.mode & MODE_FIXED_ITERS;
-    const bool in_tail = (status & ST_TAIL) != 0;
-    const bool logic = !fixed && !in_tail;  // the main loop's stopping logic runs
     const T tol_p = P.tol_abs + P.tol_rel * tmax(ntol_p, isc[FI_BNORM]);
     const T tol_d = P.tol_abs + P.tol_rel * tmax(ntol_d, P.Hv_inf_norm);
     const int itn = iter + 1;
     const bool conv = logic && (primal < tol_p) && (dual < tol_d);
     const bool feas_chk = logic && itn > 1;
-    const bool c1 = atdy <= P.tol_primal_inf * dyqp, c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp;
+    const bool c1 = atdy <= P.tol_primal_inf * dyqp;
+    bool have_b = false;
+    auto fold_b = [&]() {
+      T in[4] = {l_up, l_lm, hmax(l_dvis, l_dnu), l_dz}, r[4];
+      wave_fold4<0x3u>(lane, in, r);
+      ubp = r[0]; lbm = r[1]; dx = r[2]; dz = r[3];
+      have_b = true;
+    };
+    if (in_tail || (feas_chk && c1)) fold_b();
+    bool c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp;
     const bool infeas = feas_chk && c1 && c2;
     const bool enter_tail = infeas && !conv;
     const bool upd = logic && !conv && !infeas;
     const bool mu_up = upd && (primal > T(10) * dual), mu_dn = upd && !mu_up && (dual > T(10) * primal);
-    const bool tail_stop = !(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || itn >= P.max_iter;
+    const bool tail_stop = !(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || itn >= P.max_iter;  // (looked at with have_b only)
     const bool stop = conv || ((enter_tail || in_tail) && tail_stop) || ((upd || fixed) && itn + 1 >= P.max_iter);
     iter = itn;
     status |= (conv ? ST_CONVERGED : 0) | (infeas ? ST_PRIMAL_INF : 0) | (enter_tail ? ST_TAIL : 0) | (stop ? ST_DONE : 0);
@@ -1031,6 +1095,14 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     done = stop;
     // ---- what the getters report: written when an instance stops (the certificate's scalars also when it enters the tail
     // solve: they keep the values of the last iteration that evaluated them) -------------------------------------------------
+    T r1[8], r2[8];
+    if (stop) {
+      T in1[8] = {l_prt, l_prs, l_stf, l_dvis, l_dnu, l_dfis, l_dyis, l_dw}, in2[8] = {l_av, l_nu, l_hrefv, l_g, l_dualv, T(0), T(0), T(0)};
+      wave_fold8<false>(lane, in1, r1);
+      wave_fold8<false>(lane, in2, r2);
+      if (!logic) { primal = hmax(r1[0], r1[1]); dual = hmax(r2[4], r1[2]); }  // (the tail solve / a fixed count did not fold them)
+      if (!have_b) { fold_b(); c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp; }  // (reported; c1 was false: no decision hung on it)
+    }
     if (stop || enter_tail) {
       if (lane == 0) {
         isc[FI_PRIMAL] = primal; isc[FI_DUAL] = dual; isc[FI_DX] = dx; isc[FI_DZ] = dz; isc[FI_MULAST] = mu_used;
@@ -1041,10 +1113,6 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       }
     }
     if (stop) {
-      T in1[8] = {l_prt, l_prs, l_stf, l_dvis, l_dnu, l_dfis, l_dyis, l_dw}, in2[8] = {l_av, l_nu, l_hrefv, l_g, l_dualv, T(0), T(0), T(0)};
-      T r1[8], r2[8];
-      wave_fold8<false>(lane, in1, r1);
-      wave_fold8<false>(lane, in2, r2);
       if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) isc[FI_RED + k] = r1[k];
@@ -1105,7 +1173,7 @@ template <int NA>
 __host__ __device__ __forceinline__ size_t flat1_lds_bytes(int nc, bool has_hv, int slot_bufs = 2)
 {
   const size_t n = (size_t)flat1_xregion<NA>() + (size_t)slot_bufs * (NA + 1) * WAVE + 3 * (size_t)(WAVE + 2) + (has_hv ? (size_t)WAVE * 6 : 0) +
-                   (size_t)nc * FCD + FISC + 36;
+                   (size_t)nc * C2D + FISC + 36;
   return (n * sizeof(double) + 15) & ~(size_t)15;
 }
 
@@ -1121,7 +1189,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const int has_hv = has_hv_bits & 1;
   const bool one_buf = (has_hv_bits & 2) != 0;
   using T = double;
-  constexpr int G = WAVE, cs = FCD;
+  constexpr int G = WAVE, cs = C2D;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
   const bool a_shared = P.mode & MODE_A_SHARED;
@@ -1133,7 +1201,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   T* const pbuf = nbuf + G + 2;                          // [66]
   T* const rbuf = pbuf + G + 2;                          // [66]
   T* const shv = rbuf + G + 2;                           // [64][6] (if H_ref v_ref != 0)
-  T* const cdi = shv + (has_hv ? G * 6 : 0);             // [nc][FCD]
+  T* const cdi = shv + (has_hv ? G * 6 : 0);             // [nc][C2D]
   T* const isc = cdi + (size_t)L.nc * cs;                // [FISC]
 
   const bool isj_lane = j < L.nb;
@@ -1195,6 +1263,24 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const int ccl = lane / 6, ckl = lane - 6 * ccl;
   const bool iscl = lane < 6 * L.nc;
   T* const ccb = cdi + (iscl ? ccl : 0) * cs;
+  // (AW y)_k and (A^T y)_k of the constraint of lane 6 c + k, in ONE order of operations wherever they are formed (see k_flat2)
+  auto awy_k = [&]() -> T {
+    const T* r = ccb + C2_AW + 6 * ckl;
+    const T* y = ccb + C2_Y;
+    T a = r[0] * y[0];
+#pragma unroll
+    for (int q = 1; q < 6; ++q) a += r[q] * y[q];
+    return a;
+  };
+  auto aty_k = [&]() -> T {
+    const T* A_ = ccb + C2_A + ckl;
+    const T* y = ccb + C2_Y;
+    T a = A_[0] * y[0];
+#pragma unroll
+    for (int q = 1; q < 6; ++q) a += A_[6 * q] * y[q];
+    return a;
+  };
+  bool resumed = false;  // (SLICED) the instance came back from the queue: no first-iteration corrections
   auto force_of_motion = [&](const T* vw, T* E) {  // E = mass * (R0 v_l, R0 v_a + t0 x R0 v_l) from the world-frame motion
     T c1[3], c2[3];
     cross3(t0, vw + 3, c1);
@@ -1336,23 +1422,23 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       if (lane < 18) {
         const int which = lane / 6, k = lane % 6;
         const int pair = which == 0 ? CP_B : which == 1 ? CP_Y : CP_ATY;
-        const int dst = which == 0 ? FC_B : which == 1 ? FC_Y : FC_ATY;
+        const int dst = which == 0 ? C2_B : which == 1 ? C2_Y : C2_ATY;
         c_[dst + k] = rld<T, SLICED>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
       }
       for (int e = lane; e < LCA; e += WAVE)
-        c_[FC_A + e] = a_shared ? Bf.uni[c * LCA + e]
+        c_[C2_A + e] = a_shared ? Bf.uni[c * LCA + e]
                                 : *reinterpret_cast<const T*>(crec + (size_t)(CP_A + e / 2) * pair_bytes<T>() + (e & 1) * sizeof(T));
     }
-    if (jcslot >= 0) cdi[jcslot * cs + FC_LANE] = (T)j;
+    if (jcslot >= 0) cdi[jcslot * cs + C2_LANE] = (T)j;
     tail_sync();
     cbits = 0u;
     for (int c = 0; c < L.nc; ++c) {
-      const int cl = (int)cdi[c * cs + FC_LANE];
+      const int cl = (int)cdi[c * cs + C2_LANE];
       if (isj_lane && cl >= j && cl < j + size) cbits |= 1u << c;
     }
     if (jcslot >= 0) {
       T* c_ = cdi + jcslot * cs;
-      const T* A_ = c_ + FC_A;
+      const T* A_ = c_ + C2_A;
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         T aj[6], o[6];
@@ -1360,25 +1446,27 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         for (int k = 0; k < 6; ++k) aj[k] = A_[6 * q + k];
         act_force(R0, t0, aj, o);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) c_[FC_AW + 6 * k + q] = o[k];
+        for (int k = 0; k < 6; ++k) { c_[C2_AW + 6 * k + q] = o[k]; c_[C2_AWT + 6 * q + k] = o[k]; }
       }
       T ay[6], o[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) ay[k] = c_[FC_ATY + k];
+      for (int k = 0; k < 6; ++k) ay[k] = c_[C2_ATY + k];
       act_force(R0, t0, ay, o);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) c_[FC_ATYW + k] = o[k];
+      for (int k = 0; k < 6; ++k) c_[C2_ATYW + k] = o[k];
     }
     tail_sync();
-    for (int c = 0; c < L.nc; ++c) {
-      T* c_ = cdi + c * cs;
-      if (lane < 6) {
-        const int k = lane;
-        T ab = T(0);
+    resumed = SLICED && rldp<T, SLICED>(srec, SP_TAG).x == T(-3);
+    if (iscl) {  // A^T b at the world origin and the first iteration's corrections (see k_flat2)
+      const int k = ckl;
+      T ab = T(0);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) ab += c_[FC_AW + 6 * k + q] * c_[FC_B + q];
-        c_[FC_ATBW + k] = ab;
-      }
+      for (int q = 0; q < 6; ++q) ab += ccb[C2_AW + 6 * k + q] * ccb[C2_B + q];
+      ccb[C2_ATBW + k] = ab;
+      const T aw = awy_k(), at = aty_k();
+      ccb[C2_CW + k] = resumed ? T(0) : ccb[C2_ATYW + k] - aw;
+      ccb[C2_DLT + k] = resumed ? T(0) : at - ccb[C2_ATY + k];
+      if (resumed) ccb[C2_ATYW + k] = aw;
     }
     {
       T vw[6], E[6];
@@ -1401,15 +1489,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       }
     }
     if constexpr (SLICED) {  // an instance that comes back from the queue continues exactly where it left (see k_flat2)
-      if (rldp<T, SLICED>(srec, SP_TAG).x == T(-3)) {
-        rld6<T, SLICED>(rec, JP_P, SE);
-        if (jcslot >= 0) {
-          T aw[6];
-          rld6<T, SLICED>(rec, JP_UD, aw);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) cdi[jcslot * cs + FC_ATYW + k] = aw[k];
-        }
-      }
+      if (resumed) rld6<T, SLICED>(rec, JP_P, SE);
     }
     const typename Vec2<T>::type mu2 = rldp<T, SLICED>(srec, SP_MU), bi2 = rldp<T, SLICED>(srec, SP_BI), st2 = rldp<T, SLICED>(srec, SP_ST);
     mu = mu2.x;
@@ -1435,10 +1515,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   bool requeue = false;
   auto store_instance = [&]() {
     char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
-    if (SLICED && requeue && isj) {
-      rst6<T, SLICED>(rec, JP_P, SE);
-      if (jcslot >= 0) rst6<T, SLICED>(rec, JP_UD, cdi + jcslot * cs + FC_ATYW);
-    }
+    if (SLICED && requeue && isj) rst6<T, SLICED>(rec, JP_P, SE);
     if (isj) {
       rst6<T, SLICED>(rec, JP_V, v);
       rst6<T, SLICED>(rec, JP_F, f);
@@ -1447,13 +1524,11 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       rstp<T, SLICED>(rec, JP_NUS, nu, s);
       if (any_iter) rstp<T, SLICED>(rec, JP_R, rbuf[lane], wl[(wsel * (NA + 1) + NA) * G + lane]);  // (r_i, Dinv_i; SP_TAG = -2: see k_flat)
     }
-    for (int c = 0; c < L.nc; ++c) {
-      char* crec = ip + (size_t)(L.off_c + c * L.crec) * pair_bytes<T>();
-      if (lane < 6) {
-        const int k = lane;
-        rst<T, SLICED>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), cdi[c * cs + FC_Y + k]);
-        rst<T, SLICED>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), cdi[c * cs + FC_ATY + k]);
-      }
+    if (iscl) {  // y and A^T y (an instance that did not iterate goes back with the A^T y it came with)
+      char* crec = ip + (size_t)(L.off_c + ccl * L.crec) * pair_bytes<T>();
+      const int k = ckl;
+      rst<T, SLICED>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), ccb[C2_Y + k]);
+      rst<T, SLICED>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), any_iter ? aty_k() : ccb[C2_ATY + k]);
     }
     if (lane == 0) {
       rstp<T, SLICED>(srec, SP_MU, mu, (T)kexp);
@@ -1546,7 +1621,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         const T* c_ = cdi + c * cs;
         const T m = cmask(c);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) PB[k] += m * (c_[FC_ATYW + k] - mu_eq * c_[FC_ATBW + k]);
+        for (int k = 0; k < 6; ++k) PB[k] += m * (c_[C2_ATYW + k] - mu_eq * c_[C2_ATBW + k]);
       }
       tau = (w - mu_in * z) + dot6_halves(Sw, PB);
     }
@@ -1593,6 +1668,10 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
       for (int k = 0; k < 6; ++k) vw[k] = Sw[k] * nui;
       flat_path_sum4<T, 6>(xb, lane, opaque(pathA), opaque(pathB), pathC, njmp, vw);
+      if (jcslot >= 0) {  // the constrained links' velocities at the world origin: the task constraints' update starts from them
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cdi[jcslot * cs + C2_VC + k] = vw[k];
+      }
       actinv_motion(R0, t0, vw, vi);
       force_of_motion(vw, E);
     }
@@ -1615,29 +1694,23 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       T SEn[6], SHn[6], Fw[6];
       // ---- the task constraints' update (two dependent exchanges through the constraint blocks) with the subtree sums of E,
       // prefix-sum differences in registers, in its shadow
+      const bool first = my_iters == 1u && !resumed;  // (the first iteration of a fresh record: see k_flat2's load_instance)
       tail_sync();
-      if (jcslot >= 0) {
+      if (iscl) {  // row ckl of the lane's constraint: A v - b = AW^T v^w - b, dy, y (hxx:410-451)
+        const T* col = ccb + C2_AWT + 6 * ckl;
+        const T* vc = ccb + C2_VC;
+        T avk = col[0] * vc[0];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) cdi[jcslot * cs + FC_VC + k] = vi[k];
-      }
-      tail_sync();
-      if (iscl) {
-        const T* A_ = ccb + FC_A;
-        const T* vc = ccb + FC_VC;
-        T avk = A_[6 * ckl] * vc[0];
-#pragma unroll
-        for (int q = 1; q < 6; ++q) avk += A_[6 * ckl + q] * vc[q];
-        const T bk = ccb[FC_B + ckl];
+        for (int q = 1; q < 6; ++q) avk += col[q] * vc[q];
+        const T bk = ccb[C2_B + ckl];
         const T ek = avk - bk;
         const T dy = mu_eq * ek;
-        const T yk = ccb[FC_Y + ckl] + dy;
         l_dyis = tabs(dy);
         l_up = bk * tmax(dy, T(0));
         l_lm = bk * tmin(dy, T(0));
         l_prt = tabs(ek);
         l_av = tabs(avk);
-        ccb[FC_Y + ckl] = yk;
-        ccb[FC_DY + ckl] = dy;
+        ccb[C2_Y + ckl] += dy;
       }
       {
         T Pk[6];
@@ -1667,20 +1740,11 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
           for (int c = 0; c < 6; ++c) SHn[c] = (xb[(WAVE + 1) * 6 + src * 6 + c] - P2[c]) + E2[c];
         }
       }
-      tail_sync();
-      if (iscl) {
-        const T* A_ = ccb + FC_A;
-        const int k = ckl;
-        T at = A_[k] * ccb[FC_Y], aw = ccb[FC_AW + 6 * k] * ccb[FC_Y], atd = A_[k] * ccb[FC_DY], awd = ccb[FC_AW + 6 * k] * ccb[FC_DY];
-#pragma unroll
-        for (int q = 1; q < 6; ++q) {
-          at += A_[6 * q + k] * ccb[FC_Y + q]; aw += ccb[FC_AW + 6 * k + q] * ccb[FC_Y + q];
-          atd += A_[6 * q + k] * ccb[FC_DY + q]; awd += ccb[FC_AW + 6 * k + q] * ccb[FC_DY + q];
-        }
-        ccb[FC_DLT + k] = (at - atd) - ccb[FC_ATY + k];
-        ccb[FC_ATYF + k] = ccb[FC_ATYW + k] + awd;
-        ccb[FC_ATY + k] = at;
-        ccb[FC_ATYW + k] = aw;
+      if (iscl) {  // the constraint's force at the world origin: AW y (the next FwdPass1's A^T y; this iteration's share of f)
+        const T aw = awy_k();
+        const T cw = first ? ccb[C2_CW + ckl] : T(0);
+        ccb[C2_ATYW + ckl] = aw;
+        ccb[C2_ATYF + ckl] = aw + cw;
       }
       tail_sync();
       {
@@ -1694,9 +1758,9 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
           for (int k = 0; k < 6; ++k) gi[k] += mass * hvl[k];
         }
-        if (jcslot >= 0) {
+        if (first && jcslot >= 0) {
 #pragma unroll
-          for (int k = 0; k < 6; ++k) gi[k] += cdi[jcslot * cs + FC_DLT + k];
+          for (int k = 0; k < 6; ++k) gi[k] += cdi[jcslot * cs + C2_DLT + k];
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
@@ -1707,17 +1771,17 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
           for (int k = 0; k < 6; ++k) dvr[k] -= mass * hvl[k];
         }
-        l_dualv = inf6(dvr);
+        l_dualv = hinf6(dvr);
         l_nu = tabs(nui);
         if constexpr (HD) {
-          l_hrefv = mass * inf6(hv6);
+          l_hrefv = mass * hinf6(hv6);
         } else {
-          l_hrefv = mass * tabs(href_s) * inf6(vi);
+          l_hrefv = mass * tabs(href_s) * hinf6(vi);
         }
-        l_dvis = mass * inf6(dv6);
+        l_dvis = mass * hinf6(dv6);
         l_dnu = tabs(nui - nu);
         const T x = nui + inv_mu * w;
-        const T zi = tmin(ubi, tmax(lbi, x));
+        const T zi = hmin(ubi, hmax(lbi, x));
         l_dz = tabs(zi - z);
         l_prs = tabs(nui - zi);
         const T dwi = mu_in * (nui - zi);
@@ -1725,8 +1789,8 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         l_up += ubi * tmax(dwi, T(0));
         l_lm += lbi * tmin(dwi, T(0));
         w = w + dwi; z = zi; nu = nui;
-        l_dg = inf6(dg);
-        l_g = inf6(gi);
+        l_dg = hinf6(dg);
+        l_g = hinf6(gi);
 #pragma unroll
         for (int k = 0; k < 6; ++k) { v[k] = vi[k]; g[k] = gi[k]; }
       }
@@ -1740,7 +1804,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         const T* c_ = cdi + c * cs;
         const T m = cmask(c);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) Fw[k] += m * c_[FC_ATYF + k];
+        for (int k = 0; k < 6; ++k) Fw[k] += m * c_[C2_ATYF + k];
       }
       actinv_force(R0, t0, Fw, fi);
       si = dot6_halves(Sw, Fw);
@@ -1751,7 +1815,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       T df[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) df[k] = fi[k] - f[k];
-      l_dfis = mass * inf6(df);
+      l_dfis = mass * hinf6(df);
       si += w;
       l_stf = tabs(si);
       l_dstf = tabs(si - s);
@@ -1759,34 +1823,46 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
       for (int k = 0; k < 6; ++k) f[k] = fi[k];
     }
-    T red[8];
-    {
-      T in[8] = {tmax(l_prt, l_prs), tmax(l_dualv, l_stf), tmax(l_dvis, l_dnu), l_dz,
-                 tmax(l_dfis, tmax(l_dyis, l_dw)), tmax(l_dg, l_dstf), l_up, l_lm};
-      wave_fold8<true>(lane, in, red);
-    }
-    T ntol_p = T(0), ntol_d = T(0);
-    if (P.tol_rel != T(0)) {
-      T in2[8] = {tmax(l_av, l_nu), tmax(tmax(l_hrefv, l_g), l_stf), T(0), T(0), T(0), T(0), T(0), T(0)}, r2[8];
-      wave_fold8<false>(lane, in2, r2);
-      ntol_p = r2[0]; ntol_d = r2[1];
-    }
-    const T primal = red[0], dual = red[1], dx = red[2], dz = red[3], dyqp = red[4], atdy = red[5], ubp = red[6], lbm = red[7];
-    const T mu_used = mu;
+    // ================= the scalars of the stopping logic, folded over the wavefront ===============================================
+    // Main loop: four maxima (primal, dual, the two sides of the certificate's first test); the certificate's second test and the
+    // tail solve's stopping rule need four more scalars, folded only when they are looked at.
     const bool fixed = P.mode & MODE_FIXED_ITERS;
     const bool in_tail = (status & ST_TAIL) != 0;
-    const bool logic = !fixed && !in_tail;
+    const bool logic = !fixed && !in_tail;  // the main loop's stopping logic runs
+    T primal = T(0), dual = T(0), dyqp = T(0), atdy = T(0), dx = T(0), dz = T(0), ubp = T(0), lbm = T(0);
+    if (logic) {
+      T in[4] = {hmax(l_prt, l_prs), hmax(l_dualv, l_stf), hmax(l_dfis, hmax(l_dyis, l_dw)), hmax(l_dg, l_dstf)}, r[4];
+      wave_fold4<0u>(lane, in, r);
+      primal = r[0]; dual = r[1]; dyqp = r[2]; atdy = r[3];
+    }
+    T ntol_p = T(0), ntol_d = T(0);
+    if (P.tol_rel != T(0)) {  // (uniform) relative tolerances need two more maxima
+      T in2[4] = {hmax(l_av, l_nu), hmax(hmax(l_hrefv, l_g), l_stf), T(0), T(0)}, r2[4];
+      wave_fold4<0u>(lane, in2, r2);
+      ntol_p = r2[0]; ntol_d = r2[1];
+    }
+    // ================= CheckConvergence, CheckFeasibility, UpdateMu, the tail solve's stopping rule (hpp:377-454, :271-319) ====
+    const T mu_used = mu;
     const T tol_p = P.tol_abs + P.tol_rel * tmax(ntol_p, isc[FI_BNORM]);
     const T tol_d = P.tol_abs + P.tol_rel * tmax(ntol_d, P.Hv_inf_norm);
     const int itn = iter + 1;
     const bool conv = logic && (primal < tol_p) && (dual < tol_d);
     const bool feas_chk = logic && itn > 1;
-    const bool c1 = atdy <= P.tol_primal_inf * dyqp, c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp;
+    const bool c1 = atdy <= P.tol_primal_inf * dyqp;
+    bool have_b = false;
+    auto fold_b = [&]() {
+      T in[4] = {l_up, l_lm, hmax(l_dvis, l_dnu), l_dz}, r[4];
+      wave_fold4<0x3u>(lane, in, r);
+      ubp = r[0]; lbm = r[1]; dx = r[2]; dz = r[3];
+      have_b = true;
+    };
+    if (in_tail || (feas_chk && c1)) fold_b();
+    bool c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp;
     const bool infeas = feas_chk && c1 && c2;
     const bool enter_tail = infeas && !conv;
     const bool upd = logic && !conv && !infeas;
     const bool mu_up = upd && (primal > T(10) * dual), mu_dn = upd && !mu_up && (dual > T(10) * primal);
-    const bool tail_stop = !(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || itn >= P.max_iter;
+    const bool tail_stop = !(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || itn >= P.max_iter;  // (looked at with have_b only)
     const bool stop = conv || ((enter_tail || in_tail) && tail_stop) || ((upd || fixed) && itn + 1 >= P.max_iter);
     iter = itn;
     status |= (conv ? ST_CONVERGED : 0) | (infeas ? ST_PRIMAL_INF : 0) | (enter_tail ? ST_TAIL : 0) | (stop ? ST_DONE : 0);
@@ -1796,6 +1872,16 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     kexp += (mu_up ? 1 : 0) - (mu_dn ? 1 : 0);
     nflip += (mu_up || mu_dn) ? 1 : 0;
     done = stop;
+    // ---- what the getters report: written when an instance stops (the certificate's scalars also when it enters the tail
+    // solve: they keep the values of the last iteration that evaluated them) -------------------------------------------------
+    T r1[8], r2[8];
+    if (stop) {
+      T in1[8] = {l_prt, l_prs, l_stf, l_dvis, l_dnu, l_dfis, l_dyis, l_dw}, in2[8] = {l_av, l_nu, l_hrefv, l_g, l_dualv, T(0), T(0), T(0)};
+      wave_fold8<false>(lane, in1, r1);
+      wave_fold8<false>(lane, in2, r2);
+      if (!logic) { primal = hmax(r1[0], r1[1]); dual = hmax(r2[4], r1[2]); }  // (the tail solve / a fixed count did not fold them)
+      if (!have_b) { fold_b(); c2 = (ubp + lbm) <= P.tol_primal_inf * dyqp; }  // (reported; c1 was false: no decision hung on it)
+    }
     if (stop || enter_tail) {
       if (lane == 0) {
         isc[FI_PRIMAL] = primal; isc[FI_DUAL] = dual; isc[FI_DX] = dx; isc[FI_DZ] = dz; isc[FI_MULAST] = mu_used;
@@ -1806,10 +1892,6 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       }
     }
     if (stop) {
-      T in1[8] = {l_prt, l_prs, l_stf, l_dvis, l_dnu, l_dfis, l_dyis, l_dw}, in2[8] = {l_av, l_nu, l_hrefv, l_g, l_dualv, T(0), T(0), T(0)};
-      T r1[8], r2[8];
-      wave_fold8<false>(lane, in1, r1);
-      wave_fold8<false>(lane, in2, r2);
       if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) isc[FI_RED + k] = r1[k];

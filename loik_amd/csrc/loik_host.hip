@@ -1527,6 +1527,9 @@ void plan_engines(loikb_solver_impl* S)
   else if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) pl.why_not_flat = "LOIKB_OPT_NO_H_CACHE (no precomputed factors)";
   else if (S->opt.mu_update_strat == LOIKB_MU_OSQP) pl.why_not_flat = "OSQP penalty rule: mu is off the decade grid";
   else if (S->nb <= 16) pl.why_not_flat = "a small robot (<= 16 joints): k_solve + k_tail are faster on its short solves";
+  // (the flat engines update the task constraints on lanes 6 c + k of an instance's lanes, in one pass: ten constraints with a
+  //  wavefront per instance, five with two instances per wavefront; more go to the engines that loop over them)
+  else if (S->nc > (flat_takes_diagonal(S) ? 10 : S->flat.G / 6)) pl.why_not_flat = "more task constraints than the flat engine's lanes update in one pass";
   else if (pl.flat_waves_cu < (flat_takes_diagonal(S) ? 4 : 6)) pl.why_not_flat = "constraint blocks leave too few wavefronts per CU in LDS";
   else pl.flat = true;
   // with the lean kernel whole batches up to 2^20 instances go to it directly (it is as fast as k_solve's bulk phase and
