@@ -27,6 +27,8 @@
 // Reference: /root/reference/include/loik/loik-loid-optimized.hxx (passes as cited in loik_flat.hpp).
 #pragma once
 
+#include <type_traits>
+
 #include "loik_flat.hpp"
 
 namespace loikb {
@@ -179,47 +181,74 @@ __device__ __forceinline__ void wave_fold4(int lane, const double* in, double* o
 template <typename T>
 __device__ __forceinline__ T inf3(const T* x) { return tmax(tmax(tabs(x[0]), tabs(x[1])), tabs(x[2])); }
 
+// A lane's gather addresses (which LDS entries its shares of a sum are) are constants of the launch, packed several to a register
+// because registers are what the kernel is short of, and unpacked where they are used.  Round 3 unpacked with C shifts behind an
+// opaque copy of the register (so that the compiler would not hoist thirty addresses out of the loop): v_mov + v_bfe + v_lshl_add
+// per address, ~60 of the loop's VALU instructions.  Here the fields hold BYTE offsets and one v_bfe_u32, pinned where it stands,
+// is the address.
+template <int OFF, int W>
+__device__ __forceinline__ unsigned int field_here(unsigned int x)
+{
+  unsigned int r;
+  asm volatile("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(OFF), "n"(W));
+  return r;
+}
+__device__ __forceinline__ double lds_at(const double* base, unsigned int byte_off)
+{
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 // y_i <- sum over the root path of lane i (the joint and its ancestors) of the NC-vectors y, by pointer jumping in base 4: a
 // round adds the rows of the ancestors at distance 1, 2, 3 (x 4^round), so two rounds cover a tree of depth 16 where jumping in
-// base 2 (flat_path_sum) takes four -- the same number of LDS rows moved, half the dependent round trips.  rows: [WAVE + 1][NC],
-// row WAVE = 0; pa / pb: the lanes of the ancestors at distance 1, 2, 3 / 4, 8, 12 (bytes; WAVE = none), pc: at distance 16.
+// base 2 (flat_path_sum) takes four -- the same number of LDS rows moved, half the dependent round trips.  rows: [NC][PATH_RS],
+// component-major (one address per ancestor, the components at constant offsets), entry WAVE of a component = 0; pa / pb / pc:
+// the byte offsets (lane x 8, ten bits each) of the ancestors at distance 1, 2, 3 / 4, 8, 12 / 16 (WAVE x 8 = none).
+constexpr int PATH_RS = WAVE + 2;
 template <typename T, int NC>
-__device__ __forceinline__ void flat_path_sum4(T* rows, int lane, unsigned int pa, unsigned int pb, int pc, int njmp, T* y)
+__device__ __forceinline__ void flat_path_sum4(T* rows, int lane, unsigned int pa, unsigned int pb, unsigned int pc, int njmp, T* y)
 {
   tail_sync();
-  if (lane < NC) rows[WAVE * NC + lane] = T(0);
+  if (lane < NC) rows[lane * PATH_RS + WAVE] = T(0);
   auto round = [&](unsigned int p3) {
     tail_sync();
 #pragma unroll
-    for (int c = 0; c < NC; ++c) rows[lane * NC + c] = y[c];
+    for (int c = 0; c < NC; ++c) rows[c * PATH_RS + lane] = y[c];
     tail_sync();
-    const int r0 = (int)(p3 & 0xFFu), r1 = (int)((p3 >> 8) & 0xFFu), r2 = (int)((p3 >> 16) & 0xFFu);
+    const unsigned int r0 = field_here<0, 10>(p3), r1 = field_here<10, 10>(p3), r2 = field_here<20, 10>(p3);
     T a[NC], b[NC], d[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) a[c] = rows[r0 * NC + c];
+    for (int c = 0; c < NC; ++c) a[c] = lds_at(rows + c * PATH_RS, r0);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) b[c] = rows[r1 * NC + c];
+    for (int c = 0; c < NC; ++c) b[c] = lds_at(rows + c * PATH_RS, r1);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) d[c] = rows[r2 * NC + c];
+    for (int c = 0; c < NC; ++c) d[c] = lds_at(rows + c * PATH_RS, r2);
 #pragma unroll
     for (int c = 0; c < NC; ++c) y[c] += (a[c] + b[c]) + d[c];
   };
   round(pa);
   if (njmp > 2) round(pb);
-  if (njmp > 4) round((unsigned int)pc | ((unsigned int)WAVE << 8) | ((unsigned int)WAVE << 16));
+  if (njmp > 4) round(pc);
 }
-// the packed ancestor rows of flat_path_sum4 for the joint of FlatLane F: `off` is added to an ancestor's lane
-__device__ __forceinline__ void flat_path_rows4(const FlatLane* fl, int j, int off, unsigned int& pa, unsigned int& pb, int& pc)
+// the packed ancestor offsets of flat_path_sum4 for the joint of FlatLane F: `off` is added to an ancestor's lane
+__device__ __forceinline__ void flat_path_rows4(const FlatLane* fl, int j, int off, unsigned int& pa, unsigned int& pb, unsigned int& pc)
 {
   const int depth = fl[j].depth;
   auto row = [&](int d) -> unsigned int {
     const int k = depth - d - 1;
     const int a = (k >= 0 && k < FLAT_MAXA) ? fl[j].anc[k] : -1;
-    return (unsigned int)(a >= 0 ? a + off : WAVE);
+    return (unsigned int)(a >= 0 ? a + off : WAVE) * 8u;
   };
-  pa = row(1) | (row(2) << 8) | (row(3) << 16);
-  pb = row(4) | (row(8) << 8) | (row(12) << 16);
-  pc = (int)row(16);
+  pa = row(1) | (row(2) << 10) | (row(3) << 20);
+  pb = row(4) | (row(8) << 10) | (row(12) << 20);
+  pc = row(16) | ((unsigned int)(WAVE * 8) << 10) | ((unsigned int)(WAVE * 8) << 20);
 }
 
 // LDS of one wavefront of k_flat2<NA> (doubles): one instance
@@ -286,6 +315,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const int jflags = jd[jl + 1].flags, jcslot = isj_lane ? jd[jl + 1].cslot : -1;
   const T mass = (!isj_lane || (jflags & JF_MASSLESS)) ? T(0) : T(1);
   const T hz = h ? T(0) : T(1);  // scalar-per-joint contributions to sums come from the linear lane only
+  const T hh = T(1) - hz, mha = mass * hh;  // (1 on the angular lanes; the halves' formulas differ by terms multiplied by hz / hh:
+                                            //  a select between two doubles is two v_cndmask, a 0 / 1 factor rides in an FMA)
   constexpr bool HD = HM > 0;  // (H_ref v needs its own subtree sums)
   T hd[3];  // this half's diagonal entries of H_ref (HM = 1; = href_s for HM = 0)
 #pragma unroll
@@ -299,9 +330,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
   bool helper;
   unsigned int jrow4[(FLAT_JMP + 3) / 4];  // load time: rows of the ancestors at distance 2^r in joint-indexed rows (WAVE = identity)
-  unsigned int pathA, pathB;               // iteration: the ancestors at distance 1, 2, 3 / 4, 8, 12: their lanes of this half
-  int pathC;
-  unsigned int ra2[2], part4, anc4[(NH + 3) / 4];
+  unsigned int pathA, pathB, pathC;        // iteration: the ancestors at distance 1, 2, 3 / 4, 8, 12 / 16: byte offsets of their lanes of this half
+  unsigned int ra2[2], part2[2], anc3[(NH + 2) / 3];  // byte offsets into the product / partial / Dinv r' buffers (16 / 16 / 10 bits each)
   {
     const FlatLane F = fl[j];
     size = isj_lane ? F.size : 0;
@@ -311,26 +341,26 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     for (int k = 0; k < (FLAT_JMP + 3) / 4; ++k) jrow4[k] = 0u;
     flat_path_rows4(fl, j, h ? 32 : 0, pathA, pathB, pathC);
 #pragma unroll
-    for (int k = 0; k < (NH + 3) / 4; ++k) anc4[k] = 0u;
+    for (int k = 0; k < (NH + 2) / 3; ++k) anc3[k] = 0u;
 #pragma unroll
     for (int r = 0; r < FLAT_JMP; ++r) {
       jrow4[r >> 2] |= (unsigned int)(F.jmp[r] >= 0 ? F.jmp[r] : WAVE) << (8 * (r & 3));
     }
     // this lane's half of the joint's share of the W tau products, of its partials and of its W entries (k = 2 i + h)
     ra2[0] = ra2[1] = 0u;
-    part4 = 0u;
+    part2[0] = part2[1] = 0u;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int e = h ? F.red[4 + t] : F.red[t];  // (entry k * 32 + lane' of the product buffer: the schedule was built for G = 32)
-      ra2[t >> 1] |= (unsigned int)(e >= 0 ? (e >> 5) * GW + (e & 31) : NA * GW) << (16 * (t & 1));
+      ra2[t >> 1] |= (unsigned int)((e >= 0 ? (e >> 5) * GW + (e & 31) : NA * GW) * 8) << (16 * (t & 1));
       const int p = h ? F.part[4 + t] : F.part[t];
-      part4 |= (unsigned int)(p >= 0 ? p : G) << (8 * t);
+      part2[t >> 1] |= (unsigned int)((p >= 0 ? p : G) * 8) << (16 * (t & 1));
     }
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
       const int a0 = F.anc[2 * i], a1 = (2 * i + 1 < FLAT_MAXA) ? F.anc[2 * i + 1] : -1;
       const int a = h ? a1 : a0;
-      anc4[i >> 2] |= (unsigned int)(a >= 0 ? a : G) << (8 * (i & 3));
+      anc3[i / 3] |= (unsigned int)((a >= 0 ? a : G) * 8) << (10 * (i % 3));
     }
   }
   if (lane < 2) { nbuf[G + lane] = T(0); pbuf[G + lane] = T(0); }
@@ -798,15 +828,13 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T rn;
     {
       T a[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) a[t] = xb[unpack16(ra2, t)];
+      static_for<0, 4>([&](auto t) { a[t] = lds_at(xb, field_here<16 * (t & 1), 16>(ra2[t >> 1])); });
       T acc = (a[0] + a[1]) + (a[2] + a[3]);
       acc = pair_sum(acc);
       if (!h) pbuf[j] = helper ? acc : T(0);
       tail_sync();
       T pp[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) pp[q] = pbuf[(int)((opaque(part4) >> (8 * q)) & 0xFFu)];
+      static_for<0, 4>([&](auto q) { pp[q] = lds_at(pbuf, field_here<16 * (q & 1), 16>(part2[q >> 1])); });
       T ps = (pp[0] + pp[1]) + (pp[2] + pp[3]);
       ps = pair_sum(ps);
       if (helper) acc = T(0);
@@ -821,8 +849,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       // (measured and rejected: these gathers -- and the partial sums above -- from lane to lane through the LDS crossbar,
       //  ds_bpermute, instead of a write, a fence and the reads: one dependent trip less each, and 13.0 -> 13.9 ms)
       T nb_[NH];
-#pragma unroll
-      for (int i = 0; i < NH; ++i) nb_[i] = nbuf[unpack8(anc4, i)];
+      static_for<0, NH>([&](auto i) { nb_[i] = lds_at(nbuf, field_here<10 * (i % 3), 10>(anc3[i / 3])); });
       T acc = T(0);
 #pragma unroll
       for (int i = 0; i < NH; ++i) acc += wc[i] * nb_[i];
@@ -834,7 +861,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       T y[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) y[k] = Sw3[k] * nui;
-      flat_path_sum4<T, 3>(xb, lane, opaque(pathA), opaque(pathB), pathC, njmp, y);
+      flat_path_sum4<T, 3>(xb, lane, pathA, pathB, pathC, njmp, y);
       if (jcslot >= 0) {  // the constrained links' velocities at the world origin: the task constraints' update starts from them
 #pragma unroll
         for (int k = 0; k < 3; ++k) cdi[jcslot * cs + C2_VC + h3 + k] = y[k];
@@ -850,8 +877,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       cross3(t0, El, c2);
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        X[k] = h ? ang[k] : El[k];
-        E3[k] = mass * (h ? ang[k] + c2[k] : El[k]);
+        X[k] = y[k] - hz * c1[k];               // linear lane: El; angular lane: its own half, ang
+        E3[k] = mass * X[k] + mha * c2[k];      // mass * (El | ang + t0 x El)
       }
       mat3t_vec(R0, X, vi3);  // SE3::actInv(Motion): (R^T (v_l - t x v_a), R^T v_a)
     }
@@ -922,7 +949,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
           for (int k = 0; k < 3; ++k) both_halves(y3[k], L3[k], A3[k]);
           cross3(t0, L3, cc);
 #pragma unroll
-          for (int k = 0; k < 3; ++k) { E2[k] = h ? y3[k] + cc[k] : y3[k]; P2[k] = prefix32(E2[k]); }
+          for (int k = 0; k < 3; ++k) { E2[k] = y3[k] + hh * cc[k]; P2[k] = prefix32(E2[k]); }
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) xb[lane * 3 + c] = Pk[c];
@@ -1018,7 +1045,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         for (int k = 0; k < 3; ++k) both_halves(Fw[k], Fl[k], Fa[k]);
         cross3(t0, Fl, cc);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) X[k] = h ? Fw[k] - cc[k] : Fw[k];
+        for (int k = 0; k < 3; ++k) X[k] = Fw[k] - hh * cc[k];
         mat3t_vec(R0, X, fi3);
       }
       {
@@ -1221,8 +1248,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
   bool helper;
   unsigned int jrow4[(FLAT_JMP + 3) / 4], ra2[FLAT_RED / 2], prow4[(FLAT_PART + 3) / 4], anc4[(NA + 3) / 4];
-  unsigned int pathA, pathB;
-  int pathC;
+  unsigned int pathA, pathB, pathC;
   flat_path_rows4(fl, j, 0, pathA, pathB, pathC);
   {
     const FlatLane F = fl[j];
@@ -1240,7 +1266,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
     for (int r = 0; r < FLAT_JMP; ++r) jrow4[r >> 2] |= (unsigned int)(F.jmp[r] >= 0 ? F.jmp[r] : WAVE) << (8 * (r & 3));
 #pragma unroll
-    for (int t = 0; t < FLAT_RED; ++t) ra2[t >> 1] |= (unsigned int)(F.red[t] >= 0 ? F.red[t] : NA * G) << (16 * (t & 1));
+    for (int t = 0; t < FLAT_RED; ++t) ra2[t >> 1] |= (unsigned int)((F.red[t] >= 0 ? F.red[t] : NA * G) * 8) << (16 * (t & 1));  // (byte offsets)
 #pragma unroll
     for (int q = 0; q < FLAT_PART; ++q) prow4[q >> 2] |= (unsigned int)(F.part[q] >= 0 ? F.part[q] : WAVE) << (8 * (q & 3));
 #pragma unroll
@@ -1634,14 +1660,12 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T rn;
     {
       T a[FLAT_RED];
-#pragma unroll
-      for (int t = 0; t < FLAT_RED; ++t) a[t] = xb[unpack16(ra2, t)];
+      static_for<0, FLAT_RED>([&](auto t) { a[t] = lds_at(xb, field_here<16 * (t & 1), 16>(ra2[t >> 1])); });
       T acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
       pbuf[lane] = helper ? acc : T(0);
       tail_sync();
       T pp[FLAT_PART];
-#pragma unroll
-      for (int q = 0; q < FLAT_PART; ++q) pp[q] = pbuf[unpack8(prow4, q)];
+      static_for<0, FLAT_PART>([&](auto q) { pp[q] = pbuf[field_here<8 * (q & 3), 8>(prow4[q >> 2])]; });
       if (helper) acc = T(0);
 #pragma unroll
       for (int q = 0; q < FLAT_PART; ++q) acc += pp[q];
@@ -1654,8 +1678,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T nui;
     {
       T nb_[NA];
-#pragma unroll
-      for (int k = 0; k < NA; ++k) nb_[k] = nbuf[unpack8(anc4, k)];
+      static_for<0, NA>([&](auto k) { nb_[k] = nbuf[field_here<8 * (k & 3), 8>(anc4[k >> 2])]; });
       T acc = dinv * rn;
 #pragma unroll
       for (int k = 0; k < NA; ++k) acc += wc[k] * nb_[k];
@@ -1667,7 +1690,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       T vw[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) vw[k] = Sw[k] * nui;
-      flat_path_sum4<T, 6>(xb, lane, opaque(pathA), opaque(pathB), pathC, njmp, vw);
+      flat_path_sum4<T, 6>(xb, lane, pathA, pathB, pathC, njmp, vw);
       if (jcslot >= 0) {  // the constrained links' velocities at the world origin: the task constraints' update starts from them
 #pragma unroll
         for (int k = 0; k < 6; ++k) cdi[jcslot * cs + C2_VC + k] = vw[k];
