@@ -468,12 +468,17 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       atomicAdd(&Bf.counters[LEAN_Q_REQUEUES], 1u);
     }
   };
+#ifdef LOIKB_TAIL_PROF
+  unsigned long long prof_[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
+  const unsigned long long wall0_ = wall_clock64(), clk0_ = tprev_;
+#endif
   int next_slot = -2;  // (plain queue) the entry store_instance fetched while its stores were in flight; -2: none
   auto load_instance = [&]() {
     const int slot_in = (!SLICED && next_slot != -2) ? next_slot : fetch();
     next_slot = -2;
     has_inst = slot_in >= 0;
     if (!has_inst) return;
+    TAIL_TP(12)
     isj = isj_lane;
     const int slot = slot_in;
     lidx = slot;
@@ -536,7 +541,9 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       w = z = nu = s = T(0);
       lbi = ubi = T(0);
     }
+    TAIL_TP(13)
     flat_world_placement<T>(xb, j, j, jrow4, njmp, R0, t0);  // ... -> oMi (FwdPassInit's oMi chain, hxx:265)
+    TAIL_TP(14)
     {
       T ra3[3], c[3];
       mat3_vec(R0, ax, ra3);
@@ -607,6 +614,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       ccb[C2_DLT + k] = resumed ? T(0) : at - ccb[C2_ATY + k];
       if (resumed) ccb[C2_ATYW + k] = aw;  // (what the loop had left there)
     }
+    TAIL_TP(15)
     // subtree sums of the state the instance arrives with (cold start: v = 0) and of the reference term
     {
       T vw[6], E[6];
@@ -664,6 +672,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     tail_sync();
     my_iters = 0;
     any_iter = false;
+    TAIL_TP(16)
   };
   bool requeue = false;  // (SLICED) the instance goes back to the queue, to be continued by whichever wavefront takes it
   auto store_instance = [&]() {
@@ -731,12 +740,9 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       next_slot = nx < nslots ? ring[nx] : -1;
     }
     tail_sync();
+    TAIL_TP(19)
   };
 
-#ifdef LOIKB_TAIL_PROF
-  unsigned long long prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
-  const unsigned long long wall0_ = wall_clock64(), clk0_ = tprev_;
-#endif
   // (two loops: everything only the load / store of an instance needs lives across the inner loop without being touched in it,
   //  so the register allocator can park it around the loop instead of in it)
   while (true) {
@@ -784,6 +790,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
           kslot = kexp;
           n_slot_loads = (n_slot_loads + 0x10000u) | (1u << dsl);
           tail_sync();
+          TAIL_TP(17)
         }
       }
     }
@@ -1081,6 +1088,18 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       T in[4] = {hmax(l_prt, l_prs), hmax(l_dualv, l_stf), hmax(l_dfis, hmax(l_dyis, l_dw)), hmax(l_dg, l_dstf)}, r[4];
       wave_fold4<0u>(lane, in, r);
       primal = r[0]; dual = r[1]; dyqp = r[2]; atdy = r[3];
+      if (P.tol_rel == T(0)) {
+        // The common iteration decides nothing: not converged, the certificate's first test fails, mu stays where it is, not the
+        // last iteration.  Five compares side by side and ONE branch; the stopping logic below is a chain of ~30 dependent
+        // compare -> mask -> branch steps (900 cycles of a lone wavefront's 5400 per iteration) that only the other iterations walk.
+        const bool quiet = !((primal < P.tol_abs) & (dual < P.tol_abs)) & !((iter > 0) & (atdy <= P.tol_primal_inf * dyqp)) &
+                           !(primal > T(10) * dual) & !(dual > T(10) * primal) & (iter + 2 < P.max_iter);
+        if (quiet) {
+          ++iter;
+          TAIL_TP(7)
+          continue;
+        }
+      }
     }
     T ntol_p = T(0), ntol_d = T(0);
     if (P.tol_rel != T(0)) {  // (uniform) relative tolerances need two more maxima
@@ -1147,6 +1166,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         for (int k = 0; k < 5; ++k) isc[FI_RED + 8 + k] = r2[k];
       }
       tail_sync();
+      TAIL_TP(18)
       break;
     }
     TAIL_TP(7)
@@ -1160,7 +1180,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #ifdef LOIKB_TAIL_PROF
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     for (int k = 0; k < 8; ++k) g_tail_prof[k] = prof_[k];
-    for (int k = 8; k < 12; ++k) g_tail_prof[2 + k] = prof_[k];
+    for (int k = 8; k < 20; ++k) g_tail_prof[2 + k] = prof_[k];
     g_tail_prof[8] = n_wave_iters;
     g_tail_prof[9] = (clock64() - clk0_) * 100000ull / (wall_clock64() - wall0_ + 1);
   }
@@ -1857,6 +1877,17 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       T in[4] = {hmax(l_prt, l_prs), hmax(l_dualv, l_stf), hmax(l_dfis, hmax(l_dyis, l_dw)), hmax(l_dg, l_dstf)}, r[4];
       wave_fold4<0u>(lane, in, r);
       primal = r[0]; dual = r[1]; dyqp = r[2]; atdy = r[3];
+      if (P.tol_rel == T(0)) {
+        // The common iteration decides nothing: not converged, the certificate's first test fails, mu stays where it is, not the
+        // last iteration.  Five compares side by side and ONE branch; the stopping logic below is a chain of ~30 dependent
+        // compare -> mask -> branch steps (900 cycles of a lone wavefront's 5400 per iteration) that only the other iterations walk.
+        const bool quiet = !((primal < P.tol_abs) & (dual < P.tol_abs)) & !((iter > 0) & (atdy <= P.tol_primal_inf * dyqp)) &
+                           !(primal > T(10) * dual) & !(dual > T(10) * primal) & (iter + 2 < P.max_iter);
+        if (quiet) {
+          ++iter;
+          continue;
+        }
+      }
     }
     T ntol_p = T(0), ntol_d = T(0);
     if (P.tol_rel != T(0)) {  // (uniform) relative tolerances need two more maxima

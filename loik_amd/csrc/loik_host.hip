@@ -3249,7 +3249,7 @@ int loikb_debug_wave_dbg(unsigned long long* out)
 }
 int loikb_debug_tail_prof(unsigned long long* out)
 {
-  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(loikb::g_tail_prof), sizeof(unsigned long long) * 14));
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(loikb::g_tail_prof), sizeof(unsigned long long) * 32));
   return LOIKB_OK;
 }
 #endif

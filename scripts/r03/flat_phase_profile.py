@@ -10,7 +10,10 @@ NAMES = {8: "loop top + decade slot change", 0: "p^base sums, tau", 1: "r' = W t
          6: "norm fold", 7: "epilogue + instance switch", 9: "  task: v -> LDS, A v - b, y (two fences)", 10: "  subtree prefix sums of E (DPP) + exchange",
          11: "  task: A^T y, A^T dy at the origin (two fences)"}
 NAMES[4] = "  per-joint work on v, nu (box, w, g, norms)"
-ORDER = [8, 0, 1, 2, 9, 10, 11, 4, 5, 3, 6, 7]
+NAMES.update({12: "instance: ticket, list entry", 13: "instance: record loads, joint placement", 14: "instance: world placements (pointer jumping)",
+              15: "instance: constraint blocks at the origin", 16: "instance: subtree sums, scalars", 17: "decade slot loads (HBM)",
+              18: "stop: the getters' folds", 19: "instance: store"})
+ORDER = [8, 0, 1, 2, 9, 10, 11, 4, 5, 3, 6, 7, 12, 13, 14, 15, 16, 17, 18, 19]
 for B in [int(x) for x in sys.argv[1:]] or [64, 65536]:
     wl = workloads.talos_c3(B, seed=5)
     prm = dict(wl["params"])
@@ -19,7 +22,7 @@ for B in [int(x) for x in sys.argv[1:]] or [64, 65536]:
     for _ in range(2):
         s.Solve()
     st = s.stats()
-    out = (C.c_ulonglong * 14)()
+    out = (C.c_ulonglong * 32)()
     assert L.loikb_debug_tail_prof(out) == 0
     n = out[8]
     idx = lambda k: k if k < 8 else 2 + k
