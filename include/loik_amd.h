@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LOIKB_VERSION 305  /* round.minor: bumped whenever a struct or an entry point of this header changes */
+#define LOIKB_VERSION 401  /* round.minor: bumped whenever a struct or an entry point of this header changes */
 
 /* ---- status codes -------------------------------------------------------------------------------- */
 enum {
@@ -76,6 +76,13 @@ enum {
                                  repack when at most 85 % of the slots are still iterating; results are
                                  bit-identical, but the inter-sweep temporaries His/pis/UDinv/Dinv/r of
                                  instances that moved are not retrievable afterwards)                         */
+  LOIKB_OPT_ORDER_FROM_PREVIOUS = 32, /* The on-chip engines hand a handle's instances out longest first, by the iteration counts
+                                 its previous solve had -- by default only while the inputs are the ones those counts were taken
+                                 on (Solve() again: the counts are exact).  With this flag also after SolveInit / a tailored solve /
+                                 UpdateEqConstraint / integrate changed them: for callers whose consecutive problems resemble each
+                                 other (a planner tracking a slowly moving target).  The handle compares such launches with its
+                                 last arrival-order launch and goes back to arrival order for a few solves when they are no shorter.
+                                 The order only decides WHEN an instance runs: results are bit-identical either way.          */
   LOIKB_OPT_F32_ACCURATE = 16 /* LOIKB_F32 only (no fp32 exists upstream: src/loik-loid-optimized.cpp:10-13): the accuracy
                                  contract |z_f32 - z_f64|_inf <= tol_abs for 99 % of the instances that converge in both,
                                  for tol_abs >= 1e-3 (below that single precision does not resolve D_i = S^T H S + mu once mu

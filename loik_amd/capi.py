@@ -52,11 +52,11 @@ class Stats(C.Structure):
                 ("flat_split_launches", C.c_int), ("flat_ordered", C.c_int)]
 
 
-ABI_VERSION = 305   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
+ABI_VERSION = 401   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
 
 # enums of loik_amd.h
 F64, F32 = 0, 1
-OPT_FIXED_ITERS, OPT_NO_H_CACHE, OPT_NO_COMPACTION, OPT_OWN_STREAM, OPT_F32_ACCURATE = 1, 2, 4, 8, 16
+OPT_FIXED_ITERS, OPT_NO_H_CACHE, OPT_NO_COMPACTION, OPT_OWN_STREAM, OPT_F32_ACCURATE, OPT_ORDER_FROM_PREVIOUS = 1, 2, 4, 8, 16, 32
 IN_DEVICE, A_SHARED, BOUNDS_SHARED, B_SHARED, Q_SHARED = 1, 2, 4, 8, 16
 OUT_DEVICE = 1
 

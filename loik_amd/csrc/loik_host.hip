@@ -235,6 +235,7 @@ struct loikb_solver_impl {
     int* d_order = nullptr;              // the chunk's instances, longest first by the iteration counts of the previous solve
     unsigned int* d_order_bins = nullptr;  // [2 ORDER_BINS] counts / offsets of the counting sort
     int order_n = 0;                     // instances d_order lists (0: none yet)
+    unsigned long long order_epoch = 0;  // S->inputs_epoch of the solve whose iteration counts d_order sorts
     int order_holdoff = 0;               // solves to go in arrival order after an order that predicted badly
     int arrival_n = 0;                   // the flat engine's last launch in arrival order: instances, ...
     double arrival_ms = 0.0;             // ... its duration (0: none yet)
@@ -257,6 +258,12 @@ struct loikb_solver_impl {
   // pass-level debug path (loik_passes.hpp): the data object of the reference, field by field, per instance
   bool pass_active = false;
   bool zero_state = false;   // the solve in progress began with a reset that zeroed vis, fis, g, w, z of every instance
+  // Anything that changes what a solve computes (SolveInit, a tailored solve's q / constraint, UpdateEqConstraint, UpdateReferences,
+  // Add / RemoveEqConstraint, integrate, the setters) bumps this.  A handle's later solves are taken longest first by the previous
+  // solve's iteration counts only when those counts were taken on THESE inputs (a cold Solve() of the same problem is
+  // deterministic: the counts are exact) -- or when the caller says that consecutive problems resemble each other
+  // (LOIKB_OPT_ORDER_FROM_PREVIOUS: a tracking planner), and then under the watch of the timing comparison below.
+  unsigned long long inputs_epoch = 1;
   PassLayout PL{};
   double* d_pass = nullptr;
   int* d_pass_cslot = nullptr;
@@ -939,6 +946,7 @@ int upload_jd(loikb_solver_impl* S)
 // FwdPassInit(q), loik-loid-optimized.hxx:253-283.  q == nullptr: the configurations already resident on the device
 int fwd_pass_init(loikb_solver_impl* S, const double* q, int in_flags)
 {
+  ++S->inputs_epoch;
   if (q) {
     const bool shared = in_flags & LOIKB_Q_SHARED;
     const bool dev = (in_flags & LOIKB_IN_DEVICE) && !shared;
@@ -1297,6 +1305,7 @@ int null_constraint_slots(loikb_solver_impl* S, int c_lo, int c_hi)
 // :224-238, which keeps the old Ai
 int update_eq_single(loikb_solver_impl* S, int c_id, const double* Ai, const double* bi, int in_flags)
 {
+  ++S->inputs_epoch;
   int found = -1, count = 0;
   for (int c = 0; c < S->nc_active; ++c)
     if (S->active_ids[c] == c_id) { if (found < 0) found = c; ++count; }
@@ -1327,6 +1336,7 @@ int update_eq_single(loikb_solver_impl* S, int c_id, const double* Ai, const dou
 int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, const int* c_ids, int nc,
                 const double* Ais, const double* bis, const double* lb, const double* ub, int nbound, int in_flags)
 {
+  ++S->inputs_epoch;
   if (nbound != S->nv) { g_last_error = "lb/ub dimension differs from model.nv"; return LOIKB_ERR_INEQ_DIM; }
   if (nc != S->nc_active) { g_last_error = "number of equality constraints doesn't match initialization"; return LOIKB_ERR_EQ_C_SIZE; }
   if (!symmetric6(H_ref)) { g_last_error = "H_ref must be symmetric"; return LOIKB_ERR_HREF_NOT_SYMMETRIC; }
@@ -1466,6 +1476,18 @@ int lean_waves_per_cu(const loikb_solver_impl* S)
   while (G < S->nb) G <<= 1;
   const size_t per_wave = S->f32 ? lean_lds_bytes<float>(S->nc, G, S->a_shared) : lean_lds_bytes<double>(S->nc, G, S->a_shared);
   return (int)std::min<size_t>(8, (160 * 1024) / per_wave);
+}
+
+// May this launch take the set in the order the handle's previous solve left (k_order_*)?  Yes when the iteration counts were taken
+// on the inputs this solve has (exact: a cold Solve() of the same problem repeats itself); when the inputs changed since, only for a
+// caller that declared consecutive problems alike (LOIKB_OPT_ORDER_FROM_PREVIOUS), and then subject to the hold-off the timing
+// comparison sets -- a stale order that predicts nothing is arrival order with the long runners in random places, a few per cent
+// slower than arrival order itself.
+static bool order_usable(const loikb_solver_impl* S, const Chunk* C, int n_cur)
+{
+  if (!S->tune.flat_order || C->order_n != n_cur || (S->opt.flags & LOIKB_OPT_OWN_STREAM)) return false;
+  if (C->order_epoch == S->inputs_epoch) return true;
+  return (S->opt.flags & LOIKB_OPT_ORDER_FROM_PREVIOUS) && C->order_holdoff == 0;
 }
 
 // THE engine dispatch: (nb, nc, A shared?, children per joint, precision, options, tuning) -> plan.  Called from
@@ -1634,8 +1656,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
       // longest first: the order the previous solve of this handle left (k_order_*, loik_lean.hpp) when this launch takes the same
       // whole set; the decade slots are indexed by the position in the list, so k_fslots and the engine see the same one
-      const bool ordered = S->tune.flat_order && whole_set && list == C->d_slots && n == n_cur && C->order_n == n_cur &&
-                           C->order_holdoff == 0 && (split || one) && !(S->opt.flags & LOIKB_OPT_OWN_STREAM);
+      const bool ordered = whole_set && list == C->d_slots && n == n_cur && (split || one) && order_usable(S, C, n_cur);
+      const bool order_was_stale = ordered && C->order_epoch != S->inputs_epoch;
       if (C->order_holdoff > 0) --C->order_holdoff;
       if (ordered) HIPCHK(hipMemcpyAsync(C->d_slots, C->d_order, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, C->stream));
       C->stats.flat_ordered += ordered ? 1 : 0;
@@ -1678,9 +1700,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           // (an ordered launch runs to completion: its long runners start first and must not go to the back of the queue.  Time
           //  slices for everything behind the predicted-long prefix were tried: the SLICED build's agent-scope loads / stores of
           //  the records cost the short instances more than the slices bring -- 12.2 ms against 10.6)
-          const int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice : ordered ? 0
-                              : (n_first >= 12 * resident && n_first <= 96 * resident && (int)grid.x == per_cu * (int)(cu_sh + 0.5) &&
-                                 !(S->opt.flags & LOIKB_OPT_OWN_STREAM)) ? 160 : 0;
+          // (round 4: off by default.  With the iteration at 2.9 instead of 3.6 us the switch -- ~410 scattered agent-scope stores, ~90
+          //  loads and the set-up again -- costs more than the slices bring: headline in arrival order 10.7 ms without, 11.2 / 11.4 /
+          //  11.4 / 11.7 / 13.1 ms with slices of 256 / 160 / 128 / 96 / 64.  LOIKB_FLAT_SLICE=q switches it on.)
+          (void)resident;
+          const int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice : 0;
           // (not for a handle on a stream of its own: that is how batches are kept in flight side by side, and then the other
           //  batch's bulk fills this one's ragged end -- slicing only adds its switches, and its wavefronts that wait for queue
           //  entries hold slots the other launch could use: two headline batches in flight 21.5 ms per pair without, 24.9 with)
@@ -1707,9 +1731,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           grid = dim3((unsigned)std::min(n, per_cu1 * (int)(cu_sh + 0.5)));
           // (time slicing as in k_flat2, same window: whole body, four tasks, B = 65 536: 34.7 ms without)
           const int resident = (int)grid.x, full = per_cu1 * (int)(cu_sh + 0.5);
-          const int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice : ordered ? 0
-                              : (n_first >= 12 * resident && n_first <= 96 * resident && resident == full &&
-                                 !(S->opt.flags & LOIKB_OPT_OWN_STREAM)) ? 160 : 0;
+          (void)resident; (void)full;
+          const int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice : 0;  // (off by default since round 4: see k_flat2's launch)
 #define LOIKB_LAUNCH_FLAT1(NAV, ...)                                                                                            \
   hipLaunchKernelGGL((k_flat1<NAV, ##__VA_ARGS__>), grid, dim3(WAVE), lds1, C->stream,                                          \
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
@@ -1765,6 +1788,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         hipLaunchKernelGGL(k_order_scatter<T>, grid1(n_cur), dim3(256), 0, C->stream, A.tiles, S->L, n_cur, S->opt.max_iter, C->d_order_bins, C->d_order);
         HIPCHK(hipGetLastError());
         C->order_n = n_cur;
+        C->order_epoch = S->inputs_epoch;
       }
       HIPCHK(hipStreamSynchronize(C->stream));
       float ms = 0.f, t0 = 0.f, hms = 0.f;
@@ -1795,7 +1819,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         const double flat_ms = (double)ms - (double)hms;
         if (C->arrival_n != n_cur) { C->arrival_n = n_cur; C->arrival_ms = 0.0; }
         if (!ordered) C->arrival_ms = flat_ms;
-        else if (C->arrival_ms > 0.0 && flat_ms > 0.985 * C->arrival_ms) C->order_holdoff = S->tune.flat_order_holdoff;
+        else if (order_was_stale && C->arrival_ms > 0.0 && flat_ms > 0.985 * C->arrival_ms) C->order_holdoff = S->tune.flat_order_holdoff;
       }
       if (trace)
         fprintf(stderr, "[loikb] flat engine: %6d instances on %u workgroups, done at %8.3f ms (slots %6.3f ms)  "
@@ -1847,8 +1871,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
       // longest first, as in the flat engine: the order the handle's previous solve left, for a single whole-set launch that is not
       // time-sliced (the decade slots are indexed by the instance: k_hslots and k_lean see the same list)
-      const bool lean_ordered = S->tune.flat_order && whole_set && list == C->d_slots && n == n_cur && C->order_n == n_cur &&
-                                C->order_holdoff == 0 && quanta.size() == 1 && lean_quantum == 0 && !(S->opt.flags & LOIKB_OPT_OWN_STREAM);
+      const bool lean_ordered = whole_set && list == C->d_slots && n == n_cur && quanta.size() == 1 && lean_quantum == 0 && order_usable(S, C, n_cur);
+      const bool lean_order_was_stale = lean_ordered && C->order_epoch != S->inputs_epoch;
       if (whole_set && C->order_holdoff > 0) --C->order_holdoff;
       if (lean_ordered) HIPCHK(hipMemcpyAsync(C->d_slots, C->d_order, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, C->stream));
       C->stats.flat_ordered += lean_ordered ? 1 : 0;
@@ -1908,6 +1932,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           hipLaunchKernelGGL(k_order_scatter<T>, grid1(n_cur), dim3(256), 0, C->stream, A.tiles, S->L, n_cur, S->opt.max_iter, C->d_order_bins, C->d_order);
           HIPCHK(hipGetLastError());
           C->order_n = n_cur;
+          C->order_epoch = S->inputs_epoch;
         }
         HIPCHK(hipStreamSynchronize(C->stream));
         float ms = 0.f, t0 = 0.f;
@@ -1915,7 +1940,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         if (lean_orders) {  // (held off like the flat engine's: compared with the handle's last launch in arrival order)
           if (C->arrival_n != n_cur) { C->arrival_n = n_cur; C->arrival_ms = 0.0; }
           if (!lean_ordered) C->arrival_ms = (double)ms;
-          else if (C->arrival_ms > 0.0 && (double)ms > 0.985 * C->arrival_ms) C->order_holdoff = S->tune.flat_order_holdoff;
+          else if (lean_order_was_stale && C->arrival_ms > 0.0 && (double)ms > 0.985 * C->arrival_ms) C->order_holdoff = S->tune.flat_order_holdoff;
         }
         if (t_first < 0.f) { HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0)); t_first = t0; }
         iters += C->h_counters[1];
@@ -1962,7 +1987,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     // previous solve, as in the flat and lean engines (its lane groups pull the list in order)
     const bool tail_whole = whole_set && list == C->d_slots && n == n_cur && !(S->opt.flags & (LOIKB_OPT_OWN_STREAM | LOIKB_OPT_FIXED_ITERS)) &&
                             S->tune.flat_order;
-    const bool tail_ordered = tail_whole && C->order_n == n_cur && C->order_holdoff == 0;
+    const bool tail_ordered = tail_whole && order_usable(S, C, n_cur);
+    const bool tail_order_was_stale = tail_ordered && C->order_epoch != S->inputs_epoch;
     if (tail_whole && C->order_holdoff > 0) --C->order_holdoff;
     if (tail_ordered) HIPCHK(hipMemcpyAsync(C->d_slots, C->d_order, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, C->stream));
     C->stats.flat_ordered += tail_ordered ? 1 : 0;
@@ -1984,6 +2010,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       hipLaunchKernelGGL(k_order_scatter<T>, grid1(n_cur), dim3(256), 0, C->stream, A.tiles, S->L, n_cur, S->opt.max_iter, C->d_order_bins, C->d_order);
       HIPCHK(hipGetLastError());
       C->order_n = n_cur;
+      C->order_epoch = S->inputs_epoch;
     }
     HIPCHK(hipStreamSynchronize(C->stream));
     float ms = 0.f, t0 = 0.f;
@@ -1992,7 +2019,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     if (tail_whole) {
       if (C->arrival_n != n_cur) { C->arrival_n = n_cur; C->arrival_ms = 0.0; }
       if (!tail_ordered) C->arrival_ms = (double)ms;
-      else if (C->arrival_ms > 0.0 && (double)ms > 0.985 * C->arrival_ms) C->order_holdoff = S->tune.flat_order_holdoff;
+      else if (tail_order_was_stale && C->arrival_ms > 0.0 && (double)ms > 0.985 * C->arrival_ms) C->order_holdoff = S->tune.flat_order_holdoff;
     }
     C->tail_iv.emplace_back(t0, t0 + ms);
     total_ms += ms;
@@ -2601,6 +2628,7 @@ int loikb_update_references(loikb_solver* S, const double* H_refs, const double*
     if (!symmetric6(H_refs + 36 * e)) { g_last_error = "H_refs[i] must be symmetric"; return LOIKB_ERR_HREF_NOT_SYMMETRIC; }
   HIPCHK(hipSetDevice(S->device));
   HIPCHK(hipStreamSynchronize(S->stream));
+  ++S->inputs_epoch;
   fill_href_tab(S, H_refs, v_refs, 36, 6);
   // Hv_inf_norm_ is not reset here and the universe's entry counts (hpp:110-118: the loop runs over all nj entries)
   S->href_diag = true;
@@ -2684,6 +2712,7 @@ int loikb_add_eq_constraint(loikb_solver* S, int c_id, const double* Ai, const d
     return LOIKB_ERR_EQ_C_SIZE;
   }
   HIPCHK(hipSetDevice(S->device));
+  ++S->inputs_epoch;
   int rc;
   const int k = S->nc_active;
   if ((rc = null_constraint_slots(S, k, k + 1))) return rc;  // the new constraint's dual starts at zero
@@ -2711,6 +2740,7 @@ int loikb_remove_eq_constraint(loikb_solver* S, int c_id)
     return LOIKB_NOTHING_TO_REMOVE;
   }
   HIPCHK(hipSetDevice(S->device));
+  ++S->inputs_epoch;
   int rc;
   // the entries behind it move down with their duals; the freed last slot becomes a null constraint
   if ((rc = edit_constraints(S, found, S->nc_active, 1))) return rc;
@@ -2741,6 +2771,7 @@ int loikb_integrate(loikb_solver* S, double dt)
 {
   if (!S) return LOIKB_ERR_ARG;
   if (!S->have_q) { g_last_error = "integrate: no configurations resident on the device yet"; return LOIKB_ERR_STATE; }
+  ++S->inputs_epoch;
   HIPCHK(hipSetDevice(S->device));
   if (S->f32)
     hipLaunchKernelGGL(k_advance_q<float>, grid1(S->B), dim3(256), 0, S->stream, S->d_q, (const double*)nullptr, 0, S->nq,
@@ -3011,11 +3042,12 @@ static int pass_get(loikb_solver_impl* S, int field, void* out, bool to_dev)
   return LOIKB_OK;
 }
 
-int loikb_set_max_iter(loikb_solver* S, int v) { if (!S) return LOIKB_ERR_ARG; S->opt.max_iter = v; return LOIKB_OK; }
+int loikb_set_max_iter(loikb_solver* S, int v) { if (!S) return LOIKB_ERR_ARG; S->opt.max_iter = v; ++S->inputs_epoch; return LOIKB_OK; }
 int loikb_set_rho(loikb_solver* S, double v)
 {
   if (!S) return LOIKB_ERR_ARG;
   S->opt.rho = v;
+  ++S->inputs_epoch;
   HIPCHK(hipSetDevice(S->device));
   return reset_home(S, RS_HCACHE);
 }
@@ -3023,6 +3055,7 @@ int loikb_set_mu(loikb_solver* S, double v)
 {
   if (!S) return LOIKB_ERR_ARG;
   S->opt.mu = v;
+  ++S->inputs_epoch;
   S->seen_lo = 1 << 20; S->seen_hi = -(1 << 20);  // the decades are counted from mu0: the history no longer applies
   return LOIKB_OK;
 }
@@ -3030,11 +3063,12 @@ int loikb_set_tol(loikb_solver* S, double a, double r)
 {
   if (!S) return LOIKB_ERR_ARG;
   S->opt.tol_abs = a; S->opt.tol_rel = r;
+  ++S->inputs_epoch;
   return LOIKB_OK;
 }
-int loikb_set_tol_primal_inf(loikb_solver* S, double v) { if (!S) return LOIKB_ERR_ARG; S->opt.tol_primal_inf = v; return LOIKB_OK; }
-int loikb_set_tol_tail_solve(loikb_solver* S, double v) { if (!S) return LOIKB_ERR_ARG; S->opt.tol_tail_solve = v; return LOIKB_OK; }
-int loikb_set_warm_start(loikb_solver* S, int v) { if (!S) return LOIKB_ERR_ARG; S->opt.warm_start = v; return LOIKB_OK; }
+int loikb_set_tol_primal_inf(loikb_solver* S, double v) { if (!S) return LOIKB_ERR_ARG; S->opt.tol_primal_inf = v; ++S->inputs_epoch; return LOIKB_OK; }
+int loikb_set_tol_tail_solve(loikb_solver* S, double v) { if (!S) return LOIKB_ERR_ARG; S->opt.tol_tail_solve = v; ++S->inputs_epoch; return LOIKB_OK; }
+int loikb_set_warm_start(loikb_solver* S, int v) { if (!S) return LOIKB_ERR_ARG; S->opt.warm_start = v; ++S->inputs_epoch; return LOIKB_OK; }
 
 int loikb_batch(const loikb_solver* S) { return S ? S->B : 0; }
 int loikb_nv(const loikb_solver* S) { return S ? S->nv : 0; }

@@ -39,15 +39,30 @@ for k, d in tot.items():
     if "SQ_ACTIVE_INST_LDS" in d and d["SQ_ACTIVE_INST_LDS"] > 0 and "SQ_LDS_BANK_CONFLICT" in d:
         e["lds_bank_conflict_frac"] = d["SQ_LDS_BANK_CONFLICT"] / d["SQ_ACTIVE_INST_LDS"]
     out["kernels"][k] = e
-# wavefront-iterations of the lean kernel of one step, when the bench line of the same tag is there
+# per DISPATCH figures (the bench's default line runs W + K handles, each with one history solve before its timed one: dispatches
+# per "step" of the profiled command is not 1) and instructions per instance-iteration of the dominant kernel
+for k, e in out["kernels"].items():
+    n = max(e.get("dispatches_per_step", 1.0) * nsolves, 1.0)
+    for src, dst in (("fetch_bytes_per_step", "fetch_bytes_per_dispatch"), ("write_bytes_per_step", "write_bytes_per_dispatch"),
+                     ("valu_insts_per_step", "valu_insts_per_dispatch"), ("lds_insts_per_step", "lds_insts_per_dispatch"),
+                     ("salu_insts_per_step", "salu_insts_per_dispatch")):
+        if src in e:
+            e[dst] = e[src] * nsolves / n
 try:
     line = json.loads(open(os.path.join(out_dir, "bench_line.json")).read().strip().splitlines()[-1])
     out["bench_ms_per_step"] = line["ms_per_step"]
-    out["instance_iterations_per_step"] = line["roofline"]["units_per_launch"] * line["roofline"]["launches_per_step"]
+    out["instance_iterations_per_launch"] = line["roofline"]["units_per_launch"]
     kl = out["kernels"].get(line["roofline"]["kernel"])
-    if kl and "valu_insts_per_step" in kl:
-        # two instances per wavefront on Talos (a 32-lane group each): wavefront-iterations ~ instance-iterations / 2 at full packing
-        kl["valu_insts_per_instance_iteration"] = kl["valu_insts_per_step"] / out["instance_iterations_per_step"]
+    if kl and "valu_insts_per_dispatch" in kl:
+        kl["valu_insts_per_instance_iteration"] = kl["valu_insts_per_dispatch"] / out["instance_iterations_per_launch"]
+        if "lds_insts_per_dispatch" in kl:
+            kl["lds_insts_per_instance_iteration"] = kl["lds_insts_per_dispatch"] / out["instance_iterations_per_launch"]
 except Exception as e:  # noqa: BLE001
     out["bench_line_note"] = "no bench line: %r" % (e,)
+try:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out["csrc_sha16"] = bench.csrc_sha16()
+except Exception as e:  # noqa: BLE001
+    out["csrc_sha16"] = None
 print(json.dumps(out, indent=1))

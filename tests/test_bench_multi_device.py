@@ -66,7 +66,7 @@ def _run(argv, capsys, ndev=2):
 
 def test_gpus_2_weak_runs_two_devices_in_one_process(capsys, monkeypatch):
     monkeypatch.delenv("WORLD_SIZE", raising=False)
-    line = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "24", "--no-cpu-baseline"], capsys)
+    line = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "24", "--no-cpu-baseline", "--repeat-batch"], capsys)
     weak = sorted(CREATED[:2], key=lambda s: s.device)   # (the shards are constructed concurrently, each on its own thread)
     assert [s.device for s in weak] == [0, 1] and all(s.B == 24 for s in weak)
     assert weak[0].thread != weak[1].thread          # one host thread per device
@@ -93,12 +93,30 @@ def test_gpus_2_weak_runs_two_devices_in_one_process(capsys, monkeypatch):
 
 def test_gpus_1_and_strong_flag(capsys, monkeypatch):
     monkeypatch.delenv("WORLD_SIZE", raising=False)
-    line = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--batch", "16", "--no-cpu-baseline"], capsys, ndev=1)
+    line = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--batch", "16", "--no-cpu-baseline", "--repeat-batch"], capsys, ndev=1)
     assert line["n_gpus"] == 1 and "strong_scaling" not in line and len(CREATED) == 1
     line = _run(["--gpus", "4", "--steps", "1", "--warmup", "0", "--batch", "32", "--scaling", "strong",
-                 "--no-cpu-baseline"], capsys, ndev=4)
+                 "--no-cpu-baseline", "--repeat-batch"], capsys, ndev=4)
     assert line["scaling"] == "strong" and line["config"]["batch_per_gpu"] == 8 and line["config"]["batch_total"] == 32
     assert [s.device for s in CREATED] == [0, 1, 2, 3]
+
+
+def test_default_line_solves_a_fresh_batch_every_step(capsys, monkeypatch):
+    """`value` is what a caller with NEW problems gets -- every step (warm-up steps included) is one handle's first
+    solve of a batch no handle has solved: W + K handles per shard, each with one earlier solve of another batch (its history) and
+    its own batch resident before the timed region; value = the steps' solved instances over the wall time"""
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    line = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "16", "--no-cpu-baseline", "--no-strong-leg"], capsys)
+    assert len(CREATED) == 2 * 4 and all(s.nsolve == 2 for s in CREATED) and all(s.closed for s in CREATED)
+    by_dev = {d: [s for s in CREATED if s.device == d] for d in (0, 1)}
+    qs = [s.args[0] for s in CREATED]
+    for i in range(len(qs)):                      # every handle ended on a batch of its own
+        for j in range(i + 1, len(qs)):
+            assert not np.array_equal(qs[i], qs[j])
+    # the timed steps are the last three handles of each shard; their solved counts make up `value`
+    solved = sum(int(s.out["converged"].sum()) for d in (0, 1) for s in by_dev[d][1:])
+    assert line["value"] == pytest.approx(solved / (line["ms_per_step"] * 3e-3))
+    assert "FIRST solve" in line["config"]["schedule"]
 
 
 def test_more_shards_than_devices_needs_opt_in(capsys, monkeypatch):
@@ -108,7 +126,7 @@ def test_more_shards_than_devices_needs_opt_in(capsys, monkeypatch):
         bench.main(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8", "--no-cpu-baseline"],
                    solver_factory=FakeSolver, device_count=1)
     monkeypatch.setenv("LOIKB_ALLOW_SHARED_GPU", "1")
-    line = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8", "--no-cpu-baseline", "--no-strong-leg"],
+    line = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8", "--no-cpu-baseline", "--no-strong-leg", "--repeat-batch"],
                 capsys, ndev=1)
     assert [s.device for s in CREATED] == [0, 0] and line["config"]["shared_gpu_smoke_test"] is True
 

@@ -178,8 +178,27 @@ def test_longest_first_order_changes_nothing_but_the_schedule(robot, monkeypatch
     assert st2["flat_ordered"] == 1 and st2["lean_requeues"] == 0 and st2["tail_instances"] == B, st2
     for n in names:
         assert np.array_equal(s.get(n), first[n]), n
-    other, st3 = run(s, wl2)                           # another batch on the handle: the stale order is only a schedule
-    assert st3["flat_ordered"] == 1
+    other, st3 = run(s, wl2)                           # another batch on the handle: the counts were taken on other inputs,
+    assert st3["flat_ordered"] == 0, st3               # the stale order is NOT used (VERDICT r03 #2b) ...
+    s.Solve()
+    assert s.stats()["flat_ordered"] == 1              # ... and this batch's own counts are, from its second solve on
+    for n in names:
+        assert np.array_equal(s.get(n), other[n]), n
+    # a caller whose consecutive problems resemble each other may ask for the previous solve's order across a change of inputs
+    # (LOIKB_OPT_ORDER_FROM_PREVIOUS): only a schedule -- same bits
+    t = loik_amd.BatchedLoik(wl["model"], B, flags=loik_amd.capi.OPT_ORDER_FROM_PREVIOUS, **wl["params"])
+    run(t, wl)
+    stale, st4 = run(t, wl2)
+    assert st4["flat_ordered"] == 1, st4
+    # UpdateEqConstraint / a tailored solve / integrate / a setter between two solves invalidate the order as SolveInit does
+    s.UpdateEqConstraint(int(wl2["c_ids"][0]), wl2["Ais"][0] if wl2["Ais"].ndim == 3 else wl2["Ais"], wl2["bis"][:, 0])
+    s.Solve()
+    assert s.stats()["flat_ordered"] == 0
+    s.Solve()
+    assert s.stats()["flat_ordered"] == 1
+    s.set_tol(1e-5, 0.0)
+    s.Solve()
+    assert s.stats()["flat_ordered"] == 0
     monkeypatch.setenv("LOIKB_FLAT_ORDER", "0")
     p = loik_amd.BatchedLoik(wl["model"], B, **wl["params"])
     plain, _ = run(p, wl2)
@@ -187,7 +206,8 @@ def test_longest_first_order_changes_nothing_but_the_schedule(robot, monkeypatch
     assert p.stats()["flat_ordered"] == 0
     for n in names:
         assert np.array_equal(other[n], plain[n]), n
-    s.close(); p.close()
+        assert np.array_equal(stale[n], plain[n]), n
+    s.close(); p.close(); t.close()
 
 
 def test_zero_state_launch_fetches_less_and_computes_the_same(monkeypatch):
