@@ -34,6 +34,13 @@
 namespace loikb {
 
 constexpr int F2G = 32;  // joints per instance (lane pairs)
+constexpr int FLAT_PARKED = 1 << 30;  // ring entry: the instance is parked (k_flat2<.., SLICED>)
+constexpr int FLAT2_PARK_ROWS = 33;   // rows of 64 doubles of a parked instance's lane state
+constexpr int FLAT2_PARK_BATCH = 8;   // elements of the LDS blocks a lane moves per batch (512 per wavefront: up to three task constraints in one)
+__host__ __device__ __forceinline__ int flat2_park_stride(int nc, bool has_hv)
+{
+  return (FLAT2_PARK_ROWS * WAVE + (has_hv ? 32 * 6 : 0) + nc * 164 + 64 + 8 + 1) & ~1;   // (+ the LDS blocks, FISC <= 64, six scalars)
+}
 constexpr int F2W = 32;  // row stride of the [ancestor][joint] arrays (W rows, W tau products): lane (j, h) touches row 2 i + h
 
 // Constraint block of an instance in the LDS of k_flat2 / k_flat1 (doubles; every 6-vector starts at an even offset).  What the loop
@@ -288,7 +295,7 @@ template <int NA, int WPE, bool SLICED = false, int HM = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
         int nscan, int njmp, int* ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
-        int ndec, double href_s, int has_hv, int ring_mask, int quantum)
+        int ndec, double href_s, int has_hv, int ring_mask, int quantum, double* __restrict__ park, int park_stride)
 {
   using T = double;
   static_assert(NA % 2 == 0, "the W entries of a joint are dealt out to its two lanes");
@@ -318,18 +325,15 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const T hh = T(1) - hz, mha = mass * hh;  // (1 on the angular lanes; the halves' formulas differ by terms multiplied by hz / hh:
                                             //  a select between two doubles is two v_cndmask, a 0 / 1 factor rides in an FMA)
   constexpr bool HD = HM > 0;  // (H_ref v needs its own subtree sums)
-  T hd[3];  // this half's diagonal entries of H_ref (HM = 1; = href_s for HM = 0)
+  T hd[3];  // this half's diagonal entries of H_ref (HM = 1; HM = 0 multiplies by the uniform href_s)
 #pragma unroll
-  for (int k = 0; k < 3; ++k) hd[k] = HM == 1 ? (h ? P.Href[7 * (3 + k)] : P.Href[7 * k]) : href_s;
+  for (int k = 0; k < 3; ++k) hd[k] = HM == 1 ? (h ? P.Href[7 * (3 + k)] : P.Href[7 * k]) : T(0);
   T* const hmat = isc + FISC;  // [36] H_ref (HM = 2)
   if (HM == 2 && lane < 36) hmat[lane] = P.Href[lane];
   const T* const hrow = HM == 3 ? P.href_tab + (size_t)(jl + 1) * HREF_ROW : nullptr;  // (H_ref_i, H_ref_i v_ref_i) of this link
-  T hvl3[3];  // this half of H_ref v_ref of the link
-#pragma unroll
-  for (int k = 0; k < 3; ++k) hvl3[k] = HM == 3 ? hrow[36 + h3 + k] : (h ? P.Hv[3 + k] : P.Hv[k]);
+  auto hvl3_of = [&](int k) -> T { return HM == 3 ? hrow[36 + h3 + k] : (h ? P.Hv[3 + k] : P.Hv[k]); };  // this half of H_ref v_ref of the link
   int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
   bool helper;
-  unsigned int jrow4[(FLAT_JMP + 3) / 4];  // load time: rows of the ancestors at distance 2^r in joint-indexed rows (WAVE = identity)
   unsigned int pathA, pathB, pathC;        // iteration: the ancestors at distance 1, 2, 3 / 4, 8, 12 / 16: byte offsets of their lanes of this half
   unsigned int ra2[2], part2[2], anc3[(NH + 2) / 3];  // byte offsets into the product / partial / Dinv r' buffers (16 / 16 / 10 bits each)
   {
@@ -337,22 +341,16 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     size = isj_lane ? F.size : 0;
     helper = (F.helper & 1) != 0;
     fcol = F.helper >> 8; fdm1 = F.depth > 0 ? F.depth - 1 : 0;
-#pragma unroll
-    for (int k = 0; k < (FLAT_JMP + 3) / 4; ++k) jrow4[k] = 0u;
     flat_path_rows4(fl, j, h ? 32 : 0, pathA, pathB, pathC);
 #pragma unroll
     for (int k = 0; k < (NH + 2) / 3; ++k) anc3[k] = 0u;
-#pragma unroll
-    for (int r = 0; r < FLAT_JMP; ++r) {
-      jrow4[r >> 2] |= (unsigned int)(F.jmp[r] >= 0 ? F.jmp[r] : WAVE) << (8 * (r & 3));
-    }
     // this lane's half of the joint's share of the W tau products, of its partials and of its W entries (k = 2 i + h)
     ra2[0] = ra2[1] = 0u;
     part2[0] = part2[1] = 0u;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int e = h ? F.red[4 + t] : F.red[t];  // (entry k * 32 + lane' of the product buffer: the schedule was built for G = 32)
-      ra2[t >> 1] |= (unsigned int)((e >= 0 ? (e >> 5) * GW + (e & 31) : NA * GW) * 8) << (16 * (t & 1));
+      ra2[t >> 1] |= (unsigned int)((e >= 0 ? (e >> 5) * GW + (e & 31) : flat2_off_nbuf<NA>() + G) * 8) << (16 * (t & 1));  // (none: nbuf's zero pad)
       const int p = h ? F.part[4 + t] : F.part[t];
       part2[t >> 1] |= (unsigned int)((p >= 0 ? p : G) * 8) << (16 * (t & 1));
     }
@@ -374,27 +372,30 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   T w = T(0), z = T(0), nu = T(0), s = T(0), lbi = T(0), ubi = T(0), mu = T(1);
   int kexp = 0, kslot = -(1 << 30), kslot_o = -(1 << 30), wsel = 0;
   int iter = 0, status = ST_DONE, tail_it = 0, nflip = 0;
-  unsigned int my_iters = 0, n_wave_iters = 0, n_slot_loads = 0, n_slot_hits = 0;
+  unsigned int my_iters = 0, n_wave_iters = 0, n_slot_loads = 0, n_slot_hits = 0, n_inst_iters = 0, n_requeues = 0;
   unsigned int* q_head = Bf.counters + LEAN_Q_HEAD;
   unsigned int cbits = 0u;  // constraint c: is its joint in this joint's subtree?
   auto cmask = [&](int c) -> T { return ((cbits >> c) & 1u) ? T(1) : T(0); };
-  // the DualUpdate's lanes: lane 6 c + k owns row k of constraint c
-  const int ccl = lane / 6, ckl = lane - 6 * ccl;
+  // the DualUpdate's lanes: lane 6 c + k owns row k of constraint c.  The loop keeps TWO numbers of that (the block's byte offset and
+  // 8 k) and forms every address from them where it is used (immediate offsets of the LDS instructions): the five row / vector
+  // pointers the compiler would otherwise carry across the loop are what it spilled -- three scratch reloads per iteration in the
+  // time-sliced build, each an s_waitcnt vmcnt(0) that is cheap while the line sits in the L1 and a trip to the L2 once park
+  // records stream through it (iterations 40 % slower under time slices of 64).
   const bool iscl = lane < 6 * L.nc;
-  T* const ccb = cdi + (iscl ? ccl : 0) * cs;
+  const unsigned int cb_blk = (unsigned int)((iscl ? lane / 6 : 0) * cs * 8), cb_k = (unsigned int)((lane % 6) * 8);
   // (AW y)_k and (A^T y)_k of the constraint of lane 6 c + k: ONE order of operations wherever they are formed (load, loop, store),
   // so that an instance resumed from the queue continues with the bits it would have had
-  auto awy_k = [&]() -> T {
-    const T* r = ccb + C2_AW + 6 * ckl;
-    const T* y = ccb + C2_Y;
+  auto awy_of = [&](const char* blk, unsigned int k8) -> T {
+    const T* r = reinterpret_cast<const T*>(blk + C2_AW * 8 + 6 * k8);
+    const T* y = reinterpret_cast<const T*>(blk + C2_Y * 8);
     T a = r[0] * y[0];
 #pragma unroll
     for (int q = 1; q < 6; ++q) a += r[q] * y[q];
     return a;
   };
-  auto aty_k = [&]() -> T {
-    const T* A_ = ccb + C2_A + ckl;
-    const T* y = ccb + C2_Y;
+  auto aty_of = [&](const char* blk, unsigned int k8) -> T {
+    const T* A_ = reinterpret_cast<const T*>(blk + C2_A * 8 + k8);
+    const T* y = reinterpret_cast<const T*>(blk + C2_Y * 8);
     T a = A_[0] * y[0];
 #pragma unroll
     for (int q = 1; q < 6; ++q) a += A_[6 * q] * y[q];
@@ -447,38 +448,138 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       return __builtin_amdgcn_readfirstlane(got);
     }
   };
-  auto q_waiting = [&]() -> bool {  // do entries wait for a wavefront?
-    int wtg = 0;
-    if (lane == 0)
-      wtg = (int)(__hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                  __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > 0;
-    return __builtin_amdgcn_readfirstlane(wtg) != 0;
-  };
-  auto q_push = [&](int slot) {  // (after store_instance: every store of the record has completed before the entry appears)
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-      const unsigned int pos = atomicAdd(q_tail, 1u);
-      int* e = ring + (pos & (unsigned int)ring_mask);
-      for (unsigned int spins = 0; __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0; ++spins) {
-        if (spins > (1u << 23)) { atomicOr(Bf.counters + FLAT_COUNTERS_ERR, 2u); break; }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      __hip_atomic_store(e, slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicAdd(&Bf.counters[LEAN_Q_REQUEUES], 1u);
-    }
-  };
 #ifdef LOIKB_TAIL_PROF
   unsigned long long prof_[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev_ = clock64();
   const unsigned long long wall0_ = wall_clock64(), clk0_ = tprev_;
 #endif
+  // ---- SLICED: an instance whose time slice is used up is PARKED -- the lane state and the instance's LDS blocks, as they are, in a
+  // lane-contiguous record of its own (33 rows of 64 doubles + the LDS blocks: every access a full 512-byte row) -- and taken up
+  // again by whichever wavefront pops its entry, possibly on another XCD (agent-scope accesses; the pusher waits for its stores
+  // before the entry appears).  Round 3 sent it through the tile records (410 scattered stores, 90 loads, the whole set-up again:
+  // ~130 us of a wavefront per switch, more than the slices brought); a park / unpark pair is ~40 row accesses each way.
+  auto park_instance = [&]() {
+    T* pk = park + (size_t)lidx * park_stride;
+    int r = 0;
+    auto put = [&](T x) { cst<T>(reinterpret_cast<char*>(pk + (r++) * WAVE + lane), x); };
+#pragma unroll
+    for (int k = 0; k < 9; ++k) put(R0[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) put(t0[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) put(Sw3[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) put(v3[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) put(f3[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) put(g3[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) put(SE3[k]);
+    put(w); put(z); put(nu); put(s); put(lbi); put(ubi);
+    T* pl = pk + FLAT2_PARK_ROWS * WAVE;
+    const int nl = (has_hv ? G * 6 : 0) + L.nc * cs + FISC;   // shv | constraint blocks | the getters' scalars: contiguous in LDS
+    tail_sync();
+    // (every read of a batch before its stores: one LDS latency per batch, not per element)
+    for (int e0 = 0; e0 < nl; e0 += FLAT2_PARK_BATCH * WAVE) {
+      T lb[FLAT2_PARK_BATCH];
+#pragma unroll
+      for (int k = 0; k < FLAT2_PARK_BATCH; ++k) { const int e = e0 + k * WAVE + lane; lb[k] = e < nl ? shv[e] : T(0); }
+#pragma unroll
+      for (int k = 0; k < FLAT2_PARK_BATCH; ++k) { const int e = e0 + k * WAVE + lane; if (e < nl) cst<T>(reinterpret_cast<char*>(pl + e), lb[k]); }
+    }
+    if (lane < 6) {
+      const T x = lane == 0 ? mu : lane == 1 ? (T)kexp : lane == 2 ? (T)iter : lane == 3 ? (T)status : lane == 4 ? (T)tail_it : (T)nflip;
+      cst<T>(reinterpret_cast<char*>(pl + nl + lane), x);
+    }
+    n_inst_iters += my_iters;
+  };
+  // (ALL loads of the record in flight together -- the lane rows, the LDS blocks' elements, the six scalars behind them: one round trip
+  //  to HBM.  The first version read the LDS blocks and the scalars element by element, ten dependent round trips: 60 us per switch)
+  auto unpark = [&](int entry) {
+    const int slot = entry & 0xFFFFF, dsl_in = (entry >> 24) & 15;   // (the decade of mu the instance was parked in travels in the entry:
+    lidx = slot;                                                     //  its W columns are fetched WITH the record, not a round trip later)
+    isj = isj_lane;
+    ip = lane_ptr<T>(Bf.tiles, L, slot);
+    rec = ip + (size_t)jl * JREC * pair_bytes<T>();
+    const T* pk = park + (size_t)slot * park_stride;
+    const T* pl = pk + FLAT2_PARK_ROWS * WAVE;
+    const int nl = (has_hv ? G * 6 : 0) + L.nc * cs + FISC, nl6 = nl + 6;
+    T lb[FLAT2_PARK_BATCH];
+#pragma unroll
+    for (int k = 0; k < FLAT2_PARK_BATCH; ++k) { const int e = k * WAVE + lane; lb[k] = e < nl6 ? cld<T>(reinterpret_cast<const char*>(pl + e)) : T(0); }
+    const bool with_slot = dsl_in < ndec;
+    T win[NH + 1];
+#pragma unroll
+    for (int i = 0; i <= NH; ++i) {
+      const int k = 2 * i + (h ? 1 : 0);
+      win[i] = (with_slot && isj_lane && (k == NA || k < fdm1)) ? fslots[fslotW_at(slot, ndec, dsl_in, frows, fcol + (k == NA ? fdm1 : k))] : T(0);
+    }
+    int r = 0;
+    auto get = [&]() -> T { return cld<T>(reinterpret_cast<const char*>(pk + (r++) * WAVE + lane)); };
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R0[k] = get();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t0[k] = get();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Sw3[k] = get();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v3[k] = get();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) f3[k] = get();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g3[k] = get();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) SE3[k] = get();
+    w = get(); z = get(); nu = get(); s = get(); lbi = get(); ubi = get();
+    tail_sync();
+    auto put_lds = [&](int e, T x) { if (e < nl) shv[e] = x; else if (e < nl6) xb[e - nl] = x; };   // (the scalars: load-time rows, free now)
+#pragma unroll
+    for (int k = 0; k < FLAT2_PARK_BATCH; ++k) put_lds(k * WAVE + lane, lb[k]);
+    for (int e0 = FLAT2_PARK_BATCH * WAVE; e0 < nl6; e0 += FLAT2_PARK_BATCH * WAVE) {   // (more than three task constraints)
+#pragma unroll
+      for (int k = 0; k < FLAT2_PARK_BATCH; ++k) { const int e = e0 + k * WAVE + lane; lb[k] = e < nl6 ? cld<T>(reinterpret_cast<const char*>(pl + e)) : T(0); }
+#pragma unroll
+      for (int k = 0; k < FLAT2_PARK_BATCH; ++k) put_lds(e0 + k * WAVE + lane, lb[k]);
+    }
+    tail_sync();
+    mu = xb[0];
+    kexp = __builtin_amdgcn_readfirstlane((int)xb[1]);
+    iter = __builtin_amdgcn_readfirstlane((int)xb[2]);
+    status = __builtin_amdgcn_readfirstlane((int)xb[3]);
+    tail_it = __builtin_amdgcn_readfirstlane((int)xb[4]);
+    nflip = __builtin_amdgcn_readfirstlane((int)xb[5]);
+    cbits = 0u;
+    for (int c = 0; c < L.nc; ++c) {
+      const int cl = (int)cdi[c * cs + C2_LANE];
+      if (isj_lane && cl >= j && cl < j + size) cbits |= 1u << c;
+    }
+    kslot = -(1 << 30); kslot_o = -(1 << 30);
+    if (with_slot) {
+      wsel = 0;
+#pragma unroll
+      for (int i = 0; i <= NH; ++i) {
+        const int k = 2 * i + (h ? 1 : 0);
+        if (k <= NA) wl[k * GW + j] = win[i];
+      }
+      kslot = kexp_lo + dsl_in;
+      n_slot_loads = (n_slot_loads + 0x10000u) | (1u << dsl_in);
+    }
+    tail_sync();
+    done = false;
+    resumed = true;   // (no first-iteration corrections: it has iterated)
+    my_iters = 0;
+    any_iter = true;
+    TAIL_TP(16)
+  };
   int next_slot = -2;  // (plain queue) the entry store_instance fetched while its stores were in flight; -2: none
   auto load_instance = [&]() {
-    const int slot_in = (!SLICED && next_slot != -2) ? next_slot : fetch();
+    const int slot_in = next_slot != -2 ? next_slot : fetch();
     next_slot = -2;
     has_inst = slot_in >= 0;
     if (!has_inst) return;
     TAIL_TP(12)
+    if (SLICED && (slot_in & FLAT_PARKED)) { unpark(slot_in); return; }
+    resumed = false;
     isj = isj_lane;
     const int slot = slot_in;
     lidx = slot;
@@ -486,15 +587,15 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     rec = ip + (size_t)jl * JREC * pair_bytes<T>();
     const char* srec = ip + (size_t)L.off_s * pair_bytes<T>();
     // the scalar record travels with the joints' records (one round trip to HBM, not two: the loads are independent)
-    const typename Vec2<T>::type mu2 = rldp<T, SLICED>(srec, SP_MU), bi2 = rldp<T, SLICED>(srec, SP_BI), st2 = rldp<T, SLICED>(srec, SP_ST);
-    const typename Vec2<T>::type tag2 = rldp<T, SLICED>(srec, SP_TAG), flip2 = rldp<T, SLICED>(srec, SP_FLIP);
-    const T tail_iter0 = rld_scal<T, SLICED>(srec, SC_TAIL_ITER);
+    const typename Vec2<T>::type mu2 = rldp<T, false>(srec, SP_MU), bi2 = rldp<T, false>(srec, SP_BI), st2 = rldp<T, false>(srec, SP_ST);
+    const typename Vec2<T>::type tag2 = rldp<T, false>(srec, SP_TAG), flip2 = rldp<T, false>(srec, SP_FLIP);
+    const T tail_iter0 = rld_scal<T, false>(srec, SC_TAIL_ITER);
     T sc0[8] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
     if (lane == 0) {
-      sc0[0] = rld_scal<T, SLICED>(srec, SC_TOL_PRIMAL); sc0[1] = rld_scal<T, SLICED>(srec, SC_TOL_DUAL);
-      sc0[2] = rld_scal<T, SLICED>(srec, SC_DELTA_Y_QP); sc0[3] = rld_scal<T, SLICED>(srec, SC_AT_DELTA_Y_QP);
-      sc0[4] = rld_scal<T, SLICED>(srec, SC_UB_DY_PLUS); sc0[5] = rld_scal<T, SLICED>(srec, SC_LB_DY_MINUS);
-      sc0[6] = rld_scal<T, SLICED>(srec, SC_COND1); sc0[7] = rld_scal<T, SLICED>(srec, SC_COND2);
+      sc0[0] = rld_scal<T, false>(srec, SC_TOL_PRIMAL); sc0[1] = rld_scal<T, false>(srec, SC_TOL_DUAL);
+      sc0[2] = rld_scal<T, false>(srec, SC_DELTA_Y_QP); sc0[3] = rld_scal<T, false>(srec, SC_AT_DELTA_Y_QP);
+      sc0[4] = rld_scal<T, false>(srec, SC_UB_DY_PLUS); sc0[5] = rld_scal<T, false>(srec, SC_LB_DY_MINUS);
+      sc0[6] = rld_scal<T, false>(srec, SC_COND1); sc0[7] = rld_scal<T, false>(srec, SC_COND2);
     }
     // ---- full width on both lanes of a joint (identical values): k_flat's load, rows indexed by the joint
     T ax[3], v[6], f[6], g[6], Sw[6], SE[6];
@@ -505,19 +606,19 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       // (straight from a cold reset -- the plain queue hands every instance out once -- vis, fis, g, w, z are zeros in every
       //  record: ten of the twelve pairs of a joint are not fetched.  A record's 16-byte pairs lie 1 KiB apart in the tiles of
       //  the streaming engine: every pair costs a 64-byte line of its own)
-      const bool zero_state = !SLICED && (P.mode & MODE_ZERO_STATE);
+      const bool zero_state = (P.mode & MODE_ZERO_STATE) != 0;
       typename Vec2<T>::type wz;
       wz.x = T(0); wz.y = T(0);
-      const typename Vec2<T>::type csn = ldp<T>(rec, JP_CS), nus = rldp<T, SLICED>(rec, JP_NUS);
-      if (!zero_state) wz = rldp<T, SLICED>(rec, JP_WZ);
+      const typename Vec2<T>::type csn = ldp<T>(rec, JP_CS), nus = rldp<T, false>(rec, JP_NUS);
+      if (!zero_state) wz = rldp<T, false>(rec, JP_WZ);
       const JointDesc d = jd[jl + 1];
 #pragma unroll
       for (int k = 0; k < 3; ++k) ax[k] = isj_lane ? (T)d.axis[k] : T(0);
       joint_xform<T>(d, rec, csn.x, csn.y, R0, t0);  // liMi ...
       if (!zero_state) {
-        rld6<T, SLICED>(rec, JP_V, v);
-        rld6<T, SLICED>(rec, JP_F, f);
-        rld6<T, SLICED>(rec, JP_G, g);
+        rld6<T, false>(rec, JP_V, v);
+        rld6<T, false>(rec, JP_F, f);
+        rld6<T, false>(rec, JP_G, g);
       } else {
 #pragma unroll
         for (int k = 0; k < 6; ++k) { v[k] = T(0); f[k] = T(0); g[k] = T(0); }
@@ -542,7 +643,14 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       lbi = ubi = T(0);
     }
     TAIL_TP(13)
-    flat_world_placement<T>(xb, j, j, jrow4, njmp, R0, t0);  // ... -> oMi (FwdPassInit's oMi chain, hxx:265)
+    {
+      unsigned int jrow4[(FLAT_JMP + 3) / 4];  // rows of the ancestors at distance 2^r in joint-indexed rows (WAVE = identity)
+#pragma unroll
+      for (int k = 0; k < (FLAT_JMP + 3) / 4; ++k) jrow4[k] = 0u;
+#pragma unroll
+      for (int r = 0; r < FLAT_JMP; ++r) jrow4[r >> 2] |= (unsigned int)(fl[j].jmp[r] >= 0 ? fl[j].jmp[r] : WAVE) << (8 * (r & 3));
+      flat_world_placement<T>(xb, j, j, jrow4, njmp, R0, t0);  // ... -> oMi (FwdPassInit's oMi chain, hxx:265)
+    }
     TAIL_TP(14)
     {
       T ra3[3], c[3];
@@ -563,7 +671,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         const int which = lane / 6, k = lane % 6;
         const int pair = which == 0 ? CP_B : which == 1 ? CP_Y : CP_ATY;
         const int dst = which == 0 ? C2_B : which == 1 ? C2_Y : C2_ATY;
-        c_[dst + k] = rld<T, SLICED>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));  // (y changes in the kernel)
+        c_[dst + k] = rld<T, false>(crec + (size_t)(pair + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));  // (y changes in the kernel)
       }
       for (int e = lane; e < LCA; e += WAVE)
         c_[C2_A + e] = a_shared ? Bf.uni[c * LCA + e]
@@ -598,8 +706,9 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       for (int k = 0; k < 6; ++k) c_[C2_ATYW + k] = o[k];
     }
     tail_sync();
-    resumed = SLICED && tag2.x == T(-3);
     if (iscl) {
+      const int ccl = lane / 6, ckl = lane - 6 * ccl;
+      T* const ccb = cdi + ccl * cs;
       // A^T b at the world origin; and what the first iteration owes to an A^T y that is not A^T (the y the record holds) -- the
       // loop forms the constraint's force as AW y and g without an A^T y term, which is exact from the second iteration on
       // (DualUpdate leaves A^T y = A^T y_new, hxx:422): C2_CW = X*(A^T y used) - AW y_old goes into the first f, C2_DLT =
@@ -609,7 +718,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
       for (int q = 0; q < 6; ++q) ab += ccb[C2_AW + 6 * k + q] * ccb[C2_B + q];
       ccb[C2_ATBW + k] = ab;
-      const T aw = awy_k(), at = aty_k();
+      const T aw = awy_of(reinterpret_cast<const char*>(ccb), (unsigned int)(8 * ckl)), at = aty_of(reinterpret_cast<const char*>(ccb), (unsigned int)(8 * ckl));
       ccb[C2_CW + k] = resumed ? T(0) : ccb[C2_ATYW + k] - aw;
       ccb[C2_DLT + k] = resumed ? T(0) : at - ccb[C2_ATY + k];
       if (resumed) ccb[C2_ATYW + k] = aw;  // (what the loop had left there)
@@ -644,14 +753,6 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         for (int k = 0; k < 6; ++k) shv[j * 6 + k] = Sh[k];
       }
     }
-    if constexpr (SLICED) {
-      // An instance that comes back from the queue (SP_TAG = -3) continues EXACTLY where it left: the two quantities of the loop
-      // that are not functions of the stored record alone are the subtree sums of E (prefix-sum differences in the loop, window
-      // sums above): they travel in a record pair this engine does not otherwise use (JP_P); A^T y at the world origin is AW y,
-      // formed above in the loop's order of operations.  Time slicing then changes no bit of any result, whatever the order the
-      // hardware happens to serve the queue in.
-      if (tag2.x == T(-3)) rld6<T, SLICED>(rec, JP_P, SE);
-    }
     half(Sw, Sw3); half(v, v3); half(f, f3); half(g, g3); half(SE, SE3);
     mu = mu2.x;
     kexp = (int)mu2.y;
@@ -683,57 +784,54 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     {
       T v[6], f[6], g[6];
       whole(v3, v); whole(f3, f); whole(g3, g);
-      if (SLICED && requeue) {  // (see load_instance)
-        T se[6];
-        whole(SE3, se);
-        if (isj && !h) rst6<T, SLICED>(rec, JP_P, se);
-      }
       if (isj && !h) {
-        rst6<T, SLICED>(rec, JP_V, v);
-        rst6<T, SLICED>(rec, JP_F, f);
-        rst6<T, SLICED>(rec, JP_G, g);
-        rstp<T, SLICED>(rec, JP_WZ, w, z);
-        rstp<T, SLICED>(rec, JP_NUS, nu, s);
+        rst6<T, false>(rec, JP_V, v);
+        rst6<T, false>(rec, JP_F, f);
+        rst6<T, false>(rec, JP_G, g);
+        rstp<T, false>(rec, JP_WZ, w, z);
+        rstp<T, false>(rec, JP_NUS, nu, s);
         if (any_iter) {
           // inter-sweep temporaries of the last iteration: r_i and Dinv_i.  This engine forms neither UDinv_i nor the
           // accumulated p_i: the scalar record's tag says so (SP_TAG = -2) and the getters rebuild them (k_rebuild_ud).
-          rstp<T, SLICED>(rec, JP_R, rbuf[j], wl[(wsel * (NA + 1) + NA) * GW + j]);
+          rstp<T, false>(rec, JP_R, rbuf[j], wl[(wsel * (NA + 1) + NA) * GW + j]);
         }
       }
     }
     if (iscl) {  // y and A^T y (hxx:422; an instance that did not iterate goes back with the A^T y it came with)
+      const int ccl = lane / 6, ckl = lane - 6 * ccl;
+      const T* const ccb = cdi + ccl * cs;
       char* crec = ip + (size_t)(L.off_c + ccl * L.crec) * pair_bytes<T>();
       const int k = ckl;
-      rst<T, SLICED>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), ccb[C2_Y + k]);
-      rst<T, SLICED>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), any_iter ? aty_k() : ccb[C2_ATY + k]);
+      rst<T, false>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), ccb[C2_Y + k]);
+      rst<T, false>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), any_iter ? aty_of(reinterpret_cast<const char*>(ccb), (unsigned int)(8 * ckl)) : ccb[C2_ATY + k]);
     }
     if (lane == 0) {
-      rstp<T, SLICED>(srec, SP_MU, mu, (T)kexp);
-      rstp<T, SLICED>(srec, SP_TAG, (SLICED && requeue) ? T(-3) : any_iter ? T(-2) : isc[FI_TGIN], T(0));
-      rstp<T, SLICED>(srec, SP_BI, isc[FI_BNORM], (T)iter);
-      rstp<T, SLICED>(srec, SP_FLIP, (T)nflip, T(0));
-      rstp<T, SLICED>(srec, SP_ST, (T)(any_iter ? (status & ~ST_PFULL) : status), any_iter ? isc[FI_MULAST] : isc[FI_STY]);
+      rstp<T, false>(srec, SP_MU, mu, (T)kexp);
+      rstp<T, false>(srec, SP_TAG, any_iter ? T(-2) : isc[FI_TGIN], T(0));
+      rstp<T, false>(srec, SP_BI, isc[FI_BNORM], (T)iter);
+      rstp<T, false>(srec, SP_FLIP, (T)nflip, T(0));
+      rstp<T, false>(srec, SP_ST, (T)(any_iter ? (status & ~ST_PFULL) : status), any_iter ? isc[FI_MULAST] : isc[FI_STY]);
       if (any_iter) {
         const T* rr = isc + FI_RED;  // prt prs stf dvis dnu dfis dyis dw av nu hrefv g dualv (13), filled when the instance stopped
         const T mu_s = mu;
-        rstp<T, SLICED>(srec, SP_SCAL + 0, isc[FI_PRIMAL], isc[FI_DUAL]);
-        rstp<T, SLICED>(srec, SP_SCAL + 1, rr[0], rr[1]);
-        rstp<T, SLICED>(srec, SP_SCAL + 2, rr[12], rr[2]);
-        rstp<T, SLICED>(srec, SP_SCAL + 3, isc[FI_TOLP], isc[FI_TOLD]);
-        rstp<T, SLICED>(srec, SP_SCAL + 4, mu_s, P.mu_scale * mu_s);
-        rstp<T, SLICED>(srec, SP_SCAL + 5, mu_s, isc[FI_DX]);
-        rstp<T, SLICED>(srec, SP_SCAL + 6, isc[FI_DZ], isc[FI_DYQP]);
-        rstp<T, SLICED>(srec, SP_SCAL + 7, isc[FI_ATDY], isc[FI_UBP]);
-        rstp<T, SLICED>(srec, SP_SCAL + 8, isc[FI_LBM], rr[5]);
-        rstp<T, SLICED>(srec, SP_SCAL + 9, rr[6], rr[7]);
-        rstp<T, SLICED>(srec, SP_SCAL + 10, rr[3], rr[4]);
-        rstp<T, SLICED>(srec, SP_SCAL + 11, rr[8], rr[9]);
-        rstp<T, SLICED>(srec, SP_SCAL + 12, rr[10], rr[11]);
-        rstp<T, SLICED>(srec, SP_SCAL + 13, rr[2], isc[FI_C1]);
-        rstp<T, SLICED>(srec, SP_SCAL + 14, isc[FI_C2], (T)tail_it);
+        rstp<T, false>(srec, SP_SCAL + 0, isc[FI_PRIMAL], isc[FI_DUAL]);
+        rstp<T, false>(srec, SP_SCAL + 1, rr[0], rr[1]);
+        rstp<T, false>(srec, SP_SCAL + 2, rr[12], rr[2]);
+        rstp<T, false>(srec, SP_SCAL + 3, isc[FI_TOLP], isc[FI_TOLD]);
+        rstp<T, false>(srec, SP_SCAL + 4, mu_s, P.mu_scale * mu_s);
+        rstp<T, false>(srec, SP_SCAL + 5, mu_s, isc[FI_DX]);
+        rstp<T, false>(srec, SP_SCAL + 6, isc[FI_DZ], isc[FI_DYQP]);
+        rstp<T, false>(srec, SP_SCAL + 7, isc[FI_ATDY], isc[FI_UBP]);
+        rstp<T, false>(srec, SP_SCAL + 8, isc[FI_LBM], rr[5]);
+        rstp<T, false>(srec, SP_SCAL + 9, rr[6], rr[7]);
+        rstp<T, false>(srec, SP_SCAL + 10, rr[3], rr[4]);
+        rstp<T, false>(srec, SP_SCAL + 11, rr[8], rr[9]);
+        rstp<T, false>(srec, SP_SCAL + 12, rr[10], rr[11]);
+        rstp<T, false>(srec, SP_SCAL + 13, rr[2], isc[FI_C1]);
+        rstp<T, false>(srec, SP_SCAL + 14, isc[FI_C2], (T)tail_it);
       }
-      if (my_iters) atomicAdd(&Bf.counters[1], my_iters);
     }
+    n_inst_iters += my_iters;
     if constexpr (!SLICED) {
       const int nx = __builtin_amdgcn_readfirstlane((int)nx_raw);
       if (nx >= nslots) note_dry();
@@ -750,11 +848,19 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     if (!has_inst) break;  // the queue is empty (SLICED: and every instance has retired): this wavefront is done
     T inv_mu = T(1) / mu;  // (a division per change of mu, not per iteration: BoxProj's 1 / mu_ineq, hxx:384-397)
     int slice_iters = 0;
+    unsigned int q_pref_t = 0u, q_pref_h = 0u;
     requeue = false;
    while (true) {
-    if (SLICED && quantum > 0 && !done && slice_iters >= quantum) {
-      if (q_waiting()) { requeue = true; break; }  // time slice used up and others wait: to the back of the queue
-      slice_iters = 0;                              // nobody waits for this wavefront: carry on
+    if (SLICED && quantum > 0 && !done) {
+      // time slice used up and others wait: to the back of the queue.  The queue's counters are fetched an iteration AHEAD (their
+      // round trip runs under the slice's last iteration; slightly stale is fine: the decision is a heuristic)
+      if (slice_iters >= quantum) {
+        if (__builtin_amdgcn_readfirstlane((int)(q_pref_t - q_pref_h) > 0 ? 1 : 0)) { requeue = true; break; }
+        slice_iters = 0;   // nobody waits for this wavefront: carry on
+      } else if (slice_iters + 1 >= quantum && lane == 0) {
+        q_pref_t = __hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        q_pref_h = __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     // ---- does the instance leave before this iteration?  (fetched already finished; this launch's share of iterations used up;
     // mu left the precomputed decades.)  Then it goes back as it is.
@@ -797,6 +903,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     if (exit_now) break;
     const T* wcur = wl + (size_t)wsel * (NA + 1) * GW;
     TAIL_TP(8)
+    const unsigned int h3b = (opaque((unsigned int)lane) >> 5) * 24u;   // byte offset of this half in a 6-vector of a constraint block
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
     ++my_iters; any_iter = true;
     ++n_wave_iters;
@@ -817,7 +924,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         for (int k = 0; k < 3; ++k) PB[k] -= shv[j * 6 + h3 + k];
       }
       for (int c = 0; c < L.nc; ++c) {
-        const T* c_ = cdi + c * cs + h3;
+        const T* c_ = reinterpret_cast<const T*>(reinterpret_cast<const char*>(cdi + c * cs) + h3b);
         const T m = cmask(c);
 #pragma unroll
         for (int k = 0; k < 3; ++k) PB[k] += m * (c_[C2_ATYW + k] - mu_eq * c_[C2_ATBW + k]);
@@ -830,7 +937,6 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     tail_sync();
 #pragma unroll
     for (int i = 0; i < NH; ++i) xb[(2 * i + (h ? 1 : 0)) * GW + j] = wc[i] * tau;
-    if (lane == 0) { xb[NA * GW] = T(0); xb[NA * GW + 1] = T(0); }
     tail_sync();
     T rn;
     {
@@ -901,7 +1007,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) hv3[k] = hd[k] * vi3[k];
+      for (int k = 0; k < 3; ++k) hv3[k] = (HM == 1 ? hd[k] : href_s) * vi3[k];
     }
     TAIL_TP(2)
     // ================= DualUpdate of the task constraints (hxx:410-451) inside the subtree sum of the links' velocities ==========
@@ -915,13 +1021,15 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       // exchanges through the constraint block in LDS (lane 6 c + k owns row k).  A v_c = AW^T v^w_c: no frame change first.
       const bool first = my_iters == 1u && !resumed;  // (the first iteration of a fresh record: see load_instance)
       tail_sync();
+      const char* const ccb0 = reinterpret_cast<const char*>(cdi) + opaque(cb_blk);   // this lane's constraint block
+      const unsigned int ck8 = opaque(cb_k);                                           // 8 k
       if (iscl) {
-        const T* col = ccb + C2_AWT + 6 * ckl;
-        const T* vc = ccb + C2_VC;
+        const T* col = reinterpret_cast<const T*>(ccb0 + C2_AWT * 8 + 6 * ck8);
+        const T* vc = reinterpret_cast<const T*>(ccb0 + C2_VC * 8);
         T avk = col[0] * vc[0];
 #pragma unroll
         for (int q = 1; q < 6; ++q) avk += col[q] * vc[q];
-        const T bk = ccb[C2_B + ckl];
+        const T bk = *reinterpret_cast<const T*>(ccb0 + C2_B * 8 + ck8);
         const T ek = avk - bk;
         const T dy = mu_eq * ek;
         l_dyis = tabs(dy);
@@ -929,7 +1037,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         l_lm = bk * tmin(dy, T(0));
         l_prt = tabs(ek);
         l_av = tabs(avk);
-        ccb[C2_Y + ckl] += dy;
+        *reinterpret_cast<T*>(const_cast<char*>(ccb0) + C2_Y * 8 + ck8) += dy;
       }
       TAIL_TP(9)
       // (round 3 formed A v, A^T y, AW y, A^T dy and AW dy here, 30 multiply-adds on six lanes and 170 instructions of the
@@ -976,10 +1084,10 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       if (iscl) {
         // X* (A^T y_new) = AW y: what the next FwdPass1 adds to p of the constrained joint (hxx:329-331) and, this iteration,
         // the constraint's force in f: (A^T y used) + A^T dy
-        const T aw = awy_k();
-        const T cw = first ? ccb[C2_CW + ckl] : T(0);
-        ccb[C2_ATYW + ckl] = aw;
-        ccb[C2_ATYF + ckl] = aw + cw;
+        const T aw = awy_of(ccb0, ck8);
+        const T cw = first ? *reinterpret_cast<const T*>(ccb0 + C2_CW * 8 + ck8) : T(0);
+        *reinterpret_cast<T*>(const_cast<char*>(ccb0) + C2_ATYW * 8 + ck8) = aw;
+        *reinterpret_cast<T*>(const_cast<char*>(ccb0) + C2_ATYF * 8 + ck8) = aw + cw;
       }
       tail_sync();
       TAIL_TP(11)
@@ -994,7 +1102,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         }
         if (has_hv) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) gi[k] += mass * hvl3[k];
+          for (int k = 0; k < 3; ++k) gi[k] += mass * hvl3_of(k);
         }
         if (first && jcslot >= 0) {
 #pragma unroll
@@ -1007,7 +1115,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         }
         if (has_hv) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) dvr[k] -= mass * hvl3[k];
+          for (int k = 0; k < 3; ++k) dvr[k] -= mass * hvl3_of(k);
         }
         l_dualv = hinf3(dvr);
         l_nu = tabs(nui);
@@ -1040,7 +1148,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         for (int k = 0; k < 3; ++k) Fw[k] -= shv[j * 6 + h3 + k];
       }
       for (int c = 0; c < L.nc; ++c) {
-        const T* c_ = cdi + c * cs + h3;
+        const T* c_ = reinterpret_cast<const T*>(reinterpret_cast<const char*>(cdi + c * cs) + h3b);
         const T m = cmask(c);
 #pragma unroll
         for (int k = 0; k < 3; ++k) Fw[k] += m * c_[C2_ATYF + k];
@@ -1171,21 +1279,63 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     }
     TAIL_TP(7)
    }
-    store_instance();
-    if constexpr (SLICED) {
-      if (requeue) q_push(lidx);
-      else if (lane == 0) atomicAdd(q_retired, 1u);
+    if (SLICED && requeue) {
+      // The switch in three round trips (the first version took ten, ~58 us of a wavefront under load): (1) the park stores and,
+      // with them, the ticket for the NEXT entry; (2) once the stores have landed: this instance's place at the tail, and the entry
+      // the ticket points at; (3) that entry's record and decade slot together (unpark).
+      park_instance();
+      unsigned int tk = 0u;
+      if (lane == 0) tk = atomicAdd(q_head, 1u);
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every store of the record has completed before the entry appears
+      __builtin_amdgcn_wave_barrier();
+      int got = -1;
+      if (lane == 0) {
+        const unsigned int pos = atomicAdd(q_tail, 1u);
+        int* en = ring + (tk & (unsigned int)ring_mask);
+        got = __hip_atomic_load(en, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int* ep = ring + (pos & (unsigned int)ring_mask);
+        if (pos > (unsigned int)ring_mask) {  // (the ring has wrapped: the place must have been consumed -- it has, long ago)
+          for (unsigned int spins = 0; __hip_atomic_load(ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0; ++spins) {
+            if (spins > (1u << 23)) { atomicOr(Bf.counters + FLAT_COUNTERS_ERR, 2u); break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        const int dslp = kexp - kexp_lo;
+        __hip_atomic_store(ep, lidx | FLAT_PARKED | ((dslp >= 0 && dslp < ndec ? dslp : 15) << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (unsigned int spins = 0; got < 0; ++spins) {   // (entries were waiting when the slice ended: normally it is there)
+          if (__hip_atomic_load(q_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)nslots) break;
+          if (spins > (1u << 23)) { atomicOr(Bf.counters + FLAT_COUNTERS_ERR, 1u); break; }
+          __builtin_amdgcn_s_sleep(32);
+          got = __hip_atomic_load(en, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (got >= 0) __hip_atomic_store(en, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      next_slot = __builtin_amdgcn_readfirstlane(got);
+      ++n_requeues;
+      TAIL_TP(19)
+    } else {
+      store_instance();
+      if constexpr (SLICED) { if (lane == 0) atomicAdd(q_retired, 1u); }
     }
   }
 #ifdef LOIKB_TAIL_PROF
+  TAIL_TP(12)   // (what is left: the last, empty fetch -- with time slices the wait for the launch's last instances)
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     for (int k = 0; k < 8; ++k) g_tail_prof[k] = prof_[k];
     for (int k = 8; k < 20; ++k) g_tail_prof[2 + k] = prof_[k];
     g_tail_prof[8] = n_wave_iters;
     g_tail_prof[9] = (clock64() - clk0_) * 100000ull / (wall_clock64() - wall0_ + 1);
   }
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_tail_prof_all[k], prof_[k]);
+    for (int k = 8; k < 20; ++k) atomicAdd(&g_tail_prof_all[2 + k], prof_[k]);
+    atomicAdd(&g_tail_prof_all[8], (unsigned long long)n_wave_iters);
+    atomicAdd(&g_tail_prof_all[9], 1ull);
+  }
 #endif
   if (lane == 0) {
+    atomicAdd(&Bf.counters[1], n_inst_iters);
+    if (n_requeues) atomicAdd(&Bf.counters[LEAN_Q_REQUEUES], n_requeues);
     atomicAdd(&Bf.counters[5], n_wave_iters);
     atomicAdd(&Bf.counters[6], n_slot_loads >> 16);
     atomicAdd(&Bf.counters[FLAT_COUNTERS_SLOT_HITS], n_slot_hits);

@@ -245,6 +245,8 @@ struct loikb_solver_impl {
     size_t hslots_bytes = 0;
     void* d_fslots = nullptr;            // decade slots of the flat engine (W rows, Dinv per joint and decade)
     size_t fslots_bytes = 0;
+    void* d_park = nullptr;              // k_flat2<.., SLICED>: where instances whose time slice is used up are parked
+    size_t park_bytes = 0;
     std::vector<int> h_wave;             // host scratch for the compaction scan
     loikb_stats stats{};
     int rc = 0;
@@ -1020,6 +1022,7 @@ void destroy_chunks(loikb_solver_impl* S)
     if (C.h_counters) (void)hipHostFree(C.h_counters);
     if (C.d_hslots) (void)hipFree(C.d_hslots);
     if (C.d_fslots) (void)hipFree(C.d_fslots);
+    if (C.d_park) (void)hipFree(C.d_park);
     if (C.ev_k0) (void)hipEventDestroy(C.ev_k0);
     if (C.ev_k2) (void)hipEventDestroy(C.ev_k2);
     if (C.ev_k1) (void)hipEventDestroy(C.ev_k1);
@@ -1129,6 +1132,18 @@ int ensure_hslots(loikb_solver_impl* S)
         return LOIKB_ERR_HIP;
       }
       C.fslots_bytes = need;
+    }
+    // park records of the time-sliced launch (k_flat2 only: 17..32 joints): ~19 KB per instance, allocated for the batch sizes the
+    // slices are used on (flat_slice_window); a handle that cannot have them simply runs unsliced
+    if (S->flat.G == F2G && flat_takes_diagonal(S) && S->tune.flat_slice > 0) {
+      for (Chunk& C : S->chunks) {
+        const size_t need = (size_t)C.B * flat2_park_stride(S->nc, true) * sizeof(double);
+        if (need <= C.park_bytes) continue;
+        if (C.d_park) HIPCHK(hipFree(C.d_park));
+        C.d_park = nullptr; C.park_bytes = 0;
+        if (hipMalloc(&C.d_park, need) != hipSuccess) { (void)hipGetLastError(); continue; }
+        C.park_bytes = need;
+      }
     }
     if (flat_applicable(S) || !S->plan.lean) return LOIKB_OK;
     if (!S->have_problem) return LOIKB_OK;  // (the lean engine's slots are only needed once a solve cannot use the flat engine)
@@ -1700,11 +1715,18 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           // (an ordered launch runs to completion: its long runners start first and must not go to the back of the queue.  Time
           //  slices for everything behind the predicted-long prefix were tried: the SLICED build's agent-scope loads / stores of
           //  the records cost the short instances more than the slices bring -- 12.2 ms against 10.6)
-          // (round 4: off by default.  With the iteration at 2.9 instead of 3.6 us the switch -- ~410 scattered agent-scope stores, ~90
-          //  loads and the set-up again -- costs more than the slices bring: headline in arrival order 10.7 ms without, 11.2 / 11.4 /
-          //  11.4 / 11.7 / 13.1 ms with slices of 256 / 160 / 128 / 96 / 64.  LOIKB_FLAT_SLICE=q switches it on.)
+          // Round 4: OFF by default.  A sliced-out instance is now parked (its lane state and LDS blocks in a lane-contiguous record of
+          // its own, ~40 row accesses each way, the ticket for the next entry drawn with the stores, the decade slot fetched with the
+          // record: three round trips instead of ten through the tile records) -- and with the iteration at 2.9 instead of 3.6 us the
+          // slices still bring only 0..2.5 %: headline batch in arrival order, k_flat2 alone, ms: unsliced 9.47, slices of 192 / 128 /
+          // 96 / 64 / 48 / 32: 9.32 / 9.28 / 9.32 / 9.76 / 11.45 / 13.9; 131 072 instances 16.73 -> 16.31 (128); 32 768: 5.87 -> 5.82;
+          // 16 384 and below: slower (one straggler chain whatever the order).  A switch costs ~27 us of a wavefront under load (five
+          // dependent trips to the L2 / HBM at ~2.5 us each when 2048 wavefronts share them), a slice of 64 iterations 190 us.
+          // LOIKB_FLAT_SLICE=q switches it on.
+          const size_t park_need = (size_t)n_cur * flat2_park_stride(S->nc, true) * sizeof(double);
           (void)resident;
-          const int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice : 0;
+          int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice : 0;
+          if (quantum > 0 && (C->d_park == nullptr || park_need > C->park_bytes)) quantum = 0;
           // (not for a handle on a stream of its own: that is how batches are kept in flight side by side, and then the other
           //  batch's bulk fills this one's ragged end -- slicing only adds its switches, and its wavefronts that wait for queue
           //  entries hold slots the other launch could use: two headline batches in flight 21.5 ms per pair without, 24.9 with)
@@ -1712,7 +1734,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
   hipLaunchKernelGGL((k_flat2<FLAT_NA_SMALL, WPE, ##__VA_ARGS__>), grid, dim3(WAVE), lds2, C->stream,                            \
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
                      (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
-                     (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv, C->ring_cap - 1, quantum)
+                     (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv, C->ring_cap - 1, quantum,       \
+                     (double*)C->d_park, flat2_park_stride(S->nc, true))
           const int hm = S->per_link ? 3 : href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
           if (hm == 3) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 3); else LOIKB_LAUNCH_FLAT2(2, false, 3); }
           else if (hm == 2) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 2); else LOIKB_LAUNCH_FLAT2(2, false, 2); }
@@ -3284,6 +3307,15 @@ int loikb_debug_wave_dbg(unsigned long long* out)
 int loikb_debug_tail_prof(unsigned long long* out)
 {
   HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(loikb::g_tail_prof), sizeof(unsigned long long) * 32));
+  return LOIKB_OK;
+}
+int loikb_debug_tail_prof_all(unsigned long long* out, int reset)   // the phases summed over all wavefronts since the last reset
+{
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(loikb::g_tail_prof_all), sizeof(unsigned long long) * 32));
+  if (reset) {
+    unsigned long long z[32] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(loikb::g_tail_prof_all), z, sizeof(z)));
+  }
   return LOIKB_OK;
 }
 #endif

@@ -19,8 +19,10 @@ for B in [int(x) for x in sys.argv[1:]] or [64, 65536]:
     prm = dict(wl["params"])
     s = loik_amd.BatchedLoik(wl["model"], B, tail_max_instances=1 << 24, **prm)
     s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
-    for _ in range(2):
-        s.Solve()
+    s.Solve()
+    z = (C.c_ulonglong * 32)()
+    L.loikb_debug_tail_prof_all(z, 1)
+    s.Solve()
     st = s.stats()
     out = (C.c_ulonglong * 32)()
     assert L.loikb_debug_tail_prof(out) == 0
@@ -32,4 +34,11 @@ for B in [int(x) for x in sys.argv[1:]] or [64, 65536]:
         B, "flat" if st["flat_launches"] else "NOT flat", st["tail_ms"], st["hslots_ms"], n, tot / n, tot / n / mhz, mhz))
     for k in ORDER:
         print("   %-44s %8.0f cycles  %5.1f %%" % (NAMES[k], out[idx(k)] / n, 100.0 * out[idx(k)] / tot))
+    al = (C.c_ulonglong * 32)()
+    L.loikb_debug_tail_prof_all(al, 1)
+    na, nw = al[8], al[9]
+    tota = sum(al[idx(k)] for k in ORDER)
+    print("  ALL %d wavefronts of the launch: %d iterations, %.0f cycles per iteration of wavefront time (incl. waits for the queue)" % (nw, na, tota / max(na, 1)))
+    for k in ORDER:
+        print("   %-44s %8.0f cycles  %5.1f %%" % (NAMES[k], al[idx(k)] / max(na, 1), 100.0 * al[idx(k)] / max(tota, 1)))
     s.close()
