@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LOIKB_VERSION 401  /* round.minor: bumped whenever a struct or an entry point of this header changes */
+#define LOIKB_VERSION 402  /* round.minor: bumped whenever a struct or an entry point of this header changes */
 
 /* ---- status codes -------------------------------------------------------------------------------- */
 enum {
@@ -197,6 +197,11 @@ enum {
 };
 int loikb_get_solver_info(loikb_solver *s, int list, double *out, int out_rows_cap, int *rows);
 int loikb_solver_info_rows_cap(const loikb_solver *s);
+/* Instances of the last logged solve whose lists end before their last iteration: 0 except for a WARM-STARTED solve on the flat
+ * engine's logging build in which an instance's mu left the ten precomputed decades (mu0 * 10^-2 .. 10^7) and the instance was
+ * finished by the engine that writes no lists -- a cold solve in which that happens is repeated on the pass-by-pass implementation
+ * instead, which logs everything; a warm start cannot be repeated (the iterates it began with are gone).                        */
+int loikb_solver_info_truncated(const loikb_solver *s);
 
 /* Outer loop on the device (the caller side of the path: a sampling planner / global IK iterates
  * solve -> integrate -> re-target, README.md:5 of the reference).  The configurations q stay

@@ -52,7 +52,7 @@ class Stats(C.Structure):
                 ("flat_split_launches", C.c_int), ("flat_ordered", C.c_int)]
 
 
-ABI_VERSION = 401   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
+ABI_VERSION = 402   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
 
 # enums of loik_amd.h
 F64, F32 = 0, 1
@@ -84,7 +84,7 @@ EXPORTED_SYMBOLS = [
     "loikb_batch", "loikb_nv", "loikb_njoints", "loikb_last_error", "loikb_status_string", "loikb_version",
     "loikb_device_count", "loikb_sweep_schedule", "loikb_integrate", "loikb_synchronize", "loikb_plan_string", "loikb_pass",
     "loikb_update_references", "loikb_update_eq_constraint", "loikb_add_eq_constraint", "loikb_remove_eq_constraint",
-    "loikb_num_eq_c", "loikb_eq_c_capacity", "loikb_active_constraint_ids", "loikb_get_solver_info", "loikb_solver_info_rows_cap", "loikb_builtin_model", "loikb_builtin_joint_name",
+    "loikb_num_eq_c", "loikb_eq_c_capacity", "loikb_active_constraint_ids", "loikb_get_solver_info", "loikb_solver_info_rows_cap", "loikb_solver_info_truncated", "loikb_builtin_model", "loikb_builtin_joint_name",
     "loikb_builtin_joint_id", "loikb_flat_schedule"]
 
 _lib = None
@@ -124,6 +124,7 @@ def lib():
     L.loikb_active_constraint_ids.argtypes = [C.c_void_p, _ip, C.c_int]
     L.loikb_get_solver_info.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _ip]
     L.loikb_solver_info_rows_cap.argtypes = [C.c_void_p]
+    L.loikb_solver_info_truncated.argtypes = [C.c_void_p]
     L.loikb_set_max_iter.argtypes = [C.c_void_p, C.c_int]
     for n in ["loikb_set_rho", "loikb_set_mu", "loikb_set_tol_primal_inf", "loikb_set_tol_tail_solve"]:
         getattr(L, n).argtypes = [C.c_void_p, C.c_double]
@@ -586,6 +587,7 @@ class BatchedLoik:
             _check(self.L.loikb_get_solver_info(self.h, k, a.ctypes.data_as(_dp), cap, rows.ctypes.data_as(_ip)))
             out[name] = a
         out["rows"] = rows
+        out["truncated_instances"] = int(self.L.loikb_solver_info_truncated(self.h))   # 0 but for a warm start whose mu left the decades
         return out
 
     def stats(self):

@@ -266,6 +266,7 @@ struct loikb_solver_impl {
   // deterministic: the counts are exact) -- or when the caller says that consecutive problems resemble each other
   // (LOIKB_OPT_ORDER_FROM_PREVIOUS: a tracking planner), and then under the watch of the timing comparison below.
   unsigned long long inputs_epoch = 1;
+  int log_truncated = 0;     // instances of the last logged solve whose SolverInfo lists end early (see run_logged)
   PassLayout PL{};
   double* d_pass = nullptr;
   int* d_pass_cslot = nullptr;
@@ -2674,7 +2675,7 @@ int loikb_update_references(loikb_solver* S, const double* H_refs, const double*
   return reset_home(S, RS_HCACHE);  // H_i = rho I + H_ref_i + ...: the cached factors are stale
 }
 
-static int run_logged(loikb_solver_impl* S);
+static int run_logged(loikb_solver_impl* S, int redo_reset = 0);
 
 int loikb_solve(loikb_solver* S)
 {
@@ -2684,7 +2685,7 @@ int loikb_solve(loikb_solver* S)
   int rc;
   // ik_id_data_.ResetRecursion(); ResetSolver()  (hpp:370-374)
   if ((rc = reset_home(S, RS_RECURSION | RS_SOLVER))) return rc;
-  return S->opt.logging ? run_logged(S) : run_main_loop(S);
+  return S->opt.logging ? run_logged(S, RS_RECURSION | RS_SOLVER) : run_main_loop(S);
 }
 
 int loikb_solve_full(loikb_solver* S, const double* q, const double* H_ref, const double* v_ref, const int* c_ids,
@@ -2693,7 +2694,7 @@ int loikb_solve_full(loikb_solver* S, const double* q, const double* H_ref, cons
 {
   int rc = loikb_solve_init(S, q, H_ref, v_ref, c_ids, nc, Ais, bis, lb, ub, nbound, in_flags);
   if (rc) return rc;
-  return S->opt.logging ? run_logged(S) : run_main_loop(S);
+  return S->opt.logging ? run_logged(S, S->opt.warm_start ? 0 : (RS_SOLVER | RS_DATA_COLD)) : run_main_loop(S);
 }
 
 int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const double* Ai, const double* bi, int in_flags)
@@ -2708,7 +2709,7 @@ int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const doubl
   // upstream: the way to solve after AddEqConstraint / RemoveEqConstraint changed the set, possibly to the empty one)
   if (c_id >= 0 && (rc = update_eq_single(S, c_id, Ai, bi, in_flags))) return rc;
   if ((rc = fwd_pass_init(S, q, in_flags))) return rc;
-  return S->opt.logging ? run_logged(S) : run_main_loop(S);
+  return S->opt.logging ? run_logged(S, S->opt.warm_start ? 0 : (RS_SOLVER | RS_DATA_COLD)) : run_main_loop(S);
 }
 
 // problem_.UpdateEqConstraint (hpp:178-238), AddEqConstraint (:244-286), RemoveEqConstraint (:292-319) between solves
@@ -2883,20 +2884,30 @@ static bool logged_on_flat(const loikb_solver_impl* S)
 // Solve with logging_ = true: SolverInfo lists filled.  On the flat engine when the solve qualifies (logged_on_flat), else the
 // main loop on the plain pass implementation (k_pass_solve), whose results are then read from the pass state (loikb_get), like
 // after loikb_pass.
-static int run_logged(loikb_solver_impl* S)
+// redo_reset: the reset_home flags that put the solver into the state this solve starts from, when that state can be put back (a cold
+// Solve(), a solve that began with a cold data reset); 0 when it cannot (a warm start: the iterates the solve began with are gone)
+static int run_logged(loikb_solver_impl* S, int redo_reset)
 {
   int rc;
   if ((rc = ensure_log(S))) return rc;
-  if (!logged_on_flat(S) && (rc = start_mu(S))) return rc;  // (run_main_loop does it on the other path)
-  if (logged_on_flat(S)) {
-    // the fast engine writes the lists itself (k_flat<.., LOG>); an instance whose mu leaves the ten configured decades is
-    // finished by k_tail as in any solve and its lists end where it left (loikb_stats.lean_escaped says how many)
+  S->log_truncated = 0;
+  bool on_flat = logged_on_flat(S);
+  if (on_flat) {
+    // the fast engine writes the lists itself (k_flat<.., LOG>).  An instance whose mu leaves the configured decades is finished by
+    // k_tail, which writes no lists: its lists would end where it left the flat engine.  When that happens and the
+    // solve's starting state can be put back, the whole solve is run again on the pass-by-pass implementation, which logs every
+    // iteration of every instance; when it cannot (warm start), loikb_solver_info_truncated() says how many instances are short.
     HIPCHK(hipMemsetAsync(S->d_log_rows, 0, sizeof(int) * (size_t)S->B, S->stream));
     HIPCHK(hipStreamSynchronize(S->stream));
     if ((rc = run_main_loop(S))) return rc;
     S->have_log = true;
-    return LOIKB_OK;
+    if (S->stats.lean_escaped == 0) return LOIKB_OK;
+    if (!redo_reset) { S->log_truncated = S->stats.lean_escaped; return LOIKB_OK; }
+    if ((rc = reset_home(S, redo_reset))) return rc;
+    if ((rc = ensure_log(S))) return rc;
+    on_flat = false;
   }
+  if ((rc = start_mu(S))) return rc;  // (run_main_loop does it on the other path)
   const PassParams P = pass_params(S);
   S->pass_active = false;  // the resets / updates of this solve went to the tiles: reload
   if ((rc = ensure_pass_state(S, P))) return rc;
@@ -2959,6 +2970,7 @@ static int finish_logged(loikb_solver_impl* S, const PassParams& P)
 }
 
 int loikb_solver_info_rows_cap(const loikb_solver* S) { return (S && S->have_log) ? S->log_rows_cap : 0; }
+int loikb_solver_info_truncated(const loikb_solver* S) { return (S && S->have_log) ? S->log_truncated : 0; }
 
 int loikb_get_solver_info(loikb_solver* S, int list, double* out, int out_rows_cap, int* rows_out)
 {

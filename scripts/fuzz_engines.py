@@ -51,7 +51,7 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
     if only is None and os.environ.get("FUZZ_ONLY"):
         only = int(os.environ["FUZZ_ONLY"])
     saved_env = {k: os.environ[k] for k in ENV_KEYS if k in os.environ}
-    summary = dict(cases=0, mismatches=0, unconverged_only=0, refused=0, flat_cases=0, worst_dz_same=0.0, instances=0, off_count=0, by_engine={})
+    summary = dict(cases=0, mismatches=0, unconverged_only=0, unconverged_cases=[], refused=0, flat_cases=0, worst_dz_same=0.0, instances=0, off_count=0, by_engine={})
     for case in range(ncase):
         for_flat = bool(rng.random() < flat_bias)
         nb = int(rng.integers(17 if for_flat else 3, 45))
@@ -176,6 +176,7 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
                                       res_tol=(1e-7, 1e-5))
                     ok, why = True, "unconverged-only: %d instance(s) stopped by max_iter differ" % int(stopped.sum())
                     summary["unconverged_only"] += 1
+                    summary["unconverged_cases"].append("case %d: %s; first failure: %s" % (case, why, str(e)[:160]))
                 except AssertionError:
                     pass
             if only is not None:

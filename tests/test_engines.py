@@ -411,7 +411,10 @@ def test_fuzz_slice_every_engine(monkeypatch):
     out = _fuzz().fuzz(40, 31337, verbose=False, max_batch=700)
     assert out["cases"] + out["refused"] == 40 and out["instances"] > 5000, out
     assert out["mismatches"] == 0, out
-    assert out["unconverged_only"] <= 2, out
+    # (a case whose only differences are instances that max_iter stopped unconverged is named, not waved through)
+    for c in out["unconverged_cases"]:
+        print("unconverged-only:", c)
+    assert out["unconverged_only"] == 0, out["unconverged_cases"]
 
 
 def test_fuzz_slice_flat_engine(monkeypatch):
@@ -420,7 +423,9 @@ def test_fuzz_slice_flat_engine(monkeypatch):
     for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE"):
         monkeypatch.delenv(k, raising=False)
     out = _fuzz().fuzz(30, 4242, verbose=False, max_batch=700, flat_bias=1.0)
-    assert out["mismatches"] == 0 and out["unconverged_only"] <= 1, out
+    for c in out["unconverged_cases"]:
+        print("unconverged-only:", c)
+    assert out["mismatches"] == 0 and out["unconverged_only"] == 0, (out["unconverged_cases"], out)
     assert out["flat_cases"] >= 15, out   # (batches below 64 instances and trees the schedule refuses run elsewhere)
 
 

@@ -874,6 +874,13 @@ def test_c3_hard_population_against_the_oracle():
     # mu of the last iteration (a decade of mu0): the DEFAULT rule's decisions along the way
     mu_o = np.array([_oracle_mu(m, wl, b, prm) for b in idx[:48]])
     assert np.allclose(s.get("mu")[idx[:48]], mu_o, rtol=1e-12)
+    # the handle's SECOND solve of the batch -- the ordered launch (longest first, by the counts of the solve above) -- against the
+    # oracle directly, not only against the first solve
+    s.Solve()
+    assert s.stats()["flat_ordered"] == 1, s.stats()
+    got2 = fetch_end_to_end(s, idx, nu=False, residuals=True)
+    same2 = assert_end_to_end(got2, out, prm, same_frac=0.99, what="C3 hard population, the handle's second (ordered) solve")
+    assert np.array_equal(same, same2) and np.array_equal(got["z"], got2["z"]) and np.array_equal(got["iter"], got2["iter"])
     s.close()
 
 

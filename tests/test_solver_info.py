@@ -117,6 +117,43 @@ def test_gpu_solver_info_from_the_flat_engine(talos):
 
 
 @pytest.mark.gpu
+def test_gpu_solver_info_is_complete_when_mu_leaves_the_precomputed_decades(talos, monkeypatch):
+    """an instance whose mu leaves the flat engine's precomputed decades is finished by k_tail, which writes no
+    SolverInfo lists.  A cold logged solve in which that happens is repeated on the pass-by-pass implementation: complete lists,
+    equal to the oracle's; a warm-started one cannot be repeated and says how many instances' lists are short"""
+    from loik_amd import workloads
+    monkeypatch.setenv("LOIKB_LEAN_KLO", "0")
+    monkeypatch.setenv("LOIKB_LEAN_DECADES", "2")      # decades 0..1 only: a quarter of the headline's instances visit decade 2
+    monkeypatch.setenv("LOIKB_LEAN_ADAPT", "0")
+    B = 128
+    wl = workloads.talos_c3(B, seed=78)
+    prm = dict(wl["params"], max_iter=200)
+    s = loik_amd.BatchedLoik(talos, B, logging=True, **prm)
+    s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    s.Solve()
+    info = s.solver_info()
+    assert info["truncated_instances"] == 0
+    it, tail = s.get("iter"), s.get("tail_solve_iter")
+    assert (np.round(np.log10(s.get("mu") / prm["mu"])) >= 2).sum() >= 5, "the sample should contain instances beyond decade 1"
+    for b in range(B):
+        r = ref.RefSolver(talos, **prm)
+        r.Solve(*problem_args(wl, b))
+        n = len(r.solver_info(0))
+        assert it[b] == r.get_iter() and info["rows"][b] == n == it[b] - tail[b], (b, it[b], r.get_iter(), info["rows"][b], n)
+        for k, name in enumerate(LISTS):
+            assert_close(info[name][b, :n], r.solver_info(k), 1e-9, "%s b%d" % (name, b))
+    s.close()
+    # warm start: the flat engine's lists of the escaped instances end early, and the handle says so
+    s = loik_amd.BatchedLoik(talos, B, logging=True, **dict(prm, warm_start=True))
+    s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    s.Solve(wl["q"], int(wl["c_ids"][0]), wl["Ais"][0], wl["bis"][:, 0])
+    info = s.solver_info()
+    st = s.stats()
+    assert st["lean_escaped"] > 0 and info["truncated_instances"] == st["lean_escaped"], (st["lean_escaped"], info["truncated_instances"])
+    s.close()
+
+
+@pytest.mark.gpu
 def test_gpu_solver_info_infeasible_fixture_and_errors(talos):
     """the reference fixture's unreachable head target: the lists stop at the iteration that raises the certificate, the tail
     solve only counts (hpp:286-290)"""
