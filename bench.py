@@ -211,6 +211,55 @@ class Shard:
         return dict(solved=float(m[0]), iters=float(m[1]), batch=self.B, infeasible=float(m[2]), unfinished=float(m[3]))
 
 
+class ShardC4(Shard):
+    """BASELINE.json config 4, one GPU's share: `batch` Talos instances, T successive targets per instance through the TAILORED
+    warm-started entry Solve(q, c_id, Ai, bi) (loik-loid-optimized.hpp:596-695) -- the sampling-planner workload.  A step = one
+    tailored solve of the whole share on target k mod T (its own configuration q_t and its own feasible wrist twist b_t, both
+    resident in HBM before the timed region: loik_amd.capi.DeviceArray, LOIKB_IN_DEVICE); FwdPassInit of q_t, UpdateEqConstraint and
+    the warm start are part of the step, as they are of the reference's call.  The converged flags and iteration counts are read back
+    after every step (1 MB per step, inside the timed region: the planner needs them)."""
+
+    def __init__(self, idx, device, wl, flags, max_launch_iters, factory=None, fresh=0, fresh_wl=None):
+        import loik_amd
+        from loik_amd import capi
+        if factory is None:
+            factory = loik_amd.BatchedLoik
+        if callable(wl):
+            wl = wl()
+        self.idx, self.device, self.wl = idx, device, wl
+        self.B = wl["q"].shape[0]
+        self.pool = []
+        self.solver = factory(wl["model"], self.B, device=device, flags=flags, max_launch_iters=max_launch_iters, **wl["params"])
+        t = time.perf_counter()
+        self.solver.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+        self.t_init = time.perf_counter() - t
+        self.link = int(wl["c_ids"][0])
+        dev = (lambda a: capi.DeviceArray(a, device)) if factory is loik_amd.BatchedLoik else (lambda a: a)
+        self.targets = [(dev(q), dev(b[:, 0])) for q, b in wl["steps"]]
+        self.nstep, self.timed, self.acc, self.last, self.err = 0, [], {}, None, None
+        self.rows = []
+
+    def step(self, timed):
+        q, b = self.targets[self.nstep % len(self.targets)]
+        self.nstep += 1
+        s = self.solver
+        s.Solve(q, self.link, self.wl["Ais"][0], b)
+        conv, it = s.get("converged").astype(bool), s.get("iter")
+        if timed:
+            st = s.stats()
+            self.last = st
+            inf = s.get("primal_infeasible").astype(bool)
+            self.rows.append((int(conv.sum()), int(it.sum()), int(inf.sum()), int(((it >= self.wl["params"]["max_iter"] - 1) & ~conv).sum())))
+            for k in ("kernel_ms", "tail_ms", "tail_instances", "tail_instance_iterations", "tail_launches", "total_ms",
+                      "solve_busy_ms", "tail_busy_ms", "instance_iterations", "launches", "hslots_ms", "lean_launches",
+                      "flat_launches", "queue_dry_ms", "flat_split_launches", "flat_ordered"):
+                self.acc[k] = self.acc.get(k, 0) + st.get(k, 0)
+
+    def results(self):
+        m = np.mean(np.array(self.rows, dtype=float), axis=0)
+        return dict(solved=float(m[0]), iters=float(m[1]), batch=self.B, infeasible=float(m[2]), unfinished=float(m[3]))
+
+
 def build_shards(specs):
     """Shard(*spec) for every spec, each on a host thread of its own: the synthetic workload of a shard is generated, uploaded
     and SolveInit'ed concurrently with the others' (eight shards one after the other cost eight times the set-up of one)"""
@@ -218,7 +267,8 @@ def build_shards(specs):
 
     def work(i):
         try:
-            out[i] = Shard(*specs[i])
+            cls = specs[i][0] if isinstance(specs[i][0], type) else Shard
+            out[i] = cls(*(specs[i][1:] if isinstance(specs[i][0], type) else specs[i]))
         except Exception as e:
             errs[i] = e
 
@@ -639,7 +689,11 @@ def main(argv=None, solver_factory=None, device_count=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=HEADLINE_BATCH, help="instances per GPU (weak) / in total (strong)")
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (weak) / in total (strong); default 65536 (c3), 131072 per GPU (c4)")
+    ap.add_argument("--config", choices=["c3", "c4"], default="c3",
+                    help="c3: BASELINE.json's headline (cold Solve() of fresh batches).  c4: BASELINE.json config 4, the sampling-planner workload: "
+                         "2^20 instances over 8 GPUs = 131072 per GPU, T = 4 successive targets per instance through the tailored warm-started "
+                         "Solve(q, c_id, Ai, bi); a step = one tailored solve of every GPU's share")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the whole-body variant reported beside the headline at N = 1")
@@ -653,6 +707,12 @@ def main(argv=None, solver_factory=None, device_count=None):
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--max-launch-iters", type=int, default=0)
     args = ap.parse_args(argv)
+    if args.batch is None:
+        args.batch = HEADLINE_BATCH if args.config == "c3" else 131072
+    if args.config == "c4":
+        args.no_variants = True          # (the variants belong to the headline configuration)
+        args.no_strong_leg = True        # (C4 is defined per GPU share: weak by construction)
+        args.scaling = "weak"
     if args.arrival_order:
         os.environ["LOIKB_FLAT_ORDER"] = "0"   # (read once per handle, at loikb_create)
 
@@ -696,6 +756,14 @@ def main(argv=None, solver_factory=None, device_count=None):
 
     def measure(scaling):
         """build the shards of this process for `scaling`, run W + K steps, aggregate over the job"""
+        if args.config == "c4":
+            make = lambda g: (lambda: workloads.talos_c4(args.batch, T=4, seed=0x101C + 4 + 17 * g))
+            shards = build_shards([(ShardC4, g, device_of(g), make(g), args.flags, args.max_launch_iters, solver_factory) for g in local])
+            elapsed = run_shards(shards, args.steps, args.warmup, barrier if dist is not None else None)
+            res = [sh.results() for sh in shards]
+            cnt = {k: sum(r[k] for r in res) for k in ("solved", "iters", "batch")}
+            elapsed, tot = sharding.aggregate(dist, elapsed, cnt)
+            return shards, res, elapsed, tot
         if scaling == "weak":
             make = lambda g: (lambda: workloads.talos_c3(args.batch, seed=0x101C + 3 + g))
             fresh = lambda g: (lambda k: workloads.talos_c3(args.batch, seed=0xF5E5 + 1000 * g + k))
@@ -741,10 +809,25 @@ def main(argv=None, solver_factory=None, device_count=None):
         B0 = res0["batch"]
         total_solved, total_iters, total_B = tot["solved"], tot["iters"], tot["batch"]
         per_gpu = args.batch if args.scaling == "weak" else args.batch // n_total
+        n_ord = (acc0.get("flat_ordered", 0), args.steps)
+        if args.config == "c4":
+            schedule_note = ("C4: T = 4 targets per instance, cycled; every step is the tailored warm-started Solve(q_t, c_id, Ai, b_t) of the "
+                             "whole share (FwdPassInit of q_t + UpdateEqConstraint + solve), q_t / b_t resident in HBM; arrival order "
+                             "(%d of %d launches ordered)" % n_ord)
+        elif nfresh:
+            schedule_note = ("every timed solve is a handle's FIRST solve of a batch it has not seen (another seed of the same generator, "
+                             "resident in HBM before the timed region; the handle solved one other batch before, as a caller's would have): "
+                             "instances in arrival order, %d of %d launches ordered -- schedule_variant.repeat_same_batch is the "
+                             "reference's timing test, one batch again and again, which the engine takes longest first from the second "
+                             "solve on" % n_ord)
+        else:
+            schedule_note = ("--repeat-batch: the timed solves repeat one batch (the reference's timing test); the flat engine took %d of %d "
+                             "of them longest first, by the iteration counts of the handle's previous solve" % n_ord)
         line = {
             "csrc_sha16": csrc_sha16(),
-            "metric": "IK solves/sec to 1e-6 residual, Talos humanoid, batch=%d %s" % (
-                args.batch, "per GPU" if args.scaling == "weak" else "in total"),
+            "metric": ("IK solves/sec to 1e-6 residual, Talos humanoid, batch=%d %s" % (
+                args.batch, "per GPU" if args.scaling == "weak" else "in total")) if args.config == "c3" else
+                      "IK solves/sec to 1e-6 residual, Talos humanoid, %d instances per GPU, tailored warm-started solves (BASELINE config 4)" % args.batch,
             "value": total_solved * args.steps / elapsed,
             "unit": "solves/s",
             "n_gpus": n_total,
@@ -775,13 +858,8 @@ def main(argv=None, solver_factory=None, device_count=None):
                 "instance_iterations_per_s": total_iters * args.steps / elapsed,
                 "solve_init_s_gpu0_incl_pcie": t_init0,
                 "engines_gpu0": plan0,
-                "schedule": (("every timed solve is a handle's FIRST solve of a batch it has not seen (another seed of the same generator, "
-                              "resident in HBM before the timed region; the handle solved one other batch before, as a caller's would have): "
-                              "instances in arrival order, %d of %d launches ordered -- schedule_variant.repeat_same_batch is the "
-                              "reference's timing test, one batch again and again, which the engine takes longest first from the second solve on"
-                              if nfresh else
-                              "--repeat-batch: the timed solves repeat one batch (the reference's timing test); the flat engine took %d of %d of "
-                              "them longest first, by the iteration counts of the handle's previous solve") % (acc0.get("flat_ordered", 0), args.steps)),
+                "bench_config": args.config,
+                "schedule": schedule_note,
                 "spuriously_infeasible_note": "the instances are feasible by construction; `flagged_infeasible_fraction_gpu0` of them trip the "
                                               "reference's primal-infeasibility certificate at tol_primal_inf = 1e-2 (the CPU oracle agrees "
                                               "instance by instance) and are executed and timed but not counted as solves",
@@ -797,6 +875,11 @@ def main(argv=None, solver_factory=None, device_count=None):
                                     "ms_per_step": line["ms_per_step"],
                                     "instance_iterations_per_s": total_iters * args.steps / elapsed}
             line["strong_scaling"] = strong
+            # BASELINE.json words the metric as "batch=65536 at 1/2/4/8 GPUs": that is the STRONG leg.  Both values at the top level,
+            # each under a name that says which it is; `value` stays the weak leg (the contract's "scaling": "weak")
+            line["value_strong"] = strong["value"]
+            line["ms_per_step_strong"] = strong["ms_per_step"]
+            line["value_weak"] = line["value"]
         if n_total == 1 and not args.no_variants and solver_factory is None:
             try:
                 for sh in shards:

@@ -330,6 +330,53 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+class DeviceArray:
+    """a float64 array resident in the HBM of `device` (hipMalloc + one hipMemcpy): what a caller who keeps its inputs on the GPU
+    hands to SolveInit / the tailored Solve (LOIKB_IN_DEVICE) -- the bindings take anything with data_ptr() / is_cuda, e.g. a
+    torch tensor; this is the same without importing torch (bench.py's C4 mode, the tests)"""
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            h = C.CDLL("libamdhip64.so")
+            h.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            h.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            h.hipFree.argtypes = [C.c_void_p]
+            cls._hip = h
+        return cls._hip
+
+    def __init__(self, a, device=0):
+        a = _f64(a)
+        self.shape, self.size, self.ndim, self.dtype, self.is_cuda, self.device = a.shape, a.size, a.ndim, a.dtype, True, int(device)
+        h = self.hip()
+        if h.hipSetDevice(self.device) != 0:
+            raise RuntimeError("hipSetDevice(%d) failed" % self.device)
+        p = C.c_void_p()
+        if h.hipMalloc(C.byref(p), a.nbytes) != 0:
+            raise MemoryError("hipMalloc of %d bytes failed" % a.nbytes)
+        self._p = p
+        if h.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) != 0:   # hipMemcpyHostToDevice
+            raise RuntimeError("hipMemcpy failed")
+
+    def data_ptr(self):
+        return self._p.value
+
+    def numel(self):
+        return self.size
+
+    def free(self):
+        if self._p is not None and self._p.value:
+            self.hip().hipFree(self._p)
+        self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class BatchedLoik:
     """`FirstOrderLoikOptimized` over a batch of independent instances, on one MI355X.
 

@@ -33,9 +33,15 @@ class FakeSolver:
     def SolveInit(self, *a):
         self.args = a
 
-    def Solve(self):
+    def Solve(self, *a):
         self.thread = threading.get_ident()
-        self.out = ref.solve_batch(self.model, *self.args, nthreads=1, **self.prm)
+        if len(a) == 4:   # the tailored form Solve(q, c_id, Ai, bi): stand-in = a cold solve of that configuration and target
+            q, c_id, Ai, bi = a
+            args = list(self.args)
+            args[0], args[4], args[5] = q, np.asarray(Ai).reshape(1, 6, 6), np.asarray(bi).reshape(self.B, 1, 6)
+            self.args = tuple(args)
+            self.tailored = getattr(self, "tailored", []) + [np.asarray(bi).copy()]
+        self.out = ref.solve_batch(self.model, *self.args, nthreads=1, **dict(self.prm, warm_start=False))
         self.nsolve += 1
 
     def synchronize(self):
@@ -117,6 +123,20 @@ def test_default_line_solves_a_fresh_batch_every_step(capsys, monkeypatch):
     solved = sum(int(s.out["converged"].sum()) for d in (0, 1) for s in by_dev[d][1:])
     assert line["value"] == pytest.approx(solved / (line["ms_per_step"] * 3e-3))
     assert "FIRST solve" in line["config"]["schedule"]
+
+
+def test_config_c4_runs_tailored_steps_over_its_targets(capsys, monkeypatch):
+    """--config c4 (BASELINE.json config 4): every shard is one GPU's share, a step is the tailored Solve(q_t, c_id, Ai, b_t) on target
+    k mod 4 of the share's own sequence, value = the steps' solved instances over the wall time, no variants, weak by construction"""
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    line = _run(["--config", "c4", "--gpus", "2", "--steps", "5", "--warmup", "1", "--batch", "12", "--no-cpu-baseline"], capsys)
+    assert len(CREATED) == 2 and all(s.B == 12 and s.nsolve == 6 for s in CREATED)
+    assert line["config"]["bench_config"] == "c4" and "tailored" in line["metric"] and "strong_scaling" not in line and "whole_body_variant" not in line
+    for s in CREATED:
+        assert len(s.tailored) == 6
+        assert np.array_equal(s.tailored[0], s.tailored[4]) and not np.array_equal(s.tailored[0], s.tailored[1])   # T = 4, cycled
+    assert not np.array_equal(CREATED[0].tailored[0], CREATED[1].tailored[0])                                     # every share its own sequence
+    assert line["config"]["batch_total"] == 24 and 0.0 <= line["config"]["solved_fraction"] <= 1.0
 
 
 def test_more_shards_than_devices_needs_opt_in(capsys, monkeypatch):

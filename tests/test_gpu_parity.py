@@ -923,6 +923,38 @@ def test_whole_body_talos44_full_size_against_the_oracle():
     s.close()
 
 
+def test_bench_config_c4_eight_shares_on_the_one_gpu(monkeypatch, capsys):
+    """bench.py --config c4 --gpus 8 (BASELINE.json config 4: 2^20 instances over 8 GPUs, four tailored warm-started targets per
+    instance) with eight small shares on the one visible GPU: the line is the C4 line, and share 0's last tailored solve equals a
+    handle of its own driven with the same sequence from host arrays, bit for bit (device-resident q_t / b_t are only a transport)"""
+    import json
+    import bench
+    monkeypatch.setenv("LOIKB_ALLOW_SHARED_GPU", "1")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    line = bench.main(["--config", "c4", "--gpus", "8", "--steps", "5", "--warmup", "1", "--batch", "768", "--no-cpu-baseline"])
+    capsys.readouterr()
+    assert line["n_gpus"] == 8 and line["config"]["batch_total"] == 8 * 768 and line["config"]["bench_config"] == "c4"
+    assert "tailored" in line["metric"] and line["scaling"] == "weak" and line["config"]["solved_fraction"] > 0.5
+    assert line["roofline"]["kernel"] in ("k_flat2", "k_flat") and 0.0 < line["roofline"]["frac"] < 1.0
+    wl = workloads.talos_c4(768, T=4, seed=0x101C + 4)       # share 0's workload (bench.py: seed + 17 g)
+    s = loik_amd.BatchedLoik(wl["model"], 768, **wl["params"])
+    s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    link = int(wl["c_ids"][0])
+    for k in range(6):
+        q, b = wl["steps"][k % 4]
+        s.Solve(q, link, wl["Ais"][0], b[:, 0])
+    from loik_amd import capi
+    d = loik_amd.BatchedLoik(wl["model"], 768, **wl["params"])
+    d.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    dev = [(capi.DeviceArray(q), capi.DeviceArray(b[:, 0])) for q, b in wl["steps"]]
+    for k in range(6):
+        d.Solve(dev[k % 4][0], link, wl["Ais"][0], dev[k % 4][1])
+    for n in ("iter", "z", "nu", "w", "yis", "converged"):
+        assert np.array_equal(s.get(n), d.get(n)), n
+    assert s.get("converged").mean() > 0.5
+    s.close(); d.close()
+
+
 def _oracle_mu(model, wl, b, prm):
     r = ref.RefSolver(model, **prm)
     r.Solve(*problem_args(wl, int(b)))
