@@ -388,18 +388,13 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   auto awy_of = [&](const char* blk, unsigned int k8) -> T {
     const T* r = reinterpret_cast<const T*>(blk + C2_AW * 8 + 6 * k8);
     const T* y = reinterpret_cast<const T*>(blk + C2_Y * 8);
-    T a = r[0] * y[0];
-#pragma unroll
-    for (int q = 1; q < 6; ++q) a += r[q] * y[q];
-    return a;
+    // (two chains of three: a dependent fp64 multiply-add costs a lone wavefront 32 cycles, the six in a row 190)
+    return ((r[0] * y[0] + r[1] * y[1]) + r[2] * y[2]) + ((r[3] * y[3] + r[4] * y[4]) + r[5] * y[5]);
   };
   auto aty_of = [&](const char* blk, unsigned int k8) -> T {
     const T* A_ = reinterpret_cast<const T*>(blk + C2_A * 8 + k8);
     const T* y = reinterpret_cast<const T*>(blk + C2_Y * 8);
-    T a = A_[0] * y[0];
-#pragma unroll
-    for (int q = 1; q < 6; ++q) a += A_[6 * q] * y[q];
-    return a;
+    return ((A_[0] * y[0] + A_[6] * y[1]) + A_[12] * y[2]) + ((A_[18] * y[3] + A_[24] * y[4]) + A_[30] * y[5]);
   };
   bool resumed = false;  // (SLICED) the instance came back from the queue: no first-iteration corrections
   auto half = [&](const T* x6, T* x3) {
@@ -963,10 +958,10 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       //  ds_bpermute, instead of a write, a fence and the reads: one dependent trip less each, and 13.0 -> 13.9 ms)
       T nb_[NH];
       static_for<0, NH>([&](auto i) { nb_[i] = lds_at(nbuf, field_here<10 * (i % 3), 10>(anc3[i / 3])); });
-      T acc = T(0);
+      T acc = T(0), acc2 = T(0);   // (two chains: see awy_of)
 #pragma unroll
-      for (int i = 0; i < NH; ++i) acc += wc[i] * nb_[i];
-      nui = -(dinv * rn + pair_sum(acc));
+      for (int i = 0; i < NH; ++i) { if (i & 1) acc2 += wc[i] * nb_[i]; else acc += wc[i] * nb_[i]; }
+      nui = -(dinv * rn + pair_sum(acc + acc2));
     }
     // ================= v = J nu: path sum of S^w nu at the world origin, then into the link frame (hxx:125-134) ===============
     T vi3[3], E3[3];
@@ -1026,9 +1021,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       if (iscl) {
         const T* col = reinterpret_cast<const T*>(ccb0 + C2_AWT * 8 + 6 * ck8);
         const T* vc = reinterpret_cast<const T*>(ccb0 + C2_VC * 8);
-        T avk = col[0] * vc[0];
-#pragma unroll
-        for (int q = 1; q < 6; ++q) avk += col[q] * vc[q];
+        const T avk = ((col[0] * vc[0] + col[1] * vc[1]) + col[2] * vc[2]) + ((col[3] * vc[3] + col[4] * vc[4]) + col[5] * vc[5]);
         const T bk = *reinterpret_cast<const T*>(ccb0 + C2_B * 8 + ck8);
         const T ek = avk - bk;
         const T dy = mu_eq * ek;

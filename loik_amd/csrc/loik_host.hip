@@ -209,6 +209,8 @@ struct loikb_solver_impl {
   double* d_q = nullptr;               // [B][nq] configurations resident on the device (outer loop)
   void* d_uni = nullptr;               // A[nc][36], AtA[nc][21], lb[nb], ub[nb] (T)
   void* d_stage = nullptr;             // staging for host<->device copies
+  void* d_getscr[2] = {nullptr, nullptr};  // scratch of the getters that rebuild members (His / pis / UDinv): kept, not malloc'ed per call
+  size_t getscr_bytes[2] = {0, 0};
   size_t stage_bytes = 0;
   // tile layouts: A per instance needs the long constraint record
   Layout L{};
@@ -266,6 +268,7 @@ struct loikb_solver_impl {
   // deterministic: the counts are exact) -- or when the caller says that consecutive problems resemble each other
   // (LOIKB_OPT_ORDER_FROM_PREVIOUS: a tracking planner), and then under the watch of the timing comparison below.
   unsigned long long inputs_epoch = 1;
+  bool href_known = false;   // S->Href holds the reference weight of the problem being set up (loikb_solve_init, before the plan is made)
   int log_truncated = 0;     // instances of the last logged solve whose SolverInfo lists end early (see run_logged)
   PassLayout PL{};
   double* d_pass = nullptr;
@@ -304,6 +307,17 @@ int ensure_stage(loikb_solver_impl* S, size_t bytes)
   S->stage_bytes = 0;
   HIPCHK(hipMalloc(&S->d_stage, bytes));
   S->stage_bytes = bytes;
+  return LOIKB_OK;
+}
+
+int ensure_getscr(loikb_solver_impl* S, int k, size_t bytes)
+{
+  if (bytes <= S->getscr_bytes[k]) return LOIKB_OK;
+  if (S->d_getscr[k]) HIPCHK(hipFree(S->d_getscr[k]));
+  S->d_getscr[k] = nullptr;
+  S->getscr_bytes[k] = 0;
+  HIPCHK(hipMalloc(&S->d_getscr[k], bytes));
+  S->getscr_bytes[k] = bytes;
   return LOIKB_OK;
 }
 
@@ -1115,6 +1129,11 @@ bool flat_applicable(const loikb_solver_impl* S)
 
 int ensure_hslots(loikb_solver_impl* S)
 {
+  if (S->plan.flat && S->have_problem && !flat_applicable(S)) {
+    // (the problem in force cannot use the flat engine: its decade slots -- ~1 GB per 65 536 Talos instances -- go back)
+    for (Chunk& C : S->chunks)
+      if (C.d_fslots) { HIPCHK(hipFree(C.d_fslots)); C.d_fslots = nullptr; C.fslots_bytes = 0; }
+  }
   if (S->plan.flat && (flat_applicable(S) || !S->have_problem)) {
     // decade slots of the flat engine: (ancestors + 1) scalars per lane, decade and instance
     for (Chunk& C : S->chunks) {
@@ -1572,12 +1591,16 @@ void plan_engines(loikb_solver_impl* S)
   else pl.flat = true;
   // with the lean kernel whole batches up to 2^20 instances go to it directly (it is as fast as k_solve's bulk phase and
   // has neither ragged tiles nor compaction); without it k_solve hands over to k_tail at 32768 live instances
-  pl.tail_max = S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : ((pl.lean || pl.flat) ? (1 << 20) : 32768);
+  // (pl.flat is structural; whether THIS problem can use the flat engine also depends on its reference weight -- k_flat, the build a
+  //  logging handle or LOIKB_FLAT_SPLIT=0 runs, takes H_ref = h I only.  A handle that has neither engine for its problem hands over to
+  //  k_tail at 32 768 live instances and solves in two chunks, as before the on-chip engines: ADVICE r03)
+  const bool flat_usable = pl.flat && (!S->href_known || flat_takes_diagonal(S) || href_is_scalar(S));
+  pl.tail_max = S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : ((pl.lean || flat_usable) ? (1 << 20) : 32768);
   // Concurrent chunks pay only in the k_solve + k_tail configuration (measured on MI355X, Talos-32, B = 65536: 1 chunk
   // 52.9 ms/step, 2 chunks 47.9, 3 chunks 48.2, 4 chunks 74: one chunk's latency-bound straggler phase runs beside the
   // other's bulk phase); the lean kernel takes the whole batch in one launch.
   const int ntiles = (S->B + WAVE - 1) / WAVE;
-  pl.nchunks = (ntiles >= 512 && !pl.lean && !pl.flat) ? 2 : 1;
+  pl.nchunks = (ntiles >= 512 && !pl.lean && !flat_usable) ? 2 : 1;
   if (S->tune.chunks > 0) pl.nchunks = S->tune.chunks;
   pl.nchunks = std::max(1, std::min(pl.nchunks, ntiles));
   S->plan = pl;
@@ -1671,7 +1694,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
       // longest first: the order the previous solve of this handle left (k_order_*, loik_lean.hpp) when this launch takes the same
-      // whole set; the decade slots are indexed by the position in the list, so k_fslots and the engine see the same one
+      // whole set; the decade slots are indexed by the INSTANCE slot (sidx / lidx), so k_fslots and the engine find them under any order of the list
       const bool ordered = whole_set && list == C->d_slots && n == n_cur && (split || one) && order_usable(S, C, n_cur);
       const bool order_was_stale = ordered && C->order_epoch != S->inputs_epoch;
       if (C->order_holdoff > 0) --C->order_holdoff;
@@ -2605,6 +2628,7 @@ int loikb_destroy(loikb_solver* S)
   destroy_chunks(S);  // (first: it takes its buffers out of `allocs`)
   for (void* a : S->allocs) if (a) (void)hipFree(a);
   if (S->d_stage) (void)hipFree(S->d_stage);
+  for (int k = 0; k < 2; ++k) if (S->d_getscr[k]) (void)hipFree(S->d_getscr[k]);
   if (S->d_pass) (void)hipFree(S->d_pass);
   if (S->d_pass_cslot) (void)hipFree(S->d_pass_cslot);
   if (S->d_log) (void)hipFree(S->d_log);
@@ -2632,6 +2656,8 @@ int loikb_solve_init(loikb_solver* S, const double* q, const double* H_ref, cons
   if (!S || !q || !H_ref || !v_ref || (nc > 0 && (!c_ids || !Ais || !bis)) || !lb || !ub) return LOIKB_ERR_ARG;
   HIPCHK(hipSetDevice(S->device));
   int rc;
+  memcpy(S->Href, H_ref, 36 * sizeof(double));   // (the plan looks at the reference weight: set_problem stores it again)
+  S->href_known = true;
   if ((rc = ensure_layout(S, in_flags & LOIKB_A_SHARED))) return rc;
   S->pass_active = false;
   // problem_.Reset(); ik_id_data_.Reset(warm_start); ResetSolver()  (hpp:345-352)
@@ -3248,13 +3274,14 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   }
   if (select) {
     final_dst = dst;
-    HIPCHK(hipMalloc(&d_tmp, sizeof(double) * (size_t)S->B * nb * (field == LOIKB_F_HIS ? 21 : 6)));
+    if ((rc = ensure_getscr(S, 0, sizeof(double) * (size_t)S->B * nb * (field == LOIKB_F_HIS ? 21 : 6)))) return rc;
+    d_tmp = S->d_getscr[0];
     dst = (double*)d_tmp;
   }
   if ((field == LOIKB_F_UDINV || field == LOIKB_F_PIS) && S->ud_stale) {
     // instances left by the flat engine carry neither UDinv nor pis (tag -2 in their scalar record): rebuilt in place
-    void* d_scr = nullptr;
-    HIPCHK(hipMalloc(&d_scr, S->esz * (size_t)S->B * nb * 21));
+    if ((rc = ensure_getscr(S, 1, S->esz * (size_t)S->B * nb * 21))) return rc;
+    void* d_scr = S->d_getscr[1];
     if (S->f32)
       hipLaunchKernelGGL(k_rebuild_ud<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, (const JointDesc*)S->d_jd,
                          (const float*)S->d_uni, (float)S->opt.rho, (float)S->opt.mu_equality_scale_factor, (const float*)S->d_href,
@@ -3265,7 +3292,6 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
                          (const double*)S->d_href, (int)S->a_shared, S->B, (double*)d_scr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(S->stream));
-    HIPCHK(hipFree(d_scr));
     S->ud_stale = false;
   }
   if (field == LOIKB_F_HIS) {
@@ -3305,7 +3331,6 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
   }
   if (!to_dev) HIPCHK(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToHost, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
-  if (d_tmp) HIPCHK(hipFree(d_tmp));
   return LOIKB_OK;
 }
 

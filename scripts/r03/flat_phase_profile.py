@@ -19,6 +19,12 @@ for B in [int(x) for x in sys.argv[1:]] or [64, 65536]:
     prm = dict(wl["params"])
     s = loik_amd.BatchedLoik(wl["model"], B, tail_max_instances=1 << 24, **prm)
     s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    if B <= 256:   # a lone wavefront per instance: put the longest instance first, so that wavefront 0's timeline is a long solve's
+        s.Solve()
+        first = int(np.argmax(s.get("iter")))
+        order = np.r_[first, np.delete(np.arange(B), first)]
+        wl["q"], wl["bis"] = wl["q"][order], wl["bis"][order]
+        s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
     s.Solve()
     z = (C.c_ulonglong * 32)()
     L.loikb_debug_tail_prof_all(z, 1)
