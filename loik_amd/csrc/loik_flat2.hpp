@@ -275,7 +275,7 @@ template <int NA> __host__ __device__ constexpr int flat2_off_tail() { return fl
 template <int NA>
 __host__ __device__ __forceinline__ size_t flat2_lds_bytes(int nc, bool has_hv)
 {
-  const size_t n = (size_t)flat2_off_tail<NA>() + (has_hv ? (size_t)F2G * 6 : 0) + (size_t)nc * C2D + FISC + 36;
+  const size_t n = (size_t)flat2_off_tail<NA>() + (has_hv ? (size_t)F2G * 6 : 0) + (size_t)nc * C2D + FISC + 36 + C2D;   // (+ the null block)
   return (n * sizeof(double) + 15) & ~(size_t)15;
 }
 
@@ -330,6 +330,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   for (int k = 0; k < 3; ++k) hd[k] = HM == 1 ? (h ? P.Href[7 * (3 + k)] : P.Href[7 * k]) : T(0);
   T* const hmat = isc + FISC;  // [36] H_ref (HM = 2)
   if (HM == 2 && lane < 36) hmat[lane] = P.Href[lane];
+  for (int e = lane; e < cs; e += WAVE) hmat[36 + e] = T(0);   // the null constraint block
   const T* const hrow = HM == 3 ? P.href_tab + (size_t)(jl + 1) * HREF_ROW : nullptr;  // (H_ref_i, H_ref_i v_ref_i) of this link
   auto hvl3_of = [&](int k) -> T { return HM == 3 ? hrow[36 + h3 + k] : (h ? P.Hv[3 + k] : P.Hv[k]); };  // this half of H_ref v_ref of the link
   int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
@@ -381,8 +382,11 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   // pointers the compiler would otherwise carry across the loop are what it spilled -- three scratch reloads per iteration in the
   // time-sliced build, each an s_waitcnt vmcnt(0) that is cheap while the line sits in the L1 and a trip to the L2 once park
   // records stream through it (iterations 40 % slower under time slices of 64).
+  // The lanes that own no row work on a NULL block (zeros throughout, behind the instance's blocks): the two steps of the update
+  // then run without a branch around them, i.e. in the basic block of the subtree prefix sums, and the scheduler fills the update's
+  // LDS round trips and dependent multiply-adds with the prefix sums' DPP chains.
   const bool iscl = lane < 6 * L.nc;
-  const unsigned int cb_blk = (unsigned int)((iscl ? lane / 6 : 0) * cs * 8), cb_k = (unsigned int)((lane % 6) * 8);
+  const unsigned int cb_blk = (unsigned int)((iscl ? (lane / 6) * cs : L.nc * cs + FISC + 36) * 8), cb_k = (unsigned int)((lane % 6) * 8);
   // (AW y)_k and (A^T y)_k of the constraint of lane 6 c + k: ONE order of operations wherever they are formed (load, loop, store),
   // so that an instance resumed from the queue continues with the bits it would have had
   auto awy_of = [&](const char* blk, unsigned int k8) -> T {
@@ -1018,7 +1022,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       tail_sync();
       const char* const ccb0 = reinterpret_cast<const char*>(cdi) + opaque(cb_blk);   // this lane's constraint block
       const unsigned int ck8 = opaque(cb_k);                                           // 8 k
-      if (iscl) {
+      {
         const T* col = reinterpret_cast<const T*>(ccb0 + C2_AWT * 8 + 6 * ck8);
         const T* vc = reinterpret_cast<const T*>(ccb0 + C2_VC * 8);
         const T avk = ((col[0] * vc[0] + col[1] * vc[1]) + col[2] * vc[2]) + ((col[3] * vc[3] + col[4] * vc[4]) + col[5] * vc[5]);
@@ -1074,7 +1078,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         }
       }
       TAIL_TP(10)
-      if (iscl) {
+      {
         // X* (A^T y_new) = AW y: what the next FwdPass1 adds to p of the constrained joint (hxx:329-331) and, this iteration,
         // the constraint's force in f: (A^T y used) + A^T dy
         const T aw = awy_of(ccb0, ck8);
