@@ -48,7 +48,7 @@ constexpr int FLAT_MAXA = 16;  // strict ancestors per joint (tree depth <= 17)
 constexpr int FOLDW = 10;      // scalars per lane row of the norm fold (80 B: an odd number of 16-byte slots)
 constexpr int FLAT_COUNTERS_SLOT_HITS = 12;  // Bufs::counters[12]: decade changes served from the second LDS slot
 constexpr int FLAT_NA_SMALL = 10;  // k_flat is compiled for <= 10 and <= FLAT_MAXA ancestors per joint
-constexpr int FSLOT_ROWS = 7;      // decade slot of a joint: UDinv (6, link frame) and Dinv
+constexpr int FSLOT_ROWS = 8;      // decade slot of a joint between the passes of k_fslots: UDinv (6, world origin), Dinv, pad -- one 64-byte line
 
 // per lane of a group: the lane's joint (lane j <-> device joint j + 1, depth-first numbering) in the static tree
 struct FlatLane {
@@ -95,13 +95,17 @@ __host__ __device__ __forceinline__ size_t flat_lds_bytes(int nc, int G, bool a_
 }
 
 // Decade slot of an instance: one block of `fblk` scalars per decade.  Between the two passes of k_fslots it holds UDinv / Dinv of
-// the joints as rows [k][lane], k < 7 (fslotA_at); pass B overwrites it with the joints' columns PACKED one after the other
+// the joints as [lane][8] (7 used: fslotA_at); pass B overwrites it with the joints' columns PACKED one after the other
 // (fslotW_at): joint j's column starts at col_j = sum_{i < j} depth_i and holds its depth_j - 1 entries W_{anc_k(j), j}, nearest
 // the root first, then Dinv_j -- 168 scalars for Talos-32 where a [10 rows][32 lanes] rectangle took 320 (the rows of a rectangle
-// beyond a joint's depth are zeros).  fblk = max(7 G, sum_j depth_j).  col_j travels in the upper bits of FlatLane::helper.
+// beyond a joint's depth are zeros).  fblk = max(8 G, sum_j depth_j).  col_j travels in the upper bits of FlatLane::helper.
+// (round 4: [lane][8] instead of [k][lane] -- the seven values of a joint and decade are ONE 64-byte line, written by one lane in one
+//  go.  As rows [k][lane] every line collected its eight 8-byte pieces from joints of different tree levels, i.e. at different steps
+//  of the pipeline, milliseconds of launch time apart for the L2: 3.9 GB written for 1.9 GB of rows and columns.)
 __device__ __forceinline__ size_t fslotA_at(int idx, int ndec, int dsl, int fblk, int G, int k, int jlane)
 {
-  return ((size_t)idx * ndec + dsl) * fblk + (size_t)k * G + jlane;
+  (void)G;
+  return ((size_t)idx * ndec + dsl) * fblk + (size_t)jlane * 8 + k;
 }
 __device__ __forceinline__ size_t fslotW_at(int idx, int ndec, int dsl, int fblk, int col)
 {

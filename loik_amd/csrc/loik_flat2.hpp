@@ -1433,7 +1433,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
     for (int r = 0; r < FLAT_JMP; ++r) jrow4[r >> 2] |= (unsigned int)(F.jmp[r] >= 0 ? F.jmp[r] : WAVE) << (8 * (r & 3));
 #pragma unroll
-    for (int t = 0; t < FLAT_RED; ++t) ra2[t >> 1] |= (unsigned int)((F.red[t] >= 0 ? F.red[t] : NA * G) * 8) << (16 * (t & 1));  // (byte offsets)
+    for (int t = 0; t < FLAT_RED; ++t) ra2[t >> 1] |= (unsigned int)((F.red[t] >= 0 ? F.red[t] : flat1_xregion<NA>() + (one_buf ? 1 : 2) * (NA + 1) * G + G) * 8) << (16 * (t & 1));  // (byte offsets; none: nbuf's zero pad)
 #pragma unroll
     for (int q = 0; q < FLAT_PART; ++q) prow4[q >> 2] |= (unsigned int)(F.part[q] >= 0 ? F.part[q] : WAVE) << (8 * (q & 3));
 #pragma unroll
@@ -1455,23 +1455,17 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   auto cmask = [&](int c) -> T { return ((cbits >> c) & 1u) ? T(1) : T(0); };
   const int ccl = lane / 6, ckl = lane - 6 * ccl;
   const bool iscl = lane < 6 * L.nc;
-  T* const ccb = cdi + (iscl ? ccl : 0) * cs;
+  T* const ccb = cdi + (iscl ? ccl : 0) * cs;   // (no null block here as in k_flat2: its 1.3 KB cost the whole-body batch a wavefront per CU)
   // (AW y)_k and (A^T y)_k of the constraint of lane 6 c + k, in ONE order of operations wherever they are formed (see k_flat2)
   auto awy_k = [&]() -> T {
     const T* r = ccb + C2_AW + 6 * ckl;
     const T* y = ccb + C2_Y;
-    T a = r[0] * y[0];
-#pragma unroll
-    for (int q = 1; q < 6; ++q) a += r[q] * y[q];
-    return a;
+    return ((r[0] * y[0] + r[1] * y[1]) + r[2] * y[2]) + ((r[3] * y[3] + r[4] * y[4]) + r[5] * y[5]);
   };
   auto aty_k = [&]() -> T {
     const T* A_ = ccb + C2_A + ckl;
     const T* y = ccb + C2_Y;
-    T a = A_[0] * y[0];
-#pragma unroll
-    for (int q = 1; q < 6; ++q) a += A_[6 * q] * y[q];
-    return a;
+    return ((A_[0] * y[0] + A_[6] * y[1]) + A_[12] * y[2]) + ((A_[18] * y[3] + A_[24] * y[4]) + A_[30] * y[5]);
   };
   bool resumed = false;  // (SLICED) the instance came back from the queue: no first-iteration corrections
   auto force_of_motion = [&](const T* vw, T* E) {  // E = mass * (R0 v_l, R0 v_a + t0 x R0 v_l) from the world-frame motion
@@ -1822,7 +1816,6 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     tail_sync();
 #pragma unroll
     for (int k = 0; k < NA; ++k) xb[k * G + lane] = wc[k] * tau;
-    if (lane == 0) { xb[NA * G] = T(0); xb[NA * G + 1] = T(0); }
     tail_sync();
     T rn;
     {
@@ -1889,9 +1882,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       if (iscl) {  // row ckl of the lane's constraint: A v - b = AW^T v^w - b, dy, y (hxx:410-451)
         const T* col = ccb + C2_AWT + 6 * ckl;
         const T* vc = ccb + C2_VC;
-        T avk = col[0] * vc[0];
-#pragma unroll
-        for (int q = 1; q < 6; ++q) avk += col[q] * vc[q];
+        const T avk = ((col[0] * vc[0] + col[1] * vc[1]) + col[2] * vc[2]) + ((col[3] * vc[3] + col[4] * vc[4]) + col[5] * vc[5]);
         const T bk = ccb[C2_B + ckl];
         const T ek = avk - bk;
         const T dy = mu_eq * ek;

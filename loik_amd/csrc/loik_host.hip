@@ -165,7 +165,7 @@ struct loikb_solver_impl {
     bool ok = false;
     const char* why = "";
     int G = 0, nanc = 0, nscan = 0, njmp = 0;
-    int fblk = 0;  // scalars per decade slot of an instance: max(7 G, sum of the joints' depths)
+    int fblk = 0;  // scalars per decade slot of an instance: max(8 G, sum of the joints' depths)
     std::vector<FlatLane> lanes;
     FlatLane* d_lanes = nullptr;
   } flat;
