@@ -60,8 +60,8 @@ struct Tuning {
   bool flat = true;             // LOIKB_FLAT=0        never use k_flat (the engine without level loops, loik_flat.hpp)
   bool flat_split = true;       // LOIKB_FLAT_SPLIT=0: k_flat (one joint per lane) also where k_flat2 (two lanes per joint) applies
   int flat_split_wpe = 2;       // LOIKB_FLAT_WPE=3: k_flat2 built for three wavefronts per SIMD
-  int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's round-robin time slice in iterations (0 = run to completion; default -1:
-                                // 160 for launches of 12..96 instances per resident wavefront, where the stragglers' tail is worth it)
+  int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's / k_flat1's round-robin time slice in iterations (default: none -- run to
+                                // completion; round 4 measured 0..2.5 % from slices of 96..192 even with parked instances, see run_tail)
   bool flat_zero_state = true;  // LOIKB_FLAT_ZERO_STATE=0: k_flat2 / k_flat1 fetch vis, fis, g, w, z of every instance even straight after a cold reset
   int flat_order_holdoff = 4;   // LOIKB_FLAT_ORDER_HOLDOFF=n: solves in arrival order after an ordered launch that was not shorter (0: never hold off)
   int flat_one_slot = 1;        // LOIKB_FLAT_ONE_SLOT=0: k_flat1 always keeps two decade slots in LDS
