@@ -598,6 +598,17 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     }
     // ---- full width on both lanes of a joint (identical values): k_flat's load, rows indexed by the joint
     T ax[3], v[6], f[6], g[6], Sw[6], SE[6];
+    const bool zero_state = (P.mode & MODE_ZERO_STATE) != 0;
+    // (straight from a cold reset mu = mu0, decade 0: its W columns are requested WITH the record -- one trip to HBM, not a second
+    //  one behind it.  Should the record say otherwise, the loop's slot logic loads what it needs as always.)
+    const int dsl0 = -kexp_lo;
+    const bool slot0 = zero_state && dsl0 >= 0 && dsl0 < ndec;
+    T win0[NH + 1];
+#pragma unroll
+    for (int i = 0; i <= NH; ++i) {
+      const int k = 2 * i + (h ? 1 : 0);
+      win0[i] = (slot0 && isj_lane && (k == NA || k < fdm1)) ? fslots[fslotW_at(slot, ndec, dsl0, frows, fcol + (k == NA ? fdm1 : k))] : T(0);
+    }
     const bool rev = jflags & JF_REVOLUTE;
     const int jflags_h = jflags;
     const T pitch_h = (jflags & JF_HELICAL) ? (T)jd[jl + 1].pitch : T(0);
@@ -605,7 +616,6 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       // (straight from a cold reset -- the plain queue hands every instance out once -- vis, fis, g, w, z are zeros in every
       //  record: ten of the twelve pairs of a joint are not fetched.  A record's 16-byte pairs lie 1 KiB apart in the tiles of
       //  the streaming engine: every pair costs a 64-byte line of its own)
-      const bool zero_state = (P.mode & MODE_ZERO_STATE) != 0;
       typename Vec2<T>::type wz;
       wz.x = T(0); wz.y = T(0);
       const typename Vec2<T>::type csn = ldp<T>(rec, JP_CS), nus = rldp<T, false>(rec, JP_NUS);
@@ -741,7 +751,12 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       for (int k = 0; k < 3; ++k) E[3 + k] = vw[3 + k] + c2[k];
 #pragma unroll
       for (int k = 0; k < 6; ++k) E[k] *= mass;
-      flat_subtree_sum<T>(xb, j, j, G, size, nscan, E, SE);
+      if (zero_state) {   // (v = 0 in every record: the subtree sums are zeros -- five window-doubling exchanges not made)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) SE[k] = T(0);
+      } else {
+        flat_subtree_sum<T>(xb, j, j, G, size, nscan, E, SE);
+      }
       if (has_hv) {
         T hv[6], hw[6], Sh[6];
 #pragma unroll
@@ -756,6 +771,16 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     mu = mu2.x;
     kexp = (int)mu2.y;
     kslot = -(1 << 30); kslot_o = -(1 << 30);
+    if (slot0) {
+      wsel = 0;
+#pragma unroll
+      for (int i = 0; i <= NH; ++i) {
+        const int k = 2 * i + (h ? 1 : 0);
+        if (k <= NA) wl[k * GW + j] = win0[i];
+      }
+      kslot = 0;
+      n_slot_loads = (n_slot_loads + 0x10000u) | (1u << dsl0);
+    }
     status = (int)st2.x;
     iter = (int)bi2.y;
     tail_it = (int)tail_iter0;

@@ -1520,7 +1520,7 @@ int lean_waves_per_cu(const loikb_solver_impl* S)
 // slower than arrival order itself.
 static bool order_usable(const loikb_solver_impl* S, const Chunk* C, int n_cur)
 {
-  if (!S->tune.flat_order || C->order_n != n_cur || (S->opt.flags & LOIKB_OPT_OWN_STREAM)) return false;
+  if (!S->tune.flat_order || C->order_n != n_cur) return false;   // (round 4: handles on a stream of their own are ordered too)
   if (C->order_epoch == S->inputs_epoch) return true;
   return (S->opt.flags & LOIKB_OPT_ORDER_FROM_PREVIOUS) && C->order_holdoff == 0;
 }
@@ -1826,7 +1826,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       int* next = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
       HIPCHK(hipEventRecord(C->ev_k1, C->stream));
       HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
-      if (S->tune.flat_order && whole_set && n_first == n_cur && (split || one) && !(S->opt.flags & (LOIKB_OPT_OWN_STREAM | LOIKB_OPT_FIXED_ITERS))) {
+      if (S->tune.flat_order && whole_set && n_first == n_cur && (split || one) && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS)) {
         // the order for the handle's next solve: longest first by the iteration counts of this one (an instance that escaped to
         // k_tail counts with what it had when it left)
         HIPCHK(hipMemsetAsync(C->d_order_bins, 0, sizeof(unsigned int) * 2 * ORDER_BINS, C->stream));
@@ -1971,7 +1971,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         HIPCHK(hipEventRecord(C->ev_k1, C->stream));
         HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
         const bool lean_orders = S->tune.flat_order && whole_set && n_first_lean == n_cur && quanta.size() == 1 && lean_quantum == 0 &&
-                                 !(S->opt.flags & (LOIKB_OPT_OWN_STREAM | LOIKB_OPT_FIXED_ITERS));
+                                 !(S->opt.flags & LOIKB_OPT_FIXED_ITERS);
         if (lean_orders) {  // the order for the handle's next solve (k_order_*)
           HIPCHK(hipMemsetAsync(C->d_order_bins, 0, sizeof(unsigned int) * 2 * ORDER_BINS, C->stream));
           hipLaunchKernelGGL(k_order_count<T>, grid1(n_cur), dim3(256), 0, C->stream, A.tiles, S->L, n_cur, S->opt.max_iter, C->d_order_bins);
@@ -2032,7 +2032,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     HIPCHK(hipEventRecord(C->ev_k0, C->stream));
     // k_tail as the engine of a whole batch (OSQP rule, robots outside the on-chip engines' domain): longest first from the handle's
     // previous solve, as in the flat and lean engines (its lane groups pull the list in order)
-    const bool tail_whole = whole_set && list == C->d_slots && n == n_cur && !(S->opt.flags & (LOIKB_OPT_OWN_STREAM | LOIKB_OPT_FIXED_ITERS)) &&
+    const bool tail_whole = whole_set && list == C->d_slots && n == n_cur && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS) &&
                             S->tune.flat_order;
     const bool tail_ordered = tail_whole && order_usable(S, C, n_cur);
     const bool tail_order_was_stale = tail_ordered && C->order_epoch != S->inputs_epoch;
