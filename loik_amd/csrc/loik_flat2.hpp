@@ -185,6 +185,74 @@ __device__ __forceinline__ void wave_fold4(int lane, const double* in, double* o
   for (int q = 0; q < 4; ++q) out[q] = uniform_of(k1, 16 * q);
 }
 
+// ---- the stopping test's quick look, in single precision ---------------------------------------------------------------------
+// The common iteration decides nothing (not converged, the certificate's first test fails, mu stays, not the last iteration), but
+// finding that out took the four fp64 maxima of wave_fold4 -- six dependent v_max_f64 with two-register moves between them -- and
+// the compares behind them: ~900 cycles of a lone wavefront's 5700 per iteration, with nothing else to issue.  Rounding to fp32 is
+// monotone, so max_i RN(x_i) = RN(max_i x_i) exactly, and v_max_f32 takes its DPP move in the same instruction: the same four maxima
+// in one register each and a tenth of the latency.  The fp32 maxima then decide the iteration only when they do so with room to
+// spare (every compare is made against a threshold moved 1e-6 to the safe side, the fp32 rounding being 6e-8, and only on values in
+// [1e-30, 1e30]); otherwise -- an iteration that converges, flags, changes mu or is the last, or one within 1e-6 of doing so -- the
+// fp64 fold and the full logic run exactly as before.  Decisions and results are those of the fp64 test, bit for bit.
+#ifndef LOIKB_QUIET32
+#define LOIKB_QUIET32 0
+#endif
+#ifndef LOIKB_QUIET_SKIPS_TOP
+#define LOIKB_QUIET_SKIPS_TOP 1
+#endif
+struct QuietF32 { unsigned int tol_hi; float tpi_hi; bool ok; };   // (tol_hi: the bits of a non-negative float)
+__device__ __forceinline__ QuietF32 quiet_f32_thresholds(double tol_abs, double tol_rel, double tol_primal_inf)
+{
+  QuietF32 q;
+  q.tol_hi = __float_as_uint((float)(tol_abs * 1.000001));
+  q.tpi_hi = (float)(tol_primal_inf * 1.000001);
+  q.ok = tol_rel == 0.0 && tol_abs >= 0.0 && tol_abs < 1e30 && tol_primal_inf > 1e-30 && tol_primal_inf < 1e30;
+  return q;
+}
+__device__ __forceinline__ float hmaxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// in = {primal, dual, dyqp, atdy} of this lane; true: the iteration is certainly a quiet one
+// iter < quiet_limit: the iteration after this one is neither the last of max_iter (the logic's `iter + 2 < max_iter`) nor beyond
+// this launch's share (the loop top's `my_iters >= max_launch_iters`)
+__device__ __forceinline__ int quiet_limit(int max_iter, int max_launch_iters, int iter_at_load)
+{
+  const int a = max_iter - 2, b = max_launch_iters > (1 << 29) ? 0x7fffffff : max_launch_iters + iter_at_load - 1;
+  return a < b ? a : b;
+}
+__device__ __forceinline__ bool quiet_f32(const double* in, const QuietF32& th, int iter, int q_lim)
+{
+  float c[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) c[q] = (float)in[q];   // v_cvt_f32_f64, round to nearest: monotone
+  float k2[2], k1;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(c[q]), __float_as_int(c[q + 2]), false, false);
+    k2[q] = hmaxf(__int_as_float(r[0]), __int_as_float(r[1]));    // lower half: column q over the lane pairs (l, l + 32); upper: q + 2
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(k2[0]), __float_as_int(k2[1]), false, false);
+    k1 = hmaxf(__int_as_float(r[0]), __int_as_float(r[1]));       // row r of the wavefront: column r over the four rows
+  }
+  // four rotations inside the row, each one instruction (2 wait states between a VALU write and a DPP read of the register)
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "+v"(k1));
+  // The compares are made on the BITS of the (non-negative) floats, as unsigned integers in the scalar unit -- the order is the
+  // same, the thresholds are literals there and no vector register holds one over the loop; a NaN's bits are above 1e30's, so the
+  // range checks send it to the fp64 test.  The three products are taken per lane before the values leave the vector registers.
+  float t10, ty;
+  asm("v_mul_f32 %0, 0x411ffff6, %1" : "=v"(t10) : "v"(k1));   // 10 (1 - 1e-6) x
+  asm("v_mul_f32 %0, %1, %2" : "=v"(ty) : "s"(th.tpi_hi), "v"(k1));
+  auto bits = [](float x, int l) { return (unsigned int)__builtin_amdgcn_readlane(__float_as_int(x), l); };
+  const unsigned int p = bits(k1, 0), d = bits(k1, 16), y = bits(k1, 32), a = bits(k1, 48), p10 = bits(t10, 0), d10 = bits(t10, 16), tya = bits(ty, 32);
+  const unsigned int lo = 0x0DA24260u /* 1e-30f */, hi = 0x7149F2CAu /* 1e30f */;
+  const bool not_conv = (p > th.tol_hi) | (d > th.tol_hi);
+  const bool no_cert = (iter == 0) | ((a > tya) & (a >= lo) & (y >= lo) & (a <= hi) & (y <= hi));
+  const bool mu_stays = (p <= d10) & (d <= p10) & (p >= lo) & (d >= lo) & (p <= hi) & (d <= hi);
+  return th.ok & not_conv & no_cert & mu_stays & (iter < q_lim);
+}
+
 template <typename T>
 __device__ __forceinline__ T inf3(const T* x) { return tmax(tmax(tabs(x[0]), tabs(x[1])), tabs(x[2])); }
 
@@ -304,6 +372,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const Layout& L = P.L;
   const bool a_shared = P.mode & MODE_A_SHARED;
   const int lane = threadIdx.x;
+  const QuietF32 qth = quiet_f32_thresholds(P.tol_abs, P.tol_rel, P.tol_primal_inf);
   const int j = lane & 31;       // lanes j and 32 + j <-> device joint j + 1
   const bool h = lane >= 32;     // 0: linear halves, 1: angular halves
   const int h3 = h ? 3 : 0;
@@ -874,6 +943,9 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     int slice_iters = 0;
     unsigned int q_pref_t = 0u, q_pref_h = 0u;
     requeue = false;
+    // the last value of iter from which a quiet iteration may go straight into the next one (see quiet_f32): not the last but one of
+    // max_iter, and this launch's share of iterations not used up (my_iters = iter - iter at load + 1 inside an iteration)
+    const int q_lim = quiet_limit(P.max_iter, P.max_launch_iters, iter);
    while (true) {
     if (SLICED && quantum > 0 && !done) {
       // time slice used up and others wait: to the back of the queue.  The queue's counters are fetched an iteration AHEAD (their
@@ -927,6 +999,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     if (exit_now) break;
     const T* wcur = wl + (size_t)wsel * (NA + 1) * GW;
     TAIL_TP(8)
+   next_iteration:   // (a quiet iteration comes straight back here: nothing above can have changed)
     const unsigned int h3b = (opaque((unsigned int)lane) >> 5) * 24u;   // byte offset of this half in a 6-vector of a constraint block
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
     ++my_iters; any_iter = true;
@@ -1213,11 +1286,29 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const bool fixed = P.mode & MODE_FIXED_ITERS;
     const bool in_tail = (status & ST_TAIL) != 0;
     const bool logic = !fixed && !in_tail;  // the main loop's stopping logic runs
+#ifdef LOIKB_DBG_QUIET
+    if (lane == 0 && in_tail) atomicAdd(&g_tail_prof_all[27], 1ull);
+#endif
     T primal = T(0), dual = T(0), dyqp = T(0), atdy = T(0), dx = T(0), dz = T(0), ubp = T(0), lbm = T(0);
     if (logic) {
       T in[4] = {hmax(l_prt, l_prs), hmax(l_dualv, l_stf), hmax(l_dfis, hmax(l_dyis, l_dw)), hmax(l_dg, l_dstf)}, r[4];
+#ifdef LOIKB_DBG_QUIET
+      if (lane == 0) atomicAdd(&g_tail_prof_all[24], 1ull);
+      if (quiet_f32(in, qth, iter, q_lim) && lane == 0) atomicAdd(&g_tail_prof_all[25], 1ull);
+#endif
+      if (LOIKB_QUIET32 && quiet_f32(in, qth, iter, q_lim)) {   // (the quick look: see quiet_f32)
+        ++iter;
+        TAIL_TP(7)
+        if (SLICED && quantum > 0 && slice_iters + 1 >= quantum) continue;   // (the slice ends: through the loop's top)
+        goto next_iteration;
+      }
       wave_fold4<0u>(lane, in, r);
       primal = r[0]; dual = r[1]; dyqp = r[2]; atdy = r[3];
+#ifdef LOIKB_DBG_QUIET
+      if (lane == 0 && !(!((primal < P.tol_abs) & (dual < P.tol_abs)) & !((iter > 0) & (atdy <= P.tol_primal_inf * dyqp)) & !(primal > T(10) * dual) & !(dual > T(10) * primal) & (iter + 2 < P.max_iter))) atomicAdd(&g_tail_prof_all[26], 1ull);
+      if (lane == 0 && ((primal > T(10) * dual) || (dual > T(10) * primal))) atomicAdd(&g_tail_prof_all[28], 1ull);
+      if (lane == 0 && (iter > 0) & (atdy <= P.tol_primal_inf * dyqp)) atomicAdd(&g_tail_prof_all[29], 1ull);
+#endif
       if (P.tol_rel == T(0)) {
         // The common iteration decides nothing: not converged, the certificate's first test fails, mu stays where it is, not the
         // last iteration.  Five compares side by side and ONE branch; the stopping logic below is a chain of ~30 dependent
@@ -1227,6 +1318,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         if (quiet) {
           ++iter;
           TAIL_TP(7)
+          if (LOIKB_QUIET_SKIPS_TOP && iter <= q_lim && !(SLICED && quantum > 0 && slice_iters + 1 >= quantum)) goto next_iteration;
           continue;
         }
       }
@@ -1413,6 +1505,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const Layout& L = P.L;
   const bool a_shared = P.mode & MODE_A_SHARED;
   const int lane = threadIdx.x;
+  const QuietF32 qth = quiet_f32_thresholds(P.tol_abs, P.tol_rel, P.tol_primal_inf);
   const int j = lane;  // lane <-> device joint j + 1
   T* const xb = reinterpret_cast<T*>(smem_raw);          // load-time rows | path rows [65][6] | W tau products [NA][64]
   T* const wl = xb + flat1_xregion<NA>();                // [2][NA + 1][64]
@@ -1778,6 +1871,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T inv_mu = T(1) / mu;
     int slice_iters = 0;
     requeue = false;
+    const int q_lim = quiet_limit(P.max_iter, P.max_launch_iters, iter);   // (see k_flat2)
    while (true) {
     if (SLICED && quantum > 0 && !done && slice_iters >= quantum) {
       if (q_waiting()) { requeue = true; break; }
@@ -1810,6 +1904,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     }
     if (exit_now) break;
     const T* wcur = wl + (size_t)wsel * (NA + 1) * G;
+   next_iteration:   // (a quiet iteration comes straight back here: see k_flat2)
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
     ++my_iters; any_iter = true;
     ++n_wave_iters;
@@ -2038,6 +2133,11 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T primal = T(0), dual = T(0), dyqp = T(0), atdy = T(0), dx = T(0), dz = T(0), ubp = T(0), lbm = T(0);
     if (logic) {
       T in[4] = {hmax(l_prt, l_prs), hmax(l_dualv, l_stf), hmax(l_dfis, hmax(l_dyis, l_dw)), hmax(l_dg, l_dstf)}, r[4];
+      if (LOIKB_QUIET32 && quiet_f32(in, qth, iter, q_lim)) {   // (the quick look: see quiet_f32)
+        ++iter;
+        if (SLICED && quantum > 0 && slice_iters + 1 >= quantum) continue;
+        goto next_iteration;
+      }
       wave_fold4<0u>(lane, in, r);
       primal = r[0]; dual = r[1]; dyqp = r[2]; atdy = r[3];
       if (P.tol_rel == T(0)) {
@@ -2048,6 +2148,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
                            !(primal > T(10) * dual) & !(dual > T(10) * primal) & (iter + 2 < P.max_iter);
         if (quiet) {
           ++iter;
+          if (LOIKB_QUIET_SKIPS_TOP && iter <= q_lim && !(SLICED && quantum > 0 && slice_iters + 1 >= quantum)) goto next_iteration;
           continue;
         }
       }

@@ -1,0 +1,19 @@
+"""a LONE Talos instance with a fixed iteration count (no stopping logic, no folds): the floor of the iteration time"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import loik_amd
+from loik_amd import workloads, capi
+for name, mk in (("talos32", workloads.talos_c3), ("talos44 whole body", workloads.talos_wholebody)):
+    wl = mk(64)
+    prm = dict(wl["params"], max_iter=501)
+    s = loik_amd.BatchedLoik(wl["model"], 64, flags=capi.OPT_FIXED_ITERS, **prm)
+    s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    best = 1e9
+    for _ in range(5):
+        s.Solve()
+        st = s.stats()
+        own = st["tail_ms"] - st["hslots_ms"]
+        best = min(best, own * 1e3 / max(int(s.get("iter").max()), 1))
+    print("%s %s fixed count: lone instance %.3f us per iteration (launch %.2f ms, %d iterations; engine launches flat %d)" % (
+        os.environ.get("TAG", ""), name, best, own, int(s.get("iter").max()), st["flat_launches"]))
+    s.close()
