@@ -1039,7 +1039,7 @@ template <typename T, int NA>
 __global__ void __launch_bounds__(WAVE)
 k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
          const int* __restrict__ child_list, const FlatLane* __restrict__ fl, int maxdepth, int nanc, int frows, int njmp,
-         const int* __restrict__ slots, int nslots, int G, T* __restrict__ fslots, int kexp_lo, int ndec)
+         const int* __restrict__ slots, int nslots, int G, T* __restrict__ fslots, int kexp_lo, int ndec, int dgrp)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
@@ -1134,22 +1134,35 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
   for (int c = 0; c < NCH_REG; ++c) chl[c] = (isj_lane && c < tp.nchild) ? gbase + child_list[tp.child_start + c] : WAVE;
   tail_sync();
   if (lane < HX) xch[WAVE * HX + lane] = T(0);
+  // The decades go through the two passes in groups of `dgrp` (LOIKB_FSLOT_DGRP, default: all at once): a group's rows of pass A
+  // are read back by pass B while they are still in the L2 of the XCD (ten wavefronts x two instances x eight decades x 2 KB per CU
+  // is 10 MB per XCD, its L2 has 4), at the price of refilling the pipeline over the tree levels once per group.
+  for (int d0 = 0; d0 < ndec; d0 += dgrp) {
+  const int nd = (ndec - d0 < dgrp) ? ndec - d0 : dgrp;
+  if (d0 > 0) {
+    tail_sync();
+    if (lane < HX) xch[WAVE * HX + lane] = T(0);
+  }
   // ---- pass A
   {
     T mu = P.mu0;
-    for (int k = 0; k < kexp_lo; ++k) mu *= T(10);
-    for (int k = 0; k > kexp_lo; --k) mu *= T(0.1);
+    for (int k = 0; k < kexp_lo + d0; ++k) mu *= T(10);
+    for (int k = 0; k > kexp_lo + d0; --k) mu *= T(0.1);
     const int lag = maxdepth - depth;
     tail_sync();
-    for (int st = 0; st < maxdepth + ndec - 1; ++st) {
-      const int dsl = st - lag;
-      const bool on = isj && depth > 0 && dsl >= 0 && dsl < ndec;
+    for (int st = 0; st < maxdepth + nd - 1; ++st) {
+      const int dsl = d0 + st - lag;
+      const bool on = isj && depth > 0 && dsl >= d0 && dsl < d0 + nd;
       T hh[21];
 #pragma unroll
       for (int k = 0; k < 21; ++k) hh[k] = base0[k];
+      // (most joints of a robot have one child: the second and third rows are read only on the steps where a lane at work has them
+      //  -- 21 LDS reads each for every lane of the wavefront otherwise, of the zero row)
+      const bool any2 = __any(on && tp.nchild > 1), any3 = __any(on && tp.nchild > 2);
       if (on) {  // the children's contributions of the previous step (the same decade); a missing child is the zero row
 #pragma unroll
         for (int c = 0; c < NCH_REG; ++c) {
+          if ((c == 1 && !any2) || (c == 2 && !any3)) continue;
           const T* x = xch + chl[c] * HX;
 #pragma unroll
           for (int k = 0; k < 21; ++k) hh[k] += x[k];
@@ -1192,7 +1205,7 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
   lb[NA * WAVE + lane] = T(0);
   __builtin_amdgcn_s_waitcnt(0);
   tail_sync();
-  for (int dsl = 0; dsl < ndec; ++dsl) {
+  for (int dsl = d0; dsl < d0 + nd; ++dsl) {
     T UDw[6], dinv = T(0);
 #pragma unroll
     for (int k = 0; k < 6; ++k) UDw[k] = isj ? fslots[fslotA_at(sidx, ndec, dsl, frows, G, k, jlane)] : T(0);
@@ -1222,6 +1235,7 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
         if (k < depth - 1) fslots[base + k] = Wc[k];
       fslots[base + depth - 1] = dinv;
     }
+  }
   }
 }
 

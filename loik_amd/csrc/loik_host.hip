@@ -60,6 +60,7 @@ struct Tuning {
   bool flat = true;             // LOIKB_FLAT=0        never use k_flat (the engine without level loops, loik_flat.hpp)
   bool flat_split = true;       // LOIKB_FLAT_SPLIT=0: k_flat (one joint per lane) also where k_flat2 (two lanes per joint) applies
   int flat_split_wpe = 2;       // LOIKB_FLAT_WPE=3: k_flat2 built for three wavefronts per SIMD
+  int fslot_dgrp = 0;           // LOIKB_FSLOT_DGRP=g: k_fslots takes the decades through its two passes g at a time (default: all)
   int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's / k_flat1's round-robin time slice in iterations (default: none -- run to
                                 // completion; round 4 measured 0..2.5 % from slices of 96..192 even with parked instances, see run_tail)
   bool flat_zero_state = true;  // LOIKB_FLAT_ZERO_STATE=0: k_flat2 / k_flat1 fetch vis, fis, g, w, z of every instance even straight after a cold reset
@@ -92,6 +93,7 @@ struct Tuning {
     if (const char* e = getenv("LOIKB_FLAT_SPLIT")) flat_split = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_WPE")) flat_split_wpe = atoi(e) == 3 ? 3 : 2;
     if (const char* e = getenv("LOIKB_FLAT_SLICE")) flat_slice = std::max(-1, atoi(e));
+    if (const char* e = getenv("LOIKB_FSLOT_DGRP")) fslot_dgrp = std::max(0, atoi(e));
     if (const char* e = getenv("LOIKB_FLAT_ORDER")) flat_order = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_ZERO_STATE")) flat_zero_state = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_ONE_SLOT")) flat_one_slot = atoi(e);
@@ -1708,11 +1710,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         if (small_na)
           hipLaunchKernelGGL((k_fslots<T, FLAT_NA_SMALL>), hgrid, dim3(WAVE), slds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                              (const TailTopo*)S->d_topo, (const int*)S->d_child_list, (const FlatLane*)S->flat.d_lanes, S->maxdepth,
-                             nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, kexp_lo, ndec);
+                             nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, kexp_lo, ndec, S->tune.fslot_dgrp > 0 ? S->tune.fslot_dgrp : ndec);
         else
           hipLaunchKernelGGL((k_fslots<T, FLAT_MAXA>), hgrid, dim3(WAVE), slds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                              (const TailTopo*)S->d_topo, (const int*)S->d_child_list, (const FlatLane*)S->flat.d_lanes, S->maxdepth,
-                             nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, kexp_lo, ndec);
+                             nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, kexp_lo, ndec, S->tune.fslot_dgrp > 0 ? S->tune.fslot_dgrp : ndec);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(C->ev_k2, C->stream));
       }
