@@ -183,7 +183,8 @@ int loikb_active_constraint_ids(const loikb_solver *s, int *out, int cap); /* re
 
 /* SolverInfo / LoikSolverInfo (task-solver-base.hpp:25-52, loik-loid-optimized.hpp:47-127), filled when the handle was created
  * with options.logging = 1 ("logging residuals, should be disabled for speed", hpp:408): every Solve then runs on the plain
- * pass-by-pass implementation behind loikb_pass (or, for fp64 handles with H_ref = h I, on k_flat's logging build) and records, per instance and main-loop iteration, what
+ * pass-by-pass implementation behind loikb_pass (or, for fp64 handles whose robot the flat engines take, on that engine's logging
+ * build -- any reference weight on k_flat2 / k_flat1, H_ref = h I on k_flat) and records, per instance and main-loop iteration, what
  * upstream pushes after ComputeResiduals (hpp:406-420).  loikb_get returns the state that implementation left.
  *   out[b][k], k = iteration - 1 < rows[b]: the list of instance b ([B][out_rows_cap], zero beyond rows[b]); rows may be NULL.
  *   out_rows_cap = entries per instance the caller's buffer holds: loikb_solver_info_rows_cap() (= max_iter - 1 at the time of
@@ -337,7 +338,7 @@ typedef struct loikb_stats {
   double queue_dry_ms;                    /* flat engine: time from the start of its (last) launch until a lane group first found the
                                              work queue empty -- the bulk phase; the rest of the launch waits for its long runners */
   int flat_split_launches;                /* of flat_launches: those in the build with two lanes per joint (k_flat2,
-                                             loik_amd/csrc/loik_flat2.hpp: robots of 17..32 joints, fp64, no logging)            */
+                                             loik_amd/csrc/loik_flat2.hpp: robots of 17..32 joints, fp64)                        */
   int flat_ordered;                       /* of flat_launches: those that took their instances longest first, in the order the
                                              handle's previous solve left (LOIKB_FLAT_ORDER=0 turns that off)                   */
 } loikb_stats;

@@ -359,7 +359,9 @@ __host__ __device__ __forceinline__ size_t flat2_lds_bytes(int nc, bool has_hv)
 // H_ref v is no multiple of the link's velocity as a force at the world origin: the link velocities are weighted in the link
 // frame, carried to the world origin and summed over the subtrees beside E -- three more prefix sums and one more frame change
 // per iteration.
-template <int NA, int WPE, bool SLICED = false, int HM = 0>
+// LOG: the lists of LoikSolverInfo (loik-loid-optimized.hpp:47-127, filled at hpp:406-420), as k_flat<.., LOG> writes them: every
+// iteration of the main loop folds the four scalars the lists need and stores its row -- no quiet iterations in this build.
+template <int NA, int WPE, bool SLICED = false, int HM = 0, bool LOG = false>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
         int nscan, int njmp, int* ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
@@ -898,6 +900,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       rst<T, false>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), ccb[C2_Y + k]);
       rst<T, false>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), any_iter ? aty_of(reinterpret_cast<const char*>(ccb), (unsigned int)(8 * ckl)) : ccb[C2_ATY + k]);
     }
+    if (LOG && lane == 0 && any_iter) Bf.log_rows[lidx] = iter - ((status & ST_TAIL) ? tail_it : 0);  // (main-loop iterations)
     if (lane == 0) {
       rstp<T, false>(srec, SP_MU, mu, (T)kexp);
       rstp<T, false>(srec, SP_TAG, any_iter ? T(-2) : isc[FI_TGIN], T(0));
@@ -1296,7 +1299,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       if (lane == 0) atomicAdd(&g_tail_prof_all[24], 1ull);
       if (quiet_f32(in, qth, iter, q_lim) && lane == 0) atomicAdd(&g_tail_prof_all[25], 1ull);
 #endif
-      if (LOIKB_QUIET32 && quiet_f32(in, qth, iter, q_lim)) {   // (the quick look: see quiet_f32)
+      if (LOIKB_QUIET32 && !LOG && quiet_f32(in, qth, iter, q_lim)) {   // (the quick look: see quiet_f32)
         ++iter;
         TAIL_TP(7)
         if (SLICED && quantum > 0 && slice_iters + 1 >= quantum) continue;   // (the slice ends: through the loop's top)
@@ -1309,7 +1312,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       if (lane == 0 && ((primal > T(10) * dual) || (dual > T(10) * primal))) atomicAdd(&g_tail_prof_all[28], 1ull);
       if (lane == 0 && (iter > 0) & (atdy <= P.tol_primal_inf * dyqp)) atomicAdd(&g_tail_prof_all[29], 1ull);
 #endif
-      if (P.tol_rel == T(0)) {
+      if (!LOG && P.tol_rel == T(0)) {
         // The common iteration decides nothing: not converged, the certificate's first test fails, mu stays where it is, not the
         // last iteration.  Five compares side by side and ONE branch; the stopping logic below is a chain of ~30 dependent
         // compare -> mask -> branch steps (900 cycles of a lone wavefront's 5400 per iteration) that only the other iterations walk.
@@ -1335,6 +1338,18 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const T tol_p = P.tol_abs + P.tol_rel * tmax(ntol_p, isc[FI_BNORM]);
     const T tol_d = P.tol_abs + P.tol_rel * tmax(ntol_d, P.Hv_inf_norm);
     const int itn = iter + 1;
+    if constexpr (LOG) {
+      if (!in_tail) {   // (the nine lists of k_pass_solve, loik_passes.hpp, in k_flat's order)
+        T inl[4] = {l_prt, l_prs, l_stf, l_dualv}, rl[4];
+        wave_fold4<0u>(lane, inl, rl);
+        const int row = itn - 1;
+        if (lane == 0 && row < Bf.log_cap) {
+          const double vals[9] = {rl[0], rl[1], hmax(rl[0], rl[1]), rl[2], rl[3], hmax(rl[3], rl[2]), mu_used, P.mu_scale * mu_used, mu_used};
+#pragma unroll
+          for (int l = 0; l < 9; ++l) Bf.log[((size_t)l * Bf.log_B + lidx) * Bf.log_cap + row] = vals[l];
+        }
+      }
+    }
     const bool conv = logic && (primal < tol_p) && (dual < tol_d);
     const bool feas_chk = logic && itn > 1;
     const bool c1 = atdy <= P.tol_primal_inf * dyqp;
@@ -1488,7 +1503,7 @@ __host__ __device__ __forceinline__ size_t flat1_lds_bytes(int nc, bool has_hv, 
   return (n * sizeof(double) + 15) & ~(size_t)15;
 }
 
-template <int NA, bool SLICED = false, int HM = 0>
+template <int NA, bool SLICED = false, int HM = 0, bool LOG = false>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
         int nscan, int njmp, int* ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
@@ -1835,6 +1850,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       rst<T, SLICED>(crec + (size_t)(CP_Y + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), ccb[C2_Y + k]);
       rst<T, SLICED>(crec + (size_t)(CP_ATY + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T), any_iter ? aty_k() : ccb[C2_ATY + k]);
     }
+    if (LOG && lane == 0 && any_iter) Bf.log_rows[lidx] = iter - ((status & ST_TAIL) ? tail_it : 0);  // (main-loop iterations)
     if (lane == 0) {
       rstp<T, SLICED>(srec, SP_MU, mu, (T)kexp);
       rstp<T, SLICED>(srec, SP_TAG, (SLICED && requeue) ? T(-3) : any_iter ? T(-2) : isc[FI_TGIN], T(0));
@@ -2133,14 +2149,14 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T primal = T(0), dual = T(0), dyqp = T(0), atdy = T(0), dx = T(0), dz = T(0), ubp = T(0), lbm = T(0);
     if (logic) {
       T in[4] = {hmax(l_prt, l_prs), hmax(l_dualv, l_stf), hmax(l_dfis, hmax(l_dyis, l_dw)), hmax(l_dg, l_dstf)}, r[4];
-      if (LOIKB_QUIET32 && quiet_f32(in, qth, iter, q_lim)) {   // (the quick look: see quiet_f32)
+      if (LOIKB_QUIET32 && !LOG && quiet_f32(in, qth, iter, q_lim)) {   // (the quick look: see quiet_f32)
         ++iter;
         if (SLICED && quantum > 0 && slice_iters + 1 >= quantum) continue;
         goto next_iteration;
       }
       wave_fold4<0u>(lane, in, r);
       primal = r[0]; dual = r[1]; dyqp = r[2]; atdy = r[3];
-      if (P.tol_rel == T(0)) {
+      if (!LOG && P.tol_rel == T(0)) {
         // The common iteration decides nothing: not converged, the certificate's first test fails, mu stays where it is, not the
         // last iteration.  Five compares side by side and ONE branch; the stopping logic below is a chain of ~30 dependent
         // compare -> mask -> branch steps (900 cycles of a lone wavefront's 5400 per iteration) that only the other iterations walk.
@@ -2164,6 +2180,18 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const T tol_p = P.tol_abs + P.tol_rel * tmax(ntol_p, isc[FI_BNORM]);
     const T tol_d = P.tol_abs + P.tol_rel * tmax(ntol_d, P.Hv_inf_norm);
     const int itn = iter + 1;
+    if constexpr (LOG) {
+      if (!in_tail) {   // (the nine lists of k_pass_solve, loik_passes.hpp, in k_flat's order)
+        T inl[4] = {l_prt, l_prs, l_stf, l_dualv}, rl[4];
+        wave_fold4<0u>(lane, inl, rl);
+        const int row = itn - 1;
+        if (lane == 0 && row < Bf.log_cap) {
+          const double vals[9] = {rl[0], rl[1], hmax(rl[0], rl[1]), rl[2], rl[3], hmax(rl[3], rl[2]), mu_used, P.mu_scale * mu_used, mu_used};
+#pragma unroll
+          for (int l = 0; l < 9; ++l) Bf.log[((size_t)l * Bf.log_B + lidx) * Bf.log_cap + row] = vals[l];
+        }
+      }
+    }
     const bool conv = logic && (primal < tol_p) && (dual < tol_d);
     const bool feas_chk = logic && itn > 1;
     const bool c1 = atdy <= P.tol_primal_inf * dyqp;

@@ -1116,11 +1116,11 @@ bool href_is_diagonal(const loikb_solver_impl* S)
   return true;
 }
 // the builds with one instance per wavefront (k_flat2: 17..32 joints, <= FLAT_NA_SMALL ancestors; k_flat1: 33..64) also take a
-// diagonal or a general reference weight shared by the links (their HM = 1 / 2 instantiations); k_flat (logging handles,
+// diagonal or a general reference weight shared by the links (their HM = 1 / 2 instantiations); k_flat (other trees,
 // LOIKB_FLAT_SPLIT=0) takes h I only
 bool flat_takes_diagonal(const loikb_solver_impl* S)
 {
-  if (!S->tune.flat_split || S->f32 || S->opt.logging || !S->flat.ok) return false;
+  if (!S->tune.flat_split || S->f32 || !S->flat.ok) return false;   // (round 4: logging handles too -- the LOG builds)
   return (S->flat.G == F2G && S->flat.nanc <= FLAT_NA_SMALL) || S->flat.G == WAVE;
 }
 bool flat_applicable(const loikb_solver_impl* S)
@@ -1577,7 +1577,7 @@ void plan_engines(loikb_solver_impl* S)
       pl.flat_waves_cu = std::max(pl.flat_waves_cu, (int)std::min<size_t>(8, (160 * 1024) / pw));
     }
   }
-  // (logging = 1 does not keep a solve off the flat engine: k_flat<.., LOG> writes the SolverInfo lists itself)
+  // (logging = 1 does not keep a solve off the flat engines: their LOG builds write the SolverInfo lists themselves)
   const char* never_flat = S->opt.tail_max_instances < 0 ? never : (S->opt.flags & LOIKB_OPT_NO_COMPACTION) ? never : nullptr;
   if (never_flat) pl.why_not_flat = never_flat;
   else if (!S->tune.flat) pl.why_not_flat = S->tune.lean ? "LOIKB_FLAT=0" : "LOIKB_LEAN=0";
@@ -1593,8 +1593,8 @@ void plan_engines(loikb_solver_impl* S)
   else pl.flat = true;
   // with the lean kernel whole batches up to 2^20 instances go to it directly (it is as fast as k_solve's bulk phase and
   // has neither ragged tiles nor compaction); without it k_solve hands over to k_tail at 32768 live instances
-  // (pl.flat is structural; whether THIS problem can use the flat engine also depends on its reference weight -- k_flat, the build a
-  //  logging handle or LOIKB_FLAT_SPLIT=0 runs, takes H_ref = h I only.  A handle that has neither engine for its problem hands over to
+  // (pl.flat is structural; whether THIS problem can use the flat engine also depends on its reference weight -- k_flat, the build
+  //  other trees and LOIKB_FLAT_SPLIT=0 run, takes H_ref = h I only.  A handle that has neither engine for its problem hands over to
   //  k_tail at 32 768 live instances and solves in two chunks, as before the on-chip engines: ADVICE r03)
   const bool flat_usable = pl.flat && (!S->href_known || flat_takes_diagonal(S) || href_is_scalar(S));
   pl.tail_max = S->opt.tail_max_instances > 0 ? S->opt.tail_max_instances : ((pl.lean || flat_usable) ? (1 << 20) : 32768);
@@ -1687,9 +1687,9 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       const double cu_sh = std::max(1.0, S->ncu * ((double)C->B / (double)S->B));
       const int cap_lat = (int)std::min<size_t>(4, (160 * 1024) / flds) * (int)(cu_sh + 0.5);  // k_flat: one wavefront per SIMD
       // two lanes per joint where the layout applies: 17..32 joints, few ancestors, fp64, no lists to write
-      const bool split = S->tune.flat_split && G == F2G && small_na && sizeof(T) == 8 && !S->opt.logging;
+      const bool split = S->tune.flat_split && G == F2G && small_na && sizeof(T) == 8;
       // one instance per wavefront anyway (33..64 joints): the build with nested loops, prefix-sum subtree sums, DPP fold
-      const bool one = S->tune.flat_split && G == WAVE && sizeof(T) == 8 && !S->opt.logging;
+      const bool one = S->tune.flat_split && G == WAVE && sizeof(T) == 8;
       P.max_launch_iters = S->opt.max_iter + 1;
       const int mode_keep = P.mode;
       if (whole_set && S->zero_state && S->tune.flat_zero_state) P.mode |= MODE_ZERO_STATE;
@@ -1763,7 +1763,13 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                      (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv, C->ring_cap - 1, quantum,       \
                      (double*)C->d_park, flat2_park_stride(S->nc, true))
           const int hm = S->per_link ? 3 : href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
-          if (hm == 3) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 3); else LOIKB_LAUNCH_FLAT2(2, false, 3); }
+          if (S->opt.logging) {   // (the SolverInfo lists: unsliced; a diagonal reference weight goes as a general one)
+            quantum = 0;
+            if (hm == 3) LOIKB_LAUNCH_FLAT2(2, false, 3, true);
+            else if (hm >= 1) LOIKB_LAUNCH_FLAT2(2, false, 2, true);
+            else LOIKB_LAUNCH_FLAT2(2, false, 0, true);
+          }
+          else if (hm == 3) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 3); else LOIKB_LAUNCH_FLAT2(2, false, 3); }
           else if (hm == 2) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 2); else LOIKB_LAUNCH_FLAT2(2, false, 2); }
           else if (hm == 1) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 1); else LOIKB_LAUNCH_FLAT2(2, false, 1); }
           else if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true);
@@ -1788,7 +1794,14 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                      (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
                      (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv | (one_buf ? 2 : 0), C->ring_cap - 1, quantum)
           const int hm = S->per_link ? 3 : href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
-          if (hm == 3) {
+          if (S->opt.logging) {   // (as k_flat2's)
+            const int quantum = 0;
+            if (hm == 3) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, 3, true); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, 3, true); }
+            else if (hm >= 1) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, 2, true); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, 2, true); }
+            else if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, 0, true);
+            else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, 0, true);
+          }
+          else if (hm == 3) {
             if (quantum > 0) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, true, 3); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, true, 3); }
             else if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, 3);
             else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, 3);
@@ -2902,7 +2915,8 @@ int loikb_pass(loikb_solver* S, int pass)
 
 static int ensure_log(loikb_solver_impl* S);
 static int finish_logged(loikb_solver_impl* S, const PassParams& P);
-// a logged solve that the flat engine takes whole: fp64, H_ref = h I on every link, one chunk, the batch goes to k_flat directly
+// a logged solve that the flat engine takes whole: fp64, a reference weight the engine of the robot's size takes (k_flat2 / k_flat1:
+// any; k_flat: h I), one chunk, the batch goes to it directly
 static bool logged_on_flat(const loikb_solver_impl* S)
 {
   return S->opt.logging && !S->f32 && flat_applicable(S) && S->plan.nchunks == 1 && S->B >= 64 && S->B <= S->plan.tail_max &&
@@ -3144,8 +3158,8 @@ const char* loikb_plan_string(loikb_solver* S)
   char buf[512];
   const EnginePlan& pl = S->plan;
   if (pl.flat && (flat_applicable(S) || !S->have_problem)) {
-    const bool split = S->tune.flat_split && S->flat.G == F2G && S->flat.nanc <= FLAT_NA_SMALL && !S->f32 && !S->opt.logging;
-    const bool one = S->tune.flat_split && S->flat.G == WAVE && !S->f32 && !S->opt.logging;
+    const bool split = S->tune.flat_split && S->flat.G == F2G && S->flat.nanc <= FLAT_NA_SMALL && !S->f32;
+    const bool one = S->tune.flat_split && S->flat.G == WAVE && !S->f32;
     snprintf(buf, sizeof(buf), "k_fslots + %s (no loops over the tree levels%s) for whole batches up to %d instances (%d wavefronts per "
              "CU, decades mu0*10^%d..%d, %d ancestors per joint, %d scan steps, %d jump rounds)%s; k_solve above that; %d chunk(s)",
              split ? "k_flat2" : one ? "k_flat1" : "k_flat",
@@ -3172,7 +3186,7 @@ const char* loikb_plan_string(loikb_solver* S)
     snprintf(b2, sizeof(b2), "; decades visited by this handle's solves so far: %d..%d (the next solve builds those +-1)", S->seen_lo, S->seen_hi);
     out += b2;
   }
-  if (S->opt.logging && logged_on_flat(S)) out = "logging = 1: k_flat writes the SolverInfo lists; " + out;
+  if (S->opt.logging && logged_on_flat(S)) out = "logging = 1: the flat engine writes the SolverInfo lists; " + out;
   else if (S->opt.logging) out = "logging = 1: every solve runs on the plain pass-by-pass implementation (k_pass_solve) and fills SolverInfo; without it: " + out;
   if (S->per_link && flat_applicable(S)) out += "; per-link references in force (UpdateReferences): the flat engine reads the links' table";
   else if (pl.lean && S->per_link) out += "; per-link references in force (UpdateReferences): k_hslots + k_lean in their per-link instantiations until the next SolveInit";

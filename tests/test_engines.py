@@ -247,8 +247,8 @@ def test_engine_plan_is_made_in_one_place(talos, panda7, monkeypatch):
     s = loik_amd.BatchedLoik(talos, 256, **FIXTURE)
     assert "k_flat2" in s.plan() and "1 chunk" in s.plan() and "any reference cost" in s.plan(), s.plan()
     s.close()
-    s = loik_amd.BatchedLoik(talos, 256, logging=True, **FIXTURE)   # (logging handles: k_flat<LOG>, shared h I only)
-    assert "k_flat (" in s.plan() and "when H_ref = h I" in s.plan(), s.plan()
+    s = loik_amd.BatchedLoik(talos, 256, logging=True, **FIXTURE)   # (logging handles: the same engine, its LOG build -- round 4)
+    assert "k_flat2" in s.plan() and "any reference cost" in s.plan() and "logging = 1" in s.plan(), s.plan()
     s.close()
     monkeypatch.setenv("LOIKB_FLAT", "0")
     s = loik_amd.BatchedLoik(talos, 40000, **dict(FIXTURE, num_eq_c=2))

@@ -80,7 +80,7 @@ def test_gpu_solver_info_matches_oracle(which, request):
 
 @pytest.mark.gpu
 def test_gpu_solver_info_from_the_flat_engine(talos):
-    """logging = 1 keeps a solve on the fast engine: k_flat writes the nine lists itself (one more fold per iteration); the same
+    """logging = 1 keeps a solve on the fast engine: its LOG build writes the nine lists itself (one more fold per iteration); the same
     lists, rows and results as the oracle's, instance by instance -- incl. instances that end in the infeasibility tail solve,
     whose iterations append nothing (hpp:271-319)"""
     from loik_amd import workloads
@@ -89,7 +89,7 @@ def test_gpu_solver_info_from_the_flat_engine(talos):
     prm = dict(wl["params"], max_iter=300)
     s = loik_amd.BatchedLoik(talos, B, logging=True, **prm)
     s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
-    assert "k_flat writes the SolverInfo lists" in s.plan(), s.plan()
+    assert "the flat engine writes the SolverInfo lists" in s.plan(), s.plan()
     s.Solve()
     st = s.stats()
     assert st["flat_launches"] >= 1 and st["tail_instances"] == B and st["lean_escaped"] == 0, st
@@ -106,14 +106,64 @@ def test_gpu_solver_info_from_the_flat_engine(talos):
             assert_close(info[name][b, :n], r.solver_info(k), 1e-9, "%s b%d" % (name, b))
             assert np.all(info[name][b, n:] == 0.0)
         assert_close(z[b], r.z, 1e-9, "z")
-    # the lists restart with every solve; a handle without logging gives the same answers (it runs k_flat2, the build with two
-    # lanes per joint, which sums in another order: same iteration counts here, z to rounding)
+    # the lists restart with every solve; a handle without logging gives the same answers (the same kernel without the lists)
     s.Solve()
     assert np.array_equal(s.solver_info()["rows"], info["rows"])
     s2 = loik_amd.BatchedLoik(talos, B, **prm)
     s2.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
     assert np.array_equal(s.get("iter"), s2.get("iter")) and np.abs(s.get("z") - s2.get("z")).max() < 1e-9
     s.close(); s2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot,weight", [("talos32", "diagonal"), ("talos32", "general"), ("talos32", "per_link"), ("talos44", "scalar"),
+                                          ("talos44", "general")])
+def test_gpu_solver_info_from_the_flat_engines_with_any_reference_weight(robot, weight):
+    """a logged solve whose reference weight is not h I -- diagonal, general, per link -- and a logged solve of a
+    33..64-joint robot stay on the on-chip engines (the LOG builds of k_flat2 / k_flat1) instead of the pass-by-pass
+    implementation: the nine lists, their row counts and the results equal the oracle's, instance by instance"""
+    from loik_amd import workloads
+    model = loik_amd.builtin_model(robot)
+    B = 96
+    wl = workloads.talos_wholebody(B, seed=31, model=model) if robot == "talos44" else workloads.talos_c3(B, seed=31)
+    prm = dict(wl["params"], max_iter=250)
+    Href = np.diag([0.4, 1.5, 0.7, 3.0, 0.2, 2.2])
+    if weight == "general":
+        Q = np.linalg.qr(np.random.default_rng(4).normal(size=(6, 6)))[0]
+        Href = Q @ Href @ Q.T
+        Href = 0.5 * (Href + Href.T)
+    if weight == "scalar":
+        Href = wl["H_ref"]
+    vref = np.array([0.02, -0.01, 0.03, 0.05, -0.04, 0.01])
+    s = loik_amd.BatchedLoik(model, B, logging=True, **prm)
+    s.SolveInit(wl["q"], Href, vref, wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    H_list = v_list = None
+    if weight == "per_link":
+        rng = np.random.default_rng(8)
+        H_list = np.stack([np.diag(rng.uniform(0.2, 3.0, size=6)) for _ in range(model.njoints)])
+        v_list = rng.uniform(-0.05, 0.05, size=(model.njoints, 6))
+        s.UpdateReferences(H_list, v_list)
+    assert "the flat engine writes the SolverInfo lists" in s.plan(), s.plan()
+    s.Solve()
+    st = s.stats()
+    assert st["flat_launches"] >= 1 and st["tail_instances"] == B and st["lean_escaped"] == 0, (s.plan(), st)
+    info = s.solver_info()
+    assert info["truncated_instances"] == 0
+    it, z, tail = s.get("iter"), s.get("z"), s.get("tail_solve_iter")
+    for b in range(B):
+        r = ref.RefSolver(model, **prm)
+        r.SolveInit(wl["q"][b], Href, vref, wl["c_ids"], wl["Ais"], wl["bis"][b], wl["lb"], wl["ub"])
+        if weight == "per_link":
+            r.UpdateReferences(H_list, v_list)
+        r.Solve()
+        assert it[b] == r.get_iter() and tail[b] == int(r.scalar("tail_solve_iter")), (b, it[b], r.get_iter())
+        n = len(r.solver_info(0))
+        assert info["rows"][b] == n == it[b] - tail[b]
+        for k, name in enumerate(LISTS):
+            assert_close(info[name][b, :n], r.solver_info(k), 1e-9, "%s b%d" % (name, b))
+            assert np.all(info[name][b, n:] == 0.0)
+        assert_close(z[b], r.z, 1e-9, "z")
+    s.close()
 
 
 @pytest.mark.gpu
