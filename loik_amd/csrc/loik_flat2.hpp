@@ -1095,25 +1095,32 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       }
       mat3t_vec(R0, X, vi3);  // SE3::actInv(Motion): (R^T (v_l - t x v_a), R^T v_a)
     }
-    T hv3[3];  // this half of H_ref v_i (link frame)
-    if constexpr (HM >= 2) {
-      T vl[3], va[3];
+    auto hrefv_of = [&](const T* vv, T* out) {   // this half of H_ref v (link frame)
+      if constexpr (HM >= 2) {
+        T vl[3], va[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) both_halves(vi3[k], vl[k], va[k]);
+        for (int k = 0; k < 3; ++k) both_halves(vv[k], vl[k], va[k]);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const T* hr = (HM == 3 ? hrow : hmat) + (h3 + k) * 6;
-        hv3[k] = ((hr[0] * vl[0] + hr[1] * vl[1]) + hr[2] * vl[2]) + ((hr[3] * va[0] + hr[4] * va[1]) + hr[5] * va[2]);
+        for (int k = 0; k < 3; ++k) {
+          const T* hr = (HM == 3 ? hrow : hmat) + (h3 + k) * 6;
+          out[k] = ((hr[0] * vl[0] + hr[1] * vl[1]) + hr[2] * vl[2]) + ((hr[3] * va[0] + hr[4] * va[1]) + hr[5] * va[2]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[k] = (HM == 1 ? hd[k] : href_s) * vv[k];
       }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) hv3[k] = (HM == 1 ? hd[k] : href_s) * vi3[k];
-    }
+    };
+    T hv3[3];
+    hrefv_of(vi3, hv3);
     TAIL_TP(2)
     // ================= DualUpdate of the task constraints (hxx:410-451) inside the subtree sum of the links' velocities ==========
-    T l_dyis = T(0), l_av = T(0), l_prt = T(0), l_up = T(0), l_lm = T(0);
-    T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_prs = T(0);
-    T l_dg = T(0), l_g = T(0), l_stf = T(0), l_dstf = T(0), l_dualv = T(0);
+    // What the stopping logic looks at.  The four maxima of every iteration take these values SIGNED (v_max_f64's |x| modifiers do
+    // the abs); what only the rare iterations look at -- the certificate's second test, the tail solve's rule, the getters' norms when
+    // an instance stops, the relative tolerances -- is formed there, from these and from the state the iteration leaves (round 4:
+    // ~34 instructions of every iteration, 14 of them fp64).
+    T s_dy = T(0), s_av = T(0), s_ek = T(0);
+    T l_dfis = T(0), l_dvis = T(0), s_dnu = T(0), s_dz = T(0), s_dw = T(0), s_prs = T(0);
+    T l_dg = T(0), s_stf = T(0), s_dstf = T(0), l_dualv = T(0);
     T fi3[3], si;
     {
       T SEn[3], SHn[3], Fw[3];  // (SHn: HD only -- the subtree sums of the links' H_ref v at the world origin)
@@ -1130,11 +1137,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         const T bk = *reinterpret_cast<const T*>(ccb0 + C2_B * 8 + ck8);
         const T ek = avk - bk;
         const T dy = mu_eq * ek;
-        l_dyis = tabs(dy);
-        l_up = bk * tmax(dy, T(0));
-        l_lm = bk * tmin(dy, T(0));
-        l_prt = tabs(ek);
-        l_av = tabs(avk);
+        s_dy = dy; s_ek = ek; s_av = avk;
         *reinterpret_cast<T*>(const_cast<char*>(ccb0) + C2_Y * 8 + ck8) += dy;
       }
       TAIL_TP(9)
@@ -1216,25 +1219,16 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
           for (int k = 0; k < 3; ++k) dvr[k] -= mass * hvl3_of(k);
         }
         l_dualv = hinf3(dvr);
-        l_nu = tabs(nui);
-        if constexpr (HD) {
-          l_hrefv = mass * hinf3(hv3);
-        } else {
-          l_hrefv = mass * tabs(href_s) * hinf3(vi3);
-        }
         l_dvis = mass * hinf3(dv);
-        l_dnu = tabs(nui - nu);
+        s_dnu = nui - nu;
         const T x = nui + inv_mu * w;
         const T zi = hmin(ubi, hmax(lbi, x));
-        l_dz = tabs(zi - z);
-        l_prs = tabs(nui - zi);
+        s_dz = zi - z;
+        s_prs = nui - zi;
         const T dwi = mu_in * (nui - zi);
-        l_dw = tabs(dwi);
-        l_up += hz * (ubi * tmax(dwi, T(0)));
-        l_lm += hz * (lbi * tmin(dwi, T(0)));
+        s_dw = dwi;
         w = w + dwi; z = zi; nu = nui;
         l_dg = hinf3(dg);
-        l_g = hinf3(gi);
 #pragma unroll
         for (int k = 0; k < 3; ++k) { v3[k] = vi3[k]; g3[k] = gi[k]; }
       }
@@ -1276,8 +1270,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       for (int k = 0; k < 3; ++k) df[k] = fi3[k] - f3[k];
       l_dfis = mass * hinf3(df);
       si += w;
-      l_stf = tabs(si);
-      l_dstf = tabs(si - s);
+      s_stf = si;
+      s_dstf = si - s;
       s = si;
 #pragma unroll
       for (int k = 0; k < 3; ++k) f3[k] = fi3[k];
@@ -1286,6 +1280,18 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     // ================= the scalars of the stopping logic, folded over the wavefront ===============================================
     // Main loop: four maxima (primal, dual, the two sides of the certificate's first test); the certificate's second test and the
     // tail solve's stopping rule need four more scalars, folded only when they are looked at.
+    // (the norms only some iterations need: from the state this iteration left -- v3, g3, nu are the new iterates by now)
+    auto l_hrefv_now = [&]() -> T {
+      if constexpr (HD) { T hv[3]; hrefv_of(v3, hv); return mass * hinf3(hv); }
+      else return mass * tabs(href_s) * hinf3(v3);
+    };
+    auto ub_lb_sums = [&](T& up, T& lm) {   // this lane's terms of ub^T [dz]_+ and lb^T [dz]_- (hpp:430-446): task rows and the joint's box
+      const T bk = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(cdi) + opaque(cb_blk) + C2_B * 8 + opaque(cb_k));
+      up = bk * tmax(s_dy, T(0));
+      lm = bk * tmin(s_dy, T(0));
+      up += hz * (ubi * tmax(s_dw, T(0)));
+      lm += hz * (lbi * tmin(s_dw, T(0)));
+    };
     const bool fixed = P.mode & MODE_FIXED_ITERS;
     const bool in_tail = (status & ST_TAIL) != 0;
     const bool logic = !fixed && !in_tail;  // the main loop's stopping logic runs
@@ -1294,7 +1300,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #endif
     T primal = T(0), dual = T(0), dyqp = T(0), atdy = T(0), dx = T(0), dz = T(0), ubp = T(0), lbm = T(0);
     if (logic) {
-      T in[4] = {hmax(l_prt, l_prs), hmax(l_dualv, l_stf), hmax(l_dfis, hmax(l_dyis, l_dw)), hmax(l_dg, l_dstf)}, r[4];
+      T in[4] = {hmaxa(s_ek, s_prs), hmax_a(l_dualv, s_stf), hmax_a(hmax_a(l_dfis, s_dy), s_dw), hmax_a(l_dg, s_dstf)}, r[4];
 #ifdef LOIKB_DBG_QUIET
       if (lane == 0) atomicAdd(&g_tail_prof_all[24], 1ull);
       if (quiet_f32(in, qth, iter, q_lim) && lane == 0) atomicAdd(&g_tail_prof_all[25], 1ull);
@@ -1328,7 +1334,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     }
     T ntol_p = T(0), ntol_d = T(0);
     if (P.tol_rel != T(0)) {  // (uniform) relative tolerances need two more maxima
-      T in2[4] = {hmax(l_av, l_nu), hmax(hmax(l_hrefv, l_g), l_stf), T(0), T(0)}, r2[4];
+      T in2[4] = {hmaxa(s_av, nu), hmax_a(hmax(l_hrefv_now(), hinf3(g3)), s_stf), T(0), T(0)}, r2[4];
       wave_fold4<0u>(lane, in2, r2);
       ntol_p = r2[0]; ntol_d = r2[1];
     }
@@ -1340,7 +1346,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const int itn = iter + 1;
     if constexpr (LOG) {
       if (!in_tail) {   // (the nine lists of k_pass_solve, loik_passes.hpp, in k_flat's order)
-        T inl[4] = {l_prt, l_prs, l_stf, l_dualv}, rl[4];
+        T inl[4] = {tabs(s_ek), tabs(s_prs), tabs(s_stf), l_dualv}, rl[4];
         wave_fold4<0u>(lane, inl, rl);
         const int row = itn - 1;
         if (lane == 0 && row < Bf.log_cap) {
@@ -1355,7 +1361,9 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const bool c1 = atdy <= P.tol_primal_inf * dyqp;
     bool have_b = false;
     auto fold_b = [&]() {
-      T in[4] = {l_up, l_lm, hmax(l_dvis, l_dnu), l_dz}, r[4];
+      T l_up, l_lm;
+      ub_lb_sums(l_up, l_lm);
+      T in[4] = {l_up, l_lm, hmax_a(l_dvis, s_dnu), tabs(s_dz)}, r[4];
       wave_fold4<0x3u>(lane, in, r);
       ubp = r[0]; lbm = r[1]; dx = r[2]; dz = r[3];
       have_b = true;
@@ -1380,7 +1388,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     // solve: they keep the values of the last iteration that evaluated them) -------------------------------------------------
     T r1[8], r2[8];
     if (stop) {
-      T in1[8] = {l_prt, l_prs, l_stf, l_dvis, l_dnu, l_dfis, l_dyis, l_dw}, in2[8] = {l_av, l_nu, l_hrefv, l_g, l_dualv, T(0), T(0), T(0)};
+      T in1[8] = {tabs(s_ek), tabs(s_prs), tabs(s_stf), l_dvis, tabs(s_dnu), l_dfis, tabs(s_dy), tabs(s_dw)};
+      T in2[8] = {tabs(s_av), tabs(nu), l_hrefv_now(), hinf3(g3), l_dualv, T(0), T(0), T(0)};
       wave_fold8<false>(lane, in1, r1);
       wave_fold8<false>(lane, in2, r2);
       if (!logic) { primal = hmax(r1[0], r1[1]); dual = hmax(r2[4], r1[2]); }  // (the tail solve / a fixed count did not fold them)
@@ -1994,20 +2003,24 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       actinv_motion(R0, t0, vw, vi);
       force_of_motion(vw, E);
     }
-    T hv6[6];  // H_ref v_i (link frame)
-    if constexpr (HM >= 2) {
+    auto hrefv_of = [&](const T* vv, T* out) {   // H_ref v (link frame)
+      if constexpr (HM >= 2) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const T* hr = (HM == 3 ? hrow : hmat) + k * 6;
-        hv6[k] = ((hr[0] * vi[0] + hr[1] * vi[1]) + hr[2] * vi[2]) + ((hr[3] * vi[3] + hr[4] * vi[4]) + hr[5] * vi[5]);
+        for (int k = 0; k < 6; ++k) {
+          const T* hr = (HM == 3 ? hrow : hmat) + k * 6;
+          out[k] = ((hr[0] * vv[0] + hr[1] * vv[1]) + hr[2] * vv[2]) + ((hr[3] * vv[3] + hr[4] * vv[4]) + hr[5] * vv[5]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out[k] = hd[k] * vv[k];
       }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) hv6[k] = hd[k] * vi[k];
-    }
-    T l_dyis = T(0), l_av = T(0), l_prt = T(0), l_up = T(0), l_lm = T(0);
-    T l_nu = T(0), l_dfis = T(0), l_hrefv = T(0), l_dvis = T(0), l_dnu = T(0), l_dz = T(0), l_dw = T(0), l_prs = T(0);
-    T l_dg = T(0), l_g = T(0), l_stf = T(0), l_dstf = T(0), l_dualv = T(0);
+    };
+    T hv6[6];
+    hrefv_of(vi, hv6);
+    // (signed values for the four maxima of every iteration, the rest formed where it is looked at: see k_flat2)
+    T s_dy = T(0), s_av = T(0), s_ek = T(0);
+    T l_dfis = T(0), l_dvis = T(0), s_dnu = T(0), s_dz = T(0), s_dw = T(0), s_prs = T(0);
+    T l_dg = T(0), s_stf = T(0), s_dstf = T(0), l_dualv = T(0);
     T fi[6], si;
     {
       T SEn[6], SHn[6], Fw[6];
@@ -2022,11 +2035,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         const T bk = ccb[C2_B + ckl];
         const T ek = avk - bk;
         const T dy = mu_eq * ek;
-        l_dyis = tabs(dy);
-        l_up = bk * tmax(dy, T(0));
-        l_lm = bk * tmin(dy, T(0));
-        l_prt = tabs(ek);
-        l_av = tabs(avk);
+        s_dy = dy; s_ek = ek; s_av = avk;
         ccb[C2_Y + ckl] += dy;
       }
       {
@@ -2089,25 +2098,16 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
           for (int k = 0; k < 6; ++k) dvr[k] -= mass * hvl[k];
         }
         l_dualv = hinf6(dvr);
-        l_nu = tabs(nui);
-        if constexpr (HD) {
-          l_hrefv = mass * hinf6(hv6);
-        } else {
-          l_hrefv = mass * tabs(href_s) * hinf6(vi);
-        }
         l_dvis = mass * hinf6(dv6);
-        l_dnu = tabs(nui - nu);
+        s_dnu = nui - nu;
         const T x = nui + inv_mu * w;
         const T zi = hmin(ubi, hmax(lbi, x));
-        l_dz = tabs(zi - z);
-        l_prs = tabs(nui - zi);
+        s_dz = zi - z;
+        s_prs = nui - zi;
         const T dwi = mu_in * (nui - zi);
-        l_dw = tabs(dwi);
-        l_up += ubi * tmax(dwi, T(0));
-        l_lm += lbi * tmin(dwi, T(0));
+        s_dw = dwi;
         w = w + dwi; z = zi; nu = nui;
         l_dg = hinf6(dg);
-        l_g = hinf6(gi);
 #pragma unroll
         for (int k = 0; k < 6; ++k) { v[k] = vi[k]; g[k] = gi[k]; }
       }
@@ -2134,8 +2134,8 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       for (int k = 0; k < 6; ++k) df[k] = fi[k] - f[k];
       l_dfis = mass * hinf6(df);
       si += w;
-      l_stf = tabs(si);
-      l_dstf = tabs(si - s);
+      s_stf = si;
+      s_dstf = si - s;
       s = si;
 #pragma unroll
       for (int k = 0; k < 6; ++k) f[k] = fi[k];
@@ -2143,12 +2143,26 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     // ================= the scalars of the stopping logic, folded over the wavefront ===============================================
     // Main loop: four maxima (primal, dual, the two sides of the certificate's first test); the certificate's second test and the
     // tail solve's stopping rule need four more scalars, folded only when they are looked at.
+    auto l_hrefv_now = [&]() -> T {   // (from the state this iteration left: see k_flat2)
+      if constexpr (HD) { T hv[6]; hrefv_of(v, hv); return mass * hinf6(hv); }
+      else return mass * tabs(href_s) * hinf6(v);
+    };
+    auto ub_lb_sums = [&](T& up, T& lm) {
+      up = T(0); lm = T(0);
+      if (iscl) {
+        const T bk = ccb[C2_B + ckl];
+        up = bk * tmax(s_dy, T(0));
+        lm = bk * tmin(s_dy, T(0));
+      }
+      up += ubi * tmax(s_dw, T(0));
+      lm += lbi * tmin(s_dw, T(0));
+    };
     const bool fixed = P.mode & MODE_FIXED_ITERS;
     const bool in_tail = (status & ST_TAIL) != 0;
     const bool logic = !fixed && !in_tail;  // the main loop's stopping logic runs
     T primal = T(0), dual = T(0), dyqp = T(0), atdy = T(0), dx = T(0), dz = T(0), ubp = T(0), lbm = T(0);
     if (logic) {
-      T in[4] = {hmax(l_prt, l_prs), hmax(l_dualv, l_stf), hmax(l_dfis, hmax(l_dyis, l_dw)), hmax(l_dg, l_dstf)}, r[4];
+      T in[4] = {hmaxa(s_ek, s_prs), hmax_a(l_dualv, s_stf), hmax_a(hmax_a(l_dfis, s_dy), s_dw), hmax_a(l_dg, s_dstf)}, r[4];
       if (LOIKB_QUIET32 && !LOG && quiet_f32(in, qth, iter, q_lim)) {   // (the quick look: see quiet_f32)
         ++iter;
         if (SLICED && quantum > 0 && slice_iters + 1 >= quantum) continue;
@@ -2171,7 +2185,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     }
     T ntol_p = T(0), ntol_d = T(0);
     if (P.tol_rel != T(0)) {  // (uniform) relative tolerances need two more maxima
-      T in2[4] = {hmax(l_av, l_nu), hmax(hmax(l_hrefv, l_g), l_stf), T(0), T(0)}, r2[4];
+      T in2[4] = {hmaxa(s_av, nu), hmax_a(hmax(l_hrefv_now(), hinf6(g)), s_stf), T(0), T(0)}, r2[4];
       wave_fold4<0u>(lane, in2, r2);
       ntol_p = r2[0]; ntol_d = r2[1];
     }
@@ -2182,7 +2196,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const int itn = iter + 1;
     if constexpr (LOG) {
       if (!in_tail) {   // (the nine lists of k_pass_solve, loik_passes.hpp, in k_flat's order)
-        T inl[4] = {l_prt, l_prs, l_stf, l_dualv}, rl[4];
+        T inl[4] = {tabs(s_ek), tabs(s_prs), tabs(s_stf), l_dualv}, rl[4];
         wave_fold4<0u>(lane, inl, rl);
         const int row = itn - 1;
         if (lane == 0 && row < Bf.log_cap) {
@@ -2197,7 +2211,9 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const bool c1 = atdy <= P.tol_primal_inf * dyqp;
     bool have_b = false;
     auto fold_b = [&]() {
-      T in[4] = {l_up, l_lm, hmax(l_dvis, l_dnu), l_dz}, r[4];
+      T l_up, l_lm;
+      ub_lb_sums(l_up, l_lm);
+      T in[4] = {l_up, l_lm, hmax_a(l_dvis, s_dnu), tabs(s_dz)}, r[4];
       wave_fold4<0x3u>(lane, in, r);
       ubp = r[0]; lbm = r[1]; dx = r[2]; dz = r[3];
       have_b = true;
@@ -2222,7 +2238,8 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     // solve: they keep the values of the last iteration that evaluated them) -------------------------------------------------
     T r1[8], r2[8];
     if (stop) {
-      T in1[8] = {l_prt, l_prs, l_stf, l_dvis, l_dnu, l_dfis, l_dyis, l_dw}, in2[8] = {l_av, l_nu, l_hrefv, l_g, l_dualv, T(0), T(0), T(0)};
+      T in1[8] = {tabs(s_ek), tabs(s_prs), tabs(s_stf), l_dvis, tabs(s_dnu), l_dfis, tabs(s_dy), tabs(s_dw)};
+      T in2[8] = {tabs(s_av), tabs(nu), l_hrefv_now(), hinf6(g), l_dualv, T(0), T(0), T(0)};
       wave_fold8<false>(lane, in1, r1);
       wave_fold8<false>(lane, in2, r2);
       if (!logic) { primal = hmax(r1[0], r1[1]); dual = hmax(r2[4], r1[2]); }  // (the tail solve / a fixed count did not fold them)
