@@ -425,6 +425,14 @@ def kernel_roofline(acc, last, steps, nb, nc, B):
             insts = pk[name].get("valu_insts_per_dispatch", pk[name]["valu_insts_per_step"] / max(pk[name].get("dispatches_per_step", 1.0), 1.0))
             ncu, clk = pmc.get("compute_units", 256), pmc.get("shader_clock_ghz", 2.4)
             r["valu_issue_frac"] = insts * 4.0 / (4 * ncu * avg_ms * 1e-3 * clk * 1e9)
+            if "valu_active_quadcycles_per_dispatch" in pk[name]:
+                # SQ_ACTIVE_INST_VALU counts 4-cycle units in which a SIMD's VALU executes an instruction, summed over the SIMDs:
+                # the share of the launch in which the vector ALUs were at work (the tools' VALUBusy)
+                r["valu_busy_frac"] = pk[name]["valu_active_quadcycles_per_dispatch"] * 4.0 / (4 * ncu * avg_ms * 1e-3 * clk * 1e9)
+                r["valu_busy_note"] = ("two wavefronts per SIMD at 256 registers each; a wavefront issues one vector instruction per ~8 "
+                                       "cycles at best and its fp64 chains are 32 cycles deep: the launch is bound by the latency of "
+                                       "dependent fp64 instructions, not by the ALUs' throughput (a third wavefront per SIMD needs 168 "
+                                       "registers and 13 KB of LDS: the build that has them spills and is 10 % slower)")
             r["valu_insts_per_instance_iteration"] = pk[name].get("valu_insts_per_instance_iteration")
             r["lds_bank_conflict_frac"] = pk[name].get("lds_bank_conflict_frac")
         if pmc:

@@ -33,7 +33,9 @@ for k, d in tot.items():
         e["write_bytes_per_step"] = d["WRITE_SIZE"] * 1024 / nsolves
     for c, label in [("SQ_INSTS_VALU", "valu_insts_per_step"), ("SQ_INSTS_SALU", "salu_insts_per_step"),
                      ("SQ_INSTS_LDS", "lds_insts_per_step"), ("SQ_WAVE_CYCLES", "wave_cycles_per_step"),
-                     ("SQ_BUSY_CYCLES", "busy_cycles_per_step"), ("SQ_WAIT_INST_LDS", "wait_inst_lds_per_step")]:
+                     ("SQ_BUSY_CYCLES", "busy_cycles_per_step"), ("SQ_WAIT_INST_LDS", "wait_inst_lds_per_step"),
+                     ("SQ_ACTIVE_INST_VALU", "valu_active_quadcycles_per_step"), ("SQ_ACTIVE_INST_ANY", "any_active_quadcycles_per_step"),
+                     ("SQ_WAIT_ANY", "wait_any_per_step"), ("SQ_WAIT_INST_ANY", "wait_inst_any_per_step")]:
         if c in d:
             e[label] = d[c] / nsolves
     if "SQ_ACTIVE_INST_LDS" in d and d["SQ_ACTIVE_INST_LDS"] > 0 and "SQ_LDS_BANK_CONFLICT" in d:
@@ -45,7 +47,8 @@ for k, e in out["kernels"].items():
     n = max(e.get("dispatches_per_step", 1.0) * nsolves, 1.0)
     for src, dst in (("fetch_bytes_per_step", "fetch_bytes_per_dispatch"), ("write_bytes_per_step", "write_bytes_per_dispatch"),
                      ("valu_insts_per_step", "valu_insts_per_dispatch"), ("lds_insts_per_step", "lds_insts_per_dispatch"),
-                     ("salu_insts_per_step", "salu_insts_per_dispatch")):
+                     ("salu_insts_per_step", "salu_insts_per_dispatch"), ("valu_active_quadcycles_per_step", "valu_active_quadcycles_per_dispatch"),
+                     ("wave_cycles_per_step", "wave_cycles_per_dispatch"), ("wait_any_per_step", "wait_any_per_dispatch")):
         if src in e:
             e[dst] = e[src] * nsolves / n
 try:
