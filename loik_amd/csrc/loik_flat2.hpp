@@ -347,6 +347,15 @@ __host__ __device__ __forceinline__ size_t flat2_lds_bytes(int nc, bool has_hv)
   return (n * sizeof(double) + 15) & ~(size_t)15;
 }
 
+// A kernel argument the iteration uses, as a value of its own: the compiler re-fetches kernel arguments it has no scalar register for with
+// s_load + s_waitcnt INSIDE the loop (the SLICED build, which has a few more live scalars, did that with the tolerances of the stopping
+// test: 6 % of its iteration); a value that went through an asm is kept, or parked in a lane of a vector register (one v_readlane).
+template <bool ON, typename X>
+__device__ __forceinline__ X held(X x)
+{
+  if constexpr (ON) asm volatile("" : "+s"(x));
+  return x;
+}
 // SLICED: round-robin time slicing inside the launch (the work queue of k_lean, loik_lean.hpp: a ring of instance slots with
 // tickets on both sides).  An instance whose `quantum` iterations are used up while other instances wait for a wavefront is
 // written back and goes to the BACK of the queue; the mutable part of its record then travels between wavefronts (possibly on
@@ -375,6 +384,9 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const bool a_shared = P.mode & MODE_A_SHARED;
   const int lane = threadIdx.x;
   const QuietF32 qth = quiet_f32_thresholds(P.tol_abs, P.tol_rel, P.tol_primal_inf);
+  const int slice_len = (SLICED && quantum > 0) ? quantum : 0x3fffffff;   // (iterations per time slice; none: never ends)
+  const double tol_abs_h = held<SLICED>(P.tol_abs), tpi_h = held<SLICED>(P.tol_primal_inf);
+  const int max_iter_h = held<SLICED>(P.max_iter);
   const int j = lane & 31;       // lanes j and 32 + j <-> device joint j + 1
   const bool h = lane >= 32;     // 0: linear halves, 1: angular halves
   const int h3 = h ? 3 : 0;
@@ -943,23 +955,27 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     load_instance();
     if (!has_inst) break;  // the queue is empty (SLICED: and every instance has retired): this wavefront is done
     T inv_mu = T(1) / mu;  // (a division per change of mu, not per iteration: BoxProj's 1 / mu_ineq, hxx:384-397)
-    int slice_iters = 0;
-    unsigned int q_pref_t = 0u, q_pref_h = 0u;
     requeue = false;
     // the last value of iter from which a quiet iteration may go straight into the next one (see quiet_f32): not the last but one of
     // max_iter, and this launch's share of iterations not used up (my_iters = iter - iter at load + 1 inside an iteration)
-    const int q_lim = quiet_limit(P.max_iter, P.max_launch_iters, iter);
+    const int q_lim_run = quiet_limit(P.max_iter, P.max_launch_iters, iter);
+    // SLICED: a time slice ends at iteration slice_end, and it ends THROUGH THE SAME COMPARE -- the iteration itself has no code for
+    // the slices (a counter and its compare against the kernel argument in the loop cost the SLICED build 6 % of every iteration:
+    // the compiler fetched the argument with s_load + s_waitcnt each time)
+    int slice_end = SLICED ? iter + slice_len : 0x7fffffff;
+    int q_lim = (SLICED && slice_end - 1 < q_lim_run) ? slice_end - 1 : q_lim_run;
    while (true) {
-    if (SLICED && quantum > 0 && !done) {
-      // time slice used up and others wait: to the back of the queue.  The queue's counters are fetched an iteration AHEAD (their
-      // round trip runs under the slice's last iteration; slightly stale is fine: the decision is a heuristic)
-      if (slice_iters >= quantum) {
-        if (__builtin_amdgcn_readfirstlane((int)(q_pref_t - q_pref_h) > 0 ? 1 : 0)) { requeue = true; break; }
-        slice_iters = 0;   // nobody waits for this wavefront: carry on
-      } else if (slice_iters + 1 >= quantum && lane == 0) {
-        q_pref_t = __hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        q_pref_h = __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (SLICED && !done && iter >= slice_end) {
+      // time slice used up: if others wait, to the back of the queue (one round trip to the queue's counters per slice: ~2 us in
+      // several hundred; slightly stale is fine, the decision is a heuristic)
+      unsigned int qt = 0u, qh = 0u;
+      if (lane == 0) {
+        qt = __hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        qh = __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      if (__builtin_amdgcn_readfirstlane((int)(qt - qh) > 0 ? 1 : 0)) { requeue = true; break; }
+      slice_end = iter + slice_len;   // nobody waits for this wavefront: carry on
+      q_lim = (slice_end - 1 < q_lim_run) ? slice_end - 1 : q_lim_run;
     }
     // ---- does the instance leave before this iteration?  (fetched already finished; this launch's share of iterations used up;
     // mu left the precomputed decades.)  Then it goes back as it is.
@@ -1007,7 +1023,6 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
     ++my_iters; any_iter = true;
     ++n_wave_iters;
-    if (SLICED) ++slice_iters;
 
     // ================= p^base at the world origin, summed over the subtrees; tau  (FwdPass1 + the p part of BwdPass) ===========
     T wc[NH];  // this lane's share of the joint's W entries (ancestors k = 2 i + h): used twice, up and down
@@ -1308,7 +1323,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       if (LOIKB_QUIET32 && !LOG && quiet_f32(in, qth, iter, q_lim)) {   // (the quick look: see quiet_f32)
         ++iter;
         TAIL_TP(7)
-        if (SLICED && quantum > 0 && slice_iters + 1 >= quantum) continue;   // (the slice ends: through the loop's top)
+        if (iter > q_lim) continue;   // (SLICED: the slice ends -- through the loop's top)
         goto next_iteration;
       }
       wave_fold4<0u>(lane, in, r);
@@ -1322,12 +1337,12 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         // The common iteration decides nothing: not converged, the certificate's first test fails, mu stays where it is, not the
         // last iteration.  Five compares side by side and ONE branch; the stopping logic below is a chain of ~30 dependent
         // compare -> mask -> branch steps (900 cycles of a lone wavefront's 5400 per iteration) that only the other iterations walk.
-        const bool quiet = !((primal < P.tol_abs) & (dual < P.tol_abs)) & !((iter > 0) & (atdy <= P.tol_primal_inf * dyqp)) &
-                           !(primal > T(10) * dual) & !(dual > T(10) * primal) & (iter + 2 < P.max_iter);
+        const bool quiet = !((primal < tol_abs_h) & (dual < tol_abs_h)) & !((iter > 0) & (atdy <= tpi_h * dyqp)) &
+                           !(primal > T(10) * dual) & !(dual > T(10) * primal) & (iter + 2 < max_iter_h);
         if (quiet) {
           ++iter;
           TAIL_TP(7)
-          if (LOIKB_QUIET_SKIPS_TOP && iter <= q_lim && !(SLICED && quantum > 0 && slice_iters + 1 >= quantum)) goto next_iteration;
+          if (LOIKB_QUIET_SKIPS_TOP && iter <= q_lim) goto next_iteration;
           continue;
         }
       }
@@ -1530,6 +1545,9 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const bool a_shared = P.mode & MODE_A_SHARED;
   const int lane = threadIdx.x;
   const QuietF32 qth = quiet_f32_thresholds(P.tol_abs, P.tol_rel, P.tol_primal_inf);
+  const int slice_len = (SLICED && quantum > 0) ? quantum : 0x3fffffff;   // (iterations per time slice; none: never ends)
+  const double tol_abs_h = held<SLICED>(P.tol_abs), tpi_h = held<SLICED>(P.tol_primal_inf);   // (see k_flat2)
+  const int max_iter_h = held<SLICED>(P.max_iter);
   const int j = lane;  // lane <-> device joint j + 1
   T* const xb = reinterpret_cast<T*>(smem_raw);          // load-time rows | path rows [65][6] | W tau products [NA][64]
   T* const wl = xb + flat1_xregion<NA>();                // [2][NA + 1][64]
@@ -1894,13 +1912,15 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     load_instance();
     if (!has_inst) break;
     T inv_mu = T(1) / mu;
-    int slice_iters = 0;
     requeue = false;
-    const int q_lim = quiet_limit(P.max_iter, P.max_launch_iters, iter);   // (see k_flat2)
+    const int q_lim_run = quiet_limit(P.max_iter, P.max_launch_iters, iter);   // (see k_flat2)
+    int slice_end = SLICED ? iter + slice_len : 0x7fffffff;
+    int q_lim = (SLICED && slice_end - 1 < q_lim_run) ? slice_end - 1 : q_lim_run;
    while (true) {
-    if (SLICED && quantum > 0 && !done && slice_iters >= quantum) {
+    if (SLICED && !done && iter >= slice_end) {
       if (q_waiting()) { requeue = true; break; }
-      slice_iters = 0;
+      slice_end = iter + slice_len;
+      q_lim = (slice_end - 1 < q_lim_run) ? slice_end - 1 : q_lim_run;
     }
     bool exit_now = done || (int)my_iters >= P.max_launch_iters;
     if (!exit_now && kexp != kslot) {
@@ -1933,7 +1953,6 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
     ++my_iters; any_iter = true;
     ++n_wave_iters;
-    if (SLICED) ++slice_iters;
 
     // ---- p^base summed over the subtrees; tau
     T wc[NA];
@@ -2165,7 +2184,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       T in[4] = {hmaxa(s_ek, s_prs), hmax_a(l_dualv, s_stf), hmax_a(hmax_a(l_dfis, s_dy), s_dw), hmax_a(l_dg, s_dstf)}, r[4];
       if (LOIKB_QUIET32 && !LOG && quiet_f32(in, qth, iter, q_lim)) {   // (the quick look: see quiet_f32)
         ++iter;
-        if (SLICED && quantum > 0 && slice_iters + 1 >= quantum) continue;
+        if (iter > q_lim) continue;
         goto next_iteration;
       }
       wave_fold4<0u>(lane, in, r);
@@ -2174,11 +2193,11 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         // The common iteration decides nothing: not converged, the certificate's first test fails, mu stays where it is, not the
         // last iteration.  Five compares side by side and ONE branch; the stopping logic below is a chain of ~30 dependent
         // compare -> mask -> branch steps (900 cycles of a lone wavefront's 5400 per iteration) that only the other iterations walk.
-        const bool quiet = !((primal < P.tol_abs) & (dual < P.tol_abs)) & !((iter > 0) & (atdy <= P.tol_primal_inf * dyqp)) &
-                           !(primal > T(10) * dual) & !(dual > T(10) * primal) & (iter + 2 < P.max_iter);
+        const bool quiet = !((primal < tol_abs_h) & (dual < tol_abs_h)) & !((iter > 0) & (atdy <= tpi_h * dyqp)) &
+                           !(primal > T(10) * dual) & !(dual > T(10) * primal) & (iter + 2 < max_iter_h);
         if (quiet) {
           ++iter;
-          if (LOIKB_QUIET_SKIPS_TOP && iter <= q_lim && !(SLICED && quantum > 0 && slice_iters + 1 >= quantum)) goto next_iteration;
+          if (LOIKB_QUIET_SKIPS_TOP && iter <= q_lim) goto next_iteration;
           continue;
         }
       }

@@ -61,8 +61,8 @@ struct Tuning {
   bool flat_split = true;       // LOIKB_FLAT_SPLIT=0: k_flat (one joint per lane) also where k_flat2 (two lanes per joint) applies
   int flat_split_wpe = 2;       // LOIKB_FLAT_WPE=3: k_flat2 built for three wavefronts per SIMD
   int fslot_dgrp = 0;           // LOIKB_FSLOT_DGRP=g: k_fslots takes the decades through its two passes g at a time (default: all)
-  int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's / k_flat1's round-robin time slice in iterations (default: none -- run to
-                                // completion; round 4 measured 0..2.5 % from slices of 96..192 even with parked instances, see run_tail)
+  int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's / k_flat1's round-robin time slice in iterations (0: never; default: 288 for
+                                // launches in arrival order of >= 32 768 instances, see flat_slice_for / run_tail)
   bool flat_zero_state = true;  // LOIKB_FLAT_ZERO_STATE=0: k_flat2 / k_flat1 fetch vis, fis, g, w, z of every instance even straight after a cold reset
   int flat_order_holdoff = 4;   // LOIKB_FLAT_ORDER_HOLDOFF=n: solves in arrival order after an ordered launch that was not shorter (0: never hold off)
   int flat_one_slot = 1;        // LOIKB_FLAT_ONE_SLOT=0: k_flat1 always keeps two decade slots in LDS
@@ -1129,6 +1129,20 @@ bool flat_applicable(const loikb_solver_impl* S)
   return S->plan.flat && (flat_takes_diagonal(S) || (!S->per_link && href_is_scalar(S)));
 }
 
+// The time slice of a flat launch over n instances (0: run to completion).  End of round 4, once the SLICED builds' iteration cost
+// what the plain builds' costs (it re-fetched the stopping test's tolerances from the kernel arguments every iteration): headline
+// batch in arrival order 10.1 -> 9.4 ms at 288 (160 / 224 / 352 / 448: 9.6 / 9.5 / 9.5 / 9.8), 131 072: 17.5 -> 16.7, 262 144:
+// 33.7 -> 32.2, 32 768: 6.1 -> 6.0, whole body 20.6 -> 19.6; 16 384: 4.16 -> 4.37 and 8192: 3.08 -> 3.32 (one straggler chain
+// whatever the order: no slices below 32 768).  Not for ordered launches (their long runners start first and must not go to the
+// back of the queue) and not for a handle on a stream of its own (the other batch in flight fills this one's ragged end).
+constexpr int FLAT_SLICE_DEFAULT = 288, FLAT_SLICE_MIN_BATCH = 32768, FLAT_SLICE_MAX_BATCH = 262144;   // (above: 19 KB of park record per instance for 1.5 %)
+int flat_slice_for(const loikb_solver_impl* S, int n, bool ordered)
+{
+  if (S->tune.flat_slice >= 0) return S->tune.flat_slice;   // (LOIKB_FLAT_SLICE: as asked, whatever the launch)
+  if (ordered || n < FLAT_SLICE_MIN_BATCH || n > FLAT_SLICE_MAX_BATCH || (S->opt.flags & LOIKB_OPT_OWN_STREAM) || (S->opt.flags & LOIKB_OPT_FIXED_ITERS)) return 0;
+  return FLAT_SLICE_DEFAULT;
+}
+
 int ensure_hslots(loikb_solver_impl* S)
 {
   if (S->plan.flat && S->have_problem && !flat_applicable(S)) {
@@ -1157,7 +1171,7 @@ int ensure_hslots(loikb_solver_impl* S)
     }
     // park records of the time-sliced launch (k_flat2 only: 17..32 joints): ~19 KB per instance, allocated for the batch sizes the
     // slices are used on (flat_slice_window); a handle that cannot have them simply runs unsliced
-    if (S->flat.G == F2G && flat_takes_diagonal(S) && S->tune.flat_slice > 0) {
+    if (S->flat.G == F2G && flat_takes_diagonal(S) && flat_slice_for(S, S->B, false) > 0) {
       for (Chunk& C : S->chunks) {
         const size_t need = (size_t)C.B * flat2_park_stride(S->nc, true) * sizeof(double);
         if (need <= C.park_bytes) continue;
@@ -1749,9 +1763,10 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           // 16 384 and below: slower (one straggler chain whatever the order).  A switch costs ~27 us of a wavefront under load (five
           // dependent trips to the L2 / HBM at ~2.5 us each when 2048 wavefronts share them), a slice of 64 iterations 190 us.
           // LOIKB_FLAT_SLICE=q switches it on.
+          // End of round 4: ON again for arrival-order launches of >= 32 768 instances (flat_slice_for has the numbers).
           const size_t park_need = (size_t)n_cur * flat2_park_stride(S->nc, true) * sizeof(double);
           (void)resident;
-          int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice : 0;
+          int quantum = flat_slice_for(S, n, ordered);
           if (quantum > 0 && (C->d_park == nullptr || park_need > C->park_bytes)) quantum = 0;
           // (not for a handle on a stream of its own: that is how batches are kept in flight side by side, and then the other
           //  batch's bulk fills this one's ragged end -- slicing only adds its switches, and its wavefronts that wait for queue
@@ -1787,7 +1802,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           // (time slicing as in k_flat2, same window: whole body, four tasks, B = 65 536: 34.7 ms without)
           const int resident = (int)grid.x, full = per_cu1 * (int)(cu_sh + 0.5);
           (void)resident; (void)full;
-          const int quantum = S->tune.flat_slice >= 0 ? S->tune.flat_slice : 0;  // (off by default since round 4: see k_flat2's launch)
+          const int quantum = flat_slice_for(S, n, ordered);
 #define LOIKB_LAUNCH_FLAT1(NAV, ...)                                                                                            \
   hipLaunchKernelGGL((k_flat1<NAV, ##__VA_ARGS__>), grid, dim3(WAVE), lds1, C->stream,                                          \
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
