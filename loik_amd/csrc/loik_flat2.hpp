@@ -384,7 +384,10 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const bool a_shared = P.mode & MODE_A_SHARED;
   const int lane = threadIdx.x;
   const QuietF32 qth = quiet_f32_thresholds(P.tol_abs, P.tol_rel, P.tol_primal_inf);
-  const int slice_len = (SLICED && quantum > 0) ? quantum : 0x3fffffff;   // (iterations per time slice; none: never ends)
+  // (iterations per time slice; none: never ends.  quantum = first | later << 16: an instance's FIRST slice and its later ones -- the later
+  //  ones shorter, so that the instances still running when the queue is empty have done the same number of iterations to within that)
+  const int slice_len = (SLICED && quantum > 0) ? (quantum & 0xffff) : 0x3fffffff;
+  const int slice_len2 = (SLICED && (quantum >> 16) > 0) ? (quantum >> 16) : slice_len;
   const double tol_abs_h = held<SLICED>(P.tol_abs), tpi_h = held<SLICED>(P.tol_primal_inf);
   const int max_iter_h = held<SLICED>(P.max_iter);
   const int j = lane & 31;       // lanes j and 32 + j <-> device joint j + 1
@@ -962,7 +965,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     // SLICED: a time slice ends at iteration slice_end, and it ends THROUGH THE SAME COMPARE -- the iteration itself has no code for
     // the slices (a counter and its compare against the kernel argument in the loop cost the SLICED build 6 % of every iteration:
     // the compiler fetched the argument with s_load + s_waitcnt each time)
-    int slice_end = SLICED ? iter + slice_len : 0x7fffffff;
+    int slice_end = SLICED ? iter + (iter >= slice_len ? slice_len2 : slice_len) : 0x7fffffff;
     int q_lim = (SLICED && slice_end - 1 < q_lim_run) ? slice_end - 1 : q_lim_run;
    while (true) {
     if (SLICED && !done && iter >= slice_end) {
@@ -974,7 +977,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         qh = __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (__builtin_amdgcn_readfirstlane((int)(qt - qh) > 0 ? 1 : 0)) { requeue = true; break; }
-      slice_end = iter + slice_len;   // nobody waits for this wavefront: carry on
+      slice_end = iter + (iter >= slice_len ? slice_len2 : slice_len);   // nobody waits for this wavefront: carry on
       q_lim = (slice_end - 1 < q_lim_run) ? slice_end - 1 : q_lim_run;
     }
     // ---- does the instance leave before this iteration?  (fetched already finished; this launch's share of iterations used up;
@@ -1545,7 +1548,10 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const bool a_shared = P.mode & MODE_A_SHARED;
   const int lane = threadIdx.x;
   const QuietF32 qth = quiet_f32_thresholds(P.tol_abs, P.tol_rel, P.tol_primal_inf);
-  const int slice_len = (SLICED && quantum > 0) ? quantum : 0x3fffffff;   // (iterations per time slice; none: never ends)
+  // (iterations per time slice; none: never ends.  quantum = first | later << 16: an instance's FIRST slice and its later ones -- the later
+  //  ones shorter, so that the instances still running when the queue is empty have done the same number of iterations to within that)
+  const int slice_len = (SLICED && quantum > 0) ? (quantum & 0xffff) : 0x3fffffff;
+  const int slice_len2 = (SLICED && (quantum >> 16) > 0) ? (quantum >> 16) : slice_len;
   const double tol_abs_h = held<SLICED>(P.tol_abs), tpi_h = held<SLICED>(P.tol_primal_inf);   // (see k_flat2)
   const int max_iter_h = held<SLICED>(P.max_iter);
   const int j = lane;  // lane <-> device joint j + 1
@@ -1914,12 +1920,12 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T inv_mu = T(1) / mu;
     requeue = false;
     const int q_lim_run = quiet_limit(P.max_iter, P.max_launch_iters, iter);   // (see k_flat2)
-    int slice_end = SLICED ? iter + slice_len : 0x7fffffff;
+    int slice_end = SLICED ? iter + (iter >= slice_len ? slice_len2 : slice_len) : 0x7fffffff;
     int q_lim = (SLICED && slice_end - 1 < q_lim_run) ? slice_end - 1 : q_lim_run;
    while (true) {
     if (SLICED && !done && iter >= slice_end) {
       if (q_waiting()) { requeue = true; break; }
-      slice_end = iter + slice_len;
+      slice_end = iter + (iter >= slice_len ? slice_len2 : slice_len);
       q_lim = (slice_end - 1 < q_lim_run) ? slice_end - 1 : q_lim_run;
     }
     bool exit_now = done || (int)my_iters >= P.max_launch_iters;

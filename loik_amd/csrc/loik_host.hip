@@ -61,6 +61,7 @@ struct Tuning {
   bool flat_split = true;       // LOIKB_FLAT_SPLIT=0: k_flat (one joint per lane) also where k_flat2 (two lanes per joint) applies
   int flat_split_wpe = 2;       // LOIKB_FLAT_WPE=3: k_flat2 built for three wavefronts per SIMD
   int fslot_dgrp = 0;           // LOIKB_FSLOT_DGRP=g: k_fslots takes the decades through its two passes g at a time (default: all)
+  int flat_slice2 = 0;          // LOIKB_FLAT_SLICE2=q: an instance's later slices (0: as the first)
   int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's / k_flat1's round-robin time slice in iterations (0: never; default: 288 for
                                 // launches in arrival order of >= 32 768 instances, see flat_slice_for / run_tail)
   bool flat_zero_state = true;  // LOIKB_FLAT_ZERO_STATE=0: k_flat2 / k_flat1 fetch vis, fis, g, w, z of every instance even straight after a cold reset
@@ -92,7 +93,8 @@ struct Tuning {
     if (!lean) flat = false;  // (LOIKB_LEAN=0 asks for the engines without precomputed factors: k_solve / k_tail)
     if (const char* e = getenv("LOIKB_FLAT_SPLIT")) flat_split = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_WPE")) flat_split_wpe = atoi(e) == 3 ? 3 : 2;
-    if (const char* e = getenv("LOIKB_FLAT_SLICE")) flat_slice = std::max(-1, atoi(e));
+    if (const char* e = getenv("LOIKB_FLAT_SLICE")) flat_slice = std::min(65535, std::max(-1, atoi(e)));
+    if (const char* e = getenv("LOIKB_FLAT_SLICE2")) flat_slice2 = std::min(32767, std::max(0, atoi(e)));
     if (const char* e = getenv("LOIKB_FSLOT_DGRP")) fslot_dgrp = std::max(0, atoi(e));
     if (const char* e = getenv("LOIKB_FLAT_ORDER")) flat_order = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_ZERO_STATE")) flat_zero_state = atoi(e) != 0;
@@ -1135,12 +1137,13 @@ bool flat_applicable(const loikb_solver_impl* S)
 // 33.7 -> 32.2, 32 768: 6.1 -> 6.0, whole body 20.6 -> 19.6; 16 384: 4.16 -> 4.37 and 8192: 3.08 -> 3.32 (one straggler chain
 // whatever the order: no slices below 32 768).  Not for ordered launches (their long runners start first and must not go to the
 // back of the queue) and not for a handle on a stream of its own (the other batch in flight fills this one's ragged end).
+constexpr int FLAT_SLICE_LATER = 96;   // (an instance's later slices: 9.44 -> 9.38 ms; a SHORT first slice -- 64 / 96 / 128, then 288 -- is slower: 9.9 / 9.6 / 9.8)
 constexpr int FLAT_SLICE_DEFAULT = 288, FLAT_SLICE_MIN_BATCH = 32768, FLAT_SLICE_MAX_BATCH = 262144;   // (above: 19 KB of park record per instance for 1.5 %)
 int flat_slice_for(const loikb_solver_impl* S, int n, bool ordered)
 {
-  if (S->tune.flat_slice >= 0) return S->tune.flat_slice;   // (LOIKB_FLAT_SLICE: as asked, whatever the launch)
+  if (S->tune.flat_slice >= 0) return S->tune.flat_slice | (S->tune.flat_slice2 << 16);   // (LOIKB_FLAT_SLICE[2]: as asked, whatever the launch)
   if (ordered || n < FLAT_SLICE_MIN_BATCH || n > FLAT_SLICE_MAX_BATCH || (S->opt.flags & LOIKB_OPT_OWN_STREAM) || (S->opt.flags & LOIKB_OPT_FIXED_ITERS)) return 0;
-  return FLAT_SLICE_DEFAULT;
+  return FLAT_SLICE_DEFAULT | (FLAT_SLICE_LATER << 16);
 }
 
 int ensure_hslots(loikb_solver_impl* S)
