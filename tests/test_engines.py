@@ -430,9 +430,9 @@ def test_fuzz_slice_flat_engine(monkeypatch):
 
 
 def test_flat_time_slicing_changes_nothing(talos, monkeypatch):
-    """k_flat2's round-robin time slicing (LOIKB_FLAT_SLICE; on by default for launches of 12..96 instances per resident
-    wavefront): an instance whose slice is used up while others wait is written back and reloaded later, possibly by a wavefront
-    of another XCD (agent-scope accesses of the mutable record).  Same arithmetic, so bit-identical results; forced here with a
+    """k_flat2's round-robin time slicing (LOIKB_FLAT_SLICE; on by default for arrival-order launches of 32 768..262 144
+    instances, slices of 288 then 96 iterations): an instance whose slice is used up while others wait is parked and resumed later,
+    possibly by a wavefront of another XCD (agent-scope accesses of the park record).  Same arithmetic, so bit-identical results; forced here with a
     slice of 5 iterations and one wavefront per CU, 1500 instances: thousands of requeues."""
     from loik_amd import workloads
     B = 1500
@@ -455,6 +455,15 @@ def test_flat_time_slicing_changes_nothing(talos, monkeypatch):
         s.close()
     for k in res["plain"]:
         assert np.array_equal(res["plain"][k], res["sliced"][k]), k
+    # the default: no slices below 32 768 instances (one straggler chain whatever the order), none when the variable says 0
+    for k in ("LOIKB_FLAT_SLICE", "LOIKB_LEAN_WG_PER_CU"):
+        monkeypatch.delenv(k, raising=False)
+    s = loik_amd.BatchedLoik(talos, B, **prm)
+    s.Solve(*args)
+    assert s.stats()["lean_requeues"] == 0
+    for k in res["plain"]:
+        assert np.array_equal(res["plain"][k], s.get(k)), k
+    s.close()
 
 
 @pytest.mark.parametrize("robot", ["talos32", "talos44"])
