@@ -510,7 +510,7 @@ def whole_body_variant(args, device):
     flops = FLOPS_PER_JOINT_ITERATION * m.nv
     out = {"workload": wl["name"], "robot": "talos44 (topology of talos_full_v2.urdf, 44 x 1-DoF, depth 11, four joints on each wrist link)",
            "num_eq_c": len(wl["c_ids"]), "batch": args.batch, "ms_per_step": dt * 1e3, "value": float(solved / sum(ms)),
-           "unit": "solves/s", "schedule": "a fresh batch before every timed solve (arrival order)", "solved_fraction": float(conv.mean()),
+           "unit": "solves/s", "schedule": "a fresh batch before every timed solve (arrival order, time-sliced)", "solved_fraction": float(conv.mean()),
            "flagged_infeasible_fraction": float(s.get("primal_infeasible").astype(bool).mean()),
            "mean_admm_iterations": float(it.mean()), "instance_iterations_per_s": float(iters / sum(ms)),
            "engine": (next((k for k in ("k_flat2", "k_flat1", "k_flat") if k in s.plan()), "k_flat") if st["flat_launches"] > 0 else "k_lean")
@@ -820,12 +820,15 @@ def main(argv=None, solver_factory=None, device_count=None):
         n_ord = (acc0.get("flat_ordered", 0), args.steps)
         if args.config == "c4":
             schedule_note = ("C4: T = 4 targets per instance, cycled; every step is the tailored warm-started Solve(q_t, c_id, Ai, b_t) of the "
-                             "whole share (FwdPassInit of q_t + UpdateEqConstraint + solve), q_t / b_t resident in HBM; arrival order "
-                             "(%d of %d launches ordered)" % n_ord)
+                             "whole share (FwdPassInit of q_t + UpdateEqConstraint + solve), q_t / b_t resident in HBM; arrival order, "
+                             "long runners time-sliced inside the launch (the engine's default for 32 768..262 144 instances; "
+                             "%d of %d launches ordered)" % n_ord)
         elif nfresh:
             schedule_note = ("every timed solve is a handle's FIRST solve of a batch it has not seen (another seed of the same generator, "
                              "resident in HBM before the timed region; the handle solved one other batch before, as a caller's would have): "
-                             "instances in arrival order, %d of %d launches ordered -- schedule_variant.repeat_same_batch is the "
+                             "instances in arrival order, long runners time-sliced inside the launch (slices of 288 then 96 iterations: the engine's "
+                             "default for launches of 32 768..262 144 instances without an order; same results bit for bit), "
+                             "%d of %d launches ordered -- schedule_variant.repeat_same_batch is the "
                              "reference's timing test, one batch again and again, which the engine takes longest first from the second "
                              "solve on" % n_ord)
         else:
