@@ -1142,7 +1142,7 @@ constexpr int FLAT_SLICE_DEFAULT = 288, FLAT_SLICE_MIN_BATCH = 32768, FLAT_SLICE
 int flat_slice_for(const loikb_solver_impl* S, int n, bool ordered)
 {
   if (S->tune.flat_slice >= 0) return S->tune.flat_slice | (S->tune.flat_slice2 << 16);   // (LOIKB_FLAT_SLICE[2]: as asked, whatever the launch)
-  if (ordered || n < FLAT_SLICE_MIN_BATCH || n > FLAT_SLICE_MAX_BATCH || (S->opt.flags & LOIKB_OPT_OWN_STREAM) || (S->opt.flags & LOIKB_OPT_FIXED_ITERS)) return 0;
+  if (ordered || n < FLAT_SLICE_MIN_BATCH || n > FLAT_SLICE_MAX_BATCH || (S->opt.flags & LOIKB_OPT_OWN_STREAM) || (S->opt.flags & LOIKB_OPT_FIXED_ITERS) || S->opt.logging) return 0;
   return FLAT_SLICE_DEFAULT | (FLAT_SLICE_LATER << 16);
 }
 
@@ -3203,6 +3203,15 @@ const char* loikb_plan_string(loikb_solver* S)
     char b2[160];
     snprintf(b2, sizeof(b2), "; decades visited by this handle's solves so far: %d..%d (the next solve builds those +-1)", S->seen_lo, S->seen_hi);
     out += b2;
+  }
+  if (pl.flat && (flat_applicable(S) || !S->have_problem) && flat_takes_diagonal(S)) {
+    const int q = flat_slice_for(S, S->B, false);
+    if (q > 0) {
+      char b3[200];
+      snprintf(b3, sizeof(b3), "; launches without an order (a handle's first solve of its inputs) are time-sliced: %d iterations, then %d, "
+               "while other instances wait", q & 0xffff, ((q >> 16) & 0x3fff) ? ((q >> 16) & 0x3fff) : (q & 0xffff));
+      out += b3;
+    }
   }
   if (S->opt.logging && logged_on_flat(S)) out = "logging = 1: the flat engine writes the SolverInfo lists; " + out;
   else if (S->opt.logging) out = "logging = 1: every solve runs on the plain pass-by-pass implementation (k_pass_solve) and fills SolverInfo; without it: " + out;
