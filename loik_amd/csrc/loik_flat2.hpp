@@ -261,11 +261,30 @@ __device__ __forceinline__ T inf3(const T* x) { return tmax(tmax(tabs(x[0]), tab
 // opaque copy of the register (so that the compiler would not hoist thirty addresses out of the loop): v_mov + v_bfe + v_lshl_add
 // per address, ~60 of the loop's VALU instructions.  Here the fields hold BYTE offsets and one v_bfe_u32, pinned where it stands,
 // is the address.
+#ifndef LOIKB_FIELD_TOKEN
+#define LOIKB_FIELD_TOKEN 1
+#endif
+// (the same for a value that must not be hoisted: a copy the compiler cannot see through, tied to the iteration by the token)
+__device__ __forceinline__ unsigned int opaque_here(unsigned int x, unsigned int tok)
+{
+#if LOIKB_FIELD_TOKEN
+  asm("" : "+v"(x) : "s"(tok));
+#else
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
 template <int OFF, int W>
-__device__ __forceinline__ unsigned int field_here(unsigned int x)
+__device__ __forceinline__ unsigned int field_here(unsigned int x, unsigned int tok)
 {
   unsigned int r;
+#if LOIKB_FIELD_TOKEN
+  // (not volatile: the scheduler may place it; the unused scalar operand changes every iteration, which is what keeps the thirty
+  //  addresses from being hoisted out of the loop into registers the kernel does not have)
+  asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(OFF), "n"(W), "s"(tok));
+#else
   asm volatile("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "n"(OFF), "n"(W));
+#endif
   return r;
 }
 __device__ __forceinline__ double lds_at(const double* base, unsigned int byte_off)
@@ -288,7 +307,7 @@ __device__ __forceinline__ void static_for(F&& f)
 // the byte offsets (lane x 8, ten bits each) of the ancestors at distance 1, 2, 3 / 4, 8, 12 / 16 (WAVE x 8 = none).
 constexpr int PATH_RS = WAVE + 2;
 template <typename T, int NC>
-__device__ __forceinline__ void flat_path_sum4(T* rows, int lane, unsigned int pa, unsigned int pb, unsigned int pc, int njmp, T* y)
+__device__ __forceinline__ void flat_path_sum4(T* rows, int lane, unsigned int pa, unsigned int pb, unsigned int pc, int njmp, T* y, unsigned int tok)
 {
   tail_sync();
   if (lane < NC) rows[lane * PATH_RS + WAVE] = T(0);
@@ -297,7 +316,7 @@ __device__ __forceinline__ void flat_path_sum4(T* rows, int lane, unsigned int p
 #pragma unroll
     for (int c = 0; c < NC; ++c) rows[c * PATH_RS + lane] = y[c];
     tail_sync();
-    const unsigned int r0 = field_here<0, 10>(p3), r1 = field_here<10, 10>(p3), r2 = field_here<20, 10>(p3);
+    const unsigned int r0 = field_here<0, 10>(p3, tok), r1 = field_here<10, 10>(p3, tok), r2 = field_here<20, 10>(p3, tok);
     T a[NC], b[NC], d[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) a[c] = lds_at(rows + c * PATH_RS, r0);
@@ -1022,7 +1041,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const T* wcur = wl + (size_t)wsel * (NA + 1) * GW;
     TAIL_TP(8)
    next_iteration:   // (a quiet iteration comes straight back here: nothing above can have changed)
-    const unsigned int h3b = (opaque((unsigned int)lane) >> 5) * 24u;   // byte offset of this half in a 6-vector of a constraint block
+    const unsigned int itok = my_iters + 1u;   // (changes every iteration: see field_here)
+    const unsigned int h3b = (opaque_here((unsigned int)lane, itok) >> 5) * 24u;   // byte offset of this half in a 6-vector of a constraint block
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
     ++my_iters; any_iter = true;
     ++n_wave_iters;
@@ -1059,13 +1079,13 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T rn;
     {
       T a[4];
-      static_for<0, 4>([&](auto t) { a[t] = lds_at(xb, field_here<16 * (t & 1), 16>(ra2[t >> 1])); });
+      static_for<0, 4>([&](auto t) { a[t] = lds_at(xb, field_here<16 * (t & 1), 16>(ra2[t >> 1], itok)); });
       T acc = (a[0] + a[1]) + (a[2] + a[3]);
       acc = pair_sum(acc);
       if (!h) pbuf[j] = helper ? acc : T(0);
       tail_sync();
       T pp[4];
-      static_for<0, 4>([&](auto q) { pp[q] = lds_at(pbuf, field_here<16 * (q & 1), 16>(part2[q >> 1])); });
+      static_for<0, 4>([&](auto q) { pp[q] = lds_at(pbuf, field_here<16 * (q & 1), 16>(part2[q >> 1], itok)); });
       T ps = (pp[0] + pp[1]) + (pp[2] + pp[3]);
       ps = pair_sum(ps);
       if (helper) acc = T(0);
@@ -1080,7 +1100,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       // (measured and rejected: these gathers -- and the partial sums above -- from lane to lane through the LDS crossbar,
       //  ds_bpermute, instead of a write, a fence and the reads: one dependent trip less each, and 13.0 -> 13.9 ms)
       T nb_[NH];
-      static_for<0, NH>([&](auto i) { nb_[i] = lds_at(nbuf, field_here<10 * (i % 3), 10>(anc3[i / 3])); });
+      static_for<0, NH>([&](auto i) { nb_[i] = lds_at(nbuf, field_here<10 * (i % 3), 10>(anc3[i / 3], itok)); });
       T acc = T(0), acc2 = T(0);   // (two chains: see awy_of)
 #pragma unroll
       for (int i = 0; i < NH; ++i) { if (i & 1) acc2 += wc[i] * nb_[i]; else acc += wc[i] * nb_[i]; }
@@ -1092,7 +1112,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       T y[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) y[k] = Sw3[k] * nui;
-      flat_path_sum4<T, 3>(xb, lane, pathA, pathB, pathC, njmp, y);
+      flat_path_sum4<T, 3>(xb, lane, pathA, pathB, pathC, njmp, y, itok);
       if (jcslot >= 0) {  // the constrained links' velocities at the world origin: the task constraints' update starts from them
 #pragma unroll
         for (int k = 0; k < 3; ++k) cdi[jcslot * cs + C2_VC + h3 + k] = y[k];
@@ -1146,8 +1166,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       // exchanges through the constraint block in LDS (lane 6 c + k owns row k).  A v_c = AW^T v^w_c: no frame change first.
       const bool first = my_iters == 1u && !resumed;  // (the first iteration of a fresh record: see load_instance)
       tail_sync();
-      const char* const ccb0 = reinterpret_cast<const char*>(cdi) + opaque(cb_blk);   // this lane's constraint block
-      const unsigned int ck8 = opaque(cb_k);                                           // 8 k
+      const char* const ccb0 = reinterpret_cast<const char*>(cdi) + opaque_here(cb_blk, itok);   // this lane's constraint block
+      const unsigned int ck8 = opaque_here(cb_k, itok);                                           // 8 k
       {
         const T* col = reinterpret_cast<const T*>(ccb0 + C2_AWT * 8 + 6 * ck8);
         const T* vc = reinterpret_cast<const T*>(ccb0 + C2_VC * 8);
@@ -1304,7 +1324,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       else return mass * tabs(href_s) * hinf3(v3);
     };
     auto ub_lb_sums = [&](T& up, T& lm) {   // this lane's terms of ub^T [dz]_+ and lb^T [dz]_- (hpp:430-446): task rows and the joint's box
-      const T bk = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(cdi) + opaque(cb_blk) + C2_B * 8 + opaque(cb_k));
+      const T bk = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(cdi) + opaque_here(cb_blk, itok) + C2_B * 8 + opaque_here(cb_k, itok));
       up = bk * tmax(s_dy, T(0));
       lm = bk * tmin(s_dy, T(0));
       up += hz * (ubi * tmax(s_dw, T(0)));
@@ -1958,6 +1978,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
    next_iteration:   // (a quiet iteration comes straight back here: see k_flat2)
     const T mu_eq = P.mu_scale * mu, mu_in = mu;
     ++my_iters; any_iter = true;
+    const unsigned int itok = my_iters;   // (see field_here)
     ++n_wave_iters;
 
     // ---- p^base summed over the subtrees; tau
@@ -1990,12 +2011,12 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T rn;
     {
       T a[FLAT_RED];
-      static_for<0, FLAT_RED>([&](auto t) { a[t] = lds_at(xb, field_here<16 * (t & 1), 16>(ra2[t >> 1])); });
+      static_for<0, FLAT_RED>([&](auto t) { a[t] = lds_at(xb, field_here<16 * (t & 1), 16>(ra2[t >> 1], itok)); });
       T acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
       pbuf[lane] = helper ? acc : T(0);
       tail_sync();
       T pp[FLAT_PART];
-      static_for<0, FLAT_PART>([&](auto q) { pp[q] = pbuf[field_here<8 * (q & 3), 8>(prow4[q >> 2])]; });
+      static_for<0, FLAT_PART>([&](auto q) { pp[q] = pbuf[field_here<8 * (q & 3), 8>(prow4[q >> 2], itok)]; });
       if (helper) acc = T(0);
 #pragma unroll
       for (int q = 0; q < FLAT_PART; ++q) acc += pp[q];
@@ -2008,7 +2029,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T nui;
     {
       T nb_[NA];
-      static_for<0, NA>([&](auto k) { nb_[k] = nbuf[field_here<8 * (k & 3), 8>(anc4[k >> 2])]; });
+      static_for<0, NA>([&](auto k) { nb_[k] = nbuf[field_here<8 * (k & 3), 8>(anc4[k >> 2], itok)]; });
       T acc = dinv * rn;
 #pragma unroll
       for (int k = 0; k < NA; ++k) acc += wc[k] * nb_[k];
@@ -2020,7 +2041,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       T vw[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) vw[k] = Sw[k] * nui;
-      flat_path_sum4<T, 6>(xb, lane, pathA, pathB, pathC, njmp, vw);
+      flat_path_sum4<T, 6>(xb, lane, pathA, pathB, pathC, njmp, vw, itok);
       if (jcslot >= 0) {  // the constrained links' velocities at the world origin: the task constraints' update starts from them
 #pragma unroll
         for (int k = 0; k < 6; ++k) cdi[jcslot * cs + C2_VC + k] = vw[k];
