@@ -306,16 +306,22 @@ __device__ __forceinline__ void static_for(F&& f)
 // component-major (one address per ancestor, the components at constant offsets), entry WAVE of a component = 0; pa / pb / pc:
 // the byte offsets (lane x 8, ten bits each) of the ancestors at distance 1, 2, 3 / 4, 8, 12 / 16 (WAVE x 8 = none).
 constexpr int PATH_RS = WAVE + 2;
-template <typename T, int NC>
+// PB2 (a build for joints with at most 11 ancestors): the second round has the ancestors at distance 4 and 8 only and there is no third
+// round; the two offsets are the fields <20, 10> of pb and <22, 10> of pc -- bits the caller's other packed words have to spare (one
+// register less across the loop), and the row of the ancestor at distance 12, which does not exist, is not read.
+template <typename T, int NC, bool PB2 = false>
 __device__ __forceinline__ void flat_path_sum4(T* rows, int lane, unsigned int pa, unsigned int pb, unsigned int pc, int njmp, T* y, unsigned int tok)
 {
   tail_sync();
   if (lane < NC) rows[lane * PATH_RS + WAVE] = T(0);
-  auto round = [&](unsigned int p3) {
+  auto publish = [&]() {
     tail_sync();
 #pragma unroll
     for (int c = 0; c < NC; ++c) rows[c * PATH_RS + lane] = y[c];
     tail_sync();
+  };
+  auto round = [&](unsigned int p3) {
+    publish();
     const unsigned int r0 = field_here<0, 10>(p3, tok), r1 = field_here<10, 10>(p3, tok), r2 = field_here<20, 10>(p3, tok);
     T a[NC], b[NC], d[NC];
 #pragma unroll
@@ -328,8 +334,22 @@ __device__ __forceinline__ void flat_path_sum4(T* rows, int lane, unsigned int p
     for (int c = 0; c < NC; ++c) y[c] += (a[c] + b[c]) + d[c];
   };
   round(pa);
-  if (njmp > 2) round(pb);
-  if (njmp > 4) round(pc);
+  if constexpr (PB2) {
+    if (njmp > 2) {
+      publish();
+      const unsigned int r0 = field_here<20, 10>(pb, tok), r1 = field_here<22, 10>(pc, tok);
+      T a[NC], b[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) a[c] = lds_at(rows + c * PATH_RS, r0);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) b[c] = lds_at(rows + c * PATH_RS, r1);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) y[c] += a[c] + b[c];   // (= (a + b) + 0: the same bits as the general round)
+    }
+  } else {
+    if (njmp > 2) round(pb);
+    if (njmp > 4) round(pc);
+  }
 }
 // the packed ancestor offsets of flat_path_sum4 for the joint of FlatLane F: `off` is added to an ancestor's lane
 __device__ __forceinline__ void flat_path_rows4(const FlatLane* fl, int j, int off, unsigned int& pa, unsigned int& pb, unsigned int& pc)
@@ -353,11 +373,26 @@ __host__ __device__ constexpr int flat2_xregion()
   if (NA * F2W + 2 > n) n = NA * F2W + 2;         // W tau products (+ a zero slot)
   return (n + 1) & ~1;
 }
-template <int NA> __host__ __device__ constexpr int flat2_off_wl() { return flat2_xregion<NA>(); }                          // [2][NA + 1][32]
+// What the ITERATION keeps in the exchange region: the W tau products [NA][32] (+ a zero slot), the path rows [3][66], the prefix rows
+// [64][3] (two sets with a non-scalar reference weight: [65][3] + [64][3]).  The rows an instance's LOAD needs (XROWS * 9: the oMi
+// chain, the full-width scans) reach beyond that -- into the decade slots behind, which hold nothing while an instance is loaded
+// (kslot / kslot_o are invalid from the moment the load starts; the first decade's columns are written at its end): 1.6 KB of LDS
+// per wavefront that the third wavefront of a SIMD needs (12 wavefronts per CU: <= 13 653 bytes each).
+template <int NA>
+__host__ __device__ constexpr int flat2_xloop()
+{
+  int n = NA * F2W + 2;
+  if ((WAVE + 1) * 3 + WAVE * 3 > n) n = (WAVE + 1) * 3 + WAVE * 3;
+  if (3 * (WAVE + 2) > n) n = 3 * (WAVE + 2);
+  return (n + 1) & ~1;
+}
+template <int NA> __host__ __device__ constexpr int flat2_off_wl() { return flat2_xloop<NA>(); }                            // [2][NA + 1][32]
 template <int NA> __host__ __device__ constexpr int flat2_off_nbuf() { return flat2_off_wl<NA>() + 2 * (NA + 1) * F2W; }  // [34]
 template <int NA> __host__ __device__ constexpr int flat2_off_pbuf() { return flat2_off_nbuf<NA>() + F2G + 2; }           // [34]
 template <int NA> __host__ __device__ constexpr int flat2_off_rbuf() { return flat2_off_pbuf<NA>() + F2G + 2; }           // [32]
-template <int NA> __host__ __device__ constexpr int flat2_off_tail() { return flat2_off_rbuf<NA>() + F2G; }
+template <int NA> __host__ __device__ constexpr int flat2_off_jc() { return flat2_off_rbuf<NA>() + F2G; }                 // [32][3]: lb, ub, S^T f + w
+template <int NA> __host__ __device__ constexpr int flat2_off_tail() { return flat2_off_jc<NA>() + F2G * 3; }
+static_assert(flat2_xloop<10>() + 2 * 11 * F2W >= flat2_xregion<10>(), "the load-time rows must end inside the decade slots");
 
 template <int NA>
 __host__ __device__ __forceinline__ size_t flat2_lds_bytes(int nc, bool has_hv)
@@ -398,6 +433,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   using T = double;
   static_assert(NA % 2 == 0, "the W entries of a joint are dealt out to its two lanes");
   constexpr int G = F2G, GW = F2W, cs = C2D, NH = NA / 2;
+  constexpr bool PB2 = NA <= 11 && NH % 3 != 0;   // (the path sum's second round from spare bits of anc3 / cb_pk: flat_path_sum4)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
   const bool a_shared = P.mode & MODE_A_SHARED;
@@ -407,17 +443,21 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   //  ones shorter, so that the instances still running when the queue is empty have done the same number of iterations to within that)
   const int slice_len = (SLICED && quantum > 0) ? (quantum & 0xffff) : 0x3fffffff;
   const int slice_len2 = (SLICED && (quantum >> 16) > 0) ? (quantum >> 16) : slice_len;
-  const double tol_abs_h = held<SLICED>(P.tol_abs), tpi_h = held<SLICED>(P.tol_primal_inf);
-  const int max_iter_h = held<SLICED>(P.max_iter);
+  const double tol_abs_h = held<SLICED || WPE >= 3>(P.tol_abs), tpi_h = held<SLICED || WPE >= 3>(P.tol_primal_inf);
+  const int max_iter_h = held<SLICED || WPE >= 3>(P.max_iter);
   const int j = lane & 31;       // lanes j and 32 + j <-> device joint j + 1
   const bool h = lane >= 32;     // 0: linear halves, 1: angular halves
   const int h3 = h ? 3 : 0;
+  // Three wavefronts per SIMD leave a lane 168 registers: what an iteration touches once -- the joint's box, last iteration's
+  // S^T f + w -- then lives in LDS (one row of three per joint; both lanes of a joint read the same address).
+  constexpr bool JCL = WPE >= 3;
   // ---- LDS of the wavefront
   T* const xb = reinterpret_cast<T*>(smem_raw);   // load-time rows | path rows [65][3] | W tau products [NA][32]
   T* const wl = xb + flat2_off_wl<NA>();          // [2][NA + 1][32]  W rows and the Dinv row of two decades of mu
   T* const nbuf = xb + flat2_off_nbuf<NA>();      // [34]             Dinv r' of every joint (+ zeros)
   T* const pbuf = xb + flat2_off_pbuf<NA>();      // [34]             partial sums of long rows
   T* const rbuf = xb + flat2_off_rbuf<NA>();      // [32]             r' of the last iteration (stored with the instance)
+  T* const jc = xb + flat2_off_jc<NA>();          // [32][3]          lb, ub, S^T f + w of the joints (the builds for three wavefronts per SIMD)
   T* const shv = xb + flat2_off_tail<NA>();       // [32][6]          subtree sums of the links' H_ref v_ref (if != 0)
   T* const cdi = shv + (has_hv ? G * 6 : 0);      // [nc][C2D]        constraint blocks of the instance
   T* const isc = cdi + (size_t)L.nc * cs;         // [FISC]
@@ -440,6 +480,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   auto hvl3_of = [&](int k) -> T { return HM == 3 ? hrow[36 + h3 + k] : (h ? P.Hv[3 + k] : P.Hv[k]); };  // this half of H_ref v_ref of the link
   int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
   bool helper;
+  unsigned int pb2_d4 = 0u, pb2_d8 = 0u;
   unsigned int pathA, pathB, pathC;        // iteration: the ancestors at distance 1, 2, 3 / 4, 8, 12 / 16: byte offsets of their lanes of this half
   unsigned int ra2[2], part2[2], anc3[(NH + 2) / 3];  // byte offsets into the product / partial / Dinv r' buffers (16 / 16 / 10 bits each)
   {
@@ -448,6 +489,10 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     helper = (F.helper & 1) != 0;
     fcol = F.helper >> 8; fdm1 = F.depth > 0 ? F.depth - 1 : 0;
     flat_path_rows4(fl, j, h ? 32 : 0, pathA, pathB, pathC);
+    if constexpr (PB2) {   // (distance 4 into the last word of anc3, distance 8 into cb_pk: see flat_path_sum4)
+      pb2_d4 = pathB & 0x3FFu;
+      pb2_d8 = (pathB >> 10) & 0x3FFu;
+    }
 #pragma unroll
     for (int k = 0; k < (NH + 2) / 3; ++k) anc3[k] = 0u;
     // this lane's half of the joint's share of the W tau products, of its partials and of its W entries (k = 2 i + h)
@@ -466,6 +511,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       const int a = h ? a1 : a0;
       anc3[i / 3] |= (unsigned int)((a >= 0 ? a : G) * 8) << (10 * (i % 3));
     }
+    if constexpr (PB2) anc3[(NH + 2) / 3 - 1] |= pb2_d4 << 20;
   }
   if (lane < 2) { nbuf[G + lane] = T(0); pbuf[G + lane] = T(0); }
   for (int e = lane; e < 2 * (NA + 1) * GW; e += WAVE) wl[e] = T(0);
@@ -491,7 +537,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   // then run without a branch around them, i.e. in the basic block of the subtree prefix sums, and the scheduler fills the update's
   // LDS round trips and dependent multiply-adds with the prefix sums' DPP chains.
   const bool iscl = lane < 6 * L.nc;
-  const unsigned int cb_blk = (unsigned int)((iscl ? (lane / 6) * cs : L.nc * cs + FISC + 36) * 8), cb_k = (unsigned int)((lane % 6) * 8);
+  // (one register: the block's byte offset in the low 16 bits, 8 k above them)
+  const unsigned int cb_pk = (unsigned int)((iscl ? (lane / 6) * cs : L.nc * cs + FISC + 36) * 8) | ((unsigned int)((lane % 6) * 8) << 16) | (PB2 ? pb2_d8 << 22 : 0u);
   // (AW y)_k and (A^T y)_k of the constraint of lane 6 c + k: ONE order of operations wherever they are formed (load, loop, store),
   // so that an instance resumed from the queue continues with the bits it would have had
   auto awy_of = [&](const char* blk, unsigned int k8) -> T {
@@ -579,7 +626,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     for (int k = 0; k < 3; ++k) put(g3[k]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) put(SE3[k]);
-    put(w); put(z); put(nu); put(s); put(lbi); put(ubi);
+    if constexpr (JCL) { put(w); put(z); put(nu); put(jc[j * 3 + 2]); put(jc[j * 3]); put(jc[j * 3 + 1]); }
+    else { put(w); put(z); put(nu); put(s); put(lbi); put(ubi); }
     T* pl = pk + FLAT2_PARK_ROWS * WAVE;
     const int nl = (has_hv ? G * 6 : 0) + L.nc * cs + FISC;   // shv | constraint blocks | the getters' scalars: contiguous in LDS
     tail_sync();
@@ -636,6 +684,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     for (int k = 0; k < 3; ++k) SE3[k] = get();
     w = get(); z = get(); nu = get(); s = get(); lbi = get(); ubi = get();
     tail_sync();
+    if constexpr (JCL) { jc[j * 3] = lbi; jc[j * 3 + 1] = ubi; jc[j * 3 + 2] = s; }
     auto put_lds = [&](int e, T x) { if (e < nl) shv[e] = x; else if (e < nl6) xb[e - nl] = x; };   // (the scalars: load-time rows, free now)
 #pragma unroll
     for (int k = 0; k < FLAT2_PARK_BATCH; ++k) put_lds(k * WAVE + lane, lb[k]);
@@ -873,6 +922,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       }
     }
     half(Sw, Sw3); half(v, v3); half(f, f3); half(g, g3); half(SE, SE3);
+    if constexpr (JCL) { jc[j * 3] = lbi; jc[j * 3 + 1] = ubi; jc[j * 3 + 2] = s; }
     mu = mu2.x;
     kexp = (int)mu2.y;
     kslot = -(1 << 30); kslot_o = -(1 << 30);
@@ -918,7 +968,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         rst6<T, false>(rec, JP_F, f);
         rst6<T, false>(rec, JP_G, g);
         rstp<T, false>(rec, JP_WZ, w, z);
-        rstp<T, false>(rec, JP_NUS, nu, s);
+        rstp<T, false>(rec, JP_NUS, nu, JCL ? jc[j * 3 + 2] : s);
         if (any_iter) {
           // inter-sweep temporaries of the last iteration: r_i and Dinv_i.  This engine forms neither UDinv_i nor the
           // accumulated p_i: the scalar record's tag says so (SP_TAG = -2) and the getters rebuild them (k_rebuild_ud).
@@ -1112,7 +1162,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       T y[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) y[k] = Sw3[k] * nui;
-      flat_path_sum4<T, 3>(xb, lane, pathA, pathB, pathC, njmp, y, itok);
+      if constexpr (PB2) flat_path_sum4<T, 3, true>(xb, lane, pathA, anc3[(NH + 2) / 3 - 1], cb_pk, njmp, y, itok);
+      else flat_path_sum4<T, 3>(xb, lane, pathA, pathB, pathC, njmp, y, itok);
       if (jcslot >= 0) {  // the constrained links' velocities at the world origin: the task constraints' update starts from them
 #pragma unroll
         for (int k = 0; k < 3; ++k) cdi[jcslot * cs + C2_VC + h3 + k] = y[k];
@@ -1166,8 +1217,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       // exchanges through the constraint block in LDS (lane 6 c + k owns row k).  A v_c = AW^T v^w_c: no frame change first.
       const bool first = my_iters == 1u && !resumed;  // (the first iteration of a fresh record: see load_instance)
       tail_sync();
-      const char* const ccb0 = reinterpret_cast<const char*>(cdi) + opaque_here(cb_blk, itok);   // this lane's constraint block
-      const unsigned int ck8 = opaque_here(cb_k, itok);                                           // 8 k
+      const char* const ccb0 = reinterpret_cast<const char*>(cdi) + field_here<0, 16>(cb_pk, itok);   // this lane's constraint block
+      const unsigned int ck8 = field_here<16, 6>(cb_pk, itok);                                         // 8 k
       {
         const T* col = reinterpret_cast<const T*>(ccb0 + C2_AWT * 8 + 6 * ck8);
         const T* vc = reinterpret_cast<const T*>(ccb0 + C2_VC * 8);
@@ -1260,7 +1311,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         l_dvis = mass * hinf3(dv);
         s_dnu = nui - nu;
         const T x = nui + inv_mu * w;
-        const T zi = hmin(ubi, hmax(lbi, x));
+        const T zi = JCL ? hmin(jc[j * 3 + 1], hmax(jc[j * 3], x)) : hmin(ubi, hmax(lbi, x));
         s_dz = zi - z;
         s_prs = nui - zi;
         const T dwi = mu_in * (nui - zi);
@@ -1309,8 +1360,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       l_dfis = mass * hinf3(df);
       si += w;
       s_stf = si;
-      s_dstf = si - s;
-      s = si;
+      if constexpr (JCL) { s_dstf = si - jc[j * 3 + 2]; jc[j * 3 + 2] = si; }
+      else { s_dstf = si - s; s = si; }
 #pragma unroll
       for (int k = 0; k < 3; ++k) f3[k] = fi3[k];
     }
@@ -1324,11 +1375,11 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       else return mass * tabs(href_s) * hinf3(v3);
     };
     auto ub_lb_sums = [&](T& up, T& lm) {   // this lane's terms of ub^T [dz]_+ and lb^T [dz]_- (hpp:430-446): task rows and the joint's box
-      const T bk = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(cdi) + opaque_here(cb_blk, itok) + C2_B * 8 + opaque_here(cb_k, itok));
+      const T bk = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(cdi) + field_here<0, 16>(cb_pk, itok) + C2_B * 8 + field_here<16, 6>(cb_pk, itok));
       up = bk * tmax(s_dy, T(0));
       lm = bk * tmin(s_dy, T(0));
-      up += hz * (ubi * tmax(s_dw, T(0)));
-      lm += hz * (lbi * tmin(s_dw, T(0)));
+      up += hz * ((JCL ? jc[j * 3 + 1] : ubi) * tmax(s_dw, T(0)));
+      lm += hz * ((JCL ? jc[j * 3] : lbi) * tmin(s_dw, T(0)));
     };
     const bool fixed = P.mode & MODE_FIXED_ITERS;
     const bool in_tail = (status & ST_TAIL) != 0;

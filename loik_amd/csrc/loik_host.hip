@@ -273,6 +273,8 @@ struct loikb_solver_impl {
   // (LOIKB_OPT_ORDER_FROM_PREVIOUS: a tracking planner), and then under the watch of the timing comparison below.
   unsigned long long inputs_epoch = 1;
   bool href_known = false;   // S->Href holds the reference weight of the problem being set up (loikb_solve_init, before the plan is made)
+  bool tab_bcast = false;    // the links' reference table on the device holds ONE (H_ref, v_ref) pair for all links: tab_H / tab_v
+  double tab_H[36] = {0}, tab_v[6] = {0};
   int log_truncated = 0;     // instances of the last logged solve whose SolverInfo lists end early (see run_logged)
   PassLayout PL{};
   double* d_pass = nullptr;
@@ -323,6 +325,17 @@ int ensure_getscr(loikb_solver_impl* S, int k, size_t bytes)
   HIPCHK(hipMalloc(&S->d_getscr[k], bytes));
   S->getscr_bytes[k] = bytes;
   return LOIKB_OK;
+}
+
+// the getters' scratch goes back when a solve-side buffer needs the room (decade slots, park records): ADVICE r04
+static size_t release_getscr(loikb_solver_impl* S)
+{
+  size_t freed = 0;
+  for (int k = 0; k < 2; ++k) {
+    if (S->d_getscr[k]) { (void)hipFree(S->d_getscr[k]); S->d_getscr[k] = nullptr; freed += S->getscr_bytes[k]; S->getscr_bytes[k] = 0; }
+  }
+  (void)hipGetLastError();
+  return freed;
 }
 
 inline dim3 grid1(size_t n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
@@ -1161,8 +1174,9 @@ int ensure_hslots(loikb_solver_impl* S)
       if (need <= C.fslots_bytes) continue;
       if (C.d_fslots) HIPCHK(hipFree(C.d_fslots));
       C.d_fslots = nullptr; C.fslots_bytes = 0;
-      if (hipMalloc(&C.d_fslots, need) != hipSuccess) {
+      if (hipMalloc(&C.d_fslots, need) != hipSuccess && !(release_getscr(S) > 0 && hipMalloc(&C.d_fslots, need) == hipSuccess)) {
         (void)hipGetLastError();
+        C.d_fslots = nullptr;
         char buf[400];
         snprintf(buf, sizeof(buf), "the flat engine needs %.2f GB of decade slots for %d instances (%d decades x %d rows x %d lanes x %d B) "
                  "and the device has no room for them: create the solver with a smaller batch, or set LOIKB_FLAT=0 LOIKB_LEAN=0 to use "
@@ -1180,7 +1194,7 @@ int ensure_hslots(loikb_solver_impl* S)
         if (need <= C.park_bytes) continue;
         if (C.d_park) HIPCHK(hipFree(C.d_park));
         C.d_park = nullptr; C.park_bytes = 0;
-        if (hipMalloc(&C.d_park, need) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (hipMalloc(&C.d_park, need) != hipSuccess && !(release_getscr(S) > 0 && hipMalloc(&C.d_park, need) == hipSuccess)) { (void)hipGetLastError(); C.d_park = nullptr; continue; }
         C.park_bytes = need;
       }
     }
@@ -1387,10 +1401,10 @@ int update_eq_single(loikb_solver_impl* S, int c_id, const double* Ai, const dou
 
 // problem_.UpdateReference / UpdateIneqConstraints / UpdateEqConstraints (ik-id-description-optimized.hpp:78-171,
 // :325-339) with the batch layouts of loik_amd.h
-int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, const int* c_ids, int nc,
-                const double* Ais, const double* bis, const double* lb, const double* ub, int nbound, int in_flags)
+// the throw sites of UpdateReference / UpdateIneqConstraints / UpdateEqConstraints, before anything of the handle changes (a rejected
+// SolveInit leaves the previous problem in force, reference weight and plan included: ADVICE r04)
+int validate_problem(const loikb_solver_impl* S, const double* H_ref, const int* c_ids, int nc, int nbound)
 {
-  ++S->inputs_epoch;
   if (nbound != S->nv) { g_last_error = "lb/ub dimension differs from model.nv"; return LOIKB_ERR_INEQ_DIM; }
   if (nc != S->nc_active) { g_last_error = "number of equality constraints doesn't match initialization"; return LOIKB_ERR_EQ_C_SIZE; }
   if (!symmetric6(H_ref)) { g_last_error = "H_ref must be symmetric"; return LOIKB_ERR_HREF_NOT_SYMMETRIC; }
@@ -1399,10 +1413,19 @@ int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, 
     for (int c2 = 0; c2 < c; ++c2)
       if (c_ids[c2] == c_ids[c]) { g_last_error = "multiple constraints on the same link"; return LOIKB_ERR_DUP_CONSTRAINT; }
   }
+  return LOIKB_OK;
+}
+
+int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, const int* c_ids, int nc,
+                const double* Ais, const double* bis, const double* lb, const double* ub, int nbound, int in_flags)
+{
+  if (int vrc = validate_problem(S, H_ref, c_ids, nc, nbound)) return vrc;
+  ++S->inputs_epoch;
   const bool dev = in_flags & LOIKB_IN_DEVICE;
   int rc;
   // UpdateReference: Hv = H_ref v_ref, Hv_inf_norm_ (hpp:85-96)
-  const bool same_ref = S->d_href64 && !S->per_link && !memcmp(S->Href, H_ref, sizeof(S->Href)) && !memcmp(S->vref, v_ref, sizeof(S->vref));
+  // (what the TABLE holds, not what S->Href holds: SolveInit stores the new weight there before the plan is made)
+  const bool same_ref = S->d_href64 && S->tab_bcast && !memcmp(S->tab_H, H_ref, sizeof(S->tab_H)) && !memcmp(S->tab_v, v_ref, sizeof(S->tab_v));
   memcpy(S->Href, H_ref, sizeof(S->Href));
   memcpy(S->vref, v_ref, sizeof(S->vref));
   S->href_diag = true;
@@ -1419,7 +1442,11 @@ int set_problem(loikb_solver_impl* S, const double* H_ref, const double* v_ref, 
   S->per_link = false;
   if (!same_ref) {  // (the table the getters and the pass-level path read; the engines take the broadcast pair as arguments)
     fill_href_tab(S, H_ref, v_ref, 0, 0);
+    S->tab_bcast = false;
     if ((rc = upload_href_tab(S))) return rc;
+    memcpy(S->tab_H, H_ref, sizeof(S->tab_H));
+    memcpy(S->tab_v, v_ref, sizeof(S->tab_v));
+    S->tab_bcast = true;
   }
   // UpdateIneqConstraints
   S->bnd_shared = in_flags & LOIKB_BOUNDS_SHARED;
@@ -1790,7 +1817,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           else if (hm == 3) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 3); else LOIKB_LAUNCH_FLAT2(2, false, 3); }
           else if (hm == 2) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 2); else LOIKB_LAUNCH_FLAT2(2, false, 2); }
           else if (hm == 1) { if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 1); else LOIKB_LAUNCH_FLAT2(2, false, 1); }
-          else if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true);
+          else if (quantum > 0) { if (wpe == 3) LOIKB_LAUNCH_FLAT2(3, true); else LOIKB_LAUNCH_FLAT2(2, true); }
           else if (wpe == 3) LOIKB_LAUNCH_FLAT2(3);
           else LOIKB_LAUNCH_FLAT2(2);
 #undef LOIKB_LAUNCH_FLAT2
@@ -2689,8 +2716,10 @@ int loikb_solve_init(loikb_solver* S, const double* q, const double* H_ref, cons
   if (!S || !q || !H_ref || !v_ref || (nc > 0 && (!c_ids || !Ais || !bis)) || !lb || !ub) return LOIKB_ERR_ARG;
   HIPCHK(hipSetDevice(S->device));
   int rc;
+  if ((rc = validate_problem(S, H_ref, c_ids, nc, nbound))) return rc;   // (nothing of the handle has changed yet)
   memcpy(S->Href, H_ref, 36 * sizeof(double));   // (the plan looks at the reference weight: set_problem stores it again)
   S->href_known = true;
+  S->per_link = false;   // (UpdateReference replaces a per-link table: the plan and the slot buffers are sized for the problem being set)
   if ((rc = ensure_layout(S, in_flags & LOIKB_A_SHARED))) return rc;
   S->pass_active = false;
   // problem_.Reset(); ik_id_data_.Reset(warm_start); ResetSolver()  (hpp:345-352)
@@ -2713,6 +2742,7 @@ int loikb_update_references(loikb_solver* S, const double* H_refs, const double*
   HIPCHK(hipStreamSynchronize(S->stream));
   ++S->inputs_epoch;
   fill_href_tab(S, H_refs, v_refs, 36, 6);
+  S->tab_bcast = false;
   // Hv_inf_norm_ is not reset here and the universe's entry counts (hpp:110-118: the loop runs over all nj entries)
   S->href_diag = true;
   for (int e = 0; e < n; ++e) {
@@ -2753,7 +2783,7 @@ int loikb_solve_full(loikb_solver* S, const double* q, const double* H_ref, cons
 {
   int rc = loikb_solve_init(S, q, H_ref, v_ref, c_ids, nc, Ais, bis, lb, ub, nbound, in_flags);
   if (rc) return rc;
-  return S->opt.logging ? run_logged(S, S->opt.warm_start ? 0 : (RS_SOLVER | RS_DATA_COLD)) : run_main_loop(S);
+  return S->opt.logging ? run_logged(S, S->opt.warm_start ? 0 : (RS_SOLVER | RS_DATA_COLD | RS_Y | RS_HCACHE)) : run_main_loop(S);
 }
 
 int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const double* Ai, const double* bi, int in_flags)
@@ -2768,7 +2798,7 @@ int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const doubl
   // upstream: the way to solve after AddEqConstraint / RemoveEqConstraint changed the set, possibly to the empty one)
   if (c_id >= 0 && (rc = update_eq_single(S, c_id, Ai, bi, in_flags))) return rc;
   if ((rc = fwd_pass_init(S, q, in_flags))) return rc;
-  return S->opt.logging ? run_logged(S, S->opt.warm_start ? 0 : (RS_SOLVER | RS_DATA_COLD)) : run_main_loop(S);
+  return S->opt.logging ? run_logged(S, S->opt.warm_start ? 0 : (RS_SOLVER | RS_DATA_COLD | RS_Y | RS_HCACHE)) : run_main_loop(S);
 }
 
 // problem_.UpdateEqConstraint (hpp:178-238), AddEqConstraint (:244-286), RemoveEqConstraint (:292-319) between solves
@@ -2945,7 +2975,9 @@ static bool logged_on_flat(const loikb_solver_impl* S)
 // main loop on the plain pass implementation (k_pass_solve), whose results are then read from the pass state (loikb_get), like
 // after loikb_pass.
 // redo_reset: the reset_home flags that put the solver into the state this solve starts from, when that state can be put back (a cold
-// Solve(), a solve that began with a cold data reset); 0 when it cannot (a warm start: the iterates the solve began with are gone)
+// Solve(), a solve that began with a cold data reset); 0 when it cannot (a warm start: the iterates the solve began with are gone).
+// For the entries that begin with Reset(false) + FwdPassInit that is RS_DATA_COLD (w, z, nu, vis, fis, g) AND RS_Y (FwdPassInit's
+// yis = Aty = 0, optimized.hxx:270-278) AND RS_HCACHE (fwd_pass_init's): the first attempt left its duals and factors behind.
 static int run_logged(loikb_solver_impl* S, int redo_reset)
 {
   int rc;
@@ -3211,6 +3243,17 @@ const char* loikb_plan_string(loikb_solver* S)
       snprintf(b3, sizeof(b3), "; launches without an order (a handle's first solve of its inputs) are time-sliced: %d iterations, then %d, "
                "while other instances wait", q & 0xffff, ((q >> 16) & 0x3fff) ? ((q >> 16) & 0x3fff) : (q & 0xffff));
       out += b3;
+    }
+  }
+  {   // device memory the handle holds besides the instances' tiles (the kept getter scratch was nowhere to be seen)
+    size_t fs = 0, pk = 0, hs = 0;
+    for (const Chunk& C : S->chunks) { fs += C.fslots_bytes; pk += C.park_bytes; hs += C.hslots_bytes; }
+    const size_t gs = S->getscr_bytes[0] + S->getscr_bytes[1];
+    if (fs + pk + hs + gs > 0) {
+      char b4[240];
+      snprintf(b4, sizeof(b4), "; device buffers: decade slots %.0f MB, park records %.0f MB, getters' scratch %.0f MB (kept between calls; "
+               "given back when the slots or park records need the room)", (fs + hs) / 1048576.0, pk / 1048576.0, gs / 1048576.0);
+      out += b4;
     }
   }
   if (S->opt.logging && logged_on_flat(S)) out = "logging = 1: the flat engine writes the SolverInfo lists; " + out;

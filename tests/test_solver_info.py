@@ -193,6 +193,33 @@ def test_gpu_solver_info_is_complete_when_mu_leaves_the_precomputed_decades(talo
         for k, name in enumerate(LISTS):
             assert_close(info[name][b, :n], r.solver_info(k), 1e-9, "%s b%d" % (name, b))
     s.close()
+    # the same through the entries that begin with Reset(false) + FwdPassInit -- Solve(q, H_ref, ...) and the
+    # tailored Solve(q, c_id, Ai, bi) of a cold-start handle, the latter as the SECOND solve of the handle (the first one left duals
+    # behind): the repeat starts from yis = Aty = 0 like the first attempt (optimized.hxx:270-278), not from the first attempt's duals
+    wl2 = workloads.talos_c3(B, seed=79)
+    for entry in ("full", "tailored"):
+        s = loik_amd.BatchedLoik(talos, B, logging=True, **prm)
+        if entry == "full":
+            s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+            cur = wl
+        else:
+            s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+            s.Solve(wl2["q"], int(wl["c_ids"][0]), wl2["Ais"][0], wl2["bis"][:, 0])
+            cur = wl2
+        info = s.solver_info()
+        assert info["truncated_instances"] == 0, entry
+        assert (np.round(np.log10(s.get("mu") / prm["mu"])) >= 2).sum() >= 5, "the sample should contain instances beyond decade 1 (%s)" % entry
+        it, tail = s.get("iter"), s.get("tail_solve_iter")
+        for b in range(0, B, 2):
+            r = ref.RefSolver(talos, **prm)
+            r.Solve(*problem_args(wl, b))
+            if entry == "tailored":
+                r.Solve(wl2["q"][b], int(wl["c_ids"][0]), wl2["Ais"][0], wl2["bis"][b, 0])
+            n = len(r.solver_info(0))
+            assert it[b] == r.get_iter() and info["rows"][b] == n == it[b] - tail[b], (entry, b, it[b], r.get_iter(), info["rows"][b], n)
+            for k, name in enumerate(LISTS):
+                assert_close(info[name][b, :n], r.solver_info(k), 1e-9, "%s %s b%d" % (entry, name, b))
+        s.close()
     # warm start: the flat engine's lists of the escaped instances end early, and the handle says so
     s = loik_amd.BatchedLoik(talos, B, logging=True, **dict(prm, warm_start=True))
     s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
