@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LOIKB_VERSION 402  /* round.minor: bumped whenever a struct or an entry point of this header changes */
+#define LOIKB_VERSION 500  /* round.minor: bumped whenever a struct or an entry point of this header changes */
 
 /* ---- status codes -------------------------------------------------------------------------------- */
 enum {
@@ -341,6 +341,9 @@ typedef struct loikb_stats {
                                              loik_amd/csrc/loik_flat2.hpp: robots of 17..32 joints, fp64)                        */
   int flat_ordered;                       /* of flat_launches: those that took their instances longest first, in the order the
                                              handle's previous solve left (LOIKB_FLAT_ORDER=0 turns that off)                   */
+  int flat_built;                         /* decade slots (W / Dinv of one instance for one mu) built by the instance's own wavefront
+                                             inside k_flat2: every change of mu under the OSQP rule, decades outside the table
+                                             with LOIKB_FLAT_BUILD=1 (round 5)                                                  */
 } loikb_stats;
 int loikb_get_stats(loikb_solver *s, loikb_stats *out);
 /* which kernels the solves of this handle use and why (the engine plan is made in one place, from (nb, nc, sharing mode of

@@ -283,6 +283,14 @@ __device__ __forceinline__ int unpack16(const unsigned int* w, int k) { return (
 // (A second build of this kernel -- two wavefronts per SIMD at 256 registers, ~100 values of the iteration in scratch, drained
 // and relaunched in this build once the queue had run dry -- was measured through round 3 and removed: slower in bulk (21 against
 // 17 ms on the headline) and no faster in the tail.  k_flat2 is what two wavefronts per SIMD take: loik_flat2.hpp.)
+// mu of decade k as k_fslots and the builders form it (ONE definition: repeated products from mu0 upwards or downwards)
+__device__ __forceinline__ double flat_decade_mu(double mu0, int k)
+{
+  double mu = mu0;
+  for (int i = 0; i < k; ++i) mu *= 10.0;
+  for (int i = 0; i > k; --i) mu *= 0.1;
+  return mu;
+}
 constexpr int FLAT_COUNTERS_DRY = 13;  // Bufs::counters[13]: set by the first lane group that finds the work queue empty
 constexpr int FLAT_COUNTERS_ERR = 16;  // Bufs::counters[16]: a wavefront gave up waiting on the work queue (never: reported as an error)
 constexpr int FLAT_COUNTERS_T0 = 14, FLAT_COUNTERS_TDRY = 15;  // the 100 MHz clock (low word) when the ring was filled / when the queue ran dry
@@ -1047,6 +1055,7 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
   T* xch = reinterpret_cast<T*>(smem_raw);        // [WAVE + 1][22] placement rows [9], then the H^w a joint passes to its parent
   T* swt = xch + (WAVE + 1) * HX;                 // [WAVE + 1][6]  S^w of every lane's joint (+ a zero row)
   T* ata_l = swt + (WAVE + 1) * 6;                // [64/G][nc][21] A^T A of the instances' constraints at the world origin
+  T* mutab = ata_l + (size_t)(WAVE / G) * P.L.nc * 21;   // [16] mu of the decades (flat_decade_mu: the ONE definition the in-wave builders share)
   T* lb = xch;                                    // [NA][WAVE] + WAVE: L columns of one decade (+ zeros) -- pass B, in the rows pass A is
                                                   // done with: 14.9 instead of 20.5 KB per wavefront, ten instead of seven per CU
   const int lane = threadIdx.x;
@@ -1132,6 +1141,7 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
   int chl[NCH_REG];
 #pragma unroll
   for (int c = 0; c < NCH_REG; ++c) chl[c] = (isj_lane && c < tp.nchild) ? gbase + child_list[tp.child_start + c] : WAVE;
+  if (lane < ndec && lane < 16) mutab[lane] = (T)flat_decade_mu((double)P.mu0, kexp_lo + lane);
   tail_sync();
   if (lane < HX) xch[WAVE * HX + lane] = T(0);
   // The decades go through the two passes in groups of `dgrp` (LOIKB_FSLOT_DGRP, default: all at once): a group's rows of pass A
@@ -1145,9 +1155,6 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
   }
   // ---- pass A
   {
-    T mu = P.mu0;
-    for (int k = 0; k < kexp_lo + d0; ++k) mu *= T(10);
-    for (int k = 0; k > kexp_lo + d0; --k) mu *= T(0.1);
     const int lag = maxdepth - depth;
     tail_sync();
     for (int st = 0; st < maxdepth + nd - 1; ++st) {
@@ -1175,6 +1182,7 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
       }
       tail_sync();  // every lane has read its children's rows: they may be overwritten
       if (on) {
+        const T mu = mutab[dsl];
         const T mu_eq = P.mu_scale * mu, mu_in = mu;
         if (cslot >= 0) {
           const T* at = ata_l + (sub * L.nc + cslot) * 21;
@@ -1196,7 +1204,6 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
 #pragma unroll
             for (int b2 = a; b2 < 6; ++b2) x[sym(a, b2)] = hh[sym(a, b2)] - UD[a] * U[b2];
         }
-        mu *= T(10);
       }
       tail_sync();
     }

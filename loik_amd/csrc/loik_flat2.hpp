@@ -365,6 +365,170 @@ __device__ __forceinline__ void flat_path_rows4(const FlatLane* fl, int j, int o
   pc = row(16) | ((unsigned int)(WAVE * 8) << 10) | ((unsigned int)(WAVE * 8) << 20);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// A decade slot of ONE instance built by the instance's own wavefront: k_fslots' two passes (loik_flat.hpp) for one value of mu, one
+// joint per lane (lanes jl < G of the wavefront; `act` says which lanes take part), the same operations in the same order -- the
+// columns are those k_fslots writes for that mu, bit for bit.  What it is for: (1) an instance whose mu leaves the decades k_fslots
+// built for the launch builds the missing slot itself and carries on (it used to go back unfinished, to be finished by k_tail at
+// 10 us per iteration: narrow tables cost more than they saved, so every launch built eight to ten decades of which an instance uses
+// two or three); (2) a rule that takes mu off the decade grid (OSQP's, declared upstream at task-solver-base.hpp:13-18 and thrown at
+// loik-loid-optimized.hxx:632-637) runs on the flat engine: every change of mu is one build (2.5 per solve on the headline batch).
+// scr: (G + 1) x FB_HX exchange rows (pass B's L columns live in them afterwards), then (G + 1) x 6 rows of S^w.
+// Math: FwdPass1 + BwdPass at the world origin, hxx:290-338, :31-81 (see k_fslots).
+constexpr int FB_HX = 22;
+template <int G> __host__ __device__ constexpr int flat_build_scratch() { return (G + 1) * FB_HX + (G + 1) * 6; }
+// hb: mass x (rho I + H_ref) of the lane's link, link frame, packed symmetric; at: A^T A of the constraint on the lane's joint (zeros
+// where there is none) -- the caller reads them where k_fslots does (Params / the links' table; the constraint record or the batch's
+// shared block): the builder itself touches neither the kernel's argument block nor the instance's records.
+template <int NA, int G>
+__device__ __forceinline__ void flat_build_slot(double* scr, int lane, bool act, int jl, int nb, const JointDesc* __restrict__ jd,
+                                                const TailTopo* __restrict__ topo, const int* __restrict__ child_list,
+                                                const FlatLane* __restrict__ fl, int maxdepth, const double* R0, const double* t0,
+                                                const double* Sw, const double* hb, const double* at, double mu, double mu_scale,
+                                                double* Wc, double& dinv_out, double* bcache = nullptr, bool cached = false)
+{
+  // bcache: [G][21] the joints' base terms at the world origin, then [nc][21] the constraints' A^T A there -- neither depends on mu: an
+  // instance that builds more than once (OSQP's rule: 2.5 times per solve) carries them to the origin once (cached: they are there)
+  using T = double;
+  T* xch = scr;                         // [G + 1][FB_HX]
+  T* swt = scr + (G + 1) * FB_HX;       // [G + 1][6]
+  T* lb = scr;                          // [NA][G] + G: pass B
+  const bool isj = act && jl < nb;
+  const int jq = isj ? jl : 0;
+  const JointDesc d = jd[jq + 1];
+  const FlatLane F = fl[jq];
+  const TailTopo tp = topo[jq + 1];
+  const int depth = isj ? F.depth : 0;
+  const bool has_parent = !(d.flags & JF_PARENT_ROOT);
+  const int cslot = isj ? d.cslot : -1;
+  int arow[NA];
+#pragma unroll
+  for (int k = 0; k < NA; ++k) arow[k] = (isj && k < FLAT_MAXA && F.anc[k] >= 0) ? F.anc[k] : G;
+  constexpr int NCH_REG = 3;
+  int chl[NCH_REG];
+#pragma unroll
+  for (int c = 0; c < NCH_REG; ++c) chl[c] = (isj && c < tp.nchild) ? child_list[tp.child_start + c] : G;
+  T base0[21], atw[21];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) atw[k] = T(0);
+  if (bcache != nullptr && cached) {
+    if (act) {
+#pragma unroll
+      for (int k = 0; k < 21; ++k) base0[k] = bcache[jl * 21 + k];
+    }
+    if (cslot >= 0) {
+#pragma unroll
+      for (int k = 0; k < 21; ++k) atw[k] = bcache[(G + cslot) * 21 + k];
+    }
+  } else {
+    congr_sym(R0, t0, hb, base0);
+    if (cslot >= 0) congr_sym(R0, t0, at, atw);
+    if (bcache != nullptr) {
+      if (act) {
+#pragma unroll
+        for (int k = 0; k < 21; ++k) bcache[jl * 21 + k] = base0[k];
+      }
+      if (cslot >= 0) {
+#pragma unroll
+        for (int k = 0; k < 21; ++k) bcache[(G + cslot) * 21 + k] = atw[k];
+      }
+    }
+  }
+  tail_sync();
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) swt[jl * 6 + k] = Sw[k];
+  }
+  if (lane < 6) swt[G * 6 + lane] = T(0);
+  if (lane < FB_HX) xch[G * FB_HX + lane] = T(0);
+  // ---- pass A: leaves first, one tree level per step
+  T UD[6], dinv = T(0);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) UD[k] = T(0);
+  const int lag = maxdepth - depth;
+  tail_sync();
+  for (int st = 0; st < maxdepth; ++st) {
+    const bool on = isj && depth > 0 && st == lag;
+    T hh[21];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) hh[k] = base0[k];
+    const bool any2 = __any(on && tp.nchild > 1), any3 = __any(on && tp.nchild > 2);
+    if (on) {
+#pragma unroll
+      for (int c = 0; c < NCH_REG; ++c) {
+        if ((c == 1 && !any2) || (c == 2 && !any3)) continue;
+        const T* x = xch + chl[c] * FB_HX;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) hh[k] += x[k];
+      }
+      for (int c = NCH_REG; c < tp.nchild; ++c) {
+        const T* x = xch + child_list[tp.child_start + c] * FB_HX;
+#pragma unroll
+        for (int k = 0; k < 21; ++k) hh[k] += x[k];
+      }
+    }
+    tail_sync();
+    if (on) {
+      const T mu_eq = mu_scale * mu, mu_in = mu;
+      if (cslot >= 0) {
+#pragma unroll
+        for (int k = 0; k < 21; ++k) hh[k] += mu_eq * atw[k];
+      }
+      T U[6];
+      symv(hh, Sw, U);
+      dinv = T(1) / (dot6_halves(Sw, U) + mu_in);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) UD[k] = U[k] * dinv;
+      if (has_parent) {
+        T* x = xch + jl * FB_HX;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b2 = a; b2 < 6; ++b2) x[sym(a, b2)] = hh[sym(a, b2)] - UD[a] * U[b2];
+      }
+    }
+    tail_sync();
+  }
+  // ---- pass B: the joint's column of the unit-triangular factor's inverse
+  for (int e = lane; e < G; e += WAVE) lb[NA * G + e] = T(0);
+  T Lc[NA];
+#pragma unroll
+  for (int k = 0; k < NA; ++k) {
+    Lc[k] = dot6_halves(swt + arow[k] * 6, UD);
+    Wc[k] = T(0);
+  }
+  tail_sync();
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < NA; ++k) lb[k * G + jl] = Lc[k];
+  }
+  tail_sync();
+#pragma unroll
+  for (int k = NA - 1; k >= 0; --k) {
+    T acc = Lc[k];
+#pragma unroll
+    for (int k2 = k + 1; k2 < NA; ++k2) acc += lb[k * G + arow[k2]] * Wc[k2];
+    Wc[k] = (k < depth - 1) ? -acc : T(0);
+  }
+  dinv_out = dinv;
+  tail_sync();
+}
+
+// The call the iteration kernels make: NOT inlined -- the builder's two hundred live values must not take part in the register
+// allocation of the iteration loop (inlined, the loop of k_flat2 picked up three scratch reloads and two scalar loads per iteration) --
+// and with the lane's inputs and outputs BY VALUE (an array handed over by pointer would live in scratch for the whole kernel).
+struct FlatBuildIn { double R0[9], t0[3], Sw[6], hb[21], at[21], mu, mu_scale; };
+template <int NA> struct FlatBuildOut { double Wc[NA], dinv; };
+template <int NA, int G>
+__device__ __noinline__ FlatBuildOut<NA> flat_build_slot_call(double* scr, int lane, bool act, int jl, int nb, const JointDesc* __restrict__ jd,
+                                                              const TailTopo* __restrict__ topo, const int* __restrict__ child_list,
+                                                              const FlatLane* __restrict__ fl, int maxdepth, const FlatBuildIn in)
+{
+  FlatBuildOut<NA> o;
+  flat_build_slot<NA, G>(scr, lane, act, jl, nb, jd, topo, child_list, fl, maxdepth, in.R0, in.t0, in.Sw, in.hb, in.at, in.mu, in.mu_scale, o.Wc, o.dinv);
+  return o;
+}
+
 // LDS of one wavefront of k_flat2<NA> (doubles): one instance
 template <int NA>
 __host__ __device__ constexpr int flat2_xregion()
@@ -395,9 +559,10 @@ template <int NA> __host__ __device__ constexpr int flat2_off_tail() { return fl
 static_assert(flat2_xloop<10>() + 2 * 11 * F2W >= flat2_xregion<10>(), "the load-time rows must end inside the decade slots");
 
 template <int NA>
-__host__ __device__ __forceinline__ size_t flat2_lds_bytes(int nc, bool has_hv)
+__host__ __device__ __forceinline__ size_t flat2_lds_bytes(int nc, bool has_hv, bool build_cache = false)
 {
-  const size_t n = (size_t)flat2_off_tail<NA>() + (has_hv ? (size_t)F2G * 6 : 0) + (size_t)nc * C2D + FISC + 36 + C2D;   // (+ the null block)
+  // (+ the null block; build_cache: the in-wave builder's mu-independent terms, [32 + nc][21] -- the OSQP build)
+  const size_t n = (size_t)flat2_off_tail<NA>() + (has_hv ? (size_t)F2G * 6 : 0) + (size_t)nc * C2D + FISC + 36 + C2D + (build_cache ? (size_t)(F2G + nc) * 21 : 0);
   return (n * sizeof(double) + 15) & ~(size_t)15;
 }
 
@@ -424,12 +589,22 @@ __device__ __forceinline__ X held(X x)
 // per iteration.
 // LOG: the lists of LoikSolverInfo (loik-loid-optimized.hpp:47-127, filled at hpp:406-420), as k_flat<.., LOG> writes them: every
 // iteration of the main loop folds the four scalars the lists need and stores its row -- no quiet iterations in this build.
-template <int NA, int WPE, bool SLICED = false, int HM = 0, bool LOG = false>
+// MUR: the rule that moves mu.  0: decade steps (DEFAULT / MAXEIGENVALUE, hxx:613-641), the decades' slots from k_fslots' table; an instance
+// whose mu leaves the table goes back unfinished (k_tail finishes it).  2: the same rule, and a decade the table does not hold is built
+// by the wavefront itself (flat_build_slot) -- a build of its own because the builder's presence costs the iteration loop a few scratch
+// reloads (LOIKB_FLAT_BUILD=1 selects it).  1: OSQP's rule (update_mu, loik_device.hpp): mu is any number, there is no table, every change
+// of mu is one in-wave build; every iteration folds the two norms the rule needs and walks the whole stopping logic (no quiet shortcut).
+constexpr int FLAT_COUNTERS_BUILT = 17;  // Bufs::counters[17]: decade slots built in-wave during the launch
+constexpr int FLAT_COUNTERS_DEC = 32;    // Bufs::counters[32 .. 63]: slots taken up (loaded or built) per decade kexp + 16
+template <int NA, int WPE, bool SLICED = false, int HM = 0, bool LOG = false, int MUR = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
         int nscan, int njmp, int* ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
-        int ndec, double href_s, int has_hv, int ring_mask, int quantum, double* __restrict__ park, int park_stride)
+        int ndec, double href_s, int has_hv, int ring_mask, int quantum, double* __restrict__ park, int park_stride,
+        const TailTopo* __restrict__ topo, const int* __restrict__ child_list, int maxdepth)
 {
+  constexpr bool BUILD = MUR >= 1;
+  static_assert(flat_build_scratch<F2G>() <= flat2_off_nbuf<NA>(), "the in-wave builder's rows must end before the buffers the iteration keeps");
   using T = double;
   static_assert(NA % 2 == 0, "the W entries of a joint are dealt out to its two lanes");
   constexpr int G = F2G, GW = F2W, cs = C2D, NH = NA / 2;
@@ -443,14 +618,14 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   //  ones shorter, so that the instances still running when the queue is empty have done the same number of iterations to within that)
   const int slice_len = (SLICED && quantum > 0) ? (quantum & 0xffff) : 0x3fffffff;
   const int slice_len2 = (SLICED && (quantum >> 16) > 0) ? (quantum >> 16) : slice_len;
-  const double tol_abs_h = held<SLICED || WPE >= 3>(P.tol_abs), tpi_h = held<SLICED || WPE >= 3>(P.tol_primal_inf);
-  const int max_iter_h = held<SLICED || WPE >= 3>(P.max_iter);
+  const double tol_abs_h = held<SLICED || WPE >= 3 || MUR >= 1>(P.tol_abs), tpi_h = held<SLICED || WPE >= 3 || MUR >= 1>(P.tol_primal_inf);
+  const int max_iter_h = held<SLICED || WPE >= 3 || MUR >= 1>(P.max_iter);
   const int j = lane & 31;       // lanes j and 32 + j <-> device joint j + 1
   const bool h = lane >= 32;     // 0: linear halves, 1: angular halves
   const int h3 = h ? 3 : 0;
   // Three wavefronts per SIMD leave a lane 168 registers: what an iteration touches once -- the joint's box, last iteration's
   // S^T f + w -- then lives in LDS (one row of three per joint; both lanes of a joint read the same address).
-  constexpr bool JCL = WPE >= 3;
+  constexpr bool JCL = WPE >= 3 || MUR >= 1;   // (the builds with the in-wave builder: the loop has no register to spare for it)
   // ---- LDS of the wavefront
   T* const xb = reinterpret_cast<T*>(smem_raw);   // load-time rows | path rows [65][3] | W tau products [NA][32]
   T* const wl = xb + flat2_off_wl<NA>();          // [2][NA + 1][32]  W rows and the Dinv row of two decades of mu
@@ -476,6 +651,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   T* const hmat = isc + FISC;  // [36] H_ref (HM = 2)
   if (HM == 2 && lane < 36) hmat[lane] = P.Href[lane];
   for (int e = lane; e < cs; e += WAVE) hmat[36 + e] = T(0);   // the null constraint block
+  T* const bcache = MUR == 1 ? hmat + 36 + cs : nullptr;   // [32 + nc][21]: flat_build_slot's terms that do not depend on mu (one instance)
+  bool bc_valid = false;
   const T* const hrow = HM == 3 ? P.href_tab + (size_t)(jl + 1) * HREF_ROW : nullptr;  // (H_ref_i, H_ref_i v_ref_i) of this link
   auto hvl3_of = [&](int k) -> T { return HM == 3 ? hrow[36 + h3 + k] : (h ? P.Hv[3 + k] : P.Hv[k]); };  // this half of H_ref v_ref of the link
   int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
@@ -553,6 +730,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     return ((A_[0] * y[0] + A_[6] * y[1]) + A_[12] * y[2]) + ((A_[18] * y[3] + A_[24] * y[4]) + A_[30] * y[5]);
   };
   bool resumed = false;  // (SLICED) the instance came back from the queue: no first-iteration corrections
+  T bnorm_r = T(0);      // (MUR = 1) max |b| of the instance's constraints (bis_inf_norm_): OSQP's rule normalises the primal residual with it
   auto half = [&](const T* x6, T* x3) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) x3[k] = h ? x6[3 + k] : x6[k];
@@ -696,6 +874,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     }
     tail_sync();
     mu = xb[0];
+    if constexpr (MUR == 1) bnorm_r = isc[FI_BNORM];
     kexp = __builtin_amdgcn_readfirstlane((int)xb[1]);
     iter = __builtin_amdgcn_readfirstlane((int)xb[2]);
     status = __builtin_amdgcn_readfirstlane((int)xb[3]);
@@ -719,6 +898,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     }
     tail_sync();
     done = false;
+    bc_valid = false;
     resumed = true;   // (no first-iteration corrections: it has iterated)
     my_iters = 0;
     any_iter = true;
@@ -733,6 +913,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     TAIL_TP(12)
     if (SLICED && (slot_in & FLAT_PARKED)) { unpark(slot_in); return; }
     resumed = false;
+    bc_valid = false;
     isj = isj_lane;
     const int slot = slot_in;
     lidx = slot;
@@ -937,6 +1118,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       n_slot_loads = (n_slot_loads + 0x10000u) | (1u << dsl0);
     }
     status = (int)st2.x;
+    if constexpr (MUR == 1) bnorm_r = bi2.x;
     iter = (int)bi2.y;
     tail_it = (int)tail_iter0;
     nflip = (int)flip2.x;
@@ -1023,19 +1205,30 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 
   // (two loops: everything only the load / store of an instance needs lives across the inner loop without being touched in it,
   //  so the register allocator can park it around the loop instead of in it)
+  // (The in-wave build of a decade slot -- two hundred live values, LDS rows over both decade slots -- must not take part in the register
+  //  allocation of the iteration loop: inlined there, the loop picked up three scratch reloads and two scalar loads per iteration; as a
+  //  call it made the allocator spill around the call site through the whole loop.  The iteration loop therefore only ASKS for the
+  //  build and leaves; the build runs out here, beside the load and the store of an instance, and the loop is entered again with the
+  //  instance it had.)
+  bool need_build = false;
+  T inv_mu = T(1);
+  int q_lim_run = 0, slice_end = 0x7fffffff, q_lim = 0;
   while (true) {
+    if (!need_build) {
     load_instance();
     if (!has_inst) break;  // the queue is empty (SLICED: and every instance has retired): this wavefront is done
-    T inv_mu = T(1) / mu;  // (a division per change of mu, not per iteration: BoxProj's 1 / mu_ineq, hxx:384-397)
+    inv_mu = T(1) / mu;  // (a division per change of mu, not per iteration: BoxProj's 1 / mu_ineq, hxx:384-397)
     requeue = false;
     // the last value of iter from which a quiet iteration may go straight into the next one (see quiet_f32): not the last but one of
     // max_iter, and this launch's share of iterations not used up (my_iters = iter - iter at load + 1 inside an iteration)
-    const int q_lim_run = quiet_limit(P.max_iter, P.max_launch_iters, iter);
+    q_lim_run = quiet_limit(P.max_iter, P.max_launch_iters, iter);
     // SLICED: a time slice ends at iteration slice_end, and it ends THROUGH THE SAME COMPARE -- the iteration itself has no code for
     // the slices (a counter and its compare against the kernel argument in the loop cost the SLICED build 6 % of every iteration:
     // the compiler fetched the argument with s_load + s_waitcnt each time)
-    int slice_end = SLICED ? iter + (iter >= slice_len ? slice_len2 : slice_len) : 0x7fffffff;
-    int q_lim = (SLICED && slice_end - 1 < q_lim_run) ? slice_end - 1 : q_lim_run;
+    slice_end = SLICED ? iter + (iter >= slice_len ? slice_len2 : slice_len) : 0x7fffffff;
+    q_lim = (SLICED && slice_end - 1 < q_lim_run) ? slice_end - 1 : q_lim_run;
+    }
+    need_build = false;
    while (true) {
     if (SLICED && !done && iter >= slice_end) {
       // time slice used up: if others wait, to the back of the queue (one round trip to the queue's counters per slice: ~2 us in
@@ -1054,16 +1247,23 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     bool exit_now = done || (int)my_iters >= P.max_launch_iters;
     // ---- decade of mu: W rows and Dinv.  Two decades stay in LDS: a flip back to the previous one costs nothing.
     if (!exit_now && kexp != kslot) {
-      if (kexp == kslot_o) {
+      // (MUR = 1: the one slot the table holds is mu0's -- every instance starts there, and a solve that starts from a cold reset does its
+      //  first iterations on it: a quarter of the rule's builds saved)
+      const int dsl = MUR == 1 ? 0 : kexp - kexp_lo;
+      const bool in_table = MUR == 1 ? (ndec > 0 && __builtin_amdgcn_readfirstlane((int)(mu == P.mu0)) != 0) : (dsl >= 0 && dsl < ndec);
+      if (MUR != 1 && kexp == kslot_o) {
         { const int tk = kslot; kslot = kslot_o; kslot_o = tk; }
         wsel ^= 1;
         ++n_slot_hits;
+      } else if (!in_table && !BUILD) {
+        exit_now = true;  // mu left the precomputed decades: written back unfinished, k_tail takes over
+        if (lane == 0) atomicAdd(&Bf.counters[2], 1u);
+      } else if (__builtin_expect(!in_table, 0)) {
+        need_build = true;   // (the wavefront builds the slot itself -- OUTSIDE this loop: see the loop around it)
+        break;
       } else {
-        const int dsl = kexp - kexp_lo;
-        if (dsl < 0 || dsl >= ndec) {
-          exit_now = true;  // mu left the precomputed decades: written back unfinished, k_tail takes over
-          if (lane == 0) atomicAdd(&Bf.counters[2], 1u);
-        } else {
+        {
+          if (MUR == 2 && lane == 0) atomicAdd(&Bf.counters[FLAT_COUNTERS_DEC + (kexp < -16 ? 0 : kexp > 15 ? 31 : kexp + 16)], 1u);
           kslot_o = kslot;  // the slot that was not used last is overwritten
           wsel ^= 1;
           T* wdst = wl + (size_t)wsel * (NA + 1) * GW;
@@ -1388,13 +1588,15 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     if (lane == 0 && in_tail) atomicAdd(&g_tail_prof_all[27], 1ull);
 #endif
     T primal = T(0), dual = T(0), dyqp = T(0), atdy = T(0), dx = T(0), dz = T(0), ubp = T(0), lbm = T(0);
+    T ntol_p = T(0), ntol_d = T(0);
+    bool have_norms = false;
     if (logic) {
       T in[4] = {hmaxa(s_ek, s_prs), hmax_a(l_dualv, s_stf), hmax_a(hmax_a(l_dfis, s_dy), s_dw), hmax_a(l_dg, s_dstf)}, r[4];
 #ifdef LOIKB_DBG_QUIET
       if (lane == 0) atomicAdd(&g_tail_prof_all[24], 1ull);
       if (quiet_f32(in, qth, iter, q_lim) && lane == 0) atomicAdd(&g_tail_prof_all[25], 1ull);
 #endif
-      if (LOIKB_QUIET32 && !LOG && quiet_f32(in, qth, iter, q_lim)) {   // (the quick look: see quiet_f32)
+      if (LOIKB_QUIET32 && !LOG && MUR != 1 && quiet_f32(in, qth, iter, q_lim)) {   // (the quick look: see quiet_f32)
         ++iter;
         TAIL_TP(7)
         if (iter > q_lim) continue;   // (SLICED: the slice ends -- through the loop's top)
@@ -1411,8 +1613,23 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         // The common iteration decides nothing: not converged, the certificate's first test fails, mu stays where it is, not the
         // last iteration.  Five compares side by side and ONE branch; the stopping logic below is a chain of ~30 dependent
         // compare -> mask -> branch steps (900 cycles of a lone wavefront's 5400 per iteration) that only the other iterations walk.
-        const bool quiet = !((primal < tol_abs_h) & (dual < tol_abs_h)) & !((iter > 0) & (atdy <= tpi_h * dyqp)) &
-                           !(primal > T(10) * dual) & !(dual > T(10) * primal) & (iter + 2 < max_iter_h);
+        bool mu_stays;
+        if constexpr (MUR == 1) {
+          // OSQP's rule leaves mu alone while mu sqrt(x) stays within [0.2, 5] mu, x = r_p / (r_d + eps) the ratio of the normalised
+          // residuals (update_mu): x in [0.04, 25].  Here WITHOUT its three divisions and the root: x = p (n_d + eps) / ((n_p + eps)
+          // (d + eps (n_d + eps))), so x in (0.05, 24) is two products compared -- margins of 4 % where rounding moves 1e-16; an
+          // iteration outside that band, or with mu outside the rule's clip range, walks the logic below, which evaluates the rule itself.
+          T in2[4] = {hmaxa(s_av, nu), hmax_a(hmax(l_hrefv_now(), hinf3(g3)), s_stf), T(0), T(0)}, r2[4];
+          wave_fold4<0u>(lane, in2, r2);
+          ntol_p = r2[0]; ntol_d = r2[1];
+          have_norms = true;
+          const T e_ = T(1e-10), np_ = tmax(ntol_p, bnorm_r) + e_, nd_ = tmax(ntol_d, P.Hv_inf_norm) + e_;
+          const T A_ = primal * nd_, B_ = np_ * (dual + e_ * nd_);
+          mu_stays = (A_ < T(24) * B_) & (A_ > T(0.05) * B_) & (mu >= T(1e-6)) & (mu <= T(1e6));
+        } else {
+          mu_stays = !(primal > T(10) * dual) & !(dual > T(10) * primal);
+        }
+        const bool quiet = !((primal < tol_abs_h) & (dual < tol_abs_h)) & !((iter > 0) & (atdy <= tpi_h * dyqp)) & mu_stays & (iter + 2 < max_iter_h);
         if (quiet) {
           ++iter;
           TAIL_TP(7)
@@ -1421,8 +1638,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         }
       }
     }
-    T ntol_p = T(0), ntol_d = T(0);
-    if (P.tol_rel != T(0)) {  // (uniform) relative tolerances need two more maxima
+    if ((MUR == 1 ? logic : P.tol_rel != T(0)) && !have_norms) {  // (uniform) relative tolerances -- and OSQP's rule -- need two more maxima
       T in2[4] = {hmaxa(s_av, nu), hmax_a(hmax(l_hrefv_now(), hinf3(g3)), s_stf), T(0), T(0)}, r2[4];
       wave_fold4<0u>(lane, in2, r2);
       ntol_p = r2[0]; ntol_d = r2[1];
@@ -1462,7 +1678,20 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const bool infeas = feas_chk && c1 && c2;
     const bool enter_tail = infeas && !conv;
     const bool upd = logic && !conv && !infeas;
-    const bool mu_up = upd && (primal > T(10) * dual), mu_dn = upd && !mu_up && (dual > T(10) * primal);
+    bool mu_up = upd && (primal > T(10) * dual), mu_dn = upd && !mu_up && (dual > T(10) * primal);
+    if constexpr (MUR == 1) {   // OSQP's rule (update_mu): the normalisers are CheckConvergence's (hxx:544-552), as in k_tail / k_solve
+      mu_up = mu_dn = false;
+      if (upd) {
+        T m2 = mu;
+        int kk = kexp;
+        if (update_mu<T>(MODE_MU_OSQP, primal, dual, tmax(ntol_p, isc[FI_BNORM]), tmax(ntol_d, P.Hv_inf_norm), m2, kk)) {
+          mu = m2;
+          inv_mu = T(1) / mu;
+          ++nflip;
+          kslot = -(1 << 30);   // (the factors are those of the old mu: the next iteration starts with a build)
+        }
+      }
+    }
     const bool tail_stop = !(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || itn >= P.max_iter;  // (looked at with have_b only)
     const bool stop = conv || ((enter_tail || in_tail) && tail_stop) || ((upd || fixed) && itn + 1 >= P.max_iter);
     iter = itn;
@@ -1506,6 +1735,49 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     }
     TAIL_TP(7)
    }
+    if (__builtin_expect(need_build, 0)) {   // (cold: the allocator's spills belong here, not in the iteration loop)
+    if constexpr (BUILD) {
+      // the decade's own mu for the decade rule -- the columns k_fslots would have written --, the instance's mu for a rule off the
+      // grid.  The builder's rows lie over BOTH slots in LDS: the other one is gone.
+      T Sw6[6], hb[21], at[21], Wc[NA], dv;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) both_halves(Sw3[k], Sw6[k], Sw6[3 + k]);
+#pragma unroll
+      for (int k = 0; k < 21; ++k) { hb[k] = T(0); at[k] = T(0); }
+      if (!bc_valid) {
+#pragma unroll
+      for (int a_ = 0; a_ < 6; ++a_)   // (k_fslots' base term, read where it reads it)
+#pragma unroll
+        for (int b2 = a_; b2 < 6; ++b2)
+          hb[sym(a_, b2)] = mass * ((a_ == b2 ? P.rho : T(0)) + (P.href_tab ? P.href_tab[(size_t)(jl + 1) * HREF_ROW + 6 * a_ + b2] : P.Href[6 * a_ + b2]));
+      }
+      if (!bc_valid && jcslot >= 0) {
+        const char* crec = ip + (size_t)(L.off_c + jcslot * L.crec) * pair_bytes<T>();
+        for (int k = 0; k < 21; ++k)
+          at[k] = a_shared ? Bf.uni[L.nc * 36 + jcslot * 21 + k]
+                           : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+      }
+      flat_build_slot<NA, G>(xb, lane, !h, j, L.nb, jd, topo, child_list, fl, maxdepth, R0, t0, Sw6, hb, at,
+                             MUR == 1 ? mu : flat_decade_mu(P.mu0, kexp), P.mu_scale, Wc, dv, bcache, bc_valid);
+      bc_valid = bcache != nullptr;
+      wsel ^= 1;
+      T* wdst = wl + (size_t)wsel * (NA + 1) * GW;
+      if (!h) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) wdst[k * GW + j] = Wc[k];
+        wdst[NA * GW + j] = dv;
+      }
+      kslot_o = -(1 << 30);
+      kslot = kexp;
+      if (lane == 0) {
+        atomicAdd(&Bf.counters[FLAT_COUNTERS_BUILT], 1u);
+        if (MUR != 1) atomicAdd(&Bf.counters[FLAT_COUNTERS_DEC + (kexp < -16 ? 0 : kexp > 15 ? 31 : kexp + 16)], 1u);
+      }
+      tail_sync();
+      TAIL_TP(17)
+    }
+      continue;   // (back into the iteration loop with the instance the wavefront has)
+    }
     if (SLICED && requeue) {
       // The switch in three round trips (the first version took ten, ~58 us of a wavefront under load): (1) the park stores and,
       // with them, the ticket for the NEXT entry; (2) once the stores have landed: this instance's place at the tail, and the entry

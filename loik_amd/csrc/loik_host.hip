@@ -60,6 +60,7 @@ struct Tuning {
   bool flat = true;             // LOIKB_FLAT=0        never use k_flat (the engine without level loops, loik_flat.hpp)
   bool flat_split = true;       // LOIKB_FLAT_SPLIT=0: k_flat (one joint per lane) also where k_flat2 (two lanes per joint) applies
   int flat_split_wpe = 2;       // LOIKB_FLAT_WPE=3: k_flat2 built for three wavefronts per SIMD
+  int flat_build = 0;           // LOIKB_FLAT_BUILD=1: k_flat2 builds a decade slot its table lacks in-wave (flat_build_slot) instead of handing the instance to k_tail
   int fslot_dgrp = 0;           // LOIKB_FSLOT_DGRP=g: k_fslots takes the decades through its two passes g at a time (default: all)
   int flat_slice2 = 0;          // LOIKB_FLAT_SLICE2=q: an instance's later slices (0: as the first)
   int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's / k_flat1's round-robin time slice in iterations (0: never; default: 288 for
@@ -93,6 +94,7 @@ struct Tuning {
     if (!lean) flat = false;  // (LOIKB_LEAN=0 asks for the engines without precomputed factors: k_solve / k_tail)
     if (const char* e = getenv("LOIKB_FLAT_SPLIT")) flat_split = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_WPE")) flat_split_wpe = atoi(e) == 3 ? 3 : 2;
+    if (const char* e = getenv("LOIKB_FLAT_BUILD")) flat_build = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_SLICE")) flat_slice = std::min(65535, std::max(-1, atoi(e)));
     if (const char* e = getenv("LOIKB_FLAT_SLICE2")) flat_slice2 = std::min(32767, std::max(0, atoi(e)));
     if (const char* e = getenv("LOIKB_FSLOT_DGRP")) fslot_dgrp = std::max(0, atoi(e));
@@ -1138,8 +1140,19 @@ bool flat_takes_diagonal(const loikb_solver_impl* S)
   if (!S->tune.flat_split || S->f32 || !S->flat.ok) return false;   // (round 4: logging handles too -- the LOG builds)
   return (S->flat.G == F2G && S->flat.nanc <= FLAT_NA_SMALL) || S->flat.G == WAVE;
 }
+// OSQP's rule takes mu off the decade grid: no table of slots; k_flat2 builds the factors in-wave at every change of mu
+// (k_flat2<.., MUR = 1>: robots of 17..32 joints, fp64, no SolverInfo lists)
+bool flat_any_mu(const loikb_solver_impl* S)
+{
+  return S->opt.mu_update_strat == LOIKB_MU_OSQP;
+}
+bool flat_any_mu_ok(const loikb_solver_impl* S)
+{
+  return S->tune.flat_split && !S->f32 && S->flat.ok && S->flat.G == F2G && S->flat.nanc <= FLAT_NA_SMALL && !S->opt.logging;
+}
 bool flat_applicable(const loikb_solver_impl* S)
 {
+  if (flat_any_mu(S) && !flat_any_mu_ok(S)) return false;
   // (k_flat2 / k_flat1 take any reference cost: shared or per link; k_flat h I only)
   return S->plan.flat && (flat_takes_diagonal(S) || (!S->per_link && href_is_scalar(S)));
 }
@@ -1170,7 +1183,7 @@ int ensure_hslots(loikb_solver_impl* S)
     // decade slots of the flat engine: (ancestors + 1) scalars per lane, decade and instance
     for (Chunk& C : S->chunks) {
       const int frows = S->flat.fblk;  // (scalars per decade slot)
-      const size_t need = (size_t)C.B * S->plan.ndec * frows * S->esz;
+      const size_t need = (size_t)C.B * (flat_any_mu(S) ? 1 : S->plan.ndec) * frows * S->esz;   // (OSQP: mu0's slot only)
       if (need <= C.fslots_bytes) continue;
       if (C.d_fslots) HIPCHK(hipFree(C.d_fslots));
       C.d_fslots = nullptr; C.fslots_bytes = 0;
@@ -1628,7 +1641,8 @@ void plan_engines(loikb_solver_impl* S)
   else if (!S->flat.ok) pl.why_not_flat = S->flat.why;
   else if (S->f32) pl.why_not_flat = "fp32 solver";
   else if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) pl.why_not_flat = "LOIKB_OPT_NO_H_CACHE (no precomputed factors)";
-  else if (S->opt.mu_update_strat == LOIKB_MU_OSQP) pl.why_not_flat = "OSQP penalty rule: mu is off the decade grid";
+  else if (flat_any_mu(S) && !flat_any_mu_ok(S))
+    pl.why_not_flat = "OSQP penalty rule: mu is off the decade grid, and the in-wave builder is k_flat2's (17..32 joints, fp64, no logging)";
   else if (S->nb <= 16) pl.why_not_flat = "a small robot (<= 16 joints): k_solve + k_tail are faster on its short solves";
   // (the flat engines update the task constraints on lanes 6 c + k of an instance's lanes, in one pass: ten constraints with a
   //  wavefront per instance, five with two instances per wavefront; more go to the engines that loop over them)
@@ -1722,6 +1736,10 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       const int nanc = S->flat.nanc;
       const bool small_na = nanc <= FLAT_NA_SMALL;
       const int frows = S->flat.fblk;  // (scalars per decade slot of an instance, packed columns: loik_flat.hpp)
+      // the rule that moves mu (k_flat2's MUR): 1 = OSQP's -- no table, every change of mu is an in-wave build --, 2 = decade steps with
+      // the in-wave builder for the decades the table lacks (LOIKB_FLAT_BUILD=1), 0 = decade steps, the table or k_tail
+      const int mur = flat_any_mu(S) ? 1 : (S->tune.flat_build ? 2 : 0);
+      if (mur == 1) { ndec = 1; kexp_lo = 0; }   // (the table holds mu0's slot: where every cold solve starts)
       const size_t need = (size_t)n_cur * ndec * frows * sizeof(T);
       if (need > C->fslots_bytes) { g_last_error = "internal: decade-slot buffer of the flat engine smaller than the chunk"; return LOIKB_ERR_STATE; }
       const int has_hv = S->Hv_inf_norm != 0.0;
@@ -1746,11 +1764,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       if (C->order_holdoff > 0) --C->order_holdoff;
       if (ordered) HIPCHK(hipMemcpyAsync(C->d_slots, C->d_order, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, C->stream));
       C->stats.flat_ordered += ordered ? 1 : 0;
-      {
+      if (ndec > 0) {
         const dim3 hgrid((unsigned)((n + ipw - 1) / ipw));
-        // [65][22] exchange rows (pass B's L columns, [NA + 1][64], live in them afterwards) + [65][6] S^w + the constraints' A^T A
+        // [65][22] exchange rows (pass B's L columns, [NA + 1][64], live in them afterwards) + [65][6] S^w + the constraints' A^T A + the decades' mu
         const size_t slds = (std::max((size_t)(WAVE + 1) * 22, (size_t)((small_na ? FLAT_NA_SMALL : FLAT_MAXA) + 1) * WAVE) + (size_t)(WAVE + 1) * 6 +
-                             (size_t)ipw * S->nc * 21) * sizeof(T);
+                             (size_t)ipw * S->nc * 21 + 16) * sizeof(T);
         if (small_na)
           hipLaunchKernelGGL((k_fslots<T, FLAT_NA_SMALL>), hgrid, dim3(WAVE), slds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                              (const TailTopo*)S->d_topo, (const int*)S->d_child_list, (const FlatLane*)S->flat.d_lanes, S->maxdepth,
@@ -1760,15 +1778,15 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                              (const TailTopo*)S->d_topo, (const int*)S->d_child_list, (const FlatLane*)S->flat.d_lanes, S->maxdepth,
                              nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, kexp_lo, ndec, S->tune.fslot_dgrp > 0 ? S->tune.fslot_dgrp : ndec);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(C->ev_k2, C->stream));
       }
+      HIPCHK(hipEventRecord(C->ev_k2, C->stream));
       const int n_first = n;
       dim3 grid((unsigned)std::min((n + ipw - 1) / ipw, cap_lat));
       {
         hipLaunchKernelGGL(k_ring_fill, grid1(C->ring_cap), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, list, n, C->d_counters);
         if (split) {
           // k_flat2: two lanes per joint, one instance per wavefront, two or three wavefronts per SIMD (loik_flat2.hpp)
-          const size_t lds2 = flat2_lds_bytes<FLAT_NA_SMALL>(S->nc, has_hv != 0);
+          const size_t lds2 = flat2_lds_bytes<FLAT_NA_SMALL>(S->nc, has_hv != 0, mur == 1);
           const int wpe = S->tune.flat_split_wpe;
           int per_cu = (int)std::min<size_t>((size_t)4 * wpe, (160 * 1024) / lds2);
           if (S->tune.lean_wg_per_cu > 0) per_cu = std::min(per_cu, S->tune.lean_wg_per_cu);
@@ -1806,9 +1824,20 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
                      (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
                      (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv, C->ring_cap - 1, quantum,       \
-                     (double*)C->d_park, flat2_park_stride(S->nc, true))
+                     (double*)C->d_park, flat2_park_stride(S->nc, true), (const TailTopo*)S->d_topo, (const int*)S->d_child_list,   \
+                     S->maxdepth)
           const int hm = S->per_link ? 3 : href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
-          if (S->opt.logging) {   // (the SolverInfo lists: unsliced; a diagonal reference weight goes as a general one)
+          if (mur == 1) {   // (OSQP's rule: sliced only with H_ref = h I)
+            if (hm == 3) { quantum = 0; LOIKB_LAUNCH_FLAT2(2, false, 3, false, 1); }
+            else if (hm == 2) { quantum = 0; LOIKB_LAUNCH_FLAT2(2, false, 2, false, 1); }
+            else if (hm == 1) { quantum = 0; LOIKB_LAUNCH_FLAT2(2, false, 1, false, 1); }
+            else if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 0, false, 1);
+            else LOIKB_LAUNCH_FLAT2(2, false, 0, false, 1);
+          }
+          else if (mur == 2 && hm == 0 && !S->opt.logging) {
+            if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 0, false, 2); else LOIKB_LAUNCH_FLAT2(2, false, 0, false, 2);
+          }
+          else if (S->opt.logging) {   // (the SolverInfo lists: unsliced; a diagonal reference weight goes as a general one)
             quantum = 0;
             if (hm == 3) LOIKB_LAUNCH_FLAT2(2, false, 3, true);
             else if (hm >= 1) LOIKB_LAUNCH_FLAT2(2, false, 2, true);
@@ -1906,6 +1935,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       if (C->h_counters[FLAT_COUNTERS_ERR]) { g_last_error = "internal: a wavefront of the flat engine gave up waiting on its work queue"; return LOIKB_ERR_STATE; }
       C->stats.lean_requeues += (int)C->h_counters[LEAN_Q_REQUEUES];
       const unsigned int escaped = C->h_counters[2];
+      C->stats.flat_built += (int)C->h_counters[FLAT_COUNTERS_BUILT];
       {
         std::lock_guard<std::mutex> lock(S->alloc_mu);
         const unsigned int seen = C->h_counters[LEAN_DECADES_SEEN];
@@ -2357,6 +2387,7 @@ int run_main_loop_t(loikb_solver_impl* S)
     S->stats.flat_launches += C.stats.flat_launches;
     S->stats.flat_split_launches += C.stats.flat_split_launches;
     S->stats.flat_ordered += C.stats.flat_ordered;
+    S->stats.flat_built += C.stats.flat_built;
     S->stats.queue_dry_ms += C.stats.queue_dry_ms;
     S->stats.lean_escaped += C.stats.lean_escaped;
     S->stats.hslots_ms += C.stats.hslots_ms;
@@ -3227,6 +3258,10 @@ const char* loikb_plan_string(loikb_solver* S)
     snprintf(buf, sizeof(buf), "k_solve (team of %d), hand-over to k_tail at %d live instances; %d chunk(s); no k_lean: %s",
              S->sched[1].nw, pl.tail_max, pl.nchunks, pl.why_not_lean);
   out = buf;
+  if (pl.flat && flat_any_mu(S) && (flat_applicable(S) || !S->have_problem))
+    out += "; OSQP penalty rule: mu is off the decade grid -- k_fslots builds mu0's slot only, k_flat2 builds W / Dinv in-wave at every change of mu";
+  else if (pl.flat && S->tune.flat_build && (flat_applicable(S) || !S->have_problem))
+    out += "; LOIKB_FLAT_BUILD=1: a decade the table lacks is built in-wave (no hand-over to k_tail)";
   if (!pl.flat && *pl.why_not_flat) out += std::string("; no k_flat: ") + pl.why_not_flat;
   else if (pl.flat && S->have_problem && !flat_applicable(S))
     out += pl.lean ? "; no flat engine for this problem (per-link reference weights): k_hslots + k_lean take its place"

@@ -44,7 +44,7 @@ constexpr int LCD = 26, LCA = 36;
 // [6] decade-slot loads, and the work queue:
 constexpr int LEAN_Q_HEAD = 7, LEAN_Q_TAIL = 8, LEAN_Q_REQUEUES = 9, LEAN_Q_RETIRED = 10;
 constexpr int LEAN_DECADES_SEEN = 11;  // bit d: some instance loaded the slot of decade kexp_lo + d in this launch
-constexpr int NCOUNTERS = 20;
+constexpr int NCOUNTERS = 64;   // (32..63: k_flat2's per-decade slot counts, FLAT_COUNTERS_DEC)
 #ifndef LOIKB_POLL_MASK
 #define LOIKB_POLL_MASK 3u
 #endif

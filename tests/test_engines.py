@@ -23,6 +23,10 @@ ENGINES = {
     "hybrid_flat": (dict(), dict(tail_max_instances=120, max_launch_iters=2)),
     "hybrid_lean": (dict(LOIKB_FLAT="0"), dict(tail_max_instances=120, max_launch_iters=2)),
     "flat_escapes": (dict(LOIKB_LEAN_KLO="0", LOIKB_LEAN_DECADES="2"), dict()),
+    # round 5: the decades the table lacks are built by the instance's own wavefront (flat_build_slot), also across time slices
+    "flat_builds": (dict(LOIKB_LEAN_KLO="0", LOIKB_LEAN_DECADES="1", LOIKB_LEAN_ADAPT="0", LOIKB_FLAT_BUILD="1"), dict()),
+    "flat_builds_sliced": (dict(LOIKB_LEAN_KLO="1", LOIKB_LEAN_DECADES="1", LOIKB_LEAN_ADAPT="0", LOIKB_FLAT_BUILD="1", LOIKB_FLAT_SLICE="5",
+                                LOIKB_LEAN_WG_PER_CU="1"), dict()),
     "lean_escapes": (dict(LOIKB_FLAT="0", LOIKB_LEAN_KLO="0", LOIKB_LEAN_DECADES="2"), dict()),
 }
 FIELDS = ["nu", "z", "w", "vis", "fis", "g", "yis", "Aty", "Stf_plus_w", "primal_residual_vec", "dual_residual_vec"]
@@ -34,7 +38,8 @@ SCALARS = ["primal_residual", "dual_residual", "primal_residual_task", "primal_r
 
 def _solver(model, B, prm, engine, monkeypatch):
     env, kw = ENGINES[engine]
-    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_WG_PER_CU", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES"):
+    for k in ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_WG_PER_CU", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES",
+              "LOIKB_LEAN_ADAPT", "LOIKB_FLAT_BUILD"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -88,6 +93,8 @@ def test_every_engine_matches_the_oracle(which, engine, request, monkeypatch):
     if engine in ("hybrid_lean", "hybrid_flat"):
         assert st["lean_launches"] >= 1 and 0 < st["tail_instances"] < B
         assert (st["flat_launches"] >= 1) == (engine == "hybrid_flat")
+    if engine in ("flat_builds", "flat_builds_sliced") and which == "talos":
+        assert st["flat_split_launches"] >= 1 and st["flat_built"] > 0 and st["lean_escaped"] == 0 and st["tail_instances"] == B, (s.plan(), st)
     if engine in ("lean_escapes", "flat_escapes"):
         assert st["lean_launches"] >= 1 and st["lean_escaped"] > 0, st
         assert (st["flat_launches"] >= 1) == (engine == "flat_escapes")
@@ -427,6 +434,45 @@ def test_fuzz_slice_flat_engine(monkeypatch):
         print("unconverged-only:", c)
     assert out["mismatches"] == 0 and out["unconverged_only"] == 0, (out["unconverged_cases"], out)
     assert out["flat_cases"] >= 15, out   # (batches below 64 instances and trees the schedule refuses run elsewhere)
+
+
+def test_flat_engine_builds_the_decades_its_table_lacks(talos, monkeypatch):
+    """Round 5: with LOIKB_FLAT_BUILD=1 an instance whose mu leaves the decades k_fslots built for the launch builds the
+    missing slot in-wave (flat_build_slot: k_fslots' two passes for one mu, the same operations in the same order) and carries on -- no
+    hand-over to k_tail.  The columns are k_fslots' bit for bit, so whatever the table holds the results are THE SAME BITS: the full
+    table, a table of one decade (everything else built in-wave), and one decade with time slices (parked instances rebuild after a
+    switch) are compared on 3000 headline instances."""
+    from loik_amd import workloads
+    B = 3000
+    wl = workloads.talos_c3(B, seed=321)
+    prm = dict(wl["params"], max_iter=400)
+    args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    names = ("LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_ADAPT", "LOIKB_FLAT_BUILD", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_WG_PER_CU")
+    cases = (("table", dict()),
+             ("one_decade", dict(LOIKB_LEAN_KLO="0", LOIKB_LEAN_DECADES="1", LOIKB_LEAN_ADAPT="0", LOIKB_FLAT_BUILD="1")),
+             ("no_decade_of_use", dict(LOIKB_LEAN_KLO="-2", LOIKB_LEAN_DECADES="1", LOIKB_LEAN_ADAPT="0", LOIKB_FLAT_BUILD="1")),
+             ("one_decade_sliced", dict(LOIKB_LEAN_KLO="1", LOIKB_LEAN_DECADES="1", LOIKB_LEAN_ADAPT="0", LOIKB_FLAT_BUILD="1", LOIKB_FLAT_SLICE="7",
+                                        LOIKB_LEAN_WG_PER_CU="1")))
+    res = {}
+    for name, env in cases:
+        for k in names:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = loik_amd.BatchedLoik(talos, B, **prm)
+        s.Solve(*args)
+        st = s.stats()
+        assert st["flat_split_launches"] >= 1 and st["tail_instances"] == B and st["lean_escaped"] == 0, (name, st)
+        assert (st["flat_built"] > B // 2) == (name != "table"), (name, st["flat_built"])
+        if name != "table":
+            assert "in-wave" in s.plan(), s.plan()
+        res[name] = {k: s.get(k) for k in ("iter", "converged", "primal_infeasible", "z", "nu", "mu", "yis", "fis", "vis", "w")}
+        s.close()
+    for name, _ in cases[1:]:
+        for k in res["table"]:
+            assert np.array_equal(res["table"][k], res[name][k]), (name, k, np.abs(res["table"][k] - res[name][k]).max())
+    out = ref.solve_batch(talos, *args, nthreads=8, want_nu=True, **prm)
+    assert (res["one_decade"]["iter"] == out["iters"]).mean() > 0.99
 
 
 def test_flat_time_slicing_changes_nothing(talos, monkeypatch):
