@@ -198,6 +198,18 @@ class Shard:
         for h in self.handles():
             h.close()
 
+    def chain_summary(self, steps):
+        """per timed step of THIS shard: the on-chip launch split into its bulk (until a wavefront first finds the work queue empty) and the
+        chain of the long runners behind it (SIMDs mostly idle: what bounds small shards, i.e. the strong-scaling curve), and the slot
+        kernel -- so that a multi-GPU run separates chain from bulk per device (VERDICT r04 #8)"""
+        a = self.acc
+        n = max(steps, 1)
+        launch = (a.get("tail_ms", 0.0) - a.get("hslots_ms", 0.0)) / n
+        bulk = a.get("queue_dry_ms", 0.0) / n
+        return {"gpu": self.idx, "batch": self.B, "launch_ms": launch, "bulk_ms": bulk if bulk > 0 else None,
+                "lone_chain_ms": (launch - bulk) if bulk > 0 else None, "slots_ms": a.get("hslots_ms", 0.0) / n,
+                "instance_iterations": a.get("instance_iterations", 0) / n}
+
     def results(self):
         """per timed step (the mean over the steps' batches when every step had its own)"""
         prm = self.wl["params"]
@@ -572,22 +584,31 @@ def schedule_variant(args, device):
 
     out["repeat_same_batch"] = timed_repeat(None)
     out["same_batch_arrival_order"] = timed_repeat("0")
-    for key, fl in (("another_batch_every_solve", 0), ("another_batch_every_solve_order_from_previous", loik_amd.capi.OPT_ORDER_FROM_PREVIOUS)):
+    # (round 5: the batches are generated BEFORE the loop -- a caller has its problems; round 4 generated each one on the host between the
+    #  solves, the GPU sat idle for ~0.3 s and the same kernels then ran 6-7 % longer: profiles/r05_a_one_handle_idle_gap.txt.  The
+    #  variant `.._after_idle_gap` keeps that measurement: 100 ms of idleness before every timed Solve().)
+    batches = [workloads.talos_c3(args.batch, seed=0x5EED + i) for i in range(7)]
+    for key, fl, gap in (("another_batch_every_solve", 0, 0.0), ("another_batch_every_solve_after_idle_gap", 0, 0.1),
+                         ("another_batch_every_solve_order_from_previous", loik_amd.capi.OPT_ORDER_FROM_PREVIOUS, 0.0)):
         s = loik_amd.BatchedLoik(wl["model"], args.batch, device=device, flags=args.flags | fl, **wl["params"])
-        ms, solved, ordered = [], [], 0
-        for i in range(6):
-            w2 = workloads.talos_c3(args.batch, seed=0x5EED + i)
+        ms, solved, ordered, init_ms = [], [], 0, []
+        for i, w2 in enumerate(batches):
+            t0 = time.perf_counter()
             s.SolveInit(w2["q"], w2["H_ref"], w2["v_ref"], w2["c_ids"], w2["Ais"], w2["bis"], w2["lb"], w2["ub"])
             s.synchronize()
+            init_ms.append((time.perf_counter() - t0) * 1e3)
+            if gap:
+                time.sleep(gap)
             t0 = time.perf_counter()
             s.Solve()
             s.synchronize()
-            if i:
+            if i >= 2:
                 ms.append((time.perf_counter() - t0) * 1e3)
                 solved.append(int(s.get("converged").astype(bool).sum()))
                 ordered += s.stats()["flat_ordered"]
         out[key] = {"ms_per_step": sum(ms) / len(ms), "value": float(sum(solved) / (sum(ms) * 1e-3)), "unit": "solves/s",
-                    "solves": len(ms), "of_which_ordered": ordered}
+                    "solves": len(ms), "of_which_ordered": ordered, "solve_init_ms": sum(init_ms[2:]) / len(init_ms[2:]),
+                    "idle_gap_before_solve_s": gap}
         s.close()
     return out
 
@@ -787,7 +808,17 @@ def main(argv=None, solver_factory=None, device_count=None):
         elapsed, tot = sharding.aggregate(dist, elapsed, cnt)
         return shards, res, elapsed, tot
 
+    def gather_chains(shs):
+        """every shard's chain_summary on rank 0 (objects through the gloo group: bookkeeping after the timed region, not data path)"""
+        mine = [sh.chain_summary(args.steps) for sh in shs if hasattr(sh, "chain_summary")]
+        if dist is None:
+            return mine
+        buf = [None] * world
+        dist.all_gather_object(buf, mine)
+        return sorted((c for part in buf for c in part), key=lambda c: c["gpu"])
+
     shards, res, elapsed, tot = measure(args.scaling)
+    chains = gather_chains(shards)
     plan0 = shards[0].solver.plan() if hasattr(shards[0].solver, "plan") else None   # which kernels ran, and why
     strong = None
     if args.scaling == "weak" and n_total > 1 and not args.no_strong_leg:
@@ -796,7 +827,9 @@ def main(argv=None, solver_factory=None, device_count=None):
             sh.close()
         shards[0].close()
         s_shards, s_res, s_elapsed, s_tot = measure("strong")
-        strong = {"metric": "IK solves/sec to 1e-6 residual, Talos humanoid, batch=%d in total" % args.batch,
+        s_chains = gather_chains(s_shards)
+        strong = {"per_shard": s_chains,
+                  "metric": "IK solves/sec to 1e-6 residual, Talos humanoid, batch=%d in total" % args.batch,
                   "scaling": "strong", "n_gpus": n_total, "batch_total": int(s_tot["batch"]),
                   "batch_per_gpu": int(s_tot["batch"]) // n_total,
                   "value": s_tot["solved"] * args.steps / s_elapsed, "unit": "solves/s",
@@ -877,6 +910,9 @@ def main(argv=None, solver_factory=None, device_count=None):
                 "robot_tables": "synthetic Talos-topology tables (no URDF offline); parity with upstream binaries is unpinned (DESIGN.md 2)",
             },
             "roofline": kernel_roofline(acc0, last0, args.steps, nb, nc, B0),
+            # per device: the launch's bulk and the chain of its long runners (lone_chain_ms), so that a run on N GPUs shows which of the
+            # two bounds a shard (the chain does not shrink with the shard: DESIGN.md 6)
+            "per_shard": chains,
         }
         if strong is not None:
             # both legs as objects of their own, so that whichever a reader of the line wants is labelled: the top-level
@@ -902,6 +938,13 @@ def main(argv=None, solver_factory=None, device_count=None):
                 line["schedule_variant"] = schedule_variant(args, device_of(0))
             except Exception as e:
                 line["schedule_variant"] = {"failed": repr(e)}
+            try:   # (top-level scalars: what a caller with ONE handle and new problems gets -- VERDICT r04 #6)
+                oh = line["schedule_variant"]["another_batch_every_solve"]
+                line["value_one_handle"] = oh["value"]
+                line["ms_per_step_one_handle"] = oh["ms_per_step"]
+                line["ms_per_step_one_handle_after_idle_gap"] = line["schedule_variant"]["another_batch_every_solve_after_idle_gap"]["ms_per_step"]
+            except Exception:
+                pass
             try:
                 rp = line["schedule_variant"]["repeat_same_batch"]
                 line["roofline"]["repeat_same_batch"] = {"avg_launch_ms": rp["kernel_avg_launch_ms"], "achieved": rp["kernel_achieved_TFLOPs"],

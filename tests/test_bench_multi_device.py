@@ -94,6 +94,9 @@ def test_gpus_2_weak_runs_two_devices_in_one_process(capsys, monkeypatch):
     # both legs are labelled objects of the line; the strong one carries BASELINE.json's wording
     wk = line["weak_scaling"]
     assert wk["value"] == line["value"] and wk["batch_total"] == 48 and "per GPU" in wk["metric"]
+    # every device's launch split into bulk and the chain of its long runners, for both legs
+    assert [c["gpu"] for c in line["per_shard"]] == [0, 1] and all(c["batch"] == 24 and "lone_chain_ms" in c for c in line["per_shard"])
+    assert [c["batch"] for c in st["per_shard"]] == [12, 12]
     assert st["n_gpus"] == 2 and "batch=24 in total" in st["metric"]
 
 

@@ -201,3 +201,53 @@ def test_whole_body_four_tasks_in_the_lean_engine(robot):
         v = workloads.link_velocity(model, wl["q"], s.get("z"), int(link))
         assert np.max(np.abs(v - wl["bis"][:, c])[conv]) < 1e-5
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot,nc", [("talos32", 6), ("talos32", 10), ("talos32", 11), ("talos32", 16),
+                                      ("talos44", 6), ("talos44", 10), ("talos44", 11)])
+@pytest.mark.parametrize("per_instance_A", [False, True])
+def test_gpu_many_constraints_and_the_flat_engines_limit(robot, nc, per_instance_A):
+    """VERDICT r04 #5a / ADVICE r03 (high): k_flat2 / k_flat1 update the task constraints on lanes 6 c + k of the wavefront, ten constraints
+    in one pass; the plan sends more to the engines that loop over them (loik_host.hip::plan_engines).  The gate went in with no test
+    above num_eq_c = 4: here 6 and 10 (lanes 24..59: every row of the last constraint's block, the half-filled tail of the wavefront)
+    on both flat engines, and 11 / 16 on the fallback -- k iterations against the oracle field by field, then end to end.
+    num_eq_c is the reference's constructor argument (loik-loid-optimized.hpp:129-134); FwdPass1 / DualUpdate loop over the active
+    constraints (hxx:321-334, :410-451)."""
+    model = loik_amd.builtin_model(robot)
+    # nc distinct links spread over the tree (wrists, feet, head first, then joints along the chains)
+    links = _links(model, nc)
+    B = 128
+    wl = multi_task_batch(model, B, links, 40 + nc, per_instance_A=per_instance_A, nu_scale=0.3)
+    on_flat = nc <= 10
+    for k in (1, 2, 5):
+        prm = dict(FIXTURE, num_eq_c=nc, max_iter=k + 1, tol_abs=0.0, tol_rel=0.0, tol_primal_inf=0.0)
+        s = _gpu(model, wl, prm)
+        st = s.stats()
+        if on_flat:
+            assert ("k_flat2" if robot == "talos32" else "k_flat1") in s.plan(), s.plan()
+            assert st["flat_launches"] >= 1 and (st["flat_split_launches"] >= 1) == (robot == "talos32") and st["tail_instances"] == B, (s.plan(), st)
+        else:
+            assert "more task constraints than the flat engine" in s.plan(), s.plan()
+            assert st["flat_launches"] == 0, st
+        got = {n: s.get(n) for n in FIELDS + SCALARS}
+        got["His"] = s.His_full()
+        for b in range(0, B, 17):
+            r = ref.RefSolver(model, **prm)
+            r.Solve(*problem_args(wl, b))
+            for n in FIELDS:
+                want = r.field(n)
+                if n in ("vis", "fis", "g"):
+                    want = want[1:]
+                assert_close(got[n][b], want, 1e-9, "%s b%d k%d" % (n, b, k))
+            assert_close(got["His"][b], r.His[1:], 1e-9, "His")
+            for n in SCALARS:
+                assert_close(got[n][b], r.scalar(n), 1e-9, "%s b%d k%d" % (n, b, k))
+        s.close()
+    prm = dict(FIXTURE, num_eq_c=nc, max_iter=300, tol_abs=1e-6, tol_rel=0.0)
+    out = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"],
+                          nthreads=8, want_nu=True, **prm)
+    s = _gpu(model, wl, prm)
+    assert (s.stats()["flat_launches"] >= 1) == on_flat
+    assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.95, ztol=1e-8, what="%s nc=%d" % (robot, nc))
+    s.close()
