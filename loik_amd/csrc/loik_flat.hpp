@@ -1047,8 +1047,13 @@ template <typename T, int NA>
 __global__ void __launch_bounds__(WAVE)
 k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, const TailTopo* __restrict__ topo,
          const int* __restrict__ child_list, const FlatLane* __restrict__ fl, int maxdepth, int nanc, int frows, int njmp,
-         const int* __restrict__ slots, int nslots, int G, T* __restrict__ fslots, int kexp_lo, int ndec, int dgrp)
+         const int* __restrict__ slots, int nslots, int G, T* __restrict__ fslots, int kexp_lo, int ndec, int dgrp, int dw0, int nw,
+         unsigned int* __restrict__ fmask)
 {
+  // dw0, nw: the decades to build NOW, [dw0, dw0 + nw) of the table's [0, ndec) -- the table is addressed for its whole range and
+  // populated lazily: k_flat2<.., MUR = 2> builds the other decades of an instance in-wave if the instance ever gets there
+  // (flat_build_slot, loik_flat2.hpp) and notes it in fmask (bit d: decade d is there; bit 16 + d: written during the launch, by a
+  // wavefront of whatever XCD: coherent loads).
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Layout& L = P.L;
   constexpr int HX = 22;
@@ -1147,9 +1152,10 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
   // The decades go through the two passes in groups of `dgrp` (LOIKB_FSLOT_DGRP, default: all at once): a group's rows of pass A
   // are read back by pass B while they are still in the L2 of the XCD (ten wavefronts x two instances x eight decades x 2 KB per CU
   // is 10 MB per XCD, its L2 has 4), at the price of refilling the pipeline over the tree levels once per group.
-  for (int d0 = 0; d0 < ndec; d0 += dgrp) {
-  const int nd = (ndec - d0 < dgrp) ? ndec - d0 : dgrp;
-  if (d0 > 0) {
+  if (fmask != nullptr && has_inst && jlane == 0) fmask[sidx] = (nw >= 32 ? 0xFFFFu : ((1u << nw) - 1u)) << dw0;
+  for (int d0 = dw0; d0 < dw0 + nw; d0 += dgrp) {
+  const int nd = (dw0 + nw - d0 < dgrp) ? dw0 + nw - d0 : dgrp;
+  if (d0 > dw0) {
     tail_sync();
     if (lane < HX) xch[WAVE * HX + lane] = T(0);
   }

@@ -35,6 +35,7 @@ namespace loikb {
 
 constexpr int F2G = 32;  // joints per instance (lane pairs)
 constexpr int FLAT_PARKED = 1 << 30;  // ring entry: the instance is parked (k_flat2<.., SLICED>)
+constexpr int FLAT_BUILD_REQ = 1 << 29;  // ... and the decade it needs (bits 24..27: kexp + 8) is not in the table: whoever unparks it builds the slot first
 constexpr int FLAT2_PARK_ROWS = 33;   // rows of 64 doubles of a parked instance's lane state
 constexpr int FLAT2_PARK_BATCH = 8;   // elements of the LDS blocks a lane moves per batch (512 per wavefront: up to three task constraints in one)
 __host__ __device__ __forceinline__ int flat2_park_stride(int nc, bool has_hv)
@@ -375,6 +376,9 @@ __device__ __forceinline__ void flat_path_rows4(const FlatLane* fl, int j, int o
 // loik-loid-optimized.hxx:632-637) runs on the flat engine: every change of mu is one build (2.5 per solve on the headline batch).
 // scr: (G + 1) x FB_HX exchange rows (pass B's L columns live in them afterwards), then (G + 1) x 6 rows of S^w.
 // Math: FwdPass1 + BwdPass at the world origin, hxx:290-338, :31-81 (see k_fslots).
+#ifndef LOIKB_BUILD_CALL
+#define LOIKB_BUILD_CALL 0
+#endif
 constexpr int FB_HX = 22;
 template <int G> __host__ __device__ constexpr int flat_build_scratch() { return (G + 1) * FB_HX + (G + 1) * 6; }
 // hb: mass x (rho I + H_ref) of the lane's link, link frame, packed symmetric; at: A^T A of the constraint on the lane's joint (zeros
@@ -600,9 +604,21 @@ template <int NA, int WPE, bool SLICED = false, int HM = 0, bool LOG = false, in
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
         int nscan, int njmp, int* ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
-        int ndec, double href_s, int has_hv, int ring_mask, int quantum, double* __restrict__ park, int park_stride,
-        const TailTopo* __restrict__ topo, const int* __restrict__ child_list, int maxdepth)
+        int ndec, double href_s, int has_hv_pk, int ring_mask, int quantum, double* __restrict__ park, int park_stride,
+        const void* const* __restrict__ aux)
 {
+  // (what only the in-wave builder and the lazily populated table need comes through ONE pointer and the spare bits of has_hv: every
+  //  kernel argument is a scalar register the iteration loop then lacks -- five more arguments cost the loop twenty v_readlane per iteration)
+  // has_hv_pk: bit 0 = the reference target is not zero, bits 8..15 = the tree's depth, bits 16..31 = the decades k_fslots built for this
+  // launch (win_bits); aux[0] = TailTopo*, aux[1] = the children's list, aux[2] = fmask
+  const int has_hv = has_hv_pk & 1;
+#define topo (reinterpret_cast<const TailTopo*>(aux[0]))
+#define child_list (reinterpret_cast<const int*>(aux[1]))
+#define fmask (reinterpret_cast<unsigned int*>(const_cast<void*>(aux[2])))
+#define maxdepth ((has_hv_pk >> 8) & 0xFF)
+#define win_bits ((has_hv_pk >> 16) & 0xFFFF)
+  // fmask (MUR = 2): per instance, bit d: decade d of the table is there (k_fslots' window, win_bits, or built during the launch);
+  // bit 16 + d: built during the launch, possibly by a wavefront of another XCD: fetched with agent-scope loads
   constexpr bool BUILD = MUR >= 1;
   static_assert(flat_build_scratch<F2G>() <= flat2_off_nbuf<NA>(), "the in-wave builder's rows must end before the buffers the iteration keeps");
   using T = double;
@@ -625,7 +641,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const int h3 = h ? 3 : 0;
   // Three wavefronts per SIMD leave a lane 168 registers: what an iteration touches once -- the joint's box, last iteration's
   // S^T f + w -- then lives in LDS (one row of three per joint; both lanes of a joint read the same address).
-  constexpr bool JCL = WPE >= 3 || MUR >= 1;   // (the builds with the in-wave builder: the loop has no register to spare for it)
+  constexpr bool JCL = WPE >= 3 || MUR == 1 || (MUR == 2 && !SLICED);   // (the builds with the in-wave builder: the loop has no register to spare for it)
   // ---- LDS of the wavefront
   T* const xb = reinterpret_cast<T*>(smem_raw);   // load-time rows | path rows [65][3] | W tau products [NA][32]
   T* const wl = xb + flat2_off_wl<NA>();          // [2][NA + 1][32]  W rows and the Dinv row of two decades of mu
@@ -730,6 +746,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     return ((A_[0] * y[0] + A_[6] * y[1]) + A_[12] * y[2]) + ((A_[18] * y[3] + A_[24] * y[4]) + A_[30] * y[5]);
   };
   bool resumed = false;  // (SLICED) the instance came back from the queue: no first-iteration corrections
+  unsigned int fmask_r = 0xFFFFu;   // (MUR = 2) this instance's word of fmask, uniform
   T bnorm_r = T(0);      // (MUR = 1) max |b| of the instance's constraints (bis_inf_norm_): OSQP's rule normalises the primal residual with it
   auto half = [&](const T* x6, T* x3) {
 #pragma unroll
@@ -786,6 +803,25 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   // again by whichever wavefront pops its entry, possibly on another XCD (agent-scope accesses; the pusher waits for its stores
   // before the entry appears).  Round 3 sent it through the tile records (410 scattered stores, 90 loads, the whole set-up again:
   // ~130 us of a wavefront per switch, more than the slices brought); a park / unpark pair is ~40 row accesses each way.
+  // (MUR = 2) a slot built in-wave goes into the table, where k_fslots would have put it: the instance's later visits of the decade
+  // load it like any other (a long runner flips between two decades hundreds of times: rebuilt at every visit, the 999-iteration
+  // instances spent 7 ms of their launch building -- measured)
+  auto publish_slot = [&](int kx, const T* Wc, T dv) {
+    const int dsl = kx - kexp_lo;
+    if (dsl < 0 || dsl >= ndec || dsl >= 16) return;
+    if (!h && isj_lane) {
+      T* base = const_cast<T*>(fslots) + fslotW_at(lidx, ndec, dsl, frows, fcol);
+#pragma unroll
+      for (int k = 0; k < NA; ++k)
+        if (k < fdm1) cst<T>(reinterpret_cast<char*>(base + k), Wc[k]);
+      cst<T>(reinterpret_cast<char*>(base + fdm1), dv);
+    }
+    const unsigned int bits = (1u << dsl) | (1u << (16 + dsl));
+    fmask_r |= bits;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the column is out before the bit says so
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_fetch_or(fmask + lidx, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   auto park_instance = [&]() {
     T* pk = park + (size_t)lidx * park_stride;
     int r = 0;
@@ -826,23 +862,94 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   // (ALL loads of the record in flight together -- the lane rows, the LDS blocks' elements, the six scalars behind them: one round trip
   //  to HBM.  The first version read the LDS blocks and the scalars element by element, ten dependent round trips: 60 us per switch)
   auto unpark = [&](int entry) {
-    const int slot = entry & 0xFFFFF, dsl_in = (entry >> 24) & 15;   // (the decade of mu the instance was parked in travels in the entry:
+    const int slot = entry & 0xFFFFF, dsl_raw = (entry >> 24) & 15;  // (the decade of mu the instance was parked in travels in the entry:
     lidx = slot;                                                     //  its W columns are fetched WITH the record, not a round trip later)
     isj = isj_lane;
     ip = lane_ptr<T>(Bf.tiles, L, slot);
     rec = ip + (size_t)jl * JREC * pair_bytes<T>();
     const T* pk = park + (size_t)slot * park_stride;
+    // (SLICED, MUR = 2) the instance left the iteration loop because its decade is not in the table: the slot is built HERE, from the
+    // three lane rows the builder needs and before anything else of the instance is in registers -- nothing of the iteration's state is
+    // live across the builder, so its two hundred values do not touch the register allocation of the loop (built in place, beside the
+    // loop, they cost it four scratch reloads per iteration: 3-6 % of the headline)
+    bool built = false;
+    int kexp_b = 0;
+    if constexpr (MUR == 2) fmask_r = (unsigned int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(fmask + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if constexpr (SLICED && MUR == 2) {
+      if (entry & FLAT_BUILD_REQ) {
+        kexp_b = dsl_raw - 8;
+        T Rb[9], tb[3], Sb3[3], Sw6[6], hb[21], at[21], Wc[NA], dv;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rb[k] = cld<T>(reinterpret_cast<const char*>(pk + k * WAVE + lane));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tb[k] = cld<T>(reinterpret_cast<const char*>(pk + (9 + k) * WAVE + lane));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Sb3[k] = cld<T>(reinterpret_cast<const char*>(pk + (12 + k) * WAVE + lane));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) both_halves(Sb3[k], Sw6[k], Sw6[3 + k]);
+#pragma unroll
+        for (int a_ = 0; a_ < 6; ++a_)   // (k_fslots' base term, read where it reads it)
+#pragma unroll
+          for (int b2 = a_; b2 < 6; ++b2)
+            hb[sym(a_, b2)] = mass * ((a_ == b2 ? P.rho : T(0)) + (P.href_tab ? P.href_tab[(size_t)(jl + 1) * HREF_ROW + 6 * a_ + b2] : P.Href[6 * a_ + b2]));
+#pragma unroll
+        for (int k = 0; k < 21; ++k) at[k] = T(0);
+        if (jcslot >= 0) {
+          const char* crec = ip + (size_t)(L.off_c + jcslot * L.crec) * pair_bytes<T>();
+          for (int k = 0; k < 21; ++k)
+            at[k] = a_shared ? Bf.uni[L.nc * 36 + jcslot * 21 + k]
+                             : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+        }
+#if LOIKB_BUILD_CALL
+        {
+          FlatBuildIn bi;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) bi.R0[k] = Rb[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) bi.t0[k] = tb[k];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) bi.Sw[k] = Sw6[k];
+#pragma unroll
+          for (int k = 0; k < 21; ++k) { bi.hb[k] = hb[k]; bi.at[k] = at[k]; }
+          bi.mu = flat_decade_mu(P.mu0, kexp_b);
+          bi.mu_scale = P.mu_scale;
+          const FlatBuildOut<NA> bo = flat_build_slot_call<NA, G>(xb, lane, !h, j, L.nb, jd, topo, child_list, fl, maxdepth, bi);
+#pragma unroll
+          for (int k = 0; k < NA; ++k) Wc[k] = bo.Wc[k];
+          dv = bo.dinv;
+        }
+#else
+        flat_build_slot<NA, G>(xb, lane, !h, j, L.nb, jd, topo, child_list, fl, maxdepth, Rb, tb, Sw6, hb, at, flat_decade_mu(P.mu0, kexp_b),
+                               P.mu_scale, Wc, dv);
+#endif
+        if (!h) {   // (slot 0 of the two)
+#pragma unroll
+          for (int k = 0; k < NA; ++k) wl[k * GW + j] = Wc[k];
+          wl[NA * GW + j] = dv;
+        }
+        publish_slot(kexp_b, Wc, dv);
+        if (lane == 0) {
+          atomicAdd(&Bf.counters[FLAT_COUNTERS_BUILT], 1u);
+          atomicAdd(&Bf.counters[FLAT_COUNTERS_DEC + (kexp_b < -16 ? 0 : kexp_b > 15 ? 31 : kexp_b + 16)], 1u);
+        }
+        built = true;
+        tail_sync();
+      }
+    }
+    const int dsl_in = built ? 15 : dsl_raw;
     const T* pl = pk + FLAT2_PARK_ROWS * WAVE;
     const int nl = (has_hv ? G * 6 : 0) + L.nc * cs + FISC, nl6 = nl + 6;
     T lb[FLAT2_PARK_BATCH];
 #pragma unroll
     for (int k = 0; k < FLAT2_PARK_BATCH; ++k) { const int e = k * WAVE + lane; lb[k] = e < nl6 ? cld<T>(reinterpret_cast<const char*>(pl + e)) : T(0); }
-    const bool with_slot = dsl_in < ndec;
+    const bool with_slot = dsl_in < ndec && (MUR != 2 || ((fmask_r >> dsl_in) & 1u));
+    const bool coh_slot = MUR == 2 && ((fmask_r >> (16 + (dsl_in & 15))) & 1u);   // (written during this launch: agent-scope loads)
     T win[NH + 1];
 #pragma unroll
     for (int i = 0; i <= NH; ++i) {
       const int k = 2 * i + (h ? 1 : 0);
-      win[i] = (with_slot && isj_lane && (k == NA || k < fdm1)) ? fslots[fslotW_at(slot, ndec, dsl_in, frows, fcol + (k == NA ? fdm1 : k))] : T(0);
+      const T* src = fslots + fslotW_at(slot, ndec, dsl_in < ndec ? dsl_in : 0, frows, fcol + (k == NA ? fdm1 : k));
+      win[i] = (with_slot && isj_lane && (k == NA || k < fdm1)) ? (coh_slot ? cld<T>(reinterpret_cast<const char*>(src)) : *src) : T(0);
     }
     int r = 0;
     auto get = [&]() -> T { return cld<T>(reinterpret_cast<const char*>(pk + (r++) * WAVE + lane)); };
@@ -896,6 +1003,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       kslot = kexp_lo + dsl_in;
       n_slot_loads = (n_slot_loads + 0x10000u) | (1u << dsl_in);
     }
+    if (built) { wsel = 0; kslot = kexp_b; }   // (the slot built above)
     tail_sync();
     done = false;
     bc_valid = false;
@@ -914,6 +1022,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     if (SLICED && (slot_in & FLAT_PARKED)) { unpark(slot_in); return; }
     resumed = false;
     bc_valid = false;
+    if constexpr (MUR == 2) fmask_r = (unsigned int)win_bits;   // (what k_fslots wrote for every listed instance)
     isj = isj_lane;
     const int slot = slot_in;
     lidx = slot;
@@ -937,7 +1046,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     // (straight from a cold reset mu = mu0, decade 0: its W columns are requested WITH the record -- one trip to HBM, not a second
     //  one behind it.  Should the record say otherwise, the loop's slot logic loads what it needs as always.)
     const int dsl0 = -kexp_lo;
-    const bool slot0 = zero_state && dsl0 >= 0 && dsl0 < ndec;
+    const bool slot0 = zero_state && dsl0 >= 0 && dsl0 < ndec && (MUR != 2 || ((win_bits >> dsl0) & 1));
     T win0[NH + 1];
 #pragma unroll
     for (int i = 0; i <= NH; ++i) {
@@ -1250,7 +1359,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       // (MUR = 1: the one slot the table holds is mu0's -- every instance starts there, and a solve that starts from a cold reset does its
       //  first iterations on it: a quarter of the rule's builds saved)
       const int dsl = MUR == 1 ? 0 : kexp - kexp_lo;
-      const bool in_table = MUR == 1 ? (ndec > 0 && __builtin_amdgcn_readfirstlane((int)(mu == P.mu0)) != 0) : (dsl >= 0 && dsl < ndec);
+      const bool in_table = MUR == 1 ? (ndec > 0 && __builtin_amdgcn_readfirstlane((int)(mu == P.mu0)) != 0)
+                                     : (dsl >= 0 && dsl < ndec && (MUR != 2 || ((fmask_r >> (dsl & 15)) & 1u)));
       if (MUR != 1 && kexp == kslot_o) {
         { const int tk = kslot; kslot = kslot_o; kslot_o = tk; }
         wsel ^= 1;
@@ -1259,8 +1369,13 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         exit_now = true;  // mu left the precomputed decades: written back unfinished, k_tail takes over
         if (lane == 0) atomicAdd(&Bf.counters[2], 1u);
       } else if (__builtin_expect(!in_table, 0)) {
-        need_build = true;   // (the wavefront builds the slot itself -- OUTSIDE this loop: see the loop around it)
-        break;
+        if (SLICED && MUR == 2 && (kexp < -8 || kexp > 7)) {   // (the ring entry has four bits for the decade: beyond them, k_tail as ever)
+          exit_now = true;
+          if (lane == 0) atomicAdd(&Bf.counters[2], 1u);
+        } else {
+          need_build = true;   // (the wavefront builds the slot itself -- OUTSIDE this loop: see the loop around it)
+          break;
+        }
       } else {
         {
           if (MUR == 2 && lane == 0) atomicAdd(&Bf.counters[FLAT_COUNTERS_DEC + (kexp < -16 ? 0 : kexp > 15 ? 31 : kexp + 16)], 1u);
@@ -1269,10 +1384,12 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
           T* wdst = wl + (size_t)wsel * (NA + 1) * GW;
           // rows k = 2 i + h of the joint's column (k <= NA: the linear lane also fetches the Dinv row)
           T in[NH + 1];
+          const bool coh = MUR == 2 && ((fmask_r >> (16 + (dsl & 15))) & 1u);   // (written during this launch: agent-scope loads)
 #pragma unroll
           for (int i = 0; i <= NH; ++i) {
             const int k = 2 * i + (h ? 1 : 0);
-            in[i] = (isj && (k == NA || k < fdm1)) ? fslots[fslotW_at(lidx, ndec, dsl, frows, fcol + (k == NA ? fdm1 : k))] : T(0);
+            const T* src = fslots + fslotW_at(lidx, ndec, dsl, frows, fcol + (k == NA ? fdm1 : k));
+            in[i] = (isj && (k == NA || k < fdm1)) ? (coh ? cld<T>(reinterpret_cast<const char*>(src)) : *src) : T(0);
           }
           tail_sync();
 #pragma unroll
@@ -1735,8 +1852,12 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     }
     TAIL_TP(7)
    }
+    bool build_req = false;
+    if constexpr (SLICED && MUR == 2) {   // (parked with a build request: whoever unparks it builds the slot before the state is back in registers)
+      if (need_build) { need_build = false; requeue = true; build_req = true; }
+    }
     if (__builtin_expect(need_build, 0)) {   // (cold: the allocator's spills belong here, not in the iteration loop)
-    if constexpr (BUILD) {
+    if constexpr (BUILD && !(SLICED && MUR == 2)) {
       // the decade's own mu for the decade rule -- the columns k_fslots would have written --, the instance's mu for a rule off the
       // grid.  The builder's rows lie over BOTH slots in LDS: the other one is gone.
       T Sw6[6], hb[21], at[21], Wc[NA], dv;
@@ -1769,6 +1890,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       }
       kslot_o = -(1 << 30);
       kslot = kexp;
+      if constexpr (MUR == 2) publish_slot(kexp, Wc, dv);
       if (lane == 0) {
         atomicAdd(&Bf.counters[FLAT_COUNTERS_BUILT], 1u);
         if (MUR != 1) atomicAdd(&Bf.counters[FLAT_COUNTERS_DEC + (kexp < -16 ? 0 : kexp > 15 ? 31 : kexp + 16)], 1u);
@@ -1800,7 +1922,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
           }
         }
         const int dslp = kexp - kexp_lo;
-        __hip_atomic_store(ep, lidx | FLAT_PARKED | ((dslp >= 0 && dslp < ndec ? dslp : 15) << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int code = build_req ? (FLAT_BUILD_REQ | (((kexp + 8) & 15) << 24)) : ((dslp >= 0 && dslp < ndec ? dslp : 15) << 24);
+        __hip_atomic_store(ep, lidx | FLAT_PARKED | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (unsigned int spins = 0; got < 0; ++spins) {   // (entries were waiting when the slice ended: normally it is there)
           if (__hip_atomic_load(q_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)nslots) break;
           if (spins > (1u << 23)) { atomicOr(Bf.counters + FLAT_COUNTERS_ERR, 1u); break; }
@@ -1841,6 +1964,11 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     atomicOr(&Bf.counters[LEAN_DECADES_SEEN], n_slot_loads & 0xFFFFu);
   }
 }
+#undef topo
+#undef child_list
+#undef fmask
+#undef maxdepth
+#undef win_bits
 
 
 // ------------------------------------------------------------------------------------------------------------------------

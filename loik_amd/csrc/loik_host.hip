@@ -60,7 +60,8 @@ struct Tuning {
   bool flat = true;             // LOIKB_FLAT=0        never use k_flat (the engine without level loops, loik_flat.hpp)
   bool flat_split = true;       // LOIKB_FLAT_SPLIT=0: k_flat (one joint per lane) also where k_flat2 (two lanes per joint) applies
   int flat_split_wpe = 2;       // LOIKB_FLAT_WPE=3: k_flat2 built for three wavefronts per SIMD
-  int flat_build = 0;           // LOIKB_FLAT_BUILD=1: k_flat2 builds a decade slot its table lacks in-wave (flat_build_slot) instead of handing the instance to k_tail
+  int flat_win_lo = 0, flat_win_n = 0;   // LOIKB_FLAT_WINDOW=lo,n: (with LOIKB_FLAT_BUILD=1) k_fslots builds decades lo .. lo + n - 1 only, the rest lazily
+  int flat_build = 0;           // LOIKB_FLAT_BUILD=1: the lazily populated table on every k_flat2 launch (window: LOIKB_FLAT_WINDOW, else all of it), 2: on time-sliced launches, window from the handle's history; k_flat2 builds a decade slot its table lacks in-wave (flat_build_slot) instead of handing the instance to k_tail
   int fslot_dgrp = 0;           // LOIKB_FSLOT_DGRP=g: k_fslots takes the decades through its two passes g at a time (default: all)
   int flat_slice2 = 0;          // LOIKB_FLAT_SLICE2=q: an instance's later slices (0: as the first)
   int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's / k_flat1's round-robin time slice in iterations (0: never; default: 288 for
@@ -94,7 +95,8 @@ struct Tuning {
     if (!lean) flat = false;  // (LOIKB_LEAN=0 asks for the engines without precomputed factors: k_solve / k_tail)
     if (const char* e = getenv("LOIKB_FLAT_SPLIT")) flat_split = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_WPE")) flat_split_wpe = atoi(e) == 3 ? 3 : 2;
-    if (const char* e = getenv("LOIKB_FLAT_BUILD")) flat_build = atoi(e) != 0;
+    if (const char* e = getenv("LOIKB_FLAT_BUILD")) flat_build = std::max(0, std::min(2, atoi(e)));
+    if (const char* e = getenv("LOIKB_FLAT_WINDOW")) { if (sscanf(e, "%d,%d", &flat_win_lo, &flat_win_n) != 2) flat_win_n = 0; }
     if (const char* e = getenv("LOIKB_FLAT_SLICE")) flat_slice = std::min(65535, std::max(-1, atoi(e)));
     if (const char* e = getenv("LOIKB_FLAT_SLICE2")) flat_slice2 = std::min(32767, std::max(0, atoi(e)));
     if (const char* e = getenv("LOIKB_FSLOT_DGRP")) fslot_dgrp = std::max(0, atoi(e));
@@ -254,6 +256,9 @@ struct loikb_solver_impl {
     void* d_fslots = nullptr;            // decade slots of the flat engine (W rows, Dinv per joint and decade)
     size_t fslots_bytes = 0;
     void* d_park = nullptr;              // k_flat2<.., SLICED>: where instances whose time slice is used up are parked
+    unsigned int* d_fmask = nullptr;     // k_flat2<.., MUR = 2>: per instance, which decades of the slot table are populated
+    size_t fmask_n = 0;
+    void** d_aux = nullptr;              // k_flat2's cold pointers behind one argument: {TailTopo*, child list, fmask}
     size_t park_bytes = 0;
     std::vector<int> h_wave;             // host scratch for the compaction scan
     loikb_stats stats{};
@@ -284,6 +289,7 @@ struct loikb_solver_impl {
   // decades of mu the lean engine's instances actually visited in the solves of this handle so far (absolute exponents): the
   // next solve builds slots for [seen_lo - 1, seen_hi + 1] only (within the configured range); an escape widens it again
   int seen_lo = 1 << 20, seen_hi = -(1 << 20);
+  unsigned long long end_hist[32] = {0}, end_hist_n = 0;   // decades (kexp + 16) the instances of the last flat solve ended in
   // SolverInfo lists of a handle created with logging = 1 (k_pass_solve)
   double* d_log = nullptr;
   int* d_log_rows = nullptr;
@@ -1057,6 +1063,8 @@ void destroy_chunks(loikb_solver_impl* S)
     if (C.d_hslots) (void)hipFree(C.d_hslots);
     if (C.d_fslots) (void)hipFree(C.d_fslots);
     if (C.d_park) (void)hipFree(C.d_park);
+    if (C.d_fmask) (void)hipFree(C.d_fmask);
+    if (C.d_aux) (void)hipFree(C.d_aux);
     if (C.ev_k0) (void)hipEventDestroy(C.ev_k0);
     if (C.ev_k2) (void)hipEventDestroy(C.ev_k2);
     if (C.ev_k1) (void)hipEventDestroy(C.ev_k1);
@@ -1198,6 +1206,15 @@ int ensure_hslots(loikb_solver_impl* S)
         return LOIKB_ERR_HIP;
       }
       C.fslots_bytes = need;
+    }
+    if (S->flat.G == F2G && flat_takes_diagonal(S) && S->tune.flat_build) {   // (the lazily populated table's per-instance masks)
+      for (Chunk& C : S->chunks) {
+        if ((size_t)C.B <= C.fmask_n) continue;
+        if (C.d_fmask) HIPCHK(hipFree(C.d_fmask));
+        C.d_fmask = nullptr; C.fmask_n = 0;
+        HIPCHK(hipMalloc((void**)&C.d_fmask, sizeof(unsigned int) * (size_t)C.B));
+        C.fmask_n = (size_t)C.B;
+      }
     }
     // park records of the time-sliced launch (k_flat2 only: 17..32 joints): ~19 KB per instance, allocated for the batch sizes the
     // slices are used on (flat_slice_window); a handle that cannot have them simply runs unsliced
@@ -1728,6 +1745,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       const int lo = std::max(kexp_lo, S->seen_lo - 1), hi = std::min(kexp_lo + ndec - 1, S->seen_hi + 1);
       if (hi >= lo) { kexp_lo = lo; ndec = hi - lo + 1; }
     }
+    const int ndec_hist = ndec, kexp_lo_hist = kexp_lo;
     const size_t wave_lds = lean_lds_bytes<T>(S->nc, G, S->a_shared);
     // ---- the flat engine (loik_flat.hpp: no loops over the tree levels) takes the place of k_hslots + k_lean when the solve's
     // reference cost allows (H_ref = h I for all links)
@@ -1738,8 +1756,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       const int frows = S->flat.fblk;  // (scalars per decade slot of an instance, packed columns: loik_flat.hpp)
       // the rule that moves mu (k_flat2's MUR): 1 = OSQP's -- no table, every change of mu is an in-wave build --, 2 = decade steps with
       // the in-wave builder for the decades the table lacks (LOIKB_FLAT_BUILD=1), 0 = decade steps, the table or k_tail
-      const int mur = flat_any_mu(S) ? 1 : (S->tune.flat_build ? 2 : 0);
+      const bool can_build2 = S->tune.flat_build && G == F2G && small_na && sizeof(T) == 8 && S->tune.flat_split && C->d_fmask != nullptr &&
+                              !S->opt.logging && !S->per_link && href_is_scalar(S);
+      int mur = flat_any_mu(S) ? 1 : (can_build2 ? 2 : 0);
       if (mur == 1) { ndec = 1; kexp_lo = 0; }   // (the table holds mu0's slot: where every cold solve starts)
+      if (mur == 2) { ndec = S->plan.ndec; kexp_lo = S->plan.kexp_lo; }   // (the lazily populated table keeps its whole range: addresses, not work)
       const size_t need = (size_t)n_cur * ndec * frows * sizeof(T);
       if (need > C->fslots_bytes) { g_last_error = "internal: decade-slot buffer of the flat engine smaller than the chunk"; return LOIKB_ERR_STATE; }
       const int has_hv = S->Hv_inf_norm != 0.0;
@@ -1764,6 +1785,37 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       if (C->order_holdoff > 0) --C->order_holdoff;
       if (ordered) HIPCHK(hipMemcpyAsync(C->d_slots, C->d_order, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, C->stream));
       C->stats.flat_ordered += ordered ? 1 : 0;
+      // The decades k_fslots builds now: all of the table, or (MUR = 2) a window of it -- the rest is populated by the instances that get
+      // there (k_flat2<.., MUR = 2>, loik_flat2.hpp).  The window: LOIKB_FLAT_WINDOW=lo,n as given (any launch); else, for a time-sliced
+      // launch of a handle with a history, from the decade its previous solve's instances STARTED in (0 after a cold reset) to the one
+      // 97 % of them had ENDED in or below (k_order_count's histogram) -- the headline's instances end in decades 0..3 (8.7 / 23.8 / 60.6 /
+      // 6.9 %) of the 0..6 the handle's history says were visited by somebody: four decades built instead of nine, k_fslots 0.9 -> 0.55 ms,
+      // and the 0.2 % that go further build their slot once each (70 us).  Without a window the launch runs the build without the builder
+      // (MUR = 0: its iteration loop is 1-3 % shorter).
+      int dw0 = 0, nw = ndec;
+      if (mur == 2) {
+        int wlo = 0, whi = -1;
+        const int q = (split && !S->opt.logging) ? flat_slice_for(S, n, ordered) : 0;
+        if (S->tune.flat_win_n > 0) { wlo = S->tune.flat_win_lo; whi = wlo + S->tune.flat_win_n - 1; }
+        else if (S->tune.flat_build == 2 && q > 0 && C->d_park != nullptr && S->end_hist_n > 0) {
+          unsigned long long cum = 0;
+          int k03 = 99, k97 = 99;
+          for (int k = 0; k < 32; ++k) {
+            cum += S->end_hist[k];
+            if (k03 == 99 && cum * 100 >= 3ull * S->end_hist_n) k03 = k - 16;
+            if (k97 == 99 && cum * 100 >= 97ull * S->end_hist_n) k97 = k - 16;
+          }
+          wlo = std::min(0, k03); whi = std::max(0, k97);
+        }
+        const int lo = std::max(wlo, kexp_lo), hi = std::min(whi, kexp_lo + ndec - 1);
+        if (hi >= lo && (hi - lo + 1) < ndec) { dw0 = lo - kexp_lo; nw = hi - lo + 1; }
+        else if (S->tune.flat_build == 2) mur = 0;   // (auto: nothing to leave out -- the build without the builder)
+      }
+      if (mur == 0) {   // (the range the handle's history asks for, as ever)
+        ndec = ndec_hist; kexp_lo = kexp_lo_hist;
+        nw = ndec; dw0 = 0;
+      }
+      const int win_bits = (int)(((nw >= 16 ? 0xFFFFu : ((1u << nw) - 1u)) << dw0) & 0xFFFFu);
       if (ndec > 0) {
         const dim3 hgrid((unsigned)((n + ipw - 1) / ipw));
         // [65][22] exchange rows (pass B's L columns, [NA + 1][64], live in them afterwards) + [65][6] S^w + the constraints' A^T A + the decades' mu
@@ -1772,11 +1824,13 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         if (small_na)
           hipLaunchKernelGGL((k_fslots<T, FLAT_NA_SMALL>), hgrid, dim3(WAVE), slds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                              (const TailTopo*)S->d_topo, (const int*)S->d_child_list, (const FlatLane*)S->flat.d_lanes, S->maxdepth,
-                             nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, kexp_lo, ndec, S->tune.fslot_dgrp > 0 ? S->tune.fslot_dgrp : ndec);
+                             nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, kexp_lo, ndec, S->tune.fslot_dgrp > 0 ? S->tune.fslot_dgrp : nw,
+                             dw0, nw, mur == 2 ? C->d_fmask : (unsigned int*)nullptr);
         else
           hipLaunchKernelGGL((k_fslots<T, FLAT_MAXA>), hgrid, dim3(WAVE), slds, C->stream, P, Bf, (const JointDesc*)S->d_jd,
                              (const TailTopo*)S->d_topo, (const int*)S->d_child_list, (const FlatLane*)S->flat.d_lanes, S->maxdepth,
-                             nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, kexp_lo, ndec, S->tune.fslot_dgrp > 0 ? S->tune.fslot_dgrp : ndec);
+                             nanc, frows, S->flat.njmp, list, n, G, (T*)C->d_fslots, kexp_lo, ndec, S->tune.fslot_dgrp > 0 ? S->tune.fslot_dgrp : nw,
+                             dw0, nw, mur == 2 ? C->d_fmask : (unsigned int*)nullptr);
         HIPCHK(hipGetLastError());
       }
       HIPCHK(hipEventRecord(C->ev_k2, C->stream));
@@ -1812,6 +1866,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           // dependent trips to the L2 / HBM at ~2.5 us each when 2048 wavefronts share them), a slice of 64 iterations 190 us.
           // LOIKB_FLAT_SLICE=q switches it on.
           // End of round 4: ON again for arrival-order launches of >= 32 768 instances (flat_slice_for has the numbers).
+          if (C->d_aux == nullptr) HIPCHK(hipMalloc((void**)&C->d_aux, 4 * sizeof(void*)));
+          {
+            const void* auxh[4] = {S->d_topo, S->d_child_list, C->d_fmask, nullptr};
+            HIPCHK(hipMemcpyAsync(C->d_aux, auxh, sizeof(auxh), hipMemcpyHostToDevice, C->stream));
+          }
           const size_t park_need = (size_t)n_cur * flat2_park_stride(S->nc, true) * sizeof(double);
           (void)resident;
           int quantum = flat_slice_for(S, n, ordered);
@@ -1823,9 +1882,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
   hipLaunchKernelGGL((k_flat2<FLAT_NA_SMALL, WPE, ##__VA_ARGS__>), grid, dim3(WAVE), lds2, C->stream,                            \
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
                      (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
-                     (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv, C->ring_cap - 1, quantum,       \
-                     (double*)C->d_park, flat2_park_stride(S->nc, true), (const TailTopo*)S->d_topo, (const int*)S->d_child_list,   \
-                     S->maxdepth)
+                     (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv | ((S->maxdepth & 0xFF) << 8) | (win_bits << 16), C->ring_cap - 1, quantum,       \
+                     (double*)C->d_park, flat2_park_stride(S->nc, true), (const void* const*)C->d_aux)
           const int hm = S->per_link ? 3 : href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
           if (mur == 1) {   // (OSQP's rule: sliced only with H_ref = h I)
             if (hm == 3) { quantum = 0; LOIKB_LAUNCH_FLAT2(2, false, 3, false, 1); }
@@ -1834,7 +1892,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
             else if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 0, false, 1);
             else LOIKB_LAUNCH_FLAT2(2, false, 0, false, 1);
           }
-          else if (mur == 2 && hm == 0 && !S->opt.logging) {
+          else if (mur == 2) {
             if (quantum > 0) LOIKB_LAUNCH_FLAT2(2, true, 0, false, 2); else LOIKB_LAUNCH_FLAT2(2, false, 0, false, 2);
           }
           else if (S->opt.logging) {   // (the SolverInfo lists: unsliced; a diagonal reference weight goes as a general one)
@@ -1914,12 +1972,15 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       }
       int* next = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
       HIPCHK(hipEventRecord(C->ev_k1, C->stream));
-      HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
-      if (S->tune.flat_order && whole_set && n_first == n_cur && (split || one) && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS)) {
+      const bool order_pass = S->tune.flat_order && whole_set && n_first == n_cur && (split || one) && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS);
+      if (!order_pass) HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+      if (order_pass) {
         // the order for the handle's next solve: longest first by the iteration counts of this one (an instance that escaped to
-        // k_tail counts with what it had when it left)
+        // k_tail counts with what it had when it left); and the decades the instances ended in (the next sliced launch's table window)
         HIPCHK(hipMemsetAsync(C->d_order_bins, 0, sizeof(unsigned int) * 2 * ORDER_BINS, C->stream));
-        hipLaunchKernelGGL(k_order_count<T>, grid1(n_cur), dim3(256), 0, C->stream, A.tiles, S->L, n_cur, S->opt.max_iter, C->d_order_bins);
+        hipLaunchKernelGGL(k_order_count<T>, grid1(n_cur), dim3(256), 0, C->stream, A.tiles, S->L, n_cur, S->opt.max_iter, C->d_order_bins,
+                           C->d_counters + ORDER_DEC_HIST);
+        HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
         hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(ORDER_BINS), 0, C->stream, C->d_order_bins);
         hipLaunchKernelGGL(k_order_scatter<T>, grid1(n_cur), dim3(256), 0, C->stream, A.tiles, S->L, n_cur, S->opt.max_iter, C->d_order_bins, C->d_order);
         HIPCHK(hipGetLastError());
@@ -1942,6 +2003,14 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         for (int d = 0; d < 16; ++d)
           if (seen & (1u << d)) { S->seen_lo = std::min(S->seen_lo, kexp_lo + d); S->seen_hi = std::max(S->seen_hi, kexp_lo + d); }
         if (escaped) { S->seen_lo = S->plan.kexp_lo; S->seen_hi = S->plan.kexp_lo + S->plan.ndec - 1; }
+        if (order_pass) {   // (one chunk's instances; with several chunks the last one's: they resemble each other)
+          S->end_hist_n = 0;
+          for (int k = 0; k < 32; ++k) { S->end_hist[k] = C->h_counters[ORDER_DEC_HIST + k]; S->end_hist_n += S->end_hist[k]; }
+        }
+        if (mur == 2) {   // (the decades somebody took up, loaded or built: the handle's history as the table's range sees it)
+          for (int k = 0; k < 32; ++k)
+            if (C->h_counters[FLAT_COUNTERS_DEC + k]) { S->seen_lo = std::min(S->seen_lo, k - 16); S->seen_hi = std::max(S->seen_hi, k - 16); }
+        }
         S->ud_stale = true;
       }
       C->stats.hslots_ms += hms;
@@ -2424,7 +2493,7 @@ static int start_mu(loikb_solver_impl* S)
 {
   if (S->opt.mu_update_strat != LOIKB_MU_MAXEIGENVALUE) return LOIKB_OK;
   const double mu = spectral_mu0(S);
-  if (mu != S->mu_start) { S->seen_lo = 1 << 20; S->seen_hi = -(1 << 20); }  // the decades are counted from this mu
+  if (mu != S->mu_start) { S->seen_lo = 1 << 20; S->seen_hi = -(1 << 20); S->end_hist_n = 0; }  // the decades are counted from this mu
   S->mu_start = mu;
   return reset_home(S, RS_MU);
 }
@@ -3214,7 +3283,7 @@ int loikb_set_mu(loikb_solver* S, double v)
   if (!S) return LOIKB_ERR_ARG;
   S->opt.mu = v;
   ++S->inputs_epoch;
-  S->seen_lo = 1 << 20; S->seen_hi = -(1 << 20);  // the decades are counted from mu0: the history no longer applies
+  S->seen_lo = 1 << 20; S->seen_hi = -(1 << 20); S->end_hist_n = 0;  // the decades are counted from mu0: the history no longer applies
   return LOIKB_OK;
 }
 int loikb_set_tol(loikb_solver* S, double a, double r)
@@ -3261,7 +3330,10 @@ const char* loikb_plan_string(loikb_solver* S)
   if (pl.flat && flat_any_mu(S) && (flat_applicable(S) || !S->have_problem))
     out += "; OSQP penalty rule: mu is off the decade grid -- k_fslots builds mu0's slot only, k_flat2 builds W / Dinv in-wave at every change of mu";
   else if (pl.flat && S->tune.flat_build && (flat_applicable(S) || !S->have_problem))
-    out += "; LOIKB_FLAT_BUILD=1: a decade the table lacks is built in-wave (no hand-over to k_tail)";
+    out += S->tune.flat_build == 2 ? "; LOIKB_FLAT_BUILD=2: time-sliced launches of a handle with a history populate the decade table lazily -- k_fslots builds the "
+                                     "decades 97 % of the previous solve's instances ended within, an instance that goes further builds its slot in-wave, once"
+                                   : "; LOIKB_FLAT_BUILD=1: a decade of the table k_fslots did not build (LOIKB_FLAT_WINDOW=lo,n), or beyond the table, is built "
+                                     "in-wave by the instance that gets there (no hand-over to k_tail)";
   if (!pl.flat && *pl.why_not_flat) out += std::string("; no k_flat: ") + pl.why_not_flat;
   else if (pl.flat && S->have_problem && !flat_applicable(S))
     out += pl.lean ? "; no flat engine for this problem (per-link reference weights): k_hslots + k_lean take its place"

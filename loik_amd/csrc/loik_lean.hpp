@@ -44,7 +44,8 @@ constexpr int LCD = 26, LCA = 36;
 // [6] decade-slot loads, and the work queue:
 constexpr int LEAN_Q_HEAD = 7, LEAN_Q_TAIL = 8, LEAN_Q_REQUEUES = 9, LEAN_Q_RETIRED = 10;
 constexpr int LEAN_DECADES_SEEN = 11;  // bit d: some instance loaded the slot of decade kexp_lo + d in this launch
-constexpr int NCOUNTERS = 64;   // (32..63: k_flat2's per-decade slot counts, FLAT_COUNTERS_DEC)
+constexpr int NCOUNTERS = 96;   // (32..63: k_flat2's per-decade slot counts, FLAT_COUNTERS_DEC; 64..95: the decades the instances ENDED in, ORDER_DEC_HIST)
+constexpr int ORDER_DEC_HIST = 64;
 #ifndef LOIKB_POLL_MASK
 #define LOIKB_POLL_MASK 3u
 #endif
@@ -1031,16 +1032,27 @@ __device__ __forceinline__ int order_bin(char* tiles, const Layout& L, int b, in
   return ORDER_BINS - 1 - (k < 0 ? 0 : k > ORDER_BINS - 1 ? ORDER_BINS - 1 : k);   // (bin 0 = the longest)
 }
 // bins[0 .. ORDER_BINS) counts (zeroed by the caller)
+// dec_hist (may be null): [32] how many instances ended the solve in decade kexp = index - 16 of mu (clamped) -- what the handle's next
+// sliced launch sizes k_fslots' window with (the lazily populated table, loik_flat2.hpp)
 template <typename T>
-__global__ void __launch_bounds__(256) k_order_count(char* tiles, Layout L, int n, int max_iter, unsigned int* __restrict__ bins)
+__global__ void __launch_bounds__(256) k_order_count(char* tiles, Layout L, int n, int max_iter, unsigned int* __restrict__ bins,
+                                                     unsigned int* __restrict__ dec_hist = nullptr)
 {
-  __shared__ unsigned int h[ORDER_BINS];
+  __shared__ unsigned int h[ORDER_BINS], hd[32];
   h[threadIdx.x] = 0u;
+  if (threadIdx.x < 32) hd[threadIdx.x] = 0u;
   __syncthreads();
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < n) atomicAdd(&h[order_bin<T>(tiles, L, b, max_iter)], 1u);
+  if (b < n) {
+    atomicAdd(&h[order_bin<T>(tiles, L, b, max_iter)], 1u);
+    if (dec_hist != nullptr) {
+      const int kx = (int)ldp<T>(lane_ptr<T>(tiles, L, b) + (size_t)L.off_s * pair_bytes<T>(), SP_MU).y;
+      atomicAdd(&hd[kx < -16 ? 0 : kx > 15 ? 31 : kx + 16], 1u);
+    }
+  }
   __syncthreads();
   if (h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
+  if (dec_hist != nullptr && threadIdx.x < 32 && hd[threadIdx.x]) atomicAdd(&dec_hist[threadIdx.x], hd[threadIdx.x]);
 }
 // bins[ORDER_BINS .. 2 ORDER_BINS) <- exclusive prefix sums of the counts (one workgroup of ORDER_BINS threads)
 __global__ void __launch_bounds__(ORDER_BINS) k_order_scan(unsigned int* __restrict__ bins)

@@ -447,8 +447,12 @@ def test_flat_engine_builds_the_decades_its_table_lacks(talos, monkeypatch):
     wl = workloads.talos_c3(B, seed=321)
     prm = dict(wl["params"], max_iter=400)
     args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
-    names = ("LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_ADAPT", "LOIKB_FLAT_BUILD", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_WG_PER_CU")
+    names = ("LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_ADAPT", "LOIKB_FLAT_BUILD", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_WG_PER_CU", "LOIKB_FLAT_WINDOW")
+    # (LOIKB_FLAT_WINDOW=lo,n: the table keeps its whole range and k_fslots populates decades lo .. lo + n - 1 of it; what an instance
+    #  builds in-wave goes into the table too -- its later visits of the decade load it --, also from a wavefront of another XCD)
     cases = (("table", dict()),
+             ("window_of_one", dict(LOIKB_FLAT_BUILD="1", LOIKB_FLAT_WINDOW="0,1")),
+             ("window_of_one_sliced", dict(LOIKB_FLAT_BUILD="1", LOIKB_FLAT_WINDOW="1,1", LOIKB_FLAT_SLICE="7", LOIKB_LEAN_WG_PER_CU="1")),
              ("one_decade", dict(LOIKB_LEAN_KLO="0", LOIKB_LEAN_DECADES="1", LOIKB_LEAN_ADAPT="0", LOIKB_FLAT_BUILD="1")),
              ("no_decade_of_use", dict(LOIKB_LEAN_KLO="-2", LOIKB_LEAN_DECADES="1", LOIKB_LEAN_ADAPT="0", LOIKB_FLAT_BUILD="1")),
              ("one_decade_sliced", dict(LOIKB_LEAN_KLO="1", LOIKB_LEAN_DECADES="1", LOIKB_LEAN_ADAPT="0", LOIKB_FLAT_BUILD="1", LOIKB_FLAT_SLICE="7",
@@ -466,6 +470,8 @@ def test_flat_engine_builds_the_decades_its_table_lacks(talos, monkeypatch):
         assert (st["flat_built"] > B // 2) == (name != "table"), (name, st["flat_built"])
         if name != "table":
             assert "in-wave" in s.plan(), s.plan()
+        if name.startswith("window"):   # (every (instance, decade) pair is built at most once: the table remembers)
+            assert st["flat_built"] < 4 * B, (name, st["flat_built"])
         res[name] = {k: s.get(k) for k in ("iter", "converged", "primal_infeasible", "z", "nu", "mu", "yis", "fis", "vis", "w")}
         s.close()
     for name, _ in cases[1:]:
@@ -473,6 +479,31 @@ def test_flat_engine_builds_the_decades_its_table_lacks(talos, monkeypatch):
             assert np.array_equal(res["table"][k], res[name][k]), (name, k, np.abs(res["table"][k] - res[name][k]).max())
     out = ref.solve_batch(talos, *args, nthreads=8, want_nu=True, **prm)
     assert (res["one_decade"]["iter"] == out["iters"]).mean() > 0.99
+
+
+def test_flat_lazy_table_window_from_the_handles_history(talos, monkeypatch):
+    """LOIKB_FLAT_BUILD=2: a time-sliced launch (32 768+ instances in arrival order) of a handle with a history lets k_fslots build only the
+    decades 97 % of the previous solve's instances ended within; whoever goes further builds its slot in-wave, once, into the table.
+    Same bits as the full table; fewer decades built (the slot kernel's share of the launch shrinks)."""
+    from loik_amd import workloads
+    B = 32768
+    wa, wb = workloads.talos_c3(B, seed=11), workloads.talos_c3(B, seed=12)
+    args = lambda w: (w["q"], w["H_ref"], w["v_ref"], w["c_ids"], w["Ais"], w["bis"], w["lb"], w["ub"])
+    res, slots = {}, {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("LOIKB_FLAT_BUILD", mode)
+        s = loik_amd.BatchedLoik(talos, B, **wa["params"])
+        s.Solve(*args(wa))                       # the history
+        s.Solve(*args(wb))                       # a new batch: arrival order, sliced
+        st = s.stats()
+        assert st["flat_split_launches"] == 1 and st["flat_ordered"] == 0 and st["lean_requeues"] > 0 and st["lean_escaped"] == 0, st
+        assert (st["flat_built"] > 0) == (mode == "2"), st
+        res[mode] = {k: s.get(k) for k in ("iter", "converged", "primal_infeasible", "z", "nu", "mu", "yis")}
+        slots[mode] = st["hslots_ms"]
+        s.close()
+    for k in res["0"]:
+        assert np.array_equal(res["0"][k], res["2"][k]), k
+    assert slots["2"] < 0.8 * slots["0"], slots
 
 
 def test_flat_time_slicing_changes_nothing(talos, monkeypatch):
