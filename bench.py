@@ -52,6 +52,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP32_VALU_PEAK_TF = 157.3   # same guide: peak FP32 (vector)
 FP64_VALU_PEAK_TF = 78.6    # fp64 vector FMA issues at half the fp32 vector rate (4 cycles per wave64 instruction)
+FP64_VALU_MEASURED_TF = 55.5  # independent v_fma_f64 streams on all 256 CUs, two wavefronts per SIMD x 8 chains (scripts/ubench/fp64_rate.hip, profiles/r05_a_fp64_rate.txt)
 FLOPS_PER_JOINT_ITERATION = 935  # ~935 flop per joint and ADMM iteration
 HEADLINE_BATCH = 65536
 
@@ -407,6 +408,9 @@ def kernel_roofline(acc, last, steps, nb, nc, B):
         traffic = pmc_bytes(name)
         r = {"bound": "fp64_valu", "kernel": name, "achieved": ach, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
              "frac": ach / FP64_VALU_PEAK_TF,
+             # what a kernel of nothing but independent v_fma_f64 reaches on all 256 CUs of this part (scripts/ubench/fp64_rate.hip, two
+             # wavefronts per SIMD x 8 chains: profiles/r05_a_fp64_rate.txt; one CU alone: 65.8): the clock under full fp64 load
+             "peak_measured_dense_fma": FP64_VALU_MEASURED_TF, "frac_of_measured_peak": ach / FP64_VALU_MEASURED_TF,
              "traffic": traffic,
              "flops_per_unit": flops_iter,
              "unit_def": "one ADMM iteration of one instance: 935 flop x nb (nb = %d), SURVEY.md 8(d)" % nb,
@@ -440,11 +444,16 @@ def kernel_roofline(acc, last, steps, nb, nc, B):
             if "valu_active_quadcycles_per_dispatch" in pk[name]:
                 # SQ_ACTIVE_INST_VALU counts 4-cycle units in which a SIMD's VALU executes an instruction, summed over the SIMDs:
                 # the share of the launch in which the vector ALUs were at work (the tools' VALUBusy)
-                r["valu_busy_frac"] = pk[name]["valu_active_quadcycles_per_dispatch"] * 4.0 / (4 * ncu * avg_ms * 1e-3 * clk * 1e9)
-                r["valu_busy_note"] = ("two wavefronts per SIMD at 256 registers each; a wavefront issues one vector instruction per ~8 "
-                                       "cycles at best and its fp64 chains are 32 cycles deep: the launch is bound by the latency of "
-                                       "dependent fp64 instructions, not by the ALUs' throughput (a third wavefront per SIMD needs 168 "
-                                       "registers and 13 KB of LDS: the build that has them spills and is 10 % slower)")
+                r["valu_busy_frac_at_nominal_clock"] = pk[name]["valu_active_quadcycles_per_dispatch"] * 4.0 / (4 * ncu * avg_ms * 1e-3 * clk * 1e9)
+                r["valu_busy_frac"] = pk[name].get("valu_busy_frac_of_actual_cycles", r["valu_busy_frac_at_nominal_clock"])
+                if "shader_cycles_per_dispatch" in pk[name]:
+                    r["shader_clock_ghz_measured"] = pk[name]["shader_cycles_per_dispatch"] / (avg_ms * 1e-3) / 1e9
+                r["lds_pipe_busy_frac"] = pk[name].get("lds_pipe_busy_frac_of_actual_cycles")
+                r["valu_busy_note"] = ("SQ_ACTIVE_INST_VALU x 4 over the SIMD-cycles the dispatch actually took (GRBM_GUI_ACTIVE / 8 XCDs): with every "
+                                       "SIMD on fp64 work the chip runs at ~2.06 GHz, not the data sheet's 2.4 (`.._at_nominal_clock` is round 4's "
+                                       "figure).  Two wavefronts per SIMD at 256 registers; the vector ALUs AND the CU's LDS pipe are each busy in "
+                                       "more than half of the cycles, a wavefront issues in order: a third wavefront per SIMD (168 registers, "
+                                       "12.7 KB of LDS: built and measured in round 5, profiles/r05_a_pmc_wpe2_vs_wpe3.txt) adds no throughput")
             r["valu_insts_per_instance_iteration"] = pk[name].get("valu_insts_per_instance_iteration")
             r["lds_bank_conflict_frac"] = pk[name].get("lds_bank_conflict_frac")
         if pmc:

@@ -310,7 +310,7 @@ constexpr int PATH_RS = WAVE + 2;
 // PB2 (a build for joints with at most 11 ancestors): the second round has the ancestors at distance 4 and 8 only and there is no third
 // round; the two offsets are the fields <20, 10> of pb and <22, 10> of pc -- bits the caller's other packed words have to spare (one
 // register less across the loop), and the row of the ancestor at distance 12, which does not exist, is not read.
-template <typename T, int NC, bool PB2 = false>
+template <typename T, int NC, int PB2 = 0>
 __device__ __forceinline__ void flat_path_sum4(T* rows, int lane, unsigned int pa, unsigned int pb, unsigned int pc, int njmp, T* y, unsigned int tok)
 {
   tail_sync();
@@ -338,7 +338,9 @@ __device__ __forceinline__ void flat_path_sum4(T* rows, int lane, unsigned int p
   if constexpr (PB2) {
     if (njmp > 2) {
       publish();
-      const unsigned int r0 = field_here<20, 10>(pb, tok), r1 = field_here<22, 10>(pc, tok);
+      // (PB2 = 2, k_flat1: both in pb's upper half as LANES, eight bits each -- the word holds lane numbers)
+      const unsigned int r0 = PB2 == 2 ? field_here<16, 8>(pb, tok) * 8u : field_here<20, 10>(pb, tok),
+                         r1 = PB2 == 2 ? field_here<24, 8>(pb, tok) * 8u : field_here<22, 10>(pc, tok);
       T a[NC], b[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) a[c] = lds_at(rows + c * PATH_RS, r0);
@@ -1479,7 +1481,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       T y[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) y[k] = Sw3[k] * nui;
-      if constexpr (PB2) flat_path_sum4<T, 3, true>(xb, lane, pathA, anc3[(NH + 2) / 3 - 1], cb_pk, njmp, y, itok);
+      if constexpr (PB2) flat_path_sum4<T, 3, 1>(xb, lane, pathA, anc3[(NH + 2) / 3 - 1], cb_pk, njmp, y, itok);
       else flat_path_sum4<T, 3>(xb, lane, pathA, pathB, pathC, njmp, y, itok);
       if (jcslot >= 0) {  // the constrained links' velocities at the world origin: the task constraints' update starts from them
 #pragma unroll
@@ -2052,6 +2054,9 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   int size, fcol, fdm1;  // (fcol, fdm1: this joint's column in a packed decade slot, its number of ancestors)
   bool helper;
   unsigned int jrow4[(FLAT_JMP + 3) / 4], ra2[FLAT_RED / 2], prow4[(FLAT_PART + 3) / 4], anc4[(NA + 3) / 4];
+  // (at most 11 ancestors: the path sum's second round has the ancestors at distance 4 and 8 only, their lanes ride in the spare half of
+  //  the last word of anc4, and there is no third round: flat_path_sum4<.., 2>)
+  constexpr bool PB2F1 = NA <= 11 && (NA % 4) != 0 && (NA % 4) <= 2;
   unsigned int pathA, pathB, pathC;
   flat_path_rows4(fl, j, 0, pathA, pathB, pathC);
   {
@@ -2075,6 +2080,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     for (int q = 0; q < FLAT_PART; ++q) prow4[q >> 2] |= (unsigned int)(F.part[q] >= 0 ? F.part[q] : WAVE) << (8 * (q & 3));
 #pragma unroll
     for (int k = 0; k < NA; ++k) anc4[k >> 2] |= (unsigned int)((k < FLAT_MAXA && F.anc[k] >= 0) ? F.anc[k] : WAVE) << (8 * (k & 3));
+    if constexpr (PB2F1) anc4[(NA + 3) / 4 - 1] |= (((pathB & 0x3FFu) / 8u) << 16) | ((((pathB >> 10) & 0x3FFu) / 8u) << 24);   // (ancestors at distance 4 and 8, as lanes)
   }
   if (lane < 2) { nbuf[G + lane] = T(0); pbuf[G + lane] = T(0); }
   for (int e = lane; e < (one_buf ? 1 : 2) * (NA + 1) * G; e += WAVE) wl[e] = T(0);
@@ -2492,7 +2498,8 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       T vw[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) vw[k] = Sw[k] * nui;
-      flat_path_sum4<T, 6>(xb, lane, pathA, pathB, pathC, njmp, vw, itok);
+      if constexpr (PB2F1) flat_path_sum4<T, 6, 2>(xb, lane, pathA, anc4[(NA + 3) / 4 - 1], 0u, njmp, vw, itok);
+      else flat_path_sum4<T, 6>(xb, lane, pathA, pathB, pathC, njmp, vw, itok);
       if (jcslot >= 0) {  // the constrained links' velocities at the world origin: the task constraints' update starts from them
 #pragma unroll
         for (int k = 0; k < 6; ++k) cdi[jcslot * cs + C2_VC + k] = vw[k];

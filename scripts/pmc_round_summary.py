@@ -35,7 +35,9 @@ for k, d in tot.items():
                      ("SQ_INSTS_LDS", "lds_insts_per_step"), ("SQ_WAVE_CYCLES", "wave_cycles_per_step"),
                      ("SQ_BUSY_CYCLES", "busy_cycles_per_step"), ("SQ_WAIT_INST_LDS", "wait_inst_lds_per_step"),
                      ("SQ_ACTIVE_INST_VALU", "valu_active_quadcycles_per_step"), ("SQ_ACTIVE_INST_ANY", "any_active_quadcycles_per_step"),
-                     ("SQ_WAIT_ANY", "wait_any_per_step"), ("SQ_WAIT_INST_ANY", "wait_inst_any_per_step")]:
+                     ("SQ_WAIT_ANY", "wait_any_per_step"), ("SQ_WAIT_INST_ANY", "wait_inst_any_per_step"),
+                     ("GRBM_GUI_ACTIVE", "gui_active_cycles_x8_per_step"), ("SQ_LDS_IDX_ACTIVE", "lds_idx_active_cycles_per_step"),
+                     ("SQ_ACTIVE_INST_LDS", "lds_active_quadcycles_per_step")]:
         if c in d:
             e[label] = d[c] / nsolves
     if "SQ_ACTIVE_INST_LDS" in d and d["SQ_ACTIVE_INST_LDS"] > 0 and "SQ_LDS_BANK_CONFLICT" in d:
@@ -43,14 +45,30 @@ for k, d in tot.items():
     out["kernels"][k] = e
 # per DISPATCH figures (the bench's default line runs W + K handles, each with one history solve before its timed one: dispatches
 # per "step" of the profiled command is not 1) and instructions per instance-iteration of the dominant kernel
+# GRBM_GUI_ACTIVE is summed over the eight XCDs: / 8 = the shader cycles the dispatch took AT THE CLOCK IT RAN AT (a launch that keeps
+# every SIMD on fp64 work runs at ~2.06 GHz, not at the 2.4 GHz of the data sheet: the busy fractions below are of THOSE cycles)
 for k, e in out["kernels"].items():
     n = max(e.get("dispatches_per_step", 1.0) * nsolves, 1.0)
     for src, dst in (("fetch_bytes_per_step", "fetch_bytes_per_dispatch"), ("write_bytes_per_step", "write_bytes_per_dispatch"),
                      ("valu_insts_per_step", "valu_insts_per_dispatch"), ("lds_insts_per_step", "lds_insts_per_dispatch"),
                      ("salu_insts_per_step", "salu_insts_per_dispatch"), ("valu_active_quadcycles_per_step", "valu_active_quadcycles_per_dispatch"),
-                     ("wave_cycles_per_step", "wave_cycles_per_dispatch"), ("wait_any_per_step", "wait_any_per_dispatch")):
+                     ("wave_cycles_per_step", "wave_cycles_per_dispatch"), ("wait_any_per_step", "wait_any_per_dispatch"),
+                     ("gui_active_cycles_x8_per_step", "gui_active_cycles_x8_per_dispatch"),
+                     ("lds_idx_active_cycles_per_step", "lds_idx_active_cycles_per_dispatch"),
+                     ("lds_active_quadcycles_per_step", "lds_active_quadcycles_per_dispatch")):
         if src in e:
             e[dst] = e[src] * nsolves / n
+for k, e in out["kernels"].items():
+    if "gui_active_cycles_x8_per_dispatch" in e:
+        cyc = e["gui_active_cycles_x8_per_dispatch"] / 8.0
+        e["shader_cycles_per_dispatch"] = cyc
+        simd_cycles = 4 * out["compute_units"] * cyc
+        if "valu_active_quadcycles_per_dispatch" in e:
+            e["valu_busy_frac_of_actual_cycles"] = e["valu_active_quadcycles_per_dispatch"] * 4.0 / simd_cycles
+        if "lds_idx_active_cycles_per_dispatch" in e:
+            e["lds_pipe_busy_frac_of_actual_cycles"] = e["lds_idx_active_cycles_per_dispatch"] / (out["compute_units"] * cyc)
+        if "wait_any_per_dispatch" in e and "wave_cycles_per_dispatch" in e:
+            e["wave_time_in_waitcnt_frac"] = e["wait_any_per_dispatch"] / e["wave_cycles_per_dispatch"]
 try:
     line = json.loads(open(os.path.join(out_dir, "bench_line.json")).read().strip().splitlines()[-1])
     out["bench_ms_per_step"] = line["ms_per_step"]

@@ -18,7 +18,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace"
 echo "trace exit $?"
 find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 STEPS=3
-for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+for C in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_LDS SQ_INSTS_SMEM"; do
   D=$OUT/pmc_$(echo $C | tr ' ' '_' | cut -c1-40)
   mkdir -p "$D"
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$D" -o pmc -- python "$REPO/bench.py" --no-cpu-baseline --no-variants --steps 2 --warmup 1 "$@" > "$D/log.txt" 2>&1
