@@ -600,6 +600,9 @@ __device__ __forceinline__ X held(X x)
 // by the wavefront itself (flat_build_slot) -- a build of its own because the builder's presence costs the iteration loop a few scratch
 // reloads (LOIKB_FLAT_BUILD=1 selects it).  1: OSQP's rule (update_mu, loik_device.hpp): mu is any number, there is no table, every change
 // of mu is one in-wave build; every iteration folds the two norms the rule needs and walks the whole stopping logic (no quiet shortcut).
+#ifndef LOIKB_TAU_AHEAD
+#define LOIKB_TAU_AHEAD 1
+#endif
 constexpr int FLAT_COUNTERS_BUILT = 17;  // Bufs::counters[17]: decade slots built in-wave during the launch
 constexpr int FLAT_COUNTERS_DEC = 32;    // Bufs::counters[32 .. 63]: slots taken up (loaded or built) per decade kexp + 16
 template <int NA, int WPE, bool SLICED = false, int HM = 0, bool LOG = false, int MUR = 0>
@@ -622,6 +625,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   // fmask (MUR = 2): per instance, bit d: decade d of the table is there (k_fslots' window, win_bits, or built during the launch);
   // bit 16 + d: built during the launch, possibly by a wavefront of another XCD: fetched with agent-scope loads
   constexpr bool BUILD = MUR >= 1;
+  constexpr bool TAU_AHEAD = (LOIKB_TAU_AHEAD != 0) && !LOG;   // (the next iteration's tau formed beside this iteration's f: see `after_tau`)
   static_assert(flat_build_scratch<F2G>() <= flat2_off_nbuf<NA>(), "the in-wave builder's rows must end before the buffers the iteration keeps");
   using T = double;
   static_assert(NA % 2 == 0, "the W entries of a joint are dealt out to its two lanes");
@@ -1409,20 +1413,21 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     if (exit_now) break;
     const T* wcur = wl + (size_t)wsel * (NA + 1) * GW;
     TAIL_TP(8)
-   next_iteration:   // (a quiet iteration comes straight back here: nothing above can have changed)
-    const unsigned int itok = my_iters + 1u;   // (changes every iteration: see field_here)
-    const unsigned int h3b = (opaque_here((unsigned int)lane, itok) >> 5) * 24u;   // byte offset of this half in a 6-vector of a constraint block
-    const T mu_eq = P.mu_scale * mu, mu_in = mu;
-    ++my_iters; any_iter = true;
-    ++n_wave_iters;
-
+   next_iteration:   // (a quiet iteration of a build without LOIKB_TAU_AHEAD comes straight back here: nothing above can have changed)
+    unsigned int itok = my_iters + 1u;   // (changes every iteration: see field_here)
+    unsigned int h3b = (opaque_here((unsigned int)lane, itok) >> 5) * 24u;   // byte offset of this half in a 6-vector of a constraint block
     // ================= p^base at the world origin, summed over the subtrees; tau  (FwdPass1 + the p part of BwdPass) ===========
-    T wc[NH];  // this lane's share of the joint's W entries (ancestors k = 2 i + h): used twice, up and down
+    // (only the iterations that come through the loop's top form tau here.  A quiet iteration has formed the NEXT iteration's tau
+    //  already, beside the chain that ends in f -- everything tau needs is final by then: the new subtree sums, w, z, the constraints'
+    //  A^T y at the origin -- and goes straight to `after_tau`: the ~500 cycles of dependent steps a lone wavefront spent here at the
+    //  start of every iteration, with nothing else to issue, now run under the f chain's own latencies)
+    T tau, tau2 = T(0);
+    T wc[NH], dinv;  // this lane's share of the joint's W entries (ancestors k = 2 i + h): used twice, up and down
 #pragma unroll
     for (int i = 0; i < NH; ++i) wc[i] = wcur[(2 * i + (h ? 1 : 0)) * GW + j];
-    const T dinv = wcur[NA * GW + j];
-    T tau;
+    dinv = wcur[NA * GW + j];
     {
+      const T mu_eq = P.mu_scale * mu, mu_in = mu;
       T PB[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) PB[k] = -P.rho * SE3[k];
@@ -1439,6 +1444,10 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       const T d3 = Sw3[0] * PB[0] + Sw3[1] * PB[1] + Sw3[2] * PB[2];
       tau = (w - mu_in * z) + pair_sum(d3);
     }
+   after_tau:
+    const T mu_eq = P.mu_scale * mu, mu_in = mu;
+    ++my_iters; any_iter = true;
+    ++n_wave_iters;
     TAIL_TP(0)
     // ================= r' = W tau: products to LDS, every lane sums its share, long rows collect their partials ================
     tail_sync();
@@ -1529,7 +1538,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T s_dy = T(0), s_av = T(0), s_ek = T(0);
     T l_dfis = T(0), l_dvis = T(0), s_dnu = T(0), s_dz = T(0), s_dw = T(0), s_prs = T(0);
     T l_dg = T(0), s_stf = T(0), s_dstf = T(0), l_dualv = T(0);
-    T fi3[3], si;
+    T fi3[3], si, d32 = T(0);
     {
       T SEn[3], SHn[3], Fw[3];  // (SHn: HD only -- the subtree sums of the links' H_ref v at the world origin)
       // ---- the task constraints' update: (A v - b, dy, y), then the constraint's force AW y at the world origin: two dependent
@@ -1643,15 +1652,24 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       TAIL_TP(4)
 #pragma unroll
       for (int k = 0; k < 3; ++k) Fw[k] = HD ? P.rho * (SEn[k] - SE3[k]) + SHn[k] : (P.rho + href_s) * SEn[k] - P.rho * SE3[k];
+      // (TAU_AHEAD: the next iteration's p^base beside this iteration's F -- the operations of the loop's top, in its order, on the values
+      //  the next iteration would find: SE3 <- SEn, the blocks' A^T y at the origin as the task update just left it)
+      T PB2[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) PB2[k] = -P.rho * SEn[k];
       if (has_hv) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) Fw[k] -= shv[j * 6 + h3 + k];
+        for (int k = 0; k < 3; ++k) { Fw[k] -= shv[j * 6 + h3 + k]; if (TAU_AHEAD) PB2[k] -= shv[j * 6 + h3 + k]; }
       }
       for (int c = 0; c < L.nc; ++c) {
         const T* c_ = reinterpret_cast<const T*>(reinterpret_cast<const char*>(cdi + c * cs) + h3b);
         const T m = cmask(c);
 #pragma unroll
         for (int k = 0; k < 3; ++k) Fw[k] += m * c_[C2_ATYF + k];
+        if constexpr (TAU_AHEAD) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) PB2[k] += m * (c_[C2_ATYW + k] - mu_eq * c_[C2_ATBW + k]);
+        }
       }
       {
         // SE3::actInv(Force): (R0^T F_l, R0^T (F_a - t0 x F_l)): the angular lane needs the linear half
@@ -1667,6 +1685,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         const T d3 = Sw3[0] * Fw[0] + Sw3[1] * Fw[1] + Sw3[2] * Fw[2];
         si = pair_sum(d3);  // S^T f (hxx:231-233): the pairing of a motion and a force does not depend on the frame
       }
+      if constexpr (TAU_AHEAD) d32 = Sw3[0] * PB2[0] + Sw3[1] * PB2[1] + Sw3[2] * PB2[2];   // (its pair sum: in the fold's block, below)
 #pragma unroll
       for (int k = 0; k < 3; ++k) SE3[k] = SEn[k];
     }
@@ -1721,6 +1740,14 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         if (iter > q_lim) continue;   // (SLICED: the slice ends -- through the loop's top)
         goto next_iteration;
       }
+      // (the next iteration's tau: its exchange between the halves runs beside the fold's -- two independent chains in one block)
+      T wcn[NH], dinvn = T(0);   // (and its W entries: fetched here, so that the round trip to LDS is over when the iteration starts)
+      if constexpr (TAU_AHEAD) {
+        tau2 = (w - mu_in * z) + pair_sum(d32);
+#pragma unroll
+        for (int i = 0; i < NH; ++i) wcn[i] = wcur[(2 * i + (h ? 1 : 0)) * GW + j];
+        dinvn = wcur[NA * GW + j];
+      }
       wave_fold4<0u>(lane, in, r);
       primal = r[0]; dual = r[1]; dyqp = r[2]; atdy = r[3];
 #ifdef LOIKB_DBG_QUIET
@@ -1752,7 +1779,16 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         if (quiet) {
           ++iter;
           TAIL_TP(7)
-          if (LOIKB_QUIET_SKIPS_TOP && iter <= q_lim) goto next_iteration;
+          if (LOIKB_QUIET_SKIPS_TOP && iter <= q_lim) {
+            if constexpr (TAU_AHEAD) {
+              tau = tau2; itok = my_iters + 1u; h3b = (opaque_here((unsigned int)lane, itok) >> 5) * 24u;
+#pragma unroll
+              for (int i = 0; i < NH; ++i) wc[i] = wcn[i];
+              dinv = dinvn;
+              goto after_tau;
+            }
+            goto next_iteration;
+          }
           continue;
         }
       }
