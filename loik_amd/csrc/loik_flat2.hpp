@@ -603,6 +603,9 @@ __device__ __forceinline__ X held(X x)
 #ifndef LOIKB_TAU_AHEAD
 #define LOIKB_TAU_AHEAD 1
 #endif
+#ifndef LOIKB_HELD_ALWAYS
+#define LOIKB_HELD_ALWAYS 0
+#endif
 constexpr int FLAT_COUNTERS_BUILT = 17;  // Bufs::counters[17]: decade slots built in-wave during the launch
 constexpr int FLAT_COUNTERS_DEC = 32;    // Bufs::counters[32 .. 63]: slots taken up (loaded or built) per decade kexp + 16
 template <int NA, int WPE, bool SLICED = false, int HM = 0, bool LOG = false, int MUR = 0>
@@ -640,8 +643,9 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   //  ones shorter, so that the instances still running when the queue is empty have done the same number of iterations to within that)
   const int slice_len = (SLICED && quantum > 0) ? (quantum & 0xffff) : 0x3fffffff;
   const int slice_len2 = (SLICED && (quantum >> 16) > 0) ? (quantum >> 16) : slice_len;
-  const double tol_abs_h = held<SLICED || WPE >= 3 || MUR >= 1>(P.tol_abs), tpi_h = held<SLICED || WPE >= 3 || MUR >= 1>(P.tol_primal_inf);
-  const int max_iter_h = held<SLICED || WPE >= 3 || MUR >= 1>(P.max_iter);
+  // (LOIKB_HELD_ALWAYS=1 -- the plain build too, whose quiet test re-fetches them since round 5 -- measured: lone 2.278 -> 2.325 us, bulk +0.5 %: not adopted)
+  const double tol_abs_h = held<LOIKB_HELD_ALWAYS || SLICED || WPE >= 3 || MUR >= 1>(P.tol_abs), tpi_h = held<LOIKB_HELD_ALWAYS || SLICED || WPE >= 3 || MUR >= 1>(P.tol_primal_inf);
+  const int max_iter_h = held<LOIKB_HELD_ALWAYS || SLICED || WPE >= 3 || MUR >= 1>(P.max_iter);
   const int j = lane & 31;       // lanes j and 32 + j <-> device joint j + 1
   const bool h = lane >= 32;     // 0: linear halves, 1: angular halves
   const int h3 = h ? 3 : 0;
