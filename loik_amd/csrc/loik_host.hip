@@ -1885,7 +1885,10 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                      (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv | ((S->maxdepth & 0xFF) << 8) | (win_bits << 16), C->ring_cap - 1, quantum,       \
                      (double*)C->d_park, flat2_park_stride(S->nc, true), (const void* const*)C->d_aux)
           const int hm = S->per_link ? 3 : href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
-          if (mur == 1) {   // (OSQP's rule: sliced only with H_ref = h I)
+          if (mur == 1) {
+            // (OSQP's rule runs unsliced unless LOIKB_FLAT_SLICE asks: a parked instance rebuilds its factors when it is taken up again --
+            //  headline batch, first solve: 12.7 ms with the default slices, 11.4 without: profiles/r05_d_mu_rules.jsonl)
+            if (S->tune.flat_slice < 0) quantum = 0;
             if (hm == 3) { quantum = 0; LOIKB_LAUNCH_FLAT2(2, false, 3, false, 1); }
             else if (hm == 2) { quantum = 0; LOIKB_LAUNCH_FLAT2(2, false, 2, false, 1); }
             else if (hm == 1) { quantum = 0; LOIKB_LAUNCH_FLAT2(2, false, 1, false, 1); }
