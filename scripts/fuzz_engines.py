@@ -36,9 +36,14 @@ ENGINES = {
     # the same solve a second time on the handle: longest-first order from the first one, no fetch of the zero state (compared: the second)
     "flat_ordered": ({"LOIKB_FLAT_ORDER_HOLDOFF": "0"}, {}),
     "lean_ordered": ({"LOIKB_FLAT": "0", "LOIKB_FLAT_ORDER_HOLDOFF": "0"}, {}),   # the same with k_lean
+    # round 5: decades outside a narrow table built in-wave (k_flat2<.., MUR = 2>); the lazily populated table (k_fslots builds one decade of
+    # it, the rest is built by the instances that get there, into the table), plain and with forced time slices (parked build requests)
+    "flat_builds": ({"LOIKB_FLAT_BUILD": "1", "LOIKB_LEAN_KLO": "1", "LOIKB_LEAN_DECADES": "2", "LOIKB_LEAN_ADAPT": "0"}, {}),
+    "flat_lazy": ({"LOIKB_FLAT_BUILD": "1", "LOIKB_FLAT_WINDOW": "0,1"}, {}),
+    "flat_lazy_sliced": ({"LOIKB_FLAT_BUILD": "1", "LOIKB_FLAT_WINDOW": "1,1", "LOIKB_FLAT_SLICE": "7", "LOIKB_LEAN_WG_PER_CU": "1"}, {}),
 }
 ENV_KEYS = ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE",
-            "LOIKB_LEAN_WG_PER_CU", "LOIKB_FLAT_ORDER_HOLDOFF")
+            "LOIKB_LEAN_WG_PER_CU", "LOIKB_FLAT_ORDER_HOLDOFF", "LOIKB_FLAT_BUILD", "LOIKB_FLAT_WINDOW", "LOIKB_LEAN_ADAPT")
 
 
 def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
@@ -99,14 +104,15 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
                 M = rng.normal(size=(6, 6)); Hs[i] = M @ M.T / 6 + rng.uniform(0.2, 1.0) * np.eye(6)
             refs = (Hs, vs)
         spare = int(rng.random() < 0.2 and nc + 1 <= model.njoints - 1)   # eq_c_capacity = num_eq_c + 1
-        osqp = bool(rng.random() < 0.2) and not for_flat
+        osqp = bool(rng.random() < 0.2)   # (round 5: also inside the flat engine's domain -- k_flat2<.., MUR = 1>)
         multidof = model.nv != model.njoints - 1
         # (a tolerance of 1e-8 is below the rounding noise of the multi-DoF chain representation and of mu ~ 1e6: the iteration at
         #  which such an instance stops is then decided by that noise)
         prm = dict(FIXTURE, num_eq_c=nc, max_iter=int(rng.choice([60, 300, 1000])),
                    tol_abs=float(rng.choice([1e-4, 1e-6] if (osqp or multidof) else [1e-4, 1e-6, 1e-8])),
                    tol_rel=float(rng.choice([0.0, 1e-6])), mu_update_strat=1 if osqp else 0)
-        engine = str(rng.choice(["default", "handover", "flat_escapes", "flat_one_lane", "flat_sliced", "flat_ordered", "flat_ordered"] if for_flat else list(ENGINES)))
+        engine = str(rng.choice(["default", "handover", "flat_escapes", "flat_one_lane", "flat_sliced", "flat_ordered", "flat_ordered", "flat_builds", "flat_lazy",
+                                 "flat_lazy_sliced"] if for_flat else list(ENGINES)))
         if engine == "flat_one_lane" and (hk != 0 or refs is not None):
             engine = "default"   # (k_flat takes H_ref = h I only: such a handle would run k_lean -- covered by "lean")
         env, kw = ENGINES[engine]
@@ -190,11 +196,11 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
         e = summary["by_engine"].setdefault(engine, dict(cases=0, mismatches=0))
         e["cases"] += 1; e["mismatches"] += not ok
         say("case %3d %-14s nb %2d nv %2d nc %d%s B %4d %s Href %s max_iter %4d tol %.0e %s: same-iteration %.3f max|dz| %.1e off %d "
-              "lean %d flat %d esc %d requeue %d  %s %s" % (
+              "lean %d flat %d esc %d requeue %d built %d  %s %s" % (
                   case, engine, model.njoints - 1, model.nv, nc, "+1" if spare else "  ", B, model.name[:18], "L" if refs else str(hk),
                   prm["max_iter"], prm["tol_abs"],
                   "OSQP" if osqp else "DEF ", same.mean(), dz[same].max() if same.any() else 0.0, int((~same).sum()), st["lean_launches"], st["flat_launches"],
-                  st["lean_escaped"], st["lean_requeues"], "ok" if ok else "MISMATCH", why), flush=True)
+                  st["lean_escaped"], st["lean_requeues"], st.get("flat_built", 0), "ok" if ok else "MISMATCH", why), flush=True)
         s.close()
     for k in ENV_KEYS:   # (the engines' switches are read at loikb_create: nothing of the last case may outlive the run)
         os.environ.pop(k, None)
