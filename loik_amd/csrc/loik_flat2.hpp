@@ -1963,7 +1963,9 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
             __builtin_amdgcn_s_sleep(1);
           }
         }
-        const int dslp = kexp - kexp_lo;
+        // (MUR = 1: the table holds mu0's slot and nothing else -- an instance whose mu has moved travels without a slot and rebuilds
+        //  its factors when it is taken up again; found by the fuzz: it used to be handed mu0's factors, kexp being 0 for ever under that rule)
+        const int dslp = MUR == 1 ? (mu == P.mu0 ? 0 : 15) : kexp - kexp_lo;
         const int code = build_req ? (FLAT_BUILD_REQ | (((kexp + 8) & 15) << 24)) : ((dslp >= 0 && dslp < ndec ? dslp : 15) << 24);
         __hip_atomic_store(ep, lidx | FLAT_PARKED | code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (unsigned int spins = 0; got < 0; ++spins) {   // (entries were waiting when the slice ended: normally it is there)

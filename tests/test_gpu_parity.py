@@ -231,7 +231,7 @@ def test_error_codes_through_the_abi(talos):
     s.close()
 
 
-@pytest.mark.parametrize("engine", ["flat", "flat_handover", "tail", "solve", "hybrid"])
+@pytest.mark.parametrize("engine", ["flat", "flat_sliced", "flat_handover", "tail", "solve", "hybrid"])
 def test_osqp_mu_rule_matches_oracle(talos, engine, monkeypatch):
     """ADMMPenaltyUpdateStrat::OSQP (declared upstream at task-solver-base.hpp:13-18, throws there: hxx:632-634) -- implemented here as an
     extension (update_mu in loik_device.hpp == ref_update_mu in the oracle).  mu leaves the decade grid.  Round 5: the solve runs on the
@@ -244,14 +244,18 @@ def test_osqp_mu_rule_matches_oracle(talos, engine, monkeypatch):
     prm = dict(FIXTURE, max_iter=500, tol_abs=1e-6, tol_rel=0.0, mu_update_strat=1)
     if not engine.startswith("flat"):
         monkeypatch.setenv("LOIKB_FLAT", "0")
-    kw = {"flat": {}, "flat_handover": dict(max_launch_iters=5, tail_max_instances=1 << 20), "tail": {}, "solve": dict(tail_max_instances=-1),
+    if engine == "flat_sliced":   # (time slices of 7 iterations, one wavefront per CU: an instance whose mu has moved travels WITHOUT a slot --
+        monkeypatch.setenv("LOIKB_FLAT_SLICE", "7")        # the table holds mu0's only -- and rebuilds when it is taken up again; the fuzz found
+        monkeypatch.setenv("LOIKB_LEAN_WG_PER_CU", "1")    # it being handed mu0's factors)
+    kw = {"flat": {}, "flat_sliced": {}, "flat_handover": dict(max_launch_iters=5, tail_max_instances=1 << 20), "tail": {}, "solve": dict(tail_max_instances=-1),
           "hybrid": dict(max_launch_iters=5, tail_max_instances=1 << 20)}[engine]
     s = gpu_solve(talos, wl, prm, **kw)
     st = s.stats()
     if engine.startswith("flat"):
         assert "k_flat2" in s.plan() and "OSQP" in s.plan() and "in-wave" in s.plan(), s.plan()
         assert st["flat_split_launches"] >= 1 and st["flat_built"] > B, st   # (mu0's slot from the table, every change of mu a build)
-        assert (st["tail_instances"] == B) if engine == "flat" else (0 < st["tail_instances"] < B), st
+        assert (st["tail_instances"] == B) if engine != "flat_handover" else (0 < st["tail_instances"] < B), st
+        assert (st["lean_requeues"] > 100) == (engine == "flat_sliced"), st
     else:
         assert st["lean_launches"] == 0
         assert (st["tail_instances"] == B) if engine == "tail" else (st["tail_instances"] == 0) if engine == "solve" else (0 < st["tail_instances"] < B)
