@@ -338,7 +338,7 @@ typedef struct loikb_stats {
   double queue_dry_ms;                    /* flat engine: time from the start of its (last) launch until a lane group first found the
                                              work queue empty -- the bulk phase; the rest of the launch waits for its long runners */
   int flat_split_launches;                /* of flat_launches: those in the build with two lanes per joint (k_flat2,
-                                             loik_amd/csrc/loik_flat2.hpp: robots of 17..32 joints, fp64)                        */
+                                             loik_amd/csrc/loik_flat2.hpp: robots of 17..64 joints, fp64)                        */
   int flat_ordered;                       /* of flat_launches: those that took their instances longest first, in the order the
                                              handle's previous solve left (LOIKB_FLAT_ORDER=0 turns that off)                   */
   int flat_built;                         /* decade slots (W / Dinv of one instance for one mu) built by the instance's own wavefront

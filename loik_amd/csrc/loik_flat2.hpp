@@ -2045,12 +2045,17 @@ __host__ __device__ __forceinline__ size_t flat1_lds_bytes(int nc, bool has_hv, 
   return (n * sizeof(double) + 15) & ~(size_t)15;
 }
 
-template <int NA, bool SLICED = false, int HM = 0, bool LOG = false>
+// MUR = 1 (round 5): OSQP's rule, as in k_flat2 -- mu0's slot from the table, every change of mu one in-wave build (flat_build_slot on all 64
+// lanes: its rows lie over the exchange area and the decade slots, so the launch keeps TWO slots in LDS), a division-free quiet test; unsliced.
+// aux[0] = TailTopo*, aux[1] = the children's list (read by the builder only); has_hv_bits: bits 8..15 = the tree's depth.
+template <int NA, bool SLICED = false, int HM = 0, bool LOG = false, int MUR = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
         int nscan, int njmp, int* ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
-        int ndec, double href_s, int has_hv_bits, int ring_mask, int quantum)
+        int ndec, double href_s, int has_hv_bits, int ring_mask, int quantum, const void* const* __restrict__ aux)
 {
+  static_assert(MUR == 0 || (!SLICED && !LOG), "the OSQP build of k_flat1 runs unsliced and writes no lists");
+  static_assert(MUR == 0 || flat_build_scratch<WAVE>() <= flat1_xregion<NA>() + 2 * (NA + 1) * WAVE, "the in-wave builder's rows must end inside the two decade slots");
   // has_hv_bits: bit 0 = the reference target is not zero (H_ref v_ref rows in LDS), bit 1 = ONE decade slot in LDS instead of two
   // (a flip of mu back to the previous decade then reloads it, ~1.4 KB from the L2; the 5.6 KB it frees are worth two more
   // wavefronts per CU with four task constraints: whole body 23.6 -> see DESIGN)
@@ -2433,14 +2438,21 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     tail_sync();
   };
 
+  bool need_build = false;   // (MUR = 1: the iteration loop asks for a build and leaves; it runs out here and the loop is entered again: k_flat2)
+  T inv_mu = T(1), bnorm_r = T(0);
+  int q_lim_run = 0, slice_end = 0x7fffffff, q_lim = 0;
   while (true) {
+    if (!need_build) {
     load_instance();
     if (!has_inst) break;
-    T inv_mu = T(1) / mu;
+    inv_mu = T(1) / mu;
+    if constexpr (MUR == 1) bnorm_r = isc[FI_BNORM];
     requeue = false;
-    const int q_lim_run = quiet_limit(P.max_iter, P.max_launch_iters, iter);   // (see k_flat2)
-    int slice_end = SLICED ? iter + (iter >= slice_len ? slice_len2 : slice_len) : 0x7fffffff;
-    int q_lim = (SLICED && slice_end - 1 < q_lim_run) ? slice_end - 1 : q_lim_run;
+    q_lim_run = quiet_limit(P.max_iter, P.max_launch_iters, iter);   // (see k_flat2)
+    slice_end = SLICED ? iter + (iter >= slice_len ? slice_len2 : slice_len) : 0x7fffffff;
+    q_lim = (SLICED && slice_end - 1 < q_lim_run) ? slice_end - 1 : q_lim_run;
+    }
+    need_build = false;
    while (true) {
     if (SLICED && !done && iter >= slice_end) {
       if (q_waiting()) { requeue = true; break; }
@@ -2449,13 +2461,17 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     }
     bool exit_now = done || (int)my_iters >= P.max_launch_iters;
     if (!exit_now && kexp != kslot) {
-      if (kexp == kslot_o && !one_buf) {
+      if (MUR != 1 && kexp == kslot_o && !one_buf) {
         { const int tk = kslot; kslot = kslot_o; kslot_o = tk; }
         wsel ^= 1;
         ++n_slot_hits;
       } else {
-        const int dsl = kexp - kexp_lo;
-        if (dsl < 0 || dsl >= ndec) {
+        const int dsl = MUR == 1 ? 0 : kexp - kexp_lo;
+        const bool in_table = MUR == 1 ? (ndec > 0 && __builtin_amdgcn_readfirstlane((int)(mu == P.mu0)) != 0) : (dsl >= 0 && dsl < ndec);
+        if (MUR == 1 && __builtin_expect(!in_table, 0)) {
+          need_build = true;
+          break;
+        } else if (!in_table) {
           exit_now = true;
           if (lane == 0) atomicAdd(&Bf.counters[2], 1u);
         } else {
@@ -2707,9 +2723,11 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const bool in_tail = (status & ST_TAIL) != 0;
     const bool logic = !fixed && !in_tail;  // the main loop's stopping logic runs
     T primal = T(0), dual = T(0), dyqp = T(0), atdy = T(0), dx = T(0), dz = T(0), ubp = T(0), lbm = T(0);
+    T ntol_p = T(0), ntol_d = T(0);
+    bool have_norms = false;
     if (logic) {
       T in[4] = {hmaxa(s_ek, s_prs), hmax_a(l_dualv, s_stf), hmax_a(hmax_a(l_dfis, s_dy), s_dw), hmax_a(l_dg, s_dstf)}, r[4];
-      if (LOIKB_QUIET32 && !LOG && quiet_f32(in, qth, iter, q_lim)) {   // (the quick look: see quiet_f32)
+      if (LOIKB_QUIET32 && !LOG && MUR != 1 && quiet_f32(in, qth, iter, q_lim)) {   // (the quick look: see quiet_f32)
         ++iter;
         if (iter > q_lim) continue;
         goto next_iteration;
@@ -2720,8 +2738,19 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         // The common iteration decides nothing: not converged, the certificate's first test fails, mu stays where it is, not the
         // last iteration.  Five compares side by side and ONE branch; the stopping logic below is a chain of ~30 dependent
         // compare -> mask -> branch steps (900 cycles of a lone wavefront's 5400 per iteration) that only the other iterations walk.
-        const bool quiet = !((primal < tol_abs_h) & (dual < tol_abs_h)) & !((iter > 0) & (atdy <= tpi_h * dyqp)) &
-                           !(primal > T(10) * dual) & !(dual > T(10) * primal) & (iter + 2 < max_iter_h);
+        bool mu_stays;
+        if constexpr (MUR == 1) {   // (OSQP's band, without its divisions and root: see k_flat2)
+          T in2[4] = {hmaxa(s_av, nu), hmax_a(hmax(l_hrefv_now(), hinf6(g)), s_stf), T(0), T(0)}, r2[4];
+          wave_fold4<0u>(lane, in2, r2);
+          ntol_p = r2[0]; ntol_d = r2[1];
+          have_norms = true;
+          const T e_ = T(1e-10), np_ = tmax(ntol_p, bnorm_r) + e_, nd_ = tmax(ntol_d, P.Hv_inf_norm) + e_;
+          const T A_ = primal * nd_, B_ = np_ * (dual + e_ * nd_);
+          mu_stays = (A_ < T(24) * B_) & (A_ > T(0.05) * B_) & (mu >= T(1e-6)) & (mu <= T(1e6));
+        } else {
+          mu_stays = !(primal > T(10) * dual) & !(dual > T(10) * primal);
+        }
+        const bool quiet = !((primal < tol_abs_h) & (dual < tol_abs_h)) & !((iter > 0) & (atdy <= tpi_h * dyqp)) & mu_stays & (iter + 2 < max_iter_h);
         if (quiet) {
           ++iter;
           if (LOIKB_QUIET_SKIPS_TOP && iter <= q_lim) goto next_iteration;
@@ -2729,8 +2758,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         }
       }
     }
-    T ntol_p = T(0), ntol_d = T(0);
-    if (P.tol_rel != T(0)) {  // (uniform) relative tolerances need two more maxima
+    if ((MUR == 1 ? logic : P.tol_rel != T(0)) && !have_norms) {  // (uniform) relative tolerances -- and OSQP's rule -- need two more maxima
       T in2[4] = {hmaxa(s_av, nu), hmax_a(hmax(l_hrefv_now(), hinf6(g)), s_stf), T(0), T(0)}, r2[4];
       wave_fold4<0u>(lane, in2, r2);
       ntol_p = r2[0]; ntol_d = r2[1];
@@ -2769,7 +2797,20 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     const bool infeas = feas_chk && c1 && c2;
     const bool enter_tail = infeas && !conv;
     const bool upd = logic && !conv && !infeas;
-    const bool mu_up = upd && (primal > T(10) * dual), mu_dn = upd && !mu_up && (dual > T(10) * primal);
+    bool mu_up = upd && (primal > T(10) * dual), mu_dn = upd && !mu_up && (dual > T(10) * primal);
+    if constexpr (MUR == 1) {   // OSQP's rule (update_mu): see k_flat2
+      mu_up = mu_dn = false;
+      if (upd) {
+        T m2 = mu;
+        int kk = kexp;
+        if (update_mu<T>(MODE_MU_OSQP, primal, dual, tmax(ntol_p, isc[FI_BNORM]), tmax(ntol_d, P.Hv_inf_norm), m2, kk)) {
+          mu = m2;
+          inv_mu = T(1) / mu;
+          ++nflip;
+          kslot = -(1 << 30);
+        }
+      }
+    }
     const bool tail_stop = !(dx >= P.tol_tail_solve || dz >= P.tol_tail_solve) || itn >= P.max_iter;  // (looked at with have_b only)
     const bool stop = conv || ((enter_tail || in_tail) && tail_stop) || ((upd || fixed) && itn + 1 >= P.max_iter);
     iter = itn;
@@ -2811,6 +2852,35 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       break;
     }
    }
+    if constexpr (MUR == 1) {
+      if (__builtin_expect(need_build, 0)) {   // (W / Dinv for the instance's own mu: flat_build_slot, one joint per lane; both slots are gone afterwards)
+        T hb[21], at[21], Wc[NA], dv;
+#pragma unroll
+        for (int a_ = 0; a_ < 6; ++a_)
+#pragma unroll
+          for (int b2 = a_; b2 < 6; ++b2)
+            hb[sym(a_, b2)] = mass * ((a_ == b2 ? P.rho : T(0)) + (P.href_tab ? P.href_tab[(size_t)(jl + 1) * HREF_ROW + 6 * a_ + b2] : P.Href[6 * a_ + b2]));
+#pragma unroll
+        for (int k = 0; k < 21; ++k) at[k] = T(0);
+        if (jcslot >= 0) {
+          const char* crec = ip + (size_t)(L.off_c + jcslot * L.crec) * pair_bytes<T>();
+          for (int k = 0; k < 21; ++k)
+            at[k] = a_shared ? Bf.uni[L.nc * 36 + jcslot * 21 + k]
+                             : *reinterpret_cast<const T*>(crec + (size_t)(CP_ATA + k / 2) * pair_bytes<T>() + (k & 1) * sizeof(T));
+        }
+        flat_build_slot<NA, WAVE>(xb, lane, true, lane, L.nb, jd, reinterpret_cast<const TailTopo*>(aux[0]), reinterpret_cast<const int*>(aux[1]), fl,
+                                  (has_hv_bits >> 8) & 0xFF, R0, t0, Sw, hb, at, mu, P.mu_scale, Wc, dv);
+        wsel = 0;
+#pragma unroll
+        for (int k = 0; k < NA; ++k) wl[k * G + lane] = Wc[k];
+        wl[NA * G + lane] = dv;
+        kslot_o = -(1 << 30);
+        kslot = kexp;
+        if (lane == 0) atomicAdd(&Bf.counters[FLAT_COUNTERS_BUILT], 1u);
+        tail_sync();
+        continue;   // (back into the iteration loop with the instance the wavefront has)
+      }
+    }
     store_instance();
     if constexpr (SLICED) {
       if (requeue) q_push(lidx);

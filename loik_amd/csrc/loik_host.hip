@@ -1149,14 +1149,14 @@ bool flat_takes_diagonal(const loikb_solver_impl* S)
   return (S->flat.G == F2G && S->flat.nanc <= FLAT_NA_SMALL) || S->flat.G == WAVE;
 }
 // OSQP's rule takes mu off the decade grid: no table of slots; k_flat2 builds the factors in-wave at every change of mu
-// (k_flat2<.., MUR = 1>: robots of 17..32 joints, fp64, no SolverInfo lists)
+// (k_flat2<.., MUR = 1> / k_flat1<.., MUR = 1>: robots of 17..64 joints, fp64, no SolverInfo lists)
 bool flat_any_mu(const loikb_solver_impl* S)
 {
   return S->opt.mu_update_strat == LOIKB_MU_OSQP;
 }
 bool flat_any_mu_ok(const loikb_solver_impl* S)
 {
-  return S->tune.flat_split && !S->f32 && S->flat.ok && S->flat.G == F2G && S->flat.nanc <= FLAT_NA_SMALL && !S->opt.logging;
+  return S->tune.flat_split && !S->f32 && S->flat.ok && ((S->flat.G == F2G && S->flat.nanc <= FLAT_NA_SMALL) || S->flat.G == WAVE) && !S->opt.logging;
 }
 bool flat_applicable(const loikb_solver_impl* S)
 {
@@ -1659,7 +1659,7 @@ void plan_engines(loikb_solver_impl* S)
   else if (S->f32) pl.why_not_flat = "fp32 solver";
   else if (S->opt.flags & LOIKB_OPT_NO_H_CACHE) pl.why_not_flat = "LOIKB_OPT_NO_H_CACHE (no precomputed factors)";
   else if (flat_any_mu(S) && !flat_any_mu_ok(S))
-    pl.why_not_flat = "OSQP penalty rule: mu is off the decade grid, and the in-wave builder is k_flat2's (17..32 joints, fp64, no logging)";
+    pl.why_not_flat = "OSQP penalty rule: mu is off the decade grid, and the in-wave builder is k_flat2's / k_flat1's (17..64 joints, fp64, no logging)";
   else if (S->nb <= 16) pl.why_not_flat = "a small robot (<= 16 joints): k_solve + k_tail are faster on its short solves";
   // (the flat engines update the task constraints on lanes 6 c + k of an instance's lanes, in one pass: ten constraints with a
   //  wavefront per instance, five with two instances per wavefront; more go to the engines that loop over them)
@@ -1838,6 +1838,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       dim3 grid((unsigned)std::min((n + ipw - 1) / ipw, cap_lat));
       {
         hipLaunchKernelGGL(k_ring_fill, grid1(C->ring_cap), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, list, n, C->d_counters);
+        if (split || one) {   // (what only the in-wave builder / the lazily populated table read, behind one kernel argument)
+          if (C->d_aux == nullptr) HIPCHK(hipMalloc((void**)&C->d_aux, 4 * sizeof(void*)));
+          const void* auxh[4] = {S->d_topo, S->d_child_list, C->d_fmask, nullptr};
+          HIPCHK(hipMemcpyAsync(C->d_aux, auxh, sizeof(auxh), hipMemcpyHostToDevice, C->stream));
+        }
         if (split) {
           // k_flat2: two lanes per joint, one instance per wavefront, two or three wavefronts per SIMD (loik_flat2.hpp)
           const size_t lds2 = flat2_lds_bytes<FLAT_NA_SMALL>(S->nc, has_hv != 0, mur == 1);
@@ -1866,11 +1871,6 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           // dependent trips to the L2 / HBM at ~2.5 us each when 2048 wavefronts share them), a slice of 64 iterations 190 us.
           // LOIKB_FLAT_SLICE=q switches it on.
           // End of round 4: ON again for arrival-order launches of >= 32 768 instances (flat_slice_for has the numbers).
-          if (C->d_aux == nullptr) HIPCHK(hipMalloc((void**)&C->d_aux, 4 * sizeof(void*)));
-          {
-            const void* auxh[4] = {S->d_topo, S->d_child_list, C->d_fmask, nullptr};
-            HIPCHK(hipMemcpyAsync(C->d_aux, auxh, sizeof(auxh), hipMemcpyHostToDevice, C->stream));
-          }
           const size_t park_need = (size_t)n_cur * flat2_park_stride(S->nc, true) * sizeof(double);
           (void)resident;
           int quantum = flat_slice_for(S, n, ordered);
@@ -1914,7 +1914,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         } else if (one) {
           // one decade slot in LDS instead of two when that buys wavefronts per CU (whole body, four task constraints: 6 -> 8)
           auto lds_of = [&](int bufs) { return small_na ? flat1_lds_bytes<FLAT_NA_SMALL>(S->nc, has_hv != 0, bufs) : flat1_lds_bytes<FLAT_MAXA>(S->nc, has_hv != 0, bufs); };
-          const int one_buf = (S->tune.flat_one_slot != 0) && std::min<size_t>(8, (160 * 1024) / lds_of(1)) > std::min<size_t>(8, (160 * 1024) / lds_of(2));
+          // (OSQP's rule: the in-wave builder's rows lie over both slots -- two it is)
+          const int one_buf = mur != 1 && (S->tune.flat_one_slot != 0) && std::min<size_t>(8, (160 * 1024) / lds_of(1)) > std::min<size_t>(8, (160 * 1024) / lds_of(2));
           const size_t lds1 = lds_of(one_buf ? 1 : 2);
           int per_cu1 = (int)std::min<size_t>(8, (160 * 1024) / lds1);
           if (S->tune.lean_wg_per_cu > 0) per_cu1 = std::min(per_cu1, S->tune.lean_wg_per_cu);
@@ -1922,14 +1923,21 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           // (time slicing as in k_flat2, same window: whole body, four tasks, B = 65 536: 34.7 ms without)
           const int resident = (int)grid.x, full = per_cu1 * (int)(cu_sh + 0.5);
           (void)resident; (void)full;
-          const int quantum = flat_slice_for(S, n, ordered);
+          const int quantum = mur == 1 ? 0 : flat_slice_for(S, n, ordered);
 #define LOIKB_LAUNCH_FLAT1(NAV, ...)                                                                                            \
   hipLaunchKernelGGL((k_flat1<NAV, ##__VA_ARGS__>), grid, dim3(WAVE), lds1, C->stream,                                          \
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
                      (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
-                     (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv | (one_buf ? 2 : 0), C->ring_cap - 1, quantum)
+                     (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv | (one_buf ? 2 : 0) | ((S->maxdepth & 0xFF) << 8),  \
+                     C->ring_cap - 1, quantum, (const void* const*)C->d_aux)
           const int hm = S->per_link ? 3 : href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
-          if (S->opt.logging) {   // (as k_flat2's)
+          if (mur == 1) {   // (OSQP's rule: unsliced; a diagonal reference weight goes as a general one)
+            if (hm == 3) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, 3, false, 1); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, 3, false, 1); }
+            else if (hm >= 1) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, 2, false, 1); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, 2, false, 1); }
+            else if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, 0, false, 1);
+            else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, 0, false, 1);
+          }
+          else if (S->opt.logging) {   // (as k_flat2's)
             const int quantum = 0;
             if (hm == 3) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, 3, true); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, 3, true); }
             else if (hm >= 1) { if (small_na) LOIKB_LAUNCH_FLAT1(FLAT_NA_SMALL, false, 2, true); else LOIKB_LAUNCH_FLAT1(FLAT_MAXA, false, 2, true); }
@@ -3331,7 +3339,7 @@ const char* loikb_plan_string(loikb_solver* S)
              S->sched[1].nw, pl.tail_max, pl.nchunks, pl.why_not_lean);
   out = buf;
   if (pl.flat && flat_any_mu(S) && (flat_applicable(S) || !S->have_problem))
-    out += "; OSQP penalty rule: mu is off the decade grid -- k_fslots builds mu0's slot only, k_flat2 builds W / Dinv in-wave at every change of mu";
+    out += "; OSQP penalty rule: mu is off the decade grid -- k_fslots builds mu0's slot only, the iteration kernel builds W / Dinv in-wave at every change of mu";
   else if (pl.flat && S->tune.flat_build && (flat_applicable(S) || !S->have_problem))
     out += S->tune.flat_build == 2 ? "; LOIKB_FLAT_BUILD=2: time-sliced launches of a handle with a history populate the decade table lazily -- k_fslots builds the "
                                      "decades 97 % of the previous solve's instances ended within, an instance that goes further builds its slot in-wave, once"

@@ -594,3 +594,55 @@ def test_flat_engine_with_a_diagonal_reference_weight(robot, sliced, weight, mon
     assert (st["lean_requeues"] > 0) == sliced, st
     assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.97, ztol=1e-8, what="%s H_ref, %s" % (weight, robot))
     s.close()
+
+
+@pytest.mark.parametrize("weight", ["scalar", "general"])
+def test_whole_body_osqp_rule_on_the_flat_engine(weight, monkeypatch):
+    """OSQP's penalty rule on the 44-joint tree: k_flat1<.., MUR = 1> (one lane per joint) builds W / Dinv of its instance in-wave at every
+    change of mu, as k_flat2 does for 17..32 joints (tests/test_gpu_parity.py::test_osqp_mu_rule_matches_oracle) -- mu0's slot from the
+    table, no time slices.  k iterations field by field incl. mu, and end to end against the oracle."""
+    from loik_amd import workloads
+    model = loik_amd.builtin_model("talos44")
+    B = 600
+    wl = workloads.talos_wholebody(B, seed=13, model=model)
+    Href = wl["H_ref"]
+    if weight == "general":
+        Q = np.linalg.qr(np.random.default_rng(6).normal(size=(6, 6)))[0]
+        Href = Q @ np.diag([0.4, 1.5, 0.7, 3.0, 0.2, 2.2]) @ Q.T
+        Href = 0.5 * (Href + Href.T)
+    args = (wl["q"], Href, wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    for k in ("LOIKB_FLAT_SLICE", "LOIKB_LEAN_WG_PER_CU"):
+        monkeypatch.delenv(k, raising=False)
+    for k in (3, 9):   # (mu follows the residual ratio: after 30 iterations the roundings of the two summation orders are at 7e-8 in mu itself)
+        prm = dict(wl["params"], max_iter=k + 1, tol_abs=0.0, tol_primal_inf=0.0, mu_update_strat=1)
+        s = loik_amd.BatchedLoik(model, B, **prm)
+        s.Solve(*args)
+        st = s.stats()
+        assert "k_flat1" in s.plan() and "OSQP" in s.plan(), s.plan()
+        assert st["flat_launches"] >= 1 and st["tail_instances"] == B and st["lean_requeues"] == 0, (s.plan(), st)
+        assert st["flat_built"] > 0, st   # (the rule moves mu from the second iteration on)
+        got = {n: s.get(n) for n in FIELDS + SCALARS}
+        for b in range(0, B, 97):
+            r = ref.RefSolver(model, **prm)
+            r.Solve(wl["q"][b], Href, wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"][b], wl["lb"], wl["ub"])
+            for n in FIELDS:
+                want = r.field(n)
+                if n in ("vis", "fis", "g"):
+                    want = want[1:]
+                assert_close(got[n][b], want, 1e-8, "%s b%d k%d" % (n, b, k))
+            for n in SCALARS:   # (mu among them)
+                assert_close(got[n][b], r.scalar(n), 1e-8, "%s b%d k%d" % (n, b, k))
+        s.close()
+    prm = dict(wl["params"], max_iter=500, mu_update_strat=1)
+    out = ref.solve_batch(model, *args, nthreads=8, want_nu=True, **prm)
+    s = loik_amd.BatchedLoik(model, B, **prm)
+    s.Solve(*args)
+    st = s.stats()
+    assert st["flat_launches"] >= 1 and st["lean_escaped"] == 0 and st["tail_instances"] == B and st["flat_built"] > B, (s.plan(), st)
+    # (off the oracle's iteration count: the fuzz's budget for this rule -- an instance that needs 340 / 450 iterations under a penalty that
+    #  follows the residual ratio stops with z known to ~10 x the residual tolerance, here 7.9e-6 at tol 1e-6, flags equal)
+    assert_end_to_end(fetch_end_to_end(s, residuals=True), out, prm, same_frac=0.95, ztol=1e-8, off_ztol=1e-5, res_tol=(1e-8, 1e-6),
+                      what="OSQP rule, whole body, %s H_ref" % weight)
+    mu = s.get("mu")
+    assert np.unique(np.round(np.log10(mu), 9)).size > 12
+    s.close()
