@@ -1066,7 +1066,13 @@ k_fslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
   const int lane = threadIdx.x;
   const int ipw = WAVE / G;
   const int sub = lane / G, jlane = lane % G, gbase = sub * G;
-  const int idx = blockIdx.x * ipw + sub;
+  // Blocks b, b + 8, b + 16 .. run on the same XCD (observed, MI355X_MICROARCH.md; nothing depends on it but speed), and the 64
+  // instances of a tile share every 1 KB row of their records: handed out in launch order, the 32 blocks of a tile sat on all eight
+  // XCDs and each of the eight L2s fetched the tile's rows from HBM for its four blocks -- 21 KB fetched per instance where the records
+  // hold 2.6.  Each XCD takes a contiguous eighth of the list instead.
+  const int nblk = gridDim.x, xcd = blockIdx.x & 7, rnd = blockIdx.x >> 3;
+  const int blk = xcd * (nblk >> 3) + (xcd < (nblk & 7) ? xcd : (nblk & 7)) + rnd;
+  const int idx = blk * ipw + sub;
   const bool has_inst = idx < nslots;
   const bool isj_lane = jlane < L.nb;
   const bool isj = has_inst && isj_lane;
