@@ -6,39 +6,64 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libloik_amd.so")
-SOURCES = ["loik_host.hip", "models.c"]
-HEADERS = ["loik_device.hpp", "loik_tail.hpp", "loik_lean.hpp", "loik_flat.hpp", "loik_flat2.hpp", "loik_passes.hpp", os.path.join("..", "..", "include", "loik_amd.h"),
-           os.path.join("..", "..", "include", "loik_amd_models.h")]
+SOURCES = ["loik_host.hip", "loik_flat_kernels.hip", "models.c"]
+HEADERS = ["loik_device.hpp", "loik_tail.hpp", "loik_lean.hpp", "loik_flat.hpp", "loik_flat2.hpp", "loik_flat_inst.hpp", "loik_passes.hpp",
+           os.path.join("..", "..", "include", "loik_amd.h"), os.path.join("..", "..", "include", "loik_amd_models.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# Code generation of the flat iteration kernels' translation unit (loik_flat_kernels.hip; why: csrc/loik_flat_inst.hpp): neighbouring LDS
+# accesses stay single 64-bit instructions -- neither the IR load/store vectorizer (128-bit accesses, ds_read2_b64 where the alignment is
+# 8) nor the machine-level SI load/store optimizer (ds_read2_b64 / ds_write2_b64 / ds_read2st64_b64) merges them.
+FLAT_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-mllvm", "-amdgpu-load-store-vectorizer=0"]
 
 
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    for f in SOURCES + HEADERS:
+    for f in SOURCES + HEADERS + [os.path.join("..", "_build.py")]:
         if os.path.getmtime(os.path.join(CSRC, f)) > t:
             return True
     return False
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    """Compile every HIP source for gfx950.  hipcc cross-compiles without a GPU."""
+def build(force=False, verbose=False, extra_flags=(), flat_flags=None):
+    """Compile every HIP source for gfx950.  hipcc cross-compiles without a GPU.
+    extra_flags go to both translation units; flat_flags (default FLAT_FLAGS) only to the flat iteration kernels'.
+    A -DLOIKB_TAIL_PROF build (phase timelines: its device-side counters are globals every kernel writes and the host reads) is ONE
+    translation unit, compiled with flat_flags throughout."""
     if not force and not _stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     inc = os.path.join(HERE, "..", "include")
-    objs = []
+    flat_flags = list(FLAT_FLAGS if flat_flags is None else flat_flags)
+    extra_flags = list(extra_flags)
     c_obj = os.path.join(LIBDIR, "models.o")
     subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=c11", "-I", inc, "-c", os.path.join(CSRC, "models.c"), "-o", c_obj])
-    objs.append(c_obj)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=on", "-std=c++17", "-fPIC", "-shared", "-I", inc,
-           "-Wall", "-Wno-unused-function", "-x", "hip", os.path.join(CSRC, "loik_host.hip"),
-           "-x", "none", c_obj, "-o", LIB] + list(extra_flags)
+    base = [HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=on", "-std=c++17", "-fPIC", "-I", inc, "-Wall", "-Wno-unused-function"]
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        base.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    single_tu = any(f.startswith("-DLOIKB_TAIL_PROF") for f in extra_flags)
+    if single_tu:
+        cmd = base + ["-shared", "-x", "hip", os.path.join(CSRC, "loik_host.hip"), "-x", "none", c_obj, "-o", LIB] + flat_flags + extra_flags
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return LIB
+    host_obj, flat_obj = os.path.join(LIBDIR, "loik_host.o"), os.path.join(LIBDIR, "loik_flat_kernels.o")
+    cmds = [base + ["-DLOIKB_FLAT_SEPARATE_TU", "-c", "-x", "hip", os.path.join(CSRC, "loik_host.hip"), "-o", host_obj] + extra_flags,
+            base + ["-DLOIKB_FLAT_SEPARATE_TU", "-c", "-x", "hip", os.path.join(CSRC, "loik_flat_kernels.hip"), "-o", flat_obj] + flat_flags + extra_flags]
+    procs = []
+    for cmd in cmds:   # (the two compile side by side: ~2 minutes each)
+        if verbose:
+            print(" ".join(cmd))
+        procs.append(subprocess.Popen(cmd))
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        raise subprocess.CalledProcessError(next(r for r in rcs if r), cmds[[bool(r) for r in rcs].index(True)])
+    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", host_obj, flat_obj, c_obj, "-o", LIB]
+    if verbose:
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB
 
 

@@ -18,6 +18,12 @@
 #include "loik_flat.hpp"
 #include "loik_flat2.hpp"
 #include "loik_passes.hpp"
+#ifdef LOIKB_FLAT_SEPARATE_TU
+// k_flat2 / k_flat1 are instantiated in loik_flat_kernels.hip (its own code-generation switches: loik_flat_inst.hpp); here they are only launched
+#include "loik_flat_inst.hpp"
+LOIKB_FLAT2_INSTANCES(LOIKB_FLAT2_DECL)
+LOIKB_FLAT1_INSTANCES(LOIKB_FLAT1_DECL)
+#endif
 
 #include "../../include/loik_amd.h"
 

@@ -992,6 +992,7 @@ k_hslots(const Params<T> P, const Bufs<T> Bf, const JointDesc* __restrict__ jd, 
 }
 
 // the lean kernel's work queue at launch: ring[0 .. n) = the listed instances, the rest empty; pops start at 0, pushes at n
+#ifndef LOIKB_FLAT_KERNELS_TU   // (not a template: defined in the host translation unit only)
 __global__ void k_ring_fill(int* __restrict__ ring, int cap, const int* __restrict__ list, int n, unsigned int* __restrict__ counters)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1002,6 +1003,7 @@ __global__ void k_ring_fill(int* __restrict__ ring, int cap, const int* __restri
     counters[14] = (unsigned int)wall_clock64();  // (FLAT_COUNTERS_T0: the launch that follows starts now)
   }
 }
+#endif
 
 // the listed instances that are still iterating after a lean launch (the ones that escaped), in arbitrary order
 template <typename T>
@@ -1055,6 +1057,7 @@ __global__ void __launch_bounds__(256) k_order_count(char* tiles, Layout L, int 
   if (dec_hist != nullptr && threadIdx.x < 32 && hd[threadIdx.x]) atomicAdd(&dec_hist[threadIdx.x], hd[threadIdx.x]);
 }
 // bins[ORDER_BINS .. 2 ORDER_BINS) <- exclusive prefix sums of the counts (one workgroup of ORDER_BINS threads)
+#ifndef LOIKB_FLAT_KERNELS_TU   // (not a template: defined in the host translation unit only)
 __global__ void __launch_bounds__(ORDER_BINS) k_order_scan(unsigned int* __restrict__ bins)
 {
   __shared__ unsigned int h[ORDER_BINS];
@@ -1069,6 +1072,7 @@ __global__ void __launch_bounds__(ORDER_BINS) k_order_scan(unsigned int* __restr
   }
   bins[ORDER_BINS + t] = h[t] - bins[t];
 }
+#endif
 template <typename T>
 __global__ void __launch_bounds__(256) k_order_scatter(char* tiles, Layout L, int n, int max_iter, unsigned int* __restrict__ bins,
                                                        int* __restrict__ order)

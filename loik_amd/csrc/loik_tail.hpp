@@ -797,10 +797,12 @@ __global__ void __launch_bounds__(WAVE) k_list_live(char* tiles, Layout L, int n
 }
 
 // the identity list: every slot of a set (a batch small enough to go to the tail kernel from its first iteration)
+#ifndef LOIKB_FLAT_KERNELS_TU   // (not a template: defined in the host translation unit only)
 __global__ void k_list_iota(int* __restrict__ list, int n)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < n) list[b] = b;
 }
+#endif
 
 }  // namespace loikb

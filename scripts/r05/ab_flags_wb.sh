@@ -1,0 +1,14 @@
+#!/bin/bash
+# A/B of build flags inside ONE gpurun call, headline AND whole body: ab_flags_wb.sh "<flags A>" "<flags B>" ...  ("none" = the default build)
+cd ${GRAFT_REPO_ROOT:-.}
+for f in "$@"; do
+  ff="$f"; [ "$f" = none ] && ff=""
+  python -c "from loik_amd import _build; _build.build(force=True, extra_flags=tuple('$ff'.split()))" > /dev/null 2>&1 || echo "build failed: $f"
+  TAG="[$f]" python scripts/r04/lone.py
+  TAG="[$f ordered]" python scripts/r03/quick_headline.py 65536 6 | tail -1
+  TAG="[$f arrival]" LOIKB_FLAT_ORDER=0 python scripts/r03/quick_headline.py 65536 6 | tail -1
+  TAG="[$f]" python scripts/r03/quick_headline.py 262144 4 | tail -1
+  TAG="[$f ordered]" python scripts/r03/quick_wholebody.py 65536 6 | tail -1
+  TAG="[$f arrival]" LOIKB_FLAT_ORDER=0 python scripts/r03/quick_wholebody.py 65536 6 | tail -1
+done
+python -c "from loik_amd import _build; _build.build(force=True)" > /dev/null 2>&1
