@@ -67,7 +67,7 @@ struct Tuning {
   bool flat_split = true;       // LOIKB_FLAT_SPLIT=0: k_flat (one joint per lane) also where k_flat2 (two lanes per joint) applies
   int flat_split_wpe = 2;       // LOIKB_FLAT_WPE=3: k_flat2 built for three wavefronts per SIMD
   int flat_win_lo = 0, flat_win_n = 0;   // LOIKB_FLAT_WINDOW=lo,n: (with LOIKB_FLAT_BUILD=1) k_fslots builds decades lo .. lo + n - 1 only, the rest lazily
-  int flat_build = 0;           // LOIKB_FLAT_BUILD=1: the lazily populated table on every k_flat2 launch (window: LOIKB_FLAT_WINDOW, else all of it), 2: on time-sliced launches, window from the handle's history; k_flat2 builds a decade slot its table lacks in-wave (flat_build_slot) instead of handing the instance to k_tail
+  int flat_build = 2;           // (default 2 since the end of round 5; 0: the full table always) LOIKB_FLAT_BUILD=1: the lazily populated table on every k_flat2 launch (window: LOIKB_FLAT_WINDOW, else all of it), 2: on time-sliced launches, window from the handle's history; k_flat2 builds a decade slot its table lacks in-wave (flat_build_slot) instead of handing the instance to k_tail
   int fslot_dgrp = 0;           // LOIKB_FSLOT_DGRP=g: k_fslots takes the decades through its two passes g at a time (default: all)
   int flat_slice2 = 0;          // LOIKB_FLAT_SLICE2=q: an instance's later slices (0: as the first)
   int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's / k_flat1's round-robin time slice in iterations (0: never; default: 288 for
@@ -1813,6 +1813,15 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           }
           wlo = std::min(0, k03); whi = std::max(0, k97);
         }
+        else if (S->tune.flat_build == 2 && q > 0 && C->d_park != nullptr && n >= 49152) {
+          // No history (a handle's first solve): the five decades from mu0's upwards.  The rule moves mu up far more often than down, and
+          // rarely more than three decades; whoever leaves the window builds the slot once (results are bit-identical whatever the window:
+          // tests/test_engines.py::test_flat_lazy_table_*).  Measured, time-sliced headline launches, ms per solve incl. k_fslots, full
+          // table / this window: 65 536 instances 8.67 / 8.32, 131 072: 14.96 / 14.64, 262 144: 29.16 / 28.63; 32 768 and below no gain
+          // (5.45 / 5.49), nor on unsliced launches (the builder beside an unsliced loop costs it more than k_fslots saves:
+          // 65 536 ordered 7.44 / 7.59): profiles/r05_i_lazy_window_sizes.txt
+          wlo = 0; whi = 4;
+        }
         const int lo = std::max(wlo, kexp_lo), hi = std::min(whi, kexp_lo + ndec - 1);
         if (hi >= lo && (hi - lo + 1) < ndec) { dw0 = lo - kexp_lo; nw = hi - lo + 1; }
         else if (S->tune.flat_build == 2) mur = 0;   // (auto: nothing to leave out -- the build without the builder)
@@ -3347,8 +3356,9 @@ const char* loikb_plan_string(loikb_solver* S)
   if (pl.flat && flat_any_mu(S) && (flat_applicable(S) || !S->have_problem))
     out += "; OSQP penalty rule: mu is off the decade grid -- k_fslots builds mu0's slot only, the iteration kernel builds W / Dinv in-wave at every change of mu";
   else if (pl.flat && S->tune.flat_build && (flat_applicable(S) || !S->have_problem))
-    out += S->tune.flat_build == 2 ? "; LOIKB_FLAT_BUILD=2: time-sliced launches of a handle with a history populate the decade table lazily -- k_fslots builds the "
-                                     "decades 97 % of the previous solve's instances ended within, an instance that goes further builds its slot in-wave, once"
+    out += S->tune.flat_build == 2 ? "; lazily populated decade table (LOIKB_FLAT_BUILD=2, the default): on time-sliced launches k_fslots builds the decades 97 % of the "
+                                     "previous solve's instances ended within (a handle's first solve of 49 152+ instances: the five from mu0's upwards), an instance "
+                                     "that goes further builds its slot in-wave, once"
                                    : "; LOIKB_FLAT_BUILD=1: a decade of the table k_fslots did not build (LOIKB_FLAT_WINDOW=lo,n), or beyond the table, is built "
                                      "in-wave by the instance that gets there (no hand-over to k_tail)";
   if (!pl.flat && *pl.why_not_flat) out += std::string("; no k_flat: ") + pl.why_not_flat;

@@ -506,6 +506,33 @@ def test_flat_lazy_table_window_from_the_handles_history(talos, monkeypatch):
     assert slots["2"] < 0.8 * slots["0"], slots
 
 
+def test_flat_lazy_table_default_window_of_a_first_solve(talos, monkeypatch):
+    """The default (LOIKB_FLAT_BUILD unset = 2): a handle's FIRST time-sliced solve of 49 152+ instances lets k_fslots build the five decades from
+    mu0's upwards only; whoever leaves them builds its slot in-wave.  Same bits as the full table (LOIKB_FLAT_BUILD=0), a shorter slot kernel."""
+    from loik_amd import workloads
+    B = 65536
+    wl = workloads.talos_c3(B, seed=5)
+    args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    res, slots = {}, {}
+    for mode in ("0", None):
+        monkeypatch.delenv("LOIKB_FLAT_BUILD", raising=False)
+        monkeypatch.delenv("LOIKB_FLAT_WINDOW", raising=False)
+        if mode is not None:
+            monkeypatch.setenv("LOIKB_FLAT_BUILD", mode)
+        s = loik_amd.BatchedLoik(talos, B, **wl["params"])
+        s.Solve(*args)
+        st = s.stats()
+        assert st["flat_split_launches"] == 1 and st["flat_ordered"] == 0 and st["lean_requeues"] > 0 and st["lean_escaped"] == 0, st
+        if mode == "0":
+            assert st["flat_built"] == 0, st
+        res[mode] = {k: s.get(k) for k in ("iter", "converged", "primal_infeasible", "z", "nu", "mu", "yis", "fis")}
+        slots[mode] = st["hslots_ms"]
+        s.close()
+    for k in res["0"]:
+        assert np.array_equal(res["0"][k], res[None][k]), k
+    assert slots[None] < 0.8 * slots["0"], slots
+
+
 def test_flat_time_slicing_changes_nothing(talos, monkeypatch):
     """k_flat2's round-robin time slicing (LOIKB_FLAT_SLICE; on by default for arrival-order launches of 32 768..262 144
     instances, slices of 288 then 96 iterations): an instance whose slice is used up while others wait is parked and resumed later,
