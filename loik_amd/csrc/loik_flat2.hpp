@@ -2142,7 +2142,20 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   unsigned int my_iters = 0, n_wave_iters = 0, n_slot_loads = 0, n_slot_hits = 0;
   unsigned int* q_head = Bf.counters + LEAN_Q_HEAD;
   unsigned int cbits = 0u;
-  auto cmask = [&](int c) -> T { return ((cbits >> c) & 1u) ? T(1) : T(0); };
+  // The constraints whose joint lies in this joint's subtree as a LIST (four bits each, 15 = no more; at most ten constraints reach the flat
+  // engines) and `ncl`, the longest list of the wavefront.  The two sums over the constraints (p^base for tau, the force balance for f) visit
+  // ncl slots, not all L.nc blocks: every block read is a broadcast that occupies the LDS pipe like any other read (scripts/ubench/lds_rate.hip) --
+  // whole body, four tasks: 72 of an iteration's ~200 LDS reads and 72 multiply-adds, of which a joint's own chains need half (a joint of a
+  // fixed-base humanoid lies on the chains of at most two of the four end effectors).  A slot past a lane's list reads a valid block with weight 0,
+  // as the skipped blocks had: the sums are those of the loop over all blocks, term by term.
+  unsigned int cpk_lo = ~0u, cpk_hi = ~0u;
+  int ncl = 0;
+  auto cslot_of = [&](int s_, unsigned int tok, const T*& c_, T& m) {
+    const unsigned int wd = opaque_here(s_ < 8 ? cpk_lo : cpk_hi, tok);   // (tied to the iteration: the block addresses are not hoisted into registers)
+    const unsigned int cc = (wd >> (4 * (s_ & 7))) & 15u;
+    m = cc != 15u ? T(1) : T(0);
+    c_ = cdi + (cc != 15u ? cc : 0u) * cs;
+  };
   const int ccl = lane / 6, ckl = lane - 6 * ccl;
   const bool iscl = lane < 6 * L.nc;
   T* const ccb = cdi + (iscl ? ccl : 0) * cs;   // (no null block here as in k_flat2: its 1.3 KB cost the whole-body batch a wavefront per CU)
@@ -2312,6 +2325,16 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     for (int c = 0; c < L.nc; ++c) {
       const int cl = (int)cdi[c * cs + C2_LANE];
       if (isj_lane && cl >= j && cl < j + size) cbits |= 1u << c;
+    }
+    {
+      unsigned long long pk = ~0ull;
+      int nmine = 0;
+      for (int c = 0; c < L.nc; ++c)
+        if ((cbits >> c) & 1u) { pk = (pk & ~(15ull << (4 * nmine))) | ((unsigned long long)c << (4 * nmine)); ++nmine; }
+      cpk_lo = (unsigned int)pk; cpk_hi = (unsigned int)(pk >> 32);
+      ncl = 0;
+      for (int t = L.nc; t > 0; --t)
+        if (__any(nmine >= t)) { ncl = t; break; }
     }
     if (jcslot >= 0) {
       T* c_ = cdi + jcslot * cs;
@@ -2510,9 +2533,9 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
         for (int k = 0; k < 6; ++k) PB[k] -= shv[lane * 6 + k];
       }
-      for (int c = 0; c < L.nc; ++c) {
-        const T* c_ = cdi + c * cs;
-        const T m = cmask(c);
+      for (int s_ = 0; s_ < ncl; ++s_) {
+        const T* c_; T m;
+        cslot_of(s_, itok, c_, m);
 #pragma unroll
         for (int k = 0; k < 6; ++k) PB[k] += m * (c_[C2_ATYW + k] - mu_eq * c_[C2_ATBW + k]);
       }
@@ -2679,9 +2702,9 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #pragma unroll
         for (int k = 0; k < 6; ++k) Fw[k] -= shv[lane * 6 + k];
       }
-      for (int c = 0; c < L.nc; ++c) {
-        const T* c_ = cdi + c * cs;
-        const T m = cmask(c);
+      for (int s_ = 0; s_ < ncl; ++s_) {
+        const T* c_; T m;
+        cslot_of(s_, itok, c_, m);
 #pragma unroll
         for (int k = 0; k < 6; ++k) Fw[k] += m * c_[C2_ATYF + k];
       }

@@ -43,6 +43,19 @@ __global__ void k(double* out, int n, unsigned long long* cyc)
     } else if (KIND == 4) {   // 4 x ds_write2_b64
       asm volatile("ds_write2_b64 %0, %1, %1 offset1:64\n\tds_write2_b64 %0, %1, %1 offset0:128 offset1:192\n\tds_write2_b64 %0, %1, %1 offset1:64\n\tds_write2_b64 %0, %1, %1 offset0:128 offset1:192\n\ts_waitcnt lgkmcnt(0)"
                    :: "v"(base + a8), "v"(acc) : "memory");
+    } else if (KIND == 6) {   // 4 x ds_bpermute_b32 (the LDS crossbar, no memory)
+      int r0, r1, r2, r3;
+      asm volatile("ds_bpermute_b32 %0, %4, %5\n\tds_bpermute_b32 %1, %4, %5\n\tds_bpermute_b32 %2, %4, %5\n\tds_bpermute_b32 %3, %4, %5\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(BCAST ? 0u : (unsigned int)((lane * 7 + 3) & 63) * 4u), "v"(lane) : "memory");
+      acc += r0 + r1 + r2 + r3;
+    } else if (KIND == 7) {   // 4 x ds_write_b64 with four lanes active
+      if (lane < 4)
+      asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %1 offset:512\n\tds_write_b64 %0, %1 offset:1024\n\tds_write_b64 %0, %1 offset:1536\n\ts_waitcnt lgkmcnt(0)"
+                   :: "v"(base + a8), "v"(acc) : "memory");
+    } else if (KIND == 8) {   // 4 x ds_read_b64, a gather with a two-way bank conflict in every group of 32 lanes (lanes l and l + 16 on one bank pair, different addresses)
+      asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(v0[0]), "=&v"(v1[0]), "=&v"(v2[0]), "=&v"(v3[0]) : "v"(base + (unsigned int)(lane & 15) * 8u + (unsigned int)((lane >> 4) & 1) * 256u) : "memory");
+      acc += v0[0] + v1[0] + v2[0] + v3[0];
     } else {                  // 4 x ds_write_b128
       __attribute__((ext_vector_type(2))) double w2 = {acc, acc};
       asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %1 offset:1024\n\tds_write_b128 %0, %1\n\tds_write_b128 %0, %1 offset:1024\n\ts_waitcnt lgkmcnt(0)"
@@ -68,7 +81,7 @@ void run(const char* name, int bytes_per_lane)
   unsigned long long cy; hipMemcpy(&cy, c, 8, hipMemcpyDeviceToHost);
   const double insts = (double)n * 4 * (threads / 64);
   // clock64 counts at 100 MHz on this part (wall clock): use the event time and an assumed 2.4 GHz beside it
-  printf("%-16s %-10s: %.3f ms for %.0f wave-instructions of the CU: %.2f ns each = %.1f cycles at 2.4 GHz (%.0f B/clk)\n", name, BCAST ? "broadcast" : "contiguous", ms, insts,
+  printf("%-20s %-10s: %.3f ms for %.0f wave-instructions of the CU: %.2f ns each = %.1f cycles at 2.4 GHz (%.0f B/clk)\n", name, BCAST ? "broadcast" : "contiguous", ms, insts,
          ms * 1e6 / insts, ms * 1e6 / insts * 2.4, 64.0 * bytes_per_lane / (ms * 1e6 / insts * 2.4));
   hipFree(d); hipFree(c);
 }
@@ -76,6 +89,7 @@ int main()
 {
   run<0, false>("ds_read_b64", 8); run<1, false>("ds_read2_b64", 16); run<2, false>("ds_read_b128", 16);
   run<0, true>("ds_read_b64", 8); run<1, true>("ds_read2_b64", 16); run<2, true>("ds_read_b128", 16);
+  run<6, false>("ds_bpermute_b32", 4); run<6, true>("ds_bpermute_b32", 4); run<7, false>("ds_write_b64 4 lanes", 8); run<8, false>("ds_read_b64 2-way", 8);
   run<3, false>("ds_write_b64", 8); run<4, false>("ds_write2_b64", 16); run<5, false>("ds_write_b128", 16);
   return 0;
 }
