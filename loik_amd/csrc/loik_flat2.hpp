@@ -2034,7 +2034,7 @@ __host__ __device__ constexpr int flat1_xregion()
 {
   int n = XROWS * 9;
   if (NA * WAVE + 2 > n) n = NA * WAVE + 2;
-  if (2 * XROWS * 6 > n) n = 2 * XROWS * 6;       // two sets of prefix rows (HD)
+  if (2 * 6 * (WAVE + 2) > n) n = 2 * 6 * (WAVE + 2);   // two sets of prefix rows [6][66] (HD)
   return (n + 1) & ~1;
 }
 template <int NA>
@@ -2638,17 +2638,17 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
           for (int k = 0; k < 6; ++k) P2[k] = prefix64(E2[k]);
         }
 #pragma unroll
-        for (int c = 0; c < 6; ++c) xb[lane * 6 + c] = Pk[c];
+        for (int c = 0; c < 6; ++c) xb[c * PATH_RS + lane] = Pk[c];   // (component-major: a lane's six words 48 B apart put lanes l and l + 8 of a store, l and l + 16 of a load, on one bank)
         if constexpr (HD) {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) xb[(WAVE + 1) * 6 + lane * 6 + c] = P2[c];
+          for (int c = 0; c < 6; ++c) xb[(6 + c) * PATH_RS + lane] = P2[c];
         }
         tail_sync();
 #pragma unroll
-        for (int c = 0; c < 6; ++c) SEn[c] = (xb[src * 6 + c] - Pk[c]) + E[c];
+        for (int c = 0; c < 6; ++c) SEn[c] = (xb[c * PATH_RS + src] - Pk[c]) + E[c];
         if constexpr (HD) {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) SHn[c] = (xb[(WAVE + 1) * 6 + src * 6 + c] - P2[c]) + E2[c];
+          for (int c = 0; c < 6; ++c) SHn[c] = (xb[(6 + c) * PATH_RS + src] - P2[c]) + E2[c];
         }
       }
       if (iscl) {  // the constraint's force at the world origin: AW y (the next FwdPass1's A^T y; this iteration's share of f)
