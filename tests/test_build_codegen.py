@@ -1,0 +1,40 @@
+"""The flat iteration kernels' code generation (loik_amd/_build.py::FLAT_FLAGS, loik_amd/csrc/loik_flat_inst.hpp): k_flat2 / k_flat1 live in a
+code object of their own whose LDS accesses are single 64-bit instructions -- a ds_read2_b64 occupies the LDS pipe 3.4 x as long as a
+ds_read_b64 on MI355X (scripts/ubench/lds_rate.hip).  A toolchain or flag change that silently brought the merged forms back would cost the
+whole body ~10 % and the headline ~4 % without failing any parity test: this looks at the shipped library.  CPU only (llvm-objdump)."""
+import os
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+from loik_amd import _build
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="no llvm-objdump in this image")
+def test_flat_kernels_have_their_own_code_object_without_merged_lds_accesses():
+    lib = _build.build()
+    with tempfile.TemporaryDirectory() as d:
+        tmp = os.path.join(d, "lib.so")
+        shutil.copy(lib, tmp)
+        subprocess.run([OBJDUMP, "--offloading", tmp], check=True, capture_output=True)
+        objs = sorted(f for f in os.listdir(d) if "amdgcn" in f and "gfx950" in f)
+        assert len(objs) == 2, objs   # (host unit, flat unit)
+        seen = {}
+        for f in objs:
+            dis = subprocess.run([OBJDUMP, "-d", os.path.join(d, f)], check=True, capture_output=True, text=True).stdout
+            flat = dis.count("k_flat2") + dis.count("k_flat1") > 0
+            seen[flat] = {op: dis.count(op + " ") for op in ("ds_read2_b64", "ds_read2st64_b64", "ds_write2_b64", "ds_read_b64", "ds_write_b64")}
+        assert set(seen) == {True, False}, seen          # the flat kernels are in one object only
+        fl, host = seen[True], seen[False]
+        # a few merged reads remain outside the loops (explicit two-word loads of the load path); the loops' thousands are single accesses
+        assert fl["ds_read_b64"] > 20 * (fl["ds_read2_b64"] + fl["ds_read2st64_b64"]) and fl["ds_write2_b64"] == 0, fl
+        assert host["ds_read2_b64"] > 100, host           # (and the other kernels keep the default code generation)
+
+
+def test_flat_flags_are_what_the_design_says():
+    assert "-load-store-opt" in _build.FLAT_FLAGS and "-amdgpu-load-store-vectorizer=0" in _build.FLAT_FLAGS
+    assert "loik_flat_kernels.hip" in _build.SOURCES
