@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LOIKB_VERSION 500  /* round.minor: bumped whenever a struct or an entry point of this header changes */
+#define LOIKB_VERSION 600  /* round.minor: bumped whenever a struct or an entry point of this header changes */
 
 /* ---- status codes -------------------------------------------------------------------------------- */
 enum {
@@ -344,6 +344,11 @@ typedef struct loikb_stats {
   int flat_built;                         /* decade slots (W / Dinv of one instance for one mu) built by the instance's own wavefront
                                              inside k_flat2: every change of mu under the OSQP rule, decades outside the table
                                              with LOIKB_FLAT_BUILD=1 (round 5)                                                  */
+  int flat_probe_launches;                /* of flat_split_launches: those that ran as TWO launches -- every instance for
+                                             LOIKB_FLAT_PROBE=p iterations at most, then the survivors to completion, longest
+                                             predicted first (round 6; an experiment kept as an option: the default is one launch
+                                             with round-robin time slices, which it does not beat)                              */
+  double probe_ms;                        /* HIP-event time of those probe launches incl. the sort of the survivors (part of tail_ms) */
 } loikb_stats;
 int loikb_get_stats(loikb_solver *s, loikb_stats *out);
 /* which kernels the solves of this handle use and why (the engine plan is made in one place, from (nb, nc, sharing mode of

@@ -49,10 +49,11 @@ class Stats(C.Structure):
                 ("tail_instance_iterations", C.c_ulonglong), ("tail_launches", C.c_int), ("team", C.c_int), ("chunks", C.c_int),
                 ("solve_busy_ms", C.c_double), ("tail_busy_ms", C.c_double), ("lean_launches", C.c_int),
                 ("lean_escaped", C.c_int), ("hslots_ms", C.c_double), ("lean_requeues", C.c_int), ("flat_launches", C.c_int), ("queue_dry_ms", C.c_double),
-                ("flat_split_launches", C.c_int), ("flat_ordered", C.c_int), ("flat_built", C.c_int)]
+                ("flat_split_launches", C.c_int), ("flat_ordered", C.c_int), ("flat_built", C.c_int),
+                ("flat_probe_launches", C.c_int), ("probe_ms", C.c_double)]
 
 
-ABI_VERSION = 500   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
+ABI_VERSION = 600   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
 
 # enums of loik_amd.h
 F64, F32 = 0, 1

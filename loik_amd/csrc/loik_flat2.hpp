@@ -607,6 +607,19 @@ __device__ __forceinline__ X held(X x)
 #define LOIKB_HELD_ALWAYS 0
 #endif
 constexpr int FLAT_COUNTERS_BUILT = 17;  // Bufs::counters[17]: decade slots built in-wave during the launch
+// Two-launch schedule of a batch whose iteration counts nobody knows yet (round 6; k_flat2<.., SLICED>, flags in `quantum`):
+//  FLAT_Q_PROBE  -- the PROBE launch: every listed instance runs `first slice + later slice` iterations at most; max(primal, dual) is noted
+//    at three marks (the end of the first slice, FLAT_PROBE_LAST iterations before the probe's end, the probe's end); whoever is not done
+//    by then is parked and its ring entry appended behind the fresh ones (ring[nslots ..): nobody takes it up in this launch).
+//    k_probe_sort then orders the survivors by the iterations they are predicted to need still, longest first.
+//  FLAT_Q_FINISH -- the launch that finishes them takes that list front to back, every instance to completion: the long runners start at
+//    t = 0 of the launch and are never interrupted (the round robin of the single time-sliced launch serves the survivors of its first
+//    slice in turns for as long as there are more of them than wavefronts).  The entries are parked records: an instance continues
+//    exactly where the probe left it, so the schedule changes no bit of any result.
+constexpr int FLAT_Q_PROBE = 1 << 30, FLAT_Q_FINISH = 1 << 29;
+constexpr int FLAT_PROBE_LAST = 32;   // the probe's middle mark: this many iterations before its end
+constexpr int FLAT_COUNTERS_FIN_N = 18;   // Bufs::counters[18]: entries of the list a FLAT_Q_FINISH launch takes (k_probe_sort)
+constexpr int FI_MARK0 = FI_RED + 13, FI_MARK1 = FI_RED + 14, FI_MARKM = FI_RED + 15;   // (spare entries of the scalar block: max(primal, dual) at the marks; MARK1: the latest)
 constexpr int FLAT_COUNTERS_DEC = 32;    // Bufs::counters[32 .. 63]: slots taken up (loaded or built) per decade kexp + 16
 template <int NA, int WPE, bool SLICED = false, int HM = 0, bool LOG = false, int MUR = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
@@ -641,8 +654,8 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const QuietF32 qth = quiet_f32_thresholds(P.tol_abs, P.tol_rel, P.tol_primal_inf);
   // (iterations per time slice; none: never ends.  quantum = first | later << 16: an instance's FIRST slice and its later ones -- the later
   //  ones shorter, so that the instances still running when the queue is empty have done the same number of iterations to within that)
-  const int slice_len = (SLICED && quantum > 0) ? (quantum & 0xffff) : 0x3fffffff;
-  const int slice_len2 = (SLICED && (quantum >> 16) > 0) ? (quantum >> 16) : slice_len;
+  const int slice_len = (SLICED && (quantum & 0xffff) > 0) ? (quantum & 0xffff) : 0x3fffffff;
+  const int slice_len2 = (SLICED && ((quantum >> 16) & 0x1fff) > 0) ? ((quantum >> 16) & 0x1fff) : slice_len;
   // (LOIKB_HELD_ALWAYS=1 -- the plain build too, whose quiet test re-fetches them since round 5 -- measured: lone 2.278 -> 2.325 us, bulk +0.5 %: not adopted)
   const double tol_abs_h = held<LOIKB_HELD_ALWAYS || SLICED || WPE >= 3 || MUR >= 1>(P.tol_abs), tpi_h = held<LOIKB_HELD_ALWAYS || SLICED || WPE >= 3 || MUR >= 1>(P.tol_primal_inf);
   const int max_iter_h = held<LOIKB_HELD_ALWAYS || SLICED || WPE >= 3 || MUR >= 1>(P.max_iter);
@@ -784,11 +797,23 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       return nx < nslots ? ring[nx] : -1;
     } else {
       int got = -1;
-      if (lane == 0) {
+      if (lane == 0 && (quantum & FLAT_Q_FINISH)) {
+        // the sorted list front to back, one atomic per fetch
+        const unsigned int n2 = __hip_atomic_load(Bf.counters + FLAT_COUNTERS_FIN_N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int at = atomicAdd(q_head, 1u);
+        if (at < n2) got = __hip_atomic_load(ring + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (atomicCAS(Bf.counters + FLAT_COUNTERS_DRY, 0u, 1u) == 0u)
+          __hip_atomic_store(Bf.counters + FLAT_COUNTERS_TDRY, (unsigned int)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (lane == 0) {
         const unsigned int ticket = atomicAdd(q_head, 1u);
         int* e = ring + (ticket & (unsigned int)ring_mask);
         bool noted = false;
         for (unsigned int spins = 0;; ++spins) {
+          if ((quantum & FLAT_Q_PROBE) && ticket >= (unsigned int)nslots) {   // (the probe launch hands out the fresh entries only)
+            if (atomicCAS(Bf.counters + FLAT_COUNTERS_DRY, 0u, 1u) == 0u)
+              __hip_atomic_store(Bf.counters + FLAT_COUNTERS_TDRY, (unsigned int)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
           const int v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (v >= 0) { __hip_atomic_store(e, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); got = v; break; }
           if (__hip_atomic_load(q_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)nslots) break;
@@ -1350,15 +1375,25 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     need_build = false;
    while (true) {
     if (SLICED && !done && iter >= slice_end) {
-      // time slice used up: if others wait, to the back of the queue (one round trip to the queue's counters per slice: ~2 us in
-      // several hundred; slightly stale is fine, the decision is a heuristic)
-      unsigned int qt = 0u, qh = 0u;
-      if (lane == 0) {
-        qt = __hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        qh = __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (quantum & FLAT_Q_PROBE) {
+        // the probe launch: the slices end at the marks (the residual is noted, the instance carries on) and at the probe's length:
+        // parked, to be finished by the next launch
+        const int k0 = slice_len, k1 = slice_len + slice_len2, km = slice_len2 > FLAT_PROBE_LAST ? k1 - FLAT_PROBE_LAST : k1;
+        if (iter >= k1) { requeue = true; break; }
+        if (iter <= k0) { if (lane == 0) isc[FI_MARK0] = isc[FI_MARK1]; }
+        else if (lane == 0) isc[FI_MARKM] = isc[FI_MARK1];
+        slice_end = iter < km ? km : k1;
+      } else {
+        // time slice used up: if others wait, to the back of the queue (one round trip to the queue's counters per slice: ~2 us in
+        // several hundred; slightly stale is fine, the decision is a heuristic)
+        unsigned int qt = 0u, qh = 0u;
+        if (lane == 0) {
+          qt = __hip_atomic_load(q_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          qh = __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (__builtin_amdgcn_readfirstlane((int)(qt - qh) > 0 ? 1 : 0)) { requeue = true; break; }
+        slice_end = iter + (iter >= slice_len ? slice_len2 : slice_len);   // nobody waits for this wavefront: carry on
       }
-      if (__builtin_amdgcn_readfirstlane((int)(qt - qh) > 0 ? 1 : 0)) { requeue = true; break; }
-      slice_end = iter + (iter >= slice_len ? slice_len2 : slice_len);   // nobody waits for this wavefront: carry on
       q_lim = (slice_end - 1 < q_lim_run) ? slice_end - 1 : q_lim_run;
     }
     // ---- does the instance leave before this iteration?  (fetched already finished; this launch's share of iterations used up;
@@ -1793,6 +1828,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
             }
             goto next_iteration;
           }
+          if constexpr (SLICED) { if (lane == 0) isc[FI_MARK1] = hmax(primal, dual); }   // (a slice ends here: what the probe launch's marks read)
           continue;
         }
       }
@@ -1861,6 +1897,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     kexp += (mu_up ? 1 : 0) - (mu_dn ? 1 : 0);
     nflip += (mu_up || mu_dn) ? 1 : 0;
     done = stop;
+    if constexpr (SLICED) { if (logic && lane == 0) isc[FI_MARK1] = hmax(primal, dual); }
     // ---- what the getters report: written when an instance stops (the certificate's scalars also when it enters the tail
     // solve: they keep the values of the last iteration that evaluated them) -------------------------------------------------
     T r1[8], r2[8];
@@ -1947,11 +1984,28 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       // with them, the ticket for the NEXT entry; (2) once the stores have landed: this instance's place at the tail, and the entry
       // the ticket points at; (3) that entry's record and decade slot together (unpark).
       park_instance();
+      const bool q_probe = (quantum & FLAT_Q_PROBE) != 0, q_deque = (quantum & FLAT_Q_FINISH) != 0;
       unsigned int tk = 0u;
-      if (lane == 0) tk = atomicAdd(q_head, 1u);
+      if (lane == 0 && !q_probe && !q_deque) tk = atomicAdd(q_head, 1u);
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): every store of the record has completed before the entry appears
       __builtin_amdgcn_wave_barrier();
       int got = -1;
+      if (q_probe || q_deque) {
+        // probe launch: the entry goes behind the fresh ones and stays there (k_probe_sort reads it).  The launch that finishes the
+        // survivors parks for one reason only -- a decade slot to be built (MUR = 2) -- and the wavefront takes the instance up again itself.
+        const int dslp = MUR == 1 ? (mu == P.mu0 ? 0 : 15) : kexp - kexp_lo;
+        const int code = build_req ? (FLAT_BUILD_REQ | (((kexp + 8) & 15) << 24)) : ((dslp >= 0 && dslp < ndec ? dslp : 15) << 24);
+        const int entry = lidx | FLAT_PARKED | code;
+        if (q_probe) {
+          if (lane == 0) {
+            const unsigned int pos = atomicAdd(q_tail, 1u);
+            __hip_atomic_store(ring + (pos & (unsigned int)ring_mask), entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          got = -2;   // (the next instance: an ordinary fetch)
+        } else {
+          got = entry;
+        }
+      } else
       if (lane == 0) {
         const unsigned int pos = atomicAdd(q_tail, 1u);
         int* en = ring + (tk & (unsigned int)ring_mask);
@@ -2014,6 +2068,66 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
 #undef maxdepth
 #undef win_bits
 
+// ---- between the probe launch and the launch that finishes its survivors (FLAT_Q_PROBE / FLAT_Q_FINISH above) -----------------------
+// The survivors' ring entries (ring[n_fresh .. tail)) sorted by the iterations they are predicted to need still, longest first, into
+// ring[0 ..): a counting sort in PROBE_BINS classes of four iterations, one workgroup (the survivors are 5 % of a batch; their order
+// inside a class is whatever the atomics make it -- the order decides when an instance runs, never what it computes).  The prediction:
+// r = max(primal, dual) fell from r0 (first mark, iteration k0) over rm (middle mark, km) to r1 at the probe's end (k1); at the SLOWER of
+// the two rates -- over the whole probe, over its last stretch -- the tolerance is log(r1 / tol) / rate iterations away (the residual of
+// this ADMM falls in stretches and stalls between them, with jumps at the changes of mu: the rate over the whole probe alone ranks a few
+// instances per batch that have just stalled as nearly done, and ONE long runner started last costs the launch its whole chain; a
+// residual that stalls or rises counts as long as max_iter allows).  An instance parked BEFORE the probe's end (a decade slot to be
+// built) has no marks and counts as long.  Also resets the queue's counters for the launch that follows.
+#ifndef LOIKB_FLAT_KERNELS_TU
+constexpr int PROBE_BINS = 256;
+__global__ void __launch_bounds__(1024) k_probe_sort(int* __restrict__ ring, int n_fresh, int ring_mask, const double* __restrict__ park,
+                                                     int park_stride, int isc_off, int scal_off, unsigned int* __restrict__ counters,
+                                                     int k0, int km, int k1, int max_iter, double tol)
+{
+  __shared__ unsigned int h[PROBE_BINS], base[PROBE_BINS];
+  const int t = threadIdx.x;
+  if (t < PROBE_BINS) h[t] = 0u;
+  __syncthreads();
+  const int nsurv = (int)counters[LEAN_Q_TAIL] - n_fresh;
+  auto bin_of = [&](int entry) -> int {
+    const double* pk = park + (size_t)(entry & 0xFFFFF) * park_stride;
+    const int it = (int)pk[scal_off + 2];
+    float pr = 4.0f * PROBE_BINS;
+    if (it >= k1 && k1 > k0) {
+      const float r0 = (float)pk[isc_off + FI_MARK0], rm = (float)pk[isc_off + FI_MARKM], r1 = (float)pk[isc_off + FI_MARK1];
+      const float tl = (float)(tol > 1e-30 ? tol : 1e-30);
+      if (r0 > 0.f && r1 > 0.f) {
+        const float l1 = __logf(r1), left = l1 - __logf(tl);
+        float rate = (__logf(r0) - l1) / (float)(k1 - k0);
+        if (km > k0 && km < k1 && rm > 0.f) { const float r2 = (__logf(rm) - l1) / (float)(k1 - km); rate = r2 < rate ? r2 : rate; }
+        pr = left <= 0.f ? 0.f : (rate > 2e-4f ? left / rate : 4.0f * PROBE_BINS);
+      }
+    }
+    const float cap = (float)(max_iter - it);
+    if (pr > cap) pr = cap;
+    int b = (int)(pr * 0.25f);
+    b = b < 0 ? 0 : b > PROBE_BINS - 1 ? PROBE_BINS - 1 : b;
+    return PROBE_BINS - 1 - b;   // (class 0 = the longest)
+  };
+  for (int i = t; i < nsurv; i += blockDim.x) atomicAdd(&h[bin_of(ring[(n_fresh + i) & ring_mask])], 1u);
+  __syncthreads();
+  if (t == 0) {
+    unsigned int acc = 0u;
+    for (int b = 0; b < PROBE_BINS; ++b) { base[b] = acc; acc += h[b]; }
+  }
+  __syncthreads();
+  for (int i = t; i < nsurv; i += blockDim.x) {
+    const int entry = ring[(n_fresh + i) & ring_mask];
+    ring[atomicAdd(&base[bin_of(entry)], 1u)] = entry;
+  }
+  if (t == 0) {
+    counters[FLAT_COUNTERS_FIN_N] = (unsigned int)(nsurv > 0 ? nsurv : 0);
+    counters[LEAN_Q_HEAD] = 0u;
+    counters[FLAT_COUNTERS_DRY] = 0u;   // (the queue of the launch that follows has not run dry yet)
+  }
+}
+#endif
+
 
 // ------------------------------------------------------------------------------------------------------------------------
 // k_flat1<NA>: ONE instance per wavefront, one lane per joint -- the robots of 33..64 joints (G = 64: the 44-DoF whole-body Talos),
@@ -2070,8 +2184,8 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   const QuietF32 qth = quiet_f32_thresholds(P.tol_abs, P.tol_rel, P.tol_primal_inf);
   // (iterations per time slice; none: never ends.  quantum = first | later << 16: an instance's FIRST slice and its later ones -- the later
   //  ones shorter, so that the instances still running when the queue is empty have done the same number of iterations to within that)
-  const int slice_len = (SLICED && quantum > 0) ? (quantum & 0xffff) : 0x3fffffff;
-  const int slice_len2 = (SLICED && (quantum >> 16) > 0) ? (quantum >> 16) : slice_len;
+  const int slice_len = (SLICED && (quantum & 0xffff) > 0) ? (quantum & 0xffff) : 0x3fffffff;
+  const int slice_len2 = (SLICED && ((quantum >> 16) & 0x1fff) > 0) ? ((quantum >> 16) & 0x1fff) : slice_len;
   const double tol_abs_h = held<SLICED>(P.tol_abs), tpi_h = held<SLICED>(P.tol_primal_inf);   // (see k_flat2)
   const int max_iter_h = held<SLICED>(P.max_iter);
   const int j = lane;  // lane <-> device joint j + 1

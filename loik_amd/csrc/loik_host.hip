@@ -70,6 +70,9 @@ struct Tuning {
   int flat_build = 2;           // (default 2 since the end of round 5; 0: the full table always) LOIKB_FLAT_BUILD=1: the lazily populated table on every k_flat2 launch (window: LOIKB_FLAT_WINDOW, else all of it), 2: on time-sliced launches, window from the handle's history; k_flat2 builds a decade slot its table lacks in-wave (flat_build_slot) instead of handing the instance to k_tail
   int fslot_dgrp = 0;           // LOIKB_FSLOT_DGRP=g: k_fslots takes the decades through its two passes g at a time (default: all)
   int flat_slice2 = 0;          // LOIKB_FLAT_SLICE2=q: an instance's later slices (0: as the first)
+  int flat_probe = 0;           // (default 0: measured a wash against the round robin, profiles/r06_a_probe_and_finish_ab.txt; given: wherever LOIKB_FLAT_SLICE / the default slices it) LOIKB_FLAT_PROBE=p: a time-sliced k_flat2 launch without an order becomes TWO launches -- every instance for p iterations at
+                                // most, then the survivors to completion, longest predicted first (0: one launch, round robin: round 5's)
+  int flat_probe_mark = 32;     // LOIKB_FLAT_PROBE_MARK=k: the probe's first mark (the residual's rate of fall is taken between it and the probe's end)
   int flat_slice = -1;          // LOIKB_FLAT_SLICE=q: k_flat2's / k_flat1's round-robin time slice in iterations (0: never; default: 288 for
                                 // launches in arrival order of >= 32 768 instances, see flat_slice_for / run_tail)
   bool flat_zero_state = true;  // LOIKB_FLAT_ZERO_STATE=0: k_flat2 / k_flat1 fetch vis, fis, g, w, z of every instance even straight after a cold reset
@@ -104,7 +107,9 @@ struct Tuning {
     if (const char* e = getenv("LOIKB_FLAT_BUILD")) flat_build = std::max(0, std::min(2, atoi(e)));
     if (const char* e = getenv("LOIKB_FLAT_WINDOW")) { if (sscanf(e, "%d,%d", &flat_win_lo, &flat_win_n) != 2) flat_win_n = 0; }
     if (const char* e = getenv("LOIKB_FLAT_SLICE")) flat_slice = std::min(65535, std::max(-1, atoi(e)));
-    if (const char* e = getenv("LOIKB_FLAT_SLICE2")) flat_slice2 = std::min(32767, std::max(0, atoi(e)));
+    if (const char* e = getenv("LOIKB_FLAT_SLICE2")) flat_slice2 = std::min(8191, std::max(0, atoi(e)));
+    if (const char* e = getenv("LOIKB_FLAT_PROBE")) flat_probe = std::min(8000, std::max(0, atoi(e)));
+    if (const char* e = getenv("LOIKB_FLAT_PROBE_MARK")) flat_probe_mark = std::max(1, atoi(e));
     if (const char* e = getenv("LOIKB_FSLOT_DGRP")) fslot_dgrp = std::max(0, atoi(e));
     if (const char* e = getenv("LOIKB_FLAT_ORDER")) flat_order = atoi(e) != 0;
     if (const char* e = getenv("LOIKB_FLAT_ZERO_STATE")) flat_zero_state = atoi(e) != 0;
@@ -243,7 +248,7 @@ struct loikb_solver_impl {
     Set set[3];                          // [0] view of the home tiles of the range, [1],[2] work sets of the compaction
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_k2 = nullptr;
+    hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_k2 = nullptr, ev_k3 = nullptr;
     unsigned int* d_counters = nullptr;
     unsigned int* h_counters = nullptr;  // pinned
     int* d_slots = nullptr;              // list of the live instances handed to the tail kernel
@@ -265,6 +270,7 @@ struct loikb_solver_impl {
     unsigned int* d_fmask = nullptr;     // k_flat2<.., MUR = 2>: per instance, which decades of the slot table are populated
     size_t fmask_n = 0;
     void** d_aux = nullptr;              // k_flat2's cold pointers behind one argument: {TailTopo*, child list, fmask}
+    const void* aux_h[4] = {nullptr, nullptr, nullptr, nullptr};   // (what d_aux holds)
     size_t park_bytes = 0;
     std::vector<int> h_wave;             // host scratch for the compaction scan
     loikb_stats stats{};
@@ -1073,6 +1079,7 @@ void destroy_chunks(loikb_solver_impl* S)
     if (C.d_aux) (void)hipFree(C.d_aux);
     if (C.ev_k0) (void)hipEventDestroy(C.ev_k0);
     if (C.ev_k2) (void)hipEventDestroy(C.ev_k2);
+    if (C.ev_k3) (void)hipEventDestroy(C.ev_k3);
     if (C.ev_k1) (void)hipEventDestroy(C.ev_k1);
     if (C.own_stream && C.stream) (void)hipStreamDestroy(C.stream);
     void* ptrs[6] = {C.d_counters, C.d_slots, C.d_slots2, C.d_ring, C.d_order, C.d_order_bins};
@@ -1101,6 +1108,7 @@ int build_chunks(loikb_solver_impl* S, int nchunks)
   int rc;
   for (Chunk& C : S->chunks) {
     HIPCHK(hipEventCreate(&C.ev_k2));
+    HIPCHK(hipEventCreate(&C.ev_k3));
     HIPCHK(hipEventCreate(&C.ev_k0));
     HIPCHK(hipEventCreate(&C.ev_k1));
     HIPCHK(hipHostMalloc((void**)&C.h_counters, NCOUNTERS * sizeof(unsigned int)));
@@ -1850,13 +1858,19 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       }
       HIPCHK(hipEventRecord(C->ev_k2, C->stream));
       const int n_first = n;
+      bool probe_timed = false;
       dim3 grid((unsigned)std::min((n + ipw - 1) / ipw, cap_lat));
       {
         hipLaunchKernelGGL(k_ring_fill, grid1(C->ring_cap), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, list, n, C->d_counters);
         if (split || one) {   // (what only the in-wave builder / the lazily populated table read, behind one kernel argument)
+          // (uploaded when one of the pointers changes -- synchronously, from the chunk's own copy: ADVICE r05)
           if (C->d_aux == nullptr) HIPCHK(hipMalloc((void**)&C->d_aux, 4 * sizeof(void*)));
           const void* auxh[4] = {S->d_topo, S->d_child_list, C->d_fmask, nullptr};
-          HIPCHK(hipMemcpyAsync(C->d_aux, auxh, sizeof(auxh), hipMemcpyHostToDevice, C->stream));
+          if (memcmp(auxh, C->aux_h, sizeof(auxh)) != 0) {
+            memcpy(C->aux_h, auxh, sizeof(auxh));
+            HIPCHK(hipStreamSynchronize(C->stream));
+            HIPCHK(hipMemcpy(C->d_aux, C->aux_h, sizeof(auxh), hipMemcpyHostToDevice));
+          }
         }
         if (split) {
           // k_flat2: two lanes per joint, one instance per wavefront, two or three wavefronts per SIMD (loik_flat2.hpp)
@@ -1900,6 +1914,12 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                      (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv | ((S->maxdepth & 0xFF) << 8) | (win_bits << 16), C->ring_cap - 1, quantum,       \
                      (double*)C->d_park, flat2_park_stride(S->nc, true), (const void* const*)C->d_aux)
           const int hm = S->per_link ? 3 : href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
+          // Two launches instead of one time-sliced one (FLAT_Q_PROBE / FLAT_Q_FINISH, loik_flat2.hpp): the probe, k_probe_sort, the survivors.
+          const int probe_len = S->tune.flat_probe, probe_mark = std::min(S->tune.flat_probe_mark, std::max(1, probe_len / 2));
+          const bool two_launches = quantum > 0 && probe_len >= 2 && !ordered && mur != 1 && !S->opt.logging && wpe != 3 &&
+                                    S->opt.max_iter > probe_len && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS);
+          const int quantum_one = quantum;
+          auto launch_flat2 = [&](int quantum) {
           if (mur == 1) {
             // (OSQP's rule runs unsliced unless LOIKB_FLAT_SLICE asks: a parked instance rebuilds its factors when it is taken up again --
             //  headline batch, first solve: 12.7 ms with the default slices, 11.4 without: profiles/r05_d_mu_rules.jsonl)
@@ -1925,6 +1945,23 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           else if (quantum > 0) { if (wpe == 3) LOIKB_LAUNCH_FLAT2(3, true); else LOIKB_LAUNCH_FLAT2(2, true); }
           else if (wpe == 3) LOIKB_LAUNCH_FLAT2(3);
           else LOIKB_LAUNCH_FLAT2(2);
+          };
+          if (two_launches) {
+            launch_flat2(probe_mark | ((probe_len - probe_mark) << 16) | FLAT_Q_PROBE);
+            HIPCHK(hipGetLastError());
+            const int nl_ = (has_hv ? F2G * 6 : 0) + S->nc * C2D;   // (the record's LDS blocks: shv | constraint blocks | the scalar block)
+            hipLaunchKernelGGL(k_probe_sort, dim3(1), dim3(1024), 0, C->stream, C->d_ring, n, C->ring_cap - 1, (const double*)C->d_park,
+                               flat2_park_stride(S->nc, true), FLAT2_PARK_ROWS * WAVE + nl_, FLAT2_PARK_ROWS * WAVE + nl_ + FISC, C->d_counters,
+                               probe_mark, probe_len - probe_mark > FLAT_PROBE_LAST ? probe_len - FLAT_PROBE_LAST : probe_len, probe_len, S->opt.max_iter,
+                               (double)S->opt.tol_abs);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(C->ev_k3, C->stream));
+            launch_flat2(FLAT_Q_FINISH);
+            C->stats.flat_probe_launches++;
+            probe_timed = true;
+          } else {
+            launch_flat2(quantum_one);
+          }
 #undef LOIKB_LAUNCH_FLAT2
         } else if (one) {
           // one decade slot in LDS instead of two when that buys wavefronts per CU (whole body, four task constraints: 6 -> 8)
@@ -2040,6 +2077,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         S->ud_stale = true;
       }
       C->stats.hslots_ms += hms;
+      if (probe_timed) { float pms = 0.f; HIPCHK(hipEventElapsedTime(&pms, C->ev_k2, C->ev_k3)); C->stats.probe_ms += pms; }
       if (C->h_counters[FLAT_COUNTERS_DRY])  // (100 MHz clock, low words: from the ring fill of the last stage to the first empty fetch)
         C->stats.queue_dry_ms += (double)(unsigned int)(C->h_counters[FLAT_COUNTERS_TDRY] - C->h_counters[FLAT_COUNTERS_T0]) * 1e-5;
       if ((split || one) && whole_set && n_first == n_cur) {
@@ -2483,6 +2521,8 @@ int run_main_loop_t(loikb_solver_impl* S)
     S->stats.flat_split_launches += C.stats.flat_split_launches;
     S->stats.flat_ordered += C.stats.flat_ordered;
     S->stats.flat_built += C.stats.flat_built;
+    S->stats.flat_probe_launches += C.stats.flat_probe_launches;
+    S->stats.probe_ms += C.stats.probe_ms;
     S->stats.queue_dry_ms += C.stats.queue_dry_ms;
     S->stats.lean_escaped += C.stats.lean_escaped;
     S->stats.hslots_ms += C.stats.hslots_ms;

@@ -673,3 +673,44 @@ def test_whole_body_osqp_rule_on_the_flat_engine(weight, monkeypatch):
     mu = s.get("mu")
     assert np.unique(np.round(np.log10(mu), 9)).size > 12
     s.close()
+
+
+def test_flat_probe_and_finish_in_two_launches_changes_nothing(talos, monkeypatch):
+    """Round 6: a time-sliced k_flat2 launch without an order runs as TWO launches -- the probe (every instance for LOIKB_FLAT_PROBE
+    iterations at most, the residual noted at three marks, survivors parked), k_probe_sort (survivors ordered by the iterations they
+    are predicted to need still), and the launch that takes that list front to back, every instance to completion.  A parked instance
+    continues exactly where it stopped, so every result is bit-identical to the single unsliced launch; forced here on 1500 instances
+    with short probes (5, 40 iterations) and with longer ones, with and without the lazily populated table."""
+    from loik_amd import workloads
+    B = 1500
+    wl = workloads.talos_c3(B, seed=321)
+    prm = dict(wl["params"], max_iter=400)
+    args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    keys = ("LOIKB_FLAT_SLICE", "LOIKB_FLAT_PROBE", "LOIKB_FLAT_PROBE_MARK", "LOIKB_FLAT_BUILD", "LOIKB_FLAT_WINDOW")
+    res = {}
+    cases = (("plain", dict(LOIKB_FLAT_SLICE="0")),
+             ("probe5", dict(LOIKB_FLAT_SLICE="288", LOIKB_FLAT_PROBE="5", LOIKB_FLAT_PROBE_MARK="2")),
+             ("probe40", dict(LOIKB_FLAT_SLICE="288", LOIKB_FLAT_PROBE="40")),
+             ("probe128_full_table", dict(LOIKB_FLAT_SLICE="288", LOIKB_FLAT_PROBE="128", LOIKB_FLAT_BUILD="0")),
+             ("probe320", dict(LOIKB_FLAT_SLICE="288", LOIKB_FLAT_PROBE="320")),
+             ("probe40_window", dict(LOIKB_FLAT_SLICE="288", LOIKB_FLAT_PROBE="40", LOIKB_FLAT_BUILD="1", LOIKB_FLAT_WINDOW="0,2")))
+    for name, env in cases:
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = loik_amd.BatchedLoik(talos, B, **prm)
+        s.Solve(*args)
+        st = s.stats()
+        assert st["flat_split_launches"] >= 1 and st["tail_instances"] == B
+        assert st["flat_probe_launches"] == (0 if name == "plain" else 1), (name, st)
+        if name != "plain":
+            assert st["lean_requeues"] > (100 if name != "probe320" else 10), (name, st)   # (the survivors were parked once each)
+        if name == "probe40_window":
+            assert st["flat_built"] > 0, st   # (decades outside the window: built in-wave, in either launch)
+        res[name] = {k: s.get(k) for k in ("iter", "converged", "primal_infeasible", "z", "nu", "mu", "yis", "fis", "vis")}
+        assert st["instance_iterations"] == int(res[name]["iter"].sum()), (name, st["instance_iterations"], int(res[name]["iter"].sum()))
+        s.close()
+    for name, _ in cases[1:]:
+        for k in res["plain"]:
+            assert np.array_equal(res["plain"][k], res[name][k]), (name, k)
