@@ -52,7 +52,8 @@ enum {
  * is implemented -- OSQP's published penalty rule on LoIK's residuals and normalisers, see update_mu() in
  * loik_amd/csrc/loik_device.hpp and the identical expression in the CPU oracle -- as an extension, not a parity target: on the
  * headline workload it ends most of DEFAULT's mu limit cycles (instances hitting max_iter: 1.16 % -> 0.14 %).  mu is then
- * off the decade grid, so such solves run in the k_solve / k_tail engines.
+ * off the decade grid: fp64 robots of 17..64 joints run it on the flat engines (k_flat2 / k_flat1 with MUR = 1: the wavefront
+ * builds W / Dinv itself at every change of mu, since round 5), everything else on k_solve / k_tail.
  * MAXEIGENVALUE, also declared and unimplemented upstream (hxx:635-637), is implemented HERE as a spectral initialisation of the
  * penalty followed by DEFAULT's decade steps: every solve starts at mu = the geometric mean of the extreme eigenvalues of the
  * links' cost blocks rho I + sym(H_ref,i) (all links that carry a cost), snapped to a quarter decade 10^(k/4), clipped to

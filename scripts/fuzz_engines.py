@@ -46,7 +46,7 @@ ENV_KEYS = ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_FLAT_SLICE", 
             "LOIKB_LEAN_WG_PER_CU", "LOIKB_FLAT_ORDER_HOLDOFF", "LOIKB_FLAT_BUILD", "LOIKB_FLAT_WINDOW", "LOIKB_LEAN_ADAPT")
 
 
-def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
+def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0, capture=None):
     """`ncase` random cases from `seed`; returns the summary dict (cases, mismatches, unconverged_only, refused, flat_cases, ...).
     max_batch bounds the batch sizes drawn (the test suite's slice uses a smaller bound); only = a case index to replay;
     flat_bias = share of the cases drawn inside the flat engine's domain (> 16 joints numbered depth-first, H_ref = h I, DEFAULT
@@ -155,6 +155,9 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
         got = fetch_end_to_end(s, residuals=not loose)
         same = got["iter"] == out["iters"]
         dz = np.abs(got["z"] - out["z"]).reshape(B, -1).max(axis=1)
+        if capture is not None:   # (scripts/r06/make_fuzz_fixtures.py: a replayed case's inputs and both solvers' answers)
+            capture(dict(case=case, model=model, wl=wl, prm=prm, refs=refs, engine=engine, env=env, kw=kw, spare=spare, nc=nc, osqp=osqp, out=out, got=got,
+                         same=same, dz=dz, mu=np.asarray(s.get("mu"), dtype=float)))
         ok, why = True, ""
         try:
             # (loose cases: the digits lost in f = H v + p scale with mu; the answer itself is only good to tol_abs -- the budget is
@@ -166,7 +169,7 @@ def fuzz(ncase, seed, verbose=True, max_batch=3000, only=None, flat_bias=0.0):
             #  apart after 200 iterations on a helical tree at tol 1e-8 -- : 1e-6 for those; an instance that stops one iteration earlier
             #  or later is tol / mu away where mu < 1, the dual residual being mu |z_k - z_k-1|: 1.2e-4 at mu = 3e-3 under OSQP's rule)
             mu_dev = np.asarray(s.get("mu"), dtype=float)
-            off_scale = np.maximum(1.0, 1.0 / np.maximum(mu_dev, 1e-12))
+            off_scale = np.minimum(np.maximum(1.0, 1.0 / np.maximum(mu_dev, 1e-12)), 1e3)   # (capped: OSQP clips mu at 1e-6, and a budget of 10 is no check -- ADVICE r05)
             assert_end_to_end(got, out, prm, same_frac=0.95 if B >= 70 else 0.0,
                               ztol=(max(1e-5, (1.0 if osqp else 0.5) * prm["tol_abs"]) if loose else 1e-7),
                               off_ztol=max(1e-5 if loose else 1e-6, 10 * prm["tol_abs"]), what="case %d" % case,

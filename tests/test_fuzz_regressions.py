@@ -1,0 +1,103 @@
+"""The deviations the engine fuzz found, pinned in the driver-run suite.
+
+Two cases of round 5's long fuzz runs (profiles/r05_j_fuzz_1500.txt case 1212, profiles/r05_j_fuzz_3000.txt case 1126) differ from the
+CPU oracle by more than the fuzz's budget.  Both were replayed on the GPU box (scripts/r06/make_fuzz_fixtures.py: same draws, same numbers
+to the last digit as in round 5) and frozen as fixtures: the inputs of 128 instances of the case -- every instance that was off the
+oracle's iteration count or among the sixteen furthest from its z, filled up with the batch's first instances; instances are independent,
+so the subset reproduces each instance's numbers -- and the oracle's answers.  The tests assert the CURRENT deviations as upper bounds: a
+change that makes them worse fails here, one that closes them can tighten the bounds.
+
+* case 1212: OSQP penalty rule on the flat engine (k_flat2<.., MUR = 1>, a 20-DoF multi-DoF tree, four task constraints, tol 1e-6).
+  Twelve of 3000 instances stop at another iteration than the oracle's (the rule's `mu sqrt(r_p / r_d)` leaves [0.2 mu, 5 mu] or not on
+  the last bits of the residuals, and this engine sums in another order than the oracle: a near-tie decided differently sends the two
+  solvers through different sequences of mu), both converged, up to 1.15e-5 apart at tol 1e-6: two answers of the same QP to the
+  solver's own accuracy, tol / mu with mu ~ 1.
+* case 1126: k_flat1 on a 43-joint tree, three task constraints, per-link references, tol 1e-8.  ONE converged instance, at the oracle's
+  iteration count, is 1.36e-7 from the oracle's z; every other instance is within 1.2e-10.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import loik_amd
+from oracle import ref
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ENV_KEYS = ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_FLAT_SLICE", "LOIKB_LEAN_KLO", "LOIKB_LEAN_DECADES", "LOIKB_LEAN_SLICE",
+            "LOIKB_LEAN_WG_PER_CU", "LOIKB_FLAT_ORDER_HOLDOFF", "LOIKB_FLAT_BUILD", "LOIKB_FLAT_WINDOW", "LOIKB_LEAN_ADAPT", "LOIKB_FLAT_PROBE")
+
+
+def load_case(name):
+    fx = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    pitch = fx["pitch"] if fx["pitch"].size else None
+    model = loik_amd.Model(fx["parents"], fx["jtype"], fx["axis"], fx["placement"], pitch=pitch, name=name)
+    prm = json.loads(str(fx["prm"])); env = json.loads(str(fx["env"])); kw = json.loads(str(fx["kw"]))
+    refs = (fx["refs_H"], fx["refs_v"]) if "refs_H" in fx.files else None
+    args = (fx["q"], fx["H_ref"], fx["v_ref"], fx["c_ids"], fx["Ais"], fx["bis"], fx["lb"], fx["ub"])
+    return fx, model, prm, env, kw, refs, args
+
+
+@pytest.mark.parametrize("name", ["r05_j_fuzz_1500_case1212", "r05_j_fuzz_3000_case1126"])
+def test_fixture_holds_the_oracles_answers(name):
+    """(CPU) the frozen answers are the oracle's on the frozen inputs: the fixture is data of the checker, not of the engine"""
+    fx, model, prm, env, kw, refs, args = load_case(name)
+    out = ref.solve_batch(model, *args, nthreads=4, refs=refs, **prm)
+    assert np.array_equal(out["iters"], fx["ref_iters"])
+    assert np.array_equal(out["converged"], fx["ref_converged"]) and np.array_equal(out["primal_infeasible"], fx["ref_primal_infeasible"])
+    assert np.abs(out["z"] - fx["ref_z"]).max() <= 1e-13
+
+
+def solve_on_gpu(monkeypatch, fx, model, prm, env, kw, refs, args):
+    for k in ENV_KEYS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    B = args[0].shape[0]
+    s = loik_amd.BatchedLoik(model, B, **prm, **kw, eq_c_capacity=int(fx["nc"]) + int(fx["spare"]))
+    for _ in range(2 if str(fx["engine"]) in ("flat_ordered", "lean_ordered") else 1):   # (flat_ordered: the second solve, longest first)
+        if refs is None:
+            s.Solve(*args)
+        else:
+            s.SolveInit(*args); s.UpdateReferences(*refs); s.Solve()
+    st = s.stats()
+    got = dict(iter=np.asarray(s.get("iter")), z=np.asarray(s.get("z")), converged=np.asarray(s.get("converged")).astype(bool),
+               primal_infeasible=np.asarray(s.get("primal_infeasible")).astype(bool))
+    s.close()
+    return got, st
+
+
+@pytest.mark.gpu
+def test_fuzz_r05_case1212_osqp_rule_on_the_flat_engine(monkeypatch):
+    fx, model, prm, env, kw, refs, args = load_case("r05_j_fuzz_1500_case1212")
+    got, st = solve_on_gpu(monkeypatch, fx, model, prm, env, kw, refs, args)
+    assert st["flat_split_launches"] >= 1 and st["flat_built"] > 0, st   # (k_flat2, OSQP's rule: in-wave builds)
+    dz = np.abs(got["z"] - fx["ref_z"]).max(axis=1)
+    same = got["iter"] == fx["ref_iters"]
+    # every instance converged in both solvers (nothing here is an unconverged iterate)
+    assert got["converged"].all() and fx["ref_converged"].all()
+    # the subset reproduces what the full batch gave
+    assert np.array_equal(got["iter"], fx["gpu_iters_full_batch"]), "an instance's result depends on the batch it is solved in"
+    assert np.abs(dz - fx["gpu_dz_full_batch"]).max() <= 1e-12
+    # the pinned deviations: twelve instances off the oracle's iteration count, the furthest 1.148e-5 from its z; the others within 1.2e-6
+    assert int((~same).sum()) <= 12, int((~same).sum())
+    assert dz[~same].max() <= 1.2e-5, dz[~same].max()
+    assert dz[same].max() <= 1.3e-6, dz[same].max()
+    # (two converged answers of the same QP: each within the solver's accuracy tol_abs / mu of the optimum, mu ~ 1 here)
+    assert dz.max() <= 12 * prm["tol_abs"]
+
+
+@pytest.mark.gpu
+def test_fuzz_r05_case1126_whole_body_tree_per_link_references(monkeypatch):
+    fx, model, prm, env, kw, refs, args = load_case("r05_j_fuzz_3000_case1126")
+    got, st = solve_on_gpu(monkeypatch, fx, model, prm, env, kw, refs, args)
+    assert st["flat_launches"] >= 1, st   # (k_flat1: 43 joints)
+    dz = np.abs(got["z"] - fx["ref_z"]).max(axis=1)
+    assert np.array_equal(got["iter"], fx["ref_iters"])
+    assert np.array_equal(got["converged"], fx["ref_converged"]) and np.array_equal(got["primal_infeasible"], fx["ref_primal_infeasible"])
+    assert np.abs(dz - fx["gpu_dz_full_batch"]).max() <= 1e-12
+    worst = int(np.argmax(dz))
+    assert int(fx["pick"][worst]) == 2960   # (the one instance of the fuzz run)
+    assert dz[worst] <= 1.4e-7, dz[worst]
+    assert np.delete(dz, worst).max() <= 2e-10, np.delete(dz, worst).max()
