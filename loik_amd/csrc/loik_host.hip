@@ -70,6 +70,8 @@ struct Tuning {
   int flat_build = 2;           // (default 2 since the end of round 5; 0: the full table always) LOIKB_FLAT_BUILD=1: the lazily populated table on every k_flat2 launch (window: LOIKB_FLAT_WINDOW, else all of it), 2: on time-sliced launches, window from the handle's history; k_flat2 builds a decade slot its table lacks in-wave (flat_build_slot) instead of handing the instance to k_tail
   int fslot_dgrp = 0;           // LOIKB_FSLOT_DGRP=g: k_fslots takes the decades through its two passes g at a time (default: all)
   int flat_slice2 = 0;          // LOIKB_FLAT_SLICE2=q: an instance's later slices (0: as the first)
+  int flat_small_batch = 2048;  // LOIKB_FLAT_SMALL_BATCH=n: up to n instances a Solve() on k_flat2 / k_flat1 is the short sequence (fused queue set-up, no order pass)
+  int flat_min_batch = 1;       // LOIKB_FLAT_MIN_BATCH=n: k_flat2 / k_flat1 take batches from n instances (round 5: 64; below, k_tail)
   int flat_probe = 0;           // (default 0: measured a wash against the round robin, profiles/r06_a_probe_and_finish_ab.txt; given: wherever LOIKB_FLAT_SLICE / the default slices it) LOIKB_FLAT_PROBE=p: a time-sliced k_flat2 launch without an order becomes TWO launches -- every instance for p iterations at
                                 // most, then the survivors to completion, longest predicted first (0: one launch, round robin: round 5's)
   int flat_probe_mark = 32;     // LOIKB_FLAT_PROBE_MARK=k: the probe's first mark (the residual's rate of fall is taken between it and the probe's end)
@@ -109,6 +111,8 @@ struct Tuning {
     if (const char* e = getenv("LOIKB_FLAT_SLICE")) flat_slice = std::min(65535, std::max(-1, atoi(e)));
     if (const char* e = getenv("LOIKB_FLAT_SLICE2")) flat_slice2 = std::min(8191, std::max(0, atoi(e)));
     if (const char* e = getenv("LOIKB_FLAT_PROBE")) flat_probe = std::min(8000, std::max(0, atoi(e)));
+    if (const char* e = getenv("LOIKB_FLAT_MIN_BATCH")) flat_min_batch = std::max(1, atoi(e));
+    if (const char* e = getenv("LOIKB_FLAT_SMALL_BATCH")) flat_small_batch = std::max(0, atoi(e));
     if (const char* e = getenv("LOIKB_FLAT_PROBE_MARK")) flat_probe_mark = std::max(1, atoi(e));
     if (const char* e = getenv("LOIKB_FSLOT_DGRP")) fslot_dgrp = std::max(0, atoi(e));
     if (const char* e = getenv("LOIKB_FLAT_ORDER")) flat_order = atoi(e) != 0;
@@ -147,6 +151,13 @@ struct EnginePlan {
   int ndec = 10, kexp_lo = -2;
   int tail_max = 32768;
   int nchunks = 1;
+  // k_solve (the streaming engine) keeps the leaf->root hand-over of a sweep in LDS slots of the workgroup: one per pending branch.  A very
+  // bushy tree (8-10 children at one joint of a 40-joint tree) needs more of them than a CU has LDS.  Such a robot is not refused (round 6):
+  // whole batches go to the on-chip engines, which have no such slots (k_flat2 / k_flat1 / k_tail: any number of children), and where those
+  // do not apply -- more than 64 joints, or options that ask for k_solve's own behaviour -- to the plain pass-by-pass implementation
+  // (k_pass_solve: one instance per thread, state in HBM, no LDS at all), the engine of last resort.
+  bool solve_ok = true;
+  size_t solve_lds_need = 0;
 };
 
 struct loikb_solver_impl {
@@ -274,6 +285,7 @@ struct loikb_solver_impl {
     size_t park_bytes = 0;
     std::vector<int> h_wave;             // host scratch for the compaction scan
     loikb_stats stats{};
+    bool unfinished_counted = false;     // stats.n_unfinished of the last solve came with the on-chip launch's own counters (small batches)
     int rc = 0;
     std::string err;
     // [start, end) of every solve / tail launch of the last call, ms since the fork event (HIP events)
@@ -1694,7 +1706,24 @@ void plan_engines(loikb_solver_impl* S)
   pl.nchunks = (ntiles >= 512 && !pl.lean && !flat_usable) ? 2 : 1;
   if (S->tune.chunks > 0) pl.nchunks = S->tune.chunks;
   pl.nchunks = std::max(1, std::min(pl.nchunks, ntiles));
+  // (k_solve's LDS: edge slots of the leaf->root sweeps -- aliased by the team's scalar exchange -- + v slots; as in run_chunk)
+  {
+    auto need_of = [&](const loikb_solver_impl::TeamSched& sc) {
+      const int edge = std::max(std::max(sc.nslots, 1) * EDGE_ENT, sc.nw > 1 ? sc.nw * Norms<double>::NALL : 0);
+      return (size_t)(edge + std::max(sc.nvslots, 1) * 6) * WAVE * S->esz;
+    };
+    pl.solve_lds_need = need_of(S->sched[0]);   // (the team schedule is optional: run_chunk uses it only when it fits)
+    pl.solve_ok = pl.solve_lds_need <= (size_t)160 * 1024;
+    if (!pl.solve_ok) { pl.tail_max = 1 << 20; pl.nchunks = 1; }   // (whole batches to the on-chip engines)
+  }
   S->plan = pl;
+}
+
+// a robot k_solve cannot take (EnginePlan::solve_ok): does this solve go to the on-chip engines whole?  (run_chunk's direct_tail)
+static bool bushy_goes_on_chip(const loikb_solver_impl* S)
+{
+  return S->nb <= WAVE && S->opt.tail_max_instances >= 0 && S->opt.max_launch_iters <= 0 &&
+         !(S->opt.flags & (LOIKB_OPT_NO_COMPACTION | LOIKB_OPT_NO_H_CACHE)) && S->B <= S->plan.tail_max && S->tune.direct_tail;
 }
 
 template <typename T>
@@ -1703,7 +1732,17 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
 {
   loikb_solver_impl::Set& A = C->set[cur];
   const int nw = (n_cur + WAVE - 1) / WAVE;
-  if (whole_set) {
+  // Small batches on the one-instance-per-wavefront flat engines (every instance gets a wavefront at once: no schedule to prepare, no order
+  // to leave for the next solve): the list, the ring and the counters come from ONE kernel, the order pass is skipped, and n_unfinished is
+  // counted by k_list_unfinished -- 8 launches / copies and one synchronisation less per Solve() (B = 1: 0.168 -> see profiles/r06_*_small_batches)
+  int G0 = 8;
+  while (G0 < S->nb) G0 <<= 1;
+  const bool small_flat = whole_set && cur == 0 && S->chunks.size() == 1 && sizeof(T) == 8 && S->tune.flat_split && flat_applicable(S) && (P.mode & MODE_CACHE_H) &&
+                          ((G0 == F2G && S->flat.ok && S->flat.nanc <= FLAT_NA_SMALL) || G0 == WAVE) && n_cur <= S->tune.flat_small_batch &&
+                          n_cur >= std::max(1, S->tune.flat_min_batch);
+  if (whole_set && small_flat) {
+    // (k_queue_init_iota below, once the ring's size is known to the flat path)
+  } else if (whole_set) {
     // every slot of the set (finished instances, if any, stop at once inside the kernel)
     hipLaunchKernelGGL(k_list_iota, grid1(n_cur), dim3(256), 0, C->stream, C->d_slots, n_cur);
   } else {
@@ -1763,7 +1802,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
     const size_t wave_lds = lean_lds_bytes<T>(S->nc, G, S->a_shared);
     // ---- the flat engine (loik_flat.hpp: no loops over the tree levels) takes the place of k_hslots + k_lean when the solve's
     // reference cost allows (H_ref = h I for all links)
-    const bool flat_ok = flat_applicable(S) && (P.mode & MODE_CACHE_H) && n >= 64;
+    // (the builds with ONE instance per wavefront -- k_flat2, k_flat1 -- take any number of instances: a lone instance iterates in 2.3 us
+    //  there against k_tail's 10-12 us, and the reference's own call is one problem, tests/loik-loid.cpp:987-1032; k_flat, two instances
+    //  per wavefront, from 64 as ever)
+    const bool flat_one_per_wave = S->tune.flat_split && sizeof(T) == 8 && ((G == F2G && S->flat.ok && S->flat.nanc <= FLAT_NA_SMALL) || G == WAVE);
+    const bool flat_ok = flat_applicable(S) && (P.mode & MODE_CACHE_H) && n >= (flat_one_per_wave ? std::max(1, S->tune.flat_min_batch) : 64);
     if (flat_ok) {
       const int nanc = S->flat.nanc;
       const bool small_na = nanc <= FLAT_NA_SMALL;
@@ -1790,11 +1833,12 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       P.max_launch_iters = S->opt.max_iter + 1;
       const int mode_keep = P.mode;
       if (whole_set && S->zero_state && S->tune.flat_zero_state) P.mode |= MODE_ZERO_STATE;
-      HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
+      if (small_flat) hipLaunchKernelGGL(k_queue_init_iota, grid1(std::max(C->ring_cap, NCOUNTERS)), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, C->d_slots, n_cur, C->d_counters, NCOUNTERS);
+      else HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
       HIPCHK(hipEventRecord(C->ev_k0, C->stream));
       // longest first: the order the previous solve of this handle left (k_order_*, loik_lean.hpp) when this launch takes the same
       // whole set; the decade slots are indexed by the INSTANCE slot (sidx / lidx), so k_fslots and the engine find them under any order of the list
-      const bool ordered = whole_set && list == C->d_slots && n == n_cur && (split || one) && order_usable(S, C, n_cur);
+      const bool ordered = !small_flat && whole_set && list == C->d_slots && n == n_cur && (split || one) && order_usable(S, C, n_cur);
       const bool order_was_stale = ordered && C->order_epoch != S->inputs_epoch;
       if (C->order_holdoff > 0) --C->order_holdoff;
       if (ordered) HIPCHK(hipMemcpyAsync(C->d_slots, C->d_order, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, C->stream));
@@ -1861,7 +1905,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       bool probe_timed = false;
       dim3 grid((unsigned)std::min((n + ipw - 1) / ipw, cap_lat));
       {
-        hipLaunchKernelGGL(k_ring_fill, grid1(C->ring_cap), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, list, n, C->d_counters);
+        if (!small_flat) hipLaunchKernelGGL(k_ring_fill, grid1(C->ring_cap), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, list, n, C->d_counters);
         if (split || one) {   // (what only the in-wave builder / the lazily populated table read, behind one kernel argument)
           // (uploaded when one of the pointers changes -- synchronously, from the chunk's own copy: ADVICE r05)
           if (C->d_aux == nullptr) HIPCHK(hipMalloc((void**)&C->d_aux, 4 * sizeof(void*)));
@@ -2035,7 +2079,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       }
       int* next = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
       HIPCHK(hipEventRecord(C->ev_k1, C->stream));
-      const bool order_pass = S->tune.flat_order && whole_set && n_first == n_cur && (split || one) && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS);
+      const bool order_pass = !small_flat && S->tune.flat_order && whole_set && n_first == n_cur && (split || one) && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS);
       if (!order_pass) HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
       if (order_pass) {
         // the order for the handle's next solve: longest first by the iteration counts of this one (an instance that escaped to
@@ -2101,6 +2145,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       total_ms = ms;
       n = (int)C->h_counters[3];
       list = next;
+      if (n == 0 && small_flat && n_first == n_cur) { C->stats.n_unfinished = (int)C->h_counters[4]; C->unfinished_counted = true; }
       if (n == 0) { *ms_out = total_ms; *iters_out = iters; return LOIKB_OK; }
       // what is left escaped the precomputed decades: k_tail below finishes it
     }
@@ -2313,6 +2358,7 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
 {
   Params<T> P = make_params<T>(S);
   C->stats = loikb_stats{};
+  C->unfinished_counted = false;
   C->solve_iv.clear();
   C->tail_iv.clear();
   double kernel_ms = 0.0;
@@ -2348,9 +2394,8 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
   constexpr size_t LDS_CU = 160 * 1024, LDS_DEFAULT = 64 * 1024;
   const bool team_ok = S->sched[1].nw > 1 && lds_bytes(S->sched[1]) <= LDS_CU &&
                        5 * (S->sched[1].T_up + S->sched[1].T_down) <= 4 * (S->sched[0].T_up + S->sched[0].T_down);
-  {
+  if (S->plan.solve_ok) {
     const size_t need = std::max(lds_bytes(S->sched[0]), team_ok ? lds_bytes(S->sched[1]) : (size_t)0);
-    if (need > LDS_CU) { g_last_error = "kinematic tree too bushy: leaf->root hand-over slots exceed the LDS of a CU"; return LOIKB_ERR_MODEL; }
     if (need > LDS_DEFAULT) {
       HIPCHK(hipFuncSetAttribute((const void*)k_solve<T, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
       HIPCHK(hipFuncSetAttribute((const void*)k_solve<T, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
@@ -2368,6 +2413,9 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
   const bool direct_tail = S->nb <= WAVE && S->opt.tail_max_instances >= 0 && S->opt.max_launch_iters <= 0 &&
                            !(S->opt.flags & (LOIKB_OPT_NO_COMPACTION | LOIKB_OPT_NO_H_CACHE)) && C->B <= tail_max &&
                            S->tune.direct_tail;
+  if (!S->plan.solve_ok && !direct_tail) {   // (run_main_loop sends such a solve to k_pass_solve: never here)
+    g_last_error = "internal: a tree too bushy for k_solve's LDS slots reached the streaming engine"; return LOIKB_ERR_STATE;
+  }
   if (direct_tail) {
     double tms = 0.0;
     unsigned long long tit = 0;
@@ -2461,7 +2509,7 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
   }
   HIPCHK(hipStreamSynchronize(C->stream));
   C->stats.instance_iterations = inst_iters;
-  C->stats.n_unfinished = (int)n_live;
+  if (!C->unfinished_counted) C->stats.n_unfinished = (int)n_live;
   C->stats.kernel_ms = kernel_ms;
   return LOIKB_OK;
 }
@@ -2498,15 +2546,18 @@ int run_main_loop_t(loikb_solver_impl* S)
   }
   // n_unfinished: instances that stopped at max_iter, neither converged nor flagged (whatever engine finished them)
   Chunk* C0 = &S->chunks[0];
-  HIPCHK(hipMemsetAsync(C0->d_counters, 0, sizeof(unsigned int), S->stream));
-  hipLaunchKernelGGL(k_count_unfinished<T>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, S->B, C0->d_counters);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(C0->h_counters, C0->d_counters, sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
+  const bool counted = nchunks == 1 && C0->unfinished_counted;   // (a small batch: the on-chip launch's own counters said it)
+  if (!counted) {
+    HIPCHK(hipMemsetAsync(C0->d_counters, 0, sizeof(unsigned int), S->stream));
+    hipLaunchKernelGGL(k_count_unfinished<T>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L, S->B, C0->d_counters);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(C0->h_counters, C0->d_counters, sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
+  }
   HIPCHK(hipEventRecord(S->ev_t1, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
   float tms = 0.f;
   HIPCHK(hipEventElapsedTime(&tms, S->ev_t0, S->ev_t1));
-  S->stats.n_unfinished = (int)C0->h_counters[0];
+  S->stats.n_unfinished = counted ? C0->stats.n_unfinished : (int)C0->h_counters[0];
   for (const Chunk& C : S->chunks) {
     S->stats.instance_iterations += C.stats.instance_iterations;
     S->stats.launches += C.stats.launches;
@@ -2554,6 +2605,7 @@ int run_main_loop_t(loikb_solver_impl* S)
 }
 
 
+int run_pass_solve(loikb_solver_impl* S, bool logged);   // (the plain pass-by-pass implementation: defined beside run_logged)
 // LOIKB_MU_MAXEIGENVALUE: the solve's starting mu, from the references in force now (SolveInit's reset ran before they were stored)
 static int start_mu(loikb_solver_impl* S)
 {
@@ -2574,6 +2626,7 @@ int run_main_loop(loikb_solver_impl* S)
     return LOIKB_ERR_MU_STRATEGY;
   }
   int rc;
+  if (!S->plan.solve_ok && !bushy_goes_on_chip(S)) return run_pass_solve(S, false);   // (the engine of last resort: EnginePlan::solve_ok)
   if ((rc = start_mu(S))) return rc;
   return S->f32 ? run_main_loop_t<float>(S) : run_main_loop_t<double>(S);
 }
@@ -3165,17 +3218,34 @@ static int run_logged(loikb_solver_impl* S, int redo_reset)
     if ((rc = ensure_log(S))) return rc;
     on_flat = false;
   }
+  return run_pass_solve(S, true);
+}
+
+// the whole solve on the plain pass-by-pass implementation (one instance per thread, the data object of the reference field by field in
+// HBM): a logged solve the flat engine does not take, and the engine of last resort of a robot k_solve cannot take (EnginePlan::solve_ok)
+namespace {
+int run_pass_solve(loikb_solver_impl* S, bool logged)
+{
+  int rc;
+  if (S->opt.mu_update_strat != LOIKB_MU_DEFAULT && S->opt.mu_update_strat != LOIKB_MU_OSQP &&
+      S->opt.mu_update_strat != LOIKB_MU_MAXEIGENVALUE && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS)) {
+    g_last_error = "[FirstOrderLoikOptimizedTpl::UpdateMu]: mu update strategy not supported";
+    return LOIKB_ERR_MU_STRATEGY;
+  }
   if ((rc = start_mu(S))) return rc;  // (run_main_loop does it on the other path)
   const PassParams P = pass_params(S);
   S->pass_active = false;  // the resets / updates of this solve went to the tiles: reload
   if ((rc = ensure_pass_state(S, P))) return rc;
-  const int cap = S->log_rows_cap;
+  const int cap = logged ? S->log_rows_cap : 0;
   HIPCHK(hipEventRecord(S->ev_t0, S->stream));
   hipLaunchKernelGGL(k_pass_solve, grid1(S->B, 64), dim3(64), 0, S->stream, S->PL, P, (const JointDesc*)S->d_jd,
-                     (const int*)S->d_pass_cslot, S->d_pass, S->d_log, cap, S->d_log_rows);
+                     (const int*)S->d_pass_cslot, S->d_pass, logged ? S->d_log : (double*)nullptr, cap, logged ? S->d_log_rows : (int*)nullptr);
   HIPCHK(hipGetLastError());
-  return finish_logged(S, P);
+  if ((rc = finish_logged(S, P))) return rc;
+  if (!logged) S->have_log = false;
+  return LOIKB_OK;
 }
+}  // namespace
 
 // the SolverInfo lists of a logged solve: B x (max_iter - 1) rows x nine lists, zero beyond an instance's rows
 static int ensure_log(loikb_solver_impl* S)
@@ -3429,6 +3499,13 @@ const char* loikb_plan_string(loikb_solver* S)
                "given back when the slots or park records need the room)", (fs + hs) / 1048576.0, pk / 1048576.0, gs / 1048576.0);
       out += b4;
     }
+  }
+  if (!pl.solve_ok) {
+    char b5[400];
+    snprintf(b5, sizeof(b5), "a tree too bushy for k_solve (its leaf->root hand-over slots would need %.0f KB of a CU's 160 KB of LDS): %s; ",
+             pl.solve_lds_need / 1024.0, bushy_goes_on_chip(S) ? "whole batches go to the on-chip engines, which have no such slots"
+                                                               : "every solve runs on the plain pass-by-pass implementation (k_pass_solve), the engine of last resort");
+    out = b5 + out;
   }
   if (S->opt.logging && logged_on_flat(S)) out = "logging = 1: the flat engine writes the SolverInfo lists; " + out;
   else if (S->opt.logging) out = "logging = 1: every solve runs on the plain pass-by-pass implementation (k_pass_solve) and fills SolverInfo; without it: " + out;

@@ -1005,8 +1005,27 @@ __global__ void k_ring_fill(int* __restrict__ ring, int cap, const int* __restri
 }
 #endif
 
+// small batches (every instance gets a wavefront at once): the identity list, the ring and the launch's counters in ONE kernel -- a lone
+// problem's Solve() is a handful of launches, and each costs the stream ~5 us (tests/loik-loid.cpp:987-1032 times exactly that call)
+#ifndef LOIKB_FLAT_KERNELS_TU
+__global__ void k_queue_init_iota(int* __restrict__ ring, int cap, int* __restrict__ list, int n, unsigned int* __restrict__ counters, int ncounters)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) ring[i] = i < n ? i : -1;
+  if (i < n) list[i] = i;
+  if (i < ncounters) {
+    unsigned int v = 0u;
+    if (i == LEAN_Q_TAIL) v = (unsigned int)n;
+    if (i == 14) v = (unsigned int)wall_clock64();   // (FLAT_COUNTERS_T0)
+    counters[i] = v;
+  }
+}
+#endif
+
 // the listed instances that are still iterating after a lean launch (the ones that escaped), in arbitrary order
 template <typename T>
+// counter[1] (= Bufs::counters[4] in the on-chip launches): the listed instances that are neither converged nor flagged infeasible -- when the
+// list is a whole batch and nothing is still iterating, loikb_stats::n_unfinished without a kernel, a copy and a synchronisation of its own
 __global__ void k_list_unfinished(char* tiles, Layout L, const int* __restrict__ list_in, int n_in, int* __restrict__ list_out,
                                   unsigned int* __restrict__ counter)
 {
@@ -1016,6 +1035,7 @@ __global__ void k_list_unfinished(char* tiles, Layout L, const int* __restrict__
   char* sp = lane_ptr<T>(tiles, L, b);
   const int status = (int)ldp<T>(sp + (size_t)L.off_s * pair_bytes<T>(), SP_ST).x;
   if (!(status & ST_DONE)) list_out[atomicAdd(counter, 1u)] = b;
+  if (!(status & (ST_CONVERGED | ST_PRIMAL_INF))) atomicAdd(counter + 1, 1u);
 }
 
 // ---- longest first.  The iteration counts of a batch are heavy-tailed (headline workload: median 26, mean 80, 1.2 % run into

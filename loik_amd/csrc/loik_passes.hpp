@@ -483,7 +483,7 @@ __global__ void k_pass_solve(PassLayout L, PassParams P, const JointDesc* __rest
   sc[PS_TAIL_IT] = 0.0;
   for (int i = 1; i < P.max_iter; ++i) {
     body();  // (PASS_BEGIN_ITERATION: iter_ = i)
-    if (n < rows_cap) {
+    if (log != nullptr && n < rows_cap) {
       const double v[LOG_NLIST] = {sc[PS_PR_TASK], sc[PS_PR_SLACK], sc[PS_PRIMAL], sc[PS_DUAL_NU], sc[PS_DUAL_V], sc[PS_DUAL],
                                    sc[PS_MU], sc[PS_MU_EQ], sc[PS_MU_IN]};
       for (int l = 0; l < LOG_NLIST; ++l) log[((size_t)l * L.B + b) * rows_cap + n] = v[l];
@@ -504,7 +504,7 @@ __global__ void k_pass_solve(PassLayout L, PassParams P, const JointDesc* __rest
     }
     pass_one(PASS_UPDATE_MU, L, P, jd, cslot_of, s);
   }
-  rows[b] = n;
+  if (rows != nullptr) rows[b] = n;   // (null: a solve without SolverInfo lists -- the engine of last resort)
 }
 
 // out[b][...] of one field of the pass state (instance-major, the layouts of loikb_get)

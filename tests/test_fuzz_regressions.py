@@ -30,7 +30,7 @@ ENV_KEYS = ("LOIKB_LEAN", "LOIKB_FLAT", "LOIKB_FLAT_SPLIT", "LOIKB_FLAT_SLICE", 
 
 
 def load_case(name):
-    fx = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    fx = np.load(os.path.join(HERE, "golden", "fuzz", name + ".npz"))
     pitch = fx["pitch"] if fx["pitch"].size else None
     model = loik_amd.Model(fx["parents"], fx["jtype"], fx["axis"], fx["placement"], pitch=pitch, name=name)
     prm = json.loads(str(fx["prm"])); env = json.loads(str(fx["env"])); kw = json.loads(str(fx["kw"]))
