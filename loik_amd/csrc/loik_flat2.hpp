@@ -641,7 +641,11 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   // fmask (MUR = 2): per instance, bit d: decade d of the table is there (k_fslots' window, win_bits, or built during the launch);
   // bit 16 + d: built during the launch, possibly by a wavefront of another XCD: fetched with agent-scope loads
   constexpr bool BUILD = MUR >= 1;
-  constexpr bool TAU_AHEAD = (LOIKB_TAU_AHEAD != 0) && !LOG;   // (the next iteration's tau formed beside this iteration's f: see `after_tau`)
+  // (the next iteration's tau formed beside this iteration's f: see `after_tau`.  Round 6, with the LDS accesses unmerged: it pays in the
+  //  time-sliced builds only -- headline in arrival order 9.39 -> 8.50 ms with it -- and costs the plain build its lone iteration, 2.18 ->
+  //  2.27 us, for nothing in the bulk (4 x batch 29.53 / 29.65 ms, ordered headline 7.48 / 7.51): profiles/r06_b_flat_switches_ab.txt.
+  //  LOIKB_TAU_AHEAD=2: every build, as in round 5)
+  constexpr bool TAU_AHEAD = (LOIKB_TAU_AHEAD != 0) && !LOG && (SLICED || MUR != 0 || LOIKB_TAU_AHEAD == 2);
   static_assert(flat_build_scratch<F2G>() <= flat2_off_nbuf<NA>(), "the in-wave builder's rows must end before the buffers the iteration keeps");
   using T = double;
   static_assert(NA % 2 == 0, "the W entries of a joint are dealt out to its two lanes");
