@@ -121,8 +121,24 @@ def cpu_baseline(wl, budget_s=15.0):
         one_us = (time.perf_counter() - t2) / max(int(o2["iters"].sum()), 1) * 1e6
     except Exception:
         pass
+    # ONE problem per call, the reference's own use: wall-clock of one cold solve of instance 0 of a 1-instance batch (the GPU's figure for
+    # the same call: single_call_variant.b1_solve_wall_ms)
+    one_call_ms = one_call_iters = None
+    try:
+        from loik_amd import workloads as _w
+        w1 = _w.talos_c3(1, seed=3)
+        best = 1e9
+        for _ in range(20):
+            t3 = time.perf_counter()
+            o3 = ref.solve_batch(w1["model"], w1["q"], w1["H_ref"], w1["v_ref"], w1["c_ids"], w1["Ais"], w1["bis"], w1["lb"], w1["ub"], nthreads=1,
+                                 native=True, **w1["params"])
+            best = min(best, time.perf_counter() - t3)
+        one_call_ms, one_call_iters = best * 1e3, int(o3["iters"][0])
+    except Exception:
+        pass
     eff = rate / (cores * rate1)
-    return dict(value=float(out["converged"].sum() / dt), unit="solves/s", cores=cores, kind="port",
+    return dict(single_problem_solve_ms=one_call_ms, single_problem_iterations=one_call_iters,
+                value=float(out["converged"].sum() / dt), unit="solves/s", cores=cores, kind="port",
                 cores_note=cores_note + ", os.cpu_count(): %s" % os.cpu_count(),
                 single_thread_us_per_iteration=one_us,
                 single_thread_instance_iterations_per_s=rate1,
@@ -546,6 +562,31 @@ def whole_body_variant(args, device):
     return out
 
 
+def single_call_variant(args, device, wl0):
+    """Reported beside the headline: the reference's OWN use -- one problem per Solve() call (tests/loik-loid.cpp:987-1032 times exactly
+    that) -- and small batches: wall-clock of a cold Solve() on a handle whose problem is resident (SolveInit untimed), best of 30.
+    Round 6: batches below 64 instances run on k_flat2 (2.2 us per iteration of a lone instance; k_tail, round 5's engine for them,
+    10-12 us), and up to 2048 instances a Solve() is the short launch sequence (loik_host.hip, small_flat)."""
+    import loik_amd
+    from loik_amd import workloads
+    out = {"what": "wall-clock of Solve() (reset + solve + the host's wait), problem resident, best of 30 calls; Talos-32, the headline's parameters", "rows": []}
+    for B in (1, 8, 64, 1024):
+        wl = workloads.talos_c3(B, seed=3)
+        s = loik_amd.BatchedLoik(wl["model"], B, device=device, flags=args.flags, **wl["params"])
+        s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+        ts = []
+        for _ in range(30):
+            t = time.perf_counter(); s.Solve(); ts.append(time.perf_counter() - t)
+        it = s.get("iter")
+        st = s.stats()
+        out["rows"].append({"batch": B, "solve_wall_ms": min(ts) * 1e3, "solve_wall_ms_median": float(np.median(ts)) * 1e3, "max_iterations": int(it.max()),
+                            "mean_iterations": float(it.mean()), "on_chip_ms": st["kernel_ms"], "engine": "k_flat2" if st["flat_split_launches"] else "k_tail"})
+        s.close()
+    out["b1_solve_wall_ms"] = out["rows"][0]["solve_wall_ms"]
+    out["b1_iterations"] = out["rows"][0]["max_iterations"]
+    return out
+
+
 def schedule_variant(args, device):
     """What the order of the work queue is worth.  `value` is a handle's FIRST solve of a batch it has not seen: arrival order.  This
     variant reports the other ends: `repeat_same_batch` -- the reference's timing test (SolveInit once, then Solve() again and again,
@@ -941,8 +982,16 @@ def main(argv=None, solver_factory=None, device_count=None):
                 for sh in shards:
                     sh.close()
                 line["whole_body_variant"] = whole_body_variant(args, device_of(0))
+                # (top-level scalars, so that they survive a reader that keeps the line's first level only: VERDICT r05 #4)
+                line["whole_body_ms_per_step"] = line["whole_body_variant"]["ms_per_step"]
+                line["whole_body_frac_of_fp64_valu_peak"] = line["whole_body_variant"]["frac_of_fp64_valu_peak"]
             except Exception as e:  # the headline must survive a failing variant
                 line["whole_body_variant"] = {"failed": repr(e)}
+            try:
+                line["single_call_variant"] = single_call_variant(args, device_of(0), wl0)
+                line["b1_solve_wall_ms"] = line["single_call_variant"]["b1_solve_wall_ms"]
+            except Exception as e:
+                line["single_call_variant"] = {"failed": repr(e)}
             try:
                 line["schedule_variant"] = schedule_variant(args, device_of(0))
             except Exception as e:

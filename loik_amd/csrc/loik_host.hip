@@ -120,7 +120,7 @@ struct Tuning {
     if (const char* e = getenv("LOIKB_FLAT_ONE_SLOT")) flat_one_slot = atoi(e);
     if (const char* e = getenv("LOIKB_FLAT_ORDER_HOLDOFF")) flat_order_holdoff = std::max(0, atoi(e));
     geti("LOIKB_TAIL_WAVES", tail_waves); tail_waves = std::max(1, std::min(TAIL_WAVES, tail_waves));
-    geti("LOIKB_LEAN_DECADES", lean_decades); lean_decades = std::max(1, std::min(16, lean_decades));
+    geti("LOIKB_LEAN_DECADES", lean_decades); lean_decades = std::max(1, std::min(15, lean_decades));   // (15: a parked instance's ring entry says "no slot" with decade code 15 -- ADVICE r05)
     geti("LOIKB_LEAN_KLO", lean_klo);
     geti("LOIKB_LEAN_WG_PER_CU", lean_wg_per_cu);
     geti("LOIKB_LEAN_WG_WAVES", lean_wg_waves);
@@ -314,6 +314,7 @@ struct loikb_solver_impl {
   // next solve builds slots for [seen_lo - 1, seen_hi + 1] only (within the configured range); an escape widens it again
   int seen_lo = 1 << 20, seen_hi = -(1 << 20);
   unsigned long long end_hist[32] = {0}, end_hist_n = 0;   // decades (kexp + 16) the instances of the last flat solve ended in
+  unsigned long long solve_serial = 0, end_hist_epoch = 0; // (run_main_loop_t counts the solves; the solve end_hist was taken in)
   // SolverInfo lists of a handle created with logging = 1 (k_pass_solve)
   double* d_log = nullptr;
   int* d_log_rows = nullptr;
@@ -1853,7 +1854,9 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       int dw0 = 0, nw = ndec;
       if (mur == 2) {
         int wlo = 0, whi = -1;
-        const int q = (split && !S->opt.logging) ? flat_slice_for(S, n, ordered) : 0;
+        // (whether this launch is time-sliced, decided ONCE: the park buffer's size included -- ADVICE r05)
+        int q = (split && !S->opt.logging) ? flat_slice_for(S, n, ordered) : 0;
+        if (q > 0 && (C->d_park == nullptr || (size_t)n_cur * flat2_park_stride(S->nc, true) * sizeof(double) > C->park_bytes)) q = 0;
         if (S->tune.flat_win_n > 0) { wlo = S->tune.flat_win_lo; whi = wlo + S->tune.flat_win_n - 1; }
         else if (S->tune.flat_build == 2 && q > 0 && C->d_park != nullptr && S->end_hist_n > 0) {
           unsigned long long cum = 0;
@@ -1955,7 +1958,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
   hipLaunchKernelGGL((k_flat2<FLAT_NA_SMALL, WPE, ##__VA_ARGS__>), grid, dim3(WAVE), lds2, C->stream,                            \
                      *reinterpret_cast<const Params<double>*>(&P), *reinterpret_cast<const Bufs<double>*>(&Bf),                  \
                      (const JointDesc*)S->d_jd, (const FlatLane*)S->flat.d_lanes, nanc, S->flat.nscan, S->flat.njmp, C->d_ring, n, \
-                     (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], has_hv | ((S->maxdepth & 0xFF) << 8) | (win_bits << 16), C->ring_cap - 1, quantum,       \
+                     (const double*)C->d_fslots, frows, kexp_lo, ndec, (double)S->Href[0], (int)((unsigned int)has_hv | ((unsigned int)(S->maxdepth & 0xFF) << 8) | ((unsigned int)win_bits << 16)), C->ring_cap - 1, quantum,       \
                      (double*)C->d_park, flat2_park_stride(S->nc, true), (const void* const*)C->d_aux)
           const int hm = S->per_link ? 3 : href_is_scalar(S) ? 0 : href_is_diagonal(S) ? 1 : 2;
           // Two launches instead of one time-sliced one (FLAT_Q_PROBE / FLAT_Q_FINISH, loik_flat2.hpp): the probe, k_probe_sort, the survivors.
@@ -2110,9 +2113,9 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         for (int d = 0; d < 16; ++d)
           if (seen & (1u << d)) { S->seen_lo = std::min(S->seen_lo, kexp_lo + d); S->seen_hi = std::max(S->seen_hi, kexp_lo + d); }
         if (escaped) { S->seen_lo = S->plan.kexp_lo; S->seen_hi = S->plan.kexp_lo + S->plan.ndec - 1; }
-        if (order_pass) {   // (one chunk's instances; with several chunks the last one's: they resemble each other)
-          S->end_hist_n = 0;
-          for (int k = 0; k < 32; ++k) { S->end_hist[k] = C->h_counters[ORDER_DEC_HIST + k]; S->end_hist_n += S->end_hist[k]; }
+        if (order_pass) {   // (summed over the chunks of one solve: the first chunk to report starts the histogram anew -- ADVICE r05)
+          if (S->end_hist_epoch != S->solve_serial) { S->end_hist_epoch = S->solve_serial; S->end_hist_n = 0; for (int k = 0; k < 32; ++k) S->end_hist[k] = 0; }
+          for (int k = 0; k < 32; ++k) { S->end_hist[k] += C->h_counters[ORDER_DEC_HIST + k]; S->end_hist_n += C->h_counters[ORDER_DEC_HIST + k]; }
         }
         if (mur == 2) {   // (the decades somebody took up, loaded or built: the handle's history as the table's range sees it)
           for (int k = 0; k < 32; ++k)
@@ -2519,6 +2522,7 @@ template <typename T>
 int run_main_loop_t(loikb_solver_impl* S)
 {
   S->stats = loikb_stats{};
+  ++S->solve_serial;
   S->stats.bytes_per_instance_iteration = (double)sizeof(T) * (203.0 * S->nb + 108.0 * S->nc);
   HIPCHK(hipEventRecord(S->ev_t0, S->stream));
   const int nchunks = (int)S->chunks.size();
