@@ -2148,7 +2148,8 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       total_ms = ms;
       n = (int)C->h_counters[3];
       list = next;
-      if (n == 0 && small_flat && n_first == n_cur) { C->stats.n_unfinished = (int)C->h_counters[4]; C->unfinished_counted = true; }
+      // (the launch took the chunk's whole home set and nothing is still iterating: k_list_unfinished has counted loikb_stats::n_unfinished)
+      if (n == 0 && whole_set && cur == 0 && n_first == n_cur && S->chunks.size() == 1) { C->stats.n_unfinished = (int)C->h_counters[4]; C->unfinished_counted = true; }
       if (n == 0) { *ms_out = total_ms; *iters_out = iters; return LOIKB_OK; }
       // what is left escaped the precomputed decades: k_tail below finishes it
     }
