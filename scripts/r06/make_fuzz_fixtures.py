@@ -11,7 +11,10 @@ import fuzz_engines
 OUT = os.path.join(ROOT, "gpurun_out", "fuzz_fixtures")
 os.makedirs(OUT, exist_ok=True)
 CASES = [dict(name="r05_j_fuzz_1500_case1212", ncase=1213, seed=4242, flat_bias=0.7, only=1212),
-         dict(name="r05_j_fuzz_3000_case1126", ncase=1127, seed=9191, flat_bias=0.7, only=1126)]
+         dict(name="r05_j_fuzz_3000_case1126", ncase=1127, seed=9191, flat_bias=0.7, only=1126),
+         dict(name="r06_e_fuzz_3000_case522", ncase=523, seed=6006, flat_bias=0.7, only=522)]
+if len(sys.argv) > 1:   # (only the named cases)
+    CASES = [c for c in CASES if c["name"] in sys.argv[1:]]
 for c in CASES:
     box = {}
     fuzz_engines.fuzz(c["ncase"], c["seed"], verbose=True, only=c["only"], flat_bias=c["flat_bias"], capture=lambda d: box.update(d))
@@ -37,6 +40,7 @@ for c in CASES:
     if box["refs"] is not None:
         fx["refs_H"] = box["refs"][0]; fx["refs_v"] = box["refs"][1]
     assert not m.composite, "fixture format: no composite joints expected in these cases"
+    fx["B_full"] = np.array(B)
     np.savez_compressed(os.path.join(OUT, c["name"] + ".npz"), **fx)
     print(c["name"], "instances", len(pick), "off-count", len(off), "max |dz| same-iteration", float(box["dz"][box["same"]].max()), "max |dz| overall", float(box["dz"].max()),
           "bytes", os.path.getsize(os.path.join(OUT, c["name"] + ".npz")), flush=True)

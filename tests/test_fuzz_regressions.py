@@ -14,6 +14,15 @@ change that makes them worse fails here, one that closes them can tighten the bo
   solver's own accuracy, tol / mu with mu ~ 1.
 * case 1126: k_flat1 on a 43-joint tree, three task constraints, per-link references, tol 1e-8.  ONE converged instance, at the oracle's
   iteration count, is 1.36e-7 from the oracle's z; every other instance is within 1.2e-10.
+* case 522 of round 6's run (profiles/r06_e_fuzz_3000.txt): k_flat1 on a 33-joint helical tree, four constraints, per-link references,
+  tol 1e-6, max_iter 60: again ONE converged instance at the oracle's iteration count, 1.70e-7 from its z, the others within 4e-10.
+
+What the two k_flat1 cases are (scripts/r06/near_tie_probe.py: both solvers with logging = 1 on that one instance, the SolverInfo lists side
+by side): a NEAR-TIE of UpdateMu's compare `primal > 10 dual` (loik-loid-optimized.hxx:613-641).  Case 522, iteration 50: primal / dual =
+10.000009 here, 9.999776 in the oracle -- mu goes up one iteration earlier here; case 1126, iteration 72: 9.99951 here, 10.00158 in the
+oracle -- one iteration later.  The primal residuals agree to 1e-6 relative, the dual residuals (3e-7 and 8e-8: differences of forces five
+orders of magnitude larger) to 2e-5 relative, i.e. 7e-12 absolute; both solvers then converge at the same iteration along different
+last steps, 1e-7 apart at tol 1e-6 / 1e-8.  The same phenomenon as the off-count instances of case 1212, with the counts coinciding.
 """
 import json
 import os
@@ -39,7 +48,7 @@ def load_case(name):
     return fx, model, prm, env, kw, refs, args
 
 
-@pytest.mark.parametrize("name", ["r05_j_fuzz_1500_case1212", "r05_j_fuzz_3000_case1126"])
+@pytest.mark.parametrize("name", ["r05_j_fuzz_1500_case1212", "r05_j_fuzz_3000_case1126", "r06_e_fuzz_3000_case522"])
 def test_fixture_holds_the_oracles_answers(name):
     """(CPU) the frozen answers are the oracle's on the frozen inputs: the fixture is data of the checker, not of the engine"""
     fx, model, prm, env, kw, refs, args = load_case(name)
@@ -101,3 +110,19 @@ def test_fuzz_r05_case1126_whole_body_tree_per_link_references(monkeypatch):
     assert int(fx["pick"][worst]) == 2960   # (the one instance of the fuzz run)
     assert dz[worst] <= 1.4e-7, dz[worst]
     assert np.delete(dz, worst).max() <= 2e-10, np.delete(dz, worst).max()
+
+
+@pytest.mark.gpu
+def test_fuzz_r06_case522_helical_tree_per_link_references(monkeypatch):
+    fx, model, prm, env, kw, refs, args = load_case("r06_e_fuzz_3000_case522")
+    got, st = solve_on_gpu(monkeypatch, fx, model, prm, env, kw, refs, args)
+    assert st["flat_launches"] >= 1, st   # (k_flat1: 33 joints)
+    dz = np.abs(got["z"] - fx["ref_z"]).max(axis=1)
+    assert np.array_equal(got["iter"], fx["ref_iters"])
+    assert np.array_equal(got["converged"], fx["ref_converged"]) and np.array_equal(got["primal_infeasible"], fx["ref_primal_infeasible"])
+    assert np.abs(dz - fx["gpu_dz_full_batch"]).max() <= 1e-12
+    worst = int(np.argmax(dz))
+    assert int(fx["pick"][worst]) == 512   # (the one instance of the fuzz run: a near-tie of UpdateMu's compare at iteration 50)
+    assert dz[worst] <= 1.75e-7, dz[worst]
+    # (the others: converged ones within 1e-10; the instances max_iter = 60 stopped unconverged within 5e-10)
+    assert np.delete(dz, worst).max() <= 5e-10, np.delete(dz, worst).max()
