@@ -292,6 +292,30 @@ __device__ __forceinline__ double lds_at(const double* base, unsigned int byte_o
 {
   return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+// The same read by ABSOLUTE LDS address: BASE_BYTES (a constant of the instantiation, it ends up in the instruction's offset field) +
+// byte_off.  Why: the dynamic LDS of these kernels starts at LDS address 0 (they have no static LDS), but the compiler learns that only
+// when the module's LDS is laid out, after instruction selection -- every `base + variable offset` formed inside the loop kept its
+// `v_add_u32 v, 0, v` (eighteen per iteration of k_flat2, 4 % of its vector instructions: the gathers of W tau, of the partial sums, of
+// Dinv r' and the path sum's rounds).  An address built from the integer has nothing to add.  The kernels check the assumption once, at
+// their start (lds_starts_at_zero), and tests/test_capi_abi.py reads `.group_segment_fixed_size: 0` from the shipped code object.
+#ifndef LOIKB_LDS_ABS
+#define LOIKB_LDS_ABS 1
+#endif
+typedef __attribute__((address_space(3))) const double lds_cdouble_t;
+template <int BASE_BYTES>
+__device__ __forceinline__ double lds_abs(unsigned int byte_off)
+{
+#if LOIKB_LDS_ABS
+  return *reinterpret_cast<lds_cdouble_t*>(byte_off + (unsigned int)BASE_BYTES);
+#else
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // (the A/B build: base + offset as the compiler forms it)
+  return *reinterpret_cast<const double*>(smem_raw + BASE_BYTES + byte_off);
+#endif
+}
+__device__ __forceinline__ bool lds_starts_at_zero(const void* dyn_lds)
+{
+  return (unsigned int)(size_t)(__attribute__((address_space(3))) const char*)dyn_lds == 0u;
+}
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f)
 {
@@ -310,6 +334,7 @@ constexpr int PATH_RS = WAVE + 2;
 // PB2 (a build for joints with at most 11 ancestors): the second round has the ancestors at distance 4 and 8 only and there is no third
 // round; the two offsets are the fields <20, 10> of pb and <22, 10> of pc -- bits the caller's other packed words have to spare (one
 // register less across the loop), and the row of the ancestor at distance 12, which does not exist, is not read.
+// `rows` MUST be the start of the kernel's dynamic LDS (xb at every call site): the gathers address it absolutely (lds_abs).
 template <typename T, int NC, int PB2 = 0>
 __device__ __forceinline__ void flat_path_sum4(T* rows, int lane, unsigned int pa, unsigned int pb, unsigned int pc, int njmp, T* y, unsigned int tok)
 {
@@ -325,12 +350,9 @@ __device__ __forceinline__ void flat_path_sum4(T* rows, int lane, unsigned int p
     publish();
     const unsigned int r0 = field_here<0, 10>(p3, tok), r1 = field_here<10, 10>(p3, tok), r2 = field_here<20, 10>(p3, tok);
     T a[NC], b[NC], d[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) a[c] = lds_at(rows + c * PATH_RS, r0);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) b[c] = lds_at(rows + c * PATH_RS, r1);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) d[c] = lds_at(rows + c * PATH_RS, r2);
+    static_for<0, NC>([&](auto c) { a[c] = lds_abs<c * PATH_RS * 8>(r0); });
+    static_for<0, NC>([&](auto c) { b[c] = lds_abs<c * PATH_RS * 8>(r1); });
+    static_for<0, NC>([&](auto c) { d[c] = lds_abs<c * PATH_RS * 8>(r2); });
 #pragma unroll
     for (int c = 0; c < NC; ++c) y[c] += (a[c] + b[c]) + d[c];
   };
@@ -342,10 +364,8 @@ __device__ __forceinline__ void flat_path_sum4(T* rows, int lane, unsigned int p
       const unsigned int r0 = PB2 == 2 ? field_here<16, 8>(pb, tok) * 8u : field_here<20, 10>(pb, tok),
                          r1 = PB2 == 2 ? field_here<24, 8>(pb, tok) * 8u : field_here<22, 10>(pc, tok);
       T a[NC], b[NC];
-#pragma unroll
-      for (int c = 0; c < NC; ++c) a[c] = lds_at(rows + c * PATH_RS, r0);
-#pragma unroll
-      for (int c = 0; c < NC; ++c) b[c] = lds_at(rows + c * PATH_RS, r1);
+      static_for<0, NC>([&](auto c) { a[c] = lds_abs<c * PATH_RS * 8>(r0); });
+      static_for<0, NC>([&](auto c) { b[c] = lds_abs<c * PATH_RS * 8>(r1); });
 #pragma unroll
       for (int c = 0; c < NC; ++c) y[c] += a[c] + b[c];   // (= (a + b) + 0: the same bits as the general round)
     }
@@ -652,6 +672,10 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   constexpr int G = F2G, GW = F2W, cs = C2D, NH = NA / 2;
   constexpr bool PB2 = NA <= 11 && NH % 3 != 0;   // (the path sum's second round from spare bits of anc3 / cb_pk: flat_path_sum4)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (!lds_starts_at_zero(smem_raw)) {   // (never: see lds_abs -- reported as an error, not computed wrongly)
+    if (threadIdx.x == 0) atomicOr(Bf.counters + FLAT_COUNTERS_ERR, 4u);
+    return;
+  }
   const Layout& L = P.L;
   const bool a_shared = P.mode & MODE_A_SHARED;
   const int lane = threadIdx.x;
@@ -1500,13 +1524,13 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T rn;
     {
       T a[4];
-      static_for<0, 4>([&](auto t) { a[t] = lds_at(xb, field_here<16 * (t & 1), 16>(ra2[t >> 1], itok)); });
+      static_for<0, 4>([&](auto t) { a[t] = lds_abs<0>(field_here<16 * (t & 1), 16>(ra2[t >> 1], itok)); });   // (xb)
       T acc = (a[0] + a[1]) + (a[2] + a[3]);
       acc = pair_sum(acc);
       if (!h) pbuf[j] = helper ? acc : T(0);
       tail_sync();
       T pp[4];
-      static_for<0, 4>([&](auto q) { pp[q] = lds_at(pbuf, field_here<16 * (q & 1), 16>(part2[q >> 1], itok)); });
+      static_for<0, 4>([&](auto q) { pp[q] = lds_abs<flat2_off_pbuf<NA>() * 8>(field_here<16 * (q & 1), 16>(part2[q >> 1], itok)); });   // (pbuf)
       T ps = (pp[0] + pp[1]) + (pp[2] + pp[3]);
       ps = pair_sum(ps);
       if (helper) acc = T(0);
@@ -1521,7 +1545,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
       // (measured and rejected: these gathers -- and the partial sums above -- from lane to lane through the LDS crossbar,
       //  ds_bpermute, instead of a write, a fence and the reads: one dependent trip less each, and 13.0 -> 13.9 ms)
       T nb_[NH];
-      static_for<0, NH>([&](auto i) { nb_[i] = lds_at(nbuf, field_here<10 * (i % 3), 10>(anc3[i / 3], itok)); });
+      static_for<0, NH>([&](auto i) { nb_[i] = lds_abs<flat2_off_nbuf<NA>() * 8>(field_here<10 * (i % 3), 10>(anc3[i / 3], itok)); });   // (nbuf)
       T acc = T(0), acc2 = T(0);   // (two chains: see awy_of)
 #pragma unroll
       for (int i = 0; i < NH; ++i) { if (i & 1) acc2 += wc[i] * nb_[i]; else acc += wc[i] * nb_[i]; }
@@ -2182,6 +2206,10 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   using T = double;
   constexpr int G = WAVE, cs = C2D;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (!lds_starts_at_zero(smem_raw)) {   // (never: see lds_abs -- reported as an error, not computed wrongly)
+    if (threadIdx.x == 0) atomicOr(Bf.counters + FLAT_COUNTERS_ERR, 4u);
+    return;
+  }
   const Layout& L = P.L;
   const bool a_shared = P.mode & MODE_A_SHARED;
   const int lane = threadIdx.x;
@@ -2667,7 +2695,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     T rn;
     {
       T a[FLAT_RED];
-      static_for<0, FLAT_RED>([&](auto t) { a[t] = lds_at(xb, field_here<16 * (t & 1), 16>(ra2[t >> 1], itok)); });
+      static_for<0, FLAT_RED>([&](auto t) { a[t] = lds_abs<0>(field_here<16 * (t & 1), 16>(ra2[t >> 1], itok)); });   // (xb)
       T acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
       pbuf[lane] = helper ? acc : T(0);
       tail_sync();

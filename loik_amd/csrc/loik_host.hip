@@ -2103,7 +2103,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0));
       HIPCHK(hipEventElapsedTime(&hms, C->ev_k0, C->ev_k2));
       iters += C->h_counters[1];
-      if (C->h_counters[FLAT_COUNTERS_ERR]) { g_last_error = "internal: a wavefront of the flat engine gave up waiting on its work queue"; return LOIKB_ERR_STATE; }
+      if (C->h_counters[FLAT_COUNTERS_ERR]) {
+        g_last_error = (C->h_counters[FLAT_COUNTERS_ERR] & 4u) ? "internal: the flat engine's dynamic LDS does not start at LDS address 0 (lds_abs)"
+                                                               : "internal: a wavefront of the flat engine gave up waiting on its work queue";
+        return LOIKB_ERR_STATE;
+      }
       C->stats.lean_requeues += (int)C->h_counters[LEAN_Q_REQUEUES];
       const unsigned int escaped = C->h_counters[2];
       C->stats.flat_built += (int)C->h_counters[FLAT_COUNTERS_BUILT];

@@ -38,3 +38,35 @@ def test_flat_kernels_have_their_own_code_object_without_merged_lds_accesses():
 def test_flat_flags_are_what_the_design_says():
     assert "-load-store-opt" in _build.FLAT_FLAGS and "-amdgpu-load-store-vectorizer=0" in _build.FLAT_FLAGS
     assert "loik_flat_kernels.hip" in _build.SOURCES
+
+
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+@pytest.mark.skipif(not os.path.exists(READELF), reason="no llvm-readelf in this image")
+def test_flat_kernels_have_no_static_lds():
+    """k_flat2 / k_flat1 address their gathers by ABSOLUTE LDS address (loik_flat2.hpp::lds_abs): their dynamic LDS must start at LDS
+    address 0, i.e. the kernels must own no static LDS (`.group_segment_fixed_size: 0` in the code object's notes).  The kernels check the
+    same at run time (FLAT_COUNTERS_ERR bit 2); this is the build-time half."""
+    import re
+    import struct
+    data = open(_build.build(), "rb").read()
+    found, idx = 0, 0
+    with tempfile.TemporaryDirectory() as d:
+        while True:
+            i = data.find(b"\x7fELF\x02\x01\x01\x40", idx)   # ELFCLASS64, little endian, OSABI = AMDGPU_HSA
+            if i < 0:
+                break
+            shoff = struct.unpack_from("<Q", data, i + 0x28)[0]
+            shentsize, shnum = struct.unpack_from("<HH", data, i + 0x3A)
+            path = os.path.join(d, "co.elf")
+            with open(path, "wb") as f:
+                f.write(data[i:i + shoff + shentsize * shnum])
+            notes = subprocess.run([READELF, "--notes", path], check=True, capture_output=True, text=True).stdout
+            for blk in notes.split("- .agpr_count:")[1:]:
+                name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+                if "k_flat2" in name or "k_flat1" in name:
+                    assert re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk).group(1) == "0", name
+                    found += 1
+            idx = i + 8
+    assert found >= 20, found
