@@ -13,7 +13,13 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # Code generation of the flat iteration kernels' translation unit (loik_flat_kernels.hip; why: csrc/loik_flat_inst.hpp): neighbouring LDS
 # accesses stay single 64-bit instructions -- neither the IR load/store vectorizer (128-bit accesses, ds_read2_b64 where the alignment is
 # 8) nor the machine-level SI load/store optimizer (ds_read2_b64 / ds_write2_b64 / ds_read2st64_b64) merges them.
-FLAT_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-mllvm", "-amdgpu-load-store-vectorizer=0"]
+# Round 6: the machine scheduler of that unit is LLVM's iterative ILP scheduler (-amdgpu-sched-strategy=iterative-ilp) instead of the default
+# max-occupancy strategy -- the kernels' occupancy is fixed by their register budget (amdgpu_waves_per_eu), what they wait for is the dependent
+# chain of an iteration (LDS round trips, fp64 latencies): the lone iteration of k_flat2 2.18 -> 2.04 us, of k_flat1 2.97 -> 2.67 us, the headline
+# batch in arrival order 8.46 -> 8.06-8.14 ms, the whole body 15.5 -> 14.0-14.2 ms (profiles/r06_f_sched_strategy_ab.txt: max-ilp, max-memory-clause
+# and iterative-minreg measured beside it).  Same instructions, another order: results are bit-identical (the parity tests and the fuzz).
+FLAT_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-mllvm", "-amdgpu-load-store-vectorizer=0",
+              "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 
 
 def _stale():

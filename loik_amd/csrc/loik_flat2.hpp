@@ -623,6 +623,9 @@ __device__ __forceinline__ X held(X x)
 #ifndef LOIKB_TAU_AHEAD
 #define LOIKB_TAU_AHEAD 1
 #endif
+#ifndef LOIKB_SPIN_SLEEP
+#define LOIKB_SPIN_SLEEP 32   // (x 64 cycles between two looks of a wavefront that waits for a ring entry)
+#endif
 #ifndef LOIKB_HELD_ALWAYS
 #define LOIKB_HELD_ALWAYS 0
 #endif
@@ -851,7 +854,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
               __hip_atomic_store(Bf.counters + FLAT_COUNTERS_TDRY, (unsigned int)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           if (spins > (1u << 23)) { atomicOr(Bf.counters + FLAT_COUNTERS_ERR, 1u); break; }  // (never: a lost entry must not hang the GPU)
-          __builtin_amdgcn_s_sleep(32);
+          __builtin_amdgcn_s_sleep(LOIKB_SPIN_SLEEP);
         }
       }
       return __builtin_amdgcn_readfirstlane(got);
@@ -2053,7 +2056,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         for (unsigned int spins = 0; got < 0; ++spins) {   // (entries were waiting when the slice ended: normally it is there)
           if (__hip_atomic_load(q_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)nslots) break;
           if (spins > (1u << 23)) { atomicOr(Bf.counters + FLAT_COUNTERS_ERR, 1u); break; }
-          __builtin_amdgcn_s_sleep(32);
+          __builtin_amdgcn_s_sleep(LOIKB_SPIN_SLEEP);
           got = __hip_atomic_load(en, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (got >= 0) __hip_atomic_store(en, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2360,7 +2363,7 @@ k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
               __hip_atomic_store(Bf.counters + FLAT_COUNTERS_TDRY, (unsigned int)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           if (spins > (1u << 23)) { atomicOr(Bf.counters + FLAT_COUNTERS_ERR, 1u); break; }  // (never: a lost entry must not hang the GPU)
-          __builtin_amdgcn_s_sleep(32);
+          __builtin_amdgcn_s_sleep(LOIKB_SPIN_SLEEP);
         }
       }
       return __builtin_amdgcn_readfirstlane(got);
