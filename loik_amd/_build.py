@@ -50,6 +50,8 @@ def build(force=False, verbose=False, extra_flags=(), flat_flags=None):
         base.insert(1, "-Rpass-analysis=kernel-resource-usage")
     single_tu = any(f.startswith("-DLOIKB_TAIL_PROF") for f in extra_flags)
     if single_tu:
+        # (the iterative scheduler is for the flat unit only: it crashes the compiler on one of the other kernels)
+        flat_flags = [f for i, f in enumerate(flat_flags) if not (f.startswith("-amdgpu-sched-strategy") or (f == "-mllvm" and i + 1 < len(flat_flags) and flat_flags[i + 1].startswith("-amdgpu-sched-strategy")))]
         cmd = base + ["-shared", "-x", "hip", os.path.join(CSRC, "loik_host.hip"), "-x", "none", c_obj, "-o", LIB] + flat_flags + extra_flags
         if verbose:
             print(" ".join(cmd))

@@ -643,7 +643,7 @@ constexpr int FLAT_Q_PROBE = 1 << 30, FLAT_Q_FINISH = 1 << 29;
 constexpr int FLAT_PROBE_LAST = 32;   // the probe's middle mark: this many iterations before its end
 constexpr int FLAT_COUNTERS_FIN_N = 18;   // Bufs::counters[18]: entries of the list a FLAT_Q_FINISH launch takes (k_probe_sort)
 constexpr int FI_MARK0 = FI_RED + 13, FI_MARK1 = FI_RED + 14, FI_MARKM = FI_RED + 15;   // (spare entries of the scalar block: max(primal, dual) at the marks; MARK1: the latest)
-constexpr int FLAT_COUNTERS_DEC = 32;    // Bufs::counters[32 .. 63]: slots taken up (loaded or built) per decade kexp + 16
+constexpr int FLAT_COUNTERS_DEC = 32;    // Bufs::counters[32 .. 63]: != 0: somebody took up (loaded or built) a slot of decade kexp + 16
 template <int NA, int WPE, bool SLICED = false, int HM = 0, bool LOG = false, int MUR = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
@@ -771,7 +771,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
   T w = T(0), z = T(0), nu = T(0), s = T(0), lbi = T(0), ubi = T(0), mu = T(1);
   int kexp = 0, kslot = -(1 << 30), kslot_o = -(1 << 30), wsel = 0;
   int iter = 0, status = ST_DONE, tail_it = 0, nflip = 0;
-  unsigned int my_iters = 0, n_wave_iters = 0, n_slot_loads = 0, n_slot_hits = 0, n_inst_iters = 0, n_requeues = 0;
+  unsigned int my_iters = 0, n_wave_iters = 0, n_slot_loads = 0, n_slot_hits = 0, n_inst_iters = 0, n_requeues = 0, dec_seen = 0u;
   unsigned int* q_head = Bf.counters + LEAN_Q_HEAD;
   unsigned int cbits = 0u;  // constraint c: is its joint in this joint's subtree?
   auto cmask = [&](int c) -> T { return ((cbits >> c) & 1u) ? T(1) : T(0); };
@@ -1454,7 +1454,7 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
         }
       } else {
         {
-          if (MUR == 2 && lane == 0) atomicAdd(&Bf.counters[FLAT_COUNTERS_DEC + (kexp < -16 ? 0 : kexp > 15 ? 31 : kexp + 16)], 1u);
+          if (MUR == 2) dec_seen |= 1u << (kexp < -16 ? 0 : kexp > 15 ? 31 : kexp + 16);   // (flushed when the wavefront ends: the host asks which decades, not how often)
           kslot_o = kslot;  // the slot that was not used last is overwritten
           wsel ^= 1;
           T* wdst = wl + (size_t)wsel * (NA + 1) * GW;
@@ -2091,6 +2091,9 @@ k_flat2(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restri
     atomicAdd(&Bf.counters[6], n_slot_loads >> 16);
     atomicAdd(&Bf.counters[FLAT_COUNTERS_SLOT_HITS], n_slot_hits);
     atomicOr(&Bf.counters[LEAN_DECADES_SEEN], n_slot_loads & 0xFFFFu);
+    if constexpr (MUR == 2) {
+      for (unsigned int m = dec_seen; m; m &= m - 1u) atomicOr(&Bf.counters[FLAT_COUNTERS_DEC + __builtin_ctz(m)], 1u);
+    }
   }
 }
 #undef topo
@@ -2193,12 +2196,17 @@ __host__ __device__ __forceinline__ size_t flat1_lds_bytes(int nc, bool has_hv, 
 // MUR = 1 (round 5): OSQP's rule, as in k_flat2 -- mu0's slot from the table, every change of mu one in-wave build (flat_build_slot on all 64
 // lanes: its rows lie over the exchange area and the decade slots, so the launch keeps TWO slots in LDS), a division-free quiet test; unsliced.
 // aux[0] = TailTopo*, aux[1] = the children's list (read by the builder only); has_hv_bits: bits 8..15 = the tree's depth.
+// (MUR = 2, the lazily populated table of k_flat2, was built for this kernel in round 6 -- the builder as a function of its own, called between two
+//  instances -- and taken out again: k_fslots' window saves the whole body 0.5 ms of 14.4, the kernel gave the same back (the instances' fmask words,
+//  the coherent slot loads), and the build's register allocation tipped over with every small change of the kernel: 13 -> 43 -> 123 scratch reloads
+//  per iteration, the last one a 68 ms launch.  DESIGN section 0.)
 template <int NA, bool SLICED = false, int HM = 0, bool LOG = false, int MUR = 0>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_flat1(const Params<double> P, const Bufs<double> Bf, const JointDesc* __restrict__ jd, const FlatLane* __restrict__ fl, int nanc,
         int nscan, int njmp, int* ring, int nslots, const double* __restrict__ fslots, int frows, int kexp_lo,
         int ndec, double href_s, int has_hv_bits, int ring_mask, int quantum, const void* const* __restrict__ aux)
 {
+  static_assert(MUR == 0 || MUR == 1, "k_flat1 has no lazily populated table (see above)");
   static_assert(MUR == 0 || (!SLICED && !LOG), "the OSQP build of k_flat1 runs unsliced and writes no lists");
   static_assert(MUR == 0 || flat_build_scratch<WAVE>() <= flat1_xregion<NA>() + 2 * (NA + 1) * WAVE, "the in-wave builder's rows must end inside the two decade slots");
   // has_hv_bits: bit 0 = the reference target is not zero (H_ref v_ref rows in LDS), bit 1 = ONE decade slot in LDS instead of two

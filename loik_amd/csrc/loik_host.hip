@@ -1814,6 +1814,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       const int frows = S->flat.fblk;  // (scalars per decade slot of an instance, packed columns: loik_flat.hpp)
       // the rule that moves mu (k_flat2's MUR): 1 = OSQP's -- no table, every change of mu is an in-wave build --, 2 = decade steps with
       // the in-wave builder for the decades the table lacks (LOIKB_FLAT_BUILD=1), 0 = decade steps, the table or k_tail
+      // (k_flat2 only: for k_flat1 -- 33..64 joints -- it was built and measured in round 6 and did not pay: loik_flat2.hpp)
       const bool can_build2 = S->tune.flat_build && G == F2G && small_na && sizeof(T) == 8 && S->tune.flat_split && C->d_fmask != nullptr &&
                               !S->opt.logging && !S->per_link && href_is_scalar(S);
       int mur = flat_any_mu(S) ? 1 : (can_build2 ? 2 : 0);
@@ -1857,8 +1858,9 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         // (whether this launch is time-sliced, decided ONCE: the park buffer's size included -- ADVICE r05)
         int q = (split && !S->opt.logging) ? flat_slice_for(S, n, ordered) : 0;
         if (q > 0 && (C->d_park == nullptr || (size_t)n_cur * flat2_park_stride(S->nc, true) * sizeof(double) > C->park_bytes)) q = 0;
+        const bool win_ok = q > 0 && C->d_park != nullptr;   // (a window on time-sliced launches only: the builder beside the unsliced loop costs more than k_fslots saves)
         if (S->tune.flat_win_n > 0) { wlo = S->tune.flat_win_lo; whi = wlo + S->tune.flat_win_n - 1; }
-        else if (S->tune.flat_build == 2 && q > 0 && C->d_park != nullptr && S->end_hist_n > 0) {
+        else if (S->tune.flat_build == 2 && win_ok && S->end_hist_n > 0) {
           unsigned long long cum = 0;
           int k03 = 99, k97 = 99;
           for (int k = 0; k < 32; ++k) {
@@ -1868,7 +1870,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
           }
           wlo = std::min(0, k03); whi = std::max(0, k97);
         }
-        else if (S->tune.flat_build == 2 && q > 0 && C->d_park != nullptr && n >= 49152) {
+        else if (S->tune.flat_build == 2 && win_ok && n >= 49152) {
           // No history (a handle's first solve): the five decades from mu0's upwards.  The rule moves mu up far more often than down, and
           // rarely more than three decades; whoever leaves the window builds the slot once (results are bit-identical whatever the window:
           // tests/test_engines.py::test_flat_lazy_table_*).  Measured, time-sliced headline launches, ms per solve incl. k_fslots, full

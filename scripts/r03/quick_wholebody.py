@@ -14,6 +14,7 @@ for i in range(n):
     s.Solve()
     st = s.stats()
     rows.append((st["total_ms"], st["tail_ms"], st["hslots_ms"]))
+    if os.environ.get("VERBOSE"): print("   solve %d: total %.2f  launch %.2f  slots %.2f  built (cumulative) %d  requeues %d  ordered %d" % (i, st["total_ms"], st["tail_ms"], st["hslots_ms"], st.get("flat_built", -1), st["lean_requeues"], st["flat_ordered"]))
 r = np.array(rows[2:])
 conv = s.get("converged").astype(bool)
 print("%s whole body B=%d: total %.2f ms  launch %.2f ms  slots %.2f ms  (min %.2f)  iters %d  %.3f M solves/s  flat %d" % (
