@@ -32,9 +32,10 @@ def _stale():
     return False
 
 
-def build(force=False, verbose=False, extra_flags=(), flat_flags=None):
+def build(force=False, verbose=False, extra_flags=(), flat_flags=None, host_flags=()):
     """Compile every HIP source for gfx950.  hipcc cross-compiles without a GPU.
-    extra_flags go to both translation units; flat_flags (default FLAT_FLAGS) only to the flat iteration kernels'.
+    extra_flags go to both translation units; flat_flags (default FLAT_FLAGS) only to the flat iteration kernels', host_flags (default
+    none) only to the other unit.
     A -DLOIKB_TAIL_PROF build (phase timelines: its device-side counters are globals every kernel writes and the host reads) is ONE
     translation unit, compiled with flat_flags throughout."""
     if not force and not _stale():
@@ -58,7 +59,7 @@ def build(force=False, verbose=False, extra_flags=(), flat_flags=None):
         subprocess.check_call(cmd)
         return LIB
     host_obj, flat_obj = os.path.join(LIBDIR, "loik_host.o"), os.path.join(LIBDIR, "loik_flat_kernels.o")
-    cmds = [base + ["-DLOIKB_FLAT_SEPARATE_TU", "-c", "-x", "hip", os.path.join(CSRC, "loik_host.hip"), "-o", host_obj] + extra_flags,
+    cmds = [base + ["-DLOIKB_FLAT_SEPARATE_TU", "-c", "-x", "hip", os.path.join(CSRC, "loik_host.hip"), "-o", host_obj] + extra_flags + list(host_flags),
             base + ["-DLOIKB_FLAT_SEPARATE_TU", "-c", "-x", "hip", os.path.join(CSRC, "loik_flat_kernels.hip"), "-o", flat_obj] + flat_flags + extra_flags]
     import sys
     import tempfile
