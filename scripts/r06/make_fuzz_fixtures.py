@@ -12,7 +12,10 @@ OUT = os.path.join(ROOT, "gpurun_out", "fuzz_fixtures")
 os.makedirs(OUT, exist_ok=True)
 CASES = [dict(name="r05_j_fuzz_1500_case1212", ncase=1213, seed=4242, flat_bias=0.7, only=1212),
          dict(name="r05_j_fuzz_3000_case1126", ncase=1127, seed=9191, flat_bias=0.7, only=1126),
-         dict(name="r06_e_fuzz_3000_case522", ncase=523, seed=6006, flat_bias=0.7, only=522)]
+         dict(name="r06_e_fuzz_3000_case522", ncase=523, seed=6006, flat_bias=0.7, only=522),
+         # (second session: the 10 000-case fuzz of the final sources, profiles/r06_k_fuzz_10000.txt)
+         dict(name="r06_k_fuzz_10000_case6985", ncase=6986, seed=60606, flat_bias=0.7, only=6985),
+         dict(name="r06_k_fuzz_10000_case7785", ncase=7786, seed=60606, flat_bias=0.7, only=7785)]
 if len(sys.argv) > 1:   # (only the named cases)
     CASES = [c for c in CASES if c["name"] in sys.argv[1:]]
 for c in CASES:

@@ -17,6 +17,12 @@ change that makes them worse fails here, one that closes them can tighten the bo
 * case 522 of round 6's run (profiles/r06_e_fuzz_3000.txt): k_flat1 on a 33-joint helical tree, four constraints, per-link references,
   tol 1e-6, max_iter 60: again ONE converged instance at the oracle's iteration count, 1.70e-7 from its z, the others within 4e-10.
 
+* cases 6985 and 7785 of the 10 000-case run on round 6's final sources (profiles/r06_k_fuzz_10000.txt: 7.9 M instances, two mismatches):
+  6985 is case 1212's class again on the tree-walking engines -- OSQP's rule, a multi-DoF tree of 20 joints (nv = 24: k_solve / k_tail), four
+  constraints, tol 1e-6: four of 3000 instances stop 1 .. 6 iterations from the oracle's count, both converged, up to 1.67e-5
+  apart; 7785 is the near-tie class on ANOTHER engine, k_solve (37 joints, per-link references, tol 1e-4): one converged instance at the
+  oracle's iteration count 1.02e-4 from its z -- one tolerance --, every other instance within 3e-10.
+
 What the two k_flat1 cases are (scripts/r06/near_tie_probe.py: both solvers with logging = 1 on that one instance, the SolverInfo lists side
 by side): a NEAR-TIE of UpdateMu's compare `primal > 10 dual` (loik-loid-optimized.hxx:613-641).  Case 522, iteration 50: primal / dual =
 10.000009 here, 9.999776 in the oracle -- mu goes up one iteration earlier here; case 1126, iteration 72: 9.99951 here, 10.00158 in the
@@ -48,7 +54,8 @@ def load_case(name):
     return fx, model, prm, env, kw, refs, args
 
 
-@pytest.mark.parametrize("name", ["r05_j_fuzz_1500_case1212", "r05_j_fuzz_3000_case1126", "r06_e_fuzz_3000_case522"])
+@pytest.mark.parametrize("name", ["r05_j_fuzz_1500_case1212", "r05_j_fuzz_3000_case1126", "r06_e_fuzz_3000_case522",
+                                  "r06_k_fuzz_10000_case6985", "r06_k_fuzz_10000_case7785"])
 def test_fixture_holds_the_oracles_answers(name):
     """(CPU) the frozen answers are the oracle's on the frozen inputs: the fixture is data of the checker, not of the engine"""
     fx, model, prm, env, kw, refs, args = load_case(name)
@@ -125,4 +132,38 @@ def test_fuzz_r06_case522_helical_tree_per_link_references(monkeypatch):
     assert int(fx["pick"][worst]) == 512   # (the one instance of the fuzz run: a near-tie of UpdateMu's compare at iteration 50)
     assert dz[worst] <= 1.75e-7, dz[worst]
     # (the others: converged ones within 1e-10; the instances max_iter = 60 stopped unconverged within 5e-10)
+    assert np.delete(dz, worst).max() <= 5e-10, np.delete(dz, worst).max()
+
+
+@pytest.mark.gpu
+def test_fuzz_r06_case6985_osqp_rule_multidof_tree(monkeypatch):
+    fx, model, prm, env, kw, refs, args = load_case("r06_k_fuzz_10000_case6985")
+    got, st = solve_on_gpu(monkeypatch, fx, model, prm, env, kw, refs, args)
+    assert st["flat_launches"] == 0, st   # (multi-DoF joints, nv = 24 on 20 joints: outside the flat engines' domain -- k_solve / k_tail under OSQP's rule)
+    dz = np.abs(got["z"] - fx["ref_z"]).max(axis=1)
+    same = got["iter"] == fx["ref_iters"]
+    assert np.array_equal(got["iter"], fx["gpu_iters_full_batch"]), "an instance's result depends on the batch it is solved in"
+    assert np.abs(dz - fx["gpu_dz_full_batch"]).max() <= 1e-12
+    # flags agree wherever the counts do; the off-count instances converged in both solvers
+    assert np.array_equal(got["converged"][same], fx["ref_converged"][same]) and np.array_equal(got["primal_infeasible"][same], fx["ref_primal_infeasible"][same])
+    assert got["converged"][~same].all() and fx["ref_converged"][~same].all()
+    # the pinned deviations: four instances off the oracle's count (by 1, 6, 1, 1 iterations), the furthest 1.67e-5 from its z; the others within 1.1e-7
+    assert int((~same).sum()) <= 4, int((~same).sum())
+    assert np.abs(got["iter"] - fx["ref_iters"]).max() <= 6
+    assert dz[~same].max() <= 1.7e-5, dz[~same].max()
+    assert dz[same].max() <= 1.2e-7, dz[same].max()
+
+
+@pytest.mark.gpu
+def test_fuzz_r06_case7785_k_solve_per_link_references_near_tie(monkeypatch):
+    fx, model, prm, env, kw, refs, args = load_case("r06_k_fuzz_10000_case7785")
+    got, st = solve_on_gpu(monkeypatch, fx, model, prm, env, kw, refs, args)
+    assert st["flat_launches"] == 0 and st["lean_launches"] == 0, st   # (k_solve alone: tail_max_instances = -1)
+    dz = np.abs(got["z"] - fx["ref_z"]).max(axis=1)
+    assert np.array_equal(got["iter"], fx["ref_iters"])
+    assert np.array_equal(got["converged"], fx["ref_converged"]) and np.array_equal(got["primal_infeasible"], fx["ref_primal_infeasible"])
+    assert np.abs(dz - fx["gpu_dz_full_batch"]).max() <= 1e-12
+    worst = int(np.argmax(dz))
+    assert int(fx["pick"][worst]) == 1103   # (the one instance of the fuzz run)
+    assert dz[worst] <= 1.05e-4, dz[worst]          # (one tolerance: tol_abs = 1e-4)
     assert np.delete(dz, worst).max() <= 5e-10, np.delete(dz, worst).max()
