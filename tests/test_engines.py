@@ -760,3 +760,30 @@ def test_small_batches_run_on_the_one_instance_per_wavefront_engine(talos, B, mo
     assert s.stats()["flat_launches"] == 0
     assert np.array_equal(np.asarray(s.get("iter")), out["iters"]) and np.abs(np.asarray(s.get("z")) - out["z"]).max() < 1e-9
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot,ns_max", [("talos32", 6.0), ("talos44", 8.0)])
+@pytest.mark.parametrize("sliced", [False, True])
+def test_flat_kernels_iteration_rate_has_not_tipped_over(robot, ns_max, sliced, monkeypatch):
+    """A guard, not a benchmark.  The flat kernels' register allocation sits close to a tipping point since their unit is scheduled by the
+    iterative ILP scheduler: twice in round 6 a small source change made the compiler allocate scratch reloads INTO the iteration loop
+    (13 -> 43 -> 123 per iteration; one build ran the whole body in 68 ms instead of 14), every parity test still green.  Here: 16 384
+    instances (a batch whose launch is half straggler chain), wall time of the on-chip launch per instance-iteration -- 2.5-3.3 ns (Talos-32) /
+    3.4-3.8 ns (whole body) on an idle MI355X, bounds at twice that (a loaded box, a cold clock), less than half of what the tipped build took.  scripts/r05/loopstat.py on the unit's assembly is
+    the check that says WHY."""
+    from loik_amd import workloads
+    monkeypatch.setenv("LOIKB_FLAT_ORDER", "0")
+    monkeypatch.setenv("LOIKB_FLAT_SLICE", "288" if sliced else "0")
+    B = 16384
+    wl = (workloads.talos_c3 if robot == "talos32" else workloads.talos_wholebody)(B)
+    s = loik_amd.BatchedLoik(wl["model"], B, **wl["params"])
+    s.SolveInit(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    best = 1e9
+    for _ in range(3):
+        s.Solve()
+        st = s.stats()
+        assert st["flat_launches"] == 1, st
+        best = min(best, (st["tail_ms"] - st["hslots_ms"]) * 1e6 / st["instance_iterations"])
+    s.close()
+    assert best < ns_max, "%.2f ns per instance-iteration: has the kernel's loop acquired scratch reloads? (scripts/r05/loopstat.py)" % best
