@@ -49,7 +49,9 @@ def build(force=False, verbose=False, extra_flags=(), flat_flags=None, host_flag
     base = [HIPCC, "--offload-arch=gfx950", "-O3", "-ffp-contract=on", "-std=c++17", "-fPIC", "-I", inc, "-Wall", "-Wno-unused-function"]
     if verbose:
         base.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    single_tu = any(f.startswith("-DLOIKB_TAIL_PROF") for f in extra_flags)
+    # (-DLOIKB_TAIL_PROF alone: one unit, the default schedule everywhere -- the phase timelines of rounds 3-6.  With -DLOIKB_TAIL_PROF_TWO_UNITS beside
+    #  it: the two units as shipped, each with its own copy of the counters: the timeline of the SHIPPED schedule of the flat kernels)
+    single_tu = any(f.startswith("-DLOIKB_TAIL_PROF") for f in extra_flags) and "-DLOIKB_TAIL_PROF_TWO_UNITS" not in extra_flags
     if single_tu:
         # (the iterative scheduler is for the flat unit only: it crashes the compiler on one of the other kernels)
         flat_flags = [f for i, f in enumerate(flat_flags) if not (f.startswith("-amdgpu-sched-strategy") or (f == "-mllvm" and i + 1 < len(flat_flags) and flat_flags[i + 1].startswith("-amdgpu-sched-strategy")))]

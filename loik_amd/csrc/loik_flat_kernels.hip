@@ -8,3 +8,17 @@
 
 LOIKB_FLAT2_INSTANCES(LOIKB_FLAT2_DEF)
 LOIKB_FLAT1_INSTANCES(LOIKB_FLAT1_DEF)
+
+#ifdef LOIKB_TAIL_PROF
+// (profile build of two units: this unit's copy of the phase counters -- the ones k_flat2 / k_flat1 write -- for the host unit's debug entry points.
+//  which: 0 = g_tail_prof (wavefront 0 of the last launch), 1 = g_tail_prof_all (all wavefronts since the last reset; reset != 0 clears it))
+int loikb_flat_prof_read(unsigned long long* out, int which, int reset)
+{
+  if (hipMemcpyFromSymbol(out, which ? HIP_SYMBOL(loikb::g_tail_prof_all) : HIP_SYMBOL(loikb::g_tail_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+  if (which && reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(loikb::g_tail_prof_all), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif

@@ -23,6 +23,9 @@
 #include "loik_flat_inst.hpp"
 LOIKB_FLAT2_INSTANCES(LOIKB_FLAT2_DECL)
 LOIKB_FLAT1_INSTANCES(LOIKB_FLAT1_DECL)
+#ifdef LOIKB_TAIL_PROF
+int loikb_flat_prof_read(unsigned long long* out, int which, int reset);   // (loik_flat_kernels.hip: that unit's copy of the phase counters)
+#endif
 #endif
 
 #include "../../include/loik_amd.h"
@@ -3692,6 +3695,12 @@ int loikb_debug_wave_dbg(unsigned long long* out)
 int loikb_debug_tail_prof(unsigned long long* out)
 {
   HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(loikb::g_tail_prof), sizeof(unsigned long long) * 32));
+#ifdef LOIKB_FLAT_SEPARATE_TU
+  // (two units: the flat kernels wrote THEIR copy -- taken when it holds a launch; the callers profile one engine at a time)
+  unsigned long long f[32];
+  if (loikb_flat_prof_read(f, 0, 0)) return LOIKB_ERR_HIP;
+  if (f[8]) memcpy(out, f, sizeof(f));
+#endif
   return LOIKB_OK;
 }
 int loikb_debug_tail_prof_all(unsigned long long* out, int reset)   // the phases summed over all wavefronts since the last reset
@@ -3701,6 +3710,11 @@ int loikb_debug_tail_prof_all(unsigned long long* out, int reset)   // the phase
     unsigned long long z[32] = {0};
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(loikb::g_tail_prof_all), z, sizeof(z)));
   }
+#ifdef LOIKB_FLAT_SEPARATE_TU
+  unsigned long long f[32];
+  if (loikb_flat_prof_read(f, 1, reset)) return LOIKB_ERR_HIP;
+  for (int k = 0; k < 32; ++k) out[k] += f[k];   // (sums since the last reset: one of the two copies is zero unless both kinds of kernel ran)
+#endif
   return LOIKB_OK;
 }
 #endif

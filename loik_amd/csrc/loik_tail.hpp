@@ -77,11 +77,19 @@ __host__ __device__ __forceinline__ size_t tail_lds_bytes(int nc, int G)
 
 // Phase timeline of one wavefront (diagnostic build only: -DLOIKB_TAIL_PROF, scripts/tail_phase_profile.py)
 #ifdef LOIKB_TAIL_PROF
-__device__ unsigned long long g_tail_prof_all[32];  // the same phases summed over ALL wavefronts of the launch ([8]: iterations, [9]: wavefronts)
-__device__ unsigned long long g_tail_prof[32];  // [0..8) phases, [8] iterations, [9] clock, [10..14) finer phases of k_lean / k_flat2, [14..22) k_flat2: an instance's load / store
+// (a profile build of TWO translation units -- the flat kernels with their own code generation, as shipped -- has two copies of these: the
+//  flat unit's are its own (static), read through loikb_flat_prof_read, loik_flat_kernels.hip; the debug entry points take whichever copy
+//  holds the last launch)
+#ifdef LOIKB_FLAT_KERNELS_TU
+#define LOIKB_PROF_LINKAGE static
+#else
+#define LOIKB_PROF_LINKAGE
+#endif
+LOIKB_PROF_LINKAGE __device__ unsigned long long g_tail_prof_all[32];  // the same phases summed over ALL wavefronts of the launch ([8]: iterations, [9]: wavefronts)
+LOIKB_PROF_LINKAGE __device__ unsigned long long g_tail_prof[32];  // [0..8) phases, [8] iterations, [9] clock, [10..14) finer phases of k_lean / k_flat2, [14..22) k_flat2: an instance's load / store
 // per wavefront of the last lean launch: [0] wall clock (100 MHz) at start, [1] when the wavefront last had an instance,
 // [2] at exit, [3] wavefront-iterations, [4] wavefront-iterations with both groups active, [5] instance switches
-__device__ unsigned long long g_wave_dbg[4096][6];
+LOIKB_PROF_LINKAGE __device__ unsigned long long g_wave_dbg[4096][6];
 #define TAIL_TP(k) { const unsigned long long tn_ = clock64(); prof_[k] += tn_ - tprev_; tprev_ = tn_; }
 #else
 #define TAIL_TP(k)
