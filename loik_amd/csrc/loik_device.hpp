@@ -1861,9 +1861,9 @@ enum : int {
   RS_MU = 32,         // mu = mu0 only (the MAXEIGENVALUE rule's starting value, known once the solve's references are)
 };
 template <typename T>
-__global__ void __launch_bounds__(WAVE) k_reset(char* tiles, Layout L, int what, T mu0)
+__device__ __forceinline__ void reset_tile(char* tiles, const Layout& L, int what, T mu0, int tile, int lane)
 {
-  char* lp = tiles + (size_t)blockIdx.x * L.tile_pairs * pair_bytes<T>() + (size_t)threadIdx.x * 2 * sizeof(T);
+  char* lp = tiles + (size_t)tile * L.tile_pairs * pair_bytes<T>() + (size_t)lane * 2 * sizeof(T);
   if (what & (RS_DATA_COLD | RS_RECURSION)) {
     for (int j = 0; j < L.nb; ++j) {
       char* rec = lp + (size_t)j * JREC * pair_bytes<T>();
@@ -1888,6 +1888,11 @@ __global__ void __launch_bounds__(WAVE) k_reset(char* tiles, Layout L, int what,
   if (what & RS_SOLVER) stp<T>(srec, SP_FLIP, T(0), T(0));
   if (what & RS_MU) stp<T>(srec, SP_MU, mu0, T(0));
   if (what & RS_HCACHE) stp<T>(srec, SP_TAG, T(-1), T(0));
+}
+template <typename T>
+__global__ void __launch_bounds__(WAVE) k_reset(char* tiles, Layout L, int what, T mu0)
+{
+  reset_tile<T>(tiles, L, what, mu0, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------

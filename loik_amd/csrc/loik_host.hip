@@ -75,6 +75,10 @@ struct Tuning {
   int flat_slice2 = 0;          // LOIKB_FLAT_SLICE2=q: an instance's later slices (0: as the first)
   int flat_small_batch = 2048;  // LOIKB_FLAT_SMALL_BATCH=n: up to n instances a Solve() on k_flat2 / k_flat1 is the short sequence (fused queue set-up, no order pass)
   int flat_min_batch = 1;       // LOIKB_FLAT_MIN_BATCH=n: k_flat2 / k_flat1 take batches from n instances (round 5: 64; below, k_tail)
+  int small_finish = 1;         // LOIKB_SMALL_FINISH=0: the short sequence ends with k_list_unfinished + a copy of the counters + run_main_loop's own event and
+                                //   synchronisation, as before (1: k_small_finish writes the counters into the pinned host copy; one synchronisation per Solve())
+  int small_slot_event = 0;     // LOIKB_SMALL_SLOT_EVENT=1: an event between k_fslots and the engine in the short sequence too (default: none, loikb_stats::hslots_ms reads 0
+                                //   there -- an event costs a lone problem's Solve() 2.5 us of 116: profiles/r06_o_small_finish_ab.jsonl)
   int flat_probe = 0;           // (default 0: measured a wash against the round robin, profiles/r06_a_probe_and_finish_ab.txt; given: wherever LOIKB_FLAT_SLICE / the default slices it) LOIKB_FLAT_PROBE=p: a time-sliced k_flat2 launch without an order becomes TWO launches -- every instance for p iterations at
                                 // most, then the survivors to completion, longest predicted first (0: one launch, round robin: round 5's)
   int flat_probe_mark = 32;     // LOIKB_FLAT_PROBE_MARK=k: the probe's first mark (the residual's rate of fall is taken between it and the probe's end)
@@ -115,6 +119,8 @@ struct Tuning {
     if (const char* e = getenv("LOIKB_FLAT_SLICE2")) flat_slice2 = std::min(8191, std::max(0, atoi(e)));
     if (const char* e = getenv("LOIKB_FLAT_PROBE")) flat_probe = std::min(8000, std::max(0, atoi(e)));
     if (const char* e = getenv("LOIKB_FLAT_MIN_BATCH")) flat_min_batch = std::max(1, atoi(e));
+    if (const char* e = getenv("LOIKB_SMALL_FINISH")) small_finish = atoi(e);
+    if (const char* e = getenv("LOIKB_SMALL_SLOT_EVENT")) small_slot_event = atoi(e);
     if (const char* e = getenv("LOIKB_FLAT_SMALL_BATCH")) flat_small_batch = std::max(0, atoi(e));
     if (const char* e = getenv("LOIKB_FLAT_PROBE_MARK")) flat_probe_mark = std::max(1, atoi(e));
     if (const char* e = getenv("LOIKB_FSLOT_DGRP")) fslot_dgrp = std::max(0, atoi(e));
@@ -289,6 +295,8 @@ struct loikb_solver_impl {
     std::vector<int> h_wave;             // host scratch for the compaction scan
     loikb_stats stats{};
     bool unfinished_counted = false;     // stats.n_unfinished of the last solve came with the on-chip launch's own counters (small batches)
+    bool queue_ready = false;            // list + ring + counters of the whole home set were prepared by this solve's reset launch (reset_home, with_queue)
+    bool small_finished = false;         // ... and the launch's last kernel was k_small_finish, waited for in run_tail: nothing of this solve is pending on the stream
     int rc = 0;
     std::string err;
     // [start, end) of every solve / tail launch of the last call, ms since the fork event (HIP events)
@@ -934,11 +942,23 @@ Params<T> make_params(loikb_solver_impl* S)
 }
 
 // one k_reset launch over the home set
-int reset_home(loikb_solver_impl* S, int what)
+int reset_home(loikb_solver_impl* S, int what, bool with_queue = false)
 {
   const dim3 grid(S->home.ntiles), block(WAVE);
   // (a solve starts with RS_SOLVER: does it start from vis = fis = g = w = z = 0?  MODE_ZERO_STATE of the flat engine's launch)
   if (what & RS_SOLVER) S->zero_state = (what & (RS_DATA_COLD | RS_RECURSION)) != 0;
+  // (with_queue: the caller goes straight into the main loop.  A small fp64 handle's on-chip launch takes its list, ring and counters from this
+  //  launch -- run_tail's short sequence, which checks and clears queue_ready; a solve that goes elsewhere prepares its own as ever)
+  if (with_queue && !S->f32 && S->chunks.size() == 1 && S->tune.small_finish && S->tune.flat_split && S->B <= S->tune.flat_small_batch &&
+      S->chunks[0].d_ring != nullptr && S->chunks[0].d_slots != nullptr && S->chunks[0].d_counters != nullptr) {
+    loikb_solver_impl::Chunk& C = S->chunks[0];
+    const int qblocks = (std::max(C.ring_cap, NCOUNTERS) + WAVE - 1) / WAVE;
+    hipLaunchKernelGGL(k_reset_and_queue<double>, dim3(S->home.ntiles + qblocks), block, 0, S->stream, S->home.tiles, S->L, what, (double)solve_mu0(S),
+                       S->home.ntiles, C.d_ring, C.ring_cap, C.d_slots, S->B, C.d_counters, NCOUNTERS);
+    HIPCHK(hipGetLastError());
+    C.queue_ready = true;
+    return LOIKB_OK;
+  }
   if (S->f32) hipLaunchKernelGGL(k_reset<float>, grid, block, 0, S->stream, S->home.tiles, S->L, what, (float)solve_mu0(S));
   else hipLaunchKernelGGL(k_reset<double>, grid, block, 0, S->stream, S->home.tiles, S->L, what, (double)solve_mu0(S));
   HIPCHK(hipGetLastError());
@@ -1838,9 +1858,14 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       P.max_launch_iters = S->opt.max_iter + 1;
       const int mode_keep = P.mode;
       if (whole_set && S->zero_state && S->tune.flat_zero_state) P.mode |= MODE_ZERO_STATE;
-      if (small_flat) hipLaunchKernelGGL(k_queue_init_iota, grid1(std::max(C->ring_cap, NCOUNTERS)), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, C->d_slots, n_cur, C->d_counters, NCOUNTERS);
+      // (queue_ready: this solve's reset launch left list, ring and counters -- nothing lies between the solve's first event and this point)
+      const bool queue_ready = small_flat && C->queue_ready && n_cur == S->B;
+      C->queue_ready = false;
+      if (queue_ready) {}
+      else if (small_flat) hipLaunchKernelGGL(k_queue_init_iota, grid1(std::max(C->ring_cap, NCOUNTERS)), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, C->d_slots, n_cur, C->d_counters, NCOUNTERS);
       else HIPCHK(hipMemsetAsync(C->d_counters, 0, NCOUNTERS * sizeof(unsigned int), C->stream));
-      HIPCHK(hipEventRecord(C->ev_k0, C->stream));
+      const hipEvent_t ev_first = queue_ready ? S->ev_t0 : C->ev_k0;
+      if (!queue_ready) HIPCHK(hipEventRecord(C->ev_k0, C->stream));
       // longest first: the order the previous solve of this handle left (k_order_*, loik_lean.hpp) when this launch takes the same
       // whole set; the decade slots are indexed by the INSTANCE slot (sidx / lidx), so k_fslots and the engine find them under any order of the list
       const bool ordered = !small_flat && whole_set && list == C->d_slots && n == n_cur && (split || one) && order_usable(S, C, n_cur);
@@ -1908,9 +1933,10 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
                              dw0, nw, mur == 2 ? C->d_fmask : (unsigned int*)nullptr);
         HIPCHK(hipGetLastError());
       }
-      HIPCHK(hipEventRecord(C->ev_k2, C->stream));
+      const bool slot_event = !small_flat || S->tune.small_slot_event || S->tune.flat_probe > 0;   // (the probe launch's time is taken from this event)
+      if (slot_event) HIPCHK(hipEventRecord(C->ev_k2, C->stream));
       const int n_first = n;
-      bool probe_timed = false;
+      bool probe_timed = false, small_finish = false;
       dim3 grid((unsigned)std::min((n + ipw - 1) / ipw, cap_lat));
       {
         if (!small_flat) hipLaunchKernelGGL(k_ring_fill, grid1(C->ring_cap), dim3(256), 0, C->stream, C->d_ring, C->ring_cap, list, n, C->d_counters);
@@ -2077,7 +2103,11 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
         HIPCHK(hipGetLastError());
         P.mode = mode_keep;
         int* nxt = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
-        hipLaunchKernelGGL(k_list_unfinished<T>, grid1(n), dim3(256), 0, C->stream, A.tiles, S->L, list, n, nxt, C->d_counters + 3);
+        small_finish = small_flat && S->tune.small_finish;
+        if (small_finish)   // (one workgroup: the list, the counts, and the launch's counters into the pinned host copy -- loik_lean.hpp)
+          hipLaunchKernelGGL(k_small_finish<T>, dim3(1), dim3(256), 0, C->stream, A.tiles, S->L, list, n, nxt, C->d_counters, NCOUNTERS, C->h_counters);
+        else
+          hipLaunchKernelGGL(k_list_unfinished<T>, grid1(n), dim3(256), 0, C->stream, A.tiles, S->L, list, n, nxt, C->d_counters + 3);
         HIPCHK(hipGetLastError());
         C->stats.launches++;
         C->stats.tail_launches++;
@@ -2088,7 +2118,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       int* next = (list == C->d_slots) ? C->d_slots2 : C->d_slots;
       HIPCHK(hipEventRecord(C->ev_k1, C->stream));
       const bool order_pass = !small_flat && S->tune.flat_order && whole_set && n_first == n_cur && (split || one) && !(S->opt.flags & LOIKB_OPT_FIXED_ITERS);
-      if (!order_pass) HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
+      if (!order_pass && !small_finish) HIPCHK(hipMemcpyAsync(C->h_counters, C->d_counters, NCOUNTERS * sizeof(unsigned int), hipMemcpyDeviceToHost, C->stream));
       if (order_pass) {
         // the order for the handle's next solve: longest first by the iteration counts of this one (an instance that escaped to
         // k_tail counts with what it had when it left); and the decades the instances ended in (the next sliced launch's table window)
@@ -2104,9 +2134,9 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       }
       HIPCHK(hipStreamSynchronize(C->stream));
       float ms = 0.f, t0 = 0.f, hms = 0.f;
-      HIPCHK(hipEventElapsedTime(&ms, C->ev_k0, C->ev_k1));
-      HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0));
-      HIPCHK(hipEventElapsedTime(&hms, C->ev_k0, C->ev_k2));
+      HIPCHK(hipEventElapsedTime(&ms, ev_first, C->ev_k1));
+      if (!queue_ready) HIPCHK(hipEventElapsedTime(&t0, S->ev_t0, C->ev_k0));
+      if (slot_event) HIPCHK(hipEventElapsedTime(&hms, ev_first, C->ev_k2));
       iters += C->h_counters[1];
       if (C->h_counters[FLAT_COUNTERS_ERR]) {
         g_last_error = (C->h_counters[FLAT_COUNTERS_ERR] & 4u) ? "internal: the flat engine's dynamic LDS does not start at LDS address 0 (lds_abs)"
@@ -2158,7 +2188,7 @@ int run_tail(loikb_solver_impl* S, Chunk* C, Params<T>& P, int cur, int n_cur, i
       n = (int)C->h_counters[3];
       list = next;
       // (the launch took the chunk's whole home set and nothing is still iterating: k_list_unfinished has counted loikb_stats::n_unfinished)
-      if (n == 0 && whole_set && cur == 0 && n_first == n_cur && S->chunks.size() == 1) { C->stats.n_unfinished = (int)C->h_counters[4]; C->unfinished_counted = true; }
+      if (n == 0 && whole_set && cur == 0 && n_first == n_cur && S->chunks.size() == 1) { C->stats.n_unfinished = (int)C->h_counters[4]; C->unfinished_counted = true; C->small_finished = small_finish; }
       if (n == 0) { *ms_out = total_ms; *iters_out = iters; return LOIKB_OK; }
       // what is left escaped the precomputed decades: k_tail below finishes it
     }
@@ -2372,6 +2402,7 @@ int run_chunk(loikb_solver_impl* S, Chunk* C)
   Params<T> P = make_params<T>(S);
   C->stats = loikb_stats{};
   C->unfinished_counted = false;
+  C->small_finished = false;
   C->solve_iv.clear();
   C->tail_iv.clear();
   double kernel_ms = 0.0;
@@ -2567,10 +2598,16 @@ int run_main_loop_t(loikb_solver_impl* S)
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(C0->h_counters, C0->d_counters, sizeof(unsigned int), hipMemcpyDeviceToHost, S->stream));
   }
-  HIPCHK(hipEventRecord(S->ev_t1, S->stream));
-  HIPCHK(hipStreamSynchronize(S->stream));
   float tms = 0.f;
-  HIPCHK(hipEventElapsedTime(&tms, S->ev_t0, S->ev_t1));
+  if (counted && C0->small_finished) {
+    // (the short sequence: run_tail has waited for its last kernel, which left the counters on the host; nothing was queued since --
+    //  no event and no synchronisation of this function's own)
+    HIPCHK(hipEventElapsedTime(&tms, S->ev_t0, C0->ev_k1));
+  } else {
+    HIPCHK(hipEventRecord(S->ev_t1, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
+    HIPCHK(hipEventElapsedTime(&tms, S->ev_t0, S->ev_t1));
+  }
   S->stats.n_unfinished = counted ? C0->stats.n_unfinished : (int)C0->h_counters[0];
   for (const Chunk& C : S->chunks) {
     S->stats.instance_iterations += C.stats.instance_iterations;
@@ -2632,6 +2669,8 @@ static int start_mu(loikb_solver_impl* S)
 
 int run_main_loop(loikb_solver_impl* S)
 {
+  // (reset_home's offer of a prepared queue holds for the solve it was made for, however this function is left)
+  struct QueueOffer { loikb_solver_impl* S; ~QueueOffer() { for (loikb_solver_impl::Chunk& C : S->chunks) C.queue_ready = false; } } offer{S};
   S->pass_active = false;  // (pass-level calls work on a copy of the state: a solve continues from the solver's own)
   // UpdateMu's throw site for an unknown strategy (hxx:638-640); OSQP and MAXEIGENVALUE are extensions of this library
   if (S->opt.mu_update_strat != LOIKB_MU_DEFAULT && S->opt.mu_update_strat != LOIKB_MU_OSQP &&
@@ -2640,9 +2679,10 @@ int run_main_loop(loikb_solver_impl* S)
     return LOIKB_ERR_MU_STRATEGY;
   }
   int rc;
-  if (!S->plan.solve_ok && !bushy_goes_on_chip(S)) return run_pass_solve(S, false);   // (the engine of last resort: EnginePlan::solve_ok)
-  if ((rc = start_mu(S))) return rc;
-  return S->f32 ? run_main_loop_t<float>(S) : run_main_loop_t<double>(S);
+  if (!S->plan.solve_ok && !bushy_goes_on_chip(S)) rc = run_pass_solve(S, false);   // (the engine of last resort: EnginePlan::solve_ok)
+  else if ((rc = start_mu(S))) {}
+  else rc = S->f32 ? run_main_loop_t<float>(S) : run_main_loop_t<double>(S);
+  return rc;
 }
 
 // liMi of the caller's joints: sel[e] + 1 = the first device joint of joint e + 1, last[e] + 1 = the last one.  One device
@@ -3006,7 +3046,7 @@ int loikb_solve(loikb_solver* S)
   HIPCHK(hipSetDevice(S->device));
   int rc;
   // ik_id_data_.ResetRecursion(); ResetSolver()  (hpp:370-374)
-  if ((rc = reset_home(S, RS_RECURSION | RS_SOLVER))) return rc;
+  if ((rc = reset_home(S, RS_RECURSION | RS_SOLVER, !S->opt.logging))) return rc;
   return S->opt.logging ? run_logged(S, RS_RECURSION | RS_SOLVER) : run_main_loop(S);
 }
 

@@ -1020,6 +1020,23 @@ __global__ void k_queue_init_iota(int* __restrict__ ring, int cap, int* __restri
     counters[i] = v;
   }
 }
+// ... and, for the plain Solve() of a small handle (loikb_solve: ResetRecursion + ResetSolver, then the loop -- hpp:370-374), the reset of the
+// home set with it: workgroups [0, ntiles) are k_reset's, the rest k_queue_init_iota's -- one launch less in front of a lone problem's solve
+template <typename T>
+__global__ void __launch_bounds__(WAVE) k_reset_and_queue(char* tiles, Layout L, int what, T mu0, int ntiles, int* __restrict__ ring, int cap,
+                                                          int* __restrict__ list, int n, unsigned int* __restrict__ counters, int ncounters)
+{
+  if ((int)blockIdx.x < ntiles) { reset_tile<T>(tiles, L, what, mu0, (int)blockIdx.x, (int)threadIdx.x); return; }
+  const int i = ((int)blockIdx.x - ntiles) * WAVE + (int)threadIdx.x;
+  if (i < cap) ring[i] = i < n ? i : -1;
+  if (i < n) list[i] = i;
+  if (i < ncounters) {
+    unsigned int v = 0u;
+    if (i == LEAN_Q_TAIL) v = (unsigned int)n;
+    if (i == 14) v = (unsigned int)wall_clock64();   // (FLAT_COUNTERS_T0)
+    counters[i] = v;
+  }
+}
 #endif
 
 // the listed instances that are still iterating after a lean launch (the ones that escaped), in arbitrary order
@@ -1036,6 +1053,27 @@ __global__ void k_list_unfinished(char* tiles, Layout L, const int* __restrict__
   const int status = (int)ldp<T>(sp + (size_t)L.off_s * pair_bytes<T>(), SP_ST).x;
   if (!(status & ST_DONE)) list_out[atomicAdd(counter, 1u)] = b;
   if (!(status & (ST_CONVERGED | ST_PRIMAL_INF))) atomicAdd(counter + 1, 1u);
+}
+
+// The small batches' last kernel (run_tail, small_flat: at most a few thousand listed instances, ONE workgroup): k_list_unfinished's list and
+// counts, then the launch's counters go straight into the chunk's pinned host copy -- the memory is host-coherent and mapped, the stores
+// are out when the kernel is: a Solve() of one problem (the reference's own call, tests/loik-loid.cpp:987-1032) ends with one
+// synchronisation and no copy of its own behind the last kernel.
+template <typename T>
+__global__ void __launch_bounds__(256) k_small_finish(char* tiles, Layout L, const int* __restrict__ list_in, int n_in, int* __restrict__ list_out,
+                                                      unsigned int* __restrict__ counters, int ncounters, unsigned int* __restrict__ host_counters)
+{
+  for (int i = threadIdx.x; i < n_in; i += blockDim.x) {
+    const int b = list_in[i];
+    char* sp = lane_ptr<T>(tiles, L, b);
+    const int status = (int)ldp<T>(sp + (size_t)L.off_s * pair_bytes<T>(), SP_ST).x;
+    if (!(status & ST_DONE)) list_out[atomicAdd(counters + 3, 1u)] = b;
+    if (!(status & (ST_CONVERGED | ST_PRIMAL_INF))) atomicAdd(counters + 4, 1u);
+  }
+  __threadfence();   // (the block's atomics are performed at the L2 before anybody looks; the loads below go there too)
+  __syncthreads();
+  for (int k = threadIdx.x; k < ncounters; k += blockDim.x)
+    host_counters[k] = __hip_atomic_load(counters + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- longest first.  The iteration counts of a batch are heavy-tailed (headline workload: median 26, mean 80, 1.2 % run into

@@ -763,6 +763,46 @@ def test_small_batches_run_on_the_one_instance_per_wavefront_engine(talos, B, mo
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("robot,B", [("talos32", 1), ("talos32", 700), ("talos32", 2048), ("talos44", 3), ("talos44", 300)])
+def test_short_sequence_ends_with_one_synchronisation_and_the_same_results(robot, B, monkeypatch):
+    """Round 6, last session: a small batch's Solve() ends with k_small_finish (ONE workgroup: the list of the unfinished, the counts, and the
+    launch's counters straight into the chunk's pinned host copy) and one synchronisation; a plain Solve() starts with k_reset_and_queue (the
+    reset of ResetRecursion + ResetSolver, hpp:370-374, and the queue's set-up in one launch).  LOIKB_SMALL_FINISH=0 is the sequence as it
+    was (k_reset, k_queue_init_iota, ..., k_list_unfinished, a copy, two synchronisations): same bits, same statistics -- over Solve(args),
+    Solve() twice (the fused launch), another batch through Solve(args), Solve() again, and a warm-started handle."""
+    from loik_amd import workloads
+    make = workloads.talos_c3 if robot == "talos32" else workloads.talos_wholebody
+    wa, wb = make(B, seed=91), make(B, seed=92)
+    prm = dict(wa["params"], max_iter=250)
+    args = lambda w: (w["q"], w["H_ref"], w["v_ref"], w["c_ids"], w["Ais"], w["bis"], w["lb"], w["ub"])
+    keys = ("iter", "converged", "primal_infeasible", "z", "nu", "mu", "yis", "fis", "vis", "w")
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LOIKB_SMALL_FINISH", mode)
+        got = []
+        for warm in (False, True):
+            s = loik_amd.BatchedLoik(wa["model"], B, **dict(prm, warm_start=warm))
+            for step in ("full_a", "plain", "plain", "full_b", "plain"):
+                if step == "plain":
+                    s.Solve()
+                else:
+                    s.Solve(*args(wa if step == "full_a" else wb))
+                st = s.stats()
+                assert st["flat_launches"] == 1 and st["launches"] == 1 and st["tail_instances"] == B, (mode, step, st)
+                r = {k: np.asarray(s.get(k)) for k in keys}
+                conv, pinf = r["converged"].astype(bool), r["primal_infeasible"].astype(bool)
+                assert st["n_unfinished"] == int((~conv & ~pinf).sum()), (mode, step, st["n_unfinished"])
+                assert st["instance_iterations"] == int(r["iter"].sum()), (mode, step)
+                assert st["total_ms"] >= st["kernel_ms"] > 0.0, (mode, step, st)
+                got.append(r)
+            s.close()
+        runs[mode] = got
+    for a, b in zip(runs["0"], runs["1"]):
+        for k in keys:
+            assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("robot,ns_max", [("talos32", 6.0), ("talos44", 8.0)])
 @pytest.mark.parametrize("sliced", [False, True])
 def test_flat_kernels_iteration_rate_has_not_tipped_over(robot, ns_max, sliced, monkeypatch):
