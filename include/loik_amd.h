@@ -331,7 +331,8 @@ typedef struct loikb_stats {
                                              slots of H precomputed); the rest ran the one-wavefront-per-SIMD kernel   */
   int lean_escaped;                       /* instances whose mu left the precomputed decades in a lean launch and were
                                              finished by the other tail kernel                                         */
-  double hslots_ms;                       /* HIP-event time of the decade-slot precomputation (part of tail_ms)        */
+  double hslots_ms;                       /* HIP-event time of the decade-slot precomputation (part of tail_ms); 0 in
+                                             the short sequence of a small batch unless LOIKB_SMALL_SLOT_EVENT=1       */
   int lean_requeues;                      /* time slices that ended with the instance going to the back of the lean kernel's
                                              work queue (round-robin among the instances waiting for a slot)                */
   int flat_launches;                      /* of lean_launches: those that ran the flat engine (k_fslots + k_flat: no loops over the
