@@ -1,4 +1,5 @@
 """shared test helpers: the reference's comparison predicates, its fixture problem, random kinematic trees"""
+import os
 import numpy as np
 
 import loik_amd
@@ -235,7 +236,7 @@ def multi_task_batch(model, batch, links, seed, bound=0.5, nu_scale=0.4, per_ins
 TALLY = dict(compared=0, off_count=0, flags_exempted=0)
 
 
-def assert_end_to_end(got, out, prm, same_frac=0.97, ztol=1e-9, off_ztol=1e-6, off_iter=None, what="", res_tol=(1e-9, 1e-6),
+def assert_end_to_end(got, out, prm, same_frac=0.99, ztol=1e-9, off_ztol=1e-6, off_iter=None, what="", res_tol=(1e-9, 1e-6),
                       inf_ztol=None, off_scale=None):
     """End-to-end comparison of a batch with the oracle's `solve_batch` output -- every instance is checked, none dropped.
 
@@ -253,6 +254,12 @@ def assert_end_to_end(got, out, prm, same_frac=0.97, ztol=1e-9, off_ztol=1e-6, o
     it = np.asarray(got["iter"]); it_o = np.asarray(out["iters"])
     conv = np.asarray(got["converged"]).astype(bool); inf = np.asarray(got["primal_infeasible"]).astype(bool)
     same = it == it_o
+    if os.environ.get("LOIKB_TEST_MARGINS"):   # (a record of how much of each call's tolerance is used: scripts/r06/test_margins.sh)
+        dz_ = np.abs(np.asarray(got["z"]) - out["z"]).reshape(it.size, -1).max(axis=1)
+        with open(os.environ["LOIKB_TEST_MARGINS"], "a") as f:
+            f.write("%-60s n %6d  same %.4f (asked %.2f)  max|dz| same %.2e (ztol %.0e)  off %d max|dz| off %.2e (off_ztol %.0e)\n" % (
+                what, it.size, same.mean(), same_frac, dz_[same].max() if same.any() else 0.0, ztol, int((~same).sum()),
+                dz_[~same].max() if (~same).any() else 0.0, off_ztol))
     assert same.mean() >= same_frac, (what, "iteration counts differ", it[~same][:20], it_o[~same][:20])
     assert np.array_equal(conv[same], out["converged"][same]), what
     assert np.array_equal(inf[same], out["primal_infeasible"][same]), what

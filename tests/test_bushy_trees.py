@@ -114,7 +114,7 @@ def test_bushy_tree_is_solved_not_refused(case, nc):
     s = loik_amd.BatchedLoik(model, B, **prm)
     s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
     _check_engine(s, s.stats(), c["engine"], B)
-    assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.95, ztol=1e-8, what=case)
+    assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.99, ztol=2e-10, what=case)
     s.close()
 
 
@@ -132,5 +132,5 @@ def test_bushy_tree_with_options_that_ask_for_k_solve_takes_the_engine_of_last_r
         s = loik_amd.BatchedLoik(model, B, **prm, **kw)
         s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
         assert "k_pass_solve" in s.plan(), s.plan()
-        assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.95, ztol=1e-8, what=str(kw))
+        assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.99, ztol=2e-10, what=str(kw))
         s.close()

@@ -263,8 +263,11 @@ def test_osqp_mu_rule_matches_oracle(talos, engine, monkeypatch):
                           nthreads=4, want_nu=True, **prm)
     # (the flat engine sums at the world origin and builds its factors for the instance's own mu: 2e-9 on z where the engines that walk
     #  the tree in the oracle's order stay below 1e-9 -- mu reaches 1e4 under this rule)
-    assert_end_to_end(fetch_end_to_end(s, residuals=True), out, prm, same_frac=0.95, what="OSQP mu rule, " + engine,
-                      **(dict(ztol=1e-8, res_tol=(1e-8, 1e-6)) if engine.startswith("flat") else {}))
+    # (same_frac 0.95 -> 0.99, ztol 1e-8 -> 5e-9 on the flat engines.  Measured on this batch: every instance at the oracle's
+    #  count, max |dz| 2.04e-9; over five seeds x 700 / 4000 instances same-iteration >= 0.9998, |dz| <= 3.4e-8 at mu up to 1e4:
+    #  scripts/r06/osqp_flat_margin.py, profiles/r06_q_osqp_flat_margin.txt)
+    assert_end_to_end(fetch_end_to_end(s, residuals=True), out, prm, same_frac=0.99, what="OSQP mu rule, " + engine,
+                      **(dict(ztol=5e-9, res_tol=(1e-8, 1e-6)) if engine.startswith("flat") else {}))
     mu = s.get("mu")
     assert np.unique(np.round(np.log10(mu), 9)).size > 12  # off the decade grid: a continuum of penalties
     # k iterations exactly, full state incl. mu
@@ -315,7 +318,7 @@ def test_maxeigenvalue_mu_rule_matches_oracle(talos, engine, monkeypatch):
         assert st["tail_instances"] == 0
     out = ref.solve_batch(talos, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"],
                           nthreads=8, want_nu=True, **prm)
-    assert_end_to_end(fetch_end_to_end(s, residuals=True), out, prm, same_frac=0.97, what="MAXEIGENVALUE mu rule, " + engine)
+    assert_end_to_end(fetch_end_to_end(s, residuals=True), out, prm, same_frac=0.99, what="MAXEIGENVALUE mu rule, " + engine)
     # mu stays on the decade grid of the spectral start
     ev = np.linalg.eigvalsh(0.5 * (Href + Href.T) + prm["rho"] * np.eye(6))
     mu0 = 10.0 ** (np.round(4.0 * np.log10(np.sqrt(max(ev.min(), prm["rho"]) * ev.max()))) / 4.0)
@@ -935,7 +938,7 @@ def test_whole_body_talos44_full_size_against_the_oracle():
     # (z to 1e-7: the instances that run all 999 iterations WITHOUT converging -- four tasks' duals integrating mu_eq * rounding
     #  for 999 iterations -- reach 1.8e-8 with the subtree sums taken as differences of a prefix sum along the 44 joints
     #  (k_flat1; 1.6e-9 with k_flat's window sums); the instances that converge agree to 1e-10)
-    same = assert_end_to_end(fetch_end_to_end(s, idx, nu=False, residuals=True), out, prm, same_frac=0.97, ztol=1e-7,
+    same = assert_end_to_end(fetch_end_to_end(s, idx, nu=False, residuals=True), out, prm, same_frac=0.99, ztol=1e-7,
                              res_tol=(1e-7, 1e-6), what="whole body 44 DoF, %d instances (%d of them at max_iter)" % (idx.size, min(hard.size, 400)))
     print("whole body: identical iteration counts %d / %d; at max_iter %d of %d" % (same.sum(), idx.size, hard.size, B))
     cs = same & out["converged"]

@@ -212,7 +212,7 @@ def test_gpu_random_trees_with_multidof_joints(case):
                           wl["ub"], nthreads=4, want_nu=True, **prm)
     for kw in (dict(), dict(tail_max_instances=-1)):
         s = _gpu(model, wl, prm, **kw)
-        assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.95, ztol=1e-7, what="multidof seed %d" % case["seed"])
+        assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.99, ztol=1e-8, what="multidof seed %d" % case["seed"])
         s.close()
 
 
@@ -229,7 +229,7 @@ def test_gpu_floating_base_talos():
     out = ref.solve_batch(model, wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"],
                           wl["ub"], nthreads=4, **prm)
     s = _gpu(model, wl, prm)
-    assert_end_to_end(fetch_end_to_end(s, nu=False), out, prm, same_frac=0.95, ztol=1e-7, what="floating-base talos")
+    assert_end_to_end(fetch_end_to_end(s, nu=False), out, prm, same_frac=0.99, ztol=1e-8, what="floating-base talos")
     # the answer moves the wrist as asked: first principles, independent of both solvers
     ok = s.get("converged").astype(bool)
     assert ok.mean() > 0.5
@@ -350,7 +350,7 @@ def test_gpu_zyx_planar_unbounded_joints(case):
                           wl["ub"], nthreads=4, want_nu=True, **prm)
     for kw in (dict(), dict(tail_max_instances=-1)):
         s = _gpu(model, wl, prm, **kw)
-        assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.95, ztol=1e-7, what="new joints seed %d" % case["seed"])
+        assert_end_to_end(fetch_end_to_end(s), out, prm, same_frac=0.99, ztol=1e-8, what="new joints seed %d" % case["seed"])
         # liMi of the caller's joints (a ZYX joint's is the product over its chain)
         r = ref.RefSolver(model, **prm)
         r.Solve(*[wl[k][0] if k in ("q", "bis") else wl[k] for k in ("q", "H_ref", "v_ref", "c_ids", "Ais", "bis", "lb", "ub")])
