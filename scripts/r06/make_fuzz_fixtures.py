@@ -16,7 +16,12 @@ CASES = [dict(name="r05_j_fuzz_1500_case1212", ncase=1213, seed=4242, flat_bias=
          # (second session: the 10 000-case fuzz of the final sources, profiles/r06_k_fuzz_10000.txt)
          dict(name="r06_k_fuzz_10000_case6985", ncase=6986, seed=60606, flat_bias=0.7, only=6985),
          dict(name="r06_k_fuzz_10000_case7785", ncase=7786, seed=60606, flat_bias=0.7, only=7785),
-         dict(name="r06_m_fuzz_6000_case4656", ncase=4657, seed=31337, flat_bias=0.7, only=4656)]   # (profiles/r06_m_fuzz_6000.txt)
+         dict(name="r06_m_fuzz_6000_case4656", ncase=4657, seed=31337, flat_bias=0.7, only=4656),   # (profiles/r06_m_fuzz_6000.txt)
+         # (last session: the 12 000-case fuzz of the final sources, profiles/r06_q_fuzz_12000.txt)
+         dict(name="r06_q_fuzz_12000_case4160", ncase=4161, seed=424242, flat_bias=0.7, only=4160),
+         dict(name="r06_q_fuzz_12000_case6317", ncase=6318, seed=424242, flat_bias=0.7, only=6317),
+         dict(name="r06_q_fuzz_12000_case7166", ncase=7167, seed=424242, flat_bias=0.7, only=7166),
+         dict(name="r06_q_fuzz_12000_case10176", ncase=10177, seed=424242, flat_bias=0.7, only=10176)]
 if len(sys.argv) > 1:   # (only the named cases)
     CASES = [c for c in CASES if c["name"] in sys.argv[1:]]
 for c in CASES:

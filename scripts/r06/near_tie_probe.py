@@ -33,9 +33,10 @@ else:
 print("plan:", s.plan()[:160])
 si = s.solver_info(); g_mu = si["mu_list"][0]; g_p = si["primal_residual_list"][0]; g_d = si["dual_residual_list"][0]
 o_mu = np.asarray(r.solver_info(6)); o_p = np.asarray(r.solver_info(2)); o_d = np.asarray(r.solver_info(5))
-n = min(len(o_mu), int(np.count_nonzero(g_mu)))
-print("iterations: oracle %d, here %d;  final |dz| %.3e" % (len(o_mu), int(np.count_nonzero(g_mu)), np.abs(np.asarray(s.get("z"))[0] - r.z).max()))
-first = next((k for k in range(n) if g_mu[k] != o_mu[k]), None)
+logged = np.flatnonzero(np.asarray(g_mu) != 0)   # (a hand-over's first iterations run in k_solve, which keeps no lists: zeros)
+n = min(len(o_mu), int(logged[-1]) + 1 if logged.size else 0)
+print("iterations: oracle %d, here %d (%d of them logged);  final |dz| %.3e" % (len(o_mu), int(np.asarray(s.get("iter"))[0]), logged.size, np.abs(np.asarray(s.get("z"))[0] - r.z).max()))
+first = next((k for k in range(n) if g_mu[k] != 0 and g_mu[k] != o_mu[k]), None)
 print("first iteration whose mu differs:", first)
 lo = max(0, (first if first is not None else n) - 3)
 for k in range(lo, min(n, lo + 8)):

@@ -59,7 +59,8 @@ def load_case(name):
 
 
 @pytest.mark.parametrize("name", ["r05_j_fuzz_1500_case1212", "r05_j_fuzz_3000_case1126", "r06_e_fuzz_3000_case522",
-                                  "r06_k_fuzz_10000_case6985", "r06_k_fuzz_10000_case7785", "r06_m_fuzz_6000_case4656"])
+                                  "r06_k_fuzz_10000_case6985", "r06_k_fuzz_10000_case7785", "r06_m_fuzz_6000_case4656",
+                                  "r06_q_fuzz_12000_case4160", "r06_q_fuzz_12000_case6317", "r06_q_fuzz_12000_case7166", "r06_q_fuzz_12000_case10176"])
 def test_fixture_holds_the_oracles_answers(name):
     """(CPU) the frozen answers are the oracle's on the frozen inputs: the fixture is data of the checker, not of the engine"""
     fx, model, prm, env, kw, refs, args = load_case(name)
@@ -188,3 +189,76 @@ def test_fuzz_r06_case4656_osqp_rule_35_joint_tree(monkeypatch):
     assert np.abs(got["iter"] - fx["ref_iters"]).max() <= 25
     assert dz[~same].max() <= 1.4e-5, dz[~same].max()
     assert dz[same].max() <= 1e-9, dz[same].max()
+
+
+# ---- the 12 000-case fuzz of the round's final sources (profiles/r06_q_fuzz_12000.txt: 9.64 M instances, REFUSED 0, four mismatches, all of
+# the two known classes -- a near-tie of UpdateMu's compare under the DEFAULT rule (same count, a different last stretch), a near-tie of
+# OSQP's rule (different counts) -- and none on the launches the last session changed) ------------------------------------------------------
+
+def _same_count_one_instance_apart(monkeypatch, name, instance, bound, others):
+    fx, model, prm, env, kw, refs, args = load_case(name)
+    got, st = solve_on_gpu(monkeypatch, fx, model, prm, env, kw, refs, args)
+    dz = np.abs(got["z"] - fx["ref_z"]).max(axis=1)
+    assert np.array_equal(got["iter"], fx["ref_iters"])
+    assert np.array_equal(got["converged"], fx["ref_converged"]) and np.array_equal(got["primal_infeasible"], fx["ref_primal_infeasible"])
+    assert np.abs(dz - fx["gpu_dz_full_batch"]).max() <= 1e-12   # (the subset reproduces what the full batch gave)
+    worst = int(np.argmax(dz))
+    assert int(fx["pick"][worst]) == instance   # (the one instance of the fuzz run)
+    assert dz[worst] <= bound, dz[worst]
+    assert np.delete(dz, worst).max() <= others, np.delete(dz, worst).max()
+    return st
+
+
+@pytest.mark.gpu
+def test_fuzz_r06_case4160_39_joint_tree_same_count_near_tie(monkeypatch):
+    """one converged instance (115 iterations in both solvers) 1.59e-7 from the oracle's z at tol 1e-6; the other 127 within 5e-12"""
+    _same_count_one_instance_apart(monkeypatch, "r06_q_fuzz_12000_case4160", 59, 1.6e-7, 5e-11)
+
+
+@pytest.mark.gpu
+def test_fuzz_r06_case6317_helical_tree_handover_same_count_near_tie(monkeypatch):
+    """k_solve for three iterations, then the on-chip engine: one converged instance (59 of max_iter = 60 iterations in both solvers) 2.21e-7
+    from the oracle's z at tol 1e-6; the others within 2.5e-11"""
+    st = _same_count_one_instance_apart(monkeypatch, "r06_q_fuzz_12000_case6317", 885, 2.25e-7, 2.5e-10)
+    assert st["launches"] >= 2, st   # (the hand-over)
+
+
+@pytest.mark.gpu
+def test_fuzz_r06_case7166_osqp_rule_infeasible_instance_tail_solve(monkeypatch):
+    """OSQP's rule, multi-DoF tree (43 joints, nv = 52), tol 1e-4: ONE instance, flagged primal infeasible by both solvers, leaves its tail solve
+    after 333 iterations here and 361 in the oracle -- what such an instance returns is the iterate the tail solve stopped at, not a solution
+    (1.4e-2 apart at mu = 47); a second flagged instance, same count, 6.0e-6 apart; the converged ones within 1.4e-7"""
+    fx, model, prm, env, kw, refs, args = load_case("r06_q_fuzz_12000_case7166")
+    got, st = solve_on_gpu(monkeypatch, fx, model, prm, env, kw, refs, args)
+    assert st["flat_launches"] == 0, st   # (multi-DoF joints: k_solve / k_tail under OSQP's rule)
+    dz = np.abs(got["z"] - fx["ref_z"]).max(axis=1)
+    same = got["iter"] == fx["ref_iters"]
+    assert np.array_equal(got["iter"], fx["gpu_iters_full_batch"]), "an instance's result depends on the batch it is solved in"
+    assert np.abs(dz - fx["gpu_dz_full_batch"]).max() <= 1e-12
+    # every flag agrees, also on the off-count instance
+    assert np.array_equal(got["converged"], fx["ref_converged"]) and np.array_equal(got["primal_infeasible"], fx["ref_primal_infeasible"])
+    off = np.flatnonzero(~same)
+    assert off.size <= 1 and (off.size == 0 or (int(fx["pick"][off[0]]) == 606 and fx["ref_primal_infeasible"][off[0]] and not fx["ref_converged"][off[0]]))
+    assert dz[~same].max() <= 1.4e-2 if off.size else True
+    conv = fx["ref_converged"].astype(bool)
+    assert dz[same & conv].max() <= 1.4e-7, dz[same & conv].max()
+    assert dz[same & ~conv].max() <= 6.1e-6, dz[same & ~conv].max()   # (flagged or stopped by max_iter: iterates, not solutions)
+
+
+@pytest.mark.gpu
+def test_fuzz_r06_case10176_osqp_rule_multidof_tree(monkeypatch):
+    """OSQP's rule, multi-DoF tree (20 joints, nv = 24), tol 1e-6: three converged instances off the oracle's count (266 / 293, 88 / 82, 48 / 49
+    iterations), the furthest 1.07e-5 from its z; the others within 6.6e-8"""
+    fx, model, prm, env, kw, refs, args = load_case("r06_q_fuzz_12000_case10176")
+    got, st = solve_on_gpu(monkeypatch, fx, model, prm, env, kw, refs, args)
+    assert st["flat_launches"] == 0, st
+    dz = np.abs(got["z"] - fx["ref_z"]).max(axis=1)
+    same = got["iter"] == fx["ref_iters"]
+    assert np.array_equal(got["iter"], fx["gpu_iters_full_batch"]), "an instance's result depends on the batch it is solved in"
+    assert np.abs(dz - fx["gpu_dz_full_batch"]).max() <= 1e-12
+    assert np.array_equal(got["converged"][same], fx["ref_converged"][same]) and np.array_equal(got["primal_infeasible"][same], fx["ref_primal_infeasible"][same])
+    assert got["converged"][~same].all() and fx["ref_converged"][~same].all()
+    assert int((~same).sum()) <= 3, int((~same).sum())
+    assert np.abs(got["iter"] - fx["ref_iters"]).max() <= 27
+    assert dz[~same].max() <= 1.08e-5, dz[~same].max()
+    assert dz[same].max() <= 6.7e-8, dz[same].max()
