@@ -502,12 +502,13 @@ private:
   }
   void fetch(unsigned mask)
   {
-    if (mask & FETCH_Z) check(loikb_get(h_, LOIKB_F_Z, ik_id_data_.z.data(), 0));
-    if (mask & FETCH_NU) check(loikb_get(h_, LOIKB_F_NU, ik_id_data_.nu.data(), 0));
-    if (mask & FETCH_W) check(loikb_get(h_, LOIKB_F_W, ik_id_data_.w.data(), 0));
-    if (mask & FETCH_VIS) check(loikb_get(h_, LOIKB_F_VIS, ik_id_data_.vis.data(), 0));
-    if (mask & FETCH_FIS) check(loikb_get(h_, LOIKB_F_FIS, ik_id_data_.fis.data(), 0));
-    if ((mask & FETCH_YIS) && nc_ > 0) check(loikb_get(h_, LOIKB_F_YIS, ik_id_data_.yis.data(), 0));
+    // (one call for all of them -- loikb_get_results: one gather launch and one synchronisation for a small batch; the FETCH_* bits are LOIKB_RES_*)
+    static_assert(FETCH_Z == LOIKB_RES_Z && FETCH_NU == LOIKB_RES_NU && FETCH_W == LOIKB_RES_W && FETCH_VIS == LOIKB_RES_VIS &&
+                  FETCH_FIS == LOIKB_RES_FIS && FETCH_YIS == LOIKB_RES_YIS, "fetch mask out of step with loikb_get_results");
+    if (nc_ <= 0) mask &= ~static_cast<unsigned>(FETCH_YIS);
+    if (mask & FETCH_ALL)
+      check(loikb_get_results(h_, mask & FETCH_ALL, ik_id_data_.z.data(), ik_id_data_.nu.data(), ik_id_data_.w.data(), ik_id_data_.vis.data(),
+                              ik_id_data_.fis.data(), ik_id_data_.yis.data()));
   }
   // one download per field and solve, then O(1) per getter call
   template <typename V>

@@ -53,7 +53,7 @@ class Stats(C.Structure):
                 ("flat_probe_launches", C.c_int), ("probe_ms", C.c_double)]
 
 
-ABI_VERSION = 600   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
+ABI_VERSION = 601   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
 
 # enums of loik_amd.h
 F64, F32 = 0, 1
@@ -81,7 +81,7 @@ FIELD_ID.update({n: 32 + i for i, n in enumerate(_SCALAR_FIELDS)})
 EXPORTED_SYMBOLS = [
     "loikb_create", "loikb_destroy", "loikb_set_stream", "loikb_solve_init", "loikb_solve", "loikb_solve_full",
     "loikb_solve_tailored", "loikb_set_max_iter", "loikb_set_rho", "loikb_set_mu", "loikb_set_tol",
-    "loikb_set_tol_primal_inf", "loikb_set_tol_tail_solve", "loikb_set_warm_start", "loikb_get", "loikb_get_stats",
+    "loikb_set_tol_primal_inf", "loikb_set_tol_tail_solve", "loikb_set_warm_start", "loikb_get", "loikb_get_results", "loikb_get_stats",
     "loikb_batch", "loikb_nv", "loikb_njoints", "loikb_last_error", "loikb_status_string", "loikb_version",
     "loikb_device_count", "loikb_sweep_schedule", "loikb_integrate", "loikb_synchronize", "loikb_plan_string", "loikb_pass",
     "loikb_update_references", "loikb_update_eq_constraint", "loikb_add_eq_constraint", "loikb_remove_eq_constraint",
@@ -132,6 +132,7 @@ def lib():
     L.loikb_set_tol.argtypes = [C.c_void_p, C.c_double, C.c_double]
     L.loikb_set_warm_start.argtypes = [C.c_void_p, C.c_int]
     L.loikb_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.loikb_get_results.argtypes = [C.c_void_p, C.c_uint, _dp, _dp, _dp, _dp, _dp, _dp]
     L.loikb_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     for n in ["loikb_batch", "loikb_nv", "loikb_njoints"]:
         getattr(L, n).argtypes = [C.c_void_p]
@@ -607,6 +608,27 @@ class BatchedLoik:
         arr = np.empty(shapes.get(name, (B,)), dtype=np.int32 if is_int else np.float64)
         _check(self.L.loikb_get(self.h, fid, arr.ctypes.data_as(C.c_void_p), 0))
         return arr
+
+    RESULT_FIELDS = ("z", "nu", "w", "vis", "fis", "yis")   # (bit k of loikb_get_results' mask: LOIKB_RES_*)
+
+    def get_results(self, fields=RESULT_FIELDS):
+        """the members of the reference's data object a solve leaves behind (z, nu, w, vis, fis, yis: loik-loid-data-optimized.hpp:118-178), any
+        subset, in ONE call (loikb_get_results): {name: array}, the same values as get(name)"""
+        B, nb, nv, nc = self.batch, self.model.njoints - 1, self.model.nv, self.L.loikb_num_eq_c(self.h)
+        shapes = {"z": (B, nv), "nu": (B, nv), "w": (B, nv), "vis": (B, nb, 6), "fis": (B, nb, 6), "yis": (B, nc, 6)}
+        mask, out, ptrs = 0, {}, []
+        for k, name in enumerate(self.RESULT_FIELDS):
+            if name in fields:
+                mask |= 1 << k
+                out[name] = np.empty(shapes[name], dtype=np.float64)
+                ptrs.append(out[name].ctypes.data_as(_dp))
+            else:
+                ptrs.append(None)
+        unknown = [f for f in fields if f not in self.RESULT_FIELDS]
+        if unknown:
+            raise ValueError("get_results: not a result member: %s" % unknown)
+        _check(self.L.loikb_get_results(self.h, mask, *ptrs))
+        return out
 
     def His_full(self):
         """ik_id_data.His[i] as full symmetric 6x6 blocks: [B][nb][6][6]"""

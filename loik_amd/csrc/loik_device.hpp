@@ -1709,6 +1709,18 @@ __global__ void k_download_rows(char* tiles, Layout L, const int* __restrict__ r
   }
 }
 
+// the same, one ELEMENT per thread: what a small batch wants (one problem per call -- the reference's own use -- is one instance
+// and ~400 rows: a thread per instance walks them one dependent load after the other)
+template <typename T>
+__global__ void k_download_elems(char* tiles, Layout L, const int* __restrict__ rowmap, int n, int B, double* __restrict__ dst)
+{
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * n) return;
+  const int b = (int)(i / n), r = (int)(i - (long long)b * n);
+  const int m = rowmap[r];
+  dst[i] = (double)*elem_ptr<T>(lane_ptr<T>(tiles, L, b), m >> 1, m & 1);
+}
+
 // ---- getters for quantities the hot path no longer materialises -----------------------------------------------
 // ik_id_data.His[i] (accumulated, pre-projection: what upstream leaves in His after BwdPass, hxx:60-67) for the mu of
 // the last executed iteration.  One instance per thread, out = [B][nb][21]; the output rows double as the running

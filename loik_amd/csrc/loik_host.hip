@@ -249,6 +249,13 @@ struct loikb_solver_impl {
   void* d_uni = nullptr;               // A[nc][36], AtA[nc][21], lb[nb], ub[nb] (T)
   void* d_stage = nullptr;             // staging for host<->device copies
   void* d_getscr[2] = {nullptr, nullptr};  // scratch of the getters that rebuild members (His / pis / UDinv): kept, not malloc'ed per call
+  // loikb_get_results: the row map of the requested members on the device (rebuilt when the request or the constraint set changes) and a
+  // pinned, device-visible host buffer the gather kernel writes into
+  int* d_resmap = nullptr;
+  int resmap_key[6] = {-1, -1, -1, -1, -1, -1};   // mask, nc_active, nb, nl, off_c, crec
+  int res_n = 0, res_off[7] = {0, 0, 0, 0, 0, 0, 0};
+  double* h_res = nullptr;
+  size_t h_res_bytes = 0;
   size_t getscr_bytes[2] = {0, 0};
   size_t stage_bytes = 0;
   // tile layouts: A per instance needs the long constraint record
@@ -2962,6 +2969,8 @@ int loikb_destroy(loikb_solver* S)
   for (void* a : S->allocs) if (a) (void)hipFree(a);
   if (S->d_stage) (void)hipFree(S->d_stage);
   for (int k = 0; k < 2; ++k) if (S->d_getscr[k]) (void)hipFree(S->d_getscr[k]);
+  if (S->d_resmap) (void)hipFree(S->d_resmap);
+  if (S->h_res) (void)hipHostFree(S->h_res);
   if (S->d_pass) (void)hipFree(S->d_pass);
   if (S->d_pass_cslot) (void)hipFree(S->d_pass_cslot);
   if (S->d_log) (void)hipFree(S->d_log);
@@ -3575,6 +3584,102 @@ int loikb_get_stats(loikb_solver* S, loikb_stats* out)
   return LOIKB_OK;
 }
 
+// rows of the members a solve leaves for the caller (the same maps as loikb_get's: ONE definition)
+static bool result_rows(const loikb_solver_impl* S, int field, std::vector<int>& rm)
+{
+  const Layout& L = S->L;
+  const int nb = S->nb, nl = S->ext_nj - 1;
+  auto per_joint = [&](int pair, int half) { for (int j = 0; j < nb; ++j) rm.push_back((j * JREC + pair) * 2 + half); };
+  auto per_joint_vec = [&](int pair, int n) {  // body i of the caller's model lives in device joint link_of[i]
+    for (int i = 1; i <= nl; ++i)
+      for (int k = 0; k < n; ++k) rm.push_back(((S->link_of[i] - 1) * JREC + pair + k / 2) * 2 + (k & 1));
+  };
+  switch (field) {
+  case LOIKB_F_Z: per_joint(JP_WZ, 1); return true;
+  case LOIKB_F_NU: per_joint(JP_NUS, 0); return true;
+  case LOIKB_F_W: per_joint(JP_WZ, 0); return true;
+  case LOIKB_F_VIS: per_joint_vec(JP_V, 6); return true;
+  case LOIKB_F_FIS: per_joint_vec(JP_F, 6); return true;
+  case LOIKB_F_YIS:
+    for (int c = 0; c < S->nc_active; ++c)  // (the active constraints are the first slots; the null ones behind them hold zeros)
+      for (int k = 0; k < 6; ++k) rm.push_back((L.off_c + c * L.crec + CP_Y + k / 2) * 2 + (k & 1));
+    return true;
+  default: return false;
+  }
+}
+
+// z, nu, w, vis, fis, yis of the whole batch in ONE call: one gather launch into pinned host memory and one synchronisation for a batch whose
+// results fit LOIKB_RESULTS_FUSED_BYTES (default 4 MiB); larger batches, and a handle in the middle of pass-level calls, go field by field
+// through loikb_get (whose copies are DMA transfers of their own).
+int loikb_get_results(loikb_solver* S, unsigned int mask, double* z, double* nu, double* w, double* vis, double* fis, double* yis)
+{
+  if (!S) return LOIKB_ERR_ARG;
+  static const int fields[6] = {LOIKB_F_Z, LOIKB_F_NU, LOIKB_F_W, LOIKB_F_VIS, LOIKB_F_FIS, LOIKB_F_YIS};
+  double* outs[6] = {z, nu, w, vis, fis, yis};
+  if (mask & ~63u) { g_last_error = "loikb_get_results: unknown bits in the mask"; return LOIKB_ERR_ARG; }
+  for (int f = 0; f < 6; ++f)
+    if ((mask & (1u << f)) && !outs[f]) { g_last_error = "loikb_get_results: a requested member has no destination"; return LOIKB_ERR_ARG; }
+  if (!mask) return LOIKB_OK;
+  HIPCHK(hipSetDevice(S->device));
+  static const size_t fused_max = [] { const char* e = getenv("LOIKB_RESULTS_FUSED_BYTES"); return e ? (size_t)atoll(e) : (size_t)4 << 20; }();
+  const int key[6] = {(int)mask, S->nc_active, S->nb, S->ext_nj - 1, S->L.off_c, S->L.crec};
+  int rc;
+  if (memcmp(key, S->resmap_key, sizeof(key)) != 0) {
+    std::vector<int> rm;
+    int off = 0;
+    for (int f = 0; f < 6; ++f) {
+      S->res_off[f] = off;
+      if (mask & (1u << f)) result_rows(S, fields[f], rm);
+      off = (int)rm.size();
+    }
+    S->res_off[6] = off;
+    S->res_n = off;
+    if (S->d_resmap) { HIPCHK(hipStreamSynchronize(S->stream)); HIPCHK(hipFree(S->d_resmap)); S->d_resmap = nullptr; }
+    HIPCHK(hipMalloc((void**)&S->d_resmap, sizeof(int) * (size_t)std::max(off, 1)));
+    HIPCHK(hipMemcpy(S->d_resmap, rm.data(), sizeof(int) * (size_t)off, hipMemcpyHostToDevice));   // (synchronous: rm is a local)
+    memcpy(S->resmap_key, key, sizeof(key));
+  }
+  const int n = S->res_n;
+  const size_t bytes = sizeof(double) * (size_t)S->B * (size_t)n;
+  if (S->pass_active || bytes > fused_max || n == 0) {
+    for (int f = 0; f < 6; ++f) {
+      if (!(mask & (1u << f))) continue;
+      if (fields[f] == LOIKB_F_YIS && S->nc_active == 0) continue;
+      if ((rc = loikb_get(S, fields[f], outs[f], 0))) return rc;
+    }
+    return LOIKB_OK;
+  }
+  if (bytes > S->h_res_bytes) {
+    if (S->h_res) { HIPCHK(hipStreamSynchronize(S->stream)); HIPCHK(hipHostFree(S->h_res)); S->h_res = nullptr; S->h_res_bytes = 0; }
+    HIPCHK(hipHostMalloc((void**)&S->h_res, bytes));
+    S->h_res_bytes = bytes;
+  }
+  // one element per thread (a thread per instance walks its ~400 rows one dependent load after the other: 0.25 ms whatever the batch);
+  // a handful of instances straight into the pinned buffer, more through the staging buffer and ONE copy
+  const bool direct = bytes <= ((size_t)256 << 10);
+  double* dst = S->h_res;
+  if (!direct) {
+    if ((rc = ensure_stage(S, bytes))) return rc;
+    dst = (double*)S->d_stage;
+  }
+  {
+    const long long total = (long long)S->B * n;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (S->f32) hipLaunchKernelGGL(k_download_elems<float>, grid, dim3(256), 0, S->stream, S->home.tiles, S->L, (const int*)S->d_resmap, n, S->B, dst);
+    else hipLaunchKernelGGL(k_download_elems<double>, grid, dim3(256), 0, S->stream, S->home.tiles, S->L, (const int*)S->d_resmap, n, S->B, dst);
+    HIPCHK(hipGetLastError());
+  }
+  if (!direct) HIPCHK(hipMemcpyAsync(S->h_res, S->d_stage, bytes, hipMemcpyDeviceToHost, S->stream));
+  HIPCHK(hipStreamSynchronize(S->stream));
+  for (int f = 0; f < 6; ++f) {
+    if (!(mask & (1u << f))) continue;
+    const int o = S->res_off[f], nf = S->res_off[f + 1] - o;
+    if (nf == 0) continue;
+    for (int b = 0; b < S->B; ++b) memcpy(outs[f] + (size_t)b * nf, S->h_res + (size_t)b * n + o, sizeof(double) * (size_t)nf);
+  }
+  return LOIKB_OK;
+}
+
 int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
 {
   if (!S || !out) return LOIKB_ERR_ARG;
@@ -3614,14 +3719,10 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
       for (int k = 0; k < 6; ++k) rm.push_back((L.off_c + c * L.crec + pair + k / 2) * 2 + (k & 1));
   };
   switch (field) {
-  case LOIKB_F_Z: per_joint(JP_WZ, 1); break;
-  case LOIKB_F_NU: per_joint(JP_NUS, 0); break;
-  case LOIKB_F_W: per_joint(JP_WZ, 0); break;
+  case LOIKB_F_Z: case LOIKB_F_NU: case LOIKB_F_W: case LOIKB_F_VIS: case LOIKB_F_FIS: case LOIKB_F_YIS: result_rows(S, field, rm); break;
   case LOIKB_F_STF_PLUS_W: per_joint(JP_NUS, 1); break;
   case LOIKB_F_R: per_joint(JP_R, 0); break;
   case LOIKB_F_DINV: per_joint(JP_R, 1); break;
-  case LOIKB_F_VIS: per_joint_vec(JP_V, 6); break;
-  case LOIKB_F_FIS: per_joint_vec(JP_F, 6); break;
   case LOIKB_F_G: per_joint_vec(JP_G, 6); break;
   case LOIKB_F_PIS: break;  // the hot path keeps p_i^base: the accumulated p_i is rebuilt below
   case LOIKB_F_UDINV:  // per DoF (== per joint for 1-DoF joints; one column of the chain's elimination otherwise)
@@ -3630,7 +3731,6 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
     break;
   case LOIKB_F_HIS: break;  // not materialised by the hot path: rebuilt below
 
-  case LOIKB_F_YIS: per_constraint_vec(CP_Y); break;
   case LOIKB_F_ATY: per_constraint_vec(CP_ATY); break;
   case LOIKB_F_LIMI: break;
   case LOIKB_F_PRIMAL_RESIDUAL_VEC: case LOIKB_F_DUAL_RESIDUAL_VEC: break;  // rebuilt below

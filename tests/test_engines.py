@@ -827,3 +827,36 @@ def test_flat_kernels_iteration_rate_has_not_tipped_over(robot, ns_max, sliced, 
         best = min(best, (st["tail_ms"] - st["hslots_ms"]) * 1e6 / st["instance_iterations"])
     s.close()
     assert best < ns_max, "%.2f ns per instance-iteration: has the kernel's loop acquired scratch reloads? (scripts/r05/loopstat.py)" % best
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("robot,B,nc", [("talos32", 1, 1), ("talos32", 300, 1), ("talos44", 5, 4), ("talos32", 4096, 1)])
+def test_results_in_one_call_are_the_getters_values(robot, B, nc):
+    """loikb_get_results (round 6, last session): z, nu, w, vis, fis, yis of the reference's data object (loik-loid-data-optimized.hpp:118-178) in
+    ONE call -- one gather launch into pinned host memory and one synchronisation while the batch's results fit 4 MiB, field by field above
+    (B = 4096: 13 MB) --, any subset, bit for bit what six loikb_get calls return; also after a change of the constraint set (the row map of
+    yis changes)."""
+    from loik_amd import workloads
+    wl = (workloads.talos_c3 if robot == "talos32" else workloads.talos_wholebody)(B, seed=55)
+    prm = dict(wl["params"], max_iter=120)
+    s = loik_amd.BatchedLoik(wl["model"], B, **prm)
+    s.Solve(wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
+    assert len(wl["c_ids"]) == nc
+    names = ("z", "nu", "w", "vis", "fis", "yis")
+    one = {k: s.get(k) for k in names}
+    allr = s.get_results()
+    assert set(allr) == set(names)
+    for k in names:
+        assert allr[k].shape == one[k].shape and np.array_equal(allr[k], one[k]), k
+    sub = s.get_results(("nu", "fis"))
+    assert set(sub) == {"nu", "fis"} and np.array_equal(sub["nu"], one["nu"]) and np.array_equal(sub["fis"], one["fis"])
+    with pytest.raises(ValueError):
+        s.get_results(("z", "His"))
+    if nc > 1:   # one task less: yis has a row less per instance, the cached row map must follow
+        s.RemoveEqConstraint(int(wl["c_ids"][-1]))
+        s.Solve()
+        r = s.get_results()
+        assert r["yis"].shape == (B, nc - 1, 6)
+        for k in names:
+            assert np.array_equal(r[k], s.get(k)), k
+    s.close()
