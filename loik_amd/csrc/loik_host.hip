@@ -244,7 +244,16 @@ struct loikb_solver_impl {
   std::mutex alloc_mu;
   JointDesc* d_jd = nullptr;
   int* d_idx_q = nullptr;
-  int* d_rowmap = nullptr;
+  int* d_rowmap = nullptr;             // the row map the next upload / gather kernel reads: a cached one (rowmap_cache) or the scratch
+  int* d_rowmap_scratch = nullptr;     // [ROWMAP_CAP]: maps beyond the cache
+  struct RowmapEntry { std::vector<int> rm; int* d; };
+  std::vector<RowmapEntry> rowmap_cache;   // a handle uses a dozen distinct row maps (lb, ub, A, b, the getters' members ...), again and again: kept on the
+                                       //   device -- SolveInit of ONE problem spent more in their uploads and synchronisations than in its kernels
+  bool defer_sync = false;             // inside SolveInit / the tailored Solve: the uploads' synchronisations are left to the entry point's own at its end
+  // ... and, inside such a section, small host inputs do not travel by a copy operation at all: they are put into a pinned, device-visible
+  // buffer (h_pin, bump-allocated from pin_off; the section's final synchronisation makes it free again) and the upload kernels read them there
+  char* h_pin = nullptr;
+  size_t pin_cap = 0, pin_off = 0;
   double* d_q = nullptr;               // [B][nq] configurations resident on the device (outer loop)
   void* d_uni = nullptr;               // A[nc][36], AtA[nc][21], lb[nb], ub[nb] (T)
   void* d_stage = nullptr;             // staging for host<->device copies
@@ -976,6 +985,20 @@ int reset_home(loikb_solver_impl* S, int what, bool with_queue = false)
 int to_device(loikb_solver_impl* S, const void* src, size_t bytes, bool src_device, const void** out)
 {
   if (src_device) { *out = src; return LOIKB_OK; }
+  if (S->defer_sync && bytes <= ((size_t)64 << 10)) {
+    // (one problem per call: q, lb, ub, A, b are a few hundred bytes each -- five copy operations cost SolveInit 40 us of its 120)
+    if (S->h_pin == nullptr) {
+      if (hipHostMalloc((void**)&S->h_pin, (size_t)512 << 10) == hipSuccess) S->pin_cap = (size_t)512 << 10;
+      else { S->h_pin = nullptr; (void)hipGetLastError(); }
+    }
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (S->h_pin && S->pin_off + need <= S->pin_cap) {
+      memcpy(S->h_pin + S->pin_off, src, bytes);
+      *out = S->h_pin + S->pin_off;
+      S->pin_off += need;
+      return LOIKB_OK;
+    }
+  }
   int rc = ensure_stage(S, bytes);
   if (rc) return rc;
   HIPCHK(hipMemcpyAsync(S->d_stage, src, bytes, hipMemcpyHostToDevice, S->stream));
@@ -986,6 +1009,20 @@ int to_device(loikb_solver_impl* S, const void* src, size_t bytes, bool src_devi
 int set_rowmap(loikb_solver_impl* S, const std::vector<int>& rm)
 {
   if ((int)rm.size() > ROWMAP_CAP) { g_last_error = "row map too large"; return LOIKB_ERR_ARG; }
+  for (const loikb_solver_impl::RowmapEntry& e : S->rowmap_cache)
+    if (e.rm == rm) { S->d_rowmap = e.d; return LOIKB_OK; }   // (on the device already: no copy, no synchronisation)
+  if (S->d_rowmap_scratch == nullptr) S->d_rowmap_scratch = S->d_rowmap;
+  if (S->rowmap_cache.size() < 64 && !rm.empty()) {
+    void* p = nullptr;
+    int rc = alloc_dev(S, &p, sizeof(int) * rm.size());
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(p, rm.data(), sizeof(int) * rm.size(), hipMemcpyHostToDevice, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));   // (once per distinct map: rm is a local of the caller)
+    S->rowmap_cache.push_back(loikb_solver_impl::RowmapEntry{rm, (int*)p});
+    S->d_rowmap = (int*)p;
+    return LOIKB_OK;
+  }
+  S->d_rowmap = S->d_rowmap_scratch;
   // rm is a local of the caller: the copy must complete before it goes out of scope
   HIPCHK(hipMemcpyAsync(S->d_rowmap, rm.data(), sizeof(int) * rm.size(), hipMemcpyHostToDevice, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
@@ -1007,7 +1044,9 @@ int upload_rows(loikb_solver_impl* S, const double* src, const std::vector<int>&
     hipLaunchKernelGGL(k_upload_rows<double>, grid1(S->B), dim3(256), 0, S->stream, (const double*)dsrc, n, (int)shared,
                        S->d_rowmap, S->L, S->B, S->home.tiles);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(S->stream));  // staging buffer / rowmap are reused
+  // (the staging buffer is reused by the next upload -- in stream order; the caller's array must outlive the copy: the entry point's own
+  //  synchronisation when it defers this one)
+  if (!S->defer_sync) HIPCHK(hipStreamSynchronize(S->stream));
   return LOIKB_OK;
 }
 
@@ -1021,7 +1060,7 @@ int upload_uni(loikb_solver_impl* S, int offset, const double* src, int n)
     HIPCHK(hipStreamSynchronize(S->stream));
   } else {
     HIPCHK(hipMemcpyAsync((double*)S->d_uni + offset, src, sizeof(double) * n, hipMemcpyHostToDevice, S->stream));
-    HIPCHK(hipStreamSynchronize(S->stream));
+    if (!S->defer_sync) HIPCHK(hipStreamSynchronize(S->stream));
   }
   return LOIKB_OK;
 }
@@ -1058,7 +1097,7 @@ int fwd_pass_init(loikb_solver_impl* S, const double* q, int in_flags)
       hipLaunchKernelGGL(k_advance_q<double>, grid1(S->B), dim3(256), 0, S->stream, S->d_q, (const double*)dq, (int)shared,
                          S->nq, S->d_jd, S->d_idx_q, S->L, S->B, S->home.tiles, 0.0);
     HIPCHK(hipGetLastError());
-    if (!dev) HIPCHK(hipStreamSynchronize(S->stream));  // the staging buffer is re-used by the next upload
+    if (!dev && !S->defer_sync) HIPCHK(hipStreamSynchronize(S->stream));  // the staging buffer is re-used by the next upload
     S->have_q = true;
   } else if (!S->have_q) {
     g_last_error = "no configurations resident on the device yet (call SolveInit / Solve with a q first)";
@@ -2970,6 +3009,7 @@ int loikb_destroy(loikb_solver* S)
   if (S->d_stage) (void)hipFree(S->d_stage);
   for (int k = 0; k < 2; ++k) if (S->d_getscr[k]) (void)hipFree(S->d_getscr[k]);
   if (S->d_resmap) (void)hipFree(S->d_resmap);
+  if (S->h_pin) (void)hipHostFree(S->h_pin);
   if (S->h_res) (void)hipHostFree(S->h_res);
   if (S->d_pass) (void)hipFree(S->d_pass);
   if (S->d_pass_cslot) (void)hipFree(S->d_pass_cslot);
@@ -3004,10 +3044,16 @@ int loikb_solve_init(loikb_solver* S, const double* q, const double* H_ref, cons
   S->per_link = false;   // (UpdateReference replaces a per-link table: the plan and the slot buffers are sized for the problem being set)
   if ((rc = ensure_layout(S, in_flags & LOIKB_A_SHARED))) return rc;
   S->pass_active = false;
+  // (the uploads queue up behind each other; the caller's arrays are read by the time this function returns: ONE synchronisation, below)
+  struct Deferred { loikb_solver_impl* S; bool armed; ~Deferred() { S->defer_sync = false; if (armed) (void)hipStreamSynchronize(S->stream); } } deferred{S, true};
+  S->defer_sync = true;
+  S->pin_off = 0;
   // problem_.Reset(); ik_id_data_.Reset(warm_start); ResetSolver()  (hpp:345-352)
   if ((rc = reset_home(S, RS_SOLVER | (S->opt.warm_start ? 0 : RS_DATA_COLD)))) return rc;
   if ((rc = set_problem(S, H_ref, v_ref, c_ids, nc, Ais, bis, lb, ub, nbound, in_flags))) return rc;
   if ((rc = fwd_pass_init(S, q, in_flags))) return rc;
+  S->defer_sync = false;
+  deferred.armed = false;
   HIPCHK(hipStreamSynchronize(S->stream));
   return LOIKB_OK;
 }
@@ -3074,12 +3120,18 @@ int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const doubl
   if (!S->have_problem) { g_last_error = "tailored Solve() before SolveInit()"; return LOIKB_ERR_STATE; }
   HIPCHK(hipSetDevice(S->device));
   int rc;
+  // (as in SolveInit: the uploads queue up; whichever way this function is left, the caller's arrays have been read)
+  struct Deferred { loikb_solver_impl* S; bool armed; ~Deferred() { S->defer_sync = false; if (armed) (void)hipStreamSynchronize(S->stream); } } deferred{S, true};
+  S->defer_sync = true;
+  S->pin_off = 0;
   // ik_id_data_.Reset(warm_start); ResetSolver()  (hpp:604-608)
   if ((rc = reset_home(S, RS_SOLVER | (S->opt.warm_start ? 0 : RS_DATA_COLD)))) return rc;
   // problem_.UpdateEqConstraint(c_id, Ai, bi), ik-id-description-optimized.hpp:178-218.  c_id < 0: no constraint update (not
   // upstream: the way to solve after AddEqConstraint / RemoveEqConstraint changed the set, possibly to the empty one)
   if (c_id >= 0 && (rc = update_eq_single(S, c_id, Ai, bi, in_flags))) return rc;
   if ((rc = fwd_pass_init(S, q, in_flags))) return rc;
+  S->defer_sync = false;
+  deferred.armed = false;   // (the solve below ends with its own synchronisation)
   return S->opt.logging ? run_logged(S, S->opt.warm_start ? 0 : (RS_SOLVER | RS_DATA_COLD | RS_Y | RS_HCACHE)) : run_main_loop(S);
 }
 
