@@ -1503,16 +1503,13 @@ __device__ __forceinline__ T* elem_ptr(char* lp, int pair, int half)
 // a multi-DoF joint spreads that joint's (t, quat) over the JP_CS pairs of the chain (layout: see ROT_FREE).
 // q is instance-major [B][nq] (the caller's layout) or one shared [nq]; idx_q[i] = where joint i's coordinates start.
 template <typename T>
-__global__ void k_fk_init(const double* __restrict__ q, int nq, int q_shared, const JointDesc* __restrict__ jd,
-                          const int* __restrict__ idx_q, Layout L, int B, char* tiles)
+__device__ __forceinline__ void fk_init_joint(const double* __restrict__ qrow, const JointDesc* __restrict__ jd, const int* __restrict__ idx_q,
+                                              char* lp, int i)
 {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  char* lp = lane_ptr<T>(tiles, L, b);
   constexpr size_t RB = (size_t)JREC * pair_bytes<T>();
-  for (int i = 1; i <= L.nb; ++i) {
-    if (jd[i].flags & JF_NOQ) continue;  // its pair belongs to the first joint of the chain
-    const double* qs = q + (q_shared ? 0 : (size_t)b * nq) + idx_q[i];
+  {
+    if (jd[i].flags & JF_NOQ) return;  // its pair belongs to the first joint of the chain
+    const double* qs = qrow + idx_q[i];
     char* rec = lp + (size_t)(i - 1) * RB;
     const int rot = jd[i].rot;
     if (rot == ROT_FREE) {
@@ -1520,26 +1517,26 @@ __global__ void k_fk_init(const double* __restrict__ q, int nq, int q_shared, co
       stp<T>(rec + RB, JP_CS, (T)qs[2], (T)qs[3]);
       stp<T>(rec + 2 * RB, JP_CS, (T)qs[4], (T)qs[5]);
       stp<T>(rec + 3 * RB, JP_CS, (T)qs[6], T(0));
-      continue;
+      return;
     }
     if (rot == ROT_SPH) {
       stp<T>(rec, JP_CS, (T)qs[0], (T)qs[1]);
       stp<T>(rec + RB, JP_CS, (T)qs[2], (T)qs[3]);
-      continue;
+      return;
     }
     if (rot == ROT_TRANS) {
       stp<T>(rec, JP_CS, (T)qs[0], (T)qs[1]);
       stp<T>(rec + RB, JP_CS, (T)qs[2], T(0));
-      continue;
+      return;
     }
     if (rot == ROT_PLANAR) {
       stp<T>(rec, JP_CS, (T)qs[0], (T)qs[1]);
       stp<T>(rec + RB, JP_CS, (T)qs[2], (T)qs[3]);
-      continue;
+      return;
     }
     if (jd[i].flags & JF_CS_DIRECT) {  // JointModelRevoluteUnbounded: q = (cos, sin)
       stp<T>(rec, JP_CS, (T)qs[0], (T)qs[1]);
-      continue;
+      return;
     }
     const double qi = qs[0];
     T c, s;
@@ -1552,6 +1549,30 @@ __global__ void k_fk_init(const double* __restrict__ q, int nq, int q_shared, co
     }
     stp<T>(rec, JP_CS, c, s);
   }
+}
+template <typename T>
+__global__ void k_fk_init(const double* __restrict__ q, int nq, int q_shared, const JointDesc* __restrict__ jd,
+                          const int* __restrict__ idx_q, Layout L, int B, char* tiles)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  char* lp = lane_ptr<T>(tiles, L, b);
+  const double* qrow = q + (q_shared ? 0 : (size_t)b * nq);
+  for (int i = 1; i <= L.nb; ++i) fk_init_joint<T>(qrow, jd, idx_q, lp, i);
+}
+// a small batch's SolveInit (one problem per call: the reference's own use): the caller's q into the resident copy AND FwdPassInit's pairs in one
+// launch, one thread per coordinate / joint -- a thread per instance walks 32 joints one after the other, 19 + 7 us for one problem
+template <typename T>
+__global__ void k_set_q_fk_small(double* __restrict__ q_res, const double* __restrict__ src, int src_shared, int nq,
+                                 const JointDesc* __restrict__ jd, const int* __restrict__ idx_q, Layout L, int B, char* tiles)
+{
+  const int per = nq > L.nb ? nq : L.nb;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = (int)(idx / per), t = (int)(idx - (long long)b * per);
+  if (b >= B) return;
+  const double* qrow = src + (src_shared ? 0 : (size_t)b * nq);
+  if (t < nq) q_res[(size_t)b * nq + t] = qrow[t];
+  if (t < L.nb) fk_init_joint<T>(qrow, jd, idx_q, lane_ptr<T>(tiles, L, b), t + 1);
 }
 
 // ---- configuration-space integration of the quaternion joints (what pinocchio::integrate does for

@@ -254,6 +254,9 @@ struct loikb_solver_impl {
   // buffer (h_pin, bump-allocated from pin_off; the section's final synchronisation makes it free again) and the upload kernels read them there
   char* h_pin = nullptr;
   size_t pin_cap = 0, pin_off = 0;
+  std::vector<double> uni_host;         // fp64 handles: the host's copy of d_uni -- inside a deferred section upload_uni only writes here, flush_uni sends it once
+  bool uni_dirty = false;
+  std::vector<int> cslots_on_device;    // the joints' constraint slots as upload_jd last sent them: a SolveInit with the same task links sends nothing
   double* d_q = nullptr;               // [B][nq] configurations resident on the device (outer loop)
   void* d_uni = nullptr;               // A[nc][36], AtA[nc][21], lb[nb], ub[nb] (T)
   void* d_stage = nullptr;             // staging for host<->device copies
@@ -1059,9 +1062,22 @@ int upload_uni(loikb_solver_impl* S, int offset, const double* src, int n)
     HIPCHK(hipMemcpyAsync((float*)S->d_uni + offset, tmp.data(), sizeof(float) * n, hipMemcpyHostToDevice, S->stream));
     HIPCHK(hipStreamSynchronize(S->stream));
   } else {
+    const size_t total = (size_t)(S->nc > 0 ? S->nc : 1) * 57 + 2 * (size_t)S->nb;
+    if (S->uni_host.size() != total) S->uni_host.assign(total, 0.0);   // (d_uni starts as zeros too)
+    memcpy(S->uni_host.data() + offset, src, sizeof(double) * n);
+    if (S->defer_sync) { S->uni_dirty = true; return LOIKB_OK; }       // (src may be a local of the caller: nothing asynchronous reads it)
     HIPCHK(hipMemcpyAsync((double*)S->d_uni + offset, src, sizeof(double) * n, hipMemcpyHostToDevice, S->stream));
-    if (!S->defer_sync) HIPCHK(hipStreamSynchronize(S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
   }
+  return LOIKB_OK;
+}
+
+// what upload_uni left on the host inside a deferred section: ONE copy of the whole (small) buffer, before the first kernel that reads it
+int flush_uni(loikb_solver_impl* S)
+{
+  if (!S->uni_dirty) return LOIKB_OK;
+  S->uni_dirty = false;
+  HIPCHK(hipMemcpyAsync(S->d_uni, S->uni_host.data(), sizeof(double) * S->uni_host.size(), hipMemcpyHostToDevice, S->stream));   // (a member: it outlives the copy)
   return LOIKB_OK;
 }
 
@@ -1089,6 +1105,17 @@ int fwd_pass_init(loikb_solver_impl* S, const double* q, int in_flags)
     const void* dq = nullptr;
     int rc = to_device(S, q, sizeof(double) * (shared ? (size_t)S->nq : (size_t)S->B * S->nq), dev, &dq);
     if (rc) return rc;
+    const long long elems = (long long)S->B * std::max(S->nq, S->nb);
+    if (elems <= (1 << 16)) {
+      // a small batch: the resident copy and FwdPassInit's pairs from ONE launch with a thread per coordinate / joint (k_set_q_fk_small)
+      const dim3 g((unsigned)((elems + 255) / 256));
+      if (S->f32) hipLaunchKernelGGL(k_set_q_fk_small<float>, g, dim3(256), 0, S->stream, S->d_q, (const double*)dq, (int)shared, S->nq, S->d_jd, S->d_idx_q, S->L, S->B, S->home.tiles);
+      else hipLaunchKernelGGL(k_set_q_fk_small<double>, g, dim3(256), 0, S->stream, S->d_q, (const double*)dq, (int)shared, S->nq, S->d_jd, S->d_idx_q, S->L, S->B, S->home.tiles);
+      HIPCHK(hipGetLastError());
+      if (!dev && !S->defer_sync) HIPCHK(hipStreamSynchronize(S->stream));
+      S->have_q = true;
+      return reset_home(S, RS_HCACHE | (S->opt.warm_start ? 0 : RS_Y));   // (as below)
+    }
     // the resident copy is what the outer loop advances (loikb_integrate)
     if (S->f32)
       hipLaunchKernelGGL(k_advance_q<float>, grid1(S->B), dim3(256), 0, S->stream, S->d_q, (const double*)dq, (int)shared,
@@ -1116,6 +1143,7 @@ int fwd_pass_init(loikb_solver_impl* S, const double* q, int in_flags)
 
 int constraint_products(loikb_solver_impl* S, int c_lo, int c_hi, bool grow_only)
 {
+  if (int frc = flush_uni(S)) return frc;
   if (S->f32)
     hipLaunchKernelGGL(k_constraint_products<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, S->L,
                        (const float*)S->d_uni, (int)S->a_shared, c_lo, c_hi, S->B, (int)grow_only);
@@ -1471,7 +1499,12 @@ int bind_constraint_slots(loikb_solver_impl* S)
     S->jd[S->link_of[e]].cslot = c;
   }
   S->pass_active = false;  // (the pass-level path copies the slot table when it starts)
-  return upload_jd(S);
+  std::vector<int> cs(S->nj);
+  for (int i = 0; i < S->nj; ++i) cs[i] = S->jd[i].cslot;
+  if (cs == S->cslots_on_device) return LOIKB_OK;   // (the same task links as last time: the descriptors on the device are these)
+  int rc = upload_jd(S);
+  if (rc == LOIKB_OK) S->cslots_on_device = cs;
+  return rc;
 }
 
 int edit_constraints(loikb_solver_impl* S, int c_lo, int c_hi, int shift)
@@ -3045,13 +3078,14 @@ int loikb_solve_init(loikb_solver* S, const double* q, const double* H_ref, cons
   if ((rc = ensure_layout(S, in_flags & LOIKB_A_SHARED))) return rc;
   S->pass_active = false;
   // (the uploads queue up behind each other; the caller's arrays are read by the time this function returns: ONE synchronisation, below)
-  struct Deferred { loikb_solver_impl* S; bool armed; ~Deferred() { S->defer_sync = false; if (armed) (void)hipStreamSynchronize(S->stream); } } deferred{S, true};
+  struct Deferred { loikb_solver_impl* S; bool armed; ~Deferred() { if (armed) (void)flush_uni(S); S->defer_sync = false; if (armed) (void)hipStreamSynchronize(S->stream); } } deferred{S, true};
   S->defer_sync = true;
   S->pin_off = 0;
   // problem_.Reset(); ik_id_data_.Reset(warm_start); ResetSolver()  (hpp:345-352)
   if ((rc = reset_home(S, RS_SOLVER | (S->opt.warm_start ? 0 : RS_DATA_COLD)))) return rc;
   if ((rc = set_problem(S, H_ref, v_ref, c_ids, nc, Ais, bis, lb, ub, nbound, in_flags))) return rc;
   if ((rc = fwd_pass_init(S, q, in_flags))) return rc;
+  if ((rc = flush_uni(S))) return rc;
   S->defer_sync = false;
   deferred.armed = false;
   HIPCHK(hipStreamSynchronize(S->stream));
@@ -3121,7 +3155,7 @@ int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const doubl
   HIPCHK(hipSetDevice(S->device));
   int rc;
   // (as in SolveInit: the uploads queue up; whichever way this function is left, the caller's arrays have been read)
-  struct Deferred { loikb_solver_impl* S; bool armed; ~Deferred() { S->defer_sync = false; if (armed) (void)hipStreamSynchronize(S->stream); } } deferred{S, true};
+  struct Deferred { loikb_solver_impl* S; bool armed; ~Deferred() { if (armed) (void)flush_uni(S); S->defer_sync = false; if (armed) (void)hipStreamSynchronize(S->stream); } } deferred{S, true};
   S->defer_sync = true;
   S->pin_off = 0;
   // ik_id_data_.Reset(warm_start); ResetSolver()  (hpp:604-608)
@@ -3130,6 +3164,7 @@ int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const doubl
   // upstream: the way to solve after AddEqConstraint / RemoveEqConstraint changed the set, possibly to the empty one)
   if (c_id >= 0 && (rc = update_eq_single(S, c_id, Ai, bi, in_flags))) return rc;
   if ((rc = fwd_pass_init(S, q, in_flags))) return rc;
+  if ((rc = flush_uni(S))) return rc;
   S->defer_sync = false;
   deferred.armed = false;   // (the solve below ends with its own synchronisation)
   return S->opt.logging ? run_logged(S, S->opt.warm_start ? 0 : (RS_SOLVER | RS_DATA_COLD | RS_Y | RS_HCACHE)) : run_main_loop(S);
