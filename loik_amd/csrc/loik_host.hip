@@ -3064,9 +3064,10 @@ int loikb_set_stream(loikb_solver* S, void* hip_stream)
   return LOIKB_OK;
 }
 
-int loikb_solve_init(loikb_solver* S, const double* q, const double* H_ref, const double* v_ref, const int* c_ids,
-                     int nc, const double* Ais, const double* bis, const double* lb, const double* ub, int nbound,
-                     int in_flags)
+// final_sync = false (loikb_solve_full): the solve that follows ends with a synchronisation of its own -- the caller's arrays are read by then
+static int solve_init_impl(loikb_solver* S, const double* q, const double* H_ref, const double* v_ref, const int* c_ids,
+                           int nc, const double* Ais, const double* bis, const double* lb, const double* ub, int nbound,
+                           int in_flags, bool final_sync)
 {
   if (!S || !q || !H_ref || !v_ref || (nc > 0 && (!c_ids || !Ais || !bis)) || !lb || !ub) return LOIKB_ERR_ARG;
   HIPCHK(hipSetDevice(S->device));
@@ -3088,8 +3089,15 @@ int loikb_solve_init(loikb_solver* S, const double* q, const double* H_ref, cons
   if ((rc = flush_uni(S))) return rc;
   S->defer_sync = false;
   deferred.armed = false;
-  HIPCHK(hipStreamSynchronize(S->stream));
+  if (final_sync) HIPCHK(hipStreamSynchronize(S->stream));
   return LOIKB_OK;
+}
+
+int loikb_solve_init(loikb_solver* S, const double* q, const double* H_ref, const double* v_ref, const int* c_ids,
+                     int nc, const double* Ais, const double* bis, const double* lb, const double* ub, int nbound,
+                     int in_flags)
+{
+  return solve_init_impl(S, q, H_ref, v_ref, c_ids, nc, Ais, bis, lb, ub, nbound, in_flags, true);
 }
 
 // problem_.UpdateReferences(H_refs, v_refs), ik-id-description-optimized.hpp:103-121
@@ -3143,9 +3151,11 @@ int loikb_solve_full(loikb_solver* S, const double* q, const double* H_ref, cons
                      int nc, const double* Ais, const double* bis, const double* lb, const double* ub, int nbound,
                      int in_flags)
 {
-  int rc = loikb_solve_init(S, q, H_ref, v_ref, c_ids, nc, Ais, bis, lb, ub, nbound, in_flags);
+  int rc = solve_init_impl(S, q, H_ref, v_ref, c_ids, nc, Ais, bis, lb, ub, nbound, in_flags, false);
   if (rc) return rc;
-  return S->opt.logging ? run_logged(S, S->opt.warm_start ? 0 : (RS_SOLVER | RS_DATA_COLD | RS_Y | RS_HCACHE)) : run_main_loop(S);
+  rc = S->opt.logging ? run_logged(S, S->opt.warm_start ? 0 : (RS_SOLVER | RS_DATA_COLD | RS_Y | RS_HCACHE)) : run_main_loop(S);
+  if (rc) (void)hipStreamSynchronize(S->stream);   // (a solve that fails may return before its own: the caller's arrays must have been read)
+  return rc;
 }
 
 int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const double* Ai, const double* bi, int in_flags)

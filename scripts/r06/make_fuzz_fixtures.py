@@ -21,7 +21,9 @@ CASES = [dict(name="r05_j_fuzz_1500_case1212", ncase=1213, seed=4242, flat_bias=
          dict(name="r06_q_fuzz_12000_case4160", ncase=4161, seed=424242, flat_bias=0.7, only=4160),
          dict(name="r06_q_fuzz_12000_case6317", ncase=6318, seed=424242, flat_bias=0.7, only=6317),
          dict(name="r06_q_fuzz_12000_case7166", ncase=7167, seed=424242, flat_bias=0.7, only=7166),
-         dict(name="r06_q_fuzz_12000_case10176", ncase=10177, seed=424242, flat_bias=0.7, only=10176)]
+         dict(name="r06_q_fuzz_12000_case10176", ncase=10177, seed=424242, flat_bias=0.7, only=10176),
+         # (after SolveInit's small-batch path changed: profiles/r06_s_fuzz_6000.txt; bit-identical on the library of before, scripts/r06/replay_case_two_libs.py)
+         dict(name="r06_s_fuzz_6000_case5896", ncase=5897, seed=90210, flat_bias=0.7, only=5896)]
 if len(sys.argv) > 1:   # (only the named cases)
     CASES = [c for c in CASES if c["name"] in sys.argv[1:]]
 for c in CASES:
