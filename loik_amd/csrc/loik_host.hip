@@ -250,6 +250,7 @@ struct loikb_solver_impl {
   std::vector<RowmapEntry> rowmap_cache;   // a handle uses a dozen distinct row maps (lb, ub, A, b, the getters' members ...), again and again: kept on the
                                        //   device -- SolveInit of ONE problem spent more in their uploads and synchronisations than in its kernels
   bool defer_sync = false;             // inside SolveInit / the tailored Solve: the uploads' synchronisations are left to the entry point's own at its end
+  bool offer_queue = false;            // the full / tailored Solve: FwdPassInit's closing reset goes straight into the main loop -- reset_home(.., with_queue)
   // ... and, inside such a section, small host inputs do not travel by a copy operation at all: they are put into a pinned, device-visible
   // buffer (h_pin, bump-allocated from pin_off; the section's final synchronisation makes it free again) and the upload kernels read them there
   char* h_pin = nullptr;
@@ -1114,7 +1115,7 @@ int fwd_pass_init(loikb_solver_impl* S, const double* q, int in_flags)
       HIPCHK(hipGetLastError());
       if (!dev && !S->defer_sync) HIPCHK(hipStreamSynchronize(S->stream));
       S->have_q = true;
-      return reset_home(S, RS_HCACHE | (S->opt.warm_start ? 0 : RS_Y));   // (as below)
+      return reset_home(S, RS_HCACHE | (S->opt.warm_start ? 0 : RS_Y), S->offer_queue);   // (as below)
     }
     // the resident copy is what the outer loop advances (loikb_integrate)
     if (S->f32)
@@ -1138,7 +1139,7 @@ int fwd_pass_init(loikb_solver_impl* S, const double* q, int in_flags)
                        S->d_jd, S->d_idx_q, S->L, S->B, S->home.tiles);
   HIPCHK(hipGetLastError());
   // the H/UDinv/Dinv cache depends on liMi; cold start: yis = 0, Aty = 0 (hxx:270-278)
-  return reset_home(S, RS_HCACHE | (S->opt.warm_start ? 0 : RS_Y));
+  return reset_home(S, RS_HCACHE | (S->opt.warm_start ? 0 : RS_Y), S->offer_queue);
 }
 
 int constraint_products(loikb_solver_impl* S, int c_lo, int c_hi, bool grow_only)
@@ -3151,8 +3152,11 @@ int loikb_solve_full(loikb_solver* S, const double* q, const double* H_ref, cons
                      int nc, const double* Ais, const double* bis, const double* lb, const double* ub, int nbound,
                      int in_flags)
 {
+  if (!S) return LOIKB_ERR_ARG;
+  S->offer_queue = !S->opt.logging;
   int rc = solve_init_impl(S, q, H_ref, v_ref, c_ids, nc, Ais, bis, lb, ub, nbound, in_flags, false);
-  if (rc) return rc;
+  S->offer_queue = false;
+  if (rc) { for (loikb_solver_impl::Chunk& C : S->chunks) C.queue_ready = false; return rc; }
   rc = S->opt.logging ? run_logged(S, S->opt.warm_start ? 0 : (RS_SOLVER | RS_DATA_COLD | RS_Y | RS_HCACHE)) : run_main_loop(S);
   if (rc) (void)hipStreamSynchronize(S->stream);   // (a solve that fails may return before its own: the caller's arrays must have been read)
   return rc;
@@ -3173,8 +3177,11 @@ int loikb_solve_tailored(loikb_solver* S, const double* q, int c_id, const doubl
   // problem_.UpdateEqConstraint(c_id, Ai, bi), ik-id-description-optimized.hpp:178-218.  c_id < 0: no constraint update (not
   // upstream: the way to solve after AddEqConstraint / RemoveEqConstraint changed the set, possibly to the empty one)
   if (c_id >= 0 && (rc = update_eq_single(S, c_id, Ai, bi, in_flags))) return rc;
-  if ((rc = fwd_pass_init(S, q, in_flags))) return rc;
-  if ((rc = flush_uni(S))) return rc;
+  S->offer_queue = !S->opt.logging;
+  rc = fwd_pass_init(S, q, in_flags);
+  S->offer_queue = false;
+  if (rc == LOIKB_OK) rc = flush_uni(S);
+  if (rc) { for (loikb_solver_impl::Chunk& C : S->chunks) C.queue_ready = false; return rc; }
   S->defer_sync = false;
   deferred.armed = false;   // (the solve below ends with its own synchronisation)
   return S->opt.logging ? run_logged(S, S->opt.warm_start ? 0 : (RS_SOLVER | RS_DATA_COLD | RS_Y | RS_HCACHE)) : run_main_loop(S);
