@@ -860,3 +860,46 @@ def test_results_in_one_call_are_the_getters_values(robot, B, nc):
         for k in names:
             assert np.array_equal(r[k], s.get(k)), k
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 40, 3000])
+def test_a_handle_reused_for_other_problems_answers_as_a_fresh_one(talos, B):
+    """SolveInit's small-batch machinery (round 6, last session): row maps cached on the device, uploads queued behind each other with ONE
+    synchronisation, small host inputs read from a pinned buffer, the uniform inputs (shared A / bounds) sent from a host copy once per SolveInit,
+    the joints' descriptors sent only when the task links change, q + FwdPassInit from one joint-parallel launch, the queue prepared by
+    FwdPassInit's closing reset.  One handle taken through problems that differ in exactly those things -- another task link, A and the bounds shared
+    or per instance, the full Solve(args), SolveInit + Solve(), the tailored Solve -- returns, bit for bit, what a fresh handle returns for each."""
+    from helpers import feasible_batch
+    la, lb_ = talos.getJointId("arm_left_7_joint"), talos.getJointId("leg_right_6_joint")
+    probs = [("left wrist, shared A and bounds", feasible_batch(talos, B, la, 501, nu_scale=0.5)),
+             ("right foot, shared", feasible_batch(talos, B, lb_, 502, nu_scale=0.5)),
+             ("left wrist again, A per instance", feasible_batch(talos, B, la, 503, nu_scale=0.5, per_instance_A=True)),
+             ("right foot, bounds per instance", feasible_batch(talos, B, lb_, 504, nu_scale=0.5, per_instance_bounds=True)),
+             ("left wrist, shared again", feasible_batch(talos, B, la, 505, nu_scale=0.5))]
+    prm = dict(FIXTURE, max_iter=150, tol_abs=1e-6, tol_rel=0.0)
+    keys = ("iter", "converged", "primal_infeasible", "z", "nu", "w", "yis", "fis", "vis")
+    args = lambda w: (w["q"], w["H_ref"], w["v_ref"], w["c_ids"], w["Ais"], w["bis"], w["lb"], w["ub"])
+    one = loik_amd.BatchedLoik(talos, B, **prm)
+    for k, (name, wl) in enumerate(probs):
+        how = ("full", "init+solve", "full")[k % 3]
+        if how == "full":
+            one.Solve(*args(wl))
+        else:
+            one.SolveInit(*args(wl)); one.Solve()
+        fresh = loik_amd.BatchedLoik(talos, B, **prm)
+        fresh.Solve(*args(wl))
+        for f in keys:
+            assert np.array_equal(np.asarray(one.get(f)), np.asarray(fresh.get(f))), (name, how, f)
+        r = one.get_results()
+        for f in ("z", "nu", "w", "vis", "fis", "yis"):
+            assert np.array_equal(r[f], np.asarray(fresh.get(f))), (name, f)
+        # the tailored entry on the reused handle: a new q and target for the same link and A (hpp:596-695) against SolveInit + Solve of that problem
+        wl2 = feasible_batch(talos, B, int(wl["c_ids"][0]), 600 + k, nu_scale=0.5)
+        Ai = wl["Ais"][0] if np.asarray(wl["Ais"]).ndim == 3 else wl["Ais"][:, 0]
+        one.Solve(wl2["q"], int(wl["c_ids"][0]), Ai, wl2["bis"][:, 0])
+        fresh.Solve(wl2["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl2["bis"], wl["lb"], wl["ub"])
+        for f in keys:
+            assert np.array_equal(np.asarray(one.get(f)), np.asarray(fresh.get(f))), (name, "tailored", f)
+        fresh.close()
+    one.close()
