@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LOIKB_VERSION 601  /* round.minor: bumped whenever a struct or an entry point of this header changes */
+#define LOIKB_VERSION 602  /* round.minor: bumped whenever a struct or an entry point of this header changes */
 
 /* ---- status codes -------------------------------------------------------------------------------- */
 enum {
@@ -320,7 +320,20 @@ int loikb_get(loikb_solver *s, int field, void *out, int out_flags);
 #define LOIKB_RES_FIS 16u
 #define LOIKB_RES_YIS 32u
 #define LOIKB_RES_ALL 63u
-int loikb_get_results(loikb_solver *s, unsigned int mask, double *z, double *nu, double *w, double *vis, double *fis, double *yis);
+/* ... and what a caller asks a solver after every solve -- get_iter(), get_convergence_status(), get_primal_infeasibility_status(), the
+ * residuals and the other scalar getters (task-solver-base.hpp:87-141, loik-loid-optimized.hpp:698-755) -- in the same gather:
+ * `scalars` [batch][LOIKB_RES_NSCALARS] doubles: entries 0 .. 29 the fields LOIKB_F_PRIMAL_RESIDUAL .. LOIKB_F_TAIL_SOLVE_ITER in the
+ * enum's order, 30 the iteration count, 31 the status bits (LOIKB_F_STATUS: 1 converged, 2 primal infeasible, 4 tail solve ran,
+ * 8 finished), 32 the number of mu updates.  (Each scalar through loikb_get costs a small batch 0.025 ms: three of them cost one
+ * problem half its solve.) */
+#define LOIKB_RES_SCALARS 64u
+#define LOIKB_RES_NSCALARS 33
+#define LOIKB_RES_SCALAR_ITER 30
+#define LOIKB_RES_SCALAR_STATUS 31
+#define LOIKB_RES_SCALAR_MU_UPDATES 32
+#define LOIKB_RESULTS_FUSED_BYTES_DEFAULT (4u << 20)
+int loikb_get_results(loikb_solver *s, unsigned int mask, double *z, double *nu, double *w, double *vis, double *fis, double *yis,
+                      double *scalars);
 
 /* measurement: what the last loikb_solve* call did */
 typedef struct loikb_stats {

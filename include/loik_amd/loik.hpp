@@ -506,9 +506,40 @@ private:
     static_assert(FETCH_Z == LOIKB_RES_Z && FETCH_NU == LOIKB_RES_NU && FETCH_W == LOIKB_RES_W && FETCH_VIS == LOIKB_RES_VIS &&
                   FETCH_FIS == LOIKB_RES_FIS && FETCH_YIS == LOIKB_RES_YIS, "fetch mask out of step with loikb_get_results");
     if (nc_ <= 0) mask &= ~static_cast<unsigned>(FETCH_YIS);
-    if (mask & FETCH_ALL)
-      check(loikb_get_results(h_, mask & FETCH_ALL, ik_id_data_.z.data(), ik_id_data_.nu.data(), ik_id_data_.w.data(), ik_id_data_.vis.data(),
-                              ik_id_data_.fis.data(), ik_id_data_.yis.data()));
+    mask &= FETCH_ALL;
+    // A small batch (the fused gather of loikb_get_results will serve it): the scalars behind get_iter(), get_convergence_status(), the
+    // residuals ... ride along -- a scalar getter's own device call costs 0.025 ms, one problem's callers make two or three after every solve.
+    // A large batch keeps them lazy (one download per field that is actually asked for).
+    const std::size_t per = 3 * static_cast<std::size_t>(model_.nv) + 12 * static_cast<std::size_t>(model_.njoints - 1) +
+                            6 * static_cast<std::size_t>(nc_ > 0 ? nc_ : 0) + LOIKB_RES_NSCALARS;
+    const bool with_scalars = mask != 0 && sizeof(double) * per * static_cast<std::size_t>(batch_) <= LOIKB_RESULTS_FUSED_BYTES_DEFAULT;
+    if (with_scalars) scal_.resize(static_cast<std::size_t>(batch_) * LOIKB_RES_NSCALARS);
+    if (mask)
+      check(loikb_get_results(h_, mask | (with_scalars ? LOIKB_RES_SCALARS : 0u), ik_id_data_.z.data(), ik_id_data_.nu.data(), ik_id_data_.w.data(),
+                              ik_id_data_.vis.data(), ik_id_data_.fis.data(), ik_id_data_.yis.data(), with_scalars ? scal_.data() : nullptr));
+    if (with_scalars) {
+      const std::size_t B = static_cast<std::size_t>(batch_);
+      for (int k = 0; k < LOIKB_RES_SCALAR_ITER; ++k) {   // the 30 scalar fields, LOIKB_F_PRIMAL_RESIDUAL + k
+        Cached<DVec>& c = dcache_[LOIKB_F_PRIMAL_RESIDUAL + k];
+        c.data.resize(B);
+        for (std::size_t b = 0; b < B; ++b) c.data[b] = scal_[b * LOIKB_RES_NSCALARS + static_cast<std::size_t>(k)];
+        c.gen = generation_;
+      }
+      auto fill_int = [&](int field, int col, int mask_bits) {
+        Cached<std::vector<int>>& c = icache_[field];
+        c.data.resize(B);
+        for (std::size_t b = 0; b < B; ++b) {
+          const int v = static_cast<int>(scal_[b * LOIKB_RES_NSCALARS + static_cast<std::size_t>(col)]);
+          c.data[b] = mask_bits ? ((v & mask_bits) ? 1 : 0) : v;
+        }
+        c.gen = generation_;
+      };
+      fill_int(LOIKB_F_ITER, LOIKB_RES_SCALAR_ITER, 0);
+      fill_int(LOIKB_F_STATUS, LOIKB_RES_SCALAR_STATUS, 0);
+      fill_int(LOIKB_F_CONVERGED, LOIKB_RES_SCALAR_STATUS, 1);
+      fill_int(LOIKB_F_PRIMAL_INFEASIBLE, LOIKB_RES_SCALAR_STATUS, 2);
+      fill_int(LOIKB_F_MU_UPDATES, LOIKB_RES_SCALAR_MU_UPDATES, 0);
+    }
   }
   // one download per field and solve, then O(1) per getter call
   template <typename V>
@@ -556,6 +587,7 @@ private:
   double tol_primal_ = 0.0, tol_dual_ = 0.0;
   bool tol_primal_set_ = false, tol_dual_set_ = false;
   unsigned fetch_mask_ = FETCH_ALL;
+  DVec scal_;   // [batch][LOIKB_RES_NSCALARS]: the scalar block of the last fused fetch
   unsigned long long generation_ = 1;
   mutable std::map<int, Cached<std::vector<int>>> icache_;
   mutable std::map<int, Cached<DVec>> dcache_;

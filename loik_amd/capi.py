@@ -53,7 +53,7 @@ class Stats(C.Structure):
                 ("flat_probe_launches", C.c_int), ("probe_ms", C.c_double)]
 
 
-ABI_VERSION = 601   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
+ABI_VERSION = 602   # LOIKB_VERSION of include/loik_amd.h this binding matches (struct layouts, entry points)
 
 # enums of loik_amd.h
 F64, F32 = 0, 1
@@ -132,7 +132,7 @@ def lib():
     L.loikb_set_tol.argtypes = [C.c_void_p, C.c_double, C.c_double]
     L.loikb_set_warm_start.argtypes = [C.c_void_p, C.c_int]
     L.loikb_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
-    L.loikb_get_results.argtypes = [C.c_void_p, C.c_uint, _dp, _dp, _dp, _dp, _dp, _dp]
+    L.loikb_get_results.argtypes = [C.c_void_p, C.c_uint, _dp, _dp, _dp, _dp, _dp, _dp, _dp]
     L.loikb_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     for n in ["loikb_batch", "loikb_nv", "loikb_njoints"]:
         getattr(L, n).argtypes = [C.c_void_p]
@@ -609,13 +609,16 @@ class BatchedLoik:
         _check(self.L.loikb_get(self.h, fid, arr.ctypes.data_as(C.c_void_p), 0))
         return arr
 
-    RESULT_FIELDS = ("z", "nu", "w", "vis", "fis", "yis")   # (bit k of loikb_get_results' mask: LOIKB_RES_*)
+    RESULT_FIELDS = ("z", "nu", "w", "vis", "fis", "yis", "scalars")   # (bit k of loikb_get_results' mask: LOIKB_RES_*)
+    NSCALARS, SCALAR_ITER, SCALAR_STATUS, SCALAR_MU_UPDATES = 33, 30, 31, 32   # (LOIKB_RES_NSCALARS ...: the layout of "scalars")
 
-    def get_results(self, fields=RESULT_FIELDS):
+    def get_results(self, fields=RESULT_FIELDS[:6]):
         """the members of the reference's data object a solve leaves behind (z, nu, w, vis, fis, yis: loik-loid-data-optimized.hpp:118-178), any
-        subset, in ONE call (loikb_get_results): {name: array}, the same values as get(name)"""
+        subset, in ONE call (loikb_get_results): {name: array}, the same values as get(name).  "scalars": [B][33] -- the 30 scalar getters'
+        fields in FIELD_ID order from "primal_residual", then iter, the status bits, mu_updates (what get_iter() / get_convergence_status() / ...
+        read), from the same gather"""
         B, nb, nv, nc = self.batch, self.model.njoints - 1, self.model.nv, self.L.loikb_num_eq_c(self.h)
-        shapes = {"z": (B, nv), "nu": (B, nv), "w": (B, nv), "vis": (B, nb, 6), "fis": (B, nb, 6), "yis": (B, nc, 6)}
+        shapes = {"z": (B, nv), "nu": (B, nv), "w": (B, nv), "vis": (B, nb, 6), "fis": (B, nb, 6), "yis": (B, nc, 6), "scalars": (B, self.NSCALARS)}
         mask, out, ptrs = 0, {}, []
         for k, name in enumerate(self.RESULT_FIELDS):
             if name in fields:

@@ -264,9 +264,9 @@ struct loikb_solver_impl {
   void* d_getscr[2] = {nullptr, nullptr};  // scratch of the getters that rebuild members (His / pis / UDinv): kept, not malloc'ed per call
   // loikb_get_results: the row map of the requested members on the device (rebuilt when the request or the constraint set changes) and a
   // pinned, device-visible host buffer the gather kernel writes into
-  int* d_resmap = nullptr;
-  int resmap_key[6] = {-1, -1, -1, -1, -1, -1};   // mask, nc_active, nb, nl, off_c, crec
-  int res_n = 0, res_off[7] = {0, 0, 0, 0, 0, 0, 0};
+  struct ResMap { int* d = nullptr; int key[6] = {-1, -1, -1, -1, -1, -1}; int n = 0; int off[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };   // key: mask, nc_active, nb, nl, off_c, crec
+  ResMap resmaps[4];                   // (a caller uses one or two masks; replaced round robin)
+  int resmap_next = 0;
   double* h_res = nullptr;
   size_t h_res_bytes = 0;
   size_t getscr_bytes[2] = {0, 0};
@@ -3042,7 +3042,7 @@ int loikb_destroy(loikb_solver* S)
   for (void* a : S->allocs) if (a) (void)hipFree(a);
   if (S->d_stage) (void)hipFree(S->d_stage);
   for (int k = 0; k < 2; ++k) if (S->d_getscr[k]) (void)hipFree(S->d_getscr[k]);
-  if (S->d_resmap) (void)hipFree(S->d_resmap);
+  for (auto& rmap : S->resmaps) if (rmap.d) (void)hipFree(rmap.d);
   if (S->h_pin) (void)hipHostFree(S->h_pin);
   if (S->h_res) (void)hipHostFree(S->h_res);
   if (S->d_pass) (void)hipFree(S->d_pass);
@@ -3708,6 +3708,15 @@ static bool result_rows(const loikb_solver_impl* S, int field, std::vector<int>&
     for (int c = 0; c < S->nc_active; ++c)  // (the active constraints are the first slots; the null ones behind them hold zeros)
       for (int k = 0; k < 6; ++k) rm.push_back((L.off_c + c * L.crec + CP_Y + k / 2) * 2 + (k & 1));
     return true;
+  case -1:   // (loikb_get_results' scalar block: LOIKB_RES_NSCALARS rows, the maps loikb_get uses for the single fields)
+    for (int f = LOIKB_F_PRIMAL_RESIDUAL; f <= LOIKB_F_TAIL_SOLVE_ITER; ++f) {
+      const int idx = f - LOIKB_F_PRIMAL_RESIDUAL;
+      rm.push_back(f == LOIKB_F_MU ? (L.off_s + SP_MU) * 2 : (L.off_s + SP_SCAL + idx / 2) * 2 + (idx & 1));
+    }
+    rm.push_back((L.off_s + SP_BI) * 2 + 1);   // iter
+    rm.push_back((L.off_s + SP_ST) * 2);       // status bits
+    rm.push_back((L.off_s + SP_FLIP) * 2);     // mu updates
+    return true;
   default: return false;
   }
 }
@@ -3715,40 +3724,69 @@ static bool result_rows(const loikb_solver_impl* S, int field, std::vector<int>&
 // z, nu, w, vis, fis, yis of the whole batch in ONE call: one gather launch into pinned host memory and one synchronisation for a batch whose
 // results fit LOIKB_RESULTS_FUSED_BYTES (default 4 MiB); larger batches, and a handle in the middle of pass-level calls, go field by field
 // through loikb_get (whose copies are DMA transfers of their own).
-int loikb_get_results(loikb_solver* S, unsigned int mask, double* z, double* nu, double* w, double* vis, double* fis, double* yis)
+int loikb_get_results(loikb_solver* S, unsigned int mask, double* z, double* nu, double* w, double* vis, double* fis, double* yis, double* scalars)
 {
   if (!S) return LOIKB_ERR_ARG;
-  static const int fields[6] = {LOIKB_F_Z, LOIKB_F_NU, LOIKB_F_W, LOIKB_F_VIS, LOIKB_F_FIS, LOIKB_F_YIS};
-  double* outs[6] = {z, nu, w, vis, fis, yis};
-  if (mask & ~63u) { g_last_error = "loikb_get_results: unknown bits in the mask"; return LOIKB_ERR_ARG; }
-  for (int f = 0; f < 6; ++f)
+  constexpr int NF = 7;
+  static_assert(LOIKB_RES_NSCALARS == NSCAL + 3 && LOIKB_RES_SCALAR_ITER == NSCAL, "scalar block out of step with the scalar record");
+  static const int fields[NF] = {LOIKB_F_Z, LOIKB_F_NU, LOIKB_F_W, LOIKB_F_VIS, LOIKB_F_FIS, LOIKB_F_YIS, -1};
+  double* outs[NF] = {z, nu, w, vis, fis, yis, scalars};
+  if (mask & ~127u) { g_last_error = "loikb_get_results: unknown bits in the mask"; return LOIKB_ERR_ARG; }
+  for (int f = 0; f < NF; ++f)
     if ((mask & (1u << f)) && !outs[f]) { g_last_error = "loikb_get_results: a requested member has no destination"; return LOIKB_ERR_ARG; }
   if (!mask) return LOIKB_OK;
   HIPCHK(hipSetDevice(S->device));
   static const size_t fused_max = [] { const char* e = getenv("LOIKB_RESULTS_FUSED_BYTES"); return e ? (size_t)atoll(e) : (size_t)4 << 20; }();
   const int key[6] = {(int)mask, S->nc_active, S->nb, S->ext_nj - 1, S->L.off_c, S->L.crec};
   int rc;
-  if (memcmp(key, S->resmap_key, sizeof(key)) != 0) {
+  loikb_solver_impl::ResMap* R = nullptr;
+  for (auto& rmap : S->resmaps) if (rmap.d && memcmp(key, rmap.key, sizeof(key)) == 0) R = &rmap;
+  if (!R) {
+    R = &S->resmaps[S->resmap_next];
+    S->resmap_next = (S->resmap_next + 1) % 4;
     std::vector<int> rm;
     int off = 0;
-    for (int f = 0; f < 6; ++f) {
-      S->res_off[f] = off;
+    for (int f = 0; f < NF; ++f) {
+      R->off[f] = off;
       if (mask & (1u << f)) result_rows(S, fields[f], rm);
       off = (int)rm.size();
     }
-    S->res_off[6] = off;
-    S->res_n = off;
-    if (S->d_resmap) { HIPCHK(hipStreamSynchronize(S->stream)); HIPCHK(hipFree(S->d_resmap)); S->d_resmap = nullptr; }
-    HIPCHK(hipMalloc((void**)&S->d_resmap, sizeof(int) * (size_t)std::max(off, 1)));
-    HIPCHK(hipMemcpy(S->d_resmap, rm.data(), sizeof(int) * (size_t)off, hipMemcpyHostToDevice));   // (synchronous: rm is a local)
-    memcpy(S->resmap_key, key, sizeof(key));
+    R->off[NF] = off;
+    R->n = off;
+    if (R->d) { HIPCHK(hipStreamSynchronize(S->stream)); HIPCHK(hipFree(R->d)); R->d = nullptr; }
+    R->key[0] = -1;
+    HIPCHK(hipMalloc((void**)&R->d, sizeof(int) * (size_t)std::max(off, 1)));
+    HIPCHK(hipMemcpy(R->d, rm.data(), sizeof(int) * (size_t)off, hipMemcpyHostToDevice));   // (synchronous: rm is a local)
+    memcpy(R->key, key, sizeof(key));
   }
-  const int n = S->res_n;
+  const int n = R->n;
   const size_t bytes = sizeof(double) * (size_t)S->B * (size_t)n;
   if (S->pass_active || bytes > fused_max || n == 0) {
-    for (int f = 0; f < 6; ++f) {
+    for (int f = 0; f < NF; ++f) {
       if (!(mask & (1u << f))) continue;
       if (fields[f] == LOIKB_F_YIS && S->nc_active == 0) continue;
+      if (fields[f] == -1) {   // (the scalar block, field by field: a batch too large for the fused gather should ask for the scalars it needs instead)
+        std::vector<double> col((size_t)S->B);
+        std::vector<int> icol((size_t)S->B);
+        for (int k = 0; k < LOIKB_RES_NSCALARS; ++k) {
+          if (k < NSCAL) { if ((rc = loikb_get(S, LOIKB_F_PRIMAL_RESIDUAL + k, col.data(), 0))) return rc; }
+          else {
+            if ((rc = loikb_get(S, k == LOIKB_RES_SCALAR_ITER ? LOIKB_F_ITER : k == LOIKB_RES_SCALAR_STATUS ? LOIKB_F_STATUS : LOIKB_F_MU_UPDATES, icol.data(), 0))) return rc;
+            if (k == LOIKB_RES_SCALAR_STATUS) {
+              // (in the middle of pass-level calls the flags live in the pass state, the raw word in the tiles: bits 1 and 2 from the flags' own getters)
+              std::vector<int> fl((size_t)S->B);
+              for (int b = 0; b < S->B; ++b) icol[(size_t)b] &= ~(ST_CONVERGED | ST_PRIMAL_INF);
+              if ((rc = loikb_get(S, LOIKB_F_CONVERGED, fl.data(), 0))) return rc;
+              for (int b = 0; b < S->B; ++b) icol[(size_t)b] |= fl[(size_t)b] ? ST_CONVERGED : 0;
+              if ((rc = loikb_get(S, LOIKB_F_PRIMAL_INFEASIBLE, fl.data(), 0))) return rc;
+              for (int b = 0; b < S->B; ++b) icol[(size_t)b] |= fl[(size_t)b] ? ST_PRIMAL_INF : 0;
+            }
+            for (int b = 0; b < S->B; ++b) col[(size_t)b] = (double)icol[(size_t)b];
+          }
+          for (int b = 0; b < S->B; ++b) scalars[(size_t)b * LOIKB_RES_NSCALARS + k] = col[(size_t)b];
+        }
+        continue;
+      }
       if ((rc = loikb_get(S, fields[f], outs[f], 0))) return rc;
     }
     return LOIKB_OK;
@@ -3769,17 +3807,19 @@ int loikb_get_results(loikb_solver* S, unsigned int mask, double* z, double* nu,
   {
     const long long total = (long long)S->B * n;
     const dim3 grid((unsigned)((total + 255) / 256));
-    if (S->f32) hipLaunchKernelGGL(k_download_elems<float>, grid, dim3(256), 0, S->stream, S->home.tiles, S->L, (const int*)S->d_resmap, n, S->B, dst);
-    else hipLaunchKernelGGL(k_download_elems<double>, grid, dim3(256), 0, S->stream, S->home.tiles, S->L, (const int*)S->d_resmap, n, S->B, dst);
+    if (S->f32) hipLaunchKernelGGL(k_download_elems<float>, grid, dim3(256), 0, S->stream, S->home.tiles, S->L, (const int*)R->d, n, S->B, dst);
+    else hipLaunchKernelGGL(k_download_elems<double>, grid, dim3(256), 0, S->stream, S->home.tiles, S->L, (const int*)R->d, n, S->B, dst);
     HIPCHK(hipGetLastError());
   }
   if (!direct) HIPCHK(hipMemcpyAsync(S->h_res, S->d_stage, bytes, hipMemcpyDeviceToHost, S->stream));
   HIPCHK(hipStreamSynchronize(S->stream));
-  for (int f = 0; f < 6; ++f) {
+  for (int f = 0; f < NF; ++f) {
     if (!(mask & (1u << f))) continue;
-    const int o = S->res_off[f], nf = S->res_off[f + 1] - o;
+    const int o = R->off[f], nf = R->off[f + 1] - o;
     if (nf == 0) continue;
     for (int b = 0; b < S->B; ++b) memcpy(outs[f] + (size_t)b * nf, S->h_res + (size_t)b * n + o, sizeof(double) * (size_t)nf);
+    if (fields[f] == -1)   // (the status word carries engine-internal bits above the four the API names: LOIKB_F_STATUS's mask)
+      for (int b = 0; b < S->B; ++b) { double& x = outs[f][(size_t)b * nf + LOIKB_RES_SCALAR_STATUS]; x = (double)((int)x & (ST_CONVERGED | ST_PRIMAL_INF | ST_TAIL | ST_DONE)); }
   }
   return LOIKB_OK;
 }

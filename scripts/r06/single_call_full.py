@@ -19,5 +19,7 @@ for B in [int(a) for a in sys.argv[1:]] or [1, 8]:
         t0 = time.perf_counter(); s.SolveInit(*args); s.synchronize(); t["solve_init"].append(time.perf_counter() - t0)
         s.Solve()
         t0 = time.perf_counter(); s.get_results(); t["results"].append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); s.get_results(s.RESULT_FIELDS); t.setdefault("results_and_scalars", []).append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); s.get("iter"); s.get("converged"); s.get("primal_infeasible"); t.setdefault("three_scalar_gets", []).append(time.perf_counter() - t0)
     print(json.dumps(dict(batch=B, iterations=int(np.asarray(s.get("iter")).max()), **{k + "_ms": round(min(v) * 1e3, 4) for k, v in t.items()})), flush=True)
     s.close()

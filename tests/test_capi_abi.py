@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(L, name), "libloik_amd.so does not export %s" % name
     assert decl == set(capi.EXPORTED_SYMBOLS), decl ^ set(capi.EXPORTED_SYMBOLS)
-    assert L.loikb_version() == loik_amd.capi.ABI_VERSION == 601
+    assert L.loikb_version() == loik_amd.capi.ABI_VERSION == 602
 
 
 def test_builtin_models():

@@ -850,6 +850,18 @@ def test_results_in_one_call_are_the_getters_values(robot, B, nc):
         assert allr[k].shape == one[k].shape and np.array_equal(allr[k], one[k]), k
     sub = s.get_results(("nu", "fis"))
     assert set(sub) == {"nu", "fis"} and np.array_equal(sub["nu"], one["nu"]) and np.array_equal(sub["fis"], one["fis"])
+    # the scalar block (ABI 602): what get_iter() / get_convergence_status() / the residual getters read, from the same gather
+    from loik_amd.capi import _SCALAR_FIELDS
+    sc = s.get_results(("z", "scalars"))
+    assert sc["scalars"].shape == (B, 33) and np.array_equal(sc["z"], one["z"])
+    for k, name in enumerate(_SCALAR_FIELDS):
+        assert np.array_equal(sc["scalars"][:, k], np.asarray(s.get(name))), name
+    assert np.array_equal(sc["scalars"][:, s.SCALAR_ITER], np.asarray(s.get("iter")).astype(float))
+    assert np.array_equal(sc["scalars"][:, s.SCALAR_STATUS], np.asarray(s.get("status")).astype(float))
+    assert np.array_equal(sc["scalars"][:, s.SCALAR_MU_UPDATES], np.asarray(s.get("mu_updates")).astype(float))
+    st_bits = sc["scalars"][:, s.SCALAR_STATUS].astype(int)
+    assert np.array_equal((st_bits & 1) != 0, np.asarray(s.get("converged")).astype(bool))
+    assert np.array_equal((st_bits & 2) != 0, np.asarray(s.get("primal_infeasible")).astype(bool))
     with pytest.raises(ValueError):
         s.get_results(("z", "His"))
     if nc > 1:   # one task less: yis has a row less per instance, the cached row map must follow
