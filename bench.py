@@ -577,7 +577,7 @@ def single_call_variant(args, device, wl0):
         ts, tr, tf = [], [], []
         full_args = (wl["q"], wl["H_ref"], wl["v_ref"], wl["c_ids"], wl["Ais"], wl["bis"], wl["lb"], wl["ub"])
         for _ in range(30):
-            t = time.perf_counter(); s.Solve(); t1 = time.perf_counter(); s.get_results(); t2 = time.perf_counter()
+            t = time.perf_counter(); s.Solve(); t1 = time.perf_counter(); s.get_results(s.RESULT_FIELDS); t2 = time.perf_counter()
             ts.append(t1 - t); tr.append(t2 - t1)
             t = time.perf_counter(); s.Solve(*full_args); tf.append(time.perf_counter() - t)   # (SolveInit + Solve from host arrays: hpp:475-580)
         it = s.get("iter")
@@ -587,7 +587,7 @@ def single_call_variant(args, device, wl0):
                             "results_wall_ms": min(tr) * 1e3, "solve_plus_results_wall_ms": (min(ts) + min(tr)) * 1e3,
                             "full_solve_wall_ms": min(tf) * 1e3, "full_solve_plus_results_wall_ms": (min(tf) + min(tr)) * 1e3})
         s.close()
-    out["results_note"] = ("results_wall_ms: z, nu, w, vis, fis, yis of the reference's data object to host arrays in one call (loikb_get_results; what the C++ "
+    out["results_note"] = ("results_wall_ms: z, nu, w, vis, fis, yis of the reference's data object AND the scalar block (iteration count, flags, residuals) to host arrays in one call (loikb_get_results; what the C++ "
                            "mirror include/loik_amd/loik.hpp fetches after every solve) -- a drop-in caller's time per problem is solve + results")
     out["b1_solve_wall_ms"] = out["rows"][0]["solve_wall_ms"]
     out["b1_solve_plus_results_wall_ms"] = out["rows"][0]["solve_plus_results_wall_ms"]
