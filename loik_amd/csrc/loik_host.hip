@@ -3950,6 +3950,32 @@ int loikb_get(loikb_solver* S, int field, void* out, int out_flags)
     else hipLaunchKernelGGL(k_limi<double>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_jd, S->d_first_sel, S->d_link_sel, nl, S->B, dst);
   } else {
     if ((rc = set_rowmap(S, rm))) return rc;
+    const size_t dbytes = sizeof(double) * (size_t)S->B * (size_t)n;
+    if (!to_dev && n > 0 && dbytes <= ((size_t)256 << 10)) {
+      // a small batch, a host destination: one element per thread straight into the pinned buffer (loikb_get_results' path) and ONE synchronisation --
+      // no copy operation; the int fields' masks (k_download_rows') applied here
+      if (dbytes > S->h_res_bytes) {
+        if (S->h_res) { HIPCHK(hipStreamSynchronize(S->stream)); HIPCHK(hipHostFree(S->h_res)); S->h_res = nullptr; S->h_res_bytes = 0; }
+        HIPCHK(hipHostMalloc((void**)&S->h_res, (size_t)256 << 10));
+        S->h_res_bytes = (size_t)256 << 10;
+      }
+      const long long total = (long long)S->B * n;
+      const dim3 g((unsigned)((total + 255) / 256));
+      if (S->f32) hipLaunchKernelGGL(k_download_elems<float>, g, dim3(256), 0, S->stream, S->home.tiles, L, (const int*)S->d_rowmap, n, S->B, S->h_res);
+      else hipLaunchKernelGGL(k_download_elems<double>, g, dim3(256), 0, S->stream, S->home.tiles, L, (const int*)S->d_rowmap, n, S->B, S->h_res);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(S->stream));
+      if (is_int) {
+        int* o = (int*)out;
+        for (long long i = 0; i < total; ++i) {
+          const int v = (int)S->h_res[i];
+          o[i] = mask > 0 ? ((v & mask) ? 1 : 0) : (mask < 0 ? (v & -mask) : v);
+        }
+      } else {
+        memcpy(out, S->h_res, dbytes);
+      }
+      return LOIKB_OK;
+    }
     if (S->f32)
       hipLaunchKernelGGL(k_download_rows<float>, grid1(S->B), dim3(256), 0, S->stream, S->home.tiles, L, S->d_rowmap, n,
                          S->B, dst, (int)is_int, mask);
