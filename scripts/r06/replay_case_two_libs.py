@@ -8,7 +8,7 @@ if len(sys.argv) > 4:   # child: one replay, results to an .npz
     if sys.argv[4] == "old":
         import loik_amd.capi as capi
         capi._LIB_PATH = os.path.join(ROOT, "loik_amd", "lib", "libloik_amd_before_solveinit.so")
-        capi.ABI_VERSION = 601
+        capi.ABI_VERSION = int(os.environ.get("OLD_ABI", "601"))
     import fuzz_engines
     box = {}
     fuzz_engines.fuzz(int(sys.argv[1]), int(sys.argv[2]), verbose=False, only=int(sys.argv[3]), flat_bias=0.7, capture=lambda d: box.update(d))
