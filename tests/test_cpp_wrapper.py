@@ -42,3 +42,14 @@ def test_cpp_wrapper_matches_oracle():
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all wrapper checks passed" in out.stdout
+
+
+def test_cpp_single_call_benchmark_compiles():
+    """CPU: scripts/r06/bench_cpp_single_call.cpp -- what a C++ drop-in caller pays per problem through the mirror (profiles/r06_x_cpp_single_call.jsonl) --
+    compiles against the header and links; its input file is in place"""
+    src = os.path.join(ROOT, "scripts", "r06", "bench_cpp_single_call.cpp")
+    exe = os.path.join(ROOT, "tests", "cpp", "bench_cpp_single_call")
+    libdir = os.path.join(ROOT, "loik_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe,
+                           "-L", libdir, "-lloik_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    assert os.path.exists(exe) and os.path.exists(os.path.join(ROOT, "scripts", "r06", "bench_cpp_single_call_input.txt"))
